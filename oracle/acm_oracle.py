@@ -1,0 +1,278 @@
+"""CPU oracle for the ACM graph-convolution hot path.
+
+TEST INFRASTRUCTURE ONLY.  Nothing under ``acm_gnn_amd/`` may import this
+module; only ``tests/``, ``__graft_entry__.smoke()`` and the ``cpu_baseline``
+leg of ``bench.py`` use it, and only as the checker / the timed CPU baseline.
+
+It is a plain restatement (functional style, torch-CPU ATen ops in the same
+order as the reference issues them, so that on the same torch build the
+results are bit-identical to the imported reference) of:
+
+* the layer                ACM-Geometric/layers.py:78-116, ACM-Pytorch/models/layers.py:154-232
+* the attention heads      ACM-Geometric/layers.py:57-75,  ACM-Pytorch/models/layers.py:94-152
+* parameter init           ACM-Geometric/layers.py:31-54
+* the 2-layer wrapper      ACM-Geometric/models.py:50-76,  ACM-Pytorch/models/models.py:100-166
+* filter construction      ACM-Geometric/train.py:75-81 + utils.py:5-28 (LINKX dialect)
+                           ACM-Pytorch/utils.py:421-438,619-629       (small-graph dialect)
+* k-hop operator           ACM-Pytorch/utils.py:631-637
+* loss / train step        ACM-Geometric/train.py:119-136, ACM-Pytorch/utils.py:547-574
+
+Parity pin: ``tests/golden/*.npz`` hold inputs/outputs produced by importing the
+reference itself in the build container (``tests/golden/make_golden.py``);
+``tests/test_oracle_golden.py`` checks this file against every one of them.
+The reference ships no tests of its own, so those goldens
+are the pin.
+
+The two reference "dialects" differ in one thing the layer cannot see from its
+arguments: whether the attention LayerNorm fires for
+``acmgcnp``/``acmgcnpp``.  Here that is the explicit ``attn_layernorm`` flag.
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, Optional, Sequence
+
+import numpy as np
+import scipy.sparse as sp
+import torch
+import torch.nn.functional as F
+
+ACM_MODELS = ("acmgcn", "acmgcnp", "acmgcnpp", "acmsgc", "acmsnowball")
+LN_EPS = 1e-5
+
+
+# --------------------------------------------------------------------------
+# parameters
+# --------------------------------------------------------------------------
+def param_shapes(in_features: int, out_features: int, nnodes: int, structure_info: int):
+    """Names and shapes of the layer's parameters (layers.py:19-28)."""
+    k = 4 if structure_info else 3
+    shapes = {
+        "weight_low": (in_features, out_features),
+        "weight_high": (in_features, out_features),
+        "weight_mlp": (in_features, out_features),
+        "att_vec_low": (out_features, 1),
+        "att_vec_high": (out_features, 1),
+        "att_vec_mlp": (out_features, 1),
+        "att_struc_low": (out_features, 1),
+        "struc_low": (nnodes, out_features),
+        "att_vec": (k, k),
+    }
+    for ln in ("low", "high", "mlp", "struc_low", "struc_high"):
+        shapes[f"layer_norm_{ln}.weight"] = (out_features,)
+        shapes[f"layer_norm_{ln}.bias"] = (out_features,)
+    return shapes
+
+
+def init_params(in_features, out_features, nnodes, structure_info=0, generator=None):
+    """Reference initialisation scheme (layers.py:31-54): U(-1/sqrt(F_out), ..)
+    for the weights and struc_low, U(-1, 1) for the per-channel attention
+    vectors, U(-1/sqrt(k), ..) for the k x k mixing matrix, LN = (1, 0)."""
+    shapes = param_shapes(in_features, out_features, nnodes, structure_info)
+    p: Dict[str, torch.Tensor] = {}
+
+    def uni(shape, bound):
+        return (torch.rand(shape, generator=generator) * 2.0 - 1.0) * bound
+
+    stdv = 1.0 / math.sqrt(out_features)
+    for name in ("weight_low", "weight_high", "weight_mlp", "struc_low"):
+        p[name] = uni(shapes[name], stdv)
+    for name in ("att_vec_high", "att_vec_low", "att_vec_mlp", "att_struc_low"):
+        p[name] = uni(shapes[name], 1.0)
+    p["att_vec"] = uni(shapes["att_vec"], 1.0 / math.sqrt(shapes["att_vec"][1]))
+    for ln in ("low", "high", "mlp", "struc_low", "struc_high"):
+        p[f"layer_norm_{ln}.weight"] = torch.ones(out_features)
+        p[f"layer_norm_{ln}.bias"] = torch.zeros(out_features)
+    return p
+
+
+# --------------------------------------------------------------------------
+# the layer
+# --------------------------------------------------------------------------
+def _ln(h, p, which):
+    return F.layer_norm(h, (h.shape[1],), p[f"layer_norm_{which}.weight"],
+                        p[f"layer_norm_{which}.bias"], LN_EPS)
+
+
+def attention(p, channels: Sequence[torch.Tensor], use_ln: bool):
+    """Adaptive channel-mixing head (layers.py:57-75).
+
+    ``channels`` is (H_low, H_high, H_mlp[, H_struc]).  Returns an N x k matrix
+    of softmax weights; LayerNorm output feeds only the logits."""
+    k = len(channels)
+    ln_names = ("low", "high", "mlp", "struc_low")
+    vec_names = ("att_vec_low", "att_vec_high", "att_vec_mlp", "att_struc_low")
+    cols = []
+    for c, h in enumerate(channels):
+        hn = _ln(h, p, ln_names[c]) if use_ln else h
+        cols.append(torch.mm(hn, p[vec_names[c]]))
+    logits = torch.mm(torch.sigmoid(torch.cat(cols, 1)), p["att_vec"]) / k
+    return torch.softmax(logits, 1)
+
+
+def layer_forward(p, x, adj_low, adj_high, adj_low_unnormalized=None, *,
+                  model_type="acmgcn", variant=False, structure_info=0,
+                  attn_layernorm=False, return_att=False):
+    """One GraphConvolution forward (layers.py:78-116).
+
+    adj_low may be sparse COO/CSR or dense; adj_high sparse; the products are
+    issued exactly as the reference does (spmm(adj_low, .), spmm(adj_high, .)).
+    """
+    if model_type == "mlp":
+        return torch.mm(x, p["weight_mlp"])
+    if model_type in ("sgc", "gcn"):
+        return torch.mm(adj_low, torch.mm(x, p["weight_low"]))
+
+    z_low = torch.mm(x, p["weight_low"])
+    z_high = torch.mm(x, p["weight_high"])
+    z_mlp = torch.mm(x, p["weight_mlp"])
+
+    if model_type == "acmsgc":
+        h_low = torch.spmm(adj_low, z_low)
+        h_high = torch.spmm(adj_high, z_high)
+        h_mlp = z_mlp
+        use_ln = False                      # acmsgc never normalises (layers.py:59)
+        four = False
+    else:
+        if variant:                         # ACMII: ReLU before the filter
+            h_low = torch.spmm(adj_low, F.relu(z_low))
+            h_high = torch.spmm(adj_high, F.relu(z_high))
+        else:                               # ACM: ReLU after the filter
+            h_low = F.relu(torch.spmm(adj_low, z_low))
+            h_high = F.relu(torch.spmm(adj_high, z_high))
+        h_mlp = F.relu(z_mlp)
+        # "acmgcn+"/"acmgcn++" are the spellings ACM-Pytorch's layer tests for
+        # (models/layers.py:96,123); its CLI never passes them (quirk Q1).
+        plus = model_type in ("acmgcnp", "acmgcnpp", "acmgcn+", "acmgcn++")
+        use_ln = bool(attn_layernorm) and plus
+        four = plus and bool(structure_info)
+
+    if four:
+        h_struc = F.relu(torch.mm(adj_low_unnormalized, p["struc_low"]))
+        att = attention(p, (h_low, h_high, h_mlp, h_struc), use_ln)
+        out = 1 * (att[:, 0:1] * h_low + att[:, 1:2] * h_high
+                   + att[:, 2:3] * h_mlp + att[:, 3:4] * h_struc)
+    else:
+        att = attention(p, (h_low, h_high, h_mlp), use_ln)
+        out = 3 * (att[:, 0:1] * h_low + att[:, 1:2] * h_high + att[:, 2:3] * h_mlp)
+    return (out, att) if return_att else out
+
+
+# --------------------------------------------------------------------------
+# the 2-layer wrapper
+# --------------------------------------------------------------------------
+def _drop(t, prob, training, mask):
+    """F.dropout with an optionally injected keep-mask (1 = keep)."""
+    if mask is not None:
+        return t * mask / (1.0 - prob)
+    return F.dropout(t, prob, training=training)
+
+
+def gcn_forward(params, x, adj_low, adj_high, adj_low_unnormalized=None, *,
+                model_type="acmgcn", variant=False, structure_info=0,
+                attn_layernorm=False, dropout=0.0, training=False, masks=None):
+    """Two stacked layers (models.py:50-76).
+
+    ``params`` = {"gcns.0.<name>":.., "gcns.1.<name>":.., ["mlpX.lins.0.weight",
+    "mlpX.lins.0.bias"]}.  ``masks`` (optional) = dict with keep-masks "x",
+    "hidden" and, for acmgcnpp, "xX" -- used to replay the reference's dropout.
+    """
+    masks = masks or {}
+    kw = dict(model_type=model_type, variant=variant, structure_info=structure_info,
+              attn_layernorm=attn_layernorm)
+    p0 = {k[len("gcns.0."):]: v for k, v in params.items() if k.startswith("gcns.0.")}
+    p1 = {k[len("gcns.1."):]: v for k, v in params.items() if k.startswith("gcns.1.")}
+
+    x = _drop(x, dropout, training, masks.get("x"))
+    if model_type == "acmgcnpp":            # residual branch, MLP(num_layers=1) == Linear
+        lin = F.linear(x, params["mlpX.lins.0.weight"], params["mlpX.lins.0.bias"])
+        xx = _drop(F.relu(lin), dropout, training, masks.get("xX"))
+    fea1 = layer_forward(p0, x, adj_low, adj_high, adj_low_unnormalized, **kw)
+    fea1 = _drop(F.relu(fea1), dropout, training, masks.get("hidden"))
+    if model_type == "acmgcnpp":
+        fea1 = fea1 + xx
+    return layer_forward(p1, fea1, adj_low, adj_high, adj_low_unnormalized, **kw)
+
+
+def nll_loss_on(logits, labels, idx):
+    """log_softmax + NLLLoss over the training rows (train.py:133-134)."""
+    return F.nll_loss(F.log_softmax(logits, dim=1)[idx], labels[idx])
+
+
+def accuracy(logits, labels, idx):
+    pred = logits[idx].argmax(dim=1)
+    return (pred == labels[idx]).double().mean().item()
+
+
+# --------------------------------------------------------------------------
+# filters
+# --------------------------------------------------------------------------
+def row_normalize_sp(mx):
+    """scipy row normalisation in float64 with inf -> 0 (ACM-Geometric/utils.py:5-19)."""
+    mx = sp.csr_matrix(mx)
+    rowsum = np.asarray(mx.sum(1)).flatten()
+    with np.errstate(divide="ignore"):
+        r_inv = np.power(rowsum, -1.0)
+    r_inv[np.isinf(r_inv)] = 0.0
+    return sp.diags(r_inv, 0).dot(mx)
+
+
+def to_torch_coo(mx):
+    """scipy -> float32 torch sparse COO, *not* flagged coalesced (utils.py:21-28)."""
+    mx = mx.tocoo().astype(np.float32)
+    idx = torch.from_numpy(np.vstack((mx.row, mx.col)).astype(np.int64))
+    return torch.sparse_coo_tensor(idx, torch.from_numpy(mx.data), torch.Size(mx.shape))
+
+
+def filters_linkx(adj_unnorm_sp):
+    """A_low = D^-1 (I + A) in float64 scipy, A_high = I - A_low, both cast to
+    float32 COO (ACM-Geometric/train.py:75-81)."""
+    n = adj_unnorm_sp.shape[0]
+    low = row_normalize_sp(sp.identity(n) + adj_unnorm_sp)
+    high = sp.identity(n) - low
+    return to_torch_coo(low), to_torch_coo(high), to_torch_coo(adj_unnorm_sp)
+
+
+def row_normalize_dense(mx):
+    """Dense fp32 row normalisation through diag @ mx (ACM-Pytorch/utils.py:421-438)."""
+    r_inv = torch.pow(torch.sum(mx, 1), -1).flatten()
+    r_inv[torch.isinf(r_inv)] = 0.0
+    return torch.mm(torch.diag(r_inv), mx)
+
+
+def filters_small(adj_unnorm_dense):
+    """Dense A_low (strided), sparse A_high (ACM-Pytorch/utils.py:619-629)."""
+    n = adj_unnorm_dense.shape[0]
+    low = row_normalize_dense(torch.eye(n) + adj_unnorm_dense)
+    high = (torch.eye(n) - low).to_sparse()
+    return low, high
+
+
+def khop_low(adj_low_dense, hops):
+    """A_low^hops by repeated dense mm (ACM-Pytorch/utils.py:631-637)."""
+    acc = adj_low_dense
+    for _ in range(hops - 1):
+        acc = torch.mm(acc, adj_low_dense)
+    return acc
+
+
+# --------------------------------------------------------------------------
+# CSR helpers used by tests / the "best effort" CPU baseline
+# --------------------------------------------------------------------------
+def coo_to_csr_arrays(t):
+    """torch sparse (any layout) or dense -> (indptr int32, indices int32, vals f32), rows sorted."""
+    if t.layout == torch.strided:
+        m = sp.csr_matrix(t.numpy())
+    else:
+        t = t.coalesce() if t.layout == torch.sparse_coo else t.to_sparse_coo().coalesce()
+        i = t.indices().numpy()
+        m = sp.csr_matrix((t.values().numpy(), (i[0], i[1])), shape=tuple(t.shape))
+    m.sort_indices()
+    return m.indptr.astype(np.int32), m.indices.astype(np.int32), m.data.astype(np.float32)
+
+
+def spmm_csr_numpy(indptr, indices, vals, dense, dtype=np.float64):
+    """Reference CSR x dense product in numpy (float64 by default)."""
+    m = sp.csr_matrix((vals.astype(dtype), indices, indptr),
+                      shape=(len(indptr) - 1, dense.shape[0]))
+    return m @ dense.astype(dtype)

@@ -1,0 +1,57 @@
+"""pytest configuration: the ``gpu`` marker and shared fixture helpers."""
+import glob
+import json
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def golden_files(pattern):
+    return sorted(glob.glob(os.path.join(GOLDEN, pattern)))
+
+
+def load_npz(path):
+    with np.load(path, allow_pickle=False) as f:
+        rec = {k: f[k] for k in f.files}
+    if "cfg" in rec:
+        rec["cfg"] = json.loads(str(rec["cfg"]))
+    return rec
+
+
+def csr_to_coo_tensor(g, prefix, n=None):
+    """CSR arrays from a fixture -> coalesced float32 torch sparse COO."""
+    indptr, indices = g[prefix + "_indptr"], g[prefix + "_indices"]
+    vals = g.get(prefix + "_vals")
+    if vals is None:
+        vals = np.ones(len(indices), np.float32)
+    n = n or len(indptr) - 1
+    rows = np.repeat(np.arange(len(indptr) - 1), np.diff(indptr))
+    idx = torch.from_numpy(np.vstack([rows, indices]).astype(np.int64))
+    return torch.sparse_coo_tensor(idx, torch.from_numpy(vals.astype(np.float32)), (n, n)).coalesce()
+
+
+def graph_tensors(dialect):
+    """(adj_low, adj_high, adj_un) in the layouts the reference dialect feeds the layer."""
+    g = load_npz(os.path.join(GOLDEN, f"graph_{dialect}.npz"))
+    if dialect == "pytorch":
+        adj_low = torch.from_numpy(g["adj_low_dense"])          # dense strided (utils.py:619-629)
+    else:
+        adj_low = csr_to_coo_tensor(g, "adj_low")
+    return adj_low, csr_to_coo_tensor(g, "adj_high"), csr_to_coo_tensor(g, "adj_un"), g
+
+
+@pytest.fixture(scope="session")
+def golden_dir():
+    return GOLDEN
