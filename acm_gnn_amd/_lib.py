@@ -1,0 +1,147 @@
+"""ctypes binding of libacm_hip.so (C ABI declared in include/acm_hip.h).
+
+There is no CPU or torch fallback behind this module: if the library cannot be
+loaded, or a call fails, a RuntimeError is raised.
+"""
+import ctypes as C
+import os
+import threading
+
+from . import build as _build
+
+c_f32p = C.POINTER(C.c_float)
+c_i32p = C.POINTER(C.c_int32)
+
+ACM_OK = 0
+STATUS_NAMES = {1: "ACM_EINVAL", 2: "ACM_ESHAPE", 3: "ACM_EHIP", 4: "ACM_EUNSUPPORTED", 5: "ACM_ENOMEM"}
+ABI_VERSION = 1
+
+# every symbol include/acm_hip.h declares
+EXPORTED_SYMBOLS = (
+    "acm_version", "acm_last_error", "acm_csr_create", "acm_csr_transpose", "acm_csr_slice_rows",
+    "acm_csr_destroy", "acm_csr_info", "acm_spmm_workspace_bytes", "acm_gemm_workspace_bytes",
+    "acm_gemm", "acm_spmm", "acm_conv_fwd", "acm_conv_bwd_local_workspace_bytes",
+    "acm_conv_bwd_local", "acm_conv_bwd_spmm",
+)
+
+
+class CsrInfo(C.Structure):
+    _fields_ = [("n_rows", C.c_int64), ("n_cols", C.c_int64), ("nnz", C.c_int64),
+                ("n_items", C.c_int64), ("n_long_rows", C.c_int64), ("n_partial_slots", C.c_int64),
+                ("chunk", C.c_int32), ("max_degree", C.c_int32),
+                ("indptr", C.c_void_p), ("indices", C.c_void_p), ("vals", C.c_void_p)]
+
+
+class ConvFwd(C.Structure):
+    _fields_ = [("f_out", C.c_int32), ("n_channels", C.c_int32), ("relu_after", C.c_int32),
+                ("relu_mlp", C.c_int32), ("layernorm", C.c_int32), ("scale", C.c_float),
+                ("row_offset", C.c_int64),
+                ("g_low", C.c_void_p), ("ld_g_low", C.c_int64),
+                ("g_high", C.c_void_p), ("ld_g_high", C.c_int64),
+                ("g_struc", C.c_void_p), ("ld_g_struc", C.c_int64),
+                ("s_high", C.c_void_p), ("ld_s_high", C.c_int64),
+                ("s_mlp", C.c_void_p), ("ld_s_mlp", C.c_int64),
+                ("s_struc", C.c_void_p), ("ld_s_struc", C.c_int64),
+                ("deg", C.c_void_p),
+                ("att_vec", C.c_void_p * 4), ("ln_weight", C.c_void_p * 4), ("ln_bias", C.c_void_p * 4),
+                ("att_mix", C.c_void_p),
+                ("out", C.c_void_p), ("ld_out", C.c_int64),
+                ("pre", C.c_void_p), ("ld_pre", C.c_int64),
+                ("att", C.c_void_p)]
+
+
+class ConvBwdLocal(C.Structure):
+    _fields_ = [("f_out", C.c_int32), ("n_channels", C.c_int32), ("relu_after", C.c_int32),
+                ("relu_mlp", C.c_int32), ("layernorm", C.c_int32), ("scale", C.c_float),
+                ("grad_out", C.c_void_p), ("ld_grad_out", C.c_int64),
+                ("pre", C.c_void_p), ("ld_pre", C.c_int64),
+                ("s_mlp", C.c_void_p), ("ld_s_mlp", C.c_int64),
+                ("deg", C.c_void_p),
+                ("att_vec", C.c_void_p * 4), ("ln_weight", C.c_void_p * 4), ("ln_bias", C.c_void_p * 4),
+                ("att_mix", C.c_void_p),
+                ("g_low", C.c_void_p), ("ld_g_low", C.c_int64),
+                ("g_high", C.c_void_p), ("ld_g_high", C.c_int64),
+                ("g_mlp", C.c_void_p), ("ld_g_mlp", C.c_int64),
+                ("g_struc", C.c_void_p), ("ld_g_struc", C.c_int64),
+                ("d_att_vec", C.c_void_p * 4), ("d_ln_weight", C.c_void_p * 4),
+                ("d_ln_bias", C.c_void_p * 4), ("d_att_mix", C.c_void_p)]
+
+
+class ConvBwdSpmm(C.Structure):
+    _fields_ = [("f_out", C.c_int32), ("row_offset", C.c_int64),
+                ("g_low", C.c_void_p), ("ld_g_low", C.c_int64),
+                ("g_high", C.c_void_p), ("ld_g_high", C.c_int64),
+                ("g_struc", C.c_void_p), ("ld_g_struc", C.c_int64),
+                ("s_high", C.c_void_p), ("ld_s_high", C.c_int64),
+                ("s_struc", C.c_void_p), ("ld_s_struc", C.c_int64),
+                ("inv_deg", C.c_void_p),
+                ("mask_low", C.c_void_p), ("ld_mask_low", C.c_int64),
+                ("mask_high", C.c_void_p), ("ld_mask_high", C.c_int64),
+                ("dz_low", C.c_void_p), ("ld_dz_low", C.c_int64),
+                ("dz_high", C.c_void_p), ("ld_dz_high", C.c_int64),
+                ("d_struc", C.c_void_p), ("ld_d_struc", C.c_int64)]
+
+
+_lib = None
+_lock = threading.Lock()
+
+
+def _declare(lib):
+    vp, i64, i32, sz = C.c_void_p, C.c_int64, C.c_int, C.c_size_t
+    lib.acm_version.restype = C.c_int
+    lib.acm_version.argtypes = []
+    lib.acm_last_error.restype = C.c_char_p
+    lib.acm_last_error.argtypes = []
+    lib.acm_csr_create.argtypes = [i64, i64, i64, vp, vp, vp, i32, C.POINTER(vp)]
+    lib.acm_csr_transpose.argtypes = [vp, i32, C.POINTER(vp)]
+    lib.acm_csr_slice_rows.argtypes = [vp, i64, i64, i32, C.POINTER(vp)]
+    lib.acm_csr_destroy.argtypes = [vp]
+    lib.acm_csr_destroy.restype = None
+    lib.acm_csr_info.argtypes = [vp, C.POINTER(CsrInfo)]
+    lib.acm_spmm_workspace_bytes.argtypes = [vp, i32, C.POINTER(sz)]
+    lib.acm_gemm_workspace_bytes.argtypes = [i32, i32, i64, i64, i64, C.POINTER(sz)]
+    lib.acm_gemm.argtypes = [i32, i32, i64, i64, i64, vp, i64, vp, i64, vp, i64, i32, vp, sz, vp]
+    lib.acm_spmm.argtypes = [vp, vp, i64, i32, vp, i64, vp, sz, vp]
+    lib.acm_conv_fwd.argtypes = [vp, C.POINTER(ConvFwd), vp, sz, vp]
+    lib.acm_conv_bwd_local_workspace_bytes.argtypes = [i64, i32, i32, C.POINTER(sz)]
+    lib.acm_conv_bwd_local.argtypes = [i64, C.POINTER(ConvBwdLocal), vp, sz, vp]
+    lib.acm_conv_bwd_spmm.argtypes = [vp, C.POINTER(ConvBwdSpmm), vp, sz, vp]
+    for name in EXPORTED_SYMBOLS:
+        fn = getattr(lib, name)
+        if name not in ("acm_version", "acm_last_error", "acm_csr_destroy"):
+            fn.restype = C.c_int
+
+
+def library_path():
+    return os.environ.get("ACM_HIP_LIBRARY", _build.LIB_PATH)
+
+
+def load(build_if_missing=True):
+    """Load (building first if the in-tree .so is missing/stale and hipcc exists)."""
+    global _lib
+    with _lock:
+        if _lib is not None:
+            return _lib
+        path = library_path()
+        if "ACM_HIP_LIBRARY" not in os.environ and build_if_missing:
+            try:
+                if _build.is_stale():
+                    _build.build_library()
+            except Exception as exc:  # no hipcc on this box: fall through to the existing file
+                if not os.path.exists(path):
+                    raise RuntimeError(f"libacm_hip.so is not built and cannot be built here: {exc}")
+        if not os.path.exists(path):
+            raise RuntimeError(f"libacm_hip.so not found at {path}; run `python -m acm_gnn_amd.build`")
+        lib = C.CDLL(path)
+        _declare(lib)
+        ver = lib.acm_version()
+        if ver != ABI_VERSION:
+            raise RuntimeError(f"libacm_hip.so ABI version {ver} != expected {ABI_VERSION}")
+        _lib = lib
+        return _lib
+
+
+def check(status, what=""):
+    if status != ACM_OK:
+        msg = load().acm_last_error().decode(errors="replace")
+        raise RuntimeError(f"{what or 'libacm_hip'} failed with {STATUS_NAMES.get(status, status)}: {msg}")

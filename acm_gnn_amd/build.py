@@ -1,0 +1,75 @@
+"""Build libacm_hip.so in-tree with hipcc for gfx950 (MI355X).
+
+The library is plain C ABI (include/acm_hip.h); no torch headers are involved,
+so this is an ordinary ``hipcc -shared`` of three translation units.  The build
+is skipped when the library is newer than every source.
+"""
+import os
+import shutil
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+CSRC = os.path.join(HERE, "csrc")
+INCLUDE = os.path.join(ROOT, "include")
+LIB_DIR = os.path.join(HERE, "lib")
+LIB_PATH = os.path.join(LIB_DIR, "libacm_hip.so")
+SOURCES = ["acm_csr.cpp", "acm_gemm.hip", "acm_conv.hip"]
+ARCH = "gfx950"
+
+
+def _hipcc():
+    for cand in (os.environ.get("HIPCC"), shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
+        if cand and os.path.exists(cand):
+            return cand
+    raise RuntimeError("hipcc not found (set HIPCC or install ROCm)")
+
+
+def _deps():
+    out = [os.path.join(CSRC, s) for s in SOURCES]
+    out += [os.path.join(CSRC, "acm_common.h"), os.path.join(INCLUDE, "acm_hip.h")]
+    return out
+
+
+def is_stale():
+    if not os.path.exists(LIB_PATH):
+        return True
+    t = os.path.getmtime(LIB_PATH)
+    return any(os.path.getmtime(d) > t for d in _deps())
+
+
+def build_library(force=False, verbose=False):
+    """Compile every HIP source for gfx950 and link libacm_hip.so. Returns its path."""
+    if not force and not is_stale():
+        return LIB_PATH
+    os.makedirs(LIB_DIR, exist_ok=True)
+    hipcc = _hipcc()
+    objs = []
+    flags = [f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-I" + INCLUDE, "-I" + CSRC,
+             "-Wall", "-Wno-unused-function"]
+    procs = []
+    for src in SOURCES:
+        obj = os.path.join(LIB_DIR, os.path.splitext(src)[0] + ".o")
+        cmd = [hipcc] + flags + ["-c", os.path.join(CSRC, src), "-o", obj]
+        if verbose:
+            print(" ".join(cmd), file=sys.stderr)
+        procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
+        objs.append(obj)
+    for src, pr in procs:
+        out, _ = pr.communicate()
+        if pr.returncode != 0:
+            raise RuntimeError(f"hipcc failed on {src}:\n{out.decode(errors='replace')}")
+        if verbose and out:
+            print(out.decode(errors="replace"), file=sys.stderr)
+    tmp = LIB_PATH + ".tmp"
+    cmd = [hipcc, f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", tmp] + objs
+    res = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+    if res.returncode != 0:
+        raise RuntimeError("link failed:\n" + res.stdout.decode(errors="replace"))
+    os.replace(tmp, LIB_PATH)
+    return LIB_PATH
+
+
+if __name__ == "__main__":
+    print(build_library(force="--force" in sys.argv, verbose=True))

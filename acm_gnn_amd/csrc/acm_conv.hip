@@ -1,0 +1,867 @@
+// Fused ACM layer kernels for gfx950 (MI355X):
+//   K2  acm_conv_fwd       one CSR pass over A_low -> all graph channels + adaptive mixing
+//   K3  acm_conv_bwd_local row-local backward of the mixing head (+ parameter-gradient reduction)
+//   K4  acm_conv_bwd_spmm  transposed SpMM with the high-pass / structure identities folded in
+//       acm_spmm           plain CSR x dense (k-hop chains, tests)
+//
+// Execution shapes (wave = 64 lanes):
+//   wide   (F > 8)  one wave per work item, lane l owns columns l, l+64, ... of every channel;
+//                   the wave loads 64 (index, value) pairs with one coalesced instruction each,
+//                   broadcasts them lane by lane (v_readlane -> SGPR row base) and issues
+//                   UNR x NG x NREG independent 256 B row-segment loads before the FMAs.
+//   narrow (F <= 8) GS lanes per work item, lanes over *neighbours*, every lane gathers the
+//                   whole (NG x F)-float row of its neighbour with vector loads and the group
+//                   all-reduces at the end; epilogue runs redundantly in the group.
+// Rows longer than `chunk` neighbours are split into several work items whose partial sums
+// are combined in slot order by a fix-up kernel (deterministic, no float atomics).
+#include <math.h>
+
+#include "acm_common.h"
+
+// ------------------------------------------------------------------ layouts
+// How the F columns of one row are spread over lanes.  NV = values per lane.
+template <int NREG>
+struct LayWide {  // A: wave per row, lane owns columns lane + 64 i
+    static constexpr int NV = NREG;
+    int lane;
+    __device__ __forceinline__ int col(int i) const { return lane + 64 * i; }
+    __device__ __forceinline__ float rsum(float v) const { return acm_group_sum<64>(v); }
+    __device__ __forceinline__ bool leader() const { return lane == 0; }
+};
+template <int FP>
+struct LayPacked {  // B: FP lanes per row (64 / FP rows per wave), one column per lane
+    static constexpr int NV = 1;
+    int lane;
+    __device__ __forceinline__ int col(int) const { return lane % FP; }
+    __device__ __forceinline__ float rsum(float v) const { return acm_group_sum<FP>(v); }
+    __device__ __forceinline__ bool leader() const { return (lane % FP) == 0; }
+};
+template <int FP>
+struct LaySerial {  // C: every lane holds the whole row
+    static constexpr int NV = FP;
+    bool lead;
+    __device__ __forceinline__ int col(int i) const { return i; }
+    __device__ __forceinline__ float rsum(float v) const { return v; }
+    __device__ __forceinline__ bool leader() const { return lead; }
+};
+
+struct GatherSrc {
+    const float* p[3];
+    long ld[3];
+};
+
+// ------------------------------------------------------------------ attention head (shared by fwd / bwd)
+struct HeadOut {
+    float g[4], alpha[4], rstd[4];
+};
+struct HeadParams {  // copied out of the kernel-argument struct so every index is a constant
+    const float* att_vec[4];
+    const float* ln_w[4];
+    const float* ln_b[4];
+    const float* att_mix;
+};
+template <class P>
+__device__ __forceinline__ HeadParams acm_head_params(const P& p) {
+    HeadParams h;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        h.att_vec[c] = p.att_vec[c];
+        h.ln_w[c] = p.ln_weight[c];
+        h.ln_b[c] = p.ln_bias[c];
+    }
+    h.att_mix = p.att_mix;
+    return h;
+}
+
+// H: activated channels; hn/xhat outputs (hn = LayerNorm(H) or H).  Invalid columns hold 0.
+template <class L, int K>
+__device__ __forceinline__ void acm_head(const L& lay, int F, int layernorm,
+                                         const HeadParams& hp,
+                                         const float (&H)[4][L::NV], float (&hn)[4][L::NV],
+                                         float (&xhat)[4][L::NV], HeadOut& o) {
+    constexpr int NV = L::NV;
+    constexpr int k = K;
+    const float invF = 1.0f / (float)F;
+    float s[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        if (c >= K) {
+            o.g[c] = 0.f;
+            o.rstd[c] = 1.f;
+            continue;
+        }
+        // Without LayerNorm the same straight-line code runs with mean 0, rstd 1, gamma 1,
+        // beta 0 (exact: (H - 0) * 1 * 1 + 0 == H), so only two scalars depend on the branch.
+        float mean = 0.f, rstd = 1.f;
+        if (layernorm) {
+            float part = 0.f;
+#pragma unroll
+            for (int i = 0; i < NV; ++i) part += H[c][i];
+            mean = lay.rsum(part) * invF;
+            part = 0.f;
+#pragma unroll
+            for (int i = 0; i < NV; ++i) {
+                const float d = (lay.col(i) < F) ? (H[c][i] - mean) : 0.f;
+                part += d * d;
+            }
+            rstd = 1.0f / sqrtf(lay.rsum(part) * invF + ACM_LN_EPS);
+        }
+        o.rstd[c] = rstd;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int col = lay.col(i);
+            const bool ok = col < F;
+            const float gam = (ok && layernorm) ? hp.ln_w[c][col] : 1.f;
+            const float bet = (ok && layernorm) ? hp.ln_b[c][col] : 0.f;
+            const float xh = ok ? (H[c][i] - mean) * rstd : 0.f;
+            xhat[c][i] = xh;
+            hn[c][i] = ok ? (xh * gam + bet) : 0.f;
+        }
+        float part = 0.f;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int col = lay.col(i);
+            part += (col < F) ? hn[c][i] * hp.att_vec[c][col] : 0.f;
+        }
+        s[c] = lay.rsum(part);
+        o.g[c] = 1.0f / (1.0f + expf(-s[c]));
+    }
+    float logit[4], mx = -INFINITY;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        if (j >= k) {
+            logit[j] = -INFINITY;
+            continue;
+        }
+        float acc = 0.f;
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+            if (c < k) acc += o.g[c] * hp.att_mix[c * k + j];
+        logit[j] = acc / (float)k;
+        mx = fmaxf(mx, logit[j]);
+    }
+    float den = 0.f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        if (j >= k) continue;
+        logit[j] = expf(logit[j] - mx);
+        den += logit[j];
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) o.alpha[j] = (j < k) ? logit[j] / den : 0.f;
+}
+
+// ------------------------------------------------------------------ epilogues
+// Layouts A and B give every column exactly one owning lane; layout C replicates the row in
+// every lane of the group, so only the group leader stores.
+template <class L>
+struct Owns {
+    static __device__ __forceinline__ bool lane_stores(const L&) { return true; }
+};
+template <int FP>
+struct Owns<LaySerial<FP>> {
+    static __device__ __forceinline__ bool lane_stores(const LaySerial<FP>& l) { return l.lead; }
+};
+
+struct EpiPlain {
+    struct Args {
+        float* y;
+        long ldy;
+    };
+    template <class L, int NG>
+    static __device__ __forceinline__ void apply(const Args& a, int row, const L& lay, int F,
+                                                 const float (&acc)[NG][L::NV]) {
+        if (!Owns<L>::lane_stores(lay)) return;
+#pragma unroll
+        for (int i = 0; i < L::NV; ++i) {
+            const int col = lay.col(i);
+            if (col < F) a.y[(long)row * a.ldy + col] = acc[0][i];
+        }
+    }
+};
+
+struct EpiFwd {
+    using Args = acm_conv_fwd_t;
+    template <class L, int NG>
+    static __device__ __forceinline__ void apply(const Args& p, int row, const L& lay, int F,
+                                                 const float (&acc)[NG][L::NV]) {
+        constexpr int NV = L::NV;
+        float H[4][NV], hn[4][NV], xhat[4][NV], pre[3][NV];
+        const float dg = (NG == 3) ? p.deg[row] : 0.f;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int col = lay.col(i);
+            const bool ok = col < F;
+            const float zh = ok ? p.s_high[(long)row * p.ld_s_high + col] : 0.f;
+            const float zi = ok ? p.s_mlp[(long)row * p.ld_s_mlp + col] : 0.f;
+            const float p0 = acc[0][i];
+            const float p1 = zh - acc[1][i];
+            pre[0][i] = p0;
+            pre[1][i] = p1;
+            H[0][i] = p.relu_after ? fmaxf(p0, 0.f) : p0;
+            H[1][i] = p.relu_after ? fmaxf(p1, 0.f) : p1;
+            H[2][i] = p.relu_mlp ? fmaxf(zi, 0.f) : zi;
+            if (NG == 3) {
+                const float ss = ok ? p.s_struc[(long)row * p.ld_s_struc + col] : 0.f;
+                const float p3 = dg * acc[NG - 1][i] - ss;
+                pre[2][i] = p3;
+                H[3][i] = fmaxf(p3, 0.f);
+            } else {
+                pre[2][i] = 0.f;
+                H[3][i] = 0.f;
+            }
+            if (!ok) {
+                H[0][i] = H[1][i] = H[2][i] = H[3][i] = 0.f;
+            }
+        }
+        HeadOut ho;
+        const HeadParams hp = acm_head_params(p);
+        acm_head<L, NG + 1>(lay, F, p.layernorm, hp, H, hn, xhat, ho);
+        const bool st = Owns<L>::lane_stores(lay);
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int col = lay.col(i);
+            if (col < F && st) {
+                float o = ho.alpha[0] * H[0][i] + ho.alpha[1] * H[1][i] + ho.alpha[2] * H[2][i];
+                if (NG == 3) o += ho.alpha[3] * H[3][i];
+                p.out[(long)row * p.ld_out + col] = p.scale * o;
+                float* pr = p.pre + (long)row * p.ld_pre;
+                pr[col] = pre[0][i];
+                pr[F + col] = pre[1][i];
+                if (NG == 3) pr[2 * F + col] = pre[2][i];
+            }
+        }
+        if (lay.leader()) {
+            float4 a4 = make_float4(ho.alpha[0], ho.alpha[1], ho.alpha[2], ho.alpha[3]);
+            *reinterpret_cast<float4*>(p.att + (long)row * 4) = a4;
+        }
+    }
+};
+
+struct EpiBwd {
+    using Args = acm_conv_bwd_spmm_t;
+    template <class L, int NG>
+    static __device__ __forceinline__ void apply(const Args& p, int row, const L& lay, int F,
+                                                 const float (&acc)[NG][L::NV]) {
+        if (!Owns<L>::lane_stores(lay)) return;
+        const float idg = (NG == 3) ? p.inv_deg[row] : 0.f;
+#pragma unroll
+        for (int i = 0; i < L::NV; ++i) {
+            const int col = lay.col(i);
+            if (col >= F) continue;
+            float dl = acc[0][i];
+            float dh = p.s_high[(long)row * p.ld_s_high + col] - acc[1][i];
+            if (p.mask_low) dl = (p.mask_low[(long)row * p.ld_mask_low + col] > 0.f) ? dl : 0.f;
+            if (p.mask_high) dh = (p.mask_high[(long)row * p.ld_mask_high + col] > 0.f) ? dh : 0.f;
+            p.dz_low[(long)row * p.ld_dz_low + col] = dl;
+            p.dz_high[(long)row * p.ld_dz_high + col] = dh;
+            if (NG == 3)
+                p.d_struc[(long)row * p.ld_d_struc + col] =
+                    acc[NG - 1][i] - p.s_struc[(long)row * p.ld_s_struc + col] * idg;
+        }
+    }
+};
+
+// ------------------------------------------------------------------ wide gather
+template <int NREG, int NG, int UNR>
+__device__ __forceinline__ void gather_wide(const GatherSrc& g, int F, const int32_t* __restrict__ indices,
+                                            const float* __restrict__ vals, int begin, int end,
+                                            int lane, float (&acc)[NG][NREG]) {
+    for (int base = begin; base < end; base += 64) {
+        const int kk = base + lane;
+        int my_j = 0;
+        float my_a = 0.f;
+        if (kk < end) {
+            my_j = indices[kk];
+            my_a = vals[kk];
+        }
+        const int cnt = min(64, end - base);  // wave-uniform
+        int t = 0;
+        for (; t + UNR <= cnt; t += UNR) {
+            float z[UNR][NG][NREG];
+            float a[UNR];
+#pragma unroll
+            for (int u = 0; u < UNR; ++u) {
+                const int j = __builtin_amdgcn_readlane(my_j, t + u);
+                a[u] = acm_lane_f(my_a, t + u);
+#pragma unroll
+                for (int c = 0; c < NG; ++c) {
+                    const float* rowp = g.p[c] + (long)j * g.ld[c];
+#pragma unroll
+                    for (int r = 0; r < NREG; ++r) {
+                        const int col = lane + 64 * r;
+                        z[u][c][r] = (col < F) ? rowp[col] : 0.f;
+                    }
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < UNR; ++u)
+#pragma unroll
+                for (int c = 0; c < NG; ++c)
+#pragma unroll
+                    for (int r = 0; r < NREG; ++r) acc[c][r] = fmaf(a[u], z[u][c][r], acc[c][r]);
+        }
+        for (; t < cnt; ++t) {
+            const int j = __builtin_amdgcn_readlane(my_j, t);
+            const float a = acm_lane_f(my_a, t);
+#pragma unroll
+            for (int c = 0; c < NG; ++c) {
+                const float* rowp = g.p[c] + (long)j * g.ld[c];
+#pragma unroll
+                for (int r = 0; r < NREG; ++r) {
+                    const int col = lane + 64 * r;
+                    const float z = (col < F) ? rowp[col] : 0.f;
+                    acc[c][r] = fmaf(a, z, acc[c][r]);
+                }
+            }
+        }
+    }
+}
+
+template <int NREG, int NG, class Epi>
+__global__ __launch_bounds__(256) void spmm_wide_kernel(CsrView csr, GatherSrc g, int F,
+                                                        typename Epi::Args ea, float* __restrict__ partial) {
+    const int lane = threadIdx.x & 63;
+    const int blk = acm_xcd_swizzle(blockIdx.x, gridDim.x);
+    const int w = acm_uniform(blk * 4 + (threadIdx.x >> 6));
+    if (w >= csr.n_items) return;
+    const AcmItem it = csr.items[w];
+    const int row = acm_uniform(it.row), begin = acm_uniform(it.begin), end = acm_uniform(it.end),
+              slot = acm_uniform(it.slot);
+    float acc[NG][NREG];
+#pragma unroll
+    for (int c = 0; c < NG; ++c)
+#pragma unroll
+        for (int r = 0; r < NREG; ++r) acc[c][r] = 0.f;
+    constexpr int UNR = (NG * NREG >= 8) ? 2 : (NG * NREG >= 4 ? 4 : 8);
+    gather_wide<NREG, NG, UNR>(g, F, csr.indices, csr.vals, begin, end, lane, acc);
+    if (slot < 0) {
+        LayWide<NREG> lay{lane};
+        Epi::template apply<LayWide<NREG>, NG>(ea, row, lay, F, acc);
+    } else {
+        float* ps = partial + (long)slot * (NG * F);
+#pragma unroll
+        for (int c = 0; c < NG; ++c)
+#pragma unroll
+            for (int r = 0; r < NREG; ++r) {
+                const int col = lane + 64 * r;
+                if (col < F) ps[c * F + col] = acc[c][r];
+            }
+    }
+}
+
+// One wave per long row: add its partial slots in slot order, then the epilogue.
+template <int NREG, int NG, class Epi>
+__global__ __launch_bounds__(256) void spmm_fixup_kernel(CsrView csr, int F, typename Epi::Args ea,
+                                                         const float* __restrict__ partial) {
+    const int lane = threadIdx.x & 63;
+    const int w = acm_uniform(blockIdx.x * 4 + (threadIdx.x >> 6));
+    if (w >= csr.n_long) return;
+    const AcmLongRow lr = csr.long_rows[w];
+    const int row = acm_uniform(lr.row), sb = acm_uniform(lr.slot_begin), se = acm_uniform(lr.slot_end);
+    float acc[NG][NREG];
+#pragma unroll
+    for (int c = 0; c < NG; ++c)
+#pragma unroll
+        for (int r = 0; r < NREG; ++r) acc[c][r] = 0.f;
+    for (int s = sb; s < se; ++s) {
+        const float* ps = partial + (long)s * (NG * F);
+#pragma unroll
+        for (int c = 0; c < NG; ++c)
+#pragma unroll
+            for (int r = 0; r < NREG; ++r) {
+                const int col = lane + 64 * r;
+                if (col < F) acc[c][r] += ps[c * F + col];
+            }
+    }
+    LayWide<NREG> lay{lane};
+    Epi::template apply<LayWide<NREG>, NG>(ea, row, lay, F, acc);
+}
+
+// ------------------------------------------------------------------ narrow gather
+template <int FP>
+__device__ __forceinline__ void load_row(const float* __restrict__ p, int F, bool vec, float (&z)[FP]) {
+    if (vec) {
+        if (FP == 2) {
+            const float2 v = *reinterpret_cast<const float2*>(p);
+            z[0] = v.x;
+            z[1] = v.y;
+        } else {
+#pragma unroll
+            for (int q = 0; q < FP / 4; ++q) {
+                const float4 v = reinterpret_cast<const float4*>(p)[q];
+                z[4 * q + 0] = v.x;
+                z[4 * q + 1] = v.y;
+                z[4 * q + 2] = v.z;
+                z[4 * q + 3] = v.w;
+            }
+        }
+    } else {
+#pragma unroll
+        for (int f = 0; f < FP; ++f) z[f] = (f < F) ? p[f] : 0.f;
+    }
+}
+
+template <int FP, int NG, int GS, class Epi>
+__global__ __launch_bounds__(256) void spmm_narrow_kernel(CsrView csr, GatherSrc g, int F, int vecmask,
+                                                          typename Epi::Args ea, float* __restrict__ partial) {
+    constexpr int GPB = 256 / GS;  // groups (work items) per block
+    const int gl = threadIdx.x % GS;
+    const int blk = acm_xcd_swizzle(blockIdx.x, gridDim.x);
+    const int w = blk * GPB + threadIdx.x / GS;
+    if (w >= csr.n_items) return;   // whole groups leave together
+    const AcmItem it = csr.items[w];
+    float acc[NG][FP];
+#pragma unroll
+    for (int c = 0; c < NG; ++c)
+#pragma unroll
+        for (int f = 0; f < FP; ++f) acc[c][f] = 0.f;
+    for (int k0 = it.begin; k0 < it.end; k0 += 2 * GS) {
+        const int ka = k0 + gl, kb = ka + GS;
+        const bool va = ka < it.end, vb = kb < it.end;
+        const int ja = va ? csr.indices[ka] : 0, jb = vb ? csr.indices[kb] : 0;
+        const float aa = va ? csr.vals[ka] : 0.f, ab = vb ? csr.vals[kb] : 0.f;
+        float za[NG][FP], zb[NG][FP];
+#pragma unroll
+        for (int c = 0; c < NG; ++c) {
+            load_row<FP>(g.p[c] + (long)ja * g.ld[c], F, (vecmask >> c) & 1, za[c]);
+            load_row<FP>(g.p[c] + (long)jb * g.ld[c], F, (vecmask >> c) & 1, zb[c]);
+        }
+#pragma unroll
+        for (int c = 0; c < NG; ++c)
+#pragma unroll
+            for (int f = 0; f < FP; ++f) {
+                // the selects keep a non-finite row 0 from leaking into rows that never reference it
+                acc[c][f] = va ? fmaf(aa, za[c][f], acc[c][f]) : acc[c][f];
+                acc[c][f] = vb ? fmaf(ab, zb[c][f], acc[c][f]) : acc[c][f];
+            }
+    }
+#pragma unroll
+    for (int c = 0; c < NG; ++c)
+#pragma unroll
+        for (int f = 0; f < FP; ++f) acc[c][f] = acm_group_sum<GS>(acc[c][f]);
+    if (it.slot < 0) {
+        LaySerial<FP> lay{gl == 0};
+        Epi::template apply<LaySerial<FP>, NG>(ea, it.row, lay, F, acc);
+    } else if (gl == 0) {
+        float* ps = partial + (long)it.slot * (NG * F);
+#pragma unroll
+        for (int c = 0; c < NG; ++c)
+#pragma unroll
+            for (int f = 0; f < FP; ++f)
+                if (f < F) ps[c * F + f] = acc[c][f];
+    }
+}
+
+// ------------------------------------------------------------------ host-side dispatch
+namespace {
+
+template <int NG, class Epi>
+int launch_gather(const acm_csr* a, const GatherSrc& g, int F, const typename Epi::Args& ea,
+                  void* workspace, size_t ws_bytes, hipStream_t st, const char* who) {
+    const size_t need = (size_t)a->n_slots * (size_t)(NG * F) * sizeof(float);
+    ACM_REQUIRE(ws_bytes >= need && (need == 0 || workspace), ACM_ENOMEM,
+                "%s: workspace %zu B < required %zu B", who, ws_bytes, need);
+    float* partial = (float*)workspace;
+    const CsrView v = acm_view(a);
+    if (a->n_items == 0) return ACM_OK;
+    if (F <= 8) {
+        int vecmask = 0;
+        const int FP = F <= 2 ? 2 : (F <= 4 ? 4 : 8);
+        for (int c = 0; c < NG; ++c) {
+            const size_t al = (FP == 2) ? 8 : 16;
+            const bool ok = (F == FP) && (((uintptr_t)g.p[c]) % al == 0) &&
+                            ((g.ld[c] * sizeof(float)) % al == 0);
+            vecmask |= ok ? (1 << c) : 0;
+        }
+        const double avg = (double)a->nnz / (double)(a->n_rows > 0 ? a->n_rows : 1);
+        const bool small_groups = avg <= 12.0;
+#define ACM_NARROW(FPv, GSv)                                                                    \
+    do {                                                                                        \
+        const int gpb = 256 / GSv;                                                              \
+        const int grid = (int)((a->n_items + gpb - 1) / gpb);                                   \
+        hipLaunchKernelGGL((spmm_narrow_kernel<FPv, NG, GSv, Epi>), dim3(grid), dim3(256), 0,  \
+                           st, v, g, F, vecmask, ea, partial);                                  \
+    } while (0)
+        if (FP == 2) {
+            if (small_groups) ACM_NARROW(2, 8); else ACM_NARROW(2, 32);
+        } else if (FP == 4) {
+            if (small_groups) ACM_NARROW(4, 8); else ACM_NARROW(4, 32);
+        } else {
+            if (small_groups) ACM_NARROW(8, 8); else ACM_NARROW(8, 32);
+        }
+#undef ACM_NARROW
+    } else {
+        ACM_REQUIRE(F <= 256, ACM_EUNSUPPORTED, "%s: F = %d > 256 columns per channel", who, F);
+        const int grid = (int)((a->n_items + 3) / 4);
+        if (F <= 64)
+            hipLaunchKernelGGL((spmm_wide_kernel<1, NG, Epi>), dim3(grid), dim3(256), 0, st, v, g, F, ea, partial);
+        else if (F <= 128)
+            hipLaunchKernelGGL((spmm_wide_kernel<2, NG, Epi>), dim3(grid), dim3(256), 0, st, v, g, F, ea, partial);
+        else
+            hipLaunchKernelGGL((spmm_wide_kernel<4, NG, Epi>), dim3(grid), dim3(256), 0, st, v, g, F, ea, partial);
+    }
+    ACM_CHECK_HIP(hipGetLastError());
+    if (a->n_long) {
+        ACM_REQUIRE(F <= 256, ACM_EUNSUPPORTED, "%s: F = %d > 256", who, F);
+        const int grid = (int)((a->n_long + 3) / 4);
+        if (F <= 64)
+            hipLaunchKernelGGL((spmm_fixup_kernel<1, NG, Epi>), dim3(grid), dim3(256), 0, st, v, F, ea, partial);
+        else if (F <= 128)
+            hipLaunchKernelGGL((spmm_fixup_kernel<2, NG, Epi>), dim3(grid), dim3(256), 0, st, v, F, ea, partial);
+        else
+            hipLaunchKernelGGL((spmm_fixup_kernel<4, NG, Epi>), dim3(grid), dim3(256), 0, st, v, F, ea, partial);
+        ACM_CHECK_HIP(hipGetLastError());
+    }
+    return ACM_OK;
+}
+
+}  // namespace
+
+extern "C" int acm_spmm(const acm_csr_t* a, const float* G, int64_t ldg, int width, float* Y,
+                        int64_t ldy, void* workspace, size_t workspace_bytes, acm_stream_t stream) {
+    ACM_REQUIRE(a && G && Y, ACM_EINVAL, "acm_spmm: NULL argument");
+    ACM_REQUIRE(width > 0 && ldg >= width && ldy >= width, ACM_ESHAPE,
+                "acm_spmm: width %d ldg %lld ldy %lld", width, (long long)ldg, (long long)ldy);
+    for (int c0 = 0; c0 < width; c0 += 256) {  // column blocks of <= 256
+        const int wd = width - c0 < 256 ? width - c0 : 256;
+        GatherSrc g = {{G + c0, nullptr, nullptr}, {ldg, 0, 0}};
+        EpiPlain::Args ea = {Y + c0, ldy};
+        int st = launch_gather<1, EpiPlain>(a, g, wd, ea, workspace, workspace_bytes,
+                                            (hipStream_t)stream, "acm_spmm");
+        if (st != ACM_OK) return st;
+    }
+    return ACM_OK;
+}
+
+extern "C" int acm_conv_fwd(const acm_csr_t* a, const acm_conv_fwd_t* p, void* workspace,
+                            size_t workspace_bytes, acm_stream_t stream) {
+    ACM_REQUIRE(a && p, ACM_EINVAL, "acm_conv_fwd: NULL argument");
+    const int F = p->f_out, k = p->n_channels;
+    ACM_REQUIRE(F > 0 && (k == 3 || k == 4), ACM_ESHAPE, "acm_conv_fwd: f_out %d n_channels %d", F, k);
+    ACM_REQUIRE(p->g_low && p->g_high && p->s_high && p->s_mlp && p->out && p->pre && p->att &&
+                    p->att_mix, ACM_EINVAL, "acm_conv_fwd: NULL tensor pointer");
+    for (int c = 0; c < k; ++c) {
+        ACM_REQUIRE(p->att_vec[c], ACM_EINVAL, "acm_conv_fwd: att_vec[%d] is NULL", c);
+        ACM_REQUIRE(!p->layernorm || (p->ln_weight[c] && p->ln_bias[c]), ACM_EINVAL,
+                    "acm_conv_fwd: layernorm parameters of channel %d are NULL", c);
+    }
+    ACM_REQUIRE(p->ld_out >= F && p->ld_pre >= (k - 1) * F, ACM_ESHAPE,
+                "acm_conv_fwd: ld_out %lld / ld_pre %lld too small", (long long)p->ld_out,
+                (long long)p->ld_pre);
+    ACM_REQUIRE(((uintptr_t)p->att) % 16 == 0, ACM_EINVAL, "acm_conv_fwd: att must be 16-byte aligned");
+    if (k == 4) {
+        ACM_REQUIRE(p->g_struc && p->s_struc && p->deg, ACM_EINVAL,
+                    "acm_conv_fwd: structure channel pointers are NULL");
+        GatherSrc g = {{p->g_low, p->g_high, p->g_struc}, {p->ld_g_low, p->ld_g_high, p->ld_g_struc}};
+        return launch_gather<3, EpiFwd>(a, g, F, *p, workspace, workspace_bytes, (hipStream_t)stream,
+                                        "acm_conv_fwd");
+    }
+    GatherSrc g = {{p->g_low, p->g_high, nullptr}, {p->ld_g_low, p->ld_g_high, 0}};
+    return launch_gather<2, EpiFwd>(a, g, F, *p, workspace, workspace_bytes, (hipStream_t)stream,
+                                    "acm_conv_fwd");
+}
+
+extern "C" int acm_conv_bwd_spmm(const acm_csr_t* at, const acm_conv_bwd_spmm_t* p, void* workspace,
+                                 size_t workspace_bytes, acm_stream_t stream) {
+    ACM_REQUIRE(at && p, ACM_EINVAL, "acm_conv_bwd_spmm: NULL argument");
+    const int F = p->f_out;
+    ACM_REQUIRE(F > 0, ACM_ESHAPE, "acm_conv_bwd_spmm: f_out %d", F);
+    ACM_REQUIRE(p->g_low && p->g_high && p->s_high && p->dz_low && p->dz_high, ACM_EINVAL,
+                "acm_conv_bwd_spmm: NULL tensor pointer");
+    if (p->g_struc) {
+        ACM_REQUIRE(p->s_struc && p->inv_deg && p->d_struc, ACM_EINVAL,
+                    "acm_conv_bwd_spmm: structure channel pointers are NULL");
+        GatherSrc g = {{p->g_low, p->g_high, p->g_struc}, {p->ld_g_low, p->ld_g_high, p->ld_g_struc}};
+        return launch_gather<3, EpiBwd>(at, g, F, *p, workspace, workspace_bytes, (hipStream_t)stream,
+                                        "acm_conv_bwd_spmm");
+    }
+    GatherSrc g = {{p->g_low, p->g_high, nullptr}, {p->ld_g_low, p->ld_g_high, 0}};
+    return launch_gather<2, EpiBwd>(at, g, F, *p, workspace, workspace_bytes, (hipStream_t)stream,
+                                    "acm_conv_bwd_spmm");
+}
+
+// ================================================================== K3: row-local backward
+// Parameter-gradient vector layout (npg = 3 k F + k k floats):
+//   [ d att_vec : k x F ][ d ln_weight : k x F ][ d ln_bias : k x F ][ d att_mix : k x k ]
+template <class L>
+struct ParamAcc {
+    float dv[4][L::NV], dgam[4][L::NV], dbet[4][L::NV], dmix[16];
+    __device__ __forceinline__ void zero() {
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+#pragma unroll
+            for (int i = 0; i < L::NV; ++i) dv[c][i] = dgam[c][i] = dbet[c][i] = 0.f;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) dmix[q] = 0.f;
+    }
+};
+
+template <class L, int K>
+__device__ __forceinline__ void conv_bwd_row(const acm_conv_bwd_local_t& p, int row, bool active,
+                                             const L& lay, ParamAcc<L>& pa) {
+    constexpr int NV = L::NV;
+    constexpr int k = K;
+    const int F = p.f_out;
+    float H[4][NV], hn[4][NV], xhat[4][NV], dO[NV];
+    bool pos[4][NV];
+    const float dg = (k == 4 && active) ? p.deg[row] : 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int col = lay.col(i);
+        const bool ok = active && col < F;
+        const float* pr = p.pre + (long)row * p.ld_pre;
+        const float p0 = ok ? pr[col] : 0.f;
+        const float p1 = ok ? pr[F + col] : 0.f;
+        const float p3 = (ok && k == 4) ? pr[2 * F + col] : 0.f;
+        const float zi = ok ? p.s_mlp[(long)row * p.ld_s_mlp + col] : 0.f;
+        dO[i] = ok ? p.grad_out[(long)row * p.ld_grad_out + col] : 0.f;
+        pos[0][i] = p.relu_after ? (p0 > 0.f) : true;
+        pos[1][i] = p.relu_after ? (p1 > 0.f) : true;
+        pos[2][i] = p.relu_mlp ? (zi > 0.f) : true;
+        pos[3][i] = p3 > 0.f;
+        H[0][i] = pos[0][i] ? p0 : 0.f;
+        H[1][i] = pos[1][i] ? p1 : 0.f;
+        H[2][i] = pos[2][i] ? zi : 0.f;
+        H[3][i] = pos[3][i] ? p3 : 0.f;
+    }
+    HeadOut ho;
+    const HeadParams hp = acm_head_params(p);
+    acm_head<L, K>(lay, F, p.layernorm, hp, H, hn, xhat, ho);
+
+    float dalpha[4], dot = 0.f;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        if (c >= k) {
+            dalpha[c] = 0.f;
+            continue;
+        }
+        float part = 0.f;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) part += dO[i] * H[c][i];
+        dalpha[c] = p.scale * lay.rsum(part);
+        dot += ho.alpha[c] * dalpha[c];
+    }
+    float dlogit[4], ds[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) dlogit[j] = (j < k) ? ho.alpha[j] * (dalpha[j] - dot) : 0.f;
+    const float invk = 1.0f / (float)k;
+    const float act = active ? 1.f : 0.f;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        if (c >= k) {
+            ds[c] = 0.f;
+            continue;
+        }
+        float dgc = 0.f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if (j < k) {
+                dgc += dlogit[j] * hp.att_mix[c * k + j];
+                pa.dmix[c * 4 + j] += act * ho.g[c] * dlogit[j] * invk;
+            }
+        dgc *= invk;
+        ds[c] = dgc * ho.g[c] * (1.f - ho.g[c]);
+    }
+    const float invF = 1.0f / (float)F;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        if (c >= k) continue;
+        float dH[NV];
+        if (p.layernorm) {
+            float dxh[NV], s1 = 0.f, s2 = 0.f;
+#pragma unroll
+            for (int i = 0; i < NV; ++i) {
+                const int col = lay.col(i);
+                const bool ok = col < F;
+                const float v = ok ? hp.att_vec[c][col] : 0.f;
+                const float gam = ok ? hp.ln_w[c][col] : 0.f;
+                const float dhn = ds[c] * v;
+                pa.dgam[c][i] += act * dhn * xhat[c][i];
+                pa.dbet[c][i] += act * dhn;
+                pa.dv[c][i] += act * ds[c] * hn[c][i];
+                dxh[i] = dhn * gam;
+                s1 += dxh[i];
+                s2 += dxh[i] * xhat[c][i];
+            }
+            const float m1 = lay.rsum(s1) * invF, m2 = lay.rsum(s2) * invF;
+#pragma unroll
+            for (int i = 0; i < NV; ++i)
+                dH[i] = p.scale * ho.alpha[c] * dO[i] + ho.rstd[c] * (dxh[i] - m1 - xhat[c][i] * m2);
+        } else {
+#pragma unroll
+            for (int i = 0; i < NV; ++i) {
+                const int col = lay.col(i);
+                const float v = (col < F) ? hp.att_vec[c][col] : 0.f;
+                pa.dv[c][i] += act * ds[c] * hn[c][i];
+                dH[i] = p.scale * ho.alpha[c] * dO[i] + ds[c] * v;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int col = lay.col(i);
+            if (!(active && col < F)) continue;
+            const float gval = pos[c][i] ? dH[i] : 0.f;
+            if (c == 0) p.g_low[(long)row * p.ld_g_low + col] = gval;
+            if (c == 1) p.g_high[(long)row * p.ld_g_high + col] = gval;
+            if (c == 2) p.g_mlp[(long)row * p.ld_g_mlp + col] = gval;
+            if (c == 3) p.g_struc[(long)row * p.ld_g_struc + col] = dg * gval;
+        }
+    }
+}
+
+// Block-level deterministic reduction of the per-lane parameter-gradient accumulators:
+// wave -> LDS slab [4][npg] -> sum over the 4 waves -> partial[block][npg].
+template <class L, int RPW /* rows per wave */, int K>
+__global__ __launch_bounds__(256) void conv_bwd_local_kernel(acm_conv_bwd_local_t p, int n_rows,
+                                                             float* __restrict__ partial) {
+    extern __shared__ float lds[];
+    constexpr int k = K;
+    const int F = p.f_out;
+    const int npg = 3 * k * F + k * k;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    L lay{lane};
+    ParamAcc<L> pa;
+    pa.zero();
+    const int rows_per_block = 4 * RPW;
+    for (int r0 = blockIdx.x * rows_per_block; r0 < n_rows; r0 += gridDim.x * rows_per_block) {
+        const int row = r0 + wv * RPW + (RPW > 1 ? lane / (64 / RPW) : 0);
+        conv_bwd_row<L, K>(p, row < n_rows ? row : 0, row < n_rows, lay, pa);
+    }
+    // combine the RPW row-groups of this wave (layout B only)
+    if (RPW > 1) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+#pragma unroll
+            for (int i = 0; i < L::NV; ++i) {
+                for (int m = 64 / RPW; m < 64; m <<= 1) {
+                    pa.dv[c][i] += __shfl_xor(pa.dv[c][i], m, 64);
+                    pa.dgam[c][i] += __shfl_xor(pa.dgam[c][i], m, 64);
+                    pa.dbet[c][i] += __shfl_xor(pa.dbet[c][i], m, 64);
+                }
+            }
+#pragma unroll
+        for (int q = 0; q < 16; ++q)
+            for (int m = 64 / RPW; m < 64; m <<= 1) pa.dmix[q] += __shfl_xor(pa.dmix[q], m, 64);
+    }
+    float* slab = lds + wv * npg;
+    const bool writer = (RPW == 1) || (lane < 64 / RPW);
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        if (c >= k) continue;
+#pragma unroll
+        for (int i = 0; i < L::NV; ++i) {
+            const int col = lay.col(i);
+            if (writer && col < F) {
+                slab[(0 * k + c) * F + col] = pa.dv[c][i];
+                slab[(1 * k + c) * F + col] = pa.dgam[c][i];
+                slab[(2 * k + c) * F + col] = pa.dbet[c][i];
+            }
+        }
+    }
+    if (lane == 0) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (c < k && j < k) slab[3 * k * F + c * k + j] = pa.dmix[c * 4 + j];
+    }
+    __syncthreads();
+    for (int q = threadIdx.x; q < npg; q += 256)
+        partial[(long)blockIdx.x * npg + q] = (lds[q] + lds[npg + q]) + (lds[2 * npg + q] + lds[3 * npg + q]);
+}
+
+// grid = npg blocks; block q sums partial[0..nblk)[q] in a fixed tree order.
+__global__ __launch_bounds__(256) void conv_bwd_reduce_kernel(acm_conv_bwd_local_t p, int nblk,
+                                                              const float* __restrict__ partial) {
+    __shared__ float red[256];
+    const int F = p.f_out, k = p.n_channels;
+    const int npg = 3 * k * F + k * k;
+    const int q = blockIdx.x;
+    float s = 0.f;
+    for (int b = threadIdx.x; b < nblk; b += 256) s += partial[(long)b * npg + q];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int m = 128; m >= 1; m >>= 1) {
+        if ((int)threadIdx.x < m) red[threadIdx.x] += red[threadIdx.x + m];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        const float v = red[0];
+        if (q < 3 * k * F) {
+            const int which = q / (k * F), c = (q / F) % k, col = q % F;
+            float* dst = which == 0 ? p.d_att_vec[c] : (which == 1 ? p.d_ln_weight[c] : p.d_ln_bias[c]);
+            if (dst) dst[col] = v;
+        } else {
+            p.d_att_mix[q - 3 * k * F] = v;
+        }
+    }
+}
+
+namespace {
+int bwd_local_blocks(int64_t n_rows, int rows_per_block) {
+    int64_t nb = (n_rows + rows_per_block - 1) / rows_per_block;
+    if (nb > 1024) nb = 1024;
+    if (nb < 1) nb = 1;
+    return (int)nb;
+}
+int bwd_rows_per_wave(int F) { return F > 32 ? 1 : (F > 16 ? 2 : (F > 8 ? 4 : (F > 4 ? 8 : (F > 2 ? 16 : 32)))); }
+}  // namespace
+
+extern "C" int acm_conv_bwd_local_workspace_bytes(int64_t n_rows, int f_out, int n_channels, size_t* bytes) {
+    ACM_REQUIRE(bytes, ACM_EINVAL, "acm_conv_bwd_local_workspace_bytes: NULL argument");
+    ACM_REQUIRE(f_out > 0 && (n_channels == 3 || n_channels == 4), ACM_ESHAPE,
+                "acm_conv_bwd_local_workspace_bytes: f_out %d n_channels %d", f_out, n_channels);
+    const int npg = 3 * n_channels * f_out + n_channels * n_channels;
+    *bytes = (size_t)bwd_local_blocks(n_rows, 4 * bwd_rows_per_wave(f_out)) * npg * sizeof(float);
+    return ACM_OK;
+}
+
+extern "C" int acm_conv_bwd_local(int64_t n_rows, const acm_conv_bwd_local_t* p, void* workspace,
+                                  size_t workspace_bytes, acm_stream_t stream) {
+    ACM_REQUIRE(p, ACM_EINVAL, "acm_conv_bwd_local: NULL argument");
+    const int F = p->f_out, k = p->n_channels;
+    ACM_REQUIRE(F > 0 && F <= 256 && (k == 3 || k == 4), (F > 256 ? ACM_EUNSUPPORTED : ACM_ESHAPE),
+                "acm_conv_bwd_local: f_out %d n_channels %d", F, k);
+    ACM_REQUIRE(p->grad_out && p->pre && p->s_mlp && p->att_mix && p->g_low && p->g_high && p->g_mlp &&
+                    p->d_att_mix, ACM_EINVAL, "acm_conv_bwd_local: NULL tensor pointer");
+    ACM_REQUIRE(k == 3 || (p->g_struc && p->deg), ACM_EINVAL,
+                "acm_conv_bwd_local: structure channel pointers are NULL");
+    for (int c = 0; c < k; ++c) {
+        ACM_REQUIRE(p->att_vec[c] && p->d_att_vec[c], ACM_EINVAL, "acm_conv_bwd_local: att_vec[%d] NULL", c);
+        ACM_REQUIRE(!p->layernorm || (p->ln_weight[c] && p->ln_bias[c] && p->d_ln_weight[c] && p->d_ln_bias[c]),
+                    ACM_EINVAL, "acm_conv_bwd_local: layernorm pointers of channel %d NULL", c);
+    }
+    size_t need = 0;
+    acm_conv_bwd_local_workspace_bytes(n_rows, F, k, &need);
+    ACM_REQUIRE(workspace && workspace_bytes >= need, ACM_ENOMEM,
+                "acm_conv_bwd_local: workspace %zu B < required %zu B", workspace_bytes, need);
+    const int npg = 3 * k * F + k * k;
+    const int rpw = bwd_rows_per_wave(F);
+    const int nblk = bwd_local_blocks(n_rows, 4 * rpw);
+    const size_t lds = (size_t)4 * npg * sizeof(float);
+    hipStream_t st = (hipStream_t)stream;
+    float* partial = (float*)workspace;
+#define ACM_BWD(LAY, RPW)                                                                                   \
+    do {                                                                                                    \
+        if (k == 3)                                                                                         \
+            hipLaunchKernelGGL((conv_bwd_local_kernel<LAY, RPW, 3>), dim3(nblk), dim3(256), lds, st, *p,    \
+                               (int)n_rows, partial);                                                       \
+        else                                                                                                \
+            hipLaunchKernelGGL((conv_bwd_local_kernel<LAY, RPW, 4>), dim3(nblk), dim3(256), lds, st, *p,    \
+                               (int)n_rows, partial);                                                       \
+    } while (0)
+    if (F > 128) ACM_BWD(LayWide<4>, 1);
+    else if (F > 64) ACM_BWD(LayWide<2>, 1);
+    else if (F > 32) ACM_BWD(LayWide<1>, 1);
+    else if (F > 16) ACM_BWD(LayPacked<32>, 2);
+    else if (F > 8) ACM_BWD(LayPacked<16>, 4);
+    else if (F > 4) ACM_BWD(LayPacked<8>, 8);
+    else if (F > 2) ACM_BWD(LayPacked<4>, 16);
+    else ACM_BWD(LayPacked<2>, 32);
+#undef ACM_BWD
+    ACM_CHECK_HIP(hipGetLastError());
+    hipLaunchKernelGGL(conv_bwd_reduce_kernel, dim3(npg), dim3(256), 0, st, *p, nblk, partial);
+    ACM_CHECK_HIP(hipGetLastError());
+    return ACM_OK;
+}

@@ -1,0 +1,274 @@
+// Graph handle: CSR row block + nnz-balanced work list, transpose, row slicing.
+// One-off preprocessing (host side); the hot path never comes through here.
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <algorithm>
+#include <new>
+#include <vector>
+
+#include "acm_common.h"
+
+static thread_local char g_err[512] = "";
+
+void acm_set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+extern "C" int acm_version(void) { return ACM_ABI_VERSION; }
+extern "C" const char* acm_last_error(void) { return g_err; }
+
+namespace {
+
+void free_handle(acm_csr* a) {
+    if (!a) return;
+    if (a->indptr) (void)hipFree(a->indptr);
+    if (a->indices) (void)hipFree(a->indices);
+    if (a->vals) (void)hipFree(a->vals);
+    if (a->items) (void)hipFree(a->items);
+    if (a->long_rows) (void)hipFree(a->long_rows);
+    delete a;
+}
+
+// Split rows into work items of at most `chunk` neighbours (long rows into
+// near-equal pieces) -- host side, from a host copy of indptr.
+void build_items(const std::vector<int32_t>& indptr, int chunk, std::vector<AcmItem>& items,
+                 std::vector<AcmLongRow>& longs, int64_t& n_slots, int32_t& max_deg) {
+    const int64_t n = (int64_t)indptr.size() - 1;
+    items.clear();
+    longs.clear();
+    items.reserve(n + n / 8);
+    n_slots = 0;
+    max_deg = 0;
+    for (int64_t r = 0; r < n; ++r) {
+        const int32_t b = indptr[r], e = indptr[r + 1];
+        const int32_t deg = e - b;
+        max_deg = std::max(max_deg, deg);
+        if (deg <= chunk) {
+            items.push_back({(int32_t)r, b, e, -1});
+        } else {
+            const int32_t pieces = (deg + chunk - 1) / chunk;
+            const int32_t per = (deg + pieces - 1) / pieces;
+            AcmLongRow lr = {(int32_t)r, (int32_t)n_slots, 0, 0};
+            for (int32_t s = b; s < e; s += per) {
+                items.push_back({(int32_t)r, s, std::min(e, s + per), (int32_t)n_slots});
+                ++n_slots;
+            }
+            lr.slot_end = (int32_t)n_slots;
+            longs.push_back(lr);
+        }
+    }
+}
+
+// Finish a handle whose indptr/indices/vals device arrays are already in place.
+int finish_handle(acm_csr* a, const std::vector<int32_t>& h_indptr, int chunk) {
+    a->chunk = chunk > 0 ? chunk : ACM_DEFAULT_CHUNK;
+    std::vector<AcmItem> items;
+    std::vector<AcmLongRow> longs;
+    build_items(h_indptr, a->chunk, items, longs, a->n_slots, a->max_degree);
+    a->n_items = (int64_t)items.size();
+    a->n_long = (int64_t)longs.size();
+    if (a->n_items) {
+        ACM_CHECK_HIP(hipMalloc((void**)&a->items, items.size() * sizeof(AcmItem)));
+        ACM_CHECK_HIP(hipMemcpy(a->items, items.data(), items.size() * sizeof(AcmItem),
+                                hipMemcpyHostToDevice));
+    }
+    if (a->n_long) {
+        ACM_CHECK_HIP(hipMalloc((void**)&a->long_rows, longs.size() * sizeof(AcmLongRow)));
+        ACM_CHECK_HIP(hipMemcpy(a->long_rows, longs.data(), longs.size() * sizeof(AcmLongRow),
+                                hipMemcpyHostToDevice));
+    }
+    return ACM_OK;
+}
+
+acm_csr* new_handle(int64_t n_rows, int64_t n_cols, int64_t nnz) {
+    acm_csr* a = new (std::nothrow) acm_csr();
+    if (!a) return nullptr;
+    memset(a, 0, sizeof(*a));
+    a->n_rows = n_rows;
+    a->n_cols = n_cols;
+    a->nnz = nnz;
+    (void)hipGetDevice(&a->device);
+    return a;
+}
+
+int alloc_arrays(acm_csr* a) {
+    ACM_CHECK_HIP(hipMalloc((void**)&a->indptr, (size_t)(a->n_rows + 1) * sizeof(int32_t)));
+    // keep the arrays non-null even for an empty graph so kernels may take their address
+    const size_t m = (size_t)std::max<int64_t>(a->nnz, 1);
+    ACM_CHECK_HIP(hipMalloc((void**)&a->indices, m * sizeof(int32_t)));
+    ACM_CHECK_HIP(hipMalloc((void**)&a->vals, m * sizeof(float)));
+    return ACM_OK;
+}
+
+}  // namespace
+
+extern "C" int acm_csr_create(int64_t n_rows, int64_t n_cols, int64_t nnz,
+                              const int32_t* indptr_dev, const int32_t* indices_dev,
+                              const float* vals_dev, int chunk, acm_csr_t** out) {
+    ACM_REQUIRE(out, ACM_EINVAL, "acm_csr_create: out is NULL");
+    *out = nullptr;
+    ACM_REQUIRE(indptr_dev, ACM_EINVAL, "acm_csr_create: indptr is NULL");
+    ACM_REQUIRE(nnz == 0 || (indices_dev && vals_dev), ACM_EINVAL,
+                "acm_csr_create: indices/vals NULL with nnz > 0");
+    ACM_REQUIRE(n_rows >= 0 && n_cols >= 0 && nnz >= 0, ACM_ESHAPE, "acm_csr_create: negative size");
+    ACM_REQUIRE(n_rows < INT32_MAX && n_cols < INT32_MAX && nnz < INT32_MAX, ACM_EUNSUPPORTED,
+                "acm_csr_create: sizes must fit int32 (rows %lld cols %lld nnz %lld)",
+                (long long)n_rows, (long long)n_cols, (long long)nnz);
+    ACM_CHECK_HIP(hipDeviceSynchronize());   // the caller's producer kernels must have finished
+    std::vector<int32_t> h_indptr((size_t)n_rows + 1);
+    ACM_CHECK_HIP(hipMemcpy(h_indptr.data(), indptr_dev, h_indptr.size() * sizeof(int32_t),
+                            hipMemcpyDeviceToHost));
+    ACM_REQUIRE(h_indptr[0] == 0 && h_indptr[n_rows] == nnz, ACM_ESHAPE,
+                "acm_csr_create: indptr[0]=%d indptr[n]=%d but nnz=%lld", h_indptr[0],
+                h_indptr[n_rows], (long long)nnz);
+    for (int64_t r = 0; r < n_rows; ++r)
+        ACM_REQUIRE(h_indptr[r] <= h_indptr[r + 1], ACM_ESHAPE,
+                    "acm_csr_create: indptr not monotone at row %lld", (long long)r);
+    if (nnz) {
+        std::vector<int32_t> h_idx((size_t)nnz);
+        ACM_CHECK_HIP(hipMemcpy(h_idx.data(), indices_dev, (size_t)nnz * sizeof(int32_t),
+                                hipMemcpyDeviceToHost));
+        for (int64_t k = 0; k < nnz; ++k)
+            ACM_REQUIRE(h_idx[k] >= 0 && h_idx[k] < n_cols, ACM_ESHAPE,
+                        "acm_csr_create: column id %d out of range at position %lld", h_idx[k],
+                        (long long)k);
+    }
+    acm_csr* a = new_handle(n_rows, n_cols, nnz);
+    ACM_REQUIRE(a, ACM_ENOMEM, "acm_csr_create: host allocation failed");
+    int st = alloc_arrays(a);
+    if (st == ACM_OK) {
+        hipError_t e = hipMemcpy(a->indptr, indptr_dev, (size_t)(n_rows + 1) * sizeof(int32_t),
+                                 hipMemcpyDeviceToDevice);
+        if (e == hipSuccess && nnz)
+            e = hipMemcpy(a->indices, indices_dev, (size_t)nnz * sizeof(int32_t),
+                          hipMemcpyDeviceToDevice);
+        if (e == hipSuccess && nnz)
+            e = hipMemcpy(a->vals, vals_dev, (size_t)nnz * sizeof(float), hipMemcpyDeviceToDevice);
+        if (e != hipSuccess) {
+            acm_set_error("acm_csr_create: device copy failed: %s", hipGetErrorString(e));
+            st = ACM_EHIP;
+        }
+    }
+    if (st == ACM_OK) st = finish_handle(a, h_indptr, chunk);
+    if (st != ACM_OK) {
+        free_handle(a);
+        return st;
+    }
+    *out = a;
+    return ACM_OK;
+}
+
+extern "C" int acm_csr_transpose(const acm_csr_t* a, int chunk, acm_csr_t** out) {
+    ACM_REQUIRE(a && out, ACM_EINVAL, "acm_csr_transpose: NULL argument");
+    *out = nullptr;
+    ACM_CHECK_HIP(hipDeviceSynchronize());
+    const int64_t n = a->n_rows, m = a->n_cols, nnz = a->nnz;
+    std::vector<int32_t> ip((size_t)n + 1), ix((size_t)nnz);
+    std::vector<float> v((size_t)nnz);
+    ACM_CHECK_HIP(hipMemcpy(ip.data(), a->indptr, ip.size() * sizeof(int32_t), hipMemcpyDeviceToHost));
+    if (nnz) {
+        ACM_CHECK_HIP(hipMemcpy(ix.data(), a->indices, (size_t)nnz * sizeof(int32_t), hipMemcpyDeviceToHost));
+        ACM_CHECK_HIP(hipMemcpy(v.data(), a->vals, (size_t)nnz * sizeof(float), hipMemcpyDeviceToHost));
+    }
+    // stable counting sort by column: rows of A^T come out sorted by original row id
+    std::vector<int32_t> tp((size_t)m + 1, 0), tx((size_t)nnz);
+    std::vector<float> tv((size_t)nnz);
+    for (int64_t k = 0; k < nnz; ++k) ++tp[(size_t)ix[k] + 1];
+    for (int64_t c = 0; c < m; ++c) tp[c + 1] += tp[c];
+    std::vector<int32_t> cur(tp.begin(), tp.end() - 1);
+    for (int64_t r = 0; r < n; ++r)
+        for (int32_t k = ip[r]; k < ip[r + 1]; ++k) {
+            const int32_t pos = cur[ix[k]]++;
+            tx[pos] = (int32_t)r;
+            tv[pos] = v[k];
+        }
+    acm_csr* t = new_handle(m, n, nnz);
+    ACM_REQUIRE(t, ACM_ENOMEM, "acm_csr_transpose: host allocation failed");
+    int st = alloc_arrays(t);
+    if (st == ACM_OK) {
+        hipError_t e = hipMemcpy(t->indptr, tp.data(), tp.size() * sizeof(int32_t), hipMemcpyHostToDevice);
+        if (e == hipSuccess && nnz)
+            e = hipMemcpy(t->indices, tx.data(), (size_t)nnz * sizeof(int32_t), hipMemcpyHostToDevice);
+        if (e == hipSuccess && nnz)
+            e = hipMemcpy(t->vals, tv.data(), (size_t)nnz * sizeof(float), hipMemcpyHostToDevice);
+        if (e != hipSuccess) {
+            acm_set_error("acm_csr_transpose: upload failed: %s", hipGetErrorString(e));
+            st = ACM_EHIP;
+        }
+    }
+    if (st == ACM_OK) st = finish_handle(t, tp, chunk > 0 ? chunk : a->chunk);
+    if (st != ACM_OK) {
+        free_handle(t);
+        return st;
+    }
+    *out = t;
+    return ACM_OK;
+}
+
+extern "C" int acm_csr_slice_rows(const acm_csr_t* a, int64_t row_begin, int64_t row_end, int chunk,
+                                  acm_csr_t** out) {
+    ACM_REQUIRE(a && out, ACM_EINVAL, "acm_csr_slice_rows: NULL argument");
+    *out = nullptr;
+    ACM_REQUIRE(0 <= row_begin && row_begin <= row_end && row_end <= a->n_rows, ACM_ESHAPE,
+                "acm_csr_slice_rows: bad range [%lld,%lld) of %lld rows", (long long)row_begin,
+                (long long)row_end, (long long)a->n_rows);
+    ACM_CHECK_HIP(hipDeviceSynchronize());
+    const int64_t n = row_end - row_begin;
+    std::vector<int32_t> ip((size_t)n + 1);
+    ACM_CHECK_HIP(hipMemcpy(ip.data(), a->indptr + row_begin, ip.size() * sizeof(int32_t),
+                            hipMemcpyDeviceToHost));
+    const int32_t base = ip[0];
+    for (auto& x : ip) x -= base;
+    const int64_t nnz = ip[n];
+    acm_csr* s = new_handle(n, a->n_cols, nnz);
+    ACM_REQUIRE(s, ACM_ENOMEM, "acm_csr_slice_rows: host allocation failed");
+    int st = alloc_arrays(s);
+    if (st == ACM_OK) {
+        hipError_t e = hipMemcpy(s->indptr, ip.data(), ip.size() * sizeof(int32_t), hipMemcpyHostToDevice);
+        if (e == hipSuccess && nnz)
+            e = hipMemcpy(s->indices, a->indices + base, (size_t)nnz * sizeof(int32_t), hipMemcpyDeviceToDevice);
+        if (e == hipSuccess && nnz)
+            e = hipMemcpy(s->vals, a->vals + base, (size_t)nnz * sizeof(float), hipMemcpyDeviceToDevice);
+        if (e != hipSuccess) {
+            acm_set_error("acm_csr_slice_rows: copy failed: %s", hipGetErrorString(e));
+            st = ACM_EHIP;
+        }
+    }
+    if (st == ACM_OK) st = finish_handle(s, ip, chunk > 0 ? chunk : a->chunk);
+    if (st != ACM_OK) {
+        free_handle(s);
+        return st;
+    }
+    *out = s;
+    return ACM_OK;
+}
+
+extern "C" void acm_csr_destroy(acm_csr_t* a) { free_handle(a); }
+
+extern "C" int acm_csr_info(const acm_csr_t* a, acm_csr_info_t* info) {
+    ACM_REQUIRE(a && info, ACM_EINVAL, "acm_csr_info: NULL argument");
+    info->n_rows = a->n_rows;
+    info->n_cols = a->n_cols;
+    info->nnz = a->nnz;
+    info->n_items = a->n_items;
+    info->n_long_rows = a->n_long;
+    info->n_partial_slots = a->n_slots;
+    info->chunk = a->chunk;
+    info->max_degree = a->max_degree;
+    info->indptr = a->indptr;
+    info->indices = a->indices;
+    info->vals = a->vals;
+    return ACM_OK;
+}
+
+extern "C" int acm_spmm_workspace_bytes(const acm_csr_t* a, int width, size_t* bytes) {
+    ACM_REQUIRE(a && bytes, ACM_EINVAL, "acm_spmm_workspace_bytes: NULL argument");
+    ACM_REQUIRE(width > 0, ACM_ESHAPE, "acm_spmm_workspace_bytes: width must be positive");
+    *bytes = (size_t)a->n_slots * (size_t)width * sizeof(float);
+    return ACM_OK;
+}

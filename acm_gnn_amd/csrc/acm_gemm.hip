@@ -1,0 +1,253 @@
+// K1 / K5: dense fp32 GEMM on the gfx950 f32 MFMA pipe (v_mfma_f32_16x16x4_f32: exact fp32,
+// bitwise an fmaf chain in k order), for the per-channel projections of the ACM layer:
+//     Z      = X * [W_L | W_H | W_I]          (N x F_in) * (F_in x 3F)      NN, optional ReLU
+//     dWcat  = X^T * dZ                       (F_in x N) * (N x 3F)         TN, split-K over N
+//     dX     = dZ * Wcat^T                    (N x 3F) * (3F x F_in)        NT
+// Shapes are skinny and ragged (F_in = 7 .. 4814, 3F = 6 .. 192, N ~ 1e5), so every tile edge
+// is guarded and there are three tile shapes:
+//     64 x 64   (2x2 waves, 2x2 MFMA tiles each)   general
+//     16 x 256  (1x4 waves, 1x4 tiles each)        M <= 16  (dW of a 7-feature input)
+//     256 x 16  (4x1 waves, 4x1 tiles each)        N <= 16  (projection to 3*C classes)
+// Tiles are staged through LDS (BK = 32) in whichever orientation keeps the *global* reads
+// contiguous, with the next K-slab prefetched into registers while the current one feeds MFMA.
+#include "acm_common.h"
+
+namespace {
+
+constexpr int BK = 32;
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// LDS tile addressing.  KMAJOR: global memory is contiguous along k (A not transposed /
+// B transposed): tile[mn][k], row stride BK + 1.  Otherwise contiguous along m/n:
+// tile[k][mn], row stride BMN + 16 (so k and k + 1 land on different bank halves).
+template <bool KMAJOR, int BMN>
+struct TileLds {
+    static constexpr int STRIDE = KMAJOR ? (BK + 1) : (BMN + 16);
+    static constexpr int SIZE = KMAJOR ? BMN * STRIDE : BK * STRIDE;
+    static __device__ __forceinline__ int at(int mn, int k) {
+        return KMAJOR ? mn * STRIDE + k : k * STRIDE + mn;
+    }
+};
+
+// Global -> register staging of one BMN x BK tile.  `gmn`/`gk` strides are in elements.
+template <bool KMAJOR, int BMN>
+struct TileLoad {
+    static constexpr int PER_THREAD = BMN * BK / 256;
+    float r[PER_THREAD];
+    __device__ __forceinline__ void load(const float* __restrict__ base, long s_mn, long s_k, int mn0,
+                                         int mn_lim, int k0, int k_lim) {
+#pragma unroll
+        for (int i = 0; i < PER_THREAD; ++i) {
+            const int idx = threadIdx.x + i * 256;
+            const int mn = KMAJOR ? idx / BK : idx % BMN;
+            const int kk = KMAJOR ? idx % BK : idx / BMN;
+            const int gmn = mn0 + mn, gk = k0 + kk;
+            r[i] = (gmn < mn_lim && gk < k_lim) ? base[(long)gmn * s_mn + (long)gk * s_k] : 0.f;
+        }
+    }
+    __device__ __forceinline__ void store(float* __restrict__ lds) const {
+#pragma unroll
+        for (int i = 0; i < PER_THREAD; ++i) {
+            const int idx = threadIdx.x + i * 256;
+            const int mn = KMAJOR ? idx / BK : idx % BMN;
+            const int kk = KMAJOR ? idx % BK : idx / BMN;
+            lds[TileLds<KMAJOR, BMN>::at(mn, kk)] = r[i];
+        }
+    }
+};
+
+// C tile = op(A) op(B) over k in [k_begin, k_end) of split blockIdx.z.
+template <int WM, int WN, int WAVES_M, int WAVES_N, bool TA, bool TB>
+__global__ __launch_bounds__(256) void gemm_kernel(int M, int N, int K, const float* __restrict__ A, long lda,
+                                                   const float* __restrict__ B, long ldb,
+                                                   float* __restrict__ C, long ldc, int relu, int k_per_split,
+                                                   float* __restrict__ slabs) {
+    constexpr int BM = 16 * WM * WAVES_M, BN = 16 * WN * WAVES_N;
+    constexpr bool A_KMAJOR = !TA, B_KMAJOR = TB;
+    using LA = TileLds<A_KMAJOR, BM>;
+    using LB = TileLds<B_KMAJOR, BN>;
+    __shared__ float lds[LA::SIZE + LB::SIZE];
+    float* As = lds;
+    float* Bs = lds + LA::SIZE;
+
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int wm = wv / WAVES_N, wn = wv % WAVES_N;
+    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+    const int k_begin = blockIdx.z * k_per_split;
+    const int k_end = min(K, k_begin + k_per_split);
+    // element strides of op(A)[m][k] and op(B)[k][n] in memory
+    const long a_sm = TA ? 1 : lda, a_sk = TA ? lda : 1;
+    const long b_sn = TB ? ldb : 1, b_sk = TB ? 1 : ldb;
+
+    f32x4 acc[WM][WN];
+#pragma unroll
+    for (int i = 0; i < WM; ++i)
+#pragma unroll
+        for (int j = 0; j < WN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    TileLoad<A_KMAJOR, BM> ta;
+    TileLoad<B_KMAJOR, BN> tb;
+    if (k_begin < k_end) {
+        ta.load(A, a_sm, a_sk, m0, M, k_begin, k_end);
+        tb.load(B, b_sn, b_sk, n0, N, k_begin, k_end);
+    }
+    for (int k0 = k_begin; k0 < k_end; k0 += BK) {
+        ta.store(As);
+        tb.store(Bs);
+        __syncthreads();
+        if (k0 + BK < k_end) {  // prefetch the next slab while this one feeds the MFMAs
+            ta.load(A, a_sm, a_sk, m0, M, k0 + BK, k_end);
+            tb.load(B, b_sn, b_sk, n0, N, k0 + BK, k_end);
+        }
+#pragma unroll
+        for (int ks = 0; ks < BK / 4; ++ks) {
+            const int kk = ks * 4 + (lane >> 4);
+            float a[WM], b[WN];
+#pragma unroll
+            for (int i = 0; i < WM; ++i) a[i] = As[LA::at((wm * WM + i) * 16 + (lane & 15), kk)];
+#pragma unroll
+            for (int j = 0; j < WN; ++j) b[j] = Bs[LB::at((wn * WN + j) * 16 + (lane & 15), kk)];
+#pragma unroll
+            for (int i = 0; i < WM; ++i)
+#pragma unroll
+                for (int j = 0; j < WN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], b[j], acc[i][j], 0, 0, 0);
+        }
+        __syncthreads();
+    }
+    // C/D fragment: col = lane & 15, row = (lane >> 4) * 4 + reg
+    float* dst = C;
+    long ldd = ldc;
+    if (slabs) {
+        dst = slabs + (long)blockIdx.z * M * N;
+        ldd = N;
+    }
+#pragma unroll
+    for (int i = 0; i < WM; ++i)
+#pragma unroll
+        for (int j = 0; j < WN; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = m0 + (wm * WM + i) * 16 + (lane >> 4) * 4 + r;
+                const int col = n0 + (wn * WN + j) * 16 + (lane & 15);
+                if (row < M && col < N) {
+                    float v = acc[i][j][r];
+                    if (relu && !slabs) v = fmaxf(v, 0.f);
+                    dst[(long)row * ldd + col] = v;
+                }
+            }
+}
+
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(int M, int N, int splits,
+                                                            const float* __restrict__ slabs,
+                                                            float* __restrict__ C, long ldc, int relu) {
+    const long total = (long)M * N;
+    for (long q = (long)blockIdx.x * 256 + threadIdx.x; q < total; q += (long)gridDim.x * 256) {
+        float s = 0.f;
+        for (int z = 0; z < splits; ++z) s += slabs[(long)z * total + q];
+        if (relu) s = fmaxf(s, 0.f);
+        C[(q / N) * ldc + (q % N)] = s;
+    }
+}
+
+struct GemmPlan {
+    int shape;  // 0: 64x64, 1: 16x256, 2: 256x16
+    int bm, bn, splits, k_per_split;
+    dim3 grid;
+};
+
+GemmPlan plan_gemm(int64_t M, int64_t N, int64_t K) {
+    GemmPlan p;
+    if (N <= 16 && M > 16) {
+        p.shape = 2; p.bm = 256; p.bn = 16;
+    } else if (M <= 16) {
+        p.shape = 1; p.bm = 16; p.bn = 256;
+    } else {
+        p.shape = 0; p.bm = 64; p.bn = 64;
+    }
+    const int64_t tm = (M + p.bm - 1) / p.bm, tn = (N + p.bn - 1) / p.bn;
+    const int64_t tiles = tm * tn;
+    int64_t splits = 1;
+    if (tiles < 256 && K >= 8 * BK) {  // too few tiles to fill 256 CUs: split K
+        const int64_t want = (768 + tiles - 1) / tiles;
+        const int64_t kmax = (K + 4 * BK - 1) / (4 * BK);  // keep >= 4 slabs per split
+        splits = want < kmax ? want : kmax;
+        if (splits < 1) splits = 1;
+    }
+    int64_t kps = (K + splits - 1) / splits;
+    kps = (kps + BK - 1) / BK * BK;
+    if (kps < BK) kps = BK;
+    splits = K > 0 ? (K + kps - 1) / kps : 1;
+    p.splits = (int)splits;
+    p.k_per_split = (int)kps;
+    p.grid = dim3((unsigned)tn, (unsigned)tm, (unsigned)splits);
+    return p;
+}
+
+template <int WM, int WN, int WVM, int WVN>
+void launch_shape(int ta, int tb, const GemmPlan& p, hipStream_t st, int M, int N, int K, const float* A,
+                  long lda, const float* B, long ldb, float* C, long ldc, int relu, float* slabs) {
+#define ACM_GEMM_LAUNCH(TAv, TBv)                                                                        \
+    hipLaunchKernelGGL((gemm_kernel<WM, WN, WVM, WVN, TAv, TBv>), p.grid, dim3(256), 0, st, M, N, K, A, \
+                       lda, B, ldb, C, ldc, relu, p.k_per_split, slabs)
+    if (!ta && !tb) ACM_GEMM_LAUNCH(false, false);
+    else if (ta && !tb) ACM_GEMM_LAUNCH(true, false);
+    else if (!ta && tb) ACM_GEMM_LAUNCH(false, true);
+    else ACM_GEMM_LAUNCH(true, true);
+#undef ACM_GEMM_LAUNCH
+}
+
+}  // namespace
+
+extern "C" int acm_gemm_workspace_bytes(int transA, int transB, int64_t M, int64_t N, int64_t K,
+                                        size_t* bytes) {
+    (void)transA;
+    (void)transB;
+    ACM_REQUIRE(bytes, ACM_EINVAL, "acm_gemm_workspace_bytes: NULL argument");
+    ACM_REQUIRE(M >= 0 && N >= 0 && K >= 0, ACM_ESHAPE, "acm_gemm_workspace_bytes: negative size");
+    const GemmPlan p = plan_gemm(M, N, K);
+    *bytes = p.splits > 1 ? (size_t)p.splits * (size_t)M * (size_t)N * sizeof(float) : 0;
+    return ACM_OK;
+}
+
+extern "C" int acm_gemm(int transA, int transB, int64_t M, int64_t N, int64_t K, const float* A,
+                        int64_t lda, const float* B, int64_t ldb, float* C, int64_t ldc, int relu,
+                        void* workspace, size_t workspace_bytes, acm_stream_t stream) {
+    ACM_REQUIRE(M >= 0 && N >= 0 && K >= 0, ACM_ESHAPE, "acm_gemm: negative size");
+    ACM_REQUIRE(M < INT32_MAX && N < INT32_MAX && K < INT32_MAX, ACM_EUNSUPPORTED, "acm_gemm: size >= 2^31");
+    if (M == 0 || N == 0) return ACM_OK;
+    ACM_REQUIRE(C && (K == 0 || (A && B)), ACM_EINVAL, "acm_gemm: NULL matrix pointer");
+    ACM_REQUIRE(lda >= (transA ? M : K) && ldb >= (transB ? K : N) && ldc >= N, ACM_ESHAPE,
+                "acm_gemm: leading dimension too small (lda %lld ldb %lld ldc %lld)", (long long)lda,
+                (long long)ldb, (long long)ldc);
+    hipStream_t st = (hipStream_t)stream;
+    const GemmPlan p = plan_gemm(M, N, K);
+    ACM_REQUIRE(p.grid.y <= 65535 && p.grid.z <= 65535, ACM_EUNSUPPORTED, "acm_gemm: grid too large");
+    float* slabs = nullptr;
+    if (p.splits > 1) {
+        const size_t need = (size_t)p.splits * (size_t)M * (size_t)N * sizeof(float);
+        ACM_REQUIRE(workspace && workspace_bytes >= need, ACM_ENOMEM,
+                    "acm_gemm: workspace %zu B < required %zu B", workspace_bytes, need);
+        slabs = (float*)workspace;
+    }
+    if (K == 0) {  // empty sum
+        ACM_CHECK_HIP(hipMemset2DAsync(C, (size_t)ldc * sizeof(float), 0, (size_t)N * sizeof(float), (size_t)M, st));
+        return ACM_OK;
+    }
+    if (p.shape == 0)
+        launch_shape<2, 2, 2, 2>(transA, transB, p, st, (int)M, (int)N, (int)K, A, lda, B, ldb, C, ldc, relu, slabs);
+    else if (p.shape == 1)
+        launch_shape<1, 4, 1, 4>(transA, transB, p, st, (int)M, (int)N, (int)K, A, lda, B, ldb, C, ldc, relu, slabs);
+    else
+        launch_shape<4, 1, 4, 1>(transA, transB, p, st, (int)M, (int)N, (int)K, A, lda, B, ldb, C, ldc, relu, slabs);
+    ACM_CHECK_HIP(hipGetLastError());
+    if (slabs) {
+        const long total = (long)M * N;
+        int grid = (int)((total + 255) / 256);
+        if (grid > 2048) grid = 2048;
+        hipLaunchKernelGGL(splitk_reduce_kernel, dim3(grid), dim3(256), 0, st, (int)M, (int)N, p.splits, slabs,
+                           C, (long)ldc, relu);
+        ACM_CHECK_HIP(hipGetLastError());
+    }
+    return ACM_OK;
+}

@@ -1,0 +1,296 @@
+"""Operator-level host code: thin wrappers over the C ABI and the autograd
+Functions that make the HIP kernels differentiable.
+
+Every function here launches HIP kernels from libacm_hip.so on the current
+torch stream.  There is deliberately no eager/torch fallback: a CPU tensor or a
+missing library is an error.
+"""
+import ctypes as C
+
+import torch
+
+from . import _lib
+from .graph import CsrGraph, FilterOperators, _require_cuda, _stream
+
+_F32 = torch.float32
+
+
+def _vp(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else None
+
+
+def _as_f32c(t, name):
+    _require_cuda(t, name)
+    if t.dtype != _F32:
+        t = t.to(_F32)
+    return t.contiguous()
+
+
+# --------------------------------------------------------------------------
+# raw (non-differentiable) launches
+# --------------------------------------------------------------------------
+def gemm(a, b, trans_a=False, trans_b=False, relu=False, out=None):
+    """out = op(a) @ op(b) on the fp32 MFMA pipe (acm_gemm)."""
+    a, b = _as_f32c(a, "a"), _as_f32c(b, "b")
+    m, k = (a.shape[1], a.shape[0]) if trans_a else (a.shape[0], a.shape[1])
+    k2, n = (b.shape[1], b.shape[0]) if trans_b else (b.shape[0], b.shape[1])
+    if k != k2:
+        raise ValueError(f"gemm: inner dimensions differ ({k} vs {k2})")
+    if out is None:
+        out = torch.empty(m, n, dtype=_F32, device=a.device)
+    lib = _lib.load()
+    nbytes = C.c_size_t()
+    _lib.check(lib.acm_gemm_workspace_bytes(int(trans_a), int(trans_b), m, n, k, C.byref(nbytes)))
+    ws = torch.empty(max(nbytes.value // 4, 1), dtype=_F32, device=a.device) if nbytes.value else None
+    with torch.cuda.device(a.device):
+        st = lib.acm_gemm(int(trans_a), int(trans_b), m, n, k, _vp(a), a.stride(0), _vp(b), b.stride(0),
+                          _vp(out), out.stride(0), int(relu), _vp(ws), nbytes.value, _stream())
+    _lib.check(st, "acm_gemm")
+    return out
+
+
+def spmm(graph, dense, out=None):
+    """out = A @ dense for a CsrGraph A (acm_spmm)."""
+    dense = _as_f32c(dense, "dense")
+    if dense.shape[0] != graph.n_cols:
+        raise ValueError(f"spmm: dense has {dense.shape[0]} rows, operator has {graph.n_cols} columns")
+    width = dense.shape[1]
+    if out is None:
+        out = torch.empty(graph.n_rows, width, dtype=_F32, device=dense.device)
+    if width == 0 or graph.n_rows == 0:
+        return out
+    ws = graph.workspace(min(width, 256))
+    with torch.cuda.device(dense.device):
+        st = _lib.load().acm_spmm(graph.handle, _vp(dense), dense.stride(0), width, _vp(out), out.stride(0),
+                                  _vp(ws), ws.numel() * 4, _stream())
+    _lib.check(st, "acm_spmm")
+    return out
+
+
+class _Mm(torch.autograd.Function):
+    """Differentiable dense product on acm_gemm (used by the trivial layer branches)."""
+
+    @staticmethod
+    def forward(ctx, a, b):
+        ctx.save_for_backward(a, b)
+        return gemm(a, b)
+
+    @staticmethod
+    def backward(ctx, g):
+        a, b = ctx.saved_tensors
+        g = g.contiguous()
+        ga = gemm(g, b, trans_b=True) if ctx.needs_input_grad[0] else None
+        gb = gemm(a, g, trans_a=True) if ctx.needs_input_grad[1] else None
+        return ga, gb
+
+
+def mm(a, b):
+    return _Mm.apply(a, b)
+
+
+# --------------------------------------------------------------------------
+# the fused ACM layer
+# --------------------------------------------------------------------------
+class AcmConfig:
+    """Static description of one layer variant (what the reference selects with
+    model_type / variant / structure_info, ACM-Geometric/layers.py:78-116)."""
+
+    __slots__ = ("n_channels", "relu_before", "relu_after", "relu_mlp", "layernorm", "scale")
+
+    def __init__(self, model_type, variant, structure_info, attn_layernorm):
+        plus = model_type in ("acmgcnp", "acmgcnpp", "acmgcn+", "acmgcn++")
+        if model_type == "acmsgc":
+            self.n_channels, self.relu_before, self.relu_after, self.relu_mlp = 3, False, False, False
+            self.layernorm = False
+        else:
+            self.n_channels = 4 if (plus and structure_info) else 3
+            self.relu_before = bool(variant)          # ACMII: ReLU between projection and filter
+            self.relu_after = not bool(variant)       # ACM: ReLU after the filter
+            self.relu_mlp = True
+            self.layernorm = bool(attn_layernorm) and plus
+        self.scale = 1.0 if self.n_channels == 4 else 3.0
+
+
+def _ptr_array(tensors):
+    arr = (C.c_void_p * 4)()
+    for i in range(4):
+        arr[i] = tensors[i].data_ptr() if i < len(tensors) and tensors[i] is not None else None
+    return arr
+
+
+def _gather_rows(ops, local):
+    """All-gather row blocks of a row-sharded dense matrix (halo exchange).  Single
+    process: identity."""
+    if not ops.sharded:
+        return local
+    import torch.distributed as dist
+    world = dist.get_world_size(ops.group)
+    full = torch.empty(world * local.shape[0], local.shape[1], dtype=local.dtype, device=local.device)
+    dist.all_gather_into_tensor(full, local.contiguous(), group=ops.group)
+    return full[: ops.n_global] if full.shape[0] != ops.n_global else full
+
+
+class AcmConvFunction(torch.autograd.Function):
+    """out, att = ACM layer(x; parameters) over the operators in ``ops``.
+
+    forward : K1 acm_gemm (X [W_L|W_H|W_I]) -> K2 acm_conv_fwd
+    backward: K3 acm_conv_bwd_local -> K4 acm_conv_bwd_spmm -> K5 acm_gemm (X^T dZ, dZ Wcat^T)
+    """
+
+    @staticmethod
+    def forward(ctx, x, w_low, w_high, w_mlp, v_low, v_high, v_mlp, v_struc, struc_low, att_mix,
+                lnw_low, lnw_high, lnw_mlp, lnw_struc, lnb_low, lnb_high, lnb_mlp, lnb_struc, ops, cfg):
+        lib = _lib.load()
+        x = _as_f32c(x, "input")
+        dev = x.device
+        n, f = x.shape[0], w_low.shape[1]
+        k = cfg.n_channels
+        if n != ops.n_local:
+            raise ValueError(f"input has {n} rows but the graph operator has {ops.n_local}")
+        wcat = torch.cat([w_low, w_high, w_mlp], dim=1).to(_F32).contiguous()      # [F_in, 3F]
+        z = gemm(x, wcat, relu=cfg.relu_before)                                     # [n, 3F]
+        zg = _gather_rows(ops, z[:, : 2 * f]) if ops.sharded else z                 # gathered [Z_L|Z_H]
+        four = k == 4
+        if four:
+            if ops.deg is None:
+                raise RuntimeError("structure_info=1 needs adj_low_unnormalized")
+            s_local = _as_f32c(struc_low, "struc_low")
+            if s_local.shape[0] != n:
+                raise ValueError("struc_low rows != local nodes")
+            s_gath = _gather_rows(ops, s_local)
+        vecs = [_as_f32c(t, "att_vec") for t in ((v_low, v_high, v_mlp, v_struc) if four else (v_low, v_high, v_mlp))]
+        lnw = [_as_f32c(t, "ln") for t in (lnw_low, lnw_high, lnw_mlp, lnw_struc)[:k]] if cfg.layernorm else []
+        lnb = [_as_f32c(t, "ln") for t in (lnb_low, lnb_high, lnb_mlp, lnb_struc)[:k]] if cfg.layernorm else []
+        mix = _as_f32c(att_mix, "att_vec")
+        if tuple(mix.shape) != (k, k):
+            raise RuntimeError(f"att_vec is {tuple(mix.shape)} but the layer mixes {k} channels "
+                               "(structure_info is only valid with acmgcnp/acmgcnpp)")
+        out = torch.empty(n, f, dtype=_F32, device=dev)
+        pre = torch.empty(n, (k - 1) * f, dtype=_F32, device=dev)
+        att = torch.empty(n, 4, dtype=_F32, device=dev)
+        p = _lib.ConvFwd()
+        p.f_out, p.n_channels = f, k
+        p.relu_after, p.relu_mlp, p.layernorm = int(cfg.relu_after), int(cfg.relu_mlp), int(cfg.layernorm)
+        p.scale, p.row_offset = cfg.scale, ops.row_offset
+        p.g_low, p.ld_g_low = zg.data_ptr(), zg.stride(0)
+        p.g_high, p.ld_g_high = zg.data_ptr() + 4 * f, zg.stride(0)
+        p.s_high, p.ld_s_high = z.data_ptr() + 4 * f, z.stride(0)
+        p.s_mlp, p.ld_s_mlp = z.data_ptr() + 8 * f, z.stride(0)
+        if four:
+            p.g_struc, p.ld_g_struc = s_gath.data_ptr(), s_gath.stride(0)
+            p.s_struc, p.ld_s_struc = s_local.data_ptr(), s_local.stride(0)
+            p.deg = ops.deg.data_ptr()
+        p.att_vec = _ptr_array(vecs)
+        p.ln_weight, p.ln_bias = _ptr_array(lnw), _ptr_array(lnb)
+        p.att_mix = mix.data_ptr()
+        p.out, p.ld_out = out.data_ptr(), out.stride(0)
+        p.pre, p.ld_pre = pre.data_ptr(), pre.stride(0)
+        p.att = att.data_ptr()
+        ws = ops.low.workspace((k - 1) * f)
+        with torch.cuda.device(dev):
+            st = lib.acm_conv_fwd(ops.low.handle, C.byref(p), _vp(ws), ws.numel() * 4, _stream())
+        _lib.check(st, "acm_conv_fwd")
+        ctx.ops, ctx.cfg = ops, cfg
+        ctx.save_for_backward(x, wcat, z, pre, mix, *vecs, *lnw, *lnb)
+        ctx.mark_non_differentiable(att)
+        return out, att
+
+    @staticmethod
+    def backward(ctx, grad_out, _grad_att):
+        lib = _lib.load()
+        ops, cfg = ctx.ops, ctx.cfg
+        k = cfg.n_channels
+        saved = ctx.saved_tensors
+        x, wcat, z, pre, mix = saved[:5]
+        vecs = list(saved[5:5 + k])
+        lnw = list(saved[5 + k:5 + 2 * k]) if cfg.layernorm else []
+        lnb = list(saved[5 + 2 * k:5 + 3 * k]) if cfg.layernorm else []
+        dev = x.device
+        n, f = x.shape[0], wcat.shape[1] // 3
+        grad_out = _as_f32c(grad_out, "grad_out")
+        four = k == 4
+
+        g = torch.empty(n, 2 * f, dtype=_F32, device=dev)            # [G_L | G_H]
+        dz = torch.empty(n, 3 * f, dtype=_F32, device=dev)           # [dZ_L | dZ_H | dZ_I]
+        gs = torch.empty(n, f, dtype=_F32, device=dev) if four else None
+        d_vec = [torch.empty(f, 1, dtype=_F32, device=dev) for _ in range(k)]
+        d_lnw = [torch.empty(f, dtype=_F32, device=dev) for _ in range(k)] if cfg.layernorm else []
+        d_lnb = [torch.empty(f, dtype=_F32, device=dev) for _ in range(k)] if cfg.layernorm else []
+        d_mix = torch.empty(k, k, dtype=_F32, device=dev)
+
+        q = _lib.ConvBwdLocal()
+        q.f_out, q.n_channels = f, k
+        q.relu_after, q.relu_mlp, q.layernorm, q.scale = int(cfg.relu_after), int(cfg.relu_mlp), int(cfg.layernorm), cfg.scale
+        q.grad_out, q.ld_grad_out = grad_out.data_ptr(), grad_out.stride(0)
+        q.pre, q.ld_pre = pre.data_ptr(), pre.stride(0)
+        q.s_mlp, q.ld_s_mlp = z.data_ptr() + 8 * f, z.stride(0)
+        q.deg = ops.deg.data_ptr() if four else None
+        q.att_vec, q.ln_weight, q.ln_bias = _ptr_array(vecs), _ptr_array(lnw), _ptr_array(lnb)
+        q.att_mix = mix.data_ptr()
+        q.g_low, q.ld_g_low = g.data_ptr(), g.stride(0)
+        q.g_high, q.ld_g_high = g.data_ptr() + 4 * f, g.stride(0)
+        q.g_mlp, q.ld_g_mlp = dz.data_ptr() + 8 * f, dz.stride(0)
+        if four:
+            q.g_struc, q.ld_g_struc = gs.data_ptr(), gs.stride(0)
+        q.d_att_vec, q.d_ln_weight, q.d_ln_bias = _ptr_array(d_vec), _ptr_array(d_lnw), _ptr_array(d_lnb)
+        q.d_att_mix = d_mix.data_ptr()
+        nbytes = C.c_size_t()
+        _lib.check(lib.acm_conv_bwd_local_workspace_bytes(n, f, k, C.byref(nbytes)))
+        ws = torch.empty(max(nbytes.value // 4, 1), dtype=_F32, device=dev)
+        with torch.cuda.device(dev):
+            st = lib.acm_conv_bwd_local(n, C.byref(q), _vp(ws), ws.numel() * 4, _stream())
+        _lib.check(st, "acm_conv_bwd_local")
+
+        gg = _gather_rows(ops, g)
+        gsg = _gather_rows(ops, gs) if four else None
+        d_struc = torch.empty(n, f, dtype=_F32, device=dev) if four else None
+        r = _lib.ConvBwdSpmm()
+        r.f_out, r.row_offset = f, ops.row_offset
+        r.g_low, r.ld_g_low = gg.data_ptr(), gg.stride(0)
+        r.g_high, r.ld_g_high = gg.data_ptr() + 4 * f, gg.stride(0)
+        r.s_high, r.ld_s_high = g.data_ptr() + 4 * f, g.stride(0)
+        if four:
+            r.g_struc, r.ld_g_struc = gsg.data_ptr(), gsg.stride(0)
+            r.s_struc, r.ld_s_struc = gs.data_ptr(), gs.stride(0)
+            r.inv_deg = ops.inv_deg.data_ptr()
+            r.d_struc, r.ld_d_struc = d_struc.data_ptr(), d_struc.stride(0)
+        if cfg.relu_before:                       # ACMII: ReLU mask of the projected features
+            r.mask_low, r.ld_mask_low = z.data_ptr(), z.stride(0)
+            r.mask_high, r.ld_mask_high = z.data_ptr() + 4 * f, z.stride(0)
+        r.dz_low, r.ld_dz_low = dz.data_ptr(), dz.stride(0)
+        r.dz_high, r.ld_dz_high = dz.data_ptr() + 4 * f, dz.stride(0)
+        low_t = ops.low_t
+        ws2 = low_t.workspace((k - 1) * f)
+        with torch.cuda.device(dev):
+            st = lib.acm_conv_bwd_spmm(low_t.handle, C.byref(r), _vp(ws2), ws2.numel() * 4, _stream())
+        _lib.check(st, "acm_conv_bwd_spmm")
+
+        d_wcat = gemm(x, dz, trans_a=True)                                   # [F_in, 3F]
+        d_x = gemm(dz, wcat, trans_b=True) if ctx.needs_input_grad[0] else None
+        small = [d_wcat, d_mix] + d_vec + d_lnw + d_lnb
+        if ops.sharded:                             # replicated parameters: sum the row-shard partials
+            import torch.distributed as dist
+            flat = torch.cat([t.reshape(-1) for t in small])
+            dist.all_reduce(flat, group=ops.group)
+            off = 0
+            for t in small:
+                t.copy_(flat[off:off + t.numel()].view_as(t))
+                off += t.numel()
+        d_wl, d_wh, d_wm = (d_wcat[:, i * f:(i + 1) * f] for i in range(3))
+        none4 = [None] * 4
+        grads_vec = d_vec + [None] * (4 - k)
+        grads_lnw = (d_lnw + [None] * (4 - k)) if cfg.layernorm else none4
+        grads_lnb = (d_lnb + [None] * (4 - k)) if cfg.layernorm else none4
+        return (d_x, d_wl, d_wh, d_wm, grads_vec[0], grads_vec[1], grads_vec[2], grads_vec[3],
+                d_struc, d_mix, *grads_lnw, *grads_lnb, None, None)
+
+
+def acm_conv(x, params, ops, cfg):
+    """params: dict with the reference's parameter names (see layers.GraphConvolution)."""
+    p = params
+    return AcmConvFunction.apply(
+        x, p["weight_low"], p["weight_high"], p["weight_mlp"], p["att_vec_low"], p["att_vec_high"],
+        p["att_vec_mlp"], p["att_struc_low"], p["struc_low"], p["att_vec"],
+        p["layer_norm_low.weight"], p["layer_norm_high.weight"], p["layer_norm_mlp.weight"],
+        p["layer_norm_struc_low.weight"], p["layer_norm_low.bias"], p["layer_norm_high.bias"],
+        p["layer_norm_mlp.bias"], p["layer_norm_struc_low.bias"], ops, cfg)

@@ -1,0 +1,252 @@
+"""Device-resident CSR operators for the ACM filters.
+
+``CsrGraph`` owns an ``acm_csr_t`` handle (CSR arrays + nnz-balanced work list
+in HBM).  ``FilterOperators`` bundles what one ACM layer needs: A_low, its
+transpose (backward), and -- for the structure channel -- the degree vector
+``d = rowsum(I + A)`` that turns A_low into the raw adjacency
+(``A = D A_low - I``).
+
+``operators_for(adj_low, adj_high, adj_un)`` is the drop-in entry: it accepts
+the tensors the reference hands to ``GraphConvolution.forward`` (sparse COO,
+possibly un-coalesced, ACM-Geometric/utils.py:21-28; dense strided ``adj_low``,
+ACM-Pytorch/utils.py:619-629), converts once and caches by storage identity.
+"""
+import ctypes as C
+import weakref
+
+import torch
+
+from . import _lib
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _require_cuda(t, name):
+    if not t.is_cuda:
+        raise RuntimeError(
+            f"acm_gnn_amd: {name} is on {t.device}; the ACM operators run only on an AMD GPU "
+            "(there is no CPU fallback)")
+
+
+class CsrGraph:
+    """A CSR row block in HBM with its work list (``acm_csr_t``)."""
+
+    def __init__(self, handle, device):
+        self._h = C.c_void_p(handle)
+        self.device = device
+        info = _lib.CsrInfo()
+        _lib.check(_lib.load().acm_csr_info(self._h, C.byref(info)), "acm_csr_info")
+        self.n_rows, self.n_cols, self.nnz = info.n_rows, info.n_cols, info.nnz
+        self.n_items, self.n_long_rows = info.n_items, info.n_long_rows
+        self.n_partial_slots, self.chunk, self.max_degree = info.n_partial_slots, info.chunk, info.max_degree
+        self._ptrs = (info.indptr, info.indices, info.vals)
+        self._transposed = None
+        self._finalizer = weakref.finalize(self, _lib.load().acm_csr_destroy, C.c_void_p(handle))
+
+    # ---- construction ----------------------------------------------------
+    @classmethod
+    def from_csr(cls, indptr, indices, vals, n_cols, chunk=0):
+        """indptr/indices/vals: device tensors (int32/int32/float32)."""
+        _require_cuda(indptr, "indptr")
+        indptr = indptr.to(torch.int32).contiguous()
+        indices = indices.to(device=indptr.device, dtype=torch.int32).contiguous()
+        vals = vals.to(device=indptr.device, dtype=torch.float32).contiguous()
+        n_rows, nnz = indptr.numel() - 1, indices.numel()
+        if vals.numel() != nnz:
+            raise ValueError(f"vals has {vals.numel()} entries, indices {nnz}")
+        out = C.c_void_p()
+        with torch.cuda.device(indptr.device):
+            torch.cuda.current_stream().synchronize()
+            st = _lib.load().acm_csr_create(n_rows, int(n_cols), nnz, indptr.data_ptr(),
+                                            indices.data_ptr() if nnz else None,
+                                            vals.data_ptr() if nnz else None, int(chunk), C.byref(out))
+        _lib.check(st, "acm_csr_create")
+        return cls(out.value, indptr.device)
+
+    @classmethod
+    def from_torch(cls, adj, chunk=0):
+        """Sparse COO (coalesced or not) / sparse CSR / dense strided square-or-not matrix."""
+        _require_cuda(adj, "adjacency")
+        if adj.layout == torch.sparse_csr:
+            return cls.from_csr(adj.crow_indices(), adj.col_indices(), adj.values(), adj.shape[1], chunk)
+        if adj.layout == torch.strided:
+            adj = adj.to_sparse()
+        if adj.layout != torch.sparse_coo:
+            raise TypeError(f"unsupported adjacency layout {adj.layout}")
+        adj = adj.coalesce()                      # sorts by (row, col), sums duplicates
+        idx, vals = adj.indices(), adj.values().to(torch.float32)
+        n_rows, n_cols = adj.shape
+        counts = torch.bincount(idx[0], minlength=n_rows)
+        indptr = torch.zeros(n_rows + 1, dtype=torch.int64, device=adj.device)
+        indptr[1:] = torch.cumsum(counts, 0)
+        return cls.from_csr(indptr.to(torch.int32), idx[1].to(torch.int32), vals, n_cols, chunk)
+
+    @classmethod
+    def from_scipy(cls, mat, device, chunk=0):
+        m = mat.tocsr()
+        m.sort_indices()
+        dev = torch.device(device)
+        return cls.from_csr(torch.from_numpy(m.indptr.astype("int32")).to(dev),
+                            torch.from_numpy(m.indices.astype("int32")).to(dev),
+                            torch.from_numpy(m.data.astype("float32")).to(dev), m.shape[1], chunk)
+
+    # ---- derived operators ----------------------------------------------
+    def transpose(self):
+        if self._transposed is None:
+            out = C.c_void_p()
+            with torch.cuda.device(self.device):
+                _lib.check(_lib.load().acm_csr_transpose(self._h, 0, C.byref(out)), "acm_csr_transpose")
+            self._transposed = CsrGraph(out.value, self.device)
+        return self._transposed
+
+    def slice_rows(self, begin, end):
+        out = C.c_void_p()
+        with torch.cuda.device(self.device):
+            _lib.check(_lib.load().acm_csr_slice_rows(self._h, int(begin), int(end), 0, C.byref(out)),
+                       "acm_csr_slice_rows")
+        return CsrGraph(out.value, self.device)
+
+    # ---- views (tests, sharding) -----------------------------------------
+    def arrays(self):
+        """(indptr, indices, vals) copied out to new torch tensors."""
+        import numpy as np  # local: plumbing only
+        def pull(ptr, n, dtype):
+            t = torch.empty(n, dtype=dtype, device=self.device)
+            if n:
+                C.cdll.LoadLibrary("libamdhip64.so").hipMemcpy(
+                    C.c_void_p(t.data_ptr()), C.c_void_p(ptr), C.c_size_t(n * t.element_size()), 3)
+            return t
+        torch.cuda.synchronize(self.device)
+        return (pull(self._ptrs[0], self.n_rows + 1, torch.int32),
+                pull(self._ptrs[1], self.nnz, torch.int32),
+                pull(self._ptrs[2], self.nnz, torch.float32))
+
+    def workspace(self, width):
+        nbytes = C.c_size_t()
+        _lib.check(_lib.load().acm_spmm_workspace_bytes(self._h, int(width), C.byref(nbytes)),
+                   "acm_spmm_workspace_bytes")
+        n = max(nbytes.value // 4, 1)
+        return torch.empty(n, dtype=torch.float32, device=self.device)
+
+    @property
+    def handle(self):
+        return self._h
+
+    def __repr__(self):
+        return (f"CsrGraph({self.n_rows}x{self.n_cols}, nnz={self.nnz}, items={self.n_items}, "
+                f"long_rows={self.n_long_rows}, max_degree={self.max_degree})")
+
+
+class FilterOperators:
+    """What one ACM layer needs from the graph, for the rows this process owns."""
+
+    def __init__(self, low, deg=None, row_offset=0, n_global=None, group=None):
+        self.low = low                                  # A_low rows (local) x columns (global)
+        self._low_t = None
+        self.deg = deg                                  # d_i for local rows, or None
+        self.inv_deg = (1.0 / deg) if deg is not None else None
+        self.row_offset = int(row_offset)
+        self.n_global = int(n_global if n_global is not None else low.n_cols)
+        self.group = group                              # torch.distributed group when row-sharded
+        self.low_t_override = None                      # local rows of the global A_low^T (sharded)
+
+    @property
+    def low_t(self):
+        if self.low_t_override is not None:
+            return self.low_t_override
+        if self._low_t is None:
+            self._low_t = self.low.transpose()
+        return self._low_t
+
+    @property
+    def n_local(self):
+        return self.low.n_rows
+
+    @property
+    def sharded(self):
+        return self.group is not None
+
+
+# --------------------------------------------------------------------------
+# verification of the identities the fused kernel relies on
+# --------------------------------------------------------------------------
+def _spmm_raw(graph, dense):
+    from .functional import spmm
+    return spmm(graph, dense)
+
+
+def verify_high_is_identity_minus_low(low, adj_high, tol=1e-5):
+    """adj_high must equal I - adj_low (ACM-Geometric/train.py:78, ACM-Pytorch/utils.py:622)."""
+    if adj_high is None:
+        return True
+    high = CsrGraph.from_torch(adj_high)
+    if (high.n_rows, high.n_cols) != (low.n_rows, low.n_cols) or low.n_rows != low.n_cols:
+        return False
+    gen = torch.Generator(device="cpu").manual_seed(1234)
+    r = torch.randn(low.n_cols, 4, generator=gen).to(low.device)
+    lhs = _spmm_raw(high, r)
+    rhs = r - _spmm_raw(low, r)
+    return bool(torch.allclose(lhs, rhs, rtol=tol, atol=tol))
+
+
+def degree_from_unnormalized(low, adj_un, tol=1e-4):
+    """d = 1 + rowsum(A) and a check that A = D A_low - I (train.py:76-77)."""
+    un = CsrGraph.from_torch(adj_un)
+    ones = torch.ones(un.n_cols, 1, device=low.device)
+    deg = (_spmm_raw(un, ones) + 1.0).reshape(-1).contiguous()
+    gen = torch.Generator(device="cpu").manual_seed(4321)
+    r = torch.randn(low.n_cols, 4, generator=gen).to(low.device)
+    lhs = _spmm_raw(un, r)
+    rhs = deg[:, None] * _spmm_raw(low, r) - r
+    ok = bool(torch.allclose(lhs, rhs, rtol=tol, atol=tol * float(deg.max())))
+    return deg, ok
+
+
+_CACHE = {}
+_CACHE_LIMIT = 16
+
+
+def _key(t):
+    if t is None:
+        return None
+    if t.layout == torch.sparse_coo:
+        v = t._values()
+        return ("coo", v.data_ptr(), t._indices().data_ptr(), t._nnz(), tuple(t.shape), str(t.device))
+    if t.layout == torch.sparse_csr:
+        return ("csr", t.values().data_ptr(), t.col_indices().data_ptr(), tuple(t.shape), str(t.device))
+    return ("dense", t.data_ptr(), tuple(t.shape), tuple(t.stride()), str(t.device))
+
+
+def operators_for(adj_low, adj_high=None, adj_low_unnormalized=None, verify=True):
+    """Convert the reference's adjacency tensors once; cached by storage identity."""
+    if isinstance(adj_low, FilterOperators):
+        return adj_low
+    key = (_key(adj_low), _key(adj_high), _key(adj_low_unnormalized))
+    hit = _CACHE.get(key)
+    if hit is not None:
+        return hit
+    _require_cuda(adj_low, "adj_low")
+    low = CsrGraph.from_torch(adj_low)
+    if verify and not verify_high_is_identity_minus_low(low, adj_high):
+        raise NotImplementedError(
+            "acm_gnn_amd: adj_high != I - adj_low; the fused MI355X kernel folds the high-pass "
+            "channel into the A_low pass and supports only the reference's filter pair "
+            "(ACM-Geometric/train.py:77-78)")
+    deg = None
+    if adj_low_unnormalized is not None:
+        deg, ok = degree_from_unnormalized(low, adj_low_unnormalized)
+        if verify and not ok:
+            raise NotImplementedError(
+                "acm_gnn_amd: adj_low_unnormalized != D*adj_low - I; the structure channel is folded "
+                "into the A_low pass and needs the reference's normalisation (train.py:76-77)")
+    ops = FilterOperators(low, deg)
+    if len(_CACHE) >= _CACHE_LIMIT:
+        _CACHE.pop(next(iter(_CACHE)))
+    _CACHE[key] = ops
+    return ops
+
+
+def clear_cache():
+    _CACHE.clear()

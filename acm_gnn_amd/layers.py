@@ -1,0 +1,146 @@
+"""``GraphConvolution`` / ``MLP`` with the reference's interface, running on the
+MI355X kernels.
+
+Mirror of ACM-Geometric/layers.py:13-163 and ACM-Pytorch/models/layers.py:14-285:
+same constructor signature, parameter names (``state_dict`` compatible),
+initialisation scheme, ``forward(input, adj_low, adj_high, adj_low_unnormalized)``
+signature, ``att_low/att_high/att_mlp[/att_struc_vec_low]`` attributes after a
+forward, and ``__repr__``.  The arithmetic is the fused HIP path in
+``functional.AcmConvFunction``; nothing here falls back to torch ops.
+
+One thing the reference decides implicitly is made explicit (SURVEY.md quirk
+Q1): whether LayerNorm feeds the attention logits of ``acmgcnp``/``acmgcnpp``.
+ACM-Geometric does (layers.py:59,67), ACM-Pytorch never does because its layer
+tests for the spellings ``"acmgcn+"/"acmgcn++"`` (models/layers.py:96,123).
+``attn_layernorm=None`` resolves to ``DEFAULT_ATTN_LAYERNORM`` (True, the
+ACM-Geometric behaviour) -- ``acm_gnn_amd.dropin`` flips it for ACM-Pytorch.
+"""
+import math
+
+import torch
+import torch.nn as nn
+from torch.nn.parameter import Parameter
+
+from . import functional as AF
+from .graph import FilterOperators, operators_for
+
+DEFAULT_ATTN_LAYERNORM = True
+_PLUS_LITERAL = ("acmgcn+", "acmgcn++")          # spellings for which ACM-Pytorch's LN fires
+_PLUS = ("acmgcnp", "acmgcnpp") + _PLUS_LITERAL
+
+
+def _default_device():
+    # the reference places parameters on cuda:0 when a GPU exists (layers.py:10-11)
+    return torch.device("cuda:0" if torch.cuda.is_available() else "cpu")
+
+
+class GraphConvolution(nn.Module):
+    def __init__(self, in_features, out_features, nnodes, model_type, output_layer=0, variant=False,
+                 structure_info=0, attn_layernorm=None):
+        super().__init__()
+        self.in_features, self.out_features = in_features, out_features
+        self.output_layer, self.model_type = output_layer, model_type
+        self.structure_info, self.variant = structure_info, variant
+        if attn_layernorm is None:
+            attn_layernorm = True if model_type in _PLUS_LITERAL else DEFAULT_ATTN_LAYERNORM
+        self.attn_layernorm = bool(attn_layernorm)
+        self.att_low, self.att_high, self.att_mlp = 0, 0, 0
+        dev = _default_device()
+
+        def new(*shape):
+            return Parameter(torch.empty(*shape, dtype=torch.float32, device=dev))
+
+        self.weight_low, self.weight_high, self.weight_mlp = (new(in_features, out_features) for _ in range(3))
+        self.att_vec_low, self.att_vec_high, self.att_vec_mlp = (new(out_features, 1) for _ in range(3))
+        self.layer_norm_low, self.layer_norm_high, self.layer_norm_mlp = (nn.LayerNorm(out_features) for _ in range(3))
+        self.layer_norm_struc_low, self.layer_norm_struc_high = nn.LayerNorm(out_features), nn.LayerNorm(out_features)
+        self.att_struc_low = new(out_features, 1)
+        self.struc_low = new(nnodes, out_features)
+        k = 3 if structure_info == 0 else 4
+        self.att_vec = new(k, k)
+        self.reset_parameters()
+
+    def reset_parameters(self):
+        # same draw order as the reference (layers.py:31-54) so a seeded CPU init matches it
+        bound_w = 1.0 / math.sqrt(self.weight_mlp.size(1))
+        bound_v = 1.0 / math.sqrt(self.att_vec_mlp.size(1))
+        bound_m = 1.0 / math.sqrt(self.att_vec.size(1))
+        for p in (self.weight_low, self.weight_high, self.weight_mlp, self.struc_low):
+            p.data.uniform_(-bound_w, bound_w)
+        for p in (self.att_vec_high, self.att_vec_low, self.att_vec_mlp, self.att_struc_low):
+            p.data.uniform_(-bound_v, bound_v)
+        self.att_vec.data.uniform_(-bound_m, bound_m)
+        for ln in (self.layer_norm_low, self.layer_norm_high, self.layer_norm_mlp,
+                   self.layer_norm_struc_low, self.layer_norm_struc_high):
+            ln.reset_parameters()
+
+    # ------------------------------------------------------------------
+    def _config(self):
+        return AF.AcmConfig(self.model_type, self.variant, self.structure_info, self.attn_layernorm)
+
+    def _param_dict(self):
+        return {
+            "weight_low": self.weight_low, "weight_high": self.weight_high, "weight_mlp": self.weight_mlp,
+            "att_vec_low": self.att_vec_low, "att_vec_high": self.att_vec_high, "att_vec_mlp": self.att_vec_mlp,
+            "att_struc_low": self.att_struc_low, "struc_low": self.struc_low, "att_vec": self.att_vec,
+            "layer_norm_low.weight": self.layer_norm_low.weight, "layer_norm_low.bias": self.layer_norm_low.bias,
+            "layer_norm_high.weight": self.layer_norm_high.weight, "layer_norm_high.bias": self.layer_norm_high.bias,
+            "layer_norm_mlp.weight": self.layer_norm_mlp.weight, "layer_norm_mlp.bias": self.layer_norm_mlp.bias,
+            "layer_norm_struc_low.weight": self.layer_norm_struc_low.weight,
+            "layer_norm_struc_low.bias": self.layer_norm_struc_low.bias,
+        }
+
+    def forward(self, input, adj_low, adj_high=None, adj_low_unnormalized=None):
+        mt = self.model_type
+        if mt == "mlp":
+            return AF.mm(input, self.weight_mlp)
+        if mt in ("sgc", "gcn"):
+            # the reference calls the dense torch.mm here, so adj_low must be dense (layers.py:83-85)
+            if isinstance(adj_low, torch.Tensor) and adj_low.layout != torch.strided:
+                raise RuntimeError("model_type 'sgc'/'gcn' multiplies with torch.mm: adj_low must be dense")
+            return AF.mm(adj_low, AF.mm(input, self.weight_low))
+        cfg = self._config()
+        if isinstance(adj_low, FilterOperators):
+            ops = adj_low
+        else:
+            ops = operators_for(adj_low, adj_high, adj_low_unnormalized if cfg.n_channels == 4 else None)
+        out, att = AF.acm_conv(input, self._param_dict(), ops, cfg)
+        self.att_low, self.att_high, self.att_mlp = att[:, 0:1], att[:, 1:2], att[:, 2:3]
+        if cfg.n_channels == 4:
+            self.att_struc_vec_low = att[:, 3:4]
+        return out
+
+    def __repr__(self):
+        return f"{self.__class__.__name__} ({self.in_features} -> {self.out_features})"
+
+
+class MLP(nn.Module):
+    """Linear stack with ReLU -> BatchNorm -> dropout between layers (the residual
+    branch of ACM-GCN++ uses num_layers=1, i.e. a single Linear; layers.py:123-163)."""
+
+    def __init__(self, in_channels, hidden_channels, out_channels, num_layers, dropout=0.5):
+        super().__init__()
+        self.lins, self.bns = nn.ModuleList(), nn.ModuleList()
+        if num_layers == 1:
+            self.lins.append(nn.Linear(in_channels, out_channels))
+            self.bns.append(nn.BatchNorm1d(out_channels))
+        else:
+            self.lins.append(nn.Linear(in_channels, hidden_channels))
+            self.bns.append(nn.BatchNorm1d(hidden_channels))
+            for _ in range(num_layers - 2):
+                self.lins.append(nn.Linear(hidden_channels, hidden_channels))
+                self.bns.append(nn.BatchNorm1d(hidden_channels))
+            self.lins.append(nn.Linear(hidden_channels, out_channels))
+        self.dropout = dropout
+
+    def reset_parameters(self):
+        for m in list(self.lins) + list(self.bns):
+            m.reset_parameters()
+
+    def forward(self, data, input_tensor=False):
+        x = data if input_tensor else data.graph["node_feat"]
+        for lin, bn in zip(self.lins[:-1], self.bns):
+            x = torch.relu(lin(x))
+            x = bn(x)
+            x = nn.functional.dropout(x, p=self.dropout, training=self.training)
+        return self.lins[-1](x)

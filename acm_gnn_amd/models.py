@@ -1,0 +1,65 @@
+"""Two-layer ACM model: the caller of the hot path (ACM-Geometric/models.py:23-76,
+ACM-Pytorch/models/models.py:25-166), restated so the op can be trained and
+measured on the GPU box (the reference's Python never travels there).
+
+    x -> dropout -> GraphConvolution(nfeat -> nhid) -> relu -> dropout
+      [-> + dropout(relu(Linear(x)))   for acmgcnpp]
+      -> GraphConvolution(nhid -> nclass)
+
+Same constructor signature and ``forward(x, adj_low, adj_high, adj_low_unnormalized)``.
+Differences, on purpose: ``acmsgc`` is constructible (a single linear ACM layer,
+nfeat -> nclass; the reference raises TypeError) and
+``acmsnowball`` is rejected explicitly instead of failing inside __init__.
+"""
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from .layers import GraphConvolution, MLP
+
+_TWO_LAYER = ("acmgcn", "acmgcnp", "acmgcnpp")
+
+
+class GCN(nn.Module):
+    def __init__(self, nfeat, nhid, nclass, nlayers, nnodes, dropout, model_type, structure_info,
+                 variant=False, init_layers_X=1, attn_layernorm=None):
+        super().__init__()
+        self.model_type, self.structure_info = model_type, structure_info
+        self.nlayers, self.nnodes, self.dropout = nlayers, nnodes, dropout
+        if model_type == "acmgcnpp":
+            self.mlpX = MLP(nfeat, nhid, nhid, num_layers=init_layers_X, dropout=0)
+        self.gcns, self.mlps = nn.ModuleList(), nn.ModuleList()
+        kw = dict(model_type=model_type, variant=variant, structure_info=structure_info,
+                  attn_layernorm=attn_layernorm)
+        if model_type in _TWO_LAYER:
+            self.gcns.append(GraphConvolution(nfeat, nhid, nnodes, **kw))
+            self.gcns.append(GraphConvolution(nhid, nclass, nnodes, output_layer=1, **kw))
+        elif model_type == "acmsgc":
+            self.gcns.append(GraphConvolution(nfeat, nclass, nnodes, model_type=model_type, output_layer=1))
+        else:
+            raise ValueError(f"GCN: unsupported model_type {model_type!r} "
+                             "(acmgcn | acmgcnp | acmgcnpp | acmsgc)")
+        # The reference also registers two never-initialised 1x1 parameters (fea_param,
+        # xX_param; models.py:41) that take no part in the forward.  They are kept so
+        # state_dict keys and optimizer parameter lists line up, zero-filled.
+        dev = self.gcns[0].weight_low.device
+        self.fea_param = nn.Parameter(torch.zeros(1, 1, device=dev))
+        self.xX_param = nn.Parameter(torch.zeros(1, 1, device=dev))
+        self.reset_parameters()
+
+    def reset_parameters(self):
+        if self.model_type == "acmgcnpp":
+            self.mlpX.reset_parameters()
+
+    def forward(self, x, adj_low, adj_high=None, adj_low_unnormalized=None):
+        drop = lambda t: F.dropout(t, self.dropout, training=self.training)  # noqa: E731
+        x = drop(x)
+        if self.model_type == "acmsgc":
+            return self.gcns[0](x, adj_low, adj_high, adj_low_unnormalized)
+        if self.model_type == "acmgcnpp":
+            xx = drop(F.relu(self.mlpX(x, input_tensor=True)))
+        fea = self.gcns[0](x, adj_low, adj_high, adj_low_unnormalized)
+        fea = drop(F.relu(fea))
+        if self.model_type == "acmgcnpp":
+            fea = fea + xx
+        return self.gcns[1](fea, adj_low, adj_high, adj_low_unnormalized)

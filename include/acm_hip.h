@@ -1,0 +1,225 @@
+/*
+ * acm_hip.h -- C ABI of libacm_hip.so, the MI355X (gfx950) implementation of the
+ * ACM graph-convolution hot path.
+ *
+ * The reference (SitaoLuan/ACM-GNN) is pure Python; its "FFI" for this path is
+ * the set of torch ATen calls issued by GraphConvolution.forward and by the
+ * autograd graph they record.  Every entry point below names the reference
+ * call sites it replaces (paths relative to the reference root; G =
+ * ACM-Geometric/layers.py, P = ACM-Pytorch/models/layers.py).
+ *
+ * Conventions
+ *   - plain C: opaque handles, POD structs of device pointers and sizes, no
+ *     torch/C++ types, no exceptions across the boundary.
+ *   - every function returns ACM_OK (0) or an acm_status_t; the message for
+ *     the last failure on the calling thread is acm_last_error().
+ *   - all device buffers (inputs, outputs, saved tensors, workspaces) are owned
+ *     by the caller; the library allocates device memory only inside
+ *     acm_csr_create / acm_csr_transpose / acm_csr_slice_rows.
+ *   - all launches are asynchronous on the hipStream_t passed in (as void*);
+ *     no internal synchronisation, no global mutable state => hipGraph-capturable.
+ *   - fp32 everywhere (the reference computes in torch.FloatTensor, G:19-28),
+ *     int32 indices, row-major dense matrices with explicit leading dimensions.
+ */
+#ifndef ACM_HIP_H
+#define ACM_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ACM_ABI_VERSION 1
+
+typedef enum {
+    ACM_OK = 0,
+    ACM_EINVAL = 1,        /* null pointer / bad flag                          */
+    ACM_ESHAPE = 2,        /* inconsistent sizes                               */
+    ACM_EHIP = 3,          /* a HIP runtime call failed (text in last_error)   */
+    ACM_EUNSUPPORTED = 4,  /* valid request outside the implemented envelope   */
+    ACM_ENOMEM = 5,        /* caller workspace too small                       */
+} acm_status_t;
+
+typedef struct acm_csr acm_csr_t;   /* opaque: CSR row block + balanced work list */
+typedef void* acm_stream_t;         /* hipStream_t                                */
+
+int acm_version(void);
+const char* acm_last_error(void);
+
+/* ------------------------------------------------------------------ graph --
+ * acm_csr_create: adopt (copy) a CSR row block living in device memory and
+ * build the nnz-balanced work list the kernels walk (rows longer than `chunk`
+ * neighbours are split into several work items whose partial sums are combined
+ * deterministically in a second phase).  Rows are local (0..n_rows), column
+ * ids index the gathered matrix (0..n_cols) -- for a row-sharded graph n_cols
+ * is the global node count.
+ * Replaces: the sparse-COO tensors built at ACM-Geometric/train.py:75-81 /
+ * ACM-Pytorch/utils.py:619-629 and the per-call COO coalesce inside
+ * torch.spmm (G:87-103).  `chunk` <= 0 selects the default (256).
+ */
+int acm_csr_create(int64_t n_rows, int64_t n_cols, int64_t nnz,
+                   const int32_t* indptr_dev, const int32_t* indices_dev,
+                   const float* vals_dev, int chunk, acm_csr_t** out);
+/* Transposed operator (n_cols x n_rows) for the backward SpMM; what autograd's
+ * SparseAddmmBackward computes implicitly for loss.backward()
+ * (ACM-Geometric/train.py:135). Deterministic (stable counting sort). */
+int acm_csr_transpose(const acm_csr_t* a, int chunk, acm_csr_t** out);
+/* Row block [row_begin,row_end) of an existing operator (multi-GPU row shard). */
+int acm_csr_slice_rows(const acm_csr_t* a, int64_t row_begin, int64_t row_end,
+                       int chunk, acm_csr_t** out);
+void acm_csr_destroy(acm_csr_t* a);
+
+typedef struct {
+    int64_t n_rows, n_cols, nnz;
+    int64_t n_items;          /* work items (one wave / lane-group each)  */
+    int64_t n_long_rows;      /* rows split over several items            */
+    int64_t n_partial_slots;  /* partial-sum slots those rows need        */
+    int32_t chunk;
+    int32_t max_degree;
+    const int32_t* indptr;    /* device pointers owned by the handle      */
+    const int32_t* indices;
+    const float* vals;
+} acm_csr_info_t;
+int acm_csr_info(const acm_csr_t* a, acm_csr_info_t* info);
+
+/* Bytes of caller-provided workspace the SpMM-type entry points need for an
+ * operator when `width` fp32 columns are accumulated per row. */
+int acm_spmm_workspace_bytes(const acm_csr_t* a, int width, size_t* bytes);
+
+/* ----------------------------------------------------------------- GEMM --
+ * C[M,N] = op(A)[M,K] * op(B)[K,N]  (fp32 in / fp32 accumulate on the f32 MFMA
+ * pipe), optional ReLU epilogue.  transX = 0: X is stored row-major as written;
+ * 1: stored transposed (so op(X) = X^T).
+ * Replaces torch.mm(input, self.weight_*) G:87-89,96-104 / P:162-194 (one call
+ * with the three weights concatenated), and the MmBackward GEMMs X^T*dZ and
+ * dZ*W^T.  Workspace: acm_gemm_workspace_bytes (split-K partial slabs).
+ */
+int acm_gemm_workspace_bytes(int transA, int transB, int64_t M, int64_t N, int64_t K,
+                             size_t* bytes);
+int acm_gemm(int transA, int transB, int64_t M, int64_t N, int64_t K,
+             const float* A, int64_t lda, const float* B, int64_t ldb,
+             float* C, int64_t ldc, int relu, void* workspace, size_t workspace_bytes,
+             acm_stream_t stream);
+
+/* ----------------------------------------------------------------- SpMM --
+ * Y[r, 0:width] = sum_j A[r,j] * G[j, 0:width]   (plain CSR x dense; used for
+ * k-hop ACM-SGC chains -- ACM-Pytorch/utils.py:631-637 -- and by tests).
+ */
+int acm_spmm(const acm_csr_t* a, const float* G, int64_t ldg, int width,
+             float* Y, int64_t ldy, void* workspace, size_t workspace_bytes,
+             acm_stream_t stream);
+
+/* ---------------------------------------------------- fused ACM layer (K2) --
+ * One pass over A_low computes every graph channel and the adaptive mixing:
+ *
+ *   P_L = A_low * ZL            P_H = A_low * ZH           [P_S = A_low * S]
+ *   pre_L = P_L                 pre_H = ZH_self - P_H      [pre_S = deg * P_S - S_self]
+ *   H_c  = relu(pre_c)  (variant/acmsgc: identity on L,H -- the ReLU was applied by the GEMM)
+ *   H_I  = relu(ZI_self) (acmsgc: identity)
+ *   att  = softmax( sigmoid([LN_c](H_c) . v_c)_c  *  M / k )          k = 3 | 4
+ *   out  = scale * sum_c att_c * H_c
+ *
+ * Replaces G:86-116 / P:162-232 after the three torch.mm: 2-3 torch.spmm, 3-4
+ * relu, 3-4 LayerNorm, 3-4 skinny mm, cat, sigmoid, mm, softmax, mul/add.
+ * `A_high * Z = Z - A_low * Z` and `A * S = D (A_low S) - S` are exact
+ * identities of the reference's filters (train.py:77-78).
+ */
+typedef struct {
+    int32_t f_out;            /* F: columns per channel                                 */
+    int32_t n_channels;       /* k = 3, or 4 with the structure channel                 */
+    int32_t relu_after;       /* 1: ReLU on pre_L/pre_H (ACM);  0: ACMII / acmsgc       */
+    int32_t relu_mlp;         /* 1: ReLU on the identity channel; 0: acmsgc             */
+    int32_t layernorm;        /* 1: LayerNorm feeds the attention logits (G:59,67)      */
+    float   scale;            /* 3 (G:92,108,116) or 1 with the structure channel (G:113) */
+    int64_t row_offset;       /* global index of local row 0 (self rows of gathered src) */
+
+    /* gathered sources, indexed by column id of the operator */
+    const float* g_low;   int64_t ld_g_low;
+    const float* g_high;  int64_t ld_g_high;
+    const float* g_struc; int64_t ld_g_struc;     /* struc_low parameter, or NULL */
+    /* self sources, indexed by local row */
+    const float* s_high;  int64_t ld_s_high;
+    const float* s_mlp;   int64_t ld_s_mlp;
+    const float* s_struc; int64_t ld_s_struc;     /* or NULL */
+    const float* deg;                             /* d_i = rowsum(I + A), local rows; or NULL */
+
+    /* attention parameters */
+    const float* att_vec[4];      /* v_low, v_high, v_mlp, v_struc : F floats each       */
+    const float* ln_weight[4];    /* LayerNorm gamma per channel (NULL if !layernorm)    */
+    const float* ln_bias[4];
+    const float* att_mix;         /* k x k row-major (self.att_vec)                      */
+
+    /* outputs */
+    float* out;  int64_t ld_out;  /* [n_rows, F]                                         */
+    float* pre;  int64_t ld_pre;  /* [n_rows, (k-1)*F] pre-activations, saved for backward */
+    float* att;                   /* [n_rows, 4] mixing weights (self.att_low/...)        */
+} acm_conv_fwd_t;
+
+int acm_conv_fwd(const acm_csr_t* a_low, const acm_conv_fwd_t* p,
+                 void* workspace, size_t workspace_bytes, acm_stream_t stream);
+
+/* ------------------------------------------- backward, row-local part (K3) --
+ * From grad_out and the saved pre-activations recompute the attention head and
+ * produce (a) the per-row gradients G_c = dL/d pre_c that feed the transposed
+ * SpMM / the weight GEMM and (b) the reduced gradients of every attention /
+ * LayerNorm parameter.  Replaces the autograd replay of G:57-75,92,106-116.
+ */
+typedef struct {
+    int32_t f_out, n_channels, relu_after, relu_mlp, layernorm;
+    float   scale;
+    const float* grad_out; int64_t ld_grad_out;   /* [n_rows, F]          */
+    const float* pre;      int64_t ld_pre;        /* saved by acm_conv_fwd */
+    const float* s_mlp;    int64_t ld_s_mlp;      /* Z_I rows (local)      */
+    const float* deg;                              /* as in forward         */
+    const float* att_vec[4];
+    const float* ln_weight[4];
+    const float* ln_bias[4];
+    const float* att_mix;
+    /* outputs */
+    float* g_low;   int64_t ld_g_low;     /* dL/dpre_L                         [n_rows,F] */
+    float* g_high;  int64_t ld_g_high;    /* dL/dpre_H                                    */
+    float* g_mlp;   int64_t ld_g_mlp;     /* dL/dZ_I  (relu mask applied)                 */
+    float* g_struc; int64_t ld_g_struc;   /* deg_i * dL/dpre_S (pre-scaled for A_low^T)   */
+    float* d_att_vec[4];                  /* F floats each (written, not accumulated)     */
+    float* d_ln_weight[4];
+    float* d_ln_bias[4];
+    float* d_att_mix;                     /* k x k                                         */
+} acm_conv_bwd_local_t;
+
+int acm_conv_bwd_local_workspace_bytes(int64_t n_rows, int f_out, int n_channels, size_t* bytes);
+int acm_conv_bwd_local(int64_t n_rows, const acm_conv_bwd_local_t* p,
+                       void* workspace, size_t workspace_bytes, acm_stream_t stream);
+
+/* ------------------------------------- backward, transposed SpMM part (K4) --
+ *   dZ_L = mask_L * (A_low^T G_L)
+ *   dZ_H = mask_H * (G_H_self - A_low^T G_H)
+ *   dS   = A_low^T (D G_S) - G_S_self                      (structure channel)
+ * mask_c = [Z_c > 0] for ACMII (ReLU sits before the filter), 1 otherwise.
+ * `a_low_t` is the transposed operator (acm_csr_transpose).  Replaces
+ * SparseAddmmBackward x2-3 (autograd of G:87-88,96-103,111).
+ */
+typedef struct {
+    int32_t f_out;
+    int64_t row_offset;
+    const float* g_low;   int64_t ld_g_low;    /* gathered, indexed by column id */
+    const float* g_high;  int64_t ld_g_high;
+    const float* g_struc; int64_t ld_g_struc;  /* deg-scaled, or NULL            */
+    const float* s_high;  int64_t ld_s_high;   /* G_H rows of the local nodes    */
+    const float* s_struc; int64_t ld_s_struc;  /* deg-scaled G_S, local rows     */
+    const float* inv_deg;                       /* 1/d_i local rows (with s_struc) */
+    const float* mask_low;  int64_t ld_mask_low;   /* Z_L (post-ReLU) or NULL    */
+    const float* mask_high; int64_t ld_mask_high;
+    float* dz_low;   int64_t ld_dz_low;
+    float* dz_high;  int64_t ld_dz_high;
+    float* d_struc;  int64_t ld_d_struc;       /* grad of struc_low rows, or NULL */
+} acm_conv_bwd_spmm_t;
+
+int acm_conv_bwd_spmm(const acm_csr_t* a_low_t, const acm_conv_bwd_spmm_t* p,
+                      void* workspace, size_t workspace_bytes, acm_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ACM_HIP_H */

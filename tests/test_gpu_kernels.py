@@ -1,0 +1,146 @@
+"""HIP kernels vs. CPU references through the C ABI (runs on the MI355X box)."""
+import numpy as np
+import pytest
+import scipy.sparse as sp
+import torch
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda:0"
+
+
+def _rand_csr(n_rows, n_cols, density, seed, hub_rows=(), empty_rows=()):
+    rng = np.random.default_rng(seed)
+    m = sp.random(n_rows, n_cols, density=density, random_state=rng, format="lil", dtype=np.float32)
+    for r in hub_rows:
+        cols = rng.choice(n_cols, size=min(n_cols, hub_rows[r]), replace=False)
+        m[r, cols] = rng.standard_normal(len(cols)).astype(np.float32)
+    for r in empty_rows:
+        m[r, :] = 0
+    m = m.tocsr()
+    m.eliminate_zeros()
+    m.sort_indices()
+    return m
+
+
+@pytest.mark.parametrize("m,n,k", [(1, 1, 1), (5, 3, 2), (64, 64, 32), (65, 63, 33), (300, 192, 7),
+                                   (1000, 6, 64), (7, 192, 5000), (64, 6, 3000), (130, 70, 2089),
+                                   (16, 256, 100), (17, 17, 17), (2048, 21, 129), (3, 700, 9)])
+@pytest.mark.parametrize("ta,tb", [(0, 0), (1, 0), (0, 1), (1, 1)])
+def test_gemm_matches_fp64(m, n, k, ta, tb):
+    from acm_gnn_amd import functional as AF
+    g = torch.Generator().manual_seed(m * 131 + n * 17 + k + 2 * ta + tb)
+    a = torch.randn((k, m) if ta else (m, k), generator=g)
+    b = torch.randn((n, k) if tb else (k, n), generator=g)
+    ref = (a.double().T if ta else a.double()) @ (b.double().T if tb else b.double())
+    out = AF.gemm(a.to(DEV), b.to(DEV), trans_a=bool(ta), trans_b=bool(tb)).cpu()
+    scale = (a.abs().double().T if ta else a.abs().double()) @ (b.abs().double().T if tb else b.abs().double())
+    err = (out.double() - ref).abs()
+    assert float((err / (scale + 1e-30)).max()) < 2e-6, float(err.max())
+    out_relu = AF.gemm(a.to(DEV), b.to(DEV), trans_a=bool(ta), trans_b=bool(tb), relu=True).cpu()
+    assert torch.equal(out_relu, out.clamp_min(0))
+
+
+def test_gemm_is_an_fmaf_chain_in_k_order():
+    """f32 MFMA == k-ordered fmaf chain: integer-valued inputs must be exact."""
+    from acm_gnn_amd import functional as AF
+    g = torch.Generator().manual_seed(0)
+    a = torch.randint(-8, 9, (200, 77), generator=g).float()
+    b = torch.randint(-8, 9, (77, 45), generator=g).float()
+    assert torch.equal(AF.gemm(a.to(DEV), b.to(DEV)).cpu(), a @ b)
+
+
+def test_gemm_strided_views_and_errors():
+    from acm_gnn_amd import functional as AF
+    a = torch.randn(50, 30, device=DEV)
+    b = torch.randn(30, 40, device=DEV)
+    out = torch.zeros(50, 64, device=DEV)
+    AF.gemm(a, b, out=out[:, 8:48])
+    torch.testing.assert_close(out[:, 8:48].cpu(), (a.cpu().double() @ b.cpu().double()).float(), rtol=1e-5, atol=1e-5)
+    assert float(out[:, :8].abs().max()) == 0 and float(out[:, 48:].abs().max()) == 0
+    with pytest.raises(ValueError):
+        AF.gemm(a, torch.randn(31, 4, device=DEV))
+    with pytest.raises(RuntimeError):
+        AF.gemm(a.cpu(), b)
+
+
+@pytest.mark.parametrize("width", [1, 2, 3, 4, 5, 7, 8, 9, 16, 33, 64, 65, 128, 192, 256, 300])
+@pytest.mark.parametrize("chunk", [0, 16])
+def test_spmm_matches_scipy(width, chunk):
+    from acm_gnn_amd import functional as AF
+    from acm_gnn_amd.graph import CsrGraph
+    m = _rand_csr(517, 400, 0.03, seed=width, hub_rows={3: 390, 100: 200, 516: 70}, empty_rows=(0, 7, 515))
+    g = CsrGraph.from_scipy(m, DEV, chunk=chunk)
+    assert g.nnz == m.nnz and g.max_degree == int(np.diff(m.indptr).max())
+    if chunk:
+        assert g.n_long_rows >= 3 and g.n_partial_slots >= 6
+    dense = torch.randn(400, width, generator=torch.Generator().manual_seed(1))
+    out = AF.spmm(g, dense.to(DEV)).cpu().numpy()
+    ref = m.astype(np.float64) @ dense.double().numpy()
+    scale = abs(m).astype(np.float64) @ dense.abs().double().numpy()
+    assert np.max(np.abs(out - ref) / (scale + 1e-20) * (scale > 0)) < 2e-6
+    assert np.all(out[[0, 7, 515]] == 0)                       # empty rows write exact zeros
+    # determinism: same bits on a second launch (no float atomics anywhere)
+    out2 = AF.spmm(g, dense.to(DEV)).cpu().numpy()
+    assert np.array_equal(out, out2)
+
+
+def test_spmm_ignores_nonfinite_rows_it_never_references():
+    from acm_gnn_amd import functional as AF
+    from acm_gnn_amd.graph import CsrGraph
+    m = sp.csr_matrix(np.array([[0, 1, 1, 0], [0, 0, 1, 0], [0, 1, 0, 0], [0, 0, 0, 0]], np.float32))
+    g = CsrGraph.from_scipy(m, DEV)
+    for width in (2, 4, 8, 64):
+        dense = torch.ones(4, width)
+        dense[0] = float("inf")
+        dense[3] = float("nan")
+        out = AF.spmm(g, dense.to(DEV)).cpu()
+        assert torch.isfinite(out).all()
+
+
+def test_transpose_and_slice_handles():
+    from acm_gnn_amd import functional as AF
+    from acm_gnn_amd.graph import CsrGraph
+    m = _rand_csr(300, 211, 0.05, seed=5, hub_rows={9: 200})
+    g = CsrGraph.from_scipy(m, DEV, chunk=32)
+    gt = g.transpose()
+    ip, ix, v = (t.cpu().numpy() for t in gt.arrays())
+    mt = m.T.tocsr()
+    mt.sort_indices()
+    assert np.array_equal(ip, mt.indptr) and np.array_equal(ix, mt.indices) and np.array_equal(v, mt.data)
+    dense = torch.randn(300, 16, generator=torch.Generator().manual_seed(2))
+    ref = mt.astype(np.float64) @ dense.double().numpy()
+    np.testing.assert_allclose(AF.spmm(gt, dense.to(DEV)).cpu().numpy(), ref, rtol=1e-5, atol=1e-5)
+    sl = g.slice_rows(100, 250)
+    d2 = torch.randn(211, 8, generator=torch.Generator().manual_seed(3))
+    np.testing.assert_allclose(AF.spmm(sl, d2.to(DEV)).cpu().numpy(),
+                               m[100:250].astype(np.float64) @ d2.double().numpy(), rtol=1e-5, atol=1e-5)
+
+
+def test_from_torch_layouts_agree():
+    from acm_gnn_amd.graph import CsrGraph
+    m = _rand_csr(64, 64, 0.1, seed=8)
+    coo = m.tocoo()
+    perm = np.random.default_rng(0).permutation(coo.nnz)           # un-coalesced order
+    idx = torch.from_numpy(np.vstack([coo.row[perm], coo.col[perm]]).astype(np.int64))
+    t_coo = torch.sparse_coo_tensor(idx, torch.from_numpy(coo.data[perm]), (64, 64)).to(DEV)
+    t_dense = torch.from_numpy(m.toarray()).to(DEV)
+    t_csr = t_dense.to_sparse_csr()
+    ref = None
+    for t in (t_coo, t_dense, t_csr):
+        arrs = [a.cpu().numpy() for a in CsrGraph.from_torch(t).arrays()]
+        if ref is None:
+            ref = arrs
+            assert np.array_equal(arrs[0], m.indptr) and np.array_equal(arrs[1], m.indices)
+        for a, b in zip(arrs, ref):
+            assert np.array_equal(a, b)
+
+
+def test_create_rejects_bad_input():
+    from acm_gnn_amd.graph import CsrGraph
+    ip = torch.tensor([0, 2, 1], dtype=torch.int32, device=DEV)
+    with pytest.raises(RuntimeError, match="ACM_ESHAPE"):
+        CsrGraph.from_csr(ip, torch.zeros(1, dtype=torch.int32, device=DEV), torch.ones(1, device=DEV), 4)
+    ip = torch.tensor([0, 1], dtype=torch.int32, device=DEV)
+    with pytest.raises(RuntimeError, match="out of range"):
+        CsrGraph.from_csr(ip, torch.tensor([9], dtype=torch.int32, device=DEV), torch.ones(1, device=DEV), 4)
