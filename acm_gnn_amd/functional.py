@@ -15,6 +15,50 @@ from .graph import CsrGraph, FilterOperators, _require_cuda, _stream
 _F32 = torch.float32
 
 
+class KernelTimer:
+    """Per-launch HIP-event timing (torch.cuda.Event on the stream the kernels are launched
+    on).  ``only`` restricts timing to labels that start with it, so that the events around the
+    one kernel under study do not perturb the rest of a timed region."""
+
+    def __init__(self, only=None):
+        self.only, self.events = only, {}
+
+    def wants(self, label):
+        return self.only is None or label.startswith(self.only)
+
+    def summary(self):
+        """label -> (launches, total ms); synchronises."""
+        torch.cuda.synchronize()
+        return {k: (len(v), sum(a.elapsed_time(b) for a, b in v)) for k, v in self.events.items()}
+
+
+_TIMER = None
+
+
+def set_kernel_timer(timer):
+    global _TIMER
+    _TIMER = timer
+
+
+class _Timed:
+    def __init__(self, label):
+        self.label = label
+        self.on = _TIMER is not None and _TIMER.wants(label)
+
+    def __enter__(self):
+        if self.on:
+            self.a = torch.cuda.Event(enable_timing=True)
+            self.b = torch.cuda.Event(enable_timing=True)
+            self.a.record()
+        return self
+
+    def __exit__(self, *exc):
+        if self.on:
+            self.b.record()
+            _TIMER.events.setdefault(self.label, []).append((self.a, self.b))
+        return False
+
+
 def _vp(t):
     return C.c_void_p(t.data_ptr()) if t is not None else None
 
@@ -42,7 +86,7 @@ def gemm(a, b, trans_a=False, trans_b=False, relu=False, out=None):
     nbytes = C.c_size_t()
     _lib.check(lib.acm_gemm_workspace_bytes(int(trans_a), int(trans_b), m, n, k, C.byref(nbytes)))
     ws = torch.empty(max(nbytes.value // 4, 1), dtype=_F32, device=a.device) if nbytes.value else None
-    with torch.cuda.device(a.device):
+    with torch.cuda.device(a.device), _Timed(f"gemm_{'T' if trans_a else 'N'}{'T' if trans_b else 'N'}/{m}x{n}x{k}"):
         st = lib.acm_gemm(int(trans_a), int(trans_b), m, n, k, _vp(a), a.stride(0), _vp(b), b.stride(0),
                           _vp(out), out.stride(0), int(relu), _vp(ws), nbytes.value, _stream())
     _lib.check(st, "acm_gemm")
@@ -60,7 +104,7 @@ def spmm(graph, dense, out=None):
     if width == 0 or graph.n_rows == 0:
         return out
     ws = graph.workspace(min(width, 256))
-    with torch.cuda.device(dense.device):
+    with torch.cuda.device(dense.device), _Timed(f"spmm/W{width}"):
         st = _lib.load().acm_spmm(graph.handle, _vp(dense), dense.stride(0), width, _vp(out), out.stride(0),
                                   _vp(ws), ws.numel() * 4, _stream())
     _lib.check(st, "acm_spmm")
@@ -187,7 +231,7 @@ class AcmConvFunction(torch.autograd.Function):
         p.pre, p.ld_pre = pre.data_ptr(), pre.stride(0)
         p.att = att.data_ptr()
         ws = ops.low.workspace((k - 1) * f)
-        with torch.cuda.device(dev):
+        with torch.cuda.device(dev), _Timed(f"conv_fwd/F{f}k{k}"):
             st = lib.acm_conv_fwd(ops.low.handle, C.byref(p), _vp(ws), ws.numel() * 4, _stream())
         _lib.check(st, "acm_conv_fwd")
         ctx.ops, ctx.cfg = ops, cfg
@@ -237,7 +281,7 @@ class AcmConvFunction(torch.autograd.Function):
         nbytes = C.c_size_t()
         _lib.check(lib.acm_conv_bwd_local_workspace_bytes(n, f, k, C.byref(nbytes)))
         ws = torch.empty(max(nbytes.value // 4, 1), dtype=_F32, device=dev)
-        with torch.cuda.device(dev):
+        with torch.cuda.device(dev), _Timed(f"conv_bwd_local/F{f}k{k}"):
             st = lib.acm_conv_bwd_local(n, C.byref(q), _vp(ws), ws.numel() * 4, _stream())
         _lib.check(st, "acm_conv_bwd_local")
 
@@ -261,7 +305,7 @@ class AcmConvFunction(torch.autograd.Function):
         r.dz_high, r.ld_dz_high = dz.data_ptr() + 4 * f, dz.stride(0)
         low_t = ops.low_t
         ws2 = low_t.workspace((k - 1) * f)
-        with torch.cuda.device(dev):
+        with torch.cuda.device(dev), _Timed(f"conv_bwd_spmm/F{f}k{k}"):
             st = lib.acm_conv_bwd_spmm(low_t.handle, C.byref(r), _vp(ws2), ws2.numel() * 4, _stream())
         _lib.check(st, "acm_conv_bwd_spmm")
 
