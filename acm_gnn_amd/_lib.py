@@ -21,7 +21,8 @@ EXPORTED_SYMBOLS = (
     "acm_version", "acm_last_error", "acm_csr_create", "acm_csr_transpose", "acm_csr_slice_rows",
     "acm_csr_destroy", "acm_csr_info", "acm_spmm_workspace_bytes", "acm_gemm_workspace_bytes",
     "acm_gemm", "acm_spmm", "acm_conv_fwd", "acm_conv_bwd_local_workspace_bytes",
-    "acm_conv_bwd_local", "acm_conv_bwd_spmm",
+    "acm_conv_bwd_local", "acm_conv_bwd_spmm", "acm_conv_agg_fwd", "acm_conv_agg_bwd_workspace_bytes",
+    "acm_conv_agg_bwd",
 )
 
 
@@ -82,6 +83,31 @@ class ConvBwdSpmm(C.Structure):
                 ("d_struc", C.c_void_p), ("ld_d_struc", C.c_int64)]
 
 
+class ConvAggFwd(C.Structure):
+    _fields_ = [("f_in", C.c_int32), ("f_pad", C.c_int32), ("f_out", C.c_int32), ("relu_after", C.c_int32),
+                ("relu_mlp", C.c_int32), ("layernorm", C.c_int32), ("scale", C.c_float),
+                ("xg", C.c_void_p), ("ld_xg", C.c_int64),
+                ("xs", C.c_void_p), ("ld_xs", C.c_int64),
+                ("w_low", C.c_void_p), ("w_high", C.c_void_p), ("w_mlp", C.c_void_p), ("ld_w", C.c_int64),
+                ("att_vec", C.c_void_p * 4), ("ln_weight", C.c_void_p * 4), ("ln_bias", C.c_void_p * 4),
+                ("att_mix", C.c_void_p),
+                ("out", C.c_void_p), ("ld_out", C.c_int64),
+                ("agg", C.c_void_p), ("ld_agg", C.c_int64),
+                ("att", C.c_void_p)]
+
+
+class ConvAggBwd(C.Structure):
+    _fields_ = [("f_in", C.c_int32), ("f_pad", C.c_int32), ("f_out", C.c_int32), ("relu_after", C.c_int32),
+                ("relu_mlp", C.c_int32), ("layernorm", C.c_int32), ("scale", C.c_float),
+                ("grad_out", C.c_void_p), ("ld_grad_out", C.c_int64),
+                ("agg", C.c_void_p), ("ld_agg", C.c_int64),
+                ("xs", C.c_void_p), ("ld_xs", C.c_int64),
+                ("w_low", C.c_void_p), ("w_high", C.c_void_p), ("w_mlp", C.c_void_p), ("ld_w", C.c_int64),
+                ("att_vec", C.c_void_p * 4), ("ln_weight", C.c_void_p * 4), ("ln_bias", C.c_void_p * 4),
+                ("att_mix", C.c_void_p),
+                ("d_params", C.c_void_p)]
+
+
 _lib = None
 _lock = threading.Lock()
 
@@ -106,6 +132,9 @@ def _declare(lib):
     lib.acm_conv_bwd_local_workspace_bytes.argtypes = [i64, i32, i32, C.POINTER(sz)]
     lib.acm_conv_bwd_local.argtypes = [i64, C.POINTER(ConvBwdLocal), vp, sz, vp]
     lib.acm_conv_bwd_spmm.argtypes = [vp, C.POINTER(ConvBwdSpmm), vp, sz, vp]
+    lib.acm_conv_agg_fwd.argtypes = [vp, C.POINTER(ConvAggFwd), vp, sz, vp]
+    lib.acm_conv_agg_bwd_workspace_bytes.argtypes = [i64, i32, i32, C.POINTER(sz)]
+    lib.acm_conv_agg_bwd.argtypes = [i64, C.POINTER(ConvAggBwd), vp, sz, vp]
     for name in EXPORTED_SYMBOLS:
         fn = getattr(lib, name)
         if name not in ("acm_version", "acm_last_error", "acm_csr_destroy"):

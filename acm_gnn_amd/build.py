@@ -15,7 +15,7 @@ CSRC = os.path.join(HERE, "csrc")
 INCLUDE = os.path.join(ROOT, "include")
 LIB_DIR = os.path.join(HERE, "lib")
 LIB_PATH = os.path.join(LIB_DIR, "libacm_hip.so")
-SOURCES = ["acm_csr.cpp", "acm_gemm.hip", "acm_conv.hip"]
+SOURCES = ["acm_csr.cpp", "acm_gemm.hip", "acm_conv.hip", "acm_conv_agg.hip"]
 ARCH = "gfx950"
 
 
@@ -28,7 +28,8 @@ def _hipcc():
 
 def _deps():
     out = [os.path.join(CSRC, s) for s in SOURCES]
-    out += [os.path.join(CSRC, "acm_common.h"), os.path.join(INCLUDE, "acm_hip.h")]
+    out += [os.path.join(CSRC, "acm_common.h"), os.path.join(CSRC, "acm_conv_device.h"),
+            os.path.join(INCLUDE, "acm_hip.h")]
     return out
 
 

@@ -1,0 +1,241 @@
+// Device-side building blocks shared by the ACM layer kernels (acm_conv.hip, acm_conv_agg.hip):
+// lane layouts, the adaptive-mixing head (LayerNorm -> att_vec dot -> sigmoid -> k x k mix ->
+// softmax) and the parameter-gradient accumulators of its backward.
+#pragma once
+#include <math.h>
+
+#include "acm_common.h"
+
+// ------------------------------------------------------------------ layouts
+// How the F columns of one row are spread over lanes.  NV = values per lane.
+template <int NREG>
+struct LayWide {  // A: wave per row, lane owns columns lane + 64 i
+    static constexpr int NV = NREG;
+    int lane;
+    __device__ __forceinline__ int col(int i) const { return lane + 64 * i; }
+    __device__ __forceinline__ float rsum(float v) const { return acm_group_sum<64>(v); }
+    __device__ __forceinline__ bool leader() const { return lane == 0; }
+};
+template <int FP>
+struct LayPacked {  // B: FP lanes per row (64 / FP rows per wave), one column per lane
+    static constexpr int NV = 1;
+    int lane;
+    __device__ __forceinline__ int col(int) const { return lane % FP; }
+    __device__ __forceinline__ float rsum(float v) const { return acm_group_sum<FP>(v); }
+    __device__ __forceinline__ bool leader() const { return (lane % FP) == 0; }
+};
+template <int FP>
+struct LaySerial {  // C: every lane holds the whole row
+    static constexpr int NV = FP;
+    bool lead;
+    __device__ __forceinline__ int col(int i) const { return i; }
+    __device__ __forceinline__ float rsum(float v) const { return v; }
+    __device__ __forceinline__ bool leader() const { return lead; }
+};
+
+struct GatherSrc {
+    const float* p[3];
+    long ld[3];
+};
+
+// ------------------------------------------------------------------ attention head (shared by fwd / bwd)
+struct HeadOut {
+    float g[4], alpha[4], rstd[4];
+};
+struct HeadParams {  // copied out of the kernel-argument struct so every index is a constant
+    const float* att_vec[4];
+    const float* ln_w[4];
+    const float* ln_b[4];
+    const float* att_mix;
+};
+template <class P>
+__device__ __forceinline__ HeadParams acm_head_params(const P& p) {
+    HeadParams h;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        h.att_vec[c] = p.att_vec[c];
+        h.ln_w[c] = p.ln_weight[c];
+        h.ln_b[c] = p.ln_bias[c];
+    }
+    h.att_mix = p.att_mix;
+    return h;
+}
+
+// H: activated channels; hn/xhat outputs (hn = LayerNorm(H) or H).  Invalid columns hold 0.
+template <class L, int K>
+__device__ __forceinline__ void acm_head(const L& lay, int F, int layernorm,
+                                         const HeadParams& hp,
+                                         const float (&H)[4][L::NV], float (&hn)[4][L::NV],
+                                         float (&xhat)[4][L::NV], HeadOut& o) {
+    constexpr int NV = L::NV;
+    constexpr int k = K;
+    const float invF = 1.0f / (float)F;
+    float s[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        if (c >= K) {
+            o.g[c] = 0.f;
+            o.rstd[c] = 1.f;
+            continue;
+        }
+        // Without LayerNorm the same straight-line code runs with mean 0, rstd 1, gamma 1,
+        // beta 0 (exact: (H - 0) * 1 * 1 + 0 == H), so only two scalars depend on the branch.
+        float mean = 0.f, rstd = 1.f;
+        if (layernorm) {
+            float part = 0.f;
+#pragma unroll
+            for (int i = 0; i < NV; ++i) part += H[c][i];
+            mean = lay.rsum(part) * invF;
+            part = 0.f;
+#pragma unroll
+            for (int i = 0; i < NV; ++i) {
+                const float d = (lay.col(i) < F) ? (H[c][i] - mean) : 0.f;
+                part += d * d;
+            }
+            rstd = 1.0f / sqrtf(lay.rsum(part) * invF + ACM_LN_EPS);
+        }
+        o.rstd[c] = rstd;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int col = lay.col(i);
+            const bool ok = col < F;
+            const float gam = (ok && layernorm) ? hp.ln_w[c][col] : 1.f;
+            const float bet = (ok && layernorm) ? hp.ln_b[c][col] : 0.f;
+            const float xh = ok ? (H[c][i] - mean) * rstd : 0.f;
+            xhat[c][i] = xh;
+            hn[c][i] = ok ? (xh * gam + bet) : 0.f;
+        }
+        float part = 0.f;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int col = lay.col(i);
+            part += (col < F) ? hn[c][i] * hp.att_vec[c][col] : 0.f;
+        }
+        s[c] = lay.rsum(part);
+        o.g[c] = 1.0f / (1.0f + expf(-s[c]));
+    }
+    float logit[4], mx = -INFINITY;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        if (j >= k) {
+            logit[j] = -INFINITY;
+            continue;
+        }
+        float acc = 0.f;
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+            if (c < k) acc += o.g[c] * hp.att_mix[c * k + j];
+        logit[j] = acc / (float)k;
+        mx = fmaxf(mx, logit[j]);
+    }
+    float den = 0.f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        if (j >= k) continue;
+        logit[j] = expf(logit[j] - mx);
+        den += logit[j];
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) o.alpha[j] = (j < k) ? logit[j] / den : 0.f;
+}
+
+// Parameter-gradient vector layout of the head (npg = 3 k F + k k floats):
+//   [ d att_vec : k x F ][ d ln_weight : k x F ][ d ln_bias : k x F ][ d att_mix : k x k ]
+template <class L>
+struct ParamAcc {
+    float dv[4][L::NV], dgam[4][L::NV], dbet[4][L::NV], dmix[16];
+    __device__ __forceinline__ void zero() {
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+#pragma unroll
+            for (int i = 0; i < L::NV; ++i) dv[c][i] = dgam[c][i] = dbet[c][i] = 0.f;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) dmix[q] = 0.f;
+    }
+};
+
+
+// Backward of acm_head + the mix  out = scale * sum_c alpha_c H_c :
+//   in : dO (grad of out), the forward quantities (H, hn, xhat, ho)
+//   out: dH[c] = dL/dH_c (before any ReLU mask); parameter gradients accumulated into `pa`,
+//        weighted by `act` (0 for padding rows).
+template <class L, int K>
+__device__ __forceinline__ void acm_head_backward(const L& lay, int F, int layernorm, const HeadParams& hp,
+                                                  float scale, const float (&H)[4][L::NV],
+                                                  const float (&hn)[4][L::NV], const float (&xhat)[4][L::NV],
+                                                  const HeadOut& ho, const float (&dO)[L::NV], float act,
+                                                  ParamAcc<L>& pa, float (&dH)[4][L::NV]) {
+    constexpr int NV = L::NV;
+    constexpr int k = K;
+    float dalpha[4], dot = 0.f;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        if (c >= k) {
+            dalpha[c] = 0.f;
+            continue;
+        }
+        float part = 0.f;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) part += dO[i] * H[c][i];
+        dalpha[c] = scale * lay.rsum(part);
+        dot += ho.alpha[c] * dalpha[c];
+    }
+    float dlogit[4], ds[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) dlogit[j] = (j < k) ? ho.alpha[j] * (dalpha[j] - dot) : 0.f;
+    const float invk = 1.0f / (float)k;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        if (c >= k) {
+            ds[c] = 0.f;
+            continue;
+        }
+        float dgc = 0.f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if (j < k) {
+                dgc += dlogit[j] * hp.att_mix[c * k + j];
+                pa.dmix[c * 4 + j] += act * ho.g[c] * dlogit[j] * invk;
+            }
+        dgc *= invk;
+        ds[c] = dgc * ho.g[c] * (1.f - ho.g[c]);
+    }
+    const float invF = 1.0f / (float)F;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        if (c >= k) {
+#pragma unroll
+            for (int i = 0; i < NV; ++i) dH[c][i] = 0.f;
+            continue;
+        }
+        if (layernorm) {
+            float dxh[NV], s1 = 0.f, s2 = 0.f;
+#pragma unroll
+            for (int i = 0; i < NV; ++i) {
+                const int col = lay.col(i);
+                const bool ok = col < F;
+                const float v = ok ? hp.att_vec[c][col] : 0.f;
+                const float gam = ok ? hp.ln_w[c][col] : 0.f;
+                const float dhn = ds[c] * v;
+                pa.dgam[c][i] += act * dhn * xhat[c][i];
+                pa.dbet[c][i] += act * dhn;
+                pa.dv[c][i] += act * ds[c] * hn[c][i];
+                dxh[i] = dhn * gam;
+                s1 += dxh[i];
+                s2 += dxh[i] * xhat[c][i];
+            }
+            const float m1 = lay.rsum(s1) * invF, m2 = lay.rsum(s2) * invF;
+#pragma unroll
+            for (int i = 0; i < NV; ++i)
+                dH[c][i] = scale * ho.alpha[c] * dO[i] + ho.rstd[c] * (dxh[i] - m1 - xhat[c][i] * m2);
+        } else {
+#pragma unroll
+            for (int i = 0; i < NV; ++i) {
+                const int col = lay.col(i);
+                const float v = (col < F) ? hp.att_vec[c][col] : 0.f;
+                pa.dv[c][i] += act * ds[c] * hn[c][i];
+                dH[c][i] = scale * ho.alpha[c] * dO[i] + ds[c] * v;
+            }
+        }
+    }
+}

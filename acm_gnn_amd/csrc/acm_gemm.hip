@@ -138,15 +138,26 @@ __global__ __launch_bounds__(256) void gemm_kernel(int M, int N, int K, const fl
             }
 }
 
+// C[q] = sum_z slabs[z][q].  16 outputs x 16 split-lanes per block: each thread adds every 16th
+// slab (coalesced 64 B segments across q), then the 16 split-lanes combine in a fixed LDS tree.
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(int M, int N, int splits,
                                                             const float* __restrict__ slabs,
                                                             float* __restrict__ C, long ldc, int relu) {
+    __shared__ float red[16][17];
     const long total = (long)M * N;
-    for (long q = (long)blockIdx.x * 256 + threadIdx.x; q < total; q += (long)gridDim.x * 256) {
-        float s = 0.f;
-        for (int z = 0; z < splits; ++z) s += slabs[(long)z * total + q];
-        if (relu) s = fmaxf(s, 0.f);
-        C[(q / N) * ldc + (q % N)] = s;
+    const int tq = threadIdx.x & 15, tz = threadIdx.x >> 4;
+    const long q = (long)blockIdx.x * 16 + tq;
+    float s = 0.f;
+    if (q < total)
+        for (int z = tz; z < splits; z += 16) s += slabs[(long)z * total + q];
+    red[tz][tq] = s;
+    __syncthreads();
+    if (tz == 0 && q < total) {
+        float t = 0.f;
+#pragma unroll
+        for (int z = 0; z < 16; ++z) t += red[z][tq];
+        if (relu) t = fmaxf(t, 0.f);
+        C[(q / N) * ldc + (q % N)] = t;
     }
 }
 
@@ -169,9 +180,10 @@ GemmPlan plan_gemm(int64_t M, int64_t N, int64_t K) {
     const int64_t tiles = tm * tn;
     int64_t splits = 1;
     if (tiles < 256 && K >= 8 * BK) {  // too few tiles to fill 256 CUs: split K
-        const int64_t want = (768 + tiles - 1) / tiles;
+        const int64_t want = (512 + tiles - 1) / tiles;
         const int64_t kmax = (K + 4 * BK - 1) / (4 * BK);  // keep >= 4 slabs per split
         splits = want < kmax ? want : kmax;
+        if (splits > 256) splits = 256;
         if (splits < 1) splits = 1;
     }
     int64_t kps = (K + splits - 1) / splits;
@@ -243,8 +255,7 @@ extern "C" int acm_gemm(int transA, int transB, int64_t M, int64_t N, int64_t K,
     ACM_CHECK_HIP(hipGetLastError());
     if (slabs) {
         const long total = (long)M * N;
-        int grid = (int)((total + 255) / 256);
-        if (grid > 2048) grid = 2048;
+        const int grid = (int)((total + 15) / 16);
         hipLaunchKernelGGL(splitk_reduce_kernel, dim3(grid), dim3(256), 0, st, (int)M, (int)N, p.splits, slabs,
                            C, (long)ldc, relu);
         ACM_CHECK_HIP(hipGetLastError());

@@ -6,6 +6,7 @@ torch stream.  There is deliberately no eager/torch fallback: a CPU tensor or a
 missing library is an error.
 """
 import ctypes as C
+import os
 
 import torch
 
@@ -191,10 +192,21 @@ class AcmConvFunction(torch.autograd.Function):
         k = cfg.n_channels
         if n != ops.n_local:
             raise ValueError(f"input has {n} rows but the graph operator has {ops.n_local}")
-        wcat = torch.cat([w_low, w_high, w_mlp], dim=1).to(_F32).contiguous()      # [F_in, 3F]
-        z = gemm(x, wcat, relu=cfg.relu_before)                                     # [n, 3F]
-        zg = _gather_rows(ops, z[:, : 2 * f]) if ops.sharded else z                 # gathered [Z_L|Z_H]
+        f_in = x.shape[1]
+        # Aggregate-first (A (X W) = (A X) W): legal without a ReLU between projection and
+        # filter, worth it when F_in < F, and free of any backward SpMM when x needs no gradient.
+        ctx.agg_first = (k == 3 and not cfg.relu_before and f_in <= 16 and f_in < f and f <= 64
+                         and not ctx.needs_input_grad[0] and os.environ.get("ACM_AGG_FIRST", "1") != "0")
         four = k == 4
+        if ctx.agg_first:
+            fp = 4 if f_in <= 4 else (8 if f_in <= 8 else 16)
+            xpad = x if f_in == fp else torch.nn.functional.pad(x, (0, fp - f_in))
+            xg = _gather_rows(ops, xpad)
+            wl, wh, wm = (_as_f32c(t, "weight") for t in (w_low, w_high, w_mlp))
+        else:
+            wcat = torch.cat([w_low, w_high, w_mlp], dim=1).to(_F32).contiguous()  # [F_in, 3F]
+            z = gemm(x, wcat, relu=cfg.relu_before)                                 # [n, 3F]
+            zg = _gather_rows(ops, z[:, : 2 * f]) if ops.sharded else z             # gathered [Z_L|Z_H]
         if four:
             if ops.deg is None:
                 raise RuntimeError("structure_info=1 needs adj_low_unnormalized")
@@ -210,8 +222,29 @@ class AcmConvFunction(torch.autograd.Function):
             raise RuntimeError(f"att_vec is {tuple(mix.shape)} but the layer mixes {k} channels "
                                "(structure_info is only valid with acmgcnp/acmgcnpp)")
         out = torch.empty(n, f, dtype=_F32, device=dev)
-        pre = torch.empty(n, (k - 1) * f, dtype=_F32, device=dev)
         att = torch.empty(n, 4, dtype=_F32, device=dev)
+        if ctx.agg_first:
+            p = _lib.ConvAggFwd()
+            p.f_in, p.f_pad, p.f_out = f_in, fp, f
+            p.relu_after, p.relu_mlp, p.layernorm, p.scale = int(cfg.relu_after), int(cfg.relu_mlp), int(cfg.layernorm), cfg.scale
+            p.xg, p.ld_xg = xg.data_ptr(), xg.stride(0)
+            p.xs, p.ld_xs = xpad.data_ptr(), xpad.stride(0)
+            p.w_low, p.w_high, p.w_mlp, p.ld_w = wl.data_ptr(), wh.data_ptr(), wm.data_ptr(), f
+            p.att_vec, p.ln_weight, p.ln_bias = _ptr_array(vecs), _ptr_array(lnw), _ptr_array(lnb)
+            p.att_mix = mix.data_ptr()
+            agg = torch.empty(n, fp, dtype=_F32, device=dev)
+            p.out, p.ld_out = out.data_ptr(), out.stride(0)
+            p.agg, p.ld_agg = agg.data_ptr(), agg.stride(0)
+            p.att = att.data_ptr()
+            ws = ops.low.workspace(fp)
+            with torch.cuda.device(dev), _Timed(f"conv_agg_fwd/F{f}k{k}i{f_in}"):
+                st = lib.acm_conv_agg_fwd(ops.low.handle, C.byref(p), _vp(ws), ws.numel() * 4, _stream())
+            _lib.check(st, "acm_conv_agg_fwd")
+            ctx.ops, ctx.cfg, ctx.f_in = ops, cfg, f_in
+            ctx.save_for_backward(xpad, agg, wl, wh, wm, mix, *vecs, *lnw, *lnb)
+            ctx.mark_non_differentiable(att)
+            return out, att
+        pre = torch.empty(n, (k - 1) * f, dtype=_F32, device=dev)
         p = _lib.ConvFwd()
         p.f_out, p.n_channels = f, k
         p.relu_after, p.relu_mlp, p.layernorm = int(cfg.relu_after), int(cfg.relu_mlp), int(cfg.layernorm)
@@ -245,6 +278,8 @@ class AcmConvFunction(torch.autograd.Function):
         ops, cfg = ctx.ops, ctx.cfg
         k = cfg.n_channels
         saved = ctx.saved_tensors
+        if ctx.agg_first:
+            return AcmConvFunction._backward_agg(ctx, grad_out)
         x, wcat, z, pre, mix = saved[:5]
         vecs = list(saved[5:5 + k])
         lnw = list(saved[5 + k:5 + 2 * k]) if cfg.layernorm else []
@@ -327,6 +362,54 @@ class AcmConvFunction(torch.autograd.Function):
         grads_lnb = (d_lnb + [None] * (4 - k)) if cfg.layernorm else none4
         return (d_x, d_wl, d_wh, d_wm, grads_vec[0], grads_vec[1], grads_vec[2], grads_vec[3],
                 d_struc, d_mix, *grads_lnw, *grads_lnb, None, None)
+
+
+def _backward_agg(ctx, grad_out):
+    """Backward of the aggregate-first forward: one row-local kernel, no SpMM, no collective
+    except the all-reduce of the replicated-parameter gradients."""
+    lib = _lib.load()
+    ops, cfg, f_in = ctx.ops, ctx.cfg, ctx.f_in
+    saved = ctx.saved_tensors
+    xpad, agg, wl, wh, wm, mix = saved[:6]
+    vecs = list(saved[6:9])
+    lnw = list(saved[9:12]) if cfg.layernorm else []
+    lnb = list(saved[12:15]) if cfg.layernorm else []
+    dev = xpad.device
+    n, f, fp = xpad.shape[0], wl.shape[1], xpad.shape[1]
+    grad_out = _as_f32c(grad_out, "grad_out")
+    npg = 3 * f_in * f + 9 * f + 9
+    d_params = torch.empty(npg, dtype=_F32, device=dev)
+    q = _lib.ConvAggBwd()
+    q.f_in, q.f_pad, q.f_out = f_in, fp, f
+    q.relu_after, q.relu_mlp, q.layernorm, q.scale = int(cfg.relu_after), int(cfg.relu_mlp), int(cfg.layernorm), cfg.scale
+    q.grad_out, q.ld_grad_out = grad_out.data_ptr(), grad_out.stride(0)
+    q.agg, q.ld_agg = agg.data_ptr(), agg.stride(0)
+    q.xs, q.ld_xs = xpad.data_ptr(), xpad.stride(0)
+    q.w_low, q.w_high, q.w_mlp, q.ld_w = wl.data_ptr(), wh.data_ptr(), wm.data_ptr(), f
+    q.att_vec, q.ln_weight, q.ln_bias = _ptr_array(vecs), _ptr_array(lnw), _ptr_array(lnb)
+    q.att_mix = mix.data_ptr()
+    q.d_params = d_params.data_ptr()
+    nbytes = C.c_size_t()
+    _lib.check(lib.acm_conv_agg_bwd_workspace_bytes(n, f_in, f, C.byref(nbytes)))
+    ws = torch.empty(max(nbytes.value // 4, 1), dtype=_F32, device=dev)
+    with torch.cuda.device(dev), _Timed(f"conv_agg_bwd/F{f}k3i{f_in}"):
+        st = lib.acm_conv_agg_bwd(n, C.byref(q), _vp(ws), ws.numel() * 4, _stream())
+    _lib.check(st, "acm_conv_agg_bwd")
+    if ops.sharded:
+        import torch.distributed as dist
+        dist.all_reduce(d_params, group=ops.group)
+    wsz = f_in * f
+    d_wl, d_wh, d_wm = (d_params[i * wsz:(i + 1) * wsz].view(f_in, f) for i in range(3))
+    base = 3 * wsz
+    d_vec = [d_params[base + c * f: base + (c + 1) * f].view(f, 1) for c in range(3)]
+    d_lnw = [d_params[base + (3 + c) * f: base + (4 + c) * f] for c in range(3)] if cfg.layernorm else [None] * 3
+    d_lnb = [d_params[base + (6 + c) * f: base + (7 + c) * f] for c in range(3)] if cfg.layernorm else [None] * 3
+    d_mix = d_params[base + 9 * f:].view(3, 3)
+    return (None, d_wl, d_wh, d_wm, d_vec[0], d_vec[1], d_vec[2], None, None, d_mix,
+            d_lnw[0], d_lnw[1], d_lnw[2], None, d_lnb[0], d_lnb[1], d_lnb[2], None, None, None)
+
+
+AcmConvFunction._backward_agg = staticmethod(_backward_agg)
 
 
 def acm_conv(x, params, ops, cfg):

@@ -219,6 +219,61 @@ typedef struct {
 int acm_conv_bwd_spmm(const acm_csr_t* a_low_t, const acm_conv_bwd_spmm_t* p,
                       void* workspace, size_t workspace_bytes, acm_stream_t stream);
 
+
+/* ------------------------------ aggregate-first form of the layer (K2a / K3a) --
+ * For the ACM (non-variant) and acmsgc models the filter and the projection
+ * commute: A_low (X W) = (A_low X) W.  When F_in < F_out (twitch-gamer: 7 vs 64)
+ * gathering X rows moves F_in floats per edge instead of 2 F_out:
+ *
+ *   P     = A_low X                       (one narrow gather, shared by both graph channels)
+ *   pre_L = P W_L      pre_H = (X - P) W_H      Z_I = X W_I     (in registers, per row)
+ *   ... then the same ReLU / LayerNorm / mixing head as acm_conv_fwd.
+ *
+ * Same reference call sites as acm_gemm + acm_conv_fwd (G:87-116) in one launch;
+ * equal to them up to fp32 re-association.  3-channel layers only, f_in <= 16,
+ * and only when the layer input needs no gradient (first layer): the backward
+ * then needs no transposed SpMM at all, dW_L = P^T G_L, dW_H = (X - P)^T G_H,
+ * dW_I = X^T G_I are row-local reductions (acm_conv_agg_bwd).
+ */
+typedef struct {
+    int32_t f_in, f_pad;       /* f_pad = row length (floats) of xg / xs / agg: 4, 8 or 16, >= f_in; padding is zero */
+    int32_t f_out, relu_after, relu_mlp, layernorm;
+    float   scale;
+    const float* xg; int64_t ld_xg;    /* X rows indexed by column id (16-byte aligned rows)  */
+    const float* xs; int64_t ld_xs;    /* X rows of the local nodes                            */
+    const float* w_low; const float* w_high; const float* w_mlp; int64_t ld_w;   /* [f_in, F] each */
+    const float* att_vec[4];
+    const float* ln_weight[4];
+    const float* ln_bias[4];
+    const float* att_mix;              /* 3 x 3 */
+    float* out; int64_t ld_out;        /* [n_rows, F]                                          */
+    float* agg; int64_t ld_agg;        /* [n_rows, f_pad]  P = A_low X, saved for backward     */
+    float* att;                        /* [n_rows, 4]                                          */
+} acm_conv_agg_fwd_t;
+
+int acm_conv_agg_fwd(const acm_csr_t* a_low, const acm_conv_agg_fwd_t* p,
+                     void* workspace, size_t workspace_bytes, acm_stream_t stream);
+
+typedef struct {
+    int32_t f_in, f_pad, f_out, relu_after, relu_mlp, layernorm;
+    float   scale;
+    const float* grad_out; int64_t ld_grad_out;
+    const float* agg; int64_t ld_agg;
+    const float* xs;  int64_t ld_xs;
+    const float* w_low; const float* w_high; const float* w_mlp; int64_t ld_w;
+    const float* att_vec[4];
+    const float* ln_weight[4];
+    const float* ln_bias[4];
+    const float* att_mix;
+    /* output: one flat vector
+     *   [ dW_low : f_in x F ][ dW_high ][ dW_mlp ][ d att_vec : 3 x F ][ d ln_weight : 3 x F ][ d ln_bias : 3 x F ][ d att_mix : 3 x 3 ] */
+    float* d_params;
+} acm_conv_agg_bwd_t;
+
+int acm_conv_agg_bwd_workspace_bytes(int64_t n_rows, int f_in, int f_out, size_t* bytes);
+int acm_conv_agg_bwd(int64_t n_rows, const acm_conv_agg_bwd_t* p,
+                     void* workspace, size_t workspace_bytes, acm_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,134 @@
+"""HIP layer vs the CPU oracle on seeded inputs: both execution forms (literal project-then-
+aggregate and aggregate-first), real graph structures, split long rows.  MI355X box."""
+import os
+
+import numpy as np
+import pytest
+import scipy.sparse as sp
+import torch
+
+from conftest import GOLDEN, load_npz
+from oracle import acm_oracle as O
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _graph(n, seed, density=0.05, hub=True):
+    rng = np.random.default_rng(seed)
+    a = sp.random(n, n, density=density, random_state=rng, format="csr")
+    a = ((a + a.T) > 0).astype(np.float64).tolil()
+    if hub:
+        a[0, 1:] = 1.0
+        a[1:, 0] = 1.0
+    a[n - 1, :] = 0
+    a[:, n - 1] = 0
+    a[3, 3] = 1.0                                    # raw self-loop (quirk Q5)
+    return sp.csr_matrix(a)
+
+
+def _run_both(model_type, variant, structure_info, ln, n, f_in, f_out, seed, x_grad, monkeypatch, agg,
+              adj=None, chunk_env=None):
+    from acm_gnn_amd import GraphConvolution
+    from acm_gnn_amd.graph import clear_cache
+    monkeypatch.setenv("ACM_AGG_FIRST", "1" if agg else "0")
+    clear_cache()
+    adj = adj if adj is not None else _graph(n, seed)
+    n = adj.shape[0]
+    low, high, un = O.filters_linkx(adj)
+    torch.manual_seed(seed)
+    layer = GraphConvolution(f_in, f_out, n, model_type, variant=variant, structure_info=structure_info,
+                             attn_layernorm=ln)
+    with torch.no_grad():
+        for nm in ("low", "high", "mlp", "struc_low"):
+            getattr(layer, f"layer_norm_{nm}").weight.uniform_(0.5, 1.5)
+            getattr(layer, f"layer_norm_{nm}").bias.uniform_(-0.5, 0.5)
+    params = {k: v.detach().clone().requires_grad_(True) for k, v in layer.named_parameters()}
+    g = torch.Generator().manual_seed(seed + 1)
+    x = torch.randn(n, f_in, generator=g)
+    gout = torch.randn(n, f_out, generator=g)
+    # oracle
+    xr = x.clone().requires_grad_(x_grad)
+    ref, ref_att = O.layer_forward(params, xr, low, high, un if structure_info else None, model_type=model_type,
+                                   variant=variant, structure_info=structure_info, attn_layernorm=ln,
+                                   return_att=True)
+    ref.backward(gout)
+    # HIP
+    layer = layer.to(DEV)
+    xd = x.to(DEV).requires_grad_(x_grad)
+    out = layer(xd, low.to(DEV), high.to(DEV), un.to(DEV) if structure_info else None)
+    out.backward(gout.to(DEV))
+    scale = max(1.0, float(ref.abs().max()))
+    assert float((out.detach().cpu() - ref.detach()).abs().max()) < 2e-5 * scale
+    att = torch.cat([layer.att_low, layer.att_high, layer.att_mlp], 1).cpu()
+    assert float((att - ref_att[:, :3].detach()).abs().max()) < 2e-5
+    for k, p in layer.named_parameters():
+        rg = params[k].grad
+        if rg is None:
+            assert p.grad is None, k
+            continue
+        assert p.grad is not None, k
+        tol = 1e-4 * max(1.0, float(rg.abs().max()))
+        assert float((p.grad.cpu() - rg).abs().max()) < tol, (k, float((p.grad.cpu() - rg).abs().max()), tol)
+    if x_grad:
+        tol = 1e-4 * max(1.0, float(xr.grad.abs().max()))
+        assert float((xd.grad.cpu() - xr.grad).abs().max()) < tol
+    return out.detach().cpu()
+
+
+AGG_CASES = [("acmgcn", False, 3, 16), ("acmgcn", False, 7, 64), ("acmgcnp", True, 7, 64), ("acmgcnp", True, 8, 33),
+             ("acmgcnp", True, 4, 5), ("acmgcnp", False, 12, 64), ("acmgcnp", True, 16, 64), ("acmsgc", False, 7, 64),
+             ("acmgcnpp", True, 1, 2)]
+
+
+@pytest.mark.parametrize("model_type,ln,f_in,f_out", AGG_CASES)
+def test_aggregate_first_matches_oracle_and_literal(model_type, ln, f_in, f_out, monkeypatch):
+    from acm_gnn_amd import functional as AF
+    timer = AF.KernelTimer()
+    AF.set_kernel_timer(timer)
+    try:
+        a = _run_both(model_type, 0, 0, ln, 300, f_in, f_out, 11, False, monkeypatch, agg=True)
+        used = set(k.split("/")[0] for k in timer.events)
+        assert "conv_agg_fwd" in used and "conv_agg_bwd" in used and "conv_fwd" not in used, used
+        timer.events.clear()
+        b = _run_both(model_type, 0, 0, ln, 300, f_in, f_out, 11, False, monkeypatch, agg=False)
+        used = set(k.split("/")[0] for k in timer.events)
+        assert "conv_fwd" in used and "conv_agg_fwd" not in used, used
+    finally:
+        AF.set_kernel_timer(None)
+    assert float((a - b).abs().max()) < 2e-5 * max(1.0, float(b.abs().max()))
+
+
+def test_aggregate_first_not_used_when_illegal(monkeypatch):
+    """ACMII (ReLU between projection and filter), 4 channels, or an input that needs a
+    gradient must take the literal path."""
+    from acm_gnn_amd import functional as AF
+    for kwargs in (dict(model_type="acmgcn", variant=1, structure_info=0, x_grad=False),
+                   dict(model_type="acmgcnp", variant=0, structure_info=1, x_grad=False),
+                   dict(model_type="acmgcn", variant=0, structure_info=0, x_grad=True)):
+        timer = AF.KernelTimer()
+        AF.set_kernel_timer(timer)
+        try:
+            _run_both(kwargs["model_type"], kwargs["variant"], kwargs["structure_info"], True, 200, 7, 64, 5,
+                      kwargs["x_grad"], monkeypatch, agg=True)
+            assert not any(k.startswith("conv_agg") for k in timer.events), kwargs
+        finally:
+            AF.set_kernel_timer(None)
+
+
+@pytest.mark.parametrize("model_type,variant,s,ln,f_in,f_out", [
+    ("acmgcn", 0, 0, False, 40, 64), ("acmgcn", 1, 0, False, 40, 64), ("acmgcnp", 0, 1, True, 33, 64),
+    ("acmgcnp", 1, 1, True, 64, 5), ("acmgcnp", 0, 0, True, 64, 2), ("acmgcnp", 1, 1, True, 20, 100),
+    ("acmgcnp", 0, 1, True, 24, 130), ("acmsgc", 0, 0, False, 30, 7), ("acmgcnpp", 0, 0, True, 17, 16)])
+def test_literal_path_matches_oracle(model_type, variant, s, ln, f_in, f_out, monkeypatch):
+    _run_both(model_type, variant, s, ln, 400, f_in, f_out, 3, True, monkeypatch, agg=False)
+
+
+@pytest.mark.parametrize("name,f_out,s", [("chameleon", 64, 1), ("chameleon", 5, 0), ("squirrel", 64, 0)])
+def test_real_structures(name, f_out, s, monkeypatch):
+    """Real graphs (raw self-loops, degree up to 1.9k => long rows are split across work items)."""
+    g = load_npz(os.path.join(GOLDEN, f"graph_{name}.npz"))
+    n = int(g["n"])
+    adj = sp.csr_matrix((np.ones(len(g["adj_un_indices"])), g["adj_un_indices"], g["adj_un_indptr"]), shape=(n, n))
+    _run_both("acmgcnp", 0, s, True, n, 24, f_out, 2, True, monkeypatch, agg=False, adj=adj)
+    _run_both("acmgcnp", 0, 0, True, n, 7, 64, 2, False, monkeypatch, agg=True, adj=adj)
