@@ -91,11 +91,40 @@ __device__ __forceinline__ int acm_xcd_swizzle(int b, int nblk) {
 }
 
 // All-reduce (sum) over the W consecutive lanes that share lane / W; W power of two <= 64.
+// Pure VALU: DPP quad_perm (xor 1, xor 2), row_half_mirror / row_mirror (the partner of lane i
+// is 7-i / 15-i, which after the earlier steps holds the other half's total), then gfx950's
+// v_permlane16_swap / v_permlane32_swap for the row-crossing steps.  ~2 instructions per step,
+// no LDS crossbar (ds_bpermute) and no s_waitcnt, fixed summation tree => deterministic.
+// Every lane of the group must be active.
+template <int CTRL>
+__device__ __forceinline__ float acm_dpp(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, false));
+}
+typedef unsigned acm_u32x2 __attribute__((ext_vector_type(2)));
 template <int W>
 __device__ __forceinline__ float acm_group_sum(float v) {
-#pragma unroll
-    for (int m = W / 2; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
+    static_assert(W == 1 || W == 2 || W == 4 || W == 8 || W == 16 || W == 32 || W == 64, "group width");
+    if (W >= 2) v += acm_dpp<0xB1>(v);    // quad_perm [1,0,3,2]
+    if (W >= 4) v += acm_dpp<0x4E>(v);    // quad_perm [2,3,0,1]
+    if (W >= 8) v += acm_dpp<0x141>(v);   // row_half_mirror
+    if (W >= 16) v += acm_dpp<0x140>(v);  // row_mirror
+    if (W >= 32) {
+        const acm_u32x2 r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+        v = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+    }
+    if (W >= 64) {
+        const acm_u32x2 r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+        v = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+    }
     return v;
+}
+
+// Sum over the four 16-lane rows of a wave (lanes l, l^16, l^32, l^48); result in every lane.
+__device__ __forceinline__ float acm_cross_row_sum(float v) {
+    acm_u32x2 r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    v = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+    r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
 }
 
 __device__ __forceinline__ int acm_uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }

@@ -186,9 +186,11 @@ __device__ __forceinline__ void gather_wide(const GatherSrc& g, int F, const int
 template <int NREG, int NG, class Epi>
 __global__ __launch_bounds__(256) void spmm_wide_kernel(CsrView csr, GatherSrc g, int F,
                                                         typename Epi::Args ea, float* __restrict__ partial) {
+    // Blocks take work items in dispatch order (block b -> XCD b % 8): every XCD sees a uniform
+    // sample of the rows, and on degree-sorted graphs the heavy items start first.  (A contiguous
+    // per-XCD range, the usual GEMM swizzle, left 7 XCDs idle behind the hub rows: 133 -> 327 us.)
     const int lane = threadIdx.x & 63;
-    const int blk = acm_xcd_swizzle(blockIdx.x, gridDim.x);
-    const int w = acm_uniform(blk * 4 + (threadIdx.x >> 6));
+    const int w = acm_uniform(blockIdx.x * 4 + (threadIdx.x >> 6));
     if (w >= csr.n_items) return;
     const AcmItem it = csr.items[w];
     const int row = acm_uniform(it.row), begin = acm_uniform(it.begin), end = acm_uniform(it.end),
@@ -267,13 +269,15 @@ __device__ __forceinline__ void load_row(const float* __restrict__ p, int F, boo
     }
 }
 
-template <int FP, int NG, int GS, class Epi>
+// MERGED: channels 0 and 1 are one contiguous 16-byte-aligned block [c0 (FP) | c1 (FP)] in a row of
+// g.p[0], fetched with float4 loads -- one L2 request per neighbour instead of two (the narrow
+// kernels are bound by L1->L2 request count, profiles/r01_pmc_*.csv).
+template <int FP, int NG, int GS, bool MERGED, class Epi>
 __global__ __launch_bounds__(256) void spmm_narrow_kernel(CsrView csr, GatherSrc g, int F, int vecmask,
                                                           typename Epi::Args ea, float* __restrict__ partial) {
     constexpr int GPB = 256 / GS;  // groups (work items) per block
     const int gl = threadIdx.x % GS;
-    const int blk = acm_xcd_swizzle(blockIdx.x, gridDim.x);
-    const int w = blk * GPB + threadIdx.x / GS;
+    const int w = blockIdx.x * GPB + threadIdx.x / GS;
     if (w >= csr.n_items) return;   // whole groups leave together
     const AcmItem it = csr.items[w];
     float acc[NG][FP];
@@ -287,10 +291,30 @@ __global__ __launch_bounds__(256) void spmm_narrow_kernel(CsrView csr, GatherSrc
         const int ja = va ? csr.indices[ka] : 0, jb = vb ? csr.indices[kb] : 0;
         const float aa = va ? csr.vals[ka] : 0.f, ab = vb ? csr.vals[kb] : 0.f;
         float za[NG][FP], zb[NG][FP];
+        if (MERGED) {
+            float ta[2 * FP], tb[2 * FP];
+            load_row<2 * FP>(g.p[0] + (long)ja * g.ld[0], 2 * FP, true, ta);
+            load_row<2 * FP>(g.p[0] + (long)jb * g.ld[0], 2 * FP, true, tb);
 #pragma unroll
-        for (int c = 0; c < NG; ++c) {
-            load_row<FP>(g.p[c] + (long)ja * g.ld[c], F, (vecmask >> c) & 1, za[c]);
-            load_row<FP>(g.p[c] + (long)jb * g.ld[c], F, (vecmask >> c) & 1, zb[c]);
+            for (int f = 0; f < FP; ++f) {
+                za[0][f] = ta[f];
+                zb[0][f] = tb[f];
+                if (NG > 1) {
+                    za[1 % NG][f] = ta[FP + f];
+                    zb[1 % NG][f] = tb[FP + f];
+                }
+            }
+#pragma unroll
+            for (int c = 2; c < NG; ++c) {
+                load_row<FP>(g.p[c] + (long)ja * g.ld[c], F, (vecmask >> c) & 1, za[c]);
+                load_row<FP>(g.p[c] + (long)jb * g.ld[c], F, (vecmask >> c) & 1, zb[c]);
+            }
+        } else {
+#pragma unroll
+            for (int c = 0; c < NG; ++c) {
+                load_row<FP>(g.p[c] + (long)ja * g.ld[c], F, (vecmask >> c) & 1, za[c]);
+                load_row<FP>(g.p[c] + (long)jb * g.ld[c], F, (vecmask >> c) & 1, zb[c]);
+            }
         }
 #pragma unroll
         for (int c = 0; c < NG; ++c)
@@ -341,12 +365,19 @@ int launch_gather(const acm_csr* a, const GatherSrc& g, int F, const typename Ep
         }
         const double avg = (double)a->nnz / (double)(a->n_rows > 0 ? a->n_rows : 1);
         const bool small_groups = avg <= 12.0;
-#define ACM_NARROW(FPv, GSv)                                                                    \
-    do {                                                                                        \
-        const int gpb = 256 / GSv;                                                              \
-        const int grid = (int)((a->n_items + gpb - 1) / gpb);                                   \
-        hipLaunchKernelGGL((spmm_narrow_kernel<FPv, NG, GSv, Epi>), dim3(grid), dim3(256), 0,  \
-                           st, v, g, F, vecmask, ea, partial);                                  \
+        // [channel 0 | channel 1] contiguous and block-aligned => one vector fetch for both
+        const bool merged = NG >= 2 && F == FP && g.p[1] == g.p[0] + F && g.ld[0] == g.ld[1] &&
+                            ((uintptr_t)g.p[0]) % (8 * FP) == 0 && (g.ld[0] * sizeof(float)) % (8 * FP) == 0;
+#define ACM_NARROW(FPv, GSv)                                                                            \
+    do {                                                                                                \
+        const int gpb = 256 / GSv;                                                                      \
+        const int grid = (int)((a->n_items + gpb - 1) / gpb);                                           \
+        if (merged)                                                                                     \
+            hipLaunchKernelGGL((spmm_narrow_kernel<FPv, NG, GSv, (NG >= 2), Epi>), dim3(grid), dim3(256), 0, \
+                               st, v, g, F, vecmask, ea, partial);                                      \
+        else                                                                                            \
+            hipLaunchKernelGGL((spmm_narrow_kernel<FPv, NG, GSv, false, Epi>), dim3(grid), dim3(256), 0, \
+                               st, v, g, F, vecmask, ea, partial);                                      \
     } while (0)
         if (FP == 2) {
             if (small_groups) ACM_NARROW(2, 8); else ACM_NARROW(2, 32);

@@ -14,20 +14,8 @@
 
 namespace {
 
-template <int FP>
-struct AggWeights {  // lane l: column l of W_low / W_high / W_mlp, rows 0..FP-1 (zero beyond f_in)
-    float wl[FP], wh[FP], wm[FP];
-    __device__ __forceinline__ void load(const float* w_low, const float* w_high, const float* w_mlp, long ld,
-                                         int f_in, int F, int lane) {
-#pragma unroll
-        for (int f = 0; f < FP; ++f) {
-            const bool ok = f < f_in && lane < F;
-            wl[f] = ok ? w_low[(long)f * ld + lane] : 0.f;
-            wh[f] = ok ? w_high[(long)f * ld + lane] : 0.f;
-            wm[f] = ok ? w_mlp[(long)f * ld + lane] : 0.f;
-        }
-    }
-};
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+using LG = LayGrouped<4>;   // 16 lanes x 4 columns per row, 4 rows per wave (F <= 64)
 
 template <int FP>
 __device__ __forceinline__ void load_vec(const float* __restrict__ p, float (&v)[FP]) {
@@ -41,35 +29,71 @@ __device__ __forceinline__ void load_vec(const float* __restrict__ p, float (&v)
     }
 }
 
-// P (wave-uniform) -> projections -> head -> out / att / agg for one row.
+// The three F_in x F weight panels staged in LDS as [c][f][m][i] <-> W_c[f][col = m + 16 i]
+// (zero beyond f_in / F), so that lane m fetches its four columns of one weight row with a
+// single conflict-free ds_read_b128 (the four row-groups of a wave read the same address).
 template <int FP>
-__device__ __forceinline__ void agg_fwd_row(const acm_conv_agg_fwd_t& p, const AggWeights<FP>& W, int row,
-                                            int lane, const float (&P)[FP]) {
-    using L = LayWide<1>;
-    const int F = p.f_out;
-    float x[FP];
-    load_vec<FP>(p.xs + (long)row * p.ld_xs, x);   // same address in every lane: one broadcast fetch
-    float p0 = 0.f, p1 = 0.f, zi = 0.f;
+__device__ __forceinline__ void stage_weights(float* wlds, const float* w_low, const float* w_high,
+                                              const float* w_mlp, long ld, int f_in, int F) {
+    for (int idx = threadIdx.x; idx < 3 * FP * 64; idx += 256) {
+        const int c = idx / (FP * 64), f = (idx / 64) % FP, m = (idx % 64) / 4, i = idx % 4;
+        const int col = m + 16 * i;
+        const float* w = c == 0 ? w_low : (c == 1 ? w_high : w_mlp);
+        wlds[idx] = (f < f_in && col < F) ? w[(long)f * ld + col] : 0.f;
+    }
+}
+
+// pre_L = P W_L, pre_H = (x - P) W_H, z_I = x W_I for the lane's four columns.
+template <int FP>
+__device__ __forceinline__ void project(const float* wlds, int m, const float (&P)[FP], const float (&x)[FP],
+                                        float (&p0)[4], float (&p1)[4], float (&zi)[4]) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) p0[i] = p1[i] = zi[i] = 0.f;
 #pragma unroll
     for (int f = 0; f < FP; ++f) {
-        p0 = fmaf(P[f], W.wl[f], p0);
-        p1 = fmaf(x[f] - P[f], W.wh[f], p1);
-        zi = fmaf(x[f], W.wm[f], zi);
+        const float4 wl = *reinterpret_cast<const float4*>(wlds + ((0 * FP + f) * 16 + m) * 4);
+        const float4 wh = *reinterpret_cast<const float4*>(wlds + ((1 * FP + f) * 16 + m) * 4);
+        const float4 wm = *reinterpret_cast<const float4*>(wlds + ((2 * FP + f) * 16 + m) * 4);
+        const float d = x[f] - P[f];
+        p0[0] = fmaf(P[f], wl.x, p0[0]); p0[1] = fmaf(P[f], wl.y, p0[1]);
+        p0[2] = fmaf(P[f], wl.z, p0[2]); p0[3] = fmaf(P[f], wl.w, p0[3]);
+        p1[0] = fmaf(d, wh.x, p1[0]); p1[1] = fmaf(d, wh.y, p1[1]);
+        p1[2] = fmaf(d, wh.z, p1[2]); p1[3] = fmaf(d, wh.w, p1[3]);
+        zi[0] = fmaf(x[f], wm.x, zi[0]); zi[1] = fmaf(x[f], wm.y, zi[1]);
+        zi[2] = fmaf(x[f], wm.z, zi[2]); zi[3] = fmaf(x[f], wm.w, zi[3]);
     }
-    float H[4][1], hn[4][1], xhat[4][1];
-    const bool ok = lane < F;
-    H[0][0] = ok ? (p.relu_after ? fmaxf(p0, 0.f) : p0) : 0.f;
-    H[1][0] = ok ? (p.relu_after ? fmaxf(p1, 0.f) : p1) : 0.f;
-    H[2][0] = ok ? (p.relu_mlp ? fmaxf(zi, 0.f) : zi) : 0.f;
-    H[3][0] = 0.f;
-    L lay{lane};
+}
+
+// P (uniform in the 16-lane group) -> projections -> head -> out / att / agg for one row.
+template <int FP>
+__device__ __forceinline__ void agg_fwd_row(const acm_conv_agg_fwd_t& p, const float* wlds, int row, int lane,
+                                            const float (&P)[FP]) {
+    const int F = p.f_out, m = lane & 15;
+    float x[FP];
+    load_vec<FP>(p.xs + (long)row * p.ld_xs, x);     // same address in the whole group: broadcast
+    float p0[4], p1[4], zi[4];
+    project<FP>(wlds, m, P, x, p0, p1, zi);
+    float H[4][4], hn[4][4], xhat[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const bool ok = m + 16 * i < F;
+        H[0][i] = ok ? (p.relu_after ? fmaxf(p0[i], 0.f) : p0[i]) : 0.f;
+        H[1][i] = ok ? (p.relu_after ? fmaxf(p1[i], 0.f) : p1[i]) : 0.f;
+        H[2][i] = ok ? (p.relu_mlp ? fmaxf(zi[i], 0.f) : zi[i]) : 0.f;
+        H[3][i] = 0.f;
+    }
+    LG lay{lane};
     HeadOut ho;
     const HeadParams hp = acm_head_params(p);
-    acm_head<L, 3>(lay, F, p.layernorm, hp, H, hn, xhat, ho);
-    if (ok)
-        p.out[(long)row * p.ld_out + lane] =
-            p.scale * (ho.alpha[0] * H[0][0] + ho.alpha[1] * H[1][0] + ho.alpha[2] * H[2][0]);
-    if (lane == 0) {
+    acm_head<LG, 3>(lay, F, p.layernorm, hp, H, hn, xhat, ho);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int col = m + 16 * i;
+        if (col < F)
+            p.out[(long)row * p.ld_out + col] =
+                p.scale * (ho.alpha[0] * H[0][i] + ho.alpha[1] * H[1][i] + ho.alpha[2] * H[2][i]);
+    }
+    if (m == 0) {
         *reinterpret_cast<float4*>(p.att + (long)row * 4) = make_float4(ho.alpha[0], ho.alpha[1], ho.alpha[2], 0.f);
         float* ag = p.agg + (long)row * p.ld_agg;
 #pragma unroll
@@ -78,22 +102,22 @@ __device__ __forceinline__ void agg_fwd_row(const acm_conv_agg_fwd_t& p, const A
     }
 }
 
+// One 16-lane group per work item (4 items per wave in flight); groups are persistent.
 template <int FP>
 __global__ __launch_bounds__(256) void agg_fwd_kernel(CsrView csr, acm_conv_agg_fwd_t p, float* __restrict__ partial) {
-    const int lane = threadIdx.x & 63;
-    const int nw = gridDim.x * 4;
-    AggWeights<FP> W;
-    W.load(p.w_low, p.w_high, p.w_mlp, p.ld_w, p.f_in, p.f_out, lane);
-    for (int w = blockIdx.x * 4 + (threadIdx.x >> 6); w < csr.n_items; w += nw) {
+    __shared__ __attribute__((aligned(16))) float wlds[3 * FP * 64];
+    stage_weights<FP>(wlds, p.w_low, p.w_high, p.w_mlp, p.ld_w, p.f_in, p.f_out);
+    __syncthreads();
+    const int lane = threadIdx.x & 63, m = lane & 15;
+    const int ngroups = gridDim.x * 16;
+    for (int w = blockIdx.x * 16 + (threadIdx.x >> 4); w < csr.n_items; w += ngroups) {
         const AcmItem it = csr.items[w];
-        const int row = acm_uniform(it.row), begin = acm_uniform(it.begin), end = acm_uniform(it.end),
-                  slot = acm_uniform(it.slot);
         float acc[FP];
 #pragma unroll
         for (int f = 0; f < FP; ++f) acc[f] = 0.f;
-        for (int k0 = begin; k0 < end; k0 += 128) {      // 2 neighbours per lane in flight
-            const int ka = k0 + lane, kb = ka + 64;
-            const bool va = ka < end, vb = kb < end;
+        for (int k0 = it.begin; k0 < it.end; k0 += 32) {      // 2 neighbours per lane in flight
+            const int ka = k0 + m, kb = ka + 16;
+            const bool va = ka < it.end, vb = kb < it.end;
             const int ja = va ? csr.indices[ka] : 0, jb = vb ? csr.indices[kb] : 0;
             const float aa = va ? csr.vals[ka] : 0.f, ab = vb ? csr.vals[kb] : 0.f;
             float xa[FP], xb[FP];
@@ -106,11 +130,11 @@ __global__ __launch_bounds__(256) void agg_fwd_kernel(CsrView csr, acm_conv_agg_
             }
         }
 #pragma unroll
-        for (int f = 0; f < FP; ++f) acc[f] = acm_group_sum<64>(acc[f]);
-        if (slot < 0) {
-            agg_fwd_row<FP>(p, W, row, lane, acc);
-        } else if (lane == 0) {
-            float* ps = partial + (long)slot * FP;
+        for (int f = 0; f < FP; ++f) acc[f] = acm_group_sum<16>(acc[f]);
+        if (it.slot < 0) {
+            agg_fwd_row<FP>(p, wlds, it.row, lane, acc);
+        } else if (m == 0) {
+            float* ps = partial + (long)it.slot * FP;
 #pragma unroll
             for (int q = 0; q < FP / 4; ++q)
                 reinterpret_cast<float4*>(ps)[q] = make_float4(acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]);
@@ -121,96 +145,133 @@ __global__ __launch_bounds__(256) void agg_fwd_kernel(CsrView csr, acm_conv_agg_
 template <int FP>
 __global__ __launch_bounds__(256) void agg_fwd_fixup_kernel(CsrView csr, acm_conv_agg_fwd_t p,
                                                             const float* __restrict__ partial) {
-    const int lane = threadIdx.x & 63;
-    const int nw = gridDim.x * 4;
-    AggWeights<FP> W;
-    W.load(p.w_low, p.w_high, p.w_mlp, p.ld_w, p.f_in, p.f_out, lane);
-    for (int w = blockIdx.x * 4 + (threadIdx.x >> 6); w < csr.n_long; w += nw) {
+    __shared__ __attribute__((aligned(16))) float wlds[3 * FP * 64];
+    stage_weights<FP>(wlds, p.w_low, p.w_high, p.w_mlp, p.ld_w, p.f_in, p.f_out);
+    __syncthreads();
+    const int lane = threadIdx.x & 63, m = lane & 15;
+    const int ngroups = gridDim.x * 16;
+    for (int w = blockIdx.x * 16 + (threadIdx.x >> 4); w < csr.n_long; w += ngroups) {
         const AcmLongRow lr = csr.long_rows[w];
-        const int row = acm_uniform(lr.row), sb = acm_uniform(lr.slot_begin), se = acm_uniform(lr.slot_end);
-        // lanes split the slots, then a fixed-order butterfly combines them (deterministic)
+        // the 16 lanes split the slots, then a fixed DPP tree combines them (deterministic)
         float acc[FP];
 #pragma unroll
         for (int f = 0; f < FP; ++f) acc[f] = 0.f;
-        for (int s = sb + lane; s < se; s += 64) {
+        for (int s = lr.slot_begin + m; s < lr.slot_end; s += 16) {
             float v[FP];
             load_vec<FP>(partial + (long)s * FP, v);
 #pragma unroll
             for (int f = 0; f < FP; ++f) acc[f] += v[f];
         }
 #pragma unroll
-        for (int f = 0; f < FP; ++f) acc[f] = acm_group_sum<64>(acc[f]);
-        agg_fwd_row<FP>(p, W, row, lane, acc);
+        for (int f = 0; f < FP; ++f) acc[f] = acm_group_sum<16>(acc[f]);
+        agg_fwd_row<FP>(p, wlds, lr.row, lane, acc);
     }
 }
 
 // ---------------------------------------------------------------- backward
 // flat parameter-gradient vector: [dW_low f_in*F][dW_high][dW_mlp][dv 3F][dgamma 3F][dbeta 3F][dmix 9]
+//
+// dW_c = A_c^T G_c with A_L = P, A_H = X - P, A_I = X is accumulated on the matrix pipe: each
+// wave step covers 4 rows = the K dimension of v_mfma_f32_16x16x4_f32.  Lane (g, m) supplies
+//   A[i = m][k = g] = A_c[row_g][f = m]      (one per-lane load of P / X element m)
+//   B[k = g][j = m] = G_c[row_g][16 t + m]   (exactly the LayGrouped column the lane owns)
+// and the accumulator tile t holds dW_c[f = 4 (lane >> 4) + r][16 t + (lane & 15)].
 template <int FP>
-__global__ __launch_bounds__(256) void agg_bwd_kernel(acm_conv_agg_bwd_t p, int n_rows, float* __restrict__ partial) {
-    extern __shared__ float lds[];
-    using L = LayWide<1>;
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+__global__ __launch_bounds__(256, 2) void agg_bwd_kernel(acm_conv_agg_bwd_t p, int n_rows, float* __restrict__ partial) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, m = lane & 15, g = lane >> 4;
     const int F = p.f_out, f_in = p.f_in;
     const int npg = 3 * f_in * F + 9 * F + 9;
-    AggWeights<FP> W;
-    W.load(p.w_low, p.w_high, p.w_mlp, p.ld_w, f_in, F, lane);
-    float dwl[FP], dwh[FP], dwm[FP];
+    float* wlds = lds;                           // 3 * FP * 64 floats, dead after the row loop
+    stage_weights<FP>(wlds, p.w_low, p.w_high, p.w_mlp, p.ld_w, f_in, F);
+    __syncthreads();
+    f32x4 acc[3][4];
 #pragma unroll
-    for (int f = 0; f < FP; ++f) dwl[f] = dwh[f] = dwm[f] = 0.f;
-    ParamAcc<L> pa;
+    for (int c = 0; c < 3; ++c)
+#pragma unroll
+        for (int t = 0; t < 4; ++t) acc[c][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    ParamAcc<LG> pa;
     pa.zero();
-    L lay{lane};
+    LG lay{lane};
     const HeadParams hp = acm_head_params(p);
-    const bool ok = lane < F;
-    for (int row = blockIdx.x * 4 + wv; row < n_rows; row += gridDim.x * 4) {
+    for (int r0 = (blockIdx.x * 4 + wv) * 4; r0 < n_rows; r0 += gridDim.x * 16) {
+        const int row = r0 + g;
+        const bool active = row < n_rows;
+        const long rr = active ? row : 0;
         float P[FP], x[FP];
-        load_vec<FP>(p.agg + (long)row * p.ld_agg, P);
-        load_vec<FP>(p.xs + (long)row * p.ld_xs, x);
-        float dO[1];
-        dO[0] = ok ? p.grad_out[(long)row * p.ld_grad_out + lane] : 0.f;
-        float p0 = 0.f, p1 = 0.f, zi = 0.f;
+        load_vec<FP>(p.agg + rr * p.ld_agg, P);
+        load_vec<FP>(p.xs + rr * p.ld_xs, x);
+        const float Pm = (active && m < FP) ? p.agg[rr * p.ld_agg + m] : 0.f;
+        const float xm = (active && m < FP) ? p.xs[rr * p.ld_xs + m] : 0.f;
+        float dO[4];
 #pragma unroll
-        for (int f = 0; f < FP; ++f) {
-            p0 = fmaf(P[f], W.wl[f], p0);
-            p1 = fmaf(x[f] - P[f], W.wh[f], p1);
-            zi = fmaf(x[f], W.wm[f], zi);
+        for (int i = 0; i < 4; ++i)
+            dO[i] = (active && m + 16 * i < F) ? p.grad_out[rr * p.ld_grad_out + m + 16 * i] : 0.f;
+        float p0[4], p1[4], zi[4];
+        project<FP>(wlds, m, P, x, p0, p1, zi);
+        float H[4][4], hn[4][4], xhat[4][4], dH[4][4];
+        bool pos[3][4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const bool ok = active && m + 16 * i < F;
+            pos[0][i] = ok && (p.relu_after ? (p0[i] > 0.f) : true);
+            pos[1][i] = ok && (p.relu_after ? (p1[i] > 0.f) : true);
+            pos[2][i] = ok && (p.relu_mlp ? (zi[i] > 0.f) : true);
+            H[0][i] = pos[0][i] ? p0[i] : 0.f;
+            H[1][i] = pos[1][i] ? p1[i] : 0.f;
+            H[2][i] = pos[2][i] ? zi[i] : 0.f;
+            H[3][i] = 0.f;
         }
-        const bool pos0 = p.relu_after ? (p0 > 0.f) : true, pos1 = p.relu_after ? (p1 > 0.f) : true,
-                   pos2 = p.relu_mlp ? (zi > 0.f) : true;
-        float H[4][1], hn[4][1], xhat[4][1], dH[4][1];
-        H[0][0] = (ok && pos0) ? p0 : 0.f;
-        H[1][0] = (ok && pos1) ? p1 : 0.f;
-        H[2][0] = (ok && pos2) ? zi : 0.f;
-        H[3][0] = 0.f;
         HeadOut ho;
-        acm_head<L, 3>(lay, F, p.layernorm, hp, H, hn, xhat, ho);
-        acm_head_backward<L, 3>(lay, F, p.layernorm, hp, p.scale, H, hn, xhat, ho, dO, 1.f, pa, dH);
-        const float g0 = (ok && pos0) ? dH[0][0] : 0.f, g1 = (ok && pos1) ? dH[1][0] : 0.f,
-                    g2 = (ok && pos2) ? dH[2][0] : 0.f;
+        acm_head<LG, 3>(lay, F, p.layernorm, hp, H, hn, xhat, ho);
+        acm_head_backward<LG, 3>(lay, F, p.layernorm, hp, p.scale, H, hn, xhat, ho, dO, active ? 1.f : 0.f, pa, dH);
+        const float aL = Pm, aH = xm - Pm, aI = xm;
 #pragma unroll
-        for (int f = 0; f < FP; ++f) {
-            dwl[f] = fmaf(P[f], g0, dwl[f]);
-            dwh[f] = fmaf(x[f] - P[f], g1, dwh[f]);
-            dwm[f] = fmaf(x[f], g2, dwm[f]);
+        for (int t = 0; t < 4; ++t) {
+            const float g0 = pos[0][t] ? dH[0][t] : 0.f, g1 = pos[1][t] ? dH[1][t] : 0.f,
+                        g2 = pos[2][t] ? dH[2][t] : 0.f;
+            acc[0][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(aL, g0, acc[0][t], 0, 0, 0);
+            acc[1][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(aH, g1, acc[1][t], 0, 0, 0);
+            acc[2][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(aI, g2, acc[2][t], 0, 0, 0);
         }
     }
-    float* slab = lds + wv * npg;
-    if (ok) {
+    // head-parameter partials: combine the four row-groups of the wave
 #pragma unroll
-        for (int f = 0; f < FP; ++f)
-            if (f < f_in) {
-                slab[(0 * f_in + f) * F + lane] = dwl[f];
-                slab[(1 * f_in + f) * F + lane] = dwh[f];
-                slab[(2 * f_in + f) * F + lane] = dwm[f];
+    for (int c = 0; c < 3; ++c)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            pa.dv[c][i] = acm_cross_row_sum(pa.dv[c][i]);
+            pa.dgam[c][i] = acm_cross_row_sum(pa.dgam[c][i]);
+            pa.dbet[c][i] = acm_cross_row_sum(pa.dbet[c][i]);
+        }
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) pa.dmix[c * 4 + j] = acm_cross_row_sum(pa.dmix[c * 4 + j]);
+    __syncthreads();                              // every wave is done with wlds
+    float* slab = lds + wv * npg;
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int f = 4 * g + r, col = 16 * t + m;
+                if (f < f_in && col < F) slab[(c * f_in + f) * F + col] = acc[c][t][r];
             }
+    if (g == 0) {
         const int base = 3 * f_in * F;
 #pragma unroll
-        for (int c = 0; c < 3; ++c) {
-            slab[base + (0 * 3 + c) * F + lane] = pa.dv[c][0];
-            slab[base + (1 * 3 + c) * F + lane] = pa.dgam[c][0];
-            slab[base + (2 * 3 + c) * F + lane] = pa.dbet[c][0];
-        }
+        for (int c = 0; c < 3; ++c)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int col = m + 16 * i;
+                if (col < F) {
+                    slab[base + (0 * 3 + c) * F + col] = pa.dv[c][i];
+                    slab[base + (1 * 3 + c) * F + col] = pa.dgam[c][i];
+                    slab[base + (2 * 3 + c) * F + col] = pa.dbet[c][i];
+                }
+            }
     }
     if (lane == 0) {
 #pragma unroll
@@ -243,7 +304,7 @@ int agg_pad(int f_in) { return f_in <= 4 ? 4 : (f_in <= 8 ? 8 : 16); }
 
 int agg_bwd_blocks(int64_t n_rows) {
     int64_t nb = (n_rows + 15) / 16;
-    if (nb > 768) nb = 768;
+    if (nb > 512) nb = 512;
     if (nb < 1) nb = 1;
     return (int)nb;
 }
@@ -284,9 +345,9 @@ extern "C" int acm_conv_agg_fwd(const acm_csr_t* a, const acm_conv_agg_fwd_t* p,
     hipStream_t s = (hipStream_t)stream;
     const CsrView v = acm_view(a);
     float* partial = (float*)workspace;
-    int grid = (int)((a->n_items + 3) / 4);
-    if (grid > 2048) grid = 2048;
-    int gridf = (int)((a->n_long + 3) / 4);
+    int grid = (int)((a->n_items + 15) / 16);
+    if (grid > 1280) grid = 1280;                 // 5 blocks per CU resident (VGPR-limited), persistent
+    int gridf = (int)((a->n_long + 15) / 16);
     if (gridf > 1024) gridf = 1024;
 #define ACM_AGG(FPv)                                                                                        \
     do {                                                                                                    \
@@ -325,7 +386,8 @@ extern "C" int acm_conv_agg_bwd(int64_t n_rows, const acm_conv_agg_bwd_t* p, voi
                 workspace_bytes, need);
     const int npg = 3 * p->f_in * p->f_out + 9 * p->f_out + 9;
     const int nblk = agg_bwd_blocks(n_rows);
-    const size_t lds = (size_t)4 * npg * sizeof(float);
+    const size_t lds_w = (size_t)3 * p->f_pad * 64 * sizeof(float), lds_s = (size_t)4 * npg * sizeof(float);
+    const size_t lds = lds_w > lds_s ? lds_w : lds_s;
     ACM_REQUIRE(lds <= 64 * 1024, ACM_EUNSUPPORTED, "acm_conv_agg_bwd: %zu B of LDS needed", lds);
     hipStream_t s = (hipStream_t)stream;
     float* partial = (float*)workspace;

@@ -24,6 +24,15 @@ struct LayPacked {  // B: FP lanes per row (64 / FP rows per wave), one column p
     __device__ __forceinline__ float rsum(float v) const { return acm_group_sum<FP>(v); }
     __device__ __forceinline__ bool leader() const { return (lane % FP) == 0; }
 };
+template <int NVv>
+struct LayGrouped {  // D: 16 lanes (= one DPP row) per matrix row, 4 rows per wave; lane m owns
+                     //    columns m, m+16, ... (NV of them) -- the B-operand layout of mfma 16x16x4
+    static constexpr int NV = NVv;
+    int lane;
+    __device__ __forceinline__ int col(int i) const { return (lane & 15) + 16 * i; }
+    __device__ __forceinline__ float rsum(float v) const { return acm_group_sum<16>(v); }
+    __device__ __forceinline__ bool leader() const { return (lane & 15) == 0; }
+};
 template <int FP>
 struct LaySerial {  // C: every lane holds the whole row
     static constexpr int NV = FP;

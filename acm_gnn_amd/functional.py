@@ -205,7 +205,13 @@ class AcmConvFunction(torch.autograd.Function):
             wl, wh, wm = (_as_f32c(t, "weight") for t in (w_low, w_high, w_mlp))
         else:
             wcat = torch.cat([w_low, w_high, w_mlp], dim=1).to(_F32).contiguous()  # [F_in, 3F]
-            z = gemm(x, wcat, relu=cfg.relu_before)                                 # [n, 3F]
+            # Row pitch of Z: for narrow layers the gathered block [Z_L | Z_H] (2F floats) must be
+            # one aligned vector fetch, so rows are padded to a multiple of that block.
+            ldz = 3 * f
+            if f in (2, 4, 8):
+                ldz = -(-3 * f // (2 * f)) * (2 * f)
+            z = torch.empty(n, ldz, dtype=_F32, device=dev)[:, : 3 * f]
+            gemm(x, wcat, relu=cfg.relu_before, out=z)                              # [n, 3F] view
             zg = _gather_rows(ops, z[:, : 2 * f]) if ops.sharded else z             # gathered [Z_L|Z_H]
         if four:
             if ops.deg is None:

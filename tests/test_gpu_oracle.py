@@ -43,7 +43,7 @@ def _run_both(model_type, variant, structure_info, ln, n, f_in, f_out, seed, x_g
         for nm in ("low", "high", "mlp", "struc_low"):
             getattr(layer, f"layer_norm_{nm}").weight.uniform_(0.5, 1.5)
             getattr(layer, f"layer_norm_{nm}").bias.uniform_(-0.5, 0.5)
-    params = {k: v.detach().clone().requires_grad_(True) for k, v in layer.named_parameters()}
+    params = {k: v.detach().cpu().clone().requires_grad_(True) for k, v in layer.named_parameters()}
     g = torch.Generator().manual_seed(seed + 1)
     x = torch.randn(n, f_in, generator=g)
     gout = torch.randn(n, f_out, generator=g)
