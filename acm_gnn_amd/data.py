@@ -138,9 +138,12 @@ def build_filters(adj):
 
 
 def row_normalize_features(x):
-    """Divide each feature row by its sum, inf -> 0 (train.py:69-73; skipped for acmgcnp+structure)."""
-    s = x.sum(1, keepdims=True).astype(np.float64)
+    """Divide each feature row by its sum, inf -> 0, in the input precision and through scipy
+    exactly as the reference does (train.py:69-73 -> utils.py:5-19; skipped for
+    acmgcnp + structure_info)."""
+    m = sp.csr_matrix(x)
+    rowsum = np.asarray(m.sum(1)).flatten()
     with np.errstate(divide="ignore"):
-        inv = 1.0 / s
+        inv = np.power(rowsum, -1.0)
     inv[np.isinf(inv)] = 0.0
-    return (x * inv).astype(np.float32)
+    return np.asarray(sp.diags(inv, 0).dot(m).todense()).astype(np.float32)

@@ -11,7 +11,7 @@ import os
 import torch
 
 from . import _lib
-from .graph import CsrGraph, FilterOperators, _require_cuda, _stream
+from .graph import CsrGraph, FilterOperators, _device_ctx, _require_cuda, _stream
 
 _F32 = torch.float32
 
@@ -87,7 +87,7 @@ def gemm(a, b, trans_a=False, trans_b=False, relu=False, out=None):
     nbytes = C.c_size_t()
     _lib.check(lib.acm_gemm_workspace_bytes(int(trans_a), int(trans_b), m, n, k, C.byref(nbytes)))
     ws = torch.empty(max(nbytes.value // 4, 1), dtype=_F32, device=a.device) if nbytes.value else None
-    with torch.cuda.device(a.device), _Timed(f"gemm_{'T' if trans_a else 'N'}{'T' if trans_b else 'N'}/{m}x{n}x{k}"):
+    with _device_ctx(a.device), _Timed(f"gemm_{'T' if trans_a else 'N'}{'T' if trans_b else 'N'}/{m}x{n}x{k}"):
         st = lib.acm_gemm(int(trans_a), int(trans_b), m, n, k, _vp(a), a.stride(0), _vp(b), b.stride(0),
                           _vp(out), out.stride(0), int(relu), _vp(ws), nbytes.value, _stream())
     _lib.check(st, "acm_gemm")
@@ -105,7 +105,7 @@ def spmm(graph, dense, out=None):
     if width == 0 or graph.n_rows == 0:
         return out
     ws = graph.workspace(min(width, 256))
-    with torch.cuda.device(dense.device), _Timed(f"spmm/W{width}"):
+    with _device_ctx(dense.device), _Timed(f"spmm/W{width}"):
         st = _lib.load().acm_spmm(graph.handle, _vp(dense), dense.stride(0), width, _vp(out), out.stride(0),
                                   _vp(ws), ws.numel() * 4, _stream())
     _lib.check(st, "acm_spmm")
@@ -243,7 +243,7 @@ class AcmConvFunction(torch.autograd.Function):
             p.agg, p.ld_agg = agg.data_ptr(), agg.stride(0)
             p.att = att.data_ptr()
             ws = ops.low.workspace(fp)
-            with torch.cuda.device(dev), _Timed(f"conv_agg_fwd/F{f}k{k}i{f_in}"):
+            with _device_ctx(dev), _Timed(f"conv_agg_fwd/F{f}k{k}i{f_in}"):
                 st = lib.acm_conv_agg_fwd(ops.low.handle, C.byref(p), _vp(ws), ws.numel() * 4, _stream())
             _lib.check(st, "acm_conv_agg_fwd")
             ctx.ops, ctx.cfg, ctx.f_in = ops, cfg, f_in
@@ -270,7 +270,7 @@ class AcmConvFunction(torch.autograd.Function):
         p.pre, p.ld_pre = pre.data_ptr(), pre.stride(0)
         p.att = att.data_ptr()
         ws = ops.low.workspace((k - 1) * f)
-        with torch.cuda.device(dev), _Timed(f"conv_fwd/F{f}k{k}"):
+        with _device_ctx(dev), _Timed(f"conv_fwd/F{f}k{k}"):
             st = lib.acm_conv_fwd(ops.low.handle, C.byref(p), _vp(ws), ws.numel() * 4, _stream())
         _lib.check(st, "acm_conv_fwd")
         ctx.ops, ctx.cfg = ops, cfg
@@ -322,7 +322,7 @@ class AcmConvFunction(torch.autograd.Function):
         nbytes = C.c_size_t()
         _lib.check(lib.acm_conv_bwd_local_workspace_bytes(n, f, k, C.byref(nbytes)))
         ws = torch.empty(max(nbytes.value // 4, 1), dtype=_F32, device=dev)
-        with torch.cuda.device(dev), _Timed(f"conv_bwd_local/F{f}k{k}"):
+        with _device_ctx(dev), _Timed(f"conv_bwd_local/F{f}k{k}"):
             st = lib.acm_conv_bwd_local(n, C.byref(q), _vp(ws), ws.numel() * 4, _stream())
         _lib.check(st, "acm_conv_bwd_local")
 
@@ -346,7 +346,7 @@ class AcmConvFunction(torch.autograd.Function):
         r.dz_high, r.ld_dz_high = dz.data_ptr() + 4 * f, dz.stride(0)
         low_t = ops.low_t
         ws2 = low_t.workspace((k - 1) * f)
-        with torch.cuda.device(dev), _Timed(f"conv_bwd_spmm/F{f}k{k}"):
+        with _device_ctx(dev), _Timed(f"conv_bwd_spmm/F{f}k{k}"):
             st = lib.acm_conv_bwd_spmm(low_t.handle, C.byref(r), _vp(ws2), ws2.numel() * 4, _stream())
         _lib.check(st, "acm_conv_bwd_spmm")
 
@@ -398,7 +398,7 @@ def _backward_agg(ctx, grad_out):
     nbytes = C.c_size_t()
     _lib.check(lib.acm_conv_agg_bwd_workspace_bytes(n, f_in, f, C.byref(nbytes)))
     ws = torch.empty(max(nbytes.value // 4, 1), dtype=_F32, device=dev)
-    with torch.cuda.device(dev), _Timed(f"conv_agg_bwd/F{f}k3i{f_in}"):
+    with _device_ctx(dev), _Timed(f"conv_agg_bwd/F{f}k3i{f_in}"):
         st = lib.acm_conv_agg_bwd(n, C.byref(q), _vp(ws), ws.numel() * 4, _stream())
     _lib.check(st, "acm_conv_agg_bwd")
     if ops.sharded:

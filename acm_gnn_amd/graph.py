@@ -23,6 +23,14 @@ def _stream():
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
+def _device_ctx(dev):
+    return torch.cuda.device(dev)
+
+
+def _sync(dev):
+    torch.cuda.synchronize(dev)
+
+
 def _require_cuda(t, name):
     if not t.is_cuda:
         raise RuntimeError(
@@ -57,8 +65,8 @@ class CsrGraph:
         if vals.numel() != nnz:
             raise ValueError(f"vals has {vals.numel()} entries, indices {nnz}")
         out = C.c_void_p()
-        with torch.cuda.device(indptr.device):
-            torch.cuda.current_stream().synchronize()
+        with _device_ctx(indptr.device):
+            _sync(indptr.device)
             st = _lib.load().acm_csr_create(n_rows, int(n_cols), nnz, indptr.data_ptr(),
                                             indices.data_ptr() if nnz else None,
                                             vals.data_ptr() if nnz else None, int(chunk), C.byref(out))
@@ -96,14 +104,14 @@ class CsrGraph:
     def transpose(self):
         if self._transposed is None:
             out = C.c_void_p()
-            with torch.cuda.device(self.device):
+            with _device_ctx(self.device):
                 _lib.check(_lib.load().acm_csr_transpose(self._h, 0, C.byref(out)), "acm_csr_transpose")
             self._transposed = CsrGraph(out.value, self.device)
         return self._transposed
 
     def slice_rows(self, begin, end):
         out = C.c_void_p()
-        with torch.cuda.device(self.device):
+        with _device_ctx(self.device):
             _lib.check(_lib.load().acm_csr_slice_rows(self._h, int(begin), int(end), 0, C.byref(out)),
                        "acm_csr_slice_rows")
         return CsrGraph(out.value, self.device)
@@ -111,14 +119,13 @@ class CsrGraph:
     # ---- views (tests, sharding) -----------------------------------------
     def arrays(self):
         """(indptr, indices, vals) copied out to new torch tensors."""
-        import numpy as np  # local: plumbing only
         def pull(ptr, n, dtype):
             t = torch.empty(n, dtype=dtype, device=self.device)
             if n:
                 C.cdll.LoadLibrary("libamdhip64.so").hipMemcpy(
                     C.c_void_p(t.data_ptr()), C.c_void_p(ptr), C.c_size_t(n * t.element_size()), 3)
             return t
-        torch.cuda.synchronize(self.device)
+        _sync(self.device)
         return (pull(self._ptrs[0], self.n_rows + 1, torch.int32),
                 pull(self._ptrs[1], self.nnz, torch.int32),
                 pull(self._ptrs[2], self.nnz, torch.float32))

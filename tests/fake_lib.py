@@ -1,0 +1,330 @@
+"""A numpy stand-in for libacm_hip.so -- TEST DOUBLE, used only by the CPU test-suite.
+
+It implements the C ABI of include/acm_hip.h entry point by entry point on *host* pointers
+(float64 arithmetic, float32 storage) so that everything above the ABI -- the ctypes structs,
+the autograd Function, GraphConvolution / GCN, the row-shard plan and its gloo collectives -- can
+be exercised without a GPU.  Product code never imports this module; tests install it with
+``install(monkeypatch)``.  It is also an executable statement of what each entry point computes.
+"""
+import contextlib
+import ctypes as C
+
+import numpy as np
+
+LN_EPS = 1e-5
+
+
+def _view(ptr, rows, cols, ld, dtype=np.float32):
+    if not ptr or rows == 0 or cols == 0:
+        return np.zeros((rows, cols), dtype)
+    ptr = ptr.value if isinstance(ptr, C.c_void_p) else int(ptr)
+    n = (rows - 1) * ld + cols
+    base = np.ctypeslib.as_array((np.ctypeslib.as_ctypes_type(dtype) * n).from_address(ptr))
+    return np.lib.stride_tricks.as_strided(base, shape=(rows, cols), strides=(ld * base.itemsize, base.itemsize))
+
+
+def _vec(ptr, n, dtype=np.float32):
+    return _view(ptr, 1, n, n, dtype)[0]
+
+
+class _Csr:
+    def __init__(self, indptr, indices, vals, n_cols, chunk):
+        self.indptr, self.indices, self.vals = indptr.copy(), indices.copy(), vals.copy()
+        self.n_rows, self.n_cols, self.chunk = len(indptr) - 1, n_cols, chunk or 256
+
+    def dense_mul(self, g):
+        import scipy.sparse as sp
+        m = sp.csr_matrix((self.vals.astype(np.float64), self.indices, self.indptr), shape=(self.n_rows, self.n_cols))
+        return m @ g.astype(np.float64)
+
+
+def _head(H, k, layernorm, vecs, lnw, lnb, mix):
+    """H: list of k arrays [n, F] (float64). Returns dict with everything the backward needs."""
+    n, F = H[0].shape
+    hn, xhat, rstd, s = [], [], [], []
+    for c in range(k):
+        if layernorm:
+            mean = H[c].mean(1, keepdims=True)
+            var = ((H[c] - mean) ** 2).mean(1, keepdims=True)
+            r = 1.0 / np.sqrt(var + LN_EPS)
+            xh = (H[c] - mean) * r
+            h = xh * lnw[c][None, :] + lnb[c][None, :]
+        else:
+            r, xh, h = np.ones((n, 1)), np.zeros_like(H[c]), H[c]
+        hn.append(h)
+        xhat.append(xh)
+        rstd.append(r)
+        s.append(h @ vecs[c])
+    g = 1.0 / (1.0 + np.exp(-np.stack(s, 1)))                  # [n, k]
+    logits = g @ mix / k
+    logits = logits - logits.max(1, keepdims=True)
+    e = np.exp(logits)
+    alpha = e / e.sum(1, keepdims=True)
+    return dict(hn=hn, xhat=xhat, rstd=rstd, g=g, alpha=alpha)
+
+
+def _head_backward(H, hd, dO, k, layernorm, vecs, lnw, mix, scale):
+    n, F = H[0].shape
+    alpha, g = hd["alpha"], hd["g"]
+    dalpha = scale * np.stack([(dO * H[c]).sum(1) for c in range(k)], 1)
+    dot = (alpha * dalpha).sum(1, keepdims=True)
+    dlogit = alpha * (dalpha - dot)
+    dg = dlogit @ mix.T / k
+    d_mix = g.T @ dlogit / k
+    ds = dg * g * (1.0 - g)
+    dH, d_vec, d_lnw, d_lnb = [], [], [], []
+    for c in range(k):
+        d_vec.append((ds[:, c:c + 1] * hd["hn"][c]).sum(0))
+        if layernorm:
+            dhn = ds[:, c:c + 1] * vecs[c][None, :]
+            d_lnw.append((dhn * hd["xhat"][c]).sum(0))
+            d_lnb.append(dhn.sum(0))
+            dxh = dhn * lnw[c][None, :]
+            m1 = dxh.mean(1, keepdims=True)
+            m2 = (dxh * hd["xhat"][c]).mean(1, keepdims=True)
+            dH.append(scale * alpha[:, c:c + 1] * dO + hd["rstd"][c] * (dxh - m1 - hd["xhat"][c] * m2))
+        else:
+            dH.append(scale * alpha[:, c:c + 1] * dO + ds[:, c:c + 1] * vecs[c][None, :])
+    return dH, d_vec, d_lnw, d_lnb, d_mix
+
+
+class FakeLib:
+    def __init__(self):
+        self._handles, self._next, self._err = {}, 1, b""
+
+    # ---- plumbing ---------------------------------------------------------
+    def acm_version(self):
+        return 1
+
+    def acm_last_error(self):
+        return self._err
+
+    def _new(self, obj, out):
+        h = self._next
+        self._next += 1
+        self._handles[h] = obj
+        out._obj.value = h
+        return 0
+
+    def _get(self, h):
+        return self._handles[h.value if isinstance(h, C.c_void_p) else int(h)]
+
+    def acm_csr_create(self, n_rows, n_cols, nnz, indptr, indices, vals, chunk, out):
+        ip = _vec(indptr, n_rows + 1, np.int32)
+        ix = _vec(indices, nnz, np.int32) if nnz else np.zeros(0, np.int32)
+        v = _vec(vals, nnz, np.float32) if nnz else np.zeros(0, np.float32)
+        if ip[0] != 0 or ip[-1] != nnz or np.any(np.diff(ip) < 0) or (nnz and (ix.min() < 0 or ix.max() >= n_cols)):
+            self._err = b"acm_csr_create: bad CSR"
+            return 2
+        return self._new(_Csr(ip, ix, v, n_cols, chunk), out)
+
+    def acm_csr_transpose(self, h, chunk, out):
+        import scipy.sparse as sp
+        a = self._get(h)
+        m = sp.csr_matrix((a.vals, a.indices, a.indptr), shape=(a.n_rows, a.n_cols)).T.tocsr()
+        m.sort_indices()
+        return self._new(_Csr(m.indptr.astype(np.int32), m.indices.astype(np.int32), m.data.astype(np.float32),
+                              a.n_rows, chunk or a.chunk), out)
+
+    def acm_csr_slice_rows(self, h, b, e, chunk, out):
+        a = self._get(h)
+        ip = a.indptr[b:e + 1] - a.indptr[b]
+        return self._new(_Csr(ip, a.indices[a.indptr[b]:a.indptr[e]], a.vals[a.indptr[b]:a.indptr[e]], a.n_cols,
+                              chunk or a.chunk), out)
+
+    def acm_csr_destroy(self, h):
+        self._handles.pop(h.value if isinstance(h, C.c_void_p) else int(h), None)
+
+    def acm_csr_info(self, h, info):
+        a, i = self._get(h), info._obj
+        deg = np.diff(a.indptr)
+        longs = deg[deg > a.chunk]
+        i.n_rows, i.n_cols, i.nnz = a.n_rows, a.n_cols, len(a.indices)
+        i.n_long_rows = len(longs)
+        i.n_partial_slots = int(np.sum(-(-longs // a.chunk)))
+        i.n_items = a.n_rows - len(longs) + i.n_partial_slots
+        i.chunk, i.max_degree = a.chunk, int(deg.max()) if len(deg) else 0
+        i.indptr, i.indices, i.vals = a.indptr.ctypes.data, a.indices.ctypes.data, a.vals.ctypes.data
+        return 0
+
+    def acm_spmm_workspace_bytes(self, h, width, out):
+        out._obj.value = 0
+        return 0
+
+    def acm_gemm_workspace_bytes(self, ta, tb, m, n, k, out):
+        out._obj.value = 0
+        return 0
+
+    def acm_conv_bwd_local_workspace_bytes(self, n, f, k, out):
+        out._obj.value = 4
+        return 0
+
+    def acm_conv_agg_bwd_workspace_bytes(self, n, f_in, f, out):
+        out._obj.value = 4
+        return 0
+
+    # ---- compute ----------------------------------------------------------
+    def acm_gemm(self, ta, tb, m, n, k, a, lda, b, ldb, c, ldc, relu, ws, wsb, stream):
+        A = _view(a, k, m, lda).T if ta else _view(a, m, k, lda)
+        B = _view(b, n, k, ldb).T if tb else _view(b, k, n, ldb)
+        out = A.astype(np.float64) @ B.astype(np.float64)
+        if relu:
+            out = np.maximum(out, 0)
+        _view(c, m, n, ldc)[...] = out
+        return 0
+
+    def acm_spmm(self, h, g, ldg, width, y, ldy, ws, wsb, stream):
+        a = self._get(h)
+        _view(y, a.n_rows, width, ldy)[...] = a.dense_mul(_view(g, a.n_cols, width, ldg))
+        return 0
+
+    @staticmethod
+    def _params(p, k, F, layernorm):
+        vecs = [_vec(p.att_vec[c], F).astype(np.float64) for c in range(k)]
+        lnw = [_vec(p.ln_weight[c], F).astype(np.float64) for c in range(k)] if layernorm else None
+        lnb = [_vec(p.ln_bias[c], F).astype(np.float64) for c in range(k)] if layernorm else None
+        return vecs, lnw, lnb, _view(p.att_mix, k, k, k).astype(np.float64)
+
+    def acm_conv_fwd(self, h, pp, ws, wsb, stream):
+        a, p = self._get(h), pp._obj
+        n, F, k = a.n_rows, p.f_out, p.n_channels
+        f64 = np.float64
+        pl = a.dense_mul(_view(p.g_low, a.n_cols, F, p.ld_g_low))
+        ph = _view(p.s_high, n, F, p.ld_s_high).astype(f64) - a.dense_mul(_view(p.g_high, a.n_cols, F, p.ld_g_high))
+        zi = _view(p.s_mlp, n, F, p.ld_s_mlp).astype(f64)
+        act = (lambda t: np.maximum(t, 0)) if p.relu_after else (lambda t: t)
+        H = [act(pl), act(ph), np.maximum(zi, 0) if p.relu_mlp else zi]
+        pre = [pl, ph]
+        if k == 4:
+            deg = _vec(p.deg, n).astype(f64)[:, None]
+            ps = deg * a.dense_mul(_view(p.g_struc, a.n_cols, F, p.ld_g_struc)) - _view(p.s_struc, n, F, p.ld_s_struc)
+            H.append(np.maximum(ps, 0))
+            pre.append(ps)
+        vecs, lnw, lnb, mix = self._params(p, k, F, p.layernorm)
+        hd = _head(H, k, p.layernorm, vecs, lnw, lnb, mix)
+        _view(p.out, n, F, p.ld_out)[...] = p.scale * sum(hd["alpha"][:, c:c + 1] * H[c] for c in range(k))
+        _view(p.pre, n, (k - 1) * F, p.ld_pre)[...] = np.concatenate(pre, 1)
+        att = _view(p.att, n, 4, 4)
+        att[...] = 0
+        att[:, :k] = hd["alpha"]
+        return 0
+
+    def acm_conv_bwd_local(self, n, qq, ws, wsb, stream):
+        q = qq._obj
+        F, k = q.f_out, q.n_channels
+        f64 = np.float64
+        pre = _view(q.pre, n, (k - 1) * F, q.ld_pre).astype(f64)
+        zi = _view(q.s_mlp, n, F, q.ld_s_mlp).astype(f64)
+        raw = [pre[:, :F], pre[:, F:2 * F], zi] + ([pre[:, 2 * F:3 * F]] if k == 4 else [])
+        relu = [q.relu_after, q.relu_after, q.relu_mlp, 1][:k]
+        pos = [(r > 0) if f else np.ones_like(r, bool) for r, f in zip(raw, relu)]
+        H = [np.where(m, r, 0.0) for r, m in zip(raw, pos)]
+        vecs, lnw, lnb, mix = self._params(q, k, F, q.layernorm)
+        hd = _head(H, k, q.layernorm, vecs, lnw, lnb, mix)
+        dO = _view(q.grad_out, n, F, q.ld_grad_out).astype(f64)
+        dH, d_vec, d_lnw, d_lnb, d_mix = _head_backward(H, hd, dO, k, q.layernorm, vecs, lnw, mix, q.scale)
+        G = [np.where(m, d, 0.0) for d, m in zip(dH, pos)]
+        _view(q.g_low, n, F, q.ld_g_low)[...] = G[0]
+        _view(q.g_high, n, F, q.ld_g_high)[...] = G[1]
+        _view(q.g_mlp, n, F, q.ld_g_mlp)[...] = G[2]
+        if k == 4:
+            _view(q.g_struc, n, F, q.ld_g_struc)[...] = _vec(q.deg, n).astype(f64)[:, None] * G[3]
+        for c in range(k):
+            _vec(q.d_att_vec[c], F)[...] = d_vec[c]
+            if q.layernorm:
+                _vec(q.d_ln_weight[c], F)[...] = d_lnw[c]
+                _vec(q.d_ln_bias[c], F)[...] = d_lnb[c]
+        _view(q.d_att_mix, k, k, k)[...] = d_mix
+        return 0
+
+    def acm_conv_bwd_spmm(self, h, rr, ws, wsb, stream):
+        at, r = self._get(h), rr._obj
+        n, F = at.n_rows, r.f_out
+        f64 = np.float64
+        dl = at.dense_mul(_view(r.g_low, at.n_cols, F, r.ld_g_low))
+        dh = _view(r.s_high, n, F, r.ld_s_high).astype(f64) - at.dense_mul(_view(r.g_high, at.n_cols, F, r.ld_g_high))
+        if r.mask_low:
+            dl = np.where(_view(r.mask_low, n, F, r.ld_mask_low) > 0, dl, 0.0)
+        if r.mask_high:
+            dh = np.where(_view(r.mask_high, n, F, r.ld_mask_high) > 0, dh, 0.0)
+        _view(r.dz_low, n, F, r.ld_dz_low)[...] = dl
+        _view(r.dz_high, n, F, r.ld_dz_high)[...] = dh
+        if r.g_struc:
+            ds = at.dense_mul(_view(r.g_struc, at.n_cols, F, r.ld_g_struc)) - \
+                _view(r.s_struc, n, F, r.ld_s_struc).astype(f64) * _vec(r.inv_deg, n).astype(f64)[:, None]
+            _view(r.d_struc, n, F, r.ld_d_struc)[...] = ds
+        return 0
+
+    def _agg_common(self, p, n):
+        F, fi, fp = p.f_out, p.f_in, p.f_pad
+        f64 = np.float64
+        x = _view(p.xs, n, fp, p.ld_xs).astype(f64)[:, :fi]
+        W = [_view(w, fi, F, p.ld_w).astype(f64) for w in (p.w_low, p.w_high, p.w_mlp)]
+        return F, fi, fp, x, W
+
+    def acm_conv_agg_fwd(self, h, pp, ws, wsb, stream):
+        a, p = self._get(h), pp._obj
+        n = a.n_rows
+        F, fi, fp, x, W = self._agg_common(p, n)
+        P = a.dense_mul(_view(p.xg, a.n_cols, fp, p.ld_xg))[:, :fi]
+        raw = [P @ W[0], (x - P) @ W[1], x @ W[2]]
+        relu = [p.relu_after, p.relu_after, p.relu_mlp]
+        H = [np.maximum(r, 0) if f else r for r, f in zip(raw, relu)]
+        vecs, lnw, lnb, mix = self._params(p, 3, F, p.layernorm)
+        hd = _head(H, 3, p.layernorm, vecs, lnw, lnb, mix)
+        _view(p.out, n, F, p.ld_out)[...] = p.scale * sum(hd["alpha"][:, c:c + 1] * H[c] for c in range(3))
+        agg = _view(p.agg, n, fp, p.ld_agg)
+        agg[...] = 0
+        agg[:, :fi] = P
+        att = _view(p.att, n, 4, 4)
+        att[...] = 0
+        att[:, :3] = hd["alpha"]
+        return 0
+
+    def acm_conv_agg_bwd(self, n, qq, ws, wsb, stream):
+        q = qq._obj
+        F, fi, fp, x, W = self._agg_common(q, n)
+        P = _view(q.agg, n, fp, q.ld_agg).astype(np.float64)[:, :fi]
+        A = [P, x - P, x]
+        raw = [A[c] @ W[c] for c in range(3)]
+        relu = [q.relu_after, q.relu_after, q.relu_mlp]
+        pos = [(r > 0) if f else np.ones_like(r, bool) for r, f in zip(raw, relu)]
+        H = [np.where(m, r, 0.0) for r, m in zip(raw, pos)]
+        vecs, lnw, lnb, mix = self._params(q, 3, F, q.layernorm)
+        hd = _head(H, 3, q.layernorm, vecs, lnw, lnb, mix)
+        dO = _view(q.grad_out, n, F, q.ld_grad_out).astype(np.float64)
+        dH, d_vec, d_lnw, d_lnb, d_mix = _head_backward(H, hd, dO, 3, q.layernorm, vecs, lnw, mix, q.scale)
+        G = [np.where(m, d, 0.0) for d, m in zip(dH, pos)]
+        npg = 3 * fi * F + 9 * F + 9
+        out = _vec(q.d_params, npg)
+        out[...] = 0
+        for c in range(3):
+            out[c * fi * F:(c + 1) * fi * F] = (A[c].T @ G[c]).reshape(-1)
+        base = 3 * fi * F
+        for c in range(3):
+            out[base + c * F: base + (c + 1) * F] = d_vec[c]
+            if q.layernorm:
+                out[base + (3 + c) * F: base + (4 + c) * F] = d_lnw[c]
+                out[base + (6 + c) * F: base + (7 + c) * F] = d_lnb[c]
+        out[base + 9 * F:] = d_mix.reshape(-1)
+        return 0
+
+
+def install(monkeypatch):
+    """Route acm_gnn_amd through the test double and lift its GPU-only guards (CPU tests only)."""
+    from acm_gnn_amd import _lib, functional, graph
+    fake = FakeLib()
+    monkeypatch.setattr(_lib, "load", lambda build_if_missing=True: fake)
+    monkeypatch.setattr(_lib, "check", lambda st, what="": (_ for _ in ()).throw(
+        RuntimeError(f"{what}: {fake.acm_last_error().decode()} ({_lib.STATUS_NAMES.get(st, st)})")) if st else None)
+    for mod in (graph, functional):
+        monkeypatch.setattr(mod, "_require_cuda", lambda t, name: None)
+        monkeypatch.setattr(mod, "_stream", lambda: None)
+    monkeypatch.setattr(functional, "_device_ctx", lambda dev: contextlib.nullcontext())
+    monkeypatch.setattr(graph, "_device_ctx", lambda dev: contextlib.nullcontext())
+    monkeypatch.setattr(graph, "_sync", lambda dev: None)
+    import torch
+    from acm_gnn_amd import layers
+    monkeypatch.setattr(layers, "_default_device", lambda: torch.device("cpu"))
+    graph.clear_cache()
+    return fake
