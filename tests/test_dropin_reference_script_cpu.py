@@ -1,0 +1,63 @@
+"""The reference's own ACM-Pytorch/train.py, UNMODIFIED, running on this package's
+GraphConvolution through the drop-in shim (a11-a16 wiring check).  Only possible where the
+reference checkout exists (the build container); the kernels are replaced by the numpy test
+double because there is no GPU here -- what is exercised is the drop-in boundary itself:
+import paths, constructor / forward signatures, parameter registration with the reference's
+optimizer, train()/eval() switching, the attributes the script reads."""
+import os
+import runpy
+import sys
+import types
+
+import pytest
+
+import fake_lib
+
+REF = "/root/reference"
+pytestmark = pytest.mark.skipif(not os.path.isdir(os.path.join(REF, "ACM-Pytorch")),
+                                reason="reference checkout not present (GPU box)")
+
+
+def test_reference_acm_pytorch_train_script_runs_on_the_dropin(tmp_path, monkeypatch, capsys):
+    # scratch tree of symlinks: the script uses ../data, splits/ and writes ./logs
+    work = tmp_path / "ACM-Pytorch"
+    work.mkdir()
+    for name in ("train.py", "arg_parser.py", "logger.py", "utils.py", "models", "splits"):
+        os.symlink(os.path.join(REF, "ACM-Pytorch", name), work / name)
+    os.symlink(os.path.join(REF, "data"), tmp_path / "data")
+    os.symlink(os.path.join(REF, "BaseLogger.py"), tmp_path / "BaseLogger.py")
+    monkeypatch.chdir(work)
+    saved = dict(sys.modules)
+    saved_path = list(sys.path)
+    try:
+        sys.modules["google_drive_downloader"] = types.SimpleNamespace(GoogleDriveDownloader=object)
+        for m in ("models", "models.layers", "models.models", "utils", "logger", "arg_parser", "BaseLogger"):
+            sys.modules.pop(m, None)
+        fake_lib.install(monkeypatch)
+        from acm_gnn_amd import dropin, layers as impl
+        calls = {"fwd": 0}
+        orig_forward = impl.GraphConvolution.forward
+
+        def counting_forward(self, *a, **k):
+            calls["fwd"] += 1
+            return orig_forward(self, *a, **k)
+
+        monkeypatch.setattr(impl.GraphConvolution, "forward", counting_forward)
+        sys.path.insert(0, str(work))
+        dropin.install("pytorch")
+        monkeypatch.setattr(sys, "argv", ["train.py", "--model", "acmgcn", "--dataset_name", "cora",
+                                          "--fixed_splits", "1", "--num_splits", "1", "--epochs", "4",
+                                          "--lr", "0.01", "--weight_decay", "5e-5", "--dropout", "0.6",
+                                          "--hidden", "16", "--no-cuda"])
+        ns = runpy.run_path(str(work / "train.py"), run_name="__main__")
+    finally:
+        for k in list(sys.modules):
+            if k not in saved:
+                del sys.modules[k]
+        sys.path[:] = saved_path
+        import acm_gnn_amd.layers as impl2
+        impl2.DEFAULT_ATTN_LAYERNORM = True
+    # 4 epochs x (train forward + eval forward) x 2 layers, all through our layer
+    assert calls["fwd"] == 4 * 2 * 2
+    assert 0.0 <= float(ns["result"][0]) <= 1.0
+    assert ns["GCN"].__module__ == "models.models"            # the reference's own model wrapper
