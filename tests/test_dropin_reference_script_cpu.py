@@ -27,11 +27,13 @@ def test_reference_acm_pytorch_train_script_runs_on_the_dropin(tmp_path, monkeyp
     os.symlink(os.path.join(REF, "data"), tmp_path / "data")
     os.symlink(os.path.join(REF, "BaseLogger.py"), tmp_path / "BaseLogger.py")
     monkeypatch.chdir(work)
-    saved = dict(sys.modules)
+    ref_modules = ("models", "models.layers", "models.models", "utils", "logger", "arg_parser", "BaseLogger",
+                   "google_drive_downloader")
+    saved = {k: sys.modules.get(k) for k in ref_modules}
     saved_path = list(sys.path)
     try:
         sys.modules["google_drive_downloader"] = types.SimpleNamespace(GoogleDriveDownloader=object)
-        for m in ("models", "models.layers", "models.models", "utils", "logger", "arg_parser", "BaseLogger"):
+        for m in ref_modules[:-1]:
             sys.modules.pop(m, None)
         fake_lib.install(monkeypatch)
         from acm_gnn_amd import dropin, layers as impl
@@ -51,9 +53,11 @@ def test_reference_acm_pytorch_train_script_runs_on_the_dropin(tmp_path, monkeyp
                                           "--hidden", "16", "--no-cuda"])
         ns = runpy.run_path(str(work / "train.py"), run_name="__main__")
     finally:
-        for k in list(sys.modules):
-            if k not in saved:
-                del sys.modules[k]
+        for k, v in saved.items():          # drop only the reference's top-level modules again
+            if v is None:
+                sys.modules.pop(k, None)
+            else:
+                sys.modules[k] = v
         sys.path[:] = saved_path
         import acm_gnn_amd.layers as impl2
         impl2.DEFAULT_ATTN_LAYERNORM = True
