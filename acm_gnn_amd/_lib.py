@@ -22,7 +22,7 @@ EXPORTED_SYMBOLS = (
     "acm_csr_destroy", "acm_csr_info", "acm_spmm_workspace_bytes", "acm_gemm_workspace_bytes",
     "acm_gemm", "acm_spmm", "acm_conv_fwd", "acm_conv_bwd_local_workspace_bytes",
     "acm_conv_bwd_local", "acm_conv_bwd_spmm", "acm_conv_agg_fwd", "acm_conv_agg_bwd_workspace_bytes",
-    "acm_conv_agg_bwd",
+    "acm_conv_agg_bwd", "acm_nll_loss_workspace_bytes", "acm_nll_loss",
 )
 
 
@@ -135,6 +135,8 @@ def _declare(lib):
     lib.acm_conv_agg_fwd.argtypes = [vp, C.POINTER(ConvAggFwd), vp, sz, vp]
     lib.acm_conv_agg_bwd_workspace_bytes.argtypes = [i64, i32, i32, C.POINTER(sz)]
     lib.acm_conv_agg_bwd.argtypes = [i64, C.POINTER(ConvAggBwd), vp, sz, vp]
+    lib.acm_nll_loss_workspace_bytes.argtypes = [i64, C.POINTER(sz)]
+    lib.acm_nll_loss.argtypes = [i64, i32, vp, i64, vp, vp, vp, vp, i64, vp, sz, vp]
     for name in EXPORTED_SYMBOLS:
         fn = getattr(lib, name)
         if name not in ("acm_version", "acm_last_error", "acm_csr_destroy"):

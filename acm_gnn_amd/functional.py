@@ -133,6 +133,45 @@ def mm(a, b):
     return _Mm.apply(a, b)
 
 
+class _MaskedNll(torch.autograd.Function):
+    """loss = sum_i w_i * (logsumexp(z_i) - z_i[y_i]) with its gradient from the same pass
+    (acm_nll_loss)."""
+
+    @staticmethod
+    def forward(ctx, logits, labels, row_weight):
+        lib = _lib.load()
+        z = _as_f32c(logits, "logits")
+        w = _as_f32c(row_weight, "row_weight")
+        _require_cuda(labels, "labels")
+        y = labels.to(torch.int64).contiguous().reshape(-1)
+        n, c = z.shape
+        if y.numel() != n or w.numel() != n:
+            raise ValueError("masked_nll: labels / row_weight must have one entry per row")
+        loss = torch.empty((), dtype=_F32, device=z.device)
+        dz = torch.empty_like(z)
+        nbytes = C.c_size_t()
+        _lib.check(lib.acm_nll_loss_workspace_bytes(n, C.byref(nbytes)))
+        ws = torch.empty(max(nbytes.value // 4, 1), dtype=_F32, device=z.device)
+        with _device_ctx(z.device), _Timed(f"nll_loss/{n}x{c}"):
+            st = lib.acm_nll_loss(n, c, _vp(z), z.stride(0), _vp(y), _vp(w), _vp(loss), _vp(dz), dz.stride(0),
+                                  _vp(ws), ws.numel() * 4, _stream())
+        _lib.check(st, "acm_nll_loss")
+        ctx.save_for_backward(dz)
+        return loss
+
+    @staticmethod
+    def backward(ctx, grad_loss):
+        (dz,) = ctx.saved_tensors
+        return dz * grad_loss, None, None
+
+
+def masked_nll(logits, labels, row_weight):
+    """Fused log-softmax + NLL over the rows with non-zero weight (weights = 1/|train| on the
+    training rows reproduces F.log_softmax + NLLLoss(out[train_idx], y[train_idx]),
+    ACM-Geometric/train.py:133-134)."""
+    return _MaskedNll.apply(logits, labels, row_weight)
+
+
 # --------------------------------------------------------------------------
 # the fused ACM layer
 # --------------------------------------------------------------------------

@@ -1,0 +1,109 @@
+"""Training / evaluation harness around the ACM model: the callers of the hot path
+(ACM-Geometric/train.py:107-162, data_utils.py:115-168; ACM-Pytorch/train.py:49-139,
+utils.py:547-574), restated so the op can be trained and measured where the reference's Python
+cannot run.
+
+* ``TrainStep``      one full-batch step: forward, fused masked NLL (acm_nll_loss), backward,
+                     optimizer update; optionally captured once in a HIP graph and replayed
+                     (every launch of the step is stream-ordered and allocation-free, so the
+                     whole step is one graph launch instead of ~60 kernel launches).
+* ``evaluate``       eval-mode forward + accuracy on index sets, on device (the reference pulls the
+                     predictions to the host three times per epoch, data_utils.py:117-118).
+* ``fit``            the two model-selection rules of the reference.
+"""
+import torch
+import torch.nn.functional as F
+
+from . import functional as AF
+
+
+def row_weights(train_idx, n_rows, n_train_total=None, device=None):
+    """w_i = 1/|train| on training rows else 0 (mean NLL over the training set)."""
+    device = device if device is not None else train_idx.device
+    w = torch.zeros(n_rows, dtype=torch.float32, device=device)
+    total = n_train_total if n_train_total is not None else train_idx.numel()
+    w[train_idx.to(device)] = 1.0 / float(total)
+    return w
+
+
+class TrainStep:
+    def __init__(self, model, optimizer, x, adj, labels, weights, adj_high=None, adj_un=None, use_graph=False):
+        self.model, self.opt = model, optimizer
+        self.x, self.adj, self.adj_high, self.adj_un = x, adj, adj_high, adj_un
+        self.labels, self.weights = labels, weights
+        self.graph, self.loss = None, None
+        if use_graph:
+            self._capture()
+
+    def _eager(self):
+        self.model.train()
+        self.opt.zero_grad(set_to_none=True)
+        out = self.model(self.x, self.adj, self.adj_high, self.adj_un)
+        loss = AF.masked_nll(out, self.labels, self.weights)
+        loss.backward()
+        self.opt.step()
+        return loss
+
+    def _capture(self):
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):           # warm-up off the capture: lazy handles, allocator pools
+            for _ in range(3):
+                self._eager()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        self.graph = torch.cuda.CUDAGraph()
+        self.model.train()
+        self.opt.zero_grad(set_to_none=True)
+        with torch.cuda.graph(self.graph):
+            out = self.model(self.x, self.adj, self.adj_high, self.adj_un)
+            self.loss = AF.masked_nll(out, self.labels, self.weights)
+            self.loss.backward()
+            self.opt.step()
+
+    def __call__(self):
+        if self.graph is not None:
+            self.graph.replay()
+            return self.loss
+        return self._eager()
+
+
+@torch.no_grad()
+def evaluate(model, x, adj, labels, index_sets, adj_high=None, adj_un=None):
+    """Eval-mode logits and the accuracy on each index set (data_utils.py:153-168)."""
+    model.eval()
+    out = model(x, adj, adj_high, adj_un)
+    pred = out.argmax(dim=1)
+    accs = [float((pred[idx] == labels[idx]).float().mean()) for idx in index_sets]
+    return out, accs
+
+
+def fit(model, optimizer, x, adj, labels, train_idx, val_idx, test_idx, epochs, rule="max_val_acc",
+        early_stopping=0, adj_high=None, adj_un=None, use_graph=False):
+    """Train and return (selected test accuracy, per-epoch history).
+
+    rule = "max_val_acc":  test accuracy at the best validation accuracy, fixed number of epochs
+                           (ACM-Geometric/train.py:139-140, logger.py:17-48)
+    rule = "min_val_loss": test accuracy at the lowest validation loss, stop when the validation loss
+                           exceeds the mean of the last `early_stopping` epochs
+                           (ACM-Pytorch/train.py:129-139)
+    """
+    w = row_weights(train_idx, x.shape[0], device=x.device)
+    step = TrainStep(model, optimizer, x, adj, labels, w, adj_high, adj_un, use_graph=use_graph)
+    best_key, selected, history = None, 0.0, []
+    val_hist = []
+    for epoch in range(epochs):
+        loss = step()
+        out, (acc_tr, acc_va, acc_te) = evaluate(model, x, adj, labels, (train_idx, val_idx, test_idx),
+                                                 adj_high, adj_un)
+        val_loss = float(F.nll_loss(F.log_softmax(out, 1)[val_idx], labels[val_idx]))
+        history.append((float(loss), acc_tr, acc_va, acc_te, val_loss))
+        key = acc_va if rule == "max_val_acc" else -val_loss
+        if best_key is None or key > best_key:
+            best_key, selected = key, acc_te
+        if rule == "min_val_loss":
+            val_hist.append(val_loss)
+            if early_stopping > 0 and epoch > early_stopping:
+                if val_loss > sum(val_hist[epoch - early_stopping:epoch]) / early_stopping:
+                    break
+    return selected, history

@@ -45,6 +45,8 @@ def parse():
     ap.add_argument("--uniform", action="store_true", help="uniform random graph instead of power-law")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--graph", type=int, default=-1,
+                    help="1: time hipGraph replays of the captured step; 0: eager launches; -1: 1 on a single GPU")
     ap.add_argument("--node-order", default="degree", choices=["degree", "random"],
                     help="node relabelling applied to the whole dataset before training (data prep)")
     return ap.parse_args()
@@ -53,6 +55,16 @@ def parse():
 def algorithmic_bytes(label, n, nnz):
     """HBM bytes a launch must move if every operand is touched exactly once."""
     kind, _, shape = label.partition("/")
+    if kind == "nll_loss":
+        rows, c = (int(v) for v in shape.split("x"))
+        return rows * (4 * c + 8 + 4 + 4 * c)
+    if kind.startswith("conv_agg"):
+        f = int(shape[1:shape.index("k")])
+        fi = int(shape[shape.index("i") + 1:])
+        fp = 4 if fi <= 4 else (8 if fi <= 8 else 16)
+        if kind == "conv_agg_fwd":      # graph + gathered X once + self X + out + agg + att
+            return 4 * (n + 1) + 8 * nnz + 4 * n * fp * 2 + 4 * n * f + 4 * n * fp + 16 * n
+        return 4 * n * (f + 2 * fp)     # conv_agg_bwd: grad_out, agg, X
     if kind.startswith("gemm"):
         m, nn, k = (int(v) for v in shape.split("x"))
         return 4 * (m * k + k * nn + m * nn)
@@ -90,7 +102,7 @@ def main():
         dist.init_process_group("nccl", device_id=dev)
 
     import acm_gnn_amd
-    from acm_gnn_amd import data as D, distributed as DD, functional as AF
+    from acm_gnn_amd import data as D, distributed as DD, functional as AF, train as T
 
     # ---------------- data (synthetic, seeded; identical on every rank) ----------------
     t0 = time.time()
@@ -118,17 +130,11 @@ def main():
     torch.manual_seed(args.seed)
     model = acm_gnn_amd.GCN(x.shape[1], args.hidden, n_cls, 2, e - b, args.dropout, args.method,
                             args.structure_info, variant=bool(args.variant), attn_layernorm=True).to(dev)
-    opt = torch.optim.AdamW(model.parameters(), lr=args.lr, weight_decay=args.weight_decay)
-
-    def step():
-        model.train()
-        opt.zero_grad(set_to_none=True)
-        out = model(x, ops)
-        logp = F.log_softmax(out, dim=1)
-        loss = F.nll_loss(logp[tr_loc], y[tr_loc], reduction="sum") / n_train
-        loss.backward()
-        opt.step()
-        return loss
+    use_graph = (world == 1) if args.graph < 0 else bool(args.graph)
+    opt = torch.optim.AdamW(model.parameters(), lr=args.lr, weight_decay=args.weight_decay, capturable=use_graph)
+    # mean NLL over the (global) training set; rows a rank does not own have weight 0
+    w = T.row_weights(tr_loc, e - b, n_train_total=n_train, device=dev)
+    step = T.TrainStep(model, opt, x, ops, y, w, use_graph=False)
 
     def fence():
         if world > 1:
@@ -160,7 +166,24 @@ def main():
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
-    ms_per_step = dt / args.steps * 1e3
+    eager_ms = dt / args.steps * 1e3
+    ms_per_step = eager_ms
+    # ---------------- second timed region: the same K steps as replays of one captured HIP graph ----------------
+    if use_graph:
+        gstep = T.TrainStep(model, opt, x, ops, y, w, use_graph=True)
+        for _ in range(max(args.warmup, 1)):
+            loss = gstep()
+        fence()
+        t1 = time.perf_counter()
+        for _ in range(args.steps):
+            loss = gstep()
+        fence()
+        dtg = time.perf_counter() - t1
+        if world > 1:
+            t = torch.tensor([dtg], device=dev, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dtg = float(t.item())
+        ms_per_step = dtg / args.steps * 1e3
     final_loss = float(loss.item()) if world == 1 else None
 
     if rank != 0:
@@ -198,6 +221,8 @@ def main():
                                "step = fwd + NLL loss + bwd + optimizer update",
                    "parallelism": f"csr-row-shard x{world}" if world > 1 else "single-gpu",
                    "node_order": args.node_order,
+                   "launch": "hipGraph replay of the captured step" if use_graph else "eager launches",
+                   "eager_ms_per_step": round(eager_ms, 4),
                    "file_edges_per_s": round((adj.nnz // 2) / (ms_per_step * 1e-3), 1),
                    "kernel_ms": breakdown, "prep_s": round(prep_s, 1), "final_loss": final_loss},
         "roofline": roofline,

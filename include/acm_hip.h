@@ -274,6 +274,21 @@ int acm_conv_agg_bwd_workspace_bytes(int64_t n_rows, int f_in, int f_out, size_t
 int acm_conv_agg_bwd(int64_t n_rows, const acm_conv_agg_bwd_t* p,
                      void* workspace, size_t workspace_bytes, acm_stream_t stream);
 
+/* ------------------------------------------------ fused step tail (loss) --
+ *   loss   = sum_i w_i * (logsumexp(z_i) - z_i[y_i])
+ *   dz_i   = w_i * (softmax(z_i) - onehot(y_i))
+ * in one pass over the logits.  With w_i = 1/|train| on the training rows and 0 elsewhere this is
+ * F.log_softmax(out, 1) + nn.NLLLoss()(out[train_idx], label[train_idx]) and its autograd
+ * (ACM-Geometric/train.py:133-135, ACM-Pytorch/utils.py:566-571) without the index / index_put
+ * kernels.  n_classes <= 64.  labels: int64.  Deterministic (fixed reduction tree).
+ * Workspace: acm_nll_loss_workspace_bytes.
+ */
+int acm_nll_loss_workspace_bytes(int64_t n_rows, size_t* bytes);
+int acm_nll_loss(int64_t n_rows, int n_classes, const float* logits, int64_t ld_logits,
+                 const int64_t* labels, const float* row_weight,
+                 float* loss, float* dlogits, int64_t ld_dlogits,
+                 void* workspace, size_t workspace_bytes, acm_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

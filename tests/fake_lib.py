@@ -163,6 +163,24 @@ class FakeLib:
         out._obj.value = 4
         return 0
 
+    def acm_nll_loss_workspace_bytes(self, n, out):
+        out._obj.value = 4
+        return 0
+
+    def acm_nll_loss(self, n, c, z, ldz, y, w, loss, dz, ldd, ws, wsb, stream):
+        Z = _view(z, n, c, ldz).astype(np.float64)
+        Y = _vec(y, n, np.int64)
+        W = _vec(w, n).astype(np.float64)
+        m = Z.max(1, keepdims=True)
+        e = np.exp(Z - m)
+        s = e.sum(1, keepdims=True)
+        lse = (m + np.log(s))[:, 0]
+        onehot = np.zeros_like(Z)
+        onehot[np.arange(n), Y] = 1.0
+        _view(dz, n, c, ldd)[...] = W[:, None] * (e / s - onehot)
+        _vec(loss, 1)[0] = float((W * (lse - Z[np.arange(n), Y])).sum())
+        return 0
+
     # ---- compute ----------------------------------------------------------
     def acm_gemm(self, ta, tb, m, n, k, a, lda, b, ldb, c, ldc, relu, ws, wsb, stream):
         A = _view(a, k, m, lda).T if ta else _view(a, m, k, lda)

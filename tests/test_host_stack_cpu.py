@@ -156,3 +156,41 @@ def test_trivial_branches(monkeypatch):
     torch.testing.assert_close(mlp(x, low, high, None), x @ mlp.weight_mlp, rtol=1e-5, atol=1e-5)
     gcn = GraphConvolution(12, 5, low.shape[0], "gcn")
     torch.testing.assert_close(gcn(x, low, high, None), low @ (x @ gcn.weight_low), rtol=1e-5, atol=1e-5)
+
+
+def test_masked_nll_equals_log_softmax_nll(monkeypatch):
+    import torch.nn.functional as F
+    fake_lib.install(monkeypatch)
+    from acm_gnn_amd import functional as AF, train as T
+    g = torch.Generator().manual_seed(0)
+    z = torch.randn(50, 5, generator=g, requires_grad=True)
+    y = torch.randint(0, 5, (50,), generator=g)
+    idx = torch.randperm(50, generator=g)[:20]
+    loss = AF.masked_nll(z, y, T.row_weights(idx, 50))
+    (loss * 2.0).backward()
+    zr = z.detach().clone().requires_grad_(True)
+    ref = F.nll_loss(F.log_softmax(zr, 1)[idx], y[idx])
+    (ref * 2.0).backward()
+    torch.testing.assert_close(loss.detach(), ref.detach(), rtol=1e-6, atol=1e-6)
+    torch.testing.assert_close(z.grad, zr.grad, rtol=1e-5, atol=1e-7)
+
+
+def test_fit_selection_rules(monkeypatch):
+    fake_lib.install(monkeypatch)
+    from acm_gnn_amd import GCN, train as T
+    low, high, un, _ = graph_tensors("geometric")
+    n = low.shape[0]
+    torch.manual_seed(0)
+    x = torch.randn(n, 7)
+    y = (x[:, 0] > 0).long()
+    perm = torch.randperm(n)
+    tr, va, te = perm[:48], perm[48:72], perm[72:]
+    for rule, es in (("max_val_acc", 0), ("min_val_loss", 3)):
+        model = GCN(7, 16, 2, 2, n, 0.0, "acmgcnp", 0, variant=False)
+        opt = torch.optim.Adam(model.parameters(), lr=0.05)
+        acc, hist = T.fit(model, opt, x, low, y, tr, va, te, epochs=12, rule=rule, early_stopping=es, adj_high=high)
+        assert 0.0 <= acc <= 1.0 and 1 <= len(hist) <= 12
+        assert hist[-1][0] < hist[0][0]                       # the loss goes down
+        if rule == "max_val_acc":
+            best = max(range(len(hist)), key=lambda i: (hist[i][2], -i))
+            assert acc == hist[best][3]
