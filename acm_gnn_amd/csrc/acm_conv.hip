@@ -342,6 +342,36 @@ __global__ __launch_bounds__(256) void spmm_narrow_kernel(CsrView csr, GatherSrc
     }
 }
 
+// Long rows of the narrow path: a 16-lane group per row, lanes over the partial slots (the wide
+// fix-up would leave 62 of 64 lanes idle at F = 2 and chain up to deg/chunk dependent loads).
+template <int FP, int NG, class Epi>
+__global__ __launch_bounds__(256) void spmm_fixup_narrow_kernel(CsrView csr, int F, typename Epi::Args ea,
+                                                                const float* __restrict__ partial) {
+    const int m = threadIdx.x & 15;
+    const int w = blockIdx.x * 16 + (threadIdx.x >> 4);
+    if (w >= csr.n_long) return;
+    const AcmLongRow lr = csr.long_rows[w];
+    float acc[NG][FP];
+#pragma unroll
+    for (int c = 0; c < NG; ++c)
+#pragma unroll
+        for (int f = 0; f < FP; ++f) acc[c][f] = 0.f;
+    for (int s = lr.slot_begin + m; s < lr.slot_end; s += 16) {
+        const float* ps = partial + (long)s * (NG * F);
+#pragma unroll
+        for (int c = 0; c < NG; ++c)
+#pragma unroll
+            for (int f = 0; f < FP; ++f)
+                if (f < F) acc[c][f] += ps[c * F + f];
+    }
+#pragma unroll
+    for (int c = 0; c < NG; ++c)
+#pragma unroll
+        for (int f = 0; f < FP; ++f) acc[c][f] = acm_group_sum<16>(acc[c][f]);
+    LaySerial<FP> lay{m == 0};
+    Epi::template apply<LaySerial<FP>, NG>(ea, lr.row, lay, F, acc);
+}
+
 // ------------------------------------------------------------------ host-side dispatch
 namespace {
 
@@ -398,7 +428,16 @@ int launch_gather(const acm_csr* a, const GatherSrc& g, int F, const typename Ep
             hipLaunchKernelGGL((spmm_wide_kernel<4, NG, Epi>), dim3(grid), dim3(256), 0, st, v, g, F, ea, partial);
     }
     ACM_CHECK_HIP(hipGetLastError());
-    if (a->n_long) {
+    if (a->n_long && F <= 8) {
+        const int grid = (int)((a->n_long + 15) / 16);
+        if (F <= 2)
+            hipLaunchKernelGGL((spmm_fixup_narrow_kernel<2, NG, Epi>), dim3(grid), dim3(256), 0, st, v, F, ea, partial);
+        else if (F <= 4)
+            hipLaunchKernelGGL((spmm_fixup_narrow_kernel<4, NG, Epi>), dim3(grid), dim3(256), 0, st, v, F, ea, partial);
+        else
+            hipLaunchKernelGGL((spmm_fixup_narrow_kernel<8, NG, Epi>), dim3(grid), dim3(256), 0, st, v, F, ea, partial);
+        ACM_CHECK_HIP(hipGetLastError());
+    } else if (a->n_long) {
         ACM_REQUIRE(F <= 256, ACM_EUNSUPPORTED, "%s: F = %d > 256", who, F);
         const int grid = (int)((a->n_long + 3) / 4);
         if (F <= 64)

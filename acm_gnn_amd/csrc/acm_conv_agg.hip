@@ -93,78 +93,24 @@ __device__ __forceinline__ void agg_fwd_row(const acm_conv_agg_fwd_t& p, const f
             p.out[(long)row * p.ld_out + col] =
                 p.scale * (ho.alpha[0] * H[0][i] + ho.alpha[1] * H[1][i] + ho.alpha[2] * H[2][i]);
     }
-    if (m == 0) {
+    if (m == 0)
         *reinterpret_cast<float4*>(p.att + (long)row * 4) = make_float4(ho.alpha[0], ho.alpha[1], ho.alpha[2], 0.f);
-        float* ag = p.agg + (long)row * p.ld_agg;
-#pragma unroll
-        for (int q = 0; q < FP / 4; ++q)
-            reinterpret_cast<float4*>(ag)[q] = make_float4(P[4 * q], P[4 * q + 1], P[4 * q + 2], P[4 * q + 3]);
-    }
 }
 
-// One 16-lane group per work item (4 items per wave in flight); groups are persistent.
+// Forward = two launches: (1) P = A_low X through the lean narrow-gather kernel of acm_spmm (few
+// registers => 8 waves/SIMD in flight, which is what a request-latency-bound gather needs; the
+// fused version held the epilogue's 156 VGPRs during the gather and ran at 3 waves/SIMD), (2) this
+// streaming row-local kernel: 4 rows per wave, 16 lanes x 4 columns each.
 template <int FP>
-__global__ __launch_bounds__(256) void agg_fwd_kernel(CsrView csr, acm_conv_agg_fwd_t p, float* __restrict__ partial) {
+__global__ __launch_bounds__(256) void agg_epilogue_kernel(acm_conv_agg_fwd_t p, int n_rows) {
     __shared__ __attribute__((aligned(16))) float wlds[3 * FP * 64];
     stage_weights<FP>(wlds, p.w_low, p.w_high, p.w_mlp, p.ld_w, p.f_in, p.f_out);
     __syncthreads();
-    const int lane = threadIdx.x & 63, m = lane & 15;
-    const int ngroups = gridDim.x * 16;
-    for (int w = blockIdx.x * 16 + (threadIdx.x >> 4); w < csr.n_items; w += ngroups) {
-        const AcmItem it = csr.items[w];
-        float acc[FP];
-#pragma unroll
-        for (int f = 0; f < FP; ++f) acc[f] = 0.f;
-        for (int k0 = it.begin; k0 < it.end; k0 += 32) {      // 2 neighbours per lane in flight
-            const int ka = k0 + m, kb = ka + 16;
-            const bool va = ka < it.end, vb = kb < it.end;
-            const int ja = va ? csr.indices[ka] : 0, jb = vb ? csr.indices[kb] : 0;
-            const float aa = va ? csr.vals[ka] : 0.f, ab = vb ? csr.vals[kb] : 0.f;
-            float xa[FP], xb[FP];
-            load_vec<FP>(p.xg + (long)ja * p.ld_xg, xa);
-            load_vec<FP>(p.xg + (long)jb * p.ld_xg, xb);
-#pragma unroll
-            for (int f = 0; f < FP; ++f) {
-                acc[f] = va ? fmaf(aa, xa[f], acc[f]) : acc[f];
-                acc[f] = vb ? fmaf(ab, xb[f], acc[f]) : acc[f];
-            }
-        }
-#pragma unroll
-        for (int f = 0; f < FP; ++f) acc[f] = acm_group_sum<16>(acc[f]);
-        if (it.slot < 0) {
-            agg_fwd_row<FP>(p, wlds, it.row, lane, acc);
-        } else if (m == 0) {
-            float* ps = partial + (long)it.slot * FP;
-#pragma unroll
-            for (int q = 0; q < FP / 4; ++q)
-                reinterpret_cast<float4*>(ps)[q] = make_float4(acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]);
-        }
-    }
-}
-
-template <int FP>
-__global__ __launch_bounds__(256) void agg_fwd_fixup_kernel(CsrView csr, acm_conv_agg_fwd_t p,
-                                                            const float* __restrict__ partial) {
-    __shared__ __attribute__((aligned(16))) float wlds[3 * FP * 64];
-    stage_weights<FP>(wlds, p.w_low, p.w_high, p.w_mlp, p.ld_w, p.f_in, p.f_out);
-    __syncthreads();
-    const int lane = threadIdx.x & 63, m = lane & 15;
-    const int ngroups = gridDim.x * 16;
-    for (int w = blockIdx.x * 16 + (threadIdx.x >> 4); w < csr.n_long; w += ngroups) {
-        const AcmLongRow lr = csr.long_rows[w];
-        // the 16 lanes split the slots, then a fixed DPP tree combines them (deterministic)
-        float acc[FP];
-#pragma unroll
-        for (int f = 0; f < FP; ++f) acc[f] = 0.f;
-        for (int s = lr.slot_begin + m; s < lr.slot_end; s += 16) {
-            float v[FP];
-            load_vec<FP>(partial + (long)s * FP, v);
-#pragma unroll
-            for (int f = 0; f < FP; ++f) acc[f] += v[f];
-        }
-#pragma unroll
-        for (int f = 0; f < FP; ++f) acc[f] = acm_group_sum<16>(acc[f]);
-        agg_fwd_row<FP>(p, wlds, lr.row, lane, acc);
+    const int lane = threadIdx.x & 63;
+    for (int row = blockIdx.x * 16 + (threadIdx.x >> 4); row < n_rows; row += gridDim.x * 16) {
+        float P[FP];
+        load_vec<FP>(p.agg + (long)row * p.ld_agg, P);
+        agg_fwd_row<FP>(p, wlds, row, lane, P);
     }
 }
 
@@ -338,27 +284,20 @@ extern "C" int acm_conv_agg_fwd(const acm_csr_t* a, const acm_conv_agg_fwd_t* p,
                     ((uintptr_t)p->agg) % 16 == 0 && (p->ld_agg * 4) % 16 == 0 && p->ld_agg >= p->f_pad &&
                     ((uintptr_t)p->att) % 16 == 0, ACM_EINVAL,
                 "acm_conv_agg_fwd: xg / agg rows must be 16-byte aligned and f_pad long");
-    const size_t need = (size_t)a->n_slots * p->f_pad * sizeof(float);
-    ACM_REQUIRE(workspace_bytes >= need && (need == 0 || workspace), ACM_ENOMEM,
-                "acm_conv_agg_fwd: workspace %zu B < required %zu B", workspace_bytes, need);
-    if (a->n_items == 0) return ACM_OK;
+    if (a->n_rows == 0) return ACM_OK;
     hipStream_t s = (hipStream_t)stream;
-    const CsrView v = acm_view(a);
-    float* partial = (float*)workspace;
-    int grid = (int)((a->n_items + 15) / 16);
-    if (grid > 1280) grid = 1280;                 // 5 blocks per CU resident (VGPR-limited), persistent
-    int gridf = (int)((a->n_long + 15) / 16);
-    if (gridf > 1024) gridf = 1024;
-#define ACM_AGG(FPv)                                                                                        \
-    do {                                                                                                    \
-        hipLaunchKernelGGL((agg_fwd_kernel<FPv>), dim3(grid), dim3(256), 0, s, v, *p, partial);             \
-        if (a->n_long)                                                                                      \
-            hipLaunchKernelGGL((agg_fwd_fixup_kernel<FPv>), dim3(gridf), dim3(256), 0, s, v, *p, partial);  \
-    } while (0)
-    if (p->f_pad == 4) ACM_AGG(4);
-    else if (p->f_pad == 8) ACM_AGG(8);
-    else ACM_AGG(16);
-#undef ACM_AGG
+    // (1) P = A_low X  -> p->agg  (also the tensor saved for the backward)
+    st = acm_spmm(a, p->xg, p->ld_xg, p->f_pad, p->agg, p->ld_agg, workspace, workspace_bytes, stream);
+    if (st != ACM_OK) return st;
+    // (2) projections + head, row-local
+    int grid = (int)((a->n_rows + 15) / 16);
+    if (grid > 2048) grid = 2048;
+    if (p->f_pad == 4)
+        hipLaunchKernelGGL((agg_epilogue_kernel<4>), dim3(grid), dim3(256), 0, s, *p, (int)a->n_rows);
+    else if (p->f_pad == 8)
+        hipLaunchKernelGGL((agg_epilogue_kernel<8>), dim3(grid), dim3(256), 0, s, *p, (int)a->n_rows);
+    else
+        hipLaunchKernelGGL((agg_epilogue_kernel<16>), dim3(grid), dim3(256), 0, s, *p, (int)a->n_rows);
     ACM_CHECK_HIP(hipGetLastError());
     return ACM_OK;
 }

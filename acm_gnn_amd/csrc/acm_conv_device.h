@@ -42,6 +42,22 @@ struct LaySerial {  // C: every lane holds the whole row
     __device__ __forceinline__ bool leader() const { return lead; }
 };
 
+// 1-ulp hardware transcendentals for the mixing head.  The IEEE sequences hipcc emits for
+// expf (~20 instructions) and a / b (~10) made the row-local kernels VALU-bound; v_exp_f32 /
+// v_rcp_f32 / v_rsq_f32 are single instructions.  acm_exp keeps the exponent argument exact to
+// ~2^-48 (product error and the low word of log2 e folded back in), so the result stays within
+// ~2 ulp for |x| < 80 instead of drifting with |x| * 2^-24.
+__device__ __forceinline__ float acm_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
+__device__ __forceinline__ float acm_rsqrt(float x) { return __builtin_amdgcn_rsqf(x); }
+__device__ __forceinline__ float acm_exp(float x) {
+    const float L_HI = 1.44269502162933349609375f;   // float(log2 e)
+    const float L_LO = 1.92596299112661746e-8f;      // log2 e - L_HI
+    const float t = x * L_HI;
+    float lo = fmaf(x, L_HI, -t);
+    lo = fmaf(x, L_LO, lo);
+    return __builtin_amdgcn_exp2f(t) * fmaf(lo, 0.693147182464599609375f, 1.0f);
+}
+
 struct GatherSrc {
     const float* p[3];
     long ld[3];
@@ -101,7 +117,7 @@ __device__ __forceinline__ void acm_head(const L& lay, int F, int layernorm,
                 const float d = (lay.col(i) < F) ? (H[c][i] - mean) : 0.f;
                 part += d * d;
             }
-            rstd = 1.0f / sqrtf(lay.rsum(part) * invF + ACM_LN_EPS);
+            rstd = acm_rsqrt(lay.rsum(part) * invF + ACM_LN_EPS);
         }
         o.rstd[c] = rstd;
 #pragma unroll
@@ -121,7 +137,7 @@ __device__ __forceinline__ void acm_head(const L& lay, int F, int layernorm,
             part += (col < F) ? hn[c][i] * hp.att_vec[c][col] : 0.f;
         }
         s[c] = lay.rsum(part);
-        o.g[c] = 1.0f / (1.0f + expf(-s[c]));
+        o.g[c] = acm_rcp(1.0f + acm_exp(-s[c]));
     }
     float logit[4], mx = -INFINITY;
 #pragma unroll
@@ -134,18 +150,19 @@ __device__ __forceinline__ void acm_head(const L& lay, int F, int layernorm,
 #pragma unroll
         for (int c = 0; c < 4; ++c)
             if (c < k) acc += o.g[c] * hp.att_mix[c * k + j];
-        logit[j] = acc / (float)k;
+        logit[j] = acc * (1.0f / (float)k);
         mx = fmaxf(mx, logit[j]);
     }
     float den = 0.f;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         if (j >= k) continue;
-        logit[j] = expf(logit[j] - mx);
+        logit[j] = acm_exp(logit[j] - mx);
         den += logit[j];
     }
+    const float inv_den = acm_rcp(den);
 #pragma unroll
-    for (int j = 0; j < 4; ++j) o.alpha[j] = (j < k) ? logit[j] / den : 0.f;
+    for (int j = 0; j < 4; ++j) o.alpha[j] = (j < k) ? logit[j] * inv_den : 0.f;
 }
 
 // Parameter-gradient vector layout of the head (npg = 3 k F + k k floats):

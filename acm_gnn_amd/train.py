@@ -42,7 +42,8 @@ class TrainStep:
         loss = AF.masked_nll(out, self.labels, self.weights)
         loss.backward()
         self.opt.step()
-        return loss
+        return loss.detach()        # never hand out the autograd graph: a live AccumulateGrad node pins its
+                                    # stream and breaks a later graph capture
 
     def _capture(self):
         side = torch.cuda.Stream()
@@ -57,9 +58,11 @@ class TrainStep:
         self.opt.zero_grad(set_to_none=True)
         with torch.cuda.graph(self.graph):
             out = self.model(self.x, self.adj, self.adj_high, self.adj_un)
-            self.loss = AF.masked_nll(out, self.labels, self.weights)
-            self.loss.backward()
+            loss = AF.masked_nll(out, self.labels, self.weights)
+            loss.backward()
             self.opt.step()
+            self.loss = loss.detach()
+        del loss, out
 
     def __call__(self):
         if self.graph is not None:
