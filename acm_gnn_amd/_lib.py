@@ -14,7 +14,7 @@ c_i32p = C.POINTER(C.c_int32)
 
 ACM_OK = 0
 STATUS_NAMES = {1: "ACM_EINVAL", 2: "ACM_ESHAPE", 3: "ACM_EHIP", 4: "ACM_EUNSUPPORTED", 5: "ACM_ENOMEM"}
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 # every symbol include/acm_hip.h declares
 EXPORTED_SYMBOLS = (
@@ -48,7 +48,7 @@ class ConvFwd(C.Structure):
                 ("att_mix", C.c_void_p),
                 ("out", C.c_void_p), ("ld_out", C.c_int64),
                 ("pre", C.c_void_p), ("ld_pre", C.c_int64),
-                ("att", C.c_void_p)]
+                ("att", C.c_void_p), ("post_scale", C.c_void_p), ("ld_post_scale", C.c_int64), ("post_relu", C.c_int32)]
 
 
 class ConvBwdLocal(C.Structure):
@@ -65,7 +65,8 @@ class ConvBwdLocal(C.Structure):
                 ("g_mlp", C.c_void_p), ("ld_g_mlp", C.c_int64),
                 ("g_struc", C.c_void_p), ("ld_g_struc", C.c_int64),
                 ("d_att_vec", C.c_void_p * 4), ("d_ln_weight", C.c_void_p * 4),
-                ("d_ln_bias", C.c_void_p * 4), ("d_att_mix", C.c_void_p)]
+                ("d_ln_bias", C.c_void_p * 4), ("d_att_mix", C.c_void_p),
+                ("post_scale", C.c_void_p), ("ld_post_scale", C.c_int64), ("post_relu", C.c_int32)]
 
 
 class ConvBwdSpmm(C.Structure):
@@ -93,7 +94,7 @@ class ConvAggFwd(C.Structure):
                 ("att_mix", C.c_void_p),
                 ("out", C.c_void_p), ("ld_out", C.c_int64),
                 ("agg", C.c_void_p), ("ld_agg", C.c_int64),
-                ("att", C.c_void_p)]
+                ("att", C.c_void_p), ("post_scale", C.c_void_p), ("ld_post_scale", C.c_int64), ("post_relu", C.c_int32)]
 
 
 class ConvAggBwd(C.Structure):
@@ -105,7 +106,7 @@ class ConvAggBwd(C.Structure):
                 ("w_low", C.c_void_p), ("w_high", C.c_void_p), ("w_mlp", C.c_void_p), ("ld_w", C.c_int64),
                 ("att_vec", C.c_void_p * 4), ("ln_weight", C.c_void_p * 4), ("ln_bias", C.c_void_p * 4),
                 ("att_mix", C.c_void_p),
-                ("d_params", C.c_void_p)]
+                ("d_params", C.c_void_p), ("post_scale", C.c_void_p), ("ld_post_scale", C.c_int64), ("post_relu", C.c_int32)]
 
 
 _lib = None

@@ -89,7 +89,10 @@ struct EpiFwd {
             if (col < F && st) {
                 float o = ho.alpha[0] * H[0][i] + ho.alpha[1] * H[1][i] + ho.alpha[2] * H[2][i];
                 if (NG == 3) o += ho.alpha[3] * H[3][i];
-                p.out[(long)row * p.ld_out + col] = p.scale * o;
+                o *= p.scale;
+                if (p.post_relu) o = fmaxf(o, 0.f);
+                if (p.post_scale) o *= p.post_scale[(long)row * p.ld_post_scale + col];
+                p.out[(long)row * p.ld_out + col] = o;
                 float* pr = p.pre + (long)row * p.ld_pre;
                 pr[col] = pre[0][i];
                 pr[F + col] = pre[1][i];
@@ -551,6 +554,19 @@ __device__ __forceinline__ void conv_bwd_row(const acm_conv_bwd_local_t& p, int 
     const HeadParams hp = acm_head_params(p);
     acm_head<L, K>(lay, F, p.layernorm, hp, H, hn, xhat, ho);
 
+    if (p.post_relu || p.post_scale) {      // undo the fused post-op of the forward on the incoming gradient
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int col = lay.col(i);
+            const bool ok = active && col < F;
+            float raw = 0.f;
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+                if (c < K) raw += ho.alpha[c] * H[c][i];
+            if (p.post_relu && !(raw * p.scale > 0.f)) dO[i] = 0.f;
+            if (p.post_scale && ok) dO[i] *= p.post_scale[(long)row * p.ld_post_scale + col];
+        }
+    }
     float dH[4][NV];
     acm_head_backward<L, K>(lay, F, p.layernorm, hp, p.scale, H, hn, xhat, ho, dO, active ? 1.f : 0.f, pa, dH);
 #pragma unroll

@@ -44,57 +44,140 @@ __device__ __forceinline__ void stage_weights(float* wlds, const float* w_low, c
 }
 
 // pre_L = P W_L, pre_H = (x - P) W_H, z_I = x W_I for the lane's four columns.
+// P and x of the group's row are parked in a per-group LDS scratch (2 FP floats) so that the loop
+// over f can stay *rolled*: with a fully unrolled loop hipcc keeps all 3 FP ds_read_b128 weight rows
+// in flight (96 VGPRs at FP = 8) and the row-local kernels drop to 1-2 waves/SIMD.  Each step reads
+// P[f], x[f] (one address per group: LDS broadcast) and three weight rows.
 template <int FP>
-__device__ __forceinline__ void project(const float* wlds, int m, const float (&P)[FP], const float (&x)[FP],
-                                        float (&p0)[4], float (&p1)[4], float (&zi)[4]) {
+__device__ __forceinline__ void project(const float* wlds, float* scratch, int m, const float* __restrict__ prow,
+                                        const float* __restrict__ xrow, bool active, float (&p0)[4], float (&p1)[4],
+                                        float (&zi)[4]) {
+    // lanes 0 .. FP/4-1 of the group fetch P, the next FP/4 fetch x (16-byte pieces)
+    if (m < FP / 2) {
+        const float* src = (m < FP / 4) ? prow + 4 * m : xrow + 4 * (m - FP / 4);
+        const float4 v = active ? *reinterpret_cast<const float4*>(src) : make_float4(0.f, 0.f, 0.f, 0.f);
+        *reinterpret_cast<float4*>(scratch + 4 * m) = v;
+    }
 #pragma unroll
     for (int i = 0; i < 4; ++i) p0[i] = p1[i] = zi[i] = 0.f;
-#pragma unroll
+#pragma unroll 2
     for (int f = 0; f < FP; ++f) {
+        const float Pf = scratch[f], xf = scratch[FP + f];
         const float4 wl = *reinterpret_cast<const float4*>(wlds + ((0 * FP + f) * 16 + m) * 4);
         const float4 wh = *reinterpret_cast<const float4*>(wlds + ((1 * FP + f) * 16 + m) * 4);
         const float4 wm = *reinterpret_cast<const float4*>(wlds + ((2 * FP + f) * 16 + m) * 4);
-        const float d = x[f] - P[f];
-        p0[0] = fmaf(P[f], wl.x, p0[0]); p0[1] = fmaf(P[f], wl.y, p0[1]);
-        p0[2] = fmaf(P[f], wl.z, p0[2]); p0[3] = fmaf(P[f], wl.w, p0[3]);
+        const float d = xf - Pf;
+        p0[0] = fmaf(Pf, wl.x, p0[0]); p0[1] = fmaf(Pf, wl.y, p0[1]);
+        p0[2] = fmaf(Pf, wl.z, p0[2]); p0[3] = fmaf(Pf, wl.w, p0[3]);
         p1[0] = fmaf(d, wh.x, p1[0]); p1[1] = fmaf(d, wh.y, p1[1]);
         p1[2] = fmaf(d, wh.z, p1[2]); p1[3] = fmaf(d, wh.w, p1[3]);
-        zi[0] = fmaf(x[f], wm.x, zi[0]); zi[1] = fmaf(x[f], wm.y, zi[1]);
-        zi[2] = fmaf(x[f], wm.z, zi[2]); zi[3] = fmaf(x[f], wm.w, zi[3]);
+        zi[0] = fmaf(xf, wm.x, zi[0]); zi[1] = fmaf(xf, wm.y, zi[1]);
+        zi[2] = fmaf(xf, wm.z, zi[2]); zi[3] = fmaf(xf, wm.w, zi[3]);
     }
 }
 
-// P (uniform in the 16-lane group) -> projections -> head -> out / att / agg for one row.
-template <int FP>
-__device__ __forceinline__ void agg_fwd_row(const acm_conv_agg_fwd_t& p, const float* wlds, int row, int lane,
-                                            const float (&P)[FP]) {
-    const int F = p.f_out, m = lane & 15;
-    float x[FP];
-    load_vec<FP>(p.xs + (long)row * p.ld_xs, x);     // same address in the whole group: broadcast
-    float p0[4], p1[4], zi[4];
-    project<FP>(wlds, m, P, x, p0, p1, zi);
-    float H[4][4], hn[4][4], xhat[4][4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const bool ok = m + 16 * i < F;
-        H[0][i] = ok ? (p.relu_after ? fmaxf(p0[i], 0.f) : p0[i]) : 0.f;
-        H[1][i] = ok ? (p.relu_after ? fmaxf(p1[i], 0.f) : p1[i]) : 0.f;
-        H[2][i] = ok ? (p.relu_mlp ? fmaxf(zi[i], 0.f) : zi[i]) : 0.f;
-        H[3][i] = 0.f;
+// att_vec / LayerNorm gamma, beta staged in LDS as [array][c][m][i] (array 0 = att_vec, 1 = gamma,
+// 2 = beta; without LayerNorm gamma = 1, beta = 0): one ds_read_b128 per use, and -- unlike loads
+// from global memory -- nothing for the compiler to hoist out of the row loop into 36 VGPRs.
+__device__ __forceinline__ void stage_head_params(float* hlds, const float* const* att_vec,
+                                                  const float* const* ln_w, const float* const* ln_b, int layernorm,
+                                                  int F) {
+    for (int idx = threadIdx.x; idx < 9 * 64; idx += 256) {
+        const int arr = idx / 192, c = (idx / 64) % 3, m = (idx % 64) / 4, i = idx % 4;
+        const int col = m + 16 * i;
+        float v = (arr == 1) ? 1.f : 0.f;                  // gamma defaults to 1 (no LayerNorm)
+        if (col < F) {
+            if (arr == 0) v = att_vec[c][col];
+            else if (layernorm) v = (arr == 1) ? ln_w[c][col] : ln_b[c][col];
+        } else if (arr == 1) {
+            v = 0.f;
+        }
+        hlds[idx] = v;
     }
-    LG lay{lane};
-    HeadOut ho;
-    const HeadParams hp = acm_head_params(p);
-    acm_head<LG, 3>(lay, F, p.layernorm, hp, H, hn, xhat, ho);
+}
+
+
+// Pass 1 of a row: channel statistics and attention scalars from the activated channels H.
+struct RowHead {
+    float mean[3], rstd[3], gsig[3], alpha[3];
+};
+__device__ __forceinline__ void row_head(const float* hlds, const float* mixm, int m, int F, bool ln,
+                                         const float (&H)[3][4], RowHead& r) {
+    const float invF = 1.0f / (float)F;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const float4 v4 = *reinterpret_cast<const float4*>(hlds + ((0 * 3 + c) * 16 + m) * 4);
+        const float4 g4 = *reinterpret_cast<const float4*>(hlds + ((1 * 3 + c) * 16 + m) * 4);
+        const float4 b4 = *reinterpret_cast<const float4*>(hlds + ((2 * 3 + c) * 16 + m) * 4);
+        const float v[4] = {v4.x, v4.y, v4.z, v4.w}, gm[4] = {g4.x, g4.y, g4.z, g4.w}, bt[4] = {b4.x, b4.y, b4.z, b4.w};
+        float mu = 0.f, rs = 1.f;
+        if (ln) {
+            mu = acm_group_sum<16>((H[c][0] + H[c][1]) + (H[c][2] + H[c][3])) * invF;
+            float q = 0.f;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float d = (m + 16 * i < F) ? H[c][i] - mu : 0.f;
+                q = fmaf(d, d, q);
+            }
+            rs = acm_rsqrt(acm_group_sum<16>(q) * invF + ACM_LN_EPS);
+        }
+        r.mean[c] = mu;
+        r.rstd[c] = rs;
+        float dot = 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float hn = (m + 16 * i < F) ? fmaf((H[c][i] - mu) * rs, gm[i], bt[i]) : 0.f;
+            dot = fmaf(hn, v[i], dot);
+        }
+        r.gsig[c] = acm_rcp(1.0f + acm_exp(-acm_group_sum<16>(dot)));
+    }
+    float lg[3], mx = -INFINITY, den = 0.f;
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        lg[j] = (r.gsig[0] * mixm[j] + r.gsig[1] * mixm[3 + j] + r.gsig[2] * mixm[6 + j]) * (1.0f / 3.0f);
+        mx = fmaxf(mx, lg[j]);
+    }
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        lg[j] = acm_exp(lg[j] - mx);
+        den += lg[j];
+    }
+    const float inv = acm_rcp(den);
+#pragma unroll
+    for (int j = 0; j < 3; ++j) r.alpha[j] = lg[j] * inv;
+}
+
+// P (uniform in the 16-lane group) -> projections -> head -> out / att for one row.
+template <int FP>
+__device__ __forceinline__ void agg_fwd_row(const acm_conv_agg_fwd_t& p, const float* wlds, const float* hlds,
+                                            float* scratch, const float* mixm, int row, int lane) {
+    const int F = p.f_out, m = lane & 15;
+    float H[3][4];
+    {
+        float p0[4], p1[4], zi[4];
+        project<FP>(wlds, scratch, m, p.agg + (long)row * p.ld_agg, p.xs + (long)row * p.ld_xs, true, p0, p1, zi);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const bool ok = m + 16 * i < F;
+            H[0][i] = ok ? (p.relu_after ? fmaxf(p0[i], 0.f) : p0[i]) : 0.f;
+            H[1][i] = ok ? (p.relu_after ? fmaxf(p1[i], 0.f) : p1[i]) : 0.f;
+            H[2][i] = ok ? (p.relu_mlp ? fmaxf(zi[i], 0.f) : zi[i]) : 0.f;
+        }
+    }
+    RowHead rh;
+    row_head(hlds, mixm, m, F, p.layernorm != 0, H, rh);
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int col = m + 16 * i;
-        if (col < F)
-            p.out[(long)row * p.ld_out + col] =
-                p.scale * (ho.alpha[0] * H[0][i] + ho.alpha[1] * H[1][i] + ho.alpha[2] * H[2][i]);
+        if (col < F) {
+            float o = p.scale * (rh.alpha[0] * H[0][i] + rh.alpha[1] * H[1][i] + rh.alpha[2] * H[2][i]);
+            if (p.post_relu) o = fmaxf(o, 0.f);
+            if (p.post_scale) o *= p.post_scale[(long)row * p.ld_post_scale + col];
+            p.out[(long)row * p.ld_out + col] = o;
+        }
     }
     if (m == 0)
-        *reinterpret_cast<float4*>(p.att + (long)row * 4) = make_float4(ho.alpha[0], ho.alpha[1], ho.alpha[2], 0.f);
+        *reinterpret_cast<float4*>(p.att + (long)row * 4) = make_float4(rh.alpha[0], rh.alpha[1], rh.alpha[2], 0.f);
 }
 
 // Forward = two launches: (1) P = A_low X through the lean narrow-gather kernel of acm_spmm (few
@@ -103,15 +186,18 @@ __device__ __forceinline__ void agg_fwd_row(const acm_conv_agg_fwd_t& p, const f
 // streaming row-local kernel: 4 rows per wave, 16 lanes x 4 columns each.
 template <int FP>
 __global__ __launch_bounds__(256) void agg_epilogue_kernel(acm_conv_agg_fwd_t p, int n_rows) {
-    __shared__ __attribute__((aligned(16))) float wlds[3 * FP * 64];
+    __shared__ __attribute__((aligned(16))) float wlds[3 * FP * 64 + 9 * 64 + 16 * 2 * FP];
+    float* hlds = wlds + 3 * FP * 64;
+    float* scratch = hlds + 9 * 64 + (threadIdx.x >> 4) * 2 * FP;      // this 16-lane group's P | x
     stage_weights<FP>(wlds, p.w_low, p.w_high, p.w_mlp, p.ld_w, p.f_in, p.f_out);
+    stage_head_params(hlds, p.att_vec, p.ln_weight, p.ln_bias, p.layernorm, p.f_out);
     __syncthreads();
+    float mixm[9];
+#pragma unroll
+    for (int q = 0; q < 9; ++q) mixm[q] = p.att_mix[q];
     const int lane = threadIdx.x & 63;
-    for (int row = blockIdx.x * 16 + (threadIdx.x >> 4); row < n_rows; row += gridDim.x * 16) {
-        float P[FP];
-        load_vec<FP>(p.agg + (long)row * p.ld_agg, P);
-        agg_fwd_row<FP>(p, wlds, row, lane, P);
-    }
+    for (int row = blockIdx.x * 16 + (threadIdx.x >> 4); row < n_rows; row += gridDim.x * 16)
+        agg_fwd_row<FP>(p, wlds, hlds, scratch, mixm, row, lane);
 }
 
 // ---------------------------------------------------------------- backward
@@ -122,63 +208,141 @@ __global__ __launch_bounds__(256) void agg_epilogue_kernel(acm_conv_agg_fwd_t p,
 //   A[i = m][k = g] = A_c[row_g][f = m]      (one per-lane load of P / X element m)
 //   B[k = g][j = m] = G_c[row_g][16 t + m]   (exactly the LayGrouped column the lane owns)
 // and the accumulator tile t holds dW_c[f = 4 (lane >> 4) + r][16 t + (lane & 15)].
+//
+// Register discipline (the kernel is VALU-bound and lives or dies by waves/SIMD): the row is
+// processed in two passes.  Pass 1 keeps only H (12 values) and nine scalars (mean, rstd, g per
+// channel, then alpha / ds); pass 2 walks the channels one at a time, recomputes xhat from
+// (H, mean, rstd), and hands each channel's G straight to the MFMAs.  att_vec / LayerNorm
+// gamma, beta sit in LDS next to the weights ([array][c][m][i], one ds_read_b128 per use).
 template <int FP>
 __global__ __launch_bounds__(256, 2) void agg_bwd_kernel(acm_conv_agg_bwd_t p, int n_rows, float* __restrict__ partial) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, m = lane & 15, g = lane >> 4;
     const int F = p.f_out, f_in = p.f_in;
     const int npg = 3 * f_in * F + 9 * F + 9;
-    float* wlds = lds;                           // 3 * FP * 64 floats, dead after the row loop
+    float* wlds = lds;                           // 3 * FP * 64 floats
+    float* hlds = lds + 3 * FP * 64;             // 9 * 64 floats
+    float* scratch = hlds + 9 * 64 + (threadIdx.x >> 4) * 2 * FP;   // per-group P | x; all dead after the row loop
     stage_weights<FP>(wlds, p.w_low, p.w_high, p.w_mlp, p.ld_w, f_in, F);
+    stage_head_params(hlds, p.att_vec, p.ln_weight, p.ln_bias, p.layernorm, F);
     __syncthreads();
     f32x4 acc[3][4];
 #pragma unroll
     for (int c = 0; c < 3; ++c)
 #pragma unroll
         for (int t = 0; t < 4; ++t) acc[c][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    ParamAcc<LG> pa;
-    pa.zero();
-    LG lay{lane};
-    const HeadParams hp = acm_head_params(p);
+    float dv[3][4], dgam[3][4], dbet[3][4], dmix[9];
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) dv[c][i] = dgam[c][i] = dbet[c][i] = 0.f;
+#pragma unroll
+    for (int q = 0; q < 9; ++q) dmix[q] = 0.f;
+    float mixm[9];
+#pragma unroll
+    for (int q = 0; q < 9; ++q) mixm[q] = p.att_mix[q];
+    const float invF = 1.0f / (float)F;
+    const bool ln = p.layernorm != 0;
+
     for (int r0 = (blockIdx.x * 4 + wv) * 4; r0 < n_rows; r0 += gridDim.x * 16) {
         const int row = r0 + g;
         const bool active = row < n_rows;
         const long rr = active ? row : 0;
-        float P[FP], x[FP];
-        load_vec<FP>(p.agg + rr * p.ld_agg, P);
-        load_vec<FP>(p.xs + rr * p.ld_xs, x);
-        const float Pm = (active && m < FP) ? p.agg[rr * p.ld_agg + m] : 0.f;
-        const float xm = (active && m < FP) ? p.xs[rr * p.ld_xs + m] : 0.f;
-        float dO[4];
+        float H[3][4], dO[4];
+        {
+            float p0[4], p1[4], zi[4];
+            project<FP>(wlds, scratch, m, p.agg + rr * p.ld_agg, p.xs + rr * p.ld_xs, active, p0, p1, zi);
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
-            dO[i] = (active && m + 16 * i < F) ? p.grad_out[rr * p.ld_grad_out + m + 16 * i] : 0.f;
-        float p0[4], p1[4], zi[4];
-        project<FP>(wlds, m, P, x, p0, p1, zi);
-        float H[4][4], hn[4][4], xhat[4][4], dH[4][4];
-        bool pos[3][4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const bool ok = active && m + 16 * i < F;
-            pos[0][i] = ok && (p.relu_after ? (p0[i] > 0.f) : true);
-            pos[1][i] = ok && (p.relu_after ? (p1[i] > 0.f) : true);
-            pos[2][i] = ok && (p.relu_mlp ? (zi[i] > 0.f) : true);
-            H[0][i] = pos[0][i] ? p0[i] : 0.f;
-            H[1][i] = pos[1][i] ? p1[i] : 0.f;
-            H[2][i] = pos[2][i] ? zi[i] : 0.f;
-            H[3][i] = 0.f;
+            for (int i = 0; i < 4; ++i) {
+                const bool ok = active && m + 16 * i < F;
+                H[0][i] = ok ? (p.relu_after ? fmaxf(p0[i], 0.f) : p0[i]) : 0.f;
+                H[1][i] = ok ? (p.relu_after ? fmaxf(p1[i], 0.f) : p1[i]) : 0.f;
+                H[2][i] = ok ? (p.relu_mlp ? fmaxf(zi[i], 0.f) : zi[i]) : 0.f;
+                dO[i] = ok ? p.grad_out[rr * p.ld_grad_out + m + 16 * i] : 0.f;
+            }
         }
-        HeadOut ho;
-        acm_head<LG, 3>(lay, F, p.layernorm, hp, H, hn, xhat, ho);
-        acm_head_backward<LG, 3>(lay, F, p.layernorm, hp, p.scale, H, hn, xhat, ho, dO, active ? 1.f : 0.f, pa, dH);
-        const float aL = Pm, aH = xm - Pm, aI = xm;
+        // ---- pass 1: per-channel statistics and the attention scalars
+        RowHead rh;
+        row_head(hlds, mixm, m, F, ln, H, rh);
+        const float (&mean)[3] = rh.mean;
+        const float (&rstd)[3] = rh.rstd;
+        const float (&gsig)[3] = rh.gsig;
+        const float (&alpha)[3] = rh.alpha;
+        if (p.post_relu || p.post_scale) {        // undo the forward's fused post-op on the incoming gradient
 #pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            const float g0 = pos[0][t] ? dH[0][t] : 0.f, g1 = pos[1][t] ? dH[1][t] : 0.f,
-                        g2 = pos[2][t] ? dH[2][t] : 0.f;
-            acc[0][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(aL, g0, acc[0][t], 0, 0, 0);
-            acc[1][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(aH, g1, acc[1][t], 0, 0, 0);
-            acc[2][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(aI, g2, acc[2][t], 0, 0, 0);
+            for (int i = 0; i < 4; ++i) {
+                const float raw = alpha[0] * H[0][i] + alpha[1] * H[1][i] + alpha[2] * H[2][i];
+                if (p.post_relu && !(raw * p.scale > 0.f)) dO[i] = 0.f;
+                if (p.post_scale && active && m + 16 * i < F) dO[i] *= p.post_scale[rr * p.ld_post_scale + m + 16 * i];
+            }
+        }
+        float ds[3];
+        {
+            float dal[3], dot = 0.f;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                float part = 0.f;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) part = fmaf(dO[i], H[c][i], part);
+                dal[c] = p.scale * acm_group_sum<16>(part);
+                dot = fmaf(alpha[c], dal[c], dot);
+            }
+            float dlg[3];
+#pragma unroll
+            for (int j = 0; j < 3; ++j) dlg[j] = alpha[j] * (dal[j] - dot);
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                float dg = 0.f;
+#pragma unroll
+                for (int j = 0; j < 3; ++j) {
+                    dg = fmaf(dlg[j], mixm[c * 3 + j], dg);
+                    dmix[c * 3 + j] = fmaf(gsig[c], dlg[j] * (1.0f / 3.0f), dmix[c * 3 + j]);   // inactive rows: dlg = 0
+                }
+                ds[c] = dg * (1.0f / 3.0f) * gsig[c] * (1.f - gsig[c]);
+            }
+        }
+        // ---- pass 2: one channel at a time -> G_c -> MFMA
+        const float Pm = (m < FP) ? scratch[m] : 0.f;            // zero for inactive rows (project() stored zeros)
+        const float xm = (m < FP) ? scratch[FP + m] : 0.f;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const float4 v4 = *reinterpret_cast<const float4*>(hlds + ((0 * 3 + c) * 16 + m) * 4);
+            const float4 g4 = *reinterpret_cast<const float4*>(hlds + ((1 * 3 + c) * 16 + m) * 4);
+            const float4 b4 = *reinterpret_cast<const float4*>(hlds + ((2 * 3 + c) * 16 + m) * 4);
+            const float v[4] = {v4.x, v4.y, v4.z, v4.w}, gm[4] = {g4.x, g4.y, g4.z, g4.w}, bt[4] = {b4.x, b4.y, b4.z, b4.w};
+            const bool relu_c = (c < 2) ? (p.relu_after != 0) : (p.relu_mlp != 0);
+            const float aop = (c == 0) ? Pm : (c == 1 ? xm - Pm : xm);
+            float G[4];
+            if (ln) {
+                float xh[4], dxh[4], s1 = 0.f, s2 = 0.f;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const bool ok = m + 16 * i < F;
+                    xh[i] = ok ? (H[c][i] - mean[c]) * rstd[c] : 0.f;
+                    const float dhn = ds[c] * v[i];
+                    dgam[c][i] = fmaf(dhn, xh[i], dgam[c][i]);
+                    dbet[c][i] += dhn;
+                    dv[c][i] = fmaf(ds[c], ok ? fmaf(xh[i], gm[i], bt[i]) : 0.f, dv[c][i]);
+                    dxh[i] = dhn * gm[i];
+                    s1 += dxh[i];
+                    s2 = fmaf(dxh[i], xh[i], s2);
+                }
+                const float m1 = acm_group_sum<16>(s1) * invF, m2 = acm_group_sum<16>(s2) * invF;
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    G[i] = fmaf(p.scale * alpha[c], dO[i], rstd[c] * (dxh[i] - m1 - xh[i] * m2));
+            } else {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    dv[c][i] = fmaf(ds[c], H[c][i], dv[c][i]);
+                    G[i] = fmaf(p.scale * alpha[c], dO[i], ds[c] * v[i]);
+                }
+            }
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const bool keep = active && (m + 16 * t < F) && (!relu_c || H[c][t] > 0.f);
+                acc[c][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(aop, keep ? G[t] : 0.f, acc[c][t], 0, 0, 0);
+            }
         }
     }
     // head-parameter partials: combine the four row-groups of the wave
@@ -186,15 +350,13 @@ __global__ __launch_bounds__(256, 2) void agg_bwd_kernel(acm_conv_agg_bwd_t p, i
     for (int c = 0; c < 3; ++c)
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            pa.dv[c][i] = acm_cross_row_sum(pa.dv[c][i]);
-            pa.dgam[c][i] = acm_cross_row_sum(pa.dgam[c][i]);
-            pa.dbet[c][i] = acm_cross_row_sum(pa.dbet[c][i]);
+            dv[c][i] = acm_cross_row_sum(dv[c][i]);
+            dgam[c][i] = acm_cross_row_sum(dgam[c][i]);
+            dbet[c][i] = acm_cross_row_sum(dbet[c][i]);
         }
 #pragma unroll
-    for (int c = 0; c < 3; ++c)
-#pragma unroll
-        for (int j = 0; j < 3; ++j) pa.dmix[c * 4 + j] = acm_cross_row_sum(pa.dmix[c * 4 + j]);
-    __syncthreads();                              // every wave is done with wlds
+    for (int q = 0; q < 9; ++q) dmix[q] = acm_cross_row_sum(dmix[q]);
+    __syncthreads();                              // every wave is done with wlds / hlds
     float* slab = lds + wv * npg;
 #pragma unroll
     for (int c = 0; c < 3; ++c)
@@ -213,17 +375,15 @@ __global__ __launch_bounds__(256, 2) void agg_bwd_kernel(acm_conv_agg_bwd_t p, i
             for (int i = 0; i < 4; ++i) {
                 const int col = m + 16 * i;
                 if (col < F) {
-                    slab[base + (0 * 3 + c) * F + col] = pa.dv[c][i];
-                    slab[base + (1 * 3 + c) * F + col] = pa.dgam[c][i];
-                    slab[base + (2 * 3 + c) * F + col] = pa.dbet[c][i];
+                    slab[base + (0 * 3 + c) * F + col] = dv[c][i];
+                    slab[base + (1 * 3 + c) * F + col] = dgam[c][i];
+                    slab[base + (2 * 3 + c) * F + col] = dbet[c][i];
                 }
             }
     }
     if (lane == 0) {
 #pragma unroll
-        for (int c = 0; c < 3; ++c)
-#pragma unroll
-            for (int j = 0; j < 3; ++j) slab[3 * f_in * F + 9 * F + c * 3 + j] = pa.dmix[c * 4 + j];
+        for (int q = 0; q < 9; ++q) slab[3 * f_in * F + 9 * F + q] = dmix[q];
     }
     __syncthreads();
     for (int q = threadIdx.x; q < npg; q += 256)
@@ -325,7 +485,8 @@ extern "C" int acm_conv_agg_bwd(int64_t n_rows, const acm_conv_agg_bwd_t* p, voi
                 workspace_bytes, need);
     const int npg = 3 * p->f_in * p->f_out + 9 * p->f_out + 9;
     const int nblk = agg_bwd_blocks(n_rows);
-    const size_t lds_w = (size_t)3 * p->f_pad * 64 * sizeof(float), lds_s = (size_t)4 * npg * sizeof(float);
+    const size_t lds_w = ((size_t)3 * p->f_pad * 64 + 9 * 64 + 32 * p->f_pad) * sizeof(float),
+                 lds_s = (size_t)4 * npg * sizeof(float);
     const size_t lds = lds_w > lds_s ? lds_w : lds_s;
     ACM_REQUIRE(lds <= 64 * 1024, ACM_EUNSUPPORTED, "acm_conv_agg_bwd: %zu B of LDS needed", lds);
     hipStream_t s = (hipStream_t)stream;

@@ -180,10 +180,13 @@ GemmPlan plan_gemm(int64_t M, int64_t N, int64_t K) {
     const int64_t tiles = tm * tn;
     int64_t splits = 1;
     if (tiles < 256 && K >= 8 * BK) {  // too few tiles to fill 256 CUs: split K
-        const int64_t want = (512 + tiles - 1) / tiles;
+        const int64_t want = ((M * N <= 4096 ? 1024 : 512) + tiles - 1) / tiles;
         const int64_t kmax = (K + 4 * BK - 1) / (4 * BK);  // keep >= 4 slabs per split
         splits = want < kmax ? want : kmax;
-        if (splits > 256) splits = 256;
+        // tiny outputs (dW of a narrow layer) are pure K-streaming: more, shorter splits keep every CU
+        // loading; the slab reduce stays cheap because M*N is small
+        const int64_t cap = (M * N <= 4096) ? 1024 : 256;
+        if (splits > cap) splits = cap;
         if (splits < 1) splits = 1;
     }
     int64_t kps = (K + splits - 1) / splits;

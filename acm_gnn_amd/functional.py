@@ -223,12 +223,23 @@ class AcmConvFunction(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, w_low, w_high, w_mlp, v_low, v_high, v_mlp, v_struc, struc_low, att_mix,
-                lnw_low, lnw_high, lnw_mlp, lnw_struc, lnb_low, lnb_high, lnb_mlp, lnb_struc, ops, cfg):
+                lnw_low, lnw_high, lnw_mlp, lnw_struc, lnb_low, lnb_high, lnb_mlp, lnb_struc, ops, cfg,
+                post_relu=False, post_scale=None):
         lib = _lib.load()
         x = _as_f32c(x, "input")
         dev = x.device
         n, f = x.shape[0], w_low.shape[1]
         k = cfg.n_channels
+        if post_scale is not None:
+            post_scale = _as_f32c(post_scale, "post_scale")
+            if tuple(post_scale.shape) != (n, f):
+                raise ValueError(f"post_scale must be [{n}, {f}]")
+        ctx.post_relu, ctx.post_scale = bool(post_relu), post_scale
+
+        def set_post(st):
+            st.post_relu = int(ctx.post_relu)
+            if post_scale is not None:
+                st.post_scale, st.ld_post_scale = post_scale.data_ptr(), post_scale.stride(0)
         if n != ops.n_local:
             raise ValueError(f"input has {n} rows but the graph operator has {ops.n_local}")
         f_in = x.shape[1]
@@ -281,6 +292,7 @@ class AcmConvFunction(torch.autograd.Function):
             p.out, p.ld_out = out.data_ptr(), out.stride(0)
             p.agg, p.ld_agg = agg.data_ptr(), agg.stride(0)
             p.att = att.data_ptr()
+            set_post(p)
             ws = ops.low.workspace(fp)
             with _device_ctx(dev), _Timed(f"conv_agg_fwd/F{f}k{k}i{f_in}"):
                 st = lib.acm_conv_agg_fwd(ops.low.handle, C.byref(p), _vp(ws), ws.numel() * 4, _stream())
@@ -308,6 +320,7 @@ class AcmConvFunction(torch.autograd.Function):
         p.out, p.ld_out = out.data_ptr(), out.stride(0)
         p.pre, p.ld_pre = pre.data_ptr(), pre.stride(0)
         p.att = att.data_ptr()
+        set_post(p)
         ws = ops.low.workspace((k - 1) * f)
         with _device_ctx(dev), _Timed(f"conv_fwd/F{f}k{k}"):
             st = lib.acm_conv_fwd(ops.low.handle, C.byref(p), _vp(ws), ws.numel() * 4, _stream())
@@ -358,6 +371,9 @@ class AcmConvFunction(torch.autograd.Function):
             q.g_struc, q.ld_g_struc = gs.data_ptr(), gs.stride(0)
         q.d_att_vec, q.d_ln_weight, q.d_ln_bias = _ptr_array(d_vec), _ptr_array(d_lnw), _ptr_array(d_lnb)
         q.d_att_mix = d_mix.data_ptr()
+        q.post_relu = int(ctx.post_relu)
+        if ctx.post_scale is not None:
+            q.post_scale, q.ld_post_scale = ctx.post_scale.data_ptr(), ctx.post_scale.stride(0)
         nbytes = C.c_size_t()
         _lib.check(lib.acm_conv_bwd_local_workspace_bytes(n, f, k, C.byref(nbytes)))
         ws = torch.empty(max(nbytes.value // 4, 1), dtype=_F32, device=dev)
@@ -406,7 +422,7 @@ class AcmConvFunction(torch.autograd.Function):
         grads_lnw = (d_lnw + [None] * (4 - k)) if cfg.layernorm else none4
         grads_lnb = (d_lnb + [None] * (4 - k)) if cfg.layernorm else none4
         return (d_x, d_wl, d_wh, d_wm, grads_vec[0], grads_vec[1], grads_vec[2], grads_vec[3],
-                d_struc, d_mix, *grads_lnw, *grads_lnb, None, None)
+                d_struc, d_mix, *grads_lnw, *grads_lnb, None, None, None, None)
 
 
 def _backward_agg(ctx, grad_out):
@@ -434,6 +450,9 @@ def _backward_agg(ctx, grad_out):
     q.att_vec, q.ln_weight, q.ln_bias = _ptr_array(vecs), _ptr_array(lnw), _ptr_array(lnb)
     q.att_mix = mix.data_ptr()
     q.d_params = d_params.data_ptr()
+    q.post_relu = int(ctx.post_relu)
+    if ctx.post_scale is not None:
+        q.post_scale, q.ld_post_scale = ctx.post_scale.data_ptr(), ctx.post_scale.stride(0)
     nbytes = C.c_size_t()
     _lib.check(lib.acm_conv_agg_bwd_workspace_bytes(n, f_in, f, C.byref(nbytes)))
     ws = torch.empty(max(nbytes.value // 4, 1), dtype=_F32, device=dev)
@@ -451,18 +470,20 @@ def _backward_agg(ctx, grad_out):
     d_lnb = [d_params[base + (6 + c) * f: base + (7 + c) * f] for c in range(3)] if cfg.layernorm else [None] * 3
     d_mix = d_params[base + 9 * f:].view(3, 3)
     return (None, d_wl, d_wh, d_wm, d_vec[0], d_vec[1], d_vec[2], None, None, d_mix,
-            d_lnw[0], d_lnw[1], d_lnw[2], None, d_lnb[0], d_lnb[1], d_lnb[2], None, None, None)
+            d_lnw[0], d_lnw[1], d_lnw[2], None, d_lnb[0], d_lnb[1], d_lnb[2], None, None, None, None, None)
 
 
 AcmConvFunction._backward_agg = staticmethod(_backward_agg)
 
 
-def acm_conv(x, params, ops, cfg):
-    """params: dict with the reference's parameter names (see layers.GraphConvolution)."""
+def acm_conv(x, params, ops, cfg, post_relu=False, post_scale=None):
+    """params: dict with the reference's parameter names (see layers.GraphConvolution).
+    post_relu / post_scale: optional fused ``relu(out) * post_scale`` (the caller's inter-layer
+    ReLU + dropout; post_scale = keep_mask / (1 - p))."""
     p = params
     return AcmConvFunction.apply(
         x, p["weight_low"], p["weight_high"], p["weight_mlp"], p["att_vec_low"], p["att_vec_high"],
         p["att_vec_mlp"], p["att_struc_low"], p["struc_low"], p["att_vec"],
         p["layer_norm_low.weight"], p["layer_norm_high.weight"], p["layer_norm_mlp.weight"],
         p["layer_norm_struc_low.weight"], p["layer_norm_low.bias"], p["layer_norm_high.bias"],
-        p["layer_norm_mlp.bias"], p["layer_norm_struc_low.bias"], ops, cfg)
+        p["layer_norm_mlp.bias"], p["layer_norm_struc_low.bias"], ops, cfg, post_relu, post_scale)

@@ -47,6 +47,12 @@ class GCN(nn.Module):
         self.xX_param = nn.Parameter(torch.zeros(1, 1, device=dev))
         self.reset_parameters()
 
+    def _ones_like_hidden(self, n, f, device):
+        key = (n, f, str(device))
+        if getattr(self, "_ones_key", None) != key:
+            self._ones_key, self._ones = key, torch.ones(n, f, device=device)
+        return self._ones
+
     def reset_parameters(self):
         if self.model_type == "acmgcnpp":
             self.mlpX.reset_parameters()
@@ -58,8 +64,13 @@ class GCN(nn.Module):
             return self.gcns[0](x, adj_low, adj_high, adj_low_unnormalized)
         if self.model_type == "acmgcnpp":
             xx = drop(F.relu(self.mlpX(x, input_tensor=True)))
-        fea = self.gcns[0](x, adj_low, adj_high, adj_low_unnormalized)
-        fea = drop(F.relu(fea))
+        # dropout(relu(fea1)) (models.py:70) rides the layer's epilogue: the keep-mask / (1 - p) tensor is what
+        # F.dropout does to a tensor of ones, so a patched F.dropout (mask replay in tests) is honoured
+        scale = None
+        if self.training and self.dropout > 0:
+            ones = self._ones_like_hidden(x.shape[0], self.gcns[0].out_features, x.device)
+            scale = drop(ones)
+        fea = self.gcns[0](x, adj_low, adj_high, adj_low_unnormalized, post_relu=True, post_scale=scale)
         if self.model_type == "acmgcnpp":
             fea = fea + xx
         return self.gcns[1](fea, adj_low, adj_high, adj_low_unnormalized)

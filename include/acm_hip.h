@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define ACM_ABI_VERSION 1
+#define ACM_ABI_VERSION 2
 
 typedef enum {
     ACM_OK = 0,
@@ -155,6 +155,11 @@ typedef struct {
     float* out;  int64_t ld_out;  /* [n_rows, F]                                         */
     float* pre;  int64_t ld_pre;  /* [n_rows, (k-1)*F] pre-activations, saved for backward */
     float* att;                   /* [n_rows, 4] mixing weights (self.att_low/...)        */
+    /* optional fused post-op of the caller's inter-layer glue (models.py:70  dropout(relu(fea1))):
+     *   out <- (post_relu ? max(out, 0) : out) * (post_scale ? post_scale[row][col] : 1)
+     * post_scale is the dropout keep-mask / (1 - p); NULL = none. */
+    const float* post_scale; int64_t ld_post_scale;
+    int32_t post_relu;
 } acm_conv_fwd_t;
 
 int acm_conv_fwd(const acm_csr_t* a_low, const acm_conv_fwd_t* p,
@@ -186,6 +191,10 @@ typedef struct {
     float* d_ln_weight[4];
     float* d_ln_bias[4];
     float* d_att_mix;                     /* k x k                                         */
+    /* post-op of the forward (see acm_conv_fwd_t): grad_out is multiplied by post_scale and by
+     * [out_before_post > 0] (recomputed) on load */
+    const float* post_scale; int64_t ld_post_scale;
+    int32_t post_relu;
 } acm_conv_bwd_local_t;
 
 int acm_conv_bwd_local_workspace_bytes(int64_t n_rows, int f_out, int n_channels, size_t* bytes);
@@ -249,6 +258,8 @@ typedef struct {
     float* out; int64_t ld_out;        /* [n_rows, F]                                          */
     float* agg; int64_t ld_agg;        /* [n_rows, f_pad]  P = A_low X, saved for backward     */
     float* att;                        /* [n_rows, 4]                                          */
+    const float* post_scale; int64_t ld_post_scale;   /* fused post-op, as in acm_conv_fwd_t   */
+    int32_t post_relu;
 } acm_conv_agg_fwd_t;
 
 int acm_conv_agg_fwd(const acm_csr_t* a_low, const acm_conv_agg_fwd_t* p,
@@ -268,6 +279,8 @@ typedef struct {
     /* output: one flat vector
      *   [ dW_low : f_in x F ][ dW_high ][ dW_mlp ][ d att_vec : 3 x F ][ d ln_weight : 3 x F ][ d ln_bias : 3 x F ][ d att_mix : 3 x 3 ] */
     float* d_params;
+    const float* post_scale; int64_t ld_post_scale;   /* post-op of the forward                */
+    int32_t post_relu;
 } acm_conv_agg_bwd_t;
 
 int acm_conv_agg_bwd_workspace_bytes(int64_t n_rows, int f_in, int f_out, size_t* bytes);

@@ -38,6 +38,22 @@ class _Csr:
         return m @ g.astype(np.float64)
 
 
+def _post_fwd(p, out, n, F):
+    if p.post_relu:
+        out = np.maximum(out, 0)
+    if p.post_scale:
+        out = out * _view(p.post_scale, n, F, p.ld_post_scale)
+    return out
+
+
+def _post_bwd(p, dO, raw_out, n, F):
+    if p.post_relu:
+        dO = np.where(raw_out > 0, dO, 0.0)
+    if p.post_scale:
+        dO = dO * _view(p.post_scale, n, F, p.ld_post_scale)
+    return dO
+
+
 def _head(H, k, layernorm, vecs, lnw, lnb, mix):
     """H: list of k arrays [n, F] (float64). Returns dict with everything the backward needs."""
     n, F = H[0].shape
@@ -94,7 +110,7 @@ class FakeLib:
 
     # ---- plumbing ---------------------------------------------------------
     def acm_version(self):
-        return 1
+        return 2
 
     def acm_last_error(self):
         return self._err
@@ -220,7 +236,7 @@ class FakeLib:
             pre.append(ps)
         vecs, lnw, lnb, mix = self._params(p, k, F, p.layernorm)
         hd = _head(H, k, p.layernorm, vecs, lnw, lnb, mix)
-        _view(p.out, n, F, p.ld_out)[...] = p.scale * sum(hd["alpha"][:, c:c + 1] * H[c] for c in range(k))
+        _view(p.out, n, F, p.ld_out)[...] = _post_fwd(p, p.scale * sum(hd["alpha"][:, c:c + 1] * H[c] for c in range(k)), n, F)
         _view(p.pre, n, (k - 1) * F, p.ld_pre)[...] = np.concatenate(pre, 1)
         att = _view(p.att, n, 4, 4)
         att[...] = 0
@@ -240,6 +256,7 @@ class FakeLib:
         vecs, lnw, lnb, mix = self._params(q, k, F, q.layernorm)
         hd = _head(H, k, q.layernorm, vecs, lnw, lnb, mix)
         dO = _view(q.grad_out, n, F, q.ld_grad_out).astype(f64)
+        dO = _post_bwd(q, dO, q.scale * sum(hd["alpha"][:, c:c + 1] * H[c] for c in range(k)), n, F)
         dH, d_vec, d_lnw, d_lnb, d_mix = _head_backward(H, hd, dO, k, q.layernorm, vecs, lnw, mix, q.scale)
         G = [np.where(m, d, 0.0) for d, m in zip(dH, pos)]
         _view(q.g_low, n, F, q.ld_g_low)[...] = G[0]
@@ -290,7 +307,7 @@ class FakeLib:
         H = [np.maximum(r, 0) if f else r for r, f in zip(raw, relu)]
         vecs, lnw, lnb, mix = self._params(p, 3, F, p.layernorm)
         hd = _head(H, 3, p.layernorm, vecs, lnw, lnb, mix)
-        _view(p.out, n, F, p.ld_out)[...] = p.scale * sum(hd["alpha"][:, c:c + 1] * H[c] for c in range(3))
+        _view(p.out, n, F, p.ld_out)[...] = _post_fwd(p, p.scale * sum(hd["alpha"][:, c:c + 1] * H[c] for c in range(3)), n, F)
         agg = _view(p.agg, n, fp, p.ld_agg)
         agg[...] = 0
         agg[:, :fi] = P
@@ -311,6 +328,7 @@ class FakeLib:
         vecs, lnw, lnb, mix = self._params(q, 3, F, q.layernorm)
         hd = _head(H, 3, q.layernorm, vecs, lnw, lnb, mix)
         dO = _view(q.grad_out, n, F, q.ld_grad_out).astype(np.float64)
+        dO = _post_bwd(q, dO, q.scale * sum(hd["alpha"][:, c:c + 1] * H[c] for c in range(3)), n, F)
         dH, d_vec, d_lnw, d_lnb, d_mix = _head_backward(H, hd, dO, 3, q.layernorm, vecs, lnw, mix, q.scale)
         G = [np.where(m, d, 0.0) for d, m in zip(dH, pos)]
         npg = 3 * fi * F + 9 * F + 9
