@@ -646,6 +646,113 @@ __global__ __launch_bounds__(256) void conv_bwd_local_kernel(acm_conv_bwd_local_
         partial[(long)blockIdx.x * npg + q] = (lds[q] + lds[npg + q]) + (lds[2 * npg + q] + lds[3 * npg + q]);
 }
 
+// K3 for 16 < F <= 64: four rows per wave (16 lanes x 4 columns), head parameters in LDS, two passes per
+// row (scalars, then one channel at a time).  Same partial-vector layout as conv_bwd_local_kernel, so the
+// same reduce kernel finishes the job.  (The one-row-per-wave version spent 270-370 us here on the
+// twitch-sized graph: every lane recomputed the row scalars and the compiler parked the loop-invariant
+// parameter loads in ~36 VGPRs.)
+template <int K>
+__global__ __launch_bounds__(256) void conv_bwd_local_grouped_kernel(acm_conv_bwd_local_t p, int n_rows,
+                                                                     float* __restrict__ partial) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, m = lane & 15, g = lane >> 4;
+    const int F = p.f_out;
+    const int npg = 3 * K * F + K * K;
+    float* hlds = lds;                                   // 3 * K * 64 floats, dead after the row loop
+    stage_head_params<K>(hlds, p.att_vec, p.ln_weight, p.ln_bias, p.layernorm, F);
+    __syncthreads();
+    float dv[K][4], dgam[K][4], dbet[K][4], dmix[K * K], mixm[K * K];
+#pragma unroll
+    for (int c = 0; c < K; ++c)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) dv[c][i] = dgam[c][i] = dbet[c][i] = 0.f;
+#pragma unroll
+    for (int q = 0; q < K * K; ++q) {
+        dmix[q] = 0.f;
+        mixm[q] = p.att_mix[q];
+    }
+    const bool ln = p.layernorm != 0;
+    for (int r0 = (blockIdx.x * 4 + wv) * 4; r0 < n_rows; r0 += gridDim.x * 16) {
+        const int row = r0 + g;
+        const bool active = row < n_rows;
+        const long rr = active ? row : 0;
+        // 32-bit element offsets from the (uniform) base pointers: one VGPR per array instead of a
+        // loop-carried 64-bit pointer per access (the host checks n_rows * ld < 2^31)
+        const unsigned urow = (unsigned)rr;
+        const int mm = acm_opaque(m);             // see acm_opaque(): keeps the LDS parameter reads in the loop
+        float H[K][4], dO[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int col = m + 16 * i;
+            const bool ok = active && col < F;
+            const unsigned cc = ok ? (unsigned)col : 0u;          // clamped: loads stay unconditional (no exec branches)
+            const unsigned o_pre = urow * (unsigned)p.ld_pre + cc;
+            const float p0 = p.pre[o_pre], p1 = p.pre[o_pre + F];
+            const float zi = p.s_mlp[urow * (unsigned)p.ld_s_mlp + cc];
+            const float go = p.grad_out[urow * (unsigned)p.ld_grad_out + cc];
+            H[0][i] = ok ? (p.relu_after ? fmaxf(p0, 0.f) : p0) : 0.f;
+            H[1][i] = ok ? (p.relu_after ? fmaxf(p1, 0.f) : p1) : 0.f;
+            H[2][i] = ok ? (p.relu_mlp ? fmaxf(zi, 0.f) : zi) : 0.f;
+            if (K == 4) H[K - 1][i] = ok ? fmaxf(p.pre[o_pre + 2 * F], 0.f) : 0.f;
+            dO[i] = ok ? go : 0.f;
+        }
+        RowHead<K> rh;
+        row_head<K>(hlds, mixm, mm, F, ln, H, rh);
+        row_post_backward<K>(p, rh, H, active, rr, m, F, dO);
+        float ds[K];
+        row_head_backward_scalars<K>(rh, mixm, p.scale, H, dO, ds, dmix);
+        const float dg = (K == 4 && active) ? p.deg[rr] : 0.f;
+#pragma unroll
+        for (int c = 0; c < K; ++c) {
+            const bool relu_c = (c < 2) ? (p.relu_after != 0) : (c == 2 ? p.relu_mlp != 0 : true);
+            float G[4];
+            row_channel_backward<K>(hlds, c, mm, F, ln, p.scale, rh, ds[c], H[c], dO, dv[c], dgam[c], dbet[c], G);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int col = m + 16 * i;
+                if (!(active && col < F)) continue;
+                const float gv = (!relu_c || H[c][i] > 0.f) ? G[i] : 0.f;
+                if (c == 0) p.g_low[urow * (unsigned)p.ld_g_low + col] = gv;
+                if (c == 1) p.g_high[urow * (unsigned)p.ld_g_high + col] = gv;
+                if (c == 2) p.g_mlp[urow * (unsigned)p.ld_g_mlp + col] = gv;
+                if (c == 3) p.g_struc[urow * (unsigned)p.ld_g_struc + col] = dg * gv;
+            }
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < K; ++c)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            dv[c][i] = acm_cross_row_sum(dv[c][i]);
+            dgam[c][i] = acm_cross_row_sum(dgam[c][i]);
+            dbet[c][i] = acm_cross_row_sum(dbet[c][i]);
+        }
+#pragma unroll
+    for (int q = 0; q < K * K; ++q) dmix[q] = acm_cross_row_sum(dmix[q]);
+    __syncthreads();
+    float* slab = lds + wv * npg;
+    if (g == 0) {
+#pragma unroll
+        for (int c = 0; c < K; ++c)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int col = m + 16 * i;
+                if (col < F) {
+                    slab[(0 * K + c) * F + col] = dv[c][i];
+                    slab[(1 * K + c) * F + col] = dgam[c][i];
+                    slab[(2 * K + c) * F + col] = dbet[c][i];
+                }
+            }
+    }
+    if (lane == 0) {
+#pragma unroll
+        for (int q = 0; q < K * K; ++q) slab[3 * K * F + q] = dmix[q];
+    }
+    __syncthreads();
+    for (int q = threadIdx.x; q < npg; q += 256)
+        partial[(long)blockIdx.x * npg + q] = (lds[q] + lds[npg + q]) + (lds[2 * npg + q] + lds[3 * npg + q]);
+}
+
 // grid = npg blocks; block q sums partial[0..nblk)[q] in a fixed tree order.
 __global__ __launch_bounds__(256) void conv_bwd_reduce_kernel(acm_conv_bwd_local_t p, int nblk,
                                                               const float* __restrict__ partial) {
@@ -680,7 +787,7 @@ int bwd_local_blocks(int64_t n_rows, int rows_per_block) {
     if (nb < 1) nb = 1;
     return (int)nb;
 }
-int bwd_rows_per_wave(int F) { return F > 32 ? 1 : (F > 16 ? 2 : (F > 8 ? 4 : (F > 4 ? 8 : (F > 2 ? 16 : 32)))); }
+int bwd_rows_per_wave(int F) { return F > 64 ? 1 : (F > 16 ? 4 : (F > 8 ? 4 : (F > 4 ? 8 : (F > 2 ? 16 : 32)))); }
 }  // namespace
 
 extern "C" int acm_conv_bwd_local_workspace_bytes(int64_t n_rows, int f_out, int n_channels, size_t* bytes) {
@@ -714,9 +821,24 @@ extern "C" int acm_conv_bwd_local(int64_t n_rows, const acm_conv_bwd_local_t* p,
     const int npg = 3 * k * F + k * k;
     const int rpw = bwd_rows_per_wave(F);
     const int nblk = bwd_local_blocks(n_rows, 4 * rpw);
-    const size_t lds = (size_t)4 * npg * sizeof(float);
+    size_t lds = (size_t)4 * npg * sizeof(float);
     hipStream_t st = (hipStream_t)stream;
     float* partial = (float*)workspace;
+    if (F > 16 && F <= 64) {                      // 4-rows-per-wave lean kernel
+        const int64_t max_ld = p->ld_pre > p->ld_grad_out ? p->ld_pre : p->ld_grad_out;
+        ACM_REQUIRE(n_rows * (max_ld > p->ld_g_mlp ? max_ld : p->ld_g_mlp) < (int64_t)INT32_MAX, ACM_EUNSUPPORTED,
+                    "acm_conv_bwd_local: rows x leading dimension exceeds 2^31");
+        const size_t hl = (size_t)3 * k * 64 * sizeof(float);
+        if (hl > lds) lds = hl;
+        if (k == 3)
+            hipLaunchKernelGGL((conv_bwd_local_grouped_kernel<3>), dim3(nblk), dim3(256), lds, st, *p, (int)n_rows, partial);
+        else
+            hipLaunchKernelGGL((conv_bwd_local_grouped_kernel<4>), dim3(nblk), dim3(256), lds, st, *p, (int)n_rows, partial);
+        ACM_CHECK_HIP(hipGetLastError());
+        hipLaunchKernelGGL(conv_bwd_reduce_kernel, dim3(npg), dim3(256), 0, st, *p, nblk, partial);
+        ACM_CHECK_HIP(hipGetLastError());
+        return ACM_OK;
+    }
 #define ACM_BWD(LAY, RPW)                                                                                   \
     do {                                                                                                    \
         if (k == 3)                                                                                         \
@@ -728,8 +850,6 @@ extern "C" int acm_conv_bwd_local(int64_t n_rows, const acm_conv_bwd_local_t* p,
     } while (0)
     if (F > 128) ACM_BWD(LayWide<4>, 1);
     else if (F > 64) ACM_BWD(LayWide<2>, 1);
-    else if (F > 32) ACM_BWD(LayWide<1>, 1);
-    else if (F > 16) ACM_BWD(LayPacked<32>, 2);
     else if (F > 8) ACM_BWD(LayPacked<16>, 4);
     else if (F > 4) ACM_BWD(LayPacked<8>, 8);
     else if (F > 2) ACM_BWD(LayPacked<4>, 16);

@@ -76,77 +76,6 @@ __device__ __forceinline__ void project(const float* wlds, float* scratch, int m
     }
 }
 
-// att_vec / LayerNorm gamma, beta staged in LDS as [array][c][m][i] (array 0 = att_vec, 1 = gamma,
-// 2 = beta; without LayerNorm gamma = 1, beta = 0): one ds_read_b128 per use, and -- unlike loads
-// from global memory -- nothing for the compiler to hoist out of the row loop into 36 VGPRs.
-__device__ __forceinline__ void stage_head_params(float* hlds, const float* const* att_vec,
-                                                  const float* const* ln_w, const float* const* ln_b, int layernorm,
-                                                  int F) {
-    for (int idx = threadIdx.x; idx < 9 * 64; idx += 256) {
-        const int arr = idx / 192, c = (idx / 64) % 3, m = (idx % 64) / 4, i = idx % 4;
-        const int col = m + 16 * i;
-        float v = (arr == 1) ? 1.f : 0.f;                  // gamma defaults to 1 (no LayerNorm)
-        if (col < F) {
-            if (arr == 0) v = att_vec[c][col];
-            else if (layernorm) v = (arr == 1) ? ln_w[c][col] : ln_b[c][col];
-        } else if (arr == 1) {
-            v = 0.f;
-        }
-        hlds[idx] = v;
-    }
-}
-
-
-// Pass 1 of a row: channel statistics and attention scalars from the activated channels H.
-struct RowHead {
-    float mean[3], rstd[3], gsig[3], alpha[3];
-};
-__device__ __forceinline__ void row_head(const float* hlds, const float* mixm, int m, int F, bool ln,
-                                         const float (&H)[3][4], RowHead& r) {
-    const float invF = 1.0f / (float)F;
-#pragma unroll
-    for (int c = 0; c < 3; ++c) {
-        const float4 v4 = *reinterpret_cast<const float4*>(hlds + ((0 * 3 + c) * 16 + m) * 4);
-        const float4 g4 = *reinterpret_cast<const float4*>(hlds + ((1 * 3 + c) * 16 + m) * 4);
-        const float4 b4 = *reinterpret_cast<const float4*>(hlds + ((2 * 3 + c) * 16 + m) * 4);
-        const float v[4] = {v4.x, v4.y, v4.z, v4.w}, gm[4] = {g4.x, g4.y, g4.z, g4.w}, bt[4] = {b4.x, b4.y, b4.z, b4.w};
-        float mu = 0.f, rs = 1.f;
-        if (ln) {
-            mu = acm_group_sum<16>((H[c][0] + H[c][1]) + (H[c][2] + H[c][3])) * invF;
-            float q = 0.f;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const float d = (m + 16 * i < F) ? H[c][i] - mu : 0.f;
-                q = fmaf(d, d, q);
-            }
-            rs = acm_rsqrt(acm_group_sum<16>(q) * invF + ACM_LN_EPS);
-        }
-        r.mean[c] = mu;
-        r.rstd[c] = rs;
-        float dot = 0.f;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const float hn = (m + 16 * i < F) ? fmaf((H[c][i] - mu) * rs, gm[i], bt[i]) : 0.f;
-            dot = fmaf(hn, v[i], dot);
-        }
-        r.gsig[c] = acm_rcp(1.0f + acm_exp(-acm_group_sum<16>(dot)));
-    }
-    float lg[3], mx = -INFINITY, den = 0.f;
-#pragma unroll
-    for (int j = 0; j < 3; ++j) {
-        lg[j] = (r.gsig[0] * mixm[j] + r.gsig[1] * mixm[3 + j] + r.gsig[2] * mixm[6 + j]) * (1.0f / 3.0f);
-        mx = fmaxf(mx, lg[j]);
-    }
-#pragma unroll
-    for (int j = 0; j < 3; ++j) {
-        lg[j] = acm_exp(lg[j] - mx);
-        den += lg[j];
-    }
-    const float inv = acm_rcp(den);
-#pragma unroll
-    for (int j = 0; j < 3; ++j) r.alpha[j] = lg[j] * inv;
-}
-
 // P (uniform in the 16-lane group) -> projections -> head -> out / att for one row.
 template <int FP>
 __device__ __forceinline__ void agg_fwd_row(const acm_conv_agg_fwd_t& p, const float* wlds, const float* hlds,
@@ -164,8 +93,8 @@ __device__ __forceinline__ void agg_fwd_row(const acm_conv_agg_fwd_t& p, const f
             H[2][i] = ok ? (p.relu_mlp ? fmaxf(zi[i], 0.f) : zi[i]) : 0.f;
         }
     }
-    RowHead rh;
-    row_head(hlds, mixm, m, F, p.layernorm != 0, H, rh);
+    RowHead<3> rh;
+    row_head<3>(hlds, mixm, acm_opaque(m), F, p.layernorm != 0, H, rh);
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int col = m + 16 * i;
@@ -190,7 +119,7 @@ __global__ __launch_bounds__(256) void agg_epilogue_kernel(acm_conv_agg_fwd_t p,
     float* hlds = wlds + 3 * FP * 64;
     float* scratch = hlds + 9 * 64 + (threadIdx.x >> 4) * 2 * FP;      // this 16-lane group's P | x
     stage_weights<FP>(wlds, p.w_low, p.w_high, p.w_mlp, p.ld_w, p.f_in, p.f_out);
-    stage_head_params(hlds, p.att_vec, p.ln_weight, p.ln_bias, p.layernorm, p.f_out);
+    stage_head_params<3>(hlds, p.att_vec, p.ln_weight, p.ln_bias, p.layernorm, p.f_out);
     __syncthreads();
     float mixm[9];
 #pragma unroll
@@ -224,7 +153,7 @@ __global__ __launch_bounds__(256, 2) void agg_bwd_kernel(acm_conv_agg_bwd_t p, i
     float* hlds = lds + 3 * FP * 64;             // 9 * 64 floats
     float* scratch = hlds + 9 * 64 + (threadIdx.x >> 4) * 2 * FP;   // per-group P | x; all dead after the row loop
     stage_weights<FP>(wlds, p.w_low, p.w_high, p.w_mlp, p.ld_w, f_in, F);
-    stage_head_params(hlds, p.att_vec, p.ln_weight, p.ln_bias, p.layernorm, F);
+    stage_head_params<3>(hlds, p.att_vec, p.ln_weight, p.ln_bias, p.layernorm, F);
     __syncthreads();
     f32x4 acc[3][4];
 #pragma unroll
@@ -241,7 +170,6 @@ __global__ __launch_bounds__(256, 2) void agg_bwd_kernel(acm_conv_agg_bwd_t p, i
     float mixm[9];
 #pragma unroll
     for (int q = 0; q < 9; ++q) mixm[q] = p.att_mix[q];
-    const float invF = 1.0f / (float)F;
     const bool ln = p.layernorm != 0;
 
     for (int r0 = (blockIdx.x * 4 + wv) * 4; r0 < n_rows; r0 += gridDim.x * 16) {
@@ -258,86 +186,26 @@ __global__ __launch_bounds__(256, 2) void agg_bwd_kernel(acm_conv_agg_bwd_t p, i
                 H[0][i] = ok ? (p.relu_after ? fmaxf(p0[i], 0.f) : p0[i]) : 0.f;
                 H[1][i] = ok ? (p.relu_after ? fmaxf(p1[i], 0.f) : p1[i]) : 0.f;
                 H[2][i] = ok ? (p.relu_mlp ? fmaxf(zi[i], 0.f) : zi[i]) : 0.f;
-                dO[i] = ok ? p.grad_out[rr * p.ld_grad_out + m + 16 * i] : 0.f;
+                const float go = p.grad_out[(unsigned)rr * (unsigned)p.ld_grad_out + (ok ? m + 16 * i : 0)];
+                dO[i] = ok ? go : 0.f;
             }
         }
         // ---- pass 1: per-channel statistics and the attention scalars
-        RowHead rh;
-        row_head(hlds, mixm, m, F, ln, H, rh);
-        const float (&mean)[3] = rh.mean;
-        const float (&rstd)[3] = rh.rstd;
-        const float (&gsig)[3] = rh.gsig;
-        const float (&alpha)[3] = rh.alpha;
-        if (p.post_relu || p.post_scale) {        // undo the forward's fused post-op on the incoming gradient
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const float raw = alpha[0] * H[0][i] + alpha[1] * H[1][i] + alpha[2] * H[2][i];
-                if (p.post_relu && !(raw * p.scale > 0.f)) dO[i] = 0.f;
-                if (p.post_scale && active && m + 16 * i < F) dO[i] *= p.post_scale[rr * p.ld_post_scale + m + 16 * i];
-            }
-        }
+        const int mm = acm_opaque(m);
+        RowHead<3> rh;
+        row_head<3>(hlds, mixm, mm, F, ln, H, rh);
+        row_post_backward<3>(p, rh, H, active, rr, m, F, dO);
         float ds[3];
-        {
-            float dal[3], dot = 0.f;
-#pragma unroll
-            for (int c = 0; c < 3; ++c) {
-                float part = 0.f;
-#pragma unroll
-                for (int i = 0; i < 4; ++i) part = fmaf(dO[i], H[c][i], part);
-                dal[c] = p.scale * acm_group_sum<16>(part);
-                dot = fmaf(alpha[c], dal[c], dot);
-            }
-            float dlg[3];
-#pragma unroll
-            for (int j = 0; j < 3; ++j) dlg[j] = alpha[j] * (dal[j] - dot);
-#pragma unroll
-            for (int c = 0; c < 3; ++c) {
-                float dg = 0.f;
-#pragma unroll
-                for (int j = 0; j < 3; ++j) {
-                    dg = fmaf(dlg[j], mixm[c * 3 + j], dg);
-                    dmix[c * 3 + j] = fmaf(gsig[c], dlg[j] * (1.0f / 3.0f), dmix[c * 3 + j]);   // inactive rows: dlg = 0
-                }
-                ds[c] = dg * (1.0f / 3.0f) * gsig[c] * (1.f - gsig[c]);
-            }
-        }
+        row_head_backward_scalars<3>(rh, mixm, p.scale, H, dO, ds, dmix);
         // ---- pass 2: one channel at a time -> G_c -> MFMA
         const float Pm = (m < FP) ? scratch[m] : 0.f;            // zero for inactive rows (project() stored zeros)
         const float xm = (m < FP) ? scratch[FP + m] : 0.f;
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
-            const float4 v4 = *reinterpret_cast<const float4*>(hlds + ((0 * 3 + c) * 16 + m) * 4);
-            const float4 g4 = *reinterpret_cast<const float4*>(hlds + ((1 * 3 + c) * 16 + m) * 4);
-            const float4 b4 = *reinterpret_cast<const float4*>(hlds + ((2 * 3 + c) * 16 + m) * 4);
-            const float v[4] = {v4.x, v4.y, v4.z, v4.w}, gm[4] = {g4.x, g4.y, g4.z, g4.w}, bt[4] = {b4.x, b4.y, b4.z, b4.w};
             const bool relu_c = (c < 2) ? (p.relu_after != 0) : (p.relu_mlp != 0);
             const float aop = (c == 0) ? Pm : (c == 1 ? xm - Pm : xm);
             float G[4];
-            if (ln) {
-                float xh[4], dxh[4], s1 = 0.f, s2 = 0.f;
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const bool ok = m + 16 * i < F;
-                    xh[i] = ok ? (H[c][i] - mean[c]) * rstd[c] : 0.f;
-                    const float dhn = ds[c] * v[i];
-                    dgam[c][i] = fmaf(dhn, xh[i], dgam[c][i]);
-                    dbet[c][i] += dhn;
-                    dv[c][i] = fmaf(ds[c], ok ? fmaf(xh[i], gm[i], bt[i]) : 0.f, dv[c][i]);
-                    dxh[i] = dhn * gm[i];
-                    s1 += dxh[i];
-                    s2 = fmaf(dxh[i], xh[i], s2);
-                }
-                const float m1 = acm_group_sum<16>(s1) * invF, m2 = acm_group_sum<16>(s2) * invF;
-#pragma unroll
-                for (int i = 0; i < 4; ++i)
-                    G[i] = fmaf(p.scale * alpha[c], dO[i], rstd[c] * (dxh[i] - m1 - xh[i] * m2));
-            } else {
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    dv[c][i] = fmaf(ds[c], H[c][i], dv[c][i]);
-                    G[i] = fmaf(p.scale * alpha[c], dO[i], ds[c] * v[i]);
-                }
-            }
+            row_channel_backward<3>(hlds, c, mm, F, ln, p.scale, rh, ds[c], H[c], dO, dv[c], dgam[c], dbet[c], G);
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
                 const bool keep = active && (m + 16 * t < F) && (!relu_c || H[c][t] > 0.f);

@@ -265,3 +265,184 @@ __device__ __forceinline__ void acm_head_backward(const L& lay, int F, int layer
         }
     }
 }
+
+// =====================================================================================
+// Lean row-local head for the 4-rows-per-wave layout (LayGrouped<4>: lane m of a 16-lane group owns
+// columns m, m+16, m+32, m+48; F <= 64).  Register discipline: the head parameters live in LDS,
+// pass 1 keeps only scalars, pass 2 handles one channel at a time.
+// =====================================================================================
+
+// att_vec / LayerNorm gamma, beta staged in LDS as [array][c][m][i] (array 0 = att_vec, 1 = gamma,
+// 2 = beta; without LayerNorm gamma = 1, beta = 0; zero beyond F): one ds_read_b128 per use, and --
+// unlike loads from global memory -- nothing for the compiler to hoist out of the row loop.
+template <int K>
+__device__ __forceinline__ void stage_head_params(float* hlds, const float* const* att_vec, const float* const* ln_w,
+                                                  const float* const* ln_b, int layernorm, int F) {
+    for (int idx = threadIdx.x; idx < 3 * K * 64; idx += 256) {
+        const int arr = idx / (K * 64), c = (idx / 64) % K, m = (idx % 64) / 4, i = idx % 4;
+        const int col = m + 16 * i;
+        float v = 0.f;
+        if (col < F) {
+            if (arr == 0) v = att_vec[c][col];
+            else if (layernorm) v = (arr == 1) ? ln_w[c][col] : ln_b[c][col];
+            else v = (arr == 1) ? 1.f : 0.f;
+        }
+        hlds[idx] = v;
+    }
+}
+
+// Make a loop-invariant lane index opaque to the optimiser.  The head parameters in LDS are indexed
+// by the lane only, so LICM hoists every ds_read_b128 of them out of the row loop and pins 36-48 VGPRs
+// for the whole kernel; re-reading 9-12 x 16 B from LDS per row is far cheaper than a lost wave.
+__device__ __forceinline__ int acm_opaque(int v) {
+    asm volatile("" : "+v"(v));
+    return v;
+}
+
+template <int K>
+struct RowHead {
+    float mean[K], rstd[K], gsig[K], alpha[K];
+};
+
+template <int K>
+struct HeadVecs {   // the lane's four columns of att_vec / gamma / beta of one channel
+    float v[4], gm[4], bt[4];
+    __device__ __forceinline__ void load(const float* hlds, int c, int m) {
+        const float4 a = *reinterpret_cast<const float4*>(hlds + ((0 * K + c) * 16 + m) * 4);
+        const float4 b = *reinterpret_cast<const float4*>(hlds + ((1 * K + c) * 16 + m) * 4);
+        const float4 d = *reinterpret_cast<const float4*>(hlds + ((2 * K + c) * 16 + m) * 4);
+        v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w;
+        gm[0] = b.x; gm[1] = b.y; gm[2] = b.z; gm[3] = b.w;
+        bt[0] = d.x; bt[1] = d.y; bt[2] = d.z; bt[3] = d.w;
+    }
+};
+
+// Pass 1: channel statistics and attention scalars from the activated channels H (mixm = K x K mix, SGPRs).
+template <int K>
+__device__ __forceinline__ void row_head(const float* hlds, const float* mixm, int m, int F, bool ln,
+                                         const float (&H)[K][4], RowHead<K>& r) {
+    const float invF = 1.0f / (float)F;
+#pragma unroll
+    for (int c = 0; c < K; ++c) {
+        HeadVecs<K> hv;
+        hv.load(hlds, c, m);
+        float mu = 0.f, rs = 1.f;
+        if (ln) {
+            mu = acm_group_sum<16>((H[c][0] + H[c][1]) + (H[c][2] + H[c][3])) * invF;
+            float q = 0.f;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float d = (m + 16 * i < F) ? H[c][i] - mu : 0.f;
+                q = fmaf(d, d, q);
+            }
+            rs = acm_rsqrt(acm_group_sum<16>(q) * invF + ACM_LN_EPS);
+        }
+        r.mean[c] = mu;
+        r.rstd[c] = rs;
+        float dot = 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float hn = (m + 16 * i < F) ? fmaf((H[c][i] - mu) * rs, hv.gm[i], hv.bt[i]) : 0.f;
+            dot = fmaf(hn, hv.v[i], dot);
+        }
+        r.gsig[c] = acm_rcp(1.0f + acm_exp(-acm_group_sum<16>(dot)));
+    }
+    float lg[K], mx = -INFINITY, den = 0.f;
+#pragma unroll
+    for (int j = 0; j < K; ++j) {
+        float a = 0.f;
+#pragma unroll
+        for (int c = 0; c < K; ++c) a = fmaf(r.gsig[c], mixm[c * K + j], a);
+        lg[j] = a * (1.0f / (float)K);
+        mx = fmaxf(mx, lg[j]);
+    }
+#pragma unroll
+    for (int j = 0; j < K; ++j) {
+        lg[j] = acm_exp(lg[j] - mx);
+        den += lg[j];
+    }
+    const float inv = acm_rcp(den);
+#pragma unroll
+    for (int j = 0; j < K; ++j) r.alpha[j] = lg[j] * inv;
+}
+
+// Undo the forward's fused post-op on the incoming gradient (raw = out before the post-op).
+template <int K, class P>
+__device__ __forceinline__ void row_post_backward(const P& p, const RowHead<K>& r, const float (&H)[K][4], bool active,
+                                                  long row, int m, int F, float (&dO)[4]) {
+    if (!(p.post_relu || p.post_scale)) return;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        float raw = 0.f;
+#pragma unroll
+        for (int c = 0; c < K; ++c) raw = fmaf(r.alpha[c], H[c][i], raw);
+        if (p.post_relu && !(raw * p.scale > 0.f)) dO[i] = 0.f;
+        if (p.post_scale && active && m + 16 * i < F) dO[i] *= p.post_scale[row * p.ld_post_scale + m + 16 * i];
+    }
+}
+
+// Backward through mix / softmax / sigmoid: ds[c] = dL/ds_c; accumulates d att_mix (K x K).
+template <int K>
+__device__ __forceinline__ void row_head_backward_scalars(const RowHead<K>& r, const float* mixm, float scale,
+                                                          const float (&H)[K][4], const float (&dO)[4],
+                                                          float (&ds)[K], float (&dmix)[K * K]) {
+    float dal[K], dot = 0.f;
+#pragma unroll
+    for (int c = 0; c < K; ++c) {
+        float part = 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) part = fmaf(dO[i], H[c][i], part);
+        dal[c] = scale * acm_group_sum<16>(part);
+        dot = fmaf(r.alpha[c], dal[c], dot);
+    }
+    float dlg[K];
+#pragma unroll
+    for (int j = 0; j < K; ++j) dlg[j] = r.alpha[j] * (dal[j] - dot);
+    const float invk = 1.0f / (float)K;
+#pragma unroll
+    for (int c = 0; c < K; ++c) {
+        float dg = 0.f;
+#pragma unroll
+        for (int j = 0; j < K; ++j) {
+            dg = fmaf(dlg[j], mixm[c * K + j], dg);
+            dmix[c * K + j] = fmaf(r.gsig[c], dlg[j] * invk, dmix[c * K + j]);   // rows with dO = 0 add 0
+        }
+        ds[c] = dg * invk * r.gsig[c] * (1.f - r.gsig[c]);
+    }
+}
+
+// Pass 2 for one channel: G = dL/dH_c (before the ReLU mask), accumulating d att_vec / d gamma / d beta.
+template <int K>
+__device__ __forceinline__ void row_channel_backward(const float* hlds, int c, int m, int F, bool ln, float scale,
+                                                     const RowHead<K>& r, float ds_c, const float (&Hc)[4],
+                                                     const float (&dO)[4], float (&dv)[4], float (&dgam)[4],
+                                                     float (&dbet)[4], float (&G)[4]) {
+    HeadVecs<K> hv;
+    hv.load(hlds, c, m);
+    if (ln) {
+        const float invF = 1.0f / (float)F;
+        float xh[4], dxh[4], s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const bool ok = m + 16 * i < F;
+            xh[i] = ok ? (Hc[i] - r.mean[c]) * r.rstd[c] : 0.f;
+            const float dhn = ds_c * hv.v[i];
+            dgam[i] = fmaf(dhn, xh[i], dgam[i]);
+            dbet[i] += dhn;
+            dv[i] = fmaf(ds_c, ok ? fmaf(xh[i], hv.gm[i], hv.bt[i]) : 0.f, dv[i]);
+            dxh[i] = dhn * hv.gm[i];
+            s1 += dxh[i];
+            s2 = fmaf(dxh[i], xh[i], s2);
+        }
+        const float m1 = acm_group_sum<16>(s1) * invF, m2 = acm_group_sum<16>(s2) * invF;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            G[i] = fmaf(scale * r.alpha[c], dO[i], r.rstd[c] * (dxh[i] - m1 - xh[i] * m2));
+    } else {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            dv[i] = fmaf(ds_c, Hc[i], dv[i]);
+            G[i] = fmaf(scale * r.alpha[c], dO[i], ds_c * hv.v[i]);
+        }
+    }
+}
