@@ -49,6 +49,7 @@ struct acm_csr {
     int32_t* indptr;   // device, n_rows + 1
     int32_t* indices;  // device, nnz
     float* vals;       // device, nnz
+    int32_t* src_pos;  // device, nnz (transposed handles only): index into the source's vals
     AcmItem* items;    // device
     int64_t n_items;
     AcmLongRow* long_rows;  // device

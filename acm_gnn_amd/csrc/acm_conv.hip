@@ -32,6 +32,7 @@ struct EpiPlain {
     struct Args {
         float* y;
         long ldy;
+        int relu;
     };
     template <class L, int NG>
     static __device__ __forceinline__ void apply(const Args& a, int row, const L& lay, int F,
@@ -40,7 +41,7 @@ struct EpiPlain {
 #pragma unroll
         for (int i = 0; i < L::NV; ++i) {
             const int col = lay.col(i);
-            if (col < F) a.y[(long)row * a.ldy + col] = acc[0][i];
+            if (col < F) a.y[(long)row * a.ldy + col] = a.relu ? fmaxf(acc[0][i], 0.f) : acc[0][i];
         }
     }
 };
@@ -380,12 +381,14 @@ namespace {
 
 template <int NG, class Epi>
 int launch_gather(const acm_csr* a, const GatherSrc& g, int F, const typename Epi::Args& ea,
-                  void* workspace, size_t ws_bytes, hipStream_t st, const char* who) {
+                  void* workspace, size_t ws_bytes, hipStream_t st, const char* who,
+                  const float* vals_override = nullptr) {
     const size_t need = (size_t)a->n_slots * (size_t)(NG * F) * sizeof(float);
     ACM_REQUIRE(ws_bytes >= need && (need == 0 || workspace), ACM_ENOMEM,
                 "%s: workspace %zu B < required %zu B", who, ws_bytes, need);
     float* partial = (float*)workspace;
-    const CsrView v = acm_view(a);
+    CsrView v = acm_view(a);
+    if (vals_override) v.vals = vals_override;
     if (a->n_items == 0) return ACM_OK;
     if (F <= 8) {
         int vecmask = 0;
@@ -456,20 +459,25 @@ int launch_gather(const acm_csr* a, const GatherSrc& g, int F, const typename Ep
 
 }  // namespace
 
-extern "C" int acm_spmm(const acm_csr_t* a, const float* G, int64_t ldg, int width, float* Y,
-                        int64_t ldy, void* workspace, size_t workspace_bytes, acm_stream_t stream) {
+extern "C" int acm_spmm_v(const acm_csr_t* a, const float* vals, const float* G, int64_t ldg, int width, float* Y,
+                          int64_t ldy, int relu, void* workspace, size_t workspace_bytes, acm_stream_t stream) {
     ACM_REQUIRE(a && G && Y, ACM_EINVAL, "acm_spmm: NULL argument");
     ACM_REQUIRE(width > 0 && ldg >= width && ldy >= width, ACM_ESHAPE,
                 "acm_spmm: width %d ldg %lld ldy %lld", width, (long long)ldg, (long long)ldy);
     for (int c0 = 0; c0 < width; c0 += 256) {  // column blocks of <= 256
         const int wd = width - c0 < 256 ? width - c0 : 256;
         GatherSrc g = {{G + c0, nullptr, nullptr}, {ldg, 0, 0}};
-        EpiPlain::Args ea = {Y + c0, ldy};
+        EpiPlain::Args ea = {Y + c0, ldy, relu};
         int st = launch_gather<1, EpiPlain>(a, g, wd, ea, workspace, workspace_bytes,
-                                            (hipStream_t)stream, "acm_spmm");
+                                            (hipStream_t)stream, "acm_spmm", vals);
         if (st != ACM_OK) return st;
     }
     return ACM_OK;
+}
+
+extern "C" int acm_spmm(const acm_csr_t* a, const float* G, int64_t ldg, int width, float* Y,
+                        int64_t ldy, void* workspace, size_t workspace_bytes, acm_stream_t stream) {
+    return acm_spmm_v(a, nullptr, G, ldg, width, Y, ldy, 0, workspace, workspace_bytes, stream);
 }
 
 extern "C" int acm_conv_fwd(const acm_csr_t* a, const acm_conv_fwd_t* p, void* workspace,

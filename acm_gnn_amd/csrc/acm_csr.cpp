@@ -29,6 +29,7 @@ void free_handle(acm_csr* a) {
     if (a->indptr) (void)hipFree(a->indptr);
     if (a->indices) (void)hipFree(a->indices);
     if (a->vals) (void)hipFree(a->vals);
+    if (a->src_pos) (void)hipFree(a->src_pos);
     if (a->items) (void)hipFree(a->items);
     if (a->long_rows) (void)hipFree(a->long_rows);
     delete a;
@@ -176,7 +177,7 @@ extern "C" int acm_csr_transpose(const acm_csr_t* a, int chunk, acm_csr_t** out)
         ACM_CHECK_HIP(hipMemcpy(v.data(), a->vals, (size_t)nnz * sizeof(float), hipMemcpyDeviceToHost));
     }
     // stable counting sort by column: rows of A^T come out sorted by original row id
-    std::vector<int32_t> tp((size_t)m + 1, 0), tx((size_t)nnz);
+    std::vector<int32_t> tp((size_t)m + 1, 0), tx((size_t)nnz), tpos((size_t)nnz);
     std::vector<float> tv((size_t)nnz);
     for (int64_t k = 0; k < nnz; ++k) ++tp[(size_t)ix[k] + 1];
     for (int64_t c = 0; c < m; ++c) tp[c + 1] += tp[c];
@@ -186,6 +187,7 @@ extern "C" int acm_csr_transpose(const acm_csr_t* a, int chunk, acm_csr_t** out)
             const int32_t pos = cur[ix[k]]++;
             tx[pos] = (int32_t)r;
             tv[pos] = v[k];
+            tpos[pos] = k;
         }
     acm_csr* t = new_handle(m, n, nnz);
     ACM_REQUIRE(t, ACM_ENOMEM, "acm_csr_transpose: host allocation failed");
@@ -196,6 +198,9 @@ extern "C" int acm_csr_transpose(const acm_csr_t* a, int chunk, acm_csr_t** out)
             e = hipMemcpy(t->indices, tx.data(), (size_t)nnz * sizeof(int32_t), hipMemcpyHostToDevice);
         if (e == hipSuccess && nnz)
             e = hipMemcpy(t->vals, tv.data(), (size_t)nnz * sizeof(float), hipMemcpyHostToDevice);
+        if (e == hipSuccess) e = hipMalloc((void**)&t->src_pos, (size_t)(nnz > 0 ? nnz : 1) * sizeof(int32_t));
+        if (e == hipSuccess && nnz)
+            e = hipMemcpy(t->src_pos, tpos.data(), (size_t)nnz * sizeof(int32_t), hipMemcpyHostToDevice);
         if (e != hipSuccess) {
             acm_set_error("acm_csr_transpose: upload failed: %s", hipGetErrorString(e));
             st = ACM_EHIP;
@@ -263,6 +268,7 @@ extern "C" int acm_csr_info(const acm_csr_t* a, acm_csr_info_t* info) {
     info->indptr = a->indptr;
     info->indices = a->indices;
     info->vals = a->vals;
+    info->src_pos = a->src_pos;
     return ACM_OK;
 }
 

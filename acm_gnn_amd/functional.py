@@ -11,7 +11,7 @@ import os
 import torch
 
 from . import _lib
-from .graph import CsrGraph, FilterOperators, _device_ctx, _require_cuda, _stream
+from .graph import CsrGraph, FilterOperators, SparseFeatures, _device_ctx, _require_cuda, _stream
 
 _F32 = torch.float32
 
@@ -109,6 +109,25 @@ def spmm(graph, dense, out=None):
         st = _lib.load().acm_spmm(graph.handle, _vp(dense), dense.stride(0), width, _vp(out), out.stride(0),
                                   _vp(ws), ws.numel() * 4, _stream())
     _lib.check(st, "acm_spmm")
+    return out
+
+
+def spmm_v(graph, vals, dense, relu=False, out=None):
+    """out = A(vals) @ dense: the operator's structure with per-call values (acm_spmm_v)."""
+    dense = _as_f32c(dense, "dense")
+    vals = _as_f32c(vals, "vals")
+    if dense.shape[0] != graph.n_cols or vals.numel() != graph.nnz:
+        raise ValueError("spmm_v: shape mismatch")
+    width = dense.shape[1]
+    if out is None:
+        out = torch.empty(graph.n_rows, width, dtype=_F32, device=dense.device)
+    if width == 0 or graph.n_rows == 0:
+        return out
+    ws = graph.workspace(min(width, 256))
+    with _device_ctx(dense.device), _Timed(f"spmm_v/{graph.n_rows}x{graph.n_cols}W{width}"):
+        st = _lib.load().acm_spmm_v(graph.handle, _vp(vals), _vp(dense), dense.stride(0), width, _vp(out),
+                                    out.stride(0), int(relu), _vp(ws), ws.numel() * 4, _stream())
+    _lib.check(st, "acm_spmm_v")
     return out
 
 
@@ -226,7 +245,9 @@ class AcmConvFunction(torch.autograd.Function):
                 lnw_low, lnw_high, lnw_mlp, lnw_struc, lnb_low, lnb_high, lnb_mlp, lnb_struc, ops, cfg,
                 post_relu=False, post_scale=None):
         lib = _lib.load()
-        x = _as_f32c(x, "input")
+        sparse_x = isinstance(x, SparseFeatures)
+        if not sparse_x:
+            x = _as_f32c(x, "input")
         dev = x.device
         n, f = x.shape[0], w_low.shape[1]
         k = cfg.n_channels
@@ -245,7 +266,7 @@ class AcmConvFunction(torch.autograd.Function):
         f_in = x.shape[1]
         # Aggregate-first (A (X W) = (A X) W): legal without a ReLU between projection and
         # filter, worth it when F_in < F, and free of any backward SpMM when x needs no gradient.
-        ctx.agg_first = (k == 3 and not cfg.relu_before and f_in <= 16 and f_in < f and f <= 64
+        ctx.agg_first = (k == 3 and not cfg.relu_before and f_in <= 16 and f_in < f and f <= 64 and not sparse_x
                          and not ctx.needs_input_grad[0] and os.environ.get("ACM_AGG_FIRST", "1") != "0")
         four = k == 4
         if ctx.agg_first:
@@ -261,7 +282,10 @@ class AcmConvFunction(torch.autograd.Function):
             if f in (2, 4, 8):
                 ldz = -(-3 * f // (2 * f)) * (2 * f)
             z = torch.empty(n, ldz, dtype=_F32, device=dev)[:, : 3 * f]
-            gemm(x, wcat, relu=cfg.relu_before, out=z)                              # [n, 3F] view
+            if sparse_x:                                  # Z = X_csr Wcat: nnz(X) * 3F FMAs
+                spmm_v(x.csr, x.values, wcat, relu=cfg.relu_before, out=z)
+            else:
+                gemm(x, wcat, relu=cfg.relu_before, out=z)                          # [n, 3F] view
             zg = _gather_rows(ops, z[:, : 2 * f]) if ops.sharded else z             # gathered [Z_L|Z_H]
         if four:
             if ops.deg is None:
@@ -326,7 +350,8 @@ class AcmConvFunction(torch.autograd.Function):
             st = lib.acm_conv_fwd(ops.low.handle, C.byref(p), _vp(ws), ws.numel() * 4, _stream())
         _lib.check(st, "acm_conv_fwd")
         ctx.ops, ctx.cfg = ops, cfg
-        ctx.save_for_backward(x, wcat, z, pre, mix, *vecs, *lnw, *lnb)
+        ctx.sparse_x = x if sparse_x else None
+        ctx.save_for_backward(wcat if sparse_x else x, wcat, z, pre, mix, *vecs, *lnw, *lnb)
         ctx.mark_non_differentiable(att)
         return out, att
 
@@ -342,8 +367,8 @@ class AcmConvFunction(torch.autograd.Function):
         vecs = list(saved[5:5 + k])
         lnw = list(saved[5 + k:5 + 2 * k]) if cfg.layernorm else []
         lnb = list(saved[5 + 2 * k:5 + 3 * k]) if cfg.layernorm else []
-        dev = x.device
-        n, f = x.shape[0], wcat.shape[1] // 3
+        dev = z.device
+        n, f = z.shape[0], wcat.shape[1] // 3
         grad_out = _as_f32c(grad_out, "grad_out")
         four = k == 4
 
@@ -405,8 +430,14 @@ class AcmConvFunction(torch.autograd.Function):
             st = lib.acm_conv_bwd_spmm(low_t.handle, C.byref(r), _vp(ws2), ws2.numel() * 4, _stream())
         _lib.check(st, "acm_conv_bwd_spmm")
 
-        d_wcat = gemm(x, dz, trans_a=True)                                   # [F_in, 3F]
-        d_x = gemm(dz, wcat, trans_b=True) if ctx.needs_input_grad[0] else None
+        if ctx.sparse_x is not None:                                          # dWcat = X_csr^T dZ
+            xs = ctx.sparse_x
+            xt = xs.csr_t
+            d_wcat = spmm_v(xt, xs.values.index_select(0, xt.src_pos), dz)
+            d_x = None
+        else:
+            d_wcat = gemm(x, dz, trans_a=True)                               # [F_in, 3F]
+            d_x = gemm(dz, wcat, trans_b=True) if ctx.needs_input_grad[0] else None
         small = [d_wcat, d_mix] + d_vec + d_lnw + d_lnb
         if ops.sharded:                             # replicated parameters: sum the row-shard partials
             import torch.distributed as dist

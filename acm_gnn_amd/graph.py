@@ -31,6 +31,15 @@ def _sync(dev):
     torch.cuda.synchronize(dev)
 
 
+def _copy_from_ptr(ptr, n, dtype, device):
+    """New torch tensor holding n elements copied from a raw device pointer owned by a handle."""
+    t = torch.empty(n, dtype=dtype, device=device)
+    if n:
+        C.cdll.LoadLibrary("libamdhip64.so").hipMemcpy(
+            C.c_void_p(t.data_ptr()), C.c_void_p(ptr), C.c_size_t(n * t.element_size()), 3)   # device-to-device
+    return t
+
+
 def _require_cuda(t, name):
     if not t.is_cuda:
         raise RuntimeError(
@@ -50,6 +59,8 @@ class CsrGraph:
         self.n_items, self.n_long_rows = info.n_items, info.n_long_rows
         self.n_partial_slots, self.chunk, self.max_degree = info.n_partial_slots, info.chunk, info.max_degree
         self._ptrs = (info.indptr, info.indices, info.vals)
+        self._src_pos_ptr = info.src_pos
+        self._src_pos = None
         self._transposed = None
         self._finalizer = weakref.finalize(self, _lib.load().acm_csr_destroy, C.c_void_p(handle))
 
@@ -119,16 +130,20 @@ class CsrGraph:
     # ---- views (tests, sharding) -----------------------------------------
     def arrays(self):
         """(indptr, indices, vals) copied out to new torch tensors."""
-        def pull(ptr, n, dtype):
-            t = torch.empty(n, dtype=dtype, device=self.device)
-            if n:
-                C.cdll.LoadLibrary("libamdhip64.so").hipMemcpy(
-                    C.c_void_p(t.data_ptr()), C.c_void_p(ptr), C.c_size_t(n * t.element_size()), 3)
-            return t
         _sync(self.device)
-        return (pull(self._ptrs[0], self.n_rows + 1, torch.int32),
-                pull(self._ptrs[1], self.nnz, torch.int32),
-                pull(self._ptrs[2], self.nnz, torch.float32))
+        return (_copy_from_ptr(self._ptrs[0], self.n_rows + 1, torch.int32, self.device),
+                _copy_from_ptr(self._ptrs[1], self.nnz, torch.int32, self.device),
+                _copy_from_ptr(self._ptrs[2], self.nnz, torch.float32, self.device))
+
+    @property
+    def src_pos(self):
+        """For a transposed handle: int64 index tensor with vals_T = vals_source[src_pos]."""
+        if self._src_pos is None:
+            if not self._src_pos_ptr:
+                raise RuntimeError("src_pos exists only on handles made by transpose()")
+            _sync(self.device)
+            self._src_pos = _copy_from_ptr(self._src_pos_ptr, self.nnz, torch.int32, self.device).to(torch.int64)
+        return self._src_pos
 
     def workspace(self, width):
         nbytes = C.c_size_t()
@@ -144,6 +159,40 @@ class CsrGraph:
     def __repr__(self):
         return (f"CsrGraph({self.n_rows}x{self.n_cols}, nnz={self.nnz}, items={self.n_items}, "
                 f"long_rows={self.n_long_rows}, max_degree={self.max_degree})")
+
+
+class SparseFeatures:
+    """Node features X (n x F_in) as CSR for the wide, sparse inputs (bag-of-words, one-hot): the
+    structure lives in a CsrGraph handle (and its transpose, for dW = X^T dZ), the values in a separate
+    tensor so that input dropout can rescale them every step without touching the handle.
+    The projection then costs nnz(X) * 3F FMAs instead of N * F_in * 3F."""
+
+    def __init__(self, csr, values):
+        self.csr, self.values = csr, values
+        self.shape = (csr.n_rows, csr.n_cols)
+        self.device = csr.device
+
+    @classmethod
+    def from_scipy(cls, mat, device):
+        m = mat.tocsr()
+        m.sort_indices()
+        csr = CsrGraph.from_scipy(m, device)
+        return cls(csr, torch.from_numpy(m.data.astype("float32")).to(torch.device(device)))
+
+    @classmethod
+    def from_torch(cls, x):
+        """Dense or torch-sparse feature matrix -> SparseFeatures (exact zeros are dropped)."""
+        csr = CsrGraph.from_torch(x if x.layout != torch.strided else x.to_sparse())
+        return cls(csr, csr.arrays()[2])
+
+    def with_values(self, values):
+        if values.shape != self.values.shape:
+            raise ValueError("values must keep the CSR order and length")
+        return SparseFeatures(self.csr, values)
+
+    @property
+    def csr_t(self):
+        return self.csr.transpose()
 
 
 class FilterOperators:

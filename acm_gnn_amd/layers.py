@@ -22,7 +22,7 @@ import torch.nn as nn
 from torch.nn.parameter import Parameter
 
 from . import functional as AF
-from .graph import FilterOperators, operators_for
+from .graph import FilterOperators, SparseFeatures, operators_for
 
 DEFAULT_ATTN_LAYERNORM = True
 _PLUS_LITERAL = ("acmgcn+", "acmgcn++")          # spellings for which ACM-Pytorch's LN fires
@@ -102,6 +102,8 @@ class GraphConvolution(nn.Module):
                 raise RuntimeError("model_type 'sgc'/'gcn' multiplies with torch.mm: adj_low must be dense")
             return AF.mm(adj_low, AF.mm(input, self.weight_low))
         cfg = self._config()
+        if isinstance(input, torch.Tensor) and input.layout != torch.strided:
+            input = SparseFeatures.from_torch(input)          # torch-sparse features: CSR projection
         if isinstance(adj_low, FilterOperators):
             ops = adj_low
         else:

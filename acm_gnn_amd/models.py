@@ -15,6 +15,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from .graph import SparseFeatures
 from .layers import GraphConvolution, MLP
 
 _TWO_LAYER = ("acmgcn", "acmgcnp", "acmgcnpp")
@@ -59,7 +60,13 @@ class GCN(nn.Module):
 
     def forward(self, x, adj_low, adj_high=None, adj_low_unnormalized=None):
         drop = lambda t: F.dropout(t, self.dropout, training=self.training)  # noqa: E731
-        x = drop(x)
+        if isinstance(x, SparseFeatures):
+            # dropout of a sparse matrix = dropout of its stored values (zeros stay zero either way)
+            if self.model_type == "acmgcnpp":
+                raise NotImplementedError("acmgcnpp's dense residual branch needs dense features")
+            x = x.with_values(drop(x.values))
+        else:
+            x = drop(x)
         if self.model_type == "acmsgc":
             return self.gcns[0](x, adj_low, adj_high, adj_low_unnormalized)
         if self.model_type == "acmgcnpp":

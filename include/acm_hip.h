@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define ACM_ABI_VERSION 2
+#define ACM_ABI_VERSION 3
 
 typedef enum {
     ACM_OK = 0,
@@ -81,6 +81,8 @@ typedef struct {
     const int32_t* indptr;    /* device pointers owned by the handle      */
     const int32_t* indices;
     const float* vals;
+    const int32_t* src_pos;   /* handles made by acm_csr_transpose: position of each entry in the source
+                                 operator's value array (vals_T[k] = vals[src_pos[k]]); NULL otherwise */
 } acm_csr_info_t;
 int acm_csr_info(const acm_csr_t* a, acm_csr_info_t* info);
 
@@ -110,6 +112,18 @@ int acm_gemm(int transA, int transB, int64_t M, int64_t N, int64_t K,
 int acm_spmm(const acm_csr_t* a, const float* G, int64_t ldg, int width,
              float* Y, int64_t ldy, void* workspace, size_t workspace_bytes,
              acm_stream_t stream);
+
+/* Same product with the operator's values replaced by `vals` (device, nnz floats in the handle's
+ * CSR order; NULL = the handle's own) and an optional ReLU on the result.  This is the
+ * sparse-feature projection Z = X_csr [W_L|W_H|W_I] of the wide bag-of-words / one-hot inputs
+ * (the reference multiplies the dense N x F_in matrix: ACM-Pytorch/utils.py:298,373-383,
+ * ACM-Geometric/dataset.py:135-143), with X's *structure* in the handle and its values -- which
+ * change every step under input dropout (models.py:54) -- passed per call; dWcat = X^T dZ is the
+ * same call on acm_csr_transpose(X) with vals permuted by src_pos.
+ */
+int acm_spmm_v(const acm_csr_t* a, const float* vals, const float* G, int64_t ldg, int width,
+               float* Y, int64_t ldy, int relu, void* workspace, size_t workspace_bytes,
+               acm_stream_t stream);
 
 /* ---------------------------------------------------- fused ACM layer (K2) --
  * One pass over A_low computes every graph channel and the adaptive mixing:

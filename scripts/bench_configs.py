@@ -39,6 +39,10 @@ CONFIGS = {
     "twitch/acmiigcnp": dict(graph="syn:twitch-gamer", method="acmgcnp", s=0, variant=1, dropout=0.1),
     "arxiv-year/acmgcnp": dict(graph="syn:arxiv-year", method="acmgcnp", s=0, variant=0, dropout=0.1),
     "penn94/acmgcnp": dict(graph="syn:penn94", method="acmgcnp", s=0, variant=0, dropout=0.1),
+    # the same wide-feature configs with CSR features (sparse-feature projection)
+    "cora/acmgcn/csrX": dict(graph="cora", f_in=1433, classes=7, method="acmgcn", s=0, variant=0, dropout=0.6, sparse=1),
+    "squirrel/acmgcnp+A/csrX": dict(graph="squirrel", f_in=2089, classes=5, method="acmgcnp", s=1, variant=0, dropout=0.6, sparse=1),
+    "penn94/acmgcnp/csrX": dict(graph="syn:penn94", method="acmgcnp", s=0, variant=0, dropout=0.1, sparse=1),
 }
 
 
@@ -61,6 +65,8 @@ def run(name, cfg, steps=20):
     low, deg = D.build_filters(adj)
     ops = DD.make_sharded_operators(low, deg, DEV, with_structure=bool(cfg["s"]))
     x, y = torch.from_numpy(x_np).to(DEV), torch.from_numpy(y_np.astype(np.int64)).to(DEV)
+    if cfg.get("sparse"):
+        x = acm_gnn_amd.SparseFeatures.from_scipy(sp.csr_matrix(x_np), DEV)
     torch.manual_seed(0)
     model = acm_gnn_amd.GCN(f_in, 64, classes, 2, n, cfg["dropout"], cfg["method"], cfg["s"],
                             variant=bool(cfg["variant"]), attn_layernorm=True).to(DEV)

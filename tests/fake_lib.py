@@ -110,7 +110,7 @@ class FakeLib:
 
     # ---- plumbing ---------------------------------------------------------
     def acm_version(self):
-        return 2
+        return 3
 
     def acm_last_error(self):
         return self._err
@@ -139,8 +139,13 @@ class FakeLib:
         a = self._get(h)
         m = sp.csr_matrix((a.vals, a.indices, a.indptr), shape=(a.n_rows, a.n_cols)).T.tocsr()
         m.sort_indices()
-        return self._new(_Csr(m.indptr.astype(np.int32), m.indices.astype(np.int32), m.data.astype(np.float32),
-                              a.n_rows, chunk or a.chunk), out)
+        t = _Csr(m.indptr.astype(np.int32), m.indices.astype(np.int32), m.data.astype(np.float32),
+                 a.n_rows, chunk or a.chunk)
+        pos = sp.csr_matrix((np.arange(1, len(a.vals) + 1, dtype=np.float64), a.indices, a.indptr),
+                            shape=(a.n_rows, a.n_cols)).T.tocsr()
+        pos.sort_indices()
+        t.src_pos = (pos.data - 1).astype(np.int32)
+        return self._new(t, out)
 
     def acm_csr_slice_rows(self, h, b, e, chunk, out):
         a = self._get(h)
@@ -161,6 +166,8 @@ class FakeLib:
         i.n_items = a.n_rows - len(longs) + i.n_partial_slots
         i.chunk, i.max_degree = a.chunk, int(deg.max()) if len(deg) else 0
         i.indptr, i.indices, i.vals = a.indptr.ctypes.data, a.indices.ctypes.data, a.vals.ctypes.data
+        sp_ = getattr(a, "src_pos", None)
+        i.src_pos = sp_.ctypes.data if sp_ is not None else None
         return 0
 
     def acm_spmm_workspace_bytes(self, h, width, out):
@@ -208,8 +215,15 @@ class FakeLib:
         return 0
 
     def acm_spmm(self, h, g, ldg, width, y, ldy, ws, wsb, stream):
+        return self.acm_spmm_v(h, None, g, ldg, width, y, ldy, 0, ws, wsb, stream)
+
+    def acm_spmm_v(self, h, vals, g, ldg, width, y, ldy, relu, ws, wsb, stream):
+        import scipy.sparse as sp
         a = self._get(h)
-        _view(y, a.n_rows, width, ldy)[...] = a.dense_mul(_view(g, a.n_cols, width, ldg))
+        v = _vec(vals, len(a.vals)).astype(np.float64) if vals else a.vals.astype(np.float64)
+        m = sp.csr_matrix((v, a.indices, a.indptr), shape=(a.n_rows, a.n_cols))
+        out = m @ _view(g, a.n_cols, width, ldg).astype(np.float64)
+        _view(y, a.n_rows, width, ldy)[...] = np.maximum(out, 0) if relu else out
         return 0
 
     @staticmethod
@@ -359,6 +373,13 @@ def install(monkeypatch):
     monkeypatch.setattr(functional, "_device_ctx", lambda dev: contextlib.nullcontext())
     monkeypatch.setattr(graph, "_device_ctx", lambda dev: contextlib.nullcontext())
     monkeypatch.setattr(graph, "_sync", lambda dev: None)
+
+    def copy_from_ptr(ptr, n, dtype, device):
+        import torch
+        npdt = {torch.int32: np.int32, torch.float32: np.float32}[dtype]
+        return torch.from_numpy(_vec(ptr, n, npdt).copy())
+
+    monkeypatch.setattr(graph, "_copy_from_ptr", copy_from_ptr)
     import torch
     from acm_gnn_amd import layers
     monkeypatch.setattr(layers, "_default_device", lambda: torch.device("cpu"))

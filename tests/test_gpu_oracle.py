@@ -132,3 +132,40 @@ def test_real_structures(name, f_out, s, monkeypatch):
     adj = sp.csr_matrix((np.ones(len(g["adj_un_indices"])), g["adj_un_indices"], g["adj_un_indptr"]), shape=(n, n))
     _run_both("acmgcnp", 0, s, True, n, 24, f_out, 2, True, monkeypatch, agg=False, adj=adj)
     _run_both("acmgcnp", 0, 0, True, n, 7, 64, 2, False, monkeypatch, agg=True, adj=adj)
+
+
+@pytest.mark.parametrize("model_type,variant,s,f_out", [("acmgcn", 0, 0, 64), ("acmgcnp", 1, 1, 64), ("acmgcnp", 0, 0, 5)])
+def test_sparse_feature_projection_matches_dense_path(model_type, variant, s, f_out, monkeypatch):
+    """CSR features (acm_spmm_v forward, transposed handle with src_pos-permuted values backward) vs the
+    dense-X GEMM path and vs the oracle, incl. wide F_in and a hub feature column."""
+    from acm_gnn_amd import GraphConvolution, SparseFeatures
+    from acm_gnn_amd.graph import clear_cache
+    monkeypatch.setenv("ACM_AGG_FIRST", "1")
+    clear_cache()
+    n, f_in = 300, 700
+    adj = _graph(n, 21)
+    low, high, un = O.filters_linkx(adj)
+    g = torch.Generator().manual_seed(4)
+    x = torch.rand(n, f_in, generator=g) * (torch.rand(n, f_in, generator=g) < 0.02)
+    x[:, 5] = 1.0                                              # a feature every node has (long transposed row)
+    x[7] = 0.0                                                 # a node without features (empty row)
+    gout = torch.randn(n, f_out, generator=g)
+    torch.manual_seed(1)
+    layer = GraphConvolution(f_in, f_out, n, model_type, variant=variant, structure_info=s, attn_layernorm=True)
+    params = {k: v.detach().cpu().clone().requires_grad_(True) for k, v in layer.named_parameters()}
+    ref = O.layer_forward(params, x, low, high, un if s else None, model_type=model_type, variant=variant,
+                          structure_info=s, attn_layernorm=True)
+    ref.backward(gout)
+    layer = layer.to(DEV)
+    adj_d = (low.to(DEV), high.to(DEV), un.to(DEV) if s else None)
+    outs = []
+    for inp in (x.to(DEV), SparseFeatures.from_torch(x.to(DEV)), x.to_sparse().to(DEV)):
+        layer.zero_grad(set_to_none=True)
+        out = layer(inp, *adj_d)
+        out.backward(gout.to(DEV))
+        outs.append((out.detach().cpu(), {k: p.grad.cpu().clone() for k, p in layer.named_parameters() if p.grad is not None}))
+    for out, grads in outs:
+        assert float((out - ref.detach()).abs().max()) < 2e-5 * max(1.0, float(ref.detach().abs().max()))
+        for k, gv in grads.items():
+            rg = params[k].grad
+            assert float((gv - rg).abs().max()) < 1e-4 * max(1.0, float(rg.abs().max())), k

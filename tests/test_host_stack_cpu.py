@@ -194,3 +194,31 @@ def test_fit_selection_rules(monkeypatch):
         if rule == "max_val_acc":
             best = max(range(len(hist)), key=lambda i: (hist[i][2], -i))
             assert acc == hist[best][3]
+
+
+@pytest.mark.parametrize("model_type,variant,s", [("acmgcn", 0, 0), ("acmgcnp", 1, 1)])
+def test_sparse_feature_projection_equals_dense(model_type, variant, s, monkeypatch):
+    """CSR X through acm_spmm_v (forward) and its transpose with permuted values (dW) == dense X."""
+    fake_lib.install(monkeypatch)
+    from acm_gnn_amd import GCN, SparseFeatures
+    low, high, un, _ = graph_tensors("geometric")
+    n = low.shape[0]
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(n, 40, generator=g) * (torch.rand(n, 40, generator=g) < 0.1)
+    y = torch.randint(0, 3, (n,), generator=g)
+    res = []
+    for sparse in (False, True):
+        torch.manual_seed(0)
+        model = GCN(40, 16, 3, 2, n, 0.0, model_type, s, variant=bool(variant), attn_layernorm=True)
+        inp = SparseFeatures.from_torch(x) if sparse else x
+        out = model(inp, low, high, un if s else None)
+        torch.nn.functional.cross_entropy(out, y).backward()
+        res.append((out.detach(), {k: p.grad.clone() for k, p in model.named_parameters() if p.grad is not None}))
+    torch.testing.assert_close(res[1][0], res[0][0], rtol=1e-5, atol=1e-6)
+    assert res[0][1].keys() == res[1][1].keys()
+    for k in res[0][1]:
+        torch.testing.assert_close(res[1][1][k], res[0][1][k], rtol=1e-4, atol=1e-6, msg=lambda m, k=k: f"{k}: {m}")
+    # torch sparse tensors are accepted directly
+    torch.manual_seed(0)
+    model = GCN(40, 16, 3, 2, n, 0.0, model_type, s, variant=bool(variant), attn_layernorm=True)
+    torch.testing.assert_close(model(x.to_sparse(), low, high, un if s else None).detach(), res[0][0], rtol=1e-5, atol=1e-6)
