@@ -179,8 +179,15 @@ def main():
         avg_ms = total_ms / launches
         alg = algorithmic_bytes(dominant, e - b, ops.low.nnz)
         achieved = alg / (avg_ms * 1e-3) / 1e9
+        # PMC traffic cannot be sampled from inside this process; the figure measured for this kernel on this
+        # workload by the committed rocprofv3 passes (profiles/r01_pmc_traffic.json) is attached when it applies
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+        if world == 1 and args.dataset == "twitch-gamer" and args.node_order == "degree" and os.path.exists(tpath):
+            with open(tpath) as fh:
+                traffic = json.load(fh).get(dominant, {}).get("hbm_bytes")
         roofline = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                    "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                     "kernel": dominant, "avg_ms": round(avg_ms, 4), "launches": launches,
                     "algorithmic_bytes": alg}
         breakdown = {k: round(v[1] / v[0], 4) for k, v in sorted(warm.items(), key=lambda kv: -kv[1][1])}
