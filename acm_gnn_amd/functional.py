@@ -269,6 +269,11 @@ class AcmConvFunction(torch.autograd.Function):
         ctx.agg_first = (k == 3 and not cfg.relu_before and f_in <= 16 and f_in < f and f <= 64 and not sparse_x
                          and not ctx.needs_input_grad[0] and os.environ.get("ACM_AGG_FIRST", "1") != "0")
         four = k == 4
+        general = bool(getattr(ops, "general", False))
+        if general:
+            if ops.sharded:
+                raise NotImplementedError("general operator pairs are not row-sharded")
+            ctx.agg_first = False
         if ctx.agg_first:
             fp = 4 if f_in <= 4 else (8 if f_in <= 8 else 16)
             xpad = x if f_in == fp else torch.nn.functional.pad(x, (0, fp - f_in))
@@ -287,7 +292,11 @@ class AcmConvFunction(torch.autograd.Function):
             else:
                 gemm(x, wcat, relu=cfg.relu_before, out=z)                          # [n, 3F] view
             zg = _gather_rows(ops, z[:, : 2 * f]) if ops.sharded else z             # gathered [Z_L|Z_H]
-        if four:
+        if four and general:
+            if ops.un is None:
+                raise RuntimeError("structure_info=1 needs adj_low_unnormalized")
+            s_local = _as_f32c(struc_low, "struc_low")
+        elif four:
             if ops.deg is None:
                 raise RuntimeError("structure_info=1 needs adj_low_unnormalized")
             s_local = _as_f32c(struc_low, "struc_low")
@@ -330,14 +339,33 @@ class AcmConvFunction(torch.autograd.Function):
         p.f_out, p.n_channels = f, k
         p.relu_after, p.relu_mlp, p.layernorm = int(cfg.relu_after), int(cfg.relu_mlp), int(cfg.layernorm)
         p.scale, p.row_offset = cfg.scale, ops.row_offset
-        p.g_low, p.ld_g_low = zg.data_ptr(), zg.stride(0)
-        p.g_high, p.ld_g_high = zg.data_ptr() + 4 * f, zg.stride(0)
-        p.s_high, p.ld_s_high = z.data_ptr() + 4 * f, z.stride(0)
+        graph = ops.low
+        if general:
+            # every channel through its own operator, then the fused kernel over the identity operator as a
+            # row-local epilogue: pre_L = 1*PL, pre_H = PH - 1*0, pre_S = 1*(1*PS) - 0
+            pl = spmm(ops.low, z[:, :f])
+            ph = spmm(ops.high, z[:, f:2 * f])
+            zero = ops.zeros(n, f)
+            graph = ops.eye
+            p.g_low, p.ld_g_low = pl.data_ptr(), pl.stride(0)
+            p.g_high, p.ld_g_high = zero.data_ptr(), zero.stride(0)
+            p.s_high, p.ld_s_high = ph.data_ptr(), ph.stride(0)
+            if four:
+                ps = spmm(ops.un, s_local)
+                ones = ops.zeros(n, 1).new_ones(n)
+                p.g_struc, p.ld_g_struc = ps.data_ptr(), ps.stride(0)
+                p.s_struc, p.ld_s_struc = zero.data_ptr(), zero.stride(0)
+                p.deg = ones.data_ptr()
+            keep_alive = (pl, ph, zero) + ((ps, ones) if four else ())
+        else:
+            p.g_low, p.ld_g_low = zg.data_ptr(), zg.stride(0)
+            p.g_high, p.ld_g_high = zg.data_ptr() + 4 * f, zg.stride(0)
+            p.s_high, p.ld_s_high = z.data_ptr() + 4 * f, z.stride(0)
+            if four:
+                p.g_struc, p.ld_g_struc = s_gath.data_ptr(), s_gath.stride(0)
+                p.s_struc, p.ld_s_struc = s_local.data_ptr(), s_local.stride(0)
+                p.deg = ops.deg.data_ptr()
         p.s_mlp, p.ld_s_mlp = z.data_ptr() + 8 * f, z.stride(0)
-        if four:
-            p.g_struc, p.ld_g_struc = s_gath.data_ptr(), s_gath.stride(0)
-            p.s_struc, p.ld_s_struc = s_local.data_ptr(), s_local.stride(0)
-            p.deg = ops.deg.data_ptr()
         p.att_vec = _ptr_array(vecs)
         p.ln_weight, p.ln_bias = _ptr_array(lnw), _ptr_array(lnb)
         p.att_mix = mix.data_ptr()
@@ -345,9 +373,9 @@ class AcmConvFunction(torch.autograd.Function):
         p.pre, p.ld_pre = pre.data_ptr(), pre.stride(0)
         p.att = att.data_ptr()
         set_post(p)
-        ws = ops.low.workspace((k - 1) * f)
+        ws = graph.workspace((k - 1) * f)
         with _device_ctx(dev), _Timed(f"conv_fwd/F{f}k{k}"):
-            st = lib.acm_conv_fwd(ops.low.handle, C.byref(p), _vp(ws), ws.numel() * 4, _stream())
+            st = lib.acm_conv_fwd(graph.handle, C.byref(p), _vp(ws), ws.numel() * 4, _stream())
         _lib.check(st, "acm_conv_fwd")
         ctx.ops, ctx.cfg = ops, cfg
         ctx.sparse_x = x if sparse_x else None
@@ -386,7 +414,9 @@ class AcmConvFunction(torch.autograd.Function):
         q.grad_out, q.ld_grad_out = grad_out.data_ptr(), grad_out.stride(0)
         q.pre, q.ld_pre = pre.data_ptr(), pre.stride(0)
         q.s_mlp, q.ld_s_mlp = z.data_ptr() + 8 * f, z.stride(0)
-        q.deg = ops.deg.data_ptr() if four else None
+        general = bool(getattr(ops, "general", False))
+        ones = ops.zeros(n, 1).new_ones(n) if (four and general) else None
+        q.deg = (ones if general else ops.deg).data_ptr() if four else None
         q.att_vec, q.ln_weight, q.ln_bias = _ptr_array(vecs), _ptr_array(lnw), _ptr_array(lnb)
         q.att_mix = mix.data_ptr()
         q.g_low, q.ld_g_low = g.data_ptr(), g.stride(0)
@@ -406,25 +436,42 @@ class AcmConvFunction(torch.autograd.Function):
             st = lib.acm_conv_bwd_local(n, C.byref(q), _vp(ws), ws.numel() * 4, _stream())
         _lib.check(st, "acm_conv_bwd_local")
 
-        gg = _gather_rows(ops, g)
-        gsg = _gather_rows(ops, gs) if four else None
         d_struc = torch.empty(n, f, dtype=_F32, device=dev) if four else None
         r = _lib.ConvBwdSpmm()
         r.f_out, r.row_offset = f, ops.row_offset
-        r.g_low, r.ld_g_low = gg.data_ptr(), gg.stride(0)
-        r.g_high, r.ld_g_high = gg.data_ptr() + 4 * f, gg.stride(0)
-        r.s_high, r.ld_s_high = g.data_ptr() + 4 * f, g.stride(0)
-        if four:
-            r.g_struc, r.ld_g_struc = gsg.data_ptr(), gsg.stride(0)
-            r.s_struc, r.ld_s_struc = gs.data_ptr(), gs.stride(0)
-            r.inv_deg = ops.inv_deg.data_ptr()
-            r.d_struc, r.ld_d_struc = d_struc.data_ptr(), d_struc.stride(0)
+        if general:
+            # transposed products channel by channel, then the fused kernel over the identity operator applies the
+            # ACMII masks: dZ_L = m*(1*T_L), dZ_H = m*(T_H - 1*0), dS = 1*T_S - 0
+            t_l = spmm(ops.low.transpose(), g[:, :f])
+            t_h = spmm(ops.high.transpose(), g[:, f:])
+            zero = ops.zeros(n, f)
+            low_t = ops.eye
+            r.g_low, r.ld_g_low = t_l.data_ptr(), t_l.stride(0)
+            r.g_high, r.ld_g_high = zero.data_ptr(), zero.stride(0)
+            r.s_high, r.ld_s_high = t_h.data_ptr(), t_h.stride(0)
+            if four:
+                t_s = spmm(ops.un.transpose(), gs)
+                r.g_struc, r.ld_g_struc = t_s.data_ptr(), t_s.stride(0)
+                r.s_struc, r.ld_s_struc = zero.data_ptr(), zero.stride(0)
+                r.inv_deg = ones.data_ptr()
+                r.d_struc, r.ld_d_struc = d_struc.data_ptr(), d_struc.stride(0)
+        else:
+            gg = _gather_rows(ops, g)
+            gsg = _gather_rows(ops, gs) if four else None
+            low_t = ops.low_t
+            r.g_low, r.ld_g_low = gg.data_ptr(), gg.stride(0)
+            r.g_high, r.ld_g_high = gg.data_ptr() + 4 * f, gg.stride(0)
+            r.s_high, r.ld_s_high = g.data_ptr() + 4 * f, g.stride(0)
+            if four:
+                r.g_struc, r.ld_g_struc = gsg.data_ptr(), gsg.stride(0)
+                r.s_struc, r.ld_s_struc = gs.data_ptr(), gs.stride(0)
+                r.inv_deg = ops.inv_deg.data_ptr()
+                r.d_struc, r.ld_d_struc = d_struc.data_ptr(), d_struc.stride(0)
         if cfg.relu_before:                       # ACMII: ReLU mask of the projected features
             r.mask_low, r.ld_mask_low = z.data_ptr(), z.stride(0)
             r.mask_high, r.ld_mask_high = z.data_ptr() + 4 * f, z.stride(0)
         r.dz_low, r.ld_dz_low = dz.data_ptr(), dz.stride(0)
         r.dz_high, r.ld_dz_high = dz.data_ptr() + 4 * f, dz.stride(0)
-        low_t = ops.low_t
         ws2 = low_t.workspace((k - 1) * f)
         with _device_ctx(dev), _Timed(f"conv_bwd_spmm/F{f}k{k}"):
             st = lib.acm_conv_bwd_spmm(low_t.handle, C.byref(r), _vp(ws2), ws2.numel() * 4, _stream())

@@ -207,6 +207,12 @@ class FilterOperators:
         self.n_global = int(n_global if n_global is not None else low.n_cols)
         self.group = group                              # torch.distributed group when row-sharded
         self.low_t_override = None                      # local rows of the global A_low^T (sharded)
+        # general operator pair (adj_high != I - adj_low, or adj_un != D adj_low - I): see operators_for()
+        self.general = False
+        self.high = None                                # CsrGraph of adj_high
+        self.un = None                                  # CsrGraph of adj_low_unnormalized
+        self._eye = None
+        self._zeros = {}
 
     @property
     def low_t(self):
@@ -219,6 +225,21 @@ class FilterOperators:
     @property
     def n_local(self):
         return self.low.n_rows
+
+    @property
+    def eye(self):
+        """Identity operator: lets the fused kernels run as pure row-local epilogues in the general path."""
+        if self._eye is None:
+            n, dev = self.low.n_rows, self.low.device
+            ar = torch.arange(n + 1, dtype=torch.int32, device=dev)
+            self._eye = CsrGraph.from_csr(ar, ar[:n].clone(), torch.ones(n, device=dev), n)
+        return self._eye
+
+    def zeros(self, n, f):
+        key = (n, f)
+        if key not in self._zeros:
+            self._zeros[key] = torch.zeros(n, f, dtype=torch.float32, device=self.low.device)
+        return self._zeros[key]
 
     @property
     def sharded(self):
@@ -285,19 +306,24 @@ def operators_for(adj_low, adj_high=None, adj_low_unnormalized=None, verify=True
         return hit
     _require_cuda(adj_low, "adj_low")
     low = CsrGraph.from_torch(adj_low)
-    if verify and not verify_high_is_identity_minus_low(low, adj_high):
-        raise NotImplementedError(
-            "acm_gnn_amd: adj_high != I - adj_low; the fused MI355X kernel folds the high-pass "
-            "channel into the A_low pass and supports only the reference's filter pair "
-            "(ACM-Geometric/train.py:77-78)")
+    fused_ok = (not verify) or verify_high_is_identity_minus_low(low, adj_high)
     deg = None
-    if adj_low_unnormalized is not None:
+    if fused_ok and adj_low_unnormalized is not None:
         deg, ok = degree_from_unnormalized(low, adj_low_unnormalized)
-        if verify and not ok:
-            raise NotImplementedError(
-                "acm_gnn_amd: adj_low_unnormalized != D*adj_low - I; the structure channel is folded "
-                "into the A_low pass and needs the reference's normalisation (train.py:76-77)")
-    ops = FilterOperators(low, deg)
+        fused_ok = ok or not verify
+    if fused_ok:
+        ops = FilterOperators(low, deg)
+    else:
+        # General operator pair: the filters are not (A_low, I - A_low[, D A_low - I]) -- e.g. the
+        # reference's k-hop ACM-SGC passes A_low^k with an un-powered adj_high
+        # (ACM-Pytorch/utils.py:631-637).  Each channel then gets its own plain SpMM and the fused
+        # kernels run over the identity operator as row-local epilogues (functional._forward_general).
+        ops = FilterOperators(low, None)
+        ops.general = True
+        ops.high = CsrGraph.from_torch(adj_high) if adj_high is not None else None
+        ops.un = CsrGraph.from_torch(adj_low_unnormalized) if adj_low_unnormalized is not None else None
+        if ops.high is None:
+            raise ValueError("adj_high is required when it cannot be derived from adj_low")
     if len(_CACHE) >= _CACHE_LIMIT:
         _CACHE.pop(next(iter(_CACHE)))
     _CACHE[key] = ops

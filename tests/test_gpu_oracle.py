@@ -169,3 +169,12 @@ def test_sparse_feature_projection_matches_dense_path(model_type, variant, s, f_
         for k, gv in grads.items():
             rg = params[k].grad
             assert float((gv - rg).abs().max()) < 1e-4 * max(1.0, float(rg.abs().max())), k
+
+
+@pytest.mark.parametrize("model_type,variant,s,ln,khop", [("acmsgc", 0, 0, False, 3), ("acmgcnp", 1, 1, True, 2),
+                                                          ("acmgcn", 0, 0, False, 2)])
+def test_general_operator_pair(model_type, variant, s, ln, khop):
+    """k-hop ACM-SGC as the reference feeds it (A_low^k with an un-powered adj_high) and re-weighted raw
+    adjacency: the drop-in takes the general two-operator path and still matches the oracle."""
+    from test_host_stack_cpu import _general_case
+    _general_case(model_type, variant, s, ln, DEV, khop)

@@ -116,12 +116,14 @@ def test_operator_cache_and_filter_verification(monkeypatch):
     a = graph.operators_for(low, high, un)
     assert graph.operators_for(low, high, un) is a                     # cached by storage identity
     assert a.deg is not None and a.low.n_rows == low.shape[0]
+    # filters that are not (A_low, I - A_low[, D A_low - I]) are not an error: they select the general
+    # two-operator path (exercised in test_general_operator_pair_host_path)
     bad_high = (high * 2.0).coalesce()
-    with pytest.raises(NotImplementedError, match="adj_high"):
-        graph.operators_for(low, bad_high, None)
+    g1 = graph.operators_for(low, bad_high, None)
+    assert g1.general and g1.high is not None and not a.general
     bad_un = (un * 3.0).coalesce()
-    with pytest.raises(NotImplementedError, match="adj_low_unnormalized"):
-        graph.operators_for(low, high, bad_un)
+    g2 = graph.operators_for(low, high, bad_un)
+    assert g2.general and g2.un is not None
 
 
 def test_structure_info_with_acmgcn_is_an_error(monkeypatch):
@@ -222,3 +224,53 @@ def test_sparse_feature_projection_equals_dense(model_type, variant, s, monkeypa
     torch.manual_seed(0)
     model = GCN(40, 16, 3, 2, n, 0.0, model_type, s, variant=bool(variant), attn_layernorm=True)
     torch.testing.assert_close(model(x.to_sparse(), low, high, un if s else None).detach(), res[0][0], rtol=1e-5, atol=1e-6)
+
+
+def _general_case(model_type, variant, s, ln, dev, khop):
+    """Filters that are NOT (A_low, I - A_low): k-hop low-pass with an un-powered high-pass (the reference's
+    ACM-SGC hops > 1, ACM-Pytorch/utils.py:631-637) and a re-weighted raw adjacency."""
+    import scipy.sparse as sp
+    from oracle import acm_oracle as O
+    from acm_gnn_amd import GraphConvolution
+    from acm_gnn_amd.graph import clear_cache
+    clear_cache()
+    low, high, un, g = graph_tensors("geometric")
+    n = low.shape[0]
+    low_k = low.to_dense()
+    for _ in range(khop - 1):
+        low_k = low_k @ low.to_dense()
+    low_k = low_k.to_sparse()
+    un_w = (un * 0.5).coalesce()
+    torch.manual_seed(2)
+    layer = GraphConvolution(10, 16, n, model_type, variant=variant, structure_info=s, attn_layernorm=ln)
+    params = {k: v.detach().cpu().clone().requires_grad_(True) for k, v in layer.named_parameters()}
+    gen = torch.Generator().manual_seed(3)
+    x = torch.randn(n, 10, generator=gen)
+    gout = torch.randn(n, 16, generator=gen)
+    xr = x.clone().requires_grad_(True)
+    ref = O.layer_forward(params, xr, low_k, high, un_w if s else None, model_type=model_type, variant=variant,
+                          structure_info=s, attn_layernorm=ln)
+    ref.backward(gout)
+    layer = layer.to(dev)
+    xd = x.to(dev).requires_grad_(True)
+    out = layer(xd, low_k.to(dev), high.to(dev), un_w.to(dev) if s else None)
+    out.backward(gout.to(dev))
+    torch.testing.assert_close(out.detach().cpu(), ref.detach(), rtol=1e-4, atol=2e-5)
+    torch.testing.assert_close(xd.grad.cpu(), xr.grad, rtol=1e-3, atol=5e-5)
+    for k, p in layer.named_parameters():
+        if params[k].grad is None:
+            assert p.grad is None, k
+        else:
+            tol = 1e-4 * max(1.0, float(params[k].grad.abs().max()))
+            assert float((p.grad.cpu() - params[k].grad).abs().max()) < tol, k
+
+
+@pytest.mark.parametrize("model_type,variant,s,ln,khop", [("acmsgc", 0, 0, False, 3), ("acmgcnp", 1, 1, True, 2),
+                                                          ("acmgcn", 0, 0, False, 2)])
+def test_general_operator_pair_host_path(model_type, variant, s, ln, khop, monkeypatch):
+    fake = fake_lib.install(monkeypatch)
+    calls = []
+    orig = fake.acm_spmm_v
+    monkeypatch.setattr(fake, "acm_spmm_v", lambda *a: (calls.append(1), orig(*a))[1])
+    _general_case(model_type, variant, s, ln, "cpu", khop)
+    assert len(calls) >= 4            # separate products per channel, forward and transposed
