@@ -281,6 +281,53 @@ def degree_from_unnormalized(low, adj_un, tol=1e-4):
     return deg, ok
 
 
+# --------------------------------------------------------------------------
+# filter construction on the device, and the on-disk operator cache
+# --------------------------------------------------------------------------
+def filters_from_edge_index(edge_index, n, undirected=True, chunk=0):
+    """edge list -> A_low = D^-1 (I + A) as a device CSR operator (+ d = rowsum(I + A)), entirely on the GPU.
+
+    Restates ACM-Geometric/train.py:66-81 (to_undirected -> scipy A -> normalize_tensor(I + A) in float64 ->
+    float32): duplicate edges collapse to one (to_undirected coalesces), a raw self-loop makes the diagonal
+    2/d_i (quirk Q5), rows are sorted by column.  The float64-then-cast values of the reference equal the fp32
+    quotients computed here bit for bit (double rounding is innocuous for division when 53 >= 2*24 + 2).
+    The sort / unique passes are torch's device primitives (one-off preprocessing)."""
+    _require_cuda(edge_index, "edge_index")
+    dev = edge_index.device
+    src, dst = edge_index[0].to(torch.int64), edge_index[1].to(torch.int64)
+    if undirected:
+        src, dst = torch.cat([src, dst]), torch.cat([dst, src])
+    eye = torch.arange(n, device=dev, dtype=torch.int64)
+    keys = torch.cat([src * n + dst, eye * n + eye])            # (I + A): the identity joins the edge list
+    uniq, counts = torch.unique(keys, return_counts=True)       # sorted by (row, col); self-loop + identity -> 2
+    rows, cols = uniq // n, uniq % n
+    w = torch.where(rows == cols, counts.clamp(max=2), torch.ones_like(counts)).to(torch.float32)
+    deg = torch.zeros(n, dtype=torch.float32, device=dev).index_add_(0, rows, w)
+    vals = w / deg[rows]
+    indptr = torch.zeros(n + 1, dtype=torch.int64, device=dev)
+    indptr[1:] = torch.cumsum(torch.bincount(rows, minlength=n), 0)
+    low = CsrGraph.from_csr(indptr.to(torch.int32), cols.to(torch.int32), vals, n, chunk)
+    return FilterOperators(low, deg)
+
+
+def save_operators(path, ops):
+    """On-disk cache of a FilterOperators: numpy .npz with int32 indptr / indices, fp32 vals and d."""
+    import numpy as np
+    ip, ix, v = (t.cpu().numpy() for t in ops.low.arrays())
+    np.savez_compressed(path, indptr=ip, indices=ix, vals=v, n_cols=np.int64(ops.low.n_cols),
+                        deg=ops.deg.cpu().numpy() if ops.deg is not None else np.zeros(0, np.float32))
+
+
+def load_operators(path, device):
+    import numpy as np
+    with np.load(path) as f:
+        dev = torch.device(device)
+        low = CsrGraph.from_csr(torch.from_numpy(f["indptr"]).to(dev), torch.from_numpy(f["indices"]).to(dev),
+                                torch.from_numpy(f["vals"]).to(dev), int(f["n_cols"]))
+        deg = torch.from_numpy(f["deg"]).to(dev) if f["deg"].size else None
+    return FilterOperators(low, deg)
+
+
 _CACHE = {}
 _CACHE_LIMIT = 16
 

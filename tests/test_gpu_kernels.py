@@ -144,3 +144,30 @@ def test_create_rejects_bad_input():
     ip = torch.tensor([0, 1], dtype=torch.int32, device=DEV)
     with pytest.raises(RuntimeError, match="out of range"):
         CsrGraph.from_csr(ip, torch.tensor([9], dtype=torch.int32, device=DEV), torch.ones(1, device=DEV), 4)
+
+
+def test_device_filter_construction_is_bit_exact(tmp_path):
+    """edge list -> A_low on the GPU == the oracle's restatement of the reference (float64 scipy -> float32),
+    including duplicate edges, raw self-loops (diagonal 2/d) and isolated nodes; plus the on-disk cache."""
+    from oracle import acm_oracle as O
+    from acm_gnn_amd import graph as G, functional as AF
+    rng = np.random.default_rng(0)
+    n, e = 3000, 40000
+    src, dst = rng.integers(0, n - 5, e), rng.integers(0, n - 5, e)       # last 5 nodes isolated
+    src[:50] = dst[:50]                                                   # raw self-loops
+    src[50:100], dst[50:100] = src[100:150], dst[100:150]                 # duplicate edges
+    ei = torch.from_numpy(np.vstack([src, dst])).to(DEV)
+    ops = G.filters_from_edge_index(ei, n)
+    a = sp.coo_matrix((np.ones(2 * e), (np.concatenate([src, dst]), np.concatenate([dst, src]))), shape=(n, n)).tocsr()
+    a.data[:] = 1.0                                                       # to_undirected coalesces duplicates
+    ref_low, _, _ = O.filters_linkx(a)
+    ip, ix, v = O.coo_to_csr_arrays(ref_low)
+    got = [t.cpu().numpy() for t in ops.low.arrays()]
+    assert np.array_equal(got[0], ip) and np.array_equal(got[1], ix)
+    assert np.array_equal(got[2], v)                                      # bit-exact values
+    assert np.array_equal(ops.deg.cpu().numpy(), np.asarray((sp.identity(n) + a).sum(1)).ravel().astype(np.float32))
+    path = str(tmp_path / "ops.npz")
+    G.save_operators(path, ops)
+    back = G.load_operators(path, DEV)
+    x = torch.randn(n, 8, device=DEV)
+    assert torch.equal(AF.spmm(back.low, x), AF.spmm(ops.low, x)) and torch.equal(back.deg, ops.deg)
