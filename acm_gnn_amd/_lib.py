@@ -14,13 +14,13 @@ c_i32p = C.POINTER(C.c_int32)
 
 ACM_OK = 0
 STATUS_NAMES = {1: "ACM_EINVAL", 2: "ACM_ESHAPE", 3: "ACM_EHIP", 4: "ACM_EUNSUPPORTED", 5: "ACM_ENOMEM"}
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 # every symbol include/acm_hip.h declares
 EXPORTED_SYMBOLS = (
     "acm_version", "acm_last_error", "acm_csr_create", "acm_csr_transpose", "acm_csr_slice_rows",
     "acm_csr_destroy", "acm_csr_info", "acm_spmm_workspace_bytes", "acm_gemm_workspace_bytes",
-    "acm_gemm", "acm_spmm", "acm_spmm_v", "acm_conv_fwd", "acm_conv_bwd_local_workspace_bytes",
+    "acm_gemm", "acm_spmm", "acm_spmm_v", "acm_cast_bf16", "acm_conv_fwd", "acm_conv_bwd_local_workspace_bytes",
     "acm_conv_bwd_local", "acm_conv_bwd_spmm", "acm_conv_agg_fwd", "acm_conv_agg_bwd_workspace_bytes",
     "acm_conv_agg_bwd", "acm_nll_loss_workspace_bytes", "acm_nll_loss",
 )
@@ -49,7 +49,8 @@ class ConvFwd(C.Structure):
                 ("att_mix", C.c_void_p),
                 ("out", C.c_void_p), ("ld_out", C.c_int64),
                 ("pre", C.c_void_p), ("ld_pre", C.c_int64),
-                ("att", C.c_void_p), ("post_scale", C.c_void_p), ("ld_post_scale", C.c_int64), ("post_relu", C.c_int32)]
+                ("att", C.c_void_p), ("post_scale", C.c_void_p), ("ld_post_scale", C.c_int64), ("post_relu", C.c_int32),
+                ("gather_bf16", C.c_int32)]
 
 
 class ConvBwdLocal(C.Structure):
@@ -131,6 +132,7 @@ def _declare(lib):
     lib.acm_gemm.argtypes = [i32, i32, i64, i64, i64, vp, i64, vp, i64, vp, i64, i32, vp, sz, vp]
     lib.acm_spmm.argtypes = [vp, vp, i64, i32, vp, i64, vp, sz, vp]
     lib.acm_spmm_v.argtypes = [vp, vp, vp, i64, i32, vp, i64, i32, vp, sz, vp]
+    lib.acm_cast_bf16.argtypes = [i64, i64, vp, i64, vp, i64, vp]
     lib.acm_conv_fwd.argtypes = [vp, C.POINTER(ConvFwd), vp, sz, vp]
     lib.acm_conv_bwd_local_workspace_bytes.argtypes = [i64, i32, i32, C.POINTER(sz)]
     lib.acm_conv_bwd_local.argtypes = [i64, C.POINTER(ConvBwdLocal), vp, sz, vp]

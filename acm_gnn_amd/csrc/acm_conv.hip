@@ -132,7 +132,17 @@ struct EpiBwd {
 };
 
 // ------------------------------------------------------------------ wide gather
-template <int NREG, int NG, int UNR>
+// element load of the gathered operand: fp32, or bf16 widened to fp32 (exact)
+template <bool BF16>
+__device__ __forceinline__ float load_gathered(const float* rowp_f32_units, long row_elems, int col) {
+    if (BF16) {
+        const unsigned short* p = reinterpret_cast<const unsigned short*>(rowp_f32_units) + row_elems + col;
+        return __uint_as_float(((unsigned)*p) << 16);
+    }
+    return rowp_f32_units[row_elems + col];
+}
+
+template <int NREG, int NG, int UNR, bool BF16>
 __device__ __forceinline__ void gather_wide(const GatherSrc& g, int F, const int32_t* __restrict__ indices,
                                             const float* __restrict__ vals, int begin, int end,
                                             int lane, float (&acc)[NG][NREG]) {
@@ -155,11 +165,11 @@ __device__ __forceinline__ void gather_wide(const GatherSrc& g, int F, const int
                 a[u] = acm_lane_f(my_a, t + u);
 #pragma unroll
                 for (int c = 0; c < NG; ++c) {
-                    const float* rowp = g.p[c] + (long)j * g.ld[c];
+                    const long roff = (long)j * g.ld[c];
 #pragma unroll
                     for (int r = 0; r < NREG; ++r) {
                         const int col = lane + 64 * r;
-                        z[u][c][r] = (col < F) ? rowp[col] : 0.f;
+                        z[u][c][r] = (col < F) ? load_gathered<BF16>(g.p[c], roff, col) : 0.f;
                     }
                 }
             }
@@ -175,11 +185,11 @@ __device__ __forceinline__ void gather_wide(const GatherSrc& g, int F, const int
             const float a = acm_lane_f(my_a, t);
 #pragma unroll
             for (int c = 0; c < NG; ++c) {
-                const float* rowp = g.p[c] + (long)j * g.ld[c];
+                const long roff = (long)j * g.ld[c];
 #pragma unroll
                 for (int r = 0; r < NREG; ++r) {
                     const int col = lane + 64 * r;
-                    const float z = (col < F) ? rowp[col] : 0.f;
+                    const float z = (col < F) ? load_gathered<BF16>(g.p[c], roff, col) : 0.f;
                     acc[c][r] = fmaf(a, z, acc[c][r]);
                 }
             }
@@ -187,7 +197,7 @@ __device__ __forceinline__ void gather_wide(const GatherSrc& g, int F, const int
     }
 }
 
-template <int NREG, int NG, class Epi>
+template <int NREG, int NG, class Epi, bool BF16 = false>
 __global__ __launch_bounds__(256) void spmm_wide_kernel(CsrView csr, GatherSrc g, int F,
                                                         typename Epi::Args ea, float* __restrict__ partial) {
     // Blocks take work items in dispatch order (block b -> XCD b % 8): every XCD sees a uniform
@@ -205,7 +215,7 @@ __global__ __launch_bounds__(256) void spmm_wide_kernel(CsrView csr, GatherSrc g
 #pragma unroll
         for (int r = 0; r < NREG; ++r) acc[c][r] = 0.f;
     constexpr int UNR = (NG * NREG >= 8) ? 2 : (NG * NREG >= 4 ? 4 : 8);
-    gather_wide<NREG, NG, UNR>(g, F, csr.indices, csr.vals, begin, end, lane, acc);
+    gather_wide<NREG, NG, UNR, BF16>(g, F, csr.indices, csr.vals, begin, end, lane, acc);
     if (slot < 0) {
         LayWide<NREG> lay{lane};
         Epi::template apply<LayWide<NREG>, NG>(ea, row, lay, F, acc);
@@ -382,7 +392,7 @@ namespace {
 template <int NG, class Epi>
 int launch_gather(const acm_csr* a, const GatherSrc& g, int F, const typename Epi::Args& ea,
                   void* workspace, size_t ws_bytes, hipStream_t st, const char* who,
-                  const float* vals_override = nullptr) {
+                  const float* vals_override = nullptr, bool bf16 = false) {
     const size_t need = (size_t)a->n_slots * (size_t)(NG * F) * sizeof(float);
     ACM_REQUIRE(ws_bytes >= need && (need == 0 || workspace), ACM_ENOMEM,
                 "%s: workspace %zu B < required %zu B", who, ws_bytes, need);
@@ -390,6 +400,7 @@ int launch_gather(const acm_csr* a, const GatherSrc& g, int F, const typename Ep
     CsrView v = acm_view(a);
     if (vals_override) v.vals = vals_override;
     if (a->n_items == 0) return ACM_OK;
+    ACM_REQUIRE(!bf16 || F > 8, ACM_EUNSUPPORTED, "%s: bf16 gathered operands need F > 8 (wide path)", who);
     if (F <= 8) {
         int vecmask = 0;
         const int FP = F <= 2 ? 2 : (F <= 4 ? 4 : 8);
@@ -426,12 +437,19 @@ int launch_gather(const acm_csr* a, const GatherSrc& g, int F, const typename Ep
     } else {
         ACM_REQUIRE(F <= 256, ACM_EUNSUPPORTED, "%s: F = %d > 256 columns per channel", who, F);
         const int grid = (int)((a->n_items + 3) / 4);
-        if (F <= 64)
-            hipLaunchKernelGGL((spmm_wide_kernel<1, NG, Epi>), dim3(grid), dim3(256), 0, st, v, g, F, ea, partial);
-        else if (F <= 128)
-            hipLaunchKernelGGL((spmm_wide_kernel<2, NG, Epi>), dim3(grid), dim3(256), 0, st, v, g, F, ea, partial);
-        else
-            hipLaunchKernelGGL((spmm_wide_kernel<4, NG, Epi>), dim3(grid), dim3(256), 0, st, v, g, F, ea, partial);
+#define ACM_WIDE(NR)                                                                                              \
+    do {                                                                                                          \
+        if (bf16)                                                                                                 \
+            hipLaunchKernelGGL((spmm_wide_kernel<NR, NG, Epi, true>), dim3(grid), dim3(256), 0, st, v, g, F, ea,  \
+                               partial);                                                                          \
+        else                                                                                                      \
+            hipLaunchKernelGGL((spmm_wide_kernel<NR, NG, Epi, false>), dim3(grid), dim3(256), 0, st, v, g, F, ea, \
+                               partial);                                                                          \
+    } while (0)
+        if (F <= 64) ACM_WIDE(1);
+        else if (F <= 128) ACM_WIDE(2);
+        else ACM_WIDE(4);
+#undef ACM_WIDE
     }
     ACM_CHECK_HIP(hipGetLastError());
     if (a->n_long && F <= 8) {
@@ -458,6 +476,32 @@ int launch_gather(const acm_csr* a, const GatherSrc& g, int F, const typename Ep
 }
 
 }  // namespace
+
+__global__ __launch_bounds__(256) void cast_bf16_kernel(long n_rows, int n_cols, const float* __restrict__ src, long ld_src,
+                                                        unsigned short* __restrict__ dst, long ld_dst) {
+    const long total = n_rows * n_cols;
+    for (long q = (long)blockIdx.x * 256 + threadIdx.x; q < total; q += (long)gridDim.x * 256) {
+        const long r = q / n_cols;
+        const int c = (int)(q - r * n_cols);
+        unsigned b = __float_as_uint(src[r * ld_src + c]);
+        b += 0x7FFFu + ((b >> 16) & 1u);                 // round to nearest even
+        dst[r * ld_dst + c] = (unsigned short)(b >> 16);
+    }
+}
+
+extern "C" int acm_cast_bf16(int64_t n_rows, int64_t n_cols, const float* src, int64_t ld_src, uint16_t* dst,
+                             int64_t ld_dst, acm_stream_t stream) {
+    ACM_REQUIRE(src && dst, ACM_EINVAL, "acm_cast_bf16: NULL pointer");
+    ACM_REQUIRE(n_rows >= 0 && n_cols >= 0 && n_cols < INT32_MAX && ld_src >= n_cols && ld_dst >= n_cols, ACM_ESHAPE,
+                "acm_cast_bf16: bad sizes");
+    if (n_rows == 0 || n_cols == 0) return ACM_OK;
+    long blocks = (n_rows * n_cols + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(cast_bf16_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (long)n_rows,
+                       (int)n_cols, src, (long)ld_src, dst, (long)ld_dst);
+    ACM_CHECK_HIP(hipGetLastError());
+    return ACM_OK;
+}
 
 extern "C" int acm_spmm_v(const acm_csr_t* a, const float* vals, const float* G, int64_t ldg, int width, float* Y,
                           int64_t ldy, int relu, void* workspace, size_t workspace_bytes, acm_stream_t stream) {
@@ -501,11 +545,11 @@ extern "C" int acm_conv_fwd(const acm_csr_t* a, const acm_conv_fwd_t* p, void* w
                     "acm_conv_fwd: structure channel pointers are NULL");
         GatherSrc g = {{p->g_low, p->g_high, p->g_struc}, {p->ld_g_low, p->ld_g_high, p->ld_g_struc}};
         return launch_gather<3, EpiFwd>(a, g, F, *p, workspace, workspace_bytes, (hipStream_t)stream,
-                                        "acm_conv_fwd");
+                                        "acm_conv_fwd", nullptr, p->gather_bf16 != 0);
     }
     GatherSrc g = {{p->g_low, p->g_high, nullptr}, {p->ld_g_low, p->ld_g_high, 0}};
     return launch_gather<2, EpiFwd>(a, g, F, *p, workspace, workspace_bytes, (hipStream_t)stream,
-                                    "acm_conv_fwd");
+                                    "acm_conv_fwd", nullptr, p->gather_bf16 != 0);
 }
 
 extern "C" int acm_conv_bwd_spmm(const acm_csr_t* at, const acm_conv_bwd_spmm_t* p, void* workspace,

@@ -198,9 +198,12 @@ class AcmConfig:
     """Static description of one layer variant (what the reference selects with
     model_type / variant / structure_info, ACM-Geometric/layers.py:78-116)."""
 
-    __slots__ = ("n_channels", "relu_before", "relu_after", "relu_mlp", "layernorm", "scale")
+    __slots__ = ("n_channels", "relu_before", "relu_after", "relu_mlp", "layernorm", "scale", "gather_bf16")
 
-    def __init__(self, model_type, variant, structure_info, attn_layernorm):
+    def __init__(self, model_type, variant, structure_info, attn_layernorm, gather_dtype="fp32"):
+        if gather_dtype not in ("fp32", "bf16"):
+            raise ValueError("gather_dtype must be 'fp32' or 'bf16'")
+        self.gather_bf16 = gather_dtype == "bf16"
         plus = model_type in ("acmgcnp", "acmgcnpp", "acmgcn+", "acmgcn++")
         if model_type == "acmsgc":
             self.n_channels, self.relu_before, self.relu_after, self.relu_mlp = 3, False, False, False
@@ -219,6 +222,17 @@ def _ptr_array(tensors):
     for i in range(4):
         arr[i] = tensors[i].data_ptr() if i < len(tensors) and tensors[i] is not None else None
     return arr
+
+
+def cast_bf16(src):
+    """fp32 [n, c] (any row pitch) -> new contiguous bf16 [n, c] (acm_cast_bf16, round to nearest even)."""
+    _require_cuda(src, "src")
+    n, c = src.shape
+    dst = torch.empty(n, c, dtype=torch.bfloat16, device=src.device)
+    with _device_ctx(src.device), _Timed(f"cast_bf16/{n}x{c}"):
+        st = _lib.load().acm_cast_bf16(n, c, _vp(src), src.stride(0), _vp(dst), dst.stride(0), _stream())
+    _lib.check(st, "acm_cast_bf16")
+    return dst
 
 
 def _gather_rows(ops, local):
@@ -358,11 +372,23 @@ class AcmConvFunction(torch.autograd.Function):
                 p.deg = ones.data_ptr()
             keep_alive = (pl, ph, zero) + ((ps, ones) if four else ())
         else:
-            p.g_low, p.ld_g_low = zg.data_ptr(), zg.stride(0)
-            p.g_high, p.ld_g_high = zg.data_ptr() + 4 * f, zg.stride(0)
+            if cfg.gather_bf16 and f > 8:
+                # bf16 copy of the gathered operand(s): half the gather bytes, fp32 accumulation; the self rows
+                # (s_high / s_mlp / s_struc) stay fp32
+                zb = cast_bf16(zg[:, : 2 * f])
+                p.gather_bf16 = 1
+                p.g_low, p.ld_g_low = zb.data_ptr(), zb.stride(0)
+                p.g_high, p.ld_g_high = zb.data_ptr() + 2 * f, zb.stride(0)
+                if four:
+                    sb = cast_bf16(s_gath)
+                    p.g_struc, p.ld_g_struc = sb.data_ptr(), sb.stride(0)
+            else:
+                p.g_low, p.ld_g_low = zg.data_ptr(), zg.stride(0)
+                p.g_high, p.ld_g_high = zg.data_ptr() + 4 * f, zg.stride(0)
+                if four:
+                    p.g_struc, p.ld_g_struc = s_gath.data_ptr(), s_gath.stride(0)
             p.s_high, p.ld_s_high = z.data_ptr() + 4 * f, z.stride(0)
             if four:
-                p.g_struc, p.ld_g_struc = s_gath.data_ptr(), s_gath.stride(0)
                 p.s_struc, p.ld_s_struc = s_local.data_ptr(), s_local.stride(0)
                 p.deg = ops.deg.data_ptr()
         p.s_mlp, p.ld_s_mlp = z.data_ptr() + 8 * f, z.stride(0)

@@ -16,6 +16,7 @@ tests for the spellings ``"acmgcn+"/"acmgcn++"`` (models/layers.py:96,123).
 ACM-Geometric behaviour) -- ``acm_gnn_amd.dropin`` flips it for ACM-Pytorch.
 """
 import math
+import os
 
 import torch
 import torch.nn as nn
@@ -36,7 +37,7 @@ def _default_device():
 
 class GraphConvolution(nn.Module):
     def __init__(self, in_features, out_features, nnodes, model_type, output_layer=0, variant=False,
-                 structure_info=0, attn_layernorm=None):
+                 structure_info=0, attn_layernorm=None, gather_dtype=None):
         super().__init__()
         self.in_features, self.out_features = in_features, out_features
         self.output_layer, self.model_type = output_layer, model_type
@@ -44,6 +45,9 @@ class GraphConvolution(nn.Module):
         if attn_layernorm is None:
             attn_layernorm = True if model_type in _PLUS_LITERAL else DEFAULT_ATTN_LAYERNORM
         self.attn_layernorm = bool(attn_layernorm)
+        # storage type of the gathered operand on the wide literal path: "fp32" (reference numerics) or "bf16"
+        # (half the gather bytes, ~3 decimal digits on that operand; fp32 accumulation) -- BASELINE config 3
+        self.gather_dtype = gather_dtype or os.environ.get("ACM_GATHER_DTYPE", "fp32")
         self.att_low, self.att_high, self.att_mlp = 0, 0, 0
         dev = _default_device()
 
@@ -76,7 +80,7 @@ class GraphConvolution(nn.Module):
 
     # ------------------------------------------------------------------
     def _config(self):
-        return AF.AcmConfig(self.model_type, self.variant, self.structure_info, self.attn_layernorm)
+        return AF.AcmConfig(self.model_type, self.variant, self.structure_info, self.attn_layernorm, self.gather_dtype)
 
     def _param_dict(self):
         return {

@@ -23,7 +23,7 @@ _TWO_LAYER = ("acmgcn", "acmgcnp", "acmgcnpp")
 
 class GCN(nn.Module):
     def __init__(self, nfeat, nhid, nclass, nlayers, nnodes, dropout, model_type, structure_info,
-                 variant=False, init_layers_X=1, attn_layernorm=None):
+                 variant=False, init_layers_X=1, attn_layernorm=None, gather_dtype=None):
         super().__init__()
         self.model_type, self.structure_info = model_type, structure_info
         self.nlayers, self.nnodes, self.dropout = nlayers, nnodes, dropout
@@ -31,7 +31,7 @@ class GCN(nn.Module):
             self.mlpX = MLP(nfeat, nhid, nhid, num_layers=init_layers_X, dropout=0)
         self.gcns, self.mlps = nn.ModuleList(), nn.ModuleList()
         kw = dict(model_type=model_type, variant=variant, structure_info=structure_info,
-                  attn_layernorm=attn_layernorm)
+                  attn_layernorm=attn_layernorm, gather_dtype=gather_dtype)
         if model_type in _TWO_LAYER:
             self.gcns.append(GraphConvolution(nfeat, nhid, nnodes, **kw))
             self.gcns.append(GraphConvolution(nhid, nclass, nnodes, output_layer=1, **kw))

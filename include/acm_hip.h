@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define ACM_ABI_VERSION 3
+#define ACM_ABI_VERSION 4
 
 typedef enum {
     ACM_OK = 0,
@@ -125,6 +125,10 @@ int acm_spmm_v(const acm_csr_t* a, const float* vals, const float* G, int64_t ld
                float* Y, int64_t ldy, int relu, void* workspace, size_t workspace_bytes,
                acm_stream_t stream);
 
+/* fp32 -> bf16 (round to nearest even) copy of a [n_rows, n_cols] matrix; dst leading dimension in elements. */
+int acm_cast_bf16(int64_t n_rows, int64_t n_cols, const float* src, int64_t ld_src,
+                  uint16_t* dst, int64_t ld_dst, acm_stream_t stream);
+
 /* ---------------------------------------------------- fused ACM layer (K2) --
  * One pass over A_low computes every graph channel and the adaptive mixing:
  *
@@ -174,6 +178,10 @@ typedef struct {
      * post_scale is the dropout keep-mask / (1 - p); NULL = none. */
     const float* post_scale; int64_t ld_post_scale;
     int32_t post_relu;
+    /* 0: g_low / g_high / g_struc are fp32 (default).  1: they point to bf16 (uint16_t) matrices produced by
+     * acm_cast_bf16, leading dimensions in elements; products are accumulated in fp32.  Halves the gathered
+     * bytes of the wide (F > 8) path at ~3 decimal digits of the operand (BASELINE config 3). */
+    int32_t gather_bf16;
 } acm_conv_fwd_t;
 
 int acm_conv_fwd(const acm_csr_t* a_low, const acm_conv_fwd_t* p,

@@ -110,7 +110,7 @@ class FakeLib:
 
     # ---- plumbing ---------------------------------------------------------
     def acm_version(self):
-        return 3
+        return 4
 
     def acm_last_error(self):
         return self._err
@@ -214,6 +214,12 @@ class FakeLib:
         _view(c, m, n, ldc)[...] = out
         return 0
 
+    def acm_cast_bf16(self, n, c, src, lds, dst, ldd, stream):
+        b = _view(src, n, c, lds).copy().view(np.uint32)
+        b = b + 0x7FFF + ((b >> 16) & 1)
+        _view(dst, n, c, ldd, np.uint16)[...] = (b >> 16).astype(np.uint16)
+        return 0
+
     def acm_spmm(self, h, g, ldg, width, y, ldy, ws, wsb, stream):
         return self.acm_spmm_v(h, None, g, ldg, width, y, ldy, 0, ws, wsb, stream)
 
@@ -237,15 +243,21 @@ class FakeLib:
         a, p = self._get(h), pp._obj
         n, F, k = a.n_rows, p.f_out, p.n_channels
         f64 = np.float64
-        pl = a.dense_mul(_view(p.g_low, a.n_cols, F, p.ld_g_low))
-        ph = _view(p.s_high, n, F, p.ld_s_high).astype(f64) - a.dense_mul(_view(p.g_high, a.n_cols, F, p.ld_g_high))
+        if p.gather_bf16:
+            def gat(ptr, ld):
+                return (_view(ptr, a.n_cols, F, ld, np.uint16).astype(np.uint32) << 16).view(np.float32)
+        else:
+            def gat(ptr, ld):
+                return _view(ptr, a.n_cols, F, ld)
+        pl = a.dense_mul(gat(p.g_low, p.ld_g_low))
+        ph = _view(p.s_high, n, F, p.ld_s_high).astype(f64) - a.dense_mul(gat(p.g_high, p.ld_g_high))
         zi = _view(p.s_mlp, n, F, p.ld_s_mlp).astype(f64)
         act = (lambda t: np.maximum(t, 0)) if p.relu_after else (lambda t: t)
         H = [act(pl), act(ph), np.maximum(zi, 0) if p.relu_mlp else zi]
         pre = [pl, ph]
         if k == 4:
             deg = _vec(p.deg, n).astype(f64)[:, None]
-            ps = deg * a.dense_mul(_view(p.g_struc, a.n_cols, F, p.ld_g_struc)) - _view(p.s_struc, n, F, p.ld_s_struc)
+            ps = deg * a.dense_mul(gat(p.g_struc, p.ld_g_struc)) - _view(p.s_struc, n, F, p.ld_s_struc)
             H.append(np.maximum(ps, 0))
             pre.append(ps)
         vecs, lnw, lnb, mix = self._params(p, k, F, p.layernorm)

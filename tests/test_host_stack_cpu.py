@@ -274,3 +274,21 @@ def test_general_operator_pair_host_path(model_type, variant, s, ln, khop, monke
     monkeypatch.setattr(fake, "acm_spmm_v", lambda *a: (calls.append(1), orig(*a))[1])
     _general_case(model_type, variant, s, ln, "cpu", khop)
     assert len(calls) >= 4            # separate products per channel, forward and transposed
+
+
+def test_bf16_gather_option_host_path(monkeypatch):
+    """gather_dtype='bf16' routes through acm_cast_bf16 and differs from fp32 only at the bf16 rounding level."""
+    fake_lib.install(monkeypatch)
+    from acm_gnn_amd import GraphConvolution
+    low, high, un, _ = graph_tensors("geometric")
+    n = low.shape[0]
+    x = torch.randn(n, 20, generator=torch.Generator().manual_seed(0))
+    outs = {}
+    for dt in ("fp32", "bf16"):
+        torch.manual_seed(1)
+        layer = GraphConvolution(20, 64, n, "acmgcnp", variant=1, structure_info=1, attn_layernorm=True, gather_dtype=dt)
+        outs[dt] = layer(x, low, high, un).detach()
+    err = (outs["bf16"] - outs["fp32"]).abs().max().item()
+    assert 0 < err < 2e-2 * max(1.0, outs["fp32"].abs().max().item())
+    with pytest.raises(ValueError):
+        GraphConvolution(20, 64, n, "acmgcn", gather_dtype="fp8")._config()
