@@ -27,6 +27,10 @@ template <int FP>
 struct Owns<LaySerial<FP>> {
     static __device__ __forceinline__ bool lane_stores(const LaySerial<FP>& l) { return l.lead; }
 };
+template <>
+struct Owns<LayPair32> {
+    static __device__ __forceinline__ bool lane_stores(const LayPair32& l) { return l.lane < 32; }
+};
 
 struct EpiPlain {
     struct Args {
@@ -231,6 +235,88 @@ __global__ __launch_bounds__(256) void spmm_wide_kernel(CsrView csr, GatherSrc g
     }
 }
 
+// bf16 gathered operand, F <= 64 (even): lane l of each half-wave owns the packed column pair (2l, 2l+1), the two
+// half-waves walk alternate neighbours, so one dword load per lane fetches 2 neighbours x 128 B per channel --
+// half the bytes AND half the load instructions of the fp32 path (2-byte per-lane loads were slower than fp32:
+// 804 -> 1290 us).  The halves are combined with v_permlane32_swap, then the epilogue runs in LayPair32.
+template <int NG, class Epi>
+__global__ __launch_bounds__(256) void spmm_pair_bf16_kernel(CsrView csr, GatherSrc g, int F, typename Epi::Args ea,
+                                                             float* __restrict__ partial) {
+    const int lane = threadIdx.x & 63, half = lane >> 5, l32 = lane & 31;
+    const int w = acm_uniform(blockIdx.x * 4 + (threadIdx.x >> 6));
+    if (w >= csr.n_items) return;
+    const AcmItem it = csr.items[w];
+    const int row = acm_uniform(it.row), begin = acm_uniform(it.begin), end = acm_uniform(it.end),
+              slot = acm_uniform(it.slot);
+    float acc[NG][2];
+#pragma unroll
+    for (int c = 0; c < NG; ++c) acc[c][0] = acc[c][1] = 0.f;
+    const bool col_ok = 2 * l32 < F;
+    constexpr int UNR = 4;
+    for (int base = begin; base < end; base += 64) {
+        const int kk = base + lane;
+        int my_j = 0;
+        float my_a = 0.f;
+        if (kk < end) {
+            my_j = csr.indices[kk];
+            my_a = csr.vals[kk];
+        }
+        const int cnt = min(64, end - base);
+        for (int t = 0; t < cnt; t += 2 * UNR) {
+            unsigned zz[UNR][NG];
+            float a[UNR];
+            bool ok[UNR];
+#pragma unroll
+            for (int u = 0; u < UNR; ++u) {
+                const int t0 = t + 2 * u;                         // wave-uniform
+                const bool have0 = t0 < cnt, have1 = t0 + 1 < cnt;
+                const int j0 = __builtin_amdgcn_readlane(my_j, have0 ? t0 : 0);
+                const int j1 = __builtin_amdgcn_readlane(my_j, have1 ? t0 + 1 : 0);
+                const float a0 = acm_lane_f(my_a, have0 ? t0 : 0), a1 = acm_lane_f(my_a, have1 ? t0 + 1 : 0);
+                const int j = half ? j1 : j0;
+                a[u] = half ? a1 : a0;
+                ok[u] = (half ? have1 : have0) && col_ok;
+#pragma unroll
+                for (int c = 0; c < NG; ++c) {
+                    const unsigned* rowp = reinterpret_cast<const unsigned*>(
+                        reinterpret_cast<const unsigned short*>(g.p[c]) + (long)j * g.ld[c]);
+                    zz[u][c] = rowp[col_ok ? l32 : 0];
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < UNR; ++u)
+#pragma unroll
+                for (int c = 0; c < NG; ++c) {
+                    const float lo = __uint_as_float(zz[u][c] << 16), hi = __uint_as_float(zz[u][c] & 0xFFFF0000u);
+                    acc[c][0] = ok[u] ? fmaf(a[u], lo, acc[c][0]) : acc[c][0];
+                    acc[c][1] = ok[u] ? fmaf(a[u], hi, acc[c][1]) : acc[c][1];
+                }
+        }
+    }
+    // add the two half-waves (fixed order: lower + upper)
+#pragma unroll
+    for (int c = 0; c < NG; ++c)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const acm_u32x2 r = __builtin_amdgcn_permlane32_swap(__float_as_uint(acc[c][i]), __float_as_uint(acc[c][i]),
+                                                                 false, false);
+            acc[c][i] = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+        }
+    if (slot < 0) {
+        LayPair32 lay{lane};
+        Epi::template apply<LayPair32, NG>(ea, row, lay, F, acc);
+    } else if (lane < 32) {
+        float* ps = partial + (long)slot * (NG * F);
+#pragma unroll
+        for (int c = 0; c < NG; ++c)
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int col = 2 * l32 + i;
+                if (col < F) ps[c * F + col] = acc[c][i];
+            }
+    }
+}
+
 // One wave per long row: add its partial slots in slot order, then the epilogue.
 template <int NREG, int NG, class Epi>
 __global__ __launch_bounds__(256) void spmm_fixup_kernel(CsrView csr, int F, typename Epi::Args ea,
@@ -400,7 +486,13 @@ int launch_gather(const acm_csr* a, const GatherSrc& g, int F, const typename Ep
     CsrView v = acm_view(a);
     if (vals_override) v.vals = vals_override;
     if (a->n_items == 0) return ACM_OK;
-    ACM_REQUIRE(!bf16 || F > 8, ACM_EUNSUPPORTED, "%s: bf16 gathered operands need F > 8 (wide path)", who);
+    ACM_REQUIRE(!bf16 || (F > 8 && F <= 64 && F % 2 == 0), ACM_EUNSUPPORTED,
+                "%s: bf16 gathered operands are implemented for even 8 < F <= 64", who);
+    if (bf16) {
+        bool aligned = true;
+        for (int c = 0; c < NG; ++c) aligned = aligned && ((uintptr_t)g.p[c]) % 4 == 0 && g.ld[c] % 2 == 0;
+        ACM_REQUIRE(aligned, ACM_EINVAL, "%s: bf16 operands must be 4-byte aligned with an even leading dimension", who);
+    }
     if (F <= 8) {
         int vecmask = 0;
         const int FP = F <= 2 ? 2 : (F <= 4 ? 4 : 8);
@@ -437,19 +529,14 @@ int launch_gather(const acm_csr* a, const GatherSrc& g, int F, const typename Ep
     } else {
         ACM_REQUIRE(F <= 256, ACM_EUNSUPPORTED, "%s: F = %d > 256 columns per channel", who, F);
         const int grid = (int)((a->n_items + 3) / 4);
-#define ACM_WIDE(NR)                                                                                              \
-    do {                                                                                                          \
-        if (bf16)                                                                                                 \
-            hipLaunchKernelGGL((spmm_wide_kernel<NR, NG, Epi, true>), dim3(grid), dim3(256), 0, st, v, g, F, ea,  \
-                               partial);                                                                          \
-        else                                                                                                      \
-            hipLaunchKernelGGL((spmm_wide_kernel<NR, NG, Epi, false>), dim3(grid), dim3(256), 0, st, v, g, F, ea, \
-                               partial);                                                                          \
-    } while (0)
-        if (F <= 64) ACM_WIDE(1);
-        else if (F <= 128) ACM_WIDE(2);
-        else ACM_WIDE(4);
-#undef ACM_WIDE
+        if (bf16)
+            hipLaunchKernelGGL((spmm_pair_bf16_kernel<NG, Epi>), dim3(grid), dim3(256), 0, st, v, g, F, ea, partial);
+        else if (F <= 64)
+            hipLaunchKernelGGL((spmm_wide_kernel<1, NG, Epi>), dim3(grid), dim3(256), 0, st, v, g, F, ea, partial);
+        else if (F <= 128)
+            hipLaunchKernelGGL((spmm_wide_kernel<2, NG, Epi>), dim3(grid), dim3(256), 0, st, v, g, F, ea, partial);
+        else
+            hipLaunchKernelGGL((spmm_wide_kernel<4, NG, Epi>), dim3(grid), dim3(256), 0, st, v, g, F, ea, partial);
     }
     ACM_CHECK_HIP(hipGetLastError());
     if (a->n_long && F <= 8) {

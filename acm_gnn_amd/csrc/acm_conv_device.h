@@ -33,6 +33,14 @@ struct LayGrouped {  // D: 16 lanes (= one DPP row) per matrix row, 4 rows per w
     __device__ __forceinline__ float rsum(float v) const { return acm_group_sum<16>(v); }
     __device__ __forceinline__ bool leader() const { return (lane & 15) == 0; }
 };
+struct LayPair32 {  // E: 32 lanes per row, lane l owns the adjacent columns 2l, 2l+1 (one packed bf16 pair);
+                    //    both half-waves hold the same row after the half-combine, the lower one stores
+    static constexpr int NV = 2;
+    int lane;
+    __device__ __forceinline__ int col(int i) const { return 2 * (lane & 31) + i; }
+    __device__ __forceinline__ float rsum(float v) const { return acm_group_sum<32>(v); }
+    __device__ __forceinline__ bool leader() const { return (lane & 31) == 0; }
+};
 template <int FP>
 struct LaySerial {  // C: every lane holds the whole row
     static constexpr int NV = FP;

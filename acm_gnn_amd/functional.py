@@ -372,7 +372,7 @@ class AcmConvFunction(torch.autograd.Function):
                 p.deg = ones.data_ptr()
             keep_alive = (pl, ph, zero) + ((ps, ones) if four else ())
         else:
-            if cfg.gather_bf16 and f > 8:
+            if cfg.gather_bf16 and 8 < f <= 64 and f % 2 == 0:
                 # bf16 copy of the gathered operand(s): half the gather bytes, fp32 accumulation; the self rows
                 # (s_high / s_mlp / s_struc) stay fp32
                 zb = cast_bf16(zg[:, : 2 * f])
