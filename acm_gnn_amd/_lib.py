@@ -14,13 +14,13 @@ c_i32p = C.POINTER(C.c_int32)
 
 ACM_OK = 0
 STATUS_NAMES = {1: "ACM_EINVAL", 2: "ACM_ESHAPE", 3: "ACM_EHIP", 4: "ACM_EUNSUPPORTED", 5: "ACM_ENOMEM"}
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 # every symbol include/acm_hip.h declares
 EXPORTED_SYMBOLS = (
     "acm_version", "acm_last_error", "acm_csr_create", "acm_csr_transpose", "acm_csr_slice_rows",
     "acm_csr_destroy", "acm_csr_info", "acm_spmm_workspace_bytes", "acm_gemm_workspace_bytes",
-    "acm_gemm", "acm_spmm", "acm_spmm_v", "acm_cast_bf16", "acm_conv_fwd", "acm_conv_bwd_local_workspace_bytes",
+    "acm_gemm", "acm_spmm", "acm_spmm_v", "acm_spmm_sub", "acm_cast_bf16", "acm_conv_fwd", "acm_conv_bwd_local_workspace_bytes",
     "acm_conv_bwd_local", "acm_conv_bwd_spmm", "acm_conv_agg_fwd", "acm_conv_agg_bwd_workspace_bytes",
     "acm_conv_agg_bwd", "acm_nll_loss_workspace_bytes", "acm_nll_loss",
 )
@@ -96,7 +96,10 @@ class ConvAggFwd(C.Structure):
                 ("att_mix", C.c_void_p),
                 ("out", C.c_void_p), ("ld_out", C.c_int64),
                 ("agg", C.c_void_p), ("ld_agg", C.c_int64),
-                ("att", C.c_void_p), ("post_scale", C.c_void_p), ("ld_post_scale", C.c_int64), ("post_relu", C.c_int32)]
+                ("att", C.c_void_p), ("post_scale", C.c_void_p), ("ld_post_scale", C.c_int64), ("post_relu", C.c_int32),
+                ("n_channels", C.c_int32), ("sg", C.c_void_p), ("ld_sg", C.c_int64), ("sg_bf16", C.c_int32),
+                ("ss", C.c_void_p), ("ld_ss", C.c_int64), ("deg", C.c_void_p),
+                ("ps", C.c_void_p), ("ld_ps", C.c_int64)]
 
 
 class ConvAggBwd(C.Structure):
@@ -108,7 +111,10 @@ class ConvAggBwd(C.Structure):
                 ("w_low", C.c_void_p), ("w_high", C.c_void_p), ("w_mlp", C.c_void_p), ("ld_w", C.c_int64),
                 ("att_vec", C.c_void_p * 4), ("ln_weight", C.c_void_p * 4), ("ln_bias", C.c_void_p * 4),
                 ("att_mix", C.c_void_p),
-                ("d_params", C.c_void_p), ("post_scale", C.c_void_p), ("ld_post_scale", C.c_int64), ("post_relu", C.c_int32)]
+                ("d_params", C.c_void_p), ("post_scale", C.c_void_p), ("ld_post_scale", C.c_int64), ("post_relu", C.c_int32),
+                ("n_channels", C.c_int32), ("ps", C.c_void_p), ("ld_ps", C.c_int64),
+                ("ss", C.c_void_p), ("ld_ss", C.c_int64), ("deg", C.c_void_p),
+                ("g_struc", C.c_void_p), ("ld_g_struc", C.c_int64)]
 
 
 _lib = None
@@ -132,6 +138,7 @@ def _declare(lib):
     lib.acm_gemm.argtypes = [i32, i32, i64, i64, i64, vp, i64, vp, i64, vp, i64, i32, vp, sz, vp]
     lib.acm_spmm.argtypes = [vp, vp, i64, i32, vp, i64, vp, sz, vp]
     lib.acm_spmm_v.argtypes = [vp, vp, vp, i64, i32, vp, i64, i32, vp, sz, vp]
+    lib.acm_spmm_sub.argtypes = [vp, vp, i64, i32, vp, i64, vp, vp, i64, vp, sz, vp]
     lib.acm_cast_bf16.argtypes = [i64, i64, vp, i64, vp, i64, vp]
     lib.acm_conv_fwd.argtypes = [vp, C.POINTER(ConvFwd), vp, sz, vp]
     lib.acm_conv_bwd_local_workspace_bytes.argtypes = [i64, i32, i32, C.POINTER(sz)]

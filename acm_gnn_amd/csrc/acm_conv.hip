@@ -37,6 +37,9 @@ struct EpiPlain {
         float* y;
         long ldy;
         int relu;
+        const float* sub;         // optional: y = acc - row_scale[row] * sub[row][col]
+        long ld_sub;
+        const float* row_scale;   // optional
     };
     template <class L, int NG>
     static __device__ __forceinline__ void apply(const Args& a, int row, const L& lay, int F,
@@ -45,7 +48,11 @@ struct EpiPlain {
 #pragma unroll
         for (int i = 0; i < L::NV; ++i) {
             const int col = lay.col(i);
-            if (col < F) a.y[(long)row * a.ldy + col] = a.relu ? fmaxf(acc[0][i], 0.f) : acc[0][i];
+            if (col < F) {
+                float v = acc[0][i];
+                if (a.sub) v -= (a.row_scale ? a.row_scale[row] : 1.f) * a.sub[(long)row * a.ld_sub + col];
+                a.y[(long)row * a.ldy + col] = a.relu ? fmaxf(v, 0.f) : v;
+            }
         }
     }
 };
@@ -598,12 +605,32 @@ extern "C" int acm_spmm_v(const acm_csr_t* a, const float* vals, const float* G,
     for (int c0 = 0; c0 < width; c0 += 256) {  // column blocks of <= 256
         const int wd = width - c0 < 256 ? width - c0 : 256;
         GatherSrc g = {{G + c0, nullptr, nullptr}, {ldg, 0, 0}};
-        EpiPlain::Args ea = {Y + c0, ldy, relu};
+        EpiPlain::Args ea = {Y + c0, ldy, relu, nullptr, 0, nullptr};
         int st = launch_gather<1, EpiPlain>(a, g, wd, ea, workspace, workspace_bytes,
                                             (hipStream_t)stream, "acm_spmm", vals);
         if (st != ACM_OK) return st;
     }
     return ACM_OK;
+}
+
+extern "C" int acm_spmm_sub(const acm_csr_t* a, const float* G, int64_t ldg, int width, const float* sub,
+                            int64_t ld_sub, const float* row_scale, float* Y, int64_t ldy, void* workspace,
+                            size_t workspace_bytes, acm_stream_t stream) {
+    ACM_REQUIRE(a && G && Y && sub, ACM_EINVAL, "acm_spmm_sub: NULL argument");
+    ACM_REQUIRE(width > 0 && width <= 256 && ldg >= width && ldy >= width && ld_sub >= width, ACM_ESHAPE,
+                "acm_spmm_sub: width %d (<= 256) ldg %lld ldy %lld ld_sub %lld", width, (long long)ldg, (long long)ldy,
+                (long long)ld_sub);
+    GatherSrc g = {{G, nullptr, nullptr}, {ldg, 0, 0}};
+    EpiPlain::Args ea = {Y, ldy, 0, sub, ld_sub, row_scale};
+    return launch_gather<1, EpiPlain>(a, g, width, ea, workspace, workspace_bytes, (hipStream_t)stream, "acm_spmm_sub");
+}
+
+// internal: plain product with a bf16 gathered operand (used by the aggregate-first structure channel)
+int acm_spmm_bf16_internal(const acm_csr* a, const void* G_bf16, long ldg, int width, float* Y, long ldy, void* workspace,
+                           size_t workspace_bytes, hipStream_t stream) {
+    GatherSrc g = {{reinterpret_cast<const float*>(G_bf16), nullptr, nullptr}, {ldg, 0, 0}};
+    EpiPlain::Args ea = {Y, ldy, 0, nullptr, 0, nullptr};
+    return launch_gather<1, EpiPlain>(a, g, width, ea, workspace, workspace_bytes, stream, "acm_spmm(bf16)", nullptr, true);
 }
 
 extern "C" int acm_spmm(const acm_csr_t* a, const float* G, int64_t ldg, int width, float* Y,

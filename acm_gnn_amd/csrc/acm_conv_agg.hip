@@ -12,6 +12,10 @@
 // deterministically (wave -> LDS -> per-block partial -> tree reduce).
 #include "acm_conv_device.h"
 
+// defined in acm_conv.hip: plain product with a bf16 gathered operand
+int acm_spmm_bf16_internal(const acm_csr* a, const void* G_bf16, long ldg, int width, float* Y, long ldy, void* workspace,
+                           size_t workspace_bytes, hipStream_t stream);
+
 namespace {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -77,11 +81,11 @@ __device__ __forceinline__ void project(const float* wlds, float* scratch, int m
 }
 
 // P (uniform in the 16-lane group) -> projections -> head -> out / att for one row.
-template <int FP>
+template <int FP, int K>
 __device__ __forceinline__ void agg_fwd_row(const acm_conv_agg_fwd_t& p, const float* wlds, const float* hlds,
                                             float* scratch, const float* mixm, int row, int lane) {
     const int F = p.f_out, m = lane & 15;
-    float H[3][4];
+    float H[K][4];
     {
         float p0[4], p1[4], zi[4];
         project<FP>(wlds, scratch, m, p.agg + (long)row * p.ld_agg, p.xs + (long)row * p.ld_xs, true, p0, p1, zi);
@@ -93,40 +97,52 @@ __device__ __forceinline__ void agg_fwd_row(const acm_conv_agg_fwd_t& p, const f
             H[2][i] = ok ? (p.relu_mlp ? fmaxf(zi[i], 0.f) : zi[i]) : 0.f;
         }
     }
-    RowHead<3> rh;
-    row_head<3>(hlds, mixm, acm_opaque(m), F, p.layernorm != 0, H, rh);
+    if (K == 4) {                                  // structure channel: relu(deg * (A_low S) - S)
+        const float dg = p.deg[row];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int cc = (m + 16 * i < F) ? m + 16 * i : 0;
+            const float v = dg * p.ps[(unsigned)row * (unsigned)p.ld_ps + cc] - p.ss[(unsigned)row * (unsigned)p.ld_ss + cc];
+            H[K - 1][i] = (m + 16 * i < F) ? fmaxf(v, 0.f) : 0.f;
+        }
+    }
+    RowHead<K> rh;
+    row_head<K>(hlds, mixm, acm_opaque(m), F, p.layernorm != 0, H, rh);
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int col = m + 16 * i;
         if (col < F) {
-            float o = p.scale * (rh.alpha[0] * H[0][i] + rh.alpha[1] * H[1][i] + rh.alpha[2] * H[2][i]);
+            float o = rh.alpha[0] * H[0][i] + rh.alpha[1] * H[1][i] + rh.alpha[2] * H[2][i];
+            if (K == 4) o = fmaf(rh.alpha[K - 1], H[K - 1][i], o);
+            o *= p.scale;
             if (p.post_relu) o = fmaxf(o, 0.f);
             if (p.post_scale) o *= p.post_scale[(long)row * p.ld_post_scale + col];
             p.out[(long)row * p.ld_out + col] = o;
         }
     }
     if (m == 0)
-        *reinterpret_cast<float4*>(p.att + (long)row * 4) = make_float4(rh.alpha[0], rh.alpha[1], rh.alpha[2], 0.f);
+        *reinterpret_cast<float4*>(p.att + (long)row * 4) =
+            make_float4(rh.alpha[0], rh.alpha[1], rh.alpha[2], K == 4 ? rh.alpha[K - 1] : 0.f);
 }
 
 // Forward = two launches: (1) P = A_low X through the lean narrow-gather kernel of acm_spmm (few
 // registers => 8 waves/SIMD in flight, which is what a request-latency-bound gather needs; the
 // fused version held the epilogue's 156 VGPRs during the gather and ran at 3 waves/SIMD), (2) this
 // streaming row-local kernel: 4 rows per wave, 16 lanes x 4 columns each.
-template <int FP>
+template <int FP, int K>
 __global__ __launch_bounds__(256) void agg_epilogue_kernel(acm_conv_agg_fwd_t p, int n_rows) {
-    __shared__ __attribute__((aligned(16))) float wlds[3 * FP * 64 + 9 * 64 + 16 * 2 * FP];
+    __shared__ __attribute__((aligned(16))) float wlds[3 * FP * 64 + 3 * K * 64 + 16 * 2 * FP];
     float* hlds = wlds + 3 * FP * 64;
-    float* scratch = hlds + 9 * 64 + (threadIdx.x >> 4) * 2 * FP;      // this 16-lane group's P | x
+    float* scratch = hlds + 3 * K * 64 + (threadIdx.x >> 4) * 2 * FP;      // this 16-lane group's P | x
     stage_weights<FP>(wlds, p.w_low, p.w_high, p.w_mlp, p.ld_w, p.f_in, p.f_out);
-    stage_head_params<3>(hlds, p.att_vec, p.ln_weight, p.ln_bias, p.layernorm, p.f_out);
+    stage_head_params<K>(hlds, p.att_vec, p.ln_weight, p.ln_bias, p.layernorm, p.f_out);
     __syncthreads();
-    float mixm[9];
+    float mixm[K * K];
 #pragma unroll
-    for (int q = 0; q < 9; ++q) mixm[q] = p.att_mix[q];
+    for (int q = 0; q < K * K; ++q) mixm[q] = p.att_mix[q];
     const int lane = threadIdx.x & 63;
     for (int row = blockIdx.x * 16 + (threadIdx.x >> 4); row < n_rows; row += gridDim.x * 16)
-        agg_fwd_row<FP>(p, wlds, hlds, scratch, mixm, row, lane);
+        agg_fwd_row<FP, K>(p, wlds, hlds, scratch, mixm, row, lane);
 }
 
 // ---------------------------------------------------------------- backward
@@ -143,40 +159,50 @@ __global__ __launch_bounds__(256) void agg_epilogue_kernel(acm_conv_agg_fwd_t p,
 // channel, then alpha / ds); pass 2 walks the channels one at a time, recomputes xhat from
 // (H, mean, rstd), and hands each channel's G straight to the MFMAs.  att_vec / LayerNorm
 // gamma, beta sit in LDS next to the weights ([array][c][m][i], one ds_read_b128 per use).
-template <int FP>
+template <int FP, int K>
 __global__ __launch_bounds__(256, 2) void agg_bwd_kernel(acm_conv_agg_bwd_t p, int n_rows, float* __restrict__ partial) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, m = lane & 15, g = lane >> 4;
     const int F = p.f_out, f_in = p.f_in;
-    const int npg = 3 * f_in * F + 9 * F + 9;
+    const int npg = 3 * f_in * F + 3 * K * F + K * K;
     float* wlds = lds;                           // 3 * FP * 64 floats
-    float* hlds = lds + 3 * FP * 64;             // 9 * 64 floats
-    float* scratch = hlds + 9 * 64 + (threadIdx.x >> 4) * 2 * FP;   // per-group P | x; all dead after the row loop
+    float* hlds = lds + 3 * FP * 64;             // 3 * K * 64 floats
+    float* scratch = hlds + 3 * K * 64 + (threadIdx.x >> 4) * 2 * FP;   // per-group P | x; all dead after the row loop
     stage_weights<FP>(wlds, p.w_low, p.w_high, p.w_mlp, p.ld_w, f_in, F);
-    stage_head_params<3>(hlds, p.att_vec, p.ln_weight, p.ln_bias, p.layernorm, F);
+    stage_head_params<K>(hlds, p.att_vec, p.ln_weight, p.ln_bias, p.layernorm, F);
     __syncthreads();
     f32x4 acc[3][4];
 #pragma unroll
     for (int c = 0; c < 3; ++c)
 #pragma unroll
         for (int t = 0; t < 4; ++t) acc[c][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    float dv[3][4], dgam[3][4], dbet[3][4], dmix[9];
+    float dv[K][4], dgam[K][4], dbet[K][4], dmix[K * K];
 #pragma unroll
-    for (int c = 0; c < 3; ++c)
+    for (int c = 0; c < K; ++c)
 #pragma unroll
         for (int i = 0; i < 4; ++i) dv[c][i] = dgam[c][i] = dbet[c][i] = 0.f;
 #pragma unroll
-    for (int q = 0; q < 9; ++q) dmix[q] = 0.f;
-    float mixm[9];
+    for (int q = 0; q < K * K; ++q) dmix[q] = 0.f;
+    float mixm[K * K];
 #pragma unroll
-    for (int q = 0; q < 9; ++q) mixm[q] = p.att_mix[q];
+    for (int q = 0; q < K * K; ++q) mixm[q] = p.att_mix[q];
     const bool ln = p.layernorm != 0;
 
     for (int r0 = (blockIdx.x * 4 + wv) * 4; r0 < n_rows; r0 += gridDim.x * 16) {
         const int row = r0 + g;
         const bool active = row < n_rows;
         const long rr = active ? row : 0;
-        float H[3][4], dO[4];
+        float H[K][4], dO[4];
+        if (K == 4) {
+            const float dg0 = active ? p.deg[rr] : 0.f;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const bool ok = active && m + 16 * i < F;
+                const int cc = ok ? m + 16 * i : 0;
+                const float v = dg0 * p.ps[(unsigned)rr * (unsigned)p.ld_ps + cc] - p.ss[(unsigned)rr * (unsigned)p.ld_ss + cc];
+                H[K - 1][i] = ok ? fmaxf(v, 0.f) : 0.f;
+            }
+        }
         {
             float p0[4], p1[4], zi[4];
             project<FP>(wlds, scratch, m, p.agg + rr * p.ld_agg, p.xs + rr * p.ld_xs, active, p0, p1, zi);
@@ -192,11 +218,11 @@ __global__ __launch_bounds__(256, 2) void agg_bwd_kernel(acm_conv_agg_bwd_t p, i
         }
         // ---- pass 1: per-channel statistics and the attention scalars
         const int mm = acm_opaque(m);
-        RowHead<3> rh;
-        row_head<3>(hlds, mixm, mm, F, ln, H, rh);
-        row_post_backward<3>(p, rh, H, active, rr, m, F, dO);
-        float ds[3];
-        row_head_backward_scalars<3>(rh, mixm, p.scale, H, dO, ds, dmix);
+        RowHead<K> rh;
+        row_head<K>(hlds, mixm, mm, F, ln, H, rh);
+        row_post_backward<K>(p, rh, H, active, rr, m, F, dO);
+        float ds[K];
+        row_head_backward_scalars<K>(rh, mixm, p.scale, H, dO, ds, dmix);
         // ---- pass 2: one channel at a time -> G_c -> MFMA
         const float Pm = (m < FP) ? scratch[m] : 0.f;            // zero for inactive rows (project() stored zeros)
         const float xm = (m < FP) ? scratch[FP + m] : 0.f;
@@ -205,17 +231,27 @@ __global__ __launch_bounds__(256, 2) void agg_bwd_kernel(acm_conv_agg_bwd_t p, i
             const bool relu_c = (c < 2) ? (p.relu_after != 0) : (p.relu_mlp != 0);
             const float aop = (c == 0) ? Pm : (c == 1 ? xm - Pm : xm);
             float G[4];
-            row_channel_backward<3>(hlds, c, mm, F, ln, p.scale, rh, ds[c], H[c], dO, dv[c], dgam[c], dbet[c], G);
+            row_channel_backward<K>(hlds, c, mm, F, ln, p.scale, rh, ds[c], H[c], dO, dv[c], dgam[c], dbet[c], G);
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
                 const bool keep = active && (m + 16 * t < F) && (!relu_c || H[c][t] > 0.f);
                 acc[c][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(aop, keep ? G[t] : 0.f, acc[c][t], 0, 0, 0);
             }
         }
+        if (K == 4) {                              // structure channel: deg * G_S goes to memory for A_low^T
+            float G[4];
+            row_channel_backward<K>(hlds, K - 1, mm, F, ln, p.scale, rh, ds[K - 1], H[K - 1], dO, dv[K - 1],
+                                    dgam[K - 1], dbet[K - 1], G);
+            const float dg1 = active ? p.deg[rr] : 0.f;
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+                if (active && m + 16 * t < F)
+                    p.g_struc[(unsigned)rr * (unsigned)p.ld_g_struc + m + 16 * t] = H[K - 1][t] > 0.f ? dg1 * G[t] : 0.f;
+        }
     }
     // head-parameter partials: combine the four row-groups of the wave
 #pragma unroll
-    for (int c = 0; c < 3; ++c)
+    for (int c = 0; c < K; ++c)
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             dv[c][i] = acm_cross_row_sum(dv[c][i]);
@@ -223,7 +259,7 @@ __global__ __launch_bounds__(256, 2) void agg_bwd_kernel(acm_conv_agg_bwd_t p, i
             dbet[c][i] = acm_cross_row_sum(dbet[c][i]);
         }
 #pragma unroll
-    for (int q = 0; q < 9; ++q) dmix[q] = acm_cross_row_sum(dmix[q]);
+    for (int q = 0; q < K * K; ++q) dmix[q] = acm_cross_row_sum(dmix[q]);
     __syncthreads();                              // every wave is done with wlds / hlds
     float* slab = lds + wv * npg;
 #pragma unroll
@@ -238,20 +274,20 @@ __global__ __launch_bounds__(256, 2) void agg_bwd_kernel(acm_conv_agg_bwd_t p, i
     if (g == 0) {
         const int base = 3 * f_in * F;
 #pragma unroll
-        for (int c = 0; c < 3; ++c)
+        for (int c = 0; c < K; ++c)
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const int col = m + 16 * i;
                 if (col < F) {
-                    slab[base + (0 * 3 + c) * F + col] = dv[c][i];
-                    slab[base + (1 * 3 + c) * F + col] = dgam[c][i];
-                    slab[base + (2 * 3 + c) * F + col] = dbet[c][i];
+                    slab[base + (0 * K + c) * F + col] = dv[c][i];
+                    slab[base + (1 * K + c) * F + col] = dgam[c][i];
+                    slab[base + (2 * K + c) * F + col] = dbet[c][i];
                 }
             }
     }
     if (lane == 0) {
 #pragma unroll
-        for (int q = 0; q < 9; ++q) slab[3 * f_in * F + 9 * F + q] = dmix[q];
+        for (int q = 0; q < K * K; ++q) slab[3 * f_in * F + 3 * K * F + q] = dmix[q];
     }
     __syncthreads();
     for (int q = threadIdx.x; q < npg; q += 256)
@@ -293,10 +329,14 @@ int check_common(const P* p, const char* who) {
     ACM_REQUIRE(p->ld_w >= p->f_out, ACM_ESHAPE, "%s: ld_w too small", who);
     ACM_REQUIRE(((uintptr_t)p->xs) % 16 == 0 && (p->ld_xs * 4) % 16 == 0 && p->ld_xs >= p->f_pad, ACM_EINVAL,
                 "%s: xs rows must be 16-byte aligned and f_pad long", who);
-    for (int c = 0; c < 3; ++c) {
+    ACM_REQUIRE(p->n_channels == 3 || p->n_channels == 4, ACM_ESHAPE, "%s: n_channels %d", who, p->n_channels);
+    for (int c = 0; c < p->n_channels; ++c) {
         ACM_REQUIRE(p->att_vec[c], ACM_EINVAL, "%s: att_vec[%d] NULL", who, c);
         ACM_REQUIRE(!p->layernorm || (p->ln_weight[c] && p->ln_bias[c]), ACM_EINVAL, "%s: LayerNorm pointers NULL", who);
     }
+    if (p->n_channels == 4)
+        ACM_REQUIRE(p->ps && p->ss && p->deg && p->ld_ps >= p->f_out && p->ld_ss >= p->f_out, ACM_EINVAL,
+                    "%s: structure-channel pointers NULL / leading dimensions too small", who);
     return ACM_OK;
 }
 
@@ -317,15 +357,30 @@ extern "C" int acm_conv_agg_fwd(const acm_csr_t* a, const acm_conv_agg_fwd_t* p,
     // (1) P = A_low X  -> p->agg  (also the tensor saved for the backward)
     st = acm_spmm(a, p->xg, p->ld_xg, p->f_pad, p->agg, p->ld_agg, workspace, workspace_bytes, stream);
     if (st != ACM_OK) return st;
+    // (1b) structure channel: PS = A_low S -> p->ps (F wide; bf16 operand optional)
+    if (p->n_channels == 4) {
+        ACM_REQUIRE(p->sg, ACM_EINVAL, "acm_conv_agg_fwd: sg is NULL");
+        if (p->sg_bf16)
+            st = acm_spmm_bf16_internal(a, p->sg, (long)p->ld_sg, p->f_out, p->ps, (long)p->ld_ps, workspace,
+                                        workspace_bytes, s);
+        else
+            st = acm_spmm(a, (const float*)p->sg, p->ld_sg, p->f_out, p->ps, p->ld_ps, workspace, workspace_bytes, stream);
+        if (st != ACM_OK) return st;
+    }
     // (2) projections + head, row-local
     int grid = (int)((a->n_rows + 15) / 16);
     if (grid > 2048) grid = 2048;
-    if (p->f_pad == 4)
-        hipLaunchKernelGGL((agg_epilogue_kernel<4>), dim3(grid), dim3(256), 0, s, *p, (int)a->n_rows);
-    else if (p->f_pad == 8)
-        hipLaunchKernelGGL((agg_epilogue_kernel<8>), dim3(grid), dim3(256), 0, s, *p, (int)a->n_rows);
-    else
-        hipLaunchKernelGGL((agg_epilogue_kernel<16>), dim3(grid), dim3(256), 0, s, *p, (int)a->n_rows);
+#define ACM_EPI(FPv)                                                                                           \
+    do {                                                                                                       \
+        if (p->n_channels == 3)                                                                                \
+            hipLaunchKernelGGL((agg_epilogue_kernel<FPv, 3>), dim3(grid), dim3(256), 0, s, *p, (int)a->n_rows); \
+        else                                                                                                   \
+            hipLaunchKernelGGL((agg_epilogue_kernel<FPv, 4>), dim3(grid), dim3(256), 0, s, *p, (int)a->n_rows); \
+    } while (0)
+    if (p->f_pad == 4) ACM_EPI(4);
+    else if (p->f_pad == 8) ACM_EPI(8);
+    else ACM_EPI(16);
+#undef ACM_EPI
     ACM_CHECK_HIP(hipGetLastError());
     return ACM_OK;
 }
@@ -334,7 +389,7 @@ extern "C" int acm_conv_agg_bwd_workspace_bytes(int64_t n_rows, int f_in, int f_
     ACM_REQUIRE(bytes, ACM_EINVAL, "acm_conv_agg_bwd_workspace_bytes: NULL argument");
     ACM_REQUIRE(f_in >= 1 && f_in <= 16 && f_out >= 1 && f_out <= 64, ACM_EUNSUPPORTED,
                 "acm_conv_agg_bwd_workspace_bytes: f_in %d f_out %d unsupported", f_in, f_out);
-    const size_t npg = (size_t)3 * f_in * f_out + 9 * (size_t)f_out + 9;
+    const size_t npg = (size_t)3 * f_in * f_out + 12 * (size_t)f_out + 16;      // sized for 4 channels
     *bytes = (size_t)agg_bwd_blocks(n_rows) * npg * sizeof(float);
     return ACM_OK;
 }
@@ -345,26 +400,35 @@ extern "C" int acm_conv_agg_bwd(int64_t n_rows, const acm_conv_agg_bwd_t* p, voi
     int st = check_common(p, "acm_conv_agg_bwd");
     if (st != ACM_OK) return st;
     ACM_REQUIRE(p->grad_out && p->agg && p->d_params, ACM_EINVAL, "acm_conv_agg_bwd: NULL tensor pointer");
+    ACM_REQUIRE(p->n_channels == 3 || (p->g_struc && p->ld_g_struc >= p->f_out), ACM_EINVAL,
+                "acm_conv_agg_bwd: g_struc is NULL / too narrow");
+    ACM_REQUIRE(n_rows * 64 < (int64_t)INT32_MAX, ACM_EUNSUPPORTED, "acm_conv_agg_bwd: too many rows for 32-bit offsets");
     ACM_REQUIRE(((uintptr_t)p->agg) % 16 == 0 && (p->ld_agg * 4) % 16 == 0 && p->ld_agg >= p->f_pad, ACM_EINVAL,
                 "acm_conv_agg_bwd: agg rows must be 16-byte aligned and f_pad long");
     size_t need = 0;
     acm_conv_agg_bwd_workspace_bytes(n_rows, p->f_in, p->f_out, &need);
     ACM_REQUIRE(workspace && workspace_bytes >= need, ACM_ENOMEM, "acm_conv_agg_bwd: workspace %zu B < required %zu B",
                 workspace_bytes, need);
-    const int npg = 3 * p->f_in * p->f_out + 9 * p->f_out + 9;
+    const int K = p->n_channels;
+    const int npg = 3 * p->f_in * p->f_out + 3 * K * p->f_out + K * K;
     const int nblk = agg_bwd_blocks(n_rows);
-    const size_t lds_w = ((size_t)3 * p->f_pad * 64 + 9 * 64 + 32 * p->f_pad) * sizeof(float),
+    const size_t lds_w = ((size_t)3 * p->f_pad * 64 + 3 * K * 64 + 32 * p->f_pad) * sizeof(float),
                  lds_s = (size_t)4 * npg * sizeof(float);
     const size_t lds = lds_w > lds_s ? lds_w : lds_s;
     ACM_REQUIRE(lds <= 64 * 1024, ACM_EUNSUPPORTED, "acm_conv_agg_bwd: %zu B of LDS needed", lds);
     hipStream_t s = (hipStream_t)stream;
     float* partial = (float*)workspace;
-    if (p->f_pad == 4)
-        hipLaunchKernelGGL((agg_bwd_kernel<4>), dim3(nblk), dim3(256), lds, s, *p, (int)n_rows, partial);
-    else if (p->f_pad == 8)
-        hipLaunchKernelGGL((agg_bwd_kernel<8>), dim3(nblk), dim3(256), lds, s, *p, (int)n_rows, partial);
-    else
-        hipLaunchKernelGGL((agg_bwd_kernel<16>), dim3(nblk), dim3(256), lds, s, *p, (int)n_rows, partial);
+#define ACM_BWDK(FPv)                                                                                                  \
+    do {                                                                                                              \
+        if (K == 3)                                                                                                   \
+            hipLaunchKernelGGL((agg_bwd_kernel<FPv, 3>), dim3(nblk), dim3(256), lds, s, *p, (int)n_rows, partial);     \
+        else                                                                                                          \
+            hipLaunchKernelGGL((agg_bwd_kernel<FPv, 4>), dim3(nblk), dim3(256), lds, s, *p, (int)n_rows, partial);     \
+    } while (0)
+    if (p->f_pad == 4) ACM_BWDK(4);
+    else if (p->f_pad == 8) ACM_BWDK(8);
+    else ACM_BWDK(16);
+#undef ACM_BWDK
     ACM_CHECK_HIP(hipGetLastError());
     hipLaunchKernelGGL(reduce_columns_kernel, dim3(npg), dim3(256), 0, s, partial, nblk, npg, p->d_params);
     ACM_CHECK_HIP(hipGetLastError());

@@ -280,7 +280,7 @@ class AcmConvFunction(torch.autograd.Function):
         f_in = x.shape[1]
         # Aggregate-first (A (X W) = (A X) W): legal without a ReLU between projection and
         # filter, worth it when F_in < F, and free of any backward SpMM when x needs no gradient.
-        ctx.agg_first = (k == 3 and not cfg.relu_before and f_in <= 16 and f_in < f and f <= 64 and not sparse_x
+        ctx.agg_first = (not cfg.relu_before and f_in <= 16 and f_in < f and f <= 64 and not sparse_x
                          and not ctx.needs_input_grad[0] and os.environ.get("ACM_AGG_FIRST", "1") != "0")
         four = k == 4
         general = bool(getattr(ops, "general", False))
@@ -339,13 +339,27 @@ class AcmConvFunction(torch.autograd.Function):
             p.out, p.ld_out = out.data_ptr(), out.stride(0)
             p.agg, p.ld_agg = agg.data_ptr(), agg.stride(0)
             p.att = att.data_ptr()
+            p.n_channels = k
+            extra = ()
+            if four:                                  # pre_S = deg * (A_low S) - S: one F-wide gather of S
+                ps = torch.empty(n, f, dtype=_F32, device=dev)
+                if cfg.gather_bf16 and f % 2 == 0 and f > 8:
+                    sgt = cast_bf16(s_gath)
+                    p.sg_bf16 = 1
+                else:
+                    sgt = s_gath
+                p.sg, p.ld_sg = sgt.data_ptr(), sgt.stride(0)
+                p.ss, p.ld_ss = s_local.data_ptr(), s_local.stride(0)
+                p.deg = ops.deg.data_ptr()
+                p.ps, p.ld_ps = ps.data_ptr(), ps.stride(0)
+                extra = (ps, s_local)
             set_post(p)
-            ws = ops.low.workspace(fp)
+            ws = ops.low.workspace(max(fp, f) if four else fp)
             with _device_ctx(dev), _Timed(f"conv_agg_fwd/F{f}k{k}i{f_in}"):
                 st = lib.acm_conv_agg_fwd(ops.low.handle, C.byref(p), _vp(ws), ws.numel() * 4, _stream())
             _lib.check(st, "acm_conv_agg_fwd")
             ctx.ops, ctx.cfg, ctx.f_in = ops, cfg, f_in
-            ctx.save_for_backward(xpad, agg, wl, wh, wm, mix, *vecs, *lnw, *lnb)
+            ctx.save_for_backward(xpad, agg, wl, wh, wm, mix, *vecs, *lnw, *lnb, *extra)
             ctx.mark_non_differentiable(att)
             return out, att
         pre = torch.empty(n, (k - 1) * f, dtype=_F32, device=dev)
@@ -530,19 +544,24 @@ class AcmConvFunction(torch.autograd.Function):
 
 
 def _backward_agg(ctx, grad_out):
-    """Backward of the aggregate-first forward: one row-local kernel, no SpMM, no collective
-    except the all-reduce of the replicated-parameter gradients."""
+    """Backward of the aggregate-first forward: one row-local kernel and no SpMM for the three
+    filterbank channels; the structure channel (k = 4) adds one F-wide transposed product for
+    d struc_low.  Collectives: the all-reduce of the replicated-parameter gradients, plus the
+    all-gather of D*G_S when sharded with k = 4."""
     lib = _lib.load()
     ops, cfg, f_in = ctx.ops, ctx.cfg, ctx.f_in
+    k = cfg.n_channels
+    four = k == 4
     saved = ctx.saved_tensors
     xpad, agg, wl, wh, wm, mix = saved[:6]
-    vecs = list(saved[6:9])
-    lnw = list(saved[9:12]) if cfg.layernorm else []
-    lnb = list(saved[12:15]) if cfg.layernorm else []
+    vecs = list(saved[6:6 + k])
+    nln = k if cfg.layernorm else 0
+    lnw = list(saved[6 + k:6 + k + nln])
+    lnb = list(saved[6 + k + nln:6 + k + 2 * nln])
     dev = xpad.device
     n, f, fp = xpad.shape[0], wl.shape[1], xpad.shape[1]
     grad_out = _as_f32c(grad_out, "grad_out")
-    npg = 3 * f_in * f + 9 * f + 9
+    npg = 3 * f_in * f + 3 * k * f + k * k
     d_params = torch.empty(npg, dtype=_F32, device=dev)
     q = _lib.ConvAggBwd()
     q.f_in, q.f_pad, q.f_out = f_in, fp, f
@@ -555,26 +574,48 @@ def _backward_agg(ctx, grad_out):
     q.att_mix = mix.data_ptr()
     q.d_params = d_params.data_ptr()
     q.post_relu = int(ctx.post_relu)
+    q.n_channels = k
     if ctx.post_scale is not None:
         q.post_scale, q.ld_post_scale = ctx.post_scale.data_ptr(), ctx.post_scale.stride(0)
+    if four:
+        ps, s_local = saved[-2], saved[-1]
+        gs = torch.empty(n, f, dtype=_F32, device=dev)            # D * dL/dpre_S
+        q.ps, q.ld_ps = ps.data_ptr(), ps.stride(0)
+        q.ss, q.ld_ss = s_local.data_ptr(), s_local.stride(0)
+        q.deg = ops.deg.data_ptr()
+        q.g_struc, q.ld_g_struc = gs.data_ptr(), gs.stride(0)
     nbytes = C.c_size_t()
     _lib.check(lib.acm_conv_agg_bwd_workspace_bytes(n, f_in, f, C.byref(nbytes)))
     ws = torch.empty(max(nbytes.value // 4, 1), dtype=_F32, device=dev)
-    with _device_ctx(dev), _Timed(f"conv_agg_bwd/F{f}k3i{f_in}"):
+    with _device_ctx(dev), _Timed(f"conv_agg_bwd/F{f}k{k}i{f_in}"):
         st = lib.acm_conv_agg_bwd(n, C.byref(q), _vp(ws), ws.numel() * 4, _stream())
     _lib.check(st, "acm_conv_agg_bwd")
+    d_struc = None
+    if four:                                  # dS = A_low^T (D G_S) - G_S
+        gsg = _gather_rows(ops, gs)
+        low_t = ops.low_t
+        d_struc = torch.empty(n, f, dtype=_F32, device=dev)
+        ws2 = low_t.workspace(f)
+        with _device_ctx(dev), _Timed(f"spmm_sub/{f}"):
+            st = lib.acm_spmm_sub(low_t.handle, _vp(gsg), gsg.stride(0), f, _vp(gs), gs.stride(0),
+                                  _vp(ops.inv_deg), _vp(d_struc), d_struc.stride(0), _vp(ws2), ws2.numel() * 4,
+                                  _stream())
+        _lib.check(st, "acm_spmm_sub")
     if ops.sharded:
         import torch.distributed as dist
         dist.all_reduce(d_params, group=ops.group)
     wsz = f_in * f
     d_wl, d_wh, d_wm = (d_params[i * wsz:(i + 1) * wsz].view(f_in, f) for i in range(3))
     base = 3 * wsz
-    d_vec = [d_params[base + c * f: base + (c + 1) * f].view(f, 1) for c in range(3)]
-    d_lnw = [d_params[base + (3 + c) * f: base + (4 + c) * f] for c in range(3)] if cfg.layernorm else [None] * 3
-    d_lnb = [d_params[base + (6 + c) * f: base + (7 + c) * f] for c in range(3)] if cfg.layernorm else [None] * 3
-    d_mix = d_params[base + 9 * f:].view(3, 3)
-    return (None, d_wl, d_wh, d_wm, d_vec[0], d_vec[1], d_vec[2], None, None, d_mix,
-            d_lnw[0], d_lnw[1], d_lnw[2], None, d_lnb[0], d_lnb[1], d_lnb[2], None, None, None, None, None)
+    pad = [None] * (4 - k)
+    d_vec = [d_params[base + c * f: base + (c + 1) * f].view(f, 1) for c in range(k)] + pad
+    if cfg.layernorm:
+        d_lnw = [d_params[base + (k + c) * f: base + (k + 1 + c) * f] for c in range(k)] + pad
+        d_lnb = [d_params[base + (2 * k + c) * f: base + (2 * k + 1 + c) * f] for c in range(k)] + pad
+    else:
+        d_lnw = d_lnb = [None] * 4
+    d_mix = d_params[base + 3 * k * f:].view(k, k)
+    return (None, d_wl, d_wh, d_wm, *d_vec, d_struc, d_mix, *d_lnw, *d_lnb, None, None, None, None)
 
 
 AcmConvFunction._backward_agg = staticmethod(_backward_agg)

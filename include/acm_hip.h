@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define ACM_ABI_VERSION 4
+#define ACM_ABI_VERSION 5
 
 typedef enum {
     ACM_OK = 0,
@@ -124,6 +124,12 @@ int acm_spmm(const acm_csr_t* a, const float* G, int64_t ldg, int width,
 int acm_spmm_v(const acm_csr_t* a, const float* vals, const float* G, int64_t ldg, int width,
                float* Y, int64_t ldy, int relu, void* workspace, size_t workspace_bytes,
                acm_stream_t stream);
+
+/* Y = A * G - row_scale[r] * SUB[r, :]  (row_scale may be NULL = 1).  The gradient of the structure parameter in
+ * the aggregate-first form: d struc_low = A_low^T (D G_S) - G_S with G = D G_S, SUB = D G_S, row_scale = 1/d. */
+int acm_spmm_sub(const acm_csr_t* a, const float* G, int64_t ldg, int width, const float* sub, int64_t ld_sub,
+                 const float* row_scale, float* Y, int64_t ldy, void* workspace, size_t workspace_bytes,
+                 acm_stream_t stream);
 
 /* fp32 -> bf16 (round to nearest even) copy of a [n_rows, n_cols] matrix; dst leading dimension in elements. */
 int acm_cast_bf16(int64_t n_rows, int64_t n_cols, const float* src, int64_t ld_src,
@@ -260,11 +266,14 @@ int acm_conv_bwd_spmm(const acm_csr_t* a_low_t, const acm_conv_bwd_spmm_t* p,
  *   pre_L = P W_L      pre_H = (X - P) W_H      Z_I = X W_I     (in registers, per row)
  *   ... then the same ReLU / LayerNorm / mixing head as acm_conv_fwd.
  *
- * Same reference call sites as acm_gemm + acm_conv_fwd (G:87-116) in one launch;
- * equal to them up to fp32 re-association.  3-channel layers only, f_in <= 16,
- * and only when the layer input needs no gradient (first layer): the backward
- * then needs no transposed SpMM at all, dW_L = P^T G_L, dW_H = (X - P)^T G_H,
+ * Same reference call sites as acm_gemm + acm_conv_fwd (G:87-116);
+ * equal to them up to fp32 re-association.  f_in <= 16, F <= 64, and only when
+ * the layer input needs no gradient (first layer): the backward then needs no
+ * transposed SpMM for the low/high channels, dW_L = P^T G_L, dW_H = (X - P)^T G_H,
  * dW_I = X^T G_I are row-local reductions (acm_conv_agg_bwd).
+ * With the structure channel (n_channels = 4) the parameter S is still gathered
+ * F-wide (PS = A_low S, pre_S = deg * PS - S_self) -- 72 floats per edge instead of
+ * 192 -- and its gradient needs one F-wide transposed product (acm_spmm_sub).
  */
 typedef struct {
     int32_t f_in, f_pad;       /* f_pad = row length (floats) of xg / xs / agg: 4, 8 or 16, >= f_in; padding is zero */
@@ -282,6 +291,13 @@ typedef struct {
     float* att;                        /* [n_rows, 4]                                          */
     const float* post_scale; int64_t ld_post_scale;   /* fused post-op, as in acm_conv_fwd_t   */
     int32_t post_relu;
+    /* structure channel (n_channels = 4; att_mix is then 4 x 4, scale 1) */
+    int32_t n_channels;                /* 3 or 4                                               */
+    const void*  sg; int64_t ld_sg;    /* struc_low rows indexed by column id: fp32, or bf16 (acm_cast_bf16) if sg_bf16 */
+    int32_t sg_bf16;
+    const float* ss; int64_t ld_ss;    /* struc_low rows of the local nodes (fp32)             */
+    const float* deg;                  /* d_i = rowsum(I + A), local rows                      */
+    float* ps; int64_t ld_ps;          /* [n_rows, F]  A_low * S, saved for backward           */
 } acm_conv_agg_fwd_t;
 
 int acm_conv_agg_fwd(const acm_csr_t* a_low, const acm_conv_agg_fwd_t* p,
@@ -298,11 +314,16 @@ typedef struct {
     const float* ln_weight[4];
     const float* ln_bias[4];
     const float* att_mix;
-    /* output: one flat vector
-     *   [ dW_low : f_in x F ][ dW_high ][ dW_mlp ][ d att_vec : 3 x F ][ d ln_weight : 3 x F ][ d ln_bias : 3 x F ][ d att_mix : 3 x 3 ] */
+    /* output: one flat vector (k = n_channels)
+     *   [ dW_low : f_in x F ][ dW_high ][ dW_mlp ][ d att_vec : k x F ][ d ln_weight : k x F ][ d ln_bias : k x F ][ d att_mix : k x k ] */
     float* d_params;
     const float* post_scale; int64_t ld_post_scale;   /* post-op of the forward                */
     int32_t post_relu;
+    int32_t n_channels;                /* 3 or 4                                               */
+    const float* ps; int64_t ld_ps;    /* A_low * S saved by the forward                       */
+    const float* ss; int64_t ld_ss;    /* struc_low rows (local)                               */
+    const float* deg;
+    float* g_struc; int64_t ld_g_struc;   /* out: deg_i * dL/dpre_S  (feeds acm_spmm_sub over A_low^T) */
 } acm_conv_agg_bwd_t;
 
 int acm_conv_agg_bwd_workspace_bytes(int64_t n_rows, int f_in, int f_out, size_t* bytes);

@@ -110,7 +110,7 @@ class FakeLib:
 
     # ---- plumbing ---------------------------------------------------------
     def acm_version(self):
-        return 4
+        return 5
 
     def acm_last_error(self):
         return self._err
@@ -325,50 +325,74 @@ class FakeLib:
 
     def acm_conv_agg_fwd(self, h, pp, ws, wsb, stream):
         a, p = self._get(h), pp._obj
-        n = a.n_rows
+        n, k = a.n_rows, p.n_channels
         F, fi, fp, x, W = self._agg_common(p, n)
         P = a.dense_mul(_view(p.xg, a.n_cols, fp, p.ld_xg))[:, :fi]
         raw = [P @ W[0], (x - P) @ W[1], x @ W[2]]
         relu = [p.relu_after, p.relu_after, p.relu_mlp]
+        if k == 4:
+            if p.sg_bf16:
+                sg = (_view(p.sg, a.n_cols, F, p.ld_sg, np.uint16).astype(np.uint32) << 16).view(np.float32)
+            else:
+                sg = _view(p.sg, a.n_cols, F, p.ld_sg)
+            PS = a.dense_mul(sg)
+            _view(p.ps, n, F, p.ld_ps)[...] = PS
+            PS = _view(p.ps, n, F, p.ld_ps).astype(np.float64)
+            raw.append(_vec(p.deg, n).astype(np.float64)[:, None] * PS - _view(p.ss, n, F, p.ld_ss))
+            relu.append(1)
         H = [np.maximum(r, 0) if f else r for r, f in zip(raw, relu)]
-        vecs, lnw, lnb, mix = self._params(p, 3, F, p.layernorm)
-        hd = _head(H, 3, p.layernorm, vecs, lnw, lnb, mix)
-        _view(p.out, n, F, p.ld_out)[...] = _post_fwd(p, p.scale * sum(hd["alpha"][:, c:c + 1] * H[c] for c in range(3)), n, F)
+        vecs, lnw, lnb, mix = self._params(p, k, F, p.layernorm)
+        hd = _head(H, k, p.layernorm, vecs, lnw, lnb, mix)
+        _view(p.out, n, F, p.ld_out)[...] = _post_fwd(p, p.scale * sum(hd["alpha"][:, c:c + 1] * H[c] for c in range(k)), n, F)
         agg = _view(p.agg, n, fp, p.ld_agg)
         agg[...] = 0
         agg[:, :fi] = P
         att = _view(p.att, n, 4, 4)
         att[...] = 0
-        att[:, :3] = hd["alpha"]
+        att[:, :k] = hd["alpha"]
         return 0
 
     def acm_conv_agg_bwd(self, n, qq, ws, wsb, stream):
         q = qq._obj
+        k = q.n_channels
         F, fi, fp, x, W = self._agg_common(q, n)
         P = _view(q.agg, n, fp, q.ld_agg).astype(np.float64)[:, :fi]
         A = [P, x - P, x]
         raw = [A[c] @ W[c] for c in range(3)]
         relu = [q.relu_after, q.relu_after, q.relu_mlp]
+        if k == 4:
+            deg = _vec(q.deg, n).astype(np.float64)[:, None]
+            raw.append(deg * _view(q.ps, n, F, q.ld_ps).astype(np.float64) - _view(q.ss, n, F, q.ld_ss))
+            relu.append(1)
         pos = [(r > 0) if f else np.ones_like(r, bool) for r, f in zip(raw, relu)]
         H = [np.where(m, r, 0.0) for r, m in zip(raw, pos)]
-        vecs, lnw, lnb, mix = self._params(q, 3, F, q.layernorm)
-        hd = _head(H, 3, q.layernorm, vecs, lnw, lnb, mix)
+        vecs, lnw, lnb, mix = self._params(q, k, F, q.layernorm)
+        hd = _head(H, k, q.layernorm, vecs, lnw, lnb, mix)
         dO = _view(q.grad_out, n, F, q.ld_grad_out).astype(np.float64)
-        dO = _post_bwd(q, dO, q.scale * sum(hd["alpha"][:, c:c + 1] * H[c] for c in range(3)), n, F)
-        dH, d_vec, d_lnw, d_lnb, d_mix = _head_backward(H, hd, dO, 3, q.layernorm, vecs, lnw, mix, q.scale)
+        dO = _post_bwd(q, dO, q.scale * sum(hd["alpha"][:, c:c + 1] * H[c] for c in range(k)), n, F)
+        dH, d_vec, d_lnw, d_lnb, d_mix = _head_backward(H, hd, dO, k, q.layernorm, vecs, lnw, mix, q.scale)
         G = [np.where(m, d, 0.0) for d, m in zip(dH, pos)]
-        npg = 3 * fi * F + 9 * F + 9
+        if k == 4:
+            _view(q.g_struc, n, F, q.ld_g_struc)[...] = deg * G[3]
+        npg = 3 * fi * F + 3 * k * F + k * k
         out = _vec(q.d_params, npg)
         out[...] = 0
         for c in range(3):
             out[c * fi * F:(c + 1) * fi * F] = (A[c].T @ G[c]).reshape(-1)
         base = 3 * fi * F
-        for c in range(3):
+        for c in range(k):
             out[base + c * F: base + (c + 1) * F] = d_vec[c]
             if q.layernorm:
-                out[base + (3 + c) * F: base + (4 + c) * F] = d_lnw[c]
-                out[base + (6 + c) * F: base + (7 + c) * F] = d_lnb[c]
-        out[base + 9 * F:] = d_mix.reshape(-1)
+                out[base + (k + c) * F: base + (k + 1 + c) * F] = d_lnw[c]
+                out[base + (2 * k + c) * F: base + (2 * k + 1 + c) * F] = d_lnb[c]
+        out[base + 3 * k * F:] = d_mix.reshape(-1)
+        return 0
+
+    def acm_spmm_sub(self, h, g, ldg, width, sub, ld_sub, row_scale, y, ldy, ws, wsb, stream):
+        a = self._get(h)
+        out = a.dense_mul(_view(g, a.n_cols, width, ldg))
+        rs = _vec(row_scale, a.n_rows).astype(np.float64)[:, None] if row_scale else 1.0
+        _view(y, a.n_rows, width, ldy)[...] = out - rs * _view(sub, a.n_rows, width, ld_sub)
         return 0
 
 

@@ -62,6 +62,8 @@ def _run_both(model_type, variant, structure_info, ln, n, f_in, f_out, seed, x_g
     assert float((out.detach().cpu() - ref.detach()).abs().max()) < 2e-5 * scale
     att = torch.cat([layer.att_low, layer.att_high, layer.att_mlp], 1).cpu()
     assert float((att - ref_att[:, :3].detach()).abs().max()) < 2e-5
+    if structure_info:
+        assert float((layer.att_struc_vec_low.cpu() - ref_att[:, 3:4].detach()).abs().max()) < 2e-5
     for k, p in layer.named_parameters():
         rg = params[k].grad
         if rg is None:
@@ -99,12 +101,63 @@ def test_aggregate_first_matches_oracle_and_literal(model_type, ln, f_in, f_out,
     assert float((a - b).abs().max()) < 2e-5 * max(1.0, float(b.abs().max()))
 
 
+AGG_STRUC_CASES = [(True, 7, 64), (False, 7, 64), (True, 3, 24), (True, 16, 40), (True, 4, 5), (False, 12, 33)]
+
+
+@pytest.mark.parametrize("ln,f_in,f_out", AGG_STRUC_CASES)
+def test_aggregate_first_with_structure_channel(ln, f_in, f_out, monkeypatch):
+    """ABI v5: four channels in aggregate-first order (pre_S = deg (A_low S) - S; dS through acm_spmm_sub)."""
+    from acm_gnn_amd import functional as AF
+    timer = AF.KernelTimer()
+    AF.set_kernel_timer(timer)
+    try:
+        a = _run_both("acmgcnp", 0, 1, ln, 300, f_in, f_out, 13, False, monkeypatch, agg=True)
+        used = set(k.split("/")[0] for k in timer.events)
+        assert {"conv_agg_fwd", "conv_agg_bwd", "spmm_sub"} <= used and "conv_fwd" not in used, used
+        timer.events.clear()
+        b = _run_both("acmgcnp", 0, 1, ln, 300, f_in, f_out, 13, False, monkeypatch, agg=False)
+        used = set(k.split("/")[0] for k in timer.events)
+        assert "conv_fwd" in used and "conv_agg_fwd" not in used, used
+    finally:
+        AF.set_kernel_timer(None)
+    assert float((a - b).abs().max()) < 2e-5 * max(1.0, float(b.abs().max()))
+
+
+def test_spmm_sub_entry_point():
+    """Y = A G - row_scale * SUB, against scipy, including split long rows."""
+    import ctypes as C
+    from acm_gnn_amd import _lib
+    from acm_gnn_amd.graph import CsrGraph
+    rng = np.random.default_rng(0)
+    adj = _graph(700, 4, density=0.02)
+    a = sp.csr_matrix(adj, dtype=np.float32)
+    a.data = rng.standard_normal(a.nnz).astype(np.float32)
+    g = CsrGraph.from_scipy(a, DEV, chunk=64)
+    lib = _lib.load()
+    for width in (5, 24, 64, 100):
+        G = rng.standard_normal((700, width)).astype(np.float32)
+        S = rng.standard_normal((700, width)).astype(np.float32)
+        rs = rng.uniform(0.1, 2.0, 700).astype(np.float32)
+        for scale in (rs, None):
+            Gd, Sd = torch.from_numpy(G).to(DEV), torch.from_numpy(S).to(DEV)
+            rd = torch.from_numpy(scale).to(DEV) if scale is not None else None
+            Y = torch.empty(700, width, device=DEV)
+            ws = g.workspace(width)
+            st = lib.acm_spmm_sub(g.handle, Gd.data_ptr(), width, width, Sd.data_ptr(), width,
+                                  rd.data_ptr() if rd is not None else None, Y.data_ptr(), width, ws.data_ptr(),
+                                  ws.numel() * 4, torch.cuda.current_stream().cuda_stream)
+            _lib.check(st, "acm_spmm_sub")
+            ref = a.astype(np.float64) @ G.astype(np.float64) - (scale[:, None] if scale is not None else 1.0) * S
+            err = np.abs(Y.cpu().numpy() - ref).max()
+            assert err < 2e-5 * max(1.0, np.abs(ref).max()), (width, err)
+
+
 def test_aggregate_first_not_used_when_illegal(monkeypatch):
-    """ACMII (ReLU between projection and filter), 4 channels, or an input that needs a
-    gradient must take the literal path."""
+    """ACMII (ReLU between projection and filter) or an input that needs a gradient must take
+    the literal path."""
     from acm_gnn_amd import functional as AF
     for kwargs in (dict(model_type="acmgcn", variant=1, structure_info=0, x_grad=False),
-                   dict(model_type="acmgcnp", variant=0, structure_info=1, x_grad=False),
+                   dict(model_type="acmgcnp", variant=1, structure_info=1, x_grad=False),
                    dict(model_type="acmgcn", variant=0, structure_info=0, x_grad=True)):
         timer = AF.KernelTimer()
         AF.set_kernel_timer(timer)
@@ -131,7 +184,7 @@ def test_real_structures(name, f_out, s, monkeypatch):
     n = int(g["n"])
     adj = sp.csr_matrix((np.ones(len(g["adj_un_indices"])), g["adj_un_indices"], g["adj_un_indptr"]), shape=(n, n))
     _run_both("acmgcnp", 0, s, True, n, 24, f_out, 2, True, monkeypatch, agg=False, adj=adj)
-    _run_both("acmgcnp", 0, 0, True, n, 7, 64, 2, False, monkeypatch, agg=True, adj=adj)
+    _run_both("acmgcnp", 0, s, True, n, 7, 64, 2, False, monkeypatch, agg=True, adj=adj)
 
 
 @pytest.mark.parametrize("model_type,variant,s,f_out", [("acmgcn", 0, 0, 64), ("acmgcnp", 1, 1, 64), ("acmgcnp", 0, 0, 5)])

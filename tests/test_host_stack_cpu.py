@@ -83,11 +83,12 @@ def test_model_host_path_against_golden(path, monkeypatch):
 
 def test_aggregate_first_dispatch_rules(monkeypatch):
     """First-layer shape (F_in = 7 < F = 64, no input gradient) takes the aggregate-first entry
-    points; ACMII / structure channel / differentiable input take the literal ones."""
+    points, with or without the structure channel; ACMII / differentiable input take the literal ones."""
     fake = fake_lib.install(monkeypatch)
     from acm_gnn_amd import GraphConvolution
     calls = []
-    for name in ("acm_conv_fwd", "acm_conv_agg_fwd", "acm_conv_agg_bwd", "acm_conv_bwd_spmm", "acm_gemm"):
+    for name in ("acm_conv_fwd", "acm_conv_agg_fwd", "acm_conv_agg_bwd", "acm_conv_bwd_spmm", "acm_gemm",
+                 "acm_spmm_sub"):
         orig = getattr(fake, name)
         monkeypatch.setattr(fake, name, (lambda o, n: lambda *a: (calls.append(n), o(*a))[1])(orig, name))
     low, high, un, _ = graph_tensors("geometric")
@@ -102,11 +103,53 @@ def test_aggregate_first_dispatch_rules(monkeypatch):
 
     assert run("acmgcnp", 0, 0, False) == {"acm_conv_agg_fwd", "acm_conv_agg_bwd"}
     assert "acm_conv_agg_fwd" not in run("acmgcnp", 1, 0, False)
-    assert "acm_conv_agg_fwd" not in run("acmgcnp", 0, 1, False)
+    assert run("acmgcnp", 0, 1, False) == {"acm_conv_agg_fwd", "acm_conv_agg_bwd", "acm_spmm_sub"}
     assert "acm_conv_agg_fwd" not in run("acmgcnp", 0, 0, True)
     assert "acm_conv_agg_fwd" not in run("acmgcnp", 0, 0, False, f_in=64, f_out=2)
     monkeypatch.setenv("ACM_AGG_FIRST", "0")
     assert run("acmgcnp", 0, 0, False) == {"acm_gemm", "acm_conv_fwd", "acm_conv_bwd_spmm"}
+
+
+@pytest.mark.parametrize("ln", [False, True])
+@pytest.mark.parametrize("f_in,f_out", [(7, 64), (3, 24), (16, 40)])
+def test_aggregate_first_with_structure_equals_literal_and_oracle(f_in, f_out, ln, monkeypatch):
+    """ABI v5: the 4-channel aggregate-first path (pre_S = deg * (A_low S) - S, dS = A_low^T (D G_S) - G_S)
+    against the literal 3F-wide path and the oracle, forward and every parameter gradient."""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..", "oracle"))
+    import acm_oracle as oracle
+    fake_lib.install(monkeypatch)
+    from acm_gnn_amd import GraphConvolution
+    low, high, un, _ = graph_tensors("geometric")
+    n = low.shape[0]
+    torch.manual_seed(5)
+    layer = GraphConvolution(f_in, f_out, n, "acmgcnp", variant=0, structure_info=1, attn_layernorm=ln)
+    x = torch.randn(n, f_in)
+    go = torch.randn(n, f_out)
+    mask = (torch.rand(n, f_out) > 0.3).float() / 0.7
+
+    def run(agg):
+        monkeypatch.setenv("ACM_AGG_FIRST", "1" if agg else "0")
+        layer.zero_grad()
+        out = layer(x, low, high, un, post_relu=True, post_scale=mask)
+        out.backward(go)
+        return out.detach().clone(), {k: v.grad.clone() for k, v in layer.named_parameters() if v.grad is not None}, \
+            layer.att_struc_vec_low.detach().clone() if hasattr(layer, "att_struc_vec_low") else None
+
+    out_a, g_a, att_a = run(True)
+    out_l, g_l, att_l = run(False)
+    _close(out_a, out_l.numpy(), "out", **FWD)
+    assert set(g_a) == set(g_l) and "struc_low" in g_a
+    for k in g_l:
+        _close(g_a[k], g_l[k].numpy(), k)
+    params = {k: v.detach().clone().double().requires_grad_(True) for k, v in layer.named_parameters()}
+    ref = oracle.layer_forward(params, x.double(), low.double(), high.double(), un.double(), model_type="acmgcnp",
+                               variant=0, structure_info=1, attn_layernorm=ln)
+    ref = torch.relu(ref) * mask.double()
+    ref.backward(go.double())
+    _close(out_a, ref.detach().float().numpy(), "out vs oracle", **FWD)
+    for k in g_a:
+        _close(g_a[k], params[k].grad.float().numpy(), k + " vs oracle")
 
 
 def test_operator_cache_and_filter_verification(monkeypatch):
