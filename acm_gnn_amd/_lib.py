@@ -14,7 +14,7 @@ c_i32p = C.POINTER(C.c_int32)
 
 ACM_OK = 0
 STATUS_NAMES = {1: "ACM_EINVAL", 2: "ACM_ESHAPE", 3: "ACM_EHIP", 4: "ACM_EUNSUPPORTED", 5: "ACM_ENOMEM"}
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 # every symbol include/acm_hip.h declares
 EXPORTED_SYMBOLS = (
@@ -22,7 +22,7 @@ EXPORTED_SYMBOLS = (
     "acm_csr_destroy", "acm_csr_info", "acm_spmm_workspace_bytes", "acm_gemm_workspace_bytes",
     "acm_gemm", "acm_spmm", "acm_spmm_v", "acm_spmm_sub", "acm_cast_bf16", "acm_conv_fwd", "acm_conv_bwd_local_workspace_bytes",
     "acm_conv_bwd_local", "acm_conv_bwd_spmm", "acm_conv_agg_fwd", "acm_conv_agg_bwd_workspace_bytes",
-    "acm_conv_agg_bwd", "acm_nll_loss_workspace_bytes", "acm_nll_loss",
+    "acm_conv_agg_bwd", "acm_nll_loss_workspace_bytes", "acm_nll_loss", "acm_adam_step",
 )
 
 
@@ -117,6 +117,16 @@ class ConvAggBwd(C.Structure):
                 ("g_struc", C.c_void_p), ("ld_g_struc", C.c_int64)]
 
 
+class AdamTensor(C.Structure):
+    _fields_ = [("param", C.c_void_p), ("grad", C.c_void_p), ("exp_avg", C.c_void_p), ("exp_avg_sq", C.c_void_p),
+                ("step", C.c_void_p), ("numel", C.c_int64)]
+
+
+class AdamConfig(C.Structure):
+    _fields_ = [("lr", C.c_double), ("beta1", C.c_double), ("beta2", C.c_double), ("eps", C.c_double),
+                ("weight_decay", C.c_double), ("decoupled", C.c_int32)]
+
+
 _lib = None
 _lock = threading.Lock()
 
@@ -138,6 +148,7 @@ def _declare(lib):
     lib.acm_gemm.argtypes = [i32, i32, i64, i64, i64, vp, i64, vp, i64, vp, i64, i32, vp, sz, vp]
     lib.acm_spmm.argtypes = [vp, vp, i64, i32, vp, i64, vp, sz, vp]
     lib.acm_spmm_v.argtypes = [vp, vp, vp, i64, i32, vp, i64, i32, vp, sz, vp]
+    lib.acm_adam_step.argtypes = [i32, vp, vp, vp]
     lib.acm_spmm_sub.argtypes = [vp, vp, i64, i32, vp, i64, vp, vp, i64, vp, sz, vp]
     lib.acm_cast_bf16.argtypes = [i64, i64, vp, i64, vp, i64, vp]
     lib.acm_conv_fwd.argtypes = [vp, C.POINTER(ConvFwd), vp, sz, vp]

@@ -1,0 +1,86 @@
+"""Fused Adam / AdamW: the optimizer update that closes the reference's training step
+(ACM-Geometric/train.py:113-119 construct torch.optim.Adam / AdamW, :137 ``optimizer.step()``;
+ACM-Pytorch/train.py:70-84, utils.py:572) as ONE kernel launch per 32 parameter tensors
+(``acm_adam_step``) instead of torch's ~80 launches for the 26 parameters of the two-layer model.
+
+Same constructor arguments, update formulas, ``state`` keys (``step`` / ``exp_avg`` /
+``exp_avg_sq``, with ``step`` a device fp32 scalar as in torch's ``capturable=True`` mode) and
+``state_dict`` layout as torch.optim.Adam / AdamW, so checkpoints interchange.  The launch reads
+no host memory at run time, so a step that uses it can be captured in a hipGraph.  No CPU path.
+"""
+import ctypes as C
+
+import torch
+
+from . import _lib
+from .graph import _device_ctx, _require_cuda, _stream
+
+
+class _FusedAdamBase(torch.optim.Optimizer):
+    _decoupled = False
+
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, amsgrad=False,
+                 maximize=False, **ignored):
+        if amsgrad or maximize:
+            raise NotImplementedError("FusedAdam: amsgrad / maximize are not implemented (the reference never uses them)")
+        if isinstance(lr, torch.Tensor):
+            raise TypeError("FusedAdam: lr must be a Python number (it is a kernel argument)")
+        if lr < 0 or eps < 0 or not 0 <= betas[0] < 1 or not 0 <= betas[1] < 1 or weight_decay < 0:
+            raise ValueError("FusedAdam: invalid hyper-parameter")
+        # torch-only switches (foreach / fused / capturable / differentiable) are accepted and meaningless here
+        super().__init__(params, dict(lr=lr, betas=tuple(betas), eps=eps, weight_decay=weight_decay))
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        loss = None
+        if closure is not None:
+            with torch.enable_grad():
+                loss = closure()
+        lib = _lib.load()
+        for group in self.param_groups:
+            live = [p for p in group["params"] if p.grad is not None]
+            if not live:
+                continue
+            entries = (_lib.AdamTensor * len(live))()
+            keep = []
+            for e, p in zip(entries, live):
+                _require_cuda(p, "parameter")
+                g = p.grad
+                if g.is_sparse:
+                    raise RuntimeError("FusedAdam does not support sparse gradients")
+                if p.dtype != torch.float32 or not p.is_contiguous():
+                    raise TypeError("FusedAdam: parameters must be contiguous fp32")
+                if g.dtype != torch.float32 or not g.is_contiguous():
+                    g = g.to(torch.float32).contiguous()
+                    keep.append(g)
+                st = self.state[p]
+                if len(st) == 0:
+                    st["step"] = torch.zeros((), dtype=torch.float32, device=p.device)
+                    st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                    st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                e.param, e.grad = p.data_ptr(), g.data_ptr()
+                e.exp_avg, e.exp_avg_sq, e.step = st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr(), st["step"].data_ptr()
+                e.numel = p.numel()
+            cfg = _lib.AdamConfig(float(group["lr"]), float(group["betas"][0]), float(group["betas"][1]),
+                                  float(group["eps"]), float(group["weight_decay"]), int(self._decoupled))
+            dev = live[0].device
+            if any(p.device != dev for p in live):
+                raise RuntimeError("FusedAdam: one param group must live on one device")
+            with _device_ctx(dev):
+                status = lib.acm_adam_step(len(live), C.cast(entries, C.c_void_p), C.byref(cfg), _stream())
+            _lib.check(status, "acm_adam_step")
+            del keep
+        return loss
+
+
+class FusedAdam(_FusedAdamBase):
+    """torch.optim.Adam (weight decay added to the gradient)."""
+    _decoupled = False
+
+
+class FusedAdamW(_FusedAdamBase):
+    """torch.optim.AdamW (decoupled weight decay; default 1e-2 as in torch)."""
+    _decoupled = True
+
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2, **kw):
+        super().__init__(params, lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, **kw)

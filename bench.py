@@ -44,6 +44,8 @@ def parse():
     ap.add_argument("--weight_decay", type=float, default=1e-3)
     ap.add_argument("--uniform", action="store_true", help="uniform random graph instead of power-law")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--optimizer", default="fused", choices=["fused", "torch"],
+                    help="AdamW update: acm_adam_step (one launch) or torch.optim.AdamW (~80 launches)")
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--graph", type=int, default=-1,
                     help="1 (default): also time hipGraph replays of the captured step and report those; 0: eager only")
@@ -133,7 +135,10 @@ def main():
     model = acm_gnn_amd.GCN(x.shape[1], args.hidden, n_cls, 2, e - b, args.dropout, args.method,
                             args.structure_info, variant=bool(args.variant), attn_layernorm=True).to(dev)
     use_graph = True if args.graph < 0 else bool(args.graph)
-    opt = torch.optim.AdamW(model.parameters(), lr=args.lr, weight_decay=args.weight_decay, capturable=use_graph)
+    if args.optimizer == "fused":               # acm_adam_step: the AdamW update as one launch
+        opt = acm_gnn_amd.FusedAdamW(model.parameters(), lr=args.lr, weight_decay=args.weight_decay)
+    else:
+        opt = torch.optim.AdamW(model.parameters(), lr=args.lr, weight_decay=args.weight_decay, capturable=use_graph)
     # mean NLL over the (global) training set; rows a rank does not own have weight 0
     w = T.row_weights(tr_loc, e - b, n_train_total=n_train, device=dev)
     step = T.TrainStep(model, opt, x, ops, y, w, use_graph=False)
@@ -203,7 +208,7 @@ def main():
             "config": {"workload": f"{args.dataset}-shaped Chung-Lu graph: {n_real} nodes, {adj.nnz // 2} undirected "
                                    f"edges, nnz(A_low)={nnz}, F_in={x.shape[1]}, hidden={args.hidden}, classes={n_cls}; "
                                    f"2-layer {args.method} (variant={args.variant}, structure_info={args.structure_info}, "
-                                   f"attention LayerNorm on), dropout {args.dropout}, AdamW; "
+                                   f"attention LayerNorm on), dropout {args.dropout}, AdamW ({args.optimizer}); "
                                    "step = fwd + NLL loss + bwd + optimizer update",
                        "parallelism": f"csr-row-shard x{world}" if world > 1 else "single-gpu",
                        "node_order": args.node_order, "launch": launch,

@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define ACM_ABI_VERSION 5
+#define ACM_ABI_VERSION 6
 
 typedef enum {
     ACM_OK = 0,
@@ -344,6 +344,36 @@ int acm_nll_loss(int64_t n_rows, int n_classes, const float* logits, int64_t ld_
                  const int64_t* labels, const float* row_weight,
                  float* loss, float* dlogits, int64_t ld_dlogits,
                  void* workspace, size_t workspace_bytes, acm_stream_t stream);
+
+/* ------------------------------------------------ fused optimizer update --
+ * Adam / AdamW over a list of fp32 parameter tensors in one launch per 32 tensors: the update of
+ * torch.optim.Adam / AdamW that closes the reference's training step (ACM-Geometric/train.py:113-119,137;
+ * ACM-Pytorch/train.py:70-84, utils.py:572), same formulas in the same order:
+ *     step += 1
+ *     decoupled (AdamW): p *= 1 - lr * wd          else (Adam): g += wd * p
+ *     m += (1 - beta1) * (g - m);   v = beta2 * v + (1 - beta2) * g * g
+ *     p -= lr / (1 - beta1^step) * m / (sqrt(v) / sqrt(1 - beta2^step) + eps)
+ * `tensors` is a HOST array (its contents are copied into the kernel arguments, so a captured launch
+ * replays without touching host memory); every pointer inside is device memory, `step` is one fp32
+ * scalar per tensor (torch's capturable layout), incremented on the device.  amsgrad / maximize are not
+ * provided (the reference never enables them).
+ */
+typedef struct {
+    float*       param;
+    const float* grad;
+    float*       exp_avg;
+    float*       exp_avg_sq;
+    float*       step;
+    int64_t      numel;
+} acm_adam_tensor_t;
+
+typedef struct {
+    double  lr, beta1, beta2, eps, weight_decay;
+    int32_t decoupled;                 /* 1 = AdamW, 0 = Adam (L2 added to the gradient) */
+} acm_adam_config_t;
+
+int acm_adam_step(int32_t n_tensors, const acm_adam_tensor_t* tensors, const acm_adam_config_t* cfg,
+                  acm_stream_t stream);
 
 #ifdef __cplusplus
 }

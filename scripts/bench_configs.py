@@ -70,7 +70,7 @@ def run(name, cfg, steps=20):
     torch.manual_seed(0)
     model = acm_gnn_amd.GCN(f_in, 64, classes, 2, n, cfg["dropout"], cfg["method"], cfg["s"],
                             variant=bool(cfg["variant"]), attn_layernorm=True).to(DEV)
-    opt = torch.optim.Adam(model.parameters(), lr=0.01, weight_decay=1e-4, capturable=True)
+    opt = acm_gnn_amd.FusedAdam(model.parameters(), lr=0.01, weight_decay=1e-4)
     w = T.row_weights(torch.from_numpy(tr).to(DEV), n)
     step = T.TrainStep(model, opt, x, ops, y, w)
     for _ in range(5):

@@ -110,7 +110,7 @@ class FakeLib:
 
     # ---- plumbing ---------------------------------------------------------
     def acm_version(self):
-        return 5
+        return 6
 
     def acm_last_error(self):
         return self._err
@@ -388,6 +388,31 @@ class FakeLib:
         out[base + 3 * k * F:] = d_mix.reshape(-1)
         return 0
 
+    def acm_adam_step(self, n, tensors, cfg, stream):
+        import ctypes as C
+        from acm_gnn_amd import _lib
+        c = cfg._obj
+        arr = C.cast(tensors, C.POINTER(_lib.AdamTensor * n)).contents if n else []
+        f32 = np.float32
+        for t in arr:
+            k = int(t.numel)
+            p, g, m, v = (_vec(ptr, k) for ptr in (t.param, t.grad, t.exp_avg, t.exp_avg_sq))
+            step = _vec(t.step, 1)
+            kk = float(step[0]) + 1.0
+            step_size = f32(c.lr / (1.0 - c.beta1 ** kk))
+            bc2_sqrt = f32((1.0 - c.beta2 ** kk) ** 0.5)
+            gg = g.copy()
+            if c.weight_decay != 0:
+                if c.decoupled:
+                    p *= f32(1.0 - c.lr * c.weight_decay)
+                else:
+                    gg = gg + f32(c.weight_decay) * p
+            m += f32(1.0 - c.beta1) * (gg - m)
+            v[...] = v * f32(c.beta2) + f32(1.0 - c.beta2) * gg * gg
+            p -= step_size * (m / (np.sqrt(v) / bc2_sqrt + f32(c.eps)))
+            step[0] = kk
+        return 0
+
     def acm_spmm_sub(self, h, g, ldg, width, sub, ld_sub, row_scale, y, ldy, ws, wsb, stream):
         a = self._get(h)
         out = a.dense_mul(_view(g, a.n_cols, width, ldg))
@@ -398,15 +423,16 @@ class FakeLib:
 
 def install(monkeypatch):
     """Route acm_gnn_amd through the test double and lift its GPU-only guards (CPU tests only)."""
-    from acm_gnn_amd import _lib, functional, graph
+    from acm_gnn_amd import _lib, functional, graph, optim
     fake = FakeLib()
     monkeypatch.setattr(_lib, "load", lambda build_if_missing=True: fake)
     monkeypatch.setattr(_lib, "check", lambda st, what="": (_ for _ in ()).throw(
         RuntimeError(f"{what}: {fake.acm_last_error().decode()} ({_lib.STATUS_NAMES.get(st, st)})")) if st else None)
-    for mod in (graph, functional):
+    for mod in (graph, functional, optim):
         monkeypatch.setattr(mod, "_require_cuda", lambda t, name: None)
         monkeypatch.setattr(mod, "_stream", lambda: None)
     monkeypatch.setattr(functional, "_device_ctx", lambda dev: contextlib.nullcontext())
+    monkeypatch.setattr(optim, "_device_ctx", lambda dev: contextlib.nullcontext())
     monkeypatch.setattr(graph, "_device_ctx", lambda dev: contextlib.nullcontext())
     monkeypatch.setattr(graph, "_sync", lambda dev: None)
 

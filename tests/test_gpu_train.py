@@ -86,8 +86,10 @@ def test_geometric_adamw_trajectory_matches_reference():
     np.testing.assert_allclose(final, rec["final_logits"], rtol=5e-3, atol=2e-3)   # Adam amplifies 1e-7 gradient noise
 
 
-def test_graph_replayed_step_equals_eager():
-    """The whole step captured once in a HIP graph and replayed gives the same losses."""
+@pytest.mark.parametrize("fused", [False, True], ids=["torch_adamw", "fused_adamw"])
+def test_graph_replayed_step_equals_eager(fused):
+    """The whole step captured once in a HIP graph and replayed gives the same losses, with torch's
+    optimizer and with the one-launch acm_adam_step; the two optimizers give the same losses too."""
     from acm_gnn_amd import GCN, data as D, train as T
     from acm_gnn_amd.graph import CsrGraph, FilterOperators
     adj, x_np, y_np, (tr, _, _), _ = D.synthetic_dataset("tiny", seed=1)
@@ -99,7 +101,11 @@ def test_graph_replayed_step_equals_eager():
     for use_graph in (False, True):
         torch.manual_seed(0)
         model = GCN(7, 64, 2, 2, x.shape[0], 0.0, "acmgcnp", 0, variant=False).to(DEV)
-        opt = torch.optim.AdamW(model.parameters(), lr=0.01, weight_decay=1e-3, capturable=True)
+        if fused:
+            from acm_gnn_amd import FusedAdamW
+            opt = FusedAdamW(model.parameters(), lr=0.01, weight_decay=1e-3)
+        else:
+            opt = torch.optim.AdamW(model.parameters(), lr=0.01, weight_decay=1e-3, capturable=True)
         if use_graph:
             state = {k: v.clone() for k, v in model.state_dict().items()}
         step = T.TrainStep(model, opt, x, ops, y, w, use_graph=use_graph)
@@ -111,3 +117,9 @@ def test_graph_replayed_step_equals_eager():
                         v.zero_()
         res.append([float(step()) for _ in range(6)])
     np.testing.assert_allclose(res[1], res[0], rtol=1e-5)
+    _LOSSES[fused] = res[0]
+    if len(_LOSSES) == 2:
+        np.testing.assert_allclose(_LOSSES[True], _LOSSES[False], rtol=2e-5)
+
+
+_LOSSES = {}
