@@ -14,13 +14,13 @@ c_i32p = C.POINTER(C.c_int32)
 
 ACM_OK = 0
 STATUS_NAMES = {1: "ACM_EINVAL", 2: "ACM_ESHAPE", 3: "ACM_EHIP", 4: "ACM_EUNSUPPORTED", 5: "ACM_ENOMEM"}
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 # every symbol include/acm_hip.h declares
 EXPORTED_SYMBOLS = (
     "acm_version", "acm_last_error", "acm_csr_create", "acm_csr_transpose", "acm_csr_slice_rows",
     "acm_csr_destroy", "acm_csr_info", "acm_spmm_workspace_bytes", "acm_gemm_workspace_bytes",
-    "acm_gemm", "acm_spmm", "acm_spmm_v", "acm_spmm_sub", "acm_cast_bf16", "acm_conv_fwd", "acm_conv_bwd_local_workspace_bytes",
+    "acm_gemm", "acm_spmm", "acm_spmm_v", "acm_spmm_ex", "acm_cast_bf16", "acm_conv_fwd", "acm_conv_bwd_local_workspace_bytes",
     "acm_conv_bwd_local", "acm_conv_bwd_spmm", "acm_conv_agg_fwd", "acm_conv_agg_bwd_workspace_bytes",
     "acm_conv_agg_bwd", "acm_nll_loss_workspace_bytes", "acm_nll_loss", "acm_adam_step",
 )
@@ -50,7 +50,7 @@ class ConvFwd(C.Structure):
                 ("out", C.c_void_p), ("ld_out", C.c_int64),
                 ("pre", C.c_void_p), ("ld_pre", C.c_int64),
                 ("att", C.c_void_p), ("post_scale", C.c_void_p), ("ld_post_scale", C.c_int64), ("post_relu", C.c_int32),
-                ("gather_bf16", C.c_int32)]
+                ("gather_bf16", C.c_int32), ("row_scale", C.c_void_p)]
 
 
 class ConvBwdLocal(C.Structure):
@@ -68,7 +68,8 @@ class ConvBwdLocal(C.Structure):
                 ("g_struc", C.c_void_p), ("ld_g_struc", C.c_int64),
                 ("d_att_vec", C.c_void_p * 4), ("d_ln_weight", C.c_void_p * 4),
                 ("d_ln_bias", C.c_void_p * 4), ("d_att_mix", C.c_void_p),
-                ("post_scale", C.c_void_p), ("ld_post_scale", C.c_int64), ("post_relu", C.c_int32)]
+                ("post_scale", C.c_void_p), ("ld_post_scale", C.c_int64), ("post_relu", C.c_int32),
+                ("g_scale", C.c_void_p)]
 
 
 class ConvBwdSpmm(C.Structure):
@@ -83,7 +84,7 @@ class ConvBwdSpmm(C.Structure):
                 ("mask_high", C.c_void_p), ("ld_mask_high", C.c_int64),
                 ("dz_low", C.c_void_p), ("ld_dz_low", C.c_int64),
                 ("dz_high", C.c_void_p), ("ld_dz_high", C.c_int64),
-                ("d_struc", C.c_void_p), ("ld_d_struc", C.c_int64)]
+                ("d_struc", C.c_void_p), ("ld_d_struc", C.c_int64), ("self_scale", C.c_void_p)]
 
 
 class ConvAggFwd(C.Structure):
@@ -99,7 +100,7 @@ class ConvAggFwd(C.Structure):
                 ("att", C.c_void_p), ("post_scale", C.c_void_p), ("ld_post_scale", C.c_int64), ("post_relu", C.c_int32),
                 ("n_channels", C.c_int32), ("sg", C.c_void_p), ("ld_sg", C.c_int64), ("sg_bf16", C.c_int32),
                 ("ss", C.c_void_p), ("ld_ss", C.c_int64), ("deg", C.c_void_p),
-                ("ps", C.c_void_p), ("ld_ps", C.c_int64)]
+                ("ps", C.c_void_p), ("ld_ps", C.c_int64), ("row_scale", C.c_void_p)]
 
 
 class ConvAggBwd(C.Structure):
@@ -114,7 +115,12 @@ class ConvAggBwd(C.Structure):
                 ("d_params", C.c_void_p), ("post_scale", C.c_void_p), ("ld_post_scale", C.c_int64), ("post_relu", C.c_int32),
                 ("n_channels", C.c_int32), ("ps", C.c_void_p), ("ld_ps", C.c_int64),
                 ("ss", C.c_void_p), ("ld_ss", C.c_int64), ("deg", C.c_void_p),
-                ("g_struc", C.c_void_p), ("ld_g_struc", C.c_int64)]
+                ("g_struc", C.c_void_p), ("ld_g_struc", C.c_int64), ("g_struc_scale", C.c_void_p)]
+
+
+class SpmmOpts(C.Structure):
+    _fields_ = [("vals", C.c_void_p), ("row_scale", C.c_void_p), ("sub", C.c_void_p), ("ld_sub", C.c_int64),
+                ("sub_scale", C.c_void_p), ("relu", C.c_int32), ("g_bf16", C.c_int32)]
 
 
 class AdamTensor(C.Structure):
@@ -149,7 +155,7 @@ def _declare(lib):
     lib.acm_spmm.argtypes = [vp, vp, i64, i32, vp, i64, vp, sz, vp]
     lib.acm_spmm_v.argtypes = [vp, vp, vp, i64, i32, vp, i64, i32, vp, sz, vp]
     lib.acm_adam_step.argtypes = [i32, vp, vp, vp]
-    lib.acm_spmm_sub.argtypes = [vp, vp, i64, i32, vp, i64, vp, vp, i64, vp, sz, vp]
+    lib.acm_spmm_ex.argtypes = [vp, vp, i64, i32, vp, i64, vp, vp, sz, vp]
     lib.acm_cast_bf16.argtypes = [i64, i64, vp, i64, vp, i64, vp]
     lib.acm_conv_fwd.argtypes = [vp, C.POINTER(ConvFwd), vp, sz, vp]
     lib.acm_conv_bwd_local_workspace_bytes.argtypes = [i64, i32, i32, C.POINTER(sz)]

@@ -37,20 +37,22 @@ struct EpiPlain {
         float* y;
         long ldy;
         int relu;
-        const float* sub;         // optional: y = acc - row_scale[row] * sub[row][col]
+        const float* sub;         // optional: y = out_scale[row] * acc - sub_scale[row] * sub[row][col]
         long ld_sub;
-        const float* row_scale;   // optional
+        const float* sub_scale;   // optional (NULL = 1)
+        const float* out_scale;   // optional (NULL = 1)
     };
     template <class L, int NG>
     static __device__ __forceinline__ void apply(const Args& a, int row, const L& lay, int F,
                                                  const float (&acc)[NG][L::NV]) {
         if (!Owns<L>::lane_stores(lay)) return;
+        const float os = a.out_scale ? a.out_scale[row] : 1.f;
 #pragma unroll
         for (int i = 0; i < L::NV; ++i) {
             const int col = lay.col(i);
             if (col < F) {
-                float v = acc[0][i];
-                if (a.sub) v -= (a.row_scale ? a.row_scale[row] : 1.f) * a.sub[(long)row * a.ld_sub + col];
+                float v = os * acc[0][i];
+                if (a.sub) v -= (a.sub_scale ? a.sub_scale[row] : 1.f) * a.sub[(long)row * a.ld_sub + col];
                 a.y[(long)row * a.ldy + col] = a.relu ? fmaxf(v, 0.f) : v;
             }
         }
@@ -65,14 +67,15 @@ struct EpiFwd {
         constexpr int NV = L::NV;
         float H[4][NV], hn[4][NV], xhat[4][NV], pre[3][NV];
         const float dg = (NG == 3) ? p.deg[row] : 0.f;
+        const float rs = p.row_scale ? p.row_scale[row] : 1.f;      // pattern-only operator: A_low = D^-1 P
 #pragma unroll
         for (int i = 0; i < NV; ++i) {
             const int col = lay.col(i);
             const bool ok = col < F;
             const float zh = ok ? p.s_high[(long)row * p.ld_s_high + col] : 0.f;
             const float zi = ok ? p.s_mlp[(long)row * p.ld_s_mlp + col] : 0.f;
-            const float p0 = acc[0][i];
-            const float p1 = zh - acc[1][i];
+            const float p0 = rs * acc[0][i];
+            const float p1 = zh - rs * acc[1][i];
             pre[0][i] = p0;
             pre[1][i] = p1;
             H[0][i] = p.relu_after ? fmaxf(p0, 0.f) : p0;
@@ -80,7 +83,7 @@ struct EpiFwd {
             H[2][i] = p.relu_mlp ? fmaxf(zi, 0.f) : zi;
             if (NG == 3) {
                 const float ss = ok ? p.s_struc[(long)row * p.ld_s_struc + col] : 0.f;
-                const float p3 = dg * acc[NG - 1][i] - ss;
+                const float p3 = dg * (rs * acc[NG - 1][i]) - ss;
                 pre[2][i] = p3;
                 H[3][i] = fmaxf(p3, 0.f);
             } else {
@@ -124,13 +127,14 @@ struct EpiBwd {
     static __device__ __forceinline__ void apply(const Args& p, int row, const L& lay, int F,
                                                  const float (&acc)[NG][L::NV]) {
         if (!Owns<L>::lane_stores(lay)) return;
-        const float idg = (NG == 3) ? p.inv_deg[row] : 0.f;
+        const float idg = (NG == 3 && p.inv_deg) ? p.inv_deg[row] : 1.f;
+        const float ssc = p.self_scale ? p.self_scale[row] : 1.f;   // pattern-only: s_high holds D^-1 G_H
 #pragma unroll
         for (int i = 0; i < L::NV; ++i) {
             const int col = lay.col(i);
             if (col >= F) continue;
             float dl = acc[0][i];
-            float dh = p.s_high[(long)row * p.ld_s_high + col] - acc[1][i];
+            float dh = ssc * p.s_high[(long)row * p.ld_s_high + col] - acc[1][i];
             if (p.mask_low) dl = (p.mask_low[(long)row * p.ld_mask_low + col] > 0.f) ? dl : 0.f;
             if (p.mask_high) dh = (p.mask_high[(long)row * p.ld_mask_high + col] > 0.f) ? dh : 0.f;
             p.dz_low[(long)row * p.ld_dz_low + col] = dl;
@@ -163,7 +167,7 @@ __device__ __forceinline__ void gather_wide(const GatherSrc& g, int F, const int
         float my_a = 0.f;
         if (kk < end) {
             my_j = indices[kk];
-            my_a = vals[kk];
+            my_a = vals ? vals[kk] : 1.f;           // pattern-only operator: implicit ones
         }
         const int cnt = min(64, end - base);  // wave-uniform
         int t = 0;
@@ -266,7 +270,7 @@ __global__ __launch_bounds__(256) void spmm_pair_bf16_kernel(CsrView csr, Gather
         float my_a = 0.f;
         if (kk < end) {
             my_j = csr.indices[kk];
-            my_a = csr.vals[kk];
+            my_a = csr.vals ? csr.vals[kk] : 1.f;
         }
         const int cnt = min(64, end - base);
         for (int t = 0; t < cnt; t += 2 * UNR) {
@@ -396,7 +400,8 @@ __global__ __launch_bounds__(256) void spmm_narrow_kernel(CsrView csr, GatherSrc
         const int ka = k0 + gl, kb = ka + GS;
         const bool va = ka < it.end, vb = kb < it.end;
         const int ja = va ? csr.indices[ka] : 0, jb = vb ? csr.indices[kb] : 0;
-        const float aa = va ? csr.vals[ka] : 0.f, ab = vb ? csr.vals[kb] : 0.f;
+        const bool unit = csr.vals == nullptr;       // pattern-only operator: implicit ones, no value stream
+        const float aa = va ? (unit ? 1.f : csr.vals[ka]) : 0.f, ab = vb ? (unit ? 1.f : csr.vals[kb]) : 0.f;
         float za[NG][FP], zb[NG][FP];
         if (MERGED) {
             float ta[2 * FP], tb[2 * FP];
@@ -446,6 +451,105 @@ __global__ __launch_bounds__(256) void spmm_narrow_kernel(CsrView csr, GatherSrc
 #pragma unroll
             for (int f = 0; f < FP; ++f)
                 if (f < F) ps[c * F + f] = acc[c][f];
+    }
+}
+
+// Persistent, software-pipelined form of the narrow gather.  Most rows of a power-law graph are one
+// iteration long (79 % of the twitch rows have <= 64 neighbours), so the per-item chain
+//     item descriptor -> column ids -> gathered rows -> reduce -> epilogue
+// is four dependent memory latencies with nothing to overlap them inside the wave.  Here a group walks the
+// work list with a grid stride, and while the rows of the current step are in flight it already has the
+// next item's descriptor and the next step's column ids / values requested (of the same item, or of the
+// next one when this was its last step): two latencies per step are taken off the critical path.
+template <int FP, int NG, int GS, bool MERGED, class Epi>
+__global__ __launch_bounds__(256) void spmm_narrow_pipe_kernel(CsrView csr, GatherSrc g, int F, int vecmask,
+                                                               typename Epi::Args ea, float* __restrict__ partial) {
+    constexpr int GPB = 256 / GS;
+    const int gl = threadIdx.x % GS;
+    const int G = gridDim.x * GPB;
+    int w = blockIdx.x * GPB + threadIdx.x / GS;
+    if (w >= csr.n_items) return;
+    AcmItem it = csr.items[w];
+    int k0 = it.begin;
+    bool va = k0 + gl < it.end, vb = k0 + gl + GS < it.end;
+    int ja = va ? csr.indices[k0 + gl] : 0, jb = vb ? csr.indices[k0 + gl + GS] : 0;
+    const bool unit = csr.vals == nullptr;
+    float aa = va ? (unit ? 1.f : csr.vals[k0 + gl]) : 0.f, ab = vb ? (unit ? 1.f : csr.vals[k0 + gl + GS]) : 0.f;
+    while (true) {
+        const int wn = w + G;
+        const bool has_next = wn < csr.n_items;
+        AcmItem itn = it;
+        if (has_next) itn = csr.items[wn];
+        float acc[NG][FP];
+#pragma unroll
+        for (int c = 0; c < NG; ++c)
+#pragma unroll
+            for (int f = 0; f < FP; ++f) acc[c][f] = 0.f;
+        while (true) {
+            float za[NG][FP], zb[NG][FP];
+            if (MERGED) {
+                float ta[2 * FP], tb[2 * FP];
+                load_row<2 * FP>(g.p[0] + (long)ja * g.ld[0], 2 * FP, true, ta);
+                load_row<2 * FP>(g.p[0] + (long)jb * g.ld[0], 2 * FP, true, tb);
+#pragma unroll
+                for (int f = 0; f < FP; ++f) {
+                    za[0][f] = ta[f];
+                    zb[0][f] = tb[f];
+                    if (NG > 1) {
+                        za[1 % NG][f] = ta[FP + f];
+                        zb[1 % NG][f] = tb[FP + f];
+                    }
+                }
+#pragma unroll
+                for (int c = 2; c < NG; ++c) {
+                    load_row<FP>(g.p[c] + (long)ja * g.ld[c], F, (vecmask >> c) & 1, za[c]);
+                    load_row<FP>(g.p[c] + (long)jb * g.ld[c], F, (vecmask >> c) & 1, zb[c]);
+                }
+            } else {
+#pragma unroll
+                for (int c = 0; c < NG; ++c) {
+                    load_row<FP>(g.p[c] + (long)ja * g.ld[c], F, (vecmask >> c) & 1, za[c]);
+                    load_row<FP>(g.p[c] + (long)jb * g.ld[c], F, (vecmask >> c) & 1, zb[c]);
+                }
+            }
+            // requests of the next step, issued before the rows above are consumed
+            const int k1 = k0 + 2 * GS;
+            const bool more = k1 < it.end;
+            const int pb = more ? k1 : itn.begin;
+            const int pe = more ? it.end : (has_next ? itn.end : pb);
+            const bool pva = pb + gl < pe, pvb = pb + gl + GS < pe;
+            const int nja = pva ? csr.indices[pb + gl] : 0, njb = pvb ? csr.indices[pb + gl + GS] : 0;
+            const float naa = pva ? (unit ? 1.f : csr.vals[pb + gl]) : 0.f, nab = pvb ? (unit ? 1.f : csr.vals[pb + gl + GS]) : 0.f;
+#pragma unroll
+            for (int c = 0; c < NG; ++c)
+#pragma unroll
+                for (int f = 0; f < FP; ++f) {
+                    acc[c][f] = va ? fmaf(aa, za[c][f], acc[c][f]) : acc[c][f];
+                    acc[c][f] = vb ? fmaf(ab, zb[c][f], acc[c][f]) : acc[c][f];
+                }
+            ja = nja, jb = njb, aa = naa, ab = nab, va = pva, vb = pvb;
+            if (!more) break;
+            k0 = k1;
+        }
+#pragma unroll
+        for (int c = 0; c < NG; ++c)
+#pragma unroll
+            for (int f = 0; f < FP; ++f) acc[c][f] = acm_group_sum<GS>(acc[c][f]);
+        if (it.slot < 0) {
+            LaySerial<FP> lay{gl == 0};
+            Epi::template apply<LaySerial<FP>, NG>(ea, it.row, lay, F, acc);
+        } else if (gl == 0) {
+            float* ps = partial + (long)it.slot * (NG * F);
+#pragma unroll
+            for (int c = 0; c < NG; ++c)
+#pragma unroll
+                for (int f = 0; f < FP; ++f)
+                    if (f < F) ps[c * F + f] = acc[c][f];
+        }
+        if (!has_next) break;
+        it = itn;
+        w = wn;
+        k0 = it.begin;
     }
 }
 
@@ -514,11 +618,23 @@ int launch_gather(const acm_csr* a, const GatherSrc& g, int F, const typename Ep
         // [channel 0 | channel 1] contiguous and block-aligned => one vector fetch for both
         const bool merged = NG >= 2 && F == FP && g.p[1] == g.p[0] + F && g.ld[0] == g.ld[1] &&
                             ((uintptr_t)g.p[0]) % (8 * FP) == 0 && (g.ld[0] * sizeof(float)) % (8 * FP) == 0;
+        static const int pipe_blocks = []() {
+            const char* e = getenv("ACM_NARROW_PIPE");
+            return e ? atoi(e) : 0;
+        }();
 #define ACM_NARROW(FPv, GSv)                                                                            \
     do {                                                                                                \
         const int gpb = 256 / GSv;                                                                      \
-        const int grid = (int)((a->n_items + gpb - 1) / gpb);                                           \
-        if (merged)                                                                                     \
+        int grid = (int)((a->n_items + gpb - 1) / gpb);                                                 \
+        if (pipe_blocks > 0) {                                                                          \
+            if (grid > pipe_blocks) grid = pipe_blocks;                                                 \
+            if (merged)                                                                                 \
+                hipLaunchKernelGGL((spmm_narrow_pipe_kernel<FPv, NG, GSv, (NG >= 2), Epi>), dim3(grid), dim3(256), 0, \
+                                   st, v, g, F, vecmask, ea, partial);                                  \
+            else                                                                                        \
+                hipLaunchKernelGGL((spmm_narrow_pipe_kernel<FPv, NG, GSv, false, Epi>), dim3(grid), dim3(256), 0, \
+                                   st, v, g, F, vecmask, ea, partial);                                  \
+        } else if (merged)                                                                                     \
             hipLaunchKernelGGL((spmm_narrow_kernel<FPv, NG, GSv, (NG >= 2), Epi>), dim3(grid), dim3(256), 0, \
                                st, v, g, F, vecmask, ea, partial);                                      \
         else                                                                                            \
@@ -597,45 +713,35 @@ extern "C" int acm_cast_bf16(int64_t n_rows, int64_t n_cols, const float* src, i
     return ACM_OK;
 }
 
-extern "C" int acm_spmm_v(const acm_csr_t* a, const float* vals, const float* G, int64_t ldg, int width, float* Y,
-                          int64_t ldy, int relu, void* workspace, size_t workspace_bytes, acm_stream_t stream) {
+extern "C" int acm_spmm_ex(const acm_csr_t* a, const void* G, int64_t ldg, int width, float* Y, int64_t ldy,
+                           const acm_spmm_opts_t* o, void* workspace, size_t workspace_bytes, acm_stream_t stream) {
+    static const acm_spmm_opts_t none = {nullptr, nullptr, nullptr, 0, nullptr, 0, 0};
+    if (!o) o = &none;
     ACM_REQUIRE(a && G && Y, ACM_EINVAL, "acm_spmm: NULL argument");
-    ACM_REQUIRE(width > 0 && ldg >= width && ldy >= width, ACM_ESHAPE,
-                "acm_spmm: width %d ldg %lld ldy %lld", width, (long long)ldg, (long long)ldy);
+    ACM_REQUIRE(width > 0 && ldg >= width && ldy >= width && (!o->sub || o->ld_sub >= width), ACM_ESHAPE,
+                "acm_spmm: width %d ldg %lld ldy %lld ld_sub %lld", width, (long long)ldg, (long long)ldy,
+                (long long)o->ld_sub);
+    ACM_REQUIRE(!o->g_bf16 || width <= 256, ACM_EUNSUPPORTED, "acm_spmm: bf16 operands are one column block wide");
     for (int c0 = 0; c0 < width; c0 += 256) {  // column blocks of <= 256
         const int wd = width - c0 < 256 ? width - c0 : 256;
-        GatherSrc g = {{G + c0, nullptr, nullptr}, {ldg, 0, 0}};
-        EpiPlain::Args ea = {Y + c0, ldy, relu, nullptr, 0, nullptr};
-        int st = launch_gather<1, EpiPlain>(a, g, wd, ea, workspace, workspace_bytes,
-                                            (hipStream_t)stream, "acm_spmm", vals);
+        GatherSrc g = {{reinterpret_cast<const float*>(G) + (o->g_bf16 ? 0 : c0), nullptr, nullptr}, {ldg, 0, 0}};
+        EpiPlain::Args ea = {Y + c0, ldy, o->relu, o->sub ? o->sub + c0 : nullptr, o->ld_sub, o->sub_scale, o->row_scale};
+        int st = launch_gather<1, EpiPlain>(a, g, wd, ea, workspace, workspace_bytes, (hipStream_t)stream, "acm_spmm",
+                                            o->vals, o->g_bf16 != 0);
         if (st != ACM_OK) return st;
     }
     return ACM_OK;
 }
 
-extern "C" int acm_spmm_sub(const acm_csr_t* a, const float* G, int64_t ldg, int width, const float* sub,
-                            int64_t ld_sub, const float* row_scale, float* Y, int64_t ldy, void* workspace,
-                            size_t workspace_bytes, acm_stream_t stream) {
-    ACM_REQUIRE(a && G && Y && sub, ACM_EINVAL, "acm_spmm_sub: NULL argument");
-    ACM_REQUIRE(width > 0 && width <= 256 && ldg >= width && ldy >= width && ld_sub >= width, ACM_ESHAPE,
-                "acm_spmm_sub: width %d (<= 256) ldg %lld ldy %lld ld_sub %lld", width, (long long)ldg, (long long)ldy,
-                (long long)ld_sub);
-    GatherSrc g = {{G, nullptr, nullptr}, {ldg, 0, 0}};
-    EpiPlain::Args ea = {Y, ldy, 0, sub, ld_sub, row_scale};
-    return launch_gather<1, EpiPlain>(a, g, width, ea, workspace, workspace_bytes, (hipStream_t)stream, "acm_spmm_sub");
-}
-
-// internal: plain product with a bf16 gathered operand (used by the aggregate-first structure channel)
-int acm_spmm_bf16_internal(const acm_csr* a, const void* G_bf16, long ldg, int width, float* Y, long ldy, void* workspace,
-                           size_t workspace_bytes, hipStream_t stream) {
-    GatherSrc g = {{reinterpret_cast<const float*>(G_bf16), nullptr, nullptr}, {ldg, 0, 0}};
-    EpiPlain::Args ea = {Y, ldy, 0, nullptr, 0, nullptr};
-    return launch_gather<1, EpiPlain>(a, g, width, ea, workspace, workspace_bytes, stream, "acm_spmm(bf16)", nullptr, true);
+extern "C" int acm_spmm_v(const acm_csr_t* a, const float* vals, const float* G, int64_t ldg, int width, float* Y,
+                          int64_t ldy, int relu, void* workspace, size_t workspace_bytes, acm_stream_t stream) {
+    const acm_spmm_opts_t o = {vals, nullptr, nullptr, 0, nullptr, relu, 0};
+    return acm_spmm_ex(a, G, ldg, width, Y, ldy, &o, workspace, workspace_bytes, stream);
 }
 
 extern "C" int acm_spmm(const acm_csr_t* a, const float* G, int64_t ldg, int width, float* Y,
                         int64_t ldy, void* workspace, size_t workspace_bytes, acm_stream_t stream) {
-    return acm_spmm_v(a, nullptr, G, ldg, width, Y, ldy, 0, workspace, workspace_bytes, stream);
+    return acm_spmm_ex(a, G, ldg, width, Y, ldy, nullptr, workspace, workspace_bytes, stream);
 }
 
 extern "C" int acm_conv_fwd(const acm_csr_t* a, const acm_conv_fwd_t* p, void* workspace,
@@ -674,7 +780,7 @@ extern "C" int acm_conv_bwd_spmm(const acm_csr_t* at, const acm_conv_bwd_spmm_t*
     ACM_REQUIRE(p->g_low && p->g_high && p->s_high && p->dz_low && p->dz_high, ACM_EINVAL,
                 "acm_conv_bwd_spmm: NULL tensor pointer");
     if (p->g_struc) {
-        ACM_REQUIRE(p->s_struc && p->inv_deg && p->d_struc, ACM_EINVAL,
+        ACM_REQUIRE(p->s_struc && p->d_struc, ACM_EINVAL,
                     "acm_conv_bwd_spmm: structure channel pointers are NULL");
         GatherSrc g = {{p->g_low, p->g_high, p->g_struc}, {p->ld_g_low, p->ld_g_high, p->ld_g_struc}};
         return launch_gather<3, EpiBwd>(at, g, F, *p, workspace, workspace_bytes, (hipStream_t)stream,
@@ -696,7 +802,8 @@ __device__ __forceinline__ void conv_bwd_row(const acm_conv_bwd_local_t& p, int 
     const int F = p.f_out;
     float H[4][NV], hn[4][NV], xhat[4][NV], dO[NV];
     bool pos[4][NV];
-    const float dg = (k == 4 && active) ? p.deg[row] : 0.f;
+    const float dg = (k == 4 && active && p.deg) ? p.deg[row] : 1.f;
+    const float gsc = (active && p.g_scale) ? p.g_scale[row] : 1.f;
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
         const int col = lay.col(i);
@@ -743,8 +850,8 @@ __device__ __forceinline__ void conv_bwd_row(const acm_conv_bwd_local_t& p, int 
             const int col = lay.col(i);
             if (!(active && col < F)) continue;
             const float gval = pos[c][i] ? dH[c][i] : 0.f;
-            if (c == 0) p.g_low[(long)row * p.ld_g_low + col] = gval;
-            if (c == 1) p.g_high[(long)row * p.ld_g_high + col] = gval;
+            if (c == 0) p.g_low[(long)row * p.ld_g_low + col] = gsc * gval;
+            if (c == 1) p.g_high[(long)row * p.ld_g_high + col] = gsc * gval;
             if (c == 2) p.g_mlp[(long)row * p.ld_g_mlp + col] = gval;
             if (c == 3) p.g_struc[(long)row * p.ld_g_struc + col] = dg * gval;
         }
@@ -867,7 +974,8 @@ __global__ __launch_bounds__(256) void conv_bwd_local_grouped_kernel(acm_conv_bw
         row_post_backward<K>(p, rh, H, active, rr, m, F, dO);
         float ds[K];
         row_head_backward_scalars<K>(rh, mixm, p.scale, H, dO, ds, dmix);
-        const float dg = (K == 4 && active) ? p.deg[rr] : 0.f;
+        const float dg = (K == 4 && active && p.deg) ? p.deg[rr] : 1.f;
+        const float gsc = (active && p.g_scale) ? p.g_scale[rr] : 1.f;
 #pragma unroll
         for (int c = 0; c < K; ++c) {
             const bool relu_c = (c < 2) ? (p.relu_after != 0) : (c == 2 ? p.relu_mlp != 0 : true);
@@ -878,8 +986,8 @@ __global__ __launch_bounds__(256) void conv_bwd_local_grouped_kernel(acm_conv_bw
                 const int col = m + 16 * i;
                 if (!(active && col < F)) continue;
                 const float gv = (!relu_c || H[c][i] > 0.f) ? G[i] : 0.f;
-                if (c == 0) p.g_low[urow * (unsigned)p.ld_g_low + col] = gv;
-                if (c == 1) p.g_high[urow * (unsigned)p.ld_g_high + col] = gv;
+                if (c == 0) p.g_low[urow * (unsigned)p.ld_g_low + col] = gsc * gv;
+                if (c == 1) p.g_high[urow * (unsigned)p.ld_g_high + col] = gsc * gv;
                 if (c == 2) p.g_mlp[urow * (unsigned)p.ld_g_mlp + col] = gv;
                 if (c == 3) p.g_struc[urow * (unsigned)p.ld_g_struc + col] = dg * gv;
             }
@@ -973,7 +1081,7 @@ extern "C" int acm_conv_bwd_local(int64_t n_rows, const acm_conv_bwd_local_t* p,
                 "acm_conv_bwd_local: f_out %d n_channels %d", F, k);
     ACM_REQUIRE(p->grad_out && p->pre && p->s_mlp && p->att_mix && p->g_low && p->g_high && p->g_mlp &&
                     p->d_att_mix, ACM_EINVAL, "acm_conv_bwd_local: NULL tensor pointer");
-    ACM_REQUIRE(k == 3 || (p->g_struc && p->deg), ACM_EINVAL,
+    ACM_REQUIRE(k == 3 || p->g_struc, ACM_EINVAL,
                 "acm_conv_bwd_local: structure channel pointers are NULL");
     for (int c = 0; c < k; ++c) {
         ACM_REQUIRE(p->att_vec[c] && p->d_att_vec[c], ACM_EINVAL, "acm_conv_bwd_local: att_vec[%d] NULL", c);

@@ -12,10 +12,6 @@
 // deterministically (wave -> LDS -> per-block partial -> tree reduce).
 #include "acm_conv_device.h"
 
-// defined in acm_conv.hip: plain product with a bf16 gathered operand
-int acm_spmm_bf16_internal(const acm_csr* a, const void* G_bf16, long ldg, int width, float* Y, long ldy, void* workspace,
-                           size_t workspace_bytes, hipStream_t stream);
-
 namespace {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -242,7 +238,7 @@ __global__ __launch_bounds__(256, 2) void agg_bwd_kernel(acm_conv_agg_bwd_t p, i
             float G[4];
             row_channel_backward<K>(hlds, K - 1, mm, F, ln, p.scale, rh, ds[K - 1], H[K - 1], dO, dv[K - 1],
                                     dgam[K - 1], dbet[K - 1], G);
-            const float dg1 = active ? p.deg[rr] : 0.f;
+            const float dg1 = (active && p.g_struc_scale) ? p.g_struc_scale[rr] : 1.f;
 #pragma unroll
             for (int t = 0; t < 4; ++t)
                 if (active && m + 16 * t < F)
@@ -354,17 +350,15 @@ extern "C" int acm_conv_agg_fwd(const acm_csr_t* a, const acm_conv_agg_fwd_t* p,
                 "acm_conv_agg_fwd: xg / agg rows must be 16-byte aligned and f_pad long");
     if (a->n_rows == 0) return ACM_OK;
     hipStream_t s = (hipStream_t)stream;
-    // (1) P = A_low X  -> p->agg  (also the tensor saved for the backward)
-    st = acm_spmm(a, p->xg, p->ld_xg, p->f_pad, p->agg, p->ld_agg, workspace, workspace_bytes, stream);
+    // (1) P = A_low X  -> p->agg  (also the tensor saved for the backward); row_scale for a pattern-only a_low
+    acm_spmm_opts_t o = {nullptr, p->row_scale, nullptr, 0, nullptr, 0, 0};
+    st = acm_spmm_ex(a, p->xg, p->ld_xg, p->f_pad, p->agg, p->ld_agg, &o, workspace, workspace_bytes, stream);
     if (st != ACM_OK) return st;
     // (1b) structure channel: PS = A_low S -> p->ps (F wide; bf16 operand optional)
     if (p->n_channels == 4) {
         ACM_REQUIRE(p->sg, ACM_EINVAL, "acm_conv_agg_fwd: sg is NULL");
-        if (p->sg_bf16)
-            st = acm_spmm_bf16_internal(a, p->sg, (long)p->ld_sg, p->f_out, p->ps, (long)p->ld_ps, workspace,
-                                        workspace_bytes, s);
-        else
-            st = acm_spmm(a, (const float*)p->sg, p->ld_sg, p->f_out, p->ps, p->ld_ps, workspace, workspace_bytes, stream);
+        o.g_bf16 = p->sg_bf16;
+        st = acm_spmm_ex(a, p->sg, p->ld_sg, p->f_out, p->ps, p->ld_ps, &o, workspace, workspace_bytes, stream);
         if (st != ACM_OK) return st;
     }
     // (2) projections + head, row-local

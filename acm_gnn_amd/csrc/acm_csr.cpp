@@ -97,12 +97,12 @@ acm_csr* new_handle(int64_t n_rows, int64_t n_cols, int64_t nnz) {
     return a;
 }
 
-int alloc_arrays(acm_csr* a) {
+int alloc_arrays(acm_csr* a, bool with_vals = true) {
     ACM_CHECK_HIP(hipMalloc((void**)&a->indptr, (size_t)(a->n_rows + 1) * sizeof(int32_t)));
     // keep the arrays non-null even for an empty graph so kernels may take their address
     const size_t m = (size_t)std::max<int64_t>(a->nnz, 1);
     ACM_CHECK_HIP(hipMalloc((void**)&a->indices, m * sizeof(int32_t)));
-    ACM_CHECK_HIP(hipMalloc((void**)&a->vals, m * sizeof(float)));
+    if (with_vals) ACM_CHECK_HIP(hipMalloc((void**)&a->vals, m * sizeof(float)));   // NULL = pattern-only (implicit ones)
     return ACM_OK;
 }
 
@@ -114,8 +114,7 @@ extern "C" int acm_csr_create(int64_t n_rows, int64_t n_cols, int64_t nnz,
     ACM_REQUIRE(out, ACM_EINVAL, "acm_csr_create: out is NULL");
     *out = nullptr;
     ACM_REQUIRE(indptr_dev, ACM_EINVAL, "acm_csr_create: indptr is NULL");
-    ACM_REQUIRE(nnz == 0 || (indices_dev && vals_dev), ACM_EINVAL,
-                "acm_csr_create: indices/vals NULL with nnz > 0");
+    ACM_REQUIRE(nnz == 0 || indices_dev, ACM_EINVAL, "acm_csr_create: indices NULL with nnz > 0");
     ACM_REQUIRE(n_rows >= 0 && n_cols >= 0 && nnz >= 0, ACM_ESHAPE, "acm_csr_create: negative size");
     ACM_REQUIRE(n_rows < INT32_MAX && n_cols < INT32_MAX && nnz < INT32_MAX, ACM_EUNSUPPORTED,
                 "acm_csr_create: sizes must fit int32 (rows %lld cols %lld nnz %lld)",
@@ -141,14 +140,14 @@ extern "C" int acm_csr_create(int64_t n_rows, int64_t n_cols, int64_t nnz,
     }
     acm_csr* a = new_handle(n_rows, n_cols, nnz);
     ACM_REQUIRE(a, ACM_ENOMEM, "acm_csr_create: host allocation failed");
-    int st = alloc_arrays(a);
+    int st = alloc_arrays(a, vals_dev != nullptr);
     if (st == ACM_OK) {
         hipError_t e = hipMemcpy(a->indptr, indptr_dev, (size_t)(n_rows + 1) * sizeof(int32_t),
                                  hipMemcpyDeviceToDevice);
         if (e == hipSuccess && nnz)
             e = hipMemcpy(a->indices, indices_dev, (size_t)nnz * sizeof(int32_t),
                           hipMemcpyDeviceToDevice);
-        if (e == hipSuccess && nnz)
+        if (e == hipSuccess && nnz && vals_dev)
             e = hipMemcpy(a->vals, vals_dev, (size_t)nnz * sizeof(float), hipMemcpyDeviceToDevice);
         if (e != hipSuccess) {
             acm_set_error("acm_csr_create: device copy failed: %s", hipGetErrorString(e));
@@ -174,7 +173,7 @@ extern "C" int acm_csr_transpose(const acm_csr_t* a, int chunk, acm_csr_t** out)
     ACM_CHECK_HIP(hipMemcpy(ip.data(), a->indptr, ip.size() * sizeof(int32_t), hipMemcpyDeviceToHost));
     if (nnz) {
         ACM_CHECK_HIP(hipMemcpy(ix.data(), a->indices, (size_t)nnz * sizeof(int32_t), hipMemcpyDeviceToHost));
-        ACM_CHECK_HIP(hipMemcpy(v.data(), a->vals, (size_t)nnz * sizeof(float), hipMemcpyDeviceToHost));
+        if (a->vals) ACM_CHECK_HIP(hipMemcpy(v.data(), a->vals, (size_t)nnz * sizeof(float), hipMemcpyDeviceToHost));
     }
     // stable counting sort by column: rows of A^T come out sorted by original row id
     std::vector<int32_t> tp((size_t)m + 1, 0), tx((size_t)nnz), tpos((size_t)nnz);
@@ -191,12 +190,12 @@ extern "C" int acm_csr_transpose(const acm_csr_t* a, int chunk, acm_csr_t** out)
         }
     acm_csr* t = new_handle(m, n, nnz);
     ACM_REQUIRE(t, ACM_ENOMEM, "acm_csr_transpose: host allocation failed");
-    int st = alloc_arrays(t);
+    int st = alloc_arrays(t, a->vals != nullptr);
     if (st == ACM_OK) {
         hipError_t e = hipMemcpy(t->indptr, tp.data(), tp.size() * sizeof(int32_t), hipMemcpyHostToDevice);
         if (e == hipSuccess && nnz)
             e = hipMemcpy(t->indices, tx.data(), (size_t)nnz * sizeof(int32_t), hipMemcpyHostToDevice);
-        if (e == hipSuccess && nnz)
+        if (e == hipSuccess && nnz && t->vals)
             e = hipMemcpy(t->vals, tv.data(), (size_t)nnz * sizeof(float), hipMemcpyHostToDevice);
         if (e == hipSuccess) e = hipMalloc((void**)&t->src_pos, (size_t)(nnz > 0 ? nnz : 1) * sizeof(int32_t));
         if (e == hipSuccess && nnz)
@@ -232,12 +231,12 @@ extern "C" int acm_csr_slice_rows(const acm_csr_t* a, int64_t row_begin, int64_t
     const int64_t nnz = ip[n];
     acm_csr* s = new_handle(n, a->n_cols, nnz);
     ACM_REQUIRE(s, ACM_ENOMEM, "acm_csr_slice_rows: host allocation failed");
-    int st = alloc_arrays(s);
+    int st = alloc_arrays(s, a->vals != nullptr);
     if (st == ACM_OK) {
         hipError_t e = hipMemcpy(s->indptr, ip.data(), ip.size() * sizeof(int32_t), hipMemcpyHostToDevice);
         if (e == hipSuccess && nnz)
             e = hipMemcpy(s->indices, a->indices + base, (size_t)nnz * sizeof(int32_t), hipMemcpyDeviceToDevice);
-        if (e == hipSuccess && nnz)
+        if (e == hipSuccess && nnz && a->vals)
             e = hipMemcpy(s->vals, a->vals + base, (size_t)nnz * sizeof(float), hipMemcpyDeviceToDevice);
         if (e != hipSuccess) {
             acm_set_error("acm_csr_slice_rows: copy failed: %s", hipGetErrorString(e));

@@ -16,10 +16,12 @@ this module has no reference counterpart; its contract is "N-rank result ==
 1-rank result", tested with world_size 2 on gloo (CPU) with the kernel launches
 replaced by a test double, and by construction on RCCL.
 """
+import os
+
 import numpy as np
 import torch
 
-from .graph import CsrGraph, FilterOperators
+from .graph import CsrGraph, FilterOperators, as_implicit, implicit_form
 
 
 def shard_bounds(n_global, world, rank):
@@ -48,9 +50,31 @@ def make_sharded_operators(low_csr, deg, device, group=None, with_structure=Fals
     if group is None and not (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1):
         low = CsrGraph.from_scipy(low_csr, device)
         d = torch.from_numpy(np.ascontiguousarray(deg)).to(device) if with_structure else None
-        return FilterOperators(low, d)
+        return as_implicit(FilterOperators(low, d))
     group = group if group is not None else dist.group.WORLD
     world, rank = dist.get_world_size(group), dist.get_rank(group)
+    form = None
+    if os.environ.get("ACM_IMPLICIT", "1") != "0":
+        # pattern-only form, detected on the global matrix (host): the rank's rows of P serve A_low (row-scaled)
+        # and, P being symmetric, A_low^T on the pre-scaled all-gathered gradients -- one column-id stream, no
+        # transposed slice
+        g = low_csr.tocsr()
+        g.sort_indices()
+        form = implicit_form(torch.from_numpy(g.indptr.astype(np.int64)), torch.from_numpy(g.indices.astype(np.int64)),
+                             torch.from_numpy(g.data.astype(np.float32)), g.shape[0], g.shape[1])
+    if form is not None:
+        ip, ix, s = (t.numpy() for t in form)
+        b, e = shard_bounds(low_csr.shape[0], world, rank)
+        ip_loc = (ip[b:e + 1] - ip[b]).astype(np.int32)
+        ix_loc = ix[ip[b]:ip[e]]
+        dev = torch.device(device)
+        pat = CsrGraph.from_csr(torch.from_numpy(ip_loc).to(dev), torch.from_numpy(np.ascontiguousarray(ix_loc)).to(dev),
+                                None, low_csr.shape[1])
+        ops = FilterOperators(pat, torch.from_numpy(np.ascontiguousarray(deg[b:e])).to(dev) if with_structure else None,
+                              row_offset=b, n_global=low_csr.shape[0], group=group,
+                              row_scale=torch.from_numpy(np.ascontiguousarray(s[b:e])).to(dev))
+        ops.low_t_override = pat
+        return ops
     low_loc, low_t_loc, deg_loc, b = shard_filter_arrays(low_csr, deg, world, rank)
     ops = FilterOperators(CsrGraph.from_scipy(low_loc, device),
                           torch.from_numpy(np.ascontiguousarray(deg_loc)).to(device) if with_structure else None,

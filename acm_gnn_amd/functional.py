@@ -340,6 +340,8 @@ class AcmConvFunction(torch.autograd.Function):
             p.agg, p.ld_agg = agg.data_ptr(), agg.stride(0)
             p.att = att.data_ptr()
             p.n_channels = k
+            if ops.implicit:
+                p.row_scale = ops.row_scale.data_ptr()
             extra = ()
             if four:                                  # pre_S = deg * (A_low S) - S: one F-wide gather of S
                 ps = torch.empty(n, f, dtype=_F32, device=dev)
@@ -367,6 +369,8 @@ class AcmConvFunction(torch.autograd.Function):
         p.f_out, p.n_channels = f, k
         p.relu_after, p.relu_mlp, p.layernorm = int(cfg.relu_after), int(cfg.relu_mlp), int(cfg.layernorm)
         p.scale, p.row_offset = cfg.scale, ops.row_offset
+        if ops.implicit:
+            p.row_scale = ops.row_scale.data_ptr()
         graph = ops.low
         if general:
             # every channel through its own operator, then the fused kernel over the identity operator as a
@@ -456,7 +460,11 @@ class AcmConvFunction(torch.autograd.Function):
         q.s_mlp, q.ld_s_mlp = z.data_ptr() + 8 * f, z.stride(0)
         general = bool(getattr(ops, "general", False))
         ones = ops.zeros(n, 1).new_ones(n) if (four and general) else None
-        q.deg = (ones if general else ops.deg).data_ptr() if four else None
+        # pattern-only backward: A_low^T G = P (D^-1 G), so G_L / G_H are written pre-scaled and G_S unscaled
+        # (A_low^T (D G_S) = P G_S)
+        q.deg = None if (not four or ops.implicit) else (ones if general else ops.deg).data_ptr()
+        if ops.implicit:
+            q.g_scale = ops.row_scale.data_ptr()
         q.att_vec, q.ln_weight, q.ln_bias = _ptr_array(vecs), _ptr_array(lnw), _ptr_array(lnb)
         q.att_mix = mix.data_ptr()
         q.g_low, q.ld_g_low = g.data_ptr(), g.stride(0)
@@ -505,8 +513,10 @@ class AcmConvFunction(torch.autograd.Function):
             if four:
                 r.g_struc, r.ld_g_struc = gsg.data_ptr(), gsg.stride(0)
                 r.s_struc, r.ld_s_struc = gs.data_ptr(), gs.stride(0)
-                r.inv_deg = ops.inv_deg.data_ptr()
+                r.inv_deg = None if ops.implicit else ops.inv_deg.data_ptr()
                 r.d_struc, r.ld_d_struc = d_struc.data_ptr(), d_struc.stride(0)
+            if ops.implicit:
+                r.self_scale = ops.self_scale.data_ptr()
         if cfg.relu_before:                       # ACMII: ReLU mask of the projected features
             r.mask_low, r.ld_mask_low = z.data_ptr(), z.stride(0)
             r.mask_high, r.ld_mask_high = z.data_ptr() + 4 * f, z.stride(0)
@@ -584,6 +594,7 @@ def _backward_agg(ctx, grad_out):
         q.ss, q.ld_ss = s_local.data_ptr(), s_local.stride(0)
         q.deg = ops.deg.data_ptr()
         q.g_struc, q.ld_g_struc = gs.data_ptr(), gs.stride(0)
+        q.g_struc_scale = None if ops.implicit else ops.deg.data_ptr()
     nbytes = C.c_size_t()
     _lib.check(lib.acm_conv_agg_bwd_workspace_bytes(n, f_in, f, C.byref(nbytes)))
     ws = torch.empty(max(nbytes.value // 4, 1), dtype=_F32, device=dev)
@@ -591,16 +602,18 @@ def _backward_agg(ctx, grad_out):
         st = lib.acm_conv_agg_bwd(n, C.byref(q), _vp(ws), ws.numel() * 4, _stream())
     _lib.check(st, "acm_conv_agg_bwd")
     d_struc = None
-    if four:                                  # dS = A_low^T (D G_S) - G_S
+    if four:                                  # dS = A_low^T (D G_S) - G_S   (pattern-only: P G_S - G_S)
         gsg = _gather_rows(ops, gs)
         low_t = ops.low_t
         d_struc = torch.empty(n, f, dtype=_F32, device=dev)
         ws2 = low_t.workspace(f)
+        o = _lib.SpmmOpts()
+        o.sub, o.ld_sub = gs.data_ptr(), gs.stride(0)
+        o.sub_scale = None if ops.implicit else ops.inv_deg.data_ptr()
         with _device_ctx(dev), _Timed(f"spmm_sub/{f}"):
-            st = lib.acm_spmm_sub(low_t.handle, _vp(gsg), gsg.stride(0), f, _vp(gs), gs.stride(0),
-                                  _vp(ops.inv_deg), _vp(d_struc), d_struc.stride(0), _vp(ws2), ws2.numel() * 4,
-                                  _stream())
-        _lib.check(st, "acm_spmm_sub")
+            st = lib.acm_spmm_ex(low_t.handle, _vp(gsg), gsg.stride(0), f, _vp(d_struc), d_struc.stride(0),
+                                 C.byref(o), _vp(ws2), ws2.numel() * 4, _stream())
+        _lib.check(st, "acm_spmm_ex")
     if ops.sharded:
         import torch.distributed as dist
         dist.all_reduce(d_params, group=ops.group)

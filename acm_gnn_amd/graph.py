@@ -67,20 +67,23 @@ class CsrGraph:
     # ---- construction ----------------------------------------------------
     @classmethod
     def from_csr(cls, indptr, indices, vals, n_cols, chunk=0):
-        """indptr/indices/vals: device tensors (int32/int32/float32)."""
+        """indptr/indices/vals: device tensors (int32/int32/float32).  ``vals=None`` makes a
+        pattern-only operator (every stored entry is 1; no value stream is read by the kernels)."""
         _require_cuda(indptr, "indptr")
         indptr = indptr.to(torch.int32).contiguous()
         indices = indices.to(device=indptr.device, dtype=torch.int32).contiguous()
-        vals = vals.to(device=indptr.device, dtype=torch.float32).contiguous()
         n_rows, nnz = indptr.numel() - 1, indices.numel()
-        if vals.numel() != nnz:
-            raise ValueError(f"vals has {vals.numel()} entries, indices {nnz}")
+        if vals is not None:
+            vals = vals.to(device=indptr.device, dtype=torch.float32).contiguous()
+            if vals.numel() != nnz:
+                raise ValueError(f"vals has {vals.numel()} entries, indices {nnz}")
         out = C.c_void_p()
         with _device_ctx(indptr.device):
             _sync(indptr.device)
             st = _lib.load().acm_csr_create(n_rows, int(n_cols), nnz, indptr.data_ptr(),
                                             indices.data_ptr() if nnz else None,
-                                            vals.data_ptr() if nnz else None, int(chunk), C.byref(out))
+                                            vals.data_ptr() if (nnz and vals is not None) else None, int(chunk),
+                                            C.byref(out))
         _lib.check(st, "acm_csr_create")
         return cls(out.value, indptr.device)
 
@@ -129,11 +132,17 @@ class CsrGraph:
 
     # ---- views (tests, sharding) -----------------------------------------
     def arrays(self):
-        """(indptr, indices, vals) copied out to new torch tensors."""
+        """(indptr, indices, vals) copied out to new torch tensors (vals is None for a
+        pattern-only operator)."""
         _sync(self.device)
         return (_copy_from_ptr(self._ptrs[0], self.n_rows + 1, torch.int32, self.device),
                 _copy_from_ptr(self._ptrs[1], self.nnz, torch.int32, self.device),
-                _copy_from_ptr(self._ptrs[2], self.nnz, torch.float32, self.device))
+                _copy_from_ptr(self._ptrs[2], self.nnz, torch.float32, self.device) if self._ptrs[2] or not self.nnz
+                else None)
+
+    @property
+    def pattern_only(self):
+        return self.nnz > 0 and not self._ptrs[2]
 
     @property
     def src_pos(self):
@@ -198,9 +207,13 @@ class SparseFeatures:
 class FilterOperators:
     """What one ACM layer needs from the graph, for the rows this process owns."""
 
-    def __init__(self, low, deg=None, row_offset=0, n_global=None, group=None):
+    def __init__(self, low, deg=None, row_offset=0, n_global=None, group=None, row_scale=None):
         self.low = low                                  # A_low rows (local) x columns (global)
         self._low_t = None
+        # implicit form A_low = diag(row_scale) P: ``low`` is then the pattern-only operator P (symmetric), which
+        # also serves A_low^T G = P (diag(row_scale) G); see implicit_form() / as_implicit()
+        self.row_scale = row_scale
+        self.self_scale = (1.0 / row_scale) if row_scale is not None else None
         self.deg = deg                                  # d_i for local rows, or None
         self.inv_deg = (1.0 / deg) if deg is not None else None
         self.row_offset = int(row_offset)
@@ -215,9 +228,15 @@ class FilterOperators:
         self._zeros = {}
 
     @property
+    def implicit(self):
+        return self.row_scale is not None
+
+    @property
     def low_t(self):
         if self.low_t_override is not None:
             return self.low_t_override
+        if self.implicit:
+            return self.low                             # P is symmetric: the same column-id stream both ways
         if self._low_t is None:
             self._low_t = self.low.transpose()
         return self._low_t
@@ -244,6 +263,63 @@ class FilterOperators:
     @property
     def sharded(self):
         return self.group is not None
+
+
+# --------------------------------------------------------------------------
+# implicit (pattern-only) form of the low-pass filter
+# --------------------------------------------------------------------------
+def implicit_form(indptr, indices, vals, n_rows, n_cols, max_multiplicity=4):
+    """A (rows sorted by column) = diag(s) P with P a symmetric 0/1/2.. pattern?  -> (indptr_P, indices_P, s) or None.
+
+    The reference's low-pass filter is D^-1 (I + A) (ACM-Geometric/utils.py:5-18, train.py:75-81): one value
+    per row, except that a raw self-loop makes the diagonal of I + A count twice -- P then
+    lists that column twice.  With s_i = min of row i, every entry must be an exact small integer multiple of
+    s_i (fp32(2/d) == 2 * fp32(1/d) bit for bit) and P must equal its transpose as a multiset, so that
+        A G = diag(s) (P G)           A^T G = P (diag(s) G).
+    Works on CPU or device tensors (torch primitives only; one-off preprocessing)."""
+    if n_rows != n_cols or indices.numel() == 0:
+        return None
+    dev = indptr.device
+    ip = indptr.to(torch.int64)
+    counts = ip[1:] - ip[:-1]
+    rows = torch.repeat_interleave(torch.arange(n_rows, device=dev), counts)
+    v = vals.to(torch.float32)
+    if bool((v <= 0).any()):
+        return None
+    s = torch.full((n_rows,), float("inf"), dtype=torch.float32, device=dev).scatter_reduce(0, rows, v, "amin")
+    s = torch.where(torch.isinf(s), torch.ones_like(s), s)
+    m = v / s[rows]
+    mr = m.round()
+    if bool(((mr < 1) | (mr > max_multiplicity) | (m != mr)).any()):
+        return None
+    mult = mr.to(torch.int64)
+    cols = indices.to(torch.int64)
+    keys, perm = torch.sort(rows * n_cols + cols)
+    keys_t, perm_t = torch.sort(cols * n_cols + rows)
+    if not bool(torch.equal(keys, keys_t)) or not bool(torch.equal(mult[perm], mult[perm_t])):
+        return None
+    if bool((keys[1:] == keys[:-1]).any()):
+        return None                                     # un-coalesced input: not handled here
+    if bool((mult == 1).all()):
+        return indptr.to(torch.int32), indices.to(torch.int32), s
+    new_counts = torch.zeros(n_rows, dtype=torch.int64, device=dev).index_add_(0, rows, mult)
+    new_ip = torch.zeros(n_rows + 1, dtype=torch.int64, device=dev)
+    new_ip[1:] = torch.cumsum(new_counts, 0)
+    return new_ip.to(torch.int32), torch.repeat_interleave(cols, mult).to(torch.int32), s
+
+
+def as_implicit(ops):
+    """Replace an explicit single-process FilterOperators by its pattern-only form when A_low allows it
+    (otherwise return ``ops`` unchanged).  ACM_IMPLICIT=0 keeps the explicit value stream."""
+    import os
+    if ops.implicit or ops.general or ops.sharded or os.environ.get("ACM_IMPLICIT", "1") == "0":
+        return ops
+    ip, ix, v = ops.low.arrays()
+    form = implicit_form(ip, ix, v, ops.low.n_rows, ops.low.n_cols)
+    if form is None:
+        return ops
+    pat = CsrGraph.from_csr(form[0], form[1], None, ops.low.n_cols, ops.low.chunk)
+    return FilterOperators(pat, ops.deg, row_scale=form[2].contiguous())
 
 
 # --------------------------------------------------------------------------
@@ -307,13 +383,29 @@ def filters_from_edge_index(edge_index, n, undirected=True, chunk=0):
     indptr = torch.zeros(n + 1, dtype=torch.int64, device=dev)
     indptr[1:] = torch.cumsum(torch.bincount(rows, minlength=n), 0)
     low = CsrGraph.from_csr(indptr.to(torch.int32), cols.to(torch.int32), vals, n, chunk)
-    return FilterOperators(low, deg)
+    return as_implicit(FilterOperators(low, deg))
+
+
+def explicit_arrays(ops):
+    """(indptr, indices, vals) of A_low itself, whichever form ``ops`` holds (duplicates of the implicit
+    pattern are merged back into one entry)."""
+    ip, ix, v = ops.low.arrays()
+    if not ops.implicit:
+        return ip, ix, v
+    n = ops.low.n_rows
+    counts = (ip[1:] - ip[:-1]).to(torch.int64)
+    rows = torch.repeat_interleave(torch.arange(n, device=ip.device), counts)
+    keys, mult = torch.unique_consecutive(rows * ops.low.n_cols + ix.to(torch.int64), return_counts=True)
+    r, c = keys // ops.low.n_cols, keys % ops.low.n_cols
+    new_ip = torch.zeros(n + 1, dtype=torch.int64, device=ip.device)
+    new_ip[1:] = torch.cumsum(torch.bincount(r, minlength=n), 0)
+    return new_ip.to(torch.int32), c.to(torch.int32), mult.to(torch.float32) * ops.row_scale[r]
 
 
 def save_operators(path, ops):
     """On-disk cache of a FilterOperators: numpy .npz with int32 indptr / indices, fp32 vals and d."""
     import numpy as np
-    ip, ix, v = (t.cpu().numpy() for t in ops.low.arrays())
+    ip, ix, v = (t.cpu().numpy() for t in explicit_arrays(ops))
     np.savez_compressed(path, indptr=ip, indices=ix, vals=v, n_cols=np.int64(ops.low.n_cols),
                         deg=ops.deg.cpu().numpy() if ops.deg is not None else np.zeros(0, np.float32))
 
@@ -325,7 +417,7 @@ def load_operators(path, device):
         low = CsrGraph.from_csr(torch.from_numpy(f["indptr"]).to(dev), torch.from_numpy(f["indices"]).to(dev),
                                 torch.from_numpy(f["vals"]).to(dev), int(f["n_cols"]))
         deg = torch.from_numpy(f["deg"]).to(dev) if f["deg"].size else None
-    return FilterOperators(low, deg)
+    return as_implicit(FilterOperators(low, deg))
 
 
 _CACHE = {}
@@ -359,7 +451,7 @@ def operators_for(adj_low, adj_high=None, adj_low_unnormalized=None, verify=True
         deg, ok = degree_from_unnormalized(low, adj_low_unnormalized)
         fused_ok = ok or not verify
     if fused_ok:
-        ops = FilterOperators(low, deg)
+        ops = as_implicit(FilterOperators(low, deg))
     else:
         # General operator pair: the filters are not (A_low, I - A_low[, D A_low - I]) -- e.g. the
         # reference's k-hop ACM-SGC passes A_low^k with an un-powered adj_high

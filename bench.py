@@ -54,8 +54,11 @@ def parse():
     return ap.parse_args()
 
 
-def algorithmic_bytes(label, n, nnz):
-    """HBM bytes a launch must move if every operand is touched exactly once."""
+def algorithmic_bytes(label, n, nnz, implicit=False):
+    """HBM bytes a launch must move if every operand is touched exactly once.
+    Graph term: 4(N+1) + 8 nnz for (column id, value) pairs; 4(N+1) + 4 nnz + 4 N for the pattern-only
+    form (ids + one scale per row) -- SURVEY.md section 8(d)."""
+    per_edge, per_row = (4, 4) if implicit else (8, 0)
     kind, _, shape = label.partition("/")
     if kind == "nll_loss":
         rows, c = (int(v) for v in shape.split("x"))
@@ -65,14 +68,14 @@ def algorithmic_bytes(label, n, nnz):
         fi = int(shape[shape.index("i") + 1:])
         fp = 4 if fi <= 4 else (8 if fi <= 8 else 16)
         if kind == "conv_agg_fwd":      # graph + gathered X once + self X + out + agg + att
-            return 4 * (n + 1) + 8 * nnz + 4 * n * fp * 2 + 4 * n * f + 4 * n * fp + 16 * n
+            return 4 * (n + 1) + per_edge * nnz + per_row * n + 4 * n * fp * 2 + 4 * n * f + 4 * n * fp + 16 * n
         return 4 * n * (f + 2 * fp)     # conv_agg_bwd: grad_out, agg, X
     if kind.startswith("gemm"):
         m, nn, k = (int(v) for v in shape.split("x"))
         return 4 * (m * k + k * nn + m * nn)
     f = int(shape[1:shape.index("k")])
     k = int(shape[shape.index("k") + 1:])
-    graph = 4 * (n + 1) + 8 * nnz
+    graph = 4 * (n + 1) + per_edge * nnz + per_row * n
     if kind == "conv_fwd":       # read Z [n,3F] (+S, deg) once; write out, pre, att
         return graph + 4 * n * 3 * f + (4 * n * (f + 1) if k == 4 else 0) + 4 * n * f + 4 * n * (k - 1) * f + 16 * n
     if kind == "conv_bwd_spmm":  # read G [n,(k-1)F] once; write dZ_L, dZ_H (+dS)
@@ -182,7 +185,7 @@ def main():
     if rank == 0:
         launches, total_ms = focus.summary()[dominant]
         avg_ms = total_ms / launches
-        alg = algorithmic_bytes(dominant, e - b, ops.low.nnz)
+        alg = algorithmic_bytes(dominant, e - b, ops.low.nnz, ops.implicit)
         achieved = alg / (avg_ms * 1e-3) / 1e9
         # PMC traffic cannot be sampled from inside this process; the figure measured for this kernel on this
         # workload by the committed rocprofv3 passes (profiles/r01_pmc_traffic.json) is attached when it applies
@@ -212,6 +215,8 @@ def main():
                                    "step = fwd + NLL loss + bwd + optimizer update",
                        "parallelism": f"csr-row-shard x{world}" if world > 1 else "single-gpu",
                        "node_order": args.node_order, "launch": launch,
+                       "operator_form": "pattern-only P + row scale (shared by A_low and A_low^T)" if ops.implicit
+                       else "explicit (column id, value) CSR + transposed CSR",
                        "eager_ms_per_step": round(eager_ms, 4),
                        "file_edges_per_s": round((adj.nnz // 2) / (ms * 1e-3), 1),
                        "kernel_ms": breakdown, "prep_s": round(prep_s, 1), "final_loss": final_loss},

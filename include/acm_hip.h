@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define ACM_ABI_VERSION 6
+#define ACM_ABI_VERSION 7
 
 typedef enum {
     ACM_OK = 0,
@@ -58,6 +58,15 @@ const char* acm_last_error(void);
  * Replaces: the sparse-COO tensors built at ACM-Geometric/train.py:75-81 /
  * ACM-Pytorch/utils.py:619-629 and the per-call COO coalesce inside
  * torch.spmm (G:87-103).  `chunk` <= 0 selects the default (256).
+ *
+ * vals_dev == NULL makes a PATTERN-ONLY operator: every stored entry counts as 1 and the kernels read no
+ * value stream.  This is the form the filterbank wants: A_low = D^-1 (A + I) has one value per row, so
+ *     A_low   G = D^-1 (P G)            P = pattern of (A + I), symmetric for the reference's graphs
+ *     A_low^T G = P (D^-1 G)
+ * -- one 4-byte column-id stream shared by the forward and the backward products (and small enough to
+ * stay in the 256 MB Infinity Cache between them) instead of two 8-byte (id, value) streams; the row
+ * scales ride the epilogues (row_scale / g_scale / self_scale fields below).  A column may repeat
+ * inside a row (a raw self-loop in A makes the diagonal of A + I count twice).
  */
 int acm_csr_create(int64_t n_rows, int64_t n_cols, int64_t nnz,
                    const int32_t* indptr_dev, const int32_t* indices_dev,
@@ -125,11 +134,22 @@ int acm_spmm_v(const acm_csr_t* a, const float* vals, const float* G, int64_t ld
                float* Y, int64_t ldy, int relu, void* workspace, size_t workspace_bytes,
                acm_stream_t stream);
 
-/* Y = A * G - row_scale[r] * SUB[r, :]  (row_scale may be NULL = 1).  The gradient of the structure parameter in
- * the aggregate-first form: d struc_low = A_low^T (D G_S) - G_S with G = D G_S, SUB = D G_S, row_scale = 1/d. */
-int acm_spmm_sub(const acm_csr_t* a, const float* G, int64_t ldg, int width, const float* sub, int64_t ld_sub,
-                 const float* row_scale, float* Y, int64_t ldy, void* workspace, size_t workspace_bytes,
-                 acm_stream_t stream);
+/* The general form:  Y[r] = relu?( row_scale[r] * (A(vals) G)[r] - sub_scale[r] * SUB[r] ), every option
+ * nullable (NULL scale = 1, NULL sub = no subtraction, NULL vals = the handle's own / implicit ones).
+ * g_bf16: G points to a bf16 matrix (acm_cast_bf16), ldg in elements, 8 < width <= 64 even.
+ * Uses: A_low X = D^-1 (P X) on a pattern-only handle (row_scale = 1/d); the structure-parameter gradient of
+ * the aggregate-first form, d struc_low = A_low^T (D G_S) - G_S. */
+typedef struct {
+    const float* vals;
+    const float* row_scale;
+    const float* sub; int64_t ld_sub;
+    const float* sub_scale;
+    int32_t relu;
+    int32_t g_bf16;
+} acm_spmm_opts_t;
+
+int acm_spmm_ex(const acm_csr_t* a, const void* G, int64_t ldg, int width, float* Y, int64_t ldy,
+                const acm_spmm_opts_t* opts, void* workspace, size_t workspace_bytes, acm_stream_t stream);
 
 /* fp32 -> bf16 (round to nearest even) copy of a [n_rows, n_cols] matrix; dst leading dimension in elements. */
 int acm_cast_bf16(int64_t n_rows, int64_t n_cols, const float* src, int64_t ld_src,
@@ -188,6 +208,8 @@ typedef struct {
      * acm_cast_bf16, leading dimensions in elements; products are accumulated in fp32.  Halves the gathered
      * bytes of the wide (F > 8) path at ~3 decimal digits of the operand (BASELINE config 3). */
     int32_t gather_bf16;
+    /* optional per-row multiplier of every gathered sum (pattern-only a_low: 1/d_i); NULL = 1 */
+    const float* row_scale;
 } acm_conv_fwd_t;
 
 int acm_conv_fwd(const acm_csr_t* a_low, const acm_conv_fwd_t* p,
@@ -223,6 +245,10 @@ typedef struct {
      * [out_before_post > 0] (recomputed) on load */
     const float* post_scale; int64_t ld_post_scale;
     int32_t post_relu;
+    /* optional per-row multiplier of the g_low / g_high outputs (pattern-only backward: the operand of
+     * A_low^T G = P (D^-1 G) is written pre-scaled by 1/d_i); NULL = 1.  `deg` NULL = 1 likewise
+     * (g_struc = dL/dpre_S unscaled, which is what P needs: A_low^T (D G_S) = P G_S). */
+    const float* g_scale;
 } acm_conv_bwd_local_t;
 
 int acm_conv_bwd_local_workspace_bytes(int64_t n_rows, int f_out, int n_channels, size_t* bytes);
@@ -251,6 +277,9 @@ typedef struct {
     float* dz_low;   int64_t ld_dz_low;
     float* dz_high;  int64_t ld_dz_high;
     float* d_struc;  int64_t ld_d_struc;       /* grad of struc_low rows, or NULL */
+    /* optional per-row multiplier of the self term s_high (pattern-only backward: s_high holds D^-1 G_H, so
+     * self_scale = d_i restores G_H); NULL = 1.  inv_deg NULL = 1. */
+    const float* self_scale;
 } acm_conv_bwd_spmm_t;
 
 int acm_conv_bwd_spmm(const acm_csr_t* a_low_t, const acm_conv_bwd_spmm_t* p,
@@ -273,7 +302,7 @@ int acm_conv_bwd_spmm(const acm_csr_t* a_low_t, const acm_conv_bwd_spmm_t* p,
  * dW_I = X^T G_I are row-local reductions (acm_conv_agg_bwd).
  * With the structure channel (n_channels = 4) the parameter S is still gathered
  * F-wide (PS = A_low S, pre_S = deg * PS - S_self) -- 72 floats per edge instead of
- * 192 -- and its gradient needs one F-wide transposed product (acm_spmm_sub).
+ * 192 -- and its gradient needs one F-wide transposed product (acm_spmm_ex).
  */
 typedef struct {
     int32_t f_in, f_pad;       /* f_pad = row length (floats) of xg / xs / agg: 4, 8 or 16, >= f_in; padding is zero */
@@ -298,6 +327,7 @@ typedef struct {
     const float* ss; int64_t ld_ss;    /* struc_low rows of the local nodes (fp32)             */
     const float* deg;                  /* d_i = rowsum(I + A), local rows                      */
     float* ps; int64_t ld_ps;          /* [n_rows, F]  A_low * S, saved for backward           */
+    const float* row_scale;            /* optional per-row multiplier of both gathers (pattern-only a_low: 1/d_i) */
 } acm_conv_agg_fwd_t;
 
 int acm_conv_agg_fwd(const acm_csr_t* a_low, const acm_conv_agg_fwd_t* p,
@@ -323,7 +353,8 @@ typedef struct {
     const float* ps; int64_t ld_ps;    /* A_low * S saved by the forward                       */
     const float* ss; int64_t ld_ss;    /* struc_low rows (local)                               */
     const float* deg;
-    float* g_struc; int64_t ld_g_struc;   /* out: deg_i * dL/dpre_S  (feeds acm_spmm_sub over A_low^T) */
+    float* g_struc; int64_t ld_g_struc;   /* out: g_struc_scale_i * dL/dpre_S  (the operand of the A_low^T product) */
+    const float* g_struc_scale;           /* deg for an explicit A_low^T; NULL (= 1) for the pattern-only form  */
 } acm_conv_agg_bwd_t;
 
 int acm_conv_agg_bwd_workspace_bytes(int64_t n_rows, int f_in, int f_out, size_t* bytes);

@@ -110,7 +110,7 @@ class FakeLib:
 
     # ---- plumbing ---------------------------------------------------------
     def acm_version(self):
-        return 6
+        return 7
 
     def acm_last_error(self):
         return self._err
@@ -128,11 +128,13 @@ class FakeLib:
     def acm_csr_create(self, n_rows, n_cols, nnz, indptr, indices, vals, chunk, out):
         ip = _vec(indptr, n_rows + 1, np.int32)
         ix = _vec(indices, nnz, np.int32) if nnz else np.zeros(0, np.int32)
-        v = _vec(vals, nnz, np.float32) if nnz else np.zeros(0, np.float32)
+        v = (_vec(vals, nnz, np.float32) if vals else np.ones(nnz, np.float32)) if nnz else np.zeros(0, np.float32)
         if ip[0] != 0 or ip[-1] != nnz or np.any(np.diff(ip) < 0) or (nnz and (ix.min() < 0 or ix.max() >= n_cols)):
             self._err = b"acm_csr_create: bad CSR"
             return 2
-        return self._new(_Csr(ip, ix, v, n_cols, chunk), out)
+        obj = _Csr(ip, ix, v, n_cols, chunk)
+        obj.unit = bool(nnz) and not vals                   # pattern-only: implicit ones
+        return self._new(obj, out)
 
     def acm_csr_transpose(self, h, chunk, out):
         import scipy.sparse as sp
@@ -145,13 +147,15 @@ class FakeLib:
                             shape=(a.n_rows, a.n_cols)).T.tocsr()
         pos.sort_indices()
         t.src_pos = (pos.data - 1).astype(np.int32)
+        t.unit = getattr(a, "unit", False)
         return self._new(t, out)
 
     def acm_csr_slice_rows(self, h, b, e, chunk, out):
         a = self._get(h)
         ip = a.indptr[b:e + 1] - a.indptr[b]
-        return self._new(_Csr(ip, a.indices[a.indptr[b]:a.indptr[e]], a.vals[a.indptr[b]:a.indptr[e]], a.n_cols,
-                              chunk or a.chunk), out)
+        obj = _Csr(ip, a.indices[a.indptr[b]:a.indptr[e]], a.vals[a.indptr[b]:a.indptr[e]], a.n_cols, chunk or a.chunk)
+        obj.unit = getattr(a, "unit", False)
+        return self._new(obj, out)
 
     def acm_csr_destroy(self, h):
         self._handles.pop(h.value if isinstance(h, C.c_void_p) else int(h), None)
@@ -165,7 +169,8 @@ class FakeLib:
         i.n_partial_slots = int(np.sum(-(-longs // a.chunk)))
         i.n_items = a.n_rows - len(longs) + i.n_partial_slots
         i.chunk, i.max_degree = a.chunk, int(deg.max()) if len(deg) else 0
-        i.indptr, i.indices, i.vals = a.indptr.ctypes.data, a.indices.ctypes.data, a.vals.ctypes.data
+        i.indptr, i.indices = a.indptr.ctypes.data, a.indices.ctypes.data
+        i.vals = None if getattr(a, "unit", False) else a.vals.ctypes.data
         sp_ = getattr(a, "src_pos", None)
         i.src_pos = sp_.ctypes.data if sp_ is not None else None
         return 0
@@ -224,11 +229,31 @@ class FakeLib:
         return self.acm_spmm_v(h, None, g, ldg, width, y, ldy, 0, ws, wsb, stream)
 
     def acm_spmm_v(self, h, vals, g, ldg, width, y, ldy, relu, ws, wsb, stream):
+        return self._spmm(h, g, ldg, width, y, ldy, vals=vals, relu=relu)
+
+    def acm_spmm_ex(self, h, g, ldg, width, y, ldy, opts, ws, wsb, stream):
+        o = opts._obj if opts else None
+        if o is None:
+            return self._spmm(h, g, ldg, width, y, ldy)
+        return self._spmm(h, g, ldg, width, y, ldy, vals=o.vals, relu=o.relu, row_scale=o.row_scale, sub=o.sub,
+                          ld_sub=o.ld_sub, sub_scale=o.sub_scale, bf16=o.g_bf16)
+
+    def _spmm(self, h, g, ldg, width, y, ldy, vals=None, relu=0, row_scale=None, sub=None, ld_sub=0, sub_scale=None,
+              bf16=0):
         import scipy.sparse as sp
         a = self._get(h)
         v = _vec(vals, len(a.vals)).astype(np.float64) if vals else a.vals.astype(np.float64)
         m = sp.csr_matrix((v, a.indices, a.indptr), shape=(a.n_rows, a.n_cols))
-        out = m @ _view(g, a.n_cols, width, ldg).astype(np.float64)
+        if bf16:
+            dense = (_view(g, a.n_cols, width, ldg, np.uint16).astype(np.uint32) << 16).view(np.float32)
+        else:
+            dense = _view(g, a.n_cols, width, ldg)
+        out = m @ dense.astype(np.float64)
+        if row_scale:
+            out = _vec(row_scale, a.n_rows).astype(np.float64)[:, None] * out
+        if sub:
+            ss = _vec(sub_scale, a.n_rows).astype(np.float64)[:, None] if sub_scale else 1.0
+            out = out - ss * _view(sub, a.n_rows, width, ld_sub)
         _view(y, a.n_rows, width, ldy)[...] = np.maximum(out, 0) if relu else out
         return 0
 
@@ -249,15 +274,16 @@ class FakeLib:
         else:
             def gat(ptr, ld):
                 return _view(ptr, a.n_cols, F, ld)
-        pl = a.dense_mul(gat(p.g_low, p.ld_g_low))
-        ph = _view(p.s_high, n, F, p.ld_s_high).astype(f64) - a.dense_mul(gat(p.g_high, p.ld_g_high))
+        rs = _vec(p.row_scale, n).astype(f64)[:, None] if p.row_scale else 1.0
+        pl = rs * a.dense_mul(gat(p.g_low, p.ld_g_low))
+        ph = _view(p.s_high, n, F, p.ld_s_high).astype(f64) - rs * a.dense_mul(gat(p.g_high, p.ld_g_high))
         zi = _view(p.s_mlp, n, F, p.ld_s_mlp).astype(f64)
         act = (lambda t: np.maximum(t, 0)) if p.relu_after else (lambda t: t)
         H = [act(pl), act(ph), np.maximum(zi, 0) if p.relu_mlp else zi]
         pre = [pl, ph]
         if k == 4:
             deg = _vec(p.deg, n).astype(f64)[:, None]
-            ps = deg * a.dense_mul(gat(p.g_struc, p.ld_g_struc)) - _view(p.s_struc, n, F, p.ld_s_struc)
+            ps = deg * (rs * a.dense_mul(gat(p.g_struc, p.ld_g_struc))) - _view(p.s_struc, n, F, p.ld_s_struc)
             H.append(np.maximum(ps, 0))
             pre.append(ps)
         vecs, lnw, lnb, mix = self._params(p, k, F, p.layernorm)
@@ -285,11 +311,12 @@ class FakeLib:
         dO = _post_bwd(q, dO, q.scale * sum(hd["alpha"][:, c:c + 1] * H[c] for c in range(k)), n, F)
         dH, d_vec, d_lnw, d_lnb, d_mix = _head_backward(H, hd, dO, k, q.layernorm, vecs, lnw, mix, q.scale)
         G = [np.where(m, d, 0.0) for d, m in zip(dH, pos)]
-        _view(q.g_low, n, F, q.ld_g_low)[...] = G[0]
-        _view(q.g_high, n, F, q.ld_g_high)[...] = G[1]
+        gsc = _vec(q.g_scale, n).astype(f64)[:, None] if q.g_scale else 1.0
+        _view(q.g_low, n, F, q.ld_g_low)[...] = gsc * G[0]
+        _view(q.g_high, n, F, q.ld_g_high)[...] = gsc * G[1]
         _view(q.g_mlp, n, F, q.ld_g_mlp)[...] = G[2]
         if k == 4:
-            _view(q.g_struc, n, F, q.ld_g_struc)[...] = _vec(q.deg, n).astype(f64)[:, None] * G[3]
+            _view(q.g_struc, n, F, q.ld_g_struc)[...] = (_vec(q.deg, n).astype(f64)[:, None] if q.deg else 1.0) * G[3]
         for c in range(k):
             _vec(q.d_att_vec[c], F)[...] = d_vec[c]
             if q.layernorm:
@@ -303,7 +330,8 @@ class FakeLib:
         n, F = at.n_rows, r.f_out
         f64 = np.float64
         dl = at.dense_mul(_view(r.g_low, at.n_cols, F, r.ld_g_low))
-        dh = _view(r.s_high, n, F, r.ld_s_high).astype(f64) - at.dense_mul(_view(r.g_high, at.n_cols, F, r.ld_g_high))
+        ssc = _vec(r.self_scale, n).astype(f64)[:, None] if r.self_scale else 1.0
+        dh = ssc * _view(r.s_high, n, F, r.ld_s_high).astype(f64) - at.dense_mul(_view(r.g_high, at.n_cols, F, r.ld_g_high))
         if r.mask_low:
             dl = np.where(_view(r.mask_low, n, F, r.ld_mask_low) > 0, dl, 0.0)
         if r.mask_high:
@@ -312,7 +340,7 @@ class FakeLib:
         _view(r.dz_high, n, F, r.ld_dz_high)[...] = dh
         if r.g_struc:
             ds = at.dense_mul(_view(r.g_struc, at.n_cols, F, r.ld_g_struc)) - \
-                _view(r.s_struc, n, F, r.ld_s_struc).astype(f64) * _vec(r.inv_deg, n).astype(f64)[:, None]
+                _view(r.s_struc, n, F, r.ld_s_struc).astype(f64) * (_vec(r.inv_deg, n).astype(f64)[:, None] if r.inv_deg else 1.0)
             _view(r.d_struc, n, F, r.ld_d_struc)[...] = ds
         return 0
 
@@ -327,7 +355,8 @@ class FakeLib:
         a, p = self._get(h), pp._obj
         n, k = a.n_rows, p.n_channels
         F, fi, fp, x, W = self._agg_common(p, n)
-        P = a.dense_mul(_view(p.xg, a.n_cols, fp, p.ld_xg))[:, :fi]
+        rs = _vec(p.row_scale, n).astype(np.float64)[:, None] if p.row_scale else 1.0
+        P = (rs * a.dense_mul(_view(p.xg, a.n_cols, fp, p.ld_xg)))[:, :fi]
         raw = [P @ W[0], (x - P) @ W[1], x @ W[2]]
         relu = [p.relu_after, p.relu_after, p.relu_mlp]
         if k == 4:
@@ -335,7 +364,7 @@ class FakeLib:
                 sg = (_view(p.sg, a.n_cols, F, p.ld_sg, np.uint16).astype(np.uint32) << 16).view(np.float32)
             else:
                 sg = _view(p.sg, a.n_cols, F, p.ld_sg)
-            PS = a.dense_mul(sg)
+            PS = rs * a.dense_mul(sg)
             _view(p.ps, n, F, p.ld_ps)[...] = PS
             PS = _view(p.ps, n, F, p.ld_ps).astype(np.float64)
             raw.append(_vec(p.deg, n).astype(np.float64)[:, None] * PS - _view(p.ss, n, F, p.ld_ss))
@@ -373,7 +402,8 @@ class FakeLib:
         dH, d_vec, d_lnw, d_lnb, d_mix = _head_backward(H, hd, dO, k, q.layernorm, vecs, lnw, mix, q.scale)
         G = [np.where(m, d, 0.0) for d, m in zip(dH, pos)]
         if k == 4:
-            _view(q.g_struc, n, F, q.ld_g_struc)[...] = deg * G[3]
+            _view(q.g_struc, n, F, q.ld_g_struc)[...] = \
+                (_vec(q.g_struc_scale, n).astype(np.float64)[:, None] if q.g_struc_scale else 1.0) * G[3]
         npg = 3 * fi * F + 3 * k * F + k * k
         out = _vec(q.d_params, npg)
         out[...] = 0
@@ -411,13 +441,6 @@ class FakeLib:
             v[...] = v * f32(c.beta2) + f32(1.0 - c.beta2) * gg * gg
             p -= step_size * (m / (np.sqrt(v) / bc2_sqrt + f32(c.eps)))
             step[0] = kk
-        return 0
-
-    def acm_spmm_sub(self, h, g, ldg, width, sub, ld_sub, row_scale, y, ldy, ws, wsb, stream):
-        a = self._get(h)
-        out = a.dense_mul(_view(g, a.n_cols, width, ldg))
-        rs = _vec(row_scale, a.n_rows).astype(np.float64)[:, None] if row_scale else 1.0
-        _view(y, a.n_rows, width, ldy)[...] = out - rs * _view(sub, a.n_rows, width, ld_sub)
         return 0
 
 

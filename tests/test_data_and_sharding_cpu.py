@@ -97,13 +97,14 @@ def _worker(rank, world, port, cfg, ret):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         fake_lib.install(MP())
+        os.environ["ACM_IMPLICIT"] = str(cfg.get("implicit", 1))
         import torch.nn.functional as F
         from acm_gnn_amd import GCN, data as D, distributed as DD
         adj, x_np, y_np, (tr, _, _), _ = D.synthetic_dataset("tiny", seed=5, pad_to=world)
         low, deg = D.build_filters(adj)
         n = adj.shape[0]
         ops = DD.make_sharded_operators(low, deg, "cpu", with_structure=bool(cfg["s"]))
-        assert ops.sharded and ops.n_local == n // world
+        assert ops.sharded and ops.n_local == n // world and ops.implicit == bool(cfg.get("implicit", 1))
         b, e = DD.shard_bounds(n, world, rank)
         torch.manual_seed(0)
         full = GCN(7, 16, 2, 2, n, 0.0, cfg["model"], cfg["s"], variant=bool(cfg["variant"]), attn_layernorm=True)
@@ -128,7 +129,11 @@ def _worker(rank, world, port, cfg, ret):
 
 
 @pytest.mark.parametrize("cfg", [dict(model="acmgcnp", s=0, variant=0), dict(model="acmgcnp", s=1, variant=1),
-                                 dict(model="acmgcn", s=0, variant=1)], ids=["agg+literal", "struct-acmii", "acmii"])
+                                 dict(model="acmgcn", s=0, variant=1), dict(model="acmgcnp", s=1, variant=0),
+                                 dict(model="acmgcnp", s=1, variant=0, implicit=0),
+                                 dict(model="acmgcnp", s=1, variant=1, implicit=0)],
+                         ids=["agg+literal", "struct-acmii", "acmii", "struct-agg", "struct-agg-explicit",
+                              "struct-acmii-explicit"])
 def test_two_rank_row_shard_equals_single_process(cfg, monkeypatch):
     """world_size = 2 over gloo: the sharded forward/backward (halo all-gathers + parameter-gradient
     all-reduce issued by functional.AcmConvFunction) must reproduce the 1-process result."""
@@ -159,12 +164,13 @@ def test_two_rank_row_shard_equals_single_process(cfg, monkeypatch):
         assert p.exitcode == 0
     # single-process reference through the same host stack
     fake_lib.install(monkeypatch)
+    monkeypatch.setenv("ACM_IMPLICIT", "0")                   # the single-process reference keeps explicit values
     from acm_gnn_amd import GCN, data as D, distributed as DD
     adj, x_np, y_np, (tr, _, _), _ = D.synthetic_dataset("tiny", seed=5, pad_to=world)
     low, deg = D.build_filters(adj)
     n = adj.shape[0]
     ops = DD.make_sharded_operators(low, deg, "cpu", with_structure=bool(cfg["s"]))
-    assert not ops.sharded
+    assert not ops.sharded and not ops.implicit
     torch.manual_seed(0)
     full = GCN(7, 16, 2, 2, n, 0.0, cfg["model"], cfg["s"], variant=bool(cfg["variant"]), attn_layernorm=True)
     out = full(torch.from_numpy(x_np), ops)

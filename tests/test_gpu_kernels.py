@@ -162,7 +162,9 @@ def test_device_filter_construction_is_bit_exact(tmp_path):
     a.data[:] = 1.0                                                       # to_undirected coalesces duplicates
     ref_low, _, _ = O.filters_linkx(a)
     ip, ix, v = O.coo_to_csr_arrays(ref_low)
-    got = [t.cpu().numpy() for t in ops.low.arrays()]
+    assert ops.implicit and ops.low.pattern_only            # D^-1 (I + A) always has the pattern-only form
+    assert ops.low.nnz == len(ix) + int((a.diagonal() > 0).sum())   # raw self-loops list their column twice
+    got = [t.cpu().numpy() for t in G.explicit_arrays(ops)]
     assert np.array_equal(got[0], ip) and np.array_equal(got[1], ix)
     assert np.array_equal(got[2], v)                                      # bit-exact values
     assert np.array_equal(ops.deg.cpu().numpy(), np.asarray((sp.identity(n) + a).sum(1)).ravel().astype(np.float32))
@@ -170,4 +172,16 @@ def test_device_filter_construction_is_bit_exact(tmp_path):
     G.save_operators(path, ops)
     back = G.load_operators(path, DEV)
     x = torch.randn(n, 8, device=DEV)
+    assert back.implicit and torch.equal(back.row_scale, ops.row_scale)
     assert torch.equal(AF.spmm(back.low, x), AF.spmm(ops.low, x)) and torch.equal(back.deg, ops.deg)
+    # the pattern-only product, row-scaled, is the explicit one
+    import os
+    os.environ["ACM_IMPLICIT"] = "0"
+    try:
+        expl = G.filters_from_edge_index(ei, n)
+    finally:
+        del os.environ["ACM_IMPLICIT"]
+    assert not expl.implicit
+    want = AF.spmm(expl.low, x)
+    got2 = ops.row_scale[:, None] * AF.spmm(ops.low, x)
+    assert float((got2 - want).abs().max()) < 1e-5 * float(want.abs().max())

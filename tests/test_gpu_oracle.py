@@ -28,10 +28,11 @@ def _graph(n, seed, density=0.05, hub=True):
 
 
 def _run_both(model_type, variant, structure_info, ln, n, f_in, f_out, seed, x_grad, monkeypatch, agg,
-              adj=None, chunk_env=None):
+              adj=None, chunk_env=None, implicit=True):
     from acm_gnn_amd import GraphConvolution
-    from acm_gnn_amd.graph import clear_cache
+    from acm_gnn_amd.graph import clear_cache, operators_for
     monkeypatch.setenv("ACM_AGG_FIRST", "1" if agg else "0")
+    monkeypatch.setenv("ACM_IMPLICIT", "1" if implicit else "0")
     clear_cache()
     adj = adj if adj is not None else _graph(n, seed)
     n = adj.shape[0]
@@ -56,7 +57,9 @@ def _run_both(model_type, variant, structure_info, ln, n, f_in, f_out, seed, x_g
     # HIP
     layer = layer.to(DEV)
     xd = x.to(DEV).requires_grad_(x_grad)
-    out = layer(xd, low.to(DEV), high.to(DEV), un.to(DEV) if structure_info else None)
+    lowd, highd, und = low.to(DEV), high.to(DEV), un.to(DEV) if structure_info else None
+    assert operators_for(lowd, highd, und).implicit == implicit      # filters_linkx graphs always qualify
+    out = layer(xd, lowd, highd, und)
     out.backward(gout.to(DEV))
     scale = max(1.0, float(ref.abs().max()))
     assert float((out.detach().cpu() - ref.detach()).abs().max()) < 2e-5 * scale
@@ -106,7 +109,7 @@ AGG_STRUC_CASES = [(True, 7, 64), (False, 7, 64), (True, 3, 24), (True, 16, 40),
 
 @pytest.mark.parametrize("ln,f_in,f_out", AGG_STRUC_CASES)
 def test_aggregate_first_with_structure_channel(ln, f_in, f_out, monkeypatch):
-    """ABI v5: four channels in aggregate-first order (pre_S = deg (A_low S) - S; dS through acm_spmm_sub)."""
+    """ABI v5: four channels in aggregate-first order (pre_S = deg (A_low S) - S; dS through acm_spmm_ex)."""
     from acm_gnn_amd import functional as AF
     timer = AF.KernelTimer()
     AF.set_kernel_timer(timer)
@@ -123,33 +126,81 @@ def test_aggregate_first_with_structure_channel(ln, f_in, f_out, monkeypatch):
     assert float((a - b).abs().max()) < 2e-5 * max(1.0, float(b.abs().max()))
 
 
-def test_spmm_sub_entry_point():
-    """Y = A G - row_scale * SUB, against scipy, including split long rows."""
+def test_spmm_ex_entry_point():
+    """Y = relu?(row_scale * (A G) - sub_scale * SUB) against scipy: explicit values and pattern-only handles
+    (with a repeated column), split long rows, every width class, bf16 operand."""
     import ctypes as C
     from acm_gnn_amd import _lib
+    from acm_gnn_amd.functional import cast_bf16
     from acm_gnn_amd.graph import CsrGraph
     rng = np.random.default_rng(0)
-    adj = _graph(700, 4, density=0.02)
-    a = sp.csr_matrix(adj, dtype=np.float32)
-    a.data = rng.standard_normal(a.nnz).astype(np.float32)
-    g = CsrGraph.from_scipy(a, DEV, chunk=64)
+    n = 700
+    a = sp.csr_matrix(_graph(n, 4, density=0.02), dtype=np.float32)
+    a.sort_indices()
     lib = _lib.load()
-    for width in (5, 24, 64, 100):
-        G = rng.standard_normal((700, width)).astype(np.float32)
-        S = rng.standard_normal((700, width)).astype(np.float32)
-        rs = rng.uniform(0.1, 2.0, 700).astype(np.float32)
-        for scale in (rs, None):
-            Gd, Sd = torch.from_numpy(G).to(DEV), torch.from_numpy(S).to(DEV)
-            rd = torch.from_numpy(scale).to(DEV) if scale is not None else None
-            Y = torch.empty(700, width, device=DEV)
-            ws = g.workspace(width)
-            st = lib.acm_spmm_sub(g.handle, Gd.data_ptr(), width, width, Sd.data_ptr(), width,
-                                  rd.data_ptr() if rd is not None else None, Y.data_ptr(), width, ws.data_ptr(),
-                                  ws.numel() * 4, torch.cuda.current_stream().cuda_stream)
-            _lib.check(st, "acm_spmm_sub")
-            ref = a.astype(np.float64) @ G.astype(np.float64) - (scale[:, None] if scale is not None else 1.0) * S
-            err = np.abs(Y.cpu().numpy() - ref).max()
-            assert err < 2e-5 * max(1.0, np.abs(ref).max()), (width, err)
+    for unit in (False, True):
+        if unit:
+            # repeat the first stored column of every non-empty row: the multigraph encoding of a raw self-loop
+            ip, ix = a.indptr, a.indices
+            rep = np.ones(a.nnz, np.int64)
+            rep[ip[:-1][np.diff(ip) > 0]] = 2
+            ix2 = np.repeat(ix, rep)
+            ip2 = np.concatenate([[0], np.cumsum(np.bincount(np.repeat(np.arange(n), np.diff(ip)), weights=rep, minlength=n))]).astype(np.int32)
+            g = CsrGraph.from_csr(torch.from_numpy(ip2).to(DEV), torch.from_numpy(ix2.astype(np.int32)).to(DEV), None, n, chunk=64)
+            assert g.pattern_only and g.arrays()[2] is None
+            ref_a = sp.csr_matrix((np.ones(len(ix2)), ix2, ip2), shape=(n, n))       # duplicates add up in the product
+        else:
+            a.data = rng.standard_normal(a.nnz).astype(np.float32)
+            g = CsrGraph.from_scipy(a, DEV, chunk=64)
+            ref_a = a.astype(np.float64)
+        for width in (2, 5, 8, 24, 64, 100):
+            G = rng.standard_normal((n, width)).astype(np.float32)
+            S = rng.standard_normal((n, width)).astype(np.float32)
+            rs = rng.uniform(0.1, 2.0, n).astype(np.float32)
+            ss = rng.uniform(0.1, 2.0, n).astype(np.float32)
+            for use_rs, use_sub, use_ss, relu, bf16 in ((0, 0, 0, 0, 0), (1, 0, 0, 1, 0), (1, 1, 1, 0, 0), (0, 1, 0, 1, 0),
+                                                        (1, 1, 0, 0, 1)):
+                if bf16 and not (8 < width <= 64 and width % 2 == 0):
+                    continue
+                Gd, Sd = torch.from_numpy(G).to(DEV), torch.from_numpy(S).to(DEV)
+                rd, sd = torch.from_numpy(rs).to(DEV), torch.from_numpy(ss).to(DEV)
+                Gref = G
+                if bf16:
+                    Gb = cast_bf16(Gd)
+                    Gref = Gb.float().cpu().numpy()                       # bf16 -> fp32 is exact
+                o = _lib.SpmmOpts()
+                o.row_scale = rd.data_ptr() if use_rs else None
+                o.sub, o.ld_sub = (Sd.data_ptr(), width) if use_sub else (None, 0)
+                o.sub_scale = sd.data_ptr() if use_ss else None
+                o.relu, o.g_bf16 = relu, bf16
+                Y = torch.empty(n, width, device=DEV)
+                ws = g.workspace(width)
+                src = Gb if bf16 else Gd
+                st = lib.acm_spmm_ex(g.handle, src.data_ptr(), src.stride(0), width, Y.data_ptr(), width, C.byref(o),
+                                     ws.data_ptr(), ws.numel() * 4, torch.cuda.current_stream().cuda_stream)
+                _lib.check(st, "acm_spmm_ex")
+                ref = ref_a @ Gref.astype(np.float64)
+                if use_rs:
+                    ref = rs[:, None] * ref
+                if use_sub:
+                    ref = ref - (ss[:, None] if use_ss else 1.0) * S
+                if relu:
+                    ref = np.maximum(ref, 0)
+                err = np.abs(Y.cpu().numpy() - ref).max()
+                assert err < 3e-5 * max(1.0, np.abs(ref).max()), (unit, width, use_rs, use_sub, use_ss, relu, bf16, err)
+
+
+@pytest.mark.parametrize("model_type,variant,s,ln,f_in,f_out,x_grad,agg", [
+    ("acmgcnp", 0, 1, True, 7, 64, False, True), ("acmgcnp", 0, 0, True, 7, 64, False, True),
+    ("acmgcnp", 0, 1, True, 33, 64, True, False), ("acmgcnp", 1, 1, True, 64, 5, True, False),
+    ("acmgcn", 0, 0, False, 40, 2, True, False), ("acmgcnp", 1, 1, True, 20, 100, True, False),
+    ("acmsgc", 0, 0, False, 30, 7, True, False)])
+def test_explicit_value_form_matches_oracle(model_type, variant, s, ln, f_in, f_out, x_grad, agg, monkeypatch):
+    """ACM_IMPLICIT=0: the explicit (id, value) operators -- the form every other test leaves for the
+    pattern-only one -- against the oracle, and equal to the pattern-only result."""
+    a = _run_both(model_type, variant, s, ln, 400, f_in, f_out, 3, x_grad, monkeypatch, agg=agg, implicit=False)
+    b = _run_both(model_type, variant, s, ln, 400, f_in, f_out, 3, x_grad, monkeypatch, agg=agg, implicit=True)
+    assert float((a - b).abs().max()) < 2e-5 * max(1.0, float(b.abs().max()))
 
 
 def test_aggregate_first_not_used_when_illegal(monkeypatch):
@@ -185,6 +236,7 @@ def test_real_structures(name, f_out, s, monkeypatch):
     adj = sp.csr_matrix((np.ones(len(g["adj_un_indices"])), g["adj_un_indices"], g["adj_un_indptr"]), shape=(n, n))
     _run_both("acmgcnp", 0, s, True, n, 24, f_out, 2, True, monkeypatch, agg=False, adj=adj)
     _run_both("acmgcnp", 0, s, True, n, 7, 64, 2, False, monkeypatch, agg=True, adj=adj)
+    _run_both("acmgcnp", 0, s, True, n, 24, f_out, 2, True, monkeypatch, agg=False, adj=adj, implicit=False)
 
 
 @pytest.mark.parametrize("model_type,variant,s,f_out", [("acmgcn", 0, 0, 64), ("acmgcnp", 1, 1, 64), ("acmgcnp", 0, 0, 5)])

@@ -88,7 +88,7 @@ def test_aggregate_first_dispatch_rules(monkeypatch):
     from acm_gnn_amd import GraphConvolution
     calls = []
     for name in ("acm_conv_fwd", "acm_conv_agg_fwd", "acm_conv_agg_bwd", "acm_conv_bwd_spmm", "acm_gemm",
-                 "acm_spmm_sub"):
+                 "acm_spmm_ex"):
         orig = getattr(fake, name)
         monkeypatch.setattr(fake, name, (lambda o, n: lambda *a: (calls.append(n), o(*a))[1])(orig, name))
     low, high, un, _ = graph_tensors("geometric")
@@ -103,7 +103,7 @@ def test_aggregate_first_dispatch_rules(monkeypatch):
 
     assert run("acmgcnp", 0, 0, False) == {"acm_conv_agg_fwd", "acm_conv_agg_bwd"}
     assert "acm_conv_agg_fwd" not in run("acmgcnp", 1, 0, False)
-    assert run("acmgcnp", 0, 1, False) == {"acm_conv_agg_fwd", "acm_conv_agg_bwd", "acm_spmm_sub"}
+    assert run("acmgcnp", 0, 1, False) == {"acm_conv_agg_fwd", "acm_conv_agg_bwd", "acm_spmm_ex"}
     assert "acm_conv_agg_fwd" not in run("acmgcnp", 0, 0, True)
     assert "acm_conv_agg_fwd" not in run("acmgcnp", 0, 0, False, f_in=64, f_out=2)
     monkeypatch.setenv("ACM_AGG_FIRST", "0")

@@ -1,0 +1,122 @@
+"""The pattern-only form of the low-pass filter (A_low = diag(s) P, P symmetric): detection, the
+repeated-column encoding of raw self-loops, round trip, and that the layer gives the same numbers through
+either form (host stack on the numpy double of the ABI)."""
+import os
+
+import numpy as np
+import pytest
+import scipy.sparse as sp
+import torch
+
+import fake_lib
+from conftest import GOLDEN, graph_tensors, load_npz
+from oracle import acm_oracle as O
+
+
+def _low_of(name):
+    g = load_npz(os.path.join(GOLDEN, f"graph_{name}.npz"))
+    n = int(g["n"])
+    adj = sp.csr_matrix((np.ones(len(g["adj_un_indices"])), g["adj_un_indices"], g["adj_un_indptr"]), shape=(n, n))
+    low, _, _ = O.filters_linkx(adj)
+    low = low.coalesce()
+    m = sp.coo_matrix((low.values().numpy(), low.indices().numpy()), shape=(n, n)).tocsr()
+    m.sort_indices()
+    return m, adj
+
+
+@pytest.mark.parametrize("name", ["cora", "chameleon", "squirrel"])
+def test_detection_on_real_structures(name):
+    from acm_gnn_amd.graph import implicit_form
+    low, adj = _low_of(name)
+    n = low.shape[0]
+    form = implicit_form(torch.from_numpy(low.indptr), torch.from_numpy(low.indices), torch.from_numpy(low.data), n, n)
+    assert form is not None, name
+    ip, ix, s = (t.numpy() for t in form)
+    n_self = int(adj.diagonal().sum())
+    assert len(ix) == low.nnz + n_self                         # a raw self-loop lists its column twice (quirk Q5)
+    if name == "squirrel":
+        assert n_self > 0
+    pat = sp.csr_matrix((np.ones(len(ix), np.float32), ix, ip), shape=(n, n))     # duplicates are summed by the product
+    x = np.random.default_rng(0).standard_normal((n, 5))
+    np.testing.assert_allclose(s[:, None] * (pat @ x), low @ x, rtol=1e-6, atol=1e-7)
+    np.testing.assert_allclose(pat @ (s[:, None] * x), low.T @ x, rtol=1e-6, atol=1e-7)
+
+
+def test_detection_rejects_what_it_must():
+    from acm_gnn_amd.graph import implicit_form
+    low, _ = _low_of("cora")
+    n = low.shape[0]
+
+    def form(m):
+        m = m.tocsr()
+        m.sort_indices()
+        return implicit_form(torch.from_numpy(m.indptr), torch.from_numpy(m.indices), torch.from_numpy(m.data.astype(np.float32)),
+                             m.shape[0], m.shape[1])
+    assert form(low) is not None
+    bad = low.copy()
+    bad.data[3] *= 1.5                                        # not one value per row
+    assert form(bad) is None
+    tri = sp.triu(low, k=0).tocsr()                           # one value per row but not symmetric
+    assert form(tri) is None
+    assert form(low[:100]) is None                            # not square
+    neg = low.copy()
+    neg.data[:] *= -1
+    assert form(neg) is None
+    sym = (low @ low).tocsr()                                  # two-hop: symmetric pattern, many values per row
+    assert form(sym) is None
+
+
+@pytest.mark.parametrize("model_type,variant,s,x_grad,f_in,f_out", [
+    ("acmgcnp", 0, 1, False, 7, 64), ("acmgcnp", 0, 0, False, 7, 64), ("acmgcnp", 1, 1, True, 20, 6),
+    ("acmgcn", 0, 0, True, 33, 5), ("acmgcnp", 0, 1, True, 12, 64)])
+def test_layer_same_through_either_form(model_type, variant, s, x_grad, f_in, f_out, monkeypatch):
+    fake_lib.install(monkeypatch)
+    from acm_gnn_amd import GraphConvolution, graph
+    low, high, un, _ = graph_tensors("geometric")
+    n = low.shape[0]
+    torch.manual_seed(3)
+    layer = GraphConvolution(f_in, f_out, n, model_type, variant=variant, structure_info=s, attn_layernorm=True)
+    x0 = torch.randn(n, f_in)
+    go = torch.randn(n, f_out)
+    res = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("ACM_IMPLICIT", mode)
+        graph.clear_cache()
+        ops = graph.operators_for(low, high, un if s else None)
+        assert ops.implicit == (mode == "1")
+        if ops.implicit:
+            assert ops.low.pattern_only and ops.low_t is ops.low
+        layer.zero_grad()
+        x = x0.clone().requires_grad_(x_grad)
+        out = layer(x, low, high, un if s else None)
+        out.backward(go)
+        res[mode] = (out.detach().clone(), x.grad.clone() if x_grad else None,
+                     {k: v.grad.clone() for k, v in layer.named_parameters() if v.grad is not None})
+    a, b = res["1"], res["0"]
+    np.testing.assert_allclose(a[0].numpy(), b[0].numpy(), rtol=1e-5, atol=1e-5)
+    if x_grad:
+        np.testing.assert_allclose(a[1].numpy(), b[1].numpy(), rtol=1e-4, atol=1e-5 * float(b[1].abs().max()) + 1e-7)
+    assert set(a[2]) == set(b[2])
+    for k in b[2]:
+        np.testing.assert_allclose(a[2][k].numpy(), b[2][k].numpy(), rtol=1e-4, atol=2e-5 * float(b[2][k].abs().max()) + 1e-7,
+                                   err_msg=k)
+
+
+def test_explicit_arrays_round_trip_and_cache_file(tmp_path, monkeypatch):
+    fake_lib.install(monkeypatch)
+    from acm_gnn_amd import graph
+    low, adj = _low_of("squirrel")
+    n = low.shape[0]
+    ops = graph.FilterOperators(graph.CsrGraph.from_csr(torch.from_numpy(low.indptr), torch.from_numpy(low.indices),
+                                                        torch.from_numpy(low.data), n))
+    imp = graph.as_implicit(ops)
+    assert imp.implicit and imp.low.nnz == low.nnz + int(adj.diagonal().sum())
+    ip, ix, v = graph.explicit_arrays(imp)
+    np.testing.assert_array_equal(ip.numpy(), low.indptr)
+    np.testing.assert_array_equal(ix.numpy(), low.indices)
+    np.testing.assert_array_equal(v.numpy(), low.data)          # bit for bit: 2 * fp32(1/d) == fp32(2/d)
+    path = str(tmp_path / "ops.npz")
+    graph.save_operators(path, imp)
+    back = graph.load_operators(path, "cpu")
+    assert back.implicit and back.low.nnz == imp.low.nnz
+    np.testing.assert_array_equal(back.row_scale.numpy(), imp.row_scale.numpy())
