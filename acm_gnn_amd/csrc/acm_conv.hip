@@ -121,6 +121,43 @@ struct EpiFwd {
     }
 };
 
+// Narrow layers (F <= 8), phase 1 of the fused forward: the raw neighbour sums go to the `pre` buffer; phase 2
+// (conv_fwd_rows_kernel) finishes every row with one THREAD per row.  In the narrow gather the whole row sits
+// in one lane, so running EpiFwd there leaves 31 of 32 lanes idle through the head's exp / rsqrt chains
+// (~40 us of the 110 us F = 2 forward on the twitch graph).
+struct EpiRaw {
+    using Args = acm_conv_fwd_t;
+    template <class L, int NG>
+    static __device__ __forceinline__ void apply(const Args& p, int row, const L& lay, int F,
+                                                 const float (&acc)[NG][L::NV]) {
+        if (!Owns<L>::lane_stores(lay)) return;
+        float* pr = p.pre + (long)row * p.ld_pre;
+#pragma unroll
+        for (int i = 0; i < L::NV; ++i) {
+            const int col = lay.col(i);
+            if (col < F) {
+#pragma unroll
+                for (int c = 0; c < NG; ++c) pr[c * F + col] = acc[c][i];
+            }
+        }
+    }
+};
+
+template <int FP, int NG>
+__global__ __launch_bounds__(256) void conv_fwd_rows_kernel(acm_conv_fwd_t p, int n_rows) {
+    const int row = blockIdx.x * 256 + threadIdx.x;
+    if (row >= n_rows) return;
+    const int F = p.f_out;
+    float acc[NG][FP];
+    const float* pr = p.pre + (long)row * p.ld_pre;
+#pragma unroll
+    for (int c = 0; c < NG; ++c)
+#pragma unroll
+        for (int f = 0; f < FP; ++f) acc[c][f] = (f < F) ? pr[c * F + f] : 0.f;
+    const LaySerial<FP> lay{true};
+    EpiFwd::apply<LaySerial<FP>, NG>(p, row, lay, F, acc);     // overwrites this row of `pre` with the final values
+}
+
 struct EpiBwd {
     using Args = acm_conv_bwd_spmm_t;
     template <class L, int NG>
@@ -380,89 +417,21 @@ __device__ __forceinline__ void load_row(const float* __restrict__ p, int F, boo
     }
 }
 
+// Narrow gather (F <= 8): one neighbour per lane, GS lanes per work item, the whole gathered row in the lane.
 // MERGED: channels 0 and 1 are one contiguous 16-byte-aligned block [c0 (FP) | c1 (FP)] in a row of
 // g.p[0], fetched with float4 loads -- one L2 request per neighbour instead of two (the narrow
 // kernels are bound by L1->L2 request count, profiles/r01_pmc_*.csv).
+// Software-pipelined over the work list: most rows of a power-law graph are one step long (79 % of the
+// twitch rows have <= 64 neighbours), so the per-item chain
+//     item descriptor -> column ids -> gathered rows -> reduce -> epilogue
+// is four dependent memory latencies with nothing to overlap them inside the wave.  A group therefore walks
+// the work list with a grid stride (grid capped at NARROW_MAX_BLOCKS), and while the rows of the current
+// step are in flight it already has the next item's descriptor and the next step's column ids / values
+// requested (of the same item, or of the next one when this was its last step).
+constexpr int NARROW_MAX_BLOCKS = 8192;
+
 template <int FP, int NG, int GS, bool MERGED, class Epi>
 __global__ __launch_bounds__(256) void spmm_narrow_kernel(CsrView csr, GatherSrc g, int F, int vecmask,
-                                                          typename Epi::Args ea, float* __restrict__ partial) {
-    constexpr int GPB = 256 / GS;  // groups (work items) per block
-    const int gl = threadIdx.x % GS;
-    const int w = blockIdx.x * GPB + threadIdx.x / GS;
-    if (w >= csr.n_items) return;   // whole groups leave together
-    const AcmItem it = csr.items[w];
-    float acc[NG][FP];
-#pragma unroll
-    for (int c = 0; c < NG; ++c)
-#pragma unroll
-        for (int f = 0; f < FP; ++f) acc[c][f] = 0.f;
-    for (int k0 = it.begin; k0 < it.end; k0 += 2 * GS) {
-        const int ka = k0 + gl, kb = ka + GS;
-        const bool va = ka < it.end, vb = kb < it.end;
-        const int ja = va ? csr.indices[ka] : 0, jb = vb ? csr.indices[kb] : 0;
-        const bool unit = csr.vals == nullptr;       // pattern-only operator: implicit ones, no value stream
-        const float aa = va ? (unit ? 1.f : csr.vals[ka]) : 0.f, ab = vb ? (unit ? 1.f : csr.vals[kb]) : 0.f;
-        float za[NG][FP], zb[NG][FP];
-        if (MERGED) {
-            float ta[2 * FP], tb[2 * FP];
-            load_row<2 * FP>(g.p[0] + (long)ja * g.ld[0], 2 * FP, true, ta);
-            load_row<2 * FP>(g.p[0] + (long)jb * g.ld[0], 2 * FP, true, tb);
-#pragma unroll
-            for (int f = 0; f < FP; ++f) {
-                za[0][f] = ta[f];
-                zb[0][f] = tb[f];
-                if (NG > 1) {
-                    za[1 % NG][f] = ta[FP + f];
-                    zb[1 % NG][f] = tb[FP + f];
-                }
-            }
-#pragma unroll
-            for (int c = 2; c < NG; ++c) {
-                load_row<FP>(g.p[c] + (long)ja * g.ld[c], F, (vecmask >> c) & 1, za[c]);
-                load_row<FP>(g.p[c] + (long)jb * g.ld[c], F, (vecmask >> c) & 1, zb[c]);
-            }
-        } else {
-#pragma unroll
-            for (int c = 0; c < NG; ++c) {
-                load_row<FP>(g.p[c] + (long)ja * g.ld[c], F, (vecmask >> c) & 1, za[c]);
-                load_row<FP>(g.p[c] + (long)jb * g.ld[c], F, (vecmask >> c) & 1, zb[c]);
-            }
-        }
-#pragma unroll
-        for (int c = 0; c < NG; ++c)
-#pragma unroll
-            for (int f = 0; f < FP; ++f) {
-                // the selects keep a non-finite row 0 from leaking into rows that never reference it
-                acc[c][f] = va ? fmaf(aa, za[c][f], acc[c][f]) : acc[c][f];
-                acc[c][f] = vb ? fmaf(ab, zb[c][f], acc[c][f]) : acc[c][f];
-            }
-    }
-#pragma unroll
-    for (int c = 0; c < NG; ++c)
-#pragma unroll
-        for (int f = 0; f < FP; ++f) acc[c][f] = acm_group_sum<GS>(acc[c][f]);
-    if (it.slot < 0) {
-        LaySerial<FP> lay{gl == 0};
-        Epi::template apply<LaySerial<FP>, NG>(ea, it.row, lay, F, acc);
-    } else if (gl == 0) {
-        float* ps = partial + (long)it.slot * (NG * F);
-#pragma unroll
-        for (int c = 0; c < NG; ++c)
-#pragma unroll
-            for (int f = 0; f < FP; ++f)
-                if (f < F) ps[c * F + f] = acc[c][f];
-    }
-}
-
-// Persistent, software-pipelined form of the narrow gather.  Most rows of a power-law graph are one
-// iteration long (79 % of the twitch rows have <= 64 neighbours), so the per-item chain
-//     item descriptor -> column ids -> gathered rows -> reduce -> epilogue
-// is four dependent memory latencies with nothing to overlap them inside the wave.  Here a group walks the
-// work list with a grid stride, and while the rows of the current step are in flight it already has the
-// next item's descriptor and the next step's column ids / values requested (of the same item, or of the
-// next one when this was its last step): two latencies per step are taken off the critical path.
-template <int FP, int NG, int GS, bool MERGED, class Epi>
-__global__ __launch_bounds__(256) void spmm_narrow_pipe_kernel(CsrView csr, GatherSrc g, int F, int vecmask,
                                                                typename Epi::Args ea, float* __restrict__ partial) {
     constexpr int GPB = 256 / GS;
     const int gl = threadIdx.x % GS;
@@ -618,23 +587,12 @@ int launch_gather(const acm_csr* a, const GatherSrc& g, int F, const typename Ep
         // [channel 0 | channel 1] contiguous and block-aligned => one vector fetch for both
         const bool merged = NG >= 2 && F == FP && g.p[1] == g.p[0] + F && g.ld[0] == g.ld[1] &&
                             ((uintptr_t)g.p[0]) % (8 * FP) == 0 && (g.ld[0] * sizeof(float)) % (8 * FP) == 0;
-        static const int pipe_blocks = []() {
-            const char* e = getenv("ACM_NARROW_PIPE");
-            return e ? atoi(e) : 0;
-        }();
 #define ACM_NARROW(FPv, GSv)                                                                            \
     do {                                                                                                \
         const int gpb = 256 / GSv;                                                                      \
         int grid = (int)((a->n_items + gpb - 1) / gpb);                                                 \
-        if (pipe_blocks > 0) {                                                                          \
-            if (grid > pipe_blocks) grid = pipe_blocks;                                                 \
-            if (merged)                                                                                 \
-                hipLaunchKernelGGL((spmm_narrow_pipe_kernel<FPv, NG, GSv, (NG >= 2), Epi>), dim3(grid), dim3(256), 0, \
-                                   st, v, g, F, vecmask, ea, partial);                                  \
-            else                                                                                        \
-                hipLaunchKernelGGL((spmm_narrow_pipe_kernel<FPv, NG, GSv, false, Epi>), dim3(grid), dim3(256), 0, \
-                                   st, v, g, F, vecmask, ea, partial);                                  \
-        } else if (merged)                                                                                     \
+        if (grid > NARROW_MAX_BLOCKS) grid = NARROW_MAX_BLOCKS;                                         \
+        if (merged)                                                                                     \
             hipLaunchKernelGGL((spmm_narrow_kernel<FPv, NG, GSv, (NG >= 2), Epi>), dim3(grid), dim3(256), 0, \
                                st, v, g, F, vecmask, ea, partial);                                      \
         else                                                                                            \
@@ -760,9 +718,35 @@ extern "C" int acm_conv_fwd(const acm_csr_t* a, const acm_conv_fwd_t* p, void* w
                 "acm_conv_fwd: ld_out %lld / ld_pre %lld too small", (long long)p->ld_out,
                 (long long)p->ld_pre);
     ACM_REQUIRE(((uintptr_t)p->att) % 16 == 0, ACM_EINVAL, "acm_conv_fwd: att must be 16-byte aligned");
+    ACM_REQUIRE(k == 3 || (p->g_struc && p->s_struc && p->deg), ACM_EINVAL,
+                "acm_conv_fwd: structure channel pointers are NULL");
+    if (F <= 8) {                       // two phases: gather raw sums into `pre`, then one thread per row
+        ACM_REQUIRE(!p->gather_bf16, ACM_EUNSUPPORTED, "acm_conv_fwd: bf16 operands need F > 8");
+        hipStream_t s = (hipStream_t)stream;
+        int st;
+        if (k == 4) {
+            GatherSrc g = {{p->g_low, p->g_high, p->g_struc}, {p->ld_g_low, p->ld_g_high, p->ld_g_struc}};
+            st = launch_gather<3, EpiRaw>(a, g, F, *p, workspace, workspace_bytes, s, "acm_conv_fwd", nullptr, false);
+        } else {
+            GatherSrc g = {{p->g_low, p->g_high, nullptr}, {p->ld_g_low, p->ld_g_high, 0}};
+            st = launch_gather<2, EpiRaw>(a, g, F, *p, workspace, workspace_bytes, s, "acm_conv_fwd", nullptr, false);
+        }
+        if (st != ACM_OK || a->n_rows == 0) return st;
+        const int grid = (int)((a->n_rows + 255) / 256), n = (int)a->n_rows;
+        const int FP = F <= 2 ? 2 : (F <= 4 ? 4 : 8);
+#define ACM_ROWS(FPv)                                                                              \
+    do {                                                                                           \
+        if (k == 4) hipLaunchKernelGGL((conv_fwd_rows_kernel<FPv, 3>), dim3(grid), dim3(256), 0, s, *p, n); \
+        else hipLaunchKernelGGL((conv_fwd_rows_kernel<FPv, 2>), dim3(grid), dim3(256), 0, s, *p, n);        \
+    } while (0)
+        if (FP == 2) ACM_ROWS(2);
+        else if (FP == 4) ACM_ROWS(4);
+        else ACM_ROWS(8);
+#undef ACM_ROWS
+        ACM_CHECK_HIP(hipGetLastError());
+        return ACM_OK;
+    }
     if (k == 4) {
-        ACM_REQUIRE(p->g_struc && p->s_struc && p->deg, ACM_EINVAL,
-                    "acm_conv_fwd: structure channel pointers are NULL");
         GatherSrc g = {{p->g_low, p->g_high, p->g_struc}, {p->ld_g_low, p->ld_g_high, p->ld_g_struc}};
         return launch_gather<3, EpiFwd>(a, g, F, *p, workspace, workspace_bytes, (hipStream_t)stream,
                                         "acm_conv_fwd", nullptr, p->gather_bf16 != 0);

@@ -148,8 +148,19 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(int M, int N, int sp
     const int tq = threadIdx.x & 15, tz = threadIdx.x >> 4;
     const long q = (long)blockIdx.x * 16 + tq;
     float s = 0.f;
-    if (q < total)
-        for (int z = tz; z < splits; z += 16) s += slabs[(long)z * total + q];
+    if (q < total) {
+        // eight independent loads in flight per thread (the loop is latency-bound otherwise: 64 dependent trips at
+        // splits = 1024); the order of the additions is fixed, so the result is reproducible
+        int z = tz;
+        for (; z + 7 * 16 < splits; z += 8 * 16) {
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = slabs[(long)(z + 16 * u) * total + q];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) s += v[u];
+        }
+        for (; z < splits; z += 16) s += slabs[(long)z * total + q];
+    }
     red[tz][tq] = s;
     __syncthreads();
     if (tz == 0 && q < total) {
