@@ -61,7 +61,7 @@ template <int WM, int WN, int WAVES_M, int WAVES_N, bool TA, bool TB>
 __global__ __launch_bounds__(256) void gemm_kernel(int M, int N, int K, const float* __restrict__ A, long lda,
                                                    const float* __restrict__ B, long ldb,
                                                    float* __restrict__ C, long ldc, int relu, int k_per_split,
-                                                   float* __restrict__ slabs) {
+                                                   float* __restrict__ slabs, int cb, long cbs) {
     constexpr int BM = 16 * WM * WAVES_M, BN = 16 * WN * WAVES_N;
     constexpr bool A_KMAJOR = !TA, B_KMAJOR = TB;
     using LA = TileLds<A_KMAJOR, BM>;
@@ -133,7 +133,8 @@ __global__ __launch_bounds__(256) void gemm_kernel(int M, int N, int K, const fl
                 if (row < M && col < N) {
                     float v = acc[i][j][r];
                     if (relu && !slabs) v = fmaxf(v, 0.f);
-                    dst[(long)row * ldd + col] = v;
+                    if (cb && !slabs) dst[(long)(col / cb) * cbs + (long)row * ldd + (col % cb)] = v;   // column-block output
+                    else dst[(long)row * ldd + col] = v;
                 }
             }
 }
@@ -142,7 +143,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(int M, int N, int K, const fl
 // slab (coalesced 64 B segments across q), then the 16 split-lanes combine in a fixed LDS tree.
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(int M, int N, int splits,
                                                             const float* __restrict__ slabs,
-                                                            float* __restrict__ C, long ldc, int relu) {
+                                                            float* __restrict__ C, long ldc, int relu, int cb, long cbs) {
     __shared__ float red[16][17];
     const long total = (long)M * N;
     const int tq = threadIdx.x & 15, tz = threadIdx.x >> 4;
@@ -168,7 +169,10 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(int M, int N, int sp
 #pragma unroll
         for (int z = 0; z < 16; ++z) t += red[z][tq];
         if (relu) t = fmaxf(t, 0.f);
-        C[(q / N) * ldc + (q % N)] = t;
+        const long m = q / N;
+        const int n = (int)(q % N);
+        if (cb) C[(long)(n / cb) * cbs + m * ldc + (n % cb)] = t;
+        else C[m * ldc + n] = t;
     }
 }
 
@@ -212,10 +216,10 @@ GemmPlan plan_gemm(int64_t M, int64_t N, int64_t K) {
 
 template <int WM, int WN, int WVM, int WVN>
 void launch_shape(int ta, int tb, const GemmPlan& p, hipStream_t st, int M, int N, int K, const float* A,
-                  long lda, const float* B, long ldb, float* C, long ldc, int relu, float* slabs) {
+                  long lda, const float* B, long ldb, float* C, long ldc, int relu, float* slabs, int cb, long cbs) {
 #define ACM_GEMM_LAUNCH(TAv, TBv)                                                                        \
     hipLaunchKernelGGL((gemm_kernel<WM, WN, WVM, WVN, TAv, TBv>), p.grid, dim3(256), 0, st, M, N, K, A, \
-                       lda, B, ldb, C, ldc, relu, p.k_per_split, slabs)
+                       lda, B, ldb, C, ldc, relu, p.k_per_split, slabs, cb, cbs)
     if (!ta && !tb) ACM_GEMM_LAUNCH(false, false);
     else if (ta && !tb) ACM_GEMM_LAUNCH(true, false);
     else if (!ta && tb) ACM_GEMM_LAUNCH(false, true);
@@ -239,11 +243,21 @@ extern "C" int acm_gemm_workspace_bytes(int transA, int transB, int64_t M, int64
 extern "C" int acm_gemm(int transA, int transB, int64_t M, int64_t N, int64_t K, const float* A,
                         int64_t lda, const float* B, int64_t ldb, float* C, int64_t ldc, int relu,
                         void* workspace, size_t workspace_bytes, acm_stream_t stream) {
+    return acm_gemm_blocks(transA, transB, M, N, K, A, lda, B, ldb, C, ldc, 0, 0, relu, workspace, workspace_bytes, stream);
+}
+
+extern "C" int acm_gemm_blocks(int transA, int transB, int64_t M, int64_t N, int64_t K, const float* A,
+                               int64_t lda, const float* B, int64_t ldb, float* C, int64_t ldc, int64_t c_col_block,
+                               int64_t c_block_stride, int relu, void* workspace, size_t workspace_bytes,
+                               acm_stream_t stream) {
     ACM_REQUIRE(M >= 0 && N >= 0 && K >= 0, ACM_ESHAPE, "acm_gemm: negative size");
+    ACM_REQUIRE(c_col_block >= 0 && c_col_block < INT32_MAX, ACM_ESHAPE, "acm_gemm: bad column block");
+    const int cb = (int)c_col_block;
+    const long cbs = (long)c_block_stride;
     ACM_REQUIRE(M < INT32_MAX && N < INT32_MAX && K < INT32_MAX, ACM_EUNSUPPORTED, "acm_gemm: size >= 2^31");
     if (M == 0 || N == 0) return ACM_OK;
     ACM_REQUIRE(C && (K == 0 || (A && B)), ACM_EINVAL, "acm_gemm: NULL matrix pointer");
-    ACM_REQUIRE(lda >= (transA ? M : K) && ldb >= (transB ? K : N) && ldc >= N, ACM_ESHAPE,
+    ACM_REQUIRE(lda >= (transA ? M : K) && ldb >= (transB ? K : N) && ldc >= (cb ? (cb < N ? cb : N) : N), ACM_ESHAPE,
                 "acm_gemm: leading dimension too small (lda %lld ldb %lld ldc %lld)", (long long)lda,
                 (long long)ldb, (long long)ldc);
     hipStream_t st = (hipStream_t)stream;
@@ -257,21 +271,27 @@ extern "C" int acm_gemm(int transA, int transB, int64_t M, int64_t N, int64_t K,
         slabs = (float*)workspace;
     }
     if (K == 0) {  // empty sum
-        ACM_CHECK_HIP(hipMemset2DAsync(C, (size_t)ldc * sizeof(float), 0, (size_t)N * sizeof(float), (size_t)M, st));
+        if (!cb) {
+            ACM_CHECK_HIP(hipMemset2DAsync(C, (size_t)ldc * sizeof(float), 0, (size_t)N * sizeof(float), (size_t)M, st));
+        } else {
+            for (int64_t n0 = 0; n0 < N; n0 += cb)
+                ACM_CHECK_HIP(hipMemset2DAsync(C + (n0 / cb) * cbs, (size_t)ldc * sizeof(float), 0,
+                                               (size_t)(N - n0 < cb ? N - n0 : cb) * sizeof(float), (size_t)M, st));
+        }
         return ACM_OK;
     }
     if (p.shape == 0)
-        launch_shape<2, 2, 2, 2>(transA, transB, p, st, (int)M, (int)N, (int)K, A, lda, B, ldb, C, ldc, relu, slabs);
+        launch_shape<2, 2, 2, 2>(transA, transB, p, st, (int)M, (int)N, (int)K, A, lda, B, ldb, C, ldc, relu, slabs, cb, cbs);
     else if (p.shape == 1)
-        launch_shape<1, 4, 1, 4>(transA, transB, p, st, (int)M, (int)N, (int)K, A, lda, B, ldb, C, ldc, relu, slabs);
+        launch_shape<1, 4, 1, 4>(transA, transB, p, st, (int)M, (int)N, (int)K, A, lda, B, ldb, C, ldc, relu, slabs, cb, cbs);
     else
-        launch_shape<4, 1, 4, 1>(transA, transB, p, st, (int)M, (int)N, (int)K, A, lda, B, ldb, C, ldc, relu, slabs);
+        launch_shape<4, 1, 4, 1>(transA, transB, p, st, (int)M, (int)N, (int)K, A, lda, B, ldb, C, ldc, relu, slabs, cb, cbs);
     ACM_CHECK_HIP(hipGetLastError());
     if (slabs) {
         const long total = (long)M * N;
         const int grid = (int)((total + 15) / 16);
         hipLaunchKernelGGL(splitk_reduce_kernel, dim3(grid), dim3(256), 0, st, (int)M, (int)N, p.splits, slabs,
-                           C, (long)ldc, relu);
+                           C, (long)ldc, relu, cb, cbs);
         ACM_CHECK_HIP(hipGetLastError());
     }
     return ACM_OK;

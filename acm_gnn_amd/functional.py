@@ -74,16 +74,30 @@ def _as_f32c(t, name):
 # --------------------------------------------------------------------------
 # raw (non-differentiable) launches
 # --------------------------------------------------------------------------
-def gemm(a, b, trans_a=False, trans_b=False, relu=False, out=None):
-    """out = op(a) @ op(b) on the fp32 MFMA pipe (acm_gemm)."""
+def gemm(a, b, trans_a=False, trans_b=False, relu=False, out=None, col_blocks=0):
+    """out = op(a) @ op(b) on the fp32 MFMA pipe (acm_gemm).  ``col_blocks=j`` returns the product as a
+    contiguous [j, m, n / j] tensor of column blocks (acm_gemm_blocks)."""
     a, b = _as_f32c(a, "a"), _as_f32c(b, "b")
     m, k = (a.shape[1], a.shape[0]) if trans_a else (a.shape[0], a.shape[1])
     k2, n = (b.shape[1], b.shape[0]) if trans_b else (b.shape[0], b.shape[1])
     if k != k2:
         raise ValueError(f"gemm: inner dimensions differ ({k} vs {k2})")
+    lib = _lib.load()
+    if col_blocks:
+        if out is not None or n % col_blocks:
+            raise ValueError("gemm: col_blocks needs n divisible by the block count and no out=")
+        nb = n // col_blocks
+        out = torch.empty(col_blocks, m, nb, dtype=_F32, device=a.device)
+        nbytes = C.c_size_t()
+        _lib.check(lib.acm_gemm_workspace_bytes(int(trans_a), int(trans_b), m, n, k, C.byref(nbytes)))
+        ws = torch.empty(max(nbytes.value // 4, 1), dtype=_F32, device=a.device) if nbytes.value else None
+        with _device_ctx(a.device), _Timed(f"gemm_{'T' if trans_a else 'N'}{'T' if trans_b else 'N'}/{m}x{n}x{k}"):
+            st = lib.acm_gemm_blocks(int(trans_a), int(trans_b), m, n, k, _vp(a), a.stride(0), _vp(b), b.stride(0),
+                                     _vp(out), nb, nb, m * nb, int(relu), _vp(ws), nbytes.value, _stream())
+        _lib.check(st, "acm_gemm_blocks")
+        return out
     if out is None:
         out = torch.empty(m, n, dtype=_F32, device=a.device)
-    lib = _lib.load()
     nbytes = C.c_size_t()
     _lib.check(lib.acm_gemm_workspace_bytes(int(trans_a), int(trans_b), m, n, k, C.byref(nbytes)))
     ws = torch.empty(max(nbytes.value // 4, 1), dtype=_F32, device=a.device) if nbytes.value else None
@@ -184,6 +198,21 @@ class _MaskedNll(torch.autograd.Function):
         return dz * grad_loss, None, None
 
 
+def nll_loss_and_grad(logits, labels, row_weight):
+    """(loss, dloss/dlogits) of the masked NLL in one launch, outside autograd: a training loop can call
+    ``logits.backward(gradient=dz)`` directly instead of ``loss.backward()`` (which costs a ones-fill and a
+    scalar multiply of dz on top)."""
+    with torch.no_grad():
+        ctx = _NoCtx()
+        loss = _MaskedNll.forward(ctx, logits.detach(), labels, row_weight)
+    return loss, ctx.saved[0]
+
+
+class _NoCtx:
+    def save_for_backward(self, *t):
+        self.saved = t
+
+
 def masked_nll(logits, labels, row_weight):
     """Fused log-softmax + NLL over the rows with non-zero weight (weights = 1/|train| on the
     training rows reproduces F.log_softmax + NLLLoss(out[train_idx], y[train_idx]),
@@ -259,6 +288,7 @@ class AcmConvFunction(torch.autograd.Function):
                 lnw_low, lnw_high, lnw_mlp, lnw_struc, lnb_low, lnb_high, lnb_mlp, lnb_struc, ops, cfg,
                 post_relu=False, post_scale=None):
         lib = _lib.load()
+        ctx.set_materialize_grads(False)          # no zero-filled gradient for the (non-differentiable) att output
         sparse_x = isinstance(x, SparseFeatures)
         if not sparse_x:
             x = _as_f32c(x, "input")
@@ -429,6 +459,8 @@ class AcmConvFunction(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, grad_out, _grad_att):
+        if grad_out is None:
+            return (None,) * 22
         lib = _lib.load()
         ops, cfg = ctx.ops, ctx.cfg
         k = cfg.n_channels
@@ -533,7 +565,7 @@ class AcmConvFunction(torch.autograd.Function):
             d_wcat = spmm_v(xt, xs.values.index_select(0, xt.src_pos), dz)
             d_x = None
         else:
-            d_wcat = gemm(x, dz, trans_a=True)                               # [F_in, 3F]
+            d_wcat = gemm(x, dz, trans_a=True, col_blocks=3)                 # [3, F_in, F]: contiguous per weight
             d_x = gemm(dz, wcat, trans_b=True) if ctx.needs_input_grad[0] else None
         small = [d_wcat, d_mix] + d_vec + d_lnw + d_lnb
         if ops.sharded:                             # replicated parameters: sum the row-shard partials
@@ -544,7 +576,10 @@ class AcmConvFunction(torch.autograd.Function):
             for t in small:
                 t.copy_(flat[off:off + t.numel()].view_as(t))
                 off += t.numel()
-        d_wl, d_wh, d_wm = (d_wcat[:, i * f:(i + 1) * f] for i in range(3))
+        if d_wcat.dim() == 3:
+            d_wl, d_wh, d_wm = d_wcat[0], d_wcat[1], d_wcat[2]
+        else:
+            d_wl, d_wh, d_wm = (d_wcat[:, i * f:(i + 1) * f] for i in range(3))
         none4 = [None] * 4
         grads_vec = d_vec + [None] * (4 - k)
         grads_lnw = (d_lnw + [None] * (4 - k)) if cfg.layernorm else none4

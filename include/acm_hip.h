@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define ACM_ABI_VERSION 7
+#define ACM_ABI_VERSION 8
 
 typedef enum {
     ACM_OK = 0,
@@ -113,6 +113,17 @@ int acm_gemm(int transA, int transB, int64_t M, int64_t N, int64_t K,
              const float* A, int64_t lda, const float* B, int64_t ldb,
              float* C, int64_t ldc, int relu, void* workspace, size_t workspace_bytes,
              acm_stream_t stream);
+
+/* Same product with the columns of C delivered as consecutive blocks of `c_col_block` columns, block j starting
+ * at C + j * c_block_stride (rows of a block keep the pitch ldc >= c_col_block):
+ *     C_j[m, n'] = (op(A) op(B))[m, j * c_col_block + n'].
+ * dWcat = X^T [dZ_L | dZ_H | dZ_I] lands as three contiguous F_in x F matrices -- the layout of
+ * weight_low / weight_high / weight_mlp (layers.py:19-21), so autograd adopts them without a copy each.
+ * c_col_block = 0 is acm_gemm. */
+int acm_gemm_blocks(int transA, int transB, int64_t M, int64_t N, int64_t K,
+                    const float* A, int64_t lda, const float* B, int64_t ldb,
+                    float* C, int64_t ldc, int64_t c_col_block, int64_t c_block_stride, int relu,
+                    void* workspace, size_t workspace_bytes, acm_stream_t stream);
 
 /* ----------------------------------------------------------------- SpMM --
  * Y[r, 0:width] = sum_j A[r,j] * G[j, 0:width]   (plain CSR x dense; used for

@@ -110,7 +110,7 @@ class FakeLib:
 
     # ---- plumbing ---------------------------------------------------------
     def acm_version(self):
-        return 7
+        return 8
 
     def acm_last_error(self):
         return self._err
@@ -217,6 +217,20 @@ class FakeLib:
         if relu:
             out = np.maximum(out, 0)
         _view(c, m, n, ldc)[...] = out
+        return 0
+
+    def acm_gemm_blocks(self, ta, tb, m, n, k, a, lda, b, ldb, c, ldc, cb, cbs, relu, ws, wsb, stream):
+        if not cb:
+            return self.acm_gemm(ta, tb, m, n, k, a, lda, b, ldb, c, ldc, relu, ws, wsb, stream)
+        A = _view(a, k, m, lda).T if ta else _view(a, m, k, lda)
+        B = _view(b, n, k, ldb).T if tb else _view(b, k, n, ldb)
+        out = A.astype(np.float64) @ B.astype(np.float64)
+        if relu:
+            out = np.maximum(out, 0)
+        for j, n0 in enumerate(range(0, n, cb)):
+            w = min(cb, n - n0)
+            base = c.value if isinstance(c, C.c_void_p) else int(c)
+            _view(base + 4 * j * cbs, m, w, ldc)[...] = out[:, n0:n0 + w]
         return 0
 
     def acm_cast_bf16(self, n, c, src, lds, dst, ldd, stream):

@@ -41,6 +41,18 @@ def test_gemm_matches_fp64(m, n, k, ta, tb):
     assert torch.equal(out_relu, out.clamp_min(0))
 
 
+@pytest.mark.parametrize("m,n,k,blocks", [(64, 6, 3000, 3), (7, 192, 5000, 3), (64, 15, 5201, 3), (20, 12, 40, 4), (300, 192, 7, 3)])
+def test_gemm_column_block_output(m, n, k, blocks):
+    """acm_gemm_blocks: the same product delivered as contiguous column blocks (split-K and direct stores)."""
+    from acm_gnn_amd import functional as AF
+    g = torch.Generator().manual_seed(m + n + k)
+    a, b = torch.randn(k, m, generator=g), torch.randn(k, n, generator=g)
+    whole = AF.gemm(a.to(DEV), b.to(DEV), trans_a=True)
+    parts = AF.gemm(a.to(DEV), b.to(DEV), trans_a=True, col_blocks=blocks)
+    assert parts.shape == (blocks, m, n // blocks) and parts.is_contiguous()
+    assert torch.equal(torch.cat(list(parts), dim=1), whole)
+
+
 def test_gemm_is_an_fmaf_chain_in_k_order():
     """f32 MFMA == k-ordered fmaf chain: integer-valued inputs must be exact."""
     from acm_gnn_amd import functional as AF
