@@ -14,7 +14,7 @@ c_i32p = C.POINTER(C.c_int32)
 
 ACM_OK = 0
 STATUS_NAMES = {1: "ACM_EINVAL", 2: "ACM_ESHAPE", 3: "ACM_EHIP", 4: "ACM_EUNSUPPORTED", 5: "ACM_ENOMEM"}
-ABI_VERSION = 8
+ABI_VERSION = 9
 
 # every symbol include/acm_hip.h declares
 EXPORTED_SYMBOLS = (
@@ -22,8 +22,13 @@ EXPORTED_SYMBOLS = (
     "acm_csr_destroy", "acm_csr_info", "acm_spmm_workspace_bytes", "acm_gemm_workspace_bytes",
     "acm_gemm", "acm_gemm_blocks", "acm_spmm", "acm_spmm_v", "acm_spmm_ex", "acm_cast_bf16", "acm_conv_fwd", "acm_conv_bwd_local_workspace_bytes",
     "acm_conv_bwd_local", "acm_conv_bwd_spmm", "acm_conv_agg_fwd", "acm_conv_agg_bwd_workspace_bytes",
-    "acm_conv_agg_bwd", "acm_nll_loss_workspace_bytes", "acm_nll_loss", "acm_adam_step",
+    "acm_conv_agg_bwd", "acm_nll_loss_workspace_bytes", "acm_nll_loss", "acm_adam_step", "acm_dropout",
 )
+
+
+class Dropout(C.Structure):
+    _fields_ = [("p", C.c_float), ("tag", C.c_int32), ("seed", C.c_uint64), ("step", C.c_void_p),
+                ("row_offset", C.c_int64)]
 
 
 class CsrInfo(C.Structure):
@@ -50,7 +55,7 @@ class ConvFwd(C.Structure):
                 ("out", C.c_void_p), ("ld_out", C.c_int64),
                 ("pre", C.c_void_p), ("ld_pre", C.c_int64),
                 ("att", C.c_void_p), ("post_scale", C.c_void_p), ("ld_post_scale", C.c_int64), ("post_relu", C.c_int32),
-                ("gather_bf16", C.c_int32), ("row_scale", C.c_void_p)]
+                ("gather_bf16", C.c_int32), ("row_scale", C.c_void_p), ("post_drop", Dropout)]
 
 
 class ConvBwdLocal(C.Structure):
@@ -69,7 +74,7 @@ class ConvBwdLocal(C.Structure):
                 ("d_att_vec", C.c_void_p * 4), ("d_ln_weight", C.c_void_p * 4),
                 ("d_ln_bias", C.c_void_p * 4), ("d_att_mix", C.c_void_p),
                 ("post_scale", C.c_void_p), ("ld_post_scale", C.c_int64), ("post_relu", C.c_int32),
-                ("g_scale", C.c_void_p)]
+                ("g_scale", C.c_void_p), ("post_drop", Dropout)]
 
 
 class ConvBwdSpmm(C.Structure):
@@ -100,7 +105,7 @@ class ConvAggFwd(C.Structure):
                 ("att", C.c_void_p), ("post_scale", C.c_void_p), ("ld_post_scale", C.c_int64), ("post_relu", C.c_int32),
                 ("n_channels", C.c_int32), ("sg", C.c_void_p), ("ld_sg", C.c_int64), ("sg_bf16", C.c_int32),
                 ("ss", C.c_void_p), ("ld_ss", C.c_int64), ("deg", C.c_void_p),
-                ("ps", C.c_void_p), ("ld_ps", C.c_int64), ("row_scale", C.c_void_p)]
+                ("ps", C.c_void_p), ("ld_ps", C.c_int64), ("row_scale", C.c_void_p), ("post_drop", Dropout)]
 
 
 class ConvAggBwd(C.Structure):
@@ -115,7 +120,8 @@ class ConvAggBwd(C.Structure):
                 ("d_params", C.c_void_p), ("post_scale", C.c_void_p), ("ld_post_scale", C.c_int64), ("post_relu", C.c_int32),
                 ("n_channels", C.c_int32), ("ps", C.c_void_p), ("ld_ps", C.c_int64),
                 ("ss", C.c_void_p), ("ld_ss", C.c_int64), ("deg", C.c_void_p),
-                ("g_struc", C.c_void_p), ("ld_g_struc", C.c_int64), ("g_struc_scale", C.c_void_p)]
+                ("g_struc", C.c_void_p), ("ld_g_struc", C.c_int64), ("g_struc_scale", C.c_void_p),
+                ("post_drop", Dropout)]
 
 
 class SpmmOpts(C.Structure):
@@ -130,7 +136,7 @@ class AdamTensor(C.Structure):
 
 class AdamConfig(C.Structure):
     _fields_ = [("lr", C.c_double), ("beta1", C.c_double), ("beta2", C.c_double), ("eps", C.c_double),
-                ("weight_decay", C.c_double), ("decoupled", C.c_int32)]
+                ("weight_decay", C.c_double), ("decoupled", C.c_int32), ("also_advance", C.c_void_p)]
 
 
 _lib = None
@@ -156,6 +162,7 @@ def _declare(lib):
     lib.acm_spmm.argtypes = [vp, vp, i64, i32, vp, i64, vp, sz, vp]
     lib.acm_spmm_v.argtypes = [vp, vp, vp, i64, i32, vp, i64, i32, vp, sz, vp]
     lib.acm_adam_step.argtypes = [i32, vp, vp, vp]
+    lib.acm_dropout.argtypes = [i64, i64, vp, i64, vp, i64, i64, vp, vp]
     lib.acm_spmm_ex.argtypes = [vp, vp, i64, i32, vp, i64, vp, vp, sz, vp]
     lib.acm_cast_bf16.argtypes = [i64, i64, vp, i64, vp, i64, vp]
     lib.acm_conv_fwd.argtypes = [vp, C.POINTER(ConvFwd), vp, sz, vp]

@@ -132,4 +132,69 @@ __device__ __forceinline__ int acm_uniform(int v) { return __builtin_amdgcn_read
 __device__ __forceinline__ float acm_lane_f(float v, int lane) {
     return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane));
 }
+
+// ------------------------------------------------------------------ counter-based dropout (acm_dropout_t)
+struct AcmDropCtx {
+    unsigned k0, k1, c2, c3, thresh, tag16;
+    float inv_keep;
+    long row_offset;
+    bool on;
+};
+
+__device__ __forceinline__ AcmDropCtx acm_drop_ctx(const acm_dropout_t& d) {
+    AcmDropCtx c;
+    c.on = d.p > 0.f;
+    const unsigned long long step = c.on ? (unsigned long long)d.step[0] : 0ull;
+    c.k0 = (unsigned)d.seed;
+    c.k1 = (unsigned)(d.seed >> 32);
+    c.c2 = (unsigned)step;
+    c.c3 = (unsigned)(step >> 32);
+    const double t = (double)d.p * 4294967296.0;
+    c.thresh = t >= 4294967295.0 ? 0xFFFFFFFFu : (unsigned)t;
+    c.tag16 = ((unsigned)d.tag) << 16;
+    c.inv_keep = 1.0f / (1.0f - d.p);
+    c.row_offset = (long)d.row_offset;
+    return c;
+}
+
+// Philox4x32 with 7 rounds (Crush-resistant per Salmon et al., SC'11): four 32-bit words per (row, block)
+__device__ __forceinline__ void acm_philox7(const AcmDropCtx& c, long row, int block, unsigned (&w)[4]) {
+    unsigned x0 = (unsigned)(row + c.row_offset), x1 = (unsigned)block | c.tag16, x2 = c.c2, x3 = c.c3;
+    unsigned k0 = c.k0, k1 = c.k1;
+#pragma unroll
+    for (int r = 0; r < 7; ++r) {
+        const unsigned hi0 = __umulhi(0xD2511F53u, x0), lo0 = 0xD2511F53u * x0;
+        const unsigned hi1 = __umulhi(0xCD9E8D57u, x2), lo1 = 0xCD9E8D57u * x2;
+        x0 = hi1 ^ x1 ^ k0;
+        x1 = lo1;
+        x2 = hi0 ^ x3 ^ k1;
+        x3 = lo0;
+        k0 += 0x9E3779B9u;
+        k1 += 0xBB67AE85u;
+    }
+    w[0] = x0, w[1] = x1, w[2] = x2, w[3] = x3;
+}
+
+// factor (0 or 1/(1-p)) of one element
+__device__ __forceinline__ float acm_drop1(const AcmDropCtx& c, long row, int col) {
+    if (!c.on) return 1.f;
+    unsigned w[4];
+    acm_philox7(c, row, (col & 15) + 16 * (col >> 6), w);
+    const int q = (col >> 4) & 3;
+    const unsigned v = q == 0 ? w[0] : (q == 1 ? w[1] : (q == 2 ? w[2] : w[3]));
+    return v >= c.thresh ? c.inv_keep : 0.f;
+}
+
+// factors of columns m, m + 16, m + 32, m + 48 (the grouped layout's lane; F <= 64): one Philox call
+__device__ __forceinline__ void acm_drop4(const AcmDropCtx& c, long row, int m, float (&f)[4]) {
+    if (!c.on) {
+        f[0] = f[1] = f[2] = f[3] = 1.f;
+        return;
+    }
+    unsigned w[4];
+    acm_philox7(c, row, m, w);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) f[i] = w[i] >= c.thresh ? c.inv_keep : 0.f;
+}
+
 #endif

@@ -107,6 +107,7 @@ struct EpiFwd {
                 o *= p.scale;
                 if (p.post_relu) o = fmaxf(o, 0.f);
                 if (p.post_scale) o *= p.post_scale[(long)row * p.ld_post_scale + col];
+                if (p.post_drop.p > 0.f) o *= acm_drop1(acm_drop_ctx(p.post_drop), row, col);
                 p.out[(long)row * p.ld_out + col] = o;
                 float* pr = p.pre + (long)row * p.ld_pre;
                 pr[col] = pre[0][i];
@@ -811,7 +812,8 @@ __device__ __forceinline__ void conv_bwd_row(const acm_conv_bwd_local_t& p, int 
     const HeadParams hp = acm_head_params(p);
     acm_head<L, K>(lay, F, p.layernorm, hp, H, hn, xhat, ho);
 
-    if (p.post_relu || p.post_scale) {      // undo the fused post-op of the forward on the incoming gradient
+    if (p.post_relu || p.post_scale || p.post_drop.p > 0.f) {   // undo the fused post-op of the forward on the incoming gradient
+        const AcmDropCtx dc = acm_drop_ctx(p.post_drop);
 #pragma unroll
         for (int i = 0; i < NV; ++i) {
             const int col = lay.col(i);
@@ -822,6 +824,7 @@ __device__ __forceinline__ void conv_bwd_row(const acm_conv_bwd_local_t& p, int 
                 if (c < K) raw += ho.alpha[c] * H[c][i];
             if (p.post_relu && !(raw * p.scale > 0.f)) dO[i] = 0.f;
             if (p.post_scale && ok) dO[i] *= p.post_scale[(long)row * p.ld_post_scale + col];
+            if (dc.on && ok) dO[i] *= acm_drop1(dc, row, col);
         }
     }
     float dH[4][NV];

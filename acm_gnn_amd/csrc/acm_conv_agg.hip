@@ -104,6 +104,8 @@ __device__ __forceinline__ void agg_fwd_row(const acm_conv_agg_fwd_t& p, const f
     }
     RowHead<K> rh;
     row_head<K>(hlds, mixm, acm_opaque(m), F, p.layernorm != 0, H, rh);
+    float df[4];
+    acm_drop4(acm_drop_ctx(p.post_drop), row, m, df);
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int col = m + 16 * i;
@@ -113,6 +115,7 @@ __device__ __forceinline__ void agg_fwd_row(const acm_conv_agg_fwd_t& p, const f
             o *= p.scale;
             if (p.post_relu) o = fmaxf(o, 0.f);
             if (p.post_scale) o *= p.post_scale[(long)row * p.ld_post_scale + col];
+            if (p.post_drop.p > 0.f) o *= df[i];
             p.out[(long)row * p.ld_out + col] = o;
         }
     }

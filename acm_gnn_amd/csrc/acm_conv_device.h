@@ -378,7 +378,10 @@ __device__ __forceinline__ void row_head(const float* hlds, const float* mixm, i
 template <int K, class P>
 __device__ __forceinline__ void row_post_backward(const P& p, const RowHead<K>& r, const float (&H)[K][4], bool active,
                                                   long row, int m, int F, float (&dO)[4]) {
-    if (!(p.post_relu || p.post_scale)) return;
+    const bool drop = p.post_drop.p > 0.f;
+    if (!(p.post_relu || p.post_scale || drop)) return;
+    float df[4];
+    acm_drop4(acm_drop_ctx(p.post_drop), row, m, df);      // the forward's mask, regenerated
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         float raw = 0.f;
@@ -386,6 +389,7 @@ __device__ __forceinline__ void row_post_backward(const P& p, const RowHead<K>& 
         for (int c = 0; c < K; ++c) raw = fmaf(r.alpha[c], H[c][i], raw);
         if (p.post_relu && !(raw * p.scale > 0.f)) dO[i] = 0.f;
         if (p.post_scale && active && m + 16 * i < F) dO[i] *= p.post_scale[row * p.ld_post_scale + m + 16 * i];
+        if (drop) dO[i] *= df[i];
     }
 }
 

@@ -90,9 +90,10 @@ __global__ __launch_bounds__(256) void adam_kernel(AdamPack pk, AdamScalars hp) 
 
 // after the update of a pack: step_t += 1 for each of its tensors (stream order makes every block of the update
 // read the old value)
-__global__ void adam_advance_kernel(AdamPack pk) {
+__global__ void adam_advance_kernel(AdamPack pk, int64_t* also_advance) {
     const int t = threadIdx.x;
     if (t < pk.n) pk.step[t][0] += 1.0f;
+    if (t == 0 && also_advance) also_advance[0] += 1;
 }
 
 }  // namespace
@@ -121,7 +122,13 @@ extern "C" int acm_adam_step(int32_t n_tensors, const acm_adam_tensor_t* tensors
         }
         pk.first_block[pk.n] = blocks;
         if (blocks > 0) hipLaunchKernelGGL(adam_kernel, dim3(blocks), dim3(256), 0, s, pk, hp);
-        hipLaunchKernelGGL(adam_advance_kernel, dim3(1), dim3(PACK), 0, s, pk);
+        hipLaunchKernelGGL(adam_advance_kernel, dim3(1), dim3(PACK), 0, s, pk,
+                           first + PACK >= n_tensors ? cfg->also_advance : nullptr);
+        ACM_CHECK_HIP(hipGetLastError());
+    }
+    if (n_tensors == 0 && cfg->also_advance) {
+        AdamPack pk{};
+        hipLaunchKernelGGL(adam_advance_kernel, dim3(1), dim3(PACK), 0, s, pk, cfg->also_advance);
         ACM_CHECK_HIP(hipGetLastError());
     }
     return ACM_OK;

@@ -221,6 +221,77 @@ def masked_nll(logits, labels, row_weight):
 
 
 # --------------------------------------------------------------------------
+# counter-based dropout (acm_dropout_t)
+# --------------------------------------------------------------------------
+class DropoutState:
+    """Seed + device step counter of the counter-based dropout.  The mask of element (row, col) is a pure
+    function of (seed, step, tag, row, col), so forward and backward kernels regenerate it instead of storing
+    it.  ``advance()`` (or FusedAdam's ``also_advance`` hook) must run once per optimizer step; every forward /
+    backward between two advances sees the same masks (distinguished by ``tag``)."""
+
+    def __init__(self, device, seed=None):
+        self.seed = int(torch.initial_seed() if seed is None else seed) & 0xFFFFFFFFFFFFFFFF
+        self.step = torch.zeros(1, dtype=torch.int64, device=device)
+
+    def advance(self):
+        self.step.add_(1)
+
+    def spec(self, p, tag, row_offset=0):
+        d = _lib.Dropout()
+        d.p, d.tag, d.seed, d.step, d.row_offset = float(p), int(tag), self.seed, self.step.data_ptr(), int(row_offset)
+        return d
+
+
+def _drop_spec(post_drop, row_offset):
+    if post_drop is None:
+        return None
+    p, tag, state = post_drop
+    if not 0.0 <= p < 1.0:
+        raise ValueError("dropout probability must be in [0, 1)")
+    return state.spec(p, tag, row_offset) if p > 0 else None
+
+
+class _FusedDropout(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, p, tag, state, pad_to, row_offset):
+        x = _as_f32c(x, "input")
+        n, c = x.shape
+        width = max(c, int(pad_to or 0))
+        buf = torch.empty(n, width, dtype=_F32, device=x.device)
+        d = state.spec(p, tag, row_offset)
+        with _device_ctx(x.device), _Timed(f"dropout/{n}x{c}"):
+            st = _lib.load().acm_dropout(n, c, _vp(x), x.stride(0), _vp(buf), buf.stride(0), width, C.byref(d), _stream())
+        _lib.check(st, "acm_dropout")
+        ctx.args = (p, tag, state, row_offset, c)
+        return buf
+
+    @staticmethod
+    def backward(ctx, g):
+        p, tag, state, row_offset, c = ctx.args
+        g = _as_f32c(g, "grad")                   # [n, width]; the pad columns carry no gradient
+        out = torch.empty(g.shape[0], c, dtype=_F32, device=g.device)
+        d = state.spec(p, tag, row_offset)
+        with _device_ctx(g.device):
+            st = _lib.load().acm_dropout(g.shape[0], c, _vp(g), g.stride(0), _vp(out), out.stride(0), c, C.byref(d), _stream())
+        _lib.check(st, "acm_dropout")
+        return out, None, None, None, None, None
+
+
+def dropout(x, p, state, tag=0, pad_to=None, row_offset=0):
+    """x * keep / (1 - p) with the counter-based mask (acm_dropout).  ``pad_to`` > x.shape[1] returns an
+    [n, pad_to] tensor whose extra columns are zero -- the row layout the aggregate-first gather wants (pass
+    it to the layer with ``input_zero_padded=True``), saving the pad fill + copy."""
+    if p <= 0 and not (pad_to and pad_to > x.shape[1]):
+        return x
+    return _FusedDropout.apply(x, float(p), int(tag), state, pad_to, int(row_offset))
+
+
+def agg_pad_width(f_in):
+    """Row length (floats) of the gathered operand of the aggregate-first path, or f_in when it does not apply."""
+    return 4 if f_in <= 4 else (8 if f_in <= 8 else (16 if f_in <= 16 else f_in))
+
+
+# --------------------------------------------------------------------------
 # the fused ACM layer
 # --------------------------------------------------------------------------
 class AcmConfig:
@@ -286,7 +357,7 @@ class AcmConvFunction(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, w_low, w_high, w_mlp, v_low, v_high, v_mlp, v_struc, struc_low, att_mix,
                 lnw_low, lnw_high, lnw_mlp, lnw_struc, lnb_low, lnb_high, lnb_mlp, lnb_struc, ops, cfg,
-                post_relu=False, post_scale=None):
+                post_relu=False, post_scale=None, post_drop=None):
         lib = _lib.load()
         ctx.set_materialize_grads(False)          # no zero-filled gradient for the (non-differentiable) att output
         sparse_x = isinstance(x, SparseFeatures)
@@ -300,14 +371,22 @@ class AcmConvFunction(torch.autograd.Function):
             if tuple(post_scale.shape) != (n, f):
                 raise ValueError(f"post_scale must be [{n}, {f}]")
         ctx.post_relu, ctx.post_scale = bool(post_relu), post_scale
+        ctx.post_drop = post_drop if (post_drop is not None and post_drop[0] > 0) else None
 
         def set_post(st):
             st.post_relu = int(ctx.post_relu)
             if post_scale is not None:
                 st.post_scale, st.ld_post_scale = post_scale.data_ptr(), post_scale.stride(0)
+            spec = _drop_spec(ctx.post_drop, ops.row_offset)
+            if spec is not None:
+                st.post_drop = spec
         if n != ops.n_local:
             raise ValueError(f"input has {n} rows but the graph operator has {ops.n_local}")
-        f_in = x.shape[1]
+        f_in = w_low.shape[0]
+        ctx.x_width = x.shape[1]
+        zero_padded = x.shape[1] != f_in          # dropout(..., pad_to=...) output: extra columns are zero
+        if zero_padded and (sparse_x or x.shape[1] < f_in):
+            raise ValueError(f"input has {x.shape[1]} columns but the weights have {f_in} rows")
         # Aggregate-first (A (X W) = (A X) W): legal without a ReLU between projection and
         # filter, worth it when F_in < F, and free of any backward SpMM when x needs no gradient.
         ctx.agg_first = (not cfg.relu_before and f_in <= 16 and f_in < f and f <= 64 and not sparse_x
@@ -320,10 +399,15 @@ class AcmConvFunction(torch.autograd.Function):
             ctx.agg_first = False
         if ctx.agg_first:
             fp = 4 if f_in <= 4 else (8 if f_in <= 8 else 16)
-            xpad = x if f_in == fp else torch.nn.functional.pad(x, (0, fp - f_in))
+            if x.shape[1] == fp:
+                xpad = x
+            else:
+                xpad = torch.nn.functional.pad(x[:, :f_in], (0, fp - f_in))
             xg = _gather_rows(ops, xpad)
             wl, wh, wm = (_as_f32c(t, "weight") for t in (w_low, w_high, w_mlp))
         else:
+            if zero_padded:
+                x = x[:, :f_in].contiguous()
             wcat = torch.cat([w_low, w_high, w_mlp], dim=1).to(_F32).contiguous()  # [F_in, 3F]
             # Row pitch of Z: for narrow layers the gathered block [Z_L | Z_H] (2F floats) must be
             # one aligned vector fetch, so rows are padded to a multiple of that block.
@@ -460,7 +544,7 @@ class AcmConvFunction(torch.autograd.Function):
     @staticmethod
     def backward(ctx, grad_out, _grad_att):
         if grad_out is None:
-            return (None,) * 22
+            return (None,) * 23
         lib = _lib.load()
         ops, cfg = ctx.ops, ctx.cfg
         k = cfg.n_channels
@@ -509,6 +593,9 @@ class AcmConvFunction(torch.autograd.Function):
         q.post_relu = int(ctx.post_relu)
         if ctx.post_scale is not None:
             q.post_scale, q.ld_post_scale = ctx.post_scale.data_ptr(), ctx.post_scale.stride(0)
+        spec = _drop_spec(ctx.post_drop, ops.row_offset)
+        if spec is not None:
+            q.post_drop = spec
         nbytes = C.c_size_t()
         _lib.check(lib.acm_conv_bwd_local_workspace_bytes(n, f, k, C.byref(nbytes)))
         ws = torch.empty(max(nbytes.value // 4, 1), dtype=_F32, device=dev)
@@ -567,6 +654,8 @@ class AcmConvFunction(torch.autograd.Function):
         else:
             d_wcat = gemm(x, dz, trans_a=True, col_blocks=3)                 # [3, F_in, F]: contiguous per weight
             d_x = gemm(dz, wcat, trans_b=True) if ctx.needs_input_grad[0] else None
+            if d_x is not None and d_x.shape[1] != ctx.x_width:
+                d_x = torch.nn.functional.pad(d_x, (0, ctx.x_width - d_x.shape[1]))
         small = [d_wcat, d_mix] + d_vec + d_lnw + d_lnb
         if ops.sharded:                             # replicated parameters: sum the row-shard partials
             import torch.distributed as dist
@@ -585,7 +674,7 @@ class AcmConvFunction(torch.autograd.Function):
         grads_lnw = (d_lnw + [None] * (4 - k)) if cfg.layernorm else none4
         grads_lnb = (d_lnb + [None] * (4 - k)) if cfg.layernorm else none4
         return (d_x, d_wl, d_wh, d_wm, grads_vec[0], grads_vec[1], grads_vec[2], grads_vec[3],
-                d_struc, d_mix, *grads_lnw, *grads_lnb, None, None, None, None)
+                d_struc, d_mix, *grads_lnw, *grads_lnb, None, None, None, None, None)
 
 
 def _backward_agg(ctx, grad_out):
@@ -622,6 +711,9 @@ def _backward_agg(ctx, grad_out):
     q.n_channels = k
     if ctx.post_scale is not None:
         q.post_scale, q.ld_post_scale = ctx.post_scale.data_ptr(), ctx.post_scale.stride(0)
+    spec = _drop_spec(ctx.post_drop, ops.row_offset)
+    if spec is not None:
+        q.post_drop = spec
     if four:
         ps, s_local = saved[-2], saved[-1]
         gs = torch.empty(n, f, dtype=_F32, device=dev)            # D * dL/dpre_S
@@ -663,20 +755,21 @@ def _backward_agg(ctx, grad_out):
     else:
         d_lnw = d_lnb = [None] * 4
     d_mix = d_params[base + 3 * k * f:].view(k, k)
-    return (None, d_wl, d_wh, d_wm, *d_vec, d_struc, d_mix, *d_lnw, *d_lnb, None, None, None, None)
+    return (None, d_wl, d_wh, d_wm, *d_vec, d_struc, d_mix, *d_lnw, *d_lnb, None, None, None, None, None)
 
 
 AcmConvFunction._backward_agg = staticmethod(_backward_agg)
 
 
-def acm_conv(x, params, ops, cfg, post_relu=False, post_scale=None):
+def acm_conv(x, params, ops, cfg, post_relu=False, post_scale=None, post_drop=None):
     """params: dict with the reference's parameter names (see layers.GraphConvolution).
     post_relu / post_scale: optional fused ``relu(out) * post_scale`` (the caller's inter-layer
-    ReLU + dropout; post_scale = keep_mask / (1 - p))."""
+    ReLU + dropout; post_scale = keep_mask / (1 - p)).  post_drop = (p, tag, DropoutState): the same
+    dropout with the mask generated in registers (acm_dropout_t) instead of read from a tensor."""
     p = params
     return AcmConvFunction.apply(
         x, p["weight_low"], p["weight_high"], p["weight_mlp"], p["att_vec_low"], p["att_vec_high"],
         p["att_vec_mlp"], p["att_struc_low"], p["struc_low"], p["att_vec"],
         p["layer_norm_low.weight"], p["layer_norm_high.weight"], p["layer_norm_mlp.weight"],
         p["layer_norm_struc_low.weight"], p["layer_norm_low.bias"], p["layer_norm_high.bias"],
-        p["layer_norm_mlp.bias"], p["layer_norm_struc_low.bias"], ops, cfg, post_relu, post_scale)
+        p["layer_norm_mlp.bias"], p["layer_norm_struc_low.bias"], ops, cfg, post_relu, post_scale, post_drop)

@@ -94,9 +94,12 @@ class GraphConvolution(nn.Module):
             "layer_norm_struc_low.bias": self.layer_norm_struc_low.bias,
         }
 
-    def forward(self, input, adj_low, adj_high=None, adj_low_unnormalized=None, post_relu=False, post_scale=None):
-        """Reference signature plus two optional keyword arguments: ``post_relu`` / ``post_scale`` fuse the
-        caller's ``dropout(relu(out))`` (post_scale = keep-mask / (1 - p)) into the kernel epilogue."""
+    def forward(self, input, adj_low, adj_high=None, adj_low_unnormalized=None, post_relu=False, post_scale=None,
+                post_drop=None):
+        """Reference signature plus optional keyword arguments: ``post_relu`` / ``post_scale`` fuse the
+        caller's ``dropout(relu(out))`` (post_scale = keep-mask / (1 - p)) into the kernel epilogue;
+        ``post_drop = (p, tag, functional.DropoutState)`` does the same with the mask generated in registers.
+        ``input`` may carry zero columns beyond ``in_features`` (functional.dropout(..., pad_to=...))."""
         mt = self.model_type
         if mt == "mlp":
             return AF.mm(input, self.weight_mlp)
@@ -112,7 +115,7 @@ class GraphConvolution(nn.Module):
             ops = adj_low
         else:
             ops = operators_for(adj_low, adj_high, adj_low_unnormalized if cfg.n_channels == 4 else None)
-        out, att = AF.acm_conv(input, self._param_dict(), ops, cfg, post_relu, post_scale)
+        out, att = AF.acm_conv(input, self._param_dict(), ops, cfg, post_relu, post_scale, post_drop)
         self.att_low, self.att_high, self.att_mlp = att[:, 0:1], att[:, 1:2], att[:, 2:3]
         if cfg.n_channels == 4:
             self.att_struc_vec_low = att[:, 3:4]

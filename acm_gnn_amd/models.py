@@ -15,7 +15,8 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from .graph import SparseFeatures
+from . import functional as AF
+from .graph import FilterOperators, SparseFeatures
 from .layers import GraphConvolution, MLP
 
 _TWO_LAYER = ("acmgcn", "acmgcnp", "acmgcnpp")
@@ -46,6 +47,11 @@ class GCN(nn.Module):
         dev = self.gcns[0].weight_low.device
         self.fea_param = nn.Parameter(torch.zeros(1, 1, device=dev))
         self.xX_param = nn.Parameter(torch.zeros(1, 1, device=dev))
+        # Counter-based dropout (functional.DropoutState): off by default -- F.dropout, like the reference.  A
+        # training loop that advances ``dropout_state`` once per optimizer step (train.TrainStep does) may set
+        # ``fused_dropout = True``: the masks are then generated inside the layer kernels.
+        self.fused_dropout = False
+        self.dropout_state = None
         self.reset_parameters()
 
     def _ones_like_hidden(self, n, f, device):
@@ -58,7 +64,37 @@ class GCN(nn.Module):
         if self.model_type == "acmgcnpp":
             self.mlpX.reset_parameters()
 
+    def _forward_fused_dropout(self, x, adj_low, adj_high, adj_low_unnormalized):
+        """Training forward with every dropout drawn from ``dropout_state`` (tags: 0 input, 1 hidden, 2 the
+        ACM-GCN++ residual branch); same structure as forward()."""
+        p = self.dropout
+        if self.dropout_state is None:
+            dev = x.values.device if isinstance(x, SparseFeatures) else x.device
+            self.dropout_state = AF.DropoutState(dev)
+        st = self.dropout_state
+        off = adj_low.row_offset if isinstance(adj_low, FilterOperators) else 0
+        if isinstance(x, SparseFeatures):
+            if self.model_type == "acmgcnpp":
+                raise NotImplementedError("acmgcnpp's dense residual branch needs dense features")
+            x = x.with_values(AF.dropout(x.values.reshape(-1, 1), p, st, tag=0).reshape(-1))
+            kw = {}
+        else:
+            nfeat = x.shape[1]
+            x = AF.dropout(x, p, st, tag=0, pad_to=AF.agg_pad_width(nfeat) if self.model_type != "acmgcnpp" else None,
+                           row_offset=off)
+            kw = {}
+        if self.model_type == "acmsgc":
+            return self.gcns[0](x, adj_low, adj_high, adj_low_unnormalized)
+        if self.model_type == "acmgcnpp":
+            xx = AF.dropout(F.relu(self.mlpX(x, input_tensor=True)), p, st, tag=2, row_offset=off)
+        fea = self.gcns[0](x, adj_low, adj_high, adj_low_unnormalized, post_relu=True, post_drop=(p, 1, st), **kw)
+        if self.model_type == "acmgcnpp":
+            fea = fea + xx
+        return self.gcns[1](fea, adj_low, adj_high, adj_low_unnormalized)
+
     def forward(self, x, adj_low, adj_high=None, adj_low_unnormalized=None):
+        if self.fused_dropout and self.training and self.dropout > 0:
+            return self._forward_fused_dropout(x, adj_low, adj_high, adj_low_unnormalized)
         drop = lambda t: F.dropout(t, self.dropout, training=self.training)  # noqa: E731
         if isinstance(x, SparseFeatures):
             # dropout of a sparse matrix = dropout of its stored values (zeros stay zero either way)

@@ -29,6 +29,9 @@ class _FusedAdamBase(torch.optim.Optimizer):
             raise ValueError("FusedAdam: invalid hyper-parameter")
         # torch-only switches (foreach / fused / capturable / differentiable) are accepted and meaningless here
         super().__init__(params, dict(lr=lr, betas=tuple(betas), eps=eps, weight_decay=weight_decay))
+        # optional device int64 counter incremented by the last launch of every step() (the DropoutState.step
+        # of the model being trained: acm_adam_config_t.also_advance)
+        self.also_advance = None
 
     @torch.no_grad()
     def step(self, closure=None):
@@ -37,10 +40,11 @@ class _FusedAdamBase(torch.optim.Optimizer):
             with torch.enable_grad():
                 loss = closure()
         lib = _lib.load()
-        for group in self.param_groups:
-            live = [p for p in group["params"] if p.grad is not None]
-            if not live:
-                continue
+        groups = [(g, [p for p in g["params"] if p.grad is not None]) for g in self.param_groups]
+        groups = [(g, live) for g, live in groups if live]
+        if not groups and self.also_advance is not None:
+            self.also_advance.add_(1)
+        for gi, (group, live) in enumerate(groups):
             entries = (_lib.AdamTensor * len(live))()
             keep = []
             for e, p in zip(entries, live):
@@ -62,7 +66,9 @@ class _FusedAdamBase(torch.optim.Optimizer):
                 e.exp_avg, e.exp_avg_sq, e.step = st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr(), st["step"].data_ptr()
                 e.numel = p.numel()
             cfg = _lib.AdamConfig(float(group["lr"]), float(group["betas"][0]), float(group["betas"][1]),
-                                  float(group["eps"]), float(group["weight_decay"]), int(self._decoupled))
+                                  float(group["eps"]), float(group["weight_decay"]), int(self._decoupled),
+                                  self.also_advance.data_ptr() if (self.also_advance is not None and
+                                                                   gi == len(groups) - 1) else None)
             dev = live[0].device
             if any(p.device != dev for p in live):
                 raise RuntimeError("FusedAdam: one param group must live on one device")

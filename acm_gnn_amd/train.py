@@ -16,6 +16,8 @@ import torch.nn.functional as F
 
 from . import functional as AF
 
+_TORCH_DROPOUT = F.dropout          # to notice a patched F.dropout (mask replay in tests): see TrainStep
+
 
 def row_weights(train_idx, n_rows, n_train_total=None, device=None):
     """w_i = 1/|train| on training rows else 0 (mean NLL over the training set)."""
@@ -27,11 +29,26 @@ def row_weights(train_idx, n_rows, n_train_total=None, device=None):
 
 
 class TrainStep:
-    def __init__(self, model, optimizer, x, adj, labels, weights, adj_high=None, adj_un=None, use_graph=False):
+    def __init__(self, model, optimizer, x, adj, labels, weights, adj_high=None, adj_un=None, use_graph=False,
+                 fused_dropout=None):
         self.model, self.opt = model, optimizer
         self.x, self.adj, self.adj_high, self.adj_un = x, adj, adj_high, adj_un
         self.labels, self.weights = labels, weights
         self.graph, self.loss = None, None
+        # counter-based dropout: this loop owns the step structure (one advance per optimizer step), so the
+        # model may draw its masks inside the kernels; the advance rides FusedAdam's step-counter kernel
+        # (default: on, unless someone replaced F.dropout -- a mask-replay harness must keep seeing its masks)
+        self._manual_advance = False
+        if fused_dropout is None:
+            fused_dropout = F.dropout is _TORCH_DROPOUT
+        if fused_dropout and getattr(model, "dropout", 0) > 0 and hasattr(model, "fused_dropout"):
+            model.fused_dropout = True
+            if model.dropout_state is None:
+                model.dropout_state = AF.DropoutState(labels.device)
+            if hasattr(optimizer, "also_advance"):
+                optimizer.also_advance = model.dropout_state.step
+            else:
+                self._manual_advance = True
         if use_graph:
             self._capture()
 
@@ -42,6 +59,8 @@ class TrainStep:
         loss, dz = AF.nll_loss_and_grad(out, self.labels, self.weights)   # = masked_nll(...).backward(), two launches less
         out.backward(dz)
         self.opt.step()
+        if self._manual_advance:
+            self.model.dropout_state.advance()
         return loss                 # never hand out the autograd graph: a live AccumulateGrad node pins its
                                     # stream and breaks a later graph capture
 
@@ -61,6 +80,8 @@ class TrainStep:
             loss, dz = AF.nll_loss_and_grad(out, self.labels, self.weights)
             out.backward(dz)
             self.opt.step()
+            if self._manual_advance:
+                self.model.dropout_state.advance()
             self.loss = loss
         del loss, out, dz
 
@@ -82,7 +103,7 @@ def evaluate(model, x, adj, labels, index_sets, adj_high=None, adj_un=None):
 
 
 def fit(model, optimizer, x, adj, labels, train_idx, val_idx, test_idx, epochs, rule="max_val_acc",
-        early_stopping=0, adj_high=None, adj_un=None, use_graph=False):
+        early_stopping=0, adj_high=None, adj_un=None, use_graph=False, fused_dropout=None):
     """Train and return (selected test accuracy, per-epoch history).
 
     rule = "max_val_acc":  test accuracy at the best validation accuracy, fixed number of epochs
@@ -92,7 +113,8 @@ def fit(model, optimizer, x, adj, labels, train_idx, val_idx, test_idx, epochs, 
                            (ACM-Pytorch/train.py:129-139)
     """
     w = row_weights(train_idx, x.shape[0], device=x.device)
-    step = TrainStep(model, optimizer, x, adj, labels, w, adj_high, adj_un, use_graph=use_graph)
+    step = TrainStep(model, optimizer, x, adj, labels, w, adj_high, adj_un, use_graph=use_graph,
+                     fused_dropout=fused_dropout)
     best_key, selected, history = None, 0.0, []
     val_hist = []
     for epoch in range(epochs):

@@ -44,6 +44,8 @@ def parse():
     ap.add_argument("--weight_decay", type=float, default=1e-3)
     ap.add_argument("--uniform", action="store_true", help="uniform random graph instead of power-law")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--dropout-impl", default="fused", choices=["fused", "torch"],
+                    help="dropout masks: counter-based inside the layer kernels, or torch's F.dropout tensors")
     ap.add_argument("--optimizer", default="fused", choices=["fused", "torch"],
                     help="AdamW update: acm_adam_step (one launch) or torch.optim.AdamW (~80 launches)")
     ap.add_argument("--seed", type=int, default=0)
@@ -144,7 +146,8 @@ def main():
         opt = torch.optim.AdamW(model.parameters(), lr=args.lr, weight_decay=args.weight_decay, capturable=use_graph)
     # mean NLL over the (global) training set; rows a rank does not own have weight 0
     w = T.row_weights(tr_loc, e - b, n_train_total=n_train, device=dev)
-    step = T.TrainStep(model, opt, x, ops, y, w, use_graph=False)
+    fused_drop = args.dropout_impl == "fused"
+    step = T.TrainStep(model, opt, x, ops, y, w, use_graph=False, fused_dropout=fused_drop)
 
     def fence():
         if world > 1:
@@ -211,7 +214,8 @@ def main():
             "config": {"workload": f"{args.dataset}-shaped Chung-Lu graph: {n_real} nodes, {adj.nnz // 2} undirected "
                                    f"edges, nnz(A_low)={nnz}, F_in={x.shape[1]}, hidden={args.hidden}, classes={n_cls}; "
                                    f"2-layer {args.method} (variant={args.variant}, structure_info={args.structure_info}, "
-                                   f"attention LayerNorm on), dropout {args.dropout}, AdamW ({args.optimizer}); "
+                                   f"attention LayerNorm on), dropout {args.dropout} ({'counter-based, masks regenerated in the kernels' if fused_drop else 'F.dropout mask tensors'}), "
+                                   f"AdamW ({args.optimizer}); "
                                    "step = fwd + NLL loss + bwd + optimizer update",
                        "parallelism": f"csr-row-shard x{world}" if world > 1 else "single-gpu",
                        "node_order": args.node_order, "launch": launch,
@@ -243,7 +247,7 @@ def main():
         timer_t.daemon = True
         timer_t.start()
         try:
-            gstep = T.TrainStep(model, opt, x, ops, y, w, use_graph=True)
+            gstep = T.TrainStep(model, opt, x, ops, y, w, use_graph=True, fused_dropout=fused_drop)
             for _ in range(max(args.warmup, 1)):
                 loss = gstep()
             fence()

@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define ACM_ABI_VERSION 8
+#define ACM_ABI_VERSION 9
 
 typedef enum {
     ACM_OK = 0,
@@ -124,6 +124,31 @@ int acm_gemm_blocks(int transA, int transB, int64_t M, int64_t N, int64_t K,
                     const float* A, int64_t lda, const float* B, int64_t ldb,
                     float* C, int64_t ldc, int64_t c_col_block, int64_t c_block_stride, int relu,
                     void* workspace, size_t workspace_bytes, acm_stream_t stream);
+
+/* -------------------------------------------------------- counter-based dropout --
+ * The reference applies F.dropout to the input and to relu(layer-1 output) (ACM-Geometric/models.py:54,70;
+ * ACM-Pytorch/models/models.py:149,164).  torch materialises a mask tensor per call; here the keep/drop
+ * decision of element (row, col) is a pure function
+ *     keep = Philox4x32-7( key = seed, counter = (global row, block(col) | tag << 16, step) ).word(col) >= p * 2^32
+ *     block(col) = (col & 15) + 16 * (col >> 6),   word(col) = (col >> 4) & 3
+ * so the forward and the backward kernels regenerate it in registers instead of writing / reading an
+ * [n, F] mask (and nothing inside a captured step touches torch's generator).  `step` is a device counter
+ * the training loop advances once per optimizer step (acm_adam_config_t.also_advance does it for free), so a
+ * replayed hipGraph draws fresh masks; `tag` separates the masks drawn within one step.  Surviving elements
+ * are scaled by 1 / (1 - p) like torch.  p = 0 disables.
+ */
+typedef struct {
+    float    p;
+    int32_t  tag;
+    uint64_t seed;
+    const int64_t* step;       /* device */
+    int64_t  row_offset;       /* global index of local row 0 (a row shard draws the single-process mask) */
+} acm_dropout_t;
+
+/* dst[r, c] = src[r, c] * keep(r, c) / (1 - p) for c < n_cols, 0 for n_cols <= c < dst_cols (row padding for the
+ * 16-byte gathers of the aggregate-first path).  src may equal dst when dst_cols == n_cols. */
+int acm_dropout(int64_t n_rows, int64_t n_cols, const float* src, int64_t ld_src,
+                float* dst, int64_t ld_dst, int64_t dst_cols, const acm_dropout_t* d, acm_stream_t stream);
 
 /* ----------------------------------------------------------------- SpMM --
  * Y[r, 0:width] = sum_j A[r,j] * G[j, 0:width]   (plain CSR x dense; used for
@@ -221,6 +246,8 @@ typedef struct {
     int32_t gather_bf16;
     /* optional per-row multiplier of every gathered sum (pattern-only a_low: 1/d_i); NULL = 1 */
     const float* row_scale;
+    /* in-register dropout of the (post-ReLU) output, in addition to post_scale; p = 0: off */
+    acm_dropout_t post_drop;
 } acm_conv_fwd_t;
 
 int acm_conv_fwd(const acm_csr_t* a_low, const acm_conv_fwd_t* p,
@@ -260,6 +287,7 @@ typedef struct {
      * A_low^T G = P (D^-1 G) is written pre-scaled by 1/d_i); NULL = 1.  `deg` NULL = 1 likewise
      * (g_struc = dL/dpre_S unscaled, which is what P needs: A_low^T (D G_S) = P G_S). */
     const float* g_scale;
+    acm_dropout_t post_drop;              /* the forward's post_drop (same seed / step / tag) */
 } acm_conv_bwd_local_t;
 
 int acm_conv_bwd_local_workspace_bytes(int64_t n_rows, int f_out, int n_channels, size_t* bytes);
@@ -339,6 +367,7 @@ typedef struct {
     const float* deg;                  /* d_i = rowsum(I + A), local rows                      */
     float* ps; int64_t ld_ps;          /* [n_rows, F]  A_low * S, saved for backward           */
     const float* row_scale;            /* optional per-row multiplier of both gathers (pattern-only a_low: 1/d_i) */
+    acm_dropout_t post_drop;           /* in-register dropout of the output (see acm_conv_fwd_t) */
 } acm_conv_agg_fwd_t;
 
 int acm_conv_agg_fwd(const acm_csr_t* a_low, const acm_conv_agg_fwd_t* p,
@@ -366,6 +395,7 @@ typedef struct {
     const float* deg;
     float* g_struc; int64_t ld_g_struc;   /* out: g_struc_scale_i * dL/dpre_S  (the operand of the A_low^T product) */
     const float* g_struc_scale;           /* deg for an explicit A_low^T; NULL (= 1) for the pattern-only form  */
+    acm_dropout_t post_drop;
 } acm_conv_agg_bwd_t;
 
 int acm_conv_agg_bwd_workspace_bytes(int64_t n_rows, int f_in, int f_out, size_t* bytes);
@@ -412,6 +442,8 @@ typedef struct {
 typedef struct {
     double  lr, beta1, beta2, eps, weight_decay;
     int32_t decoupled;                 /* 1 = AdamW, 0 = Adam (L2 added to the gradient) */
+    int64_t* also_advance;             /* optional device counter incremented by 1 with the step counters
+                                          (the acm_dropout_t.step of the model being trained) */
 } acm_adam_config_t;
 
 int acm_adam_step(int32_t n_tensors, const acm_adam_tensor_t* tensors, const acm_adam_config_t* cfg,

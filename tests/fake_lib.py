@@ -38,11 +38,45 @@ class _Csr:
         return m @ g.astype(np.float64)
 
 
+def philox7_words(seed, step, tag, rows, blocks):
+    """Philox4x32-7 words of the dropout mask (numpy restatement of acm_philox7): rows/blocks are integer arrays
+    of equal shape; returns uint32 [4, ...]."""
+    M0, M1, W0, W1 = 0xD2511F53, 0xCD9E8D57, 0x9E3779B9, 0xBB67AE85
+    mask = np.uint64(0xFFFFFFFF)
+    x0 = np.asarray(rows).astype(np.uint64) & mask
+    x1 = (np.asarray(blocks).astype(np.uint64) | np.uint64((int(tag) << 16) & 0xFFFFFFFF)) & mask
+    x2 = np.full(x0.shape, int(step) & 0xFFFFFFFF, np.uint64)
+    x3 = np.full(x0.shape, (int(step) >> 32) & 0xFFFFFFFF, np.uint64)
+    k0, k1 = int(seed) & 0xFFFFFFFF, (int(seed) >> 32) & 0xFFFFFFFF
+    for _ in range(7):
+        p0, p1 = np.uint64(M0) * x0, np.uint64(M1) * x2
+        hi0, lo0, hi1, lo1 = p0 >> np.uint64(32), p0 & mask, p1 >> np.uint64(32), p1 & mask
+        x0, x1, x2, x3 = hi1 ^ x1 ^ np.uint64(k0), lo1, hi0 ^ x3 ^ np.uint64(k1), lo0
+        k0, k1 = (k0 + W0) & 0xFFFFFFFF, (k1 + W1) & 0xFFFFFFFF
+    return np.stack([x0, x1, x2, x3]).astype(np.uint32)
+
+
+def dropout_factors(d, n_rows, n_cols):
+    """[n_rows, n_cols] factors (0 or 1/(1-p)) of an acm_dropout_t (ctypes struct or None)."""
+    if d is None or d.p <= 0:
+        return np.ones((n_rows, n_cols))
+    step = int(_vec(d.step, 1, np.int64)[0])
+    r, c = np.meshgrid(np.arange(n_rows) + int(d.row_offset), np.arange(n_cols), indexing="ij")
+    w = philox7_words(d.seed, step, d.tag, r, (c & 15) + 16 * (c >> 6))
+    word = np.take_along_axis(w, ((c >> 4) & 3)[None], 0)[0]
+    t = float(np.float32(d.p)) * 4294967296.0
+    thresh = 0xFFFFFFFF if t >= 4294967295.0 else int(t)
+    inv = np.float32(1.0) / (np.float32(1.0) - np.float32(d.p))
+    return np.where(word >= thresh, np.float64(inv), 0.0)
+
+
 def _post_fwd(p, out, n, F):
     if p.post_relu:
         out = np.maximum(out, 0)
     if p.post_scale:
         out = out * _view(p.post_scale, n, F, p.ld_post_scale)
+    if p.post_drop.p > 0:
+        out = out * dropout_factors(p.post_drop, n, F)
     return out
 
 
@@ -51,6 +85,8 @@ def _post_bwd(p, dO, raw_out, n, F):
         dO = np.where(raw_out > 0, dO, 0.0)
     if p.post_scale:
         dO = dO * _view(p.post_scale, n, F, p.ld_post_scale)
+    if p.post_drop.p > 0:
+        dO = dO * dropout_factors(p.post_drop, n, F)
     return dO
 
 
@@ -110,7 +146,7 @@ class FakeLib:
 
     # ---- plumbing ---------------------------------------------------------
     def acm_version(self):
-        return 8
+        return 9
 
     def acm_last_error(self):
         return self._err
@@ -432,10 +468,18 @@ class FakeLib:
         out[base + 3 * k * F:] = d_mix.reshape(-1)
         return 0
 
+    def acm_dropout(self, n, c, src, lds, dst, ldd, dst_cols, d, stream):
+        out = np.zeros((n, dst_cols))
+        out[:, :c] = _view(src, n, c, lds).astype(np.float64) * dropout_factors(d._obj, n, c)
+        _view(dst, n, dst_cols, ldd)[...] = out
+        return 0
+
     def acm_adam_step(self, n, tensors, cfg, stream):
         import ctypes as C
         from acm_gnn_amd import _lib
         c = cfg._obj
+        if c.also_advance:
+            _vec(c.also_advance, 1, np.int64)[0] += 1
         arr = C.cast(tensors, C.POINTER(_lib.AdamTensor * n)).contents if n else []
         f32 = np.float32
         for t in arr:

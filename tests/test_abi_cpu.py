@@ -45,7 +45,7 @@ def test_calls_without_gpu_fail_loudly_not_silently():
 
 STRUCTS = {"acm_csr_info_t": "CsrInfo", "acm_conv_fwd_t": "ConvFwd", "acm_conv_bwd_local_t": "ConvBwdLocal",
            "acm_conv_bwd_spmm_t": "ConvBwdSpmm", "acm_conv_agg_fwd_t": "ConvAggFwd", "acm_conv_agg_bwd_t": "ConvAggBwd",
-           "acm_spmm_opts_t": "SpmmOpts", "acm_adam_tensor_t": "AdamTensor", "acm_adam_config_t": "AdamConfig"}
+           "acm_spmm_opts_t": "SpmmOpts", "acm_dropout_t": "Dropout", "acm_adam_tensor_t": "AdamTensor", "acm_adam_config_t": "AdamConfig"}
 
 
 def test_ctypes_struct_layouts_match_the_c_header(tmp_path):
