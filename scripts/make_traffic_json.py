@@ -1,0 +1,59 @@
+#!/usr/bin/env python3
+"""HBM bytes per launch of the bench step's kernels from the FETCH_SIZE / WRITE_SIZE PMC summaries
+(scripts/rocpd_pmc_summary.py CSVs):  hbm_bytes = (2 * FETCH_SIZE + WRITE_SIZE) * 1024, FETCH_SIZE doubled as
+/opt/skills/guides/MI355X_MICROARCH.md prescribes for gfx950.  Keys are bench.py's kernel labels; a label
+made of several launches (gather + fix-up + epilogue) sums them.
+
+    python scripts/make_traffic_json.py pmc_fetch_size_kb.csv pmc_write_size_kb.csv > pmc_traffic.json
+"""
+import csv
+import json
+import sys
+
+# bench label -> substrings identifying its kernels in the profiler's names
+LABELS = {
+    "conv_agg_fwd/F64k3i7": ["spmm_narrow_kernel<8, 1, 32, false, EpiPlain>", "spmm_fixup_narrow_kernel<8, 1, EpiPlain>",
+                             "agg_epilogue_kernel<8, 3>"],
+    "conv_agg_bwd/F64k3i7": ["agg_bwd_kernel<8, 3>", "reduce_columns_kernel"],
+    "conv_fwd/F2k3": ["spmm_narrow_kernel<2, 2, 32, true, EpiRaw>", "spmm_fixup_narrow_kernel<2, 2, EpiRaw>",
+                      "conv_fwd_rows_kernel<2, 2>"],
+    "conv_bwd_spmm/F2k3": ["spmm_narrow_kernel<2, 2, 32, true, EpiBwd>", "spmm_fixup_narrow_kernel<2, 2, EpiBwd>"],
+    "conv_bwd_local/F2k3": ["conv_bwd_local_kernel<LayPacked<2>, 32, 3>", "conv_bwd_reduce_kernel"],
+    "gemm_TN/64x6x168114": ["gemm_kernel<4, 1, 4, 1, true, false>", "splitk_reduce_kernel"],
+    "gemm_NT/168114x64x6": ["gemm_kernel<2, 2, 2, 2, false, true>"],
+    "gemm_NN/168114x6x64": ["gemm_kernel<4, 1, 4, 1, false, false>"],
+}
+
+
+def load(path, column):
+    out = {}
+    with open(path) as fh:
+        for row in csv.DictReader(fh):
+            out[row["kernel"]] = float(row[column])
+    return out
+
+
+def main(fetch_csv, write_csv):
+    fetch, write = load(fetch_csv, "FETCH_SIZE_avg"), load(write_csv, "WRITE_SIZE_avg")
+    doc = {"_doc": "HBM-side bytes per launch from rocprofv3 PMC (separate --pmc FETCH_SIZE / WRITE_SIZE passes over "
+                   "bench.py's default workload). hbm_bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024: FETCH_SIZE doubled as "
+                   "MI355X_MICROARCH.md prescribes for gfx950 (calibrated there on wide coalesced streams; the random "
+                   "16-32 B gathers here are outside that calibration, so read ratios to algorithmic bytes as 1x..2x)."}
+    for label, needles in LABELS.items():
+        f = w = 0.0
+        found = []
+        for needle in needles:
+            for name in fetch:
+                if needle in name:
+                    f += fetch[name]
+                    w += write.get(name, 0.0)
+                    found.append(needle)
+                    break
+        if found:
+            doc[label] = {"fetch_kb": round(f, 1), "write_kb": round(w, 1), "kernels": found,
+                          "hbm_bytes": int((2 * f + w) * 1024)}
+    json.dump(doc, sys.stdout, indent=1)
+
+
+if __name__ == "__main__":
+    main(sys.argv[1], sys.argv[2])
