@@ -84,10 +84,13 @@ def gemm(a, b, trans_a=False, trans_b=False, relu=False, out=None, col_blocks=0)
         raise ValueError(f"gemm: inner dimensions differ ({k} vs {k2})")
     lib = _lib.load()
     if col_blocks:
-        if out is not None or n % col_blocks:
-            raise ValueError("gemm: col_blocks needs n divisible by the block count and no out=")
+        if n % col_blocks:
+            raise ValueError("gemm: col_blocks needs n divisible by the block count")
         nb = n // col_blocks
-        out = torch.empty(col_blocks, m, nb, dtype=_F32, device=a.device)
+        if out is None:
+            out = torch.empty(col_blocks, m, nb, dtype=_F32, device=a.device)
+        elif tuple(out.shape) != (col_blocks, m, nb) or not out.is_contiguous() or out.dtype != _F32:
+            raise ValueError("gemm: out must be a contiguous fp32 [col_blocks, m, n / col_blocks] tensor")
         nbytes = C.c_size_t()
         _lib.check(lib.acm_gemm_workspace_bytes(int(trans_a), int(trans_b), m, n, k, C.byref(nbytes)))
         ws = torch.empty(max(nbytes.value // 4, 1), dtype=_F32, device=a.device) if nbytes.value else None
@@ -403,7 +406,13 @@ class AcmConvFunction(torch.autograd.Function):
                 xpad = x
             else:
                 xpad = torch.nn.functional.pad(x[:, :f_in], (0, fp - f_in))
-            xg = _gather_rows(ops, xpad)
+            pre = getattr(ops, "_pregathered", None)
+            ops._pregathered = None
+            if (pre is not None and pre[0].data_ptr() == xpad.data_ptr() and pre[1].shape[1] == fp
+                    and pre[1].shape[0] == ops.n_global):
+                xg = pre[1]                           # the caller already holds every node's (dropped) input
+            else:
+                xg = _gather_rows(ops, xpad)
             wl, wh, wm = (_as_f32c(t, "weight") for t in (w_low, w_high, w_mlp))
         else:
             if zero_padded:
@@ -563,10 +572,16 @@ class AcmConvFunction(torch.autograd.Function):
         g = torch.empty(n, 2 * f, dtype=_F32, device=dev)            # [G_L | G_H]
         dz = torch.empty(n, 3 * f, dtype=_F32, device=dev)           # [dZ_L | dZ_H | dZ_I]
         gs = torch.empty(n, f, dtype=_F32, device=dev) if four else None
-        d_vec = [torch.empty(f, 1, dtype=_F32, device=dev) for _ in range(k)]
-        d_lnw = [torch.empty(f, dtype=_F32, device=dev) for _ in range(k)] if cfg.layernorm else []
-        d_lnb = [torch.empty(f, dtype=_F32, device=dev) for _ in range(k)] if cfg.layernorm else []
-        d_mix = torch.empty(k, k, dtype=_F32, device=dev)
+        # every replicated-parameter gradient is a view of one flat buffer: a row-sharded run sums the partials
+        # with a single all-reduce and no pack / unpack launches
+        f_in_w = wcat.shape[0]
+        nw, nln = 3 * f_in_w * f, (k * f if cfg.layernorm else 0)
+        flat = torch.empty(nw + k * f + 2 * nln + k * k, dtype=_F32, device=dev)
+        d_vec = [flat[nw + c * f: nw + (c + 1) * f].view(f, 1) for c in range(k)]
+        o1 = nw + k * f
+        d_lnw = [flat[o1 + c * f: o1 + (c + 1) * f] for c in range(k)] if cfg.layernorm else []
+        d_lnb = [flat[o1 + nln + c * f: o1 + nln + (c + 1) * f] for c in range(k)] if cfg.layernorm else []
+        d_mix = flat[o1 + 2 * nln:].view(k, k)
 
         q = _lib.ConvBwdLocal()
         q.f_out, q.n_channels = f, k
@@ -649,22 +664,17 @@ class AcmConvFunction(torch.autograd.Function):
         if ctx.sparse_x is not None:                                          # dWcat = X_csr^T dZ
             xs = ctx.sparse_x
             xt = xs.csr_t
-            d_wcat = spmm_v(xt, xs.values.index_select(0, xt.src_pos), dz)
+            d_wcat = spmm_v(xt, xs.values.index_select(0, xt.src_pos), dz, out=flat[:nw].view(f_in_w, 3 * f))
             d_x = None
         else:
-            d_wcat = gemm(x, dz, trans_a=True, col_blocks=3)                 # [3, F_in, F]: contiguous per weight
+            d_wcat = gemm(x, dz, trans_a=True, col_blocks=3,
+                          out=flat[:nw].view(3, f_in_w, f))                   # contiguous per weight
             d_x = gemm(dz, wcat, trans_b=True) if ctx.needs_input_grad[0] else None
             if d_x is not None and d_x.shape[1] != ctx.x_width:
                 d_x = torch.nn.functional.pad(d_x, (0, ctx.x_width - d_x.shape[1]))
-        small = [d_wcat, d_mix] + d_vec + d_lnw + d_lnb
         if ops.sharded:                             # replicated parameters: sum the row-shard partials
             import torch.distributed as dist
-            flat = torch.cat([t.reshape(-1) for t in small])
             dist.all_reduce(flat, group=ops.group)
-            off = 0
-            for t in small:
-                t.copy_(flat[off:off + t.numel()].view_as(t))
-                off += t.numel()
         if d_wcat.dim() == 3:
             d_wl, d_wh, d_wm = d_wcat[0], d_wcat[1], d_wcat[2]
         else:

@@ -220,6 +220,10 @@ class FilterOperators:
         self.n_global = int(n_global if n_global is not None else low.n_cols)
         self.group = group                              # torch.distributed group when row-sharded
         self.low_t_override = None                      # local rows of the global A_low^T (sharded)
+        # optional, row-sharded runs: the full (replicated, static) input matrix.  With counter-based dropout every
+        # rank can then produce the dropped input of ALL nodes itself and the first layer needs no halo all-gather
+        self.x_full = None
+        self._pregathered = None
         # general operator pair (adj_high != I - adj_low, or adj_un != D adj_low - I): see operators_for()
         self.general = False
         self.high = None                                # CsrGraph of adj_high

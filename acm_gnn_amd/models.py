@@ -80,8 +80,16 @@ class GCN(nn.Module):
             kw = {}
         else:
             nfeat = x.shape[1]
-            x = AF.dropout(x, p, st, tag=0, pad_to=AF.agg_pad_width(nfeat) if self.model_type != "acmgcnpp" else None,
-                           row_offset=off)
+            pad = AF.agg_pad_width(nfeat) if self.model_type != "acmgcnpp" else None
+            ops = adj_low if isinstance(adj_low, FilterOperators) else None
+            if ops is not None and ops.sharded and ops.x_full is not None and self.model_type != "acmgcnpp":
+                # the mask is a function of the global position: drop the replicated full input locally instead of
+                # all-gathering the dropped row blocks
+                xg = AF.dropout(ops.x_full, p, st, tag=0, pad_to=pad, row_offset=0)
+                x = xg[off:off + x.shape[0]]
+                ops._pregathered = (x, xg)
+            else:
+                x = AF.dropout(x, p, st, tag=0, pad_to=pad, row_offset=off)
             kw = {}
         if self.model_type == "acmsgc":
             return self.gcns[0](x, adj_low, adj_high, adj_low_unnormalized)

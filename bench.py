@@ -130,6 +130,9 @@ def main():
                                     group=dist.group.WORLD if (force_sharded and dist.is_initialized()) else None)
     b, e = DD.shard_bounds(n_glob, world, rank)
     x = torch.from_numpy(np.ascontiguousarray(x_np[b:e])).to(dev)
+    if ops.sharded:
+        ops.x_full = torch.from_numpy(np.ascontiguousarray(x_np)).to(dev)   # replicated static input (4.7 MB): no halo
+                                                                             # all-gather for the first layer
     y = torch.from_numpy(np.ascontiguousarray(y_np[b:e])).to(dev)
     tr_loc = torch.from_numpy(DD.local_index(tr, world, rank, n_glob)).to(dev)
     n_train = len(tr)

@@ -107,8 +107,14 @@ def _worker(rank, world, port, cfg, ret):
         assert ops.sharded and ops.n_local == n // world and ops.implicit == bool(cfg.get("implicit", 1))
         b, e = DD.shard_bounds(n, world, rank)
         torch.manual_seed(0)
-        full = GCN(7, 16, 2, 2, n, 0.0, cfg["model"], cfg["s"], variant=bool(cfg["variant"]), attn_layernorm=True)
-        model = GCN(7, 16, 2, 2, e - b, 0.0, cfg["model"], cfg["s"], variant=bool(cfg["variant"]), attn_layernorm=True)
+        pdrop = cfg.get("dropout", 0.0)
+        full = GCN(7, 16, 2, 2, n, pdrop, cfg["model"], cfg["s"], variant=bool(cfg["variant"]), attn_layernorm=True)
+        model = GCN(7, 16, 2, 2, e - b, pdrop, cfg["model"], cfg["s"], variant=bool(cfg["variant"]), attn_layernorm=True)
+        if pdrop:                                       # counter-based dropout: every rank draws the global mask
+            from acm_gnn_amd import functional as AF
+            model.fused_dropout, model.dropout_state = True, AF.DropoutState("cpu", seed=7)
+            if cfg.get("x_full"):
+                ops.x_full = torch.from_numpy(x_np)
         sd = full.state_dict()
         for k in list(sd):
             if k.endswith(".struc_low"):
@@ -131,9 +137,12 @@ def _worker(rank, world, port, cfg, ret):
 @pytest.mark.parametrize("cfg", [dict(model="acmgcnp", s=0, variant=0), dict(model="acmgcnp", s=1, variant=1),
                                  dict(model="acmgcn", s=0, variant=1), dict(model="acmgcnp", s=1, variant=0),
                                  dict(model="acmgcnp", s=1, variant=0, implicit=0),
-                                 dict(model="acmgcnp", s=1, variant=1, implicit=0)],
+                                 dict(model="acmgcnp", s=1, variant=1, implicit=0),
+                                 dict(model="acmgcnp", s=0, variant=0, dropout=0.5),
+                                 dict(model="acmgcnp", s=1, variant=0, dropout=0.5, x_full=1),
+                                 dict(model="acmgcn", s=0, variant=1, dropout=0.5, x_full=1)],
                          ids=["agg+literal", "struct-acmii", "acmii", "struct-agg", "struct-agg-explicit",
-                              "struct-acmii-explicit"])
+                              "struct-acmii-explicit", "dropout", "dropout-xfull-struct", "dropout-xfull-acmii"])
 def test_two_rank_row_shard_equals_single_process(cfg, monkeypatch):
     """world_size = 2 over gloo: the sharded forward/backward (halo all-gathers + parameter-gradient
     all-reduce issued by functional.AcmConvFunction) must reproduce the 1-process result."""
@@ -172,7 +181,11 @@ def test_two_rank_row_shard_equals_single_process(cfg, monkeypatch):
     ops = DD.make_sharded_operators(low, deg, "cpu", with_structure=bool(cfg["s"]))
     assert not ops.sharded and not ops.implicit
     torch.manual_seed(0)
-    full = GCN(7, 16, 2, 2, n, 0.0, cfg["model"], cfg["s"], variant=bool(cfg["variant"]), attn_layernorm=True)
+    full = GCN(7, 16, 2, 2, n, cfg.get("dropout", 0.0), cfg["model"], cfg["s"], variant=bool(cfg["variant"]),
+               attn_layernorm=True)
+    if cfg.get("dropout"):
+        from acm_gnn_amd import functional as AF
+        full.fused_dropout, full.dropout_state = True, AF.DropoutState("cpu", seed=7)
     out = full(torch.from_numpy(x_np), ops)
     idx = torch.from_numpy(tr)
     loss = F.nll_loss(F.log_softmax(out, 1)[idx], torch.from_numpy(y_np)[idx], reduction="sum") / len(tr)
