@@ -1,0 +1,151 @@
+// Backward of a skinny projection Z = X W (W: f_in x Q with Q <= 15, e.g. the output layer's [W_L|W_H|W_I] with
+// <= 5 classes):  dX = dZ W^T  and  dW = X^T dZ  in ONE pass over X (gfx950).
+// As two GEMMs (acm_gemm NT + TN with split-K) the N x f_in matrix X is streamed twice and dX once, in three
+// launches (55 us at N = 168k, f_in = 64); both products are pure streaming (a few FMAs per loaded float), so here a
+// 16-lane group takes one row -- lane m owns the four consecutive columns 4m..4m+3 of a 64-column chunk (one
+// float4 load of X, one float4 store of dX, 256 contiguous bytes per row) -- with its 4 x Q slice of W and its
+// 4 x Q accumulators of dW in registers.  dW partials: four row-groups of a wave by v_permlane swaps, the four
+// waves through LDS, one slab per block, then a fixed-order column reduce (deterministic).
+#include "acm_common.h"
+
+namespace {
+
+constexpr int PROJ_MAX_BLOCKS = 1024;
+
+template <int Q>
+__global__ __launch_bounds__(256) void proj_bwd_kernel(int n_rows, int f_in, const float* __restrict__ X, long ldx,
+                                                       const float* __restrict__ dZ, long lddz,
+                                                       const float* __restrict__ W, long ldw, float* __restrict__ dX,
+                                                       long lddx, float* __restrict__ partial) {
+    __shared__ float red[4][64 * Q];            // per wave: the wave's dW slice of the current chunk
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int g = lane >> 4, m = lane & 15;
+    const bool vec = ((((uintptr_t)X | (uintptr_t)dX) & 15) == 0) && (ldx % 4 == 0) && (lddx % 4 == 0);
+    float* slab = partial + (long)blockIdx.x * f_in * Q;
+    for (int j0 = 0; j0 < f_in; j0 += 64) {
+        const int jb = j0 + 4 * m;              // first of this lane's four columns
+        float w[4][Q], acc[4][Q];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int q = 0; q < Q; ++q) {
+                w[i][q] = (jb + i < f_in) ? W[(long)(jb + i) * ldw + q] : 0.f;
+                acc[i][q] = 0.f;
+            }
+        const bool full = vec && jb + 3 < f_in;
+        for (int row = (blockIdx.x * 4 + wave) * 4 + g; row < n_rows; row += gridDim.x * 16) {
+            float dz[Q];
+#pragma unroll
+            for (int q = 0; q < Q; ++q) dz[q] = dZ[(long)row * lddz + q];
+            float x[4];
+            if (full) {
+                const float4 v = *reinterpret_cast<const float4*>(X + (long)row * ldx + jb);
+                x[0] = v.x, x[1] = v.y, x[2] = v.z, x[3] = v.w;
+            } else {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) x[i] = (jb + i < f_in) ? X[(long)row * ldx + jb + i] : 0.f;
+            }
+            float dx[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int q = 0; q < Q; ++q)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    dx[i] = fmaf(dz[q], w[i][q], dx[i]);
+                    acc[i][q] = fmaf(x[i], dz[q], acc[i][q]);
+                }
+            if (full) {
+                *reinterpret_cast<float4*>(dX + (long)row * lddx + jb) = make_float4(dx[0], dx[1], dx[2], dx[3]);
+            } else {
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    if (jb + i < f_in) dX[(long)row * lddx + jb + i] = dx[i];
+            }
+        }
+        // wave: sum the four row-groups; block: the four waves in a fixed order
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int q = 0; q < Q; ++q) {
+                const float s = acm_cross_row_sum(acc[i][q]);
+                if (g == 0) red[wave][(4 * m + i) * Q + q] = s;
+            }
+        __syncthreads();
+        for (int e = threadIdx.x; e < 64 * Q; e += 256) {
+            const int j = j0 + e / Q;
+            if (j < f_in) slab[(long)j * Q + (e % Q)] = (red[0][e] + red[1][e]) + (red[2][e] + red[3][e]);
+        }
+        __syncthreads();
+    }
+}
+
+// dW[j][q] = sum_b partial[b][j * Q + q]; one block per output element; optional column-block layout of dW
+__global__ __launch_bounds__(256) void proj_reduce_kernel(const float* __restrict__ partial, int nblk, int f_in, int Q,
+                                                          float* __restrict__ dW, long lddw, int cb, long cbs) {
+    __shared__ float red[256];
+    const int e = blockIdx.x, j = e / Q, q = e % Q;
+    float s = 0.f;
+    for (int b = threadIdx.x; b < nblk; b += 256) s += partial[(long)b * f_in * Q + e];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int k = 128; k >= 1; k >>= 1) {
+        if ((int)threadIdx.x < k) red[threadIdx.x] += red[threadIdx.x + k];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        if (cb) dW[(long)(q / cb) * cbs + (long)j * lddw + (q % cb)] = red[0];
+        else dW[(long)j * lddw + q] = red[0];
+    }
+}
+
+int proj_blocks(int64_t n_rows) {
+    int64_t nb = (n_rows + 15) / 16;
+    if (nb > PROJ_MAX_BLOCKS) nb = PROJ_MAX_BLOCKS;
+    if (nb < 1) nb = 1;
+    return (int)nb;
+}
+
+}  // namespace
+
+extern "C" int acm_proj_bwd_workspace_bytes(int64_t n_rows, int64_t f_in, int n_out, size_t* bytes) {
+    ACM_REQUIRE(bytes, ACM_EINVAL, "acm_proj_bwd_workspace_bytes: NULL argument");
+    ACM_REQUIRE(n_rows >= 0 && f_in >= 0 && n_out >= 1, ACM_ESHAPE, "acm_proj_bwd_workspace_bytes: bad sizes");
+    ACM_REQUIRE(n_out <= 15 && n_out % 3 == 0, ACM_EUNSUPPORTED,
+                "acm_proj_bwd: n_out = %d (supported: 3, 6, 9, 12, 15; use acm_gemm otherwise)", n_out);
+    *bytes = (size_t)proj_blocks(n_rows) * (size_t)f_in * (size_t)n_out * sizeof(float);
+    return ACM_OK;
+}
+
+extern "C" int acm_proj_bwd(int64_t n_rows, int64_t f_in, int n_out, const float* X, int64_t ldx, const float* dZ,
+                            int64_t lddz, const float* W, int64_t ldw, float* dX, int64_t lddx, float* dW,
+                            int64_t lddw, int64_t dw_col_block, int64_t dw_block_stride, void* workspace,
+                            size_t workspace_bytes, acm_stream_t stream) {
+    size_t need = 0;
+    int st = acm_proj_bwd_workspace_bytes(n_rows, f_in, n_out, &need);
+    if (st != ACM_OK) return st;
+    ACM_REQUIRE(X && dZ && W && dX && dW, ACM_EINVAL, "acm_proj_bwd: NULL pointer");
+    ACM_REQUIRE(n_rows < INT32_MAX && f_in < INT32_MAX && ldx >= f_in && lddx >= f_in && lddz >= n_out && ldw >= n_out &&
+                    dw_col_block >= 0 && lddw >= (dw_col_block ? (dw_col_block < n_out ? dw_col_block : n_out) : n_out),
+                ACM_ESHAPE, "acm_proj_bwd: bad sizes / leading dimensions");
+    if (f_in == 0) return ACM_OK;
+    ACM_REQUIRE(workspace && workspace_bytes >= need, ACM_ENOMEM, "acm_proj_bwd: workspace %zu B < required %zu B",
+                workspace_bytes, need);
+    hipStream_t s = (hipStream_t)stream;
+    float* partial = (float*)workspace;
+    const int nblk = proj_blocks(n_rows);
+#define ACM_PROJ(Qv)                                                                                              \
+    hipLaunchKernelGGL((proj_bwd_kernel<Qv>), dim3(nblk), dim3(256), 0, s, (int)n_rows, (int)f_in, X, (long)ldx, dZ, \
+                       (long)lddz, W, (long)ldw, dX, (long)lddx, partial)
+    switch (n_out) {
+        case 3: ACM_PROJ(3); break;
+        case 6: ACM_PROJ(6); break;
+        case 9: ACM_PROJ(9); break;
+        case 12: ACM_PROJ(12); break;
+        default: ACM_PROJ(15); break;
+    }
+#undef ACM_PROJ
+    ACM_CHECK_HIP(hipGetLastError());
+    hipLaunchKernelGGL(proj_reduce_kernel, dim3((unsigned)(f_in * n_out)), dim3(256), 0, s, partial, nblk, (int)f_in, n_out,
+                       dW, (long)lddw, (int)dw_col_block, (long)dw_block_stride);
+    ACM_CHECK_HIP(hipGetLastError());
+    return ACM_OK;
+}

@@ -111,6 +111,32 @@ def gemm(a, b, trans_a=False, trans_b=False, relu=False, out=None, col_blocks=0)
     return out
 
 
+def proj_bwd(x, dz, w, d_w_out):
+    """Backward of the skinny projection Z = x @ w in one pass over x (acm_proj_bwd):
+    returns dX = dz @ w.T and fills ``d_w_out`` ([blocks, f_in, n_out / blocks], contiguous) with x.T @ dz."""
+    x, dz, w = _as_f32c(x, "x"), _as_f32c(dz, "dz"), _as_f32c(w, "w")
+    n, f_in = x.shape
+    q = w.shape[1]
+    blocks = d_w_out.shape[0]
+    nb = q // blocks
+    if tuple(d_w_out.shape) != (blocks, f_in, nb) or not d_w_out.is_contiguous() or dz.shape != (n, q):
+        raise ValueError("proj_bwd: shape mismatch")
+    lib = _lib.load()
+    dx = torch.empty(n, f_in, dtype=_F32, device=x.device)
+    nbytes = C.c_size_t()
+    _lib.check(lib.acm_proj_bwd_workspace_bytes(n, f_in, q, C.byref(nbytes)), "acm_proj_bwd_workspace_bytes")
+    ws = torch.empty(max(nbytes.value // 4, 1), dtype=_F32, device=x.device)
+    with _device_ctx(x.device), _Timed(f"proj_bwd/{n}x{f_in}x{q}"):
+        st = lib.acm_proj_bwd(n, f_in, q, _vp(x), x.stride(0), _vp(dz), dz.stride(0), _vp(w), w.stride(0), _vp(dx),
+                              dx.stride(0), _vp(d_w_out), nb, nb, f_in * nb, _vp(ws), nbytes.value, _stream())
+    _lib.check(st, "acm_proj_bwd")
+    return dx
+
+
+def proj_bwd_supported(q):
+    return q in (3, 6, 9, 12, 15)
+
+
 def spmm(graph, dense, out=None):
     """out = A @ dense for a CsrGraph A (acm_spmm)."""
     dense = _as_f32c(dense, "dense")
@@ -666,12 +692,15 @@ class AcmConvFunction(torch.autograd.Function):
             xt = xs.csr_t
             d_wcat = spmm_v(xt, xs.values.index_select(0, xt.src_pos), dz, out=flat[:nw].view(f_in_w, 3 * f))
             d_x = None
+        elif ctx.needs_input_grad[0] and proj_bwd_supported(3 * f) and os.environ.get("ACM_PROJ_BWD", "1") != "0":
+            d_wcat = flat[:nw].view(3, f_in_w, f)                             # narrow output layer: dX and dW in one
+            d_x = proj_bwd(x, dz, wcat, d_wcat)                               # pass over x (acm_proj_bwd)
         else:
             d_wcat = gemm(x, dz, trans_a=True, col_blocks=3,
                           out=flat[:nw].view(3, f_in_w, f))                   # contiguous per weight
             d_x = gemm(dz, wcat, trans_b=True) if ctx.needs_input_grad[0] else None
-            if d_x is not None and d_x.shape[1] != ctx.x_width:
-                d_x = torch.nn.functional.pad(d_x, (0, ctx.x_width - d_x.shape[1]))
+        if d_x is not None and d_x.shape[1] != ctx.x_width:
+            d_x = torch.nn.functional.pad(d_x, (0, ctx.x_width - d_x.shape[1]))
         if ops.sharded:                             # replicated parameters: sum the row-shard partials
             import torch.distributed as dist
             dist.all_reduce(flat, group=ops.group)

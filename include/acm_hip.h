@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define ACM_ABI_VERSION 9
+#define ACM_ABI_VERSION 10
 
 typedef enum {
     ACM_OK = 0,
@@ -149,6 +149,19 @@ typedef struct {
  * 16-byte gathers of the aggregate-first path).  src may equal dst when dst_cols == n_cols. */
 int acm_dropout(int64_t n_rows, int64_t n_cols, const float* src, int64_t ld_src,
                 float* dst, int64_t ld_dst, int64_t dst_cols, const acm_dropout_t* d, acm_stream_t stream);
+
+/* Backward of a skinny projection Z = X W  (W: f_in x n_out, n_out in {3, 6, 9, 12, 15} -- the output layer's
+ * [W_L | W_H | W_I] with up to five classes) in one pass over X:
+ *     dX = dZ W^T          [n_rows, f_in]
+ *     dW = X^T dZ          [f_in, n_out], optionally as column blocks like acm_gemm_blocks
+ * i.e. MmBackward of `torch.mm(input, self.weight_*)` (layers.py:87-89) for both operands at once; as two
+ * split-K GEMMs the N x f_in input is streamed twice.  Deterministic (fixed reduction order).
+ * Workspace: acm_proj_bwd_workspace_bytes. */
+int acm_proj_bwd_workspace_bytes(int64_t n_rows, int64_t f_in, int n_out, size_t* bytes);
+int acm_proj_bwd(int64_t n_rows, int64_t f_in, int n_out, const float* X, int64_t ldx,
+                 const float* dZ, int64_t lddz, const float* W, int64_t ldw,
+                 float* dX, int64_t lddx, float* dW, int64_t lddw, int64_t dw_col_block, int64_t dw_block_stride,
+                 void* workspace, size_t workspace_bytes, acm_stream_t stream);
 
 /* ----------------------------------------------------------------- SpMM --
  * Y[r, 0:width] = sum_j A[r,j] * G[j, 0:width]   (plain CSR x dense; used for

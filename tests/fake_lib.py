@@ -146,7 +146,7 @@ class FakeLib:
 
     # ---- plumbing ---------------------------------------------------------
     def acm_version(self):
-        return 9
+        return 10
 
     def acm_last_error(self):
         return self._err
@@ -217,6 +217,27 @@ class FakeLib:
 
     def acm_gemm_workspace_bytes(self, ta, tb, m, n, k, out):
         out._obj.value = 0
+        return 0
+
+    def acm_proj_bwd_workspace_bytes(self, n, f_in, q, out):
+        if q not in (3, 6, 9, 12, 15):
+            self._err = b"acm_proj_bwd: unsupported n_out"
+            return 4
+        out._obj.value = 4
+        return 0
+
+    def acm_proj_bwd(self, n, f_in, q, x, ldx, dz, lddz, w, ldw, dx, lddx, dw, lddw, cb, cbs, ws, wsb, stream):
+        X, DZ, W = (_view(x, n, f_in, ldx).astype(np.float64), _view(dz, n, q, lddz).astype(np.float64),
+                    _view(w, f_in, q, ldw).astype(np.float64))
+        _view(dx, n, f_in, lddx)[...] = DZ @ W.T
+        full = X.T @ DZ
+        base = dw.value if isinstance(dw, C.c_void_p) else int(dw)
+        if not cb:
+            _view(base, f_in, q, lddw)[...] = full
+        else:
+            for j, q0 in enumerate(range(0, q, cb)):
+                wd = min(cb, q - q0)
+                _view(base + 4 * j * cbs, f_in, wd, lddw)[...] = full[:, q0:q0 + wd]
         return 0
 
     def acm_conv_bwd_local_workspace_bytes(self, n, f, k, out):

@@ -53,6 +53,31 @@ def test_gemm_column_block_output(m, n, k, blocks):
     assert torch.equal(torch.cat(list(parts), dim=1), whole)
 
 
+@pytest.mark.parametrize("n,f_in,q", [(1000, 64, 6), (777, 64, 15), (513, 40, 9), (300, 130, 3), (4097, 64, 12), (5, 7, 6),
+                                      (168114, 64, 6)])
+def test_proj_bwd_matches_fp64(n, f_in, q):
+    """acm_proj_bwd: dX = dZ W^T and dW = X^T dZ in one pass, vs fp64; dW delivered as three column blocks."""
+    from acm_gnn_amd import functional as AF
+    g = torch.Generator().manual_seed(n + f_in + q)
+    x, dz, w = torch.randn(n, f_in, generator=g), torch.randn(n, q, generator=g), torch.randn(f_in, q, generator=g)
+    dw = torch.empty(3, f_in, q // 3, device=DEV)
+    dx = AF.proj_bwd(x.to(DEV), dz.to(DEV), w.to(DEV), dw)
+    ref_dx = dz.double() @ w.double().T
+    ref_dw = x.double().T @ dz.double()
+    sc_dx = dz.abs().double() @ w.abs().double().T
+    sc_dw = x.abs().double().T @ dz.abs().double()
+    assert float(((dx.cpu().double() - ref_dx).abs() / (sc_dx + 1e-30)).max()) < 2e-6
+    got = torch.cat(list(dw.cpu()), dim=1).double()
+    assert float(((got - ref_dw).abs() / (sc_dw + 1e-30)).max()) < 3e-6
+    dw2 = torch.empty_like(dw)
+    dx2 = AF.proj_bwd(x.to(DEV), dz.to(DEV), w.to(DEV), dw2)
+    assert torch.equal(dx, dx2) and torch.equal(dw, dw2)            # deterministic
+    # unaligned / strided operands take the scalar path
+    xs = torch.randn(n, f_in + 3, generator=g)[:, 1:f_in + 1]
+    dxs = AF.proj_bwd(xs.to(DEV), dz.to(DEV), w.to(DEV), dw2)
+    assert float(((dxs.cpu().double() - ref_dx).abs() / (sc_dx + 1e-30)).max()) < 2e-6
+
+
 def test_gemm_is_an_fmaf_chain_in_k_order():
     """f32 MFMA == k-ordered fmaf chain: integer-valued inputs must be exact."""
     from acm_gnn_amd import functional as AF
