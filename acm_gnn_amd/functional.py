@@ -137,8 +137,8 @@ def proj_bwd_supported(q):
     return q in (3, 6, 9, 12, 15)
 
 
-def spmm(graph, dense, out=None):
-    """out = A @ dense for a CsrGraph A (acm_spmm)."""
+def spmm(graph, dense, out=None, row_scale=None):
+    """out = A @ dense for a CsrGraph A (acm_spmm); with ``row_scale``: diag(row_scale) (A @ dense) (acm_spmm_ex)."""
     dense = _as_f32c(dense, "dense")
     if dense.shape[0] != graph.n_cols:
         raise ValueError(f"spmm: dense has {dense.shape[0]} rows, operator has {graph.n_cols} columns")
@@ -149,8 +149,14 @@ def spmm(graph, dense, out=None):
         return out
     ws = graph.workspace(min(width, 256))
     with _device_ctx(dense.device), _Timed(f"spmm/W{width}"):
-        st = _lib.load().acm_spmm(graph.handle, _vp(dense), dense.stride(0), width, _vp(out), out.stride(0),
-                                  _vp(ws), ws.numel() * 4, _stream())
+        if row_scale is None:
+            st = _lib.load().acm_spmm(graph.handle, _vp(dense), dense.stride(0), width, _vp(out), out.stride(0),
+                                      _vp(ws), ws.numel() * 4, _stream())
+        else:
+            o = _lib.SpmmOpts()
+            o.row_scale = _as_f32c(row_scale, "row_scale").data_ptr()
+            st = _lib.load().acm_spmm_ex(graph.handle, _vp(dense), dense.stride(0), width, _vp(out), out.stride(0),
+                                         C.byref(o), _vp(ws), ws.numel() * 4, _stream())
     _lib.check(st, "acm_spmm")
     return out
 
@@ -376,6 +382,17 @@ def _gather_rows(ops, local):
     return full[: ops.n_global] if full.shape[0] != ops.n_global else full
 
 
+def _low_product(ops, t_local, transpose=False):
+    """A_low @ t (or A_low^T @ t) for a row-local t [n_local, w]: one hop of the ACM-SGC k-hop chain, with the
+    halo all-gather when row-sharded.  Pattern-only operators: D^-1 (P t) and P (D^-1 t)."""
+    if transpose:
+        if ops.implicit:
+            return spmm(ops.low_t, _gather_rows(ops, t_local * ops.row_scale[:, None]))
+        return spmm(ops.low_t, _gather_rows(ops, t_local))
+    tg = _gather_rows(ops, t_local.contiguous())
+    return spmm(ops.low, tg, row_scale=ops.row_scale if ops.implicit else None)
+
+
 class AcmConvFunction(torch.autograd.Function):
     """out, att = ACM layer(x; parameters) over the operators in ``ops``.
 
@@ -422,6 +439,14 @@ class AcmConvFunction(torch.autograd.Function):
                          and not ctx.needs_input_grad[0] and os.environ.get("ACM_AGG_FIRST", "1") != "0")
         four = k == 4
         general = bool(getattr(ops, "general", False))
+        # k-hop low-pass channel (ACM-SGC, ACM-Pytorch/utils.py:631-637 materialises the dense A_low^k): here the
+        # chain A_low (A_low (... Z_L)) with the 1-hop operator, adj_high stays 1-hop like the reference's
+        hops = int(getattr(ops, "hops", 1))
+        ctx.hops = hops
+        if hops > 1:
+            if cfg.relu_before or cfg.relu_after or four or general:
+                raise NotImplementedError("hops > 1 is the ACM-SGC chain: model_type 'acmsgc' only")
+            ctx.agg_first = False
         if general:
             if ops.sharded:
                 raise NotImplementedError("general operator pairs are not row-sharded")
@@ -454,7 +479,16 @@ class AcmConvFunction(torch.autograd.Function):
                 spmm_v(x.csr, x.values, wcat, relu=cfg.relu_before, out=z)
             else:
                 gemm(x, wcat, relu=cfg.relu_before, out=z)                          # [n, 3F] view
-            zg = _gather_rows(ops, z[:, : 2 * f]) if ops.sharded else z             # gathered [Z_L|Z_H]
+            if hops > 1:
+                t = z[:, :f]
+                for _ in range(hops - 1):
+                    t = _low_product(ops, t)
+                zc = torch.empty(n, 2 * f, dtype=_F32, device=dev)               # [A_low^(k-1) Z_L | Z_H]
+                zc[:, :f] = t
+                zc[:, f:] = z[:, f:2 * f]
+                zg = _gather_rows(ops, zc)
+            else:
+                zg = _gather_rows(ops, z[:, : 2 * f]) if ops.sharded else z         # gathered [Z_L|Z_H]
         if four and general:
             if ops.un is None:
                 raise RuntimeError("structure_info=1 needs adj_low_unnormalized")
@@ -686,6 +720,11 @@ class AcmConvFunction(torch.autograd.Function):
         with _device_ctx(dev), _Timed(f"conv_bwd_spmm/F{f}k{k}"):
             st = lib.acm_conv_bwd_spmm(low_t.handle, C.byref(r), _vp(ws2), ws2.numel() * 4, _stream())
         _lib.check(st, "acm_conv_bwd_spmm")
+        if ctx.hops > 1:                                  # the remaining k-1 transposed hops of the low channel
+            t = dz[:, :f]
+            for _ in range(ctx.hops - 1):
+                t = _low_product(ops, t, transpose=True)
+            dz[:, :f] = t
 
         if ctx.sparse_x is not None:                                          # dWcat = X_csr^T dZ
             xs = ctx.sparse_x

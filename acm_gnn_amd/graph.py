@@ -224,6 +224,9 @@ class FilterOperators:
         # rank can then produce the dropped input of ALL nodes itself and the first layer needs no halo all-gather
         self.x_full = None
         self._pregathered = None
+        # low-pass hops of the ACM-SGC layer: A_low^hops on the low channel as a chain of 1-hop products (the
+        # reference materialises the dense power, ACM-Pytorch/utils.py:631-637); adj_high stays 1-hop
+        self.hops = 1
         # general operator pair (adj_high != I - adj_low, or adj_un != D adj_low - I): see operators_for()
         self.general = False
         self.high = None                                # CsrGraph of adj_high
@@ -323,7 +326,9 @@ def as_implicit(ops):
     if form is None:
         return ops
     pat = CsrGraph.from_csr(form[0], form[1], None, ops.low.n_cols, ops.low.chunk)
-    return FilterOperators(pat, ops.deg, row_scale=form[2].contiguous())
+    out = FilterOperators(pat, ops.deg, row_scale=form[2].contiguous())
+    out.hops = ops.hops
+    return out
 
 
 # --------------------------------------------------------------------------

@@ -105,6 +105,7 @@ def _worker(rank, world, port, cfg, ret):
         n = adj.shape[0]
         ops = DD.make_sharded_operators(low, deg, "cpu", with_structure=bool(cfg["s"]))
         assert ops.sharded and ops.n_local == n // world and ops.implicit == bool(cfg.get("implicit", 1))
+        ops.hops = cfg.get("hops", 1)
         b, e = DD.shard_bounds(n, world, rank)
         torch.manual_seed(0)
         pdrop = cfg.get("dropout", 0.0)
@@ -140,9 +141,12 @@ def _worker(rank, world, port, cfg, ret):
                                  dict(model="acmgcnp", s=1, variant=1, implicit=0),
                                  dict(model="acmgcnp", s=0, variant=0, dropout=0.5),
                                  dict(model="acmgcnp", s=1, variant=0, dropout=0.5, x_full=1),
-                                 dict(model="acmgcn", s=0, variant=1, dropout=0.5, x_full=1)],
+                                 dict(model="acmgcn", s=0, variant=1, dropout=0.5, x_full=1),
+                                 dict(model="acmsgc", s=0, variant=0, hops=3),
+                                 dict(model="acmsgc", s=0, variant=0, hops=2, implicit=0)],
                          ids=["agg+literal", "struct-acmii", "acmii", "struct-agg", "struct-agg-explicit",
-                              "struct-acmii-explicit", "dropout", "dropout-xfull-struct", "dropout-xfull-acmii"])
+                              "struct-acmii-explicit", "dropout", "dropout-xfull-struct", "dropout-xfull-acmii",
+                              "sgc-3hop", "sgc-2hop-explicit"])
 def test_two_rank_row_shard_equals_single_process(cfg, monkeypatch):
     """world_size = 2 over gloo: the sharded forward/backward (halo all-gathers + parameter-gradient
     all-reduce issued by functional.AcmConvFunction) must reproduce the 1-process result."""
@@ -180,6 +184,7 @@ def test_two_rank_row_shard_equals_single_process(cfg, monkeypatch):
     n = adj.shape[0]
     ops = DD.make_sharded_operators(low, deg, "cpu", with_structure=bool(cfg["s"]))
     assert not ops.sharded and not ops.implicit
+    ops.hops = cfg.get("hops", 1)
     torch.manual_seed(0)
     full = GCN(7, 16, 2, 2, n, cfg.get("dropout", 0.0), cfg["model"], cfg["s"], variant=bool(cfg["variant"]),
                attn_layernorm=True)

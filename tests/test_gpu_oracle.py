@@ -203,6 +203,13 @@ def test_explicit_value_form_matches_oracle(model_type, variant, s, ln, f_in, f_
     assert float((a - b).abs().max()) < 2e-5 * max(1.0, float(b.abs().max()))
 
 
+@pytest.mark.parametrize("hops,f_out,implicit", [(3, 5, True), (2, 64, True), (3, 2, False)])
+def test_acmsgc_khop_chain(hops, f_out, implicit, monkeypatch):
+    """ACM-SGC k-hop (BASELINE config 5) as a chain of 1-hop products vs the dense A_low^k of the reference."""
+    from test_host_stack_cpu import _khop_chain_case
+    _khop_chain_case(DEV, hops, f_out, implicit, monkeypatch)
+
+
 def test_aggregate_first_not_used_when_illegal(monkeypatch):
     """ACMII (ReLU between projection and filter) or an input that needs a gradient must take
     the literal path."""

@@ -308,6 +308,64 @@ def _general_case(model_type, variant, s, ln, dev, khop):
             assert float((p.grad.cpu() - params[k].grad).abs().max()) < tol, k
 
 
+def _khop_chain_case(dev, hops, f_out, implicit, monkeypatch):
+    """ACM-SGC with ``ops.hops = k`` (chain of 1-hop products, nothing materialised) == the oracle fed the dense
+    A_low^k the reference builds (ACM-Pytorch/utils.py:631-637), forward and every gradient."""
+    from oracle import acm_oracle as O
+    from acm_gnn_amd import GraphConvolution
+    from acm_gnn_amd.graph import clear_cache, operators_for
+    monkeypatch.setenv("ACM_IMPLICIT", "1" if implicit else "0")
+    clear_cache()
+    low, high, un, g = graph_tensors("geometric")
+    n = low.shape[0]
+    low_k = O.khop_low(low.to_dense(), hops).to_sparse()
+    torch.manual_seed(2)
+    layer = GraphConvolution(10, f_out, n, "acmsgc")
+    params = {k: v.detach().cpu().clone().requires_grad_(True) for k, v in layer.named_parameters()}
+    gen = torch.Generator().manual_seed(3)
+    x, gout = torch.randn(n, 10, generator=gen), torch.randn(n, f_out, generator=gen)
+    xr = x.clone().requires_grad_(True)
+    ref = O.layer_forward(params, xr, low_k, high, None, model_type="acmsgc", variant=0, structure_info=0,
+                          attn_layernorm=False)
+    ref.backward(gout)
+    layer = layer.to(dev)
+    ops = operators_for(low.to(dev), high.to(dev), None)
+    assert ops.implicit == implicit and not ops.general
+    ops.hops = hops
+    xd = x.to(dev).requires_grad_(True)
+    out = layer(xd, ops)
+    out.backward(gout.to(dev))
+    ops.hops = 1
+    torch.testing.assert_close(out.detach().cpu(), ref.detach(), rtol=1e-4, atol=2e-5)
+    torch.testing.assert_close(xd.grad.cpu(), xr.grad, rtol=1e-3, atol=5e-5)
+    for k, p in layer.named_parameters():
+        if params[k].grad is None:
+            assert p.grad is None, k
+        else:
+            tol = 1e-4 * max(1.0, float(params[k].grad.abs().max()))
+            assert float((p.grad.cpu() - params[k].grad).abs().max()) < tol, k
+
+
+@pytest.mark.parametrize("hops,f_out,implicit", [(3, 5, True), (2, 16, True), (3, 5, False)])
+def test_acmsgc_khop_chain_host_path(hops, f_out, implicit, monkeypatch):
+    fake_lib.install(monkeypatch)
+    _khop_chain_case("cpu", hops, f_out, implicit, monkeypatch)
+
+
+def test_khop_is_refused_where_it_is_not_defined(monkeypatch):
+    fake_lib.install(monkeypatch)
+    from acm_gnn_amd import GraphConvolution
+    from acm_gnn_amd.graph import operators_for
+    low, high, un, _ = graph_tensors("geometric")
+    ops = operators_for(low, high, None)
+    ops.hops = 2
+    try:
+        with pytest.raises(NotImplementedError, match="ACM-SGC chain"):
+            GraphConvolution(10, 16, low.shape[0], "acmgcn")(torch.randn(low.shape[0], 10), ops)
+    finally:
+        ops.hops = 1
+
+
 @pytest.mark.parametrize("model_type,variant,s,ln,khop", [("acmsgc", 0, 0, False, 3), ("acmgcnp", 1, 1, True, 2),
                                                           ("acmgcn", 0, 0, False, 2)])
 def test_general_operator_pair_host_path(model_type, variant, s, ln, khop, monkeypatch):
