@@ -19,11 +19,33 @@ import torch
 from . import _lib
 
 
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+
+
 def _stream():
+    """hipStream_t of torch's current stream on the current device (the raw getter is ~10x cheaper than building a
+    torch.cuda.Stream object; it is what torch's own extensions use)."""
+    if _raw_stream is not None:
+        return C.c_void_p(_raw_stream(torch.cuda.current_device()))
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
+class _NoSwitch:
+    def __enter__(self):
+        return None
+
+    def __exit__(self, *a):
+        return False
+
+
+_NO_SWITCH = _NoSwitch()
+
+
 def _device_ctx(dev):
+    """Make ``dev`` current for the launch; free when it already is (one process per GPU: always)."""
+    idx = dev.index if isinstance(dev, torch.device) else torch.device(dev).index
+    if idx is None or idx == torch.cuda.current_device():
+        return _NO_SWITCH
     return torch.cuda.device(dev)
 
 

@@ -32,6 +32,11 @@ class _FusedAdamBase(torch.optim.Optimizer):
         # optional device int64 counter incremented by the last launch of every step() (the DropoutState.step
         # of the model being trained: acm_adam_config_t.also_advance)
         self.also_advance = None
+        self._tables = {}
+
+    def load_state_dict(self, state_dict):
+        super().load_state_dict(state_dict)
+        self._tables = {}                     # the cached pointer tables refer to the replaced state tensors
 
     @torch.no_grad()
     def step(self, closure=None):
@@ -45,33 +50,47 @@ class _FusedAdamBase(torch.optim.Optimizer):
         if not groups and self.also_advance is not None:
             self.also_advance.add_(1)
         for gi, (group, live) in enumerate(groups):
-            entries = (_lib.AdamTensor * len(live))()
+            # the table of (param, moments, step) pointers is cached per set of live parameters: only the gradient
+            # pointers change from step to step (the host side of an eager step is what bounds it)
+            key = tuple(id(p) for p in live)
+            cached = self._tables.get(gi)
+            if cached is None or cached[0] != key:
+                entries = (_lib.AdamTensor * len(live))()
+                for e, p in zip(entries, live):
+                    _require_cuda(p, "parameter")
+                    if p.dtype != torch.float32 or not p.is_contiguous():
+                        raise TypeError("FusedAdam: parameters must be contiguous fp32")
+                    st = self.state[p]
+                    if len(st) == 0:
+                        st["step"] = torch.zeros((), dtype=torch.float32, device=p.device)
+                        st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                        st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                    e.param = p.data_ptr()
+                    e.exp_avg, e.exp_avg_sq, e.step = st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr(), st["step"].data_ptr()
+                    e.numel = p.numel()
+                dev = live[0].device
+                if any(p.device != dev for p in live):
+                    raise RuntimeError("FusedAdam: one param group must live on one device")
+                cached = (key, entries, [(p, self.state[p]) for p in live], dev)
+                self._tables[gi] = cached
+            _, entries, pairs, dev = cached
             keep = []
-            for e, p in zip(entries, live):
-                _require_cuda(p, "parameter")
+            for e, (p, st) in zip(entries, pairs):
                 g = p.grad
-                if g.is_sparse:
-                    raise RuntimeError("FusedAdam does not support sparse gradients")
-                if p.dtype != torch.float32 or not p.is_contiguous():
-                    raise TypeError("FusedAdam: parameters must be contiguous fp32")
-                if g.dtype != torch.float32 or not g.is_contiguous():
+                if g.dtype != torch.float32 or not g.is_contiguous() or g.is_sparse:
+                    if g.is_sparse:
+                        raise RuntimeError("FusedAdam does not support sparse gradients")
                     g = g.to(torch.float32).contiguous()
                     keep.append(g)
-                st = self.state[p]
-                if len(st) == 0:
-                    st["step"] = torch.zeros((), dtype=torch.float32, device=p.device)
-                    st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
-                    st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
-                e.param, e.grad = p.data_ptr(), g.data_ptr()
-                e.exp_avg, e.exp_avg_sq, e.step = st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr(), st["step"].data_ptr()
-                e.numel = p.numel()
+                e.grad = g.data_ptr()
+                # load_state_dict / .to() may have replaced the tensors behind the cached pointers
+                if e.param != p.data_ptr() or e.exp_avg != st["exp_avg"].data_ptr():
+                    e.param, e.exp_avg = p.data_ptr(), st["exp_avg"].data_ptr()
+                    e.exp_avg_sq, e.step = st["exp_avg_sq"].data_ptr(), st["step"].data_ptr()
             cfg = _lib.AdamConfig(float(group["lr"]), float(group["betas"][0]), float(group["betas"][1]),
                                   float(group["eps"]), float(group["weight_decay"]), int(self._decoupled),
                                   self.also_advance.data_ptr() if (self.also_advance is not None and
                                                                    gi == len(groups) - 1) else None)
-            dev = live[0].device
-            if any(p.device != dev for p in live):
-                raise RuntimeError("FusedAdam: one param group must live on one device")
             with _device_ctx(dev):
                 status = lib.acm_adam_step(len(live), C.cast(entries, C.c_void_p), C.byref(cfg), _stream())
             _lib.check(status, "acm_adam_step")

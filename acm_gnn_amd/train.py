@@ -53,7 +53,8 @@ class TrainStep:
             self._capture()
 
     def _eager(self):
-        self.model.train()
+        if not self.model.training:
+            self.model.train()
         self.opt.zero_grad(set_to_none=True)
         out = self.model(self.x, self.adj, self.adj_high, self.adj_un)
         loss, dz = AF.nll_loss_and_grad(out, self.labels, self.weights)   # = masked_nll(...).backward(), two launches less

@@ -16,7 +16,7 @@ low, deg = D.build_filters(adj)
 ops = DD.make_sharded_operators(low, deg, dev)
 x, y = torch.from_numpy(x_np).to(dev), torch.from_numpy(y_np).to(dev)
 model = acm_gnn_amd.GCN(7, 64, 2, 2, n, 0.1, "acmgcnp", 0, variant=False).to(dev)
-opt = torch.optim.AdamW(model.parameters(), lr=0.05, weight_decay=1e-3)
+opt = acm_gnn_amd.FusedAdamW(model.parameters(), lr=0.05, weight_decay=1e-3)
 w = T.row_weights(torch.from_numpy(tr).to(dev), n)
 step = T.TrainStep(model, opt, x, ops, y, w)
 for _ in range(10):
