@@ -53,6 +53,7 @@ struct acm_csr {
     AcmItem* items;    // device
     int64_t n_items;
     AcmLongRow* long_rows;  // device
+    int32_t* long_index;    // device, n_rows: index into long_rows, or -1 (NULL when there are no long rows)
     int64_t n_long;
     int64_t n_slots;
     int device;
@@ -63,6 +64,7 @@ struct CsrView {
     const AcmItem* items;
     int n_items;
     const AcmLongRow* long_rows;
+    const int32_t* long_index;
     int n_long;
     const int32_t* indices;
     const float* vals;
@@ -73,6 +75,7 @@ static inline CsrView acm_view(const acm_csr* a) {
     v.items = a->items;
     v.n_items = (int)a->n_items;
     v.long_rows = a->long_rows;
+    v.long_index = a->long_index;
     v.n_long = (int)a->n_long;
     v.indices = a->indices;
     v.vals = a->vals;

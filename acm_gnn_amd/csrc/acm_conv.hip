@@ -16,6 +16,10 @@
 // are combined in slot order by a fix-up kernel (deterministic, no float atomics).
 #include "acm_conv_device.h"
 
+int acm_spmm_internal(const acm_csr* a, const void* G, int64_t ldg, int width, float* Y, int64_t ldy,
+                      const acm_spmm_opts_t* o, void* workspace, size_t workspace_bytes, acm_stream_t stream,
+                      bool defer_fixup);
+
 // ------------------------------------------------------------------ epilogues
 // Layouts A and B give every column exactly one owning lane; layout C replicates the row in
 // every lane of the group, so only the group leader stores.
@@ -145,11 +149,41 @@ struct EpiRaw {
 };
 
 template <int FP, int NG>
-__global__ __launch_bounds__(256) void conv_fwd_rows_kernel(acm_conv_fwd_t p, int n_rows) {
-    const int row = blockIdx.x * 256 + threadIdx.x;
-    if (row >= n_rows) return;
+__global__ __launch_bounds__(256) void conv_fwd_rows_kernel(acm_conv_fwd_t p, int n_rows, CsrView csr,
+                                                            const float* __restrict__ partial, int row_blocks) {
     const int F = p.f_out;
     float acc[NG][FP];
+    if ((int)blockIdx.x >= row_blocks) {
+        // tail blocks: the long rows, whose work items left partial sums in the slots -- a 16-lane group per row,
+        // lanes over the slots (slot order within a lane, fixed DPP tree across lanes), then the same head.  This is
+        // the fix-up pass of the gather folded into this launch (the two parts do not depend on each other).
+        const int m = threadIdx.x & 15;
+        const int w = ((int)blockIdx.x - row_blocks) * 16 + (threadIdx.x >> 4);
+        if (w >= csr.n_long) return;
+        const AcmLongRow lr = csr.long_rows[w];
+#pragma unroll
+        for (int c = 0; c < NG; ++c)
+#pragma unroll
+            for (int f = 0; f < FP; ++f) acc[c][f] = 0.f;
+        for (int s = lr.slot_begin + m; s < lr.slot_end; s += 16) {
+            const float* ps = partial + (long)s * (NG * F);
+#pragma unroll
+            for (int c = 0; c < NG; ++c)
+#pragma unroll
+                for (int f = 0; f < FP; ++f)
+                    if (f < F) acc[c][f] += ps[c * F + f];
+        }
+#pragma unroll
+        for (int c = 0; c < NG; ++c)
+#pragma unroll
+            for (int f = 0; f < FP; ++f) acc[c][f] = acm_group_sum<16>(acc[c][f]);
+        const LaySerial<FP> lay{m == 0};
+        EpiFwd::apply<LaySerial<FP>, NG>(p, lr.row, lay, F, acc);
+        return;
+    }
+    const int row = blockIdx.x * 256 + threadIdx.x;
+    if (row >= n_rows) return;
+    if (csr.long_index && csr.long_index[row] >= 0) return;      // done by a tail block
     const float* pr = p.pre + (long)row * p.ld_pre;
 #pragma unroll
     for (int c = 0; c < NG; ++c)
@@ -559,7 +593,7 @@ namespace {
 template <int NG, class Epi>
 int launch_gather(const acm_csr* a, const GatherSrc& g, int F, const typename Epi::Args& ea,
                   void* workspace, size_t ws_bytes, hipStream_t st, const char* who,
-                  const float* vals_override = nullptr, bool bf16 = false) {
+                  const float* vals_override = nullptr, bool bf16 = false, bool defer_fixup = false) {
     const size_t need = (size_t)a->n_slots * (size_t)(NG * F) * sizeof(float);
     ACM_REQUIRE(ws_bytes >= need && (need == 0 || workspace), ACM_ENOMEM,
                 "%s: workspace %zu B < required %zu B", who, ws_bytes, need);
@@ -623,6 +657,7 @@ int launch_gather(const acm_csr* a, const GatherSrc& g, int F, const typename Ep
             hipLaunchKernelGGL((spmm_wide_kernel<4, NG, Epi>), dim3(grid), dim3(256), 0, st, v, g, F, ea, partial);
     }
     ACM_CHECK_HIP(hipGetLastError());
+    if (defer_fixup) return ACM_OK;         // the caller's next kernel adds the partial slots of the long rows itself
     if (a->n_long && F <= 8) {
         const int grid = (int)((a->n_long + 15) / 16);
         if (F <= 2)
@@ -676,6 +711,14 @@ extern "C" int acm_cast_bf16(int64_t n_rows, int64_t n_cols, const float* src, i
 
 extern "C" int acm_spmm_ex(const acm_csr_t* a, const void* G, int64_t ldg, int width, float* Y, int64_t ldy,
                            const acm_spmm_opts_t* o, void* workspace, size_t workspace_bytes, acm_stream_t stream) {
+    return acm_spmm_internal(a, G, ldg, width, Y, ldy, o, workspace, workspace_bytes, stream, false);
+}
+
+// defer_fixup: leave the partial sums of the long rows in the workspace slots (width <= 256); the caller's next
+// kernel adds them (acm_conv_agg_fwd's epilogue)
+int acm_spmm_internal(const acm_csr* a, const void* G, int64_t ldg, int width, float* Y, int64_t ldy,
+                      const acm_spmm_opts_t* o, void* workspace, size_t workspace_bytes, acm_stream_t stream,
+                      bool defer_fixup) {
     static const acm_spmm_opts_t none = {nullptr, nullptr, nullptr, 0, nullptr, 0, 0};
     if (!o) o = &none;
     ACM_REQUIRE(a && G && Y, ACM_EINVAL, "acm_spmm: NULL argument");
@@ -688,7 +731,7 @@ extern "C" int acm_spmm_ex(const acm_csr_t* a, const void* G, int64_t ldg, int w
         GatherSrc g = {{reinterpret_cast<const float*>(G) + (o->g_bf16 ? 0 : c0), nullptr, nullptr}, {ldg, 0, 0}};
         EpiPlain::Args ea = {Y + c0, ldy, o->relu, o->sub ? o->sub + c0 : nullptr, o->ld_sub, o->sub_scale, o->row_scale};
         int st = launch_gather<1, EpiPlain>(a, g, wd, ea, workspace, workspace_bytes, (hipStream_t)stream, "acm_spmm",
-                                            o->vals, o->g_bf16 != 0);
+                                            o->vals, o->g_bf16 != 0, defer_fixup && width <= 256);
         if (st != ACM_OK) return st;
     }
     return ACM_OK;
@@ -729,18 +772,23 @@ extern "C" int acm_conv_fwd(const acm_csr_t* a, const acm_conv_fwd_t* p, void* w
         int st;
         if (k == 4) {
             GatherSrc g = {{p->g_low, p->g_high, p->g_struc}, {p->ld_g_low, p->ld_g_high, p->ld_g_struc}};
-            st = launch_gather<3, EpiRaw>(a, g, F, *p, workspace, workspace_bytes, s, "acm_conv_fwd", nullptr, false);
+            st = launch_gather<3, EpiRaw>(a, g, F, *p, workspace, workspace_bytes, s, "acm_conv_fwd", nullptr, false, true);
         } else {
             GatherSrc g = {{p->g_low, p->g_high, nullptr}, {p->ld_g_low, p->ld_g_high, 0}};
-            st = launch_gather<2, EpiRaw>(a, g, F, *p, workspace, workspace_bytes, s, "acm_conv_fwd", nullptr, false);
+            st = launch_gather<2, EpiRaw>(a, g, F, *p, workspace, workspace_bytes, s, "acm_conv_fwd", nullptr, false, true);
         }
         if (st != ACM_OK || a->n_rows == 0) return st;
         const int grid = (int)((a->n_rows + 255) / 256), n = (int)a->n_rows;
         const int FP = F <= 2 ? 2 : (F <= 4 ? 4 : 8);
+        const CsrView cv = acm_view(a);
+        const float* part = (const float*)workspace;
+        const int tail = (int)((a->n_long + 15) / 16);
 #define ACM_ROWS(FPv)                                                                              \
     do {                                                                                           \
-        if (k == 4) hipLaunchKernelGGL((conv_fwd_rows_kernel<FPv, 3>), dim3(grid), dim3(256), 0, s, *p, n); \
-        else hipLaunchKernelGGL((conv_fwd_rows_kernel<FPv, 2>), dim3(grid), dim3(256), 0, s, *p, n);        \
+        if (k == 4)                                                                                                   \
+            hipLaunchKernelGGL((conv_fwd_rows_kernel<FPv, 3>), dim3(grid + tail), dim3(256), 0, s, *p, n, cv, part, grid); \
+        else                                                                                                          \
+            hipLaunchKernelGGL((conv_fwd_rows_kernel<FPv, 2>), dim3(grid + tail), dim3(256), 0, s, *p, n, cv, part, grid); \
     } while (0)
         if (FP == 2) ACM_ROWS(2);
         else if (FP == 4) ACM_ROWS(4);

@@ -12,6 +12,11 @@
 // deterministically (wave -> LDS -> per-block partial -> tree reduce).
 #include "acm_conv_device.h"
 
+// defined in acm_conv.hip
+int acm_spmm_internal(const acm_csr* a, const void* G, int64_t ldg, int width, float* Y, int64_t ldy,
+                      const acm_spmm_opts_t* o, void* workspace, size_t workspace_bytes, acm_stream_t stream,
+                      bool defer_fixup);
+
 namespace {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -52,8 +57,9 @@ template <int FP>
 __device__ __forceinline__ void project(const float* wlds, float* scratch, int m, const float* __restrict__ prow,
                                         const float* __restrict__ xrow, bool active, float (&p0)[4], float (&p1)[4],
                                         float (&zi)[4]) {
-    // lanes 0 .. FP/4-1 of the group fetch P, the next FP/4 fetch x (16-byte pieces)
-    if (m < FP / 2) {
+    // lanes 0 .. FP/4-1 of the group fetch P, the next FP/4 fetch x (16-byte pieces); prow == nullptr: P is
+    // already in the scratch (a long row whose partial sums were added by the caller)
+    if (m < FP / 2 && (prow || m >= FP / 4)) {
         const float* src = (m < FP / 4) ? prow + 4 * m : xrow + 4 * (m - FP / 4);
         const float4 v = active ? *reinterpret_cast<const float4*>(src) : make_float4(0.f, 0.f, 0.f, 0.f);
         *reinterpret_cast<float4*>(scratch + 4 * m) = v;
@@ -79,12 +85,42 @@ __device__ __forceinline__ void project(const float* wlds, float* scratch, int m
 // P (uniform in the 16-lane group) -> projections -> head -> out / att for one row.
 template <int FP, int K>
 __device__ __forceinline__ void agg_fwd_row(const acm_conv_agg_fwd_t& p, const float* wlds, const float* hlds,
-                                            float* scratch, const float* mixm, int row, int lane) {
+                                            float* scratch, const float* mixm, int row, int lane, const CsrView& csr,
+                                            const float* __restrict__ partial) {
     const int F = p.f_out, m = lane & 15;
     float H[K][4];
     {
+        // A long row's work items left partial sums of P in the slots: the 16 lanes of the group add them here (slot
+        // order within a lane, fixed DPP tree across lanes) instead of a separate fix-up launch after the gather.
+        const float* prow = p.agg + (long)row * p.ld_agg;
+        if (K == 3 && partial) {
+            const int li = csr.long_index[row];                  // uniform in the group
+            if (li >= 0) {
+                const AcmLongRow lr = csr.long_rows[li];
+                float a[FP];
+#pragma unroll
+                for (int f = 0; f < FP; ++f) a[f] = 0.f;
+                for (int s = lr.slot_begin + m; s < lr.slot_end; s += 16) {
+                    float v[FP];
+                    load_vec<FP>(partial + (long)s * FP, v);
+#pragma unroll
+                    for (int f = 0; f < FP; ++f) a[f] += v[f];
+                }
+                const float rs = p.row_scale ? p.row_scale[row] : 1.f;
+#pragma unroll
+                for (int f = 0; f < FP; ++f) a[f] = rs * acm_group_sum<16>(a[f]);
+                if (m == 0) {
+#pragma unroll
+                    for (int f = 0; f < FP; ++f) {
+                        scratch[f] = a[f];
+                        p.agg[(long)row * p.ld_agg + f] = a[f];      // saved for the backward
+                    }
+                }
+                prow = nullptr;
+            }
+        }
         float p0[4], p1[4], zi[4];
-        project<FP>(wlds, scratch, m, p.agg + (long)row * p.ld_agg, p.xs + (long)row * p.ld_xs, true, p0, p1, zi);
+        project<FP>(wlds, scratch, m, prow, p.xs + (long)row * p.ld_xs, true, p0, p1, zi);
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const bool ok = m + 16 * i < F;
@@ -129,7 +165,8 @@ __device__ __forceinline__ void agg_fwd_row(const acm_conv_agg_fwd_t& p, const f
 // fused version held the epilogue's 156 VGPRs during the gather and ran at 3 waves/SIMD), (2) this
 // streaming row-local kernel: 4 rows per wave, 16 lanes x 4 columns each.
 template <int FP, int K>
-__global__ __launch_bounds__(256) void agg_epilogue_kernel(acm_conv_agg_fwd_t p, int n_rows) {
+__global__ __launch_bounds__(256) void agg_epilogue_kernel(acm_conv_agg_fwd_t p, int n_rows, CsrView csr,
+                                                           const float* __restrict__ partial) {
     __shared__ __attribute__((aligned(16))) float wlds[3 * FP * 64 + 3 * K * 64 + 16 * 2 * FP];
     float* hlds = wlds + 3 * FP * 64;
     float* scratch = hlds + 3 * K * 64 + (threadIdx.x >> 4) * 2 * FP;      // this 16-lane group's P | x
@@ -141,7 +178,7 @@ __global__ __launch_bounds__(256) void agg_epilogue_kernel(acm_conv_agg_fwd_t p,
     for (int q = 0; q < K * K; ++q) mixm[q] = p.att_mix[q];
     const int lane = threadIdx.x & 63;
     for (int row = blockIdx.x * 16 + (threadIdx.x >> 4); row < n_rows; row += gridDim.x * 16)
-        agg_fwd_row<FP, K>(p, wlds, hlds, scratch, mixm, row, lane);
+        agg_fwd_row<FP, K>(p, wlds, hlds, scratch, mixm, row, lane, csr, partial);
 }
 
 // ---------------------------------------------------------------- backward
@@ -355,7 +392,10 @@ extern "C" int acm_conv_agg_fwd(const acm_csr_t* a, const acm_conv_agg_fwd_t* p,
     hipStream_t s = (hipStream_t)stream;
     // (1) P = A_low X  -> p->agg  (also the tensor saved for the backward); row_scale for a pattern-only a_low
     acm_spmm_opts_t o = {nullptr, p->row_scale, nullptr, 0, nullptr, 0, 0};
-    st = acm_spmm_ex(a, p->xg, p->ld_xg, p->f_pad, p->agg, p->ld_agg, &o, workspace, workspace_bytes, stream);
+    // three channels: the long rows' partial sums stay in the workspace and the epilogue kernel adds them (one launch
+    // less); with the structure channel the second gather reuses the workspace, so the fix-up runs right away
+    const bool defer = p->n_channels == 3 && a->n_long > 0 && a->long_index != nullptr;
+    st = acm_spmm_internal(a, p->xg, p->ld_xg, p->f_pad, p->agg, p->ld_agg, &o, workspace, workspace_bytes, stream, defer);
     if (st != ACM_OK) return st;
     // (1b) structure channel: PS = A_low S -> p->ps (F wide; bf16 operand optional)
     if (p->n_channels == 4) {
@@ -367,12 +407,15 @@ extern "C" int acm_conv_agg_fwd(const acm_csr_t* a, const acm_conv_agg_fwd_t* p,
     // (2) projections + head, row-local
     int grid = (int)((a->n_rows + 15) / 16);
     if (grid > 2048) grid = 2048;
+    const CsrView cv = acm_view(a);
 #define ACM_EPI(FPv)                                                                                           \
     do {                                                                                                       \
         if (p->n_channels == 3)                                                                                \
-            hipLaunchKernelGGL((agg_epilogue_kernel<FPv, 3>), dim3(grid), dim3(256), 0, s, *p, (int)a->n_rows); \
+            hipLaunchKernelGGL((agg_epilogue_kernel<FPv, 3>), dim3(grid), dim3(256), 0, s, *p, (int)a->n_rows, cv, \
+                               defer ? (const float*)workspace : nullptr);                                     \
         else                                                                                                   \
-            hipLaunchKernelGGL((agg_epilogue_kernel<FPv, 4>), dim3(grid), dim3(256), 0, s, *p, (int)a->n_rows); \
+            hipLaunchKernelGGL((agg_epilogue_kernel<FPv, 4>), dim3(grid), dim3(256), 0, s, *p, (int)a->n_rows, cv, \
+                               (const float*)nullptr);                                                         \
     } while (0)
     if (p->f_pad == 4) ACM_EPI(4);
     else if (p->f_pad == 8) ACM_EPI(8);

@@ -29,6 +29,7 @@ void free_handle(acm_csr* a) {
     if (a->indptr) (void)hipFree(a->indptr);
     if (a->indices) (void)hipFree(a->indices);
     if (a->vals) (void)hipFree(a->vals);
+    if (a->long_index) (void)hipFree(a->long_index);
     if (a->src_pos) (void)hipFree(a->src_pos);
     if (a->items) (void)hipFree(a->items);
     if (a->long_rows) (void)hipFree(a->long_rows);
@@ -82,6 +83,11 @@ int finish_handle(acm_csr* a, const std::vector<int32_t>& h_indptr, int chunk) {
         ACM_CHECK_HIP(hipMalloc((void**)&a->long_rows, longs.size() * sizeof(AcmLongRow)));
         ACM_CHECK_HIP(hipMemcpy(a->long_rows, longs.data(), longs.size() * sizeof(AcmLongRow),
                                 hipMemcpyHostToDevice));
+        // row -> long-row record, for consumers that fold the fix-up of a long row into their own pass
+        std::vector<int32_t> index((size_t)a->n_rows, -1);
+        for (size_t i = 0; i < longs.size(); ++i) index[(size_t)longs[i].row] = (int32_t)i;
+        ACM_CHECK_HIP(hipMalloc((void**)&a->long_index, index.size() * sizeof(int32_t)));
+        ACM_CHECK_HIP(hipMemcpy(a->long_index, index.data(), index.size() * sizeof(int32_t), hipMemcpyHostToDevice));
     }
     return ACM_OK;
 }
