@@ -322,9 +322,9 @@ __global__ __launch_bounds__(256) void spmm_wide_kernel(CsrView csr, GatherSrc g
 // half-waves walk alternate neighbours, so one dword load per lane fetches 2 neighbours x 128 B per channel --
 // half the bytes AND half the load instructions of the fp32 path (2-byte per-lane loads were slower than fp32:
 // 804 -> 1290 us).  The halves are combined with v_permlane32_swap, then the epilogue runs in LayPair32.
-template <int NG, class Epi>
-__global__ __launch_bounds__(256) void spmm_pair_bf16_kernel(CsrView csr, GatherSrc g, int F, typename Epi::Args ea,
-                                                             float* __restrict__ partial) {
+template <int NG, class Epi, bool BF16>
+__global__ __launch_bounds__(256) void spmm_pair_kernel(CsrView csr, GatherSrc g, int F, typename Epi::Args ea,
+                                                        float* __restrict__ partial) {
     const int lane = threadIdx.x & 63, half = lane >> 5, l32 = lane & 31;
     const int w = acm_uniform(blockIdx.x * 4 + (threadIdx.x >> 6));
     if (w >= csr.n_items) return;
@@ -346,7 +346,8 @@ __global__ __launch_bounds__(256) void spmm_pair_bf16_kernel(CsrView csr, Gather
         }
         const int cnt = min(64, end - base);
         for (int t = 0; t < cnt; t += 2 * UNR) {
-            unsigned zz[UNR][NG];
+            unsigned zz[UNR][NG];      // bf16: one packed pair
+            float2 zf[UNR][NG];        // fp32: the two adjacent columns
             float a[UNR];
             bool ok[UNR];
 #pragma unroll
@@ -361,16 +362,22 @@ __global__ __launch_bounds__(256) void spmm_pair_bf16_kernel(CsrView csr, Gather
                 ok[u] = (half ? have1 : have0) && col_ok;
 #pragma unroll
                 for (int c = 0; c < NG; ++c) {
-                    const unsigned* rowp = reinterpret_cast<const unsigned*>(
-                        reinterpret_cast<const unsigned short*>(g.p[c]) + (long)j * g.ld[c]);
-                    zz[u][c] = rowp[col_ok ? l32 : 0];
+                    if (BF16) {
+                        const unsigned* rowp = reinterpret_cast<const unsigned*>(
+                            reinterpret_cast<const unsigned short*>(g.p[c]) + (long)j * g.ld[c]);
+                        zz[u][c] = rowp[col_ok ? l32 : 0];
+                    } else {
+                        const float2* rowp = reinterpret_cast<const float2*>(g.p[c] + (long)j * g.ld[c]);
+                        zf[u][c] = rowp[col_ok ? l32 : 0];
+                    }
                 }
             }
 #pragma unroll
             for (int u = 0; u < UNR; ++u)
 #pragma unroll
                 for (int c = 0; c < NG; ++c) {
-                    const float lo = __uint_as_float(zz[u][c] << 16), hi = __uint_as_float(zz[u][c] & 0xFFFF0000u);
+                    const float lo = BF16 ? __uint_as_float(zz[u][c] << 16) : zf[u][c].x;
+                    const float hi = BF16 ? __uint_as_float(zz[u][c] & 0xFFFF0000u) : zf[u][c].y;
                     acc[c][0] = ok[u] ? fmaf(a[u], lo, acc[c][0]) : acc[c][0];
                     acc[c][1] = ok[u] ? fmaf(a[u], hi, acc[c][1]) : acc[c][1];
                 }
@@ -647,8 +654,17 @@ int launch_gather(const acm_csr* a, const GatherSrc& g, int F, const typename Ep
     } else {
         ACM_REQUIRE(F <= 256, ACM_EUNSUPPORTED, "%s: F = %d > 256 columns per channel", who, F);
         const int grid = (int)((a->n_items + 3) / 4);
+        // fp32 rows of 34..64 columns whose gathered matrices fit the L2 (Squirrel / Chameleon / Cora sizes): 32 lanes x
+        // float2 cover a row, so the two half-waves take two neighbours per instruction -- the wide kernel spends one
+        // load + one FMA instruction per neighbour on a half-empty wave and is issue-bound there (81 -> 69 us on
+        // Squirrel).  On the 168k-node graph the same gather is bound by the Infinity-Cache fills and the pair form is
+        // 5-10 % slower, so it is not used.
+        bool pair32 = !bf16 && F > 32 && F <= 64 && F % 2 == 0 && (size_t)a->n_cols * F * NG * sizeof(float) <= (8u << 20);
+        for (int c = 0; c < NG && pair32; ++c) pair32 = ((uintptr_t)g.p[c]) % 8 == 0 && g.ld[c] % 2 == 0;
         if (bf16)
-            hipLaunchKernelGGL((spmm_pair_bf16_kernel<NG, Epi>), dim3(grid), dim3(256), 0, st, v, g, F, ea, partial);
+            hipLaunchKernelGGL((spmm_pair_kernel<NG, Epi, true>), dim3(grid), dim3(256), 0, st, v, g, F, ea, partial);
+        else if (pair32)
+            hipLaunchKernelGGL((spmm_pair_kernel<NG, Epi, false>), dim3(grid), dim3(256), 0, st, v, g, F, ea, partial);
         else if (F <= 64)
             hipLaunchKernelGGL((spmm_wide_kernel<1, NG, Epi>), dim3(grid), dim3(256), 0, st, v, g, F, ea, partial);
         else if (F <= 128)
