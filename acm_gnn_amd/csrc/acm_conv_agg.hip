@@ -86,14 +86,14 @@ __device__ __forceinline__ void project(const float* wlds, float* scratch, int m
 template <int FP, int K>
 __device__ __forceinline__ void agg_fwd_row(const acm_conv_agg_fwd_t& p, const float* wlds, const float* hlds,
                                             float* scratch, const float* mixm, int row, int lane, const CsrView& csr,
-                                            const float* __restrict__ partial) {
+                                            const float* __restrict__ partial, bool p_in_scratch = false) {
     const int F = p.f_out, m = lane & 15;
     float H[K][4];
     {
         // A long row's work items left partial sums of P in the slots: the 16 lanes of the group add them here (slot
         // order within a lane, fixed DPP tree across lanes) instead of a separate fix-up launch after the gather.
-        const float* prow = p.agg + (long)row * p.ld_agg;
-        if (K == 3 && partial) {
+        const float* prow = p_in_scratch ? nullptr : p.agg + (long)row * p.ld_agg;
+        if (K == 3 && partial && !p_in_scratch) {
             const int li = csr.long_index[row];                  // uniform in the group
             if (li >= 0) {
                 const AcmLongRow lr = csr.long_rows[li];
@@ -179,6 +179,105 @@ __global__ __launch_bounds__(256) void agg_epilogue_kernel(acm_conv_agg_fwd_t p,
     const int lane = threadIdx.x & 63;
     for (int row = blockIdx.x * 16 + (threadIdx.x >> 4); row < n_rows; row += gridDim.x * 16)
         agg_fwd_row<FP, K>(p, wlds, hlds, scratch, mixm, row, lane, csr, partial);
+}
+
+// The gather and the epilogue in ONE kernel (three channels, f_pad <= 8, 16 lanes per work item): the narrow gather's
+// 16-lane group ends with the aggregated row P replicated in its lanes -- exactly the input layout of agg_fwd_row (16
+// lanes x 4 columns of one row) -- so the projections and the head run right there, on lanes that would otherwise
+// idle through the next item's gather latency.  Same software pipeline over the work list as spmm_narrow_kernel.
+// Work items of long rows write their partial sums to the slots; agg_long_rows_kernel finishes those rows.
+template <int FP>
+__global__ __launch_bounds__(256) void agg_fused_kernel(acm_conv_agg_fwd_t p, CsrView csr, float* __restrict__ partial) {
+    constexpr int K = 3, GS = 16, GPB = 16;
+    __shared__ __attribute__((aligned(16))) float wlds[3 * FP * 64 + 3 * K * 64 + 16 * 2 * FP];
+    float* hlds = wlds + 3 * FP * 64;
+    float* scratch = hlds + 3 * K * 64 + (threadIdx.x >> 4) * 2 * FP;
+    stage_weights<FP>(wlds, p.w_low, p.w_high, p.w_mlp, p.ld_w, p.f_in, p.f_out);
+    stage_head_params<K>(hlds, p.att_vec, p.ln_weight, p.ln_bias, p.layernorm, p.f_out);
+    __syncthreads();
+    float mixm[K * K];
+#pragma unroll
+    for (int q = 0; q < K * K; ++q) mixm[q] = p.att_mix[q];
+    const int gl = threadIdx.x & 15, lane = threadIdx.x & 63;
+    const int G = gridDim.x * GPB;
+    int w = blockIdx.x * GPB + (threadIdx.x >> 4);
+    if (w >= csr.n_items) return;
+    const bool unit = csr.vals == nullptr;
+    AcmItem it = csr.items[w];
+    int k0 = it.begin;
+    bool va = k0 + gl < it.end, vb = k0 + gl + GS < it.end;
+    int ja = va ? csr.indices[k0 + gl] : 0, jb = vb ? csr.indices[k0 + gl + GS] : 0;
+    float aa = va ? (unit ? 1.f : csr.vals[k0 + gl]) : 0.f, ab = vb ? (unit ? 1.f : csr.vals[k0 + gl + GS]) : 0.f;
+    while (true) {
+        const int wn = w + G;
+        const bool has_next = wn < csr.n_items;
+        AcmItem itn = it;
+        if (has_next) itn = csr.items[wn];
+        float acc[FP];
+#pragma unroll
+        for (int f = 0; f < FP; ++f) acc[f] = 0.f;
+        while (true) {
+            float za[FP], zb[FP];
+            load_vec<FP>(p.xg + (long)ja * p.ld_xg, za);
+            load_vec<FP>(p.xg + (long)jb * p.ld_xg, zb);
+            const int k1 = k0 + 2 * GS;
+            const bool more = k1 < it.end;
+            const int pb = more ? k1 : itn.begin;
+            const int pe = more ? it.end : (has_next ? itn.end : pb);
+            const bool pva = pb + gl < pe, pvb = pb + gl + GS < pe;
+            const int nja = pva ? csr.indices[pb + gl] : 0, njb = pvb ? csr.indices[pb + gl + GS] : 0;
+            const float naa = pva ? (unit ? 1.f : csr.vals[pb + gl]) : 0.f, nab = pvb ? (unit ? 1.f : csr.vals[pb + gl + GS]) : 0.f;
+#pragma unroll
+            for (int f = 0; f < FP; ++f) {
+                acc[f] = va ? fmaf(aa, za[f], acc[f]) : acc[f];
+                acc[f] = vb ? fmaf(ab, zb[f], acc[f]) : acc[f];
+            }
+            ja = nja, jb = njb, aa = naa, ab = nab, va = pva, vb = pvb;
+            if (!more) break;
+            k0 = k1;
+        }
+#pragma unroll
+        for (int f = 0; f < FP; ++f) acc[f] = acm_group_sum<GS>(acc[f]);
+        if (it.slot < 0) {
+            const float rs = p.row_scale ? p.row_scale[it.row] : 1.f;
+            if (gl == 0) {
+#pragma unroll
+                for (int f = 0; f < FP; ++f) {
+                    const float v = rs * acc[f];
+                    scratch[f] = v;
+                    p.agg[(long)it.row * p.ld_agg + f] = v;          // P = A_low X, saved for the backward
+                }
+            }
+            agg_fwd_row<FP, K>(p, wlds, hlds, scratch, mixm, it.row, lane, csr, nullptr, true);
+        } else if (gl == 0) {
+            float* ps = partial + (long)it.slot * FP;
+#pragma unroll
+            for (int f = 0; f < FP; ++f) ps[f] = acc[f];
+        }
+        if (!has_next) break;
+        it = itn;
+        w = wn;
+        k0 = it.begin;
+    }
+}
+
+// the long rows of the fused form: partial slots -> P -> projections -> head
+template <int FP>
+__global__ __launch_bounds__(256) void agg_long_rows_kernel(acm_conv_agg_fwd_t p, CsrView csr,
+                                                            const float* __restrict__ partial) {
+    constexpr int K = 3;
+    __shared__ __attribute__((aligned(16))) float wlds[3 * FP * 64 + 3 * K * 64 + 16 * 2 * FP];
+    float* hlds = wlds + 3 * FP * 64;
+    float* scratch = hlds + 3 * K * 64 + (threadIdx.x >> 4) * 2 * FP;
+    stage_weights<FP>(wlds, p.w_low, p.w_high, p.w_mlp, p.ld_w, p.f_in, p.f_out);
+    stage_head_params<K>(hlds, p.att_vec, p.ln_weight, p.ln_bias, p.layernorm, p.f_out);
+    __syncthreads();
+    float mixm[K * K];
+#pragma unroll
+    for (int q = 0; q < K * K; ++q) mixm[q] = p.att_mix[q];
+    const int lane = threadIdx.x & 63;
+    for (int i = blockIdx.x * 16 + (threadIdx.x >> 4); i < csr.n_long; i += gridDim.x * 16)
+        agg_fwd_row<FP, K>(p, wlds, hlds, scratch, mixm, csr.long_rows[i].row, lane, csr, partial);
 }
 
 // ---------------------------------------------------------------- backward
@@ -390,6 +489,34 @@ extern "C" int acm_conv_agg_fwd(const acm_csr_t* a, const acm_conv_agg_fwd_t* p,
                 "acm_conv_agg_fwd: xg / agg rows must be 16-byte aligned and f_pad long");
     if (a->n_rows == 0) return ACM_OK;
     hipStream_t s = (hipStream_t)stream;
+    // (0) fused form: gather + epilogue in one kernel, plus a small one for the long rows
+    {
+        const double avg = (double)a->nnz / (double)(a->n_rows > 0 ? a->n_rows : 1);
+        static const bool fused_off = getenv("ACM_AGG_UNFUSED") != nullptr;
+        const bool fused = !fused_off && p->n_channels == 3 && p->f_pad <= 8 && avg > 12.0 && avg <= 160.0 &&
+                           ((uintptr_t)p->xg) % 16 == 0 && (p->ld_xg * sizeof(float)) % 16 == 0 &&
+                           (a->n_long == 0 || a->long_index != nullptr);
+        if (fused) {
+            const size_t need = (size_t)a->n_slots * (size_t)p->f_pad * sizeof(float);
+            ACM_REQUIRE(workspace_bytes >= need && (need == 0 || workspace), ACM_ENOMEM,
+                        "acm_conv_agg_fwd: workspace %zu B < required %zu B", workspace_bytes, need);
+            const CsrView cv = acm_view(a);
+            float* partial = (float*)workspace;
+            int grid = (int)((a->n_items + 15) / 16);
+            if (grid > 8192) grid = 8192;
+            int tail = (int)((a->n_long + 15) / 16);
+            if (tail > 1024) tail = 1024;
+            if (p->f_pad == 4) {
+                hipLaunchKernelGGL((agg_fused_kernel<4>), dim3(grid), dim3(256), 0, s, *p, cv, partial);
+                if (tail) hipLaunchKernelGGL((agg_long_rows_kernel<4>), dim3(tail), dim3(256), 0, s, *p, cv, partial);
+            } else {
+                hipLaunchKernelGGL((agg_fused_kernel<8>), dim3(grid), dim3(256), 0, s, *p, cv, partial);
+                if (tail) hipLaunchKernelGGL((agg_long_rows_kernel<8>), dim3(tail), dim3(256), 0, s, *p, cv, partial);
+            }
+            ACM_CHECK_HIP(hipGetLastError());
+            return ACM_OK;
+        }
+    }
     // (1) P = A_low X  -> p->agg  (also the tensor saved for the backward); row_scale for a pattern-only a_low
     acm_spmm_opts_t o = {nullptr, p->row_scale, nullptr, 0, nullptr, 0, 0};
     // three channels: the long rows' partial sums stay in the workspace and the epilogue kernel adds them (one launch
