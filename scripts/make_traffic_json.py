@@ -12,15 +12,12 @@ import sys
 
 # bench label -> substrings identifying its kernels in the profiler's names
 LABELS = {
-    "conv_agg_fwd/F64k3i7": ["spmm_narrow_kernel<8, 1, 32, false, EpiPlain>", "spmm_fixup_narrow_kernel<8, 1, EpiPlain>",
-                             "agg_epilogue_kernel<8, 3>"],
+    "conv_agg_fwd/F64k3i7": ["agg_fused_kernel<8>", "agg_long_rows_kernel<8>"],
     "conv_agg_bwd/F64k3i7": ["agg_bwd_kernel<8, 3>", "reduce_columns_kernel"],
-    "conv_fwd/F2k3": ["spmm_narrow_kernel<2, 2, 32, true, EpiRaw>", "spmm_fixup_narrow_kernel<2, 2, EpiRaw>",
-                      "conv_fwd_rows_kernel<2, 2>"],
-    "conv_bwd_spmm/F2k3": ["spmm_narrow_kernel<2, 2, 32, true, EpiBwd>", "spmm_fixup_narrow_kernel<2, 2, EpiBwd>"],
+    "conv_fwd/F2k3": ["spmm_narrow_kernel<2, 2, 16, true, EpiRaw>", "conv_fwd_rows_kernel<2, 2>"],
+    "conv_bwd_spmm/F2k3": ["spmm_narrow_kernel<2, 2, 16, true, EpiBwd>", "spmm_fixup_narrow_kernel<2, 2, EpiBwd>"],
     "conv_bwd_local/F2k3": ["conv_bwd_local_kernel<LayPacked<2>, 32, 3>", "conv_bwd_reduce_kernel"],
-    "gemm_TN/64x6x168114": ["gemm_kernel<4, 1, 4, 1, true, false>", "splitk_reduce_kernel"],
-    "gemm_NT/168114x64x6": ["gemm_kernel<2, 2, 2, 2, false, true>"],
+    "proj_bwd/168114x64x6": ["proj_bwd_kernel<6>", "proj_reduce_kernel"],
     "gemm_NN/168114x6x64": ["gemm_kernel<4, 1, 4, 1, false, false>"],
 }
 
