@@ -18,6 +18,28 @@ __global__ __launch_bounds__(256) void dropout_kernel(long n_rows, int n_cols, c
     }
 }
 
+// Wide matrices (>= 64 columns): one thread per (row, Philox block) = the four columns c, c + 16, c + 32, c + 48 of a
+// 64-column panel, so every Philox call serves four elements (the per-element form wastes three of its four words).
+__global__ __launch_bounds__(256) void dropout_wide_kernel(long n_rows, int n_cols, const float* __restrict__ src,
+                                                           long ld_src, float* __restrict__ dst, long ld_dst, int dst_cols,
+                                                           acm_dropout_t d) {
+    const AcmDropCtx dc = acm_drop_ctx(d);
+    const int panels = (dst_cols + 63) / 64;
+    const long total = n_rows * panels * 16;
+    for (long q = (long)blockIdx.x * 256 + threadIdx.x; q < total; q += (long)gridDim.x * 256) {
+        const long r = q / (panels * 16);
+        const int b = (int)(q - r * (panels * 16));           // block id: (col & 15) + 16 * (col >> 6)
+        const int c0 = (b & 15) + 64 * (b >> 4);
+        float f[4];
+        acm_drop4(dc, r, b, f);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int c = c0 + 16 * i;
+            if (c < dst_cols) dst[r * ld_dst + c] = c < n_cols ? src[r * ld_src + c] * f[i] : 0.f;
+        }
+    }
+}
+
 }  // namespace
 
 extern "C" int acm_dropout(int64_t n_rows, int64_t n_cols, const float* src, int64_t ld_src, float* dst, int64_t ld_dst,
@@ -29,10 +51,17 @@ extern "C" int acm_dropout(int64_t n_rows, int64_t n_cols, const float* src, int
     ACM_REQUIRE(d->p == 0.f || d->step, ACM_EINVAL, "acm_dropout: step counter is NULL");
     ACM_REQUIRE(n_cols <= 65536, ACM_EUNSUPPORTED, "acm_dropout: more than 65536 columns");
     if (n_rows == 0 || dst_cols == 0) return ACM_OK;
-    long blocks = (n_rows * dst_cols + 255) / 256;
-    if (blocks > 8192) blocks = 8192;
-    hipLaunchKernelGGL(dropout_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (long)n_rows,
-                       (int)n_cols, src, (long)ld_src, dst, (long)ld_dst, (int)dst_cols, *d);
+    if (dst_cols >= 64) {
+        long blocks = (n_rows * ((dst_cols + 63) / 64) * 16 + 255) / 256;
+        if (blocks > 16384) blocks = 16384;
+        hipLaunchKernelGGL(dropout_wide_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (long)n_rows,
+                           (int)n_cols, src, (long)ld_src, dst, (long)ld_dst, (int)dst_cols, *d);
+    } else {
+        long blocks = (n_rows * dst_cols + 255) / 256;
+        if (blocks > 8192) blocks = 8192;
+        hipLaunchKernelGGL(dropout_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (long)n_rows,
+                           (int)n_cols, src, (long)ld_src, dst, (long)ld_dst, (int)dst_cols, *d);
+    }
     ACM_CHECK_HIP(hipGetLastError());
     return ACM_OK;
 }
