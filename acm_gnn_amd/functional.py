@@ -428,6 +428,8 @@ class AcmConvFunction(torch.autograd.Function):
                 st.post_drop = spec
         if n != ops.n_local:
             raise ValueError(f"input has {n} rows but the graph operator has {ops.n_local}")
+        pregathered = getattr(ops, "_pregathered", None)      # one-shot hand-over from the caller (models.GCN)
+        ops._pregathered = None
         f_in = w_low.shape[0]
         ctx.x_width = x.shape[1]
         zero_padded = x.shape[1] != f_in          # dropout(..., pad_to=...) output: extra columns are zero
@@ -457,11 +459,9 @@ class AcmConvFunction(torch.autograd.Function):
                 xpad = x
             else:
                 xpad = torch.nn.functional.pad(x[:, :f_in], (0, fp - f_in))
-            pre = getattr(ops, "_pregathered", None)
-            ops._pregathered = None
-            if (pre is not None and pre[0].data_ptr() == xpad.data_ptr() and pre[1].shape[1] == fp
-                    and pre[1].shape[0] == ops.n_global):
-                xg = pre[1]                           # the caller already holds every node's (dropped) input
+            if (pregathered is not None and pregathered[0].data_ptr() == xpad.data_ptr()
+                    and pregathered[1].shape[1] == fp and pregathered[1].shape[0] == ops.n_global):
+                xg = pregathered[1]                   # the caller already holds every node's (dropped) input
             else:
                 xg = _gather_rows(ops, xpad)
             wl, wh, wm = (_as_f32c(t, "weight") for t in (w_low, w_high, w_mlp))
