@@ -261,6 +261,107 @@ __global__ __launch_bounds__(256) void agg_fused_kernel(acm_conv_agg_fwd_t p, Cs
     }
 }
 
+// f_pad = 8 (32-byte rows): the same kernel with TWO lanes per neighbour, each fetching one 16-byte half of the row.
+// A lane can load at most 16 bytes per instruction, so with one neighbour per lane a row costs two requests from every
+// lane, each to a distinct cache line (128 line look-ups per 64 neighbours); with adjacent lanes on the two halves of
+// one row the address coalescer sees 32 lines per 32 neighbours -- half the look-ups per byte, which is what bounds the
+// gather once the rows hit in L1/L2 (scripts/probe_gather.py: 63 us with every row in L1).
+// Lane (e = gl >> 1, h = gl & 1) of the 16-lane group: neighbours k0 + e + 8 u (u = 0..3), columns 4 h .. 4 h + 3.
+__global__ __launch_bounds__(256) void agg_fused_pair_kernel(acm_conv_agg_fwd_t p, CsrView csr, float* __restrict__ partial) {
+    constexpr int FP = 8, K = 3, GPB = 16, U = 4, STEP = 8 * U;
+    __shared__ __attribute__((aligned(16))) float wlds[3 * FP * 64 + 3 * K * 64 + 16 * 2 * FP];
+    float* hlds = wlds + 3 * FP * 64;
+    float* scratch = hlds + 3 * K * 64 + (threadIdx.x >> 4) * 2 * FP;
+    stage_weights<FP>(wlds, p.w_low, p.w_high, p.w_mlp, p.ld_w, p.f_in, p.f_out);
+    stage_head_params<K>(hlds, p.att_vec, p.ln_weight, p.ln_bias, p.layernorm, p.f_out);
+    __syncthreads();
+    float mixm[K * K];
+#pragma unroll
+    for (int q = 0; q < K * K; ++q) mixm[q] = p.att_mix[q];
+    const int gl = threadIdx.x & 15, lane = threadIdx.x & 63, e = gl >> 1, h = gl & 1;
+    const int G = gridDim.x * GPB;
+    int w = blockIdx.x * GPB + (threadIdx.x >> 4);
+    if (w >= csr.n_items) return;
+    const bool unit = csr.vals == nullptr;
+    const float* xh = p.xg + 4 * h;
+    AcmItem it = csr.items[w];
+    int k0 = it.begin;
+    int j[U];
+    float a[U];
+    bool v[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        const int k = k0 + e + 8 * u;
+        v[u] = k < it.end;
+        j[u] = v[u] ? csr.indices[k] : 0;
+        a[u] = v[u] ? (unit ? 1.f : csr.vals[k]) : 0.f;
+    }
+    while (true) {
+        const int wn = w + G;
+        const bool has_next = wn < csr.n_items;
+        AcmItem itn = it;
+        if (has_next) itn = csr.items[wn];
+        float acc[4] = {0.f, 0.f, 0.f, 0.f};
+        while (true) {
+            float4 z[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) z[u] = *reinterpret_cast<const float4*>(xh + (long)j[u] * p.ld_xg);
+            const int k1 = k0 + STEP;
+            const bool more = k1 < it.end;
+            const int pb = more ? k1 : itn.begin;
+            const int pe = more ? it.end : (has_next ? itn.end : pb);
+            int nj[U];
+            float na[U];
+            bool nv[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int k = pb + e + 8 * u;
+                nv[u] = k < pe;
+                nj[u] = nv[u] ? csr.indices[k] : 0;
+                na[u] = nv[u] ? (unit ? 1.f : csr.vals[k]) : 0.f;
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                acc[0] = v[u] ? fmaf(a[u], z[u].x, acc[0]) : acc[0];
+                acc[1] = v[u] ? fmaf(a[u], z[u].y, acc[1]) : acc[1];
+                acc[2] = v[u] ? fmaf(a[u], z[u].z, acc[2]) : acc[2];
+                acc[3] = v[u] ? fmaf(a[u], z[u].w, acc[3]) : acc[3];
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) j[u] = nj[u], a[u] = na[u], v[u] = nv[u];
+            if (!more) break;
+            k0 = k1;
+        }
+        // sum over the eight lanes of the group with the same half (lanes gl, gl^2, gl+-4, gl+-8): fixed order
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            acc[i] += acm_dpp<0x4E>(acc[i]);     // quad_perm [2,3,0,1]
+            acc[i] += acm_dpp<0x124>(acc[i]);    // row_ror:4
+            acc[i] += acm_dpp<0x128>(acc[i]);    // row_ror:8
+        }
+        if (it.slot < 0) {
+            const float rs = p.row_scale ? p.row_scale[it.row] : 1.f;
+            if (gl < 2) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const float val = rs * acc[i];
+                    scratch[4 * h + i] = val;
+                    p.agg[(long)it.row * p.ld_agg + 4 * h + i] = val;
+                }
+            }
+            agg_fwd_row<FP, K>(p, wlds, hlds, scratch, mixm, it.row, lane, csr, nullptr, true);
+        } else if (gl < 2) {
+            float* ps = partial + (long)it.slot * FP + 4 * h;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) ps[i] = acc[i];
+        }
+        if (!has_next) break;
+        it = itn;
+        w = wn;
+        k0 = it.begin;
+    }
+}
+
 // the long rows of the fused form: partial slots -> P -> projections -> head
 template <int FP>
 __global__ __launch_bounds__(256) void agg_long_rows_kernel(acm_conv_agg_fwd_t p, CsrView csr,
@@ -510,7 +611,11 @@ extern "C" int acm_conv_agg_fwd(const acm_csr_t* a, const acm_conv_agg_fwd_t* p,
                 hipLaunchKernelGGL((agg_fused_kernel<4>), dim3(grid), dim3(256), 0, s, *p, cv, partial);
                 if (tail) hipLaunchKernelGGL((agg_long_rows_kernel<4>), dim3(tail), dim3(256), 0, s, *p, cv, partial);
             } else {
-                hipLaunchKernelGGL((agg_fused_kernel<8>), dim3(grid), dim3(256), 0, s, *p, cv, partial);
+                static const bool pair_lanes = getenv("ACM_AGG_NO_PAIR") == nullptr;
+                if (pair_lanes)
+                    hipLaunchKernelGGL(agg_fused_pair_kernel, dim3(grid), dim3(256), 0, s, *p, cv, partial);
+                else
+                    hipLaunchKernelGGL((agg_fused_kernel<8>), dim3(grid), dim3(256), 0, s, *p, cv, partial);
                 if (tail) hipLaunchKernelGGL((agg_long_rows_kernel<8>), dim3(tail), dim3(256), 0, s, *p, cv, partial);
             }
             ACM_CHECK_HIP(hipGetLastError());
