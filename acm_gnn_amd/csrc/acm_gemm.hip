@@ -61,7 +61,8 @@ template <int WM, int WN, int WAVES_M, int WAVES_N, bool TA, bool TB>
 __global__ __launch_bounds__(256) void gemm_kernel(int M, int N, int K, const float* __restrict__ A, long lda,
                                                    const float* __restrict__ B, long ldb,
                                                    float* __restrict__ C, long ldc, int relu, int k_per_split,
-                                                   float* __restrict__ slabs, int cb, long cbs) {
+                                                   float* __restrict__ slabs, int cb, long cbs, int split,
+                                                   float* __restrict__ C2, long ldc2) {
     constexpr int BM = 16 * WM * WAVES_M, BN = 16 * WN * WAVES_N;
     constexpr bool A_KMAJOR = !TA, B_KMAJOR = TB;
     using LA = TileLds<A_KMAJOR, BM>;
@@ -133,7 +134,9 @@ __global__ __launch_bounds__(256) void gemm_kernel(int M, int N, int K, const fl
                 if (row < M && col < N) {
                     float v = acc[i][j][r];
                     if (relu && !slabs) v = fmaxf(v, 0.f);
-                    if (cb && !slabs) dst[(long)(col / cb) * cbs + (long)row * ldd + (col % cb)] = v;   // column-block output
+                    if (slabs) dst[(long)row * ldd + col] = v;
+                    else if (cb) dst[(long)(col / cb) * cbs + (long)row * ldd + (col % cb)] = v;   // column-block output
+                    else if (split && col >= split) C2[(long)row * ldc2 + (col - split)] = v;       // two-matrix output
                     else dst[(long)row * ldd + col] = v;
                 }
             }
@@ -143,7 +146,8 @@ __global__ __launch_bounds__(256) void gemm_kernel(int M, int N, int K, const fl
 // slab (coalesced 64 B segments across q), then the 16 split-lanes combine in a fixed LDS tree.
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(int M, int N, int splits,
                                                             const float* __restrict__ slabs,
-                                                            float* __restrict__ C, long ldc, int relu, int cb, long cbs) {
+                                                            float* __restrict__ C, long ldc, int relu, int cb, long cbs,
+                                                            int split, float* __restrict__ C2, long ldc2) {
     __shared__ float red[16][17];
     const long total = (long)M * N;
     const int tq = threadIdx.x & 15, tz = threadIdx.x >> 4;
@@ -172,6 +176,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(int M, int N, int sp
         const long m = q / N;
         const int n = (int)(q % N);
         if (cb) C[(long)(n / cb) * cbs + m * ldc + (n % cb)] = t;
+        else if (split && n >= split) C2[m * ldc2 + (n - split)] = t;
         else C[m * ldc + n] = t;
     }
 }
@@ -216,10 +221,11 @@ GemmPlan plan_gemm(int64_t M, int64_t N, int64_t K) {
 
 template <int WM, int WN, int WVM, int WVN>
 void launch_shape(int ta, int tb, const GemmPlan& p, hipStream_t st, int M, int N, int K, const float* A,
-                  long lda, const float* B, long ldb, float* C, long ldc, int relu, float* slabs, int cb, long cbs) {
+                  long lda, const float* B, long ldb, float* C, long ldc, int relu, float* slabs, int cb, long cbs,
+                  int split, float* C2, long ldc2) {
 #define ACM_GEMM_LAUNCH(TAv, TBv)                                                                        \
     hipLaunchKernelGGL((gemm_kernel<WM, WN, WVM, WVN, TAv, TBv>), p.grid, dim3(256), 0, st, M, N, K, A, \
-                       lda, B, ldb, C, ldc, relu, p.k_per_split, slabs, cb, cbs)
+                       lda, B, ldb, C, ldc, relu, p.k_per_split, slabs, cb, cbs, split, C2, ldc2)
     if (!ta && !tb) ACM_GEMM_LAUNCH(false, false);
     else if (ta && !tb) ACM_GEMM_LAUNCH(true, false);
     else if (!ta && tb) ACM_GEMM_LAUNCH(false, true);
@@ -246,10 +252,31 @@ extern "C" int acm_gemm(int transA, int transB, int64_t M, int64_t N, int64_t K,
     return acm_gemm_blocks(transA, transB, M, N, K, A, lda, B, ldb, C, ldc, 0, 0, relu, workspace, workspace_bytes, stream);
 }
 
+static int gemm_core(int transA, int transB, int64_t M, int64_t N, int64_t K, const float* A, int64_t lda, const float* B,
+                     int64_t ldb, float* C, int64_t ldc, int64_t c_col_block, int64_t c_block_stride, int64_t split_col,
+                     float* C2, int64_t ldc2, int relu, void* workspace, size_t workspace_bytes, acm_stream_t stream);
+
 extern "C" int acm_gemm_blocks(int transA, int transB, int64_t M, int64_t N, int64_t K, const float* A,
                                int64_t lda, const float* B, int64_t ldb, float* C, int64_t ldc, int64_t c_col_block,
                                int64_t c_block_stride, int relu, void* workspace, size_t workspace_bytes,
                                acm_stream_t stream) {
+    return gemm_core(transA, transB, M, N, K, A, lda, B, ldb, C, ldc, c_col_block, c_block_stride, 0, nullptr, 0, relu,
+                     workspace, workspace_bytes, stream);
+}
+
+extern "C" int acm_gemm_split(int transA, int transB, int64_t M, int64_t N, int64_t K, const float* A, int64_t lda,
+                              const float* B, int64_t ldb, float* C, int64_t ldc, int64_t split_col, float* C2,
+                              int64_t ldc2, int relu, void* workspace, size_t workspace_bytes, acm_stream_t stream) {
+    ACM_REQUIRE(split_col > 0 && split_col < N && C2 && ldc2 >= N - split_col && ldc >= split_col, ACM_ESHAPE,
+                "acm_gemm_split: split %lld of %lld columns, ldc %lld ldc2 %lld", (long long)split_col, (long long)N,
+                (long long)ldc, (long long)ldc2);
+    return gemm_core(transA, transB, M, N, K, A, lda, B, ldb, C, ldc, 0, 0, split_col, C2, ldc2, relu, workspace,
+                     workspace_bytes, stream);
+}
+
+static int gemm_core(int transA, int transB, int64_t M, int64_t N, int64_t K, const float* A, int64_t lda, const float* B,
+                     int64_t ldb, float* C, int64_t ldc, int64_t c_col_block, int64_t c_block_stride, int64_t split_col,
+                     float* C2, int64_t ldc2, int relu, void* workspace, size_t workspace_bytes, acm_stream_t stream) {
     ACM_REQUIRE(M >= 0 && N >= 0 && K >= 0, ACM_ESHAPE, "acm_gemm: negative size");
     ACM_REQUIRE(c_col_block >= 0 && c_col_block < INT32_MAX, ACM_ESHAPE, "acm_gemm: bad column block");
     const int cb = (int)c_col_block;
@@ -257,7 +284,9 @@ extern "C" int acm_gemm_blocks(int transA, int transB, int64_t M, int64_t N, int
     ACM_REQUIRE(M < INT32_MAX && N < INT32_MAX && K < INT32_MAX, ACM_EUNSUPPORTED, "acm_gemm: size >= 2^31");
     if (M == 0 || N == 0) return ACM_OK;
     ACM_REQUIRE(C && (K == 0 || (A && B)), ACM_EINVAL, "acm_gemm: NULL matrix pointer");
-    ACM_REQUIRE(lda >= (transA ? M : K) && ldb >= (transB ? K : N) && ldc >= (cb ? (cb < N ? cb : N) : N), ACM_ESHAPE,
+    const int split = (int)split_col;
+    ACM_REQUIRE(lda >= (transA ? M : K) && ldb >= (transB ? K : N) &&
+                    ldc >= (cb ? (cb < N ? cb : N) : (split ? split : N)), ACM_ESHAPE,
                 "acm_gemm: leading dimension too small (lda %lld ldb %lld ldc %lld)", (long long)lda,
                 (long long)ldb, (long long)ldc);
     hipStream_t st = (hipStream_t)stream;
@@ -271,7 +300,10 @@ extern "C" int acm_gemm_blocks(int transA, int transB, int64_t M, int64_t N, int
         slabs = (float*)workspace;
     }
     if (K == 0) {  // empty sum
-        if (!cb) {
+        if (split) {
+            ACM_CHECK_HIP(hipMemset2DAsync(C, (size_t)ldc * sizeof(float), 0, (size_t)split * sizeof(float), (size_t)M, st));
+            ACM_CHECK_HIP(hipMemset2DAsync(C2, (size_t)ldc2 * sizeof(float), 0, (size_t)(N - split) * sizeof(float), (size_t)M, st));
+        } else if (!cb) {
             ACM_CHECK_HIP(hipMemset2DAsync(C, (size_t)ldc * sizeof(float), 0, (size_t)N * sizeof(float), (size_t)M, st));
         } else {
             for (int64_t n0 = 0; n0 < N; n0 += cb)
@@ -281,17 +313,17 @@ extern "C" int acm_gemm_blocks(int transA, int transB, int64_t M, int64_t N, int
         return ACM_OK;
     }
     if (p.shape == 0)
-        launch_shape<2, 2, 2, 2>(transA, transB, p, st, (int)M, (int)N, (int)K, A, lda, B, ldb, C, ldc, relu, slabs, cb, cbs);
+        launch_shape<2, 2, 2, 2>(transA, transB, p, st, (int)M, (int)N, (int)K, A, lda, B, ldb, C, ldc, relu, slabs, cb, cbs, split, C2, (long)ldc2);
     else if (p.shape == 1)
-        launch_shape<1, 4, 1, 4>(transA, transB, p, st, (int)M, (int)N, (int)K, A, lda, B, ldb, C, ldc, relu, slabs, cb, cbs);
+        launch_shape<1, 4, 1, 4>(transA, transB, p, st, (int)M, (int)N, (int)K, A, lda, B, ldb, C, ldc, relu, slabs, cb, cbs, split, C2, (long)ldc2);
     else
-        launch_shape<4, 1, 4, 1>(transA, transB, p, st, (int)M, (int)N, (int)K, A, lda, B, ldb, C, ldc, relu, slabs, cb, cbs);
+        launch_shape<4, 1, 4, 1>(transA, transB, p, st, (int)M, (int)N, (int)K, A, lda, B, ldb, C, ldc, relu, slabs, cb, cbs, split, C2, (long)ldc2);
     ACM_CHECK_HIP(hipGetLastError());
     if (slabs) {
         const long total = (long)M * N;
         const int grid = (int)((total + 15) / 16);
         hipLaunchKernelGGL(splitk_reduce_kernel, dim3(grid), dim3(256), 0, st, (int)M, (int)N, p.splits, slabs,
-                           C, (long)ldc, relu, cb, cbs);
+                           C, (long)ldc, relu, cb, cbs, split, C2, (long)ldc2);
         ACM_CHECK_HIP(hipGetLastError());
     }
     return ACM_OK;

@@ -111,6 +111,24 @@ def gemm(a, b, trans_a=False, trans_b=False, relu=False, out=None, col_blocks=0)
     return out
 
 
+def gemm_split(a, b, out1, out2, relu=False):
+    """[out1 | out2] = a @ b: the first out1.shape[1] columns go to out1, the rest to out2 (acm_gemm_split)."""
+    a, b = _as_f32c(a, "a"), _as_f32c(b, "b")
+    m, k = a.shape
+    n = b.shape[1]
+    split = out1.shape[1]
+    if b.shape[0] != k or out2.shape[1] != n - split or out1.shape[0] != m or out2.shape[0] != m:
+        raise ValueError("gemm_split: shape mismatch")
+    lib = _lib.load()
+    nbytes = C.c_size_t()
+    _lib.check(lib.acm_gemm_workspace_bytes(0, 0, m, n, k, C.byref(nbytes)))
+    ws = torch.empty(max(nbytes.value // 4, 1), dtype=_F32, device=a.device) if nbytes.value else None
+    with _device_ctx(a.device), _Timed(f"gemm_NN/{m}x{n}x{k}"):
+        st = lib.acm_gemm_split(0, 0, m, n, k, _vp(a), a.stride(0), _vp(b), b.stride(0), _vp(out1), out1.stride(0), split,
+                                _vp(out2), out2.stride(0), int(relu), _vp(ws), nbytes.value, _stream())
+    _lib.check(st, "acm_gemm_split")
+
+
 def proj_bwd(x, dz, w, d_w_out):
     """Backward of the skinny projection Z = x @ w in one pass over x (acm_proj_bwd):
     returns dX = dz @ w.T and fills ``d_w_out`` ([blocks, f_in, n_out / blocks], contiguous) with x.T @ dz."""
@@ -474,21 +492,29 @@ class AcmConvFunction(torch.autograd.Function):
             ldz = 3 * f
             if f in (2, 4, 8):
                 ldz = -(-3 * f // (2 * f)) * (2 * f)
-            z = torch.empty(n, ldz, dtype=_F32, device=dev)[:, : 3 * f]
-            if sparse_x:                                  # Z = X_csr Wcat: nnz(X) * 3F FMAs
-                spmm_v(x.csr, x.values, wcat, relu=cfg.relu_before, out=z)
+            if f in (2, 4, 8) and not sparse_x:
+                # narrow layer: [Z_L | Z_H] as its own compact table (what the gather walks: half the cache footprint of
+                # [Z_L | Z_H | Z_I | pad] rows), Z_I next to it -- one GEMM with a two-matrix output
+                zlh = torch.empty(n, 2 * f, dtype=_F32, device=dev)
+                zi = torch.empty(n, f, dtype=_F32, device=dev)
+                gemm_split(x, wcat, zlh, zi, relu=cfg.relu_before)
             else:
-                gemm(x, wcat, relu=cfg.relu_before, out=z)                          # [n, 3F] view
+                z = torch.empty(n, ldz, dtype=_F32, device=dev)[:, : 3 * f]
+                if sparse_x:                              # Z = X_csr Wcat: nnz(X) * 3F FMAs
+                    spmm_v(x.csr, x.values, wcat, relu=cfg.relu_before, out=z)
+                else:
+                    gemm(x, wcat, relu=cfg.relu_before, out=z)                      # [n, 3F] view
+                zlh, zi = z[:, : 2 * f], z[:, 2 * f:]
             if hops > 1:
-                t = z[:, :f]
+                t = zlh[:, :f]
                 for _ in range(hops - 1):
                     t = _low_product(ops, t)
                 zc = torch.empty(n, 2 * f, dtype=_F32, device=dev)               # [A_low^(k-1) Z_L | Z_H]
                 zc[:, :f] = t
-                zc[:, f:] = z[:, f:2 * f]
+                zc[:, f:] = zlh[:, f:]
                 zg = _gather_rows(ops, zc)
             else:
-                zg = _gather_rows(ops, z[:, : 2 * f]) if ops.sharded else z         # gathered [Z_L|Z_H]
+                zg = _gather_rows(ops, zlh) if ops.sharded else zlh                 # gathered [Z_L|Z_H]
         if four and general:
             if ops.un is None:
                 raise RuntimeError("structure_info=1 needs adj_low_unnormalized")
@@ -558,8 +584,8 @@ class AcmConvFunction(torch.autograd.Function):
         if general:
             # every channel through its own operator, then the fused kernel over the identity operator as a
             # row-local epilogue: pre_L = 1*PL, pre_H = PH - 1*0, pre_S = 1*(1*PS) - 0
-            pl = spmm(ops.low, z[:, :f])
-            ph = spmm(ops.high, z[:, f:2 * f])
+            pl = spmm(ops.low, zlh[:, :f])
+            ph = spmm(ops.high, zlh[:, f:])
             zero = ops.zeros(n, f)
             graph = ops.eye
             p.g_low, p.ld_g_low = pl.data_ptr(), pl.stride(0)
@@ -588,11 +614,11 @@ class AcmConvFunction(torch.autograd.Function):
                 p.g_high, p.ld_g_high = zg.data_ptr() + 4 * f, zg.stride(0)
                 if four:
                     p.g_struc, p.ld_g_struc = s_gath.data_ptr(), s_gath.stride(0)
-            p.s_high, p.ld_s_high = z.data_ptr() + 4 * f, z.stride(0)
+            p.s_high, p.ld_s_high = zlh.data_ptr() + 4 * f, zlh.stride(0)
             if four:
                 p.s_struc, p.ld_s_struc = s_local.data_ptr(), s_local.stride(0)
                 p.deg = ops.deg.data_ptr()
-        p.s_mlp, p.ld_s_mlp = z.data_ptr() + 8 * f, z.stride(0)
+        p.s_mlp, p.ld_s_mlp = zi.data_ptr(), zi.stride(0)
         p.att_vec = _ptr_array(vecs)
         p.ln_weight, p.ln_bias = _ptr_array(lnw), _ptr_array(lnb)
         p.att_mix = mix.data_ptr()
@@ -606,7 +632,7 @@ class AcmConvFunction(torch.autograd.Function):
         _lib.check(st, "acm_conv_fwd")
         ctx.ops, ctx.cfg = ops, cfg
         ctx.sparse_x = x if sparse_x else None
-        ctx.save_for_backward(wcat if sparse_x else x, wcat, z, pre, mix, *vecs, *lnw, *lnb)
+        ctx.save_for_backward(wcat if sparse_x else x, wcat, zlh, zi, pre, mix, *vecs, *lnw, *lnb)
         ctx.mark_non_differentiable(att)
         return out, att
 
@@ -620,12 +646,12 @@ class AcmConvFunction(torch.autograd.Function):
         saved = ctx.saved_tensors
         if ctx.agg_first:
             return AcmConvFunction._backward_agg(ctx, grad_out)
-        x, wcat, z, pre, mix = saved[:5]
-        vecs = list(saved[5:5 + k])
-        lnw = list(saved[5 + k:5 + 2 * k]) if cfg.layernorm else []
-        lnb = list(saved[5 + 2 * k:5 + 3 * k]) if cfg.layernorm else []
-        dev = z.device
-        n, f = z.shape[0], wcat.shape[1] // 3
+        x, wcat, zlh, zi, pre, mix = saved[:6]
+        vecs = list(saved[6:6 + k])
+        lnw = list(saved[6 + k:6 + 2 * k]) if cfg.layernorm else []
+        lnb = list(saved[6 + 2 * k:6 + 3 * k]) if cfg.layernorm else []
+        dev = zlh.device
+        n, f = zlh.shape[0], wcat.shape[1] // 3
         grad_out = _as_f32c(grad_out, "grad_out")
         four = k == 4
 
@@ -648,7 +674,7 @@ class AcmConvFunction(torch.autograd.Function):
         q.relu_after, q.relu_mlp, q.layernorm, q.scale = int(cfg.relu_after), int(cfg.relu_mlp), int(cfg.layernorm), cfg.scale
         q.grad_out, q.ld_grad_out = grad_out.data_ptr(), grad_out.stride(0)
         q.pre, q.ld_pre = pre.data_ptr(), pre.stride(0)
-        q.s_mlp, q.ld_s_mlp = z.data_ptr() + 8 * f, z.stride(0)
+        q.s_mlp, q.ld_s_mlp = zi.data_ptr(), zi.stride(0)
         general = bool(getattr(ops, "general", False))
         ones = ops.zeros(n, 1).new_ones(n) if (four and general) else None
         # pattern-only backward: A_low^T G = P (D^-1 G), so G_L / G_H are written pre-scaled and G_S unscaled
@@ -712,8 +738,8 @@ class AcmConvFunction(torch.autograd.Function):
             if ops.implicit:
                 r.self_scale = ops.self_scale.data_ptr()
         if cfg.relu_before:                       # ACMII: ReLU mask of the projected features
-            r.mask_low, r.ld_mask_low = z.data_ptr(), z.stride(0)
-            r.mask_high, r.ld_mask_high = z.data_ptr() + 4 * f, z.stride(0)
+            r.mask_low, r.ld_mask_low = zlh.data_ptr(), zlh.stride(0)
+            r.mask_high, r.ld_mask_high = zlh.data_ptr() + 4 * f, zlh.stride(0)
         r.dz_low, r.ld_dz_low = dz.data_ptr(), dz.stride(0)
         r.dz_high, r.ld_dz_high = dz.data_ptr() + 4 * f, dz.stride(0)
         ws2 = low_t.workspace((k - 1) * f)

@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define ACM_ABI_VERSION 10
+#define ACM_ABI_VERSION 11
 
 typedef enum {
     ACM_OK = 0,
@@ -149,6 +149,14 @@ typedef struct {
  * 16-byte gathers of the aggregate-first path).  src may equal dst when dst_cols == n_cols. */
 int acm_dropout(int64_t n_rows, int64_t n_cols, const float* src, int64_t ld_src,
                 float* dst, int64_t ld_dst, int64_t dst_cols, const acm_dropout_t* d, acm_stream_t stream);
+
+/* Same product delivered as two matrices: columns [0, split_col) to C (pitch ldc), the rest to C2 (pitch ldc2).
+ * The projection of a narrow layer writes the gathered block [Z_L | Z_H] as its own compact 2F-float rows (the table
+ * the fused SpMM gathers from: half the cache footprint of [Z_L | Z_H | Z_I | pad] rows) and Z_I next to it. */
+int acm_gemm_split(int transA, int transB, int64_t M, int64_t N, int64_t K,
+                   const float* A, int64_t lda, const float* B, int64_t ldb,
+                   float* C, int64_t ldc, int64_t split_col, float* C2, int64_t ldc2, int relu,
+                   void* workspace, size_t workspace_bytes, acm_stream_t stream);
 
 /* Backward of a skinny projection Z = X W  (W: f_in x n_out, n_out in {3, 6, 9, 12, 15} -- the output layer's
  * [W_L | W_H | W_I] with up to five classes) in one pass over X:

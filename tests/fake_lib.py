@@ -146,7 +146,7 @@ class FakeLib:
 
     # ---- plumbing ---------------------------------------------------------
     def acm_version(self):
-        return 10
+        return 11
 
     def acm_last_error(self):
         return self._err
@@ -274,6 +274,16 @@ class FakeLib:
         if relu:
             out = np.maximum(out, 0)
         _view(c, m, n, ldc)[...] = out
+        return 0
+
+    def acm_gemm_split(self, ta, tb, m, n, k, a, lda, b, ldb, c, ldc, split, c2, ldc2, relu, ws, wsb, stream):
+        A = _view(a, k, m, lda).T if ta else _view(a, m, k, lda)
+        B = _view(b, n, k, ldb).T if tb else _view(b, k, n, ldb)
+        out = A.astype(np.float64) @ B.astype(np.float64)
+        if relu:
+            out = np.maximum(out, 0)
+        _view(c, m, split, ldc)[...] = out[:, :split]
+        _view(c2, m, n - split, ldc2)[...] = out[:, split:]
         return 0
 
     def acm_gemm_blocks(self, ta, tb, m, n, k, a, lda, b, ldb, c, ldc, cb, cbs, relu, ws, wsb, stream):

@@ -78,6 +78,19 @@ def test_proj_bwd_matches_fp64(n, f_in, q):
     assert float(((dxs.cpu().double() - ref_dx).abs() / (sc_dx + 1e-30)).max()) < 2e-6
 
 
+@pytest.mark.parametrize("m,n,k,split", [(1000, 6, 64, 4), (168114, 6, 64, 4), (300, 24, 7, 16), (64, 12, 3000, 8), (5, 3, 2, 2)])
+def test_gemm_two_matrix_output(m, n, k, split):
+    """acm_gemm_split: columns [0, split) to one matrix, the rest to another (direct and split-K stores)."""
+    from acm_gnn_amd import functional as AF
+    g = torch.Generator().manual_seed(m + n + k)
+    a, b = torch.randn(m, k, generator=g), torch.randn(k, n, generator=g)
+    whole = AF.gemm(a.to(DEV), b.to(DEV), relu=True)
+    o1 = torch.full((m, split + 3), 7.0, device=DEV)[:, :split]          # strided destinations keep their padding
+    o2 = torch.full((m, n - split), 7.0, device=DEV)
+    AF.gemm_split(a.to(DEV), b.to(DEV), o1, o2, relu=True)
+    assert torch.equal(o1, whole[:, :split]) and torch.equal(o2, whole[:, split:])
+
+
 def test_gemm_is_an_fmaf_chain_in_k_order():
     """f32 MFMA == k-ordered fmaf chain: integer-valued inputs must be exact."""
     from acm_gnn_amd import functional as AF
