@@ -84,16 +84,6 @@ static inline CsrView acm_view(const acm_csr* a) {
 
 #ifdef __HIPCC__
 // ---- device helpers ---------------------------------------------------------
-// Remap the linear block id so that each XCD (private 4 MiB L2) walks a contiguous
-// range of work items: block b runs on XCD b % 8 (observed dispatch order; speed
-// only, never correctness).  Bijective for any grid size.
-__device__ __forceinline__ int acm_xcd_swizzle(int b, int nblk) {
-    const int xcd = b % ACM_NXCD, idx = b / ACM_NXCD;
-    const int q = nblk / ACM_NXCD, r = nblk % ACM_NXCD;
-    const int start = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
-    return start + idx;
-}
-
 // All-reduce (sum) over the W consecutive lanes that share lane / W; W power of two <= 64.
 // Pure VALU: DPP quad_perm (xor 1, xor 2), row_half_mirror / row_mirror (the partner of lane i
 // is 7-i / 15-i, which after the earlier steps holds the other half's total), then gfx950's

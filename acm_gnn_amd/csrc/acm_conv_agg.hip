@@ -593,7 +593,7 @@ extern "C" int acm_conv_agg_fwd(const acm_csr_t* a, const acm_conv_agg_fwd_t* p,
     // (0) fused form: gather + epilogue in one kernel, plus a small one for the long rows
     {
         const double avg = (double)a->nnz / (double)(a->n_rows > 0 ? a->n_rows : 1);
-        static const bool fused_off = getenv("ACM_AGG_UNFUSED") != nullptr;
+        const bool fused_off = getenv("ACM_AGG_UNFUSED") != nullptr;      // read per call: tests switch forms
         const bool fused = !fused_off && p->n_channels == 3 && p->f_pad <= 8 && avg > 12.0 && avg <= 160.0 &&
                            ((uintptr_t)p->xg) % 16 == 0 && (p->ld_xg * sizeof(float)) % 16 == 0 &&
                            (a->n_long == 0 || a->long_index != nullptr);
@@ -611,7 +611,7 @@ extern "C" int acm_conv_agg_fwd(const acm_csr_t* a, const acm_conv_agg_fwd_t* p,
                 hipLaunchKernelGGL((agg_fused_kernel<4>), dim3(grid), dim3(256), 0, s, *p, cv, partial);
                 if (tail) hipLaunchKernelGGL((agg_long_rows_kernel<4>), dim3(tail), dim3(256), 0, s, *p, cv, partial);
             } else {
-                static const bool pair_lanes = getenv("ACM_AGG_NO_PAIR") == nullptr;
+                const bool pair_lanes = getenv("ACM_AGG_NO_PAIR") == nullptr;
                 if (pair_lanes)
                     hipLaunchKernelGGL(agg_fused_pair_kernel, dim3(grid), dim3(256), 0, s, *p, cv, partial);
                 else

@@ -104,6 +104,21 @@ def test_aggregate_first_matches_oracle_and_literal(model_type, ln, f_in, f_out,
     assert float((a - b).abs().max()) < 2e-5 * max(1.0, float(b.abs().max()))
 
 
+@pytest.mark.parametrize("form", ["fused-pair", "fused", "two-stage"])
+@pytest.mark.parametrize("f_in,f_out,hub", [(7, 64, True), (3, 16, True), (8, 33, False)])
+def test_aggregate_first_kernel_forms(form, f_in, f_out, hub, monkeypatch):
+    """The three implementations of the three-channel aggregate-first forward -- one kernel with two lanes per
+    neighbour (default for 32-byte rows), one kernel with one lane per neighbour, and gather + epilogue with the
+    long rows' partial sums added by the epilogue -- against the oracle, on a graph with a split hub row."""
+    if form != "fused-pair":
+        monkeypatch.setenv("ACM_AGG_NO_PAIR", "1")
+    if form == "two-stage":
+        monkeypatch.setenv("ACM_AGG_UNFUSED", "1")
+    adj = _graph(700, 21, density=0.04, hub=hub)
+    _run_both("acmgcnp", 0, 0, True, 700, f_in, f_out, 21, False, monkeypatch, agg=True, adj=adj)
+    _run_both("acmgcn", 0, 0, False, 700, f_in, f_out, 22, False, monkeypatch, agg=True, adj=adj, implicit=False)
+
+
 AGG_STRUC_CASES = [(True, 7, 64), (False, 7, 64), (True, 3, 24), (True, 16, 40), (True, 4, 5), (False, 12, 33)]
 
 
