@@ -40,7 +40,7 @@ __device__ __forceinline__ void adam_one(float& p, float g, float& m, float& v, 
     p = p - step_size * (m / denom);
 }
 
-__global__ __launch_bounds__(256) void adam_kernel(AdamPack pk, AdamScalars hp) {
+__global__ __launch_bounds__(256) void adam_kernel(AdamPack pk, AdamScalars hp, int* arrive, int64_t* also_advance) {
     __shared__ float sc[2];
     int t = 0;
     while (t + 1 < pk.n && (int)blockIdx.x >= pk.first_block[t + 1]) ++t;      // uniform: <= 31 scalar compares
@@ -86,6 +86,24 @@ __global__ __launch_bounds__(256) void adam_kernel(AdamPack pk, AdamScalars hp) 
             v[i] = vv;
         }
     }
+    // Advance the step counters in the same launch: every block read its counter at the top, so the last block to get
+    // here may increment them.  Only the arrival counter is shared between blocks (a device-scope atomic; no data is
+    // handed from block to block, hence no fence); the incremented values are for the NEXT launch, which the kernel
+    // boundary orders.
+    if (arrive) {
+        __shared__ int s_last;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const int ticket = atomicAdd(arrive, 1);
+            s_last = ticket == (int)gridDim.x - 1;
+            if (s_last) atomicExch(arrive, 0);
+        }
+        __syncthreads();
+        if (s_last) {
+            if ((int)threadIdx.x < pk.n) pk.step[threadIdx.x][0] += 1.0f;
+            if (threadIdx.x == 0 && also_advance) also_advance[0] += 1;
+        }
+    }
 }
 
 // after the update of a pack: step_t += 1 for each of its tensors (stream order makes every block of the update
@@ -121,9 +139,13 @@ extern "C" int acm_adam_step(int32_t n_tensors, const acm_adam_tensor_t* tensors
             blocks += (int)((t.numel + CHUNK - 1) / CHUNK);
         }
         pk.first_block[pk.n] = blocks;
-        if (blocks > 0) hipLaunchKernelGGL(adam_kernel, dim3(blocks), dim3(256), 0, s, pk, hp);
-        hipLaunchKernelGGL(adam_advance_kernel, dim3(1), dim3(PACK), 0, s, pk,
-                           first + PACK >= n_tensors ? cfg->also_advance : nullptr);
+        int64_t* adv = first + PACK >= n_tensors ? cfg->also_advance : nullptr;
+        if (blocks > 0 && cfg->arrive) {          // one launch: the last block advances the counters
+            hipLaunchKernelGGL(adam_kernel, dim3(blocks), dim3(256), 0, s, pk, hp, cfg->arrive, adv);
+        } else {
+            if (blocks > 0) hipLaunchKernelGGL(adam_kernel, dim3(blocks), dim3(256), 0, s, pk, hp, (int*)nullptr, (int64_t*)nullptr);
+            hipLaunchKernelGGL(adam_advance_kernel, dim3(1), dim3(PACK), 0, s, pk, adv);
+        }
         ACM_CHECK_HIP(hipGetLastError());
     }
     if (n_tensors == 0 && cfg->also_advance) {

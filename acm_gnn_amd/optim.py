@@ -33,6 +33,7 @@ class _FusedAdamBase(torch.optim.Optimizer):
         # of the model being trained: acm_adam_config_t.also_advance)
         self.also_advance = None
         self._tables = {}
+        self._arrive = {}                     # per device: the zeroed int32 arrival counter of acm_adam_step
 
     def load_state_dict(self, state_dict):
         super().load_state_dict(state_dict)
@@ -87,10 +88,14 @@ class _FusedAdamBase(torch.optim.Optimizer):
                 if e.param != p.data_ptr() or e.exp_avg != st["exp_avg"].data_ptr():
                     e.param, e.exp_avg = p.data_ptr(), st["exp_avg"].data_ptr()
                     e.exp_avg_sq, e.step = st["exp_avg_sq"].data_ptr(), st["step"].data_ptr()
+            arrive = self._arrive.get(dev)
+            if arrive is None:
+                arrive = self._arrive[dev] = torch.zeros(1, dtype=torch.int32, device=dev)
             cfg = _lib.AdamConfig(float(group["lr"]), float(group["betas"][0]), float(group["betas"][1]),
                                   float(group["eps"]), float(group["weight_decay"]), int(self._decoupled),
                                   self.also_advance.data_ptr() if (self.also_advance is not None and
-                                                                   gi == len(groups) - 1) else None)
+                                                                   gi == len(groups) - 1) else None,
+                                  arrive.data_ptr())
             with _device_ctx(dev):
                 status = lib.acm_adam_step(len(live), C.cast(entries, C.c_void_p), C.byref(cfg), _stream())
             _lib.check(status, "acm_adam_step")

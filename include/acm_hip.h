@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define ACM_ABI_VERSION 11
+#define ACM_ABI_VERSION 12
 
 typedef enum {
     ACM_OK = 0,
@@ -465,6 +465,9 @@ typedef struct {
     int32_t decoupled;                 /* 1 = AdamW, 0 = Adam (L2 added to the gradient) */
     int64_t* also_advance;             /* optional device counter incremented by 1 with the step counters
                                           (the acm_dropout_t.step of the model being trained) */
+    int32_t* arrive;                   /* optional device int32, zero before the first call and left zero: with it the
+                                          counters are advanced by the last block of the update launch itself instead
+                                          of a second launch (calls sharing one `arrive` must be stream-ordered) */
 } acm_adam_config_t;
 
 int acm_adam_step(int32_t n_tensors, const acm_adam_tensor_t* tensors, const acm_adam_config_t* cfg,

@@ -108,7 +108,7 @@ int main(void) {
     for (int i = 0; i < W * W; ++i) { g[i] = 0.01f * (float)(i - 30); p0[i] = c[i]; }
     acm_adam_tensor_t t = {d_c, (float*)to_dev(g, sizeof(g)), (float*)to_dev(m, sizeof(m)), (float*)to_dev(vv, sizeof(vv)),
                            (float*)to_dev(&step, sizeof(step)), W * W};
-    acm_adam_config_t cfg = {0.1, 0.9, 0.999, 1e-8, 0.01, 1, NULL};
+    acm_adam_config_t cfg = {0.1, 0.9, 0.999, 1e-8, 0.01, 1, NULL, NULL};
     CHECK_ACM(acm_adam_step(1, &t, &cfg, NULL));
     CHECK_HIP(hipDeviceSynchronize());
     CHECK_HIP(hipMemcpy(c, d_c, sizeof(c), hipMemcpyDeviceToHost));

@@ -146,7 +146,7 @@ class FakeLib:
 
     # ---- plumbing ---------------------------------------------------------
     def acm_version(self):
-        return 11
+        return 12
 
     def acm_last_error(self):
         return self._err

@@ -82,10 +82,10 @@ def test_adam_entry_point_rejects_bad_arguments():
     import ctypes as C
     from acm_gnn_amd import _lib
     lib = _lib.load()
-    cfg = _lib.AdamConfig(0.01, 0.9, 0.999, 1e-8, 0.0, 1)
+    cfg = _lib.AdamConfig(0.01, 0.9, 0.999, 1e-8, 0.0, 1, None, None)
     assert lib.acm_adam_step(1, None, C.byref(cfg), None) == 1
     ent = (_lib.AdamTensor * 1)()
     assert lib.acm_adam_step(1, C.cast(ent, C.c_void_p), C.byref(cfg), None) == 1 and b"NULL" in lib.acm_last_error()
-    bad = _lib.AdamConfig(0.01, 1.5, 0.999, 1e-8, 0.0, 1)
+    bad = _lib.AdamConfig(0.01, 1.5, 0.999, 1e-8, 0.0, 1, None, None)
     assert lib.acm_adam_step(0, None, C.byref(bad), None) == 1
     assert lib.acm_adam_step(0, None, C.byref(cfg), None) == 0
