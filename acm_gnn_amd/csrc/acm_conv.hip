@@ -987,11 +987,13 @@ __global__ __launch_bounds__(256) void conv_bwd_local_grouped_kernel(acm_conv_bw
     float* hlds = lds;                                   // 3 * K * 64 floats, dead after the row loop
     stage_head_params<K>(hlds, p.att_vec, p.ln_weight, p.ln_bias, p.layernorm, F);
     __syncthreads();
-    float dv[K][4], dgam[K][4], dbet[K][4], dmix[K * K], mixm[K * K];
+    float pA[K][4], pS[K], dmix[K * K], mixm[K * K];     // head-parameter accumulators (see row_channel_backward)
 #pragma unroll
-    for (int c = 0; c < K; ++c)
+    for (int c = 0; c < K; ++c) {
+        pS[c] = 0.f;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) dv[c][i] = dgam[c][i] = dbet[c][i] = 0.f;
+        for (int i = 0; i < 4; ++i) pA[c][i] = 0.f;
+    }
 #pragma unroll
     for (int q = 0; q < K * K; ++q) {
         dmix[q] = 0.f;
@@ -1033,7 +1035,7 @@ __global__ __launch_bounds__(256) void conv_bwd_local_grouped_kernel(acm_conv_bw
         for (int c = 0; c < K; ++c) {
             const bool relu_c = (c < 2) ? (p.relu_after != 0) : (c == 2 ? p.relu_mlp != 0 : true);
             float G[4];
-            row_channel_backward<K>(hlds, c, mm, F, ln, p.scale, rh, ds[c], H[c], dO, dv[c], dgam[c], dbet[c], G);
+            row_channel_backward<K>(hlds, c, mm, F, ln, p.scale, rh, ds[c], H[c], dO, pA[c], pS[c], G);
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const int col = m + 16 * i;
@@ -1046,14 +1048,14 @@ __global__ __launch_bounds__(256) void conv_bwd_local_grouped_kernel(acm_conv_bw
             }
         }
     }
+    float dv[K][4], dgam[K][4], dbet[K][4];
 #pragma unroll
-    for (int c = 0; c < K; ++c)
+    for (int c = 0; c < K; ++c) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            dv[c][i] = acm_cross_row_sum(dv[c][i]);
-            dgam[c][i] = acm_cross_row_sum(dgam[c][i]);
-            dbet[c][i] = acm_cross_row_sum(dbet[c][i]);
-        }
+        for (int i = 0; i < 4; ++i) pA[c][i] = acm_cross_row_sum(pA[c][i]);
+        pS[c] = acm_cross_row_sum(pS[c]);
+        row_param_grads<K>(hlds, c, m, pA[c], pS[c], dv[c], dgam[c], dbet[c]);      // hlds is still intact here
+    }
 #pragma unroll
     for (int q = 0; q < K * K; ++q) dmix[q] = acm_cross_row_sum(dmix[q]);
     __syncthreads();

@@ -412,11 +412,13 @@ __global__ __launch_bounds__(256, 2) void agg_bwd_kernel(acm_conv_agg_bwd_t p, i
     for (int c = 0; c < 3; ++c)
 #pragma unroll
         for (int t = 0; t < 4; ++t) acc[c][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    float dv[K][4], dgam[K][4], dbet[K][4], dmix[K * K];
+    float pA[K][4], pS[K], dmix[K * K];          // head-parameter accumulators (see row_channel_backward)
 #pragma unroll
-    for (int c = 0; c < K; ++c)
+    for (int c = 0; c < K; ++c) {
+        pS[c] = 0.f;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) dv[c][i] = dgam[c][i] = dbet[c][i] = 0.f;
+        for (int i = 0; i < 4; ++i) pA[c][i] = 0.f;
+    }
 #pragma unroll
     for (int q = 0; q < K * K; ++q) dmix[q] = 0.f;
     float mixm[K * K];
@@ -467,7 +469,7 @@ __global__ __launch_bounds__(256, 2) void agg_bwd_kernel(acm_conv_agg_bwd_t p, i
             const bool relu_c = (c < 2) ? (p.relu_after != 0) : (p.relu_mlp != 0);
             const float aop = (c == 0) ? Pm : (c == 1 ? xm - Pm : xm);
             float G[4];
-            row_channel_backward<K>(hlds, c, mm, F, ln, p.scale, rh, ds[c], H[c], dO, dv[c], dgam[c], dbet[c], G);
+            row_channel_backward<K>(hlds, c, mm, F, ln, p.scale, rh, ds[c], H[c], dO, pA[c], pS[c], G);
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
                 const bool keep = active && (m + 16 * t < F) && (!relu_c || H[c][t] > 0.f);
@@ -476,8 +478,7 @@ __global__ __launch_bounds__(256, 2) void agg_bwd_kernel(acm_conv_agg_bwd_t p, i
         }
         if (K == 4) {                              // structure channel: deg * G_S goes to memory for A_low^T
             float G[4];
-            row_channel_backward<K>(hlds, K - 1, mm, F, ln, p.scale, rh, ds[K - 1], H[K - 1], dO, dv[K - 1],
-                                    dgam[K - 1], dbet[K - 1], G);
+            row_channel_backward<K>(hlds, K - 1, mm, F, ln, p.scale, rh, ds[K - 1], H[K - 1], dO, pA[K - 1], pS[K - 1], G);
             const float dg1 = (active && p.g_struc_scale) ? p.g_struc_scale[rr] : 1.f;
 #pragma unroll
             for (int t = 0; t < 4; ++t)
@@ -486,14 +487,14 @@ __global__ __launch_bounds__(256, 2) void agg_bwd_kernel(acm_conv_agg_bwd_t p, i
         }
     }
     // head-parameter partials: combine the four row-groups of the wave
+    float dv[K][4], dgam[K][4], dbet[K][4];
 #pragma unroll
-    for (int c = 0; c < K; ++c)
+    for (int c = 0; c < K; ++c) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            dv[c][i] = acm_cross_row_sum(dv[c][i]);
-            dgam[c][i] = acm_cross_row_sum(dgam[c][i]);
-            dbet[c][i] = acm_cross_row_sum(dbet[c][i]);
-        }
+        for (int i = 0; i < 4; ++i) pA[c][i] = acm_cross_row_sum(pA[c][i]);
+        pS[c] = acm_cross_row_sum(pS[c]);
+        row_param_grads<K>(hlds, c, m, pA[c], pS[c], dv[c], dgam[c], dbet[c]);      // hlds is still intact here
+    }
 #pragma unroll
     for (int q = 0; q < K * K; ++q) dmix[q] = acm_cross_row_sum(dmix[q]);
     __syncthreads();                              // every wave is done with wlds / hlds

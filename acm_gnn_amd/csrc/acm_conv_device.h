@@ -427,10 +427,15 @@ __device__ __forceinline__ void row_head_backward_scalars(const RowHead<K>& r, c
 template <int K>
 __device__ __forceinline__ void row_channel_backward(const float* hlds, int c, int m, int F, bool ln, float scale,
                                                      const RowHead<K>& r, float ds_c, const float (&Hc)[4],
-                                                     const float (&dO)[4], float (&dv)[4], float (&dgam)[4],
-                                                     float (&dbet)[4], float (&G)[4]) {
+                                                     const float (&dO)[4], float (&A)[4], float& S, float (&G)[4]) {
+    // Parameter gradients of the head are rank-structured in the per-row scalar ds_c = dL/ds_c:
+    //     d att_vec = gamma * A + beta * S,   d gamma = att_vec * A,   d beta = att_vec * S
+    // with A[col] = sum_rows ds_c * xhat[row][col] and S = sum_rows ds_c, so a channel needs 4 + 1 accumulators per
+    // lane instead of 12 (row_param_grads() expands them after the row loop).  Without LayerNorm xhat = H, gamma = 1,
+    // beta = 0 (what stage_head_params stores), and the same formulas give d att_vec = A.
     HeadVecs<K> hv;
     hv.load(hlds, c, m);
+    S += ds_c;
     if (ln) {
         const float invF = 1.0f / (float)F;
         float xh[4], dxh[4], s1 = 0.f, s2 = 0.f;
@@ -438,11 +443,8 @@ __device__ __forceinline__ void row_channel_backward(const float* hlds, int c, i
         for (int i = 0; i < 4; ++i) {
             const bool ok = m + 16 * i < F;
             xh[i] = ok ? (Hc[i] - r.mean[c]) * r.rstd[c] : 0.f;
-            const float dhn = ds_c * hv.v[i];
-            dgam[i] = fmaf(dhn, xh[i], dgam[i]);
-            dbet[i] += dhn;
-            dv[i] = fmaf(ds_c, ok ? fmaf(xh[i], hv.gm[i], hv.bt[i]) : 0.f, dv[i]);
-            dxh[i] = dhn * hv.gm[i];
+            A[i] = fmaf(ds_c, xh[i], A[i]);
+            dxh[i] = ds_c * hv.v[i] * hv.gm[i];
             s1 += dxh[i];
             s2 = fmaf(dxh[i], xh[i], s2);
         }
@@ -453,8 +455,22 @@ __device__ __forceinline__ void row_channel_backward(const float* hlds, int c, i
     } else {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            dv[i] = fmaf(ds_c, Hc[i], dv[i]);
+            A[i] = fmaf(ds_c, Hc[i], A[i]);
             G[i] = fmaf(scale * r.alpha[c], dO[i], ds_c * hv.v[i]);
         }
+    }
+}
+
+// (A, S) summed over all rows -> the lane's four columns of d att_vec / d gamma / d beta of channel c
+template <int K>
+__device__ __forceinline__ void row_param_grads(const float* hlds, int c, int m, const float (&A)[4], float S,
+                                                float (&dv)[4], float (&dgam)[4], float (&dbet)[4]) {
+    HeadVecs<K> hv;
+    hv.load(hlds, c, m);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        dv[i] = fmaf(hv.gm[i], A[i], hv.bt[i] * S);
+        dgam[i] = hv.v[i] * A[i];
+        dbet[i] = hv.v[i] * S;
     }
 }
