@@ -987,7 +987,8 @@ __global__ __launch_bounds__(256) void conv_bwd_local_grouped_kernel(acm_conv_bw
     float* hlds = lds;                                   // 3 * K * 64 floats, dead after the row loop
     stage_head_params<K>(hlds, p.att_vec, p.ln_weight, p.ln_bias, p.layernorm, F);
     __syncthreads();
-    float pA[K][4], pS[K], dmix[K * K], mixm[K * K];     // head-parameter accumulators (see row_channel_backward)
+    float pA[K][4], pS[K], dmix1 = 0.f, mixm[K * K];     // head-parameter accumulators (see row_channel_backward)
+    const int qc = (m < K * K ? m : 0) / K, qj = (m < K * K ? m : 0) % K;    // the att_mix element this lane accumulates
 #pragma unroll
     for (int c = 0; c < K; ++c) {
         pS[c] = 0.f;
@@ -996,7 +997,6 @@ __global__ __launch_bounds__(256) void conv_bwd_local_grouped_kernel(acm_conv_bw
     }
 #pragma unroll
     for (int q = 0; q < K * K; ++q) {
-        dmix[q] = 0.f;
         mixm[q] = p.att_mix[q];
     }
     const bool ln = p.layernorm != 0;
@@ -1028,7 +1028,7 @@ __global__ __launch_bounds__(256) void conv_bwd_local_grouped_kernel(acm_conv_bw
         row_head<K>(hlds, mixm, mm, F, ln, H, rh);
         row_post_backward<K>(p, rh, H, active, rr, m, F, dO);
         float ds[K];
-        row_head_backward_scalars<K>(rh, mixm, p.scale, H, dO, ds, dmix);
+        row_head_backward_scalars<K>(rh, mixm, p.scale, H, dO, ds, qc, qj, dmix1);
         const float dg = (K == 4 && active && p.deg) ? p.deg[rr] : 1.f;
         const float gsc = (active && p.g_scale) ? p.g_scale[rr] : 1.f;
 #pragma unroll
@@ -1056,8 +1056,7 @@ __global__ __launch_bounds__(256) void conv_bwd_local_grouped_kernel(acm_conv_bw
         pS[c] = acm_cross_row_sum(pS[c]);
         row_param_grads<K>(hlds, c, m, pA[c], pS[c], dv[c], dgam[c], dbet[c]);      // hlds is still intact here
     }
-#pragma unroll
-    for (int q = 0; q < K * K; ++q) dmix[q] = acm_cross_row_sum(dmix[q]);
+    dmix1 = acm_cross_row_sum(dmix1);
     __syncthreads();
     float* slab = lds + wv * npg;
     if (g == 0) {
@@ -1073,10 +1072,7 @@ __global__ __launch_bounds__(256) void conv_bwd_local_grouped_kernel(acm_conv_bw
                 }
             }
     }
-    if (lane == 0) {
-#pragma unroll
-        for (int q = 0; q < K * K; ++q) slab[3 * K * F + q] = dmix[q];
-    }
+    if (g == 0 && m < K * K) slab[3 * K * F + m] = dmix1;
     __syncthreads();
     for (int q = threadIdx.x; q < npg; q += 256)
         partial[(long)blockIdx.x * npg + q] = (lds[q] + lds[npg + q]) + (lds[2 * npg + q] + lds[3 * npg + q]);

@@ -412,15 +412,14 @@ __global__ __launch_bounds__(256, 2) void agg_bwd_kernel(acm_conv_agg_bwd_t p, i
     for (int c = 0; c < 3; ++c)
 #pragma unroll
         for (int t = 0; t < 4; ++t) acc[c][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    float pA[K][4], pS[K], dmix[K * K];          // head-parameter accumulators (see row_channel_backward)
+    float pA[K][4], pS[K], dmix1 = 0.f;          // head-parameter accumulators (see row_channel_backward)
+    const int qc = (m < K * K ? m : 0) / K, qj = (m < K * K ? m : 0) % K;    // the att_mix element this lane accumulates
 #pragma unroll
     for (int c = 0; c < K; ++c) {
         pS[c] = 0.f;
 #pragma unroll
         for (int i = 0; i < 4; ++i) pA[c][i] = 0.f;
     }
-#pragma unroll
-    for (int q = 0; q < K * K; ++q) dmix[q] = 0.f;
     float mixm[K * K];
 #pragma unroll
     for (int q = 0; q < K * K; ++q) mixm[q] = p.att_mix[q];
@@ -460,7 +459,7 @@ __global__ __launch_bounds__(256, 2) void agg_bwd_kernel(acm_conv_agg_bwd_t p, i
         row_head<K>(hlds, mixm, mm, F, ln, H, rh);
         row_post_backward<K>(p, rh, H, active, rr, m, F, dO);
         float ds[K];
-        row_head_backward_scalars<K>(rh, mixm, p.scale, H, dO, ds, dmix);
+        row_head_backward_scalars<K>(rh, mixm, p.scale, H, dO, ds, qc, qj, dmix1);
         // ---- pass 2: one channel at a time -> G_c -> MFMA
         const float Pm = (m < FP) ? scratch[m] : 0.f;            // zero for inactive rows (project() stored zeros)
         const float xm = (m < FP) ? scratch[FP + m] : 0.f;
@@ -495,8 +494,7 @@ __global__ __launch_bounds__(256, 2) void agg_bwd_kernel(acm_conv_agg_bwd_t p, i
         pS[c] = acm_cross_row_sum(pS[c]);
         row_param_grads<K>(hlds, c, m, pA[c], pS[c], dv[c], dgam[c], dbet[c]);      // hlds is still intact here
     }
-#pragma unroll
-    for (int q = 0; q < K * K; ++q) dmix[q] = acm_cross_row_sum(dmix[q]);
+    dmix1 = acm_cross_row_sum(dmix1);
     __syncthreads();                              // every wave is done with wlds / hlds
     float* slab = lds + wv * npg;
 #pragma unroll
@@ -522,10 +520,7 @@ __global__ __launch_bounds__(256, 2) void agg_bwd_kernel(acm_conv_agg_bwd_t p, i
                 }
             }
     }
-    if (lane == 0) {
-#pragma unroll
-        for (int q = 0; q < K * K; ++q) slab[3 * f_in * F + 3 * K * F + q] = dmix[q];
-    }
+    if (g == 0 && m < K * K) slab[3 * f_in * F + 3 * K * F + m] = dmix1;
     __syncthreads();
     for (int q = threadIdx.x; q < npg; q += 256)
         partial[(long)blockIdx.x * npg + q] = (lds[q] + lds[npg + q]) + (lds[2 * npg + q] + lds[3 * npg + q]);

@@ -397,7 +397,7 @@ __device__ __forceinline__ void row_post_backward(const P& p, const RowHead<K>& 
 template <int K>
 __device__ __forceinline__ void row_head_backward_scalars(const RowHead<K>& r, const float* mixm, float scale,
                                                           const float (&H)[K][4], const float (&dO)[4],
-                                                          float (&ds)[K], float (&dmix)[K * K]) {
+                                                          float (&ds)[K], int qc, int qj, float& dmix1) {
     float dal[K], dot = 0.f;
 #pragma unroll
     for (int c = 0; c < K; ++c) {
@@ -415,12 +415,18 @@ __device__ __forceinline__ void row_head_backward_scalars(const RowHead<K>& r, c
     for (int c = 0; c < K; ++c) {
         float dg = 0.f;
 #pragma unroll
-        for (int j = 0; j < K; ++j) {
-            dg = fmaf(dlg[j], mixm[c * K + j], dg);
-            dmix[c * K + j] = fmaf(r.gsig[c], dlg[j] * invk, dmix[c * K + j]);   // rows with dO = 0 add 0
-        }
+        for (int j = 0; j < K; ++j) dg = fmaf(dlg[j], mixm[c * K + j], dg);
         ds[c] = dg * invk * r.gsig[c] * (1.f - r.gsig[c]);
     }
+    // d att_mix[c][j] += gsig[c] * dlg[j] / k: the K x K terms are uniform in the 16-lane group, so lane m keeps
+    // element m = (qc, qj) only (one accumulator per lane instead of K * K); rows with dO = 0 add 0
+    float gq = r.gsig[0], lq = dlg[0];
+#pragma unroll
+    for (int c = 1; c < K; ++c) {
+        gq = (qc == c) ? r.gsig[c] : gq;
+        lq = (qj == c) ? dlg[c] : lq;
+    }
+    dmix1 = fmaf(gq, lq * invk, dmix1);
 }
 
 // Pass 2 for one channel: G = dL/dH_c (before the ReLU mask), accumulating d att_vec / d gamma / d beta.
