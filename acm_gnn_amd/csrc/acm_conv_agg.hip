@@ -395,11 +395,12 @@ __global__ __launch_bounds__(256) void agg_long_rows_kernel(acm_conv_agg_fwd_t p
 // channel, then alpha / ds); pass 2 walks the channels one at a time, recomputes xhat from
 // (H, mean, rstd), and hands each channel's G straight to the MFMAs.  att_vec / LayerNorm
 // gamma, beta sit in LDS next to the weights ([array][c][m][i], one ds_read_b128 per use).
-template <int FP, int K>
+// FULL: f_out == 64 (the reference's hidden width), every column guard `m + 16 i < F` folds away at compile time.
+template <int FP, int K, bool FULL>
 __global__ __launch_bounds__(256, 2) void agg_bwd_kernel(acm_conv_agg_bwd_t p, int n_rows, float* __restrict__ partial) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, m = lane & 15, g = lane >> 4;
-    const int F = p.f_out, f_in = p.f_in;
+    const int F = FULL ? 64 : p.f_out, f_in = p.f_in;
     const int npg = 3 * f_in * F + 3 * K * F + K * K;
     float* wlds = lds;                           // 3 * FP * 64 floats
     float* hlds = lds + 3 * FP * 64;             // 3 * K * 64 floats
@@ -688,10 +689,14 @@ extern "C" int acm_conv_agg_bwd(int64_t n_rows, const acm_conv_agg_bwd_t* p, voi
     float* partial = (float*)workspace;
 #define ACM_BWDK(FPv)                                                                                                  \
     do {                                                                                                              \
-        if (K == 3)                                                                                                   \
-            hipLaunchKernelGGL((agg_bwd_kernel<FPv, 3>), dim3(nblk), dim3(256), lds, s, *p, (int)n_rows, partial);     \
+        if (K == 3 && p->f_out == 64)                                                                                  \
+            hipLaunchKernelGGL((agg_bwd_kernel<FPv, 3, true>), dim3(nblk), dim3(256), lds, s, *p, (int)n_rows, partial); \
+        else if (K == 3)                                                                                              \
+            hipLaunchKernelGGL((agg_bwd_kernel<FPv, 3, false>), dim3(nblk), dim3(256), lds, s, *p, (int)n_rows, partial); \
+        else if (p->f_out == 64)                                                                                      \
+            hipLaunchKernelGGL((agg_bwd_kernel<FPv, 4, true>), dim3(nblk), dim3(256), lds, s, *p, (int)n_rows, partial); \
         else                                                                                                          \
-            hipLaunchKernelGGL((agg_bwd_kernel<FPv, 4>), dim3(nblk), dim3(256), lds, s, *p, (int)n_rows, partial);     \
+            hipLaunchKernelGGL((agg_bwd_kernel<FPv, 4, false>), dim3(nblk), dim3(256), lds, s, *p, (int)n_rows, partial); \
     } while (0)
     if (p->f_pad == 4) ACM_BWDK(4);
     else if (p->f_pad == 8) ACM_BWDK(8);
