@@ -83,11 +83,11 @@ __device__ __forceinline__ void project(const float* wlds, float* scratch, int m
 }
 
 // P (uniform in the 16-lane group) -> projections -> head -> out / att for one row.
-template <int FP, int K>
+template <int FP, int K, bool FULL = false>
 __device__ __forceinline__ void agg_fwd_row(const acm_conv_agg_fwd_t& p, const float* wlds, const float* hlds,
                                             float* scratch, const float* mixm, int row, int lane, const CsrView& csr,
                                             const float* __restrict__ partial, bool p_in_scratch = false) {
-    const int F = p.f_out, m = lane & 15;
+    const int F = FULL ? 64 : p.f_out, m = lane & 15;     // FULL: f_out == 64, the column guards fold away
     float H[K][4];
     {
         // A long row's work items left partial sums of P in the slots: the 16 lanes of the group add them here (slot
@@ -186,7 +186,7 @@ __global__ __launch_bounds__(256) void agg_epilogue_kernel(acm_conv_agg_fwd_t p,
 // lanes x 4 columns of one row) -- so the projections and the head run right there, on lanes that would otherwise
 // idle through the next item's gather latency.  Same software pipeline over the work list as spmm_narrow_kernel.
 // Work items of long rows write their partial sums to the slots; agg_long_rows_kernel finishes those rows.
-template <int FP>
+template <int FP, bool FULL>
 __global__ __launch_bounds__(256) void agg_fused_kernel(acm_conv_agg_fwd_t p, CsrView csr, float* __restrict__ partial) {
     constexpr int K = 3, GS = 16, GPB = 16;
     __shared__ __attribute__((aligned(16))) float wlds[3 * FP * 64 + 3 * K * 64 + 16 * 2 * FP];
@@ -248,7 +248,7 @@ __global__ __launch_bounds__(256) void agg_fused_kernel(acm_conv_agg_fwd_t p, Cs
                     p.agg[(long)it.row * p.ld_agg + f] = v;          // P = A_low X, saved for the backward
                 }
             }
-            agg_fwd_row<FP, K>(p, wlds, hlds, scratch, mixm, it.row, lane, csr, nullptr, true);
+            agg_fwd_row<FP, K, FULL>(p, wlds, hlds, scratch, mixm, it.row, lane, csr, nullptr, true);
         } else if (gl == 0) {
             float* ps = partial + (long)it.slot * FP;
 #pragma unroll
@@ -267,6 +267,7 @@ __global__ __launch_bounds__(256) void agg_fused_kernel(acm_conv_agg_fwd_t p, Cs
 // one row the address coalescer sees 32 lines per 32 neighbours -- half the look-ups per byte, which is what bounds the
 // gather once the rows hit in L1/L2 (scripts/probe_gather.py: 63 us with every row in L1).
 // Lane (e = gl >> 1, h = gl & 1) of the 16-lane group: neighbours k0 + e + 8 u (u = 0..3), columns 4 h .. 4 h + 3.
+template <bool FULL>
 __global__ __launch_bounds__(256) void agg_fused_pair_kernel(acm_conv_agg_fwd_t p, CsrView csr, float* __restrict__ partial) {
     constexpr int FP = 8, K = 3, GPB = 16, U = 4, STEP = 8 * U;
     __shared__ __attribute__((aligned(16))) float wlds[3 * FP * 64 + 3 * K * 64 + 16 * 2 * FP];
@@ -349,7 +350,7 @@ __global__ __launch_bounds__(256) void agg_fused_pair_kernel(acm_conv_agg_fwd_t 
                     p.agg[(long)it.row * p.ld_agg + 4 * h + i] = val;
                 }
             }
-            agg_fwd_row<FP, K>(p, wlds, hlds, scratch, mixm, it.row, lane, csr, nullptr, true);
+            agg_fwd_row<FP, K, FULL>(p, wlds, hlds, scratch, mixm, it.row, lane, csr, nullptr, true);
         } else if (gl < 2) {
             float* ps = partial + (long)it.slot * FP + 4 * h;
 #pragma unroll
@@ -604,15 +605,21 @@ extern "C" int acm_conv_agg_fwd(const acm_csr_t* a, const acm_conv_agg_fwd_t* p,
             if (grid > 8192) grid = 8192;
             int tail = (int)((a->n_long + 15) / 16);
             if (tail > 1024) tail = 1024;
+            const bool full = p->f_out == 64;
             if (p->f_pad == 4) {
-                hipLaunchKernelGGL((agg_fused_kernel<4>), dim3(grid), dim3(256), 0, s, *p, cv, partial);
+                if (full) hipLaunchKernelGGL((agg_fused_kernel<4, true>), dim3(grid), dim3(256), 0, s, *p, cv, partial);
+                else hipLaunchKernelGGL((agg_fused_kernel<4, false>), dim3(grid), dim3(256), 0, s, *p, cv, partial);
                 if (tail) hipLaunchKernelGGL((agg_long_rows_kernel<4>), dim3(tail), dim3(256), 0, s, *p, cv, partial);
             } else {
                 const bool pair_lanes = getenv("ACM_AGG_NO_PAIR") == nullptr;
-                if (pair_lanes)
-                    hipLaunchKernelGGL(agg_fused_pair_kernel, dim3(grid), dim3(256), 0, s, *p, cv, partial);
+                if (pair_lanes && full)
+                    hipLaunchKernelGGL((agg_fused_pair_kernel<true>), dim3(grid), dim3(256), 0, s, *p, cv, partial);
+                else if (pair_lanes)
+                    hipLaunchKernelGGL((agg_fused_pair_kernel<false>), dim3(grid), dim3(256), 0, s, *p, cv, partial);
+                else if (full)
+                    hipLaunchKernelGGL((agg_fused_kernel<8, true>), dim3(grid), dim3(256), 0, s, *p, cv, partial);
                 else
-                    hipLaunchKernelGGL((agg_fused_kernel<8>), dim3(grid), dim3(256), 0, s, *p, cv, partial);
+                    hipLaunchKernelGGL((agg_fused_kernel<8, false>), dim3(grid), dim3(256), 0, s, *p, cv, partial);
                 if (tail) hipLaunchKernelGGL((agg_long_rows_kernel<8>), dim3(tail), dim3(256), 0, s, *p, cv, partial);
             }
             ACM_CHECK_HIP(hipGetLastError());

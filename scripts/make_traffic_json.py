@@ -12,7 +12,7 @@ import sys
 
 # bench label -> substrings identifying its kernels in the profiler's names
 LABELS = {
-    "conv_agg_fwd/F64k3i7": ["agg_fused_pair_kernel", "agg_fused_kernel<8>", "agg_long_rows_kernel<8>"],
+    "conv_agg_fwd/F64k3i7": ["agg_fused_pair_kernel", "agg_fused_kernel<8", "agg_long_rows_kernel<8>"],
     "conv_agg_bwd/F64k3i7": ["agg_bwd_kernel<8, 3>", "reduce_columns_kernel"],
     "conv_fwd/F2k3": ["spmm_narrow_kernel<2, 2, 16, true, EpiRaw>", "conv_fwd_rows_kernel<2, 2>"],
     "conv_bwd_spmm/F2k3": ["spmm_narrow_kernel<2, 2, 16, true, EpiBwd>", "spmm_fixup_narrow_kernel<2, 2, EpiBwd>"],
