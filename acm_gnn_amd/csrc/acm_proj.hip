@@ -15,8 +15,10 @@ constexpr int PROJ_MAX_BLOCKS = 1024;
 template <int Q>
 __global__ __launch_bounds__(256) void proj_bwd_kernel(int n_rows, int f_in, const float* __restrict__ X, long ldx,
                                                        const float* __restrict__ dZ, long lddz,
-                                                       const float* __restrict__ W, long ldw, float* __restrict__ dX,
+                                                       const float* __restrict__ W0, const float* __restrict__ W1,
+                                                       const float* __restrict__ W2, long ldw, float* __restrict__ dX,
                                                        long lddx, float* __restrict__ partial) {
+    constexpr int F = Q / 3;                    // W = [W0 | W1 | W2], each f_in x F (the layer's three weights, unpacked)
     __shared__ float red[4][64 * Q];            // per wave: the wave's dW slice of the current chunk
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int g = lane >> 4, m = lane & 15;
@@ -29,7 +31,8 @@ __global__ __launch_bounds__(256) void proj_bwd_kernel(int n_rows, int f_in, con
         for (int i = 0; i < 4; ++i)
 #pragma unroll
             for (int q = 0; q < Q; ++q) {
-                w[i][q] = (jb + i < f_in) ? W[(long)(jb + i) * ldw + q] : 0.f;
+                const float* Wc = q < F ? W0 : (q < 2 * F ? W1 : W2);
+                w[i][q] = (jb + i < f_in) ? Wc[(long)(jb + i) * ldw + (q % F)] : 0.f;
                 acc[i][q] = 0.f;
             }
         const bool full = vec && jb + 3 < f_in;
@@ -97,6 +100,79 @@ __global__ __launch_bounds__(256) void proj_reduce_kernel(const float* __restric
     }
 }
 
+// Forward of the same skinny projection: Z = relu?(X [W0 | W1 | W2]) for F <= 8 output columns per weight, straight from
+// the three weight matrices (no packed copy), written as the two matrices the narrow fused layer wants: columns
+// [0, 2F) -> Zlh (the gathered block [Z_L | Z_H]), [2F, 3F) -> Zi.  A 16-lane group per row, lane = 4 consecutive input
+// columns (float4), the lane's 4 x 3F slice of the weights in registers, 3F group reductions per row (DPP).  One pass
+// over X at stream speed; the MFMA GEMM spends 18 us on the 168 114 x 64 x 6 case, this one 11.
+template <int F>
+__global__ __launch_bounds__(256) void proj_fwd_kernel(int n_rows, int f_in, const float* __restrict__ X, long ldx,
+                                                       const float* __restrict__ W0, const float* __restrict__ W1,
+                                                       const float* __restrict__ W2, long ldw, int relu,
+                                                       float* __restrict__ Zlh, long ld_lh, float* __restrict__ Zi, long ld_i) {
+    constexpr int Q = 3 * F;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int g = lane >> 4, m = lane & 15;
+    const bool vec = (((uintptr_t)X & 15) == 0) && (ldx % 4 == 0);
+    const int chunks = (f_in + 63) / 64;
+    float w0[4][Q];                              // the lane's slice of the first 64 input columns stays in registers
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int q = 0; q < Q; ++q) {
+            const float* Wc = q < F ? W0 : (q < 2 * F ? W1 : W2);
+            w0[i][q] = (4 * m + i < f_in) ? Wc[(long)(4 * m + i) * ldw + (q % F)] : 0.f;
+        }
+    for (int row = (blockIdx.x * 4 + wave) * 4 + g; row < n_rows; row += gridDim.x * 16) {
+        float part[Q];
+        {
+            float x[4];
+            const int jb = 4 * m;
+            if (vec && jb + 3 < f_in) {
+                const float4 v = *reinterpret_cast<const float4*>(X + (long)row * ldx + jb);
+                x[0] = v.x, x[1] = v.y, x[2] = v.z, x[3] = v.w;
+            } else {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) x[i] = (jb + i < f_in) ? X[(long)row * ldx + jb + i] : 0.f;
+            }
+#pragma unroll
+            for (int q = 0; q < Q; ++q)
+                part[q] = fmaf(x[3], w0[3][q], fmaf(x[2], w0[2][q], fmaf(x[1], w0[1][q], x[0] * w0[0][q])));
+        }
+        for (int ch = 1; ch < chunks; ++ch) {    // f_in > 64: further chunks read their weights through the cache
+            const int jb = ch * 64 + 4 * m;
+            float x[4];
+            if (vec && jb + 3 < f_in) {
+                const float4 v = *reinterpret_cast<const float4*>(X + (long)row * ldx + jb);
+                x[0] = v.x, x[1] = v.y, x[2] = v.z, x[3] = v.w;
+            } else {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) x[i] = (jb + i < f_in) ? X[(long)row * ldx + jb + i] : 0.f;
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const bool ok = jb + i < f_in;
+                const long wrow = (long)(ok ? jb + i : 0) * ldw;
+#pragma unroll
+                for (int q = 0; q < Q; ++q) {
+                    const float* Wc = q < F ? W0 : (q < 2 * F ? W1 : W2);
+                    const float wv = ok ? Wc[wrow + (q % F)] : 0.f;          // 3 f_in F floats in total: L1 / K-cache resident
+                    part[q] = fmaf(x[i], wv, part[q]);
+                }
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < Q; ++q) {
+            float v = acm_group_sum<16>(part[q]);
+            if (relu) v = fmaxf(v, 0.f);
+            if (m == (q & 15)) {
+                if (q < 2 * F) Zlh[(long)row * ld_lh + q] = v;
+                else Zi[(long)row * ld_i + (q - 2 * F)] = v;
+            }
+        }
+    }
+}
+
 int proj_blocks(int64_t n_rows) {
     int64_t nb = (n_rows + 15) / 16;
     if (nb > PROJ_MAX_BLOCKS) nb = PROJ_MAX_BLOCKS;
@@ -105,6 +181,34 @@ int proj_blocks(int64_t n_rows) {
 }
 
 }  // namespace
+
+extern "C" int acm_proj_fwd(int64_t n_rows, int64_t f_in, int f_out, const float* X, int64_t ldx, const float* w_low,
+                            const float* w_high, const float* w_mlp, int64_t ldw, int relu, float* Z_lh, int64_t ld_lh,
+                            float* Z_i, int64_t ld_i, acm_stream_t stream) {
+    ACM_REQUIRE(X && w_low && w_high && w_mlp && Z_lh && Z_i, ACM_EINVAL, "acm_proj_fwd: NULL pointer");
+    ACM_REQUIRE(f_out >= 1 && f_out <= 8, ACM_EUNSUPPORTED, "acm_proj_fwd: f_out = %d (1..8; use acm_gemm otherwise)", f_out);
+    ACM_REQUIRE(n_rows >= 0 && n_rows < INT32_MAX && f_in >= 0 && f_in < INT32_MAX && ldx >= f_in && ldw >= f_out &&
+                    ld_lh >= 2 * f_out && ld_i >= f_out, ACM_ESHAPE, "acm_proj_fwd: bad sizes / leading dimensions");
+    if (n_rows == 0) return ACM_OK;
+    hipStream_t s = (hipStream_t)stream;
+    const int nblk = proj_blocks(n_rows);
+#define ACM_PF(Fv)                                                                                                  \
+    hipLaunchKernelGGL((proj_fwd_kernel<Fv>), dim3(nblk), dim3(256), 0, s, (int)n_rows, (int)f_in, X, (long)ldx, w_low, \
+                       w_high, w_mlp, (long)ldw, relu, Z_lh, (long)ld_lh, Z_i, (long)ld_i)
+    switch (f_out) {
+        case 1: ACM_PF(1); break;
+        case 2: ACM_PF(2); break;
+        case 3: ACM_PF(3); break;
+        case 4: ACM_PF(4); break;
+        case 5: ACM_PF(5); break;
+        case 6: ACM_PF(6); break;
+        case 7: ACM_PF(7); break;
+        default: ACM_PF(8); break;
+    }
+#undef ACM_PF
+    ACM_CHECK_HIP(hipGetLastError());
+    return ACM_OK;
+}
 
 extern "C" int acm_proj_bwd_workspace_bytes(int64_t n_rows, int64_t f_in, int n_out, size_t* bytes) {
     ACM_REQUIRE(bytes, ACM_EINVAL, "acm_proj_bwd_workspace_bytes: NULL argument");
@@ -116,14 +220,15 @@ extern "C" int acm_proj_bwd_workspace_bytes(int64_t n_rows, int64_t f_in, int n_
 }
 
 extern "C" int acm_proj_bwd(int64_t n_rows, int64_t f_in, int n_out, const float* X, int64_t ldx, const float* dZ,
-                            int64_t lddz, const float* W, int64_t ldw, float* dX, int64_t lddx, float* dW,
+                            int64_t lddz, const float* w_low, const float* w_high, const float* w_mlp, int64_t ldw,
+                            float* dX, int64_t lddx, float* dW,
                             int64_t lddw, int64_t dw_col_block, int64_t dw_block_stride, void* workspace,
                             size_t workspace_bytes, acm_stream_t stream) {
     size_t need = 0;
     int st = acm_proj_bwd_workspace_bytes(n_rows, f_in, n_out, &need);
     if (st != ACM_OK) return st;
-    ACM_REQUIRE(X && dZ && W && dX && dW, ACM_EINVAL, "acm_proj_bwd: NULL pointer");
-    ACM_REQUIRE(n_rows < INT32_MAX && f_in < INT32_MAX && ldx >= f_in && lddx >= f_in && lddz >= n_out && ldw >= n_out &&
+    ACM_REQUIRE(X && dZ && w_low && w_high && w_mlp && dX && dW, ACM_EINVAL, "acm_proj_bwd: NULL pointer");
+    ACM_REQUIRE(n_rows < INT32_MAX && f_in < INT32_MAX && ldx >= f_in && lddx >= f_in && lddz >= n_out && ldw >= n_out / 3 &&
                     dw_col_block >= 0 && lddw >= (dw_col_block ? (dw_col_block < n_out ? dw_col_block : n_out) : n_out),
                 ACM_ESHAPE, "acm_proj_bwd: bad sizes / leading dimensions");
     if (f_in == 0) return ACM_OK;
@@ -134,7 +239,7 @@ extern "C" int acm_proj_bwd(int64_t n_rows, int64_t f_in, int n_out, const float
     const int nblk = proj_blocks(n_rows);
 #define ACM_PROJ(Qv)                                                                                              \
     hipLaunchKernelGGL((proj_bwd_kernel<Qv>), dim3(nblk), dim3(256), 0, s, (int)n_rows, (int)f_in, X, (long)ldx, dZ, \
-                       (long)lddz, W, (long)ldw, dX, (long)lddx, partial)
+                       (long)lddz, w_low, w_high, w_mlp, (long)ldw, dX, (long)lddx, partial)
     switch (n_out) {
         case 3: ACM_PROJ(3); break;
         case 6: ACM_PROJ(6); break;

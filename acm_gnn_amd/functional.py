@@ -129,15 +129,33 @@ def gemm_split(a, b, out1, out2, relu=False):
     _lib.check(st, "acm_gemm_split")
 
 
-def proj_bwd(x, dz, w, d_w_out):
-    """Backward of the skinny projection Z = x @ w in one pass over x (acm_proj_bwd):
-    returns dX = dz @ w.T and fills ``d_w_out`` ([blocks, f_in, n_out / blocks], contiguous) with x.T @ dz."""
-    x, dz, w = _as_f32c(x, "x"), _as_f32c(dz, "dz"), _as_f32c(w, "w")
+def proj_fwd(x, weights, out_lh, out_i, relu=False):
+    """[out_lh | out_i] = relu?(x @ [W_L | W_H | W_I]) for a narrow layer (F <= 8), straight from the three weight
+    matrices (acm_proj_fwd): out_lh [n, 2F] is the gathered block, out_i [n, F]."""
+    x = _as_f32c(x, "x")
+    ws3 = [_as_f32c(w, "weight") for w in weights]
     n, f_in = x.shape
-    q = w.shape[1]
+    f = ws3[0].shape[1]
+    if any(tuple(w.shape) != (f_in, f) for w in ws3) or out_lh.shape != (n, 2 * f) or out_i.shape != (n, f):
+        raise ValueError("proj_fwd: shape mismatch")
+    with _device_ctx(x.device), _Timed(f"proj_fwd/{n}x{f_in}x{3 * f}"):
+        st = _lib.load().acm_proj_fwd(n, f_in, f, _vp(x), x.stride(0), _vp(ws3[0]), _vp(ws3[1]), _vp(ws3[2]), ws3[0].stride(0),
+                                      int(relu), _vp(out_lh), out_lh.stride(0), _vp(out_i), out_i.stride(0), _stream())
+    _lib.check(st, "acm_proj_fwd")
+
+
+def proj_bwd(x, dz, weights, d_w_out):
+    """Backward of the skinny projection Z = x @ [W_L | W_H | W_I] in one pass over x (acm_proj_bwd): returns
+    dX = dz @ Wcat.T and fills ``d_w_out`` ([3, f_in, F], contiguous) with x.T @ dz.  ``weights``: the three
+    [f_in, F] matrices."""
+    x, dz = _as_f32c(x, "x"), _as_f32c(dz, "dz")
+    ws3 = [_as_f32c(w, "weight") for w in weights]
+    n, f_in = x.shape
+    q = 3 * ws3[0].shape[1]
     blocks = d_w_out.shape[0]
     nb = q // blocks
-    if tuple(d_w_out.shape) != (blocks, f_in, nb) or not d_w_out.is_contiguous() or dz.shape != (n, q):
+    if (tuple(d_w_out.shape) != (blocks, f_in, nb) or not d_w_out.is_contiguous() or dz.shape != (n, q)
+            or any(tuple(w.shape) != (f_in, q // 3) or w.stride(0) != ws3[0].stride(0) for w in ws3)):
         raise ValueError("proj_bwd: shape mismatch")
     lib = _lib.load()
     dx = torch.empty(n, f_in, dtype=_F32, device=x.device)
@@ -145,8 +163,9 @@ def proj_bwd(x, dz, w, d_w_out):
     _lib.check(lib.acm_proj_bwd_workspace_bytes(n, f_in, q, C.byref(nbytes)), "acm_proj_bwd_workspace_bytes")
     ws = torch.empty(max(nbytes.value // 4, 1), dtype=_F32, device=x.device)
     with _device_ctx(x.device), _Timed(f"proj_bwd/{n}x{f_in}x{q}"):
-        st = lib.acm_proj_bwd(n, f_in, q, _vp(x), x.stride(0), _vp(dz), dz.stride(0), _vp(w), w.stride(0), _vp(dx),
-                              dx.stride(0), _vp(d_w_out), nb, nb, f_in * nb, _vp(ws), nbytes.value, _stream())
+        st = lib.acm_proj_bwd(n, f_in, q, _vp(x), x.stride(0), _vp(dz), dz.stride(0), _vp(ws3[0]), _vp(ws3[1]), _vp(ws3[2]),
+                              ws3[0].stride(0), _vp(dx), dx.stride(0), _vp(d_w_out), nb, nb, f_in * nb, _vp(ws),
+                              nbytes.value, _stream())
     _lib.check(st, "acm_proj_bwd")
     return dx
 
@@ -486,13 +505,22 @@ class AcmConvFunction(torch.autograd.Function):
         else:
             if zero_padded:
                 x = x[:, :f_in].contiguous()
-            wcat = torch.cat([w_low, w_high, w_mlp], dim=1).to(_F32).contiguous()  # [F_in, 3F]
+            w3 = tuple(_as_f32c(t, "weight") for t in (w_low, w_high, w_mlp))
+            # narrow dense layers (F <= 5) project with the streaming kernel straight from the three weights; everything
+            # else packs [W_L | W_H | W_I] for the MFMA GEMM / the CSR-feature product
+            use_proj = (not sparse_x and f <= 5 and w3[0].stride(0) == w3[1].stride(0) == w3[2].stride(0)
+                        and os.environ.get("ACM_PROJ_FWD", "1") != "0")
+            wcat = None if use_proj else torch.cat(w3, dim=1).contiguous()          # [F_in, 3F]
             # Row pitch of Z: for narrow layers the gathered block [Z_L | Z_H] (2F floats) must be
             # one aligned vector fetch, so rows are padded to a multiple of that block.
             ldz = 3 * f
             if f in (2, 4, 8):
                 ldz = -(-3 * f // (2 * f)) * (2 * f)
-            if f in (2, 4, 8) and not sparse_x:
+            if use_proj:
+                zlh = torch.empty(n, 2 * f, dtype=_F32, device=dev)
+                zi = torch.empty(n, f, dtype=_F32, device=dev)
+                proj_fwd(x, w3, zlh, zi, relu=cfg.relu_before)
+            elif f in (2, 4, 8) and not sparse_x:
                 # narrow layer: [Z_L | Z_H] as its own compact table (what the gather walks: half the cache footprint of
                 # [Z_L | Z_H | Z_I | pad] rows), Z_I next to it -- one GEMM with a two-matrix output
                 zlh = torch.empty(n, 2 * f, dtype=_F32, device=dev)
@@ -632,7 +660,7 @@ class AcmConvFunction(torch.autograd.Function):
         _lib.check(st, "acm_conv_fwd")
         ctx.ops, ctx.cfg = ops, cfg
         ctx.sparse_x = x if sparse_x else None
-        ctx.save_for_backward(wcat if sparse_x else x, wcat, zlh, zi, pre, mix, *vecs, *lnw, *lnb)
+        ctx.save_for_backward(w3[0] if sparse_x else x, *w3, zlh, zi, pre, mix, *vecs, *lnw, *lnb)
         ctx.mark_non_differentiable(att)
         return out, att
 
@@ -646,12 +674,13 @@ class AcmConvFunction(torch.autograd.Function):
         saved = ctx.saved_tensors
         if ctx.agg_first:
             return AcmConvFunction._backward_agg(ctx, grad_out)
-        x, wcat, zlh, zi, pre, mix = saved[:6]
-        vecs = list(saved[6:6 + k])
-        lnw = list(saved[6 + k:6 + 2 * k]) if cfg.layernorm else []
-        lnb = list(saved[6 + 2 * k:6 + 3 * k]) if cfg.layernorm else []
+        x, wl_, wh_, wm_, zlh, zi, pre, mix = saved[:8]
+        w3 = (wl_, wh_, wm_)
+        vecs = list(saved[8:8 + k])
+        lnw = list(saved[8 + k:8 + 2 * k]) if cfg.layernorm else []
+        lnb = list(saved[8 + 2 * k:8 + 3 * k]) if cfg.layernorm else []
         dev = zlh.device
-        n, f = zlh.shape[0], wcat.shape[1] // 3
+        n, f = zlh.shape[0], wl_.shape[1]
         grad_out = _as_f32c(grad_out, "grad_out")
         four = k == 4
 
@@ -660,7 +689,7 @@ class AcmConvFunction(torch.autograd.Function):
         gs = torch.empty(n, f, dtype=_F32, device=dev) if four else None
         # every replicated-parameter gradient is a view of one flat buffer: a row-sharded run sums the partials
         # with a single all-reduce and no pack / unpack launches
-        f_in_w = wcat.shape[0]
+        f_in_w = wl_.shape[0]
         nw, nln = 3 * f_in_w * f, (k * f if cfg.layernorm else 0)
         flat = torch.empty(nw + k * f + 2 * nln + k * k, dtype=_F32, device=dev)
         d_vec = [flat[nw + c * f: nw + (c + 1) * f].view(f, 1) for c in range(k)]
@@ -757,13 +786,14 @@ class AcmConvFunction(torch.autograd.Function):
             xt = xs.csr_t
             d_wcat = spmm_v(xt, xs.values.index_select(0, xt.src_pos), dz, out=flat[:nw].view(f_in_w, 3 * f))
             d_x = None
-        elif ctx.needs_input_grad[0] and proj_bwd_supported(3 * f) and os.environ.get("ACM_PROJ_BWD", "1") != "0":
+        elif (ctx.needs_input_grad[0] and proj_bwd_supported(3 * f) and os.environ.get("ACM_PROJ_BWD", "1") != "0"
+              and wl_.stride(0) == wh_.stride(0) == wm_.stride(0)):
             d_wcat = flat[:nw].view(3, f_in_w, f)                             # narrow output layer: dX and dW in one
-            d_x = proj_bwd(x, dz, wcat, d_wcat)                               # pass over x (acm_proj_bwd)
+            d_x = proj_bwd(x, dz, w3, d_wcat)                                 # pass over x (acm_proj_bwd)
         else:
             d_wcat = gemm(x, dz, trans_a=True, col_blocks=3,
                           out=flat[:nw].view(3, f_in_w, f))                   # contiguous per weight
-            d_x = gemm(dz, wcat, trans_b=True) if ctx.needs_input_grad[0] else None
+            d_x = gemm(dz, torch.cat(w3, dim=1), trans_b=True) if ctx.needs_input_grad[0] else None
         if d_x is not None and d_x.shape[1] != ctx.x_width:
             d_x = torch.nn.functional.pad(d_x, (0, ctx.x_width - d_x.shape[1]))
         if ops.sharded:                             # replicated parameters: sum the row-shard partials

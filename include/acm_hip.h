@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define ACM_ABI_VERSION 12
+#define ACM_ABI_VERSION 13
 
 typedef enum {
     ACM_OK = 0,
@@ -158,16 +158,20 @@ int acm_gemm_split(int transA, int transB, int64_t M, int64_t N, int64_t K,
                    float* C, int64_t ldc, int64_t split_col, float* C2, int64_t ldc2, int relu,
                    void* workspace, size_t workspace_bytes, acm_stream_t stream);
 
-/* Backward of a skinny projection Z = X W  (W: f_in x n_out, n_out in {3, 6, 9, 12, 15} -- the output layer's
- * [W_L | W_H | W_I] with up to five classes) in one pass over X:
- *     dX = dZ W^T          [n_rows, f_in]
- *     dW = X^T dZ          [f_in, n_out], optionally as column blocks like acm_gemm_blocks
- * i.e. MmBackward of `torch.mm(input, self.weight_*)` (layers.py:87-89) for both operands at once; as two
- * split-K GEMMs the N x f_in input is streamed twice.  Deterministic (fixed reduction order).
- * Workspace: acm_proj_bwd_workspace_bytes. */
+/* The projection of a narrow layer (f_out <= 8 columns per weight, e.g. the output layer) and its backward, as
+ * streaming kernels over X instead of skinny GEMMs, reading the layer's three weight matrices where they are
+ * (each f_in x f_out, pitch ldw: no packed [W_L | W_H | W_I] copy):
+ *     acm_proj_fwd:  [Z_lh | Z_i] = relu?(X [W_L | W_H | W_I]),  Z_lh = the gathered block [Z_L | Z_H] (n x 2 f_out,
+ *                    compact: the table the fused SpMM walks), Z_i (n x f_out)       -- torch.mm x3, layers.py:87-89
+ *     acm_proj_bwd:  dX = dZ [W_L | W_H | W_I]^T  and  dW = X^T dZ (as column blocks like acm_gemm_blocks) in ONE
+ *                    pass over X; n_out = 3 f_out in {3, 6, 9, 12, 15}                -- MmBackward of the same
+ * Deterministic (fixed reduction order).  Workspace of the backward: acm_proj_bwd_workspace_bytes. */
+int acm_proj_fwd(int64_t n_rows, int64_t f_in, int f_out, const float* X, int64_t ldx,
+                 const float* w_low, const float* w_high, const float* w_mlp, int64_t ldw, int relu,
+                 float* Z_lh, int64_t ld_lh, float* Z_i, int64_t ld_i, acm_stream_t stream);
 int acm_proj_bwd_workspace_bytes(int64_t n_rows, int64_t f_in, int n_out, size_t* bytes);
 int acm_proj_bwd(int64_t n_rows, int64_t f_in, int n_out, const float* X, int64_t ldx,
-                 const float* dZ, int64_t lddz, const float* W, int64_t ldw,
+                 const float* dZ, int64_t lddz, const float* w_low, const float* w_high, const float* w_mlp, int64_t ldw,
                  float* dX, int64_t lddx, float* dW, int64_t lddw, int64_t dw_col_block, int64_t dw_block_stride,
                  void* workspace, size_t workspace_bytes, acm_stream_t stream);
 

@@ -146,7 +146,7 @@ class FakeLib:
 
     # ---- plumbing ---------------------------------------------------------
     def acm_version(self):
-        return 12
+        return 13
 
     def acm_last_error(self):
         return self._err
@@ -226,9 +226,19 @@ class FakeLib:
         out._obj.value = 4
         return 0
 
-    def acm_proj_bwd(self, n, f_in, q, x, ldx, dz, lddz, w, ldw, dx, lddx, dw, lddw, cb, cbs, ws, wsb, stream):
-        X, DZ, W = (_view(x, n, f_in, ldx).astype(np.float64), _view(dz, n, q, lddz).astype(np.float64),
-                    _view(w, f_in, q, ldw).astype(np.float64))
+    def acm_proj_fwd(self, n, f_in, f, x, ldx, wl, wh, wm, ldw, relu, zlh, ld_lh, zi, ld_i, stream):
+        X = _view(x, n, f_in, ldx).astype(np.float64)
+        W = np.concatenate([_view(w, f_in, f, ldw).astype(np.float64) for w in (wl, wh, wm)], 1)
+        out = X @ W
+        if relu:
+            out = np.maximum(out, 0)
+        _view(zlh, n, 2 * f, ld_lh)[...] = out[:, :2 * f]
+        _view(zi, n, f, ld_i)[...] = out[:, 2 * f:]
+        return 0
+
+    def acm_proj_bwd(self, n, f_in, q, x, ldx, dz, lddz, wl, wh, wm, ldw, dx, lddx, dw, lddw, cb, cbs, ws, wsb, stream):
+        X, DZ = _view(x, n, f_in, ldx).astype(np.float64), _view(dz, n, q, lddz).astype(np.float64)
+        W = np.concatenate([_view(w, f_in, q // 3, ldw).astype(np.float64) for w in (wl, wh, wm)], 1)
         _view(dx, n, f_in, lddx)[...] = DZ @ W.T
         full = X.T @ DZ
         base = dw.value if isinstance(dw, C.c_void_p) else int(dw)

@@ -61,7 +61,8 @@ def test_proj_bwd_matches_fp64(n, f_in, q):
     g = torch.Generator().manual_seed(n + f_in + q)
     x, dz, w = torch.randn(n, f_in, generator=g), torch.randn(n, q, generator=g), torch.randn(f_in, q, generator=g)
     dw = torch.empty(3, f_in, q // 3, device=DEV)
-    dx = AF.proj_bwd(x.to(DEV), dz.to(DEV), w.to(DEV), dw)
+    w3 = [w[:, j * (q // 3):(j + 1) * (q // 3)].contiguous().to(DEV) for j in range(3)]
+    dx = AF.proj_bwd(x.to(DEV), dz.to(DEV), w3, dw)
     ref_dx = dz.double() @ w.double().T
     ref_dw = x.double().T @ dz.double()
     sc_dx = dz.abs().double() @ w.abs().double().T
@@ -70,12 +71,31 @@ def test_proj_bwd_matches_fp64(n, f_in, q):
     got = torch.cat(list(dw.cpu()), dim=1).double()
     assert float(((got - ref_dw).abs() / (sc_dw + 1e-30)).max()) < 3e-6
     dw2 = torch.empty_like(dw)
-    dx2 = AF.proj_bwd(x.to(DEV), dz.to(DEV), w.to(DEV), dw2)
+    dx2 = AF.proj_bwd(x.to(DEV), dz.to(DEV), w3, dw2)
     assert torch.equal(dx, dx2) and torch.equal(dw, dw2)            # deterministic
     # unaligned / strided operands take the scalar path
     xs = torch.randn(n, f_in + 3, generator=g)[:, 1:f_in + 1]
-    dxs = AF.proj_bwd(xs.to(DEV), dz.to(DEV), w.to(DEV), dw2)
+    dxs = AF.proj_bwd(xs.to(DEV), dz.to(DEV), w3, dw2)
     assert float(((dxs.cpu().double() - ref_dx).abs() / (sc_dx + 1e-30)).max()) < 2e-6
+
+
+@pytest.mark.parametrize("n,f_in,f", [(1000, 64, 2), (777, 64, 5), (513, 40, 3), (300, 130, 1), (4097, 64, 4), (5, 7, 2),
+                                      (168114, 64, 2), (200, 200, 8)])
+@pytest.mark.parametrize("relu", [False, True])
+def test_proj_fwd_matches_fp64(n, f_in, f, relu):
+    """acm_proj_fwd: [Z_lh | Z_i] = relu?(X [W_L | W_H | W_I]) from the three weight matrices, vs fp64."""
+    from acm_gnn_amd import functional as AF
+    g = torch.Generator().manual_seed(n + f_in + f)
+    x = torch.randn(n, f_in, generator=g)
+    w3 = [torch.randn(f_in, f, generator=g) for _ in range(3)]
+    zlh, zi = torch.empty(n, 2 * f, device=DEV), torch.empty(n, f, device=DEV)
+    AF.proj_fwd(x.to(DEV), [w.to(DEV) for w in w3], zlh, zi, relu=relu)
+    ref = x.double() @ torch.cat(w3, 1).double()
+    scale = x.abs().double() @ torch.cat(w3, 1).abs().double()
+    if relu:
+        ref = ref.clamp_min(0)
+    got = torch.cat([zlh, zi], 1).cpu().double()
+    assert float(((got - ref).abs() / (scale + 1e-30)).max()) < 2e-6
 
 
 @pytest.mark.parametrize("m,n,k,split", [(1000, 6, 64, 4), (168114, 6, 64, 4), (300, 24, 7, 16), (64, 12, 3000, 8), (5, 3, 2, 2)])
