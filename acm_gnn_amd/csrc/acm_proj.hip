@@ -26,15 +26,23 @@ __global__ __launch_bounds__(256) void proj_bwd_kernel(int n_rows, int f_in, con
     float* slab = partial + (long)blockIdx.x * f_in * Q;
     for (int j0 = 0; j0 < f_in; j0 += 64) {
         const int jb = j0 + 4 * m;              // first of this lane's four columns
+        // this chunk of [W0 | W1 | W2] through LDS (coalesced, once per block; `red` is free until the end of the chunk),
+        // then the lane's 4 x Q slice into registers
+        for (int e = threadIdx.x; e < 64 * Q; e += 256) {
+            const int j = j0 + e / Q, q = e % Q;
+            const float* Wc = q < F ? W0 : (q < 2 * F ? W1 : W2);
+            red[0][e] = j < f_in ? Wc[(long)j * ldw + (q % F)] : 0.f;
+        }
+        __syncthreads();
         float w[4][Q], acc[4][Q];
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
             for (int q = 0; q < Q; ++q) {
-                const float* Wc = q < F ? W0 : (q < 2 * F ? W1 : W2);
-                w[i][q] = (jb + i < f_in) ? Wc[(long)(jb + i) * ldw + (q % F)] : 0.f;
+                w[i][q] = red[0][(4 * m + i) * Q + q];
                 acc[i][q] = 0.f;
             }
+        __syncthreads();                        // everyone has its slice before `red` is reused for the reduction
         const bool full = vec && jb + 3 < f_in;
         for (int row = (blockIdx.x * 4 + wave) * 4 + g; row < n_rows; row += gridDim.x * 16) {
             float dz[Q];
@@ -114,15 +122,22 @@ __global__ __launch_bounds__(256) void proj_fwd_kernel(int n_rows, int f_in, con
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int g = lane >> 4, m = lane & 15;
     const bool vec = (((uintptr_t)X & 15) == 0) && (ldx % 4 == 0);
+    const bool out_vec = (((uintptr_t)Zlh & 15) == 0) && (ld_lh % 4 == 0) && (((uintptr_t)Zi & 7) == 0) && (ld_i % 2 == 0);
     const int chunks = (f_in + 63) / 64;
-    float w0[4][Q];                              // the lane's slice of the first 64 input columns stays in registers
+    // the first 64 input columns of [W0 | W1 | W2]: staged once per block through LDS (coalesced), then the lane's
+    // 4 x Q slice stays in registers (per-lane global loads of it cost as much as the whole stream of X)
+    __shared__ float wl[64 * Q];
+    for (int e = threadIdx.x; e < 64 * Q; e += 256) {
+        const int j = e / Q, q = e % Q;
+        const float* Wc = q < F ? W0 : (q < 2 * F ? W1 : W2);
+        wl[e] = j < f_in ? Wc[(long)j * ldw + (q % F)] : 0.f;
+    }
+    __syncthreads();
+    float w0[4][Q];
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int q = 0; q < Q; ++q) {
-            const float* Wc = q < F ? W0 : (q < 2 * F ? W1 : W2);
-            w0[i][q] = (4 * m + i < f_in) ? Wc[(long)(4 * m + i) * ldw + (q % F)] : 0.f;
-        }
+        for (int q = 0; q < Q; ++q) w0[i][q] = wl[(4 * m + i) * Q + q];
     for (int row = (blockIdx.x * 4 + wave) * 4 + g; row < n_rows; row += gridDim.x * 16) {
         float part[Q];
         {
@@ -163,12 +178,21 @@ __global__ __launch_bounds__(256) void proj_fwd_kernel(int n_rows, int f_in, con
         }
 #pragma unroll
         for (int q = 0; q < Q; ++q) {
-            float v = acm_group_sum<16>(part[q]);
-            if (relu) v = fmaxf(v, 0.f);
-            if (m == (q & 15)) {
-                if (q < 2 * F) Zlh[(long)row * ld_lh + q] = v;
-                else Zi[(long)row * ld_i + (q - 2 * F)] = v;
+            part[q] = acm_group_sum<16>(part[q]);               // every lane of the group ends with the total
+            if (relu) part[q] = fmaxf(part[q], 0.f);
+        }
+        if (F == 2 && out_vec) {                                // 16 + 8 bytes per row: two stores by the group leader
+            if (m == 0) {
+                *reinterpret_cast<float4*>(Zlh + (long)row * ld_lh) = make_float4(part[0], part[1], part[2], part[3]);
+                *reinterpret_cast<float2*>(Zi + (long)row * ld_i) = make_float2(part[4], part[5]);
             }
+        } else {
+#pragma unroll
+            for (int q = 0; q < Q; ++q)
+                if (m == (q & 15)) {
+                    if (q < 2 * F) Zlh[(long)row * ld_lh + q] = part[q];
+                    else Zi[(long)row * ld_i + (q - 2 * F)] = part[q];
+                }
         }
     }
 }
