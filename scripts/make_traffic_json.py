@@ -18,7 +18,7 @@ LABELS = {
     "conv_bwd_spmm/F2k3": ["spmm_narrow_kernel<2, 2, 16, true, EpiBwd>", "spmm_fixup_narrow_kernel<2, 2, EpiBwd>"],
     "conv_bwd_local/F2k3": ["conv_bwd_local_kernel<LayPacked<2>, 32, 3>", "conv_bwd_reduce_kernel"],
     "proj_bwd/168114x64x6": ["proj_bwd_kernel<6>", "proj_reduce_kernel"],
-    "gemm_NN/168114x6x64": ["gemm_kernel<4, 1, 4, 1, false, false>"],
+    "proj_fwd/168114x64x6": ["proj_fwd_kernel<2>"],
 }
 
 
