@@ -508,7 +508,8 @@ class AcmConvFunction(torch.autograd.Function):
             w3 = tuple(_as_f32c(t, "weight") for t in (w_low, w_high, w_mlp))
             # narrow dense layers (F <= 5) project with the streaming kernel straight from the three weights; everything
             # else packs [W_L | W_H | W_I] for the MFMA GEMM / the CSR-feature product
-            use_proj = (not sparse_x and f <= 5 and w3[0].stride(0) == w3[1].stride(0) == w3[2].stride(0)
+            use_proj = (not sparse_x and f <= 5 and f_in <= 64     # wider inputs: the MFMA GEMM is the faster stream
+                        and w3[0].stride(0) == w3[1].stride(0) == w3[2].stride(0)
                         and os.environ.get("ACM_PROJ_FWD", "1") != "0")
             wcat = None if use_proj else torch.cat(w3, dim=1).contiguous()          # [F_in, 3F]
             # Row pitch of Z: for narrow layers the gathered block [Z_L | Z_H] (2F floats) must be
