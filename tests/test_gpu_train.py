@@ -40,7 +40,7 @@ def _set_params(module, rec):
             sd[k[6:]].copy_(torch.from_numpy(v))
 
 
-def _trajectory(rec, adj_low, adj_high, adj_un, x, labels, train_idx, use_graph):
+def _trajectory(rec, adj_low, adj_high, adj_un, x, labels, train_idx, use_graph, fused=False):
     from acm_gnn_amd import GCN, train as T
     from acm_gnn_amd.graph import clear_cache
     clear_cache()
@@ -49,8 +49,13 @@ def _trajectory(rec, adj_low, adj_high, adj_un, x, labels, train_idx, use_graph)
     model = GCN(x.shape[1], cfg["hidden"], int(labels.max()) + 1, 2, n, 0.0, cfg["model_type"], cfg["structure_info"],
                 variant=bool(cfg["variant"]), attn_layernorm=bool(cfg["attn_layernorm"])).to(DEV)
     _set_params(model, rec)
-    opt_cls = torch.optim.Adam if cfg["optimizer"] == "adam" else torch.optim.AdamW
-    opt = opt_cls(model.parameters(), lr=cfg["lr"], weight_decay=cfg["weight_decay"], capturable=use_graph)
+    if fused:                                   # acm_adam_step against the reference's recorded trajectory
+        from acm_gnn_amd import FusedAdam, FusedAdamW
+        opt = (FusedAdam if cfg["optimizer"] == "adam" else FusedAdamW)(model.parameters(), lr=cfg["lr"],
+                                                                         weight_decay=cfg["weight_decay"])
+    else:
+        opt_cls = torch.optim.Adam if cfg["optimizer"] == "adam" else torch.optim.AdamW
+        opt = opt_cls(model.parameters(), lr=cfg["lr"], weight_decay=cfg["weight_decay"], capturable=use_graph)
     w = T.row_weights(train_idx.to(DEV), n)
     step = T.TrainStep(model, opt, x.to(DEV), adj_low.to(DEV), labels.to(DEV), w, adj_high.to(DEV),
                        adj_un.to(DEV) if adj_un is not None else None, use_graph=False)
@@ -60,8 +65,9 @@ def _trajectory(rec, adj_low, adj_high, adj_un, x, labels, train_idx, use_graph)
     return np.asarray(losses), out.cpu().numpy()
 
 
+@pytest.mark.parametrize("fused", [False, True], ids=["torch_adam", "fused_adam"])
 @pytest.mark.parametrize("tag", ["acmgcn_adam", "acmgcnp_s1_adam"])
-def test_cora_adam_trajectory_matches_reference(tag):
+def test_cora_adam_trajectory_matches_reference(tag, fused):
     """10 Adam steps recorded from the reference's own train_model on Cora (dense A_low dialect)."""
     rec = load_npz(os.path.join(GOLDEN, f"traj_cora_{tag}.npz"))
     g = load_npz(os.path.join(GOLDEN, "graph_cora.npz"))
@@ -72,16 +78,17 @@ def test_cora_adam_trajectory_matches_reference(tag):
     adj_high = csr_to_coo_tensor(g, "adj_high")
     adj_un = csr_to_coo_tensor(g, "adj_un") if rec["cfg"]["structure_info"] else None
     train_idx = torch.from_numpy(np.nonzero(g["train_mask"])[0])
-    losses, final = _trajectory(rec, adj_low, adj_high, adj_un, x, torch.from_numpy(g["labels"]), train_idx, False)
+    losses, final = _trajectory(rec, adj_low, adj_high, adj_un, x, torch.from_numpy(g["labels"]), train_idx, False, fused)
     np.testing.assert_allclose(losses, rec["losses"], rtol=5e-5)
     np.testing.assert_allclose(final, rec["final_logits"], rtol=5e-3, atol=2e-3)   # Adam amplifies 1e-7 gradient noise
 
 
-def test_geometric_adamw_trajectory_matches_reference():
+@pytest.mark.parametrize("fused", [False, True], ids=["torch_adamw", "fused_adamw"])
+def test_geometric_adamw_trajectory_matches_reference(fused):
     rec = load_npz(os.path.join(GOLDEN, "traj_geometric_acmgcnp_adamw.npz"))
     low, high, _, _ = graph_tensors("geometric")
     losses, final = _trajectory(rec, low, high, None, torch.from_numpy(rec["x"]), torch.from_numpy(rec["labels"]),
-                                torch.from_numpy(rec["train_idx"]), False)
+                                torch.from_numpy(rec["train_idx"]), False, fused)
     np.testing.assert_allclose(losses, rec["losses"], rtol=5e-5)
     np.testing.assert_allclose(final, rec["final_logits"], rtol=5e-3, atol=2e-3)   # Adam amplifies 1e-7 gradient noise
 
