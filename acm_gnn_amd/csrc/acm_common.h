@@ -9,7 +9,9 @@
 
 #define ACM_WAVE 64
 #define ACM_NXCD 8
-#define ACM_DEFAULT_CHUNK 256
+#define ACM_MIN_CHUNK 128
+#define ACM_MAX_CHUNK 1024
+#define ACM_GROUPS_IN_FLIGHT 8192  // 256 CUs x 8 waves x four 16-lane groups
 #define ACM_LN_EPS 1e-5f
 
 void acm_set_error(const char* fmt, ...);

@@ -68,7 +68,15 @@ void build_items(const std::vector<int32_t>& indptr, int chunk, std::vector<AcmI
 
 // Finish a handle whose indptr/indices/vals device arrays are already in place.
 int finish_handle(acm_csr* a, const std::vector<int32_t>& h_indptr, int chunk) {
-    a->chunk = chunk > 0 ? chunk : ACM_DEFAULT_CHUNK;
+    // chunk <= 0: size the chunks to the work one 16-lane group gets when the chip is full (256 CUs x 8 waves
+    // x 4 groups): long chunks mean fewer partial sums and a shorter fix-up pass, but one item must not
+    // outlast the average group's whole share.  Measured optimum per graph (profiles/r01_o_chunk_sweep.txt):
+    // 128 for squirrel/chameleon (<=0.4 M nnz), 256 for penn94/arxiv-year (2.5 M), 1024 for twitch-gamer (13.7 M).
+    const char* env = getenv("ACM_CHUNK");
+    const int env_chunk = env ? atoi(env) : 0;
+    int auto_chunk = ACM_MIN_CHUNK;
+    while (auto_chunk < ACM_MAX_CHUNK && 2 * (int64_t)auto_chunk <= a->nnz / ACM_GROUPS_IN_FLIGHT) auto_chunk *= 2;
+    a->chunk = chunk > 0 ? chunk : (env_chunk > 0 ? env_chunk : auto_chunk);
     std::vector<AcmItem> items;
     std::vector<AcmLongRow> longs;
     build_items(h_indptr, a->chunk, items, longs, a->n_slots, a->max_degree);
@@ -211,7 +219,7 @@ extern "C" int acm_csr_transpose(const acm_csr_t* a, int chunk, acm_csr_t** out)
             st = ACM_EHIP;
         }
     }
-    if (st == ACM_OK) st = finish_handle(t, tp, chunk > 0 ? chunk : a->chunk);
+    if (st == ACM_OK) st = finish_handle(t, tp, chunk);
     if (st != ACM_OK) {
         free_handle(t);
         return st;
@@ -249,7 +257,7 @@ extern "C" int acm_csr_slice_rows(const acm_csr_t* a, int64_t row_begin, int64_t
             st = ACM_EHIP;
         }
     }
-    if (st == ACM_OK) st = finish_handle(s, ip, chunk > 0 ? chunk : a->chunk);
+    if (st == ACM_OK) st = finish_handle(s, ip, chunk);
     if (st != ACM_OK) {
         free_handle(s);
         return st;

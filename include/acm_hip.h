@@ -57,7 +57,10 @@ const char* acm_last_error(void);
  * is the global node count.
  * Replaces: the sparse-COO tensors built at ACM-Geometric/train.py:75-81 /
  * ACM-Pytorch/utils.py:619-629 and the per-call COO coalesce inside
- * torch.spmm (G:87-103).  `chunk` <= 0 selects the default (256).
+ * torch.spmm (G:87-103).  `chunk` <= 0 sizes the chunks to the graph: a power of two in 128..1024
+ * chosen so that one work item stays below the share of a 16-lane group when the chip is full
+ * (nnz / 8192); the environment variable ACM_CHUNK overrides that choice for tuning.  The same rule
+ * applies to acm_csr_transpose and acm_csr_slice_rows (computed from the new handle's own nnz).
  *
  * vals_dev == NULL makes a PATTERN-ONLY operator: every stored entry counts as 1 and the kernels read no
  * value stream.  This is the form the filterbank wants: A_low = D^-1 (A + I) has one value per row, so

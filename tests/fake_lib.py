@@ -30,7 +30,11 @@ def _vec(ptr, n, dtype=np.float32):
 class _Csr:
     def __init__(self, indptr, indices, vals, n_cols, chunk):
         self.indptr, self.indices, self.vals = indptr.copy(), indices.copy(), vals.copy()
-        self.n_rows, self.n_cols, self.chunk = len(indptr) - 1, n_cols, chunk or 256
+        self.n_rows, self.n_cols = len(indptr) - 1, n_cols
+        auto = 128
+        while auto < 1024 and 2 * auto <= len(indices) // 8192:
+            auto *= 2
+        self.chunk = chunk or auto
 
     def dense_mul(self, g):
         import scipy.sparse as sp
@@ -178,7 +182,7 @@ class FakeLib:
         m = sp.csr_matrix((a.vals, a.indices, a.indptr), shape=(a.n_rows, a.n_cols)).T.tocsr()
         m.sort_indices()
         t = _Csr(m.indptr.astype(np.int32), m.indices.astype(np.int32), m.data.astype(np.float32),
-                 a.n_rows, chunk or a.chunk)
+                 a.n_rows, chunk)
         pos = sp.csr_matrix((np.arange(1, len(a.vals) + 1, dtype=np.float64), a.indices, a.indptr),
                             shape=(a.n_rows, a.n_cols)).T.tocsr()
         pos.sort_indices()
@@ -189,7 +193,7 @@ class FakeLib:
     def acm_csr_slice_rows(self, h, b, e, chunk, out):
         a = self._get(h)
         ip = a.indptr[b:e + 1] - a.indptr[b]
-        obj = _Csr(ip, a.indices[a.indptr[b]:a.indptr[e]], a.vals[a.indptr[b]:a.indptr[e]], a.n_cols, chunk or a.chunk)
+        obj = _Csr(ip, a.indices[a.indptr[b]:a.indptr[e]], a.vals[a.indptr[b]:a.indptr[e]], a.n_cols, chunk)
         obj.unit = getattr(a, "unit", False)
         return self._new(obj, out)
 

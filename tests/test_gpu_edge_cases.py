@@ -67,14 +67,18 @@ def test_one_feature_one_class(monkeypatch):
     _check(a, 1, 2, x_grad=False, monkeypatch=monkeypatch, agg=True)
 
 
+@pytest.mark.parametrize("chunk", [0, 256, 1024])
 @pytest.mark.parametrize("n", [300, 1025, 3000])
-def test_star_and_chunk_boundaries(n, monkeypatch):
-    """Node 0 is connected to everybody (a row of n entries, split into ceil(n / 256) work items); a few rows have
-    exactly 255 / 256 / 257 entries after the +I."""
+def test_star_and_chunk_boundaries(n, chunk, monkeypatch):
+    """Node 0 is connected to everybody (a row of n entries, split into ceil(n / chunk) work items); a few rows have
+    exactly chunk - 1 / chunk / chunk + 1 entries after the +I, for the automatic chunk of a small graph (128) and
+    for the chunks larger graphs get (ACM_CHUNK pins them here)."""
+    if chunk:
+        monkeypatch.setenv("ACM_CHUNK", str(chunk))
     a = np.zeros((n, n))
     a[0, 1:] = 1
     a[1:, 0] = 1
-    for r, deg in ((5, 254), (6, 255), (7, 256)):
+    for r, deg in ((3, 126), (4, 127), (5, 128), (6, 254), (7, 255), (8, 256)):
         cols = np.arange(10, 10 + deg)
         a[r, cols] = 1
         a[cols, r] = 1
