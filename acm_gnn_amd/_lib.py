@@ -14,7 +14,7 @@ c_i32p = C.POINTER(C.c_int32)
 
 ACM_OK = 0
 STATUS_NAMES = {1: "ACM_EINVAL", 2: "ACM_ESHAPE", 3: "ACM_EHIP", 4: "ACM_EUNSUPPORTED", 5: "ACM_ENOMEM"}
-ABI_VERSION = 13
+ABI_VERSION = 14
 
 # every symbol include/acm_hip.h declares
 EXPORTED_SYMBOLS = (
@@ -23,6 +23,7 @@ EXPORTED_SYMBOLS = (
     "acm_gemm", "acm_gemm_blocks", "acm_gemm_split", "acm_proj_fwd", "acm_proj_bwd_workspace_bytes", "acm_proj_bwd", "acm_spmm", "acm_spmm_v", "acm_spmm_ex", "acm_cast_bf16", "acm_conv_fwd", "acm_conv_bwd_local_workspace_bytes",
     "acm_conv_bwd_local", "acm_conv_bwd_spmm", "acm_conv_agg_fwd", "acm_conv_agg_bwd_workspace_bytes",
     "acm_conv_agg_bwd", "acm_nll_loss_workspace_bytes", "acm_nll_loss", "acm_adam_step", "acm_dropout",
+    "acm_reduce_flush",
 )
 
 
@@ -74,7 +75,7 @@ class ConvBwdLocal(C.Structure):
                 ("d_att_vec", C.c_void_p * 4), ("d_ln_weight", C.c_void_p * 4),
                 ("d_ln_bias", C.c_void_p * 4), ("d_att_mix", C.c_void_p),
                 ("post_scale", C.c_void_p), ("ld_post_scale", C.c_int64), ("post_relu", C.c_int32),
-                ("g_scale", C.c_void_p), ("post_drop", Dropout)]
+                ("g_scale", C.c_void_p), ("post_drop", Dropout), ("defer", C.c_void_p)]
 
 
 class ConvBwdSpmm(C.Structure):
@@ -121,7 +122,18 @@ class ConvAggBwd(C.Structure):
                 ("n_channels", C.c_int32), ("ps", C.c_void_p), ("ld_ps", C.c_int64),
                 ("ss", C.c_void_p), ("ld_ss", C.c_int64), ("deg", C.c_void_p),
                 ("g_struc", C.c_void_p), ("ld_g_struc", C.c_int64), ("g_struc_scale", C.c_void_p),
-                ("post_drop", Dropout)]
+                ("post_drop", Dropout), ("defer", C.c_void_p)]
+
+
+class ReduceSeg(C.Structure):
+    _fields_ = [("partial", C.c_void_p), ("nblk", C.c_int32), ("row_stride", C.c_int32),
+                ("q0", C.c_int32), ("len", C.c_int32), ("dst", C.c_void_p),
+                ("inner", C.c_int32), ("col_block", C.c_int32),
+                ("outer_stride", C.c_int64), ("block_stride", C.c_int64)]
+
+
+class ReduceList(C.Structure):
+    _fields_ = [("n", C.c_int32), ("cap", C.c_int32), ("segs", C.POINTER(ReduceSeg))]
 
 
 class SpmmOpts(C.Structure):
@@ -161,7 +173,7 @@ def _declare(lib):
     lib.acm_gemm.argtypes = [i32, i32, i64, i64, i64, vp, i64, vp, i64, vp, i64, i32, vp, sz, vp]
     lib.acm_proj_bwd_workspace_bytes.argtypes = [i64, i64, i32, C.POINTER(sz)]
     lib.acm_proj_fwd.argtypes = [i64, i64, i32, vp, i64, vp, vp, vp, i64, i32, vp, i64, vp, i64, vp]
-    lib.acm_proj_bwd.argtypes = [i64, i64, i32, vp, i64, vp, i64, vp, vp, vp, i64, vp, i64, vp, i64, i64, i64, vp, sz, vp]
+    lib.acm_proj_bwd.argtypes = [i64, i64, i32, vp, i64, vp, i64, vp, vp, vp, i64, vp, i64, vp, i64, i64, i64, vp, sz, vp, vp]
     lib.acm_gemm_split.argtypes = [i32, i32, i64, i64, i64, vp, i64, vp, i64, vp, i64, i64, vp, i64, i32, vp, sz, vp]
     lib.acm_gemm_blocks.argtypes = [i32, i32, i64, i64, i64, vp, i64, vp, i64, vp, i64, i64, i64, i32, vp, sz, vp]
     lib.acm_spmm.argtypes = [vp, vp, i64, i32, vp, i64, vp, sz, vp]
@@ -178,7 +190,8 @@ def _declare(lib):
     lib.acm_conv_agg_bwd_workspace_bytes.argtypes = [i64, i32, i32, C.POINTER(sz)]
     lib.acm_conv_agg_bwd.argtypes = [i64, C.POINTER(ConvAggBwd), vp, sz, vp]
     lib.acm_nll_loss_workspace_bytes.argtypes = [i64, C.POINTER(sz)]
-    lib.acm_nll_loss.argtypes = [i64, i32, vp, i64, vp, vp, vp, vp, i64, vp, sz, vp]
+    lib.acm_nll_loss.argtypes = [i64, i32, vp, i64, vp, vp, vp, vp, i64, vp, sz, vp, vp]
+    lib.acm_reduce_flush.argtypes = [vp, vp]
     for name in EXPORTED_SYMBOLS:
         fn = getattr(lib, name)
         if name not in ("acm_version", "acm_last_error", "acm_csr_destroy"):

@@ -72,6 +72,9 @@ struct CsrView {
     const float* vals;
 };
 
+// Second phase of a partial-sum reduction: launch `segs` now (defer == NULL) or append them to the caller's list.
+int acm_reduce_emit(acm_reduce_list_t* defer, const acm_reduce_seg_t* segs, int n, hipStream_t st);
+
 static inline CsrView acm_view(const acm_csr* a) {
     CsrView v;
     v.items = a->items;

@@ -1078,39 +1078,27 @@ __global__ __launch_bounds__(256) void conv_bwd_local_grouped_kernel(acm_conv_bw
         partial[(long)blockIdx.x * npg + q] = (lds[q] + lds[npg + q]) + (lds[2 * npg + q] + lds[3 * npg + q]);
 }
 
-// grid = npg blocks; block q sums partial[0..nblk)[q] in a fixed tree order.
-__global__ __launch_bounds__(256) void conv_bwd_reduce_kernel(acm_conv_bwd_local_t p, int nblk,
-                                                              const float* __restrict__ partial) {
-    __shared__ float red[256];
-    const int F = p.f_out, k = p.n_channels;
-    const int npg = 3 * k * F + k * k;
-    const int q = blockIdx.x;
-    float s = 0.f;
-    for (int b = threadIdx.x; b < nblk; b += 256) s += partial[(long)b * npg + q];
-    red[threadIdx.x] = s;
-    __syncthreads();
-    for (int m = 128; m >= 1; m >>= 1) {
-        if ((int)threadIdx.x < m) red[threadIdx.x] += red[threadIdx.x + m];
-        __syncthreads();
-    }
-    if (threadIdx.x == 0) {
-        const float v = red[0];
-        if (q < 3 * k * F) {
-            const int which = q / (k * F), c = (q / F) % k, col = q % F;
-            float* dst = which == 0 ? p.d_att_vec[c] : (which == 1 ? p.d_ln_weight[c] : p.d_ln_bias[c]);
-            if (dst) dst[col] = v;
-        } else {
-            p.d_att_mix[q - 3 * k * F] = v;
-        }
-    }
-}
-
 namespace {
 int bwd_local_blocks(int64_t n_rows, int rows_per_block) {
     int64_t nb = (n_rows + rows_per_block - 1) / rows_per_block;
     if (nb > 1024) nb = 1024;
     if (nb < 1) nb = 1;
     return (int)nb;
+}
+
+// Second phase of K3: the [d att_vec | d ln_weight | d ln_bias] (k x F each) | d att_mix (k x k) columns of the
+// per-block partials go to up to 3k + 1 destinations.
+int bwd_local_reduce(const acm_conv_bwd_local_t* p, const float* partial, int nblk, hipStream_t st) {
+    const int F = p->f_out, k = p->n_channels, npg = 3 * k * F + k * k;
+    acm_reduce_seg_t segs[13];
+    int n = 0;
+    for (int which = 0; which < 3; ++which)
+        for (int c = 0; c < k; ++c) {
+            float* dst = which == 0 ? p->d_att_vec[c] : (which == 1 ? p->d_ln_weight[c] : p->d_ln_bias[c]);
+            if (dst) segs[n++] = {partial, nblk, npg, (which * k + c) * F, F, dst, F, 0, 0, 0};
+        }
+    segs[n++] = {partial, nblk, npg, 3 * k * F, k * k, p->d_att_mix, k * k, 0, 0, 0};
+    return acm_reduce_emit(p->defer, segs, n, st);
 }
 int bwd_rows_per_wave(int F) { return F > 64 ? 1 : (F > 16 ? 4 : (F > 8 ? 4 : (F > 4 ? 8 : (F > 2 ? 16 : 32)))); }
 }  // namespace
@@ -1160,9 +1148,7 @@ extern "C" int acm_conv_bwd_local(int64_t n_rows, const acm_conv_bwd_local_t* p,
         else
             hipLaunchKernelGGL((conv_bwd_local_grouped_kernel<4>), dim3(nblk), dim3(256), lds, st, *p, (int)n_rows, partial);
         ACM_CHECK_HIP(hipGetLastError());
-        hipLaunchKernelGGL(conv_bwd_reduce_kernel, dim3(npg), dim3(256), 0, st, *p, nblk, partial);
-        ACM_CHECK_HIP(hipGetLastError());
-        return ACM_OK;
+        return bwd_local_reduce(p, partial, nblk, st);
     }
 #define ACM_BWD(LAY, RPW)                                                                                   \
     do {                                                                                                    \
@@ -1181,7 +1167,5 @@ extern "C" int acm_conv_bwd_local(int64_t n_rows, const acm_conv_bwd_local_t* p,
     else ACM_BWD(LayPacked<2>, 32);
 #undef ACM_BWD
     ACM_CHECK_HIP(hipGetLastError());
-    hipLaunchKernelGGL(conv_bwd_reduce_kernel, dim3(npg), dim3(256), 0, st, *p, nblk, partial);
-    ACM_CHECK_HIP(hipGetLastError());
-    return ACM_OK;
+    return bwd_local_reduce(p, partial, nblk, st);
 }

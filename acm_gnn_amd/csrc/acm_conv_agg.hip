@@ -528,22 +528,6 @@ __global__ __launch_bounds__(256, 2) void agg_bwd_kernel(acm_conv_agg_bwd_t p, i
         partial[(long)blockIdx.x * npg + q] = (lds[q] + lds[npg + q]) + (lds[2 * npg + q] + lds[3 * npg + q]);
 }
 
-// dst[q] = sum_b partial[b][q], fixed tree order; grid = npg blocks.
-__global__ __launch_bounds__(256) void reduce_columns_kernel(const float* __restrict__ partial, int nblk, int npg,
-                                                             float* __restrict__ dst) {
-    __shared__ float red[256];
-    const int q = blockIdx.x;
-    float s = 0.f;
-    for (int b = threadIdx.x; b < nblk; b += 256) s += partial[(long)b * npg + q];
-    red[threadIdx.x] = s;
-    __syncthreads();
-    for (int m = 128; m >= 1; m >>= 1) {
-        if ((int)threadIdx.x < m) red[threadIdx.x] += red[threadIdx.x + m];
-        __syncthreads();
-    }
-    if (threadIdx.x == 0) dst[q] = red[0];
-}
-
 int agg_pad(int f_in) { return f_in <= 4 ? 4 : (f_in <= 8 ? 8 : 16); }
 
 int agg_bwd_blocks(int64_t n_rows) {
@@ -712,7 +696,6 @@ extern "C" int acm_conv_agg_bwd(int64_t n_rows, const acm_conv_agg_bwd_t* p, voi
     else ACM_BWDK(16);
 #undef ACM_BWDK
     ACM_CHECK_HIP(hipGetLastError());
-    hipLaunchKernelGGL(reduce_columns_kernel, dim3(npg), dim3(256), 0, s, partial, nblk, npg, p->d_params);
-    ACM_CHECK_HIP(hipGetLastError());
-    return ACM_OK;
+    const acm_reduce_seg_t seg = {partial, nblk, npg, 0, npg, p->d_params, npg, 0, 0, 0};   // d_params[q] = sum_b partial[b][q]
+    return acm_reduce_emit(p->defer, &seg, 1, s);
 }

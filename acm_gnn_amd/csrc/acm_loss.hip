@@ -39,20 +39,6 @@ __global__ __launch_bounds__(256) void nll_rows_kernel(int n, int C, const float
     if (threadIdx.x == 0) partial[blockIdx.x] = red[0];
 }
 
-__global__ __launch_bounds__(256) void nll_final_kernel(int nblk, const float* __restrict__ partial,
-                                                        float* __restrict__ loss) {
-    __shared__ float red[256];
-    float s = 0.f;
-    for (int b = threadIdx.x; b < nblk; b += 256) s += partial[b];
-    red[threadIdx.x] = s;
-    __syncthreads();
-    for (int k = 128; k >= 1; k >>= 1) {
-        if ((int)threadIdx.x < k) red[threadIdx.x] += red[threadIdx.x + k];
-        __syncthreads();
-    }
-    if (threadIdx.x == 0) *loss = red[0];
-}
-
 int nll_blocks(int64_t n) {
     int64_t nb = (n + 255) / 256;
     if (nb > 1024) nb = 1024;
@@ -71,7 +57,8 @@ extern "C" int acm_nll_loss_workspace_bytes(int64_t n_rows, size_t* bytes) {
 
 extern "C" int acm_nll_loss(int64_t n_rows, int n_classes, const float* logits, int64_t ld_logits,
                             const int64_t* labels, const float* row_weight, float* loss, float* dlogits,
-                            int64_t ld_dlogits, void* workspace, size_t workspace_bytes, acm_stream_t stream) {
+                            int64_t ld_dlogits, void* workspace, size_t workspace_bytes, acm_reduce_list_t* defer,
+                            acm_stream_t stream) {
     ACM_REQUIRE(logits && labels && row_weight && loss && dlogits, ACM_EINVAL, "acm_nll_loss: NULL pointer");
     ACM_REQUIRE(n_rows >= 0 && n_rows < INT32_MAX && n_classes >= 1, ACM_ESHAPE, "acm_nll_loss: bad sizes");
     ACM_REQUIRE(n_classes <= 64, ACM_EUNSUPPORTED, "acm_nll_loss: %d classes > 64", n_classes);
@@ -83,7 +70,6 @@ extern "C" int acm_nll_loss(int64_t n_rows, int n_classes, const float* logits, 
     hipLaunchKernelGGL(nll_rows_kernel, dim3(nblk), dim3(256), 0, st, (int)n_rows, n_classes, logits, (long)ld_logits,
                        labels, row_weight, dlogits, (long)ld_dlogits, partial);
     ACM_CHECK_HIP(hipGetLastError());
-    hipLaunchKernelGGL(nll_final_kernel, dim3(1), dim3(256), 0, st, nblk, partial, loss);
-    ACM_CHECK_HIP(hipGetLastError());
-    return ACM_OK;
+    const acm_reduce_seg_t seg = {partial, nblk, 1, 0, 1, loss, 1, 0, 0, 0};
+    return acm_reduce_emit(defer, &seg, 1, st);
 }

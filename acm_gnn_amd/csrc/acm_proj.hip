@@ -89,25 +89,6 @@ __global__ __launch_bounds__(256) void proj_bwd_kernel(int n_rows, int f_in, con
     }
 }
 
-// dW[j][q] = sum_b partial[b][j * Q + q]; one block per output element; optional column-block layout of dW
-__global__ __launch_bounds__(256) void proj_reduce_kernel(const float* __restrict__ partial, int nblk, int f_in, int Q,
-                                                          float* __restrict__ dW, long lddw, int cb, long cbs) {
-    __shared__ float red[256];
-    const int e = blockIdx.x, j = e / Q, q = e % Q;
-    float s = 0.f;
-    for (int b = threadIdx.x; b < nblk; b += 256) s += partial[(long)b * f_in * Q + e];
-    red[threadIdx.x] = s;
-    __syncthreads();
-    for (int k = 128; k >= 1; k >>= 1) {
-        if ((int)threadIdx.x < k) red[threadIdx.x] += red[threadIdx.x + k];
-        __syncthreads();
-    }
-    if (threadIdx.x == 0) {
-        if (cb) dW[(long)(q / cb) * cbs + (long)j * lddw + (q % cb)] = red[0];
-        else dW[(long)j * lddw + q] = red[0];
-    }
-}
-
 // Forward of the same skinny projection: Z = relu?(X [W0 | W1 | W2]) for F <= 8 output columns per weight, straight from
 // the three weight matrices (no packed copy), written as the two matrices the narrow fused layer wants: columns
 // [0, 2F) -> Zlh (the gathered block [Z_L | Z_H]), [2F, 3F) -> Zi.  A 16-lane group per row, lane = 4 consecutive input
@@ -247,7 +228,7 @@ extern "C" int acm_proj_bwd(int64_t n_rows, int64_t f_in, int n_out, const float
                             int64_t lddz, const float* w_low, const float* w_high, const float* w_mlp, int64_t ldw,
                             float* dX, int64_t lddx, float* dW,
                             int64_t lddw, int64_t dw_col_block, int64_t dw_block_stride, void* workspace,
-                            size_t workspace_bytes, acm_stream_t stream) {
+                            size_t workspace_bytes, acm_reduce_list_t* defer, acm_stream_t stream) {
     size_t need = 0;
     int st = acm_proj_bwd_workspace_bytes(n_rows, f_in, n_out, &need);
     if (st != ACM_OK) return st;
@@ -273,8 +254,8 @@ extern "C" int acm_proj_bwd(int64_t n_rows, int64_t f_in, int n_out, const float
     }
 #undef ACM_PROJ
     ACM_CHECK_HIP(hipGetLastError());
-    hipLaunchKernelGGL(proj_reduce_kernel, dim3((unsigned)(f_in * n_out)), dim3(256), 0, s, partial, nblk, (int)f_in, n_out,
-                       dW, (long)lddw, (int)dw_col_block, (long)dw_block_stride);
-    ACM_CHECK_HIP(hipGetLastError());
-    return ACM_OK;
+    // dW[j][q] = sum_b partial[b][j * n_out + q], optionally in the column-block layout of dW
+    const acm_reduce_seg_t seg = {partial, nblk, (int32_t)(f_in * n_out), 0, (int32_t)(f_in * n_out), dW, n_out,
+                                  (int32_t)dw_col_block, lddw, dw_block_stride};
+    return acm_reduce_emit(defer, &seg, 1, s);
 }

@@ -60,6 +60,88 @@ class _Timed:
         return False
 
 
+class DeferredReductions:
+    """The pending second phases (acm_reduce_list_t) of the calls made while this object is current: the loss sum and
+    the parameter-gradient sums of K3 / acm_proj_bwd / acm_conv_agg_bwd.  Until :meth:`flush` their outputs (the
+    loss, every ``.grad`` those kernels produce) are UNDEFINED, so only a loop that owns the whole step may defer
+    (``train.TrainStep`` does: nothing reads a gradient between ``backward`` and the flush it issues before the
+    optimizer / the gradient all-reduce).  One launch instead of four per step (~5 us each in a replayed graph)."""
+    CAP = 96
+
+    def __init__(self):
+        self._segs = (_lib.ReduceSeg * self.CAP)()
+        self._list = _lib.ReduceList(0, self.CAP, C.cast(self._segs, C.POINTER(_lib.ReduceSeg)))
+        self._keep = []                 # workspaces the pending segments read
+        self.outputs = []               # (data_ptr, nbytes) of tensors whose content arrives with the flush
+
+    def pointer(self):
+        return C.addressof(self._list)
+
+    def hold(self, workspace, outputs, keep=None):
+        """A deferred call's workspace, the tensors its second phase will write (`outputs`: address ranges for
+        all_adopted) and what must stay allocated for that write (`keep`, default the outputs themselves; pass the
+        base buffer when the outputs are views autograd should still be able to adopt -- a held view has one
+        reference too many for that)."""
+        self._keep.append(workspace)
+        self._keep.extend(outputs if keep is None else keep)
+        self.outputs.extend((t.data_ptr(), t.numel() * t.element_size()) for t in outputs if t is not None)
+
+    @property
+    def pending(self):
+        return int(self._list.n)
+
+    def all_adopted(self, tensors):
+        """True if every output of a deferred call is (the storage of) at least one of `tensors` -- e.g. the loss and
+        the ``.grad`` of every parameter: autograd adopted what the kernels wrote instead of copying or accumulating
+        it before the flush."""
+        ptrs = sorted(t.data_ptr() for t in tensors if t is not None)
+        import bisect
+        for a, nb in self.outputs:
+            i = bisect.bisect_left(ptrs, a)
+            if i == len(ptrs) or ptrs[i] >= a + nb:
+                return False
+        return True
+
+    def flush(self):
+        if self._list.n:
+            dev = self._keep[0].device
+            with _device_ctx(dev), _Timed("reduce_flush"):
+                st = _lib.load().acm_reduce_flush(C.byref(self._list), _stream())
+            _lib.check(st, "acm_reduce_flush")
+        self._keep.clear()
+
+    def discard(self):
+        self._list.n = 0
+        self._keep.clear()
+
+
+_DEFER = None          # module-wide on purpose: autograd runs backward() on its own thread
+
+
+class deferred_reductions:
+    """``with deferred_reductions() as d: ...; d.flush()`` -- the calls inside append their second phases to ``d``.
+    Leaving the block flushes whatever is still pending (or drops it when an exception is propagating)."""
+
+    def __enter__(self):
+        global _DEFER
+        self.prev, self.d = _DEFER, DeferredReductions()
+        _DEFER = self.d
+        return self.d
+
+    def __exit__(self, exc_type, *rest):
+        global _DEFER
+        _DEFER = self.prev
+        if exc_type is None:
+            self.d.flush()
+        else:
+            self.d.discard()
+        return False
+
+
+def _defer_ptr():
+    return _DEFER.pointer() if _DEFER is not None else None
+
+
 def _vp(t):
     return C.c_void_p(t.data_ptr()) if t is not None else None
 
@@ -165,8 +247,10 @@ def proj_bwd(x, dz, weights, d_w_out):
     with _device_ctx(x.device), _Timed(f"proj_bwd/{n}x{f_in}x{q}"):
         st = lib.acm_proj_bwd(n, f_in, q, _vp(x), x.stride(0), _vp(dz), dz.stride(0), _vp(ws3[0]), _vp(ws3[1]), _vp(ws3[2]),
                               ws3[0].stride(0), _vp(dx), dx.stride(0), _vp(d_w_out), nb, nb, f_in * nb, _vp(ws),
-                              nbytes.value, _stream())
+                              nbytes.value, _defer_ptr(), _stream())
     _lib.check(st, "acm_proj_bwd")
+    if _DEFER is not None:
+        _DEFER.hold(ws, [d_w_out])
     return dx
 
 
@@ -259,8 +343,10 @@ class _MaskedNll(torch.autograd.Function):
         ws = torch.empty(max(nbytes.value // 4, 1), dtype=_F32, device=z.device)
         with _device_ctx(z.device), _Timed(f"nll_loss/{n}x{c}"):
             st = lib.acm_nll_loss(n, c, _vp(z), z.stride(0), _vp(y), _vp(w), _vp(loss), _vp(dz), dz.stride(0),
-                                  _vp(ws), ws.numel() * 4, _stream())
+                                  _vp(ws), ws.numel() * 4, _defer_ptr(), _stream())
         _lib.check(st, "acm_nll_loss")
+        if _DEFER is not None:
+            _DEFER.hold(ws, [loss])
         ctx.save_for_backward(dz)
         return loss
 
@@ -730,9 +816,12 @@ class AcmConvFunction(torch.autograd.Function):
         nbytes = C.c_size_t()
         _lib.check(lib.acm_conv_bwd_local_workspace_bytes(n, f, k, C.byref(nbytes)))
         ws = torch.empty(max(nbytes.value // 4, 1), dtype=_F32, device=dev)
+        q.defer = _defer_ptr()
         with _device_ctx(dev), _Timed(f"conv_bwd_local/F{f}k{k}"):
             st = lib.acm_conv_bwd_local(n, C.byref(q), _vp(ws), ws.numel() * 4, _stream())
         _lib.check(st, "acm_conv_bwd_local")
+        if _DEFER is not None:
+            _DEFER.hold(ws, [d_mix, *d_vec, *d_lnw, *d_lnb], keep=[flat])
 
         d_struc = torch.empty(n, f, dtype=_F32, device=dev) if four else None
         r = _lib.ConvBwdSpmm()
@@ -799,6 +888,8 @@ class AcmConvFunction(torch.autograd.Function):
             d_x = torch.nn.functional.pad(d_x, (0, ctx.x_width - d_x.shape[1]))
         if ops.sharded:                             # replicated parameters: sum the row-shard partials
             import torch.distributed as dist
+            if _DEFER is not None:
+                _DEFER.flush()                      # the all-reduce reads the reduced gradients
             dist.all_reduce(flat, group=ops.group)
         if d_wcat.dim() == 3:
             d_wl, d_wh, d_wm = d_wcat[0], d_wcat[1], d_wcat[2]
@@ -860,9 +951,12 @@ def _backward_agg(ctx, grad_out):
     nbytes = C.c_size_t()
     _lib.check(lib.acm_conv_agg_bwd_workspace_bytes(n, f_in, f, C.byref(nbytes)))
     ws = torch.empty(max(nbytes.value // 4, 1), dtype=_F32, device=dev)
+    q.defer = _defer_ptr()
     with _device_ctx(dev), _Timed(f"conv_agg_bwd/F{f}k{k}i{f_in}"):
         st = lib.acm_conv_agg_bwd(n, C.byref(q), _vp(ws), ws.numel() * 4, _stream())
     _lib.check(st, "acm_conv_agg_bwd")
+    if _DEFER is not None:
+        _DEFER.hold(ws, [d_params])
     d_struc = None
     if four:                                  # dS = A_low^T (D G_S) - G_S   (pattern-only: P G_S - G_S)
         gsg = _gather_rows(ops, gs)
@@ -878,6 +972,8 @@ def _backward_agg(ctx, grad_out):
         _lib.check(st, "acm_spmm_ex")
     if ops.sharded:
         import torch.distributed as dist
+        if _DEFER is not None:
+            _DEFER.flush()
         dist.all_reduce(d_params, group=ops.group)
     wsz = f_in * f
     d_wl, d_wh, d_wm = (d_params[i * wsz:(i + 1) * wsz].view(f_in, f) for i in range(3))

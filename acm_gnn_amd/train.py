@@ -39,6 +39,7 @@ class TrainStep:
         # model may draw its masks inside the kernels; the advance rides FusedAdam's step-counter kernel
         # (default: on, unless someone replaced F.dropout -- a mask-replay harness must keep seeing its masks)
         self._manual_advance = False
+        self._defer = True
         if fused_dropout is None:
             fused_dropout = F.dropout is _TORCH_DROPOUT
         if fused_dropout and getattr(model, "dropout", 0) > 0 and hasattr(model, "fused_dropout"):
@@ -52,13 +53,35 @@ class TrainStep:
         if use_graph:
             self._capture()
 
+    def _forward_backward(self):
+        """Forward, fused loss and backward; the loss sum and the parameter-gradient sums of the backward kernels run
+        as ONE deferred launch at the end (AF.deferred_reductions: four launches less per step).  That is only sound
+        while nothing reads a gradient before the flush, which this method checks on every pass: every ``.grad``
+        must be the tensor the backward kernels wrote (autograd adopts it when ``.grad`` is None), not a copy taken
+        before the flush -- otherwise deferral is switched off for good and the step is redone."""
+        model = self.model
+        if not self._defer:
+            out = model(self.x, self.adj, self.adj_high, self.adj_un)
+            loss, dz = AF.nll_loss_and_grad(out, self.labels, self.weights)   # = masked_nll(...).backward(), two launches less
+            out.backward(dz)
+            return loss
+        with AF.deferred_reductions() as pending:
+            out = model(self.x, self.adj, self.adj_high, self.adj_un)
+            loss, dz = AF.nll_loss_and_grad(out, self.labels, self.weights)
+            out.backward(dz)
+            adopted = pending.all_adopted([loss] + [p.grad for p in model.parameters()])
+            pending.flush()
+        if not adopted:
+            self._defer = False
+            self.opt.zero_grad(set_to_none=True)
+            return self._forward_backward()
+        return loss
+
     def _eager(self):
         if not self.model.training:
             self.model.train()
         self.opt.zero_grad(set_to_none=True)
-        out = self.model(self.x, self.adj, self.adj_high, self.adj_un)
-        loss, dz = AF.nll_loss_and_grad(out, self.labels, self.weights)   # = masked_nll(...).backward(), two launches less
-        out.backward(dz)
+        loss = self._forward_backward()
         self.opt.step()
         if self._manual_advance:
             self.model.dropout_state.advance()
@@ -77,14 +100,12 @@ class TrainStep:
         self.model.train()
         self.opt.zero_grad(set_to_none=True)
         with torch.cuda.graph(self.graph):
-            out = self.model(self.x, self.adj, self.adj_high, self.adj_un)
-            loss, dz = AF.nll_loss_and_grad(out, self.labels, self.weights)
-            out.backward(dz)
+            loss = self._forward_backward()
             self.opt.step()
             if self._manual_advance:
                 self.model.dropout_state.advance()
             self.loss = loss
-        del loss, out, dz
+        del loss
 
     def __call__(self):
         if self.graph is not None:

@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define ACM_ABI_VERSION 13
+#define ACM_ABI_VERSION 14
 
 typedef enum {
     ACM_OK = 0,
@@ -153,6 +153,39 @@ typedef struct {
 int acm_dropout(int64_t n_rows, int64_t n_cols, const float* src, int64_t ld_src,
                 float* dst, int64_t ld_dst, int64_t dst_cols, const acm_dropout_t* d, acm_stream_t stream);
 
+/* ------------------------------------------------ deferred final reductions --
+ * Every backward kernel that produces parameter gradients (acm_conv_bwd_local, acm_proj_bwd, acm_conv_agg_bwd) and
+ * acm_nll_loss end in the same second phase: per-block partial sums in the call's workspace, summed by one block per
+ * output element in a fixed order.  On the GPU each of those second phases is a launch of its own (~5 us in a
+ * replayed graph), and nothing reads their results before the optimizer.  A caller that owns the whole step may
+ * therefore hand each of those calls an acm_reduce_list_t: the call then runs its main kernel, APPENDS the
+ * description of its second phase to the list instead of launching it, and acm_reduce_flush runs all of them in one
+ * launch (per 32 segments).  Contract while a call's segments are pending: its workspace must stay allocated and
+ * untouched, and its reduced outputs (the loss, d_att_vec / d_ln_* / d_att_mix, dW, d_params) are undefined until
+ * the flush.  The summation order is the one of the immediate form (thread t of 256 adds blocks t, t + 256, ...,
+ * then a binary tree), so deferred and immediate results are bit-identical.
+ * `defer` == NULL everywhere means "reduce now" (the only behaviour before ABI 14).
+ * Replaces: nothing in the reference (autograd reduces inside each op); this is launch-count plumbing for the
+ * captured training step of ACM-Geometric/train.py:119-137.
+ */
+typedef struct {
+    const float* partial;      /* [nblk rows] x row_stride floats                                              */
+    int32_t nblk, row_stride;
+    int32_t q0, len;           /* this segment sums columns q0 .. q0 + len of `partial`                        */
+    float*  dst;               /* element e -> dst[(e / inner) * outer_stride + blk(e % inner)]                */
+    int32_t inner;             /* columns per destination row (len for a flat vector)                          */
+    int32_t col_block;         /* 0: blk(q) = q;  else blk(q) = (q / col_block) * block_stride + q % col_block */
+    int64_t outer_stride, block_stride;
+} acm_reduce_seg_t;
+
+typedef struct {
+    int32_t n, cap;            /* segments in use / allocated                                                   */
+    acm_reduce_seg_t* segs;    /* host memory owned by the caller                                               */
+} acm_reduce_list_t;
+
+/* Run every pending segment of `list` on `stream` (ceil(n / 32) launches) and reset list->n to 0. */
+int acm_reduce_flush(acm_reduce_list_t* list, acm_stream_t stream);
+
 /* Same product delivered as two matrices: columns [0, split_col) to C (pitch ldc), the rest to C2 (pitch ldc2).
  * The projection of a narrow layer writes the gathered block [Z_L | Z_H] as its own compact 2F-float rows (the table
  * the fused SpMM gathers from: half the cache footprint of [Z_L | Z_H | Z_I | pad] rows) and Z_I next to it. */
@@ -176,7 +209,7 @@ int acm_proj_bwd_workspace_bytes(int64_t n_rows, int64_t f_in, int n_out, size_t
 int acm_proj_bwd(int64_t n_rows, int64_t f_in, int n_out, const float* X, int64_t ldx,
                  const float* dZ, int64_t lddz, const float* w_low, const float* w_high, const float* w_mlp, int64_t ldw,
                  float* dX, int64_t lddx, float* dW, int64_t lddw, int64_t dw_col_block, int64_t dw_block_stride,
-                 void* workspace, size_t workspace_bytes, acm_stream_t stream);
+                 void* workspace, size_t workspace_bytes, acm_reduce_list_t* defer, acm_stream_t stream);
 
 /* ----------------------------------------------------------------- SpMM --
  * Y[r, 0:width] = sum_j A[r,j] * G[j, 0:width]   (plain CSR x dense; used for
@@ -316,6 +349,7 @@ typedef struct {
      * (g_struc = dL/dpre_S unscaled, which is what P needs: A_low^T (D G_S) = P G_S). */
     const float* g_scale;
     acm_dropout_t post_drop;              /* the forward's post_drop (same seed / step / tag) */
+    acm_reduce_list_t* defer;             /* NULL: reduce the parameter gradients now; else append (see above) */
 } acm_conv_bwd_local_t;
 
 int acm_conv_bwd_local_workspace_bytes(int64_t n_rows, int f_out, int n_channels, size_t* bytes);
@@ -424,6 +458,7 @@ typedef struct {
     float* g_struc; int64_t ld_g_struc;   /* out: g_struc_scale_i * dL/dpre_S  (the operand of the A_low^T product) */
     const float* g_struc_scale;           /* deg for an explicit A_low^T; NULL (= 1) for the pattern-only form  */
     acm_dropout_t post_drop;
+    acm_reduce_list_t* defer;             /* NULL: reduce d_params now; else append to the list                 */
 } acm_conv_agg_bwd_t;
 
 int acm_conv_agg_bwd_workspace_bytes(int64_t n_rows, int f_in, int f_out, size_t* bytes);
@@ -443,7 +478,7 @@ int acm_nll_loss_workspace_bytes(int64_t n_rows, size_t* bytes);
 int acm_nll_loss(int64_t n_rows, int n_classes, const float* logits, int64_t ld_logits,
                  const int64_t* labels, const float* row_weight,
                  float* loss, float* dlogits, int64_t ld_dlogits,
-                 void* workspace, size_t workspace_bytes, acm_stream_t stream);
+                 void* workspace, size_t workspace_bytes, acm_reduce_list_t* defer, acm_stream_t stream);
 
 /* ------------------------------------------------ fused optimizer update --
  * Adam / AdamW over a list of fp32 parameter tensors in one launch per 32 tensors: the update of

@@ -1,5 +1,6 @@
 /* A plain-C client of libacm_hip.so: no Python, no torch -- only the HIP runtime for device memory.
- * Builds a small graph, runs acm_spmm / acm_spmm_ex (pattern-only handle + row scale) / acm_gemm / acm_adam_step
+ * Builds a small graph, runs acm_spmm / acm_spmm_ex (pattern-only handle + row scale) / acm_gemm / acm_adam_step /
+ * acm_nll_loss (immediate and deferred + acm_reduce_flush)
  * and checks them against loops on the host.  Compiled and run by tests/test_gpu_c_abi.py:
  *     gcc -std=c11 -D__HIP_PLATFORM_AMD__ abi_smoke.c -I include -I/opt/rocm/include -L acm_gnn_amd/lib -lacm_hip \
  *         -L/opt/rocm/lib -lamdhip64 -lm -o abi_smoke
@@ -121,7 +122,40 @@ int main(void) {
         if (fabs(p - upd - c[i]) > 1e-4 * fmax(1.0, fabs(p))) { printf("acm_adam_step mismatch at %d: %g vs %g\n", i, c[i], p - upd); return 9; }
     }
 
-    /* 5. errors are codes + messages, never crashes */
+    /* 5. masked NLL, immediate and with its final sum deferred to acm_reduce_flush (bit-identical) */
+    enum { C2 = 2 };
+    long long lab[N];
+    float wt[N], zz[N * C2];
+    for (int i = 0; i < N; ++i) { lab[i] = i % C2; wt[i] = (i % 3 == 0) ? 3.0f / N : 0.f; zz[2 * i] = x[i * W]; zz[2 * i + 1] = x[i * W + 1]; }
+    float* d_z = (float*)to_dev(zz, sizeof(zz));
+    float* d_dz = (float*)to_dev(NULL, sizeof(zz));
+    float* d_w = (float*)to_dev(wt, sizeof(wt));
+    long long* d_lab = (long long*)to_dev(lab, sizeof(lab));
+    float* d_loss = (float*)to_dev(NULL, 2 * sizeof(float));
+    size_t lws = 0;
+    CHECK_ACM(acm_nll_loss_workspace_bytes(N, &lws));
+    void* lw = to_dev(NULL, lws);
+    CHECK_ACM(acm_nll_loss(N, C2, d_z, C2, (const int64_t*)d_lab, d_w, d_loss, d_dz, C2, lw, lws, NULL, NULL));
+    acm_reduce_seg_t segs[4];
+    acm_reduce_list_t pending = {0, 4, segs};
+    void* lw2 = to_dev(NULL, lws);
+    CHECK_ACM(acm_nll_loss(N, C2, d_z, C2, (const int64_t*)d_lab, d_w, d_loss + 1, d_dz, C2, lw2, lws, &pending, NULL));
+    if (pending.n != 1) { printf("deferred acm_nll_loss appended %d segments\n", pending.n); return 12; }
+    CHECK_ACM(acm_reduce_flush(&pending, NULL));
+    if (pending.n != 0) { printf("acm_reduce_flush left %d segments\n", pending.n); return 13; }
+    CHECK_HIP(hipDeviceSynchronize());
+    float loss2[2];
+    CHECK_HIP(hipMemcpy(loss2, d_loss, sizeof(loss2), hipMemcpyDeviceToHost));
+    double want = 0;
+    for (int i = 0; i < N; ++i) {
+        double a0 = zz[2 * i], a1 = zz[2 * i + 1], mx = fmax(a0, a1), lse = mx + log(exp(a0 - mx) + exp(a1 - mx));
+        want += wt[i] * (lse - zz[2 * i + lab[i]]);
+    }
+    if (loss2[0] != loss2[1] || fabs(loss2[0] - want) > 1e-5) { printf("acm_nll_loss %g / deferred %g vs %g\n", loss2[0], loss2[1], want); return 14; }
+    pending.cap = 0;
+    if (acm_nll_loss(N, C2, d_z, C2, (const int64_t*)d_lab, d_w, d_loss, d_dz, C2, lw, lws, &pending, NULL) != ACM_ENOMEM) { printf("full deferral list accepted\n"); return 15; }
+
+    /* 6. errors are codes + messages, never crashes */
     if (acm_spmm(NULL, d_x, W, W, d_y, W, ws, ws_bytes, NULL) != ACM_EINVAL) { printf("NULL handle accepted\n"); return 10; }
     if (acm_spmm(a, d_x, W, W, d_y, W, NULL, 0, NULL) != ACM_ENOMEM) { printf("missing workspace accepted\n"); return 11; }
     acm_csr_destroy(a);

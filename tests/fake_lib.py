@@ -147,10 +147,40 @@ def _head_backward(H, hd, dO, k, layernorm, vecs, lnw, mix, scale):
 class FakeLib:
     def __init__(self):
         self._handles, self._next, self._err = {}, 1, b""
+        self._pending = {}
 
     # ---- plumbing ---------------------------------------------------------
     def acm_version(self):
-        return 13
+        return 14
+
+    # ---- deferred second phases (acm_reduce_list_t): results of a deferred call are poisoned with NaN until the
+    # flush, so a consumer that reads them too early fails its test instead of passing by accident
+    def _emit(self, defer, writes):
+        """writes: [(destination ndarray view, value)]"""
+        if not defer:
+            for dst, val in writes:
+                dst[...] = val
+            return 0
+        from acm_gnn_amd._lib import ReduceList
+        addr = defer.value if isinstance(defer, C.c_void_p) else int(defer)
+        lst = ReduceList.from_address(addr)
+        if lst.n + len(writes) > lst.cap:
+            self._err = b"acm_reduce: deferral list full"
+            return 5
+        for dst, val in writes:
+            dst[...] = np.nan
+        self._pending.setdefault(addr, []).extend((dst, np.array(val, dtype=np.float64)) for dst, val in writes)
+        lst.n += len(writes)
+        return 0
+
+    def acm_reduce_flush(self, lst_ref, stream):
+        from acm_gnn_amd._lib import ReduceList
+        lst = lst_ref._obj if hasattr(lst_ref, "_obj") else ReduceList.from_address(int(lst_ref))
+        addr = C.addressof(lst)
+        for dst, val in self._pending.pop(addr, []):
+            dst[...] = val
+        lst.n = 0
+        return 0
 
     def acm_last_error(self):
         return self._err
@@ -240,19 +270,20 @@ class FakeLib:
         _view(zi, n, f, ld_i)[...] = out[:, 2 * f:]
         return 0
 
-    def acm_proj_bwd(self, n, f_in, q, x, ldx, dz, lddz, wl, wh, wm, ldw, dx, lddx, dw, lddw, cb, cbs, ws, wsb, stream):
+    def acm_proj_bwd(self, n, f_in, q, x, ldx, dz, lddz, wl, wh, wm, ldw, dx, lddx, dw, lddw, cb, cbs, ws, wsb, defer, stream):
         X, DZ = _view(x, n, f_in, ldx).astype(np.float64), _view(dz, n, q, lddz).astype(np.float64)
         W = np.concatenate([_view(w, f_in, q // 3, ldw).astype(np.float64) for w in (wl, wh, wm)], 1)
         _view(dx, n, f_in, lddx)[...] = DZ @ W.T
         full = X.T @ DZ
         base = dw.value if isinstance(dw, C.c_void_p) else int(dw)
+        writes = []
         if not cb:
-            _view(base, f_in, q, lddw)[...] = full
+            writes.append((_view(base, f_in, q, lddw), full))
         else:
             for j, q0 in enumerate(range(0, q, cb)):
                 wd = min(cb, q - q0)
-                _view(base + 4 * j * cbs, f_in, wd, lddw)[...] = full[:, q0:q0 + wd]
-        return 0
+                writes.append((_view(base + 4 * j * cbs, f_in, wd, lddw), full[:, q0:q0 + wd]))
+        return self._emit(defer, writes)
 
     def acm_conv_bwd_local_workspace_bytes(self, n, f, k, out):
         out._obj.value = 4
@@ -266,7 +297,7 @@ class FakeLib:
         out._obj.value = 4
         return 0
 
-    def acm_nll_loss(self, n, c, z, ldz, y, w, loss, dz, ldd, ws, wsb, stream):
+    def acm_nll_loss(self, n, c, z, ldz, y, w, loss, dz, ldd, ws, wsb, defer, stream):
         Z = _view(z, n, c, ldz).astype(np.float64)
         Y = _vec(y, n, np.int64)
         W = _vec(w, n).astype(np.float64)
@@ -277,8 +308,7 @@ class FakeLib:
         onehot = np.zeros_like(Z)
         onehot[np.arange(n), Y] = 1.0
         _view(dz, n, c, ldd)[...] = W[:, None] * (e / s - onehot)
-        _vec(loss, 1)[0] = float((W * (lse - Z[np.arange(n), Y])).sum())
-        return 0
+        return self._emit(defer, [(_vec(loss, 1), float((W * (lse - Z[np.arange(n), Y])).sum()))])
 
     # ---- compute ----------------------------------------------------------
     def acm_gemm(self, ta, tb, m, n, k, a, lda, b, ldb, c, ldc, relu, ws, wsb, stream):
@@ -412,13 +442,14 @@ class FakeLib:
         _view(q.g_mlp, n, F, q.ld_g_mlp)[...] = G[2]
         if k == 4:
             _view(q.g_struc, n, F, q.ld_g_struc)[...] = (_vec(q.deg, n).astype(f64)[:, None] if q.deg else 1.0) * G[3]
+        writes = []
         for c in range(k):
-            _vec(q.d_att_vec[c], F)[...] = d_vec[c]
+            writes.append((_vec(q.d_att_vec[c], F), d_vec[c]))
             if q.layernorm:
-                _vec(q.d_ln_weight[c], F)[...] = d_lnw[c]
-                _vec(q.d_ln_bias[c], F)[...] = d_lnb[c]
-        _view(q.d_att_mix, k, k, k)[...] = d_mix
-        return 0
+                writes.append((_vec(q.d_ln_weight[c], F), d_lnw[c]))
+                writes.append((_vec(q.d_ln_bias[c], F), d_lnb[c]))
+        writes.append((_view(q.d_att_mix, k, k, k), d_mix))
+        return self._emit(q.defer, writes)
 
     def acm_conv_bwd_spmm(self, h, rr, ws, wsb, stream):
         at, r = self._get(h), rr._obj
@@ -500,8 +531,8 @@ class FakeLib:
             _view(q.g_struc, n, F, q.ld_g_struc)[...] = \
                 (_vec(q.g_struc_scale, n).astype(np.float64)[:, None] if q.g_struc_scale else 1.0) * G[3]
         npg = 3 * fi * F + 3 * k * F + k * k
-        out = _vec(q.d_params, npg)
-        out[...] = 0
+        dst = _vec(q.d_params, npg)
+        out = np.zeros(npg)
         for c in range(3):
             out[c * fi * F:(c + 1) * fi * F] = (A[c].T @ G[c]).reshape(-1)
         base = 3 * fi * F
@@ -511,7 +542,7 @@ class FakeLib:
                 out[base + (k + c) * F: base + (k + 1 + c) * F] = d_lnw[c]
                 out[base + (2 * k + c) * F: base + (2 * k + 1 + c) * F] = d_lnb[c]
         out[base + 3 * k * F:] = d_mix.reshape(-1)
-        return 0
+        return self._emit(q.defer, [(dst, out)])
 
     def acm_dropout(self, n, c, src, lds, dst, ldd, dst_cols, d, stream):
         out = np.zeros((n, dst_cols))

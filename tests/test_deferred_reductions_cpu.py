@@ -1,0 +1,110 @@
+"""Deferred second phases (acm_reduce_list_t, include/acm_hip.h) through the numpy double of the C ABI, which poisons
+the outputs of a deferred call with NaN until acm_reduce_flush: the host plumbing (functional.deferred_reductions,
+train.TrainStep) must flush before anything reads a gradient, give the results of the immediate form, and fall back
+to the immediate form when autograd did not adopt the kernels' output tensors."""
+import numpy as np
+import torch
+
+import fake_lib
+
+
+def _setup(model_type="acmgcnp", s=0, hidden=16):
+    from acm_gnn_amd import GCN, data as D, train as T
+    from acm_gnn_amd.graph import CsrGraph, FilterOperators
+    adj, x_np, y_np, (tr, _, _), _ = D.synthetic_dataset("tiny", seed=3)
+    low, _ = D.build_filters(adj)
+    ops = FilterOperators(CsrGraph.from_scipy(low, "cpu"))
+    x, y = torch.from_numpy(D.row_normalize_features(x_np)), torch.from_numpy(y_np)
+    w = T.row_weights(torch.from_numpy(tr), x.shape[0])
+    torch.manual_seed(0)
+    model = GCN(x.shape[1], hidden, int(y.max()) + 1, 2, x.shape[0], 0.0, model_type, s)
+    return model, ops, x, y, w
+
+
+def _grads(model):
+    return {k: v.grad.clone() for k, v in model.named_parameters() if v.grad is not None}
+
+
+def test_outputs_are_undefined_until_the_flush_and_equal_the_immediate_form(monkeypatch):
+    fake_lib.install(monkeypatch)
+    from acm_gnn_amd import functional as AF
+    model, ops, x, y, w = _setup()
+    out = model(x, ops)
+    loss0, dz = AF.nll_loss_and_grad(out, y, w)
+    out.backward(dz)
+    want = _grads(model)
+    model.zero_grad(set_to_none=True)
+    with AF.deferred_reductions() as pending:
+        out = model(x, ops)
+        loss, dz = AF.nll_loss_and_grad(out, y, w)
+        assert torch.isfinite(dz).all() and torch.isnan(loss)        # dz is first-phase output, the loss is not
+        out.backward(dz)
+        assert pending.pending >= 4                                  # loss, K3, acm_proj_bwd, acm_conv_agg_bwd
+        poisoned = [k for k, v in model.named_parameters() if v.grad is not None and torch.isnan(v.grad).any()]
+        assert len(poisoned) >= len(want) - 1                        # everything the reduced kernels produce
+        assert pending.all_adopted([loss] + [p.grad for p in model.parameters()])
+        pending.flush()
+        assert pending.pending == 0
+    assert float(loss) == float(loss0)
+    got = _grads(model)
+    assert got.keys() == want.keys()
+    for k in want:
+        assert torch.equal(got[k], want[k]), k
+
+
+def test_leaving_the_block_flushes_and_an_exception_discards(monkeypatch):
+    fake_lib.install(monkeypatch)
+    from acm_gnn_amd import functional as AF
+    model, ops, x, y, w = _setup()
+    with AF.deferred_reductions():
+        loss, _ = AF.nll_loss_and_grad(model(x, ops), y, w)
+    assert torch.isfinite(loss)
+    try:
+        with AF.deferred_reductions() as pending:
+            AF.nll_loss_and_grad(model(x, ops), y, w)
+            raise KeyError("boom")
+    except KeyError:
+        pass
+    assert pending.pending == 0 and AF._DEFER is None
+
+
+def test_train_step_defers_and_matches_the_immediate_trajectory(monkeypatch):
+    fake_lib.install(monkeypatch)
+    from acm_gnn_amd import FusedAdam, train as T
+    traj = {}
+    for defer in (True, False):
+        model, ops, x, y, w = _setup()
+        opt = FusedAdam(model.parameters(), lr=0.01, weight_decay=5e-4)
+        step = T.TrainStep(model, opt, x, ops, y, w)
+        step._defer = defer
+        traj[defer] = [float(step()) for _ in range(4)]
+        assert step._defer == defer
+        assert all(torch.isfinite(p).all() for p in model.parameters())
+    assert traj[True] == traj[False]
+
+
+def test_train_step_falls_back_when_a_gradient_was_accumulated_instead_of_adopted(monkeypatch):
+    fake_lib.install(monkeypatch)
+    from acm_gnn_amd import train as T
+
+    class KeepsGrads(torch.optim.SGD):                    # an optimizer that does not clear .grad: autograd then
+        def zero_grad(self, set_to_none=True):            # ACCUMULATES into it, i.e. reads the new gradient at once
+            for g in self.param_groups:
+                for p in g["params"]:
+                    if p.grad is not None:
+                        p.grad.zero_()
+
+    model, ops, x, y, w = _setup()
+    ref, *_ = _setup()
+    ref.load_state_dict(model.state_dict())
+    opt = KeepsGrads(model.parameters(), lr=0.1)
+    step = T.TrainStep(model, opt, x, ops, y, w)
+    first = float(step())                                 # .grad is None here: adopted
+    assert step._defer
+    second = float(step())                                # .grad exists: detected, redone without deferral
+    assert not step._defer
+    ref_step = T.TrainStep(ref, torch.optim.SGD(ref.parameters(), lr=0.1), x, ops, y, w)
+    ref_step._defer = False
+    assert [first, second] == [float(ref_step()), float(ref_step())]
+    for a, b in zip(model.parameters(), ref.parameters()):
+        assert torch.isfinite(a).all() and torch.allclose(a, b, rtol=1e-6, atol=1e-7)

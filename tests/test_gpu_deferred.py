@@ -1,0 +1,76 @@
+"""Deferred second phases on the GPU (acm_reduce_list_t / acm_reduce_flush): bit-identical to the immediate form,
+for every op that has one, in eager and graph-replayed training steps."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = torch.device("cuda:0")
+
+
+def _setup(model_type, s, hidden, f_in=None, dataset="tiny", seed=3, dropout=0.0):
+    from acm_gnn_amd import GCN, data as D, train as T
+    from oracle import acm_oracle as O
+    adj, x_np, y_np, (tr, _, _), _ = D.synthetic_dataset(dataset, seed=seed)
+    ops = tuple(m.to(DEV) for m in O.filters_linkx(adj))          # (A_low, A_high, A) as the reference passes them
+    x = torch.from_numpy(D.row_normalize_features(x_np)).to(DEV)
+    if f_in:
+        x = torch.cat([x] * (f_in // x.shape[1] + 1), 1)[:, :f_in].contiguous()
+    y = torch.from_numpy(y_np).to(DEV)
+    w = T.row_weights(torch.from_numpy(tr), x.shape[0]).to(DEV)
+    torch.manual_seed(0)
+    model = GCN(x.shape[1], hidden, int(y.max()) + 1, 2, x.shape[0], dropout, model_type, s).to(DEV)
+    return model, ops, x, y, w
+
+
+@pytest.mark.parametrize("model_type,s,hidden,f_in", [("acmgcn", 0, 64, None), ("acmgcnp", 0, 64, None),
+                                                      ("acmgcnp", 1, 64, None), ("acmgcnp", 0, 16, 40),
+                                                      ("acmgcnpp", 1, 32, 100)])
+def test_deferred_equals_immediate_bitwise(model_type, s, hidden, f_in):
+    from acm_gnn_amd import functional as AF
+    model, ops, x, y, w = _setup(model_type, s, hidden, f_in)
+    out = model(x, *ops)
+    loss0, dz = AF.nll_loss_and_grad(out, y, w)
+    out.backward(dz)
+    want = {k: v.grad.clone() for k, v in model.named_parameters() if v.grad is not None}
+    model.zero_grad(set_to_none=True)
+    with AF.deferred_reductions() as pending:
+        out = model(x, *ops)
+        loss, dz = AF.nll_loss_and_grad(out, y, w)
+        out.backward(dz)
+        assert pending.pending >= 3
+        assert pending.all_adopted([loss] + [p.grad for p in model.parameters()])
+        pending.flush()
+    assert float(loss) == float(loss0) and np.isfinite(float(loss))
+    got = {k: v.grad for k, v in model.named_parameters() if v.grad is not None}
+    assert got.keys() == want.keys()
+    for k in want:
+        assert torch.equal(got[k], want[k]), k
+
+
+@pytest.mark.parametrize("use_graph", [False, True])
+def test_train_step_trajectory_is_the_same_with_and_without_deferral(use_graph, monkeypatch):
+    from acm_gnn_amd import FusedAdamW, train as T
+    params = {}
+    for defer in (True, False):
+        model, ops, x, y, w = _setup("acmgcnp", 1, 64, dropout=0.3)
+        opt = FusedAdamW(model.parameters(), lr=0.01, weight_decay=1e-3)
+        if not defer:
+            monkeypatch.setattr(T.TrainStep, "_forward_backward", _immediate)
+        model.dropout_state = None
+        step = T.TrainStep(model, opt, x, ops[0], y, w, ops[1], ops[2], use_graph=use_graph)
+        losses = [float(step()) for _ in range(6)]
+        assert step._defer == defer or not defer
+        params[defer] = (losses, [p.detach().clone() for p in model.parameters()])
+        monkeypatch.undo()
+    assert params[True][0] == params[False][0]
+    for a, b in zip(params[True][1], params[False][1]):
+        assert torch.equal(a, b)
+
+
+def _immediate(self):
+    from acm_gnn_amd import functional as AF
+    out = self.model(self.x, self.adj, self.adj_high, self.adj_un)
+    loss, dz = AF.nll_loss_and_grad(out, self.labels, self.weights)
+    out.backward(dz)
+    return loss
