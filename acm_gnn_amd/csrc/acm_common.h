@@ -9,6 +9,7 @@
 
 #define ACM_WAVE 64
 #define ACM_NXCD 8
+#define ACM_WINDOW 16         // work items per window of the piece region (see build_items)
 #define ACM_MIN_CHUNK 128
 #define ACM_MAX_CHUNK 1024
 #define ACM_GROUPS_IN_FLIGHT 8192  // 256 CUs x 8 waves x four 16-lane groups
@@ -35,8 +36,9 @@ void acm_set_error(const char* fmt, ...);
     } while (0)
 
 // A work item: neighbours [begin,end) of `row`; slot < 0 => the item is the whole
-// row and its owner runs the epilogue, otherwise it is one chunk of a long row and
-// its partial sums go to partial slot `slot` (combined in order by the fix-up pass).
+// row and its owner runs the epilogue, otherwise it is one piece of a long row and
+// its partial sums go to partial slot `slot` (combined in order by the fix-up pass, or
+// through LDS by a kernel that takes whole windows, see build_items in acm_csr.cpp).
 struct AcmItem {
     int32_t row, begin, end, slot;
 };
@@ -58,6 +60,7 @@ struct acm_csr {
     int32_t* long_index;    // device, n_rows: index into long_rows, or -1 (NULL when there are no long rows)
     int64_t n_long;
     int64_t n_slots;
+    int64_t n_windows;      // the first n_windows * ACM_WINDOW items are the pieces of the long rows
     int device;
 };
 
@@ -68,6 +71,7 @@ struct CsrView {
     const AcmLongRow* long_rows;
     const int32_t* long_index;
     int n_long;
+    int n_windows;
     const int32_t* indices;
     const float* vals;
 };
@@ -82,6 +86,7 @@ static inline CsrView acm_view(const acm_csr* a) {
     v.long_rows = a->long_rows;
     v.long_index = a->long_index;
     v.n_long = (int)a->n_long;
+    v.n_windows = (int)a->n_windows;
     v.indices = a->indices;
     v.vals = a->vals;
     return v;

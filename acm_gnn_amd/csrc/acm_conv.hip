@@ -18,7 +18,7 @@
 
 int acm_spmm_internal(const acm_csr* a, const void* G, int64_t ldg, int width, float* Y, int64_t ldy,
                       const acm_spmm_opts_t* o, void* workspace, size_t workspace_bytes, acm_stream_t stream,
-                      bool defer_fixup);
+                      bool* defer_fixup);
 
 // ------------------------------------------------------------------ epilogues
 // Layouts A and B give every column exactly one owning lane; layout C replicates the row in
@@ -476,6 +476,10 @@ template <int FP, int NG, int GS, bool MERGED, class Epi>
 __global__ __launch_bounds__(256) void spmm_narrow_kernel(CsrView csr, GatherSrc g, int F, int vecmask,
                                                                typename Epi::Args ea, float* __restrict__ partial) {
     constexpr int GPB = 256 / GS;
+    // GS == 16: a workgroup round is one window of the work list, so the pieces of a long row meet in LDS and the
+    // first piece's group finishes the row -- no partial slots, no fix-up launch (acm_csr.cpp, build_items)
+    constexpr bool COOP = GS == ACM_WINDOW && GPB == ACM_WINDOW;
+    __shared__ float coop_lds[COOP ? ACM_WINDOW * NG * FP : 1];
     const int gl = threadIdx.x % GS;
     const int G = gridDim.x * GPB;
     int w = blockIdx.x * GPB + threadIdx.x / GS;
@@ -546,7 +550,31 @@ __global__ __launch_bounds__(256) void spmm_narrow_kernel(CsrView csr, GatherSrc
         for (int c = 0; c < NG; ++c)
 #pragma unroll
             for (int f = 0; f < FP; ++f) acc[c][f] = acm_group_sum<GS>(acc[c][f]);
-        if (it.slot < 0) {
+        if (COOP && w / ACM_WINDOW < csr.n_windows) {          // uniform over the workgroup: every item here is a piece
+            const int g = threadIdx.x / GS;
+            if (gl == 0) {
+#pragma unroll
+                for (int c = 0; c < NG; ++c)
+#pragma unroll
+                    for (int f = 0; f < FP; ++f) coop_lds[(g * NG + c) * FP + f] = acc[c][f];
+            }
+            __syncthreads();
+            const AcmLongRow lr = csr.long_rows[csr.long_index[it.row]];
+            if (it.slot == lr.slot_begin) {                     // first piece: add the others in slot order
+                const int pieces = lr.slot_end - lr.slot_begin;
+#pragma unroll
+                for (int c = 0; c < NG; ++c)
+#pragma unroll
+                    for (int f = 0; f < FP; ++f) {
+                        float t = 0.f;
+                        for (int q = 0; q < pieces; ++q) t += coop_lds[((g + q) * NG + c) * FP + f];
+                        acc[c][f] = t;
+                    }
+                LaySerial<FP> lay{gl == 0};
+                Epi::template apply<LaySerial<FP>, NG>(ea, it.row, lay, F, acc);
+            }
+            __syncthreads();
+        } else if (it.slot < 0) {
             LaySerial<FP> lay{gl == 0};
             Epi::template apply<LaySerial<FP>, NG>(ea, it.row, lay, F, acc);
         } else if (gl == 0) {
@@ -597,6 +625,15 @@ __global__ __launch_bounds__(256) void spmm_fixup_narrow_kernel(CsrView csr, int
 // ------------------------------------------------------------------ host-side dispatch
 namespace {
 
+// lanes per work item of the narrow gather: 8 for very sparse graphs, 16 up to an average degree of 160 (a power-law
+// graph with mean 82 has median 30: with 32 lanes x 2 neighbours most lanes of most rows idle), 32 beyond
+int narrow_lanes(const acm_csr* a) {
+    const double avg = (double)a->nnz / (double)(a->n_rows > 0 ? a->n_rows : 1);
+    return avg <= 12.0 ? 8 : (avg <= 160.0 ? 16 : 32);
+}
+// with 16 lanes per item a workgroup round is one window: the narrow gather finishes the long rows itself
+bool narrow_finishes_long_rows(const acm_csr* a) { return narrow_lanes(a) == ACM_WINDOW; }
+
 template <int NG, class Epi>
 int launch_gather(const acm_csr* a, const GatherSrc& g, int F, const typename Epi::Args& ea,
                   void* workspace, size_t ws_bytes, hipStream_t st, const char* who,
@@ -624,10 +661,7 @@ int launch_gather(const acm_csr* a, const GatherSrc& g, int F, const typename Ep
                             ((g.ld[c] * sizeof(float)) % al == 0);
             vecmask |= ok ? (1 << c) : 0;
         }
-        const double avg = (double)a->nnz / (double)(a->n_rows > 0 ? a->n_rows : 1);
-        // lanes per work item: 8 for very sparse graphs, 16 up to an average degree of 160 (a power-law graph with
-        // mean 82 has median 30: with 32 lanes x 2 neighbours most lanes of most rows idle), 32 beyond
-        const int gs = avg <= 12.0 ? 8 : (avg <= 160.0 ? 16 : 32);
+        const int gs = narrow_lanes(a);
         // [channel 0 | channel 1] contiguous and block-aligned => one vector fetch for both
         const bool merged = NG >= 2 && F == FP && g.p[1] == g.p[0] + F && g.ld[0] == g.ld[1] &&
                             ((uintptr_t)g.p[0]) % (8 * FP) == 0 && (g.ld[0] * sizeof(float)) % (8 * FP) == 0;
@@ -675,6 +709,7 @@ int launch_gather(const acm_csr* a, const GatherSrc& g, int F, const typename Ep
     ACM_CHECK_HIP(hipGetLastError());
     if (defer_fixup) return ACM_OK;         // the caller's next kernel adds the partial slots of the long rows itself
     if (a->n_long && F <= 8) {
+        if (narrow_finishes_long_rows(a)) return ACM_OK;
         const int grid = (int)((a->n_long + 15) / 16);
         if (F <= 2)
             hipLaunchKernelGGL((spmm_fixup_narrow_kernel<2, NG, Epi>), dim3(grid), dim3(256), 0, st, v, F, ea, partial);
@@ -727,14 +762,17 @@ extern "C" int acm_cast_bf16(int64_t n_rows, int64_t n_cols, const float* src, i
 
 extern "C" int acm_spmm_ex(const acm_csr_t* a, const void* G, int64_t ldg, int width, float* Y, int64_t ldy,
                            const acm_spmm_opts_t* o, void* workspace, size_t workspace_bytes, acm_stream_t stream) {
-    return acm_spmm_internal(a, G, ldg, width, Y, ldy, o, workspace, workspace_bytes, stream, false);
+    return acm_spmm_internal(a, G, ldg, width, Y, ldy, o, workspace, workspace_bytes, stream, nullptr);
 }
 
-// defer_fixup: leave the partial sums of the long rows in the workspace slots (width <= 256); the caller's next
-// kernel adds them (acm_conv_agg_fwd's epilogue)
+// *defer_fixup (in): leave the partial sums of the long rows in the workspace slots (width <= 256) for the caller's
+// next kernel to add (acm_conv_agg_fwd's epilogue); (out): false when the gather finished those rows itself (the narrow
+// kernel with 16 lanes per item) or the width rules it out -- Y is complete then.
 int acm_spmm_internal(const acm_csr* a, const void* G, int64_t ldg, int width, float* Y, int64_t ldy,
                       const acm_spmm_opts_t* o, void* workspace, size_t workspace_bytes, acm_stream_t stream,
-                      bool defer_fixup) {
+                      bool* defer_fixup) {
+    bool defer = defer_fixup && *defer_fixup && a && width <= 256 && !(width <= 8 && narrow_finishes_long_rows(a));
+    if (defer_fixup) *defer_fixup = defer;
     static const acm_spmm_opts_t none = {nullptr, nullptr, nullptr, 0, nullptr, 0, 0};
     if (!o) o = &none;
     ACM_REQUIRE(a && G && Y, ACM_EINVAL, "acm_spmm: NULL argument");
@@ -747,7 +785,7 @@ int acm_spmm_internal(const acm_csr* a, const void* G, int64_t ldg, int width, f
         GatherSrc g = {{reinterpret_cast<const float*>(G) + (o->g_bf16 ? 0 : c0), nullptr, nullptr}, {ldg, 0, 0}};
         EpiPlain::Args ea = {Y + c0, ldy, o->relu, o->sub ? o->sub + c0 : nullptr, o->ld_sub, o->sub_scale, o->row_scale};
         int st = launch_gather<1, EpiPlain>(a, g, wd, ea, workspace, workspace_bytes, (hipStream_t)stream, "acm_spmm",
-                                            o->vals, o->g_bf16 != 0, defer_fixup && width <= 256);
+                                            o->vals, o->g_bf16 != 0, defer);
         if (st != ACM_OK) return st;
     }
     return ACM_OK;
@@ -796,9 +834,11 @@ extern "C" int acm_conv_fwd(const acm_csr_t* a, const acm_conv_fwd_t* p, void* w
         if (st != ACM_OK || a->n_rows == 0) return st;
         const int grid = (int)((a->n_rows + 255) / 256), n = (int)a->n_rows;
         const int FP = F <= 2 ? 2 : (F <= 4 ? 4 : 8);
-        const CsrView cv = acm_view(a);
+        CsrView cv = acm_view(a);
         const float* part = (const float*)workspace;
-        const int tail = (int)((a->n_long + 15) / 16);
+        const bool done = narrow_finishes_long_rows(a);     // the gather left complete raw sums for every row
+        if (done) cv.long_index = nullptr;
+        const int tail = done ? 0 : (int)((a->n_long + 15) / 16);
 #define ACM_ROWS(FPv)                                                                              \
     do {                                                                                           \
         if (k == 4)                                                                                                   \

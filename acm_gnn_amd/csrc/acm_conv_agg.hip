@@ -15,7 +15,7 @@
 // defined in acm_conv.hip
 int acm_spmm_internal(const acm_csr* a, const void* G, int64_t ldg, int width, float* Y, int64_t ldy,
                       const acm_spmm_opts_t* o, void* workspace, size_t workspace_bytes, acm_stream_t stream,
-                      bool defer_fixup);
+                      bool* defer_fixup);
 
 namespace {
 
@@ -185,11 +185,14 @@ __global__ __launch_bounds__(256) void agg_epilogue_kernel(acm_conv_agg_fwd_t p,
 // 16-lane group ends with the aggregated row P replicated in its lanes -- exactly the input layout of agg_fwd_row (16
 // lanes x 4 columns of one row) -- so the projections and the head run right there, on lanes that would otherwise
 // idle through the next item's gather latency.  Same software pipeline over the work list as spmm_narrow_kernel.
-// Work items of long rows write their partial sums to the slots; agg_long_rows_kernel finishes those rows.
+// The pieces of a long row fill whole windows of the work list (acm_csr.cpp, build_items): a workgroup round is one
+// window, the pieces meet in LDS and the first piece's group finishes the row -- no partial slots, no second launch.
 template <int FP, bool FULL>
-__global__ __launch_bounds__(256) void agg_fused_kernel(acm_conv_agg_fwd_t p, CsrView csr, float* __restrict__ partial) {
+__global__ __launch_bounds__(256) void agg_fused_kernel(acm_conv_agg_fwd_t p, CsrView csr) {
     constexpr int K = 3, GS = 16, GPB = 16;
+    static_assert(GPB == ACM_WINDOW, "one window of work items per workgroup round");
     __shared__ __attribute__((aligned(16))) float wlds[3 * FP * 64 + 3 * K * 64 + 16 * 2 * FP];
+    __shared__ float coop[ACM_WINDOW * FP];
     float* hlds = wlds + 3 * FP * 64;
     float* scratch = hlds + 3 * K * 64 + (threadIdx.x >> 4) * 2 * FP;
     stage_weights<FP>(wlds, p.w_low, p.w_high, p.w_mlp, p.ld_w, p.f_in, p.f_out);
@@ -238,7 +241,28 @@ __global__ __launch_bounds__(256) void agg_fused_kernel(acm_conv_agg_fwd_t p, Cs
         }
 #pragma unroll
         for (int f = 0; f < FP; ++f) acc[f] = acm_group_sum<GS>(acc[f]);
-        if (it.slot < 0) {
+        bool finish = it.slot < 0;
+        if (w / ACM_WINDOW < csr.n_windows) {                   // a window of pieces (uniform over the workgroup):
+            const int g = threadIdx.x >> 4;                     // they meet in LDS, the first piece finishes the row
+            if (gl == 0) {
+#pragma unroll
+                for (int f = 0; f < FP; ++f) coop[g * FP + f] = acc[f];
+            }
+            __syncthreads();
+            const AcmLongRow lr = csr.long_rows[csr.long_index[it.row]];
+            finish = it.slot == lr.slot_begin;
+            if (finish) {
+                const int pieces = lr.slot_end - lr.slot_begin;
+#pragma unroll
+                for (int f = 0; f < FP; ++f) {
+                    float t = 0.f;
+                    for (int q = 0; q < pieces; ++q) t += coop[(g + q) * FP + f];
+                    acc[f] = t;
+                }
+            }
+            __syncthreads();
+        }
+        if (finish) {
             const float rs = p.row_scale ? p.row_scale[it.row] : 1.f;
             if (gl == 0) {
 #pragma unroll
@@ -249,10 +273,6 @@ __global__ __launch_bounds__(256) void agg_fused_kernel(acm_conv_agg_fwd_t p, Cs
                 }
             }
             agg_fwd_row<FP, K, FULL>(p, wlds, hlds, scratch, mixm, it.row, lane, csr, nullptr, true);
-        } else if (gl == 0) {
-            float* ps = partial + (long)it.slot * FP;
-#pragma unroll
-            for (int f = 0; f < FP; ++f) ps[f] = acc[f];
         }
         if (!has_next) break;
         it = itn;
@@ -268,9 +288,11 @@ __global__ __launch_bounds__(256) void agg_fused_kernel(acm_conv_agg_fwd_t p, Cs
 // gather once the rows hit in L1/L2 (scripts/probe_gather.py: 63 us with every row in L1).
 // Lane (e = gl >> 1, h = gl & 1) of the 16-lane group: neighbours k0 + e + 8 u (u = 0..3), columns 4 h .. 4 h + 3.
 template <bool FULL>
-__global__ __launch_bounds__(256) void agg_fused_pair_kernel(acm_conv_agg_fwd_t p, CsrView csr, float* __restrict__ partial) {
+__global__ __launch_bounds__(256) void agg_fused_pair_kernel(acm_conv_agg_fwd_t p, CsrView csr) {
     constexpr int FP = 8, K = 3, GPB = 16, U = 4, STEP = 8 * U;
+    static_assert(GPB == ACM_WINDOW, "one window of work items per workgroup round");
     __shared__ __attribute__((aligned(16))) float wlds[3 * FP * 64 + 3 * K * 64 + 16 * 2 * FP];
+    __shared__ float coop[ACM_WINDOW * FP];
     float* hlds = wlds + 3 * FP * 64;
     float* scratch = hlds + 3 * K * 64 + (threadIdx.x >> 4) * 2 * FP;
     stage_weights<FP>(wlds, p.w_low, p.w_high, p.w_mlp, p.ld_w, p.f_in, p.f_out);
@@ -340,7 +362,28 @@ __global__ __launch_bounds__(256) void agg_fused_pair_kernel(acm_conv_agg_fwd_t 
             acc[i] += acm_dpp<0x124>(acc[i]);    // row_ror:4
             acc[i] += acm_dpp<0x128>(acc[i]);    // row_ror:8
         }
-        if (it.slot < 0) {
+        bool finish = it.slot < 0;
+        if (w / ACM_WINDOW < csr.n_windows) {                   // a window of pieces: see agg_fused_kernel
+            const int g = threadIdx.x >> 4;
+            if (gl < 2) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) coop[g * FP + 4 * h + i] = acc[i];
+            }
+            __syncthreads();
+            const AcmLongRow lr = csr.long_rows[csr.long_index[it.row]];
+            finish = it.slot == lr.slot_begin;
+            if (finish && gl < 2) {
+                const int pieces = lr.slot_end - lr.slot_begin;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    float t = 0.f;
+                    for (int q = 0; q < pieces; ++q) t += coop[(g + q) * FP + 4 * h + i];
+                    acc[i] = t;
+                }
+            }
+            __syncthreads();
+        }
+        if (finish) {
             const float rs = p.row_scale ? p.row_scale[it.row] : 1.f;
             if (gl < 2) {
 #pragma unroll
@@ -351,35 +394,12 @@ __global__ __launch_bounds__(256) void agg_fused_pair_kernel(acm_conv_agg_fwd_t 
                 }
             }
             agg_fwd_row<FP, K, FULL>(p, wlds, hlds, scratch, mixm, it.row, lane, csr, nullptr, true);
-        } else if (gl < 2) {
-            float* ps = partial + (long)it.slot * FP + 4 * h;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) ps[i] = acc[i];
         }
         if (!has_next) break;
         it = itn;
         w = wn;
         k0 = it.begin;
     }
-}
-
-// the long rows of the fused form: partial slots -> P -> projections -> head
-template <int FP>
-__global__ __launch_bounds__(256) void agg_long_rows_kernel(acm_conv_agg_fwd_t p, CsrView csr,
-                                                            const float* __restrict__ partial) {
-    constexpr int K = 3;
-    __shared__ __attribute__((aligned(16))) float wlds[3 * FP * 64 + 3 * K * 64 + 16 * 2 * FP];
-    float* hlds = wlds + 3 * FP * 64;
-    float* scratch = hlds + 3 * K * 64 + (threadIdx.x >> 4) * 2 * FP;
-    stage_weights<FP>(wlds, p.w_low, p.w_high, p.w_mlp, p.ld_w, p.f_in, p.f_out);
-    stage_head_params<K>(hlds, p.att_vec, p.ln_weight, p.ln_bias, p.layernorm, p.f_out);
-    __syncthreads();
-    float mixm[K * K];
-#pragma unroll
-    for (int q = 0; q < K * K; ++q) mixm[q] = p.att_mix[q];
-    const int lane = threadIdx.x & 63;
-    for (int i = blockIdx.x * 16 + (threadIdx.x >> 4); i < csr.n_long; i += gridDim.x * 16)
-        agg_fwd_row<FP, K>(p, wlds, hlds, scratch, mixm, csr.long_rows[i].row, lane, csr, partial);
 }
 
 // ---------------------------------------------------------------- backward
@@ -572,7 +592,7 @@ extern "C" int acm_conv_agg_fwd(const acm_csr_t* a, const acm_conv_agg_fwd_t* p,
                 "acm_conv_agg_fwd: xg / agg rows must be 16-byte aligned and f_pad long");
     if (a->n_rows == 0) return ACM_OK;
     hipStream_t s = (hipStream_t)stream;
-    // (0) fused form: gather + epilogue in one kernel, plus a small one for the long rows
+    // (0) fused form: gather + epilogue in one kernel (long rows included)
     {
         const double avg = (double)a->nnz / (double)(a->n_rows > 0 ? a->n_rows : 1);
         const bool fused_off = getenv("ACM_AGG_UNFUSED") != nullptr;      // read per call: tests switch forms
@@ -580,33 +600,25 @@ extern "C" int acm_conv_agg_fwd(const acm_csr_t* a, const acm_conv_agg_fwd_t* p,
                            ((uintptr_t)p->xg) % 16 == 0 && (p->ld_xg * sizeof(float)) % 16 == 0 &&
                            (a->n_long == 0 || a->long_index != nullptr);
         if (fused) {
-            const size_t need = (size_t)a->n_slots * (size_t)p->f_pad * sizeof(float);
-            ACM_REQUIRE(workspace_bytes >= need && (need == 0 || workspace), ACM_ENOMEM,
-                        "acm_conv_agg_fwd: workspace %zu B < required %zu B", workspace_bytes, need);
             const CsrView cv = acm_view(a);
-            float* partial = (float*)workspace;
             int grid = (int)((a->n_items + 15) / 16);
             // every block stages the weights and head parameters (8.4 KB) before it starts: 12 blocks per CU keep that
             // prologue small against the gather (8192 blocks: 125 us, 3072: 115 us, 1024: 125 us on the twitch graph)
             if (grid > 3072) grid = 3072;
-            int tail = (int)((a->n_long + 15) / 16);
-            if (tail > 1024) tail = 1024;
             const bool full = p->f_out == 64;
             if (p->f_pad == 4) {
-                if (full) hipLaunchKernelGGL((agg_fused_kernel<4, true>), dim3(grid), dim3(256), 0, s, *p, cv, partial);
-                else hipLaunchKernelGGL((agg_fused_kernel<4, false>), dim3(grid), dim3(256), 0, s, *p, cv, partial);
-                if (tail) hipLaunchKernelGGL((agg_long_rows_kernel<4>), dim3(tail), dim3(256), 0, s, *p, cv, partial);
+                if (full) hipLaunchKernelGGL((agg_fused_kernel<4, true>), dim3(grid), dim3(256), 0, s, *p, cv);
+                else hipLaunchKernelGGL((agg_fused_kernel<4, false>), dim3(grid), dim3(256), 0, s, *p, cv);
             } else {
                 const bool pair_lanes = getenv("ACM_AGG_NO_PAIR") == nullptr;
                 if (pair_lanes && full)
-                    hipLaunchKernelGGL((agg_fused_pair_kernel<true>), dim3(grid), dim3(256), 0, s, *p, cv, partial);
+                    hipLaunchKernelGGL((agg_fused_pair_kernel<true>), dim3(grid), dim3(256), 0, s, *p, cv);
                 else if (pair_lanes)
-                    hipLaunchKernelGGL((agg_fused_pair_kernel<false>), dim3(grid), dim3(256), 0, s, *p, cv, partial);
+                    hipLaunchKernelGGL((agg_fused_pair_kernel<false>), dim3(grid), dim3(256), 0, s, *p, cv);
                 else if (full)
-                    hipLaunchKernelGGL((agg_fused_kernel<8, true>), dim3(grid), dim3(256), 0, s, *p, cv, partial);
+                    hipLaunchKernelGGL((agg_fused_kernel<8, true>), dim3(grid), dim3(256), 0, s, *p, cv);
                 else
-                    hipLaunchKernelGGL((agg_fused_kernel<8, false>), dim3(grid), dim3(256), 0, s, *p, cv, partial);
-                if (tail) hipLaunchKernelGGL((agg_long_rows_kernel<8>), dim3(tail), dim3(256), 0, s, *p, cv, partial);
+                    hipLaunchKernelGGL((agg_fused_kernel<8, false>), dim3(grid), dim3(256), 0, s, *p, cv);
             }
             ACM_CHECK_HIP(hipGetLastError());
             return ACM_OK;
@@ -616,8 +628,8 @@ extern "C" int acm_conv_agg_fwd(const acm_csr_t* a, const acm_conv_agg_fwd_t* p,
     acm_spmm_opts_t o = {nullptr, p->row_scale, nullptr, 0, nullptr, 0, 0};
     // three channels: the long rows' partial sums stay in the workspace and the epilogue kernel adds them (one launch
     // less); with the structure channel the second gather reuses the workspace, so the fix-up runs right away
-    const bool defer = p->n_channels == 3 && a->n_long > 0 && a->long_index != nullptr;
-    st = acm_spmm_internal(a, p->xg, p->ld_xg, p->f_pad, p->agg, p->ld_agg, &o, workspace, workspace_bytes, stream, defer);
+    bool defer = p->n_channels == 3 && a->n_long > 0 && a->long_index != nullptr;
+    st = acm_spmm_internal(a, p->xg, p->ld_xg, p->f_pad, p->agg, p->ld_agg, &o, workspace, workspace_bytes, stream, &defer);
     if (st != ACM_OK) return st;
     // (1b) structure channel: PS = A_low S -> p->ps (F wide; bf16 operand optional)
     if (p->n_channels == 4) {

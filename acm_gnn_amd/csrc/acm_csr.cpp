@@ -36,10 +36,15 @@ void free_handle(acm_csr* a) {
     delete a;
 }
 
-// Split rows into work items of at most `chunk` neighbours (long rows into
-// near-equal pieces) -- host side, from a host copy of indptr.
+// Split rows into work items of at most `chunk` neighbours -- host side, from a host copy of indptr.
+// A long row (more than `chunk` neighbours) becomes P = min(16, ceil(deg / chunk)) near-equal pieces with consecutive
+// partial slots.  All pieces come FIRST in the list, packed into windows of ACM_WINDOW = 16 items so that the pieces of
+// one row never straddle a window (a window that cannot take the next row is filled up with empty pieces of the row
+// before, and so is the last one): a kernel whose workgroup takes one window per round (16 groups of 16 lanes) can
+// combine the pieces of a row through LDS and finish the row itself instead of leaving partial sums to a second
+// launch; every other kernel writes the pieces to their partial slots as before.  The whole rows follow in row order.
 void build_items(const std::vector<int32_t>& indptr, int chunk, std::vector<AcmItem>& items,
-                 std::vector<AcmLongRow>& longs, int64_t& n_slots, int32_t& max_deg) {
+                 std::vector<AcmLongRow>& longs, int64_t& n_slots, int32_t& max_deg, int64_t& n_windows) {
     const int64_t n = (int64_t)indptr.size() - 1;
     items.clear();
     longs.clear();
@@ -50,20 +55,32 @@ void build_items(const std::vector<int32_t>& indptr, int chunk, std::vector<AcmI
         const int32_t b = indptr[r], e = indptr[r + 1];
         const int32_t deg = e - b;
         max_deg = std::max(max_deg, deg);
-        if (deg <= chunk) {
-            items.push_back({(int32_t)r, b, e, -1});
-        } else {
-            const int32_t pieces = (deg + chunk - 1) / chunk;
-            const int32_t per = (deg + pieces - 1) / pieces;
-            AcmLongRow lr = {(int32_t)r, (int32_t)n_slots, 0, 0};
-            for (int32_t s = b; s < e; s += per) {
-                items.push_back({(int32_t)r, s, std::min(e, s + per), (int32_t)n_slots});
-                ++n_slots;
-            }
-            lr.slot_end = (int32_t)n_slots;
-            longs.push_back(lr);
+        if (deg <= chunk) continue;
+        int32_t pieces = (deg + chunk - 1) / chunk;
+        if (pieces > ACM_WINDOW) pieces = ACM_WINDOW;
+        const int32_t room = ACM_WINDOW - (int32_t)(items.size() % ACM_WINDOW);
+        if (room < pieces && room < ACM_WINDOW) {                 // does not fit: pad with empty pieces of the row before
+            AcmLongRow& prev = longs.back();
+            for (int32_t q = 0; q < room; ++q) items.push_back({prev.row, indptr[prev.row + 1], indptr[prev.row + 1], (int32_t)n_slots++});
+            prev.slot_end = (int32_t)n_slots;
         }
+        const int32_t per = (deg + pieces - 1) / pieces;
+        AcmLongRow lr = {(int32_t)r, (int32_t)n_slots, 0, 0};
+        for (int32_t q = 0; q < pieces; ++q) {
+            const int32_t s = std::min(e, b + q * per);
+            items.push_back({(int32_t)r, s, std::min(e, s + per), (int32_t)n_slots++});
+        }
+        lr.slot_end = (int32_t)n_slots;
+        longs.push_back(lr);
     }
+    if (!longs.empty() && items.size() % ACM_WINDOW) {
+        AcmLongRow& prev = longs.back();
+        while (items.size() % ACM_WINDOW) items.push_back({prev.row, indptr[prev.row + 1], indptr[prev.row + 1], (int32_t)n_slots++});
+        prev.slot_end = (int32_t)n_slots;
+    }
+    n_windows = (int64_t)items.size() / ACM_WINDOW;
+    for (int64_t r = 0; r < n; ++r)
+        if (indptr[r + 1] - indptr[r] <= chunk) items.push_back({(int32_t)r, indptr[r], indptr[r + 1], -1});
 }
 
 // Finish a handle whose indptr/indices/vals device arrays are already in place.
@@ -79,7 +96,7 @@ int finish_handle(acm_csr* a, const std::vector<int32_t>& h_indptr, int chunk) {
     a->chunk = chunk > 0 ? chunk : (env_chunk > 0 ? env_chunk : auto_chunk);
     std::vector<AcmItem> items;
     std::vector<AcmLongRow> longs;
-    build_items(h_indptr, a->chunk, items, longs, a->n_slots, a->max_degree);
+    build_items(h_indptr, a->chunk, items, longs, a->n_slots, a->max_degree, a->n_windows);
     a->n_items = (int64_t)items.size();
     a->n_long = (int64_t)longs.size();
     if (a->n_items) {

@@ -236,7 +236,16 @@ class FakeLib:
         longs = deg[deg > a.chunk]
         i.n_rows, i.n_cols, i.nnz = a.n_rows, a.n_cols, len(a.indices)
         i.n_long_rows = len(longs)
-        i.n_partial_slots = int(np.sum(-(-longs // a.chunk)))
+        # the library's work list (acm_csr.cpp, build_items): min(16, ceil(deg / chunk)) pieces per long row, packed
+        # into windows of 16 items that no row straddles (gaps and the last window filled with empty pieces)
+        used = 0
+        for p in np.minimum(16, -(-longs // a.chunk)):
+            room = 16 - used % 16
+            if room < p and room < 16:
+                used += room
+            used += int(p)
+        used += (-used) % 16
+        i.n_partial_slots = used
         i.n_items = a.n_rows - len(longs) + i.n_partial_slots
         i.chunk, i.max_degree = a.chunk, int(deg.max()) if len(deg) else 0
         i.indptr, i.indices = a.indptr.ctypes.data, a.indices.ctypes.data

@@ -155,6 +155,36 @@ def test_spmm_matches_scipy(width, chunk):
     assert np.array_equal(out, out2)
 
 
+@pytest.mark.parametrize("chunk,hubs", [(16, {3: 390, 100: 200, 516: 70}), (16, {0: 17, 1: 17, 2: 300, 9: 33}),
+                                        (64, {5: 400, 6: 65, 7: 129, 8: 1000}), (0, {1: 390})])
+def test_work_list_layout(chunk, hubs):
+    """Long rows are min(16, ceil(deg / chunk)) pieces, packed into windows of 16 work items that no row straddles
+    (the kernels that take one window per workgroup round finish those rows through LDS): the counts the library
+    reports equal the restatement in tests/fake_lib.py."""
+    import ctypes as C
+    import fake_lib
+    from acm_gnn_amd import _lib
+    from acm_gnn_amd.graph import CsrGraph
+    m = _rand_csr(1200, 1100, 0.01, seed=4, hub_rows=hubs)
+    g = CsrGraph.from_scipy(m, DEV, chunk=chunk)
+    fake = fake_lib.FakeLib()
+    h = C.c_void_p()
+    ip, ix, v = (np.ascontiguousarray(a) for a in (m.indptr.astype(np.int32), m.indices.astype(np.int32), m.data.astype(np.float32)))
+    assert fake.acm_csr_create(m.shape[0], m.shape[1], m.nnz, ip.ctypes.data, ix.ctypes.data, v.ctypes.data, chunk, C.byref(h)) == 0
+    info = _lib.CsrInfo()
+    assert fake.acm_csr_info(h, C.byref(info)) == 0
+    assert (g.chunk, g.n_long_rows, g.n_partial_slots, g.n_items, g.max_degree) == \
+        (info.chunk, info.n_long_rows, info.n_partial_slots, info.n_items, info.max_degree)
+    assert g.n_partial_slots % 16 == 0 and (g.n_long_rows == 0) == (g.n_partial_slots == 0)
+    for width in (2, 8, 64):                                   # narrow (cooperative) and wide (slots + fix-up) gathers
+        from acm_gnn_amd import functional as AF
+        dense = torch.randn(1100, width, generator=torch.Generator().manual_seed(width))
+        out = AF.spmm(g, dense.to(DEV)).cpu().numpy()
+        ref = m.astype(np.float64) @ dense.double().numpy()
+        scale = abs(m).astype(np.float64) @ dense.abs().double().numpy()
+        assert np.max(np.abs(out - ref) / (scale + 1e-20) * (scale > 0)) < 2e-6
+
+
 def test_spmm_ignores_nonfinite_rows_it_never_references():
     from acm_gnn_amd import functional as AF
     from acm_gnn_amd.graph import CsrGraph
