@@ -2,7 +2,7 @@
 """HBM bytes per launch of the bench step's kernels from the FETCH_SIZE / WRITE_SIZE PMC summaries
 (scripts/rocpd_pmc_summary.py CSVs):  hbm_bytes = (2 * FETCH_SIZE + WRITE_SIZE) * 1024, FETCH_SIZE doubled as
 /opt/skills/guides/MI355X_MICROARCH.md prescribes for gfx950.  Keys are bench.py's kernel labels; a label
-made of several launches (gather + fix-up + epilogue) sums them.
+made of several launches (gather + row epilogue) sums them.
 
     python scripts/make_traffic_json.py pmc_fetch_size_kb.csv pmc_write_size_kb.csv > pmc_traffic.json
 """
@@ -12,13 +12,17 @@ import sys
 
 # bench label -> substrings identifying its kernels in the profiler's names
 LABELS = {
-    "conv_agg_fwd/F64k3i7": ["agg_fused_pair_kernel", "agg_fused_kernel<8", "agg_long_rows_kernel<8>"],
-    "conv_agg_bwd/F64k3i7": ["agg_bwd_kernel<8, 3>", "reduce_columns_kernel"],
+    "conv_agg_fwd/F64k3i7": ["agg_fused_pair_kernel", "agg_fused_kernel<8"],
+    "conv_agg_bwd/F64k3i7": ["agg_bwd_kernel<8, 3"],
     "conv_fwd/F2k3": ["spmm_narrow_kernel<2, 2, 16, true, EpiRaw>", "conv_fwd_rows_kernel<2, 2>"],
-    "conv_bwd_spmm/F2k3": ["spmm_narrow_kernel<2, 2, 16, true, EpiBwd>", "spmm_fixup_narrow_kernel<2, 2, EpiBwd>"],
-    "conv_bwd_local/F2k3": ["conv_bwd_local_kernel<LayPacked<2>, 32, 3>", "conv_bwd_reduce_kernel"],
-    "proj_bwd/168114x64x6": ["proj_bwd_kernel<6>", "proj_reduce_kernel"],
+    "conv_bwd_spmm/F2k3": ["spmm_narrow_kernel<2, 2, 16, true, EpiBwd>"],
+    "conv_bwd_local/F2k3": ["conv_bwd_local_kernel<LayPacked<2>, 32, 3>"],
+    "proj_bwd/168114x64x6": ["proj_bwd_kernel<6>"],
     "proj_fwd/168114x64x6": ["proj_fwd_kernel<2>"],
+    "nll_loss/168114x2": ["nll_rows_kernel"],
+    "dropout/168114x7": ["dropout_kernel"],
+    "reduce_flush": ["reduce_segments_kernel"],          # every deferred second phase of the step, one launch
+    "adam_step": ["adam_kernel"],
 }
 
 
