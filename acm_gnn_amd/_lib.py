@@ -14,7 +14,7 @@ c_i32p = C.POINTER(C.c_int32)
 
 ACM_OK = 0
 STATUS_NAMES = {1: "ACM_EINVAL", 2: "ACM_ESHAPE", 3: "ACM_EHIP", 4: "ACM_EUNSUPPORTED", 5: "ACM_ENOMEM"}
-ABI_VERSION = 14
+ABI_VERSION = 15
 
 # every symbol include/acm_hip.h declares
 EXPORTED_SYMBOLS = (
@@ -106,7 +106,8 @@ class ConvAggFwd(C.Structure):
                 ("att", C.c_void_p), ("post_scale", C.c_void_p), ("ld_post_scale", C.c_int64), ("post_relu", C.c_int32),
                 ("n_channels", C.c_int32), ("sg", C.c_void_p), ("ld_sg", C.c_int64), ("sg_bf16", C.c_int32),
                 ("ss", C.c_void_p), ("ld_ss", C.c_int64), ("deg", C.c_void_p),
-                ("ps", C.c_void_p), ("ld_ps", C.c_int64), ("row_scale", C.c_void_p), ("post_drop", Dropout)]
+                ("ps", C.c_void_p), ("ld_ps", C.c_int64), ("row_scale", C.c_void_p), ("post_drop", Dropout),
+                ("head_stats", C.c_void_p), ("ld_head_stats", C.c_int64)]
 
 
 class ConvAggBwd(C.Structure):
@@ -122,7 +123,8 @@ class ConvAggBwd(C.Structure):
                 ("n_channels", C.c_int32), ("ps", C.c_void_p), ("ld_ps", C.c_int64),
                 ("ss", C.c_void_p), ("ld_ss", C.c_int64), ("deg", C.c_void_p),
                 ("g_struc", C.c_void_p), ("ld_g_struc", C.c_int64), ("g_struc_scale", C.c_void_p),
-                ("post_drop", Dropout), ("defer", C.c_void_p)]
+                ("post_drop", Dropout), ("defer", C.c_void_p),
+                ("head_stats", C.c_void_p), ("ld_head_stats", C.c_int64)]
 
 
 class ReduceSeg(C.Structure):

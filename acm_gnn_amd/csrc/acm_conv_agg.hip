@@ -140,6 +140,7 @@ __device__ __forceinline__ void agg_fwd_row(const acm_conv_agg_fwd_t& p, const f
     }
     RowHead<K> rh;
     row_head<K>(hlds, mixm, acm_opaque(m), F, p.layernorm != 0, H, rh);
+    if (p.head_stats && m == 0) row_head_store<K>(p.head_stats + (long)row * p.ld_head_stats, rh);
     float df[4];
     acm_drop4(acm_drop_ctx(p.post_drop), row, m, df);
 #pragma unroll
@@ -478,7 +479,8 @@ __global__ __launch_bounds__(256, 2) void agg_bwd_kernel(acm_conv_agg_bwd_t p, i
         // ---- pass 1: per-channel statistics and the attention scalars
         const int mm = acm_opaque(m);
         RowHead<K> rh;
-        row_head<K>(hlds, mixm, mm, F, ln, H, rh);
+        if (p.head_stats) row_head_load<K>(p.head_stats + rr * p.ld_head_stats, rh);     // as the forward computed them
+        else row_head<K>(hlds, mixm, mm, F, ln, H, rh);
         row_post_backward<K>(p, rh, H, active, rr, m, F, dO);
         float ds[K];
         row_head_backward_scalars<K>(rh, mixm, p.scale, H, dO, ds, qc, qj, dmix1);
@@ -568,6 +570,9 @@ int check_common(const P* p, const char* who) {
     ACM_REQUIRE(((uintptr_t)p->xs) % 16 == 0 && (p->ld_xs * 4) % 16 == 0 && p->ld_xs >= p->f_pad, ACM_EINVAL,
                 "%s: xs rows must be 16-byte aligned and f_pad long", who);
     ACM_REQUIRE(p->n_channels == 3 || p->n_channels == 4, ACM_ESHAPE, "%s: n_channels %d", who, p->n_channels);
+    ACM_REQUIRE(!p->head_stats || (((uintptr_t)p->head_stats) % 16 == 0 && p->ld_head_stats % 4 == 0 &&
+                                   p->ld_head_stats >= 4 * p->n_channels), ACM_EINVAL,
+                "%s: head_stats rows must be 16-byte aligned and 4 * n_channels long", who);
     for (int c = 0; c < p->n_channels; ++c) {
         ACM_REQUIRE(p->att_vec[c], ACM_EINVAL, "%s: att_vec[%d] NULL", who, c);
         ACM_REQUIRE(!p->layernorm || (p->ln_weight[c] && p->ln_bias[c]), ACM_EINVAL, "%s: LayerNorm pointers NULL", who);

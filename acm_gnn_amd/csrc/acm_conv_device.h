@@ -312,6 +312,28 @@ struct RowHead {
     float mean[K], rstd[K], gsig[K], alpha[K];
 };
 
+// head_stats row (acm_conv_agg_fwd_t): mean[K] | rstd[K] | gsig[K] | alpha[K], 16-byte aligned
+template <int K>
+__device__ __forceinline__ void row_head_store(float* __restrict__ dst, const RowHead<K>& r) {
+    float v[4 * K];
+#pragma unroll
+    for (int c = 0; c < K; ++c) v[c] = r.mean[c], v[K + c] = r.rstd[c], v[2 * K + c] = r.gsig[c], v[3 * K + c] = r.alpha[c];
+#pragma unroll
+    for (int q = 0; q < K; ++q)
+        reinterpret_cast<float4*>(dst)[q] = make_float4(v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]);
+}
+template <int K>
+__device__ __forceinline__ void row_head_load(const float* __restrict__ src, RowHead<K>& r) {
+    float v[4 * K];
+#pragma unroll
+    for (int q = 0; q < K; ++q) {
+        const float4 t = reinterpret_cast<const float4*>(src)[q];
+        v[4 * q] = t.x, v[4 * q + 1] = t.y, v[4 * q + 2] = t.z, v[4 * q + 3] = t.w;
+    }
+#pragma unroll
+    for (int c = 0; c < K; ++c) r.mean[c] = v[c], r.rstd[c] = v[K + c], r.gsig[c] = v[2 * K + c], r.alpha[c] = v[3 * K + c];
+}
+
 template <int K>
 struct HeadVecs {   // the lane's four columns of att_vec / gamma / beta of one channel
     float v[4], gm[4], bt[4];

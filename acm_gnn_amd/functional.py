@@ -680,6 +680,12 @@ class AcmConvFunction(torch.autograd.Function):
                 p.ps, p.ld_ps = ps.data_ptr(), ps.stride(0)
                 extra = (ps, s_local)
             set_post(p)
+            # the row's head statistics (mean | rstd | sigmoid | alpha per channel): 16 k bytes per row that save
+            # the backward three 16-lane reductions per channel and row
+            stats = torch.empty(n, 4 * k, dtype=_F32, device=dev) if any(ctx.needs_input_grad) else None
+            if stats is not None:
+                p.head_stats, p.ld_head_stats = stats.data_ptr(), stats.stride(0)
+            ctx.head_stats = stats
             ws = ops.low.workspace(max(fp, f) if four else fp)
             with _device_ctx(dev), _Timed(f"conv_agg_fwd/F{f}k{k}i{f_in}"):
                 st = lib.acm_conv_agg_fwd(ops.low.handle, C.byref(p), _vp(ws), ws.numel() * 4, _stream())
@@ -928,6 +934,8 @@ def _backward_agg(ctx, grad_out):
     q.relu_after, q.relu_mlp, q.layernorm, q.scale = int(cfg.relu_after), int(cfg.relu_mlp), int(cfg.layernorm), cfg.scale
     q.grad_out, q.ld_grad_out = grad_out.data_ptr(), grad_out.stride(0)
     q.agg, q.ld_agg = agg.data_ptr(), agg.stride(0)
+    if getattr(ctx, "head_stats", None) is not None:
+        q.head_stats, q.ld_head_stats = ctx.head_stats.data_ptr(), ctx.head_stats.stride(0)
     q.xs, q.ld_xs = xpad.data_ptr(), xpad.stride(0)
     q.w_low, q.w_high, q.w_mlp, q.ld_w = wl.data_ptr(), wh.data_ptr(), wm.data_ptr(), f
     q.att_vec, q.ln_weight, q.ln_bias = _ptr_array(vecs), _ptr_array(lnw), _ptr_array(lnb)

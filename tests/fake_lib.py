@@ -151,7 +151,7 @@ class FakeLib:
 
     # ---- plumbing ---------------------------------------------------------
     def acm_version(self):
-        return 14
+        return 15
 
     # ---- deferred second phases (acm_reduce_list_t): results of a deferred call are poisoned with NaN until the
     # flush, so a consumer that reads them too early fails its test instead of passing by accident
@@ -514,6 +514,13 @@ class FakeLib:
         att = _view(p.att, n, 4, 4)
         att[...] = 0
         att[:, :k] = hd["alpha"]
+        if p.head_stats:                                    # mean | rstd | sigmoid | alpha per channel
+            st = _view(p.head_stats, n, 4 * k, p.ld_head_stats)
+            for c in range(k):
+                st[:, c] = H[c].mean(1) if p.layernorm else 0.0
+                st[:, k + c] = np.asarray(hd["rstd"][c]).reshape(-1) if p.layernorm else 1.0
+                st[:, 2 * k + c] = hd["g"][:, c]
+                st[:, 3 * k + c] = hd["alpha"][:, c]
         return 0
 
     def acm_conv_agg_bwd(self, n, qq, ws, wsb, stream):

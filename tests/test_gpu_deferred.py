@@ -74,3 +74,36 @@ def _immediate(self):
     loss, dz = AF.nll_loss_and_grad(out, self.labels, self.weights)
     out.backward(dz)
     return loss
+
+
+@pytest.mark.parametrize("s,ln", [(0, True), (0, False), (1, True)])
+def test_saved_head_statistics_equal_the_recomputation_bitwise(s, ln, monkeypatch):
+    """acm_conv_agg_fwd hands its row statistics (mean | rstd | sigmoid | alpha) to acm_conv_agg_bwd; without them the
+    backward recomputes the same numbers with the same code, so every gradient agrees bit for bit."""
+    from acm_gnn_amd import GraphConvolution, functional as AF, data as D
+    from oracle import acm_oracle as O
+    adj, x_np, _, _, _ = D.synthetic_dataset("tiny", seed=5)
+    low, high, un = (m.to(DEV) for m in O.filters_linkx(adj))
+    n = adj.shape[0]
+    torch.manual_seed(1)
+    layer = GraphConvolution(7, 64, n, "acmgcnp", structure_info=s, attn_layernorm=ln).to(DEV)
+    x = torch.from_numpy(x_np[:, :7].astype(np.float32)).to(DEV).requires_grad_(True)
+    gout = torch.randn(n, 64, device=DEV)
+    grads = []
+    for use_stats in (True, False):
+        if not use_stats:
+            real = AF._lib.ConvAggBwd
+
+            class NoStats(real):                       # same struct; the stats pointer is dropped before the call
+                def __setattr__(self, k, v):
+                    if k not in ("head_stats", "ld_head_stats"):
+                        super().__setattr__(k, v)
+            monkeypatch.setattr(AF._lib, "ConvAggBwd", NoStats)
+        layer.zero_grad(set_to_none=True)
+        x.grad = None
+        out = layer(x, low, high, un if s else None)
+        out.backward(gout)
+        grads.append({k: v.grad.clone() for k, v in layer.named_parameters() if v.grad is not None} | {"x": x.grad.clone()})
+    assert grads[0].keys() == grads[1].keys() and len(grads[0]) >= 8
+    for k in grads[0]:
+        assert torch.equal(grads[0][k], grads[1][k]), k
