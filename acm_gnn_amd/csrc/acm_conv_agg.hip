@@ -465,7 +465,8 @@ __global__ __launch_bounds__(256, 2) void agg_bwd_kernel(acm_conv_agg_bwd_t p, i
         }
         {
             float p0[4], p1[4], zi[4];
-            project<FP>(wlds, scratch, m, p.agg + rr * p.ld_agg, p.xs + rr * p.ld_xs, active, p0, p1, zi);
+            // 32-bit element offsets (the host checks n_rows * ld < 2^31): a long x long product is three quarter-rate multiplies
+            project<FP>(wlds, scratch, m, p.agg + (unsigned)rr * (unsigned)p.ld_agg, p.xs + (unsigned)rr * (unsigned)p.ld_xs, active, p0, p1, zi);
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const bool ok = active && m + 16 * i < F;
@@ -479,7 +480,7 @@ __global__ __launch_bounds__(256, 2) void agg_bwd_kernel(acm_conv_agg_bwd_t p, i
         // ---- pass 1: per-channel statistics and the attention scalars
         const int mm = acm_opaque(m);
         RowHead<K> rh;
-        if (p.head_stats) row_head_load<K>(p.head_stats + rr * p.ld_head_stats, rh);     // as the forward computed them
+        if (p.head_stats) row_head_load<K>(p.head_stats + (unsigned)rr * (unsigned)p.ld_head_stats, rh);   // as the forward computed them
         else row_head<K>(hlds, mixm, mm, F, ln, H, rh);
         row_post_backward<K>(p, rh, H, active, rr, m, F, dO);
         float ds[K];
@@ -681,7 +682,12 @@ extern "C" int acm_conv_agg_bwd(int64_t n_rows, const acm_conv_agg_bwd_t* p, voi
     ACM_REQUIRE(p->grad_out && p->agg && p->d_params, ACM_EINVAL, "acm_conv_agg_bwd: NULL tensor pointer");
     ACM_REQUIRE(p->n_channels == 3 || (p->g_struc && p->ld_g_struc >= p->f_out), ACM_EINVAL,
                 "acm_conv_agg_bwd: g_struc is NULL / too narrow");
-    ACM_REQUIRE(n_rows * 64 < (int64_t)INT32_MAX, ACM_EUNSUPPORTED, "acm_conv_agg_bwd: too many rows for 32-bit offsets");
+    {
+        int64_t ld_max = 64;
+        for (int64_t ld : {p->ld_grad_out, p->ld_agg, p->ld_xs, p->ld_head_stats, p->ld_post_scale, p->ld_ps, p->ld_ss, p->ld_g_struc})
+            ld_max = ld > ld_max ? ld : ld_max;
+        ACM_REQUIRE(n_rows * ld_max < (int64_t)INT32_MAX, ACM_EUNSUPPORTED, "acm_conv_agg_bwd: too many rows for 32-bit offsets");
+    }
     ACM_REQUIRE(((uintptr_t)p->agg) % 16 == 0 && (p->ld_agg * 4) % 16 == 0 && p->ld_agg >= p->f_pad, ACM_EINVAL,
                 "acm_conv_agg_bwd: agg rows must be 16-byte aligned and f_pad long");
     size_t need = 0;
