@@ -86,7 +86,8 @@ __device__ __forceinline__ void project(const float* wlds, float* scratch, int m
 template <int FP, int K, bool FULL = false>
 __device__ __forceinline__ void agg_fwd_row(const acm_conv_agg_fwd_t& p, const float* wlds, const float* hlds,
                                             float* scratch, const float* mixm, int row, int lane, const CsrView& csr,
-                                            const float* __restrict__ partial, bool p_in_scratch = false) {
+                                            const float* __restrict__ partial, const AcmDropCtx& dc,
+                                            bool p_in_scratch = false) {
     const int F = FULL ? 64 : p.f_out, m = lane & 15;     // FULL: f_out == 64, the column guards fold away
     float H[K][4];
     {
@@ -142,7 +143,7 @@ __device__ __forceinline__ void agg_fwd_row(const acm_conv_agg_fwd_t& p, const f
     row_head<K>(hlds, mixm, acm_opaque(m), F, p.layernorm != 0, H, rh);
     if (p.head_stats && m == 0) row_head_store<K>(p.head_stats + (long)row * p.ld_head_stats, rh);
     float df[4];
-    acm_drop4(acm_drop_ctx(p.post_drop), row, m, df);
+    acm_drop4(dc, row, m, df);        // dc: read once per launch (its step counter is a global load)
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int col = m + 16 * i;
@@ -177,9 +178,10 @@ __global__ __launch_bounds__(256) void agg_epilogue_kernel(acm_conv_agg_fwd_t p,
     float mixm[K * K];
 #pragma unroll
     for (int q = 0; q < K * K; ++q) mixm[q] = p.att_mix[q];
+    const AcmDropCtx dc = acm_drop_ctx(p.post_drop);
     const int lane = threadIdx.x & 63;
     for (int row = blockIdx.x * 16 + (threadIdx.x >> 4); row < n_rows; row += gridDim.x * 16)
-        agg_fwd_row<FP, K>(p, wlds, hlds, scratch, mixm, row, lane, csr, partial);
+        agg_fwd_row<FP, K>(p, wlds, hlds, scratch, mixm, row, lane, csr, partial, dc);
 }
 
 // The gather and the epilogue in ONE kernel (three channels, f_pad <= 8, 16 lanes per work item): the narrow gather's
@@ -202,6 +204,7 @@ __global__ __launch_bounds__(256) void agg_fused_kernel(acm_conv_agg_fwd_t p, Cs
     float mixm[K * K];
 #pragma unroll
     for (int q = 0; q < K * K; ++q) mixm[q] = p.att_mix[q];
+    const AcmDropCtx dc = acm_drop_ctx(p.post_drop);
     const int gl = threadIdx.x & 15, lane = threadIdx.x & 63;
     const int G = gridDim.x * GPB;
     int w = blockIdx.x * GPB + (threadIdx.x >> 4);
@@ -273,7 +276,7 @@ __global__ __launch_bounds__(256) void agg_fused_kernel(acm_conv_agg_fwd_t p, Cs
                     p.agg[(long)it.row * p.ld_agg + f] = v;          // P = A_low X, saved for the backward
                 }
             }
-            agg_fwd_row<FP, K, FULL>(p, wlds, hlds, scratch, mixm, it.row, lane, csr, nullptr, true);
+            agg_fwd_row<FP, K, FULL>(p, wlds, hlds, scratch, mixm, it.row, lane, csr, nullptr, dc, true);
         }
         if (!has_next) break;
         it = itn;
@@ -302,6 +305,7 @@ __global__ __launch_bounds__(256) void agg_fused_pair_kernel(acm_conv_agg_fwd_t 
     float mixm[K * K];
 #pragma unroll
     for (int q = 0; q < K * K; ++q) mixm[q] = p.att_mix[q];
+    const AcmDropCtx dc = acm_drop_ctx(p.post_drop);
     const int gl = threadIdx.x & 15, lane = threadIdx.x & 63, e = gl >> 1, h = gl & 1;
     const int G = gridDim.x * GPB;
     int w = blockIdx.x * GPB + (threadIdx.x >> 4);
@@ -394,7 +398,7 @@ __global__ __launch_bounds__(256) void agg_fused_pair_kernel(acm_conv_agg_fwd_t 
                     p.agg[(long)it.row * p.ld_agg + 4 * h + i] = val;
                 }
             }
-            agg_fwd_row<FP, K, FULL>(p, wlds, hlds, scratch, mixm, it.row, lane, csr, nullptr, true);
+            agg_fwd_row<FP, K, FULL>(p, wlds, hlds, scratch, mixm, it.row, lane, csr, nullptr, dc, true);
         }
         if (!has_next) break;
         it = itn;
