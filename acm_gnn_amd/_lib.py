@@ -14,7 +14,7 @@ c_i32p = C.POINTER(C.c_int32)
 
 ACM_OK = 0
 STATUS_NAMES = {1: "ACM_EINVAL", 2: "ACM_ESHAPE", 3: "ACM_EHIP", 4: "ACM_EUNSUPPORTED", 5: "ACM_ENOMEM"}
-ABI_VERSION = 15
+ABI_VERSION = 16
 
 # every symbol include/acm_hip.h declares
 EXPORTED_SYMBOLS = (
@@ -23,7 +23,7 @@ EXPORTED_SYMBOLS = (
     "acm_gemm", "acm_gemm_blocks", "acm_gemm_split", "acm_proj_fwd", "acm_proj_bwd_workspace_bytes", "acm_proj_bwd", "acm_spmm", "acm_spmm_v", "acm_spmm_ex", "acm_cast_bf16", "acm_conv_fwd", "acm_conv_bwd_local_workspace_bytes",
     "acm_conv_bwd_local", "acm_conv_bwd_spmm", "acm_conv_agg_fwd", "acm_conv_agg_bwd_workspace_bytes",
     "acm_conv_agg_bwd", "acm_nll_loss_workspace_bytes", "acm_nll_loss", "acm_adam_step", "acm_dropout",
-    "acm_reduce_flush",
+    "acm_reduce_flush", "acm_conv_fwd_tail_workspace_bytes", "acm_conv_fwd_tail",
 )
 
 
@@ -127,6 +127,11 @@ class ConvAggBwd(C.Structure):
                 ("head_stats", C.c_void_p), ("ld_head_stats", C.c_int64)]
 
 
+class Loss(C.Structure):
+    _fields_ = [("n_classes", C.c_int32), ("labels", C.c_void_p), ("row_weight", C.c_void_p),
+                ("loss", C.c_void_p), ("dlogits", C.c_void_p), ("ld_dlogits", C.c_int64)]
+
+
 class ReduceSeg(C.Structure):
     _fields_ = [("partial", C.c_void_p), ("nblk", C.c_int32), ("row_stride", C.c_int32),
                 ("q0", C.c_int32), ("len", C.c_int32), ("dst", C.c_void_p),
@@ -194,6 +199,8 @@ def _declare(lib):
     lib.acm_nll_loss_workspace_bytes.argtypes = [i64, C.POINTER(sz)]
     lib.acm_nll_loss.argtypes = [i64, i32, vp, i64, vp, vp, vp, vp, i64, vp, sz, vp, vp]
     lib.acm_reduce_flush.argtypes = [vp, vp]
+    lib.acm_conv_fwd_tail_workspace_bytes.argtypes = [i64, i32, i32, C.POINTER(sz)]
+    lib.acm_conv_fwd_tail.argtypes = [vp, C.POINTER(ConvFwd), C.POINTER(Loss), C.POINTER(ConvBwdLocal), vp, sz, vp, sz, vp]
     for name in EXPORTED_SYMBOLS:
         fn = getattr(lib, name)
         if name not in ("acm_version", "acm_last_error", "acm_csr_destroy"):

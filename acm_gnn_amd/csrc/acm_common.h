@@ -3,6 +3,7 @@
 #pragma once
 
 #include <hip/hip_runtime.h>
+#include <math.h>
 #include <stdint.h>
 
 #include "acm_hip.h"
@@ -134,6 +135,24 @@ __device__ __forceinline__ float acm_cross_row_sum(float v) {
 __device__ __forceinline__ int acm_uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
 __device__ __forceinline__ float acm_lane_f(float v, int lane) {
     return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane));
+}
+
+// One row of the masked NLL (acm_nll_loss): di = wi (softmax(zi) - onehot(yi)); returns wi (logsumexp(zi) - zi[yi]).
+// Rows outside the training set (wi == 0) get a zero gradient and no loss.
+__device__ __forceinline__ float acm_nll_row(int C, const float* zi, int yi, float wi, float* di) {
+    if (wi == 0.f) {
+        for (int c = 0; c < C; ++c) di[c] = 0.f;
+        return 0.f;
+    }
+    float m = -INFINITY;
+    for (int c = 0; c < C; ++c) m = fmaxf(m, zi[c]);
+    float s = 0.f;
+    for (int c = 0; c < C; ++c) s += expf(zi[c] - m);
+    const float lse = m + logf(s);
+    const float inv = 1.0f / s;
+    const float zy = zi[yi];
+    for (int c = 0; c < C; ++c) di[c] = wi * (expf(zi[c] - m) * inv - (c == yi ? 1.f : 0.f));
+    return wi * (lse - zy);
 }
 
 // ------------------------------------------------------------------ counter-based dropout (acm_dropout_t)

@@ -951,24 +951,14 @@ __device__ __forceinline__ void conv_bwd_row(const acm_conv_bwd_local_t& p, int 
     }
 }
 
-// Block-level deterministic reduction of the per-lane parameter-gradient accumulators:
-// wave -> LDS slab [4][npg] -> sum over the 4 waves -> partial[block][npg].
-template <class L, int RPW /* rows per wave */, int K>
-__global__ __launch_bounds__(256) void conv_bwd_local_kernel(acm_conv_bwd_local_t p, int n_rows,
-                                                             float* __restrict__ partial) {
-    extern __shared__ float lds[];
+// Block-level deterministic reduction of the per-lane parameter-gradient accumulators of K3:
+// the RPW row-groups of a wave (shuffles) -> LDS slab [4 waves][npg] -> sum over the waves -> out[npg].
+template <class L, int RPW, int K>
+__device__ __forceinline__ void bwd_local_block_reduce(ParamAcc<L>& pa, const L& lay, int F, float* lds,
+                                                       float* __restrict__ out) {
     constexpr int k = K;
-    const int F = p.f_out;
     const int npg = 3 * k * F + k * k;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    L lay{lane};
-    ParamAcc<L> pa;
-    pa.zero();
-    const int rows_per_block = 4 * RPW;
-    for (int r0 = blockIdx.x * rows_per_block; r0 < n_rows; r0 += gridDim.x * rows_per_block) {
-        const int row = r0 + wv * RPW + (RPW > 1 ? lane / (64 / RPW) : 0);
-        conv_bwd_row<L, K>(p, row < n_rows ? row : 0, row < n_rows, lay, pa);
-    }
     // combine the RPW row-groups of this wave (layout B only)
     if (RPW > 1) {
 #pragma unroll
@@ -1009,7 +999,28 @@ __global__ __launch_bounds__(256) void conv_bwd_local_kernel(acm_conv_bwd_local_
     }
     __syncthreads();
     for (int q = threadIdx.x; q < npg; q += 256)
-        partial[(long)blockIdx.x * npg + q] = (lds[q] + lds[npg + q]) + (lds[2 * npg + q] + lds[3 * npg + q]);
+        out[q] = (lds[q] + lds[npg + q]) + (lds[2 * npg + q] + lds[3 * npg + q]);
+}
+
+
+// K3, one launch: rows -> accumulators -> bwd_local_block_reduce -> partial[block][npg].
+template <class L, int RPW /* rows per wave */, int K>
+__global__ __launch_bounds__(256) void conv_bwd_local_kernel(acm_conv_bwd_local_t p, int n_rows,
+                                                             float* __restrict__ partial) {
+    extern __shared__ float lds[];
+    constexpr int k = K;
+    const int F = p.f_out;
+    const int npg = 3 * k * F + k * k;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    L lay{lane};
+    ParamAcc<L> pa;
+    pa.zero();
+    const int rows_per_block = 4 * RPW;
+    for (int r0 = blockIdx.x * rows_per_block; r0 < n_rows; r0 += gridDim.x * rows_per_block) {
+        const int row = r0 + wv * RPW + (RPW > 1 ? lane / (64 / RPW) : 0);
+        conv_bwd_row<L, K>(p, row < n_rows ? row : 0, row < n_rows, lay, pa);
+    }
+    bwd_local_block_reduce<L, RPW, K>(pa, lay, F, lds, partial + (long)blockIdx.x * npg);
 }
 
 // K3 for 16 < F <= 64: four rows per wave (16 lanes x 4 columns), head parameters in LDS, two passes per
@@ -1208,4 +1219,108 @@ extern "C" int acm_conv_bwd_local(int64_t n_rows, const acm_conv_bwd_local_t* p,
 #undef ACM_BWD
     ACM_CHECK_HIP(hipGetLastError());
     return bwd_local_reduce(p, partial, nblk, st);
+}
+
+// ================================================================== output layer + loss + K3 in one row pass
+// One thread per row, three steps that hand their results to each other through the row's own few bytes of global
+// memory (written and read back by the same thread): the head of the narrow forward, the masked NLL of its logits, the
+// row-local backward with that gradient.  Block-level reductions: loss partial, K3 parameter partials.
+template <int FP, int NG>
+__global__ __launch_bounds__(256) void conv_tail_rows_kernel(acm_conv_fwd_t pf, acm_loss_t pl, acm_conv_bwd_local_t pb,
+                                                             int n_rows, float* __restrict__ loss_partial,
+                                                             float* __restrict__ k3_partial) {
+    extern __shared__ float lds[];
+    __shared__ float red[256];
+    constexpr int K = NG + 1;
+    const int F = pf.f_out;
+    const int npg = 3 * K * F + K * K;
+    const int row = blockIdx.x * 256 + threadIdx.x;
+    const bool active = row < n_rows;
+    const LaySerial<FP> lay{true};
+    ParamAcc<LaySerial<FP>> pa;
+    pa.zero();
+    float term = 0.f;
+    if (active) {
+        float acc[NG][FP];
+        const float* pr = pf.pre + (long)row * pf.ld_pre;
+#pragma unroll
+        for (int c = 0; c < NG; ++c)
+#pragma unroll
+            for (int f = 0; f < FP; ++f) acc[c][f] = (f < F) ? pr[c * F + f] : 0.f;
+        EpiFwd::apply<LaySerial<FP>, NG>(pf, row, lay, F, acc);
+        term = acm_nll_row(F, pf.out + (long)row * pf.ld_out, (int)pl.labels[row], pl.row_weight[row],
+                           pl.dlogits + (long)row * pl.ld_dlogits);
+        conv_bwd_row<LaySerial<FP>, K>(pb, row, true, lay, pa);      // LaySerial: no cross-lane step, divergence is fine
+    }
+    red[threadIdx.x] = term;
+    __syncthreads();
+    for (int m = 128; m >= 1; m >>= 1) {
+        if ((int)threadIdx.x < m) red[threadIdx.x] += red[threadIdx.x + m];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) loss_partial[blockIdx.x] = red[0];
+    bwd_local_block_reduce<LaySerial<FP>, 64, K>(pa, lay, F, lds, k3_partial + (long)blockIdx.x * npg);
+}
+
+extern "C" int acm_conv_fwd_tail_workspace_bytes(int64_t n_rows, int f_out, int n_channels, size_t* bytes) {
+    ACM_REQUIRE(bytes, ACM_EINVAL, "acm_conv_fwd_tail_workspace_bytes: NULL argument");
+    ACM_REQUIRE(n_rows >= 0 && f_out > 0 && f_out <= 8 && n_channels == 3, ACM_EUNSUPPORTED,
+                "acm_conv_fwd_tail: f_out %d n_channels %d (needs f_out <= 8, three channels)", f_out, n_channels);
+    const int64_t nblk = (n_rows + 255) / 256 > 0 ? (n_rows + 255) / 256 : 1;
+    *bytes = (size_t)nblk * (size_t)(1 + 3 * n_channels * f_out + n_channels * n_channels) * sizeof(float);
+    return ACM_OK;
+}
+
+extern "C" int acm_conv_fwd_tail(const acm_csr_t* a, const acm_conv_fwd_t* p, const acm_loss_t* l,
+                                 const acm_conv_bwd_local_t* b, void* workspace, size_t workspace_bytes,
+                                 void* tail_workspace, size_t tail_workspace_bytes, acm_stream_t stream) {
+    ACM_REQUIRE(a && p && l && b, ACM_EINVAL, "acm_conv_fwd_tail: NULL argument");
+    const int F = p->f_out, k = p->n_channels;
+    size_t need = 0;
+    int st = acm_conv_fwd_tail_workspace_bytes(a->n_rows, F, k, &need);
+    if (st != ACM_OK) return st;
+    ACM_REQUIRE(l->n_classes == F && b->f_out == F && b->n_channels == k, ACM_EUNSUPPORTED,
+                "acm_conv_fwd_tail: the layer's f_out must be the number of classes");
+    ACM_REQUIRE(!p->post_relu && !p->post_scale && p->post_drop.p == 0.f && !b->post_relu && !b->post_scale &&
+                    b->post_drop.p == 0.f && !p->gather_bf16, ACM_EUNSUPPORTED,
+                "acm_conv_fwd_tail: post-ops / bf16 operands are not part of the fused tail");
+    ACM_REQUIRE(a->n_long == 0 || narrow_finishes_long_rows(a), ACM_EUNSUPPORTED,
+                "acm_conv_fwd_tail: this graph's narrow gather leaves partial sums of long rows");
+    ACM_REQUIRE(p->g_low && p->g_high && p->s_high && p->s_mlp && p->out && p->pre && p->att && p->att_mix &&
+                    l->labels && l->row_weight && l->loss && l->dlogits && b->att_mix && b->g_low && b->g_high &&
+                    b->g_mlp && b->d_att_mix, ACM_EINVAL, "acm_conv_fwd_tail: NULL tensor pointer");
+    ACM_REQUIRE(b->grad_out == l->dlogits && b->ld_grad_out == l->ld_dlogits && b->pre == p->pre &&
+                    b->ld_pre == p->ld_pre && b->s_mlp == p->s_mlp && b->ld_s_mlp == p->ld_s_mlp, ACM_EINVAL,
+                "acm_conv_fwd_tail: bwd must read what fwd / loss write (grad_out = dlogits, pre, s_mlp)");
+    ACM_REQUIRE(p->ld_out >= F && p->ld_pre >= (k - 1) * F && l->ld_dlogits >= F && ((uintptr_t)p->att) % 16 == 0,
+                ACM_ESHAPE, "acm_conv_fwd_tail: leading dimensions / alignment");
+    for (int c = 0; c < k; ++c) {
+        ACM_REQUIRE(p->att_vec[c] && b->att_vec[c], ACM_EINVAL, "acm_conv_fwd_tail: att_vec[%d] is NULL", c);
+        ACM_REQUIRE(!p->layernorm || (p->ln_weight[c] && p->ln_bias[c] && b->ln_weight[c] && b->ln_bias[c]), ACM_EINVAL,
+                    "acm_conv_fwd_tail: layernorm parameters of channel %d are NULL", c);
+    }
+    ACM_REQUIRE(tail_workspace && tail_workspace_bytes >= need, ACM_ENOMEM,
+                "acm_conv_fwd_tail: tail workspace %zu B < required %zu B", tail_workspace_bytes, need);
+    if (a->n_rows == 0) return ACM_OK;
+    hipStream_t s = (hipStream_t)stream;
+    GatherSrc g = {{p->g_low, p->g_high, nullptr}, {p->ld_g_low, p->ld_g_high, 0}};
+    st = launch_gather<2, EpiRaw>(a, g, F, *p, workspace, workspace_bytes, s, "acm_conv_fwd_tail", nullptr, false, true);
+    if (st != ACM_OK) return st;
+    const int n = (int)a->n_rows, nblk = (n + 255) / 256;
+    const int npg = 3 * k * F + k * k;
+    float* loss_partial = (float*)tail_workspace;
+    float* k3_partial = loss_partial + nblk;
+    const size_t lds = (size_t)4 * npg * sizeof(float);
+    const int FP = F <= 2 ? 2 : (F <= 4 ? 4 : 8);
+    if (FP == 2)
+        hipLaunchKernelGGL((conv_tail_rows_kernel<2, 2>), dim3(nblk), dim3(256), lds, s, *p, *l, *b, n, loss_partial, k3_partial);
+    else if (FP == 4)
+        hipLaunchKernelGGL((conv_tail_rows_kernel<4, 2>), dim3(nblk), dim3(256), lds, s, *p, *l, *b, n, loss_partial, k3_partial);
+    else
+        hipLaunchKernelGGL((conv_tail_rows_kernel<8, 2>), dim3(nblk), dim3(256), lds, s, *p, *l, *b, n, loss_partial, k3_partial);
+    ACM_CHECK_HIP(hipGetLastError());
+    const acm_reduce_seg_t seg = {loss_partial, nblk, 1, 0, 1, l->loss, 1, 0, 0, 0};
+    st = acm_reduce_emit(b->defer, &seg, 1, s);
+    if (st != ACM_OK) return st;
+    return bwd_local_reduce(b, k3_partial, nblk, s);
 }

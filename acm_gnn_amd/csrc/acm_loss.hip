@@ -13,22 +13,7 @@ __global__ __launch_bounds__(256) void nll_rows_kernel(int n, int C, const float
     __shared__ float red[256];
     float acc = 0.f;
     for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
-        const float wi = w[i];
-        const float* zi = z + (long)i * ldz;
-        float* di = dz + (long)i * ldd;
-        if (wi == 0.f) {                       // rows outside the training set: zero gradient, no loss
-            for (int c = 0; c < C; ++c) di[c] = 0.f;
-            continue;
-        }
-        float m = -INFINITY;
-        for (int c = 0; c < C; ++c) m = fmaxf(m, zi[c]);
-        float s = 0.f;
-        for (int c = 0; c < C; ++c) s += expf(zi[c] - m);
-        const float lse = m + logf(s);
-        const int yi = (int)y[i];
-        const float inv = 1.0f / s;
-        for (int c = 0; c < C; ++c) di[c] = wi * (expf(zi[c] - m) * inv - (c == yi ? 1.f : 0.f));
-        acc += wi * (lse - zi[yi]);
+        acc += acm_nll_row(C, z + (long)i * ldz, (int)y[i], w[i], dz + (long)i * ldd);
     }
     red[threadIdx.x] = acc;
     __syncthreads();

@@ -142,6 +142,37 @@ def _defer_ptr():
     return _DEFER.pointer() if _DEFER is not None else None
 
 
+class fused_loss_tail:
+    """``with fused_loss_tail(labels, row_weight) as tail: out = model(...)`` -- a request to the model's OUTPUT layer
+    (a narrow three-channel ACM layer called with ``output_layer`` set and no post-op) to run its row phase, the
+    masked NLL of its logits and its own row-local backward (K3) as ONE kernel (acm_conv_fwd_tail).  Afterwards
+    ``tail.matches(out)`` says whether ``out`` is that layer's output; if so ``tail.loss`` / ``tail.dz`` are what
+    nll_loss_and_grad(out, labels, row_weight) returns, and ``out.backward(tail.dz)`` skips K3.  Any other gradient
+    handed to that layer's backward makes it run K3 as usual, so a request that is not honoured costs nothing but time."""
+
+    def __init__(self, labels, row_weight):
+        self.labels, self.row_weight = labels, row_weight
+        self.loss = self.dz = self.out = None
+
+    def __enter__(self):
+        global _TAIL
+        self.prev = _TAIL
+        _TAIL = self
+        return self
+
+    def __exit__(self, *exc):
+        global _TAIL
+        _TAIL = self.prev
+        return False
+
+    def matches(self, out):
+        return self.out is not None and out is not None and out.data_ptr() == self.out.data_ptr() \
+            and out.shape == self.out.shape
+
+_TAIL = None            # the pending request, consumed by the first layer that qualifies
+_TAIL_LAYER = False     # set by layers.GraphConvolution.forward around the call of an output layer without post-op
+
+
 def _vp(t):
     return C.c_void_p(t.data_ptr()) if t is not None else None
 
@@ -516,6 +547,63 @@ def _low_product(ops, t_local, transpose=False):
     return spmm(ops.low, tg, row_scale=ops.row_scale if ops.implicit else None)
 
 
+def _flat_views(flat, nw, k, f, layernorm):
+    """The head-parameter gradients as views of the layer's flat gradient buffer (fresh tensor objects on every call:
+    autograd adopts a returned gradient only while nobody else holds that tensor object)."""
+    nln = k * f if layernorm else 0
+    d_vec = [flat[nw + c * f: nw + (c + 1) * f].view(f, 1) for c in range(k)]
+    o1 = nw + k * f
+    d_lnw = [flat[o1 + c * f: o1 + (c + 1) * f] for c in range(k)] if layernorm else []
+    d_lnb = [flat[o1 + nln + c * f: o1 + nln + (c + 1) * f] for c in range(k)] if layernorm else []
+    d_mix = flat[o1 + 2 * nln:].view(k, k)
+    return d_vec, d_lnw, d_lnb, d_mix
+
+
+def _k3_setup(cfg, ops, k, f, n, dev, f_in_w, pre, zi, vecs, lnw, lnb, mix, grad_out, post_relu, post_scale, post_drop):
+    """Buffers and acm_conv_bwd_local_t of the row-local backward of one layer: G tables, dZ, the flat buffer every
+    replicated-parameter gradient is a view of."""
+    four = k == 4
+    g = torch.empty(n, 2 * f, dtype=_F32, device=dev)            # [G_L | G_H]
+    dz = torch.empty(n, 3 * f, dtype=_F32, device=dev)           # [dZ_L | dZ_H | dZ_I]
+    gs = torch.empty(n, f, dtype=_F32, device=dev) if four else None
+    # every replicated-parameter gradient is a view of one flat buffer: a row-sharded run sums the partials
+    # with a single all-reduce and no pack / unpack launches
+    nw, nln = 3 * f_in_w * f, (k * f if cfg.layernorm else 0)
+    flat = torch.empty(nw + k * f + 2 * nln + k * k, dtype=_F32, device=dev)
+    d_vec, d_lnw, d_lnb, d_mix = _flat_views(flat, nw, k, f, cfg.layernorm)
+
+    q = _lib.ConvBwdLocal()
+    q.f_out, q.n_channels = f, k
+    q.relu_after, q.relu_mlp, q.layernorm, q.scale = int(cfg.relu_after), int(cfg.relu_mlp), int(cfg.layernorm), cfg.scale
+    q.grad_out, q.ld_grad_out = grad_out.data_ptr(), grad_out.stride(0)
+    q.pre, q.ld_pre = pre.data_ptr(), pre.stride(0)
+    q.s_mlp, q.ld_s_mlp = zi.data_ptr(), zi.stride(0)
+    general = bool(getattr(ops, "general", False))
+    ones = ops.zeros(n, 1).new_ones(n) if (four and general) else None
+    # pattern-only backward: A_low^T G = P (D^-1 G), so G_L / G_H are written pre-scaled and G_S unscaled
+    # (A_low^T (D G_S) = P G_S)
+    q.deg = None if (not four or ops.implicit) else (ones if general else ops.deg).data_ptr()
+    if ops.implicit:
+        q.g_scale = ops.row_scale.data_ptr()
+    q.att_vec, q.ln_weight, q.ln_bias = _ptr_array(vecs), _ptr_array(lnw), _ptr_array(lnb)
+    q.att_mix = mix.data_ptr()
+    q.g_low, q.ld_g_low = g.data_ptr(), g.stride(0)
+    q.g_high, q.ld_g_high = g.data_ptr() + 4 * f, g.stride(0)
+    q.g_mlp, q.ld_g_mlp = dz.data_ptr() + 8 * f, dz.stride(0)
+    if four:
+        q.g_struc, q.ld_g_struc = gs.data_ptr(), gs.stride(0)
+    q.d_att_vec, q.d_ln_weight, q.d_ln_bias = _ptr_array(d_vec), _ptr_array(d_lnw), _ptr_array(d_lnb)
+    q.d_att_mix = d_mix.data_ptr()
+    q.post_relu = int(post_relu)
+    if post_scale is not None:
+        q.post_scale, q.ld_post_scale = post_scale.data_ptr(), post_scale.stride(0)
+    spec = _drop_spec(post_drop, ops.row_offset)
+    if spec is not None:
+        q.post_drop = spec
+    return dict(q=q, g=g, dz=dz, gs=gs, flat=flat, nw=nw, d_vec=d_vec, d_lnw=d_lnw, d_lnb=d_lnb, d_mix=d_mix,
+                general=general, ones=ones, grad_out=grad_out)
+
+
 class AcmConvFunction(torch.autograd.Function):
     """out, att = ACM layer(x; parameters) over the operators in ``ops``.
 
@@ -748,9 +836,45 @@ class AcmConvFunction(torch.autograd.Function):
         p.att = att.data_ptr()
         set_post(p)
         ws = graph.workspace((k - 1) * f)
-        with _device_ctx(dev), _Timed(f"conv_fwd/F{f}k{k}"):
-            st = lib.acm_conv_fwd(graph.handle, C.byref(p), _vp(ws), ws.numel() * 4, _stream())
-        _lib.check(st, "acm_conv_fwd")
+        # output layer + loss + K3 in one row pass (acm_conv_fwd_tail) when a training loop asked for it
+        global _TAIL_LAYER
+        tail_req, layer_ok, _TAIL_LAYER = _TAIL, _TAIL_LAYER, False
+        ctx.tail = None
+        st = None
+        if (tail_req is not None and tail_req.out is None and layer_ok and not general and k == 3 and f <= 8
+                and not cfg.gather_bf16 and not post_relu and post_scale is None and post_drop is None
+                and any(ctx.needs_input_grad) and tail_req.labels.numel() == n
+                and (graph.n_long_rows == 0 or 12.0 < graph.nnz / max(graph.n_rows, 1) <= 160.0)):
+            dlog = torch.empty(n, f, dtype=_F32, device=dev)
+            st3 = _k3_setup(cfg, ops, k, f, n, dev, w3[0].shape[0], pre, zi, vecs, lnw, lnb, mix, dlog, False, None, None)
+            loss = torch.empty((), dtype=_F32, device=dev)
+            lo = _lib.Loss()
+            lo.n_classes = f
+            y = tail_req.labels.to(torch.int64).contiguous().reshape(-1)
+            w_row = _as_f32c(tail_req.row_weight, "row_weight")
+            lo.labels, lo.row_weight = y.data_ptr(), w_row.data_ptr()
+            lo.loss, lo.dlogits, lo.ld_dlogits = loss.data_ptr(), dlog.data_ptr(), dlog.stride(0)
+            q = st3["q"]
+            q.defer = _defer_ptr()
+            nbytes = C.c_size_t()
+            if lib.acm_conv_fwd_tail_workspace_bytes(n, f, k, C.byref(nbytes)) == 0:
+                wt = torch.empty(max(nbytes.value // 4, 1), dtype=_F32, device=dev)
+                with _device_ctx(dev), _Timed(f"conv_fwd_tail/F{f}k{k}"):
+                    st = lib.acm_conv_fwd_tail(graph.handle, C.byref(p), C.byref(lo), C.byref(q), _vp(ws), ws.numel() * 4,
+                                               _vp(wt), nbytes.value, _stream())
+                if st == 0:
+                    st3["keep"] = (y, w_row, wt)
+                    ctx.tail = st3
+                    tail_req.loss, tail_req.dz, tail_req.out = loss, dlog, out
+                    if _DEFER is not None:
+                        _DEFER.hold(wt, [loss, st3["d_mix"], *st3["d_vec"], *st3["d_lnw"], *st3["d_lnb"]],
+                                    keep=[loss, st3["flat"]])
+                elif st != 4:                       # ACM_EUNSUPPORTED: the layer does not qualify, three calls then
+                    _lib.check(st, "acm_conv_fwd_tail")
+        if st != 0:
+            with _device_ctx(dev), _Timed(f"conv_fwd/F{f}k{k}"):
+                st = lib.acm_conv_fwd(graph.handle, C.byref(p), _vp(ws), ws.numel() * 4, _stream())
+            _lib.check(st, "acm_conv_fwd")
         ctx.ops, ctx.cfg = ops, cfg
         ctx.sparse_x = x if sparse_x else None
         ctx.save_for_backward(w3[0] if sparse_x else x, *w3, zlh, zi, pre, mix, *vecs, *lnw, *lnb)
@@ -777,57 +901,27 @@ class AcmConvFunction(torch.autograd.Function):
         grad_out = _as_f32c(grad_out, "grad_out")
         four = k == 4
 
-        g = torch.empty(n, 2 * f, dtype=_F32, device=dev)            # [G_L | G_H]
-        dz = torch.empty(n, 3 * f, dtype=_F32, device=dev)           # [dZ_L | dZ_H | dZ_I]
-        gs = torch.empty(n, f, dtype=_F32, device=dev) if four else None
-        # every replicated-parameter gradient is a view of one flat buffer: a row-sharded run sums the partials
-        # with a single all-reduce and no pack / unpack launches
         f_in_w = wl_.shape[0]
-        nw, nln = 3 * f_in_w * f, (k * f if cfg.layernorm else 0)
-        flat = torch.empty(nw + k * f + 2 * nln + k * k, dtype=_F32, device=dev)
-        d_vec = [flat[nw + c * f: nw + (c + 1) * f].view(f, 1) for c in range(k)]
-        o1 = nw + k * f
-        d_lnw = [flat[o1 + c * f: o1 + (c + 1) * f] for c in range(k)] if cfg.layernorm else []
-        d_lnb = [flat[o1 + nln + c * f: o1 + nln + (c + 1) * f] for c in range(k)] if cfg.layernorm else []
-        d_mix = flat[o1 + 2 * nln:].view(k, k)
-
-        q = _lib.ConvBwdLocal()
-        q.f_out, q.n_channels = f, k
-        q.relu_after, q.relu_mlp, q.layernorm, q.scale = int(cfg.relu_after), int(cfg.relu_mlp), int(cfg.layernorm), cfg.scale
-        q.grad_out, q.ld_grad_out = grad_out.data_ptr(), grad_out.stride(0)
-        q.pre, q.ld_pre = pre.data_ptr(), pre.stride(0)
-        q.s_mlp, q.ld_s_mlp = zi.data_ptr(), zi.stride(0)
-        general = bool(getattr(ops, "general", False))
-        ones = ops.zeros(n, 1).new_ones(n) if (four and general) else None
-        # pattern-only backward: A_low^T G = P (D^-1 G), so G_L / G_H are written pre-scaled and G_S unscaled
-        # (A_low^T (D G_S) = P G_S)
-        q.deg = None if (not four or ops.implicit) else (ones if general else ops.deg).data_ptr()
-        if ops.implicit:
-            q.g_scale = ops.row_scale.data_ptr()
-        q.att_vec, q.ln_weight, q.ln_bias = _ptr_array(vecs), _ptr_array(lnw), _ptr_array(lnb)
-        q.att_mix = mix.data_ptr()
-        q.g_low, q.ld_g_low = g.data_ptr(), g.stride(0)
-        q.g_high, q.ld_g_high = g.data_ptr() + 4 * f, g.stride(0)
-        q.g_mlp, q.ld_g_mlp = dz.data_ptr() + 8 * f, dz.stride(0)
-        if four:
-            q.g_struc, q.ld_g_struc = gs.data_ptr(), gs.stride(0)
-        q.d_att_vec, q.d_ln_weight, q.d_ln_bias = _ptr_array(d_vec), _ptr_array(d_lnw), _ptr_array(d_lnb)
-        q.d_att_mix = d_mix.data_ptr()
-        q.post_relu = int(ctx.post_relu)
-        if ctx.post_scale is not None:
-            q.post_scale, q.ld_post_scale = ctx.post_scale.data_ptr(), ctx.post_scale.stride(0)
-        spec = _drop_spec(ctx.post_drop, ops.row_offset)
-        if spec is not None:
-            q.post_drop = spec
-        nbytes = C.c_size_t()
-        _lib.check(lib.acm_conv_bwd_local_workspace_bytes(n, f, k, C.byref(nbytes)))
-        ws = torch.empty(max(nbytes.value // 4, 1), dtype=_F32, device=dev)
-        q.defer = _defer_ptr()
-        with _device_ctx(dev), _Timed(f"conv_bwd_local/F{f}k{k}"):
-            st = lib.acm_conv_bwd_local(n, C.byref(q), _vp(ws), ws.numel() * 4, _stream())
-        _lib.check(st, "acm_conv_bwd_local")
-        if _DEFER is not None:
-            _DEFER.hold(ws, [d_mix, *d_vec, *d_lnw, *d_lnb], keep=[flat])
+        tail = getattr(ctx, "tail", None)
+        done = tail is not None and grad_out.data_ptr() == tail["grad_out"].data_ptr()
+        st3 = tail if done else _k3_setup(cfg, ops, k, f, n, dev, f_in_w, pre, zi, vecs, lnw, lnb, mix, grad_out,
+                                          ctx.post_relu, ctx.post_scale, ctx.post_drop)
+        q, g, dz, gs, flat, nw = st3["q"], st3["g"], st3["dz"], st3["gs"], st3["flat"], st3["nw"]
+        general, ones = st3["general"], st3["ones"]
+        if done:
+            ctx.tail = None
+        d_vec, d_lnw, d_lnb, d_mix = _flat_views(flat, nw, k, f, cfg.layernorm)    # this call's own view objects
+        del st3, tail
+        if not done:                 # else: acm_conv_fwd_tail already ran K3 with exactly this gradient
+            nbytes = C.c_size_t()
+            _lib.check(lib.acm_conv_bwd_local_workspace_bytes(n, f, k, C.byref(nbytes)))
+            ws = torch.empty(max(nbytes.value // 4, 1), dtype=_F32, device=dev)
+            q.defer = _defer_ptr()
+            with _device_ctx(dev), _Timed(f"conv_bwd_local/F{f}k{k}"):
+                st = lib.acm_conv_bwd_local(n, C.byref(q), _vp(ws), ws.numel() * 4, _stream())
+            _lib.check(st, "acm_conv_bwd_local")
+            if _DEFER is not None:
+                _DEFER.hold(ws, [d_mix, *d_vec, *d_lnw, *d_lnb], keep=[flat])
 
         d_struc = torch.empty(n, f, dtype=_F32, device=dev) if four else None
         r = _lib.ConvBwdSpmm()

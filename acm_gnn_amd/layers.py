@@ -115,7 +115,12 @@ class GraphConvolution(nn.Module):
             ops = adj_low
         else:
             ops = operators_for(adj_low, adj_high, adj_low_unnormalized if cfg.n_channels == 4 else None)
-        out, att = AF.acm_conv(input, self._param_dict(), ops, cfg, post_relu, post_scale, post_drop)
+        # an output layer without post-op may take a pending functional.fused_loss_tail request (row phase + loss + K3)
+        AF._TAIL_LAYER = bool(self.output_layer) and not post_relu and post_scale is None and post_drop is None
+        try:
+            out, att = AF.acm_conv(input, self._param_dict(), ops, cfg, post_relu, post_scale, post_drop)
+        finally:
+            AF._TAIL_LAYER = False
         self.att_low, self.att_high, self.att_mlp = att[:, 0:1], att[:, 1:2], att[:, 2:3]
         if cfg.n_channels == 4:
             self.att_struc_vec_low = att[:, 3:4]

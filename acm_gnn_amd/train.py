@@ -61,13 +61,11 @@ class TrainStep:
         before the flush -- otherwise deferral is switched off for good and the step is redone."""
         model = self.model
         if not self._defer:
-            out = model(self.x, self.adj, self.adj_high, self.adj_un)
-            loss, dz = AF.nll_loss_and_grad(out, self.labels, self.weights)   # = masked_nll(...).backward(), two launches less
+            loss, dz, out = self._forward_loss()
             out.backward(dz)
             return loss
         with AF.deferred_reductions() as pending:
-            out = model(self.x, self.adj, self.adj_high, self.adj_un)
-            loss, dz = AF.nll_loss_and_grad(out, self.labels, self.weights)
+            loss, dz, out = self._forward_loss()
             out.backward(dz)
             adopted = pending.all_adopted([loss] + [p.grad for p in model.parameters()])
             pending.flush()
@@ -76,6 +74,17 @@ class TrainStep:
             self.opt.zero_grad(set_to_none=True)
             return self._forward_backward()
         return loss
+
+    def _forward_loss(self):
+        """Forward and fused loss: (loss, dloss/dlogits, logits).  The model's output layer is asked to run its row
+        phase, the loss and its own row-local backward as one kernel (AF.fused_loss_tail); when it does not qualify
+        (wide output, structure channel, a wrapper around the output) the loss is its own launch."""
+        with AF.fused_loss_tail(self.labels, self.weights) as tail:
+            out = self.model(self.x, self.adj, self.adj_high, self.adj_un)
+        if tail.matches(out):
+            return tail.loss, tail.dz, out
+        loss, dz = AF.nll_loss_and_grad(out, self.labels, self.weights)   # = masked_nll(...).backward(), two launches less
+        return loss, dz, out
 
     def _eager(self):
         if not self.model.training:

@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define ACM_ABI_VERSION 15
+#define ACM_ABI_VERSION 16
 
 typedef enum {
     ACM_OK = 0,
@@ -484,6 +484,30 @@ int acm_nll_loss(int64_t n_rows, int n_classes, const float* logits, int64_t ld_
                  const int64_t* labels, const float* row_weight,
                  float* loss, float* dlogits, int64_t ld_dlogits,
                  void* workspace, size_t workspace_bytes, acm_reduce_list_t* defer, acm_stream_t stream);
+
+/* ---------------------------------------- output layer + loss + K3, fused --
+ * For a narrow OUTPUT layer (f_out = n_classes <= 8, three channels, no post-op) whose result goes straight into the
+ * masked NLL, the three row-local passes that follow its gather -- the head (acm_conv_fwd's row phase), acm_nll_loss
+ * and acm_conv_bwd_local -- read and write the same few bytes per row: acm_conv_fwd_tail runs the gather and then ONE
+ * row kernel that does all three (two launches less per step).  `fwd`, `loss` and `bwd` are exactly the arguments the
+ * three separate calls would get, with bwd->grad_out == loss->dlogits and bwd->pre == fwd->pre; every output of the
+ * three calls is produced (logits, pre, att, loss, dlogits, G tables, parameter-gradient sums).  The second phases
+ * (loss sum, parameter-gradient sums) honour bwd->defer.  Returns ACM_EUNSUPPORTED when the layer does not qualify;
+ * the caller then makes the three calls.
+ * Replaces: ACM-Geometric/layers.py:57-63,86-116 (output layer) + train.py:133-135 in one pass.
+ */
+typedef struct {
+    int32_t n_classes;
+    const int64_t* labels;
+    const float*   row_weight;
+    float* loss;
+    float* dlogits; int64_t ld_dlogits;
+} acm_loss_t;
+
+int acm_conv_fwd_tail_workspace_bytes(int64_t n_rows, int f_out, int n_channels, size_t* bytes);
+int acm_conv_fwd_tail(const acm_csr_t* a_low, const acm_conv_fwd_t* fwd, const acm_loss_t* loss,
+                      const acm_conv_bwd_local_t* bwd, void* workspace, size_t workspace_bytes,
+                      void* tail_workspace, size_t tail_workspace_bytes, acm_stream_t stream);
 
 /* ------------------------------------------------ fused optimizer update --
  * Adam / AdamW over a list of fp32 parameter tensors in one launch per 32 tensors: the update of

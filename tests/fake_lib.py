@@ -151,7 +151,7 @@ class FakeLib:
 
     # ---- plumbing ---------------------------------------------------------
     def acm_version(self):
-        return 15
+        return 16
 
     # ---- deferred second phases (acm_reduce_list_t): results of a deferred call are poisoned with NaN until the
     # flush, so a consumer that reads them too early fails its test instead of passing by accident
@@ -301,6 +301,32 @@ class FakeLib:
     def acm_conv_agg_bwd_workspace_bytes(self, n, f_in, f, out):
         out._obj.value = 4
         return 0
+
+    def acm_conv_fwd_tail_workspace_bytes(self, n, f, k, out):
+        if f > 8 or k != 3:
+            self._err = b"acm_conv_fwd_tail: needs f_out <= 8, three channels"
+            return 4
+        out._obj.value = 4
+        return 0
+
+    def acm_conv_fwd_tail(self, h, pp, ll, bb, ws, wsb, wt, wtb, stream):
+        """The three calls it fuses, in order (same arguments, same outputs)."""
+        p, l, b = pp._obj, ll._obj, bb._obj
+        a = self._get(h)
+        if p.f_out > 8 or p.n_channels != 3 or l.n_classes != p.f_out or p.post_relu or p.post_scale or p.post_drop.p > 0:
+            self._err = b"acm_conv_fwd_tail: layer does not qualify"
+            return 4
+        if b.grad_out != l.dlogits or b.pre != p.pre:
+            self._err = b"acm_conv_fwd_tail: bwd must read what fwd / loss write"
+            return 1
+        st = self.acm_conv_fwd(h, pp, ws, wsb, stream)
+        if st:
+            return st
+        st = self.acm_nll_loss(a.n_rows, l.n_classes, p.out, p.ld_out, l.labels, l.row_weight, l.loss, l.dlogits,
+                               l.ld_dlogits, wt, wtb, b.defer, stream)
+        if st:
+            return st
+        return self.acm_conv_bwd_local(a.n_rows, bb, wt, wtb, stream)
 
     def acm_nll_loss_workspace_bytes(self, n, out):
         out._obj.value = 4

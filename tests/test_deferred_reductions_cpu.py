@@ -108,3 +108,36 @@ def test_train_step_falls_back_when_a_gradient_was_accumulated_instead_of_adopte
     assert [first, second] == [float(ref_step()), float(ref_step())]
     for a, b in zip(model.parameters(), ref.parameters()):
         assert torch.isfinite(a).all() and torch.allclose(a, b, rtol=1e-6, atol=1e-7)
+
+
+def test_fused_loss_tail_is_taken_by_the_output_layer_and_equals_the_three_calls(monkeypatch):
+    fake = fake_lib.install(monkeypatch)
+    from acm_gnn_amd import functional as AF
+    calls = []
+    real = fake.acm_conv_fwd_tail
+    monkeypatch.setattr(fake, "acm_conv_fwd_tail", lambda *a: (calls.append(1), real(*a))[1])
+    model, ops, x, y, w = _setup()
+    out = model(x, ops)
+    loss0, dz0 = AF.nll_loss_and_grad(out, y, w)
+    out.backward(dz0)
+    want = _grads(model)
+    assert not calls
+    model.zero_grad(set_to_none=True)
+    with AF.fused_loss_tail(y, w) as tail:
+        out = model(x, ops)
+    assert calls == [1] and tail.matches(out)                    # only the output layer took the request
+    assert torch.equal(tail.dz, dz0) and float(tail.loss) == float(loss0)
+    out.backward(tail.dz)
+    got = _grads(model)
+    assert got.keys() == want.keys() and all(torch.equal(got[k], want[k]) for k in want)
+    # any other gradient makes the layer run its row-local backward again
+    model.zero_grad(set_to_none=True)
+    with AF.fused_loss_tail(y, w) as tail:
+        out = model(x, ops)
+    out.backward(2.0 * tail.dz)
+    for k, v in _grads(model).items():
+        assert torch.allclose(v, 2.0 * want[k], rtol=1e-5, atol=1e-7), k
+    # no request, or a layer that does not qualify: nothing changes
+    with AF.fused_loss_tail(y, w) as tail:
+        hidden = model.gcns[0](x, ops)
+    assert tail.out is None and not tail.matches(hidden)

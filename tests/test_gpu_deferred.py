@@ -107,3 +107,37 @@ def test_saved_head_statistics_equal_the_recomputation_bitwise(s, ln, monkeypatc
     assert grads[0].keys() == grads[1].keys() and len(grads[0]) >= 8
     for k in grads[0]:
         assert torch.equal(grads[0][k], grads[1][k]), k
+
+
+@pytest.mark.parametrize("model_type,hidden,classes_graph", [("acmgcn", 64, "tiny"), ("acmgcnp", 64, "tiny"), ("acmgcnp", 16, "tiny")])
+def test_fused_loss_tail_equals_the_three_calls(model_type, hidden, classes_graph):
+    """acm_conv_fwd_tail (row phase + masked NLL + K3 in one kernel) against acm_conv_fwd, acm_nll_loss and
+    acm_conv_bwd_local: logits, dz and the G tables bit for bit; the loss and the parameter-gradient sums up to the
+    different (fixed) order of their block partials."""
+    from acm_gnn_amd import functional as AF
+    model, ops, x, y, w = _setup(model_type, 0, hidden, dataset=classes_graph)
+    out0 = model(x, *ops)
+    loss0, dz0 = AF.nll_loss_and_grad(out0, y, w)
+    out0.backward(dz0)
+    want = {k: v.grad.clone() for k, v in model.named_parameters() if v.grad is not None}
+    model.zero_grad(set_to_none=True)
+    with AF.fused_loss_tail(y, w) as tail:
+        out = model(x, *ops)
+    assert tail.matches(out), "the output layer did not take the request"
+    assert torch.equal(out, out0) and torch.equal(tail.dz, dz0)
+    np.testing.assert_allclose(float(tail.loss), float(loss0), rtol=2e-6)
+    out.backward(tail.dz)
+    got = {k: v.grad for k, v in model.named_parameters() if v.grad is not None}
+    assert got.keys() == want.keys()
+    for k in want:
+        scale = float(want[k].abs().max()) + 1e-12
+        assert float((got[k] - want[k]).abs().max()) <= 3e-6 * scale, k
+    # a different gradient: the layer's own K3 runs again
+    model.zero_grad(set_to_none=True)
+    with AF.fused_loss_tail(y, w) as tail:
+        out = model(x, *ops)
+    out.backward(tail.dz * 3.0)
+    for k, v in model.named_parameters():
+        if v.grad is not None:
+            scale = float(want[k].abs().max()) + 1e-12
+            assert float((v.grad - 3.0 * want[k]).abs().max()) <= 1e-5 * scale, k
