@@ -14,12 +14,10 @@ import sys
 LABELS = {
     "conv_agg_fwd/F64k3i7": ["agg_fused_pair_kernel", "agg_fused_kernel<8"],
     "conv_agg_bwd/F64k3i7": ["agg_bwd_kernel<8, 3"],
-    "conv_fwd/F2k3": ["spmm_narrow_kernel<2, 2, 16, true, EpiRaw>", "conv_fwd_rows_kernel<2, 2>"],
+    "conv_fwd_tail/F2k3": ["spmm_narrow_kernel<2, 2, 16, true, EpiRaw>", "conv_tail_rows_kernel<2, 2>"],   # + loss + K3
     "conv_bwd_spmm/F2k3": ["spmm_narrow_kernel<2, 2, 16, true, EpiBwd>"],
-    "conv_bwd_local/F2k3": ["conv_bwd_local_kernel<LayPacked<2>, 32, 3>"],
     "proj_bwd/168114x64x6": ["proj_bwd_kernel<6>"],
     "proj_fwd/168114x64x6": ["proj_fwd_kernel<2>"],
-    "nll_loss/168114x2": ["nll_rows_kernel"],
     "dropout/168114x7": ["dropout_kernel"],
     "reduce_flush": ["reduce_segments_kernel"],          # every deferred second phase of the step, one launch
     "adam_step": ["adam_kernel"],
