@@ -78,8 +78,12 @@ def algorithmic_bytes(label, n, nnz, implicit=False):
     f = int(shape[1:shape.index("k")])
     k = int(shape[shape.index("k") + 1:])
     graph = 4 * (n + 1) + per_edge * nnz + per_row * n
-    if kind == "conv_fwd":       # read Z [n,3F] (+S, deg) once; write out, pre, att
-        return graph + 4 * n * 3 * f + (4 * n * (f + 1) if k == 4 else 0) + 4 * n * f + 4 * n * (k - 1) * f + 16 * n
+    if kind in ("conv_fwd", "conv_fwd_tail"):   # read Z [n,3F] (+S, deg) once; write out, pre, att
+        fwd = graph + 4 * n * 3 * f + (4 * n * (f + 1) if k == 4 else 0) + 4 * n * f + 4 * n * (k - 1) * f + 16 * n
+        if kind == "conv_fwd":
+            return fwd
+        # + the loss (labels, weights, dlogits) and the layer's K3 outputs (G_L, G_H, G_I) in the same row pass
+        return fwd + n * (8 + 4 + 4 * f) + 4 * n * f * k
     if kind == "conv_bwd_spmm":  # read G [n,(k-1)F] once; write dZ_L, dZ_H (+dS)
         return graph + 4 * n * (k - 1) * f + 4 * n * (k - 1) * f
     if kind == "conv_bwd_local":  # read grad_out, pre, Z_I; write G_L, G_H, G_I (+G_S)
