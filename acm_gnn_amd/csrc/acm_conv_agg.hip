@@ -557,9 +557,13 @@ __global__ __launch_bounds__(256, 2) void agg_bwd_kernel(acm_conv_agg_bwd_t p, i
 
 int agg_pad(int f_in) { return f_in <= 4 ? 4 : (f_in <= 8 ? 8 : 16); }
 
-int agg_bwd_blocks(int64_t n_rows) {
+// Persistent grid of agg_bwd_kernel: as many workgroups as stay resident.  Three channels: 151 VGPRs, three workgroups
+// (3 waves/SIMD) per CU -- 768 blocks take the twitch layer 85 -> 77 us against 512 (1 024 do not fit: 82 us);
+// with the structure channel (185-191 VGPRs) two fit.
+int agg_bwd_blocks(int64_t n_rows, int n_channels, size_t lds_bytes) {
     int64_t nb = (n_rows + 15) / 16;
-    if (nb > 512) nb = 512;
+    const int cap = (n_channels == 3 && 3 * lds_bytes <= 160 * 1024) ? 768 : 512;     // registers and LDS of three
+    if (nb > cap) nb = cap;
     if (nb < 1) nb = 1;
     return (int)nb;
 }
@@ -674,7 +678,7 @@ extern "C" int acm_conv_agg_bwd_workspace_bytes(int64_t n_rows, int f_in, int f_
     ACM_REQUIRE(f_in >= 1 && f_in <= 16 && f_out >= 1 && f_out <= 64, ACM_EUNSUPPORTED,
                 "acm_conv_agg_bwd_workspace_bytes: f_in %d f_out %d unsupported", f_in, f_out);
     const size_t npg = (size_t)3 * f_in * f_out + 12 * (size_t)f_out + 16;      // sized for 4 channels
-    *bytes = (size_t)agg_bwd_blocks(n_rows) * npg * sizeof(float);
+    *bytes = (size_t)agg_bwd_blocks(n_rows, 3, 0) * npg * sizeof(float);      // the larger of the two grids
     return ACM_OK;
 }
 
@@ -700,11 +704,11 @@ extern "C" int acm_conv_agg_bwd(int64_t n_rows, const acm_conv_agg_bwd_t* p, voi
                 workspace_bytes, need);
     const int K = p->n_channels;
     const int npg = 3 * p->f_in * p->f_out + 3 * K * p->f_out + K * K;
-    const int nblk = agg_bwd_blocks(n_rows);
     const size_t lds_w = ((size_t)3 * p->f_pad * 64 + 3 * K * 64 + 32 * p->f_pad) * sizeof(float),
                  lds_s = (size_t)4 * npg * sizeof(float);
     const size_t lds = lds_w > lds_s ? lds_w : lds_s;
     ACM_REQUIRE(lds <= 64 * 1024, ACM_EUNSUPPORTED, "acm_conv_agg_bwd: %zu B of LDS needed", lds);
+    const int nblk = agg_bwd_blocks(n_rows, p->n_channels, lds);
     hipStream_t s = (hipStream_t)stream;
     float* partial = (float*)workspace;
 #define ACM_BWDK(FPv)                                                                                                  \
