@@ -14,7 +14,7 @@ c_i32p = C.POINTER(C.c_int32)
 
 ACM_OK = 0
 STATUS_NAMES = {1: "ACM_EINVAL", 2: "ACM_ESHAPE", 3: "ACM_EHIP", 4: "ACM_EUNSUPPORTED", 5: "ACM_ENOMEM"}
-ABI_VERSION = 16
+ABI_VERSION = 17
 
 # every symbol include/acm_hip.h declares
 EXPORTED_SYMBOLS = (
@@ -23,7 +23,7 @@ EXPORTED_SYMBOLS = (
     "acm_gemm", "acm_gemm_blocks", "acm_gemm_split", "acm_proj_fwd", "acm_proj_bwd_workspace_bytes", "acm_proj_bwd", "acm_spmm", "acm_spmm_v", "acm_spmm_ex", "acm_cast_bf16", "acm_conv_fwd", "acm_conv_bwd_local_workspace_bytes",
     "acm_conv_bwd_local", "acm_conv_bwd_spmm", "acm_conv_agg_fwd", "acm_conv_agg_bwd_workspace_bytes",
     "acm_conv_agg_bwd", "acm_nll_loss_workspace_bytes", "acm_nll_loss", "acm_adam_step", "acm_dropout",
-    "acm_reduce_flush", "acm_conv_fwd_tail_workspace_bytes", "acm_conv_fwd_tail",
+    "acm_reduce_flush", "acm_conv_fwd_tail_workspace_bytes", "acm_conv_fwd_tail", "acm_shard_plan",
 )
 
 
@@ -175,6 +175,7 @@ def _declare(lib):
     lib.acm_csr_destroy.argtypes = [vp]
     lib.acm_csr_destroy.restype = None
     lib.acm_csr_info.argtypes = [vp, C.POINTER(CsrInfo)]
+    lib.acm_shard_plan.argtypes = [i64, vp, i32, i64, vp]
     lib.acm_spmm_workspace_bytes.argtypes = [vp, i32, C.POINTER(sz)]
     lib.acm_gemm_workspace_bytes.argtypes = [i32, i32, i64, i64, i64, C.POINTER(sz)]
     lib.acm_gemm.argtypes = [i32, i32, i64, i64, i64, vp, i64, vp, i64, vp, i64, i32, vp, sz, vp]

@@ -285,6 +285,30 @@ extern "C" int acm_csr_slice_rows(const acm_csr_t* a, int64_t row_begin, int64_t
 
 extern "C" void acm_csr_destroy(acm_csr_t* a) { free_handle(a); }
 
+extern "C" int acm_shard_plan(int64_t n_rows, const int64_t* indptr, int world, int64_t row_cost, int64_t* bounds) {
+    ACM_REQUIRE(indptr && bounds, ACM_EINVAL, "acm_shard_plan: NULL argument");
+    ACM_REQUIRE(n_rows >= 0 && world >= 1 && row_cost >= 0, ACM_ESHAPE, "acm_shard_plan: n_rows %lld world %d row_cost %lld",
+                (long long)n_rows, world, (long long)row_cost);
+    ACM_REQUIRE(indptr[0] == 0, ACM_EINVAL, "acm_shard_plan: indptr[0] must be 0");
+    // cost prefix c(r) = indptr[r] + row_cost * r, non-decreasing in r
+    auto cost = [&](int64_t r) { return (__int128)indptr[r] + (__int128)row_cost * r; };
+    const __int128 total = cost(n_rows);
+    bounds[0] = 0;
+    for (int p = 1; p < world; ++p) {
+        const __int128 target = total * p / world;
+        int64_t lo = bounds[p - 1], hi = n_rows;          // smallest r in [lo, n_rows] with c(r) >= target
+        while (lo < hi) {
+            const int64_t mid = lo + (hi - lo) / 2;
+            if (cost(mid) >= target) hi = mid; else lo = mid + 1;
+        }
+        int64_t r = lo;
+        if (r > bounds[p - 1] && target - cost(r - 1) < cost(r) - target) --r;      // the nearer boundary
+        bounds[p] = r;
+    }
+    bounds[world] = n_rows;
+    return ACM_OK;
+}
+
 extern "C" int acm_csr_info(const acm_csr_t* a, acm_csr_info_t* info) {
     ACM_REQUIRE(a && info, ACM_EINVAL, "acm_csr_info: NULL argument");
     info->n_rows = a->n_rows;

@@ -147,3 +147,24 @@ def row_normalize_features(x):
         inv = np.power(rowsum, -1.0)
     inv[np.isinf(inv)] = 0.0
     return np.asarray(sp.diags(inv, 0).dot(m).todense()).astype(np.float32)
+
+
+def bench_workload(dataset="twitch-gamer", seed=0, node_order="degree", normalize_features=True, uniform=False,
+                   pad_to=1):
+    """The synthetic workload of bench.py as one call (the full-size parity tests build exactly this):
+    Chung-Lu graph of the dataset's shape, optional relabelling of the real nodes by decreasing degree (data
+    preparation: results are identical up to the permutation), feature row normalisation (train.py:69-73; the
+    caller passes normalize_features=False for acmgcnp/acmgcnpp with structure_info), A_low and d.
+
+    Returns a dict: adj (scipy CSR, 0/1), x, y, splits (train, val, test), n_real, low (scipy CSR fp32), deg."""
+    adj, x, y, splits, n_real = synthetic_dataset(dataset, seed=seed, uniform=uniform, pad_to=pad_to)
+    if node_order == "degree":
+        perm = degree_order(adj[:n_real][:, :n_real].tocsr())
+        full = np.concatenate([perm, np.arange(n_real, adj.shape[0])])
+        adj, x, y, splits = permute_dataset(adj, x, y, splits, full)
+    elif node_order != "random":
+        raise ValueError("node_order: 'degree' or 'random'")
+    if normalize_features:
+        x = row_normalize_features(x)
+    low, deg = build_filters(adj)
+    return dict(adj=adj, x=x, y=y, splits=splits, n_real=n_real, low=low, deg=deg)

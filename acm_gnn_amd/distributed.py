@@ -1,10 +1,19 @@
 """Row-sharded ACM operators: one process per GPU, RCCL (torch.distributed "nccl")
 over xGMI for the halo exchange.
 
-Partition: contiguous, equal-sized row blocks (the node count is padded to a
-multiple of the world size with isolated dummy nodes, see data.synthetic_dataset).
-Rank p owns rows [p*n_loc, (p+1)*n_loc) of A_low, of A_low^T, of X / Z / H / out,
-of struc_low and of the labels.  Per layer the only data-path collectives are
+Partition: P contiguous row blocks balanced by WORK, not by row count --
+``shard_plan`` cuts the prefix sum of ``nnz(row) + row_cost`` into equal shares (the C ABI's
+``acm_shard_plan``; equal rows put 64 % of the edges of a degree-ordered power-law graph on rank 0 of
+8).  Blocks may therefore differ in length.  Rank p owns rows [bounds[p], bounds[p+1]) of A_low, of
+A_low^T, of X / Z / H / out, of struc_low and of the labels.
+
+Halo layout: every all-gather moves ``n_max = max block length`` rows per rank (shorter blocks are
+zero-padded), so the gathered table has P * n_max rows and node j of rank r sits at row
+``r * n_max + (j - bounds[r])``.  The local operators are built with their column ids already in that
+padded numbering (``ShardPlan.padded_ids``): the gather kernels index the all-gather output directly,
+no compaction pass, and with equal blocks the numbering is the identity.
+
+Per layer the only data-path collectives are
 
     forward : all-gather of the projected features [Z_L | Z_H] (and struc_low rows)
     backward: all-gather of the row-local gradients [G_L | G_H] (and D*G_S)
@@ -13,29 +22,122 @@ of struc_low and of the labels.  Per layer the only data-path collectives are
 (functional.AcmConvFunction issues them through ``FilterOperators.group``).
 The reference is single-process (no collective call sites), so
 this module has no reference counterpart; its contract is "N-rank result ==
-1-rank result", tested with world_size 2 on gloo (CPU) with the kernel launches
-replaced by a test double, and by construction on RCCL.
+1-rank result", tested with world_size 2 and 4 on gloo (CPU) with the kernel launches
+replaced by a test double, with two ranks on one GPU, and by construction on RCCL.
 """
+import ctypes as C
 import os
 
 import numpy as np
 import torch
 
+from . import _lib
 from .graph import CsrGraph, FilterOperators, as_implicit, implicit_form
+
+# Row-local work of a training step expressed in "edges per row": on the twitch-shaped graph the per-row kernels
+# (projections, head, K3a, output-layer tail, optimizer) take ~150 us for 168 k rows, the gathers ~180 us for 13.8 M
+# edges (profiles/r01_q_step_timeline.txt) => one row costs about as much as 68 gathered edges.
+DEFAULT_ROW_COST = 64
+
+
+class ShardPlan:
+    """Contiguous row blocks [bounds[p], bounds[p+1]) for P ranks and the padded halo numbering."""
+
+    def __init__(self, bounds):
+        self.bounds = np.asarray(bounds, dtype=np.int64)
+        if self.bounds.ndim != 1 or self.bounds.size < 2 or self.bounds[0] != 0 or np.any(np.diff(self.bounds) < 0):
+            raise ValueError("ShardPlan: bounds must be a non-decreasing vector starting at 0")
+        self.world = self.bounds.size - 1
+        self.n_global = int(self.bounds[-1])
+        self.n_max = int(np.diff(self.bounds).max())
+
+    def rows(self, rank):
+        return int(self.bounds[rank]), int(self.bounds[rank + 1])
+
+    @property
+    def uniform(self):
+        """Equal blocks: the padded numbering is the identity and the gathered table has n_global rows."""
+        return bool(np.all(np.diff(self.bounds) == self.n_max))
+
+    @property
+    def n_gathered(self):
+        return self.world * self.n_max
+
+    def owner(self, ids):
+        return np.searchsorted(self.bounds, np.asarray(ids), side="right") - 1
+
+    def padded_ids(self, ids):
+        """Global node ids -> row in the all-gathered (padded) table."""
+        ids = np.asarray(ids, dtype=np.int64)
+        if self.uniform:
+            return ids
+        r = np.minimum(self.owner(ids), self.world - 1)
+        return r * self.n_max + (ids - self.bounds[r])
+
+    def pad_rows(self, array):
+        """A global [n_global, ...] array laid out like the gathered table ([world * n_max, ...], zero padding)."""
+        if self.uniform:
+            return array
+        out = np.zeros((self.n_gathered,) + array.shape[1:], dtype=array.dtype)
+        out[self.padded_ids(np.arange(self.n_global))] = array
+        return out
+
+    def work(self, indptr, row_cost=0):
+        """Per-rank (rows, nnz, nnz + row_cost * rows)."""
+        ip = np.asarray(indptr, dtype=np.int64)
+        rows = np.diff(self.bounds)
+        nnz = ip[self.bounds[1:]] - ip[self.bounds[:-1]]
+        return rows, nnz, nnz + row_cost * rows
+
+    def imbalance(self, indptr, row_cost=0):
+        """max / mean of the per-rank nnz and of the per-rank work: the factor by which the slowest rank's gathers /
+        whole step exceed the average."""
+        _, nnz, cost = self.work(indptr, row_cost)
+        return float(nnz.max() / max(nnz.mean(), 1e-30)), float(cost.max() / max(cost.mean(), 1e-30))
+
+    def __repr__(self):
+        return f"ShardPlan(world={self.world}, rows={np.diff(self.bounds).tolist()})"
+
+
+def equal_rows_plan(n_global, world):
+    """Equal row counts (the node count must be a multiple of the world size: pad the graph)."""
+    if n_global % world:
+        raise ValueError(f"node count {n_global} is not a multiple of the world size {world}; pad the graph")
+    return ShardPlan(np.arange(world + 1, dtype=np.int64) * (n_global // world))
+
+
+def shard_plan(indptr, world, row_cost=DEFAULT_ROW_COST):
+    """Work-balanced contiguous blocks: bounds[p] = the row at which the prefix sum of (nnz(row) + row_cost) crosses
+    p / world of its total (acm_shard_plan, host code of the C ABI; binary search over indptr)."""
+    ip = np.ascontiguousarray(indptr, dtype=np.int64)
+    n = ip.size - 1
+    bounds = np.zeros(world + 1, dtype=np.int64)
+    st = _lib.load().acm_shard_plan(n, ip.ctypes.data_as(C.c_void_p), int(world), int(row_cost),
+                                    bounds.ctypes.data_as(C.c_void_p))
+    _lib.check(st, "acm_shard_plan")
+    return ShardPlan(bounds)
 
 
 def shard_bounds(n_global, world, rank):
-    if n_global % world:
-        raise ValueError(f"node count {n_global} is not a multiple of the world size {world}; pad the graph")
-    n_loc = n_global // world
-    return rank * n_loc, (rank + 1) * n_loc
+    """Row range of `rank` under the equal-rows plan."""
+    return equal_rows_plan(n_global, world).rows(rank)
 
 
-def shard_filter_arrays(low_csr, deg, world, rank):
+def interleave_order(n, world):
+    """Permutation (new id -> old id) that deals rows 0, 1, 2, ... to the ranks like cards: new block p = old rows
+    p, p + P, p + 2P, ....  Applied to a degree-sorted graph (data.degree_order) it makes EQUAL contiguous blocks
+    balanced in rows and in nnz at once (each rank gets every P-th row of the degree ranking, itself still sorted by
+    degree), which a contiguous cut of the sorted ranking cannot do: there rank 0 holds the hubs and few rows, the last
+    rank many short rows.  n must be a multiple of world."""
+    if n % world:
+        raise ValueError("interleave_order: pad the node count to a multiple of the world size")
+    return np.arange(n, dtype=np.int64).reshape(n // world, world).T.reshape(-1).copy()
+
+
+def shard_filter_arrays(low_csr, deg, plan, rank):
     """Host-side split of a global scipy CSR A_low (and d) into the arrays rank `rank` needs:
     its rows of A_low and its rows of A_low^T, both with global column ids."""
-    n = low_csr.shape[0]
-    b, e = shard_bounds(n, world, rank)
+    b, e = plan.rows(rank)
     low_loc = low_csr[b:e].tocsr()
     low_loc.sort_indices()
     low_t = low_csr.T.tocsr()
@@ -44,8 +146,16 @@ def shard_filter_arrays(low_csr, deg, world, rank):
     return low_loc, low_t_loc, (deg[b:e].copy() if deg is not None else None), b
 
 
-def make_sharded_operators(low_csr, deg, device, group=None, with_structure=False):
-    """FilterOperators for this rank (or the unsharded ones when no process group is active)."""
+def _padded_columns(mat, plan):
+    """scipy CSR with global column ids -> (indptr, padded column ids sorted within each row, values)."""
+    m = mat.tocsr()
+    m.sort_indices()                               # the padded numbering is monotone in the global id: order is kept
+    return m.indptr.astype(np.int32), plan.padded_ids(m.indices).astype(np.int32), m.data.astype(np.float32)
+
+
+def make_sharded_operators(low_csr, deg, device, group=None, with_structure=False, plan=None, row_cost=DEFAULT_ROW_COST):
+    """FilterOperators for this rank (or the unsharded ones when no process group is active).  ``plan``: a ShardPlan
+    (default: work-balanced blocks of this graph, identical on every rank because it is a function of indptr only)."""
     import torch.distributed as dist
     if group is None and not (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1):
         low = CsrGraph.from_scipy(low_csr, device)
@@ -53,44 +163,56 @@ def make_sharded_operators(low_csr, deg, device, group=None, with_structure=Fals
         return as_implicit(FilterOperators(low, d))
     group = group if group is not None else dist.group.WORLD
     world, rank = dist.get_world_size(group), dist.get_rank(group)
+    low_csr = low_csr.tocsr()
+    if plan is None:
+        plan = shard_plan(low_csr.indptr, world, row_cost)
+    if plan.world != world or plan.n_global != low_csr.shape[0]:
+        raise ValueError(f"{plan} does not match {world} ranks / {low_csr.shape[0]} rows")
+    b, e = plan.rows(rank)
+    dev = torch.device(device)
+
+    def dev_t(a):
+        return torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+
     form = None
     if os.environ.get("ACM_IMPLICIT", "1") != "0":
         # pattern-only form, detected on the global matrix (host): the rank's rows of P serve A_low (row-scaled)
         # and, P being symmetric, A_low^T on the pre-scaled all-gathered gradients -- one column-id stream, no
         # transposed slice
-        g = low_csr.tocsr()
+        g = low_csr
         g.sort_indices()
         form = implicit_form(torch.from_numpy(g.indptr.astype(np.int64)), torch.from_numpy(g.indices.astype(np.int64)),
                              torch.from_numpy(g.data.astype(np.float32)), g.shape[0], g.shape[1])
+    common = dict(row_offset=b, n_global=plan.n_global, group=group)
     if form is not None:
         ip, ix, s = (t.numpy() for t in form)
-        b, e = shard_bounds(low_csr.shape[0], world, rank)
         ip_loc = (ip[b:e + 1] - ip[b]).astype(np.int32)
-        ix_loc = ix[ip[b]:ip[e]]
-        dev = torch.device(device)
-        pat = CsrGraph.from_csr(torch.from_numpy(ip_loc).to(dev), torch.from_numpy(np.ascontiguousarray(ix_loc)).to(dev),
-                                None, low_csr.shape[1])
-        ops = FilterOperators(pat, torch.from_numpy(np.ascontiguousarray(deg[b:e])).to(dev) if with_structure else None,
-                              row_offset=b, n_global=low_csr.shape[0], group=group,
-                              row_scale=torch.from_numpy(np.ascontiguousarray(s[b:e])).to(dev))
+        ix_loc = plan.padded_ids(ix[ip[b]:ip[e]]).astype(np.int32)
+        pat = CsrGraph.from_csr(dev_t(ip_loc), dev_t(ix_loc), None, plan.n_gathered)
+        ops = FilterOperators(pat, dev_t(deg[b:e]) if with_structure else None, row_scale=dev_t(s[b:e]), **common)
         ops.low_t_override = pat
-        return ops
-    low_loc, low_t_loc, deg_loc, b = shard_filter_arrays(low_csr, deg, world, rank)
-    ops = FilterOperators(CsrGraph.from_scipy(low_loc, device),
-                          torch.from_numpy(np.ascontiguousarray(deg_loc)).to(device) if with_structure else None,
-                          row_offset=b, n_global=low_csr.shape[0], group=group)
-    ops.low_t_override = CsrGraph.from_scipy(low_t_loc, device)
+    else:
+        low_loc, low_t_loc, deg_loc, _ = shard_filter_arrays(low_csr, deg, plan, rank)
+        ip, ix, v = _padded_columns(low_loc, plan)
+        ops = FilterOperators(CsrGraph.from_csr(dev_t(ip), dev_t(ix), dev_t(v), plan.n_gathered),
+                              dev_t(deg_loc) if with_structure else None, **common)
+        ip, ix, v = _padded_columns(low_t_loc, plan)
+        ops.low_t_override = CsrGraph.from_csr(dev_t(ip), dev_t(ix), dev_t(v), plan.n_gathered)
+    ops.plan = plan
     return ops
 
 
-def local_rows(array, world, rank):
-    b, e = shard_bounds(array.shape[0], world, rank)
+def local_rows(array, plan, rank):
+    b, e = plan.rows(rank)
     return array[b:e]
 
 
-def local_index(idx, world, rank, n_global):
-    """Global node indices -> indices into this rank's row block (only the owned ones)."""
-    b, e = shard_bounds(n_global, world, rank)
+def local_index(idx, plan, rank, n_global=None):
+    """Global node indices -> indices into this rank's row block (only the owned ones).  ``plan``: a ShardPlan, or
+    (legacy) the world size of an equal-rows plan over ``n_global`` nodes."""
+    if not isinstance(plan, ShardPlan):
+        plan = equal_rows_plan(n_global, int(plan))
+    b, e = plan.rows(rank)
     idx = np.asarray(idx)
     own = idx[(idx >= b) & (idx < e)]
     return own - b

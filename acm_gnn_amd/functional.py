@@ -525,15 +525,22 @@ def cast_bf16(src):
 
 
 def _gather_rows(ops, local):
-    """All-gather row blocks of a row-sharded dense matrix (halo exchange).  Single
-    process: identity."""
+    """All-gather row blocks of a row-sharded dense matrix (halo exchange) into the layout the local operators'
+    column ids refer to: rank r's rows start at r * n_max, shorter blocks are zero-padded (distributed.ShardPlan).
+    Single process: identity."""
     if not ops.sharded:
         return local
     import torch.distributed as dist
     world = dist.get_world_size(ops.group)
-    full = torch.empty(world * local.shape[0], local.shape[1], dtype=local.dtype, device=local.device)
-    dist.all_gather_into_tensor(full, local.contiguous(), group=ops.group)
-    return full[: ops.n_global] if full.shape[0] != ops.n_global else full
+    n_max = ops.n_gathered // world
+    local = local.contiguous()
+    if local.shape[0] != n_max:                       # work-balanced blocks differ in length
+        buf = local.new_zeros(n_max, local.shape[1])
+        buf[: local.shape[0]] = local
+        local = buf
+    full = torch.empty(world * n_max, local.shape[1], dtype=local.dtype, device=local.device)
+    dist.all_gather_into_tensor(full, local, group=ops.group)
+    return full
 
 
 def _low_product(ops, t_local, transpose=False):
@@ -671,7 +678,7 @@ class AcmConvFunction(torch.autograd.Function):
             else:
                 xpad = torch.nn.functional.pad(x[:, :f_in], (0, fp - f_in))
             if (pregathered is not None and pregathered[0].data_ptr() == xpad.data_ptr()
-                    and pregathered[1].shape[1] == fp and pregathered[1].shape[0] == ops.n_global):
+                    and pregathered[1].shape[1] == fp and pregathered[1].shape[0] == ops.n_gathered):
                 xg = pregathered[1]                   # the caller already holds every node's (dropped) input
             else:
                 xg = _gather_rows(ops, xpad)

@@ -241,6 +241,7 @@ class FilterOperators:
         self.row_offset = int(row_offset)
         self.n_global = int(n_global if n_global is not None else low.n_cols)
         self.group = group                              # torch.distributed group when row-sharded
+        self.plan = None                                # distributed.ShardPlan when row-sharded (halo numbering)
         self.low_t_override = None                      # local rows of the global A_low^T (sharded)
         # optional, row-sharded runs: the full (replicated, static) input matrix.  With counter-based dropout every
         # rank can then produce the dropped input of ALL nodes itself and the first layer needs no halo all-gather
@@ -292,6 +293,16 @@ class FilterOperators:
     @property
     def sharded(self):
         return self.group is not None
+
+    @property
+    def n_gathered(self):
+        """Rows of an all-gathered halo table (= columns of the local operators): world * the longest block."""
+        return self.plan.n_gathered if self.plan is not None else self.n_global
+
+    @property
+    def uniform(self):
+        """All ranks own equally many rows: the halo numbering is the global numbering."""
+        return self.plan is None or self.plan.uniform
 
 
 # --------------------------------------------------------------------------

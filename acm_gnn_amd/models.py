@@ -22,6 +22,31 @@ from .layers import GraphConvolution, MLP
 _TWO_LAYER = ("acmgcn", "acmgcnp", "acmgcnpp")
 
 
+class _SumGradsOverRanks(torch.autograd.Function):
+    """Identity on replicated parameters whose gradients are per-rank partial sums over the local rows (the
+    ACM-GCN++ residual Linear): the backward sums them over the row shards with one all-reduce, like the ACM layers do
+    for their own replicated parameters -- otherwise every rank would step its replica with a different gradient."""
+
+    @staticmethod
+    def forward(ctx, group, *tensors):
+        ctx.group = group
+        return tuple(t.view_as(t) for t in tensors)
+
+    @staticmethod
+    def backward(ctx, *grads):
+        import torch.distributed as dist
+        from . import functional as AF
+        if AF._DEFER is not None:
+            AF._DEFER.flush()
+        flat = torch.cat([g.reshape(-1) for g in grads])
+        dist.all_reduce(flat, group=ctx.group)
+        out, o = [], 0
+        for g in grads:
+            out.append(flat[o:o + g.numel()].view_as(g))
+            o += g.numel()
+        return (None, *out)
+
+
 class GCN(nn.Module):
     def __init__(self, nfeat, nhid, nclass, nlayers, nnodes, dropout, model_type, structure_info,
                  variant=False, init_layers_X=1, attn_layernorm=None, gather_dtype=None):
@@ -64,6 +89,18 @@ class GCN(nn.Module):
         if self.model_type == "acmgcnpp":
             self.mlpX.reset_parameters()
 
+    def _residual(self, x, adj_low):
+        """relu(Linear(x)) of the ACM-GCN++ branch (ACM-Geometric/models.py:26-27,55-56).  Row-sharded: the Linear's
+        weight / bias gradients are summed over the ranks."""
+        ops = adj_low if isinstance(adj_low, FilterOperators) else None
+        if ops is not None and ops.sharded:
+            if len(self.mlpX.lins) != 1:
+                raise NotImplementedError("row-sharded acmgcnpp supports init_layers_X = 1 (no BatchNorm statistics to sync)")
+            lin = self.mlpX.lins[0]
+            w, b = _SumGradsOverRanks.apply(ops.group, lin.weight, lin.bias)
+            return F.relu(F.linear(x, w, b))
+        return F.relu(self.mlpX(x, input_tensor=True))
+
     def _forward_fused_dropout(self, x, adj_low, adj_high, adj_low_unnormalized):
         """Training forward with every dropout drawn from ``dropout_state`` (tags: 0 input, 1 hidden, 2 the
         ACM-GCN++ residual branch); same structure as forward()."""
@@ -82,9 +119,10 @@ class GCN(nn.Module):
             nfeat = x.shape[1]
             pad = AF.agg_pad_width(nfeat) if self.model_type != "acmgcnpp" else None
             ops = adj_low if isinstance(adj_low, FilterOperators) else None
-            if ops is not None and ops.sharded and ops.x_full is not None and self.model_type != "acmgcnpp":
+            if (ops is not None and ops.sharded and ops.uniform and ops.x_full is not None
+                    and self.model_type != "acmgcnpp"):
                 # the mask is a function of the global position: drop the replicated full input locally instead of
-                # all-gathering the dropped row blocks
+                # all-gathering the dropped row blocks (equal blocks only: there the halo numbering is the global one)
                 xg = AF.dropout(ops.x_full, p, st, tag=0, pad_to=pad, row_offset=0)
                 x = xg[off:off + x.shape[0]]
                 ops._pregathered = (x, xg)
@@ -94,7 +132,7 @@ class GCN(nn.Module):
         if self.model_type == "acmsgc":
             return self.gcns[0](x, adj_low, adj_high, adj_low_unnormalized)
         if self.model_type == "acmgcnpp":
-            xx = AF.dropout(F.relu(self.mlpX(x, input_tensor=True)), p, st, tag=2, row_offset=off)
+            xx = AF.dropout(self._residual(x, adj_low), p, st, tag=2, row_offset=off)
         fea = self.gcns[0](x, adj_low, adj_high, adj_low_unnormalized, post_relu=True, post_drop=(p, 1, st), **kw)
         if self.model_type == "acmgcnpp":
             fea = fea + xx
@@ -114,7 +152,7 @@ class GCN(nn.Module):
         if self.model_type == "acmsgc":
             return self.gcns[0](x, adj_low, adj_high, adj_low_unnormalized)
         if self.model_type == "acmgcnpp":
-            xx = drop(F.relu(self.mlpX(x, input_tensor=True)))
+            xx = drop(self._residual(x, adj_low))
         # dropout(relu(fea1)) (models.py:70) rides the layer's epilogue: the keep-mask / (1 - p) tensor is what
         # F.dropout does to a tensor of ones, so a patched F.dropout (mask replay in tests) is honoured
         scale = None

@@ -118,17 +118,10 @@ def main():
 
     # ---------------- data (synthetic, seeded; identical on every rank) ----------------
     t0 = time.time()
-    adj, x_np, y_np, (tr, va, te), n_real = D.synthetic_dataset(args.dataset, seed=args.seed,
-                                                                uniform=args.uniform, pad_to=world)
-    if args.node_order == "degree":
-        # relabel the REAL nodes by decreasing degree (padding nodes stay at the end)
-        perm = D.degree_order(adj[:n_real][:, :n_real].tocsr())
-        full = np.concatenate([perm, np.arange(n_real, adj.shape[0])])
-        adj, x_np, y_np, (tr, va, te) = D.permute_dataset(adj, x_np, y_np, (tr, va, te), full)
+    wl = D.bench_workload(args.dataset, seed=args.seed, node_order=args.node_order, uniform=args.uniform, pad_to=world,
+                          normalize_features=not (args.method in ("acmgcnp", "acmgcnpp") and args.structure_info))
+    adj, x_np, y_np, (tr, va, te), n_real, low, deg = (wl[k] for k in ("adj", "x", "y", "splits", "n_real", "low", "deg"))
     n_glob = adj.shape[0]
-    if not (args.method in ("acmgcnp", "acmgcnpp") and args.structure_info):
-        x_np = D.row_normalize_features(x_np)              # train.py:69-73
-    low, deg = D.build_filters(adj)
     nnz = int(low.nnz)
     ops = DD.make_sharded_operators(low, deg, dev, with_structure=bool(args.structure_info),
                                     group=dist.group.WORLD if (force_sharded and dist.is_initialized()) else None)

@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define ACM_ABI_VERSION 16
+#define ACM_ABI_VERSION 17
 
 typedef enum {
     ACM_OK = 0,
@@ -82,6 +82,18 @@ int acm_csr_transpose(const acm_csr_t* a, int chunk, acm_csr_t** out);
 int acm_csr_slice_rows(const acm_csr_t* a, int64_t row_begin, int64_t row_end,
                        int chunk, acm_csr_t** out);
 void acm_csr_destroy(acm_csr_t* a);
+
+/* acm_shard_plan: the row partition of a multi-GPU run ("contiguous, nnz-balanced row
+ * blocks"; the reference is single-device -- ACM-Geometric/layers.py:10-11, models.py:20-21 -- and uses several
+ * GPUs only as replicas, sh/run_all_settings.sh:2-24, so this has no reference counterpart).  Host code, no
+ * device access: `indptr_host` is the CSR row-pointer array of the GLOBAL operator in host memory
+ * (n_rows + 1 entries).  Writes bounds[0..world]: rank p owns rows [bounds[p], bounds[p+1]).  The cuts
+ * equalise the prefix sum of  nnz(row) + row_cost  (row_cost >= 0: the per-row work of the row-local
+ * kernels expressed in gathered edges; 0 = pure nnz balance); each cut is the row boundary nearest to
+ * p / world of the total, found by binary search, and cuts never cross (a row heavier than one share gets a
+ * block of its own).  Deterministic: every rank computes the same plan from the same indptr. */
+int acm_shard_plan(int64_t n_rows, const int64_t* indptr_host, int world, int64_t row_cost,
+                   int64_t* bounds_host);
 
 typedef struct {
     int64_t n_rows, n_cols, nnz;

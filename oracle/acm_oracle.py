@@ -256,6 +256,24 @@ def khop_low(adj_low_dense, hops):
     return acc
 
 
+def sgc_khop_forward(p, x, adj_low, adj_high, hops, return_att=False):
+    """The acmsgc branch (layers.py:86-92) with adj_low^hops applied as `hops` chained products,
+    A_low (A_low (... (X W_L))), instead of the dense power ACM-Pytorch/utils.py:631-637 materialises
+    (N^2 floats: 114 GB at arXiv-year size, so the reference cannot run this configuration).  Matrix
+    products associate, so this equals layer_forward(p, x, khop_low(adj_low_dense, hops), adj_high,
+    model_type="acmsgc") -- tests/test_oracle_golden.py checks that on the golden A_low^3.  adj_high stays
+    1-hop, as in the reference.  Works in any dtype (the full-size tests run it in float64)."""
+    mm = torch.sparse.mm if x.layout != torch.strided else torch.mm
+    h_low = mm(x, p["weight_low"])
+    for _ in range(hops):
+        h_low = torch.spmm(adj_low, h_low)
+    h_high = torch.spmm(adj_high, mm(x, p["weight_high"]))
+    h_mlp = mm(x, p["weight_mlp"])
+    att = attention(p, (h_low, h_high, h_mlp), False)
+    out = 3 * (att[:, 0:1] * h_low + att[:, 1:2] * h_high + att[:, 2:3] * h_mlp)
+    return (out, att) if return_att else out
+
+
 # --------------------------------------------------------------------------
 # CSR helpers used by tests / the "best effort" CPU baseline
 # --------------------------------------------------------------------------

@@ -151,7 +151,24 @@ class FakeLib:
 
     # ---- plumbing ---------------------------------------------------------
     def acm_version(self):
-        return 16
+        return 17
+
+    def acm_shard_plan(self, n_rows, indptr, world, row_cost, bounds):
+        """numpy restatement of the host routine: nearest row boundary to p / world of the cost prefix."""
+        ip = _vec(indptr, n_rows + 1, np.int64).astype(object)
+        out = _vec(bounds, world + 1, np.int64)
+        cost = [int(ip[r]) + int(row_cost) * r for r in range(n_rows + 1)]
+        out[0] = 0
+        for p in range(1, world):
+            target = cost[n_rows] * p // world
+            r = int(out[p - 1])
+            while r < n_rows and cost[r] < target:
+                r += 1
+            if r > out[p - 1] and target - cost[r - 1] < cost[r] - target:
+                r -= 1
+            out[p] = r
+        out[world] = n_rows
+        return 0
 
     # ---- deferred second phases (acm_reduce_list_t): results of a deferred call are poisoned with NaN until the
     # flush, so a consumer that reads them too early fails its test instead of passing by accident

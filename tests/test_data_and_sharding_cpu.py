@@ -61,9 +61,11 @@ def test_shard_plan_rows_of_a_and_a_transpose():
     adj, *_ = D.synthetic_dataset("tiny", seed=4, pad_to=4)
     low, deg = D.build_filters(adj)
     n = low.shape[0]
+    plan = DD.equal_rows_plan(n, 4)
+    assert plan.uniform and plan.n_gathered == n and plan.n_max == n // 4
     rows, rows_t = [], []
     for r in range(4):
-        lo, lt, dg, off = DD.shard_filter_arrays(low, deg, 4, r)
+        lo, lt, dg, off = DD.shard_filter_arrays(low, deg, plan, r)
         assert off == r * n // 4 and lo.shape == (n // 4, n) and lt.shape == (n // 4, n)
         assert np.array_equal(dg, deg[off:off + n // 4])
         rows.append(lo)
@@ -73,6 +75,83 @@ def test_shard_plan_rows_of_a_and_a_transpose():
         DD.shard_bounds(10, 4, 0)
     idx = np.array([0, 3, n // 4, n - 1])
     assert DD.local_index(idx, 4, 0, n).tolist() == [0, 3] and DD.local_index(idx, 4, 3, n).tolist() == [n // 4 - 1]
+    assert DD.local_index(idx, plan, 3).tolist() == [n // 4 - 1]
+
+
+def _powerlaw(n=24_000, e=480_000, seed=3):
+    from acm_gnn_amd import data as D
+    adj = D.chung_lu_graph(n, e, 6_000, seed=seed)
+    perm = D.degree_order(adj)
+    return adj, adj[perm][:, perm].tocsr()
+
+
+@pytest.mark.parametrize("world", [2, 4, 8])
+def test_work_balanced_shard_plan(world):
+    """acm_shard_plan (the real host routine of libacm_hip.so: no device needed) on a degree-ordered power-law graph,
+    the case where equal rows fail (rank 0 gets the hubs): pure nnz balance to 5 %, the row-cost variant balances
+    nnz + row_cost * rows, cuts are monotone, the numpy test double computes the same plan."""
+    import ctypes as C
+    import fake_lib
+    from acm_gnn_amd import data as D, distributed as DD
+    _, adj = _powerlaw()
+    low, _ = D.build_filters(adj)
+    n = low.shape[0]
+    eq = DD.equal_rows_plan(n - n % world, world)
+    ip_eq = low.indptr[: n - n % world + 1]
+    assert eq.imbalance(ip_eq)[0] > 1.5                                 # what round 1 shipped: >= 1.5x on rank 0
+    plan = DD.shard_plan(low.indptr, world, row_cost=0)
+    assert plan.world == world and plan.n_global == n and np.all(np.diff(plan.bounds) > 0)
+    nnz_ratio, _ = plan.imbalance(low.indptr)
+    assert nnz_ratio <= 1.05, nnz_ratio
+    plan_w = DD.shard_plan(low.indptr, world, row_cost=64)
+    assert plan_w.imbalance(low.indptr, 64)[1] <= 1.05
+    assert not plan.uniform and plan.n_gathered == world * plan.n_max
+    fake = fake_lib.FakeLib()
+    for rc in (0, 64):
+        ip = np.ascontiguousarray(low.indptr, dtype=np.int64)
+        out = np.zeros(world + 1, np.int64)
+        assert fake.acm_shard_plan(n, ip.ctypes.data_as(C.c_void_p), world, rc, out.ctypes.data_as(C.c_void_p)) == 0
+        assert np.array_equal(out, DD.shard_plan(low.indptr, world, rc).bounds)
+    # padded halo numbering: a bijection onto the used rows of the gathered table, monotone inside a block
+    ids = plan.padded_ids(np.arange(n))
+    assert len(np.unique(ids)) == n and ids.max() < plan.n_gathered
+    for r in range(world):
+        b, e = plan.rows(r)
+        assert np.array_equal(ids[b:e], r * plan.n_max + np.arange(e - b))
+    padded = plan.pad_rows(np.arange(n, dtype=np.float32)[:, None])
+    assert padded.shape == (plan.n_gathered, 1) and np.array_equal(padded[ids, 0], np.arange(n))
+
+
+def test_shard_plan_degenerate_inputs():
+    from acm_gnn_amd import distributed as DD
+    one_hub = np.array([0, 1000, 1001, 1002, 1003], dtype=np.int64)     # one row heavier than a share
+    plan = DD.shard_plan(one_hub, 4, row_cost=0)
+    assert plan.bounds[0] == 0 and plan.bounds[-1] == 4 and np.all(np.diff(plan.bounds) >= 0)
+    assert (0, 1) in [plan.rows(r) for r in range(4)]                   # the hub row has a block of its own
+    empty = DD.shard_plan(np.zeros(1, np.int64), 3, row_cost=5)
+    assert empty.bounds.tolist() == [0, 0, 0, 0]
+    assert DD.shard_plan(np.arange(9, dtype=np.int64), 1).bounds.tolist() == [0, 8]
+    with pytest.raises(RuntimeError):
+        DD.shard_plan(np.arange(1, 10, dtype=np.int64), 2)              # indptr[0] != 0
+
+
+def test_interleaved_degree_order_balances_equal_blocks():
+    """Dealing the degree ranking to the ranks like cards makes EQUAL contiguous blocks balanced in rows and nnz at
+    once (what bench.py does for --node-order degree on several GPUs)."""
+    from acm_gnn_amd import data as D, distributed as DD
+    _, adj = _powerlaw()
+    n = adj.shape[0]
+    for world in (2, 4, 8):
+        perm = DD.interleave_order(n, world)
+        assert sorted(perm.tolist()) == list(range(n))
+        a2 = adj[perm][:, perm].tocsr()
+        low, _ = D.build_filters(a2)
+        plan = DD.equal_rows_plan(n, world)
+        nnz_ratio, _ = plan.imbalance(low.indptr)
+        assert nnz_ratio <= 1.02, (world, nnz_ratio)
+        for r in range(world):                                          # every block is itself sorted by degree
+            b, e = plan.rows(r)
+            assert np.all(np.diff(np.diff(a2.indptr)[b:e]) <= 0)
 
 
 def _free_port():
@@ -101,12 +180,17 @@ def _worker(rank, world, port, cfg, ret):
         import torch.nn.functional as F
         from acm_gnn_amd import GCN, data as D, distributed as DD
         adj, x_np, y_np, (tr, _, _), _ = D.synthetic_dataset("tiny", seed=5, pad_to=world)
+        if cfg.get("plan") == "work":                 # hubs first: the case equal blocks cannot balance
+            adj, x_np, y_np, (tr, _, _) = D.permute_dataset(adj, x_np, y_np, (tr, tr, tr), D.degree_order(adj))
         low, deg = D.build_filters(adj)
         n = adj.shape[0]
-        ops = DD.make_sharded_operators(low, deg, "cpu", with_structure=bool(cfg["s"]))
-        assert ops.sharded and ops.n_local == n // world and ops.implicit == bool(cfg.get("implicit", 1))
+        # "rows": equal blocks; "work": the nnz-balanced plan of acm_shard_plan (blocks of different lengths: padded halo)
+        plan = DD.equal_rows_plan(n, world) if cfg.get("plan", "rows") == "rows" else DD.shard_plan(low.indptr, world, 8)
+        ops = DD.make_sharded_operators(low, deg, "cpu", with_structure=bool(cfg["s"]), plan=plan)
+        b, e = plan.rows(rank)
+        assert ops.sharded and ops.n_local == e - b and ops.implicit == bool(cfg.get("implicit", 1))
+        assert ops.low.n_cols == plan.n_gathered and ops.uniform == plan.uniform
         ops.hops = cfg.get("hops", 1)
-        b, e = DD.shard_bounds(n, world, rank)
         torch.manual_seed(0)
         pdrop = cfg.get("dropout", 0.0)
         full = GCN(7, 16, 2, 2, n, pdrop, cfg["model"], cfg["s"], variant=bool(cfg["variant"]), attn_layernorm=True)
@@ -115,7 +199,7 @@ def _worker(rank, world, port, cfg, ret):
             from acm_gnn_amd import functional as AF
             model.fused_dropout, model.dropout_state = True, AF.DropoutState("cpu", seed=7)
             if cfg.get("x_full"):
-                ops.x_full = torch.from_numpy(x_np)
+                ops.x_full = torch.from_numpy(x_np)       # honoured with equal blocks only
         sd = full.state_dict()
         for k in list(sd):
             if k.endswith(".struc_low"):
@@ -123,14 +207,14 @@ def _worker(rank, world, port, cfg, ret):
         model.load_state_dict(sd)
         x = torch.from_numpy(x_np[b:e])
         y = torch.from_numpy(y_np[b:e])
-        idx = torch.from_numpy(DD.local_index(tr, world, rank, n))
+        idx = torch.from_numpy(DD.local_index(tr, plan, rank))
         out = model(x, ops)
         loss = F.nll_loss(F.log_softmax(out, 1)[idx], y[idx], reduction="sum") / len(tr)
         loss.backward()
         tot = loss.detach().clone()
         dist.all_reduce(tot)
         grads = {k: p.grad.numpy().copy() for k, p in model.named_parameters() if p.grad is not None}
-        ret.put((rank, out.detach().numpy().copy(), float(tot), grads))    # numpy: pickled by value
+        ret.put((rank, out.detach().numpy().copy(), float(tot), grads, (b, e)))    # numpy: pickled by value
     finally:
         dist.destroy_process_group()
 
@@ -143,17 +227,28 @@ def _worker(rank, world, port, cfg, ret):
                                  dict(model="acmgcnp", s=1, variant=0, dropout=0.5, x_full=1),
                                  dict(model="acmgcn", s=0, variant=1, dropout=0.5, x_full=1),
                                  dict(model="acmsgc", s=0, variant=0, hops=3),
-                                 dict(model="acmsgc", s=0, variant=0, hops=2, implicit=0)],
+                                 dict(model="acmsgc", s=0, variant=0, hops=2, implicit=0),
+                                 dict(model="acmgcnp", s=1, variant=0, plan="work"),
+                                 dict(model="acmgcnp", s=1, variant=1, plan="work", implicit=0),
+                                 dict(model="acmgcnp", s=0, variant=0, dropout=0.5, x_full=1, plan="work"),
+                                 dict(model="acmgcnp", s=1, variant=1, world=4),
+                                 dict(model="acmgcnp", s=1, variant=0, world=4, plan="work", dropout=0.5),
+                                 dict(model="acmsgc", s=0, variant=0, hops=3, world=4, plan="work"),
+                                 dict(model="acmgcnpp", s=0, variant=0, dropout=0.5),
+                                 dict(model="acmgcnpp", s=1, variant=1, world=4, plan="work")],
                          ids=["agg+literal", "struct-acmii", "acmii", "struct-agg", "struct-agg-explicit",
                               "struct-acmii-explicit", "dropout", "dropout-xfull-struct", "dropout-xfull-acmii",
-                              "sgc-3hop", "sgc-2hop-explicit"])
-def test_two_rank_row_shard_equals_single_process(cfg, monkeypatch):
-    """world_size = 2 over gloo: the sharded forward/backward (halo all-gathers + parameter-gradient
-    all-reduce issued by functional.AcmConvFunction) must reproduce the 1-process result."""
+                              "sgc-3hop", "sgc-2hop-explicit", "work-plan-struct-agg", "work-plan-acmii-explicit",
+                              "work-plan-dropout", "4-ranks-struct-acmii", "4-ranks-work-plan-dropout",
+                              "4-ranks-work-plan-sgc-3hop", "acmgcnpp-dropout", "4-ranks-work-plan-acmgcnpp"])
+def test_row_shard_equals_single_process(cfg, monkeypatch):
+    """world_size = 2 and 4 over gloo: the sharded forward/backward (halo all-gathers + parameter-gradient
+    all-reduce issued by functional.AcmConvFunction) must reproduce the 1-process result -- with equal blocks and
+    with the work-balanced plan (blocks of different lengths, padded halo numbering)."""
     import torch.multiprocessing as mp
     import torch.nn.functional as F
     import fake_lib
-    world, port = 2, _free_port()
+    world, port = cfg.get("world", 2), _free_port()
     ctx = mp.get_context("spawn")
     ret = ctx.Queue()
     procs = [ctx.Process(target=_worker, args=(r, world, port, cfg, ret)) for r in range(world)]
@@ -180,10 +275,14 @@ def test_two_rank_row_shard_equals_single_process(cfg, monkeypatch):
     monkeypatch.setenv("ACM_IMPLICIT", "0")                   # the single-process reference keeps explicit values
     from acm_gnn_amd import GCN, data as D, distributed as DD
     adj, x_np, y_np, (tr, _, _), _ = D.synthetic_dataset("tiny", seed=5, pad_to=world)
+    if cfg.get("plan") == "work":
+        adj, x_np, y_np, (tr, _, _) = D.permute_dataset(adj, x_np, y_np, (tr, tr, tr), D.degree_order(adj))
     low, deg = D.build_filters(adj)
     n = adj.shape[0]
     ops = DD.make_sharded_operators(low, deg, "cpu", with_structure=bool(cfg["s"]))
     assert not ops.sharded and not ops.implicit
+    if cfg.get("plan") == "work":
+        assert len({r[4][1] - r[4][0] for r in results}) > 1               # the blocks really differ in length
     ops.hops = cfg.get("hops", 1)
     torch.manual_seed(0)
     full = GCN(7, 16, 2, 2, n, cfg.get("dropout", 0.0), cfg["model"], cfg["s"], variant=bool(cfg["variant"]),
@@ -198,11 +297,10 @@ def test_two_rank_row_shard_equals_single_process(cfg, monkeypatch):
     got = torch.from_numpy(np.concatenate([r[1] for r in results]))
     torch.testing.assert_close(got, out.detach(), rtol=1e-5, atol=1e-6)
     assert abs(results[0][2] - loss.item()) < 1e-6
-    half = n // world
     for k, p in full.named_parameters():
         if p.grad is None:
             continue
-        for rank, _, _, grads in results:
-            ref = p.grad[rank * half:(rank + 1) * half] if k.endswith(".struc_low") else p.grad
+        for rank, _, _, grads, (b, e) in results:
+            ref = p.grad[b:e] if k.endswith(".struc_low") else p.grad
             torch.testing.assert_close(torch.from_numpy(grads[k]), ref, rtol=1e-4, atol=1e-6,
                                        msg=lambda m, k=k: f"{k}: {m}")

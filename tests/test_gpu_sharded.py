@@ -38,11 +38,14 @@ def _worker(rank, world, port, cfg, ret):
     try:
         from acm_gnn_amd import data as D, distributed as DD, functional as AF
         adj, x_np, y_np, (tr, _, _), _ = D.synthetic_dataset("tiny", seed=5, pad_to=world)
+        if cfg.get("plan") == "work":                 # hubs first + the work-balanced plan: blocks of different lengths
+            adj, x_np, y_np, (tr, _, _) = D.permute_dataset(adj, x_np, y_np, (tr, tr, tr), D.degree_order(adj))
         low, deg = D.build_filters(adj)
         n = adj.shape[0]
-        ops = DD.make_sharded_operators(low, deg, DEV, with_structure=bool(cfg["s"]))
-        assert ops.sharded
-        b, e = DD.shard_bounds(n, world, rank)
+        plan = DD.shard_plan(low.indptr, world, 8) if cfg.get("plan") == "work" else DD.equal_rows_plan(n, world)
+        ops = DD.make_sharded_operators(low, deg, DEV, with_structure=bool(cfg["s"]), plan=plan)
+        assert ops.sharded and ops.uniform == (cfg.get("plan") != "work")
+        b, e = plan.rows(rank)
         full, model = _build(cfg, e - b, n, DEV)
         sd = full.state_dict()
         for k in list(sd):
@@ -55,21 +58,24 @@ def _worker(rank, world, port, cfg, ret):
             ops.x_full = torch.from_numpy(x_np).to(DEV)
         x = torch.from_numpy(x_np[b:e]).to(DEV)
         y = torch.from_numpy(y_np[b:e]).to(DEV)
-        idx = torch.from_numpy(DD.local_index(tr, world, rank, n)).to(DEV)
+        idx = torch.from_numpy(DD.local_index(tr, plan, rank)).to(DEV)
         out = model(x, ops)
         loss = F.nll_loss(F.log_softmax(out, 1)[idx], y[idx], reduction="sum") / len(tr)
         loss.backward()
         torch.cuda.synchronize()
         grads = {k: p.grad.cpu().numpy().copy() for k, p in model.named_parameters() if p.grad is not None}
-        ret.put((rank, out.detach().cpu().numpy().copy(), grads))
+        ret.put((rank, out.detach().cpu().numpy().copy(), grads, (b, e)))
     finally:
         dist.destroy_process_group()
 
 
 @pytest.mark.parametrize("cfg", [dict(model="acmgcnp", s=0, variant=0, dropout=0.0),
                                  dict(model="acmgcnp", s=1, variant=0, dropout=0.3),
-                                 dict(model="acmgcn", s=0, variant=1, dropout=0.0)],
-                         ids=["agg", "struct-dropout", "acmii"])
+                                 dict(model="acmgcn", s=0, variant=1, dropout=0.0),
+                                 dict(model="acmgcnp", s=1, variant=1, dropout=0.3, plan="work"),
+                                 dict(model="acmgcnp", s=0, variant=0, dropout=0.3, plan="work"),
+                                 dict(model="acmgcnpp", s=0, variant=0, dropout=0.3)],
+                         ids=["agg", "struct-dropout", "acmii", "work-plan-struct-acmii", "work-plan-agg", "acmgcnpp"])
 def test_two_ranks_on_one_gpu_equal_single_process(cfg):
     import queue
     import time
@@ -95,6 +101,8 @@ def test_two_ranks_on_one_gpu_equal_single_process(cfg):
     results.sort(key=lambda t: t[0])
     from acm_gnn_amd import data as D, distributed as DD, functional as AF
     adj, x_np, y_np, (tr, _, _), _ = D.synthetic_dataset("tiny", seed=5, pad_to=world)
+    if cfg.get("plan") == "work":
+        adj, x_np, y_np, (tr, _, _) = D.permute_dataset(adj, x_np, y_np, (tr, tr, tr), D.degree_order(adj))
     low, deg = D.build_filters(adj)
     n = adj.shape[0]
     ops = DD.make_sharded_operators(low, deg, DEV, with_structure=bool(cfg["s"]))
@@ -108,11 +116,10 @@ def test_two_ranks_on_one_gpu_equal_single_process(cfg):
     loss.backward()
     got = np.concatenate([r[1] for r in results])
     np.testing.assert_allclose(got, out.detach().cpu().numpy(), rtol=1e-4, atol=1e-5)
-    half = n // world
     for k, p in full.named_parameters():
         if p.grad is None:
             continue
-        for rank, _, grads in results:
-            ref = p.grad[rank * half:(rank + 1) * half] if k.endswith(".struc_low") else p.grad
+        for rank, _, grads, (b, e) in results:
+            ref = p.grad[b:e] if k.endswith(".struc_low") else p.grad
             np.testing.assert_allclose(grads[k], ref.cpu().numpy(), rtol=1e-3, atol=1e-5 * max(1.0, float(ref.abs().max())),
                                        err_msg=k)

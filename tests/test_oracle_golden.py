@@ -86,6 +86,25 @@ def test_filters_linkx_dialect():
                                g["feat_rownorm"], rtol=1e-12)
 
 
+def test_chained_khop_equals_the_materialised_power():
+    """oracle.sgc_khop_forward (what the full-size config-5 tests compare against) == the acmsgc layer fed the dense
+    A_low^3 of the reference's k-hop construction (ACM-Pytorch/utils.py:631-637, golden adj_low_pow3_dense)."""
+    g = load_npz(os.path.join(GOLDEN, "graph_pytorch.npz"))
+    low = torch.from_numpy(g["adj_low_dense"]).double()
+    low3 = O.khop_low(low, 3)                      # the reference's construction, here in float64
+    np.testing.assert_allclose(low3.numpy(), g["adj_low_pow3_dense"], rtol=1e-5, atol=1e-8)   # its fp32 golden
+    n = low.shape[0]
+    high = (torch.eye(n, dtype=torch.float64) - low).to_sparse()
+    gen = torch.Generator().manual_seed(5)
+    p = {k: v.double() for k, v in O.init_params(9, 4, n, 0, gen).items()}
+    x = torch.randn(n, 9, generator=gen, dtype=torch.float64)
+    ref = O.layer_forward(p, x, low3, high, model_type="acmsgc")
+    got = O.sgc_khop_forward(p, x, low.to_sparse_csr(), high, 3)
+    np.testing.assert_allclose(got.numpy(), ref.numpy(), rtol=1e-10, atol=1e-12)
+    got_sx = O.sgc_khop_forward(p, x.to_sparse_csr(), low.to_sparse_csr(), high, 3)      # CSR features (Penn94)
+    np.testing.assert_allclose(got_sx.numpy(), ref.numpy(), rtol=1e-10, atol=1e-12)
+
+
 def test_filters_small_dialect_and_khop():
     g = load_npz(os.path.join(GOLDEN, "graph_pytorch.npz"))
     a_un = csr_to_coo_tensor(g, "adj_un").to_dense()
