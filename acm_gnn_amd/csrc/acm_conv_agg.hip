@@ -604,6 +604,11 @@ extern "C" int acm_conv_agg_fwd(const acm_csr_t* a, const acm_conv_agg_fwd_t* p,
                     ((uintptr_t)p->agg) % 16 == 0 && (p->ld_agg * 4) % 16 == 0 && p->ld_agg >= p->f_pad &&
                     ((uintptr_t)p->att) % 16 == 0, ACM_EINVAL,
                 "acm_conv_agg_fwd: xg / agg rows must be 16-byte aligned and f_pad long");
+    if (p->n_channels == 4) {       // agg_fwd_row indexes ps / ss with 32-bit element offsets
+        const int64_t ld_max = p->ld_ps > p->ld_ss ? p->ld_ps : p->ld_ss;
+        ACM_REQUIRE(a->n_rows * ld_max < (int64_t)INT32_MAX, ACM_EUNSUPPORTED,
+                    "acm_conv_agg_fwd: too many rows for 32-bit offsets into ps / ss");
+    }
     if (a->n_rows == 0) return ACM_OK;
     hipStream_t s = (hipStream_t)stream;
     // (0) fused form: gather + epilogue in one kernel (long rows included)

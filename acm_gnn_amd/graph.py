@@ -477,14 +477,47 @@ def _key(t):
     return ("dense", t.data_ptr(), tuple(t.shape), tuple(t.stride()), str(t.device))
 
 
+def _source_state(t):
+    """(weak reference, version counter) of a source tensor: the cache entry is valid only while the tensor it was
+    built from is alive (its address cannot have been handed to another tensor) and unmodified (in-place edits bump
+    the version counter, which views / detach() / the values of a sparse tensor share)."""
+    if t is None:
+        return None
+    payload = t._values() if t.layout == torch.sparse_coo else (t.values() if t.layout == torch.sparse_csr else t)
+    return weakref.ref(t), payload._version
+
+
+def _source_valid(state, t):
+    if state is None:
+        return t is None
+    if t is None:
+        return False
+    ref, version = state
+    src = ref()
+    if src is None:
+        return False
+    payload = t._values() if t.layout == torch.sparse_coo else (t.values() if t.layout == torch.sparse_csr else t)
+    # `t` may be another wrapper of the live source's storage (same key => same address, shape, nnz)
+    return payload._version == version
+
+
 def operators_for(adj_low, adj_high=None, adj_low_unnormalized=None, verify=True):
-    """Convert the reference's adjacency tensors once; cached by storage identity."""
+    """Convert the reference's adjacency tensors once; cached by storage identity.  A hit is honoured only if every
+    tensor the entry was built from is still alive and has not been written to since (otherwise a freed adjacency's
+    address reused by a new one of the same shape / nnz, or an in-place re-normalisation, would silently get the
+    stale operators)."""
     if isinstance(adj_low, FilterOperators):
         return adj_low
-    key = (_key(adj_low), _key(adj_high), _key(adj_low_unnormalized))
+    sources = (adj_low, adj_high, adj_low_unnormalized)
+    key = tuple(_key(t) for t in sources)
     hit = _CACHE.get(key)
     if hit is not None:
-        return hit
+        ops, states = hit
+        if all(_source_valid(st, t) for st, t in zip(states, sources)):
+            return ops
+        del _CACHE[key]
+    for k in [k for k, (_, states) in _CACHE.items() if any(st is not None and st[0]() is None for st in states)]:
+        del _CACHE[k]                                   # entries whose source tensors died
     _require_cuda(adj_low, "adj_low")
     low = CsrGraph.from_torch(adj_low)
     fused_ok = (not verify) or verify_high_is_identity_minus_low(low, adj_high)
@@ -507,7 +540,7 @@ def operators_for(adj_low, adj_high=None, adj_low_unnormalized=None, verify=True
             raise ValueError("adj_high is required when it cannot be derived from adj_low")
     if len(_CACHE) >= _CACHE_LIMIT:
         _CACHE.pop(next(iter(_CACHE)))
-    _CACHE[key] = ops
+    _CACHE[key] = (ops, tuple(_source_state(t) for t in sources))
     return ops
 
 

@@ -38,6 +38,29 @@ class _FusedAdamBase(torch.optim.Optimizer):
     def load_state_dict(self, state_dict):
         super().load_state_dict(state_dict)
         self._tables = {}                     # the cached pointer tables refer to the replaced state tensors
+        for p, st in self.state.items():
+            self._normalize_state(p, st)
+
+    @staticmethod
+    def _normalize_state(p, st):
+        """The kernel dereferences these on the device: after loading a torch.optim.Adam / AdamW checkpoint (`step` is
+        a CPU tensor or a Python number there unless capturable=True), or one mapped to the CPU, move `step` to a
+        0-dim fp32 tensor on the parameter's device and the moments to contiguous fp32 on it."""
+        if not st:
+            return
+        step = st.get("step", 0.0)
+        if not torch.is_tensor(step):
+            st["step"] = torch.tensor(float(step), dtype=torch.float32, device=p.device)
+        elif step.device != p.device or step.dtype != torch.float32 or step.dim() != 0:
+            st["step"] = step.detach().to(device=p.device, dtype=torch.float32).reshape(()).clone()
+        for key in ("exp_avg", "exp_avg_sq"):
+            v = st.get(key)
+            if v is None:
+                st[key] = torch.zeros_like(p, memory_format=torch.preserve_format)
+            elif v.device != p.device or v.dtype != torch.float32 or not v.is_contiguous() or v.shape != p.shape:
+                if v.numel() != p.numel():
+                    raise RuntimeError(f"FusedAdam: state '{key}' has {v.numel()} elements, the parameter {p.numel()}")
+                st[key] = v.detach().to(device=p.device, dtype=torch.float32).reshape(p.shape).contiguous()
 
     @torch.no_grad()
     def step(self, closure=None):
@@ -66,6 +89,8 @@ class _FusedAdamBase(torch.optim.Optimizer):
                         st["step"] = torch.zeros((), dtype=torch.float32, device=p.device)
                         st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
                         st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                    else:
+                        self._normalize_state(p, st)
                     e.param = p.data_ptr()
                     e.exp_avg, e.exp_avg_sq, e.step = st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr(), st["step"].data_ptr()
                     e.numel = p.numel()

@@ -97,7 +97,41 @@ class TrainStep:
         return loss                 # never hand out the autograd graph: a live AccumulateGrad node pins its
                                     # stream and breaks a later graph capture
 
+    def _snapshot(self):
+        """Values of everything a training step changes: parameters / buffers, optimizer state, dropout counter."""
+        model_state = [(t, t.detach().clone()) for t in self.model.state_dict().values() if torch.is_tensor(t)]
+        opt_state = [(p, {k: (v.detach().clone() if torch.is_tensor(v) else v) for k, v in st.items()})
+                     for p, st in self.opt.state.items()]
+        ds = getattr(self.model, "dropout_state", None)
+        return model_state, opt_state, (ds.step.clone() if ds is not None else None)
+
+    def _restore(self, snap):
+        """Put the snapshot back IN PLACE (the captured graph and the optimizer's pointer tables keep their addresses);
+        optimizer state created since the snapshot is zeroed -- what a fresh optimizer starts from."""
+        model_state, opt_state, drop_step = snap
+        with torch.no_grad():
+            for t, v in model_state:
+                t.copy_(v)
+            had = {id(p): st for p, st in opt_state}
+            for p, st in self.opt.state.items():
+                old = had.get(id(p))
+                for k, v in st.items():
+                    if not torch.is_tensor(v):
+                        if old is not None and k in old:
+                            st[k] = old[k]
+                        continue
+                    if old is not None and k in old:
+                        v.copy_(old[k])
+                    else:
+                        v.zero_()
+            if drop_step is not None:
+                self.model.dropout_state.step.copy_(drop_step)
+
     def _capture(self):
+        # The warm-up runs real steps (lazy handles, allocator pools, optimizer state) -- on a snapshot: the model,
+        # the optimizer moments / step counts and the dropout counter are put back afterwards, so a captured
+        # TrainStep starts from exactly the state an eager one starts from (fit(epochs=N) trains N steps, not N + 3).
+        snap = self._snapshot()
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):           # warm-up off the capture: lazy handles, allocator pools
@@ -105,6 +139,7 @@ class TrainStep:
                 self._eager()
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
+        self._restore(snap)
         self.graph = torch.cuda.CUDAGraph()
         self.model.train()
         self.opt.zero_grad(set_to_none=True)

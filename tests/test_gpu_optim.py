@@ -89,3 +89,37 @@ def test_adam_entry_point_rejects_bad_arguments():
     bad = _lib.AdamConfig(0.01, 1.5, 0.999, 1e-8, 0.0, 1, None, None)
     assert lib.acm_adam_step(0, None, C.byref(bad), None) == 1
     assert lib.acm_adam_step(0, None, C.byref(cfg), None) == 0
+
+
+def test_load_torch_adam_checkpoint_and_step_on_device():
+    """A torch.optim.Adam state_dict (CPU `step` tensors) and one mapped to the CPU load into FusedAdam and step on the
+    GPU with the same result as torch continuing from the same state."""
+    from acm_gnn_amd import FusedAdam
+    g = torch.Generator().manual_seed(0)
+    shapes = [(7, 64), (64, 1), (3, 3), (5000, 3)]
+    base = [torch.randn(*s, generator=g) for s in shapes]
+    grads = [torch.randn(*s, generator=g) for s in shapes]
+    ref_p = [torch.nn.Parameter(t.clone().to(DEV)) for t in base]
+    ref = torch.optim.Adam(ref_p, lr=0.01, weight_decay=5e-4, foreach=False)
+    for p, gr in zip(ref_p, grads):
+        p.grad = gr.to(DEV)
+    ref.step()
+    sd = ref.state_dict()
+    assert sd["state"][0]["step"].device.type == "cpu"               # what the advisor's finding is about
+    sd_cpu = {"state": {k: {kk: vv.cpu() for kk, vv in v.items()} for k, v in sd["state"].items()},
+              "param_groups": sd["param_groups"]}
+    for which in (sd, sd_cpu):
+        mine_p = [torch.nn.Parameter(p.detach().clone()) for p in ref_p]
+        mine = FusedAdam(mine_p, lr=0.01, weight_decay=5e-4)
+        mine.load_state_dict(which)
+        cont_p = [torch.nn.Parameter(p.detach().clone()) for p in ref_p]
+        cont = torch.optim.Adam(cont_p, lr=0.01, weight_decay=5e-4, foreach=False)
+        cont.load_state_dict(sd)
+        for p, q, gr in zip(mine_p, cont_p, grads):
+            p.grad, q.grad = (2 * gr).to(DEV), (2 * gr).to(DEV)
+        mine.step()
+        cont.step()
+        torch.cuda.synchronize()
+        for p, q in zip(mine_p, cont_p):
+            torch.testing.assert_close(p.detach(), q.detach(), rtol=3e-6, atol=3e-7)
+        assert all(st["step"].is_cuda and float(st["step"]) == 2.0 for st in mine.state.values())

@@ -169,6 +169,69 @@ def test_operator_cache_and_filter_verification(monkeypatch):
     assert g2.general and g2.un is not None
 
 
+def test_operator_cache_rejects_stale_and_modified_sources(monkeypatch):
+    """A cache hit needs the tensors the entry was built from to be alive and unmodified: a freed adjacency whose
+    address the allocator hands to a new one of the same shape / nnz, or an in-place re-normalisation, must rebuild."""
+    import gc
+    fake_lib.install(monkeypatch)
+    from acm_gnn_amd import graph
+    low, high, un, _ = graph_tensors("geometric")
+    a = graph.operators_for(low, high, None)
+    assert graph.operators_for(low, high, None) is a
+    assert graph.operators_for(low.detach(), high, None) is a              # another wrapper of the same live storage
+    low._values().mul_(1.0)                                                # in-place write: version counter moves
+    b = graph.operators_for(low, high, None)
+    assert b is not a and graph.operators_for(low, high, None) is b
+    # a dead source: simulate address reuse by keeping the key and killing the tensor the entry refers to
+    key = next(iter(graph._CACHE))
+    ops, states = graph._CACHE[key]
+    tmp = low.clone()
+    graph._CACHE[key] = (ops, (graph._source_state(tmp),) + tuple(states[1:]))
+    del tmp
+    gc.collect()
+    c = graph.operators_for(low, high, None)
+    assert c is not b
+    assert all(st is None or st[0]() is not None for _, sts in graph._CACHE.values() for st in sts)
+
+
+def test_captured_train_step_starts_from_the_eager_state(monkeypatch):
+    """TrainStep's capture warm-up runs real optimizer steps; they must leave no trace (parameters, Adam moments and
+    step counts, dropout counter).  Exercised on the host with the capture itself stubbed out."""
+    fake_lib.install(monkeypatch)
+    from acm_gnn_amd import GCN, FusedAdamW, train as T
+    from acm_gnn_amd import functional as AF
+    low, high, un, g = graph_tensors("geometric")
+    n = low.shape[0]
+    torch.manual_seed(0)
+    model = GCN(12, 16, 3, 2, n, 0.5, "acmgcnpp", 0, init_layers_X=2)      # with BatchNorm buffers in mlpX
+    opt = FusedAdamW(model.parameters(), lr=0.05)
+    x, y = torch.randn(n, 12), torch.randint(0, 3, (n,))
+    w = T.row_weights(torch.arange(0, n, 2), n)
+    step = T.TrainStep(model, opt, x, low, y, w, high, None, use_graph=False, fused_dropout=True)
+    step()                                                                  # one real step: non-trivial Adam state
+    before = {k: v.clone() for k, v in model.state_dict().items()}
+    opt_before = {id(p): {k: v.clone() for k, v in st.items()} for p, st in opt.state.items()}
+    drop_before = int(model.dropout_state.step.item())
+    snap = step._snapshot()
+    for _ in range(3):
+        step._eager()
+    assert any(not torch.equal(before[k], v) for k, v in model.state_dict().items())
+    step._restore(snap)
+    for k, v in model.state_dict().items():
+        assert torch.equal(before[k], v), k
+    for p, st in opt.state.items():
+        for k, v in st.items():
+            assert torch.equal(opt_before[id(p)][k], v), k
+    assert int(model.dropout_state.step.item()) == drop_before
+    # fresh optimizer: state created by the warm-up is zeroed in place
+    opt2 = FusedAdamW(model.parameters(), lr=0.05)
+    step2 = T.TrainStep(model, opt2, x, low, y, w, high, None, use_graph=False, fused_dropout=True)
+    snap2 = step2._snapshot()
+    step2._eager()
+    step2._restore(snap2)
+    assert all(float(v.abs().sum()) == 0.0 for st in opt2.state.values() for v in st.values())
+
+
 def test_structure_info_with_acmgcn_is_an_error(monkeypatch):
     """Reference quirk Q3: att_vec is 4x4 but acmgcn mixes 3 channels -> RuntimeError there too."""
     fake_lib.install(monkeypatch)

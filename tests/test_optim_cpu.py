@@ -55,6 +55,33 @@ def test_trajectory_equals_torch_optim(decoupled, wd, monkeypatch):
         np.testing.assert_allclose(p.detach().numpy(), q.detach().numpy(), rtol=3e-6, atol=3e-7)
 
 
+def test_state_loaded_from_a_torch_checkpoint_is_made_kernel_ready(monkeypatch):
+    """torch.optim.Adam keeps `step` as a CPU tensor (a Python number in old checkpoints) and a checkpoint may carry
+    fp64 / transposed moments: load_state_dict must hand the kernel 0-dim fp32 `step` tensors on the parameter's device
+    and contiguous fp32 moments (on a GPU a host `step` pointer would fault)."""
+    fake_lib.install(monkeypatch)
+    from acm_gnn_amd import FusedAdam
+    ps = [torch.nn.Parameter(t.clone()) for t in _params(3)[:3]]
+    ref = torch.optim.Adam(ps, lr=0.01, foreach=False)
+    for p in ps:
+        p.grad = torch.ones_like(p)
+    ref.step()
+    sd = ref.state_dict()
+    sd["state"][0]["step"] = 1                                  # legacy: Python number
+    sd["state"][1]["exp_avg"] = sd["state"][1]["exp_avg"].double()
+    sd["state"][2]["step"] = sd["state"][2]["step"].reshape(1)
+    opt = FusedAdam(ps, lr=0.01)
+    opt.load_state_dict(sd)
+    for p in ps:
+        st = opt.state[p]
+        assert st["step"].dim() == 0 and st["step"].dtype == torch.float32 and st["step"].device == p.device
+        assert float(st["step"]) == 1.0
+        for k in ("exp_avg", "exp_avg_sq"):
+            assert st[k].dtype == torch.float32 and st[k].is_contiguous() and st[k].shape == p.shape
+    opt.step()
+    assert all(float(opt.state[p]["step"]) == 2.0 for p in ps)
+
+
 def test_argument_validation(monkeypatch):
     fake_lib.install(monkeypatch)
     from acm_gnn_amd import FusedAdam, FusedAdamW
