@@ -35,6 +35,10 @@ template <>
 struct Owns<LayPair32> {
     static __device__ __forceinline__ bool lane_stores(const LayPair32& l) { return l.lane < 32; }
 };
+template <int NB>
+struct Owns<LayVec16<NB>> {
+    static __device__ __forceinline__ bool lane_stores(const LayVec16<NB>& l) { return l.lane < 16; }
+};
 
 struct EpiPlain {
     struct Args {
@@ -407,6 +411,122 @@ __global__ __launch_bounds__(256) void spmm_pair_kernel(CsrView csr, GatherSrc g
     }
 }
 
+// ------------------------------------------------------------------ wide gather, vector form
+// Four neighbours per load instruction: a 16-lane group (one DPP row) fetches one 64-column block of one neighbour's
+// row with a dwordx4 per lane (256 B per group, 1 KB per wave instruction -- the dword-per-lane form above moves 256 B
+// per instruction), the four groups of the wave walk four consecutive neighbours.  Column ids are loaded TRANSPOSED
+// (lane (q, m) holds neighbour 4 m + q of the 64-id batch) so that step u needs lane u of every group: one
+// `v_mov_b32_dpp row_newbcast:u` per step, no readlane / select chain and no LDS crossbar.  UNR steps x NG channels x NB
+// blocks of loads are in flight per wave (8 KB at NG = 2), the four groups' partial sums meet at the end through
+// v_permlane16/32_swap (fixed order), and the epilogue runs in LayVec16 (lane m owns columns 4 m .. 4 m + 3 of every
+// block).  Needs 16-byte aligned rows (F % 4 == 0, ld % 4 == 0); row offsets are 32-bit byte offsets (table < 4 GB).
+// lane u of each 16-lane row -> every lane of that row; u is a constant after unrolling, so the switch folds
+__device__ __forceinline__ int acm_row_bcast(int v, int u) {
+#define ACM_BC(U) case U: return __builtin_amdgcn_update_dpp(0, v, 0x150 + U, 0xf, 0xf, false)
+    switch (u & 15) {
+        ACM_BC(0); ACM_BC(1); ACM_BC(2); ACM_BC(3); ACM_BC(4); ACM_BC(5); ACM_BC(6); ACM_BC(7);
+        ACM_BC(8); ACM_BC(9); ACM_BC(10); ACM_BC(11); ACM_BC(12); ACM_BC(13); ACM_BC(14);
+        default: return __builtin_amdgcn_update_dpp(0, v, 0x15F, 0xf, 0xf, false);
+    }
+#undef ACM_BC
+}
+
+template <int NG, int NB, int UNR, int BLK>
+__device__ __forceinline__ void gather_vec_block(const GatherSrc& g, const unsigned (&ldb)[3], unsigned lane_off, bool col_ok,
+                                                 int my_j, float my_a, float (&acc)[NG][4 * NB]) {
+    float4 z[UNR][NG][NB];
+    float a[UNR];
+#pragma unroll
+    for (int uu = 0; uu < UNR; ++uu) {
+        const unsigned j = (unsigned)acm_row_bcast(my_j, BLK * UNR + uu);
+        a[uu] = __int_as_float(acm_row_bcast(__float_as_int(my_a), BLK * UNR + uu));
+#pragma unroll
+        for (int c = 0; c < NG; ++c) {
+            const char* rp = reinterpret_cast<const char*>(g.p[c]) + (size_t)(j * ldb[c] + lane_off);
+#pragma unroll
+            for (int b = 0; b < NB; ++b) z[uu][c][b] = *reinterpret_cast<const float4*>(rp + 256 * b);
+        }
+    }
+#pragma unroll
+    for (int uu = 0; uu < UNR; ++uu) {
+        const float av = col_ok ? a[uu] : 0.f;
+#pragma unroll
+        for (int c = 0; c < NG; ++c)
+#pragma unroll
+            for (int b = 0; b < NB; ++b) {
+                acc[c][4 * b + 0] = fmaf(av, z[uu][c][b].x, acc[c][4 * b + 0]);
+                acc[c][4 * b + 1] = fmaf(av, z[uu][c][b].y, acc[c][4 * b + 1]);
+                acc[c][4 * b + 2] = fmaf(av, z[uu][c][b].z, acc[c][4 * b + 2]);
+                acc[c][4 * b + 3] = fmaf(av, z[uu][c][b].w, acc[c][4 * b + 3]);
+            }
+    }
+}
+
+template <int NG, int NB, class Epi>
+__global__ __launch_bounds__(256) void spmm_vec_kernel(CsrView csr, GatherSrc g, int F, typename Epi::Args ea,
+                                                       float* __restrict__ partial) {
+    constexpr int UNR = (NG * NB >= 4) ? 2 : 4;          // 8 (NG * NB <= 2), 12 (NG = 3) or NG * NB * 2 loads in flight
+    const int lane = threadIdx.x & 63, m = lane & 15, q = lane >> 4;
+    const int w = acm_uniform(blockIdx.x * 4 + (threadIdx.x >> 6));
+    if (w >= csr.n_items) return;
+    const AcmItem it = csr.items[w];
+    const int row = acm_uniform(it.row), begin = acm_uniform(it.begin), end = acm_uniform(it.end),
+              slot = acm_uniform(it.slot);
+    float acc[NG][4 * NB];
+#pragma unroll
+    for (int c = 0; c < NG; ++c)
+#pragma unroll
+        for (int i = 0; i < 4 * NB; ++i) acc[c][i] = 0.f;
+    // a lane whose columns lie beyond F (F < 64 NB) reads the row's first bytes and contributes nothing
+    const bool col_ok = 4 * m < F;                       // block b > 0: checked per column in the epilogue (F % 4 == 0)
+    const unsigned lane_off = col_ok ? 16u * m : 0u;
+    unsigned ldb[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) ldb[c] = c < NG ? (unsigned)g.ld[c] * 4u : 0u;
+    const int pos = 4 * m + q;                           // transposed id layout (see above)
+    for (int base = begin; base < end; base += 64) {
+        const int cnt = min(64, end - base);             // wave-uniform
+        int my_j = 0;
+        float my_a = 0.f;
+        if (pos < cnt) {
+            my_j = csr.indices[base + pos];
+            my_a = csr.vals ? csr.vals[base + pos] : 1.f;
+        }
+        const int steps = (cnt + 3) >> 2;
+        // the step index must be a compile-time constant for the DPP broadcast: 16 / UNR unrolled blocks, uniform exits
+#define ACM_VEC_BLK(B)                                                                                          \
+        if (B * UNR < steps) gather_vec_block<NG, NB, UNR, B>(g, ldb, lane_off, col_ok, my_j, my_a, acc)
+        ACM_VEC_BLK(0);
+        ACM_VEC_BLK(1);
+        ACM_VEC_BLK(2);
+        ACM_VEC_BLK(3);
+        if (UNR == 2) {
+            ACM_VEC_BLK(4);
+            ACM_VEC_BLK(5);
+            ACM_VEC_BLK(6);
+            ACM_VEC_BLK(7);
+        }
+#undef ACM_VEC_BLK
+    }
+#pragma unroll
+    for (int c = 0; c < NG; ++c)
+#pragma unroll
+        for (int i = 0; i < 4 * NB; ++i) acc[c][i] = acm_cross_row_sum(acc[c][i]);
+    if (slot < 0) {
+        LayVec16<NB> lay{lane};
+        Epi::template apply<LayVec16<NB>, NG>(ea, row, lay, F, acc);
+    } else if (q == 0) {
+        float* ps = partial + (long)slot * (NG * F);
+#pragma unroll
+        for (int c = 0; c < NG; ++c)
+#pragma unroll
+            for (int i = 0; i < 4 * NB; ++i) {
+                const int col = 64 * (i >> 2) + 4 * m + (i & 3);
+                if (col < F) ps[c * F + col] = acc[c][i];
+            }
+    }
+}
+
 // One wave per long row: add its partial slots in slot order, then the epilogue.
 template <int NREG, int NG, class Epi>
 __global__ __launch_bounds__(256) void spmm_fixup_kernel(CsrView csr, int F, typename Epi::Args ea,
@@ -695,7 +815,20 @@ int launch_gather(const acm_csr* a, const GatherSrc& g, int F, const typename Ep
         // 5-10 % slower, so it is not used.
         bool pair32 = !bf16 && F > 32 && F <= 64 && F % 2 == 0 && (size_t)a->n_cols * F * NG * sizeof(float) <= (8u << 20);
         for (int c = 0; c < NG && pair32; ++c) pair32 = ((uintptr_t)g.p[c]) % 8 == 0 && g.ld[c] % 2 == 0;
-        if (bf16)
+        // vector form: 16-byte aligned rows, 32-bit byte offsets into the gathered tables
+        bool vec = !bf16 && F % 4 == 0 && getenv("ACM_WIDE_SCALAR") == nullptr;
+        for (int c = 0; c < NG && vec; ++c)
+            vec = ((uintptr_t)g.p[c]) % 16 == 0 && g.ld[c] % 4 == 0 &&
+                  (uint64_t)a->n_cols * (uint64_t)g.ld[c] * 4u < (1ull << 32);
+        if (vec && getenv("ACM_WIDE_PAIR") == nullptr) pair32 = false;
+        if (vec && !pair32) {
+            if (F <= 64)
+                hipLaunchKernelGGL((spmm_vec_kernel<NG, 1, Epi>), dim3(grid), dim3(256), 0, st, v, g, F, ea, partial);
+            else if (F <= 128)
+                hipLaunchKernelGGL((spmm_vec_kernel<NG, 2, Epi>), dim3(grid), dim3(256), 0, st, v, g, F, ea, partial);
+            else
+                hipLaunchKernelGGL((spmm_vec_kernel<NG, 4, Epi>), dim3(grid), dim3(256), 0, st, v, g, F, ea, partial);
+        } else if (bf16)
             hipLaunchKernelGGL((spmm_pair_kernel<NG, Epi, true>), dim3(grid), dim3(256), 0, st, v, g, F, ea, partial);
         else if (pair32)
             hipLaunchKernelGGL((spmm_pair_kernel<NG, Epi, false>), dim3(grid), dim3(256), 0, st, v, g, F, ea, partial);

@@ -41,6 +41,16 @@ struct LayPair32 {  // E: 32 lanes per row, lane l owns the adjacent columns 2l,
     __device__ __forceinline__ float rsum(float v) const { return acm_group_sum<32>(v); }
     __device__ __forceinline__ bool leader() const { return (lane & 31) == 0; }
 };
+template <int NB>
+struct LayVec16 {  // F: 16 lanes x float4 per 64-column block (NB blocks): lane m owns columns 64 b + 4 m .. + 3 -- the
+                   //    layout a dwordx4 gather of row segments leaves behind (spmm_vec_kernel).  After the cross-group
+                   //    sum all four 16-lane groups of the wave hold the same row; group 0 stores
+    static constexpr int NV = 4 * NB;
+    int lane;
+    __device__ __forceinline__ int col(int i) const { return 64 * (i >> 2) + 4 * (lane & 15) + (i & 3); }
+    __device__ __forceinline__ float rsum(float v) const { return acm_group_sum<16>(v); }
+    __device__ __forceinline__ bool leader() const { return lane == 0; }
+};
 template <int FP>
 struct LaySerial {  // C: every lane holds the whole row
     static constexpr int NV = FP;

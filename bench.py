@@ -384,8 +384,10 @@ def _csr_operands(low, adj):
 
 def sampled_check(args, model, wl_now, ops, x, rows, rank, world, n_sample=4096):
     """Eval-mode logits of the model that was just trained and timed, on `n_sample` sampled rows of rank 0's block,
-    against oracle.gcn_forward on the host (CSR operands, the same parameters).  Tolerance: 2e-4 of the logit range
-    plus 1e-3 of the row's own magnitude (fp32 sums over up to 21 k neighbours in different orders)."""
+    against oracle.gcn_forward on the host (CSR operands, the same parameters).  Tolerance per element: 1e-6 of the
+    logit range (a few rows of this workload carry logits 1e4 times the typical one: row-normalised N(0,1) features,
+    train.py:69-73) plus 1e-4 of the element's own magnitude -- fp32 sums over up to 21 k neighbours in different
+    orders; measured: max |err| 5e-4 at a logit range of 2.6e4."""
     import torch
     from oracle import acm_oracle as O
     if world > 1 and args.structure_info:
@@ -408,7 +410,7 @@ def sampled_check(args, model, wl_now, ops, x, rows, rank, world, n_sample=4096)
     ref = ref[b:e]
     pick = torch.from_numpy(np.random.default_rng(args.seed).choice(e - b, size=min(n_sample, e - b), replace=False))
     d = (got[pick] - ref[pick]).abs()
-    tol = 2e-4 * float(ref.abs().max()) + 1e-3 * ref[pick].abs()
+    tol = 1e-6 * float(ref.abs().max()) + 1e-4 * ref[pick].abs()
     ok = bool((d <= tol).all()) and bool(torch.isfinite(got).all())
     return {"checked": ok, "check": {"rows": int(pick.numel()), "max_abs_err": float(d.max()),
                                      "logit_range": float(ref.abs().max()),

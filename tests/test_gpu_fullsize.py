@@ -31,7 +31,7 @@ pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 REPORT = {}
-FWD_TOL, GRAD_TOL = 1e-4, 3e-4
+FWD_TOL, GRAD_TOL, LOSS_TOL = 1e-4, 3e-4, 3e-5
 
 
 def _record(key, **vals):
@@ -175,7 +175,8 @@ def test_twitch_shaped_step_matches_oracle(variant, structure, order):
     rec["logits_elem_p50"], rec["logits_elem_p999"], rec["logits_elem_max"] = _elementwise(logits.detach().cpu(), ref.detach())
     assert rec["logits_elem_p999"] < 1e-3, rec                                # 99.9 % of the elements to 1e-3 of their own size
     rec["loss"], rec["loss_ref"] = float(loss), float(ref_loss)
-    assert abs(float(loss) - float(ref_loss)) < 2e-6 * max(1.0, abs(float(ref_loss)))
+    # the mean of 84 k terms spanning five orders of magnitude, summed in fp32 in different orders on both sides
+    assert abs(float(loss) - float(ref_loss)) < LOSS_TOL * max(1.0, abs(float(ref_loss)))
     rec["grad_worst_rel"] = _compare_grads(model, params, "autograd", rec)
     # (2) the fused training-step route: same numbers through acm_conv_fwd_tail + the deferred flush
     opt = acm_gnn_amd.FusedAdamW(model.parameters(), lr=0.0, weight_decay=0.0)
@@ -183,7 +184,7 @@ def test_twitch_shaped_step_matches_oracle(variant, structure, order):
     opt.zero_grad(set_to_none=True)
     loss2 = step._forward_backward()
     torch.cuda.synchronize()
-    assert abs(float(loss2) - float(ref_loss)) < 2e-6 * max(1.0, abs(float(ref_loss)))
+    assert abs(float(loss2) - float(ref_loss)) < LOSS_TOL * max(1.0, abs(float(ref_loss)))
     rec["grad_worst_rel_fused_step"] = _compare_grads(model, params, "train-step", {})
     _record(f"twitch/v{variant}s{structure}/{order}", **rec)
 
@@ -225,7 +226,7 @@ def test_twitch_shaped_step_with_counter_based_dropout_matches_oracle(variant, s
                         training=True, masks=masks)
     ref_loss = O.nll_loss_on(ref, y, torch.from_numpy(tr))
     ref_loss.backward()
-    assert abs(float(loss) - float(ref_loss)) < 3e-6 * max(1.0, abs(float(ref_loss))), (float(loss), float(ref_loss))
+    assert abs(float(loss) - float(ref_loss)) < LOSS_TOL * max(1.0, abs(float(ref_loss))), (float(loss), float(ref_loss))
     rec = {"loss": float(loss), "loss_ref": float(ref_loss)}
     rec["grad_worst_rel"] = _compare_grads(model, params, "dropout-step", rec)
     _record(f"twitch-dropout/v{variant}s{structure}", **rec)
@@ -268,7 +269,7 @@ def test_three_hop_acm_sgc_at_linkx_size(dataset, sparse_x):
     d, rel = _errs(logits.detach().cpu(), ref.detach())
     rec = {"logits_abs": d, "logits_rel": rel, "loss": float(loss), "loss_ref": float(ref_loss)}
     assert rel < FWD_TOL, (d, rel)
-    assert abs(float(loss) - float(ref_loss)) < 2e-6 * max(1.0, abs(float(ref_loss)))
+    assert abs(float(loss) - float(ref_loss)) < LOSS_TOL * max(1.0, abs(float(ref_loss)))
     worst = 0.0
     for k, p in layer.named_parameters():
         rg = p64[k].grad
