@@ -24,6 +24,7 @@ EXPORTED_SYMBOLS = (
     "acm_conv_bwd_local", "acm_conv_bwd_spmm", "acm_conv_agg_fwd", "acm_conv_agg_bwd_workspace_bytes",
     "acm_conv_agg_bwd", "acm_nll_loss_workspace_bytes", "acm_nll_loss", "acm_adam_step", "acm_dropout",
     "acm_reduce_flush", "acm_conv_fwd_tail_workspace_bytes", "acm_conv_fwd_tail", "acm_shard_plan",
+    "acm_linear_fwd", "acm_bias_act", "acm_bias_act_bwd_workspace_bytes", "acm_bias_act_bwd",
 )
 
 
@@ -176,6 +177,10 @@ def _declare(lib):
     lib.acm_csr_destroy.restype = None
     lib.acm_csr_info.argtypes = [vp, C.POINTER(CsrInfo)]
     lib.acm_shard_plan.argtypes = [i64, vp, i32, i64, vp]
+    lib.acm_linear_fwd.argtypes = [i64, i64, i64, vp, i64, vp, i64, vp, i32, vp, vp, i64, vp, sz, vp]
+    lib.acm_bias_act.argtypes = [i64, i32, vp, i64, vp, i32, vp, vp]
+    lib.acm_bias_act_bwd_workspace_bytes.argtypes = [i64, i32, C.POINTER(sz)]
+    lib.acm_bias_act_bwd.argtypes = [i64, i32, vp, i64, vp, i64, C.c_float, i32, vp, i64, vp, vp, sz, vp, vp]
     lib.acm_spmm_workspace_bytes.argtypes = [vp, i32, C.POINTER(sz)]
     lib.acm_gemm_workspace_bytes.argtypes = [i32, i32, i64, i64, i64, C.POINTER(sz)]
     lib.acm_gemm.argtypes = [i32, i32, i64, i64, i64, vp, i64, vp, i64, vp, i64, i32, vp, sz, vp]

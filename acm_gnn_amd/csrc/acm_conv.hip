@@ -449,15 +449,18 @@ __device__ __forceinline__ void gather_vec_block(const GatherSrc& g, const unsig
     }
 #pragma unroll
     for (int uu = 0; uu < UNR; ++uu) {
-        const float av = col_ok ? a[uu] : 0.f;
+        // an idle slot (beyond the row's end, or columns beyond F) fetched row 0: select, never multiply by a zero
+        // weight (0 * inf = NaN would leak a non-finite row the operator does not reference)
+        const bool live = col_ok && a[uu] != 0.f;
+        const float av = a[uu];
 #pragma unroll
         for (int c = 0; c < NG; ++c)
 #pragma unroll
             for (int b = 0; b < NB; ++b) {
-                acc[c][4 * b + 0] = fmaf(av, z[uu][c][b].x, acc[c][4 * b + 0]);
-                acc[c][4 * b + 1] = fmaf(av, z[uu][c][b].y, acc[c][4 * b + 1]);
-                acc[c][4 * b + 2] = fmaf(av, z[uu][c][b].z, acc[c][4 * b + 2]);
-                acc[c][4 * b + 3] = fmaf(av, z[uu][c][b].w, acc[c][4 * b + 3]);
+                acc[c][4 * b + 0] = live ? fmaf(av, z[uu][c][b].x, acc[c][4 * b + 0]) : acc[c][4 * b + 0];
+                acc[c][4 * b + 1] = live ? fmaf(av, z[uu][c][b].y, acc[c][4 * b + 1]) : acc[c][4 * b + 1];
+                acc[c][4 * b + 2] = live ? fmaf(av, z[uu][c][b].z, acc[c][4 * b + 2]) : acc[c][4 * b + 2];
+                acc[c][4 * b + 3] = live ? fmaf(av, z[uu][c][b].w, acc[c][4 * b + 3]) : acc[c][4 * b + 3];
             }
     }
 }
@@ -816,7 +819,13 @@ int launch_gather(const acm_csr* a, const GatherSrc& g, int F, const typename Ep
         bool pair32 = !bf16 && F > 32 && F <= 64 && F % 2 == 0 && (size_t)a->n_cols * F * NG * sizeof(float) <= (8u << 20);
         for (int c = 0; c < NG && pair32; ++c) pair32 = ((uintptr_t)g.p[c]) % 8 == 0 && g.ld[c] % 2 == 0;
         // vector form: 16-byte aligned rows, 32-bit byte offsets into the gathered tables
-        bool vec = !bf16 && F % 4 == 0 && getenv("ACM_WIDE_SCALAR") == nullptr;
+        // Measured on the twitch-shaped graph (scripts/probe_wide.py, profiles/r02_probe_wide.txt): rows served by the L2
+        // come at 21 TB/s through the vector form against 12 TB/s, rows from the Infinity Cache at 7.5 TB/s through
+        // either -- the fabric, not the load instruction, bounds the large-graph gathers.  With a fused head (EpiFwd) the
+        // vector layout runs the head four times redundantly, and with two gathered channels its 58 VGPRs cost
+        // occupancy, so it is the default for single-channel products (k-hop chains, spmm_sub, the S gather of the
+        // aggregate-first structure channel); ACM_WIDE_VEC=1 forces it everywhere, ACM_WIDE_SCALAR=1 nowhere.
+        bool vec = !bf16 && F % 4 == 0 && getenv("ACM_WIDE_SCALAR") == nullptr && (NG == 1 || getenv("ACM_WIDE_VEC") != nullptr);
         for (int c = 0; c < NG && vec; ++c)
             vec = ((uintptr_t)g.p[c]) % 16 == 0 && g.ld[c] % 4 == 0 &&
                   (uint64_t)a->n_cols * (uint64_t)g.ld[c] * 4u < (1ull << 32);

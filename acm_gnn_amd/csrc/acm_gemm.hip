@@ -62,7 +62,8 @@ __global__ __launch_bounds__(256) void gemm_kernel(int M, int N, int K, const fl
                                                    const float* __restrict__ B, long ldb,
                                                    float* __restrict__ C, long ldc, int relu, int k_per_split,
                                                    float* __restrict__ slabs, int cb, long cbs, int split,
-                                                   float* __restrict__ C2, long ldc2) {
+                                                   float* __restrict__ C2, long ldc2, const float* __restrict__ bias,
+                                                   acm_dropout_t drop) {
     constexpr int BM = 16 * WM * WAVES_M, BN = 16 * WN * WAVES_N;
     constexpr bool A_KMAJOR = !TA, B_KMAJOR = TB;
     using LA = TileLds<A_KMAJOR, BM>;
@@ -123,6 +124,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(int M, int N, int K, const fl
         dst = slabs + (long)blockIdx.z * M * N;
         ldd = N;
     }
+    const AcmDropCtx dc = acm_drop_ctx(drop);             // epilogue of acm_linear_fwd: bias -> ReLU -> dropout
 #pragma unroll
     for (int i = 0; i < WM; ++i)
 #pragma unroll
@@ -133,7 +135,11 @@ __global__ __launch_bounds__(256) void gemm_kernel(int M, int N, int K, const fl
                 const int col = n0 + (wn * WN + j) * 16 + (lane & 15);
                 if (row < M && col < N) {
                     float v = acc[i][j][r];
-                    if (relu && !slabs) v = fmaxf(v, 0.f);
+                    if (!slabs) {
+                        if (bias) v += bias[col];
+                        if (relu) v = fmaxf(v, 0.f);
+                        if (dc.on) v *= acm_drop1(dc, row, col);
+                    }
                     if (slabs) dst[(long)row * ldd + col] = v;
                     else if (cb) dst[(long)(col / cb) * cbs + (long)row * ldd + (col % cb)] = v;   // column-block output
                     else if (split && col >= split) C2[(long)row * ldc2 + (col - split)] = v;       // two-matrix output
@@ -147,7 +153,8 @@ __global__ __launch_bounds__(256) void gemm_kernel(int M, int N, int K, const fl
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(int M, int N, int splits,
                                                             const float* __restrict__ slabs,
                                                             float* __restrict__ C, long ldc, int relu, int cb, long cbs,
-                                                            int split, float* __restrict__ C2, long ldc2) {
+                                                            int split, float* __restrict__ C2, long ldc2,
+                                                            const float* __restrict__ bias, acm_dropout_t drop) {
     __shared__ float red[16][17];
     const long total = (long)M * N;
     const int tq = threadIdx.x & 15, tz = threadIdx.x >> 4;
@@ -172,9 +179,11 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(int M, int N, int sp
         float t = 0.f;
 #pragma unroll
         for (int z = 0; z < 16; ++z) t += red[z][tq];
-        if (relu) t = fmaxf(t, 0.f);
         const long m = q / N;
         const int n = (int)(q % N);
+        if (bias) t += bias[n];
+        if (relu) t = fmaxf(t, 0.f);
+        if (drop.p > 0.f) t *= acm_drop1(acm_drop_ctx(drop), m, n);
         if (cb) C[(long)(n / cb) * cbs + m * ldc + (n % cb)] = t;
         else if (split && n >= split) C2[m * ldc2 + (n - split)] = t;
         else C[m * ldc + n] = t;
@@ -222,10 +231,10 @@ GemmPlan plan_gemm(int64_t M, int64_t N, int64_t K) {
 template <int WM, int WN, int WVM, int WVN>
 void launch_shape(int ta, int tb, const GemmPlan& p, hipStream_t st, int M, int N, int K, const float* A,
                   long lda, const float* B, long ldb, float* C, long ldc, int relu, float* slabs, int cb, long cbs,
-                  int split, float* C2, long ldc2) {
+                  int split, float* C2, long ldc2, const float* bias, const acm_dropout_t& drop) {
 #define ACM_GEMM_LAUNCH(TAv, TBv)                                                                        \
     hipLaunchKernelGGL((gemm_kernel<WM, WN, WVM, WVN, TAv, TBv>), p.grid, dim3(256), 0, st, M, N, K, A, \
-                       lda, B, ldb, C, ldc, relu, p.k_per_split, slabs, cb, cbs, split, C2, ldc2)
+                       lda, B, ldb, C, ldc, relu, p.k_per_split, slabs, cb, cbs, split, C2, ldc2, bias, drop)
     if (!ta && !tb) ACM_GEMM_LAUNCH(false, false);
     else if (ta && !tb) ACM_GEMM_LAUNCH(true, false);
     else if (!ta && tb) ACM_GEMM_LAUNCH(false, true);
@@ -254,7 +263,19 @@ extern "C" int acm_gemm(int transA, int transB, int64_t M, int64_t N, int64_t K,
 
 static int gemm_core(int transA, int transB, int64_t M, int64_t N, int64_t K, const float* A, int64_t lda, const float* B,
                      int64_t ldb, float* C, int64_t ldc, int64_t c_col_block, int64_t c_block_stride, int64_t split_col,
-                     float* C2, int64_t ldc2, int relu, void* workspace, size_t workspace_bytes, acm_stream_t stream);
+                     float* C2, int64_t ldc2, int relu, void* workspace, size_t workspace_bytes, acm_stream_t stream,
+                     const float* bias = nullptr, const acm_dropout_t* drop = nullptr);
+
+// Y = dropout(relu?(X W^T + b)): the residual branch of ACM-GCN++ (ACM-Geometric/models.py:26-27,55-56:
+// F.dropout(F.relu(self.mlpX(x))) with mlpX = one nn.Linear) as one GEMM with the bias, the ReLU and the counter-based
+// dropout in its epilogue.  W is in nn.Linear's layout [f_out, f_in].
+extern "C" int acm_linear_fwd(int64_t n_rows, int64_t f_in, int64_t f_out, const float* X, int64_t ldx, const float* W,
+                              int64_t ldw, const float* bias, int relu, const acm_dropout_t* drop, float* Y, int64_t ldy,
+                              void* workspace, size_t workspace_bytes, acm_stream_t stream) {
+    ACM_REQUIRE(X && W && Y, ACM_EINVAL, "acm_linear_fwd: NULL argument");
+    return gemm_core(0, 1, n_rows, f_out, f_in, X, ldx, W, ldw, Y, ldy, 0, 0, 0, nullptr, 0, relu, workspace, workspace_bytes,
+                     stream, bias, drop);
+}
 
 extern "C" int acm_gemm_blocks(int transA, int transB, int64_t M, int64_t N, int64_t K, const float* A,
                                int64_t lda, const float* B, int64_t ldb, float* C, int64_t ldc, int64_t c_col_block,
@@ -276,7 +297,11 @@ extern "C" int acm_gemm_split(int transA, int transB, int64_t M, int64_t N, int6
 
 static int gemm_core(int transA, int transB, int64_t M, int64_t N, int64_t K, const float* A, int64_t lda, const float* B,
                      int64_t ldb, float* C, int64_t ldc, int64_t c_col_block, int64_t c_block_stride, int64_t split_col,
-                     float* C2, int64_t ldc2, int relu, void* workspace, size_t workspace_bytes, acm_stream_t stream) {
+                     float* C2, int64_t ldc2, int relu, void* workspace, size_t workspace_bytes, acm_stream_t stream,
+                     const float* bias, const acm_dropout_t* drop_in) {
+    acm_dropout_t drop = {0.f, 0, 0, nullptr, 0};
+    if (drop_in) drop = *drop_in;
+    ACM_REQUIRE(drop.p == 0.f || (drop.p > 0.f && drop.p < 1.f && drop.step), ACM_EINVAL, "acm_gemm: bad dropout spec");
     ACM_REQUIRE(M >= 0 && N >= 0 && K >= 0, ACM_ESHAPE, "acm_gemm: negative size");
     ACM_REQUIRE(c_col_block >= 0 && c_col_block < INT32_MAX, ACM_ESHAPE, "acm_gemm: bad column block");
     const int cb = (int)c_col_block;
@@ -299,6 +324,7 @@ static int gemm_core(int transA, int transB, int64_t M, int64_t N, int64_t K, co
                     "acm_gemm: workspace %zu B < required %zu B", workspace_bytes, need);
         slabs = (float*)workspace;
     }
+    ACM_REQUIRE(K > 0 || (!bias && drop.p == 0.f), ACM_EUNSUPPORTED, "acm_linear_fwd: f_in must be positive");
     if (K == 0) {  // empty sum
         if (split) {
             ACM_CHECK_HIP(hipMemset2DAsync(C, (size_t)ldc * sizeof(float), 0, (size_t)split * sizeof(float), (size_t)M, st));
@@ -313,17 +339,17 @@ static int gemm_core(int transA, int transB, int64_t M, int64_t N, int64_t K, co
         return ACM_OK;
     }
     if (p.shape == 0)
-        launch_shape<2, 2, 2, 2>(transA, transB, p, st, (int)M, (int)N, (int)K, A, lda, B, ldb, C, ldc, relu, slabs, cb, cbs, split, C2, (long)ldc2);
+        launch_shape<2, 2, 2, 2>(transA, transB, p, st, (int)M, (int)N, (int)K, A, lda, B, ldb, C, ldc, relu, slabs, cb, cbs, split, C2, (long)ldc2, bias, drop);
     else if (p.shape == 1)
-        launch_shape<1, 4, 1, 4>(transA, transB, p, st, (int)M, (int)N, (int)K, A, lda, B, ldb, C, ldc, relu, slabs, cb, cbs, split, C2, (long)ldc2);
+        launch_shape<1, 4, 1, 4>(transA, transB, p, st, (int)M, (int)N, (int)K, A, lda, B, ldb, C, ldc, relu, slabs, cb, cbs, split, C2, (long)ldc2, bias, drop);
     else
-        launch_shape<4, 1, 4, 1>(transA, transB, p, st, (int)M, (int)N, (int)K, A, lda, B, ldb, C, ldc, relu, slabs, cb, cbs, split, C2, (long)ldc2);
+        launch_shape<4, 1, 4, 1>(transA, transB, p, st, (int)M, (int)N, (int)K, A, lda, B, ldb, C, ldc, relu, slabs, cb, cbs, split, C2, (long)ldc2, bias, drop);
     ACM_CHECK_HIP(hipGetLastError());
     if (slabs) {
         const long total = (long)M * N;
         const int grid = (int)((total + 15) / 16);
         hipLaunchKernelGGL(splitk_reduce_kernel, dim3(grid), dim3(256), 0, st, (int)M, (int)N, p.splits, slabs,
-                           C, (long)ldc, relu, cb, cbs, split, C2, (long)ldc2);
+                           C, (long)ldc, relu, cb, cbs, split, C2, (long)ldc2, bias, drop);
         ACM_CHECK_HIP(hipGetLastError());
     }
     return ACM_OK;

@@ -481,6 +481,100 @@ def agg_pad_width(f_in):
 
 
 # --------------------------------------------------------------------------
+# the ACM-GCN++ residual branch
+# --------------------------------------------------------------------------
+class _ResidualLinear(torch.autograd.Function):
+    """y = dropout(relu(x W^T + b)) (ACM-Geometric/models.py:26-27,55-56): dense x through acm_linear_fwd (bias / ReLU /
+    counter-based dropout in the GEMM epilogue), CSR features through acm_spmm_v + acm_bias_act.  Backward:
+    acm_bias_act_bwd (masks read off y), then dW = G^T x; row-sharded runs sum [dW | db] over the ranks."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, relu, drop, group):
+        lib = _lib.load()
+        sparse_x = isinstance(x, SparseFeatures)
+        w = _as_f32c(weight, "weight")
+        b = _as_f32c(bias, "bias") if bias is not None else None
+        f_out, f_in = w.shape
+        n = x.shape[0]
+        dev = w.device
+        y = torch.empty(n, f_out, dtype=_F32, device=dev)
+        spec = _drop_spec(drop[:3], drop[3]) if drop is not None else None
+        if sparse_x:
+            spmm_v(x.csr, x.values, w.t().contiguous(), out=y)
+            with _device_ctx(dev), _Timed(f"bias_act/{n}x{f_out}"):
+                st = lib.acm_bias_act(n, f_out, _vp(y), y.stride(0), _vp(b), int(relu),
+                                      C.byref(spec) if spec is not None else None, _stream())
+            _lib.check(st, "acm_bias_act")
+        else:
+            x = _as_f32c(x, "input")
+            if x.shape[1] < f_in:
+                raise ValueError(f"input has {x.shape[1]} columns but the Linear has {f_in} input features")
+            nbytes = C.c_size_t()
+            _lib.check(lib.acm_gemm_workspace_bytes(0, 1, n, f_out, f_in, C.byref(nbytes)))
+            ws = torch.empty(max(nbytes.value // 4, 1), dtype=_F32, device=dev) if nbytes.value else None
+            with _device_ctx(dev), _Timed(f"linear_fwd/{n}x{f_out}x{f_in}"):
+                st = lib.acm_linear_fwd(n, f_in, f_out, _vp(x), x.stride(0), _vp(w), w.stride(0), _vp(b), int(relu),
+                                        C.byref(spec) if spec is not None else None, _vp(y), y.stride(0), _vp(ws),
+                                        nbytes.value, _stream())
+            _lib.check(st, "acm_linear_fwd")
+        ctx.relu, ctx.group, ctx.has_bias = bool(relu), group, b is not None
+        ctx.keep_scale = 1.0 / (1.0 - drop[0]) if (drop is not None and drop[0] > 0) else 1.0
+        ctx.sparse_x = x if sparse_x else None
+        ctx.save_for_backward(w if sparse_x else x, w, y)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        lib = _lib.load()
+        x, w, y = ctx.saved_tensors
+        dy = _as_f32c(dy, "grad")
+        n, f_out = y.shape
+        f_in = w.shape[1]
+        dev = y.device
+        g = torch.empty(n, f_out, dtype=_F32, device=dev)
+        flat = torch.empty(f_out * f_in + f_out, dtype=_F32, device=dev)      # [dW | db]: one all-reduce when sharded
+        d_w, d_b = flat[: f_out * f_in].view(f_out, f_in), flat[f_out * f_in:]
+        nbytes = C.c_size_t()
+        _lib.check(lib.acm_bias_act_bwd_workspace_bytes(n, f_out, C.byref(nbytes)), "acm_bias_act_bwd_workspace_bytes")
+        ws = torch.empty(max(nbytes.value // 4, 1), dtype=_F32, device=dev)
+        with _device_ctx(dev), _Timed(f"bias_act_bwd/{n}x{f_out}"):
+            st = lib.acm_bias_act_bwd(n, f_out, _vp(y), y.stride(0), _vp(dy), dy.stride(0), float(ctx.keep_scale),
+                                      int(ctx.relu), _vp(g), g.stride(0), _vp(d_b), _vp(ws), nbytes.value, _defer_ptr(),
+                                      _stream())
+        _lib.check(st, "acm_bias_act_bwd")
+        if _DEFER is not None:
+            _DEFER.hold(ws, [d_b], keep=[flat])
+        d_x = None
+        if ctx.sparse_x is not None:                          # dW^T = X_csr^T G
+            xs = ctx.sparse_x
+            xt = xs.csr_t
+            d_w.copy_(spmm_v(xt, xs.values.index_select(0, xt.src_pos), g).t())
+        else:
+            if x.shape[1] == f_in:
+                gemm(g, x, trans_a=True, out=d_w)
+            else:                                             # zero-padded input rows (dropout(..., pad_to=...))
+                d_w.copy_(gemm(g, x, trans_a=True)[:, :f_in])
+            if ctx.needs_input_grad[0]:
+                d_x = gemm(g, w)
+                if d_x.shape[1] != x.shape[1]:
+                    d_x = torch.nn.functional.pad(d_x, (0, x.shape[1] - d_x.shape[1]))
+        if ctx.group is not None:
+            import torch.distributed as dist
+            if _DEFER is not None:
+                _DEFER.flush()
+            dist.all_reduce(flat, group=ctx.group)
+        return d_x, d_w, (d_b if ctx.has_bias else None), None, None, None
+
+
+def residual_linear(x, weight, bias, relu=True, drop=None, group=None):
+    """dropout(relu(x @ weight.T + bias)) on the HIP kernels.  ``drop = (p, tag, DropoutState, row_offset)`` draws the
+    counter-based mask in the epilogue; ``group``: row-sharded run (the parameter gradients are summed over it)."""
+    if drop is not None and not drop[0] > 0:
+        drop = None
+    return _ResidualLinear.apply(x, weight, bias, bool(relu), drop, group)
+
+
+# --------------------------------------------------------------------------
 # the fused ACM layer
 # --------------------------------------------------------------------------
 class AcmConfig:
@@ -496,6 +590,10 @@ class AcmConfig:
         plus = model_type in ("acmgcnp", "acmgcnpp", "acmgcn+", "acmgcn++")
         if model_type == "acmsgc":
             self.n_channels, self.relu_before, self.relu_after, self.relu_mlp = 3, False, False, False
+            self.layernorm = False
+        elif model_type == "acmsnowball":                 # the layer's generic branch: three channels, no LayerNorm, the
+            self.n_channels = 3                           # structure channel never (layers.py:59,106-108)
+            self.relu_before, self.relu_after, self.relu_mlp = bool(variant), not bool(variant), True
             self.layernorm = False
         else:
             self.n_channels = 4 if (plus and structure_info) else 3

@@ -7,9 +7,12 @@ measured on the GPU box (the reference's Python never travels there).
       -> GraphConvolution(nhid -> nclass)
 
 Same constructor signature and ``forward(x, adj_low, adj_high, adj_low_unnormalized)``.
-Differences, on purpose: ``acmsgc`` is constructible (a single linear ACM layer,
-nfeat -> nclass; the reference raises TypeError) and
-``acmsnowball`` is rejected explicitly instead of failing inside __init__.
+Differences, on purpose: ``acmsgc`` and ``acmsnowball`` are constructible -- the reference's
+constructor omits the layer's positional ``nnodes`` for both and raises TypeError (SURVEY.md quirk Q2;
+ACM-Geometric/models.py:35,38-39).  With that argument supplied, ``acmsgc`` is a single linear ACM
+layer nfeat -> nclass (its forward returns that layer's output: the reference's ``fea2`` is never
+assigned on this path) and ``acmsnowball`` is the dense stack the reference's forward spells out
+(models.py:57-64): layer k reads [x | h_0 | ... | h_{k-1}], the classifier layer reads all of them.
 """
 import torch
 import torch.nn as nn
@@ -20,31 +23,6 @@ from .graph import FilterOperators, SparseFeatures
 from .layers import GraphConvolution, MLP
 
 _TWO_LAYER = ("acmgcn", "acmgcnp", "acmgcnpp")
-
-
-class _SumGradsOverRanks(torch.autograd.Function):
-    """Identity on replicated parameters whose gradients are per-rank partial sums over the local rows (the
-    ACM-GCN++ residual Linear): the backward sums them over the row shards with one all-reduce, like the ACM layers do
-    for their own replicated parameters -- otherwise every rank would step its replica with a different gradient."""
-
-    @staticmethod
-    def forward(ctx, group, *tensors):
-        ctx.group = group
-        return tuple(t.view_as(t) for t in tensors)
-
-    @staticmethod
-    def backward(ctx, *grads):
-        import torch.distributed as dist
-        from . import functional as AF
-        if AF._DEFER is not None:
-            AF._DEFER.flush()
-        flat = torch.cat([g.reshape(-1) for g in grads])
-        dist.all_reduce(flat, group=ctx.group)
-        out, o = [], 0
-        for g in grads:
-            out.append(flat[o:o + g.numel()].view_as(g))
-            o += g.numel()
-        return (None, *out)
 
 
 class GCN(nn.Module):
@@ -63,9 +41,16 @@ class GCN(nn.Module):
             self.gcns.append(GraphConvolution(nhid, nclass, nnodes, output_layer=1, **kw))
         elif model_type == "acmsgc":
             self.gcns.append(GraphConvolution(nfeat, nclass, nnodes, model_type=model_type, output_layer=1))
+        elif model_type == "acmsnowball":
+            # models.py:38-39 with the missing nnodes supplied; structure_info is not forwarded there either
+            for k in range(nlayers):
+                self.gcns.append(GraphConvolution(k * nhid + nfeat, nhid, nnodes, model_type=model_type, variant=variant,
+                                                  attn_layernorm=attn_layernorm, gather_dtype=gather_dtype))
+            self.gcns.append(GraphConvolution(nlayers * nhid + nfeat, nclass, nnodes, model_type=model_type,
+                                              variant=variant, attn_layernorm=attn_layernorm, gather_dtype=gather_dtype))
         else:
             raise ValueError(f"GCN: unsupported model_type {model_type!r} "
-                             "(acmgcn | acmgcnp | acmgcnpp | acmsgc)")
+                             "(acmgcn | acmgcnp | acmgcnpp | acmsgc | acmsnowball)")
         # The reference also registers two never-initialised 1x1 parameters (fea_param,
         # xX_param; models.py:41) that take no part in the forward.  They are kept so
         # state_dict keys and optimizer parameter lists line up, zero-filled.
@@ -89,17 +74,26 @@ class GCN(nn.Module):
         if self.model_type == "acmgcnpp":
             self.mlpX.reset_parameters()
 
-    def _residual(self, x, adj_low):
-        """relu(Linear(x)) of the ACM-GCN++ branch (ACM-Geometric/models.py:26-27,55-56).  Row-sharded: the Linear's
-        weight / bias gradients are summed over the ranks."""
+    def _residual(self, x, adj_low, drop=None):
+        """relu(Linear(x)) of the ACM-GCN++ branch (ACM-Geometric/models.py:26-27,55-56), optionally with the
+        counter-based dropout in the same epilogue (``drop`` = (p, tag, state, row_offset)): one GEMM launch
+        (functional.residual_linear; CSR features: acm_spmm_v + acm_bias_act).  Row-sharded: the Linear's weight / bias
+        gradients are summed over the ranks.  mlpX stacks deeper than one Linear (init_layers_X > 1: BatchNorm between
+        the layers) stay on torch modules and are single-process only."""
         ops = adj_low if isinstance(adj_low, FilterOperators) else None
-        if ops is not None and ops.sharded:
-            if len(self.mlpX.lins) != 1:
-                raise NotImplementedError("row-sharded acmgcnpp supports init_layers_X = 1 (no BatchNorm statistics to sync)")
+        group = ops.group if (ops is not None and ops.sharded) else None
+        if len(self.mlpX.lins) == 1:
             lin = self.mlpX.lins[0]
-            w, b = _SumGradsOverRanks.apply(ops.group, lin.weight, lin.bias)
-            return F.relu(F.linear(x, w, b))
-        return F.relu(self.mlpX(x, input_tensor=True))
+            return AF.residual_linear(x, lin.weight, lin.bias, relu=True, drop=drop, group=group)
+        if group is not None:
+            raise NotImplementedError("row-sharded acmgcnpp supports init_layers_X = 1 (no BatchNorm statistics to sync)")
+        if isinstance(x, SparseFeatures):
+            raise NotImplementedError("CSR features with init_layers_X > 1")
+        f_in = self.mlpX.lins[0].in_features              # x may carry zero pad columns (dropout(..., pad_to=...))
+        out = F.relu(self.mlpX(x if x.shape[1] == f_in else x[:, :f_in], input_tensor=True))
+        if drop is not None and drop[0] > 0:
+            out = AF.dropout(out, drop[0], drop[2], tag=drop[1], row_offset=drop[3])
+        return out
 
     def _forward_fused_dropout(self, x, adj_low, adj_high, adj_low_unnormalized):
         """Training forward with every dropout drawn from ``dropout_state`` (tags: 0 input, 1 hidden, 2 the
@@ -111,16 +105,13 @@ class GCN(nn.Module):
         st = self.dropout_state
         off = adj_low.row_offset if isinstance(adj_low, FilterOperators) else 0
         if isinstance(x, SparseFeatures):
-            if self.model_type == "acmgcnpp":
-                raise NotImplementedError("acmgcnpp's dense residual branch needs dense features")
             x = x.with_values(AF.dropout(x.values.reshape(-1, 1), p, st, tag=0).reshape(-1))
             kw = {}
         else:
             nfeat = x.shape[1]
-            pad = AF.agg_pad_width(nfeat) if self.model_type != "acmgcnpp" else None
+            pad = AF.agg_pad_width(nfeat)
             ops = adj_low if isinstance(adj_low, FilterOperators) else None
-            if (ops is not None and ops.sharded and ops.uniform and ops.x_full is not None
-                    and self.model_type != "acmgcnpp"):
+            if ops is not None and ops.sharded and ops.uniform and ops.x_full is not None:
                 # the mask is a function of the global position: drop the replicated full input locally instead of
                 # all-gathering the dropped row blocks (equal blocks only: there the halo numbering is the global one)
                 xg = AF.dropout(ops.x_full, p, st, tag=0, pad_to=pad, row_offset=0)
@@ -132,20 +123,49 @@ class GCN(nn.Module):
         if self.model_type == "acmsgc":
             return self.gcns[0](x, adj_low, adj_high, adj_low_unnormalized)
         if self.model_type == "acmgcnpp":
-            xx = AF.dropout(self._residual(x, adj_low), p, st, tag=2, row_offset=off)
+            xx = self._residual(x, adj_low, drop=(p, 2, st, off))
         fea = self.gcns[0](x, adj_low, adj_high, adj_low_unnormalized, post_relu=True, post_drop=(p, 1, st), **kw)
         if self.model_type == "acmgcnpp":
             fea = fea + xx
         return self.gcns[1](fea, adj_low, adj_high, adj_low_unnormalized)
 
+    def _forward_snowball(self, x, adj_low, adj_high, fused):
+        """models.py:57-64: h_k = dropout(relu(layer_k([x | h_0 | ... | h_{k-1}]))), out = layer_last([x | h_0 | ...]).
+        The ReLU + dropout after every hidden layer ride that layer's epilogue (post_relu / post_scale / post_drop);
+        the concatenations are plain copies."""
+        if isinstance(x, SparseFeatures):
+            raise NotImplementedError("acmsnowball concatenates the input with the hidden blocks: dense features only")
+        p, st = self.dropout, self.dropout_state
+        off = adj_low.row_offset if isinstance(adj_low, FilterOperators) else 0
+        if fused:
+            x = AF.dropout(x, p, st, tag=0, row_offset=off)
+        else:
+            x = F.dropout(x, p, training=self.training)
+        blocks = []
+        for k in range(self.nlayers):
+            inp = x if k == 0 else torch.cat([x] + blocks, 1)
+            if fused:
+                h = self.gcns[k](inp, adj_low, adj_high, None, post_relu=True, post_drop=(p, 1 + k, st))
+            else:
+                scale = None
+                if self.training and p > 0:
+                    scale = F.dropout(self._ones_like_hidden(x.shape[0], self.gcns[k].out_features, x.device), p, training=True)
+                h = self.gcns[k](inp, adj_low, adj_high, None, post_relu=True, post_scale=scale)
+            blocks.append(h)
+        return self.gcns[-1](torch.cat([x] + blocks, 1), adj_low, adj_high, None)
+
     def forward(self, x, adj_low, adj_high=None, adj_low_unnormalized=None):
-        if self.fused_dropout and self.training and self.dropout > 0:
+        fused = self.fused_dropout and self.training and self.dropout > 0
+        if fused and self.dropout_state is None:
+            dev = x.values.device if isinstance(x, SparseFeatures) else x.device
+            self.dropout_state = AF.DropoutState(dev)
+        if self.model_type == "acmsnowball":
+            return self._forward_snowball(x, adj_low, adj_high, fused)
+        if fused:
             return self._forward_fused_dropout(x, adj_low, adj_high, adj_low_unnormalized)
         drop = lambda t: F.dropout(t, self.dropout, training=self.training)  # noqa: E731
         if isinstance(x, SparseFeatures):
             # dropout of a sparse matrix = dropout of its stored values (zeros stay zero either way)
-            if self.model_type == "acmgcnpp":
-                raise NotImplementedError("acmgcnpp's dense residual branch needs dense features")
             x = x.with_values(drop(x.values))
         else:
             x = drop(x)

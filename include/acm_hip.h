@@ -223,6 +223,26 @@ int acm_proj_bwd(int64_t n_rows, int64_t f_in, int n_out, const float* X, int64_
                  float* dX, int64_t lddx, float* dW, int64_t lddw, int64_t dw_col_block, int64_t dw_block_stride,
                  void* workspace, size_t workspace_bytes, acm_reduce_list_t* defer, acm_stream_t stream);
 
+/* ------------------------------------------------ ACM-GCN++ residual branch --
+ * xX = F.dropout(F.relu(self.mlpX(x)))  with mlpX = one nn.Linear  (ACM-Geometric/models.py:26-27,55-56,73;
+ * ACM-Pytorch/models/models.py:50-53,150-152,165).
+ *   acm_linear_fwd    Y = dropout(relu?(X W^T + b)) as ONE GEMM with bias / ReLU / counter-based dropout in its
+ *                     epilogue; W in nn.Linear's layout [f_out, f_in] (pitch ldw); drop NULL or p = 0: none.
+ *                     Workspace: acm_gemm_workspace_bytes(0, 1, n_rows, f_out, f_in).
+ *   acm_bias_act      the same epilogue in place on a product that came out of acm_spmm_v (CSR features).
+ *   acm_bias_act_bwd  G = dY * keep_scale * [Y > 0] (keep_scale = 1 / (1 - p); both masks are read off the forward's
+ *                     output), d_bias = column sums of G (deferrable second phase); f <= 256.  The weight gradient is
+ *                     then dW = G^T X (acm_gemm with transA, or acm_spmm_v on the transposed feature handle). */
+int acm_linear_fwd(int64_t n_rows, int64_t f_in, int64_t f_out, const float* X, int64_t ldx,
+                   const float* W, int64_t ldw, const float* bias, int relu, const acm_dropout_t* drop,
+                   float* Y, int64_t ldy, void* workspace, size_t workspace_bytes, acm_stream_t stream);
+int acm_bias_act(int64_t n_rows, int f, float* Y, int64_t ldy, const float* bias, int relu,
+                 const acm_dropout_t* drop, acm_stream_t stream);
+int acm_bias_act_bwd_workspace_bytes(int64_t n_rows, int f, size_t* bytes);
+int acm_bias_act_bwd(int64_t n_rows, int f, const float* Y, int64_t ldy, const float* dY, int64_t lddy,
+                     float keep_scale, int relu, float* G, int64_t ldg, float* d_bias,
+                     void* workspace, size_t workspace_bytes, acm_reduce_list_t* defer, acm_stream_t stream);
+
 /* ----------------------------------------------------------------- SpMM --
  * Y[r, 0:width] = sum_j A[r,j] * G[j, 0:width]   (plain CSR x dense; used for
  * k-hop ACM-SGC chains -- ACM-Pytorch/utils.py:631-637 -- and by tests).

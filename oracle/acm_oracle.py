@@ -194,6 +194,28 @@ def gcn_forward(params, x, adj_low, adj_high, adj_low_unnormalized=None, *,
     return layer_forward(p1, fea1, adj_low, adj_high, adj_low_unnormalized, **kw)
 
 
+def snowball_forward(params, x, adj_low, adj_high, *, nlayers, variant=False, dropout=0.0, training=False, masks=None):
+    """The acmsnowball forward exactly as ACM-Geometric/models.py:57-64 spells it (the reference's constructor cannot
+    build the model -- quirk Q2 -- so this is pinned at layer level by the goldens plus this literal wiring):
+        h_k = dropout(relu(layer_k(cat([x, h_0 .. h_{k-1}])))),  out = layer_last(cat([x, h_0 .. h_{n-1}]))
+    ``params`` = {"gcns.<k>.<name>"}; ``masks`` (optional): keep-masks "x", "h0", "h1", ...  The layer's forward takes
+    the generic branch for this model_type: three channels, no LayerNorm (layers.py:59,101-108)."""
+    masks = masks or {}
+    kw = dict(model_type="acmsnowball", variant=variant, structure_info=0, attn_layernorm=False)
+
+    def layer_params(k):
+        pre = f"gcns.{k}."
+        return {n[len(pre):]: v for n, v in params.items() if n.startswith(pre)}
+
+    x = _drop(x, dropout, training, masks.get("x"))
+    blocks = []
+    for k in range(nlayers):
+        inp = x if k == 0 else torch.cat([x] + blocks, 1)
+        h = layer_forward(layer_params(k), inp, adj_low, adj_high, **kw)
+        blocks.append(_drop(F.relu(h), dropout, training, masks.get(f"h{k}")))
+    return layer_forward(layer_params(nlayers), torch.cat([x] + blocks, 1), adj_low, adj_high, **kw)
+
+
 def nll_loss_on(logits, labels, idx):
     """log_softmax + NLLLoss over the training rows (train.py:133-134)."""
     return F.nll_loss(F.log_softmax(logits, dim=1)[idx], labels[idx])

@@ -6,7 +6,8 @@ projection and filter; the structure channel; hidden -> hidden layers).
     python scripts/bench_wide.py [--modes scalar,vec] [--configs twitch/acmii,...]
 
 mode = environment switches read per launch by libacm_hip.so:  scalar: ACM_WIDE_SCALAR=1 (dword-per-lane kernel),
-vec: default (dwordx4 rows, four neighbours per instruction).
+default: the library's choice (vector form for single-channel products), vec: ACM_WIDE_VEC=1 (dwordx4 rows, four
+neighbours per instruction, everywhere).
 """
 import argparse
 import json
@@ -31,7 +32,7 @@ CONFIGS = {
     "arxiv/acm": dict(ds="arxiv-year", method="acmgcnp", s=0, variant=0, dropout=0.1),
     "penn94/acm/csrX": dict(ds="penn94", method="acmgcnp", s=0, variant=0, dropout=0.1, sparse=1),
 }
-MODES = {"scalar": {"ACM_WIDE_SCALAR": "1"}, "vec": {}, "pair": {"ACM_WIDE_PAIR": "1"}}
+MODES = {"scalar": {"ACM_WIDE_SCALAR": "1"}, "default": {}, "vec": {"ACM_WIDE_VEC": "1"}, "pair": {"ACM_WIDE_PAIR": "1"}}
 _WL = {}
 
 
@@ -43,7 +44,7 @@ def workload(ds, normalize):
 
 
 def run(name, cfg, mode, steps=20):
-    for k in ("ACM_WIDE_SCALAR", "ACM_WIDE_PAIR"):
+    for k in ("ACM_WIDE_SCALAR", "ACM_WIDE_PAIR", "ACM_WIDE_VEC"):
         os.environ.pop(k, None)
     os.environ.update(MODES[mode])
     wl = workload(cfg["ds"], not cfg["s"])

@@ -372,6 +372,46 @@ class FakeLib:
         _view(c, m, n, ldc)[...] = out
         return 0
 
+    # ---- ACM-GCN++ residual branch ------------------------------------------------
+    @staticmethod
+    def _drop_obj(d):
+        return None if d is None else getattr(d, "_obj", d)
+
+    def acm_linear_fwd(self, n, f_in, f_out, x, ldx, w, ldw, bias, relu, drop, y, ldy, ws, wsb, stream):
+        out = _view(x, n, f_in, ldx).astype(np.float64) @ _view(w, f_out, f_in, ldw).astype(np.float64).T
+        if bias:
+            out = out + _vec(bias, f_out).astype(np.float64)[None, :]
+        if relu:
+            out = np.maximum(out, 0)
+        out = out * dropout_factors(self._drop_obj(drop), n, f_out)
+        _view(y, n, f_out, ldy)[...] = out
+        return 0
+
+    def acm_bias_act(self, n, f, y, ldy, bias, relu, drop, stream):
+        Y = _view(y, n, f, ldy)
+        out = Y.astype(np.float64)
+        if bias:
+            out = out + _vec(bias, f).astype(np.float64)[None, :]
+        if relu:
+            out = np.maximum(out, 0)
+        Y[...] = out * dropout_factors(self._drop_obj(drop), n, f)
+        return 0
+
+    def acm_bias_act_bwd_workspace_bytes(self, n, f, out):
+        out._obj.value = 4 * f * min(max(n, 1), 1024)
+        return 0
+
+    def acm_bias_act_bwd(self, n, f, y, ldy, dy, lddy, keep_scale, relu, g, ldg, d_bias, ws, wsb, defer, stream):
+        Y, dY = _view(y, n, f, ldy).astype(np.float64), _view(dy, n, f, lddy).astype(np.float64)
+        if relu:
+            G = np.where(Y > 0, dY * keep_scale, 0.0)
+        elif keep_scale != 1.0:
+            G = np.where(Y != 0, dY * keep_scale, 0.0)
+        else:
+            G = dY
+        _view(g, n, f, ldg)[...] = G
+        return self._emit(defer, [(_vec(d_bias, f), G.sum(0))])
+
     def acm_gemm_split(self, ta, tb, m, n, k, a, lda, b, ldb, c, ldc, split, c2, ldc2, relu, ws, wsb, stream):
         A = _view(a, k, m, lda).T if ta else _view(a, m, k, lda)
         B = _view(b, n, k, ldb).T if tb else _view(b, k, n, ldb)

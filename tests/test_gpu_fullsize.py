@@ -87,7 +87,12 @@ def _elementwise(got, ref):
     return float(q[0]), float(q[1]), float(e.max())
 
 
-def _compare_grads(model, params, tag, rec):
+def _compare_grads(model, params, tag, rec, params64=None):
+    """Every parameter gradient against the oracle.  Yardstick: GRAD_TOL of the gradient's own range plus 1e-6 (sums of
+    ~1e5 terms of size ~1e-5: the fp32 noise floor of a gradient whose range is itself 1e-4).  When the float64 oracle
+    gradients are given (`params64`), a gradient may instead be as far from them as 5x the fp32 oracle's OWN error:
+    the row-normalised features of this workload reach 1e4, so fp32 sums of the first layer's weight gradients carry
+    absolute errors of 1e-2 in any summation order -- the reference's included."""
     worst = 0.0
     for k, p in model.named_parameters():
         if k in ("fea_param", "xX_param"):
@@ -97,12 +102,37 @@ def _compare_grads(model, params, tag, rec):
             assert p.grad is None, k
             continue
         assert p.grad is not None, k
-        d, rel = _errs(p.grad.cpu(), rg)
+        got = p.grad.cpu()
+        d, rel = _errs(got, rg)
+        tol = GRAD_TOL * float(rg.abs().max()) + 1e-6
+        if params64 is not None:
+            r64 = params64[k].grad
+            d64, _ = _errs(got, r64)
+            e_ref, _ = _errs(rg, r64)
+            rec[f"grad64:{k}"] = [d64, e_ref]
+            ok = d < tol or d64 <= max(5.0 * e_ref, tol)
+        else:
+            ok = d < tol
         rec[f"grad:{k}"] = rel
         worst = max(worst, rel)
-        # GRAD_TOL of the gradient's own range (the existing small-graph tests use 1e-4 with a floor of 1)
-        assert rel < GRAD_TOL, (tag, k, d, rel)
+        assert ok, (tag, k, d, rel, rec.get(f"grad64:{k}"))
     return worst
+
+
+def _oracle_step(params, x, y, tr, ops_t, structure, variant, dtype=torch.float32, **kw):
+    """oracle.gcn_forward + loss + backward in `dtype`; returns (logits, loss, params with .grad)."""
+    low_t, high_t, un_t = ops_t
+    if dtype != torch.float32:
+        conv = lambda t: torch.sparse_csr_tensor(t.crow_indices(), t.col_indices(), t.values().to(dtype), size=t.shape)  # noqa: E731
+        low_t, high_t, un_t = conv(low_t), conv(high_t), conv(un_t)
+    ps = {k: v.detach().to(dtype).clone().requires_grad_(True) for k, v in params.items()}
+    if "masks" in kw and kw["masks"]:
+        kw = dict(kw, masks={k: v.to(dtype) for k, v in kw["masks"].items()})
+    ref = O.gcn_forward(ps, x.to(dtype), low_t, high_t, un_t if structure else None, model_type="acmgcnp",
+                        variant=bool(variant), structure_info=structure, attn_layernorm=True, training=True, **kw)
+    loss = O.nll_loss_on(ref, y, torch.from_numpy(tr))
+    loss.backward()
+    return ref.detach(), loss.detach(), ps
 
 
 def _factors(state, p, tag, n, c):
@@ -136,15 +166,12 @@ def test_twitch_shaped_step_matches_oracle(variant, structure, order):
             for nm in ("low", "high", "mlp", "struc_low"):
                 getattr(m, f"layer_norm_{nm}").weight.uniform_(0.5, 1.5)
                 getattr(m, f"layer_norm_{nm}").bias.uniform_(-0.5, 0.5)
-    params = {k: v.detach().cpu().clone().requires_grad_(True) for k, v in model.named_parameters()
-              if k not in ("fea_param", "xX_param")}
-    low_t, high_t, un_t = _oracle_operands(wl)
+    p0 = {k: v.detach().cpu().clone() for k, v in model.named_parameters() if k not in ("fea_param", "xX_param")}
+    ops_t = _oracle_operands(wl)
     t0 = time.time()
-    ref = O.gcn_forward(params, x, low_t, high_t, un_t if structure else None, model_type="acmgcnp",
-                        variant=bool(variant), structure_info=structure, attn_layernorm=True, dropout=0.0, training=True)
-    ref_loss = O.nll_loss_on(ref, y, torch.from_numpy(tr))
-    ref_loss.backward()
+    ref, ref_loss, params = _oracle_step(p0, x, y, tr, ops_t, structure, variant, dropout=0.0)
     t_oracle = time.time() - t0
+    _, _, params64 = _oracle_step(p0, x, y, tr, ops_t, structure, variant, dtype=torch.float64, dropout=0.0)
 
     model = model.to(DEV)
     ops = DD.make_sharded_operators(wl["low"], wl["deg"], DEV, with_structure=bool(structure))
@@ -177,7 +204,7 @@ def test_twitch_shaped_step_matches_oracle(variant, structure, order):
     rec["loss"], rec["loss_ref"] = float(loss), float(ref_loss)
     # the mean of 84 k terms spanning five orders of magnitude, summed in fp32 in different orders on both sides
     assert abs(float(loss) - float(ref_loss)) < LOSS_TOL * max(1.0, abs(float(ref_loss)))
-    rec["grad_worst_rel"] = _compare_grads(model, params, "autograd", rec)
+    rec["grad_worst_rel"] = _compare_grads(model, params, "autograd", rec, params64)
     # (2) the fused training-step route: same numbers through acm_conv_fwd_tail + the deferred flush
     opt = acm_gnn_amd.FusedAdamW(model.parameters(), lr=0.0, weight_decay=0.0)
     step = T.TrainStep(model, opt, xd, ops, yd, w, use_graph=False, fused_dropout=False)
@@ -185,7 +212,7 @@ def test_twitch_shaped_step_matches_oracle(variant, structure, order):
     loss2 = step._forward_backward()
     torch.cuda.synchronize()
     assert abs(float(loss2) - float(ref_loss)) < LOSS_TOL * max(1.0, abs(float(ref_loss)))
-    rec["grad_worst_rel_fused_step"] = _compare_grads(model, params, "train-step", {})
+    rec["grad_worst_rel_fused_step"] = _compare_grads(model, params, "train-step", {}, params64)
     _record(f"twitch/v{variant}s{structure}/{order}", **rec)
 
 
@@ -220,15 +247,13 @@ def test_twitch_shaped_step_with_counter_based_dropout_matches_oracle(variant, s
     torch.cuda.synchronize()
     masks = {"x": torch.from_numpy(_factors(st, p_drop, 0, n, x.shape[1]) > 0).float(),
              "hidden": torch.from_numpy(_factors(st, p_drop, 1, n, 64) > 0).float()}
-    low_t, high_t, un_t = _oracle_operands(wl)
-    ref = O.gcn_forward(params, x, low_t, high_t, un_t if structure else None, model_type="acmgcnp",
-                        variant=bool(variant), structure_info=structure, attn_layernorm=True, dropout=p_drop,
-                        training=True, masks=masks)
-    ref_loss = O.nll_loss_on(ref, y, torch.from_numpy(tr))
-    ref_loss.backward()
+    ops_t = _oracle_operands(wl)
+    p0 = {k: v.detach() for k, v in params.items()}
+    _, ref_loss, params = _oracle_step(p0, x, y, tr, ops_t, structure, variant, dropout=p_drop, masks=masks)
+    _, _, params64 = _oracle_step(p0, x, y, tr, ops_t, structure, variant, dtype=torch.float64, dropout=p_drop, masks=masks)
     assert abs(float(loss) - float(ref_loss)) < LOSS_TOL * max(1.0, abs(float(ref_loss))), (float(loss), float(ref_loss))
     rec = {"loss": float(loss), "loss_ref": float(ref_loss)}
-    rec["grad_worst_rel"] = _compare_grads(model, params, "dropout-step", rec)
+    rec["grad_worst_rel"] = _compare_grads(model, params, "dropout-step", rec, params64)
     _record(f"twitch-dropout/v{variant}s{structure}", **rec)
 
 

@@ -108,13 +108,14 @@ def test_load_torch_adam_checkpoint_and_step_on_device():
     assert sd["state"][0]["step"].device.type == "cpu"               # what the advisor's finding is about
     sd_cpu = {"state": {k: {kk: vv.cpu() for kk, vv in v.items()} for k, v in sd["state"].items()},
               "param_groups": sd["param_groups"]}
+    import copy
     for which in (sd, sd_cpu):
         mine_p = [torch.nn.Parameter(p.detach().clone()) for p in ref_p]
         mine = FusedAdam(mine_p, lr=0.01, weight_decay=5e-4)
-        mine.load_state_dict(which)
+        mine.load_state_dict(copy.deepcopy(which))      # load_state_dict adopts tensors that already sit on the device
         cont_p = [torch.nn.Parameter(p.detach().clone()) for p in ref_p]
         cont = torch.optim.Adam(cont_p, lr=0.01, weight_decay=5e-4, foreach=False)
-        cont.load_state_dict(sd)
+        cont.load_state_dict(copy.deepcopy(sd))
         for p, q, gr in zip(mine_p, cont_p, grads):
             p.grad, q.grad = (2 * gr).to(DEV), (2 * gr).to(DEV)
         mine.step()

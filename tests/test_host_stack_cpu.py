@@ -7,6 +7,8 @@ import numpy as np
 import pytest
 import torch
 
+import torch.nn.functional as F
+
 import fake_lib
 from conftest import GOLDEN, golden_files, graph_tensors, load_npz
 
@@ -230,6 +232,73 @@ def test_captured_train_step_starts_from_the_eager_state(monkeypatch):
     step2._eager()
     step2._restore(snap2)
     assert all(float(v.abs().sum()) == 0.0 for st in opt2.state.values() for v in st.values())
+
+
+def _model_grads(model):
+    return {k: p.grad.clone() for k, p in model.named_parameters() if p.grad is not None}
+
+
+def test_acmgcnpp_residual_kernel_dense_and_csr_features(monkeypatch):
+    """The ACM-GCN++ residual branch on the library's kernels (acm_linear_fwd / acm_spmm_v + acm_bias_act /
+    acm_bias_act_bwd): dense features against the oracle (models.py:26-27,55-56,73), CSR features against dense."""
+    fake_lib.install(monkeypatch)
+    from oracle import acm_oracle as oracle
+    from acm_gnn_amd import GCN, SparseFeatures
+    low, high, un, g = graph_tensors("geometric")
+    n = low.shape[0]
+    gen = torch.Generator().manual_seed(3)
+    x = torch.randn(n, 12, generator=gen) * (torch.rand(n, 12, generator=gen) < 0.3)
+    y = torch.randint(0, 3, (n,), generator=gen)
+    idx = torch.arange(0, n, 2)
+    outs = {}
+    for kind in ("dense", "csr"):
+        torch.manual_seed(1)
+        model = GCN(12, 16, 3, 2, n, 0.0, "acmgcnpp", 1, variant=True, attn_layernorm=True)
+        xin = SparseFeatures.from_torch(x) if kind == "csr" else x
+        out = model(xin, low, high, un)
+        F.nll_loss(F.log_softmax(out, 1)[idx], y[idx]).backward()
+        outs[kind] = (out.detach(), _model_grads(model), model)
+    _close(outs["csr"][0], outs["dense"][0].numpy(), "csr vs dense logits", **FWD)
+    for k, v in outs["dense"][1].items():
+        _close(outs["csr"][1][k], v.numpy(), "csr vs dense " + k)
+    model = outs["dense"][2]
+    params = {k: v.detach().clone().double().requires_grad_(True) for k, v in model.named_parameters()
+              if k not in ("fea_param", "xX_param")}
+    ref = oracle.gcn_forward(params, x.double(), low.double(), high.double(), un.double(), model_type="acmgcnpp",
+                             variant=True, structure_info=1, attn_layernorm=True)
+    oracle.nll_loss_on(ref, y, idx).backward()
+    _close(outs["dense"][0], ref.detach().float().numpy(), "logits vs oracle", **FWD)
+    for k in ("mlpX.lins.0.weight", "mlpX.lins.0.bias", "gcns.0.weight_low", "gcns.1.weight_mlp"):
+        _close(outs["dense"][1][k], params[k].grad.float().numpy(), k + " vs oracle")
+
+
+@pytest.mark.parametrize("variant,nlayers", [(False, 2), (True, 3)])
+def test_snowball_model_matches_the_reference_wiring(variant, nlayers, monkeypatch):
+    """acmsnowball (ACM-Geometric/models.py:38-39,57-64 with the missing nnodes supplied, quirk Q2) against the oracle's
+    literal restatement of that forward."""
+    fake_lib.install(monkeypatch)
+    from oracle import acm_oracle as oracle
+    from acm_gnn_amd import GCN
+    low, high, un, g = graph_tensors("geometric")
+    n = low.shape[0]
+    gen = torch.Generator().manual_seed(4)
+    x = torch.randn(n, 9, generator=gen)
+    y = torch.randint(0, 4, (n,), generator=gen)
+    idx = torch.arange(1, n, 3)
+    torch.manual_seed(2)
+    model = GCN(9, 8, 4, nlayers, n, 0.0, "acmsnowball", 0, variant=variant)
+    assert [m.in_features for m in model.gcns] == [9 + 8 * k for k in range(nlayers + 1)]
+    out = model(x, low, high, un)
+    F.nll_loss(F.log_softmax(out, 1)[idx], y[idx]).backward()
+    params = {k: v.detach().clone().double().requires_grad_(True) for k, v in model.named_parameters()
+              if k not in ("fea_param", "xX_param")}
+    ref = oracle.snowball_forward(params, x.double(), low.double(), high.double(), nlayers=nlayers, variant=variant)
+    oracle.nll_loss_on(ref, y, idx).backward()
+    _close(out, ref.detach().float().numpy(), "snowball logits", **FWD)
+    for k, p in model.named_parameters():
+        if k in params and params[k].grad is not None:
+            assert p.grad is not None, k
+            _close(p.grad, params[k].grad.float().numpy(), k)
 
 
 def test_structure_info_with_acmgcn_is_an_error(monkeypatch):
