@@ -24,7 +24,7 @@ EXPORTED_SYMBOLS = (
     "acm_conv_bwd_local", "acm_conv_bwd_spmm", "acm_conv_agg_fwd", "acm_conv_agg_bwd_workspace_bytes",
     "acm_conv_agg_bwd", "acm_nll_loss_workspace_bytes", "acm_nll_loss", "acm_adam_step", "acm_dropout",
     "acm_reduce_flush", "acm_conv_fwd_tail_workspace_bytes", "acm_conv_fwd_tail", "acm_shard_plan",
-    "acm_linear_fwd", "acm_bias_act", "acm_bias_act_bwd_workspace_bytes", "acm_bias_act_bwd",
+    "acm_conv_acmii_fwd", "acm_linear_fwd", "acm_bias_act", "acm_bias_act_bwd_workspace_bytes", "acm_bias_act_bwd",
 )
 
 
@@ -128,6 +128,19 @@ class ConvAggBwd(C.Structure):
                 ("head_stats", C.c_void_p), ("ld_head_stats", C.c_int64)]
 
 
+class ConvAcmiiFwd(C.Structure):
+    _fields_ = [("f_in", C.c_int32), ("f_pad", C.c_int32), ("f_out", C.c_int32), ("layernorm", C.c_int32),
+                ("scale", C.c_float),
+                ("xg", C.c_void_p), ("ld_xg", C.c_int64), ("xs", C.c_void_p), ("ld_xs", C.c_int64),
+                ("w_low", C.c_void_p), ("w_high", C.c_void_p), ("w_mlp", C.c_void_p), ("ld_w", C.c_int64),
+                ("att_vec", C.c_void_p * 4), ("ln_weight", C.c_void_p * 4), ("ln_bias", C.c_void_p * 4),
+                ("att_mix", C.c_void_p),
+                ("out", C.c_void_p), ("ld_out", C.c_int64), ("pre", C.c_void_p), ("ld_pre", C.c_int64),
+                ("att", C.c_void_p), ("zlh", C.c_void_p), ("ld_zlh", C.c_int64), ("zi", C.c_void_p), ("ld_zi", C.c_int64),
+                ("post_scale", C.c_void_p), ("ld_post_scale", C.c_int64), ("post_relu", C.c_int32),
+                ("row_scale", C.c_void_p), ("post_drop", Dropout)]
+
+
 class Loss(C.Structure):
     _fields_ = [("n_classes", C.c_int32), ("labels", C.c_void_p), ("row_weight", C.c_void_p),
                 ("loss", C.c_void_p), ("dlogits", C.c_void_p), ("ld_dlogits", C.c_int64)]
@@ -177,6 +190,7 @@ def _declare(lib):
     lib.acm_csr_destroy.restype = None
     lib.acm_csr_info.argtypes = [vp, C.POINTER(CsrInfo)]
     lib.acm_shard_plan.argtypes = [i64, vp, i32, i64, vp]
+    lib.acm_conv_acmii_fwd.argtypes = [vp, C.POINTER(ConvAcmiiFwd), vp, sz, vp]
     lib.acm_linear_fwd.argtypes = [i64, i64, i64, vp, i64, vp, i64, vp, i32, vp, vp, i64, vp, sz, vp]
     lib.acm_bias_act.argtypes = [i64, i32, vp, i64, vp, i32, vp, vp]
     lib.acm_bias_act_bwd_workspace_bytes.argtypes = [i64, i32, C.POINTER(sz)]

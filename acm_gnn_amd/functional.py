@@ -769,8 +769,15 @@ class AcmConvFunction(torch.autograd.Function):
             if ops.sharded:
                 raise NotImplementedError("general operator pairs are not row-sharded")
             ctx.agg_first = False
-        if ctx.agg_first:
+        # ACMII first layer with a narrow input: gather the input rows and recompute relu(x_j [W_L | W_H]) per edge on
+        # the matrix pipe instead of gathering the 2F-wide projected rows (acm_conv_acmii_fwd = K1 + K2)
+        ctx.recompute = (cfg.relu_before and not cfg.relu_after and cfg.relu_mlp and k == 3 and f == 64 and f_in <= 8
+                         and not sparse_x and not general and hops == 1 and not cfg.gather_bf16
+                         and os.environ.get("ACM_ACMII_RECOMPUTE", "1") != "0")
+        if ctx.agg_first or ctx.recompute:
             fp = 4 if f_in <= 4 else (8 if f_in <= 8 else 16)
+            if ctx.recompute:
+                fp = 8
             if x.shape[1] == fp:
                 xpad = x
             else:
@@ -781,6 +788,9 @@ class AcmConvFunction(torch.autograd.Function):
             else:
                 xg = _gather_rows(ops, xpad)
             wl, wh, wm = (_as_f32c(t, "weight") for t in (w_low, w_high, w_mlp))
+            if ctx.recompute:
+                w3 = (wl, wh, wm)
+                x = x[:, :f_in].contiguous() if zero_padded else x      # saved for K5 (dWcat = X^T dZ)
         else:
             if zero_padded:
                 x = x[:, :f_in].contiguous()
@@ -843,6 +853,34 @@ class AcmConvFunction(torch.autograd.Function):
                                "(structure_info is only valid with acmgcnp/acmgcnpp)")
         out = torch.empty(n, f, dtype=_F32, device=dev)
         att = torch.empty(n, 4, dtype=_F32, device=dev)
+        if ctx.recompute:
+            zlh = torch.empty(n, 2 * f, dtype=_F32, device=dev)
+            zi = torch.empty(n, f, dtype=_F32, device=dev)
+            pre = torch.empty(n, 2 * f, dtype=_F32, device=dev)
+            p = _lib.ConvAcmiiFwd()
+            p.f_in, p.f_pad, p.f_out, p.layernorm, p.scale = f_in, fp, f, int(cfg.layernorm), cfg.scale
+            p.xg, p.ld_xg = xg.data_ptr(), xg.stride(0)
+            p.xs, p.ld_xs = xpad.data_ptr(), xpad.stride(0)
+            p.w_low, p.w_high, p.w_mlp, p.ld_w = wl.data_ptr(), wh.data_ptr(), wm.data_ptr(), f
+            p.att_vec, p.ln_weight, p.ln_bias = _ptr_array(vecs), _ptr_array(lnw), _ptr_array(lnb)
+            p.att_mix = mix.data_ptr()
+            p.out, p.ld_out = out.data_ptr(), out.stride(0)
+            p.pre, p.ld_pre = pre.data_ptr(), pre.stride(0)
+            p.att = att.data_ptr()
+            p.zlh, p.ld_zlh = zlh.data_ptr(), zlh.stride(0)
+            p.zi, p.ld_zi = zi.data_ptr(), zi.stride(0)
+            if ops.implicit:
+                p.row_scale = ops.row_scale.data_ptr()
+            set_post(p)
+            ws = ops.low.workspace(2 * f)
+            with _device_ctx(dev), _Timed(f"conv_acmii_fwd/F{f}i{f_in}"):
+                st = lib.acm_conv_acmii_fwd(ops.low.handle, C.byref(p), _vp(ws), ws.numel() * 4, _stream())
+            _lib.check(st, "acm_conv_acmii_fwd")
+            ctx.agg_first, ctx.tail, ctx.sparse_x = False, None, None
+            ctx.ops, ctx.cfg = ops, cfg
+            ctx.save_for_backward(x, *w3, zlh, zi, pre, mix, *vecs, *lnw, *lnb)
+            ctx.mark_non_differentiable(att)
+            return out, att
         if ctx.agg_first:
             p = _lib.ConvAggFwd()
             p.f_in, p.f_pad, p.f_out = f_in, fp, f

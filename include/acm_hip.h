@@ -502,6 +502,42 @@ int acm_conv_agg_bwd_workspace_bytes(int64_t n_rows, int f_in, int f_out, size_t
 int acm_conv_agg_bwd(int64_t n_rows, const acm_conv_agg_bwd_t* p,
                      void* workspace, size_t workspace_bytes, acm_stream_t stream);
 
+/* ------------------------------- ACMII first layer: recompute on gather (K1 + K2) --
+ * ACMII (ACM-Geometric/layers.py:94-99; the default of ACM-Geometric, parse.py:57) applies the ReLU between the
+ * projection and the filter, H_L = A_low relu(X W_L), H_H = (I - A_low) relu(X W_H), so the aggregate-first rewrite
+ * does not apply and acm_gemm + acm_conv_fwd gather 2 F projected floats per edge.  When the layer input is narrow
+ * (f_in <= 8, f_out = 64: the first layer on twitch-gamer) this entry point gathers the neighbour's INPUT row
+ * (f_pad = 8 floats, a table that fits the L2) and recomputes relu(x_j [W_L | W_H]) per edge on the matrix pipe
+ * (v_mfma_f32_16x16x4_f32, 16 neighbours per tile): same outputs as the two calls it replaces -- out, pre = [pre_L |
+ * pre_H] and att as acm_conv_fwd, zlh = relu(X [W_L | W_H]) and zi = relu(X W_I) as the GEMM (K4's masks / self rows,
+ * K3's s_mlp) -- equal to them up to fp32 re-association.  Three channels.  Values of an explicit operator must be
+ * non-negative (relu(a z) = a relu(z)).  Workspace: acm_spmm_workspace_bytes(a_low, 2 * f_out).  The backward is
+ * acm_conv_bwd_local / acm_conv_bwd_spmm / acm_gemm as for the literal form. */
+typedef struct {
+    int32_t f_in, f_pad, f_out;        /* f_pad = 8, f_out = 64                                                */
+    int32_t layernorm;
+    float   scale;
+    const float* xg; int64_t ld_xg;    /* input rows indexed by column id, f_pad long, zero padded, 8-byte aligned */
+    const float* xs; int64_t ld_xs;    /* input rows of the local nodes                                          */
+    const float* w_low; const float* w_high; const float* w_mlp; int64_t ld_w;   /* [f_in, f_out] each          */
+    const float* att_vec[4];
+    const float* ln_weight[4];
+    const float* ln_bias[4];
+    const float* att_mix;              /* 3 x 3 */
+    float* out; int64_t ld_out;        /* [n_rows, f_out]                                                        */
+    float* pre; int64_t ld_pre;        /* [n_rows, 2 f_out]                                                      */
+    float* att;                        /* [n_rows, 4]                                                            */
+    float* zlh; int64_t ld_zlh;        /* [n_rows, 2 f_out]  relu(X [W_L | W_H])                                 */
+    float* zi;  int64_t ld_zi;         /* [n_rows, f_out]    relu(X W_I)                                         */
+    const float* post_scale; int64_t ld_post_scale;   /* fused post-op, as in acm_conv_fwd_t                    */
+    int32_t post_relu;
+    const float* row_scale;            /* pattern-only a_low: 1 / d_i                                            */
+    acm_dropout_t post_drop;
+} acm_conv_acmii_fwd_t;
+
+int acm_conv_acmii_fwd(const acm_csr_t* a_low, const acm_conv_acmii_fwd_t* p,
+                       void* workspace, size_t workspace_bytes, acm_stream_t stream);
+
 /* ------------------------------------------------ fused step tail (loss) --
  *   loss   = sum_i w_i * (logsumexp(z_i) - z_i[y_i])
  *   dz_i   = w_i * (softmax(z_i) - onehot(y_i))

@@ -372,6 +372,34 @@ class FakeLib:
         _view(c, m, n, ldc)[...] = out
         return 0
 
+    # ---- ACMII first layer, recompute on gather: K1 + K2 through the doubles of those two calls --------------------
+    def acm_conv_acmii_fwd(self, handle, pp, ws, wsb, stream):
+        from acm_gnn_amd import _lib
+        p = pp._obj
+        g = self._handles[handle.value if isinstance(handle, C.c_void_p) else int(handle)]
+        n, F, fi = g.n_rows, p.f_out, p.f_in
+        if F != 64 or p.f_pad != 8 or fi > 8:
+            self._err = b"acm_conv_acmii_fwd: unsupported shape"
+            return 4
+        w = np.concatenate([_view(ptr, fi, F, p.ld_w) for ptr in (p.w_low, p.w_high, p.w_mlp)], 1).astype(np.float64)
+        zg = np.maximum(_view(p.xg, g.n_cols, fi, p.ld_xg).astype(np.float64) @ w, 0)          # relu(X Wcat), all nodes
+        zs = np.maximum(_view(p.xs, n, fi, p.ld_xs).astype(np.float64) @ w, 0)
+        _view(p.zlh, n, 2 * F, p.ld_zlh)[...] = zs[:, :2 * F]
+        _view(p.zi, n, F, p.ld_zi)[...] = zs[:, 2 * F:]
+        self._keep_acmii = zg32 = np.ascontiguousarray(zg[:, :2 * F].astype(np.float32))
+        q = _lib.ConvFwd()
+        q.f_out, q.n_channels, q.relu_after, q.relu_mlp, q.layernorm, q.scale = F, 3, 0, 1, p.layernorm, p.scale
+        q.g_low, q.ld_g_low = zg32.ctypes.data, 2 * F
+        q.g_high, q.ld_g_high = zg32.ctypes.data + 4 * F, 2 * F
+        q.s_high, q.ld_s_high = p.zlh + 4 * F, p.ld_zlh
+        q.s_mlp, q.ld_s_mlp = p.zi, p.ld_zi
+        for c in range(4):
+            q.att_vec[c], q.ln_weight[c], q.ln_bias[c] = p.att_vec[c], p.ln_weight[c], p.ln_bias[c]
+        q.att_mix, q.out, q.ld_out, q.pre, q.ld_pre, q.att = p.att_mix, p.out, p.ld_out, p.pre, p.ld_pre, p.att
+        q.post_scale, q.ld_post_scale, q.post_relu, q.row_scale, q.post_drop = (p.post_scale, p.ld_post_scale, p.post_relu,
+                                                                                p.row_scale, p.post_drop)
+        return self.acm_conv_fwd(handle, C.byref(q), ws, wsb, stream)
+
     # ---- ACM-GCN++ residual branch ------------------------------------------------
     @staticmethod
     def _drop_obj(d):

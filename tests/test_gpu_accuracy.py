@@ -25,7 +25,7 @@ def _load(name):
         x = sp.csr_matrix((g["feat_vals"], g["feat_indices"], g["feat_indptr"]), shape=(n, int(g["feat_dim"]))).toarray()
         masks = [(g["train_mask"], g["val_mask"], g["test_mask"])]
         return n, torch.from_numpy(x.astype(np.float32)), torch.from_numpy(g["labels"]), g, masks
-    g = load_npz(os.path.join(GOLDEN, "graph_squirrel.npz"))
+    g = load_npz(os.path.join(GOLDEN, f"graph_{name}.npz"))          # squirrel, film: binary bag-of-words features
     n = int(g["n"])
     x = sp.csr_matrix((np.ones(len(g["feat_indices"]), np.float32), g["feat_indices"], g["feat_indptr"]),
                       shape=(n, int(g["feat_dim"]))).toarray()
@@ -40,17 +40,22 @@ def _cora_masks(split):
     return None
 
 
-@pytest.mark.parametrize("name", ["cora", "squirrel"])
+# name -> (mean |selected acc - reference run| bound, per-split bound); see the criterion below
+REPLAYS = {"cora": (0.002, 0.01), "squirrel": (0.004, 0.025), "film_v0": (0.004, 0.025), "film_v1": (0.004, 0.025)}
+
+
+@pytest.mark.parametrize("name", list(REPLAYS))
 def test_fixed_split_accuracy_matches_reference_run(name, monkeypatch):
     path = os.path.join(GOLDEN, f"accuracy_{name}.npz")
     if not os.path.exists(path):
         pytest.skip(f"{path} not generated")
     rec = load_npz(path)
     cfg = rec["cfg"]
+    dataset = cfg.get("dataset", name)
     from acm_gnn_amd import GCN, layers, train as T
     from acm_gnn_amd.graph import clear_cache
-    n, x, labels, g, masks = _load(name)
-    splits_path = os.path.join(GOLDEN, f"splits_{name}.npz")
+    n, x, labels, g, masks = _load(dataset)
+    splits_path = os.path.join(GOLDEN, f"splits_{dataset}.npz")
     if os.path.exists(splits_path):
         sp_rec = load_npz(splits_path)
         masks = {int(k.split("_")[1]): None for k in sp_rec if k.startswith("train_")}
@@ -115,13 +120,20 @@ def test_fixed_split_accuracy_matches_reference_run(name, monkeypatch):
     print(f"\n{name}: reference-run {100 * ref.mean():.2f} +- {100 * ref.std():.2f}  |  MI355X {100 * got.mean():.2f} "
           f"+- {100 * got.std():.2f}  | selected, per split {np.round(100 * (got - ref), 2).tolist()}"
           f"  | mean test-acc over the 2nd half of training, per split {np.round(100 * np.asarray(curve_gap), 2).tolist()} pp")
+    out_dir = os.path.join(os.path.dirname(GOLDEN), "..", "gpurun_out")
+    os.makedirs(out_dir, exist_ok=True)
+    with open(os.path.join(out_dir, f"accuracy_replay_{name}.json"), "w") as fh:
+        import json
+        json.dump({"config": cfg, "reference_run": ref.tolist(), "mi355x": got.tolist(),
+                   "mean_diff_pp": float(100 * (got.mean() - ref.mean())), "curve_gap_pp": (100 * np.asarray(curve_gap)).tolist()}, fh)
     # Parity criterion (+-0.2 pp): the test-accuracy curves, averaged over the second half of
     # training, agree to 0.2 pp on every split.  The *selected* accuracy (test acc at the arg-min of a flat validation
     # loss) is a noisier functional -- one epoch's difference moves it by more than a point, cf. the reference's own
-    # 0.9-2.2 pp split-to-split std -- so it is bounded per split by 2.5 pp and on average by 0.7 pp.
+    # 0.9-2.2 pp split-to-split std -- so it is bounded per split and on the mean over the splits (REPLAYS).
+    mean_bound, split_bound = REPLAYS[name]
     assert np.all(np.abs(curve_gap) <= 0.002), curve_gap
-    assert np.all(np.abs(got - ref) <= 0.025)
-    assert abs(got.mean() - ref.mean()) <= 0.007
+    assert np.all(np.abs(got - ref) <= split_bound), (got - ref)
+    assert abs(got.mean() - ref.mean()) <= mean_bound, (got.mean(), ref.mean())
 
 
 @pytest.mark.parametrize("name,n_splits", [("cora", 5), ("squirrel", 3)])

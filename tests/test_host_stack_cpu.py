@@ -301,6 +301,39 @@ def test_snowball_model_matches_the_reference_wiring(variant, nlayers, monkeypat
             _close(p.grad, params[k].grad.float().numpy(), k)
 
 
+@pytest.mark.parametrize("f_in", [7, 3])
+def test_acmii_recompute_host_path_equals_literal(f_in, monkeypatch):
+    """Host plumbing of the ACMII recompute-on-gather route (functional.AcmConvFunction -> acm_conv_acmii_fwd, then the
+    literal backward on the tensors that call saved) against the literal route and the oracle."""
+    fake_lib.install(monkeypatch)
+    from oracle import acm_oracle as oracle
+    from acm_gnn_amd import GraphConvolution
+    from acm_gnn_amd.graph import clear_cache
+    low, high, un, g = graph_tensors("geometric")
+    n = low.shape[0]
+    gen = torch.Generator().manual_seed(11)
+    x, go = torch.randn(n, f_in, generator=gen), torch.randn(n, 64, generator=gen)
+    res = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("ACM_ACMII_RECOMPUTE", mode)
+        clear_cache()
+        torch.manual_seed(3)
+        layer = GraphConvolution(f_in, 64, n, "acmgcnp", variant=True, attn_layernorm=True)
+        out = layer(x, low, high, None)
+        out.backward(go)
+        res[mode] = (out.detach(), _model_grads(layer), layer)
+    _close(res["1"][0], res["0"][0].numpy(), "recompute vs literal", **FWD)
+    for k, v in res["0"][1].items():
+        _close(res["1"][1][k], v.numpy(), "recompute vs literal " + k)
+    params = {k: v.detach().clone().double().requires_grad_(True) for k, v in res["1"][2].named_parameters()}
+    ref = oracle.layer_forward(params, x.double(), low.double(), high.double(), None, model_type="acmgcnp", variant=True,
+                               attn_layernorm=True)
+    ref.backward(go.double())
+    _close(res["1"][0], ref.detach().float().numpy(), "recompute vs oracle", **FWD)
+    for k, v in res["1"][1].items():
+        _close(v, params[k].grad.float().numpy(), k + " vs oracle")
+
+
 def test_structure_info_with_acmgcn_is_an_error(monkeypatch):
     """Reference quirk Q3: att_vec is 4x4 but acmgcn mixes 3 channels -> RuntimeError there too."""
     fake_lib.install(monkeypatch)
