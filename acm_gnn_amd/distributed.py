@@ -32,7 +32,7 @@ import numpy as np
 import torch
 
 from . import _lib
-from .graph import CsrGraph, FilterOperators, as_implicit, implicit_form
+from .graph import CsrGraph, FilterOperators, as_implicit, implicit_form, relabel_by_degree
 
 # Row-local work of a training step expressed in "edges per row": on the twitch-shaped graph the per-row kernels
 # (projections, head, K3a, output-layer tail, optimizer) take ~150 us for 168 k rows, the gathers ~180 us for 13.8 M
@@ -153,14 +153,17 @@ def _padded_columns(mat, plan):
     return m.indptr.astype(np.int32), plan.padded_ids(m.indices).astype(np.int32), m.data.astype(np.float32)
 
 
-def make_sharded_operators(low_csr, deg, device, group=None, with_structure=False, plan=None, row_cost=DEFAULT_ROW_COST):
+def make_sharded_operators(low_csr, deg, device, group=None, with_structure=False, plan=None, row_cost=DEFAULT_ROW_COST,
+                           relabel=False):
     """FilterOperators for this rank (or the unsharded ones when no process group is active).  ``plan``: a ShardPlan
-    (default: work-balanced blocks of this graph, identical on every rank because it is a function of indptr only)."""
+    (default: work-balanced blocks of this graph, identical on every rank because it is a function of indptr only).
+    ``relabel`` (single process): sort the node numbering by degree inside the operator (graph.relabel_by_degree)."""
     import torch.distributed as dist
     if group is None and not (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1):
         low = CsrGraph.from_scipy(low_csr, device)
         d = torch.from_numpy(np.ascontiguousarray(deg)).to(device) if with_structure else None
-        return as_implicit(FilterOperators(low, d))
+        ops = as_implicit(FilterOperators(low, d))
+        return relabel_by_degree(ops) if relabel else ops
     group = group if group is not None else dist.group.WORLD
     world, rank = dist.get_world_size(group), dist.get_rank(group)
     low_csr = low_csr.tocsr()

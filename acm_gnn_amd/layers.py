@@ -48,7 +48,7 @@ class GraphConvolution(nn.Module):
         # storage type of the gathered operand on the wide literal path: "fp32" (reference numerics) or "bf16"
         # (half the gather bytes, ~3 decimal digits on that operand; fp32 accumulation) -- BASELINE config 3
         self.gather_dtype = gather_dtype or os.environ.get("ACM_GATHER_DTYPE", "fp32")
-        self.att_low, self.att_high, self.att_mlp = 0, 0, 0
+        self._att_raw, self._att_inv = None, None            # see the att_low / att_high / att_mlp properties
         dev = _default_device()
 
         def new(*shape):
@@ -95,11 +95,14 @@ class GraphConvolution(nn.Module):
         }
 
     def forward(self, input, adj_low, adj_high=None, adj_low_unnormalized=None, post_relu=False, post_scale=None,
-                post_drop=None):
+                post_drop=None, rows_permuted=False):
         """Reference signature plus optional keyword arguments: ``post_relu`` / ``post_scale`` fuse the
         caller's ``dropout(relu(out))`` (post_scale = keep-mask / (1 - p)) into the kernel epilogue;
         ``post_drop = (p, tag, functional.DropoutState)`` does the same with the mask generated in registers.
-        ``input`` may carry zero columns beyond ``in_features`` (functional.dropout(..., pad_to=...))."""
+        ``input`` may carry zero columns beyond ``in_features`` (functional.dropout(..., pad_to=...)).
+        ``rows_permuted``: the operators are relabelled (graph.relabel_by_degree) and the caller already works in
+        that numbering -- input, post_scale and the result are rows of the relabelled graph (models.GCN keeps the
+        hidden activations there); otherwise the layer translates at its boundary."""
         mt = self.model_type
         if mt == "mlp":
             return AF.mm(input, self.weight_mlp)
@@ -115,16 +118,48 @@ class GraphConvolution(nn.Module):
             ops = adj_low
         else:
             ops = operators_for(adj_low, adj_high, adj_low_unnormalized if cfg.n_channels == 4 else None)
-        # an output layer without post-op may take a pending functional.fused_loss_tail request (row phase + loss + K3)
-        AF._TAIL_LAYER = bool(self.output_layer) and not post_relu and post_scale is None and post_drop is None
+        params = self._param_dict()
+        translate = ops.perm is not None and not rows_permuted
+        if ops.perm is not None:
+            if cfg.n_channels == 4:                       # struc_low is a parameter in the caller's numbering
+                params["struc_low"] = self.struc_low.index_select(0, ops.perm)
+            if translate:
+                input = input.permute_rows(ops.perm) if isinstance(input, SparseFeatures) else input.index_select(0, ops.perm)
+                if post_scale is not None:
+                    post_scale = post_scale.index_select(0, ops.perm)
+        # an output layer without post-op may take a pending functional.fused_loss_tail request (row phase + loss + K3);
+        # the request's labels / weights are rows of the numbering the layer works in
+        AF._TAIL_LAYER = (bool(self.output_layer) and not post_relu and post_scale is None and post_drop is None
+                          and not translate)
         try:
-            out, att = AF.acm_conv(input, self._param_dict(), ops, cfg, post_relu, post_scale, post_drop)
+            out, att = AF.acm_conv(input, params, ops, cfg, post_relu, post_scale, post_drop)
         finally:
             AF._TAIL_LAYER = False
-        self.att_low, self.att_high, self.att_mlp = att[:, 0:1], att[:, 1:2], att[:, 2:3]
-        if cfg.n_channels == 4:
-            self.att_struc_vec_low = att[:, 3:4]
+        if translate:
+            out = out.index_select(0, ops.inv_perm)
+        # the mixing weights stay where the kernel wrote them; the attributes translate rows when they are read
+        self._att_raw, self._att_inv, self._att_k = att, ops.inv_perm, cfg.n_channels
         return out
+
+    # After a forward the reference's layer holds att_low / att_high / att_mlp (/ att_struc_vec_low): N x 1 tensors, 0
+    # before the first call (layers.py:17, 91, 107).  Here they are views of the kernel's [n, 4] output, translated
+    # back to the caller's node numbering on access when the operators are relabelled.
+    def _att_col(self, c):
+        if self._att_raw is None:
+            return 0
+        if self._att_inv is not None:
+            self._att_raw, self._att_inv = self._att_raw.index_select(0, self._att_inv), None
+        return self._att_raw[:, c:c + 1]
+
+    att_low = property(lambda self: self._att_col(0))
+    att_high = property(lambda self: self._att_col(1))
+    att_mlp = property(lambda self: self._att_col(2))
+
+    @property
+    def att_struc_vec_low(self):
+        if self._att_raw is None or self._att_k != 4:
+            raise AttributeError("att_struc_vec_low exists after a forward with structure_info (layers.py:111)")
+        return self._att_col(3)
 
     def __repr__(self):
         return f"{self.__class__.__name__} ({self.in_features} -> {self.out_features})"

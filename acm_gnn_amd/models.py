@@ -121,13 +121,13 @@ class GCN(nn.Module):
                 x = AF.dropout(x, p, st, tag=0, pad_to=pad, row_offset=off)
             kw = {}
         if self.model_type == "acmsgc":
-            return self.gcns[0](x, adj_low, adj_high, adj_low_unnormalized)
+            return self.gcns[0](x, adj_low, adj_high, adj_low_unnormalized, rows_permuted=self._rows_permuted)
         if self.model_type == "acmgcnpp":
             xx = self._residual(x, adj_low, drop=(p, 2, st, off))
-        fea = self.gcns[0](x, adj_low, adj_high, adj_low_unnormalized, post_relu=True, post_drop=(p, 1, st), **kw)
+        fea = self.gcns[0](x, adj_low, adj_high, adj_low_unnormalized, post_relu=True, post_drop=(p, 1, st), **kw, rows_permuted=self._rows_permuted)
         if self.model_type == "acmgcnpp":
             fea = fea + xx
-        return self.gcns[1](fea, adj_low, adj_high, adj_low_unnormalized)
+        return self.gcns[1](fea, adj_low, adj_high, adj_low_unnormalized, rows_permuted=self._rows_permuted)
 
     def _forward_snowball(self, x, adj_low, adj_high, fused):
         """models.py:57-64: h_k = dropout(relu(layer_k([x | h_0 | ... | h_{k-1}]))), out = layer_last([x | h_0 | ...]).
@@ -145,16 +145,31 @@ class GCN(nn.Module):
         for k in range(self.nlayers):
             inp = x if k == 0 else torch.cat([x] + blocks, 1)
             if fused:
-                h = self.gcns[k](inp, adj_low, adj_high, None, post_relu=True, post_drop=(p, 1 + k, st))
+                h = self.gcns[k](inp, adj_low, adj_high, None, post_relu=True, post_drop=(p, 1 + k, st), rows_permuted=self._rows_permuted)
             else:
                 scale = None
                 if self.training and p > 0:
                     scale = F.dropout(self._ones_like_hidden(x.shape[0], self.gcns[k].out_features, x.device), p, training=True)
-                h = self.gcns[k](inp, adj_low, adj_high, None, post_relu=True, post_scale=scale)
+                h = self.gcns[k](inp, adj_low, adj_high, None, post_relu=True, post_scale=scale, rows_permuted=self._rows_permuted)
             blocks.append(h)
-        return self.gcns[-1](torch.cat([x] + blocks, 1), adj_low, adj_high, None)
+        return self.gcns[-1](torch.cat([x] + blocks, 1), adj_low, adj_high, None, rows_permuted=self._rows_permuted)
 
-    def forward(self, x, adj_low, adj_high=None, adj_low_unnormalized=None):
+    def forward(self, x, adj_low, adj_high=None, adj_low_unnormalized=None, rows_permuted=False):
+        """Reference signature.  With relabelled operators (graph.relabel_by_degree) the rows are translated ONCE here
+        -- x on the way in, the logits on the way out -- and every layer in between works in the relabelled numbering
+        (``rows_permuted=True``: the caller, e.g. train.TrainStep, already did and wants the result there too)."""
+        ops = adj_low if isinstance(adj_low, FilterOperators) else None
+        if ops is None and isinstance(adj_low, torch.Tensor):
+            from .graph import operators_for
+            four = self.structure_info and self.model_type in ("acmgcnp", "acmgcnpp")
+            ops = adj_low = operators_for(adj_low, adj_high, adj_low_unnormalized if four else None)
+        self._rows_permuted = ops is not None and ops.perm is not None
+        if self._rows_permuted and not rows_permuted:
+            x = x.permute_rows(ops.perm) if isinstance(x, SparseFeatures) else x.index_select(0, ops.perm)
+            return self._forward(x, adj_low, adj_high, adj_low_unnormalized).index_select(0, ops.inv_perm)
+        return self._forward(x, adj_low, adj_high, adj_low_unnormalized)
+
+    def _forward(self, x, adj_low, adj_high, adj_low_unnormalized):
         fused = self.fused_dropout and self.training and self.dropout > 0
         if fused and self.dropout_state is None:
             dev = x.values.device if isinstance(x, SparseFeatures) else x.device
@@ -170,7 +185,7 @@ class GCN(nn.Module):
         else:
             x = drop(x)
         if self.model_type == "acmsgc":
-            return self.gcns[0](x, adj_low, adj_high, adj_low_unnormalized)
+            return self.gcns[0](x, adj_low, adj_high, adj_low_unnormalized, rows_permuted=self._rows_permuted)
         if self.model_type == "acmgcnpp":
             xx = drop(self._residual(x, adj_low))
         # dropout(relu(fea1)) (models.py:70) rides the layer's epilogue: the keep-mask / (1 - p) tensor is what
@@ -179,7 +194,7 @@ class GCN(nn.Module):
         if self.training and self.dropout > 0:
             ones = self._ones_like_hidden(x.shape[0], self.gcns[0].out_features, x.device)
             scale = drop(ones)
-        fea = self.gcns[0](x, adj_low, adj_high, adj_low_unnormalized, post_relu=True, post_scale=scale)
+        fea = self.gcns[0](x, adj_low, adj_high, adj_low_unnormalized, post_relu=True, post_scale=scale, rows_permuted=self._rows_permuted)
         if self.model_type == "acmgcnpp":
             fea = fea + xx
-        return self.gcns[1](fea, adj_low, adj_high, adj_low_unnormalized)
+        return self.gcns[1](fea, adj_low, adj_high, adj_low_unnormalized, rows_permuted=self._rows_permuted)

@@ -15,6 +15,7 @@ import torch
 import torch.nn.functional as F
 
 from . import functional as AF
+from .graph import FilterOperators, SparseFeatures, operators_for
 
 _TORCH_DROPOUT = F.dropout          # to notice a patched F.dropout (mask replay in tests): see TrainStep
 
@@ -34,6 +35,19 @@ class TrainStep:
         self.model, self.opt = model, optimizer
         self.x, self.adj, self.adj_high, self.adj_un = x, adj, adj_high, adj_un
         self.labels, self.weights = labels, weights
+        # Relabelled operators (graph.relabel_by_degree; operators_for applies it to large graphs): the static inputs
+        # of the step -- features, labels, row weights -- are moved into the operator's numbering ONCE, and the step
+        # never leaves it (the loss does not care about the order of the rows).
+        self._permuted = False
+        ops = adj
+        if not isinstance(adj, FilterOperators) and isinstance(adj, torch.Tensor) and hasattr(model, "structure_info"):
+            four = model.structure_info and getattr(model, "model_type", "") in ("acmgcnp", "acmgcnpp")
+            ops = operators_for(adj, adj_high, adj_un if four else None)
+        if isinstance(ops, FilterOperators) and ops.perm is not None and hasattr(model, "_forward"):
+            self.adj = ops
+            self.x = x.permute_rows(ops.perm) if isinstance(x, SparseFeatures) else x.index_select(0, ops.perm)
+            self.labels, self.weights = labels.index_select(0, ops.perm), weights.index_select(0, ops.perm)
+            self._permuted = True
         self.graph, self.loss = None, None
         # counter-based dropout: this loop owns the step structure (one advance per optimizer step), so the
         # model may draw its masks inside the kernels; the advance rides FusedAdam's step-counter kernel
@@ -80,7 +94,10 @@ class TrainStep:
         phase, the loss and its own row-local backward as one kernel (AF.fused_loss_tail); when it does not qualify
         (wide output, structure channel, a wrapper around the output) the loss is its own launch."""
         with AF.fused_loss_tail(self.labels, self.weights) as tail:
-            out = self.model(self.x, self.adj, self.adj_high, self.adj_un)
+            if self._permuted:
+                out = self.model(self.x, self.adj, self.adj_high, self.adj_un, rows_permuted=True)
+            else:
+                out = self.model(self.x, self.adj, self.adj_high, self.adj_un)
         if tail.matches(out):
             return tail.loss, tail.dz, out
         loss, dz = AF.nll_loss_and_grad(out, self.labels, self.weights)   # = masked_nll(...).backward(), two launches less

@@ -346,16 +346,21 @@ def side_measurements(args, timed_graph_steps, model, opt, x, ops, y, w, fused_d
     other = "random" if args.node_order == "degree" else "degree"
     wl = D.bench_workload(args.dataset, seed=args.seed, node_order=other, uniform=args.uniform,
                           normalize_features=not (args.method in ("acmgcnp", "acmgcnpp") and args.structure_info))
-    ops2 = DD.make_sharded_operators(wl["low"], wl["deg"], dev, with_structure=bool(args.structure_info))
     n = wl["adj"].shape[0]
     x2, y2 = torch.from_numpy(wl["x"]).to(dev), torch.from_numpy(wl["y"]).to(dev)
-    torch.manual_seed(args.seed)
-    model2 = acm_gnn_amd.GCN(x2.shape[1], args.hidden, int(wl["y"].max()) + 1, 2, n, args.dropout, args.method,
-                             args.structure_info, variant=bool(args.variant), attn_layernorm=True).to(dev)
-    opt2 = acm_gnn_amd.FusedAdamW(model2.parameters(), lr=args.lr, weight_decay=args.weight_decay)
     w2 = T.row_weights(torch.from_numpy(wl["splits"][0]).to(dev), n, device=dev)
-    ms, _ = timed_graph_steps(T.TrainStep(model2, opt2, x2, ops2, y2, w2, use_graph=True, fused_dropout=fused_drop))
-    out[f"{other}_order_ms_per_step"] = round(ms, 4)
+    # the generator's random ids, (a) as they are, (b) with the degree relabelling done INSIDE the operator
+    # (graph.relabel_by_degree: what operators_for does for the drop-in route; TrainStep moves x / labels once)
+    for key, relabel in ((f"{other}_order_ms_per_step", False), (f"{other}_order_relabelled_in_operator_ms_per_step", True)):
+        if relabel and other != "random":
+            continue
+        ops2 = DD.make_sharded_operators(wl["low"], wl["deg"], dev, with_structure=bool(args.structure_info), relabel=relabel)
+        torch.manual_seed(args.seed)
+        model2 = acm_gnn_amd.GCN(x2.shape[1], args.hidden, int(wl["y"].max()) + 1, 2, n, args.dropout, args.method,
+                                 args.structure_info, variant=bool(args.variant), attn_layernorm=True).to(dev)
+        opt2 = acm_gnn_amd.FusedAdamW(model2.parameters(), lr=args.lr, weight_decay=args.weight_decay)
+        ms, _ = timed_graph_steps(T.TrainStep(model2, opt2, x2, ops2, y2, w2, use_graph=True, fused_dropout=fused_drop))
+        out[key] = round(ms, 4)
     return out
 
 

@@ -334,6 +334,51 @@ def test_acmii_recompute_host_path_equals_literal(f_in, monkeypatch):
         _close(v, params[k].grad.float().numpy(), k + " vs oracle")
 
 
+@pytest.mark.parametrize("model_type,variant,s,sparse_x", [("acmgcnp", 0, 1, False), ("acmgcnp", 1, 0, False),
+                                                           ("acmgcnpp", 0, 0, True), ("acmsnowball", 1, 0, False)])
+def test_in_operator_relabelling_is_transparent(model_type, variant, s, sparse_x, monkeypatch):
+    """graph.relabel_by_degree: the operators live in a degree-sorted numbering, layers / GCN / TrainStep translate rows
+    at the boundary -- logits, attention weights and every gradient (struc_low included) equal the un-relabelled run."""
+    fake_lib.install(monkeypatch)
+    from acm_gnn_amd import GCN, SparseFeatures, graph, train as T
+    low, high, un, g = graph_tensors("geometric")
+    n = low.shape[0]
+    gen = torch.Generator().manual_seed(21)
+    x = torch.randn(n, 9, generator=gen) * (torch.rand(n, 9, generator=gen) < 0.5)
+    y = torch.randint(0, 3, (n,), generator=gen)
+    w = T.row_weights(torch.arange(0, n, 2), n)
+    res = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("ACM_RELABEL", mode)
+        graph.clear_cache()
+        ops = graph.operators_for(low, high, un if s else None)
+        assert (ops.perm is not None) == (mode == "1")
+        if mode == "1":
+            d = np.diff(graph.explicit_arrays(ops)[0].numpy())        # (a raw self-loop is listed twice in the pattern-only form)
+            assert np.all(np.diff(d) <= 0) and sorted(ops.perm.tolist()) == list(range(n))
+        torch.manual_seed(5)
+        model = GCN(9, 16, 3, 2, n, 0.0, model_type, s, variant=bool(variant), attn_layernorm=True)
+        xin = SparseFeatures.from_torch(x) if sparse_x else x
+        out = model(xin, low, high, un)                                 # model-level translation (tensors, like the reference)
+        T.F.nll_loss(T.F.log_softmax(out, 1)[::2], y[::2]).backward()
+        att = model.gcns[0].att_low.detach().clone()
+        grads = _model_grads(model)
+        model.zero_grad(set_to_none=True)
+        out_l = model.gcns[0](xin, low, high, un if s else None)        # layer-level translation (the drop-in route)
+        step = T.TrainStep(model, torch.optim.SGD(model.parameters(), lr=0.0), xin, low, y, w, high, un, fused_dropout=False)
+        assert step._permuted == (mode == "1")
+        loss = step()
+        res[mode] = (out.detach(), grads, out_l.detach(), float(loss), _model_grads(model), att)
+    _close(res["1"][0], res["0"][0].numpy(), "logits", **FWD)
+    _close(res["1"][2], res["0"][2].numpy(), "layer output", **FWD)
+    _close(res["1"][5], res["0"][5].numpy(), "attention weights", **FWD)
+    assert abs(res["1"][3] - res["0"][3]) < 1e-6
+    for k, v in res["0"][1].items():
+        _close(res["1"][1][k], v.numpy(), k)
+    for k, v in res["0"][4].items():
+        _close(res["1"][4][k], v.numpy(), "train step " + k)
+
+
 def test_structure_info_with_acmgcn_is_an_error(monkeypatch):
     """Reference quirk Q3: att_vec is 4x4 but acmgcn mixes 3 channels -> RuntimeError there too."""
     fake_lib.install(monkeypatch)
