@@ -9,12 +9,12 @@
 // neighbour's INPUT row instead (f_pad floats = 32 B: a 5 MB table that lives in the L2) and recomputes
 // relu(x_j [W_L | W_H]) per edge on the matrix pipe:
 //
-//   one wave per work item, batches of 16 neighbours = the M dimension of v_mfma_f32_16x16x4_f32;
-//   A[i][k] = x_{j_i}[feature], lane (i = lane & 15, kq = lane >> 4) fetches the float2 (2 kq, 2 kq + 1) of its
-//             neighbour's row (K-step s uses feature 2 kq + s: one 8-byte load per lane and batch);
+//   one wave per FOUR work items; a batch = 4 neighbours of each = the 16 rows (M) of v_mfma_f32_16x16x4_f32;
+//   A[i][k] = x_{j_i}[feature], lane (i = lane & 15, kq = lane >> 4) fetches the float2 (2 kq, 2 kq + 1) of the
+//             neighbour in slot i & 3 of item i >> 2 (K-step s uses feature 2 kq + s: one 8-byte load per lane and batch);
 //   B[k][n] = [W_L | W_H][2 kq + s][16 t + i], 16 loop-invariant registers per lane (waves are persistent);
-//   D tile t = 16 neighbours x 16 columns; ReLU and the sum over the tile's four row registers on the VALU,
-//   accumulated per lane, the four kq groups summed once per row (v_permlane16/32_swap).
+//   D tile t = 16 (item, neighbour) rows x 16 columns; ReLU and the sum over the tile's four row registers -- the four
+//   neighbours of lane group g's item -- on the VALU, accumulated per lane: no cross-lane reduction at all.
 //
 // 2 x 8 x 128 FLOP per edge = 28 GFLOP per pass; at the 157 TFLOP/s fp32 MFMA peak 0.18 ms.
 // Values of an explicit operator (a_ij > 0) scale the gathered row before the product: relu(a z) = a relu(z).
@@ -31,6 +31,12 @@ struct RowOut {
     float H[K][4];
 };
 
+// One wave = FOUR consecutive work items.  The 16 rows of the MFMA's A operand are (item g = row >> 2, neighbour slot
+// r = row & 3); the result rows 4 g .. 4 g + 3 then sit in the four registers of lane group g, so the sum over a row's
+// neighbours never crosses lanes and each 16-lane group ends up with ITS item's aggregated row in the
+// 16-lane x 4-column layout the head works in (LayGrouped<4>) -- four rows per epilogue pass, no redundancy.  The
+// work list is in row order (degree-sorted graphs: neighbouring items have similar lengths), so a quad's items
+// finish within a batch or two of each other; idle slots multiply zeros.
 __global__ __launch_bounds__(256) void acmii_fwd_kernel(acm_conv_acmii_fwd_t p, CsrView csr, float* __restrict__ partial) {
     constexpr int K = 3, T = 8;                  // T = tiles of 16 gathered columns: [Z_L (4) | Z_H (4)], F = 64
     __shared__ __attribute__((aligned(16))) float hlds[3 * K * 64];
@@ -38,6 +44,7 @@ __global__ __launch_bounds__(256) void acmii_fwd_kernel(acm_conv_acmii_fwd_t p, 
     stage_head_params<K>(hlds, p.att_vec, p.ln_weight, p.ln_bias, p.layernorm, F);
     __syncthreads();
     const int lane = threadIdx.x & 63, i = lane & 15, kq = lane >> 4;
+    const int ga = i >> 2, ra = i & 3;           // this lane's A-operand row: item ga of the quad, neighbour slot ra
     // B operands: feature f = 2 kq + s of the three weight matrices for column 16 t + i (zero beyond f_in)
     float bw[2][T], bi[2][4];
 #pragma unroll
@@ -58,69 +65,77 @@ __global__ __launch_bounds__(256) void acmii_fwd_kernel(acm_conv_acmii_fwd_t p, 
     const AcmDropCtx dc = acm_drop_ctx(p.post_drop);
     const bool unit = csr.vals == nullptr;
     const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+    const int n_quads = (csr.n_items + 3) >> 2;
 
-    for (int w = blockIdx.x * 4 + (threadIdx.x >> 6); w < csr.n_items; w += gridDim.x * 4) {
-        const AcmItem it = csr.items[acm_uniform(w)];
-        const int row = acm_uniform(it.row), begin = acm_uniform(it.begin), end = acm_uniform(it.end),
-                  slot = acm_uniform(it.slot);
+    for (int q = blockIdx.x * 4 + (threadIdx.x >> 6); q < n_quads; q += gridDim.x * 4) {
+        const int wa = 4 * q + ga, wd = 4 * q + kq;
+        const bool valid_a = wa < csr.n_items, valid_d = wd < csr.n_items;
+        const AcmItem ia = csr.items[valid_a ? wa : 0], id = csr.items[valid_d ? wd : 0];
+        const int beg_a = ia.begin, end_a = valid_a ? ia.end : ia.begin;
+        const int len = end_a - beg_a;
+        const int maxlen = max(max(__builtin_amdgcn_readlane(len, 0), __builtin_amdgcn_readlane(len, 4)),
+                               max(__builtin_amdgcn_readlane(len, 8), __builtin_amdgcn_readlane(len, 12)));
+        const int nb = (maxlen + 3) >> 2;        // wave-uniform
         float acc[T];
 #pragma unroll
         for (int t = 0; t < T; ++t) acc[t] = 0.f;
-        // software pipeline over batches of 16 neighbours: the next batch's ids and rows are requested before the
-        // current batch's MFMAs
-        int k0 = begin;
-        bool v = k0 + i < end;
-        int j = v ? csr.indices[k0 + i] : 0;
-        float a = v ? (unit ? 1.f : csr.vals[k0 + i]) : 0.f;
-        float2 x2 = v ? *reinterpret_cast<const float2*>(p.xg + (long)j * p.ld_xg + 2 * kq) : make_float2(0.f, 0.f);
-        while (k0 < end) {
-            const int k1 = k0 + 16;
-            const bool nv = k1 + i < end;
-            const int nj = nv ? csr.indices[k1 + i] : 0;
-            const float na = nv ? (unit ? 1.f : csr.vals[k1 + i]) : 0.f;
-            const float2 nx2 = nv ? *reinterpret_cast<const float2*>(p.xg + (long)nj * p.ld_xg + 2 * kq) : make_float2(0.f, 0.f);
-            const float a0 = v ? a * x2.x : 0.f, a1 = v ? a * x2.y : 0.f;     // idle slots contribute relu(0) = 0
+        // software pipeline: column ids two batches ahead, gathered rows one batch ahead of the MFMAs
+        const int pos0 = beg_a + ra;
+        bool ok0 = pos0 < end_a, ok1 = pos0 + 4 < end_a;
+        int j0 = ok0 ? csr.indices[pos0] : 0, j1 = ok1 ? csr.indices[pos0 + 4] : 0;
+        float a0v = ok0 ? (unit ? 1.f : csr.vals[pos0]) : 0.f, a1v = ok1 ? (unit ? 1.f : csr.vals[pos0 + 4]) : 0.f;
+        float2 x0 = ok0 ? *reinterpret_cast<const float2*>(p.xg + (long)j0 * p.ld_xg + 2 * kq) : make_float2(0.f, 0.f);
+        for (int b = 0; b < nb; ++b) {
+            const int pos2 = pos0 + 4 * (b + 2);
+            const bool ok2 = pos2 < end_a;
+            const int j2 = ok2 ? csr.indices[pos2] : 0;
+            const float a2v = ok2 ? (unit ? 1.f : csr.vals[pos2]) : 0.f;
+            const float2 x1 = ok1 ? *reinterpret_cast<const float2*>(p.xg + (long)j1 * p.ld_xg + 2 * kq) : make_float2(0.f, 0.f);
+            const float e0 = ok0 ? a0v * x0.x : 0.f, e1 = ok0 ? a0v * x0.y : 0.f;     // idle slots contribute relu(0) = 0
             f32x4 d[T];
 #pragma unroll
-            for (int t = 0; t < T; ++t) d[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, bw[0][t], zero4, 0, 0, 0);
+            for (int t = 0; t < T; ++t) d[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(e0, bw[0][t], zero4, 0, 0, 0);
 #pragma unroll
-            for (int t = 0; t < T; ++t) d[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, bw[1][t], d[t], 0, 0, 0);
+            for (int t = 0; t < T; ++t) d[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(e1, bw[1][t], d[t], 0, 0, 0);
 #pragma unroll
             for (int t = 0; t < T; ++t)
                 acc[t] += (fmaxf(d[t][0], 0.f) + fmaxf(d[t][1], 0.f)) + (fmaxf(d[t][2], 0.f) + fmaxf(d[t][3], 0.f));
-            k0 = k1;
-            v = nv, j = nj, a = na, x2 = nx2;
+            ok0 = ok1, j0 = j1, a0v = a1v, x0 = x1;
+            ok1 = ok2, j1 = j2, a1v = a2v;
         }
-#pragma unroll
-        for (int t = 0; t < T; ++t) acc[t] = acm_cross_row_sum(acc[t]);   // every lane: column 16 t + i of [P_L | P_H]
-        const bool owner = slot < 0 || (csr.long_index && csr.long_rows[csr.long_index[row]].slot_begin == slot);
-        // the row's own projected features relu(x_i [W_L | W_H | W_I]) (what K1 writes in the literal path)
+        // the rows' own projected features relu(x_i [W_L | W_H | W_I]) (what K1 writes in the literal path): A row 4 g of
+        // the operand carries item g's own input row, so register 0 of lane group g holds its result
         float zs[12];
-        if (owner) {
-            const float2 xi = *reinterpret_cast<const float2*>(p.xs + (long)row * p.ld_xs + 2 * kq);
+        {
+            const float2 xi = (valid_a && ra == 0) ? *reinterpret_cast<const float2*>(p.xs + (long)ia.row * p.ld_xs + 2 * kq)
+                                                   : make_float2(0.f, 0.f);
 #pragma unroll
             for (int t = 0; t < 12; ++t) {
                 const float b0 = t < T ? bw[0][t] : bi[0][t - T], b1 = t < T ? bw[1][t] : bi[1][t - T];
-                zs[t] = fmaxf(acm_cross_row_sum(fmaf(xi.x, b0, xi.y * b1)), 0.f);
-            }
-            if (kq == 0) {
-#pragma unroll
-                for (int t = 0; t < T; ++t) p.zlh[(long)row * p.ld_zlh + 16 * t + i] = zs[t];
-#pragma unroll
-                for (int t = 0; t < 4; ++t) p.zi[(long)row * p.ld_zi + 16 * t + i] = zs[T + t];
+                f32x4 d = __builtin_amdgcn_mfma_f32_16x16x4f32(xi.x, b0, zero4, 0, 0, 0);
+                d = __builtin_amdgcn_mfma_f32_16x16x4f32(xi.y, b1, d, 0, 0, 0);
+                zs[t] = fmaxf(d[0], 0.f);
             }
         }
-        if (slot >= 0) {                                   // a piece of a long row: raw sums to its slot
-            if (kq == 0) {
-                float* ps = partial + (long)slot * (2 * F);
+        // ---- per 16-lane group: its item (row, slot)
+        const int row = id.row, slot = id.slot;
+        const long rr = valid_d ? row : 0;
+        bool owner = valid_d && slot < 0;
+        if (valid_d && slot >= 0) owner = csr.long_rows[csr.long_index[row]].slot_begin == slot;   // first piece of a long row
+        if (owner) {
 #pragma unroll
-                for (int t = 0; t < T; ++t) ps[16 * t + i] = acc[t];
-            }
-            continue;
+            for (int t = 0; t < T; ++t) p.zlh[rr * p.ld_zlh + 16 * t + i] = zs[t];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) p.zi[rr * p.ld_zi + 16 * t + i] = zs[T + t];
         }
-        // ---- epilogue in the 16-lane x 4-column layout (LayGrouped<4>: lane i owns columns i, i + 16, i + 32, i + 48),
-        // identical in the four groups; group 0 stores
-        const float rs = p.row_scale ? p.row_scale[row] : 1.f;
+        if (valid_d && slot >= 0) {                        // a piece of a long row: raw sums to its slot
+            float* ps = partial + (long)slot * (2 * F);
+#pragma unroll
+            for (int t = 0; t < T; ++t) ps[16 * t + i] = acc[t];
+        }
+        const bool full = valid_d && slot < 0;
+        // ---- epilogue in the 16-lane x 4-column layout (lane i owns columns i, i + 16, i + 32, i + 48 of its group's row)
+        const float rs = p.row_scale ? p.row_scale[rr] : 1.f;
         float H[K][4], pre[2][4];
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
@@ -133,21 +148,21 @@ __global__ __launch_bounds__(256) void acmii_fwd_kernel(acm_conv_acmii_fwd_t p, 
         RowHead<K> rh;
         row_head<K>(hlds, mixm, acm_opaque(i), F, p.layernorm != 0, H, rh);
         float df[4];
-        acm_drop4(dc, row, i, df);
-        if (kq == 0) {
+        acm_drop4(dc, rr, i, df);
+        if (full) {
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
                 const int col = i + 16 * t;
                 float o = p.scale * (rh.alpha[0] * H[0][t] + rh.alpha[1] * H[1][t] + rh.alpha[2] * H[2][t]);
                 if (p.post_relu) o = fmaxf(o, 0.f);
-                if (p.post_scale) o *= p.post_scale[(long)row * p.ld_post_scale + col];
+                if (p.post_scale) o *= p.post_scale[rr * p.ld_post_scale + col];
                 if (p.post_drop.p > 0.f) o *= df[t];
-                p.out[(long)row * p.ld_out + col] = o;
-                p.pre[(long)row * p.ld_pre + col] = pre[0][t];
-                p.pre[(long)row * p.ld_pre + F + col] = pre[1][t];
+                p.out[rr * p.ld_out + col] = o;
+                p.pre[rr * p.ld_pre + col] = pre[0][t];
+                p.pre[rr * p.ld_pre + F + col] = pre[1][t];
             }
             if (i == 0)
-                *reinterpret_cast<float4*>(p.att + (long)row * 4) = make_float4(rh.alpha[0], rh.alpha[1], rh.alpha[2], 0.f);
+                *reinterpret_cast<float4*>(p.att + rr * 4) = make_float4(rh.alpha[0], rh.alpha[1], rh.alpha[2], 0.f);
         }
     }
 }
@@ -212,10 +227,10 @@ extern "C" int acm_conv_acmii_fwd(const acm_csr_t* a, const acm_conv_acmii_fwd_t
     if (a->n_rows == 0 || a->n_items == 0) return ACM_OK;
     hipStream_t s = (hipStream_t)stream;
     const CsrView cv = acm_view(a);
-    int grid = (int)((a->n_items + 3) / 4);
-    // persistent waves (the 24 weight registers are loaded once per wave): four workgroups per CU keep every SIMD's
-    // matrix pipe fed while other waves sit in their epilogues
-    if (grid > 2048) grid = 2048;
+    int grid = (int)((a->n_items + 15) / 16);            // a wave takes four items, a workgroup sixteen
+    // persistent waves (the 24 weight registers are loaded once per wave): three workgroups per CU = the 3 waves / SIMD
+    // the register footprint allows
+    if (grid > 768) grid = 768;
     hipLaunchKernelGGL(acmii_fwd_kernel, dim3(grid), dim3(256), 0, s, *p, cv, (float*)workspace);
     ACM_CHECK_HIP(hipGetLastError());
     if (a->n_long) {
