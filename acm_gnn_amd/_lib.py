@@ -24,7 +24,7 @@ EXPORTED_SYMBOLS = (
     "acm_conv_bwd_local", "acm_conv_bwd_spmm", "acm_conv_agg_fwd", "acm_conv_agg_bwd_workspace_bytes",
     "acm_conv_agg_bwd", "acm_nll_loss_workspace_bytes", "acm_nll_loss", "acm_adam_step", "acm_dropout",
     "acm_reduce_flush", "acm_conv_fwd_tail_workspace_bytes", "acm_conv_fwd_tail", "acm_shard_plan",
-    "acm_conv_acmii_fwd", "acm_linear_fwd", "acm_bias_act", "acm_bias_act_bwd_workspace_bytes", "acm_bias_act_bwd",
+    "acm_conv_acmii_fwd_workspace_bytes", "acm_conv_acmii_fwd", "acm_linear_fwd", "acm_bias_act", "acm_bias_act_bwd_workspace_bytes", "acm_bias_act_bwd",
 )
 
 
@@ -190,6 +190,7 @@ def _declare(lib):
     lib.acm_csr_destroy.restype = None
     lib.acm_csr_info.argtypes = [vp, C.POINTER(CsrInfo)]
     lib.acm_shard_plan.argtypes = [i64, vp, i32, i64, vp]
+    lib.acm_conv_acmii_fwd_workspace_bytes.argtypes = [vp, C.POINTER(sz)]
     lib.acm_conv_acmii_fwd.argtypes = [vp, C.POINTER(ConvAcmiiFwd), vp, sz, vp]
     lib.acm_linear_fwd.argtypes = [i64, i64, i64, vp, i64, vp, i64, vp, i32, vp, vp, i64, vp, sz, vp]
     lib.acm_bias_act.argtypes = [i64, i32, vp, i64, vp, i32, vp, vp]

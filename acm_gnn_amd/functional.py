@@ -872,7 +872,9 @@ class AcmConvFunction(torch.autograd.Function):
             if ops.implicit:
                 p.row_scale = ops.row_scale.data_ptr()
             set_post(p)
-            ws = ops.low.workspace(2 * f)
+            nbytes = C.c_size_t()
+            _lib.check(lib.acm_conv_acmii_fwd_workspace_bytes(ops.low.handle, C.byref(nbytes)), "acm_conv_acmii_fwd_workspace_bytes")
+            ws = torch.empty(max(nbytes.value // 4, 1), dtype=_F32, device=dev)
             with _device_ctx(dev), _Timed(f"conv_acmii_fwd/F{f}i{f_in}"):
                 st = lib.acm_conv_acmii_fwd(ops.low.handle, C.byref(p), _vp(ws), ws.numel() * 4, _stream())
             _lib.check(st, "acm_conv_acmii_fwd")

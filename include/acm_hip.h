@@ -511,8 +511,10 @@ int acm_conv_agg_bwd(int64_t n_rows, const acm_conv_agg_bwd_t* p,
  * (v_mfma_f32_16x16x4_f32, 16 neighbours per tile): same outputs as the two calls it replaces -- out, pre = [pre_L |
  * pre_H] and att as acm_conv_fwd, zlh = relu(X [W_L | W_H]) and zi = relu(X W_I) as the GEMM (K4's masks / self rows,
  * K3's s_mlp) -- equal to them up to fp32 re-association.  Three channels.  Values of an explicit operator must be
- * non-negative (relu(a z) = a relu(z)).  Workspace: acm_spmm_workspace_bytes(a_low, 2 * f_out).  The backward is
- * acm_conv_bwd_local / acm_conv_bwd_spmm / acm_gemm as for the literal form. */
+ * non-negative (relu(a z) = a relu(z)).  Workspace: acm_conv_acmii_fwd_workspace_bytes (partial sums of the long rows'
+ * pieces + the work counter of the persistent waves, reset by the call itself with a stream-ordered memset, so the
+ * call is hipGraph-capturable).  The backward is acm_conv_bwd_local / acm_conv_bwd_spmm / acm_gemm as for the literal
+ * form. */
 typedef struct {
     int32_t f_in, f_pad, f_out;        /* f_pad = 8, f_out = 64                                                */
     int32_t layernorm;
@@ -535,6 +537,7 @@ typedef struct {
     acm_dropout_t post_drop;
 } acm_conv_acmii_fwd_t;
 
+int acm_conv_acmii_fwd_workspace_bytes(const acm_csr_t* a_low, size_t* bytes);
 int acm_conv_acmii_fwd(const acm_csr_t* a_low, const acm_conv_acmii_fwd_t* p,
                        void* workspace, size_t workspace_bytes, acm_stream_t stream);
 

@@ -373,6 +373,10 @@ class FakeLib:
         return 0
 
     # ---- ACMII first layer, recompute on gather: K1 + K2 through the doubles of those two calls --------------------
+    def acm_conv_acmii_fwd_workspace_bytes(self, handle, out):
+        out._obj.value = 64
+        return 0
+
     def acm_conv_acmii_fwd(self, handle, pp, ws, wsb, stream):
         from acm_gnn_amd import _lib
         p = pp._obj
