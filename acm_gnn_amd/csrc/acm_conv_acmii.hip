@@ -26,6 +26,14 @@ namespace {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+// max(x, 0) as ONE instruction: fmaxf lowers to v_max_f32 x, x, x (quieting) + v_max_f32 .., 0 under IEEE mode, and the
+// per-edge ReLUs are a third of this kernel's VALU work
+__device__ __forceinline__ float relu1(float x) {
+    float r;
+    asm("v_max_f32_e32 %0, 0, %1" : "=v"(r) : "v"(x));
+    return r;
+}
+
 template <int K>
 struct RowOut {
     float H[K][4];
@@ -37,8 +45,7 @@ struct RowOut {
 // 16-lane x 4-column layout the head works in (LayGrouped<4>) -- four rows per epilogue pass, no redundancy.  The
 // work list is in row order (degree-sorted graphs: neighbouring items have similar lengths), so a quad's items
 // finish within a batch or two of each other; idle slots multiply zeros.
-__global__ __launch_bounds__(256) void acmii_fwd_kernel(acm_conv_acmii_fwd_t p, CsrView csr, float* __restrict__ partial,
-                                                        int* __restrict__ next_quad) {
+__global__ __launch_bounds__(256) void acmii_fwd_kernel(acm_conv_acmii_fwd_t p, CsrView csr, float* __restrict__ partial) {
     constexpr int K = 3, T = 8;                  // T = tiles of 16 gathered columns: [Z_L (4) | Z_H (4)], F = 64
     __shared__ __attribute__((aligned(16))) float hlds[3 * K * 64];
     const int F = 64;
@@ -68,14 +75,13 @@ __global__ __launch_bounds__(256) void acmii_fwd_kernel(acm_conv_acmii_fwd_t p, 
     const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
     const int n_quads = (csr.n_items + 3) >> 2;
 
-    // Waves take quads from a shared counter, in list order: the pieces of the long rows first, then the rows by
-    // decreasing length on a degree-sorted graph -- longest-first list scheduling.  (A static stride left the waves that
-    // drew the 1 300-neighbour pieces with 1.8x the mean load.)
-    while (true) {
-        int q = 0;
-        if (lane == 0) q = atomicAdd(next_quad, 1);
-        q = __builtin_amdgcn_readfirstlane(q);
-        if (q >= n_quads) break;
+    // One wave per quad, workgroups dispatched in list order: the pieces of the long rows first, then the rows by
+    // decreasing length on a degree-sorted graph -- the hardware dispatcher does longest-first list scheduling.  (Persistent
+    // waves with a static stride left those that drew the 1 300-neighbour pieces with 1.8x the mean load; a shared
+    // atomic work counter serialised 42 k fetches on one L2 line: 667 -> 786 us.)
+    {
+        const int q = blockIdx.x * 4 + (threadIdx.x >> 6);
+        if (q >= n_quads) return;
         const int wa = 4 * q + ga, wd = 4 * q + kq;
         const bool valid_a = wa < csr.n_items, valid_d = wd < csr.n_items;
         const AcmItem ia = csr.items[valid_a ? wa : 0], id = csr.items[valid_d ? wd : 0];
@@ -87,18 +93,28 @@ __global__ __launch_bounds__(256) void acmii_fwd_kernel(acm_conv_acmii_fwd_t p, 
         float acc[T];
 #pragma unroll
         for (int t = 0; t < T; ++t) acc[t] = 0.f;
-        // software pipeline: column ids two batches ahead, gathered rows one batch ahead of the MFMAs
+        // software pipeline: column ids FOUR batches ahead, gathered rows TWO batches ahead of the MFMAs (a wave that
+        // holds pieces of a hub row walks ~330 batches back to back: every exposed latency is on its critical path)
         const int pos0 = beg_a + ra;
-        bool ok0 = pos0 < end_a, ok1 = pos0 + 4 < end_a;
-        int j0 = ok0 ? csr.indices[pos0] : 0, j1 = ok1 ? csr.indices[pos0 + 4] : 0;
-        float a0v = ok0 ? (unit ? 1.f : csr.vals[pos0]) : 0.f, a1v = ok1 ? (unit ? 1.f : csr.vals[pos0 + 4]) : 0.f;
-        float2 x0 = ok0 ? *reinterpret_cast<const float2*>(p.xg + (long)j0 * p.ld_xg + 2 * kq) : make_float2(0.f, 0.f);
+        auto id_at = [&](int b, bool& ok, float& av) {
+            const int pos = pos0 + 4 * b;
+            ok = pos < end_a;
+            av = ok ? (unit ? 1.f : csr.vals[pos]) : 0.f;
+            return ok ? csr.indices[pos] : 0;
+        };
+        auto row_at = [&](int j, bool ok) {
+            return ok ? *reinterpret_cast<const float2*>(p.xg + (long)j * p.ld_xg + 2 * kq) : make_float2(0.f, 0.f);
+        };
+        bool ok0, ok1, ok2, ok3;
+        float a0v, a1v, a2v, a3v;
+        int j0 = id_at(0, ok0, a0v), j1 = id_at(1, ok1, a1v), j2 = id_at(2, ok2, a2v), j3 = id_at(3, ok3, a3v);
+        float2 x0 = row_at(j0, ok0), x1 = row_at(j1, ok1);
+        (void)j0;
         for (int b = 0; b < nb; ++b) {
-            const int pos2 = pos0 + 4 * (b + 2);
-            const bool ok2 = pos2 < end_a;
-            const int j2 = ok2 ? csr.indices[pos2] : 0;
-            const float a2v = ok2 ? (unit ? 1.f : csr.vals[pos2]) : 0.f;
-            const float2 x1 = ok1 ? *reinterpret_cast<const float2*>(p.xg + (long)j1 * p.ld_xg + 2 * kq) : make_float2(0.f, 0.f);
+            bool ok4;
+            float a4v;
+            const int j4 = id_at(b + 4, ok4, a4v);
+            const float2 x2 = row_at(j2, ok2);
             const float e0 = ok0 ? a0v * x0.x : 0.f, e1 = ok0 ? a0v * x0.y : 0.f;     // idle slots contribute relu(0) = 0
             f32x4 d[T];
 #pragma unroll
@@ -107,9 +123,11 @@ __global__ __launch_bounds__(256) void acmii_fwd_kernel(acm_conv_acmii_fwd_t p, 
             for (int t = 0; t < T; ++t) d[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(e1, bw[1][t], d[t], 0, 0, 0);
 #pragma unroll
             for (int t = 0; t < T; ++t)
-                acc[t] += (fmaxf(d[t][0], 0.f) + fmaxf(d[t][1], 0.f)) + (fmaxf(d[t][2], 0.f) + fmaxf(d[t][3], 0.f));
-            ok0 = ok1, j0 = j1, a0v = a1v, x0 = x1;
-            ok1 = ok2, j1 = j2, a1v = a2v;
+                acc[t] += (relu1(d[t][0]) + relu1(d[t][1])) + (relu1(d[t][2]) + relu1(d[t][3]));
+            ok0 = ok1, a0v = a1v, x0 = x1;
+            ok1 = ok2, a1v = a2v, x1 = x2;
+            ok2 = ok3, a2v = a3v, j2 = j3;
+            ok3 = ok4, a3v = a4v, j3 = j4;
         }
         // the rows' own projected features relu(x_i [W_L | W_H | W_I]) (what K1 writes in the literal path): A row 4 g of
         // the operand carries item g's own input row, so register 0 of lane group g holds its result
@@ -122,7 +140,7 @@ __global__ __launch_bounds__(256) void acmii_fwd_kernel(acm_conv_acmii_fwd_t p, 
                 const float b0 = t < T ? bw[0][t] : bi[0][t - T], b1 = t < T ? bw[1][t] : bi[1][t - T];
                 f32x4 d = __builtin_amdgcn_mfma_f32_16x16x4f32(xi.x, b0, zero4, 0, 0, 0);
                 d = __builtin_amdgcn_mfma_f32_16x16x4f32(xi.y, b1, d, 0, 0, 0);
-                zs[t] = fmaxf(d[0], 0.f);
+                zs[t] = relu1(d[0]);
             }
         }
         // ---- per 16-lane group: its item (row, slot)
@@ -211,10 +229,10 @@ __global__ __launch_bounds__(256) void acmii_fixup_kernel(acm_conv_acmii_fwd_t p
 
 }  // namespace
 
-// partial slots of the long rows' pieces ([n_slots, 2 F]) + the work counter of the persistent waves
+// partial slots of the long rows' pieces ([n_slots, 2 F])
 extern "C" int acm_conv_acmii_fwd_workspace_bytes(const acm_csr_t* a, size_t* bytes) {
     ACM_REQUIRE(a && bytes, ACM_EINVAL, "acm_conv_acmii_fwd_workspace_bytes: NULL argument");
-    *bytes = (size_t)a->n_slots * 128 * sizeof(float) + 64;
+    *bytes = (size_t)a->n_slots * 128 * sizeof(float) + 64;      // never zero: the caller always has a buffer to pass
     return ACM_OK;
 }
 
@@ -243,13 +261,8 @@ extern "C" int acm_conv_acmii_fwd(const acm_csr_t* a, const acm_conv_acmii_fwd_t
     if (a->n_rows == 0 || a->n_items == 0) return ACM_OK;
     hipStream_t s = (hipStream_t)stream;
     const CsrView cv = acm_view(a);
-    int grid = (int)((a->n_items + 15) / 16);            // a wave takes four items, a workgroup sixteen
-    // persistent waves (the 24 weight registers are loaded once per wave): three workgroups per CU = the 3 waves / SIMD
-    // the register footprint allows
-    if (grid > 768) grid = 768;
-    int* next_quad = reinterpret_cast<int*>(reinterpret_cast<char*>(workspace) + (size_t)a->n_slots * 128 * sizeof(float));
-    ACM_CHECK_HIP(hipMemsetAsync(next_quad, 0, sizeof(int), s));
-    hipLaunchKernelGGL(acmii_fwd_kernel, dim3(grid), dim3(256), 0, s, *p, cv, (float*)workspace, next_quad);
+    const int grid = (int)((a->n_items + 15) / 16);      // a wave takes four items, a workgroup sixteen
+    hipLaunchKernelGGL(acmii_fwd_kernel, dim3(grid), dim3(256), 0, s, *p, cv, (float*)workspace);
     ACM_CHECK_HIP(hipGetLastError());
     if (a->n_long) {
         hipLaunchKernelGGL(acmii_fixup_kernel, dim3((unsigned)((a->n_long + 3) / 4)), dim3(256), 0, s, *p, cv,
