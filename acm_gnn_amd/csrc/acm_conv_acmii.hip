@@ -28,6 +28,13 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 // max(x, 0) as ONE instruction: fmaxf lowers to v_max_f32 x, x, x (quieting) + v_max_f32 .., 0 under IEEE mode, and the
 // per-edge ReLUs are a third of this kernel's VALU work
+// |a| + |b| in one instruction (source modifiers); plain C++ gets SLP-packed into v_pk_add_f32, which has no |.| and
+// costs a v_and_b32 per operand
+__device__ __forceinline__ float abs_add(float a, float b) {
+    float r;
+    asm("v_add_f32_e64 %0, |%1|, |%2|" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
 __device__ __forceinline__ float relu1(float x) {
     float r;
     asm("v_max_f32_e32 %0, 0, %1" : "=v"(r) : "v"(x));
@@ -96,38 +103,55 @@ __global__ __launch_bounds__(256) void acmii_fwd_kernel(acm_conv_acmii_fwd_t p, 
         // software pipeline: column ids FOUR batches ahead, gathered rows TWO batches ahead of the MFMAs (a wave that
         // holds pieces of a hub row walks ~330 batches back to back: every exposed latency is on its critical path)
         const int pos0 = beg_a + ra;
+        // branch-free loads (clamped addresses): guarded loads become exec-mask branches, and the compiler then waits
+        // for EVERY outstanding load (s_waitcnt vmcnt(0)) before the MFMAs instead of only for the oldest
         auto id_at = [&](int b, bool& ok, float& av) {
             const int pos = pos0 + 4 * b;
             ok = pos < end_a;
-            av = ok ? (unit ? 1.f : csr.vals[pos]) : 0.f;
-            return ok ? csr.indices[pos] : 0;
+            const int pc = ok ? pos : 0;
+            av = unit ? 1.f : csr.vals[pc];
+            return csr.indices[pc];
         };
         auto row_at = [&](int j, bool ok) {
-            return ok ? *reinterpret_cast<const float2*>(p.xg + (long)j * p.ld_xg + 2 * kq) : make_float2(0.f, 0.f);
+            return *reinterpret_cast<const float2*>(p.xg + (long)(ok ? j : 0) * p.ld_xg + 2 * kq);
         };
         bool ok0, ok1, ok2, ok3;
         float a0v, a1v, a2v, a3v;
         int j0 = id_at(0, ok0, a0v), j1 = id_at(1, ok1, a1v), j2 = id_at(2, ok2, a2v), j3 = id_at(3, ok3, a3v);
         float2 x0 = row_at(j0, ok0), x1 = row_at(j1, ok1);
         (void)j0;
+        float sx0 = 0.f, sx1 = 0.f;                        // sum over this lane's neighbours of its two A-operand features
         for (int b = 0; b < nb; ++b) {
             bool ok4;
             float a4v;
             const int j4 = id_at(b + 4, ok4, a4v);
             const float2 x2 = row_at(j2, ok2);
             const float e0 = ok0 ? a0v * x0.x : 0.f, e1 = ok0 ? a0v * x0.y : 0.f;     // idle slots contribute relu(0) = 0
+            sx0 += e0;
+            sx1 += e1;
             f32x4 d[T];
 #pragma unroll
             for (int t = 0; t < T; ++t) d[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(e0, bw[0][t], zero4, 0, 0, 0);
 #pragma unroll
             for (int t = 0; t < T; ++t) d[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(e1, bw[1][t], d[t], 0, 0, 0);
+            // relu(z) = (z + |z|) / 2: only sum |z| per edge (|.| is a free source modifier of v_add_f32: 4 VALU
+            // instructions per tile instead of 8); sum z is linear in the gathered rows and comes out of one more MFMA
+            // pass per quad below (from the lane's running sums sx0 / sx1 of its A operands)
 #pragma unroll
             for (int t = 0; t < T; ++t)
-                acc[t] += (relu1(d[t][0]) + relu1(d[t][1])) + (relu1(d[t][2]) + relu1(d[t][3]));
+                acc[t] += abs_add(d[t][0], d[t][1]) + abs_add(d[t][2], d[t][3]);
             ok0 = ok1, a0v = a1v, x0 = x1;
             ok1 = ok2, a1v = a2v, x1 = x2;
             ok2 = ok3, a2v = a3v, j2 = j3;
             ok3 = ok4, a3v = a4v, j3 = j4;
+        }
+        // sum_j relu(z_j) = (sum_j z_j + sum_j |z_j|) / 2, with sum_j z_j = (sum_j a_ij x_j) [W_L | W_H] on the matrix pipe: the
+        // four A rows of item g carry the partial sums of its four neighbour slots
+#pragma unroll
+        for (int t = 0; t < T; ++t) {
+            f32x4 d = __builtin_amdgcn_mfma_f32_16x16x4f32(sx0, bw[0][t], zero4, 0, 0, 0);
+            d = __builtin_amdgcn_mfma_f32_16x16x4f32(sx1, bw[1][t], d, 0, 0, 0);
+            acc[t] = 0.5f * (((d[0] + d[1]) + (d[2] + d[3])) + acc[t]);
         }
         // the rows' own projected features relu(x_i [W_L | W_H | W_I]) (what K1 writes in the literal path): A row 4 g of
         // the operand carries item g's own input row, so register 0 of lane group g holds its result
