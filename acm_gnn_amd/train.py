@@ -145,6 +145,10 @@ class TrainStep:
                 self.model.dropout_state.step.copy_(drop_step)
 
     def _capture(self):
+        # NOTE for callers: no autograd graph of an earlier, un-captured backward through this model may still be alive
+        # (e.g. a retained `out` of `out = model(x); loss(out).backward()`): its AccumulateGrad nodes are bound to the
+        # stream they were created on, and the captured backward would have to synchronise with that stream --
+        # torch aborts the capture (a segmentation fault in capture_end on ROCm).  Drop such references first.
         # The warm-up runs real steps (lazy handles, allocator pools, optimizer state) -- on a snapshot: the model,
         # the optimizer moments / step counts and the dropout counter are put back afterwards, so a captured
         # TrainStep starts from exactly the state an eager one starts from (fit(epochs=N) trains N steps, not N + 3).

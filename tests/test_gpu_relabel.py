@@ -43,9 +43,11 @@ def test_relabelled_operators_give_the_same_results(model_type, variant, s, f_in
         model = GCN(f_in, 64, 3, 2, n, 0.0, model_type, s, variant=bool(variant), attn_layernorm=True).to(DEV)
         out = model(x, low, high, un)
         F.nll_loss(F.log_softmax(out, 1)[idx], y[idx]).backward()
+        out = out.detach()          # drop the autograd graph: a live AccumulateGrad node pins the stream it was created on
         grads = {k: p.grad.clone() for k, p in model.named_parameters() if p.grad is not None}
         att = model.gcns[0].att_high.clone()
-        layer_out = model.gcns[0](x, low, high, un if s else None).detach()
+        with torch.no_grad():
+            layer_out = model.gcns[0](x, low, high, un if s else None)
         model.zero_grad(set_to_none=True)
         opt = torch.optim.SGD(model.parameters(), lr=0.0)
         losses = []
@@ -53,7 +55,7 @@ def test_relabelled_operators_give_the_same_results(model_type, variant, s, f_in
             step = T.TrainStep(model, opt, x, low, y, w, high, un, use_graph=use_graph, fused_dropout=False)
             assert step._permuted == (mode == "1")
             losses.append(float(step()))
-        res[mode] = (out.detach(), grads, att, layer_out, losses, {k: p.grad.clone() for k, p in model.named_parameters()
+        res[mode] = (out, grads, att, layer_out, losses, {k: p.grad.clone() for k, p in model.named_parameters()
                                                                   if p.grad is not None})
     a, b = res["1"], res["0"]
     scale = max(1.0, float(b[0].abs().max()))
