@@ -222,6 +222,55 @@ struct EpiBwd {
     }
 };
 
+// The three outputs of K4 do not depend on each other, so the wide backward can run ONE CHANNEL PER PASS: a pass then
+// gathers 64-column rows (256 B, two cache lines per neighbour) of a table whose hot part -- the hub rows -- is half as
+// large as that of the [G_L | G_H] rows, more of it stays in the 4 MB L2 of an XCD, and the single-channel passes take the
+// vector form (scripts/probe_wide.py: 2 x 270 us against 610 us for the 128-column gather on the twitch-shaped graph).
+struct EpiBwdLow {
+    using Args = acm_conv_bwd_spmm_t;
+    template <class L, int NG>
+    static __device__ __forceinline__ void apply(const Args& p, int row, const L& lay, int F, const float (&acc)[NG][L::NV]) {
+        if (!Owns<L>::lane_stores(lay)) return;
+#pragma unroll
+        for (int i = 0; i < L::NV; ++i) {
+            const int col = lay.col(i);
+            if (col >= F) continue;
+            float dl = acc[0][i];
+            if (p.mask_low) dl = (p.mask_low[(long)row * p.ld_mask_low + col] > 0.f) ? dl : 0.f;
+            p.dz_low[(long)row * p.ld_dz_low + col] = dl;
+        }
+    }
+};
+struct EpiBwdHigh {
+    using Args = acm_conv_bwd_spmm_t;
+    template <class L, int NG>
+    static __device__ __forceinline__ void apply(const Args& p, int row, const L& lay, int F, const float (&acc)[NG][L::NV]) {
+        if (!Owns<L>::lane_stores(lay)) return;
+        const float ssc = p.self_scale ? p.self_scale[row] : 1.f;
+#pragma unroll
+        for (int i = 0; i < L::NV; ++i) {
+            const int col = lay.col(i);
+            if (col >= F) continue;
+            float dh = ssc * p.s_high[(long)row * p.ld_s_high + col] - acc[0][i];
+            if (p.mask_high) dh = (p.mask_high[(long)row * p.ld_mask_high + col] > 0.f) ? dh : 0.f;
+            p.dz_high[(long)row * p.ld_dz_high + col] = dh;
+        }
+    }
+};
+struct EpiBwdStruc {
+    using Args = acm_conv_bwd_spmm_t;
+    template <class L, int NG>
+    static __device__ __forceinline__ void apply(const Args& p, int row, const L& lay, int F, const float (&acc)[NG][L::NV]) {
+        if (!Owns<L>::lane_stores(lay)) return;
+        const float idg = p.inv_deg ? p.inv_deg[row] : 1.f;
+#pragma unroll
+        for (int i = 0; i < L::NV; ++i) {
+            const int col = lay.col(i);
+            if (col < F) p.d_struc[(long)row * p.ld_d_struc + col] = acc[0][i] - p.s_struc[(long)row * p.ld_s_struc + col] * idg;
+        }
+    }
+};
+
 // ------------------------------------------------------------------ wide gather
 // element load of the gathered operand: fp32, or bf16 widened to fp32 (exact)
 template <bool BF16>
@@ -1012,9 +1061,23 @@ extern "C" int acm_conv_bwd_spmm(const acm_csr_t* at, const acm_conv_bwd_spmm_t*
     ACM_REQUIRE(F > 0, ACM_ESHAPE, "acm_conv_bwd_spmm: f_out %d", F);
     ACM_REQUIRE(p->g_low && p->g_high && p->s_high && p->dz_low && p->dz_high, ACM_EINVAL,
                 "acm_conv_bwd_spmm: NULL tensor pointer");
+    if (p->g_struc) ACM_REQUIRE(p->s_struc && p->d_struc, ACM_EINVAL, "acm_conv_bwd_spmm: structure channel pointers are NULL");
+    // wide layers on graphs whose gathered tables exceed the L2: one channel per pass (see EpiBwdLow)
+    // (ACM_BWD_SPLIT=1 / ACM_BWD_FUSED=1 force either form, for tests and A/B measurements)
+    const bool split = getenv("ACM_BWD_FUSED") ? false
+                       : (getenv("ACM_BWD_SPLIT") ? true : (size_t)at->n_cols * (size_t)F * sizeof(float) > (8u << 20));
+    if (F > 8 && F <= 256 && split) {
+        hipStream_t s = (hipStream_t)stream;
+        GatherSrc gl = {{p->g_low, nullptr, nullptr}, {p->ld_g_low, 0, 0}};
+        int st = launch_gather<1, EpiBwdLow>(at, gl, F, *p, workspace, workspace_bytes, s, "acm_conv_bwd_spmm");
+        if (st != ACM_OK) return st;
+        GatherSrc gh = {{p->g_high, nullptr, nullptr}, {p->ld_g_high, 0, 0}};
+        st = launch_gather<1, EpiBwdHigh>(at, gh, F, *p, workspace, workspace_bytes, s, "acm_conv_bwd_spmm");
+        if (st != ACM_OK || !p->g_struc) return st;
+        GatherSrc gs = {{p->g_struc, nullptr, nullptr}, {p->ld_g_struc, 0, 0}};
+        return launch_gather<1, EpiBwdStruc>(at, gs, F, *p, workspace, workspace_bytes, s, "acm_conv_bwd_spmm");
+    }
     if (p->g_struc) {
-        ACM_REQUIRE(p->s_struc && p->d_struc, ACM_EINVAL,
-                    "acm_conv_bwd_spmm: structure channel pointers are NULL");
         GatherSrc g = {{p->g_low, p->g_high, p->g_struc}, {p->ld_g_low, p->ld_g_high, p->ld_g_struc}};
         return launch_gather<3, EpiBwd>(at, g, F, *p, workspace, workspace_bytes, (hipStream_t)stream,
                                         "acm_conv_bwd_spmm");

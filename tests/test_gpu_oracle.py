@@ -478,3 +478,17 @@ def test_acmii_recompute_on_gather_matches_oracle_and_literal(model_type, ln, f_
     finally:
         AF.set_kernel_timer(None)
     assert float((a - b).abs().max()) < 2e-5 * max(1.0, float(b.abs().max()))
+
+
+@pytest.mark.parametrize("model_type,variant,s,f_out", [("acmgcnp", 1, 0, 64), ("acmgcnp", 1, 1, 64), ("acmgcnp", 0, 1, 40),
+                                                        ("acmgcn", 1, 0, 130)])
+def test_channel_per_pass_backward_matches_oracle(model_type, variant, s, f_out, monkeypatch):
+    """K4 with one gathered channel per pass (the form large graphs take: acm_conv_bwd_spmm, EpiBwdLow / High / Struc)
+    forced on a small graph with a split hub row, against the oracle; and equal to the single-pass form."""
+    adj = _graph(600, 41, density=0.04, hub=True)
+    monkeypatch.setenv("ACM_BWD_SPLIT", "1")
+    a = _run_both(model_type, variant, s, True, 600, 30, f_out, 41, True, monkeypatch, agg=False, adj=adj)
+    monkeypatch.delenv("ACM_BWD_SPLIT")
+    monkeypatch.setenv("ACM_BWD_FUSED", "1")
+    b = _run_both(model_type, variant, s, True, 600, 30, f_out, 41, True, monkeypatch, agg=False, adj=adj)
+    assert float((a - b).abs().max()) < 2e-5 * max(1.0, float(b.abs().max()))
