@@ -138,7 +138,9 @@ class ConvAcmiiFwd(C.Structure):
                 ("out", C.c_void_p), ("ld_out", C.c_int64), ("pre", C.c_void_p), ("ld_pre", C.c_int64),
                 ("att", C.c_void_p), ("zlh", C.c_void_p), ("ld_zlh", C.c_int64), ("zi", C.c_void_p), ("ld_zi", C.c_int64),
                 ("post_scale", C.c_void_p), ("ld_post_scale", C.c_int64), ("post_relu", C.c_int32),
-                ("row_scale", C.c_void_p), ("post_drop", Dropout)]
+                ("row_scale", C.c_void_p), ("post_drop", Dropout),
+                ("n_channels", C.c_int32), ("ps", C.c_void_p), ("ld_ps", C.c_int64), ("ss", C.c_void_p), ("ld_ss", C.c_int64),
+                ("deg", C.c_void_p)]
 
 
 class Loss(C.Structure):

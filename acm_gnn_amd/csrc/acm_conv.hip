@@ -1064,8 +1064,11 @@ extern "C" int acm_conv_bwd_spmm(const acm_csr_t* at, const acm_conv_bwd_spmm_t*
     if (p->g_struc) ACM_REQUIRE(p->s_struc && p->d_struc, ACM_EINVAL, "acm_conv_bwd_spmm: structure channel pointers are NULL");
     // wide layers on graphs whose gathered tables exceed the L2: one channel per pass (see EpiBwdLow)
     // (ACM_BWD_SPLIT=1 / ACM_BWD_FUSED=1 force either form, for tests and A/B measurements)
-    const bool split = getenv("ACM_BWD_FUSED") ? false
-                       : (getenv("ACM_BWD_SPLIT") ? true : (size_t)at->n_cols * (size_t)F * sizeof(float) > (8u << 20));
+    // Measured (profiles/r02_wide_kernels.jsonl): twitch-shaped (mean degree 82) 640 -> 613 us, with the structure channel
+    // 1004 -> 899, Penn94-shaped (66) 121 -> 106; arXiv-year-shaped (15) 160 -> 190: short rows pay the per-item cost of
+    // every pass, so the split needs a mean degree of 32.
+    const bool big = (size_t)at->n_cols * (size_t)F * sizeof(float) > (8u << 20) && at->nnz >= 32 * at->n_rows;
+    const bool split = getenv("ACM_BWD_FUSED") ? false : (getenv("ACM_BWD_SPLIT") ? true : big);
     if (F > 8 && F <= 256 && split) {
         hipStream_t s = (hipStream_t)stream;
         GatherSrc gl = {{p->g_low, nullptr, nullptr}, {p->ld_g_low, 0, 0}};

@@ -52,8 +52,9 @@ struct RowOut {
 // 16-lane x 4-column layout the head works in (LayGrouped<4>) -- four rows per epilogue pass, no redundancy.  The
 // work list is in row order (degree-sorted graphs: neighbouring items have similar lengths), so a quad's items
 // finish within a batch or two of each other; idle slots multiply zeros.
+template <int K>
 __global__ __launch_bounds__(256) void acmii_fwd_kernel(acm_conv_acmii_fwd_t p, CsrView csr, float* __restrict__ partial) {
-    constexpr int K = 3, T = 8;                  // T = tiles of 16 gathered columns: [Z_L (4) | Z_H (4)], F = 64
+    constexpr int T = 8;                         // T = tiles of 16 gathered columns: [Z_L (4) | Z_H (4)], F = 64
     __shared__ __attribute__((aligned(16))) float hlds[3 * K * 64];
     const int F = 64;
     stage_head_params<K>(hlds, p.att_vec, p.ln_weight, p.ln_bias, p.layernorm, F);
@@ -186,7 +187,8 @@ __global__ __launch_bounds__(256) void acmii_fwd_kernel(acm_conv_acmii_fwd_t p, 
         const bool full = valid_d && slot < 0;
         // ---- epilogue in the 16-lane x 4-column layout (lane i owns columns i, i + 16, i + 32, i + 48 of its group's row)
         const float rs = p.row_scale ? p.row_scale[rr] : 1.f;
-        float H[K][4], pre[2][4];
+        float H[K][4], pre[3][4];
+        const float dg = K == 4 ? p.deg[rr] : 0.f;
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
             pre[0][t] = rs * acc[t];
@@ -194,6 +196,10 @@ __global__ __launch_bounds__(256) void acmii_fwd_kernel(acm_conv_acmii_fwd_t p, 
             H[0][t] = pre[0][t];                           // ACMII: no ReLU after the filter
             H[1][t] = pre[1][t];
             H[2][t] = zs[T + t];
+            if (K == 4) {                                  // structure channel: relu(A S) = relu(deg (A_low S) - S), ps = A_low S
+                pre[2][t] = dg * p.ps[rr * p.ld_ps + i + 16 * t] - p.ss[rr * p.ld_ss + i + 16 * t];
+                H[K - 1][t] = fmaxf(pre[2][t], 0.f);
+            }
         }
         RowHead<K> rh;
         row_head<K>(hlds, mixm, acm_opaque(i), F, p.layernorm != 0, H, rh);
@@ -203,24 +209,28 @@ __global__ __launch_bounds__(256) void acmii_fwd_kernel(acm_conv_acmii_fwd_t p, 
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
                 const int col = i + 16 * t;
-                float o = p.scale * (rh.alpha[0] * H[0][t] + rh.alpha[1] * H[1][t] + rh.alpha[2] * H[2][t]);
+                float o = rh.alpha[0] * H[0][t] + rh.alpha[1] * H[1][t] + rh.alpha[2] * H[2][t];
+                if (K == 4) o = fmaf(rh.alpha[K - 1], H[K - 1][t], o);
+                o *= p.scale;
                 if (p.post_relu) o = fmaxf(o, 0.f);
                 if (p.post_scale) o *= p.post_scale[rr * p.ld_post_scale + col];
                 if (p.post_drop.p > 0.f) o *= df[t];
                 p.out[rr * p.ld_out + col] = o;
                 p.pre[rr * p.ld_pre + col] = pre[0][t];
                 p.pre[rr * p.ld_pre + F + col] = pre[1][t];
+                if (K == 4) p.pre[rr * p.ld_pre + 2 * F + col] = pre[2][t];
             }
             if (i == 0)
-                *reinterpret_cast<float4*>(p.att + rr * 4) = make_float4(rh.alpha[0], rh.alpha[1], rh.alpha[2], 0.f);
+                *reinterpret_cast<float4*>(p.att + rr * 4) =
+                    make_float4(rh.alpha[0], rh.alpha[1], rh.alpha[2], K == 4 ? rh.alpha[K - 1] : 0.f);
         }
     }
 }
 
 // Long rows: one wave per row adds the pieces' partial sums in slot order and runs the same epilogue
 // (lane l owns column l of each channel; 64-lane reductions).
+template <int K>
 __global__ __launch_bounds__(256) void acmii_fixup_kernel(acm_conv_acmii_fwd_t p, CsrView csr, const float* __restrict__ partial) {
-    constexpr int K = 3;
     const int F = 64, lane = threadIdx.x & 63;
     const int w = acm_uniform(blockIdx.x * 4 + (threadIdx.x >> 6));
     if (w >= csr.n_long) return;
@@ -233,7 +243,8 @@ __global__ __launch_bounds__(256) void acmii_fixup_kernel(acm_conv_acmii_fwd_t p
     }
     const float rs = p.row_scale ? p.row_scale[row] : 1.f;
     const float pre0 = rs * pl, pre1 = p.zlh[(long)row * p.ld_zlh + F + lane] - rs * ph;
-    float H[4][1] = {{pre0}, {pre1}, {p.zi[(long)row * p.ld_zi + lane]}, {0.f}}, hn[4][1], xhat[4][1];
+    const float pre2 = K == 4 ? p.deg[row] * p.ps[(long)row * p.ld_ps + lane] - p.ss[(long)row * p.ld_ss + lane] : 0.f;
+    float H[4][1] = {{pre0}, {pre1}, {p.zi[(long)row * p.ld_zi + lane]}, {fmaxf(pre2, 0.f)}}, hn[4][1], xhat[4][1];
     HeadOut ho;
     HeadParams hp;
 #pragma unroll
@@ -241,14 +252,18 @@ __global__ __launch_bounds__(256) void acmii_fixup_kernel(acm_conv_acmii_fwd_t p
     hp.att_mix = p.att_mix;
     const LayWide<1> lay{lane};
     acm_head<LayWide<1>, K>(lay, F, p.layernorm, hp, H, hn, xhat, ho);
-    float o = p.scale * (ho.alpha[0] * H[0][0] + ho.alpha[1] * H[1][0] + ho.alpha[2] * H[2][0]);
+    float o = ho.alpha[0] * H[0][0] + ho.alpha[1] * H[1][0] + ho.alpha[2] * H[2][0];
+    if (K == 4) o += ho.alpha[3] * H[3][0];
+    o *= p.scale;
     if (p.post_relu) o = fmaxf(o, 0.f);
     if (p.post_scale) o *= p.post_scale[(long)row * p.ld_post_scale + lane];
     if (p.post_drop.p > 0.f) o *= acm_drop1(acm_drop_ctx(p.post_drop), row, lane);
     p.out[(long)row * p.ld_out + lane] = o;
     p.pre[(long)row * p.ld_pre + lane] = pre0;
     p.pre[(long)row * p.ld_pre + F + lane] = pre1;
-    if (lane == 0) *reinterpret_cast<float4*>(p.att + (long)row * 4) = make_float4(ho.alpha[0], ho.alpha[1], ho.alpha[2], 0.f);
+    if (K == 4) p.pre[(long)row * p.ld_pre + 2 * F + lane] = pre2;
+    if (lane == 0)
+        *reinterpret_cast<float4*>(p.att + (long)row * 4) = make_float4(ho.alpha[0], ho.alpha[1], ho.alpha[2], K == 4 ? ho.alpha[3] : 0.f);
 }
 
 }  // namespace
@@ -271,9 +286,13 @@ extern "C" int acm_conv_acmii_fwd(const acm_csr_t* a, const acm_conv_acmii_fwd_t
     ACM_REQUIRE(((uintptr_t)p->xg) % 8 == 0 && p->ld_xg % 2 == 0 && p->ld_xg >= p->f_pad && ((uintptr_t)p->xs) % 8 == 0 &&
                     p->ld_xs % 2 == 0 && p->ld_xs >= p->f_pad && ((uintptr_t)p->att) % 16 == 0, ACM_EINVAL,
                 "acm_conv_acmii_fwd: xg / xs rows must be 8-byte aligned and f_pad long, att 16-byte aligned");
-    ACM_REQUIRE(p->ld_w >= 64 && p->ld_out >= 64 && p->ld_pre >= 128 && p->ld_zlh >= 128 && p->ld_zi >= 64, ACM_ESHAPE,
+    const int K = p->n_channels;
+    ACM_REQUIRE(K == 3 || K == 4, ACM_ESHAPE, "acm_conv_acmii_fwd: n_channels %d", K);
+    ACM_REQUIRE(p->ld_w >= 64 && p->ld_out >= 64 && p->ld_pre >= 64 * (K - 1) && p->ld_zlh >= 128 && p->ld_zi >= 64, ACM_ESHAPE,
                 "acm_conv_acmii_fwd: leading dimension too small");
-    for (int c = 0; c < 3; ++c) {
+    ACM_REQUIRE(K == 3 || (p->ps && p->ss && p->deg && p->ld_ps >= 64 && p->ld_ss >= 64), ACM_EINVAL,
+                "acm_conv_acmii_fwd: structure-channel pointers NULL / leading dimensions too small");
+    for (int c = 0; c < K; ++c) {
         ACM_REQUIRE(p->att_vec[c], ACM_EINVAL, "acm_conv_acmii_fwd: att_vec[%d] NULL", c);
         ACM_REQUIRE(!p->layernorm || (p->ln_weight[c] && p->ln_bias[c]), ACM_EINVAL, "acm_conv_acmii_fwd: LayerNorm pointers NULL");
     }
@@ -286,11 +305,13 @@ extern "C" int acm_conv_acmii_fwd(const acm_csr_t* a, const acm_conv_acmii_fwd_t
     hipStream_t s = (hipStream_t)stream;
     const CsrView cv = acm_view(a);
     const int grid = (int)((a->n_items + 15) / 16);      // a wave takes four items, a workgroup sixteen
-    hipLaunchKernelGGL(acmii_fwd_kernel, dim3(grid), dim3(256), 0, s, *p, cv, (float*)workspace);
+    if (K == 3) hipLaunchKernelGGL(acmii_fwd_kernel<3>, dim3(grid), dim3(256), 0, s, *p, cv, (float*)workspace);
+    else hipLaunchKernelGGL(acmii_fwd_kernel<4>, dim3(grid), dim3(256), 0, s, *p, cv, (float*)workspace);
     ACM_CHECK_HIP(hipGetLastError());
     if (a->n_long) {
-        hipLaunchKernelGGL(acmii_fixup_kernel, dim3((unsigned)((a->n_long + 3) / 4)), dim3(256), 0, s, *p, cv,
-                           (const float*)workspace);
+        const dim3 fg((unsigned)((a->n_long + 3) / 4));
+        if (K == 3) hipLaunchKernelGGL(acmii_fixup_kernel<3>, fg, dim3(256), 0, s, *p, cv, (const float*)workspace);
+        else hipLaunchKernelGGL(acmii_fixup_kernel<4>, fg, dim3(256), 0, s, *p, cv, (const float*)workspace);
         ACM_CHECK_HIP(hipGetLastError());
     }
     return ACM_OK;

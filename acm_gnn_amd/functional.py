@@ -771,7 +771,7 @@ class AcmConvFunction(torch.autograd.Function):
             ctx.agg_first = False
         # ACMII first layer with a narrow input: gather the input rows and recompute relu(x_j [W_L | W_H]) per edge on
         # the matrix pipe instead of gathering the 2F-wide projected rows (acm_conv_acmii_fwd = K1 + K2)
-        ctx.recompute = (cfg.relu_before and not cfg.relu_after and cfg.relu_mlp and k == 3 and f == 64 and f_in <= 8
+        ctx.recompute = (cfg.relu_before and not cfg.relu_after and cfg.relu_mlp and f == 64 and f_in <= 8
                          and not sparse_x and not general and hops == 1 and not cfg.gather_bf16
                          and os.environ.get("ACM_ACMII_RECOMPUTE", "1") != "0")
         if ctx.agg_first or ctx.recompute:
@@ -856,9 +856,15 @@ class AcmConvFunction(torch.autograd.Function):
         if ctx.recompute:
             zlh = torch.empty(n, 2 * f, dtype=_F32, device=dev)
             zi = torch.empty(n, f, dtype=_F32, device=dev)
-            pre = torch.empty(n, 2 * f, dtype=_F32, device=dev)
+            pre = torch.empty(n, (k - 1) * f, dtype=_F32, device=dev)
             p = _lib.ConvAcmiiFwd()
             p.f_in, p.f_pad, p.f_out, p.layernorm, p.scale = f_in, fp, f, int(cfg.layernorm), cfg.scale
+            p.n_channels = k
+            if four:                                  # ps = A_low S: one F-wide single-channel gather of the parameter
+                ps = spmm(ops.low, s_gath, row_scale=ops.row_scale if ops.implicit else None)
+                p.ps, p.ld_ps = ps.data_ptr(), ps.stride(0)
+                p.ss, p.ld_ss = s_local.data_ptr(), s_local.stride(0)
+                p.deg = ops.deg.data_ptr()
             p.xg, p.ld_xg = xg.data_ptr(), xg.stride(0)
             p.xs, p.ld_xs = xpad.data_ptr(), xpad.stride(0)
             p.w_low, p.w_high, p.w_mlp, p.ld_w = wl.data_ptr(), wh.data_ptr(), wm.data_ptr(), f

@@ -510,7 +510,7 @@ int acm_conv_agg_bwd(int64_t n_rows, const acm_conv_agg_bwd_t* p,
  * (f_pad = 8 floats, a table that fits the L2) and recomputes relu(x_j [W_L | W_H]) per edge on the matrix pipe
  * (v_mfma_f32_16x16x4_f32, 16 neighbours per tile): same outputs as the two calls it replaces -- out, pre = [pre_L |
  * pre_H] and att as acm_conv_fwd, zlh = relu(X [W_L | W_H]) and zi = relu(X W_I) as the GEMM (K4's masks / self rows,
- * K3's s_mlp) -- equal to them up to fp32 re-association.  Three channels.  Values of an explicit operator must be
+ * K3's s_mlp) -- equal to them up to fp32 re-association.  Values of an explicit operator must be
  * non-negative (relu(a z) = a relu(z)).  Workspace: acm_conv_acmii_fwd_workspace_bytes (partial sums of the long rows'
  * pieces + the work counter of the persistent waves, reset by the call itself with a stream-ordered memset, so the
  * call is hipGraph-capturable).  The backward is acm_conv_bwd_local / acm_conv_bwd_spmm / acm_gemm as for the literal
@@ -535,6 +535,12 @@ typedef struct {
     int32_t post_relu;
     const float* row_scale;            /* pattern-only a_low: 1 / d_i                                            */
     acm_dropout_t post_drop;
+    /* structure channel (n_channels = 4; att_mix 4 x 4, scale 1, pre is [n_rows, 3 f_out]): the caller gathers the
+     * parameter first, ps = A_low S (acm_spmm_ex), as for acm_conv_agg_fwd; H_S = relu(deg * ps - ss) */
+    int32_t n_channels;                /* 3 or 4                                                                 */
+    const float* ps; int64_t ld_ps;    /* [n_rows, f_out]  A_low * S                                             */
+    const float* ss; int64_t ld_ss;    /* struc_low rows of the local nodes                                      */
+    const float* deg;                  /* d_i = rowsum(I + A)                                                    */
 } acm_conv_acmii_fwd_t;
 
 int acm_conv_acmii_fwd_workspace_bytes(const acm_csr_t* a_low, size_t* bytes);

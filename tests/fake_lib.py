@@ -392,7 +392,10 @@ class FakeLib:
         _view(p.zi, n, F, p.ld_zi)[...] = zs[:, 2 * F:]
         self._keep_acmii = zg32 = np.ascontiguousarray(zg[:, :2 * F].astype(np.float32))
         q = _lib.ConvFwd()
-        q.f_out, q.n_channels, q.relu_after, q.relu_mlp, q.layernorm, q.scale = F, 3, 0, 1, p.layernorm, p.scale
+        k = p.n_channels
+        q.f_out, q.n_channels, q.relu_after, q.relu_mlp, q.layernorm, q.scale = F, k, 0, 1, p.layernorm, p.scale
+        if k == 4:        # the call receives ps = A_low S already aggregated, acm_conv_fwd wants the parameter itself:
+            return self._acmii_four(handle, p, zg, zs)      # restate the four-channel math directly
         q.g_low, q.ld_g_low = zg32.ctypes.data, 2 * F
         q.g_high, q.ld_g_high = zg32.ctypes.data + 4 * F, 2 * F
         q.s_high, q.ld_s_high = p.zlh + 4 * F, p.ld_zlh
@@ -403,6 +406,27 @@ class FakeLib:
         q.post_scale, q.ld_post_scale, q.post_relu, q.row_scale, q.post_drop = (p.post_scale, p.ld_post_scale, p.post_relu,
                                                                                 p.row_scale, p.post_drop)
         return self.acm_conv_fwd(handle, C.byref(q), ws, wsb, stream)
+
+    def _acmii_four(self, handle, p, zg, zs):
+        """ACMII layer with the structure channel from the precomputed ps = A_low S (numpy, float64)."""
+        g = self._handles[handle.value if isinstance(handle, C.c_void_p) else int(handle)]
+        n, F = g.n_rows, p.f_out
+        f64 = np.float64
+        rs = _vec(p.row_scale, n).astype(f64)[:, None] if p.row_scale else 1.0
+        pl = rs * g.dense_mul(zg[:, :F].astype(np.float32))
+        ph = zs[:, F:2 * F] - rs * g.dense_mul(zg[:, F:2 * F].astype(np.float32))
+        pS = _vec(p.deg, n).astype(f64)[:, None] * _view(p.ps, n, F, p.ld_ps).astype(f64) - _view(p.ss, n, F, p.ld_ss).astype(f64)
+        H = [pl, ph, zs[:, 2 * F:], np.maximum(pS, 0)]
+        vecs = [_vec(p.att_vec[c], F).astype(f64) for c in range(4)]
+        lnw = [_vec(p.ln_weight[c], F).astype(f64) for c in range(4)] if p.layernorm else None
+        lnb = [_vec(p.ln_bias[c], F).astype(f64) for c in range(4)] if p.layernorm else None
+        hd = _head(H, 4, p.layernorm, vecs, lnw, lnb, _view(p.att_mix, 4, 4, 4).astype(f64))
+        out = p.scale * sum(hd["alpha"][:, c:c + 1] * H[c] for c in range(4))
+        _view(p.out, n, F, p.ld_out)[...] = _post_fwd(p, out, n, F)
+        pre = _view(p.pre, n, 3 * F, p.ld_pre)
+        pre[:, :F], pre[:, F:2 * F], pre[:, 2 * F:] = pl, ph, pS
+        _view(p.att, n, 4, 4)[...] = hd["alpha"]
+        return 0
 
     # ---- ACM-GCN++ residual branch ------------------------------------------------
     @staticmethod

@@ -455,9 +455,10 @@ def test_snowball_matches_oracle(variant, nlayers, p_drop):
             assert float((p.grad.cpu() - rg).abs().max()) < 1e-4 * max(1.0, float(rg.abs().max())), k
 
 
-@pytest.mark.parametrize("model_type,ln,f_in,implicit", [("acmgcnp", True, 7, True), ("acmgcn", False, 8, True),
-                                                         ("acmgcnp", True, 3, False), ("acmgcnpp", False, 1, True)])
-def test_acmii_recompute_on_gather_matches_oracle_and_literal(model_type, ln, f_in, implicit, monkeypatch):
+@pytest.mark.parametrize("model_type,ln,f_in,implicit,s", [("acmgcnp", True, 7, True, 0), ("acmgcn", False, 8, True, 0),
+                                                           ("acmgcnp", True, 3, False, 0), ("acmgcnpp", False, 1, True, 0),
+                                                           ("acmgcnp", True, 7, True, 1), ("acmgcnpp", False, 5, False, 1)])
+def test_acmii_recompute_on_gather_matches_oracle_and_literal(model_type, ln, f_in, implicit, s, monkeypatch):
     """ACMII first layer with a narrow input (layers.py:94-99): acm_conv_acmii_fwd gathers the 32-byte input rows and
     recomputes relu(x_j [W_L | W_H]) per edge on the matrix pipe; against the oracle (forward, every gradient) and
     against the literal project-then-gather form, on a graph with a split hub row."""
@@ -467,12 +468,12 @@ def test_acmii_recompute_on_gather_matches_oracle_and_literal(model_type, ln, f_
     AF.set_kernel_timer(timer)
     try:
         monkeypatch.setenv("ACM_ACMII_RECOMPUTE", "1")
-        a = _run_both(model_type, 1, 0, ln, 700, f_in, 64, 31, False, monkeypatch, agg=True, adj=adj, implicit=implicit)
+        a = _run_both(model_type, 1, s, ln, 700, f_in, 64, 31, False, monkeypatch, agg=True, adj=adj, implicit=implicit)
         used = set(k.split("/")[0] for k in timer.events)
         assert "conv_acmii_fwd" in used and "conv_fwd" not in used and "conv_bwd_spmm" in used, used
         timer.events.clear()
         monkeypatch.setenv("ACM_ACMII_RECOMPUTE", "0")
-        b = _run_both(model_type, 1, 0, ln, 700, f_in, 64, 31, False, monkeypatch, agg=True, adj=adj, implicit=implicit)
+        b = _run_both(model_type, 1, s, ln, 700, f_in, 64, 31, False, monkeypatch, agg=True, adj=adj, implicit=implicit)
         used = set(k.split("/")[0] for k in timer.events)
         assert "conv_fwd" in used and "conv_acmii_fwd" not in used, used
     finally:

@@ -301,8 +301,8 @@ def test_snowball_model_matches_the_reference_wiring(variant, nlayers, monkeypat
             _close(p.grad, params[k].grad.float().numpy(), k)
 
 
-@pytest.mark.parametrize("f_in", [7, 3])
-def test_acmii_recompute_host_path_equals_literal(f_in, monkeypatch):
+@pytest.mark.parametrize("f_in,s_info", [(7, 0), (3, 0), (7, 1)])
+def test_acmii_recompute_host_path_equals_literal(f_in, s_info, monkeypatch):
     """Host plumbing of the ACMII recompute-on-gather route (functional.AcmConvFunction -> acm_conv_acmii_fwd, then the
     literal backward on the tensors that call saved) against the literal route and the oracle."""
     fake_lib.install(monkeypatch)
@@ -318,16 +318,16 @@ def test_acmii_recompute_host_path_equals_literal(f_in, monkeypatch):
         monkeypatch.setenv("ACM_ACMII_RECOMPUTE", mode)
         clear_cache()
         torch.manual_seed(3)
-        layer = GraphConvolution(f_in, 64, n, "acmgcnp", variant=True, attn_layernorm=True)
-        out = layer(x, low, high, None)
+        layer = GraphConvolution(f_in, 64, n, "acmgcnp", variant=True, structure_info=s_info, attn_layernorm=True)
+        out = layer(x, low, high, un if s_info else None)
         out.backward(go)
         res[mode] = (out.detach(), _model_grads(layer), layer)
     _close(res["1"][0], res["0"][0].numpy(), "recompute vs literal", **FWD)
     for k, v in res["0"][1].items():
         _close(res["1"][1][k], v.numpy(), "recompute vs literal " + k)
     params = {k: v.detach().clone().double().requires_grad_(True) for k, v in res["1"][2].named_parameters()}
-    ref = oracle.layer_forward(params, x.double(), low.double(), high.double(), None, model_type="acmgcnp", variant=True,
-                               attn_layernorm=True)
+    ref = oracle.layer_forward(params, x.double(), low.double(), high.double(), un.double() if s_info else None,
+                               model_type="acmgcnp", variant=True, structure_info=s_info, attn_layernorm=True)
     ref.backward(go.double())
     _close(res["1"][0], ref.detach().float().numpy(), "recompute vs oracle", **FWD)
     for k, v in res["1"][1].items():
