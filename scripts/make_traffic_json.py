@@ -4,7 +4,7 @@
 /opt/skills/guides/MI355X_MICROARCH.md prescribes for gfx950.  Keys are bench.py's kernel labels; a label
 made of several launches (gather + row epilogue) sums them.
 
-    python scripts/make_traffic_json.py pmc_fetch_size_kb.csv pmc_write_size_kb.csv > pmc_traffic.json
+    python scripts/make_traffic_json.py pmc_fetch_size_kb.csv pmc_write_size_kb.csv [commit] > pmc_traffic.json
 """
 import csv
 import json
@@ -32,9 +32,10 @@ def load(path, column):
     return out
 
 
-def main(fetch_csv, write_csv):
+def main(fetch_csv, write_csv, commit=None):
     fetch, write = load(fetch_csv, "FETCH_SIZE_avg"), load(write_csv, "WRITE_SIZE_avg")
-    doc = {"_doc": "HBM-side bytes per launch from rocprofv3 PMC (separate --pmc FETCH_SIZE / WRITE_SIZE passes over "
+    doc = {"_commit": commit or "unknown",
+           "_doc": "HBM-side bytes per launch from rocprofv3 PMC (separate --pmc FETCH_SIZE / WRITE_SIZE passes over "
                    "bench.py's default workload). hbm_bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024: FETCH_SIZE doubled as "
                    "MI355X_MICROARCH.md prescribes for gfx950 (calibrated there on wide coalesced streams; the random "
                    "16-32 B gathers here are outside that calibration, so read ratios to algorithmic bytes as 1x..2x)."}
@@ -55,4 +56,4 @@ def main(fetch_csv, write_csv):
 
 
 if __name__ == "__main__":
-    main(sys.argv[1], sys.argv[2])
+    main(sys.argv[1], sys.argv[2], sys.argv[3] if len(sys.argv) > 3 else None)
