@@ -481,8 +481,8 @@ __device__ __forceinline__ int acm_row_bcast(int v, int u) {
 }
 
 template <int NG, int NB, int UNR, int BLK>
-__device__ __forceinline__ void gather_vec_block(const GatherSrc& g, const unsigned (&ldb)[3], unsigned lane_off, bool col_ok,
-                                                 int my_j, float my_a, float (&acc)[NG][4 * NB]) {
+__device__ __forceinline__ void gather_vec_block(const GatherSrc& g, const unsigned (&ldb)[3], const unsigned (&blk_off)[NB],
+                                                 unsigned ok_mask, int my_j, float my_a, float (&acc)[NG][4 * NB]) {
     float4 z[UNR][NG][NB];
     float a[UNR];
 #pragma unroll
@@ -491,21 +491,22 @@ __device__ __forceinline__ void gather_vec_block(const GatherSrc& g, const unsig
         a[uu] = __int_as_float(acm_row_bcast(__float_as_int(my_a), BLK * UNR + uu));
 #pragma unroll
         for (int c = 0; c < NG; ++c) {
-            const char* rp = reinterpret_cast<const char*>(g.p[c]) + (size_t)(j * ldb[c] + lane_off);
+            const char* rp = reinterpret_cast<const char*>(g.p[c]) + (size_t)(j * ldb[c]);
 #pragma unroll
-            for (int b = 0; b < NB; ++b) z[uu][c][b] = *reinterpret_cast<const float4*>(rp + 256 * b);
+            for (int b = 0; b < NB; ++b) z[uu][c][b] = *reinterpret_cast<const float4*>(rp + blk_off[b]);
         }
     }
 #pragma unroll
     for (int uu = 0; uu < UNR; ++uu) {
-        // an idle slot (beyond the row's end, or columns beyond F) fetched row 0: select, never multiply by a zero
-        // weight (0 * inf = NaN would leak a non-finite row the operator does not reference)
-        const bool live = col_ok && a[uu] != 0.f;
+        // an idle slot (beyond the row's end) fetched row 0 and a lane whose columns lie beyond F fetched the row's first
+        // bytes: select, never multiply by a zero weight (0 * inf = NaN would leak a non-finite row the operator does not
+        // reference)
         const float av = a[uu];
 #pragma unroll
         for (int c = 0; c < NG; ++c)
 #pragma unroll
             for (int b = 0; b < NB; ++b) {
+                const bool live = ((ok_mask >> b) & 1u) && av != 0.f;
                 acc[c][4 * b + 0] = live ? fmaf(av, z[uu][c][b].x, acc[c][4 * b + 0]) : acc[c][4 * b + 0];
                 acc[c][4 * b + 1] = live ? fmaf(av, z[uu][c][b].y, acc[c][4 * b + 1]) : acc[c][4 * b + 1];
                 acc[c][4 * b + 2] = live ? fmaf(av, z[uu][c][b].z, acc[c][4 * b + 2]) : acc[c][4 * b + 2];
@@ -529,9 +530,15 @@ __global__ __launch_bounds__(256) void spmm_vec_kernel(CsrView csr, GatherSrc g,
     for (int c = 0; c < NG; ++c)
 #pragma unroll
         for (int i = 0; i < 4 * NB; ++i) acc[c][i] = 0.f;
-    // a lane whose columns lie beyond F (F < 64 NB) reads the row's first bytes and contributes nothing
-    const bool col_ok = 4 * m < F;                       // block b > 0: checked per column in the epilogue (F % 4 == 0)
-    const unsigned lane_off = col_ok ? 16u * m : 0u;
+    // byte offset of the lane's float4 in column block b; a lane whose columns lie beyond F (F % 4 == 0, F < 64 NB) reads
+    // the row's first bytes instead (always inside the row) and contributes nothing
+    unsigned blk_off[NB], ok_mask = 0;
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+        const bool ok = 64 * b + 4 * m < F;
+        blk_off[b] = ok ? 256u * b + 16u * m : 0u;
+        ok_mask |= ok ? (1u << b) : 0u;
+    }
     unsigned ldb[3];
 #pragma unroll
     for (int c = 0; c < 3; ++c) ldb[c] = c < NG ? (unsigned)g.ld[c] * 4u : 0u;
@@ -547,7 +554,7 @@ __global__ __launch_bounds__(256) void spmm_vec_kernel(CsrView csr, GatherSrc g,
         const int steps = (cnt + 3) >> 2;
         // the step index must be a compile-time constant for the DPP broadcast: 16 / UNR unrolled blocks, uniform exits
 #define ACM_VEC_BLK(B)                                                                                          \
-        if (B * UNR < steps) gather_vec_block<NG, NB, UNR, B>(g, ldb, lane_off, col_ok, my_j, my_a, acc)
+        if (B * UNR < steps) gather_vec_block<NG, NB, UNR, B>(g, ldb, blk_off, ok_mask, my_j, my_a, acc)
         ACM_VEC_BLK(0);
         ACM_VEC_BLK(1);
         ACM_VEC_BLK(2);
@@ -874,7 +881,10 @@ int launch_gather(const acm_csr* a, const GatherSrc& g, int F, const typename Ep
         // vector layout runs the head four times redundantly, and with two gathered channels its 58 VGPRs cost
         // occupancy, so it is the default for single-channel products (k-hop chains, spmm_sub, the S gather of the
         // aggregate-first structure channel); ACM_WIDE_VEC=1 forces it everywhere, ACM_WIDE_SCALAR=1 nowhere.
-        bool vec = !bf16 && F % 4 == 0 && getenv("ACM_WIDE_SCALAR") == nullptr && (NG == 1 || getenv("ACM_WIDE_VEC") != nullptr);
+        // Rows of a few entries (CSR feature matrices: 5-18 per row) never fill the four-neighbour steps: 24 -> 35 us for
+        // the Penn94-shaped feature projection, so the vector form also needs a mean row length of 16.
+        bool vec = !bf16 && F % 4 == 0 && getenv("ACM_WIDE_SCALAR") == nullptr &&
+                   ((NG == 1 && a->nnz >= 16 * a->n_rows) || getenv("ACM_WIDE_VEC") != nullptr);
         for (int c = 0; c < NG && vec; ++c)
             vec = ((uintptr_t)g.p[c]) % 16 == 0 && g.ld[c] % 4 == 0 &&
                   (uint64_t)a->n_cols * (uint64_t)g.ld[c] * 4u < (1ull << 32);
@@ -884,6 +894,8 @@ int launch_gather(const acm_csr* a, const GatherSrc& g, int F, const typename Ep
                 hipLaunchKernelGGL((spmm_vec_kernel<NG, 1, Epi>), dim3(grid), dim3(256), 0, st, v, g, F, ea, partial);
             else if (F <= 128)
                 hipLaunchKernelGGL((spmm_vec_kernel<NG, 2, Epi>), dim3(grid), dim3(256), 0, st, v, g, F, ea, partial);
+            else if (F <= 192)
+                hipLaunchKernelGGL((spmm_vec_kernel<NG, 3, Epi>), dim3(grid), dim3(256), 0, st, v, g, F, ea, partial);
             else
                 hipLaunchKernelGGL((spmm_vec_kernel<NG, 4, Epi>), dim3(grid), dim3(256), 0, st, v, g, F, ea, partial);
         } else if (bf16)
