@@ -285,3 +285,32 @@ def test_device_filter_construction_is_bit_exact(tmp_path):
     want = AF.spmm(expl.low, x)
     got2 = ops.row_scale[:, None] * AF.spmm(ops.low, x)
     assert float((got2 - want).abs().max()) < 1e-5 * float(want.abs().max())
+
+
+@pytest.mark.parametrize("width", [16, 64, 68, 100, 128, 132, 192, 200, 256, 320])
+@pytest.mark.parametrize("mode", ["vec", "scalar"])
+def test_wide_gather_forms_match_scipy(width, mode, monkeypatch):
+    """The vector form of the wide gather (dwordx4 rows, four neighbours per instruction; spmm_vec_kernel) forced on,
+    and the dword-per-lane form, for widths that fill column blocks exactly, partially (no read may leave the row:
+    the last table row ends the allocation), and beyond 256 columns (two kernel passes); split hub rows, empty rows,
+    pattern-only handles and a non-finite row the operator never references."""
+    from acm_gnn_amd import functional as AF
+    from acm_gnn_amd.graph import CsrGraph
+    monkeypatch.setenv("ACM_WIDE_VEC" if mode == "vec" else "ACM_WIDE_SCALAR", "1")
+    m = _rand_csr(400, 333, 0.06, seed=width, hub_rows={5: 300, 399: 150}, empty_rows=(0, 17))
+    m[:, 332] = 0                                                   # nobody references the last table row ...
+    m = sp.csr_matrix(m)
+    m.eliminate_zeros()
+    dense = torch.randn(333, width, generator=torch.Generator().manual_seed(width))
+    dense[332] = float("nan")                                       # ... which is poisoned
+    ref = m.astype(np.float64) @ np.nan_to_num(dense.double().numpy())
+    for chunk in (0, 32):
+        g = CsrGraph.from_scipy(m, DEV, chunk=chunk)
+        out = AF.spmm(g, dense.to(DEV)).cpu().numpy()
+        assert np.isfinite(out).all()
+        np.testing.assert_allclose(out, ref, rtol=1e-5, atol=1e-5)
+    ip, ix, _ = (t for t in CsrGraph.from_scipy(m, DEV).arrays())
+    pat = CsrGraph.from_csr(ip, ix, None, 333)
+    ones = sp.csr_matrix((np.ones(m.nnz), m.indices, m.indptr), shape=m.shape)
+    np.testing.assert_allclose(AF.spmm(pat, dense.to(DEV)).cpu().numpy(), ones @ np.nan_to_num(dense.double().numpy()),
+                               rtol=1e-5, atol=1e-5)
