@@ -308,9 +308,9 @@ def test_wide_gather_forms_match_scipy(width, mode, monkeypatch):
         g = CsrGraph.from_scipy(m, DEV, chunk=chunk)
         out = AF.spmm(g, dense.to(DEV)).cpu().numpy()
         assert np.isfinite(out).all()
-        np.testing.assert_allclose(out, ref, rtol=1e-5, atol=1e-5)
+        np.testing.assert_allclose(out, ref, rtol=1e-5, atol=4e-5)      # hub rows: sums of 300 N(0,1)-sized terms
     ip, ix, _ = (t for t in CsrGraph.from_scipy(m, DEV).arrays())
     pat = CsrGraph.from_csr(ip, ix, None, 333)
     ones = sp.csr_matrix((np.ones(m.nnz), m.indices, m.indptr), shape=m.shape)
     np.testing.assert_allclose(AF.spmm(pat, dense.to(DEV)).cpu().numpy(), ones @ np.nan_to_num(dense.double().numpy()),
-                               rtol=1e-5, atol=1e-5)
+                               rtol=1e-5, atol=4e-5)
