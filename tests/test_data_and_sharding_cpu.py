@@ -193,8 +193,9 @@ def _worker(rank, world, port, cfg, ret):
         ops.hops = cfg.get("hops", 1)
         torch.manual_seed(0)
         pdrop = cfg.get("dropout", 0.0)
-        full = GCN(7, 16, 2, 2, n, pdrop, cfg["model"], cfg["s"], variant=bool(cfg["variant"]), attn_layernorm=True)
-        model = GCN(7, 16, 2, 2, e - b, pdrop, cfg["model"], cfg["s"], variant=bool(cfg["variant"]), attn_layernorm=True)
+        hid = cfg.get("hid", 16)
+        full = GCN(7, hid, 2, 2, n, pdrop, cfg["model"], cfg["s"], variant=bool(cfg["variant"]), attn_layernorm=True)
+        model = GCN(7, hid, 2, 2, e - b, pdrop, cfg["model"], cfg["s"], variant=bool(cfg["variant"]), attn_layernorm=True)
         if pdrop:                                       # counter-based dropout: every rank draws the global mask
             from acm_gnn_amd import functional as AF
             model.fused_dropout, model.dropout_state = True, AF.DropoutState("cpu", seed=7)
@@ -235,12 +236,15 @@ def _worker(rank, world, port, cfg, ret):
                                  dict(model="acmgcnp", s=1, variant=0, world=4, plan="work", dropout=0.5),
                                  dict(model="acmsgc", s=0, variant=0, hops=3, world=4, plan="work"),
                                  dict(model="acmgcnpp", s=0, variant=0, dropout=0.5),
-                                 dict(model="acmgcnpp", s=1, variant=1, world=4, plan="work")],
+                                 dict(model="acmgcnpp", s=1, variant=1, world=4, plan="work"),
+                                 dict(model="acmgcnp", s=0, variant=1, hid=64, dropout=0.5, x_full=1),
+                                 dict(model="acmgcnp", s=1, variant=1, hid=64, plan="work")],
                          ids=["agg+literal", "struct-acmii", "acmii", "struct-agg", "struct-agg-explicit",
                               "struct-acmii-explicit", "dropout", "dropout-xfull-struct", "dropout-xfull-acmii",
                               "sgc-3hop", "sgc-2hop-explicit", "work-plan-struct-agg", "work-plan-acmii-explicit",
                               "work-plan-dropout", "4-ranks-struct-acmii", "4-ranks-work-plan-dropout",
-                              "4-ranks-work-plan-sgc-3hop", "acmgcnpp-dropout", "4-ranks-work-plan-acmgcnpp"])
+                              "4-ranks-work-plan-sgc-3hop", "acmgcnpp-dropout", "4-ranks-work-plan-acmgcnpp",
+                              "acmii-recompute-dropout-xfull", "acmii-recompute-struct-work-plan"])
 def test_row_shard_equals_single_process(cfg, monkeypatch):
     """world_size = 2 and 4 over gloo: the sharded forward/backward (halo all-gathers + parameter-gradient
     all-reduce issued by functional.AcmConvFunction) must reproduce the 1-process result -- with equal blocks and
@@ -285,7 +289,7 @@ def test_row_shard_equals_single_process(cfg, monkeypatch):
         assert len({r[4][1] - r[4][0] for r in results}) > 1               # the blocks really differ in length
     ops.hops = cfg.get("hops", 1)
     torch.manual_seed(0)
-    full = GCN(7, 16, 2, 2, n, cfg.get("dropout", 0.0), cfg["model"], cfg["s"], variant=bool(cfg["variant"]),
+    full = GCN(7, cfg.get("hid", 16), 2, 2, n, cfg.get("dropout", 0.0), cfg["model"], cfg["s"], variant=bool(cfg["variant"]),
                attn_layernorm=True)
     if cfg.get("dropout"):
         from acm_gnn_amd import functional as AF
