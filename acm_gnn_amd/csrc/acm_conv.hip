@@ -883,8 +883,14 @@ int launch_gather(const acm_csr* a, const GatherSrc& g, int F, const typename Ep
         // aggregate-first structure channel); ACM_WIDE_VEC=1 forces it everywhere, ACM_WIDE_SCALAR=1 nowhere.
         // Rows of a few entries (CSR feature matrices: 5-18 per row) never fill the four-neighbour steps: 24 -> 35 us for
         // the Penn94-shaped feature projection, so the vector form also needs a mean row length of 16.
+        // (iii) gathered tables that fit the L2 (Squirrel / Chameleon / Cora sizes) take it for any channel count: there
+        // the rows arrive at L2 speed and the instruction count is what bounds the kernel (Squirrel with the structure
+        // channel: conv_bwd_spmm 57.8 -> 42.6 us, conv_fwd 64.1 -> 57.7, step 0.283 -> 0.265 ms; it replaces the
+        // two-neighbours-per-instruction pair form of round 1 on those graphs).
+        const bool l2_resident = (size_t)a->n_cols * F * NG * sizeof(float) <= (8u << 20);
         bool vec = !bf16 && F % 4 == 0 && getenv("ACM_WIDE_SCALAR") == nullptr &&
-                   ((NG == 1 && a->nnz >= 16 * a->n_rows) || getenv("ACM_WIDE_VEC") != nullptr);
+                   ((NG == 1 && a->nnz >= 16 * a->n_rows) || (l2_resident && NG > 1 && a->nnz >= 4 * a->n_rows) ||
+                    getenv("ACM_WIDE_VEC") != nullptr);
         for (int c = 0; c < NG && vec; ++c)
             vec = ((uintptr_t)g.p[c]) % 16 == 0 && g.ld[c] % 4 == 0 &&
                   (uint64_t)a->n_cols * (uint64_t)g.ld[c] * 4u < (1ull << 32);
