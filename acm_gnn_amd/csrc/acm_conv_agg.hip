@@ -445,36 +445,63 @@ __global__ __launch_bounds__(256) void agg_fused_pair_mfma_kernel(acm_conv_agg_f
     const int gl = threadIdx.x & 15, lane = threadIdx.x & 63, e = gl >> 1, h = gl & 1, kq = lane >> 4;
     const int G = gridDim.x * GPB;
     int w = blockIdx.x * GPB + (threadIdx.x >> 4);
-    // every wave runs the same number of rounds (the MFMA epilogue needs the whole wave): a group without an item idles
+    // every wave runs the same number of rounds (the MFMA epilogue needs the whole wave): a group without an item walks an
+    // empty one.  Same software pipeline over the work list as agg_fused_pair_kernel: the next step's ids (of this item or
+    // of the next one) are requested while the current rows are in flight.
     const int rounds = (csr.n_items - blockIdx.x * GPB + G - 1) / G;
     const bool unit = csr.vals == nullptr;
     const float* xh = p.xg + 4 * h;
     const f32x4m zero4 = {0.f, 0.f, 0.f, 0.f};
-    for (int rd = 0; rd < rounds; ++rd, w += G) {
+    auto item_at = [&](int idx) {
+        AcmItem t = csr.items[idx < csr.n_items ? idx : 0];
+        if (idx >= csr.n_items) t.end = t.begin, t.slot = 0x7fffffff;
+        return t;
+    };
+    AcmItem it = item_at(w);
+    int j[U];
+    float a[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        const int k = it.begin + e + 8 * u;
+        const bool v = k < it.end;
+        const int kc = v ? k : 0;
+        j[u] = csr.indices[kc];
+        a[u] = v ? (unit ? 1.f : csr.vals[kc]) : 0.f;
+    }
+    for (int rd = 0; rd < rounds; ++rd) {
         const bool have = w < csr.n_items;
-        AcmItem it = csr.items[have ? w : 0];
-        if (!have) it.end = it.begin;
+        const AcmItem itn = item_at(w + G);
         float acc[4] = {0.f, 0.f, 0.f, 0.f};
-        for (int k0 = it.begin; k0 < it.end; k0 += STEP) {
-            int j[U];
-            float a[U];
+        int k0 = it.begin;
+        while (true) {
+            float4 z[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) z[u] = *reinterpret_cast<const float4*>(xh + (long)j[u] * p.ld_xg);
+            const int k1 = k0 + STEP;
+            const bool more = k1 < it.end;
+            const int pb = more ? k1 : itn.begin, pe = more ? it.end : itn.end;
+            int nj[U];
+            float na[U];
 #pragma unroll
             for (int u = 0; u < U; ++u) {
-                const int k = k0 + e + 8 * u;
-                const bool v = k < it.end;
-                const int kc = v ? k : it.begin;
-                j[u] = csr.indices[kc];
-                a[u] = v ? (unit ? 1.f : csr.vals[kc]) : 0.f;
+                const int k = pb + e + 8 * u;
+                const bool v = k < pe;
+                const int kc = v ? k : 0;
+                nj[u] = csr.indices[kc];
+                na[u] = v ? (unit ? 1.f : csr.vals[kc]) : 0.f;
             }
 #pragma unroll
             for (int u = 0; u < U; ++u) {
-                const float4 z = *reinterpret_cast<const float4*>(xh + (long)j[u] * p.ld_xg);
                 const bool v = a[u] != 0.f;
-                acc[0] = v ? fmaf(a[u], z.x, acc[0]) : acc[0];
-                acc[1] = v ? fmaf(a[u], z.y, acc[1]) : acc[1];
-                acc[2] = v ? fmaf(a[u], z.z, acc[2]) : acc[2];
-                acc[3] = v ? fmaf(a[u], z.w, acc[3]) : acc[3];
+                acc[0] = v ? fmaf(a[u], z[u].x, acc[0]) : acc[0];
+                acc[1] = v ? fmaf(a[u], z[u].y, acc[1]) : acc[1];
+                acc[2] = v ? fmaf(a[u], z[u].z, acc[2]) : acc[2];
+                acc[3] = v ? fmaf(a[u], z[u].w, acc[3]) : acc[3];
             }
+#pragma unroll
+            for (int u = 0; u < U; ++u) j[u] = nj[u], a[u] = na[u];
+            if (!more) break;
+            k0 = k1;
         }
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -562,6 +589,8 @@ __global__ __launch_bounds__(256) void agg_fused_pair_mfma_kernel(acm_conv_agg_f
             }
             if (gl == 0) *reinterpret_cast<float4*>(p.att + row * 4) = make_float4(rh.alpha[0], rh.alpha[1], rh.alpha[2], 0.f);
         }
+        it = itn;
+        w += G;
     }
 }
 
