@@ -21,8 +21,7 @@ ARCH = "gfx950"
 # with the results in AGPRs hipcc copies each of them through v_accvgpr_read (32 extra VALU instructions per 16 MFMAs and
 # 28 more registers); the VGPR form of the MFMA writes them where the VALU can use them (150 -> 95 instructions per batch,
 # 152 -> 96 registers).
-EXTRA_FLAGS = {"acm_conv_acmii.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"],
-               "acm_conv_agg.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"]}   # the MFMA-projection epilogue; agg_bwd's code is unchanged by it
+EXTRA_FLAGS = {"acm_conv_acmii.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"]}
 
 
 def _hipcc():

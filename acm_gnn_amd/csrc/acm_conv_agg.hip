@@ -407,193 +407,6 @@ __global__ __launch_bounds__(256) void agg_fused_pair_kernel(acm_conv_agg_fwd_t 
     }
 }
 
-// ---- the same kernel with the three 8 x 64 projections on the MATRIX pipe (f_pad = 8, F = 64, three channels).
-// The VALU projection costs the epilogue ~140 of its ~450 instructions per four rows (96 FMAs + 24 ds_read_b128 + the
-// scratch broadcasts); the epilogue is issue-bound and sits in the wave's serial chain behind the gather.  Here the
-// four finished rows of a wave are rows 0, 4, 8, 12 of the A operand of v_mfma_f32_16x16x4_f32 (lane (i, kq) supplies
-// feature 2 kq + s of the row of lane group i >> 2 when i & 3 == 0, zero otherwise), B = the weights from LDS in operand
-// layout, and register 0 of the result tile in lane group g is row g's projection for column 16 t + (lane & 15) -- the
-// layout the head works in.  24 MFMAs per four rows on an otherwise idle pipe; results in VGPR form (build.py).
-typedef float f32x4m __attribute__((ext_vector_type(4)));
-
-// weights in MFMA B-operand layout: wb[((c * 2 + s) * 4 + t) * 64 + lane] = W_c[2 (lane >> 4) + s][16 t + (lane & 15)]
-__device__ __forceinline__ void stage_weights_mfma(float* wb, const float* w_low, const float* w_high, const float* w_mlp,
-                                                   long ld, int f_in) {
-    for (int idx = threadIdx.x; idx < 24 * 64; idx += 256) {
-        const int l = idx & 63, t = (idx >> 6) & 3, s = (idx >> 8) & 1, c = idx >> 9;
-        const int f = 2 * (l >> 4) + s;
-        const float* w = c == 0 ? w_low : (c == 1 ? w_high : w_mlp);
-        wb[idx] = f < f_in ? w[(long)f * ld + 16 * t + (l & 15)] : 0.f;
-    }
-}
-
-__global__ __launch_bounds__(256) void agg_fused_pair_mfma_kernel(acm_conv_agg_fwd_t p, CsrView csr) {
-    constexpr int FP = 8, K = 3, GPB = 16, U = 4, STEP = 8 * U;
-    static_assert(GPB == ACM_WINDOW, "one window of work items per workgroup round");
-    __shared__ __attribute__((aligned(16))) float wb[24 * 64 + 3 * K * 64 + 16 * 2 * FP];
-    __shared__ float coop[ACM_WINDOW * FP];
-    float* hlds = wb + 24 * 64;
-    float* scr_wave = hlds + 3 * K * 64 + (threadIdx.x >> 6) * 4 * 2 * FP;     // this wave's four groups: P | x each
-    float* scratch = scr_wave + ((threadIdx.x >> 4) & 3) * 2 * FP;
-    stage_weights_mfma(wb, p.w_low, p.w_high, p.w_mlp, p.ld_w, p.f_in);
-    stage_head_params<K>(hlds, p.att_vec, p.ln_weight, p.ln_bias, p.layernorm, 64);
-    __syncthreads();
-    float mixm[K * K];
-#pragma unroll
-    for (int q = 0; q < K * K; ++q) mixm[q] = p.att_mix[q];
-    const AcmDropCtx dc = acm_drop_ctx(p.post_drop);
-    const int gl = threadIdx.x & 15, lane = threadIdx.x & 63, e = gl >> 1, h = gl & 1, kq = lane >> 4;
-    const int G = gridDim.x * GPB;
-    int w = blockIdx.x * GPB + (threadIdx.x >> 4);
-    // every wave runs the same number of rounds (the MFMA epilogue needs the whole wave): a group without an item walks an
-    // empty one.  Same software pipeline over the work list as agg_fused_pair_kernel: the next step's ids (of this item or
-    // of the next one) are requested while the current rows are in flight.
-    const int rounds = (csr.n_items - blockIdx.x * GPB + G - 1) / G;
-    const bool unit = csr.vals == nullptr;
-    const float* xh = p.xg + 4 * h;
-    const f32x4m zero4 = {0.f, 0.f, 0.f, 0.f};
-    auto item_at = [&](int idx) {
-        AcmItem t = csr.items[idx < csr.n_items ? idx : 0];
-        if (idx >= csr.n_items) t.end = t.begin, t.slot = 0x7fffffff;
-        return t;
-    };
-    AcmItem it = item_at(w);
-    int j[U];
-    float a[U];
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-        const int k = it.begin + e + 8 * u;
-        const bool v = k < it.end;
-        const int kc = v ? k : 0;
-        j[u] = csr.indices[kc];
-        a[u] = v ? (unit ? 1.f : csr.vals[kc]) : 0.f;
-    }
-    for (int rd = 0; rd < rounds; ++rd) {
-        const bool have = w < csr.n_items;
-        const AcmItem itn = item_at(w + G);
-        float acc[4] = {0.f, 0.f, 0.f, 0.f};
-        int k0 = it.begin;
-        while (true) {
-            float4 z[U];
-#pragma unroll
-            for (int u = 0; u < U; ++u) z[u] = *reinterpret_cast<const float4*>(xh + (long)j[u] * p.ld_xg);
-            const int k1 = k0 + STEP;
-            const bool more = k1 < it.end;
-            const int pb = more ? k1 : itn.begin, pe = more ? it.end : itn.end;
-            int nj[U];
-            float na[U];
-#pragma unroll
-            for (int u = 0; u < U; ++u) {
-                const int k = pb + e + 8 * u;
-                const bool v = k < pe;
-                const int kc = v ? k : 0;
-                nj[u] = csr.indices[kc];
-                na[u] = v ? (unit ? 1.f : csr.vals[kc]) : 0.f;
-            }
-#pragma unroll
-            for (int u = 0; u < U; ++u) {
-                const bool v = a[u] != 0.f;
-                acc[0] = v ? fmaf(a[u], z[u].x, acc[0]) : acc[0];
-                acc[1] = v ? fmaf(a[u], z[u].y, acc[1]) : acc[1];
-                acc[2] = v ? fmaf(a[u], z[u].z, acc[2]) : acc[2];
-                acc[3] = v ? fmaf(a[u], z[u].w, acc[3]) : acc[3];
-            }
-#pragma unroll
-            for (int u = 0; u < U; ++u) j[u] = nj[u], a[u] = na[u];
-            if (!more) break;
-            k0 = k1;
-        }
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            acc[i] += acm_dpp<0x4E>(acc[i]);     // quad_perm [2,3,0,1]
-            acc[i] += acm_dpp<0x124>(acc[i]);    // row_ror:4
-            acc[i] += acm_dpp<0x128>(acc[i]);    // row_ror:8
-        }
-        bool finish = have && it.slot < 0;
-        if (w / ACM_WINDOW < csr.n_windows) {                   // a window of pieces: see agg_fused_kernel
-            const int g = threadIdx.x >> 4;
-            if (gl < 2) {
-#pragma unroll
-                for (int i = 0; i < 4; ++i) coop[g * FP + 4 * h + i] = acc[i];
-            }
-            __syncthreads();
-            const AcmLongRow lr = csr.long_rows[csr.long_index[it.row]];
-            finish = it.slot == lr.slot_begin;
-            if (finish && gl < 2) {
-                const int pieces = lr.slot_end - lr.slot_begin;
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    float t = 0.f;
-                    for (int q = 0; q < pieces; ++q) t += coop[(g + q) * FP + 4 * h + i];
-                    acc[i] = t;
-                }
-            }
-            __syncthreads();
-        }
-        const long row = it.row;
-        // P | x of the group's row into the wave's scratch (lanes 0, 1: P halves; lanes 2, 3: x halves)
-        {
-            const float rs = p.row_scale ? p.row_scale[row] : 1.f;
-            float4 v4;
-            if (gl < 2) {
-                v4 = make_float4(rs * acc[0], rs * acc[1], rs * acc[2], rs * acc[3]);
-                if (finish) *reinterpret_cast<float4*>(p.agg + row * p.ld_agg + 4 * h) = v4;      // P = A_low X, saved
-            } else {
-                v4 = *reinterpret_cast<const float4*>(p.xs + row * p.ld_xs + 4 * (gl & 1));
-            }
-            if (gl < 4) *reinterpret_cast<float4*>(scratch + 4 * gl) = v4;
-        }
-        // A operands: row 4 g of the tile = lane group g's row; lane (i = lane & 15, kq) holds features 2 kq, 2 kq + 1
-        float aP0 = 0.f, aP1 = 0.f, aX0 = 0.f, aX1 = 0.f;
-        {
-            const float* sg = scr_wave + (gl >> 2) * 2 * FP;
-            const float2 pp = *reinterpret_cast<const float2*>(sg + 2 * kq);
-            const float2 xx = *reinterpret_cast<const float2*>(sg + FP + 2 * kq);
-            if ((gl & 3) == 0) aP0 = pp.x, aP1 = pp.y, aX0 = xx.x, aX1 = xx.y;
-        }
-        float p0[4], p1[4], zi[4];
-#pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            f32x4m d = __builtin_amdgcn_mfma_f32_16x16x4f32(aP0, wb[((0 * 2 + 0) * 4 + t) * 64 + lane], zero4, 0, 0, 0);
-            d = __builtin_amdgcn_mfma_f32_16x16x4f32(aP1, wb[((0 * 2 + 1) * 4 + t) * 64 + lane], d, 0, 0, 0);
-            p0[t] = d[0];
-            d = __builtin_amdgcn_mfma_f32_16x16x4f32(aX0 - aP0, wb[((1 * 2 + 0) * 4 + t) * 64 + lane], zero4, 0, 0, 0);
-            d = __builtin_amdgcn_mfma_f32_16x16x4f32(aX1 - aP1, wb[((1 * 2 + 1) * 4 + t) * 64 + lane], d, 0, 0, 0);
-            p1[t] = d[0];
-            d = __builtin_amdgcn_mfma_f32_16x16x4f32(aX0, wb[((2 * 2 + 0) * 4 + t) * 64 + lane], zero4, 0, 0, 0);
-            d = __builtin_amdgcn_mfma_f32_16x16x4f32(aX1, wb[((2 * 2 + 1) * 4 + t) * 64 + lane], d, 0, 0, 0);
-            zi[t] = d[0];
-        }
-        // ---- head + stores (the whole wave computes, finishing groups store)
-        float H[K][4];
-#pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            H[0][t] = p.relu_after ? fmaxf(p0[t], 0.f) : p0[t];
-            H[1][t] = p.relu_after ? fmaxf(p1[t], 0.f) : p1[t];
-            H[2][t] = p.relu_mlp ? fmaxf(zi[t], 0.f) : zi[t];
-        }
-        RowHead<K> rh;
-        row_head<K>(hlds, mixm, acm_opaque(gl), 64, p.layernorm != 0, H, rh);
-        float df[4];
-        acm_drop4(dc, row, gl, df);
-        if (finish) {
-            if (p.head_stats && gl == 0) row_head_store<K>(p.head_stats + row * p.ld_head_stats, rh);
-#pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                const int col = gl + 16 * t;
-                float o = p.scale * (rh.alpha[0] * H[0][t] + rh.alpha[1] * H[1][t] + rh.alpha[2] * H[2][t]);
-                if (p.post_relu) o = fmaxf(o, 0.f);
-                if (p.post_scale) o *= p.post_scale[row * p.ld_post_scale + col];
-                if (p.post_drop.p > 0.f) o *= df[t];
-                p.out[row * p.ld_out + col] = o;
-            }
-            if (gl == 0) *reinterpret_cast<float4*>(p.att + row * 4) = make_float4(rh.alpha[0], rh.alpha[1], rh.alpha[2], 0.f);
-        }
-        it = itn;
-        w += G;
-    }
-}
-
 // ---------------------------------------------------------------- backward
 // flat parameter-gradient vector: [dW_low f_in*F][dW_high][dW_mlp][dv 3F][dgamma 3F][dbeta 3F][dmix 9]
 //
@@ -817,9 +630,7 @@ extern "C" int acm_conv_agg_fwd(const acm_csr_t* a, const acm_conv_agg_fwd_t* p,
                 else hipLaunchKernelGGL((agg_fused_kernel<4, false>), dim3(grid), dim3(256), 0, s, *p, cv);
             } else {
                 const bool pair_lanes = getenv("ACM_AGG_NO_PAIR") == nullptr;
-                if (pair_lanes && full && getenv("ACM_AGG_MFMA") != nullptr)
-                    hipLaunchKernelGGL(agg_fused_pair_mfma_kernel, dim3(grid), dim3(256), 0, s, *p, cv);
-                else if (pair_lanes && full)
+                if (pair_lanes && full)
                     hipLaunchKernelGGL((agg_fused_pair_kernel<true>), dim3(grid), dim3(256), 0, s, *p, cv);
                 else if (pair_lanes)
                     hipLaunchKernelGGL((agg_fused_pair_kernel<false>), dim3(grid), dim3(256), 0, s, *p, cv);

@@ -104,15 +104,13 @@ def test_aggregate_first_matches_oracle_and_literal(model_type, ln, f_in, f_out,
     assert float((a - b).abs().max()) < 2e-5 * max(1.0, float(b.abs().max()))
 
 
-@pytest.mark.parametrize("form", ["fused-pair", "fused-pair-mfma", "fused", "two-stage"])
+@pytest.mark.parametrize("form", ["fused-pair", "fused", "two-stage"])
 @pytest.mark.parametrize("f_in,f_out,hub", [(7, 64, True), (3, 16, True), (8, 33, False)])
 def test_aggregate_first_kernel_forms(form, f_in, f_out, hub, monkeypatch):
     """The three implementations of the three-channel aggregate-first forward -- one kernel with two lanes per
     neighbour (default for 32-byte rows), one kernel with one lane per neighbour, and gather + epilogue with the
     long rows' partial sums added by the epilogue -- against the oracle, on a graph with a split hub row."""
-    if form == "fused-pair-mfma":
-        monkeypatch.setenv("ACM_AGG_MFMA", "1")
-    elif form != "fused-pair":
+    if form != "fused-pair":
         monkeypatch.setenv("ACM_AGG_NO_PAIR", "1")
     if form == "two-stage":
         monkeypatch.setenv("ACM_AGG_UNFUSED", "1")
