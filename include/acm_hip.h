@@ -512,9 +512,8 @@ int acm_conv_agg_bwd(int64_t n_rows, const acm_conv_agg_bwd_t* p,
  * pre_H] and att as acm_conv_fwd, zlh = relu(X [W_L | W_H]) and zi = relu(X W_I) as the GEMM (K4's masks / self rows,
  * K3's s_mlp) -- equal to them up to fp32 re-association.  Values of an explicit operator must be
  * non-negative (relu(a z) = a relu(z)).  Workspace: acm_conv_acmii_fwd_workspace_bytes (partial sums of the long rows'
- * pieces + the work counter of the persistent waves, reset by the call itself with a stream-ordered memset, so the
- * call is hipGraph-capturable).  The backward is acm_conv_bwd_local / acm_conv_bwd_spmm / acm_gemm as for the literal
- * form. */
+ * pieces, added in slot order by a second launch; never zero bytes).  The backward is acm_conv_bwd_local /
+ * acm_conv_bwd_spmm / acm_gemm as for the literal form. */
 typedef struct {
     int32_t f_in, f_pad, f_out;        /* f_pad = 8, f_out = 64                                                */
     int32_t layernorm;
