@@ -12,7 +12,7 @@
 //   one wave per FOUR work items; a batch = 4 neighbours of each = the 16 rows (M) of v_mfma_f32_16x16x4_f32;
 //   A[i][k] = x_{j_i}[feature], lane (i = lane & 15, kq = lane >> 4) fetches the float2 (2 kq, 2 kq + 1) of the
 //             neighbour in slot i & 3 of item i >> 2 (K-step s uses feature 2 kq + s: one 8-byte load per lane and batch);
-//   B[k][n] = [W_L | W_H][2 kq + s][16 t + i], 16 loop-invariant registers per lane (waves are persistent);
+//   B[k][n] = [W_L | W_H][2 kq + s][16 t + i], 16 loop-invariant registers per lane;
 //   D tile t = 16 (item, neighbour) rows x 16 columns; ReLU and the sum over the tile's four row registers -- the four
 //   neighbours of lane group g's item -- on the VALU, accumulated per lane: no cross-lane reduction at all.
 //
