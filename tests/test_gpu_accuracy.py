@@ -45,15 +45,12 @@ REPLAYS = {"cora": (0.002, 0.01), "squirrel": (0.007, 0.025), "film_v0": (0.004,
 
 
 @pytest.mark.parametrize("name", list(REPLAYS))
-def test_fixed_split_accuracy_matches_reference_run(name, monkeypatch):
-    path = os.path.join(GOLDEN, f"accuracy_{name}.npz")
-    if not os.path.exists(path):
-        pytest.skip(f"{path} not generated")
-    rec = load_npz(path)
+def _prepare(name):
+    """Everything a replay needs, on the host: config, recorded run, features / labels, the small-graph dialect's
+    filters (ACM-Pytorch/utils.py:612-629, built with the torch ops the reference uses), the fixed splits."""
+    rec = load_npz(os.path.join(GOLDEN, f"accuracy_{name}.npz"))
     cfg = rec["cfg"]
     dataset = cfg.get("dataset", name)
-    from acm_gnn_amd import GCN, layers, train as T
-    from acm_gnn_amd.graph import clear_cache
     n, x, labels, g, masks = _load(dataset)
     splits_path = os.path.join(GOLDEN, f"splits_{dataset}.npz")
     if len(masks) >= len(cfg["splits"]):             # the graph fixture carries every fixed split (squirrel, film)
@@ -65,8 +62,6 @@ def test_fixed_split_accuracy_matches_reference_run(name, monkeypatch):
                  for i in masks}
     else:
         masks = dict(enumerate(masks))
-    # filters exactly as the small-graph dialect builds them (ACM-Pytorch/utils.py:612-629) -- on the host
-    # with the oracle-free torch ops the reference uses, then handed to the layer as it would be
     a_un = csr_to_coo_tensor(g, "adj_un")
     if not (cfg["model"] in ("acmgcnp", "acmgcnpp") and cfg["structure_info"]):
         rs = x.sum(1)
@@ -78,37 +73,77 @@ def test_fixed_split_accuracy_matches_reference_run(name, monkeypatch):
     inv[torch.isinf(inv)] = 0.0
     adj_low = torch.mm(torch.diag(inv), torch.eye(n) + a_un.to_dense())
     adj_high = (torch.eye(n) - adj_low).to_sparse()
+    return rec, cfg, dataset, n, x, labels, masks, a_un, adj_low, adj_high
+
+
+def _replay_splits(name, splits):
+    """Worker (its own process: the replay is bound by the CPU generation of the recorded dropout masks, 80 ms per
+    epoch on Squirrel, so the splits of one dataset run side by side on the one GPU): train the given splits exactly as
+    the recorded reference run did and return {split: (selected test acc, val-loss curve, test-acc curve)}."""
+    from acm_gnn_amd import GCN, layers, train as T
+    from acm_gnn_amd.graph import clear_cache
+    rec, cfg, dataset, n, x, labels, masks, a_un, adj_low, adj_high = _prepare(name)
+    torch.set_num_threads(4)
     xd, yd = x.to(DEV), labels.to(DEV)
     low_d, high_d = adj_low.to(DEV), adj_high.to(DEV)
     un_d = a_un.to(DEV) if cfg["structure_info"] else None
+    layers._default_device = lambda: torch.device("cpu")            # seeded CPU initialisation, like the reference run
+    real_dropout = F.dropout
+    out = {}
+    try:
+        for split in splits:
+            tr, va, te = (torch.from_numpy(np.nonzero(m)[0]).to(DEV) for m in masks[split])
+            clear_cache()
+            torch.manual_seed(1000 + split)
+            model = GCN(x.shape[1], cfg["hidden"], int(labels.max()) + 1, 1, n, cfg["dropout"], cfg["model"],
+                        cfg["structure_info"], variant=bool(cfg["variant"]), attn_layernorm=False).to(DEV)
+            opt = torch.optim.Adam(model.parameters(), lr=cfg["lr"], weight_decay=cfg["weight_decay"])
+            drop = SeededDropout(seed=split)
+            F.dropout = drop
+            w = T.row_weights(tr, n)
+            step = T.TrainStep(model, opt, xd, low_d, yd, w, high_d, un_d)
+            best_val, curr, vals, accs = float("inf"), 0.0, [], []
+            for epoch in range(cfg["epochs"]):
+                drop.next_epoch()
+                step()
+                o, (acc_te,) = T.evaluate(model, xd, low_d, yd, (te,), high_d, un_d)
+                val_loss = float(F.nll_loss(F.log_softmax(o, 1)[va], yd[va]))
+                vals.append(val_loss)
+                accs.append(acc_te)
+                if val_loss < best_val:
+                    best_val, curr = val_loss, acc_te
+                if cfg["early_stopping"] > 0 and epoch > cfg["early_stopping"]:
+                    if val_loss > np.mean(vals[epoch - cfg["early_stopping"]:epoch]):
+                        break
+            out[split] = (curr, vals, accs)
+    finally:
+        F.dropout = real_dropout
+    return out
+
+
+def test_fixed_split_accuracy_matches_reference_run(name):
+    path = os.path.join(GOLDEN, f"accuracy_{name}.npz")
+    if not os.path.exists(path):
+        pytest.skip(f"{path} not generated")
+    rec = load_npz(path)
+    cfg = rec["cfg"]
+    dataset = cfg.get("dataset", name)
+    _, _, _, _, _, _, masks, *_ = _prepare(name)
+    todo = [s for s in cfg["splits"] if s in masks]
+    # the splits side by side in worker processes (spawned: each gets its own HIP context on the same GPU)
+    import concurrent.futures as cf
+    import multiprocessing as mp
+    workers = min(5, len(todo))
+    chunks = [todo[i::workers] for i in range(workers)]
+    results = {}
+    with cf.ProcessPoolExecutor(max_workers=workers, mp_context=mp.get_context("spawn")) as pool:
+        for part in pool.map(_replay_splits, [name] * workers, chunks):
+            results.update(part)
     got, ref, curve_gap, curves, at_ref_epoch = [], [], [], [], []
     for si, split in enumerate(cfg["splits"]):
-        if split not in masks:
+        if split not in results:
             continue
-        tr, va, te = (torch.from_numpy(np.nonzero(m)[0]).to(DEV) for m in masks[split])
-        clear_cache()
-        monkeypatch.setattr(layers, "_default_device", lambda: torch.device("cpu"))
-        torch.manual_seed(1000 + split)
-        model = GCN(x.shape[1], cfg["hidden"], int(labels.max()) + 1, 1, n, cfg["dropout"], cfg["model"],
-                    cfg["structure_info"], variant=bool(cfg["variant"]), attn_layernorm=False).to(DEV)
-        opt = torch.optim.Adam(model.parameters(), lr=cfg["lr"], weight_decay=cfg["weight_decay"])
-        drop = SeededDropout(seed=split)
-        monkeypatch.setattr(F, "dropout", drop)
-        w = T.row_weights(tr, n)
-        step = T.TrainStep(model, opt, xd, low_d, yd, w, high_d, un_d)
-        best_val, curr, vals, accs = float("inf"), 0.0, [], []
-        for epoch in range(cfg["epochs"]):
-            drop.next_epoch()
-            step()
-            out, (acc_te,) = T.evaluate(model, xd, low_d, yd, (te,), high_d, un_d)
-            val_loss = float(F.nll_loss(F.log_softmax(out, 1)[va], yd[va]))
-            vals.append(val_loss)
-            accs.append(acc_te)
-            if val_loss < best_val:
-                best_val, curr = val_loss, acc_te
-            if cfg["early_stopping"] > 0 and epoch > cfg["early_stopping"]:
-                if val_loss > np.mean(vals[epoch - cfg["early_stopping"]:epoch]):
-                    break
+        curr, vals, accs = results[split]
         got.append(curr)
         ref.append(float(rec["test_acc"][si]))
         hist = rec[f"hist_{split}"]
