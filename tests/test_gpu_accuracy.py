@@ -44,7 +44,6 @@ def _cora_masks(split):
 REPLAYS = {"cora": (0.002, 0.01), "squirrel": (0.007, 0.025), "film_v0": (0.004, 0.025), "film_v1": (0.004, 0.025)}
 
 
-@pytest.mark.parametrize("name", list(REPLAYS))
 def _prepare(name):
     """Everything a replay needs, on the host: config, recorded run, features / labels, the small-graph dialect's
     filters (ACM-Pytorch/utils.py:612-629, built with the torch ops the reference uses), the fixed splits."""
@@ -121,6 +120,7 @@ def _replay_splits(name, splits):
     return out
 
 
+@pytest.mark.parametrize("name", list(REPLAYS))
 def test_fixed_split_accuracy_matches_reference_run(name):
     path = os.path.join(GOLDEN, f"accuracy_{name}.npz")
     if not os.path.exists(path):
