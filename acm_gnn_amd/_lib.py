@@ -14,12 +14,12 @@ c_i32p = C.POINTER(C.c_int32)
 
 ACM_OK = 0
 STATUS_NAMES = {1: "ACM_EINVAL", 2: "ACM_ESHAPE", 3: "ACM_EHIP", 4: "ACM_EUNSUPPORTED", 5: "ACM_ENOMEM"}
-ABI_VERSION = 17
+ABI_VERSION = 18
 
 # every symbol include/acm_hip.h declares
 EXPORTED_SYMBOLS = (
     "acm_version", "acm_last_error", "acm_csr_create", "acm_csr_transpose", "acm_csr_slice_rows",
-    "acm_csr_destroy", "acm_csr_info", "acm_spmm_workspace_bytes", "acm_gemm_workspace_bytes",
+    "acm_csr_destroy", "acm_csr_info", "acm_csr_build_streams", "acm_spmm_workspace_bytes", "acm_gemm_workspace_bytes",
     "acm_gemm", "acm_gemm_blocks", "acm_gemm_split", "acm_proj_fwd", "acm_proj_bwd_workspace_bytes", "acm_proj_bwd", "acm_spmm", "acm_spmm_v", "acm_spmm_ex", "acm_cast_bf16", "acm_conv_fwd", "acm_conv_bwd_local_workspace_bytes",
     "acm_conv_bwd_local", "acm_conv_bwd_spmm", "acm_conv_agg_fwd", "acm_conv_agg_bwd_workspace_bytes",
     "acm_conv_agg_bwd", "acm_nll_loss_workspace_bytes", "acm_nll_loss", "acm_adam_step", "acm_dropout",
@@ -38,7 +38,9 @@ class CsrInfo(C.Structure):
                 ("n_items", C.c_int64), ("n_long_rows", C.c_int64), ("n_partial_slots", C.c_int64),
                 ("chunk", C.c_int32), ("max_degree", C.c_int32),
                 ("indptr", C.c_void_p), ("indices", C.c_void_p), ("vals", C.c_void_p),
-                ("src_pos", C.c_void_p)]
+                ("src_pos", C.c_void_p),
+                ("stream_steps", C.c_int64), ("stream_slices", C.c_int64),
+                ("stream_waves", C.c_int32), ("stream_long_rows", C.c_int32)]
 
 
 class ConvFwd(C.Structure):
@@ -191,6 +193,7 @@ def _declare(lib):
     lib.acm_csr_destroy.argtypes = [vp]
     lib.acm_csr_destroy.restype = None
     lib.acm_csr_info.argtypes = [vp, C.POINTER(CsrInfo)]
+    lib.acm_csr_build_streams.argtypes = [vp, i32, i32]
     lib.acm_shard_plan.argtypes = [i64, vp, i32, i64, vp]
     lib.acm_conv_acmii_fwd_workspace_bytes.argtypes = [vp, C.POINTER(sz)]
     lib.acm_conv_acmii_fwd.argtypes = [vp, C.POINTER(ConvAcmiiFwd), vp, sz, vp]

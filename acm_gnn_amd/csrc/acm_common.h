@@ -48,6 +48,28 @@ struct AcmLongRow {
     int32_t row, slot_begin, slot_end, pad;
 };
 
+// Per-wave id streams of a pattern-only operator (acm_csr_build_streams, acm_csr.cpp): the column ids laid out in the
+// order a wave of the streamed aggregate-first kernel consumes them.  A SLICE = four work items (rows, or pieces of at
+// most `lmax` neighbours of a long row) of similar length, one per 16-lane group of a wave; it takes
+// steps = ceil(longest / 32) wave steps of 32 neighbours per group; a step is 128 ids, [group][lane pair][4], padded with
+// ACM_STREAM_SENTINEL (an id whose row offset lies beyond any table: a buffer load answers it with zeros, no memory access).
+// The slices are dealt to `n_waves` waves (longest first, each to the least loaded wave); a wave's slices are contiguous
+// in every array, so it walks ONE linear id stream and its descriptors come through the scalar unit.
+#define ACM_STREAM_SENTINEL 0x07FFFFFF
+#define ACM_STREAM_PAD_STEPS 4
+struct AcmStreams {
+    int32_t* ids;           // device, (total_steps + ACM_STREAM_PAD_STEPS) * 128
+    int32_t* waves;         // device, n_waves x {slice_begin, slice_end, first_step, total_steps}
+    int32_t* items;         // device, (n_slices + 2) x 4 groups x {row, slot, steps of the slice, 0}; row < 0: no item,
+                            // slot < 0: a whole row
+    AcmLongRow* long_rows;  // device: rows cut into pieces, with their partial slots
+    int32_t* long_index;    // device, n_rows: index into long_rows or -1 (NULL without long rows)
+    int32_t* counters;      // device, n_long arrival counters (zero between launches: the last arriver resets its own)
+    float* slots;           // device, n_slots x 8 partial sums
+    int64_t total_steps, n_slices, n_long, n_slots;
+    int32_t n_waves, lmax;
+};
+
 struct acm_csr {
     int64_t n_rows, n_cols, nnz;
     int32_t chunk, max_degree;
@@ -62,7 +84,20 @@ struct acm_csr {
     int64_t n_long;
     int64_t n_slots;
     int64_t n_windows;      // the first n_windows * ACM_WINDOW items are the pieces of the long rows
+    AcmStreams* streams;    // NULL until acm_csr_build_streams
     int device;
+};
+
+struct StreamView {
+    const int32_t* ids;
+    const int32_t* waves;
+    const int32_t* items;
+    const AcmLongRow* long_rows;
+    const int32_t* long_index;
+    int32_t* counters;
+    float* slots;
+    unsigned ids_bytes, slots_bytes;
+    int n_waves;
 };
 
 // Device-side view handed to kernels by value.
@@ -130,6 +165,18 @@ __device__ __forceinline__ float acm_cross_row_sum(float v) {
     v = __uint_as_float(r[0]) + __uint_as_float(r[1]);
     r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
     return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+
+// lane u of each 16-lane row -> every lane of that row (v_mov_b32_dpp row_newbcast:u); u is a constant after unrolling,
+// so the switch folds
+__device__ __forceinline__ int acm_row_bcast(int v, int u) {
+#define ACM_BC(U) case U: return __builtin_amdgcn_update_dpp(0, v, 0x150 + U, 0xf, 0xf, false)
+    switch (u & 15) {
+        ACM_BC(0); ACM_BC(1); ACM_BC(2); ACM_BC(3); ACM_BC(4); ACM_BC(5); ACM_BC(6); ACM_BC(7);
+        ACM_BC(8); ACM_BC(9); ACM_BC(10); ACM_BC(11); ACM_BC(12); ACM_BC(13); ACM_BC(14);
+        default: return __builtin_amdgcn_update_dpp(0, v, 0x15F, 0xf, 0xf, false);
+    }
+#undef ACM_BC
 }
 
 __device__ __forceinline__ int acm_uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }

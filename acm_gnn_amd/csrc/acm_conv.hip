@@ -469,17 +469,6 @@ __global__ __launch_bounds__(256) void spmm_pair_kernel(CsrView csr, GatherSrc g
 // blocks of loads are in flight per wave (8 KB at NG = 2), the four groups' partial sums meet at the end through
 // v_permlane16/32_swap (fixed order), and the epilogue runs in LayVec16 (lane m owns columns 4 m .. 4 m + 3 of every
 // block).  Needs 16-byte aligned rows (F % 4 == 0, ld % 4 == 0); row offsets are 32-bit byte offsets (table < 4 GB).
-// lane u of each 16-lane row -> every lane of that row; u is a constant after unrolling, so the switch folds
-__device__ __forceinline__ int acm_row_bcast(int v, int u) {
-#define ACM_BC(U) case U: return __builtin_amdgcn_update_dpp(0, v, 0x150 + U, 0xf, 0xf, false)
-    switch (u & 15) {
-        ACM_BC(0); ACM_BC(1); ACM_BC(2); ACM_BC(3); ACM_BC(4); ACM_BC(5); ACM_BC(6); ACM_BC(7);
-        ACM_BC(8); ACM_BC(9); ACM_BC(10); ACM_BC(11); ACM_BC(12); ACM_BC(13); ACM_BC(14);
-        default: return __builtin_amdgcn_update_dpp(0, v, 0x15F, 0xf, 0xf, false);
-    }
-#undef ACM_BC
-}
-
 template <int NG, int NB, int UNR, int BLK>
 __device__ __forceinline__ void gather_vec_block(const GatherSrc& g, const unsigned (&ldb)[3], const unsigned (&blk_off)[NB],
                                                  unsigned ok_mask, int my_j, float my_a, float (&acc)[NG][4 * NB]) {

@@ -56,10 +56,10 @@ __device__ __forceinline__ void stage_weights(float* wlds, const float* w_low, c
 template <int FP>
 __device__ __forceinline__ void project(const float* wlds, float* scratch, int m, const float* __restrict__ prow,
                                         const float* __restrict__ xrow, bool active, float (&p0)[4], float (&p1)[4],
-                                        float (&zi)[4]) {
+                                        float (&zi)[4], bool x_in_scratch = false) {
     // lanes 0 .. FP/4-1 of the group fetch P, the next FP/4 fetch x (16-byte pieces); prow == nullptr: P is
-    // already in the scratch (a long row whose partial sums were added by the caller)
-    if (m < FP / 2 && (prow || m >= FP / 4)) {
+    // already in the scratch (a long row whose partial sums were added by the caller); x_in_scratch: so is x
+    if (!x_in_scratch && m < FP / 2 && (prow || m >= FP / 4)) {
         const float* src = (m < FP / 4) ? prow + 4 * m : xrow + 4 * (m - FP / 4);
         const float4 v = active ? *reinterpret_cast<const float4*>(src) : make_float4(0.f, 0.f, 0.f, 0.f);
         *reinterpret_cast<float4*>(scratch + 4 * m) = v;
@@ -87,7 +87,7 @@ template <int FP, int K, bool FULL = false>
 __device__ __forceinline__ void agg_fwd_row(const acm_conv_agg_fwd_t& p, const float* wlds, const float* hlds,
                                             float* scratch, const float* mixm, int row, int lane, const CsrView& csr,
                                             const float* __restrict__ partial, const AcmDropCtx& dc,
-                                            bool p_in_scratch = false) {
+                                            bool p_in_scratch = false, bool active = true, bool x_in_scratch = false) {
     const int F = FULL ? 64 : p.f_out, m = lane & 15;     // FULL: f_out == 64, the column guards fold away
     float H[K][4];
     {
@@ -121,7 +121,7 @@ __device__ __forceinline__ void agg_fwd_row(const acm_conv_agg_fwd_t& p, const f
             }
         }
         float p0[4], p1[4], zi[4];
-        project<FP>(wlds, scratch, m, prow, p.xs + (long)row * p.ld_xs, true, p0, p1, zi);
+        project<FP>(wlds, scratch, m, prow, p.xs + (long)row * p.ld_xs, true, p0, p1, zi, x_in_scratch);
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const bool ok = m + 16 * i < F;
@@ -141,13 +141,13 @@ __device__ __forceinline__ void agg_fwd_row(const acm_conv_agg_fwd_t& p, const f
     }
     RowHead<K> rh;
     row_head<K>(hlds, mixm, acm_opaque(m), F, p.layernorm != 0, H, rh);
-    if (p.head_stats && m == 0) row_head_store<K>(p.head_stats + (long)row * p.ld_head_stats, rh);
+    if (p.head_stats && m == 0 && active) row_head_store<K>(p.head_stats + (long)row * p.ld_head_stats, rh);
     float df[4];
     acm_drop4(dc, row, m, df);        // dc: read once per launch (its step counter is a global load)
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int col = m + 16 * i;
-        if (col < F) {
+        if (col < F && active) {
             float o = rh.alpha[0] * H[0][i] + rh.alpha[1] * H[1][i] + rh.alpha[2] * H[2][i];
             if (K == 4) o = fmaf(rh.alpha[K - 1], H[K - 1][i], o);
             o *= p.scale;
@@ -157,7 +157,7 @@ __device__ __forceinline__ void agg_fwd_row(const acm_conv_agg_fwd_t& p, const f
             p.out[(long)row * p.ld_out + col] = o;
         }
     }
-    if (m == 0)
+    if (m == 0 && active)
         *reinterpret_cast<float4*>(p.att + (long)row * 4) =
             make_float4(rh.alpha[0], rh.alpha[1], rh.alpha[2], K == 4 ? rh.alpha[K - 1] : 0.f);
 }
@@ -407,6 +407,135 @@ __global__ __launch_bounds__(256) void agg_fused_pair_kernel(acm_conv_agg_fwd_t 
     }
 }
 
+
+// ---------------------------------------------------------------- streamed form (acm_csr_build_streams)
+// The same fused forward over per-wave id streams.  What the CSR form above spends per wave step -- four guarded id
+// loads, per-lane bounds, 64-bit row addresses, 16 selects, the item descriptors through the vector unit and 45
+// exec-mask branches -- is gone: ONE dwordx4 id load per step (issued two steps ahead), rows through a buffer
+// descriptor with 32-bit offsets (an idle slot holds the sentinel id: its load is answered with zeros without a memory
+// access, so the sums need no select), slice descriptors through the scalar unit, wave-uniform control flow.  The rows of
+// the NEXT step (the next slice's first step included) are requested before the row-local stage of a finished slice
+// runs, so every wave has gathers in flight while it does the projections and the head.
+// Lane (g, e, h): group g = one work item of the slice, neighbours 4 e .. 4 e + 3 of the step, half h of the 32-byte row.
+// Pieces of a long row: partial sum -> its slot (write-through store), arrival counter; the last piece adds the slots
+// in slot order (bypassing the L1 / the XCD's L2) and finishes the row.
+typedef float acm_f32x4 __attribute__((ext_vector_type(4)));
+typedef int acm_i32x4 __attribute__((ext_vector_type(4)));
+
+template <bool FULL>
+__global__ __launch_bounds__(256) void agg_stream_kernel(acm_conv_agg_fwd_t p, StreamView sv, unsigned xg_bytes) {
+    constexpr int FP = 8, K = 3;
+    __shared__ __attribute__((aligned(16))) float wlds[3 * FP * 64 + 3 * K * 64 + 16 * 2 * FP];
+    float* hlds = wlds + 3 * FP * 64;
+    float* scratch = hlds + 3 * K * 64 + (threadIdx.x >> 4) * 2 * FP;
+    stage_weights<FP>(wlds, p.w_low, p.w_high, p.w_mlp, p.ld_w, p.f_in, p.f_out);
+    stage_head_params<K>(hlds, p.att_vec, p.ln_weight, p.ln_bias, p.layernorm, p.f_out);
+    __syncthreads();
+    float mixm[K * K];
+#pragma unroll
+    for (int q = 0; q < K * K; ++q) mixm[q] = p.att_mix[q];
+    const AcmDropCtx dc = acm_drop_ctx(p.post_drop);
+    const int lane = threadIdx.x & 63, g = lane >> 4, gl = lane & 15, e = gl >> 1, h = gl & 1;
+    const int W = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
+    if (W >= sv.n_waves) return;
+    int s = sv.waves[W * 4 + 0];
+    const int s_end = sv.waves[W * 4 + 1];
+    if (s >= s_end) return;
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.xg), 0, xg_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t ri = __builtin_amdgcn_make_buffer_rsrc(const_cast<int32_t*>(sv.ids), 0, sv.ids_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rp = __builtin_amdgcn_make_buffer_rsrc(sv.slots, 0, sv.slots_bytes, 0x00020000);
+    int ioff = sv.waves[W * 4 + 2] * 512 + (g * 8 + e) * 16;
+    const int hoff = h * 16;
+    acm_f32x4 z0, z1, z2, z3;
+#define ACM_ISSUE(J)                                                                                          \
+    do {                                                                                                      \
+        z0 = __builtin_bit_cast(acm_f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, (J).x * 32 + hoff, 0, 0)); \
+        z1 = __builtin_bit_cast(acm_f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, (J).y * 32 + hoff, 0, 0)); \
+        z2 = __builtin_bit_cast(acm_f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, (J).z * 32 + hoff, 0, 0)); \
+        z3 = __builtin_bit_cast(acm_f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, (J).w * 32 + hoff, 0, 0)); \
+    } while (0)
+#define ACM_IDS(OFF) __builtin_bit_cast(acm_i32x4, __builtin_amdgcn_raw_buffer_load_b128(ri, (OFF), 0, 0))
+    // slice descriptors {row, slot, steps, -} per group, requested two slices ahead; the row-local stage's own operands
+    // (row scale, the row's x) one slice ahead and BEFORE that slice's gathers: loads return in order, so waiting for
+    // them later leaves the younger row requests in flight
+    const acm_i32x4* items = reinterpret_cast<const acm_i32x4*>(sv.items);
+    const unsigned xs_row_bytes = (unsigned)p.ld_xs * 4u;
+    const char* xs_half = reinterpret_cast<const char*>(p.xs) + hoff;
+    acm_i32x4 item = items[s * 4 + g];
+    int rem = __builtin_amdgcn_readfirstlane(item.z);
+    float rs_cur = p.row_scale ? p.row_scale[item.x >= 0 ? item.x : 0] : 1.f;
+    acm_f32x4 x_cur = *reinterpret_cast<const acm_f32x4*>(xs_half + (size_t)(unsigned)(item.x >= 0 ? item.x : 0) * xs_row_bytes);
+    acm_i32x4 item_next = items[(s + 1) * 4 + g];
+    {
+        const acm_i32x4 j = ACM_IDS(ioff);
+        ACM_ISSUE(j);
+    }
+    acm_i32x4 q0 = ACM_IDS(ioff + 512), q1 = ACM_IDS(ioff + 1024);
+    ioff += 1536;
+    acm_f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    const CsrView no_csr = {};
+    for (int t = sv.waves[W * 4 + 3]; t > 0; --t) {
+        acc += (z0 + z1) + (z2 + z3);
+        ACM_ISSUE(q0);
+        q0 = q1;
+        q1 = ACM_IDS(ioff);
+        ioff += 512;
+        if (--rem != 0) continue;
+        // ---- the slice is complete.  First the requests for the slices after it ...
+        const int rown = item_next.x >= 0 ? item_next.x : 0;
+        const float rs_n = p.row_scale ? p.row_scale[rown] : 1.f;
+        const acm_f32x4 x_n = *reinterpret_cast<const acm_f32x4*>(xs_half + (size_t)(unsigned)rown * xs_row_bytes);
+        const acm_i32x4 item_nn = items[(s + 2) * 4 + g];
+        // ... then the sum over the eight lane pairs of each group (fixed order)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            acc[i] += acm_dpp<0x4E>(acc[i]);     // quad_perm [2,3,0,1]
+            acc[i] += acm_dpp<0x124>(acc[i]);    // row_ror:4
+            acc[i] += acm_dpp<0x128>(acc[i]);    // row_ror:8
+        }
+        const int slot = item.y;
+        bool active = item.x >= 0 && slot < 0;
+        const int row = item.x >= 0 ? item.x : 0;
+        if (__builtin_amdgcn_ballot_w64(slot >= 0) != 0ull) {      // some group holds a piece of a long row
+            if (slot >= 0) {
+                const int li = sv.long_index[row];
+                const AcmLongRow lr = sv.long_rows[li];
+                if (gl < 2)
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(acm_i32x4, acc), rp, slot * 32 + hoff, 0, /*sc1*/ 16);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                int old = 0;
+                if (gl == 0) old = __hip_atomic_fetch_add(sv.counters + li, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                old = acm_row_bcast(old, 0);
+                if (old == lr.slot_end - lr.slot_begin - 1) {      // every other piece has arrived
+                    if (gl == 0) __hip_atomic_store(sv.counters + li, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    acm_f32x4 tot = {0.f, 0.f, 0.f, 0.f};
+                    for (int q = lr.slot_begin; q < lr.slot_end; ++q)
+                        tot += __builtin_bit_cast(acm_f32x4, __builtin_amdgcn_raw_buffer_load_b128(rp, q * 32 + hoff, 0, /*sc1*/ 16));
+                    acc = tot;
+                    active = true;
+                }
+            }
+        }
+        if (__builtin_amdgcn_ballot_w64(active) != 0ull) {
+            if (gl < 4) {                                    // lanes 0, 1: P; lanes 2, 3: x (the layout project() reads)
+                const acm_f32x4 v = gl < 2 ? rs_cur * acc : x_cur;
+                *reinterpret_cast<acm_f32x4*>(scratch + 4 * gl) = v;
+                if (active && gl < 2) *reinterpret_cast<acm_f32x4*>(p.agg + (long)row * p.ld_agg + 4 * h) = v;   // P, saved for the backward
+            }
+            agg_fwd_row<FP, K, FULL>(p, wlds, hlds, scratch, mixm, row, lane, no_csr, nullptr, dc, true, active, true);
+        }
+        acc = acm_f32x4{0.f, 0.f, 0.f, 0.f};
+        ++s;
+        rem = s < s_end ? __builtin_amdgcn_readfirstlane(item_next.z) : 0x7fffffff;
+        item = item_next;
+        item_next = item_nn;
+        rs_cur = rs_n;
+        x_cur = x_n;
+    }
+#undef ACM_ISSUE
+#undef ACM_IDS
+}
+
 // ---------------------------------------------------------------- backward
 // flat parameter-gradient vector: [dW_low f_in*F][dW_high][dW_mlp][dv 3F][dgamma 3F][dbeta 3F][dmix 9]
 //
@@ -619,6 +748,29 @@ extern "C" int acm_conv_agg_fwd(const acm_csr_t* a, const acm_conv_agg_fwd_t* p,
                            ((uintptr_t)p->xg) % 16 == 0 && (p->ld_xg * sizeof(float)) % 16 == 0 &&
                            (a->n_long == 0 || a->long_index != nullptr);
         if (fused) {
+            const AcmStreams* t = a->streams;
+            const int64_t table_bytes = a->n_cols * 32;
+            if (t && p->f_pad == 8 && p->ld_xg == 8 && a->vals == nullptr && table_bytes < (int64_t)0xFFFFFFE0u &&
+                getenv("ACM_AGG_NO_STREAM") == nullptr) {
+                StreamView sv;
+                sv.ids = t->ids;
+                sv.waves = t->waves;
+                sv.items = t->items;
+                sv.long_rows = t->long_rows;
+                sv.long_index = t->long_index;
+                sv.counters = t->counters;
+                sv.slots = t->slots;
+                sv.ids_bytes = (unsigned)((t->total_steps + ACM_STREAM_PAD_STEPS) * 512);
+                sv.slots_bytes = (unsigned)(t->n_slots * 32);
+                sv.n_waves = t->n_waves;
+                const int grid = t->n_waves / 4;
+                if (p->f_out == 64)
+                    hipLaunchKernelGGL((agg_stream_kernel<true>), dim3(grid), dim3(256), 0, s, *p, sv, (unsigned)table_bytes);
+                else
+                    hipLaunchKernelGGL((agg_stream_kernel<false>), dim3(grid), dim3(256), 0, s, *p, sv, (unsigned)table_bytes);
+                ACM_CHECK_HIP(hipGetLastError());
+                return ACM_OK;
+            }
             const CsrView cv = acm_view(a);
             int grid = (int)((a->n_items + 15) / 16);
             // every block stages the weights and head parameters (8.4 KB) before it starts: 12 blocks per CU keep that

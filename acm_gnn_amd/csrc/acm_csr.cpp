@@ -4,8 +4,13 @@
 #include <stdio.h>
 #include <string.h>
 
+#include <stdlib.h>
+
 #include <algorithm>
+#include <functional>
 #include <new>
+#include <queue>
+#include <utility>
 #include <vector>
 
 #include "acm_common.h"
@@ -24,6 +29,14 @@ extern "C" const char* acm_last_error(void) { return g_err; }
 
 namespace {
 
+void free_streams(AcmStreams* t) {
+    if (!t) return;
+    for (void* q : {(void*)t->ids, (void*)t->waves, (void*)t->items, (void*)t->long_rows,
+                    (void*)t->long_index, (void*)t->counters, (void*)t->slots})
+        if (q) (void)hipFree(q);
+    delete t;
+}
+
 void free_handle(acm_csr* a) {
     if (!a) return;
     if (a->indptr) (void)hipFree(a->indptr);
@@ -33,6 +46,7 @@ void free_handle(acm_csr* a) {
     if (a->src_pos) (void)hipFree(a->src_pos);
     if (a->items) (void)hipFree(a->items);
     if (a->long_rows) (void)hipFree(a->long_rows);
+    free_streams(a->streams);
     delete a;
 }
 
@@ -309,6 +323,153 @@ extern "C" int acm_shard_plan(int64_t n_rows, const int64_t* indptr, int world, 
     return ACM_OK;
 }
 
+
+// ------------------------------------------------------------------ per-wave id streams
+namespace {
+
+template <class T>
+int upload(T** dev, const std::vector<T>& host, size_t min_elems = 1) {
+    const size_t n = std::max(host.size(), min_elems);
+    ACM_CHECK_HIP(hipMalloc((void**)dev, n * sizeof(T)));
+    if (!host.empty()) ACM_CHECK_HIP(hipMemcpy(*dev, host.data(), host.size() * sizeof(T), hipMemcpyHostToDevice));
+    return ACM_OK;
+}
+
+}  // namespace
+
+extern "C" int acm_csr_build_streams(acm_csr_t* a, int n_waves, int lmax) {
+    ACM_REQUIRE(a, ACM_EINVAL, "acm_csr_build_streams: NULL handle");
+    if (a->streams) return ACM_OK;
+    ACM_REQUIRE(a->vals == nullptr, ACM_EUNSUPPORTED, "acm_csr_build_streams: pattern-only operators only");
+    ACM_REQUIRE(a->n_cols < ACM_STREAM_SENTINEL, ACM_EUNSUPPORTED, "acm_csr_build_streams: %lld columns", (long long)a->n_cols);
+    if (lmax <= 0) {
+        const char* env = getenv("ACM_STREAM_LMAX");
+        lmax = env && atoi(env) > 0 ? atoi(env) : 512;
+    }
+    ACM_REQUIRE(lmax % 32 == 0 && lmax <= 4096, ACM_EINVAL, "acm_csr_build_streams: lmax %d must be a multiple of 32, at most 4096", lmax);
+    ACM_CHECK_HIP(hipDeviceSynchronize());
+    const int64_t n = a->n_rows, nnz = a->nnz;
+    std::vector<int32_t> ip((size_t)n + 1), ix((size_t)nnz);
+    ACM_CHECK_HIP(hipMemcpy(ip.data(), a->indptr, ip.size() * sizeof(int32_t), hipMemcpyDeviceToHost));
+    if (nnz) ACM_CHECK_HIP(hipMemcpy(ix.data(), a->indices, (size_t)nnz * sizeof(int32_t), hipMemcpyDeviceToHost));
+    // work items: whole rows of at most lmax neighbours, near-equal pieces (whole steps) of the longer ones
+    struct Item { int32_t row, begin, len, slot; };
+    std::vector<Item> items;
+    items.reserve((size_t)n + (size_t)(nnz / lmax) + 16);
+    std::vector<AcmLongRow> longs;
+    int64_t n_slots = 0;
+    for (int64_t r = 0; r < n; ++r) {
+        const int32_t b = ip[r], deg = ip[r + 1] - ip[r];
+        if (deg <= lmax) {
+            items.push_back({(int32_t)r, b, deg, -1});
+            continue;
+        }
+        const int32_t pieces = (deg + lmax - 1) / lmax;
+        const int32_t per = (((deg + pieces - 1) / pieces) + 31) / 32 * 32;
+        AcmLongRow lr = {(int32_t)r, (int32_t)n_slots, 0, 0};
+        for (int32_t q = 0; q * per < deg; ++q) items.push_back({(int32_t)r, b + q * per, std::min(per, deg - q * per), (int32_t)n_slots++});
+        lr.slot_end = (int32_t)n_slots;
+        longs.push_back(lr);
+    }
+    std::stable_sort(items.begin(), items.end(), [](const Item& x, const Item& y) { return x.len > y.len; });
+    const int64_t n_items = (int64_t)items.size(), n_slices = (n_items + 3) / 4;
+    std::vector<int32_t> sl_steps((size_t)n_slices);
+    int64_t total_steps = 0;
+    for (int64_t s = 0; s < n_slices; ++s) {
+        const int32_t longest = items[(size_t)s * 4].len;            // sorted: the first of the four
+        sl_steps[(size_t)s] = std::max(1, (longest + 31) / 32);
+        total_steps += sl_steps[(size_t)s];
+    }
+    ACM_REQUIRE((total_steps + ACM_STREAM_PAD_STEPS) * 512 < (int64_t)0xFFFFFFF0u, ACM_EUNSUPPORTED,
+                "acm_csr_build_streams: %lld steps exceed 32-bit stream offsets", (long long)total_steps);
+    if (n_waves <= 0) {
+        const char* env = getenv("ACM_STREAM_WAVES");
+        if (env && atoi(env) > 0) n_waves = atoi(env);
+    }
+    if (n_waves <= 0) {
+        int cus = 256;
+        (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, a->device);
+        n_waves = cus * 4 * 5;                                       // five waves per SIMD (the kernel's occupancy)
+    }
+    if ((int64_t)n_waves > n_slices) n_waves = (int)std::max<int64_t>(n_slices, 1);
+    n_waves = (n_waves + 3) / 4 * 4;
+    // longest slice first, each to the least loaded wave (cost = steps + the row-local stage of its four rows)
+    const int64_t epi_cost = 2;
+    std::vector<int32_t> wave_of((size_t)n_slices);
+    {
+        typedef std::pair<int64_t, int32_t> Load;
+        std::priority_queue<Load, std::vector<Load>, std::greater<Load>> heap;
+        for (int32_t w = 0; w < n_waves; ++w) heap.push({0, w});
+        for (int64_t s = 0; s < n_slices; ++s) {
+            Load l = heap.top();
+            heap.pop();
+            wave_of[(size_t)s] = l.second;
+            l.first += sl_steps[(size_t)s] + epi_cost;
+            heap.push(l);
+        }
+    }
+    // wave-major order (a wave's slices keep their longest-first order)
+    std::vector<int32_t> count((size_t)n_waves + 1, 0);
+    for (int64_t s = 0; s < n_slices; ++s) ++count[(size_t)wave_of[(size_t)s] + 1];
+    for (int32_t w = 0; w < n_waves; ++w) count[(size_t)w + 1] += count[(size_t)w];
+    std::vector<int32_t> pos_of((size_t)n_slices), cur(count.begin(), count.end() - 1);
+    for (int64_t s = 0; s < n_slices; ++s) pos_of[(size_t)s] = cur[(size_t)wave_of[(size_t)s]]++;
+    std::vector<int32_t> h_steps((size_t)n_slices + 2, 1), h_items(((size_t)n_slices + 2) * 16, -1), step_base((size_t)n_slices + 1, 0);
+    for (int64_t s = 0; s < n_slices; ++s) h_steps[(size_t)pos_of[(size_t)s]] = sl_steps[(size_t)s];
+    for (int64_t q = 0; q < n_slices; ++q) step_base[(size_t)q + 1] = step_base[(size_t)q] + h_steps[(size_t)q];
+    std::vector<int32_t> h_waves((size_t)n_waves * 4);
+    for (int32_t w = 0; w < n_waves; ++w) {
+        const int32_t b = count[(size_t)w], e = count[(size_t)w + 1];
+        h_waves[(size_t)w * 4 + 0] = b;
+        h_waves[(size_t)w * 4 + 1] = e;
+        h_waves[(size_t)w * 4 + 2] = step_base[(size_t)b];
+        h_waves[(size_t)w * 4 + 3] = step_base[(size_t)e] - step_base[(size_t)b];
+    }
+    std::vector<int32_t> h_ids(((size_t)total_steps + ACM_STREAM_PAD_STEPS) * 128, ACM_STREAM_SENTINEL);
+    for (int64_t s = 0; s < n_slices; ++s) {
+        const size_t q = (size_t)pos_of[(size_t)s];
+        for (int g = 0; g < 4; ++g) {
+            const int64_t i = s * 4 + g;
+            if (i >= n_items) break;
+            const Item& it = items[(size_t)i];
+            h_items[q * 16 + 4 * g + 0] = it.row;
+            h_items[q * 16 + 4 * g + 1] = it.slot;
+            int32_t* dst = h_ids.data() + (size_t)step_base[q] * 128 + (size_t)g * 32;
+            for (int32_t k = 0; k < it.len; ++k) dst[(size_t)(k >> 5) * 128 + (k & 31)] = ix[(size_t)it.begin + k];
+        }
+    }
+    for (size_t q = 0; q < (size_t)n_slices + 2; ++q)
+        for (int g = 0; g < 4; ++g) h_items[q * 16 + 4 * g + 2] = h_steps[q], h_items[q * 16 + 4 * g + 3] = 0;
+    AcmStreams* t = new (std::nothrow) AcmStreams();
+    ACM_REQUIRE(t, ACM_ENOMEM, "acm_csr_build_streams: host allocation failed");
+    memset(t, 0, sizeof(*t));
+    t->total_steps = total_steps;
+    t->n_slices = n_slices;
+    t->n_long = (int64_t)longs.size();
+    t->n_slots = n_slots;
+    t->n_waves = n_waves;
+    t->lmax = lmax;
+    int st = upload(&t->ids, h_ids);
+    if (st == ACM_OK) st = upload(&t->waves, h_waves);
+    if (st == ACM_OK) st = upload(&t->items, h_items);
+    if (st == ACM_OK && !longs.empty()) {
+        st = upload(&t->long_rows, longs);
+        std::vector<int32_t> index((size_t)n, -1);
+        for (size_t i = 0; i < longs.size(); ++i) index[(size_t)longs[i].row] = (int32_t)i;
+        if (st == ACM_OK) st = upload(&t->long_index, index);
+        if (st == ACM_OK && hipMalloc((void**)&t->counters, longs.size() * sizeof(int32_t)) != hipSuccess) st = ACM_EHIP;
+        if (st == ACM_OK && hipMemset(t->counters, 0, longs.size() * sizeof(int32_t)) != hipSuccess) st = ACM_EHIP;
+        if (st == ACM_OK && hipMalloc((void**)&t->slots, (size_t)n_slots * 8 * sizeof(float)) != hipSuccess) st = ACM_EHIP;
+        if (st == ACM_EHIP) acm_set_error("acm_csr_build_streams: device allocation failed");
+    }
+    if (st != ACM_OK) {
+        free_streams(t);
+        return st;
+    }
+    a->streams = t;
+    return ACM_OK;
+}
+
 extern "C" int acm_csr_info(const acm_csr_t* a, acm_csr_info_t* info) {
     ACM_REQUIRE(a && info, ACM_EINVAL, "acm_csr_info: NULL argument");
     info->n_rows = a->n_rows;
@@ -323,6 +484,10 @@ extern "C" int acm_csr_info(const acm_csr_t* a, acm_csr_info_t* info) {
     info->indices = a->indices;
     info->vals = a->vals;
     info->src_pos = a->src_pos;
+    info->stream_steps = a->streams ? a->streams->total_steps : 0;
+    info->stream_slices = a->streams ? a->streams->n_slices : 0;
+    info->stream_waves = a->streams ? a->streams->n_waves : 0;
+    info->stream_long_rows = a->streams ? (int32_t)a->streams->n_long : 0;
     return ACM_OK;
 }
 

@@ -12,6 +12,7 @@ possibly un-coalesced, ACM-Geometric/utils.py:21-28; dense strided ``adj_low``,
 ACM-Pytorch/utils.py:619-629), converts once and caches by storage identity.
 """
 import ctypes as C
+import os
 import weakref
 
 import torch
@@ -84,6 +85,8 @@ class CsrGraph:
         self._src_pos_ptr = info.src_pos
         self._src_pos = None
         self._transposed = None
+        self.stream_steps, self.stream_waves = info.stream_steps, info.stream_waves
+        self.stream_slices, self.stream_long_rows = info.stream_slices, info.stream_long_rows
         self._finalizer = weakref.finalize(self, _lib.load().acm_csr_destroy, C.c_void_p(handle))
 
     # ---- construction ----------------------------------------------------
@@ -135,6 +138,31 @@ class CsrGraph:
         return cls.from_csr(torch.from_numpy(m.indptr.astype("int32")).to(dev),
                             torch.from_numpy(m.indices.astype("int32")).to(dev),
                             torch.from_numpy(m.data.astype("float32")).to(dev), m.shape[1], chunk)
+
+    # ---- per-wave id streams -------------------------------------------
+    def build_streams(self, n_waves=0, lmax=0):
+        """Sliced-ELL copy of the id stream for the streamed aggregate-first forward (``acm_csr_build_streams``):
+        one-off host-side preprocessing, pattern-only operators only, idempotent.  Returns True when the streams exist."""
+        if self.stream_steps:
+            return True
+        if self._ptrs[2]:                                  # explicit values: the kernels keep the CSR walk
+            return False
+        with _device_ctx(self.device):
+            _sync(self.device)
+            st = _lib.load().acm_csr_build_streams(self._h, int(n_waves), int(lmax))
+        _lib.check(st, "acm_csr_build_streams")
+        info = _lib.CsrInfo()
+        _lib.check(_lib.load().acm_csr_info(self._h, C.byref(info)), "acm_csr_info")
+        self.stream_steps, self.stream_waves = info.stream_steps, info.stream_waves
+        self.stream_slices, self.stream_long_rows = info.stream_slices, info.stream_long_rows
+        return True
+
+    def want_streams(self):
+        """Streams pay on graphs whose gathers are the step (ACM_STREAMS: "auto" = at least 2^20 entries, "1", "0")."""
+        mode = os.environ.get("ACM_STREAMS", "auto")
+        if mode == "0":
+            return False
+        return mode == "1" or self.nnz >= (1 << 20)
 
     # ---- derived operators ----------------------------------------------
     def transpose(self):

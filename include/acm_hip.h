@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define ACM_ABI_VERSION 17
+#define ACM_ABI_VERSION 18
 
 typedef enum {
     ACM_OK = 0,
@@ -107,8 +107,27 @@ typedef struct {
     const float* vals;
     const int32_t* src_pos;   /* handles made by acm_csr_transpose: position of each entry in the source
                                  operator's value array (vals_T[k] = vals[src_pos[k]]); NULL otherwise */
+    int64_t stream_steps;     /* acm_csr_build_streams: wave steps (128 id slots each), 0 = not built   */
+    int64_t stream_slices;    /* slices (four work items each)                                          */
+    int32_t stream_waves;     /* waves the streams are cut for = 4 x the blocks of the streamed kernel  */
+    int32_t stream_long_rows; /* rows cut into pieces (combined by the last piece to arrive)            */
 } acm_csr_info_t;
 int acm_csr_info(const acm_csr_t* a, acm_csr_info_t* info);
+
+/* acm_csr_build_streams: lay the column ids of a PATTERN-ONLY operator out in the order the waves of the streamed
+ * aggregate-first kernel (acm_conv_agg_fwd, f_pad = 8, three channels) consume them -- a sliced-ELL copy of the id
+ * stream: four rows of similar length per wave ("slice"), 32 neighbours per row and wave step, 128 ids per step padded
+ * with an out-of-range sentinel (a buffer load answers it with zeros without touching memory), the slices dealt
+ * longest-first to `n_waves` waves, each wave's slices contiguous.  A wave then walks ONE linear id stream with its
+ * loads issued ahead, takes its slice descriptors through the scalar unit and runs no per-lane bounds logic.  Rows longer
+ * than `lmax` neighbours are cut into pieces; the piece that arrives last (a device-scope arrival counter per row) adds
+ * the partial sums in slot order and finishes the row, so results do not depend on the arrival order.
+ * One-off host-side preprocessing like acm_csr_create (synchronises the device; must not be called while a stream is
+ * capturing); idempotent.  n_waves <= 0: five waves per SIMD of the current device (env ACM_STREAM_WAVES overrides);
+ * lmax <= 0: 512 (env ACM_STREAM_LMAX).  The handle owns the arrival counters and partial slots, so launches that use the
+ * streams of one handle must be stream-ordered.  Costs (total steps x 512 B) of device memory, ~1.2 x the id array.
+ * No reference counterpart (the reference hands torch.spmm a COO tensor, ACM-Geometric/layers.py:87-103). */
+int acm_csr_build_streams(acm_csr_t* a, int n_waves, int lmax);
 
 /* Bytes of caller-provided workspace the SpMM-type entry points need for an
  * operator when `width` fp32 columns are accumulated per row. */

@@ -247,8 +247,24 @@ class FakeLib:
     def acm_csr_destroy(self, h):
         self._handles.pop(h.value if isinstance(h, C.c_void_p) else int(h), None)
 
+    def acm_csr_build_streams(self, h, n_waves, lmax):
+        a = self._get(h)
+        if not getattr(a, "unit", False):
+            self._err = b"acm_csr_build_streams: pattern-only operators only"
+            return 4
+        lmax = lmax if lmax > 0 else 512
+        deg = np.diff(a.indptr)
+        pieces = np.maximum(1, -(-deg // lmax))
+        a.stream_slices = int(-(-pieces.sum() // 4))
+        a.stream_steps = max(a.stream_slices, int(-(-deg.sum() // 128)))      # a double: only "built" matters
+        a.stream_waves = n_waves if n_waves > 0 else min(5120, -(-a.stream_slices // 4) * 4)
+        a.stream_long = int((deg > lmax).sum())
+        return 0
+
     def acm_csr_info(self, h, info):
         a, i = self._get(h), info._obj
+        i.stream_steps, i.stream_slices = getattr(a, "stream_steps", 0), getattr(a, "stream_slices", 0)
+        i.stream_waves, i.stream_long_rows = getattr(a, "stream_waves", 0), getattr(a, "stream_long", 0)
         deg = np.diff(a.indptr)
         longs = deg[deg > a.chunk]
         i.n_rows, i.n_cols, i.nnz = a.n_rows, a.n_cols, len(a.indices)
