@@ -56,7 +56,7 @@ struct AcmLongRow {
 // The slices are dealt to `n_waves` waves (longest first, each to the least loaded wave); a wave's slices are contiguous
 // in every array, so it walks ONE linear id stream and its descriptors come through the scalar unit.
 #define ACM_STREAM_SENTINEL 0x07FFFFFF
-#define ACM_STREAM_PAD_STEPS 4
+#define ACM_STREAM_PAD_STEPS 8
 struct AcmStreams {
     int32_t* ids;           // device, (total_steps + ACM_STREAM_PAD_STEPS) * 128
     int32_t* waves;         // device, n_waves x {slice_begin, slice_end, first_step, total_steps}
@@ -98,6 +98,8 @@ struct StreamView {
     float* slots;
     unsigned ids_bytes, slots_bytes;
     int n_waves;
+    int probe;      // ACM_STREAM_PROBE (measurement only): 1 = gathers without the row-local stage, 2 = row-local stage
+                    // without the gathers (every id replaced by the sentinel)
 };
 
 // Device-side view handed to kernels by value.

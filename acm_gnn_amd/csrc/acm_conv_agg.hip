@@ -83,7 +83,7 @@ __device__ __forceinline__ void project(const float* wlds, float* scratch, int m
 }
 
 // P (uniform in the 16-lane group) -> projections -> head -> out / att for one row.
-template <int FP, int K, bool FULL = false>
+template <int FP, int K, bool FULL = false, bool NT = false>
 __device__ __forceinline__ void agg_fwd_row(const acm_conv_agg_fwd_t& p, const float* wlds, const float* hlds,
                                             float* scratch, const float* mixm, int row, int lane, const CsrView& csr,
                                             const float* __restrict__ partial, const AcmDropCtx& dc,
@@ -154,7 +154,10 @@ __device__ __forceinline__ void agg_fwd_row(const acm_conv_agg_fwd_t& p, const f
             if (p.post_relu) o = fmaxf(o, 0.f);
             if (p.post_scale) o *= p.post_scale[(long)row * p.ld_post_scale + col];
             if (p.post_drop.p > 0.f) o *= df[i];
-            p.out[(long)row * p.ld_out + col] = o;
+            // NT: the output is a 43 MB stream no later step of this kernel reads; allocated in the L2 it evicts rows of the
+            // gathered table
+            if (NT) __builtin_nontemporal_store(o, p.out + (long)row * p.ld_out + col);
+            else p.out[(long)row * p.ld_out + col] = o;
         }
     }
     if (m == 0 && active)
@@ -422,7 +425,12 @@ __global__ __launch_bounds__(256) void agg_fused_pair_kernel(acm_conv_agg_fwd_t 
 typedef float acm_f32x4 __attribute__((ext_vector_type(4)));
 typedef int acm_i32x4 __attribute__((ext_vector_type(4)));
 
-template <bool FULL>
+__device__ __forceinline__ acm_i32x4 acm_probe_ids(acm_i32x4 j, int probe) {
+    if (probe >= 2) j = acm_i32x4{ACM_STREAM_SENTINEL, ACM_STREAM_SENTINEL, ACM_STREAM_SENTINEL, ACM_STREAM_SENTINEL};
+    return j;
+}
+
+template <bool FULL, bool NT>
 __global__ __launch_bounds__(256) void agg_stream_kernel(acm_conv_agg_fwd_t p, StreamView sv, unsigned xg_bytes) {
     constexpr int FP = 8, K = 3;
     __shared__ __attribute__((aligned(16))) float wlds[3 * FP * 64 + 3 * K * 64 + 16 * 2 * FP];
@@ -446,18 +454,20 @@ __global__ __launch_bounds__(256) void agg_stream_kernel(acm_conv_agg_fwd_t p, S
     const __amdgpu_buffer_rsrc_t rp = __builtin_amdgcn_make_buffer_rsrc(sv.slots, 0, sv.slots_bytes, 0x00020000);
     int ioff = sv.waves[W * 4 + 2] * 512 + (g * 8 + e) * 16;
     const int hoff = h * 16;
-    acm_f32x4 z0, z1, z2, z3;
-#define ACM_ISSUE(J)                                                                                          \
-    do {                                                                                                      \
-        z0 = __builtin_bit_cast(acm_f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, (J).x * 32 + hoff, 0, 0)); \
-        z1 = __builtin_bit_cast(acm_f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, (J).y * 32 + hoff, 0, 0)); \
-        z2 = __builtin_bit_cast(acm_f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, (J).z * 32 + hoff, 0, 0)); \
-        z3 = __builtin_bit_cast(acm_f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, (J).w * 32 + hoff, 0, 0)); \
+    // two steps of rows in flight per wave (za, zb): with the row-local stage between the steps a wave spends a good part of
+    // its time on the VALU, and one step in flight then leaves the memory system short of requests
+    acm_f32x4 za[4], zb[4];
+#define ACM_ISSUE(Z, J)                                                                                         \
+    do {                                                                                                        \
+        Z[0] = __builtin_bit_cast(acm_f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, (J).x * 32 + hoff, 0, 0)); \
+        Z[1] = __builtin_bit_cast(acm_f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, (J).y * 32 + hoff, 0, 0)); \
+        Z[2] = __builtin_bit_cast(acm_f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, (J).z * 32 + hoff, 0, 0)); \
+        Z[3] = __builtin_bit_cast(acm_f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, (J).w * 32 + hoff, 0, 0)); \
     } while (0)
-#define ACM_IDS(OFF) __builtin_bit_cast(acm_i32x4, __builtin_amdgcn_raw_buffer_load_b128(ri, (OFF), 0, 0))
+#define ACM_IDS(OFF) acm_probe_ids(__builtin_bit_cast(acm_i32x4, __builtin_amdgcn_raw_buffer_load_b128(ri, (OFF), 0, NT ? 2 : 0)), sv.probe)
     // slice descriptors {row, slot, steps, -} per group, requested two slices ahead; the row-local stage's own operands
-    // (row scale, the row's x) one slice ahead and BEFORE that slice's gathers: loads return in order, so waiting for
-    // them later leaves the younger row requests in flight
+    // (row scale, the row's x) one slice ahead, at the end of the slice before: loads return in order, so waiting for
+    // them in the next row-local stage leaves the younger row requests in flight
     const acm_i32x4* items = reinterpret_cast<const acm_i32x4*>(sv.items);
     const unsigned xs_row_bytes = (unsigned)p.ld_xs * 4u;
     const char* xs_half = reinterpret_cast<const char*>(p.xs) + hoff;
@@ -466,27 +476,21 @@ __global__ __launch_bounds__(256) void agg_stream_kernel(acm_conv_agg_fwd_t p, S
     float rs_cur = p.row_scale ? p.row_scale[item.x >= 0 ? item.x : 0] : 1.f;
     acm_f32x4 x_cur = *reinterpret_cast<const acm_f32x4*>(xs_half + (size_t)(unsigned)(item.x >= 0 ? item.x : 0) * xs_row_bytes);
     acm_i32x4 item_next = items[(s + 1) * 4 + g];
+    // issue order of the steady state (rows, ids, rows, ids): the counted waits of the loop are derived from it
+    acm_i32x4 q0, q1;
     {
-        const acm_i32x4 j = ACM_IDS(ioff);
-        ACM_ISSUE(j);
+        const acm_i32x4 j0 = ACM_IDS(ioff), j1 = ACM_IDS(ioff + 512);
+        ACM_ISSUE(za, j0);
+        q0 = ACM_IDS(ioff + 1024);
+        ACM_ISSUE(zb, j1);
+        q1 = ACM_IDS(ioff + 1536);
     }
-    acm_i32x4 q0 = ACM_IDS(ioff + 512), q1 = ACM_IDS(ioff + 1024);
-    ioff += 1536;
+    ioff += 2048;
     acm_f32x4 acc = {0.f, 0.f, 0.f, 0.f};
     const CsrView no_csr = {};
-    for (int t = sv.waves[W * 4 + 3]; t > 0; --t) {
-        acc += (z0 + z1) + (z2 + z3);
-        ACM_ISSUE(q0);
-        q0 = q1;
-        q1 = ACM_IDS(ioff);
-        ioff += 512;
-        if (--rem != 0) continue;
-        // ---- the slice is complete.  First the requests for the slices after it ...
-        const int rown = item_next.x >= 0 ? item_next.x : 0;
-        const float rs_n = p.row_scale ? p.row_scale[rown] : 1.f;
-        const acm_f32x4 x_n = *reinterpret_cast<const acm_f32x4*>(xs_half + (size_t)(unsigned)rown * xs_row_bytes);
-        const acm_i32x4 item_nn = items[(s + 2) * 4 + g];
-        // ... then the sum over the eight lane pairs of each group (fixed order)
+    // ---- a slice is complete
+    auto finish = [&]() __attribute__((always_inline)) {
+        // the sum over the eight lane pairs of each group (fixed order)
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             acc[i] += acm_dpp<0x4E>(acc[i]);     // quad_perm [2,3,0,1]
@@ -508,9 +512,17 @@ __global__ __launch_bounds__(256) void agg_stream_kernel(acm_conv_agg_fwd_t p, S
                 old = acm_row_bcast(old, 0);
                 if (old == lr.slot_end - lr.slot_begin - 1) {      // every other piece has arrived
                     if (gl == 0) __hip_atomic_store(sv.counters + li, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    // lane pair e adds slots e, e + 8, ... (a hub has dozens of pieces: one lane reading them one after
+                    // the other was the kernel's tail), then the same fixed tree over the eight pairs
                     acm_f32x4 tot = {0.f, 0.f, 0.f, 0.f};
-                    for (int q = lr.slot_begin; q < lr.slot_end; ++q)
+                    for (int q = lr.slot_begin + e; q < lr.slot_end; q += 8)
                         tot += __builtin_bit_cast(acm_f32x4, __builtin_amdgcn_raw_buffer_load_b128(rp, q * 32 + hoff, 0, /*sc1*/ 16));
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        tot[i] += acm_dpp<0x4E>(tot[i]);
+                        tot[i] += acm_dpp<0x124>(tot[i]);
+                        tot[i] += acm_dpp<0x128>(tot[i]);
+                    }
                     acc = tot;
                     active = true;
                 }
@@ -522,16 +534,38 @@ __global__ __launch_bounds__(256) void agg_stream_kernel(acm_conv_agg_fwd_t p, S
                 *reinterpret_cast<acm_f32x4*>(scratch + 4 * gl) = v;
                 if (active && gl < 2) *reinterpret_cast<acm_f32x4*>(p.agg + (long)row * p.ld_agg + 4 * h) = v;   // P, saved for the backward
             }
-            agg_fwd_row<FP, K, FULL>(p, wlds, hlds, scratch, mixm, row, lane, no_csr, nullptr, dc, true, active, true);
+            if (sv.probe != 1 && sv.probe != 3)
+                agg_fwd_row<FP, K, FULL, NT>(p, wlds, hlds, scratch, mixm, row, lane, no_csr, nullptr, dc, true, active, true);
         }
         acc = acm_f32x4{0.f, 0.f, 0.f, 0.f};
         ++s;
         rem = s < s_end ? __builtin_amdgcn_readfirstlane(item_next.z) : 0x7fffffff;
+        // the next slice's descriptor arrived a slice ago; its row operands and the descriptor after it are requested
+        // straight into the registers they are used from (a copy of a value still in flight would wait for everything)
         item = item_next;
-        item_next = item_nn;
-        rs_cur = rs_n;
-        x_cur = x_n;
+        item_next = items[(s + 1) * 4 + g];
+        {
+            const int rown = item.x >= 0 ? item.x : 0;
+            rs_cur = p.row_scale ? p.row_scale[rown] : 1.f;
+            x_cur = *reinterpret_cast<const acm_f32x4*>(xs_half + (size_t)(unsigned)rown * xs_row_bytes);
+        }
+    };
+#define ACM_STEP(Z)                                  \
+    do {                                             \
+        acc += (Z[0] + Z[1]) + (Z[2] + Z[3]);        \
+        ACM_ISSUE(Z, q0);                            \
+        q0 = q1;                                     \
+        q1 = ACM_IDS(ioff);                          \
+        ioff += 512;                                 \
+        if (--rem == 0) finish();                    \
+    } while (0)
+    // an odd step count runs one step past the wave's share: its ids are the next wave's (or the padding), its sums are
+    // never used (rem is "infinite" after the last slice)
+    for (int t = sv.waves[W * 4 + 3]; t > 0; t -= 2) {
+        ACM_STEP(za);
+        ACM_STEP(zb);
     }
+#undef ACM_STEP
 #undef ACM_ISSUE
 #undef ACM_IDS
 }
@@ -763,11 +797,15 @@ extern "C" int acm_conv_agg_fwd(const acm_csr_t* a, const acm_conv_agg_fwd_t* p,
                 sv.ids_bytes = (unsigned)((t->total_steps + ACM_STREAM_PAD_STEPS) * 512);
                 sv.slots_bytes = (unsigned)(t->n_slots * 32);
                 sv.n_waves = t->n_waves;
+                sv.probe = getenv("ACM_STREAM_PROBE") ? atoi(getenv("ACM_STREAM_PROBE")) : 0;
                 const int grid = t->n_waves / 4;
-                if (p->f_out == 64)
-                    hipLaunchKernelGGL((agg_stream_kernel<true>), dim3(grid), dim3(256), 0, s, *p, sv, (unsigned)table_bytes);
+                const bool nt = getenv("ACM_AGG_NT") != nullptr;
+                if (p->f_out == 64 && nt)
+                    hipLaunchKernelGGL((agg_stream_kernel<true, true>), dim3(grid), dim3(256), 0, s, *p, sv, (unsigned)table_bytes);
+                else if (p->f_out == 64)
+                    hipLaunchKernelGGL((agg_stream_kernel<true, false>), dim3(grid), dim3(256), 0, s, *p, sv, (unsigned)table_bytes);
                 else
-                    hipLaunchKernelGGL((agg_stream_kernel<false>), dim3(grid), dim3(256), 0, s, *p, sv, (unsigned)table_bytes);
+                    hipLaunchKernelGGL((agg_stream_kernel<false, false>), dim3(grid), dim3(256), 0, s, *p, sv, (unsigned)table_bytes);
                 ACM_CHECK_HIP(hipGetLastError());
                 return ACM_OK;
             }

@@ -394,7 +394,10 @@ extern "C" int acm_csr_build_streams(acm_csr_t* a, int n_waves, int lmax) {
     if ((int64_t)n_waves > n_slices) n_waves = (int)std::max<int64_t>(n_slices, 1);
     n_waves = (n_waves + 3) / 4 * 4;
     // longest slice first, each to the least loaded wave (cost = steps + the row-local stage of its four rows)
-    const int64_t epi_cost = 2;
+    // cost of a slice in quarter steps: 4 per wave step + the row-local stage of its four rows (ACM_STREAM_EPI, default 1:
+    // the stage overlaps with the next step's gathers, so a wave's time is close to its step count)
+    const char* epi_env = getenv("ACM_STREAM_EPI");
+    const int64_t epi_cost = epi_env ? atoi(epi_env) : 1;
     std::vector<int32_t> wave_of((size_t)n_slices);
     {
         typedef std::pair<int64_t, int32_t> Load;
@@ -404,16 +407,36 @@ extern "C" int acm_csr_build_streams(acm_csr_t* a, int n_waves, int lmax) {
             Load l = heap.top();
             heap.pop();
             wave_of[(size_t)s] = l.second;
-            l.first += sl_steps[(size_t)s] + epi_cost;
+            l.first += 4 * (int64_t)sl_steps[(size_t)s] + epi_cost;
             heap.push(l);
         }
     }
-    // wave-major order (a wave's slices keep their longest-first order)
+    // wave-major order.  Within a wave the slices are SHUFFLED (a fixed permutation seeded by the wave's index; ACM_STREAM_ORDER=
+    // sorted keeps longest-first): long slices are gather-bound (16 steps per row-local stage, neighbours all over the
+    // table), short ones are bound by the row-local stage's VALU work; longest-first makes every wave -- the whole chip --
+    // memory-bound first and VALU-bound last, so the two never overlap
     std::vector<int32_t> count((size_t)n_waves + 1, 0);
     for (int64_t s = 0; s < n_slices; ++s) ++count[(size_t)wave_of[(size_t)s] + 1];
     for (int32_t w = 0; w < n_waves; ++w) count[(size_t)w + 1] += count[(size_t)w];
     std::vector<int32_t> pos_of((size_t)n_slices), cur(count.begin(), count.end() - 1);
     for (int64_t s = 0; s < n_slices; ++s) pos_of[(size_t)s] = cur[(size_t)wave_of[(size_t)s]]++;
+    {
+        const char* ord = getenv("ACM_STREAM_ORDER");
+        if (!(ord && strcmp(ord, "sorted") == 0)) {
+            std::vector<int32_t> slice_at((size_t)n_slices);
+            for (int64_t s = 0; s < n_slices; ++s) slice_at[(size_t)pos_of[(size_t)s]] = (int32_t)s;
+            for (int32_t w = 0; w < n_waves; ++w) {
+                const int32_t b = count[(size_t)w], m = count[(size_t)w + 1] - b;
+                uint64_t state = 0x9E3779B97F4A7C15ull * (uint64_t)(w + 1);
+                for (int32_t i = m - 1; i > 0; --i) {                // Fisher-Yates with a 64-bit LCG
+                    state = state * 6364136223846793005ull + 1442695040888963407ull;
+                    const int32_t j = (int32_t)((state >> 33) % (uint64_t)(i + 1));
+                    std::swap(slice_at[(size_t)(b + i)], slice_at[(size_t)(b + j)]);
+                }
+            }
+            for (int64_t q = 0; q < n_slices; ++q) pos_of[(size_t)slice_at[(size_t)q]] = (int32_t)q;
+        }
+    }
     std::vector<int32_t> h_steps((size_t)n_slices + 2, 1), h_items(((size_t)n_slices + 2) * 16, -1), step_base((size_t)n_slices + 1, 0);
     for (int64_t s = 0; s < n_slices; ++s) h_steps[(size_t)pos_of[(size_t)s]] = sl_steps[(size_t)s];
     for (int64_t q = 0; q < n_slices; ++q) step_base[(size_t)q + 1] = step_base[(size_t)q] + h_steps[(size_t)q];

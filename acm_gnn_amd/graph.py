@@ -158,11 +158,10 @@ class CsrGraph:
         return True
 
     def want_streams(self):
-        """Streams pay on graphs whose gathers are the step (ACM_STREAMS: "auto" = at least 2^20 entries, "1", "0")."""
-        mode = os.environ.get("ACM_STREAMS", "auto")
-        if mode == "0":
-            return False
-        return mode == "1" or self.nnz >= (1 << 20)
+        """ACM_STREAMS=1 routes the three-channel aggregate-first forward (f_pad = 8) through the streamed kernel.  Off
+        by default: on the twitch-shaped graph it takes 112 us against 107 us for the CSR walk (DESIGN.md section 4,
+        "streamed form")."""
+        return os.environ.get("ACM_STREAMS", "0") == "1"
 
     # ---- derived operators ----------------------------------------------
     def transpose(self):

@@ -47,7 +47,7 @@ def _run_layer(adj, f_in, f_out, seed, lmax, n_waves, streams, repeats=1, varian
         low, high, _ = O.filters_linkx(adj)
         torch.manual_seed(seed)
         layer = GraphConvolution(f_in, f_out, n, "acmgcnp", variant=variant, structure_info=0, attn_layernorm=True)
-        params = {k: v.detach().clone() for k, v in layer.named_parameters()}
+        params = {k: v.detach().cpu().clone() for k, v in layer.named_parameters()}
         layer = layer.to(DEV)
         x = torch.randn(n, f_in, generator=torch.Generator().manual_seed(seed + 1))
         lowd, highd = low.to(DEV), high.to(DEV)
@@ -106,7 +106,7 @@ def test_stream_kernel_backward_matches_oracle():
         clear_cache()
         torch.manual_seed(0)
         layer = GraphConvolution(7, 64, n, "acmgcnp", variant=0, structure_info=0, attn_layernorm=True)
-        params = {k: v.detach().clone().requires_grad_(True) for k, v in layer.named_parameters()}
+        params = {k: v.detach().cpu().clone().requires_grad_(True) for k, v in layer.named_parameters()}
         layer = layer.to(DEV)
         x = torch.randn(n, 7)
         gout = torch.randn(n, 64)
