@@ -127,7 +127,8 @@ class ConvAggBwd(C.Structure):
                 ("ss", C.c_void_p), ("ld_ss", C.c_int64), ("deg", C.c_void_p),
                 ("g_struc", C.c_void_p), ("ld_g_struc", C.c_int64), ("g_struc_scale", C.c_void_p),
                 ("post_drop", Dropout), ("defer", C.c_void_p),
-                ("head_stats", C.c_void_p), ("ld_head_stats", C.c_int64)]
+                ("head_stats", C.c_void_p), ("ld_head_stats", C.c_int64),
+                ("out", C.c_void_p), ("ld_out", C.c_int64)]
 
 
 class ConvAcmiiFwd(C.Structure):

@@ -614,6 +614,8 @@ __global__ __launch_bounds__(256, 2) void agg_bwd_kernel(acm_conv_agg_bwd_t p, i
 #pragma unroll
     for (int q = 0; q < K * K; ++q) mixm[q] = p.att_mix[q];
     const bool ln = p.layernorm != 0;
+    const bool out_mask = p.out != nullptr && p.post_relu && !p.post_scale;
+    const float post_gain = p.post_drop.p > 0.f ? acm_drop_ctx(p.post_drop).inv_keep : 1.f;
 
     for (int r0 = (blockIdx.x * 4 + wv) * 4; r0 < n_rows; r0 += gridDim.x * 16) {
         const int row = r0 + g;
@@ -649,7 +651,15 @@ __global__ __launch_bounds__(256, 2) void agg_bwd_kernel(acm_conv_agg_bwd_t p, i
         RowHead<K> rh;
         if (p.head_stats) row_head_load<K>(p.head_stats + (unsigned)rr * (unsigned)p.ld_head_stats, rh);   // as the forward computed them
         else row_head<K>(hlds, mixm, mm, F, ln, H, rh);
-        row_post_backward<K>(p, rh, H, active, rr, m, F, dO);
+        if (out_mask) {                           // the forward's output tells which elements the post-op let through
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float o = p.out[(unsigned)rr * (unsigned)p.ld_out + ((m + 16 * i < F) ? m + 16 * i : 0)];
+                dO[i] = (o != 0.f) ? dO[i] * post_gain : 0.f;
+            }
+        } else {
+            row_post_backward<K>(p, rh, H, active, rr, m, F, dO);
+        }
         float ds[K];
         row_head_backward_scalars<K>(rh, mixm, p.scale, H, dO, ds, qc, qj, dmix1);
         // ---- pass 2: one channel at a time -> G_c -> MFMA
@@ -887,7 +897,7 @@ extern "C" int acm_conv_agg_bwd(int64_t n_rows, const acm_conv_agg_bwd_t* p, voi
                 "acm_conv_agg_bwd: g_struc is NULL / too narrow");
     {
         int64_t ld_max = 64;
-        for (int64_t ld : {p->ld_grad_out, p->ld_agg, p->ld_xs, p->ld_head_stats, p->ld_post_scale, p->ld_ps, p->ld_ss, p->ld_g_struc})
+        for (int64_t ld : {p->ld_grad_out, p->ld_agg, p->ld_xs, p->ld_head_stats, p->ld_post_scale, p->ld_ps, p->ld_ss, p->ld_g_struc, p->ld_out})
             ld_max = ld > ld_max ? ld : ld_max;
         ACM_REQUIRE(n_rows * ld_max < (int64_t)INT32_MAX, ACM_EUNSUPPORTED, "acm_conv_agg_bwd: too many rows for 32-bit offsets");
     }

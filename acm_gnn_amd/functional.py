@@ -933,7 +933,10 @@ class AcmConvFunction(torch.autograd.Function):
                 st = lib.acm_conv_agg_fwd(ops.low.handle, C.byref(p), _vp(ws), ws.numel() * 4, _stream())
             _lib.check(st, "acm_conv_agg_fwd")
             ctx.ops, ctx.cfg, ctx.f_in = ops, cfg, f_in
-            ctx.save_for_backward(xpad, agg, wl, wh, wm, mix, *vecs, *lnw, *lnb, *extra)
+            # with a fused ReLU the output itself records which elements the post-op let through: the backward reads it
+            # instead of regenerating the dropout mask (no extra memory: the next layer keeps the same tensor alive)
+            ctx.out_mask = bool(ctx.post_relu) and ctx.post_scale is None and os.environ.get("ACM_AGG_OUT_MASK", "1") != "0"
+            ctx.save_for_backward(xpad, agg, wl, wh, wm, mix, *vecs, *lnw, *lnb, *extra, *((out,) if ctx.out_mask else ()))
             ctx.mark_non_differentiable(att)
             return out, att
         pre = torch.empty(n, (k - 1) * f, dtype=_F32, device=dev)
@@ -1167,6 +1170,9 @@ def _backward_agg(ctx, grad_out):
     k = cfg.n_channels
     four = k == 4
     saved = ctx.saved_tensors
+    out_fwd = None
+    if getattr(ctx, "out_mask", False):
+        out_fwd, saved = saved[-1], saved[:-1]
     xpad, agg, wl, wh, wm, mix = saved[:6]
     vecs = list(saved[6:6 + k])
     nln = k if cfg.layernorm else 0
@@ -1196,6 +1202,8 @@ def _backward_agg(ctx, grad_out):
     spec = _drop_spec(ctx.post_drop, ops.row_offset)
     if spec is not None:
         q.post_drop = spec
+    if out_fwd is not None:
+        q.out, q.ld_out = out_fwd.data_ptr(), out_fwd.stride(0)
     if four:
         ps, s_local = saved[-2], saved[-1]
         gs = torch.empty(n, f, dtype=_F32, device=dev)            # D * dL/dpre_S

@@ -515,6 +515,10 @@ typedef struct {
     acm_dropout_t post_drop;
     acm_reduce_list_t* defer;             /* NULL: reduce d_params now; else append to the list                 */
     const float* head_stats; int64_t ld_head_stats;   /* the forward's head_stats, or NULL: recompute            */
+    const float* out; int64_t ld_out;     /* the forward's `out`, or NULL.  With post_relu set and no post_scale the fused
+                                           * post-op is undone by reading it -- out != 0 <=> the ReLU passed AND the dropout
+                                           * kept the element (relu'(0) = 0 as in torch) -- instead of recomputing the mixed
+                                           * row and regenerating the Philox mask (an eighth of the kernel's VALU work)  */
 } acm_conv_agg_bwd_t;
 
 int acm_conv_agg_bwd_workspace_bytes(int64_t n_rows, int f_in, int f_out, size_t* bytes);
