@@ -350,3 +350,42 @@ extern "C" int sell_gather_id(int depth, int idp, const int* stream, unsigned st
     LAUNCH_ID(12, 1) LAUNCH_ID(12, 2)
     return -1;
 }
+
+// (d) the COLD neighbours (column id >= hot_rows) partitioned by column range over the eight XCDs: block b serves range
+//     b % 8 (its XCD: the slice of the table it needs, 1/8 of the cold part, stays in that XCD's L2), one lane PAIR per work
+//     item (a row's few cold neighbours inside the range), 32 items per wave and slice, ids stored [step][32 items].
+//     wave_ptr / wave_step / desc as above (desc: 40 ints per slice = {steps, -, -, -, -, -, -, -, out index x 32}).
+__global__ __launch_bounds__(256) void cold_partials(const int* __restrict__ stream, const int* __restrict__ wave_ptr,
+                                                     const int* __restrict__ wave_step, const int* __restrict__ desc,
+                                                     const float* __restrict__ x, unsigned x_bytes, float* __restrict__ out) {
+    const int lane = threadIdx.x & 63, pr = lane >> 1, h = lane & 1;
+    const int W = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
+    int s = wave_ptr[W];
+    const int s_end = wave_ptr[W + 1];
+    if (s >= s_end) return;
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(x), 0, x_bytes, 0x00020000);
+    const int* ids = stream + (long)wave_step[W] * 32 + pr;
+    int q0 = ids[0], q1 = ids[32];
+    ids += 64;
+    const int hoff = h * 16;
+    for (; s < s_end; ++s) {
+        const int ns = desc[s * 40];
+        const int o = desc[s * 40 + 8 + pr];
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        for (int t = 0; t < ns; ++t) {
+            const f32x4 z = ld_row(rs, q0 * 32 + hoff);
+            q0 = q1;
+            q1 = *ids;
+            ids += 32;
+            acc += z;
+        }
+        if (o >= 0) *reinterpret_cast<f32x4*>(out + (long)o * 8 + 4 * h) = acc;
+    }
+}
+
+extern "C" int cold_gather(const int* stream, const int* wave_ptr, const int* wave_step, const int* desc, const float* x,
+                           unsigned x_bytes, float* out, int n_waves, void* stream_handle) {
+    hipLaunchKernelGGL(cold_partials, dim3(n_waves / 4), dim3(256), 0, (hipStream_t)stream_handle, stream, wave_ptr, wave_step,
+                       desc, x, x_bytes, out);
+    return (int)hipGetLastError();
+}
