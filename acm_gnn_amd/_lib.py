@@ -155,7 +155,8 @@ class ReduceSeg(C.Structure):
     _fields_ = [("partial", C.c_void_p), ("nblk", C.c_int32), ("row_stride", C.c_int32),
                 ("q0", C.c_int32), ("len", C.c_int32), ("dst", C.c_void_p),
                 ("inner", C.c_int32), ("col_block", C.c_int32),
-                ("outer_stride", C.c_int64), ("block_stride", C.c_int64)]
+                ("outer_stride", C.c_int64), ("block_stride", C.c_int64),
+                ("elem_stride", C.c_int32), ("reserved", C.c_int32)]
 
 
 class ReduceList(C.Structure):

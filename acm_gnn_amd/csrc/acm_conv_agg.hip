@@ -724,8 +724,10 @@ __global__ __launch_bounds__(256, 2) void agg_bwd_kernel(acm_conv_agg_bwd_t p, i
     }
     if (g == 0 && m < K * K) slab[3 * f_in * F + 3 * K * F + m] = dmix1;
     __syncthreads();
+    // the slab is stored in groups of 32 parameters, partial[q / 32][block][q % 32] (acm_reduce_seg_t.elem_stride): whole
+    // 128-byte lines here, and the second phase reads one line per block and group instead of one float per line
     for (int q = threadIdx.x; q < npg; q += 256)
-        partial[(long)blockIdx.x * npg + q] = (lds[q] + lds[npg + q]) + (lds[2 * npg + q] + lds[3 * npg + q]);
+        partial[((long)(q >> 5) * gridDim.x + blockIdx.x) * 32 + (q & 31)] = (lds[q] + lds[npg + q]) + (lds[2 * npg + q] + lds[3 * npg + q]);
 }
 
 int agg_pad(int f_in) { return f_in <= 4 ? 4 : (f_in <= 8 ? 8 : 16); }
@@ -882,7 +884,7 @@ extern "C" int acm_conv_agg_bwd_workspace_bytes(int64_t n_rows, int f_in, int f_
     ACM_REQUIRE(bytes, ACM_EINVAL, "acm_conv_agg_bwd_workspace_bytes: NULL argument");
     ACM_REQUIRE(f_in >= 1 && f_in <= 16 && f_out >= 1 && f_out <= 64, ACM_EUNSUPPORTED,
                 "acm_conv_agg_bwd_workspace_bytes: f_in %d f_out %d unsupported", f_in, f_out);
-    const size_t npg = (size_t)3 * f_in * f_out + 12 * (size_t)f_out + 16;      // sized for 4 channels
+    const size_t npg = ((size_t)3 * f_in * f_out + 12 * (size_t)f_out + 16 + 31) / 32 * 32;      // sized for 4 channels, whole groups of 32
     *bytes = (size_t)agg_bwd_blocks(n_rows, 3, 0) * npg * sizeof(float);      // the larger of the two grids
     return ACM_OK;
 }
@@ -932,6 +934,6 @@ extern "C" int acm_conv_agg_bwd(int64_t n_rows, const acm_conv_agg_bwd_t* p, voi
     else ACM_BWDK(16);
 #undef ACM_BWDK
     ACM_CHECK_HIP(hipGetLastError());
-    const acm_reduce_seg_t seg = {partial, nblk, npg, 0, npg, p->d_params, npg, 0, 0, 0};   // d_params[q] = sum_b partial[b][q]
+    const acm_reduce_seg_t seg = {partial, nblk, 32, 0, npg, p->d_params, npg, 0, 0, 0, nblk * 32, 0};   // d_params[q] = sum_b partial[q / 32][b][q % 32]
     return acm_reduce_emit(p->defer, &seg, 1, s);
 }

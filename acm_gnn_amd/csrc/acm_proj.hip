@@ -23,7 +23,6 @@ __global__ __launch_bounds__(256) void proj_bwd_kernel(int n_rows, int f_in, con
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int g = lane >> 4, m = lane & 15;
     const bool vec = ((((uintptr_t)X | (uintptr_t)dX) & 15) == 0) && (ldx % 4 == 0) && (lddx % 4 == 0);
-    float* slab = partial + (long)blockIdx.x * f_in * Q;
     for (int j0 = 0; j0 < f_in; j0 += 64) {
         const int jb = j0 + 4 * m;              // first of this lane's four columns
         // this chunk of [W0 | W1 | W2] through LDS (coalesced, once per block; `red` is free until the end of the chunk),
@@ -83,7 +82,11 @@ __global__ __launch_bounds__(256) void proj_bwd_kernel(int n_rows, int f_in, con
         __syncthreads();
         for (int e = threadIdx.x; e < 64 * Q; e += 256) {
             const int j = j0 + e / Q;
-            if (j < f_in) slab[(long)j * Q + (e % Q)] = (red[0][e] + red[1][e]) + (red[2][e] + red[3][e]);
+            // slab in groups of 32 elements, partial[q / 32][block][q % 32] (acm_reduce_seg_t.elem_stride): see agg_bwd_kernel
+            if (j < f_in) {
+                const long q = (long)j * Q + (e % Q);
+                partial[((q >> 5) * gridDim.x + blockIdx.x) * 32 + (q & 31)] = (red[0][e] + red[1][e]) + (red[2][e] + red[3][e]);
+            }
         }
         __syncthreads();
     }
@@ -220,7 +223,7 @@ extern "C" int acm_proj_bwd_workspace_bytes(int64_t n_rows, int64_t f_in, int n_
     ACM_REQUIRE(n_rows >= 0 && f_in >= 0 && n_out >= 1, ACM_ESHAPE, "acm_proj_bwd_workspace_bytes: bad sizes");
     ACM_REQUIRE(n_out <= 15 && n_out % 3 == 0, ACM_EUNSUPPORTED,
                 "acm_proj_bwd: n_out = %d (supported: 3, 6, 9, 12, 15; use acm_gemm otherwise)", n_out);
-    *bytes = (size_t)proj_blocks(n_rows) * (size_t)f_in * (size_t)n_out * sizeof(float);
+    *bytes = (size_t)proj_blocks(n_rows) * (((size_t)f_in * (size_t)n_out + 31) / 32 * 32) * sizeof(float);     // whole groups of 32
     return ACM_OK;
 }
 
@@ -254,8 +257,8 @@ extern "C" int acm_proj_bwd(int64_t n_rows, int64_t f_in, int n_out, const float
     }
 #undef ACM_PROJ
     ACM_CHECK_HIP(hipGetLastError());
-    // dW[j][q] = sum_b partial[b][j * n_out + q], optionally in the column-block layout of dW
-    const acm_reduce_seg_t seg = {partial, nblk, (int32_t)(f_in * n_out), 0, (int32_t)(f_in * n_out), dW, n_out,
-                                  (int32_t)dw_col_block, lddw, dw_block_stride};
+    // dW[j][q] = sum_b partial[(j * n_out + q) / 32][b][(j * n_out + q) % 32], optionally in the column-block layout of dW
+    const acm_reduce_seg_t seg = {partial, nblk, 32, 0, (int32_t)(f_in * n_out), dW, n_out,
+                                  (int32_t)dw_col_block, lddw, dw_block_stride, nblk * 32, 0};
     return acm_reduce_emit(defer, &seg, 1, s);
 }

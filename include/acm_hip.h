@@ -207,6 +207,13 @@ typedef struct {
     int32_t inner;             /* columns per destination row (len for a flat vector)                          */
     int32_t col_block;         /* 0: blk(q) = q;  else blk(q) = (q / col_block) * block_stride + q % col_block */
     int64_t outer_stride, block_stride;
+    int32_t elem_stride;       /* 0: partial[b][q] at b * row_stride + q (row-major slabs, row_stride >= q0 + len);
+                                * > 0: slabs stored in GROUPS of row_stride elements, partial[q / row_stride][b][q % row_stride]
+                                * at (q / row_stride) * elem_stride + b * row_stride + q % row_stride, elem_stride >= nblk *
+                                * row_stride.  With row_stride == 32 (one 128-byte line per block and group) a block of the
+                                * second phase sums a whole group, reading one line per producer block instead of one float
+                                * out of each of 32 lines -- same order of additions per element, bit-identical results  */
+    int32_t reserved;
 } acm_reduce_seg_t;
 
 typedef struct {
