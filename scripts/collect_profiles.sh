@@ -15,13 +15,13 @@ cd /tmp && export TMPDIR=/tmp
 COMMIT=${2:-unknown}
 BENCH="python $REPO/bench.py"
 $BENCH > $OUT/bench.json 2> $OUT/bench.err
-rm -rf /tmp/prof_kt && rocprofv3 --kernel-trace --stats -d /tmp/prof_kt -o kt -- $BENCH --no-cpu-baseline --no-extras --no-check > /dev/null 2> $OUT/kt.err
+rm -rf /tmp/prof_kt && timeout 400 rocprofv3 --kernel-trace --stats -d /tmp/prof_kt -o kt -- $BENCH --no-cpu-baseline --no-extras --no-check > /dev/null 2> $OUT/kt.err
 DB=$(find /tmp/prof_kt -name "*.db" | head -1)
 python $REPO/scripts/rocpd_summary.py $DB > $OUT/kernel_stats.csv
 python $REPO/scripts/rocpd_sequence.py $DB 60 > $OUT/step_timeline.txt
 for PASS in "FETCH_SIZE:pmc_fetch_size_kb" "WRITE_SIZE:pmc_write_size_kb" "TCC_HIT_sum TCC_MISS_sum TCP_TCC_READ_REQ_sum TCP_TOTAL_CACHE_ACCESSES_sum:pmc_cache"; do
   CNT=${PASS%%:*}; NAME=${PASS##*:}
-  rm -rf /tmp/prof_pmc && rocprofv3 --pmc $CNT --kernel-trace -d /tmp/prof_pmc -o pmc -- python $REPO/bench.py --steps 8 --warmup 2 --no-cpu-baseline --no-extras --no-check > /dev/null 2> $OUT/$NAME.err
+  rm -rf /tmp/prof_pmc && timeout 400 rocprofv3 --pmc $CNT --kernel-trace -d /tmp/prof_pmc -o pmc -- python $REPO/bench.py --steps 8 --warmup 2 --no-cpu-baseline --no-extras --no-check > /dev/null 2> $OUT/$NAME.err
   DB=$(find /tmp/prof_pmc -name "*.db" | head -1)
   python $REPO/scripts/rocpd_pmc_summary.py $DB > $OUT/$NAME.csv 2>> $OUT/$NAME.err
 done
