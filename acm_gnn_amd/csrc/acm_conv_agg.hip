@@ -737,7 +737,11 @@ int agg_pad(int f_in) { return f_in <= 4 ? 4 : (f_in <= 8 ? 8 : 16); }
 // with the structure channel (185-191 VGPRs) two fit.
 int agg_bwd_blocks(int64_t n_rows, int n_channels, size_t lds_bytes) {
     int64_t nb = (n_rows + 15) / 16;
-    const int cap = (n_channels == 3 && 3 * lds_bytes <= 160 * 1024) ? 768 : 512;     // registers and LDS of three
+    int cap = (n_channels == 3 && 3 * lds_bytes <= 160 * 1024) ? 768 : 512;     // registers and LDS of three
+    if (const char* env = getenv("ACM_AGG_BWD_BLOCKS")) {                        // tuning / overlap experiments
+        const int v = atoi(env);
+        if (v >= 1 && v <= cap) cap = v;
+    }
     if (nb > cap) nb = cap;
     if (nb < 1) nb = 1;
     return (int)nb;

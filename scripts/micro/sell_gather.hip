@@ -389,3 +389,79 @@ extern "C" int cold_gather(const int* stream, const int* wave_ptr, const int* wa
                        desc, x, x_bytes, out);
     return (int)hipGetLastError();
 }
+
+// (e) 16-byte rows (the output-layer gathers): the first hub_rows rows of X in LDS (up to 128 KB = 8 192 rows, half of the
+//     twitch-shaped graph's edges), branch-free as in (b): hub neighbours read LDS and send an out-of-range offset to the
+//     buffer load, the others read the zero row behind the hub table.
+template <int D, bool LDSHUB, int WPB>
+__global__ __launch_bounds__(WPB * 64) void sell_gather_quad_v(const int* __restrict__ stream, const int* __restrict__ wave_ptr,
+                                                               const int* __restrict__ wave_step, const int* __restrict__ desc,
+                                                               const float* __restrict__ x, unsigned x_bytes,
+                                                               float* __restrict__ out, int hub_rows) {
+    extern __shared__ f32x4 hub[];
+    if (LDSHUB) {
+        for (int i = threadIdx.x; i < hub_rows; i += WPB * 64) hub[i] = reinterpret_cast<const f32x4*>(x)[i];
+        if (threadIdx.x == 0) hub[hub_rows] = f32x4{0.f, 0.f, 0.f, 0.f};
+        __syncthreads();
+    }
+    const int lane = threadIdx.x & 63, g = lane >> 4, gl = lane & 15;
+    const int W = __builtin_amdgcn_readfirstlane(blockIdx.x * WPB + (threadIdx.x >> 6));
+    int s = wave_ptr[W];
+    const int s_end = wave_ptr[W + 1];
+    if (s >= s_end) return;
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(x), 0, x_bytes, 0x00020000);
+    const int2* ids = reinterpret_cast<const int2*>(stream) + (long)wave_step[W] * 64 + (g * 16 + gl);
+    int2 q[D];
+#pragma unroll
+    for (int d = 0; d < D; ++d) q[d] = ids[d * 64];
+    ids += D * 64;
+    int total = 0;
+    for (int t = s; t < s_end; ++t) total += desc[t * 8];
+    int rem = desc[s * 8];
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    for (int t = 0; t < total; ++t) {
+        const int2 j = q[0];
+#pragma unroll
+        for (int d = 0; d + 1 < D; ++d) q[d] = q[d + 1];
+        q[D - 1] = *ids;
+        ids += 64;
+        if (LDSHUB) {
+            const bool h0 = j.x < hub_rows, h1 = j.y < hub_rows;
+            const f32x4 l0 = hub[h0 ? j.x : hub_rows], l1 = hub[h1 ? j.y : hub_rows];
+            const f32x4 z0 = ld_row(rs, h0 ? -16 : j.x * 16), z1 = ld_row(rs, h1 ? -16 : j.y * 16);
+            acc += (l0 + l1) + (z0 + z1);
+        } else {
+            acc += ld_row(rs, j.x * 16) + ld_row(rs, j.y * 16);
+        }
+        if (--rem == 0) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                acc[i] += dpp<0xB1>(acc[i]);
+                acc[i] += dpp<0x4E>(acc[i]);
+                acc[i] += dpp<0x124>(acc[i]);
+                acc[i] += dpp<0x128>(acc[i]);
+            }
+            const int o = desc[s * 8 + 1 + g];
+            if (gl == 0 && o >= 0) *reinterpret_cast<f32x4*>(out + (long)o * 4) = acc;
+            acc = f32x4{0.f, 0.f, 0.f, 0.f};
+            ++s;
+            rem = s < s_end ? desc[s * 8] : 0x7fffffff;
+        }
+    }
+}
+
+#define LAUNCH_Q(HUBV, WPBV)                                                                                       \
+    if ((hub_rows > 0) == HUBV && wpb == WPBV) {                                                                   \
+        auto k = sell_gather_quad_v<2, HUBV, WPBV>;                                                                \
+        if (HUBV) (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, hub_rows * 16 + 16); \
+        hipLaunchKernelGGL(k, dim3(n_waves / WPBV), dim3(WPBV * 64), HUBV ? hub_rows * 16 + 16 : 0,                \
+                           (hipStream_t)stream_handle, stream, wave_ptr, wave_step, desc, x, x_bytes, out, hub_rows); \
+        return (int)hipGetLastError();                                                                             \
+    }
+
+extern "C" int sell_gather_q(int hub_rows, int wpb, const int* stream, const int* wave_ptr, const int* wave_step,
+                             const int* desc, const float* x, unsigned x_bytes, float* out, int n_waves,
+                             void* stream_handle) {
+    LAUNCH_Q(false, 4) LAUNCH_Q(false, 16) LAUNCH_Q(true, 16) LAUNCH_Q(true, 8)
+    return -1;
+}

@@ -108,6 +108,8 @@ def main():
             torch.cuda.synchronize()
             return e0.elapsed_time(e1) / reps * 1e3
 
+        if width == 8 and os.environ.get("HUB4"):
+            continue
         if width == 8 and os.environ.get("VARIANTS", "1") == "1":
             lib.sell_gather_v.argtypes = [C.c_int, C.c_int, C.c_int] + [C.c_void_p] * 5 + [C.c_uint, C.c_void_p, C.c_int, C.c_void_p]
             for n_waves in ((4096, 8192) if os.environ.get("HUB_VARIANTS") else ()):
@@ -154,6 +156,28 @@ def main():
                 print(" ".join(line), flush=True)
             if os.environ.get("ONLY_VARIANTS"):
                 return
+        if width == 4 and os.environ.get("HUB4"):
+            lib.sell_gather_q.argtypes = [C.c_int, C.c_int] + [C.c_void_p] * 5 + [C.c_uint, C.c_void_p, C.c_int, C.c_void_p]
+            for n_waves in (4096, 8192):
+                stream, wptr, wstep, desc, item_row, total_steps = build_streams(indptr, indices, n_waves, max_steps=8, sentinel=SENT4)
+                d_stream, d_wptr, d_wstep, d_desc = (torch.from_numpy(a).to(DEV) for a in (stream, wptr, wstep, desc))
+                out = torch.zeros(item_row.size, width, device=DEV)
+                line = [f"  16-byte rows, hub rows in LDS, waves {n_waves}:"]
+                for hub, wpb in ((0, 4), (0, 16), (2048, 16), (4096, 16), (8190, 16), (2048, 8), (4095, 8)):
+                    def run():
+                        st = lib.sell_gather_q(hub, wpb, d_stream.data_ptr(), d_wptr.data_ptr(), d_wstep.data_ptr(),
+                                               d_desc.data_ptr(), x.data_ptr(), n * width * 4, out.data_ptr(), n_waves, stream_h)
+                        assert st == 0, st
+                    out.zero_()
+                    run()
+                    torch.cuda.synchronize()
+                    got = np.zeros((n, width))
+                    np.add.at(got, item_row, out.cpu().double().numpy())
+                    e = float(np.abs(got - ref.numpy()).max())
+                    assert e < 1e-3, (hub, wpb, e)
+                    line.append(f"hub{hub}/wpb{wpb} {timeit(run):6.1f}")
+                print(" ".join(line), flush=True)
+            return
         t_csr = timeit(lambda: AF.spmm(g, x, out=y))
         err = float((y.cpu().double() - ref).abs().max())
         print(f"width {width}: CSR kernel {t_csr:7.1f} us  (err {err:.1e})")
