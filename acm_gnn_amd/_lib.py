@@ -110,7 +110,10 @@ class ConvAggFwd(C.Structure):
                 ("n_channels", C.c_int32), ("sg", C.c_void_p), ("ld_sg", C.c_int64), ("sg_bf16", C.c_int32),
                 ("ss", C.c_void_p), ("ld_ss", C.c_int64), ("deg", C.c_void_p),
                 ("ps", C.c_void_p), ("ld_ps", C.c_int64), ("row_scale", C.c_void_p), ("post_drop", Dropout),
-                ("head_stats", C.c_void_p), ("ld_head_stats", C.c_int64)]
+                ("head_stats", C.c_void_p), ("ld_head_stats", C.c_int64),
+                ("next_w_low", C.c_void_p), ("next_w_high", C.c_void_p), ("next_w_mlp", C.c_void_p), ("next_ld_w", C.c_int64),
+                ("next_f", C.c_int32), ("next_relu", C.c_int32),
+                ("next_zlh", C.c_void_p), ("ld_next_zlh", C.c_int64), ("next_zi", C.c_void_p), ("ld_next_zi", C.c_int64)]
 
 
 class ConvAggBwd(C.Structure):

@@ -48,6 +48,18 @@ __device__ __forceinline__ void stage_weights(float* wlds, const float* w_low, c
     }
 }
 
+// The next layer's three F x F' weight panels (F' <= 2) as one [col][8] table: [W_L'(col,:) | W_H'(col,:) | W_I'(col,:) | 0].
+// A lane reads the rows of its four columns with two ds_read_b128 each.
+#define ACM_NEXT_LDS (64 * 8)
+__device__ __forceinline__ void stage_next_weights(float* nlds, const acm_conv_agg_fwd_t& p) {
+    if (p.next_f <= 0) return;
+    for (int idx = threadIdx.x; idx < ACM_NEXT_LDS; idx += 256) {
+        const int col = idx >> 3, j = idx & 7, c = j / p.next_f, q = j % p.next_f;
+        const float* w = c == 0 ? p.next_w_low : (c == 1 ? p.next_w_high : p.next_w_mlp);
+        nlds[idx] = (col < p.f_out && c < 3) ? w[(long)col * p.next_ld_w + q] : 0.f;
+    }
+}
+
 // pre_L = P W_L, pre_H = (x - P) W_H, z_I = x W_I for the lane's four columns.
 // P and x of the group's row are parked in a per-group LDS scratch (2 FP floats) so that the loop
 // over f can stay *rolled*: with a fully unrolled loop hipcc keeps all 3 FP ds_read_b128 weight rows
@@ -83,11 +95,12 @@ __device__ __forceinline__ void project(const float* wlds, float* scratch, int m
 }
 
 // P (uniform in the 16-lane group) -> projections -> head -> out / att for one row.
-template <int FP, int K, bool FULL = false, bool NT = false>
+template <int FP, int K, bool FULL = false, bool NT = false, bool NEXT = false>
 __device__ __forceinline__ void agg_fwd_row(const acm_conv_agg_fwd_t& p, const float* wlds, const float* hlds,
                                             float* scratch, const float* mixm, int row, int lane, const CsrView& csr,
                                             const float* __restrict__ partial, const AcmDropCtx& dc,
-                                            bool p_in_scratch = false, bool active = true, bool x_in_scratch = false) {
+                                            bool p_in_scratch = false, bool active = true, bool x_in_scratch = false,
+                                            const float* nlds = nullptr) {
     const int F = FULL ? 64 : p.f_out, m = lane & 15;     // FULL: f_out == 64, the column guards fold away
     float H[K][4];
     {
@@ -144,9 +157,11 @@ __device__ __forceinline__ void agg_fwd_row(const acm_conv_agg_fwd_t& p, const f
     if (p.head_stats && m == 0 && active) row_head_store<K>(p.head_stats + (long)row * p.ld_head_stats, rh);
     float df[4];
     acm_drop4(dc, row, m, df);        // dc: read once per launch (its step counter is a global load)
+    float ov[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int col = m + 16 * i;
+        ov[i] = 0.f;
         if (col < F && active) {
             float o = rh.alpha[0] * H[0][i] + rh.alpha[1] * H[1][i] + rh.alpha[2] * H[2][i];
             if (K == 4) o = fmaf(rh.alpha[K - 1], H[K - 1][i], o);
@@ -158,6 +173,35 @@ __device__ __forceinline__ void agg_fwd_row(const acm_conv_agg_fwd_t& p, const f
             // gathered table
             if (NT) __builtin_nontemporal_store(o, p.out + (long)row * p.ld_out + col);
             else p.out[(long)row * p.ld_out + col] = o;
+            if (NEXT) ov[i] = o;
+        }
+    }
+    if (NEXT) {
+        // the next layer's projection of this row, [out W_L' | out W_H' | out W_I'] (3 F' <= 8 values): the lane's four
+        // columns against their rows of the [col][8] table, then the 16-lane sum
+        float z8[6];
+#pragma unroll
+        for (int j = 0; j < 6; ++j) z8[j] = 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float4 wa = *reinterpret_cast<const float4*>(nlds + (m + 16 * i) * 8);
+            const float2 wb = *reinterpret_cast<const float2*>(nlds + (m + 16 * i) * 8 + 4);
+            z8[0] = fmaf(ov[i], wa.x, z8[0]); z8[1] = fmaf(ov[i], wa.y, z8[1]);
+            z8[2] = fmaf(ov[i], wa.z, z8[2]); z8[3] = fmaf(ov[i], wa.w, z8[3]);
+            z8[4] = fmaf(ov[i], wb.x, z8[4]); z8[5] = fmaf(ov[i], wb.y, z8[5]);
+        }
+        const int nf = p.next_f;
+#pragma unroll
+        for (int j = 0; j < 6; ++j) {
+            z8[j] = acm_group_sum<16>(z8[j]);
+            if (p.next_relu) z8[j] = fmaxf(z8[j], 0.f);
+        }
+        if (m == 0 && active) {
+#pragma unroll
+            for (int j = 0; j < 6; ++j) {
+                if (j < 2 * nf) p.next_zlh[(long)row * p.ld_next_zlh + j] = z8[j];
+                else if (j < 3 * nf) p.next_zi[(long)row * p.ld_next_zi + (j - 2 * nf)] = z8[j];
+            }
         }
     }
     if (m == 0 && active)
@@ -294,16 +338,19 @@ __global__ __launch_bounds__(256) void agg_fused_kernel(acm_conv_agg_fwd_t p, Cs
 // one row the address coalescer sees 32 lines per 32 neighbours -- half the look-ups per byte, which is what bounds the
 // gather once the rows hit in L1/L2 (scripts/probe_gather.py: 63 us with every row in L1).
 // Lane (e = gl >> 1, h = gl & 1) of the 16-lane group: neighbours k0 + e + 8 u (u = 0..3), columns 4 h .. 4 h + 3.
-template <bool FULL>
-__global__ __launch_bounds__(256) void agg_fused_pair_kernel(acm_conv_agg_fwd_t p, CsrView csr) {
+// NEXT: the following layer's narrow projection rides the epilogue (acm_conv_agg_fwd_t.next_*).
+template <bool FULL, bool NEXT = false>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5))) void agg_fused_pair_kernel(acm_conv_agg_fwd_t p, CsrView csr) {
     constexpr int FP = 8, K = 3, GPB = 16, U = 4, STEP = 8 * U;
     static_assert(GPB == ACM_WINDOW, "one window of work items per workgroup round");
-    __shared__ __attribute__((aligned(16))) float wlds[3 * FP * 64 + 3 * K * 64 + 16 * 2 * FP];
+    __shared__ __attribute__((aligned(16))) float wlds[3 * FP * 64 + 3 * K * 64 + 16 * 2 * FP + (NEXT ? ACM_NEXT_LDS : 0)];
     __shared__ float coop[ACM_WINDOW * FP];
     float* hlds = wlds + 3 * FP * 64;
     float* scratch = hlds + 3 * K * 64 + (threadIdx.x >> 4) * 2 * FP;
+    float* nlds = hlds + 3 * K * 64 + 16 * 2 * FP;
     stage_weights<FP>(wlds, p.w_low, p.w_high, p.w_mlp, p.ld_w, p.f_in, p.f_out);
     stage_head_params<K>(hlds, p.att_vec, p.ln_weight, p.ln_bias, p.layernorm, p.f_out);
+    if (NEXT) stage_next_weights(nlds, p);
     __syncthreads();
     float mixm[K * K];
 #pragma unroll
@@ -401,7 +448,7 @@ __global__ __launch_bounds__(256) void agg_fused_pair_kernel(acm_conv_agg_fwd_t 
                     p.agg[(long)it.row * p.ld_agg + 4 * h + i] = val;
                 }
             }
-            agg_fwd_row<FP, K, FULL>(p, wlds, hlds, scratch, mixm, it.row, lane, csr, nullptr, dc, true);
+            agg_fwd_row<FP, K, FULL, false, NEXT>(p, wlds, hlds, scratch, mixm, it.row, lane, csr, nullptr, dc, true, true, false, nlds);
         }
         if (!has_next) break;
         it = itn;
@@ -773,6 +820,13 @@ int check_common(const P* p, const char* who) {
 
 }  // namespace
 
+// The requested next-layer projection for the paths whose epilogue does not carry it: a launch of its own.
+static int next_projection(const acm_csr_t* a, const acm_conv_agg_fwd_t* p, acm_stream_t stream) {
+    if (p->next_f <= 0) return ACM_OK;
+    return acm_proj_fwd(a->n_rows, p->f_out, p->next_f, p->out, p->ld_out, p->next_w_low, p->next_w_high, p->next_w_mlp,
+                        p->next_ld_w, p->next_relu, p->next_zlh, p->ld_next_zlh, p->next_zi, p->ld_next_zi, stream);
+}
+
 extern "C" int acm_conv_agg_fwd(const acm_csr_t* a, const acm_conv_agg_fwd_t* p, void* workspace,
                                 size_t workspace_bytes, acm_stream_t stream) {
     ACM_REQUIRE(a && p, ACM_EINVAL, "acm_conv_agg_fwd: NULL argument");
@@ -788,8 +842,15 @@ extern "C" int acm_conv_agg_fwd(const acm_csr_t* a, const acm_conv_agg_fwd_t* p,
         ACM_REQUIRE(a->n_rows * ld_max < (int64_t)INT32_MAX, ACM_EUNSUPPORTED,
                     "acm_conv_agg_fwd: too many rows for 32-bit offsets into ps / ss");
     }
+    if (p->next_f != 0) {
+        ACM_REQUIRE(p->next_f >= 1 && p->next_f <= 2, ACM_EUNSUPPORTED, "acm_conv_agg_fwd: next_f %d (fused next projection: 1 or 2)", p->next_f);
+        ACM_REQUIRE(p->next_w_low && p->next_w_high && p->next_w_mlp && p->next_zlh && p->next_zi && p->next_ld_w >= p->next_f &&
+                        p->ld_next_zlh >= 2 * p->next_f && p->ld_next_zi >= p->next_f, ACM_EINVAL,
+                    "acm_conv_agg_fwd: fused next projection: NULL pointer / leading dimension too small");
+    }
     if (a->n_rows == 0) return ACM_OK;
     hipStream_t s = (hipStream_t)stream;
+    bool next_done = false;
     // (0) fused form: gather + epilogue in one kernel (long rows included)
     {
         const double avg = (double)a->nnz / (double)(a->n_rows > 0 ? a->n_rows : 1);
@@ -823,7 +884,7 @@ extern "C" int acm_conv_agg_fwd(const acm_csr_t* a, const acm_conv_agg_fwd_t* p,
                 else
                     hipLaunchKernelGGL((agg_stream_kernel<false, false>), dim3(grid), dim3(256), 0, s, *p, sv, (unsigned)table_bytes);
                 ACM_CHECK_HIP(hipGetLastError());
-                return ACM_OK;
+                return next_projection(a, p, stream);
             }
             const CsrView cv = acm_view(a);
             int grid = (int)((a->n_items + 15) / 16);
@@ -836,7 +897,10 @@ extern "C" int acm_conv_agg_fwd(const acm_csr_t* a, const acm_conv_agg_fwd_t* p,
                 else hipLaunchKernelGGL((agg_fused_kernel<4, false>), dim3(grid), dim3(256), 0, s, *p, cv);
             } else {
                 const bool pair_lanes = getenv("ACM_AGG_NO_PAIR") == nullptr;
-                if (pair_lanes && full)
+                if (pair_lanes && full && p->next_f > 0 && getenv("ACM_AGG_NO_NEXT") == nullptr) {
+                    hipLaunchKernelGGL((agg_fused_pair_kernel<true, true>), dim3(grid), dim3(256), 0, s, *p, cv);
+                    next_done = true;
+                } else if (pair_lanes && full)
                     hipLaunchKernelGGL((agg_fused_pair_kernel<true>), dim3(grid), dim3(256), 0, s, *p, cv);
                 else if (pair_lanes)
                     hipLaunchKernelGGL((agg_fused_pair_kernel<false>), dim3(grid), dim3(256), 0, s, *p, cv);
@@ -846,7 +910,7 @@ extern "C" int acm_conv_agg_fwd(const acm_csr_t* a, const acm_conv_agg_fwd_t* p,
                     hipLaunchKernelGGL((agg_fused_kernel<8, false>), dim3(grid), dim3(256), 0, s, *p, cv);
             }
             ACM_CHECK_HIP(hipGetLastError());
-            return ACM_OK;
+            return next_done ? ACM_OK : next_projection(a, p, stream);
         }
     }
     // (1) P = A_low X  -> p->agg  (also the tensor saved for the backward); row_scale for a pattern-only a_low
@@ -881,7 +945,7 @@ extern "C" int acm_conv_agg_fwd(const acm_csr_t* a, const acm_conv_agg_fwd_t* p,
     else ACM_EPI(16);
 #undef ACM_EPI
     ACM_CHECK_HIP(hipGetLastError());
-    return ACM_OK;
+    return next_projection(a, p, stream);
 }
 
 extern "C" int acm_conv_agg_bwd_workspace_bytes(int64_t n_rows, int f_in, int f_out, size_t* bytes) {

@@ -171,6 +171,42 @@ class fused_loss_tail:
 
 _TAIL = None            # the pending request, consumed by the first layer that qualifies
 _TAIL_LAYER = False     # set by layers.GraphConvolution.forward around the call of an output layer without post-op
+# Cross-layer hand-off of the narrow projection (acm_conv_agg_fwd_t.next_*): models.GCN names the FOLLOWING layer in
+# _NEXT_PROJ around the call of a hidden layer; an aggregate-first forward that can carry that layer's projection in its
+# epilogue computes [out W_L' | out W_H'], out W_I' there and leaves them in _PRE_PROJ, and the following layer's forward
+# takes them instead of launching acm_proj_fwd -- provided it is handed exactly that output tensor and those weights.
+_NEXT_PROJ = None
+_PRE_PROJ = None
+
+
+def _next_proj_request(f, dev):
+    """(weights, relu_before, F') of the layer named in _NEXT_PROJ when its projection can ride this layer's epilogue."""
+    global _NEXT_PROJ
+    nxt, _NEXT_PROJ = _NEXT_PROJ, None
+    if nxt is None or os.environ.get("ACM_NEXT_PROJ", "1") == "0":
+        return None
+    try:
+        w3 = (nxt.weight_low, nxt.weight_high, nxt.weight_mlp)
+        cfg = nxt._config()
+    except AttributeError:
+        return None
+    f2 = w3[0].shape[1]
+    ok = (f2 <= 2 and cfg.n_channels == 3 and all(w.dtype == _F32 and w.is_contiguous() and w.device == dev and
+                                                   tuple(w.shape) == (f, f2) for w in w3))
+    return (w3, bool(cfg.relu_before), f2) if ok else None
+
+
+def _take_pre_proj(x, w3, relu):
+    """The projection a preceding layer left for (x, w3, relu), or None."""
+    global _PRE_PROJ
+    pre, _PRE_PROJ = _PRE_PROJ, None
+    if pre is None or not isinstance(x, torch.Tensor):
+        return None
+    out, zlh, zi, ptrs, prelu = pre
+    if (x.data_ptr() == out.data_ptr() and x.shape == out.shape and x.stride() == out.stride() and prelu == bool(relu)
+            and tuple(w.data_ptr() for w in w3) == ptrs):
+        return zlh, zi
+    return None
 
 
 def _vp(t):
@@ -806,7 +842,10 @@ class AcmConvFunction(torch.autograd.Function):
             ldz = 3 * f
             if f in (2, 4, 8):
                 ldz = -(-3 * f // (2 * f)) * (2 * f)
-            if use_proj:
+            pre = _take_pre_proj(x, w3, cfg.relu_before) if use_proj else None
+            if pre is not None:
+                zlh, zi = pre                              # computed in the preceding layer's epilogue
+            elif use_proj:
                 zlh = torch.empty(n, 2 * f, dtype=_F32, device=dev)
                 zi = torch.empty(n, f, dtype=_F32, device=dev)
                 proj_fwd(x, w3, zlh, zi, relu=cfg.relu_before)
@@ -925,6 +964,15 @@ class AcmConvFunction(torch.autograd.Function):
             if stats is not None:
                 p.head_stats, p.ld_head_stats = stats.data_ptr(), stats.stride(0)
             ctx.head_stats = stats
+            nxt = _next_proj_request(f, dev)
+            if nxt is not None:
+                n_w3, n_relu, f2 = nxt
+                n_zlh = torch.empty(n, 2 * f2, dtype=_F32, device=dev)
+                n_zi = torch.empty(n, f2, dtype=_F32, device=dev)
+                p.next_w_low, p.next_w_high, p.next_w_mlp = (w.data_ptr() for w in n_w3)
+                p.next_ld_w, p.next_f, p.next_relu = n_w3[0].stride(0), f2, int(n_relu)
+                p.next_zlh, p.ld_next_zlh = n_zlh.data_ptr(), n_zlh.stride(0)
+                p.next_zi, p.ld_next_zi = n_zi.data_ptr(), n_zi.stride(0)
             ws = ops.low.workspace(max(fp, f) if four else fp)
             if (not four and fp == 8 and xg.stride(0) == 8 and ops.implicit and not ops.low.stream_steps
                     and ops.low.want_streams() and not (dev.type == "cuda" and torch.cuda.is_current_stream_capturing())):
@@ -932,6 +980,9 @@ class AcmConvFunction(torch.autograd.Function):
             with _device_ctx(dev), _Timed(f"conv_agg_fwd/F{f}k{k}i{f_in}"):
                 st = lib.acm_conv_agg_fwd(ops.low.handle, C.byref(p), _vp(ws), ws.numel() * 4, _stream())
             _lib.check(st, "acm_conv_agg_fwd")
+            if nxt is not None:
+                global _PRE_PROJ
+                _PRE_PROJ = (out, n_zlh, n_zi, tuple(w.data_ptr() for w in n_w3), n_relu)
             ctx.ops, ctx.cfg, ctx.f_in = ops, cfg, f_in
             # with a fused ReLU the output itself records which elements the post-op let through: the backward reads it
             # instead of regenerating the dropout mask (no extra memory: the next layer keeps the same tensor alive)

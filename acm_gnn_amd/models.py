@@ -124,10 +124,19 @@ class GCN(nn.Module):
             return self.gcns[0](x, adj_low, adj_high, adj_low_unnormalized, rows_permuted=self._rows_permuted)
         if self.model_type == "acmgcnpp":
             xx = self._residual(x, adj_low, drop=(p, 2, st, off))
-        fea = self.gcns[0](x, adj_low, adj_high, adj_low_unnormalized, post_relu=True, post_drop=(p, 1, st), **kw, rows_permuted=self._rows_permuted)
+        # the output layer's narrow projection may ride the hidden layer's epilogue (functional._NEXT_PROJ); not with the
+        # ACM-GCN++ residual, which changes the hidden activations in between
+        AF._NEXT_PROJ = self.gcns[1] if self.model_type != "acmgcnpp" else None
+        try:
+            fea = self.gcns[0](x, adj_low, adj_high, adj_low_unnormalized, post_relu=True, post_drop=(p, 1, st), **kw, rows_permuted=self._rows_permuted)
+        finally:
+            AF._NEXT_PROJ = None
         if self.model_type == "acmgcnpp":
             fea = fea + xx
-        return self.gcns[1](fea, adj_low, adj_high, adj_low_unnormalized, rows_permuted=self._rows_permuted)
+        try:
+            return self.gcns[1](fea, adj_low, adj_high, adj_low_unnormalized, rows_permuted=self._rows_permuted)
+        finally:
+            AF._PRE_PROJ = None
 
     def _forward_snowball(self, x, adj_low, adj_high, fused):
         """models.py:57-64: h_k = dropout(relu(layer_k([x | h_0 | ... | h_{k-1}]))), out = layer_last([x | h_0 | ...]).
@@ -194,7 +203,14 @@ class GCN(nn.Module):
         if self.training and self.dropout > 0:
             ones = self._ones_like_hidden(x.shape[0], self.gcns[0].out_features, x.device)
             scale = drop(ones)
-        fea = self.gcns[0](x, adj_low, adj_high, adj_low_unnormalized, post_relu=True, post_scale=scale, rows_permuted=self._rows_permuted)
+        AF._NEXT_PROJ = self.gcns[1] if self.model_type != "acmgcnpp" else None     # see _forward_fused_dropout
+        try:
+            fea = self.gcns[0](x, adj_low, adj_high, adj_low_unnormalized, post_relu=True, post_scale=scale, rows_permuted=self._rows_permuted)
+        finally:
+            AF._NEXT_PROJ = None
         if self.model_type == "acmgcnpp":
             fea = fea + xx
-        return self.gcns[1](fea, adj_low, adj_high, adj_low_unnormalized, rows_permuted=self._rows_permuted)
+        try:
+            return self.gcns[1](fea, adj_low, adj_high, adj_low_unnormalized, rows_permuted=self._rows_permuted)
+        finally:
+            AF._PRE_PROJ = None

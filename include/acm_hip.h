@@ -492,6 +492,15 @@ typedef struct {
      * mean_c | rstd_c | sigmoid_c | alpha_c as the forward computed them.  Handed to acm_conv_agg_bwd they save it
      * the recomputation (three 16-lane reductions per channel and row: ~12 % of that kernel); bit-identical results. */
     float* head_stats; int64_t ld_head_stats;
+    /* Optional: the NEXT layer's narrow projection (layers.py:87-89 of the following GraphConvolution), fused into this
+     * layer's epilogue while the finished row (after the post-op) is still in registers:
+     *   next_zlh[row] = [out_row W_L' | out_row W_H'],  next_zi[row] = out_row W_I'   (ReLU'd when next_relu is set)
+     * -- what acm_proj_fwd would compute from `out` in a launch of its own.  next_f = F' <= 2 (0 = off);
+     * the three weights are f_out x F' with leading dimension next_ld_w.                                             */
+    const float* next_w_low; const float* next_w_high; const float* next_w_mlp; int64_t next_ld_w;
+    int32_t next_f, next_relu;
+    float* next_zlh; int64_t ld_next_zlh;
+    float* next_zi;  int64_t ld_next_zi;
 } acm_conv_agg_fwd_t;
 
 int acm_conv_agg_fwd(const acm_csr_t* a_low, const acm_conv_agg_fwd_t* p,

@@ -663,6 +663,14 @@ class FakeLib:
         vecs, lnw, lnb, mix = self._params(p, k, F, p.layernorm)
         hd = _head(H, k, p.layernorm, vecs, lnw, lnb, mix)
         _view(p.out, n, F, p.ld_out)[...] = _post_fwd(p, p.scale * sum(hd["alpha"][:, c:c + 1] * H[c] for c in range(k)), n, F)
+        if p.next_f > 0:                                   # the following layer's narrow projection of `out`
+            f2 = p.next_f
+            o = _view(p.out, n, F, p.ld_out).astype(np.float64)
+            z = [o @ _view(w, F, f2, p.next_ld_w).astype(np.float64) for w in (p.next_w_low, p.next_w_high, p.next_w_mlp)]
+            if p.next_relu:
+                z = [np.maximum(t, 0) for t in z]
+            _view(p.next_zlh, n, 2 * f2, p.ld_next_zlh)[...] = np.concatenate(z[:2], 1)
+            _view(p.next_zi, n, f2, p.ld_next_zi)[...] = z[2]
         agg = _view(p.agg, n, fp, p.ld_agg)
         agg[...] = 0
         agg[:, :fi] = P

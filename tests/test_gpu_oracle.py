@@ -493,3 +493,59 @@ def test_channel_per_pass_backward_matches_oracle(model_type, variant, s, f_out,
     monkeypatch.setenv("ACM_BWD_FUSED", "1")
     b = _run_both(model_type, variant, s, True, 600, 30, f_out, 41, True, monkeypatch, agg=False, adj=adj)
     assert float((a - b).abs().max()) < 2e-5 * max(1.0, float(b.abs().max()))
+
+
+@pytest.mark.parametrize("hidden,n_cls,p_drop,chunk", [(64, 2, 0.3, None), (64, 1, 0.0, None), (64, 2, 0.25, "128"),
+                                                        (32, 2, 0.3, None), (64, 3, 0.3, None)])
+def test_next_layer_projection_in_the_hidden_layers_epilogue(hidden, n_cls, p_drop, chunk, monkeypatch):
+    """acm_conv_agg_fwd_t.next_*: the output layer's narrow projection computed in the aggregate-first hidden layer's
+    epilogue (the F = 64 pair kernel carries it; other kernels, e.g. hidden 32, fall back to a launch of acm_proj_fwd
+    inside the same call; three classes are not fused at all) -- training-mode logits and every gradient against the
+    oracle with the counter-based masks replayed, and against the run with the hand-off switched off."""
+    from acm_gnn_amd import GCN, functional as AF
+    from acm_gnn_amd.graph import clear_cache
+    if chunk:
+        monkeypatch.setenv("ACM_CHUNK", chunk)             # the hub row (349 neighbours) becomes window-packed pieces
+    n = 350
+    adj = _graph(n, 21)
+    low, high, _ = O.filters_linkx(adj)
+    g = torch.Generator().manual_seed(2)
+    x = torch.randn(n, 7, generator=g)
+    y = torch.randint(0, max(n_cls, 2), (n,), generator=g).clamp_max(n_cls - 1)
+    idx = torch.arange(0, n, 3)
+    res = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("ACM_NEXT_PROJ", mode)
+        clear_cache()
+        torch.manual_seed(4)
+        model = GCN(7, hidden, n_cls, 2, n, p_drop, "acmgcnp", 0, variant=False, attn_layernorm=True)
+        params = {k: v.detach().cpu().clone().requires_grad_(True) for k, v in model.named_parameters()}
+        model = model.to(DEV)
+        masks = None
+        if p_drop:
+            model.fused_dropout, model.dropout_state = True, AF.DropoutState(DEV, seed=7)
+            model.dropout_state.step.fill_(2)
+            st = model.dropout_state
+            masks = {"x": _philox_mask(st, p_drop, 0, n, 7), "hidden": _philox_mask(st, p_drop, 1, n, hidden)}
+        model.train()
+        timer = AF.KernelTimer()
+        AF.set_kernel_timer(timer)
+        out = model(x.to(DEV), low.to(DEV), high.to(DEV), None)
+        AF.set_kernel_timer(None)
+        labels = {k.split("/")[0] for k in timer.events}
+        assert "conv_agg_fwd" in labels
+        assert ("proj_fwd" not in labels) == (mode == "1" and n_cls <= 2), labels
+        loss = torch.nn.functional.nll_loss(torch.log_softmax(out, 1)[idx.to(DEV)], y.to(DEV)[idx.to(DEV)])
+        loss.backward()
+        res[mode] = (out.detach().cpu(), {k: p.grad.cpu() for k, p in model.named_parameters() if p.grad is not None})
+    ref = O.gcn_forward(params, x, low, high, None, model_type="acmgcnp", variant=False, structure_info=0,
+                        attn_layernorm=True, dropout=p_drop, training=True, masks=masks)
+    O.nll_loss_on(ref, y, idx).backward()
+    scale = max(1.0, float(ref.abs().max()))
+    for mode in ("1", "0"):
+        out, grads = res[mode]
+        assert float((out - ref.detach()).abs().max()) < 3e-5 * scale, mode
+        for k, gq in grads.items():
+            rg = params[k].grad
+            assert float((gq - rg).abs().max()) < 1e-4 * max(1.0, float(rg.abs().max())), (mode, k)
+    assert float((res["1"][0] - res["0"][0]).abs().max()) < 1e-5 * scale

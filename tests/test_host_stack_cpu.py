@@ -603,3 +603,45 @@ def test_bf16_gather_option_host_path(monkeypatch):
     assert 0 < err < 2e-2 * max(1.0, outs["fp32"].abs().max().item())
     with pytest.raises(ValueError):
         GraphConvolution(20, 64, n, "acmgcn", gather_dtype="fp8")._config()
+
+
+@pytest.mark.parametrize("fused_dropout", [False, True])
+@pytest.mark.parametrize("n_cls", [1, 2, 3])
+def test_next_layer_projection_rides_the_hidden_layers_epilogue(n_cls, fused_dropout, monkeypatch):
+    """models.GCN names the output layer while it calls the hidden one; an aggregate-first hidden layer then carries the
+    output layer's narrow projection (acm_conv_agg_fwd_t.next_*) and the output layer does not launch acm_proj_fwd --
+    for F' <= 2 only, and with results and gradients equal to the separate launch."""
+    fake = fake_lib.install(monkeypatch)
+    from acm_gnn_amd import GCN, functional as AF
+    low, high, un, _ = graph_tensors("geometric")
+    n = low.shape[0]
+    calls = []
+    for name in ("acm_proj_fwd", "acm_conv_agg_fwd"):
+        orig = getattr(fake, name)
+        monkeypatch.setattr(fake, name, (lambda o, nm: lambda *a: (calls.append(nm), o(*a))[1])(orig, name))
+    x = torch.randn(n, 7, generator=torch.Generator().manual_seed(1))
+
+    def run(env):
+        monkeypatch.setenv("ACM_NEXT_PROJ", env)
+        calls.clear()
+        torch.manual_seed(5)
+        model = GCN(7, 64, n_cls, 2, n, 0.3, "acmgcnp", 0, variant=0, attn_layernorm=True)
+        model.fused_dropout = fused_dropout
+        model.train()
+        if fused_dropout:
+            model.dropout_state = AF.DropoutState(torch.device("cpu"), seed=9)
+        else:
+            torch.manual_seed(11)                          # the F.dropout masks
+        out = model(x, low, high)
+        out.square().sum().backward()
+        assert AF._NEXT_PROJ is None and AF._PRE_PROJ is None
+        return out.detach(), {k: p.grad.clone() for k, p in model.named_parameters() if p.grad is not None}, list(calls)
+
+    out_f, g_f, calls_f = run("1")
+    out_s, g_s, calls_s = run("0")
+    assert "acm_proj_fwd" in calls_s
+    assert ("acm_proj_fwd" not in calls_f) == (n_cls <= 2)
+    np.testing.assert_allclose(out_f.numpy(), out_s.numpy(), rtol=1e-5, atol=1e-5 * max(1.0, float(out_s.abs().max())))
+    for k in g_s:
+        np.testing.assert_allclose(g_f[k].numpy(), g_s[k].numpy(), err_msg=k, rtol=1e-4,
+                                   atol=5e-5 * max(1.0, float(g_s[k].abs().max())))
