@@ -339,8 +339,8 @@ __global__ __launch_bounds__(256) void agg_fused_kernel(acm_conv_agg_fwd_t p, Cs
 // gather once the rows hit in L1/L2 (scripts/probe_gather.py: 63 us with every row in L1).
 // Lane (e = gl >> 1, h = gl & 1) of the 16-lane group: neighbours k0 + e + 8 u (u = 0..3), columns 4 h .. 4 h + 3.
 // NEXT: the following layer's narrow projection rides the epilogue (acm_conv_agg_fwd_t.next_*).
-template <bool FULL, bool NEXT = false>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5))) void agg_fused_pair_kernel(acm_conv_agg_fwd_t p, CsrView csr) {
+template <bool FULL, bool NEXT>
+__device__ __forceinline__ void agg_fused_pair_body(const acm_conv_agg_fwd_t& p, const CsrView& csr) {
     constexpr int FP = 8, K = 3, GPB = 16, U = 4, STEP = 8 * U;
     static_assert(GPB == ACM_WINDOW, "one window of work items per workgroup round");
     __shared__ __attribute__((aligned(16))) float wlds[3 * FP * 64 + 3 * K * 64 + 16 * 2 * FP + (NEXT ? ACM_NEXT_LDS : 0)];
@@ -457,6 +457,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5))) void a
     }
 }
 
+
+template <bool FULL>
+__global__ __launch_bounds__(256) void agg_fused_pair_kernel(acm_conv_agg_fwd_t p, CsrView csr) {
+    agg_fused_pair_body<FULL, false>(p, csr);
+}
+// with the next layer's projection: the extra kernel arguments spill scalars; capped to the registers of five waves per SIMD
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5))) void agg_fused_pair_next_kernel(acm_conv_agg_fwd_t p, CsrView csr) {
+    agg_fused_pair_body<true, true>(p, csr);
+}
 
 // ---------------------------------------------------------------- streamed form (acm_csr_build_streams)
 // The same fused forward over per-wave id streams.  What the CSR form above spends per wave step -- four guarded id
@@ -898,7 +907,7 @@ extern "C" int acm_conv_agg_fwd(const acm_csr_t* a, const acm_conv_agg_fwd_t* p,
             } else {
                 const bool pair_lanes = getenv("ACM_AGG_NO_PAIR") == nullptr;
                 if (pair_lanes && full && p->next_f > 0 && getenv("ACM_AGG_NO_NEXT") == nullptr) {
-                    hipLaunchKernelGGL((agg_fused_pair_kernel<true, true>), dim3(grid), dim3(256), 0, s, *p, cv);
+                    hipLaunchKernelGGL(agg_fused_pair_next_kernel, dim3(grid), dim3(256), 0, s, *p, cv);
                     next_done = true;
                 } else if (pair_lanes && full)
                     hipLaunchKernelGGL((agg_fused_pair_kernel<true>), dim3(grid), dim3(256), 0, s, *p, cv);

@@ -183,7 +183,7 @@ def _next_proj_request(f, dev):
     """(weights, relu_before, F') of the layer named in _NEXT_PROJ when its projection can ride this layer's epilogue."""
     global _NEXT_PROJ
     nxt, _NEXT_PROJ = _NEXT_PROJ, None
-    if nxt is None or os.environ.get("ACM_NEXT_PROJ", "1") == "0":
+    if nxt is None or os.environ.get("ACM_NEXT_PROJ", "0") != "1":        # opt-in: measured neutral (DESIGN.md section 9a)
         return None
     try:
         w3 = (nxt.weight_low, nxt.weight_high, nxt.weight_mlp)
