@@ -371,12 +371,18 @@ extern "C" int acm_csr_build_streams(acm_csr_t* a, int n_waves, int lmax) {
         lr.slot_end = (int32_t)n_slots;
         longs.push_back(lr);
     }
-    std::stable_sort(items.begin(), items.end(), [](const Item& x, const Item& y) { return x.len > y.len; });
+    // ACM_STREAM_ORDER: "rows" keeps the items in row order and deals the slices round-robin (the walk of the CSR kernels:
+    // at any time the chip works on one window of neighbouring rows -- their outputs and row operands are neighbours in
+    // memory; on a degree-sorted graph the four rows of a slice still have similar lengths); "sorted" / default: by length
+    const char* order_env = getenv("ACM_STREAM_ORDER");
+    const bool row_order = order_env && strcmp(order_env, "rows") == 0;
+    if (!row_order) std::stable_sort(items.begin(), items.end(), [](const Item& x, const Item& y) { return x.len > y.len; });
     const int64_t n_items = (int64_t)items.size(), n_slices = (n_items + 3) / 4;
     std::vector<int32_t> sl_steps((size_t)n_slices);
     int64_t total_steps = 0;
     for (int64_t s = 0; s < n_slices; ++s) {
-        const int32_t longest = items[(size_t)s * 4].len;            // sorted: the first of the four
+        int32_t longest = 0;
+        for (int64_t i = s * 4; i < std::min(n_items, s * 4 + 4); ++i) longest = std::max(longest, items[(size_t)i].len);
         sl_steps[(size_t)s] = std::max(1, (longest + 31) / 32);
         total_steps += sl_steps[(size_t)s];
     }
@@ -404,6 +410,10 @@ extern "C" int acm_csr_build_streams(acm_csr_t* a, int n_waves, int lmax) {
         std::priority_queue<Load, std::vector<Load>, std::greater<Load>> heap;
         for (int32_t w = 0; w < n_waves; ++w) heap.push({0, w});
         for (int64_t s = 0; s < n_slices; ++s) {
+            if (row_order) {
+                wave_of[(size_t)s] = (int32_t)(s % n_waves);
+                continue;
+            }
             Load l = heap.top();
             heap.pop();
             wave_of[(size_t)s] = l.second;
@@ -422,7 +432,7 @@ extern "C" int acm_csr_build_streams(acm_csr_t* a, int n_waves, int lmax) {
     for (int64_t s = 0; s < n_slices; ++s) pos_of[(size_t)s] = cur[(size_t)wave_of[(size_t)s]]++;
     {
         const char* ord = getenv("ACM_STREAM_ORDER");
-        if (!(ord && strcmp(ord, "sorted") == 0)) {
+        if (!(ord && (strcmp(ord, "sorted") == 0 || strcmp(ord, "rows") == 0))) {
             std::vector<int32_t> slice_at((size_t)n_slices);
             for (int64_t s = 0; s < n_slices; ++s) slice_at[(size_t)pos_of[(size_t)s]] = (int32_t)s;
             for (int32_t w = 0; w < n_waves; ++w) {
