@@ -47,11 +47,11 @@ def _prepare(cfg, world):
     return adj, x_np, y_np, tr, low, deg, plan
 
 
-def _build(cfg, n_local, n, dev):
+def _build(cfg, n_local, n, dev, f_in=7, n_cls=2):
     from acm_gnn_amd import GCN, functional as AF
     torch.manual_seed(0)
-    full = GCN(7, 64, 2, 2, n, cfg["dropout"], cfg["model"], cfg["s"], variant=bool(cfg["variant"]), attn_layernorm=True)
-    model = GCN(7, 64, 2, 2, n_local, cfg["dropout"], cfg["model"], cfg["s"], variant=bool(cfg["variant"]),
+    full = GCN(f_in, 64, n_cls, 2, n, cfg["dropout"], cfg["model"], cfg["s"], variant=bool(cfg["variant"]), attn_layernorm=True)
+    model = GCN(f_in, 64, n_cls, 2, n_local, cfg["dropout"], cfg["model"], cfg["s"], variant=bool(cfg["variant"]),
                 attn_layernorm=True)
     return full, model
 
@@ -67,8 +67,9 @@ def _worker(rank, world, port, cfg, ret):
         n = adj.shape[0]
         ops = DD.make_sharded_operators(low, deg, DEV, with_structure=bool(cfg["s"]), plan=plan)
         assert ops.sharded and ops.uniform == (cfg.get("plan") != "work")
+        ops.hops = cfg.get("hops", 1)
         b, e = plan.rows(rank)
-        full, model = _build(cfg, e - b, n, DEV)
+        full, model = _build(cfg, e - b, n, DEV, x_np.shape[1], int(y_np.max()) + 1)
         sd = full.state_dict()
         for k in list(sd):
             if k.endswith(".struc_low"):
@@ -98,9 +99,10 @@ def _worker(rank, world, port, cfg, ret):
                                  dict(model="acmgcnp", s=0, variant=0, dropout=0.3, plan="work"),
                                  dict(model="acmgcnpp", s=0, variant=0, dropout=0.3),
                                  dict(model="acmgcnp", s=0, variant=0, dropout=0.1, dataset="twitch-gamer", plan="interleave"),
-                                 dict(model="acmgcnp", s=0, variant=0, dropout=0.1, dataset="twitch-gamer", plan="work")],
+                                 dict(model="acmgcnp", s=0, variant=0, dropout=0.1, dataset="twitch-gamer", plan="work"),
+                                 dict(model="acmsgc", s=0, variant=0, dropout=0.0, dataset="arxiv-year", plan="work", hops=3)],
                          ids=["agg", "struct-dropout", "acmii", "work-plan-struct-acmii", "work-plan-agg", "acmgcnpp",
-                              "twitch-degree-interleaved", "twitch-random-work-plan"])
+                              "twitch-degree-interleaved", "twitch-random-work-plan", "arxiv-year-3hop-sgc-work-plan"])
 def test_two_ranks_on_one_gpu_equal_single_process(cfg):
     import queue
     import time
@@ -132,7 +134,8 @@ def test_two_ranks_on_one_gpu_equal_single_process(cfg):
         _, nnz_r, work_r = plan.work(low.indptr, DD.DEFAULT_ROW_COST)
         assert work_r.max() / work_r.mean() < 1.05 and nnz_r.max() / nnz_r.mean() < (1.05 if cfg["plan"] == "interleave" else 1.6)
     ops = DD.make_sharded_operators(low, deg, DEV, with_structure=bool(cfg["s"]))
-    full, _ = _build(cfg, n, n, DEV)
+    ops.hops = cfg.get("hops", 1)
+    full, _ = _build(cfg, n, n, DEV, x_np.shape[1], int(y_np.max()) + 1)
     full = full.to(DEV)
     if cfg["dropout"]:
         full.fused_dropout, full.dropout_state = True, AF.DropoutState(DEV, seed=7)
