@@ -1174,8 +1174,23 @@ __device__ __forceinline__ void bwd_local_block_reduce(ParamAcc<L>& pa, const L&
     constexpr int k = K;
     const int npg = 3 * k * F + k * k;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    // combine the RPW row-groups of this wave (layout B only)
-    if (RPW > 1) {
+    // combine the RPW row-groups of this wave.  One row per lane (RPW = 64: the thread-per-row kernels of the narrow
+    // layers) sums all 64 lanes with the DPP / permlane tree of acm_group_sum -- the xor butterfly below lowers to one
+    // ds_bpermute + s_waitcnt per step, 6 steps x (12 NV + 16) values per block: it was most of the fused output-layer
+    // tail's 18 us
+    if (RPW == 64) {
+#pragma unroll
+        for (int c = 0; c < k; ++c)
+#pragma unroll
+            for (int i = 0; i < L::NV; ++i) {
+                pa.dv[c][i] = acm_group_sum<64>(pa.dv[c][i]);
+                pa.dgam[c][i] = acm_group_sum<64>(pa.dgam[c][i]);
+                pa.dbet[c][i] = acm_group_sum<64>(pa.dbet[c][i]);
+            }
+#pragma unroll
+        for (int q = 0; q < 16; ++q)
+            if ((q >> 2) < k && (q & 3) < k) pa.dmix[q] = acm_group_sum<64>(pa.dmix[q]);
+    } else if (RPW > 1) {
 #pragma unroll
         for (int c = 0; c < 4; ++c)
 #pragma unroll
