@@ -885,6 +885,9 @@ extern "C" int acm_conv_agg_fwd(const acm_csr_t* a, const acm_conv_agg_fwd_t* p,
                 sv.n_waves = t->n_waves;
                 sv.probe = getenv("ACM_STREAM_PROBE") ? atoi(getenv("ACM_STREAM_PROBE")) : 0;
                 const int grid = t->n_waves / 4;
+                // the arrival counters reset themselves (the last piece of a row stores 0), but a launch that died half-way
+                // would leave them poisoned for every later one: clear them ahead of the kernel
+                if (t->n_long) ACM_CHECK_HIP(hipMemsetAsync(t->counters, 0, (size_t)t->n_long * sizeof(int32_t), s));
                 const bool nt = getenv("ACM_AGG_NT") != nullptr;
                 if (p->f_out == 64 && nt)
                     hipLaunchKernelGGL((agg_stream_kernel<true, true>), dim3(grid), dim3(256), 0, s, *p, sv, (unsigned)table_bytes);

@@ -124,8 +124,8 @@ int acm_csr_info(const acm_csr_t* a, acm_csr_info_t* info);
  * the partial sums in slot order and finishes the row, so results do not depend on the arrival order.
  * One-off host-side preprocessing like acm_csr_create (synchronises the device; must not be called while a stream is
  * capturing); idempotent.  n_waves <= 0: five waves per SIMD of the current device (env ACM_STREAM_WAVES overrides);
- * lmax <= 0: 512 (env ACM_STREAM_LMAX).  The handle owns the arrival counters and partial slots, so launches that use the
- * streams of one handle must be stream-ordered.  Costs (total steps x 512 B) of device memory, ~1.2 x the id array.
+ * lmax <= 0: 512 (env ACM_STREAM_LMAX).  The handle owns the arrival counters (cleared ahead of every launch) and partial
+ * slots, so launches that use the streams of one handle must be stream-ordered.  Costs (total steps x 512 B) of device memory, ~1.2 x the id array.
  * No reference counterpart (the reference hands torch.spmm a COO tensor, ACM-Geometric/layers.py:87-103). */
 int acm_csr_build_streams(acm_csr_t* a, int n_waves, int lmax);
 
