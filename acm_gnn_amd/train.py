@@ -190,6 +190,58 @@ def evaluate(model, x, adj, labels, index_sets, adj_high=None, adj_un=None):
     return out, accs
 
 
+class EvalStep:
+    """The per-epoch evaluation pass of the reference's loops (ACM-Geometric/train.py:138-140 + data_utils.py:153-168,
+    ACM-Pytorch/train.py:129-139): eval-mode logits, the accuracy on every index set and the NLL on one of them
+    (``loss_set``: the validation set).  Everything stays on the device -- the index sets become [k, n] averaging
+    weights, accuracies and loss land in one small tensor -- so a call costs ONE device-to-host copy, and with
+    ``use_graph`` the whole pass (the library's forward kernels + a handful of torch reductions) is a hipGraph replay.
+    Returns (logits, [accuracy per index set], loss on ``loss_set``)."""
+
+    def __init__(self, model, x, adj, labels, index_sets, adj_high=None, adj_un=None, loss_set=1, use_graph=False):
+        self.model, self.x, self.adj, self.adj_high, self.adj_un = model, x, adj, adj_high, adj_un
+        self.labels = labels
+        n, dev = labels.shape[0], labels.device
+        w = torch.zeros(len(index_sets), n, dtype=torch.float32, device=dev)
+        for k, idx in enumerate(index_sets):
+            idx = torch.as_tensor(idx, device=dev).long()
+            w[k].index_fill_(0, idx, 1.0 / max(int(idx.numel()), 1))
+        self.w, self.loss_set = w, int(loss_set)
+        self.graph, self.out, self.res = None, None, None
+        if use_graph:
+            self._capture()
+
+    @torch.no_grad()
+    def _run(self):
+        self.model.eval()
+        out = self.model(self.x, self.adj, self.adj_high, self.adj_un)
+        correct = (out.argmax(dim=1) == self.labels).to(torch.float32)
+        nll = -F.log_softmax(out, 1).gather(1, self.labels.view(-1, 1)).view(-1)
+        res = torch.cat([self.w @ correct, (self.w[self.loss_set] * nll).sum().view(1)])
+        return out, res
+
+    def _capture(self):
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):           # warm-up off the capture (lazy handles, allocator pools)
+            for _ in range(2):
+                self._run()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self.out, self.res = self._run()
+
+    def __call__(self):
+        if self.graph is not None:
+            self.graph.replay()
+            out, res = self.out, self.res
+        else:
+            out, res = self._run()
+        vals = res.tolist()                     # the one synchronising copy of the pass
+        return out, vals[:-1], vals[-1]
+
+
 def fit(model, optimizer, x, adj, labels, train_idx, val_idx, test_idx, epochs, rule="max_val_acc",
         early_stopping=0, adj_high=None, adj_un=None, use_graph=False, fused_dropout=None):
     """Train and return (selected test accuracy, per-epoch history).
@@ -205,11 +257,17 @@ def fit(model, optimizer, x, adj, labels, train_idx, val_idx, test_idx, epochs, 
                      fused_dropout=fused_dropout)
     best_key, selected, history = None, 0.0, []
     val_hist = []
+    # the evaluation pass of every epoch: its own captured graph when the training step is one
+    ev = EvalStep(model, x, adj, labels, (train_idx, val_idx, test_idx), adj_high, adj_un, loss_set=1,
+                  use_graph=use_graph) if use_graph else None
     for epoch in range(epochs):
         loss = step()
-        out, (acc_tr, acc_va, acc_te) = evaluate(model, x, adj, labels, (train_idx, val_idx, test_idx),
-                                                 adj_high, adj_un)
-        val_loss = float(F.nll_loss(F.log_softmax(out, 1)[val_idx], labels[val_idx]))
+        if ev is not None:
+            out, (acc_tr, acc_va, acc_te), val_loss = ev()
+        else:
+            out, (acc_tr, acc_va, acc_te) = evaluate(model, x, adj, labels, (train_idx, val_idx, test_idx),
+                                                     adj_high, adj_un)
+            val_loss = float(F.nll_loss(F.log_softmax(out, 1)[val_idx], labels[val_idx]))
         history.append((float(loss), acc_tr, acc_va, acc_te, val_loss))
         key = acc_va if rule == "max_val_acc" else -val_loss
         if best_key is None or key > best_key:

@@ -313,7 +313,7 @@ def main():
     extras = {}
     if world == 1 and use_graph and graph_ok and not args.no_extras:
         try:
-            extras = side_measurements(args, timed_graph_steps, model, opt, x, ops, y, w, fused_drop, dev)
+            extras = side_measurements(args, timed_graph_steps, model, opt, x, ops, y, w, fused_drop, dev, (tr, va, te))
         except Exception as exc:
             extras = {"extras_error": repr(exc)}
 
@@ -328,7 +328,7 @@ def main():
         sys.exit(1)
 
 
-def side_measurements(args, timed_graph_steps, model, opt, x, ops, y, w, fused_drop, dev):
+def side_measurements(args, timed_graph_steps, model, opt, x, ops, y, w, fused_drop, dev, splits=None):
     """{literal_ms_per_step, random_order_ms_per_step, ...}: hipGraph replays of the same training step (a) with the
     aggregate-first rewrite switched off (ACM_AGG_FIRST=0: project, then gather the 2F-wide rows, as the reference's op
     order does), (b) on the same graph with the generator's random node ids instead of the degree relabelling."""
@@ -336,6 +336,20 @@ def side_measurements(args, timed_graph_steps, model, opt, x, ops, y, w, fused_d
     import acm_gnn_amd
     from acm_gnn_amd import data as D, distributed as DD, train as T
     out = {}
+    if splits is not None:
+        # an EPOCH of the reference's loops = the training step + the evaluation pass (eval-mode forward, accuracy on the
+        # three index sets, validation NLL, one host copy: ACM-Geometric/train.py:119-140) -- the unit of the paper's
+        # ms/epoch tables; both halves as hipGraph replays
+        ev = T.EvalStep(model, x, ops, y, tuple(torch.from_numpy(np.asarray(s_)).to(dev) for s_ in splits), loss_set=1,
+                        use_graph=True)
+        gstep = T.TrainStep(model, opt, x, ops, y, w, use_graph=True, fused_dropout=fused_drop)
+
+        def epoch():
+            loss = gstep()
+            ev()
+            return loss
+        ms, _ = timed_graph_steps(epoch)
+        out["train_plus_eval_ms_per_epoch"] = round(ms, 4)
     if not args.variant and os.environ.get("ACM_AGG_FIRST", "1") != "0":
         os.environ["ACM_AGG_FIRST"] = "0"
         try:

@@ -130,3 +130,36 @@ def test_graph_replayed_step_equals_eager(fused):
 
 
 _LOSSES = {}
+
+
+def test_captured_eval_step_and_fit_with_graphs():
+    """train.EvalStep as a hipGraph replay equals the eager evaluation, and fit(use_graph=True) -- captured training step
+    + captured evaluation pass per epoch -- reproduces the history of the eager loop (same fused dropout, same optimizer)."""
+    import acm_gnn_amd
+    from acm_gnn_amd import data as D, distributed as DD, train as T
+    from acm_gnn_amd.graph import clear_cache
+    clear_cache()
+    adj, x_np, y_np, (tr, va, te), n = D.synthetic_dataset("tiny", seed=3)
+    low, deg = D.build_filters(adj)
+    ops = DD.make_sharded_operators(low, deg, DEV)
+    x, y = torch.from_numpy(x_np).to(DEV), torch.from_numpy(y_np).to(DEV)
+    sets = tuple(torch.from_numpy(s).to(DEV) for s in (tr, va, te))
+    n_cls = int(y_np.max()) + 1
+    hist = {}
+    for use_graph in (False, True):
+        torch.manual_seed(1)
+        model = acm_gnn_amd.GCN(x.shape[1], 64, n_cls, 2, n, 0.3, "acmgcnp", 0, variant=False).to(DEV)
+        opt = acm_gnn_amd.FusedAdamW(model.parameters(), lr=0.02, weight_decay=1e-3)
+        if use_graph:
+            ev = T.EvalStep(model, x, ops, y, sets, loss_set=1, use_graph=True)
+            ev_eager = T.EvalStep(model, x, ops, y, sets, loss_set=1)
+            (o1, a1, l1), (o2, a2, l2) = ev(), ev_eager()
+            assert torch.equal(o1, o2) and a1 == a2 and l1 == l2
+        acc, h = T.fit(model, opt, x, ops, y, *sets, epochs=8, rule="min_val_loss", early_stopping=0,
+                       use_graph=use_graph, fused_dropout=True)
+        hist[use_graph] = (acc, h)
+    (acc_e, h_e), (acc_g, h_g) = hist[False], hist[True]
+    assert len(h_e) == len(h_g) == 8
+    for e, g in zip(h_e, h_g):
+        np.testing.assert_allclose(g, e, rtol=2e-4, atol=2e-5)
+    assert abs(acc_e - acc_g) < 1e-6

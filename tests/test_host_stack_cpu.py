@@ -645,3 +645,26 @@ def test_next_layer_projection_rides_the_hidden_layers_epilogue(n_cls, fused_dro
     for k in g_s:
         np.testing.assert_allclose(g_f[k].numpy(), g_s[k].numpy(), err_msg=k, rtol=1e-4,
                                    atol=5e-5 * max(1.0, float(g_s[k].abs().max())))
+
+
+def test_eval_step_equals_evaluate(monkeypatch):
+    """train.EvalStep (accuracies and validation NLL reduced on the device, one host copy) against train.evaluate +
+    F.nll_loss, the code path fit() uses without a captured graph."""
+    fake_lib.install(monkeypatch)
+    from acm_gnn_amd import GCN, train as T
+    low, high, un, _ = graph_tensors("geometric")
+    n = low.shape[0]
+    torch.manual_seed(3)
+    x = torch.randn(n, 7)
+    y = torch.randint(0, 3, (n,))
+    perm = torch.randperm(n)
+    sets = (perm[:40], perm[40:70], perm[70:])
+    model = GCN(7, 16, 3, 2, n, 0.5, "acmgcnp", 0, variant=False)
+    ev = T.EvalStep(model, x, low, y, sets, adj_high=high, loss_set=1)
+    out, accs, val_loss = ev()
+    ref_out, ref_accs = T.evaluate(model, x, low, y, sets, adj_high=high)
+    assert torch.equal(out, ref_out)
+    np.testing.assert_allclose(accs, ref_accs, rtol=1e-5, atol=1e-6)
+    ref_loss = float(F.nll_loss(F.log_softmax(ref_out, 1)[sets[1]], y[sets[1]]))
+    assert abs(val_loss - ref_loss) < 1e-5 * max(1.0, abs(ref_loss))
+    assert not model.training
