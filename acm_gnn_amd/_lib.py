@@ -113,7 +113,8 @@ class ConvAggFwd(C.Structure):
                 ("head_stats", C.c_void_p), ("ld_head_stats", C.c_int64),
                 ("next_w_low", C.c_void_p), ("next_w_high", C.c_void_p), ("next_w_mlp", C.c_void_p), ("next_ld_w", C.c_int64),
                 ("next_f", C.c_int32), ("next_relu", C.c_int32),
-                ("next_zlh", C.c_void_p), ("ld_next_zlh", C.c_int64), ("next_zi", C.c_void_p), ("ld_next_zi", C.c_int64)]
+                ("next_zlh", C.c_void_p), ("ld_next_zlh", C.c_int64), ("next_zi", C.c_void_p), ("ld_next_zi", C.c_int64),
+                ("agg_given", C.c_int32), ("reserved", C.c_int32)]
 
 
 class ConvAggBwd(C.Structure):

@@ -841,8 +841,8 @@ extern "C" int acm_conv_agg_fwd(const acm_csr_t* a, const acm_conv_agg_fwd_t* p,
     ACM_REQUIRE(a && p, ACM_EINVAL, "acm_conv_agg_fwd: NULL argument");
     int st = check_common(p, "acm_conv_agg_fwd");
     if (st != ACM_OK) return st;
-    ACM_REQUIRE(p->xg && p->out && p->agg && p->att, ACM_EINVAL, "acm_conv_agg_fwd: NULL tensor pointer");
-    ACM_REQUIRE(((uintptr_t)p->xg) % 16 == 0 && (p->ld_xg * 4) % 16 == 0 && p->ld_xg >= p->f_pad &&
+    ACM_REQUIRE((p->xg || p->agg_given) && p->out && p->agg && p->att, ACM_EINVAL, "acm_conv_agg_fwd: NULL tensor pointer");
+    ACM_REQUIRE((p->agg_given || (((uintptr_t)p->xg) % 16 == 0 && (p->ld_xg * 4) % 16 == 0 && p->ld_xg >= p->f_pad)) &&
                     ((uintptr_t)p->agg) % 16 == 0 && (p->ld_agg * 4) % 16 == 0 && p->ld_agg >= p->f_pad &&
                     ((uintptr_t)p->att) % 16 == 0, ACM_EINVAL,
                 "acm_conv_agg_fwd: xg / agg rows must be 16-byte aligned and f_pad long");
@@ -860,8 +860,9 @@ extern "C" int acm_conv_agg_fwd(const acm_csr_t* a, const acm_conv_agg_fwd_t* p,
     if (a->n_rows == 0) return ACM_OK;
     hipStream_t s = (hipStream_t)stream;
     bool next_done = false;
+    ACM_REQUIRE(!p->agg_given || p->n_channels == 3, ACM_EUNSUPPORTED, "acm_conv_agg_fwd: agg_given needs three channels");
     // (0) fused form: gather + epilogue in one kernel (long rows included)
-    {
+    if (!p->agg_given) {
         const double avg = (double)a->nnz / (double)(a->n_rows > 0 ? a->n_rows : 1);
         const bool fused_off = getenv("ACM_AGG_UNFUSED") != nullptr;      // read per call: tests switch forms
         const bool fused = !fused_off && p->n_channels == 3 && p->f_pad <= 8 && avg > 12.0 && avg <= 160.0 &&
@@ -929,9 +930,11 @@ extern "C" int acm_conv_agg_fwd(const acm_csr_t* a, const acm_conv_agg_fwd_t* p,
     acm_spmm_opts_t o = {nullptr, p->row_scale, nullptr, 0, nullptr, 0, 0};
     // three channels: the long rows' partial sums stay in the workspace and the epilogue kernel adds them (one launch
     // less); with the structure channel the second gather reuses the workspace, so the fix-up runs right away
-    bool defer = p->n_channels == 3 && a->n_long > 0 && a->long_index != nullptr;
-    st = acm_spmm_internal(a, p->xg, p->ld_xg, p->f_pad, p->agg, p->ld_agg, &o, workspace, workspace_bytes, stream, &defer);
-    if (st != ACM_OK) return st;
+    bool defer = !p->agg_given && p->n_channels == 3 && a->n_long > 0 && a->long_index != nullptr;
+    if (!p->agg_given) {
+        st = acm_spmm_internal(a, p->xg, p->ld_xg, p->f_pad, p->agg, p->ld_agg, &o, workspace, workspace_bytes, stream, &defer);
+        if (st != ACM_OK) return st;
+    }
     // (1b) structure channel: PS = A_low S -> p->ps (F wide; bf16 operand optional)
     if (p->n_channels == 4) {
         ACM_REQUIRE(p->sg, ACM_EINVAL, "acm_conv_agg_fwd: sg is NULL");

@@ -177,6 +177,10 @@ _TAIL_LAYER = False     # set by layers.GraphConvolution.forward around the call
 # takes them instead of launching acm_proj_fwd -- provided it is handed exactly that output tensor and those weights.
 _NEXT_PROJ = None
 _PRE_PROJ = None
+# Evaluation passes over a static feature matrix: layers.GraphConvolution hands a holder {"agg": tensor-or-None} around an
+# eval-mode, no-grad call; an aggregate-first forward then reuses P = A_low X from the holder (acm_conv_agg_fwd_t.agg_given:
+# the gather is skipped) or leaves the P it computed there for the next pass.  The layer decides when the holder is valid.
+_AGG_CACHE = None
 
 
 def _next_proj_request(f, dev):
@@ -818,7 +822,16 @@ class AcmConvFunction(torch.autograd.Function):
                 xpad = x
             else:
                 xpad = torch.nn.functional.pad(x[:, :f_in], (0, fp - f_in))
-            if (pregathered is not None and pregathered[0].data_ptr() == xpad.data_ptr()
+            global _AGG_CACHE
+            agg_holder, _AGG_CACHE = _AGG_CACHE, None
+            if agg_holder is not None and (k != 3 or ops.sharded or torch.is_grad_enabled()):       # no backward follows
+                agg_holder = None
+            agg_given = agg_holder.get("agg") if agg_holder is not None else None
+            if agg_given is not None and tuple(agg_given.shape) != (n, fp):
+                agg_given = None
+            if agg_given is not None:
+                xg = xpad                             # not read: P = A_low X comes from the holder
+            elif (pregathered is not None and pregathered[0].data_ptr() == xpad.data_ptr()
                     and pregathered[1].shape[1] == fp and pregathered[1].shape[0] == ops.n_gathered):
                 xg = pregathered[1]                   # the caller already holds every node's (dropped) input
             else:
@@ -937,7 +950,8 @@ class AcmConvFunction(torch.autograd.Function):
             p.w_low, p.w_high, p.w_mlp, p.ld_w = wl.data_ptr(), wh.data_ptr(), wm.data_ptr(), f
             p.att_vec, p.ln_weight, p.ln_bias = _ptr_array(vecs), _ptr_array(lnw), _ptr_array(lnb)
             p.att_mix = mix.data_ptr()
-            agg = torch.empty(n, fp, dtype=_F32, device=dev)
+            agg = agg_given if agg_given is not None else torch.empty(n, fp, dtype=_F32, device=dev)
+            p.agg_given = int(agg_given is not None)
             p.out, p.ld_out = out.data_ptr(), out.stride(0)
             p.agg, p.ld_agg = agg.data_ptr(), agg.stride(0)
             p.att = att.data_ptr()
@@ -980,6 +994,8 @@ class AcmConvFunction(torch.autograd.Function):
             with _device_ctx(dev), _Timed(f"conv_agg_fwd/F{f}k{k}i{f_in}"):
                 st = lib.acm_conv_agg_fwd(ops.low.handle, C.byref(p), _vp(ws), ws.numel() * 4, _stream())
             _lib.check(st, "acm_conv_agg_fwd")
+            if agg_holder is not None and agg_given is None:
+                agg_holder["agg"] = agg
             if nxt is not None:
                 global _PRE_PROJ
                 _PRE_PROJ = (out, n_zlh, n_zi, tuple(w.data_ptr() for w in n_w3), n_relu)

@@ -501,6 +501,10 @@ typedef struct {
     int32_t next_f, next_relu;
     float* next_zlh; int64_t ld_next_zlh;
     float* next_zi;  int64_t ld_next_zi;
+    /* agg_given != 0 (three channels only): `agg` already holds A_low * xg -- an earlier call of this operator on the same
+     * input wrote it (e.g. every evaluation pass over a static feature matrix after the first) -- so the gather is
+     * skipped and only the row-local stage runs; xg is not read.                                                     */
+    int32_t agg_given, reserved;
 } acm_conv_agg_fwd_t;
 
 int acm_conv_agg_fwd(const acm_csr_t* a_low, const acm_conv_agg_fwd_t* p,

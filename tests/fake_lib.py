@@ -646,7 +646,10 @@ class FakeLib:
         n, k = a.n_rows, p.n_channels
         F, fi, fp, x, W = self._agg_common(p, n)
         rs = _vec(p.row_scale, n).astype(np.float64)[:, None] if p.row_scale else 1.0
-        P = (rs * a.dense_mul(_view(p.xg, a.n_cols, fp, p.ld_xg)))[:, :fi]
+        if p.agg_given:                                    # P = A_low X from an earlier call
+            P = _view(p.agg, n, fp, p.ld_agg).astype(np.float64)[:, :fi].copy()
+        else:
+            P = (rs * a.dense_mul(_view(p.xg, a.n_cols, fp, p.ld_xg)))[:, :fi]
         raw = [P @ W[0], (x - P) @ W[1], x @ W[2]]
         relu = [p.relu_after, p.relu_after, p.relu_mlp]
         if k == 4:

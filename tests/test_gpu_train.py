@@ -163,3 +163,44 @@ def test_captured_eval_step_and_fit_with_graphs():
     for e, g in zip(h_e, h_g):
         np.testing.assert_allclose(g, e, rtol=2e-4, atol=2e-5)
     assert abs(acc_e - acc_g) < 1e-6
+
+
+def test_eval_passes_reuse_the_aggregated_input_on_the_gpu(monkeypatch):
+    """acm_conv_agg_fwd_t.agg_given: the second evaluation pass over the same input skips the gather and returns the very
+    same logits (the row-local stage reads the P the first pass stored); an in-place edit of the input takes the gather
+    again; the captured EvalStep holds the shortened pass."""
+    import acm_gnn_amd
+    from acm_gnn_amd import data as D, distributed as DD, functional as AF, train as T
+    from acm_gnn_amd.graph import clear_cache
+    clear_cache()
+    adj, x_np, y_np, (tr, va, te), n = D.synthetic_dataset("tiny", seed=4)
+    low, deg = D.build_filters(adj)
+    ops = DD.make_sharded_operators(low, deg, DEV)
+    x, y = torch.from_numpy(x_np).to(DEV), torch.from_numpy(y_np).to(DEV)
+    torch.manual_seed(2)
+    model = acm_gnn_amd.GCN(x.shape[1], 64, int(y_np.max()) + 1, 2, n, 0.3, "acmgcnp", 0, variant=False).to(DEV)
+    model.eval()
+    calls = []
+    orig = AF._gather_rows
+    monkeypatch.setattr(AF, "_gather_rows", lambda o, t: (calls.append(tuple(t.shape)), orig(o, t))[1])
+    with torch.no_grad():
+        o1 = model(x, ops)
+        n1 = len(calls)
+        o2 = model(x, ops)
+        assert torch.equal(o1, o2)
+        assert len(calls) - n1 < n1                     # the layer-1 gather of the input is gone
+        monkeypatch.setenv("ACM_EVAL_AGG_CACHE", "0")
+        o0 = model(x, ops)
+        assert torch.equal(o0, o1)                      # identical to the pass that gathers
+        monkeypatch.delenv("ACM_EVAL_AGG_CACHE")
+        x.add_(0.25)
+        o3 = model(x, ops)
+        assert not torch.equal(o3, o1)
+        monkeypatch.setenv("ACM_EVAL_AGG_CACHE", "0")
+        assert torch.equal(model(x, ops), o3)
+    sets = tuple(torch.from_numpy(s).to(DEV) for s in (tr, va, te))
+    monkeypatch.delenv("ACM_EVAL_AGG_CACHE")
+    ev_g = T.EvalStep(model, x, ops, y, sets, use_graph=True)
+    ev_e = T.EvalStep(model, x, ops, y, sets)
+    (og, ag, lg), (oe, ae, le) = ev_g(), ev_e()
+    assert torch.equal(og, oe) and ag == ae and lg == le

@@ -663,8 +663,45 @@ def test_eval_step_equals_evaluate(monkeypatch):
     ev = T.EvalStep(model, x, low, y, sets, adj_high=high, loss_set=1)
     out, accs, val_loss = ev()
     ref_out, ref_accs = T.evaluate(model, x, low, y, sets, adj_high=high)
-    assert torch.equal(out, ref_out)
+    # (the second pass reuses P = A_low X of the first: the numpy double computes it in float64 the first time)
+    np.testing.assert_allclose(out.numpy(), ref_out.numpy(), rtol=1e-5, atol=1e-6)
     np.testing.assert_allclose(accs, ref_accs, rtol=1e-5, atol=1e-6)
     ref_loss = float(F.nll_loss(F.log_softmax(ref_out, 1)[sets[1]], y[sets[1]]))
     assert abs(val_loss - ref_loss) < 1e-5 * max(1.0, abs(ref_loss))
     assert not model.training
+
+
+def test_eval_passes_reuse_the_aggregated_input(monkeypatch):
+    """An eval-mode, no-grad pass over the same unmodified input reuses P = A_low X of the previous pass
+    (acm_conv_agg_fwd_t.agg_given): no gather the second time, same logits; an in-place edit of the input or a
+    training-mode call takes the gather again."""
+    fake = fake_lib.install(monkeypatch)
+    from acm_gnn_amd import GCN, functional as AF
+    low, high, un, _ = graph_tensors("geometric")
+    n = low.shape[0]
+    given = []
+    orig = fake.acm_conv_agg_fwd
+    monkeypatch.setattr(fake, "acm_conv_agg_fwd", lambda h, pp, *a: (given.append(int(pp._obj.agg_given)), orig(h, pp, *a))[1])
+    torch.manual_seed(2)
+    model = GCN(7, 64, 2, 2, n, 0.4, "acmgcnp", 0, variant=False)
+    x = torch.randn(n, 7)
+    model.eval()
+    with torch.no_grad():
+        o1 = model(x, low, high)
+        o2 = model(x, low, high)
+        assert given == [0, 1] and torch.allclose(o1, o2, rtol=1e-5, atol=1e-6)
+        x.mul_(1.5)                                    # in-place edit: the version counter moves
+        o3 = model(x, low, high)
+        assert given == [0, 1, 0] and not torch.equal(o1, o3)
+        o4 = model(x.clone(), low, high)               # another tensor
+        assert given[-1] == 0 and torch.allclose(o3, o4, rtol=1e-5, atol=1e-6)
+    model(x, low, high)                                # autograd on: never from the cache
+    model.train()
+    with torch.no_grad():
+        model(x, low, high)
+    assert given[-2:] == [0, 0]
+    monkeypatch.setenv("ACM_EVAL_AGG_CACHE", "0")
+    model.eval()
+    with torch.no_grad():
+        model(x, low, high), model(x, low, high)
+    assert given[-2:] == [0, 0]
