@@ -187,20 +187,24 @@ def test_eval_passes_reuse_the_aggregated_input_on_the_gpu(monkeypatch):
         o1 = model(x, ops)
         n1 = len(calls)
         o2 = model(x, ops)
-        assert torch.equal(o1, o2)
+        o2b = model(x, ops)
+        # the shortened pass runs the row-local stage as its own kernel (another instantiation of the same code): equal
+        # to the fused kernel's result to rounding, and bit-identical from one shortened pass to the next
+        tol = 1e-5 * max(1.0, float(o1.abs().max()))
+        assert float((o1 - o2).abs().max()) < tol and torch.equal(o2, o2b)
         assert len(calls) - n1 < n1                     # the layer-1 gather of the input is gone
         monkeypatch.setenv("ACM_EVAL_AGG_CACHE", "0")
         o0 = model(x, ops)
-        assert torch.equal(o0, o1)                      # identical to the pass that gathers
+        assert torch.equal(o0, o1)                      # the pass that gathers is unchanged
         monkeypatch.delenv("ACM_EVAL_AGG_CACHE")
         x.add_(0.25)
         o3 = model(x, ops)
-        assert not torch.equal(o3, o1)
+        assert float((o3 - o1).abs().max()) > 1e-3
         monkeypatch.setenv("ACM_EVAL_AGG_CACHE", "0")
-        assert torch.equal(model(x, ops), o3)
+        assert float((model(x, ops) - o3).abs().max()) < tol
     sets = tuple(torch.from_numpy(s).to(DEV) for s in (tr, va, te))
     monkeypatch.delenv("ACM_EVAL_AGG_CACHE")
     ev_g = T.EvalStep(model, x, ops, y, sets, use_graph=True)
     ev_e = T.EvalStep(model, x, ops, y, sets)
     (og, ag, lg), (oe, ae, le) = ev_g(), ev_e()
-    assert torch.equal(og, oe) and ag == ae and lg == le
+    assert torch.equal(og, oe) and ag == ae and lg == le          # both are shortened passes by now
