@@ -29,6 +29,18 @@ def row_weights(train_idx, n_rows, n_train_total=None, device=None):
     return w
 
 
+def _capture_mode():
+    """Keyword arguments of torch.cuda.graph for a capture.  With a process group alive, ProcessGroupNCCL's watchdog
+    thread polls the events of earlier collectives (hipEventQuery) whenever it wakes up; under the default GLOBAL capture
+    mode such a call from another thread while this thread captures is an error that aborts the process
+    ("operation not permitted when stream is capturing", seen on a single-rank RCCL run).  Thread-local mode confines the
+    restriction to the capturing thread."""
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized():
+        return {"capture_error_mode": "thread_local"}
+    return {}
+
+
 class TrainStep:
     def __init__(self, model, optimizer, x, adj, labels, weights, adj_high=None, adj_un=None, use_graph=False,
                  fused_dropout=None):
@@ -165,7 +177,7 @@ class TrainStep:
         self.graph = torch.cuda.CUDAGraph()
         self.model.train()
         self.opt.zero_grad(set_to_none=True)
-        with torch.cuda.graph(self.graph):
+        with torch.cuda.graph(self.graph, **_capture_mode()):
             loss = self._forward_backward()
             self.opt.step()
             if self._manual_advance:
@@ -229,7 +241,7 @@ class EvalStep:
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph):
+        with torch.cuda.graph(self.graph, **_capture_mode()):
             self.out, self.res = self._run()
 
     def __call__(self):
