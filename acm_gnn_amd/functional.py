@@ -73,6 +73,7 @@ class DeferredReductions:
         self._list = _lib.ReduceList(0, self.CAP, C.cast(self._segs, C.POINTER(_lib.ReduceSeg)))
         self._keep = []                 # workspaces the pending segments read
         self.outputs = []               # (data_ptr, nbytes) of tensors whose content arrives with the flush
+        self._allreduce = []            # (tensor, group): row-shard gradient sums to all-reduce right after the flush
 
     def pointer(self):
         return C.addressof(self._list)
@@ -102,17 +103,38 @@ class DeferredReductions:
                 return False
         return True
 
+    def allreduce(self, tensor, group):
+        """Row-sharded runs: `tensor` holds this rank's partial sums of replicated-parameter gradients, complete only
+        after the flush.  Instead of flushing and all-reducing at every layer's backward, the tensors are collected and
+        summed over the ranks right after the ONE flush of the step -- as one coalesced collective where the backend
+        offers it (RCCL), one after the other otherwise."""
+        self._allreduce.append((tensor, group))
+
     def flush(self):
         if self._list.n:
             dev = self._keep[0].device
             with _device_ctx(dev), _Timed("reduce_flush"):
                 st = _lib.load().acm_reduce_flush(C.byref(self._list), _stream())
             _lib.check(st, "acm_reduce_flush")
+        if self._allreduce:
+            import torch.distributed as dist
+            pending, self._allreduce = self._allreduce, []
+            group = pending[0][1]
+            coalesce = (len(pending) > 1 and all(g is group for _, g in pending) and hasattr(dist, "_coalescing_manager")
+                        and dist.get_backend(group) == "nccl")
+            if coalesce:
+                with dist._coalescing_manager(group=group, device=pending[0][0].device, async_ops=False):
+                    for t, _ in pending:
+                        dist.all_reduce(t, group=group)
+            else:
+                for t, g in pending:
+                    dist.all_reduce(t, group=g)
         self._keep.clear()
 
     def discard(self):
         self._list.n = 0
         self._keep.clear()
+        self._allreduce = []
 
 
 _DEFER = None          # module-wide on purpose: autograd runs backward() on its own thread
@@ -601,8 +623,9 @@ class _ResidualLinear(torch.autograd.Function):
         if ctx.group is not None:
             import torch.distributed as dist
             if _DEFER is not None:
-                _DEFER.flush()
-            dist.all_reduce(flat, group=ctx.group)
+                _DEFER.allreduce(flat, ctx.group)
+            else:
+                dist.all_reduce(flat, group=ctx.group)
         return d_x, d_w, (d_b if ctx.has_bias else None), None, None, None
 
 
@@ -1213,8 +1236,9 @@ class AcmConvFunction(torch.autograd.Function):
         if ops.sharded:                             # replicated parameters: sum the row-shard partials
             import torch.distributed as dist
             if _DEFER is not None:
-                _DEFER.flush()                      # the all-reduce reads the reduced gradients
-            dist.all_reduce(flat, group=ops.group)
+                _DEFER.allreduce(flat, ops.group)   # after the step's single flush (the all-reduce reads its sums)
+            else:
+                dist.all_reduce(flat, group=ops.group)
         if d_wcat.dim() == 3:
             d_wl, d_wh, d_wm = d_wcat[0], d_wcat[1], d_wcat[2]
         else:
@@ -1304,8 +1328,9 @@ def _backward_agg(ctx, grad_out):
     if ops.sharded:
         import torch.distributed as dist
         if _DEFER is not None:
-            _DEFER.flush()
-        dist.all_reduce(d_params, group=ops.group)
+            _DEFER.allreduce(d_params, ops.group)
+        else:
+            dist.all_reduce(d_params, group=ops.group)
     wsz = f_in * f
     d_wl, d_wh, d_wm = (d_params[i * wsz:(i + 1) * wsz].view(f_in, f) for i in range(3))
     base = 3 * wsz

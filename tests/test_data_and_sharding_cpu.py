@@ -308,3 +308,98 @@ def test_row_shard_equals_single_process(cfg, monkeypatch):
             ref = p.grad[b:e] if k.endswith(".struc_low") else p.grad
             torch.testing.assert_close(torch.from_numpy(grads[k]), ref, rtol=1e-4, atol=1e-6,
                                        msg=lambda m, k=k: f"{k}: {m}")
+
+
+def _train_worker(rank, world, port, cfg, ret):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import torch.distributed as dist
+    import fake_lib
+
+    class MP:
+        def setattr(self, obj, name, val):
+            setattr(obj, name, val)
+
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        fake_lib.install(MP())
+        import acm_gnn_amd
+        from acm_gnn_amd import GCN, data as D, distributed as DD, functional as AF, train as T
+        adj, x_np, y_np, (tr, _, _), _ = D.synthetic_dataset("tiny", seed=5, pad_to=world)
+        low, deg = D.build_filters(adj)
+        n = adj.shape[0]
+        plan = DD.equal_rows_plan(n, world) if cfg["plan"] == "rows" else DD.shard_plan(low.indptr, world, 8)
+        ops = DD.make_sharded_operators(low, deg, "cpu", with_structure=bool(cfg["s"]), plan=plan)
+        b, e = plan.rows(rank)
+        torch.manual_seed(0)
+        full = GCN(7, 16, 2, 2, n, cfg["dropout"], cfg["model"], cfg["s"], variant=bool(cfg["variant"]), attn_layernorm=True)
+        model = GCN(7, 16, 2, 2, e - b, cfg["dropout"], cfg["model"], cfg["s"], variant=bool(cfg["variant"]), attn_layernorm=True)
+        sd = full.state_dict()
+        for k in list(sd):
+            if k.endswith(".struc_low"):
+                sd[k] = sd[k][b:e].clone()
+        model.load_state_dict(sd)
+        model.dropout_state = AF.DropoutState("cpu", seed=7)
+        opt = acm_gnn_amd.FusedAdamW(model.parameters(), lr=0.02, weight_decay=1e-3)
+        w = T.row_weights(torch.from_numpy(DD.local_index(tr, plan, rank)), e - b, n_train_total=len(tr))
+        step = T.TrainStep(model, opt, torch.from_numpy(x_np[b:e]), ops, torch.from_numpy(y_np[b:e]), w, fused_dropout=True)
+        losses = [float(step()) for _ in range(3)]
+        assert step._defer                                  # the deferred path stayed on
+        params = {k: p.detach().numpy().copy() for k, p in model.named_parameters()}
+        ret.put((rank, losses, params, (b, e)))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("cfg", [dict(model="acmgcnp", s=0, variant=0, dropout=0.3, plan="rows"),
+                                 dict(model="acmgcnp", s=1, variant=1, dropout=0.0, plan="work"),
+                                 dict(model="acmgcnpp", s=0, variant=0, dropout=0.3, plan="rows")],
+                         ids=["agg-dropout", "struct-acmii-work-plan", "acmgcnpp"])
+def test_sharded_train_step_equals_single_process(cfg, monkeypatch):
+    """train.TrainStep on two gloo ranks: the second phases of every partial sum run as ONE deferred launch per step and
+    the row-shard gradient sums are all-reduced right after it (DeferredReductions.allreduce), before the optimizer --
+    three steps must leave every rank with the parameters of the single-process run."""
+    import queue
+    import time
+    import torch.multiprocessing as mp
+    import fake_lib
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    ret = ctx.Queue()
+    procs = [ctx.Process(target=_train_worker, args=(r, world, port, cfg, ret)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results, deadline = [], time.time() + 300
+    while len(results) < world:
+        try:
+            results.append(ret.get(timeout=2))
+        except queue.Empty:
+            if [p.exitcode for p in procs if p.exitcode not in (None, 0)] or time.time() > deadline:
+                for p in procs:
+                    p.terminate()
+                pytest.fail(f"sharded train workers failed (exit codes {[p.exitcode for p in procs]})")
+    for p in procs:
+        p.join(60)
+    results.sort(key=lambda t: t[0])
+    fake_lib.install(monkeypatch)
+    import acm_gnn_amd
+    from acm_gnn_amd import GCN, data as D, distributed as DD, functional as AF, train as T
+    adj, x_np, y_np, (tr, _, _), _ = D.synthetic_dataset("tiny", seed=5, pad_to=world)
+    low, deg = D.build_filters(adj)
+    n = adj.shape[0]
+    ops = DD.make_sharded_operators(low, deg, "cpu", with_structure=bool(cfg["s"]))
+    torch.manual_seed(0)
+    full = GCN(7, 16, 2, 2, n, cfg["dropout"], cfg["model"], cfg["s"], variant=bool(cfg["variant"]), attn_layernorm=True)
+    full.dropout_state = AF.DropoutState("cpu", seed=7)
+    opt = acm_gnn_amd.FusedAdamW(full.parameters(), lr=0.02, weight_decay=1e-3)
+    w = T.row_weights(torch.from_numpy(tr), n)
+    step = T.TrainStep(full, opt, torch.from_numpy(x_np), ops, torch.from_numpy(y_np), w, fused_dropout=True)
+    ref_losses = [float(step()) for _ in range(3)]
+    for rank, losses, params, (b, e) in results:
+        for k, p in full.named_parameters():
+            ref = p.detach()[b:e] if k.endswith(".struc_low") else p.detach()
+            torch.testing.assert_close(torch.from_numpy(params[k]), ref, rtol=2e-4, atol=2e-6, msg=lambda m, k=k: f"{k}: {m}")
+    # each rank reports the loss over its own rows: the ranks' losses add up to the single-process loss
+    for i in range(3):
+        assert abs(sum(r[1][i] for r in results) - ref_losses[i]) < 1e-5 * max(1.0, abs(ref_losses[i]))
