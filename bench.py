@@ -298,6 +298,9 @@ def main():
             sys.stderr.write(f"bench.py: hipGraph capture failed ({exc!r}); reporting eager launches\n")
         state["done"] = True
         timer_t.cancel()
+    if world > 1:                                  # each rank holds the loss over its own rows
+        loss = loss.detach().clone()
+        dist.all_reduce(loss)
     final_loss = float(loss.item())
 
     # ---------------- parity of what was just timed: eval-mode logits of the trained model against the CPU oracle
