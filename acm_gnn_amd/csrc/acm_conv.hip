@@ -831,7 +831,9 @@ int launch_gather(const acm_csr* a, const GatherSrc& g, int F, const typename Ep
         }
         const int gs = narrow_lanes(a);
         // [channel 0 | channel 1] contiguous and block-aligned => one vector fetch for both
-        const bool merged = NG >= 2 && F == FP && g.p[1] == g.p[0] + F && g.ld[0] == g.ld[1] &&
+        // (F < FP: the channels are blocks of FP columns, [c0 pad | c1 pad]; what the fetch reads beyond F lands in
+        // accumulator columns no epilogue looks at)
+        const bool merged = NG >= 2 && g.p[1] == g.p[0] + FP && g.ld[0] == g.ld[1] &&
                             ((uintptr_t)g.p[0]) % (8 * FP) == 0 && (g.ld[0] * sizeof(float)) % (8 * FP) == 0;
 #define ACM_NARROW(FPv, GSv)                                                                            \
     do {                                                                                                \

@@ -101,7 +101,8 @@ template <int F>
 __global__ __launch_bounds__(256) void proj_fwd_kernel(int n_rows, int f_in, const float* __restrict__ X, long ldx,
                                                        const float* __restrict__ W0, const float* __restrict__ W1,
                                                        const float* __restrict__ W2, long ldw, int relu,
-                                                       float* __restrict__ Zlh, long ld_lh, float* __restrict__ Zi, long ld_i) {
+                                                       float* __restrict__ Zlh, long ld_lh, float* __restrict__ Zi, long ld_i,
+                                                       int h_col) {
     constexpr int Q = 3 * F;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int g = lane >> 4, m = lane & 15;
@@ -165,7 +166,7 @@ __global__ __launch_bounds__(256) void proj_fwd_kernel(int n_rows, int f_in, con
             part[q] = acm_group_sum<16>(part[q]);               // every lane of the group ends with the total
             if (relu) part[q] = fmaxf(part[q], 0.f);
         }
-        if (F == 2 && out_vec) {                                // 16 + 8 bytes per row: two stores by the group leader
+        if (F == 2 && out_vec && h_col == F) {                  // 16 + 8 bytes per row: two stores by the group leader
             if (m == 0) {
                 *reinterpret_cast<float4*>(Zlh + (long)row * ld_lh) = make_float4(part[0], part[1], part[2], part[3]);
                 *reinterpret_cast<float2*>(Zi + (long)row * ld_i) = make_float2(part[4], part[5]);
@@ -174,7 +175,8 @@ __global__ __launch_bounds__(256) void proj_fwd_kernel(int n_rows, int f_in, con
 #pragma unroll
             for (int q = 0; q < Q; ++q)
                 if (m == (q & 15)) {
-                    if (q < 2 * F) Zlh[(long)row * ld_lh + q] = part[q];
+                    if (q < F) Zlh[(long)row * ld_lh + q] = part[q];
+                    else if (q < 2 * F) Zlh[(long)row * ld_lh + h_col + (q - F)] = part[q];       // Z_H starts at column h_col
                     else Zi[(long)row * ld_i + (q - 2 * F)] = part[q];
                 }
         }
@@ -193,16 +195,23 @@ int proj_blocks(int64_t n_rows) {
 extern "C" int acm_proj_fwd(int64_t n_rows, int64_t f_in, int f_out, const float* X, int64_t ldx, const float* w_low,
                             const float* w_high, const float* w_mlp, int64_t ldw, int relu, float* Z_lh, int64_t ld_lh,
                             float* Z_i, int64_t ld_i, acm_stream_t stream) {
+    return acm_proj_fwd_at(n_rows, f_in, f_out, X, ldx, w_low, w_high, w_mlp, ldw, relu, Z_lh, ld_lh, f_out, Z_i, ld_i, stream);
+}
+
+extern "C" int acm_proj_fwd_at(int64_t n_rows, int64_t f_in, int f_out, const float* X, int64_t ldx, const float* w_low,
+                               const float* w_high, const float* w_mlp, int64_t ldw, int relu, float* Z_lh, int64_t ld_lh,
+                               int64_t h_col, float* Z_i, int64_t ld_i, acm_stream_t stream) {
     ACM_REQUIRE(X && w_low && w_high && w_mlp && Z_lh && Z_i, ACM_EINVAL, "acm_proj_fwd: NULL pointer");
     ACM_REQUIRE(f_out >= 1 && f_out <= 8, ACM_EUNSUPPORTED, "acm_proj_fwd: f_out = %d (1..8; use acm_gemm otherwise)", f_out);
     ACM_REQUIRE(n_rows >= 0 && n_rows < INT32_MAX && f_in >= 0 && f_in < INT32_MAX && ldx >= f_in && ldw >= f_out &&
-                    ld_lh >= 2 * f_out && ld_i >= f_out, ACM_ESHAPE, "acm_proj_fwd: bad sizes / leading dimensions");
+                    h_col >= f_out && ld_lh >= h_col + f_out && ld_i >= f_out, ACM_ESHAPE,
+                "acm_proj_fwd: bad sizes / leading dimensions");
     if (n_rows == 0) return ACM_OK;
     hipStream_t s = (hipStream_t)stream;
     const int nblk = proj_blocks(n_rows);
 #define ACM_PF(Fv)                                                                                                  \
     hipLaunchKernelGGL((proj_fwd_kernel<Fv>), dim3(nblk), dim3(256), 0, s, (int)n_rows, (int)f_in, X, (long)ldx, w_low, \
-                       w_high, w_mlp, (long)ldw, relu, Z_lh, (long)ld_lh, Z_i, (long)ld_i)
+                       w_high, w_mlp, (long)ldw, relu, Z_lh, (long)ld_lh, Z_i, (long)ld_i, (int)h_col)
     switch (f_out) {
         case 1: ACM_PF(1); break;
         case 2: ACM_PF(2); break;

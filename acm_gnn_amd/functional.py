@@ -304,19 +304,23 @@ def gemm_split(a, b, out1, out2, relu=False):
     _lib.check(st, "acm_gemm_split")
 
 
-def proj_fwd(x, weights, out_lh, out_i, relu=False):
+def proj_fwd(x, weights, out_lh, out_i, relu=False, h_col=None):
     """[out_lh | out_i] = relu?(x @ [W_L | W_H | W_I]) for a narrow layer (F <= 8), straight from the three weight
-    matrices (acm_proj_fwd): out_lh [n, 2F] is the gathered block, out_i [n, F]."""
+    matrices (acm_proj_fwd): out_lh [n, 2F] is the gathered block, out_i [n, F].  ``h_col`` (acm_proj_fwd_at): Z_H starts
+    at that column of out_lh ([n, h_col + F] at least) instead of column F -- channel blocks of 4 / 8 columns."""
     x = _as_f32c(x, "x")
     ws3 = [_as_f32c(w, "weight") for w in weights]
     n, f_in = x.shape
     f = ws3[0].shape[1]
-    if any(tuple(w.shape) != (f_in, f) for w in ws3) or out_lh.shape != (n, 2 * f) or out_i.shape != (n, f):
+    h_col = f if h_col is None else int(h_col)
+    if (any(tuple(w.shape) != (f_in, f) for w in ws3) or out_lh.shape[0] != n or out_lh.shape[1] < h_col + f or h_col < f
+            or out_i.shape != (n, f)):
         raise ValueError("proj_fwd: shape mismatch")
     with _device_ctx(x.device), _Timed(f"proj_fwd/{n}x{f_in}x{3 * f}"):
-        st = _lib.load().acm_proj_fwd(n, f_in, f, _vp(x), x.stride(0), _vp(ws3[0]), _vp(ws3[1]), _vp(ws3[2]), ws3[0].stride(0),
-                                      int(relu), _vp(out_lh), out_lh.stride(0), _vp(out_i), out_i.stride(0), _stream())
-    _lib.check(st, "acm_proj_fwd")
+        st = _lib.load().acm_proj_fwd_at(n, f_in, f, _vp(x), x.stride(0), _vp(ws3[0]), _vp(ws3[1]), _vp(ws3[2]),
+                                         ws3[0].stride(0), int(relu), _vp(out_lh), out_lh.stride(0), h_col, _vp(out_i),
+                                         out_i.stride(0), _stream())
+    _lib.check(st, "acm_proj_fwd_at")
 
 
 def proj_bwd(x, dz, weights, d_w_out):
@@ -727,11 +731,23 @@ def _flat_views(flat, nw, k, f, layernorm):
     return d_vec, d_lnw, d_lnb, d_mix
 
 
-def _k3_setup(cfg, ops, k, f, n, dev, f_in_w, pre, zi, vecs, lnw, lnb, mix, grad_out, post_relu, post_scale, post_drop):
+def _chan_block(f):
+    """Column distance of the two gathered channels inside [Z_L | Z_H] / [G_L | G_H].  F in {3, 5, 6, 7} pads each channel
+    to a block of 4 / 8 columns: the narrow gather then fetches a neighbour's row with aligned 16-byte loads (the
+    merged path of spmm_narrow_kernel) instead of 2 F scalar ones -- on the arXiv-year-shaped graph (5 classes) the
+    output layer's gathers are 3-4x faster.  The pad columns are never read into a result."""
+    if f in (3, 5, 6, 7) and os.environ.get("ACM_PAD_CHANNELS", "1") != "0":
+        return 4 if f == 3 else 8
+    return f
+
+
+def _k3_setup(cfg, ops, k, f, n, dev, f_in_w, pre, zi, vecs, lnw, lnb, mix, grad_out, post_relu, post_scale, post_drop,
+              fb=None):
     """Buffers and acm_conv_bwd_local_t of the row-local backward of one layer: G tables, dZ, the flat buffer every
     replicated-parameter gradient is a view of."""
     four = k == 4
-    g = torch.empty(n, 2 * f, dtype=_F32, device=dev)            # [G_L | G_H]
+    fb = f if fb is None else fb
+    g = torch.empty(n, 2 * fb, dtype=_F32, device=dev)           # [G_L | G_H] (channel blocks of fb columns)
     dz = torch.empty(n, 3 * f, dtype=_F32, device=dev)           # [dZ_L | dZ_H | dZ_I]
     gs = torch.empty(n, f, dtype=_F32, device=dev) if four else None
     # every replicated-parameter gradient is a view of one flat buffer: a row-sharded run sums the partials
@@ -756,7 +772,7 @@ def _k3_setup(cfg, ops, k, f, n, dev, f_in_w, pre, zi, vecs, lnw, lnb, mix, grad
     q.att_vec, q.ln_weight, q.ln_bias = _ptr_array(vecs), _ptr_array(lnw), _ptr_array(lnb)
     q.att_mix = mix.data_ptr()
     q.g_low, q.ld_g_low = g.data_ptr(), g.stride(0)
-    q.g_high, q.ld_g_high = g.data_ptr() + 4 * f, g.stride(0)
+    q.g_high, q.ld_g_high = g.data_ptr() + 4 * fb, g.stride(0)
     q.g_mlp, q.ld_g_mlp = dz.data_ptr() + 8 * f, dz.stride(0)
     if four:
         q.g_struc, q.ld_g_struc = gs.data_ptr(), gs.stride(0)
@@ -824,6 +840,7 @@ class AcmConvFunction(torch.autograd.Function):
         # chain A_low (A_low (... Z_L)) with the 1-hop operator, adj_high stays 1-hop like the reference's
         hops = int(getattr(ops, "hops", 1))
         ctx.hops = hops
+        ctx.fb = f                               # set by the literal path below (_chan_block)
         if hops > 1:
             if cfg.relu_before or cfg.relu_after or four or general:
                 raise NotImplementedError("hops > 1 is the ACM-SGC chain: model_type 'acmsgc' only")
@@ -837,6 +854,7 @@ class AcmConvFunction(torch.autograd.Function):
         ctx.recompute = (cfg.relu_before and not cfg.relu_after and cfg.relu_mlp and f == 64 and f_in <= 8
                          and not sparse_x and not general and hops == 1 and not cfg.gather_bf16
                          and os.environ.get("ACM_ACMII_RECOMPUTE", "1") != "0")
+        fb = f                                   # column distance of the two gathered channels (see _chan_block)
         if ctx.agg_first or ctx.recompute:
             fp = 4 if f_in <= 4 else (8 if f_in <= 8 else 16)
             if ctx.recompute:
@@ -872,19 +890,28 @@ class AcmConvFunction(torch.autograd.Function):
             use_proj = (not sparse_x and f <= 5 and f_in <= 64     # wider inputs: the MFMA GEMM is the faster stream
                         and w3[0].stride(0) == w3[1].stride(0) == w3[2].stride(0)
                         and os.environ.get("ACM_PROJ_FWD", "1") != "0")
-            wcat = None if use_proj else torch.cat(w3, dim=1).contiguous()          # [F_in, 3F]
+            fb = ctx.fb = _chan_block(f)
+            if use_proj:
+                wcat = None
+            elif fb != f:                      # [W_L 0 | W_H 0 | W_I]: the product lands in channel blocks of fb columns
+                zpad = w3[0].new_zeros(w3[0].shape[0], fb - f)
+                wcat = torch.cat((w3[0], zpad, w3[1], zpad, w3[2]), dim=1).contiguous()
+            else:
+                wcat = torch.cat(w3, dim=1).contiguous()                            # [F_in, 3F]
             # Row pitch of Z: for narrow layers the gathered block [Z_L | Z_H] (2F floats) must be
             # one aligned vector fetch, so rows are padded to a multiple of that block.
             ldz = 3 * f
             if f in (2, 4, 8):
                 ldz = -(-3 * f // (2 * f)) * (2 * f)
+            elif fb != f:
+                ldz = -(-(2 * fb + f) // 4) * 4
             pre = _take_pre_proj(x, w3, cfg.relu_before) if use_proj else None
             if pre is not None:
                 zlh, zi = pre                              # computed in the preceding layer's epilogue
             elif use_proj:
-                zlh = torch.empty(n, 2 * f, dtype=_F32, device=dev)
+                zlh = torch.empty(n, 2 * fb, dtype=_F32, device=dev)
                 zi = torch.empty(n, f, dtype=_F32, device=dev)
-                proj_fwd(x, w3, zlh, zi, relu=cfg.relu_before)
+                proj_fwd(x, w3, zlh, zi, relu=cfg.relu_before, h_col=fb)
             elif f in (2, 4, 8) and not sparse_x:
                 # narrow layer: [Z_L | Z_H] as its own compact table (what the gather walks: half the cache footprint of
                 # [Z_L | Z_H | Z_I | pad] rows), Z_I next to it -- one GEMM with a two-matrix output
@@ -892,19 +919,19 @@ class AcmConvFunction(torch.autograd.Function):
                 zi = torch.empty(n, f, dtype=_F32, device=dev)
                 gemm_split(x, wcat, zlh, zi, relu=cfg.relu_before)
             else:
-                z = torch.empty(n, ldz, dtype=_F32, device=dev)[:, : 3 * f]
+                z = torch.empty(n, ldz, dtype=_F32, device=dev)[:, : 2 * fb + f]
                 if sparse_x:                              # Z = X_csr Wcat: nnz(X) * 3F FMAs
                     spmm_v(x.csr, x.values, wcat, relu=cfg.relu_before, out=z)
                 else:
                     gemm(x, wcat, relu=cfg.relu_before, out=z)                      # [n, 3F] view
-                zlh, zi = z[:, : 2 * f], z[:, 2 * f:]
+                zlh, zi = z[:, : 2 * fb], z[:, 2 * fb:]
             if hops > 1:
                 t = zlh[:, :f]
                 for _ in range(hops - 1):
                     t = _low_product(ops, t)
-                zc = torch.empty(n, 2 * f, dtype=_F32, device=dev)               # [A_low^(k-1) Z_L | Z_H]
+                zc = torch.empty(n, 2 * fb, dtype=_F32, device=dev)              # [A_low^(k-1) Z_L | Z_H]
                 zc[:, :f] = t
-                zc[:, f:] = zlh[:, f:]
+                zc[:, fb:fb + f] = zlh[:, fb:fb + f]
                 zg = _gather_rows(ops, zc)
             else:
                 zg = _gather_rows(ops, zlh) if ops.sharded else zlh                 # gathered [Z_L|Z_H]
@@ -1041,7 +1068,7 @@ class AcmConvFunction(torch.autograd.Function):
             # every channel through its own operator, then the fused kernel over the identity operator as a
             # row-local epilogue: pre_L = 1*PL, pre_H = PH - 1*0, pre_S = 1*(1*PS) - 0
             pl = spmm(ops.low, zlh[:, :f])
-            ph = spmm(ops.high, zlh[:, f:])
+            ph = spmm(ops.high, zlh[:, fb:fb + f])
             zero = ops.zeros(n, f)
             graph = ops.eye
             p.g_low, p.ld_g_low = pl.data_ptr(), pl.stride(0)
@@ -1067,10 +1094,10 @@ class AcmConvFunction(torch.autograd.Function):
                     p.g_struc, p.ld_g_struc = sb.data_ptr(), sb.stride(0)
             else:
                 p.g_low, p.ld_g_low = zg.data_ptr(), zg.stride(0)
-                p.g_high, p.ld_g_high = zg.data_ptr() + 4 * f, zg.stride(0)
+                p.g_high, p.ld_g_high = zg.data_ptr() + 4 * fb, zg.stride(0)
                 if four:
                     p.g_struc, p.ld_g_struc = s_gath.data_ptr(), s_gath.stride(0)
-            p.s_high, p.ld_s_high = zlh.data_ptr() + 4 * f, zlh.stride(0)
+            p.s_high, p.ld_s_high = zlh.data_ptr() + 4 * fb, zlh.stride(0)
             if four:
                 p.s_struc, p.ld_s_struc = s_local.data_ptr(), s_local.stride(0)
                 p.deg = ops.deg.data_ptr()
@@ -1093,7 +1120,8 @@ class AcmConvFunction(torch.autograd.Function):
                 and any(ctx.needs_input_grad) and tail_req.labels.numel() == n
                 and (graph.n_long_rows == 0 or 12.0 < graph.nnz / max(graph.n_rows, 1) <= 160.0)):
             dlog = torch.empty(n, f, dtype=_F32, device=dev)
-            st3 = _k3_setup(cfg, ops, k, f, n, dev, w3[0].shape[0], pre, zi, vecs, lnw, lnb, mix, dlog, False, None, None)
+            st3 = _k3_setup(cfg, ops, k, f, n, dev, w3[0].shape[0], pre, zi, vecs, lnw, lnb, mix, dlog, False, None, None,
+                            fb=fb)
             loss = torch.empty((), dtype=_F32, device=dev)
             lo = _lib.Loss()
             lo.n_classes = f
@@ -1151,8 +1179,9 @@ class AcmConvFunction(torch.autograd.Function):
         f_in_w = wl_.shape[0]
         tail = getattr(ctx, "tail", None)
         done = tail is not None and grad_out.data_ptr() == tail["grad_out"].data_ptr()
+        fb = getattr(ctx, "fb", f)
         st3 = tail if done else _k3_setup(cfg, ops, k, f, n, dev, f_in_w, pre, zi, vecs, lnw, lnb, mix, grad_out,
-                                          ctx.post_relu, ctx.post_scale, ctx.post_drop)
+                                          ctx.post_relu, ctx.post_scale, ctx.post_drop, fb=fb)
         q, g, dz, gs, flat, nw = st3["q"], st3["g"], st3["dz"], st3["gs"], st3["flat"], st3["nw"]
         general, ones = st3["general"], st3["ones"]
         if done:
@@ -1177,7 +1206,7 @@ class AcmConvFunction(torch.autograd.Function):
             # transposed products channel by channel, then the fused kernel over the identity operator applies the
             # ACMII masks: dZ_L = m*(1*T_L), dZ_H = m*(T_H - 1*0), dS = 1*T_S - 0
             t_l = spmm(ops.low.transpose(), g[:, :f])
-            t_h = spmm(ops.high.transpose(), g[:, f:])
+            t_h = spmm(ops.high.transpose(), g[:, fb:fb + f])
             zero = ops.zeros(n, f)
             low_t = ops.eye
             r.g_low, r.ld_g_low = t_l.data_ptr(), t_l.stride(0)
@@ -1194,8 +1223,8 @@ class AcmConvFunction(torch.autograd.Function):
             gsg = _gather_rows(ops, gs) if four else None
             low_t = ops.low_t
             r.g_low, r.ld_g_low = gg.data_ptr(), gg.stride(0)
-            r.g_high, r.ld_g_high = gg.data_ptr() + 4 * f, gg.stride(0)
-            r.s_high, r.ld_s_high = g.data_ptr() + 4 * f, g.stride(0)
+            r.g_high, r.ld_g_high = gg.data_ptr() + 4 * fb, gg.stride(0)
+            r.s_high, r.ld_s_high = g.data_ptr() + 4 * fb, g.stride(0)
             if four:
                 r.g_struc, r.ld_g_struc = gsg.data_ptr(), gsg.stride(0)
                 r.s_struc, r.ld_s_struc = gs.data_ptr(), gs.stride(0)
@@ -1205,7 +1234,7 @@ class AcmConvFunction(torch.autograd.Function):
                 r.self_scale = ops.self_scale.data_ptr()
         if cfg.relu_before:                       # ACMII: ReLU mask of the projected features
             r.mask_low, r.ld_mask_low = zlh.data_ptr(), zlh.stride(0)
-            r.mask_high, r.ld_mask_high = zlh.data_ptr() + 4 * f, zlh.stride(0)
+            r.mask_high, r.ld_mask_high = zlh.data_ptr() + 4 * fb, zlh.stride(0)
         r.dz_low, r.ld_dz_low = dz.data_ptr(), dz.stride(0)
         r.dz_high, r.ld_dz_high = dz.data_ptr() + 4 * f, dz.stride(0)
         ws2 = low_t.workspace((k - 1) * f)

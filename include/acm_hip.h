@@ -243,6 +243,12 @@ int acm_gemm_split(int transA, int transB, int64_t M, int64_t N, int64_t K,
 int acm_proj_fwd(int64_t n_rows, int64_t f_in, int f_out, const float* X, int64_t ldx,
                  const float* w_low, const float* w_high, const float* w_mlp, int64_t ldw, int relu,
                  float* Z_lh, int64_t ld_lh, float* Z_i, int64_t ld_i, acm_stream_t stream);
+/* The same with Z_H written at column h_col >= f_out of Z_lh instead of column f_out: for f_out in {3, 5, 6, 7} the
+ * narrow gather wants the two gathered channels as blocks of 4 / 8 columns, [Z_L pad | Z_H pad], so that a neighbour's
+ * row is a few aligned 16-byte fetches instead of 2 f_out scalar ones (the pad columns are never read into a result). */
+int acm_proj_fwd_at(int64_t n_rows, int64_t f_in, int f_out, const float* X, int64_t ldx,
+                    const float* w_low, const float* w_high, const float* w_mlp, int64_t ldw, int relu,
+                    float* Z_lh, int64_t ld_lh, int64_t h_col, float* Z_i, int64_t ld_i, acm_stream_t stream);
 int acm_proj_bwd_workspace_bytes(int64_t n_rows, int64_t f_in, int n_out, size_t* bytes);
 int acm_proj_bwd(int64_t n_rows, int64_t f_in, int n_out, const float* X, int64_t ldx,
                  const float* dZ, int64_t lddz, const float* w_low, const float* w_high, const float* w_mlp, int64_t ldw,

@@ -303,12 +303,19 @@ class FakeLib:
         return 0
 
     def acm_proj_fwd(self, n, f_in, f, x, ldx, wl, wh, wm, ldw, relu, zlh, ld_lh, zi, ld_i, stream):
+        return self.acm_proj_fwd_at(n, f_in, f, x, ldx, wl, wh, wm, ldw, relu, zlh, ld_lh, f, zi, ld_i, stream)
+
+    def acm_proj_fwd_at(self, n, f_in, f, x, ldx, wl, wh, wm, ldw, relu, zlh, ld_lh, h_col, zi, ld_i, stream):
         X = _view(x, n, f_in, ldx).astype(np.float64)
         W = np.concatenate([_view(w, f_in, f, ldw).astype(np.float64) for w in (wl, wh, wm)], 1)
         out = X @ W
         if relu:
             out = np.maximum(out, 0)
-        _view(zlh, n, 2 * f, ld_lh)[...] = out[:, :2 * f]
+        zv = _view(zlh, n, h_col + f, ld_lh)
+        if h_col > f:
+            zv[:, f:h_col] = np.nan                       # the pad columns are undefined: nothing may depend on them
+        zv[:, :f] = out[:, :f]
+        zv[:, h_col:h_col + f] = out[:, f:2 * f]
         _view(zi, n, f, ld_i)[...] = out[:, 2 * f:]
         return 0
 

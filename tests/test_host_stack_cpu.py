@@ -616,7 +616,7 @@ def test_next_layer_projection_rides_the_hidden_layers_epilogue(n_cls, fused_dro
     low, high, un, _ = graph_tensors("geometric")
     n = low.shape[0]
     calls = []
-    for name in ("acm_proj_fwd", "acm_conv_agg_fwd"):
+    for name in ("acm_proj_fwd_at", "acm_conv_agg_fwd"):
         orig = getattr(fake, name)
         monkeypatch.setattr(fake, name, (lambda o, nm: lambda *a: (calls.append(nm), o(*a))[1])(orig, name))
     x = torch.randn(n, 7, generator=torch.Generator().manual_seed(1))
@@ -639,8 +639,8 @@ def test_next_layer_projection_rides_the_hidden_layers_epilogue(n_cls, fused_dro
 
     out_f, g_f, calls_f = run("1")
     out_s, g_s, calls_s = run("0")
-    assert "acm_proj_fwd" in calls_s
-    assert ("acm_proj_fwd" not in calls_f) == (n_cls <= 2)
+    assert "acm_proj_fwd_at" in calls_s
+    assert ("acm_proj_fwd_at" not in calls_f) == (n_cls <= 2)
     np.testing.assert_allclose(out_f.numpy(), out_s.numpy(), rtol=1e-5, atol=1e-5 * max(1.0, float(out_s.abs().max())))
     for k in g_s:
         np.testing.assert_allclose(g_f[k].numpy(), g_s[k].numpy(), err_msg=k, rtol=1e-4,
