@@ -825,7 +825,9 @@ int launch_gather(const acm_csr* a, const GatherSrc& g, int F, const typename Ep
         const int FP = F <= 2 ? 2 : (F <= 4 ? 4 : 8);
         for (int c = 0; c < NG; ++c) {
             const size_t al = (FP == 2) ? 8 : 16;
-            const bool ok = (F == FP) && (((uintptr_t)g.p[c]) % al == 0) &&
+            // F < FP: a row pitch of at least FP columns lets the fetch read the whole block (what lies beyond F lands in
+            // accumulator columns no epilogue looks at); the operand must cover n_cols x ld floats (acm_hip.h)
+            const bool ok = (F == FP || g.ld[c] >= FP) && (((uintptr_t)g.p[c]) % al == 0) &&
                             ((g.ld[c] * sizeof(float)) % al == 0);
             vecmask |= ok ? (1 << c) : 0;
         }

@@ -246,6 +246,17 @@ def _as_f32c(t, name):
     return t.contiguous()
 
 
+def _as_f32_rows(t, name):
+    """fp32 with unit column stride: a column slice of a wider matrix is handed to the C ABI as (pointer, ld) instead of
+    being copied."""
+    _require_cuda(t, name)
+    if t.dtype != _F32:
+        t = t.to(_F32)
+    if t.dim() == 2 and t.stride(1) == 1 and t.stride(0) >= t.shape[1] and t.shape[1] > 0:
+        return t
+    return t.contiguous()
+
+
 # --------------------------------------------------------------------------
 # raw (non-differentiable) launches
 # --------------------------------------------------------------------------
@@ -357,7 +368,7 @@ def proj_bwd_supported(q):
 
 def spmm(graph, dense, out=None, row_scale=None):
     """out = A @ dense for a CsrGraph A (acm_spmm); with ``row_scale``: diag(row_scale) (A @ dense) (acm_spmm_ex)."""
-    dense = _as_f32c(dense, "dense")
+    dense = _as_f32_rows(dense, "dense")
     if dense.shape[0] != graph.n_cols:
         raise ValueError(f"spmm: dense has {dense.shape[0]} rows, operator has {graph.n_cols} columns")
     width = dense.shape[1]
@@ -708,15 +719,26 @@ def _gather_rows(ops, local):
     return full
 
 
-def _low_product(ops, t_local, transpose=False):
+def _hop_buffer(t_like, width):
+    """[n, width] view of a buffer whose rows are padded to the next of 4 / 8 columns: the narrow gather fetches such rows
+    as aligned 16-byte blocks (see _chan_block)."""
+    pitch = width if width > 8 else (8 if width > 4 else (4 if width > 2 else width))
+    return torch.empty(t_like.shape[0], pitch, dtype=_F32, device=t_like.device)[:, :width]
+
+
+def _low_product(ops, t_local, transpose=False, out=None):
     """A_low @ t (or A_low^T @ t) for a row-local t [n_local, w]: one hop of the ACM-SGC k-hop chain, with the
-    halo all-gather when row-sharded.  Pattern-only operators: D^-1 (P t) and P (D^-1 t)."""
+    halo all-gather when row-sharded.  Pattern-only operators: D^-1 (P t) and P (D^-1 t).  ``out``: where the product
+    goes (default: a row-padded buffer, _hop_buffer)."""
+    if out is None:
+        out = _hop_buffer(t_local, t_local.shape[1])
     if transpose:
         if ops.implicit:
-            return spmm(ops.low_t, _gather_rows(ops, t_local * ops.row_scale[:, None]))
-        return spmm(ops.low_t, _gather_rows(ops, t_local))
-    tg = _gather_rows(ops, t_local.contiguous())
-    return spmm(ops.low, tg, row_scale=ops.row_scale if ops.implicit else None)
+            scaled = _hop_buffer(t_local, t_local.shape[1])
+            torch.mul(t_local, ops.row_scale[:, None], out=scaled)
+            return spmm(ops.low_t, _gather_rows(ops, scaled), out=out)
+        return spmm(ops.low_t, _gather_rows(ops, t_local), out=out)
+    return spmm(ops.low, _gather_rows(ops, t_local), out=out, row_scale=ops.row_scale if ops.implicit else None)
 
 
 def _flat_views(flat, nw, k, f, layernorm):
@@ -926,11 +948,10 @@ class AcmConvFunction(torch.autograd.Function):
                     gemm(x, wcat, relu=cfg.relu_before, out=z)                      # [n, 3F] view
                 zlh, zi = z[:, : 2 * fb], z[:, 2 * fb:]
             if hops > 1:
-                t = zlh[:, :f]
-                for _ in range(hops - 1):
-                    t = _low_product(ops, t)
                 zc = torch.empty(n, 2 * fb, dtype=_F32, device=dev)              # [A_low^(k-1) Z_L | Z_H]
-                zc[:, :f] = t
+                t = zlh[:, :f]
+                for hop in range(hops - 1):                                      # the last hop lands in its slot of zc
+                    t = _low_product(ops, t, out=zc[:, :f] if hop == hops - 2 else None)
                 zc[:, fb:fb + f] = zlh[:, fb:fb + f]
                 zg = _gather_rows(ops, zc)
             else:
@@ -1243,9 +1264,11 @@ class AcmConvFunction(torch.autograd.Function):
         _lib.check(st, "acm_conv_bwd_spmm")
         if ctx.hops > 1:                                  # the remaining k-1 transposed hops of the low channel
             t = dz[:, :f]
-            for _ in range(ctx.hops - 1):
-                t = _low_product(ops, t, transpose=True)
-            dz[:, :f] = t
+            last = ctx.hops - 2
+            for hop in range(ctx.hops - 1):               # the last hop writes dZ_L in place unless it reads it
+                t = _low_product(ops, t, transpose=True, out=dz[:, :f] if (hop == last and hop > 0) else None)
+            if last == 0:
+                dz[:, :f] = t
 
         if ctx.sparse_x is not None:                                          # dWcat = X_csr^T dZ
             xs = ctx.sparse_x

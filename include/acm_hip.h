@@ -279,6 +279,8 @@ int acm_bias_act_bwd(int64_t n_rows, int f, const float* Y, int64_t ldy, const f
  * Y[r, 0:width] = sum_j A[r,j] * G[j, 0:width]   (plain CSR x dense; used for
  * k-hop ACM-SGC chains -- ACM-Pytorch/utils.py:631-637 -- and by tests).
  */
+/* Narrow operands (width <= 8): when the rows of G are 16-byte aligned (8-byte for width <= 2) and ldg is at least the
+ * next of 2 / 4 / 8 above `width`, a row is fetched as that whole block -- G must cover n_cols x ldg floats. */
 int acm_spmm(const acm_csr_t* a, const float* G, int64_t ldg, int width,
              float* Y, int64_t ldy, void* workspace, size_t workspace_bytes,
              acm_stream_t stream);
