@@ -1194,6 +1194,18 @@ __device__ __forceinline__ void bwd_local_block_reduce(ParamAcc<L>& pa, const L&
 #pragma unroll
         for (int q = 0; q < 16; ++q)
             if ((q >> 2) < k && (q & 3) < k) pa.dmix[q] = acm_group_sum<64>(pa.dmix[q]);
+    } else if (RPW == 8) {                       // eight lanes per row: lanes l, l ^ 8 (DPP row_ror:8), then the four 16-lane rows
+#pragma unroll
+        for (int c = 0; c < k; ++c)
+#pragma unroll
+            for (int i = 0; i < L::NV; ++i) {
+                pa.dv[c][i] = acm_cross_row_sum(pa.dv[c][i] + acm_dpp<0x128>(pa.dv[c][i]));
+                pa.dgam[c][i] = acm_cross_row_sum(pa.dgam[c][i] + acm_dpp<0x128>(pa.dgam[c][i]));
+                pa.dbet[c][i] = acm_cross_row_sum(pa.dbet[c][i] + acm_dpp<0x128>(pa.dbet[c][i]));
+            }
+#pragma unroll
+        for (int q = 0; q < 16; ++q)
+            if ((q >> 2) < k && (q & 3) < k) pa.dmix[q] = acm_cross_row_sum(pa.dmix[q] + acm_dpp<0x128>(pa.dmix[q]));
     } else if (RPW > 1) {
 #pragma unroll
         for (int c = 0; c < 4; ++c)
@@ -1496,11 +1508,70 @@ __global__ __launch_bounds__(256) void conv_tail_rows_kernel(acm_conv_fwd_t pf, 
     bwd_local_block_reduce<LaySerial<FP>, 64, K>(pa, lay, F, lds, k3_partial + (long)blockIdx.x * npg);
 }
 
+// The same for 4 < F <= 8 with EIGHT LANES PER ROW (LayPacked<8>: one column per lane, eight rows per wave): the
+// thread-per-row form above holds three channels x 8 columns of every stage in registers (169 VGPRs, 3 waves/SIMD) and
+// walks a row's head, loss and backward as one serial chain -- 50 us for the 169 k rows of the arXiv-year-shaped graph.
+// Here a lane reads back only what it wrote itself (its own logit, its own dlogit), the row-wise max / sums of the loss are
+// 8-lane DPP reductions.
+__device__ __forceinline__ float acm_group8_max(float v) {
+    v = fmaxf(v, acm_dpp<0xB1>(v));      // quad_perm [1,0,3,2]
+    v = fmaxf(v, acm_dpp<0x4E>(v));      // quad_perm [2,3,0,1]
+    return fmaxf(v, acm_dpp<0x141>(v));  // row_half_mirror
+}
+
+template <int NG>
+__global__ __launch_bounds__(256) void conv_tail_packed8_kernel(acm_conv_fwd_t pf, acm_loss_t pl, acm_conv_bwd_local_t pb,
+                                                                int n_rows, float* __restrict__ loss_partial,
+                                                                float* __restrict__ k3_partial) {
+    extern __shared__ float lds[];
+    __shared__ float red[256];
+    constexpr int K = NG + 1;
+    using L = LayPacked<8>;
+    const int F = pf.f_out;
+    const int npg = 3 * K * F + K * K;
+    const int lane = threadIdx.x & 63, col = lane & 7;
+    const int row = blockIdx.x * 32 + (threadIdx.x >> 3);
+    const bool active = row < n_rows;
+    const int rr = active ? row : 0;
+    const L lay{lane};
+    ParamAcc<L> pa;
+    pa.zero();
+    float term = 0.f;
+    {
+        float acc[NG][1];
+        const float* pr = pf.pre + (long)rr * pf.ld_pre;
+#pragma unroll
+        for (int c = 0; c < NG; ++c) acc[c][0] = (col < F) ? pr[c * F + col] : 0.f;
+        if (active) EpiFwd::apply<L, NG>(pf, rr, lay, F, acc);          // every lane of an active row takes part
+        // masked NLL of the row's logits: the lane's own logit back from memory (it wrote it), the rest by reduction
+        const bool mine = active && col < F;
+        const float z = mine ? pf.out[(long)rr * pf.ld_out + col] : -INFINITY;
+        const float wi = active ? pl.row_weight[rr] : 0.f;
+        const int yi = active ? (int)pl.labels[rr] : 0;
+        const float m = acm_group8_max(z);
+        const float e = mine ? expf(z - m) : 0.f;
+        const float ssum = acm_group_sum<8>(e);
+        const float zy = acm_group_sum<8>((mine && col == yi) ? z : 0.f);
+        if (mine) pl.dlogits[(long)rr * pl.ld_dlogits + col] = (wi == 0.f) ? 0.f : wi * (e / ssum - (col == yi ? 1.f : 0.f));
+        if (active && col == 0 && wi != 0.f) term = wi * (m + logf(ssum) - zy);
+        conv_bwd_row<L, K>(pb, rr, active, lay, pa);
+    }
+    red[threadIdx.x] = term;
+    __syncthreads();
+    for (int m = 128; m >= 1; m >>= 1) {
+        if ((int)threadIdx.x < m) red[threadIdx.x] += red[threadIdx.x + m];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) loss_partial[blockIdx.x] = red[0];
+    bwd_local_block_reduce<L, 8, K>(pa, lay, F, lds, k3_partial + (long)blockIdx.x * npg);
+}
+
 extern "C" int acm_conv_fwd_tail_workspace_bytes(int64_t n_rows, int f_out, int n_channels, size_t* bytes) {
     ACM_REQUIRE(bytes, ACM_EINVAL, "acm_conv_fwd_tail_workspace_bytes: NULL argument");
     ACM_REQUIRE(n_rows >= 0 && f_out > 0 && f_out <= 8 && n_channels == 3, ACM_EUNSUPPORTED,
                 "acm_conv_fwd_tail: f_out %d n_channels %d (needs f_out <= 8, three channels)", f_out, n_channels);
-    const int64_t nblk = (n_rows + 255) / 256 > 0 ? (n_rows + 255) / 256 : 1;
+    const int64_t rows_per_block = f_out > 4 ? 32 : 256;         // 4 < F <= 8: eight lanes per row
+    const int64_t nblk = (n_rows + rows_per_block - 1) / rows_per_block > 0 ? (n_rows + rows_per_block - 1) / rows_per_block : 1;
     *bytes = (size_t)nblk * (size_t)(1 + 3 * n_channels * f_out + n_channels * n_channels) * sizeof(float);
     return ACM_OK;
 }
@@ -1540,13 +1611,16 @@ extern "C" int acm_conv_fwd_tail(const acm_csr_t* a, const acm_conv_fwd_t* p, co
     GatherSrc g = {{p->g_low, p->g_high, nullptr}, {p->ld_g_low, p->ld_g_high, 0}};
     st = launch_gather<2, EpiRaw>(a, g, F, *p, workspace, workspace_bytes, s, "acm_conv_fwd_tail", nullptr, false, true);
     if (st != ACM_OK) return st;
-    const int n = (int)a->n_rows, nblk = (n + 255) / 256;
+    const int FP = F <= 2 ? 2 : (F <= 4 ? 4 : 8);
+    const bool packed = FP == 8 && getenv("ACM_TAIL_SERIAL") == nullptr;
+    const int n = (int)a->n_rows, nblk = packed ? (n + 31) / 32 : (n + 255) / 256;
     const int npg = 3 * k * F + k * k;
     float* loss_partial = (float*)tail_workspace;
     float* k3_partial = loss_partial + nblk;
     const size_t lds = (size_t)4 * npg * sizeof(float);
-    const int FP = F <= 2 ? 2 : (F <= 4 ? 4 : 8);
-    if (FP == 2)
+    if (packed)
+        hipLaunchKernelGGL((conv_tail_packed8_kernel<2>), dim3(nblk), dim3(256), lds, s, *p, *l, *b, n, loss_partial, k3_partial);
+    else if (FP == 2)
         hipLaunchKernelGGL((conv_tail_rows_kernel<2, 2>), dim3(nblk), dim3(256), lds, s, *p, *l, *b, n, loss_partial, k3_partial);
     else if (FP == 4)
         hipLaunchKernelGGL((conv_tail_rows_kernel<4, 2>), dim3(nblk), dim3(256), lds, s, *p, *l, *b, n, loss_partial, k3_partial);
