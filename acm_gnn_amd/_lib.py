@@ -14,7 +14,7 @@ c_i32p = C.POINTER(C.c_int32)
 
 ACM_OK = 0
 STATUS_NAMES = {1: "ACM_EINVAL", 2: "ACM_ESHAPE", 3: "ACM_EHIP", 4: "ACM_EUNSUPPORTED", 5: "ACM_ENOMEM"}
-ABI_VERSION = 18
+ABI_VERSION = 19
 
 # every symbol include/acm_hip.h declares
 EXPORTED_SYMBOLS = (
@@ -30,7 +30,7 @@ EXPORTED_SYMBOLS = (
 
 class Dropout(C.Structure):
     _fields_ = [("p", C.c_float), ("tag", C.c_int32), ("seed", C.c_uint64), ("step", C.c_void_p),
-                ("row_offset", C.c_int64)]
+                ("row_offset", C.c_int64), ("step_offset", C.c_int64)]
 
 
 class CsrInfo(C.Structure):
@@ -114,7 +114,8 @@ class ConvAggFwd(C.Structure):
                 ("next_w_low", C.c_void_p), ("next_w_high", C.c_void_p), ("next_w_mlp", C.c_void_p), ("next_ld_w", C.c_int64),
                 ("next_f", C.c_int32), ("next_relu", C.c_int32),
                 ("next_zlh", C.c_void_p), ("ld_next_zlh", C.c_int64), ("next_zi", C.c_void_p), ("ld_next_zi", C.c_int64),
-                ("agg_given", C.c_int32), ("reserved", C.c_int32)]
+                ("agg_given", C.c_int32), ("reserved", C.c_int32),
+                ("agg_copy", C.c_void_p), ("ld_agg_copy", C.c_int64), ("xs_copy", C.c_void_p), ("ld_xs_copy", C.c_int64)]
 
 
 class ConvAggBwd(C.Structure):
@@ -132,7 +133,9 @@ class ConvAggBwd(C.Structure):
                 ("g_struc", C.c_void_p), ("ld_g_struc", C.c_int64), ("g_struc_scale", C.c_void_p),
                 ("post_drop", Dropout), ("defer", C.c_void_p),
                 ("head_stats", C.c_void_p), ("ld_head_stats", C.c_int64),
-                ("out", C.c_void_p), ("ld_out", C.c_int64)]
+                ("out", C.c_void_p), ("ld_out", C.c_int64),
+                ("next_a", C.c_void_p), ("next_xg", C.c_void_p), ("ld_next_xg", C.c_int64),
+                ("next_row_scale", C.c_void_p), ("next_agg", C.c_void_p), ("ld_next_agg", C.c_int64)]
 
 
 class ConvAcmiiFwd(C.Structure):

@@ -215,7 +215,7 @@ struct AcmDropCtx {
 __device__ __forceinline__ AcmDropCtx acm_drop_ctx(const acm_dropout_t& d) {
     AcmDropCtx c;
     c.on = d.p > 0.f;
-    const unsigned long long step = c.on ? (unsigned long long)d.step[0] : 0ull;
+    const unsigned long long step = c.on ? (unsigned long long)(d.step[0] + d.step_offset) : 0ull;
     c.k0 = (unsigned)d.seed;
     c.k1 = (unsigned)(d.seed >> 32);
     c.c2 = (unsigned)step;

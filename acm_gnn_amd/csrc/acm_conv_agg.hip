@@ -227,8 +227,16 @@ __global__ __launch_bounds__(256) void agg_epilogue_kernel(acm_conv_agg_fwd_t p,
     for (int q = 0; q < K * K; ++q) mixm[q] = p.att_mix[q];
     const AcmDropCtx dc = acm_drop_ctx(p.post_drop);
     const int lane = threadIdx.x & 63;
-    for (int row = blockIdx.x * 16 + (threadIdx.x >> 4); row < n_rows; row += gridDim.x * 16)
+    const int m = lane & 15;
+    for (int row = blockIdx.x * 16 + (threadIdx.x >> 4); row < n_rows; row += gridDim.x * 16) {
         agg_fwd_row<FP, K>(p, wlds, hlds, scratch, mixm, row, lane, csr, partial, dc);
+        if (p.agg_copy && m < FP / 2) {           // the P | x rows just read (still parked in the group's scratch)
+            const float4 v = *reinterpret_cast<const float4*>(scratch + 4 * m);
+            float* dst = (m < FP / 4) ? p.agg_copy + (long)row * p.ld_agg_copy + 4 * m
+                                      : p.xs_copy + (long)row * p.ld_xs_copy + 4 * (m - FP / 4);
+            *reinterpret_cast<float4*>(dst) = v;
+        }
+    }
 }
 
 // The gather and the epilogue in ONE kernel (three channels, f_pad <= 8, 16 lanes per work item): the narrow gather's
@@ -535,11 +543,15 @@ __global__ __launch_bounds__(256) void agg_stream_kernel(acm_conv_agg_fwd_t p, S
     // issue order of the steady state (rows, ids, rows, ids): the counted waits of the loop are derived from it
     acm_i32x4 q0, q1;
     {
+        // (scheduling barriers: see stream_gather_role -- the loop's counted waits assume this issue order)
         const acm_i32x4 j0 = ACM_IDS(ioff), j1 = ACM_IDS(ioff + 512);
+        __builtin_amdgcn_sched_barrier(0);
         ACM_ISSUE(za, j0);
         q0 = ACM_IDS(ioff + 1024);
+        __builtin_amdgcn_sched_barrier(0);
         ACM_ISSUE(zb, j1);
         q1 = ACM_IDS(ioff + 1536);
+        __builtin_amdgcn_sched_barrier(0);
     }
     ioff += 2048;
     acm_f32x4 acc = {0.f, 0.f, 0.f, 0.f};
@@ -626,6 +638,125 @@ __global__ __launch_bounds__(256) void agg_stream_kernel(acm_conv_agg_fwd_t p, S
 #undef ACM_IDS
 }
 
+// ---------------------------------------------------------------- the gather alone, as a ROLE of another kernel
+// One wave's share of  agg = row_scale * (A xg)  over the id streams (32-byte rows, pattern-only operator): the loop of
+// agg_stream_kernel without the row-local stage.  acm_conv_agg_bwd runs it in two extra waves per workgroup for the NEXT
+// step's first layer (acm_conv_agg_bwd_t.next_agg): the backward's waves keep the vector unit busy, these keep the memory
+// system busy, and a kernel of each kind on two streams would not share the CUs.
+struct GatherRole {
+    StreamView sv;
+    const float* xg;
+    unsigned xg_bytes;
+    const float* row_scale;
+    float* agg;
+    long ld_agg;
+    int roles;               // 3: both; 1: backward only, 2: gather only (ACM_AGG_BWD_ROLES: measurements)
+};
+
+__device__ __forceinline__ void stream_gather_role(const GatherRole& gr, const int W) {
+    const StreamView& sv = gr.sv;
+    const int lane = threadIdx.x & 63, g = lane >> 4, gl = lane & 15, e = gl >> 1, h = gl & 1;
+    if (W >= sv.n_waves) return;
+    int s = sv.waves[W * 4 + 0];
+    const int s_end = sv.waves[W * 4 + 1];
+    if (s >= s_end) return;
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(gr.xg), 0, gr.xg_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t ri = __builtin_amdgcn_make_buffer_rsrc(const_cast<int32_t*>(sv.ids), 0, sv.ids_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rp = __builtin_amdgcn_make_buffer_rsrc(sv.slots, 0, sv.slots_bytes, 0x00020000);
+    int ioff = sv.waves[W * 4 + 2] * 512 + (g * 8 + e) * 16;
+    const int hoff = h * 16;
+    acm_f32x4 za[4], zb[4];
+#define ACM_ISSUE(Z, J)                                                                                         \
+    do {                                                                                                        \
+        Z[0] = __builtin_bit_cast(acm_f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, (J).x * 32 + hoff, 0, 0)); \
+        Z[1] = __builtin_bit_cast(acm_f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, (J).y * 32 + hoff, 0, 0)); \
+        Z[2] = __builtin_bit_cast(acm_f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, (J).z * 32 + hoff, 0, 0)); \
+        Z[3] = __builtin_bit_cast(acm_f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, (J).w * 32 + hoff, 0, 0)); \
+    } while (0)
+#define ACM_IDS(OFF) __builtin_bit_cast(acm_i32x4, __builtin_amdgcn_raw_buffer_load_b128(ri, (OFF), 0, 0))
+    // slice descriptors {row, slot, steps, -} per group, requested a slice ahead (as the row scale of the slice's rows)
+    const acm_i32x4* items = reinterpret_cast<const acm_i32x4*>(sv.items);
+    acm_i32x4 item = items[s * 4 + g];
+    int rem = __builtin_amdgcn_readfirstlane(item.z);
+    float rs_cur = gr.row_scale ? gr.row_scale[item.x >= 0 ? item.x : 0] : 1.f;
+    acm_i32x4 item_next = items[(s + 1) * 4 + g];
+    acm_i32x4 q0, q1;
+    {
+        // (scheduling barriers: the loop's counted waits assume exactly this issue order -- za, ids, zb, ids; if the
+        // scheduler swaps the two independent row groups here, the loop head must wait for everything, every time)
+        const acm_i32x4 j0 = ACM_IDS(ioff), j1 = ACM_IDS(ioff + 512);
+        __builtin_amdgcn_sched_barrier(0);
+        ACM_ISSUE(za, j0);
+        q0 = ACM_IDS(ioff + 1024);
+        __builtin_amdgcn_sched_barrier(0);
+        ACM_ISSUE(zb, j1);
+        q1 = ACM_IDS(ioff + 1536);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    ioff += 2048;
+    acm_f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    auto finish = [&]() __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            acc[i] += acm_dpp<0x4E>(acc[i]);     // quad_perm [2,3,0,1]
+            acc[i] += acm_dpp<0x124>(acc[i]);    // row_ror:4
+            acc[i] += acm_dpp<0x128>(acc[i]);    // row_ror:8
+        }
+        const int slot = item.y;
+        bool active = item.x >= 0 && slot < 0;
+        const int row = item.x >= 0 ? item.x : 0;
+        if (__builtin_amdgcn_ballot_w64(slot >= 0) != 0ull) {      // some group holds a piece of a long row
+            if (slot >= 0) {
+                const int li = sv.long_index[row];
+                const AcmLongRow lr = sv.long_rows[li];
+                if (gl < 2)
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(acm_i32x4, acc), rp, slot * 32 + hoff, 0, /*sc1*/ 16);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                int old = 0;
+                if (gl == 0) old = __hip_atomic_fetch_add(sv.counters + li, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                old = acm_row_bcast(old, 0);
+                if (old == lr.slot_end - lr.slot_begin - 1) {      // every other piece has arrived
+                    if (gl == 0) __hip_atomic_store(sv.counters + li, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    acm_f32x4 tot = {0.f, 0.f, 0.f, 0.f};
+                    for (int q = lr.slot_begin + e; q < lr.slot_end; q += 8)
+                        tot += __builtin_bit_cast(acm_f32x4, __builtin_amdgcn_raw_buffer_load_b128(rp, q * 32 + hoff, 0, /*sc1*/ 16));
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        tot[i] += acm_dpp<0x4E>(tot[i]);
+                        tot[i] += acm_dpp<0x124>(tot[i]);
+                        tot[i] += acm_dpp<0x128>(tot[i]);
+                    }
+                    acc = tot;
+                    active = true;
+                }
+            }
+        }
+        if (active && gl < 2) *reinterpret_cast<acm_f32x4*>(gr.agg + (long)row * gr.ld_agg + 4 * h) = rs_cur * acc;
+        acc = acm_f32x4{0.f, 0.f, 0.f, 0.f};
+        ++s;
+        rem = s < s_end ? __builtin_amdgcn_readfirstlane(item_next.z) : 0x7fffffff;
+        item = item_next;
+        item_next = items[(s + 1) * 4 + g];
+        rs_cur = gr.row_scale ? gr.row_scale[item.x >= 0 ? item.x : 0] : 1.f;
+    };
+#define ACM_STEP(Z)                                  \
+    do {                                             \
+        acc += (Z[0] + Z[1]) + (Z[2] + Z[3]);        \
+        ACM_ISSUE(Z, q0);                            \
+        q0 = q1;                                     \
+        q1 = ACM_IDS(ioff);                          \
+        ioff += 512;                                 \
+        if (--rem == 0) finish();                    \
+    } while (0)
+    for (int t = sv.waves[W * 4 + 3]; t > 0; t -= 2) {
+        ACM_STEP(za);
+        ACM_STEP(zb);
+    }
+#undef ACM_STEP
+#undef ACM_ISSUE
+#undef ACM_IDS
+}
+
 // ---------------------------------------------------------------- backward
 // flat parameter-gradient vector: [dW_low f_in*F][dW_high][dW_mlp][dv 3F][dgamma 3F][dbeta 3F][dmix 9]
 //
@@ -641,17 +772,30 @@ __global__ __launch_bounds__(256) void agg_stream_kernel(acm_conv_agg_fwd_t p, S
 // (H, mean, rstd), and hands each channel's G straight to the MFMAs.  att_vec / LayerNorm
 // gamma, beta sit in LDS next to the weights ([array][c][m][i], one ds_read_b128 per use).
 // FULL: f_out == 64 (the reference's hidden width), every column guard `m + 16 i < F` folds away at compile time.
-template <int FP, int K, bool FULL>
-__global__ __launch_bounds__(256, 2) void agg_bwd_kernel(acm_conv_agg_bwd_t p, int n_rows, float* __restrict__ partial) {
+template <int FP, int K, bool FULL, bool GATHER>
+__device__ __forceinline__ void agg_bwd_body(const acm_conv_agg_bwd_t& p, int n_rows, float* __restrict__ partial, const GatherRole* gr) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, m = lane & 15, g = lane >> 4;
+    // GATHER: one workgroup of twelve waves per CU -- the hardware deals a workgroup's waves round-robin over the four
+    // SIMDs, so each SIMD holds two backward waves and one gather wave (two six-wave workgroups per CU do not both fit:
+    // the second one's waves land on the SIMDs the first one filled)
+    constexpr int BW = GATHER ? 8 : 4;            // backward waves per workgroup
+    if (GATHER && wv >= BW) {                     // waves 8..11: the next step's input gather; same barrier count as below
+        __syncthreads();
+        if (gr->roles & 2) stream_gather_role(*gr, __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (wv - BW)));
+        __syncthreads();
+        __syncthreads();
+        return;
+    }
     const int F = FULL ? 64 : p.f_out, f_in = p.f_in;
     const int npg = 3 * f_in * F + 3 * K * F + K * K;
     float* wlds = lds;                           // 3 * FP * 64 floats
     float* hlds = lds + 3 * FP * 64;             // 3 * K * 64 floats
     float* scratch = hlds + 3 * K * 64 + (threadIdx.x >> 4) * 2 * FP;   // per-group P | x; all dead after the row loop
-    stage_weights<FP>(wlds, p.w_low, p.w_high, p.w_mlp, p.ld_w, f_in, F);
-    stage_head_params<K>(hlds, p.att_vec, p.ln_weight, p.ln_bias, p.layernorm, F);
+    if (wv < 4) {                                 // (the staging loops stride by 256 threads)
+        stage_weights<FP>(wlds, p.w_low, p.w_high, p.w_mlp, p.ld_w, f_in, F);
+        stage_head_params<K>(hlds, p.att_vec, p.ln_weight, p.ln_bias, p.layernorm, F);
+    }
     __syncthreads();
     f32x4 acc[3][4];
 #pragma unroll
@@ -673,7 +817,8 @@ __global__ __launch_bounds__(256, 2) void agg_bwd_kernel(acm_conv_agg_bwd_t p, i
     const bool out_mask = p.out != nullptr && p.post_relu && !p.post_scale;
     const float post_gain = p.post_drop.p > 0.f ? acm_drop_ctx(p.post_drop).inv_keep : 1.f;
 
-    for (int r0 = (blockIdx.x * 4 + wv) * 4; r0 < n_rows; r0 += gridDim.x * 16) {
+    const int n_rows_bwd = (GATHER && !(gr->roles & 1)) ? 0 : n_rows;
+    for (int r0 = (blockIdx.x * BW + wv) * 4; r0 < n_rows_bwd; r0 += gridDim.x * BW * 4) {
         const int row = r0 + g;
         const bool active = row < n_rows;
         const long rr = active ? row : 0;
@@ -782,10 +927,23 @@ __global__ __launch_bounds__(256, 2) void agg_bwd_kernel(acm_conv_agg_bwd_t p, i
     __syncthreads();
     // the slab is stored in groups of 32 parameters, partial[q / 32][block][q % 32] (acm_reduce_seg_t.elem_stride): whole
     // 128-byte lines here, and the second phase reads one line per block and group instead of one float per line
-    for (int q = threadIdx.x; q < npg; q += 256)
-        partial[((long)(q >> 5) * gridDim.x + blockIdx.x) * 32 + (q & 31)] = (lds[q] + lds[npg + q]) + (lds[2 * npg + q] + lds[3 * npg + q]);
+    for (int q = threadIdx.x; q < npg; q += BW * 64) {
+        float v = (lds[q] + lds[npg + q]) + (lds[2 * npg + q] + lds[3 * npg + q]);
+        if (BW == 8) v += (lds[4 * npg + q] + lds[5 * npg + q]) + (lds[6 * npg + q] + lds[7 * npg + q]);
+        partial[((long)(q >> 5) * gridDim.x + blockIdx.x) * 32 + (q & 31)] = v;
+    }
 }
 
+template <int FP, int K, bool FULL>
+__global__ __launch_bounds__(256, 2) void agg_bwd_kernel(acm_conv_agg_bwd_t p, int n_rows, float* __restrict__ partial) {
+    agg_bwd_body<FP, K, FULL, false>(p, n_rows, partial, nullptr);
+}
+// twelve waves: eight for the backward, four for the next step's gather; one workgroup (3 waves/SIMD) per CU
+__global__ __launch_bounds__(768) __attribute__((amdgpu_waves_per_eu(3, 3))) void agg_bwd_gather_kernel(acm_conv_agg_bwd_t p, int n_rows,
+                                                                                                  float* __restrict__ partial,
+                                                                                                  GatherRole gr) {
+    agg_bwd_body<8, 3, true, true>(p, n_rows, partial, &gr);
+}
 int agg_pad(int f_in) { return f_in <= 4 ? 4 : (f_in <= 8 ? 8 : 16); }
 
 // Persistent grid of agg_bwd_kernel: as many workgroups as stay resident.  Three channels: 151 VGPRs, three workgroups
@@ -827,6 +985,22 @@ int check_common(const P* p, const char* who) {
     return ACM_OK;
 }
 
+StreamView stream_view(const AcmStreams* t) {
+    StreamView sv;
+    sv.ids = t->ids;
+    sv.waves = t->waves;
+    sv.items = t->items;
+    sv.long_rows = t->long_rows;
+    sv.long_index = t->long_index;
+    sv.counters = t->counters;
+    sv.slots = t->slots;
+    sv.ids_bytes = (unsigned)((t->total_steps + ACM_STREAM_PAD_STEPS) * 512);
+    sv.slots_bytes = (unsigned)(t->n_slots * 32);
+    sv.n_waves = t->n_waves;
+    sv.probe = 0;
+    return sv;
+}
+
 }  // namespace
 
 // The requested next-layer projection for the paths whose epilogue does not carry it: a launch of its own.
@@ -861,6 +1035,10 @@ extern "C" int acm_conv_agg_fwd(const acm_csr_t* a, const acm_conv_agg_fwd_t* p,
     hipStream_t s = (hipStream_t)stream;
     bool next_done = false;
     ACM_REQUIRE(!p->agg_given || p->n_channels == 3, ACM_EUNSUPPORTED, "acm_conv_agg_fwd: agg_given needs three channels");
+    ACM_REQUIRE(!p->agg_copy || (p->agg_given && p->xs_copy && ((uintptr_t)p->agg_copy) % 16 == 0 && ((uintptr_t)p->xs_copy) % 16 == 0 &&
+                                 (p->ld_agg_copy * 4) % 16 == 0 && (p->ld_xs_copy * 4) % 16 == 0 && p->ld_agg_copy >= p->f_pad &&
+                                 p->ld_xs_copy >= p->f_pad && p->agg_copy != p->agg && p->xs_copy != p->xs), ACM_EINVAL,
+                "acm_conv_agg_fwd: agg_copy / xs_copy need agg_given, 16-byte aligned rows of f_pad floats, no aliasing");
     // (0) fused form: gather + epilogue in one kernel (long rows included)
     if (!p->agg_given) {
         const double avg = (double)a->nnz / (double)(a->n_rows > 0 ? a->n_rows : 1);
@@ -873,22 +1051,11 @@ extern "C" int acm_conv_agg_fwd(const acm_csr_t* a, const acm_conv_agg_fwd_t* p,
             const int64_t table_bytes = a->n_cols * 32;
             if (t && p->f_pad == 8 && p->ld_xg == 8 && a->vals == nullptr && table_bytes < (int64_t)0xFFFFFFE0u &&
                 getenv("ACM_AGG_NO_STREAM") == nullptr) {
-                StreamView sv;
-                sv.ids = t->ids;
-                sv.waves = t->waves;
-                sv.items = t->items;
-                sv.long_rows = t->long_rows;
-                sv.long_index = t->long_index;
-                sv.counters = t->counters;
-                sv.slots = t->slots;
-                sv.ids_bytes = (unsigned)((t->total_steps + ACM_STREAM_PAD_STEPS) * 512);
-                sv.slots_bytes = (unsigned)(t->n_slots * 32);
-                sv.n_waves = t->n_waves;
+                StreamView sv = stream_view(t);
                 sv.probe = getenv("ACM_STREAM_PROBE") ? atoi(getenv("ACM_STREAM_PROBE")) : 0;
                 const int grid = t->n_waves / 4;
-                // the arrival counters reset themselves (the last piece of a row stores 0), but a launch that died half-way
-                // would leave them poisoned for every later one: clear them ahead of the kernel
-                if (t->n_long) ACM_CHECK_HIP(hipMemsetAsync(t->counters, 0, (size_t)t->n_long * sizeof(int32_t), s));
+                // (the arrival counters reset themselves -- the last piece of a row stores 0 -- and start at zero; a
+                // hipMemsetAsync ahead of every launch would cost two fill kernels, ~10 us in a replayed graph)
                 const bool nt = getenv("ACM_AGG_NT") != nullptr;
                 if (p->f_out == 64 && nt)
                     hipLaunchKernelGGL((agg_stream_kernel<true, true>), dim3(grid), dim3(256), 0, s, *p, sv, (unsigned)table_bytes);
@@ -944,7 +1111,14 @@ extern "C" int acm_conv_agg_fwd(const acm_csr_t* a, const acm_conv_agg_fwd_t* p,
     }
     // (2) projections + head, row-local
     int grid = (int)((a->n_rows + 15) / 16);
-    if (grid > 2048) grid = 2048;
+    {
+        int cap = 2048;
+        if (const char* env = getenv("ACM_AGG_EPI_BLOCKS")) {
+            const int v = atoi(env);
+            if (v >= 1) cap = v;
+        }
+        if (grid > cap) grid = cap;
+    }
     const CsrView cv = acm_view(a);
 #define ACM_EPI(FPv)                                                                                           \
     do {                                                                                                       \
@@ -998,9 +1172,40 @@ extern "C" int acm_conv_agg_bwd(int64_t n_rows, const acm_conv_agg_bwd_t* p, voi
                  lds_s = (size_t)4 * npg * sizeof(float);
     const size_t lds = lds_w > lds_s ? lds_w : lds_s;
     ACM_REQUIRE(lds <= 64 * 1024, ACM_EUNSUPPORTED, "acm_conv_agg_bwd: %zu B of LDS needed", lds);
-    const int nblk = agg_bwd_blocks(n_rows, p->n_channels, lds);
+    int nblk = agg_bwd_blocks(n_rows, p->n_channels, lds);
     hipStream_t s = (hipStream_t)stream;
     float* partial = (float*)workspace;
+    if (p->next_agg) {                            // the next step's input gather rides along (header: acm_conv_agg_bwd_t.next_agg)
+        const acm_csr_t* na = p->next_a;
+        ACM_REQUIRE(na && p->next_xg, ACM_EINVAL, "acm_conv_agg_bwd: next_agg without next_a / next_xg");
+        ACM_REQUIRE(K == 3 && p->f_pad == 8 && p->f_out == 64, ACM_EUNSUPPORTED,
+                    "acm_conv_agg_bwd: the carried gather needs three channels, f_pad 8 and f_out 64");
+        const AcmStreams* t = na->streams;
+        ACM_REQUIRE(t && t->n_waves >= 4 && t->n_waves % 4 == 0 && t->n_waves <= 1024, ACM_EINVAL,
+                    "acm_conv_agg_bwd: next_a needs id streams for a multiple of four waves <= 1024 (acm_csr_build_streams)");
+        ACM_REQUIRE(na->vals == nullptr && p->ld_next_xg == 8 && ((uintptr_t)p->next_xg) % 16 == 0 &&
+                        na->n_cols * 32 < (int64_t)0xFFFFFFE0u && ((uintptr_t)p->next_agg) % 16 == 0 &&
+                        (p->ld_next_agg * 4) % 16 == 0 && p->ld_next_agg >= 8, ACM_EINVAL,
+                    "acm_conv_agg_bwd: carried gather: pattern-only operator, 32-byte rows of next_xg, 16-byte aligned next_agg");
+        ACM_REQUIRE(p->next_agg != p->agg && p->next_xg != p->xs, ACM_EINVAL, "acm_conv_agg_bwd: next_agg / next_xg alias agg / xs");
+        GatherRole gr;
+        gr.sv = stream_view(t);
+        gr.xg = p->next_xg;
+        gr.xg_bytes = (unsigned)(na->n_cols * 32);
+        gr.row_scale = p->next_row_scale;
+        gr.agg = p->next_agg;
+        gr.ld_agg = (long)p->ld_next_agg;
+        gr.roles = getenv("ACM_AGG_BWD_ROLES") ? atoi(getenv("ACM_AGG_BWD_ROLES")) : 3;
+        ACM_REQUIRE(t->n_waves / 4 <= agg_bwd_blocks(n_rows, 3, 0), ACM_EUNSUPPORTED,
+                    "acm_conv_agg_bwd: %d stream waves for %lld rows (the workspace holds one slab per 16 rows)", t->n_waves, (long long)n_rows);
+        nblk = t->n_waves / 4;
+        const size_t lds_g = std::max(((size_t)3 * 8 * 64 + 3 * K * 64 + 64 * 8) * sizeof(float), (size_t)8 * npg * sizeof(float));
+        ACM_REQUIRE(lds_g <= 64 * 1024, ACM_EUNSUPPORTED, "acm_conv_agg_bwd: %zu B of LDS needed", lds_g);
+        hipLaunchKernelGGL(agg_bwd_gather_kernel, dim3(nblk), dim3(768), lds_g, s, *p, (int)n_rows, partial, gr);
+        ACM_CHECK_HIP(hipGetLastError());
+        const acm_reduce_seg_t seg = {partial, nblk, 32, 0, npg, p->d_params, npg, 0, 0, 0, nblk * 32, 0};
+        return acm_reduce_emit(p->defer, &seg, 1, s);
+    }
 #define ACM_BWDK(FPv)                                                                                                  \
     do {                                                                                                              \
         if (K == 3 && p->f_out == 64)                                                                                  \

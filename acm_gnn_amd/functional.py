@@ -203,6 +203,103 @@ _PRE_PROJ = None
 # eval-mode, no-grad call; an aggregate-first forward then reuses P = A_low X from the holder (acm_conv_agg_fwd_t.agg_given:
 # the gather is skipped) or leaves the P it computed there for the next pass.  The layer decides when the holder is valid.
 _AGG_CACHE = None
+# Input pipelining of a training loop (InputPipeline below; acm_conv_agg_bwd_t.next_agg): the loop sets _PIPE around its
+# forward + backward; models.GCN takes the step's dropped input from it, the first layer's aggregate-first forward its
+# P = A_low dropout(x) (acm_conv_agg_fwd_t.agg_given), and that layer's backward carries the gather for the next step.
+_PIPE = None
+
+
+class InputPipeline:
+    """The first layer's input aggregation P_t = A_low dropout_t(x), computed one optimizer step AHEAD inside the layer's
+    own backward.  x is constant and the mask of step t + 1 is a function of the step counter (acm_dropout_t.step_offset),
+    so P_{t+1} depends on nothing step t computes; the row-local backward kernel of the aggregate-first layer is bound
+    by its vector instructions and leaves the memory system idle, the narrow gather is bound by memory latency -- in one
+    kernel (two extra waves per workgroup) they overlap, as two kernels they do not.
+
+    Buffers (fixed addresses: a captured graph keeps them): ``filled`` = [dropout(x) padded to 8 columns | P] for the step
+    about to run, ``saved`` = the copy of both that the forward's row-local kernel leaves for the backward
+    (acm_conv_agg_fwd_t.agg_copy / xs_copy: it reads those rows anyway).  A step runs
+    forward (reads filled, writes saved) -> make_next() (filled table <- dropout_{t+1}(x)) -> backward (reads saved;
+    its gather waves read the filled table and write the filled P) -> optimizer -> end_step().
+    prime() fills ``filled`` for the current counter value; it must be called again whenever the counter is set from
+    outside (train.TrainStep does after its warm-up)."""
+
+    def __init__(self, ops, x, p, state, tag=0):
+        n = x.shape[0]
+        self.ops, self.x, self.p, self.state, self.tag = ops, x, float(p), state, int(tag)
+        self.filled = torch.zeros(2, n, 8, dtype=_F32, device=x.device)
+        self.saved = torch.zeros(2, n, 8, dtype=_F32, device=x.device)
+        self.primed = False
+        self.next_table_ready = False
+        self.next_agg_ready = False
+
+    @staticmethod
+    def eligible(model, ops, x):
+        """Conditions under which train.TrainStep pipelines: the twitch-class configuration -- a dense input of 5..8
+        features into a three-channel ACM layer of width 64, one device, pattern-only operator, counter-based dropout."""
+        from .graph import FilterOperators
+        if os.environ.get("ACM_PIPELINE", "1") == "0" or not isinstance(ops, FilterOperators) or not isinstance(x, torch.Tensor):
+            return False
+        if getattr(model, "model_type", None) not in ("acmgcn", "acmgcnp") or getattr(model, "structure_info", 0):
+            return False
+        gcns = getattr(model, "gcns", None)
+        if not gcns or len(gcns) != 2 or not getattr(model, "fused_dropout", False) or getattr(model, "dropout", 0) <= 0:
+            return False
+        l0 = gcns[0]
+        try:
+            cfg = l0._config()
+            f_in, f = l0.weight_low.shape
+        except AttributeError:
+            return False
+        if cfg.relu_before or cfg.n_channels != 3 or f != 64 or not 4 < f_in <= 8 or x.dim() != 2 or x.shape[1] != f_in:
+            return False
+        if ops.sharded or not ops.implicit or getattr(ops, "general", False) or int(getattr(ops, "hops", 1)) != 1:
+            return False
+        if x.dtype != _F32 or x.device != l0.weight_low.device or x.requires_grad:
+            return False
+        n, nnz = ops.low.n_rows, ops.low.nnz
+        min_rows = int(os.environ.get("ACM_PIPELINE_MIN_ROWS", 16 * 512))          # below: launch-bound, nothing to hide
+        if n != x.shape[0] or n < max(min_rows, 32) or not 12.0 * n < nnz <= 160.0 * n:    # the regime of the fused forward
+            return False
+        if x.device.type == "cuda" and torch.cuda.is_current_stream_capturing():
+            return False
+        # four gather waves per workgroup of the backward, one workgroup per 16 rows at most (its workspace), 256 at most
+        if not ops.low.build_streams(n_waves=max(4, min(1024, 4 * ((n + 15) // 16)))):
+            return False
+        return ops.low.stream_waves % 4 == 0 and 4 <= ops.low.stream_waves <= min(1024, 4 * ((n + 15) // 16))
+
+    def table(self):
+        return self.filled[0]
+
+    def agg(self):
+        return self.filled[1]
+
+    def _drop_into(self, dst, step_offset):
+        d = self.state.spec(self.p, self.tag, 0)
+        d.step_offset = int(step_offset)
+        n, c = self.x.shape
+        with _device_ctx(self.x.device), _Timed(f"dropout/{n}x{c}"):
+            st = _lib.load().acm_dropout(n, c, _vp(self.x), self.x.stride(0), _vp(dst), dst.stride(0), 8, C.byref(d), _stream())
+        _lib.check(st, "acm_dropout")
+
+    def prime(self):
+        self._drop_into(self.filled[0], 0)
+        spmm(self.ops.low, self.filled[0], out=self.filled[1], row_scale=self.ops.row_scale)
+        self.primed = True
+        self.next_table_ready = self.next_agg_ready = False
+
+    def make_next(self):
+        """Between the forward and the backward: the next step's dropped input replaces this step's (the forward has
+        left its copy in ``saved``)."""
+        self._drop_into(self.filled[0], 1)
+        self.next_table_ready = True
+
+    def end_step(self):
+        """After the optimizer step (which advanced the counter).  If the layer's backward did not carry the gather (it
+        fell back to another path), ``filled`` is stale: prime() again before the next forward."""
+        if not (self.next_table_ready and self.next_agg_ready):
+            self.primed = False
+        self.next_table_ready = self.next_agg_ready = False
 
 
 def _next_proj_request(f, dev):
@@ -892,6 +989,13 @@ class AcmConvFunction(torch.autograd.Function):
             agg_given = agg_holder.get("agg") if agg_holder is not None else None
             if agg_given is not None and tuple(agg_given.shape) != (n, fp):
                 agg_given = None
+            # a training loop's input pipeline (InputPipeline): P for this step came out of the previous step's backward
+            pipe = _PIPE
+            ctx.pipe = None
+            if (pipe is not None and pipe.primed and ctx.agg_first and k == 3 and fp == 8 and f == 64 and ops is pipe.ops
+                    and xpad.data_ptr() == pipe.table().data_ptr() and agg_holder is None):     # (_PIPE is only set by a training step)
+                agg_given = pipe.agg()
+                ctx.pipe = pipe
             if agg_given is not None:
                 xg = xpad                             # not read: P = A_low X comes from the holder
             elif (pregathered is not None and pregathered[0].data_ptr() == xpad.data_ptr()
@@ -1023,6 +1127,9 @@ class AcmConvFunction(torch.autograd.Function):
             p.att_mix = mix.data_ptr()
             agg = agg_given if agg_given is not None else torch.empty(n, fp, dtype=_F32, device=dev)
             p.agg_given = int(agg_given is not None)
+            if ctx.pipe is not None:                  # the backward's operands: copies the row-local kernel leaves
+                p.agg_copy, p.ld_agg_copy = ctx.pipe.saved[1].data_ptr(), ctx.pipe.saved[1].stride(0)
+                p.xs_copy, p.ld_xs_copy = ctx.pipe.saved[0].data_ptr(), ctx.pipe.saved[0].stride(0)
             p.out, p.ld_out = out.data_ptr(), out.stride(0)
             p.agg, p.ld_agg = agg.data_ptr(), agg.stride(0)
             p.att = att.data_ptr()
@@ -1062,7 +1169,7 @@ class AcmConvFunction(torch.autograd.Function):
             if (not four and fp == 8 and xg.stride(0) == 8 and ops.implicit and not ops.low.stream_steps
                     and ops.low.want_streams() and not (dev.type == "cuda" and torch.cuda.is_current_stream_capturing())):
                 ops.low.build_streams()       # one-off: the id streams of the streamed kernel (never during a capture)
-            with _device_ctx(dev), _Timed(f"conv_agg_fwd/F{f}k{k}i{f_in}"):
+            with _device_ctx(dev), _Timed(f"conv_agg_{'epi' if agg_given is not None else 'fwd'}/F{f}k{k}i{f_in}"):
                 st = lib.acm_conv_agg_fwd(ops.low.handle, C.byref(p), _vp(ws), ws.numel() * 4, _stream())
             _lib.check(st, "acm_conv_agg_fwd")
             if agg_holder is not None and agg_given is None:
@@ -1074,6 +1181,8 @@ class AcmConvFunction(torch.autograd.Function):
             # with a fused ReLU the output itself records which elements the post-op let through: the backward reads it
             # instead of regenerating the dropout mask (no extra memory: the next layer keeps the same tensor alive)
             ctx.out_mask = bool(ctx.post_relu) and ctx.post_scale is None and os.environ.get("ACM_AGG_OUT_MASK", "1") != "0"
+            if ctx.pipe is not None:
+                xpad, agg = ctx.pipe.saved[0], ctx.pipe.saved[1]
             ctx.save_for_backward(xpad, agg, wl, wh, wm, mix, *vecs, *lnw, *lnb, *extra, *((out,) if ctx.out_mask else ()))
             ctx.mark_non_differentiable(att)
             return out, att
@@ -1359,9 +1468,18 @@ def _backward_agg(ctx, grad_out):
     _lib.check(lib.acm_conv_agg_bwd_workspace_bytes(n, f_in, f, C.byref(nbytes)))
     ws = torch.empty(max(nbytes.value // 4, 1), dtype=_F32, device=dev)
     q.defer = _defer_ptr()
-    with _device_ctx(dev), _Timed(f"conv_agg_bwd/F{f}k{k}i{f_in}"):
+    pipe = getattr(ctx, "pipe", None)
+    carry = pipe is not None and pipe.next_table_ready and not pipe.next_agg_ready
+    if carry:                                     # the next step's P = A_low dropout(x) rides this launch
+        q.next_a = ops.low.handle
+        q.next_xg, q.ld_next_xg = pipe.filled[0].data_ptr(), pipe.filled[0].stride(0)
+        q.next_row_scale = ops.row_scale.data_ptr()
+        q.next_agg, q.ld_next_agg = pipe.filled[1].data_ptr(), pipe.filled[1].stride(0)
+    with _device_ctx(dev), _Timed(f"conv_agg_bwd{'+gather' if carry else ''}/F{f}k{k}i{f_in}"):
         st = lib.acm_conv_agg_bwd(n, C.byref(q), _vp(ws), ws.numel() * 4, _stream())
     _lib.check(st, "acm_conv_agg_bwd")
+    if carry:
+        pipe.next_agg_ready = True
     if _DEFER is not None:
         _DEFER.hold(ws, [d_params])
     d_struc = None

@@ -117,6 +117,9 @@ class GCN(nn.Module):
                 xg = AF.dropout(ops.x_full, p, st, tag=0, pad_to=pad, row_offset=0)
                 x = xg[off:off + x.shape[0]]
                 ops._pregathered = (x, xg)
+            elif (AF._PIPE is not None and AF._PIPE.primed and AF._PIPE.ops is ops and AF._PIPE.state is st
+                    and AF._PIPE.x.data_ptr() == x.data_ptr() and AF._PIPE.x.shape == x.shape and torch.is_grad_enabled()):
+                x = AF._PIPE.table()          # dropout_t(x), drawn one step ahead (functional.InputPipeline)
             else:
                 x = AF.dropout(x, p, st, tag=0, pad_to=pad, row_offset=off)
             kw = {}

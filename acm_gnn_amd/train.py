@@ -43,7 +43,7 @@ def _capture_mode():
 
 class TrainStep:
     def __init__(self, model, optimizer, x, adj, labels, weights, adj_high=None, adj_un=None, use_graph=False,
-                 fused_dropout=None):
+                 fused_dropout=None, pipeline_input=None):
         self.model, self.opt = model, optimizer
         self.x, self.adj, self.adj_high, self.adj_un = x, adj, adj_high, adj_un
         self.labels, self.weights = labels, weights
@@ -77,6 +77,11 @@ class TrainStep:
             else:
                 self._manual_advance = True
         self._params = list(model.parameters())          # walked every step: module.parameters() costs 0.1 ms of host time
+        # the first layer's input aggregation one step ahead, inside its own backward (functional.InputPipeline)
+        self.pipe = None
+        if pipeline_input is not False and not self._manual_advance and getattr(model, "fused_dropout", False) \
+                and AF.InputPipeline.eligible(model, self.adj, self.x):
+            self.pipe = AF.InputPipeline(self.adj, self.x, model.dropout, model.dropout_state, tag=0)
         if use_graph:
             self._capture()
 
@@ -87,13 +92,28 @@ class TrainStep:
         must be the tensor the backward kernels wrote (autograd adopts it when ``.grad`` is None), not a copy taken
         before the flush -- otherwise deferral is switched off for good and the step is redone."""
         model = self.model
+        pipe = self.pipe
+        if pipe is not None and not pipe.primed:
+            pipe.prime()
         if not self._defer:
             loss, dz, out = self._forward_loss()
-            out.backward(dz)
+            if pipe is not None:
+                pipe.make_next()
+            AF._PIPE = pipe
+            try:
+                out.backward(dz)
+            finally:
+                AF._PIPE = None
             return loss
         with AF.deferred_reductions() as pending:
             loss, dz, out = self._forward_loss()
-            out.backward(dz)
+            if pipe is not None:
+                pipe.make_next()              # dropout_{t+1}(x): the operand of the gather the backward carries
+            AF._PIPE = pipe
+            try:
+                out.backward(dz)
+            finally:
+                AF._PIPE = None
             adopted = pending.all_adopted([loss] + [p.grad for p in self._params])
             pending.flush()
         if not adopted:
@@ -106,11 +126,15 @@ class TrainStep:
         """Forward and fused loss: (loss, dloss/dlogits, logits).  The model's output layer is asked to run its row
         phase, the loss and its own row-local backward as one kernel (AF.fused_loss_tail); when it does not qualify
         (wide output, structure channel, a wrapper around the output) the loss is its own launch."""
-        with AF.fused_loss_tail(self.labels, self.weights) as tail:
-            if self._permuted:
-                out = self.model(self.x, self.adj, self.adj_high, self.adj_un, rows_permuted=True)
-            else:
-                out = self.model(self.x, self.adj, self.adj_high, self.adj_un)
+        AF._PIPE = self.pipe
+        try:
+            with AF.fused_loss_tail(self.labels, self.weights) as tail:
+                if self._permuted:
+                    out = self.model(self.x, self.adj, self.adj_high, self.adj_un, rows_permuted=True)
+                else:
+                    out = self.model(self.x, self.adj, self.adj_high, self.adj_un)
+        finally:
+            AF._PIPE = None
         if tail.matches(out):
             return tail.loss, tail.dz, out
         loss, dz = AF.nll_loss_and_grad(out, self.labels, self.weights)   # = masked_nll(...).backward(), two launches less
@@ -124,6 +148,8 @@ class TrainStep:
         self.opt.step()
         if self._manual_advance:
             self.model.dropout_state.advance()
+        if self.pipe is not None:
+            self.pipe.end_step()
         return loss                 # never hand out the autograd graph: a live AccumulateGrad node pins its
                                     # stream and breaks a later graph capture
 
@@ -174,6 +200,9 @@ class TrainStep:
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         self._restore(snap)
+        if self.pipe is not None:
+            self.pipe.prime()                   # for the restored counter, outside the capture
+            torch.cuda.synchronize()
         self.graph = torch.cuda.CUDAGraph()
         self.model.train()
         self.opt.zero_grad(set_to_none=True)
@@ -182,6 +211,8 @@ class TrainStep:
             self.opt.step()
             if self._manual_advance:
                 self.model.dropout_state.advance()
+            if self.pipe is not None:
+                self.pipe.end_step()
             self.loss = loss
         del loss
 

@@ -77,7 +77,12 @@ def algorithmic_bytes(label, n, nnz, implicit=False):
         stats = 16 * k * n              # head_stats: mean | rstd | sigmoid | alpha per channel, written by the forward
         if kind == "conv_agg_fwd":      # graph + gathered X once + self X + out + agg + att + head_stats
             return 4 * (n + 1) + per_edge * nnz + per_row * n + 4 * n * fp * 2 + 4 * n * f + 4 * n * fp + 16 * n + stats
-        return 4 * n * (f + 2 * fp) + stats     # conv_agg_bwd: grad_out, agg, X, head_stats
+        if kind == "conv_agg_epi":      # the row-local stage alone (P given): agg + self X + out + att + head_stats
+            return 4 * n * fp * 2 + 4 * n * f + 16 * n + stats
+        bwd = 4 * n * (f + 2 * fp) + stats      # conv_agg_bwd: grad_out, agg, X, head_stats
+        if kind == "conv_agg_bwd+gather":       # + the next step's P = A_low dropout(x): graph, table once, P written
+            return bwd + 4 * (n + 1) + per_edge * nnz + per_row * n + 4 * n * fp * 2
+        return bwd
     if kind.startswith("gemm"):
         m, nn, k = (int(v) for v in shape.split("x"))
         return 4 * (m * k + k * nn + m * nn)

@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define ACM_ABI_VERSION 18
+#define ACM_ABI_VERSION 19
 
 typedef enum {
     ACM_OK = 0,
@@ -177,6 +177,7 @@ typedef struct {
     uint64_t seed;
     const int64_t* step;       /* device */
     int64_t  row_offset;       /* global index of local row 0 (a row shard draws the single-process mask) */
+    int64_t  step_offset;      /* added to *step: 1 draws the masks of the NEXT optimizer step (input pipelining)  */
 } acm_dropout_t;
 
 /* dst[r, c] = src[r, c] * keep(r, c) / (1 - p) for c < n_cols, 0 for n_cols <= c < dst_cols (row padding for the
@@ -513,6 +514,11 @@ typedef struct {
      * input wrote it (e.g. every evaluation pass over a static feature matrix after the first) -- so the gather is
      * skipped and only the row-local stage runs; xg is not read.                                                     */
     int32_t agg_given, reserved;
+    /* With agg_given: the row-local stage also stores the rows of `agg` and `xs` it read to agg_copy / xs_copy (NULL:
+     * off; rows of f_pad floats) -- the operands of this layer's backward when `agg` / `xs` themselves are the buffers
+     * an input pipeline refills before that backward runs (acm_conv_agg_bwd_t.next_agg).                             */
+    float* agg_copy; int64_t ld_agg_copy;
+    float* xs_copy;  int64_t ld_xs_copy;
 } acm_conv_agg_fwd_t;
 
 int acm_conv_agg_fwd(const acm_csr_t* a_low, const acm_conv_agg_fwd_t* p,
@@ -547,6 +553,19 @@ typedef struct {
                                            * post-op is undone by reading it -- out != 0 <=> the ReLU passed AND the dropout
                                            * kept the element (relu'(0) = 0 as in torch) -- instead of recomputing the mixed
                                            * row and regenerating the Philox mask (an eighth of the kernel's VALU work)  */
+    /* The NEXT step's input aggregation, carried by this launch (NULL next_agg: off).  This kernel is bound by its vector
+     * instructions and leaves the memory system idle; the narrow gather  next_agg = next_row_scale * (A_low next_xg)  of the
+     * next training step's first layer is bound by memory latency and depends on nothing this step computes (the input
+     * features are constant, the dropout mask a function of the step counter: acm_dropout_t.step_offset = 1).  With
+     * next_agg set, every workgroup is eight waves of the row-local backward and four waves that walk next_a's id streams
+     * (acm_csr_build_streams; the grid becomes stream_waves / 4 workgroups, one per CU); the next forward then runs with
+     * acm_conv_agg_fwd_t.agg_given.  Needs: three channels, f_pad = 8, f_out = 64, ld_next_xg = 8, a pattern-only next_a
+     * with streams built for a multiple of four waves <= 1024 (and <= n_rows / 4).  next_agg / next_xg must not alias
+     * agg / xs.                                                                                                        */
+    const acm_csr_t* next_a;
+    const float* next_xg; int64_t ld_next_xg;
+    const float* next_row_scale;
+    float* next_agg; int64_t ld_next_agg;
 } acm_conv_agg_bwd_t;
 
 int acm_conv_agg_bwd_workspace_bytes(int64_t n_rows, int f_in, int f_out, size_t* bytes);

@@ -465,3 +465,113 @@ extern "C" int sell_gather_q(int hub_rows, int wpb, const int* stream, const int
     LAUNCH_Q(false, 4) LAUNCH_Q(false, 16) LAUNCH_Q(true, 16) LAUNCH_Q(true, 8)
     return -1;
 }
+
+// (f) TWO ROLES IN ONE KERNEL: can a VALU-bound row-local kernel (the layer-1 backward agg_bwd, 151 VGPRs, 3 waves/SIMD,
+//     65 us) carry the memory-bound gather of the NEXT step's P = A dropout(X) (it does not depend on the parameter update)
+//     in extra waves of the same workgroups?  Two kernels on two streams do not share the CUs (scripts/probe_overlap.py);
+//     here waves 0..3 of a block run a dependent-FMA loop (`iters` x 16 FMAs: the stand-in for the backward's instruction
+//     stream), waves 4..4+GW-1 walk an id stream each (the pair form above, R steps of rows in flight).  80 KB of dynamic
+//     LDS per block keep two blocks on a CU, i.e. (4 + GW) * 2 waves per CU -- the occupancy the backward's registers allow.
+//     mode 1: VALU waves only, 2: gather waves only, 3: both.
+template <int R, int GW>
+__global__ __launch_bounds__((4 + GW) * 64) void roles_kernel(int mode, int iters, const int* __restrict__ stream,
+                                                              const int* __restrict__ wave_ptr, const int* __restrict__ wave_step,
+                                                              const int* __restrict__ desc, const float* __restrict__ x,
+                                                              unsigned x_bytes, float* __restrict__ out, float* __restrict__ sink) {
+    extern __shared__ float pad_lds[];
+    const int wv = threadIdx.x >> 6;
+    if (wv < 4) {
+        if (!(mode & 1)) return;
+        float a[16];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) a[k] = (float)(threadIdx.x + k) * 1e-3f;
+        const float c1 = 0.999f + 1e-9f * (float)blockIdx.x, c2 = 1e-4f;
+        for (int i = 0; i < iters; ++i) {
+#pragma unroll
+            for (int k = 0; k < 16; ++k) a[k] = __builtin_fmaf(a[k], c1, c2);
+        }
+        float s = 0.f;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) s += a[k];
+        if (s == 123.456f) sink[threadIdx.x] = s + pad_lds[threadIdx.x];
+        return;
+    }
+    if (!(mode & 2)) return;
+    constexpr int D = 2;
+    const int lane = threadIdx.x & 63, g = lane >> 4, gl = lane & 15, e = gl >> 1, h = gl & 1;
+    const int W = __builtin_amdgcn_readfirstlane(blockIdx.x * GW + (wv - 4));
+    int s = wave_ptr[W];
+    const int s_end = wave_ptr[W + 1];
+    if (s >= s_end) return;
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(x), 0, x_bytes, 0x00020000);
+    const i32x4* ids = reinterpret_cast<const i32x4*>(stream) + (long)wave_step[W] * 32 + (g * 8 + e);
+    i32x4 q[D];
+#pragma unroll
+    for (int d = 0; d < D; ++d) q[d] = ids[d * 32];
+    ids += D * 32;
+    const int hoff = h * 16;
+    int total = 0;
+    for (int t = s; t < s_end; ++t) total += desc[t * 8];
+    int rem = desc[s * 8];
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    f32x4 z[R][4];
+#pragma unroll
+    for (int r = 0; r < R - 1; ++r) {
+        const i32x4 j = q[0];
+        q[0] = q[1];
+        q[1] = *ids;
+        ids += 32;
+        z[r][0] = ld_row(rs, j.x * 32 + hoff);
+        z[r][1] = ld_row(rs, j.y * 32 + hoff);
+        z[r][2] = ld_row(rs, j.z * 32 + hoff);
+        z[r][3] = ld_row(rs, j.w * 32 + hoff);
+    }
+    for (int t = 0; t < total; t += R) {
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const int wr = (r + R - 1) % R;
+            {
+                const i32x4 j = q[0];
+                q[0] = q[1];
+                q[1] = *ids;
+                ids += 32;
+                z[wr][0] = ld_row(rs, j.x * 32 + hoff);
+                z[wr][1] = ld_row(rs, j.y * 32 + hoff);
+                z[wr][2] = ld_row(rs, j.z * 32 + hoff);
+                z[wr][3] = ld_row(rs, j.w * 32 + hoff);
+            }
+            acc += (z[r][0] + z[r][1]) + (z[r][2] + z[r][3]);
+            if (--rem == 0) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    acc[i] += dpp<0x4E>(acc[i]);
+                    acc[i] += dpp<0x124>(acc[i]);
+                    acc[i] += dpp<0x128>(acc[i]);
+                }
+                const int o = desc[s * 8 + 1 + g];
+                if (gl < 2 && o >= 0) *reinterpret_cast<f32x4*>(out + (long)o * 8 + 4 * h) = acc;
+                acc = f32x4{0.f, 0.f, 0.f, 0.f};
+                ++s;
+                rem = s < s_end ? desc[s * 8] : 0x7fffffff;
+            }
+        }
+    }
+}
+
+#define LAUNCH_R(RR, GG)                                                                                           \
+    if (rows == RR && gw == GG) {                                                                                  \
+        auto k = roles_kernel<RR, GG>;                                                                             \
+        (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);          \
+        hipLaunchKernelGGL(k, dim3(n_blocks), dim3((4 + GG) * 64), lds_bytes, (hipStream_t)stream_handle, mode, iters, \
+                           stream, wave_ptr, wave_step, desc, x, x_bytes, out, sink);                              \
+        return (int)hipGetLastError();                                                                             \
+    }
+
+extern "C" int roles(int mode, int rows, int gw, int iters, int n_blocks, int lds_bytes, const int* stream,
+                     const int* wave_ptr, const int* wave_step, const int* desc, const float* x, unsigned x_bytes,
+                     float* out, float* sink, void* stream_handle) {
+    LAUNCH_R(2, 2) LAUNCH_R(4, 2) LAUNCH_R(6, 2) LAUNCH_R(8, 2)
+    LAUNCH_R(2, 4) LAUNCH_R(4, 4) LAUNCH_R(6, 4)
+    LAUNCH_R(2, 8) LAUNCH_R(4, 8)
+    return -1;
+}

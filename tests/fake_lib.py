@@ -64,7 +64,7 @@ def dropout_factors(d, n_rows, n_cols):
     """[n_rows, n_cols] factors (0 or 1/(1-p)) of an acm_dropout_t (ctypes struct or None)."""
     if d is None or d.p <= 0:
         return np.ones((n_rows, n_cols))
-    step = int(_vec(d.step, 1, np.int64)[0])
+    step = int(_vec(d.step, 1, np.int64)[0]) + int(getattr(d, "step_offset", 0))
     r, c = np.meshgrid(np.arange(n_rows) + int(d.row_offset), np.arange(n_cols), indexing="ij")
     w = philox7_words(d.seed, step, d.tag, r, (c & 15) + 16 * (c >> 6))
     word = np.take_along_axis(w, ((c >> 4) & 3)[None], 0)[0]
@@ -684,6 +684,12 @@ class FakeLib:
         agg = _view(p.agg, n, fp, p.ld_agg)
         agg[...] = 0
         agg[:, :fi] = P
+        if p.agg_copy:                                      # the backward's operands, left by the row-local stage
+            if not p.agg_given or not p.xs_copy:
+                self._err = b"acm_conv_agg_fwd: agg_copy needs agg_given and xs_copy"
+                return 1
+            _view(p.agg_copy, n, fp, p.ld_agg_copy)[...] = agg
+            _view(p.xs_copy, n, fp, p.ld_xs_copy)[...] = _view(p.xs, n, fp, p.ld_xs)
         att = _view(p.att, n, 4, 4)
         att[...] = 0
         att[:, :k] = hd["alpha"]
@@ -731,6 +737,20 @@ class FakeLib:
                 out[base + (k + c) * F: base + (k + 1 + c) * F] = d_lnw[c]
                 out[base + (2 * k + c) * F: base + (2 * k + 1 + c) * F] = d_lnb[c]
         out[base + 3 * k * F:] = d_mix.reshape(-1)
+        if q.next_agg:                            # the next step's input aggregation rides along
+            a = self._get(q.next_a)
+            if k != 3 or fp != 8 or F != 64 or not getattr(a, "stream_waves", 0) or a.stream_waves % 4 or a.stream_waves > 1024:
+                self._err = b"acm_conv_agg_bwd: carried gather: unsupported configuration"
+                return 4
+            if a.stream_waves // 4 > min((n + 15) // 16, 768):
+                self._err = b"acm_conv_agg_bwd: too many stream waves for the workspace"
+                return 4
+            xg = _view(q.next_xg, a.n_cols, 8, q.ld_next_xg).astype(np.float64)
+            import scipy.sparse as sp
+            pn = sp.csr_matrix((a.vals.astype(np.float64), a.indices, a.indptr), shape=(a.n_rows, a.n_cols)) @ xg
+            if q.next_row_scale:
+                pn = pn * _vec(q.next_row_scale, a.n_rows).astype(np.float64)[:, None]
+            _view(q.next_agg, a.n_rows, 8, q.ld_next_agg)[...] = pn
         return self._emit(q.defer, [(dst, out)])
 
     def acm_dropout(self, n, c, src, lds, dst, ldd, dst_cols, d, stream):

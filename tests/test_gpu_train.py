@@ -208,3 +208,109 @@ def test_eval_passes_reuse_the_aggregated_input_on_the_gpu(monkeypatch):
     ev_e = T.EvalStep(model, x, ops, y, sets)
     (og, ag, lg), (oe, ae, le) = ev_g(), ev_e()
     assert torch.equal(og, oe) and ag == ae and lg == le          # both are shortened passes by now
+
+
+def _pipeline_case(n, avg, seed):
+    """A random graph in the input pipeline's regime (dense input of 7 features, 12 < nnz / n <= 160) + a fresh model."""
+    from acm_gnn_amd import data as D
+    from acm_gnn_amd.distributed import make_sharded_operators
+    rng = np.random.default_rng(seed)
+    m = n * avg // 2
+    w = 1.0 / (np.arange(n) + 10.0) ** 0.6                       # skewed degrees: a few long rows (pieces of id streams)
+    r, c = rng.choice(n, m, p=w / w.sum()), rng.integers(0, n, m)
+    adj = sp.csr_matrix((np.ones(m, np.float32), (r, c)), shape=(n, n))
+    adj = ((adj + adj.T) > 0).astype(np.float32).tocsr()
+    adj.setdiag(0)
+    adj.eliminate_zeros()
+    low, deg = D.build_filters(adj)
+    ops = make_sharded_operators(low, deg, torch.device(DEV))
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(n, 7, generator=g).to(DEV)
+    y = torch.randint(0, 2, (n,), generator=g).to(DEV)
+    return ops, x, y
+
+
+@pytest.mark.parametrize("use_graph", [False, True], ids=["eager", "graph"])
+@pytest.mark.parametrize("n,avg", [(3000, 40), (20000, 24)])
+def test_input_pipeline_matches_plain_step(monkeypatch, n, avg, use_graph):
+    """TrainStep with the input pipeline (the next step's P = A_low dropout(x) gathered by two extra waves per SIMD of the
+    first layer's backward kernel; acm_conv_agg_bwd_t.next_agg, acm_conv_agg_fwd_t.agg_given / agg_copy,
+    acm_dropout_t.step_offset) against the plain step: same masks, same losses and parameters up to the summation
+    order of the gather; P itself against acm_spmm.  The small case has fewer stream waves than CUs and rows of
+    several pieces; the large one is past the default size threshold."""
+    from acm_gnn_amd import GCN, FusedAdamW, functional as AF, train as T
+    monkeypatch.setenv("ACM_PIPELINE_MIN_ROWS", "1024")
+    ops, x, y = _pipeline_case(n, avg, seed=n)
+    w = T.row_weights(torch.arange(0, n, 3, device=DEV), n)
+
+    def run(pipeline):
+        torch.manual_seed(0)
+        model = GCN(7, 64, 2, 2, n, 0.2, "acmgcnp", 0, variant=False, attn_layernorm=True).to(DEV)
+        model.dropout_state = AF.DropoutState(torch.device(DEV), seed=99)
+        opt = FusedAdamW(model.parameters(), lr=0.01)
+        step = T.TrainStep(model, opt, x, ops, y, w, use_graph=use_graph, pipeline_input=pipeline)
+        losses = [float(step()) for _ in range(8)]
+        return step, model, losses
+
+    step_a, model_a, loss_a = run(False)
+    step_b, model_b, loss_b = run(None)
+    assert step_a.pipe is None and step_b.pipe is not None and step_b.pipe.primed
+    np.testing.assert_allclose(loss_b, loss_a, rtol=2e-4, atol=1e-5)
+    for (k, pa), (_, pb) in zip(model_a.state_dict().items(), model_b.state_dict().items()):
+        torch.testing.assert_close(pb, pa, rtol=5e-3, atol=5e-4, msg=k)
+    # the buffers after step 8: filled = operands of step 9 (dropout with the current counter), saved = those of step 8
+    pipe = step_b.pipe
+    want_table = AF.dropout(x, 0.2, model_b.dropout_state, tag=0, pad_to=8)
+    torch.testing.assert_close(pipe.filled[0], want_table, rtol=0, atol=0)
+    want_p = AF.spmm(ops.low, want_table, row_scale=ops.row_scale)
+    torch.testing.assert_close(pipe.filled[1], want_p, rtol=1e-5, atol=1e-5)
+    assert float((pipe.saved[0] - pipe.filled[0]).abs().max()) > 0         # a different mask
+
+
+def test_carried_gather_leaves_the_backward_unchanged():
+    """acm_conv_agg_bwd with and without next_agg: the parameter gradients agree (eight instead of four slabs per
+    workgroup: another summation order), and the carried P equals the stand-alone product bit for bit across launches."""
+    from acm_gnn_amd import GraphConvolution, functional as AF
+    n = 6000
+    ops, x, _ = _pipeline_case(n, 30, seed=3)
+    assert ops.low.build_streams(n_waves=1024) and ops.low.stream_waves % 4 == 0
+    torch.manual_seed(1)
+    layer = GraphConvolution(7, 64, n, "acmgcnp", variant=0, structure_info=0, attn_layernorm=True).to(DEV)
+    st = AF.DropoutState(torch.device(DEV), seed=5)
+    pipe = AF.InputPipeline(ops, x, 0.3, st)
+    pipe.prime()
+    gout = torch.randn(n, 64, device=DEV)
+    params = [p for p in layer.parameters() if p.requires_grad]
+
+    def grads(carry):
+        for p in params:
+            p.grad = None
+        AF._PIPE = pipe if carry else None
+        try:
+            xin = pipe.table() if carry else pipe.table().clone()
+            out = layer(xin, ops, None, post_relu=True)
+            if carry:
+                pipe.make_next()
+            out.backward(gout)
+        finally:
+            AF._PIPE = None
+        return [p.grad.clone() for p in params if p.grad is not None], out.detach().clone()
+
+    g_plain, out_plain = grads(False)
+    g_carry, out_carry = grads(True)
+    assert pipe.next_agg_ready
+    torch.testing.assert_close(out_carry, out_plain, rtol=1e-5, atol=1e-5)
+    for a, b in zip(g_carry, g_plain):
+        torch.testing.assert_close(a, b, rtol=2e-4, atol=2e-5)
+    st.step += 1                                                  # what the optimizer's step would do
+    want = AF.spmm(ops.low, AF.dropout(x, 0.3, st, tag=0, pad_to=8), row_scale=ops.row_scale)
+    torch.testing.assert_close(pipe.filled[1], want, rtol=1e-5, atol=1e-5)
+    first = pipe.filled[1].clone()
+    st.step -= 1
+    pipe.prime()
+    pipe.end_step()
+    pipe.primed = True
+    g_again, _ = grads(True)
+    assert torch.equal(pipe.filled[1], first)                     # deterministic: slot order, not arrival order
+    for a, b in zip(g_again, g_carry):
+        assert torch.equal(a, b)

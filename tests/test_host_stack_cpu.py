@@ -705,3 +705,63 @@ def test_eval_passes_reuse_the_aggregated_input(monkeypatch):
     with torch.no_grad():
         model(x, low, high), model(x, low, high)
     assert given[-2:] == [0, 0]
+
+
+def _dense_graph_ops(n=160, avg=20, seed=5):
+    """FilterOperators of a random graph dense enough for the input pipeline's regime (12 < nnz / n <= 160)."""
+    import scipy.sparse as sp
+    from acm_gnn_amd import data as D
+    from acm_gnn_amd.distributed import make_sharded_operators
+    rng = np.random.default_rng(seed)
+    m = n * avg // 2
+    r, c = rng.integers(0, n, m), rng.integers(0, n, m)
+    adj = sp.csr_matrix((np.ones(m, np.float32), (r, c)), shape=(n, n))
+    adj = ((adj + adj.T) > 0).astype(np.float32).tocsr()
+    adj.setdiag(0)
+    adj.eliminate_zeros()
+    low, deg = D.build_filters(adj)
+    return make_sharded_operators(low, deg, torch.device("cpu")), n
+
+
+def test_input_pipeline_equals_plain_train_step(monkeypatch):
+    """train.TrainStep with the input pipeline (functional.InputPipeline: the first layer's P = A_low dropout(x) of step
+    t + 1 gathered inside the layer's backward of step t, acm_conv_agg_bwd_t.next_agg / acm_dropout_t.step_offset)
+    against the plain step: same losses and parameters; the forward runs with agg_given, every backward carries the
+    gather, prime() runs once."""
+    fake = fake_lib.install(monkeypatch)
+    monkeypatch.setenv("ACM_PIPELINE_MIN_ROWS", "32")
+    from acm_gnn_amd import GCN, FusedAdamW, functional as AF, train as T
+    ops, n = _dense_graph_ops()
+    x, y = torch.randn(n, 7, generator=torch.Generator().manual_seed(1)), torch.randint(0, 2, (n,), generator=torch.Generator().manual_seed(2))
+    w = T.row_weights(torch.arange(0, n, 2), n)
+    calls = {"given": [], "carried": [], "spmm": 0}
+    fwd, bwd, spmm_ex = fake.acm_conv_agg_fwd, fake.acm_conv_agg_bwd, fake.acm_spmm_ex
+    monkeypatch.setattr(fake, "acm_conv_agg_fwd", lambda h, pp, *a: (calls["given"].append(int(pp._obj.agg_given)), fwd(h, pp, *a))[1])
+    monkeypatch.setattr(fake, "acm_conv_agg_bwd", lambda nn, qq, *a: (calls["carried"].append(bool(qq._obj.next_agg)), bwd(nn, qq, *a))[1])
+
+    def run(pipeline):
+        torch.manual_seed(0)
+        model = GCN(7, 64, 2, 2, n, 0.3, "acmgcnp", 0, variant=False, attn_layernorm=True)
+        model.dropout_state = AF.DropoutState(torch.device("cpu"), seed=77)
+        opt = FusedAdamW(model.parameters(), lr=0.02)
+        step = T.TrainStep(model, opt, x, ops, y, w, use_graph=False, fused_dropout=True, pipeline_input=pipeline)
+        losses = [float(step()) for _ in range(5)]
+        return step, losses, {k: v.clone() for k, v in model.state_dict().items()}
+
+    step_a, loss_a, sd_a = run(False)
+    assert step_a.pipe is None and calls["given"] == [0] * 5 and calls["carried"] == [False] * 5
+    calls["given"].clear(), calls["carried"].clear()
+    step_b, loss_b, sd_b = run(None)
+    assert step_b.pipe is not None and ops.low.stream_waves == 40          # four gather waves per 16 rows
+    assert calls["given"] == [1] * 5 and calls["carried"] == [True] * 5
+    np.testing.assert_allclose(loss_b, loss_a, rtol=1e-5, atol=1e-6)
+    for k in sd_a:
+        np.testing.assert_allclose(sd_b[k].numpy(), sd_a[k].numpy(), rtol=1e-4, atol=1e-5, err_msg=k)
+    # the counter set from outside (TrainStep._restore after a capture's warm-up): prime() again, then in step again
+    snap = step_b._snapshot()
+    step_b._eager()
+    step_b._restore(snap)
+    step_b.pipe.prime()
+    again = float(step_b())
+    step_a._restore(step_a._snapshot())
+    np.testing.assert_allclose(again, float(step_a()), rtol=1e-5, atol=1e-6)
