@@ -77,7 +77,8 @@ class TrainStep:
             else:
                 self._manual_advance = True
         self._params = list(model.parameters())          # walked every step: module.parameters() costs 0.1 ms of host time
-        # the first layer's input aggregation one step ahead, inside its own backward (functional.InputPipeline)
+        # the first layer's input aggregation one step ahead, inside its own backward (functional.InputPipeline);
+        # pipeline_input: None = when the configuration qualifies (InputPipeline.eligible), False = never
         self.pipe = None
         if pipeline_input is not False and not self._manual_advance and getattr(model, "fused_dropout", False) \
                 and AF.InputPipeline.eligible(model, self.adj, self.x):
@@ -286,8 +287,13 @@ class EvalStep:
 
 
 def fit(model, optimizer, x, adj, labels, train_idx, val_idx, test_idx, epochs, rule="max_val_acc",
-        early_stopping=0, adj_high=None, adj_un=None, use_graph=False, fused_dropout=None):
+        early_stopping=0, adj_high=None, adj_un=None, use_graph=False, fused_dropout=None, pipeline_input=False):
     """Train and return (selected test accuracy, per-epoch history).
+
+    ``pipeline_input``: TrainStep's input pipeline.  Off by default HERE: with an evaluation pass after every step the
+    pipelined step loses what it wins alone (twitch-shaped graph: 0.551 against 0.544 ms per epoch, while the step alone
+    goes 0.346 -> 0.338 ms) -- its gather walks the id streams, a second 64 MB copy of the operator's column ids that
+    competes with the CSR's for the Infinity Cache once the evaluation pass's gathers run in between.
 
     rule = "max_val_acc":  test accuracy at the best validation accuracy, fixed number of epochs
                            (ACM-Geometric/train.py:139-140, logger.py:17-48)
@@ -297,7 +303,7 @@ def fit(model, optimizer, x, adj, labels, train_idx, val_idx, test_idx, epochs, 
     """
     w = row_weights(train_idx, x.shape[0], device=x.device)
     step = TrainStep(model, optimizer, x, adj, labels, w, adj_high, adj_un, use_graph=use_graph,
-                     fused_dropout=fused_dropout)
+                     fused_dropout=fused_dropout, pipeline_input=pipeline_input)
     best_key, selected, history = None, 0.0, []
     val_hist = []
     # the evaluation pass of every epoch: its own captured graph when the training step is one

@@ -325,6 +325,9 @@ def main():
         except Exception as exc:
             extras = {"extras_error": repr(exc)}
 
+    # which form of the step was timed: with the first layer's input aggregation of step t + 1 inside that layer's backward
+    # of step t (train.TrainStep's default where it qualifies; ACM_PIPELINE=0 switches it off) or without
+    extras["input_pipeline"] = step.pipe is not None
     if rank == 0:
         emit(ms_per_step, "hipGraph replay of the captured step" if graph_ok else "eager launches", final_loss,
              with_cpu=True, extras=extras, check=check)
@@ -350,7 +353,8 @@ def side_measurements(args, timed_graph_steps, model, opt, x, ops, y, w, fused_d
         # ms/epoch tables; both halves as hipGraph replays
         ev = T.EvalStep(model, x, ops, y, tuple(torch.from_numpy(np.asarray(s_)).to(dev) for s_ in splits), loss_set=1,
                         use_graph=True)
-        gstep = T.TrainStep(model, opt, x, ops, y, w, use_graph=True, fused_dropout=fused_drop)
+        gstep = T.TrainStep(model, opt, x, ops, y, w, use_graph=True, fused_dropout=fused_drop,
+                            pipeline_input=False)       # as train.fit does: an evaluation pass follows every step
 
         def epoch():
             loss = gstep()
