@@ -114,7 +114,7 @@ class ConvAggFwd(C.Structure):
                 ("next_w_low", C.c_void_p), ("next_w_high", C.c_void_p), ("next_w_mlp", C.c_void_p), ("next_ld_w", C.c_int64),
                 ("next_f", C.c_int32), ("next_relu", C.c_int32),
                 ("next_zlh", C.c_void_p), ("ld_next_zlh", C.c_int64), ("next_zi", C.c_void_p), ("ld_next_zi", C.c_int64),
-                ("agg_given", C.c_int32), ("reserved", C.c_int32),
+                ("agg_given", C.c_int32), ("use_streams", C.c_int32),
                 ("agg_copy", C.c_void_p), ("ld_agg_copy", C.c_int64), ("xs_copy", C.c_void_p), ("ld_xs_copy", C.c_int64)]
 
 

@@ -1049,7 +1049,7 @@ extern "C" int acm_conv_agg_fwd(const acm_csr_t* a, const acm_conv_agg_fwd_t* p,
         if (fused) {
             const AcmStreams* t = a->streams;
             const int64_t table_bytes = a->n_cols * 32;
-            if (t && p->f_pad == 8 && p->ld_xg == 8 && a->vals == nullptr && table_bytes < (int64_t)0xFFFFFFE0u &&
+            if (p->use_streams && t && p->f_pad == 8 && p->ld_xg == 8 && a->vals == nullptr && table_bytes < (int64_t)0xFFFFFFE0u &&
                 getenv("ACM_AGG_NO_STREAM") == nullptr) {
                 StreamView sv = stream_view(t);
                 sv.probe = getenv("ACM_STREAM_PROBE") ? atoi(getenv("ACM_STREAM_PROBE")) : 0;

@@ -1169,6 +1169,7 @@ class AcmConvFunction(torch.autograd.Function):
             if (not four and fp == 8 and xg.stride(0) == 8 and ops.implicit and not ops.low.stream_steps
                     and ops.low.want_streams() and not (dev.type == "cuda" and torch.cuda.is_current_stream_capturing())):
                 ops.low.build_streams()       # one-off: the id streams of the streamed kernel (never during a capture)
+            p.use_streams = int(not four and ops.low.want_streams() and bool(ops.low.stream_steps))
             with _device_ctx(dev), _Timed(f"conv_agg_{'epi' if agg_given is not None else 'fwd'}/F{f}k{k}i{f_in}"):
                 st = lib.acm_conv_agg_fwd(ops.low.handle, C.byref(p), _vp(ws), ws.numel() * 4, _stream())
             _lib.check(st, "acm_conv_agg_fwd")

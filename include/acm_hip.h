@@ -513,7 +513,11 @@ typedef struct {
     /* agg_given != 0 (three channels only): `agg` already holds A_low * xg -- an earlier call of this operator on the same
      * input wrote it (e.g. every evaluation pass over a static feature matrix after the first) -- so the gather is
      * skipped and only the row-local stage runs; xg is not read.                                                     */
-    int32_t agg_given, reserved;
+    int32_t agg_given;
+    /* use_streams != 0: walk the handle's per-wave id streams (acm_csr_build_streams; three channels, f_pad = 8,
+     * ld_xg = 8, pattern-only operator) instead of the CSR work list.  Off by default: slower on the graphs measured
+     * (DESIGN.md section 4), and a handle may carry streams laid out for another consumer (acm_conv_agg_bwd_t.next_agg). */
+    int32_t use_streams;
     /* With agg_given: the row-local stage also stores the rows of `agg` and `xs` it read to agg_copy / xs_copy (NULL:
      * off; rows of f_pad floats) -- the operands of this layer's backward when `agg` / `xs` themselves are the buffers
      * an input pipeline refills before that backward runs (acm_conv_agg_bwd_t.next_agg).                             */
