@@ -114,8 +114,9 @@ typedef struct {
 } acm_csr_info_t;
 int acm_csr_info(const acm_csr_t* a, acm_csr_info_t* info);
 
-/* acm_csr_build_streams: lay the column ids of a PATTERN-ONLY operator out in the order the waves of the streamed
- * aggregate-first kernel (acm_conv_agg_fwd, f_pad = 8, three channels) consume them -- a sliced-ELL copy of the id
+/* acm_csr_build_streams: lay the column ids of a PATTERN-ONLY operator out in the order the waves of a streamed
+ * gather consume them (the gather waves of acm_conv_agg_bwd_t.next_agg; acm_conv_agg_fwd with use_streams, f_pad = 8,
+ * three channels) -- a sliced-ELL copy of the id
  * stream: four rows of similar length per wave ("slice"), 32 neighbours per row and wave step, 128 ids per step padded
  * with an out-of-range sentinel (a buffer load answers it with zeros without touching memory), the slices dealt
  * longest-first to `n_waves` waves, each wave's slices contiguous.  A wave then walks ONE linear id stream with its
@@ -124,7 +125,7 @@ int acm_csr_info(const acm_csr_t* a, acm_csr_info_t* info);
  * the partial sums in slot order and finishes the row, so results do not depend on the arrival order.
  * One-off host-side preprocessing like acm_csr_create (synchronises the device; must not be called while a stream is
  * capturing); idempotent.  n_waves <= 0: five waves per SIMD of the current device (env ACM_STREAM_WAVES overrides);
- * lmax <= 0: 512 (env ACM_STREAM_LMAX).  The handle owns the arrival counters (cleared ahead of every launch) and partial
+ * lmax <= 0: 512 (env ACM_STREAM_LMAX).  The handle owns the arrival counters (zero between launches: the last piece of a row resets its counter) and partial
  * slots, so launches that use the streams of one handle must be stream-ordered.  Costs (total steps x 512 B) of device memory, ~1.2 x the id array.
  * No reference counterpart (the reference hands torch.spmm a COO tensor, ACM-Geometric/layers.py:87-103). */
 int acm_csr_build_streams(acm_csr_t* a, int n_waves, int lmax);

@@ -231,8 +231,8 @@ def _pipeline_case(n, avg, seed):
 
 
 @pytest.mark.parametrize("use_graph", [False, True], ids=["eager", "graph"])
-@pytest.mark.parametrize("n,avg", [(3000, 40), (20000, 24)])
-def test_input_pipeline_matches_plain_step(monkeypatch, n, avg, use_graph):
+@pytest.mark.parametrize("n,avg,model_type", [(3000, 40, "acmgcnp"), (20000, 24, "acmgcnp"), (3000, 40, "acmgcn")])
+def test_input_pipeline_matches_plain_step(monkeypatch, n, avg, model_type, use_graph):
     """TrainStep with the input pipeline (the next step's P = A_low dropout(x) gathered by two extra waves per SIMD of the
     first layer's backward kernel; acm_conv_agg_bwd_t.next_agg, acm_conv_agg_fwd_t.agg_given / agg_copy,
     acm_dropout_t.step_offset) against the plain step: same masks, same losses and parameters up to the summation
@@ -245,7 +245,7 @@ def test_input_pipeline_matches_plain_step(monkeypatch, n, avg, use_graph):
 
     def run(pipeline):
         torch.manual_seed(0)
-        model = GCN(7, 64, 2, 2, n, 0.2, "acmgcnp", 0, variant=False, attn_layernorm=True).to(DEV)
+        model = GCN(7, 64, 2, 2, n, 0.2, model_type, 0, variant=False, attn_layernorm=model_type == "acmgcnp").to(DEV)
         model.dropout_state = AF.DropoutState(torch.device(DEV), seed=99)
         opt = FusedAdamW(model.parameters(), lr=0.01)
         step = T.TrainStep(model, opt, x, ops, y, w, use_graph=use_graph, pipeline_input=pipeline)
