@@ -222,7 +222,8 @@ class InputPipeline:
     forward (reads filled, writes saved) -> make_next() (filled table <- dropout_{t+1}(x)) -> backward (reads saved;
     its gather waves read the filled table and write the filled P) -> optimizer -> end_step().
     prime() fills ``filled`` for the current counter value; it must be called again whenever the counter is set from
-    outside (train.TrainStep does after its warm-up)."""
+    outside (train.TrainStep does after its warm-up) or x is modified in place (``stale()`` notices the latter between
+    eager steps; a captured graph replays without host code, so there the caller has to)."""
 
     def __init__(self, ops, x, p, state, tag=0):
         n = x.shape[0]
@@ -230,6 +231,7 @@ class InputPipeline:
         self.filled = torch.zeros(2, n, 8, dtype=_F32, device=x.device)
         self.saved = torch.zeros(2, n, 8, dtype=_F32, device=x.device)
         self.primed = False
+        self._x_version = x._version
         self.next_table_ready = False
         self.next_agg_ready = False
 
@@ -282,10 +284,14 @@ class InputPipeline:
             st = _lib.load().acm_dropout(n, c, _vp(self.x), self.x.stride(0), _vp(dst), dst.stride(0), 8, C.byref(d), _stream())
         _lib.check(st, "acm_dropout")
 
+    def stale(self):
+        return not self.primed or self.x._version != self._x_version
+
     def prime(self):
         self._drop_into(self.filled[0], 0)
         spmm(self.ops.low, self.filled[0], out=self.filled[1], row_scale=self.ops.row_scale)
         self.primed = True
+        self._x_version = self.x._version
         self.next_table_ready = self.next_agg_ready = False
 
     def make_next(self):

@@ -94,7 +94,7 @@ class TrainStep:
         before the flush -- otherwise deferral is switched off for good and the step is redone."""
         model = self.model
         pipe = self.pipe
-        if pipe is not None and not pipe.primed:
+        if pipe is not None and pipe.stale() and not (self.x.is_cuda and torch.cuda.is_current_stream_capturing()):
             pipe.prime()
         if not self._defer:
             loss, dz, out = self._forward_loss()
@@ -183,6 +183,8 @@ class TrainStep:
                         v.zero_()
             if drop_step is not None:
                 self.model.dropout_state.step.copy_(drop_step)
+        if getattr(self, "pipe", None) is not None:
+            self.pipe.primed = False            # its buffers belong to another counter value now
 
     def _capture(self):
         # NOTE for callers: no autograd graph of an earlier, un-captured backward through this model may still be alive

@@ -757,11 +757,15 @@ def test_input_pipeline_equals_plain_train_step(monkeypatch):
     np.testing.assert_allclose(loss_b, loss_a, rtol=1e-5, atol=1e-6)
     for k in sd_a:
         np.testing.assert_allclose(sd_b[k].numpy(), sd_a[k].numpy(), rtol=1e-4, atol=1e-5, err_msg=k)
-    # the counter set from outside (TrainStep._restore after a capture's warm-up): prime() again, then in step again
+    # the counter set from outside (TrainStep._restore after a capture's warm-up): the buffers are re-primed, in step again
     snap = step_b._snapshot()
     step_b._eager()
     step_b._restore(snap)
-    step_b.pipe.prime()
+    assert step_b.pipe.stale()
     again = float(step_b())
     step_a._restore(step_a._snapshot())
     np.testing.assert_allclose(again, float(step_a()), rtol=1e-5, atol=1e-6)
+    # an in-place edit of the features between eager steps is noticed (version counter) and P recomputed
+    x.mul_(0.5)
+    assert step_b.pipe.stale()
+    np.testing.assert_allclose(float(step_b()), float(step_a()), rtol=1e-4, atol=1e-6)     # (seven fp32 steps apart by now)
