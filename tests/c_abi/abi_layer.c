@@ -3,7 +3,8 @@
  *
  *   literal form        acm_gemm (X [W_L|W_H|W_I]) -> acm_conv_fwd -> acm_conv_bwd_local -> acm_conv_bwd_spmm (on
  *                       acm_csr_transpose) -> acm_gemm (X^T dZ)
- *   aggregate-first     acm_conv_agg_fwd -> acm_conv_agg_bwd
+ *   aggregate-first     acm_conv_agg_fwd -> acm_conv_agg_bwd, and the pipelined pair (P given, the backward carrying the
+ *                       next step's gather over the operator's id streams)
  *
  * on a 300-node ring (+-8 neighbours) with a hub row that is split into several work items, for the ACM-GCN+ layer
  * (ReLU after the filter, LayerNorm in the attention head, sigmoid / 3x3 mix / softmax, scale 3).  Checked against a
@@ -305,6 +306,92 @@ int main(void) {
         return 8;
     }
 
+    /* ======================= the NEXT step's input aggregation carried by the backward =======================
+     * (acm_conv_agg_bwd_t.next_agg, acm_conv_agg_fwd_t.agg_given / agg_copy / xs_copy; width 64, pattern-only operator
+     * with id streams).  Checked: the carried product against host loops, the copies bit for bit, the gradients against
+     * the same call without the gather. */
+    enum { F2 = 64, NW2 = 3 * FIN * F2, NPAR2 = NW2 + 3 * K * F2 + K * K };
+    static float theta2[NPAR2], g2[N * F2], rs[N], xnext[N * FPAD];
+    for (int i = 0; i < NW2; ++i) theta2[i] = 0.4f * rnd();
+    for (int i = 0; i < K * F2; ++i) theta2[NW2 + i] = rnd();
+    for (int i = 0; i < K * F2; ++i) theta2[NW2 + K * F2 + i] = 1.0f + 0.3f * rnd();
+    for (int i = 0; i < K * F2; ++i) theta2[NW2 + 2 * K * F2 + i] = 0.3f * rnd();
+    for (int i = 0; i < K * K; ++i) theta2[NW2 + 3 * K * F2 + i] = 0.6f * rnd();
+    for (int i = 0; i < N * F2; ++i) g2[i] = rnd();
+    for (int r = 0; r < N; ++r) rs[r] = 1.0f / (float)(ip[r + 1] - ip[r]);
+    for (int r = 0; r < N; ++r) for (int f = 0; f < FPAD; ++f) xnext[r * FPAD + f] = f < FIN ? rnd() : 0.f;
+    float* d_theta2 = (float*)to_dev(theta2, sizeof(theta2));
+    float* d_g2 = (float*)to_dev(g2, sizeof(g2));
+    float* d_rs = (float*)to_dev(rs, sizeof(rs));
+    float* d_xnext = (float*)to_dev(xnext, sizeof(xnext));
+    float* d_o64 = (float*)to_dev(NULL, N * F2 * sizeof(float));
+    float* d_o64b = (float*)to_dev(NULL, N * F2 * sizeof(float));
+    float* d_p = (float*)to_dev(NULL, N * FPAD * sizeof(float));
+    float* d_pc = (float*)to_dev(NULL, N * FPAD * sizeof(float));
+    float* d_xc = (float*)to_dev(NULL, N * FPAD * sizeof(float));
+    float* d_pnext = (float*)to_dev(NULL, N * FPAD * sizeof(float));
+    float* d_st64 = (float*)to_dev(NULL, N * 4 * K * sizeof(float));
+    float* d_dpa = (float*)to_dev(NULL, NPAR2 * sizeof(float));
+    float* d_dpb = (float*)to_dev(NULL, NPAR2 * sizeof(float));
+    if (!d_theta2 || !d_g2 || !d_rs || !d_xnext || !d_o64 || !d_o64b || !d_p || !d_pc || !d_xc || !d_pnext || !d_st64 || !d_dpa || !d_dpb) return 2;
+    acm_csr_t* ap = NULL;                                   /* the same graph as a pattern: values = rs[row] */
+    CHECK_ACM(acm_csr_create(N, N, nnz, d_ip, d_ix, NULL, 64, &ap));
+    CHECK_ACM(acm_csr_build_streams(ap, 4 * ((N + 15) / 16), 64));          /* 64 neighbours per piece: the hub row has five */
+    acm_csr_info_t sinfo;
+    CHECK_ACM(acm_csr_info(ap, &sinfo));
+    if (sinfo.stream_waves % 4 != 0 || sinfo.stream_long_rows < 1) { printf("streams: %d waves, %d long rows\n", sinfo.stream_waves, sinfo.stream_long_rows); return 11; }
+    acm_conv_agg_fwd_t w = u;
+    w.f_out = F2; w.ld_w = F2;
+    w.w_low = d_theta2; w.w_high = d_theta2 + FIN * F2; w.w_mlp = d_theta2 + 2 * FIN * F2;
+    for (int c = 0; c < K; ++c) { w.att_vec[c] = d_theta2 + NW2 + c * F2; w.ln_weight[c] = d_theta2 + NW2 + (K + c) * F2; w.ln_bias[c] = d_theta2 + NW2 + (2 * K + c) * F2; }
+    w.att_mix = d_theta2 + NW2 + 3 * K * F2;
+    w.row_scale = d_rs;
+    w.out = d_o64; w.ld_out = F2;
+    w.agg = d_p;
+    w.head_stats = d_st64;
+    size_t wsp_bytes = 0;
+    CHECK_ACM(acm_spmm_workspace_bytes(ap, F2, &wsp_bytes));
+    void* wsp = to_dev(NULL, wsp_bytes);
+    CHECK_ACM(acm_conv_agg_fwd(ap, &w, wsp, wsp_bytes, NULL));             /* step t, plain: gathers P itself */
+    acm_conv_agg_bwd_t wb = ub;
+    wb.f_out = F2; wb.ld_w = F2; wb.ld_grad_out = F2; wb.grad_out = d_g2;
+    wb.w_low = w.w_low; wb.w_high = w.w_high; wb.w_mlp = w.w_mlp;
+    for (int c = 0; c < K; ++c) { wb.att_vec[c] = w.att_vec[c]; wb.ln_weight[c] = w.ln_weight[c]; wb.ln_bias[c] = w.ln_bias[c]; }
+    wb.att_mix = w.att_mix;
+    wb.agg = d_p; wb.head_stats = d_st64; wb.d_params = d_dpa;
+    size_t ab2_bytes = 0;
+    CHECK_ACM(acm_conv_agg_bwd_workspace_bytes(N, FIN, F2, &ab2_bytes));
+    void* abw2 = to_dev(NULL, ab2_bytes);
+    CHECK_ACM(acm_conv_agg_bwd(N, &wb, abw2, ab2_bytes, NULL));
+    /* the same step as a pipelined loop runs it: P given, copies left for the backward, which carries A_low x_next */
+    acm_conv_agg_fwd_t wp = w;
+    wp.agg_given = 1; wp.out = d_o64b;
+    wp.agg_copy = d_pc; wp.ld_agg_copy = FPAD; wp.xs_copy = d_xc; wp.ld_xs_copy = FPAD;
+    CHECK_ACM(acm_conv_agg_fwd(ap, &wp, wsp, wsp_bytes, NULL));
+    acm_conv_agg_bwd_t wq = wb;
+    wq.agg = d_pc; wq.xs = d_xc; wq.d_params = d_dpb;
+    wq.next_a = ap; wq.next_xg = d_xnext; wq.ld_next_xg = FPAD; wq.next_row_scale = d_rs; wq.next_agg = d_pnext; wq.ld_next_agg = FPAD;
+    CHECK_ACM(acm_conv_agg_bwd(N, &wq, abw2, ab2_bytes, NULL));
+    CHECK_HIP(hipDeviceSynchronize());
+    static float o64[N * F2], o64b[N * F2], pp[N * FPAD], pc[N * FPAD], xc[N * FPAD], pnext[N * FPAD], dpa[NPAR2], dpb[NPAR2];
+    if (from_dev(o64, d_o64, sizeof(o64)) || from_dev(o64b, d_o64b, sizeof(o64b)) || from_dev(pp, d_p, sizeof(pp)) || from_dev(pc, d_pc, sizeof(pc)) ||
+        from_dev(xc, d_xc, sizeof(xc)) || from_dev(pnext, d_pnext, sizeof(pnext)) || from_dev(dpa, d_dpa, sizeof(dpa)) || from_dev(dpb, d_dpb, sizeof(dpb))) return 2;
+    if (memcmp(pp, pc, sizeof(pp)) || memcmp(xpad, xc, sizeof(xc))) { printf("agg_copy / xs_copy differ from agg / xs\n"); return 12; }
+    double e_o = 0, s_o = 0, e_pn = 0, e_dp = 0, s_dp = 0;
+    for (int i = 0; i < N * F2; ++i) { e_o = fmax(e_o, fabs(o64[i] - o64b[i])); s_o = fmax(s_o, fabs(o64[i])); }
+    for (int r = 0; r < N; ++r)
+        for (int f = 0; f < FPAD; ++f) {
+            double sum = 0;
+            for (int k = ip[r]; k < ip[r + 1]; ++k) sum += xnext[ix[k] * FPAD + f];
+            e_pn = fmax(e_pn, fabs(sum * rs[r] - pnext[r * FPAD + f]));
+        }
+    for (int i = 0; i < NPAR2; ++i) { e_dp = fmax(e_dp, fabs(dpa[i] - dpb[i])); s_dp = fmax(s_dp, fabs(dpa[i])); }
+    if (e_o > 2e-5 * s_o || e_pn > 1e-5 || e_dp > 2e-5 * s_dp) { printf("carried gather: out %g (scale %g) next P %g d_params %g (scale %g)\n", e_o, s_o, e_pn, e_dp, s_dp); return 13; }
+    acm_conv_agg_bwd_t bad3 = wq;
+    bad3.next_agg = d_pc;                                   /* aliases the backward's own operand */
+    if (acm_conv_agg_bwd(N, &bad3, abw2, ab2_bytes, NULL) != ACM_EINVAL) { printf("aliasing next_agg accepted\n"); return 14; }
+    acm_csr_destroy(ap);
+
     /* errors are codes, not crashes */
     acm_conv_fwd_t bad = p;
     bad.out = NULL;
@@ -314,7 +401,7 @@ int main(void) {
     if (acm_conv_agg_fwd(a, &bad2, ws, ws_bytes, NULL) != ACM_ESHAPE) { printf("wrong f_pad accepted\n"); return 10; }
     acm_csr_destroy(a);
     acm_csr_destroy(at);
-    printf("abi_layer ok: n=%d nnz=%d | fwd max|err| %.2e (literal) %.2e (aggregate-first) | grads vs FD: dW %.2e / %.2e, head %.2e / %.2e (ranges %.2g, %.2g)\n",
-           N, nnz, e_out, e_out2, e_dw, e_par_w, e_dh, e_par_h, gw_scale, gh_scale);
+    printf("abi_layer ok: n=%d nnz=%d | fwd max|err| %.2e (literal) %.2e (aggregate-first) | grads vs FD: dW %.2e / %.2e, head %.2e / %.2e (ranges %.2g, %.2g) | carried gather: next P %.2e, d_params %.2e of %.2g\n",
+           N, nnz, e_out, e_out2, e_dw, e_par_w, e_dh, e_par_h, gw_scale, gh_scale, e_pn, e_dp, s_dp);
     return 0;
 }
