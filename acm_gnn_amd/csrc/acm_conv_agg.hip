@@ -779,10 +779,16 @@ __device__ __forceinline__ void agg_bwd_body(const acm_conv_agg_bwd_t& p, int n_
     // GATHER: one workgroup of twelve waves per CU -- the hardware deals a workgroup's waves round-robin over the four
     // SIMDs, so each SIMD holds two backward waves and one gather wave (two six-wave workgroups per CU do not both fit:
     // the second one's waves land on the SIMDs the first one filled)
-    constexpr int BW = GATHER ? 8 : 4;            // backward waves per workgroup
-    if (GATHER && wv >= BW) {                     // waves 8..11: the next step's input gather; same barrier count as below
+    // LDSACC (the gather variant): dW lives in a per-wave LDS slab instead of 48 accumulator registers -- a tile is read
+    // as the MFMA's C operand and written back (one writer per slab: a fixed order of additions; ds_add_f32 instead costs
+    // ~80 clocks per wave instruction: 370 us) -- that takes the
+    // kernel from 147 to under 128 registers, i.e. four waves per SIMD: three backward waves and the gather wave
+    constexpr bool LDSACC = GATHER;
+    constexpr int BW = GATHER ? 12 : 4;           // backward waves per workgroup (the gather variant: 16 - BW gather waves)
+    constexpr int SLAB = 3 * FP * 64 + 3 * K * 64 + 16;     // LDSACC: [dW, rows padded to FP][dv | dgamma | dbeta][dmix]
+    if (GATHER && wv >= BW) {                     // the last four waves: the next step's input gather; same barrier count as below
         __syncthreads();
-        if (gr->roles & 2) stream_gather_role(*gr, __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (wv - BW)));
+        if (gr->roles & 2) stream_gather_role(*gr, __builtin_amdgcn_readfirstlane(blockIdx.x * (16 - BW) + (wv - BW)));
         __syncthreads();
         __syncthreads();
         return;
@@ -796,12 +802,20 @@ __device__ __forceinline__ void agg_bwd_body(const acm_conv_agg_bwd_t& p, int n_
         stage_weights<FP>(wlds, p.w_low, p.w_high, p.w_mlp, p.ld_w, f_in, F);
         stage_head_params<K>(hlds, p.att_vec, p.ln_weight, p.ln_bias, p.layernorm, F);
     }
+    float* slabs = hlds + 3 * K * 64 + BW * 4 * 2 * FP;      // LDSACC: behind the groups' scratch, live through the row loop
+    if (LDSACC)
+        for (int i = threadIdx.x; i < BW * SLAB; i += BW * 64) slabs[i] = 0.f;
     __syncthreads();
-    f32x4 acc[3][4];
+    f32x4 acc[LDSACC ? 1 : 3][LDSACC ? 1 : 4];
+    if (!LDSACC) {
 #pragma unroll
-    for (int c = 0; c < 3; ++c)
+        for (int c = 0; c < 3; ++c)
 #pragma unroll
-        for (int t = 0; t < 4; ++t) acc[c][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            for (int t = 0; t < 4; ++t) acc[LDSACC ? 0 : c][LDSACC ? 0 : t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+    // LDSACC slab layout of dW: tile (c, t) = 32 lanes x 4 floats, [(c * 4 + t) * 32 + (f / 4) * 16 + m][f % 4] for
+    // (f, col = 16 t + m): a lane's four results of one MFMA are one 16-byte LDS access
+    float* my_dw = slabs + wv * SLAB + (g * 16 + m) * 4;
     float pA[K][4], pS[K], dmix1 = 0.f;          // head-parameter accumulators (see row_channel_backward)
     const int qc = (m < K * K ? m : 0) / K, qj = (m < K * K ? m : 0) % K;    // the att_mix element this lane accumulates
 #pragma unroll
@@ -871,11 +885,22 @@ __device__ __forceinline__ void agg_bwd_body(const acm_conv_agg_bwd_t& p, int n_
             const bool relu_c = (c < 2) ? (p.relu_after != 0) : (p.relu_mlp != 0);
             const float aop = (c == 0) ? Pm : (c == 1 ? xm - Pm : xm);
             float G[4];
+            f32x4 tile[4];                        // LDSACC: the channel's four dW tiles, requested before the channel's math
+            if (LDSACC) {
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+                    tile[t] = (g < FP / 4) ? *reinterpret_cast<const f32x4*>(my_dw + (c * 4 + t) * 128) : (f32x4){0.f, 0.f, 0.f, 0.f};
+            }
             row_channel_backward<K>(hlds, c, mm, F, ln, p.scale, rh, ds[c], H[c], dO, pA[c], pS[c], G);
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
                 const bool keep = active && (m + 16 * t < F) && (!relu_c || H[c][t] > 0.f);
-                acc[c][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(aop, keep ? G[t] : 0.f, acc[c][t], 0, 0, 0);
+                if (LDSACC) {
+                    tile[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(aop, keep ? G[t] : 0.f, tile[t], 0, 0, 0);
+                    if (g < FP / 4) *reinterpret_cast<f32x4*>(my_dw + (c * 4 + t) * 128) = tile[t];   // rows f >= FP: zero by construction
+                } else {
+                    acc[LDSACC ? 0 : c][LDSACC ? 0 : t] = __builtin_amdgcn_mfma_f32_16x16x4f32(aop, keep ? G[t] : 0.f, acc[LDSACC ? 0 : c][LDSACC ? 0 : t], 0, 0, 0);
+                }
             }
         }
         if (K == 4) {                              // structure channel: deg * G_S goes to memory for A_low^T
@@ -899,6 +924,37 @@ __device__ __forceinline__ void agg_bwd_body(const acm_conv_agg_bwd_t& p, int n_
     }
     dmix1 = acm_cross_row_sum(dmix1);
     __syncthreads();                              // every wave is done with wlds / hlds
+    if (LDSACC) {
+        // the wave's dW already sits in its slab; append the head parameters, then sum the slabs in a fixed order
+        float* slab = slabs + wv * SLAB;
+        if (g == 0) {
+#pragma unroll
+            for (int c = 0; c < K; ++c)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int col = m + 16 * i;
+                    slab[3 * FP * 64 + (0 * K + c) * 64 + col] = dv[c][i];
+                    slab[3 * FP * 64 + (1 * K + c) * 64 + col] = dgam[c][i];
+                    slab[3 * FP * 64 + (2 * K + c) * 64 + col] = dbet[c][i];
+                }
+            if (m < K * K) slab[3 * FP * 64 + 3 * K * 64 + m] = dmix1;
+        }
+        __syncthreads();
+        for (int q = threadIdx.x; q < npg; q += BW * 64) {
+            int src;                              // position of flat parameter q in the padded slab layout (F == 64 here)
+            if (q < 3 * f_in * 64) {
+                const int c = q / (f_in * 64), rem = q - c * f_in * 64, f = rem >> 6, col = rem & 63;
+                src = (((c * 4 + (col >> 4)) * 32 + (f >> 2) * 16 + (col & 15)) << 2) + (f & 3);
+            } else {
+                src = 3 * FP * 64 + (q - 3 * f_in * 64);
+            }
+            const float* sp = slabs + src;
+            float v = ((sp[0] + sp[SLAB]) + (sp[2 * SLAB] + sp[3 * SLAB])) + ((sp[4 * SLAB] + sp[5 * SLAB]) + (sp[6 * SLAB] + sp[7 * SLAB]));
+            v += (sp[8 * SLAB] + sp[9 * SLAB]) + (sp[10 * SLAB] + sp[11 * SLAB]);
+            partial[((long)(q >> 5) * gridDim.x + blockIdx.x) * 32 + (q & 31)] = v;
+        }
+        return;
+    }
     float* slab = lds + wv * npg;
 #pragma unroll
     for (int c = 0; c < 3; ++c)
@@ -907,7 +963,7 @@ __device__ __forceinline__ void agg_bwd_body(const acm_conv_agg_bwd_t& p, int n_
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int f = 4 * g + r, col = 16 * t + m;
-                if (f < f_in && col < F) slab[(c * f_in + f) * F + col] = acc[c][t][r];
+                if (f < f_in && col < F) slab[(c * f_in + f) * F + col] = acc[LDSACC ? 0 : c][LDSACC ? 0 : t][r];
             }
     if (g == 0) {
         const int base = 3 * f_in * F;
@@ -928,8 +984,7 @@ __device__ __forceinline__ void agg_bwd_body(const acm_conv_agg_bwd_t& p, int n_
     // the slab is stored in groups of 32 parameters, partial[q / 32][block][q % 32] (acm_reduce_seg_t.elem_stride): whole
     // 128-byte lines here, and the second phase reads one line per block and group instead of one float per line
     for (int q = threadIdx.x; q < npg; q += BW * 64) {
-        float v = (lds[q] + lds[npg + q]) + (lds[2 * npg + q] + lds[3 * npg + q]);
-        if (BW == 8) v += (lds[4 * npg + q] + lds[5 * npg + q]) + (lds[6 * npg + q] + lds[7 * npg + q]);
+        const float v = (lds[q] + lds[npg + q]) + (lds[2 * npg + q] + lds[3 * npg + q]);
         partial[((long)(q >> 5) * gridDim.x + blockIdx.x) * 32 + (q & 31)] = v;
     }
 }
@@ -938,8 +993,8 @@ template <int FP, int K, bool FULL>
 __global__ __launch_bounds__(256, 2) void agg_bwd_kernel(acm_conv_agg_bwd_t p, int n_rows, float* __restrict__ partial) {
     agg_bwd_body<FP, K, FULL, false>(p, n_rows, partial, nullptr);
 }
-// twelve waves: eight for the backward, four for the next step's gather; one workgroup (3 waves/SIMD) per CU
-__global__ __launch_bounds__(768) __attribute__((amdgpu_waves_per_eu(3, 3))) void agg_bwd_gather_kernel(acm_conv_agg_bwd_t p, int n_rows,
+// sixteen waves: twelve for the backward, four for the next step's gather; one workgroup (4 waves/SIMD) per CU
+__global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4, 4))) void agg_bwd_gather_kernel(acm_conv_agg_bwd_t p, int n_rows,
                                                                                                   float* __restrict__ partial,
                                                                                                   GatherRole gr) {
     agg_bwd_body<8, 3, true, true>(p, n_rows, partial, &gr);
@@ -1181,7 +1236,8 @@ extern "C" int acm_conv_agg_bwd(int64_t n_rows, const acm_conv_agg_bwd_t* p, voi
         ACM_REQUIRE(K == 3 && p->f_pad == 8 && p->f_out == 64, ACM_EUNSUPPORTED,
                     "acm_conv_agg_bwd: the carried gather needs three channels, f_pad 8 and f_out 64");
         const AcmStreams* t = na->streams;
-        ACM_REQUIRE(t && t->n_waves >= 4 && t->n_waves % 4 == 0 && t->n_waves <= 1024, ACM_EINVAL,
+        const int gw = 4;                         // gather waves per workgroup (eight + eight backward waves: 124 us against 110)
+        ACM_REQUIRE(t && t->n_waves >= gw && t->n_waves % gw == 0 && t->n_waves <= 256 * gw, ACM_EINVAL,
                     "acm_conv_agg_bwd: next_a needs id streams for a multiple of four waves <= 1024 (acm_csr_build_streams)");
         ACM_REQUIRE(na->vals == nullptr && p->ld_next_xg == 8 && ((uintptr_t)p->next_xg) % 16 == 0 &&
                         na->n_cols * 32 < (int64_t)0xFFFFFFE0u && ((uintptr_t)p->next_agg) % 16 == 0 &&
@@ -1196,12 +1252,14 @@ extern "C" int acm_conv_agg_bwd(int64_t n_rows, const acm_conv_agg_bwd_t* p, voi
         gr.agg = p->next_agg;
         gr.ld_agg = (long)p->ld_next_agg;
         gr.roles = getenv("ACM_AGG_BWD_ROLES") ? atoi(getenv("ACM_AGG_BWD_ROLES")) : 3;
-        ACM_REQUIRE(t->n_waves / 4 <= agg_bwd_blocks(n_rows, 3, 0), ACM_EUNSUPPORTED,
+        ACM_REQUIRE(t->n_waves / gw <= agg_bwd_blocks(n_rows, 3, 0), ACM_EUNSUPPORTED,
                     "acm_conv_agg_bwd: %d stream waves for %lld rows (the workspace holds one slab per 16 rows)", t->n_waves, (long long)n_rows);
-        nblk = t->n_waves / 4;
-        const size_t lds_g = std::max(((size_t)3 * 8 * 64 + 3 * K * 64 + 64 * 8) * sizeof(float), (size_t)8 * npg * sizeof(float));
-        ACM_REQUIRE(lds_g <= 64 * 1024, ACM_EUNSUPPORTED, "acm_conv_agg_bwd: %zu B of LDS needed", lds_g);
-        hipLaunchKernelGGL(agg_bwd_gather_kernel, dim3(nblk), dim3(768), lds_g, s, *p, (int)n_rows, partial, gr);
+        nblk = t->n_waves / gw;
+        // weights + head parameters + the groups' scratch + twelve per-wave slabs (dW accumulates there): 114 KB of the CU's 160
+        const size_t lds_g = ((size_t)3 * 8 * 64 + 3 * K * 64 + 12 * 4 * 2 * 8 + (size_t)12 * (3 * 8 * 64 + 3 * K * 64 + 16)) * sizeof(float);
+        ACM_REQUIRE(lds_g <= 160 * 1024, ACM_EUNSUPPORTED, "acm_conv_agg_bwd: %zu B of LDS needed", lds_g);
+        ACM_CHECK_HIP(hipFuncSetAttribute((const void*)agg_bwd_gather_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_g));
+        hipLaunchKernelGGL(agg_bwd_gather_kernel, dim3(nblk), dim3(1024), lds_g, s, *p, (int)n_rows, partial, gr);
         ACM_CHECK_HIP(hipGetLastError());
         const acm_reduce_seg_t seg = {partial, nblk, 32, 0, npg, p->d_params, npg, 0, 0, 0, nblk * 32, 0};
         return acm_reduce_emit(p->defer, &seg, 1, s);

@@ -266,9 +266,10 @@ class InputPipeline:
         if x.device.type == "cuda" and torch.cuda.is_current_stream_capturing():
             return False
         # four gather waves per workgroup of the backward, one workgroup per 16 rows at most (its workspace), 256 at most
-        if not ops.low.build_streams(n_waves=max(4, min(1024, 4 * ((n + 15) // 16)))):
+        gw = 4                                                                      # gather waves per workgroup
+        if not ops.low.build_streams(n_waves=max(gw, min(256 * gw, gw * ((n + 15) // 16)))):
             return False
-        return ops.low.stream_waves % 4 == 0 and 4 <= ops.low.stream_waves <= min(1024, 4 * ((n + 15) // 16))
+        return ops.low.stream_waves % gw == 0 and gw <= ops.low.stream_waves <= min(256 * gw, gw * ((n + 15) // 16))
 
     def table(self):
         return self.filled[0]

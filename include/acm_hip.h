@@ -562,7 +562,8 @@ typedef struct {
      * instructions and leaves the memory system idle; the narrow gather  next_agg = next_row_scale * (A_low next_xg)  of the
      * next training step's first layer is bound by memory latency and depends on nothing this step computes (the input
      * features are constant, the dropout mask a function of the step counter: acm_dropout_t.step_offset = 1).  With
-     * next_agg set, every workgroup is eight waves of the row-local backward and four waves that walk next_a's id streams
+     * next_agg set, every workgroup is twelve waves of the row-local backward (their dW tiles accumulate in LDS instead
+     * of registers, so that four waves fit a SIMD) and four waves that walk next_a's id streams
      * (acm_csr_build_streams; the grid becomes stream_waves / 4 workgroups, one per CU); the next forward then runs with
      * acm_conv_agg_fwd_t.agg_given.  Needs: three channels, f_pad = 8, f_out = 64, ld_next_xg = 8, a pattern-only next_a
      * with streams built for a multiple of four waves <= 1024 (and <= n_rows / 4).  next_agg / next_xg must not alias
