@@ -776,13 +776,12 @@ template <int FP, int K, bool FULL, bool GATHER>
 __device__ __forceinline__ void agg_bwd_body(const acm_conv_agg_bwd_t& p, int n_rows, float* __restrict__ partial, const GatherRole* gr) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, m = lane & 15, g = lane >> 4;
-    // GATHER: one workgroup of twelve waves per CU -- the hardware deals a workgroup's waves round-robin over the four
-    // SIMDs, so each SIMD holds two backward waves and one gather wave (two six-wave workgroups per CU do not both fit:
-    // the second one's waves land on the SIMDs the first one filled)
+    // GATHER: one workgroup of sixteen waves per CU -- the hardware deals a workgroup's waves round-robin over the four
+    // SIMDs, so each SIMD holds three backward waves and one gather wave (several smaller workgroups per CU do not all
+    // become resident: the next one's waves land on the SIMDs the first one filled).
     // LDSACC (the gather variant): dW lives in a per-wave LDS slab instead of 48 accumulator registers -- a tile is read
-    // as the MFMA's C operand and written back (one writer per slab: a fixed order of additions; ds_add_f32 instead costs
-    // ~80 clocks per wave instruction: 370 us) -- that takes the
-    // kernel from 147 to under 128 registers, i.e. four waves per SIMD: three backward waves and the gather wave
+    // as the MFMA's C operand and written back (one writer per slab: a fixed order of additions; ds_add_f32 instead
+    // costs ~80 clocks per wave instruction: 370 us) -- which takes the kernel from 147 to 123 registers: four waves per SIMD
     constexpr bool LDSACC = GATHER;
     constexpr int BW = GATHER ? 12 : 4;           // backward waves per workgroup (the gather variant: 16 - BW gather waves)
     constexpr int SLAB = 3 * FP * 64 + 3 * K * 64 + 16;     // LDSACC: [dW, rows padded to FP][dv | dgamma | dbeta][dmix]
