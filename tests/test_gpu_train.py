@@ -210,7 +210,7 @@ def test_eval_passes_reuse_the_aggregated_input_on_the_gpu(monkeypatch):
     assert torch.equal(og, oe) and ag == ae and lg == le          # both are shortened passes by now
 
 
-def _pipeline_case(n, avg, seed):
+def _pipeline_case(n, avg, seed, relabel=False):
     """A random graph in the input pipeline's regime (dense input of 7 features, 12 < nnz / n <= 160) + a fresh model."""
     from acm_gnn_amd import data as D
     from acm_gnn_amd.distributed import make_sharded_operators
@@ -223,7 +223,7 @@ def _pipeline_case(n, avg, seed):
     adj.setdiag(0)
     adj.eliminate_zeros()
     low, deg = D.build_filters(adj)
-    ops = make_sharded_operators(low, deg, torch.device(DEV))
+    ops = make_sharded_operators(low, deg, torch.device(DEV), relabel=relabel)
     g = torch.Generator().manual_seed(seed)
     x = torch.randn(n, 7, generator=g).to(DEV)
     y = torch.randint(0, 2, (n,), generator=g).to(DEV)
@@ -231,7 +231,8 @@ def _pipeline_case(n, avg, seed):
 
 
 @pytest.mark.parametrize("use_graph", [False, True], ids=["eager", "graph"])
-@pytest.mark.parametrize("n,avg,model_type", [(3000, 40, "acmgcnp"), (20000, 24, "acmgcnp"), (3000, 40, "acmgcn")])
+@pytest.mark.parametrize("n,avg,model_type", [(3000, 40, "acmgcnp"), (20000, 24, "acmgcnp"), (3000, 40, "acmgcn"),
+                                              (3001, 40, "acmgcnp")])          # 3001: degree relabelling inside the operator
 def test_input_pipeline_matches_plain_step(monkeypatch, n, avg, model_type, use_graph):
     """TrainStep with the input pipeline (the next step's P = A_low dropout(x) gathered by two extra waves per SIMD of the
     first layer's backward kernel; acm_conv_agg_bwd_t.next_agg, acm_conv_agg_fwd_t.agg_given / agg_copy,
@@ -240,7 +241,8 @@ def test_input_pipeline_matches_plain_step(monkeypatch, n, avg, model_type, use_
     several pieces; the large one is past the default size threshold."""
     from acm_gnn_amd import GCN, FusedAdamW, functional as AF, train as T
     monkeypatch.setenv("ACM_PIPELINE_MIN_ROWS", "1024")
-    ops, x, y = _pipeline_case(n, avg, seed=n)
+    ops, x, y = _pipeline_case(n, avg, seed=n, relabel=n == 3001)
+    assert (ops.perm is not None) == (n == 3001)
     w = T.row_weights(torch.arange(0, n, 3, device=DEV), n)
 
     def run(pipeline):
@@ -260,7 +262,7 @@ def test_input_pipeline_matches_plain_step(monkeypatch, n, avg, model_type, use_
         torch.testing.assert_close(pb, pa, rtol=5e-3, atol=5e-4, msg=k)
     # the buffers after step 8: filled = operands of step 9 (dropout with the current counter), saved = those of step 8
     pipe = step_b.pipe
-    want_table = AF.dropout(x, 0.2, model_b.dropout_state, tag=0, pad_to=8)
+    want_table = AF.dropout(step_b.x, 0.2, model_b.dropout_state, tag=0, pad_to=8)      # (step_b.x: in the operator's numbering)
     torch.testing.assert_close(pipe.filled[0], want_table, rtol=0, atol=0)
     want_p = AF.spmm(ops.low, want_table, row_scale=ops.row_scale)
     torch.testing.assert_close(pipe.filled[1], want_p, rtol=1e-5, atol=1e-5)
