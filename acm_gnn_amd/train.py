@@ -94,8 +94,11 @@ class TrainStep:
         before the flush -- otherwise deferral is switched off for good and the step is redone."""
         model = self.model
         pipe = self.pipe
-        if pipe is not None and pipe.stale() and not (self.x.is_cuda and torch.cuda.is_current_stream_capturing()):
-            pipe.prime()
+        if pipe is not None and pipe.stale():
+            if self.x.is_cuda and torch.cuda.is_current_stream_capturing():
+                self.pipe = pipe = None           # its buffers cannot be refilled inside a capture: the plain step
+            else:
+                pipe.prime()
         if not self._defer:
             loss, dz, out = self._forward_loss()
             if pipe is not None:
@@ -120,6 +123,8 @@ class TrainStep:
         if not adopted:
             self._defer = False
             self.opt.zero_grad(set_to_none=True)
+            if pipe is not None:
+                pipe.primed = False               # the first pass has already refilled its buffers for the next step
             return self._forward_backward()
         return loss
 

@@ -769,3 +769,38 @@ def test_input_pipeline_equals_plain_train_step(monkeypatch):
     x.mul_(0.5)
     assert step_b.pipe.stale()
     np.testing.assert_allclose(float(step_b()), float(step_a()), rtol=1e-4, atol=1e-6)     # (seven fp32 steps apart by now)
+
+
+def test_input_pipeline_survives_a_redone_step(monkeypatch):
+    """TrainStep redoes a step without deferred reductions when a gradient was not adopted; by then the first pass has
+    refilled the pipeline's buffers for the NEXT step, so the redo must refill them for this one: same losses as the
+    plain step."""
+    fake_lib.install(monkeypatch)
+    monkeypatch.setenv("ACM_PIPELINE_MIN_ROWS", "32")
+    from acm_gnn_amd import GCN, FusedAdamW, functional as AF, train as T
+    ops, n = _dense_graph_ops(seed=9)
+    x, y = torch.randn(n, 7, generator=torch.Generator().manual_seed(4)), torch.randint(0, 2, (n,), generator=torch.Generator().manual_seed(5))
+    w = T.row_weights(torch.arange(0, n, 2), n)
+
+    def run(pipeline, refuse_first):
+        torch.manual_seed(0)
+        model = GCN(7, 64, 2, 2, n, 0.3, "acmgcnp", 0, variant=False, attn_layernorm=True)
+        model.dropout_state = AF.DropoutState(torch.device("cpu"), seed=11)
+        step = T.TrainStep(model, FusedAdamW(model.parameters(), lr=0.02), x, ops, y, w, use_graph=False, fused_dropout=True,
+                           pipeline_input=pipeline)
+        if refuse_first:
+            real, calls = AF.DeferredReductions.all_adopted, []
+            monkeypatch.setattr(AF.DeferredReductions, "all_adopted",
+                                lambda self, t: (calls.append(1), real(self, t) and len(calls) > 1)[1])
+        losses = [float(step()) for _ in range(4)]
+        if refuse_first:
+            monkeypatch.undo()
+            fake_lib.install(monkeypatch)
+            monkeypatch.setenv("ACM_PIPELINE_MIN_ROWS", "32")
+            assert not step._defer
+        return step, losses
+
+    _, plain = run(False, False)
+    step, redone = run(None, True)
+    assert step.pipe is not None
+    np.testing.assert_allclose(redone, plain, rtol=1e-5, atol=1e-6)
