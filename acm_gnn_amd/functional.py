@@ -232,6 +232,7 @@ class InputPipeline:
         self.saved = torch.zeros(2, n, 8, dtype=_F32, device=x.device)
         self.primed = False
         self._x_version = x._version
+        self._host_steps = state.host_steps
         self.next_table_ready = False
         self.next_agg_ready = False
 
@@ -286,13 +287,17 @@ class InputPipeline:
         _lib.check(st, "acm_dropout")
 
     def stale(self):
-        return not self.primed or self.x._version != self._x_version
+        """The buffers do not belong to the step about to run: never filled, the features edited in place, a step that
+        did not finish (exception between make_next and end_step), or the counter advanced by someone else."""
+        return (not self.primed or self.x._version != self._x_version or self.next_table_ready
+                or self.state.host_steps != self._host_steps)
 
     def prime(self):
         self._drop_into(self.filled[0], 0)
         spmm(self.ops.low, self.filled[0], out=self.filled[1], row_scale=self.ops.row_scale)
         self.primed = True
         self._x_version = self.x._version
+        self._host_steps = self.state.host_steps
         self.next_table_ready = self.next_agg_ready = False
 
     def make_next(self):
@@ -307,6 +312,7 @@ class InputPipeline:
         if not (self.next_table_ready and self.next_agg_ready):
             self.primed = False
         self.next_table_ready = self.next_agg_ready = False
+        self._host_steps = self.state.host_steps
 
 
 def _next_proj_request(f, dev):
@@ -602,9 +608,12 @@ class DropoutState:
     def __init__(self, device, seed=None):
         self.seed = int(torch.initial_seed() if seed is None else seed) & 0xFFFFFFFFFFFFFFFF
         self.step = torch.zeros(1, dtype=torch.int64, device=device)
+        self.host_steps = 0          # host-side count of advances (whoever advances `step` on the device bumps it too):
+                                     # lets a consumer that works ahead (InputPipeline) notice that someone else stepped
 
     def advance(self):
         self.step.add_(1)
+        self.host_steps += 1
 
     def spec(self, p, tag, row_offset=0):
         d = _lib.Dropout()

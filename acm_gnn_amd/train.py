@@ -152,8 +152,7 @@ class TrainStep:
         self.opt.zero_grad(set_to_none=True)
         loss = self._forward_backward()
         self.opt.step()
-        if self._manual_advance:
-            self.model.dropout_state.advance()
+        self._count_advance()
         if self.pipe is not None:
             self.pipe.end_step()
         return loss                 # never hand out the autograd graph: a live AccumulateGrad node pins its
@@ -165,7 +164,7 @@ class TrainStep:
         opt_state = [(p, {k: (v.detach().clone() if torch.is_tensor(v) else v) for k, v in st.items()})
                      for p, st in self.opt.state.items()]
         ds = getattr(self.model, "dropout_state", None)
-        return model_state, opt_state, (ds.step.clone() if ds is not None else None)
+        return model_state, opt_state, ((ds.step.clone(), ds.host_steps) if ds is not None else None)
 
     def _restore(self, snap):
         """Put the snapshot back IN PLACE (the captured graph and the optimizer's pointer tables keep their addresses);
@@ -187,7 +186,8 @@ class TrainStep:
                     else:
                         v.zero_()
             if drop_step is not None:
-                self.model.dropout_state.step.copy_(drop_step)
+                self.model.dropout_state.step.copy_(drop_step[0])
+                self.model.dropout_state.host_steps = drop_step[1]
         if getattr(self, "pipe", None) is not None:
             self.pipe.primed = False            # its buffers belong to another counter value now
 
@@ -217,16 +217,26 @@ class TrainStep:
         with torch.cuda.graph(self.graph, **_capture_mode()):
             loss = self._forward_backward()
             self.opt.step()
-            if self._manual_advance:
-                self.model.dropout_state.advance()
+            self._count_advance()
             if self.pipe is not None:
                 self.pipe.end_step()
             self.loss = loss
         del loss
 
+    def _count_advance(self):
+        """The dropout counter moves once per optimizer step: by FusedAdam's kernel (also_advance) or by hand."""
+        ds = getattr(self.model, "dropout_state", None)
+        if self._manual_advance:
+            ds.advance()
+        elif ds is not None and getattr(self.opt, "also_advance", None) is ds.step:
+            ds.host_steps += 1
+
     def __call__(self):
         if self.graph is not None:
             self.graph.replay()
+            ds = getattr(self.model, "dropout_state", None)
+            if ds is not None:
+                ds.host_steps += 1            # the replayed step advanced the device counter
             return self.loss
         return self._eager()
 

@@ -804,3 +804,32 @@ def test_input_pipeline_survives_a_redone_step(monkeypatch):
     step, redone = run(None, True)
     assert step.pipe is not None
     np.testing.assert_allclose(redone, plain, rtol=1e-5, atol=1e-6)
+
+
+def test_input_pipeline_notices_steps_made_by_someone_else(monkeypatch):
+    """Two TrainSteps on one model (bench.py keeps an eager and a captured one): when the other one has advanced the
+    dropout counter, the pipelined step's look-ahead buffers belong to a past step -- DropoutState.host_steps tells."""
+    fake_lib.install(monkeypatch)
+    monkeypatch.setenv("ACM_PIPELINE_MIN_ROWS", "32")
+    from acm_gnn_amd import GCN, FusedAdamW, functional as AF, train as T
+    ops, n = _dense_graph_ops(seed=13)
+    x, y = torch.randn(n, 7, generator=torch.Generator().manual_seed(6)), torch.randint(0, 2, (n,), generator=torch.Generator().manual_seed(7))
+    w = T.row_weights(torch.arange(0, n, 2), n)
+
+    def fresh():
+        torch.manual_seed(0)
+        model = GCN(7, 64, 2, 2, n, 0.3, "acmgcnp", 0, variant=False, attn_layernorm=True)
+        model.dropout_state = AF.DropoutState(torch.device("cpu"), seed=21)
+        return model, FusedAdamW(model.parameters(), lr=0.02)
+
+    model, opt = fresh()
+    plain = T.TrainStep(model, opt, x, ops, y, w, fused_dropout=True, pipeline_input=False)
+    want = [float(plain()) for _ in range(4)]
+    model, opt = fresh()
+    piped = T.TrainStep(model, opt, x, ops, y, w, fused_dropout=True)
+    other = T.TrainStep(model, opt, x, ops, y, w, fused_dropout=True, pipeline_input=False)
+    assert piped.pipe is not None and other.pipe is None
+    got = [float(piped()), float(piped()), float(other())]
+    assert piped.pipe.stale()
+    got.append(float(piped()))
+    np.testing.assert_allclose(got, want, rtol=1e-5, atol=1e-6)
