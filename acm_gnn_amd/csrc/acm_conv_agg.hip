@@ -16,6 +16,8 @@
 int acm_spmm_internal(const acm_csr* a, const void* G, int64_t ldg, int width, float* Y, int64_t ldy,
                       const acm_spmm_opts_t* o, void* workspace, size_t workspace_bytes, acm_stream_t stream,
                       bool* defer_fixup);
+// defined in acm_conv_agg16.hip: the row-local forward stage in the transposed matrix-core layout (-1: not its case)
+int acm_agg_epi16(const acm_conv_agg_fwd_t* p, int64_t n_rows, bool* next_done, hipStream_t s);
 
 namespace {
 
@@ -1151,7 +1153,9 @@ extern "C" int acm_conv_agg_fwd(const acm_csr_t* a, const acm_conv_agg_fwd_t* p,
     acm_spmm_opts_t o = {nullptr, p->row_scale, nullptr, 0, nullptr, 0, 0};
     // three channels: the long rows' partial sums stay in the workspace and the epilogue kernel adds them (one launch
     // less); with the structure channel the second gather reuses the workspace, so the fix-up runs right away
-    bool defer = !p->agg_given && p->n_channels == 3 && a->n_long > 0 && a->long_index != nullptr;
+    // (the sixteen-rows-per-wave stage of acm_conv_agg16.hip reads finished rows of P: the fix-up runs right away there)
+    const bool epi16 = p->n_channels == 3 && p->f_pad == 8 && p->f_out == 64 && getenv("ACM_EPI16_OFF") == nullptr;
+    bool defer = !p->agg_given && p->n_channels == 3 && a->n_long > 0 && a->long_index != nullptr && !epi16;
     if (!p->agg_given) {
         st = acm_spmm_internal(a, p->xg, p->ld_xg, p->f_pad, p->agg, p->ld_agg, &o, workspace, workspace_bytes, stream, &defer);
         if (st != ACM_OK) return st;
@@ -1164,6 +1168,11 @@ extern "C" int acm_conv_agg_fwd(const acm_csr_t* a, const acm_conv_agg_fwd_t* p,
         if (st != ACM_OK) return st;
     }
     // (2) projections + head, row-local
+    if (epi16 && !defer) {
+        st = acm_agg_epi16(p, a->n_rows, &next_done, s);
+        if (st == ACM_OK) return next_done ? ACM_OK : next_projection(a, p, stream);
+        if (st > 0) return st;
+    }
     int grid = (int)((a->n_rows + 15) / 16);
     {
         int cap = 2048;
