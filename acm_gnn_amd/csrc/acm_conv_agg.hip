@@ -18,6 +18,8 @@ int acm_spmm_internal(const acm_csr* a, const void* G, int64_t ldg, int width, f
                       bool* defer_fixup);
 // defined in acm_conv_agg16.hip: the row-local forward stage in the transposed matrix-core layout (-1: not its case)
 int acm_agg_epi16(const acm_conv_agg_fwd_t* p, int64_t n_rows, bool* next_done, hipStream_t s);
+// ... and the row-local backward (blocks launched; 0: not its case; < 0: error)
+int acm_agg_bwd16(const acm_conv_agg_bwd_t* p, int64_t n_rows, float* partial, int max_blocks, hipStream_t s);
 
 namespace {
 
@@ -1271,6 +1273,14 @@ extern "C" int acm_conv_agg_bwd(int64_t n_rows, const acm_conv_agg_bwd_t* p, voi
         ACM_CHECK_HIP(hipGetLastError());
         const acm_reduce_seg_t seg = {partial, nblk, 32, 0, npg, p->d_params, npg, 0, 0, 0, nblk * 32, 0};
         return acm_reduce_emit(p->defer, &seg, 1, s);
+    }
+    if (!p->next_agg) {                           // sixteen rows per wave, transposed matrix-core layout (acm_conv_agg16.hip)
+        const int nb16 = acm_agg_bwd16(p, n_rows, partial, nblk, s);
+        if (nb16 < 0) return -nb16;
+        if (nb16 > 0) {
+            const acm_reduce_seg_t seg = {partial, nb16, 32, 0, npg, p->d_params, npg, 0, 0, 0, nb16 * 32, 0};
+            return acm_reduce_emit(p->defer, &seg, 1, s);
+        }
     }
 #define ACM_BWDK(FPv)                                                                                                  \
     do {                                                                                                              \

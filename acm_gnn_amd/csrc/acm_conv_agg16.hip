@@ -258,6 +258,303 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     epi16_body<LN, NEXT>(p, n_rows);
 }
 
+// ---------------------------------------------------------------- backward (K3a) in the same layout
+// Per wave step (16 rows): the projections again on the matrix pipe (H is not stored: 768 B per row), the row's head
+// statistics as the forward computed them (head_stats), the head backward with one cross-row sum per reduction, and
+//     dW_c[f][col] += sum_rows A_c[row][f] G_c[row][col]
+// on the matrix pipe as before -- but its operands want the ROW index on lane >> 4 (the contraction index of
+// v_mfma_f32_16x16x4_f32) while the transposed layout has it on lane & 15, so each channel's G passes through a per-wave
+// LDS tile (16 rows x 64 columns, written as 16-byte pieces, read back as the MFMA's B operand; the wave's own LDS
+// accesses are ordered, no barrier).  The row-sums of the head parameters (A_c[col] = sum_rows ds_c xhat_c, see
+// row_channel_backward) accumulate per lane for the lane's own row and are summed over the 16 row-lanes once, after the
+// row loop.
+#define ACM_B16_TS 68                  /* floats per tile row: 16-byte writes of eight consecutive row-lanes and the B-operand reads
+                                          (rows 4 g + s: two row groups per LDS pass, 16 banks apart) are conflict-free */
+#define ACM_B16_PS 17                  /* floats per [P | x] row */
+#define ACM_B16_LDS (4 * 2121 + 64)    /* tiles | [P|x] rows | head parameters | weights; the end-of-kernel slabs alias it */
+
+// sum over the 16 lanes of a row for 16 values per lane, leaving value i's total in lane i (m = i): a reduce-scatter of four
+// DPP exchange steps (partner = 15 - m, 7 - m within the half, m ^ 2, m ^ 1; each lane keeps the half of the values its
+// own lane bit selects and adds the partner's copy of them) -- 45 instructions, where sixteen all-reduces cost 64 and
+// sixteen per-lane accumulators would pin 48 registers per kernel.
+__device__ __forceinline__ float row_reduce_scatter16(const float (&v)[16], int m) {
+    const bool b3 = (m & 8) != 0, b2 = (m & 4) != 0, b1 = (m & 2) != 0, b0 = (m & 1) != 0;
+    float a[8], b[4], c[2];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) a[i] = (b3 ? v[i + 8] : v[i]) + acm_dpp<0x140>(b3 ? v[i] : v[i + 8]);       // row_mirror
+#pragma unroll
+    for (int i = 0; i < 4; ++i) b[i] = (b2 ? a[i + 4] : a[i]) + acm_dpp<0x141>(b2 ? a[i] : a[i + 4]);       // row_half_mirror
+#pragma unroll
+    for (int i = 0; i < 2; ++i) c[i] = (b1 ? b[i + 2] : b[i]) + acm_dpp<0x4E>(b1 ? b[i] : b[i + 2]);        // quad_perm [2,3,0,1]
+    return (b0 ? c[1] : c[0]) + acm_dpp<0xB1>(b0 ? c[0] : c[1]);                                            // quad_perm [1,0,3,2]
+}
+
+template <bool LN, bool OUT_MASK>
+__global__ __launch_bounds__(256) void agg_bwd16_kernel(acm_conv_agg_bwd_t p, int n_rows, float* __restrict__ partial) {
+    __shared__ __attribute__((aligned(16))) float lds[ACM_B16_LDS];
+    const int lane = threadIdx.x & 63, m = lane & 15, g = lane >> 4, wv = threadIdx.x >> 6;
+    float* gt = lds + wv * (16 * ACM_B16_TS);                 // this wave's G tile
+    float* px = lds + 4 * 16 * ACM_B16_TS + wv * 16 * ACM_B16_PS;   // this wave's [P | x] rows, 16 floats each
+    float* hl = lds + 4 * 16 * ACM_B16_TS + 4 * 16 * ACM_B16_PS + 16;   // [att_vec | gamma | beta][c][col]  (576 floats) + u_c (192); 16-byte aligned
+    float* ul = hl + 576;
+    float* wl = ul + 192;                                     // A operands of the projections, [(c, kb, t)][lane]
+    static_assert(ACM_B16_LDS >= 4 * 16 * ACM_B16_TS + 4 * 16 * ACM_B16_PS + 16 + 768 + 24 * 64, "tiles | [P|x] rows | head parameters | weights");
+    const int f_in = p.f_in;
+    // one round of independent global loads, one barrier: the head parameters, u = att_vec * gamma, the projections' A
+    // operands W_c[f = 4 kb + g][col = 16 t + m] (the same for every wave), c1_c = mean_col(u_c)
+    for (int idx = threadIdx.x; idx < 576; idx += 256) {
+        const int arr = idx / 192, c = (idx / 64) % 3, col = idx & 63;
+        const float* av = c == 0 ? p.att_vec[0] : (c == 1 ? p.att_vec[1] : p.att_vec[2]);
+        float v;
+        if (arr == 0) v = av[col];
+        else if (LN) {
+            const float* gw = c == 0 ? p.ln_weight[0] : (c == 1 ? p.ln_weight[1] : p.ln_weight[2]);
+            const float* gb = c == 0 ? p.ln_bias[0] : (c == 1 ? p.ln_bias[1] : p.ln_bias[2]);
+            v = arr == 1 ? gw[col] : gb[col];
+        } else v = arr == 1 ? 1.f : 0.f;
+        hl[idx] = v;
+    }
+    float c1[3];
+    if (threadIdx.x < 192) {
+        const int c = threadIdx.x >> 6, col = threadIdx.x & 63;
+        const float* av = c == 0 ? p.att_vec[0] : (c == 1 ? p.att_vec[1] : p.att_vec[2]);
+        float u = av[col];
+        if (LN) {
+            const float* gw = c == 0 ? p.ln_weight[0] : (c == 1 ? p.ln_weight[1] : p.ln_weight[2]);
+            u *= gw[col];
+        }
+        ul[threadIdx.x] = u;
+    }
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        float u = p.att_vec[c][lane];
+        if (LN) u *= p.ln_weight[c][lane];
+        c1[c] = acm_group_sum<64>(u) * (1.0f / 64.0f);
+    }
+    for (int idx = threadIdx.x; idx < 24 * 64; idx += 256) {
+        const int e = idx >> 6, l2 = idx & 63, c = e >> 3, kb = (e >> 2) & 1, t = e & 3, f = 4 * kb + (l2 >> 4);
+        const float* w = c == 0 ? p.w_low : (c == 1 ? p.w_high : p.w_mlp);
+        wl[idx] = f < f_in ? w[(long)f * p.ld_w + 16 * t + (l2 & 15)] : 0.f;
+    }
+    float mixm[9];
+#pragma unroll
+    for (int q = 0; q < 9; ++q) mixm[q] = p.att_mix[q];
+    __syncthreads();
+    const float lo_a = p.relu_after ? 0.f : -INFINITY, lo_m = p.relu_mlp ? 0.f : -INFINITY;
+    constexpr bool out_mask = OUT_MASK;
+    const float post_gain = p.post_drop.p > 0.f ? 1.0f / (1.0f - p.post_drop.p) : 1.f;
+    const unsigned ld_agg = (unsigned)p.ld_agg, ld_xs = (unsigned)p.ld_xs, ld_go = (unsigned)p.ld_grad_out,
+                   ld_out = (unsigned)p.ld_out, ld_hs = (unsigned)p.ld_head_stats;
+    const int wave = blockIdx.x * 4 + wv, nwaves = gridDim.x * 4;
+    const float wq = g == 0 ? 1.f : 0.f;            // a row's scalars sit in four lanes: one of them accumulates
+    const float fsel = m < 8 ? 1.f : 0.f;           // A operand of the dW products: feature f = m (< f_pad)
+
+    f32x4 acc[3][4];
+    float pA[3], pS[3], dmix[9];         // pA[c]: lane (g, m) accumulates column 16 (m >> 2) + 4 g + (m & 3) of A_c
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        pS[c] = pA[c] = 0.f;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) acc[c][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+#pragma unroll
+    for (int q = 0; q < 9; ++q) dmix[q] = 0.f;
+
+    int base = wave * 16;
+    float nPa = 0.f, nPb = 0.f, nxa = 0.f, nxb = 0.f;
+    f32x4 ngo[4], nou[4], nst[3];
+    // the small operands (P, x, head statistics: 112 B per row) are requested one step ahead; grad_out and out (512 B per row)
+    // at the top of their own step, ahead of the projections
+#define ACM_B16_LOAD(BASE)                                                                              \
+    do {                                                                                                \
+        const unsigned r2 = (unsigned)min((BASE) + m, n_rows - 1);                                      \
+        nPa = p.agg[r2 * ld_agg + g], nPb = p.agg[r2 * ld_agg + 4 + g];                                 \
+        nxa = p.xs[r2 * ld_xs + g], nxb = p.xs[r2 * ld_xs + 4 + g];                                     \
+        _Pragma("unroll") for (int q = 0; q < 3; ++q)                                                   \
+            nst[q] = *reinterpret_cast<const f32x4*>(p.head_stats + r2 * ld_hs + 4 * q);                \
+    } while (0)
+    if (base < n_rows) ACM_B16_LOAD(base);
+    for (; base < n_rows; base += nwaves * 16) {
+        const bool valid = base + m < n_rows;
+        const float Pa = nPa, Pb = nPb, xa = nxa, xb = nxb;
+        {
+            const unsigned r1 = (unsigned)min(base + m, n_rows - 1);
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                ngo[t] = *reinterpret_cast<const f32x4*>(p.grad_out + r1 * ld_go + 16 * t + 4 * g);
+                if (out_mask) nou[t] = *reinterpret_cast<const f32x4*>(p.out + r1 * ld_out + 16 * t + 4 * g);
+            }
+        }
+        const float mean[3] = {nst[0][0], nst[0][1], nst[0][2]}, rstd[3] = {nst[0][3], nst[1][0], nst[1][1]};
+        const float gsig[3] = {nst[1][2], nst[1][3], nst[2][0]}, al[3] = {nst[2][1], nst[2][2], nst[2][3]};
+        ACM_B16_LOAD(base + nwaves * 16);           // the next step's operands (the addresses are clamped)
+        const int gq = acm_opaque(g), mq = acm_opaque(m);
+        px[mq * ACM_B16_PS + gq] = Pa, px[mq * ACM_B16_PS + 4 + gq] = Pb, px[mq * ACM_B16_PS + 8 + gq] = xa, px[mq * ACM_B16_PS + 12 + gq] = xb;
+        const float opa[3] = {Pa, xa - Pa, xa}, opb[3] = {Pb, xb - Pb, xb};
+        f32x4 D[3][4];
+        const int lq = acm_opaque(lane);
+#pragma unroll
+        for (int c = 0; c < 3; ++c)
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+                D[c][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(wl[((c * 2 + 0) * 4 + t) * 64 + lq], opa[c], (f32x4){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+#pragma unroll
+        for (int c = 0; c < 3; ++c)
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+                D[c][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(wl[((c * 2 + 1) * 4 + t) * 64 + lq], opb[c], D[c][t], 0, 0, 0);
+        // A operands of the dW products: MFMA step s contracts rows 4 g + s of this wave step, feature m
+        float aP[4], aX[4];
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            aP[s] = px[(4 * gq + s) * ACM_B16_PS + (mq & 7)] * fsel;
+            aX[s] = px[(4 * gq + s) * ACM_B16_PS + 8 + (mq & 7)] * fsel;
+        }
+        f32x4 dO[4];
+        {
+            const float gate = valid ? post_gain : 0.f;
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    dO[t][r] = out_mask ? ((nou[t][r] != 0.f) ? ngo[t][r] * gate : 0.f) : (valid ? ngo[t][r] : 0.f);
+        }
+        // ---- mix / softmax / sigmoid backward: ds_c = dL/ds_c per row
+        float dal[3], ds[3];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const float lo = c < 2 ? lo_a : lo_m;
+            float part = 0.f;
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    D[c][t][r] = fmaxf(D[c][t][r], lo);
+                    part = fmaf(dO[t][r], D[c][t][r], part);
+                }
+            dal[c] = p.scale * row4_sum(part);
+        }
+        {
+            const float dot = fmaf(al[2], dal[2], fmaf(al[1], dal[1], al[0] * dal[0]));
+            float dlg[3];
+#pragma unroll
+            for (int j = 0; j < 3; ++j) dlg[j] = al[j] * (dal[j] - dot);
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                float dg = 0.f;
+#pragma unroll
+                for (int j = 0; j < 3; ++j) {
+                    dg = fmaf(dlg[j], mixm[c * 3 + j], dg);
+                    dmix[c * 3 + j] = fmaf(wq * gsig[c], dlg[j] * (1.0f / 3.0f), dmix[c * 3 + j]);
+                }
+                ds[c] = dg * (1.0f / 3.0f) * gsig[c] * (1.f - gsig[c]);
+                pS[c] = fmaf(wq, ds[c], pS[c]);
+            }
+        }
+        // ---- one channel at a time: G_c -> LDS tile -> dW_c on the matrix pipe
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const float lo = c < 2 ? lo_a : lo_m;
+            const float aal = p.scale * al[c];
+            f32x4 G[4];
+            if (LN) {
+                float t2 = 0.f, contrib[16];
+                f32x4 xh[4];
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    const f32x4 u = *reinterpret_cast<const f32x4*>(ul + c * 64 + 16 * t + 4 * gq);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        xh[t][r] = (D[c][t][r] - mean[c]) * rstd[c];
+                        contrib[4 * t + r] = ds[c] * xh[t][r];
+                        t2 = fmaf(u[r], xh[t][r], t2);
+                    }
+                }
+                pA[c] += row_reduce_scatter16(contrib, mq);
+                const float m1 = ds[c] * c1[c], m2 = ds[c] * row4_sum(t2) * (1.0f / 64.0f);
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    const f32x4 u = *reinterpret_cast<const f32x4*>(ul + c * 64 + 16 * t + 4 * gq);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float v = fmaf(aal, dO[t][r], rstd[c] * (fmaf(ds[c], u[r], -m1) - xh[t][r] * m2));
+                        G[t][r] = D[c][t][r] > lo ? v : 0.f;
+                    }
+                }
+            } else {
+                float contrib[16];
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    const f32x4 u = *reinterpret_cast<const f32x4*>(ul + c * 64 + 16 * t + 4 * gq);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        contrib[4 * t + r] = ds[c] * D[c][t][r];
+                        const float v = fmaf(aal, dO[t][r], ds[c] * u[r]);
+                        G[t][r] = D[c][t][r] > lo ? v : 0.f;
+                    }
+                }
+                pA[c] += row_reduce_scatter16(contrib, mq);
+            }
+#pragma unroll
+            for (int t = 0; t < 4; ++t) *reinterpret_cast<f32x4*>(gt + mq * ACM_B16_TS + 16 * t + 4 * gq) = G[t];
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                const float aop = c == 0 ? aP[s] : (c == 1 ? aX[s] - aP[s] : aX[s]);
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+                    acc[c][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(aop, gt[(4 * gq + s) * ACM_B16_TS + 16 * t + mq], acc[c][t], 0, 0, 0);
+            }
+        }
+    }
+#undef ACM_B16_LOAD
+    // ---- end of the row loop: head-parameter sums over the 16 row-lanes, then the block's partial slab
+    const int npg = 3 * f_in * 64 + 9 * 64 + 9;
+    // value i = 4 t + r of lane (g, m = i) is column 16 t + 4 g + r: one column of A_c per lane
+    const int mycol = 16 * (m >> 2) + 4 * g + (m & 3);
+    float dv[3], dgam[3], dbet[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        pS[c] = acm_group_sum<64>(pS[c]);
+        const float v = hl[c * 64 + mycol], gm = hl[192 + c * 64 + mycol], bt = hl[384 + c * 64 + mycol];
+        dv[c] = fmaf(gm, pA[c], bt * pS[c]);
+        dgam[c] = v * pA[c];
+        dbet[c] = v * pS[c];
+    }
+#pragma unroll
+    for (int q = 0; q < 9; ++q) dmix[q] = acm_group_sum<64>(dmix[q]);
+    __syncthreads();                               // every wave is done with the tiles and the staged parameters
+    float* slab = lds + wv * npg;
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int f = 4 * g + r;
+                if (f < f_in) slab[(c * f_in + f) * 64 + 16 * t + m] = acc[c][t][r];
+            }
+    {
+        const int b2 = 3 * f_in * 64;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            slab[b2 + (0 * 3 + c) * 64 + mycol] = dv[c];
+            slab[b2 + (1 * 3 + c) * 64 + mycol] = dgam[c];
+            slab[b2 + (2 * 3 + c) * 64 + mycol] = dbet[c];
+        }
+    }
+    if (lane < 9) {
+        float v = dmix[0];
+#pragma unroll
+        for (int q = 1; q < 9; ++q) v = lane == q ? dmix[q] : v;
+        slab[3 * f_in * 64 + 9 * 64 + lane] = v;
+    }
+    __syncthreads();
+    for (int q = threadIdx.x; q < npg; q += 256) {
+        const float v = (lds[q] + lds[npg + q]) + (lds[2 * npg + q] + lds[3 * npg + q]);
+        partial[((long)(q >> 5) * gridDim.x + blockIdx.x) * 32 + (q & 31)] = v;
+    }
+}
+
 }  // namespace
 
 // The row-local forward stage over an existing P = A_low X (p->agg).  Returns ACM_OK after a launch, -1 when the
@@ -296,4 +593,35 @@ int acm_agg_epi16(const acm_conv_agg_fwd_t* p, int64_t n_rows, bool* next_done, 
     ACM_CHECK_HIP(hipGetLastError());
     *next_done = next;
     return ACM_OK;
+}
+
+// The row-local backward over the forward's head_stats.  Returns the number of blocks launched (> 0), 0 when the
+// configuration is not this kernel's (the caller runs agg_bwd_kernel), or a negative acm_status_t.
+int acm_agg_bwd16(const acm_conv_agg_bwd_t* p, int64_t n_rows, float* partial, int max_blocks, hipStream_t s) {
+    if (p->n_channels != 3 || p->f_pad != 8 || p->f_out != 64 || !p->head_stats || getenv("ACM_BWD16_OFF") != nullptr) return 0;
+    const bool out_mask = p->out != nullptr && p->post_relu && !p->post_scale;
+    const bool no_post = !p->post_relu && !p->post_scale && !(p->post_drop.p > 0.f);
+    if (!out_mask && !no_post) return 0;
+    for (const void* q : {(const void*)p->grad_out, (const void*)p->out, (const void*)p->head_stats})
+        if (((uintptr_t)q) % 16 != 0) return 0;
+    if (p->ld_grad_out % 4 != 0 || (out_mask && p->ld_out % 4 != 0) || p->ld_head_stats % 4 != 0) return 0;
+    acm_conv_agg_bwd_t q = *p;
+    if (!out_mask) q.out = nullptr;
+    int grid = (int)((n_rows + 63) / 64);
+    int cap = 512;
+    if (const char* env = getenv("ACM_BWD16_BLOCKS")) {
+        const int v = atoi(env);
+        if (v >= 1) cap = v;
+    }
+    if (cap > max_blocks) cap = max_blocks;
+    if (grid > cap) grid = cap;
+    if (p->layernorm) {
+        if (out_mask) hipLaunchKernelGGL((agg_bwd16_kernel<true, true>), dim3(grid), dim3(256), 0, s, q, (int)n_rows, partial);
+        else hipLaunchKernelGGL((agg_bwd16_kernel<true, false>), dim3(grid), dim3(256), 0, s, q, (int)n_rows, partial);
+    } else {
+        if (out_mask) hipLaunchKernelGGL((agg_bwd16_kernel<false, true>), dim3(grid), dim3(256), 0, s, q, (int)n_rows, partial);
+        else hipLaunchKernelGGL((agg_bwd16_kernel<false, false>), dim3(grid), dim3(256), 0, s, q, (int)n_rows, partial);
+    }
+    if (hipGetLastError() != hipSuccess) return -ACM_EHIP;
+    return grid;
 }

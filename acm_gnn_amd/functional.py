@@ -7,6 +7,7 @@ missing library is an error.
 """
 import ctypes as C
 import os
+import threading
 
 import torch
 
@@ -137,22 +138,62 @@ class DeferredReductions:
         self._allreduce = []
 
 
-_DEFER = None          # module-wide on purpose: autograd runs backward() on its own thread
+class CallContext:
+    """What a caller hands DOWN one forward (and, captured by the autograd Functions, its backward) beside the tensors:
+
+    * ``defer``     a DeferredReductions the second phases of the call's kernels are appended to (or None: reduce at once)
+    * ``tail``      a pending fused_loss_tail request for the model's output layer
+    * ``pipe``      the training loop's InputPipeline
+    * ``next_proj`` / ``pre_proj``  the narrow-projection hand-off between a hidden layer and the layer that follows it
+
+    A context belongs to ONE model call: models.GCN / layers.GraphConvolution take it as ``call=`` (train.TrainStep passes
+    its own) or derive a fresh one from the thread's ambient context -- what ``with deferred_reductions()`` /
+    ``with fused_loss_tail()`` blocks of the calling thread have set.  Nothing lives in module globals: two models, two
+    threads or an exception between two layers cannot see each other's hand-offs, and a backward (which autograd may run on
+    another thread) uses the context its forward captured."""
+    __slots__ = ("defer", "tail", "pipe", "next_proj", "pre_proj")
+
+    def __init__(self, defer=None, tail=None, pipe=None):
+        self.defer, self.tail, self.pipe = defer, tail, pipe
+        self.next_proj = self.pre_proj = None
+
+    @classmethod
+    def from_ambient(cls):
+        a = _ambient()
+        return cls(a.defer, a.tail, a.pipe)
+
+    def defer_ptr(self):
+        return self.defer.pointer() if self.defer is not None else None
+
+
+_TLS = threading.local()
+
+
+def _ambient():
+    """The calling thread's ambient context (created on first use)."""
+    c = getattr(_TLS, "call", None)
+    if c is None:
+        c = _TLS.call = CallContext()
+    return c
+
+
+def _call_or_ambient(call):
+    return call if call is not None else CallContext.from_ambient()
 
 
 class deferred_reductions:
-    """``with deferred_reductions() as d: ...; d.flush()`` -- the calls inside append their second phases to ``d``.
-    Leaving the block flushes whatever is still pending (or drops it when an exception is propagating)."""
+    """``with deferred_reductions() as d: ...; d.flush()`` -- the calls the thread makes inside (and the backward of what
+    it ran forward inside) append their second phases to ``d``.  Leaving the block flushes whatever is still pending (or
+    drops it when an exception is propagating)."""
 
     def __enter__(self):
-        global _DEFER
-        self.prev, self.d = _DEFER, DeferredReductions()
-        _DEFER = self.d
+        a = _ambient()
+        self.prev, self.d = a.defer, DeferredReductions()
+        a.defer = self.d
         return self.d
 
     def __exit__(self, exc_type, *rest):
-        global _DEFER
-        _DEFER = self.prev
+        _ambient().defer = self.prev
         if exc_type is None:
             self.d.flush()
         else:
@@ -160,8 +201,21 @@ class deferred_reductions:
         return False
 
 
-def _defer_ptr():
-    return _DEFER.pointer() if _DEFER is not None else None
+class deferred_reductions_as:
+    """``with deferred_reductions_as(d): ...`` -- make an existing DeferredReductions (or None) the thread's ambient one;
+    the caller keeps the responsibility to flush or discard it."""
+
+    def __init__(self, d):
+        self.d = d
+
+    def __enter__(self):
+        a = _ambient()
+        self.prev, a.defer = a.defer, self.d
+        return self.d
+
+    def __exit__(self, *exc):
+        _ambient().defer = self.prev
+        return False
 
 
 class fused_loss_tail:
@@ -177,36 +231,35 @@ class fused_loss_tail:
         self.loss = self.dz = self.out = None
 
     def __enter__(self):
-        global _TAIL
-        self.prev = _TAIL
-        _TAIL = self
+        a = _ambient()
+        self.prev = a.tail
+        a.tail = self
         return self
 
     def __exit__(self, *exc):
-        global _TAIL
-        _TAIL = self.prev
+        _ambient().tail = self.prev
         return False
 
     def matches(self, out):
         return self.out is not None and out is not None and out.data_ptr() == self.out.data_ptr() \
             and out.shape == self.out.shape
 
-_TAIL = None            # the pending request, consumed by the first layer that qualifies
-_TAIL_LAYER = False     # set by layers.GraphConvolution.forward around the call of an output layer without post-op
-# Cross-layer hand-off of the narrow projection (acm_conv_agg_fwd_t.next_*): models.GCN names the FOLLOWING layer in
-# _NEXT_PROJ around the call of a hidden layer; an aggregate-first forward that can carry that layer's projection in its
-# epilogue computes [out W_L' | out W_H'], out W_I' there and leaves them in _PRE_PROJ, and the following layer's forward
-# takes them instead of launching acm_proj_fwd -- provided it is handed exactly that output tensor and those weights.
-_NEXT_PROJ = None
-_PRE_PROJ = None
-# Evaluation passes over a static feature matrix: layers.GraphConvolution hands a holder {"agg": tensor-or-None} around an
-# eval-mode, no-grad call; an aggregate-first forward then reuses P = A_low X from the holder (acm_conv_agg_fwd_t.agg_given:
-# the gather is skipped) or leaves the P it computed there for the next pass.  The layer decides when the holder is valid.
-_AGG_CACHE = None
-# Input pipelining of a training loop (InputPipeline below; acm_conv_agg_bwd_t.next_agg): the loop sets _PIPE around its
-# forward + backward; models.GCN takes the step's dropped input from it, the first layer's aggregate-first forward its
-# P = A_low dropout(x) (acm_conv_agg_fwd_t.agg_given), and that layer's backward carries the gather for the next step.
-_PIPE = None
+
+class input_pipeline:
+    """``with input_pipeline(pipe): ...`` -- the thread's model calls inside see the training loop's InputPipeline."""
+
+    def __init__(self, pipe):
+        self.pipe = pipe
+
+    def __enter__(self):
+        a = _ambient()
+        self.prev = a.pipe
+        a.pipe = self.pipe
+        return self.pipe
+
+    def __exit__(self, *exc):
+        _ambient().pipe = self.prev
+        return False
 
 
 class InputPipeline:
@@ -235,6 +288,7 @@ class InputPipeline:
         self._host_steps = state.host_steps
         self.next_table_ready = False
         self.next_agg_ready = False
+        self.adopted = False             # set by the forward that took P from this pipeline (and left its copies in ``saved``)
 
     @staticmethod
     def eligible(model, ops, x):
@@ -298,28 +352,36 @@ class InputPipeline:
         self.primed = True
         self._x_version = self.x._version
         self._host_steps = self.state.host_steps
-        self.next_table_ready = self.next_agg_ready = False
+        self.next_table_ready = self.next_agg_ready = self.adopted = False
 
     def make_next(self):
-        """Between the forward and the backward: the next step's dropped input replaces this step's (the forward has
-        left its copy in ``saved``)."""
+        """Between the forward and the backward: the next step's dropped input replaces this step's -- only if the forward
+        took this step's from the pipeline and left its copies in ``saved`` (``adopted``); a forward that went another way
+        (an environment switch, another path of the layer) may have saved the table itself for its backward."""
+        if not self.adopted:
+            return False
         self._drop_into(self.filled[0], 1)
         self.next_table_ready = True
+        return True
 
     def end_step(self):
         """After the optimizer step (which advanced the counter).  If the layer's backward did not carry the gather (it
         fell back to another path), ``filled`` is stale: prime() again before the next forward."""
         if not (self.next_table_ready and self.next_agg_ready):
             self.primed = False
-        self.next_table_ready = self.next_agg_ready = False
+        self.next_table_ready = self.next_agg_ready = self.adopted = False
         self._host_steps = self.state.host_steps
 
 
-def _next_proj_request(f, dev):
-    """(weights, relu_before, F') of the layer named in _NEXT_PROJ when its projection can ride this layer's epilogue."""
-    global _NEXT_PROJ
-    nxt, _NEXT_PROJ = _NEXT_PROJ, None
-    if nxt is None or os.environ.get("ACM_NEXT_PROJ", "0") != "1":        # opt-in: measured neutral (DESIGN.md section 9a)
+def _next_proj_request(call, f, dev, row_local_only=False):
+    """(weights, relu_before, F') of the layer named in ``call.next_proj`` when its projection can ride this layer's epilogue.
+    Default: only where the row-local stage runs as its own kernel (``row_local_only``: P = A_low X is given -- the input
+    pipeline, evaluation passes -- and the sixteen-rows-per-wave kernel of acm_conv_agg16.hip carries the projection for
+    ~6 us against the ~20 us of a separate acm_proj_fwd launch); inside the fused gather kernel it costs what it saves
+    (DESIGN.md section 9a).  ACM_NEXT_PROJ=1 / 0 forces it on / off."""
+    nxt, call.next_proj = call.next_proj, None
+    want = os.environ.get("ACM_NEXT_PROJ", "auto")
+    if nxt is None or want == "0" or (want != "1" and not row_local_only):
         return None
     try:
         w3 = (nxt.weight_low, nxt.weight_high, nxt.weight_mlp)
@@ -332,10 +394,9 @@ def _next_proj_request(f, dev):
     return (w3, bool(cfg.relu_before), f2) if ok else None
 
 
-def _take_pre_proj(x, w3, relu):
-    """The projection a preceding layer left for (x, w3, relu), or None."""
-    global _PRE_PROJ
-    pre, _PRE_PROJ = _PRE_PROJ, None
+def _take_pre_proj(call, x, w3, relu):
+    """The projection a preceding layer of the same model call left for (x, w3, relu), or None."""
+    pre, call.pre_proj = call.pre_proj, None
     if pre is None or not isinstance(x, torch.Tensor):
         return None
     out, zlh, zi, ptrs, prelu = pre
@@ -444,10 +505,12 @@ def proj_fwd(x, weights, out_lh, out_i, relu=False, h_col=None):
     _lib.check(st, "acm_proj_fwd_at")
 
 
-def proj_bwd(x, dz, weights, d_w_out):
+def proj_bwd(x, dz, weights, d_w_out, defer=None):
     """Backward of the skinny projection Z = x @ [W_L | W_H | W_I] in one pass over x (acm_proj_bwd): returns
     dX = dz @ Wcat.T and fills ``d_w_out`` ([3, f_in, F], contiguous) with x.T @ dz.  ``weights``: the three
-    [f_in, F] matrices."""
+    [f_in, F] matrices.  ``defer``: a DeferredReductions the second phase is appended to (default: the thread's)."""
+    if defer is None:
+        defer = _ambient().defer
     x, dz = _as_f32c(x, "x"), _as_f32c(dz, "dz")
     ws3 = [_as_f32c(w, "weight") for w in weights]
     n, f_in = x.shape
@@ -465,10 +528,10 @@ def proj_bwd(x, dz, weights, d_w_out):
     with _device_ctx(x.device), _Timed(f"proj_bwd/{n}x{f_in}x{q}"):
         st = lib.acm_proj_bwd(n, f_in, q, _vp(x), x.stride(0), _vp(dz), dz.stride(0), _vp(ws3[0]), _vp(ws3[1]), _vp(ws3[2]),
                               ws3[0].stride(0), _vp(dx), dx.stride(0), _vp(d_w_out), nb, nb, f_in * nb, _vp(ws),
-                              nbytes.value, _defer_ptr(), _stream())
+                              nbytes.value, defer.pointer() if defer is not None else None, _stream())
     _lib.check(st, "acm_proj_bwd")
-    if _DEFER is not None:
-        _DEFER.hold(ws, [d_w_out])
+    if defer is not None:
+        defer.hold(ws, [d_w_out])
     return dx
 
 
@@ -545,7 +608,7 @@ class _MaskedNll(torch.autograd.Function):
     (acm_nll_loss)."""
 
     @staticmethod
-    def forward(ctx, logits, labels, row_weight):
+    def forward(ctx, logits, labels, row_weight, defer=None):
         lib = _lib.load()
         z = _as_f32c(logits, "logits")
         w = _as_f32c(row_weight, "row_weight")
@@ -561,26 +624,28 @@ class _MaskedNll(torch.autograd.Function):
         ws = torch.empty(max(nbytes.value // 4, 1), dtype=_F32, device=z.device)
         with _device_ctx(z.device), _Timed(f"nll_loss/{n}x{c}"):
             st = lib.acm_nll_loss(n, c, _vp(z), z.stride(0), _vp(y), _vp(w), _vp(loss), _vp(dz), dz.stride(0),
-                                  _vp(ws), ws.numel() * 4, _defer_ptr(), _stream())
+                                  _vp(ws), ws.numel() * 4, defer.pointer() if defer is not None else None, _stream())
         _lib.check(st, "acm_nll_loss")
-        if _DEFER is not None:
-            _DEFER.hold(ws, [loss])
+        if defer is not None:
+            defer.hold(ws, [loss])
         ctx.save_for_backward(dz)
         return loss
 
     @staticmethod
     def backward(ctx, grad_loss):
         (dz,) = ctx.saved_tensors
-        return dz * grad_loss, None, None
+        return dz * grad_loss, None, None, None
 
 
-def nll_loss_and_grad(logits, labels, row_weight):
+def nll_loss_and_grad(logits, labels, row_weight, defer=None):
     """(loss, dloss/dlogits) of the masked NLL in one launch, outside autograd: a training loop can call
     ``logits.backward(gradient=dz)`` directly instead of ``loss.backward()`` (which costs a ones-fill and a
-    scalar multiply of dz on top)."""
+    scalar multiply of dz on top).  ``defer``: see proj_bwd."""
+    if defer is None:
+        defer = _ambient().defer
     with torch.no_grad():
         ctx = _NoCtx()
-        loss = _MaskedNll.forward(ctx, logits.detach(), labels, row_weight)
+        loss = _MaskedNll.forward(ctx, logits.detach(), labels, row_weight, defer)
     return loss, ctx.saved[0]
 
 
@@ -593,7 +658,7 @@ def masked_nll(logits, labels, row_weight):
     """Fused log-softmax + NLL over the rows with non-zero weight (weights = 1/|train| on the
     training rows reproduces F.log_softmax + NLLLoss(out[train_idx], y[train_idx]),
     ACM-Geometric/train.py:133-134)."""
-    return _MaskedNll.apply(logits, labels, row_weight)
+    return _MaskedNll.apply(logits, labels, row_weight, _ambient().defer)
 
 
 # --------------------------------------------------------------------------
@@ -679,8 +744,9 @@ class _ResidualLinear(torch.autograd.Function):
     acm_bias_act_bwd (masks read off y), then dW = G^T x; row-sharded runs sum [dW | db] over the ranks."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, relu, drop, group):
+    def forward(ctx, x, weight, bias, relu, drop, group, call=None):
         lib = _lib.load()
+        ctx.defer = call.defer if call is not None else None
         sparse_x = isinstance(x, SparseFeatures)
         w = _as_f32c(weight, "weight")
         b = _as_f32c(bias, "bias") if bias is not None else None
@@ -729,11 +795,11 @@ class _ResidualLinear(torch.autograd.Function):
         ws = torch.empty(max(nbytes.value // 4, 1), dtype=_F32, device=dev)
         with _device_ctx(dev), _Timed(f"bias_act_bwd/{n}x{f_out}"):
             st = lib.acm_bias_act_bwd(n, f_out, _vp(y), y.stride(0), _vp(dy), dy.stride(0), float(ctx.keep_scale),
-                                      int(ctx.relu), _vp(g), g.stride(0), _vp(d_b), _vp(ws), nbytes.value, _defer_ptr(),
-                                      _stream())
+                                      int(ctx.relu), _vp(g), g.stride(0), _vp(d_b), _vp(ws), nbytes.value,
+                                      ctx.defer.pointer() if ctx.defer is not None else None, _stream())
         _lib.check(st, "acm_bias_act_bwd")
-        if _DEFER is not None:
-            _DEFER.hold(ws, [d_b], keep=[flat])
+        if ctx.defer is not None:
+            ctx.defer.hold(ws, [d_b], keep=[flat])
         d_x = None
         if ctx.sparse_x is not None:                          # dW^T = X_csr^T G
             xs = ctx.sparse_x
@@ -750,19 +816,20 @@ class _ResidualLinear(torch.autograd.Function):
                     d_x = torch.nn.functional.pad(d_x, (0, x.shape[1] - d_x.shape[1]))
         if ctx.group is not None:
             import torch.distributed as dist
-            if _DEFER is not None:
-                _DEFER.allreduce(flat, ctx.group)
+            if ctx.defer is not None:
+                ctx.defer.allreduce(flat, ctx.group)
             else:
                 dist.all_reduce(flat, group=ctx.group)
-        return d_x, d_w, (d_b if ctx.has_bias else None), None, None, None
+        return d_x, d_w, (d_b if ctx.has_bias else None), None, None, None, None
 
 
-def residual_linear(x, weight, bias, relu=True, drop=None, group=None):
+def residual_linear(x, weight, bias, relu=True, drop=None, group=None, call=None):
     """dropout(relu(x @ weight.T + bias)) on the HIP kernels.  ``drop = (p, tag, DropoutState, row_offset)`` draws the
-    counter-based mask in the epilogue; ``group``: row-sharded run (the parameter gradients are summed over it)."""
+    counter-based mask in the epilogue; ``group``: row-sharded run (the parameter gradients are summed over it);
+    ``call``: the model call's CallContext (its deferral list; default: the thread's ambient one)."""
     if drop is not None and not drop[0] > 0:
         drop = None
-    return _ResidualLinear.apply(x, weight, bias, bool(relu), drop, group)
+    return _ResidualLinear.apply(x, weight, bias, bool(relu), drop, group, _call_or_ambient(call))
 
 
 # --------------------------------------------------------------------------
@@ -933,9 +1000,13 @@ class AcmConvFunction(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, w_low, w_high, w_mlp, v_low, v_high, v_mlp, v_struc, struc_low, att_mix,
                 lnw_low, lnw_high, lnw_mlp, lnw_struc, lnb_low, lnb_high, lnb_mlp, lnb_struc, ops, cfg,
-                post_relu=False, post_scale=None, post_drop=None):
+                post_relu=False, post_scale=None, post_drop=None, call=None, tail_layer=False, agg_holder=None):
         lib = _lib.load()
         ctx.set_materialize_grads(False)          # no zero-filled gradient for the (non-differentiable) att output
+        # the model call's context (deferral list, loss-tail request, input pipeline, projection hand-off); ``tail_layer``:
+        # the caller is an output layer without post-op working in the operator's numbering (it may take call.tail);
+        # ``agg_holder``: layers.GraphConvolution's {"agg": P-or-None} of an evaluation pass over a static input
+        call = ctx.call = _call_or_ambient(call)
         sparse_x = isinstance(x, SparseFeatures)
         if not sparse_x:
             x = _as_f32c(x, "input")
@@ -998,20 +1069,19 @@ class AcmConvFunction(torch.autograd.Function):
                 xpad = x
             else:
                 xpad = torch.nn.functional.pad(x[:, :f_in], (0, fp - f_in))
-            global _AGG_CACHE
-            agg_holder, _AGG_CACHE = _AGG_CACHE, None
             if agg_holder is not None and (k != 3 or ops.sharded or torch.is_grad_enabled()):       # no backward follows
                 agg_holder = None
             agg_given = agg_holder.get("agg") if agg_holder is not None else None
             if agg_given is not None and tuple(agg_given.shape) != (n, fp):
                 agg_given = None
             # a training loop's input pipeline (InputPipeline): P for this step came out of the previous step's backward
-            pipe = _PIPE
+            pipe = call.pipe
             ctx.pipe = None
             if (pipe is not None and pipe.primed and ctx.agg_first and k == 3 and fp == 8 and f == 64 and ops is pipe.ops
-                    and xpad.data_ptr() == pipe.table().data_ptr() and agg_holder is None):     # (_PIPE is only set by a training step)
+                    and xpad.data_ptr() == pipe.table().data_ptr() and agg_holder is None):     # (only a training step carries a pipe)
                 agg_given = pipe.agg()
                 ctx.pipe = pipe
+                pipe.adopted = True               # the loop may refill the table: this forward leaves its copies in ``saved``
             if agg_given is not None:
                 xg = xpad                             # not read: P = A_low X comes from the holder
             elif (pregathered is not None and pregathered[0].data_ptr() == xpad.data_ptr()
@@ -1047,7 +1117,7 @@ class AcmConvFunction(torch.autograd.Function):
                 ldz = -(-3 * f // (2 * f)) * (2 * f)
             elif fb != f:
                 ldz = -(-(2 * fb + f) // 4) * 4
-            pre = _take_pre_proj(x, w3, cfg.relu_before) if use_proj else None
+            pre = _take_pre_proj(call, x, w3, cfg.relu_before) if use_proj else None
             if pre is not None:
                 zlh, zi = pre                              # computed in the preceding layer's epilogue
             elif use_proj:
@@ -1172,7 +1242,7 @@ class AcmConvFunction(torch.autograd.Function):
             if stats is not None:
                 p.head_stats, p.ld_head_stats = stats.data_ptr(), stats.stride(0)
             ctx.head_stats = stats
-            nxt = _next_proj_request(f, dev)
+            nxt = _next_proj_request(call, f, dev, row_local_only=agg_given is not None and k == 3 and fp == 8 and f == 64)
             if nxt is not None:
                 n_w3, n_relu, f2 = nxt
                 n_zlh = torch.empty(n, 2 * f2, dtype=_F32, device=dev)
@@ -1192,8 +1262,7 @@ class AcmConvFunction(torch.autograd.Function):
             if agg_holder is not None and agg_given is None:
                 agg_holder["agg"] = agg
             if nxt is not None:
-                global _PRE_PROJ
-                _PRE_PROJ = (out, n_zlh, n_zi, tuple(w.data_ptr() for w in n_w3), n_relu)
+                call.pre_proj = (out, n_zlh, n_zi, tuple(w.data_ptr() for w in n_w3), n_relu)
             ctx.ops, ctx.cfg, ctx.f_in = ops, cfg, f_in
             # with a fused ReLU the output itself records which elements the post-op let through: the backward reads it
             # instead of regenerating the dropout mask (no extra memory: the next layer keeps the same tensor alive)
@@ -1258,8 +1327,7 @@ class AcmConvFunction(torch.autograd.Function):
         set_post(p)
         ws = graph.workspace((k - 1) * f)
         # output layer + loss + K3 in one row pass (acm_conv_fwd_tail) when a training loop asked for it
-        global _TAIL_LAYER
-        tail_req, layer_ok, _TAIL_LAYER = _TAIL, _TAIL_LAYER, False
+        tail_req, layer_ok = call.tail, bool(tail_layer)
         ctx.tail = None
         st = None
         if (tail_req is not None and tail_req.out is None and layer_ok and not general and k == 3 and f <= 8
@@ -1277,7 +1345,7 @@ class AcmConvFunction(torch.autograd.Function):
             lo.labels, lo.row_weight = y.data_ptr(), w_row.data_ptr()
             lo.loss, lo.dlogits, lo.ld_dlogits = loss.data_ptr(), dlog.data_ptr(), dlog.stride(0)
             q = st3["q"]
-            q.defer = _defer_ptr()
+            q.defer = call.defer_ptr()
             nbytes = C.c_size_t()
             if lib.acm_conv_fwd_tail_workspace_bytes(n, f, k, C.byref(nbytes)) == 0:
                 wt = torch.empty(max(nbytes.value // 4, 1), dtype=_F32, device=dev)
@@ -1288,9 +1356,9 @@ class AcmConvFunction(torch.autograd.Function):
                     st3["keep"] = (y, w_row, wt)
                     ctx.tail = st3
                     tail_req.loss, tail_req.dz, tail_req.out = loss, dlog, out
-                    if _DEFER is not None:
-                        _DEFER.hold(wt, [loss, st3["d_mix"], *st3["d_vec"], *st3["d_lnw"], *st3["d_lnb"]],
-                                    keep=[loss, st3["flat"]])
+                    if call.defer is not None:
+                        call.defer.hold(wt, [loss, st3["d_mix"], *st3["d_vec"], *st3["d_lnw"], *st3["d_lnb"]],
+                                        keep=[loss, st3["flat"]])
                 elif st != 4:                       # ACM_EUNSUPPORTED: the layer does not qualify, three calls then
                     _lib.check(st, "acm_conv_fwd_tail")
         if st != 0:
@@ -1306,9 +1374,10 @@ class AcmConvFunction(torch.autograd.Function):
     @staticmethod
     def backward(ctx, grad_out, _grad_att):
         if grad_out is None:
-            return (None,) * 23
+            return (None,) * 26
         lib = _lib.load()
         ops, cfg = ctx.ops, ctx.cfg
+        defer = ctx.call.defer                    # the deferral list of the model call this backward belongs to
         k = cfg.n_channels
         saved = ctx.saved_tensors
         if ctx.agg_first:
@@ -1339,12 +1408,12 @@ class AcmConvFunction(torch.autograd.Function):
             nbytes = C.c_size_t()
             _lib.check(lib.acm_conv_bwd_local_workspace_bytes(n, f, k, C.byref(nbytes)))
             ws = torch.empty(max(nbytes.value // 4, 1), dtype=_F32, device=dev)
-            q.defer = _defer_ptr()
+            q.defer = defer.pointer() if defer is not None else None
             with _device_ctx(dev), _Timed(f"conv_bwd_local/F{f}k{k}"):
                 st = lib.acm_conv_bwd_local(n, C.byref(q), _vp(ws), ws.numel() * 4, _stream())
             _lib.check(st, "acm_conv_bwd_local")
-            if _DEFER is not None:
-                _DEFER.hold(ws, [d_mix, *d_vec, *d_lnw, *d_lnb], keep=[flat])
+            if defer is not None:
+                defer.hold(ws, [d_mix, *d_vec, *d_lnw, *d_lnb], keep=[flat])
 
         d_struc = torch.empty(n, f, dtype=_F32, device=dev) if four else None
         r = _lib.ConvBwdSpmm()
@@ -1404,7 +1473,7 @@ class AcmConvFunction(torch.autograd.Function):
         elif (ctx.needs_input_grad[0] and proj_bwd_supported(3 * f) and os.environ.get("ACM_PROJ_BWD", "1") != "0"
               and wl_.stride(0) == wh_.stride(0) == wm_.stride(0)):
             d_wcat = flat[:nw].view(3, f_in_w, f)                             # narrow output layer: dX and dW in one
-            d_x = proj_bwd(x, dz, w3, d_wcat)                                 # pass over x (acm_proj_bwd)
+            d_x = proj_bwd(x, dz, w3, d_wcat, defer=defer)                    # pass over x (acm_proj_bwd)
         else:
             d_wcat = gemm(x, dz, trans_a=True, col_blocks=3,
                           out=flat[:nw].view(3, f_in_w, f))                   # contiguous per weight
@@ -1413,8 +1482,8 @@ class AcmConvFunction(torch.autograd.Function):
             d_x = torch.nn.functional.pad(d_x, (0, ctx.x_width - d_x.shape[1]))
         if ops.sharded:                             # replicated parameters: sum the row-shard partials
             import torch.distributed as dist
-            if _DEFER is not None:
-                _DEFER.allreduce(flat, ops.group)   # after the step's single flush (the all-reduce reads its sums)
+            if defer is not None:
+                defer.allreduce(flat, ops.group)    # after the step's single flush (the all-reduce reads its sums)
             else:
                 dist.all_reduce(flat, group=ops.group)
         if d_wcat.dim() == 3:
@@ -1426,7 +1495,7 @@ class AcmConvFunction(torch.autograd.Function):
         grads_lnw = (d_lnw + [None] * (4 - k)) if cfg.layernorm else none4
         grads_lnb = (d_lnb + [None] * (4 - k)) if cfg.layernorm else none4
         return (d_x, d_wl, d_wh, d_wm, grads_vec[0], grads_vec[1], grads_vec[2], grads_vec[3],
-                d_struc, d_mix, *grads_lnw, *grads_lnb, None, None, None, None, None)
+                d_struc, d_mix, *grads_lnw, *grads_lnb, None, None, None, None, None, None, None, None)
 
 
 def _backward_agg(ctx, grad_out):
@@ -1484,7 +1553,8 @@ def _backward_agg(ctx, grad_out):
     nbytes = C.c_size_t()
     _lib.check(lib.acm_conv_agg_bwd_workspace_bytes(n, f_in, f, C.byref(nbytes)))
     ws = torch.empty(max(nbytes.value // 4, 1), dtype=_F32, device=dev)
-    q.defer = _defer_ptr()
+    defer = ctx.call.defer
+    q.defer = defer.pointer() if defer is not None else None
     pipe = getattr(ctx, "pipe", None)
     carry = pipe is not None and pipe.next_table_ready and not pipe.next_agg_ready
     if carry:                                     # the next step's P = A_low dropout(x) rides this launch
@@ -1497,8 +1567,8 @@ def _backward_agg(ctx, grad_out):
     _lib.check(st, "acm_conv_agg_bwd")
     if carry:
         pipe.next_agg_ready = True
-    if _DEFER is not None:
-        _DEFER.hold(ws, [d_params])
+    if defer is not None:
+        defer.hold(ws, [d_params])
     d_struc = None
     if four:                                  # dS = A_low^T (D G_S) - G_S   (pattern-only: P G_S - G_S)
         gsg = _gather_rows(ops, gs)
@@ -1514,8 +1584,8 @@ def _backward_agg(ctx, grad_out):
         _lib.check(st, "acm_spmm_ex")
     if ops.sharded:
         import torch.distributed as dist
-        if _DEFER is not None:
-            _DEFER.allreduce(d_params, ops.group)
+        if defer is not None:
+            defer.allreduce(d_params, ops.group)
         else:
             dist.all_reduce(d_params, group=ops.group)
     wsz = f_in * f
@@ -1529,21 +1599,24 @@ def _backward_agg(ctx, grad_out):
     else:
         d_lnw = d_lnb = [None] * 4
     d_mix = d_params[base + 3 * k * f:].view(k, k)
-    return (None, d_wl, d_wh, d_wm, *d_vec, d_struc, d_mix, *d_lnw, *d_lnb, None, None, None, None, None)
+    return (None, d_wl, d_wh, d_wm, *d_vec, d_struc, d_mix, *d_lnw, *d_lnb, None, None, None, None, None, None, None, None)
 
 
 AcmConvFunction._backward_agg = staticmethod(_backward_agg)
 
 
-def acm_conv(x, params, ops, cfg, post_relu=False, post_scale=None, post_drop=None):
+def acm_conv(x, params, ops, cfg, post_relu=False, post_scale=None, post_drop=None, call=None, tail_layer=False,
+             agg_holder=None):
     """params: dict with the reference's parameter names (see layers.GraphConvolution).
     post_relu / post_scale: optional fused ``relu(out) * post_scale`` (the caller's inter-layer
     ReLU + dropout; post_scale = keep_mask / (1 - p)).  post_drop = (p, tag, DropoutState): the same
-    dropout with the mask generated in registers (acm_dropout_t) instead of read from a tensor."""
+    dropout with the mask generated in registers (acm_dropout_t) instead of read from a tensor.
+    call / tail_layer / agg_holder: see AcmConvFunction.forward."""
     p = params
     return AcmConvFunction.apply(
         x, p["weight_low"], p["weight_high"], p["weight_mlp"], p["att_vec_low"], p["att_vec_high"],
         p["att_vec_mlp"], p["att_struc_low"], p["struc_low"], p["att_vec"],
         p["layer_norm_low.weight"], p["layer_norm_high.weight"], p["layer_norm_mlp.weight"],
         p["layer_norm_struc_low.weight"], p["layer_norm_low.bias"], p["layer_norm_high.bias"],
-        p["layer_norm_mlp.bias"], p["layer_norm_struc_low.bias"], ops, cfg, post_relu, post_scale, post_drop)
+        p["layer_norm_mlp.bias"], p["layer_norm_struc_low.bias"], ops, cfg, post_relu, post_scale, post_drop,
+        call, tail_layer, agg_holder)

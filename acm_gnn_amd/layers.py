@@ -95,14 +95,16 @@ class GraphConvolution(nn.Module):
         }
 
     def forward(self, input, adj_low, adj_high=None, adj_low_unnormalized=None, post_relu=False, post_scale=None,
-                post_drop=None, rows_permuted=False):
+                post_drop=None, rows_permuted=False, call=None):
         """Reference signature plus optional keyword arguments: ``post_relu`` / ``post_scale`` fuse the
         caller's ``dropout(relu(out))`` (post_scale = keep-mask / (1 - p)) into the kernel epilogue;
         ``post_drop = (p, tag, functional.DropoutState)`` does the same with the mask generated in registers.
         ``input`` may carry zero columns beyond ``in_features`` (functional.dropout(..., pad_to=...)).
         ``rows_permuted``: the operators are relabelled (graph.relabel_by_degree) and the caller already works in
         that numbering -- input, post_scale and the result are rows of the relabelled graph (models.GCN keeps the
-        hidden activations there); otherwise the layer translates at its boundary."""
+        hidden activations there); otherwise the layer translates at its boundary.
+        ``call``: the model call's functional.CallContext (models.GCN passes one per forward; default: a fresh one derived
+        from the calling thread's ``with functional.deferred_reductions() / fused_loss_tail()`` blocks)."""
         mt = self.model_type
         if mt == "mlp":
             return AF.mm(input, self.weight_mlp)
@@ -130,14 +132,10 @@ class GraphConvolution(nn.Module):
                     post_scale = post_scale.index_select(0, ops.perm)
         # an output layer without post-op may take a pending functional.fused_loss_tail request (row phase + loss + K3);
         # the request's labels / weights are rows of the numbering the layer works in
-        AF._TAIL_LAYER = (bool(self.output_layer) and not post_relu and post_scale is None and post_drop is None
-                          and not translate)
-        AF._AGG_CACHE = self._eval_agg_holder(raw_input, ops)
-        try:
-            out, att = AF.acm_conv(input, params, ops, cfg, post_relu, post_scale, post_drop)
-        finally:
-            AF._TAIL_LAYER = False
-            AF._AGG_CACHE = None
+        tail_layer = (bool(self.output_layer) and not post_relu and post_scale is None and post_drop is None
+                      and not translate)
+        out, att = AF.acm_conv(input, params, ops, cfg, post_relu, post_scale, post_drop, call=call,
+                               tail_layer=tail_layer, agg_holder=self._eval_agg_holder(raw_input, ops))
         if translate:
             out = out.index_select(0, ops.inv_perm)
         # the mixing weights stay where the kernel wrote them; the attributes translate rows when they are read
@@ -153,10 +151,12 @@ class GraphConvolution(nn.Module):
             return None
         # the entry keeps the input alive, so its storage cannot be handed to another tensor while the entry exists; an
         # in-place edit bumps the version counter (shared by every alias of the storage)
-        key = (x.data_ptr(), x._version, tuple(x.shape), tuple(x.stride()), id(ops))
+        # (the entry also keeps the operators alive and compares them by identity: an id() of a collected object can be
+        # handed to the next one)
+        key = (x.data_ptr(), x._version, tuple(x.shape), tuple(x.stride()))
         cached = getattr(self, "_eval_agg", None)
-        if cached is None or cached[0] != key:
-            cached = (key, x, {"agg": None})
+        if cached is None or cached[0] != key or cached[3] is not ops:
+            cached = (key, x, {"agg": None}, ops)
             self._eval_agg = cached
         return cached[2]
 

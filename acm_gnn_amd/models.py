@@ -74,28 +74,30 @@ class GCN(nn.Module):
         if self.model_type == "acmgcnpp":
             self.mlpX.reset_parameters()
 
-    def _residual(self, x, adj_low, drop=None):
+    def _residual(self, x, adj_low, drop=None, call=None):
         """relu(Linear(x)) of the ACM-GCN++ branch (ACM-Geometric/models.py:26-27,55-56), optionally with the
         counter-based dropout in the same epilogue (``drop`` = (p, tag, state, row_offset)): one GEMM launch
         (functional.residual_linear; CSR features: acm_spmm_v + acm_bias_act).  Row-sharded: the Linear's weight / bias
         gradients are summed over the ranks.  mlpX stacks deeper than one Linear (init_layers_X > 1: BatchNorm between
-        the layers) stay on torch modules and are single-process only."""
+        the layers) and Linears wider than 256 outputs (acm_bias_act_bwd's column budget) stay on torch modules and are
+        single-process only."""
         ops = adj_low if isinstance(adj_low, FilterOperators) else None
         group = ops.group if (ops is not None and ops.sharded) else None
-        if len(self.mlpX.lins) == 1:
+        if len(self.mlpX.lins) == 1 and self.mlpX.lins[0].out_features <= 256:      # (acm_bias_act_bwd's column budget)
             lin = self.mlpX.lins[0]
-            return AF.residual_linear(x, lin.weight, lin.bias, relu=True, drop=drop, group=group)
+            return AF.residual_linear(x, lin.weight, lin.bias, relu=True, drop=drop, group=group, call=call)
         if group is not None:
-            raise NotImplementedError("row-sharded acmgcnpp supports init_layers_X = 1 (no BatchNorm statistics to sync)")
+            raise NotImplementedError("row-sharded acmgcnpp supports init_layers_X = 1 with nhid <= 256 (the torch fallback "
+                                      "does not reduce its gradients over the ranks)")
         if isinstance(x, SparseFeatures):
-            raise NotImplementedError("CSR features with init_layers_X > 1")
+            raise NotImplementedError("CSR features with init_layers_X > 1 or nhid > 256")
         f_in = self.mlpX.lins[0].in_features              # x may carry zero pad columns (dropout(..., pad_to=...))
         out = F.relu(self.mlpX(x if x.shape[1] == f_in else x[:, :f_in], input_tensor=True))
         if drop is not None and drop[0] > 0:
             out = AF.dropout(out, drop[0], drop[2], tag=drop[1], row_offset=drop[3])
         return out
 
-    def _forward_fused_dropout(self, x, adj_low, adj_high, adj_low_unnormalized):
+    def _forward_fused_dropout(self, x, adj_low, adj_high, adj_low_unnormalized, call):
         """Training forward with every dropout drawn from ``dropout_state`` (tags: 0 input, 1 hidden, 2 the
         ACM-GCN++ residual branch); same structure as forward()."""
         p = self.dropout
@@ -117,31 +119,27 @@ class GCN(nn.Module):
                 xg = AF.dropout(ops.x_full, p, st, tag=0, pad_to=pad, row_offset=0)
                 x = xg[off:off + x.shape[0]]
                 ops._pregathered = (x, xg)
-            elif (AF._PIPE is not None and AF._PIPE.primed and AF._PIPE.ops is ops and AF._PIPE.state is st
-                    and AF._PIPE.x.data_ptr() == x.data_ptr() and AF._PIPE.x.shape == x.shape and torch.is_grad_enabled()):
-                x = AF._PIPE.table()          # dropout_t(x), drawn one step ahead (functional.InputPipeline)
+            elif (call.pipe is not None and call.pipe.primed and call.pipe.ops is ops and call.pipe.state is st
+                    and call.pipe.x.data_ptr() == x.data_ptr() and call.pipe.x.shape == x.shape and torch.is_grad_enabled()):
+                x = call.pipe.table()         # dropout_t(x), drawn one step ahead (functional.InputPipeline)
             else:
                 x = AF.dropout(x, p, st, tag=0, pad_to=pad, row_offset=off)
             kw = {}
         if self.model_type == "acmsgc":
-            return self.gcns[0](x, adj_low, adj_high, adj_low_unnormalized, rows_permuted=self._rows_permuted)
+            return self.gcns[0](x, adj_low, adj_high, adj_low_unnormalized, rows_permuted=self._rows_permuted, call=call)
         if self.model_type == "acmgcnpp":
-            xx = self._residual(x, adj_low, drop=(p, 2, st, off))
-        # the output layer's narrow projection may ride the hidden layer's epilogue (functional._NEXT_PROJ); not with the
-        # ACM-GCN++ residual, which changes the hidden activations in between
-        AF._NEXT_PROJ = self.gcns[1] if self.model_type != "acmgcnpp" else None
-        try:
-            fea = self.gcns[0](x, adj_low, adj_high, adj_low_unnormalized, post_relu=True, post_drop=(p, 1, st), **kw, rows_permuted=self._rows_permuted)
-        finally:
-            AF._NEXT_PROJ = None
+            xx = self._residual(x, adj_low, drop=(p, 2, st, off), call=call)
+        # the output layer's narrow projection may ride the hidden layer's epilogue (CallContext.next_proj / pre_proj); not
+        # with the ACM-GCN++ residual, which changes the hidden activations in between
+        call.next_proj = self.gcns[1] if self.model_type != "acmgcnpp" else None
+        fea = self.gcns[0](x, adj_low, adj_high, adj_low_unnormalized, post_relu=True, post_drop=(p, 1, st), **kw,
+                           rows_permuted=self._rows_permuted, call=call)
+        call.next_proj = None
         if self.model_type == "acmgcnpp":
             fea = fea + xx
-        try:
-            return self.gcns[1](fea, adj_low, adj_high, adj_low_unnormalized, rows_permuted=self._rows_permuted)
-        finally:
-            AF._PRE_PROJ = None
+        return self.gcns[1](fea, adj_low, adj_high, adj_low_unnormalized, rows_permuted=self._rows_permuted, call=call)
 
-    def _forward_snowball(self, x, adj_low, adj_high, fused):
+    def _forward_snowball(self, x, adj_low, adj_high, fused, call):
         """models.py:57-64: h_k = dropout(relu(layer_k([x | h_0 | ... | h_{k-1}]))), out = layer_last([x | h_0 | ...]).
         The ReLU + dropout after every hidden layer ride that layer's epilogue (post_relu / post_scale / post_drop);
         the concatenations are plain copies."""
@@ -157,19 +155,22 @@ class GCN(nn.Module):
         for k in range(self.nlayers):
             inp = x if k == 0 else torch.cat([x] + blocks, 1)
             if fused:
-                h = self.gcns[k](inp, adj_low, adj_high, None, post_relu=True, post_drop=(p, 1 + k, st), rows_permuted=self._rows_permuted)
+                h = self.gcns[k](inp, adj_low, adj_high, None, post_relu=True, post_drop=(p, 1 + k, st), rows_permuted=self._rows_permuted, call=call)
             else:
                 scale = None
                 if self.training and p > 0:
                     scale = F.dropout(self._ones_like_hidden(x.shape[0], self.gcns[k].out_features, x.device), p, training=True)
-                h = self.gcns[k](inp, adj_low, adj_high, None, post_relu=True, post_scale=scale, rows_permuted=self._rows_permuted)
+                h = self.gcns[k](inp, adj_low, adj_high, None, post_relu=True, post_scale=scale, rows_permuted=self._rows_permuted, call=call)
             blocks.append(h)
-        return self.gcns[-1](torch.cat([x] + blocks, 1), adj_low, adj_high, None, rows_permuted=self._rows_permuted)
+        return self.gcns[-1](torch.cat([x] + blocks, 1), adj_low, adj_high, None, rows_permuted=self._rows_permuted, call=call)
 
-    def forward(self, x, adj_low, adj_high=None, adj_low_unnormalized=None, rows_permuted=False):
+    def forward(self, x, adj_low, adj_high=None, adj_low_unnormalized=None, rows_permuted=False, call=None):
         """Reference signature.  With relabelled operators (graph.relabel_by_degree) the rows are translated ONCE here
         -- x on the way in, the logits on the way out -- and every layer in between works in the relabelled numbering
-        (``rows_permuted=True``: the caller, e.g. train.TrainStep, already did and wants the result there too)."""
+        (``rows_permuted=True``: the caller, e.g. train.TrainStep, already did and wants the result there too).
+        ``call``: a functional.CallContext for this forward (train.TrainStep passes its own); by default a fresh one that
+        inherits what the calling thread's ``with functional.deferred_reductions() / fused_loss_tail()`` blocks set."""
+        call = AF.CallContext.from_ambient() if call is None else call
         ops = adj_low if isinstance(adj_low, FilterOperators) else None
         if ops is None and isinstance(adj_low, torch.Tensor):
             from .graph import operators_for
@@ -178,18 +179,18 @@ class GCN(nn.Module):
         self._rows_permuted = ops is not None and ops.perm is not None
         if self._rows_permuted and not rows_permuted:
             x = x.permute_rows(ops.perm) if isinstance(x, SparseFeatures) else x.index_select(0, ops.perm)
-            return self._forward(x, adj_low, adj_high, adj_low_unnormalized).index_select(0, ops.inv_perm)
-        return self._forward(x, adj_low, adj_high, adj_low_unnormalized)
+            return self._forward(x, adj_low, adj_high, adj_low_unnormalized, call).index_select(0, ops.inv_perm)
+        return self._forward(x, adj_low, adj_high, adj_low_unnormalized, call)
 
-    def _forward(self, x, adj_low, adj_high, adj_low_unnormalized):
+    def _forward(self, x, adj_low, adj_high, adj_low_unnormalized, call):
         fused = self.fused_dropout and self.training and self.dropout > 0
         if fused and self.dropout_state is None:
             dev = x.values.device if isinstance(x, SparseFeatures) else x.device
             self.dropout_state = AF.DropoutState(dev)
         if self.model_type == "acmsnowball":
-            return self._forward_snowball(x, adj_low, adj_high, fused)
+            return self._forward_snowball(x, adj_low, adj_high, fused, call)
         if fused:
-            return self._forward_fused_dropout(x, adj_low, adj_high, adj_low_unnormalized)
+            return self._forward_fused_dropout(x, adj_low, adj_high, adj_low_unnormalized, call)
         drop = lambda t: F.dropout(t, self.dropout, training=self.training)  # noqa: E731
         if isinstance(x, SparseFeatures):
             # dropout of a sparse matrix = dropout of its stored values (zeros stay zero either way)
@@ -197,23 +198,19 @@ class GCN(nn.Module):
         else:
             x = drop(x)
         if self.model_type == "acmsgc":
-            return self.gcns[0](x, adj_low, adj_high, adj_low_unnormalized, rows_permuted=self._rows_permuted)
+            return self.gcns[0](x, adj_low, adj_high, adj_low_unnormalized, rows_permuted=self._rows_permuted, call=call)
         if self.model_type == "acmgcnpp":
-            xx = drop(self._residual(x, adj_low))
+            xx = drop(self._residual(x, adj_low, call=call))
         # dropout(relu(fea1)) (models.py:70) rides the layer's epilogue: the keep-mask / (1 - p) tensor is what
         # F.dropout does to a tensor of ones, so a patched F.dropout (mask replay in tests) is honoured
         scale = None
         if self.training and self.dropout > 0:
             ones = self._ones_like_hidden(x.shape[0], self.gcns[0].out_features, x.device)
             scale = drop(ones)
-        AF._NEXT_PROJ = self.gcns[1] if self.model_type != "acmgcnpp" else None     # see _forward_fused_dropout
-        try:
-            fea = self.gcns[0](x, adj_low, adj_high, adj_low_unnormalized, post_relu=True, post_scale=scale, rows_permuted=self._rows_permuted)
-        finally:
-            AF._NEXT_PROJ = None
+        call.next_proj = self.gcns[1] if self.model_type != "acmgcnpp" else None     # see _forward_fused_dropout
+        fea = self.gcns[0](x, adj_low, adj_high, adj_low_unnormalized, post_relu=True, post_scale=scale,
+                           rows_permuted=self._rows_permuted, call=call)
+        call.next_proj = None
         if self.model_type == "acmgcnpp":
             fea = fea + xx
-        try:
-            return self.gcns[1](fea, adj_low, adj_high, adj_low_unnormalized, rows_permuted=self._rows_permuted)
-        finally:
-            AF._PRE_PROJ = None
+        return self.gcns[1](fea, adj_low, adj_high, adj_low_unnormalized, rows_permuted=self._rows_permuted, call=call)

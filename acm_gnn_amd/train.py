@@ -77,6 +77,11 @@ class TrainStep:
             else:
                 self._manual_advance = True
         self._params = list(model.parameters())          # walked every step: module.parameters() costs 0.1 ms of host time
+        import inspect
+        try:                                             # models.GCN takes the step's CallContext as a keyword
+            self._takes_call = "call" in inspect.signature(model.forward).parameters
+        except (TypeError, ValueError):
+            self._takes_call = False
         # the first layer's input aggregation one step ahead, inside its own backward (functional.InputPipeline);
         # pipeline_input: None = when the configuration qualifies (InputPipeline.eligible), False = never
         self.pipe = None
@@ -92,34 +97,30 @@ class TrainStep:
         while nothing reads a gradient before the flush, which this method checks on every pass: every ``.grad``
         must be the tensor the backward kernels wrote (autograd adopts it when ``.grad`` is None), not a copy taken
         before the flush -- otherwise deferral is switched off for good and the step is redone."""
-        model = self.model
         pipe = self.pipe
         if pipe is not None and pipe.stale():
             if self.x.is_cuda and torch.cuda.is_current_stream_capturing():
                 self.pipe = pipe = None           # its buffers cannot be refilled inside a capture: the plain step
             else:
                 pipe.prime()
-        if not self._defer:
-            loss, dz, out = self._forward_loss()
+        # this step's own context: the deferral list, the loss-tail request and the pipeline travel with the model call
+        # (and, captured by the autograd Functions, with its backward) -- nothing is parked in module state
+        pending = AF.DeferredReductions() if self._defer else None
+        call = AF.CallContext(defer=pending, pipe=pipe)
+        try:
+            loss, dz, out = self._forward_loss(call)
             if pipe is not None:
-                pipe.make_next()
-            AF._PIPE = pipe
-            try:
-                out.backward(dz)
-            finally:
-                AF._PIPE = None
+                pipe.make_next()              # dropout_{t+1}(x): the operand of the gather the backward carries (only if
+                                              # the forward adopted the pipeline's buffers)
+            out.backward(dz)
+        except BaseException:
+            if pending is not None:
+                pending.discard()
+            raise
+        if pending is None:
             return loss
-        with AF.deferred_reductions() as pending:
-            loss, dz, out = self._forward_loss()
-            if pipe is not None:
-                pipe.make_next()              # dropout_{t+1}(x): the operand of the gather the backward carries
-            AF._PIPE = pipe
-            try:
-                out.backward(dz)
-            finally:
-                AF._PIPE = None
-            adopted = pending.all_adopted([loss] + [p.grad for p in self._params])
-            pending.flush()
+        adopted = pending.all_adopted([loss] + [p.grad for p in self._params])
+        pending.flush()
         if not adopted:
             self._defer = False
             self.opt.zero_grad(set_to_none=True)
@@ -128,22 +129,23 @@ class TrainStep:
             return self._forward_backward()
         return loss
 
-    def _forward_loss(self):
+    def _forward_loss(self, call):
         """Forward and fused loss: (loss, dloss/dlogits, logits).  The model's output layer is asked to run its row
         phase, the loss and its own row-local backward as one kernel (AF.fused_loss_tail); when it does not qualify
         (wide output, structure channel, a wrapper around the output) the loss is its own launch."""
-        AF._PIPE = self.pipe
-        try:
-            with AF.fused_loss_tail(self.labels, self.weights) as tail:
-                if self._permuted:
-                    out = self.model(self.x, self.adj, self.adj_high, self.adj_un, rows_permuted=True)
-                else:
-                    out = self.model(self.x, self.adj, self.adj_high, self.adj_un)
-        finally:
-            AF._PIPE = None
+        tail = call.tail = AF.fused_loss_tail(self.labels, self.weights)
+        kw = {"call": call} if self._takes_call else {}
+        if self._permuted:
+            kw["rows_permuted"] = True
+        if self._takes_call:
+            out = self.model(self.x, self.adj, self.adj_high, self.adj_un, **kw)
+        else:                                     # a wrapper without the ``call`` keyword: the thread's ambient context
+            with AF.deferred_reductions_as(call.defer), AF.input_pipeline(call.pipe), tail:
+                out = self.model(self.x, self.adj, self.adj_high, self.adj_un, **kw)
+        call.tail = None
         if tail.matches(out):
             return tail.loss, tail.dz, out
-        loss, dz = AF.nll_loss_and_grad(out, self.labels, self.weights)   # = masked_nll(...).backward(), two launches less
+        loss, dz = AF.nll_loss_and_grad(out, self.labels, self.weights, defer=call.defer)   # = masked_nll(...).backward(), two launches less
         return loss, dz, out
 
     def _eager(self):
@@ -257,19 +259,36 @@ class EvalStep:
     (``loss_set``: the validation set).  Everything stays on the device -- the index sets become [k, n] averaging
     weights, accuracies and loss land in one small tensor -- so a call costs ONE device-to-host copy, and with
     ``use_graph`` the whole pass (the library's forward kernels + a handful of torch reductions) is a hipGraph replay.
-    Returns (logits, [accuracy per index set], loss on ``loss_set``)."""
+    Returns (logits, [accuracy per index set], loss on ``loss_set``).
+
+    Index sets may be index tensors or boolean masks.  Rows outside every set may carry the reference's "unlabeled"
+    marker -1 (data_utils.rand_train_test_idx, ignore_negative): they have zero weight and their label is clamped before
+    the gather.  A CAPTURED pass bakes in the addresses of what its warm-up left behind -- in particular the first layer's
+    P = A_low X of an aggregate-first layer (layers.GraphConvolution._eval_agg) -- so it assumes ``x`` is not modified
+    in place afterwards (call :meth:`refresh` if it was) and it keeps those tensors alive itself: another evaluation of
+    the same model on other inputs may replace the layers' cache entries, the replay still reads valid memory."""
 
     def __init__(self, model, x, adj, labels, index_sets, adj_high=None, adj_un=None, loss_set=1, use_graph=False):
         self.model, self.x, self.adj, self.adj_high, self.adj_un = model, x, adj, adj_high, adj_un
         self.labels = labels
+        self._labels_safe = labels.clamp_min(0)             # -1 = unlabeled (never in an index set)
         n, dev = labels.shape[0], labels.device
         w = torch.zeros(len(index_sets), n, dtype=torch.float32, device=dev)
         for k, idx in enumerate(index_sets):
-            idx = torch.as_tensor(idx, device=dev).long()
+            idx = torch.as_tensor(idx, device=dev)
+            idx = idx.nonzero().view(-1) if idx.dtype == torch.bool else idx.long()
             w[k].index_fill_(0, idx, 1.0 / max(int(idx.numel()), 1))
         self.w, self.loss_set = w, int(loss_set)
         self.graph, self.out, self.res = None, None, None
+        self._held = None
+        self._use_graph = bool(use_graph)
         if use_graph:
+            self._capture()
+
+    def refresh(self):
+        """Re-capture after an in-place edit of the features (or of anything else the captured pass read once)."""
+        if self._use_graph:
+            self.graph = None
             self._capture()
 
     @torch.no_grad()
@@ -277,7 +296,7 @@ class EvalStep:
         self.model.eval()
         out = self.model(self.x, self.adj, self.adj_high, self.adj_un)
         correct = (out.argmax(dim=1) == self.labels).to(torch.float32)
-        nll = -F.log_softmax(out, 1).gather(1, self.labels.view(-1, 1)).view(-1)
+        nll = -F.log_softmax(out, 1).gather(1, self._labels_safe.view(-1, 1)).view(-1)
         res = torch.cat([self.w @ correct, (self.w[self.loss_set] * nll).sum().view(1)])
         return out, res
 
@@ -292,6 +311,10 @@ class EvalStep:
         self.graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph, **_capture_mode()):
             self.out, self.res = self._run()
+        # what the captured kernels read beyond the pool of the graph: the layers' evaluation-pass cache entries
+        # (key, input, {"agg": P}, operators) as they are now -- held here so that a later eval-mode forward of the same
+        # model on another input cannot free them under the replay
+        self._held = [m._eval_agg for m in self.model.modules() if getattr(m, "_eval_agg", None) is not None]
 
     def __call__(self):
         if self.graph is not None:

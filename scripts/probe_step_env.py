@@ -1,0 +1,73 @@
+#!/usr/bin/env python3
+"""Run ON THE GPU BOX: the benchmark's training step under a list of environment settings (the kernels read their
+tuning switches with getenv per call), per-kernel HIP-event times of the eager step and the replayed-graph step time.
+
+    python scripts/probe_step_env.py "ACM_EPI16_BLOCKS=512" "ACM_EPI16_CAP4=1,ACM_EPI16_BLOCKS=768" ...
+An empty string is the default configuration."""
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+import acm_gnn_amd  # noqa: E402
+from acm_gnn_amd import data as D, distributed as DD, functional as AF, optim as O, train as T  # noqa: E402
+
+
+def main():
+    dev = torch.device("cuda", 0)
+    wl = D.bench_workload("twitch-gamer", seed=0, node_order="degree")
+    low, deg, x_np, y_np, (tr, va, te) = wl["low"], wl["deg"], wl["x"], wl["y"], wl["splits"]
+    n = low.shape[0]
+    x = torch.from_numpy(x_np).to(dev)
+    y = torch.from_numpy(y_np).to(dev)
+    w = T.row_weights(torch.from_numpy(tr).to(dev), n, device=dev)
+    configs = sys.argv[1:] or [""]
+    for cfg in configs:
+        keys = []
+        for kv in filter(None, cfg.split(",")):
+            k, v = kv.split("=")
+            os.environ[k] = v
+            keys.append(k)
+        ops = DD.make_sharded_operators(low, deg, dev)
+        torch.manual_seed(0)
+        model = acm_gnn_amd.GCN(x.shape[1], 64, int(y_np.max()) + 1, 2, n, 0.1, "acmgcnp", 0, variant=False).to(dev)
+        opt = O.FusedAdamW(model.parameters(), lr=0.05, weight_decay=1e-3)
+        step = T.TrainStep(model, opt, x, ops, y, w)
+        for _ in range(5):
+            step()
+        timer = AF.KernelTimer()
+        AF.set_kernel_timer(timer)
+        for _ in range(20):
+            step()
+        AF.set_kernel_timer(None)
+        ks = {k: round(v[1] / v[0] * 1e3, 1) for k, v in timer.summary().items()}
+        # the captured step
+        model2 = acm_gnn_amd.GCN(x.shape[1], 64, int(y_np.max()) + 1, 2, n, 0.1, "acmgcnp", 0, variant=False).to(dev)
+        opt2 = O.FusedAdamW(model2.parameters(), lr=0.05, weight_decay=1e-3)
+        gstep = T.TrainStep(model2, opt2, x, ops, y, w, use_graph=True)
+        for _ in range(10):
+            gstep()
+        best = []
+        for _ in range(5):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(50):
+                gstep()
+            torch.cuda.synchronize()
+            best.append((time.perf_counter() - t0) / 50 * 1e3)
+        print(json.dumps({"env": cfg, "graph_ms": [round(b, 4) for b in sorted(best)], "pipe": step.pipe is not None,
+                          "kernel_us": ks}), flush=True)
+        for k in keys:
+            os.environ.pop(k, None)
+        del step, gstep, model, model2, opt, opt2, ops
+        from acm_gnn_amd.graph import clear_cache
+        clear_cache()
+
+
+if __name__ == "__main__":
+    main()

@@ -42,22 +42,7 @@ class _Csr:
         return m @ g.astype(np.float64)
 
 
-def philox7_words(seed, step, tag, rows, blocks):
-    """Philox4x32-7 words of the dropout mask (numpy restatement of acm_philox7): rows/blocks are integer arrays
-    of equal shape; returns uint32 [4, ...]."""
-    M0, M1, W0, W1 = 0xD2511F53, 0xCD9E8D57, 0x9E3779B9, 0xBB67AE85
-    mask = np.uint64(0xFFFFFFFF)
-    x0 = np.asarray(rows).astype(np.uint64) & mask
-    x1 = (np.asarray(blocks).astype(np.uint64) | np.uint64((int(tag) << 16) & 0xFFFFFFFF)) & mask
-    x2 = np.full(x0.shape, int(step) & 0xFFFFFFFF, np.uint64)
-    x3 = np.full(x0.shape, (int(step) >> 32) & 0xFFFFFFFF, np.uint64)
-    k0, k1 = int(seed) & 0xFFFFFFFF, (int(seed) >> 32) & 0xFFFFFFFF
-    for _ in range(7):
-        p0, p1 = np.uint64(M0) * x0, np.uint64(M1) * x2
-        hi0, lo0, hi1, lo1 = p0 >> np.uint64(32), p0 & mask, p1 >> np.uint64(32), p1 & mask
-        x0, x1, x2, x3 = hi1 ^ x1 ^ np.uint64(k0), lo1, hi0 ^ x3 ^ np.uint64(k1), lo0
-        k0, k1 = (k0 + W0) & 0xFFFFFFFF, (k1 + W1) & 0xFFFFFFFF
-    return np.stack([x0, x1, x2, x3]).astype(np.uint32)
+from oracle.philox import philox7_words, dropout_factors as _keep_factors  # noqa: E402  (the numpy restatement of the mask)
 
 
 def dropout_factors(d, n_rows, n_cols):
@@ -65,13 +50,7 @@ def dropout_factors(d, n_rows, n_cols):
     if d is None or d.p <= 0:
         return np.ones((n_rows, n_cols))
     step = int(_vec(d.step, 1, np.int64)[0]) + int(getattr(d, "step_offset", 0))
-    r, c = np.meshgrid(np.arange(n_rows) + int(d.row_offset), np.arange(n_cols), indexing="ij")
-    w = philox7_words(d.seed, step, d.tag, r, (c & 15) + 16 * (c >> 6))
-    word = np.take_along_axis(w, ((c >> 4) & 3)[None], 0)[0]
-    t = float(np.float32(d.p)) * 4294967296.0
-    thresh = 0xFFFFFFFF if t >= 4294967295.0 else int(t)
-    inv = np.float32(1.0) / (np.float32(1.0) - np.float32(d.p))
-    return np.where(word >= thresh, np.float64(inv), 0.0)
+    return _keep_factors(d.seed, step, d.tag, float(np.float32(d.p)), n_rows, n_cols, row_offset=int(d.row_offset))
 
 
 def _post_fwd(p, out, n, F):

@@ -65,7 +65,7 @@ def test_leaving_the_block_flushes_and_an_exception_discards(monkeypatch):
             raise KeyError("boom")
     except KeyError:
         pass
-    assert pending.pending == 0 and AF._DEFER is None
+    assert pending.pending == 0 and AF._ambient().defer is None
 
 
 def test_train_step_defers_and_matches_the_immediate_trajectory(monkeypatch):

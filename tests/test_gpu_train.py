@@ -287,15 +287,11 @@ def test_carried_gather_leaves_the_backward_unchanged():
     def grads(carry):
         for p in params:
             p.grad = None
-        AF._PIPE = pipe if carry else None
-        try:
-            xin = pipe.table() if carry else pipe.table().clone()
-            out = layer(xin, ops, None, post_relu=True)
-            if carry:
-                pipe.make_next()
-            out.backward(gout)
-        finally:
-            AF._PIPE = None
+        xin = pipe.table() if carry else pipe.table().clone()
+        out = layer(xin, ops, None, post_relu=True, call=AF.CallContext(pipe=pipe if carry else None))
+        if carry:
+            assert pipe.make_next()
+        out.backward(gout)
         return [p.grad.clone() for p in params if p.grad is not None], out.detach().clone()
 
     g_plain, out_plain = grads(False)

@@ -634,7 +634,7 @@ def test_next_layer_projection_rides_the_hidden_layers_epilogue(n_cls, fused_dro
             torch.manual_seed(11)                          # the F.dropout masks
         out = model(x, low, high)
         out.square().sum().backward()
-        assert AF._NEXT_PROJ is None and AF._PRE_PROJ is None
+        assert AF._ambient().next_proj is None and AF._ambient().pre_proj is None
         return out.detach(), {k: p.grad.clone() for k, p in model.named_parameters() if p.grad is not None}, list(calls)
 
     out_f, g_f, calls_f = run("1")
@@ -833,3 +833,124 @@ def test_input_pipeline_notices_steps_made_by_someone_else(monkeypatch):
     assert piped.pipe.stale()
     got.append(float(piped()))
     np.testing.assert_allclose(got, want, rtol=1e-5, atol=1e-6)
+
+
+def _two_step_setups(n, ops):
+    """Two different models (ACM-GCN+ with the input pipeline, ACM-GCN++ without) on the same operators."""
+    from acm_gnn_amd import GCN, FusedAdamW, functional as AF, train as T
+    x = torch.randn(n, 7, generator=torch.Generator().manual_seed(1))
+    y = torch.randint(0, 2, (n,), generator=torch.Generator().manual_seed(2))
+    w = T.row_weights(torch.arange(0, n, 2), n)
+
+    def make(kind):
+        torch.manual_seed(3)
+        mt = "acmgcnp" if kind == 0 else "acmgcnpp"
+        model = GCN(7, 64, 2, 2, n, 0.3, mt, 0, variant=False, attn_layernorm=True)
+        model.dropout_state = AF.DropoutState(torch.device("cpu"), seed=50 + kind)
+        return T.TrainStep(model, FusedAdamW(model.parameters(), lr=0.02), x, ops, y, w, use_graph=False, fused_dropout=True,
+                           pipeline_input=None if kind == 0 else False)
+    return make
+
+
+def test_two_train_steps_interleaved_equal_running_them_apart(monkeypatch):
+    """The per-call context (functional.CallContext: deferral list, loss-tail request, input pipeline, projection
+    hand-off) travels with each model call: two TrainSteps of different models stepped alternately -- and with the forward
+    of one between the forward and the backward of the other -- give exactly the losses and parameters of the two run
+    one after the other."""
+    fake_lib.install(monkeypatch)
+    monkeypatch.setenv("ACM_PIPELINE_MIN_ROWS", "32")
+    from acm_gnn_amd import functional as AF
+    ops, n = _dense_graph_ops(seed=5)
+    make = _two_step_setups(n, ops)
+    apart = []
+    for kind in (0, 1):
+        step = make(kind)
+        apart.append(([float(step()) for _ in range(4)], {k: v.clone() for k, v in step.model.state_dict().items()}))
+    a, b = make(0), make(1)
+    assert a.pipe is not None and b.pipe is None
+    la, lb = [], []
+    for _ in range(4):
+        la.append(float(a()))
+        lb.append(float(b()))
+    assert la == apart[0][0] and lb == apart[1][0]
+    for step, (_, sd) in ((a, apart[0]), (b, apart[1])):
+        for k, v in step.model.state_dict().items():
+            assert torch.equal(v, sd[k]), k
+    # a forward of model B between the forward and the backward of model A (what a hand-off parked in module state cannot
+    # survive): drive the two halves of A's step by hand
+    a2, b2 = make(0), make(1)
+    ref = make(0)
+    for _ in range(2):
+        a2.model.train()
+        a2.opt.zero_grad(set_to_none=True)
+        if a2.pipe.stale():
+            a2.pipe.prime()
+        call = AF.CallContext(defer=AF.DeferredReductions(), pipe=a2.pipe)
+        loss, dz, out = a2._forward_loss(call)
+        lb2 = float(b2())                                     # a whole step of the other model in between
+        assert a2.pipe.make_next()
+        out.backward(dz)
+        call.defer.flush()
+        a2.opt.step()
+        a2._count_advance()
+        a2.pipe.end_step()
+        assert float(loss) == float(ref()) and np.isfinite(lb2)
+    assert AF._ambient().defer is None and AF._ambient().tail is None and AF._ambient().pipe is None
+
+
+def test_two_train_steps_in_threads_equal_running_them_apart(monkeypatch):
+    fake_lib.install(monkeypatch)
+    monkeypatch.setenv("ACM_PIPELINE_MIN_ROWS", "32")
+    import threading
+    ops, n = _dense_graph_ops(seed=6)
+    make = _two_step_setups(n, ops)
+    apart = []
+    for kind in (0, 1):
+        step = make(kind)
+        apart.append([float(step()) for _ in range(6)])
+    steps = [make(0), make(1)]
+    got, errs = [None, None], []
+    barrier = threading.Barrier(2)
+
+    def work(i):
+        try:
+            out = []
+            for _ in range(6):
+                barrier.wait(timeout=60)
+                out.append(float(steps[i]()))
+            got[i] = out
+        except BaseException as e:                      # noqa: BLE001
+            errs.append(e)
+            barrier.abort()
+
+    ts = [threading.Thread(target=work, args=(i,)) for i in range(2)]
+    [t.start() for t in ts]
+    [t.join() for t in ts]
+    assert not errs, errs
+    assert got[0] == apart[0] and got[1] == apart[1]
+
+
+def test_pipeline_is_not_refilled_when_the_forward_did_not_adopt_it(monkeypatch):
+    """make_next() must not overwrite the pipeline's table when the layer went another way (here
+    ACM_AGG_FIRST=0: the literal path saves the table itself for dW): the step then equals the plain step."""
+    fake_lib.install(monkeypatch)
+    monkeypatch.setenv("ACM_PIPELINE_MIN_ROWS", "32")
+    from acm_gnn_amd import GCN, FusedAdamW, functional as AF, train as T
+    ops, n = _dense_graph_ops(seed=7)
+    x, y = torch.randn(n, 7, generator=torch.Generator().manual_seed(1)), torch.randint(0, 2, (n,), generator=torch.Generator().manual_seed(2))
+    w = T.row_weights(torch.arange(0, n, 2), n)
+
+    def run(pipeline):
+        torch.manual_seed(0)
+        model = GCN(7, 64, 2, 2, n, 0.3, "acmgcnp", 0, variant=False, attn_layernorm=True)
+        model.dropout_state = AF.DropoutState(torch.device("cpu"), seed=21)
+        step = T.TrainStep(model, FusedAdamW(model.parameters(), lr=0.02), x, ops, y, w, use_graph=False, fused_dropout=True,
+                           pipeline_input=pipeline)
+        if pipeline is None:
+            assert step.pipe is not None
+        monkeypatch.setenv("ACM_AGG_FIRST", "0")               # after eligibility was decided: the layer now goes the literal way
+        out = [float(step()) for _ in range(3)]
+        monkeypatch.delenv("ACM_AGG_FIRST")
+        return out
+
+    np.testing.assert_allclose(run(None), run(False), rtol=1e-5, atol=1e-6)
