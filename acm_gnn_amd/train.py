@@ -239,6 +239,8 @@ class TrainStep:
             ds = getattr(self.model, "dropout_state", None)
             if ds is not None:
                 ds.host_steps += 1            # the replayed step advanced the device counter
+                if self.pipe is not None:     # ... and refilled the pipeline's buffers for the new value
+                    self.pipe._host_steps = ds.host_steps
             return self.loss
         return self._eager()
 

@@ -27,7 +27,8 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured stream)
 FP32_MFMA_PEAK_TF = 157.3
-TRAFFIC_FILE = "r02_pmc_traffic.json"
+TRAFFIC_FILE = "r03_pmc_traffic.json"
+WINDOWS = 5                    # timed windows of --steps replays each; ms_per_step is the median window
 
 
 def parse():
@@ -56,7 +57,8 @@ def parse():
                     help="node relabelling applied to the whole dataset before training (data prep)")
     ap.add_argument("--no-extras", action="store_true",
                     help="skip the side measurements of the single-GPU run (literal form, random node order)")
-    ap.add_argument("--no-check", action="store_true", help="skip the sampled comparison with the CPU oracle")
+    ap.add_argument("--no-check", action="store_true", help="skip the comparisons with the CPU oracle (eval-mode logits on "
+                    "sampled rows; one training-mode step: loss and every parameter gradient)")
     return ap.parse_args()
 
 
@@ -226,8 +228,13 @@ def main():
         if world == 1 and args.dataset == "twitch-gamer" and args.node_order == "degree" and os.path.exists(tpath):
             with open(tpath) as fh:
                 rec = json.load(fh)
-            traffic = rec.get(dominant, {}).get("hbm_bytes")
+            sys.path.insert(0, os.path.join(ROOT, "scripts"))
+            from make_traffic_json import kernel_source_hash
             traffic_source = f"profiles/{TRAFFIC_FILE}" + (f"@{rec['_commit']}" if "_commit" in rec else "")
+            if rec.get("_kernel_source_hash") == kernel_source_hash():
+                traffic = rec.get(dominant, {}).get("hbm_bytes")
+            else:                                   # counters collected for other kernels: not quoted
+                traffic_source += " (STALE: the kernel sources changed since the counters were collected)"
         roofline = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_source,
                     "kernel": dominant, "avg_ms": round(avg_ms, 4), "launches": launches,
@@ -262,25 +269,35 @@ def main():
         }
         print(json.dumps(result), flush=True)
 
-    def timed_graph_steps(gstep):
+    def timed_graph_steps(gstep, spread=None):
+        """ms per step of `gstep`: WINDOWS windows of exactly --steps calls, each bracketed by barrier + synchronize and
+        reduced with MAX over the ranks; the MEDIAN window is reported (``spread`` receives min / median / max)."""
         for _ in range(max(args.warmup, 1)):
             out = gstep()
-        fence()
-        t = time.perf_counter()
-        for _ in range(args.steps):
-            out = gstep()
-        fence()
-        dtg = time.perf_counter() - t
-        if world > 1:
-            tt = torch.tensor([dtg], device=dev, dtype=torch.float64)
-            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-            dtg = float(tt.item())
-        return dtg / args.steps * 1e3, out
+        wins = []
+        for _ in range(WINDOWS):
+            fence()
+            t = time.perf_counter()
+            for _ in range(args.steps):
+                out = gstep()
+            fence()
+            dtg = time.perf_counter() - t
+            if world > 1:
+                tt = torch.tensor([dtg], device=dev, dtype=torch.float64)
+                dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+                dtg = float(tt.item())
+            wins.append(dtg / args.steps * 1e3)
+        wins.sort()
+        if spread is not None:
+            spread.update({"windows": WINDOWS, "steps_per_window": args.steps, "min": round(wins[0], 4),
+                           "median": round(wins[len(wins) // 2], 4), "max": round(wins[-1], 4)})
+        return wins[len(wins) // 2], out
 
     # ---------------- second timed region: the same K steps as replays of one captured HIP graph ----------------
     # (collectives included when sharded).  A watchdog makes the run fall back to the eager measurement if the
     # captured path does not finish: rank 0 then reports the eager numbers instead of hanging the job.
     graph_ok = False
+    spread = {}
     if use_graph:
         import threading
         state = {"done": False}
@@ -297,7 +314,7 @@ def main():
         timer_t.start()
         try:
             gstep = T.TrainStep(model, opt, x, ops, y, w, use_graph=True, fused_dropout=fused_drop)
-            ms_per_step, loss = timed_graph_steps(gstep)
+            ms_per_step, loss = timed_graph_steps(gstep, spread)
             graph_ok = True
         except Exception as exc:                      # capture refused: keep the eager measurement
             sys.stderr.write(f"bench.py: hipGraph capture failed ({exc!r}); reporting eager launches\n")
@@ -313,6 +330,11 @@ def main():
     check = None
     if not args.no_check:
         check = sampled_check(args, model, wl_now=(adj, x_np, low), ops=ops, x=x, rows=(b, e), rank=rank, world=world)
+        if check is not None and world == 1 and fused_drop and args.optimizer == "fused":
+            # ... and of the step as it is timed: one TRAINING-mode step (through the input pipeline where it applies)
+            tcheck = training_step_check(args, model, (adj, x_np, y_np, tr, low), ops, x, y, w)
+            check["check_train"] = tcheck
+            check["checked"] = bool(check["checked"] and tcheck["ok"])
         if check is not None and not check["checked"]:
             sys.stderr.write(f"bench.py: PARITY CHECK FAILED: {check}\n")
 
@@ -328,6 +350,8 @@ def main():
     # which form of the step was timed: with the first layer's input aggregation of step t + 1 inside that layer's backward
     # of step t (train.TrainStep's default where it qualifies; ACM_PIPELINE=0 switches it off) or without
     extras["input_pipeline"] = step.pipe is not None
+    if spread:
+        extras["ms_per_step_windows"] = spread
     if rank == 0:
         emit(ms_per_step, "hipGraph replay of the captured step" if graph_ok else "eager launches", final_loss,
              with_cpu=True, extras=extras, check=check)
@@ -362,6 +386,9 @@ def side_measurements(args, timed_graph_steps, model, opt, x, ops, y, w, fused_d
             return loss
         ms, _ = timed_graph_steps(epoch)
         out["train_plus_eval_ms_per_epoch"] = round(ms, 4)
+        # the same captured step alone: what train.fit() and the row-sharded runs execute (no input pipeline)
+        ms, _ = timed_graph_steps(gstep)
+        out["plain_ms_per_step"] = round(ms, 4)
     if not args.variant and os.environ.get("ACM_AGG_FIRST", "1") != "0":
         os.environ["ACM_AGG_FIRST"] = "0"
         try:
@@ -446,6 +473,76 @@ def sampled_check(args, model, wl_now, ops, x, rows, rank, world, n_sample=4096)
     return {"checked": ok, "check": {"rows": int(pick.numel()), "max_abs_err": float(d.max()),
                                      "logit_range": float(ref.abs().max()),
                                      "max_err_over_tol": float((d / tol).max()), "against": "oracle.gcn_forward (CPU, CSR operands), eval mode"}}
+
+
+def training_step_check(args, model, wl_now, ops, x, y, w):
+    """One TRAINING-mode step of the model that was just timed, as it was timed (counter-based dropout inside the kernels;
+    through the input pipeline when the configuration qualifies, so that the first layer's P is the one the previous
+    step's backward kernel carried), against the oracle's step on the host with the masks regenerated in numpy
+    (oracle/philox.py): the loss and EVERY parameter gradient.  lr = 0, so the parameters stay what the timed run left.
+    Tolerances as in tests/test_gpu_fullsize.py: loss 3e-5 relative; a gradient within 3e-4 of its range (+1e-6), or --
+    the first layer's weight gradients sum products with feature values up to 1e4 -- within 5x the fp32 oracle's own
+    distance from a float64 run of the oracle."""
+    import torch
+    import acm_gnn_amd
+    from acm_gnn_amd import train as T
+    from oracle import acm_oracle as O
+    from oracle.philox import dropout_factors
+    adj, x_np, y_np, tr, low = wl_now
+    n = x_np.shape[0]
+    opt0 = acm_gnn_amd.FusedAdamW(model.parameters(), lr=0.0, weight_decay=0.0)
+    chk = T.TrainStep(model, opt0, x, ops, y, w, use_graph=False, fused_dropout=True)
+    st = model.dropout_state
+    chk()                                            # a whole step: its backward carries the next step's P (pipeline)
+    opt0.zero_grad(set_to_none=True)
+    counter = int(st.step.item())
+    loss = chk._forward_backward()
+    torch.cuda.synchronize()
+    got = {k: p.grad.detach().cpu() for k, p in model.named_parameters() if p.grad is not None}
+    masks = {"x": torch.from_numpy(dropout_factors(st.seed, counter, 0, args.dropout, n, x_np.shape[1]) > 0).float(),
+             "hidden": torch.from_numpy(dropout_factors(st.seed, counter, 1, args.dropout, n, args.hidden) > 0).float()}
+    torch.set_num_threads(min(os.cpu_count(), 32))
+    operands = _csr_operands(low, adj)
+    xt, yt, idx = torch.from_numpy(x_np), torch.from_numpy(y_np), torch.from_numpy(tr)
+
+    def oracle_step(dtype):
+        ops_t = operands
+        if dtype != torch.float32:
+            ops_t = tuple(torch.sparse_csr_tensor(t.crow_indices(), t.col_indices(), t.values().to(dtype), size=t.shape)
+                          for t in operands)
+        ps = {k: v.to(dtype).requires_grad_(True) for k, v in _oracle_params(model).items()}
+        ref = O.gcn_forward(ps, xt.to(dtype), ops_t[0], ops_t[1], ops_t[2] if args.structure_info else None,
+                            model_type=args.method, variant=bool(args.variant), structure_info=args.structure_info,
+                            attn_layernorm=True, dropout=args.dropout, training=True,
+                            masks={k: v.to(dtype) for k, v in masks.items()})
+        ls = O.nll_loss_on(ref, yt, idx)
+        ls.backward()
+        return float(ls), {k: v.grad for k, v in ps.items() if v.grad is not None}
+
+    ref_loss, ref_g = oracle_step(torch.float32)
+    ok = abs(float(loss) - ref_loss) <= 3e-5 * max(1.0, abs(ref_loss))
+    worst, needs64 = 0.0, []
+    for k, rg in ref_g.items():
+        if k not in got:
+            ok = False
+            continue
+        d = float((got[k].double() - rg.double()).abs().max())
+        tol = 3e-4 * float(rg.abs().max()) + 1e-6
+        worst = max(worst, d / max(float(rg.abs().max()), 1e-30))
+        if d >= tol:
+            needs64.append((k, d, tol))
+    used64 = {}
+    if needs64:
+        _, g64 = oracle_step(torch.float64)
+        for k, d, tol in needs64:
+            d64 = float((got[k].double() - g64[k]).abs().max())
+            e_ref = float((ref_g[k].double() - g64[k]).abs().max())
+            used64[k] = [d64, e_ref]
+            ok = ok and d64 <= max(5.0 * e_ref, tol)
+    return {"ok": bool(ok), "input_pipeline": chk.pipe is not None, "dropout_counter": counter, "loss": float(loss),
+            "loss_oracle": ref_loss, "gradients": len(ref_g), "worst_grad_err_over_range_vs_fp32_oracle": worst,
+            "vs_fp64_oracle_[gpu_err, fp32_oracle_err]": used64,
+            "against": "oracle.gcn_forward + NLL + backward (CPU, CSR operands), training mode, masks regenerated (oracle/philox.py)"}
 
 
 def cpu_baseline(args, model, wl):

@@ -25,5 +25,6 @@ for PASS in "FETCH_SIZE:pmc_fetch_size_kb" "WRITE_SIZE:pmc_write_size_kb" "TCC_H
   DB=$(find /tmp/prof_pmc -name "*.db" | head -1)
   python $REPO/scripts/rocpd_pmc_summary.py $DB > $OUT/$NAME.csv 2>> $OUT/$NAME.err
 done
+if [ "$COMMIT" = "unknown" ]; then echo "collect_profiles.sh: pass the commit the box runs (git rev-parse --short HEAD) as the second argument" >&2; fi
 python $REPO/scripts/make_traffic_json.py $OUT/pmc_fetch_size_kb.csv $OUT/pmc_write_size_kb.csv $COMMIT > $OUT/pmc_traffic.json
 tail -1 $OUT/bench.json | cut -c1-400

@@ -137,14 +137,9 @@ def _oracle_step(params, x, y, tr, ops_t, structure, variant, dtype=torch.float3
     return ref.detach(), loss.detach(), ps
 
 
-def _factors(state, p, tag, n, c):
-    class D:
-        pass
-    dd = D()
-    dd.p, dd.tag, dd.seed, dd.row_offset = np.float32(p), tag, state.seed, 0
-    host = np.array([int(state.step.item())], np.int64)
-    dd.step = host.ctypes.data
-    return fake_lib.dropout_factors(dd, n, c)
+def _factors(state, p, tag, n, c, step=None):
+    from oracle.philox import dropout_factors
+    return dropout_factors(state.seed, int(state.step.item()) if step is None else step, tag, float(np.float32(p)), n, c)
 
 
 TWITCH = [(v, s, o) for o in ("degree", "random") for s in (0, 1) for v in (0, 1)]      # grouped by workload
@@ -247,6 +242,7 @@ def test_twitch_shaped_step_with_counter_based_dropout_matches_oracle(variant, s
     opt = acm_gnn_amd.FusedAdamW(model.parameters(), lr=0.0, weight_decay=0.0)
     step = T.TrainStep(model, opt, xd, ops, yd, w, use_graph=False, fused_dropout=True)
     assert model.fused_dropout
+    assert (step.pipe is not None) == (not variant and not structure)     # the headline cell runs through the input pipeline
     st = model.dropout_state
     st.step.fill_(41)
     opt.zero_grad(set_to_none=True)
@@ -263,6 +259,78 @@ def test_twitch_shaped_step_with_counter_based_dropout_matches_oracle(variant, s
     rec = {"loss": float(loss), "loss_ref": float(ref_loss)}
     rec["grad_worst_rel"] = _compare_grads(model, params, "dropout-step", rec, params64)
     _record(f"twitch-dropout/v{variant}s{structure}", **rec)
+
+
+@pytest.mark.parametrize("mode", ["eager", "graph"])
+def test_twitch_shaped_pipelined_steps_match_oracle(mode):
+    """The headline configuration of bench.py as it is timed: train.TrainStep WITH the input pipeline (asserted), at bench
+    size.  Two consecutive steps with lr = 0 (the parameters stay put, the dropout counter moves 41 -> 42 -> 43):
+      * after step one, the P the first layer's backward kernel carried (acm_conv_agg_bwd_t.next_agg: 256 workgroups of
+        sixteen waves, id streams with the 21 k-degree hub in pieces) must be A_low (x (.) mask_42 / (1 - p)) -- checked
+        against a float64 scipy product with the mask regenerated in numpy;
+      * step two -- whose forward consumed exactly that P and whose first-layer forward ran as the row-local stage alone --
+        must give the oracle's loss and every parameter gradient under the replayed masks of counter 42
+        (ACM-Geometric/models.py:54,70; train.py:133-135).
+    'graph': the same through the captured step (hipGraph replays), which is what bench.py's headline number times."""
+    import acm_gnn_amd
+    from acm_gnn_amd import distributed as DD, functional as AF, train as T
+    p_drop = 0.1
+    wl = _workload("twitch-gamer", "degree", True)
+    n = wl["adj"].shape[0]
+    tr = wl["splits"][0]
+    x, y = torch.from_numpy(wl["x"]), torch.from_numpy(wl["y"])
+    torch.manual_seed(9)
+    model = acm_gnn_amd.GCN(x.shape[1], 64, 2, 2, n, p_drop, "acmgcnp", 0, variant=False, attn_layernorm=True)
+    p0 = {k: v.detach().cpu().clone() for k, v in model.named_parameters() if k not in ("fea_param", "xX_param")}
+    model = model.to(DEV)
+    ops = DD.make_sharded_operators(wl["low"], wl["deg"], DEV)
+    xd, yd = x.to(DEV), y.to(DEV)
+    w = T.row_weights(torch.from_numpy(tr).to(DEV), n)
+    opt = acm_gnn_amd.FusedAdamW(model.parameters(), lr=0.0, weight_decay=0.0)
+    model.dropout_state = st = AF.DropoutState(torch.device(DEV), seed=1234)
+    st.step.fill_(41)
+    timer = AF.KernelTimer()
+    AF.set_kernel_timer(timer if mode == "eager" else None)      # (no timing events inside a capture)
+    try:
+        step = T.TrainStep(model, opt, xd, ops, yd, w, use_graph=(mode == "graph"), fused_dropout=True)
+        assert step.pipe is not None, "the benchmark configuration must qualify for the input pipeline"
+        assert int(st.step.item()) == 41                 # (a capture's warm-up is undone)
+        step()                                           # counter 41 -> 42; its backward carried P_42
+        torch.cuda.synchronize()
+    finally:
+        AF.set_kernel_timer(None)
+    assert int(st.step.item()) == 42 and step.pipe.primed and not step.pipe.stale()
+    if mode == "eager":
+        used = sorted(set(k.split("/")[0] for k in timer.events))
+        assert "conv_agg_bwd+gather" in used and "conv_agg_epi" in used, used
+    # ---- the carried P against float64
+    f42 = _factors(st, p_drop, 0, n, x.shape[1], step=42)
+    xdrop = wl["x"].astype(np.float64) * f42
+    p_ref = wl["low"].astype(np.float64) @ xdrop
+    got_tab = step.pipe.filled[0].cpu().double().numpy()
+    got_p = step.pipe.filled[1].cpu().double().numpy()
+    assert np.array_equal(got_tab[:, :x.shape[1]], (wl["x"] * f42.astype(np.float32)).astype(np.float64)) and not got_tab[:, x.shape[1]:].any()
+    scale = float(np.abs(p_ref).max())
+    err_p = float(np.abs(got_p[:, :x.shape[1]] - p_ref).max())
+    row_err = np.abs(got_p[:, :x.shape[1]] - p_ref).max(1) / (np.abs(wl["low"]).astype(np.float64) @ np.abs(xdrop)).max(1).clip(1e-30)
+    rec = {"carried_P_max_abs": err_p, "carried_P_range": scale, "carried_P_rowwise_rel": float(row_err.max())}
+    assert err_p < 1e-5 * scale and not got_p[:, x.shape[1]:].any(), rec
+    assert float(row_err.max()) < 2e-5, rec              # every row to fp32 summation error of its own terms
+    # ---- step two against the oracle under the masks of counter 42
+    if mode == "graph":
+        loss2 = step()                                   # a replay: gradients stay in the captured .grad tensors
+    else:
+        opt.zero_grad(set_to_none=True)
+        loss2 = step._forward_backward()
+    torch.cuda.synchronize()
+    masks = {"x": torch.from_numpy(f42 > 0).float(), "hidden": torch.from_numpy(_factors(st, p_drop, 1, n, 64, step=42) > 0).float()}
+    ops_t = _oracle_operands(wl)
+    _, ref_loss, params = _oracle_step(p0, x, y, tr, ops_t, 0, 0, dropout=p_drop, masks=masks)
+    params64 = lambda: _oracle_step(p0, x, y, tr, ops_t, 0, 0, dtype=torch.float64, dropout=p_drop, masks=masks)[2]  # noqa: E731
+    rec["loss"], rec["loss_ref"] = float(loss2), float(ref_loss)
+    assert abs(float(loss2) - float(ref_loss)) < LOSS_TOL * max(1.0, abs(float(ref_loss))), rec
+    rec["grad_worst_rel"] = _compare_grads(model, params, "pipelined-" + mode, rec, params64)
+    _record(f"twitch-pipelined/{mode}", **rec)
 
 
 @pytest.mark.parametrize("dataset,sparse_x", [("arxiv-year", False), ("penn94", True), ("penn94", False)])
