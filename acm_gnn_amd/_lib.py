@@ -14,7 +14,7 @@ c_i32p = C.POINTER(C.c_int32)
 
 ACM_OK = 0
 STATUS_NAMES = {1: "ACM_EINVAL", 2: "ACM_ESHAPE", 3: "ACM_EHIP", 4: "ACM_EUNSUPPORTED", 5: "ACM_ENOMEM"}
-ABI_VERSION = 19
+ABI_VERSION = 20
 
 # every symbol include/acm_hip.h declares
 EXPORTED_SYMBOLS = (
@@ -135,7 +135,10 @@ class ConvAggBwd(C.Structure):
                 ("head_stats", C.c_void_p), ("ld_head_stats", C.c_int64),
                 ("out", C.c_void_p), ("ld_out", C.c_int64),
                 ("next_a", C.c_void_p), ("next_xg", C.c_void_p), ("ld_next_xg", C.c_int64),
-                ("next_row_scale", C.c_void_p), ("next_agg", C.c_void_p), ("ld_next_agg", C.c_int64)]
+                ("next_row_scale", C.c_void_p), ("next_agg", C.c_void_p), ("ld_next_agg", C.c_int64),
+                ("proj_dz", C.c_void_p), ("ld_proj_dz", C.c_int64),
+                ("proj_w_low", C.c_void_p), ("proj_w_high", C.c_void_p), ("proj_w_mlp", C.c_void_p), ("proj_ld_w", C.c_int64),
+                ("proj_f", C.c_int32), ("proj_d_w", C.c_void_p)]
 
 
 class ConvAcmiiFwd(C.Structure):

@@ -34,7 +34,7 @@ def _hipcc():
 
 def _deps():
     out = [os.path.join(CSRC, s) for s in SOURCES]
-    out += [os.path.join(CSRC, "acm_common.h"), os.path.join(CSRC, "acm_conv_device.h"),
+    out += [os.path.join(CSRC, "acm_common.h"), os.path.join(CSRC, "acm_conv_device.h"), os.path.join(CSRC, "acm_stream_device.h"),
             os.path.join(INCLUDE, "acm_hip.h")]
     return out
 

@@ -11,6 +11,7 @@
 // are outer-product reductions over rows, accumulated per lane in registers and combined
 // deterministically (wave -> LDS -> per-block partial -> tree reduce).
 #include "acm_conv_device.h"
+#include "acm_stream_device.h"
 
 // defined in acm_conv.hip
 int acm_spmm_internal(const acm_csr* a, const void* G, int64_t ldg, int width, float* Y, int64_t ldy,
@@ -19,7 +20,9 @@ int acm_spmm_internal(const acm_csr* a, const void* G, int64_t ldg, int width, f
 // defined in acm_conv_agg16.hip: the row-local forward stage in the transposed matrix-core layout (-1: not its case)
 int acm_agg_epi16(const acm_conv_agg_fwd_t* p, int64_t n_rows, bool* next_done, hipStream_t s);
 // ... and the row-local backward (blocks launched; 0: not its case; < 0: error)
-int acm_agg_bwd16(const acm_conv_agg_bwd_t* p, int64_t n_rows, float* partial, int max_blocks, hipStream_t s);
+struct GatherRole;
+int acm_agg_bwd16(const acm_conv_agg_bwd_t* p, int64_t n_rows, float* partial, int max_blocks, hipStream_t s, const GatherRole* gr,
+                  int gather_blocks);
 
 namespace {
 
@@ -490,8 +493,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5))) void a
 // Lane (g, e, h): group g = one work item of the slice, neighbours 4 e .. 4 e + 3 of the step, half h of the 32-byte row.
 // Pieces of a long row: partial sum -> its slot (write-through store), arrival counter; the last piece adds the slots
 // in slot order (bypassing the L1 / the XCD's L2) and finishes the row.
-typedef float acm_f32x4 __attribute__((ext_vector_type(4)));
-typedef int acm_i32x4 __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ acm_i32x4 acm_probe_ids(acm_i32x4 j, int probe) {
     if (probe >= 2) j = acm_i32x4{ACM_STREAM_SENTINEL, ACM_STREAM_SENTINEL, ACM_STREAM_SENTINEL, ACM_STREAM_SENTINEL};
@@ -633,125 +634,6 @@ __global__ __launch_bounds__(256) void agg_stream_kernel(acm_conv_agg_fwd_t p, S
     } while (0)
     // an odd step count runs one step past the wave's share: its ids are the next wave's (or the padding), its sums are
     // never used (rem is "infinite" after the last slice)
-    for (int t = sv.waves[W * 4 + 3]; t > 0; t -= 2) {
-        ACM_STEP(za);
-        ACM_STEP(zb);
-    }
-#undef ACM_STEP
-#undef ACM_ISSUE
-#undef ACM_IDS
-}
-
-// ---------------------------------------------------------------- the gather alone, as a ROLE of another kernel
-// One wave's share of  agg = row_scale * (A xg)  over the id streams (32-byte rows, pattern-only operator): the loop of
-// agg_stream_kernel without the row-local stage.  acm_conv_agg_bwd runs it in two extra waves per workgroup for the NEXT
-// step's first layer (acm_conv_agg_bwd_t.next_agg): the backward's waves keep the vector unit busy, these keep the memory
-// system busy, and a kernel of each kind on two streams would not share the CUs.
-struct GatherRole {
-    StreamView sv;
-    const float* xg;
-    unsigned xg_bytes;
-    const float* row_scale;
-    float* agg;
-    long ld_agg;
-    int roles;               // 3: both; 1: backward only, 2: gather only (ACM_AGG_BWD_ROLES: measurements)
-};
-
-__device__ __forceinline__ void stream_gather_role(const GatherRole& gr, const int W) {
-    const StreamView& sv = gr.sv;
-    const int lane = threadIdx.x & 63, g = lane >> 4, gl = lane & 15, e = gl >> 1, h = gl & 1;
-    if (W >= sv.n_waves) return;
-    int s = sv.waves[W * 4 + 0];
-    const int s_end = sv.waves[W * 4 + 1];
-    if (s >= s_end) return;
-    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(gr.xg), 0, gr.xg_bytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t ri = __builtin_amdgcn_make_buffer_rsrc(const_cast<int32_t*>(sv.ids), 0, sv.ids_bytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rp = __builtin_amdgcn_make_buffer_rsrc(sv.slots, 0, sv.slots_bytes, 0x00020000);
-    int ioff = sv.waves[W * 4 + 2] * 512 + (g * 8 + e) * 16;
-    const int hoff = h * 16;
-    acm_f32x4 za[4], zb[4];
-#define ACM_ISSUE(Z, J)                                                                                         \
-    do {                                                                                                        \
-        Z[0] = __builtin_bit_cast(acm_f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, (J).x * 32 + hoff, 0, 0)); \
-        Z[1] = __builtin_bit_cast(acm_f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, (J).y * 32 + hoff, 0, 0)); \
-        Z[2] = __builtin_bit_cast(acm_f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, (J).z * 32 + hoff, 0, 0)); \
-        Z[3] = __builtin_bit_cast(acm_f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, (J).w * 32 + hoff, 0, 0)); \
-    } while (0)
-#define ACM_IDS(OFF) __builtin_bit_cast(acm_i32x4, __builtin_amdgcn_raw_buffer_load_b128(ri, (OFF), 0, 0))
-    // slice descriptors {row, slot, steps, -} per group, requested a slice ahead (as the row scale of the slice's rows)
-    const acm_i32x4* items = reinterpret_cast<const acm_i32x4*>(sv.items);
-    acm_i32x4 item = items[s * 4 + g];
-    int rem = __builtin_amdgcn_readfirstlane(item.z);
-    float rs_cur = gr.row_scale ? gr.row_scale[item.x >= 0 ? item.x : 0] : 1.f;
-    acm_i32x4 item_next = items[(s + 1) * 4 + g];
-    acm_i32x4 q0, q1;
-    {
-        // (scheduling barriers: the loop's counted waits assume exactly this issue order -- za, ids, zb, ids; if the
-        // scheduler swaps the two independent row groups here, the loop head must wait for everything, every time)
-        const acm_i32x4 j0 = ACM_IDS(ioff), j1 = ACM_IDS(ioff + 512);
-        __builtin_amdgcn_sched_barrier(0);
-        ACM_ISSUE(za, j0);
-        q0 = ACM_IDS(ioff + 1024);
-        __builtin_amdgcn_sched_barrier(0);
-        ACM_ISSUE(zb, j1);
-        q1 = ACM_IDS(ioff + 1536);
-        __builtin_amdgcn_sched_barrier(0);
-    }
-    ioff += 2048;
-    acm_f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-    auto finish = [&]() __attribute__((always_inline)) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            acc[i] += acm_dpp<0x4E>(acc[i]);     // quad_perm [2,3,0,1]
-            acc[i] += acm_dpp<0x124>(acc[i]);    // row_ror:4
-            acc[i] += acm_dpp<0x128>(acc[i]);    // row_ror:8
-        }
-        const int slot = item.y;
-        bool active = item.x >= 0 && slot < 0;
-        const int row = item.x >= 0 ? item.x : 0;
-        if (__builtin_amdgcn_ballot_w64(slot >= 0) != 0ull) {      // some group holds a piece of a long row
-            if (slot >= 0) {
-                const int li = sv.long_index[row];
-                const AcmLongRow lr = sv.long_rows[li];
-                if (gl < 2)
-                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(acm_i32x4, acc), rp, slot * 32 + hoff, 0, /*sc1*/ 16);
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                int old = 0;
-                if (gl == 0) old = __hip_atomic_fetch_add(sv.counters + li, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                old = acm_row_bcast(old, 0);
-                if (old == lr.slot_end - lr.slot_begin - 1) {      // every other piece has arrived
-                    if (gl == 0) __hip_atomic_store(sv.counters + li, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    acm_f32x4 tot = {0.f, 0.f, 0.f, 0.f};
-                    for (int q = lr.slot_begin + e; q < lr.slot_end; q += 8)
-                        tot += __builtin_bit_cast(acm_f32x4, __builtin_amdgcn_raw_buffer_load_b128(rp, q * 32 + hoff, 0, /*sc1*/ 16));
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        tot[i] += acm_dpp<0x4E>(tot[i]);
-                        tot[i] += acm_dpp<0x124>(tot[i]);
-                        tot[i] += acm_dpp<0x128>(tot[i]);
-                    }
-                    acc = tot;
-                    active = true;
-                }
-            }
-        }
-        if (active && gl < 2) *reinterpret_cast<acm_f32x4*>(gr.agg + (long)row * gr.ld_agg + 4 * h) = rs_cur * acc;
-        acc = acm_f32x4{0.f, 0.f, 0.f, 0.f};
-        ++s;
-        rem = s < s_end ? __builtin_amdgcn_readfirstlane(item_next.z) : 0x7fffffff;
-        item = item_next;
-        item_next = items[(s + 1) * 4 + g];
-        rs_cur = gr.row_scale ? gr.row_scale[item.x >= 0 ? item.x : 0] : 1.f;
-    };
-#define ACM_STEP(Z)                                  \
-    do {                                             \
-        acc += (Z[0] + Z[1]) + (Z[2] + Z[3]);        \
-        ACM_ISSUE(Z, q0);                            \
-        q0 = q1;                                     \
-        q1 = ACM_IDS(ioff);                          \
-        ioff += 512;                                 \
-        if (--rem == 0) finish();                    \
-    } while (0)
     for (int t = sv.waves[W * 4 + 3]; t > 0; t -= 2) {
         ACM_STEP(za);
         ACM_STEP(zb);
@@ -1206,7 +1088,8 @@ extern "C" int acm_conv_agg_bwd_workspace_bytes(int64_t n_rows, int f_in, int f_
     ACM_REQUIRE(bytes, ACM_EINVAL, "acm_conv_agg_bwd_workspace_bytes: NULL argument");
     ACM_REQUIRE(f_in >= 1 && f_in <= 16 && f_out >= 1 && f_out <= 64, ACM_EUNSUPPORTED,
                 "acm_conv_agg_bwd_workspace_bytes: f_in %d f_out %d unsupported", f_in, f_out);
-    const size_t npg = ((size_t)3 * f_in * f_out + 12 * (size_t)f_out + 16 + 31) / 32 * 32;      // sized for 4 channels, whole groups of 32
+    // sized for 4 channels, whole groups of 32, + the following layer's weight gradient (acm_conv_agg_bwd_t.proj_*)
+    const size_t npg = ((size_t)3 * f_in * f_out + 12 * (size_t)f_out + 16 + 31) / 32 * 32 + (size_t)6 * f_out;
     *bytes = (size_t)agg_bwd_blocks(n_rows, 3, 0) * npg * sizeof(float);      // the larger of the two grids
     return ACM_OK;
 }
@@ -1216,7 +1099,7 @@ extern "C" int acm_conv_agg_bwd(int64_t n_rows, const acm_conv_agg_bwd_t* p, voi
     ACM_REQUIRE(p, ACM_EINVAL, "acm_conv_agg_bwd: NULL argument");
     int st = check_common(p, "acm_conv_agg_bwd");
     if (st != ACM_OK) return st;
-    ACM_REQUIRE(p->grad_out && p->agg && p->d_params, ACM_EINVAL, "acm_conv_agg_bwd: NULL tensor pointer");
+    ACM_REQUIRE((p->grad_out || p->proj_dz) && p->agg && p->d_params, ACM_EINVAL, "acm_conv_agg_bwd: NULL tensor pointer");
     ACM_REQUIRE(p->n_channels == 3 || (p->g_struc && p->ld_g_struc >= p->f_out), ACM_EINVAL,
                 "acm_conv_agg_bwd: g_struc is NULL / too narrow");
     {
@@ -1265,6 +1148,17 @@ extern "C" int acm_conv_agg_bwd(int64_t n_rows, const acm_conv_agg_bwd_t* p, voi
         ACM_REQUIRE(t->n_waves / gw <= agg_bwd_blocks(n_rows, 3, 0), ACM_EUNSUPPORTED,
                     "acm_conv_agg_bwd: %d stream waves for %lld rows (the workspace holds one slab per 16 rows)", t->n_waves, (long long)n_rows);
         nblk = t->n_waves / gw;
+        {   // eight-wave workgroups of the sixteen-rows-per-wave backward + the gather role (acm_conv_agg16.hip)
+            const int nb16 = acm_agg_bwd16(p, n_rows, partial, agg_bwd_blocks(n_rows, 3, 0), s, &gr, nblk);
+            if (nb16 < 0) return -nb16;
+            if (nb16 > 0) {
+                const int off2 = (npg + 31) / 32 * 32, n2 = p->proj_dz ? 3 * p->f_out * p->proj_f : 0;
+                const acm_reduce_seg_t segs[2] = {{partial, nb16, 32, 0, npg, p->d_params, npg, 0, 0, 0, nb16 * 32, 0},
+                                                  {partial, nb16, 32, off2, n2, p->proj_d_w, n2 > 0 ? n2 : 1, 0, 0, 0, nb16 * 32, 0}};
+                return acm_reduce_emit(p->defer, segs, n2 > 0 ? 2 : 1, s);
+            }
+            ACM_REQUIRE(!p->proj_dz, ACM_EUNSUPPORTED, "acm_conv_agg_bwd: proj_dz needs the sixteen-rows-per-wave kernel");
+        }
         // weights + head parameters + the groups' scratch + twelve per-wave slabs (dW accumulates there): 114 KB of the CU's 160
         const size_t lds_g = ((size_t)3 * 8 * 64 + 3 * K * 64 + 12 * 4 * 2 * 8 + (size_t)12 * (3 * 8 * 64 + 3 * K * 64 + 16)) * sizeof(float);
         ACM_REQUIRE(lds_g <= 160 * 1024, ACM_EUNSUPPORTED, "acm_conv_agg_bwd: %zu B of LDS needed", lds_g);
@@ -1275,13 +1169,17 @@ extern "C" int acm_conv_agg_bwd(int64_t n_rows, const acm_conv_agg_bwd_t* p, voi
         return acm_reduce_emit(p->defer, &seg, 1, s);
     }
     if (!p->next_agg) {                           // sixteen rows per wave, transposed matrix-core layout (acm_conv_agg16.hip)
-        const int nb16 = acm_agg_bwd16(p, n_rows, partial, nblk, s);
+        const int nb16 = acm_agg_bwd16(p, n_rows, partial, nblk, s, nullptr, 0);
         if (nb16 < 0) return -nb16;
         if (nb16 > 0) {
-            const acm_reduce_seg_t seg = {partial, nb16, 32, 0, npg, p->d_params, npg, 0, 0, 0, nb16 * 32, 0};
-            return acm_reduce_emit(p->defer, &seg, 1, s);
+            const int off2 = (npg + 31) / 32 * 32, n2 = p->proj_dz ? 3 * p->f_out * p->proj_f : 0;
+            const acm_reduce_seg_t segs[2] = {{partial, nb16, 32, 0, npg, p->d_params, npg, 0, 0, 0, nb16 * 32, 0},
+                                              {partial, nb16, 32, off2, n2, p->proj_d_w, n2 > 0 ? n2 : 1, 0, 0, 0, nb16 * 32, 0}};
+            return acm_reduce_emit(p->defer, segs, n2 > 0 ? 2 : 1, s);
         }
     }
+    ACM_REQUIRE(!p->proj_dz, ACM_EUNSUPPORTED, "acm_conv_agg_bwd: proj_dz needs the sixteen-rows-per-wave kernel (three channels, "
+                "f_pad 8, f_out 64, head_stats, `out`, proj_f <= 2); run acm_proj_bwd and pass grad_out");
 #define ACM_BWDK(FPv)                                                                                                  \
     do {                                                                                                              \
         if (K == 3 && p->f_out == 64)                                                                                  \

@@ -18,6 +18,7 @@
 // row is stored as four 16-byte pieces per lane.  The MFMA is an exact k-ordered fmaf chain, so the projections are
 // bit-identical to the older kernels'; the head statistics differ by summation order only.
 #include "acm_conv_device.h"
+#include "acm_stream_device.h"
 
 namespace {
 
@@ -271,7 +272,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
 #define ACM_B16_TS 68                  /* floats per tile row: 16-byte writes of eight consecutive row-lanes and the B-operand reads
                                           (rows 4 g + s: two row groups per LDS pass, 16 banks apart) are conflict-free */
 #define ACM_B16_PS 17                  /* floats per [P | x] row */
-#define ACM_B16_LDS (4 * 2121 + 64)    /* tiles | [P|x] rows | head parameters | weights; the end-of-kernel slabs alias it */
+#define ACM_B16_LDS (4 * (2144 + 384) + 64)    /* tiles | [P|x] rows | head parameters | weights; the end-of-kernel slabs alias it */
 
 // sum over the 16 lanes of a row for 16 values per lane, leaving value i's total in lane i (m = i): a reduce-scatter of four
 // DPP exchange steps (partner = 15 - m, 7 - m within the half, m ^ 2, m ^ 1; each lane keeps the half of the values its
@@ -289,8 +290,15 @@ __device__ __forceinline__ float row_reduce_scatter16(const float (&v)[16], int 
     return (b0 ? c[1] : c[0]) + acm_dpp<0xB1>(b0 ? c[0] : c[1]);                                            // quad_perm [1,0,3,2]
 }
 
-template <bool LN, bool OUT_MASK>
-__global__ __launch_bounds__(256) void agg_bwd16_kernel(acm_conv_agg_bwd_t p, int n_rows, float* __restrict__ partial) {
+// PROJ: the following layer's projection backward rides along (acm_conv_agg_bwd_t.proj_*): grad_out is formed per row from
+// proj_dz (6 floats) and the 64 x 6 weight table in LDS instead of being read (256 B per row), and proj_d_w = out^T proj_dz
+// is one more set of MFMAs over the `out` tile (which passes through the same LDS tile as the G_c do).
+// GATHER: a workgroup of EIGHT waves, one per SIMD for each role: waves 0-3 run this backward, waves 4-7 walk the operator's
+// id streams for the next training step's P = A_low dropout(x) (acm_conv_agg_bwd_t.next_agg; stream_gather_role).  The
+// kernel is compiled for two waves per SIMD either way, so the pair costs the backward no occupancy; its waves get the
+// vector and matrix pipes almost to themselves (the gather waves wait on memory), the gather waves the memory system.
+template <bool LN, bool OUT_MASK, bool PROJ, bool GATHER>
+__device__ __forceinline__ void bwd16_body(const acm_conv_agg_bwd_t& p, int n_rows, float* __restrict__ partial, const GatherRole* gr) {
     __shared__ __attribute__((aligned(16))) float lds[ACM_B16_LDS];
     const int lane = threadIdx.x & 63, m = lane & 15, g = lane >> 4, wv = threadIdx.x >> 6;
     float* gt = lds + wv * (16 * ACM_B16_TS);                 // this wave's G tile
@@ -298,11 +306,13 @@ __global__ __launch_bounds__(256) void agg_bwd16_kernel(acm_conv_agg_bwd_t p, in
     float* hl = lds + 4 * 16 * ACM_B16_TS + 4 * 16 * ACM_B16_PS + 16;   // [att_vec | gamma | beta][c][col]  (576 floats) + u_c (192); 16-byte aligned
     float* ul = hl + 576;
     float* wl = ul + 192;                                     // A operands of the projections, [(c, kb, t)][lane]
-    static_assert(ACM_B16_LDS >= 4 * 16 * ACM_B16_TS + 4 * 16 * ACM_B16_PS + 16 + 768 + 24 * 64, "tiles | [P|x] rows | head parameters | weights");
+    float* pw = wl + 24 * 64;                                 // PROJ: [col][8] = [W_L'(col, :) | W_H'(col, :) | W_I'(col, :) | 0]
+    static_assert(ACM_B16_LDS >= 4 * 16 * ACM_B16_TS + 4 * 16 * ACM_B16_PS + 16 + 768 + 24 * 64 + 512, "tiles | [P|x] rows | head parameters | weights");
+    static_assert(ACM_B16_LDS >= 4 * (2144 + 384), "the four end-of-kernel slabs (f_in = 8: 2121 -> 2144 entries, proj_f = 2) alias everything");
     const int f_in = p.f_in;
     // one round of independent global loads, one barrier: the head parameters, u = att_vec * gamma, the projections' A
     // operands W_c[f = 4 kb + g][col = 16 t + m] (the same for every wave), c1_c = mean_col(u_c)
-    for (int idx = threadIdx.x; idx < 576; idx += 256) {
+    for (int idx = threadIdx.x; idx < 576; idx += blockDim.x) {
         const int arr = idx / 192, c = (idx / 64) % 3, col = idx & 63;
         const float* av = c == 0 ? p.att_vec[0] : (c == 1 ? p.att_vec[1] : p.att_vec[2]);
         float v;
@@ -331,15 +341,29 @@ __global__ __launch_bounds__(256) void agg_bwd16_kernel(acm_conv_agg_bwd_t p, in
         if (LN) u *= p.ln_weight[c][lane];
         c1[c] = acm_group_sum<64>(u) * (1.0f / 64.0f);
     }
-    for (int idx = threadIdx.x; idx < 24 * 64; idx += 256) {
+    for (int idx = threadIdx.x; idx < 24 * 64; idx += blockDim.x) {
         const int e = idx >> 6, l2 = idx & 63, c = e >> 3, kb = (e >> 2) & 1, t = e & 3, f = 4 * kb + (l2 >> 4);
         const float* w = c == 0 ? p.w_low : (c == 1 ? p.w_high : p.w_mlp);
         wl[idx] = f < f_in ? w[(long)f * p.ld_w + 16 * t + (l2 & 15)] : 0.f;
+    }
+    const int nq = PROJ ? 3 * p.proj_f : 0;                   // columns of proj_dz
+    if (PROJ) {
+        for (int idx = threadIdx.x; idx < 512; idx += blockDim.x) {
+            const int col = idx >> 3, j = idx & 7, c = j / p.proj_f, q = j % p.proj_f;
+            const float* w = c == 0 ? p.proj_w_low : (c == 1 ? p.proj_w_high : p.proj_w_mlp);
+            pw[idx] = (c < 3) ? w[(long)col * p.proj_ld_w + q] : 0.f;
+        }
     }
     float mixm[9];
 #pragma unroll
     for (int q = 0; q < 9; ++q) mixm[q] = p.att_mix[q];
     __syncthreads();
+    if (GATHER && wv >= 4) {                      // the gather role; then the same two barriers as the backward's end phase
+        if (gr->roles & 2) stream_gather_role(*gr, __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (wv - 4)));
+        __syncthreads();
+        __syncthreads();
+        return;
+    }
     const float lo_a = p.relu_after ? 0.f : -INFINITY, lo_m = p.relu_mlp ? 0.f : -INFINITY;
     constexpr bool out_mask = OUT_MASK;
     const float post_gain = p.post_drop.p > 0.f ? 1.0f / (1.0f - p.post_drop.p) : 1.f;
@@ -349,7 +373,10 @@ __global__ __launch_bounds__(256) void agg_bwd16_kernel(acm_conv_agg_bwd_t p, in
     const float wq = g == 0 ? 1.f : 0.f;            // a row's scalars sit in four lanes: one of them accumulates
     const float fsel = m < 8 ? 1.f : 0.f;           // A operand of the dW products: feature f = m (< f_pad)
 
-    f32x4 acc[3][4];
+    f32x4 acc[3][4], acc2[4];            // acc2 (PROJ): proj_d_w^T tiles, D[i = j of proj_dz][col]
+#pragma unroll
+    for (int t = 0; t < 4; ++t) acc2[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const unsigned ld_pz = (unsigned)p.ld_proj_dz;
     float pA[3], pS[3], dmix[9];         // pA[c]: lane (g, m) accumulates column 16 (m >> 2) + 4 g + (m & 3) of A_c
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
@@ -360,33 +387,41 @@ __global__ __launch_bounds__(256) void agg_bwd16_kernel(acm_conv_agg_bwd_t p, in
 #pragma unroll
     for (int q = 0; q < 9; ++q) dmix[q] = 0.f;
 
-    int base = wave * 16;
+    int base = (GATHER && !(gr->roles & 1)) ? n_rows : wave * 16;
     float nPa = 0.f, nPb = 0.f, nxa = 0.f, nxb = 0.f;
     f32x4 ngo[4], nou[4], nst[3];
-    // the small operands (P, x, head statistics: 112 B per row) are requested one step ahead; grad_out and out (512 B per row)
-    // at the top of their own step, ahead of the projections
+    // the operands of the projections (P, x: 64 B per row) are requested one step ahead; grad_out / out (512 B per row), the
+    // head statistics and proj_dz at the top of their own step -- the projections' MFMAs run while they arrive
 #define ACM_B16_LOAD(BASE)                                                                              \
     do {                                                                                                \
         const unsigned r2 = (unsigned)min((BASE) + m, n_rows - 1);                                      \
         nPa = p.agg[r2 * ld_agg + g], nPb = p.agg[r2 * ld_agg + 4 + g];                                 \
         nxa = p.xs[r2 * ld_xs + g], nxb = p.xs[r2 * ld_xs + 4 + g];                                     \
-        _Pragma("unroll") for (int q = 0; q < 3; ++q)                                                   \
-            nst[q] = *reinterpret_cast<const f32x4*>(p.head_stats + r2 * ld_hs + 4 * q);                \
     } while (0)
     if (base < n_rows) ACM_B16_LOAD(base);
     for (; base < n_rows; base += nwaves * 16) {
         const bool valid = base + m < n_rows;
         const float Pa = nPa, Pb = nPb, xa = nxa, xb = nxb;
+        float dzr[6], dza[4];            // PROJ: proj_dz of row m; of rows 4 g + s at column m (the A operand of proj_d_w)
         {
             const unsigned r1 = (unsigned)min(base + m, n_rows - 1);
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
-                ngo[t] = *reinterpret_cast<const f32x4*>(p.grad_out + r1 * ld_go + 16 * t + 4 * g);
-                if (out_mask) nou[t] = *reinterpret_cast<const f32x4*>(p.out + r1 * ld_out + 16 * t + 4 * g);
+                if (!PROJ) ngo[t] = *reinterpret_cast<const f32x4*>(p.grad_out + r1 * ld_go + 16 * t + 4 * g);
+                if (out_mask || PROJ) nou[t] = *reinterpret_cast<const f32x4*>(p.out + r1 * ld_out + 16 * t + 4 * g);
+            }
+#pragma unroll
+            for (int q = 0; q < 3; ++q) nst[q] = *reinterpret_cast<const f32x4*>(p.head_stats + r1 * ld_hs + 4 * q);
+            if (PROJ) {
+#pragma unroll
+                for (int j = 0; j < 6; ++j) dzr[j] = (j < nq && valid) ? p.proj_dz[r1 * ld_pz + j] : 0.f;
+#pragma unroll
+                for (int s = 0; s < 4; ++s) {
+                    const int rs = base + 4 * g + s;
+                    dza[s] = (m < nq && rs < n_rows) ? p.proj_dz[(unsigned)min(rs, n_rows - 1) * ld_pz + min(m, 5)] : 0.f;
+                }
             }
         }
-        const float mean[3] = {nst[0][0], nst[0][1], nst[0][2]}, rstd[3] = {nst[0][3], nst[1][0], nst[1][1]};
-        const float gsig[3] = {nst[1][2], nst[1][3], nst[2][0]}, al[3] = {nst[2][1], nst[2][2], nst[2][3]};
         ACM_B16_LOAD(base + nwaves * 16);           // the next step's operands (the addresses are clamped)
         const int gq = acm_opaque(g), mq = acm_opaque(m);
         px[mq * ACM_B16_PS + gq] = Pa, px[mq * ACM_B16_PS + 4 + gq] = Pb, px[mq * ACM_B16_PS + 8 + gq] = xa, px[mq * ACM_B16_PS + 12 + gq] = xb;
@@ -403,22 +438,38 @@ __global__ __launch_bounds__(256) void agg_bwd16_kernel(acm_conv_agg_bwd_t p, in
 #pragma unroll
             for (int t = 0; t < 4; ++t)
                 D[c][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(wl[((c * 2 + 1) * 4 + t) * 64 + lq], opb[c], D[c][t], 0, 0, 0);
-        // A operands of the dW products: MFMA step s contracts rows 4 g + s of this wave step, feature m
-        float aP[4], aX[4];
-#pragma unroll
-        for (int s = 0; s < 4; ++s) {
-            aP[s] = px[(4 * gq + s) * ACM_B16_PS + (mq & 7)] * fsel;
-            aX[s] = px[(4 * gq + s) * ACM_B16_PS + 8 + (mq & 7)] * fsel;
-        }
         f32x4 dO[4];
-        {
-            const float gate = valid ? post_gain : 0.f;
+        const float gate = valid ? post_gain : 0.f;
+        if (PROJ) {
+            // the following layer's weight gradient: out^T proj_dz, the `out` tile through LDS like the G_c below; then this
+            // layer's output gradient row by row, proj_dz[row] [W_L' | W_H' | W_I']^T, masked by the post-op right away
+#pragma unroll
+            for (int t = 0; t < 4; ++t) *reinterpret_cast<f32x4*>(gt + mq * ACM_B16_TS + 16 * t + 4 * gq) = nou[t];
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+                    acc2[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(dza[s], gt[(4 * gq + s) * ACM_B16_TS + 16 * t + mq], acc2[t], 0, 0, 0);
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float4 wa = *reinterpret_cast<const float4*>(pw + (16 * t + 4 * gq + r) * 8);
+                    const float2 wb = *reinterpret_cast<const float2*>(pw + (16 * t + 4 * gq + r) * 8 + 4);
+                    float v = dzr[0] * wa.x;
+                    v = fmaf(dzr[1], wa.y, v), v = fmaf(dzr[2], wa.z, v), v = fmaf(dzr[3], wa.w, v);
+                    v = fmaf(dzr[4], wb.x, v), v = fmaf(dzr[5], wb.y, v);
+                    dO[t][r] = out_mask ? ((nou[t][r] != 0.f) ? v * gate : 0.f) : v;        // (dzr is zero on padding rows)
+                }
+        } else {
 #pragma unroll
             for (int t = 0; t < 4; ++t)
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
                     dO[t][r] = out_mask ? ((nou[t][r] != 0.f) ? ngo[t][r] * gate : 0.f) : (valid ? ngo[t][r] : 0.f);
         }
+        const float mean[3] = {nst[0][0], nst[0][1], nst[0][2]}, rstd[3] = {nst[0][3], nst[1][0], nst[1][1]};
+        const float gsig[3] = {nst[1][2], nst[1][3], nst[2][0]}, al[3] = {nst[2][1], nst[2][2], nst[2][3]};
         // ---- mix / softmax / sigmoid backward: ds_c = dL/ds_c per row
         float dal[3], ds[3];
 #pragma unroll
@@ -456,50 +507,43 @@ __global__ __launch_bounds__(256) void agg_bwd16_kernel(acm_conv_agg_bwd_t p, in
         for (int c = 0; c < 3; ++c) {
             const float lo = c < 2 ? lo_a : lo_m;
             const float aal = p.scale * al[c];
-            f32x4 G[4];
-            if (LN) {
-                float t2 = 0.f, contrib[16];
-                f32x4 xh[4];
+            // two passes over the lane's 16 columns, four at a time, so that neither xhat nor G is held as a whole: (A) the
+            // row sums (contrib -> the reduce-scatter; t2 = sum_col u xhat), (B) xhat again, G, straight into the LDS tile
+            float contrib[16], t2 = 0.f;
 #pragma unroll
-                for (int t = 0; t < 4; ++t) {
-                    const f32x4 u = *reinterpret_cast<const f32x4*>(ul + c * 64 + 16 * t + 4 * gq);
+            for (int t = 0; t < 4; ++t) {
+                const f32x4 u = *reinterpret_cast<const f32x4*>(ul + c * 64 + 16 * t + 4 * gq);
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        xh[t][r] = (D[c][t][r] - mean[c]) * rstd[c];
-                        contrib[4 * t + r] = ds[c] * xh[t][r];
-                        t2 = fmaf(u[r], xh[t][r], t2);
-                    }
+                for (int r = 0; r < 4; ++r) {
+                    const float xh = LN ? (D[c][t][r] - mean[c]) * rstd[c] : D[c][t][r];
+                    contrib[4 * t + r] = ds[c] * xh;
+                    if (LN) t2 = fmaf(u[r], xh, t2);
                 }
-                pA[c] += row_reduce_scatter16(contrib, mq);
-                const float m1 = ds[c] * c1[c], m2 = ds[c] * row4_sum(t2) * (1.0f / 64.0f);
+            }
+            pA[c] += row_reduce_scatter16(contrib, mq);
+            const float m1 = LN ? ds[c] * c1[c] : 0.f, m2 = LN ? ds[c] * row4_sum(t2) * (1.0f / 64.0f) : 0.f;
 #pragma unroll
-                for (int t = 0; t < 4; ++t) {
-                    const f32x4 u = *reinterpret_cast<const f32x4*>(ul + c * 64 + 16 * t + 4 * gq);
+            for (int t = 0; t < 4; ++t) {
+                const f32x4 u = *reinterpret_cast<const f32x4*>(ul + c * 64 + 16 * t + 4 * gq);
+                f32x4 G;
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const float v = fmaf(aal, dO[t][r], rstd[c] * (fmaf(ds[c], u[r], -m1) - xh[t][r] * m2));
-                        G[t][r] = D[c][t][r] > lo ? v : 0.f;
+                for (int r = 0; r < 4; ++r) {
+                    float v;
+                    if (LN) {
+                        const float xh = (D[c][t][r] - mean[c]) * rstd[c];
+                        v = fmaf(aal, dO[t][r], rstd[c] * (fmaf(ds[c], u[r], -m1) - xh * m2));
+                    } else {
+                        v = fmaf(aal, dO[t][r], ds[c] * u[r]);
                     }
+                    G[r] = D[c][t][r] > lo ? v : 0.f;
                 }
-            } else {
-                float contrib[16];
-#pragma unroll
-                for (int t = 0; t < 4; ++t) {
-                    const f32x4 u = *reinterpret_cast<const f32x4*>(ul + c * 64 + 16 * t + 4 * gq);
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        contrib[4 * t + r] = ds[c] * D[c][t][r];
-                        const float v = fmaf(aal, dO[t][r], ds[c] * u[r]);
-                        G[t][r] = D[c][t][r] > lo ? v : 0.f;
-                    }
-                }
-                pA[c] += row_reduce_scatter16(contrib, mq);
+                *reinterpret_cast<f32x4*>(gt + mq * ACM_B16_TS + 16 * t + 4 * gq) = G;
             }
 #pragma unroll
-            for (int t = 0; t < 4; ++t) *reinterpret_cast<f32x4*>(gt + mq * ACM_B16_TS + 16 * t + 4 * gq) = G[t];
-#pragma unroll
             for (int s = 0; s < 4; ++s) {
-                const float aop = c == 0 ? aP[s] : (c == 1 ? aX[s] - aP[s] : aX[s]);
+                // A operand: feature m of row 4 g + s of this wave step (P | x rows parked in LDS at the top of the step)
+                const float ap = px[(4 * gq + s) * ACM_B16_PS + (mq & 7)], ax = px[(4 * gq + s) * ACM_B16_PS + 8 + (mq & 7)];
+                const float aop = fsel * (c == 0 ? ap : (c == 1 ? ax - ap : ax));
 #pragma unroll
                 for (int t = 0; t < 4; ++t)
                     acc[c][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(aop, gt[(4 * gq + s) * ACM_B16_TS + 16 * t + mq], acc[c][t], 0, 0, 0);
@@ -508,7 +552,9 @@ __global__ __launch_bounds__(256) void agg_bwd16_kernel(acm_conv_agg_bwd_t p, in
     }
 #undef ACM_B16_LOAD
     // ---- end of the row loop: head-parameter sums over the 16 row-lanes, then the block's partial slab
-    const int npg = 3 * f_in * 64 + 9 * 64 + 9;
+    const int npg0 = 3 * f_in * 64 + 9 * 64 + 9;
+    const int off2 = (npg0 + 31) & ~31;              // PROJ: proj_d_w behind d_params at a whole group of 32 (the second phase
+    const int npg = PROJ ? off2 + 64 * nq : npg0;    // sums it by lines), [c][col][q] = flat index (j / f') 64 f' + col f' + j % f'
     // value i = 4 t + r of lane (g, m = i) is column 16 t + 4 g + r: one column of A_c per lane
     const int mycol = 16 * (m >> 2) + 4 * g + (m & 3);
     float dv[3], dgam[3], dbet[3];
@@ -548,11 +594,31 @@ __global__ __launch_bounds__(256) void agg_bwd16_kernel(acm_conv_agg_bwd_t p, in
         for (int q = 1; q < 9; ++q) v = lane == q ? dmix[q] : v;
         slab[3 * f_in * 64 + 9 * 64 + lane] = v;
     }
+    if (PROJ) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int j = 4 * g + r, col = 16 * t + m;
+                if (j < nq) slab[off2 + (j / p.proj_f) * 64 * p.proj_f + col * p.proj_f + j % p.proj_f] = acc2[t][r];
+            }
+    }
     __syncthreads();
-    for (int q = threadIdx.x; q < npg; q += 256) {
-        const float v = (lds[q] + lds[npg + q]) + (lds[2 * npg + q] + lds[3 * npg + q]);
+    for (int q = threadIdx.x; q < npg; q += 256) {                    // (the four backward waves)
+        float v = (lds[q] + lds[npg + q]) + (lds[2 * npg + q] + lds[3 * npg + q]);
+        if (PROJ && q >= npg0 && q < off2) v = 0.f;                    // the gap up to the group boundary
         partial[((long)(q >> 5) * gridDim.x + blockIdx.x) * 32 + (q & 31)] = v;
     }
+}
+
+template <bool LN, bool OUT_MASK, bool PROJ>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void agg_bwd16_kernel(acm_conv_agg_bwd_t p, int n_rows, float* __restrict__ partial) {
+    bwd16_body<LN, OUT_MASK, PROJ, false>(p, n_rows, partial, nullptr);
+}
+template <bool LN, bool OUT_MASK, bool PROJ>
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void agg_bwd16_gather_kernel(acm_conv_agg_bwd_t p, int n_rows, float* __restrict__ partial,
+                                                                                                   GatherRole gr) {
+    bwd16_body<LN, OUT_MASK, PROJ, true>(p, n_rows, partial, &gr);
 }
 
 }  // namespace
@@ -596,17 +662,23 @@ int acm_agg_epi16(const acm_conv_agg_fwd_t* p, int64_t n_rows, bool* next_done, 
 }
 
 // The row-local backward over the forward's head_stats.  Returns the number of blocks launched (> 0), 0 when the
-// configuration is not this kernel's (the caller runs agg_bwd_kernel), or a negative acm_status_t.
-int acm_agg_bwd16(const acm_conv_agg_bwd_t* p, int64_t n_rows, float* partial, int max_blocks, hipStream_t s) {
+// configuration is not this kernel's (the caller runs agg_bwd_kernel), or a negative acm_status_t.  The partial slab has
+// npg + 64 * 3 * proj_f entries per block (acm_conv_agg_bwd_t.proj_*: the following layer's weight gradient behind d_params).
+int acm_agg_bwd16(const acm_conv_agg_bwd_t* p, int64_t n_rows, float* partial, int max_blocks, hipStream_t s, const GatherRole* gr,
+                  int gather_blocks) {
     if (p->n_channels != 3 || p->f_pad != 8 || p->f_out != 64 || !p->head_stats || getenv("ACM_BWD16_OFF") != nullptr) return 0;
     const bool out_mask = p->out != nullptr && p->post_relu && !p->post_scale;
     const bool no_post = !p->post_relu && !p->post_scale && !(p->post_drop.p > 0.f);
     if (!out_mask && !no_post) return 0;
-    for (const void* q : {(const void*)p->grad_out, (const void*)p->out, (const void*)p->head_stats})
+    const bool proj = p->proj_dz != nullptr;
+    if (proj && (!p->out || p->proj_f < 1 || p->proj_f > 2 || !p->proj_w_low || !p->proj_w_high || !p->proj_w_mlp || !p->proj_d_w ||
+                 p->ld_proj_dz < 3 * p->proj_f || p->proj_ld_w < p->proj_f || n_rows * p->ld_proj_dz >= (int64_t)INT32_MAX))
+        return 0;
+    for (const void* q : {(const void*)(proj ? nullptr : p->grad_out), (const void*)p->out, (const void*)p->head_stats})
         if (((uintptr_t)q) % 16 != 0) return 0;
-    if (p->ld_grad_out % 4 != 0 || (out_mask && p->ld_out % 4 != 0) || p->ld_head_stats % 4 != 0) return 0;
+    if ((!proj && p->ld_grad_out % 4 != 0) || ((out_mask || proj) && p->ld_out % 4 != 0) || p->ld_head_stats % 4 != 0) return 0;
     acm_conv_agg_bwd_t q = *p;
-    if (!out_mask) q.out = nullptr;
+    if (!out_mask && !proj) q.out = nullptr;
     int grid = (int)((n_rows + 63) / 64);
     int cap = 512;
     if (const char* env = getenv("ACM_BWD16_BLOCKS")) {
@@ -615,13 +687,23 @@ int acm_agg_bwd16(const acm_conv_agg_bwd_t* p, int64_t n_rows, float* partial, i
     }
     if (cap > max_blocks) cap = max_blocks;
     if (grid > cap) grid = cap;
-    if (p->layernorm) {
-        if (out_mask) hipLaunchKernelGGL((agg_bwd16_kernel<true, true>), dim3(grid), dim3(256), 0, s, q, (int)n_rows, partial);
-        else hipLaunchKernelGGL((agg_bwd16_kernel<true, false>), dim3(grid), dim3(256), 0, s, q, (int)n_rows, partial);
-    } else {
-        if (out_mask) hipLaunchKernelGGL((agg_bwd16_kernel<false, true>), dim3(grid), dim3(256), 0, s, q, (int)n_rows, partial);
-        else hipLaunchKernelGGL((agg_bwd16_kernel<false, false>), dim3(grid), dim3(256), 0, s, q, (int)n_rows, partial);
+    if (gr) {                                         // one workgroup of eight waves per four stream waves
+        if (gather_blocks < 1 || gather_blocks > max_blocks) return 0;
+        grid = gather_blocks;
     }
+#define ACM_B16(LNv, OMv, PJv)                                                                                                      \
+    do {                                                                                                                            \
+        if (gr) hipLaunchKernelGGL((agg_bwd16_gather_kernel<LNv, OMv, PJv>), dim3(grid), dim3(512), 0, s, q, (int)n_rows, partial, *gr); \
+        else hipLaunchKernelGGL((agg_bwd16_kernel<LNv, OMv, PJv>), dim3(grid), dim3(256), 0, s, q, (int)n_rows, partial);            \
+    } while (0)
+    if (proj) {                                       // (the `out` tile is read either way: the mask flag only gates its use)
+        if (p->layernorm) { if (out_mask) ACM_B16(true, true, true); else ACM_B16(true, false, true); }
+        else { if (out_mask) ACM_B16(false, true, true); else ACM_B16(false, false, true); }
+    } else {
+        if (p->layernorm) { if (out_mask) ACM_B16(true, true, false); else ACM_B16(true, false, false); }
+        else { if (out_mask) ACM_B16(false, true, false); else ACM_B16(false, false, false); }
+    }
+#undef ACM_B16
     if (hipGetLastError() != hipSuccess) return -ACM_EHIP;
     return grid;
 }

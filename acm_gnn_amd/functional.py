@@ -24,6 +24,7 @@ class KernelTimer:
 
     def __init__(self, only=None):
         self.only, self.events = only, {}
+        self.bytes = {}                 # label -> bytes this rank SENT into collectives under that label
 
     def wants(self, label):
         return self.only is None or label.startswith(self.only)
@@ -43,9 +44,11 @@ def set_kernel_timer(timer):
 
 
 class _Timed:
-    def __init__(self, label):
+    def __init__(self, label, nbytes=0):
         self.label = label
         self.on = _TIMER is not None and _TIMER.wants(label)
+        if self.on and nbytes:
+            _TIMER.bytes[label] = _TIMER.bytes.get(label, 0) + int(nbytes)
 
     def __enter__(self):
         if self.on:
@@ -123,13 +126,14 @@ class DeferredReductions:
             group = pending[0][1]
             coalesce = (len(pending) > 1 and all(g is group for _, g in pending) and hasattr(dist, "_coalescing_manager")
                         and dist.get_backend(group) == "nccl")
-            if coalesce:
-                with dist._coalescing_manager(group=group, device=pending[0][0].device, async_ops=False):
-                    for t, _ in pending:
-                        dist.all_reduce(t, group=group)
-            else:
-                for t, g in pending:
-                    dist.all_reduce(t, group=g)
+            with _Timed("all_reduce/gradients", sum(t.numel() * t.element_size() for t, _ in pending)):
+                if coalesce:
+                    with dist._coalescing_manager(group=group, device=pending[0][0].device, async_ops=False):
+                        for t, _ in pending:
+                            dist.all_reduce(t, group=group)
+                else:
+                    for t, g in pending:
+                        dist.all_reduce(t, group=g)
         self._keep.clear()
 
     def discard(self):
@@ -145,17 +149,22 @@ class CallContext:
     * ``tail``      a pending fused_loss_tail request for the model's output layer
     * ``pipe``      the training loop's InputPipeline
     * ``next_proj`` / ``pre_proj``  the narrow-projection hand-off between a hidden layer and the layer that follows it
+    * ``hidden_private``  the hidden activation tensor only the following layer consumes (backward-side hand-off)
 
     A context belongs to ONE model call: models.GCN / layers.GraphConvolution take it as ``call=`` (train.TrainStep passes
     its own) or derive a fresh one from the thread's ambient context -- what ``with deferred_reductions()`` /
     ``with fused_loss_tail()`` blocks of the calling thread have set.  Nothing lives in module globals: two models, two
     threads or an exception between two layers cannot see each other's hand-offs, and a backward (which autograd may run on
     another thread) uses the context its forward captured."""
-    __slots__ = ("defer", "tail", "pipe", "next_proj", "pre_proj")
+    __slots__ = ("defer", "tail", "pipe", "next_proj", "pre_proj", "hidden_private")
 
     def __init__(self, defer=None, tail=None, pipe=None):
         self.defer, self.tail, self.pipe = defer, tail, pipe
         self.next_proj = self.pre_proj = None
+        # set by a model around the call of a layer whose input tensor is the previous layer's output and is used NOWHERE
+        # else (models.GCN: the hidden activations of the two-layer models): that layer's backward may then leave its input
+        # gradient to the previous layer's backward kernel (acm_conv_agg_bwd_t.proj_*) instead of materialising it
+        self.hidden_private = None
 
     @classmethod
     def from_ambient(cls):
@@ -505,7 +514,7 @@ def proj_fwd(x, weights, out_lh, out_i, relu=False, h_col=None):
     _lib.check(st, "acm_proj_fwd_at")
 
 
-def proj_bwd(x, dz, weights, d_w_out, defer=None):
+def proj_bwd(x, dz, weights, d_w_out, defer=None, dx_out=None):
     """Backward of the skinny projection Z = x @ [W_L | W_H | W_I] in one pass over x (acm_proj_bwd): returns
     dX = dz @ Wcat.T and fills ``d_w_out`` ([3, f_in, F], contiguous) with x.T @ dz.  ``weights``: the three
     [f_in, F] matrices.  ``defer``: a DeferredReductions the second phase is appended to (default: the thread's)."""
@@ -521,7 +530,7 @@ def proj_bwd(x, dz, weights, d_w_out, defer=None):
             or any(tuple(w.shape) != (f_in, q // 3) or w.stride(0) != ws3[0].stride(0) for w in ws3)):
         raise ValueError("proj_bwd: shape mismatch")
     lib = _lib.load()
-    dx = torch.empty(n, f_in, dtype=_F32, device=x.device)
+    dx = torch.empty(n, f_in, dtype=_F32, device=x.device) if dx_out is None else dx_out[:, :f_in]
     nbytes = C.c_size_t()
     _lib.check(lib.acm_proj_bwd_workspace_bytes(n, f_in, q, C.byref(nbytes)), "acm_proj_bwd_workspace_bytes")
     ws = torch.empty(max(nbytes.value // 4, 1), dtype=_F32, device=x.device)
@@ -895,7 +904,8 @@ def _gather_rows(ops, local):
         buf[: local.shape[0]] = local
         local = buf
     full = torch.empty(world * n_max, local.shape[1], dtype=local.dtype, device=local.device)
-    dist.all_gather_into_tensor(full, local, group=ops.group)
+    with _Timed(f"all_gather/{n_max}x{local.shape[1]}", local.numel() * local.element_size()):
+        dist.all_gather_into_tensor(full, local, group=ops.group)
     return full
 
 
@@ -1367,6 +1377,15 @@ class AcmConvFunction(torch.autograd.Function):
             _lib.check(st, "acm_conv_fwd")
         ctx.ops, ctx.cfg = ops, cfg
         ctx.sparse_x = x if sparse_x else None
+        # Lazy input gradient: when the input IS the output tensor of an aggregate-first layer of the same model call and
+        # the model vouches that nothing else consumes it (call.hidden_private), this layer's backward may hand
+        # dX = dZ Wcat^T and dW = X^T dZ to that layer's backward kernel (acm_conv_agg_bwd_t.proj_*) instead of running
+        # acm_proj_bwd: the [n, F] gradient then never exists in memory.
+        ctx.lazy_producer = None
+        prod = getattr(x, "grad_fn", None) if not sparse_x else None
+        if (call.hidden_private is x and prod is not None and getattr(prod, "agg_first", False) and getattr(prod, "call", None) is call
+                and not zero_padded and not ops.sharded and hops == 1 and os.environ.get("ACM_LAZY_DX", "1") != "0"):
+            ctx.lazy_producer = prod
         ctx.save_for_backward(w3[0] if sparse_x else x, *w3, zlh, zi, pre, mix, *vecs, *lnw, *lnb)
         ctx.mark_non_differentiable(att)
         return out, att
@@ -1473,7 +1492,14 @@ class AcmConvFunction(torch.autograd.Function):
         elif (ctx.needs_input_grad[0] and proj_bwd_supported(3 * f) and os.environ.get("ACM_PROJ_BWD", "1") != "0"
               and wl_.stride(0) == wh_.stride(0) == wm_.stride(0)):
             d_wcat = flat[:nw].view(3, f_in_w, f)                             # narrow output layer: dX and dW in one
-            d_x = proj_bwd(x, dz, w3, d_wcat, defer=defer)                    # pass over x (acm_proj_bwd)
+            prod = getattr(ctx, "lazy_producer", None)
+            if (prod is not None and f <= 2 and f_in_w == 64 and x.shape[1] == 64 and getattr(prod, "lazy", None) is None
+                    and all(w.stride(0) == f and w.is_contiguous() for w in w3)):
+                # ... left to the producing layer's backward kernel: the placeholder is what autograd carries there
+                d_x = torch.empty(n, x.shape[1], dtype=_F32, device=dev)
+                prod.lazy = dict(dz=dz, w3=w3, d_w=d_wcat, x=x, placeholder=d_x)
+            else:
+                d_x = proj_bwd(x, dz, w3, d_wcat, defer=defer)                # pass over x (acm_proj_bwd)
         else:
             d_wcat = gemm(x, dz, trans_a=True, col_blocks=3,
                           out=flat[:nw].view(3, f_in_w, f))                   # contiguous per weight
@@ -1518,6 +1544,15 @@ def _backward_agg(ctx, grad_out):
     lnb = list(saved[6 + k + nln:6 + k + 2 * nln])
     dev = xpad.device
     n, f, fp = xpad.shape[0], wl.shape[1], xpad.shape[1]
+    lazy, ctx.lazy = getattr(ctx, "lazy", None), None
+    if lazy is not None and (grad_out is not lazy["placeholder"] and grad_out.data_ptr() != lazy["placeholder"].data_ptr()):
+        raise RuntimeError("acm_conv: the hidden activation marked private (CallContext.hidden_private) received a gradient "
+                           "from somewhere else as well")
+    fuse_proj = (lazy is not None and k == 3 and fp == 8 and f == 64 and out_fwd is not None and ctx.post_scale is None
+                 and getattr(ctx, "head_stats", None) is not None)
+    if lazy is not None and not fuse_proj:            # the kernel cannot take it: materialise dX and dW' now
+        proj_bwd(lazy["x"], lazy["dz"], lazy["w3"], lazy["d_w"], defer=ctx.call.defer, dx_out=lazy["placeholder"])
+        lazy = None
     grad_out = _as_f32c(grad_out, "grad_out")
     npg = 3 * f_in * f + 3 * k * f + k * k
     d_params = torch.empty(npg, dtype=_F32, device=dev)
@@ -1525,6 +1560,13 @@ def _backward_agg(ctx, grad_out):
     q.f_in, q.f_pad, q.f_out = f_in, fp, f
     q.relu_after, q.relu_mlp, q.layernorm, q.scale = int(cfg.relu_after), int(cfg.relu_mlp), int(cfg.layernorm), cfg.scale
     q.grad_out, q.ld_grad_out = grad_out.data_ptr(), grad_out.stride(0)
+    if lazy is not None:                              # the following layer's projection backward rides this launch
+        dz2, w32 = lazy["dz"], lazy["w3"]
+        q.grad_out = None
+        q.proj_dz, q.ld_proj_dz = dz2.data_ptr(), dz2.stride(0)
+        q.proj_w_low, q.proj_w_high, q.proj_w_mlp = (w.data_ptr() for w in w32)
+        q.proj_ld_w, q.proj_f = w32[0].stride(0), w32[0].shape[1]
+        q.proj_d_w = lazy["d_w"].data_ptr()
     q.agg, q.ld_agg = agg.data_ptr(), agg.stride(0)
     if getattr(ctx, "head_stats", None) is not None:
         q.head_stats, q.ld_head_stats = ctx.head_stats.data_ptr(), ctx.head_stats.stride(0)
@@ -1562,13 +1604,19 @@ def _backward_agg(ctx, grad_out):
         q.next_xg, q.ld_next_xg = pipe.filled[0].data_ptr(), pipe.filled[0].stride(0)
         q.next_row_scale = ops.row_scale.data_ptr()
         q.next_agg, q.ld_next_agg = pipe.filled[1].data_ptr(), pipe.filled[1].stride(0)
-    with _device_ctx(dev), _Timed(f"conv_agg_bwd{'+gather' if carry else ''}/F{f}k{k}i{f_in}"):
+    with _device_ctx(dev), _Timed(f"conv_agg_bwd{'+gather' if carry else ''}{'+proj' if lazy is not None else ''}/F{f}k{k}i{f_in}"):
         st = lib.acm_conv_agg_bwd(n, C.byref(q), _vp(ws), ws.numel() * 4, _stream())
+    if st == 4 and lazy is not None:                  # ACM_EUNSUPPORTED for this shape after all: the two launches
+        proj_bwd(lazy["x"], lazy["dz"], lazy["w3"], lazy["d_w"], defer=defer, dx_out=lazy["placeholder"])
+        q.grad_out, q.proj_dz, lazy = grad_out.data_ptr(), None, None
+        with _device_ctx(dev), _Timed(f"conv_agg_bwd/F{f}k{k}i{f_in}"):
+            st = lib.acm_conv_agg_bwd(n, C.byref(q), _vp(ws), ws.numel() * 4, _stream())
     _lib.check(st, "acm_conv_agg_bwd")
     if carry:
         pipe.next_agg_ready = True
     if defer is not None:
-        defer.hold(ws, [d_params])
+        defer.hold(ws, [d_params] + ([lazy["d_w"]] if lazy is not None else []),
+                   keep=[d_params] + ([lazy["d_w"]._base if lazy["d_w"]._base is not None else lazy["d_w"]] if lazy is not None else []))
     d_struc = None
     if four:                                  # dS = A_low^T (D G_S) - G_S   (pattern-only: P G_S - G_S)
         gsg = _gather_rows(ops, gs)

@@ -137,7 +137,12 @@ class GCN(nn.Module):
         call.next_proj = None
         if self.model_type == "acmgcnpp":
             fea = fea + xx
-        return self.gcns[1](fea, adj_low, adj_high, adj_low_unnormalized, rows_permuted=self._rows_permuted, call=call)
+        else:
+            call.hidden_private = fea          # consumed by the output layer only: its gradient may stay implicit
+        try:
+            return self.gcns[1](fea, adj_low, adj_high, adj_low_unnormalized, rows_permuted=self._rows_permuted, call=call)
+        finally:
+            call.hidden_private = None
 
     def _forward_snowball(self, x, adj_low, adj_high, fused, call):
         """models.py:57-64: h_k = dropout(relu(layer_k([x | h_0 | ... | h_{k-1}]))), out = layer_last([x | h_0 | ...]).
@@ -213,4 +218,9 @@ class GCN(nn.Module):
         call.next_proj = None
         if self.model_type == "acmgcnpp":
             fea = fea + xx
-        return self.gcns[1](fea, adj_low, adj_high, adj_low_unnormalized, rows_permuted=self._rows_permuted, call=call)
+        else:
+            call.hidden_private = fea          # see _forward_fused_dropout
+        try:
+            return self.gcns[1](fea, adj_low, adj_high, adj_low_unnormalized, rows_permuted=self._rows_permuted, call=call)
+        finally:
+            call.hidden_private = None

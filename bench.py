@@ -82,7 +82,9 @@ def algorithmic_bytes(label, n, nnz, implicit=False):
         if kind == "conv_agg_epi":      # the row-local stage alone (P given): agg + self X + out + att + head_stats
             return 4 * n * fp * 2 + 4 * n * f + 16 * n + stats
         bwd = 4 * n * (f + 2 * fp) + stats      # conv_agg_bwd: grad_out, agg, X, head_stats
-        if kind == "conv_agg_bwd+gather":       # + the next step's P = A_low dropout(x): graph, table once, P written
+        if "+proj" in kind:                     # the following layer's projection backward inside (acm_conv_agg_bwd_t.proj_*):
+            bwd += 4 * n * 6                    # `out` (F floats per row) is read in place of grad_out, + proj_dz (6 floats)
+        if "+gather" in kind:                   # + the next step's P = A_low dropout(x): graph, table once, P written
             return bwd + 4 * (n + 1) + per_edge * nnz + per_row * n + 4 * n * fp * 2
         return bwd
     if kind.startswith("gemm"):
@@ -195,6 +197,21 @@ def main():
         loss = step()
     warm = timer.summary()
     AF.set_kernel_timer(None)
+    # row-sharded runs: what each rank spent per step in the library's kernels and in the collectives (HIP events of the
+    # three calibration steps), and the bytes it sent -- to read a scaling line against DESIGN.md section 7's estimate
+    if shard is not None:
+        coll = {k: v for k, v in warm.items() if k.startswith(("all_gather", "all_reduce"))}
+        mine = {"kernels_ms_per_step": round(sum(v[1] for k, v in warm.items() if k not in coll) / 3, 4),
+                "collectives_ms_per_step": round(sum(v[1] for v in coll.values()) / 3, 4),
+                "collective_calls_per_step": sum(v[0] for v in coll.values()) // 3,
+                "collective_bytes_sent_per_step": sum(timer.bytes.values()) // 3}
+        per_rank = [None] * world
+        if dist.is_initialized() and world > 1:
+            dist.all_gather_object(per_rank, mine)
+        else:
+            per_rank = [mine]
+        shard["per_rank"] = per_rank
+    warm = {k: v for k, v in warm.items() if not k.startswith(("all_gather", "all_reduce"))}
     dominant = max(warm, key=lambda k: warm[k][1])
     # ---------------- timed region ----------------
     focus = AF.KernelTimer(only=dominant)

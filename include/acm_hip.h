@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define ACM_ABI_VERSION 19
+#define ACM_ABI_VERSION 20
 
 typedef enum {
     ACM_OK = 0,
@@ -572,6 +572,20 @@ typedef struct {
     const float* next_xg; int64_t ld_next_xg;
     const float* next_row_scale;
     float* next_agg; int64_t ld_next_agg;
+    /* Optional (ABI 20): the backward of the FOLLOWING layer's narrow projection  Z' = out [W_L' | W_H' | W_I']
+     * (ACM-Geometric/layers.py:87-89 of the next GraphConvolution; what acm_proj_bwd computes in a launch of its own)
+     * inside this kernel.  With proj_dz set, grad_out is NOT read: the gradient of this layer's output is formed per row,
+     *     grad_out[row, :] = proj_dz[row, :] [W_L' | W_H' | W_I']^T        proj_dz = dL/dZ', [n_rows, 3 proj_f],
+     * and the following layer's weight gradients
+     *     proj_d_w[c][col][q] = sum_rows out[row, col] proj_dz[row, c proj_f + q]     (three f_out x proj_f blocks)
+     * are reduced with d_params (same `defer`).  That removes the [n_rows, f_out] gradient from memory altogether
+     * (43 MB written and read back on the twitch-shaped graph) and one launch.  Needs `out` (= the following layer's
+     * input), three channels, f_pad = 8, f_out = 64, proj_f <= 2 and no next_agg; ACM_EUNSUPPORTED otherwise -- the
+     * caller then runs acm_proj_bwd itself and calls again with grad_out. */
+    const float* proj_dz; int64_t ld_proj_dz;
+    const float* proj_w_low; const float* proj_w_high; const float* proj_w_mlp; int64_t proj_ld_w;
+    int32_t proj_f;
+    float* proj_d_w;
 } acm_conv_agg_bwd_t;
 
 int acm_conv_agg_bwd_workspace_bytes(int64_t n_rows, int f_in, int f_out, size_t* bytes);

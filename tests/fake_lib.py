@@ -697,7 +697,21 @@ class FakeLib:
         H = [np.where(m, r, 0.0) for r, m in zip(raw, pos)]
         vecs, lnw, lnb, mix = self._params(q, k, F, q.layernorm)
         hd = _head(H, k, q.layernorm, vecs, lnw, lnb, mix)
-        dO = _view(q.grad_out, n, F, q.ld_grad_out).astype(np.float64)
+        extra = []
+        if q.proj_dz:                             # the following layer's projection backward rides along (ABI 20)
+            f2 = q.proj_f
+            if (k != 3 or fp != 8 or F != 64 or not q.head_stats or not q.out or not 1 <= f2 <= 2
+                    or q.post_scale or not (q.post_relu or q.post_drop.p == 0)):
+                self._err = b"acm_conv_agg_bwd: proj_dz: unsupported configuration"
+                return 4
+            dz2 = _view(q.proj_dz, n, 3 * f2, q.ld_proj_dz).astype(np.float64)
+            wcat = np.concatenate([_view(ptr, F, f2, q.proj_ld_w) for ptr in (q.proj_w_low, q.proj_w_high, q.proj_w_mlp)], 1)
+            dO = dz2 @ wcat.astype(np.float64).T
+            outf = _view(q.out, n, F, q.ld_out).astype(np.float64)
+            dw2 = outf.T @ dz2                                              # [F, 3 f2] -> three contiguous F x f2 blocks
+            extra = [(_vec(q.proj_d_w, 3 * F * f2), np.concatenate([dw2[:, c * f2:(c + 1) * f2].reshape(-1) for c in range(3)]))]
+        else:
+            dO = _view(q.grad_out, n, F, q.ld_grad_out).astype(np.float64)
         dO = _post_bwd(q, dO, q.scale * sum(hd["alpha"][:, c:c + 1] * H[c] for c in range(k)), n, F)
         dH, d_vec, d_lnw, d_lnb, d_mix = _head_backward(H, hd, dO, k, q.layernorm, vecs, lnw, mix, q.scale)
         G = [np.where(m, d, 0.0) for d, m in zip(dH, pos)]
@@ -730,7 +744,7 @@ class FakeLib:
             if q.next_row_scale:
                 pn = pn * _vec(q.next_row_scale, a.n_rows).astype(np.float64)[:, None]
             _view(q.next_agg, a.n_rows, 8, q.ld_next_agg)[...] = pn
-        return self._emit(q.defer, [(dst, out)])
+        return self._emit(q.defer, [(dst, out)] + extra)
 
     def acm_dropout(self, n, c, src, lds, dst, ldd, dst_cols, d, stream):
         out = np.zeros((n, dst_cols))

@@ -238,15 +238,19 @@ def _worker(rank, world, port, cfg, ret):
                                  dict(model="acmgcnpp", s=0, variant=0, dropout=0.5),
                                  dict(model="acmgcnpp", s=1, variant=1, world=4, plan="work"),
                                  dict(model="acmgcnp", s=0, variant=1, hid=64, dropout=0.5, x_full=1),
-                                 dict(model="acmgcnp", s=1, variant=1, hid=64, plan="work")],
+                                 dict(model="acmgcnp", s=1, variant=1, hid=64, plan="work"),
+                                 dict(model="acmgcnp", s=1, variant=0, world=8, plan="work", dropout=0.5),
+                                 dict(model="acmsgc", s=0, variant=0, hops=3, world=8, plan="work"),
+                                 dict(model="acmgcnp", s=0, variant=0, world=8, dropout=0.5, x_full=1)],
                          ids=["agg+literal", "struct-acmii", "acmii", "struct-agg", "struct-agg-explicit",
                               "struct-acmii-explicit", "dropout", "dropout-xfull-struct", "dropout-xfull-acmii",
                               "sgc-3hop", "sgc-2hop-explicit", "work-plan-struct-agg", "work-plan-acmii-explicit",
                               "work-plan-dropout", "4-ranks-struct-acmii", "4-ranks-work-plan-dropout",
                               "4-ranks-work-plan-sgc-3hop", "acmgcnpp-dropout", "4-ranks-work-plan-acmgcnpp",
-                              "acmii-recompute-dropout-xfull", "acmii-recompute-struct-work-plan"])
+                              "acmii-recompute-dropout-xfull", "acmii-recompute-struct-work-plan",
+                              "8-ranks-work-plan-struct-dropout", "8-ranks-work-plan-sgc-3hop", "8-ranks-equal-blocks-xfull"])
 def test_row_shard_equals_single_process(cfg, monkeypatch):
-    """world_size = 2 and 4 over gloo: the sharded forward/backward (halo all-gathers + parameter-gradient
+    """world_size = 2, 4 and 8 (the node's GPU count) over gloo: the sharded forward/backward (halo all-gathers + parameter-gradient
     all-reduce issued by functional.AcmConvFunction) must reproduce the 1-process result -- with equal blocks and
     with the work-balanced plan (blocks of different lengths, padded halo numbering)."""
     import torch.multiprocessing as mp

@@ -302,7 +302,7 @@ def test_twitch_shaped_pipelined_steps_match_oracle(mode):
     assert int(st.step.item()) == 42 and step.pipe.primed and not step.pipe.stale()
     if mode == "eager":
         used = sorted(set(k.split("/")[0] for k in timer.events))
-        assert "conv_agg_bwd+gather" in used and "conv_agg_epi" in used, used
+        assert any(k.startswith("conv_agg_bwd+gather") for k in used) and "conv_agg_epi" in used, used
     # ---- the carried P against float64
     f42 = _factors(st, p_drop, 0, n, x.shape[1], step=42)
     xdrop = wl["x"].astype(np.float64) * f42
