@@ -40,8 +40,28 @@ def _cora_masks(split):
     return None
 
 
-# name -> (mean |selected acc - reference run| bound, per-split bound); see the criterion below
-REPLAYS = {"cora": (0.002, 0.01), "squirrel": (0.007, 0.025), "film_v0": (0.004, 0.025), "film_v1": (0.004, 0.025)}
+# name -> (mean |selected acc - reference run| bound, per-split bound); see the criterion below.  The mean bound is
+# max(0.2 pp, the distance between two runs of the REFERENCE ITSELF that differ only in fp32 summation order) when the
+# second reference run is recorded (accuracy_<name>_b.npz, make_accuracy_golden.py --b: Squirrel 66.11 vs 65.81 %, 0.30 pp),
+# the listed value otherwise.
+REPLAYS = {"cora": (0.002, 0.01), "squirrel": (0.002, 0.025), "film_v0": (0.004, 0.025), "film_v1": (0.004, 0.025)}
+
+
+def _reference_band(name, splits):
+    """|mean selected accuracy of reference run A - of reference run B| over `splits` (and the per-split differences), or
+    None when run B was not recorded."""
+    path = os.path.join(GOLDEN, f"accuracy_{name}_b.npz")
+    if not os.path.exists(path):
+        return None
+    a, b = load_npz(os.path.join(GOLDEN, f"accuracy_{name}.npz")), load_npz(path)
+    ia = {s: i for i, s in enumerate(a["cfg"]["splits"])}
+    ib = {s: i for i, s in enumerate(b["cfg"]["splits"])}
+    common = [s for s in splits if s in ia and s in ib]
+    if not common:
+        return None
+    da = np.asarray([a["test_acc"][ia[s]] for s in common], dtype=np.float64)
+    db = np.asarray([b["test_acc"][ib[s]] for s in common], dtype=np.float64)
+    return abs(float(da.mean() - db.mean())), (db - da)
 
 
 def _prepare(name):
@@ -165,7 +185,10 @@ def test_fixed_split_accuracy_matches_reference_run(name):
     os.makedirs(out_dir, exist_ok=True)
     with open(os.path.join(out_dir, f"accuracy_replay_{name}.json"), "w") as fh:
         import json
+        band0 = _reference_band(name, [s for s in cfg["splits"] if s in results])
         json.dump({"config": cfg, "reference_run": ref.tolist(), "mi355x": got.tolist(),
+                   "reference_run_b_mean_distance_pp": None if band0 is None else 100 * band0[0],
+                   "reference_run_b_minus_a_pp": None if band0 is None else (100 * band0[1]).tolist(),
                    "mean_diff_pp": float(100 * (got.mean() - ref.mean())), "curve_gap_pp": (100 * np.asarray(curve_gap)).tolist(),
                    "at_reference_epoch_diff_pp": (100 * np.asarray(at_ref_epoch)).tolist(),
                    "curves": curves}, fh)
@@ -183,6 +206,11 @@ def test_fixed_split_accuracy_matches_reference_run(name):
     #      the mean of ten splits; the reference's own split-to-split std is 1.7 pp) -- bounded per split and on the
     #      mean (REPLAYS).
     mean_bound, split_bound = REPLAYS[name]
+    band = _reference_band(name, [s for s in cfg["splits"] if s in results])
+    if band is not None:                               # the reference's own run-to-run distance, measured
+        print(f"   two runs of the reference itself (summation order only): mean {100 * band[0]:.2f} pp apart, per split "
+              f"{np.round(100 * band[1], 2).tolist()}")
+        mean_bound = max(0.002, band[0])
     assert abs(np.mean(curve_gap)) <= 0.002 and np.all(np.abs(curve_gap) <= 0.004), curve_gap
     assert abs(np.mean(at_ref_epoch)) <= 0.002, at_ref_epoch
     assert np.all(np.abs(got - ref) <= split_bound), (got - ref)
