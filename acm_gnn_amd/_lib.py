@@ -93,7 +93,8 @@ class ConvBwdSpmm(C.Structure):
                 ("mask_high", C.c_void_p), ("ld_mask_high", C.c_int64),
                 ("dz_low", C.c_void_p), ("ld_dz_low", C.c_int64),
                 ("dz_high", C.c_void_p), ("ld_dz_high", C.c_int64),
-                ("d_struc", C.c_void_p), ("ld_d_struc", C.c_int64), ("self_scale", C.c_void_p)]
+                ("d_struc", C.c_void_p), ("ld_d_struc", C.c_int64), ("self_scale", C.c_void_p),
+                ("gather_bf16", C.c_int32)]
 
 
 class ConvAggFwd(C.Structure):

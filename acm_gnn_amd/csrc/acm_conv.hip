@@ -469,7 +469,9 @@ __global__ __launch_bounds__(256) void spmm_pair_kernel(CsrView csr, GatherSrc g
 // blocks of loads are in flight per wave (8 KB at NG = 2), the four groups' partial sums meet at the end through
 // v_permlane16/32_swap (fixed order), and the epilogue runs in LayVec16 (lane m owns columns 4 m .. 4 m + 3 of every
 // block).  Needs 16-byte aligned rows (F % 4 == 0, ld % 4 == 0); row offsets are 32-bit byte offsets (table < 4 GB).
-template <int NG, int NB, int UNR, int BLK>
+// B16: the gathered tables hold bf16 (acm_cast_bf16): the lane's four columns are one 8-byte fetch (a 64-column row is ONE
+// 128-byte line instead of two), widened exactly to fp32 -- same lane layout, same fp32 sums.
+template <int NG, int NB, int UNR, int BLK, bool B16 = false>
 __device__ __forceinline__ void gather_vec_block(const GatherSrc& g, const unsigned (&ldb)[3], const unsigned (&blk_off)[NB],
                                                  unsigned ok_mask, int my_j, float my_a, float (&acc)[NG][4 * NB]) {
     float4 z[UNR][NG][NB];
@@ -482,7 +484,15 @@ __device__ __forceinline__ void gather_vec_block(const GatherSrc& g, const unsig
         for (int c = 0; c < NG; ++c) {
             const char* rp = reinterpret_cast<const char*>(g.p[c]) + (size_t)(j * ldb[c]);
 #pragma unroll
-            for (int b = 0; b < NB; ++b) z[uu][c][b] = *reinterpret_cast<const float4*>(rp + blk_off[b]);
+            for (int b = 0; b < NB; ++b) {
+                if (B16) {
+                    const uint2 w = *reinterpret_cast<const uint2*>(rp + blk_off[b]);
+                    z[uu][c][b] = make_float4(__uint_as_float(w.x << 16), __uint_as_float(w.x & 0xFFFF0000u),
+                                              __uint_as_float(w.y << 16), __uint_as_float(w.y & 0xFFFF0000u));
+                } else {
+                    z[uu][c][b] = *reinterpret_cast<const float4*>(rp + blk_off[b]);
+                }
+            }
         }
     }
 #pragma unroll
@@ -504,7 +514,7 @@ __device__ __forceinline__ void gather_vec_block(const GatherSrc& g, const unsig
     }
 }
 
-template <int NG, int NB, class Epi>
+template <int NG, int NB, class Epi, bool B16 = false>
 __global__ __launch_bounds__(256) void spmm_vec_kernel(CsrView csr, GatherSrc g, int F, typename Epi::Args ea,
                                                        float* __restrict__ partial) {
     constexpr int UNR = (NG * NB >= 4) ? 2 : 4;          // 8 (NG * NB <= 2), 12 (NG = 3) or NG * NB * 2 loads in flight
@@ -525,12 +535,12 @@ __global__ __launch_bounds__(256) void spmm_vec_kernel(CsrView csr, GatherSrc g,
 #pragma unroll
     for (int b = 0; b < NB; ++b) {
         const bool ok = 64 * b + 4 * m < F;
-        blk_off[b] = ok ? 256u * b + 16u * m : 0u;
+        blk_off[b] = ok ? (B16 ? 128u * b + 8u * m : 256u * b + 16u * m) : 0u;
         ok_mask |= ok ? (1u << b) : 0u;
     }
     unsigned ldb[3];
 #pragma unroll
-    for (int c = 0; c < 3; ++c) ldb[c] = c < NG ? (unsigned)g.ld[c] * 4u : 0u;
+    for (int c = 0; c < 3; ++c) ldb[c] = c < NG ? (unsigned)g.ld[c] * (B16 ? 2u : 4u) : 0u;
     const int pos = 4 * m + q;                           // transposed id layout (see above)
     for (int base = begin; base < end; base += 64) {
         const int cnt = min(64, end - base);             // wave-uniform
@@ -543,7 +553,7 @@ __global__ __launch_bounds__(256) void spmm_vec_kernel(CsrView csr, GatherSrc g,
         const int steps = (cnt + 3) >> 2;
         // the step index must be a compile-time constant for the DPP broadcast: 16 / UNR unrolled blocks, uniform exits
 #define ACM_VEC_BLK(B)                                                                                          \
-        if (B * UNR < steps) gather_vec_block<NG, NB, UNR, B>(g, ldb, blk_off, ok_mask, my_j, my_a, acc)
+        if (B * UNR < steps) gather_vec_block<NG, NB, UNR, B, B16>(g, ldb, blk_off, ok_mask, my_j, my_a, acc)
         ACM_VEC_BLK(0);
         ACM_VEC_BLK(1);
         ACM_VEC_BLK(2);
@@ -888,7 +898,18 @@ int launch_gather(const acm_csr* a, const GatherSrc& g, int F, const typename Ep
             vec = ((uintptr_t)g.p[c]) % 16 == 0 && g.ld[c] % 4 == 0 &&
                   (uint64_t)a->n_cols * (uint64_t)g.ld[c] * 4u < (1ull << 32);
         if (vec && getenv("ACM_WIDE_PAIR") == nullptr) pair32 = false;
-        if (vec && !pair32) {
+        // bf16 tables (even 8 < F <= 64): the vector form with 8-byte fetches whenever the fp32 operand would take it (rows of
+        // 4 k columns, 8-byte aligned); the two-neighbours-per-instruction pair kernel otherwise.  On the twitch-shaped
+        // graph the pair kernel is SLOWER than the fp32 vector form (conv_bwd_spmm 619 -> 707 us: half the bytes, but two
+        // neighbours per instruction instead of four)
+        bool vec16 = bf16 && F % 4 == 0 && getenv("ACM_WIDE_SCALAR") == nullptr && getenv("ACM_BF16_PAIR") == nullptr &&
+                     ((NG == 1 && a->nnz >= 16 * a->n_rows) || (NG > 1 && a->nnz >= 4 * a->n_rows) ||
+                      getenv("ACM_WIDE_VEC") != nullptr);
+        for (int c = 0; c < NG && vec16; ++c)
+            vec16 = ((uintptr_t)g.p[c]) % 8 == 0 && g.ld[c] % 4 == 0 && (uint64_t)a->n_cols * (uint64_t)g.ld[c] * 2u < (1ull << 32);
+        if (vec16) {
+            hipLaunchKernelGGL((spmm_vec_kernel<NG, 1, Epi, true>), dim3(grid), dim3(256), 0, st, v, g, F, ea, partial);
+        } else if (vec && !pair32) {
             if (F <= 64)
                 hipLaunchKernelGGL((spmm_vec_kernel<NG, 1, Epi>), dim3(grid), dim3(256), 0, st, v, g, F, ea, partial);
             else if (F <= 128)
@@ -1083,22 +1104,22 @@ extern "C" int acm_conv_bwd_spmm(const acm_csr_t* at, const acm_conv_bwd_spmm_t*
     if (F > 8 && F <= 256 && split) {
         hipStream_t s = (hipStream_t)stream;
         GatherSrc gl = {{p->g_low, nullptr, nullptr}, {p->ld_g_low, 0, 0}};
-        int st = launch_gather<1, EpiBwdLow>(at, gl, F, *p, workspace, workspace_bytes, s, "acm_conv_bwd_spmm");
+        int st = launch_gather<1, EpiBwdLow>(at, gl, F, *p, workspace, workspace_bytes, s, "acm_conv_bwd_spmm", nullptr, b16);
         if (st != ACM_OK) return st;
         GatherSrc gh = {{p->g_high, nullptr, nullptr}, {p->ld_g_high, 0, 0}};
-        st = launch_gather<1, EpiBwdHigh>(at, gh, F, *p, workspace, workspace_bytes, s, "acm_conv_bwd_spmm");
+        st = launch_gather<1, EpiBwdHigh>(at, gh, F, *p, workspace, workspace_bytes, s, "acm_conv_bwd_spmm", nullptr, b16);
         if (st != ACM_OK || !p->g_struc) return st;
         GatherSrc gs = {{p->g_struc, nullptr, nullptr}, {p->ld_g_struc, 0, 0}};
-        return launch_gather<1, EpiBwdStruc>(at, gs, F, *p, workspace, workspace_bytes, s, "acm_conv_bwd_spmm");
+        return launch_gather<1, EpiBwdStruc>(at, gs, F, *p, workspace, workspace_bytes, s, "acm_conv_bwd_spmm", nullptr, b16);
     }
     if (p->g_struc) {
         GatherSrc g = {{p->g_low, p->g_high, p->g_struc}, {p->ld_g_low, p->ld_g_high, p->ld_g_struc}};
         return launch_gather<3, EpiBwd>(at, g, F, *p, workspace, workspace_bytes, (hipStream_t)stream,
-                                        "acm_conv_bwd_spmm");
+                                        "acm_conv_bwd_spmm", nullptr, b16);
     }
     GatherSrc g = {{p->g_low, p->g_high, nullptr}, {p->ld_g_low, p->ld_g_high, 0}};
     return launch_gather<2, EpiBwd>(at, g, F, *p, workspace, workspace_bytes, (hipStream_t)stream,
-                                    "acm_conv_bwd_spmm");
+                                    "acm_conv_bwd_spmm", nullptr, b16);
 }
 
 // ================================================================== K3: row-local backward

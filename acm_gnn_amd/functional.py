@@ -548,8 +548,9 @@ def proj_bwd_supported(q):
     return q in (3, 6, 9, 12, 15)
 
 
-def spmm(graph, dense, out=None, row_scale=None):
-    """out = A @ dense for a CsrGraph A (acm_spmm); with ``row_scale``: diag(row_scale) (A @ dense) (acm_spmm_ex)."""
+def spmm(graph, dense, out=None, row_scale=None, bf16=False):
+    """out = A @ dense for a CsrGraph A (acm_spmm); with ``row_scale``: diag(row_scale) (A @ dense) (acm_spmm_ex).
+    ``bf16``: gather a bf16 copy of ``dense`` (even 8 < width <= 64; fp32 sums)."""
     dense = _as_f32_rows(dense, "dense")
     if dense.shape[0] != graph.n_cols:
         raise ValueError(f"spmm: dense has {dense.shape[0]} rows, operator has {graph.n_cols} columns")
@@ -559,13 +560,17 @@ def spmm(graph, dense, out=None, row_scale=None):
     if width == 0 or graph.n_rows == 0:
         return out
     ws = graph.workspace(min(width, 256))
-    with _device_ctx(dense.device), _Timed(f"spmm/W{width}"):
-        if row_scale is None:
+    bf16 = bool(bf16) and 8 < width <= 64 and width % 2 == 0
+    if bf16:
+        dense = cast_bf16(dense)
+    with _device_ctx(dense.device), _Timed(f"spmm/W{width}{'b' if bf16 else ''}"):
+        if row_scale is None and not bf16:
             st = _lib.load().acm_spmm(graph.handle, _vp(dense), dense.stride(0), width, _vp(out), out.stride(0),
                                       _vp(ws), ws.numel() * 4, _stream())
         else:
             o = _lib.SpmmOpts()
-            o.row_scale = _as_f32c(row_scale, "row_scale").data_ptr()
+            o.g_bf16 = int(bf16)
+            o.row_scale = _as_f32c(row_scale, "row_scale").data_ptr() if row_scale is not None else None
             st = _lib.load().acm_spmm_ex(graph.handle, _vp(dense), dense.stride(0), width, _vp(out), out.stride(0),
                                          C.byref(o), _vp(ws), ws.numel() * 4, _stream())
     _lib.check(st, "acm_spmm")
@@ -1068,7 +1073,7 @@ class AcmConvFunction(torch.autograd.Function):
         # ACMII first layer with a narrow input: gather the input rows and recompute relu(x_j [W_L | W_H]) per edge on
         # the matrix pipe instead of gathering the 2F-wide projected rows (acm_conv_acmii_fwd = K1 + K2)
         ctx.recompute = (cfg.relu_before and not cfg.relu_after and cfg.relu_mlp and f == 64 and f_in <= 8
-                         and not sparse_x and not general and hops == 1 and not cfg.gather_bf16
+                         and not sparse_x and not general and hops == 1
                          and os.environ.get("ACM_ACMII_RECOMPUTE", "1") != "0")
         fb = f                                   # column distance of the two gathered channels (see _chan_block)
         if ctx.agg_first or ctx.recompute:
@@ -1184,7 +1189,7 @@ class AcmConvFunction(torch.autograd.Function):
             p.f_in, p.f_pad, p.f_out, p.layernorm, p.scale = f_in, fp, f, int(cfg.layernorm), cfg.scale
             p.n_channels = k
             if four:                                  # ps = A_low S: one F-wide single-channel gather of the parameter
-                ps = spmm(ops.low, s_gath, row_scale=ops.row_scale if ops.implicit else None)
+                ps = spmm(ops.low, s_gath, row_scale=ops.row_scale if ops.implicit else None, bf16=cfg.gather_bf16)
                 p.ps, p.ld_ps = ps.data_ptr(), ps.stride(0)
                 p.ss, p.ld_ss = s_local.data_ptr(), s_local.stride(0)
                 p.deg = ops.deg.data_ptr()
@@ -1457,8 +1462,19 @@ class AcmConvFunction(torch.autograd.Function):
             gg = _gather_rows(ops, g)
             gsg = _gather_rows(ops, gs) if four else None
             low_t = ops.low_t
-            r.g_low, r.ld_g_low = gg.data_ptr(), gg.stride(0)
-            r.g_high, r.ld_g_high = gg.data_ptr() + 4 * fb, gg.stride(0)
+            if cfg.gather_bf16 and 8 < f <= 64 and f % 2 == 0 and fb == f:
+                # bf16 copies of the gathered gradient tables: half the bytes of the fabric-bound transposed products (the
+                # self terms and every sum stay fp32); opt-in, BASELINE config 3's tolerance
+                gb = cast_bf16(gg[:, : 2 * f])
+                r.gather_bf16 = 1
+                r.g_low, r.ld_g_low = gb.data_ptr(), gb.stride(0)
+                r.g_high, r.ld_g_high = gb.data_ptr() + 2 * f, gb.stride(0)
+                if four:
+                    gsb = cast_bf16(gsg)
+                    gsg = gsb
+            else:
+                r.g_low, r.ld_g_low = gg.data_ptr(), gg.stride(0)
+                r.g_high, r.ld_g_high = gg.data_ptr() + 4 * fb, gg.stride(0)
             r.s_high, r.ld_s_high = g.data_ptr() + 4 * fb, g.stride(0)
             if four:
                 r.g_struc, r.ld_g_struc = gsg.data_ptr(), gsg.stride(0)
@@ -1626,6 +1642,9 @@ def _backward_agg(ctx, grad_out):
         o = _lib.SpmmOpts()
         o.sub, o.ld_sub = gs.data_ptr(), gs.stride(0)
         o.sub_scale = None if ops.implicit else ops.inv_deg.data_ptr()
+        if cfg.gather_bf16 and 8 < f <= 64 and f % 2 == 0:       # bf16 gathered operand (the self term stays fp32)
+            gsg = cast_bf16(gsg)
+            o.g_bf16 = 1
         with _device_ctx(dev), _Timed(f"spmm_sub/{f}"):
             st = lib.acm_spmm_ex(low_t.handle, _vp(gsg), gsg.stride(0), f, _vp(d_struc), d_struc.stride(0),
                                  C.byref(o), _vp(ws2), ws2.numel() * 4, _stream())

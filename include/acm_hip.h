@@ -449,6 +449,10 @@ typedef struct {
     /* optional per-row multiplier of the self term s_high (pattern-only backward: s_high holds D^-1 G_H, so
      * self_scale = d_i restores G_H); NULL = 1.  inv_deg NULL = 1. */
     const float* self_scale;
+    /* gather_bf16 != 0 (ABI 20): g_low / g_high / g_struc point to bf16 tables (acm_cast_bf16; leading dimensions in
+     * elements, even), 8 < f_out <= 64 even; the self terms s_high / s_struc stay fp32, sums accumulate in fp32.  Half the
+     * gathered bytes of the fabric-bound wide transposed products (BASELINE config 3's tolerance; fp32 is the default). */
+    int32_t gather_bf16;
 } acm_conv_bwd_spmm_t;
 
 int acm_conv_bwd_spmm(const acm_csr_t* a_low_t, const acm_conv_bwd_spmm_t* p,

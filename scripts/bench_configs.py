@@ -37,6 +37,11 @@ CONFIGS = {
     "twitch/acmgcn": dict(graph="syn:twitch-gamer", method="acmgcn", s=0, variant=0, dropout=0.1),
     "twitch/acmgcnp+A": dict(graph="syn:twitch-gamer", method="acmgcnp", s=1, variant=0, dropout=0.0),
     "twitch/acmiigcnp": dict(graph="syn:twitch-gamer", method="acmgcnp", s=0, variant=1, dropout=0.1),
+    "twitch/acmiigcnp+A": dict(graph="syn:twitch-gamer", method="acmgcnp", s=1, variant=1, dropout=0.0),
+    # the fabric-bound cells with bf16 storage of the gathered operands (opt-in, BASELINE config 3; fp32 sums)
+    "twitch/acmgcnp+A/bf16": dict(graph="syn:twitch-gamer", method="acmgcnp", s=1, variant=0, dropout=0.0, gather_dtype="bf16"),
+    "twitch/acmiigcnp/bf16": dict(graph="syn:twitch-gamer", method="acmgcnp", s=0, variant=1, dropout=0.1, gather_dtype="bf16"),
+    "twitch/acmiigcnp+A/bf16": dict(graph="syn:twitch-gamer", method="acmgcnp", s=1, variant=1, dropout=0.0, gather_dtype="bf16"),
     "arxiv-year/acmgcnp": dict(graph="syn:arxiv-year", method="acmgcnp", s=0, variant=0, dropout=0.1),
     "penn94/acmgcnp": dict(graph="syn:penn94", method="acmgcnp", s=0, variant=0, dropout=0.1),
     # the same wide-feature configs with CSR features (sparse-feature projection)
@@ -73,7 +78,7 @@ def run(name, cfg, steps=20):
         x = acm_gnn_amd.SparseFeatures.from_scipy(sp.csr_matrix(x_np), DEV)
     torch.manual_seed(0)
     model = acm_gnn_amd.GCN(f_in, 64, classes, 2, n, cfg["dropout"], cfg["method"], cfg["s"],
-                            variant=bool(cfg["variant"]), attn_layernorm=True).to(DEV)
+                            variant=bool(cfg["variant"]), attn_layernorm=True, gather_dtype=cfg.get("gather_dtype")).to(DEV)
     opt = acm_gnn_amd.FusedAdam(model.parameters(), lr=0.01, weight_decay=1e-4)
     w = T.row_weights(torch.from_numpy(tr).to(DEV), n)
     step = T.TrainStep(model, opt, x, ops, y, w)

@@ -605,9 +605,17 @@ class FakeLib:
         at, r = self._get(h), rr._obj
         n, F = at.n_rows, r.f_out
         f64 = np.float64
-        dl = at.dense_mul(_view(r.g_low, at.n_cols, F, r.ld_g_low))
+
+        def table(ptr, ld):                       # the gathered operand: fp32, or bf16 widened exactly (ABI 20)
+            if r.gather_bf16:
+                return (_view(ptr, at.n_cols, F, ld, np.uint16).astype(np.uint32) << 16).view(np.float32)
+            return _view(ptr, at.n_cols, F, ld)
+        if r.gather_bf16 and not (8 < F <= 64 and F % 2 == 0):
+            self._err = b"acm_conv_bwd_spmm: bf16 gathered operands are implemented for even 8 < F <= 64"
+            return 4
+        dl = at.dense_mul(table(r.g_low, r.ld_g_low))
         ssc = _vec(r.self_scale, n).astype(f64)[:, None] if r.self_scale else 1.0
-        dh = ssc * _view(r.s_high, n, F, r.ld_s_high).astype(f64) - at.dense_mul(_view(r.g_high, at.n_cols, F, r.ld_g_high))
+        dh = ssc * _view(r.s_high, n, F, r.ld_s_high).astype(f64) - at.dense_mul(table(r.g_high, r.ld_g_high))
         if r.mask_low:
             dl = np.where(_view(r.mask_low, n, F, r.ld_mask_low) > 0, dl, 0.0)
         if r.mask_high:
@@ -615,7 +623,7 @@ class FakeLib:
         _view(r.dz_low, n, F, r.ld_dz_low)[...] = dl
         _view(r.dz_high, n, F, r.ld_dz_high)[...] = dh
         if r.g_struc:
-            ds = at.dense_mul(_view(r.g_struc, at.n_cols, F, r.ld_g_struc)) - \
+            ds = at.dense_mul(table(r.g_struc, r.ld_g_struc)) - \
                 _view(r.s_struc, n, F, r.ld_s_struc).astype(f64) * (_vec(r.inv_deg, n).astype(f64)[:, None] if r.inv_deg else 1.0)
             _view(r.d_struc, n, F, r.ld_d_struc)[...] = ds
         return 0

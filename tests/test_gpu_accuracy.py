@@ -95,10 +95,11 @@ def _prepare(name):
     return rec, cfg, dataset, n, x, labels, masks, a_un, adj_low, adj_high
 
 
-def _replay_splits(name, splits):
+def _replay_splits(name, splits, gather_dtype="fp32"):
     """Worker (its own process: the replay is bound by the CPU generation of the recorded dropout masks, 80 ms per
     epoch on Squirrel, so the splits of one dataset run side by side on the one GPU): train the given splits exactly as
     the recorded reference run did and return {split: (selected test acc, val-loss curve, test-acc curve)}."""
+    os.environ["ACM_GATHER_DTYPE"] = gather_dtype       # the layers' default storage type of the gathered operands
     from acm_gnn_amd import GCN, layers, train as T
     from acm_gnn_amd.graph import clear_cache
     rec, cfg, dataset, n, x, labels, masks, a_un, adj_low, adj_high = _prepare(name)
@@ -215,6 +216,56 @@ def test_fixed_split_accuracy_matches_reference_run(name):
     assert abs(np.mean(at_ref_epoch)) <= 0.002, at_ref_epoch
     assert np.all(np.abs(got - ref) <= split_bound), (got - ref)
     assert abs(got.mean() - ref.mean()) <= mean_bound, (got.mean(), ref.mean())
+
+
+@pytest.mark.parametrize("name", ["film_v1", "squirrel"])
+def test_bf16_gathered_operands_keep_the_accuracy(name):
+    """the opt-in bf16 storage of the gathered operands (gather_dtype = "bf16": the wide forward
+    gathers, the structure-channel gathers, and -- new -- the transposed products of the backward, acm_conv_bwd_spmm_t.
+    gather_bf16 / spmm_sub) must not cost accuracy.  The recorded reference experiments (Film ACMII-GCN+, Squirrel ACM-GCN+
+    with A: same init, masks, optimizer, selection rule) replayed twice on the MI355X, fp32 and bf16: the test-accuracy
+    curves over the second half of training agree to 0.2 pp on the mean of the splits, and the selected accuracy to
+    max(0.2 pp, the reference's own run-to-run band) -- the selection functional moves by that much under ANY change of
+    fp32 summation order."""
+    path = os.path.join(GOLDEN, f"accuracy_{name}.npz")
+    if not os.path.exists(path):
+        pytest.skip(f"{path} not generated")
+    rec = load_npz(path)
+    todo = list(rec["cfg"]["splits"])
+    import concurrent.futures as cf
+    import multiprocessing as mp
+    workers = min(5, len(todo))
+    chunks = [todo[i::workers] for i in range(workers)]
+    runs = {}
+    for dt in ("fp32", "bf16"):
+        res = {}
+        with cf.ProcessPoolExecutor(max_workers=workers, mp_context=mp.get_context("spawn")) as pool:
+            for part in pool.map(_replay_splits, [name] * workers, chunks, [dt] * workers):
+                res.update(part)
+        runs[dt] = res
+    sel = {dt: np.asarray([runs[dt][s][0] for s in todo]) for dt in runs}
+    half = []
+    for s in todo:
+        a32, a16 = np.asarray(runs["fp32"][s][2]), np.asarray(runs["bf16"][s][2])
+        m = min(len(a32), len(a16))
+        half.append(float(a16[m // 2:m].mean() - a32[m // 2:m].mean()))
+    band = _reference_band(name, todo)
+    bound = max(0.002, band[0]) if band is not None else 0.004
+    print(f"\n{name}: fp32 {100 * sel['fp32'].mean():.2f} % | bf16 {100 * sel['bf16'].mean():.2f} % | selected, per split "
+          f"{np.round(100 * (sel['bf16'] - sel['fp32']), 2).tolist()} | 2nd-half curve mean, per split {np.round(100 * np.asarray(half), 2).tolist()} pp")
+    out_dir = os.path.join(os.path.dirname(GOLDEN), "..", "gpurun_out")
+    os.makedirs(out_dir, exist_ok=True)
+    with open(os.path.join(out_dir, f"accuracy_bf16_{name}.json"), "w") as fh:
+        import json
+        json.dump({"fp32_selected": sel["fp32"].tolist(), "bf16_selected": sel["bf16"].tolist(),
+                   "selected_mean_diff_pp": float(100 * (sel["bf16"].mean() - sel["fp32"].mean())),
+                   "curve_second_half_diff_pp": (100 * np.asarray(half)).tolist(), "selected_bound_pp": 100 * bound}, fh)
+    # the curves agree; the SELECTED accuracy must not be lower by more than the bound (measured: Film ACMII-GCN+ selects
+    # +0.44 pp HIGHER under bf16 -- per split -0.13 ... +1.18 pp, the arg-min of a flat validation loss landing elsewhere --
+    # with the curves 0.06 pp apart; Squirrel see the printed line); a two-sided sanity bound of 0.8 pp on top
+    assert abs(np.mean(half)) <= 0.002 and np.all(np.abs(half) <= 0.006), half
+    assert sel["bf16"].mean() >= sel["fp32"].mean() - bound, (sel["bf16"].mean(), sel["fp32"].mean(), bound)
+    assert abs(sel["bf16"].mean() - sel["fp32"].mean()) <= 0.008, (sel["bf16"].mean(), sel["fp32"].mean())
 
 
 @pytest.mark.parametrize("name,n_splits", [("cora", 5), ("squirrel", 3)])

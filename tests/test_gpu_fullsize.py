@@ -195,7 +195,7 @@ def test_twitch_shaped_step_matches_oracle(variant, structure, order):
     used = sorted(set(k.split("/")[0] for k in timer.events))
     rec["kernels"] = used
     if not variant:
-        assert "conv_agg_fwd" in used and "conv_agg_bwd" in used, used       # the headline kernels, at headline size
+        assert "conv_agg_fwd" in used and any(k.startswith("conv_agg_bwd") for k in used), used       # the headline kernels, at headline size
     else:
         assert "conv_fwd" in used and "conv_bwd_spmm" in used, used          # the wide gathers
     d, rel = _errs(logits.detach().cpu(), ref.detach())
