@@ -20,7 +20,7 @@ ABI_VERSION = 20
 EXPORTED_SYMBOLS = (
     "acm_version", "acm_last_error", "acm_csr_create", "acm_csr_transpose", "acm_csr_slice_rows",
     "acm_csr_destroy", "acm_csr_info", "acm_csr_build_streams", "acm_spmm_workspace_bytes", "acm_gemm_workspace_bytes",
-    "acm_gemm", "acm_gemm_blocks", "acm_gemm_split", "acm_proj_fwd", "acm_proj_fwd_at", "acm_proj_bwd_workspace_bytes", "acm_proj_bwd", "acm_spmm", "acm_spmm_v", "acm_spmm_ex", "acm_cast_bf16", "acm_conv_fwd", "acm_conv_bwd_local_workspace_bytes",
+    "acm_gemm", "acm_gemm_blocks", "acm_gemm_drop", "acm_gemm_split", "acm_proj_fwd", "acm_proj_fwd_at", "acm_proj_bwd_workspace_bytes", "acm_proj_bwd", "acm_spmm", "acm_spmm_v", "acm_spmm_ex", "acm_cast_bf16", "acm_conv_fwd", "acm_conv_bwd_local_workspace_bytes",
     "acm_conv_bwd_local", "acm_conv_bwd_spmm", "acm_conv_agg_fwd", "acm_conv_agg_bwd_workspace_bytes",
     "acm_conv_agg_bwd", "acm_nll_loss_workspace_bytes", "acm_nll_loss", "acm_adam_step", "acm_dropout",
     "acm_reduce_flush", "acm_conv_fwd_tail_workspace_bytes", "acm_conv_fwd_tail", "acm_shard_plan",

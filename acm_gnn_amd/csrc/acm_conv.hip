@@ -1100,7 +1100,11 @@ extern "C" int acm_conv_bwd_spmm(const acm_csr_t* at, const acm_conv_bwd_spmm_t*
     // 1004 -> 899, Penn94-shaped (66) 121 -> 106; arXiv-year-shaped (15) 160 -> 190: short rows pay the per-item cost of
     // every pass, so the split needs a mean degree of 32.
     const bool big = (size_t)at->n_cols * (size_t)F * sizeof(float) > (8u << 20) && at->nnz >= 32 * at->n_rows;
-    const bool split = getenv("ACM_BWD_FUSED") ? false : (getenv("ACM_BWD_SPLIT") ? true : big);
+    // bf16 tables (gather_bf16): [G_L | G_H] of a neighbour are 2 x 128 bytes -- what ONE fp32 channel is -- so the fused pass
+    // keeps the hot set of a single fp32 pass and saves the second walk over the operator (twitch-shaped, F = 64: 430 us in
+    // two passes, 387 us fused; fp32: 619 us in two passes)
+    const bool b16 = p->gather_bf16 != 0;             // launch_gather checks the shape (even 8 < F <= 64) and alignment
+    const bool split = getenv("ACM_BWD_FUSED") ? false : (getenv("ACM_BWD_SPLIT") ? true : (big && !b16));
     if (F > 8 && F <= 256 && split) {
         hipStream_t s = (hipStream_t)stream;
         GatherSrc gl = {{p->g_low, nullptr, nullptr}, {p->ld_g_low, 0, 0}};

@@ -12,6 +12,15 @@
 // contiguous, with the next K-slab prefetched into registers while the current one feeds MFMA.
 #include "acm_common.h"
 
+// acm_gemm_rows.hip: row-panel kernels for n >> K, N (X read once, optional input dropout in the tile load)
+bool acm_gemm_rows_nn_ok(int64_t M, int64_t N, int64_t K, const float* B, int64_t ldb);
+int acm_gemm_rows_nn(int64_t M, int64_t N, int64_t K, const float* A, int64_t lda, const float* B, int64_t ldb, float* C,
+                     int64_t ldc, int relu, const acm_dropout_t* drop, hipStream_t st);
+bool acm_gemm_rows_tn_ok(int64_t n_rows, int64_t K, int64_t N, const float* Dz, int64_t lddz);
+int acm_gemm_rows_tn_blocks(int64_t n_rows);
+int acm_gemm_rows_tn(int64_t n_rows, int64_t K, int64_t N, const float* X, int64_t ldx, const float* Dz, int64_t lddz,
+                     float* slabs, int blocks, const acm_dropout_t* drop, hipStream_t st);
+
 namespace {
 
 constexpr int BK = 32;
@@ -251,7 +260,12 @@ extern "C" int acm_gemm_workspace_bytes(int transA, int transB, int64_t M, int64
     ACM_REQUIRE(bytes, ACM_EINVAL, "acm_gemm_workspace_bytes: NULL argument");
     ACM_REQUIRE(M >= 0 && N >= 0 && K >= 0, ACM_ESHAPE, "acm_gemm_workspace_bytes: negative size");
     const GemmPlan p = plan_gemm(M, N, K);
-    *bytes = p.splits > 1 ? (size_t)p.splits * (size_t)M * (size_t)N * sizeof(float) : 0;
+    size_t need = p.splits > 1 ? (size_t)p.splits * (size_t)M * (size_t)N * sizeof(float) : 0;
+    if (transA && !transB && acm_gemm_rows_tn_ok(K, M, N, nullptr, 4)) {        // the row-panel form: one slab per workgroup
+        const size_t rows = (size_t)acm_gemm_rows_tn_blocks(K) * (size_t)M * (size_t)N * sizeof(float);
+        need = rows > need ? rows : need;
+    }
+    *bytes = need;
     return ACM_OK;
 }
 
@@ -264,7 +278,20 @@ extern "C" int acm_gemm(int transA, int transB, int64_t M, int64_t N, int64_t K,
 static int gemm_core(int transA, int transB, int64_t M, int64_t N, int64_t K, const float* A, int64_t lda, const float* B,
                      int64_t ldb, float* C, int64_t ldc, int64_t c_col_block, int64_t c_block_stride, int64_t split_col,
                      float* C2, int64_t ldc2, int relu, void* workspace, size_t workspace_bytes, acm_stream_t stream,
-                     const float* bias = nullptr, const acm_dropout_t* drop = nullptr);
+                     const float* bias = nullptr, const acm_dropout_t* drop = nullptr, const acm_dropout_t* a_drop = nullptr);
+
+// op(A) with the counter-based dropout applied to the STORED matrix A while its tiles are staged (element [r][c] of A as it
+// lies in memory: the node-feature matrix X, whichever side of the product it is on):
+//     transA = 0:  C = drop(A) B        (Z = dropout(X) W,        ACM-Geometric/models.py:54 + layers.py:86-88)
+//     transA = 1:  C = drop(A)^T B      (dW = dropout(X)^T dZ,    the MmBackward of the same)
+// Only the row-panel kernels carry it (A with many more rows than columns, N <= 192, ...): ACM_EUNSUPPORTED otherwise, and
+// the caller applies acm_dropout itself.  a_drop NULL or p = 0: acm_gemm_blocks.
+extern "C" int acm_gemm_drop(int transA, int transB, int64_t M, int64_t N, int64_t K, const float* A, int64_t lda,
+                             const float* B, int64_t ldb, float* C, int64_t ldc, int64_t c_col_block, int64_t c_block_stride,
+                             int relu, const acm_dropout_t* a_drop, void* workspace, size_t workspace_bytes, acm_stream_t stream) {
+    return gemm_core(transA, transB, M, N, K, A, lda, B, ldb, C, ldc, c_col_block, c_block_stride, 0, nullptr, 0, relu,
+                     workspace, workspace_bytes, stream, nullptr, nullptr, (a_drop && a_drop->p > 0.f) ? a_drop : nullptr);
+}
 
 // Y = dropout(relu?(X W^T + b)): the residual branch of ACM-GCN++ (ACM-Geometric/models.py:26-27,55-56:
 // F.dropout(F.relu(self.mlpX(x))) with mlpX = one nn.Linear) as one GEMM with the bias, the ReLU and the counter-based
@@ -298,7 +325,7 @@ extern "C" int acm_gemm_split(int transA, int transB, int64_t M, int64_t N, int6
 static int gemm_core(int transA, int transB, int64_t M, int64_t N, int64_t K, const float* A, int64_t lda, const float* B,
                      int64_t ldb, float* C, int64_t ldc, int64_t c_col_block, int64_t c_block_stride, int64_t split_col,
                      float* C2, int64_t ldc2, int relu, void* workspace, size_t workspace_bytes, acm_stream_t stream,
-                     const float* bias, const acm_dropout_t* drop_in) {
+                     const float* bias, const acm_dropout_t* drop_in, const acm_dropout_t* a_drop) {
     acm_dropout_t drop = {0.f, 0, 0, nullptr, 0};
     if (drop_in) drop = *drop_in;
     ACM_REQUIRE(drop.p == 0.f || (drop.p > 0.f && drop.p < 1.f && drop.step), ACM_EINVAL, "acm_gemm: bad dropout spec");
@@ -315,6 +342,25 @@ static int gemm_core(int transA, int transB, int64_t M, int64_t N, int64_t K, co
                 "acm_gemm: leading dimension too small (lda %lld ldb %lld ldc %lld)", (long long)lda,
                 (long long)ldb, (long long)ldc);
     hipStream_t st = (hipStream_t)stream;
+    ACM_REQUIRE(!a_drop || (a_drop->p > 0.f && a_drop->p < 1.f && a_drop->step), ACM_EINVAL, "acm_gemm_drop: bad dropout spec");
+    // row-panel forms (acm_gemm_rows.hip): A = the tall node-feature matrix, read exactly once
+    const bool plain_out = !split && !bias && drop.p == 0.f;
+    if (K > 0 && !transA && !transB && plain_out && !cb && acm_gemm_rows_nn_ok(M, N, K, B, ldb))
+        return acm_gemm_rows_nn(M, N, K, A, lda, B, ldb, C, ldc, relu, a_drop, st);
+    if (K > 0 && transA && !transB && plain_out && acm_gemm_rows_tn_ok(K, M, N, B, ldb)) {
+        const int blocks = acm_gemm_rows_tn_blocks(K);
+        const size_t need = (size_t)blocks * (size_t)M * (size_t)N * sizeof(float);
+        ACM_REQUIRE(workspace && workspace_bytes >= need, ACM_ENOMEM, "acm_gemm: workspace %zu B < required %zu B", workspace_bytes, need);
+        int rc = acm_gemm_rows_tn(K, M, N, A, lda, B, ldb, (float*)workspace, blocks, a_drop, st);
+        if (rc != ACM_OK) return rc;
+        const long total = (long)M * N;
+        hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((total + 15) / 16)), dim3(256), 0, st, (int)M, (int)N, blocks,
+                           (const float*)workspace, C, (long)ldc, relu, cb, cbs, 0, (float*)nullptr, 0L, (const float*)nullptr, drop);
+        ACM_CHECK_HIP(hipGetLastError());
+        return ACM_OK;
+    }
+    ACM_REQUIRE(!a_drop, ACM_EUNSUPPORTED, "acm_gemm_drop: the dropout in the tile load exists in the row-panel kernels only "
+                "(tall A, N <= 192; at most 128 columns of A for the transposed product)");
     const GemmPlan p = plan_gemm(M, N, K);
     ACM_REQUIRE(p.grid.y <= 65535 && p.grid.z <= 65535, ACM_EUNSUPPORTED, "acm_gemm: grid too large");
     float* slabs = nullptr;

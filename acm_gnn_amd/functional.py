@@ -440,9 +440,17 @@ def _as_f32_rows(t, name):
 # --------------------------------------------------------------------------
 # raw (non-differentiable) launches
 # --------------------------------------------------------------------------
-def gemm(a, b, trans_a=False, trans_b=False, relu=False, out=None, col_blocks=0):
+def gemm_drop_supported(n_rows, f_in, n_out):
+    """Whether BOTH products of a dense projection -- Z = drop(X) W (NN) and dW = drop(X)^T dZ (TN) -- can take the input
+    dropout in their tile loads (acm_gemm_drop: the row-panel kernels of acm_gemm_rows.hip)."""
+    return (n_rows >= 8192 and 16 <= f_in <= 128 and 1 <= n_out <= 192
+            and os.environ.get("ACM_GEMM_ROWS_OFF") is None and os.environ.get("ACM_GEMM_DROP", "1") != "0")
+
+
+def gemm(a, b, trans_a=False, trans_b=False, relu=False, out=None, col_blocks=0, a_drop=None):
     """out = op(a) @ op(b) on the fp32 MFMA pipe (acm_gemm).  ``col_blocks=j`` returns the product as a
-    contiguous [j, m, n / j] tensor of column blocks (acm_gemm_blocks)."""
+    contiguous [j, m, n / j] tensor of column blocks (acm_gemm_blocks).  ``a_drop``: an acm_dropout_t applied to the stored
+    matrix ``a`` while its tiles are staged (acm_gemm_drop; see gemm_drop_supported)."""
     a, b = _as_f32c(a, "a"), _as_f32c(b, "b")
     m, k = (a.shape[1], a.shape[0]) if trans_a else (a.shape[0], a.shape[1])
     k2, n = (b.shape[1], b.shape[0]) if trans_b else (b.shape[0], b.shape[1])
@@ -461,8 +469,12 @@ def gemm(a, b, trans_a=False, trans_b=False, relu=False, out=None, col_blocks=0)
         _lib.check(lib.acm_gemm_workspace_bytes(int(trans_a), int(trans_b), m, n, k, C.byref(nbytes)))
         ws = torch.empty(max(nbytes.value // 4, 1), dtype=_F32, device=a.device) if nbytes.value else None
         with _device_ctx(a.device), _Timed(f"gemm_{'T' if trans_a else 'N'}{'T' if trans_b else 'N'}/{m}x{n}x{k}"):
-            st = lib.acm_gemm_blocks(int(trans_a), int(trans_b), m, n, k, _vp(a), a.stride(0), _vp(b), b.stride(0),
-                                     _vp(out), nb, nb, m * nb, int(relu), _vp(ws), nbytes.value, _stream())
+            if a_drop is not None:
+                st = lib.acm_gemm_drop(int(trans_a), int(trans_b), m, n, k, _vp(a), a.stride(0), _vp(b), b.stride(0),
+                                       _vp(out), nb, nb, m * nb, int(relu), C.byref(a_drop), _vp(ws), nbytes.value, _stream())
+            else:
+                st = lib.acm_gemm_blocks(int(trans_a), int(trans_b), m, n, k, _vp(a), a.stride(0), _vp(b), b.stride(0),
+                                         _vp(out), nb, nb, m * nb, int(relu), _vp(ws), nbytes.value, _stream())
         _lib.check(st, "acm_gemm_blocks")
         return out
     if out is None:
@@ -471,8 +483,12 @@ def gemm(a, b, trans_a=False, trans_b=False, relu=False, out=None, col_blocks=0)
     _lib.check(lib.acm_gemm_workspace_bytes(int(trans_a), int(trans_b), m, n, k, C.byref(nbytes)))
     ws = torch.empty(max(nbytes.value // 4, 1), dtype=_F32, device=a.device) if nbytes.value else None
     with _device_ctx(a.device), _Timed(f"gemm_{'T' if trans_a else 'N'}{'T' if trans_b else 'N'}/{m}x{n}x{k}"):
-        st = lib.acm_gemm(int(trans_a), int(trans_b), m, n, k, _vp(a), a.stride(0), _vp(b), b.stride(0),
-                          _vp(out), out.stride(0), int(relu), _vp(ws), nbytes.value, _stream())
+        if a_drop is not None:
+            st = lib.acm_gemm_drop(int(trans_a), int(trans_b), m, n, k, _vp(a), a.stride(0), _vp(b), b.stride(0),
+                                   _vp(out), out.stride(0), 0, 0, int(relu), C.byref(a_drop), _vp(ws), nbytes.value, _stream())
+        else:
+            st = lib.acm_gemm(int(trans_a), int(trans_b), m, n, k, _vp(a), a.stride(0), _vp(b), b.stride(0),
+                              _vp(out), out.stride(0), int(relu), _vp(ws), nbytes.value, _stream())
     _lib.check(st, "acm_gemm")
     return out
 
@@ -1015,13 +1031,17 @@ class AcmConvFunction(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, w_low, w_high, w_mlp, v_low, v_high, v_mlp, v_struc, struc_low, att_mix,
                 lnw_low, lnw_high, lnw_mlp, lnw_struc, lnb_low, lnb_high, lnb_mlp, lnb_struc, ops, cfg,
-                post_relu=False, post_scale=None, post_drop=None, call=None, tail_layer=False, agg_holder=None):
+                post_relu=False, post_scale=None, post_drop=None, call=None, tail_layer=False, agg_holder=None,
+                in_drop=None):
         lib = _lib.load()
         ctx.set_materialize_grads(False)          # no zero-filled gradient for the (non-differentiable) att output
         # the model call's context (deferral list, loss-tail request, input pipeline, projection hand-off); ``tail_layer``:
         # the caller is an output layer without post-op working in the operator's numbering (it may take call.tail);
         # ``agg_holder``: layers.GraphConvolution's {"agg": P-or-None} of an evaluation pass over a static input
+        # ``in_drop = (p, tag, DropoutState)``: the caller's INPUT dropout (models.py:54), left to this layer: the dense
+        # projection applies it while staging X (acm_gemm_drop), forward and backward, and X itself is saved un-dropped
         call = ctx.call = _call_or_ambient(call)
+        ctx.in_drop = in_drop if (in_drop is not None and in_drop[0] > 0) else None
         sparse_x = isinstance(x, SparseFeatures)
         if not sparse_x:
             x = _as_f32c(x, "input")
@@ -1150,7 +1170,9 @@ class AcmConvFunction(torch.autograd.Function):
                 if sparse_x:                              # Z = X_csr Wcat: nnz(X) * 3F FMAs
                     spmm_v(x.csr, x.values, wcat, relu=cfg.relu_before, out=z)
                 else:
-                    gemm(x, wcat, relu=cfg.relu_before, out=z)                      # [n, 3F] view
+                    gemm(x, wcat, relu=cfg.relu_before, out=z,                      # [n, 3F] view
+                         a_drop=_drop_spec(ctx.in_drop, ops.row_offset) if ctx.in_drop is not None else None)
+                    ctx.in_drop_used = ctx.in_drop is not None
                 zlh, zi = z[:, : 2 * fb], z[:, 2 * fb:]
             if hops > 1:
                 zc = torch.empty(n, 2 * fb, dtype=_F32, device=dev)              # [A_low^(k-1) Z_L | Z_H]
@@ -1398,7 +1420,7 @@ class AcmConvFunction(torch.autograd.Function):
     @staticmethod
     def backward(ctx, grad_out, _grad_att):
         if grad_out is None:
-            return (None,) * 26
+            return (None,) * 27
         lib = _lib.load()
         ops, cfg = ctx.ops, ctx.cfg
         defer = ctx.call.defer                    # the deferral list of the model call this backward belongs to
@@ -1518,7 +1540,8 @@ class AcmConvFunction(torch.autograd.Function):
                 d_x = proj_bwd(x, dz, w3, d_wcat, defer=defer)                # pass over x (acm_proj_bwd)
         else:
             d_wcat = gemm(x, dz, trans_a=True, col_blocks=3,
-                          out=flat[:nw].view(3, f_in_w, f))                   # contiguous per weight
+                          out=flat[:nw].view(3, f_in_w, f),                   # contiguous per weight
+                          a_drop=_drop_spec(ctx.in_drop, ops.row_offset) if getattr(ctx, "in_drop_used", False) else None)
             d_x = gemm(dz, torch.cat(w3, dim=1), trans_b=True) if ctx.needs_input_grad[0] else None
         if d_x is not None and d_x.shape[1] != ctx.x_width:
             d_x = torch.nn.functional.pad(d_x, (0, ctx.x_width - d_x.shape[1]))
@@ -1537,7 +1560,7 @@ class AcmConvFunction(torch.autograd.Function):
         grads_lnw = (d_lnw + [None] * (4 - k)) if cfg.layernorm else none4
         grads_lnb = (d_lnb + [None] * (4 - k)) if cfg.layernorm else none4
         return (d_x, d_wl, d_wh, d_wm, grads_vec[0], grads_vec[1], grads_vec[2], grads_vec[3],
-                d_struc, d_mix, *grads_lnw, *grads_lnb, None, None, None, None, None, None, None, None)
+                d_struc, d_mix, *grads_lnw, *grads_lnb, None, None, None, None, None, None, None, None, None)
 
 
 def _backward_agg(ctx, grad_out):
@@ -1666,14 +1689,31 @@ def _backward_agg(ctx, grad_out):
     else:
         d_lnw = d_lnb = [None] * 4
     d_mix = d_params[base + 3 * k * f:].view(k, k)
-    return (None, d_wl, d_wh, d_wm, *d_vec, d_struc, d_mix, *d_lnw, *d_lnb, None, None, None, None, None, None, None, None)
+    return (None, d_wl, d_wh, d_wm, *d_vec, d_struc, d_mix, *d_lnw, *d_lnb, None, None, None, None, None, None, None, None, None)
 
 
 AcmConvFunction._backward_agg = staticmethod(_backward_agg)
 
 
+def in_drop_supported(x, ops, cfg, f_in, f_out):
+    """Whether a layer can take its caller's input dropout into its dense projection (AcmConvFunction ``in_drop``): the
+    literal form on the MFMA GEMM (not aggregate-first, not the narrow streaming projection, not CSR features), an input
+    that needs no gradient, shapes the row-panel GEMMs cover."""
+    if isinstance(x, SparseFeatures) or not isinstance(x, torch.Tensor) or x.requires_grad or x.dim() != 2:
+        return False
+    if x.shape[1] != f_in or x.dtype != _F32 or not x.is_contiguous():
+        return False
+    agg_first = not cfg.relu_before and f_in <= 16 and f_in < f_out and f_out <= 64
+    recompute = cfg.relu_before and f_out == 64 and f_in <= 8
+    narrow = f_out <= 5 and f_in <= 64
+    if agg_first or recompute or narrow or f_out in (2, 4, 8):
+        return False
+    fb = _chan_block(f_out)
+    return gemm_drop_supported(x.shape[0], f_in, 2 * fb + f_out)
+
+
 def acm_conv(x, params, ops, cfg, post_relu=False, post_scale=None, post_drop=None, call=None, tail_layer=False,
-             agg_holder=None):
+             agg_holder=None, in_drop=None):
     """params: dict with the reference's parameter names (see layers.GraphConvolution).
     post_relu / post_scale: optional fused ``relu(out) * post_scale`` (the caller's inter-layer
     ReLU + dropout; post_scale = keep_mask / (1 - p)).  post_drop = (p, tag, DropoutState): the same
@@ -1686,4 +1726,4 @@ def acm_conv(x, params, ops, cfg, post_relu=False, post_scale=None, post_drop=No
         p["layer_norm_low.weight"], p["layer_norm_high.weight"], p["layer_norm_mlp.weight"],
         p["layer_norm_struc_low.weight"], p["layer_norm_low.bias"], p["layer_norm_high.bias"],
         p["layer_norm_mlp.bias"], p["layer_norm_struc_low.bias"], ops, cfg, post_relu, post_scale, post_drop,
-        call, tail_layer, agg_holder)
+        call, tail_layer, agg_holder, in_drop)

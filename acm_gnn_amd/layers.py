@@ -95,7 +95,7 @@ class GraphConvolution(nn.Module):
         }
 
     def forward(self, input, adj_low, adj_high=None, adj_low_unnormalized=None, post_relu=False, post_scale=None,
-                post_drop=None, rows_permuted=False, call=None):
+                post_drop=None, rows_permuted=False, call=None, input_drop=None):
         """Reference signature plus optional keyword arguments: ``post_relu`` / ``post_scale`` fuse the
         caller's ``dropout(relu(out))`` (post_scale = keep-mask / (1 - p)) into the kernel epilogue;
         ``post_drop = (p, tag, functional.DropoutState)`` does the same with the mask generated in registers.
@@ -103,6 +103,9 @@ class GraphConvolution(nn.Module):
         ``rows_permuted``: the operators are relabelled (graph.relabel_by_degree) and the caller already works in
         that numbering -- input, post_scale and the result are rows of the relabelled graph (models.GCN keeps the
         hidden activations there); otherwise the layer translates at its boundary.
+        ``input_drop = (p, tag, functional.DropoutState)``: the caller's dropout of ``input`` (models.py:54), applied by this
+        layer -- inside the dense projection's tile loads where the shapes allow (functional.in_drop_supported), as a launch
+        of its own otherwise.
         ``call``: the model call's functional.CallContext (models.GCN passes one per forward; default: a fresh one derived
         from the calling thread's ``with functional.deferred_reductions() / fused_loss_tail()`` blocks)."""
         mt = self.model_type
@@ -134,8 +137,12 @@ class GraphConvolution(nn.Module):
         # the request's labels / weights are rows of the numbering the layer works in
         tail_layer = (bool(self.output_layer) and not post_relu and post_scale is None and post_drop is None
                       and not translate)
+        if input_drop is not None and not AF.in_drop_supported(input, ops, cfg, self.in_features, self.out_features):
+            p_in, tag_in, st_in = input_drop          # the projection cannot carry it: the dropped copy, as a launch of its own
+            input = AF.dropout(input, p_in, st_in, tag=tag_in, row_offset=ops.row_offset)
+            input_drop = None
         out, att = AF.acm_conv(input, params, ops, cfg, post_relu, post_scale, post_drop, call=call,
-                               tail_layer=tail_layer, agg_holder=self._eval_agg_holder(raw_input, ops))
+                               tail_layer=tail_layer, agg_holder=self._eval_agg_holder(raw_input, ops), in_drop=input_drop)
         if translate:
             out = out.index_select(0, ops.inv_perm)
         # the mixing weights stay where the kernel wrote them; the attributes translate rows when they are read

@@ -106,9 +106,9 @@ class GCN(nn.Module):
             self.dropout_state = AF.DropoutState(dev)
         st = self.dropout_state
         off = adj_low.row_offset if isinstance(adj_low, FilterOperators) else 0
+        kw = {}
         if isinstance(x, SparseFeatures):
             x = x.with_values(AF.dropout(x.values.reshape(-1, 1), p, st, tag=0).reshape(-1))
-            kw = {}
         else:
             nfeat = x.shape[1]
             pad = AF.agg_pad_width(nfeat)
@@ -122,11 +122,16 @@ class GCN(nn.Module):
             elif (call.pipe is not None and call.pipe.primed and call.pipe.ops is ops and call.pipe.state is st
                     and call.pipe.x.data_ptr() == x.data_ptr() and call.pipe.x.shape == x.shape and torch.is_grad_enabled()):
                 x = call.pipe.table()         # dropout_t(x), drawn one step ahead (functional.InputPipeline)
+            elif (self.model_type in ("acmgcn", "acmgcnp", "acmsgc") and pad == nfeat and not x.requires_grad
+                    and AF.in_drop_supported(x, ops, self.gcns[0]._config(), nfeat, self.gcns[0].out_features)
+                    if ops is not None else False):
+                # a wide dense input: the first layer's projection applies the input dropout while it stages X (forward
+                # and backward); the dropped copy of X is never written
+                kw = {"input_drop": (p, 0, st)}
             else:
                 x = AF.dropout(x, p, st, tag=0, pad_to=pad, row_offset=off)
-            kw = {}
         if self.model_type == "acmsgc":
-            return self.gcns[0](x, adj_low, adj_high, adj_low_unnormalized, rows_permuted=self._rows_permuted, call=call)
+            return self.gcns[0](x, adj_low, adj_high, adj_low_unnormalized, rows_permuted=self._rows_permuted, call=call, **kw)
         if self.model_type == "acmgcnpp":
             xx = self._residual(x, adj_low, drop=(p, 2, st, off), call=call)
         # the output layer's narrow projection may ride the hidden layer's epilogue (CallContext.next_proj / pre_proj); not

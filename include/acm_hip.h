@@ -186,6 +186,19 @@ typedef struct {
 int acm_dropout(int64_t n_rows, int64_t n_cols, const float* src, int64_t ld_src,
                 float* dst, int64_t ld_dst, int64_t dst_cols, const acm_dropout_t* d, acm_stream_t stream);
 
+/* The same product with the counter-based dropout (acm_dropout_t) applied to the STORED matrix A while
+ * its tiles are staged -- A = the node-feature matrix X, whichever side of the product it is on:
+ *     transA = 0:  C = drop(A) B        Z  = dropout(X) W        (ACM-Geometric/models.py:54 + layers.py:86-88,101-103)
+ *     transA = 1:  C = drop(A)^T B      dW = dropout(X)^T dZ     (the MmBackward of the same)
+ * so the dropped copy of X is never written (173 MB written and read on the arXiv-year-shaped graph).  Carried by the
+ * row-panel kernels only (A much taller than wide: >= 4096 rows, 16..4096 columns; N <= 192; for transA = 1: >= 8192 rows
+ * and at most 128 columns of A): ACM_EUNSUPPORTED otherwise -- the caller then applies acm_dropout itself.
+ * a_drop NULL or p = 0: acm_gemm_blocks.  Workspace: acm_gemm_workspace_bytes. (ABI 20) */
+int acm_gemm_drop(int transA, int transB, int64_t M, int64_t N, int64_t K,
+                  const float* A, int64_t lda, const float* B, int64_t ldb,
+                  float* C, int64_t ldc, int64_t c_col_block, int64_t c_block_stride, int relu,
+                  const acm_dropout_t* a_drop, void* workspace, size_t workspace_bytes, acm_stream_t stream);
+
 /* ------------------------------------------------ deferred final reductions --
  * Every backward kernel that produces parameter gradients (acm_conv_bwd_local, acm_proj_bwd, acm_conv_agg_bwd) and
  * acm_nll_loss end in the same second phase: per-block partial sums in the call's workspace, summed by one block per

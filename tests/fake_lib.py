@@ -480,6 +480,32 @@ class FakeLib:
         _view(c2, m, n - split, ldc2)[...] = out[:, split:]
         return 0
 
+    def acm_gemm_drop(self, ta, tb, m, n, k, a, lda, b, ldb, c, ldc, cb, cbs, relu, drop, ws, wsb, stream):
+        """acm_gemm_blocks with the dropout applied to the stored matrix A (ABI 20); the shape envelope of the row-panel
+        kernels is enforced like the library does."""
+        d = self._drop_obj(drop)
+        if d is None or d.p <= 0:
+            return self.acm_gemm_blocks(ta, tb, m, n, k, a, lda, b, ldb, c, ldc, cb, cbs, relu, ws, wsb, stream)
+        rows, cols = (k, m) if ta else (m, k)
+        ok = (not tb and 1 <= n <= 192 and 16 <= cols and
+              ((not ta and rows >= 4096 and cols <= 4096) or (ta and rows >= 8192 and cols <= 128)))
+        if not ok:
+            self._err = b"acm_gemm_drop: the dropout in the tile load exists in the row-panel kernels only"
+            return 4
+        A = _view(a, rows, cols, lda).astype(np.float64) * dropout_factors(d, rows, cols)
+        A = A.T if ta else A
+        out = A @ _view(b, k, n, ldb).astype(np.float64)
+        if relu:
+            out = np.maximum(out, 0)
+        if not cb:
+            _view(c, m, n, ldc)[...] = out
+            return 0
+        for j, n0 in enumerate(range(0, n, cb)):
+            w = min(cb, n - n0)
+            base = c.value if isinstance(c, C.c_void_p) else int(c)
+            _view(base + 4 * j * cbs, m, w, ldc)[...] = out[:, n0:n0 + w]
+        return 0
+
     def acm_gemm_blocks(self, ta, tb, m, n, k, a, lda, b, ldb, c, ldc, cb, cbs, relu, ws, wsb, stream):
         if not cb:
             return self.acm_gemm(ta, tb, m, n, k, a, lda, b, ldb, c, ldc, relu, ws, wsb, stream)

@@ -314,3 +314,70 @@ def test_wide_gather_forms_match_scipy(width, mode, monkeypatch):
     ones = sp.csr_matrix((np.ones(m.nnz), m.indices, m.indptr), shape=m.shape)
     np.testing.assert_allclose(AF.spmm(pat, dense.to(DEV)).cpu().numpy(), ones @ np.nan_to_num(dense.double().numpy()),
                                rtol=1e-5, atol=4e-5)
+
+
+ROWS_NN = [(9000, 192, 128), (4100, 21, 100), (20000, 15, 64), (168114, 192, 128), (5000, 64, 300), (8192, 180, 17)]
+
+
+@pytest.mark.parametrize("m,n,k", ROWS_NN)
+def test_row_panel_gemm_equals_the_tile_kernel_bit_for_bit(m, n, k, monkeypatch):
+    """acm_gemm_rows.hip (NN): a tall A (>= 4096 rows) takes the row-panel kernel -- A read once, all N columns per
+    workgroup.  Both kernels are k-ordered fmaf chains on the fp32 MFMA, so their results are IDENTICAL, ragged shapes and
+    the ReLU epilogue included; and integer inputs are exact."""
+    from acm_gnn_amd import functional as AF
+    g = torch.Generator().manual_seed(m + n + k)
+    a, b = torch.randn(m, k, generator=g).to(DEV), torch.randn(k, n, generator=g).to(DEV)
+    timer = AF.KernelTimer()
+    new = AF.gemm(a, b, relu=True)
+    monkeypatch.setenv("ACM_GEMM_ROWS_OFF", "1")
+    old = AF.gemm(a, b, relu=True)
+    monkeypatch.delenv("ACM_GEMM_ROWS_OFF")
+    assert torch.equal(new, old)
+    ai, bi = torch.randint(-8, 9, (m, k), generator=g).float(), torch.randint(-8, 9, (k, n), generator=g).float()
+    assert torch.equal(AF.gemm(ai.to(DEV), bi.to(DEV)).cpu(), ai @ bi)
+    out = torch.full((m, n + 5), 3.0, device=DEV)                     # a strided destination keeps its padding
+    AF.gemm(a, b, out=out[:, 2:2 + n])
+    assert torch.equal(out[:, 2:2 + n], AF.gemm(a, b)) and float((out[:, :2] - 3).abs().max()) == 0 and float((out[:, 2 + n:] - 3).abs().max()) == 0
+
+
+@pytest.mark.parametrize("rows,f_in,n,blocks", [(9000, 128, 192, 3), (20001, 100, 15, 3), (168114, 128, 192, 3), (8192, 17, 21, 0),
+                                                (40000, 64, 180, 0)])
+def test_row_panel_transposed_gemm_matches_fp64(rows, f_in, n, blocks):
+    """acm_gemm_rows.hip (TN): dW = X^T dZ over >= 8192 rows as one K x N slab per workgroup + the deterministic slab sum;
+    vs float64, as column blocks too, and bit-identical from launch to launch."""
+    from acm_gnn_amd import functional as AF
+    g = torch.Generator().manual_seed(rows + f_in + n)
+    x, dz = torch.randn(rows, f_in, generator=g), torch.randn(rows, n, generator=g)
+    ref = x.double().T @ dz.double()
+    scale = x.abs().double().T @ dz.abs().double()
+    got = AF.gemm(x.to(DEV), dz.to(DEV), trans_a=True)
+    assert float(((got.cpu().double() - ref).abs() / (scale + 1e-30)).max()) < 3e-6
+    assert torch.equal(got, AF.gemm(x.to(DEV), dz.to(DEV), trans_a=True))
+    if blocks:
+        parts = AF.gemm(x.to(DEV), dz.to(DEV), trans_a=True, col_blocks=blocks)
+        assert torch.equal(torch.cat(list(parts), dim=1), got)
+
+
+@pytest.mark.parametrize("rows,f_in,n", [(9000, 128, 192), (20001, 100, 15), (8200, 17, 21), (168114, 128, 192)])
+def test_gemm_with_the_input_dropout_in_the_tile_load(rows, f_in, n):
+    """acm_gemm_drop: Z = drop(X) W and dW = drop(X)^T dZ with the counter-based mask drawn while X is staged equal the
+    products of the dropped copy acm_dropout writes (same mask: numpy Philox, oracle/philox.py) -- NN bit for bit (same
+    fmaf chain on the same operand values), TN to fp32 summation order."""
+    from acm_gnn_amd import functional as AF
+    from oracle.philox import dropout_factors
+    g = torch.Generator().manual_seed(rows + n)
+    x, w, dz = torch.randn(rows, f_in, generator=g).to(DEV), torch.randn(f_in, n, generator=g).to(DEV), torch.randn(rows, n, generator=g).to(DEV)
+    st = AF.DropoutState(torch.device(DEV), seed=77)
+    st.step.fill_(5)
+    p, tag, off = 0.35, 0, 1000
+    xd = AF.dropout(x, p, st, tag=tag, row_offset=off)                  # the dropped copy (acm_dropout)
+    keep = torch.from_numpy(dropout_factors(st.seed, 5, tag, p, rows, f_in, row_offset=off) > 0)
+    assert torch.equal(xd.cpu() != 0, keep & (x.cpu() != 0))            # ... is the numpy mask
+    spec = st.spec(p, tag, off)
+    z = AF.gemm(x, w, relu=True, a_drop=spec)
+    assert torch.equal(z, AF.gemm(xd, w, relu=True))
+    dw = AF.gemm(x, dz, trans_a=True, a_drop=spec)
+    ref = xd.cpu().double().T @ dz.cpu().double()
+    scale = xd.cpu().abs().double().T @ dz.cpu().abs().double()
+    assert float(((dw.cpu().double() - ref).abs() / (scale + 1e-30)).max()) < 3e-6
+    assert torch.equal(dw, AF.gemm(xd, dz, trans_a=True))               # the same kernel on the dropped copy: identical

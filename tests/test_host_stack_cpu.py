@@ -1000,3 +1000,39 @@ def test_output_layer_projection_backward_rides_the_hidden_layers_backward(monke
         torch.testing.assert_close(g_a[k], g_b[k], rtol=1e-5, atol=1e-6, msg=lambda m, k=k: f"{k}: {m}")
     _, _, calls_c = run("acmgcnpp", True)
     assert "agg_bwd+proj" not in calls_c and "proj_bwd" in calls_c, calls_c
+
+
+@pytest.mark.parametrize("model_type,hops", [("acmgcnp", 1), ("acmsgc", 3)])
+def test_input_dropout_rides_the_dense_projection(monkeypatch, model_type, hops):
+    """acm_gemm_drop (ABI 20): for a wide dense input the first layer's projection Z = drop(X) W and its backward
+    dW = drop(X)^T dZ draw the input-dropout mask while they stage X (ACM-Geometric/models.py:54 + layers.py:86-88), so
+    the separate acm_dropout pass and the dropped copy of X disappear; same loss and gradients as with ACM_GEMM_DROP=0."""
+    fake = fake_lib.install(monkeypatch)
+    from acm_gnn_amd import GCN, functional as AF
+    ops, n = _dense_graph_ops(n=8192, avg=14, seed=2)
+    ops.hops = hops
+    x = torch.randn(n, 128, generator=torch.Generator().manual_seed(1))
+    calls = []
+    for name in ("acm_gemm_drop", "acm_dropout"):
+        orig = getattr(fake, name)
+        monkeypatch.setattr(fake, name, (lambda o, nm: lambda *a: (calls.append(nm), o(*a))[1])(orig, name))
+
+    def run(fused):
+        monkeypatch.setenv("ACM_GEMM_DROP", "1" if fused else "0")
+        calls.clear()
+        torch.manual_seed(5)
+        model = GCN(128, 64, 5, 2, n, 0.4, model_type, 0, variant=0, attn_layernorm=True)
+        model.train()
+        model.fused_dropout, model.dropout_state = True, AF.DropoutState(torch.device("cpu"), seed=9)
+        out = model(x, ops)
+        out.square().sum().backward()
+        return out.detach(), {k: p.grad.clone() for k, p in model.named_parameters() if p.grad is not None}, list(calls)
+
+    out_a, g_a, calls_a = run(True)
+    out_b, g_b, calls_b = run(False)
+    assert calls_a.count("acm_gemm_drop") == 2 and "acm_dropout" not in calls_a, calls_a          # forward + backward
+    assert "acm_gemm_drop" not in calls_b and calls_b.count("acm_dropout") >= 1, calls_b
+    torch.testing.assert_close(out_a, out_b, rtol=1e-6, atol=1e-6 * float(out_b.abs().max()))
+    assert g_a.keys() == g_b.keys()
+    for k in g_a:
+        torch.testing.assert_close(g_a[k], g_b[k], rtol=1e-5, atol=1e-5 * float(g_b[k].abs().max()), msg=lambda m, k=k: f"{k}: {m}")
