@@ -223,6 +223,7 @@ def _declare(lib):
     lib.acm_proj_bwd.argtypes = [i64, i64, i32, vp, i64, vp, i64, vp, vp, vp, i64, vp, i64, vp, i64, i64, i64, vp, sz, vp, vp]
     lib.acm_gemm_split.argtypes = [i32, i32, i64, i64, i64, vp, i64, vp, i64, vp, i64, i64, vp, i64, i32, vp, sz, vp]
     lib.acm_gemm_blocks.argtypes = [i32, i32, i64, i64, i64, vp, i64, vp, i64, vp, i64, i64, i64, i32, vp, sz, vp]
+    lib.acm_gemm_drop.argtypes = [i32, i32, i64, i64, i64, vp, i64, vp, i64, vp, i64, i64, i64, i32, C.POINTER(Dropout), vp, sz, vp]
     lib.acm_spmm.argtypes = [vp, vp, i64, i32, vp, i64, vp, sz, vp]
     lib.acm_spmm_v.argtypes = [vp, vp, vp, i64, i32, vp, i64, i32, vp, sz, vp]
     lib.acm_adam_step.argtypes = [i32, vp, vp, vp]

@@ -261,7 +261,7 @@ extern "C" int acm_gemm_workspace_bytes(int transA, int transB, int64_t M, int64
     ACM_REQUIRE(M >= 0 && N >= 0 && K >= 0, ACM_ESHAPE, "acm_gemm_workspace_bytes: negative size");
     const GemmPlan p = plan_gemm(M, N, K);
     size_t need = p.splits > 1 ? (size_t)p.splits * (size_t)M * (size_t)N * sizeof(float) : 0;
-    if (transA && !transB && acm_gemm_rows_tn_ok(K, M, N, nullptr, 4)) {        // the row-panel form: one slab per workgroup
+    if (transA && !transB && acm_gemm_rows_tn_ok(K, M, N, nullptr, 4)) {        // the row-panel form (may be taken): one slab per workgroup
         const size_t rows = (size_t)acm_gemm_rows_tn_blocks(K) * (size_t)M * (size_t)N * sizeof(float);
         need = rows > need ? rows : need;
     }
@@ -345,9 +345,15 @@ static int gemm_core(int transA, int transB, int64_t M, int64_t N, int64_t K, co
     ACM_REQUIRE(!a_drop || (a_drop->p > 0.f && a_drop->p < 1.f && a_drop->step), ACM_EINVAL, "acm_gemm_drop: bad dropout spec");
     // row-panel forms (acm_gemm_rows.hip): A = the tall node-feature matrix, read exactly once
     const bool plain_out = !split && !bias && drop.p == 0.f;
-    if (K > 0 && !transA && !transB && plain_out && !cb && acm_gemm_rows_nn_ok(M, N, K, B, ldb))
+    // Measured on the arXiv-year projection shapes (scripts/probe_gemm_rows.py -> profiles/r03_gemm_rows.txt), us, row-panel
+    // against tile kernel:  NN 169343 x 192 x 128: 140 / 131;  x 21: 31 / 44;  TN 128 x 192 x 169343: 127 / 150;  x 41554: 53 / 41
+    // -- one wave per SIMD serialises matrix pipe (43 % busy), staging and stores in the row-panel NN.  So without a dropout
+    // to carry, the row-panel forms take only the shapes they win: narrow outputs (NN), very tall contractions (TN).
+    if (K > 0 && !transA && !transB && plain_out && !cb && acm_gemm_rows_nn_ok(M, N, K, B, ldb) &&
+        (a_drop || N <= 64 || getenv("ACM_GEMM_ROWS_ALWAYS")))
         return acm_gemm_rows_nn(M, N, K, A, lda, B, ldb, C, ldc, relu, a_drop, st);
-    if (K > 0 && transA && !transB && plain_out && acm_gemm_rows_tn_ok(K, M, N, B, ldb)) {
+    if (K > 0 && transA && !transB && plain_out && acm_gemm_rows_tn_ok(K, M, N, B, ldb) &&
+        (a_drop || K >= 100000 || getenv("ACM_GEMM_ROWS_ALWAYS"))) {
         const int blocks = acm_gemm_rows_tn_blocks(K);
         const size_t need = (size_t)blocks * (size_t)M * (size_t)N * sizeof(float);
         ACM_REQUIRE(workspace && workspace_bytes >= need, ACM_ENOMEM, "acm_gemm: workspace %zu B < required %zu B", workspace_bytes, need);

@@ -24,6 +24,35 @@ constexpr int RBM = 64;            // rows per workgroup (NN): 73 KB of LDS at N
 
 __device__ __forceinline__ int pad16(int n) { return ((n + 31) / 32) * 32 + 16; }   // row stride = 16 mod 32 floats
 
+// The contraction loop over KS steps of four: the NEXT step's operands are read from LDS (1 + NT dwords per lane) before the
+// current step's MFMAs are issued -- two register sets, so the reads never wait on the matrix pipe and the MFMAs never wait on
+// an LDS round trip (hipcc otherwise reuses one register pair: read, wait, two MFMAs, read, wait, ...).
+template <int NT, int NA>
+__device__ __forceinline__ void mma_steps(const float* __restrict__ As, int sa, int a_off, const float* __restrict__ Bs, int sb,
+                                          int m, int g, int ksteps, f32x4 (&acc)[NA][NT]) {
+    float a0[NA], b0[NT], a1[NA], b1[NT];
+    auto rd = [&](int ks, float (&a)[NA], float (&b)[NT]) {
+        const int kk = 4 * ks + g;
+#pragma unroll
+        for (int i = 0; i < NA; ++i) a[i] = As[kk * sa + a_off + 16 * i + m];
+#pragma unroll
+        for (int j = 0; j < NT; ++j) b[j] = Bs[kk * sb + 16 * j + m];
+    };
+    auto mm = [&](const float (&a)[NA], const float (&b)[NT]) {
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+            for (int i = 0; i < NA; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], b[j], acc[i][j], 0, 0, 0);
+    };
+    rd(0, a0, b0);
+    for (int ks = 0; ks < ksteps; ks += 2) {       // ksteps is even (slabs of 64 columns)
+        rd(ks + 1, a1, b1);
+        mm(a0, b0);
+        if (ks + 2 < ksteps) rd(ks + 2, a0, b0);
+        mm(a1, b1);
+    }
+}
+
 // ---- NN: C[m0 .. m0+64, 0 .. N) = drop(A)[.., K] B[K, N];  NT = N / 16 column tiles (<= 12), wave w: rows 16 w .. 16 w + 15
 template <int NT>
 __global__ __launch_bounds__(256) void gemm_rows_nn_kernel(int M, int N, int K, const float* __restrict__ A, long lda,
@@ -37,9 +66,9 @@ __global__ __launch_bounds__(256) void gemm_rows_nn_kernel(int M, int N, int K, 
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, m = lane & 15, g = lane >> 4;
     const int m0 = blockIdx.x * RBM;
     const AcmDropCtx dc = acm_drop_ctx(drop);
-    f32x4 acc[NT];
+    f32x4 acc[1][NT];
 #pragma unroll
-    for (int j = 0; j < NT; ++j) acc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int j = 0; j < NT; ++j) acc[0][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
     // staging: thread t handles pairs (row = t / 16 + 16 i, c = t % 16), i = 0..3: columns k0 + c + 16 q, q = 0..3
     const int sc = threadIdx.x & 15, sr = threadIdx.x >> 4;
     for (int k0 = 0; k0 < K; k0 += RBK) {
@@ -80,14 +109,7 @@ __global__ __launch_bounds__(256) void gemm_rows_nn_kernel(int M, int N, int K, 
             *reinterpret_cast<f32x4*>(Bs + kk * SB + 4 * c4) = v;
         }
         __syncthreads();
-#pragma unroll 4
-        for (int ks = 0; ks < RBK / 4; ++ks) {
-            const int kk = 4 * ks + g;
-            const float a0 = As[kk * SA + 16 * wv + m];
-#pragma unroll
-            for (int j = 0; j < NT; ++j)
-                acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, Bs[kk * SB + 16 * j + m], acc[j], 0, 0, 0);
-        }
+        mma_steps<NT, 1>(As, SA, 16 * wv, Bs, SB, m, g, RBK / 4, acc);
     }
 #pragma unroll
     for (int j = 0; j < NT; ++j)
@@ -95,11 +117,99 @@ __global__ __launch_bounds__(256) void gemm_rows_nn_kernel(int M, int N, int K, 
         for (int r = 0; r < 4; ++r) {
             const int row = m0 + 16 * wv + 4 * g + r, col = 16 * j + m;
             if (row < M && col < N) {
-                float v = acc[j][r];
+                float v = acc[0][j][r];
                 if (relu) v = fmaxf(v, 0.f);
                 C[(long)row * ldc + col] = v;
             }
         }
+}
+
+// ---- NN with the whole B resident (K <= 128: the ACM projections of a 128-feature input): a persistent workgroup per CU
+// stages W once (106 KB at N = 192), then walks 64-row panels of A -- the next panel's 32 floats per thread are requested
+// before the current panel feeds the matrix pipe, masked and parked in LDS after it.
+template <int NT>
+__global__ __launch_bounds__(256) void gemm_rows_nn_wres_kernel(int M, int N, int K, const float* __restrict__ A, long lda,
+                                                                const float* __restrict__ B, long ldb, float* __restrict__ C, long ldc,
+                                                                int relu, acm_dropout_t drop, int vecb) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    constexpr int SA = RBM + 17;               // As[k][row]: 81 -- the staging writes (16 columns x 4 rows per wave) spread over the
+                                               // banks (17 c + r), the operand reads of the two row groups stay apart
+    const int SB = pad16(NT * 16);
+    const int KP = (K + 63) / 64 * 64;         // K padded to whole 64-column groups (zero rows / columns)
+    float* Ws = lds;                           // KP x SB
+    float* As = lds + KP * SB;                 // KP x SA
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, m = lane & 15, g = lane >> 4;
+    const AcmDropCtx dc = acm_drop_ctx(drop);
+    for (int idx = threadIdx.x; idx < KP * NT * 4; idx += 256) {
+        const int kk = idx / (NT * 4), c4 = idx % (NT * 4);
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (kk < K && 4 * c4 < N) {
+            const float* src = B + (long)kk * ldb + 4 * c4;
+            if (vecb) v = *reinterpret_cast<const f32x4*>(src);
+            else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = (4 * c4 + e < N) ? src[e] : 0.f;
+            }
+        }
+        *reinterpret_cast<f32x4*>(Ws + kk * SB + 4 * c4) = v;
+    }
+    const int sc = threadIdx.x & 15, sr = threadIdx.x >> 4;
+    const int npanels = (M + RBM - 1) / RBM;
+    float av[2][RBM / 16][4];                  // [64-column group][row quarter][q]
+    auto fetch = [&](int panel) {
+#pragma unroll
+        for (int grp = 0; grp < 2; ++grp)
+#pragma unroll
+            for (int i = 0; i < RBM / 16; ++i) {
+                const int row = panel * RBM + sr + 16 * i;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int col = 64 * grp + sc + 16 * q;
+                    av[grp][i][q] = (row < M && col < K) ? A[(long)row * lda + col] : 0.f;
+                }
+            }
+    };
+    auto park = [&](int panel) {
+#pragma unroll
+        for (int grp = 0; grp < 2; ++grp) {
+            if (64 * grp >= KP) continue;
+#pragma unroll
+            for (int i = 0; i < RBM / 16; ++i) {
+                const int r = sr + 16 * i, row = panel * RBM + r;
+                if (dc.on) {
+                    unsigned w[4];
+                    acm_philox7(dc, row, sc + 16 * grp, w);
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) av[grp][i][q] = (w[q] >= dc.thresh) ? av[grp][i][q] * dc.inv_keep : 0.f;
+                }
+#pragma unroll
+                for (int q = 0; q < 4; ++q) As[(64 * grp + sc + 16 * q) * SA + r] = av[grp][i][q];
+            }
+        }
+    };
+    int panel = blockIdx.x;
+    if (panel < npanels) fetch(panel);
+    for (; panel < npanels; panel += gridDim.x) {
+        __syncthreads();                        // W staged (first round) / every wave done with the previous panel
+        park(panel);
+        __syncthreads();
+        if (panel + (int)gridDim.x < npanels) fetch(panel + gridDim.x);
+        f32x4 acc[1][NT];
+#pragma unroll
+        for (int j = 0; j < NT; ++j) acc[0][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        mma_steps<NT, 1>(As, SA, 16 * wv, Ws, SB, m, g, KP / 4, acc);
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = panel * RBM + 16 * wv + 4 * g + r, col = 16 * j + m;
+                if (row < M && col < N) {
+                    float v = acc[0][j][r];
+                    if (relu) v = fmaxf(v, 0.f);
+                    C[(long)row * ldc + col] = v;
+                }
+            }
+    }
 }
 
 // ---- TN: slab[b][K, N] = drop(X)[rows of block b]^T dZ[rows of block b];  KT = ceil(K / 16) <= 8 row tiles of the output,
@@ -183,19 +293,7 @@ __global__ __launch_bounds__(256) void gemm_rows_tn_kernel(int n_rows, int K, in
         __syncthreads();                        // the slab is in LDS
         const bool more = r0 + RBK < r_end;
         if (more) fetch(r0 + RBK);
-        if (wave_live) {
-#pragma unroll 4
-            for (int ks = 0; ks < RBK / 4; ++ks) {
-                const int kk = 4 * ks + g;
-                const float a0 = Xs[kk * SX + 32 * wv + m], a1 = Xs[kk * SX + 32 * wv + 16 + m];
-#pragma unroll
-                for (int j = 0; j < NT; ++j) {
-                    const float b = Bs[kk * SB + 16 * j + m];
-                    acc[0][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b, acc[0][j], 0, 0, 0);
-                    acc[1][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b, acc[1][j], 0, 0, 0);
-                }
-            }
-        }
+        if (wave_live) mma_steps<NT, 2>(Xs, SX, 32 * wv, Bs, SB, m, g, RBK / 4, acc);
         __syncthreads();                        // every wave is done reading the slab
         if (more) park(r0 + RBK);
     }
@@ -230,8 +328,34 @@ int acm_gemm_rows_nn(int64_t M, int64_t N, int64_t K, const float* A, int64_t ld
     acm_dropout_t drop = {0.f, 0, 0, nullptr, 0, 0};
     if (drop_in) drop = *drop_in;
     const int nt = (int)((N + 15) / 16);
-    const int grid = (int)((M + RBM - 1) / RBM);
-    const size_t lds = ((size_t)RBK * (RBM + 16) + (size_t)RBK * (((nt * 16 + 31) / 32) * 32 + 16)) * sizeof(float);
+    int grid = (int)((M + RBM - 1) / RBM);
+    const int ntr = nt <= 4 ? nt : (nt <= 6 ? 6 : (nt <= 8 ? 8 : (nt <= 10 ? 10 : 12)));      // the instantiated tile counts
+    if (K <= 128 && getenv("ACM_GEMM_WRES_OFF") == nullptr) {          // B resident, persistent workgroups
+        const int kp = (int)((K + 63) / 64 * 64);
+        const size_t lds_w = ((size_t)kp * (((ntr * 16 + 31) / 32) * 32 + 16) + (size_t)kp * (RBM + 17)) * sizeof(float);
+        const int blocks_per_cu = lds_w <= 48 * 1024 ? 3 : (lds_w <= 78 * 1024 ? 2 : 1);
+        if (grid > 256 * blocks_per_cu) grid = 256 * blocks_per_cu;
+#define ACM_RNW(NTv)                                                                                                    \
+    do {                                                                                                                \
+        ACM_CHECK_HIP(hipFuncSetAttribute((const void*)gemm_rows_nn_wres_kernel<NTv>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_w)); \
+        hipLaunchKernelGGL((gemm_rows_nn_wres_kernel<NTv>), dim3(grid), dim3(256), lds_w, st, (int)M, (int)N, (int)K, A, (long)lda, B, \
+                           (long)ldb, C, (long)ldc, relu, drop, rows_vecb(N, B, ldb));                                  \
+    } while (0)
+        switch (ntr) {
+            case 1: ACM_RNW(1); break;
+            case 2: ACM_RNW(2); break;
+            case 3: ACM_RNW(3); break;
+            case 4: ACM_RNW(4); break;
+            case 6: ACM_RNW(6); break;
+            case 8: ACM_RNW(8); break;
+            case 10: ACM_RNW(10); break;
+            default: ACM_RNW(12); break;
+        }
+#undef ACM_RNW
+        ACM_CHECK_HIP(hipGetLastError());
+        return ACM_OK;
+    }
+    const size_t lds = ((size_t)RBK * (RBM + 16) + (size_t)RBK * (((ntr * 16 + 31) / 32) * 32 + 16)) * sizeof(float);
 #define ACM_RNN(NTv)                                                                                                    \
     do {                                                                                                                \
         ACM_CHECK_HIP(hipFuncSetAttribute((const void*)gemm_rows_nn_kernel<NTv>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
