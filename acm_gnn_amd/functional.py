@@ -288,12 +288,23 @@ class InputPipeline:
     eager steps; a captured graph replays without host code, so there the caller has to)."""
 
     def __init__(self, ops, x, p, state, tag=0):
-        n = x.shape[0]
-        self.ops, self.x, self.p, self.state, self.tag = ops, x, float(p), state, int(tag)
-        self.filled = torch.zeros(2, n, 8, dtype=_F32, device=x.device)
+        # Row-sharded with equal blocks and the replicated input registered (ops.x_full): every rank draws the dropped
+        # input of ALL nodes itself (the mask is a function of the global position), so the table has every node's row,
+        # P and the saved copies this rank's rows only, and the carried gather needs no exchange -- N ranks run the same
+        # step as one.
+        self.x_rows = x                                   # the rows the caller hands the model
+        src = ops.x_full if getattr(ops, "sharded", False) else x
+        n_tab, n = src.shape[0], x.shape[0]
+        self.row_offset = int(getattr(ops, "row_offset", 0)) if getattr(ops, "sharded", False) else 0
+        self.ops, self.x, self.p, self.state, self.tag = ops, src, float(p), state, int(tag)
+        if n_tab == n:
+            both = torch.zeros(2, n, 8, dtype=_F32, device=x.device)
+            self.filled = (both[0], both[1])
+        else:
+            self.filled = (torch.zeros(n_tab, 8, dtype=_F32, device=x.device), torch.zeros(n, 8, dtype=_F32, device=x.device))
         self.saved = torch.zeros(2, n, 8, dtype=_F32, device=x.device)
         self.primed = False
-        self._x_version = x._version
+        self._x_version = (src._version, x._version)
         self._host_steps = state.host_steps
         self.next_table_ready = False
         self.next_agg_ready = False
@@ -319,8 +330,13 @@ class InputPipeline:
             return False
         if cfg.relu_before or cfg.n_channels != 3 or f != 64 or not 4 < f_in <= 8 or x.dim() != 2 or x.shape[1] != f_in:
             return False
-        if ops.sharded or not ops.implicit or getattr(ops, "general", False) or int(getattr(ops, "hops", 1)) != 1:
+        if not ops.implicit or getattr(ops, "general", False) or int(getattr(ops, "hops", 1)) != 1:
             return False
+        if ops.sharded:                          # equal blocks + the replicated input: the table is drawn locally (no halo)
+            xf = ops.x_full
+            if (not ops.uniform or xf is None or xf.dtype != _F32 or xf.dim() != 2 or xf.shape != (ops.low.n_cols, f_in)
+                    or xf.device != x.device or xf.requires_grad or os.environ.get("ACM_PIPELINE_SHARDED", "1") == "0"):
+                return False
         if x.dtype != _F32 or x.device != l0.weight_low.device or x.requires_grad:
             return False
         n, nnz = ops.low.n_rows, ops.low.nnz
@@ -336,7 +352,12 @@ class InputPipeline:
         return ops.low.stream_waves % gw == 0 and gw <= ops.low.stream_waves <= min(256 * gw, gw * ((n + 15) // 16))
 
     def table(self):
+        """dropout_t(x) of every node the operator's columns name, padded to 8 columns."""
         return self.filled[0]
+
+    def local_table(self):
+        """This rank's rows of table() (all of it on one device)."""
+        return self.filled[0][self.row_offset:self.row_offset + self.x_rows.shape[0]]
 
     def agg(self):
         return self.filled[1]
@@ -352,14 +373,14 @@ class InputPipeline:
     def stale(self):
         """The buffers do not belong to the step about to run: never filled, the features edited in place, a step that
         did not finish (exception between make_next and end_step), or the counter advanced by someone else."""
-        return (not self.primed or self.x._version != self._x_version or self.next_table_ready
+        return (not self.primed or (self.x._version, self.x_rows._version) != self._x_version or self.next_table_ready
                 or self.state.host_steps != self._host_steps)
 
     def prime(self):
         self._drop_into(self.filled[0], 0)
         spmm(self.ops.low, self.filled[0], out=self.filled[1], row_scale=self.ops.row_scale)
         self.primed = True
-        self._x_version = self.x._version
+        self._x_version = (self.x._version, self.x_rows._version)
         self._host_steps = self.state.host_steps
         self.next_table_ready = self.next_agg_ready = self.adopted = False
 
@@ -1113,7 +1134,7 @@ class AcmConvFunction(torch.autograd.Function):
             pipe = call.pipe
             ctx.pipe = None
             if (pipe is not None and pipe.primed and ctx.agg_first and k == 3 and fp == 8 and f == 64 and ops is pipe.ops
-                    and xpad.data_ptr() == pipe.table().data_ptr() and agg_holder is None):     # (only a training step carries a pipe)
+                    and xpad.data_ptr() == pipe.local_table().data_ptr() and agg_holder is None):   # (only a training step carries a pipe)
                 agg_given = pipe.agg()
                 ctx.pipe = pipe
                 pipe.adopted = True               # the loop may refill the table: this forward leaves its copies in ``saved``
@@ -1411,7 +1432,10 @@ class AcmConvFunction(torch.autograd.Function):
         ctx.lazy_producer = None
         prod = getattr(x, "grad_fn", None) if not sparse_x else None
         if (call.hidden_private is x and prod is not None and getattr(prod, "agg_first", False) and getattr(prod, "call", None) is call
-                and not zero_padded and not ops.sharded and hops == 1 and os.environ.get("ACM_LAZY_DX", "1") != "0"):
+                and not zero_padded and hops == 1 and os.environ.get("ACM_LAZY_DX", "1") != "0"
+                # row-sharded: dW' is a per-rank partial sum the other kernel writes later -- only when the all-reduce of
+                # this layer's flat gradient vector is deferred behind the step's flush as well
+                and (not ops.sharded or call.defer is not None)):
             ctx.lazy_producer = prod
         ctx.save_for_backward(w3[0] if sparse_x else x, *w3, zlh, zi, pre, mix, *vecs, *lnw, *lnb)
         ctx.mark_non_differentiable(att)
@@ -1640,9 +1664,9 @@ def _backward_agg(ctx, grad_out):
     carry = pipe is not None and pipe.next_table_ready and not pipe.next_agg_ready
     if carry:                                     # the next step's P = A_low dropout(x) rides this launch
         q.next_a = ops.low.handle
-        q.next_xg, q.ld_next_xg = pipe.filled[0].data_ptr(), pipe.filled[0].stride(0)
+        q.next_xg, q.ld_next_xg = pipe.table().data_ptr(), pipe.table().stride(0)
         q.next_row_scale = ops.row_scale.data_ptr()
-        q.next_agg, q.ld_next_agg = pipe.filled[1].data_ptr(), pipe.filled[1].stride(0)
+        q.next_agg, q.ld_next_agg = pipe.agg().data_ptr(), pipe.agg().stride(0)
     with _device_ctx(dev), _Timed(f"conv_agg_bwd{'+gather' if carry else ''}{'+proj' if lazy is not None else ''}/F{f}k{k}i{f_in}"):
         st = lib.acm_conv_agg_bwd(n, C.byref(q), _vp(ws), ws.numel() * 4, _stream())
     if st == 4 and lazy is not None:                  # ACM_EUNSUPPORTED for this shape after all: the two launches

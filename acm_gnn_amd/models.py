@@ -113,15 +113,21 @@ class GCN(nn.Module):
             nfeat = x.shape[1]
             pad = AF.agg_pad_width(nfeat)
             ops = adj_low if isinstance(adj_low, FilterOperators) else None
-            if ops is not None and ops.sharded and ops.uniform and ops.x_full is not None:
+            piped = (call.pipe is not None and call.pipe.primed and call.pipe.ops is ops and call.pipe.state is st
+                     and call.pipe.x_rows.data_ptr() == x.data_ptr() and call.pipe.x_rows.shape == x.shape
+                     and torch.is_grad_enabled())
+            if piped:
+                # dropout_t(x), drawn one step ahead (functional.InputPipeline); row-sharded: of every node, this rank's
+                # rows a view of it
+                x = call.pipe.local_table()
+                if ops.sharded:
+                    ops._pregathered = (x, call.pipe.table())
+            elif ops is not None and ops.sharded and ops.uniform and ops.x_full is not None:
                 # the mask is a function of the global position: drop the replicated full input locally instead of
                 # all-gathering the dropped row blocks (equal blocks only: there the halo numbering is the global one)
                 xg = AF.dropout(ops.x_full, p, st, tag=0, pad_to=pad, row_offset=0)
                 x = xg[off:off + x.shape[0]]
                 ops._pregathered = (x, xg)
-            elif (call.pipe is not None and call.pipe.primed and call.pipe.ops is ops and call.pipe.state is st
-                    and call.pipe.x.data_ptr() == x.data_ptr() and call.pipe.x.shape == x.shape and torch.is_grad_enabled()):
-                x = call.pipe.table()         # dropout_t(x), drawn one step ahead (functional.InputPipeline)
             elif (self.model_type in ("acmgcn", "acmgcnp", "acmsgc") and pad == nfeat and not x.requires_grad
                     and AF.in_drop_supported(x, ops, self.gcns[0]._config(), nfeat, self.gcns[0].out_features)
                     if ops is not None else False):

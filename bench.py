@@ -403,6 +403,16 @@ def side_measurements(args, timed_graph_steps, model, opt, x, ops, y, w, fused_d
             return loss
         ms, _ = timed_graph_steps(epoch)
         out["train_plus_eval_ms_per_epoch"] = round(ms, 4)
+        # ... and with the input pipeline left on in the training half (fit(pipeline_input=None))
+        pstep = T.TrainStep(model, opt, x, ops, y, w, use_graph=True, fused_dropout=fused_drop)
+        if pstep.pipe is not None:
+            def epoch_p():
+                loss = pstep()
+                ev()
+                return loss
+            ms, _ = timed_graph_steps(epoch_p)
+            out["train_plus_eval_pipelined_ms_per_epoch"] = round(ms, 4)
+        del pstep
         # the same captured step alone: what train.fit() and the row-sharded runs execute (no input pipeline)
         ms, _ = timed_graph_steps(gstep)
         out["plain_ms_per_step"] = round(ms, 4)

@@ -314,6 +314,27 @@ def test_row_shard_equals_single_process(cfg, monkeypatch):
                                        msg=lambda m, k=k: f"{k}: {m}")
 
 
+def _train_dataset(cfg, world):
+    """("tiny" synthetic dataset) or, for the input pipeline's regime (12 < nnz / n <= 160 in every row block), a random
+    graph of mean degree ~20."""
+    from acm_gnn_amd import data as D
+    if cfg.get("graph") != "dense":
+        adj, x_np, y_np, (tr, _, _), _ = D.synthetic_dataset("tiny", seed=5, pad_to=world)
+        return adj, x_np, y_np, tr
+    import scipy.sparse as sp
+    n = 96 * world
+    rng = np.random.default_rng(17)
+    m = n * 10
+    r, c = rng.integers(0, n, m), rng.integers(0, n, m)
+    adj = sp.csr_matrix((np.ones(m, np.float32), (r, c)), shape=(n, n))
+    adj = ((adj + adj.T) > 0).astype(np.float32).tocsr()
+    adj.setdiag(0)
+    adj.eliminate_zeros()
+    x_np = rng.standard_normal((n, 7)).astype(np.float32)
+    y_np = rng.integers(0, 2, n)
+    return adj, x_np, y_np, np.sort(rng.permutation(n)[: n // 2])
+
+
 def _train_worker(rank, world, port, cfg, ret):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -330,15 +351,20 @@ def _train_worker(rank, world, port, cfg, ret):
         fake_lib.install(MP())
         import acm_gnn_amd
         from acm_gnn_amd import GCN, data as D, distributed as DD, functional as AF, train as T
-        adj, x_np, y_np, (tr, _, _), _ = D.synthetic_dataset("tiny", seed=5, pad_to=world)
+        if cfg.get("pipeline"):
+            os.environ["ACM_PIPELINE_MIN_ROWS"] = "32"
+        adj, x_np, y_np, tr = _train_dataset(cfg, world)
         low, deg = D.build_filters(adj)
         n = adj.shape[0]
         plan = DD.equal_rows_plan(n, world) if cfg["plan"] == "rows" else DD.shard_plan(low.indptr, world, 8)
         ops = DD.make_sharded_operators(low, deg, "cpu", with_structure=bool(cfg["s"]), plan=plan)
         b, e = plan.rows(rank)
+        if cfg.get("x_full"):
+            ops.x_full = torch.from_numpy(x_np)
+        hid = cfg.get("hid", 16)
         torch.manual_seed(0)
-        full = GCN(7, 16, 2, 2, n, cfg["dropout"], cfg["model"], cfg["s"], variant=bool(cfg["variant"]), attn_layernorm=True)
-        model = GCN(7, 16, 2, 2, e - b, cfg["dropout"], cfg["model"], cfg["s"], variant=bool(cfg["variant"]), attn_layernorm=True)
+        full = GCN(7, hid, 2, 2, n, cfg["dropout"], cfg["model"], cfg["s"], variant=bool(cfg["variant"]), attn_layernorm=True)
+        model = GCN(7, hid, 2, 2, e - b, cfg["dropout"], cfg["model"], cfg["s"], variant=bool(cfg["variant"]), attn_layernorm=True)
         sd = full.state_dict()
         for k in list(sd):
             if k.endswith(".struc_low"):
@@ -347,9 +373,16 @@ def _train_worker(rank, world, port, cfg, ret):
         model.dropout_state = AF.DropoutState("cpu", seed=7)
         opt = acm_gnn_amd.FusedAdamW(model.parameters(), lr=0.02, weight_decay=1e-3)
         w = T.row_weights(torch.from_numpy(DD.local_index(tr, plan, rank)), e - b, n_train_total=len(tr))
+        carried = []
+        if cfg.get("pipeline"):
+            fake, bwd = acm_gnn_amd._lib.load(), acm_gnn_amd._lib.load().acm_conv_agg_bwd
+            fake.acm_conv_agg_bwd = lambda nn, qq, *a: (carried.append((bool(qq._obj.next_agg), bool(qq._obj.proj_dz))), bwd(nn, qq, *a))[1]
         step = T.TrainStep(model, opt, torch.from_numpy(x_np[b:e]), ops, torch.from_numpy(y_np[b:e]), w, fused_dropout=True)
         losses = [float(step()) for _ in range(3)]
         assert step._defer                                  # the deferred path stayed on
+        if cfg.get("pipeline"):                             # every backward carried the next step's gather (of THIS rank's
+            assert step.pipe is not None and carried == [(True, True)] * 3, carried    # rows) and the output layer's projection
+            assert step.pipe.table().shape[0] == n and step.pipe.agg().shape[0] == e - b
         params = {k: p.detach().numpy().copy() for k, p in model.named_parameters()}
         ret.put((rank, losses, params, (b, e)))
     finally:
@@ -358,8 +391,12 @@ def _train_worker(rank, world, port, cfg, ret):
 
 @pytest.mark.parametrize("cfg", [dict(model="acmgcnp", s=0, variant=0, dropout=0.3, plan="rows"),
                                  dict(model="acmgcnp", s=1, variant=1, dropout=0.0, plan="work"),
-                                 dict(model="acmgcnpp", s=0, variant=0, dropout=0.3, plan="rows")],
-                         ids=["agg-dropout", "struct-acmii-work-plan", "acmgcnpp"])
+                                 dict(model="acmgcnpp", s=0, variant=0, dropout=0.3, plan="rows"),
+                                 dict(model="acmgcnp", s=0, variant=0, dropout=0.3, plan="rows", graph="dense", hid=64, x_full=1,
+                                      pipeline=1),
+                                 dict(model="acmgcnp", s=0, variant=0, dropout=0.3, plan="rows", graph="dense", hid=64, x_full=1,
+                                      pipeline=1, world=4)],
+                         ids=["agg-dropout", "struct-acmii-work-plan", "acmgcnpp", "input-pipeline", "4-ranks-input-pipeline"])
 def test_sharded_train_step_equals_single_process(cfg, monkeypatch):
     """train.TrainStep on two gloo ranks: the second phases of every partial sum run as ONE deferred launch per step and
     the row-shard gradient sums are all-reduced right after it (DeferredReductions.allreduce), before the optimizer --
@@ -368,7 +405,7 @@ def test_sharded_train_step_equals_single_process(cfg, monkeypatch):
     import time
     import torch.multiprocessing as mp
     import fake_lib
-    world, port = 2, _free_port()
+    world, port = cfg.get("world", 2), _free_port()
     ctx = mp.get_context("spawn")
     ret = ctx.Queue()
     procs = [ctx.Process(target=_train_worker, args=(r, world, port, cfg, ret)) for r in range(world)]
@@ -389,16 +426,16 @@ def test_sharded_train_step_equals_single_process(cfg, monkeypatch):
     fake_lib.install(monkeypatch)
     import acm_gnn_amd
     from acm_gnn_amd import GCN, data as D, distributed as DD, functional as AF, train as T
-    adj, x_np, y_np, (tr, _, _), _ = D.synthetic_dataset("tiny", seed=5, pad_to=world)
+    adj, x_np, y_np, tr = _train_dataset(cfg, world)
     low, deg = D.build_filters(adj)
     n = adj.shape[0]
     ops = DD.make_sharded_operators(low, deg, "cpu", with_structure=bool(cfg["s"]))
     torch.manual_seed(0)
-    full = GCN(7, 16, 2, 2, n, cfg["dropout"], cfg["model"], cfg["s"], variant=bool(cfg["variant"]), attn_layernorm=True)
+    full = GCN(7, cfg.get("hid", 16), 2, 2, n, cfg["dropout"], cfg["model"], cfg["s"], variant=bool(cfg["variant"]), attn_layernorm=True)
     full.dropout_state = AF.DropoutState("cpu", seed=7)
     opt = acm_gnn_amd.FusedAdamW(full.parameters(), lr=0.02, weight_decay=1e-3)
     w = T.row_weights(torch.from_numpy(tr), n)
-    step = T.TrainStep(full, opt, torch.from_numpy(x_np), ops, torch.from_numpy(y_np), w, fused_dropout=True)
+    step = T.TrainStep(full, opt, torch.from_numpy(x_np), ops, torch.from_numpy(y_np), w, fused_dropout=True, pipeline_input=False)
     ref_losses = [float(step()) for _ in range(3)]
     for rank, losses, params, (b, e) in results:
         for k, p in full.named_parameters():

@@ -159,3 +159,97 @@ def test_two_ranks_on_one_gpu_equal_single_process(cfg):
             else:
                 np.testing.assert_allclose(grads[k], ref.cpu().numpy(), rtol=1e-3,
                                            atol=1e-5 * max(1.0, float(ref.abs().max())), err_msg=k)
+
+
+def _train_worker(rank, world, port, cfg, ret):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import acm_gnn_amd
+        from acm_gnn_amd import distributed as DD, functional as AF, train as T
+        adj, x_np, y_np, tr, low, deg, plan = _prepare(cfg, world)
+        n = adj.shape[0]
+        ops = DD.make_sharded_operators(low, deg, DEV, plan=plan)
+        b, e = plan.rows(rank)
+        full, model = _build(cfg, e - b, n, DEV, x_np.shape[1], int(y_np.max()) + 1)
+        sd = full.state_dict()
+        for k in list(sd):
+            if k.endswith(".struc_low"):
+                sd[k] = sd[k][b:e].clone()
+        model.load_state_dict(sd)
+        model = model.to(DEV)
+        model.dropout_state = AF.DropoutState(DEV, seed=7)
+        ops.x_full = torch.from_numpy(x_np).to(DEV)
+        opt = acm_gnn_amd.FusedAdamW(model.parameters(), lr=0.01, weight_decay=1e-3)
+        w = T.row_weights(torch.from_numpy(DD.local_index(tr, plan, rank)).to(DEV), e - b, n_train_total=len(tr))
+        step = T.TrainStep(model, opt, torch.from_numpy(x_np[b:e]).to(DEV), ops, torch.from_numpy(y_np[b:e]).to(DEV), w,
+                           fused_dropout=True)
+        timer = AF.KernelTimer()
+        AF.set_kernel_timer(timer)
+        losses = [float(step()) for _ in range(3)]
+        AF.set_kernel_timer(None)
+        torch.cuda.synchronize()
+        labels = sorted(timer.summary())
+        pipe = step.pipe
+        ret.put((rank, losses, {k: p.detach().cpu().numpy().copy() for k, p in model.named_parameters()}, labels,
+                 None if pipe is None else (tuple(pipe.table().shape), tuple(pipe.agg().shape), bool(pipe.primed))))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_ranks_with_the_input_pipeline_equal_the_plain_single_process_step():
+    """bench.py's N > 1 configuration (degree ranking dealt like cards, equal blocks, replicated input) with
+    train.TrainStep's input pipeline ON in both ranks: each rank's backward kernel carries the gather of ITS rows of the next
+    step's P = A_low dropout(x) out of a locally drawn table of ALL nodes (no exchange), and also the output layer's
+    projection backward.  Three optimizer steps against the single-process step with the pipeline off."""
+    import queue
+    import time
+    import torch.multiprocessing as mp
+    cfg = dict(model="acmgcnp", s=0, variant=0, dropout=0.1, dataset="twitch-gamer", plan="interleave")
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    ret = ctx.Queue()
+    procs = [ctx.Process(target=_train_worker, args=(r, world, port, cfg, ret)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results, deadline = [], time.time() + 400
+    while len(results) < world:
+        try:
+            results.append(ret.get(timeout=2))
+        except queue.Empty:
+            if [p.exitcode for p in procs if p.exitcode not in (None, 0)] or time.time() > deadline:
+                for p in procs:
+                    p.terminate()
+                pytest.fail(f"sharded GPU train workers failed (exit codes {[p.exitcode for p in procs]})")
+    for p in procs:
+        p.join(60)
+    results.sort(key=lambda t: t[0])
+    import acm_gnn_amd
+    from acm_gnn_amd import distributed as DD, functional as AF, train as T
+    adj, x_np, y_np, tr, low, deg, plan = _prepare(cfg, world)
+    n = adj.shape[0]
+    for rank, _, _, labels, pipe in results:
+        b, e = plan.rows(rank)
+        assert pipe == ((n, 8), (e - b, 8), True), pipe
+        assert any(s.startswith("conv_agg_bwd+gather+proj") for s in labels), labels      # the combined kernel ran
+        assert not any(s.startswith("proj_bwd") for s in labels), labels                  # no separate projection backward
+        assert sorted(s for s in labels if s.startswith("all_gather")) == [f"all_gather/{plan.n_max}x4"], labels   # the output
+        # layer's [Z_L | Z_H] and [G_L | G_H] halos only: nothing is exchanged for the first layer or its carried gather
+    ops = DD.make_sharded_operators(low, deg, DEV)
+    full, _ = _build(cfg, n, n, DEV, x_np.shape[1], int(y_np.max()) + 1)
+    full = full.to(DEV)
+    full.dropout_state = AF.DropoutState(DEV, seed=7)
+    opt = acm_gnn_amd.FusedAdamW(full.parameters(), lr=0.01, weight_decay=1e-3)
+    w = T.row_weights(torch.from_numpy(tr).to(DEV), n)
+    step = T.TrainStep(full, opt, torch.from_numpy(x_np).to(DEV), ops, torch.from_numpy(y_np).to(DEV), w, fused_dropout=True,
+                       pipeline_input=False)
+    ref_losses = [float(step()) for _ in range(3)]
+    for i in range(3):
+        assert abs(sum(r[1][i] for r in results) - ref_losses[i]) < 2e-5 * max(1.0, abs(ref_losses[i])), (i, ref_losses)
+    for rank, _, params, _, _ in results:
+        for k, p in full.named_parameters():
+            if k.endswith(".struc_low"):
+                continue                                   # unused without the structure channel
+            ref = p.detach().cpu().numpy()
+            assert float(np.abs(params[k] - ref).max()) < 2e-4 * float(np.abs(ref).max()) + 1e-6, k
