@@ -153,6 +153,126 @@ def _padded_columns(mat, plan):
     return m.indptr.astype(np.int32), plan.padded_ids(m.indices).astype(np.int32), m.data.astype(np.float32)
 
 
+_P61 = (1 << 61) - 1
+
+
+def _edge_hash(a, b, m, n):
+    """A 61-bit hash per (a, b, multiplicity) edge (splitmix64 of the pair's index), as Python-int-safe uint64."""
+    with np.errstate(over="ignore"):
+        z = (a.astype(np.uint64) * np.uint64(n) + b.astype(np.uint64)) * np.uint64(4) + m.astype(np.uint64)
+        z = z + np.uint64(0x9E3779B97F4A7C15)
+        z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+        z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+        z = z ^ (z >> np.uint64(31))
+    return z >> np.uint64(3)                              # < 2^61
+
+
+def _sum_mod_p61(h):
+    """sum(h) mod 2^61 - 1 without overflow: 61-bit values summed in two 31-bit halves."""
+    lo = int((h & np.uint64(0x7FFFFFFF)).sum(dtype=np.uint64))          # < 2^31 * nnz: fine below 2^33 edges
+    hi = int((h >> np.uint64(31)).sum(dtype=np.uint64))
+    return (lo + (hi << 31)) % _P61
+
+
+def pattern_form_of_rows(indptr, indices, vals, row_begin, n_global, group=None, max_multiplicity=4):
+    """The pattern-only form (graph.implicit_form) decided from THIS rank's rows alone plus one tiny exchange.
+
+    ``indptr / indices / vals``: the rank's row block of A_low, global column ids, columns ascending inside every row.
+    Row-local part: every value an exact small multiple of the row's minimum s_i, no column listed twice.  Global part:
+    the multiset {(i, j, m)} must equal {(j, i, m)} -- each rank hashes its edges both ways, the per-rank sums (mod
+    2^61 - 1) are all-gathered (16 bytes per rank) and compared: equal multisets give equal sums, different ones
+    differ except with probability ~2^-61.  Every rank returns the same decision.
+    -> (indptr_P, indices_P, s) of the rank's rows, or None."""
+    import torch.distributed as dist
+    ip = np.asarray(indptr, dtype=np.int64)
+    ix = np.asarray(indices, dtype=np.int64)
+    v = np.asarray(vals, dtype=np.float32)
+    n_loc = ip.size - 1
+    counts = np.diff(ip)
+    rows = np.repeat(np.arange(n_loc, dtype=np.int64), counts)
+    ok = bool(ix.size == 0 or (v > 0).all())
+    s = np.ones(n_loc, np.float32)
+    mult = np.ones(ix.size, np.int64)
+    if ok and ix.size:
+        np.minimum.at(s := np.full(n_loc, np.inf, np.float32), rows, v)
+        s = np.where(np.isinf(s), np.float32(1), s).astype(np.float32)
+        m = v / s[rows]
+        mr = np.round(m)
+        ok = bool(((mr >= 1) & (mr <= max_multiplicity) & (m == mr)).all())
+        mult = mr.astype(np.int64)
+        same_row = rows[1:] == rows[:-1]
+        ok = ok and not bool((same_row & (ix[1:] <= ix[:-1])).any())      # sorted, coalesced rows
+    h_fwd = h_bwd = 0
+    if ok:
+        g = rows + int(row_begin)
+        h_fwd = _sum_mod_p61(_edge_hash(g, ix, mult, n_global))
+        h_bwd = _sum_mod_p61(_edge_hash(ix, g, mult, n_global))
+    mine = torch.tensor([int(ok), h_fwd, h_bwd], dtype=torch.int64)
+    if group is not None or (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1):
+        group = group if group is not None else dist.group.WORLD
+        dev = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend(group) == "nccl" else torch.device("cpu")
+        every = [torch.zeros(3, dtype=torch.int64, device=dev) for _ in range(dist.get_world_size(group))]
+        dist.all_gather(every, mine.to(dev), group=group)
+        every = torch.stack(every).cpu()
+    else:
+        every = mine[None]
+    if not bool(every[:, 0].all()):
+        return None
+    if sum(int(t) for t in every[:, 1]) % _P61 != sum(int(t) for t in every[:, 2]) % _P61:
+        return None                                       # the pattern is not symmetric
+    if bool((mult == 1).all()):
+        return ip.astype(np.int32), ix.astype(np.int32), s
+    new_ip = np.zeros(n_loc + 1, np.int64)
+    np.add.at(new_ip, rows + 1, mult)
+    return np.cumsum(new_ip).astype(np.int32), np.repeat(ix, mult).astype(np.int32), s
+
+
+def make_sharded_operators_from_rows(indptr, indices, vals, deg_rows, plan, rank, device, group=None, with_structure=False,
+                                     t_rows=None, _form="decide"):
+    """This rank's FilterOperators from ITS OWN rows of A_low -- (indptr, indices, vals) of the row block
+    [plan.rows(rank)) with global column ids sorted inside every row, ``deg_rows`` the block of d = rowsum(I + A) -- so
+    that no rank has to hold, sort or transpose the whole graph (a loader can read each rank's rows straight from a
+    row-partitioned file).  Pattern-only form whenever A_low allows it (pattern_form_of_rows: a row-local test and a
+    16-byte-per-rank exchange for the symmetry of the pattern); otherwise the explicit form, which also needs the
+    rank's rows of A_low^T: ``t_rows = (indptr, indices, vals)`` (columns of A_low the rank does not own -- the caller
+    has to provide them, make_sharded_operators does from the global matrix)."""
+    import torch.distributed as dist
+    group = group if group is not None else dist.group.WORLD
+    b, e = plan.rows(rank)
+    dev = torch.device(device)
+    ip = np.asarray(indptr)
+    if ip.size != e - b + 1:
+        raise ValueError(f"make_sharded_operators_from_rows: {ip.size - 1} rows given, the plan gives rank {rank} {e - b}")
+
+    def dev_t(a):
+        return torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+
+    common = dict(row_offset=b, n_global=plan.n_global, group=group)
+    form = _form                                       # (make_sharded_operators has decided already)
+    if isinstance(form, str):
+        form = None
+        if os.environ.get("ACM_IMPLICIT", "1") != "0":
+            form = pattern_form_of_rows(ip, indices, vals, b, plan.n_global, group)
+    if form is not None:
+        ipp, ixp, s = form
+        pat = CsrGraph.from_csr(dev_t(ipp.astype(np.int32)), dev_t(plan.padded_ids(ixp).astype(np.int32)), None, plan.n_gathered)
+        ops = FilterOperators(pat, dev_t(deg_rows) if with_structure else None, row_scale=dev_t(s), **common)
+        ops.low_t_override = pat
+    else:
+        if t_rows is None:
+            raise ValueError("make_sharded_operators_from_rows: A_low has no pattern-only form here (or ACM_IMPLICIT=0); the "
+                             "explicit form needs the rank's rows of A_low^T (t_rows)")
+        ops = FilterOperators(CsrGraph.from_csr(dev_t(ip.astype(np.int32)), dev_t(plan.padded_ids(indices).astype(np.int32)),
+                                                dev_t(np.asarray(vals, np.float32)), plan.n_gathered),
+                              dev_t(deg_rows) if with_structure else None, **common)
+        tip, tix, tv = t_rows
+        ops.low_t_override = CsrGraph.from_csr(dev_t(np.asarray(tip).astype(np.int32)),
+                                               dev_t(plan.padded_ids(tix).astype(np.int32)),
+                                               dev_t(np.asarray(tv, np.float32)), plan.n_gathered)
+    ops.plan = plan
+    return ops
+
+
 def make_sharded_operators(low_csr, deg, device, group=None, with_structure=False, plan=None, row_cost=DEFAULT_ROW_COST,
                            relabel=False):
     """FilterOperators for this rank (or the unsharded ones when no process group is active).  ``plan``: a ShardPlan
@@ -171,38 +291,21 @@ def make_sharded_operators(low_csr, deg, device, group=None, with_structure=Fals
         plan = shard_plan(low_csr.indptr, world, row_cost)
     if plan.world != world or plan.n_global != low_csr.shape[0]:
         raise ValueError(f"{plan} does not match {world} ranks / {low_csr.shape[0]} rows")
+    # every rank cuts ITS rows out of the host matrix and builds from those alone (make_sharded_operators_from_rows: what a
+    # loader with a row-partitioned file calls directly); only the explicit form also needs the rank's rows of A_low^T
     b, e = plan.rows(rank)
-    dev = torch.device(device)
-
-    def dev_t(a):
-        return torch.from_numpy(np.ascontiguousarray(a)).to(dev)
-
+    loc = low_csr[b:e].tocsr()
+    loc.sort_indices()
     form = None
     if os.environ.get("ACM_IMPLICIT", "1") != "0":
-        # pattern-only form, detected on the global matrix (host): the rank's rows of P serve A_low (row-scaled)
-        # and, P being symmetric, A_low^T on the pre-scaled all-gathered gradients -- one column-id stream, no
-        # transposed slice
-        g = low_csr
-        g.sort_indices()
-        form = implicit_form(torch.from_numpy(g.indptr.astype(np.int64)), torch.from_numpy(g.indices.astype(np.int64)),
-                             torch.from_numpy(g.data.astype(np.float32)), g.shape[0], g.shape[1])
-    common = dict(row_offset=b, n_global=plan.n_global, group=group)
-    if form is not None:
-        ip, ix, s = (t.numpy() for t in form)
-        ip_loc = (ip[b:e + 1] - ip[b]).astype(np.int32)
-        ix_loc = plan.padded_ids(ix[ip[b]:ip[e]]).astype(np.int32)
-        pat = CsrGraph.from_csr(dev_t(ip_loc), dev_t(ix_loc), None, plan.n_gathered)
-        ops = FilterOperators(pat, dev_t(deg[b:e]) if with_structure else None, row_scale=dev_t(s[b:e]), **common)
-        ops.low_t_override = pat
-    else:
-        low_loc, low_t_loc, deg_loc, _ = shard_filter_arrays(low_csr, deg, plan, rank)
-        ip, ix, v = _padded_columns(low_loc, plan)
-        ops = FilterOperators(CsrGraph.from_csr(dev_t(ip), dev_t(ix), dev_t(v), plan.n_gathered),
-                              dev_t(deg_loc) if with_structure else None, **common)
-        ip, ix, v = _padded_columns(low_t_loc, plan)
-        ops.low_t_override = CsrGraph.from_csr(dev_t(ip), dev_t(ix), dev_t(v), plan.n_gathered)
-    ops.plan = plan
-    return ops
+        form = pattern_form_of_rows(loc.indptr, loc.indices, loc.data, b, plan.n_global, group)
+    t_rows = None
+    if form is None:
+        _, low_t_loc, _, _ = shard_filter_arrays(low_csr, deg, plan, rank)
+        low_t_loc.sort_indices()
+        t_rows = (low_t_loc.indptr, low_t_loc.indices, low_t_loc.data)
+    return make_sharded_operators_from_rows(loc.indptr, loc.indices, loc.data, deg[b:e] if deg is not None else None,
+                                            plan, rank, device, group, with_structure, t_rows, _form=form)
 
 
 def local_rows(array, plan, rank):

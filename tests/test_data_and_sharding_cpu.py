@@ -444,3 +444,88 @@ def test_sharded_train_step_equals_single_process(cfg, monkeypatch):
     # each rank reports the loss over its own rows: the ranks' losses add up to the single-process loss
     for i in range(3):
         assert abs(sum(r[1][i] for r in results) - ref_losses[i]) < 1e-5 * max(1.0, abs(ref_losses[i]))
+
+
+def _rows_worker(rank, world, port, case, ret):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import torch.distributed as dist
+    import fake_lib
+
+    class MP:
+        def setattr(self, obj, name, val):
+            setattr(obj, name, val)
+
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        fake_lib.install(MP())
+        from acm_gnn_amd import data as D, distributed as DD
+        adj, x_np, _, _, _ = D.synthetic_dataset("tiny", seed=5, pad_to=world)
+        if case == "self-loops":                       # raw self-loops: the diagonal of I + A counts twice
+            adj = adj.tolil()
+            for i in (1, adj.shape[0] - 2):
+                adj[i, i] = 1.0
+            adj = adj.tocsr()
+        low, deg = D.build_filters(adj)
+        low = low.tocsr()
+        low.sort_indices()
+        if case == "asymmetric":                       # one edge without its mirror image, held by the LAST rank only
+            low = low.tolil()
+            i = low.shape[0] - 1
+            j = next(c for c in range(low.shape[0]) if low[i, c] == 0 and c != i)
+            low[i, j] = low[i, i]
+            low = low.tocsr()
+            low.sort_indices()
+        n = low.shape[0]
+        plan = DD.shard_plan(low.indptr, world, 8)
+        b, e = plan.rows(rank)
+        mine = low[b:e]                                # all this rank ever looks at
+        form = DD.pattern_form_of_rows(mine.indptr, mine.indices, mine.data, b, n)
+        if case == "asymmetric":
+            ret.put((rank, form is None, None))
+            return
+        ops = DD.make_sharded_operators_from_rows(mine.indptr, mine.indices, mine.data, deg[b:e], plan, rank, "cpu",
+                                                  with_structure=True)
+        ref = DD.make_sharded_operators(low, deg, "cpu", with_structure=True, plan=plan)
+        same = all(torch.equal(a, c) for a, c in zip(ops.low.arrays()[:2], ref.low.arrays()[:2]))
+        same = same and torch.equal(ops.row_scale, ref.row_scale) and torch.equal(ops.deg, ref.deg) and ops.implicit
+        # ... and the product: rows [b, e) of A_low @ X from the pattern, the row scale and the padded table
+        from acm_gnn_amd import functional as AF
+        table = torch.from_numpy(plan.pad_rows(x_np))
+        got = AF.spmm(ops.low, table, row_scale=ops.row_scale).numpy()
+        want = (low @ x_np)[b:e]
+        ret.put((rank, bool(same), float(np.abs(got - want).max())))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("case", ["plain", "self-loops", "asymmetric"])
+def test_operators_built_from_each_ranks_own_rows(case):
+    """distributed.make_sharded_operators_from_rows: each rank sees only its row block of A_low; the pattern-only form is
+    decided row-locally plus a 16-byte-per-rank exchange of edge-hash sums for the symmetry of the pattern (an edge whose
+    mirror image is missing on ANOTHER rank is noticed by every rank)."""
+    import queue
+    import time
+    import torch.multiprocessing as mp
+    world, port = 4, _free_port()
+    ctx = mp.get_context("spawn")
+    ret = ctx.Queue()
+    procs = [ctx.Process(target=_rows_worker, args=(r, world, port, case, ret)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results, deadline = [], time.time() + 300
+    while len(results) < world:
+        try:
+            results.append(ret.get(timeout=2))
+        except queue.Empty:
+            if [p.exitcode for p in procs if p.exitcode not in (None, 0)] or time.time() > deadline:
+                for p in procs:
+                    p.terminate()
+                pytest.fail(f"workers failed (exit codes {[p.exitcode for p in procs]})")
+    for p in procs:
+        p.join(60)
+    for rank, flag, err in results:
+        assert flag, (case, rank)
+        if err is not None:
+            assert err < 1e-5, (case, rank, err)
