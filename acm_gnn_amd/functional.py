@@ -309,6 +309,15 @@ class InputPipeline:
         self.next_table_ready = False
         self.next_agg_ready = False
         self.adopted = False             # set by the forward that took P from this pipeline (and left its copies in ``saved``)
+        # ACM_PIPE_SIDE_STREAM=1: the table of the next step is drawn on a SIDE stream as soon as the first layer's forward
+        # kernel has read this step's -- beside the output layer's halo all-gathers and gathers instead of between the
+        # forward and the backward; the backward that carries the gather joins it.  Off by default: on one device (also as
+        # a single-rank RCCL run) the fork / join costs more than the 9 us it hides (0.276 -> 0.293 ms per captured step,
+        # DESIGN.md section 9b); whether the halo latency of a real 8-rank run pays for it is for that run to tell.
+        self._side = None
+        if x.device.type == "cuda" and os.environ.get("ACM_PIPE_SIDE_STREAM", "0") == "1":
+            self._side = torch.cuda.Stream(device=x.device)
+        self._join_pending = False
 
     @staticmethod
     def eligible(model, ops, x):
@@ -377,6 +386,7 @@ class InputPipeline:
                 or self.state.host_steps != self._host_steps)
 
     def prime(self):
+        self.join()
         self._drop_into(self.filled[0], 0)
         spmm(self.ops.low, self.filled[0], out=self.filled[1], row_scale=self.ops.row_scale)
         self.primed = True
@@ -384,19 +394,38 @@ class InputPipeline:
         self._host_steps = self.state.host_steps
         self.next_table_ready = self.next_agg_ready = self.adopted = False
 
-    def make_next(self):
+    def make_next(self, early=False):
         """Between the forward and the backward: the next step's dropped input replaces this step's -- only if the forward
         took this step's from the pipeline and left its copies in ``saved`` (``adopted``); a forward that went another way
-        (an environment switch, another path of the layer) may have saved the table itself for its backward."""
+        (an environment switch, another path of the layer) may have saved the table itself for its backward.
+        ``early``: the call of the first layer's forward itself, right behind its kernel -- taken only with a side stream
+        (the table is then drawn beside the rest of the forward; join() before its reader)."""
         if not self.adopted:
             return False
-        self._drop_into(self.filled[0], 1)
+        if self.next_table_ready:
+            return True
+        if early and self._side is None:
+            return False
+        if self._side is not None:
+            self._side.wait_stream(torch.cuda.current_stream(self.x.device))
+            with torch.cuda.stream(self._side):
+                self._drop_into(self.filled[0], 1)
+            self._join_pending = True
+        else:
+            self._drop_into(self.filled[0], 1)
         self.next_table_ready = True
         return True
+
+    def join(self):
+        """The current stream waits for the side stream's table (no-op without one)."""
+        if self._join_pending:
+            torch.cuda.current_stream(self.x.device).wait_stream(self._side)
+            self._join_pending = False
 
     def end_step(self):
         """After the optimizer step (which advanced the counter).  If the layer's backward did not carry the gather (it
         fell back to another path), ``filled`` is stale: prime() again before the next forward."""
+        self.join()
         if not (self.next_table_ready and self.next_agg_ready):
             self.primed = False
         self.next_table_ready = self.next_agg_ready = self.adopted = False
@@ -1317,6 +1346,8 @@ class AcmConvFunction(torch.autograd.Function):
             with _device_ctx(dev), _Timed(f"conv_agg_{'epi' if agg_given is not None else 'fwd'}/F{f}k{k}i{f_in}"):
                 st = lib.acm_conv_agg_fwd(ops.low.handle, C.byref(p), _vp(ws), ws.numel() * 4, _stream())
             _lib.check(st, "acm_conv_agg_fwd")
+            if ctx.pipe is not None:
+                ctx.pipe.make_next(early=True)        # (side stream only) this step's table has been read: draw the next one
             if agg_holder is not None and agg_given is None:
                 agg_holder["agg"] = agg
             if nxt is not None:
@@ -1662,6 +1693,8 @@ def _backward_agg(ctx, grad_out):
     q.defer = defer.pointer() if defer is not None else None
     pipe = getattr(ctx, "pipe", None)
     carry = pipe is not None and pipe.next_table_ready and not pipe.next_agg_ready
+    if pipe is not None:
+        pipe.join()                               # (the table drawn on the side stream)
     if carry:                                     # the next step's P = A_low dropout(x) rides this launch
         q.next_a = ops.low.handle
         q.next_xg, q.ld_next_xg = pipe.table().data_ptr(), pipe.table().stride(0)
