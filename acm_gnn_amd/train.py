@@ -329,13 +329,13 @@ class EvalStep:
 
 
 def fit(model, optimizer, x, adj, labels, train_idx, val_idx, test_idx, epochs, rule="max_val_acc",
-        early_stopping=0, adj_high=None, adj_un=None, use_graph=False, fused_dropout=None, pipeline_input=False):
+        early_stopping=0, adj_high=None, adj_un=None, use_graph=False, fused_dropout=None, pipeline_input=None):
     """Train and return (selected test accuracy, per-epoch history).
 
-    ``pipeline_input``: TrainStep's input pipeline.  Off by default HERE: with an evaluation pass after every step the
-    pipelined step loses what it wins alone (twitch-shaped graph: 0.551 against 0.544 ms per epoch, while the step alone
-    goes 0.346 -> 0.338 ms) -- its gather walks the id streams, a second 64 MB copy of the operator's column ids that
-    competes with the CSR's for the Infinity Cache once the evaluation pass's gathers run in between.
+    ``pipeline_input``: TrainStep's input pipeline (None = where the configuration qualifies, False = never).  On by
+    default since round 3: with the sixteen-rows-per-wave backward kernel carrying the gather, an epoch (training step +
+    evaluation pass, both captured) of the twitch-shaped graph takes 0.463 ms with it against 0.483 ms without
+    (round 2, with the older kernel: 0.551 against 0.544, so it was off here).
 
     rule = "max_val_acc":  test accuracy at the best validation accuracy, fixed number of epochs
                            (ACM-Geometric/train.py:139-140, logger.py:17-48)

@@ -269,6 +269,57 @@ def test_input_pipeline_matches_plain_step(monkeypatch, n, avg, model_type, use_
     assert float((pipe.saved[0] - pipe.filled[0]).abs().max()) > 0         # a different mask
 
 
+def test_fit_with_the_input_pipeline_equals_fit_without(monkeypatch):
+    """train.fit (captured training step + captured evaluation pass per epoch) with the input pipeline in its training
+    half -- the default -- against pipeline_input=False: the evaluation pass in between neither disturbs the look-ahead
+    buffers nor advances the dropout counter; same histories, same selected accuracy."""
+    from acm_gnn_amd import GCN, FusedAdamW, functional as AF, train as T
+    monkeypatch.setenv("ACM_PIPELINE_MIN_ROWS", "1024")
+    n = 6000
+    ops, x, y = _pipeline_case(n, 30, seed=11)
+    idx = torch.randperm(n, generator=torch.Generator().manual_seed(3)).to(DEV)
+    sets = (idx[: n // 2], idx[n // 2: 3 * n // 4], idx[3 * n // 4:])
+
+    def run(pipeline):
+        torch.manual_seed(0)
+        model = GCN(7, 64, 2, 2, n, 0.3, "acmgcnp", 0, variant=False, attn_layernorm=True).to(DEV)
+        model.dropout_state = AF.DropoutState(torch.device(DEV), seed=5)
+        opt = FusedAdamW(model.parameters(), lr=0.01, weight_decay=1e-3)
+        return T.fit(model, opt, x, ops, y, *sets, epochs=12, use_graph=True, pipeline_input=pipeline)
+
+    acc_a, hist_a = run(False)
+    acc_b, hist_b = run(None)
+    assert abs(acc_a - acc_b) < 5e-3
+    a = np.array([[float(v) for v in h.values()] if isinstance(h, dict) else [float(v) for v in h] for h in hist_a])
+    b = np.array([[float(v) for v in h.values()] if isinstance(h, dict) else [float(v) for v in h] for h in hist_b])
+    np.testing.assert_allclose(b, a, rtol=5e-3, atol=5e-3)
+
+
+def test_side_stream_for_the_next_table_changes_nothing(monkeypatch):
+    """ACM_PIPE_SIDE_STREAM=1: the next step's table is drawn on a side stream right behind the first layer's forward kernel
+    and joined by the backward that gathers from it -- eager and captured steps equal to the default order bit for bit."""
+    from acm_gnn_amd import GCN, FusedAdamW, functional as AF, train as T
+    monkeypatch.setenv("ACM_PIPELINE_MIN_ROWS", "1024")
+    n = 6000
+    ops, x, y = _pipeline_case(n, 30, seed=13)
+    w = T.row_weights(torch.arange(0, n, 3, device=DEV), n)
+
+    def run(side, use_graph):
+        monkeypatch.setenv("ACM_PIPE_SIDE_STREAM", side)
+        torch.manual_seed(0)
+        model = GCN(7, 64, 2, 2, n, 0.2, "acmgcnp", 0, variant=False, attn_layernorm=True).to(DEV)
+        model.dropout_state = AF.DropoutState(torch.device(DEV), seed=9)
+        step = T.TrainStep(model, FusedAdamW(model.parameters(), lr=0.01), x, ops, y, w, use_graph=use_graph)
+        assert step.pipe is not None and (step.pipe._side is not None) == (side == "1")
+        return [float(step()) for _ in range(6)], [p.detach().clone() for p in model.parameters()]
+
+    for use_graph in (False, True):
+        la, pa = run("0", use_graph)
+        lb, pb = run("1", use_graph)
+        assert la == lb
+        assert all(torch.equal(u, v) for u, v in zip(pa, pb))
+
+
 def test_carried_gather_leaves_the_backward_unchanged():
     """acm_conv_agg_bwd with and without next_agg: the parameter gradients agree (eight instead of four slabs per
     workgroup: another summation order), and the carried P equals the stand-alone product bit for bit across launches."""
