@@ -21,6 +21,15 @@ int acm_gemm_rows_tn_blocks(int64_t n_rows);
 int acm_gemm_rows_tn(int64_t n_rows, int64_t K, int64_t N, const float* X, int64_t ldx, const float* Dz, int64_t lddz,
                      float* slabs, int blocks, const acm_dropout_t* drop, hipStream_t st);
 
+// acm_gemm_bx3.hip: the same products on the bf16 matrix pipe at fp32 accuracy (three-way split operands), K <= 128
+bool acm_gemm_bx3_nn_ok(int64_t M, int64_t N, int64_t K, const float* A, int64_t lda);
+int acm_gemm_bx3_nn(int64_t M, int64_t N, int64_t K, const float* A, int64_t lda, const float* B, int64_t ldb, float* C,
+                    int64_t ldc, int relu, const acm_dropout_t* drop, hipStream_t st);
+bool acm_gemm_bx3_tn_ok(int64_t n_rows, int64_t K, int64_t N);
+int acm_gemm_bx3_tn_blocks(int64_t n_rows);
+int acm_gemm_bx3_tn(int64_t n_rows, int64_t K, int64_t N, const float* X, int64_t ldx, const float* Dz, int64_t lddz,
+                    float* slabs, int blocks, const acm_dropout_t* drop, hipStream_t st);
+
 namespace {
 
 constexpr int BK = 32;
@@ -261,8 +270,8 @@ extern "C" int acm_gemm_workspace_bytes(int transA, int transB, int64_t M, int64
     ACM_REQUIRE(M >= 0 && N >= 0 && K >= 0, ACM_ESHAPE, "acm_gemm_workspace_bytes: negative size");
     const GemmPlan p = plan_gemm(M, N, K);
     size_t need = p.splits > 1 ? (size_t)p.splits * (size_t)M * (size_t)N * sizeof(float) : 0;
-    if (transA && !transB && acm_gemm_rows_tn_ok(K, M, N, nullptr, 4)) {        // the row-panel form (may be taken): one slab per workgroup
-        const size_t rows = (size_t)acm_gemm_rows_tn_blocks(K) * (size_t)M * (size_t)N * sizeof(float);
+    if (transA && !transB && (acm_gemm_rows_tn_ok(K, M, N, nullptr, 4) || acm_gemm_bx3_tn_ok(K, M, N))) {   // the row-panel forms (may be taken): one slab per workgroup
+        const size_t rows = (size_t)256 * (size_t)M * (size_t)N * sizeof(float);
         need = rows > need ? rows : need;
     }
     *bytes = need;
@@ -349,15 +358,19 @@ static int gemm_core(int transA, int transB, int64_t M, int64_t N, int64_t K, co
     // against tile kernel:  NN 169343 x 192 x 128: 140 / 131;  x 21: 31 / 44;  TN 128 x 192 x 169343: 127 / 150;  x 41554: 53 / 41
     // -- one wave per SIMD serialises matrix pipe (43 % busy), staging and stores in the row-panel NN.  So without a dropout
     // to carry, the row-panel forms take only the shapes they win: narrow outputs (NN), very tall contractions (TN).
+    if (K > 0 && !transA && !transB && plain_out && !cb && acm_gemm_bx3_nn_ok(M, N, K, A, lda))
+        return acm_gemm_bx3_nn(M, N, K, A, lda, B, ldb, C, ldc, relu, a_drop, st);
     if (K > 0 && !transA && !transB && plain_out && !cb && acm_gemm_rows_nn_ok(M, N, K, B, ldb) &&
         (a_drop || N <= 64 || getenv("ACM_GEMM_ROWS_ALWAYS")))
         return acm_gemm_rows_nn(M, N, K, A, lda, B, ldb, C, ldc, relu, a_drop, st);
-    if (K > 0 && transA && !transB && plain_out && acm_gemm_rows_tn_ok(K, M, N, B, ldb) &&
-        (a_drop || K >= 100000 || getenv("ACM_GEMM_ROWS_ALWAYS"))) {
-        const int blocks = acm_gemm_rows_tn_blocks(K);
+    const bool bx3_tn = K > 0 && transA && !transB && plain_out && acm_gemm_bx3_tn_ok(K, M, N);
+    if (bx3_tn || (K > 0 && transA && !transB && plain_out && acm_gemm_rows_tn_ok(K, M, N, B, ldb) &&
+                   (a_drop || K >= 100000 || getenv("ACM_GEMM_ROWS_ALWAYS")))) {
+        const int blocks = bx3_tn ? acm_gemm_bx3_tn_blocks(K) : acm_gemm_rows_tn_blocks(K);
         const size_t need = (size_t)blocks * (size_t)M * (size_t)N * sizeof(float);
         ACM_REQUIRE(workspace && workspace_bytes >= need, ACM_ENOMEM, "acm_gemm: workspace %zu B < required %zu B", workspace_bytes, need);
-        int rc = acm_gemm_rows_tn(K, M, N, A, lda, B, ldb, (float*)workspace, blocks, a_drop, st);
+        int rc = bx3_tn ? acm_gemm_bx3_tn(K, M, N, A, lda, B, ldb, (float*)workspace, blocks, a_drop, st)
+                        : acm_gemm_rows_tn(K, M, N, A, lda, B, ldb, (float*)workspace, blocks, a_drop, st);
         if (rc != ACM_OK) return rc;
         const long total = (long)M * N;
         hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((total + 15) / 16)), dim3(256), 0, st, (int)M, (int)N, blocks,

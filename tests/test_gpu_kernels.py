@@ -101,12 +101,14 @@ def test_proj_fwd_matches_fp64(n, f_in, f, relu):
 
 
 @pytest.mark.parametrize("m,n,k,split", [(1000, 6, 64, 4), (168114, 6, 64, 4), (300, 24, 7, 16), (64, 12, 3000, 8), (5, 3, 2, 2)])
-def test_gemm_two_matrix_output(m, n, k, split):
+def test_gemm_two_matrix_output(m, n, k, split, monkeypatch):
     """acm_gemm_split: columns [0, split) to one matrix, the rest to another (direct and split-K stores)."""
     from acm_gnn_amd import functional as AF
     g = torch.Generator().manual_seed(m + n + k)
     a, b = torch.randn(m, k, generator=g), torch.randn(k, n, generator=g)
+    monkeypatch.setenv("ACM_GEMM_BX3_OFF", "1")          # the single-output product on the same kernel family (fp32 MFMA chain)
     whole = AF.gemm(a.to(DEV), b.to(DEV), relu=True)
+    monkeypatch.delenv("ACM_GEMM_BX3_OFF")
     o1 = torch.full((m, split + 3), 7.0, device=DEV)[:, :split]          # strided destinations keep their padding
     o2 = torch.full((m, n - split), 7.0, device=DEV)
     AF.gemm_split(a.to(DEV), b.to(DEV), o1, o2, relu=True)
@@ -330,6 +332,7 @@ def test_row_panel_gemm_equals_the_tile_kernel_bit_for_bit(m, n, k, monkeypatch)
     g = torch.Generator().manual_seed(m + n + k)
     a, b = torch.randn(m, k, generator=g).to(DEV), torch.randn(k, n, generator=g).to(DEV)
     monkeypatch.setenv("ACM_GEMM_ROWS_ALWAYS", "1")                   # (by default only the shapes it wins on, or with a dropout)
+    monkeypatch.setenv("ACM_GEMM_BX3_OFF", "1")                       # (K <= 128 otherwise takes the split-bf16 kernels, below)
     new = AF.gemm(a, b, relu=True)
     monkeypatch.setenv("ACM_GEMM_ROWS_OFF", "1")
     old = AF.gemm(a, b, relu=True)
@@ -349,6 +352,7 @@ def test_row_panel_transposed_gemm_matches_fp64(rows, f_in, n, blocks):
     vs float64, as column blocks too, and bit-identical from launch to launch."""
     from acm_gnn_amd import functional as AF
     os.environ["ACM_GEMM_ROWS_ALWAYS"] = "1"
+    os.environ["ACM_GEMM_BX3_OFF"] = "1"
     g = torch.Generator().manual_seed(rows + f_in + n)
     x, dz = torch.randn(rows, f_in, generator=g), torch.randn(rows, n, generator=g)
     ref = x.double().T @ dz.double()
@@ -360,6 +364,70 @@ def test_row_panel_transposed_gemm_matches_fp64(rows, f_in, n, blocks):
         parts = AF.gemm(x.to(DEV), dz.to(DEV), trans_a=True, col_blocks=blocks)
         assert torch.equal(torch.cat(list(parts), dim=1), got)
     os.environ.pop("ACM_GEMM_ROWS_ALWAYS", None)
+    os.environ.pop("ACM_GEMM_BX3_OFF", None)
+
+
+def _rel_err(got, a64, b64):
+    return float(((got.cpu().double() - a64 @ b64).abs() / (a64.abs() @ b64.abs() + 1e-30)).max())
+
+
+@pytest.mark.parametrize("m,n,k", [(9000, 192, 128), (8200, 21, 100), (20000, 15, 64), (168114, 192, 128), (10000, 180, 36),
+                                   (8192, 70, 32)])
+def test_split_bf16_projection_keeps_fp32_accuracy(m, n, k, monkeypatch):
+    """acm_gemm_bx3.hip (NN): Z = X W for a tall X of <= 128 columns on the bf16 matrix pipe, every fp32 operand split
+    EXACTLY into three bf16 numbers and six of the nine partial products kept: the error against float64 (relative to
+    sum |x||w|) stays at the level of the fp32 fmaf chain of the other kernels -- with entries spanning seven orders of
+    magnitude -- small integers are exact, the ReLU epilogue, ragged N / K and strided destinations work, and the result
+    is the same from launch to launch."""
+    from acm_gnn_amd import functional as AF
+    g = torch.Generator().manual_seed(m + n + k)
+    a, b = torch.randn(m, k, generator=g), torch.randn(k, n, generator=g)
+    a[::7] *= 1e3
+    a[::5] *= 1e-4
+    a, b = a.to(DEV), b.to(DEV)
+    new = AF.gemm(a, b)
+    monkeypatch.setenv("ACM_GEMM_BX3_OFF", "1")
+    old = AF.gemm(a, b)
+    monkeypatch.delenv("ACM_GEMM_BX3_OFF")
+    assert not torch.equal(new, old)                                   # (another kernel did run)
+    a64, b64 = a.cpu().double(), b.cpu().double()
+    e_new, e_old = _rel_err(new, a64, b64), _rel_err(old, a64, b64)
+    assert e_new < 1e-6 and e_new < 1.5 * e_old + 1e-8, (e_new, e_old)
+    assert torch.equal(new, AF.gemm(a, b))
+    assert torch.equal(AF.gemm(a, b, relu=True), new.clamp_min(0))
+    ai, bi = torch.randint(-8, 9, (m, k), generator=g).float(), torch.randint(-8, 9, (k, n), generator=g).float()
+    assert torch.equal(AF.gemm(ai.to(DEV), bi.to(DEV)).cpu(), ai @ bi)
+    out = torch.full((m, n + 5), 3.0, device=DEV)                     # a strided (and 16-byte misaligned) destination
+    AF.gemm(a, b, out=out[:, 2:2 + n])
+    assert torch.equal(out[:, 2:2 + n], new) and float((out[:, :2] - 3).abs().max()) == 0 and float((out[:, 2 + n:] - 3).abs().max()) == 0
+
+
+@pytest.mark.parametrize("rows,f_in,n,blocks", [(9000, 128, 192, 3), (20001, 100, 15, 3), (168114, 128, 192, 3), (8192, 33, 21, 0),
+                                                (40000, 64, 180, 0)])
+def test_split_bf16_weight_gradient_keeps_fp32_accuracy(rows, f_in, n, blocks, monkeypatch):
+    """acm_gemm_bx3.hip (TN): dW = X^T dZ, the contraction over the rows: tiles split while they are staged, operands read
+    from LDS as packed row pairs; vs float64 at the fp32 kernels' level, exact on small integers, deterministic, column
+    blocks."""
+    from acm_gnn_amd import functional as AF
+    g = torch.Generator().manual_seed(rows + f_in + n)
+    x, dz = torch.randn(rows, f_in, generator=g), torch.randn(rows, n, generator=g)
+    x[::3] *= 1e2
+    dz[::11] *= 1e-3
+    x, dz = x.to(DEV), dz.to(DEV)
+    new = AF.gemm(x, dz, trans_a=True)
+    monkeypatch.setenv("ACM_GEMM_BX3_OFF", "1")
+    old = AF.gemm(x, dz, trans_a=True)
+    monkeypatch.delenv("ACM_GEMM_BX3_OFF")
+    assert not torch.equal(new, old)
+    x64, dz64 = x.cpu().double(), dz.cpu().double()
+    e_new, e_old = _rel_err(new, x64.T, dz64), _rel_err(old, x64.T, dz64)
+    assert e_new < 1e-6 and e_new < 2.0 * e_old + 1e-8, (e_new, e_old)
+    assert torch.equal(new, AF.gemm(x, dz, trans_a=True))
+    xi, zi = torch.randint(-3, 4, (rows, f_in), generator=g).float(), torch.randint(-3, 4, (rows, n), generator=g).float()
+    assert torch.equal(AF.gemm(xi.to(DEV), zi.to(DEV), trans_a=True).cpu().double(), xi.double().T @ zi.double())
+    if blocks:
+        parts = AF.gemm(x, dz, trans_a=True, col_blocks=blocks)
+        assert torch.equal(torch.cat(list(parts), dim=1), new)
 
 
 @pytest.mark.parametrize("rows,f_in,n", [(9000, 128, 192), (20001, 100, 15), (8200, 17, 21), (168114, 128, 192)])
