@@ -208,32 +208,83 @@ __global__ __launch_bounds__(512, NT <= 4 ? 4 : 2) void gemm_bx3_nn_kernel(int M
     }
 }
 
-// ---- TN: slab[b][K, N] = drop(X)[rows of block b]^T dZ[rows of block b].  512 threads; a 32-row slab of X (<= 128 columns) and
-// dZ (16 NT columns) is split while it is staged and parked in LDS as T[part][column][row pairs] (16 dwords + 4 of padding
-// per column: the operand reads -- lane (g, m): column 16 t + m, rows 8 g .. 8 g + 7 = one ds_read_b128 -- and the staging
-// writes both fall on 64 distinct banks).  Two LDS buffers: the next slab's rows are requested before the current slab feeds
-// the matrix pipe and parked after it, one barrier per slab.  Wave w: output rows 32 (w & 3) .. + 31, half of the columns.
+// ---- TN: slab[b][K, N] = drop(X)[rows of block b]^T dZ[rows of block b].  A 32-row slab of X (<= 128 columns) and dZ (16 NT
+// columns) is split while it is staged and parked in LDS as T[part][column][row pairs] (16 dwords + 4 of padding per column:
+// the operand reads -- lane (g, m): column 16 t + m, rows 8 g .. 8 g + 7 = one ds_read_b128 -- and the staging writes both
+// fall on 64 distinct banks).  512 threads = TWO groups of four waves, each a pipeline of its own over every other slab with
+// its own LDS buffer and a full set of accumulators (wave w of a group: output rows 32 w .. + 31, all columns): while one
+// group feeds the matrix pipe from its buffer, the other splits and parks its next slab, so every SIMD holds one wave of
+// each kind and the vector and matrix pipes overlap (with all eight waves in one phase a slab cost its VALU work PLUS its
+// matrix work: 75 us for the 169 343 x 128 x 192 product).  The rows of a group's next slab are requested before it starts
+// feeding the pipe.  The two groups' accumulators meet in LDS at the end.
 constexpr int TS = 20;                     // dwords per column in LDS
+// Workgroup barrier that orders LDS traffic only: __syncthreads() also drains the global loads in flight (s_waitcnt vmcnt(0)),
+// i.e. the next slab's rows requested a phase ahead -- every phase would last a full memory latency.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 template <int NT>
 __global__ __launch_bounds__(512, 2) void gemm_bx3_tn_kernel(int n_rows, int K, int N, const float* __restrict__ X, long ldx,
                                                              const float* __restrict__ Dz, long lddz, float* __restrict__ slabs,
-                                                             int rows_per_block, acm_dropout_t drop) {
-    extern __shared__ __attribute__((aligned(16))) unsigned Tl[];    // [buf 2][part 3][128 + 16 NT columns][TS]
-    constexpr int COLS = 128 + 16 * NT, BUF = 3 * COLS * TS, ZT = (64 * NT + 511) / 512, HT = NT / 2;
+                                                             int rows_per_block, acm_dropout_t drop, int dbg) {
+    extern __shared__ __attribute__((aligned(16))) unsigned Tl[];    // [group 2][part 3][128 + 16 NT columns][TS]
+    constexpr int COLS = 128 + 16 * NT, BUF = 3 * COLS * TS, ZT = (64 * NT + 255) / 256;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, m = lane & 15, g = lane >> 4;
+    const int grp = wv >> 2, wg = wv & 3, tid = threadIdx.x & 255;
     const int r_begin = blockIdx.x * rows_per_block, r_end = min(n_rows, r_begin + rows_per_block);
+    const int ns = (r_end - r_begin + 31) / 32, iters = (ns + 1) / 2;
     const AcmDropCtx dc = acm_drop_ctx(drop);
-    const int xc = threadIdx.x & 127, xrg = threadIdx.x >> 7;        // this thread's column / group of eight rows of the X slab
-    float xv[8], zv[ZT][8];
-    auto fetch = [&](int r0) {
+    unsigned* T = Tl + grp * BUF;
+    // staging tasks of a group's 256 threads: X: (column 0..127) x (eight rows 8 rg .. 8 rg + 7), two per thread;
+    // dZ: (column 0..16 NT - 1) x rg, ZT per thread
+    float xv[2][8], zv[ZT][8];
+    // per-task lane offsets (loop-invariant, 32-bit) and validity; the row part of an address is uniform: base + row * ld
+    unsigned xoff[2], zoff[ZT];
+    bool xok[2], zok[ZT];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            const int row = r0 + 8 * xrg + e;
-            xv[e] = (row < r_end && xc < K) ? X[(long)row * ldx + xc] : 0.f;
+    for (int u = 0; u < 2; ++u) {
+        const int t = tid + 256 * u, xc = t & 127, xrg = t >> 7;
+        xok[u] = xc < K;
+        xoff[u] = (unsigned)(8 * xrg) * (unsigned)ldx + (unsigned)(xok[u] ? xc : 0);
+    }
+#pragma unroll
+    for (int u = 0; u < ZT; ++u) {
+        const int t = tid + 256 * u, zc = t % (16 * NT), zrg = t / (16 * NT);
+        zok[u] = zrg < 4 && zc < N;
+        zoff[u] = (unsigned)(8 * (zok[u] ? zrg : 0)) * (unsigned)lddz + (unsigned)(zok[u] ? zc : 0);
+    }
+    auto fetch = [&](int r0) {
+        if (dbg & 4) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                xv[0][e] = xv[1][e] = 0.f;
+#pragma unroll
+                for (int u = 0; u < ZT; ++u) zv[u][e] = 0.f;
+            }
+            return;
+        }
+        if (r0 + 32 <= r_end) {                    // whole slab: no row guards, uniform row bases + the lane's 32-bit offset
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float* xr = X + (long)(r0 + e) * ldx;
+                const float* zr = Dz + (long)(r0 + e) * lddz;
+#pragma unroll
+                for (int u = 0; u < 2; ++u) xv[u][e] = xr[xoff[u]];
+#pragma unroll
+                for (int u = 0; u < ZT; ++u) zv[u][e] = zr[zoff[u]];
+            }
+            return;                                 // (columns beyond K / N are zeroed where the values are used: park)
+        }
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {              // the last, ragged slab of the matrix
+            const int t = tid + 256 * u, xc = t & 127, xrg = t >> 7;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int row = r0 + 8 * xrg + e;
+                xv[u][e] = (row < r_end && xc < K) ? X[(long)row * ldx + xc] : 0.f;
+            }
         }
 #pragma unroll
         for (int u = 0; u < ZT; ++u) {
-            const int t = threadIdx.x + 512 * u, zc = t % (16 * NT), zrg = t / (16 * NT);
+            const int t = tid + 256 * u, zc = t % (16 * NT), zrg = t / (16 * NT);
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
                 const int row = r0 + 8 * zrg + e;
@@ -241,35 +292,44 @@ __global__ __launch_bounds__(512, 2) void gemm_bx3_tn_kernel(int n_rows, int K, 
             }
         }
     };
-    auto park = [&](int r0, unsigned* T) {
-        if (dc.on) {
-            // lane l of a wave holds column 64 G + l: word l >> 4 of Philox(row, (l & 15) + 16 G).  Each lane draws TWO of the
-            // eight rows (2 q, 2 q + 1 with q = l >> 4) and keeps 8 bits; four ds_bpermutes hand every lane its own eight.
-            const int q = lane >> 4, blockc = (lane & 15) + 16 * (xc >> 6);
-            unsigned bits = 0;
-#pragma unroll
-            for (int jj = 0; jj < 2; ++jj) {
-                unsigned w[4];
-                acm_philox7(dc, r0 + 8 * xrg + 2 * q + jj, blockc, w);
-#pragma unroll
-                for (int u = 0; u < 4; ++u) bits |= (w[u] >= dc.thresh ? 1u : 0u) << (4 * jj + u);
-            }
-#pragma unroll
-            for (int sq = 0; sq < 4; ++sq) {
-                const unsigned b = (unsigned)__builtin_amdgcn_ds_bpermute(4 * (16 * sq + (lane & 15)), (int)bits);
-#pragma unroll
-                for (int jj = 0; jj < 2; ++jj)
-                    xv[2 * sq + jj] = ((b >> (4 * jj + q)) & 1u) ? xv[2 * sq + jj] * dc.inv_keep : 0.f;
-            }
-        }
+    auto park = [&](int r0) {
         u32x4 hi, md, lo;
-        split3(xv, hi, md, lo);
-        *reinterpret_cast<u32x4*>(T + (0 * COLS + xc) * TS + 4 * xrg) = hi;
-        *reinterpret_cast<u32x4*>(T + (1 * COLS + xc) * TS + 4 * xrg) = md;
-        *reinterpret_cast<u32x4*>(T + (2 * COLS + xc) * TS + 4 * xrg) = lo;
+        if (dbg & 2) { if (xv[0][0] == 123.f && zv[0][0] == 77.f) T[tid] = 1; return; }
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int t = tid + 256 * u, xc = t & 127, xrg = t >> 7;
+            if (dc.on) {
+                // lane l of a wave holds column 64 G + l: word l >> 4 of Philox(row, (l & 15) + 16 G).  Each lane draws TWO of
+                // the eight rows (2 q, 2 q + 1 with q = l >> 4) and keeps 8 bits; four ds_bpermutes hand every lane its eight.
+                const int q = lane >> 4, blockc = (lane & 15) + 16 * (xc >> 6);
+                unsigned bits = 0;
+#pragma unroll
+                for (int jj = 0; jj < 2; ++jj) {
+                    unsigned w[4];
+                    acm_philox7(dc, r0 + 8 * xrg + 2 * q + jj, blockc, w);
+#pragma unroll
+                    for (int v = 0; v < 4; ++v) bits |= (w[v] >= dc.thresh ? 1u : 0u) << (4 * jj + v);
+                }
+#pragma unroll
+                for (int sq = 0; sq < 4; ++sq) {
+                    const unsigned bb = (unsigned)__builtin_amdgcn_ds_bpermute(4 * (16 * sq + (lane & 15)), (int)bits);
+#pragma unroll
+                    for (int jj = 0; jj < 2; ++jj)
+                        xv[u][2 * sq + jj] = ((bb >> (4 * jj + q)) & 1u) ? xv[u][2 * sq + jj] * dc.inv_keep : 0.f;
+                }
+            }
+#pragma unroll
+            for (int e = 0; e < 8; ++e) xv[u][e] = xok[u] ? xv[u][e] : 0.f;
+            split3(xv[u], hi, md, lo);
+            *reinterpret_cast<u32x4*>(T + (0 * COLS + xc) * TS + 4 * xrg) = hi;
+            *reinterpret_cast<u32x4*>(T + (1 * COLS + xc) * TS + 4 * xrg) = md;
+            *reinterpret_cast<u32x4*>(T + (2 * COLS + xc) * TS + 4 * xrg) = lo;
+        }
 #pragma unroll
         for (int u = 0; u < ZT; ++u) {
-            const int t = threadIdx.x + 512 * u, zc = t % (16 * NT), zrg = t / (16 * NT);
+            const int t = tid + 256 * u, zc = t % (16 * NT), zrg = t / (16 * NT);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) zv[u][e] = zok[u] ? zv[u][e] : 0.f;
             split3(zv[u], hi, md, lo);
             if (zrg < 4) {
                 *reinterpret_cast<u32x4*>(T + (0 * COLS + 128 + zc) * TS + 4 * zrg) = hi;
@@ -278,14 +338,14 @@ __global__ __launch_bounds__(512, 2) void gemm_bx3_tn_kernel(int n_rows, int K, 
             }
         }
     };
-    f32x4 acc[2][HT];
+    f32x4 acc[2][NT];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < HT; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    const int it0 = 2 * (wv & 3), jt0 = HT * (wv >> 2);
+        for (int j = 0; j < NT; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const int it0 = 2 * wg;
     const bool live = 16 * it0 < K;
-    auto feed = [&](const unsigned* T) {
+    auto feed = [&]() {
         u32x4 a[2][3];
 #pragma unroll
         for (int i = 0; i < 2; ++i)
@@ -293,11 +353,11 @@ __global__ __launch_bounds__(512, 2) void gemm_bx3_tn_kernel(int n_rows, int K, 
             for (int part = 0; part < 3; ++part)
                 a[i][part] = *reinterpret_cast<const u32x4*>(T + (part * COLS + 16 * (it0 + i) + m) * TS + 4 * g);
 #pragma unroll
-        for (int j = 0; j < HT; ++j) {
+        for (int j = 0; j < NT; ++j) {
             u32x4 b[3];
 #pragma unroll
             for (int part = 0; part < 3; ++part)
-                b[part] = *reinterpret_cast<const u32x4*>(T + (part * COLS + 128 + 16 * (jt0 + j) + m) * TS + 4 * g);
+                b[part] = *reinterpret_cast<const u32x4*>(T + (part * COLS + 128 + 16 * j + m) * TS + 4 * g);
             // A operand = X^T (hi, mid, lo = a[i][0..2]), B operand = dZ; two accumulators alternate, small terms first
             acc[0][j] = mma(a[0][2], b[0], acc[0][j]);
             acc[1][j] = mma(a[1][2], b[0], acc[1][j]);
@@ -313,30 +373,39 @@ __global__ __launch_bounds__(512, 2) void gemm_bx3_tn_kernel(int n_rows, int K, 
             acc[1][j] = mma(a[1][0], b[0], acc[1][j]);
         }
     };
-    // (Requesting 64 rows at a time -- twice the bytes in flight -- measured no faster: with every wave of the workgroup in the
-    // same phase the slab costs its VALU work (split, guards) PLUS its matrix work, not the larger of the two.)
-    if (r_begin < r_end) {
-        fetch(r_begin);
-        park(r_begin, Tl);
+    // group 0 parks in even phases and feeds in odd ones, group 1 the other way round; every wave passes 2 iters + 1 barriers
+    if (grp < ns) fetch(r_begin + 32 * grp);
+    if (grp == 1) lds_barrier();
+    for (int i = 0; i < ((dbg & 16) ? 0 : iters); ++i) {
+        const int sl = grp + 2 * i;
+        if (sl < ns) park(r_begin + 32 * sl);
+        lds_barrier();
+        if (sl + 2 < ns) fetch(r_begin + 32 * (sl + 2));
+        if (sl < ns && live && !(dbg & 1)) feed();
+        lds_barrier();
     }
-    int buf = 0;
-    for (int r0 = r_begin; r0 < r_end; r0 += 32, buf ^= 1) {
-        __syncthreads();                            // slab `buf` is parked; everyone is done with the other buffer
-        const bool more = r0 + 32 < r_end;
-        if (more) fetch(r0 + 32);
-        if (live) feed(Tl + buf * BUF);
-        if (more) park(r0 + 32, Tl + (buf ^ 1) * BUF);
-    }
-    float* dst = slabs + (long)blockIdx.x * K * N;
-    if (live) {
+    if (grp == 0) lds_barrier();
+    // the two groups' sums meet in LDS: group 1 writes [K rows][16 NT columns], group 0 adds and stores
+    float* S = reinterpret_cast<float*>(Tl);
+    if (grp == 1 && live) {
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
-            for (int j = 0; j < HT; ++j)
+            for (int j = 0; j < NT; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) S[(16 * (it0 + i) + 4 * g + r) * (16 * NT) + 16 * j + m] = acc[i][j][r];
+    }
+    __syncthreads();
+    float* dst = slabs + (long)blockIdx.x * K * N;
+    if (grp == 0 && live) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < NT; ++j)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const int f = 16 * (it0 + i) + 4 * g + r, col = 16 * (jt0 + j) + m;
-                    if (f < K && col < N) dst[(long)f * N + col] = acc[i][j][r];
+                    const int f = 16 * (it0 + i) + 4 * g + r, col = 16 * j + m;
+                    if (f < K && col < N && !(dbg & 8)) dst[(long)f * N + col] = acc[i][j][r] + S[f * (16 * NT) + col];
                 }
     }
 }
@@ -399,11 +468,12 @@ int acm_gemm_bx3_tn(int64_t n_rows, int64_t K, int64_t N, const float* X, int64_
     int64_t rpb = (n_rows + blocks - 1) / blocks;
     rpb = (rpb + 31) / 32 * 32;
     const size_t lds = (size_t)2 * 3 * (128 + 16 * ntr) * 20 * sizeof(unsigned);
+    const int dbg = getenv("ACM_GEMM_BX3_DBG") ? atoi(getenv("ACM_GEMM_BX3_DBG")) : 0;
 #define ACM_BX3T(NTv)                                                                                                   \
     do {                                                                                                                \
         ACM_CHECK_HIP(hipFuncSetAttribute((const void*)gemm_bx3_tn_kernel<NTv>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
         hipLaunchKernelGGL((gemm_bx3_tn_kernel<NTv>), dim3(blocks), dim3(512), lds, st, (int)n_rows, (int)K, (int)N, X,  \
-                           (long)ldx, Dz, (long)lddz, slabs, (int)rpb, drop);                                          \
+                           (long)ldx, Dz, (long)lddz, slabs, (int)rpb, drop, dbg);                                        \
     } while (0)
     switch (ntr) {
         case 2: ACM_BX3T(2); break;
