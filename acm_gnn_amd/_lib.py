@@ -14,13 +14,13 @@ c_i32p = C.POINTER(C.c_int32)
 
 ACM_OK = 0
 STATUS_NAMES = {1: "ACM_EINVAL", 2: "ACM_ESHAPE", 3: "ACM_EHIP", 4: "ACM_EUNSUPPORTED", 5: "ACM_ENOMEM"}
-ABI_VERSION = 20
+ABI_VERSION = 21
 
 # every symbol include/acm_hip.h declares
 EXPORTED_SYMBOLS = (
     "acm_version", "acm_last_error", "acm_csr_create", "acm_csr_transpose", "acm_csr_slice_rows",
     "acm_csr_destroy", "acm_csr_info", "acm_csr_build_streams", "acm_spmm_workspace_bytes", "acm_gemm_workspace_bytes",
-    "acm_gemm", "acm_gemm_blocks", "acm_gemm_drop", "acm_gemm_split", "acm_proj_fwd", "acm_proj_fwd_at", "acm_proj_bwd_workspace_bytes", "acm_proj_bwd", "acm_spmm", "acm_spmm_v", "acm_spmm_ex", "acm_cast_bf16", "acm_conv_fwd", "acm_conv_bwd_local_workspace_bytes",
+    "acm_gemm", "acm_gemm_blocks", "acm_gemm_drop", "acm_proj3", "acm_gemm_split", "acm_proj_fwd", "acm_proj_fwd_at", "acm_proj_bwd_workspace_bytes", "acm_proj_bwd", "acm_spmm", "acm_spmm_v", "acm_spmm_ex", "acm_cast_bf16", "acm_conv_fwd", "acm_conv_bwd_local_workspace_bytes",
     "acm_conv_bwd_local", "acm_conv_bwd_spmm", "acm_conv_agg_fwd", "acm_conv_agg_bwd_workspace_bytes",
     "acm_conv_agg_bwd", "acm_nll_loss_workspace_bytes", "acm_nll_loss", "acm_adam_step", "acm_dropout",
     "acm_reduce_flush", "acm_conv_fwd_tail_workspace_bytes", "acm_conv_fwd_tail", "acm_shard_plan",
@@ -224,6 +224,7 @@ def _declare(lib):
     lib.acm_gemm_split.argtypes = [i32, i32, i64, i64, i64, vp, i64, vp, i64, vp, i64, i64, vp, i64, i32, vp, sz, vp]
     lib.acm_gemm_blocks.argtypes = [i32, i32, i64, i64, i64, vp, i64, vp, i64, vp, i64, i64, i64, i32, vp, sz, vp]
     lib.acm_gemm_drop.argtypes = [i32, i32, i64, i64, i64, vp, i64, vp, i64, vp, i64, i64, i64, i32, C.POINTER(Dropout), vp, sz, vp]
+    lib.acm_proj3.argtypes = [i64, i64, vp, i64, vp, vp, vp, i64, i64, i64, vp, i64, i64, vp, i64, i32, C.POINTER(Dropout), vp]
     lib.acm_spmm.argtypes = [vp, vp, i64, i32, vp, i64, vp, sz, vp]
     lib.acm_spmm_v.argtypes = [vp, vp, vp, i64, i32, vp, i64, i32, vp, sz, vp]
     lib.acm_adam_step.argtypes = [i32, vp, vp, vp]

@@ -599,7 +599,29 @@ __global__ __launch_bounds__(256) void spmm_fixup_kernel(CsrView csr, int F, typ
     for (int c = 0; c < NG; ++c)
 #pragma unroll
         for (int r = 0; r < NREG; ++r) acc[c][r] = 0.f;
-    for (int s = sb; s < se; ++s) {
+    // four slots' loads in flight, added in slot order (a dependent load per slot made this the latency of 16 round trips)
+    int s = sb;
+    for (; s + 4 <= se; s += 4) {
+        float v[4][NG][NREG];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const float* ps = partial + (long)(s + u) * (NG * F);
+#pragma unroll
+            for (int c = 0; c < NG; ++c)
+#pragma unroll
+                for (int r = 0; r < NREG; ++r) {
+                    const int col = lane + 64 * r;
+                    v[u][c][r] = col < F ? ps[c * F + col] : 0.f;
+                }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int c = 0; c < NG; ++c)
+#pragma unroll
+                for (int r = 0; r < NREG; ++r) acc[c][r] += v[u][c][r];
+    }
+    for (; s < se; ++s) {
         const float* ps = partial + (long)s * (NG * F);
 #pragma unroll
         for (int c = 0; c < NG; ++c)

@@ -54,12 +54,24 @@ __device__ __forceinline__ f32x4 mma(u32x4 a, u32x4 b, f32x4 c) {
 // column of X / row of W behind contraction slot (k block kb, lane group g, element e)
 __device__ __forceinline__ int bx3_k(int kb, int g, int e) { return 64 * (kb >> 1) + 16 * (2 * (kb & 1) + (e >> 2)) + 4 * g + (e & 3); }
 
+// Where the columns of the product come from and go to.  b1 != nullptr: B = [B0 0 | B1 0 | B2], three [K, f] matrices read in
+// place, the first two at a column pitch of fb >= f (zero columns between: acm_proj3).  split > 0: columns [0, split) to C,
+// the rest to C2.
+struct Bx3Cols {
+    const float* b1;
+    const float* b2;
+    int f, fb, split;
+    float* c2;
+    long ldc2;
+    int vecc2;
+};
+
 // ---- NN.  NT column tiles of 16 (even); 512 threads = 8 waves, each on its own panels of 16 NA rows (grid-stride).  The rows of
 // the NEXT panel are requested before the current one feeds the matrix pipe (two register sets).
 template <int NT, int NA>
 __global__ __launch_bounds__(512, NT <= 4 ? 4 : 2) void gemm_bx3_nn_kernel(int M, int N, int K, const float* __restrict__ A, long lda,
                                                           const float* __restrict__ B, long ldb, float* __restrict__ C, long ldc,
-                                                          int relu, acm_dropout_t drop, int vecc, int dbg) {
+                                                          int relu, acm_dropout_t drop, int vecc, int dbg, Bx3Cols cs) {
     extern __shared__ __attribute__((aligned(16))) u32x4 Ws[];       // [part 3][tile NT][kb 4][lane 64]
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, m = lane & 15, g = lane >> 4;
     // W^T as the A operand: lane (g, i = m) of tile j, k block kb holds W[bx3_k(kb, g, e)][16 j + i], e = 0..7
@@ -72,7 +84,16 @@ __global__ __launch_bounds__(512, NT <= 4 ? 4 : 2) void gemm_bx3_nn_kernel(int M
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
             const int kr = bx3_k(kb, gi, e);
-            wst[it][e] = (idx < NT * 256 && kr < K && col < N) ? B[(long)kr * ldb + col] : 0.f;
+            const float* bp = B;
+            int cc = col;
+            bool ok = idx < NT * 256 && kr < K && col < N;
+            if (cs.b1) {                           // three matrices in place, channel blocks of fb columns
+                const int blk = col < 2 * cs.fb ? col / cs.fb : 2;
+                cc = col - blk * cs.fb;
+                bp = blk == 0 ? B : (blk == 1 ? cs.b1 : cs.b2);
+                ok = ok && cc < cs.f;
+            }
+            wst[it][e] = ok ? bp[(long)kr * ldb + cc] : 0.f;
         }
     }
 #pragma unroll
@@ -197,7 +218,18 @@ __global__ __launch_bounds__(512, NT <= 4 ? 4 : 2) void gemm_bx3_nn_kernel(int M
                 f32x4 v = acc[p][j];
                 if (relu) v = (f32x4){fmaxf(v[0], 0.f), fmaxf(v[1], 0.f), fmaxf(v[2], 0.f), fmaxf(v[3], 0.f)};
                 const int col = 16 * j + 4 * g;
-                if (vecc && col + 3 < N) *reinterpret_cast<f32x4*>(dst + 16 * j) = v;
+                if (cs.split > 0 && col + 3 >= cs.split) {          // (a group of four straddling the cut goes element-wise)
+                    float* d2 = cs.c2 + (long)row * cs.ldc2;
+                    if (col >= cs.split && cs.vecc2 && col + 3 < N) *reinterpret_cast<f32x4*>(d2 + (col - cs.split)) = v;
+                    else {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            if (col + r >= N) continue;
+                            if (col + r < cs.split) dst[16 * j + r] = v[r];
+                            else d2[col + r - cs.split] = v[r];
+                        }
+                    }
+                } else if (vecc && col + 3 < N) *reinterpret_cast<f32x4*>(dst + 16 * j) = v;
                 else {
 #pragma unroll
                     for (int r = 0; r < 4; ++r)
@@ -418,8 +450,13 @@ bool acm_gemm_bx3_nn_ok(int64_t M, int64_t N, int64_t K, const float* A, int64_t
            getenv("ACM_GEMM_BX3_OFF") == nullptr;
 }
 
-int acm_gemm_bx3_nn(int64_t M, int64_t N, int64_t K, const float* A, int64_t lda, const float* B, int64_t ldb, float* C,
-                    int64_t ldc, int relu, const acm_dropout_t* drop_in, hipStream_t st) {
+// w3 != nullptr: B, w3[0], w3[1] are the three [K, f] matrices of acm_proj3 (pitch ldb each), N = 2 fb + f
+static int bx3_nn_ex(int64_t M, int64_t N, int64_t K, const float* A, int64_t lda, const float* B, int64_t ldb, float* C,
+                     int64_t ldc, int relu, const acm_dropout_t* drop_in, hipStream_t st, const float* const* w3, int f, int fb,
+                     int64_t split, float* C2, int64_t ldc2) {
+    Bx3Cols cs = {nullptr, nullptr, f, fb, (int)split, C2, (long)ldc2, 0};
+    if (w3) cs.b1 = w3[0], cs.b2 = w3[1];
+    cs.vecc2 = split > 0 && split % 4 == 0 && ldc2 % 4 == 0 && ((uintptr_t)C2) % 16 == 0;
     acm_dropout_t drop = {0.f, 0, 0, nullptr, 0, 0};
     if (drop_in) drop = *drop_in;
     const int nt = (int)((N + 15) / 16);
@@ -437,7 +474,7 @@ int acm_gemm_bx3_nn(int64_t M, int64_t N, int64_t K, const float* A, int64_t lda
     do {                                                                                                                \
         ACM_CHECK_HIP(hipFuncSetAttribute((const void*)gemm_bx3_nn_kernel<NTv, NAv>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
         hipLaunchKernelGGL((gemm_bx3_nn_kernel<NTv, NAv>), dim3(grid), dim3(512), lds, st, (int)M, (int)N, (int)K, A, (long)lda, B,  \
-                           (long)ldb, C, (long)ldc, relu, drop, vecc, dbg);                                                \
+                           (long)ldb, C, (long)ldc, relu, drop, vecc, dbg, cs);                                                \
     } while (0)
     switch (ntr) {
         case 2: ACM_BX3(2, 1); break;
@@ -484,4 +521,27 @@ int acm_gemm_bx3_tn(int64_t n_rows, int64_t K, int64_t N, const float* X, int64_
 #undef ACM_BX3T
     ACM_CHECK_HIP(hipGetLastError());
     return ACM_OK;
+}
+
+int acm_gemm_bx3_nn(int64_t M, int64_t N, int64_t K, const float* A, int64_t lda, const float* B, int64_t ldb, float* C,
+                    int64_t ldc, int relu, const acm_dropout_t* drop_in, hipStream_t st) {
+    return bx3_nn_ex(M, N, K, A, lda, B, ldb, C, ldc, relu, drop_in, st, nullptr, 0, 0, 0, nullptr, 0);
+}
+
+// Z = relu?(drop?(X) [W_L 0 | W_H 0 | W_I]): header acm_proj3
+extern "C" int acm_proj3(int64_t n_rows, int64_t K, const float* X, int64_t ldx, const float* w_low, const float* w_high,
+                         const float* w_mlp, int64_t ld_w, int64_t f, int64_t f_block, float* C, int64_t ldc, int64_t split_col,
+                         float* C2, int64_t ldc2, int relu, const acm_dropout_t* x_drop, acm_stream_t stream) {
+    ACM_REQUIRE(X && w_low && w_high && w_mlp && C, ACM_EINVAL, "acm_proj3: NULL argument");
+    ACM_REQUIRE(f >= 1 && f_block >= f && ld_w >= f && ldc >= 1 && split_col >= 0 && (split_col == 0 || (C2 && ldc2 >= 1)), ACM_ESHAPE,
+                "acm_proj3: f %lld f_block %lld ld_w %lld split %lld", (long long)f, (long long)f_block, (long long)ld_w, (long long)split_col);
+    const int64_t N = 2 * f_block + f;
+    ACM_REQUIRE(split_col <= N, ACM_ESHAPE, "acm_proj3: split_col %lld > %lld columns", (long long)split_col, (long long)N);
+    if (n_rows == 0) return ACM_OK;
+    ACM_REQUIRE(acm_gemm_bx3_nn_ok(n_rows, N, K, X, ldx), ACM_EUNSUPPORTED,
+                "acm_proj3: the split-bf16 row-panel kernel takes >= 8192 rows of 32..128 features (a multiple of 4, 16-byte aligned "
+                "rows) and at most 192 product columns; got %lld x %lld -> %lld", (long long)n_rows, (long long)K, (long long)N);
+    const float* w3[2] = {w_high, w_mlp};
+    return bx3_nn_ex(n_rows, N, K, X, ldx, w_low, ld_w, C, ldc, relu, (x_drop && x_drop->p > 0.f) ? x_drop : nullptr,
+                     (hipStream_t)stream, w3, (int)f, (int)f_block, split_col, C2, ldc2);
 }

@@ -561,6 +561,35 @@ def gemm_split(a, b, out1, out2, relu=False):
     _lib.check(st, "acm_gemm_split")
 
 
+def proj3(x, weights, f_block, out, out2=None, relu=False, x_drop=None):
+    """[Z_L 0 | Z_H 0 | Z_I] = relu?(drop?(x) @ [W_L 0 | W_H 0 | W_I]) with the three weight matrices read in place
+    (acm_proj3: no packed copy of the weights, the input dropout drawn in the operand load): the first two channels in
+    blocks of ``f_block`` columns; all 2 f_block + F columns go to ``out``, or the first out.shape[1] to ``out`` and the rest
+    to ``out2``.  Returns False -- nothing launched -- outside the kernel's envelope (tall dense x of 32..128 features)."""
+    if not isinstance(x, torch.Tensor) or x.dtype != _F32 or x.dim() != 2 or os.environ.get("ACM_PROJ3", "1") == "0":
+        return False
+    n, k = x.shape
+    ws3 = list(weights)
+    f = ws3[0].shape[1]
+    ncols = 2 * int(f_block) + f
+    if (n < 8192 or not 32 <= k <= 128 or k % 4 or x.stride(1) != 1 or x.stride(0) % 4 or x.data_ptr() % 16 or ncols > 192
+            or any(w.dtype != _F32 or tuple(w.shape) != (k, f) or w.stride(1) != 1 or w.stride(0) != ws3[0].stride(0)
+                   or w.device != x.device for w in ws3)
+            or os.environ.get("ACM_GEMM_BX3_OFF") is not None):
+        return False
+    split = 0 if out2 is None else out.shape[1]
+    if out.shape[0] != n or (out2 is None and out.shape[1] != ncols) or (out2 is not None and tuple(out2.shape) != (n, ncols - split)):
+        raise ValueError("proj3: shape mismatch")
+    with _device_ctx(x.device), _Timed(f"proj3/{n}x{ncols}x{k}"):
+        st = _lib.load().acm_proj3(n, k, _vp(x), x.stride(0), _vp(ws3[0]), _vp(ws3[1]), _vp(ws3[2]), ws3[0].stride(0), f,
+                                   int(f_block), _vp(out), out.stride(0), split, _vp(out2), out2.stride(0) if out2 is not None else 0,
+                                   int(relu), C.byref(x_drop) if x_drop is not None else None, _stream())
+    if st == 4:                                   # ACM_EUNSUPPORTED after all
+        return False
+    _lib.check(st, "acm_proj3")
+    return True
+
+
 def proj_fwd(x, weights, out_lh, out_i, relu=False, h_col=None):
     """[out_lh | out_i] = relu?(x @ [W_L | W_H | W_I]) for a narrow layer (F <= 8), straight from the three weight
     matrices (acm_proj_fwd): out_lh [n, 2F] is the gathered block, out_i [n, F].  ``h_col`` (acm_proj_fwd_at): Z_H starts
@@ -1188,13 +1217,6 @@ class AcmConvFunction(torch.autograd.Function):
                         and w3[0].stride(0) == w3[1].stride(0) == w3[2].stride(0)
                         and os.environ.get("ACM_PROJ_FWD", "1") != "0")
             fb = ctx.fb = _chan_block(f)
-            if use_proj:
-                wcat = None
-            elif fb != f:                      # [W_L 0 | W_H 0 | W_I]: the product lands in channel blocks of fb columns
-                zpad = w3[0].new_zeros(w3[0].shape[0], fb - f)
-                wcat = torch.cat((w3[0], zpad, w3[1], zpad, w3[2]), dim=1).contiguous()
-            else:
-                wcat = torch.cat(w3, dim=1).contiguous()                            # [F_in, 3F]
             # Row pitch of Z: for narrow layers the gathered block [Z_L | Z_H] (2F floats) must be
             # one aligned vector fetch, so rows are padded to a multiple of that block.
             ldz = 3 * f
@@ -1203,32 +1225,59 @@ class AcmConvFunction(torch.autograd.Function):
             elif fb != f:
                 ldz = -(-(2 * fb + f) // 4) * 4
             pre = _take_pre_proj(call, x, w3, cfg.relu_before) if use_proj else None
-            if pre is not None:
+            drop_spec = _drop_spec(ctx.in_drop, ops.row_offset) if ctx.in_drop is not None else None
+            # [Z_L | Z_H] as a compact table of its own (what a narrow gather / the k-hop chain walks: 16-byte-block rows at
+            # their own pitch instead of [Z_L | Z_H | Z_I | pad] rows), Z_I next to it
+            two_tables = (use_proj or f in (2, 4, 8) or hops > 1) and not sparse_x
+            done3 = False
+            if pre is None and not sparse_x:
+                # tall dense inputs of 32..128 features: the three weight matrices in place on the split-bf16 kernel (no cat)
+                if two_tables:
+                    zlh = torch.empty(n, 2 * fb, dtype=_F32, device=dev)
+                    zi = torch.empty(n, f, dtype=_F32, device=dev)
+                    done3 = proj3(x, w3, fb, zlh, zi, relu=cfg.relu_before, x_drop=drop_spec)
+                else:
+                    z = torch.empty(n, ldz, dtype=_F32, device=dev)[:, : 2 * fb + f]
+                    done3 = proj3(x, w3, fb, z, relu=cfg.relu_before, x_drop=drop_spec)
+                    zlh, zi = z[:, : 2 * fb], z[:, 2 * fb:]
+                if done3:
+                    ctx.in_drop_used = drop_spec is not None
+            if done3:
+                pass
+            elif pre is not None:
                 zlh, zi = pre                              # computed in the preceding layer's epilogue
             elif use_proj:
                 zlh = torch.empty(n, 2 * fb, dtype=_F32, device=dev)
                 zi = torch.empty(n, f, dtype=_F32, device=dev)
                 proj_fwd(x, w3, zlh, zi, relu=cfg.relu_before, h_col=fb)
-            elif f in (2, 4, 8) and not sparse_x:
-                # narrow layer: [Z_L | Z_H] as its own compact table (what the gather walks: half the cache footprint of
-                # [Z_L | Z_H | Z_I | pad] rows), Z_I next to it -- one GEMM with a two-matrix output
-                zlh = torch.empty(n, 2 * f, dtype=_F32, device=dev)
-                zi = torch.empty(n, f, dtype=_F32, device=dev)
-                gemm_split(x, wcat, zlh, zi, relu=cfg.relu_before)
             else:
-                z = torch.empty(n, ldz, dtype=_F32, device=dev)[:, : 2 * fb + f]
-                if sparse_x:                              # Z = X_csr Wcat: nnz(X) * 3F FMAs
-                    spmm_v(x.csr, x.values, wcat, relu=cfg.relu_before, out=z)
+                if fb != f:                        # [W_L 0 | W_H 0 | W_I]: the product lands in channel blocks of fb columns
+                    zpad = w3[0].new_zeros(w3[0].shape[0], fb - f)
+                    wcat = torch.cat((w3[0], zpad, w3[1], zpad, w3[2]), dim=1).contiguous()
                 else:
-                    gemm(x, wcat, relu=cfg.relu_before, out=z,                      # [n, 3F] view
-                         a_drop=_drop_spec(ctx.in_drop, ops.row_offset) if ctx.in_drop is not None else None)
-                    ctx.in_drop_used = ctx.in_drop is not None
-                zlh, zi = z[:, : 2 * fb], z[:, 2 * fb:]
-            if hops > 1:
-                zc = torch.empty(n, 2 * fb, dtype=_F32, device=dev)              # [A_low^(k-1) Z_L | Z_H]
+                    wcat = torch.cat(w3, dim=1).contiguous()                            # [F_in, 3F]
+                if two_tables:                            # one GEMM with a two-matrix output
+                    zlh = torch.empty(n, 2 * fb, dtype=_F32, device=dev)
+                    zi = torch.empty(n, f, dtype=_F32, device=dev)
+                    gemm_split(x, wcat, zlh, zi, relu=cfg.relu_before)
+                else:
+                    z = torch.empty(n, ldz, dtype=_F32, device=dev)[:, : 2 * fb + f]
+                    if sparse_x:                              # Z = X_csr Wcat: nnz(X) * 3F FMAs
+                        spmm_v(x.csr, x.values, wcat, relu=cfg.relu_before, out=z)
+                    else:
+                        gemm(x, wcat, relu=cfg.relu_before, out=z, a_drop=drop_spec)        # [n, 3F] view
+                        ctx.in_drop_used = ctx.in_drop is not None
+                    zlh, zi = z[:, : 2 * fb], z[:, 2 * fb:]
+            if hops > 2:
+                # [A_low^(k-1) Z_L | Z_H] in place: the last of the k - 1 >= 2 products reads a hop buffer and writes over
+                # Z_L (which nothing reads again: no ReLU mask in the k-hop layer) -- no copy of Z_H into a second table
                 t = zlh[:, :f]
-                for hop in range(hops - 1):                                      # the last hop lands in its slot of zc
-                    t = _low_product(ops, t, out=zc[:, :f] if hop == hops - 2 else None)
+                for hop in range(hops - 1):
+                    t = _low_product(ops, t, out=zlh[:, :f] if hop == hops - 2 else None)
+                zg = _gather_rows(ops, zlh) if ops.sharded else zlh
+            elif hops > 1:
+                zc = torch.empty(n, 2 * fb, dtype=_F32, device=dev)              # [A_low Z_L | Z_H]
+                _low_product(ops, zlh[:, :f], out=zc[:, :f])
                 zc[:, fb:fb + f] = zlh[:, fb:fb + f]
                 zg = _gather_rows(ops, zc)
             else:
@@ -1569,7 +1618,16 @@ class AcmConvFunction(torch.autograd.Function):
         with _device_ctx(dev), _Timed(f"conv_bwd_spmm/F{f}k{k}"):
             st = lib.acm_conv_bwd_spmm(low_t.handle, C.byref(r), _vp(ws2), ws2.numel() * 4, _stream())
         _lib.check(st, "acm_conv_bwd_spmm")
-        if ctx.hops > 1:                                  # the remaining k-1 transposed hops of the low channel
+        if ctx.hops > 2 and ops.implicit:
+            # the remaining k - 1 >= 2 transposed hops of the low channel with a pattern-only operator:
+            # (P D^-1)^(k-1) t = P [D^-1 P]^(k-2) (D^-1 t) -- ONE input scaling, then k - 2 row-scaled products (the forward's
+            # form) and a final plain one written over dZ_L (it reads a hop buffer), instead of a scaling pass per hop
+            sc = _hop_buffer(dz, f)
+            torch.mul(dz[:, :f], ops.row_scale[:, None], out=sc)
+            for hop in range(ctx.hops - 2):
+                sc = spmm(ops.low_t, _gather_rows(ops, sc), out=_hop_buffer(dz, f), row_scale=ops.row_scale)
+            spmm(ops.low_t, _gather_rows(ops, sc), out=dz[:, :f])
+        elif ctx.hops > 1:                                # the remaining k-1 transposed hops of the low channel
             t = dz[:, :f]
             last = ctx.hops - 2
             for hop in range(ctx.hops - 1):               # the last hop writes dZ_L in place unless it reads it

@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define ACM_ABI_VERSION 20
+#define ACM_ABI_VERSION 21
 
 typedef enum {
     ACM_OK = 0,
@@ -198,6 +198,20 @@ int acm_gemm_drop(int transA, int transB, int64_t M, int64_t N, int64_t K,
                   const float* A, int64_t lda, const float* B, int64_t ldb,
                   float* C, int64_t ldc, int64_t c_col_block, int64_t c_block_stride, int relu,
                   const acm_dropout_t* a_drop, void* workspace, size_t workspace_bytes, acm_stream_t stream);
+
+/* The three projections of an ACM layer with the weight matrices read IN PLACE (ABI 21):
+ *     [Z_L 0 | Z_H 0 | Z_I] = relu?( drop?(X) [W_L 0 | W_H 0 | W_I] )        ACM-Geometric/layers.py:86-88,101-103 (+ models.py:54)
+ * -- torch.mm(input, self.weight_*) x 3 as ONE launch without a packed copy of the weights (no torch.cat / fill launches in
+ * the step).  w_*: [K, f], row pitch ld_w.  The first two channels sit in blocks of f_block >= f columns (zero columns
+ * between: the 16-byte rows the narrow gathers fetch, see acm_conv_fwd), the product has 2 f_block + f columns; columns
+ * [0, split_col) go to C, the rest to C2 (split_col = 0: all to C) -- the two tables of a narrow layer.  x_drop: the
+ * caller's input dropout drawn while X is loaded (NULL / p = 0: none).  Runs on the split-bf16 row-panel kernel (fp32
+ * accuracy, acm_gemm_bx3.hip): n_rows >= 8192, 32 <= K <= 128 with K % 4 == 0 and 16-byte aligned rows of X, at most 192
+ * product columns; ACM_EUNSUPPORTED otherwise (the caller packs the weights and calls acm_gemm / acm_gemm_split). */
+int acm_proj3(int64_t n_rows, int64_t K, const float* X, int64_t ldx,
+              const float* w_low, const float* w_high, const float* w_mlp, int64_t ld_w, int64_t f, int64_t f_block,
+              float* C, int64_t ldc, int64_t split_col, float* C2, int64_t ldc2, int relu,
+              const acm_dropout_t* x_drop, acm_stream_t stream);
 
 /* ------------------------------------------------ deferred final reductions --
  * Every backward kernel that produces parameter gradients (acm_conv_bwd_local, acm_proj_bwd, acm_conv_agg_bwd) and

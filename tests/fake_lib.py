@@ -506,6 +506,33 @@ class FakeLib:
             _view(base + 4 * j * cbs, m, w, ldc)[...] = out[:, n0:n0 + w]
         return 0
 
+    def acm_proj3(self, n_rows, k, x, ldx, wl, wh, wm, ld_w, f, fb, c, ldc, split, c2, ldc2, relu, drop, stream):
+        """[Z_L 0 | Z_H 0 | Z_I] = relu?(drop?(X) [W_L 0 | W_H 0 | W_I]) from the three weight matrices in place (ABI 21); the
+        shape envelope of the split-bf16 kernel is enforced like the library does."""
+        n_cols = 2 * fb + f
+        ptr = x.value if isinstance(x, C.c_void_p) else int(x)
+        if n_rows == 0:
+            return 0
+        if not (n_rows >= 8192 and 32 <= k <= 128 and k % 4 == 0 and ldx % 4 == 0 and ptr % 16 == 0 and n_cols <= 192):
+            self._err = b"acm_proj3: the split-bf16 row-panel kernel takes >= 8192 rows of 32..128 features"
+            return 4
+        X = _view(x, n_rows, k, ldx).astype(np.float64)
+        d = self._drop_obj(drop)
+        if d is not None and d.p > 0:
+            X = X * dropout_factors(d, n_rows, k)
+        W = np.zeros((k, n_cols))
+        for blk, w in enumerate((wl, wh, wm)):
+            W[:, blk * fb: blk * fb + f] = _view(w, k, f, ld_w)
+        out = X @ W
+        if relu:
+            out = np.maximum(out, 0)
+        if split:
+            _view(c, n_rows, split, ldc)[...] = out[:, :split]
+            _view(c2, n_rows, n_cols - split, ldc2)[...] = out[:, split:]
+        else:
+            _view(c, n_rows, n_cols, ldc)[...] = out
+        return 0
+
     def acm_gemm_blocks(self, ta, tb, m, n, k, a, lda, b, ldb, c, ldc, cb, cbs, relu, ws, wsb, stream):
         if not cb:
             return self.acm_gemm(ta, tb, m, n, k, a, lda, b, ldb, c, ldc, relu, ws, wsb, stream)

@@ -457,3 +457,43 @@ def test_gemm_with_the_input_dropout_in_the_tile_load(rows, f_in, n):
         assert torch.equal(dw, AF.gemm(xd, dz, trans_a=True))
     finally:
         os.environ.pop("ACM_GEMM_ROWS_ALWAYS", None)
+
+
+@pytest.mark.parametrize("n,k,f,fb,split", [(9000, 128, 64, 64, 0), (9000, 64, 5, 8, 16), (20000, 100, 5, 8, 0), (8192, 32, 2, 2, 4),
+                                            (168114, 64, 2, 2, 4), (10000, 128, 7, 8, 16)])
+def test_projection_from_three_weight_matrices_in_place(n, k, f, fb, split):
+    """acm_proj3 (ABI 21): [Z_L 0 | Z_H 0 | Z_I] = relu?(drop?(X) [W_L 0 | W_H 0 | W_I]) with the weights read in place --
+    bit-identical to the same kernel on the packed matrix torch.cat builds (zero columns between the channel blocks), one
+    or two output tables, the ReLU, the dropout drawn in the load against the product of the dropped copy; shapes outside
+    the envelope are refused without a launch."""
+    from acm_gnn_amd import functional as AF
+    g = torch.Generator().manual_seed(n + k + f)
+    x = torch.randn(n, k, generator=g).to(DEV)
+    w3 = [torch.randn(k, f, generator=g).to(DEV) for _ in range(3)]
+    zpad = torch.zeros(k, fb - f, device=DEV)
+    wcat = torch.cat([w3[0], zpad, w3[1], zpad, w3[2]], 1).contiguous()
+    ncols = 2 * fb + f
+    for relu in (False, True):
+        want = AF.gemm(x, wcat, relu=relu)
+        if split:
+            o1, o2 = torch.full((n, split), 7.0, device=DEV), torch.full((n, ncols - split + 3), 7.0, device=DEV)[:, : ncols - split]
+            assert AF.proj3(x, w3, fb, o1, o2, relu=relu)
+            assert torch.equal(o1, want[:, :split]) and torch.equal(o2, want[:, split:])
+        else:
+            out = torch.full((n, ncols + 4), 7.0, device=DEV)
+            assert AF.proj3(x, w3, fb, out[:, :ncols], relu=relu)
+            assert torch.equal(out[:, :ncols], want) and float((out[:, ncols:] - 7).abs().max()) == 0
+    st = AF.DropoutState(torch.device(DEV), seed=3)
+    st.step.fill_(2)
+    spec = st.spec(0.3, 0, 500)
+    xd = AF.dropout(x, 0.3, st, tag=0, row_offset=500)
+    out = torch.empty(n, ncols, device=DEV)
+    assert AF.proj3(x, w3, fb, out, x_drop=spec)
+    assert torch.equal(out, AF.gemm(xd, wcat))
+    a64 = x.cpu().double()
+    err = ((AF.gemm(x, wcat).cpu().double() - a64 @ wcat.cpu().double()).abs() / (a64.abs() @ wcat.cpu().double().abs() + 1e-30)).max()
+    assert float(err) < 1e-6
+    # outside the envelope: nothing launched
+    small = torch.randn(100, k, device=DEV)
+    assert AF.proj3(small, w3, fb, torch.empty(100, ncols, device=DEV)) is False
+    assert AF.proj3(x[:, : k - 1], [w[: k - 1] for w in w3], fb, torch.empty(n, ncols, device=DEV)) is False

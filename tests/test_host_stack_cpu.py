@@ -1004,16 +1004,17 @@ def test_output_layer_projection_backward_rides_the_hidden_layers_backward(monke
 
 @pytest.mark.parametrize("model_type,hops", [("acmgcnp", 1), ("acmsgc", 3)])
 def test_input_dropout_rides_the_dense_projection(monkeypatch, model_type, hops):
-    """acm_gemm_drop (ABI 20): for a wide dense input the first layer's projection Z = drop(X) W and its backward
-    dW = drop(X)^T dZ draw the input-dropout mask while they stage X (ACM-Geometric/models.py:54 + layers.py:86-88), so
-    the separate acm_dropout pass and the dropped copy of X disappear; same loss and gradients as with ACM_GEMM_DROP=0."""
+    """acm_proj3 (ABI 21) / acm_gemm_drop (ABI 20): for a wide dense input the first layer's projection Z = drop(X) W -- the
+    three weight matrices read in place, no torch.cat -- and its backward dW = drop(X)^T dZ draw the input-dropout mask while
+    they load X (ACM-Geometric/models.py:54 + layers.py:86-88), so the separate acm_dropout pass and the dropped copy of X
+    disappear; same loss and gradients as with ACM_GEMM_DROP=0."""
     fake = fake_lib.install(monkeypatch)
     from acm_gnn_amd import GCN, functional as AF
     ops, n = _dense_graph_ops(n=8192, avg=14, seed=2)
     ops.hops = hops
     x = torch.randn(n, 128, generator=torch.Generator().manual_seed(1))
     calls = []
-    for name in ("acm_gemm_drop", "acm_dropout"):
+    for name in ("acm_gemm_drop", "acm_proj3", "acm_dropout"):
         orig = getattr(fake, name)
         monkeypatch.setattr(fake, name, (lambda o, nm: lambda *a: (calls.append(nm), o(*a))[1])(orig, name))
 
@@ -1030,7 +1031,8 @@ def test_input_dropout_rides_the_dense_projection(monkeypatch, model_type, hops)
 
     out_a, g_a, calls_a = run(True)
     out_b, g_b, calls_b = run(False)
-    assert calls_a.count("acm_gemm_drop") == 2 and "acm_dropout" not in calls_a, calls_a          # forward + backward
+    # forward (the 64 -> 5 output layer of the 2-layer model projects through acm_proj3 as well), backward
+    assert calls_a.count("acm_proj3") == (2 if hops == 1 else 1) and calls_a.count("acm_gemm_drop") == 1 and "acm_dropout" not in calls_a, calls_a
     assert "acm_gemm_drop" not in calls_b and calls_b.count("acm_dropout") >= 1, calls_b
     torch.testing.assert_close(out_a, out_b, rtol=1e-6, atol=1e-6 * float(out_b.abs().max()))
     assert g_a.keys() == g_b.keys()
