@@ -829,6 +829,10 @@ namespace {
 // graph with mean 82 has median 30: with 32 lanes x 2 neighbours most lanes of most rows idle), 32 beyond
 int narrow_lanes(const acm_csr* a) {
     const double avg = (double)a->nnz / (double)(a->n_rows > 0 ? a->n_rows : 1);
+    if (const char* e = getenv("ACM_NARROW_LANES")) {
+        const int v = atoi(e);
+        if (v == 8 || v == 16 || v == 32) return v;
+    }
     return avg <= 12.0 ? 8 : (avg <= 160.0 ? 16 : 32);
 }
 // with 16 lanes per item a workgroup round is one window: the narrow gather finishes the long rows itself
