@@ -194,8 +194,9 @@ def pattern_form_of_rows(indptr, indices, vals, row_begin, n_global, group=None,
     s = np.ones(n_loc, np.float32)
     mult = np.ones(ix.size, np.int64)
     if ok and ix.size:
-        np.minimum.at(s := np.full(n_loc, np.inf, np.float32), rows, v)
-        s = np.where(np.isinf(s), np.float32(1), s).astype(np.float32)
+        s = np.full(n_loc, np.inf, np.float32)
+        np.minimum.at(s, rows, v)                                        # the row's smallest value
+        s = np.where(np.isinf(s), np.float32(1), s).astype(np.float32)   # (empty rows)
         m = v / s[rows]
         mr = np.round(m)
         ok = bool(((mr >= 1) & (mr <= max_multiplicity) & (m == mr)).all())

@@ -1243,7 +1243,7 @@ class AcmConvFunction(torch.autograd.Function):
                 if done3:
                     ctx.in_drop_used = drop_spec is not None
             if done3:
-                pass
+                pass                                       # [Z_L | Z_H], Z_I are written
             elif pre is not None:
                 zlh, zi = pre                              # computed in the preceding layer's epilogue
             elif use_proj:
