@@ -823,6 +823,9 @@ __global__ __launch_bounds__(256) void spmm_fixup_narrow_kernel(CsrView csr, int
 }
 
 // ------------------------------------------------------------------ host-side dispatch
+// acm_conv_local16.hip: K3 at F = 64, k = 3 with sixteen rows per wave
+int acm_bwd_local16(const acm_conv_bwd_local_t* p, int64_t n_rows, float* partial, int max_blocks, hipStream_t s);
+
 namespace {
 
 // lanes per work item of the narrow gather: 8 for very sparse graphs, 16 up to an average degree of 160 (a power-law
@@ -1485,6 +1488,11 @@ extern "C" int acm_conv_bwd_local(int64_t n_rows, const acm_conv_bwd_local_t* p,
     size_t lds = (size_t)4 * npg * sizeof(float);
     hipStream_t st = (hipStream_t)stream;
     float* partial = (float*)workspace;
+    if (F == 64 && k == 3) {                      // sixteen rows per wave, 16-byte accesses (acm_conv_local16.hip)
+        const int nb16 = acm_bwd_local16(p, n_rows, partial, nblk, st);
+        if (nb16 < 0) return -nb16;
+        if (nb16 > 0) return bwd_local_reduce(p, partial, nb16, st);
+    }
     if (F > 16 && F <= 64) {                      // 4-rows-per-wave lean kernel
         const int64_t max_ld = p->ld_pre > p->ld_grad_out ? p->ld_pre : p->ld_grad_out;
         ACM_REQUIRE(n_rows * (max_ld > p->ld_g_mlp ? max_ld : p->ld_g_mlp) < (int64_t)INT32_MAX, ACM_EUNSUPPORTED,

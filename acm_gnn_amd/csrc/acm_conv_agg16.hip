@@ -19,6 +19,7 @@
 // bit-identical to the older kernels'; the head statistics differ by summation order only.
 #include "acm_conv_device.h"
 #include "acm_stream_device.h"
+#include "acm_rows16_device.h"
 
 namespace {
 
@@ -26,8 +27,6 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 #define ACM_E16_NEXT_LDS (64 * 8)
 
-// sum over the four lanes that hold one row (lanes m, m + 16, m + 32, m + 48); result in all four
-__device__ __forceinline__ float row4_sum(float v) { return acm_cross_row_sum(v); }
 
 template <bool LN, bool NEXT>
 __device__ __forceinline__ void epi16_body(const acm_conv_agg_fwd_t& p, int n_rows) {
@@ -273,22 +272,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
                                           (rows 4 g + s: two row groups per LDS pass, 16 banks apart) are conflict-free */
 #define ACM_B16_PS 17                  /* floats per [P | x] row */
 #define ACM_B16_LDS (4 * (2144 + 384) + 64)    /* tiles | [P|x] rows | head parameters | weights; the end-of-kernel slabs alias it */
-
-// sum over the 16 lanes of a row for 16 values per lane, leaving value i's total in lane i (m = i): a reduce-scatter of four
-// DPP exchange steps (partner = 15 - m, 7 - m within the half, m ^ 2, m ^ 1; each lane keeps the half of the values its
-// own lane bit selects and adds the partner's copy of them) -- 45 instructions, where sixteen all-reduces cost 64 and
-// sixteen per-lane accumulators would pin 48 registers per kernel.
-__device__ __forceinline__ float row_reduce_scatter16(const float (&v)[16], int m) {
-    const bool b3 = (m & 8) != 0, b2 = (m & 4) != 0, b1 = (m & 2) != 0, b0 = (m & 1) != 0;
-    float a[8], b[4], c[2];
-#pragma unroll
-    for (int i = 0; i < 8; ++i) a[i] = (b3 ? v[i + 8] : v[i]) + acm_dpp<0x140>(b3 ? v[i] : v[i + 8]);       // row_mirror
-#pragma unroll
-    for (int i = 0; i < 4; ++i) b[i] = (b2 ? a[i + 4] : a[i]) + acm_dpp<0x141>(b2 ? a[i] : a[i + 4]);       // row_half_mirror
-#pragma unroll
-    for (int i = 0; i < 2; ++i) c[i] = (b1 ? b[i + 2] : b[i]) + acm_dpp<0x4E>(b1 ? b[i] : b[i + 2]);        // quad_perm [2,3,0,1]
-    return (b0 ? c[1] : c[0]) + acm_dpp<0xB1>(b0 ? c[0] : c[1]);                                            // quad_perm [1,0,3,2]
-}
 
 // PROJ: the following layer's projection backward rides along (acm_conv_agg_bwd_t.proj_*): grad_out is formed per row from
 // proj_dz (6 floats) and the 64 x 6 weight table in LDS instead of being read (256 B per row), and proj_d_w = out^T proj_dz
