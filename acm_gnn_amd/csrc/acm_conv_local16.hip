@@ -272,10 +272,11 @@ int acm_bwd_local16(const acm_conv_bwd_local_t* p, int64_t n_rows, float* partia
     }
     if (n_rows * ld_max >= (int64_t)INT32_MAX) return 0;                   // 32-bit element offsets
     int grid = (int)((n_rows + 63) / 64);
+    if (grid > 512) grid = 512;                    // two resident workgroups per CU (220 registers); fewer slabs for the flush
     if (grid > max_blocks) grid = max_blocks;
     if (const char* env = getenv("ACM_LOCAL16_BLOCKS")) {
         const int v = atoi(env);
-        if (v >= 1 && v < grid) grid = v;
+        if (v >= 1 && v <= max_blocks) grid = v;
     }
     if (p->layernorm) hipLaunchKernelGGL((bwd_local16_kernel<true>), dim3(grid), dim3(256), 0, s, *p, (int)n_rows, partial);
     else hipLaunchKernelGGL((bwd_local16_kernel<false>), dim3(grid), dim3(256), 0, s, *p, (int)n_rows, partial);
