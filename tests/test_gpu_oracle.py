@@ -549,3 +549,53 @@ def test_next_layer_projection_in_the_hidden_layers_epilogue(hidden, n_cls, p_dr
             rg = params[k].grad
             assert float((gq - rg).abs().max()) < 1e-4 * max(1.0, float(rg.abs().max())), (mode, k)
     assert float((res["1"][0] - res["0"][0]).abs().max()) < 1e-5 * scale
+
+
+@pytest.mark.parametrize("n", [5, 400, 4099])
+@pytest.mark.parametrize("model_type,variant,ln,implicit,p_drop", [("acmgcnp", 0, True, True, 0.0), ("acmgcn", 1, False, True, 0.3),
+                                                                   ("acmgcnp", 1, True, False, 0.4), ("acmgcnp", 0, True, True, 0.25)])
+def test_sixteen_rows_per_wave_local_backward_equals_the_older_kernel(n, model_type, variant, ln, implicit, p_drop, monkeypatch):
+    """acm_conv_local16.hip (K3 of the literal layer at F = 64, k = 3: sixteen rows per wave, 16-byte accesses, the head
+    recomputed with in-lane sums, the post-op undone by recomputing the mixed row's sign and regenerating the Philox mask)
+    against conv_bwd_local_grouped_kernel (ACM_LOCAL16_OFF=1): every gradient of the layer, with and without LayerNorm, both
+    variants, pattern-only and explicit operators (g_scale), fused ReLU + counter-based dropout, row counts that are not a
+    multiple of 16 / smaller than one wave step -- and against the oracle for the plain case."""
+    from acm_gnn_amd import GraphConvolution, functional as AF
+    from acm_gnn_amd.graph import clear_cache
+    monkeypatch.setenv("ACM_AGG_FIRST", "0")
+    monkeypatch.setenv("ACM_IMPLICIT", "1" if implicit else "0")
+    adj = _graph(max(n, 4), 11, density=min(0.5, 20.0 / max(n, 4)), hub=n > 10)
+    n = adj.shape[0]
+    low, high, _ = O.filters_linkx(adj)
+    g = torch.Generator().manual_seed(n)
+    x, gout = torch.randn(n, 24, generator=g).to(DEV), torch.randn(n, 64, generator=g).to(DEV)
+
+    def run(off):
+        if off:
+            monkeypatch.setenv("ACM_LOCAL16_OFF", "1")
+        else:
+            monkeypatch.delenv("ACM_LOCAL16_OFF", raising=False)
+        clear_cache()
+        torch.manual_seed(2)
+        layer = GraphConvolution(24, 64, n, model_type, variant=variant, structure_info=0, attn_layernorm=ln).to(DEV)
+        st = AF.DropoutState(torch.device(DEV), seed=4)
+        xd = x.clone().requires_grad_(True)
+        kw = dict(post_relu=True, post_drop=(p_drop, 1, st)) if p_drop else {}
+        timer = AF.KernelTimer()
+        AF.set_kernel_timer(timer)
+        out = layer(xd, low.to(DEV), high.to(DEV), None, **kw)
+        out.backward(gout)
+        AF.set_kernel_timer(None)
+        assert any(k.startswith("conv_bwd_local/F64k3") for k in timer.summary()), list(timer.summary())
+        return out.detach(), xd.grad, {k: p.grad for k, p in layer.named_parameters() if p.grad is not None}
+
+    out_a, dx_a, g_a = run(True)
+    out_b, dx_b, g_b = run(False)
+    assert torch.equal(out_a, out_b)
+    assert g_a.keys() == g_b.keys()
+    for k in g_a:
+        tol = 2e-5 * max(1.0, float(g_a[k].abs().max()))
+        assert float((g_a[k] - g_b[k]).abs().max()) < tol, (k, float((g_a[k] - g_b[k]).abs().max()), tol)
+    assert float((dx_a - dx_b).abs().max()) < 2e-5 * max(1.0, float(dx_a.abs().max()))
+    if not p_drop and n == 400:
+        _run_both(model_type, variant, 0, ln, 400, 24, 64, 5, True, monkeypatch, agg=False, implicit=implicit)
