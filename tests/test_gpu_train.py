@@ -269,7 +269,8 @@ def test_input_pipeline_matches_plain_step(monkeypatch, n, avg, model_type, use_
     assert float((pipe.saved[0] - pipe.filled[0]).abs().max()) > 0         # a different mask
 
 
-def test_fit_with_the_input_pipeline_equals_fit_without(monkeypatch):
+@pytest.mark.parametrize("use_graph", [True, False], ids=["graph", "eager"])
+def test_fit_with_the_input_pipeline_equals_fit_without(monkeypatch, use_graph):
     """train.fit (captured training step + captured evaluation pass per epoch) with the input pipeline in its training
     half -- the default -- against pipeline_input=False: the evaluation pass in between neither disturbs the look-ahead
     buffers nor advances the dropout counter; same histories, same selected accuracy."""
@@ -285,7 +286,7 @@ def test_fit_with_the_input_pipeline_equals_fit_without(monkeypatch):
         model = GCN(7, 64, 2, 2, n, 0.3, "acmgcnp", 0, variant=False, attn_layernorm=True).to(DEV)
         model.dropout_state = AF.DropoutState(torch.device(DEV), seed=5)
         opt = FusedAdamW(model.parameters(), lr=0.01, weight_decay=1e-3)
-        return T.fit(model, opt, x, ops, y, *sets, epochs=12, use_graph=True, pipeline_input=pipeline)
+        return T.fit(model, opt, x, ops, y, *sets, epochs=12, use_graph=use_graph, pipeline_input=pipeline)
 
     acc_a, hist_a = run(False)
     acc_b, hist_b = run(None)
