@@ -26,7 +26,7 @@ bool acm_gemm_bx3_nn_ok(int64_t M, int64_t N, int64_t K, const float* A, int64_t
 int acm_gemm_bx3_nn(int64_t M, int64_t N, int64_t K, const float* A, int64_t lda, const float* B, int64_t ldb, float* C,
                     int64_t ldc, int relu, const acm_dropout_t* drop, hipStream_t st);
 bool acm_gemm_bx3_tn_ok(int64_t n_rows, int64_t K, int64_t N);
-int acm_gemm_bx3_tn_blocks(int64_t n_rows);
+int acm_gemm_bx3_tn_blocks(int64_t n_rows, int64_t K);
 int acm_gemm_bx3_tn(int64_t n_rows, int64_t K, int64_t N, const float* X, int64_t ldx, const float* Dz, int64_t lddz,
                     float* slabs, int blocks, const acm_dropout_t* drop, hipStream_t st);
 
@@ -271,7 +271,9 @@ extern "C" int acm_gemm_workspace_bytes(int transA, int transB, int64_t M, int64
     const GemmPlan p = plan_gemm(M, N, K);
     size_t need = p.splits > 1 ? (size_t)p.splits * (size_t)M * (size_t)N * sizeof(float) : 0;
     if (transA && !transB && (acm_gemm_rows_tn_ok(K, M, N, nullptr, 4) || acm_gemm_bx3_tn_ok(K, M, N))) {   // the row-panel forms (may be taken): one slab per workgroup
-        const size_t rows = (size_t)256 * (size_t)M * (size_t)N * sizeof(float);
+        const int nb_bx3 = acm_gemm_bx3_tn_ok(K, M, N) ? acm_gemm_bx3_tn_blocks(K, M) : 0;
+        const int nb_rows = acm_gemm_rows_tn_ok(K, M, N, nullptr, 4) ? acm_gemm_rows_tn_blocks(K) : 0;
+        const size_t rows = (size_t)(nb_bx3 > nb_rows ? nb_bx3 : nb_rows) * (size_t)M * (size_t)N * sizeof(float);
         need = rows > need ? rows : need;
     }
     *bytes = need;
@@ -366,7 +368,7 @@ static int gemm_core(int transA, int transB, int64_t M, int64_t N, int64_t K, co
     const bool bx3_tn = K > 0 && transA && !transB && plain_out && acm_gemm_bx3_tn_ok(K, M, N);
     if (bx3_tn || (K > 0 && transA && !transB && plain_out && acm_gemm_rows_tn_ok(K, M, N, B, ldb) &&
                    (a_drop || K >= 100000 || getenv("ACM_GEMM_ROWS_ALWAYS")))) {
-        const int blocks = bx3_tn ? acm_gemm_bx3_tn_blocks(K) : acm_gemm_rows_tn_blocks(K);
+        const int blocks = bx3_tn ? acm_gemm_bx3_tn_blocks(K, M) : acm_gemm_rows_tn_blocks(K);
         const size_t need = (size_t)blocks * (size_t)M * (size_t)N * sizeof(float);
         ACM_REQUIRE(workspace && workspace_bytes >= need, ACM_ENOMEM, "acm_gemm: workspace %zu B < required %zu B", workspace_bytes, need);
         int rc = bx3_tn ? acm_gemm_bx3_tn(K, M, N, A, lda, B, ldb, (float*)workspace, blocks, a_drop, st)

@@ -254,13 +254,16 @@ constexpr int TS = 20;                     // dwords per column in LDS
 // i.e. the next slab's rows requested a phase ahead -- every phase would last a full memory latency.
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 template <int NT>
-__global__ __launch_bounds__(512, 2) void gemm_bx3_tn_kernel(int n_rows, int K, int N, const float* __restrict__ X, long ldx,
+__global__ __launch_bounds__(512, 2) void gemm_bx3_tn_kernel(int n_rows, int Ktot, int N, const float* __restrict__ Xall, long ldx,
                                                              const float* __restrict__ Dz, long lddz, float* __restrict__ slabs,
                                                              int rows_per_block, acm_dropout_t drop, int dbg) {
     extern __shared__ __attribute__((aligned(16))) unsigned Tl[];    // [group 2][part 3][128 + 16 NT columns][TS]
     constexpr int COLS = 128 + 16 * NT, BUF = 3 * COLS * TS, ZT = (64 * NT + 255) / 256;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, m = lane & 15, g = lane >> 4;
     const int grp = wv >> 2, wg = wv & 3, tid = threadIdx.x & 255;
+    // blockIdx.y: which 128 columns of X (= rows of the output) this workgroup owns
+    const int k0 = 128 * blockIdx.y, K = min(128, Ktot - k0);
+    const float* __restrict__ X = Xall + k0;
     const int r_begin = blockIdx.x * rows_per_block, r_end = min(n_rows, r_begin + rows_per_block);
     const int ns = (r_end - r_begin + 31) / 32, iters = (ns + 1) / 2;
     const AcmDropCtx dc = acm_drop_ctx(drop);
@@ -333,7 +336,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bx3_tn_kernel(int n_rows, int K, 
             if (dc.on) {
                 // lane l of a wave holds column 64 G + l: word l >> 4 of Philox(row, (l & 15) + 16 G).  Each lane draws TWO of
                 // the eight rows (2 q, 2 q + 1 with q = l >> 4) and keeps 8 bits; four ds_bpermutes hand every lane its eight.
-                const int q = lane >> 4, blockc = (lane & 15) + 16 * (xc >> 6);
+                const int q = lane >> 4, blockc = (lane & 15) + 16 * ((xc + k0) >> 6);
                 unsigned bits = 0;
 #pragma unroll
                 for (int jj = 0; jj < 2; ++jj) {
@@ -428,7 +431,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bx3_tn_kernel(int n_rows, int K, 
                 for (int r = 0; r < 4; ++r) S[(16 * (it0 + i) + 4 * g + r) * (16 * NT) + 16 * j + m] = acc[i][j][r];
     }
     __syncthreads();
-    float* dst = slabs + (long)blockIdx.x * K * N;
+    float* dst = slabs + ((long)blockIdx.x * Ktot + k0) * N;
     if (grp == 0 && live) {
 #pragma unroll
         for (int i = 0; i < 2; ++i)
@@ -487,12 +490,18 @@ static int bx3_nn_ex(int64_t M, int64_t N, int64_t K, const float* A, int64_t ld
     return ACM_OK;
 }
 
+// n_rows: the contraction length (rows of X and dZ); K: columns of X = rows of the output, in blocks of 128 per workgroup
 bool acm_gemm_bx3_tn_ok(int64_t n_rows, int64_t K, int64_t N) {
-    return n_rows >= 8192 && K >= 32 && K <= 128 && N >= 1 && N <= 192 && getenv("ACM_GEMM_BX3_OFF") == nullptr;
+    if (getenv("ACM_GEMM_BX3_OFF") != nullptr || K < 32 || N < 1 || N > 192) return false;
+    return K <= 128 ? n_rows >= 8192 : (n_rows >= 4096 && getenv("ACM_GEMM_BX3_WIDE_OFF") == nullptr);   // (wide: 2 k-row graphs measured no faster)
 }
-int acm_gemm_bx3_tn_blocks(int64_t n_rows) {
-    int64_t nb = (n_rows + 127) / 128;                               // at least four slabs per workgroup
-    return (int)(nb > 256 ? 256 : (nb < 1 ? 1 : nb));
+// row ranges (one slab of the output per range): enough workgroups for the chip, at least four 32-row slabs each
+int acm_gemm_bx3_tn_blocks(int64_t n_rows, int64_t K) {
+    const int64_t kb = (K + 127) / 128;
+    int64_t nb = (n_rows + 127) / 128, want = (512 + kb - 1) / kb;
+    if (want > 256) want = 256;
+    if (nb > want) nb = want;
+    return (int)(nb < 1 ? 1 : nb);
 }
 
 // slabs: blocks x K x N floats; the caller reduces them (splitk_reduce_kernel of acm_gemm.hip)
@@ -509,7 +518,7 @@ int acm_gemm_bx3_tn(int64_t n_rows, int64_t K, int64_t N, const float* X, int64_
 #define ACM_BX3T(NTv)                                                                                                   \
     do {                                                                                                                \
         ACM_CHECK_HIP(hipFuncSetAttribute((const void*)gemm_bx3_tn_kernel<NTv>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
-        hipLaunchKernelGGL((gemm_bx3_tn_kernel<NTv>), dim3(blocks), dim3(512), lds, st, (int)n_rows, (int)K, (int)N, X,  \
+        hipLaunchKernelGGL((gemm_bx3_tn_kernel<NTv>), dim3(blocks, (unsigned)((K + 127) / 128)), dim3(512), lds, st, (int)n_rows, (int)K, (int)N, X,  \
                            (long)ldx, Dz, (long)lddz, slabs, (int)rpb, drop, dbg);                                        \
     } while (0)
     switch (ntr) {
@@ -545,3 +554,4 @@ extern "C" int acm_proj3(int64_t n_rows, int64_t K, const float* X, int64_t ldx,
     return bx3_nn_ex(n_rows, N, K, X, ldx, w_low, ld_w, C, ldc, relu, (x_drop && x_drop->p > 0.f) ? x_drop : nullptr,
                      (hipStream_t)stream, w3, (int)f, (int)f_block, split_col, C2, ldc2);
 }
+

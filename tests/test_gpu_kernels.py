@@ -403,7 +403,7 @@ def test_split_bf16_projection_keeps_fp32_accuracy(m, n, k, monkeypatch):
 
 
 @pytest.mark.parametrize("rows,f_in,n,blocks", [(9000, 128, 192, 3), (20001, 100, 15, 3), (168114, 128, 192, 3), (8192, 33, 21, 0),
-                                                (40000, 64, 180, 0)])
+                                                (40000, 64, 180, 0), (5201, 2089, 192, 3), (4100, 300, 70, 0), (41554, 1030, 21, 3)])
 def test_split_bf16_weight_gradient_keeps_fp32_accuracy(rows, f_in, n, blocks, monkeypatch):
     """acm_gemm_bx3.hip (TN): dW = X^T dZ, the contraction over the rows: tiles split while they are staged, operands read
     from LDS as packed row pairs; vs float64 at the fp32 kernels' level, exact on small integers, deterministic, column
@@ -497,3 +497,22 @@ def test_projection_from_three_weight_matrices_in_place(n, k, f, fb, split):
     small = torch.randn(100, k, device=DEV)
     assert AF.proj3(small, w3, fb, torch.empty(100, ncols, device=DEV)) is False
     assert AF.proj3(x[:, : k - 1], [w[: k - 1] for w in w3], fb, torch.empty(n, ncols, device=DEV)) is False
+
+
+def test_wide_weight_gradient_with_the_dropout_in_the_operand_load():
+    """acm_gemm_bx3.hip (TN) for inputs wider than 128 features (workgroups own blocks of 128 output rows): dW = drop(X)^T dZ
+    with the mask drawn while X is staged equals the product of the dropped copy (Philox block = column mod 16 + 16 * (column
+    / 64), any column) bit for bit."""
+    from acm_gnn_amd import functional as AF
+    g = torch.Generator().manual_seed(5)
+    rows, f_in, n = 6000, 452, 40
+    x, dz = torch.randn(rows, f_in, generator=g).to(DEV), torch.randn(rows, n, generator=g).to(DEV)
+    st = AF.DropoutState(torch.device(DEV), seed=21)
+    st.step.fill_(3)
+    spec = st.spec(0.3, 0, 77)
+    xd = AF.dropout(x, 0.3, st, tag=0, row_offset=77)
+    dw = AF.gemm(x, dz, trans_a=True, a_drop=spec)
+    assert torch.equal(dw, AF.gemm(xd, dz, trans_a=True))
+    ref = xd.cpu().double().T @ dz.cpu().double()
+    scale = xd.cpu().abs().double().T @ dz.cpu().abs().double()
+    assert float(((dw.cpu().double() - ref).abs() / (scale + 1e-30)).max()) < 1e-6
