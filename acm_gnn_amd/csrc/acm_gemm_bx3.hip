@@ -493,7 +493,10 @@ static int bx3_nn_ex(int64_t M, int64_t N, int64_t K, const float* A, int64_t ld
 // n_rows: the contraction length (rows of X and dZ); K: columns of X = rows of the output, in blocks of 128 per workgroup
 bool acm_gemm_bx3_tn_ok(int64_t n_rows, int64_t K, int64_t N) {
     if (getenv("ACM_GEMM_BX3_OFF") != nullptr || K < 32 || N < 1 || N > 192) return false;
-    return K <= 128 ? n_rows >= 8192 : (n_rows >= 4096 && getenv("ACM_GEMM_BX3_WIDE_OFF") == nullptr);   // (wide: 2 k-row graphs measured no faster)
+    // wide inputs: from 16 384 rows (Penn94-like: 1 161 -> 625 us).  5 k rows (Squirrel) gain 7 us of 88, 2-3 k rows nothing.
+    const char* e = getenv("ACM_GEMM_BX3_WIDE_ROWS");
+    const int64_t wide_rows = e && atoll(e) > 0 ? atoll(e) : 16384;
+    return K <= 128 ? n_rows >= 8192 : (n_rows >= wide_rows && getenv("ACM_GEMM_BX3_WIDE_OFF") == nullptr);
 }
 // row ranges (one slab of the output per range): enough workgroups for the chip, at least four 32-row slabs each
 int acm_gemm_bx3_tn_blocks(int64_t n_rows, int64_t K) {

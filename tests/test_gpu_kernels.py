@@ -405,6 +405,7 @@ def test_split_bf16_projection_keeps_fp32_accuracy(m, n, k, monkeypatch):
 @pytest.mark.parametrize("rows,f_in,n,blocks", [(9000, 128, 192, 3), (20001, 100, 15, 3), (168114, 128, 192, 3), (8192, 33, 21, 0),
                                                 (40000, 64, 180, 0), (5201, 2089, 192, 3), (4100, 300, 70, 0), (41554, 1030, 21, 3)])
 def test_split_bf16_weight_gradient_keeps_fp32_accuracy(rows, f_in, n, blocks, monkeypatch):
+    monkeypatch.setenv("ACM_GEMM_BX3_WIDE_ROWS", "4096")             # (default 16 384: the wide form on mid-sized inputs too)
     """acm_gemm_bx3.hip (TN): dW = X^T dZ, the contraction over the rows: tiles split while they are staged, operands read
     from LDS as packed row pairs; vs float64 at the fp32 kernels' level, exact on small integers, deterministic, column
     blocks."""
@@ -504,6 +505,7 @@ def test_wide_weight_gradient_with_the_dropout_in_the_operand_load():
     with the mask drawn while X is staged equals the product of the dropped copy (Philox block = column mod 16 + 16 * (column
     / 64), any column) bit for bit."""
     from acm_gnn_amd import functional as AF
+    os.environ["ACM_GEMM_BX3_WIDE_ROWS"] = "4096"
     g = torch.Generator().manual_seed(5)
     rows, f_in, n = 6000, 452, 40
     x, dz = torch.randn(rows, f_in, generator=g).to(DEV), torch.randn(rows, n, generator=g).to(DEV)
@@ -516,3 +518,4 @@ def test_wide_weight_gradient_with_the_dropout_in_the_operand_load():
     ref = xd.cpu().double().T @ dz.cpu().double()
     scale = xd.cpu().abs().double().T @ dz.cpu().abs().double()
     assert float(((dw.cpu().double() - ref).abs() / (scale + 1e-30)).max()) < 1e-6
+    os.environ.pop("ACM_GEMM_BX3_WIDE_ROWS", None)
