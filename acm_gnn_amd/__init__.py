@@ -9,5 +9,6 @@ from .layers import GraphConvolution, MLP  # noqa: F401
 from .models import GCN  # noqa: F401
 from .graph import CsrGraph, FilterOperators, SparseFeatures, operators_for  # noqa: F401
 from .optim import FusedAdam, FusedAdamW  # noqa: F401
+from . import tuning  # noqa: F401
 
 __all__ = ["GraphConvolution", "MLP", "GCN", "CsrGraph", "FilterOperators", "SparseFeatures", "operators_for", "FusedAdam", "FusedAdamW"]

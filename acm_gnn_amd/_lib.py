@@ -14,11 +14,11 @@ c_i32p = C.POINTER(C.c_int32)
 
 ACM_OK = 0
 STATUS_NAMES = {1: "ACM_EINVAL", 2: "ACM_ESHAPE", 3: "ACM_EHIP", 4: "ACM_EUNSUPPORTED", 5: "ACM_ENOMEM"}
-ABI_VERSION = 21
+ABI_VERSION = 22
 
 # every symbol include/acm_hip.h declares
 EXPORTED_SYMBOLS = (
-    "acm_version", "acm_last_error", "acm_csr_create", "acm_csr_transpose", "acm_csr_slice_rows",
+    "acm_version", "acm_last_error", "acm_tuning_get", "acm_tuning_set", "acm_csr_create", "acm_csr_transpose", "acm_csr_slice_rows",
     "acm_csr_destroy", "acm_csr_info", "acm_csr_build_streams", "acm_spmm_workspace_bytes", "acm_gemm_workspace_bytes",
     "acm_gemm", "acm_gemm_blocks", "acm_gemm_drop", "acm_proj3", "acm_gemm_split", "acm_proj_fwd", "acm_proj_fwd_at", "acm_proj_bwd_workspace_bytes", "acm_proj_bwd", "acm_spmm", "acm_spmm_v", "acm_spmm_ex", "acm_cast_bf16", "acm_conv_fwd", "acm_conv_bwd_local_workspace_bytes",
     "acm_conv_bwd_local", "acm_conv_bwd_spmm", "acm_conv_agg_fwd", "acm_conv_agg_bwd_workspace_bytes",
@@ -115,7 +115,7 @@ class ConvAggFwd(C.Structure):
                 ("next_w_low", C.c_void_p), ("next_w_high", C.c_void_p), ("next_w_mlp", C.c_void_p), ("next_ld_w", C.c_int64),
                 ("next_f", C.c_int32), ("next_relu", C.c_int32),
                 ("next_zlh", C.c_void_p), ("ld_next_zlh", C.c_int64), ("next_zi", C.c_void_p), ("ld_next_zi", C.c_int64),
-                ("agg_given", C.c_int32), ("use_streams", C.c_int32),
+                ("agg_given", C.c_int32), ("reserved0", C.c_int32),
                 ("agg_copy", C.c_void_p), ("ld_agg_copy", C.c_int64), ("xs_copy", C.c_void_p), ("ld_xs_copy", C.c_int64)]
 
 

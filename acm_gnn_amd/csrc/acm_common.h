@@ -17,6 +17,16 @@
 #define ACM_LN_EPS 1e-5f
 
 void acm_set_error(const char* fmt, ...);
+// The process-wide tuning record (acm_hip.h: acm_tuning_t; defined in acm_csr.cpp).  Dispatch code reads it through this
+// accessor -- never the environment.
+const acm_tuning_t& acm_tuning();
+#define ACM_ROWS16_EPI 1
+#define ACM_ROWS16_BWD 2
+#define ACM_ROWS16_LOCAL 4
+#define ACM_GEMM_ROWS 1
+#define ACM_GEMM_BX3 2
+#define ACM_GEMM_BX3_WIDE 4
+#define ACM_GEMM_ROWS_ALWAYS 8
 
 #define ACM_CHECK_HIP(expr)                                                            \
     do {                                                                               \
@@ -98,8 +108,6 @@ struct StreamView {
     float* slots;
     unsigned ids_bytes, slots_bytes;
     int n_waves;
-    int probe;      // ACM_STREAM_PROBE (measurement only): 1 = gathers without the row-local stage, 2 = row-local stage
-                    // without the gathers (every id replaced by the sentinel)
 };
 
 // Device-side view handed to kernels by value.

@@ -832,10 +832,6 @@ namespace {
 // graph with mean 82 has median 30: with 32 lanes x 2 neighbours most lanes of most rows idle), 32 beyond
 int narrow_lanes(const acm_csr* a) {
     const double avg = (double)a->nnz / (double)(a->n_rows > 0 ? a->n_rows : 1);
-    if (const char* e = getenv("ACM_NARROW_LANES")) {
-        const int v = atoi(e);
-        if (v == 8 || v == 16 || v == 32) return v;
-    }
     return avg <= 12.0 ? 8 : (avg <= 160.0 ? 16 : 32);
 }
 // with 16 lanes per item a workgroup round is one window: the narrow gather finishes the long rows itself
@@ -912,7 +908,7 @@ int launch_gather(const acm_csr* a, const GatherSrc& g, int F, const typename Ep
         // either -- the fabric, not the load instruction, bounds the large-graph gathers.  With a fused head (EpiFwd) the
         // vector layout runs the head four times redundantly, and with two gathered channels its 58 VGPRs cost
         // occupancy, so it is the default for single-channel products (k-hop chains, spmm_sub, the S gather of the
-        // aggregate-first structure channel); ACM_WIDE_VEC=1 forces it everywhere, ACM_WIDE_SCALAR=1 nowhere.
+        // aggregate-first structure channel); acm_tuning_t.wide_form = 2 forces it everywhere, 1 nowhere, 3 keeps the pair form.
         // Rows of a few entries (CSR feature matrices: 5-18 per row) never fill the four-neighbour steps: 24 -> 35 us for
         // the Penn94-shaped feature projection, so the vector form also needs a mean row length of 16.
         // (iii) gathered tables that fit the L2 (Squirrel / Chameleon / Cora sizes) take it for any channel count: there
@@ -920,20 +916,19 @@ int launch_gather(const acm_csr* a, const GatherSrc& g, int F, const typename Ep
         // channel: conv_bwd_spmm 57.8 -> 42.6 us, conv_fwd 64.1 -> 57.7, step 0.283 -> 0.265 ms; it replaces the
         // two-neighbours-per-instruction pair form of round 1 on those graphs).
         const bool l2_resident = (size_t)a->n_cols * F * NG * sizeof(float) <= (8u << 20);
-        bool vec = !bf16 && F % 4 == 0 && getenv("ACM_WIDE_SCALAR") == nullptr &&
-                   ((NG == 1 && a->nnz >= 16 * a->n_rows) || (l2_resident && NG > 1 && a->nnz >= 4 * a->n_rows) ||
-                    getenv("ACM_WIDE_VEC") != nullptr);
+        const int form = acm_tuning().wide_form;
+        bool vec = !bf16 && F % 4 == 0 && form != 1 &&
+                   ((NG == 1 && a->nnz >= 16 * a->n_rows) || (l2_resident && NG > 1 && a->nnz >= 4 * a->n_rows) || form == 2);
         for (int c = 0; c < NG && vec; ++c)
             vec = ((uintptr_t)g.p[c]) % 16 == 0 && g.ld[c] % 4 == 0 &&
                   (uint64_t)a->n_cols * (uint64_t)g.ld[c] * 4u < (1ull << 32);
-        if (vec && getenv("ACM_WIDE_PAIR") == nullptr) pair32 = false;
+        if (vec && form != 3) pair32 = false;
         // bf16 tables (even 8 < F <= 64): the vector form with 8-byte fetches whenever the fp32 operand would take it (rows of
         // 4 k columns, 8-byte aligned); the two-neighbours-per-instruction pair kernel otherwise.  On the twitch-shaped
         // graph the pair kernel is SLOWER than the fp32 vector form (conv_bwd_spmm 619 -> 707 us: half the bytes, but two
         // neighbours per instruction instead of four)
-        bool vec16 = bf16 && F % 4 == 0 && getenv("ACM_WIDE_SCALAR") == nullptr && getenv("ACM_BF16_PAIR") == nullptr &&
-                     ((NG == 1 && a->nnz >= 16 * a->n_rows) || (NG > 1 && a->nnz >= 4 * a->n_rows) ||
-                      getenv("ACM_WIDE_VEC") != nullptr);
+        bool vec16 = bf16 && F % 4 == 0 && form != 1 && form != 3 &&
+                     ((NG == 1 && a->nnz >= 16 * a->n_rows) || (NG > 1 && a->nnz >= 4 * a->n_rows) || form == 2);
         for (int c = 0; c < NG && vec16; ++c)
             vec16 = ((uintptr_t)g.p[c]) % 8 == 0 && g.ld[c] % 4 == 0 && (uint64_t)a->n_cols * (uint64_t)g.ld[c] * 2u < (1ull << 32);
         if (vec16) {
@@ -1124,7 +1119,7 @@ extern "C" int acm_conv_bwd_spmm(const acm_csr_t* at, const acm_conv_bwd_spmm_t*
                 "acm_conv_bwd_spmm: NULL tensor pointer");
     if (p->g_struc) ACM_REQUIRE(p->s_struc && p->d_struc, ACM_EINVAL, "acm_conv_bwd_spmm: structure channel pointers are NULL");
     // wide layers on graphs whose gathered tables exceed the L2: one channel per pass (see EpiBwdLow)
-    // (ACM_BWD_SPLIT=1 / ACM_BWD_FUSED=1 force either form, for tests and A/B measurements)
+    // (acm_tuning_t.bwd_split = 1 / 0 force either form, for tests and A/B measurements)
     // Measured (profiles/r02_wide_kernels.jsonl): twitch-shaped (mean degree 82) 640 -> 613 us, with the structure channel
     // 1004 -> 899, Penn94-shaped (66) 121 -> 106; arXiv-year-shaped (15) 160 -> 190: short rows pay the per-item cost of
     // every pass, so the split needs a mean degree of 32.
@@ -1133,7 +1128,8 @@ extern "C" int acm_conv_bwd_spmm(const acm_csr_t* at, const acm_conv_bwd_spmm_t*
     // keeps the hot set of a single fp32 pass and saves the second walk over the operator (twitch-shaped, F = 64: 430 us in
     // two passes, 387 us fused; fp32: 619 us in two passes)
     const bool b16 = p->gather_bf16 != 0;             // launch_gather checks the shape (even 8 < F <= 64) and alignment
-    const bool split = getenv("ACM_BWD_FUSED") ? false : (getenv("ACM_BWD_SPLIT") ? true : (big && !b16));
+    const int want_split = acm_tuning().bwd_split;
+    const bool split = want_split == 0 ? false : (want_split == 1 ? true : (big && !b16));
     if (F > 8 && F <= 256 && split) {
         hipStream_t s = (hipStream_t)stream;
         GatherSrc gl = {{p->g_low, nullptr, nullptr}, {p->ld_g_low, 0, 0}};
@@ -1671,7 +1667,7 @@ extern "C" int acm_conv_fwd_tail(const acm_csr_t* a, const acm_conv_fwd_t* p, co
     st = launch_gather<2, EpiRaw>(a, g, F, *p, workspace, workspace_bytes, s, "acm_conv_fwd_tail", nullptr, false, true);
     if (st != ACM_OK) return st;
     const int FP = F <= 2 ? 2 : (F <= 4 ? 4 : 8);
-    const bool packed = FP == 8 && getenv("ACM_TAIL_SERIAL") == nullptr;
+    const bool packed = FP == 8;
     const int n = (int)a->n_rows, nblk = packed ? (n + 31) / 32 : (n + 255) / 256;
     const int npg = 3 * k * F + k * k;
     float* loss_partial = (float*)tail_workspace;
@@ -1681,10 +1677,8 @@ extern "C" int acm_conv_fwd_tail(const acm_csr_t* a, const acm_conv_fwd_t* p, co
         hipLaunchKernelGGL((conv_tail_packed8_kernel<2>), dim3(nblk), dim3(256), lds, s, *p, *l, *b, n, loss_partial, k3_partial);
     else if (FP == 2)
         hipLaunchKernelGGL((conv_tail_rows_kernel<2, 2>), dim3(nblk), dim3(256), lds, s, *p, *l, *b, n, loss_partial, k3_partial);
-    else if (FP == 4)
-        hipLaunchKernelGGL((conv_tail_rows_kernel<4, 2>), dim3(nblk), dim3(256), lds, s, *p, *l, *b, n, loss_partial, k3_partial);
     else
-        hipLaunchKernelGGL((conv_tail_rows_kernel<8, 2>), dim3(nblk), dim3(256), lds, s, *p, *l, *b, n, loss_partial, k3_partial);
+        hipLaunchKernelGGL((conv_tail_rows_kernel<4, 2>), dim3(nblk), dim3(256), lds, s, *p, *l, *b, n, loss_partial, k3_partial);
     ACM_CHECK_HIP(hipGetLastError());
     const acm_reduce_seg_t seg = {loss_partial, nblk, 1, 0, 1, l->loss, 1, 0, 0, 0};
     st = acm_reduce_emit(b->defer, &seg, 1, s);

@@ -26,20 +26,19 @@ namespace {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-// max(x, 0) as ONE instruction: fmaxf lowers to v_max_f32 x, x, x (quieting) + v_max_f32 .., 0 under IEEE mode, and the
-// per-edge ReLUs are a third of this kernel's VALU work
-// |a| + |b| in one instruction (source modifiers); plain C++ gets SLP-packed into v_pk_add_f32, which has no |.| and
-// costs a v_and_b32 per operand
+// |a| + |b| and max(x, 0) written with BUILTINS, so that the compiler sees every read of an MFMA result: its hazard
+// recogniser inserts the wait states between a v_mfma and a VALU read of its VGPR results (-amdgpu-mfma-vgpr-form) only
+// for instructions it scheduled itself -- reads hidden inside inline assembly are invisible to it (round 3 saw stale
+// registers behind a bf16 MFMA with the inline-assembly form of this helper).  |.| folds into v_add_f32 as a source
+// modifier (one instruction); the empty asm on the RESULT (no instruction, reads no MFMA register) only keeps the
+// SLP vectoriser from pairing two of these into v_pk_add_f32, which has no |.| and costs a v_and_b32 per operand.
 __device__ __forceinline__ float abs_add(float a, float b) {
-    float r;
-    asm("v_add_f32_e64 %0, |%1|, |%2|" : "=v"(r) : "v"(a), "v"(b));
+    float r = __builtin_fabsf(a) + __builtin_fabsf(b);
+    asm volatile("" : "+v"(r));
     return r;
 }
-__device__ __forceinline__ float relu1(float x) {
-    float r;
-    asm("v_max_f32_e32 %0, 0, %1" : "=v"(r) : "v"(x));
-    return r;
-}
+// (twelve per quad of rows, outside the per-edge loop: the plain library form is good enough)
+__device__ __forceinline__ float relu1(float x) { return fmaxf(x, 0.f); }
 
 template <int K>
 struct RowOut {

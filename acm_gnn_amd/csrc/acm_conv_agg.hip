@@ -55,18 +55,6 @@ __device__ __forceinline__ void stage_weights(float* wlds, const float* w_low, c
     }
 }
 
-// The next layer's three F x F' weight panels (F' <= 2) as one [col][8] table: [W_L'(col,:) | W_H'(col,:) | W_I'(col,:) | 0].
-// A lane reads the rows of its four columns with two ds_read_b128 each.
-#define ACM_NEXT_LDS (64 * 8)
-__device__ __forceinline__ void stage_next_weights(float* nlds, const acm_conv_agg_fwd_t& p) {
-    if (p.next_f <= 0) return;
-    for (int idx = threadIdx.x; idx < ACM_NEXT_LDS; idx += 256) {
-        const int col = idx >> 3, j = idx & 7, c = j / p.next_f, q = j % p.next_f;
-        const float* w = c == 0 ? p.next_w_low : (c == 1 ? p.next_w_high : p.next_w_mlp);
-        nlds[idx] = (col < p.f_out && c < 3) ? w[(long)col * p.next_ld_w + q] : 0.f;
-    }
-}
-
 // pre_L = P W_L, pre_H = (x - P) W_H, z_I = x W_I for the lane's four columns.
 // P and x of the group's row are parked in a per-group LDS scratch (2 FP floats) so that the loop
 // over f can stay *rolled*: with a fully unrolled loop hipcc keeps all 3 FP ds_read_b128 weight rows
@@ -75,10 +63,10 @@ __device__ __forceinline__ void stage_next_weights(float* nlds, const acm_conv_a
 template <int FP>
 __device__ __forceinline__ void project(const float* wlds, float* scratch, int m, const float* __restrict__ prow,
                                         const float* __restrict__ xrow, bool active, float (&p0)[4], float (&p1)[4],
-                                        float (&zi)[4], bool x_in_scratch = false) {
+                                        float (&zi)[4]) {
     // lanes 0 .. FP/4-1 of the group fetch P, the next FP/4 fetch x (16-byte pieces); prow == nullptr: P is
-    // already in the scratch (a long row whose partial sums were added by the caller); x_in_scratch: so is x
-    if (!x_in_scratch && m < FP / 2 && (prow || m >= FP / 4)) {
+    // already in the scratch (a long row whose partial sums were added by the caller)
+    if (m < FP / 2 && (prow || m >= FP / 4)) {
         const float* src = (m < FP / 4) ? prow + 4 * m : xrow + 4 * (m - FP / 4);
         const float4 v = active ? *reinterpret_cast<const float4*>(src) : make_float4(0.f, 0.f, 0.f, 0.f);
         *reinterpret_cast<float4*>(scratch + 4 * m) = v;
@@ -102,12 +90,12 @@ __device__ __forceinline__ void project(const float* wlds, float* scratch, int m
 }
 
 // P (uniform in the 16-lane group) -> projections -> head -> out / att for one row.
-template <int FP, int K, bool FULL = false, bool NT = false, bool NEXT = false>
+template <int FP, int K, bool FULL = false>
 __device__ __forceinline__ void agg_fwd_row(const acm_conv_agg_fwd_t& p, const float* wlds, const float* hlds,
                                             float* scratch, const float* mixm, int row, int lane, const CsrView& csr,
                                             const float* __restrict__ partial, const AcmDropCtx& dc,
-                                            bool p_in_scratch = false, bool active = true, bool x_in_scratch = false,
-                                            const float* nlds = nullptr) {
+                                            bool p_in_scratch = false) {
+    constexpr bool active = true;
     const int F = FULL ? 64 : p.f_out, m = lane & 15;     // FULL: f_out == 64, the column guards fold away
     float H[K][4];
     {
@@ -141,7 +129,7 @@ __device__ __forceinline__ void agg_fwd_row(const acm_conv_agg_fwd_t& p, const f
             }
         }
         float p0[4], p1[4], zi[4];
-        project<FP>(wlds, scratch, m, prow, p.xs + (long)row * p.ld_xs, true, p0, p1, zi, x_in_scratch);
+        project<FP>(wlds, scratch, m, prow, p.xs + (long)row * p.ld_xs, true, p0, p1, zi);
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const bool ok = m + 16 * i < F;
@@ -164,11 +152,9 @@ __device__ __forceinline__ void agg_fwd_row(const acm_conv_agg_fwd_t& p, const f
     if (p.head_stats && m == 0 && active) row_head_store<K>(p.head_stats + (long)row * p.ld_head_stats, rh);
     float df[4];
     acm_drop4(dc, row, m, df);        // dc: read once per launch (its step counter is a global load)
-    float ov[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int col = m + 16 * i;
-        ov[i] = 0.f;
         if (col < F && active) {
             float o = rh.alpha[0] * H[0][i] + rh.alpha[1] * H[1][i] + rh.alpha[2] * H[2][i];
             if (K == 4) o = fmaf(rh.alpha[K - 1], H[K - 1][i], o);
@@ -176,39 +162,7 @@ __device__ __forceinline__ void agg_fwd_row(const acm_conv_agg_fwd_t& p, const f
             if (p.post_relu) o = fmaxf(o, 0.f);
             if (p.post_scale) o *= p.post_scale[(long)row * p.ld_post_scale + col];
             if (p.post_drop.p > 0.f) o *= df[i];
-            // NT: the output is a 43 MB stream no later step of this kernel reads; allocated in the L2 it evicts rows of the
-            // gathered table
-            if (NT) __builtin_nontemporal_store(o, p.out + (long)row * p.ld_out + col);
-            else p.out[(long)row * p.ld_out + col] = o;
-            if (NEXT) ov[i] = o;
-        }
-    }
-    if (NEXT) {
-        // the next layer's projection of this row, [out W_L' | out W_H' | out W_I'] (3 F' <= 8 values): the lane's four
-        // columns against their rows of the [col][8] table, then the 16-lane sum
-        float z8[6];
-#pragma unroll
-        for (int j = 0; j < 6; ++j) z8[j] = 0.f;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const float4 wa = *reinterpret_cast<const float4*>(nlds + (m + 16 * i) * 8);
-            const float2 wb = *reinterpret_cast<const float2*>(nlds + (m + 16 * i) * 8 + 4);
-            z8[0] = fmaf(ov[i], wa.x, z8[0]); z8[1] = fmaf(ov[i], wa.y, z8[1]);
-            z8[2] = fmaf(ov[i], wa.z, z8[2]); z8[3] = fmaf(ov[i], wa.w, z8[3]);
-            z8[4] = fmaf(ov[i], wb.x, z8[4]); z8[5] = fmaf(ov[i], wb.y, z8[5]);
-        }
-        const int nf = p.next_f;
-#pragma unroll
-        for (int j = 0; j < 6; ++j) {
-            z8[j] = acm_group_sum<16>(z8[j]);
-            if (p.next_relu) z8[j] = fmaxf(z8[j], 0.f);
-        }
-        if (m == 0 && active) {
-#pragma unroll
-            for (int j = 0; j < 6; ++j) {
-                if (j < 2 * nf) p.next_zlh[(long)row * p.ld_next_zlh + j] = z8[j];
-                else if (j < 3 * nf) p.next_zi[(long)row * p.ld_next_zi + (j - 2 * nf)] = z8[j];
-            }
+            p.out[(long)row * p.ld_out + col] = o;
         }
     }
     if (m == 0 && active)
@@ -353,19 +307,16 @@ __global__ __launch_bounds__(256) void agg_fused_kernel(acm_conv_agg_fwd_t p, Cs
 // one row the address coalescer sees 32 lines per 32 neighbours -- half the look-ups per byte, which is what bounds the
 // gather once the rows hit in L1/L2 (scripts/probe_gather.py: 63 us with every row in L1).
 // Lane (e = gl >> 1, h = gl & 1) of the 16-lane group: neighbours k0 + e + 8 u (u = 0..3), columns 4 h .. 4 h + 3.
-// NEXT: the following layer's narrow projection rides the epilogue (acm_conv_agg_fwd_t.next_*).
-template <bool FULL, bool NEXT>
+template <bool FULL>
 __device__ __forceinline__ void agg_fused_pair_body(const acm_conv_agg_fwd_t& p, const CsrView& csr) {
     constexpr int FP = 8, K = 3, GPB = 16, U = 4, STEP = 8 * U;
     static_assert(GPB == ACM_WINDOW, "one window of work items per workgroup round");
-    __shared__ __attribute__((aligned(16))) float wlds[3 * FP * 64 + 3 * K * 64 + 16 * 2 * FP + (NEXT ? ACM_NEXT_LDS : 0)];
+    __shared__ __attribute__((aligned(16))) float wlds[3 * FP * 64 + 3 * K * 64 + 16 * 2 * FP];
     __shared__ float coop[ACM_WINDOW * FP];
     float* hlds = wlds + 3 * FP * 64;
     float* scratch = hlds + 3 * K * 64 + (threadIdx.x >> 4) * 2 * FP;
-    float* nlds = hlds + 3 * K * 64 + 16 * 2 * FP;
     stage_weights<FP>(wlds, p.w_low, p.w_high, p.w_mlp, p.ld_w, p.f_in, p.f_out);
     stage_head_params<K>(hlds, p.att_vec, p.ln_weight, p.ln_bias, p.layernorm, p.f_out);
-    if (NEXT) stage_next_weights(nlds, p);
     __syncthreads();
     float mixm[K * K];
 #pragma unroll
@@ -463,7 +414,7 @@ __device__ __forceinline__ void agg_fused_pair_body(const acm_conv_agg_fwd_t& p,
                     p.agg[(long)it.row * p.ld_agg + 4 * h + i] = val;
                 }
             }
-            agg_fwd_row<FP, K, FULL, false, NEXT>(p, wlds, hlds, scratch, mixm, it.row, lane, csr, nullptr, dc, true, true, false, nlds);
+            agg_fwd_row<FP, K, FULL>(p, wlds, hlds, scratch, mixm, it.row, lane, csr, nullptr, dc, true);
         }
         if (!has_next) break;
         it = itn;
@@ -475,172 +426,7 @@ __device__ __forceinline__ void agg_fused_pair_body(const acm_conv_agg_fwd_t& p,
 
 template <bool FULL>
 __global__ __launch_bounds__(256) void agg_fused_pair_kernel(acm_conv_agg_fwd_t p, CsrView csr) {
-    agg_fused_pair_body<FULL, false>(p, csr);
-}
-// with the next layer's projection: the extra kernel arguments spill scalars; capped to the registers of five waves per SIMD
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5))) void agg_fused_pair_next_kernel(acm_conv_agg_fwd_t p, CsrView csr) {
-    agg_fused_pair_body<true, true>(p, csr);
-}
-
-// ---------------------------------------------------------------- streamed form (acm_csr_build_streams)
-// The same fused forward over per-wave id streams.  What the CSR form above spends per wave step -- four guarded id
-// loads, per-lane bounds, 64-bit row addresses, 16 selects, the item descriptors through the vector unit and 45
-// exec-mask branches -- is gone: ONE dwordx4 id load per step (issued two steps ahead), rows through a buffer
-// descriptor with 32-bit offsets (an idle slot holds the sentinel id: its load is answered with zeros without a memory
-// access, so the sums need no select), slice descriptors through the scalar unit, wave-uniform control flow.  The rows of
-// the NEXT step (the next slice's first step included) are requested before the row-local stage of a finished slice
-// runs, so every wave has gathers in flight while it does the projections and the head.
-// Lane (g, e, h): group g = one work item of the slice, neighbours 4 e .. 4 e + 3 of the step, half h of the 32-byte row.
-// Pieces of a long row: partial sum -> its slot (write-through store), arrival counter; the last piece adds the slots
-// in slot order (bypassing the L1 / the XCD's L2) and finishes the row.
-
-__device__ __forceinline__ acm_i32x4 acm_probe_ids(acm_i32x4 j, int probe) {
-    if (probe >= 2) j = acm_i32x4{ACM_STREAM_SENTINEL, ACM_STREAM_SENTINEL, ACM_STREAM_SENTINEL, ACM_STREAM_SENTINEL};
-    return j;
-}
-
-template <bool FULL, bool NT>
-__global__ __launch_bounds__(256) void agg_stream_kernel(acm_conv_agg_fwd_t p, StreamView sv, unsigned xg_bytes) {
-    constexpr int FP = 8, K = 3;
-    __shared__ __attribute__((aligned(16))) float wlds[3 * FP * 64 + 3 * K * 64 + 16 * 2 * FP];
-    float* hlds = wlds + 3 * FP * 64;
-    float* scratch = hlds + 3 * K * 64 + (threadIdx.x >> 4) * 2 * FP;
-    stage_weights<FP>(wlds, p.w_low, p.w_high, p.w_mlp, p.ld_w, p.f_in, p.f_out);
-    stage_head_params<K>(hlds, p.att_vec, p.ln_weight, p.ln_bias, p.layernorm, p.f_out);
-    __syncthreads();
-    float mixm[K * K];
-#pragma unroll
-    for (int q = 0; q < K * K; ++q) mixm[q] = p.att_mix[q];
-    const AcmDropCtx dc = acm_drop_ctx(p.post_drop);
-    const int lane = threadIdx.x & 63, g = lane >> 4, gl = lane & 15, e = gl >> 1, h = gl & 1;
-    const int W = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
-    if (W >= sv.n_waves) return;
-    int s = sv.waves[W * 4 + 0];
-    const int s_end = sv.waves[W * 4 + 1];
-    if (s >= s_end) return;
-    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.xg), 0, xg_bytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t ri = __builtin_amdgcn_make_buffer_rsrc(const_cast<int32_t*>(sv.ids), 0, sv.ids_bytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rp = __builtin_amdgcn_make_buffer_rsrc(sv.slots, 0, sv.slots_bytes, 0x00020000);
-    int ioff = sv.waves[W * 4 + 2] * 512 + (g * 8 + e) * 16;
-    const int hoff = h * 16;
-    // two steps of rows in flight per wave (za, zb): with the row-local stage between the steps a wave spends a good part of
-    // its time on the VALU, and one step in flight then leaves the memory system short of requests
-    acm_f32x4 za[4], zb[4];
-#define ACM_ISSUE(Z, J)                                                                                         \
-    do {                                                                                                        \
-        Z[0] = __builtin_bit_cast(acm_f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, (J).x * 32 + hoff, 0, 0)); \
-        Z[1] = __builtin_bit_cast(acm_f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, (J).y * 32 + hoff, 0, 0)); \
-        Z[2] = __builtin_bit_cast(acm_f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, (J).z * 32 + hoff, 0, 0)); \
-        Z[3] = __builtin_bit_cast(acm_f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, (J).w * 32 + hoff, 0, 0)); \
-    } while (0)
-#define ACM_IDS(OFF) acm_probe_ids(__builtin_bit_cast(acm_i32x4, __builtin_amdgcn_raw_buffer_load_b128(ri, (OFF), 0, NT ? 2 : 0)), sv.probe)
-    // slice descriptors {row, slot, steps, -} per group, requested two slices ahead; the row-local stage's own operands
-    // (row scale, the row's x) one slice ahead, at the end of the slice before: loads return in order, so waiting for
-    // them in the next row-local stage leaves the younger row requests in flight
-    const acm_i32x4* items = reinterpret_cast<const acm_i32x4*>(sv.items);
-    const unsigned xs_row_bytes = (unsigned)p.ld_xs * 4u;
-    const char* xs_half = reinterpret_cast<const char*>(p.xs) + hoff;
-    acm_i32x4 item = items[s * 4 + g];
-    int rem = __builtin_amdgcn_readfirstlane(item.z);
-    float rs_cur = p.row_scale ? p.row_scale[item.x >= 0 ? item.x : 0] : 1.f;
-    acm_f32x4 x_cur = *reinterpret_cast<const acm_f32x4*>(xs_half + (size_t)(unsigned)(item.x >= 0 ? item.x : 0) * xs_row_bytes);
-    acm_i32x4 item_next = items[(s + 1) * 4 + g];
-    // issue order of the steady state (rows, ids, rows, ids): the counted waits of the loop are derived from it
-    acm_i32x4 q0, q1;
-    {
-        // (scheduling barriers: see stream_gather_role -- the loop's counted waits assume this issue order)
-        const acm_i32x4 j0 = ACM_IDS(ioff), j1 = ACM_IDS(ioff + 512);
-        __builtin_amdgcn_sched_barrier(0);
-        ACM_ISSUE(za, j0);
-        q0 = ACM_IDS(ioff + 1024);
-        __builtin_amdgcn_sched_barrier(0);
-        ACM_ISSUE(zb, j1);
-        q1 = ACM_IDS(ioff + 1536);
-        __builtin_amdgcn_sched_barrier(0);
-    }
-    ioff += 2048;
-    acm_f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-    const CsrView no_csr = {};
-    // ---- a slice is complete
-    auto finish = [&]() __attribute__((always_inline)) {
-        // the sum over the eight lane pairs of each group (fixed order)
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            acc[i] += acm_dpp<0x4E>(acc[i]);     // quad_perm [2,3,0,1]
-            acc[i] += acm_dpp<0x124>(acc[i]);    // row_ror:4
-            acc[i] += acm_dpp<0x128>(acc[i]);    // row_ror:8
-        }
-        const int slot = item.y;
-        bool active = item.x >= 0 && slot < 0;
-        const int row = item.x >= 0 ? item.x : 0;
-        if (__builtin_amdgcn_ballot_w64(slot >= 0) != 0ull) {      // some group holds a piece of a long row
-            if (slot >= 0) {
-                const int li = sv.long_index[row];
-                const AcmLongRow lr = sv.long_rows[li];
-                if (gl < 2)
-                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(acm_i32x4, acc), rp, slot * 32 + hoff, 0, /*sc1*/ 16);
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                int old = 0;
-                if (gl == 0) old = __hip_atomic_fetch_add(sv.counters + li, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                old = acm_row_bcast(old, 0);
-                if (old == lr.slot_end - lr.slot_begin - 1) {      // every other piece has arrived
-                    if (gl == 0) __hip_atomic_store(sv.counters + li, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    // lane pair e adds slots e, e + 8, ... (a hub has dozens of pieces: one lane reading them one after
-                    // the other was the kernel's tail), then the same fixed tree over the eight pairs
-                    acm_f32x4 tot = {0.f, 0.f, 0.f, 0.f};
-                    for (int q = lr.slot_begin + e; q < lr.slot_end; q += 8)
-                        tot += __builtin_bit_cast(acm_f32x4, __builtin_amdgcn_raw_buffer_load_b128(rp, q * 32 + hoff, 0, /*sc1*/ 16));
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        tot[i] += acm_dpp<0x4E>(tot[i]);
-                        tot[i] += acm_dpp<0x124>(tot[i]);
-                        tot[i] += acm_dpp<0x128>(tot[i]);
-                    }
-                    acc = tot;
-                    active = true;
-                }
-            }
-        }
-        if (__builtin_amdgcn_ballot_w64(active) != 0ull) {
-            if (gl < 4) {                                    // lanes 0, 1: P; lanes 2, 3: x (the layout project() reads)
-                const acm_f32x4 v = gl < 2 ? rs_cur * acc : x_cur;
-                *reinterpret_cast<acm_f32x4*>(scratch + 4 * gl) = v;
-                if (active && gl < 2) *reinterpret_cast<acm_f32x4*>(p.agg + (long)row * p.ld_agg + 4 * h) = v;   // P, saved for the backward
-            }
-            if (sv.probe != 1 && sv.probe != 3)
-                agg_fwd_row<FP, K, FULL, NT>(p, wlds, hlds, scratch, mixm, row, lane, no_csr, nullptr, dc, true, active, true);
-        }
-        acc = acm_f32x4{0.f, 0.f, 0.f, 0.f};
-        ++s;
-        rem = s < s_end ? __builtin_amdgcn_readfirstlane(item_next.z) : 0x7fffffff;
-        // the next slice's descriptor arrived a slice ago; its row operands and the descriptor after it are requested
-        // straight into the registers they are used from (a copy of a value still in flight would wait for everything)
-        item = item_next;
-        item_next = items[(s + 1) * 4 + g];
-        {
-            const int rown = item.x >= 0 ? item.x : 0;
-            rs_cur = p.row_scale ? p.row_scale[rown] : 1.f;
-            x_cur = *reinterpret_cast<const acm_f32x4*>(xs_half + (size_t)(unsigned)rown * xs_row_bytes);
-        }
-    };
-#define ACM_STEP(Z)                                  \
-    do {                                             \
-        acc += (Z[0] + Z[1]) + (Z[2] + Z[3]);        \
-        ACM_ISSUE(Z, q0);                            \
-        q0 = q1;                                     \
-        q1 = ACM_IDS(ioff);                          \
-        ioff += 512;                                 \
-        if (--rem == 0) finish();                    \
-    } while (0)
-    // an odd step count runs one step past the wave's share: its ids are the next wave's (or the padding), its sums are
-    // never used (rem is "infinite" after the last slice)
-    for (int t = sv.waves[W * 4 + 3]; t > 0; t -= 2) {
-        ACM_STEP(za);
-        ACM_STEP(zb);
-    }
-#undef ACM_STEP
-#undef ACM_ISSUE
-#undef ACM_IDS
+    agg_fused_pair_body<FULL>(p, csr);
 }
 
 // ---------------------------------------------------------------- backward
@@ -658,49 +444,24 @@ __global__ __launch_bounds__(256) void agg_stream_kernel(acm_conv_agg_fwd_t p, S
 // (H, mean, rstd), and hands each channel's G straight to the MFMAs.  att_vec / LayerNorm
 // gamma, beta sit in LDS next to the weights ([array][c][m][i], one ds_read_b128 per use).
 // FULL: f_out == 64 (the reference's hidden width), every column guard `m + 16 i < F` folds away at compile time.
-template <int FP, int K, bool FULL, bool GATHER>
-__device__ __forceinline__ void agg_bwd_body(const acm_conv_agg_bwd_t& p, int n_rows, float* __restrict__ partial, const GatherRole* gr) {
+template <int FP, int K, bool FULL>
+__device__ __forceinline__ void agg_bwd_body(const acm_conv_agg_bwd_t& p, int n_rows, float* __restrict__ partial) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, m = lane & 15, g = lane >> 4;
-    // GATHER: one workgroup of sixteen waves per CU -- the hardware deals a workgroup's waves round-robin over the four
-    // SIMDs, so each SIMD holds three backward waves and one gather wave (several smaller workgroups per CU do not all
-    // become resident: the next one's waves land on the SIMDs the first one filled).
-    // LDSACC (the gather variant): dW lives in a per-wave LDS slab instead of 48 accumulator registers -- a tile is read
-    // as the MFMA's C operand and written back (one writer per slab: a fixed order of additions; ds_add_f32 instead
-    // costs ~80 clocks per wave instruction: 370 us) -- which takes the kernel from 147 to 123 registers: four waves per SIMD
-    constexpr bool LDSACC = GATHER;
-    constexpr int BW = GATHER ? 12 : 4;           // backward waves per workgroup (the gather variant: 16 - BW gather waves)
-    constexpr int SLAB = 3 * FP * 64 + 3 * K * 64 + 16;     // LDSACC: [dW, rows padded to FP][dv | dgamma | dbeta][dmix]
-    if (GATHER && wv >= BW) {                     // the last four waves: the next step's input gather; same barrier count as below
-        __syncthreads();
-        if (gr->roles & 2) stream_gather_role(*gr, __builtin_amdgcn_readfirstlane(blockIdx.x * (16 - BW) + (wv - BW)));
-        __syncthreads();
-        __syncthreads();
-        return;
-    }
+    constexpr int BW = 4;                         // waves per workgroup
     const int F = FULL ? 64 : p.f_out, f_in = p.f_in;
     const int npg = 3 * f_in * F + 3 * K * F + K * K;
     float* wlds = lds;                           // 3 * FP * 64 floats
     float* hlds = lds + 3 * FP * 64;             // 3 * K * 64 floats
     float* scratch = hlds + 3 * K * 64 + (threadIdx.x >> 4) * 2 * FP;   // per-group P | x; all dead after the row loop
-    if (wv < 4) {                                 // (the staging loops stride by 256 threads)
-        stage_weights<FP>(wlds, p.w_low, p.w_high, p.w_mlp, p.ld_w, f_in, F);
-        stage_head_params<K>(hlds, p.att_vec, p.ln_weight, p.ln_bias, p.layernorm, F);
-    }
-    float* slabs = hlds + 3 * K * 64 + BW * 4 * 2 * FP;      // LDSACC: behind the groups' scratch, live through the row loop
-    if (LDSACC)
-        for (int i = threadIdx.x; i < BW * SLAB; i += BW * 64) slabs[i] = 0.f;
+    stage_weights<FP>(wlds, p.w_low, p.w_high, p.w_mlp, p.ld_w, f_in, F);
+    stage_head_params<K>(hlds, p.att_vec, p.ln_weight, p.ln_bias, p.layernorm, F);
     __syncthreads();
-    f32x4 acc[LDSACC ? 1 : 3][LDSACC ? 1 : 4];
-    if (!LDSACC) {
+    f32x4 acc[3][4];
 #pragma unroll
-        for (int c = 0; c < 3; ++c)
+    for (int c = 0; c < 3; ++c)
 #pragma unroll
-            for (int t = 0; t < 4; ++t) acc[LDSACC ? 0 : c][LDSACC ? 0 : t] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    }
-    // LDSACC slab layout of dW: tile (c, t) = 32 lanes x 4 floats, [(c * 4 + t) * 32 + (f / 4) * 16 + m][f % 4] for
-    // (f, col = 16 t + m): a lane's four results of one MFMA are one 16-byte LDS access
-    float* my_dw = slabs + wv * SLAB + (g * 16 + m) * 4;
+        for (int t = 0; t < 4; ++t) acc[c][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
     float pA[K][4], pS[K], dmix1 = 0.f;          // head-parameter accumulators (see row_channel_backward)
     const int qc = (m < K * K ? m : 0) / K, qj = (m < K * K ? m : 0) % K;    // the att_mix element this lane accumulates
 #pragma unroll
@@ -716,8 +477,7 @@ __device__ __forceinline__ void agg_bwd_body(const acm_conv_agg_bwd_t& p, int n_
     const bool out_mask = p.out != nullptr && p.post_relu && !p.post_scale;
     const float post_gain = p.post_drop.p > 0.f ? acm_drop_ctx(p.post_drop).inv_keep : 1.f;
 
-    const int n_rows_bwd = (GATHER && !(gr->roles & 1)) ? 0 : n_rows;
-    for (int r0 = (blockIdx.x * BW + wv) * 4; r0 < n_rows_bwd; r0 += gridDim.x * BW * 4) {
+    for (int r0 = (blockIdx.x * BW + wv) * 4; r0 < n_rows; r0 += gridDim.x * BW * 4) {
         const int row = r0 + g;
         const bool active = row < n_rows;
         const long rr = active ? row : 0;
@@ -770,22 +530,11 @@ __device__ __forceinline__ void agg_bwd_body(const acm_conv_agg_bwd_t& p, int n_
             const bool relu_c = (c < 2) ? (p.relu_after != 0) : (p.relu_mlp != 0);
             const float aop = (c == 0) ? Pm : (c == 1 ? xm - Pm : xm);
             float G[4];
-            f32x4 tile[4];                        // LDSACC: the channel's four dW tiles, requested before the channel's math
-            if (LDSACC) {
-#pragma unroll
-                for (int t = 0; t < 4; ++t)
-                    tile[t] = (g < FP / 4) ? *reinterpret_cast<const f32x4*>(my_dw + (c * 4 + t) * 128) : (f32x4){0.f, 0.f, 0.f, 0.f};
-            }
             row_channel_backward<K>(hlds, c, mm, F, ln, p.scale, rh, ds[c], H[c], dO, pA[c], pS[c], G);
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
                 const bool keep = active && (m + 16 * t < F) && (!relu_c || H[c][t] > 0.f);
-                if (LDSACC) {
-                    tile[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(aop, keep ? G[t] : 0.f, tile[t], 0, 0, 0);
-                    if (g < FP / 4) *reinterpret_cast<f32x4*>(my_dw + (c * 4 + t) * 128) = tile[t];   // rows f >= FP: zero by construction
-                } else {
-                    acc[LDSACC ? 0 : c][LDSACC ? 0 : t] = __builtin_amdgcn_mfma_f32_16x16x4f32(aop, keep ? G[t] : 0.f, acc[LDSACC ? 0 : c][LDSACC ? 0 : t], 0, 0, 0);
-                }
+                acc[c][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(aop, keep ? G[t] : 0.f, acc[c][t], 0, 0, 0);
             }
         }
         if (K == 4) {                              // structure channel: deg * G_S goes to memory for A_low^T
@@ -809,37 +558,6 @@ __device__ __forceinline__ void agg_bwd_body(const acm_conv_agg_bwd_t& p, int n_
     }
     dmix1 = acm_cross_row_sum(dmix1);
     __syncthreads();                              // every wave is done with wlds / hlds
-    if (LDSACC) {
-        // the wave's dW already sits in its slab; append the head parameters, then sum the slabs in a fixed order
-        float* slab = slabs + wv * SLAB;
-        if (g == 0) {
-#pragma unroll
-            for (int c = 0; c < K; ++c)
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const int col = m + 16 * i;
-                    slab[3 * FP * 64 + (0 * K + c) * 64 + col] = dv[c][i];
-                    slab[3 * FP * 64 + (1 * K + c) * 64 + col] = dgam[c][i];
-                    slab[3 * FP * 64 + (2 * K + c) * 64 + col] = dbet[c][i];
-                }
-            if (m < K * K) slab[3 * FP * 64 + 3 * K * 64 + m] = dmix1;
-        }
-        __syncthreads();
-        for (int q = threadIdx.x; q < npg; q += BW * 64) {
-            int src;                              // position of flat parameter q in the padded slab layout (F == 64 here)
-            if (q < 3 * f_in * 64) {
-                const int c = q / (f_in * 64), rem = q - c * f_in * 64, f = rem >> 6, col = rem & 63;
-                src = (((c * 4 + (col >> 4)) * 32 + (f >> 2) * 16 + (col & 15)) << 2) + (f & 3);
-            } else {
-                src = 3 * FP * 64 + (q - 3 * f_in * 64);
-            }
-            const float* sp = slabs + src;
-            float v = ((sp[0] + sp[SLAB]) + (sp[2 * SLAB] + sp[3 * SLAB])) + ((sp[4 * SLAB] + sp[5 * SLAB]) + (sp[6 * SLAB] + sp[7 * SLAB]));
-            v += (sp[8 * SLAB] + sp[9 * SLAB]) + (sp[10 * SLAB] + sp[11 * SLAB]);
-            partial[((long)(q >> 5) * gridDim.x + blockIdx.x) * 32 + (q & 31)] = v;
-        }
-        return;
-    }
     float* slab = lds + wv * npg;
 #pragma unroll
     for (int c = 0; c < 3; ++c)
@@ -848,7 +566,7 @@ __device__ __forceinline__ void agg_bwd_body(const acm_conv_agg_bwd_t& p, int n_
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int f = 4 * g + r, col = 16 * t + m;
-                if (f < f_in && col < F) slab[(c * f_in + f) * F + col] = acc[LDSACC ? 0 : c][LDSACC ? 0 : t][r];
+                if (f < f_in && col < F) slab[(c * f_in + f) * F + col] = acc[c][t][r];
             }
     if (g == 0) {
         const int base = 3 * f_in * F;
@@ -876,13 +594,7 @@ __device__ __forceinline__ void agg_bwd_body(const acm_conv_agg_bwd_t& p, int n_
 
 template <int FP, int K, bool FULL>
 __global__ __launch_bounds__(256, 2) void agg_bwd_kernel(acm_conv_agg_bwd_t p, int n_rows, float* __restrict__ partial) {
-    agg_bwd_body<FP, K, FULL, false>(p, n_rows, partial, nullptr);
-}
-// sixteen waves: twelve for the backward, four for the next step's gather; one workgroup (4 waves/SIMD) per CU
-__global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4, 4))) void agg_bwd_gather_kernel(acm_conv_agg_bwd_t p, int n_rows,
-                                                                                                  float* __restrict__ partial,
-                                                                                                  GatherRole gr) {
-    agg_bwd_body<8, 3, true, true>(p, n_rows, partial, &gr);
+    agg_bwd_body<FP, K, FULL>(p, n_rows, partial);
 }
 int agg_pad(int f_in) { return f_in <= 4 ? 4 : (f_in <= 8 ? 8 : 16); }
 
@@ -891,11 +603,7 @@ int agg_pad(int f_in) { return f_in <= 4 ? 4 : (f_in <= 8 ? 8 : 16); }
 // with the structure channel (185-191 VGPRs) two fit.
 int agg_bwd_blocks(int64_t n_rows, int n_channels, size_t lds_bytes) {
     int64_t nb = (n_rows + 15) / 16;
-    int cap = (n_channels == 3 && 3 * lds_bytes <= 160 * 1024) ? 768 : 512;     // registers and LDS of three
-    if (const char* env = getenv("ACM_AGG_BWD_BLOCKS")) {                        // tuning / overlap experiments
-        const int v = atoi(env);
-        if (v >= 1 && v <= cap) cap = v;
-    }
+    const int cap = (n_channels == 3 && 3 * lds_bytes <= 160 * 1024) ? 768 : 512;     // registers and LDS of three
     if (nb > cap) nb = cap;
     if (nb < 1) nb = 1;
     return (int)nb;
@@ -937,7 +645,6 @@ StreamView stream_view(const AcmStreams* t) {
     sv.ids_bytes = (unsigned)((t->total_steps + ACM_STREAM_PAD_STEPS) * 512);
     sv.slots_bytes = (unsigned)(t->n_slots * 32);
     sv.n_waves = t->n_waves;
-    sv.probe = 0;
     return sv;
 }
 
@@ -982,30 +689,10 @@ extern "C" int acm_conv_agg_fwd(const acm_csr_t* a, const acm_conv_agg_fwd_t* p,
     // (0) fused form: gather + epilogue in one kernel (long rows included)
     if (!p->agg_given) {
         const double avg = (double)a->nnz / (double)(a->n_rows > 0 ? a->n_rows : 1);
-        const bool fused_off = getenv("ACM_AGG_UNFUSED") != nullptr;      // read per call: tests switch forms
-        const bool fused = !fused_off && p->n_channels == 3 && p->f_pad <= 8 && avg > 12.0 && avg <= 160.0 &&
+        const bool fused = acm_tuning().agg_fused != 0 && p->n_channels == 3 && p->f_pad <= 8 && avg > 12.0 && avg <= 160.0 &&
                            ((uintptr_t)p->xg) % 16 == 0 && (p->ld_xg * sizeof(float)) % 16 == 0 &&
                            (a->n_long == 0 || a->long_index != nullptr);
         if (fused) {
-            const AcmStreams* t = a->streams;
-            const int64_t table_bytes = a->n_cols * 32;
-            if (p->use_streams && t && p->f_pad == 8 && p->ld_xg == 8 && a->vals == nullptr && table_bytes < (int64_t)0xFFFFFFE0u &&
-                getenv("ACM_AGG_NO_STREAM") == nullptr) {
-                StreamView sv = stream_view(t);
-                sv.probe = getenv("ACM_STREAM_PROBE") ? atoi(getenv("ACM_STREAM_PROBE")) : 0;
-                const int grid = t->n_waves / 4;
-                // (the arrival counters reset themselves -- the last piece of a row stores 0 -- and start at zero; a
-                // hipMemsetAsync ahead of every launch would cost two fill kernels, ~10 us in a replayed graph)
-                const bool nt = getenv("ACM_AGG_NT") != nullptr;
-                if (p->f_out == 64 && nt)
-                    hipLaunchKernelGGL((agg_stream_kernel<true, true>), dim3(grid), dim3(256), 0, s, *p, sv, (unsigned)table_bytes);
-                else if (p->f_out == 64)
-                    hipLaunchKernelGGL((agg_stream_kernel<true, false>), dim3(grid), dim3(256), 0, s, *p, sv, (unsigned)table_bytes);
-                else
-                    hipLaunchKernelGGL((agg_stream_kernel<false, false>), dim3(grid), dim3(256), 0, s, *p, sv, (unsigned)table_bytes);
-                ACM_CHECK_HIP(hipGetLastError());
-                return next_projection(a, p, stream);
-            }
             const CsrView cv = acm_view(a);
             int grid = (int)((a->n_items + 15) / 16);
             // every block stages the weights and head parameters (8.4 KB) before it starts: 12 blocks per CU keep that
@@ -1015,22 +702,12 @@ extern "C" int acm_conv_agg_fwd(const acm_csr_t* a, const acm_conv_agg_fwd_t* p,
             if (p->f_pad == 4) {
                 if (full) hipLaunchKernelGGL((agg_fused_kernel<4, true>), dim3(grid), dim3(256), 0, s, *p, cv);
                 else hipLaunchKernelGGL((agg_fused_kernel<4, false>), dim3(grid), dim3(256), 0, s, *p, cv);
-            } else {
-                const bool pair_lanes = getenv("ACM_AGG_NO_PAIR") == nullptr;
-                if (pair_lanes && full && p->next_f > 0 && getenv("ACM_AGG_NO_NEXT") == nullptr) {
-                    hipLaunchKernelGGL(agg_fused_pair_next_kernel, dim3(grid), dim3(256), 0, s, *p, cv);
-                    next_done = true;
-                } else if (pair_lanes && full)
-                    hipLaunchKernelGGL((agg_fused_pair_kernel<true>), dim3(grid), dim3(256), 0, s, *p, cv);
-                else if (pair_lanes)
-                    hipLaunchKernelGGL((agg_fused_pair_kernel<false>), dim3(grid), dim3(256), 0, s, *p, cv);
-                else if (full)
-                    hipLaunchKernelGGL((agg_fused_kernel<8, true>), dim3(grid), dim3(256), 0, s, *p, cv);
-                else
-                    hipLaunchKernelGGL((agg_fused_kernel<8, false>), dim3(grid), dim3(256), 0, s, *p, cv);
+            } else {                                  // 32-byte rows: two lanes per neighbour
+                if (full) hipLaunchKernelGGL((agg_fused_pair_kernel<true>), dim3(grid), dim3(256), 0, s, *p, cv);
+                else hipLaunchKernelGGL((agg_fused_pair_kernel<false>), dim3(grid), dim3(256), 0, s, *p, cv);
             }
             ACM_CHECK_HIP(hipGetLastError());
-            return next_done ? ACM_OK : next_projection(a, p, stream);
+            return next_projection(a, p, stream);
         }
     }
     // (1) P = A_low X  -> p->agg  (also the tensor saved for the backward); row_scale for a pattern-only a_low
@@ -1038,7 +715,7 @@ extern "C" int acm_conv_agg_fwd(const acm_csr_t* a, const acm_conv_agg_fwd_t* p,
     // three channels: the long rows' partial sums stay in the workspace and the epilogue kernel adds them (one launch
     // less); with the structure channel the second gather reuses the workspace, so the fix-up runs right away
     // (the sixteen-rows-per-wave stage of acm_conv_agg16.hip reads finished rows of P: the fix-up runs right away there)
-    const bool epi16 = p->n_channels == 3 && p->f_pad == 8 && p->f_out == 64 && getenv("ACM_EPI16_OFF") == nullptr;
+    const bool epi16 = p->n_channels == 3 && p->f_pad == 8 && p->f_out == 64 && (acm_tuning().rows16 & ACM_ROWS16_EPI) != 0;
     bool defer = !p->agg_given && p->n_channels == 3 && a->n_long > 0 && a->long_index != nullptr && !epi16;
     if (!p->agg_given) {
         st = acm_spmm_internal(a, p->xg, p->ld_xg, p->f_pad, p->agg, p->ld_agg, &o, workspace, workspace_bytes, stream, &defer);
@@ -1058,14 +735,7 @@ extern "C" int acm_conv_agg_fwd(const acm_csr_t* a, const acm_conv_agg_fwd_t* p,
         if (st > 0) return st;
     }
     int grid = (int)((a->n_rows + 15) / 16);
-    {
-        int cap = 2048;
-        if (const char* env = getenv("ACM_AGG_EPI_BLOCKS")) {
-            const int v = atoi(env);
-            if (v >= 1) cap = v;
-        }
-        if (grid > cap) grid = cap;
-    }
+    if (grid > 2048) grid = 2048;
     const CsrView cv = acm_view(a);
 #define ACM_EPI(FPv)                                                                                           \
     do {                                                                                                       \
@@ -1144,7 +814,6 @@ extern "C" int acm_conv_agg_bwd(int64_t n_rows, const acm_conv_agg_bwd_t* p, voi
         gr.row_scale = p->next_row_scale;
         gr.agg = p->next_agg;
         gr.ld_agg = (long)p->ld_next_agg;
-        gr.roles = getenv("ACM_AGG_BWD_ROLES") ? atoi(getenv("ACM_AGG_BWD_ROLES")) : 3;
         ACM_REQUIRE(t->n_waves / gw <= agg_bwd_blocks(n_rows, 3, 0), ACM_EUNSUPPORTED,
                     "acm_conv_agg_bwd: %d stream waves for %lld rows (the workspace holds one slab per 16 rows)", t->n_waves, (long long)n_rows);
         nblk = t->n_waves / gw;
@@ -1157,16 +826,9 @@ extern "C" int acm_conv_agg_bwd(int64_t n_rows, const acm_conv_agg_bwd_t* p, voi
                                                   {partial, nb16, 32, off2, n2, p->proj_d_w, n2 > 0 ? n2 : 1, 0, 0, 0, nb16 * 32, 0}};
                 return acm_reduce_emit(p->defer, segs, n2 > 0 ? 2 : 1, s);
             }
-            ACM_REQUIRE(!p->proj_dz, ACM_EUNSUPPORTED, "acm_conv_agg_bwd: proj_dz needs the sixteen-rows-per-wave kernel");
         }
-        // weights + head parameters + the groups' scratch + twelve per-wave slabs (dW accumulates there): 114 KB of the CU's 160
-        const size_t lds_g = ((size_t)3 * 8 * 64 + 3 * K * 64 + 12 * 4 * 2 * 8 + (size_t)12 * (3 * 8 * 64 + 3 * K * 64 + 16)) * sizeof(float);
-        ACM_REQUIRE(lds_g <= 160 * 1024, ACM_EUNSUPPORTED, "acm_conv_agg_bwd: %zu B of LDS needed", lds_g);
-        ACM_CHECK_HIP(hipFuncSetAttribute((const void*)agg_bwd_gather_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_g));
-        hipLaunchKernelGGL(agg_bwd_gather_kernel, dim3(nblk), dim3(1024), lds_g, s, *p, (int)n_rows, partial, gr);
-        ACM_CHECK_HIP(hipGetLastError());
-        const acm_reduce_seg_t seg = {partial, nblk, 32, 0, npg, p->d_params, npg, 0, 0, 0, nblk * 32, 0};
-        return acm_reduce_emit(p->defer, &seg, 1, s);
+        ACM_REQUIRE(false, ACM_EUNSUPPORTED, "acm_conv_agg_bwd: the carried gather (next_agg) needs the sixteen-rows-per-wave backward "
+                    "(head_stats, the forward's `out` behind a fused ReLU or no post-op at all, acm_tuning_t.rows16 bit 2)");
     }
     if (!p->next_agg) {                           // sixteen rows per wave, transposed matrix-core layout (acm_conv_agg16.hip)
         const int nb16 = acm_agg_bwd16(p, n_rows, partial, nblk, s, nullptr, 0);

@@ -252,11 +252,6 @@ template <bool LN, bool NEXT>
 __global__ __launch_bounds__(256) void agg_epi16_kernel(acm_conv_agg_fwd_t p, int n_rows) {
     epi16_body<LN, NEXT>(p, n_rows);
 }
-// the same capped to the registers of four waves per SIMD (a handful of spilled registers with LayerNorm)
-template <bool LN, bool NEXT>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void agg_epi16_cap4_kernel(acm_conv_agg_fwd_t p, int n_rows) {
-    epi16_body<LN, NEXT>(p, n_rows);
-}
 
 // ---------------------------------------------------------------- backward (K3a) in the same layout
 // Per wave step (16 rows): the projections again on the matrix pipe (H is not stored: 768 B per row), the row's head
@@ -342,7 +337,7 @@ __device__ __forceinline__ void bwd16_body(const acm_conv_agg_bwd_t& p, int n_ro
     for (int q = 0; q < 9; ++q) mixm[q] = p.att_mix[q];
     __syncthreads();
     if (GATHER && wv >= 4) {                      // the gather role; then the same two barriers as the backward's end phase
-        if (gr->roles & 2) stream_gather_role(*gr, __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (wv - 4)));
+        stream_gather_role(*gr, __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (wv - 4)));
         __syncthreads();
         __syncthreads();
         return;
@@ -370,7 +365,7 @@ __device__ __forceinline__ void bwd16_body(const acm_conv_agg_bwd_t& p, int n_ro
 #pragma unroll
     for (int q = 0; q < 9; ++q) dmix[q] = 0.f;
 
-    int base = (GATHER && !(gr->roles & 1)) ? n_rows : wave * 16;
+    int base = wave * 16;
     float nPa = 0.f, nPb = 0.f, nxa = 0.f, nxb = 0.f;
     f32x4 ngo[4], nou[4], nst[3];
     // the operands of the projections (P, x: 64 B per row) are requested one step ahead; grad_out / out (512 B per row), the
@@ -610,22 +605,16 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 // configuration is not the one this kernel is written for (the caller then runs agg_epilogue_kernel), or an error.
 int acm_agg_epi16(const acm_conv_agg_fwd_t* p, int64_t n_rows, bool* next_done, hipStream_t s) {
     *next_done = false;
-    if (p->n_channels != 3 || p->f_pad != 8 || p->f_out != 64 || getenv("ACM_EPI16_OFF") != nullptr) return -1;
+    if (p->n_channels != 3 || p->f_pad != 8 || p->f_out != 64 || !(acm_tuning().rows16 & ACM_ROWS16_EPI)) return -1;
     int64_t ld_max = 64;
     for (int64_t ld : {p->ld_agg, p->ld_xs, p->ld_out, p->ld_head_stats, p->ld_post_scale, p->ld_agg_copy, p->ld_xs_copy})
         ld_max = ld > ld_max ? ld : ld_max;
     if (n_rows * ld_max >= (int64_t)INT32_MAX) return -1;                  // 32-bit element offsets
     if ((((uintptr_t)p->out) % 16) != 0 || (p->ld_out % 4) != 0) return -1;
     if (p->post_scale && ((((uintptr_t)p->post_scale) % 16) != 0 || (p->ld_post_scale % 4) != 0)) return -1;
-    const bool next = p->next_f > 0 && getenv("ACM_AGG_NO_NEXT") == nullptr;
+    const bool next = p->next_f > 0;
     int grid = (int)((n_rows + 63) / 64);
-    int cap = 1024;                                  // four workgroups (sixteen waves) per CU
-    if (const char* env = getenv("ACM_EPI16_BLOCKS")) {
-        const int v = atoi(env);
-        if (v >= 1) cap = v;
-    }
-    if (grid > cap) grid = cap;
-    const bool cap4 = getenv("ACM_EPI16_CAP4") != nullptr;
+    if (grid > 1024) grid = 1024;                    // four workgroups (sixteen waves) per CU
 #define ACM_E16(KERNEL)                                                                                              \
     do {                                                                                                             \
         if (p->layernorm) {                                                                                          \
@@ -636,8 +625,7 @@ int acm_agg_epi16(const acm_conv_agg_fwd_t* p, int64_t n_rows, bool* next_done, 
             else hipLaunchKernelGGL((KERNEL<false, false>), dim3(grid), dim3(256), 0, s, *p, (int)n_rows);           \
         }                                                                                                            \
     } while (0)
-    if (cap4) ACM_E16(agg_epi16_cap4_kernel);
-    else ACM_E16(agg_epi16_kernel);
+    ACM_E16(agg_epi16_kernel);
 #undef ACM_E16
     ACM_CHECK_HIP(hipGetLastError());
     *next_done = next;
@@ -649,7 +637,7 @@ int acm_agg_epi16(const acm_conv_agg_fwd_t* p, int64_t n_rows, bool* next_done, 
 // npg + 64 * 3 * proj_f entries per block (acm_conv_agg_bwd_t.proj_*: the following layer's weight gradient behind d_params).
 int acm_agg_bwd16(const acm_conv_agg_bwd_t* p, int64_t n_rows, float* partial, int max_blocks, hipStream_t s, const GatherRole* gr,
                   int gather_blocks) {
-    if (p->n_channels != 3 || p->f_pad != 8 || p->f_out != 64 || !p->head_stats || getenv("ACM_BWD16_OFF") != nullptr) return 0;
+    if (p->n_channels != 3 || p->f_pad != 8 || p->f_out != 64 || !p->head_stats || !(acm_tuning().rows16 & ACM_ROWS16_BWD)) return 0;
     const bool out_mask = p->out != nullptr && p->post_relu && !p->post_scale;
     const bool no_post = !p->post_relu && !p->post_scale && !(p->post_drop.p > 0.f);
     if (!out_mask && !no_post) return 0;
@@ -664,10 +652,6 @@ int acm_agg_bwd16(const acm_conv_agg_bwd_t* p, int64_t n_rows, float* partial, i
     if (!out_mask && !proj) q.out = nullptr;
     int grid = (int)((n_rows + 63) / 64);
     int cap = 512;
-    if (const char* env = getenv("ACM_BWD16_BLOCKS")) {
-        const int v = atoi(env);
-        if (v >= 1) cap = v;
-    }
     if (cap > max_blocks) cap = max_blocks;
     if (grid > cap) grid = cap;
     if (gr) {                                         // one workgroup of eight waves per four stream waves

@@ -261,7 +261,7 @@ __global__ __launch_bounds__(256) void bwd_local16_kernel(acm_conv_bwd_local_t p
 // Returns the number of blocks launched (> 0), 0 when the configuration is not this kernel's (the caller runs the older
 // kernels), or a negative acm_status_t.  partial: max_blocks x (3 * 3 * 64 + 9) floats.
 int acm_bwd_local16(const acm_conv_bwd_local_t* p, int64_t n_rows, float* partial, int max_blocks, hipStream_t s) {
-    if (p->f_out != 64 || p->n_channels != 3 || p->post_scale || n_rows < 1 || getenv("ACM_LOCAL16_OFF") != nullptr) return 0;
+    if (p->f_out != 64 || p->n_channels != 3 || p->post_scale || n_rows < 1 || !(acm_tuning().rows16 & ACM_ROWS16_LOCAL)) return 0;
     for (const void* q : {(const void*)p->pre, (const void*)p->s_mlp, (const void*)p->grad_out, (const void*)p->g_low,
                           (const void*)p->g_high, (const void*)p->g_mlp})
         if (((uintptr_t)q) % 16 != 0) return 0;
@@ -274,10 +274,6 @@ int acm_bwd_local16(const acm_conv_bwd_local_t* p, int64_t n_rows, float* partia
     int grid = (int)((n_rows + 63) / 64);
     if (grid > 512) grid = 512;                    // two resident workgroups per CU (220 registers); fewer slabs for the flush
     if (grid > max_blocks) grid = max_blocks;
-    if (const char* env = getenv("ACM_LOCAL16_BLOCKS")) {
-        const int v = atoi(env);
-        if (v >= 1 && v <= max_blocks) grid = v;
-    }
     if (p->layernorm) hipLaunchKernelGGL((bwd_local16_kernel<true>), dim3(grid), dim3(256), 0, s, *p, (int)n_rows, partial);
     else hipLaunchKernelGGL((bwd_local16_kernel<false>), dim3(grid), dim3(256), 0, s, *p, (int)n_rows, partial);
     if (hipGetLastError() != hipSuccess) return -ACM_EHIP;

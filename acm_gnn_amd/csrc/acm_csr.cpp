@@ -10,6 +10,7 @@
 #include <functional>
 #include <new>
 #include <queue>
+#include <string>
 #include <utility>
 #include <vector>
 
@@ -26,6 +27,81 @@ void acm_set_error(const char* fmt, ...) {
 
 extern "C" int acm_version(void) { return ACM_ABI_VERSION; }
 extern "C" const char* acm_last_error(void) { return g_err; }
+
+// ---------------------------------------------------------------- tuning record
+namespace {
+const acm_tuning_t kTuningDefaults = {0, 0, -1, 7, 1, 7, {0}};
+struct TuningField { const char* name; int32_t acm_tuning_t::*field; };
+const TuningField kTuningFields[] = {{"chunk", &acm_tuning_t::chunk},           {"wide_form", &acm_tuning_t::wide_form},
+                                     {"bwd_split", &acm_tuning_t::bwd_split},   {"rows16", &acm_tuning_t::rows16},
+                                     {"agg_fused", &acm_tuning_t::agg_fused},   {"gemm_forms", &acm_tuning_t::gemm_forms}};
+// host-side keys of the same variable (acm_gnn_amd/tuning.py reads them; listed here so that they are not "unknown")
+const char* const kHostKeys[] = {"rewrites", "implicit", "relabel", "pipeline"};
+
+const char* tuning_invalid(const acm_tuning_t& t) {
+    if (t.chunk != 0 && (t.chunk < 8 || t.chunk > 4096 || (t.chunk & (t.chunk - 1)))) return "chunk";
+    if (t.wide_form < 0 || t.wide_form > 3) return "wide_form";
+    if (t.bwd_split < -1 || t.bwd_split > 1) return "bwd_split";
+    if (t.rows16 < 0 || t.rows16 > 7) return "rows16";
+    if (t.agg_fused < 0 || t.agg_fused > 1) return "agg_fused";
+    if (t.gemm_forms < 0 || t.gemm_forms > 15) return "gemm_forms";
+    return nullptr;
+}
+
+// defaults + ACM_TUNING; a malformed variable is reported on stderr (once, at load) and the offending item ignored
+acm_tuning_t tuning_from_environment() {
+    acm_tuning_t t = kTuningDefaults;
+    const char* env = getenv("ACM_TUNING");
+    if (!env) return t;
+    std::string text(env);
+    size_t pos = 0;
+    while (pos < text.size()) {
+        size_t end = text.find(',', pos);
+        if (end == std::string::npos) end = text.size();
+        const std::string item = text.substr(pos, end - pos);
+        pos = end + 1;
+        if (item.empty()) continue;
+        const size_t eq = item.find('=');
+        const std::string key = item.substr(0, eq), val = eq == std::string::npos ? "" : item.substr(eq + 1);
+        bool known = false;
+        for (const char* h : kHostKeys) known = known || key == h;
+        for (const TuningField& f : kTuningFields) {
+            if (key != f.name) continue;
+            known = true;
+            char* stop = nullptr;
+            const long v = strtol(val.c_str(), &stop, 0);
+            acm_tuning_t probe = t;
+            probe.*(f.field) = (int32_t)v;
+            if (val.empty() || *stop || tuning_invalid(probe)) fprintf(stderr, "libacm_hip: ACM_TUNING: bad value '%s' ignored\n", item.c_str());
+            else t = probe;
+        }
+        if (!known) fprintf(stderr, "libacm_hip: ACM_TUNING: unknown key '%s' ignored\n", key.c_str());
+    }
+    return t;
+}
+const acm_tuning_t g_tuning_loaded = tuning_from_environment();      // read ONCE, when the library is loaded
+acm_tuning_t g_tuning = g_tuning_loaded;
+}  // namespace
+
+const acm_tuning_t& acm_tuning() { return g_tuning; }
+
+extern "C" int acm_tuning_get(acm_tuning_t* out) {
+    ACM_REQUIRE(out, ACM_EINVAL, "acm_tuning_get: NULL argument");
+    *out = g_tuning;
+    return ACM_OK;
+}
+
+extern "C" int acm_tuning_set(const acm_tuning_t* in) {
+    if (!in) {
+        g_tuning = g_tuning_loaded;
+        return ACM_OK;
+    }
+    const char* bad = tuning_invalid(*in);
+    ACM_REQUIRE(!bad, ACM_EINVAL, "acm_tuning_set: field '%s' out of range", bad);
+    g_tuning = *in;
+    for (int32_t& r : g_tuning.reserved) r = 0;
+    return ACM_OK;
+}
 
 namespace {
 
@@ -103,8 +179,7 @@ int finish_handle(acm_csr* a, const std::vector<int32_t>& h_indptr, int chunk) {
     // x 4 groups): long chunks mean fewer partial sums and a shorter fix-up pass, but one item must not
     // outlast the average group's whole share.  Measured optimum per graph (profiles/r01_o_chunk_sweep.txt):
     // 128 for squirrel/chameleon (<=0.4 M nnz), 256 for penn94/arxiv-year (2.5 M), 1024 for twitch-gamer (13.7 M).
-    const char* env = getenv("ACM_CHUNK");
-    const int env_chunk = env ? atoi(env) : 0;
+    const int env_chunk = acm_tuning().chunk;
     int auto_chunk = ACM_MIN_CHUNK;
     while (auto_chunk < ACM_MAX_CHUNK && 2 * (int64_t)auto_chunk <= a->nnz / ACM_GROUPS_IN_FLIGHT) auto_chunk *= 2;
     a->chunk = chunk > 0 ? chunk : (env_chunk > 0 ? env_chunk : auto_chunk);
@@ -342,10 +417,7 @@ extern "C" int acm_csr_build_streams(acm_csr_t* a, int n_waves, int lmax) {
     if (a->streams) return ACM_OK;
     ACM_REQUIRE(a->vals == nullptr, ACM_EUNSUPPORTED, "acm_csr_build_streams: pattern-only operators only");
     ACM_REQUIRE(a->n_cols < ACM_STREAM_SENTINEL, ACM_EUNSUPPORTED, "acm_csr_build_streams: %lld columns", (long long)a->n_cols);
-    if (lmax <= 0) {
-        const char* env = getenv("ACM_STREAM_LMAX");
-        lmax = env && atoi(env) > 0 ? atoi(env) : 512;
-    }
+    if (lmax <= 0) lmax = 512;
     ACM_REQUIRE(lmax % 32 == 0 && lmax <= 4096, ACM_EINVAL, "acm_csr_build_streams: lmax %d must be a multiple of 32, at most 4096", lmax);
     ACM_CHECK_HIP(hipDeviceSynchronize());
     const int64_t n = a->n_rows, nnz = a->nnz;
@@ -371,12 +443,8 @@ extern "C" int acm_csr_build_streams(acm_csr_t* a, int n_waves, int lmax) {
         lr.slot_end = (int32_t)n_slots;
         longs.push_back(lr);
     }
-    // ACM_STREAM_ORDER: "rows" keeps the items in row order and deals the slices round-robin (the walk of the CSR kernels:
-    // at any time the chip works on one window of neighbouring rows -- their outputs and row operands are neighbours in
-    // memory; on a degree-sorted graph the four rows of a slice still have similar lengths); "sorted" / default: by length
-    const char* order_env = getenv("ACM_STREAM_ORDER");
-    const bool row_order = order_env && strcmp(order_env, "rows") == 0;
-    if (!row_order) std::stable_sort(items.begin(), items.end(), [](const Item& x, const Item& y) { return x.len > y.len; });
+    // by length (row order with round-robin dealing was measured and is slower: profiles/r02_probe_roles_order.txt)
+    std::stable_sort(items.begin(), items.end(), [](const Item& x, const Item& y) { return x.len > y.len; });
     const int64_t n_items = (int64_t)items.size(), n_slices = (n_items + 3) / 4;
     std::vector<int32_t> sl_steps((size_t)n_slices);
     int64_t total_steps = 0;
@@ -389,10 +457,6 @@ extern "C" int acm_csr_build_streams(acm_csr_t* a, int n_waves, int lmax) {
     ACM_REQUIRE((total_steps + ACM_STREAM_PAD_STEPS) * 512 < (int64_t)0xFFFFFFF0u, ACM_EUNSUPPORTED,
                 "acm_csr_build_streams: %lld steps exceed 32-bit stream offsets", (long long)total_steps);
     if (n_waves <= 0) {
-        const char* env = getenv("ACM_STREAM_WAVES");
-        if (env && atoi(env) > 0) n_waves = atoi(env);
-    }
-    if (n_waves <= 0) {
         int cus = 256;
         (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, a->device);
         n_waves = cus * 4 * 5;                                       // five waves per SIMD (the kernel's occupancy)
@@ -400,20 +464,14 @@ extern "C" int acm_csr_build_streams(acm_csr_t* a, int n_waves, int lmax) {
     if ((int64_t)n_waves > n_slices) n_waves = (int)std::max<int64_t>(n_slices, 1);
     n_waves = (n_waves + 3) / 4 * 4;
     // longest slice first, each to the least loaded wave (cost = steps + the row-local stage of its four rows)
-    // cost of a slice in quarter steps: 4 per wave step + the row-local stage of its four rows (ACM_STREAM_EPI, default 1:
-    // the stage overlaps with the next step's gathers, so a wave's time is close to its step count)
-    const char* epi_env = getenv("ACM_STREAM_EPI");
-    const int64_t epi_cost = epi_env ? atoi(epi_env) : 1;
+    // cost of a slice in quarter steps: 4 per wave step + 1 per slice (descriptor + the finish of its four rows)
+    const int64_t epi_cost = 1;
     std::vector<int32_t> wave_of((size_t)n_slices);
     {
         typedef std::pair<int64_t, int32_t> Load;
         std::priority_queue<Load, std::vector<Load>, std::greater<Load>> heap;
         for (int32_t w = 0; w < n_waves; ++w) heap.push({0, w});
         for (int64_t s = 0; s < n_slices; ++s) {
-            if (row_order) {
-                wave_of[(size_t)s] = (int32_t)(s % n_waves);
-                continue;
-            }
             Load l = heap.top();
             heap.pop();
             wave_of[(size_t)s] = l.second;
@@ -421,8 +479,7 @@ extern "C" int acm_csr_build_streams(acm_csr_t* a, int n_waves, int lmax) {
             heap.push(l);
         }
     }
-    // wave-major order.  Within a wave the slices are SHUFFLED (a fixed permutation seeded by the wave's index; ACM_STREAM_ORDER=
-    // sorted keeps longest-first): long slices are gather-bound (16 steps per row-local stage, neighbours all over the
+    // wave-major order.  Within a wave the slices are SHUFFLED (a fixed permutation seeded by the wave's index): long slices are gather-bound (16 steps per row-local stage, neighbours all over the
     // table), short ones are bound by the row-local stage's VALU work; longest-first makes every wave -- the whole chip --
     // memory-bound first and VALU-bound last, so the two never overlap
     std::vector<int32_t> count((size_t)n_waves + 1, 0);
@@ -431,8 +488,7 @@ extern "C" int acm_csr_build_streams(acm_csr_t* a, int n_waves, int lmax) {
     std::vector<int32_t> pos_of((size_t)n_slices), cur(count.begin(), count.end() - 1);
     for (int64_t s = 0; s < n_slices; ++s) pos_of[(size_t)s] = cur[(size_t)wave_of[(size_t)s]]++;
     {
-        const char* ord = getenv("ACM_STREAM_ORDER");
-        if (!(ord && (strcmp(ord, "sorted") == 0 || strcmp(ord, "rows") == 0))) {
+        {
             std::vector<int32_t> slice_at((size_t)n_slices);
             for (int64_t s = 0; s < n_slices; ++s) slice_at[(size_t)pos_of[(size_t)s]] = (int32_t)s;
             for (int32_t w = 0; w < n_waves; ++w) {

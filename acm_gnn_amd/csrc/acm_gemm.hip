@@ -363,11 +363,11 @@ static int gemm_core(int transA, int transB, int64_t M, int64_t N, int64_t K, co
     if (K > 0 && !transA && !transB && plain_out && !cb && acm_gemm_bx3_nn_ok(M, N, K, A, lda))
         return acm_gemm_bx3_nn(M, N, K, A, lda, B, ldb, C, ldc, relu, a_drop, st);
     if (K > 0 && !transA && !transB && plain_out && !cb && acm_gemm_rows_nn_ok(M, N, K, B, ldb) &&
-        (a_drop || N <= 64 || getenv("ACM_GEMM_ROWS_ALWAYS")))
+        (a_drop || N <= 64 || (acm_tuning().gemm_forms & ACM_GEMM_ROWS_ALWAYS)))
         return acm_gemm_rows_nn(M, N, K, A, lda, B, ldb, C, ldc, relu, a_drop, st);
     const bool bx3_tn = K > 0 && transA && !transB && plain_out && acm_gemm_bx3_tn_ok(K, M, N);
     if (bx3_tn || (K > 0 && transA && !transB && plain_out && acm_gemm_rows_tn_ok(K, M, N, B, ldb) &&
-                   (a_drop || K >= 100000 || getenv("ACM_GEMM_ROWS_ALWAYS")))) {
+                   (a_drop || K >= 100000 || (acm_tuning().gemm_forms & ACM_GEMM_ROWS_ALWAYS)))) {
         const int blocks = bx3_tn ? acm_gemm_bx3_tn_blocks(K, M) : acm_gemm_rows_tn_blocks(K);
         const size_t need = (size_t)blocks * (size_t)M * (size_t)N * sizeof(float);
         ACM_REQUIRE(workspace && workspace_bytes >= need, ACM_ENOMEM, "acm_gemm: workspace %zu B < required %zu B", workspace_bytes, need);

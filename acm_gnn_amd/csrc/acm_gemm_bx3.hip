@@ -71,7 +71,7 @@ struct Bx3Cols {
 template <int NT, int NA>
 __global__ __launch_bounds__(512, NT <= 4 ? 4 : 2) void gemm_bx3_nn_kernel(int M, int N, int K, const float* __restrict__ A, long lda,
                                                           const float* __restrict__ B, long ldb, float* __restrict__ C, long ldc,
-                                                          int relu, acm_dropout_t drop, int vecc, int dbg, Bx3Cols cs) {
+                                                          int relu, acm_dropout_t drop, int vecc, Bx3Cols cs) {
     extern __shared__ __attribute__((aligned(16))) u32x4 Ws[];       // [part 3][tile NT][kb 4][lane 64]
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, m = lane & 15, g = lane >> 4;
     // W^T as the A operand: lane (g, i = m) of tile j, k block kb holds W[bx3_k(kb, g, e)][16 j + i], e = 0..7
@@ -121,7 +121,7 @@ __global__ __launch_bounds__(512, NT <= 4 ? 4 : 2) void gemm_bx3_nn_kernel(int M
             for (int G = 0; G < 2; ++G)
 #pragma unroll
                 for (int q = 0; q < 4; ++q)
-                    nxt[p][G][q] = (64 * G + 16 * q + 4 * g < K && !(dbg & 4)) ? *reinterpret_cast<const f32x4*>(src + 64 * G + 16 * q)
+                    nxt[p][G][q] = (64 * G + 16 * q + 4 * g < K) ? *reinterpret_cast<const f32x4*>(src + 64 * G + 16 * q)
                                                                                : (f32x4){0.f, 0.f, 0.f, 0.f};
         }
     };
@@ -161,7 +161,7 @@ __global__ __launch_bounds__(512, NT <= 4 ? 4 : 2) void gemm_bx3_nn_kernel(int M
             for (int j = 0; j < NT; ++j) acc[p][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int kb = 0; kb < 4; ++kb) {
-            if (64 * (kb >> 1) >= K || (dbg & 2)) continue;
+            if (64 * (kb >> 1) >= K) continue;
             u32x4 xh[NA], xm[NA], xl[NA];
 #pragma unroll
             for (int p = 0; p < NA; ++p) {
@@ -211,7 +211,7 @@ __global__ __launch_bounds__(512, NT <= 4 ? 4 : 2) void gemm_bx3_nn_kernel(int M
 #pragma unroll
         for (int p = 0; p < NA; ++p) {
             const int row = pan * 16 * NA + 16 * p + m;
-            if (row >= M || (dbg & 1)) continue;
+            if (row >= M) continue;
             float* dst = C + (long)row * ldc + 4 * g;
 #pragma unroll
             for (int j = 0; j < NT; ++j) {
@@ -256,7 +256,7 @@ __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(
 template <int NT>
 __global__ __launch_bounds__(512, 2) void gemm_bx3_tn_kernel(int n_rows, int Ktot, int N, const float* __restrict__ Xall, long ldx,
                                                              const float* __restrict__ Dz, long lddz, float* __restrict__ slabs,
-                                                             int rows_per_block, acm_dropout_t drop, int dbg) {
+                                                             int rows_per_block, acm_dropout_t drop) {
     extern __shared__ __attribute__((aligned(16))) unsigned Tl[];    // [group 2][part 3][128 + 16 NT columns][TS]
     constexpr int COLS = 128 + 16 * NT, BUF = 3 * COLS * TS, ZT = (64 * NT + 255) / 256;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, m = lane & 15, g = lane >> 4;
@@ -287,15 +287,6 @@ __global__ __launch_bounds__(512, 2) void gemm_bx3_tn_kernel(int n_rows, int Kto
         zoff[u] = (unsigned)(8 * (zok[u] ? zrg : 0)) * (unsigned)lddz + (unsigned)(zok[u] ? zc : 0);
     }
     auto fetch = [&](int r0) {
-        if (dbg & 4) {
-#pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                xv[0][e] = xv[1][e] = 0.f;
-#pragma unroll
-                for (int u = 0; u < ZT; ++u) zv[u][e] = 0.f;
-            }
-            return;
-        }
         if (r0 + 32 <= r_end) {                    // whole slab: no row guards, uniform row bases + the lane's 32-bit offset
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
@@ -329,7 +320,6 @@ __global__ __launch_bounds__(512, 2) void gemm_bx3_tn_kernel(int n_rows, int Kto
     };
     auto park = [&](int r0) {
         u32x4 hi, md, lo;
-        if (dbg & 2) { if (xv[0][0] == 123.f && zv[0][0] == 77.f) T[tid] = 1; return; }
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
             const int t = tid + 256 * u, xc = t & 127, xrg = t >> 7;
@@ -411,12 +401,12 @@ __global__ __launch_bounds__(512, 2) void gemm_bx3_tn_kernel(int n_rows, int Kto
     // group 0 parks in even phases and feeds in odd ones, group 1 the other way round; every wave passes 2 iters + 1 barriers
     if (grp < ns) fetch(r_begin + 32 * grp);
     if (grp == 1) lds_barrier();
-    for (int i = 0; i < ((dbg & 16) ? 0 : iters); ++i) {
+    for (int i = 0; i < iters; ++i) {
         const int sl = grp + 2 * i;
         if (sl < ns) park(r_begin + 32 * sl);
         lds_barrier();
         if (sl + 2 < ns) fetch(r_begin + 32 * (sl + 2));
-        if (sl < ns && live && !(dbg & 1)) feed();
+        if (sl < ns && live) feed();
         lds_barrier();
     }
     if (grp == 0) lds_barrier();
@@ -440,7 +430,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bx3_tn_kernel(int n_rows, int Kto
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int f = 16 * (it0 + i) + 4 * g + r, col = 16 * j + m;
-                    if (f < K && col < N && !(dbg & 8)) dst[(long)f * N + col] = acc[i][j][r] + S[f * (16 * NT) + col];
+                    if (f < K && col < N) dst[(long)f * N + col] = acc[i][j][r] + S[f * (16 * NT) + col];
                 }
     }
 }
@@ -450,7 +440,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bx3_tn_kernel(int n_rows, int Kto
 // Shapes: tall X with at most 128 columns in 16-byte aligned rows (K a multiple of 4), at most 192 output columns.
 bool acm_gemm_bx3_nn_ok(int64_t M, int64_t N, int64_t K, const float* A, int64_t lda) {
     return M >= 8192 && K >= 32 && K <= 128 && K % 4 == 0 && N >= 1 && N <= 192 && lda % 4 == 0 && ((uintptr_t)A) % 16 == 0 &&
-           getenv("ACM_GEMM_BX3_OFF") == nullptr;
+           (acm_tuning().gemm_forms & ACM_GEMM_BX3) != 0;
 }
 
 // w3 != nullptr: B, w3[0], w3[1] are the three [K, f] matrices of acm_proj3 (pitch ldb each), N = 2 fb + f
@@ -470,14 +460,12 @@ static int bx3_nn_ex(int64_t M, int64_t N, int64_t K, const float* A, int64_t ld
     const int64_t npan = (M + 16 * na - 1) / (16 * na);
     int grid = (int)((npan + 7) / 8);
     if (grid > 256 * per_cu) grid = 256 * per_cu;
-    if (const char* e = getenv("ACM_GEMM_BX3_BLOCKS")) grid = atoi(e) > 0 ? atoi(e) : grid;
     const int vecc = ldc % 4 == 0 && ((uintptr_t)C) % 16 == 0;
-    const int dbg = getenv("ACM_GEMM_BX3_DBG") ? atoi(getenv("ACM_GEMM_BX3_DBG")) : 0;
 #define ACM_BX3(NTv, NAv)                                                                                                    \
     do {                                                                                                                \
         ACM_CHECK_HIP(hipFuncSetAttribute((const void*)gemm_bx3_nn_kernel<NTv, NAv>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
         hipLaunchKernelGGL((gemm_bx3_nn_kernel<NTv, NAv>), dim3(grid), dim3(512), lds, st, (int)M, (int)N, (int)K, A, (long)lda, B,  \
-                           (long)ldb, C, (long)ldc, relu, drop, vecc, dbg, cs);                                                \
+                           (long)ldb, C, (long)ldc, relu, drop, vecc, cs);                                                \
     } while (0)
     switch (ntr) {
         case 2: ACM_BX3(2, 1); break;
@@ -492,11 +480,10 @@ static int bx3_nn_ex(int64_t M, int64_t N, int64_t K, const float* A, int64_t ld
 
 // n_rows: the contraction length (rows of X and dZ); K: columns of X = rows of the output, in blocks of 128 per workgroup
 bool acm_gemm_bx3_tn_ok(int64_t n_rows, int64_t K, int64_t N) {
-    if (getenv("ACM_GEMM_BX3_OFF") != nullptr || K < 32 || N < 1 || N > 192) return false;
+    const int forms = acm_tuning().gemm_forms;
+    if (!(forms & ACM_GEMM_BX3) || K < 32 || N < 1 || N > 192) return false;
     // wide inputs: from 16 384 rows (Penn94-like: 1 161 -> 625 us).  5 k rows (Squirrel) gain 7 us of 88, 2-3 k rows nothing.
-    const char* e = getenv("ACM_GEMM_BX3_WIDE_ROWS");
-    const int64_t wide_rows = e && atoll(e) > 0 ? atoll(e) : 16384;
-    return K <= 128 ? n_rows >= 8192 : (n_rows >= wide_rows && getenv("ACM_GEMM_BX3_WIDE_OFF") == nullptr);
+    return K <= 128 ? n_rows >= 8192 : (n_rows >= 16384 && (forms & ACM_GEMM_BX3_WIDE) != 0);
 }
 // row ranges (one slab of the output per range): enough workgroups for the chip, at least four 32-row slabs each
 int acm_gemm_bx3_tn_blocks(int64_t n_rows, int64_t K) {
@@ -517,12 +504,11 @@ int acm_gemm_bx3_tn(int64_t n_rows, int64_t K, int64_t N, const float* X, int64_
     int64_t rpb = (n_rows + blocks - 1) / blocks;
     rpb = (rpb + 31) / 32 * 32;
     const size_t lds = (size_t)2 * 3 * (128 + 16 * ntr) * 20 * sizeof(unsigned);
-    const int dbg = getenv("ACM_GEMM_BX3_DBG") ? atoi(getenv("ACM_GEMM_BX3_DBG")) : 0;
 #define ACM_BX3T(NTv)                                                                                                   \
     do {                                                                                                                \
         ACM_CHECK_HIP(hipFuncSetAttribute((const void*)gemm_bx3_tn_kernel<NTv>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
         hipLaunchKernelGGL((gemm_bx3_tn_kernel<NTv>), dim3(blocks, (unsigned)((K + 127) / 128)), dim3(512), lds, st, (int)n_rows, (int)K, (int)N, X,  \
-                           (long)ldx, Dz, (long)lddz, slabs, (int)rpb, drop, dbg);                                        \
+                           (long)ldx, Dz, (long)lddz, slabs, (int)rpb, drop);                                        \
     } while (0)
     switch (ntr) {
         case 2: ACM_BX3T(2); break;

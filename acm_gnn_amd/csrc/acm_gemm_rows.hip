@@ -320,7 +320,7 @@ static int rows_vecb(int64_t N, const float* B, int64_t ldb) { return N % 4 == 0
 
 bool acm_gemm_rows_nn_ok(int64_t M, int64_t N, int64_t K, const float* B, int64_t ldb) {
     (void)B, (void)ldb;
-    return M >= 4096 && K >= 16 && K <= 4096 && rows_shape_ok(N) && getenv("ACM_GEMM_ROWS_OFF") == nullptr;
+    return M >= 4096 && K >= 16 && K <= 4096 && rows_shape_ok(N) && (acm_tuning().gemm_forms & (ACM_GEMM_ROWS | ACM_GEMM_ROWS_ALWAYS)) != 0;
 }
 
 int acm_gemm_rows_nn(int64_t M, int64_t N, int64_t K, const float* A, int64_t lda, const float* B, int64_t ldb, float* C,
@@ -330,7 +330,7 @@ int acm_gemm_rows_nn(int64_t M, int64_t N, int64_t K, const float* A, int64_t ld
     const int nt = (int)((N + 15) / 16);
     int grid = (int)((M + RBM - 1) / RBM);
     const int ntr = nt <= 4 ? nt : (nt <= 6 ? 6 : (nt <= 8 ? 8 : (nt <= 10 ? 10 : 12)));      // the instantiated tile counts
-    if (K <= 128 && getenv("ACM_GEMM_WRES_OFF") == nullptr) {          // B resident, persistent workgroups
+    if (K <= 128) {          // B resident, persistent workgroups
         const int kp = (int)((K + 63) / 64 * 64);
         const size_t lds_w = ((size_t)kp * (((ntr * 16 + 31) / 32) * 32 + 16) + (size_t)kp * (RBM + 17)) * sizeof(float);
         const int blocks_per_cu = lds_w <= 48 * 1024 ? 3 : (lds_w <= 78 * 1024 ? 2 : 1);
@@ -379,7 +379,7 @@ int acm_gemm_rows_nn(int64_t M, int64_t N, int64_t K, const float* A, int64_t ld
 
 bool acm_gemm_rows_tn_ok(int64_t n_rows, int64_t K, int64_t N, const float* Dz, int64_t lddz) {
     (void)Dz, (void)lddz;
-    return n_rows >= 8192 && K >= 16 && K <= 128 && rows_shape_ok(N) && getenv("ACM_GEMM_ROWS_OFF") == nullptr;
+    return n_rows >= 8192 && K >= 16 && K <= 128 && rows_shape_ok(N) && (acm_tuning().gemm_forms & (ACM_GEMM_ROWS | ACM_GEMM_ROWS_ALWAYS)) != 0;
 }
 int acm_gemm_rows_tn_blocks(int64_t n_rows) {
     int64_t nb = (n_rows + 4 * RBK - 1) / (4 * RBK);          // at least four slabs per workgroup

@@ -18,7 +18,6 @@ struct GatherRole {
     const float* row_scale;
     float* agg;
     long ld_agg;
-    int roles;               // 3: both; 1: backward only, 2: gather only (ACM_AGG_BWD_ROLES: measurements)
 };
 
 static __device__ __forceinline__ void stream_gather_role(const GatherRole& gr, const int W) {

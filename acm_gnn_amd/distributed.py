@@ -26,12 +26,11 @@ this module has no reference counterpart; its contract is "N-rank result ==
 replaced by a test double, with two ranks on one GPU, and by construction on RCCL.
 """
 import ctypes as C
-import os
 
 import numpy as np
 import torch
 
-from . import _lib
+from . import _lib, tuning
 from .graph import CsrGraph, FilterOperators, as_implicit, implicit_form, relabel_by_degree
 
 # Row-local work of a training step expressed in "edges per row": on the twitch-shaped graph the per-row kernels
@@ -252,7 +251,7 @@ def make_sharded_operators_from_rows(indptr, indices, vals, deg_rows, plan, rank
     form = _form                                       # (make_sharded_operators has decided already)
     if isinstance(form, str):
         form = None
-        if os.environ.get("ACM_IMPLICIT", "1") != "0":
+        if tuning.HOST.implicit:
             form = pattern_form_of_rows(ip, indices, vals, b, plan.n_global, group)
     if form is not None:
         ipp, ixp, s = form
@@ -298,7 +297,7 @@ def make_sharded_operators(low_csr, deg, device, group=None, with_structure=Fals
     loc = low_csr[b:e].tocsr()
     loc.sort_indices()
     form = None
-    if os.environ.get("ACM_IMPLICIT", "1") != "0":
+    if tuning.HOST.implicit:
         form = pattern_form_of_rows(loc.indptr, loc.indices, loc.data, b, plan.n_global, group)
     t_rows = None
     if form is None:

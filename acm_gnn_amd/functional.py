@@ -6,12 +6,11 @@ torch stream.  There is deliberately no eager/torch fallback: a CPU tensor or a
 missing library is an error.
 """
 import ctypes as C
-import os
 import threading
 
 import torch
 
-from . import _lib
+from . import _lib, tuning
 from .graph import CsrGraph, FilterOperators, SparseFeatures, _device_ctx, _require_cuda, _stream
 
 _F32 = torch.float32
@@ -309,22 +308,13 @@ class InputPipeline:
         self.next_table_ready = False
         self.next_agg_ready = False
         self.adopted = False             # set by the forward that took P from this pipeline (and left its copies in ``saved``)
-        # ACM_PIPE_SIDE_STREAM=1: the table of the next step is drawn on a SIDE stream as soon as the first layer's forward
-        # kernel has read this step's -- beside the output layer's halo all-gathers and gathers instead of between the
-        # forward and the backward; the backward that carries the gather joins it.  Off by default: on one device (also as
-        # a single-rank RCCL run) the fork / join costs more than the 9 us it hides (0.276 -> 0.293 ms per captured step,
-        # DESIGN.md section 9b); whether the halo latency of a real 8-rank run pays for it is for that run to tell.
-        self._side = None
-        if x.device.type == "cuda" and os.environ.get("ACM_PIPE_SIDE_STREAM", "0") == "1":
-            self._side = torch.cuda.Stream(device=x.device)
-        self._join_pending = False
 
     @staticmethod
     def eligible(model, ops, x):
         """Conditions under which train.TrainStep pipelines: the twitch-class configuration -- a dense input of 5..8
         features into a three-channel ACM layer of width 64, one device, pattern-only operator, counter-based dropout."""
         from .graph import FilterOperators
-        if os.environ.get("ACM_PIPELINE", "1") == "0" or not isinstance(ops, FilterOperators) or not isinstance(x, torch.Tensor):
+        if tuning.HOST.pipeline <= 0 or not isinstance(ops, FilterOperators) or not isinstance(x, torch.Tensor):
             return False
         if getattr(model, "model_type", None) not in ("acmgcn", "acmgcnp") or getattr(model, "structure_info", 0):
             return False
@@ -344,12 +334,12 @@ class InputPipeline:
         if ops.sharded:                          # equal blocks + the replicated input: the table is drawn locally (no halo)
             xf = ops.x_full
             if (not ops.uniform or xf is None or xf.dtype != _F32 or xf.dim() != 2 or xf.shape != (ops.low.n_cols, f_in)
-                    or xf.device != x.device or xf.requires_grad or os.environ.get("ACM_PIPELINE_SHARDED", "1") == "0"):
+                    or xf.device != x.device or xf.requires_grad):
                 return False
         if x.dtype != _F32 or x.device != l0.weight_low.device or x.requires_grad:
             return False
         n, nnz = ops.low.n_rows, ops.low.nnz
-        min_rows = int(os.environ.get("ACM_PIPELINE_MIN_ROWS", 16 * 512))          # below: launch-bound, nothing to hide
+        min_rows = tuning.HOST.pipeline                                             # below (8192): launch-bound, nothing to hide
         if n != x.shape[0] or n < max(min_rows, 32) or not 12.0 * n < nnz <= 160.0 * n:    # the regime of the fused forward
             return False
         if x.device.type == "cuda" and torch.cuda.is_current_stream_capturing():
@@ -386,7 +376,6 @@ class InputPipeline:
                 or self.state.host_steps != self._host_steps)
 
     def prime(self):
-        self.join()
         self._drop_into(self.filled[0], 0)
         spmm(self.ops.low, self.filled[0], out=self.filled[1], row_scale=self.ops.row_scale)
         self.primed = True
@@ -394,38 +383,22 @@ class InputPipeline:
         self._host_steps = self.state.host_steps
         self.next_table_ready = self.next_agg_ready = self.adopted = False
 
-    def make_next(self, early=False):
+    def make_next(self):
         """Between the forward and the backward: the next step's dropped input replaces this step's -- only if the forward
         took this step's from the pipeline and left its copies in ``saved`` (``adopted``); a forward that went another way
-        (an environment switch, another path of the layer) may have saved the table itself for its backward.
-        ``early``: the call of the first layer's forward itself, right behind its kernel -- taken only with a side stream
-        (the table is then drawn beside the rest of the forward; join() before its reader)."""
+        (a tuning switch, another path of the layer) may have saved the table itself for its backward.  (Drawing the
+        table on a side stream right behind the first layer's forward was built and measured slower on one device:
+        DESIGN.md section 9b.)"""
         if not self.adopted:
             return False
-        if self.next_table_ready:
-            return True
-        if early and self._side is None:
-            return False
-        if self._side is not None:
-            self._side.wait_stream(torch.cuda.current_stream(self.x.device))
-            with torch.cuda.stream(self._side):
-                self._drop_into(self.filled[0], 1)
-            self._join_pending = True
-        else:
+        if not self.next_table_ready:
             self._drop_into(self.filled[0], 1)
-        self.next_table_ready = True
+            self.next_table_ready = True
         return True
-
-    def join(self):
-        """The current stream waits for the side stream's table (no-op without one)."""
-        if self._join_pending:
-            torch.cuda.current_stream(self.x.device).wait_stream(self._side)
-            self._join_pending = False
 
     def end_step(self):
         """After the optimizer step (which advanced the counter).  If the layer's backward did not carry the gather (it
         fell back to another path), ``filled`` is stale: prime() again before the next forward."""
-        self.join()
         if not (self.next_table_ready and self.next_agg_ready):
             self.primed = False
         self.next_table_ready = self.next_agg_ready = self.adopted = False
@@ -437,10 +410,9 @@ def _next_proj_request(call, f, dev, row_local_only=False):
     Default: only where the row-local stage runs as its own kernel (``row_local_only``: P = A_low X is given -- the input
     pipeline, evaluation passes -- and the sixteen-rows-per-wave kernel of acm_conv_agg16.hip carries the projection for
     ~6 us against the ~20 us of a separate acm_proj_fwd launch); inside the fused gather kernel it costs what it saves
-    (DESIGN.md section 9a).  ACM_NEXT_PROJ=1 / 0 forces it on / off."""
+    (built, measured, removed)."""
     nxt, call.next_proj = call.next_proj, None
-    want = os.environ.get("ACM_NEXT_PROJ", "auto")
-    if nxt is None or want == "0" or (want != "1" and not row_local_only):
+    if nxt is None or not row_local_only or not (tuning.kernel()["rows16"] & tuning.ROWS16_EPI):
         return None
     try:
         w3 = (nxt.weight_low, nxt.weight_high, nxt.weight_mlp)
@@ -494,7 +466,7 @@ def gemm_drop_supported(n_rows, f_in, n_out):
     """Whether BOTH products of a dense projection -- Z = drop(X) W (NN) and dW = drop(X)^T dZ (TN) -- can take the input
     dropout in their tile loads (acm_gemm_drop: the row-panel kernels of acm_gemm_rows.hip)."""
     return (n_rows >= 8192 and 16 <= f_in <= 128 and 1 <= n_out <= 192
-            and os.environ.get("ACM_GEMM_ROWS_OFF") is None and os.environ.get("ACM_GEMM_DROP", "1") != "0")
+            and (tuning.gemm_forms() & (tuning.GEMM_ROWS | tuning.GEMM_ROWS_ALWAYS)) != 0)
 
 
 def gemm(a, b, trans_a=False, trans_b=False, relu=False, out=None, col_blocks=0, a_drop=None):
@@ -566,7 +538,7 @@ def proj3(x, weights, f_block, out, out2=None, relu=False, x_drop=None):
     (acm_proj3: no packed copy of the weights, the input dropout drawn in the operand load): the first two channels in
     blocks of ``f_block`` columns; all 2 f_block + F columns go to ``out``, or the first out.shape[1] to ``out`` and the rest
     to ``out2``.  Returns False -- nothing launched -- outside the kernel's envelope (tall dense x of 32..128 features)."""
-    if not isinstance(x, torch.Tensor) or x.dtype != _F32 or x.dim() != 2 or os.environ.get("ACM_PROJ3", "1") == "0":
+    if not isinstance(x, torch.Tensor) or x.dtype != _F32 or x.dim() != 2 or not (tuning.gemm_forms() & tuning.GEMM_BX3):
         return False
     n, k = x.shape
     ws3 = list(weights)
@@ -574,8 +546,7 @@ def proj3(x, weights, f_block, out, out2=None, relu=False, x_drop=None):
     ncols = 2 * int(f_block) + f
     if (n < 8192 or not 32 <= k <= 128 or k % 4 or x.stride(1) != 1 or x.stride(0) % 4 or x.data_ptr() % 16 or ncols > 192
             or any(w.dtype != _F32 or tuple(w.shape) != (k, f) or w.stride(1) != 1 or w.stride(0) != ws3[0].stride(0)
-                   or w.device != x.device for w in ws3)
-            or os.environ.get("ACM_GEMM_BX3_OFF") is not None):
+                   or w.device != x.device for w in ws3)):
         return False
     split = 0 if out2 is None else out.shape[1]
     if out.shape[0] != n or (out2 is None and out.shape[1] != ncols) or (out2 is not None and tuple(out2.shape) != (n, ncols - split)):
@@ -830,6 +801,16 @@ class _FusedDropout(torch.autograd.Function):
         return out, None, None, None, None, None
 
 
+def _drop_now(x, spec):
+    """x * keep / (1 - p) for an acm_dropout_t ``spec`` (non-differentiable launch; same mask as the fused forms)."""
+    n, c = x.shape
+    buf = torch.empty(n, c, dtype=_F32, device=x.device)
+    with _device_ctx(x.device), _Timed(f"dropout/{n}x{c}"):
+        st = _lib.load().acm_dropout(n, c, _vp(x), x.stride(0), _vp(buf), buf.stride(0), c, C.byref(spec), _stream())
+    _lib.check(st, "acm_dropout")
+    return buf
+
+
 def dropout(x, p, state, tag=0, pad_to=None, row_offset=0):
     """x * keep / (1 - p) with the counter-based mask (acm_dropout).  ``pad_to`` > x.shape[1] returns an
     [n, pad_to] tensor whose extra columns are zero -- the row layout the aggregate-first gather wants (pass
@@ -1048,7 +1029,7 @@ def _chan_block(f):
     to a block of 4 / 8 columns: the narrow gather then fetches a neighbour's row with aligned 16-byte loads (the
     merged path of spmm_narrow_kernel) instead of 2 F scalar ones -- on the arXiv-year-shaped graph (5 classes) the
     output layer's gathers are 3-4x faster.  The pad columns are never read into a result."""
-    if f in (3, 5, 6, 7) and os.environ.get("ACM_PAD_CHANNELS", "1") != "0":
+    if f in (3, 5, 6, 7):
         return 4 if f == 3 else 8
     return f
 
@@ -1153,7 +1134,7 @@ class AcmConvFunction(torch.autograd.Function):
         # Aggregate-first (A (X W) = (A X) W): legal without a ReLU between projection and
         # filter, worth it when F_in < F, and free of any backward SpMM when x needs no gradient.
         ctx.agg_first = (not cfg.relu_before and f_in <= 16 and f_in < f and f <= 64 and not sparse_x
-                         and not ctx.needs_input_grad[0] and os.environ.get("ACM_AGG_FIRST", "1") != "0")
+                         and not ctx.needs_input_grad[0] and (tuning.HOST.rewrites & tuning.REWRITE_AGG_FIRST) != 0)
         four = k == 4
         general = bool(getattr(ops, "general", False))
         # k-hop low-pass channel (ACM-SGC, ACM-Pytorch/utils.py:631-637 materialises the dense A_low^k): here the
@@ -1173,9 +1154,12 @@ class AcmConvFunction(torch.autograd.Function):
         # the matrix pipe instead of gathering the 2F-wide projected rows (acm_conv_acmii_fwd = K1 + K2)
         ctx.recompute = (cfg.relu_before and not cfg.relu_after and cfg.relu_mlp and f == 64 and f_in <= 8
                          and not sparse_x and not general and hops == 1
-                         and os.environ.get("ACM_ACMII_RECOMPUTE", "1") != "0")
+                         and (tuning.HOST.rewrites & tuning.REWRITE_ACMII_RECOMPUTE) != 0)
         fb = f                                   # column distance of the two gathered channels (see _chan_block)
         if ctx.agg_first or ctx.recompute:
+            if ctx.in_drop is not None:               # these forms gather the input itself: they need the dropped rows
+                x = _drop_now(x, _drop_spec(ctx.in_drop, ops.row_offset))
+                ctx.in_drop_materialised = True
             fp = 4 if f_in <= 4 else (8 if f_in <= 8 else 16)
             if ctx.recompute:
                 fp = 8
@@ -1214,8 +1198,7 @@ class AcmConvFunction(torch.autograd.Function):
             # narrow dense layers (F <= 5) project with the streaming kernel straight from the three weights; everything
             # else packs [W_L | W_H | W_I] for the MFMA GEMM / the CSR-feature product
             use_proj = (not sparse_x and f <= 5 and f_in <= 64     # wider inputs: the MFMA GEMM is the faster stream
-                        and w3[0].stride(0) == w3[1].stride(0) == w3[2].stride(0)
-                        and os.environ.get("ACM_PROJ_FWD", "1") != "0")
+                        and w3[0].stride(0) == w3[1].stride(0) == w3[2].stride(0))
             fb = ctx.fb = _chan_block(f)
             # Row pitch of Z: for narrow layers the gathered block [Z_L | Z_H] (2F floats) must be
             # one aligned vector fetch, so rows are padded to a multiple of that block.
@@ -1242,6 +1225,16 @@ class AcmConvFunction(torch.autograd.Function):
                     zlh, zi = z[:, : 2 * fb], z[:, 2 * fb:]
                 if done3:
                     ctx.in_drop_used = drop_spec is not None
+            if (not done3 and drop_spec is not None
+                    and (pre is not None or use_proj or two_tables or sparse_x or not gemm_drop_supported(n, f_in, 2 * fb + f))):
+                # the caller left its input dropout to this layer (in_drop) but the projection about to run cannot draw
+                # the mask in its operand load (the two-table / k-hop GEMM, the narrow streaming projection, shapes outside
+                # acm_gemm_drop): apply it here, same counter-based mask, and save the DROPPED input for the backward
+                if sparse_x:
+                    raise NotImplementedError("in_drop with CSR features: the caller applies the dropout to the values")
+                x, pre = _drop_now(x, drop_spec), None
+                ctx.in_drop_materialised = True
+                drop_spec = None
             if done3:
                 pass                                       # [Z_L | Z_H], Z_I are written
             elif pre is not None:
@@ -1266,7 +1259,7 @@ class AcmConvFunction(torch.autograd.Function):
                         spmm_v(x.csr, x.values, wcat, relu=cfg.relu_before, out=z)
                     else:
                         gemm(x, wcat, relu=cfg.relu_before, out=z, a_drop=drop_spec)        # [n, 3F] view
-                        ctx.in_drop_used = ctx.in_drop is not None
+                        ctx.in_drop_used = drop_spec is not None
                     zlh, zi = z[:, : 2 * fb], z[:, 2 * fb:]
             if hops > 2:
                 # [A_low^(k-1) Z_L | Z_H] in place: the last of the k - 1 >= 2 products reads a hop buffer and writes over
@@ -1388,15 +1381,9 @@ class AcmConvFunction(torch.autograd.Function):
                 p.next_zlh, p.ld_next_zlh = n_zlh.data_ptr(), n_zlh.stride(0)
                 p.next_zi, p.ld_next_zi = n_zi.data_ptr(), n_zi.stride(0)
             ws = ops.low.workspace(max(fp, f) if four else fp)
-            if (not four and fp == 8 and xg.stride(0) == 8 and ops.implicit and not ops.low.stream_steps
-                    and ops.low.want_streams() and not (dev.type == "cuda" and torch.cuda.is_current_stream_capturing())):
-                ops.low.build_streams()       # one-off: the id streams of the streamed kernel (never during a capture)
-            p.use_streams = int(not four and ops.low.want_streams() and bool(ops.low.stream_steps))
             with _device_ctx(dev), _Timed(f"conv_agg_{'epi' if agg_given is not None else 'fwd'}/F{f}k{k}i{f_in}"):
                 st = lib.acm_conv_agg_fwd(ops.low.handle, C.byref(p), _vp(ws), ws.numel() * 4, _stream())
             _lib.check(st, "acm_conv_agg_fwd")
-            if ctx.pipe is not None:
-                ctx.pipe.make_next(early=True)        # (side stream only) this step's table has been read: draw the next one
             if agg_holder is not None and agg_given is None:
                 agg_holder["agg"] = agg
             if nxt is not None:
@@ -1404,7 +1391,7 @@ class AcmConvFunction(torch.autograd.Function):
             ctx.ops, ctx.cfg, ctx.f_in = ops, cfg, f_in
             # with a fused ReLU the output itself records which elements the post-op let through: the backward reads it
             # instead of regenerating the dropout mask (no extra memory: the next layer keeps the same tensor alive)
-            ctx.out_mask = bool(ctx.post_relu) and ctx.post_scale is None and os.environ.get("ACM_AGG_OUT_MASK", "1") != "0"
+            ctx.out_mask = bool(ctx.post_relu) and ctx.post_scale is None
             if ctx.pipe is not None:
                 xpad, agg = ctx.pipe.saved[0], ctx.pipe.saved[1]
             ctx.save_for_backward(xpad, agg, wl, wh, wm, mix, *vecs, *lnw, *lnb, *extra, *((out,) if ctx.out_mask else ()))
@@ -1509,14 +1496,19 @@ class AcmConvFunction(torch.autograd.Function):
         # the model vouches that nothing else consumes it (call.hidden_private), this layer's backward may hand
         # dX = dZ Wcat^T and dW = X^T dZ to that layer's backward kernel (acm_conv_agg_bwd_t.proj_*) instead of running
         # acm_proj_bwd: the [n, F] gradient then never exists in memory.
+        # ONLY under a deferral list (call.defer): this layer's dW' is then written by a LATER kernel than the one this
+        # backward returns from -- exactly the contract of DeferredReductions ("every .grad is undefined until the flush";
+        # the loop that owns the step checks all_adopted() and flushes before anything reads a gradient).  Without one,
+        # autograd's AccumulateGrad may ADD the still unwritten dW' to an existing .grad right behind this node
+        # (zero_grad(set_to_none=False), gradient accumulation, hooks), or the producer's backward may never run
+        # (torch.autograd.grad on a subset): the plain GCN API therefore materialises dX and dW' here.
         ctx.lazy_producer = None
         prod = getattr(x, "grad_fn", None) if not sparse_x else None
         if (call.hidden_private is x and prod is not None and getattr(prod, "agg_first", False) and getattr(prod, "call", None) is call
-                and not zero_padded and hops == 1 and os.environ.get("ACM_LAZY_DX", "1") != "0"
-                # row-sharded: dW' is a per-rank partial sum the other kernel writes later -- only when the all-reduce of
-                # this layer's flat gradient vector is deferred behind the step's flush as well
-                and (not ops.sharded or call.defer is not None)):
+                and not zero_padded and hops == 1 and call.defer is not None):
             ctx.lazy_producer = prod
+        if ctx.in_drop is not None and not (getattr(ctx, "in_drop_used", False) or getattr(ctx, "in_drop_materialised", False)):
+            raise RuntimeError("acm_conv: the caller's input dropout (in_drop) was not applied by any projection path")
         ctx.save_for_backward(w3[0] if sparse_x else x, *w3, zlh, zi, pre, mix, *vecs, *lnw, *lnb)
         ctx.mark_non_differentiable(att)
         return out, att
@@ -1640,7 +1632,7 @@ class AcmConvFunction(torch.autograd.Function):
             xt = xs.csr_t
             d_wcat = spmm_v(xt, xs.values.index_select(0, xt.src_pos), dz, out=flat[:nw].view(f_in_w, 3 * f))
             d_x = None
-        elif (ctx.needs_input_grad[0] and proj_bwd_supported(3 * f) and os.environ.get("ACM_PROJ_BWD", "1") != "0"
+        elif (ctx.needs_input_grad[0] and proj_bwd_supported(3 * f)
               and wl_.stride(0) == wh_.stride(0) == wm_.stride(0)):
             d_wcat = flat[:nw].view(3, f_in_w, f)                             # narrow output layer: dX and dW in one
             prod = getattr(ctx, "lazy_producer", None)
@@ -1751,8 +1743,6 @@ def _backward_agg(ctx, grad_out):
     q.defer = defer.pointer() if defer is not None else None
     pipe = getattr(ctx, "pipe", None)
     carry = pipe is not None and pipe.next_table_ready and not pipe.next_agg_ready
-    if pipe is not None:
-        pipe.join()                               # (the table drawn on the side stream)
     if carry:                                     # the next step's P = A_low dropout(x) rides this launch
         q.next_a = ops.low.handle
         q.next_xg, q.ld_next_xg = pipe.table().data_ptr(), pipe.table().stride(0)
@@ -1760,9 +1750,12 @@ def _backward_agg(ctx, grad_out):
         q.next_agg, q.ld_next_agg = pipe.agg().data_ptr(), pipe.agg().stride(0)
     with _device_ctx(dev), _Timed(f"conv_agg_bwd{'+gather' if carry else ''}{'+proj' if lazy is not None else ''}/F{f}k{k}i{f_in}"):
         st = lib.acm_conv_agg_bwd(n, C.byref(q), _vp(ws), ws.numel() * 4, _stream())
-    if st == 4 and lazy is not None:                  # ACM_EUNSUPPORTED for this shape after all: the two launches
-        proj_bwd(lazy["x"], lazy["dz"], lazy["w3"], lazy["d_w"], defer=defer, dx_out=lazy["placeholder"])
-        q.grad_out, q.proj_dz, lazy = grad_out.data_ptr(), None, None
+    if st == 4 and (lazy is not None or carry):       # ACM_EUNSUPPORTED for this shape after all: the plain launch(es)
+        if lazy is not None:
+            proj_bwd(lazy["x"], lazy["dz"], lazy["w3"], lazy["d_w"], defer=defer, dx_out=lazy["placeholder"])
+            q.grad_out, q.proj_dz, lazy = grad_out.data_ptr(), None, None
+        if carry:                                     # (the pipeline notices in end_step() and primes itself again)
+            q.next_a, q.next_xg, q.next_row_scale, q.next_agg, carry = None, None, None, None, False
         with _device_ctx(dev), _Timed(f"conv_agg_bwd/F{f}k{k}i{f_in}"):
             st = lib.acm_conv_agg_bwd(n, C.byref(q), _vp(ws), ws.numel() * 4, _stream())
     _lib.check(st, "acm_conv_agg_bwd")

@@ -12,7 +12,6 @@ possibly un-coalesced, ACM-Geometric/utils.py:21-28; dense strided ``adj_low``,
 ACM-Pytorch/utils.py:619-629), converts once and caches by storage identity.
 """
 import ctypes as C
-import os
 import weakref
 
 import torch
@@ -141,7 +140,7 @@ class CsrGraph:
 
     # ---- per-wave id streams -------------------------------------------
     def build_streams(self, n_waves=0, lmax=0):
-        """Sliced-ELL copy of the id stream for the streamed aggregate-first forward (``acm_csr_build_streams``):
+        """Sliced-ELL copy of the id stream for the gather waves of the pipelined backward (``acm_csr_build_streams``):
         one-off host-side preprocessing, pattern-only operators only, idempotent.  Returns True when the streams exist."""
         if self.stream_steps:
             return True
@@ -156,12 +155,6 @@ class CsrGraph:
         self.stream_steps, self.stream_waves = info.stream_steps, info.stream_waves
         self.stream_slices, self.stream_long_rows = info.stream_slices, info.stream_long_rows
         return True
-
-    def want_streams(self):
-        """ACM_STREAMS=1 routes the three-channel aggregate-first forward (f_pad = 8) through the streamed kernel.  Off
-        by default: on the twitch-shaped graph it takes 112 us against 107 us for the CSR walk (DESIGN.md section 4,
-        "streamed form")."""
-        return os.environ.get("ACM_STREAMS", "0") == "1"
 
     # ---- derived operators ----------------------------------------------
     def transpose(self):
@@ -402,9 +395,9 @@ def implicit_form(indptr, indices, vals, n_rows, n_cols, max_multiplicity=4):
 
 def as_implicit(ops):
     """Replace an explicit single-process FilterOperators by its pattern-only form when A_low allows it
-    (otherwise return ``ops`` unchanged).  ACM_IMPLICIT=0 keeps the explicit value stream."""
-    import os
-    if ops.implicit or ops.general or ops.sharded or os.environ.get("ACM_IMPLICIT", "1") == "0":
+    (otherwise return ``ops`` unchanged).  ``tuning.HOST.implicit = 0`` keeps the explicit value stream."""
+    from . import tuning
+    if ops.implicit or ops.general or ops.sharded or not tuning.HOST.implicit:
         return ops
     ip, ix, v = ops.low.arrays()
     form = implicit_form(ip, ix, v, ops.low.n_rows, ops.low.n_cols)
@@ -551,9 +544,9 @@ def relabel_by_degree(ops, force=False):
 
 
 def _want_relabel(n):
-    import os
-    mode = os.environ.get("ACM_RELABEL", "auto")
-    return mode == "1" or (mode == "auto" and n >= 32768)
+    from . import tuning
+    mode = tuning.HOST.relabel                       # -1: by size, 0: never, 1: always
+    return mode == 1 or (mode < 0 and n >= 32768)
 
 
 _CACHE = {}

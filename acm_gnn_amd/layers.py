@@ -16,7 +16,6 @@ tests for the spellings ``"acmgcn+"/"acmgcn++"`` (models/layers.py:96,123).
 ACM-Geometric behaviour) -- ``acm_gnn_amd.dropin`` flips it for ACM-Pytorch.
 """
 import math
-import os
 
 import torch
 import torch.nn as nn
@@ -47,7 +46,10 @@ class GraphConvolution(nn.Module):
         self.attn_layernorm = bool(attn_layernorm)
         # storage type of the gathered operand on the wide literal path: "fp32" (reference numerics) or "bf16"
         # (half the gather bytes, ~3 decimal digits on that operand; fp32 accumulation) -- BASELINE config 3
-        self.gather_dtype = gather_dtype or os.environ.get("ACM_GATHER_DTYPE", "fp32")
+        self.gather_dtype = gather_dtype or "fp32"
+        # evaluation passes over an unmodified input reuse P = A_low X of the previous pass (_eval_agg_holder); a plain
+        # attribute so that a caller who edits features through views the version counter cannot see can switch it off
+        self.eval_agg_cache = True
         self._att_raw, self._att_inv = None, None            # see the att_low / att_high / att_mlp properties
         dev = _default_device()
 
@@ -154,7 +156,7 @@ class GraphConvolution(nn.Module):
         forward reuses P = A_low X of the previous pass over the SAME input -- same tensor object, unmodified since
         (``_version``), same operators.  Training-mode calls (fresh dropout every step) and anything else get None."""
         if (self.training or torch.is_grad_enabled() or not isinstance(x, torch.Tensor) or x.requires_grad
-                or os.environ.get("ACM_EVAL_AGG_CACHE", "1") == "0"):
+                or not self.eval_agg_cache):
             return None
         # the entry keeps the input alive, so its storage cannot be handed to another tensor while the entry exists; an
         # in-place edit bumps the version counter (shared by every alias of the storage)

@@ -55,6 +55,9 @@ def parse():
                     help="1 (default): also time hipGraph replays of the captured step and report those; 0: eager only")
     ap.add_argument("--node-order", default="degree", choices=["degree", "random"],
                     help="node relabelling applied to the whole dataset before training (data prep)")
+    ap.add_argument("--force-sharded", action="store_true",
+                    help="take the row-sharded path (RCCL collectives inside the captured step) even with one rank; needs a "
+                         "torch.distributed launch")
     ap.add_argument("--no-extras", action="store_true",
                     help="skip the side measurements of the single-GPU run (literal form, random node order)")
     ap.add_argument("--no-check", action="store_true", help="skip the comparisons with the CPU oracle (eval-mode logits on "
@@ -123,7 +126,7 @@ def main():
         sys.exit("bench.py needs an MI355X (torch.cuda.is_available() is False)")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    force_sharded = os.environ.get("ACM_FORCE_SHARDED", "0") == "1"      # exercise the RCCL path with one rank
+    force_sharded = bool(args.force_sharded)                              # exercise the RCCL path with one rank
     if world > 1 or (force_sharded and "RANK" in os.environ):
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         dist.init_process_group("nccl", device_id=dev)
@@ -365,7 +368,7 @@ def main():
             extras = {"extras_error": repr(exc)}
 
     # which form of the step was timed: with the first layer's input aggregation of step t + 1 inside that layer's backward
-    # of step t (train.TrainStep's default where it qualifies; ACM_PIPELINE=0 switches it off) or without
+    # of step t (train.TrainStep's default where it qualifies; ACM_TUNING=pipeline=0 switches it off) or without
     extras["input_pipeline"] = step.pipe is not None
     if spread:
         extras["ms_per_step_windows"] = spread
@@ -382,7 +385,7 @@ def main():
 
 def side_measurements(args, timed_graph_steps, model, opt, x, ops, y, w, fused_drop, dev, splits=None):
     """{literal_ms_per_step, random_order_ms_per_step, ...}: hipGraph replays of the same training step (a) with the
-    aggregate-first rewrite switched off (ACM_AGG_FIRST=0: project, then gather the 2F-wide rows, as the reference's op
+    aggregate-first rewrite switched off (tuning rewrites=0: project, then gather the 2F-wide rows, as the reference's op
     order does), (b) on the same graph with the generator's random node ids instead of the degree relabelling."""
     import torch
     import acm_gnn_amd
@@ -416,13 +419,11 @@ def side_measurements(args, timed_graph_steps, model, opt, x, ops, y, w, fused_d
         # the same captured step alone: what train.fit() and the row-sharded runs execute (no input pipeline)
         ms, _ = timed_graph_steps(gstep)
         out["plain_ms_per_step"] = round(ms, 4)
-    if not args.variant and os.environ.get("ACM_AGG_FIRST", "1") != "0":
-        os.environ["ACM_AGG_FIRST"] = "0"
-        try:
+    from acm_gnn_amd import tuning
+    if not args.variant and (tuning.HOST.rewrites & tuning.REWRITE_AGG_FIRST):
+        with tuning.override(rewrites=tuning.HOST.rewrites & ~tuning.REWRITE_AGG_FIRST):
             ms, _ = timed_graph_steps(T.TrainStep(model, opt, x, ops, y, w, use_graph=True, fused_dropout=fused_drop))
             out["literal_ms_per_step"] = round(ms, 4)
-        finally:
-            os.environ["ACM_AGG_FIRST"] = "1"
     other = "random" if args.node_order == "degree" else "degree"
     wl = D.bench_workload(args.dataset, seed=args.seed, node_order=other, uniform=args.uniform,
                           normalize_features=not (args.method in ("acmgcnp", "acmgcnpp") and args.structure_info))

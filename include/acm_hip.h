@@ -17,7 +17,9 @@
  *     by the caller; the library allocates device memory only inside
  *     acm_csr_create / acm_csr_transpose / acm_csr_slice_rows.
  *   - all launches are asynchronous on the hipStream_t passed in (as void*);
- *     no internal synchronisation, no global mutable state => hipGraph-capturable.
+ *     no internal synchronisation => hipGraph-capturable.  The only process-wide state is the
+ *     thread-local error string and the tuning record below (acm_tuning_t): no entry point reads
+ *     the environment.
  *   - fp32 everywhere (the reference computes in torch.FloatTensor, G:19-28),
  *     int32 indices, row-major dense matrices with explicit leading dimensions.
  */
@@ -31,7 +33,7 @@
 extern "C" {
 #endif
 
-#define ACM_ABI_VERSION 21
+#define ACM_ABI_VERSION 22
 
 typedef enum {
     ACM_OK = 0,
@@ -48,6 +50,38 @@ typedef void* acm_stream_t;         /* hipStream_t                              
 int acm_version(void);
 const char* acm_last_error(void);
 
+/* ---------------------------------------------------------------- tuning --
+ * The ONE dispatch mechanism of the library: where two execution forms compute the same result (up to fp32
+ * re-association; the parity tests compare them with each other and with the oracle), this record says which one
+ * the entry points launch.  It is filled ONCE, when the library is loaded, from the environment variable
+ *     ACM_TUNING="key=value,key=value,..."        (keys = the field names below; unknown keys are an error at load)
+ * and changed afterwards only through acm_tuning_set -- no acm_* launch path calls getenv.  Process-wide, not
+ * synchronised: set it before launching, not while other threads launch.  Every value is validated by
+ * acm_tuning_set (ACM_EINVAL names the field).  No reference counterpart (the reference has one execution form:
+ * the ATen calls of ACM-Geometric/layers.py:78-116). */
+typedef struct {
+    int32_t chunk;        /* work-item length of acm_csr_create / _transpose / _slice_rows when their `chunk` argument
+                             is <= 0: 0 = sized to the graph (128..1024, see acm_csr_create), else a power of two 8..4096 */
+    int32_t wide_form;    /* gathers of rows wider than 8 floats: 0 = chosen per call (table size, width, operand type),
+                             1 = one dword per lane (spmm_wide_kernel), 2 = four neighbours per dwordx4 instruction
+                             (spmm_vec_kernel), 3 = two neighbours per instruction (spmm_pair_kernel) where it exists */
+    int32_t bwd_split;    /* acm_conv_bwd_spmm (K4): -1 = chosen per call (one channel per pass for tables beyond the L2 at
+                             mean degree >= 32), 0 = all channels in one pass, 1 = one channel per pass */
+    int32_t rows16;       /* bit mask of the sixteen-rows-per-wave row-local kernels: 1 = forward stage (agg_epi16_kernel),
+                             2 = aggregate-first backward (agg_bwd16_kernel, also the carrier of proj_* / next_agg),
+                             4 = literal K3 (bwd_local16_kernel).  Default 7; a cleared bit falls back to the
+                             four-rows-per-wave kernels */
+    int32_t agg_fused;    /* acm_conv_agg_fwd: 1 = gather + row-local stage in one kernel where the shape allows (default),
+                             0 = always two stages (acm_spmm_ex, then the row-local kernel) */
+    int32_t gemm_forms;   /* bit mask for tall products: 1 = row-panel fp32 kernels (acm_gemm_rows.hip), 2 = split-bf16
+                             projections for K <= 128 (acm_gemm_bx3.hip), 4 = split-bf16 TN form for K > 128 from
+                             16 384 rows, 8 = row-panel kernels for EVERY shape they cover (tests).  Default 7;
+                             0 = the 64x64 tile kernel only */
+    int32_t reserved[10]; /* zero */
+} acm_tuning_t;
+int acm_tuning_get(acm_tuning_t* out);
+int acm_tuning_set(const acm_tuning_t* in);   /* NULL: back to the load-time record (defaults + ACM_TUNING) */
+
 /* ------------------------------------------------------------------ graph --
  * acm_csr_create: adopt (copy) a CSR row block living in device memory and
  * build the nnz-balanced work list the kernels walk (rows longer than `chunk`
@@ -59,7 +93,7 @@ const char* acm_last_error(void);
  * ACM-Pytorch/utils.py:619-629 and the per-call COO coalesce inside
  * torch.spmm (G:87-103).  `chunk` <= 0 sizes the chunks to the graph: a power of two in 128..1024
  * chosen so that one work item stays below the share of a 16-lane group when the chip is full
- * (nnz / 8192); the environment variable ACM_CHUNK overrides that choice for tuning.  The same rule
+ * (nnz / 8192); acm_tuning_t.chunk overrides that choice.  The same rule
  * applies to acm_csr_transpose and acm_csr_slice_rows (computed from the new handle's own nnz).
  *
  * vals_dev == NULL makes a PATTERN-ONLY operator: every stored entry counts as 1 and the kernels read no
@@ -115,8 +149,7 @@ typedef struct {
 int acm_csr_info(const acm_csr_t* a, acm_csr_info_t* info);
 
 /* acm_csr_build_streams: lay the column ids of a PATTERN-ONLY operator out in the order the waves of a streamed
- * gather consume them (the gather waves of acm_conv_agg_bwd_t.next_agg; acm_conv_agg_fwd with use_streams, f_pad = 8,
- * three channels) -- a sliced-ELL copy of the id
+ * gather consume them (the gather waves of acm_conv_agg_bwd_t.next_agg) -- a sliced-ELL copy of the id
  * stream: four rows of similar length per wave ("slice"), 32 neighbours per row and wave step, 128 ids per step padded
  * with an out-of-range sentinel (a buffer load answers it with zeros without touching memory), the slices dealt
  * longest-first to `n_waves` waves, each wave's slices contiguous.  A wave then walks ONE linear id stream with its
@@ -124,8 +157,8 @@ int acm_csr_info(const acm_csr_t* a, acm_csr_info_t* info);
  * than `lmax` neighbours are cut into pieces; the piece that arrives last (a device-scope arrival counter per row) adds
  * the partial sums in slot order and finishes the row, so results do not depend on the arrival order.
  * One-off host-side preprocessing like acm_csr_create (synchronises the device; must not be called while a stream is
- * capturing); idempotent.  n_waves <= 0: five waves per SIMD of the current device (env ACM_STREAM_WAVES overrides);
- * lmax <= 0: 512 (env ACM_STREAM_LMAX).  The handle owns the arrival counters (zero between launches: the last piece of a row resets its counter) and partial
+ * capturing); idempotent.  n_waves <= 0: five waves per SIMD of the current device;
+ * lmax <= 0: 512.  The handle owns the arrival counters (zero between launches: the last piece of a row resets its counter) and partial
  * slots, so launches that use the streams of one handle must be stream-ordered.  Costs (total steps x 512 B) of device memory, ~1.2 x the id array.
  * No reference counterpart (the reference hands torch.spmm a COO tensor, ACM-Geometric/layers.py:87-103). */
 int acm_csr_build_streams(acm_csr_t* a, int n_waves, int lmax);
@@ -546,10 +579,8 @@ typedef struct {
      * input wrote it (e.g. every evaluation pass over a static feature matrix after the first) -- so the gather is
      * skipped and only the row-local stage runs; xg is not read.                                                     */
     int32_t agg_given;
-    /* use_streams != 0: walk the handle's per-wave id streams (acm_csr_build_streams; three channels, f_pad = 8,
-     * ld_xg = 8, pattern-only operator) instead of the CSR work list.  Off by default: slower on the graphs measured
-     * (DESIGN.md section 4), and a handle may carry streams laid out for another consumer (acm_conv_agg_bwd_t.next_agg). */
-    int32_t use_streams;
+    int32_t reserved0;                 /* zero (ABI <= 21: use_streams, the streamed form of the fused forward -- measured
+                                          slower than the CSR walk, DESIGN.md section 4, and removed in ABI 22)      */
     /* With agg_given: the row-local stage also stores the rows of `agg` and `xs` it read to agg_copy / xs_copy (NULL:
      * off; rows of f_pad floats) -- the operands of this layer's backward when `agg` / `xs` themselves are the buffers
      * an input pipeline refills before that backward runs (acm_conv_agg_bwd_t.next_agg).                             */
@@ -593,12 +624,13 @@ typedef struct {
      * instructions and leaves the memory system idle; the narrow gather  next_agg = next_row_scale * (A_low next_xg)  of the
      * next training step's first layer is bound by memory latency and depends on nothing this step computes (the input
      * features are constant, the dropout mask a function of the step counter: acm_dropout_t.step_offset = 1).  With
-     * next_agg set, every workgroup is twelve waves of the row-local backward (their dW tiles accumulate in LDS instead
-     * of registers, so that four waves fit a SIMD) and four waves that walk next_a's id streams
-     * (acm_csr_build_streams; the grid becomes stream_waves / 4 workgroups, one per CU); the next forward then runs with
-     * acm_conv_agg_fwd_t.agg_given.  Needs: three channels, f_pad = 8, f_out = 64, ld_next_xg = 8, a pattern-only next_a
-     * with streams built for a multiple of four waves <= 1024 (and <= n_rows / 4).  next_agg / next_xg must not alias
-     * agg / xs.                                                                                                        */
+     * next_agg set, every workgroup is eight waves: four run the sixteen-rows-per-wave backward (acm_conv_agg16.hip),
+     * four walk next_a's id streams (acm_csr_build_streams; the grid becomes stream_waves / 4 workgroups, one per CU);
+     * the next forward then runs with acm_conv_agg_fwd_t.agg_given.  Needs: the shapes of the sixteen-rows-per-wave
+     * backward (f_out = 64, head_stats, `out` behind a fused ReLU or no post-op; acm_tuning_t.rows16 bit 2),
+     * ld_next_xg = f_pad, a pattern-only next_a with streams built for a multiple of four waves <= 1024 (and
+     * <= n_rows / 4); ACM_EUNSUPPORTED otherwise.  next_agg / next_xg must not alias agg / xs.  May be combined
+     * with proj_* below (one kernel then carries all three: bench.py's dominant launch).                              */
     const acm_csr_t* next_a;
     const float* next_xg; int64_t ld_next_xg;
     const float* next_row_scale;
@@ -611,8 +643,9 @@ typedef struct {
      *     proj_d_w[c][col][q] = sum_rows out[row, col] proj_dz[row, c proj_f + q]     (three f_out x proj_f blocks)
      * are reduced with d_params (same `defer`).  That removes the [n_rows, f_out] gradient from memory altogether
      * (43 MB written and read back on the twitch-shaped graph) and one launch.  Needs `out` (= the following layer's
-     * input), three channels, f_pad = 8, f_out = 64, proj_f <= 2 and no next_agg; ACM_EUNSUPPORTED otherwise -- the
-     * caller then runs acm_proj_bwd itself and calls again with grad_out. */
+     * input), the shapes of the sixteen-rows-per-wave backward (f_out = 64, head_stats) and proj_f <= 2; with or
+     * without next_agg.  ACM_EUNSUPPORTED otherwise -- the caller then runs acm_proj_bwd itself and calls again with
+     * grad_out. */
     const float* proj_dz; int64_t ld_proj_dz;
     const float* proj_w_low; const float* proj_w_high; const float* proj_w_mlp; int64_t proj_ld_w;
     int32_t proj_f;

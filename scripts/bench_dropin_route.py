@@ -4,7 +4,7 @@ reference's sparse-COO adjacency TENSORS, F.log_softmax + nll_loss on the traini
 on the twitch-shaped graph with the generator's RANDOM node ids -- what a user of the unmodified reference script gets
 from the drop-in layer.  Three arms:
     relabel=auto   operators_for relabels by degree inside the operator (default for >= 32 768 nodes)
-    relabel=off    ACM_RELABEL=0: the operator keeps the random numbering
+    relabel=off    tuning relabel=0: the operator keeps the random numbering
     pre-sorted     the dataset itself relabelled by degree beforehand (what bench.py does as data preparation)
 Prints ms per eager step of the whole loop (dominated by torch's own launches: indexing + its sort-based backward,
 F.dropout, ~80 AdamW kernels) and the time of the library's kernels inside it, which is what the relabelling changes.
@@ -33,7 +33,7 @@ def coo(m):
 
 
 def run(order, relabel, steps=30):
-    os.environ["ACM_RELABEL"] = relabel
+    acm_gnn_amd.tuning.apply(relabel={"auto": -1}.get(relabel, None) if relabel == "auto" else int(relabel))
     graph.clear_cache()
     wl = D.bench_workload("twitch-gamer", node_order=order)
     n = wl["adj"].shape[0]
@@ -73,7 +73,7 @@ def run(order, relabel, steps=30):
     lib_us = sum(v[1] for v in timer.summary().values()) / 5 * 1e3
     AF.set_kernel_timer(None)
     ops = graph.operators_for(low, high, None)
-    return {"node_order": order, "ACM_RELABEL": relabel, "relabelled_in_operator": ops.perm is not None,
+    return {"node_order": order, "relabel": relabel, "relabelled_in_operator": ops.perm is not None,
             "eager_ms_per_step": round(ms, 3), "library_kernels_us_per_step": round(lib_us, 1), "loss": float(loss)}
 
 

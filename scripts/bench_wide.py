@@ -5,8 +5,8 @@ projection and filter; the structure channel; hidden -> hidden layers).
 
     python scripts/bench_wide.py [--modes scalar,vec] [--configs twitch/acmii,...]
 
-mode = environment switches read per launch by libacm_hip.so:  scalar: ACM_WIDE_SCALAR=1 (dword-per-lane kernel),
-default: the library's choice (vector form for single-channel products), vec: ACM_WIDE_VEC=1 (dwordx4 rows, four
+mode = acm_tuning_t.wide_form:  scalar: 1 (dword-per-lane kernel),
+default: 0, the library's choice (vector form for single-channel products), vec: 2 (dwordx4 rows, four
 neighbours per instruction, everywhere).
 """
 import argparse
@@ -32,7 +32,7 @@ CONFIGS = {
     "arxiv/acm": dict(ds="arxiv-year", method="acmgcnp", s=0, variant=0, dropout=0.1),
     "penn94/acm/csrX": dict(ds="penn94", method="acmgcnp", s=0, variant=0, dropout=0.1, sparse=1),
 }
-MODES = {"scalar": {"ACM_WIDE_SCALAR": "1"}, "default": {}, "vec": {"ACM_WIDE_VEC": "1"}, "pair": {"ACM_WIDE_PAIR": "1"}}
+MODES = {"scalar": 1, "default": 0, "vec": 2, "pair": 3}
 _WL = {}
 
 
@@ -44,9 +44,7 @@ def workload(ds, normalize):
 
 
 def run(name, cfg, mode, steps=20):
-    for k in ("ACM_WIDE_SCALAR", "ACM_WIDE_PAIR", "ACM_WIDE_VEC"):
-        os.environ.pop(k, None)
-    os.environ.update(MODES[mode])
+    acm_gnn_amd.tuning.apply(wide_form=MODES[mode])
     wl = workload(cfg["ds"], not cfg["s"])
     n = wl["adj"].shape[0]
     ops = DD.make_sharded_operators(wl["low"], wl["deg"], DEV, with_structure=bool(cfg["s"]))

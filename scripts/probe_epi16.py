@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Run ON THE GPU BOX: the sixteen-rows-per-wave row-local stages (acm_conv_agg16.hip) against the older kernels
-(ACM_EPI16_OFF / ACM_BWD16_OFF) on the benchmark's first layer: results, head statistics, gradients, and HIP-event times
+(acm_tuning_t.rows16 bits 1 / 2 cleared) on the benchmark's first layer: results, head statistics, gradients, and HIP-event times
 of both.  Prints one line per comparison."""
 import json
 import os
@@ -17,13 +17,8 @@ from acm_gnn_amd.layers import GraphConvolution  # noqa: E402
 
 
 def run(layer, x, ops, go, drop, unfused, off):
-    for k in ("ACM_AGG_UNFUSED", "ACM_EPI16_OFF", "ACM_BWD16_OFF"):
-        os.environ.pop(k, None)
-    if unfused:
-        os.environ["ACM_AGG_UNFUSED"] = "1"
-    if off:
-        os.environ["ACM_EPI16_OFF"] = "1"
-        os.environ["ACM_BWD16_OFF"] = "1"
+    from acm_gnn_amd import tuning
+    tuning.apply(agg_fused=0 if unfused else 1, rows16=4 if off else 7)
     layer.zero_grad(set_to_none=True)
     out = layer(x, ops, post_relu=True, post_drop=drop)
     out.backward(go)

@@ -5,7 +5,7 @@ import json, os, sys, time
 import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-from acm_gnn_amd import functional as AF
+from acm_gnn_amd import functional as AF, tuning
 
 dev = torch.device("cuda", 0)
 def timeit(fn, reps=10, inner=10):
@@ -43,10 +43,7 @@ for (n, k, nn) in ((169343, 128, 192), (169343, 128, 21), (169343, 128, 15), (41
     ref_zd = xd.double() @ w.double()
     ref_dwd = xd.double().t() @ dz.double()
     for off in ("1", ""):
-        if off:
-            os.environ["ACM_GEMM_BX3_OFF"] = "1"
-        else:
-            os.environ.pop("ACM_GEMM_BX3_OFF", None)
+        tuning.apply(gemm_forms=1 if off else 7)
         tag = "f32" if off else "bx3"
         z = torch.empty(n, nn, device=dev); dw = torch.empty(k, nn, device=dev)
         res[f"nn_{tag}_us"] = round(timeit(lambda: AF.gemm(x, w, out=z)), 1)
@@ -61,5 +58,5 @@ for (n, k, nn) in ((169343, 128, 192), (169343, 128, 21), (169343, 128, 15), (41
                 res[f"tn_{tag}_drop_err"] = err(dw, ref_dwd, sc_dw)
             except Exception as e:  # noqa: BLE001
                 res[f"{tag}_drop"] = str(e)[:80]
-    os.environ.pop("ACM_GEMM_BX3_OFF", None)
+    tuning.reset()
     print(json.dumps(res), flush=True)

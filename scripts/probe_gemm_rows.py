@@ -4,7 +4,7 @@ import json, os, sys, time
 import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-from acm_gnn_amd import functional as AF
+from acm_gnn_amd import functional as AF, tuning
 
 dev = torch.device("cuda", 0)
 def timeit(fn, reps=20):
@@ -23,14 +23,11 @@ for (n, k, nn) in ((169343, 128, 192), (169343, 128, 21), (41554, 128, 192)):
     dw = torch.empty(k, nn, device=dev)
     res = {"shape": [n, k, nn]}
     for off in ("", "1"):
-        if off:
-            os.environ["ACM_GEMM_ROWS_OFF"] = "1"
-        else:
-            os.environ.pop("ACM_GEMM_ROWS_OFF", None)
+        tuning.apply(gemm_forms=0 if off else 9)
         tag = "tile" if off else "rows"
         res[f"nn_{tag}_us"] = round(timeit(lambda: AF.gemm(x, w, out=z)), 1)
         res[f"tn_{tag}_us"] = round(timeit(lambda: AF.gemm(x, dz, trans_a=True, out=dw)), 1)
-    os.environ.pop("ACM_GEMM_ROWS_OFF", None)
+    tuning.apply(gemm_forms=9)
     res["nn_rows_drop_us"] = round(timeit(lambda: AF.gemm(x, w, out=z, a_drop=spec)), 1)
     res["tn_rows_drop_us"] = round(timeit(lambda: AF.gemm(x, dz, trans_a=True, out=dw, a_drop=spec)), 1)
     res["dropout_pass_us"] = round(timeit(lambda: AF.dropout(x, 0.1, st)), 1)

@@ -5,7 +5,7 @@ import json, os, sys
 import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "scripts"))
-from acm_gnn_amd import functional as AF
+from acm_gnn_amd import functional as AF, tuning
 from probe_bx3_parts import timeit
 dev = torch.device("cuda", 0)
 def err(got, a, b):
@@ -16,13 +16,12 @@ for (n, k, nn) in ((5201, 2089, 192), (2708, 1433, 192), (41554, 4814, 192), (41
     res = {"shape": [n, k, nn]}
     x64, w64, dz64 = x.double(), w.double(), dz.double()
     for off in ("1", ""):
-        if off: os.environ["ACM_GEMM_BX3_WIDE_OFF"] = "1"
-        else: os.environ.pop("ACM_GEMM_BX3_WIDE_OFF", None)
+        tuning.apply(gemm_forms=3 if off else 7)
         tag = "f32" if off else "bx3"
         z = torch.empty(n, nn, device=dev); dw = torch.empty(k, nn, device=dev)
         res[f"nn_{tag}_us"] = round(timeit(lambda: AF.gemm(x, w, out=z)), 1)
         res[f"nn_{tag}_err"] = err(z, x64, w64)
         res[f"tn_{tag}_us"] = round(timeit(lambda: AF.gemm(x, dz, trans_a=True, out=dw)), 1)
         res[f"tn_{tag}_err"] = err(dw, x64.t(), dz64)
-    os.environ.pop("ACM_GEMM_BX3_WIDE_OFF", None)
+    tuning.reset()
     print(json.dumps(res), flush=True)

@@ -1,8 +1,8 @@
 #!/usr/bin/env python3
-"""Run ON THE GPU BOX: the benchmark's training step under a list of environment settings (the kernels read their
-tuning switches with getenv per call), per-kernel HIP-event times of the eager step and the replayed-graph step time.
+"""Run ON THE GPU BOX: the benchmark's training step under a list of tuning settings (acm_gnn_amd.tuning: the items of
+ACM_TUNING), per-kernel HIP-event times of the eager step and the replayed-graph step time.
 
-    python scripts/probe_step_env.py "ACM_EPI16_BLOCKS=512" "ACM_EPI16_CAP4=1,ACM_EPI16_BLOCKS=768" ...
+    python scripts/probe_step_env.py "" "rows16=5" "rows16=6,pipeline=0" ...
 An empty string is the default configuration."""
 import json
 import os
@@ -28,11 +28,9 @@ def main():
     w = T.row_weights(torch.from_numpy(tr).to(dev), n, device=dev)
     configs = sys.argv[1:] or [""]
     for cfg in configs:
-        keys = []
-        for kv in filter(None, cfg.split(",")):
-            k, v = kv.split("=")
-            os.environ[k] = v
-            keys.append(k)
+        kern, host = acm_gnn_amd.tuning.parse(cfg)
+        acm_gnn_amd.tuning.reset()
+        acm_gnn_amd.tuning.apply(**kern, **host)
         ops = DD.make_sharded_operators(low, deg, dev)
         torch.manual_seed(0)
         model = acm_gnn_amd.GCN(x.shape[1], 64, int(y_np.max()) + 1, 2, n, 0.1, "acmgcnp", 0, variant=False).to(dev)
@@ -62,8 +60,7 @@ def main():
             best.append((time.perf_counter() - t0) / 50 * 1e3)
         print(json.dumps({"env": cfg, "graph_ms": [round(b, 4) for b in sorted(best)], "pipe": step.pipe is not None,
                           "kernel_us": ks}), flush=True)
-        for k in keys:
-            os.environ.pop(k, None)
+        acm_gnn_amd.tuning.reset()
         del step, gstep, model, model2, opt, opt2, ops
         from acm_gnn_amd.graph import clear_cache
         clear_cache()

@@ -6,7 +6,7 @@ ids) with 64- and 128-column tables, column ids rewritten to control which cache
     top64k    column = random in [0, 65536)     (16 MB: beyond one XCD's L2, inside the Infinity Cache)
     random    column = uniform random in [0, N) (43 / 86 MB table through the Infinity Cache)
     seq       column = edge position mod N      (streaming floor)
-for the dword-per-lane kernel (ACM_WIDE_SCALAR=1) and the dwordx4 kernel.  Prints us per call (20 back-to-back).
+for the dword-per-lane kernel (acm_tuning_t.wide_form = 1) and the dwordx4 kernel.  Prints us per call (20 back-to-back).
     python scripts/probe_wide.py [variant ...]
 """
 import os
@@ -18,7 +18,7 @@ import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-from acm_gnn_amd import data as D, functional as AF  # noqa: E402
+from acm_gnn_amd import data as D, functional as AF, tuning  # noqa: E402
 from acm_gnn_amd.graph import CsrGraph  # noqa: E402
 
 DEV = torch.device("cuda:0")
@@ -46,10 +46,7 @@ def main():
             out = torch.empty(n, width, device=DEV)
             res = {}
             for mode in ("scalar", "vec"):
-                if mode == "scalar":
-                    os.environ["ACM_WIDE_SCALAR"] = "1"
-                else:
-                    os.environ.pop("ACM_WIDE_SCALAR", None)
+                tuning.apply(wide_form=1 if mode == "scalar" else 0)
                 for _ in range(3):
                     AF.spmm(g, dense, out=out)
                 torch.cuda.synchronize()

@@ -1,4 +1,5 @@
 """pytest configuration: the ``gpu`` marker and shared fixture helpers."""
+import contextlib
 import glob
 import json
 import os
@@ -55,3 +56,32 @@ def graph_tensors(dialect):
 @pytest.fixture(scope="session")
 def golden_dir():
     return GOLDEN
+
+
+def tune_now(**kw):
+    """``tune_now(agg_first=0, rows16=5, ...)``: set tuning switches (acm_gnn_amd.tuning: the host record and the library's
+    acm_tuning_t) for the rest of the running test -- the autouse guard below restores both records afterwards.  Besides
+    the real keys it takes two conveniences: ``agg_first`` / ``acmii_recompute`` = bits 1 / 2 of ``rewrites``."""
+    from acm_gnn_amd import tuning
+    bits = {"agg_first": tuning.REWRITE_AGG_FIRST, "acmii_recompute": tuning.REWRITE_ACMII_RECOMPUTE}
+    rew = tuning.HOST.rewrites
+    for name, bit in bits.items():
+        if name in kw:
+            rew = (rew | bit) if int(kw.pop(name)) else (rew & ~bit)
+            kw["rewrites"] = rew
+    tuning.apply(**kw)
+
+
+@pytest.fixture
+def tune():
+    """The same as a fixture (so that a test's signature says that it flips execution forms)."""
+    return tune_now
+
+
+@pytest.fixture(autouse=True)
+def _tuning_guard():
+    """Every test starts from, and leaves behind, the load-time tuning records."""
+    from acm_gnn_amd import tuning
+    tuning.reset(kernel_too=False)
+    yield
+    tuning.reset()

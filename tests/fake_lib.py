@@ -127,10 +127,36 @@ class FakeLib:
     def __init__(self):
         self._handles, self._next, self._err = {}, 1, b""
         self._pending = {}
+        self._tuning = dict(self.TUNING_DEFAULTS)
 
     # ---- plumbing ---------------------------------------------------------
     def acm_version(self):
-        return 17
+        return 22
+
+    # ---- the tuning record (acm_tuning_t): plain storage + the library's validation; the entry points below consult it
+    # where the library's dispatch does (gemm_forms, rows16)
+    TUNING_DEFAULTS = dict(chunk=0, wide_form=0, bwd_split=-1, rows16=7, agg_fused=1, gemm_forms=7)
+
+    def acm_tuning_get(self, out):
+        t = out._obj
+        for k, v in self._tuning.items():
+            setattr(t, k, v)
+        return 0
+
+    def acm_tuning_set(self, ptr):
+        if not ptr:
+            self._tuning = dict(self.TUNING_DEFAULTS)
+            return 0
+        t = ptr._obj
+        new = {k: int(getattr(t, k)) for k in self.TUNING_DEFAULTS}
+        ok = ((new["chunk"] == 0 or (8 <= new["chunk"] <= 4096 and new["chunk"] & (new["chunk"] - 1) == 0))
+              and 0 <= new["wide_form"] <= 3 and -1 <= new["bwd_split"] <= 1 and 0 <= new["rows16"] <= 7
+              and new["agg_fused"] in (0, 1) and 0 <= new["gemm_forms"] <= 15)
+        if not ok:
+            self._err = b"acm_tuning_set: field out of range"
+            return 1
+        self._tuning = new
+        return 0
 
     def acm_shard_plan(self, n_rows, indptr, world, row_cost, bounds):
         """numpy restatement of the host routine: nearest row boundary to p / world of the cost prefix."""
@@ -487,7 +513,7 @@ class FakeLib:
         if d is None or d.p <= 0:
             return self.acm_gemm_blocks(ta, tb, m, n, k, a, lda, b, ldb, c, ldc, cb, cbs, relu, ws, wsb, stream)
         rows, cols = (k, m) if ta else (m, k)
-        ok = (not tb and 1 <= n <= 192 and 16 <= cols and
+        ok = (not tb and 1 <= n <= 192 and 16 <= cols and (self._tuning["gemm_forms"] & 9) != 0 and
               ((not ta and rows >= 4096 and cols <= 4096) or (ta and rows >= 8192 and cols <= 128)))
         if not ok:
             self._err = b"acm_gemm_drop: the dropout in the tile load exists in the row-panel kernels only"
@@ -513,7 +539,8 @@ class FakeLib:
         ptr = x.value if isinstance(x, C.c_void_p) else int(x)
         if n_rows == 0:
             return 0
-        if not (n_rows >= 8192 and 32 <= k <= 128 and k % 4 == 0 and ldx % 4 == 0 and ptr % 16 == 0 and n_cols <= 192):
+        if not (n_rows >= 8192 and 32 <= k <= 128 and k % 4 == 0 and ldx % 4 == 0 and ptr % 16 == 0 and n_cols <= 192
+                and (self._tuning["gemm_forms"] & 2)):
             self._err = b"acm_proj3: the split-bf16 row-panel kernel takes >= 8192 rows of 32..128 features"
             return 4
         X = _view(x, n_rows, k, ldx).astype(np.float64)
@@ -761,8 +788,7 @@ class FakeLib:
         extra = []
         if q.proj_dz:                             # the following layer's projection backward rides along (ABI 20)
             f2 = q.proj_f
-            if (k != 3 or fp != 8 or F != 64 or not q.head_stats or not q.out or not 1 <= f2 <= 2
-                    or q.post_scale or not (q.post_relu or q.post_drop.p == 0)):
+            if not self._bwd16_ok(q, k, fp, F) or not q.out or not 1 <= f2 <= 2:
                 self._err = b"acm_conv_agg_bwd: proj_dz: unsupported configuration"
                 return 4
             dz2 = _view(q.proj_dz, n, 3 * f2, q.ld_proj_dz).astype(np.float64)
@@ -793,7 +819,8 @@ class FakeLib:
         out[base + 3 * k * F:] = d_mix.reshape(-1)
         if q.next_agg:                            # the next step's input aggregation rides along
             a = self._get(q.next_a)
-            if k != 3 or fp != 8 or F != 64 or not getattr(a, "stream_waves", 0) or a.stream_waves % 4 or a.stream_waves > 1024:
+            if (not self._bwd16_ok(q, k, fp, F) or not getattr(a, "stream_waves", 0) or a.stream_waves % 4
+                    or a.stream_waves > 1024):
                 self._err = b"acm_conv_agg_bwd: carried gather: unsupported configuration"
                 return 4
             if a.stream_waves // 4 > min((n + 15) // 16, 768):
@@ -806,6 +833,14 @@ class FakeLib:
                 pn = pn * _vec(q.next_row_scale, a.n_rows).astype(np.float64)[:, None]
             _view(q.next_agg, a.n_rows, 8, q.ld_next_agg)[...] = pn
         return self._emit(q.defer, [(dst, out)] + extra)
+
+    def _bwd16_ok(self, q, k, fp, F):
+        """The envelope of the sixteen-rows-per-wave backward (acm_conv_agg16.hip: acm_agg_bwd16), the only carrier of
+        proj_* and next_agg."""
+        out_mask = bool(q.out) and bool(q.post_relu) and not q.post_scale
+        no_post = not q.post_relu and not q.post_scale and not q.post_drop.p > 0
+        return (k == 3 and fp == 8 and F == 64 and bool(q.head_stats) and (out_mask or no_post)
+                and (self._tuning["rows16"] & 2) != 0)
 
     def acm_dropout(self, n, c, src, lds, dst, ldd, dst_cols, d, stream):
         out = np.zeros((n, dst_cols))
@@ -843,8 +878,9 @@ class FakeLib:
 
 def install(monkeypatch):
     """Route acm_gnn_amd through the test double and lift its GPU-only guards (CPU tests only)."""
-    from acm_gnn_amd import _lib, functional, graph, optim
+    from acm_gnn_amd import _lib, functional, graph, optim, tuning
     fake = FakeLib()
+    monkeypatch.setattr(tuning, "_kernel_cache", None)        # the cached acm_tuning_t belongs to whichever library was loaded
     monkeypatch.setattr(_lib, "load", lambda build_if_missing=True: fake)
     monkeypatch.setattr(_lib, "check", lambda st, what="": (_ for _ in ()).throw(
         RuntimeError(f"{what}: {fake.acm_last_error().decode()} ({_lib.STATUS_NAMES.get(st, st)})")) if st else None)

@@ -45,7 +45,13 @@ def test_calls_without_gpu_fail_loudly_not_silently():
 
 STRUCTS = {"acm_csr_info_t": "CsrInfo", "acm_conv_fwd_t": "ConvFwd", "acm_conv_bwd_local_t": "ConvBwdLocal",
            "acm_conv_bwd_spmm_t": "ConvBwdSpmm", "acm_conv_agg_fwd_t": "ConvAggFwd", "acm_conv_agg_bwd_t": "ConvAggBwd",
-           "acm_spmm_opts_t": "SpmmOpts", "acm_dropout_t": "Dropout", "acm_adam_tensor_t": "AdamTensor", "acm_adam_config_t": "AdamConfig"}
+           "acm_spmm_opts_t": "SpmmOpts", "acm_dropout_t": "Dropout", "acm_adam_tensor_t": "AdamTensor", "acm_adam_config_t": "AdamConfig",
+           "acm_tuning_t": "Tuning"}
+
+
+def _struct(pyname):
+    from acm_gnn_amd import _lib, tuning
+    return tuning.Tuning if pyname == "Tuning" else getattr(_lib, pyname)
 
 
 def test_ctypes_struct_layouts_match_the_c_header(tmp_path):
@@ -54,7 +60,7 @@ def test_ctypes_struct_layouts_match_the_c_header(tmp_path):
     from acm_gnn_amd import _lib
     lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "acm_hip.h"', "int main(void){"]
     for cname, pyname in STRUCTS.items():
-        cls = getattr(_lib, pyname)
+        cls = _struct(pyname)
         lines.append(f'printf("{cname} size %zu\\n", sizeof({cname}));')
         for fname, _ in cls._fields_:
             lines.append(f'printf("{cname} {fname} %zu\\n", offsetof({cname}, {fname}));')
@@ -68,10 +74,72 @@ def test_ctypes_struct_layouts_match_the_c_header(tmp_path):
         s, f, v = ln.split()
         got[(s, f)] = int(v)
     for cname, pyname in STRUCTS.items():
-        cls = getattr(_lib, pyname)
+        cls = _struct(pyname)
         assert got[(cname, "size")] == C.sizeof(cls), cname
         for fname, _ in cls._fields_:
             assert got[(cname, fname)] == getattr(cls, fname).offset, (cname, fname)
+
+
+def test_tuning_record_is_the_one_dispatch_mechanism():
+    """acm_tuning_t: layout, get / set / validation / reset through the real library; no acm_* launch path reads the
+    environment (no getenv in any .hip translation unit; one read of ACM_TUNING at load time in acm_csr.cpp)."""
+    import glob
+    from acm_gnn_amd import _lib, tuning
+    lib = _lib.load()
+    t = tuning.Tuning()
+    assert C.sizeof(t) == 4 * 16
+    assert lib.acm_tuning_get(C.byref(t)) == 0
+    loaded = {k: getattr(t, k) for k in tuning.KERNEL_KEYS}
+    assert loaded == dict(chunk=0, wide_form=0, bwd_split=-1, rows16=7, agg_fused=1, gemm_forms=7), loaded
+    t.rows16, t.chunk = 5, 256
+    assert lib.acm_tuning_set(C.byref(t)) == 0
+    u = tuning.Tuning()
+    lib.acm_tuning_get(C.byref(u))
+    assert (u.rows16, u.chunk) == (5, 256)
+    t.chunk = 100                                         # not a power of two
+    assert lib.acm_tuning_set(C.byref(t)) == 1 and b"chunk" in lib.acm_last_error()
+    lib.acm_tuning_get(C.byref(u))
+    assert (u.rows16, u.chunk) == (5, 256)                # a rejected record changes nothing
+    assert lib.acm_tuning_set(None) == 0                  # NULL: back to the load-time record
+    lib.acm_tuning_get(C.byref(u))
+    assert {k: getattr(u, k) for k in tuning.KERNEL_KEYS} == loaded
+    tuning.invalidate()
+    for path in glob.glob(os.path.join(ROOT, "acm_gnn_amd", "csrc", "*.hip")) + glob.glob(os.path.join(ROOT, "acm_gnn_amd", "csrc", "*.h")):
+        assert "getenv" not in open(path).read(), path
+    host = open(os.path.join(ROOT, "acm_gnn_amd", "csrc", "acm_csr.cpp")).read()
+    assert host.count("getenv(") == 1 and 'getenv("ACM_TUNING")' in host
+    for path in glob.glob(os.path.join(ROOT, "acm_gnn_amd", "*.py")) + glob.glob(os.path.join(ROOT, "acm_gnn_amd", "*", "*.py")):
+        if os.path.basename(path) in ("tuning.py", "_lib.py", "build.py"):      # ACM_TUNING; the library path; HIPCC
+            continue
+        assert "os.environ" not in open(path).read(), path
+
+
+def test_acm_tuning_variable_is_read_once_at_load(tmp_path):
+    """ACM_TUNING in a child's environment: the library's record and the host record both take it at load / import; later
+    changes of the variable do nothing; unknown keys are reported (stderr by the library, ValueError by the host parser)."""
+    code = (
+        "import ctypes as C, os, sys\n"
+        "from acm_gnn_amd import _lib, tuning\n"
+        "_lib.load()\n"
+        "os.environ['ACM_TUNING'] = 'rows16=0'\n"          # too late: both records were filled at load / import
+        "k = tuning.kernel()\n"
+        "print(k['rows16'], k['gemm_forms'], k['wide_form'], tuning.HOST.rewrites, tuning.HOST.pipeline, tuning.HOST.relabel)\n")
+    env = dict(os.environ, ACM_TUNING="rows16=5,gemm_forms=1,rewrites=2,pipeline=0", PYTHONPATH=ROOT)
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, check=True)
+    assert out.stdout.split() == ["5", "1", "0", "2", "0", "-1"], (out.stdout, out.stderr)
+    env["ACM_TUNING"] = "rows16=9,nonsense=1"
+    out = subprocess.run([sys.executable, "-c", "import ctypes as C\nfrom acm_gnn_amd import _lib\n_lib.load()"], env=env,
+                         capture_output=True, text=True)
+    assert "bad value 'rows16=9'" in out.stderr and "unknown key 'nonsense'" in out.stderr, out.stderr
+    from acm_gnn_amd import tuning
+    with pytest.raises(ValueError):
+        tuning.parse("nonsense=1")
+    with pytest.raises(ValueError):
+        tuning.parse("relabel=7")
+    assert tuning.parse("rows16=5, rewrites=0") == ({"rows16": 5}, {"rewrites": 0})
+    with tuning.override(rewrites=0, implicit=0):
+        assert (tuning.HOST.rewrites, tuning.HOST.implicit) == (0, 0)
+    assert (tuning.HOST.rewrites, tuning.HOST.implicit) == (3, 1)
 
 
 def test_header_is_plain_c():

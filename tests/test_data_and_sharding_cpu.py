@@ -176,7 +176,8 @@ def _worker(rank, world, port, cfg, ret):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         fake_lib.install(MP())
-        os.environ["ACM_IMPLICIT"] = str(cfg.get("implicit", 1))
+        from acm_gnn_amd import tuning
+        tuning.HOST.implicit = int(cfg.get("implicit", 1))          # (a child process of its own: nothing to restore)
         import torch.nn.functional as F
         from acm_gnn_amd import GCN, data as D, distributed as DD
         adj, x_np, y_np, (tr, _, _), _ = D.synthetic_dataset("tiny", seed=5, pad_to=world)
@@ -249,7 +250,7 @@ def _worker(rank, world, port, cfg, ret):
                               "4-ranks-work-plan-sgc-3hop", "acmgcnpp-dropout", "4-ranks-work-plan-acmgcnpp",
                               "acmii-recompute-dropout-xfull", "acmii-recompute-struct-work-plan",
                               "8-ranks-work-plan-struct-dropout", "8-ranks-work-plan-sgc-3hop", "8-ranks-equal-blocks-xfull"])
-def test_row_shard_equals_single_process(cfg, monkeypatch):
+def test_row_shard_equals_single_process(cfg, monkeypatch, tune):
     """world_size = 2, 4 and 8 (the node's GPU count) over gloo: the sharded forward/backward (halo all-gathers + parameter-gradient
     all-reduce issued by functional.AcmConvFunction) must reproduce the 1-process result -- with equal blocks and
     with the work-balanced plan (blocks of different lengths, padded halo numbering)."""
@@ -280,7 +281,7 @@ def test_row_shard_equals_single_process(cfg, monkeypatch):
         assert p.exitcode == 0
     # single-process reference through the same host stack
     fake_lib.install(monkeypatch)
-    monkeypatch.setenv("ACM_IMPLICIT", "0")                   # the single-process reference keeps explicit values
+    tune(implicit=0)                   # the single-process reference keeps explicit values
     from acm_gnn_amd import GCN, data as D, distributed as DD
     adj, x_np, y_np, (tr, _, _), _ = D.synthetic_dataset("tiny", seed=5, pad_to=world)
     if cfg.get("plan") == "work":
@@ -352,7 +353,7 @@ def _train_worker(rank, world, port, cfg, ret):
         import acm_gnn_amd
         from acm_gnn_amd import GCN, data as D, distributed as DD, functional as AF, train as T
         if cfg.get("pipeline"):
-            os.environ["ACM_PIPELINE_MIN_ROWS"] = "32"
+            acm_gnn_amd.tuning.HOST.pipeline = 32                    # (a child process of its own: nothing to restore)
         adj, x_np, y_np, tr = _train_dataset(cfg, world)
         low, deg = D.build_filters(adj)
         n = adj.shape[0]

@@ -41,10 +41,10 @@ def test_single_gpu_command_line():
 
 
 def test_torchrun_launch_with_collectives_in_the_captured_step():
-    env = dict(os.environ, ACM_FORCE_SHARDED="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
     d = _run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
               "--master-port", str(_free_port()), "bench.py", "--gpus", "1", "--steps", "10", "--warmup", "3",
-              "--no-cpu-baseline"], env)
+              "--no-cpu-baseline", "--force-sharded"], env)
     assert KEYS <= set(d) and d["config"]["checked"] is True
     assert d["config"]["launch"].startswith("hipGraph"), d["config"]["launch"]
     assert d["config"]["shard"]["work_max_over_mean"] <= 1.05

@@ -58,10 +58,10 @@ CASES = [("acmgcnp", 0, 0, True, 7, 64, False, True),      # aggregate-first, gr
 
 
 @pytest.mark.parametrize("model_type,variant,s,ln,f_in,f_out,x_grad,agg", CASES)
-def test_layer_with_in_register_dropout_matches_oracle(model_type, variant, s, ln, f_in, f_out, x_grad, agg, monkeypatch):
+def test_layer_with_in_register_dropout_matches_oracle(model_type, variant, s, ln, f_in, f_out, x_grad, agg, monkeypatch, tune):
     from acm_gnn_amd import GraphConvolution, functional as AF
     from acm_gnn_amd.graph import clear_cache
-    monkeypatch.setenv("ACM_AGG_FIRST", "1" if agg else "0")
+    tune(agg_first=int(bool(agg)))
     clear_cache()
     rng = np.random.default_rng(3)
     n, p = 500, 0.35

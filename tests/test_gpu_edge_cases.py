@@ -4,6 +4,7 @@ empty graph handle.  Each case is checked against the oracle, forward and backwa
 where they apply."""
 import numpy as np
 import pytest
+from conftest import tune_now as tune
 import scipy.sparse as sp
 import torch
 
@@ -16,7 +17,7 @@ DEV = "cuda:0"
 def _check(adj, f_in, f_out, model_type="acmgcnp", s=0, variant=0, x_grad=True, monkeypatch=None, agg=False):
     from acm_gnn_amd import GraphConvolution
     from acm_gnn_amd.graph import clear_cache
-    monkeypatch.setenv("ACM_AGG_FIRST", "1" if agg else "0")
+    tune(agg_first=int(bool(agg)))
     clear_cache()
     n = adj.shape[0]
     low, high, un = O.filters_linkx(sp.csr_matrix(adj))
@@ -69,12 +70,12 @@ def test_one_feature_one_class(monkeypatch):
 
 @pytest.mark.parametrize("chunk", [0, 256, 1024])
 @pytest.mark.parametrize("n", [300, 1025, 3000])
-def test_star_and_chunk_boundaries(n, chunk, monkeypatch):
+def test_star_and_chunk_boundaries(n, chunk, monkeypatch, tune):
     """Node 0 is connected to everybody (a row of n entries, split into ceil(n / chunk) work items); a few rows have
     exactly chunk - 1 / chunk / chunk + 1 entries after the +I, for the automatic chunk of a small graph (128) and
     for the chunks larger graphs get (ACM_CHUNK pins them here)."""
     if chunk:
-        monkeypatch.setenv("ACM_CHUNK", str(chunk))
+        tune(chunk=int(chunk))
     a = np.zeros((n, n))
     a[0, 1:] = 1
     a[1:, 0] = 1

@@ -3,6 +3,7 @@ import os
 
 import numpy as np
 import pytest
+from acm_gnn_amd import tuning
 import scipy.sparse as sp
 import torch
 
@@ -101,14 +102,14 @@ def test_proj_fwd_matches_fp64(n, f_in, f, relu):
 
 
 @pytest.mark.parametrize("m,n,k,split", [(1000, 6, 64, 4), (168114, 6, 64, 4), (300, 24, 7, 16), (64, 12, 3000, 8), (5, 3, 2, 2)])
-def test_gemm_two_matrix_output(m, n, k, split, monkeypatch):
+def test_gemm_two_matrix_output(m, n, k, split, monkeypatch, tune):
     """acm_gemm_split: columns [0, split) to one matrix, the rest to another (direct and split-K stores)."""
     from acm_gnn_amd import functional as AF
     g = torch.Generator().manual_seed(m + n + k)
     a, b = torch.randn(m, k, generator=g), torch.randn(k, n, generator=g)
-    monkeypatch.setenv("ACM_GEMM_BX3_OFF", "1")          # the single-output product on the same kernel family (fp32 MFMA chain)
+    tune(gemm_forms=tuning.kernel()["gemm_forms"] & ~6)          # the single-output product on the same kernel family (fp32 MFMA chain)
     whole = AF.gemm(a.to(DEV), b.to(DEV), relu=True)
-    monkeypatch.delenv("ACM_GEMM_BX3_OFF")
+    tune(gemm_forms=tuning.kernel()["gemm_forms"] | 6)
     o1 = torch.full((m, split + 3), 7.0, device=DEV)[:, :split]          # strided destinations keep their padding
     o2 = torch.full((m, n - split), 7.0, device=DEV)
     AF.gemm_split(a.to(DEV), b.to(DEV), o1, o2, relu=True)
@@ -279,12 +280,8 @@ def test_device_filter_construction_is_bit_exact(tmp_path):
     assert back.implicit and torch.equal(back.row_scale, ops.row_scale)
     assert torch.equal(AF.spmm(back.low, x), AF.spmm(ops.low, x)) and torch.equal(back.deg, ops.deg)
     # the pattern-only product, row-scaled, is the explicit one
-    import os
-    os.environ["ACM_IMPLICIT"] = "0"
-    try:
+    with tuning.override(implicit=0):
         expl = G.filters_from_edge_index(ei, n)
-    finally:
-        del os.environ["ACM_IMPLICIT"]
     assert not expl.implicit
     want = AF.spmm(expl.low, x)
     got2 = ops.row_scale[:, None] * AF.spmm(ops.low, x)
@@ -293,14 +290,14 @@ def test_device_filter_construction_is_bit_exact(tmp_path):
 
 @pytest.mark.parametrize("width", [16, 64, 68, 100, 128, 132, 192, 200, 256, 320])
 @pytest.mark.parametrize("mode", ["vec", "scalar"])
-def test_wide_gather_forms_match_scipy(width, mode, monkeypatch):
+def test_wide_gather_forms_match_scipy(width, mode, monkeypatch, tune):
     """The vector form of the wide gather (dwordx4 rows, four neighbours per instruction; spmm_vec_kernel) forced on,
     and the dword-per-lane form, for widths that fill column blocks exactly, partially (no read may leave the row:
     the last table row ends the allocation), and beyond 256 columns (two kernel passes); split hub rows, empty rows,
     pattern-only handles and a non-finite row the operator never references."""
     from acm_gnn_amd import functional as AF
     from acm_gnn_amd.graph import CsrGraph
-    monkeypatch.setenv("ACM_WIDE_VEC" if mode == "vec" else "ACM_WIDE_SCALAR", "1")
+    tune(wide_form=2 if mode == "vec" else 1)
     m = _rand_csr(400, 333, 0.06, seed=width, hub_rows={5: 300, 399: 150}, empty_rows=(0, 17))
     m[:, 332] = 0                                                   # nobody references the last table row ...
     m = sp.csr_matrix(m)
@@ -324,19 +321,19 @@ ROWS_NN = [(9000, 192, 128), (4100, 21, 100), (20000, 15, 64), (168114, 192, 128
 
 
 @pytest.mark.parametrize("m,n,k", ROWS_NN)
-def test_row_panel_gemm_equals_the_tile_kernel_bit_for_bit(m, n, k, monkeypatch):
+def test_row_panel_gemm_equals_the_tile_kernel_bit_for_bit(m, n, k, monkeypatch, tune):
     """acm_gemm_rows.hip (NN): a tall A (>= 4096 rows) takes the row-panel kernel -- A read once, all N columns per
     workgroup.  Both kernels are k-ordered fmaf chains on the fp32 MFMA, so their results are IDENTICAL, ragged shapes and
     the ReLU epilogue included; and integer inputs are exact."""
     from acm_gnn_amd import functional as AF
     g = torch.Generator().manual_seed(m + n + k)
     a, b = torch.randn(m, k, generator=g).to(DEV), torch.randn(k, n, generator=g).to(DEV)
-    monkeypatch.setenv("ACM_GEMM_ROWS_ALWAYS", "1")                   # (by default only the shapes it wins on, or with a dropout)
-    monkeypatch.setenv("ACM_GEMM_BX3_OFF", "1")                       # (K <= 128 otherwise takes the split-bf16 kernels, below)
+    tune(gemm_forms=tuning.kernel()["gemm_forms"] | 8)                   # (by default only the shapes it wins on, or with a dropout)
+    tune(gemm_forms=tuning.kernel()["gemm_forms"] & ~6)                       # (K <= 128 otherwise takes the split-bf16 kernels, below)
     new = AF.gemm(a, b, relu=True)
-    monkeypatch.setenv("ACM_GEMM_ROWS_OFF", "1")
+    tune(gemm_forms=tuning.kernel()["gemm_forms"] & ~9)
     old = AF.gemm(a, b, relu=True)
-    monkeypatch.delenv("ACM_GEMM_ROWS_OFF")
+    tune(gemm_forms=tuning.kernel()["gemm_forms"] | 9)
     assert torch.equal(new, old)
     ai, bi = torch.randint(-8, 9, (m, k), generator=g).float(), torch.randint(-8, 9, (k, n), generator=g).float()
     assert torch.equal(AF.gemm(ai.to(DEV), bi.to(DEV)).cpu(), ai @ bi)
@@ -347,12 +344,11 @@ def test_row_panel_gemm_equals_the_tile_kernel_bit_for_bit(m, n, k, monkeypatch)
 
 @pytest.mark.parametrize("rows,f_in,n,blocks", [(9000, 128, 192, 3), (20001, 100, 15, 3), (168114, 128, 192, 3), (8192, 17, 21, 0),
                                                 (40000, 64, 180, 0)])
-def test_row_panel_transposed_gemm_matches_fp64(rows, f_in, n, blocks):
+def test_row_panel_transposed_gemm_matches_fp64(rows, f_in, n, blocks, tune):
     """acm_gemm_rows.hip (TN): dW = X^T dZ over >= 8192 rows as one K x N slab per workgroup + the deterministic slab sum;
     vs float64, as column blocks too, and bit-identical from launch to launch."""
     from acm_gnn_amd import functional as AF
-    os.environ["ACM_GEMM_ROWS_ALWAYS"] = "1"
-    os.environ["ACM_GEMM_BX3_OFF"] = "1"
+    tune(gemm_forms=9)                                  # row-panel kernels for every shape they cover, no split-bf16
     g = torch.Generator().manual_seed(rows + f_in + n)
     x, dz = torch.randn(rows, f_in, generator=g), torch.randn(rows, n, generator=g)
     ref = x.double().T @ dz.double()
@@ -363,8 +359,6 @@ def test_row_panel_transposed_gemm_matches_fp64(rows, f_in, n, blocks):
     if blocks:
         parts = AF.gemm(x.to(DEV), dz.to(DEV), trans_a=True, col_blocks=blocks)
         assert torch.equal(torch.cat(list(parts), dim=1), got)
-    os.environ.pop("ACM_GEMM_ROWS_ALWAYS", None)
-    os.environ.pop("ACM_GEMM_BX3_OFF", None)
 
 
 def _rel_err(got, a64, b64):
@@ -373,7 +367,7 @@ def _rel_err(got, a64, b64):
 
 @pytest.mark.parametrize("m,n,k", [(9000, 192, 128), (8200, 21, 100), (20000, 15, 64), (168114, 192, 128), (10000, 180, 36),
                                    (8192, 70, 32)])
-def test_split_bf16_projection_keeps_fp32_accuracy(m, n, k, monkeypatch):
+def test_split_bf16_projection_keeps_fp32_accuracy(m, n, k, monkeypatch, tune):
     """acm_gemm_bx3.hip (NN): Z = X W for a tall X of <= 128 columns on the bf16 matrix pipe, every fp32 operand split
     EXACTLY into three bf16 numbers and six of the nine partial products kept: the error against float64 (relative to
     sum |x||w|) stays at the level of the fp32 fmaf chain of the other kernels -- with entries spanning seven orders of
@@ -386,9 +380,9 @@ def test_split_bf16_projection_keeps_fp32_accuracy(m, n, k, monkeypatch):
     a[::5] *= 1e-4
     a, b = a.to(DEV), b.to(DEV)
     new = AF.gemm(a, b)
-    monkeypatch.setenv("ACM_GEMM_BX3_OFF", "1")
+    tune(gemm_forms=tuning.kernel()["gemm_forms"] & ~6)
     old = AF.gemm(a, b)
-    monkeypatch.delenv("ACM_GEMM_BX3_OFF")
+    tune(gemm_forms=tuning.kernel()["gemm_forms"] | 6)
     assert not torch.equal(new, old)                                   # (another kernel did run)
     a64, b64 = a.cpu().double(), b.cpu().double()
     e_new, e_old = _rel_err(new, a64, b64), _rel_err(old, a64, b64)
@@ -403,9 +397,8 @@ def test_split_bf16_projection_keeps_fp32_accuracy(m, n, k, monkeypatch):
 
 
 @pytest.mark.parametrize("rows,f_in,n,blocks", [(9000, 128, 192, 3), (20001, 100, 15, 3), (168114, 128, 192, 3), (8192, 33, 21, 0),
-                                                (40000, 64, 180, 0), (5201, 2089, 192, 3), (4100, 300, 70, 0), (41554, 1030, 21, 3)])
-def test_split_bf16_weight_gradient_keeps_fp32_accuracy(rows, f_in, n, blocks, monkeypatch):
-    monkeypatch.setenv("ACM_GEMM_BX3_WIDE_ROWS", "4096")             # (default 16 384: the wide form on mid-sized inputs too)
+                                                (40000, 64, 180, 0), (16500, 2089, 192, 3), (16400, 300, 70, 0), (41554, 1030, 21, 3)])
+def test_split_bf16_weight_gradient_keeps_fp32_accuracy(rows, f_in, n, blocks, monkeypatch, tune):
     """acm_gemm_bx3.hip (TN): dW = X^T dZ, the contraction over the rows: tiles split while they are staged, operands read
     from LDS as packed row pairs; vs float64 at the fp32 kernels' level, exact on small integers, deterministic, column
     blocks."""
@@ -416,9 +409,9 @@ def test_split_bf16_weight_gradient_keeps_fp32_accuracy(rows, f_in, n, blocks, m
     dz[::11] *= 1e-3
     x, dz = x.to(DEV), dz.to(DEV)
     new = AF.gemm(x, dz, trans_a=True)
-    monkeypatch.setenv("ACM_GEMM_BX3_OFF", "1")
+    tune(gemm_forms=tuning.kernel()["gemm_forms"] & ~6)
     old = AF.gemm(x, dz, trans_a=True)
-    monkeypatch.delenv("ACM_GEMM_BX3_OFF")
+    tune(gemm_forms=tuning.kernel()["gemm_forms"] | 6)
     assert not torch.equal(new, old)
     x64, dz64 = x.cpu().double(), dz.cpu().double()
     e_new, e_old = _rel_err(new, x64.T, dz64), _rel_err(old, x64.T, dz64)
@@ -453,11 +446,8 @@ def test_gemm_with_the_input_dropout_in_the_tile_load(rows, f_in, n):
     ref = xd.cpu().double().T @ dz.cpu().double()
     scale = xd.cpu().abs().double().T @ dz.cpu().abs().double()
     assert float(((dw.cpu().double() - ref).abs() / (scale + 1e-30)).max()) < 3e-6
-    os.environ["ACM_GEMM_ROWS_ALWAYS"] = "1"                            # the same kernel on the dropped copy: identical
-    try:
+    with tuning.override(gemm_forms=tuning.kernel()["gemm_forms"] | 8):     # the same kernel on the dropped copy: identical
         assert torch.equal(dw, AF.gemm(xd, dz, trans_a=True))
-    finally:
-        os.environ.pop("ACM_GEMM_ROWS_ALWAYS", None)
 
 
 @pytest.mark.parametrize("n,k,f,fb,split", [(9000, 128, 64, 64, 0), (9000, 64, 5, 8, 16), (20000, 100, 5, 8, 0), (8192, 32, 2, 2, 4),
@@ -505,9 +495,8 @@ def test_wide_weight_gradient_with_the_dropout_in_the_operand_load():
     with the mask drawn while X is staged equals the product of the dropped copy (Philox block = column mod 16 + 16 * (column
     / 64), any column) bit for bit."""
     from acm_gnn_amd import functional as AF
-    os.environ["ACM_GEMM_BX3_WIDE_ROWS"] = "4096"
     g = torch.Generator().manual_seed(5)
-    rows, f_in, n = 6000, 452, 40
+    rows, f_in, n = 16400, 452, 40                      # (the wide form starts at 16 384 rows)
     x, dz = torch.randn(rows, f_in, generator=g).to(DEV), torch.randn(rows, n, generator=g).to(DEV)
     st = AF.DropoutState(torch.device(DEV), seed=21)
     st.step.fill_(3)
@@ -518,4 +507,3 @@ def test_wide_weight_gradient_with_the_dropout_in_the_operand_load():
     ref = xd.cpu().double().T @ dz.cpu().double()
     scale = xd.cpu().abs().double().T @ dz.cpu().abs().double()
     assert float(((dw.cpu().double() - ref).abs() / (scale + 1e-30)).max()) < 1e-6
-    os.environ.pop("ACM_GEMM_BX3_WIDE_ROWS", None)

@@ -7,7 +7,7 @@ import pytest
 import scipy.sparse as sp
 import torch
 
-from conftest import GOLDEN, load_npz
+from conftest import GOLDEN, load_npz, tune_now as tune
 from oracle import acm_oracle as O
 
 pytestmark = pytest.mark.gpu
@@ -31,8 +31,8 @@ def _run_both(model_type, variant, structure_info, ln, n, f_in, f_out, seed, x_g
               adj=None, chunk_env=None, implicit=True):
     from acm_gnn_amd import GraphConvolution
     from acm_gnn_amd.graph import clear_cache, operators_for
-    monkeypatch.setenv("ACM_AGG_FIRST", "1" if agg else "0")
-    monkeypatch.setenv("ACM_IMPLICIT", "1" if implicit else "0")
+    tune(agg_first=int(bool(agg)))
+    tune(implicit=int(bool(implicit)))
     clear_cache()
     adj = adj if adj is not None else _graph(n, seed)
     n = adj.shape[0]
@@ -104,16 +104,17 @@ def test_aggregate_first_matches_oracle_and_literal(model_type, ln, f_in, f_out,
     assert float((a - b).abs().max()) < 2e-5 * max(1.0, float(b.abs().max()))
 
 
-@pytest.mark.parametrize("form", ["fused-pair", "fused", "two-stage"])
+@pytest.mark.parametrize("form", ["fused", "two-stage", "two-stage-4rows"])
 @pytest.mark.parametrize("f_in,f_out,hub", [(7, 64, True), (3, 16, True), (8, 33, False)])
-def test_aggregate_first_kernel_forms(form, f_in, f_out, hub, monkeypatch):
-    """The three implementations of the three-channel aggregate-first forward -- one kernel with two lanes per
-    neighbour (default for 32-byte rows), one kernel with one lane per neighbour, and gather + epilogue with the
-    long rows' partial sums added by the epilogue -- against the oracle, on a graph with a split hub row."""
-    if form != "fused-pair":
-        monkeypatch.setenv("ACM_AGG_NO_PAIR", "1")
-    if form == "two-stage":
-        monkeypatch.setenv("ACM_AGG_UNFUSED", "1")
+def test_aggregate_first_kernel_forms(form, f_in, f_out, hub, monkeypatch, tune):
+    """The implementations of the three-channel aggregate-first forward -- one kernel (two lanes per neighbour for
+    32-byte rows, one lane per neighbour for 16-byte rows), gather + the sixteen-rows-per-wave row-local stage, and
+    gather + the four-rows-per-wave stage with the long rows' partial sums added by that stage -- against the oracle, on
+    a graph with a split hub row."""
+    if form != "fused":
+        tune(agg_fused=0)
+    if form == "two-stage-4rows":
+        tune(rows16=6)
     adj = _graph(700, 21, density=0.04, hub=hub)
     _run_both("acmgcnp", 0, 0, True, 700, f_in, f_out, 21, False, monkeypatch, agg=True, adj=adj)
     _run_both("acmgcn", 0, 0, False, 700, f_in, f_out, 22, False, monkeypatch, agg=True, adj=adj, implicit=False)
@@ -262,12 +263,12 @@ def test_real_structures(name, f_out, s, monkeypatch):
 
 
 @pytest.mark.parametrize("model_type,variant,s,f_out", [("acmgcn", 0, 0, 64), ("acmgcnp", 1, 1, 64), ("acmgcnp", 0, 0, 5)])
-def test_sparse_feature_projection_matches_dense_path(model_type, variant, s, f_out, monkeypatch):
+def test_sparse_feature_projection_matches_dense_path(model_type, variant, s, f_out, monkeypatch, tune):
     """CSR features (acm_spmm_v forward, transposed handle with src_pos-permuted values backward) vs the
     dense-X GEMM path and vs the oracle, incl. wide F_in and a hub feature column."""
     from acm_gnn_amd import GraphConvolution, SparseFeatures
     from acm_gnn_amd.graph import clear_cache
-    monkeypatch.setenv("ACM_AGG_FIRST", "1")
+    tune(agg_first=1)
     clear_cache()
     n, f_in = 300, 700
     adj = _graph(n, 21)
@@ -458,7 +459,7 @@ def test_snowball_matches_oracle(variant, nlayers, p_drop):
 @pytest.mark.parametrize("model_type,ln,f_in,implicit,s", [("acmgcnp", True, 7, True, 0), ("acmgcn", False, 8, True, 0),
                                                            ("acmgcnp", True, 3, False, 0), ("acmgcnpp", False, 1, True, 0),
                                                            ("acmgcnp", True, 7, True, 1), ("acmgcnpp", False, 5, False, 1)])
-def test_acmii_recompute_on_gather_matches_oracle_and_literal(model_type, ln, f_in, implicit, s, monkeypatch):
+def test_acmii_recompute_on_gather_matches_oracle_and_literal(model_type, ln, f_in, implicit, s, monkeypatch, tune):
     """ACMII first layer with a narrow input (layers.py:94-99): acm_conv_acmii_fwd gathers the 32-byte input rows and
     recomputes relu(x_j [W_L | W_H]) per edge on the matrix pipe; against the oracle (forward, every gradient) and
     against the literal project-then-gather form, on a graph with a split hub row."""
@@ -467,12 +468,12 @@ def test_acmii_recompute_on_gather_matches_oracle_and_literal(model_type, ln, f_
     timer = AF.KernelTimer()
     AF.set_kernel_timer(timer)
     try:
-        monkeypatch.setenv("ACM_ACMII_RECOMPUTE", "1")
+        tune(acmii_recompute=1)
         a = _run_both(model_type, 1, s, ln, 700, f_in, 64, 31, False, monkeypatch, agg=True, adj=adj, implicit=implicit)
         used = set(k.split("/")[0] for k in timer.events)
         assert "conv_acmii_fwd" in used and "conv_fwd" not in used and "conv_bwd_spmm" in used, used
         timer.events.clear()
-        monkeypatch.setenv("ACM_ACMII_RECOMPUTE", "0")
+        tune(acmii_recompute=0)
         b = _run_both(model_type, 1, s, ln, 700, f_in, 64, 31, False, monkeypatch, agg=True, adj=adj, implicit=implicit)
         used = set(k.split("/")[0] for k in timer.events)
         assert "conv_fwd" in used and "conv_acmii_fwd" not in used, used
@@ -483,78 +484,21 @@ def test_acmii_recompute_on_gather_matches_oracle_and_literal(model_type, ln, f_
 
 @pytest.mark.parametrize("model_type,variant,s,f_out", [("acmgcnp", 1, 0, 64), ("acmgcnp", 1, 1, 64), ("acmgcnp", 0, 1, 40),
                                                         ("acmgcn", 1, 0, 130)])
-def test_channel_per_pass_backward_matches_oracle(model_type, variant, s, f_out, monkeypatch):
+def test_channel_per_pass_backward_matches_oracle(model_type, variant, s, f_out, monkeypatch, tune):
     """K4 with one gathered channel per pass (the form large graphs take: acm_conv_bwd_spmm, EpiBwdLow / High / Struc)
     forced on a small graph with a split hub row, against the oracle; and equal to the single-pass form."""
     adj = _graph(600, 41, density=0.04, hub=True)
-    monkeypatch.setenv("ACM_BWD_SPLIT", "1")
+    tune(bwd_split=1)
     a = _run_both(model_type, variant, s, True, 600, 30, f_out, 41, True, monkeypatch, agg=False, adj=adj)
-    monkeypatch.delenv("ACM_BWD_SPLIT")
-    monkeypatch.setenv("ACM_BWD_FUSED", "1")
+    tune(bwd_split=0)
     b = _run_both(model_type, variant, s, True, 600, 30, f_out, 41, True, monkeypatch, agg=False, adj=adj)
     assert float((a - b).abs().max()) < 2e-5 * max(1.0, float(b.abs().max()))
-
-
-@pytest.mark.parametrize("hidden,n_cls,p_drop,chunk", [(64, 2, 0.3, None), (64, 1, 0.0, None), (64, 2, 0.25, "128"),
-                                                        (32, 2, 0.3, None), (64, 3, 0.3, None)])
-def test_next_layer_projection_in_the_hidden_layers_epilogue(hidden, n_cls, p_drop, chunk, monkeypatch):
-    """acm_conv_agg_fwd_t.next_*: the output layer's narrow projection computed in the aggregate-first hidden layer's
-    epilogue (the F = 64 pair kernel carries it; other kernels, e.g. hidden 32, fall back to a launch of acm_proj_fwd
-    inside the same call; three classes are not fused at all) -- training-mode logits and every gradient against the
-    oracle with the counter-based masks replayed, and against the run with the hand-off switched off."""
-    from acm_gnn_amd import GCN, functional as AF
-    from acm_gnn_amd.graph import clear_cache
-    if chunk:
-        monkeypatch.setenv("ACM_CHUNK", chunk)             # the hub row (349 neighbours) becomes window-packed pieces
-    n = 350
-    adj = _graph(n, 21)
-    low, high, _ = O.filters_linkx(adj)
-    g = torch.Generator().manual_seed(2)
-    x = torch.randn(n, 7, generator=g)
-    y = torch.randint(0, max(n_cls, 2), (n,), generator=g).clamp_max(n_cls - 1)
-    idx = torch.arange(0, n, 3)
-    res = {}
-    for mode in ("1", "0"):
-        monkeypatch.setenv("ACM_NEXT_PROJ", mode)
-        clear_cache()
-        torch.manual_seed(4)
-        model = GCN(7, hidden, n_cls, 2, n, p_drop, "acmgcnp", 0, variant=False, attn_layernorm=True)
-        params = {k: v.detach().cpu().clone().requires_grad_(True) for k, v in model.named_parameters()}
-        model = model.to(DEV)
-        masks = None
-        if p_drop:
-            model.fused_dropout, model.dropout_state = True, AF.DropoutState(DEV, seed=7)
-            model.dropout_state.step.fill_(2)
-            st = model.dropout_state
-            masks = {"x": _philox_mask(st, p_drop, 0, n, 7), "hidden": _philox_mask(st, p_drop, 1, n, hidden)}
-        model.train()
-        timer = AF.KernelTimer()
-        AF.set_kernel_timer(timer)
-        out = model(x.to(DEV), low.to(DEV), high.to(DEV), None)
-        AF.set_kernel_timer(None)
-        labels = {k.split("/")[0] for k in timer.events}
-        assert "conv_agg_fwd" in labels
-        assert ("proj_fwd" not in labels) == (mode == "1" and n_cls <= 2), labels
-        loss = torch.nn.functional.nll_loss(torch.log_softmax(out, 1)[idx.to(DEV)], y.to(DEV)[idx.to(DEV)])
-        loss.backward()
-        res[mode] = (out.detach().cpu(), {k: p.grad.cpu() for k, p in model.named_parameters() if p.grad is not None})
-    ref = O.gcn_forward(params, x, low, high, None, model_type="acmgcnp", variant=False, structure_info=0,
-                        attn_layernorm=True, dropout=p_drop, training=True, masks=masks)
-    O.nll_loss_on(ref, y, idx).backward()
-    scale = max(1.0, float(ref.abs().max()))
-    for mode in ("1", "0"):
-        out, grads = res[mode]
-        assert float((out - ref.detach()).abs().max()) < 3e-5 * scale, mode
-        for k, gq in grads.items():
-            rg = params[k].grad
-            assert float((gq - rg).abs().max()) < 1e-4 * max(1.0, float(rg.abs().max())), (mode, k)
-    assert float((res["1"][0] - res["0"][0]).abs().max()) < 1e-5 * scale
 
 
 @pytest.mark.parametrize("n", [5, 400, 4099])
 @pytest.mark.parametrize("model_type,variant,ln,implicit,p_drop", [("acmgcnp", 0, True, True, 0.0), ("acmgcn", 1, False, True, 0.3),
                                                                    ("acmgcnp", 1, True, False, 0.4), ("acmgcnp", 0, True, True, 0.25)])
-def test_sixteen_rows_per_wave_local_backward_equals_the_older_kernel(n, model_type, variant, ln, implicit, p_drop, monkeypatch):
+def test_sixteen_rows_per_wave_local_backward_equals_the_older_kernel(n, model_type, variant, ln, implicit, p_drop, monkeypatch, tune):
     """acm_conv_local16.hip (K3 of the literal layer at F = 64, k = 3: sixteen rows per wave, 16-byte accesses, the head
     recomputed with in-lane sums, the post-op undone by recomputing the mixed row's sign and regenerating the Philox mask)
     against conv_bwd_local_grouped_kernel (ACM_LOCAL16_OFF=1): every gradient of the layer, with and without LayerNorm, both
@@ -562,8 +506,8 @@ def test_sixteen_rows_per_wave_local_backward_equals_the_older_kernel(n, model_t
     multiple of 16 / smaller than one wave step -- and against the oracle for the plain case."""
     from acm_gnn_amd import GraphConvolution, functional as AF
     from acm_gnn_amd.graph import clear_cache
-    monkeypatch.setenv("ACM_AGG_FIRST", "0")
-    monkeypatch.setenv("ACM_IMPLICIT", "1" if implicit else "0")
+    tune(agg_first=0)
+    tune(implicit=int(bool(implicit)))
     adj = _graph(max(n, 4), 11, density=min(0.5, 20.0 / max(n, 4)), hub=n > 10)
     n = adj.shape[0]
     low, high, _ = O.filters_linkx(adj)
@@ -572,9 +516,9 @@ def test_sixteen_rows_per_wave_local_backward_equals_the_older_kernel(n, model_t
 
     def run(off):
         if off:
-            monkeypatch.setenv("ACM_LOCAL16_OFF", "1")
+            tune(rows16=3)
         else:
-            monkeypatch.delenv("ACM_LOCAL16_OFF", raising=False)
+            tune(rows16=7)
         clear_cache()
         torch.manual_seed(2)
         layer = GraphConvolution(24, 64, n, model_type, variant=variant, structure_info=0, attn_layernorm=ln).to(DEV)

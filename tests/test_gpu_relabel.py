@@ -25,7 +25,7 @@ def _graph(n, seed):
 
 @pytest.mark.parametrize("model_type,variant,s,f_in", [("acmgcnp", 0, 0, 7), ("acmgcnp", 0, 1, 7), ("acmgcnp", 1, 1, 7),
                                                        ("acmgcnpp", 1, 0, 40), ("acmsgc", 0, 0, 12)])
-def test_relabelled_operators_give_the_same_results(model_type, variant, s, f_in, monkeypatch):
+def test_relabelled_operators_give_the_same_results(model_type, variant, s, f_in, monkeypatch, tune):
     from acm_gnn_amd import GCN, graph, train as T
     n = 600
     low, high, un = (t.to(DEV) for t in O.filters_linkx(_graph(n, 4)))
@@ -35,7 +35,7 @@ def test_relabelled_operators_give_the_same_results(model_type, variant, s, f_in
     w = T.row_weights(idx, n)
     res = {}
     for mode in ("0", "1"):
-        monkeypatch.setenv("ACM_RELABEL", mode)
+        tune(relabel={"auto": -1}.get(mode, None) if mode == "auto" else int(mode))
         graph.clear_cache()
         ops = graph.operators_for(low, high, un if s else None)
         assert (ops.perm is not None) == (mode == "1")

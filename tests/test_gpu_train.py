@@ -193,17 +193,17 @@ def test_eval_passes_reuse_the_aggregated_input_on_the_gpu(monkeypatch):
         tol = 1e-5 * max(1.0, float(o1.abs().max()))
         assert float((o1 - o2).abs().max()) < tol and torch.equal(o2, o2b)
         assert len(calls) - n1 < n1                     # the layer-1 gather of the input is gone
-        monkeypatch.setenv("ACM_EVAL_AGG_CACHE", "0")
+        for _l in model.gcns: _l.eval_agg_cache = False
         o0 = model(x, ops)
         assert torch.equal(o0, o1)                      # the pass that gathers is unchanged
-        monkeypatch.delenv("ACM_EVAL_AGG_CACHE")
+        for _l in model.gcns: _l.eval_agg_cache = True
         x.add_(0.25)
         o3 = model(x, ops)
         assert float((o3 - o1).abs().max()) > 1e-3
-        monkeypatch.setenv("ACM_EVAL_AGG_CACHE", "0")
+        for _l in model.gcns: _l.eval_agg_cache = False
         assert float((model(x, ops) - o3).abs().max()) < tol
     sets = tuple(torch.from_numpy(s).to(DEV) for s in (tr, va, te))
-    monkeypatch.delenv("ACM_EVAL_AGG_CACHE")
+    for _l in model.gcns: _l.eval_agg_cache = True
     ev_g = T.EvalStep(model, x, ops, y, sets, use_graph=True)
     ev_e = T.EvalStep(model, x, ops, y, sets)
     (og, ag, lg), (oe, ae, le) = ev_g(), ev_e()
@@ -233,14 +233,14 @@ def _pipeline_case(n, avg, seed, relabel=False):
 @pytest.mark.parametrize("use_graph", [False, True], ids=["eager", "graph"])
 @pytest.mark.parametrize("n,avg,model_type", [(3000, 40, "acmgcnp"), (20000, 24, "acmgcnp"), (3000, 40, "acmgcn"),
                                               (3001, 40, "acmgcnp")])          # 3001: degree relabelling inside the operator
-def test_input_pipeline_matches_plain_step(monkeypatch, n, avg, model_type, use_graph):
+def test_input_pipeline_matches_plain_step(monkeypatch, n, avg, model_type, use_graph, tune):
     """TrainStep with the input pipeline (the next step's P = A_low dropout(x) gathered by two extra waves per SIMD of the
     first layer's backward kernel; acm_conv_agg_bwd_t.next_agg, acm_conv_agg_fwd_t.agg_given / agg_copy,
     acm_dropout_t.step_offset) against the plain step: same masks, same losses and parameters up to the summation
     order of the gather; P itself against acm_spmm.  The small case has fewer stream waves than CUs and rows of
     several pieces; the large one is past the default size threshold."""
     from acm_gnn_amd import GCN, FusedAdamW, functional as AF, train as T
-    monkeypatch.setenv("ACM_PIPELINE_MIN_ROWS", "1024")
+    tune(pipeline=1024)
     ops, x, y = _pipeline_case(n, avg, seed=n, relabel=n == 3001)
     assert (ops.perm is not None) == (n == 3001)
     w = T.row_weights(torch.arange(0, n, 3, device=DEV), n)
@@ -270,12 +270,12 @@ def test_input_pipeline_matches_plain_step(monkeypatch, n, avg, model_type, use_
 
 
 @pytest.mark.parametrize("use_graph", [True, False], ids=["graph", "eager"])
-def test_fit_with_the_input_pipeline_equals_fit_without(monkeypatch, use_graph):
+def test_fit_with_the_input_pipeline_equals_fit_without(monkeypatch, use_graph, tune):
     """train.fit (captured training step + captured evaluation pass per epoch) with the input pipeline in its training
     half -- the default -- against pipeline_input=False: the evaluation pass in between neither disturbs the look-ahead
     buffers nor advances the dropout counter; same histories, same selected accuracy."""
     from acm_gnn_amd import GCN, FusedAdamW, functional as AF, train as T
-    monkeypatch.setenv("ACM_PIPELINE_MIN_ROWS", "1024")
+    tune(pipeline=1024)
     n = 6000
     ops, x, y = _pipeline_case(n, 30, seed=11)
     idx = torch.randperm(n, generator=torch.Generator().manual_seed(3)).to(DEV)
@@ -294,31 +294,6 @@ def test_fit_with_the_input_pipeline_equals_fit_without(monkeypatch, use_graph):
     a = np.array([[float(v) for v in h.values()] if isinstance(h, dict) else [float(v) for v in h] for h in hist_a])
     b = np.array([[float(v) for v in h.values()] if isinstance(h, dict) else [float(v) for v in h] for h in hist_b])
     np.testing.assert_allclose(b, a, rtol=5e-3, atol=5e-3)
-
-
-def test_side_stream_for_the_next_table_changes_nothing(monkeypatch):
-    """ACM_PIPE_SIDE_STREAM=1: the next step's table is drawn on a side stream right behind the first layer's forward kernel
-    and joined by the backward that gathers from it -- eager and captured steps equal to the default order bit for bit."""
-    from acm_gnn_amd import GCN, FusedAdamW, functional as AF, train as T
-    monkeypatch.setenv("ACM_PIPELINE_MIN_ROWS", "1024")
-    n = 6000
-    ops, x, y = _pipeline_case(n, 30, seed=13)
-    w = T.row_weights(torch.arange(0, n, 3, device=DEV), n)
-
-    def run(side, use_graph):
-        monkeypatch.setenv("ACM_PIPE_SIDE_STREAM", side)
-        torch.manual_seed(0)
-        model = GCN(7, 64, 2, 2, n, 0.2, "acmgcnp", 0, variant=False, attn_layernorm=True).to(DEV)
-        model.dropout_state = AF.DropoutState(torch.device(DEV), seed=9)
-        step = T.TrainStep(model, FusedAdamW(model.parameters(), lr=0.01), x, ops, y, w, use_graph=use_graph)
-        assert step.pipe is not None and (step.pipe._side is not None) == (side == "1")
-        return [float(step()) for _ in range(6)], [p.detach().clone() for p in model.parameters()]
-
-    for use_graph in (False, True):
-        la, pa = run("0", use_graph)
-        lb, pb = run("1", use_graph)
-        assert la == lb
-        assert all(torch.equal(u, v) for u, v in zip(pa, pb))
 
 
 def test_carried_gather_leaves_the_backward_unchanged():

@@ -10,7 +10,7 @@ import torch
 import torch.nn.functional as F
 
 import fake_lib
-from conftest import GOLDEN, golden_files, graph_tensors, load_npz
+from conftest import GOLDEN, golden_files, graph_tensors, load_npz, tune_now as tune
 
 FWD = dict(rtol=1e-5, atol=1e-5)
 
@@ -83,7 +83,7 @@ def test_model_host_path_against_golden(path, monkeypatch):
             _close(named[k[5:]].grad, v, k)
 
 
-def test_aggregate_first_dispatch_rules(monkeypatch):
+def test_aggregate_first_dispatch_rules(monkeypatch, tune):
     """First-layer shape (F_in = 7 < F = 64, no input gradient) takes the aggregate-first entry
     points, with or without the structure channel; ACMII / differentiable input take the literal ones."""
     fake = fake_lib.install(monkeypatch)
@@ -108,13 +108,13 @@ def test_aggregate_first_dispatch_rules(monkeypatch):
     assert run("acmgcnp", 0, 1, False) == {"acm_conv_agg_fwd", "acm_conv_agg_bwd", "acm_spmm_ex"}
     assert "acm_conv_agg_fwd" not in run("acmgcnp", 0, 0, True)
     assert "acm_conv_agg_fwd" not in run("acmgcnp", 0, 0, False, f_in=64, f_out=2)
-    monkeypatch.setenv("ACM_AGG_FIRST", "0")
+    tune(agg_first=0)
     assert run("acmgcnp", 0, 0, False) == {"acm_gemm", "acm_conv_fwd", "acm_conv_bwd_spmm"}
 
 
 @pytest.mark.parametrize("ln", [False, True])
 @pytest.mark.parametrize("f_in,f_out", [(7, 64), (3, 24), (16, 40)])
-def test_aggregate_first_with_structure_equals_literal_and_oracle(f_in, f_out, ln, monkeypatch):
+def test_aggregate_first_with_structure_equals_literal_and_oracle(f_in, f_out, ln, monkeypatch, tune):
     """ABI v5: the 4-channel aggregate-first path (pre_S = deg * (A_low S) - S, dS = A_low^T (D G_S) - G_S)
     against the literal 3F-wide path and the oracle, forward and every parameter gradient."""
     import sys
@@ -131,7 +131,7 @@ def test_aggregate_first_with_structure_equals_literal_and_oracle(f_in, f_out, l
     mask = (torch.rand(n, f_out) > 0.3).float() / 0.7
 
     def run(agg):
-        monkeypatch.setenv("ACM_AGG_FIRST", "1" if agg else "0")
+        tune(agg_first=int(bool(agg)))
         layer.zero_grad()
         out = layer(x, low, high, un, post_relu=True, post_scale=mask)
         out.backward(go)
@@ -302,7 +302,7 @@ def test_snowball_model_matches_the_reference_wiring(variant, nlayers, monkeypat
 
 
 @pytest.mark.parametrize("f_in,s_info", [(7, 0), (3, 0), (7, 1)])
-def test_acmii_recompute_host_path_equals_literal(f_in, s_info, monkeypatch):
+def test_acmii_recompute_host_path_equals_literal(f_in, s_info, monkeypatch, tune):
     """Host plumbing of the ACMII recompute-on-gather route (functional.AcmConvFunction -> acm_conv_acmii_fwd, then the
     literal backward on the tensors that call saved) against the literal route and the oracle."""
     fake_lib.install(monkeypatch)
@@ -315,7 +315,7 @@ def test_acmii_recompute_host_path_equals_literal(f_in, s_info, monkeypatch):
     x, go = torch.randn(n, f_in, generator=gen), torch.randn(n, 64, generator=gen)
     res = {}
     for mode in ("1", "0"):
-        monkeypatch.setenv("ACM_ACMII_RECOMPUTE", mode)
+        tune(acmii_recompute=int(mode))
         clear_cache()
         torch.manual_seed(3)
         layer = GraphConvolution(f_in, 64, n, "acmgcnp", variant=True, structure_info=s_info, attn_layernorm=True)
@@ -336,7 +336,7 @@ def test_acmii_recompute_host_path_equals_literal(f_in, s_info, monkeypatch):
 
 @pytest.mark.parametrize("model_type,variant,s,sparse_x", [("acmgcnp", 0, 1, False), ("acmgcnp", 1, 0, False),
                                                            ("acmgcnpp", 0, 0, True), ("acmsnowball", 1, 0, False)])
-def test_in_operator_relabelling_is_transparent(model_type, variant, s, sparse_x, monkeypatch):
+def test_in_operator_relabelling_is_transparent(model_type, variant, s, sparse_x, monkeypatch, tune):
     """graph.relabel_by_degree: the operators live in a degree-sorted numbering, layers / GCN / TrainStep translate rows
     at the boundary -- logits, attention weights and every gradient (struc_low included) equal the un-relabelled run."""
     fake_lib.install(monkeypatch)
@@ -349,7 +349,7 @@ def test_in_operator_relabelling_is_transparent(model_type, variant, s, sparse_x
     w = T.row_weights(torch.arange(0, n, 2), n)
     res = {}
     for mode in ("0", "1"):
-        monkeypatch.setenv("ACM_RELABEL", mode)
+        tune(relabel={"auto": -1}.get(mode, None) if mode == "auto" else int(mode))
         graph.clear_cache()
         ops = graph.operators_for(low, high, un if s else None)
         assert (ops.perm is not None) == (mode == "1")
@@ -524,7 +524,7 @@ def _khop_chain_case(dev, hops, f_out, implicit, monkeypatch):
     from oracle import acm_oracle as O
     from acm_gnn_amd import GraphConvolution
     from acm_gnn_amd.graph import clear_cache, operators_for
-    monkeypatch.setenv("ACM_IMPLICIT", "1" if implicit else "0")
+    tune(implicit=int(bool(implicit)))
     clear_cache()
     low, high, un, g = graph_tensors("geometric")
     n = low.shape[0]
@@ -605,46 +605,43 @@ def test_bf16_gather_option_host_path(monkeypatch):
         GraphConvolution(20, 64, n, "acmgcn", gather_dtype="fp8")._config()
 
 
-@pytest.mark.parametrize("fused_dropout", [False, True])
 @pytest.mark.parametrize("n_cls", [1, 2, 3])
-def test_next_layer_projection_rides_the_hidden_layers_epilogue(n_cls, fused_dropout, monkeypatch):
-    """models.GCN names the output layer while it calls the hidden one; an aggregate-first hidden layer then carries the
-    output layer's narrow projection (acm_conv_agg_fwd_t.next_*) and the output layer does not launch acm_proj_fwd --
-    for F' <= 2 only, and with results and gradients equal to the separate launch."""
+def test_next_layer_projection_rides_the_row_local_stage(n_cls, monkeypatch, tune):
+    """models.GCN names the output layer while it calls the hidden one; where the hidden layer's row-local stage runs as
+    its own kernel (P = A_low X given: here the second evaluation pass over an unmodified input; in training the input
+    pipeline) it carries the output layer's narrow projection (acm_conv_agg_fwd_t.next_*) and the output layer does not
+    launch acm_proj_fwd -- for F' <= 2 only, with the same logits; the fused gather kernel never carries it."""
     fake = fake_lib.install(monkeypatch)
-    from acm_gnn_amd import GCN, functional as AF
+    from acm_gnn_amd import GCN
     low, high, un, _ = graph_tensors("geometric")
     n = low.shape[0]
     calls = []
     for name in ("acm_proj_fwd_at", "acm_conv_agg_fwd"):
         orig = getattr(fake, name)
-        monkeypatch.setattr(fake, name, (lambda o, nm: lambda *a: (calls.append(nm), o(*a))[1])(orig, name))
-    x = torch.randn(n, 7, generator=torch.Generator().manual_seed(1))
-
-    def run(env):
-        monkeypatch.setenv("ACM_NEXT_PROJ", env)
-        calls.clear()
-        torch.manual_seed(5)
-        model = GCN(7, 64, n_cls, 2, n, 0.3, "acmgcnp", 0, variant=0, attn_layernorm=True)
-        model.fused_dropout = fused_dropout
-        model.train()
-        if fused_dropout:
-            model.dropout_state = AF.DropoutState(torch.device("cpu"), seed=9)
+        if name == "acm_conv_agg_fwd":
+            monkeypatch.setattr(fake, name, (lambda o: lambda h, pp, *a: (calls.append(("agg", int(pp._obj.agg_given), int(pp._obj.next_f))), o(h, pp, *a))[1])(orig))
         else:
-            torch.manual_seed(11)                          # the F.dropout masks
-        out = model(x, low, high)
-        out.square().sum().backward()
-        assert AF._ambient().next_proj is None and AF._ambient().pre_proj is None
-        return out.detach(), {k: p.grad.clone() for k, p in model.named_parameters() if p.grad is not None}, list(calls)
-
-    out_f, g_f, calls_f = run("1")
-    out_s, g_s, calls_s = run("0")
-    assert "acm_proj_fwd_at" in calls_s
-    assert ("acm_proj_fwd_at" not in calls_f) == (n_cls <= 2)
-    np.testing.assert_allclose(out_f.numpy(), out_s.numpy(), rtol=1e-5, atol=1e-5 * max(1.0, float(out_s.abs().max())))
-    for k in g_s:
-        np.testing.assert_allclose(g_f[k].numpy(), g_s[k].numpy(), err_msg=k, rtol=1e-4,
-                                   atol=5e-5 * max(1.0, float(g_s[k].abs().max())))
+            monkeypatch.setattr(fake, name, (lambda o, nm: lambda *a: (calls.append(nm), o(*a))[1])(orig, name))
+    x = torch.randn(n, 7, generator=torch.Generator().manual_seed(1))
+    torch.manual_seed(5)
+    model = GCN(7, 64, n_cls, 2, n, 0.3, "acmgcnp", 0, variant=0, attn_layernorm=True)
+    model.eval()
+    with torch.no_grad():
+        o1 = model(x, low, high)
+        first = list(calls)
+        calls.clear()
+        o2 = model(x, low, high)
+        second = list(calls)
+        tune(rows16=6)                                 # without the sixteen-rows-per-wave stage nothing carries it
+        calls.clear()
+        o3 = model(x, low, high)
+        third = list(calls)
+    assert first[0] == ("agg", 0, 0) and "acm_proj_fwd_at" in first
+    assert second[0][:2] == ("agg", 1) and (second[0][2] == n_cls) == (n_cls <= 2)
+    assert ("acm_proj_fwd_at" not in second) == (n_cls <= 2)
+    assert third[0] == ("agg", 1, 0) and "acm_proj_fwd_at" in third
+    for o in (o2, o3):
+        np.testing.assert_allclose(o.numpy(), o1.numpy(), rtol=1e-5, atol=1e-5 * max(1.0, float(o1.abs().max())))
 
 
 def test_eval_step_equals_evaluate(monkeypatch):
@@ -700,7 +697,7 @@ def test_eval_passes_reuse_the_aggregated_input(monkeypatch):
     with torch.no_grad():
         model(x, low, high)
     assert given[-2:] == [0, 0]
-    monkeypatch.setenv("ACM_EVAL_AGG_CACHE", "0")
+    for _l in model.gcns: _l.eval_agg_cache = False
     model.eval()
     with torch.no_grad():
         model(x, low, high), model(x, low, high)
@@ -723,13 +720,13 @@ def _dense_graph_ops(n=160, avg=20, seed=5):
     return make_sharded_operators(low, deg, torch.device("cpu")), n
 
 
-def test_input_pipeline_equals_plain_train_step(monkeypatch):
+def test_input_pipeline_equals_plain_train_step(monkeypatch, tune):
     """train.TrainStep with the input pipeline (functional.InputPipeline: the first layer's P = A_low dropout(x) of step
     t + 1 gathered inside the layer's backward of step t, acm_conv_agg_bwd_t.next_agg / acm_dropout_t.step_offset)
     against the plain step: same losses and parameters; the forward runs with agg_given, every backward carries the
     gather, prime() runs once."""
     fake = fake_lib.install(monkeypatch)
-    monkeypatch.setenv("ACM_PIPELINE_MIN_ROWS", "32")
+    tune(pipeline=32)
     from acm_gnn_amd import GCN, FusedAdamW, functional as AF, train as T
     ops, n = _dense_graph_ops()
     x, y = torch.randn(n, 7, generator=torch.Generator().manual_seed(1)), torch.randint(0, 2, (n,), generator=torch.Generator().manual_seed(2))
@@ -771,12 +768,12 @@ def test_input_pipeline_equals_plain_train_step(monkeypatch):
     np.testing.assert_allclose(float(step_b()), float(step_a()), rtol=1e-4, atol=1e-6)     # (seven fp32 steps apart by now)
 
 
-def test_input_pipeline_survives_a_redone_step(monkeypatch):
+def test_input_pipeline_survives_a_redone_step(monkeypatch, tune):
     """TrainStep redoes a step without deferred reductions when a gradient was not adopted; by then the first pass has
     refilled the pipeline's buffers for the NEXT step, so the redo must refill them for this one: same losses as the
     plain step."""
     fake_lib.install(monkeypatch)
-    monkeypatch.setenv("ACM_PIPELINE_MIN_ROWS", "32")
+    tune(pipeline=32)
     from acm_gnn_amd import GCN, FusedAdamW, functional as AF, train as T
     ops, n = _dense_graph_ops(seed=9)
     x, y = torch.randn(n, 7, generator=torch.Generator().manual_seed(4)), torch.randint(0, 2, (n,), generator=torch.Generator().manual_seed(5))
@@ -796,7 +793,7 @@ def test_input_pipeline_survives_a_redone_step(monkeypatch):
         if refuse_first:
             monkeypatch.undo()
             fake_lib.install(monkeypatch)
-            monkeypatch.setenv("ACM_PIPELINE_MIN_ROWS", "32")
+            tune(pipeline=32)
             assert not step._defer
         return step, losses
 
@@ -806,11 +803,11 @@ def test_input_pipeline_survives_a_redone_step(monkeypatch):
     np.testing.assert_allclose(redone, plain, rtol=1e-5, atol=1e-6)
 
 
-def test_input_pipeline_notices_steps_made_by_someone_else(monkeypatch):
+def test_input_pipeline_notices_steps_made_by_someone_else(monkeypatch, tune):
     """Two TrainSteps on one model (bench.py keeps an eager and a captured one): when the other one has advanced the
     dropout counter, the pipelined step's look-ahead buffers belong to a past step -- DropoutState.host_steps tells."""
     fake_lib.install(monkeypatch)
-    monkeypatch.setenv("ACM_PIPELINE_MIN_ROWS", "32")
+    tune(pipeline=32)
     from acm_gnn_amd import GCN, FusedAdamW, functional as AF, train as T
     ops, n = _dense_graph_ops(seed=13)
     x, y = torch.randn(n, 7, generator=torch.Generator().manual_seed(6)), torch.randint(0, 2, (n,), generator=torch.Generator().manual_seed(7))
@@ -852,13 +849,13 @@ def _two_step_setups(n, ops):
     return make
 
 
-def test_two_train_steps_interleaved_equal_running_them_apart(monkeypatch):
+def test_two_train_steps_interleaved_equal_running_them_apart(monkeypatch, tune):
     """The per-call context (functional.CallContext: deferral list, loss-tail request, input pipeline, projection
     hand-off) travels with each model call: two TrainSteps of different models stepped alternately -- and with the forward
     of one between the forward and the backward of the other -- give exactly the losses and parameters of the two run
     one after the other."""
     fake_lib.install(monkeypatch)
-    monkeypatch.setenv("ACM_PIPELINE_MIN_ROWS", "32")
+    tune(pipeline=32)
     from acm_gnn_amd import functional as AF
     ops, n = _dense_graph_ops(seed=5)
     make = _two_step_setups(n, ops)
@@ -898,9 +895,9 @@ def test_two_train_steps_interleaved_equal_running_them_apart(monkeypatch):
     assert AF._ambient().defer is None and AF._ambient().tail is None and AF._ambient().pipe is None
 
 
-def test_two_train_steps_in_threads_equal_running_them_apart(monkeypatch):
+def test_two_train_steps_in_threads_equal_running_them_apart(monkeypatch, tune):
     fake_lib.install(monkeypatch)
-    monkeypatch.setenv("ACM_PIPELINE_MIN_ROWS", "32")
+    tune(pipeline=32)
     import threading
     ops, n = _dense_graph_ops(seed=6)
     make = _two_step_setups(n, ops)
@@ -930,11 +927,11 @@ def test_two_train_steps_in_threads_equal_running_them_apart(monkeypatch):
     assert got[0] == apart[0] and got[1] == apart[1]
 
 
-def test_pipeline_is_not_refilled_when_the_forward_did_not_adopt_it(monkeypatch):
+def test_pipeline_is_not_refilled_when_the_forward_did_not_adopt_it(monkeypatch, tune):
     """make_next() must not overwrite the pipeline's table when the layer went another way (here
     ACM_AGG_FIRST=0: the literal path saves the table itself for dW): the step then equals the plain step."""
     fake_lib.install(monkeypatch)
-    monkeypatch.setenv("ACM_PIPELINE_MIN_ROWS", "32")
+    tune(pipeline=32)
     from acm_gnn_amd import GCN, FusedAdamW, functional as AF, train as T
     ops, n = _dense_graph_ops(seed=7)
     x, y = torch.randn(n, 7, generator=torch.Generator().manual_seed(1)), torch.randint(0, 2, (n,), generator=torch.Generator().manual_seed(2))
@@ -948,9 +945,9 @@ def test_pipeline_is_not_refilled_when_the_forward_did_not_adopt_it(monkeypatch)
                            pipeline_input=pipeline)
         if pipeline is None:
             assert step.pipe is not None
-        monkeypatch.setenv("ACM_AGG_FIRST", "0")               # after eligibility was decided: the layer now goes the literal way
+        tune(agg_first=0)               # after eligibility was decided: the layer now goes the literal way
         out = [float(step()) for _ in range(3)]
-        monkeypatch.delenv("ACM_AGG_FIRST")
+        tune(agg_first=1)
         return out
 
     np.testing.assert_allclose(run(None), run(False), rtol=1e-5, atol=1e-6)
@@ -960,9 +957,10 @@ def test_pipeline_is_not_refilled_when_the_forward_did_not_adopt_it(monkeypatch)
 def test_output_layer_projection_backward_rides_the_hidden_layers_backward(monkeypatch, fused_dropout):
     """acm_conv_agg_bwd_t.proj_* (ABI 20): in the two-layer models the output layer's dX = dZ Wcat^T and dW = X^T dZ are
     left to the hidden layer's row-local backward kernel -- models.GCN vouches that the hidden activations feed nothing
-    else (CallContext.hidden_private) -- so acm_proj_bwd is not launched and the [n, 64] gradient never exists.  Same
-    gradients as with ACM_LAZY_DX=0; a model whose hidden tensor is not private (ACM-GCN++: the residual is added in
-    between) keeps the two launches."""
+    else (CallContext.hidden_private) -- so acm_proj_bwd is not launched and the [n, 64] gradient never exists.  ONLY under
+    a deferral list (the contract "every .grad is undefined until the flush": ADVICE r03 -- without one, autograd may
+    accumulate the still unwritten dW' into an existing .grad); same gradients as the plain call; a model whose hidden
+    tensor is not private (ACM-GCN++: the residual is added in between) keeps the two launches."""
     fake = fake_lib.install(monkeypatch)
     from acm_gnn_amd import GCN, functional as AF
     ops, n = _dense_graph_ops(seed=3)
@@ -976,7 +974,6 @@ def test_output_layer_projection_backward_rides_the_hidden_layers_backward(monke
             monkeypatch.setattr(fake, name, (lambda o: lambda *a: (calls.append("proj_bwd"), o(*a))[1])(orig))
 
     def run(model_type, lazy):
-        monkeypatch.setenv("ACM_LAZY_DX", "1" if lazy else "0")
         calls.clear()
         torch.manual_seed(5)
         model = GCN(7, 64, 2, 2, n, 0.3, model_type, 0, variant=0, attn_layernorm=True)
@@ -985,8 +982,14 @@ def test_output_layer_projection_backward_rides_the_hidden_layers_backward(monke
             model.fused_dropout, model.dropout_state = True, AF.DropoutState(torch.device("cpu"), seed=9)
         else:
             torch.manual_seed(11)
-        out = model(x, ops)
-        out.square().sum().backward()
+        if lazy:                                       # the loop owns the step: defer, backward, flush, then read
+            with AF.deferred_reductions() as pending:
+                out = model(x, ops)
+                out.square().sum().backward()
+                assert pending.all_adopted([p.grad for p in model.parameters()])
+        else:
+            out = model(x, ops)
+            out.square().sum().backward()
         return out.detach(), {k: p.grad.clone() for k, p in model.named_parameters() if p.grad is not None}, list(calls)
 
     out_a, g_a, calls_a = run("acmgcnp", True)
@@ -1002,12 +1005,81 @@ def test_output_layer_projection_backward_rides_the_hidden_layers_backward(monke
     assert "agg_bwd+proj" not in calls_c and "proj_bwd" in calls_c, calls_c
 
 
+def test_plain_backward_into_existing_grads_accumulates_finished_values(monkeypatch):
+    """with ``zero_grad(set_to_none=False)`` / gradient accumulation autograd ADDS what the output
+    layer's backward returns to the existing ``.grad`` right behind that node -- so outside a deferral list the layer must
+    return finished dW' (acm_proj_bwd), never views the hidden layer's kernel fills later.  Two backward passes into
+    pre-zeroed grads equal twice the single-pass gradient; torch.autograd.grad on the output layer's weights alone (the
+    hidden layer's backward never runs) is finite and equal too."""
+    fake_lib.install(monkeypatch)
+    from acm_gnn_amd import GCN, functional as AF
+    ops, n = _dense_graph_ops(seed=3)
+    x = torch.randn(n, 7, generator=torch.Generator().manual_seed(1))
+    torch.manual_seed(5)
+    model = GCN(7, 64, 2, 2, n, 0.3, "acmgcnp", 0, variant=0, attn_layernorm=True)
+    model.train()
+    model.fused_dropout, model.dropout_state = True, AF.DropoutState(torch.device("cpu"), seed=9)
+    model(x, ops).square().sum().backward()
+    once = {k: p.grad.clone() for k, p in model.named_parameters() if p.grad is not None}
+    for p in model.parameters():
+        if p.grad is not None:
+            p.grad.zero_()                              # zero_grad(set_to_none=False)
+    for _ in range(2):
+        model(x, ops).square().sum().backward()
+    for k, p in model.named_parameters():
+        if p.grad is not None:
+            assert torch.isfinite(p.grad).all(), k
+            torch.testing.assert_close(p.grad, 2 * once[k], rtol=1e-5, atol=1e-6, msg=lambda m, k=k: f"{k}: {m}")
+    w2 = [model.gcns[1].weight_low, model.gcns[1].weight_high, model.gcns[1].weight_mlp]
+    g2 = torch.autograd.grad(model(x, ops).square().sum(), w2)
+    for g, w, nm in zip(g2, w2, ("weight_low", "weight_high", "weight_mlp")):
+        torch.testing.assert_close(g, once[f"gcns.1.{nm}"], rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.parametrize("f_in,forms", [(20, 7), (128, 5), (128, 0)])
+def test_input_dropout_of_the_khop_layer_is_never_lost(monkeypatch, tune, f_in, forms):
+    """models.GCN leaves the input dropout to the first layer (in_drop) whenever the dense projection
+    CAN draw the mask in its operand load -- but the k-hop layer (acmsgc, hops = 3) projects into two tables, and when
+    acm_proj3 declines (fewer than 32 features; the split-bf16 kernels switched off) that path has no dropout in the load:
+    the layer then applies acm_dropout itself.  Output and gradients equal the run with the dropped input handed in."""
+    fake = fake_lib.install(monkeypatch)
+    from acm_gnn_amd import GCN, functional as AF
+    tune(gemm_forms=forms)
+    ops, n = _dense_graph_ops(n=8192, avg=14, seed=2)
+    ops.hops = 3
+    x = torch.randn(n, f_in, generator=torch.Generator().manual_seed(1))
+    calls = []
+    for name in ("acm_gemm_drop", "acm_proj3", "acm_dropout"):
+        orig = getattr(fake, name)
+        monkeypatch.setattr(fake, name, (lambda o, nm: lambda *a: (calls.append(nm), o(*a))[1])(orig, name))
+    def run(layer_takes_it):
+        if not layer_takes_it:                          # the model then applies acm_dropout itself and hands the dropped x down
+            monkeypatch.setattr(AF, "in_drop_supported", lambda *a, **k: False)
+        calls.clear()
+        torch.manual_seed(5)
+        model = GCN(f_in, 64, 5, 2, n, 0.4, "acmsgc", 0, variant=0, attn_layernorm=True)
+        model.train()
+        model.fused_dropout, model.dropout_state = True, AF.DropoutState(torch.device("cpu"), seed=9)
+        out = model(x, ops)
+        out.square().sum().backward()
+        return out.detach(), {k: p.grad.clone() for k, p in model.named_parameters() if p.grad is not None}, list(calls)
+
+    out_a, g_a, calls_a = run(True)
+    out_b, g_b, calls_b = run(False)
+    assert calls_a.count("acm_dropout") == 1 and calls_b.count("acm_dropout") == 1, (calls_a, calls_b)    # never lost, never twice
+    assert "acm_gemm_drop" not in calls_a
+    torch.testing.assert_close(out_a, out_b, rtol=1e-6, atol=1e-6 * float(out_b.abs().max()))
+    assert g_a.keys() == g_b.keys()
+    for k in g_a:
+        torch.testing.assert_close(g_a[k], g_b[k], rtol=1e-5, atol=1e-5 * float(g_b[k].abs().max()), msg=lambda m, k=k: f"{k}: {m}")
+
+
 @pytest.mark.parametrize("model_type,hops", [("acmgcnp", 1), ("acmsgc", 3)])
-def test_input_dropout_rides_the_dense_projection(monkeypatch, model_type, hops):
+def test_input_dropout_rides_the_dense_projection(monkeypatch, model_type, hops, tune):
     """acm_proj3 (ABI 21) / acm_gemm_drop (ABI 20): for a wide dense input the first layer's projection Z = drop(X) W -- the
     three weight matrices read in place, no torch.cat -- and its backward dW = drop(X)^T dZ draw the input-dropout mask while
     they load X (ACM-Geometric/models.py:54 + layers.py:86-88), so the separate acm_dropout pass and the dropped copy of X
-    disappear; same loss and gradients as with ACM_GEMM_DROP=0."""
+    disappear; same loss and gradients as without the row-panel kernels (acm_tuning_t.gemm_forms bit 1 cleared)."""
     fake = fake_lib.install(monkeypatch)
     from acm_gnn_amd import GCN, functional as AF
     ops, n = _dense_graph_ops(n=8192, avg=14, seed=2)
@@ -1019,7 +1091,8 @@ def test_input_dropout_rides_the_dense_projection(monkeypatch, model_type, hops)
         monkeypatch.setattr(fake, name, (lambda o, nm: lambda *a: (calls.append(nm), o(*a))[1])(orig, name))
 
     def run(fused):
-        monkeypatch.setenv("ACM_GEMM_DROP", "1" if fused else "0")
+        if not fused:
+            tune(gemm_forms=6)                         # no row-panel kernels: no dropout in the operand loads either
         calls.clear()
         torch.manual_seed(5)
         model = GCN(128, 64, 5, 2, n, 0.4, model_type, 0, variant=0, attn_layernorm=True)

@@ -69,7 +69,7 @@ def test_detection_rejects_what_it_must():
 @pytest.mark.parametrize("model_type,variant,s,x_grad,f_in,f_out", [
     ("acmgcnp", 0, 1, False, 7, 64), ("acmgcnp", 0, 0, False, 7, 64), ("acmgcnp", 1, 1, True, 20, 6),
     ("acmgcn", 0, 0, True, 33, 5), ("acmgcnp", 0, 1, True, 12, 64)])
-def test_layer_same_through_either_form(model_type, variant, s, x_grad, f_in, f_out, monkeypatch):
+def test_layer_same_through_either_form(model_type, variant, s, x_grad, f_in, f_out, monkeypatch, tune):
     fake_lib.install(monkeypatch)
     from acm_gnn_amd import GraphConvolution, graph
     low, high, un, _ = graph_tensors("geometric")
@@ -80,7 +80,7 @@ def test_layer_same_through_either_form(model_type, variant, s, x_grad, f_in, f_
     go = torch.randn(n, f_out)
     res = {}
     for mode in ("1", "0"):
-        monkeypatch.setenv("ACM_IMPLICIT", mode)
+        tune(implicit=int(mode))
         graph.clear_cache()
         ops = graph.operators_for(low, high, un if s else None)
         assert ops.implicit == (mode == "1")
