@@ -75,7 +75,31 @@ def build_library(force=False, verbose=False):
     if res.returncode != 0:
         raise RuntimeError("link failed:\n" + res.stdout.decode(errors="replace"))
     os.replace(tmp, LIB_PATH)
+    _build_agpr_variant(hipcc, flags, objs, verbose)
     return LIB_PATH
+
+
+# The same library with acm_conv_acmii.hip compiled WITHOUT -amdgpu-mfma-vgpr-form (MFMA results in AGPRs, copied out by
+# v_accvgpr_read): tests/test_gpu_mfma_forms.py requires bit-identical conv_acmii_fwd output from both builds -- the
+# arithmetic is the same, so any difference is a register hazard (round 3 saw one with inline assembly reading MFMA
+# results; the reads are builtins now).  Test infrastructure: nothing loads it unless ACM_HIP_LIBRARY names it.
+VARIANT_PATH = os.path.join(LIB_DIR, "libacm_hip_acmii_agpr.so")
+
+
+def _build_agpr_variant(hipcc, flags, objs, verbose=False):
+    src = "acm_conv_acmii.hip"
+    obj = os.path.join(LIB_DIR, "acm_conv_acmii.agpr.o")
+    cmd = [hipcc] + flags + ["-c", os.path.join(CSRC, src), "-o", obj]
+    res = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+    if res.returncode != 0:
+        raise RuntimeError(f"hipcc failed on {src} (AGPR variant):\n{res.stdout.decode(errors='replace')}")
+    std = os.path.join(LIB_DIR, "acm_conv_acmii.o")
+    tmp = VARIANT_PATH + ".tmp"
+    cmd = [hipcc, f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", tmp] + [obj if o == std else o for o in objs]
+    res = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+    if res.returncode != 0:
+        raise RuntimeError("link failed (AGPR variant):\n" + res.stdout.decode(errors="replace"))
+    os.replace(tmp, VARIANT_PATH)
 
 
 if __name__ == "__main__":

@@ -128,9 +128,12 @@ def test_acm_tuning_variable_is_read_once_at_load(tmp_path):
     out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, check=True)
     assert out.stdout.split() == ["5", "1", "0", "2", "0", "-1"], (out.stdout, out.stderr)
     env["ACM_TUNING"] = "rows16=9,nonsense=1"
-    out = subprocess.run([sys.executable, "-c", "import ctypes as C\nfrom acm_gnn_amd import _lib\n_lib.load()"], env=env,
-                         capture_output=True, text=True)
+    from acm_gnn_amd import _lib
+    out = subprocess.run([sys.executable, "-c", f"import ctypes\nctypes.CDLL({_lib.library_path()!r})"], env=env,
+                         capture_output=True, text=True)                   # the library alone: reports and ignores the items
     assert "bad value 'rows16=9'" in out.stderr and "unknown key 'nonsense'" in out.stderr, out.stderr
+    out = subprocess.run([sys.executable, "-c", "import acm_gnn_amd"], env=env, capture_output=True, text=True)
+    assert out.returncode != 0 and "unknown key 'nonsense'" in out.stderr   # the package refuses to start with it
     from acm_gnn_amd import tuning
     with pytest.raises(ValueError):
         tuning.parse("nonsense=1")

@@ -1,0 +1,198 @@
+"""The reference's own ACM-Geometric code, UNMODIFIED, on this package's GraphConvolution / MLP through the drop-in shim
+(north_star: "both train.py scripts run unmodified"; ACM-Pytorch's twin is test_dropin_reference_script_cpu.py).
+
+  * ``models.GCN`` and ``parse.parse_method`` (ACM-Geometric/models.py:23-76, parse.py:3-13) imported from the reference
+    checkout with ``layers`` shadowed by ``dropin.install("geometric")``: forward + loss + backward for the six recorded
+    2-layer cases (tests/golden/model_geometric_*.npz -- written by tests/golden/make_golden.py from the reference's OWN
+    layer) must reproduce the recorded logits and parameter gradients;
+  * ``train.py`` itself (ACM-Geometric/train.py:19-183) for a few epochs on a 500-node graph, fed by stub ``dataset`` /
+    ``torch_geometric.utils`` modules (the LINKX loaders are out of scope) while ``parse``, ``data_utils``
+    (eval_acc, evaluate_acmgcn), ``utils`` (normalize_tensor, the COO conversion) and ``logger`` are the reference's.
+
+Only possible where the reference checkout exists (the build container); the kernels are the numpy test double of the
+ABI because there is no GPU here -- what is exercised is the boundary: import paths, constructor / forward signatures,
+parameter registration with the reference's optimizer, train() / eval() switching, the attributes the scripts read."""
+import os
+import runpy
+import sys
+import types
+
+import numpy as np
+import pytest
+import scipy.sparse as sp
+import torch
+import torch.nn.functional as F
+
+import fake_lib
+from conftest import golden_files, graph_tensors, load_npz
+
+REF = "/root/reference"
+GEO = os.path.join(REF, "ACM-Geometric")
+pytestmark = pytest.mark.skipif(not os.path.isdir(GEO), reason="reference checkout not present (GPU box)")
+
+REF_MODULES = ("layers", "models", "parse", "utils", "logger", "data_utils", "dataset", "load_data")
+STUB_MODULES = ("dgl", "dgl.function", "dgl.utils", "dgl.nn", "dgl.nn.pytorch", "torch_sparse", "google_drive_downloader",
+                "torch_geometric", "torch_geometric.utils", "torch_geometric.utils.convert", "tqdm")
+
+
+@pytest.fixture
+def reference_geometric(monkeypatch):
+    """sys.modules / sys.path prepared the way a user of the drop-in would find them: the third-party packages the
+    reference imports but this image lacks (dgl, torch_sparse: imported by models.py, never used on this path) as empty
+    stand-ins, the reference directory on the path, ``layers`` replaced by the shim.  Everything is restored afterwards."""
+    saved = {k: sys.modules.get(k) for k in REF_MODULES + STUB_MODULES}
+    saved_path = list(sys.path)
+    for m in REF_MODULES:
+        sys.modules.pop(m, None)
+    for m in ("dgl", "dgl.function", "dgl.utils", "dgl.nn", "dgl.nn.pytorch"):
+        sys.modules[m] = types.ModuleType(m)
+    sys.modules["dgl"].function, sys.modules["dgl"].utils = sys.modules["dgl.function"], sys.modules["dgl.utils"]
+    sys.modules["dgl"].nn = sys.modules["dgl.nn"]
+    sys.modules["dgl.nn"].pytorch = sys.modules["dgl.nn.pytorch"]
+    sys.modules["torch_sparse"] = types.SimpleNamespace(SparseTensor=object, matmul=None)
+    sys.modules["google_drive_downloader"] = types.SimpleNamespace(GoogleDriveDownloader=object)
+    if "tqdm" not in sys.modules:
+        try:
+            import tqdm  # noqa: F401
+        except ImportError:
+            sys.modules["tqdm"] = types.ModuleType("tqdm")
+    fake = fake_lib.install(monkeypatch)
+    from acm_gnn_amd import dropin
+    sys.path.insert(0, GEO)
+    shim = dropin.install("geometric")
+    try:
+        yield fake, shim
+    finally:
+        for k, v in saved.items():
+            if v is None:
+                sys.modules.pop(k, None)
+            else:
+                sys.modules[k] = v
+        sys.path[:] = saved_path
+        import acm_gnn_amd.layers as impl
+        impl.DEFAULT_ATTN_LAYERNORM = True
+
+
+def _close(actual, desired, what, rtol=1e-4, atol=5e-5):
+    atol = atol * max(1.0, float(np.abs(desired).max()))
+    np.testing.assert_allclose(actual.detach().numpy(), desired, err_msg=what, rtol=rtol, atol=atol)
+
+
+@pytest.mark.parametrize("path", golden_files("model_geometric_*.npz"), ids=os.path.basename)
+def test_reference_geometric_model_code_runs_on_the_shim(path, reference_geometric, monkeypatch):
+    import acm_gnn_amd
+    import models as ref_models                         # ACM-Geometric/models.py, the reference's own file
+    from parse import parse_method                       # ACM-Geometric/parse.py:3-13
+    assert os.path.samefile(ref_models.__file__, os.path.join(GEO, "models.py"))
+    assert ref_models.GraphConvolution is acm_gnn_amd.GraphConvolution and ref_models.MLP is acm_gnn_amd.MLP
+    rec = load_npz(path)
+    cfg = rec["cfg"]
+    low, high, un, _ = graph_tensors("geometric")
+    n = rec["x"].shape[0]
+    args = types.SimpleNamespace(hidden_channels=cfg["hidden"], num_layers=2, dropout=cfg["dropout"], method=cfg["model_type"],
+                                 structure_info=cfg["structure_info"], variant=cfg["variant"])
+    model = parse_method(args, n, cfg["classes"], cfg["f_in"], torch.device("cpu"))
+    assert type(model) is ref_models.GCN and all(type(layer) is acm_gnn_amd.GraphConvolution for layer in model.gcns)
+    sd = model.state_dict()
+    for k, v in rec.items():
+        if k.startswith("param:"):
+            assert tuple(sd[k[6:]].shape) == tuple(v.shape), k
+            sd[k[6:]].copy_(torch.from_numpy(v))
+    with torch.no_grad():                                # (torch.FloatTensor(1, 1): uninitialised in the reference, unused)
+        model.fea_param.zero_()
+        model.xX_param.zero_()
+    order = ["x"] + (["xX"] if cfg["model_type"] == "acmgcnpp" else []) + ["hidden"]
+    masks = [torch.from_numpy(rec["mask:" + nm].astype(np.float32)) for nm in order if "mask:" + nm in rec]
+
+    def replay(inp, p=0.5, training=True, inplace=False):
+        return inp if (not training or p == 0.0) else inp * masks.pop(0) / (1.0 - p)
+
+    monkeypatch.setattr(F, "dropout", replay)
+    model.train()
+    logits = model(torch.from_numpy(rec["x"]), low, high, un if cfg["structure_info"] else None)
+    idx, labels = torch.from_numpy(rec["train_idx"]), torch.from_numpy(rec["labels"])
+    loss = F.nll_loss(F.log_softmax(logits, dim=1)[idx], labels[idx])
+    loss.backward()
+    _close(logits, rec["logits"], "logits", rtol=1e-5, atol=1e-5)
+    named = dict(model.named_parameters())
+    n_grads = 0
+    for k, v in rec.items():
+        if k.startswith("grad:"):
+            _close(named[k[5:]].grad, v, k)
+            n_grads += 1
+    assert n_grads >= 10
+
+
+def _stub_data_modules(n=500, f=7, classes=2, seed=0):
+    """``dataset`` and ``torch_geometric.utils`` for train.py: a seeded 500-node graph in the shape load_nc_dataset returns
+    (an object with .label, .graph = {edge_index, node_feat, num_nodes} and .get_idx_split: ACM-Geometric/dataset.py:21-63)."""
+    rng = np.random.default_rng(seed)
+    deg = np.minimum((rng.pareto(1.5, n) * 6 + 2).astype(np.int64), n - 1)
+    rows = np.repeat(np.arange(n), deg)
+    cols = rng.integers(0, n, rows.size)
+    keep = rows != cols
+    edge_index = torch.from_numpy(np.vstack((rows[keep], cols[keep])).astype(np.int64))
+    feat = torch.from_numpy(np.abs(rng.standard_normal((n, f))).astype(np.float32))
+    label = torch.from_numpy(rng.integers(0, classes, n).astype(np.int64))
+
+    class NCDataset:
+        def __init__(self):
+            self.name = "stub"
+            self.graph = {"edge_index": edge_index.clone(), "node_feat": feat.clone(), "edge_feat": None, "num_nodes": n}
+            self.label = label.clone()
+
+        def get_idx_split(self, split_type="random", train_prop=.5, valid_prop=.25):
+            perm = torch.as_tensor(np.random.permutation(n), dtype=torch.int64)
+            a, b = int(n * train_prop), int(n * (train_prop + valid_prop))
+            return {"train": perm[:a], "valid": perm[a:b], "test": perm[b:]}
+
+    dataset = types.ModuleType("dataset")
+    dataset.load_nc_dataset = lambda name, sub="": NCDataset()
+
+    def to_undirected(ei):
+        both = torch.cat([ei, ei.flip(0)], dim=1)
+        return torch.unique(both, dim=1)
+
+    def to_scipy_sparse_matrix(ei, num_nodes=None):
+        m = int(ei.max()) + 1 if num_nodes is None else num_nodes
+        return sp.coo_matrix((np.ones(ei.shape[1]), (ei[0].numpy(), ei[1].numpy())), shape=(max(m, n), max(m, n)))
+
+    tg, tgu, tgc = (types.ModuleType(m) for m in ("torch_geometric", "torch_geometric.utils", "torch_geometric.utils.convert"))
+    tgu.to_undirected, tgc.to_scipy_sparse_matrix = to_undirected, to_scipy_sparse_matrix
+    tg.utils, tgu.convert = tgu, tgc
+    return {"dataset": dataset, "torch_geometric": tg, "torch_geometric.utils": tgu, "torch_geometric.utils.convert": tgc}
+
+
+@pytest.mark.parametrize("method,variant,structure_info", [("acmgcnp", 0, 0), ("acmgcnp", 1, 1), ("acmgcnpp", 1, 0)])
+def test_reference_geometric_train_script_runs_on_the_dropin(method, variant, structure_info, reference_geometric, tmp_path,
+                                                             monkeypatch, capsys):
+    from acm_gnn_amd import layers as impl
+    sys.modules.update(_stub_data_modules())
+    (tmp_path / "results").mkdir()
+    monkeypatch.chdir(tmp_path)                          # train.py appends to results/<dataset>.csv
+    calls = {"fwd": 0, "train": 0}
+    orig_forward = impl.GraphConvolution.forward
+
+    def counting_forward(self, *a, **k):
+        calls["fwd"] += 1
+        calls["train"] += int(self.training)
+        return orig_forward(self, *a, **k)
+
+    monkeypatch.setattr(impl.GraphConvolution, "forward", counting_forward)
+    epochs = 3
+    monkeypatch.setattr(sys, "argv", ["train.py", "--dataset", "stub", "--method", method, "--variant", str(variant),
+                                      "--structure_info", str(structure_info), "--rand_split", "--num_splits", "1",
+                                      "--epochs", str(epochs), "--hidden_channels", "64", "--lr", "0.01", "--dropout", "0.3"])
+    ns = runpy.run_path(os.path.join(GEO, "train.py"), run_name="__main__")
+    out = capsys.readouterr().out
+    # per epoch: one training forward + one evaluation forward (evaluate_acmgcn), two layers each, all through our layer
+    assert calls["fwd"] == epochs * 2 * 2 and calls["train"] == epochs * 2, calls
+    assert type(ns["model"]).__module__ == "models" and os.path.samefile(sys.modules["models"].__file__, os.path.join(GEO, "models.py"))
+    assert all(type(layer) is impl.GraphConvolution for layer in ns["model"].gcns)
+    assert isinstance(ns["optimizer"], torch.optim.AdamW)
+    losses = [float(line.split("Loss:")[1].split(",")[0]) for line in out.splitlines() if line.startswith("Epoch:")]
+    assert len(losses) == epochs and all(np.isfinite(losses)) and 0.0 <= float(ns["best_test"].mean()) <= 100.0
+    assert os.path.exists(tmp_path / "results" / "stub.csv")
+    for p in ns["model"].parameters():                   # the reference's optimizer stepped our parameters
+        if p.grad is not None:
+            assert torch.isfinite(p.grad).all()
