@@ -681,7 +681,6 @@ extern "C" int acm_conv_agg_fwd(const acm_csr_t* a, const acm_conv_agg_fwd_t* p,
     if (a->n_rows == 0) return ACM_OK;
     hipStream_t s = (hipStream_t)stream;
     bool next_done = false;
-    ACM_REQUIRE(!p->agg_given || p->n_channels == 3, ACM_EUNSUPPORTED, "acm_conv_agg_fwd: agg_given needs three channels");
     ACM_REQUIRE(!p->agg_copy || (p->agg_given && p->xs_copy && ((uintptr_t)p->agg_copy) % 16 == 0 && ((uintptr_t)p->xs_copy) % 16 == 0 &&
                                  (p->ld_agg_copy * 4) % 16 == 0 && (p->ld_xs_copy * 4) % 16 == 0 && p->ld_agg_copy >= p->f_pad &&
                                  p->ld_xs_copy >= p->f_pad && p->agg_copy != p->agg && p->xs_copy != p->xs), ACM_EINVAL,
@@ -715,7 +714,7 @@ extern "C" int acm_conv_agg_fwd(const acm_csr_t* a, const acm_conv_agg_fwd_t* p,
     // three channels: the long rows' partial sums stay in the workspace and the epilogue kernel adds them (one launch
     // less); with the structure channel the second gather reuses the workspace, so the fix-up runs right away
     // (the sixteen-rows-per-wave stage of acm_conv_agg16.hip reads finished rows of P: the fix-up runs right away there)
-    const bool epi16 = p->n_channels == 3 && p->f_pad == 8 && p->f_out == 64 && (acm_tuning().rows16 & ACM_ROWS16_EPI) != 0;
+    const bool epi16 = p->f_out == 64 && (acm_tuning().rows16 & ACM_ROWS16_EPI) != 0;
     bool defer = !p->agg_given && p->n_channels == 3 && a->n_long > 0 && a->long_index != nullptr && !epi16;
     if (!p->agg_given) {
         st = acm_spmm_internal(a, p->xg, p->ld_xg, p->f_pad, p->agg, p->ld_agg, &o, workspace, workspace_bytes, stream, &defer);
@@ -796,8 +795,7 @@ extern "C" int acm_conv_agg_bwd(int64_t n_rows, const acm_conv_agg_bwd_t* p, voi
     if (p->next_agg) {                            // the next step's input gather rides along (header: acm_conv_agg_bwd_t.next_agg)
         const acm_csr_t* na = p->next_a;
         ACM_REQUIRE(na && p->next_xg, ACM_EINVAL, "acm_conv_agg_bwd: next_agg without next_a / next_xg");
-        ACM_REQUIRE(K == 3 && p->f_pad == 8 && p->f_out == 64, ACM_EUNSUPPORTED,
-                    "acm_conv_agg_bwd: the carried gather needs three channels, f_pad 8 and f_out 64");
+        ACM_REQUIRE(p->f_pad == 8 && p->f_out == 64, ACM_EUNSUPPORTED, "acm_conv_agg_bwd: the carried gather needs f_pad 8 and f_out 64");
         const AcmStreams* t = na->streams;
         const int gw = 4;                         // gather waves per workgroup (eight + eight backward waves: 124 us against 110)
         ACM_REQUIRE(t && t->n_waves >= gw && t->n_waves % gw == 0 && t->n_waves <= 256 * gw, ACM_EINVAL,

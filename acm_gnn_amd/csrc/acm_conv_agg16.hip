@@ -1,6 +1,8 @@
 // Row-local stages of the aggregate-first ACM layer in the TRANSPOSED matrix-core layout (gfx950), for the
-// reference's hidden width: three channels, f_pad = 8, F = 64 (ACM-Geometric/layers.py:57-63,101-108 after
-// P = A_low X has been gathered).
+// reference's hidden width F = 64: three channels or four (structure_info: the fourth channel relu(deg (A_low S) - S)
+// arrives as finished rows, ACM-Geometric/layers.py:110-113), f_pad = 4, 8 or 16 (ACM-Geometric/layers.py:57-63,101-108
+// after P = A_low X has been gathered).  Template parameters: NC = channels, FP = f_pad (KB = FP / 4 contraction steps of
+// v_mfma_f32_16x16x4_f32 per projection).
 //
 // The older row-local kernels (acm_conv_agg.hip) give a matrix row to a 16-lane group: the projections
 // P W_L, (X - P) W_H, X W_I are 96 FMAs per lane and row, every reduction of the head is a 16-lane DPP tree per row,
@@ -28,49 +30,51 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 #define ACM_E16_NEXT_LDS (64 * 8)
 
 
-template <bool LN, bool NEXT>
+// pointer c of a kernel-argument array without dynamic indexing (which would move the struct to scratch)
+#define ACM_SEL4(arr, c) ((c) == 0 ? (arr)[0] : ((c) == 1 ? (arr)[1] : ((c) == 2 ? (arr)[2] : (arr)[3])))
+
+template <int NC, int FP, bool LN, bool NEXT>
 __device__ __forceinline__ void epi16_body(const acm_conv_agg_fwd_t& p, int n_rows) {
-    __shared__ __attribute__((aligned(16))) float ulds[3 * 64 + (NEXT ? ACM_E16_NEXT_LDS : 0)];
+    constexpr int KB = FP / 4;
+    __shared__ __attribute__((aligned(16))) float ulds[NC * 64 + (NEXT ? ACM_E16_NEXT_LDS : 0)];
     const int lane = threadIdx.x & 63, m = lane & 15, g = lane >> 4;
     // u_c = gamma_c (.) att_vec_c (LayerNorm folded into the attention vector): with d = H - mean,
     //   s_c = sum_col (d * rstd * gamma + beta) * v = rstd * sum_col d * u_c + c0_c,   c0_c = sum_col beta_c * v_c
-    for (int idx = threadIdx.x; idx < 192; idx += 256) {
+    for (int idx = threadIdx.x; idx < NC * 64; idx += 256) {
         const int c = idx >> 6, col = idx & 63;
-        const float* av = c == 0 ? p.att_vec[0] : (c == 1 ? p.att_vec[1] : p.att_vec[2]);
+        const float* av = ACM_SEL4(p.att_vec, c);
         float u = av[col];
         if (LN) {
-            const float* gw = c == 0 ? p.ln_weight[0] : (c == 1 ? p.ln_weight[1] : p.ln_weight[2]);
+            const float* gw = ACM_SEL4(p.ln_weight, c);
             u *= gw[col];
         }
         ulds[idx] = u;
     }
     if (NEXT) {                     // [col][8] = [W_L'(col, :) | W_H'(col, :) | W_I'(col, :) | 0]
-        float* nlds = ulds + 192;
+        float* nlds = ulds + NC * 64;
         for (int idx = threadIdx.x; idx < ACM_E16_NEXT_LDS; idx += 256) {
             const int col = idx >> 3, j = idx & 7, c = j / p.next_f, q = j % p.next_f;
             const float* w = c == 0 ? p.next_w_low : (c == 1 ? p.next_w_high : p.next_w_mlp);
             nlds[idx] = (c < 3) ? w[(long)col * p.next_ld_w + q] : 0.f;
         }
     }
-    float c0[3] = {0.f, 0.f, 0.f};
-    if (LN) {
+    float c0[NC];
 #pragma unroll
-        for (int c = 0; c < 3; ++c) c0[c] = acm_group_sum<64>(p.ln_bias[c][lane] * p.att_vec[c][lane]);
-    }
+    for (int c = 0; c < NC; ++c) c0[c] = LN ? acm_group_sum<64>(p.ln_bias[c][lane] * p.att_vec[c][lane]) : 0.f;
     // A operands: W_c[f = 4 kb + g][col = 16 t + m]
-    float wreg[3][2][4];
+    float wreg[3][KB][4];
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
         const float* w = c == 0 ? p.w_low : (c == 1 ? p.w_high : p.w_mlp);
 #pragma unroll
-        for (int kb = 0; kb < 2; ++kb)
+        for (int kb = 0; kb < KB; ++kb)
 #pragma unroll
             for (int t = 0; t < 4; ++t)
                 wreg[c][kb][t] = (4 * kb + g < p.f_in) ? w[(long)(4 * kb + g) * p.ld_w + 16 * t + m] : 0.f;
     }
-    float mixm[9];
+    float mixm[NC * NC];
 #pragma unroll
-    for (int q = 0; q < 9; ++q) mixm[q] = p.att_mix[q];
+    for (int q = 0; q < NC * NC; ++q) mixm[q] = p.att_mix[q];
     __syncthreads();
     const AcmDropCtx dc = acm_drop_ctx(p.post_drop);
     const float lo_a = p.relu_after ? 0.f : -INFINITY, lo_m = p.relu_mlp ? 0.f : -INFINITY;
@@ -81,49 +85,59 @@ __device__ __forceinline__ void epi16_body(const acm_conv_agg_fwd_t& p, int n_ro
     int base = wave * 16;
     if (base >= n_rows) return;
     // the operands of the NEXT step are requested before this step's math (one step of loads in flight)
-    float nPa, nPb, nxa, nxb;
+    float nP[KB], nx[KB];
     {
         const unsigned rr = (unsigned)min(base + m, n_rows - 1);
-        nPa = p.agg[rr * ld_agg + g], nPb = p.agg[rr * ld_agg + 4 + g];
-        nxa = p.xs[rr * ld_xs + g], nxb = p.xs[rr * ld_xs + 4 + g];
+#pragma unroll
+        for (int kb = 0; kb < KB; ++kb) nP[kb] = p.agg[rr * ld_agg + 4 * kb + g], nx[kb] = p.xs[rr * ld_xs + 4 * kb + g];
     }
     for (; base < n_rows; base += nwaves * 16) {
         const int row = base + m;
         const bool valid = row < n_rows;
         const unsigned rr = (unsigned)(valid ? row : n_rows - 1);
-        const float Pa = nPa, Pb = nPb, xa = nxa, xb = nxb;
+        float P[KB], x[KB];
+#pragma unroll
+        for (int kb = 0; kb < KB; ++kb) P[kb] = nP[kb], x[kb] = nx[kb];
+        f32x4 D[NC][4];
+        if (NC == 4) {                             // structure channel: relu(deg (A_low S) - S), finished rows of 64 floats
+            const float dg = p.deg[rr];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const f32x4 ps = *reinterpret_cast<const f32x4*>(p.ps + rr * (unsigned)p.ld_ps + 16 * t + 4 * g);
+                const f32x4 ss = *reinterpret_cast<const f32x4*>(p.ss + rr * (unsigned)p.ld_ss + 16 * t + 4 * g);
+                D[NC - 1][t] = dg * ps - ss;
+            }
+        }
         {
             const int nb = base + nwaves * 16;
             const unsigned r2 = (unsigned)min(nb + m, n_rows - 1);
-            nPa = p.agg[r2 * ld_agg + g], nPb = p.agg[r2 * ld_agg + 4 + g];
-            nxa = p.xs[r2 * ld_xs + g], nxb = p.xs[r2 * ld_xs + 4 + g];
+#pragma unroll
+            for (int kb = 0; kb < KB; ++kb) nP[kb] = p.agg[r2 * ld_agg + 4 * kb + g], nx[kb] = p.xs[r2 * ld_xs + 4 * kb + g];
         }
         if (p.agg_copy && valid) {                 // the backward's operands (input pipeline): the rows just read
-            p.agg_copy[rr * (unsigned)p.ld_agg_copy + g] = Pa;
-            p.agg_copy[rr * (unsigned)p.ld_agg_copy + 4 + g] = Pb;
-            p.xs_copy[rr * (unsigned)p.ld_xs_copy + g] = xa;
-            p.xs_copy[rr * (unsigned)p.ld_xs_copy + 4 + g] = xb;
+#pragma unroll
+            for (int kb = 0; kb < KB; ++kb) {
+                p.agg_copy[rr * (unsigned)p.ld_agg_copy + 4 * kb + g] = P[kb];
+                p.xs_copy[rr * (unsigned)p.ld_xs_copy + 4 * kb + g] = x[kb];
+            }
         }
         // (an opaque copy of the lane's group index: the LDS operands below depend on the lane only, and hoisted out of the
         //  row loop they would pin 48 .. 144 registers)
         const int gq = acm_opaque(g);
-        const float opa[3] = {Pa, xa - Pa, xa}, opb[3] = {Pb, xb - Pb, xb};
-        f32x4 D[3][4];
 #pragma unroll
-        for (int c = 0; c < 3; ++c)
+        for (int kb = 0; kb < KB; ++kb) {
+            const float op[3] = {P[kb], x[kb] - P[kb], x[kb]};
 #pragma unroll
-            for (int t = 0; t < 4; ++t)
-                D[c][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(wreg[c][0][t], opa[c], (f32x4){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+            for (int c = 0; c < 3; ++c)
 #pragma unroll
-        for (int c = 0; c < 3; ++c)
-#pragma unroll
-            for (int t = 0; t < 4; ++t)
-                D[c][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(wreg[c][1][t], opb[c], D[c][t], 0, 0, 0);
+                for (int t = 0; t < 4; ++t)
+                    D[c][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(wreg[c][kb][t], op[c], kb == 0 ? (f32x4){0.f, 0.f, 0.f, 0.f} : D[c][t], 0, 0, 0);
+        }
         // ---- head: statistics and attention scalars of row m (four lanes per row)
-        float mean[3], rstd[3], gs[3];
+        float mean[NC], rstd[NC], gs[NC];
 #pragma unroll
-        for (int c = 0; c < 3; ++c) {
-            const float lo = c < 2 ? lo_a : lo_m;
+        for (int c = 0; c < NC; ++c) {
+            const float lo = c < 2 ? lo_a : (c == 2 ? lo_m : 0.f);
 #pragma unroll
             for (int t = 0; t < 4; ++t)
 #pragma unroll
@@ -161,44 +175,49 @@ __device__ __forceinline__ void epi16_body(const acm_conv_agg_fwd_t& p, int n_ro
             }
             gs[c] = acm_rcp(1.0f + acm_exp(-dot));
         }
-        float al[3];
+        float al[NC];
         {
-            float lg[3], mx = -INFINITY, den = 0.f;
+            float lg[NC], mx = -INFINITY, den = 0.f;
 #pragma unroll
-            for (int j = 0; j < 3; ++j) {
+            for (int j = 0; j < NC; ++j) {
                 float a = 0.f;
 #pragma unroll
-                for (int c = 0; c < 3; ++c) a = fmaf(gs[c], mixm[c * 3 + j], a);
-                lg[j] = a * (1.0f / 3.0f);
+                for (int c = 0; c < NC; ++c) a = fmaf(gs[c], mixm[c * NC + j], a);
+                lg[j] = a * (1.0f / NC);
                 mx = fmaxf(mx, lg[j]);
             }
 #pragma unroll
-            for (int j = 0; j < 3; ++j) {
+            for (int j = 0; j < NC; ++j) {
                 lg[j] = acm_exp(lg[j] - mx);
                 den += lg[j];
             }
             const float inv = acm_rcp(den);
 #pragma unroll
-            for (int j = 0; j < 3; ++j) al[j] = lg[j] * inv;
+            for (int j = 0; j < NC; ++j) al[j] = lg[j] * inv;
         }
         if (valid) {
-            if (p.head_stats && g == 0) {
+            if (p.head_stats && g == 0) {          // [mean_c | rstd_c | sigmoid_c | alpha_c], NC each (row_head_store)
+                float hv[4 * NC];
+#pragma unroll
+                for (int c = 0; c < NC; ++c) hv[c] = mean[c], hv[NC + c] = rstd[c], hv[2 * NC + c] = gs[c], hv[3 * NC + c] = al[c];
                 float* hs = p.head_stats + rr * (unsigned)p.ld_head_stats;
-                reinterpret_cast<float4*>(hs)[0] = make_float4(mean[0], mean[1], mean[2], rstd[0]);
-                reinterpret_cast<float4*>(hs)[1] = make_float4(rstd[1], rstd[2], gs[0], gs[1]);
-                reinterpret_cast<float4*>(hs)[2] = make_float4(gs[2], al[0], al[1], al[2]);
+#pragma unroll
+                for (int q = 0; q < NC; ++q) reinterpret_cast<float4*>(hs)[q] = make_float4(hv[4 * q], hv[4 * q + 1], hv[4 * q + 2], hv[4 * q + 3]);
             }
-            if (g == 1) *reinterpret_cast<float4*>(p.att + (size_t)rr * 4) = make_float4(al[0], al[1], al[2], 0.f);
+            if (g == 1) *reinterpret_cast<float4*>(p.att + (size_t)rr * 4) = make_float4(al[0], al[1], al[2], NC == 4 ? al[NC - 1] : 0.f);
         }
         // ---- mix, post-op, store; the row's next-layer projection
-        const float a0 = al[0] * p.scale, a1 = al[1] * p.scale, a2 = al[2] * p.scale;
+        const float a0 = al[0] * p.scale, a1 = al[1] * p.scale, a2 = al[2] * p.scale, a3 = al[NC - 1] * p.scale;
         float z8[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
         f32x4 o[4];
 #pragma unroll
         for (int t = 0; t < 4; ++t)
 #pragma unroll
-            for (int r = 0; r < 4; ++r)
-                o[t][r] = fmaxf(fmaf(a2, D[2][t][r], fmaf(a1, D[1][t][r], a0 * D[0][t][r])), lo_post);
+            for (int r = 0; r < 4; ++r) {
+                float v = fmaf(a2, D[2][t][r], fmaf(a1, D[1][t][r], a0 * D[0][t][r]));
+                if (NC == 4) v = fmaf(a3, D[NC - 1][t][r], v);
+                o[t][r] = fmaxf(v, lo_post);
+            }
         if (p.post_scale) {
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
@@ -220,7 +239,7 @@ __device__ __forceinline__ void epi16_body(const acm_conv_agg_fwd_t& p, int n_ro
             for (int t = 0; t < 4; ++t) *reinterpret_cast<f32x4*>(p.out + rr * ld_out + 16 * t + 4 * g) = o[t];
         }
         if (NEXT) {
-            const float* nlds = ulds + 192;
+            const float* nlds = ulds + NC * 64;
 #pragma unroll
             for (int t = 0; t < 4; ++t)
 #pragma unroll
@@ -248,9 +267,9 @@ __device__ __forceinline__ void epi16_body(const acm_conv_agg_fwd_t& p, int n_ro
     }
 }
 
-template <bool LN, bool NEXT>
+template <int NC, int FP, bool LN, bool NEXT>
 __global__ __launch_bounds__(256) void agg_epi16_kernel(acm_conv_agg_fwd_t p, int n_rows) {
-    epi16_body<LN, NEXT>(p, n_rows);
+    epi16_body<NC, FP, LN, NEXT>(p, n_rows);
 }
 
 // ---------------------------------------------------------------- backward (K3a) in the same layout
@@ -263,10 +282,25 @@ __global__ __launch_bounds__(256) void agg_epi16_kernel(acm_conv_agg_fwd_t p, in
 // accesses are ordered, no barrier).  The row-sums of the head parameters (A_c[col] = sum_rows ds_c xhat_c, see
 // row_channel_backward) accumulate per lane for the lane's own row and are summed over the 16 row-lanes once, after the
 // row loop.
+// Structure channel (NC = 4): H_S = relu(deg (A_low S) - S) is read as finished rows (twice: for its dot with dO before the
+// softmax backward, and again -- from the L1 / L2 -- for its own channel pass, so that its 16 registers are not held
+// across the three projected channels); its G_S leaves as 16-byte stores (deg * G_S for an explicit operator) for the
+// F-wide transposed product d struc_low = A_low^T (D G_S) - G_S that follows (acm_spmm_ex); no dW for it.
 #define ACM_B16_TS 68                  /* floats per tile row: 16-byte writes of eight consecutive row-lanes and the B-operand reads
                                           (rows 4 g + s: two row groups per LDS pass, 16 banks apart) are conflict-free */
-#define ACM_B16_PS 17                  /* floats per [P | x] row */
-#define ACM_B16_LDS (4 * (2144 + 384) + 64)    /* tiles | [P|x] rows | head parameters | weights; the end-of-kernel slabs alias it */
+
+template <int NC, int FP, bool PROJ>
+struct B16Lds {
+    static constexpr int KB = FP / 4;
+    static constexpr int PS = 2 * FP + 1;                                   // floats per [P | x] row (odd: no bank conflicts)
+    static constexpr int TILES = 4 * 16 * ACM_B16_TS, PX = 4 * 16 * PS + 16 - (4 * 16 * PS) % 16;   // (16-byte aligned end)
+    static constexpr int HL = 3 * NC * 64, UL = NC * 64, WL = 3 * KB * 4 * 64, PW = PROJ ? 512 : 0;
+    static constexpr int FRONT = TILES + PX + HL + UL + WL + PW;
+    static constexpr int NPG0 = 3 * FP * 64 + 3 * NC * 64 + NC * NC;         // f_in = FP at most
+    static constexpr int SLAB = ((NPG0 + 31) & ~31) + (PROJ ? 6 * 64 : 0);
+    static constexpr int TOTAL = (FRONT > 4 * SLAB ? FRONT : 4 * SLAB) + 64;
+    static_assert(TOTAL * 4 <= 64 * 1024, "static LDS of one workgroup");
+};
 
 // PROJ: the following layer's projection backward rides along (acm_conv_agg_bwd_t.proj_*): grad_out is formed per row from
 // proj_dz (6 floats) and the 64 x 6 weight table in LDS instead of being read (256 B per row), and proj_d_w = out^T proj_dz
@@ -275,52 +309,52 @@ __global__ __launch_bounds__(256) void agg_epi16_kernel(acm_conv_agg_fwd_t p, in
 // id streams for the next training step's P = A_low dropout(x) (acm_conv_agg_bwd_t.next_agg; stream_gather_role).  The
 // kernel is compiled for two waves per SIMD either way, so the pair costs the backward no occupancy; its waves get the
 // vector and matrix pipes almost to themselves (the gather waves wait on memory), the gather waves the memory system.
-template <bool LN, bool OUT_MASK, bool PROJ, bool GATHER>
+template <int NC, int FP, bool LN, bool OUT_MASK, bool PROJ, bool GATHER>
 __device__ __forceinline__ void bwd16_body(const acm_conv_agg_bwd_t& p, int n_rows, float* __restrict__ partial, const GatherRole* gr) {
-    __shared__ __attribute__((aligned(16))) float lds[ACM_B16_LDS];
+    using L = B16Lds<NC, FP, PROJ>;
+    constexpr int KB = L::KB, PS = L::PS;
+    __shared__ __attribute__((aligned(16))) float lds[L::TOTAL];
     const int lane = threadIdx.x & 63, m = lane & 15, g = lane >> 4, wv = threadIdx.x >> 6;
     float* gt = lds + wv * (16 * ACM_B16_TS);                 // this wave's G tile
-    float* px = lds + 4 * 16 * ACM_B16_TS + wv * 16 * ACM_B16_PS;   // this wave's [P | x] rows, 16 floats each
-    float* hl = lds + 4 * 16 * ACM_B16_TS + 4 * 16 * ACM_B16_PS + 16;   // [att_vec | gamma | beta][c][col]  (576 floats) + u_c (192); 16-byte aligned
-    float* ul = hl + 576;
-    float* wl = ul + 192;                                     // A operands of the projections, [(c, kb, t)][lane]
-    float* pw = wl + 24 * 64;                                 // PROJ: [col][8] = [W_L'(col, :) | W_H'(col, :) | W_I'(col, :) | 0]
-    static_assert(ACM_B16_LDS >= 4 * 16 * ACM_B16_TS + 4 * 16 * ACM_B16_PS + 16 + 768 + 24 * 64 + 512, "tiles | [P|x] rows | head parameters | weights");
-    static_assert(ACM_B16_LDS >= 4 * (2144 + 384), "the four end-of-kernel slabs (f_in = 8: 2121 -> 2144 entries, proj_f = 2) alias everything");
+    float* px = lds + L::TILES + wv * 16 * PS;                // this wave's [P | x] rows, 2 FP floats each
+    float* hl = lds + L::TILES + L::PX;                       // [att_vec | gamma | beta][c][col]; 16-byte aligned
+    float* ul = hl + L::HL;                                   // u_c = att_vec_c * gamma_c
+    float* wl = ul + L::UL;                                   // A operands of the projections, [(c, kb, t)][lane]
+    float* pw = wl + L::WL;                                   // PROJ: [col][8] = [W_L'(col, :) | W_H'(col, :) | W_I'(col, :) | 0]
     const int f_in = p.f_in;
     // one round of independent global loads, one barrier: the head parameters, u = att_vec * gamma, the projections' A
     // operands W_c[f = 4 kb + g][col = 16 t + m] (the same for every wave), c1_c = mean_col(u_c)
-    for (int idx = threadIdx.x; idx < 576; idx += blockDim.x) {
-        const int arr = idx / 192, c = (idx / 64) % 3, col = idx & 63;
-        const float* av = c == 0 ? p.att_vec[0] : (c == 1 ? p.att_vec[1] : p.att_vec[2]);
+    for (int idx = threadIdx.x; idx < 3 * NC * 64; idx += blockDim.x) {
+        const int arr = idx / (NC * 64), c = (idx / 64) % NC, col = idx & 63;
+        const float* av = ACM_SEL4(p.att_vec, c);
         float v;
         if (arr == 0) v = av[col];
         else if (LN) {
-            const float* gw = c == 0 ? p.ln_weight[0] : (c == 1 ? p.ln_weight[1] : p.ln_weight[2]);
-            const float* gb = c == 0 ? p.ln_bias[0] : (c == 1 ? p.ln_bias[1] : p.ln_bias[2]);
+            const float* gw = ACM_SEL4(p.ln_weight, c);
+            const float* gb = ACM_SEL4(p.ln_bias, c);
             v = arr == 1 ? gw[col] : gb[col];
         } else v = arr == 1 ? 1.f : 0.f;
         hl[idx] = v;
     }
-    float c1[3];
-    if (threadIdx.x < 192) {
-        const int c = threadIdx.x >> 6, col = threadIdx.x & 63;
-        const float* av = c == 0 ? p.att_vec[0] : (c == 1 ? p.att_vec[1] : p.att_vec[2]);
+    float c1[NC];
+    for (int idx = threadIdx.x; idx < NC * 64; idx += blockDim.x) {
+        const int c = idx >> 6, col = idx & 63;
+        const float* av = ACM_SEL4(p.att_vec, c);
         float u = av[col];
         if (LN) {
-            const float* gw = c == 0 ? p.ln_weight[0] : (c == 1 ? p.ln_weight[1] : p.ln_weight[2]);
+            const float* gw = ACM_SEL4(p.ln_weight, c);
             u *= gw[col];
         }
-        ul[threadIdx.x] = u;
+        ul[idx] = u;
     }
 #pragma unroll
-    for (int c = 0; c < 3; ++c) {
+    for (int c = 0; c < NC; ++c) {
         float u = p.att_vec[c][lane];
         if (LN) u *= p.ln_weight[c][lane];
         c1[c] = acm_group_sum<64>(u) * (1.0f / 64.0f);
     }
-    for (int idx = threadIdx.x; idx < 24 * 64; idx += blockDim.x) {
-        const int e = idx >> 6, l2 = idx & 63, c = e >> 3, kb = (e >> 2) & 1, t = e & 3, f = 4 * kb + (l2 >> 4);
+    for (int idx = threadIdx.x; idx < 3 * KB * 4 * 64; idx += blockDim.x) {
+        const int e = idx >> 6, l2 = idx & 63, c = e / (4 * KB), kb = (e >> 2) % KB, t = e & 3, f = 4 * kb + (l2 >> 4);
         const float* w = c == 0 ? p.w_low : (c == 1 ? p.w_high : p.w_mlp);
         wl[idx] = f < f_in ? w[(long)f * p.ld_w + 16 * t + (l2 & 15)] : 0.f;
     }
@@ -332,9 +366,9 @@ __device__ __forceinline__ void bwd16_body(const acm_conv_agg_bwd_t& p, int n_ro
             pw[idx] = (c < 3) ? w[(long)col * p.proj_ld_w + q] : 0.f;
         }
     }
-    float mixm[9];
+    float mixm[NC * NC];
 #pragma unroll
-    for (int q = 0; q < 9; ++q) mixm[q] = p.att_mix[q];
+    for (int q = 0; q < NC * NC; ++q) mixm[q] = p.att_mix[q];
     __syncthreads();
     if (GATHER && wv >= 4) {                      // the gather role; then the same two barriers as the backward's end phase
         stream_gather_role(*gr, __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (wv - 4)));
@@ -349,47 +383,53 @@ __device__ __forceinline__ void bwd16_body(const acm_conv_agg_bwd_t& p, int n_ro
                    ld_out = (unsigned)p.ld_out, ld_hs = (unsigned)p.ld_head_stats;
     const int wave = blockIdx.x * 4 + wv, nwaves = gridDim.x * 4;
     const float wq = g == 0 ? 1.f : 0.f;            // a row's scalars sit in four lanes: one of them accumulates
-    const float fsel = m < 8 ? 1.f : 0.f;           // A operand of the dW products: feature f = m (< f_pad)
+    const float fsel = m < FP ? 1.f : 0.f;          // A operand of the dW products: feature f = m (< f_pad)
 
     f32x4 acc[3][4], acc2[4];            // acc2 (PROJ): proj_d_w^T tiles, D[i = j of proj_dz][col]
 #pragma unroll
     for (int t = 0; t < 4; ++t) acc2[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
     const unsigned ld_pz = (unsigned)p.ld_proj_dz;
-    float pA[3], pS[3], dmix[9];         // pA[c]: lane (g, m) accumulates column 16 (m >> 2) + 4 g + (m & 3) of A_c
+    // pA[c]: lane (g, m) accumulates column 16 (m >> 2) + 4 g + (m & 3) of A_c; dmx[j]: lane group g accumulates row c = g of
+    // d att_mix for its own row m (NC accumulators per lane instead of NC^2; summed over the 16 row-lanes after the loop)
+    float pA[NC], pS[NC], dmx[NC];
 #pragma unroll
-    for (int c = 0; c < 3; ++c) {
-        pS[c] = pA[c] = 0.f;
+    for (int c = 0; c < NC; ++c) pS[c] = pA[c] = dmx[c] = 0.f;
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
 #pragma unroll
         for (int t = 0; t < 4; ++t) acc[c][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    }
-#pragma unroll
-    for (int q = 0; q < 9; ++q) dmix[q] = 0.f;
 
     int base = wave * 16;
-    float nPa = 0.f, nPb = 0.f, nxa = 0.f, nxb = 0.f;
-    f32x4 ngo[4], nou[4], nst[3];
-    // the operands of the projections (P, x: 64 B per row) are requested one step ahead; grad_out / out (512 B per row), the
-    // head statistics and proj_dz at the top of their own step -- the projections' MFMAs run while they arrive
+    float nP[KB], nx[KB];
+    f32x4 ngo[4], nou[4], nst[NC];
+    // the operands of the projections (P, x: 8 FP bytes per row) are requested one step ahead; grad_out / out (512 B per row),
+    // the head statistics and proj_dz at the top of their own step -- the projections' MFMAs run while they arrive
 #define ACM_B16_LOAD(BASE)                                                                              \
     do {                                                                                                \
         const unsigned r2 = (unsigned)min((BASE) + m, n_rows - 1);                                      \
-        nPa = p.agg[r2 * ld_agg + g], nPb = p.agg[r2 * ld_agg + 4 + g];                                 \
-        nxa = p.xs[r2 * ld_xs + g], nxb = p.xs[r2 * ld_xs + 4 + g];                                     \
+        _Pragma("unroll") for (int kb = 0; kb < KB; ++kb)                                               \
+            nP[kb] = p.agg[r2 * ld_agg + 4 * kb + g], nx[kb] = p.xs[r2 * ld_xs + 4 * kb + g];           \
     } while (0)
+#pragma unroll
+    for (int kb = 0; kb < KB; ++kb) nP[kb] = nx[kb] = 0.f;
     if (base < n_rows) ACM_B16_LOAD(base);
     for (; base < n_rows; base += nwaves * 16) {
         const bool valid = base + m < n_rows;
-        const float Pa = nPa, Pb = nPb, xa = nxa, xb = nxb;
+        float P[KB], x[KB];
+#pragma unroll
+        for (int kb = 0; kb < KB; ++kb) P[kb] = nP[kb], x[kb] = nx[kb];
         float dzr[6], dza[4];            // PROJ: proj_dz of row m; of rows 4 g + s at column m (the A operand of proj_d_w)
+        const unsigned r1 = (unsigned)min(base + m, n_rows - 1);
+        float dgs = 0.f;                 // NC == 4: deg of row m
         {
-            const unsigned r1 = (unsigned)min(base + m, n_rows - 1);
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
                 if (!PROJ) ngo[t] = *reinterpret_cast<const f32x4*>(p.grad_out + r1 * ld_go + 16 * t + 4 * g);
                 if (out_mask || PROJ) nou[t] = *reinterpret_cast<const f32x4*>(p.out + r1 * ld_out + 16 * t + 4 * g);
             }
 #pragma unroll
-            for (int q = 0; q < 3; ++q) nst[q] = *reinterpret_cast<const f32x4*>(p.head_stats + r1 * ld_hs + 4 * q);
+            for (int q = 0; q < NC; ++q) nst[q] = *reinterpret_cast<const f32x4*>(p.head_stats + r1 * ld_hs + 4 * q);
+            if (NC == 4) dgs = p.deg[r1];
             if (PROJ) {
 #pragma unroll
                 for (int j = 0; j < 6; ++j) dzr[j] = (j < nq && valid) ? p.proj_dz[r1 * ld_pz + j] : 0.f;
@@ -402,20 +442,25 @@ __device__ __forceinline__ void bwd16_body(const acm_conv_agg_bwd_t& p, int n_ro
         }
         ACM_B16_LOAD(base + nwaves * 16);           // the next step's operands (the addresses are clamped)
         const int gq = acm_opaque(g), mq = acm_opaque(m);
-        px[mq * ACM_B16_PS + gq] = Pa, px[mq * ACM_B16_PS + 4 + gq] = Pb, px[mq * ACM_B16_PS + 8 + gq] = xa, px[mq * ACM_B16_PS + 12 + gq] = xb;
-        const float opa[3] = {Pa, xa - Pa, xa}, opb[3] = {Pb, xb - Pb, xb};
-        f32x4 D[3][4];
+#pragma unroll
+        for (int kb = 0; kb < KB; ++kb) px[mq * PS + 4 * kb + gq] = P[kb], px[mq * PS + FP + 4 * kb + gq] = x[kb];
+        // RECOMP (four channels): a projected channel lives in 16 registers at a time -- computed for its dot product with dO,
+        // dropped, and computed AGAIN (8 MFMAs: the matrix pipe is a quarter busy) in its own pass below -- instead of all
+        // three (48 registers) across both passes: with the structure channel's extra state the kernel otherwise spills
+        constexpr bool RECOMP = NC == 4;
+        f32x4 D[RECOMP ? 1 : 3][4];
         const int lq = acm_opaque(lane);
+#define ACM_B16_PROJECT_C(CH, DST)                                                                                      \
+        _Pragma("unroll") for (int kb = 0; kb < KB; ++kb) {                                                             \
+            const float opc = (CH) == 0 ? P[kb] : ((CH) == 1 ? x[kb] - P[kb] : x[kb]);                                  \
+            _Pragma("unroll") for (int t = 0; t < 4; ++t)                                                               \
+                DST[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(wl[(((CH) * KB + kb) * 4 + t) * 64 + lq], opc,            \
+                                                              kb == 0 ? (f32x4){0.f, 0.f, 0.f, 0.f} : DST[t], 0, 0, 0); \
+        }
+        if (!RECOMP) {                               // three channels: all of them now, the MFMAs run while grad_out arrives
 #pragma unroll
-        for (int c = 0; c < 3; ++c)
-#pragma unroll
-            for (int t = 0; t < 4; ++t)
-                D[c][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(wl[((c * 2 + 0) * 4 + t) * 64 + lq], opa[c], (f32x4){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
-#pragma unroll
-        for (int c = 0; c < 3; ++c)
-#pragma unroll
-            for (int t = 0; t < 4; ++t)
-                D[c][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(wl[((c * 2 + 1) * 4 + t) * 64 + lq], opb[c], D[c][t], 0, 0, 0);
+            for (int c = 0; c < 3; ++c) ACM_B16_PROJECT_C(c, D[RECOMP ? 0 : c])
+        }
         f32x4 dO[4];
         const float gate = valid ? post_gain : 0.f;
         if (PROJ) {
@@ -446,45 +491,88 @@ __device__ __forceinline__ void bwd16_body(const acm_conv_agg_bwd_t& p, int n_ro
                 for (int r = 0; r < 4; ++r)
                     dO[t][r] = out_mask ? ((nou[t][r] != 0.f) ? ngo[t][r] * gate : 0.f) : (valid ? ngo[t][r] : 0.f);
         }
-        const float mean[3] = {nst[0][0], nst[0][1], nst[0][2]}, rstd[3] = {nst[0][3], nst[1][0], nst[1][1]};
-        const float gsig[3] = {nst[1][2], nst[1][3], nst[2][0]}, al[3] = {nst[2][1], nst[2][2], nst[2][3]};
+        float mean[NC], rstd[NC], gsig[NC], al[NC];      // head_stats: [mean_c | rstd_c | sigmoid_c | alpha_c], NC each
+        {
+            float hv[4 * NC];
+#pragma unroll
+            for (int q = 0; q < NC; ++q)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) hv[4 * q + r] = nst[q][r];
+#pragma unroll
+            for (int c = 0; c < NC; ++c) mean[c] = hv[c], rstd[c] = hv[NC + c], gsig[c] = hv[2 * NC + c], al[c] = hv[3 * NC + c];
+        }
         // ---- mix / softmax / sigmoid backward: ds_c = dL/ds_c per row
-        float dal[3], ds[3];
+        float dal[NC], ds[NC];
+        if (NC == 4) {                               // H_S dot dO (the rows are read again in the channel's own pass)
+            float part = 0.f;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const f32x4 ps = *reinterpret_cast<const f32x4*>(p.ps + r1 * (unsigned)p.ld_ps + 16 * t + 4 * g);
+                const f32x4 ss = *reinterpret_cast<const f32x4*>(p.ss + r1 * (unsigned)p.ld_ss + 16 * t + 4 * g);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) part = fmaf(dO[t][r], fmaxf(fmaf(dgs, ps[r], -ss[r]), 0.f), part);
+            }
+            dal[NC - 1] = p.scale * row4_sum(part);
+        }
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
             const float lo = c < 2 ? lo_a : lo_m;
             float part = 0.f;
+            if (RECOMP) ACM_B16_PROJECT_C(c, D[0])
 #pragma unroll
             for (int t = 0; t < 4; ++t)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    D[c][t][r] = fmaxf(D[c][t][r], lo);
-                    part = fmaf(dO[t][r], D[c][t][r], part);
+                    D[RECOMP ? 0 : c][t][r] = fmaxf(D[RECOMP ? 0 : c][t][r], lo);
+                    part = fmaf(dO[t][r], D[RECOMP ? 0 : c][t][r], part);
                 }
             dal[c] = p.scale * row4_sum(part);
         }
         {
-            const float dot = fmaf(al[2], dal[2], fmaf(al[1], dal[1], al[0] * dal[0]));
-            float dlg[3];
+            float dot = 0.f;
 #pragma unroll
-            for (int j = 0; j < 3; ++j) dlg[j] = al[j] * (dal[j] - dot);
+            for (int j = 0; j < NC; ++j) dot = fmaf(al[j], dal[j], dot);
+            float dlg[NC];
 #pragma unroll
-            for (int c = 0; c < 3; ++c) {
+            for (int j = 0; j < NC; ++j) dlg[j] = al[j] * (dal[j] - dot);
+#pragma unroll
+            for (int c = 0; c < NC; ++c) {
                 float dg = 0.f;
 #pragma unroll
-                for (int j = 0; j < 3; ++j) {
-                    dg = fmaf(dlg[j], mixm[c * 3 + j], dg);
-                    dmix[c * 3 + j] = fmaf(wq * gsig[c], dlg[j] * (1.0f / 3.0f), dmix[c * 3 + j]);
+                for (int j = 0; j < NC; ++j) {
+                    dg = fmaf(dlg[j], mixm[c * NC + j], dg);
                 }
-                ds[c] = dg * (1.0f / 3.0f) * gsig[c] * (1.f - gsig[c]);
+                ds[c] = dg * (1.0f / NC) * gsig[c] * (1.f - gsig[c]);
                 pS[c] = fmaf(wq, ds[c], pS[c]);
             }
-        }
-        // ---- one channel at a time: G_c -> LDS tile -> dW_c on the matrix pipe
+            const float gsel = valid ? (g == 0 ? gsig[0] : (g == 1 ? gsig[1] : (g == 2 ? gsig[2] : (NC == 4 ? gsig[NC - 1] : 0.f)))) : 0.f;
 #pragma unroll
-        for (int c = 0; c < 3; ++c) {
-            const float lo = c < 2 ? lo_a : lo_m;
+            for (int j = 0; j < NC; ++j) dmx[j] = fmaf(gsel, dlg[j] * (1.0f / NC), dmx[j]);
+        }
+        // ---- one channel at a time: G_c -> LDS tile -> dW_c on the matrix pipe (the structure channel: G_S -> memory)
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            const float lo = c < 2 ? lo_a : (c == 2 ? lo_m : 0.f);
             const float aal = p.scale * al[c];
+            f32x4 HS[4];                               // c == 3: the channel's rows, again (an opaque row index: the compiler
+            if (c == 3) {                              // must not keep the first read's 16 registers alive instead)
+                const unsigned r3 = (unsigned)acm_opaque((int)r1);
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    const f32x4 ps = *reinterpret_cast<const f32x4*>(p.ps + r3 * (unsigned)p.ld_ps + 16 * t + 4 * g);
+                    const f32x4 ss = *reinterpret_cast<const f32x4*>(p.ss + r3 * (unsigned)p.ld_ss + 16 * t + 4 * g);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) HS[t][r] = fmaxf(fmaf(dgs, ps[r], -ss[r]), 0.f);
+                }
+            }
+            if (RECOMP && c < 3) {                     // the channel again (same MFMA chain: bit-identical to the first time)
+                ACM_B16_PROJECT_C(c, D[0])
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) D[0][t][r] = fmaxf(D[0][t][r], lo);
+            }
+#define ACM_B16_H(t, r) (c == 3 ? HS[t][r] : D[(RECOMP || c > 2) ? 0 : c][t][r])
             // two passes over the lane's 16 columns, four at a time, so that neither xhat nor G is held as a whole: (A) the
             // row sums (contrib -> the reduce-scatter; t2 = sum_col u xhat), (B) xhat again, G, straight into the LDS tile
             float contrib[16], t2 = 0.f;
@@ -493,13 +581,14 @@ __device__ __forceinline__ void bwd16_body(const acm_conv_agg_bwd_t& p, int n_ro
                 const f32x4 u = *reinterpret_cast<const f32x4*>(ul + c * 64 + 16 * t + 4 * gq);
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const float xh = LN ? (D[c][t][r] - mean[c]) * rstd[c] : D[c][t][r];
+                    const float xh = LN ? (ACM_B16_H(t, r) - mean[c]) * rstd[c] : ACM_B16_H(t, r);
                     contrib[4 * t + r] = ds[c] * xh;
                     if (LN) t2 = fmaf(u[r], xh, t2);
                 }
             }
             pA[c] += row_reduce_scatter16(contrib, mq);
             const float m1 = LN ? ds[c] * c1[c] : 0.f, m2 = LN ? ds[c] * row4_sum(t2) * (1.0f / 64.0f) : 0.f;
+            const float dg1 = (c == 3 && p.g_struc_scale) ? p.g_struc_scale[r1] : 1.f;
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
                 const f32x4 u = *reinterpret_cast<const f32x4*>(ul + c * 64 + 16 * t + 4 * gq);
@@ -508,44 +597,52 @@ __device__ __forceinline__ void bwd16_body(const acm_conv_agg_bwd_t& p, int n_ro
                 for (int r = 0; r < 4; ++r) {
                     float v;
                     if (LN) {
-                        const float xh = (D[c][t][r] - mean[c]) * rstd[c];
+                        const float xh = (ACM_B16_H(t, r) - mean[c]) * rstd[c];
                         v = fmaf(aal, dO[t][r], rstd[c] * (fmaf(ds[c], u[r], -m1) - xh * m2));
                     } else {
                         v = fmaf(aal, dO[t][r], ds[c] * u[r]);
                     }
-                    G[r] = D[c][t][r] > lo ? v : 0.f;
+                    G[r] = ACM_B16_H(t, r) > lo ? v : 0.f;
                 }
-                *reinterpret_cast<f32x4*>(gt + mq * ACM_B16_TS + 16 * t + 4 * gq) = G;
+                if (c == 3) {
+                    if (valid) *reinterpret_cast<f32x4*>(p.g_struc + r1 * (unsigned)p.ld_g_struc + 16 * t + 4 * g) = dg1 * G;
+                } else {
+                    *reinterpret_cast<f32x4*>(gt + mq * ACM_B16_TS + 16 * t + 4 * gq) = G;
+                }
             }
+#undef ACM_B16_H
+            if (c < 3) {
 #pragma unroll
-            for (int s = 0; s < 4; ++s) {
-                // A operand: feature m of row 4 g + s of this wave step (P | x rows parked in LDS at the top of the step)
-                const float ap = px[(4 * gq + s) * ACM_B16_PS + (mq & 7)], ax = px[(4 * gq + s) * ACM_B16_PS + 8 + (mq & 7)];
-                const float aop = fsel * (c == 0 ? ap : (c == 1 ? ax - ap : ax));
+                for (int s = 0; s < 4; ++s) {
+                    // A operand: feature m of row 4 g + s of this wave step (P | x rows parked in LDS at the top of the step)
+                    const float ap = px[(4 * gq + s) * PS + (mq & (FP - 1))], ax = px[(4 * gq + s) * PS + FP + (mq & (FP - 1))];
+                    const float aop = fsel * (c == 0 ? ap : (c == 1 ? ax - ap : ax));
 #pragma unroll
-                for (int t = 0; t < 4; ++t)
-                    acc[c][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(aop, gt[(4 * gq + s) * ACM_B16_TS + 16 * t + mq], acc[c][t], 0, 0, 0);
+                    for (int t = 0; t < 4; ++t)
+                        acc[c < 3 ? c : 0][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(aop, gt[(4 * gq + s) * ACM_B16_TS + 16 * t + mq], acc[c < 3 ? c : 0][t], 0, 0, 0);
+                }
             }
         }
     }
+#undef ACM_B16_PROJECT_C
 #undef ACM_B16_LOAD
     // ---- end of the row loop: head-parameter sums over the 16 row-lanes, then the block's partial slab
-    const int npg0 = 3 * f_in * 64 + 9 * 64 + 9;
+    const int npg0 = 3 * f_in * 64 + 3 * NC * 64 + NC * NC;
     const int off2 = (npg0 + 31) & ~31;              // PROJ: proj_d_w behind d_params at a whole group of 32 (the second phase
     const int npg = PROJ ? off2 + 64 * nq : npg0;    // sums it by lines), [c][col][q] = flat index (j / f') 64 f' + col f' + j % f'
     // value i = 4 t + r of lane (g, m = i) is column 16 t + 4 g + r: one column of A_c per lane
     const int mycol = 16 * (m >> 2) + 4 * g + (m & 3);
-    float dv[3], dgam[3], dbet[3];
+    float dv[NC], dgam[NC], dbet[NC];
 #pragma unroll
-    for (int c = 0; c < 3; ++c) {
+    for (int c = 0; c < NC; ++c) {
         pS[c] = acm_group_sum<64>(pS[c]);
-        const float v = hl[c * 64 + mycol], gm = hl[192 + c * 64 + mycol], bt = hl[384 + c * 64 + mycol];
+        const float v = hl[c * 64 + mycol], gm = hl[NC * 64 + c * 64 + mycol], bt = hl[2 * NC * 64 + c * 64 + mycol];
         dv[c] = fmaf(gm, pA[c], bt * pS[c]);
         dgam[c] = v * pA[c];
         dbet[c] = v * pS[c];
     }
 #pragma unroll
-    for (int q = 0; q < 9; ++q) dmix[q] = acm_group_sum<64>(dmix[q]);
+    for (int j = 0; j < NC; ++j) dmx[j] = acm_group_sum<16>(dmx[j]);     // over the 16 rows of the lane group: d att_mix[g][j]
     __syncthreads();                               // every wave is done with the tiles and the staged parameters
     float* slab = lds + wv * npg;
 #pragma unroll
@@ -560,17 +657,15 @@ __device__ __forceinline__ void bwd16_body(const acm_conv_agg_bwd_t& p, int n_ro
     {
         const int b2 = 3 * f_in * 64;
 #pragma unroll
-        for (int c = 0; c < 3; ++c) {
-            slab[b2 + (0 * 3 + c) * 64 + mycol] = dv[c];
-            slab[b2 + (1 * 3 + c) * 64 + mycol] = dgam[c];
-            slab[b2 + (2 * 3 + c) * 64 + mycol] = dbet[c];
+        for (int c = 0; c < NC; ++c) {
+            slab[b2 + (0 * NC + c) * 64 + mycol] = dv[c];
+            slab[b2 + (1 * NC + c) * 64 + mycol] = dgam[c];
+            slab[b2 + (2 * NC + c) * 64 + mycol] = dbet[c];
         }
     }
-    if (lane < 9) {
-        float v = dmix[0];
+    if (m == 0 && g < NC) {
 #pragma unroll
-        for (int q = 1; q < 9; ++q) v = lane == q ? dmix[q] : v;
-        slab[3 * f_in * 64 + 9 * 64 + lane] = v;
+        for (int j = 0; j < NC; ++j) slab[3 * f_in * 64 + 3 * NC * 64 + g * NC + j] = dmx[j];
     }
     if (PROJ) {
 #pragma unroll
@@ -589,65 +684,84 @@ __device__ __forceinline__ void bwd16_body(const acm_conv_agg_bwd_t& p, int n_ro
     }
 }
 
-template <bool LN, bool OUT_MASK, bool PROJ>
+template <int NC, int FP, bool LN, bool OUT_MASK, bool PROJ>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void agg_bwd16_kernel(acm_conv_agg_bwd_t p, int n_rows, float* __restrict__ partial) {
-    bwd16_body<LN, OUT_MASK, PROJ, false>(p, n_rows, partial, nullptr);
+    bwd16_body<NC, FP, LN, OUT_MASK, PROJ, false>(p, n_rows, partial, nullptr);
 }
-template <bool LN, bool OUT_MASK, bool PROJ>
+template <int NC, bool LN, bool PROJ>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void agg_bwd16_gather_kernel(acm_conv_agg_bwd_t p, int n_rows, float* __restrict__ partial,
                                                                                                    GatherRole gr) {
-    bwd16_body<LN, OUT_MASK, PROJ, true>(p, n_rows, partial, &gr);
+    bwd16_body<NC, 8, LN, true, PROJ, true>(p, n_rows, partial, &gr);
 }
 
 }  // namespace
 
-// The row-local forward stage over an existing P = A_low X (p->agg).  Returns ACM_OK after a launch, -1 when the
-// configuration is not the one this kernel is written for (the caller then runs agg_epilogue_kernel), or an error.
+// The row-local forward stage over an existing P = A_low X (p->agg; with four channels also p->ps = A_low S).  Returns
+// ACM_OK after a launch, -1 when the configuration is not one this kernel is written for (the caller then runs
+// agg_epilogue_kernel), or an error.
 int acm_agg_epi16(const acm_conv_agg_fwd_t* p, int64_t n_rows, bool* next_done, hipStream_t s) {
     *next_done = false;
-    if (p->n_channels != 3 || p->f_pad != 8 || p->f_out != 64 || !(acm_tuning().rows16 & ACM_ROWS16_EPI)) return -1;
+    const int NC = p->n_channels, FP = p->f_pad;
+    if ((NC != 3 && NC != 4) || (FP != 4 && FP != 8 && FP != 16) || p->f_out != 64 || !(acm_tuning().rows16 & ACM_ROWS16_EPI)) return -1;
     int64_t ld_max = 64;
-    for (int64_t ld : {p->ld_agg, p->ld_xs, p->ld_out, p->ld_head_stats, p->ld_post_scale, p->ld_agg_copy, p->ld_xs_copy})
+    for (int64_t ld : {p->ld_agg, p->ld_xs, p->ld_out, p->ld_head_stats, p->ld_post_scale, p->ld_agg_copy, p->ld_xs_copy, p->ld_ps, p->ld_ss})
         ld_max = ld > ld_max ? ld : ld_max;
     if (n_rows * ld_max >= (int64_t)INT32_MAX) return -1;                  // 32-bit element offsets
     if ((((uintptr_t)p->out) % 16) != 0 || (p->ld_out % 4) != 0) return -1;
     if (p->post_scale && ((((uintptr_t)p->post_scale) % 16) != 0 || (p->ld_post_scale % 4) != 0)) return -1;
+    if (NC == 4 && ((((uintptr_t)p->ps) % 16) != 0 || (((uintptr_t)p->ss) % 16) != 0 || p->ld_ps % 4 != 0 || p->ld_ss % 4 != 0)) return -1;
     const bool next = p->next_f > 0;
     int grid = (int)((n_rows + 63) / 64);
     if (grid > 1024) grid = 1024;                    // four workgroups (sixteen waves) per CU
-#define ACM_E16(KERNEL)                                                                                              \
-    do {                                                                                                             \
-        if (p->layernorm) {                                                                                          \
-            if (next) hipLaunchKernelGGL((KERNEL<true, true>), dim3(grid), dim3(256), 0, s, *p, (int)n_rows);        \
-            else hipLaunchKernelGGL((KERNEL<true, false>), dim3(grid), dim3(256), 0, s, *p, (int)n_rows);            \
-        } else {                                                                                                     \
-            if (next) hipLaunchKernelGGL((KERNEL<false, true>), dim3(grid), dim3(256), 0, s, *p, (int)n_rows);       \
-            else hipLaunchKernelGGL((KERNEL<false, false>), dim3(grid), dim3(256), 0, s, *p, (int)n_rows);           \
-        }                                                                                                            \
+#define ACM_E16_L(NCv, FPv)                                                                                                   \
+    do {                                                                                                                     \
+        if (p->layernorm) {                                                                                                  \
+            if (next) hipLaunchKernelGGL((agg_epi16_kernel<NCv, FPv, true, true>), dim3(grid), dim3(256), 0, s, *p, (int)n_rows);   \
+            else hipLaunchKernelGGL((agg_epi16_kernel<NCv, FPv, true, false>), dim3(grid), dim3(256), 0, s, *p, (int)n_rows);       \
+        } else {                                                                                                             \
+            if (next) hipLaunchKernelGGL((agg_epi16_kernel<NCv, FPv, false, true>), dim3(grid), dim3(256), 0, s, *p, (int)n_rows);  \
+            else hipLaunchKernelGGL((agg_epi16_kernel<NCv, FPv, false, false>), dim3(grid), dim3(256), 0, s, *p, (int)n_rows);      \
+        }                                                                                                                    \
     } while (0)
-    ACM_E16(agg_epi16_kernel);
+#define ACM_E16(NCv)                            \
+    do {                                        \
+        if (FP == 4) ACM_E16_L(NCv, 4);         \
+        else if (FP == 8) ACM_E16_L(NCv, 8);    \
+        else ACM_E16_L(NCv, 16);                \
+    } while (0)
+    if (NC == 3) ACM_E16(3);
+    else ACM_E16(4);
 #undef ACM_E16
+#undef ACM_E16_L
     ACM_CHECK_HIP(hipGetLastError());
     *next_done = next;
     return ACM_OK;
 }
 
+// Floats of the per-block partial slab the sixteen-rows-per-wave backward writes (acm_conv_agg_bwd_workspace_bytes).
 // The row-local backward over the forward's head_stats.  Returns the number of blocks launched (> 0), 0 when the
 // configuration is not this kernel's (the caller runs agg_bwd_kernel), or a negative acm_status_t.  The partial slab has
 // npg + 64 * 3 * proj_f entries per block (acm_conv_agg_bwd_t.proj_*: the following layer's weight gradient behind d_params).
 int acm_agg_bwd16(const acm_conv_agg_bwd_t* p, int64_t n_rows, float* partial, int max_blocks, hipStream_t s, const GatherRole* gr,
                   int gather_blocks) {
-    if (p->n_channels != 3 || p->f_pad != 8 || p->f_out != 64 || !p->head_stats || !(acm_tuning().rows16 & ACM_ROWS16_BWD)) return 0;
+    const int NC = p->n_channels, FP = p->f_pad;
+    if ((NC != 3 && NC != 4) || (FP != 4 && FP != 8 && FP != 16) || p->f_out != 64 || !p->head_stats ||
+        !(acm_tuning().rows16 & ACM_ROWS16_BWD))
+        return 0;
     const bool out_mask = p->out != nullptr && p->post_relu && !p->post_scale;
     const bool no_post = !p->post_relu && !p->post_scale && !(p->post_drop.p > 0.f);
     if (!out_mask && !no_post) return 0;
     const bool proj = p->proj_dz != nullptr;
+    if ((proj || gr) && (FP != 8 || !out_mask)) return 0;      // the carriers exist for the hidden layer of a training step
     if (proj && (!p->out || p->proj_f < 1 || p->proj_f > 2 || !p->proj_w_low || !p->proj_w_high || !p->proj_w_mlp || !p->proj_d_w ||
                  p->ld_proj_dz < 3 * p->proj_f || p->proj_ld_w < p->proj_f || n_rows * p->ld_proj_dz >= (int64_t)INT32_MAX))
         return 0;
-    for (const void* q : {(const void*)(proj ? nullptr : p->grad_out), (const void*)p->out, (const void*)p->head_stats})
+    for (const void* q : {(const void*)(proj ? nullptr : p->grad_out), (const void*)p->out, (const void*)p->head_stats,
+                          (const void*)(NC == 4 ? p->ps : nullptr), (const void*)(NC == 4 ? p->ss : nullptr),
+                          (const void*)(NC == 4 ? p->g_struc : nullptr)})
         if (((uintptr_t)q) % 16 != 0) return 0;
     if ((!proj && p->ld_grad_out % 4 != 0) || ((out_mask || proj) && p->ld_out % 4 != 0) || p->ld_head_stats % 4 != 0) return 0;
+    if (NC == 4 && (p->ld_ps % 4 != 0 || p->ld_ss % 4 != 0 || p->ld_g_struc % 4 != 0 || !p->deg)) return 0;
     acm_conv_agg_bwd_t q = *p;
     if (!out_mask && !proj) q.out = nullptr;
     int grid = (int)((n_rows + 63) / 64);
@@ -658,19 +772,44 @@ int acm_agg_bwd16(const acm_conv_agg_bwd_t* p, int64_t n_rows, float* partial, i
         if (gather_blocks < 1 || gather_blocks > max_blocks) return 0;
         grid = gather_blocks;
     }
-#define ACM_B16(LNv, OMv, PJv)                                                                                                      \
-    do {                                                                                                                            \
-        if (gr) hipLaunchKernelGGL((agg_bwd16_gather_kernel<LNv, OMv, PJv>), dim3(grid), dim3(512), 0, s, q, (int)n_rows, partial, *gr); \
-        else hipLaunchKernelGGL((agg_bwd16_kernel<LNv, OMv, PJv>), dim3(grid), dim3(256), 0, s, q, (int)n_rows, partial);            \
+    const bool ln = p->layernorm != 0;
+#define ACM_B16_BASE(NCv, FPv)                                                                                                     \
+    do {                                                                                                                          \
+        if (ln) {                                                                                                                 \
+            if (out_mask) hipLaunchKernelGGL((agg_bwd16_kernel<NCv, FPv, true, true, false>), dim3(grid), dim3(256), 0, s, q, (int)n_rows, partial);   \
+            else hipLaunchKernelGGL((agg_bwd16_kernel<NCv, FPv, true, false, false>), dim3(grid), dim3(256), 0, s, q, (int)n_rows, partial);           \
+        } else {                                                                                                                  \
+            if (out_mask) hipLaunchKernelGGL((agg_bwd16_kernel<NCv, FPv, false, true, false>), dim3(grid), dim3(256), 0, s, q, (int)n_rows, partial);  \
+            else hipLaunchKernelGGL((agg_bwd16_kernel<NCv, FPv, false, false, false>), dim3(grid), dim3(256), 0, s, q, (int)n_rows, partial);          \
+        }                                                                                                                         \
     } while (0)
-    if (proj) {                                       // (the `out` tile is read either way: the mask flag only gates its use)
-        if (p->layernorm) { if (out_mask) ACM_B16(true, true, true); else ACM_B16(true, false, true); }
-        else { if (out_mask) ACM_B16(false, true, true); else ACM_B16(false, false, true); }
+    // the carriers (FP = 8, the output read behind a fused ReLU): + proj_*, + next_agg, or both
+#define ACM_B16_CARRY(NCv)                                                                                                          \
+    do {                                                                                                                          \
+        if (gr) {                                                                                                                 \
+            if (ln) { if (proj) hipLaunchKernelGGL((agg_bwd16_gather_kernel<NCv, true, true>), dim3(grid), dim3(512), 0, s, q, (int)n_rows, partial, *gr);   \
+                      else hipLaunchKernelGGL((agg_bwd16_gather_kernel<NCv, true, false>), dim3(grid), dim3(512), 0, s, q, (int)n_rows, partial, *gr); }       \
+            else { if (proj) hipLaunchKernelGGL((agg_bwd16_gather_kernel<NCv, false, true>), dim3(grid), dim3(512), 0, s, q, (int)n_rows, partial, *gr);     \
+                   else hipLaunchKernelGGL((agg_bwd16_gather_kernel<NCv, false, false>), dim3(grid), dim3(512), 0, s, q, (int)n_rows, partial, *gr); }         \
+        } else {                                                                                                                  \
+            if (ln) hipLaunchKernelGGL((agg_bwd16_kernel<NCv, 8, true, true, true>), dim3(grid), dim3(256), 0, s, q, (int)n_rows, partial);                   \
+            else hipLaunchKernelGGL((agg_bwd16_kernel<NCv, 8, false, true, true>), dim3(grid), dim3(256), 0, s, q, (int)n_rows, partial);                     \
+        }                                                                                                                         \
+    } while (0)
+    if (proj || gr) {
+        if (NC == 3) ACM_B16_CARRY(3);
+        else ACM_B16_CARRY(4);
+    } else if (NC == 3) {
+        if (FP == 4) ACM_B16_BASE(3, 4);
+        else if (FP == 8) ACM_B16_BASE(3, 8);
+        else ACM_B16_BASE(3, 16);
     } else {
-        if (p->layernorm) { if (out_mask) ACM_B16(true, true, false); else ACM_B16(true, false, false); }
-        else { if (out_mask) ACM_B16(false, true, false); else ACM_B16(false, false, false); }
+        if (FP == 4) ACM_B16_BASE(4, 4);
+        else if (FP == 8) ACM_B16_BASE(4, 8);
+        else ACM_B16_BASE(4, 16);
     }
-#undef ACM_B16
+#undef ACM_B16_BASE
+#undef ACM_B16_CARRY
     if (hipGetLastError() != hipSuccess) return -ACM_EHIP;
     return grid;
 }

@@ -316,7 +316,7 @@ class InputPipeline:
         from .graph import FilterOperators
         if tuning.HOST.pipeline <= 0 or not isinstance(ops, FilterOperators) or not isinstance(x, torch.Tensor):
             return False
-        if getattr(model, "model_type", None) not in ("acmgcn", "acmgcnp") or getattr(model, "structure_info", 0):
+        if getattr(model, "model_type", None) not in ("acmgcn", "acmgcnp"):
             return False
         gcns = getattr(model, "gcns", None)
         if not gcns or len(gcns) != 2 or not getattr(model, "fused_dropout", False) or getattr(model, "dropout", 0) <= 0:
@@ -327,7 +327,7 @@ class InputPipeline:
             f_in, f = l0.weight_low.shape
         except AttributeError:
             return False
-        if cfg.relu_before or cfg.n_channels != 3 or f != 64 or not 4 < f_in <= 8 or x.dim() != 2 or x.shape[1] != f_in:
+        if cfg.relu_before or f != 64 or not 4 < f_in <= 8 or x.dim() != 2 or x.shape[1] != f_in:
             return False
         if not ops.implicit or getattr(ops, "general", False) or int(getattr(ops, "hops", 1)) != 1:
             return False
@@ -420,7 +420,7 @@ def _next_proj_request(call, f, dev, row_local_only=False):
     except AttributeError:
         return None
     f2 = w3[0].shape[1]
-    ok = (f2 <= 2 and cfg.n_channels == 3 and all(w.dtype == _F32 and w.is_contiguous() and w.device == dev and
+    ok = (f2 <= 2 and all(w.dtype == _F32 and w.is_contiguous() and w.device == dev and
                                                    tuple(w.shape) == (f, f2) for w in w3))
     return (w3, bool(cfg.relu_before), f2) if ok else None
 
@@ -1163,19 +1163,25 @@ class AcmConvFunction(torch.autograd.Function):
             fp = 4 if f_in <= 4 else (8 if f_in <= 8 else 16)
             if ctx.recompute:
                 fp = 8
+            # (the pipeline's table is refilled in place through raw pointers -- no version bump: never through the holder;
+            #  ACMII recomputes per edge from the gathered rows: there is no P to keep)
+            if agg_holder is not None and (ops.sharded or call.pipe is not None or ctx.recompute or ctx.in_drop is not None):
+                agg_holder = None
             if x.shape[1] == fp:
                 xpad = x
-            else:
-                xpad = torch.nn.functional.pad(x[:, :f_in], (0, fp - f_in))
-            if agg_holder is not None and (k != 3 or ops.sharded or torch.is_grad_enabled()):       # no backward follows
-                agg_holder = None
+            else:                                     # the zero-padded copy of a static input is kept with its P
+                xpad = agg_holder.get("xpad") if agg_holder is not None else None
+                if xpad is None or tuple(xpad.shape) != (n, fp):
+                    xpad = torch.nn.functional.pad(x[:, :f_in], (0, fp - f_in))
+                    if agg_holder is not None:
+                        agg_holder["xpad"] = xpad
             agg_given = agg_holder.get("agg") if agg_holder is not None else None
             if agg_given is not None and tuple(agg_given.shape) != (n, fp):
                 agg_given = None
             # a training loop's input pipeline (InputPipeline): P for this step came out of the previous step's backward
             pipe = call.pipe
             ctx.pipe = None
-            if (pipe is not None and pipe.primed and ctx.agg_first and k == 3 and fp == 8 and f == 64 and ops is pipe.ops
+            if (pipe is not None and pipe.primed and ctx.agg_first and fp == 8 and f == 64 and ops is pipe.ops
                     and xpad.data_ptr() == pipe.local_table().data_ptr() and agg_holder is None):   # (only a training step carries a pipe)
                 agg_given = pipe.agg()
                 ctx.pipe = pipe
@@ -1371,7 +1377,8 @@ class AcmConvFunction(torch.autograd.Function):
             if stats is not None:
                 p.head_stats, p.ld_head_stats = stats.data_ptr(), stats.stride(0)
             ctx.head_stats = stats
-            nxt = _next_proj_request(call, f, dev, row_local_only=agg_given is not None and k == 3 and fp == 8 and f == 64)
+            # (the row-local stage is a kernel of its own when P is given, and always with the structure channel)
+            nxt = _next_proj_request(call, f, dev, row_local_only=f == 64 and (agg_given is not None or four))
             if nxt is not None:
                 n_w3, n_relu, f2 = nxt
                 n_zlh = torch.empty(n, 2 * f2, dtype=_F32, device=dev)
@@ -1692,7 +1699,7 @@ def _backward_agg(ctx, grad_out):
     if lazy is not None and (grad_out is not lazy["placeholder"] and grad_out.data_ptr() != lazy["placeholder"].data_ptr()):
         raise RuntimeError("acm_conv: the hidden activation marked private (CallContext.hidden_private) received a gradient "
                            "from somewhere else as well")
-    fuse_proj = (lazy is not None and k == 3 and fp == 8 and f == 64 and out_fwd is not None and ctx.post_scale is None
+    fuse_proj = (lazy is not None and fp == 8 and f == 64 and out_fwd is not None and ctx.post_scale is None
                  and getattr(ctx, "head_stats", None) is not None)
     if lazy is not None and not fuse_proj:            # the kernel cannot take it: materialise dX and dW' now
         proj_bwd(lazy["x"], lazy["dz"], lazy["w3"], lazy["d_w"], defer=ctx.call.defer, dx_out=lazy["placeholder"])

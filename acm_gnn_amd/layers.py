@@ -152,11 +152,13 @@ class GraphConvolution(nn.Module):
         return out
 
     def _eval_agg_holder(self, x, ops):
-        """Evaluation passes (module in eval mode, autograd off, dense input): the holder through which an aggregate-first
-        forward reuses P = A_low X of the previous pass over the SAME input -- same tensor object, unmodified since
-        (``_version``), same operators.  Training-mode calls (fresh dropout every step) and anything else get None."""
-        if (self.training or torch.is_grad_enabled() or not isinstance(x, torch.Tensor) or x.requires_grad
-                or not self.eval_agg_cache):
+        """The holder through which an aggregate-first forward reuses P = A_low X of the previous pass over the SAME dense
+        input -- same tensor object, unmodified since (``_version``), same operators, no gradient asked for it: every
+        evaluation pass over a static feature matrix after the first, and (round 4) every TRAINING step of a model without
+        input dropout (the reference's twitch-gamer ACM-GCN+ runs: dropout 0), whose first-layer gather -- a quarter of a
+        step's gathered bytes -- then runs once per training run instead of once per step.  With input dropout the input
+        is a fresh tensor every step and simply never matches."""
+        if not isinstance(x, torch.Tensor) or x.requires_grad or x.grad_fn is not None or not self.eval_agg_cache:
             return None
         # the entry keeps the input alive, so its storage cannot be handed to another tensor while the entry exists; an
         # in-place edit bumps the version counter (shared by every alias of the storage)

@@ -575,9 +575,9 @@ typedef struct {
     int32_t next_f, next_relu;
     float* next_zlh; int64_t ld_next_zlh;
     float* next_zi;  int64_t ld_next_zi;
-    /* agg_given != 0 (three channels only): `agg` already holds A_low * xg -- an earlier call of this operator on the same
-     * input wrote it (e.g. every evaluation pass over a static feature matrix after the first) -- so the gather is
-     * skipped and only the row-local stage runs; xg is not read.                                                     */
+    /* agg_given != 0: `agg` already holds A_low * xg -- an earlier call of this operator on the same input wrote it
+     * (e.g. every evaluation pass over a static feature matrix after the first; a training loop's input pipeline) -- so
+     * that gather is skipped (the structure channel's A_low * S still runs) and xg is not read.                      */
     int32_t agg_given;
     int32_t reserved0;                 /* zero (ABI <= 21: use_streams, the streamed form of the fused forward -- measured
                                           slower than the CSR walk, DESIGN.md section 4, and removed in ABI 22)      */

@@ -37,6 +37,10 @@ CONFIGS = {
     "twitch/acmgcn": dict(graph="syn:twitch-gamer", method="acmgcn", s=0, variant=0, dropout=0.1),
     "twitch/acmgcnp+A": dict(graph="syn:twitch-gamer", method="acmgcnp", s=1, variant=0, dropout=0.0),
     "twitch/acmiigcnp": dict(graph="syn:twitch-gamer", method="acmgcnp", s=0, variant=1, dropout=0.1),
+    # ACM-GCN++ (the residual Linear on the raw features; ACM-Geometric/sh/run_all_settings.sh:13-14, models.py:27,55-56,73)
+    "twitch/acmgcnpp": dict(graph="syn:twitch-gamer", method="acmgcnpp", s=0, variant=0, dropout=0.1),
+    "twitch/acmgcnpp+A": dict(graph="syn:twitch-gamer", method="acmgcnpp", s=1, variant=0, dropout=0.0),
+    "twitch/acmiigcnpp": dict(graph="syn:twitch-gamer", method="acmgcnpp", s=0, variant=1, dropout=0.1),
     "twitch/acmiigcnp+A": dict(graph="syn:twitch-gamer", method="acmgcnp", s=1, variant=1, dropout=0.0),
     # the fabric-bound cells with bf16 storage of the gathered operands (opt-in, BASELINE config 3; fp32 sums)
     "twitch/acmgcnp+A/bf16": dict(graph="syn:twitch-gamer", method="acmgcnp", s=1, variant=0, dropout=0.0, gather_dtype="bf16"),

@@ -839,8 +839,7 @@ class FakeLib:
         proj_* and next_agg."""
         out_mask = bool(q.out) and bool(q.post_relu) and not q.post_scale
         no_post = not q.post_relu and not q.post_scale and not q.post_drop.p > 0
-        return (k == 3 and fp == 8 and F == 64 and bool(q.head_stats) and (out_mask or no_post)
-                and (self._tuning["rows16"] & 2) != 0)
+        return (fp == 8 and F == 64 and bool(q.head_stats) and out_mask and (self._tuning["rows16"] & 2) != 0)
 
     def acm_dropout(self, n, c, src, lds, dst, ldd, dst_cols, d, stream):
         out = np.zeros((n, dst_cols))

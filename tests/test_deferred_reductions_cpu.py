@@ -48,8 +48,10 @@ def test_outputs_are_undefined_until_the_flush_and_equal_the_immediate_form(monk
     assert float(loss) == float(loss0)
     got = _grads(model)
     assert got.keys() == want.keys()
+    # (under the deferral list the output layer's projection backward rides the hidden layer's kernel -- acm_conv_agg_bwd_t.
+    #  proj_*, round 4: only there -- so the two runs differ by the rounding of one more fused product)
     for k in want:
-        assert torch.equal(got[k], want[k]), k
+        torch.testing.assert_close(got[k], want[k], rtol=1e-5, atol=1e-6 * float(want[k].abs().max()), msg=lambda m, k=k: f"{k}: {m}")
 
 
 def test_leaving_the_block_flushes_and_an_exception_discards(monkeypatch):
@@ -117,6 +119,7 @@ def test_fused_loss_tail_is_taken_by_the_output_layer_and_equals_the_three_calls
     real = fake.acm_conv_fwd_tail
     monkeypatch.setattr(fake, "acm_conv_fwd_tail", lambda *a: (calls.append(1), real(*a))[1])
     model, ops, x, y, w = _setup()
+    model(x, ops)                                   # (no input dropout: the first pass leaves P = A_low X for every later one)
     out = model(x, ops)
     loss0, dz0 = AF.nll_loss_and_grad(out, y, w)
     out.backward(dz0)

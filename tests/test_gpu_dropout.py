@@ -50,6 +50,10 @@ def test_dropout_kernel_equals_numpy_philox(n, c, pad, p, off):
 CASES = [("acmgcnp", 0, 0, True, 7, 64, False, True),      # aggregate-first, grouped layout
          ("acmgcnp", 0, 1, True, 7, 64, False, True),      # + structure channel
          ("acmgcnp", 0, 0, True, 12, 24, False, True),
+         # the sixteen-rows-per-wave kernels behind a fused ReLU + dropout (out-mask form): f_pad 4 / 8 / 16, three and four channels
+         ("acmgcnp", 0, 0, True, 3, 64, False, True), ("acmgcnp", 0, 1, True, 4, 64, False, True),
+         ("acmgcn", 0, 0, False, 12, 64, False, True), ("acmgcnp", 0, 1, True, 16, 64, False, True),
+         ("acmgcnp", 0, 1, False, 8, 64, False, True),
          ("acmgcnp", 1, 1, True, 30, 64, True, False),     # literal, grouped backward (16 < F <= 64)
          ("acmgcn", 0, 0, False, 30, 5, True, False),      # literal, packed layout / row-parallel narrow forward
          ("acmgcnp", 0, 0, True, 30, 2, True, False),

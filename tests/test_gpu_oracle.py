@@ -120,6 +120,29 @@ def test_aggregate_first_kernel_forms(form, f_in, f_out, hub, monkeypatch, tune)
     _run_both("acmgcn", 0, 0, False, 700, f_in, f_out, 22, False, monkeypatch, agg=True, adj=adj, implicit=False)
 
 
+@pytest.mark.parametrize("ln", [True, False], ids=["ln", "no-ln"])
+@pytest.mark.parametrize("s,f_in", [(0, 3), (0, 7), (0, 12), (1, 4), (1, 7), (1, 8), (1, 13), (1, 16)])
+def test_sixteen_rows_per_wave_stages_cover_channels_and_pad_widths(s, f_in, ln, monkeypatch, tune):
+    """Round 4: agg_epi16_kernel / agg_bwd16_kernel for three AND four channels (the structure channel
+    arrives as finished rows) and f_pad = 4, 8, 16 -- the two-stage forward + the row-local backward against the oracle
+    (forward, mixing weights, every gradient incl. d struc_low), on a graph with a split hub row and a row count that is
+    not a multiple of 16; and against the four-rows-per-wave kernels they replace."""
+    from acm_gnn_amd import functional as AF
+    adj = _graph(333, 17, density=0.05, hub=True)
+    tune(agg_fused=0)                                  # the row-local stage as its own kernel for three channels too
+    timer = AF.KernelTimer()
+    AF.set_kernel_timer(timer)
+    try:
+        a = _run_both("acmgcnp", 0, s, ln, 333, f_in, 64, 31, False, monkeypatch, agg=True, adj=adj)
+        used = set(k.split("/")[0] for k in timer.events)
+        assert {"conv_agg_fwd", "conv_agg_bwd"} <= used and "conv_fwd" not in used, used
+    finally:
+        AF.set_kernel_timer(None)
+    tune(rows16=4)
+    b = _run_both("acmgcnp", 0, s, ln, 333, f_in, 64, 31, False, monkeypatch, agg=True, adj=adj)
+    assert float((a - b).abs().max()) < 2e-5 * max(1.0, float(b.abs().max()))
+
+
 AGG_STRUC_CASES = [(True, 7, 64), (False, 7, 64), (True, 3, 24), (True, 16, 40), (True, 4, 5), (False, 12, 33)]
 
 

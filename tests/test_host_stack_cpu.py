@@ -1111,3 +1111,53 @@ def test_input_dropout_rides_the_dense_projection(monkeypatch, model_type, hops,
     assert g_a.keys() == g_b.keys()
     for k in g_a:
         torch.testing.assert_close(g_a[k], g_b[k], rtol=1e-5, atol=1e-5 * float(g_b[k].abs().max()), msg=lambda m, k=k: f"{k}: {m}")
+
+
+@pytest.mark.parametrize("s", [0, 1])
+def test_training_without_input_dropout_gathers_the_static_input_once(s, monkeypatch):
+    """Round 4: a model without input dropout (the reference's twitch-gamer ACM-GCN+ runs: --dropout 0) hands the SAME
+    unmodified feature tensor to its first layer every step, so P = A_low X (and the zero-padded copy of X) of the first
+    step serve every later one -- forward with agg_given, backward from the kept P -- until the features are edited in
+    place (version counter).  Losses and gradients equal a run with the cache switched off."""
+    fake = fake_lib.install(monkeypatch)
+    from acm_gnn_amd import GCN
+    ops, n = _dense_graph_ops(seed=4)
+    if s:
+        import scipy.sparse as sp
+        from acm_gnn_amd.graph import CsrGraph, FilterOperators
+        ip, ix, _ = ops.low.arrays()
+        pat = sp.csr_matrix((np.ones(len(ix), np.float32), ix.numpy(), ip.numpy()), shape=(n, n))
+        deg = np.asarray(pat.sum(1)).ravel().astype(np.float32)
+        low = sp.diags(1.0 / deg) @ pat
+        ops = FilterOperators(CsrGraph.from_scipy(sp.csr_matrix(low).astype(np.float32), "cpu"), deg=torch.from_numpy(deg))
+    x = torch.randn(n, 7, generator=torch.Generator().manual_seed(1))
+    given = []
+    orig = fake.acm_conv_agg_fwd
+    monkeypatch.setattr(fake, "acm_conv_agg_fwd", lambda h, pp, *a: (given.append(int(pp._obj.agg_given)), orig(h, pp, *a))[1])
+
+    def run(cache):
+        given.clear()
+        torch.manual_seed(5)
+        model = GCN(7, 64, 2, 2, n, 0.0, "acmgcnp", s, variant=0, attn_layernorm=True)
+        for layer in model.gcns:
+            layer.eval_agg_cache = cache
+        model.train()
+        opt = torch.optim.SGD(model.parameters(), lr=0.05)
+        losses = []
+        for it in range(4):
+            if it == 3:
+                x.mul_(1.5)                               # an in-place edit: the next step gathers again
+            opt.zero_grad()
+            loss = model(x, ops).square().mean()
+            loss.backward()
+            opt.step()
+            losses.append(float(loss))
+        x.div_(1.5)
+        return losses, [p.detach().clone() for p in model.parameters()], list(given)
+
+    la, pa, ga = run(True)
+    lb, pb, gb = run(False)
+    assert ga == [0, 1, 1, 0] and gb == [0, 0, 0, 0], (ga, gb)
+    np.testing.assert_allclose(la, lb, rtol=1e-5)
+    for u, v in zip(pa, pb):
+        torch.testing.assert_close(u, v, rtol=1e-4, atol=1e-6)
