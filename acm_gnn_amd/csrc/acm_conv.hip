@@ -822,6 +822,114 @@ __global__ __launch_bounds__(256) void spmm_fixup_narrow_kernel(CsrView csr, int
     Epi::template apply<LaySerial<FP>, NG>(ea, lr.row, lay, F, acc);
 }
 
+// The four-channel narrow gather (structure_info = 1, F = 2: the output layer of the reference's two-class models) over
+// PACKED 32-byte rows [c0 c0 c1 c1 | c2 c2 - -]: with the third gathered channel in a table of its own a neighbour costs two
+// fetches to two distinct lines (the [c0 | c1] block and the 8-byte c2 row) -- 115 us on the twitch-shaped graph against
+// 51 us for the three-channel layer -- while what bounds these gathers is the number of distinct lines per wave
+// instruction, not their width (ta_rate).  Two adjacent lanes fetch the two 16-byte halves of a
+// neighbour's row (the form of agg_fused_pair_kernel): one line per neighbour again.
+// Lane (e = gl >> 1, h = gl & 1) of the 16-lane group: neighbours k0 + e + 8 u (u = 0..3), half h of the row.
+template <class Epi>
+__global__ __launch_bounds__(256) void spmm_narrow_pair3_kernel(CsrView csr, const float* __restrict__ table, typename Epi::Args ea) {
+    constexpr int FP = 2, NG = 3, GPB = 16, U = 4, STEP = 8 * U;
+    static_assert(GPB == ACM_WINDOW, "one window of work items per workgroup round");
+    __shared__ float coop[ACM_WINDOW * 8];
+    const int gl = threadIdx.x & 15, e = gl >> 1, h = gl & 1;
+    const int G = gridDim.x * GPB;
+    int w = blockIdx.x * GPB + (threadIdx.x >> 4);
+    if (w >= csr.n_items) return;
+    const bool unit = csr.vals == nullptr;
+    const float* th = table + 4 * h;
+    AcmItem it = csr.items[w];
+    int k0 = it.begin;
+    int j[U];
+    float a[U];
+    bool v[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        const int k = k0 + e + 8 * u;
+        v[u] = k < it.end;
+        j[u] = v[u] ? csr.indices[k] : 0;
+        a[u] = v[u] ? (unit ? 1.f : csr.vals[k]) : 0.f;
+    }
+    while (true) {
+        const int wn = w + G;
+        const bool has_next = wn < csr.n_items;
+        AcmItem itn = it;
+        if (has_next) itn = csr.items[wn];
+        float acc[4] = {0.f, 0.f, 0.f, 0.f};
+        while (true) {
+            float4 z[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) z[u] = *reinterpret_cast<const float4*>(th + (long)j[u] * 8);
+            const int k1 = k0 + STEP;
+            const bool more = k1 < it.end;
+            const int pb = more ? k1 : itn.begin;
+            const int pe = more ? it.end : (has_next ? itn.end : pb);
+            int nj[U];
+            float na[U];
+            bool nv[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int k = pb + e + 8 * u;
+                nv[u] = k < pe;
+                nj[u] = nv[u] ? csr.indices[k] : 0;
+                na[u] = nv[u] ? (unit ? 1.f : csr.vals[k]) : 0.f;
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                acc[0] = v[u] ? fmaf(a[u], z[u].x, acc[0]) : acc[0];
+                acc[1] = v[u] ? fmaf(a[u], z[u].y, acc[1]) : acc[1];
+                acc[2] = v[u] ? fmaf(a[u], z[u].z, acc[2]) : acc[2];
+                acc[3] = v[u] ? fmaf(a[u], z[u].w, acc[3]) : acc[3];
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) j[u] = nj[u], a[u] = na[u], v[u] = nv[u];
+            if (!more) break;
+            k0 = k1;
+        }
+        // sum over the eight lanes of the group with the same half (lanes gl, gl^2, gl+-4, gl+-8): fixed order
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            acc[i] += acm_dpp<0x4E>(acc[i]);     // quad_perm [2,3,0,1]
+            acc[i] += acm_dpp<0x124>(acc[i]);    // row_ror:4
+            acc[i] += acm_dpp<0x128>(acc[i]);    // row_ror:8
+        }
+        bool finish = it.slot < 0;
+        if (w / ACM_WINDOW < csr.n_windows) {                   // a window of pieces: they meet in LDS (see spmm_narrow_kernel)
+            const int g = threadIdx.x >> 4;
+            if (gl < 2) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) coop[g * 8 + 4 * h + i] = acc[i];
+            }
+            __syncthreads();
+            const AcmLongRow lr = csr.long_rows[csr.long_index[it.row]];
+            finish = it.slot == lr.slot_begin;
+            if (finish && gl < 2) {
+                const int pieces = lr.slot_end - lr.slot_begin;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    float t = 0.f;
+                    for (int q = 0; q < pieces; ++q) t += coop[(g + q) * 8 + 4 * h + i];
+                    acc[i] = t;
+                }
+            }
+            __syncthreads();
+        }
+        // lane 0 of the group: [c0 | c1] are its own sums, c2 its neighbour's (the other half of the row)
+        const float s0 = acm_dpp<0xB1>(acc[0]), s1 = acm_dpp<0xB1>(acc[1]);      // quad_perm [1,0,3,2]
+        if (finish) {
+            float out[NG][FP] = {{acc[0], acc[1]}, {acc[2], acc[3]}, {s0, s1}};
+            LaySerial<FP> lay{gl == 0};
+            Epi::template apply<LaySerial<FP>, NG>(ea, it.row, lay, 2, out);
+        }
+        if (!has_next) break;
+        it = itn;
+        w = wn;
+        k0 = it.begin;
+    }
+}
+
 // ------------------------------------------------------------------ host-side dispatch
 // acm_conv_local16.hip: K3 at F = 64, k = 3 with sixteen rows per wave
 int acm_bwd_local16(const acm_conv_bwd_local_t* p, int64_t n_rows, float* partial, int max_blocks, hipStream_t s);
@@ -836,6 +944,12 @@ int narrow_lanes(const acm_csr* a) {
 }
 // with 16 lanes per item a workgroup round is one window: the narrow gather finishes the long rows itself
 bool narrow_finishes_long_rows(const acm_csr* a) { return narrow_lanes(a) == ACM_WINDOW; }
+
+// (spmm_narrow_pair3_kernel exists for three gathered channels only; other NG never reach the call)
+template <int NG, class Epi>
+void launch_pair3(int grid, hipStream_t st, const CsrView& v, const float* table, const typename Epi::Args& ea) {
+    if constexpr (NG == 3) hipLaunchKernelGGL((spmm_narrow_pair3_kernel<Epi>), dim3(grid), dim3(256), 0, st, v, table, ea);
+}
 
 template <int NG, class Epi>
 int launch_gather(const acm_csr* a, const GatherSrc& g, int F, const typename Epi::Args& ea,
@@ -867,6 +981,15 @@ int launch_gather(const acm_csr* a, const GatherSrc& g, int F, const typename Ep
             vecmask |= ok ? (1 << c) : 0;
         }
         const int gs = narrow_lanes(a);
+        // three gathered channels of two columns each in packed 32-byte rows [c0 c0 c1 c1 | c2 c2 - -]: the pair-lane kernel
+        if (NG == 3 && F == 2 && gs == 16 && !bf16 && g.p[1] == g.p[0] + 2 && g.p[2] == g.p[0] + 4 && g.ld[0] == 8 && g.ld[1] == 8 &&
+            g.ld[2] == 8 && ((uintptr_t)g.p[0]) % 32 == 0 && (a->n_long == 0 || a->long_index != nullptr)) {
+            int grid = (int)((a->n_items + 15) / 16);
+            if (grid > NARROW_MAX_BLOCKS) grid = NARROW_MAX_BLOCKS;
+            launch_pair3<NG, Epi>(grid, st, v, g.p[0], ea);
+            ACM_CHECK_HIP(hipGetLastError());
+            return ACM_OK;
+        }
         // [channel 0 | channel 1] contiguous and block-aligned => one vector fetch for both
         // (F < FP: the channels are blocks of FP columns, [c0 pad | c1 pad]; what the fetch reads beyond F lands in
         // accumulator columns no epilogue looks at)

@@ -30,9 +30,6 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 #define ACM_E16_NEXT_LDS (64 * 8)
 
 
-// pointer c of a kernel-argument array without dynamic indexing (which would move the struct to scratch)
-#define ACM_SEL4(arr, c) ((c) == 0 ? (arr)[0] : ((c) == 1 ? (arr)[1] : ((c) == 2 ? (arr)[2] : (arr)[3])))
-
 template <int NC, int FP, bool LN, bool NEXT>
 __device__ __forceinline__ void epi16_body(const acm_conv_agg_fwd_t& p, int n_rows) {
     constexpr int KB = FP / 4;
@@ -40,15 +37,15 @@ __device__ __forceinline__ void epi16_body(const acm_conv_agg_fwd_t& p, int n_ro
     const int lane = threadIdx.x & 63, m = lane & 15, g = lane >> 4;
     // u_c = gamma_c (.) att_vec_c (LayerNorm folded into the attention vector): with d = H - mean,
     //   s_c = sum_col (d * rstd * gamma + beta) * v = rstd * sum_col d * u_c + c0_c,   c0_c = sum_col beta_c * v_c
-    for (int idx = threadIdx.x; idx < NC * 64; idx += 256) {
-        const int c = idx >> 6, col = idx & 63;
-        const float* av = ACM_SEL4(p.att_vec, c);
-        float u = av[col];
-        if (LN) {
-            const float* gw = ACM_SEL4(p.ln_weight, c);
-            u *= gw[col];
+    // (compile-time channel indices only: a run-time index into the pointer arrays of the by-value argument struct -- also
+    //  in the disguise of a four-way select chain, which LLVM folds back into one -- moves the whole struct to scratch)
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+        if ((threadIdx.x >> 6) == (c & 3)) {
+            float u = p.att_vec[c][lane];
+            if (LN) u *= p.ln_weight[c][lane];
+            ulds[c * 64 + lane] = u;
         }
-        ulds[idx] = u;
     }
     if (NEXT) {                     // [col][8] = [W_L'(col, :) | W_H'(col, :) | W_I'(col, :) | 0]
         float* nlds = ulds + NC * 64;
@@ -324,34 +321,20 @@ __device__ __forceinline__ void bwd16_body(const acm_conv_agg_bwd_t& p, int n_ro
     const int f_in = p.f_in;
     // one round of independent global loads, one barrier: the head parameters, u = att_vec * gamma, the projections' A
     // operands W_c[f = 4 kb + g][col = 16 t + m] (the same for every wave), c1_c = mean_col(u_c)
-    for (int idx = threadIdx.x; idx < 3 * NC * 64; idx += blockDim.x) {
-        const int arr = idx / (NC * 64), c = (idx / 64) % NC, col = idx & 63;
-        const float* av = ACM_SEL4(p.att_vec, c);
-        float v;
-        if (arr == 0) v = av[col];
-        else if (LN) {
-            const float* gw = ACM_SEL4(p.ln_weight, c);
-            const float* gb = ACM_SEL4(p.ln_bias, c);
-            v = arr == 1 ? gw[col] : gb[col];
-        } else v = arr == 1 ? 1.f : 0.f;
-        hl[idx] = v;
-    }
+    // (compile-time channel indices only: a run-time index into the pointer arrays of the by-value argument struct -- also
+    //  in the disguise of a four-way select chain, which LLVM folds back into one -- moves the whole struct to scratch and
+    //  turns every load of the kernel into a flat load: 142 us instead of ~80 for the four-channel kernel)
     float c1[NC];
-    for (int idx = threadIdx.x; idx < NC * 64; idx += blockDim.x) {
-        const int c = idx >> 6, col = idx & 63;
-        const float* av = ACM_SEL4(p.att_vec, c);
-        float u = av[col];
-        if (LN) {
-            const float* gw = ACM_SEL4(p.ln_weight, c);
-            u *= gw[col];
-        }
-        ul[idx] = u;
-    }
 #pragma unroll
     for (int c = 0; c < NC; ++c) {
-        float u = p.att_vec[c][lane];
-        if (LN) u *= p.ln_weight[c][lane];
-        c1[c] = acm_group_sum<64>(u) * (1.0f / 64.0f);
+        const float av = p.att_vec[c][lane];
+        const float gw = LN ? p.ln_weight[c][lane] : 1.f, gb = LN ? p.ln_bias[c][lane] : 0.f;
+        const float u = av * gw;
+        if (wv == (c & 3)) {
+            hl[c * 64 + lane] = av, hl[NC * 64 + c * 64 + lane] = gw, hl[2 * NC * 64 + c * 64 + lane] = gb;
+            ul[c * 64 + lane] = u;
+        }
+        c1[c] = __builtin_amdgcn_readfirstlane(acm_group_sum<64>(u) * (1.0f / 64.0f));      // (wave-uniform: a scalar register)
     }
     for (int idx = threadIdx.x; idx < 3 * KB * 4 * 64; idx += blockDim.x) {
         const int e = idx >> 6, l2 = idx & 63, c = e / (4 * KB), kb = (e >> 2) % KB, t = e & 3, f = 4 * kb + (l2 >> 4);
@@ -391,9 +374,12 @@ __device__ __forceinline__ void bwd16_body(const acm_conv_agg_bwd_t& p, int n_ro
     const unsigned ld_pz = (unsigned)p.ld_proj_dz;
     // pA[c]: lane (g, m) accumulates column 16 (m >> 2) + 4 g + (m & 3) of A_c; dmx[j]: lane group g accumulates row c = g of
     // d att_mix for its own row m (NC accumulators per lane instead of NC^2; summed over the 16 row-lanes after the loop)
-    float pA[NC], pS[NC], dmx[NC];
+    constexpr int NDM = NC == 3 ? 9 : NC;                // (three channels: the nine accumulators of round 3, registers permitting)
+    float pA[NC], pS[NC], dmx[NDM];
 #pragma unroll
-    for (int c = 0; c < NC; ++c) pS[c] = pA[c] = dmx[c] = 0.f;
+    for (int c = 0; c < NC; ++c) pS[c] = pA[c] = 0.f;
+#pragma unroll
+    for (int q = 0; q < NDM; ++q) dmx[q] = 0.f;
 #pragma unroll
     for (int c = 0; c < 3; ++c)
 #pragma unroll
@@ -458,8 +444,16 @@ __device__ __forceinline__ void bwd16_body(const acm_conv_agg_bwd_t& p, int n_ro
                                                               kb == 0 ? (f32x4){0.f, 0.f, 0.f, 0.f} : DST[t], 0, 0, 0); \
         }
         if (!RECOMP) {                               // three channels: all of them now, the MFMAs run while grad_out arrives
+#pragma unroll                                       // (twelve independent MFMAs per contraction step)
+            for (int kb = 0; kb < KB; ++kb) {
+                const float op[3] = {P[kb], x[kb] - P[kb], x[kb]};
 #pragma unroll
-            for (int c = 0; c < 3; ++c) ACM_B16_PROJECT_C(c, D[RECOMP ? 0 : c])
+                for (int c = 0; c < 3; ++c)
+#pragma unroll
+                    for (int t = 0; t < 4; ++t)
+                        D[RECOMP ? 0 : c][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(wl[((c * KB + kb) * 4 + t) * 64 + lq], op[c],
+                                                                                kb == 0 ? (f32x4){0.f, 0.f, 0.f, 0.f} : D[RECOMP ? 0 : c][t], 0, 0, 0);
+            }
         }
         f32x4 dO[4];
         const float gate = valid ? post_gain : 0.f;
@@ -541,13 +535,16 @@ __device__ __forceinline__ void bwd16_body(const acm_conv_agg_bwd_t& p, int n_ro
 #pragma unroll
                 for (int j = 0; j < NC; ++j) {
                     dg = fmaf(dlg[j], mixm[c * NC + j], dg);
+                    if (NC == 3) dmx[(c * NC + j) % NDM] = fmaf(wq * gsig[c], dlg[j] * (1.0f / NC), dmx[(c * NC + j) % NDM]);
                 }
                 ds[c] = dg * (1.0f / NC) * gsig[c] * (1.f - gsig[c]);
                 pS[c] = fmaf(wq, ds[c], pS[c]);
             }
-            const float gsel = valid ? (g == 0 ? gsig[0] : (g == 1 ? gsig[1] : (g == 2 ? gsig[2] : (NC == 4 ? gsig[NC - 1] : 0.f)))) : 0.f;
+            if (NC == 4) {
+                const float gsel = valid ? (g == 0 ? gsig[0] : (g == 1 ? gsig[1] : (g == 2 ? gsig[2] : gsig[NC - 1]))) : 0.f;
 #pragma unroll
-            for (int j = 0; j < NC; ++j) dmx[j] = fmaf(gsel, dlg[j] * (1.0f / NC), dmx[j]);
+                for (int j = 0; j < NC; ++j) dmx[j % NDM] = fmaf(gsel, dlg[j] * (1.0f / NC), dmx[j % NDM]);
+            }
         }
         // ---- one channel at a time: G_c -> LDS tile -> dW_c on the matrix pipe (the structure channel: G_S -> memory)
 #pragma unroll
@@ -589,9 +586,10 @@ __device__ __forceinline__ void bwd16_body(const acm_conv_agg_bwd_t& p, int n_ro
             pA[c] += row_reduce_scatter16(contrib, mq);
             const float m1 = LN ? ds[c] * c1[c] : 0.f, m2 = LN ? ds[c] * row4_sum(t2) * (1.0f / 64.0f) : 0.f;
             const float dg1 = (c == 3 && p.g_struc_scale) ? p.g_struc_scale[r1] : 1.f;
+            const int gq2 = NC == 4 ? acm_opaque(gq) : gq;   // (four channels: u is read again, not kept across the reduce-scatter)
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
-                const f32x4 u = *reinterpret_cast<const f32x4*>(ul + c * 64 + 16 * t + 4 * gq);
+                const f32x4 u = *reinterpret_cast<const f32x4*>(ul + c * 64 + 16 * t + 4 * gq2);
                 f32x4 G;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
@@ -642,7 +640,8 @@ __device__ __forceinline__ void bwd16_body(const acm_conv_agg_bwd_t& p, int n_ro
         dbet[c] = v * pS[c];
     }
 #pragma unroll
-    for (int j = 0; j < NC; ++j) dmx[j] = acm_group_sum<16>(dmx[j]);     // over the 16 rows of the lane group: d att_mix[g][j]
+    for (int q = 0; q < NDM; ++q) dmx[q] = NC == 3 ? acm_group_sum<64>(dmx[q]) : acm_group_sum<16>(dmx[q]);   // (four channels: the
+                                                                   // 16 rows of the lane group: d att_mix[g][j])
     __syncthreads();                               // every wave is done with the tiles and the staged parameters
     float* slab = lds + wv * npg;
 #pragma unroll
@@ -663,9 +662,16 @@ __device__ __forceinline__ void bwd16_body(const acm_conv_agg_bwd_t& p, int n_ro
             slab[b2 + (2 * NC + c) * 64 + mycol] = dbet[c];
         }
     }
-    if (m == 0 && g < NC) {
+    if (NC == 3) {
+        if (lane < 9) {
+            float v = dmx[0];
 #pragma unroll
-        for (int j = 0; j < NC; ++j) slab[3 * f_in * 64 + 3 * NC * 64 + g * NC + j] = dmx[j];
+            for (int q = 1; q < 9; ++q) v = lane == q ? dmx[q % NDM] : v;
+            slab[3 * f_in * 64 + 9 * 64 + lane] = v;
+        }
+    } else if (m == 0) {
+#pragma unroll
+        for (int j = 0; j < NC; ++j) slab[3 * f_in * 64 + 3 * NC * 64 + g * NC + j] = dmx[j % NDM];
     }
     if (PROJ) {
 #pragma unroll

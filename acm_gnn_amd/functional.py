@@ -422,7 +422,8 @@ def _next_proj_request(call, f, dev, row_local_only=False):
     f2 = w3[0].shape[1]
     ok = (f2 <= 2 and all(w.dtype == _F32 and w.is_contiguous() and w.device == dev and
                                                    tuple(w.shape) == (f, f2) for w in w3))
-    return (w3, bool(cfg.relu_before), f2) if ok else None
+    # (a four-channel two-column consumer gathers [Z_L | Z_H | struc_low] from packed 32-byte rows: _narrow_tables)
+    return (w3, bool(cfg.relu_before), f2, cfg.n_channels == 4 and f2 == 2) if ok else None
 
 
 def _take_pre_proj(call, x, w3, relu):
@@ -1034,15 +1035,27 @@ def _chan_block(f):
     return f
 
 
+def _narrow_tables(n, fb, f, dev, packed):
+    """The gathered tables of a narrow layer: ([c0 | c1] block rows, third-channel rows or None).  ``packed`` (four channels
+    of two columns: the output layer of a two-class model with structure_info): views of ONE table of 32-byte rows
+    [c0 c0 c1 c1 | c2 c2 - -], which the pair-lane gather (acm_conv.hip: spmm_narrow_pair3_kernel) walks with one line per
+    neighbour instead of two."""
+    if packed:
+        base = torch.empty(n, 8, dtype=_F32, device=dev)
+        return base[:, :4], base[:, 4:6]
+    return torch.empty(n, 2 * fb, dtype=_F32, device=dev), None
+
+
 def _k3_setup(cfg, ops, k, f, n, dev, f_in_w, pre, zi, vecs, lnw, lnb, mix, grad_out, post_relu, post_scale, post_drop,
               fb=None):
     """Buffers and acm_conv_bwd_local_t of the row-local backward of one layer: G tables, dZ, the flat buffer every
     replicated-parameter gradient is a view of."""
     four = k == 4
     fb = f if fb is None else fb
-    g = torch.empty(n, 2 * fb, dtype=_F32, device=dev)           # [G_L | G_H] (channel blocks of fb columns)
+    g, gs = _narrow_tables(n, fb, f, dev, packed=four and f == 2 and fb == 2)      # [G_L | G_H] (channel blocks of fb columns)
     dz = torch.empty(n, 3 * f, dtype=_F32, device=dev)           # [dZ_L | dZ_H | dZ_I]
-    gs = torch.empty(n, f, dtype=_F32, device=dev) if four else None
+    if four and gs is None:
+        gs = torch.empty(n, f, dtype=_F32, device=dev)
     # every replicated-parameter gradient is a view of one flat buffer: a row-sharded run sums the partials
     # with a single all-reduce and no pack / unpack launches
     nw, nln = 3 * f_in_w * f, (k * f if cfg.layernorm else 0)
@@ -1218,11 +1231,13 @@ class AcmConvFunction(torch.autograd.Function):
             # [Z_L | Z_H] as a compact table of its own (what a narrow gather / the k-hop chain walks: 16-byte-block rows at
             # their own pitch instead of [Z_L | Z_H | Z_I | pad] rows), Z_I next to it
             two_tables = (use_proj or f in (2, 4, 8) or hops > 1) and not sparse_x
+            # four channels of two columns: [Z_L | Z_H] and the gathered struc_low rows share 32-byte rows (_narrow_tables)
+            pack4 = four and f == 2 and fb == 2 and two_tables and not ops.sharded and not general
             done3 = False
             if pre is None and not sparse_x:
                 # tall dense inputs of 32..128 features: the three weight matrices in place on the split-bf16 kernel (no cat)
                 if two_tables:
-                    zlh = torch.empty(n, 2 * fb, dtype=_F32, device=dev)
+                    zlh, _ = _narrow_tables(n, fb, f, dev, pack4)
                     zi = torch.empty(n, f, dtype=_F32, device=dev)
                     done3 = proj3(x, w3, fb, zlh, zi, relu=cfg.relu_before, x_drop=drop_spec)
                 else:
@@ -1246,7 +1261,7 @@ class AcmConvFunction(torch.autograd.Function):
             elif pre is not None:
                 zlh, zi = pre                              # computed in the preceding layer's epilogue
             elif use_proj:
-                zlh = torch.empty(n, 2 * fb, dtype=_F32, device=dev)
+                zlh, _ = _narrow_tables(n, fb, f, dev, pack4)
                 zi = torch.empty(n, f, dtype=_F32, device=dev)
                 proj_fwd(x, w3, zlh, zi, relu=cfg.relu_before, h_col=fb)
             else:
@@ -1256,7 +1271,7 @@ class AcmConvFunction(torch.autograd.Function):
                 else:
                     wcat = torch.cat(w3, dim=1).contiguous()                            # [F_in, 3F]
                 if two_tables:                            # one GEMM with a two-matrix output
-                    zlh = torch.empty(n, 2 * fb, dtype=_F32, device=dev)
+                    zlh, _ = _narrow_tables(n, fb, f, dev, pack4)
                     zi = torch.empty(n, f, dtype=_F32, device=dev)
                     gemm_split(x, wcat, zlh, zi, relu=cfg.relu_before)
                 else:
@@ -1380,8 +1395,8 @@ class AcmConvFunction(torch.autograd.Function):
             # (the row-local stage is a kernel of its own when P is given, and always with the structure channel)
             nxt = _next_proj_request(call, f, dev, row_local_only=f == 64 and (agg_given is not None or four))
             if nxt is not None:
-                n_w3, n_relu, f2 = nxt
-                n_zlh = torch.empty(n, 2 * f2, dtype=_F32, device=dev)
+                n_w3, n_relu, f2, n_pack = nxt
+                n_zlh, _ = _narrow_tables(n, f2, f2, dev, n_pack)
                 n_zi = torch.empty(n, f2, dtype=_F32, device=dev)
                 p.next_w_low, p.next_w_high, p.next_w_mlp = (w.data_ptr() for w in n_w3)
                 p.next_ld_w, p.next_f, p.next_relu = n_w3[0].stride(0), f2, int(n_relu)
@@ -1445,6 +1460,12 @@ class AcmConvFunction(torch.autograd.Function):
                 p.g_high, p.ld_g_high = zg.data_ptr() + 4 * fb, zg.stride(0)
                 if four:
                     p.g_struc, p.ld_g_struc = s_gath.data_ptr(), s_gath.stride(0)
+                    if (f == 2 and fb == 2 and zg is zlh and zlh.stride(0) == 8 and zlh.data_ptr() % 32 == 0 and s_gath is s_local
+                            and zlh.untyped_storage().nbytes() - zlh.storage_offset() * 4 >= n * 32):
+                        # packed rows (this call's _narrow_tables, or the producing layer's epilogue): the parameter's rows
+                        # are copied beside [Z_L | Z_H] -- one small launch for half the lines of the gather
+                        torch.as_strided(zlh, (n, 2), (8, 1), zlh.storage_offset() + 4).copy_(s_local)
+                        p.g_struc, p.ld_g_struc = zlh.data_ptr() + 16, 8
             p.s_high, p.ld_s_high = zlh.data_ptr() + 4 * fb, zlh.stride(0)
             if four:
                 p.s_struc, p.ld_s_struc = s_local.data_ptr(), s_local.stride(0)

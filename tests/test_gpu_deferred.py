@@ -47,7 +47,7 @@ def test_deferred_equals_immediate_bitwise(model_type, s, hidden, f_in):
     # Under a deferral list the two-class output layer of the three-channel models leaves its projection backward to the
     # hidden layer's kernel (acm_conv_agg_bwd_t.proj_*: another summation order for that layer's dW and for what flows on);
     # everything else is the same launches with the second phases postponed: bit-identical
-    lazy = s == 0 and hidden == 64 and int(y.max()) + 1 <= 2
+    lazy = model_type != "acmgcnpp" and hidden == 64 and int(y.max()) + 1 <= 2
     for k in want:
         if lazy:
             torch.testing.assert_close(got[k], want[k], rtol=2e-4, atol=2e-5 * float(want[k].abs().max()), msg=lambda m, k=k: f"{k}: {m}")

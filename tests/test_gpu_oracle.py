@@ -233,7 +233,10 @@ def test_spmm_ex_entry_point():
     ("acmgcnp", 0, 1, True, 7, 64, False, True), ("acmgcnp", 0, 0, True, 7, 64, False, True),
     ("acmgcnp", 0, 1, True, 33, 64, True, False), ("acmgcnp", 1, 1, True, 64, 5, True, False),
     ("acmgcn", 0, 0, False, 40, 2, True, False), ("acmgcnp", 1, 1, True, 20, 100, True, False),
-    ("acmsgc", 0, 0, False, 30, 7, True, False)])
+    ("acmsgc", 0, 0, False, 30, 7, True, False),
+    # four channels of two columns: the packed 32-byte rows of the pair-lane narrow gather (forward and transposed), with
+    # values and pattern-only, hub row split into window-packed pieces
+    ("acmgcnp", 0, 1, True, 64, 2, True, False), ("acmgcnp", 1, 1, True, 64, 2, True, False)])
 def test_explicit_value_form_matches_oracle(model_type, variant, s, ln, f_in, f_out, x_grad, agg, monkeypatch):
     """ACM_IMPLICIT=0: the explicit (id, value) operators -- the form every other test leaves for the
     pattern-only one -- against the oracle, and equal to the pattern-only result."""
