@@ -334,7 +334,8 @@ __device__ __forceinline__ void bwd16_body(const acm_conv_agg_bwd_t& p, int n_ro
             hl[c * 64 + lane] = av, hl[NC * 64 + c * 64 + lane] = gw, hl[2 * NC * 64 + c * 64 + lane] = gb;
             ul[c * 64 + lane] = u;
         }
-        c1[c] = __builtin_amdgcn_readfirstlane(acm_group_sum<64>(u) * (1.0f / 64.0f));      // (wave-uniform: a scalar register)
+        // (wave-uniform: kept in a scalar register -- readfirstlane is an integer builtin, hence the bit casts)
+        c1[c] = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, acm_group_sum<64>(u) * (1.0f / 64.0f))));
     }
     for (int idx = threadIdx.x; idx < 3 * KB * 4 * 64; idx += blockDim.x) {
         const int e = idx >> 6, l2 = idx & 63, c = e / (4 * KB), kb = (e >> 2) % KB, t = e & 3, f = 4 * kb + (l2 >> 4);

@@ -43,8 +43,15 @@ def _capture_mode():
 
 class TrainStep:
     def __init__(self, model, optimizer, x, adj, labels, weights, adj_high=None, adj_un=None, use_graph=False,
-                 fused_dropout=None, pipeline_input=None):
+                 fused_dropout=None, pipeline_input=None, steps_per_graph=1):
+        """``steps_per_graph`` (with ``use_graph``): capture that many consecutive optimizer steps in ONE hipGraph, so that a
+        call runs them all (``steps_per_call``; the loss returned is the last one, ``losses`` holds every one) -- the ~8 us
+        between two graph launches is then paid once per call instead of once per step.  Every captured step is a complete
+        step (fresh counter-based masks: the step counters live on the device); a loop that looks at the model between two
+        steps (train.fit's evaluation pass) keeps the default of one."""
         self.model, self.opt = model, optimizer
+        self.steps_per_call = max(int(steps_per_graph), 1) if use_graph else 1
+        self.losses = []
         self.x, self.adj, self.adj_high, self.adj_un = x, adj, adj_high, adj_un
         self.labels, self.weights = labels, weights
         # Relabelled operators (graph.relabel_by_degree; operators_for applies it to large graphs): the static inputs
@@ -216,14 +223,19 @@ class TrainStep:
         self.graph = torch.cuda.CUDAGraph()
         self.model.train()
         self.opt.zero_grad(set_to_none=True)
+        losses = []
         with torch.cuda.graph(self.graph, **_capture_mode()):
-            loss = self._forward_backward()
-            self.opt.step()
-            self._count_advance()
-            if self.pipe is not None:
-                self.pipe.end_step()
-            self.loss = loss
-        del loss
+            for k in range(self.steps_per_call):
+                if k:
+                    self.opt.zero_grad(set_to_none=True)
+                loss = self._forward_backward()
+                self.opt.step()
+                self._count_advance()
+                if self.pipe is not None:
+                    self.pipe.end_step()
+                losses.append(loss)
+            self.loss, self.losses = loss, losses
+        del loss, losses
 
     def _count_advance(self):
         """The dropout counter moves once per optimizer step: by FusedAdam's kernel (also_advance) or by hand."""
@@ -238,7 +250,7 @@ class TrainStep:
             self.graph.replay()
             ds = getattr(self.model, "dropout_state", None)
             if ds is not None:
-                ds.host_steps += 1            # the replayed step advanced the device counter
+                ds.host_steps += self.steps_per_call      # the replayed step(s) advanced the device counter
                 if self.pipe is not None:     # ... and refilled the pipeline's buffers for the new value
                     self.pipe._host_steps = ds.host_steps
             return self.loss

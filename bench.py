@@ -58,6 +58,8 @@ def parse():
     ap.add_argument("--force-sharded", action="store_true",
                     help="take the row-sharded path (RCCL collectives inside the captured step) even with one rank; needs a "
                          "torch.distributed launch")
+    ap.add_argument("--steps-per-graph", type=int, default=-1,
+                    help="optimizer steps captured per hipGraph (default: the largest of 5, 4, 2, 1 that divides --steps)")
     ap.add_argument("--no-extras", action="store_true",
                     help="skip the side measurements of the single-GPU run (literal form, random node order)")
     ap.add_argument("--no-check", action="store_true", help="skip the comparisons with the CPU oracle (eval-mode logits on "
@@ -292,13 +294,15 @@ def main():
     def timed_graph_steps(gstep, spread=None):
         """ms per step of `gstep`: WINDOWS windows of exactly --steps calls, each bracketed by barrier + synchronize and
         reduced with MAX over the ranks; the MEDIAN window is reported (``spread`` receives min / median / max)."""
-        for _ in range(max(args.warmup, 1)):
+        per_call = int(getattr(gstep, "steps_per_call", 1))      # optimizer steps one call runs (TrainStep(steps_per_graph=...))
+        assert args.steps % per_call == 0
+        for _ in range(max(-(-args.warmup // per_call), 1)):
             out = gstep()
         wins = []
         for _ in range(WINDOWS):
             fence()
             t = time.perf_counter()
-            for _ in range(args.steps):
+            for _ in range(args.steps // per_call):                # exactly --steps optimizer steps per window
                 out = gstep()
             fence()
             dtg = time.perf_counter() - t
@@ -333,8 +337,12 @@ def main():
         timer_t.daemon = True
         timer_t.start()
         try:
-            gstep = T.TrainStep(model, opt, x, ops, y, w, use_graph=True, fused_dropout=fused_drop)
+            # several consecutive optimizer steps per captured graph (the ~8 us between two graph launches once per call
+            # instead of once per step): the largest of 5, 4, 2 that divides --steps
+            spg = next((k for k in (5, 4, 2) if args.steps % k == 0), 1) if args.steps_per_graph < 0 else args.steps_per_graph
+            gstep = T.TrainStep(model, opt, x, ops, y, w, use_graph=True, fused_dropout=fused_drop, steps_per_graph=spg)
             ms_per_step, loss = timed_graph_steps(gstep, spread)
+            spread["steps_per_graph"] = spg
             graph_ok = True
         except Exception as exc:                      # capture refused: keep the eager measurement
             sys.stderr.write(f"bench.py: hipGraph capture failed ({exc!r}); reporting eager launches\n")
@@ -373,7 +381,8 @@ def main():
     if spread:
         extras["ms_per_step_windows"] = spread
     if rank == 0:
-        emit(ms_per_step, "hipGraph replay of the captured step" if graph_ok else "eager launches", final_loss,
+        emit(ms_per_step, (f"hipGraph replay of the captured step ({spread.get('steps_per_graph', 1)} consecutive steps per graph)"
+                           if graph_ok else "eager launches"), final_loss,
              with_cpu=True, extras=extras, check=check)
     if dist.is_initialized():
         if world > 1:

@@ -29,6 +29,7 @@ def _setup(model_type, s, hidden, f_in=None, dataset="tiny", seed=3, dropout=0.0
 def test_deferred_equals_immediate_bitwise(model_type, s, hidden, f_in):
     from acm_gnn_amd import functional as AF
     model, ops, x, y, w = _setup(model_type, s, hidden, f_in)
+    model(x, *ops)                  # (no input dropout: the first pass leaves P = A_low X for every later pass over this x)
     out = model(x, *ops)
     loss0, dz = AF.nll_loss_and_grad(out, y, w)
     out.backward(dz)
@@ -70,9 +71,11 @@ def test_train_step_trajectory_is_the_same_with_and_without_deferral(use_graph, 
         assert step._defer == defer or not defer
         params[defer] = (losses, [p.detach().clone() for p in model.parameters()])
         monkeypatch.undo()
-    assert params[True][0] == params[False][0]
+    # (the deferred step leaves the output layer's projection backward to the hidden layer's kernel -- proj_*, only under a
+    #  deferral list since round 4 -- so the two trajectories agree to rounding, not bit for bit)
+    np.testing.assert_allclose(params[True][0], params[False][0], rtol=2e-5)
     for a, b in zip(params[True][1], params[False][1]):
-        assert torch.equal(a, b)
+        torch.testing.assert_close(a, b, rtol=2e-3, atol=2e-5)
 
 
 def _immediate(self):
@@ -123,6 +126,7 @@ def test_fused_loss_tail_equals_the_three_calls(model_type, hidden, classes_grap
     different (fixed) order of their block partials."""
     from acm_gnn_amd import functional as AF
     model, ops, x, y, w = _setup(model_type, 0, hidden, dataset=classes_graph)
+    model(x, *ops)                  # (no input dropout: the first pass leaves P = A_low X for every later pass over this x)
     out0 = model(x, *ops)
     loss0, dz0 = AF.nll_loss_and_grad(out0, y, w)
     out0.backward(dz0)

@@ -339,3 +339,34 @@ def test_carried_gather_leaves_the_backward_unchanged():
     assert torch.equal(pipe.filled[1], first)                     # deterministic: slot order, not arrival order
     for a, b in zip(g_again, g_carry):
         assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("pipeline", [None, False], ids=["pipelined", "plain"])
+def test_several_steps_per_captured_graph_equal_single_step_replays(pipeline, tune):
+    """TrainStep(steps_per_graph=K): K consecutive optimizer steps in ONE hipGraph (fresh counter-based masks per step: the
+    step counters live on the device; the input pipeline's hand-over from step to step inside the graph) -- two calls
+    equal 2 K replays of the single-step graph: every loss, every parameter, the dropout counter."""
+    from acm_gnn_amd import GCN, FusedAdamW, functional as AF, train as T
+    tune(pipeline=1024)
+    n, K = 5000, 4
+    ops, x, y = _pipeline_case(n, 30, seed=21)
+    w = T.row_weights(torch.arange(0, n, 3, device=DEV), n)
+
+    def run(spg):
+        torch.manual_seed(0)
+        model = GCN(7, 64, 2, 2, n, 0.25, "acmgcnp", 0, variant=False, attn_layernorm=True).to(DEV)
+        model.dropout_state = AF.DropoutState(torch.device(DEV), seed=31)
+        opt = FusedAdamW(model.parameters(), lr=0.01, weight_decay=1e-3)
+        step = T.TrainStep(model, opt, x, ops, y, w, use_graph=True, pipeline_input=pipeline, steps_per_graph=spg)
+        assert step.steps_per_call == spg and (step.pipe is not None) == (pipeline is None)
+        losses = []
+        for _ in range(2 * K // spg):
+            step()
+            losses += [float(v) for v in step.losses] if spg > 1 else [float(step.loss)]
+        return losses, [p.detach().clone() for p in model.parameters()], int(model.dropout_state.step.item())
+
+    la, pa, ca = run(1)
+    lb, pb, cb = run(K)
+    assert ca == cb == 2 * K and len(la) == len(lb) == 2 * K
+    assert la == lb, (la, lb)
+    assert all(torch.equal(u, v) for u, v in zip(pa, pb))
