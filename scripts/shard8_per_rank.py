@@ -66,6 +66,7 @@ def main():
     ap.add_argument("--world", type=int, default=8)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--dataset", default="twitch-gamer")
+    ap.add_argument("--ranks", default="", help="comma-separated ranks to measure (default: all)")
     args = ap.parse_args()
     dev = torch.device("cuda", 0)
     install_stand_ins()
@@ -79,7 +80,7 @@ def main():
     low = low.tocsr()
     low.sort_indices()
     per_rank = []
-    for rank in range(world):
+    for rank in ([int(r) for r in args.ranks.split(",")] if args.ranks else range(world)):
         b, e = plan.rows(rank)
         loc = low[b:e].tocsr()
         s = (1.0 / deg[b:e]).astype(np.float32)                      # A_low = D^-1 (A + I): one value per row
