@@ -27,7 +27,7 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured stream)
 FP32_MFMA_PEAK_TF = 157.3
-TRAFFIC_FILE = "r03_pmc_traffic.json"
+TRAFFIC_FILE = "r04_pmc_traffic.json"        # profiles/: HBM bytes per launch from the rocprofv3 --pmc passes (collect_profiles.sh)
 WINDOWS = 5                    # timed windows of --steps replays each; ms_per_step is the median window
 
 
@@ -59,7 +59,10 @@ def parse():
                     help="take the row-sharded path (RCCL collectives inside the captured step) even with one rank; needs a "
                          "torch.distributed launch")
     ap.add_argument("--steps-per-graph", type=int, default=-1,
-                    help="optimizer steps captured per hipGraph (default: the largest of 5, 4, 2, 1 that divides --steps)")
+                    help="optimizer steps captured per hipGraph (default 1; must divide --steps)")
+    ap.add_argument("--traffic-json", default=None,
+                    help="pmc_traffic.json of scripts/make_traffic_json.py to quote roofline.traffic from (default: the committed "
+                         "profiles/ file; either is quoted only while the kernel sources hash to what it was collected on)")
     ap.add_argument("--no-extras", action="store_true",
                     help="skip the side measurements of the single-GPU run (literal form, random node order)")
     ap.add_argument("--no-check", action="store_true", help="skip the comparisons with the CPU oracle (eval-mode logits on "
@@ -246,13 +249,14 @@ def main():
         # PMC traffic cannot be sampled from inside this process; the figure measured for this kernel on this
         # workload by the committed rocprofv3 --pmc passes (scripts/collect_profiles.sh) is attached when it applies
         traffic, traffic_source = None, None
-        tpath = os.path.join(ROOT, "profiles", TRAFFIC_FILE)
+        tpath = args.traffic_json or os.path.join(ROOT, "profiles", TRAFFIC_FILE)
         if world == 1 and args.dataset == "twitch-gamer" and args.node_order == "degree" and os.path.exists(tpath):
             with open(tpath) as fh:
                 rec = json.load(fh)
             sys.path.insert(0, os.path.join(ROOT, "scripts"))
             from make_traffic_json import kernel_source_hash
-            traffic_source = f"profiles/{TRAFFIC_FILE}" + (f"@{rec['_commit']}" if "_commit" in rec else "")
+            traffic_source = (os.path.relpath(tpath, ROOT) if args.traffic_json else f"profiles/{TRAFFIC_FILE}") + \
+                (f"@{rec['_commit']}" if "_commit" in rec else "")
             if rec.get("_kernel_source_hash") == kernel_source_hash():
                 traffic = rec.get(dominant, {}).get("hbm_bytes")
             else:                                   # counters collected for other kernels: not quoted
@@ -337,9 +341,10 @@ def main():
         timer_t.daemon = True
         timer_t.start()
         try:
-            # several consecutive optimizer steps per captured graph (the ~8 us between two graph launches once per call
-            # instead of once per step): the largest of 5, 4, 2 that divides --steps
-            spg = next((k for k in (5, 4, 2) if args.steps % k == 0), 1) if args.steps_per_graph < 0 else args.steps_per_graph
+            # one optimizer step per captured graph.  (--steps-per-graph K captures K consecutive steps in one graph: measured
+            # SLOWER on the same box, 0.2842 ms against 0.2785 / 0.2798 at K = 5 / 1 -- back-to-back replays of a small graph
+            # already overlap the next launch with the running one; profiles/r04_steps_per_graph.txt)
+            spg = 1 if args.steps_per_graph < 0 else args.steps_per_graph
             gstep = T.TrainStep(model, opt, x, ops, y, w, use_graph=True, fused_dropout=fused_drop, steps_per_graph=spg)
             ms_per_step, loss = timed_graph_steps(gstep, spread)
             spread["steps_per_graph"] = spg

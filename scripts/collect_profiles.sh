@@ -27,4 +27,7 @@ for PASS in "FETCH_SIZE:pmc_fetch_size_kb" "WRITE_SIZE:pmc_write_size_kb" "TCC_H
 done
 if [ "$COMMIT" = "unknown" ]; then echo "collect_profiles.sh: pass the commit the box runs (git rev-parse --short HEAD) as the second argument" >&2; fi
 python $REPO/scripts/make_traffic_json.py $OUT/pmc_fetch_size_kb.csv $OUT/pmc_write_size_kb.csv $COMMIT > $OUT/pmc_traffic.json
+# the driver's line LAST, quoting the counters just collected (same kernel sources by construction: no stale traffic)
+mv $OUT/bench.json $OUT/bench_first.json
+$BENCH --traffic-json $OUT/pmc_traffic.json > $OUT/bench.json 2>> $OUT/bench.err
 tail -1 $OUT/bench.json | cut -c1-400

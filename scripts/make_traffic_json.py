@@ -36,15 +36,16 @@ def kernel_source_hash(root=ROOT):
 LABELS = {
     "conv_agg_fwd/F64k3i7": ["agg_fused_pair_kernel", "agg_fused_kernel<8"],
     "conv_agg_bwd/F64k3i7": ["agg_bwd16_kernel", "agg_bwd_kernel<8, 3"],     # (whichever ran: the first needle found wins)
-    "conv_agg_epi/F64k3i7": ["agg_epi16_kernel", "agg_epi16_cap4_kernel", "agg_epilogue_kernel<8, 3>"],   # pipelined step: the row-local stage of the forward alone
-    "conv_agg_bwd+gather/F64k3i7": ["agg_bwd_gather_kernel"],        # ... and the backward carrying the next step's gather
-    "conv_agg_bwd+gather+proj/F64k3i7": ["agg_bwd16_gather_kernel<true, true, true>"],   # ... and the output layer's projection backward
-    "conv_agg_bwd+proj/F64k3i7": ["agg_bwd16_kernel<true, true, true>"],
+    "conv_agg_epi/F64k3i7": ["agg_epi16_kernel", "agg_epilogue_kernel<8, 3>"],   # pipelined step: the row-local stage of the forward alone
+    "conv_agg_bwd+gather/F64k3i7": ["agg_bwd16_gather_kernel<3, true, false>"],        # ... and the backward carrying the next step's gather
+    "conv_agg_bwd+gather+proj/F64k3i7": ["agg_bwd16_gather_kernel<3, true, true>"],   # ... and the output layer's projection backward
+    "conv_agg_bwd+proj/F64k3i7": ["agg_bwd16_kernel<3, 8, true, true, true>"],
     "conv_fwd_tail/F2k3": ["spmm_narrow_kernel<2, 2, 16, true, EpiRaw>", "conv_tail_rows_kernel<2, 2>"],   # + loss + K3
     "conv_bwd_spmm/F2k3": ["spmm_narrow_kernel<2, 2, 16, true, EpiBwd>"],
     "proj_bwd/168114x64x6": ["proj_bwd_kernel<6>"],
     "proj_fwd/168114x64x6": ["proj_fwd_kernel<2>"],
     "dropout/168114x7": ["dropout_kernel"],
+    "dropout/168120x7": ["dropout_kernel"],
     "reduce_flush": ["reduce_segments_kernel"],          # every deferred second phase of the step, one launch
     "adam_step": ["adam_kernel"],
 }

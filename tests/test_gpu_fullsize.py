@@ -121,7 +121,7 @@ def _compare_grads(model, params, tag, rec, params64=None):
     return worst
 
 
-def _oracle_step(params, x, y, tr, ops_t, structure, variant, dtype=torch.float32, **kw):
+def _oracle_step(params, x, y, tr, ops_t, structure, variant, dtype=torch.float32, model_type="acmgcnp", **kw):
     """oracle.gcn_forward + loss + backward in `dtype`; returns (logits, loss, params with .grad)."""
     low_t, high_t, un_t = ops_t
     if dtype != torch.float32:
@@ -130,7 +130,7 @@ def _oracle_step(params, x, y, tr, ops_t, structure, variant, dtype=torch.float3
     ps = {k: v.detach().to(dtype).clone().requires_grad_(True) for k, v in params.items()}
     if "masks" in kw and kw["masks"]:
         kw = dict(kw, masks={k: v.to(dtype) for k, v in kw["masks"].items()})
-    ref = O.gcn_forward(ps, x.to(dtype), low_t, high_t, un_t if structure else None, model_type="acmgcnp",
+    ref = O.gcn_forward(ps, x.to(dtype), low_t, high_t, un_t if structure else None, model_type=model_type,
                         variant=bool(variant), structure_info=structure, attn_layernorm=True, training=True, **kw)
     loss = O.nll_loss_on(ref, y, torch.from_numpy(tr))
     loss.backward()
@@ -142,11 +142,15 @@ def _factors(state, p, tag, n, c, step=None):
     return dropout_factors(state.seed, int(state.step.item()) if step is None else step, tag, float(np.float32(p)), n, c)
 
 
-TWITCH = [(v, s, o) for o in ("degree", "random") for s in (0, 1) for v in (0, 1)]      # grouped by workload
+# (variant, structure_info, node order, model): every cell of the reference's grid on the degree-ordered graph
+# (ACM-Geometric/sh/run_all_settings.sh:10-14: variant x structure_info x {acmgcnp, acmgcnpp}); the random order -- the
+# in-operator relabelling, other row lengths per block -- for the two cells that take different kernels
+TWITCH = [(v, s, "degree", "acmgcnp") for s in (0, 1) for v in (0, 1)] + \
+         [(0, 0, "degree", "acmgcnpp"), (1, 1, "degree", "acmgcnpp"), (0, 0, "random", "acmgcnp"), (1, 1, "random", "acmgcnp")]
 
 
-@pytest.mark.parametrize("variant,structure,order", TWITCH)
-def test_twitch_shaped_step_matches_oracle(variant, structure, order):
+@pytest.mark.parametrize("variant,structure,order,model_type", TWITCH)
+def test_twitch_shaped_step_matches_oracle(variant, structure, order, model_type):
     """One forward + loss + backward of the bench model at bench size; the plain autograd route and the fused
     training-step route (output-layer tail kernel, deferred reductions) against the oracle."""
     import acm_gnn_amd
@@ -156,7 +160,7 @@ def test_twitch_shaped_step_matches_oracle(variant, structure, order):
     tr = wl["splits"][0]
     x, y = torch.from_numpy(wl["x"]), torch.from_numpy(wl["y"])
     torch.manual_seed(7)
-    model = acm_gnn_amd.GCN(x.shape[1], 64, 2, 2, n, 0.0, "acmgcnp", structure, variant=bool(variant),
+    model = acm_gnn_amd.GCN(x.shape[1], 64, 2, 2, n, 0.0, model_type, structure, variant=bool(variant),
                             attn_layernorm=True)
     with torch.no_grad():                              # non-trivial LayerNorm parameters
         for m in model.gcns:
@@ -166,13 +170,14 @@ def test_twitch_shaped_step_matches_oracle(variant, structure, order):
     p0 = {k: v.detach().cpu().clone() for k, v in model.named_parameters() if k not in ("fea_param", "xX_param")}
     ops_t = _oracle_operands(wl)
     t0 = time.time()
-    ref, ref_loss, params = _oracle_step(p0, x, y, tr, ops_t, structure, variant, dropout=0.0)
+    ref, ref_loss, params = _oracle_step(p0, x, y, tr, ops_t, structure, variant, dropout=0.0, model_type=model_type)
     t_oracle = time.time() - t0
     cache64 = {}
 
     def params64():
         if "p" not in cache64:
-            cache64["p"] = _oracle_step(p0, x, y, tr, ops_t, structure, variant, dtype=torch.float64, dropout=0.0)[2]
+            cache64["p"] = _oracle_step(p0, x, y, tr, ops_t, structure, variant, dtype=torch.float64, dropout=0.0,
+                                        model_type=model_type)[2]
         return cache64["p"]
 
     model = model.to(DEV)
@@ -215,7 +220,7 @@ def test_twitch_shaped_step_matches_oracle(variant, structure, order):
     torch.cuda.synchronize()
     assert abs(float(loss2) - float(ref_loss)) < LOSS_TOL * max(1.0, abs(float(ref_loss)))
     rec["grad_worst_rel_fused_step"] = _compare_grads(model, params, "train-step", {}, params64)
-    _record(f"twitch/v{variant}s{structure}/{order}", **rec)
+    _record(f"twitch/{model_type}/v{variant}s{structure}/{order}", **rec)
 
 
 @pytest.mark.parametrize("variant,structure", [(0, 0), (1, 1)])

@@ -7,8 +7,8 @@ snap-patents (2.92 M nodes, 13.98 M DIRECTED edges, 269 features; ACM-Geometric/
     logits, loss and every parameter gradient;
   * every `n_rows * ld >= 2^31` guard of the row-local kernels (32-bit element offsets inside the kernels): driven through
     the C ABI with operands whose leading dimension is large enough to trip it at 70 k rows -- the sixteen-rows-per-wave
-    kernels must decline and the four-rows-per-wave kernels (64-bit row addresses) must return the same numbers as for
-    compact operands; guards that have no fallback must fail loudly (ACM_EUNSUPPORTED), never index out of range.
+    forward stage must decline and the four-rows-per-wave kernel (64-bit row addresses) must return the same numbers as for
+    compact operands; the entry points without a 64-bit route must fail loudly (ACM_EUNSUPPORTED), never index out of range.
 
 The graphs are drawn on the GPU (a power-law pairing with torch: the numpy Chung-Lu generator of acm_gnn_amd.data needs two
 minutes for 30 M edges; what matters here is the SIZE and the degree skew, not the exact edge count)."""
@@ -73,7 +73,7 @@ def test_training_step_at_linkx_scale_matches_oracle(name, n, n_edges, max_deg, 
     t_prep = time.time() - t0
     torch.manual_seed(5)
     model = acm_gnn_amd.GCN(f_in, 64, n_cls, 2, n, 0.0, "acmgcnp", 0, variant=False, attn_layernorm=True)
-    p0 = {k: v.detach().clone().requires_grad_(True) for k, v in model.named_parameters() if k not in ("fea_param", "xX_param")}
+    p0 = {k: v.detach().cpu().clone().requires_grad_(True) for k, v in model.named_parameters() if k not in ("fea_param", "xX_param")}
     # ---- the HIP path: the operators as operators_for would build them (pattern-only where the pattern is symmetric, the
     # explicit form + an explicit transposed CSR otherwise; degree relabelling inside the operator for graphs this size)
     ops = relabel_by_degree(as_implicit(FilterOperators(CsrGraph.from_scipy(low, DEV))))
@@ -224,11 +224,10 @@ def test_rows_times_pitch_beyond_2_31_takes_the_64_bit_kernels_or_fails_loudly()
     rc = lib.acm_conv_agg_bwd(n, C.byref(q), C.c_void_p(ws.data_ptr()), ws.numel() * 4, None)
     torch.cuda.synchronize()
     assert rc == 0 and torch.isfinite(d_params).all()
-    # (4) K3 of the literal layer: acm_bwd_local16 declines at that pitch (acm_conv_local16.hip), conv_bwd_local_grouped_kernel
-    #     (64-bit rows) returns what the sixteen-rows-per-wave kernel returns on compact operands
+    # (4) K3 of the literal layer: acm_conv_bwd_local refuses a pitch beyond 32-bit offsets as a whole (both of its kernels
+    #     index with them), and runs on the compact operands
     g = torch.Generator().manual_seed(4)
     pre, zi = torch.randn(n, 128, generator=g).to(DEV), torch.randn(n, 64, generator=g).to(DEV)
-    res = {}
     for tag, go in (("compact", c["grad_out"]), ("wide", go_w)):
         b = _lib.ConvBwdLocal()
         b.f_out, b.n_channels, b.relu_after, b.relu_mlp, b.layernorm, b.scale = 64, 3, 1, 1, 1, 3.0
@@ -249,7 +248,7 @@ def test_rows_times_pitch_beyond_2_31_takes_the_64_bit_kernels_or_fails_loudly()
         wsb = torch.empty(nbytes.value // 4 + 1, device=DEV)
         rc = lib.acm_conv_bwd_local(n, C.byref(b), C.c_void_p(wsb.data_ptr()), wsb.numel() * 4, None)
         torch.cuda.synchronize()
-        assert rc == 0, lib.acm_last_error()
-        res[tag] = (gl.clone(), dz[:, 128:].clone(), flat.clone())
-    for u, v in zip(res["compact"], res["wide"]):
-        assert float((u - v).abs().max()) < 1e-4 * max(1.0, float(u.abs().max()))
+        if tag == "wide":
+            assert rc == 4 and b"2^31" in lib.acm_last_error(), (rc, lib.acm_last_error())
+        else:
+            assert rc == 0 and torch.isfinite(gl).all() and torch.isfinite(flat).all(), lib.acm_last_error()
