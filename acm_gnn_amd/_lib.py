@@ -116,7 +116,8 @@ class ConvAggFwd(C.Structure):
                 ("next_f", C.c_int32), ("next_relu", C.c_int32),
                 ("next_zlh", C.c_void_p), ("ld_next_zlh", C.c_int64), ("next_zi", C.c_void_p), ("ld_next_zi", C.c_int64),
                 ("agg_given", C.c_int32), ("reserved0", C.c_int32),
-                ("agg_copy", C.c_void_p), ("ld_agg_copy", C.c_int64), ("xs_copy", C.c_void_p), ("ld_xs_copy", C.c_int64)]
+                ("agg_copy", C.c_void_p), ("ld_agg_copy", C.c_int64), ("xs_copy", C.c_void_p), ("ld_xs_copy", C.c_int64),
+                ("next_x", C.c_void_p), ("ld_next_x", C.c_int64), ("next_drop", Dropout)]
 
 
 class ConvAggBwd(C.Structure):

@@ -685,6 +685,9 @@ extern "C" int acm_conv_agg_fwd(const acm_csr_t* a, const acm_conv_agg_fwd_t* p,
                                  (p->ld_agg_copy * 4) % 16 == 0 && (p->ld_xs_copy * 4) % 16 == 0 && p->ld_agg_copy >= p->f_pad &&
                                  p->ld_xs_copy >= p->f_pad && p->agg_copy != p->agg && p->xs_copy != p->xs), ACM_EINVAL,
                 "acm_conv_agg_fwd: agg_copy / xs_copy need agg_given, 16-byte aligned rows of f_pad floats, no aliasing");
+    ACM_REQUIRE(!p->next_x || (p->agg_copy && p->ld_next_x >= p->f_in && p->next_drop.p >= 0.f && p->next_drop.p < 1.f &&
+                               (p->next_drop.p == 0.f || p->next_drop.step)), ACM_EINVAL,
+                "acm_conv_agg_fwd: next_x needs agg_copy / xs_copy (xs is refilled in place), ld_next_x >= f_in and a valid next_drop");
     // (0) fused form: gather + epilogue in one kernel (long rows included)
     if (!p->agg_given) {
         const double avg = (double)a->nnz / (double)(a->n_rows > 0 ? a->n_rows : 1);
@@ -729,7 +732,7 @@ extern "C" int acm_conv_agg_fwd(const acm_csr_t* a, const acm_conv_agg_fwd_t* p,
     }
     // (2) projections + head, row-local
     if (epi16 && !defer) {
-        st = acm_agg_epi16(p, a->n_rows, &next_done, s);
+        st = acm_agg_epi16(p, a->n_rows, &next_done, s);        // (carries next_x: the refill of xs)
         if (st == ACM_OK) return next_done ? ACM_OK : next_projection(a, p, stream);
         if (st > 0) return st;
     }
@@ -750,6 +753,10 @@ extern "C" int acm_conv_agg_fwd(const acm_csr_t* a, const acm_conv_agg_fwd_t* p,
     else ACM_EPI(16);
 #undef ACM_EPI
     ACM_CHECK_HIP(hipGetLastError());
+    if (p->next_x) {                              // the four-rows-per-wave stage does not carry the refill: a launch of its own
+        st = acm_dropout(a->n_rows, p->f_in, p->next_x, p->ld_next_x, const_cast<float*>(p->xs), p->ld_xs, p->f_pad, &p->next_drop, stream);
+        if (st != ACM_OK) return st;
+    }
     return next_projection(a, p, stream);
 }
 

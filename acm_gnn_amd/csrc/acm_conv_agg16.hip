@@ -74,6 +74,8 @@ __device__ __forceinline__ void epi16_body(const acm_conv_agg_fwd_t& p, int n_ro
     for (int q = 0; q < NC * NC; ++q) mixm[q] = p.att_mix[q];
     __syncthreads();
     const AcmDropCtx dc = acm_drop_ctx(p.post_drop);
+    AcmDropCtx ndc = dc;                           // (only read with next_x)
+    if (p.next_x) ndc = acm_drop_ctx(p.next_drop);
     const float lo_a = p.relu_after ? 0.f : -INFINITY, lo_m = p.relu_mlp ? 0.f : -INFINITY;
     const float lo_post = p.post_relu ? 0.f : -INFINITY;
     const unsigned ld_agg = (unsigned)p.ld_agg, ld_xs = (unsigned)p.ld_xs, ld_out = (unsigned)p.ld_out;
@@ -116,6 +118,15 @@ __device__ __forceinline__ void epi16_body(const acm_conv_agg_fwd_t& p, int n_ro
             for (int kb = 0; kb < KB; ++kb) {
                 p.agg_copy[rr * (unsigned)p.ld_agg_copy + 4 * kb + g] = P[kb];
                 p.xs_copy[rr * (unsigned)p.ld_xs_copy + 4 * kb + g] = x[kb];
+            }
+            if (p.next_x) {                        // ... and the NEXT step's dropped input over the elements just read (next_drop)
+#pragma unroll
+                for (int kb = 0; kb < KB; ++kb) {
+                    const int col = 4 * kb + g;
+                    float v = 0.f;
+                    if (col < p.f_in) v = p.next_x[(long)rr * p.ld_next_x + col] * acm_drop1(ndc, row, col);
+                    const_cast<float*>(p.xs)[rr * ld_xs + col] = v;
+                }
             }
         }
         // (an opaque copy of the lane's group index: the LDS operands below depend on the lane only, and hoisted out of the

@@ -383,6 +383,16 @@ class InputPipeline:
         self._host_steps = self.state.host_steps
         self.next_table_ready = self.next_agg_ready = self.adopted = False
 
+    def refill_spec(self, p):
+        """Ask the forward's row-local kernel (acm_conv_agg_fwd_t.next_x / next_drop) to write the NEXT step's dropped input
+        over the table rows it reads -- possible where the table holds exactly the rows the layer works on (one device)."""
+        if self.filled[0].shape[0] != self.x_rows.shape[0] or self.next_table_ready or self.x.stride(1) != 1:
+            return False
+        d = self.state.spec(self.p, self.tag, 0)
+        d.step_offset = 1
+        p.next_x, p.ld_next_x, p.next_drop = self.x.data_ptr(), self.x.stride(0), d
+        return True
+
     def make_next(self):
         """Between the forward and the backward: the next step's dropped input replaces this step's -- only if the forward
         took this step's from the pipeline and left its copies in ``saved`` (``adopted``); a forward that went another way
@@ -1363,9 +1373,13 @@ class AcmConvFunction(torch.autograd.Function):
             p.att_mix = mix.data_ptr()
             agg = agg_given if agg_given is not None else torch.empty(n, fp, dtype=_F32, device=dev)
             p.agg_given = int(agg_given is not None)
+            refill = False
             if ctx.pipe is not None:                  # the backward's operands: copies the row-local kernel leaves
                 p.agg_copy, p.ld_agg_copy = ctx.pipe.saved[1].data_ptr(), ctx.pipe.saved[1].stride(0)
                 p.xs_copy, p.ld_xs_copy = ctx.pipe.saved[0].data_ptr(), ctx.pipe.saved[0].stride(0)
+                # ... and (one device: the table IS this rank's rows) it refills the table with dropout_{t+1}(x) over the rows
+                # it has just copied: make_next()'s acm_dropout launch is gone
+                refill = ctx.pipe.refill_spec(p)
             p.out, p.ld_out = out.data_ptr(), out.stride(0)
             p.agg, p.ld_agg = agg.data_ptr(), agg.stride(0)
             p.att = att.data_ptr()
@@ -1406,6 +1420,8 @@ class AcmConvFunction(torch.autograd.Function):
             with _device_ctx(dev), _Timed(f"conv_agg_{'epi' if agg_given is not None else 'fwd'}/F{f}k{k}i{f_in}"):
                 st = lib.acm_conv_agg_fwd(ops.low.handle, C.byref(p), _vp(ws), ws.numel() * 4, _stream())
             _lib.check(st, "acm_conv_agg_fwd")
+            if refill:
+                ctx.pipe.next_table_ready = True
             if agg_holder is not None and agg_given is None:
                 agg_holder["agg"] = agg
             if nxt is not None:

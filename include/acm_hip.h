@@ -586,6 +586,14 @@ typedef struct {
      * an input pipeline refills before that backward runs (acm_conv_agg_bwd_t.next_agg).                             */
     float* agg_copy; int64_t ld_agg_copy;
     float* xs_copy;  int64_t ld_xs_copy;
+    /* With agg_copy / xs_copy (ABI 22): the row-local stage REFILLS `xs` in place for the next training step,
+     *     xs[row, :f_in] <- next_x[row, :f_in] * mask(next_drop),   xs[row, f_in:f_pad] <- 0
+     * -- what acm_dropout(next_x -> xs, f_pad columns, next_drop) would do in a launch of its own (a lane overwrites exactly
+     * the elements it has just read and copied to xs_copy).  next_x = NULL: off.  next_drop.step_offset = 1 draws the mask of
+     * the step after this one.  The input pipeline's hand-over (acm_conv_agg_bwd_t.next_agg gathers from the refilled xs)
+     * without its dropout launch.                                                                                     */
+    const float* next_x; int64_t ld_next_x;
+    acm_dropout_t next_drop;
 } acm_conv_agg_fwd_t;
 
 int acm_conv_agg_fwd(const acm_csr_t* a_low, const acm_conv_agg_fwd_t* p,

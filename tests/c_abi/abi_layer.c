@@ -349,6 +349,7 @@ int main(void) {
     w.out = d_o64; w.ld_out = F2;
     w.agg = d_p;
     w.head_stats = d_st64;
+    w.post_relu = 1;                                        /* the hidden layer's fused ReLU: the backward reads `out` as its mask */
     size_t wsp_bytes = 0;
     CHECK_ACM(acm_spmm_workspace_bytes(ap, F2, &wsp_bytes));
     void* wsp = to_dev(NULL, wsp_bytes);
@@ -359,6 +360,7 @@ int main(void) {
     for (int c = 0; c < K; ++c) { wb.att_vec[c] = w.att_vec[c]; wb.ln_weight[c] = w.ln_weight[c]; wb.ln_bias[c] = w.ln_bias[c]; }
     wb.att_mix = w.att_mix;
     wb.agg = d_p; wb.head_stats = d_st64; wb.d_params = d_dpa;
+    wb.post_relu = 1; wb.out = d_o64; wb.ld_out = F2;
     size_t ab2_bytes = 0;
     CHECK_ACM(acm_conv_agg_bwd_workspace_bytes(N, FIN, F2, &ab2_bytes));
     void* abw2 = to_dev(NULL, ab2_bytes);
@@ -367,10 +369,13 @@ int main(void) {
     acm_conv_agg_fwd_t wp = w;
     wp.agg_given = 1; wp.out = d_o64b;
     wp.agg_copy = d_pc; wp.ld_agg_copy = FPAD; wp.xs_copy = d_xc; wp.ld_xs_copy = FPAD;
+    /* ... and (ABI 22) the row-local stage refills `xs` in place with the next step's input (next_x; no dropout here: p = 0),
+     * so the table the backward's gather waves walk IS `xs` */
+    wp.next_x = d_xnext; wp.ld_next_x = FPAD; wp.next_drop.p = 0.f;
     CHECK_ACM(acm_conv_agg_fwd(ap, &wp, wsp, wsp_bytes, NULL));
     acm_conv_agg_bwd_t wq = wb;
-    wq.agg = d_pc; wq.xs = d_xc; wq.d_params = d_dpb;
-    wq.next_a = ap; wq.next_xg = d_xnext; wq.ld_next_xg = FPAD; wq.next_row_scale = d_rs; wq.next_agg = d_pnext; wq.ld_next_agg = FPAD;
+    wq.agg = d_pc; wq.xs = d_xc; wq.d_params = d_dpb; wq.out = d_o64b;
+    wq.next_a = ap; wq.next_xg = wp.xs; wq.ld_next_xg = FPAD; wq.next_row_scale = d_rs; wq.next_agg = d_pnext; wq.ld_next_agg = FPAD;
     CHECK_ACM(acm_conv_agg_bwd(N, &wq, abw2, ab2_bytes, NULL));
     CHECK_HIP(hipDeviceSynchronize());
     static float o64[N * F2], o64b[N * F2], pp[N * FPAD], pc[N * FPAD], xc[N * FPAD], pnext[N * FPAD], dpa[NPAR2], dpb[NPAR2];

@@ -757,6 +757,10 @@ class FakeLib:
                 return 1
             _view(p.agg_copy, n, fp, p.ld_agg_copy)[...] = agg
             _view(p.xs_copy, n, fp, p.ld_xs_copy)[...] = _view(p.xs, n, fp, p.ld_xs)
+            if p.next_x:                                    # ... and refills xs for the next step (ABI 22)
+                nxt = np.zeros((n, fp))
+                nxt[:, :fi] = _view(p.next_x, n, fi, p.ld_next_x).astype(np.float64) * dropout_factors(p.next_drop, n, fi)
+                _view(p.xs, n, fp, p.ld_xs)[...] = nxt
         att = _view(p.att, n, 4, 4)
         att[...] = 0
         att[:, :k] = hd["alpha"]

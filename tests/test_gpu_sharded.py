@@ -100,15 +100,19 @@ def _worker(rank, world, port, cfg, ret):
                                  dict(model="acmgcnpp", s=0, variant=0, dropout=0.3),
                                  dict(model="acmgcnp", s=0, variant=0, dropout=0.1, dataset="twitch-gamer", plan="interleave"),
                                  dict(model="acmgcnp", s=0, variant=0, dropout=0.1, dataset="twitch-gamer", plan="work"),
-                                 dict(model="acmsgc", s=0, variant=0, dropout=0.0, dataset="arxiv-year", plan="work", hops=3)],
+                                 dict(model="acmsgc", s=0, variant=0, dropout=0.0, dataset="arxiv-year", plan="work", hops=3),
+                                 # EIGHT ranks on the one device: eight HIP contexts, the halos through gloo
+                                 dict(model="acmgcnp", s=1, variant=0, dropout=0.3, world=8),
+                                 dict(model="acmgcnp", s=0, variant=1, dropout=0.3, plan="work", world=8)],
                          ids=["agg", "struct-dropout", "acmii", "work-plan-struct-acmii", "work-plan-agg", "acmgcnpp",
-                              "twitch-degree-interleaved", "twitch-random-work-plan", "arxiv-year-3hop-sgc-work-plan"])
+                              "twitch-degree-interleaved", "twitch-random-work-plan", "arxiv-year-3hop-sgc-work-plan",
+                              "world8-struct-dropout", "world8-work-plan-acmii"])
 def test_two_ranks_on_one_gpu_equal_single_process(cfg):
     import queue
     import time
     import torch.multiprocessing as mp
     import torch.nn.functional as F
-    world, port = 2, _free_port()
+    world, port = int(cfg.get("world", 2)), _free_port()
     ctx = mp.get_context("spawn")
     ret = ctx.Queue()
     procs = [ctx.Process(target=_worker, args=(r, world, port, cfg, ret)) for r in range(world)]

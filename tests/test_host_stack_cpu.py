@@ -731,9 +731,11 @@ def test_input_pipeline_equals_plain_train_step(monkeypatch, tune):
     ops, n = _dense_graph_ops()
     x, y = torch.randn(n, 7, generator=torch.Generator().manual_seed(1)), torch.randint(0, 2, (n,), generator=torch.Generator().manual_seed(2))
     w = T.row_weights(torch.arange(0, n, 2), n)
-    calls = {"given": [], "carried": [], "spmm": 0}
-    fwd, bwd, spmm_ex = fake.acm_conv_agg_fwd, fake.acm_conv_agg_bwd, fake.acm_spmm_ex
-    monkeypatch.setattr(fake, "acm_conv_agg_fwd", lambda h, pp, *a: (calls["given"].append(int(pp._obj.agg_given)), fwd(h, pp, *a))[1])
+    calls = {"given": [], "carried": [], "spmm": 0, "refill": [], "dropout": 0}
+    fwd, bwd, spmm_ex, drop = fake.acm_conv_agg_fwd, fake.acm_conv_agg_bwd, fake.acm_spmm_ex, fake.acm_dropout
+    monkeypatch.setattr(fake, "acm_conv_agg_fwd", lambda h, pp, *a: (calls["given"].append(int(pp._obj.agg_given)),
+                                                                    calls["refill"].append(bool(pp._obj.next_x)), fwd(h, pp, *a))[2])
+    monkeypatch.setattr(fake, "acm_dropout", lambda *a: (calls.__setitem__("dropout", calls["dropout"] + 1), drop(*a))[1])
     monkeypatch.setattr(fake, "acm_conv_agg_bwd", lambda nn, qq, *a: (calls["carried"].append(bool(qq._obj.next_agg)), bwd(nn, qq, *a))[1])
 
     def run(pipeline):
@@ -751,6 +753,9 @@ def test_input_pipeline_equals_plain_train_step(monkeypatch, tune):
     step_b, loss_b, sd_b = run(None)
     assert step_b.pipe is not None and ops.low.stream_waves == 40          # four gather waves per 16 rows
     assert calls["given"] == [1] * 5 and calls["carried"] == [True] * 5
+    # ... and (ABI 22) refills the table with the next step's dropped input itself: one acm_dropout launch in prime(), none
+    # per step (the plain run above: one per step)
+    assert calls["refill"][-5:] == [True] * 5 and calls["dropout"] == 5 + 1, calls
     np.testing.assert_allclose(loss_b, loss_a, rtol=1e-5, atol=1e-6)
     for k in sd_a:
         np.testing.assert_allclose(sd_b[k].numpy(), sd_a[k].numpy(), rtol=1e-4, atol=1e-5, err_msg=k)
