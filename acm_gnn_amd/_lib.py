@@ -14,7 +14,7 @@ c_i32p = C.POINTER(C.c_int32)
 
 ACM_OK = 0
 STATUS_NAMES = {1: "ACM_EINVAL", 2: "ACM_ESHAPE", 3: "ACM_EHIP", 4: "ACM_EUNSUPPORTED", 5: "ACM_ENOMEM"}
-ABI_VERSION = 22
+ABI_VERSION = 23
 
 # every symbol include/acm_hip.h declares
 EXPORTED_SYMBOLS = (
@@ -40,7 +40,7 @@ class CsrInfo(C.Structure):
                 ("indptr", C.c_void_p), ("indices", C.c_void_p), ("vals", C.c_void_p),
                 ("src_pos", C.c_void_p),
                 ("stream_steps", C.c_int64), ("stream_slices", C.c_int64),
-                ("stream_waves", C.c_int32), ("stream_long_rows", C.c_int32)]
+                ("stream_waves", C.c_int32), ("stream_long_rows", C.c_int32), ("hub_ids", C.c_int64)]
 
 
 class ConvFwd(C.Structure):
@@ -188,7 +188,7 @@ class AdamTensor(C.Structure):
 class AdamConfig(C.Structure):
     _fields_ = [("lr", C.c_double), ("beta1", C.c_double), ("beta2", C.c_double), ("eps", C.c_double),
                 ("weight_decay", C.c_double), ("decoupled", C.c_int32), ("also_advance", C.c_void_p),
-                ("arrive", C.c_void_p)]
+                ("arrive", C.c_void_p), ("pending", C.c_void_p)]
 
 
 _lib = None

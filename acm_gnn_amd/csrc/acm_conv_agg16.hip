@@ -84,19 +84,22 @@ __device__ __forceinline__ void epi16_body(const acm_conv_agg_fwd_t& p, int n_ro
     int base = wave * 16;
     if (base >= n_rows) return;
     // the operands of the NEXT step are requested before this step's math (one step of loads in flight)
-    float nP[KB], nx[KB];
+    float nP[KB], nx[KB], nr[KB];                  // (nr: the raw input rows of the refill, next_x -- requested with the others)
     {
         const unsigned rr = (unsigned)min(base + m, n_rows - 1);
 #pragma unroll
-        for (int kb = 0; kb < KB; ++kb) nP[kb] = p.agg[rr * ld_agg + 4 * kb + g], nx[kb] = p.xs[rr * ld_xs + 4 * kb + g];
+        for (int kb = 0; kb < KB; ++kb) {
+            nP[kb] = p.agg[rr * ld_agg + 4 * kb + g], nx[kb] = p.xs[rr * ld_xs + 4 * kb + g];
+            nr[kb] = (p.next_x && 4 * kb + g < p.f_in) ? p.next_x[(long)rr * p.ld_next_x + 4 * kb + g] : 0.f;
+        }
     }
     for (; base < n_rows; base += nwaves * 16) {
         const int row = base + m;
         const bool valid = row < n_rows;
         const unsigned rr = (unsigned)(valid ? row : n_rows - 1);
-        float P[KB], x[KB];
+        float P[KB], x[KB], xraw[KB];
 #pragma unroll
-        for (int kb = 0; kb < KB; ++kb) P[kb] = nP[kb], x[kb] = nx[kb];
+        for (int kb = 0; kb < KB; ++kb) P[kb] = nP[kb], x[kb] = nx[kb], xraw[kb] = nr[kb];
         f32x4 D[NC][4];
         if (NC == 4) {                             // structure channel: relu(deg (A_low S) - S), finished rows of 64 floats
             const float dg = p.deg[rr];
@@ -111,7 +114,10 @@ __device__ __forceinline__ void epi16_body(const acm_conv_agg_fwd_t& p, int n_ro
             const int nb = base + nwaves * 16;
             const unsigned r2 = (unsigned)min(nb + m, n_rows - 1);
 #pragma unroll
-            for (int kb = 0; kb < KB; ++kb) nP[kb] = p.agg[r2 * ld_agg + 4 * kb + g], nx[kb] = p.xs[r2 * ld_xs + 4 * kb + g];
+            for (int kb = 0; kb < KB; ++kb) {
+                nP[kb] = p.agg[r2 * ld_agg + 4 * kb + g], nx[kb] = p.xs[r2 * ld_xs + 4 * kb + g];
+                nr[kb] = (p.next_x && 4 * kb + g < p.f_in) ? p.next_x[(long)r2 * p.ld_next_x + 4 * kb + g] : 0.f;
+            }
         }
         if (p.agg_copy && valid) {                 // the backward's operands (input pipeline): the rows just read
 #pragma unroll
@@ -123,9 +129,7 @@ __device__ __forceinline__ void epi16_body(const acm_conv_agg_fwd_t& p, int n_ro
 #pragma unroll
                 for (int kb = 0; kb < KB; ++kb) {
                     const int col = 4 * kb + g;
-                    float v = 0.f;
-                    if (col < p.f_in) v = p.next_x[(long)rr * p.ld_next_x + col] * acm_drop1(ndc, row, col);
-                    const_cast<float*>(p.xs)[rr * ld_xs + col] = v;
+                    const_cast<float*>(p.xs)[rr * ld_xs + col] = col < p.f_in ? xraw[kb] * acm_drop1(ndc, row, col) : 0.f;
                 }
             }
         }

@@ -135,6 +135,15 @@ class DeferredReductions:
                         dist.all_reduce(t, group=g)
         self._keep.clear()
 
+    @property
+    def collectives_pending(self):
+        return bool(self._allreduce)
+
+    def flushed(self):
+        """The list was flushed by someone else (acm_adam_step with acm_adam_config_t.pending): release what it held."""
+        assert self._list.n == 0 and not self._allreduce
+        self._keep.clear()
+
     def discard(self):
         self._list.n = 0
         self._keep.clear()
@@ -1798,8 +1807,9 @@ def _backward_agg(ctx, grad_out):
         if lazy is not None:
             proj_bwd(lazy["x"], lazy["dz"], lazy["w3"], lazy["d_w"], defer=defer, dx_out=lazy["placeholder"])
             q.grad_out, q.proj_dz, lazy = grad_out.data_ptr(), None, None
-        if carry:                                     # (the pipeline notices in end_step() and primes itself again)
-            q.next_a, q.next_xg, q.next_row_scale, q.next_agg, carry = None, None, None, None, False
+        if carry:                                     # the gather as its own launch, right here: the pipeline stays valid
+            q.next_a, q.next_xg, q.next_row_scale, q.next_agg = None, None, None, None          # (also inside a capture, where
+            spmm(ops.low, pipe.table(), out=pipe.agg(), row_scale=ops.row_scale)                 # nobody could prime() it again)
         with _device_ctx(dev), _Timed(f"conv_agg_bwd/F{f}k{k}i{f_in}"):
             st = lib.acm_conv_agg_bwd(n, C.byref(q), _vp(ws), ws.numel() * 4, _stream())
     _lib.check(st, "acm_conv_agg_bwd")

@@ -16,6 +16,11 @@ from . import _lib
 from .graph import _device_ctx, _require_cuda, _stream
 
 
+def _timed(name):
+    from .functional import _Timed          # (functional imports nothing from here; late to keep import order free)
+    return _Timed(name)
+
+
 class _FusedAdamBase(torch.optim.Optimizer):
     _decoupled = False
 
@@ -63,7 +68,11 @@ class _FusedAdamBase(torch.optim.Optimizer):
                 st[key] = v.detach().to(device=p.device, dtype=torch.float32).reshape(p.shape).contiguous()
 
     @torch.no_grad()
-    def step(self, closure=None):
+    def step(self, closure=None, pending=None):
+        """``pending``: a functional.DeferredReductions the training loop has NOT flushed -- the update launch flushes it
+        itself (acm_adam_config_t.pending: the reducing blocks lead the grid and apply the update to the gradient elements
+        they produce; one launch less per step).  Only train.TrainStep passes it, and only when nothing else (a gradient
+        all-reduce, a reader of .grad) has to come between the flush and the update."""
         loss = None
         if closure is not None:
             with torch.enable_grad():
@@ -71,6 +80,9 @@ class _FusedAdamBase(torch.optim.Optimizer):
         lib = _lib.load()
         groups = [(g, [p for p in g["params"] if p.grad is not None]) for g in self.param_groups]
         groups = [(g, live) for g, live in groups if live]
+        if pending is not None and len(groups) != 1:          # several launches (or none): the flush on its own, first
+            pending.flush()
+            pending = None
         if not groups and self.also_advance is not None:
             self.also_advance.add_(1)
         for gi, (group, live) in enumerate(groups):
@@ -106,6 +118,9 @@ class _FusedAdamBase(torch.optim.Optimizer):
                 if g.dtype != torch.float32 or not g.is_contiguous() or g.is_sparse:
                     if g.is_sparse:
                         raise RuntimeError("FusedAdam does not support sparse gradients")
+                    if pending is not None:               # a copy reads the gradient: its sums must have landed
+                        pending.flush()
+                        pending = None
                     g = g.to(torch.float32).contiguous()
                     keep.append(g)
                 e.grad = g.data_ptr()
@@ -120,10 +135,12 @@ class _FusedAdamBase(torch.optim.Optimizer):
                                   float(group["eps"]), float(group["weight_decay"]), int(self._decoupled),
                                   self.also_advance.data_ptr() if (self.also_advance is not None and
                                                                    gi == len(groups) - 1) else None,
-                                  arrive.data_ptr())
-            with _device_ctx(dev):
+                                  arrive.data_ptr(), pending.pointer() if pending is not None else None)
+            with _device_ctx(dev), _timed("adam" + ("+flush" if pending is not None and pending.pending else "")):
                 status = lib.acm_adam_step(len(live), C.cast(entries, C.c_void_p), C.byref(cfg), _stream())
             _lib.check(status, "acm_adam_step")
+            if pending is not None:
+                pending.flushed()
             del keep
         return loss
 

@@ -43,8 +43,11 @@ def _capture_mode():
 
 class TrainStep:
     def __init__(self, model, optimizer, x, adj, labels, weights, adj_high=None, adj_un=None, use_graph=False,
-                 fused_dropout=None, pipeline_input=None, steps_per_graph=1):
-        """``steps_per_graph`` (with ``use_graph``): capture that many consecutive optimizer steps in ONE hipGraph, so that a
+                 fused_dropout=None, pipeline_input=None, steps_per_graph=1, flush_in_optimizer=True):
+        """``flush_in_optimizer``: with this package's FusedAdam / FusedAdamW the step's deferred gradient sums are flushed by
+        the optimizer's own launch (acm_adam_config_t.pending) instead of a launch of their own.
+
+        ``steps_per_graph`` (with ``use_graph``): capture that many consecutive optimizer steps in ONE hipGraph, so that a
         call runs them all (``steps_per_call``; the loss returned is the last one, ``losses`` holds every one) -- the ~8 us
         between two graph launches is then paid once per call instead of once per step.  Every captured step is a complete
         step (fresh counter-based masks: the step counters live on the device); a loop that looks at the model between two
@@ -73,6 +76,9 @@ class TrainStep:
         # (default: on, unless someone replaced F.dropout -- a mask-replay harness must keep seeing its masks)
         self._manual_advance = False
         self._defer = True
+        from .optim import _FusedAdamBase
+        self._opt_flushes = bool(flush_in_optimizer) and isinstance(optimizer, _FusedAdamBase)
+        self._unflushed = None
         if fused_dropout is None:
             fused_dropout = F.dropout is _TORCH_DROPOUT
         if fused_dropout and getattr(model, "dropout", 0) > 0 and hasattr(model, "fused_dropout"):
@@ -98,12 +104,14 @@ class TrainStep:
         if use_graph:
             self._capture()
 
-    def _forward_backward(self):
+    def _forward_backward(self, for_optimizer=False):
         """Forward, fused loss and backward; the loss sum and the parameter-gradient sums of the backward kernels run
         as ONE deferred launch at the end (AF.deferred_reductions: four launches less per step).  That is only sound
         while nothing reads a gradient before the flush, which this method checks on every pass: every ``.grad``
         must be the tensor the backward kernels wrote (autograd adopts it when ``.grad`` is None), not a copy taken
-        before the flush -- otherwise deferral is switched off for good and the step is redone."""
+        before the flush -- otherwise deferral is switched off for good and the step is redone.
+        ``for_optimizer``: the caller runs ``_opt_step()`` next, which may take the flush into the optimizer's launch; without
+        it the gradients and the loss are complete on return."""
         pipe = self.pipe
         if pipe is not None and pipe.stale():
             if self.x.is_cuda and torch.cuda.is_current_stream_capturing():
@@ -127,13 +135,19 @@ class TrainStep:
         if pending is None:
             return loss
         adopted = pending.all_adopted([loss] + [p.grad for p in self._params])
+        # The optimizer's launch can flush the list itself (acm_adam_config_t.pending: one launch and one grid drain less)
+        # when nothing has to come between the flush and the update: no gradient all-reduce, our own optimizer.
+        self._unflushed = None
+        if for_optimizer and adopted and self._opt_flushes and not pending.collectives_pending:
+            self._unflushed = pending
+            return loss
         pending.flush()
         if not adopted:
             self._defer = False
             self.opt.zero_grad(set_to_none=True)
             if pipe is not None:
                 pipe.primed = False               # the first pass has already refilled its buffers for the next step
-            return self._forward_backward()
+            return self._forward_backward(for_optimizer)
         return loss
 
     def _forward_loss(self, call):
@@ -159,8 +173,8 @@ class TrainStep:
         if not self.model.training:
             self.model.train()
         self.opt.zero_grad(set_to_none=True)
-        loss = self._forward_backward()
-        self.opt.step()
+        loss = self._forward_backward(for_optimizer=True)
+        self._opt_step()
         self._count_advance()
         if self.pipe is not None:
             self.pipe.end_step()
@@ -228,14 +242,21 @@ class TrainStep:
             for k in range(self.steps_per_call):
                 if k:
                     self.opt.zero_grad(set_to_none=True)
-                loss = self._forward_backward()
-                self.opt.step()
+                loss = self._forward_backward(for_optimizer=True)
+                self._opt_step()
                 self._count_advance()
                 if self.pipe is not None:
                     self.pipe.end_step()
                 losses.append(loss)
             self.loss, self.losses = loss, losses
         del loss, losses
+
+    def _opt_step(self):
+        pending, self._unflushed = self._unflushed, None
+        if pending is not None:
+            self.opt.step(pending=pending)
+        else:
+            self.opt.step()
 
     def _count_advance(self):
         """The dropout counter moves once per optimizer step: by FusedAdam's kernel (also_advance) or by hand."""

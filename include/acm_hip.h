@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define ACM_ABI_VERSION 22
+#define ACM_ABI_VERSION 23
 
 typedef enum {
     ACM_OK = 0,
@@ -71,8 +71,11 @@ typedef struct {
                              2 = aggregate-first backward (agg_bwd16_kernel, also the carrier of proj_* / next_agg),
                              4 = literal K3 (bwd_local16_kernel).  Default 7; a cleared bit falls back to the
                              four-rows-per-wave kernels */
-    int32_t agg_fused;    /* acm_conv_agg_fwd: 1 = gather + row-local stage in one kernel where the shape allows (default),
-                             0 = always two stages (acm_spmm_ex, then the row-local kernel) */
+    int32_t gather_forms; /* bit mask of the narrow-gather forms: 1 = acm_conv_agg_fwd runs gather + row-local stage in one
+                             kernel where the shape allows (cleared: always two stages, acm_spmm_ex then the row-local
+                             kernel); 2 = the 16-byte gathers of two-column layers keep the first 8192 rows of the table
+                             (the hubs of a graph numbered by degree) in LDS when at least a quarter of the column ids
+                             fall there (spmm_narrow_hub_kernel).  Default 3 */
     int32_t gemm_forms;   /* bit mask for tall products: 1 = row-panel fp32 kernels (acm_gemm_rows.hip), 2 = split-bf16
                              projections for K <= 128 (acm_gemm_bx3.hip), 4 = split-bf16 TN form for K > 128 from
                              16 384 rows, 8 = row-panel kernels for EVERY shape they cover (tests).  Default 7;
@@ -145,6 +148,7 @@ typedef struct {
     int64_t stream_slices;    /* slices (four work items each)                                          */
     int32_t stream_waves;     /* waves the streams are cut for = 4 x the blocks of the streamed kernel  */
     int32_t stream_long_rows; /* rows cut into pieces (combined by the last piece to arrive)            */
+    int64_t hub_ids;          /* (ABI 23) column ids below 8192: the gathers LDS-resident hub rows serve (acm_tuning_t.gather_forms) */
 } acm_csr_info_t;
 int acm_csr_info(const acm_csr_t* a, acm_csr_info_t* info);
 
@@ -777,6 +781,13 @@ typedef struct {
     int32_t* arrive;                   /* optional device int32, zero before the first call and left zero: with it the
                                           counters are advanced by the last block of the update launch itself instead
                                           of a second launch (calls sharing one `arrive` must be stream-ordered) */
+    acm_reduce_list_t* pending;        /* optional (ABI 23): the step's deferred second phases.  The call flushes them --
+                                          inside the update launch itself where it can: the reducing blocks lead the grid,
+                                          a sum that is an element of a tensor's `grad` is stored AND applied at once (same
+                                          formulas, same values as flush-then-update: bit-identical), the other tensors are
+                                          updated by the blocks behind.  Needs `arrive`, <= 32 tensors, <= 24 segments and
+                                          every `grad` written by the segments entirely or not at all; otherwise the call
+                                          runs acm_reduce_flush first and then the plain update.  The list is empty afterwards */
 } acm_adam_config_t;
 
 int acm_adam_step(int32_t n_tensors, const acm_adam_tensor_t* tensors, const acm_adam_config_t* cfg,

@@ -47,7 +47,8 @@ LABELS = {
     "dropout/168114x7": ["dropout_kernel"],
     "dropout/168120x7": ["dropout_kernel"],
     "reduce_flush": ["reduce_segments_kernel"],          # every deferred second phase of the step, one launch
-    "adam_step": ["adam_kernel"],
+    "adam": ["adam_kernel"],
+    "adam+flush": ["adam_flush_kernel"],                 # the update launch that also runs the deferred second phases
 }
 
 

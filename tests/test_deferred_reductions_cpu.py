@@ -85,6 +85,40 @@ def test_train_step_defers_and_matches_the_immediate_trajectory(monkeypatch):
     assert traj[True] == traj[False]
 
 
+def test_train_step_leaves_the_flush_to_the_optimizer_launch(monkeypatch):
+    """With this package's optimizer the step's deferral list travels to acm_adam_step (acm_adam_config_t.pending, ABI 23)
+    unflushed: no acm_reduce_flush call of the host's, one flush inside every update -- and the same trajectory as with
+    flush_in_optimizer=False.  A foreign optimizer, two parameter groups or a pending gradient all-reduce keep the host's
+    own flush (nothing may read a gradient before it)."""
+    fake = fake_lib.install(monkeypatch)
+    from acm_gnn_amd import FusedAdam, FusedAdamW, functional as AF, train as T
+    flushes = {"host": 0}
+    real = AF.DeferredReductions.flush
+    monkeypatch.setattr(AF.DeferredReductions, "flush", lambda self: (flushes.__setitem__("host", flushes["host"] + 1), real(self))[1])
+    traj = {}
+    for inside in (True, False):
+        model, ops, x, y, w = _setup()
+        opt = FusedAdamW(model.parameters(), lr=0.01, weight_decay=5e-4)
+        step = T.TrainStep(model, opt, x, ops, y, w, flush_in_optimizer=inside)
+        flushes["host"], fake.adam_flushed = 0, 0
+        traj[inside] = [float(step()) for _ in range(4)]
+        assert (flushes["host"], fake.adam_flushed) == ((0, 4) if inside else (4, 0))
+        assert all(torch.isfinite(p).all() for p in model.parameters())
+    assert traj[True] == traj[False]
+    # two parameter groups: the optimizer flushes on the host before its first launch
+    model, ops, x, y, w = _setup()
+    ps = list(model.parameters())
+    opt = FusedAdam([{"params": ps[:3]}, {"params": ps[3:], "lr": 0.02}], lr=0.01)
+    step = T.TrainStep(model, opt, x, ops, y, w)
+    flushes["host"], fake.adam_flushed = 0, 0
+    assert np.isfinite(float(step())) and (flushes["host"], fake.adam_flushed) == (1, 0)
+    # a foreign optimizer: the step flushes itself, as before
+    model, ops, x, y, w = _setup()
+    step = T.TrainStep(model, torch.optim.SGD(model.parameters(), lr=0.1), x, ops, y, w)
+    flushes["host"] = 0
+    assert np.isfinite(float(step())) and flushes["host"] == 1 and step._unflushed is None
+
+
 def test_train_step_falls_back_when_a_gradient_was_accumulated_instead_of_adopted(monkeypatch):
     fake_lib.install(monkeypatch)
     from acm_gnn_amd import train as T

@@ -78,7 +78,7 @@ def test_train_step_trajectory_is_the_same_with_and_without_deferral(use_graph, 
         torch.testing.assert_close(a, b, rtol=2e-3, atol=2e-5)
 
 
-def _immediate(self):
+def _immediate(self, for_optimizer=False):
     from acm_gnn_amd import functional as AF
     out = self.model(self.x, self.adj, self.adj_high, self.adj_un)
     loss, dz = AF.nll_loss_and_grad(out, self.labels, self.weights)

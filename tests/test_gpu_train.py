@@ -269,6 +269,35 @@ def test_input_pipeline_matches_plain_step(monkeypatch, n, avg, model_type, use_
     assert float((pipe.saved[0] - pipe.filled[0]).abs().max()) > 0         # a different mask
 
 
+@pytest.mark.parametrize("use_graph", [False, True], ids=["eager", "graph"])
+def test_input_pipeline_whose_backward_cannot_carry_the_gather(use_graph, tune):
+    """rows16 without the backward bit: acm_conv_agg_bwd declines next_agg (ACM_EUNSUPPORTED) and the host launches the
+    gather itself right there -- also inside a capture, where a pipeline left unprimed would replay a stale P for ever
+    (found with scripts/probe_step_env.py in round 4: the captured step was 25 us "faster" and wrong)."""
+    from acm_gnn_amd import GCN, FusedAdamW, functional as AF, train as T
+    n = 3000
+    ops, x, y = _pipeline_case(n, 40, seed=n)
+    w = T.row_weights(torch.arange(0, n, 3, device=DEV), n)
+
+    def run(**tuning_items):
+        tune(pipeline=1024, **tuning_items)
+        torch.manual_seed(0)
+        model = GCN(7, 64, 2, 2, n, 0.2, "acmgcnp", 0, variant=False, attn_layernorm=True).to(DEV)
+        model.dropout_state = AF.DropoutState(torch.device(DEV), seed=99)
+        step = T.TrainStep(model, FusedAdamW(model.parameters(), lr=0.01), x, ops, y, w, use_graph=use_graph)
+        return step, model, [float(step()) for _ in range(8)]
+
+    _, model_a, loss_a = run()
+    step_b, model_b, loss_b = run(rows16=5)
+    assert step_b.pipe is not None and step_b.pipe.primed
+    np.testing.assert_allclose(loss_b, loss_a, rtol=2e-4, atol=1e-5)
+    for (k, pa), (_, pb) in zip(model_a.state_dict().items(), model_b.state_dict().items()):
+        torch.testing.assert_close(pb, pa, rtol=5e-3, atol=5e-4, msg=k)
+    want_table = AF.dropout(step_b.x, 0.2, model_b.dropout_state, tag=0, pad_to=8)
+    torch.testing.assert_close(step_b.pipe.filled[0], want_table, rtol=0, atol=0)
+    torch.testing.assert_close(step_b.pipe.filled[1], AF.spmm(ops.low, want_table, row_scale=ops.row_scale), rtol=1e-5, atol=1e-5)
+
+
 @pytest.mark.parametrize("use_graph", [True, False], ids=["graph", "eager"])
 def test_fit_with_the_input_pipeline_equals_fit_without(monkeypatch, use_graph, tune):
     """train.fit (captured training step + captured evaluation pass per epoch) with the input pipeline in its training
@@ -370,3 +399,44 @@ def test_several_steps_per_captured_graph_equal_single_step_replays(pipeline, tu
     assert ca == cb == 2 * K and len(la) == len(lb) == 2 * K
     assert la == lb, (la, lb)
     assert all(torch.equal(u, v) for u, v in zip(pa, pb))
+
+
+@pytest.mark.parametrize("implicit", [1, 0], ids=["pattern_only", "explicit_values"])
+def test_hub_rows_in_lds_gather_is_bit_identical(implicit, tune):
+    """acm_tuning_t.gather_forms bit 2: the 16-byte gathers of a two-column layer keep the first 8192 table rows in LDS
+    (spmm_narrow_hub_kernel: one 1024-thread workgroup per CU, four windows of the work list per round) when the graph is
+    large (nnz >= 2^21) and numbered by degree (>= 25 % of the column ids below 8192).  Same work items, same order of
+    additions per item, same LDS meeting of the pieces of a long row as spmm_narrow_kernel: losses, gradients and
+    parameters after three steps must be bit-identical with the bit cleared -- for the forward gather with the raw
+    epilogue, the backward gather over the transposed operator, pattern-only and explicit-value operators."""
+    from acm_gnn_amd import GCN, FusedAdamW, data as D, functional as AF, train as T
+    from acm_gnn_amd.distributed import make_sharded_operators
+    n = 40000
+    adj = D.chung_lu_graph(n, 1_250_000, 9000, seed=4)
+    perm = D.degree_order(adj)
+    adj = adj[perm][:, perm].tocsr()
+    adj.sort_indices()
+    low, deg = D.build_filters(adj)
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn(n, 7, generator=g).abs().to(DEV)
+    y = torch.randint(0, 2, (n,), generator=g).to(DEV)
+    w = T.row_weights(torch.arange(0, n, 2, device=DEV), n)
+    runs = []
+    for forms in (1, 3):
+        tune(gather_forms=forms, implicit=implicit, pipeline=0)
+        from acm_gnn_amd.graph import clear_cache
+        clear_cache()
+        ops = make_sharded_operators(low, deg, torch.device(DEV))
+        assert ops.implicit == bool(implicit)
+        assert ops.low.nnz >= 1 << 21 and 4 * ops.low.hub_ids >= ops.low.nnz and 4 * ops.low_t.hub_ids >= ops.low_t.nnz
+        assert ops.low.n_long_rows > 0                                   # pieces meeting in LDS are part of the case
+        torch.manual_seed(0)
+        model = GCN(7, 64, 2, 2, n, 0.2, "acmgcnp", 0, variant=False).to(DEV)
+        model.dropout_state = AF.DropoutState(torch.device(DEV), seed=9)
+        step = T.TrainStep(model, FusedAdamW(model.parameters(), lr=0.01), x, ops, y, w)
+        losses = [float(step()) for _ in range(3)]
+        runs.append((losses, [p.detach().clone() for p in model.parameters()], [p.grad.clone() for p in model.parameters()]))
+    (la, pa, ga), (lb, pb, gb) = runs
+    assert la == lb and all(np.isfinite(la))
+    for a, b in zip(pa + ga, pb + gb):
+        assert torch.equal(a, b)
