@@ -40,7 +40,7 @@ class CsrInfo(C.Structure):
                 ("indptr", C.c_void_p), ("indices", C.c_void_p), ("vals", C.c_void_p),
                 ("src_pos", C.c_void_p),
                 ("stream_steps", C.c_int64), ("stream_slices", C.c_int64),
-                ("stream_waves", C.c_int32), ("stream_long_rows", C.c_int32), ("hub_ids", C.c_int64)]
+                ("stream_waves", C.c_int32), ("stream_long_rows", C.c_int32)]
 
 
 class ConvFwd(C.Structure):

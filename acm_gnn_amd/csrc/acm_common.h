@@ -27,9 +27,6 @@ const acm_tuning_t& acm_tuning();
 #define ACM_GEMM_BX3 2
 #define ACM_GEMM_BX3_WIDE 4
 #define ACM_GEMM_ROWS_ALWAYS 8
-#define ACM_GATHER_FUSED 1
-#define ACM_GATHER_HUB 2
-#define ACM_HUB_ROWS 8192        /* table rows spmm_narrow_hub_kernel keeps in LDS (16 bytes each) */
 
 #define ACM_CHECK_HIP(expr)                                                            \
     do {                                                                               \
@@ -97,7 +94,6 @@ struct acm_csr {
     int64_t n_long;
     int64_t n_slots;
     int64_t n_windows;      // the first n_windows * ACM_WINDOW items are the pieces of the long rows
-    int64_t hub_hits;       // column ids below ACM_HUB_ROWS (the share of the gathers LDS-resident hub rows would serve)
     AcmStreams* streams;    // NULL until acm_csr_build_streams
     int device;
 };

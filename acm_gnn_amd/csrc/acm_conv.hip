@@ -930,106 +930,6 @@ __global__ __launch_bounds__(256) void spmm_narrow_pair3_kernel(CsrView csr, con
     }
 }
 
-// HUB ROWS IN LDS.  The two-column, two-channel gathers of the output layer ([c0 c0 c1 c1]: one 16-byte fetch per
-// neighbour) run at the rate the L1 takes lines from the L2: ~2.3 clocks per missing line and CU (profiles/r02_ta_rate.txt),
-// 13.8 M fetches of which ~2/3 miss.  On a graph numbered by degree the first rows of the table are the hubs: rows
-// 0..8191 of the twitch-shaped graph take 51 % of all fetches.  One workgroup of sixteen waves per CU keeps those rows
-// in LDS (128 KB, filled once by the persistent workgroup: 33 MB over the whole chip) and fetches from there whatever
-// column id falls below the mark; the L1 then serves the other half alone.  Work items as in spmm_narrow_kernel with
-// sixteen lanes each; a workgroup round is FOUR windows of the work list (pieces of long rows meet in LDS per
-// 256-thread quarter), and every thread makes the same number of rounds so that the barriers stay uniform.
-constexpr int HUB_ROWS = 8192, HUB_THREADS = 1024, HUB_QUARTERS = HUB_THREADS / 256;
-
-template <class Epi>
-__global__ __launch_bounds__(HUB_THREADS) void spmm_narrow_hub_kernel(CsrView csr, const float* __restrict__ table, int ld,
-                                                                       int hub_rows, typename Epi::Args ea) {
-    constexpr int FP = 2, NG = 2, GS = 16;
-    __shared__ float4 hub[HUB_ROWS];
-    __shared__ float coop_lds[HUB_QUARTERS * ACM_WINDOW * NG * FP];
-    for (int i = threadIdx.x; i < hub_rows; i += HUB_THREADS) hub[i] = *reinterpret_cast<const float4*>(table + (long)i * ld);
-    __syncthreads();
-    const int gl = threadIdx.x % GS, quarter = threadIdx.x >> 8, g = (threadIdx.x >> 4) & 15;
-    const int G = gridDim.x * (HUB_THREADS / GS);                          // work items per round of the whole grid
-    const int n_rounds = (csr.n_items + G - 1) / G;
-    const bool unit = csr.vals == nullptr;
-    const AcmItem none{0, 0, 0, -1};
-    int w = (blockIdx.x * HUB_QUARTERS + quarter) * ACM_WINDOW + g;
-    AcmItem it = w < csr.n_items ? csr.items[w] : none;
-    int k0 = it.begin;
-    bool va = k0 + gl < it.end, vb = k0 + gl + GS < it.end;
-    int ja = va ? csr.indices[k0 + gl] : 0, jb = vb ? csr.indices[k0 + gl + GS] : 0;
-    float aa = va ? (unit ? 1.f : csr.vals[k0 + gl]) : 0.f, ab = vb ? (unit ? 1.f : csr.vals[k0 + gl + GS]) : 0.f;
-    for (int round = 0; round < n_rounds; ++round) {
-        const int wn = w + G;
-        const bool has_next = wn < csr.n_items;
-        const AcmItem itn = has_next ? csr.items[wn] : none;
-        float acc[NG][FP] = {{0.f, 0.f}, {0.f, 0.f}};
-        while (true) {
-            const float4 ta = ja < hub_rows ? hub[ja] : *reinterpret_cast<const float4*>(table + (long)ja * ld);
-            const float4 tb = jb < hub_rows ? hub[jb] : *reinterpret_cast<const float4*>(table + (long)jb * ld);
-            // requests of the next step, issued before the rows above are consumed
-            const int k1 = k0 + 2 * GS;
-            const bool more = k1 < it.end;
-            const int pb = more ? k1 : itn.begin;
-            const int pe = more ? it.end : itn.end;
-            const bool pva = pb + gl < pe, pvb = pb + gl + GS < pe;
-            const int nja = pva ? csr.indices[pb + gl] : 0, njb = pvb ? csr.indices[pb + gl + GS] : 0;
-            const float naa = pva ? (unit ? 1.f : csr.vals[pb + gl]) : 0.f, nab = pvb ? (unit ? 1.f : csr.vals[pb + gl + GS]) : 0.f;
-            acc[0][0] = va ? fmaf(aa, ta.x, acc[0][0]) : acc[0][0];
-            acc[0][0] = vb ? fmaf(ab, tb.x, acc[0][0]) : acc[0][0];
-            acc[0][1] = va ? fmaf(aa, ta.y, acc[0][1]) : acc[0][1];
-            acc[0][1] = vb ? fmaf(ab, tb.y, acc[0][1]) : acc[0][1];
-            acc[1][0] = va ? fmaf(aa, ta.z, acc[1][0]) : acc[1][0];
-            acc[1][0] = vb ? fmaf(ab, tb.z, acc[1][0]) : acc[1][0];
-            acc[1][1] = va ? fmaf(aa, ta.w, acc[1][1]) : acc[1][1];
-            acc[1][1] = vb ? fmaf(ab, tb.w, acc[1][1]) : acc[1][1];
-            ja = nja, jb = njb, aa = naa, ab = nab, va = pva, vb = pvb;
-            if (!more) break;
-            k0 = k1;
-        }
-#pragma unroll
-        for (int c = 0; c < NG; ++c)
-#pragma unroll
-            for (int f = 0; f < FP; ++f) acc[c][f] = acm_group_sum<GS>(acc[c][f]);
-        const int first_window = (round * (int)gridDim.x + (int)blockIdx.x) * HUB_QUARTERS;
-        bool finish = it.slot < 0 && w < csr.n_items;
-        if (first_window < csr.n_windows) {                     // workgroup-uniform: some quarter holds a window of pieces
-            const bool pieces_here = first_window + quarter < csr.n_windows;
-            float* mine = coop_lds + quarter * (ACM_WINDOW * NG * FP);
-            if (pieces_here && gl == 0) {
-#pragma unroll
-                for (int c = 0; c < NG; ++c)
-#pragma unroll
-                    for (int f = 0; f < FP; ++f) mine[(g * NG + c) * FP + f] = acc[c][f];
-            }
-            __syncthreads();
-            if (pieces_here) {
-                const AcmLongRow lr = csr.long_rows[csr.long_index[it.row]];
-                finish = it.slot == lr.slot_begin;              // first piece: add the others in slot order
-                if (finish) {
-                    const int pieces = lr.slot_end - lr.slot_begin;
-#pragma unroll
-                    for (int c = 0; c < NG; ++c)
-#pragma unroll
-                        for (int f = 0; f < FP; ++f) {
-                            float t = 0.f;
-                            for (int q = 0; q < pieces; ++q) t += mine[((g + q) * NG + c) * FP + f];
-                            acc[c][f] = t;
-                        }
-                }
-            }
-            __syncthreads();
-        }
-        if (finish) {
-            LaySerial<FP> lay{gl == 0};
-            Epi::template apply<LaySerial<FP>, NG>(ea, it.row, lay, FP, acc);
-        }
-        it = itn;
-        w = wn;
-        k0 = it.begin;
-    }
-}
-
 // ------------------------------------------------------------------ host-side dispatch
 // acm_conv_local16.hip: K3 at F = 64, k = 3 with sixteen rows per wave
 int acm_bwd_local16(const acm_conv_bwd_local_t* p, int64_t n_rows, float* partial, int max_blocks, hipStream_t s);
@@ -1049,23 +949,6 @@ bool narrow_finishes_long_rows(const acm_csr* a) { return narrow_lanes(a) == ACM
 template <int NG, class Epi>
 void launch_pair3(int grid, hipStream_t st, const CsrView& v, const float* table, const typename Epi::Args& ea) {
     if constexpr (NG == 3) hipLaunchKernelGGL((spmm_narrow_pair3_kernel<Epi>), dim3(grid), dim3(256), 0, st, v, table, ea);
-}
-
-template <int NG, class Epi>
-void launch_hub(int grid, hipStream_t st, const CsrView& v, const float* table, int ld, int hub_rows, const typename Epi::Args& ea) {
-    if constexpr (NG == 2)
-        hipLaunchKernelGGL((spmm_narrow_hub_kernel<Epi>), dim3(grid), dim3(HUB_THREADS), 0, st, v, table, ld, hub_rows, ea);
-}
-
-int acm_cu_count(int device) {
-    static int cached[16] = {0};
-    if (device < 0 || device >= 16) device = 0;
-    if (!cached[device]) {
-        int n = 0;
-        if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || n <= 0) n = 256;
-        cached[device] = n;
-    }
-    return cached[device];
 }
 
 template <int NG, class Epi>
@@ -1112,17 +995,6 @@ int launch_gather(const acm_csr* a, const GatherSrc& g, int F, const typename Ep
         // accumulator columns no epilogue looks at)
         const bool merged = NG >= 2 && g.p[1] == g.p[0] + FP && g.ld[0] == g.ld[1] &&
                             ((uintptr_t)g.p[0]) % (8 * FP) == 0 && (g.ld[0] * sizeof(float)) % (8 * FP) == 0;
-        // two channels of two columns in 16-byte rows, a large graph whose column ids fall on the first ACM_HUB_ROWS rows
-        // for a quarter at least (a graph numbered by degree): those rows in LDS (spmm_narrow_hub_kernel)
-        if (NG == 2 && F == 2 && gs == 16 && merged && !bf16 && (acm_tuning().gather_forms & ACM_GATHER_HUB) &&
-            a->nnz >= (1 << 21) && 4 * a->hub_hits >= a->nnz && g.ld[0] % 4 == 0 && (a->n_long == 0 || a->long_index != nullptr)) {
-            int grid = (int)((a->n_items + 63) / 64), cus = acm_cu_count(a->device);
-            if (grid > cus) grid = cus;                           // 129 KB of LDS: one workgroup per CU, persistent
-            const int hub_rows = a->n_cols < ACM_HUB_ROWS ? (int)a->n_cols : ACM_HUB_ROWS;
-            launch_hub<NG, Epi>(grid, st, v, g.p[0], (int)g.ld[0], hub_rows, ea);
-            ACM_CHECK_HIP(hipGetLastError());
-            return ACM_OK;
-        }
 #define ACM_NARROW(FPv, GSv)                                                                            \
     do {                                                                                                \
         const int gpb = 256 / GSv;                                                                      \

@@ -30,11 +30,11 @@ extern "C" const char* acm_last_error(void) { return g_err; }
 
 // ---------------------------------------------------------------- tuning record
 namespace {
-const acm_tuning_t kTuningDefaults = {0, 0, -1, 7, 3, 7, {0}};
+const acm_tuning_t kTuningDefaults = {0, 0, -1, 7, 1, 7, {0}};
 struct TuningField { const char* name; int32_t acm_tuning_t::*field; };
 const TuningField kTuningFields[] = {{"chunk", &acm_tuning_t::chunk},           {"wide_form", &acm_tuning_t::wide_form},
                                      {"bwd_split", &acm_tuning_t::bwd_split},   {"rows16", &acm_tuning_t::rows16},
-                                     {"gather_forms", &acm_tuning_t::gather_forms},   {"gemm_forms", &acm_tuning_t::gemm_forms}};
+                                     {"agg_fused", &acm_tuning_t::agg_fused},   {"gemm_forms", &acm_tuning_t::gemm_forms}};
 // host-side keys of the same variable (acm_gnn_amd/tuning.py reads them; listed here so that they are not "unknown")
 const char* const kHostKeys[] = {"rewrites", "implicit", "relabel", "pipeline"};
 
@@ -43,7 +43,7 @@ const char* tuning_invalid(const acm_tuning_t& t) {
     if (t.wide_form < 0 || t.wide_form > 3) return "wide_form";
     if (t.bwd_split < -1 || t.bwd_split > 1) return "bwd_split";
     if (t.rows16 < 0 || t.rows16 > 7) return "rows16";
-    if (t.gather_forms < 0 || t.gather_forms > 3) return "gather_forms";
+    if (t.agg_fused < 0 || t.agg_fused > 1) return "agg_fused";
     if (t.gemm_forms < 0 || t.gemm_forms > 15) return "gemm_forms";
     return nullptr;
 }
@@ -249,21 +249,17 @@ extern "C" int acm_csr_create(int64_t n_rows, int64_t n_cols, int64_t nnz,
     for (int64_t r = 0; r < n_rows; ++r)
         ACM_REQUIRE(h_indptr[r] <= h_indptr[r + 1], ACM_ESHAPE,
                     "acm_csr_create: indptr not monotone at row %lld", (long long)r);
-    int64_t hub_hits = 0;
     if (nnz) {
         std::vector<int32_t> h_idx((size_t)nnz);
         ACM_CHECK_HIP(hipMemcpy(h_idx.data(), indices_dev, (size_t)nnz * sizeof(int32_t),
                                 hipMemcpyDeviceToHost));
-        for (int64_t k = 0; k < nnz; ++k) {
+        for (int64_t k = 0; k < nnz; ++k)
             ACM_REQUIRE(h_idx[k] >= 0 && h_idx[k] < n_cols, ACM_ESHAPE,
                         "acm_csr_create: column id %d out of range at position %lld", h_idx[k],
                         (long long)k);
-            hub_hits += h_idx[k] < ACM_HUB_ROWS;
-        }
     }
     acm_csr* a = new_handle(n_rows, n_cols, nnz);
     ACM_REQUIRE(a, ACM_ENOMEM, "acm_csr_create: host allocation failed");
-    a->hub_hits = hub_hits;
     int st = alloc_arrays(a, vals_dev != nullptr);
     if (st == ACM_OK) {
         hipError_t e = hipMemcpy(a->indptr, indptr_dev, (size_t)(n_rows + 1) * sizeof(int32_t),
@@ -314,7 +310,6 @@ extern "C" int acm_csr_transpose(const acm_csr_t* a, int chunk, acm_csr_t** out)
         }
     acm_csr* t = new_handle(m, n, nnz);
     ACM_REQUIRE(t, ACM_ENOMEM, "acm_csr_transpose: host allocation failed");
-    for (int64_t r = 0; r < n && r < ACM_HUB_ROWS; ++r) t->hub_hits += ip[r + 1] - ip[r];    // its column ids are A's row ids
     int st = alloc_arrays(t, a->vals != nullptr);
     if (st == ACM_OK) {
         hipError_t e = hipMemcpy(t->indptr, tp.data(), tp.size() * sizeof(int32_t), hipMemcpyHostToDevice);
@@ -367,11 +362,6 @@ extern "C" int acm_csr_slice_rows(const acm_csr_t* a, int64_t row_begin, int64_t
             acm_set_error("acm_csr_slice_rows: copy failed: %s", hipGetErrorString(e));
             st = ACM_EHIP;
         }
-    }
-    if (st == ACM_OK && nnz) {                       // (a slice is made once per rank: one more copy of its column ids)
-        std::vector<int32_t> ix((size_t)nnz);
-        if (hipMemcpy(ix.data(), s->indices, (size_t)nnz * sizeof(int32_t), hipMemcpyDeviceToHost) == hipSuccess)
-            for (int64_t k = 0; k < nnz; ++k) s->hub_hits += ix[k] < ACM_HUB_ROWS;
     }
     if (st == ACM_OK) st = finish_handle(s, ip, chunk);
     if (st != ACM_OK) {
@@ -587,7 +577,6 @@ extern "C" int acm_csr_info(const acm_csr_t* a, acm_csr_info_t* info) {
     info->stream_slices = a->streams ? a->streams->n_slices : 0;
     info->stream_waves = a->streams ? a->streams->n_waves : 0;
     info->stream_long_rows = a->streams ? (int32_t)a->streams->n_long : 0;
-    info->hub_ids = a->hub_hits;
     return ACM_OK;
 }
 

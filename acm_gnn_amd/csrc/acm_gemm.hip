@@ -16,7 +16,7 @@
 bool acm_gemm_rows_nn_ok(int64_t M, int64_t N, int64_t K, const float* B, int64_t ldb);
 int acm_gemm_rows_nn(int64_t M, int64_t N, int64_t K, const float* A, int64_t lda, const float* B, int64_t ldb, float* C,
                      int64_t ldc, int relu, const acm_dropout_t* drop, hipStream_t st);
-bool acm_gemm_rows_tn_ok(int64_t n_rows, int64_t K, int64_t N, const float* Dz, int64_t lddz);
+bool acm_gemm_rows_tn_ok(int64_t n_rows, int64_t K, int64_t N);
 int acm_gemm_rows_tn_blocks(int64_t n_rows);
 int acm_gemm_rows_tn(int64_t n_rows, int64_t K, int64_t N, const float* X, int64_t ldx, const float* Dz, int64_t lddz,
                      float* slabs, int blocks, const acm_dropout_t* drop, hipStream_t st);
@@ -262,6 +262,19 @@ void launch_shape(int ta, int tb, const GemmPlan& p, hipStream_t st, int M, int 
 
 }  // namespace
 
+// C[M, N] = A^T B over a tall contraction K (A: [K, M], B: [K, N]): which row-panel forms take the shape, and the slabs each
+// writes (0 = does not apply).  ONE predicate for acm_gemm_workspace_bytes and for the dispatch in gemm_core.
+struct TnPanel {
+    int bx3_blocks, rows_blocks;
+};
+static TnPanel tn_panel(int64_t M, int64_t N, int64_t K) {
+    TnPanel t{0, 0};
+    if (K <= 0) return t;
+    if (acm_gemm_bx3_tn_ok(K, M, N)) t.bx3_blocks = acm_gemm_bx3_tn_blocks(K, M);
+    if (acm_gemm_rows_tn_ok(K, M, N)) t.rows_blocks = acm_gemm_rows_tn_blocks(K);
+    return t;
+}
+
 extern "C" int acm_gemm_workspace_bytes(int transA, int transB, int64_t M, int64_t N, int64_t K,
                                         size_t* bytes) {
     (void)transA;
@@ -270,10 +283,10 @@ extern "C" int acm_gemm_workspace_bytes(int transA, int transB, int64_t M, int64
     ACM_REQUIRE(M >= 0 && N >= 0 && K >= 0, ACM_ESHAPE, "acm_gemm_workspace_bytes: negative size");
     const GemmPlan p = plan_gemm(M, N, K);
     size_t need = p.splits > 1 ? (size_t)p.splits * (size_t)M * (size_t)N * sizeof(float) : 0;
-    if (transA && !transB && (acm_gemm_rows_tn_ok(K, M, N, nullptr, 4) || acm_gemm_bx3_tn_ok(K, M, N))) {   // the row-panel forms (may be taken): one slab per workgroup
-        const int nb_bx3 = acm_gemm_bx3_tn_ok(K, M, N) ? acm_gemm_bx3_tn_blocks(K, M) : 0;
-        const int nb_rows = acm_gemm_rows_tn_ok(K, M, N, nullptr, 4) ? acm_gemm_rows_tn_blocks(K) : 0;
-        const size_t rows = (size_t)(nb_bx3 > nb_rows ? nb_bx3 : nb_rows) * (size_t)M * (size_t)N * sizeof(float);
+    if (transA && !transB) {                                 // the row-panel forms (may be taken): one slab per workgroup
+        const TnPanel tp = tn_panel(M, N, K);
+        const int nb = tp.bx3_blocks > tp.rows_blocks ? tp.bx3_blocks : tp.rows_blocks;
+        const size_t rows = (size_t)nb * (size_t)M * (size_t)N * sizeof(float);
         need = rows > need ? rows : need;
     }
     *bytes = need;
@@ -365,10 +378,10 @@ static int gemm_core(int transA, int transB, int64_t M, int64_t N, int64_t K, co
     if (K > 0 && !transA && !transB && plain_out && !cb && acm_gemm_rows_nn_ok(M, N, K, B, ldb) &&
         (a_drop || N <= 64 || (acm_tuning().gemm_forms & ACM_GEMM_ROWS_ALWAYS)))
         return acm_gemm_rows_nn(M, N, K, A, lda, B, ldb, C, ldc, relu, a_drop, st);
-    const bool bx3_tn = K > 0 && transA && !transB && plain_out && acm_gemm_bx3_tn_ok(K, M, N);
-    if (bx3_tn || (K > 0 && transA && !transB && plain_out && acm_gemm_rows_tn_ok(K, M, N, B, ldb) &&
-                   (a_drop || K >= 100000 || (acm_tuning().gemm_forms & ACM_GEMM_ROWS_ALWAYS)))) {
-        const int blocks = bx3_tn ? acm_gemm_bx3_tn_blocks(K, M) : acm_gemm_rows_tn_blocks(K);
+    const TnPanel tp = (transA && !transB && plain_out) ? tn_panel(M, N, K) : TnPanel{0, 0};
+    const bool bx3_tn = tp.bx3_blocks > 0;
+    if (bx3_tn || (tp.rows_blocks > 0 && (a_drop || K >= 100000 || (acm_tuning().gemm_forms & ACM_GEMM_ROWS_ALWAYS)))) {
+        const int blocks = bx3_tn ? tp.bx3_blocks : tp.rows_blocks;
         const size_t need = (size_t)blocks * (size_t)M * (size_t)N * sizeof(float);
         ACM_REQUIRE(workspace && workspace_bytes >= need, ACM_ENOMEM, "acm_gemm: workspace %zu B < required %zu B", workspace_bytes, need);
         int rc = bx3_tn ? acm_gemm_bx3_tn(K, M, N, A, lda, B, ldb, (float*)workspace, blocks, a_drop, st)

@@ -377,8 +377,7 @@ int acm_gemm_rows_nn(int64_t M, int64_t N, int64_t K, const float* A, int64_t ld
     return ACM_OK;
 }
 
-bool acm_gemm_rows_tn_ok(int64_t n_rows, int64_t K, int64_t N, const float* Dz, int64_t lddz) {
-    (void)Dz, (void)lddz;
+bool acm_gemm_rows_tn_ok(int64_t n_rows, int64_t K, int64_t N) {
     return n_rows >= 8192 && K >= 16 && K <= 128 && rows_shape_ok(N) && (acm_tuning().gemm_forms & (ACM_GEMM_ROWS | ACM_GEMM_ROWS_ALWAYS)) != 0;
 }
 int acm_gemm_rows_tn_blocks(int64_t n_rows) {

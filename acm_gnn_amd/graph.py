@@ -81,7 +81,6 @@ class CsrGraph:
         self.n_items, self.n_long_rows = info.n_items, info.n_long_rows
         self.n_partial_slots, self.chunk, self.max_degree = info.n_partial_slots, info.chunk, info.max_degree
         self._ptrs = (info.indptr, info.indices, info.vals)
-        self.hub_ids = info.hub_ids              # column ids below 8192 (spmm_narrow_hub_kernel serves those from LDS)
         self._src_pos_ptr = info.src_pos
         self._src_pos = None
         self._transposed = None

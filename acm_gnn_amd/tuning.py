@@ -11,7 +11,7 @@ rewrite / operator form / loop structure the Python host layer picks).  Nothing 
 environment for dispatch, and no ``acm_*`` launch path calls ``getenv``.
 
 Kernel-level keys (acm_tuning_t; see the header for the values):
-    chunk, wide_form, bwd_split, rows16, gather_forms, gemm_forms
+    chunk, wide_form, bwd_split, rows16, agg_fused, gemm_forms
 Host-level keys:
     rewrites   bit mask of the algebraic rewrites of a first layer: 1 = aggregate-first ``A (X W) = (A X) W`` (ACM,
                acmsgc), 2 = ACMII recompute-on-gather.  Default 3; 0 = the literal form (project, then gather 2F floats
@@ -30,7 +30,7 @@ import ctypes as C
 import os
 import threading
 
-KERNEL_KEYS = ("chunk", "wide_form", "bwd_split", "rows16", "gather_forms", "gemm_forms")
+KERNEL_KEYS = ("chunk", "wide_form", "bwd_split", "rows16", "agg_fused", "gemm_forms")
 HOST_DEFAULTS = {"rewrites": 3, "implicit": 1, "relabel": -1, "pipeline": 8192}
 HOST_RANGES = {"rewrites": (0, 3), "implicit": (0, 1), "relabel": (-1, 1), "pipeline": (0, 1 << 31)}
 

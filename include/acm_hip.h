@@ -71,11 +71,8 @@ typedef struct {
                              2 = aggregate-first backward (agg_bwd16_kernel, also the carrier of proj_* / next_agg),
                              4 = literal K3 (bwd_local16_kernel).  Default 7; a cleared bit falls back to the
                              four-rows-per-wave kernels */
-    int32_t gather_forms; /* bit mask of the narrow-gather forms: 1 = acm_conv_agg_fwd runs gather + row-local stage in one
-                             kernel where the shape allows (cleared: always two stages, acm_spmm_ex then the row-local
-                             kernel); 2 = the 16-byte gathers of two-column layers keep the first 8192 rows of the table
-                             (the hubs of a graph numbered by degree) in LDS when at least a quarter of the column ids
-                             fall there (spmm_narrow_hub_kernel).  Default 3 */
+    int32_t agg_fused;    /* acm_conv_agg_fwd: 1 = gather + row-local stage in one kernel where the shape allows (default),
+                             0 = always two stages (acm_spmm_ex, then the row-local kernel) */
     int32_t gemm_forms;   /* bit mask for tall products: 1 = row-panel fp32 kernels (acm_gemm_rows.hip), 2 = split-bf16
                              projections for K <= 128 (acm_gemm_bx3.hip), 4 = split-bf16 TN form for K > 128 from
                              16 384 rows, 8 = row-panel kernels for EVERY shape they cover (tests).  Default 7;
@@ -148,7 +145,6 @@ typedef struct {
     int64_t stream_slices;    /* slices (four work items each)                                          */
     int32_t stream_waves;     /* waves the streams are cut for = 4 x the blocks of the streamed kernel  */
     int32_t stream_long_rows; /* rows cut into pieces (combined by the last piece to arrive)            */
-    int64_t hub_ids;          /* (ABI 23) column ids below 8192: the gathers LDS-resident hub rows serve (acm_tuning_t.gather_forms) */
 } acm_csr_info_t;
 int acm_csr_info(const acm_csr_t* a, acm_csr_info_t* info);
 

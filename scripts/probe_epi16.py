@@ -18,7 +18,7 @@ from acm_gnn_amd.layers import GraphConvolution  # noqa: E402
 
 def run(layer, x, ops, go, drop, unfused, off):
     from acm_gnn_amd import tuning
-    tuning.apply(gather_forms=2 if unfused else 3, rows16=4 if off else 7)
+    tuning.apply(agg_fused=0 if unfused else 1, rows16=4 if off else 7)
     layer.zero_grad(set_to_none=True)
     out = layer(x, ops, post_relu=True, post_drop=drop)
     out.backward(go)

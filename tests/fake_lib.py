@@ -135,7 +135,7 @@ class FakeLib:
 
     # ---- the tuning record (acm_tuning_t): plain storage + the library's validation; the entry points below consult it
     # where the library's dispatch does (gemm_forms, rows16)
-    TUNING_DEFAULTS = dict(chunk=0, wide_form=0, bwd_split=-1, rows16=7, gather_forms=3, gemm_forms=7)
+    TUNING_DEFAULTS = dict(chunk=0, wide_form=0, bwd_split=-1, rows16=7, agg_fused=1, gemm_forms=7)
 
     def acm_tuning_get(self, out):
         t = out._obj
@@ -151,7 +151,7 @@ class FakeLib:
         new = {k: int(getattr(t, k)) for k in self.TUNING_DEFAULTS}
         ok = ((new["chunk"] == 0 or (8 <= new["chunk"] <= 4096 and new["chunk"] & (new["chunk"] - 1) == 0))
               and 0 <= new["wide_form"] <= 3 and -1 <= new["bwd_split"] <= 1 and 0 <= new["rows16"] <= 7
-              and new["gather_forms"] in (0, 1, 2, 3) and 0 <= new["gemm_forms"] <= 15)
+              and new["agg_fused"] in (0, 1) and 0 <= new["gemm_forms"] <= 15)
         if not ok:
             self._err = b"acm_tuning_set: field out of range"
             return 1
@@ -286,7 +286,6 @@ class FakeLib:
         i.n_partial_slots = used
         i.n_items = a.n_rows - len(longs) + i.n_partial_slots
         i.chunk, i.max_degree = a.chunk, int(deg.max()) if len(deg) else 0
-        i.hub_ids = int((a.indices < 8192).sum())
         i.indptr, i.indices = a.indptr.ctypes.data, a.indices.ctypes.data
         i.vals = None if getattr(a, "unit", False) else a.vals.ctypes.data
         sp_ = getattr(a, "src_pos", None)

@@ -90,7 +90,7 @@ def test_tuning_record_is_the_one_dispatch_mechanism():
     assert C.sizeof(t) == 4 * 16
     assert lib.acm_tuning_get(C.byref(t)) == 0
     loaded = {k: getattr(t, k) for k in tuning.KERNEL_KEYS}
-    assert loaded == dict(chunk=0, wide_form=0, bwd_split=-1, rows16=7, gather_forms=3, gemm_forms=7), loaded
+    assert loaded == dict(chunk=0, wide_form=0, bwd_split=-1, rows16=7, agg_fused=1, gemm_forms=7), loaded
     t.rows16, t.chunk = 5, 256
     assert lib.acm_tuning_set(C.byref(t)) == 0
     u = tuning.Tuning()

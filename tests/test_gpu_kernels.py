@@ -396,6 +396,61 @@ def test_split_bf16_projection_keeps_fp32_accuracy(m, n, k, monkeypatch, tune):
     assert torch.equal(out[:, 2:2 + n], new) and float((out[:, :2] - 3).abs().max()) == 0 and float((out[:, 2 + n:] - 3).abs().max()) == 0
 
 
+def test_split_bf16_products_with_extreme_and_nonfinite_inputs(tune):
+    """the split-bf16 kernels are the DEFAULT for tall fp32 products, so what they do outside the comfortable
+    range is part of the fp32 path's contract.  (1) Entries from 1e-30 to 1e30 (the splits keep fp32's exponent range):
+    error vs float64 relative to sum |x||w| at fp32 level.  (2) A non-finite entry poisons exactly what it poisons in the
+    fp32 kernel -- the output row of that X row (NN), the dW row of that feature (TN) -- and nothing else: every other
+    output element is bit-identical to the run with the entry replaced by 1.  The poisoned elements are non-finite in both
+    kernels; their CLASS may differ (inf - bf16(inf) is NaN: the split turns an inf operand into NaN where the fmaf chain
+    keeps +-inf), which is stated here rather than hidden.  (3) Subnormal operands contribute at most their own magnitude
+    (the matrix pipe may flush them): absolute error <= 1e-37 x K."""
+    from acm_gnn_amd import functional as AF
+    g = torch.Generator().manual_seed(11)
+    m, k, n = 9000, 64, 21
+    # (1) extreme range, rows scaled by powers of ten from 1e-30 to 1e30 (products stay below fp32's maximum)
+    x, w = torch.randn(m, k, generator=g), torch.randn(k, n, generator=g)
+    scale = 10.0 ** torch.linspace(-30, 30, m).round()
+    x = x * scale[:, None]
+    z = AF.gemm(x.to(DEV), w.to(DEV))
+    ref = x.double() @ w.double()
+    mag = x.double().abs() @ w.double().abs()
+    assert torch.isfinite(z).all()
+    assert float(((z.cpu().double() - ref).abs() / mag).max()) < 1e-6
+    dz = torch.randn(m, n, generator=g)
+    xs = torch.randn(m, k, generator=g) * (10.0 ** torch.linspace(-15, 15, m).round())[:, None]
+    dw = AF.gemm(xs.to(DEV), dz.to(DEV), trans_a=True)
+    ref = xs.double().T @ dz.double()
+    mag = xs.double().abs().T @ dz.double().abs()
+    assert torch.isfinite(dw).all() and float(((dw.cpu().double() - ref).abs() / mag).max()) < 1e-6
+    # (2) non-finite entries
+    x = torch.randn(m, k, generator=g)
+    clean = x.clone()
+    bad = {(5, 3): float("inf"), (77, 0): float("nan"), (8999, 63): float("-inf")}
+    for (r, c), v in bad.items():
+        x[r, c], clean[r, c] = v, 1.0
+    for forms in ("split-bf16", "fp32"):
+        if forms == "fp32":
+            tune(gemm_forms=tuning.kernel()["gemm_forms"] & ~6)
+        z_bad, z_ok = AF.gemm(x.to(DEV), w.to(DEV)).cpu(), AF.gemm(clean.to(DEV), w.to(DEV)).cpu()
+        rows = sorted({r for r, _ in bad})
+        assert not torch.isfinite(z_bad[rows]).any(), forms                   # every element of a poisoned row (w has no zeros)
+        keep = torch.ones(m, dtype=torch.bool)
+        keep[rows] = False
+        assert torch.equal(z_bad[keep], z_ok[keep]), forms
+        d_bad, d_ok = AF.gemm(x.to(DEV), dz.to(DEV), trans_a=True).cpu(), AF.gemm(clean.to(DEV), dz.to(DEV), trans_a=True).cpu()
+        feats = sorted({c for _, c in bad})
+        assert not torch.isfinite(d_bad[feats]).any(), forms
+        keep = torch.ones(k, dtype=torch.bool)
+        keep[feats] = False
+        assert torch.equal(d_bad[keep], d_ok[keep]), forms
+    tune(gemm_forms=tuning.kernel()["gemm_forms"] | 6)
+    # (3) subnormal operands
+    tiny = torch.full((m, k), 1e-40)
+    z = AF.gemm(tiny.to(DEV), torch.ones(k, n, device=DEV))
+    assert float((z.cpu().double() - 1e-40 * k).abs().max()) <= 1e-37 * k
+
+
 @pytest.mark.parametrize("rows,f_in,n,blocks", [(9000, 128, 192, 3), (20001, 100, 15, 3), (168114, 128, 192, 3), (8192, 33, 21, 0),
                                                 (40000, 64, 180, 0), (16500, 2089, 192, 3), (16400, 300, 70, 0), (41554, 1030, 21, 3)])
 def test_split_bf16_weight_gradient_keeps_fp32_accuracy(rows, f_in, n, blocks, monkeypatch, tune):

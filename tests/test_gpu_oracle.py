@@ -112,7 +112,7 @@ def test_aggregate_first_kernel_forms(form, f_in, f_out, hub, monkeypatch, tune)
     gather + the four-rows-per-wave stage with the long rows' partial sums added by that stage -- against the oracle, on
     a graph with a split hub row."""
     if form != "fused":
-        tune(gather_forms=2)
+        tune(agg_fused=0)
     if form == "two-stage-4rows":
         tune(rows16=6)
     adj = _graph(700, 21, density=0.04, hub=hub)
@@ -129,7 +129,7 @@ def test_sixteen_rows_per_wave_stages_cover_channels_and_pad_widths(s, f_in, ln,
     not a multiple of 16; and against the four-rows-per-wave kernels they replace."""
     from acm_gnn_amd import functional as AF
     adj = _graph(333, 17, density=0.05, hub=True)
-    tune(gather_forms=2)                                  # the row-local stage as its own kernel for three channels too
+    tune(agg_fused=0)                                  # the row-local stage as its own kernel for three channels too
     timer = AF.KernelTimer()
     AF.set_kernel_timer(timer)
     try:

@@ -399,44 +399,3 @@ def test_several_steps_per_captured_graph_equal_single_step_replays(pipeline, tu
     assert ca == cb == 2 * K and len(la) == len(lb) == 2 * K
     assert la == lb, (la, lb)
     assert all(torch.equal(u, v) for u, v in zip(pa, pb))
-
-
-@pytest.mark.parametrize("implicit", [1, 0], ids=["pattern_only", "explicit_values"])
-def test_hub_rows_in_lds_gather_is_bit_identical(implicit, tune):
-    """acm_tuning_t.gather_forms bit 2: the 16-byte gathers of a two-column layer keep the first 8192 table rows in LDS
-    (spmm_narrow_hub_kernel: one 1024-thread workgroup per CU, four windows of the work list per round) when the graph is
-    large (nnz >= 2^21) and numbered by degree (>= 25 % of the column ids below 8192).  Same work items, same order of
-    additions per item, same LDS meeting of the pieces of a long row as spmm_narrow_kernel: losses, gradients and
-    parameters after three steps must be bit-identical with the bit cleared -- for the forward gather with the raw
-    epilogue, the backward gather over the transposed operator, pattern-only and explicit-value operators."""
-    from acm_gnn_amd import GCN, FusedAdamW, data as D, functional as AF, train as T
-    from acm_gnn_amd.distributed import make_sharded_operators
-    n = 40000
-    adj = D.chung_lu_graph(n, 1_250_000, 9000, seed=4)
-    perm = D.degree_order(adj)
-    adj = adj[perm][:, perm].tocsr()
-    adj.sort_indices()
-    low, deg = D.build_filters(adj)
-    g = torch.Generator().manual_seed(1)
-    x = torch.randn(n, 7, generator=g).abs().to(DEV)
-    y = torch.randint(0, 2, (n,), generator=g).to(DEV)
-    w = T.row_weights(torch.arange(0, n, 2, device=DEV), n)
-    runs = []
-    for forms in (1, 3):
-        tune(gather_forms=forms, implicit=implicit, pipeline=0)
-        from acm_gnn_amd.graph import clear_cache
-        clear_cache()
-        ops = make_sharded_operators(low, deg, torch.device(DEV))
-        assert ops.implicit == bool(implicit)
-        assert ops.low.nnz >= 1 << 21 and 4 * ops.low.hub_ids >= ops.low.nnz and 4 * ops.low_t.hub_ids >= ops.low_t.nnz
-        assert ops.low.n_long_rows > 0                                   # pieces meeting in LDS are part of the case
-        torch.manual_seed(0)
-        model = GCN(7, 64, 2, 2, n, 0.2, "acmgcnp", 0, variant=False).to(DEV)
-        model.dropout_state = AF.DropoutState(torch.device(DEV), seed=9)
-        step = T.TrainStep(model, FusedAdamW(model.parameters(), lr=0.01), x, ops, y, w)
-        losses = [float(step()) for _ in range(3)]
-        runs.append((losses, [p.detach().clone() for p in model.parameters()], [p.grad.clone() for p in model.parameters()]))
-    (la, pa, ga), (lb, pb, gb) = runs
-    assert la == lb and all(np.isfinite(la))
-    for a, b in zip(pa + ga, pb + gb):
-        assert torch.equal(a, b)
