@@ -55,7 +55,7 @@ struct AcmItem {
 };
 // A long row and its partial slots [slot_begin, slot_end).
 struct AcmLongRow {
-    int32_t row, slot_begin, slot_end, pad;
+    int32_t row, slot_begin, slot_end, windows;   // windows > 1: the row's pieces fill that many whole windows (acm_csr.cpp)
 };
 
 // Per-wave id streams of a pattern-only operator (acm_csr_build_streams, acm_csr.cpp): the column ids laid out in the
@@ -94,6 +94,7 @@ struct acm_csr {
     int64_t n_long;
     int64_t n_slots;
     int64_t n_windows;      // the first n_windows * ACM_WINDOW items are the pieces of the long rows
+    int64_t n_multi;        // long rows that take several windows (their window sums are added by a second launch)
     AcmStreams* streams;    // NULL until acm_csr_build_streams
     int device;
 };
@@ -118,6 +119,7 @@ struct CsrView {
     const int32_t* long_index;
     int n_long;
     int n_windows;
+    int n_multi;
     const int32_t* indices;
     const float* vals;
 };
@@ -134,6 +136,7 @@ static inline CsrView acm_view(const acm_csr* a) {
     v.long_index = a->long_index;
     v.n_long = (int)a->n_long;
     v.n_windows = (int)a->n_windows;
+    v.n_multi = (int)a->n_multi;
     v.indices = a->indices;
     v.vals = a->vals;
     return v;

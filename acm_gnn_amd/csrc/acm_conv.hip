@@ -671,8 +671,16 @@ __device__ __forceinline__ void load_row(const float* __restrict__ p, int F, boo
 // step are in flight it already has the next item's descriptor and the next step's column ids / values
 // requested (of the same item, or of the next one when this was its last step).
 constexpr int NARROW_MAX_BLOCKS = 8192;
+#ifndef ACM_NARROW_U
+#define ACM_NARROW_U 2
+#endif
 
-template <int FP, int NG, int GS, bool MERGED, class Epi>
+// U = neighbours per lane and step (rows in flight per lane): a lane takes neighbours gl, gl + GS, gl + 2 GS, ... of its item in
+// that order whatever U is, so U changes how many steps an item takes -- the dependent chain of a long item -- and not one bit
+// of the result.  Measured (round 4, profiles/r04_narrow_u4.txt): U = 4 changes neither the single-GPU kernels (70.4 / 56.0 us
+// against 72 / 54.6) nor a rank's kernels of the 8-rank plan (33.0 us against 32.9): the sixteen pieces of the longest row
+// are bound by the texture path of the ONE CU their window runs on, not by the number of dependent steps.
+template <int FP, int NG, int GS, bool MERGED, class Epi, int U = ACM_NARROW_U>
 __global__ __launch_bounds__(256) void spmm_narrow_kernel(CsrView csr, GatherSrc g, int F, int vecmask,
                                                                typename Epi::Args ea, float* __restrict__ partial) {
     constexpr int GPB = 256 / GS;
@@ -686,10 +694,17 @@ __global__ __launch_bounds__(256) void spmm_narrow_kernel(CsrView csr, GatherSrc
     if (w >= csr.n_items) return;
     AcmItem it = csr.items[w];
     int k0 = it.begin;
-    bool va = k0 + gl < it.end, vb = k0 + gl + GS < it.end;
-    int ja = va ? csr.indices[k0 + gl] : 0, jb = vb ? csr.indices[k0 + gl + GS] : 0;
     const bool unit = csr.vals == nullptr;
-    float aa = va ? (unit ? 1.f : csr.vals[k0 + gl]) : 0.f, ab = vb ? (unit ? 1.f : csr.vals[k0 + gl + GS]) : 0.f;
+    bool v[U];
+    int j[U];
+    float a[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        const int k = k0 + gl + u * GS;
+        v[u] = k < it.end;
+        j[u] = v[u] ? csr.indices[k] : 0;
+        a[u] = v[u] ? (unit ? 1.f : csr.vals[k]) : 0.f;
+    }
     while (true) {
         const int wn = w + G;
         const bool has_next = wn < csr.n_items;
@@ -701,48 +716,47 @@ __global__ __launch_bounds__(256) void spmm_narrow_kernel(CsrView csr, GatherSrc
 #pragma unroll
             for (int f = 0; f < FP; ++f) acc[c][f] = 0.f;
         while (true) {
-            float za[NG][FP], zb[NG][FP];
-            if (MERGED) {
-                float ta[2 * FP], tb[2 * FP];
-                load_row<2 * FP>(g.p[0] + (long)ja * g.ld[0], 2 * FP, true, ta);
-                load_row<2 * FP>(g.p[0] + (long)jb * g.ld[0], 2 * FP, true, tb);
+            float z[U][NG][FP];
 #pragma unroll
-                for (int f = 0; f < FP; ++f) {
-                    za[0][f] = ta[f];
-                    zb[0][f] = tb[f];
-                    if (NG > 1) {
-                        za[1 % NG][f] = ta[FP + f];
-                        zb[1 % NG][f] = tb[FP + f];
+            for (int u = 0; u < U; ++u) {
+                if (MERGED) {
+                    float t[2 * FP];
+                    load_row<2 * FP>(g.p[0] + (long)j[u] * g.ld[0], 2 * FP, true, t);
+#pragma unroll
+                    for (int f = 0; f < FP; ++f) {
+                        z[u][0][f] = t[f];
+                        if (NG > 1) z[u][1 % NG][f] = t[FP + f];
                     }
-                }
 #pragma unroll
-                for (int c = 2; c < NG; ++c) {
-                    load_row<FP>(g.p[c] + (long)ja * g.ld[c], F, (vecmask >> c) & 1, za[c]);
-                    load_row<FP>(g.p[c] + (long)jb * g.ld[c], F, (vecmask >> c) & 1, zb[c]);
-                }
-            } else {
+                    for (int c = 2; c < NG; ++c) load_row<FP>(g.p[c] + (long)j[u] * g.ld[c], F, (vecmask >> c) & 1, z[u][c]);
+                } else {
 #pragma unroll
-                for (int c = 0; c < NG; ++c) {
-                    load_row<FP>(g.p[c] + (long)ja * g.ld[c], F, (vecmask >> c) & 1, za[c]);
-                    load_row<FP>(g.p[c] + (long)jb * g.ld[c], F, (vecmask >> c) & 1, zb[c]);
+                    for (int c = 0; c < NG; ++c) load_row<FP>(g.p[c] + (long)j[u] * g.ld[c], F, (vecmask >> c) & 1, z[u][c]);
                 }
             }
             // requests of the next step, issued before the rows above are consumed
-            const int k1 = k0 + 2 * GS;
+            const int k1 = k0 + U * GS;
             const bool more = k1 < it.end;
             const int pb = more ? k1 : itn.begin;
             const int pe = more ? it.end : (has_next ? itn.end : pb);
-            const bool pva = pb + gl < pe, pvb = pb + gl + GS < pe;
-            const int nja = pva ? csr.indices[pb + gl] : 0, njb = pvb ? csr.indices[pb + gl + GS] : 0;
-            const float naa = pva ? (unit ? 1.f : csr.vals[pb + gl]) : 0.f, nab = pvb ? (unit ? 1.f : csr.vals[pb + gl + GS]) : 0.f;
+            bool nv[U];
+            int nj[U];
+            float na[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int k = pb + gl + u * GS;
+                nv[u] = k < pe;
+                nj[u] = nv[u] ? csr.indices[k] : 0;
+                na[u] = nv[u] ? (unit ? 1.f : csr.vals[k]) : 0.f;
+            }
 #pragma unroll
             for (int c = 0; c < NG; ++c)
 #pragma unroll
-                for (int f = 0; f < FP; ++f) {
-                    acc[c][f] = va ? fmaf(aa, za[c][f], acc[c][f]) : acc[c][f];
-                    acc[c][f] = vb ? fmaf(ab, zb[c][f], acc[c][f]) : acc[c][f];
-                }
-            ja = nja, jb = njb, aa = naa, ab = nab, va = pva, vb = pvb;
+                for (int f = 0; f < FP; ++f)
+#pragma unroll
+                    for (int u = 0; u < U; ++u) acc[c][f] = v[u] ? fmaf(a[u], z[u][c][f], acc[c][f]) : acc[c][f];
+#pragma unroll
+            for (int u = 0; u < U; ++u) j[u] = nj[u], a[u] = na[u], v[u] = nv[u];
             if (!more) break;
             k0 = k1;
         }
@@ -760,8 +774,11 @@ __global__ __launch_bounds__(256) void spmm_narrow_kernel(CsrView csr, GatherSrc
             }
             __syncthreads();
             const AcmLongRow lr = csr.long_rows[csr.long_index[it.row]];
-            if (it.slot == lr.slot_begin) {                     // first piece: add the others in slot order
-                const int pieces = lr.slot_end - lr.slot_begin;
+            // a row of several windows (acm_csr.cpp, build_items) fills this window alone: its sum goes to the slot of the
+            // window's first piece and spmm_fixup_windows_kernel adds the windows
+            const bool multi = lr.windows > 1;
+            if (multi ? g == 0 : it.slot == lr.slot_begin) {    // first piece: add the others in slot order
+                const int pieces = multi ? ACM_WINDOW : lr.slot_end - lr.slot_begin;
 #pragma unroll
                 for (int c = 0; c < NG; ++c)
 #pragma unroll
@@ -770,8 +787,17 @@ __global__ __launch_bounds__(256) void spmm_narrow_kernel(CsrView csr, GatherSrc
                         for (int q = 0; q < pieces; ++q) t += coop_lds[((g + q) * NG + c) * FP + f];
                         acc[c][f] = t;
                     }
-                LaySerial<FP> lay{gl == 0};
-                Epi::template apply<LaySerial<FP>, NG>(ea, it.row, lay, F, acc);
+                if (!multi) {
+                    LaySerial<FP> lay{gl == 0};
+                    Epi::template apply<LaySerial<FP>, NG>(ea, it.row, lay, F, acc);
+                } else if (gl == 0) {
+                    float* ps = partial + (long)it.slot * (NG * F);
+#pragma unroll
+                    for (int c = 0; c < NG; ++c)
+#pragma unroll
+                        for (int f = 0; f < FP; ++f)
+                            if (f < F) ps[c * F + f] = acc[c][f];
+                }
             }
             __syncthreads();
         } else if (it.slot < 0) {
@@ -822,6 +848,30 @@ __global__ __launch_bounds__(256) void spmm_fixup_narrow_kernel(CsrView csr, int
     Epi::template apply<LaySerial<FP>, NG>(ea, lr.row, lay, F, acc);
 }
 
+// Rows of several windows (AcmLongRow.windows > 1) after a narrow gather with sixteen lanes per item: window q of the row
+// left its sum in slot slot_begin + 16 q; lane q of a 16-lane group fetches it, one group sum (fixed order), epilogue.
+template <int FP, int NG, class Epi>
+__global__ __launch_bounds__(256) void spmm_fixup_windows_kernel(CsrView csr, int F, typename Epi::Args ea,
+                                                                 const float* __restrict__ partial) {
+    const int m = threadIdx.x & 15;
+    const int w = blockIdx.x * 16 + (threadIdx.x >> 4);
+    if (w >= csr.n_long) return;
+    const AcmLongRow lr = csr.long_rows[w];
+    if (lr.windows <= 1) return;
+    float acc[NG][FP];
+    const float* ps = partial + (long)(lr.slot_begin + ACM_WINDOW * m) * (NG * F);
+#pragma unroll
+    for (int c = 0; c < NG; ++c)
+#pragma unroll
+        for (int f = 0; f < FP; ++f) acc[c][f] = (m < lr.windows && f < F) ? ps[c * F + f] : 0.f;
+#pragma unroll
+    for (int c = 0; c < NG; ++c)
+#pragma unroll
+        for (int f = 0; f < FP; ++f) acc[c][f] = acm_group_sum<16>(acc[c][f]);
+    LaySerial<FP> lay{m == 0};
+    Epi::template apply<LaySerial<FP>, NG>(ea, lr.row, lay, F, acc);
+}
+
 // The four-channel narrow gather (structure_info = 1, F = 2: the output layer of the reference's two-class models) over
 // PACKED 32-byte rows [c0 c0 c1 c1 | c2 c2 - -]: with the third gathered channel in a table of its own a neighbour costs two
 // fetches to two distinct lines (the [c0 | c1] block and the 8-byte c2 row) -- 115 us on the twitch-shaped graph against
@@ -830,7 +880,8 @@ __global__ __launch_bounds__(256) void spmm_fixup_narrow_kernel(CsrView csr, int
 // neighbour's row (the form of agg_fused_pair_kernel): one line per neighbour again.
 // Lane (e = gl >> 1, h = gl & 1) of the 16-lane group: neighbours k0 + e + 8 u (u = 0..3), half h of the row.
 template <class Epi>
-__global__ __launch_bounds__(256) void spmm_narrow_pair3_kernel(CsrView csr, const float* __restrict__ table, typename Epi::Args ea) {
+__global__ __launch_bounds__(256) void spmm_narrow_pair3_kernel(CsrView csr, const float* __restrict__ table, typename Epi::Args ea,
+                                                                float* __restrict__ partial) {
     constexpr int FP = 2, NG = 3, GPB = 16, U = 4, STEP = 8 * U;
     static_assert(GPB == ACM_WINDOW, "one window of work items per workgroup round");
     __shared__ float coop[ACM_WINDOW * 8];
@@ -904,16 +955,23 @@ __global__ __launch_bounds__(256) void spmm_narrow_pair3_kernel(CsrView csr, con
             }
             __syncthreads();
             const AcmLongRow lr = csr.long_rows[csr.long_index[it.row]];
-            finish = it.slot == lr.slot_begin;
+            const bool multi = lr.windows > 1;                  // a row of several windows: see spmm_narrow_kernel
+            finish = multi ? g == 0 : it.slot == lr.slot_begin;
             if (finish && gl < 2) {
-                const int pieces = lr.slot_end - lr.slot_begin;
+                const int pieces = multi ? ACM_WINDOW : lr.slot_end - lr.slot_begin;
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
                     float t = 0.f;
                     for (int q = 0; q < pieces; ++q) t += coop[(g + q) * 8 + 4 * h + i];
                     acc[i] = t;
                 }
+                if (multi) {                                    // [c0 c0 c1 c1] from half 0, [c2 c2] from half 1: slot layout c * 2 + f
+                    float* ps = partial + (long)it.slot * (NG * FP) + 4 * h;
+                    ps[0] = acc[0], ps[1] = acc[1];
+                    if (h == 0) ps[2] = acc[2], ps[3] = acc[3];
+                }
             }
+            if (multi) finish = false;
             __syncthreads();
         }
         // lane 0 of the group: [c0 | c1] are its own sums, c2 its neighbour's (the other half of the row)
@@ -947,8 +1005,20 @@ bool narrow_finishes_long_rows(const acm_csr* a) { return narrow_lanes(a) == ACM
 
 // (spmm_narrow_pair3_kernel exists for three gathered channels only; other NG never reach the call)
 template <int NG, class Epi>
-void launch_pair3(int grid, hipStream_t st, const CsrView& v, const float* table, const typename Epi::Args& ea) {
-    if constexpr (NG == 3) hipLaunchKernelGGL((spmm_narrow_pair3_kernel<Epi>), dim3(grid), dim3(256), 0, st, v, table, ea);
+void launch_pair3(int grid, hipStream_t st, const CsrView& v, const float* table, const typename Epi::Args& ea, float* partial) {
+    if constexpr (NG == 3) hipLaunchKernelGGL((spmm_narrow_pair3_kernel<Epi>), dim3(grid), dim3(256), 0, st, v, table, ea, partial);
+}
+
+// after a narrow gather with sixteen lanes per item: the rows of several windows (none on most operators)
+template <int NG, class Epi>
+int finish_window_rows(const acm_csr* a, const CsrView& v, int F, const typename Epi::Args& ea, const float* partial, hipStream_t st) {
+    if (a->n_multi == 0) return ACM_OK;
+    const int grid = (int)((a->n_long + 15) / 16);
+    if (F <= 2) hipLaunchKernelGGL((spmm_fixup_windows_kernel<2, NG, Epi>), dim3(grid), dim3(256), 0, st, v, F, ea, partial);
+    else if (F <= 4) hipLaunchKernelGGL((spmm_fixup_windows_kernel<4, NG, Epi>), dim3(grid), dim3(256), 0, st, v, F, ea, partial);
+    else hipLaunchKernelGGL((spmm_fixup_windows_kernel<8, NG, Epi>), dim3(grid), dim3(256), 0, st, v, F, ea, partial);
+    ACM_CHECK_HIP(hipGetLastError());
+    return ACM_OK;
 }
 
 template <int NG, class Epi>
@@ -986,9 +1056,9 @@ int launch_gather(const acm_csr* a, const GatherSrc& g, int F, const typename Ep
             g.ld[2] == 8 && ((uintptr_t)g.p[0]) % 32 == 0 && (a->n_long == 0 || a->long_index != nullptr)) {
             int grid = (int)((a->n_items + 15) / 16);
             if (grid > NARROW_MAX_BLOCKS) grid = NARROW_MAX_BLOCKS;
-            launch_pair3<NG, Epi>(grid, st, v, g.p[0], ea);
+            launch_pair3<NG, Epi>(grid, st, v, g.p[0], ea, partial);
             ACM_CHECK_HIP(hipGetLastError());
-            return ACM_OK;
+            return finish_window_rows<NG, Epi>(a, v, F, ea, partial, st);
         }
         // [channel 0 | channel 1] contiguous and block-aligned => one vector fetch for both
         // (F < FP: the channels are blocks of FP columns, [c0 pad | c1 pad]; what the fetch reads beyond F lands in
@@ -1077,9 +1147,11 @@ int launch_gather(const acm_csr* a, const GatherSrc& g, int F, const typename Ep
             hipLaunchKernelGGL((spmm_wide_kernel<4, NG, Epi>), dim3(grid), dim3(256), 0, st, v, g, F, ea, partial);
     }
     ACM_CHECK_HIP(hipGetLastError());
-    if (defer_fixup) return ACM_OK;         // the caller's next kernel adds the partial slots of the long rows itself
+    if (defer_fixup)                        // the caller's next kernel adds the partial slots of the long rows itself -- except
+        return (F <= 8 && narrow_finishes_long_rows(a)) ? finish_window_rows<NG, Epi>(a, v, F, ea, partial, st) : ACM_OK;   // where
+                                            // the gather finishes them (sixteen lanes per item): then also the rows of several windows
     if (a->n_long && F <= 8) {
-        if (narrow_finishes_long_rows(a)) return ACM_OK;
+        if (narrow_finishes_long_rows(a)) return finish_window_rows<NG, Epi>(a, v, F, ea, partial, st);
         const int grid = (int)((a->n_long + 15) / 16);
         if (F <= 2)
             hipLaunchKernelGGL((spmm_fixup_narrow_kernel<2, NG, Epi>), dim3(grid), dim3(256), 0, st, v, F, ea, partial);

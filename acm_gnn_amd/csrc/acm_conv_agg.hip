@@ -693,7 +693,8 @@ extern "C" int acm_conv_agg_fwd(const acm_csr_t* a, const acm_conv_agg_fwd_t* p,
         const double avg = (double)a->nnz / (double)(a->n_rows > 0 ? a->n_rows : 1);
         const bool fused = acm_tuning().agg_fused != 0 && p->n_channels == 3 && p->f_pad <= 8 && avg > 12.0 && avg <= 160.0 &&
                            ((uintptr_t)p->xg) % 16 == 0 && (p->ld_xg * sizeof(float)) % 16 == 0 &&
-                           (a->n_long == 0 || a->long_index != nullptr);
+                           (a->n_long == 0 || a->long_index != nullptr) &&
+                           a->n_multi == 0;       // (rows of several windows: the two-stage form, whose gather finishes them)
         if (fused) {
             const CsrView cv = acm_view(a);
             int grid = (int)((a->n_items + 15) / 16);

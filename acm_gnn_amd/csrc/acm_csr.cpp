@@ -133,34 +133,54 @@ void free_handle(acm_csr* a) {
 // before, and so is the last one): a kernel whose workgroup takes one window per round (16 groups of 16 lanes) can
 // combine the pieces of a row through LDS and finish the row itself instead of leaving partial sums to a second
 // launch; every other kernel writes the pieces to their partial slots as before.  The whole rows follow in row order.
+// Returns in n_multi the rows that take several windows.
 void build_items(const std::vector<int32_t>& indptr, int chunk, std::vector<AcmItem>& items,
-                 std::vector<AcmLongRow>& longs, int64_t& n_slots, int32_t& max_deg, int64_t& n_windows) {
+                 std::vector<AcmLongRow>& longs, int64_t& n_slots, int32_t& max_deg, int64_t& n_windows, int64_t& n_multi) {
     const int64_t n = (int64_t)indptr.size() - 1;
     items.clear();
     longs.clear();
     items.reserve(n + n / 8);
     n_slots = 0;
     max_deg = 0;
+    n_multi = 0;
     for (int64_t r = 0; r < n; ++r) {
         const int32_t b = indptr[r], e = indptr[r + 1];
         const int32_t deg = e - b;
         max_deg = std::max(max_deg, deg);
         if (deg <= chunk) continue;
         int32_t pieces = (deg + chunk - 1) / chunk;
-        if (pieces > ACM_WINDOW) pieces = ACM_WINDOW;
+        // A row that sixteen pieces of up to 4 x chunk neighbours do not cover takes SEVERAL whole windows (at most sixteen)
+        // of pieces of about 2 x chunk: sixteen pieces in one window all run on the CU that window's workgroup lands on,
+        // and a row of 21 k neighbours then keeps one texture path busy for ~20 us whatever the rest of the chip does (the
+        // floor of a rank's gathers in an 8-rank plan: DESIGN.md section 7).  With the chunk sized to the operator
+        // (nnz / 32768 < chunk <= nnz / 16384) the bar of 64 x chunk neighbours is 0.5 .. 1 x the mean CU's share of the
+        // whole operator: no row of the twitch- or arXiv-year-shaped graphs reaches it on one GPU, the top rows of a rank
+        // of an 8-rank plan do.  (A lower bar -- every row above 32 x chunk that is also above nnz / 128 -- left the rows of
+        // 8-13 k neighbours in one window each and was slower per rank: 27-29 us against 22-27 us for the output-layer
+        // backward gather.)  A window of such a row leaves its sum in its first piece's slot and a small second launch adds
+        // the windows (AcmLongRow.windows > 1).
+        int32_t windows = 0;
+        if (pieces > ACM_WINDOW && (deg + ACM_WINDOW - 1) / ACM_WINDOW > 4 * chunk) {
+            windows = (deg + 2 * ACM_WINDOW * chunk - 1) / (2 * ACM_WINDOW * chunk);
+            if (windows > ACM_WINDOW) windows = ACM_WINDOW;
+            pieces = windows * ACM_WINDOW;
+        } else if (pieces > ACM_WINDOW) {
+            pieces = ACM_WINDOW;
+        }
         const int32_t room = ACM_WINDOW - (int32_t)(items.size() % ACM_WINDOW);
-        if (room < pieces && room < ACM_WINDOW) {                 // does not fit: pad with empty pieces of the row before
+        if ((room < pieces || windows) && room < ACM_WINDOW) {    // does not fit: pad with empty pieces of the row before
             AcmLongRow& prev = longs.back();
             for (int32_t q = 0; q < room; ++q) items.push_back({prev.row, indptr[prev.row + 1], indptr[prev.row + 1], (int32_t)n_slots++});
             prev.slot_end = (int32_t)n_slots;
         }
         const int32_t per = (deg + pieces - 1) / pieces;
-        AcmLongRow lr = {(int32_t)r, (int32_t)n_slots, 0, 0};
+        AcmLongRow lr = {(int32_t)r, (int32_t)n_slots, 0, windows};
         for (int32_t q = 0; q < pieces; ++q) {
             const int32_t s = std::min(e, b + q * per);
             items.push_back({(int32_t)r, s, std::min(e, s + per), (int32_t)n_slots++});
         }
         lr.slot_end = (int32_t)n_slots;
+        n_multi += windows > 1;
         longs.push_back(lr);
     }
     if (!longs.empty() && items.size() % ACM_WINDOW) {
@@ -185,7 +205,7 @@ int finish_handle(acm_csr* a, const std::vector<int32_t>& h_indptr, int chunk) {
     a->chunk = chunk > 0 ? chunk : (env_chunk > 0 ? env_chunk : auto_chunk);
     std::vector<AcmItem> items;
     std::vector<AcmLongRow> longs;
-    build_items(h_indptr, a->chunk, items, longs, a->n_slots, a->max_degree, a->n_windows);
+    build_items(h_indptr, a->chunk, items, longs, a->n_slots, a->max_degree, a->n_windows, a->n_multi);
     a->n_items = (int64_t)items.size();
     a->n_long = (int64_t)longs.size();
     if (a->n_items) {

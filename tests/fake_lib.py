@@ -276,12 +276,17 @@ class FakeLib:
         i.n_long_rows = len(longs)
         # the library's work list (acm_csr.cpp, build_items): min(16, ceil(deg / chunk)) pieces per long row, packed
         # into windows of 16 items that no row straddles (gaps and the last window filled with empty pieces)
+        # (a row that sixteen pieces of 4 x chunk do not cover takes ceil(deg / (32 chunk)) <= 16 WHOLE windows)
         used = 0
-        for p in np.minimum(16, -(-longs // a.chunk)):
+        for deg_r in longs:
+            p, multi = int(-(-deg_r // a.chunk)), False
+            if p > 16 and -(-deg_r // 16) > 4 * a.chunk:
+                p, multi = 16 * min(16, int(-(-deg_r // (32 * a.chunk)))), True
+            p = p if multi else min(p, 16)
             room = 16 - used % 16
-            if room < p and room < 16:
+            if (room < p or multi) and room < 16:
                 used += room
-            used += int(p)
+            used += p
         used += (-used) % 16
         i.n_partial_slots = used
         i.n_items = a.n_rows - len(longs) + i.n_partial_slots

@@ -161,11 +161,13 @@ def test_spmm_matches_scipy(width, chunk):
 
 
 @pytest.mark.parametrize("chunk,hubs", [(16, {3: 390, 100: 200, 516: 70}), (16, {0: 17, 1: 17, 2: 300, 9: 33}),
-                                        (64, {5: 400, 6: 65, 7: 129, 8: 1000}), (0, {1: 390})])
+                                        (64, {5: 400, 6: 65, 7: 129, 8: 1000}), (0, {1: 390}),
+                                        (8, {2: 1100, 7: 600, 20: 300, 400: 90})])
 def test_work_list_layout(chunk, hubs):
     """Long rows are min(16, ceil(deg / chunk)) pieces, packed into windows of 16 work items that no row straddles
-    (the kernels that take one window per workgroup round finish those rows through LDS): the counts the library
-    reports equal the restatement in tests/fake_lib.py."""
+    (the kernels that take one window per workgroup round finish those rows through LDS); a row that sixteen pieces of
+    4 x chunk do not cover takes ceil(deg / (32 chunk)) whole windows (the last case: 5 and 3 windows for the rows of
+    1100 and 600): the counts the library reports equal the restatement in tests/fake_lib.py."""
     import ctypes as C
     import fake_lib
     from acm_gnn_amd import _lib

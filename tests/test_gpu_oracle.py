@@ -120,6 +120,30 @@ def test_aggregate_first_kernel_forms(form, f_in, f_out, hub, monkeypatch, tune)
     _run_both("acmgcn", 0, 0, False, 700, f_in, f_out, 22, False, monkeypatch, agg=True, adj=adj, implicit=False)
 
 
+@pytest.mark.parametrize("model_type,s,f_in,f_out,agg,implicit", [
+    ("acmgcnp", 0, 7, 64, True, True),      # aggregate-first: the fused kernel declines rows of several windows -> two stages
+    ("acmgcnp", 1, 7, 64, True, True),      # ... with the structure channel (narrow P gather + wide S gather)
+    ("acmgcnp", 0, 64, 2, False, True),     # literal two-class layer: EpiRaw + row kernel forward, EpiBwd backward
+    ("acmgcnp", 1, 64, 2, False, True),     # ... four channels: the pair-lane kernel over packed 32-byte rows
+    ("acmgcnp", 0, 40, 5, False, False),    # blocks of 8 columns, explicit values
+    ("acmgcn", 0, 33, 3, False, True)])
+def test_rows_of_several_windows_match_oracle(model_type, s, f_in, f_out, agg, implicit, monkeypatch, tune):
+    """Work lists with rows that sixteen pieces of 4 x chunk do not cover (acm_csr.cpp, build_items: such a row takes
+    several whole windows, each window leaves its sum in a partial slot, spmm_fixup_windows_kernel adds them) -- forced
+    here with chunk = 8 on a 700-node graph whose node 0 has 699 neighbours (3 windows of 16 pieces), every other row
+    an ordinary long row of <= 16 pieces.  Layer forward + backward against the oracle for the narrow gathers of both
+    forms."""
+    from acm_gnn_amd.graph import CsrGraph
+    tune(chunk=8)
+    adj = _graph(700, 31, density=0.04, hub=True)
+    low = O.filters_linkx(adj)[0].coalesce()
+    idx = low.indices().numpy()
+    probe = CsrGraph.from_scipy(sp.csr_matrix((low.values().numpy(), (idx[0], idx[1])), shape=tuple(low.shape)), DEV)
+    assert probe.chunk == 8 and probe.max_degree >= 699
+    assert probe.n_partial_slots % 16 == 0 and probe.n_items >= 700 + 48 - 1    # the hub alone: 48 pieces in 3 windows
+    _run_both(model_type, 0, s, True, 700, f_in, f_out, 31, False, monkeypatch, agg=agg, adj=adj, implicit=implicit)
+
+
 @pytest.mark.parametrize("ln", [True, False], ids=["ln", "no-ln"])
 @pytest.mark.parametrize("s,f_in", [(0, 3), (0, 7), (0, 12), (1, 4), (1, 7), (1, 8), (1, 13), (1, 16)])
 def test_sixteen_rows_per_wave_stages_cover_channels_and_pad_widths(s, f_in, ln, monkeypatch, tune):
