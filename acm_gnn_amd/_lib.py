@@ -14,7 +14,7 @@ c_i32p = C.POINTER(C.c_int32)
 
 ACM_OK = 0
 STATUS_NAMES = {1: "ACM_EINVAL", 2: "ACM_ESHAPE", 3: "ACM_EHIP", 4: "ACM_EUNSUPPORTED", 5: "ACM_ENOMEM"}
-ABI_VERSION = 23
+ABI_VERSION = 24
 
 # every symbol include/acm_hip.h declares
 EXPORTED_SYMBOLS = (
@@ -25,6 +25,7 @@ EXPORTED_SYMBOLS = (
     "acm_conv_agg_bwd", "acm_nll_loss_workspace_bytes", "acm_nll_loss", "acm_adam_step", "acm_dropout",
     "acm_reduce_flush", "acm_conv_fwd_tail_workspace_bytes", "acm_conv_fwd_tail", "acm_shard_plan",
     "acm_conv_acmii_fwd_workspace_bytes", "acm_conv_acmii_fwd", "acm_linear_fwd", "acm_bias_act", "acm_bias_act_bwd_workspace_bytes", "acm_bias_act_bwd",
+    "acm_acmii_table_bytes", "acm_acmii_table", "acm_conv_acmii_v_fwd", "acm_conv_acmii_v_bwd_workspace_bytes", "acm_conv_acmii_v_bwd",
 )
 
 
@@ -158,6 +159,15 @@ class ConvAcmiiFwd(C.Structure):
                 ("deg", C.c_void_p)]
 
 
+class ConvAcmiiBwd(C.Structure):
+    _fields_ = [("f_in", C.c_int32), ("table", C.c_void_p),
+                ("g_low", C.c_void_p), ("ld_g_low", C.c_int64), ("g_high", C.c_void_p), ("ld_g_high", C.c_int64),
+                ("g_mlp", C.c_void_p), ("ld_g_mlp", C.c_int64), ("x", C.c_void_p), ("ld_x", C.c_int64),
+                ("row_scale", C.c_void_p),
+                ("d_w_low", C.c_void_p), ("d_w_high", C.c_void_p), ("d_w_mlp", C.c_void_p), ("ld_dw", C.c_int64),
+                ("defer", C.c_void_p)]
+
+
 class Loss(C.Structure):
     _fields_ = [("n_classes", C.c_int32), ("labels", C.c_void_p), ("row_weight", C.c_void_p),
                 ("loss", C.c_void_p), ("dlogits", C.c_void_p), ("ld_dlogits", C.c_int64)]
@@ -211,6 +221,11 @@ def _declare(lib):
     lib.acm_shard_plan.argtypes = [i64, vp, i32, i64, vp]
     lib.acm_conv_acmii_fwd_workspace_bytes.argtypes = [vp, C.POINTER(sz)]
     lib.acm_conv_acmii_fwd.argtypes = [vp, C.POINTER(ConvAcmiiFwd), vp, sz, vp]
+    lib.acm_acmii_table_bytes.argtypes = [i64, C.POINTER(sz)]
+    lib.acm_acmii_table.argtypes = [i64, i32, vp, i64, vp, vp, i64, vp, sz, vp]
+    lib.acm_conv_acmii_v_fwd.argtypes = [vp, C.POINTER(ConvAcmiiFwd), vp, vp, sz, vp]
+    lib.acm_conv_acmii_v_bwd_workspace_bytes.argtypes = [vp, C.POINTER(sz)]
+    lib.acm_conv_acmii_v_bwd.argtypes = [vp, C.POINTER(ConvAcmiiBwd), vp, sz, vp]
     lib.acm_linear_fwd.argtypes = [i64, i64, i64, vp, i64, vp, i64, vp, i32, vp, vp, i64, vp, sz, vp]
     lib.acm_bias_act.argtypes = [i64, i32, vp, i64, vp, i32, vp, vp]
     lib.acm_bias_act_bwd_workspace_bytes.argtypes = [i64, i32, C.POINTER(sz)]

@@ -15,14 +15,15 @@ CSRC = os.path.join(HERE, "csrc")
 INCLUDE = os.path.join(ROOT, "include")
 LIB_DIR = os.path.join(HERE, "lib")
 LIB_PATH = os.path.join(LIB_DIR, "libacm_hip.so")
-SOURCES = ["acm_csr.cpp", "acm_gemm.hip", "acm_conv.hip", "acm_conv_agg.hip", "acm_loss.hip", "acm_optim.hip", "acm_dropout.hip", "acm_proj.hip", "acm_reduce.hip", "acm_linear.hip", "acm_conv_acmii.hip", "acm_conv_agg16.hip", "acm_gemm_rows.hip", "acm_gemm_bx3.hip", "acm_conv_local16.hip"]
+SOURCES = ["acm_csr.cpp", "acm_gemm.hip", "acm_conv.hip", "acm_conv_agg.hip", "acm_loss.hip", "acm_optim.hip", "acm_dropout.hip", "acm_proj.hip", "acm_reduce.hip", "acm_linear.hip", "acm_conv_acmii.hip", "acm_conv_agg16.hip", "acm_gemm_rows.hip", "acm_gemm_bx3.hip", "acm_conv_local16.hip", "acm_conv_acmii_v.hip"]
 ARCH = "gfx950"
 # Per-source compiler switches.  acm_conv_acmii.hip reads every MFMA result on the VALU right away (ReLU + sum per edge):
 # with the results in AGPRs hipcc copies each of them through v_accvgpr_read (32 extra VALU instructions per 16 MFMAs and
 # 28 more registers); the VGPR form of the MFMA writes them where the VALU can use them (150 -> 95 instructions per batch,
 # 152 -> 96 registers).
 EXTRA_FLAGS = {"acm_conv_acmii.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"],
-               "acm_conv_agg16.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"]}
+               "acm_conv_agg16.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"],
+               "acm_conv_acmii_v.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"]}
 
 
 def _hipcc():

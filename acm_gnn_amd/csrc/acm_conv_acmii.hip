@@ -267,6 +267,18 @@ __global__ __launch_bounds__(256) void acmii_fixup_kernel(acm_conv_acmii_fwd_t p
 
 }  // namespace
 
+// The long rows' second launch on its own: acm_conv_acmii_v_fwd (acm_conv_acmii_v.hip) leaves the pieces' raw sums in the same
+// slots and the rows' own relu(x_i W_H) in zlh's second half -- everything this kernel reads.
+int acm_acmii_fixup_launch(const acm_csr_t* a, const acm_conv_acmii_fwd_t* p, const float* partial, hipStream_t s) {
+    if (!a->n_long) return ACM_OK;
+    const CsrView cv = acm_view(a);
+    const dim3 fg((unsigned)((a->n_long + 3) / 4));
+    if (p->n_channels == 3) hipLaunchKernelGGL(acmii_fixup_kernel<3>, fg, dim3(256), 0, s, *p, cv, partial);
+    else hipLaunchKernelGGL(acmii_fixup_kernel<4>, fg, dim3(256), 0, s, *p, cv, partial);
+    ACM_CHECK_HIP(hipGetLastError());
+    return ACM_OK;
+}
+
 // partial slots of the long rows' pieces ([n_slots, 2 F])
 extern "C" int acm_conv_acmii_fwd_workspace_bytes(const acm_csr_t* a, size_t* bytes) {
     ACM_REQUIRE(a && bytes, ACM_EINVAL, "acm_conv_acmii_fwd_workspace_bytes: NULL argument");

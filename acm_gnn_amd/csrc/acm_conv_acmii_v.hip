@@ -1,0 +1,576 @@
+// ACMII first layers with a narrow input (F_in <= 8 < F = 64) on the bf16 matrix pipe, at fp32 accuracy: the mask form.
+//
+// ACMII (ACM-Geometric/layers.py:94-99, the default of ACM-Geometric: parse.py:57 --variant 1) puts the ReLU BETWEEN
+// projection and filter: H_L = A_low relu(X W_L), H_H = relu(X W_H) - A_low relu(X W_H).  acm_conv_acmii.hip gathers the
+// neighbour's input row and recomputes relu(x_j [W_L | W_H]) per edge on the fp32 matrix pipe (28 GFLOP per pass: 380 us on
+// the twitch-shaped graph), and its backward gathers two 64-wide gradient tables over the transposed operator (7 GB: 600 us).
+// Both are replaced here by ONE observation: with the mask m_j[c] = [x_j W[:, c] > 0],
+//
+//     relu(x_j W[:, c]) = m_j[c] * sum_f x_j[f] W[f, c]
+//  => sum_j a_ij relu(x_j W[:, c]) = sum_f W[f, c] * V_i[c, f],      V_i[c, f] = sum_j a_ij m_j[c] x_j[f]
+//
+// and V_i = (masks of the neighbours)^T (inputs of the neighbours) is a matrix product over the NEIGHBOUR index whose one
+// operand is 0 / 1 -- exact in bf16 -- and whose other operand, an fp32 input, is EXACTLY the sum of three bf16 numbers
+// (hi + mid + lo, acm_gemm_bx3.hip).  Every product is exact and the fp32 accumulator of v_mfma_f32_16x16x32_bf16 adds
+// them: V_i carries the rounding of an fp32 sum over the neighbours, like the reference's spmm, at sixteen times the rate of
+// the fp32 MFMA.  The backward needs no transposed product at all (the layer input needs no gradient):
+//
+//     dW_L[f, c] = sum_i G_L[i, c] * rs_i V^L_i[c, f]            (G = dH, rs_i = 1 / d_i: pattern-only operator)
+//     dW_H[f, c] = sum_i G_H[i, c] * (m^H_i[c] x_i[f] - rs_i V^H_i[c, f])
+//
+// -- the SAME products over the SAME rows, contracted with G instead of W.
+//
+//   table   one 64-byte row per node, rebuilt every step by acmii_table_kernel (the masks depend on W):
+//           [x hi (8 bf16) | x mid (8 bf16) | x lo (8 bf16) | 16 mask bytes]; bit q = 4 ch + t of byte n = m^ch[16 t + n].
+//           Row n_rows is all zero: what idle slots fetch.
+//   batch   32 neighbours of ONE work item per wave step: two 16-byte fetches per lane (a neighbour's row = four lanes) ->
+//           2 KB of wave-private LDS -> operands.  Lane (g = lane >> 4, m = lane & 15), contraction slot e = 0..7 <-> the
+//           neighbour in LDS row 4 e + g (any bijection serves, both operands use this one: bank-conflict free):
+//             A  (16 x 32, x):     rows 0..7 = features, slots (neighbour, part): hi | lo; rows 8..15: mid | 0   (v_batch)
+//             B  (32 x 16, masks): column n = m of tile q: ((byte pair) & (0x00010001 << q)) * (0x3F80 >> q) = two bf16 0 / 1
+//           16 MFMAs (8 tiles x 2 steps of 16 neighbours); D[4 g + r][n]: lane (g, n) holds V[c = 16 t + n][f = 4 (g & 1) + r],
+//           hi + lo in lane rows 0, 1 and mid in rows 2, 3.
+//   item end forward:  S[c] = sum over the four lane rows of sum_r W[4 (g & 1) + r][c] * D[r]; the wave's four items
+//           leave their sums in the four lane rows and share the epilogue of acm_conv_acmii.hip (head, mix, post-op).
+//   item end backward: acc += (+-rs_i G[i, c]) * D -- 32 accumulators per lane, splits and waves summed once per workgroup.
+#include "acm_conv_device.h"
+
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef u32x4 u32x4_ma __attribute__((may_alias));
+typedef unsigned short u16_ma __attribute__((may_alias));
+typedef unsigned char u8_ma __attribute__((may_alias));
+
+__device__ __forceinline__ unsigned fbits(float x) { return __builtin_bit_cast(unsigned, x); }
+__device__ __forceinline__ float bitsf(unsigned x) { return __builtin_bit_cast(float, x); }
+// two fp32 -> their upper halves as one dword (the first in the low half)
+__device__ __forceinline__ unsigned pack_hi16(unsigned a, unsigned b) { return __builtin_amdgcn_perm(b, a, 0x07060302u); }
+
+__device__ __forceinline__ f32x4 mma(u32x4 a, u32x4 b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+
+// ------------------------------------------------------------------ the table
+// Sixteen lanes per node: lane n computes z[ch][16 t + n] (its mask byte) and writes dword n of the row.
+__global__ __launch_bounds__(256) void acmii_table_kernel(long n_rows, int f_in, const float* __restrict__ x, long ldx,
+                                                          const float* __restrict__ w_low, const float* __restrict__ w_high,
+                                                          long ldw, unsigned* __restrict__ table) {
+    const int n = threadIdx.x & 15, part = n >> 2, pr = n & 3;
+    float w[8][8];                                   // [q = 4 ch + t][f]
+#pragma unroll
+    for (int q = 0; q < 8; ++q)
+#pragma unroll
+        for (int f = 0; f < 8; ++f) {
+            const float wv = (q < 4 ? w_low : w_high)[(long)(f < f_in ? f : 0) * ldw + 16 * (q & 3) + n];
+            w[q][f] = f < f_in ? wv : 0.f;
+        }
+    const long stride = (long)gridDim.x * 16;
+    for (long row = (long)blockIdx.x * 16 + (threadIdx.x >> 4); row <= n_rows; row += stride) {
+        unsigned dw = 0;
+        if (row < n_rows) {                          // uniform over the sixteen lanes of a node
+            float xv[8];
+#pragma unroll
+            for (int h = 0; h < 4; ++h) {
+                const float2 v = *reinterpret_cast<const float2*>(x + row * ldx + 2 * h);
+                xv[2 * h] = v.x, xv[2 * h + 1] = v.y;
+            }
+            unsigned b = 0;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                float z = 0.f;
+#pragma unroll
+                for (int f = 0; f < 8; ++f) z = fmaf(xv[f], w[q][f], z);
+                b |= (z > 0.f ? 1u : 0u) << q;
+            }
+            const float a = pr == 0 ? xv[0] : (pr == 1 ? xv[2] : (pr == 2 ? xv[4] : xv[6]));
+            const float c = pr == 0 ? xv[1] : (pr == 1 ? xv[3] : (pr == 2 ? xv[5] : xv[7]));
+            const float ra = a - bitsf(fbits(a) & 0xFFFF0000u), rc = c - bitsf(fbits(c) & 0xFFFF0000u);
+            const float sa = ra - bitsf(fbits(ra) & 0xFFFF0000u), sc = rc - bitsf(fbits(rc) & 0xFFFF0000u);
+            const unsigned hi = pack_hi16(fbits(a), fbits(c)), mid = pack_hi16(fbits(ra), fbits(rc)), lo = pack_hi16(fbits(sa), fbits(sc));
+            const unsigned m0 = __shfl(b, 4 * pr, 16), m1 = __shfl(b, 4 * pr + 1, 16), m2 = __shfl(b, 4 * pr + 2, 16),
+                           m3 = __shfl(b, 4 * pr + 3, 16);
+            const unsigned md = m0 | (m1 << 8) | (m2 << 16) | (m3 << 24);
+            dw = part == 0 ? hi : (part == 1 ? mid : (part == 2 ? lo : md));
+        }
+        table[row * 16 + n] = dw;
+    }
+}
+
+// ------------------------------------------------------------------ the wave's batch sequence
+__device__ __forceinline__ int sel4(int a0, int a1, int a2, int a3, int i) { return i == 0 ? a0 : (i == 1 ? a1 : (i == 2 ? a2 : a3)); }
+
+struct VQuad {                 // the wave's four work items (wave-uniform); an absent item has beg == end
+    int b0, b1, b2, b3, e0, e1, e2, e3;
+    __device__ __forceinline__ int beg(int i) const { return sel4(b0, b1, b2, b3, i); }
+    __device__ __forceinline__ int end(int i) const { return sel4(e0, e1, e2, e3, i); }
+};
+
+// first batch of the first non-empty item at or after `it` (it == 4: none)
+__device__ __forceinline__ void v_seek(const VQuad& vq, int& it, int& k) {
+    while (it < 4 && vq.beg(it) >= vq.end(it)) ++it;
+    k = it < 4 ? vq.beg(it) : 0;
+}
+__device__ __forceinline__ void v_next(const VQuad& vq, int& it, int& k) {
+    if (it >= 4) return;
+    if (k + 32 < vq.end(it)) {
+        k += 32;
+        return;
+    }
+    ++it;
+    v_seek(vq, it, k);
+}
+
+// column ids of the batch's 32 neighbours, the one of LDS row (lane >> 2) and of row 16 + (lane >> 2); idle slots: the zero row.
+// Branch-free (clamped address + select): a guarded load becomes an exec-mask branch and a wait for every load in flight.
+__device__ __forceinline__ void v_ids(const int32_t* __restrict__ indices, const VQuad& vq, int it, int k, int zero_row, int lane,
+                                      int& j0, int& j1) {
+    const int e = it < 4 ? vq.end(it) : 0;
+    const int p0 = k + (lane >> 2), p1 = p0 + 16;
+    const int t0 = indices[p0 < e ? p0 : 0], t1 = indices[p1 < e ? p1 : 0];
+    j0 = p0 < e ? t0 : zero_row;
+    j1 = p1 < e ? t1 : zero_row;
+}
+__device__ __forceinline__ u32x4 v_row(const u32x4* __restrict__ table, int j, int lane) { return table[(long)j * 4 + (lane & 3)]; }
+
+// One batch: rows -> LDS -> operands -> 16 MFMAs.  `lds` = the wave's 2 KB; only this wave touches it and its LDS
+// instructions execute in order, so no barrier: the accesses alias (may_alias types) and the compiler keeps their order.
+// A batch is two MFMA steps of 16 neighbours; a step's 32 contraction slots are (neighbour, part): lane row g takes the
+// neighbours a, b, c, d = LDS rows 16 h + g + {0, 4, 8, 12} in the slot order [a.0 b.0 a.1 b.1 c.0 d.0 c.1 d.1], with
+//     A row m < 8  (feature m):      part 0 = hi, part 1 = lo          -> D row m     = sum mask * (hi + lo)
+//     A row m >= 8 (feature m - 8):  part 0 = mid, part 1 = 0          -> D row m     = sum mask * mid
+//     B column n: the neighbour's mask in BOTH parts: dwords 0 and 1 are the same pair (a, b), dwords 2 and 3 the pair (c, d)
+// so hi + lo share an accumulator row (exact products, one fp32 accumulator) and a lane holds 32 accumulators, not 64.
+__device__ __forceinline__ void v_batch(unsigned char* lds, int lane, u32x4 r0, u32x4 r1, f32x4 (&d)[8]) {
+    u32x4_ma* l4 = reinterpret_cast<u32x4_ma*>(lds);
+    l4[lane] = r0;
+    l4[64 + lane] = r1;
+    const int g = lane >> 4, m = lane & 15;
+    const unsigned part1 = m < 8 ? 0xFFFFFFFFu : 0u;
+    const u16_ma* l16 = reinterpret_cast<const u16_ma*>(lds);
+    const u8_ma* l8 = reinterpret_cast<const u8_ma*>(lds);
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const int ra = 16 * h + g, rb = ra + 4, rc = ra + 8, rd = ra + 12;
+        u32x4 A;
+        A[0] = (unsigned)l16[ra * 32 + m] | ((unsigned)l16[rb * 32 + m] << 16);
+        A[1] = ((unsigned)l16[ra * 32 + 16 + (m & 7)] | ((unsigned)l16[rb * 32 + 16 + (m & 7)] << 16)) & part1;
+        A[2] = (unsigned)l16[rc * 32 + m] | ((unsigned)l16[rd * 32 + m] << 16);
+        A[3] = ((unsigned)l16[rc * 32 + 16 + (m & 7)] | ((unsigned)l16[rd * 32 + 16 + (m & 7)] << 16)) & part1;
+        const unsigned wab = (unsigned)l8[ra * 64 + 48 + m] | ((unsigned)l8[rb * 64 + 48 + m] << 16);
+        const unsigned wcd = (unsigned)l8[rc * 64 + 48 + m] | ((unsigned)l8[rd * 64 + 48 + m] << 16);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            u32x4 B;
+            B[0] = B[1] = __umul24(wab & (0x00010001u << q), 0x3F80u >> q);
+            B[2] = B[3] = __umul24(wcd & (0x00010001u << q), 0x3F80u >> q);
+            d[q] = mma(A, B, d[q]);
+        }
+    }
+}
+
+// The batch loop of a wave over its four items, one flat sequence of batches.  `item_begin(u)` runs before item u's first
+// batch, `item_end(u, d)` after its last one (also for items without neighbours).  Memory pipeline in STATIC registers (the
+// loop body is unrolled over the ring, so no value moves between registers and a load is awaited only where it is used):
+// table rows RD batches ahead, column ids RD + JD batches ahead -- 79 % of the twitch rows are one or two batches long, so
+// the pipeline runs across item boundaries.
+constexpr int V_RD = 4, V_JD = 4, V_RING = V_RD + V_JD;
+template <class ItemBegin, class ItemEnd>
+__device__ __forceinline__ void v_items(const VQuad& vq, const int32_t* __restrict__ indices, const u32x4* __restrict__ table,
+                                        int zero_row, unsigned char* lds, int lane, ItemBegin&& item_begin, ItemEnd&& item_end) {
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+    int it = 0, k = 0;
+    v_seek(vq, it, k);
+    int J0[V_RING], J1[V_RING];
+    u32x4 R0[V_RD], R1[V_RD];
+    int itj = it, kj = k;
+#pragma unroll
+    for (int s = 0; s < V_RING; ++s) {
+        v_ids(indices, vq, itj, kj, zero_row, lane, J0[s], J1[s]);
+        v_next(vq, itj, kj);
+    }
+#pragma unroll
+    for (int s = 0; s < V_RD; ++s) R0[s] = v_row(table, J0[s], lane), R1[s] = v_row(table, J1[s], lane);
+    f32x4 d[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) d[q] = zero4;
+    int u = 0;
+    item_begin(0);
+    while (true) {
+#pragma unroll
+        for (int s = 0; s < V_RING; ++s) {
+            while (u < it) {                       // close the items before the one this batch belongs to (it == 4: all of them)
+                item_end(u, d);
+                if (++u == 4) return;
+                item_begin(u);
+#pragma unroll
+                for (int q = 0; q < 8; ++q) d[q] = zero4;
+            }
+            const u32x4 a0 = R0[s % V_RD], a1 = R1[s % V_RD];
+            R0[s % V_RD] = v_row(table, J0[(s + V_RD) % V_RING], lane);       // the batch V_RD ahead
+            R1[s % V_RD] = v_row(table, J1[(s + V_RD) % V_RING], lane);
+            v_ids(indices, vq, itj, kj, zero_row, lane, J0[s], J1[s]);         // the ids V_RING ahead
+            v_next(vq, itj, kj);
+            v_batch(lds, lane, a0, a1, d);
+            v_next(vq, it, k);
+        }
+    }
+}
+
+// the quad's items: lane row kq of the wave holds item 4 q + kq (`id`, `valid`); begin / end of all four, wave-uniform
+__device__ __forceinline__ VQuad v_quad(const AcmItem& id, bool valid) {
+    const int b = id.begin, e = valid ? id.end : id.begin;
+    VQuad vq;
+    vq.b0 = __builtin_amdgcn_readlane(b, 0), vq.b1 = __builtin_amdgcn_readlane(b, 16);
+    vq.b2 = __builtin_amdgcn_readlane(b, 32), vq.b3 = __builtin_amdgcn_readlane(b, 48);
+    vq.e0 = __builtin_amdgcn_readlane(e, 0), vq.e1 = __builtin_amdgcn_readlane(e, 16);
+    vq.e2 = __builtin_amdgcn_readlane(e, 32), vq.e3 = __builtin_amdgcn_readlane(e, 48);
+    return vq;
+}
+
+// ------------------------------------------------------------------ forward
+template <int K>
+__global__ __launch_bounds__(256) void acmii_v_fwd_kernel(acm_conv_acmii_fwd_t p, CsrView csr, const u32x4* __restrict__ table,
+                                                          int zero_row, float* __restrict__ partial) {
+    constexpr int T = 8;
+    __shared__ __attribute__((aligned(16))) float hlds[3 * K * 64];
+    __shared__ __attribute__((aligned(16))) unsigned char stage[4][2048];
+    const int F = 64;
+    stage_head_params<K>(hlds, p.att_vec, p.ln_weight, p.ln_bias, p.layernorm, F);
+    __syncthreads();
+    const int lane = threadIdx.x & 63, i = lane & 15, kq = lane >> 4;
+    const int ga = i >> 2, ra = i & 3;           // the self term's A-operand row: item ga of the quad (acm_conv_acmii.hip)
+    // contraction weights of this lane's four D rows: W_ch[4 (kq & 1) + r][16 t + i]
+    float wc[T][4];
+#pragma unroll
+    for (int q = 0; q < T; ++q)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int f = 4 * (kq & 1) + r;
+            const float wv = (q < 4 ? p.w_low : p.w_high)[(long)(f < p.f_in ? f : 0) * p.ld_w + 16 * (q & 3) + i];   // branch-free
+            wc[q][r] = f < p.f_in ? wv : 0.f;
+        }
+    // B operands of the rows' own projections relu(x_i [W_H | W_I]) on the fp32 matrix pipe: feature f = 2 kq + s
+    float bs[2][8];
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+        const int f = 2 * kq + s;
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+            const float wv = (t < 4 ? p.w_high : p.w_mlp)[(long)(f < p.f_in ? f : 0) * p.ld_w + 16 * (t & 3) + i];
+            bs[s][t] = f < p.f_in ? wv : 0.f;
+        }
+    }
+    float mixm[K * K];
+#pragma unroll
+    for (int q = 0; q < K * K; ++q) mixm[q] = p.att_mix[q];
+    const AcmDropCtx dc = acm_drop_ctx(p.post_drop);
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+    const int n_quads = (csr.n_items + 3) >> 2;
+    const int q = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (q >= n_quads) return;
+    const int wa = 4 * q + ga, wd = 4 * q + kq;
+    const bool valid_a = wa < csr.n_items, valid_d = wd < csr.n_items;
+    const AcmItem ia = csr.items[valid_a ? wa : 0], id = csr.items[valid_d ? wd : 0];
+    const VQuad vq = v_quad(id, valid_d);
+    float acc[T];
+#pragma unroll
+    for (int t = 0; t < T; ++t) acc[t] = 0.f;
+    v_items(vq, csr.indices, table, zero_row, stage[threadIdx.x >> 6], lane, [](int) {},
+            [&](int u, const f32x4 (&d)[8]) {
+#pragma unroll
+                for (int t = 0; t < T; ++t) {
+                    float s = 0.f;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) s = fmaf(d[t][r], wc[t][r], s);
+                    s = acm_cross_row_sum(s);
+                    acc[t] = kq == u ? s : acc[t];
+                }
+            });
+    // the rows' own projected features relu(x_i [W_H | W_I]): A row 4 g of the operand carries item g's input row
+    float zs[8];
+    {
+        const float2 xi = (valid_a && ra == 0) ? *reinterpret_cast<const float2*>(p.xs + (long)ia.row * p.ld_xs + 2 * kq)
+                                               : make_float2(0.f, 0.f);
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+            f32x4 d = __builtin_amdgcn_mfma_f32_16x16x4f32(xi.x, bs[0][t], zero4, 0, 0, 0);
+            d = __builtin_amdgcn_mfma_f32_16x16x4f32(xi.y, bs[1][t], d, 0, 0, 0);
+            zs[t] = fmaxf(d[0], 0.f);
+        }
+    }
+    // ---- per 16-lane row: its item (row, slot); from here on as acm_conv_acmii.hip
+    const int row = id.row, slot = id.slot;
+    const long rr = valid_d ? row : 0;
+    bool owner = valid_d && slot < 0;
+    if (valid_d && slot >= 0) owner = csr.long_rows[csr.long_index[row]].slot_begin == slot;   // first piece of a long row
+    if (owner) {
+        if (p.zlh) {                               // the H half only (self term of a long row's fix-up); the L half is not computed here
+#pragma unroll
+            for (int t = 0; t < 4; ++t) p.zlh[rr * p.ld_zlh + F + 16 * t + i] = zs[t];
+        }
+#pragma unroll
+        for (int t = 0; t < 4; ++t) p.zi[rr * p.ld_zi + 16 * t + i] = zs[4 + t];
+    }
+    if (valid_d && slot >= 0) {                        // a piece of a long row: raw sums to its slot
+        float* ps = partial + (long)slot * (2 * F);
+#pragma unroll
+        for (int t = 0; t < T; ++t) ps[16 * t + i] = acc[t];
+    }
+    const bool full = valid_d && slot < 0;
+    const float rs = p.row_scale ? p.row_scale[rr] : 1.f;
+    float H[K][4], pre[3][4];
+    const float dg = K == 4 ? p.deg[rr] : 0.f;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        pre[0][t] = rs * acc[t];
+        pre[1][t] = zs[t] - rs * acc[4 + t];
+        H[0][t] = pre[0][t];                           // ACMII: no ReLU after the filter
+        H[1][t] = pre[1][t];
+        H[2][t] = zs[4 + t];
+        if (K == 4) {                                  // structure channel: relu(A S) = relu(deg (A_low S) - S), ps = A_low S
+            pre[2][t] = dg * p.ps[rr * p.ld_ps + i + 16 * t] - p.ss[rr * p.ld_ss + i + 16 * t];
+            H[K - 1][t] = fmaxf(pre[2][t], 0.f);
+        }
+    }
+    RowHead<K> rh;
+    row_head<K>(hlds, mixm, acm_opaque(i), F, p.layernorm != 0, H, rh);
+    float df[4];
+    acm_drop4(dc, rr, i, df);
+    if (full) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int col = i + 16 * t;
+            float o = rh.alpha[0] * H[0][t] + rh.alpha[1] * H[1][t] + rh.alpha[2] * H[2][t];
+            if (K == 4) o = fmaf(rh.alpha[K - 1], H[K - 1][t], o);
+            o *= p.scale;
+            if (p.post_relu) o = fmaxf(o, 0.f);
+            if (p.post_scale) o *= p.post_scale[rr * p.ld_post_scale + col];
+            if (p.post_drop.p > 0.f) o *= df[t];
+            p.out[rr * p.ld_out + col] = o;
+            p.pre[rr * p.ld_pre + col] = pre[0][t];
+            p.pre[rr * p.ld_pre + F + col] = pre[1][t];
+            if (K == 4) p.pre[rr * p.ld_pre + 2 * F + col] = pre[2][t];
+        }
+        if (i == 0)
+            *reinterpret_cast<float4*>(p.att + rr * 4) =
+                make_float4(rh.alpha[0], rh.alpha[1], rh.alpha[2], K == 4 ? rh.alpha[K - 1] : 0.f);
+    }
+}
+
+// ------------------------------------------------------------------ backward: dW_L, dW_H, dW_I
+// partial: [48 groups][n_blocks][32]: group = column / 32 of the 1536 columns (ch, f, c) = 512 ch + 64 f + c, ch = L, H, I.
+// The row-local terms -- the high-pass channel's self term G_H[i, c] m^H_i[c] x_i[f] and the identity channel's
+// dZ_I[i, c] x_i[f] -- are plain fp32 FMAs: lane (kq, i) owns features 2 kq, 2 kq + 1 of column i of every tile.
+__global__ __launch_bounds__(256) void acmii_v_bwd_kernel(acm_conv_acmii_bwd_t p, CsrView csr, const u32x4* __restrict__ table,
+                                                          int zero_row, float* __restrict__ partial) {
+    constexpr int T = 8;
+    __shared__ __attribute__((aligned(16))) unsigned char stage[4][2048];
+    __shared__ float red[4][1536];
+    const int lane = threadIdx.x & 63, i = lane & 15, kq = lane >> 4, wv = threadIdx.x >> 6;
+    const int n_quads = (csr.n_items + 3) >> 2;
+    const int q = blockIdx.x * 4 + wv;
+    const int wd = 4 * q + kq;
+    const bool valid_d = q < n_quads && wd < csr.n_items;
+    const AcmItem id = csr.items[valid_d ? wd : 0];
+    const VQuad vq = v_quad(id, valid_d);
+    bool owner = valid_d && id.slot < 0;
+    if (valid_d && id.slot >= 0) owner = csr.long_rows[csr.long_index[id.row]].slot_begin == id.slot;
+    // the four items' rows / validity / "runs the row-local terms" (whole row or first piece of a long one), wave-uniform
+    const int rw0 = __builtin_amdgcn_readlane(id.row, 0), rw1 = __builtin_amdgcn_readlane(id.row, 16),
+              rw2 = __builtin_amdgcn_readlane(id.row, 32), rw3 = __builtin_amdgcn_readlane(id.row, 48);
+    const int vl = valid_d ? 1 : 0, ol = owner ? 1 : 0;
+    const int vd0 = __builtin_amdgcn_readlane(vl, 0), vd1 = __builtin_amdgcn_readlane(vl, 16), vd2 = __builtin_amdgcn_readlane(vl, 32),
+              vd3 = __builtin_amdgcn_readlane(vl, 48);
+    const int ow0 = __builtin_amdgcn_readlane(ol, 0), ow1 = __builtin_amdgcn_readlane(ol, 16), ow2 = __builtin_amdgcn_readlane(ol, 32),
+              ow3 = __builtin_amdgcn_readlane(ol, 48);
+    float accd[T][4], accs[4][2], acci[4][2];
+#pragma unroll
+    for (int t = 0; t < T; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) accd[t][r] = 0.f;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) accs[t][0] = accs[t][1] = acci[t][0] = acci[t][1] = 0.f;
+    // the wave works through its four items one after the other, all four lane rows on the same item: lane (kq, i) owns the
+    // D rows of split kq >> 1, features 4 (kq & 1) + r, column i of every tile
+    float gu[T], gi[4], rsu = 0.f, own = 0.f;
+    float2 xv = make_float2(0.f, 0.f);
+    unsigned mself = 0;
+    v_items(vq, csr.indices, table, zero_row, stage[wv], lane,
+            [&](int u) {             // the item's G rows, scale, own input and masks: requested before its batches, used after them
+                const long ru = sel4(rw0, rw1, rw2, rw3, u);
+                rsu = sel4(vd0, vd1, vd2, vd3, u) ? p.row_scale[ru] : 0.f;
+                own = sel4(ow0, ow1, ow2, ow3, u) ? 1.f : 0.f;
+#pragma unroll
+                for (int t = 0; t < T; ++t)
+                    gu[t] = t < 4 ? p.g_low[ru * p.ld_g_low + 16 * t + i] : p.g_high[ru * p.ld_g_high + 16 * (t & 3) + i];
+#pragma unroll
+                for (int t = 0; t < 4; ++t) gi[t] = p.g_mlp[ru * p.ld_g_mlp + 16 * t + i];
+                xv = *reinterpret_cast<const float2*>(p.x + ru * p.ld_x + 2 * kq);
+                mself = reinterpret_cast<const unsigned char*>(table)[ru * 64 + 48 + i];
+            },
+            [&](int u, const f32x4 (&d)[8]) {
+#pragma unroll
+                for (int t = 0; t < T; ++t) {
+                    const float cf = (t < 4 ? rsu : -rsu) * gu[t];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) accd[t][r] = fmaf(cf, d[t][r], accd[t][r]);
+                }
+                const float x0 = own * xv.x, x1 = own * xv.y;      // pieces that do not own the row: nothing
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    const float gm = ((mself >> (4 + t)) & 1u) ? gu[4 + t] : 0.f;
+                    accs[t][0] = fmaf(gm, x0, accs[t][0]);
+                    accs[t][1] = fmaf(gm, x1, accs[t][1]);
+                    acci[t][0] = fmaf(gi[t], x0, acci[t][0]);
+                    acci[t][1] = fmaf(gi[t], x1, acci[t][1]);
+                }
+            });
+    // splits: hi + lo (lane rows 0, 1) + mid (rows 2, 3) -> lane rows 0, 1 hold features 4 kq + r
+#pragma unroll
+    for (int t = 0; t < T; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const acm_u32x2 sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(accd[t][r]), __float_as_uint(accd[t][r]), false, false);
+            const float tot = __uint_as_float(sw[0]) + __uint_as_float(sw[1]);
+            if (kq < 2) red[wv][512 * (t >> 2) + 64 * (4 * kq + r) + 16 * (t & 3) + i] = tot;
+        }
+    __syncthreads();
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            red[wv][512 + 64 * (2 * kq + s) + 16 * t + i] += accs[t][s];
+            red[wv][1024 + 64 * (2 * kq + s) + 16 * t + i] = acci[t][s];
+        }
+    __syncthreads();
+    const long gstride = (long)gridDim.x * 32;
+#pragma unroll
+    for (int h = 0; h < 6; ++h) {
+        const int col = threadIdx.x + 256 * h;
+        const float s = (red[0][col] + red[1][col]) + (red[2][col] + red[3][col]);
+        partial[(long)(col >> 5) * gstride + (long)blockIdx.x * 32 + (col & 31)] = s;
+    }
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------ C ABI
+extern "C" int acm_acmii_table_bytes(int64_t n_rows, size_t* bytes) {
+    ACM_REQUIRE(bytes && n_rows >= 0, ACM_EINVAL, "acm_acmii_table_bytes: NULL argument / negative row count");
+    *bytes = (size_t)(n_rows + 1) * 64;
+    return ACM_OK;
+}
+
+extern "C" int acm_acmii_table(int64_t n_rows, int f_in, const float* x, int64_t ld_x, const float* w_low, const float* w_high,
+                               int64_t ld_w, void* table, size_t table_bytes, acm_stream_t stream) {
+    ACM_REQUIRE(x && w_low && w_high && table, ACM_EINVAL, "acm_acmii_table: NULL argument");
+    ACM_REQUIRE(f_in >= 1 && f_in <= 8 && ld_x >= 8 && ld_x % 2 == 0 && ((uintptr_t)x) % 8 == 0 && ld_w >= 64, ACM_EUNSUPPORTED,
+                "acm_acmii_table: f_in %d (needs f_in <= 8, rows of 8 zero-padded floats, 8-byte aligned; 64 output columns)", f_in);
+    ACM_REQUIRE(table_bytes >= (size_t)(n_rows + 1) * 64 && ((uintptr_t)table) % 16 == 0, ACM_ENOMEM,
+                "acm_acmii_table: table of %zu B < %zu B, or not 16-byte aligned", table_bytes, (size_t)(n_rows + 1) * 64);
+    ACM_REQUIRE(n_rows < (int64_t)1 << 31, ACM_EUNSUPPORTED, "acm_acmii_table: %lld rows", (long long)n_rows);
+    const long groups = n_rows + 1;
+    const int grid = (int)((groups + 15) / 16 < 4096 ? (groups + 15) / 16 : 4096);
+    hipLaunchKernelGGL(acmii_table_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, (long)n_rows, f_in, x, (long)ld_x, w_low,
+                       w_high, (long)ld_w, (unsigned*)table);
+    ACM_CHECK_HIP(hipGetLastError());
+    return ACM_OK;
+}
+
+static int acmii_v_check_operator(const acm_csr_t* a, const void* table, const char* who) {
+    ACM_REQUIRE(a && table, ACM_EINVAL, "%s: NULL argument", who);
+    ACM_REQUIRE(a->vals == nullptr, ACM_EUNSUPPORTED, "%s: pattern-only operators only (explicit values scale the inputs, not the masks)", who);
+    ACM_REQUIRE(a->n_rows == a->n_cols, ACM_EUNSUPPORTED, "%s: square operators only (the table holds the rows' own entries)", who);
+    ACM_REQUIRE(a->nnz > 0 && a->n_rows < ((int64_t)1 << 31) - 1, ACM_EUNSUPPORTED, "%s: empty operator / too many rows", who);
+    ACM_REQUIRE(((uintptr_t)table) % 16 == 0, ACM_EINVAL, "%s: table not 16-byte aligned", who);
+    ACM_REQUIRE(a->n_long == 0 || a->long_index, ACM_EUNSUPPORTED, "%s: handle without a long-row index", who);
+    return ACM_OK;
+}
+
+// The forward on a table acm_acmii_table has just written for the SAME x and weights.  p as for acm_conv_acmii_fwd; p->xg is not
+// read (the table replaces it), p->zlh may be NULL (only its high-pass half would be written).  Long rows: the pieces' partial
+// sums are combined by acm_conv_acmii_fwd's fix-up launch, which reads zlh's high-pass half -- so zlh is required with long rows.
+extern "C" int acm_conv_acmii_v_fwd(const acm_csr_t* a, const acm_conv_acmii_fwd_t* p, const void* table, void* workspace,
+                                    size_t workspace_bytes, acm_stream_t stream);
+int acm_acmii_fixup_launch(const acm_csr_t* a, const acm_conv_acmii_fwd_t* p, const float* partial, hipStream_t s);   // acm_conv_acmii.hip
+
+extern "C" int acm_conv_acmii_v_fwd(const acm_csr_t* a, const acm_conv_acmii_fwd_t* p, const void* table, void* workspace,
+                                    size_t workspace_bytes, acm_stream_t stream) {
+    ACM_REQUIRE(p, ACM_EINVAL, "acm_conv_acmii_v_fwd: NULL argument");
+    const int st = acmii_v_check_operator(a, table, "acm_conv_acmii_v_fwd");
+    if (st != ACM_OK) return st;
+    ACM_REQUIRE(p->f_out == 64 && p->f_in >= 1 && p->f_in <= 8 && p->f_pad == 8, ACM_EUNSUPPORTED,
+                "acm_conv_acmii_v_fwd: f_in %d f_pad %d f_out %d (needs f_in <= 8 = f_pad, f_out = 64)", p->f_in, p->f_pad, p->f_out);
+    ACM_REQUIRE(p->xs && p->w_low && p->w_high && p->w_mlp && p->att_mix && p->out && p->pre && p->att && p->zi && p->row_scale,
+                ACM_EINVAL, "acm_conv_acmii_v_fwd: NULL tensor pointer (row_scale is required: pattern-only operator)");
+    ACM_REQUIRE(((uintptr_t)p->xs) % 8 == 0 && p->ld_xs % 2 == 0 && p->ld_xs >= p->f_pad && ((uintptr_t)p->att) % 16 == 0, ACM_EINVAL,
+                "acm_conv_acmii_v_fwd: xs rows must be 8-byte aligned and f_pad long, att 16-byte aligned");
+    const int K = p->n_channels;
+    ACM_REQUIRE(K == 3 || K == 4, ACM_ESHAPE, "acm_conv_acmii_v_fwd: n_channels %d", K);
+    ACM_REQUIRE(p->ld_w >= 64 && p->ld_out >= 64 && p->ld_pre >= 64 * (K - 1) && p->ld_zi >= 64 && (!p->zlh || p->ld_zlh >= 128), ACM_ESHAPE,
+                "acm_conv_acmii_v_fwd: leading dimension too small");
+    ACM_REQUIRE(K == 3 || (p->ps && p->ss && p->deg && p->ld_ps >= 64 && p->ld_ss >= 64), ACM_EINVAL,
+                "acm_conv_acmii_v_fwd: structure-channel pointers NULL / leading dimensions too small");
+    ACM_REQUIRE(a->n_long == 0 || p->zlh, ACM_EINVAL, "acm_conv_acmii_v_fwd: zlh is required when the operator has long rows");
+    for (int c = 0; c < K; ++c) {
+        ACM_REQUIRE(p->att_vec[c], ACM_EINVAL, "acm_conv_acmii_v_fwd: att_vec[%d] NULL", c);
+        ACM_REQUIRE(!p->layernorm || (p->ln_weight[c] && p->ln_bias[c]), ACM_EINVAL, "acm_conv_acmii_v_fwd: LayerNorm pointers NULL");
+    }
+    size_t need = 0;
+    acm_conv_acmii_fwd_workspace_bytes(a, &need);
+    ACM_REQUIRE(workspace && workspace_bytes >= need, ACM_ENOMEM, "acm_conv_acmii_v_fwd: workspace %zu B < required %zu B", workspace_bytes, need);
+    if (a->n_rows == 0 || a->n_items == 0) return ACM_OK;
+    hipStream_t s = (hipStream_t)stream;
+    const CsrView cv = acm_view(a);
+    const int grid = (int)((a->n_items + 15) / 16);
+    const int zero_row = (int)a->n_rows;
+    if (K == 3) hipLaunchKernelGGL(acmii_v_fwd_kernel<3>, dim3(grid), dim3(256), 0, s, *p, cv, (const u32x4*)table, zero_row, (float*)workspace);
+    else hipLaunchKernelGGL(acmii_v_fwd_kernel<4>, dim3(grid), dim3(256), 0, s, *p, cv, (const u32x4*)table, zero_row, (float*)workspace);
+    ACM_CHECK_HIP(hipGetLastError());
+    if (a->n_long) return acm_acmii_fixup_launch(a, p, (const float*)workspace, s);
+    return ACM_OK;
+}
+
+extern "C" int acm_conv_acmii_v_bwd_workspace_bytes(const acm_csr_t* a, size_t* bytes) {
+    ACM_REQUIRE(a && bytes, ACM_EINVAL, "acm_conv_acmii_v_bwd_workspace_bytes: NULL argument");
+    const size_t grid = (size_t)((a->n_items + 15) / 16);
+    *bytes = (grid > 0 ? grid : 1) * 1536 * sizeof(float);
+    return ACM_OK;
+}
+
+extern "C" int acm_conv_acmii_v_bwd(const acm_csr_t* a, const acm_conv_acmii_bwd_t* p, void* workspace, size_t workspace_bytes,
+                                    acm_stream_t stream) {
+    ACM_REQUIRE(p, ACM_EINVAL, "acm_conv_acmii_v_bwd: NULL argument");
+    const int st = acmii_v_check_operator(a, p->table, "acm_conv_acmii_v_bwd");
+    if (st != ACM_OK) return st;
+    ACM_REQUIRE(p->f_in >= 1 && p->f_in <= 8, ACM_EUNSUPPORTED, "acm_conv_acmii_v_bwd: f_in %d", p->f_in);
+    ACM_REQUIRE(p->g_low && p->g_high && p->g_mlp && p->x && p->row_scale && p->d_w_low && p->d_w_high && p->d_w_mlp, ACM_EINVAL,
+                "acm_conv_acmii_v_bwd: NULL tensor pointer");
+    ACM_REQUIRE(p->ld_g_low >= 64 && p->ld_g_high >= 64 && p->ld_g_mlp >= 64 && p->ld_dw >= 64 && p->ld_x >= 8 && p->ld_x % 2 == 0 &&
+                    ((uintptr_t)p->x) % 8 == 0, ACM_ESHAPE, "acm_conv_acmii_v_bwd: leading dimension too small / x rows not 8-byte aligned");
+    size_t need = 0;
+    acm_conv_acmii_v_bwd_workspace_bytes(a, &need);
+    ACM_REQUIRE(workspace && workspace_bytes >= need && ((uintptr_t)workspace) % 16 == 0, ACM_ENOMEM,
+                "acm_conv_acmii_v_bwd: workspace %zu B < required %zu B (or not 16-byte aligned)", workspace_bytes, need);
+    hipStream_t s = (hipStream_t)stream;
+    if (a->n_rows == 0 || a->n_items == 0) {
+        ACM_CHECK_HIP(hipMemset2DAsync(p->d_w_low, (size_t)p->ld_dw * 4, 0, 64 * 4, (size_t)p->f_in, s));
+        ACM_CHECK_HIP(hipMemset2DAsync(p->d_w_high, (size_t)p->ld_dw * 4, 0, 64 * 4, (size_t)p->f_in, s));
+        ACM_CHECK_HIP(hipMemset2DAsync(p->d_w_mlp, (size_t)p->ld_dw * 4, 0, 64 * 4, (size_t)p->f_in, s));
+        return ACM_OK;
+    }
+    const CsrView cv = acm_view(a);
+    const int grid = (int)((a->n_items + 15) / 16);
+    ACM_REQUIRE((int64_t)grid * 32 < ((int64_t)1 << 31), ACM_EUNSUPPORTED, "acm_conv_acmii_v_bwd: %d workgroups", grid);
+    float* partial = (float*)workspace;
+    hipLaunchKernelGGL(acmii_v_bwd_kernel, dim3(grid), dim3(256), 0, s, *p, cv, (const u32x4*)p->table, (int)a->n_rows, partial);
+    ACM_CHECK_HIP(hipGetLastError());
+    const int len = p->f_in * 64;
+    const acm_reduce_seg_t segs[3] = {{partial, grid, 32, 0, len, p->d_w_low, 64, 0, p->ld_dw, 0, grid * 32, 0},
+                                      {partial, grid, 32, 512, len, p->d_w_high, 64, 0, p->ld_dw, 0, grid * 32, 0},
+                                      {partial, grid, 32, 1024, len, p->d_w_mlp, 64, 0, p->ld_dw, 0, grid * 32, 0}};
+    return acm_reduce_emit(p->defer, segs, 3, s);
+}

@@ -1363,9 +1363,35 @@ class AcmConvFunction(torch.autograd.Function):
             nbytes = C.c_size_t()
             _lib.check(lib.acm_conv_acmii_fwd_workspace_bytes(ops.low.handle, C.byref(nbytes)), "acm_conv_acmii_fwd_workspace_bytes")
             ws = torch.empty(max(nbytes.value // 4, 1), dtype=_F32, device=dev)
-            with _device_ctx(dev), _Timed(f"conv_acmii_fwd/F{f}i{f_in}"):
-                st = lib.acm_conv_acmii_fwd(ops.low.handle, C.byref(p), _vp(ws), ws.numel() * 4, _stream())
-            _lib.check(st, "acm_conv_acmii_fwd")
+            # The mask form (acm_conv_acmii_v.hip): relu(x_j W) = m_j * (x_j W), so the aggregate is W contracted with
+            # V_i = sum_j m_j (x) x_j -- a product over the neighbour index on the bf16 matrix pipe, exact operands -- and the
+            # weight gradients are the same V contracted with dH: no transposed product.  Three channels, a pattern-only
+            # operator over this process's own rows, no gradient into x.
+            ctx.mask_table = None
+            st = 4
+            if (k == 3 and ops.implicit and not ops.sharded and not ctx.needs_input_grad[0] and n > 0
+                    and xg.data_ptr() == xpad.data_ptr() and (tuning.HOST.rewrites & tuning.REWRITE_ACMII_MASK) != 0):
+                tb = C.c_size_t()
+                _lib.check(lib.acm_acmii_table_bytes(n, C.byref(tb)), "acm_acmii_table_bytes")
+                table = torch.empty(tb.value // 4, dtype=torch.int32, device=dev)
+                with _device_ctx(dev), _Timed(f"acmii_table/{n}x{f_in}"):
+                    st = lib.acm_acmii_table(n, f_in, xpad.data_ptr(), xpad.stride(0), wl.data_ptr(), wh.data_ptr(), f,
+                                             table.data_ptr(), tb.value, _stream())
+                if st == 0:
+                    if ops.low.n_long_rows == 0:          # only the fix-up of long rows reads zlh (its high-pass half)
+                        p.zlh, p.ld_zlh = None, 0
+                    with _device_ctx(dev), _Timed(f"conv_acmii_v_fwd/F{f}i{f_in}"):
+                        st = lib.acm_conv_acmii_v_fwd(ops.low.handle, C.byref(p), table.data_ptr(), _vp(ws), ws.numel() * 4, _stream())
+                    if st == 0:
+                        ctx.mask_table, ctx.mask_x = table, xpad
+                    else:
+                        p.zlh, p.ld_zlh = zlh.data_ptr(), zlh.stride(0)
+                if st not in (0, 4):                      # 4 = ACM_EUNSUPPORTED: the fp32 kernel below
+                    _lib.check(st, "acm_conv_acmii_v_fwd")
+            if ctx.mask_table is None:
+                with _device_ctx(dev), _Timed(f"conv_acmii_fwd/F{f}i{f_in}"):
+                    st = lib.acm_conv_acmii_fwd(ops.low.handle, C.byref(p), _vp(ws), ws.numel() * 4, _stream())
+                _lib.check(st, "acm_conv_acmii_fwd")
             ctx.agg_first, ctx.tail, ctx.sparse_x = False, None, None
             ctx.ops, ctx.cfg = ops, cfg
             ctx.save_for_backward(x, *w3, zlh, zi, pre, mix, *vecs, *lnw, *lnb)
@@ -1597,6 +1623,8 @@ class AcmConvFunction(torch.autograd.Function):
         general, ones = st3["general"], st3["ones"]
         if done:
             ctx.tail = None
+        elif getattr(ctx, "mask_table", None) is not None:
+            q.g_scale = None                     # the mask form's backward scales by 1 / d_i itself: G_L, G_H as they are
         d_vec, d_lnw, d_lnb, d_mix = _flat_views(flat, nw, k, f, cfg.layernorm)    # this call's own view objects
         del st3, tail
         if not done:                 # else: acm_conv_fwd_tail already ran K3 with exactly this gradient
@@ -1609,6 +1637,36 @@ class AcmConvFunction(torch.autograd.Function):
             _lib.check(st, "acm_conv_bwd_local")
             if defer is not None:
                 defer.hold(ws, [d_mix, *d_vec, *d_lnw, *d_lnb], keep=[flat])
+
+        table = getattr(ctx, "mask_table", None)
+        if table is not None:
+            # the mask form's backward: dW_L, dW_H straight from dH_L, dH_H (K3's g) over the FORWARD operator and the
+            # forward's table, and the row-local dW_I = X^T dZ_I in the same launch
+            d_wcat = flat[:nw].view(3, f_in_w, f)
+            xt = ctx.mask_x
+            b = _lib.ConvAcmiiBwd()
+            b.f_in, b.table = f_in_w, table.data_ptr()
+            b.g_low, b.ld_g_low = g.data_ptr(), g.stride(0)
+            b.g_high, b.ld_g_high = g.data_ptr() + 4 * fb, g.stride(0)
+            b.g_mlp, b.ld_g_mlp = dz.data_ptr() + 8 * f, dz.stride(0)
+            b.x, b.ld_x = xt.data_ptr(), xt.stride(0)
+            b.row_scale = ops.row_scale.data_ptr()
+            b.d_w_low, b.d_w_high, b.d_w_mlp, b.ld_dw = d_wcat[0].data_ptr(), d_wcat[1].data_ptr(), d_wcat[2].data_ptr(), f
+            b.defer = defer.pointer() if defer is not None else None
+            nbytes = C.c_size_t()
+            _lib.check(lib.acm_conv_acmii_v_bwd_workspace_bytes(ops.low.handle, C.byref(nbytes)), "acm_conv_acmii_v_bwd_workspace_bytes")
+            wsb = torch.empty(max(nbytes.value // 4, 1), dtype=_F32, device=dev)
+            with _device_ctx(dev), _Timed(f"conv_acmii_v_bwd/F{f}i{f_in_w}"):
+                st = lib.acm_conv_acmii_v_bwd(ops.low.handle, C.byref(b), _vp(wsb), wsb.numel() * 4, _stream())
+            _lib.check(st, "acm_conv_acmii_v_bwd")
+            if defer is not None:
+                defer.hold(wsb, [d_wcat[0], d_wcat[1], d_wcat[2]], keep=[flat, table, g, dz, xt])
+            none4 = [None] * 4
+            grads_vec = d_vec + [None] * (4 - k)
+            grads_lnw = (d_lnw + [None] * (4 - k)) if cfg.layernorm else none4
+            grads_lnb = (d_lnb + [None] * (4 - k)) if cfg.layernorm else none4
+            return (None, d_wcat[0], d_wcat[1], d_wcat[2], grads_vec[0], grads_vec[1], grads_vec[2], grads_vec[3],
+                    None, d_mix, *grads_lnw, *grads_lnb, None, None, None, None, None, None, None, None, None)
 
         d_struc = torch.empty(n, f, dtype=_F32, device=dev) if four else None
         r = _lib.ConvBwdSpmm()

@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define ACM_ABI_VERSION 23
+#define ACM_ABI_VERSION 24
 
 typedef enum {
     ACM_OK = 0,
@@ -707,6 +707,50 @@ typedef struct {
 int acm_conv_acmii_fwd_workspace_bytes(const acm_csr_t* a_low, size_t* bytes);
 int acm_conv_acmii_fwd(const acm_csr_t* a_low, const acm_conv_acmii_fwd_t* p,
                        void* workspace, size_t workspace_bytes, acm_stream_t stream);
+
+/* ------------------------ ACMII first layer on the bf16 matrix pipe: the mask form (ABI 24) --
+ * relu(x_j W[:, c]) = m_j[c] * (x_j W[:, c]) with the mask m_j[c] = [x_j W[:, c] > 0], so
+ *     sum_j a_ij relu(x_j W[:, c]) = sum_f W[f, c] V_i[c, f],    V_i[c, f] = sum_j a_ij m_j[c] x_j[f]:
+ * V_i is a matrix product over the neighbour index with one 0 / 1 operand (exact in bf16) and one fp32 operand that is
+ * exactly the sum of three bf16 numbers -- v_mfma_f32_16x16x32_bf16 at fp32 accuracy, sixteen times the rate of the fp32
+ * matrix pipe acm_conv_acmii_fwd uses.  The same V gives the layer's weight gradients without any transposed product
+ * (the layer input takes no gradient):  dW_L[f, c] = sum_i dH_L[i, c] rs_i V^L_i[c, f],
+ *     dW_H[f, c] = sum_i dH_H[i, c] (m^H_i[c] x_i[f] - rs_i V^H_i[c, f])      (rs_i = 1 / d_i, pattern-only operator).
+ * Replaces, for ACM-Geometric/layers.py:94-99 with f_in <= 8 and f_out = 64: torch.mm + F.relu + torch.spmm (x2) of the
+ * forward, and SpmmBackward (x2) + ReluBackward + MmBackward of weight_low / weight_high.
+ *
+ *   acm_acmii_table        one 64-byte row per node, [x hi | x mid | x lo (8 bf16 each) | 16 mask bytes], plus an all-zero
+ *                          row n_rows.  Rebuilt whenever x (input dropout) or the weights change: every training step.
+ *                          x: [n_rows, ld_x >= 8], zero padded beyond f_in, 8-byte aligned rows.
+ *   acm_conv_acmii_v_fwd   acm_conv_acmii_fwd's outputs from the table (p->xg is not read; p->row_scale is required;
+ *                          p->zlh may be NULL when the operator has no long rows -- only its second half, the rows' own
+ *                          relu(x_i W_H), is written).  Square pattern-only operators whose column ids index the table.
+ *                          Workspace: acm_conv_acmii_fwd_workspace_bytes.
+ *   acm_conv_acmii_v_bwd   d_w_low, d_w_high ([f_in, 64], pitch ld_dw) from g_low = dH_L, g_high = dH_H ([n_rows, 64]) over
+ *                          the SAME (forward) operator and table, and d_w_mlp = X^T dZ_I on the way (row-local: the launch
+ *                          has every row in hand); deterministic; the final sums honour `defer`.
+ * ACM_EUNSUPPORTED for operators with explicit values, non-square operators, f_in > 8: the caller keeps
+ * acm_conv_acmii_fwd / acm_conv_bwd_spmm / acm_gemm. */
+typedef struct {
+    int32_t f_in;
+    const void* table;                          /* acm_acmii_table's output for this step's x and weights           */
+    const float* g_low;  int64_t ld_g_low;      /* dH_L [n_rows, 64]                                                 */
+    const float* g_high; int64_t ld_g_high;     /* dH_H [n_rows, 64]                                                 */
+    const float* g_mlp;  int64_t ld_g_mlp;      /* dZ_I [n_rows, 64] = dH_I masked by the identity channel's ReLU    */
+    const float* x; int64_t ld_x;               /* the rows the table was built from ([n_rows, >= 8], zero padded)   */
+    const float* row_scale;                     /* 1 / d_i                                                           */
+    float* d_w_low; float* d_w_high; float* d_w_mlp; int64_t ld_dw;   /* [f_in, 64] each; d_w_mlp = X^T dZ_I        */
+    acm_reduce_list_t* defer;                   /* NULL: reduce now; else append the two second phases              */
+} acm_conv_acmii_bwd_t;
+
+int acm_acmii_table_bytes(int64_t n_rows, size_t* bytes);
+int acm_acmii_table(int64_t n_rows, int f_in, const float* x, int64_t ld_x, const float* w_low, const float* w_high,
+                    int64_t ld_w, void* table, size_t table_bytes, acm_stream_t stream);
+int acm_conv_acmii_v_fwd(const acm_csr_t* a_low, const acm_conv_acmii_fwd_t* p, const void* table,
+                         void* workspace, size_t workspace_bytes, acm_stream_t stream);
+int acm_conv_acmii_v_bwd_workspace_bytes(const acm_csr_t* a_low, size_t* bytes);
+int acm_conv_acmii_v_bwd(const acm_csr_t* a_low, const acm_conv_acmii_bwd_t* p,
+                         void* workspace, size_t workspace_bytes, acm_stream_t stream);
 
 /* ------------------------------------------------ fused step tail (loss) --
  *   loss   = sum_i w_i * (logsumexp(z_i) - z_i[y_i])

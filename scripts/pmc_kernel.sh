@@ -1,6 +1,8 @@
 #!/bin/bash
 # Counter passes for the kernels of the benchmark step whose name contains <kernel-substring>:
 #   scripts/pmc_kernel.sh <out-prefix> <kernel-substring> "<pass> <pass> ..." [env assignments...]
+# PMC_CMD (environment) replaces the profiled command (default: bench.py's short run), e.g.
+#   PMC_CMD="python scripts/bench_configs.py twitch/acmiigcnp" scripts/pmc_kernel.sh acmii_v acmii_v "sq sq2 mfma"
 # passes: sq sq2 cache ta lds fetch write.  Writes gpurun_out/<prefix>_<pass>.csv.  Separate --pmc passes, --kernel-trace only
 # (never with another trace domain), each under its own timeout.
 set -u
@@ -16,11 +18,13 @@ for NAME in $PASSES; do
     cache) CNT="TCC_HIT_sum TCC_MISS_sum TCP_TCC_READ_REQ_sum TCP_TOTAL_CACHE_ACCESSES_sum";;
     ta) CNT="TA_BUSY_avr TA_TA_BUSY_sum TD_TD_BUSY_sum TCP_PENDING_STALL_CYCLES_sum TA_ADDR_STALLED_BY_TC_CYCLES_sum TA_DATA_STALLED_BY_TC_CYCLES_sum";;
     lds) CNT="SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_ACTIVE_INST_VMEM SQ_INST_LEVEL_VMEM SQ_BUSY_CU_CYCLES SQ_INSTS_VMEM_WR";;
+    mfma) CNT="SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_WAIT_INST_ANY";;
     fetch) CNT="FETCH_SIZE";;
     write) CNT="WRITE_SIZE";;
   esac
   rm -rf /tmp/prof_pmc
-  env "$@" timeout 300 rocprofv3 --pmc $CNT --kernel-trace -d /tmp/prof_pmc -o pmc -- python $REPO/bench.py --steps 8 --warmup 2 --no-cpu-baseline --no-extras --no-check > /dev/null 2> $OUT/${PREFIX}_$NAME.err
+  CMD=${PMC_CMD:-"python $REPO/bench.py --steps 8 --warmup 2 --no-cpu-baseline --no-extras --no-check"}
+  (cd $REPO && env "$@" timeout 300 rocprofv3 --pmc $CNT --kernel-trace -d /tmp/prof_pmc -o pmc -- $CMD > /dev/null 2> $OUT/${PREFIX}_$NAME.err)
   DB=$(find /tmp/prof_pmc -name "*.db" | head -1)
   [ -n "$DB" ] && python $REPO/scripts/rocpd_pmc_summary.py $DB 2>> $OUT/${PREFIX}_$NAME.err | grep -E "^kernel|$MATCH" > $OUT/${PREFIX}_$NAME.csv
 done

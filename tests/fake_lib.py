@@ -461,6 +461,68 @@ class FakeLib:
         _view(p.att, n, 4, 4)[...] = hd["alpha"]
         return 0
 
+    # ---- ACMII first layer, the mask form (acm_conv_acmii_v.hip): the table keeps what the kernels would read from it ----
+    def acm_acmii_table_bytes(self, n_rows, out):
+        out._obj.value = (int(n_rows) + 1) * 64
+        return 0
+
+    def acm_acmii_table(self, n_rows, f_in, x, ldx, w_low, w_high, ldw, table, table_bytes, stream):
+        if f_in > 8 or table_bytes < (n_rows + 1) * 64:
+            self._err = b"acm_acmii_table: unsupported"
+            return 4
+        key = table.value if isinstance(table, C.c_void_p) else int(table)
+        if not hasattr(self, "_acmii_tables"):
+            self._acmii_tables = {}
+        self._acmii_tables[key] = dict(x=_view(x, n_rows, f_in, ldx).astype(np.float32).copy(),
+                                       w_low=_view(w_low, f_in, 64, ldw).astype(np.float64).copy(),
+                                       w_high=_view(w_high, f_in, 64, ldw).astype(np.float64).copy())
+        return 0
+
+    def _acmii_table(self, table):
+        key = table.value if isinstance(table, C.c_void_p) else int(table)
+        return getattr(self, "_acmii_tables", {}).get(key)
+
+    def acm_conv_acmii_v_fwd(self, handle, pp, table, ws, wsb, stream):
+        from acm_gnn_amd import _lib
+        p, t = pp._obj, self._acmii_table(table)
+        g = self._handles[handle.value if isinstance(handle, C.c_void_p) else int(handle)]
+        if t is None or np.any(g.vals != 1) or g.n_rows != g.n_cols or not p.row_scale:
+            self._err = b"acm_conv_acmii_v_fwd: unsupported operator / unknown table"
+            return 4
+        q = _lib.ConvAcmiiFwd.from_buffer_copy(p)
+        xg = np.zeros((g.n_cols, 8), np.float32)
+        xg[:, :t["x"].shape[1]] = t["x"]
+        q.xg, q.ld_xg = xg.ctypes.data, 8
+        zlh = None
+        if not p.zlh:
+            zlh = np.zeros((g.n_rows, 128), np.float32)
+            q.zlh, q.ld_zlh = zlh.ctypes.data, 128
+        return self.acm_conv_acmii_fwd(handle, C.byref(q), ws, wsb, stream)
+
+    def acm_conv_acmii_v_bwd_workspace_bytes(self, handle, out):
+        out._obj.value = 64
+        return 0
+
+    def acm_conv_acmii_v_bwd(self, handle, pp, ws, wsb, stream):
+        p = pp._obj
+        t = self._acmii_table(p.table)
+        g = self._handles[handle.value if isinstance(handle, C.c_void_p) else int(handle)]
+        if t is None or np.any(g.vals != 1) or g.n_rows != g.n_cols:
+            self._err = b"acm_conv_acmii_v_bwd: unsupported operator / unknown table"
+            return 4
+        import scipy.sparse as sp
+        n, fi = g.n_rows, p.f_in
+        x = t["x"].astype(np.float64)
+        a = sp.csr_matrix((g.vals.astype(np.float64), g.indices, g.indptr), shape=(n, n))
+        rs = _vec(p.row_scale, n).astype(np.float64)[:, None]
+        gl, gh = _view(p.g_low, n, 64, p.ld_g_low).astype(np.float64), _view(p.g_high, n, 64, p.ld_g_high).astype(np.float64)
+        ml, mh = (x @ t["w_low"] > 0), (x @ t["w_high"] > 0)
+        d_l = x.T @ (ml * (a.T @ (rs * gl)))                      # X^T (m_L o A_low^T G_L),  A_low = diag(rs) P
+        d_h = x.T @ (mh * (gh - a.T @ (rs * gh)))
+        d_i = _view(p.x, n, fi, p.ld_x).astype(np.float64).T @ _view(p.g_mlp, n, 64, p.ld_g_mlp).astype(np.float64)
+        return self._emit(p.defer, [(_view(p.d_w_low, fi, 64, p.ld_dw), d_l), (_view(p.d_w_high, fi, 64, p.ld_dw), d_h),
+                                    (_view(p.d_w_mlp, fi, 64, p.ld_dw), d_i)])
+
     # ---- ACM-GCN++ residual branch ------------------------------------------------
     @staticmethod
     def _drop_obj(d):

@@ -518,10 +518,21 @@ def test_acmii_recompute_on_gather_matches_oracle_and_literal(model_type, ln, f_
     timer = AF.KernelTimer()
     AF.set_kernel_timer(timer)
     try:
-        tune(acmii_recompute=1)
+        tune(acmii_recompute=1, acmii_mask=0)
         a = _run_both(model_type, 1, s, ln, 700, f_in, 64, 31, False, monkeypatch, agg=True, adj=adj, implicit=implicit)
         used = set(k.split("/")[0] for k in timer.events)
         assert "conv_acmii_fwd" in used and "conv_fwd" not in used and "conv_bwd_spmm" in used, used
+        timer.events.clear()
+        # the mask form of the same layer (acm_conv_acmii_v.hip: bf16 matrix pipe, weight gradients without a transposed
+        # product) where it applies -- three channels over a pattern-only operator; elsewhere the switch changes nothing
+        tune(acmii_mask=1)
+        c = _run_both(model_type, 1, s, ln, 700, f_in, 64, 31, False, monkeypatch, agg=True, adj=adj, implicit=implicit)
+        used = set(k.split("/")[0] for k in timer.events)
+        if implicit and not s:
+            assert {"acmii_table", "conv_acmii_v_fwd", "conv_acmii_v_bwd"} <= used and "conv_bwd_spmm" not in used, used
+        else:
+            assert "conv_acmii_fwd" in used and "conv_bwd_spmm" in used and "conv_acmii_v_fwd" not in used, used
+        assert float((a - c).abs().max()) < 2e-5 * max(1.0, float(a.abs().max()))
         timer.events.clear()
         tune(acmii_recompute=0)
         b = _run_both(model_type, 1, s, ln, 700, f_in, 64, 31, False, monkeypatch, agg=True, adj=adj, implicit=implicit)
