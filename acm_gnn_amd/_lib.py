@@ -19,7 +19,7 @@ ABI_VERSION = 24
 # every symbol include/acm_hip.h declares
 EXPORTED_SYMBOLS = (
     "acm_version", "acm_last_error", "acm_tuning_get", "acm_tuning_set", "acm_csr_create", "acm_csr_transpose", "acm_csr_slice_rows",
-    "acm_csr_destroy", "acm_csr_info", "acm_csr_build_streams", "acm_spmm_workspace_bytes", "acm_gemm_workspace_bytes",
+    "acm_csr_destroy", "acm_csr_info", "acm_csr_build_streams", "acm_csr_build_item_streams", "acm_spmm_workspace_bytes", "acm_gemm_workspace_bytes",
     "acm_gemm", "acm_gemm_blocks", "acm_gemm_drop", "acm_proj3", "acm_gemm_split", "acm_proj_fwd", "acm_proj_fwd_at", "acm_proj_bwd_workspace_bytes", "acm_proj_bwd", "acm_spmm", "acm_spmm_v", "acm_spmm_ex", "acm_cast_bf16", "acm_conv_fwd", "acm_conv_bwd_local_workspace_bytes",
     "acm_conv_bwd_local", "acm_conv_bwd_spmm", "acm_conv_agg_fwd", "acm_conv_agg_bwd_workspace_bytes",
     "acm_conv_agg_bwd", "acm_nll_loss_workspace_bytes", "acm_nll_loss", "acm_adam_step", "acm_dropout",
@@ -41,7 +41,8 @@ class CsrInfo(C.Structure):
                 ("indptr", C.c_void_p), ("indices", C.c_void_p), ("vals", C.c_void_p),
                 ("src_pos", C.c_void_p),
                 ("stream_steps", C.c_int64), ("stream_slices", C.c_int64),
-                ("stream_waves", C.c_int32), ("stream_long_rows", C.c_int32)]
+                ("stream_waves", C.c_int32), ("stream_long_rows", C.c_int32),
+                ("item_stream_waves", C.c_int32), ("reserved", C.c_int32), ("item_stream_batches", C.c_int64)]
 
 
 class ConvFwd(C.Structure):
@@ -218,6 +219,7 @@ def _declare(lib):
     lib.acm_csr_destroy.restype = None
     lib.acm_csr_info.argtypes = [vp, C.POINTER(CsrInfo)]
     lib.acm_csr_build_streams.argtypes = [vp, i32, i32]
+    lib.acm_csr_build_item_streams.argtypes = [vp, i32]
     lib.acm_shard_plan.argtypes = [i64, vp, i32, i64, vp]
     lib.acm_conv_acmii_fwd_workspace_bytes.argtypes = [vp, C.POINTER(sz)]
     lib.acm_conv_acmii_fwd.argtypes = [vp, C.POINTER(ConvAcmiiFwd), vp, sz, vp]

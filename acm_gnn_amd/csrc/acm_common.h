@@ -80,6 +80,21 @@ struct AcmStreams {
     int32_t n_waves, lmax;
 };
 
+// Per-wave BATCH streams over the handle's own work items (acm_csr_build_item_streams, acm_csr.cpp) for kernels that take one
+// item at a time, 32 neighbours per wave step (acm_conv_acmii_v.hip).  The item list is cut into QUADS of four consecutive
+// items (a wave finishes four rows together); quads are dealt longest-first to the least loaded of `n_waves` persistent
+// waves; a wave's quads and their column ids are contiguous: batch b of the stream = ids[32 b .. 32 b + 31], idle slots and
+// ACM_ITEM_STREAM_PAD batches behind the last wave hold n_cols (the index of a zero row the caller appends to its table).
+#define ACM_ITEM_STREAM_PAD 8
+struct AcmItemStreams {
+    int32_t* ids;           // device, (total_batches + ACM_ITEM_STREAM_PAD) * 32
+    int32_t* quads;         // device, n_quads x 4 items x {row, slot, batches, flags}; flags: 1 = item exists, 2 = it runs the row's
+                            // own terms (a whole row, or the first piece of a long one)
+    int32_t* waves;         // device, n_waves x {quad_begin, quad_end, first_batch, batches}
+    int64_t total_batches, n_quads;
+    int32_t n_waves;
+};
+
 struct acm_csr {
     int64_t n_rows, n_cols, nnz;
     int32_t chunk, max_degree;
@@ -96,6 +111,7 @@ struct acm_csr {
     int64_t n_windows;      // the first n_windows * ACM_WINDOW items are the pieces of the long rows
     int64_t n_multi;        // long rows that take several windows (their window sums are added by a second launch)
     AcmStreams* streams;    // NULL until acm_csr_build_streams
+    AcmItemStreams* item_streams;   // NULL until acm_csr_build_item_streams
     int device;
 };
 

@@ -23,13 +23,15 @@
 //   table   one 64-byte row per node, rebuilt every step by acmii_table_kernel (the masks depend on W):
 //           [x hi (8 bf16) | x mid (8 bf16) | x lo (8 bf16) | 16 mask bytes]; bit q = 4 ch + t of byte n = m^ch[16 t + n].
 //           Row n_rows is all zero: what idle slots fetch.
+//   waves   persistent, over the handle's item streams (acm_csr_build_item_streams): a wave reads its parameters once, walks one
+//           linear id stream through its quads of four items and fetches ahead across item and quad boundaries.
 //   batch   32 neighbours of ONE work item per wave step: two 16-byte fetches per lane (a neighbour's row = four lanes) ->
 //           2 KB of wave-private LDS -> operands.  Lane (g = lane >> 4, m = lane & 15), contraction slot e = 0..7 <-> the
 //           neighbour in LDS row 4 e + g (any bijection serves, both operands use this one: bank-conflict free):
-//             A  (16 x 32, x):     rows 0..7 = features, slots (neighbour, part): hi | lo; rows 8..15: mid | 0   (v_batch)
+//             A  (16 x 32, x):     rows 0..7 = hi of the features, rows 8..15 = mid;   A2: rows 0..7 = lo, rows 8..15 = 0
 //             B  (32 x 16, masks): column n = m of tile q: ((byte pair) & (0x00010001 << q)) * (0x3F80 >> q) = two bf16 0 / 1
-//           16 MFMAs (8 tiles x 2 steps of 16 neighbours); D[4 g + r][n]: lane (g, n) holds V[c = 16 t + n][f = 4 (g & 1) + r],
-//           hi + lo in lane rows 0, 1 and mid in rows 2, 3.
+//           16 MFMAs (8 tiles x {A, A2}, both into the same accumulator); D[4 g + r][n]: lane (g, n) holds
+//           V[c = 16 t + n][f = 4 (g & 1) + r], hi + lo in lane rows 0, 1 and mid in rows 2, 3.
 //   item end forward:  S[c] = sum over the four lane rows of sum_r W[4 (g & 1) + r][c] * D[r]; the wave's four items
 //           leave their sums in the four lane rows and share the epilogue of acm_conv_acmii.hip (head, mix, post-op).
 //   item end backward: acc += (+-rs_i G[i, c]) * D -- 32 accumulators per lane, splits and waves summed once per workgroup.
@@ -100,140 +102,134 @@ __global__ __launch_bounds__(256) void acmii_table_kernel(long n_rows, int f_in,
 }
 
 // ------------------------------------------------------------------ the wave's batch sequence
-__device__ __forceinline__ int sel4(int a0, int a1, int a2, int a3, int i) { return i == 0 ? a0 : (i == 1 ? a1 : (i == 2 ? a2 : a3)); }
-
-struct VQuad {                 // the wave's four work items (wave-uniform); an absent item has beg == end
-    int b0, b1, b2, b3, e0, e1, e2, e3;
-    __device__ __forceinline__ int beg(int i) const { return sel4(b0, b1, b2, b3, i); }
-    __device__ __forceinline__ int end(int i) const { return sel4(e0, e1, e2, e3, i); }
+// Persistent waves over the handle's item streams (acm_csr_build_item_streams, acm_common.h: AcmItemStreams): a wave walks
+// ONE linear id stream -- batch b = ids[32 b .. 32 b + 31], idle slots hold the zero row's index -- through its quads of
+// four items; it reads its parameters once and fetches ahead across item and quad boundaries.
+struct VStreamView {
+    const int32_t* ids;
+    const int32_t* quads;
+    const int32_t* waves;
+    int n_waves;
 };
 
-// first batch of the first non-empty item at or after `it` (it == 4: none)
-__device__ __forceinline__ void v_seek(const VQuad& vq, int& it, int& k) {
-    while (it < 4 && vq.beg(it) >= vq.end(it)) ++it;
-    k = it < 4 ? vq.beg(it) : 0;
-}
-__device__ __forceinline__ void v_next(const VQuad& vq, int& it, int& k) {
-    if (it >= 4) return;
-    if (k + 32 < vq.end(it)) {
-        k += 32;
-        return;
-    }
-    ++it;
-    v_seek(vq, it, k);
-}
-
-// column ids of the batch's 32 neighbours, the one of LDS row (lane >> 2) and of row 16 + (lane >> 2); idle slots: the zero row.
-// Branch-free (clamped address + select): a guarded load becomes an exec-mask branch and a wait for every load in flight.
-__device__ __forceinline__ void v_ids(const int32_t* __restrict__ indices, const VQuad& vq, int it, int k, int zero_row, int lane,
-                                      int& j0, int& j1) {
-    const int e = it < 4 ? vq.end(it) : 0;
-    const int p0 = k + (lane >> 2), p1 = p0 + 16;
-    const int t0 = indices[p0 < e ? p0 : 0], t1 = indices[p1 < e ? p1 : 0];
-    j0 = p0 < e ? t0 : zero_row;
-    j1 = p1 < e ? t1 : zero_row;
-}
+__device__ __forceinline__ int sel4(int a0, int a1, int a2, int a3, int i) { return i == 0 ? a0 : (i == 1 ? a1 : (i == 2 ? a2 : a3)); }
 __device__ __forceinline__ u32x4 v_row(const u32x4* __restrict__ table, int j, int lane) { return table[(long)j * 4 + (lane & 3)]; }
 
 // One batch: rows -> LDS -> operands -> 16 MFMAs.  `lds` = the wave's 2 KB; only this wave touches it and its LDS
 // instructions execute in order, so no barrier: the accesses alias (may_alias types) and the compiler keeps their order.
-// A batch is two MFMA steps of 16 neighbours; a step's 32 contraction slots are (neighbour, part): lane row g takes the
-// neighbours a, b, c, d = LDS rows 16 h + g + {0, 4, 8, 12} in the slot order [a.0 b.0 a.1 b.1 c.0 d.0 c.1 d.1], with
-//     A row m < 8  (feature m):      part 0 = hi, part 1 = lo          -> D row m     = sum mask * (hi + lo)
-//     A row m >= 8 (feature m - 8):  part 0 = mid, part 1 = 0          -> D row m     = sum mask * mid
-//     B column n: the neighbour's mask in BOTH parts: dwords 0 and 1 are the same pair (a, b), dwords 2 and 3 the pair (c, d)
-// so hi + lo share an accumulator row (exact products, one fp32 accumulator) and a lane holds 32 accumulators, not 64.
+// Lane (g, m), contraction slot e <-> the neighbour in LDS row 4 e + g (both operands: any bijection serves; this one is
+// bank-conflict free).  A = [hi (rows 0..7) | mid (rows 8..15)], A2 = [lo | 0]; both products go to the SAME accumulator
+// (exact products, one fp32 sum): D row m < 8 = sum mask (hi + lo) of feature m, row m >= 8 = sum mask mid of feature m - 8.
 __device__ __forceinline__ void v_batch(unsigned char* lds, int lane, u32x4 r0, u32x4 r1, f32x4 (&d)[8]) {
     u32x4_ma* l4 = reinterpret_cast<u32x4_ma*>(lds);
     l4[lane] = r0;
     l4[64 + lane] = r1;
     const int g = lane >> 4, m = lane & 15;
-    const unsigned part1 = m < 8 ? 0xFFFFFFFFu : 0u;
+    const unsigned lo_rows = m < 8 ? 0xFFFFFFFFu : 0u;
     const u16_ma* l16 = reinterpret_cast<const u16_ma*>(lds);
     const u8_ma* l8 = reinterpret_cast<const u8_ma*>(lds);
+    u32x4 A, A2;
+    unsigned wp[4];
 #pragma unroll
-    for (int h = 0; h < 2; ++h) {
-        const int ra = 16 * h + g, rb = ra + 4, rc = ra + 8, rd = ra + 12;
-        u32x4 A;
-        A[0] = (unsigned)l16[ra * 32 + m] | ((unsigned)l16[rb * 32 + m] << 16);
-        A[1] = ((unsigned)l16[ra * 32 + 16 + (m & 7)] | ((unsigned)l16[rb * 32 + 16 + (m & 7)] << 16)) & part1;
-        A[2] = (unsigned)l16[rc * 32 + m] | ((unsigned)l16[rd * 32 + m] << 16);
-        A[3] = ((unsigned)l16[rc * 32 + 16 + (m & 7)] | ((unsigned)l16[rd * 32 + 16 + (m & 7)] << 16)) & part1;
-        const unsigned wab = (unsigned)l8[ra * 64 + 48 + m] | ((unsigned)l8[rb * 64 + 48 + m] << 16);
-        const unsigned wcd = (unsigned)l8[rc * 64 + 48 + m] | ((unsigned)l8[rd * 64 + 48 + m] << 16);
-#pragma unroll
-        for (int q = 0; q < 8; ++q) {
-            u32x4 B;
-            B[0] = B[1] = __umul24(wab & (0x00010001u << q), 0x3F80u >> q);
-            B[2] = B[3] = __umul24(wcd & (0x00010001u << q), 0x3F80u >> q);
-            d[q] = mma(A, B, d[q]);
-        }
+    for (int p = 0; p < 4; ++p) {
+        const int ra = 4 * (2 * p) + g, rb = 4 * (2 * p + 1) + g;
+        A[p] = (unsigned)l16[ra * 32 + m] | ((unsigned)l16[rb * 32 + m] << 16);
+        A2[p] = ((unsigned)l16[ra * 32 + 16 + (m & 7)] | ((unsigned)l16[rb * 32 + 16 + (m & 7)] << 16)) & lo_rows;
+        wp[p] = (unsigned)l8[ra * 64 + 48 + m] | ((unsigned)l8[rb * 64 + 48 + m] << 16);
     }
+    u32x4 B[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+#pragma unroll
+        for (int p = 0; p < 4; ++p) B[q][p] = __umul24(wp[p] & (0x00010001u << q), 0x3F80u >> q);
+        d[q] = mma(A, B[q], d[q]);
+    }
+#pragma unroll
+    for (int q = 0; q < 8; ++q) d[q] = mma(A2, B[q], d[q]);
 }
 
-// The batch loop of a wave over its four items, one flat sequence of batches.  `item_begin(u)` runs before item u's first
-// batch, `item_end(u, d)` after its last one (also for items without neighbours).  Memory pipeline in STATIC registers (the
-// loop body is unrolled over the ring, so no value moves between registers and a load is awaited only where it is used):
-// table rows RD batches ahead, column ids RD + JD batches ahead -- 79 % of the twitch rows are one or two batches long, so
-// the pipeline runs across item boundaries.
-constexpr int V_RD = 4, V_JD = 4, V_RING = V_RD + V_JD;
-template <class ItemBegin, class ItemEnd>
-__device__ __forceinline__ void v_items(const VQuad& vq, const int32_t* __restrict__ indices, const u32x4* __restrict__ table,
-                                        int zero_row, unsigned char* lds, int lane, ItemBegin&& item_begin, ItemEnd&& item_end) {
+// The memory pipeline of a wave in STATIC registers: table rows V_RD batches ahead, column ids V_RD + V_JD batches ahead of
+// the batch in hand.  The loop over a quad's batches is unrolled over the ring (no value moves between registers, a load is
+// awaited only where it is used); when a quad ends in the middle of the ring the live entries are rotated to phase 0 -- a
+// handful of moves per four rows -- so that the code after the loop (the rows' epilogue) exists once.
+constexpr int V_RD = 2, V_JD = 2, V_RING = V_RD + V_JD;
+
+// The wave's quads [qb, qe) with their batches.  `quad_begin(id)` (id = lane row kq's item {row, slot, batches, flags}) runs before
+// a quad's first batch, `item_begin(u)` before item u's first batch, `item_end(u, d)` after its last one (also for items
+// without batches), `quad_end(id)` after the quad's last item.
+template <class QuadBegin, class ItemBegin, class ItemEnd, class QuadEnd>
+__device__ __forceinline__ void v_wave_quads(const int32_t* __restrict__ ids, const int32_t* __restrict__ quads, int qb, int qe,
+                                             int first_batch, const u32x4* __restrict__ table, unsigned char* lds, int lane,
+                                             QuadBegin&& quad_begin, ItemBegin&& item_begin, ItemEnd&& item_end, QuadEnd&& quad_end) {
     const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
-    int it = 0, k = 0;
-    v_seek(vq, it, k);
+    const int kq = lane >> 4;
     int J0[V_RING], J1[V_RING];
     u32x4 R0[V_RD], R1[V_RD];
-    int itj = it, kj = k;
+    const int32_t* idp = ids + (long)first_batch * 32 + (lane >> 2);          // the batch whose ids are fetched next
 #pragma unroll
-    for (int s = 0; s < V_RING; ++s) {
-        v_ids(indices, vq, itj, kj, zero_row, lane, J0[s], J1[s]);
-        v_next(vq, itj, kj);
-    }
+    for (int s = 0; s < V_RING; ++s) J0[s] = idp[0], J1[s] = idp[16], idp += 32;
 #pragma unroll
     for (int s = 0; s < V_RD; ++s) R0[s] = v_row(table, J0[s], lane), R1[s] = v_row(table, J1[s], lane);
-    f32x4 d[8];
+    int4 dn = *reinterpret_cast<const int4*>(quads + 16 * (long)qb + 4 * kq);
+    for (int qd = qb; qd < qe; ++qd) {
+        const int4 id = dn;                                  // {row, slot, batches, flags} of lane row kq's item
+        dn = *reinterpret_cast<const int4*>(quads + 16 * (long)(qd + 1 < qe ? qd + 1 : qd) + 4 * kq);    // a quad ahead
+        const int nb0 = __builtin_amdgcn_readlane(id.z, 0), nb1 = __builtin_amdgcn_readlane(id.z, 16),
+                  nb2 = __builtin_amdgcn_readlane(id.z, 32), nb3 = __builtin_amdgcn_readlane(id.z, 48);
+        quad_begin(id);
+        f32x4 d[8];
 #pragma unroll
-    for (int q = 0; q < 8; ++q) d[q] = zero4;
-    int u = 0;
-    item_begin(0);
-    while (true) {
+        for (int q = 0; q < 8; ++q) d[q] = zero4;
+        int u = 0, left = nb0;
+        item_begin(0);
+        bool more = true;
+        while (more) {
 #pragma unroll
-        for (int s = 0; s < V_RING; ++s) {
-            while (u < it) {                       // close the items before the one this batch belongs to (it == 4: all of them)
-                item_end(u, d);
-                if (++u == 4) return;
-                item_begin(u);
+            for (int s = 0; s < V_RING; ++s) {
+                if (more) {
+                    while (left == 0) {
+                        item_end(u, d);
+                        if (++u == 4) {
+                            more = false;
+                            break;
+                        }
+                        left = sel4(nb0, nb1, nb2, nb3, u);
+                        item_begin(u);
 #pragma unroll
-                for (int q = 0; q < 8; ++q) d[q] = zero4;
+                        for (int q = 0; q < 8; ++q) d[q] = zero4;
+                    }
+                    if (more) {
+                        const u32x4 a0 = R0[s % V_RD], a1 = R1[s % V_RD];
+                        R0[s % V_RD] = v_row(table, J0[(s + V_RD) % V_RING], lane);       // the batch V_RD ahead
+                        R1[s % V_RD] = v_row(table, J1[(s + V_RD) % V_RING], lane);
+                        J0[s] = idp[0], J1[s] = idp[16], idp += 32;                       // the ids V_RING ahead
+                        v_batch(lds, lane, a0, a1, d);
+                        --left;
+                    } else if (s != 0) {                   // the quad ended at phase s: rotate the live entries to phase 0
+                        const u32x4 t0 = R0[s % V_RD], t1 = R1[s % V_RD], t2 = R0[(s + 1) % V_RD], t3 = R1[(s + 1) % V_RD];
+                        const int j0 = J0[(s + 2) % V_RING], j1 = J1[(s + 2) % V_RING], j2 = J0[(s + 3) % V_RING], j3 = J1[(s + 3) % V_RING];
+                        R0[0] = t0, R1[0] = t1, R0[1] = t2, R1[1] = t3;
+                        J0[2] = j0, J1[2] = j1, J0[3] = j2, J1[3] = j3;
+                    }
+                }
             }
-            const u32x4 a0 = R0[s % V_RD], a1 = R1[s % V_RD];
-            R0[s % V_RD] = v_row(table, J0[(s + V_RD) % V_RING], lane);       // the batch V_RD ahead
-            R1[s % V_RD] = v_row(table, J1[(s + V_RD) % V_RING], lane);
-            v_ids(indices, vq, itj, kj, zero_row, lane, J0[s], J1[s]);         // the ids V_RING ahead
-            v_next(vq, itj, kj);
-            v_batch(lds, lane, a0, a1, d);
-            v_next(vq, it, k);
         }
+        quad_end(id);
     }
 }
+static_assert(V_RD == 2 && V_RING == 4, "the rotation above is written out for a ring of 2 + 2");
 
-// the quad's items: lane row kq of the wave holds item 4 q + kq (`id`, `valid`); begin / end of all four, wave-uniform
-__device__ __forceinline__ VQuad v_quad(const AcmItem& id, bool valid) {
-    const int b = id.begin, e = valid ? id.end : id.begin;
-    VQuad vq;
-    vq.b0 = __builtin_amdgcn_readlane(b, 0), vq.b1 = __builtin_amdgcn_readlane(b, 16);
-    vq.b2 = __builtin_amdgcn_readlane(b, 32), vq.b3 = __builtin_amdgcn_readlane(b, 48);
-    vq.e0 = __builtin_amdgcn_readlane(e, 0), vq.e1 = __builtin_amdgcn_readlane(e, 16);
-    vq.e2 = __builtin_amdgcn_readlane(e, 32), vq.e3 = __builtin_amdgcn_readlane(e, 48);
-    return vq;
+// the wave's range of quads and its first batch (wave-uniform)
+__device__ __forceinline__ void v_wave(const VStreamView& sv, int w, int& qb, int& qe, int& first_batch) {
+    const int4 wd = *reinterpret_cast<const int4*>(sv.waves + 4 * (long)w);
+    qb = __builtin_amdgcn_readfirstlane(wd.x);
+    qe = __builtin_amdgcn_readfirstlane(wd.y);
+    first_batch = __builtin_amdgcn_readfirstlane(wd.z);
 }
-
 // ------------------------------------------------------------------ forward
 template <int K>
-__global__ __launch_bounds__(256) void acmii_v_fwd_kernel(acm_conv_acmii_fwd_t p, CsrView csr, const u32x4* __restrict__ table,
-                                                          int zero_row, float* __restrict__ partial) {
+__global__ __launch_bounds__(256) void acmii_v_fwd_kernel(acm_conv_acmii_fwd_t p, VStreamView sv, const AcmLongRow* __restrict__ long_rows,
+                                                          const u32x4* __restrict__ table, float* __restrict__ partial) {
     constexpr int T = 8;
     __shared__ __attribute__((aligned(16))) float hlds[3 * K * 64];
     __shared__ __attribute__((aligned(16))) unsigned char stage[4][2048];
@@ -268,124 +264,116 @@ __global__ __launch_bounds__(256) void acmii_v_fwd_kernel(acm_conv_acmii_fwd_t p
     for (int q = 0; q < K * K; ++q) mixm[q] = p.att_mix[q];
     const AcmDropCtx dc = acm_drop_ctx(p.post_drop);
     const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
-    const int n_quads = (csr.n_items + 3) >> 2;
-    const int q = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (q >= n_quads) return;
-    const int wa = 4 * q + ga, wd = 4 * q + kq;
-    const bool valid_a = wa < csr.n_items, valid_d = wd < csr.n_items;
-    const AcmItem ia = csr.items[valid_a ? wa : 0], id = csr.items[valid_d ? wd : 0];
-    const VQuad vq = v_quad(id, valid_d);
+    const int w = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (w >= sv.n_waves) return;
+    int qb, qe, first_batch;
+    v_wave(sv, w, qb, qe, first_batch);
+    if (qb >= qe) return;
     float acc[T];
+    v_wave_quads(
+        sv.ids, sv.quads, qb, qe, first_batch, table, stage[threadIdx.x >> 6], lane,
+        [&](const int4&) {
 #pragma unroll
-    for (int t = 0; t < T; ++t) acc[t] = 0.f;
-    v_items(vq, csr.indices, table, zero_row, stage[threadIdx.x >> 6], lane, [](int) {},
-            [&](int u, const f32x4 (&d)[8]) {
+            for (int t = 0; t < T; ++t) acc[t] = 0.f;
+        },
+        [](int) {},
+        [&](int u, const f32x4 (&d)[8]) {
 #pragma unroll
-                for (int t = 0; t < T; ++t) {
-                    float s = 0.f;
+            for (int t = 0; t < T; ++t) {
+                float s = 0.f;
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) s = fmaf(d[t][r], wc[t][r], s);
-                    s = acm_cross_row_sum(s);
-                    acc[t] = kq == u ? s : acc[t];
+                for (int r = 0; r < 4; ++r) s = fmaf(d[t][r], wc[t][r], s);
+                s = acm_cross_row_sum(s);
+                acc[t] = kq == u ? s : acc[t];
+            }
+        },
+        [&](const int4& id) {
+            const bool valid_d = (id.w & 1) != 0;
+            const int row = id.x, slot = id.y;
+            const long rr = valid_d ? row : 0;
+            // the rows' own projected features relu(x_i [W_H | W_I]): A row 4 g of the operand carries item g's input row
+            float zs[8];
+            {
+                const int row_a = __shfl(row, 16 * ga), flags_a = __shfl(id.w, 16 * ga);
+                const float2 xi = ((flags_a & 1) && ra == 0) ? *reinterpret_cast<const float2*>(p.xs + (long)row_a * p.ld_xs + 2 * kq)
+                                                             : make_float2(0.f, 0.f);
+#pragma unroll
+                for (int t = 0; t < 8; ++t) {
+                    f32x4 d = __builtin_amdgcn_mfma_f32_16x16x4f32(xi.x, bs[0][t], zero4, 0, 0, 0);
+                    d = __builtin_amdgcn_mfma_f32_16x16x4f32(xi.y, bs[1][t], d, 0, 0, 0);
+                    zs[t] = fmaxf(d[0], 0.f);
                 }
-            });
-    // the rows' own projected features relu(x_i [W_H | W_I]): A row 4 g of the operand carries item g's input row
-    float zs[8];
-    {
-        const float2 xi = (valid_a && ra == 0) ? *reinterpret_cast<const float2*>(p.xs + (long)ia.row * p.ld_xs + 2 * kq)
-                                               : make_float2(0.f, 0.f);
+            }
+            // ---- per 16-lane row: its item (row, slot); from here on as acm_conv_acmii.hip
+            const bool owner = (id.w & 2) != 0;                // a whole row, or the first piece of a long one
+            if (owner) {
+                if (p.zlh) {                               // the H half only (self term of a long row's fix-up); the L half is not computed here
 #pragma unroll
-        for (int t = 0; t < 8; ++t) {
-            f32x4 d = __builtin_amdgcn_mfma_f32_16x16x4f32(xi.x, bs[0][t], zero4, 0, 0, 0);
-            d = __builtin_amdgcn_mfma_f32_16x16x4f32(xi.y, bs[1][t], d, 0, 0, 0);
-            zs[t] = fmaxf(d[0], 0.f);
-        }
-    }
-    // ---- per 16-lane row: its item (row, slot); from here on as acm_conv_acmii.hip
-    const int row = id.row, slot = id.slot;
-    const long rr = valid_d ? row : 0;
-    bool owner = valid_d && slot < 0;
-    if (valid_d && slot >= 0) owner = csr.long_rows[csr.long_index[row]].slot_begin == slot;   // first piece of a long row
-    if (owner) {
-        if (p.zlh) {                               // the H half only (self term of a long row's fix-up); the L half is not computed here
+                    for (int t = 0; t < 4; ++t) p.zlh[rr * p.ld_zlh + F + 16 * t + i] = zs[t];
+                }
 #pragma unroll
-            for (int t = 0; t < 4; ++t) p.zlh[rr * p.ld_zlh + F + 16 * t + i] = zs[t];
-        }
+                for (int t = 0; t < 4; ++t) p.zi[rr * p.ld_zi + 16 * t + i] = zs[4 + t];
+            }
+            if (valid_d && slot >= 0) {                        // a piece of a long row: raw sums to its slot
+                float* ps = partial + (long)slot * (2 * F);
 #pragma unroll
-        for (int t = 0; t < 4; ++t) p.zi[rr * p.ld_zi + 16 * t + i] = zs[4 + t];
-    }
-    if (valid_d && slot >= 0) {                        // a piece of a long row: raw sums to its slot
-        float* ps = partial + (long)slot * (2 * F);
+                for (int t = 0; t < T; ++t) ps[16 * t + i] = acc[t];
+            }
+            const bool full = valid_d && slot < 0;
+            const float rs = p.row_scale[rr];
+            float H[K][4], pre[3][4];
+            const float dg = K == 4 ? p.deg[rr] : 0.f;
 #pragma unroll
-        for (int t = 0; t < T; ++t) ps[16 * t + i] = acc[t];
-    }
-    const bool full = valid_d && slot < 0;
-    const float rs = p.row_scale ? p.row_scale[rr] : 1.f;
-    float H[K][4], pre[3][4];
-    const float dg = K == 4 ? p.deg[rr] : 0.f;
+            for (int t = 0; t < 4; ++t) {
+                pre[0][t] = rs * acc[t];
+                pre[1][t] = zs[t] - rs * acc[4 + t];
+                H[0][t] = pre[0][t];                           // ACMII: no ReLU after the filter
+                H[1][t] = pre[1][t];
+                H[2][t] = zs[4 + t];
+                if (K == 4) {                                  // structure channel: relu(A S) = relu(deg (A_low S) - S), ps = A_low S
+                    pre[2][t] = dg * p.ps[rr * p.ld_ps + i + 16 * t] - p.ss[rr * p.ld_ss + i + 16 * t];
+                    H[K - 1][t] = fmaxf(pre[2][t], 0.f);
+                }
+            }
+            RowHead<K> rh;
+            row_head<K>(hlds, mixm, acm_opaque(i), F, p.layernorm != 0, H, rh);
+            float df[4];
+            acm_drop4(dc, rr, i, df);
+            if (full) {
 #pragma unroll
-    for (int t = 0; t < 4; ++t) {
-        pre[0][t] = rs * acc[t];
-        pre[1][t] = zs[t] - rs * acc[4 + t];
-        H[0][t] = pre[0][t];                           // ACMII: no ReLU after the filter
-        H[1][t] = pre[1][t];
-        H[2][t] = zs[4 + t];
-        if (K == 4) {                                  // structure channel: relu(A S) = relu(deg (A_low S) - S), ps = A_low S
-            pre[2][t] = dg * p.ps[rr * p.ld_ps + i + 16 * t] - p.ss[rr * p.ld_ss + i + 16 * t];
-            H[K - 1][t] = fmaxf(pre[2][t], 0.f);
-        }
-    }
-    RowHead<K> rh;
-    row_head<K>(hlds, mixm, acm_opaque(i), F, p.layernorm != 0, H, rh);
-    float df[4];
-    acm_drop4(dc, rr, i, df);
-    if (full) {
-#pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            const int col = i + 16 * t;
-            float o = rh.alpha[0] * H[0][t] + rh.alpha[1] * H[1][t] + rh.alpha[2] * H[2][t];
-            if (K == 4) o = fmaf(rh.alpha[K - 1], H[K - 1][t], o);
-            o *= p.scale;
-            if (p.post_relu) o = fmaxf(o, 0.f);
-            if (p.post_scale) o *= p.post_scale[rr * p.ld_post_scale + col];
-            if (p.post_drop.p > 0.f) o *= df[t];
-            p.out[rr * p.ld_out + col] = o;
-            p.pre[rr * p.ld_pre + col] = pre[0][t];
-            p.pre[rr * p.ld_pre + F + col] = pre[1][t];
-            if (K == 4) p.pre[rr * p.ld_pre + 2 * F + col] = pre[2][t];
-        }
-        if (i == 0)
-            *reinterpret_cast<float4*>(p.att + rr * 4) =
-                make_float4(rh.alpha[0], rh.alpha[1], rh.alpha[2], K == 4 ? rh.alpha[K - 1] : 0.f);
-    }
+                for (int t = 0; t < 4; ++t) {
+                    const int col = i + 16 * t;
+                    float o = rh.alpha[0] * H[0][t] + rh.alpha[1] * H[1][t] + rh.alpha[2] * H[2][t];
+                    if (K == 4) o = fmaf(rh.alpha[K - 1], H[K - 1][t], o);
+                    o *= p.scale;
+                    if (p.post_relu) o = fmaxf(o, 0.f);
+                    if (p.post_scale) o *= p.post_scale[rr * p.ld_post_scale + col];
+                    if (p.post_drop.p > 0.f) o *= df[t];
+                    p.out[rr * p.ld_out + col] = o;
+                    p.pre[rr * p.ld_pre + col] = pre[0][t];
+                    p.pre[rr * p.ld_pre + F + col] = pre[1][t];
+                    if (K == 4) p.pre[rr * p.ld_pre + 2 * F + col] = pre[2][t];
+                }
+                if (i == 0)
+                    *reinterpret_cast<float4*>(p.att + rr * 4) =
+                        make_float4(rh.alpha[0], rh.alpha[1], rh.alpha[2], K == 4 ? rh.alpha[K - 1] : 0.f);
+            }
+        });
 }
 
 // ------------------------------------------------------------------ backward: dW_L, dW_H, dW_I
 // partial: [48 groups][n_blocks][32]: group = column / 32 of the 1536 columns (ch, f, c) = 512 ch + 64 f + c, ch = L, H, I.
 // The row-local terms -- the high-pass channel's self term G_H[i, c] m^H_i[c] x_i[f] and the identity channel's
 // dZ_I[i, c] x_i[f] -- are plain fp32 FMAs: lane (kq, i) owns features 2 kq, 2 kq + 1 of column i of every tile.
-__global__ __launch_bounds__(256) void acmii_v_bwd_kernel(acm_conv_acmii_bwd_t p, CsrView csr, const u32x4* __restrict__ table,
-                                                          int zero_row, float* __restrict__ partial) {
+__global__ __launch_bounds__(256) void acmii_v_bwd_kernel(acm_conv_acmii_bwd_t p, VStreamView sv, const u32x4* __restrict__ table,
+                                                          float* __restrict__ partial) {
     constexpr int T = 8;
     __shared__ __attribute__((aligned(16))) unsigned char stage[4][2048];
     __shared__ float red[4][1536];
     const int lane = threadIdx.x & 63, i = lane & 15, kq = lane >> 4, wv = threadIdx.x >> 6;
-    const int n_quads = (csr.n_items + 3) >> 2;
-    const int q = blockIdx.x * 4 + wv;
-    const int wd = 4 * q + kq;
-    const bool valid_d = q < n_quads && wd < csr.n_items;
-    const AcmItem id = csr.items[valid_d ? wd : 0];
-    const VQuad vq = v_quad(id, valid_d);
-    bool owner = valid_d && id.slot < 0;
-    if (valid_d && id.slot >= 0) owner = csr.long_rows[csr.long_index[id.row]].slot_begin == id.slot;
-    // the four items' rows / validity / "runs the row-local terms" (whole row or first piece of a long one), wave-uniform
-    const int rw0 = __builtin_amdgcn_readlane(id.row, 0), rw1 = __builtin_amdgcn_readlane(id.row, 16),
-              rw2 = __builtin_amdgcn_readlane(id.row, 32), rw3 = __builtin_amdgcn_readlane(id.row, 48);
-    const int vl = valid_d ? 1 : 0, ol = owner ? 1 : 0;
-    const int vd0 = __builtin_amdgcn_readlane(vl, 0), vd1 = __builtin_amdgcn_readlane(vl, 16), vd2 = __builtin_amdgcn_readlane(vl, 32),
-              vd3 = __builtin_amdgcn_readlane(vl, 48);
-    const int ow0 = __builtin_amdgcn_readlane(ol, 0), ow1 = __builtin_amdgcn_readlane(ol, 16), ow2 = __builtin_amdgcn_readlane(ol, 32),
-              ow3 = __builtin_amdgcn_readlane(ol, 48);
+    const int w = blockIdx.x * 4 + wv;
+    int qb = 0, qe = 0, first_batch = 0;
+    if (w < sv.n_waves) v_wave(sv, w, qb, qe, first_batch);
     float accd[T][4], accs[4][2], acci[4][2];
 #pragma unroll
     for (int t = 0; t < T; ++t)
@@ -393,16 +381,26 @@ __global__ __launch_bounds__(256) void acmii_v_bwd_kernel(acm_conv_acmii_bwd_t p
         for (int r = 0; r < 4; ++r) accd[t][r] = 0.f;
 #pragma unroll
     for (int t = 0; t < 4; ++t) accs[t][0] = accs[t][1] = acci[t][0] = acci[t][1] = 0.f;
-    // the wave works through its four items one after the other, all four lane rows on the same item: lane (kq, i) owns the
-    // D rows of split kq >> 1, features 4 (kq & 1) + r, column i of every tile
-    float gu[T], gi[4], rsu = 0.f, own = 0.f;
-    float2 xv = make_float2(0.f, 0.f);
-    unsigned mself = 0;
-    v_items(vq, csr.indices, table, zero_row, stage[wv], lane,
-            [&](int u) {             // the item's G rows, scale, own input and masks: requested before its batches, used after them
-                const long ru = sel4(rw0, rw1, rw2, rw3, u);
-                rsu = sel4(vd0, vd1, vd2, vd3, u) ? p.row_scale[ru] : 0.f;
-                own = sel4(ow0, ow1, ow2, ow3, u) ? 1.f : 0.f;
+    if (qb < qe) {
+        // all four lane rows work on the same item: lane (kq, i) owns the D rows 4 kq + r (hi + lo: kq 0, 1; mid: kq 2, 3;
+        // features 4 (kq & 1) + r), column i of every tile
+        int rw0 = 0, rw1 = 0, rw2 = 0, rw3 = 0, fl0 = 0, fl1 = 0, fl2 = 0, fl3 = 0;
+        float gu[T], gi[4], rsu = 0.f, own = 0.f;
+        float2 xv = make_float2(0.f, 0.f);
+        unsigned mself = 0;
+        v_wave_quads(
+            sv.ids, sv.quads, qb, qe, first_batch, table, stage[wv], lane,
+            [&](const int4& id) {
+                rw0 = __builtin_amdgcn_readlane(id.x, 0), rw1 = __builtin_amdgcn_readlane(id.x, 16);
+                rw2 = __builtin_amdgcn_readlane(id.x, 32), rw3 = __builtin_amdgcn_readlane(id.x, 48);
+                fl0 = __builtin_amdgcn_readlane(id.w, 0), fl1 = __builtin_amdgcn_readlane(id.w, 16);
+                fl2 = __builtin_amdgcn_readlane(id.w, 32), fl3 = __builtin_amdgcn_readlane(id.w, 48);
+            },
+            [&](int u) {             // the item's G rows, scale, own input and masks: requested before its batches
+                const long ru = sel4(rw0, rw1, rw2, rw3, u);     // (row 0 for an absent item: scaled by zero)
+                const int fl = sel4(fl0, fl1, fl2, fl3, u);
+                rsu = (fl & 1) ? p.row_scale[ru] : 0.f;
+                own = (fl & 2) ? 1.f : 0.f;
 #pragma unroll
                 for (int t = 0; t < T; ++t)
                     gu[t] = t < 4 ? p.g_low[ru * p.ld_g_low + 16 * t + i] : p.g_high[ru * p.ld_g_high + 16 * (t & 3) + i];
@@ -427,7 +425,9 @@ __global__ __launch_bounds__(256) void acmii_v_bwd_kernel(acm_conv_acmii_bwd_t p
                     acci[t][0] = fmaf(gi[t], x0, acci[t][0]);
                     acci[t][1] = fmaf(gi[t], x1, acci[t][1]);
                 }
-            });
+            },
+            [](const int4&) {});
+    }
     // splits: hi + lo (lane rows 0, 1) + mid (rows 2, 3) -> lane rows 0, 1 hold features 4 kq + r
 #pragma unroll
     for (int t = 0; t < T; ++t)
@@ -487,7 +487,14 @@ static int acmii_v_check_operator(const acm_csr_t* a, const void* table, const c
     ACM_REQUIRE(a->nnz > 0 && a->n_rows < ((int64_t)1 << 31) - 1, ACM_EUNSUPPORTED, "%s: empty operator / too many rows", who);
     ACM_REQUIRE(((uintptr_t)table) % 16 == 0, ACM_EINVAL, "%s: table not 16-byte aligned", who);
     ACM_REQUIRE(a->n_long == 0 || a->long_index, ACM_EUNSUPPORTED, "%s: handle without a long-row index", who);
+    ACM_REQUIRE(a->item_streams, ACM_EINVAL, "%s: the operator has no item streams (acm_csr_build_item_streams)", who);
     return ACM_OK;
+}
+
+static VStreamView stream_view(const AcmItemStreams* t) {
+    VStreamView v;
+    v.ids = t->ids, v.quads = t->quads, v.waves = t->waves, v.n_waves = t->n_waves;
+    return v;
 }
 
 // The forward on a table acm_acmii_table has just written for the SAME x and weights.  p as for acm_conv_acmii_fwd; p->xg is not
@@ -524,11 +531,10 @@ extern "C" int acm_conv_acmii_v_fwd(const acm_csr_t* a, const acm_conv_acmii_fwd
     ACM_REQUIRE(workspace && workspace_bytes >= need, ACM_ENOMEM, "acm_conv_acmii_v_fwd: workspace %zu B < required %zu B", workspace_bytes, need);
     if (a->n_rows == 0 || a->n_items == 0) return ACM_OK;
     hipStream_t s = (hipStream_t)stream;
-    const CsrView cv = acm_view(a);
-    const int grid = (int)((a->n_items + 15) / 16);
-    const int zero_row = (int)a->n_rows;
-    if (K == 3) hipLaunchKernelGGL(acmii_v_fwd_kernel<3>, dim3(grid), dim3(256), 0, s, *p, cv, (const u32x4*)table, zero_row, (float*)workspace);
-    else hipLaunchKernelGGL(acmii_v_fwd_kernel<4>, dim3(grid), dim3(256), 0, s, *p, cv, (const u32x4*)table, zero_row, (float*)workspace);
+    const VStreamView sv = stream_view(a->item_streams);
+    const int grid = a->item_streams->n_waves / 4;           // persistent waves: the streams were cut for exactly these
+    if (K == 3) hipLaunchKernelGGL(acmii_v_fwd_kernel<3>, dim3(grid), dim3(256), 0, s, *p, sv, a->long_rows, (const u32x4*)table, (float*)workspace);
+    else hipLaunchKernelGGL(acmii_v_fwd_kernel<4>, dim3(grid), dim3(256), 0, s, *p, sv, a->long_rows, (const u32x4*)table, (float*)workspace);
     ACM_CHECK_HIP(hipGetLastError());
     if (a->n_long) return acm_acmii_fixup_launch(a, p, (const float*)workspace, s);
     return ACM_OK;
@@ -536,8 +542,8 @@ extern "C" int acm_conv_acmii_v_fwd(const acm_csr_t* a, const acm_conv_acmii_fwd
 
 extern "C" int acm_conv_acmii_v_bwd_workspace_bytes(const acm_csr_t* a, size_t* bytes) {
     ACM_REQUIRE(a && bytes, ACM_EINVAL, "acm_conv_acmii_v_bwd_workspace_bytes: NULL argument");
-    const size_t grid = (size_t)((a->n_items + 15) / 16);
-    *bytes = (grid > 0 ? grid : 1) * 1536 * sizeof(float);
+    ACM_REQUIRE(a->item_streams, ACM_EINVAL, "acm_conv_acmii_v_bwd_workspace_bytes: the operator has no item streams (acm_csr_build_item_streams)");
+    *bytes = (size_t)(a->item_streams->n_waves / 4) * 1536 * sizeof(float);       // one slab of 1536 sums per workgroup
     return ACM_OK;
 }
 
@@ -552,7 +558,8 @@ extern "C" int acm_conv_acmii_v_bwd(const acm_csr_t* a, const acm_conv_acmii_bwd
     ACM_REQUIRE(p->ld_g_low >= 64 && p->ld_g_high >= 64 && p->ld_g_mlp >= 64 && p->ld_dw >= 64 && p->ld_x >= 8 && p->ld_x % 2 == 0 &&
                     ((uintptr_t)p->x) % 8 == 0, ACM_ESHAPE, "acm_conv_acmii_v_bwd: leading dimension too small / x rows not 8-byte aligned");
     size_t need = 0;
-    acm_conv_acmii_v_bwd_workspace_bytes(a, &need);
+    const int stw = acm_conv_acmii_v_bwd_workspace_bytes(a, &need);
+    if (stw != ACM_OK) return stw;
     ACM_REQUIRE(workspace && workspace_bytes >= need && ((uintptr_t)workspace) % 16 == 0, ACM_ENOMEM,
                 "acm_conv_acmii_v_bwd: workspace %zu B < required %zu B (or not 16-byte aligned)", workspace_bytes, need);
     hipStream_t s = (hipStream_t)stream;
@@ -562,11 +569,10 @@ extern "C" int acm_conv_acmii_v_bwd(const acm_csr_t* a, const acm_conv_acmii_bwd
         ACM_CHECK_HIP(hipMemset2DAsync(p->d_w_mlp, (size_t)p->ld_dw * 4, 0, 64 * 4, (size_t)p->f_in, s));
         return ACM_OK;
     }
-    const CsrView cv = acm_view(a);
-    const int grid = (int)((a->n_items + 15) / 16);
-    ACM_REQUIRE((int64_t)grid * 32 < ((int64_t)1 << 31), ACM_EUNSUPPORTED, "acm_conv_acmii_v_bwd: %d workgroups", grid);
+    const VStreamView sv = stream_view(a->item_streams);
+    const int grid = a->item_streams->n_waves / 4;
     float* partial = (float*)workspace;
-    hipLaunchKernelGGL(acmii_v_bwd_kernel, dim3(grid), dim3(256), 0, s, *p, cv, (const u32x4*)p->table, (int)a->n_rows, partial);
+    hipLaunchKernelGGL(acmii_v_bwd_kernel, dim3(grid), dim3(256), 0, s, *p, sv, (const u32x4*)p->table, partial);
     ACM_CHECK_HIP(hipGetLastError());
     const int len = p->f_in * 64;
     const acm_reduce_seg_t segs[3] = {{partial, grid, 32, 0, len, p->d_w_low, 64, 0, p->ld_dw, 0, grid * 32, 0},

@@ -113,6 +113,13 @@ void free_streams(AcmStreams* t) {
     delete t;
 }
 
+void free_item_streams(AcmItemStreams* t) {
+    if (!t) return;
+    for (void* q : {(void*)t->ids, (void*)t->quads, (void*)t->waves})
+        if (q) (void)hipFree(q);
+    delete t;
+}
+
 void free_handle(acm_csr* a) {
     if (!a) return;
     if (a->indptr) (void)hipFree(a->indptr);
@@ -123,6 +130,7 @@ void free_handle(acm_csr* a) {
     if (a->items) (void)hipFree(a->items);
     if (a->long_rows) (void)hipFree(a->long_rows);
     free_streams(a->streams);
+    free_item_streams(a->item_streams);
     delete a;
 }
 
@@ -579,6 +587,107 @@ extern "C" int acm_csr_build_streams(acm_csr_t* a, int n_waves, int lmax) {
     return ACM_OK;
 }
 
+extern "C" int acm_csr_build_item_streams(acm_csr_t* a, int n_waves) {
+    ACM_REQUIRE(a, ACM_EINVAL, "acm_csr_build_item_streams: NULL handle");
+    if (a->item_streams) return ACM_OK;
+    ACM_REQUIRE(a->vals == nullptr, ACM_EUNSUPPORTED, "acm_csr_build_item_streams: pattern-only operators only");
+    ACM_REQUIRE(a->n_items > 0 && a->nnz > 0, ACM_EUNSUPPORTED, "acm_csr_build_item_streams: empty operator");
+    ACM_REQUIRE(a->n_cols < ((int64_t)1 << 31) - 1, ACM_EUNSUPPORTED, "acm_csr_build_item_streams: %lld columns", (long long)a->n_cols);
+    ACM_CHECK_HIP(hipDeviceSynchronize());
+    const int64_t n_items = a->n_items, nnz = a->nnz;
+    std::vector<AcmItem> items((size_t)n_items);
+    std::vector<AcmLongRow> longs((size_t)a->n_long);
+    std::vector<int32_t> ix((size_t)nnz), lidx;
+    ACM_CHECK_HIP(hipMemcpy(items.data(), a->items, items.size() * sizeof(AcmItem), hipMemcpyDeviceToHost));
+    ACM_CHECK_HIP(hipMemcpy(ix.data(), a->indices, ix.size() * sizeof(int32_t), hipMemcpyDeviceToHost));
+    if (a->n_long) {
+        ACM_REQUIRE(a->long_index, ACM_EUNSUPPORTED, "acm_csr_build_item_streams: handle without a long-row index");
+        lidx.resize((size_t)a->n_rows);
+        ACM_CHECK_HIP(hipMemcpy(longs.data(), a->long_rows, longs.size() * sizeof(AcmLongRow), hipMemcpyDeviceToHost));
+        ACM_CHECK_HIP(hipMemcpy(lidx.data(), a->long_index, lidx.size() * sizeof(int32_t), hipMemcpyDeviceToHost));
+    }
+    const int64_t n_quads = (n_items + 3) / 4;
+    std::vector<int32_t> qb((size_t)n_quads, 0);                      // batches of a quad
+    int64_t total = 0;
+    for (int64_t i = 0; i < n_items; ++i) {
+        const int32_t nb = (items[(size_t)i].end - items[(size_t)i].begin + 31) / 32;
+        qb[(size_t)(i / 4)] += nb;
+        total += nb;
+    }
+    ACM_REQUIRE((total + ACM_ITEM_STREAM_PAD) * 32 < ((int64_t)1 << 31), ACM_EUNSUPPORTED,
+                "acm_csr_build_item_streams: %lld batches exceed 32-bit stream offsets", (long long)total);
+    if (n_waves <= 0) {
+        int cus = 256;
+        (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, a->device);
+        n_waves = cus * 8;                                           // two waves per SIMD (the kernels' occupancy)
+    }
+    if ((int64_t)n_waves > n_quads) n_waves = (int)n_quads;
+    n_waves = (n_waves + 3) / 4 * 4;
+    // longest quad first, each to the least loaded wave; cost in batches: its batches + the four item ends and the rows' epilogue
+    const int64_t quad_cost = 10;
+    std::vector<int32_t> order((size_t)n_quads), wave_of((size_t)n_quads);
+    for (int64_t q = 0; q < n_quads; ++q) order[(size_t)q] = (int32_t)q;
+    std::stable_sort(order.begin(), order.end(), [&](int32_t x, int32_t y) { return qb[(size_t)x] > qb[(size_t)y]; });
+    {
+        typedef std::pair<int64_t, int32_t> Load;
+        std::priority_queue<Load, std::vector<Load>, std::greater<Load>> heap;
+        for (int32_t w = 0; w < n_waves; ++w) heap.push({0, w});
+        for (int64_t o = 0; o < n_quads; ++o) {
+            Load l = heap.top();
+            heap.pop();
+            wave_of[(size_t)order[(size_t)o]] = l.second;
+            l.first += qb[(size_t)order[(size_t)o]] + quad_cost;
+            heap.push(l);
+        }
+    }
+    std::vector<int32_t> count((size_t)n_waves + 1, 0);
+    for (int64_t q = 0; q < n_quads; ++q) ++count[(size_t)wave_of[(size_t)q] + 1];
+    for (int32_t w = 0; w < n_waves; ++w) count[(size_t)w + 1] += count[(size_t)w];
+    std::vector<int32_t> cur(count.begin(), count.end() - 1), quad_at((size_t)n_quads);
+    for (int64_t o = 0; o < n_quads; ++o) quad_at[(size_t)cur[(size_t)wave_of[(size_t)order[(size_t)o]]]++] = order[(size_t)o];
+    const int32_t zero_row = (int32_t)a->n_cols;
+    std::vector<int32_t> h_quads((size_t)n_quads * 16, 0), h_waves((size_t)n_waves * 4, 0),
+        h_ids(((size_t)total + ACM_ITEM_STREAM_PAD) * 32, zero_row);
+    int64_t batch = 0;
+    for (int32_t w = 0; w < n_waves; ++w) {
+        h_waves[(size_t)w * 4 + 0] = count[(size_t)w];
+        h_waves[(size_t)w * 4 + 1] = count[(size_t)w + 1];
+        h_waves[(size_t)w * 4 + 2] = (int32_t)batch;
+        for (int32_t pos = count[(size_t)w]; pos < count[(size_t)w + 1]; ++pos) {
+            const int64_t q = quad_at[(size_t)pos];
+            for (int g = 0; g < 4; ++g) {
+                int32_t* d = h_quads.data() + (size_t)pos * 16 + 4 * g;
+                const int64_t i = q * 4 + g;
+                d[1] = -1;
+                if (i >= n_items) continue;
+                const AcmItem& it = items[(size_t)i];
+                const int32_t len = it.end - it.begin, nb = (len + 31) / 32;
+                bool owner = it.slot < 0;
+                if (!owner) owner = longs[(size_t)lidx[(size_t)it.row]].slot_begin == it.slot;
+                d[0] = it.row, d[1] = it.slot, d[2] = nb, d[3] = 1 | (owner ? 2 : 0);
+                for (int32_t k = 0; k < len; ++k) h_ids[(size_t)batch * 32 + (size_t)k] = ix[(size_t)it.begin + (size_t)k];
+                batch += nb;
+            }
+        }
+        h_waves[(size_t)w * 4 + 3] = (int32_t)batch - h_waves[(size_t)w * 4 + 2];
+    }
+    AcmItemStreams* t = new (std::nothrow) AcmItemStreams();
+    ACM_REQUIRE(t, ACM_ENOMEM, "acm_csr_build_item_streams: host allocation failed");
+    memset(t, 0, sizeof(*t));
+    t->total_batches = total;
+    t->n_quads = n_quads;
+    t->n_waves = n_waves;
+    int st = upload(&t->ids, h_ids);
+    if (st == ACM_OK) st = upload(&t->quads, h_quads);
+    if (st == ACM_OK) st = upload(&t->waves, h_waves);
+    if (st != ACM_OK) {
+        free_item_streams(t);
+        return st;
+    }
+    a->item_streams = t;
+    return ACM_OK;
+}
+
 extern "C" int acm_csr_info(const acm_csr_t* a, acm_csr_info_t* info) {
     ACM_REQUIRE(a && info, ACM_EINVAL, "acm_csr_info: NULL argument");
     info->n_rows = a->n_rows;
@@ -597,6 +706,9 @@ extern "C" int acm_csr_info(const acm_csr_t* a, acm_csr_info_t* info) {
     info->stream_slices = a->streams ? a->streams->n_slices : 0;
     info->stream_waves = a->streams ? a->streams->n_waves : 0;
     info->stream_long_rows = a->streams ? (int32_t)a->streams->n_long : 0;
+    info->item_stream_waves = a->item_streams ? a->item_streams->n_waves : 0;
+    info->reserved = 0;
+    info->item_stream_batches = a->item_streams ? a->item_streams->total_batches : 0;
     return ACM_OK;
 }
 

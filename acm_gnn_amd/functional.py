@@ -1370,7 +1370,8 @@ class AcmConvFunction(torch.autograd.Function):
             ctx.mask_table = None
             st = 4
             if (k == 3 and ops.implicit and not ops.sharded and not ctx.needs_input_grad[0] and n > 0
-                    and xg.data_ptr() == xpad.data_ptr() and (tuning.HOST.rewrites & tuning.REWRITE_ACMII_MASK) != 0):
+                    and xg.data_ptr() == xpad.data_ptr() and (tuning.HOST.rewrites & tuning.REWRITE_ACMII_MASK) != 0
+                    and ops.low.build_item_streams()):         # (one-off per operator; a captured step finds them built)
                 tb = C.c_size_t()
                 _lib.check(lib.acm_acmii_table_bytes(n, C.byref(tb)), "acm_acmii_table_bytes")
                 table = torch.empty(tb.value // 4, dtype=torch.int32, device=dev)

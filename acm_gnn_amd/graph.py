@@ -156,6 +156,25 @@ class CsrGraph:
         self.stream_slices, self.stream_long_rows = info.stream_slices, info.stream_long_rows
         return True
 
+    def build_item_streams(self, n_waves=0):
+        """Per-wave batch streams over the handle's own work items (``acm_csr_build_item_streams``) for the mask form of
+        the ACMII first layer: one-off host-side preprocessing, pattern-only operators only, idempotent.  Returns True
+        when they exist."""
+        if getattr(self, "item_stream_waves", 0):
+            return True
+        if self._ptrs[2] or self.nnz == 0:
+            return False
+        with _device_ctx(self.device):
+            _sync(self.device)
+            st = _lib.load().acm_csr_build_item_streams(self._h, int(n_waves))
+        if st == 4:                                        # ACM_EUNSUPPORTED: the caller keeps the other form
+            return False
+        _lib.check(st, "acm_csr_build_item_streams")
+        info = _lib.CsrInfo()
+        _lib.check(_lib.load().acm_csr_info(self._h, C.byref(info)), "acm_csr_info")
+        self.item_stream_waves = info.item_stream_waves
+        return self.item_stream_waves > 0
+
     # ---- derived operators ----------------------------------------------
     def transpose(self):
         if self._transposed is None:

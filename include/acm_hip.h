@@ -145,6 +145,9 @@ typedef struct {
     int64_t stream_slices;    /* slices (four work items each)                                          */
     int32_t stream_waves;     /* waves the streams are cut for = 4 x the blocks of the streamed kernel  */
     int32_t stream_long_rows; /* rows cut into pieces (combined by the last piece to arrive)            */
+    int32_t item_stream_waves; /* acm_csr_build_item_streams: waves, 0 = not built (ABI 24)             */
+    int32_t reserved;
+    int64_t item_stream_batches; /* 32-neighbour batches over all waves                                 */
 } acm_csr_info_t;
 int acm_csr_info(const acm_csr_t* a, acm_csr_info_t* info);
 
@@ -162,6 +165,17 @@ int acm_csr_info(const acm_csr_t* a, acm_csr_info_t* info);
  * slots, so launches that use the streams of one handle must be stream-ordered.  Costs (total steps x 512 B) of device memory, ~1.2 x the id array.
  * No reference counterpart (the reference hands torch.spmm a COO tensor, ACM-Geometric/layers.py:87-103). */
 int acm_csr_build_streams(acm_csr_t* a, int n_waves, int lmax);
+
+/* acm_csr_build_item_streams (ABI 24): per-wave BATCH streams over the handle's own work items, for kernels that take one
+ * item at a time with 32 neighbours per wave step (acm_conv_acmii_v_fwd / _bwd).  The item list (rows, and the pieces of the
+ * long rows with their partial slots -- the same items every other kernel walks) is cut into quads of four consecutive items;
+ * quads are dealt longest-first to the least loaded of `n_waves` persistent waves; a wave's quads, and the column ids of
+ * their batches, are contiguous, idle slots padded with n_cols (the index of an all-zero row the caller appends to its
+ * table).  A wave then walks ONE linear id stream, fetches ahead across row boundaries, reads its parameters once, and
+ * the waves' loads are balanced when the handle is built instead of by the dispatcher.  Same contract as
+ * acm_csr_build_streams (one-off, synchronises, idempotent, pattern-only); n_waves <= 0: two waves per SIMD.
+ * acm_csr_info_t.item_stream_waves says whether (and for how many waves) they exist.  No reference counterpart. */
+int acm_csr_build_item_streams(acm_csr_t* a, int n_waves);
 
 /* Bytes of caller-provided workspace the SpMM-type entry points need for an
  * operator when `width` fp32 columns are accumulated per row. */

@@ -252,6 +252,14 @@ class FakeLib:
     def acm_csr_destroy(self, h):
         self._handles.pop(h.value if isinstance(h, C.c_void_p) else int(h), None)
 
+    def acm_csr_build_item_streams(self, h, n_waves):
+        a = self._get(h)
+        if np.any(a.vals != 1) or len(a.indices) == 0:
+            self._err = b"acm_csr_build_item_streams: pattern-only operators only"
+            return 4
+        a.item_stream_waves = int(n_waves) if n_waves > 0 else 2048
+        return 0
+
     def acm_csr_build_streams(self, h, n_waves, lmax):
         a = self._get(h)
         if not getattr(a, "unit", False):
@@ -270,6 +278,7 @@ class FakeLib:
         a, i = self._get(h), info._obj
         i.stream_steps, i.stream_slices = getattr(a, "stream_steps", 0), getattr(a, "stream_slices", 0)
         i.stream_waves, i.stream_long_rows = getattr(a, "stream_waves", 0), getattr(a, "stream_long", 0)
+        i.item_stream_waves = getattr(a, "item_stream_waves", 0)
         deg = np.diff(a.indptr)
         longs = deg[deg > a.chunk]
         i.n_rows, i.n_cols, i.nnz = a.n_rows, a.n_cols, len(a.indices)
