@@ -1365,11 +1365,12 @@ class AcmConvFunction(torch.autograd.Function):
             ws = torch.empty(max(nbytes.value // 4, 1), dtype=_F32, device=dev)
             # The mask form (acm_conv_acmii_v.hip): relu(x_j W) = m_j * (x_j W), so the aggregate is W contracted with
             # V_i = sum_j m_j (x) x_j -- a product over the neighbour index on the bf16 matrix pipe, exact operands -- and the
-            # weight gradients are the same V contracted with dH: no transposed product.  Three channels, a pattern-only
-            # operator over this process's own rows, no gradient into x.
+            # weight gradients are the same V contracted with dH: no transposed product for them (the structure channel's
+            # parameter keeps its one F-wide transposed product).  A pattern-only operator over this process's own rows, no
+            # gradient into x.
             ctx.mask_table = None
             st = 4
-            if (k == 3 and ops.implicit and not ops.sharded and not ctx.needs_input_grad[0] and n > 0
+            if (ops.implicit and not ops.sharded and not ctx.needs_input_grad[0] and n > 0
                     and xg.data_ptr() == xpad.data_ptr() and (tuning.HOST.rewrites & tuning.REWRITE_ACMII_MASK) != 0
                     and ops.low.build_item_streams()):         # (one-off per operator; a captured step finds them built)
                 tb = C.c_size_t()
@@ -1662,12 +1663,27 @@ class AcmConvFunction(torch.autograd.Function):
             _lib.check(st, "acm_conv_acmii_v_bwd")
             if defer is not None:
                 defer.hold(wsb, [d_wcat[0], d_wcat[1], d_wcat[2]], keep=[flat, table, g, dz, xt])
+            d_struc = None
+            if four:                                  # dS = A_low^T (D G_S) - G_S = P G_S - G_S (pattern-only; K3 left G_S unscaled)
+                d_struc = torch.empty(n, f, dtype=_F32, device=dev)
+                low_t = ops.low_t
+                ws2 = low_t.workspace(f)
+                o = _lib.SpmmOpts()
+                o.sub, o.ld_sub = gs.data_ptr(), gs.stride(0)
+                gsg = gs
+                if cfg.gather_bf16 and 8 < f <= 64 and f % 2 == 0:       # bf16 gathered operand (the self term stays fp32)
+                    gsg = cast_bf16(gs)
+                    o.g_bf16 = 1
+                with _device_ctx(dev), _Timed(f"spmm_sub/{f}"):
+                    st = lib.acm_spmm_ex(low_t.handle, _vp(gsg), gsg.stride(0), f, _vp(d_struc), d_struc.stride(0),
+                                         C.byref(o), _vp(ws2), ws2.numel() * 4, _stream())
+                _lib.check(st, "acm_spmm_ex")
             none4 = [None] * 4
             grads_vec = d_vec + [None] * (4 - k)
             grads_lnw = (d_lnw + [None] * (4 - k)) if cfg.layernorm else none4
             grads_lnb = (d_lnb + [None] * (4 - k)) if cfg.layernorm else none4
             return (None, d_wcat[0], d_wcat[1], d_wcat[2], grads_vec[0], grads_vec[1], grads_vec[2], grads_vec[3],
-                    None, d_mix, *grads_lnw, *grads_lnb, None, None, None, None, None, None, None, None, None)
+                    d_struc, d_mix, *grads_lnw, *grads_lnb, None, None, None, None, None, None, None, None, None)
 
         d_struc = torch.empty(n, f, dtype=_F32, device=dev) if four else None
         r = _lib.ConvBwdSpmm()

@@ -524,12 +524,13 @@ def test_acmii_recompute_on_gather_matches_oracle_and_literal(model_type, ln, f_
         assert "conv_acmii_fwd" in used and "conv_fwd" not in used and "conv_bwd_spmm" in used, used
         timer.events.clear()
         # the mask form of the same layer (acm_conv_acmii_v.hip: bf16 matrix pipe, weight gradients without a transposed
-        # product) where it applies -- three channels over a pattern-only operator; elsewhere the switch changes nothing
+        # product) where it applies -- a pattern-only operator; elsewhere the switch changes nothing
         tune(acmii_mask=1)
         c = _run_both(model_type, 1, s, ln, 700, f_in, 64, 31, False, monkeypatch, agg=True, adj=adj, implicit=implicit)
         used = set(k.split("/")[0] for k in timer.events)
-        if implicit and not s:
+        if implicit:
             assert {"acmii_table", "conv_acmii_v_fwd", "conv_acmii_v_bwd"} <= used and "conv_bwd_spmm" not in used, used
+            assert ("spmm_sub" in used) == bool(s), used
         else:
             assert "conv_acmii_fwd" in used and "conv_bwd_spmm" in used and "conv_acmii_v_fwd" not in used, used
         assert float((a - c).abs().max()) < 2e-5 * max(1.0, float(a.abs().max()))
