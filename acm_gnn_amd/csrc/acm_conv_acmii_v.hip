@@ -152,7 +152,10 @@ __device__ __forceinline__ void v_batch(unsigned char* lds, int lane, u32x4 r0, 
 // the batch in hand.  The loop over a quad's batches is unrolled over the ring (no value moves between registers, a load is
 // awaited only where it is used); when a quad ends in the middle of the ring the live entries are rotated to phase 0 -- a
 // handful of moves per four rows -- so that the code after the loop (the rows' epilogue) exists once.
-constexpr int V_RD = 2, V_JD = 2, V_RING = V_RD + V_JD;
+#ifndef ACM_V_RD
+#define ACM_V_RD 2
+#endif
+constexpr int V_RD = ACM_V_RD, V_JD = ACM_V_RD, V_RING = V_RD + V_JD;
 
 // The wave's quads [qb, qe) with their batches.  `quad_begin(id)` (id = lane row kq's item {row, slot, batches, flags}) runs before
 // a quad's first batch, `item_begin(u)` before item u's first batch, `item_end(u, d)` after its last one (also for items
@@ -206,10 +209,16 @@ __device__ __forceinline__ void v_wave_quads(const int32_t* __restrict__ ids, co
                         v_batch(lds, lane, a0, a1, d);
                         --left;
                     } else if (s != 0) {                   // the quad ended at phase s: rotate the live entries to phase 0
-                        const u32x4 t0 = R0[s % V_RD], t1 = R1[s % V_RD], t2 = R0[(s + 1) % V_RD], t3 = R1[(s + 1) % V_RD];
-                        const int j0 = J0[(s + 2) % V_RING], j1 = J1[(s + 2) % V_RING], j2 = J0[(s + 3) % V_RING], j3 = J1[(s + 3) % V_RING];
-                        R0[0] = t0, R1[0] = t1, R0[1] = t2, R1[1] = t3;
-                        J0[2] = j0, J1[2] = j1, J0[3] = j2, J1[3] = j3;
+                        u32x4 t0[V_RD], t1[V_RD];
+                        int tj0[V_JD], tj1[V_JD];
+#pragma unroll
+                        for (int i = 0; i < V_RD; ++i) t0[i] = R0[(s + i) % V_RD], t1[i] = R1[(s + i) % V_RD];
+#pragma unroll
+                        for (int i = 0; i < V_JD; ++i) tj0[i] = J0[(s + V_RD + i) % V_RING], tj1[i] = J1[(s + V_RD + i) % V_RING];
+#pragma unroll
+                        for (int i = 0; i < V_RD; ++i) R0[i] = t0[i], R1[i] = t1[i];
+#pragma unroll
+                        for (int i = 0; i < V_JD; ++i) J0[V_RD + i] = tj0[i], J1[V_RD + i] = tj1[i];
                     }
                 }
             }
@@ -217,7 +226,6 @@ __device__ __forceinline__ void v_wave_quads(const int32_t* __restrict__ ids, co
         quad_end(id);
     }
 }
-static_assert(V_RD == 2 && V_RING == 4, "the rotation above is written out for a ring of 2 + 2");
 
 // the wave's range of quads and its first batch (wave-uniform)
 __device__ __forceinline__ void v_wave(const VStreamView& sv, int w, int& qb, int& qe, int& first_batch) {

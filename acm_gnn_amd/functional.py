@@ -457,6 +457,10 @@ def _take_pre_proj(call, x, w3, relu):
     return None
 
 
+def _capturing(dev):
+    return dev.type == "cuda" and torch.cuda.is_available() and torch.cuda.is_current_stream_capturing()
+
+
 def _vp(t):
     return C.c_void_p(t.data_ptr()) if t is not None else None
 
@@ -1372,7 +1376,8 @@ class AcmConvFunction(torch.autograd.Function):
             st = 4
             if (ops.implicit and not ops.sharded and not ctx.needs_input_grad[0] and n > 0
                     and xg.data_ptr() == xpad.data_ptr() and (tuning.HOST.rewrites & tuning.REWRITE_ACMII_MASK) != 0
-                    and ops.low.build_item_streams()):         # (one-off per operator; a captured step finds them built)
+                    and (getattr(ops.low, "item_stream_waves", 0) > 0         # one-off per operator (synchronises: never
+                         or (not _capturing(dev) and ops.low.build_item_streams()))):     # inside a capture, whose warm-up built them)
                 tb = C.c_size_t()
                 _lib.check(lib.acm_acmii_table_bytes(n, C.byref(tb)), "acm_acmii_table_bytes")
                 table = torch.empty(tb.value // 4, dtype=torch.int32, device=dev)
