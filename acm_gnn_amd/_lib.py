@@ -164,7 +164,7 @@ class ConvAcmiiBwd(C.Structure):
     _fields_ = [("f_in", C.c_int32), ("table", C.c_void_p),
                 ("g_low", C.c_void_p), ("ld_g_low", C.c_int64), ("g_high", C.c_void_p), ("ld_g_high", C.c_int64),
                 ("g_mlp", C.c_void_p), ("ld_g_mlp", C.c_int64), ("x", C.c_void_p), ("ld_x", C.c_int64),
-                ("row_scale", C.c_void_p),
+                ("self_offset", C.c_int64), ("row_scale", C.c_void_p),
                 ("d_w_low", C.c_void_p), ("d_w_high", C.c_void_p), ("d_w_mlp", C.c_void_p), ("ld_dw", C.c_int64),
                 ("defer", C.c_void_p)]
 

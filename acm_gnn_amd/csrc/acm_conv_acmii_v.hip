@@ -415,7 +415,7 @@ __global__ __launch_bounds__(256) void acmii_v_bwd_kernel(acm_conv_acmii_bwd_t p
 #pragma unroll
                 for (int t = 0; t < 4; ++t) gi[t] = p.g_mlp[ru * p.ld_g_mlp + 16 * t + i];
                 xv = *reinterpret_cast<const float2*>(p.x + ru * p.ld_x + 2 * kq);
-                mself = reinterpret_cast<const unsigned char*>(table)[ru * 64 + 48 + i];
+                mself = reinterpret_cast<const unsigned char*>(table)[(ru + p.self_offset) * 64 + 48 + i];
             },
             [&](int u, const f32x4 (&d)[8]) {
 #pragma unroll
@@ -491,8 +491,7 @@ extern "C" int acm_acmii_table(int64_t n_rows, int f_in, const float* x, int64_t
 static int acmii_v_check_operator(const acm_csr_t* a, const void* table, const char* who) {
     ACM_REQUIRE(a && table, ACM_EINVAL, "%s: NULL argument", who);
     ACM_REQUIRE(a->vals == nullptr, ACM_EUNSUPPORTED, "%s: pattern-only operators only (explicit values scale the inputs, not the masks)", who);
-    ACM_REQUIRE(a->n_rows == a->n_cols, ACM_EUNSUPPORTED, "%s: square operators only (the table holds the rows' own entries)", who);
-    ACM_REQUIRE(a->nnz > 0 && a->n_rows < ((int64_t)1 << 31) - 1, ACM_EUNSUPPORTED, "%s: empty operator / too many rows", who);
+    ACM_REQUIRE(a->nnz > 0 && a->n_cols < ((int64_t)1 << 31) - 1, ACM_EUNSUPPORTED, "%s: empty operator / too many columns", who);
     ACM_REQUIRE(((uintptr_t)table) % 16 == 0, ACM_EINVAL, "%s: table not 16-byte aligned", who);
     ACM_REQUIRE(a->n_long == 0 || a->long_index, ACM_EUNSUPPORTED, "%s: handle without a long-row index", who);
     ACM_REQUIRE(a->item_streams, ACM_EINVAL, "%s: the operator has no item streams (acm_csr_build_item_streams)", who);
@@ -561,6 +560,9 @@ extern "C" int acm_conv_acmii_v_bwd(const acm_csr_t* a, const acm_conv_acmii_bwd
     const int st = acmii_v_check_operator(a, p->table, "acm_conv_acmii_v_bwd");
     if (st != ACM_OK) return st;
     ACM_REQUIRE(p->f_in >= 1 && p->f_in <= 8, ACM_EUNSUPPORTED, "acm_conv_acmii_v_bwd: f_in %d", p->f_in);
+    ACM_REQUIRE(p->self_offset >= 0 && p->self_offset + a->n_rows <= a->n_cols, ACM_EINVAL,
+                "acm_conv_acmii_v_bwd: self_offset %lld + %lld rows exceed the table's %lld rows", (long long)p->self_offset,
+                (long long)a->n_rows, (long long)a->n_cols);
     ACM_REQUIRE(p->g_low && p->g_high && p->g_mlp && p->x && p->row_scale && p->d_w_low && p->d_w_high && p->d_w_mlp, ACM_EINVAL,
                 "acm_conv_acmii_v_bwd: NULL tensor pointer");
     ACM_REQUIRE(p->ld_g_low >= 64 && p->ld_g_high >= 64 && p->ld_g_mlp >= 64 && p->ld_dw >= 64 && p->ld_x >= 8 && p->ld_x % 2 == 0 &&

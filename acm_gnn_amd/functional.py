@@ -1374,15 +1374,18 @@ class AcmConvFunction(torch.autograd.Function):
             # gradient into x.
             ctx.mask_table = None
             st = 4
-            if (ops.implicit and not ops.sharded and not ctx.needs_input_grad[0] and n > 0
-                    and xg.data_ptr() == xpad.data_ptr() and (tuning.HOST.rewrites & tuning.REWRITE_ACMII_MASK) != 0
+            if (ops.implicit and not ctx.needs_input_grad[0] and n > 0 and xg.shape[0] == ops.low.n_cols
+                    and (tuning.HOST.rewrites & tuning.REWRITE_ACMII_MASK) != 0
                     and (getattr(ops.low, "item_stream_waves", 0) > 0         # one-off per operator (synchronises: never
                          or (not _capturing(dev) and ops.low.build_item_streams()))):     # inside a capture, whose warm-up built them)
+                # the table covers every column of the operator: this process's rows, or (row-sharded) the all-gathered input --
+                # each rank evaluates the masks of its halo itself, and its backward then needs NO all-gather of gradients
+                ng = xg.shape[0]
                 tb = C.c_size_t()
-                _lib.check(lib.acm_acmii_table_bytes(n, C.byref(tb)), "acm_acmii_table_bytes")
+                _lib.check(lib.acm_acmii_table_bytes(ng, C.byref(tb)), "acm_acmii_table_bytes")
                 table = torch.empty(tb.value // 4, dtype=torch.int32, device=dev)
-                with _device_ctx(dev), _Timed(f"acmii_table/{n}x{f_in}"):
-                    st = lib.acm_acmii_table(n, f_in, xpad.data_ptr(), xpad.stride(0), wl.data_ptr(), wh.data_ptr(), f,
+                with _device_ctx(dev), _Timed(f"acmii_table/{ng}x{f_in}"):
+                    st = lib.acm_acmii_table(ng, f_in, xg.data_ptr(), xg.stride(0), wl.data_ptr(), wh.data_ptr(), f,
                                              table.data_ptr(), tb.value, _stream())
                 if st == 0:
                     if ops.low.n_long_rows == 0:          # only the fix-up of long rows reads zlh (its high-pass half)
@@ -1391,6 +1394,10 @@ class AcmConvFunction(torch.autograd.Function):
                         st = lib.acm_conv_acmii_v_fwd(ops.low.handle, C.byref(p), table.data_ptr(), _vp(ws), ws.numel() * 4, _stream())
                     if st == 0:
                         ctx.mask_table, ctx.mask_x = table, xpad
+                        ctx.mask_self_offset = 0
+                        if ops.sharded:                   # this rank's rows inside the gathered numbering (_gather_rows)
+                            import torch.distributed as dist
+                            ctx.mask_self_offset = dist.get_rank(ops.group) * (ops.n_gathered // dist.get_world_size(ops.group))
                     else:
                         p.zlh, p.ld_zlh = zlh.data_ptr(), zlh.stride(0)
                 if st not in (0, 4):                      # 4 = ACM_EUNSUPPORTED: the fp32 kernel below
@@ -1657,6 +1664,7 @@ class AcmConvFunction(torch.autograd.Function):
             b.g_high, b.ld_g_high = g.data_ptr() + 4 * fb, g.stride(0)
             b.g_mlp, b.ld_g_mlp = dz.data_ptr() + 8 * f, dz.stride(0)
             b.x, b.ld_x = xt.data_ptr(), xt.stride(0)
+            b.self_offset = ctx.mask_self_offset
             b.row_scale = ops.row_scale.data_ptr()
             b.d_w_low, b.d_w_high, b.d_w_mlp, b.ld_dw = d_wcat[0].data_ptr(), d_wcat[1].data_ptr(), d_wcat[2].data_ptr(), f
             b.defer = defer.pointer() if defer is not None else None
@@ -1675,14 +1683,20 @@ class AcmConvFunction(torch.autograd.Function):
                 ws2 = low_t.workspace(f)
                 o = _lib.SpmmOpts()
                 o.sub, o.ld_sub = gs.data_ptr(), gs.stride(0)
-                gsg = gs
+                gsg = _gather_rows(ops, gs)
                 if cfg.gather_bf16 and 8 < f <= 64 and f % 2 == 0:       # bf16 gathered operand (the self term stays fp32)
-                    gsg = cast_bf16(gs)
+                    gsg = cast_bf16(gsg)
                     o.g_bf16 = 1
                 with _device_ctx(dev), _Timed(f"spmm_sub/{f}"):
                     st = lib.acm_spmm_ex(low_t.handle, _vp(gsg), gsg.stride(0), f, _vp(d_struc), d_struc.stride(0),
                                          C.byref(o), _vp(ws2), ws2.numel() * 4, _stream())
                 _lib.check(st, "acm_spmm_ex")
+            if ops.sharded:                             # replicated parameters: sum the row-shard partials
+                import torch.distributed as dist
+                if defer is not None:
+                    defer.allreduce(flat, ops.group)    # after the step's single flush (the all-reduce reads its sums)
+                else:
+                    dist.all_reduce(flat, group=ops.group)
             none4 = [None] * 4
             grads_vec = d_vec + [None] * (4 - k)
             grads_lnw = (d_lnw + [None] * (4 - k)) if cfg.layernorm else none4

@@ -738,12 +738,13 @@ int acm_conv_acmii_fwd(const acm_csr_t* a_low, const acm_conv_acmii_fwd_t* p,
  *                          x: [n_rows, ld_x >= 8], zero padded beyond f_in, 8-byte aligned rows.
  *   acm_conv_acmii_v_fwd   acm_conv_acmii_fwd's outputs from the table (p->xg is not read; p->row_scale is required;
  *                          p->zlh may be NULL when the operator has no long rows -- only its second half, the rows' own
- *                          relu(x_i W_H), is written).  Square pattern-only operators whose column ids index the table.
+ *                          relu(x_i W_H), is written).  Pattern-only operators whose column ids index the table (n_cols + 1
+ *                          rows); a row block of a row-sharded operator qualifies (xs = its own rows, table over all columns).
  *                          Workspace: acm_conv_acmii_fwd_workspace_bytes.
  *   acm_conv_acmii_v_bwd   d_w_low, d_w_high ([f_in, 64], pitch ld_dw) from g_low = dH_L, g_high = dH_H ([n_rows, 64]) over
  *                          the SAME (forward) operator and table, and d_w_mlp = X^T dZ_I on the way (row-local: the launch
  *                          has every row in hand); deterministic; the final sums honour `defer`.
- * ACM_EUNSUPPORTED for operators with explicit values, non-square operators, f_in > 8: the caller keeps
+ * ACM_EUNSUPPORTED for operators with explicit values and f_in > 8: the caller keeps
  * acm_conv_acmii_fwd / acm_conv_bwd_spmm / acm_gemm. */
 typedef struct {
     int32_t f_in;
@@ -751,7 +752,9 @@ typedef struct {
     const float* g_low;  int64_t ld_g_low;      /* dH_L [n_rows, 64]                                                 */
     const float* g_high; int64_t ld_g_high;     /* dH_H [n_rows, 64]                                                 */
     const float* g_mlp;  int64_t ld_g_mlp;      /* dZ_I [n_rows, 64] = dH_I masked by the identity channel's ReLU    */
-    const float* x; int64_t ld_x;               /* the rows the table was built from ([n_rows, >= 8], zero padded)   */
+    const float* x; int64_t ld_x;               /* the operator's OWN rows of the table's source ([n_rows, >= 8], zero padded) */
+    int64_t self_offset;                        /* table row of the operator's row r = r + self_offset (0 unless the operator is a
+                                                   row block of a larger one: rank * longest block of a row-sharded run)   */
     const float* row_scale;                     /* 1 / d_i                                                           */
     float* d_w_low; float* d_w_high; float* d_w_mlp; int64_t ld_dw;   /* [f_in, 64] each; d_w_mlp = X^T dZ_I        */
     acm_reduce_list_t* defer;                   /* NULL: reduce now; else append the two second phases              */

@@ -495,8 +495,8 @@ class FakeLib:
         from acm_gnn_amd import _lib
         p, t = pp._obj, self._acmii_table(table)
         g = self._handles[handle.value if isinstance(handle, C.c_void_p) else int(handle)]
-        if t is None or np.any(g.vals != 1) or g.n_rows != g.n_cols or not p.row_scale:
-            self._err = b"acm_conv_acmii_v_fwd: unsupported operator / unknown table"
+        if t is None or np.any(g.vals != 1) or t["x"].shape[0] != g.n_cols or not p.row_scale or not getattr(g, "item_stream_waves", 0):
+            self._err = b"acm_conv_acmii_v_fwd: unsupported operator / unknown table / no item streams"
             return 4
         q = _lib.ConvAcmiiFwd.from_buffer_copy(p)
         xg = np.zeros((g.n_cols, 8), np.float32)
@@ -516,18 +516,19 @@ class FakeLib:
         p = pp._obj
         t = self._acmii_table(p.table)
         g = self._handles[handle.value if isinstance(handle, C.c_void_p) else int(handle)]
-        if t is None or np.any(g.vals != 1) or g.n_rows != g.n_cols:
-            self._err = b"acm_conv_acmii_v_bwd: unsupported operator / unknown table"
+        if t is None or np.any(g.vals != 1) or t["x"].shape[0] != g.n_cols or not getattr(g, "item_stream_waves", 0):
+            self._err = b"acm_conv_acmii_v_bwd: unsupported operator / unknown table / no item streams"
             return 4
         import scipy.sparse as sp
-        n, fi = g.n_rows, p.f_in
-        x = t["x"].astype(np.float64)
-        a = sp.csr_matrix((g.vals.astype(np.float64), g.indices, g.indptr), shape=(n, n))
+        n, nc, fi, off = g.n_rows, g.n_cols, p.f_in, int(p.self_offset)
+        xg = t["x"].astype(np.float64)                                       # every column of the operator
+        xs = _view(p.x, n, fi, p.ld_x).astype(np.float64)                     # its own rows
+        a = sp.csr_matrix((g.vals.astype(np.float64), g.indices, g.indptr), shape=(n, nc))
         rs = _vec(p.row_scale, n).astype(np.float64)[:, None]
         gl, gh = _view(p.g_low, n, 64, p.ld_g_low).astype(np.float64), _view(p.g_high, n, 64, p.ld_g_high).astype(np.float64)
-        ml, mh = (x @ t["w_low"] > 0), (x @ t["w_high"] > 0)
-        d_l = x.T @ (ml * (a.T @ (rs * gl)))                      # X^T (m_L o A_low^T G_L),  A_low = diag(rs) P
-        d_h = x.T @ (mh * (gh - a.T @ (rs * gh)))
+        ml, mh = (xg @ t["w_low"] > 0), (xg @ t["w_high"] > 0)
+        d_l = xg.T @ (ml * (a.T @ (rs * gl)))                     # X^T (m_L o A_low^T G_L),  A_low = diag(rs) P
+        d_h = xs.T @ (mh[off:off + n] * gh) - xg.T @ (mh * (a.T @ (rs * gh)))
         d_i = _view(p.x, n, fi, p.ld_x).astype(np.float64).T @ _view(p.g_mlp, n, 64, p.ld_g_mlp).astype(np.float64)
         return self._emit(p.defer, [(_view(p.d_w_low, fi, 64, p.ld_dw), d_l), (_view(p.d_w_high, fi, 64, p.ld_dw), d_h),
                                     (_view(p.d_w_mlp, fi, 64, p.ld_dw), d_i)])

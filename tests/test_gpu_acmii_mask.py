@@ -162,6 +162,14 @@ def test_forward_and_weight_gradients_through_the_c_abi(n, density, hub, f_in, l
     b.f_in, b.table = f_in, table.data_ptr()
     b.g_low, b.ld_g_low, b.g_high, b.ld_g_high, b.g_mlp, b.ld_g_mlp = gl.data_ptr(), 64, gh.data_ptr(), 64, gi.data_ptr(), 64
     b.x, b.ld_x, b.row_scale = x8.data_ptr(), 8, rs.data_ptr()
+    b.self_offset = 1                                                    # rows beyond the table: refused
+    nb0 = C.c_size_t()
+    _lib.check(lib.acm_conv_acmii_v_bwd_workspace_bytes(gph.handle, C.byref(nb0)))
+    ws0 = torch.empty(nb0.value // 4, device=DEV)
+    b.d_w_low = b.d_w_high = b.d_w_mlp = ws0.data_ptr()
+    b.ld_dw = 64
+    assert lib.acm_conv_acmii_v_bwd(gph.handle, C.byref(b), ws0.data_ptr(), ws0.numel() * 4, None) == 1
+    b.self_offset = 0
     b.d_w_low, b.d_w_high, b.d_w_mlp, b.ld_dw = dw[0].data_ptr(), dw[1].data_ptr(), dw[2].data_ptr(), 64
     nb2 = C.c_size_t()
     _lib.check(lib.acm_conv_acmii_v_bwd_workspace_bytes(gph.handle, C.byref(nb2)))
@@ -198,8 +206,3 @@ def test_mask_form_declines_what_it_does_not_cover():
     tb = torch.empty(201 * 16, dtype=torch.int32, device=DEV)
     assert lib.acm_acmii_table(200, 9, x8.data_ptr(), 8, w.data_ptr(), w.data_ptr(), 64, tb.data_ptr(), tb.numel() * 4, None) == 4
     assert lib.acm_acmii_table(200, 7, x8.data_ptr(), 8, w.data_ptr(), w.data_ptr(), 64, tb.data_ptr(), 64, None) == 5    # ACM_ENOMEM
-    rect = CsrGraph.from_csr(*(CsrGraph.from_scipy(sp.csr_matrix(a[:, :150]), DEV).arrays()[:2]), None, 150)
-    assert rect.build_item_streams()
-    p = _lib.ConvAcmiiFwd()
-    ws = torch.empty(1024, device=DEV)
-    assert lib.acm_conv_acmii_v_fwd(rect.handle, C.byref(p), tb.data_ptr(), ws.data_ptr(), ws.numel() * 4, None) == 4      # not square

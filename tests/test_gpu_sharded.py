@@ -82,10 +82,19 @@ def _worker(rank, world, port, cfg, ret):
         x = torch.from_numpy(x_np[b:e]).to(DEV)
         y = torch.from_numpy(y_np[b:e]).to(DEV)
         idx = torch.from_numpy(DD.local_index(tr, plan, rank)).to(DEV)
+        timer = AF.KernelTimer()
+        AF.set_kernel_timer(timer)
         out = model(x, ops)
         loss = F.nll_loss(F.log_softmax(out, 1)[idx], y[idx], reduction="sum") / len(tr)
         loss.backward()
         torch.cuda.synchronize()
+        AF.set_kernel_timer(None)
+        if cfg["variant"] and x_np.shape[1] <= 8:
+            # the ACMII first layer runs in the mask form on every rank: the table over the all-gathered input, and NO
+            # all-gather of the 128-float gradient rows in its backward (the fp32 form's transposed products need one)
+            used = set(k.split("/")[0] for k in timer.events)
+            assert {"acmii_table", "conv_acmii_v_fwd", "conv_acmii_v_bwd"} <= used, sorted(used)
+            assert not any(k.startswith("all_gather/") and k.endswith("x128") for k in timer.events), sorted(timer.events)
         grads = {k: p.grad.cpu().numpy().copy() for k, p in model.named_parameters() if p.grad is not None}
         ret.put((rank, out.detach().cpu().numpy().copy(), grads, (b, e)))
     finally:
