@@ -241,6 +241,7 @@ __global__ __launch_bounds__(256) void acmii_v_fwd_kernel(acm_conv_acmii_fwd_t p
     constexpr int T = 8;
     __shared__ __attribute__((aligned(16))) float hlds[3 * K * 64];
     __shared__ __attribute__((aligned(16))) unsigned char stage[4][2048];
+    __shared__ float spl[4][4 * T * 64];
     const int F = 64;
     stage_head_params<K>(hlds, p.att_vec, p.ln_weight, p.ln_bias, p.layernorm, F);
     __syncthreads();
@@ -277,25 +278,27 @@ __global__ __launch_bounds__(256) void acmii_v_fwd_kernel(acm_conv_acmii_fwd_t p
     int qb, qe, first_batch;
     v_wave(sv, w, qb, qe, first_batch);
     if (qb >= qe) return;
-    float acc[T];
+    // item u's contraction per lane row goes to the wave's LDS slab [u][t][lane]; at the quad's end lane (kq, i) adds the four
+    // lane rows of ITS item kq -- 4 reads + 3 adds per tile instead of a four-row swap-and-add reduction per item and tile
+    float* spw = spl[threadIdx.x >> 6];
     v_wave_quads(
-        sv.ids, sv.quads, qb, qe, first_batch, table, stage[threadIdx.x >> 6], lane,
-        [&](const int4&) {
-#pragma unroll
-            for (int t = 0; t < T; ++t) acc[t] = 0.f;
-        },
-        [](int) {},
+        sv.ids, sv.quads, qb, qe, first_batch, table, stage[threadIdx.x >> 6], lane, [](const int4&) {}, [](int) {},
         [&](int u, const f32x4 (&d)[8]) {
 #pragma unroll
             for (int t = 0; t < T; ++t) {
-                float s = 0.f;
+                float s = d[t][0] * wc[t][0];
 #pragma unroll
-                for (int r = 0; r < 4; ++r) s = fmaf(d[t][r], wc[t][r], s);
-                s = acm_cross_row_sum(s);
-                acc[t] = kq == u ? s : acc[t];
+                for (int r = 1; r < 4; ++r) s = fmaf(d[t][r], wc[t][r], s);
+                spw[(u * T + t) * 64 + lane] = s;
             }
         },
         [&](const int4& id) {
+            float acc[T];
+#pragma unroll
+            for (int t = 0; t < T; ++t) {
+                const float* q = spw + (kq * T + t) * 64 + i;
+                acc[t] = (q[0] + q[16]) + (q[32] + q[48]);
+            }
             const bool valid_d = (id.w & 1) != 0;
             const int row = id.x, slot = id.y;
             const long rr = valid_d ? row : 0;

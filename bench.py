@@ -438,6 +438,21 @@ def side_measurements(args, timed_graph_steps, model, opt, x, ops, y, w, fused_d
         with tuning.override(rewrites=tuning.HOST.rewrites & ~tuning.REWRITE_AGG_FIRST):
             ms, _ = timed_graph_steps(T.TrainStep(model, opt, x, ops, y, w, use_graph=True, fused_dropout=fused_drop))
             out["literal_ms_per_step"] = round(ms, 4)
+    if not args.variant and x.shape[1] <= 8 and args.hidden == 64:
+        # the reference's DEFAULT variant (ACM-Geometric/parse.py:57: --variant 1, ACMII: the ReLU between projection and filter)
+        # on the same graph and split: the mask form on the bf16 matrix pipe, and the round-3 path (fp32-MFMA recompute
+        # forward + two transposed 64-wide gathers in the backward) it replaces
+        torch.manual_seed(args.seed)
+        n_cls = int(y.max().item()) + 1
+        model_v = acm_gnn_amd.GCN(x.shape[1], args.hidden, n_cls, 2, x.shape[0], args.dropout, args.method, args.structure_info,
+                                  variant=True, attn_layernorm=True).to(dev)
+        opt_v = acm_gnn_amd.FusedAdamW(model_v.parameters(), lr=args.lr, weight_decay=args.weight_decay)
+        ms, _ = timed_graph_steps(T.TrainStep(model_v, opt_v, x, ops, y, w, use_graph=True, fused_dropout=fused_drop))
+        out["acmii_ms_per_step"] = round(ms, 4)
+        with tuning.override(rewrites=tuning.HOST.rewrites & ~tuning.REWRITE_ACMII_MASK):
+            ms, _ = timed_graph_steps(T.TrainStep(model_v, opt_v, x, ops, y, w, use_graph=True, fused_dropout=fused_drop))
+            out["acmii_fp32_mfma_ms_per_step"] = round(ms, 4)
+        del model_v, opt_v
     other = "random" if args.node_order == "degree" else "degree"
     wl = D.bench_workload(args.dataset, seed=args.seed, node_order=other, uniform=args.uniform,
                           normalize_features=not (args.method in ("acmgcnp", "acmgcnpp") and args.structure_info))
