@@ -120,6 +120,8 @@ __device__ __forceinline__ u32x4 v_row(const u32x4* __restrict__ table, int j, i
 // Lane (g, m), contraction slot e <-> the neighbour in LDS row 4 e + g (both operands: any bijection serves; this one is
 // bank-conflict free).  A = [hi (rows 0..7) | mid (rows 8..15)], A2 = [lo | 0]; both products go to the SAME accumulator
 // (exact products, one fp32 sum): D row m < 8 = sum mask (hi + lo) of feature m, row m >= 8 = sum mask mid of feature m - 8.
+// FIRST: the item's first batch -- the accumulators start from the MFMA's zero C operand instead of 32 register moves.
+template <bool FIRST>
 __device__ __forceinline__ void v_batch(unsigned char* lds, int lane, u32x4 r0, u32x4 r1, f32x4 (&d)[8]) {
     u32x4_ma* l4 = reinterpret_cast<u32x4_ma*>(lds);
     l4[lane] = r0;
@@ -142,7 +144,8 @@ __device__ __forceinline__ void v_batch(unsigned char* lds, int lane, u32x4 r0, 
     for (int q = 0; q < 8; ++q) {
 #pragma unroll
         for (int p = 0; p < 4; ++p) B[q][p] = __umul24(wp[p] & (0x00010001u << q), 0x3F80u >> q);
-        d[q] = mma(A, B[q], d[q]);
+        const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+        d[q] = mma(A, B[q], FIRST ? zero4 : d[q]);
     }
 #pragma unroll
     for (int q = 0; q < 8; ++q) d[q] = mma(A2, B[q], d[q]);
@@ -185,12 +188,16 @@ __device__ __forceinline__ void v_wave_quads(const int32_t* __restrict__ ids, co
         for (int q = 0; q < 8; ++q) d[q] = zero4;
         int u = 0, left = nb0;
         item_begin(0);
-        bool more = true;
+        bool more = true, fresh = true;               // fresh: the item has not run a batch yet
         while (more) {
 #pragma unroll
             for (int s = 0; s < V_RING; ++s) {
                 if (more) {
                     while (left == 0) {
+                        if (fresh) {                   // an item without neighbours: its sums are zero
+#pragma unroll
+                            for (int q = 0; q < 8; ++q) d[q] = zero4;
+                        }
                         item_end(u, d);
                         if (++u == 4) {
                             more = false;
@@ -198,15 +205,16 @@ __device__ __forceinline__ void v_wave_quads(const int32_t* __restrict__ ids, co
                         }
                         left = sel4(nb0, nb1, nb2, nb3, u);
                         item_begin(u);
-#pragma unroll
-                        for (int q = 0; q < 8; ++q) d[q] = zero4;
+                        fresh = true;
                     }
                     if (more) {
                         const u32x4 a0 = R0[s % V_RD], a1 = R1[s % V_RD];
                         R0[s % V_RD] = v_row(table, J0[(s + V_RD) % V_RING], lane);       // the batch V_RD ahead
                         R1[s % V_RD] = v_row(table, J1[(s + V_RD) % V_RING], lane);
                         J0[s] = idp[0], J1[s] = idp[16], idp += 32;                       // the ids V_RING ahead
-                        v_batch(lds, lane, a0, a1, d);
+                        if (fresh) v_batch<true>(lds, lane, a0, a1, d);
+                        else v_batch<false>(lds, lane, a0, a1, d);
+                        fresh = false;
                         --left;
                     } else if (s != 0) {                   // the quad ended at phase s: rotate the live entries to phase 0
                         u32x4 t0[V_RD], t1[V_RD];
