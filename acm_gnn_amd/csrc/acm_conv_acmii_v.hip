@@ -21,17 +21,17 @@
 // -- the SAME products over the SAME rows, contracted with G instead of W.
 //
 //   table   one 64-byte row per node, rebuilt every step by acmii_table_kernel (the masks depend on W):
-//           [x hi (8 bf16) | x mid (8 bf16) | x lo (8 bf16) | 16 mask bytes]; bit q = 4 ch + t of byte n = m^ch[16 t + n].
+//           [x hi (8 bf16) | x mid (8 bf16) | x lo / 2 (8 bf16) | 16 mask bytes]; bit q = 4 ch + t of byte n = m^ch[16 t + n].
 //           Row n_rows is all zero: what idle slots fetch.
 //   waves   persistent, over the handle's item streams (acm_csr_build_item_streams): a wave reads its parameters once, walks one
 //           linear id stream through its quads of four items and fetches ahead across item and quad boundaries.
 //   batch   32 neighbours of ONE work item per wave step: two 16-byte fetches per lane (a neighbour's row = four lanes) ->
 //           2 KB of wave-private LDS -> operands.  Lane (g = lane >> 4, m = lane & 15), contraction slot e = 0..7 <-> the
 //           neighbour in LDS row 4 e + g (any bijection serves, both operands use this one: bank-conflict free):
-//             A  (16 x 32, x):     rows 0..7 = hi of the features, rows 8..15 = mid;   A2: rows 0..7 = lo, rows 8..15 = 0
+//             A  (16 x 32, x):     rows 0..7 = hi of the features, rows 8..15 = mid;   A2: rows 0..7 = rows 8..15 = lo / 2
 //             B  (32 x 16, masks): column n = m of tile q: ((byte pair) & (0x00010001 << q)) * (0x3F80 >> q) = two bf16 0 / 1
 //           16 MFMAs (8 tiles x {A, A2}, both into the same accumulator); D[4 g + r][n]: lane (g, n) holds
-//           V[c = 16 t + n][f = 4 (g & 1) + r], hi + lo in lane rows 0, 1 and mid in rows 2, 3.
+//           V[c = 16 t + n][f = 4 (g & 1) + r], hi + lo / 2 in lane rows 0, 1 and mid + lo / 2 in rows 2, 3.
 //   item end forward:  S[c] = sum over the four lane rows of sum_r W[4 (g & 1) + r][c] * D[r]; the wave's four items
 //           leave their sums in the four lane rows and share the epilogue of acm_conv_acmii.hip (head, mix, post-op).
 //   item end backward: acc += (+-rs_i G[i, c]) * D -- 32 accumulators per lane, splits and waves summed once per workgroup.
@@ -91,7 +91,10 @@ __global__ __launch_bounds__(256) void acmii_table_kernel(long n_rows, int f_in,
             const float c = pr == 0 ? xv[1] : (pr == 1 ? xv[3] : (pr == 2 ? xv[5] : xv[7]));
             const float ra = a - bitsf(fbits(a) & 0xFFFF0000u), rc = c - bitsf(fbits(c) & 0xFFFF0000u);
             const float sa = ra - bitsf(fbits(ra) & 0xFFFF0000u), sc = rc - bitsf(fbits(rc) & 0xFFFF0000u);
-            const unsigned hi = pack_hi16(fbits(a), fbits(c)), mid = pack_hi16(fbits(ra), fbits(rc)), lo = pack_hi16(fbits(sa), fbits(sc));
+            // (the third part is stored HALVED -- exact, a power of two -- because the kernels add it twice: once beside hi,
+            //  once beside mid, see v_batch)
+            const unsigned hi = pack_hi16(fbits(a), fbits(c)), mid = pack_hi16(fbits(ra), fbits(rc)),
+                           lo = pack_hi16(fbits(0.5f * sa), fbits(0.5f * sc));
             const unsigned m0 = __shfl(b, 4 * pr, 16), m1 = __shfl(b, 4 * pr + 1, 16), m2 = __shfl(b, 4 * pr + 2, 16),
                            m3 = __shfl(b, 4 * pr + 3, 16);
             const unsigned md = m0 | (m1 << 8) | (m2 << 16) | (m3 << 24);
@@ -113,13 +116,18 @@ struct VStreamView {
 };
 
 __device__ __forceinline__ int sel4(int a0, int a1, int a2, int a3, int i) { return i == 0 ? a0 : (i == 1 ? a1 : (i == 2 ? a2 : a3)); }
-__device__ __forceinline__ u32x4 v_row(const u32x4* __restrict__ table, int j, int lane) { return table[(long)j * 4 + (lane & 3)]; }
+// 16 bytes of table row j: a 32-bit byte offset beside the scalar base (the launch checks that the table is below 4 GB)
+__device__ __forceinline__ u32x4 v_row(const u32x4* __restrict__ table, int j, int lane) {
+    const unsigned off = (unsigned)j * 64u + (unsigned)(lane & 3) * 16u;
+    return *reinterpret_cast<const u32x4*>(reinterpret_cast<const unsigned char*>(table) + off);
+}
 
 // One batch: rows -> LDS -> operands -> 16 MFMAs.  `lds` = the wave's 2 KB; only this wave touches it and its LDS
 // instructions execute in order, so no barrier: the accesses alias (may_alias types) and the compiler keeps their order.
 // Lane (g, m), contraction slot e <-> the neighbour in LDS row 4 e + g (both operands: any bijection serves; this one is
-// bank-conflict free).  A = [hi (rows 0..7) | mid (rows 8..15)], A2 = [lo | 0]; both products go to the SAME accumulator
-// (exact products, one fp32 sum): D row m < 8 = sum mask (hi + lo) of feature m, row m >= 8 = sum mask mid of feature m - 8.
+// bank-conflict free).  A = [hi (rows 0..7) | mid (rows 8..15)], A2 = [lo / 2 | lo / 2] (the table stores the halved third
+// part, so no lane has to blank its rows); both products go to the SAME accumulator (exact products, one fp32 sum): D row
+// m < 8 = sum mask (hi + lo / 2) of feature m, row m >= 8 = sum mask (mid + lo / 2) of feature m - 8; every consumer adds the two.
 // FIRST: the item's first batch -- the accumulators start from the MFMA's zero C operand instead of 32 register moves.
 template <bool FIRST>
 __device__ __forceinline__ void v_batch(unsigned char* lds, int lane, u32x4 r0, u32x4 r1, f32x4 (&d)[8]) {
@@ -127,7 +135,6 @@ __device__ __forceinline__ void v_batch(unsigned char* lds, int lane, u32x4 r0, 
     l4[lane] = r0;
     l4[64 + lane] = r1;
     const int g = lane >> 4, m = lane & 15;
-    const unsigned lo_rows = m < 8 ? 0xFFFFFFFFu : 0u;
     const u16_ma* l16 = reinterpret_cast<const u16_ma*>(lds);
     const u8_ma* l8 = reinterpret_cast<const u8_ma*>(lds);
     u32x4 A, A2;
@@ -136,7 +143,7 @@ __device__ __forceinline__ void v_batch(unsigned char* lds, int lane, u32x4 r0, 
     for (int p = 0; p < 4; ++p) {
         const int ra = 4 * (2 * p) + g, rb = 4 * (2 * p + 1) + g;
         A[p] = (unsigned)l16[ra * 32 + m] | ((unsigned)l16[rb * 32 + m] << 16);
-        A2[p] = ((unsigned)l16[ra * 32 + 16 + (m & 7)] | ((unsigned)l16[rb * 32 + 16 + (m & 7)] << 16)) & lo_rows;
+        A2[p] = (unsigned)l16[ra * 32 + 16 + (m & 7)] | ((unsigned)l16[rb * 32 + 16 + (m & 7)] << 16);
         wp[p] = (unsigned)l8[ra * 64 + 48 + m] | ((unsigned)l8[rb * 64 + 48 + m] << 16);
     }
     u32x4 B[8];
@@ -171,9 +178,10 @@ __device__ __forceinline__ void v_wave_quads(const int32_t* __restrict__ ids, co
     const int kq = lane >> 4;
     int J0[V_RING], J1[V_RING];
     u32x4 R0[V_RD], R1[V_RD];
-    const int32_t* idp = ids + (long)first_batch * 32 + (lane >> 2);          // the batch whose ids are fetched next
+    unsigned ido = ((unsigned)first_batch * 32u + (unsigned)(lane >> 2)) * 4u;   // byte offset of the batch whose ids are fetched next
+    auto id_at = [&](unsigned o) { return *reinterpret_cast<const int32_t*>(reinterpret_cast<const unsigned char*>(ids) + o); };
 #pragma unroll
-    for (int s = 0; s < V_RING; ++s) J0[s] = idp[0], J1[s] = idp[16], idp += 32;
+    for (int s = 0; s < V_RING; ++s) J0[s] = id_at(ido), J1[s] = id_at(ido + 64u), ido += 128u;
 #pragma unroll
     for (int s = 0; s < V_RD; ++s) R0[s] = v_row(table, J0[s], lane), R1[s] = v_row(table, J1[s], lane);
     int4 dn = *reinterpret_cast<const int4*>(quads + 16 * (long)qb + 4 * kq);
@@ -211,7 +219,7 @@ __device__ __forceinline__ void v_wave_quads(const int32_t* __restrict__ ids, co
                         const u32x4 a0 = R0[s % V_RD], a1 = R1[s % V_RD];
                         R0[s % V_RD] = v_row(table, J0[(s + V_RD) % V_RING], lane);       // the batch V_RD ahead
                         R1[s % V_RD] = v_row(table, J1[(s + V_RD) % V_RING], lane);
-                        J0[s] = idp[0], J1[s] = idp[16], idp += 32;                       // the ids V_RING ahead
+                        J0[s] = id_at(ido), J1[s] = id_at(ido + 64u), ido += 128u;        // the ids V_RING ahead
                         if (fresh) v_batch<true>(lds, lane, a0, a1, d);
                         else v_batch<false>(lds, lane, a0, a1, d);
                         fresh = false;
@@ -502,7 +510,7 @@ extern "C" int acm_acmii_table(int64_t n_rows, int f_in, const float* x, int64_t
 static int acmii_v_check_operator(const acm_csr_t* a, const void* table, const char* who) {
     ACM_REQUIRE(a && table, ACM_EINVAL, "%s: NULL argument", who);
     ACM_REQUIRE(a->vals == nullptr, ACM_EUNSUPPORTED, "%s: pattern-only operators only (explicit values scale the inputs, not the masks)", who);
-    ACM_REQUIRE(a->nnz > 0 && a->n_cols < ((int64_t)1 << 31) - 1, ACM_EUNSUPPORTED, "%s: empty operator / too many columns", who);
+    ACM_REQUIRE(a->nnz > 0 && (a->n_cols + 1) * 64 < ((int64_t)1 << 32), ACM_EUNSUPPORTED, "%s: empty operator / a table of 4 GB or more", who);
     ACM_REQUIRE(((uintptr_t)table) % 16 == 0, ACM_EINVAL, "%s: table not 16-byte aligned", who);
     ACM_REQUIRE(a->n_long == 0 || a->long_index, ACM_EUNSUPPORTED, "%s: handle without a long-row index", who);
     ACM_REQUIRE(a->item_streams, ACM_EINVAL, "%s: the operator has no item streams (acm_csr_build_item_streams)", who);

@@ -733,7 +733,7 @@ int acm_conv_acmii_fwd(const acm_csr_t* a_low, const acm_conv_acmii_fwd_t* p,
  * Replaces, for ACM-Geometric/layers.py:94-99 with f_in <= 8 and f_out = 64: torch.mm + F.relu + torch.spmm (x2) of the
  * forward, and SpmmBackward (x2) + ReluBackward + MmBackward of weight_low / weight_high.
  *
- *   acm_acmii_table        one 64-byte row per node, [x hi | x mid | x lo (8 bf16 each) | 16 mask bytes], plus an all-zero
+ *   acm_acmii_table        one 64-byte row per node, [x hi | x mid | x lo / 2 (8 bf16 each) | 16 mask bytes], plus an all-zero
  *                          row n_rows.  Rebuilt whenever x (input dropout) or the weights change: every training step.
  *                          x: [n_rows, ld_x >= 8], zero padded beyond f_in, 8-byte aligned rows.
  *   acm_conv_acmii_v_fwd   acm_conv_acmii_fwd's outputs from the table (p->xg is not read; p->row_scale is required;

@@ -27,7 +27,7 @@ def _pattern(n, density, seed, hub=0, empty=()):
 
 
 def _bf16_parts(row_dwords):
-    """[hi (4 dwords) | mid | lo | masks] -> float32 hi, mid, lo of the eight features"""
+    """[hi (4 dwords) | mid | lo / 2 | masks] -> float32 hi, mid, lo / 2 of the eight features"""
     out = []
     for part in range(3):
         d = row_dwords[:, 4 * part:4 * part + 4].astype(np.uint32)
@@ -63,7 +63,7 @@ def test_table_rows_are_exact_splits_and_the_masks_of_the_projection(n, f_in):
     assert not rows[n].any()                                         # the zero row idle slots fetch
     hi, mid, lo = _bf16_parts(rows[:n])
     xs = x8.numpy()
-    assert np.array_equal((hi.astype(np.float64) + mid + lo).astype(np.float32), xs)          # x = hi + mid + lo, exactly
+    assert np.array_equal((hi.astype(np.float64) + mid + 2.0 * lo).astype(np.float32), xs)    # x = hi + mid + 2 (lo / 2), exactly
     assert np.array_equal(hi.view(np.uint32) & 0xFFFF, np.zeros_like(hi, np.uint32))
     # mask byte m of a row: bit 4 ch + t = [x W_ch[:, 16 t + m] > 0]; a sign may differ only where z is rounding noise
     mb = rows[:n, 12:16].copy().view(np.uint8).reshape(n, 16)
