@@ -48,6 +48,139 @@ __global__ __launch_bounds__(256) void bias_act_bwd_kernel(long n_rows, int f, c
 
 int bias_bwd_blocks(int64_t n_rows) { return (int)(n_rows < 1024 ? (n_rows < 1 ? 1 : n_rows) : 1024); }
 
+// ---- the residual Linear on a NARROW dense input (f_in <= 16: the raw features; 7 columns on twitch-gamer), as streaming
+// kernels.  A wave takes chunks of EIGHT consecutive rows (chunk = wave index + k * waves): the 8 x FI block of X goes through
+// 256-512 B of wave-private LDS (one coalesced load, then broadcast reads: no barrier, one wave, in-order LDS), lane = output
+// column, 8 (forward: stores) or 16 (backward: Y and dY) row accesses in flight.
+template <int FI>
+__device__ __forceinline__ void stage_x_rows(float* xs, const float* __restrict__ x, long ldx, long r0, long n_rows, int f_in, int lane) {
+#pragma unroll
+    for (int e0 = 0; e0 < 8 * FI; e0 += 64) {
+        const int e = e0 + lane, u = e / FI, f = e % FI;
+        const long r = r0 + u;
+        xs[e] = (r < n_rows && f < f_in) ? x[r * ldx + f] : 0.f;
+    }
+}
+
+// Forward: Y = dropout(relu(X W^T + b)).  The product is an fmaf chain in k order from zero, bias -> ReLU -> dropout after it: the
+// arithmetic (and the bits) of the GEMM route with its epilogue.  The counter-based mask: one Philox call yields the factors
+// of columns i, i + 16, i + 32, i + 48 of a row (acm_drop4), so lane row g of the wave draws for row g of a half chunk and
+// the 64 factors of a row meet in LDS -- a quarter of the per-element calls of the GEMM epilogue.
+template <int FI>
+__global__ __launch_bounds__(256) void linear_fwd_narrow_kernel(long n_rows, int f_in, int f_out, const float* __restrict__ x, long ldx,
+                                                                const float* __restrict__ w, long ldw, const float* __restrict__ bias,
+                                                                int relu, acm_dropout_t drop, float* __restrict__ y, long ldy) {
+    __shared__ __attribute__((aligned(16))) float xs_all[4][8 * FI];
+    __shared__ float fac_all[4][8 * 64];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, g = lane >> 4, i = lane & 15;
+    float* xs = xs_all[wv];
+    float* fac = fac_all[wv];
+    const long n_waves = (long)gridDim.x * 4, gw = (long)blockIdx.x * 4 + wv;
+    const AcmDropCtx dc = acm_drop_ctx(drop);
+    const long n_chunks = (n_rows + 7) / 8;
+    for (int c0 = 0; c0 < f_out; c0 += 64) {
+        const int o = c0 + lane;
+        const bool ok = o < f_out;
+        float wr[FI];
+#pragma unroll
+        for (int f = 0; f < FI; ++f) wr[f] = (ok && f < f_in) ? w[(long)o * ldw + f] : 0.f;
+        const float b = (ok && bias) ? bias[o] : 0.f;
+        for (long ch = gw; ch < n_chunks; ch += n_waves) {
+            const long r0 = ch * 8;
+            stage_x_rows<FI>(xs, x, ldx, r0, n_rows, f_in, lane);
+            if (dc.on) {
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    float f4[4];
+                    acm_drop4(dc, r0 + 4 * h + g, i + 16 * (c0 >> 6), f4);
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) fac[(4 * h + g) * 64 + 16 * q + i] = f4[q];
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const long r = r0 + u;
+                float v = 0.f;
+#pragma unroll
+                for (int f = 0; f < FI; ++f)
+                    if (f < f_in) v = fmaf(xs[u * FI + f], wr[f], v);
+                v += b;
+                if (relu) v = fmaxf(v, 0.f);
+                if (dc.on) v *= fac[u * 64 + lane];
+                if (ok && r < n_rows) y[r * ldy + o] = v;
+            }
+        }
+    }
+}
+
+// Backward: dW = G^T X and db = column sums of G in ONE pass over (Y, dY, X), G = bias_act_bwd_kernel's gradient formed in
+// registers and never stored -- the two launches it replaces wrote and re-read the [n, f_out] matrix G (2 x 43 MB on the
+// twitch graph) and ran 64 of 256 threads.  Fixed summation order: deterministic.
+// partial: [groups of 32 columns][block][32], column = f * f_out + o (f = f_in: the bias).
+template <int FI>
+__global__ __launch_bounds__(256) void linear_bwd_narrow_kernel(long n_rows, int f_in, int f_out, const float* __restrict__ x, long ldx,
+                                                                const float* __restrict__ y, long ldy, const float* __restrict__ dy,
+                                                                long lddy, float inv_keep, int relu, float* __restrict__ partial) {
+    __shared__ __attribute__((aligned(16))) float xs_all[4][8 * FI];
+    __shared__ float red[4][64 * (FI + 1)];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    float* xs = xs_all[wv];
+    const long n_waves = (long)gridDim.x * 4, gw = (long)blockIdx.x * 4 + wv;
+    const long gstride = (long)gridDim.x * 32;
+    const long n_chunks = (n_rows + 7) / 8;
+    for (int c0 = 0; c0 < f_out; c0 += 64) {
+        const int o = c0 + lane;
+        const bool ok = o < f_out;
+        const int oc = ok ? o : 0;
+        float acc[FI], accb = 0.f;
+#pragma unroll
+        for (int f = 0; f < FI; ++f) acc[f] = 0.f;
+        for (long ch = gw; ch < n_chunks; ch += n_waves) {
+            const long r0 = ch * 8;
+            float gv[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const long r = r0 + u;
+                const bool in = r < n_rows;
+                const long rc = in ? r : r0;
+                const float out = y[rc * ldy + oc];
+                float v = dy[rc * lddy + oc];
+                // (bias_act_bwd_kernel's formula: both masks are read off the forward's output)
+                if (relu) v = out > 0.f ? v * inv_keep : 0.f;
+                else if (inv_keep != 1.f) v = out != 0.f ? v * inv_keep : 0.f;
+                gv[u] = (in && ok) ? v : 0.f;
+            }
+            stage_x_rows<FI>(xs, x, ldx, r0, n_rows, f_in, lane);
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                accb += gv[u];
+#pragma unroll
+                for (int f = 0; f < FI; ++f)
+                    if (f < f_in) acc[f] = fmaf(gv[u], xs[u * FI + f], acc[f]);
+            }
+        }
+#pragma unroll
+        for (int f = 0; f < FI; ++f) red[wv][f * 64 + lane] = acc[f];
+        red[wv][FI * 64 + lane] = accb;
+        __syncthreads();
+        for (int q = threadIdx.x; q < 64 * (FI + 1); q += 256) {
+            const int f = q >> 6, l = q & 63;
+            const int fo = f == FI ? f_in : f;           // the bias sits behind the f_in weight rows
+            if ((f < f_in || f == FI) && c0 + l < f_out) {
+                const float s = (red[0][q] + red[1][q]) + (red[2][q] + red[3][q]);
+                const int col = fo * f_out + c0 + l;
+                partial[(long)(col >> 5) * gstride + (long)blockIdx.x * 32 + (col & 31)] = s;
+            }
+        }
+        __syncthreads();
+    }
+}
+
+int linear_bwd_blocks(int64_t n_rows) {
+    const int64_t b = (n_rows + 63) / 64;                // >= 16 rows per wave before another block pays
+    return (int)(b < 1 ? 1 : (b > 2048 ? 2048 : b));
+}
+
 }  // namespace
 
 extern "C" int acm_bias_act(int64_t n_rows, int f, float* Y, int64_t ldy, const float* bias, int relu,
@@ -91,4 +224,61 @@ extern "C" int acm_bias_act_bwd(int64_t n_rows, int f, const float* Y, int64_t l
     ACM_CHECK_HIP(hipGetLastError());
     const acm_reduce_seg_t seg = {partial, nblk, f, 0, f, d_bias, f, 0, 0, 0};
     return acm_reduce_emit(defer, &seg, 1, (hipStream_t)stream);
+}
+
+extern "C" int acm_linear_bwd_workspace_bytes(int64_t n_rows, int f_in, int f_out, size_t* bytes) {
+    ACM_REQUIRE(bytes, ACM_EINVAL, "acm_linear_bwd_workspace_bytes: NULL argument");
+    ACM_REQUIRE(n_rows >= 0 && f_in >= 1 && f_in <= 16 && f_out >= 1 && f_out <= 256, ACM_EUNSUPPORTED,
+                "acm_linear_bwd: f_in %d (1..16), f_out %d (1..256)", f_in, f_out);
+    const size_t groups = ((size_t)(f_in + 1) * f_out + 31) / 32;
+    *bytes = groups * (size_t)linear_bwd_blocks(n_rows) * 32 * sizeof(float);
+    return ACM_OK;
+}
+
+extern "C" int acm_linear_bwd(int64_t n_rows, int f_in, int f_out, const float* X, int64_t ldx, const float* Y, int64_t ldy,
+                              const float* dY, int64_t lddy, float keep_scale, int relu, float* dW, int64_t lddw, float* d_bias,
+                              void* workspace, size_t workspace_bytes, acm_reduce_list_t* defer, acm_stream_t stream) {
+    ACM_REQUIRE(X && Y && dY && dW && d_bias, ACM_EINVAL, "acm_linear_bwd: NULL argument");
+    size_t need = 0;
+    const int st = acm_linear_bwd_workspace_bytes(n_rows, f_in, f_out, &need);
+    if (st != ACM_OK) return st;
+    ACM_REQUIRE(ldx >= f_in && ldy >= f_out && lddy >= f_out && lddw >= f_in && keep_scale >= 1.f, ACM_ESHAPE,
+                "acm_linear_bwd: leading dimensions / scale");
+    ACM_REQUIRE(workspace && workspace_bytes >= need && ((uintptr_t)workspace) % 16 == 0, ACM_ENOMEM,
+                "acm_linear_bwd: workspace %zu B < required %zu B (or not 16-byte aligned)", workspace_bytes, need);
+    ACM_REQUIRE(n_rows < ((int64_t)1 << 40), ACM_EUNSUPPORTED, "acm_linear_bwd: %lld rows", (long long)n_rows);
+    hipStream_t s = (hipStream_t)stream;
+    const int nblk = linear_bwd_blocks(n_rows);
+    float* partial = (float*)workspace;
+    if (n_rows == 0) ACM_CHECK_HIP(hipMemsetAsync(partial, 0, need, s));
+    else if (f_in <= 8)
+        hipLaunchKernelGGL(linear_bwd_narrow_kernel<8>, dim3(nblk), dim3(256), 0, s, (long)n_rows, f_in, f_out, X, (long)ldx, Y, (long)ldy,
+                           dY, (long)lddy, keep_scale, relu, partial);
+    else
+        hipLaunchKernelGGL(linear_bwd_narrow_kernel<16>, dim3(nblk), dim3(256), 0, s, (long)n_rows, f_in, f_out, X, (long)ldx, Y, (long)ldy,
+                           dY, (long)lddy, keep_scale, relu, partial);
+    ACM_CHECK_HIP(hipGetLastError());
+    // dW[o][f] <- column f * f_out + o: inner = f_out columns per "row" f, destination o * lddw + f (col_block 1, block_stride lddw)
+    const acm_reduce_seg_t segs[2] = {{partial, nblk, 32, 0, f_in * f_out, dW, f_out, 1, 1, lddw, nblk * 32, 0},
+                                      {partial, nblk, 32, f_in * f_out, f_out, d_bias, f_out, 0, 0, 0, nblk * 32, 0}};
+    return acm_reduce_emit(defer, segs, 2, s);
+}
+
+// acm_linear_fwd's route for narrow inputs (called from acm_gemm.hip); ACM_EUNSUPPORTED: the GEMM route
+int acm_linear_fwd_narrow(int64_t n_rows, int64_t f_in, int64_t f_out, const float* X, int64_t ldx, const float* W, int64_t ldw,
+                          const float* bias, int relu, const acm_dropout_t* drop, float* Y, int64_t ldy, hipStream_t s) {
+    if (f_in < 1 || f_in > 16 || f_out < 1 || f_out > 256 || n_rows < 1024) return ACM_EUNSUPPORTED;
+    acm_dropout_t d = {0.f, 0, 0, nullptr, 0};
+    if (drop) d = *drop;
+    ACM_REQUIRE(d.p == 0.f || (d.p > 0.f && d.p < 1.f && d.step), ACM_EINVAL, "acm_linear_fwd: bad dropout spec");
+    ACM_REQUIRE(ldx >= f_in && ldw >= f_in && ldy >= f_out, ACM_ESHAPE, "acm_linear_fwd: leading dimension too small");
+    const int nblk = linear_bwd_blocks(n_rows);
+    if (f_in <= 8)
+        hipLaunchKernelGGL(linear_fwd_narrow_kernel<8>, dim3(nblk), dim3(256), 0, s, (long)n_rows, (int)f_in, (int)f_out, X, (long)ldx, W,
+                           (long)ldw, bias, relu, d, Y, (long)ldy);
+    else
+        hipLaunchKernelGGL(linear_fwd_narrow_kernel<16>, dim3(nblk), dim3(256), 0, s, (long)n_rows, (int)f_in, (int)f_out, X, (long)ldx, W,
+                           (long)ldw, bias, relu, d, Y, (long)ldy);
+    ACM_CHECK_HIP(hipGetLastError());
+    return ACM_OK;
 }

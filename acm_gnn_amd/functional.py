@@ -901,9 +901,29 @@ class _ResidualLinear(torch.autograd.Function):
         n, f_out = y.shape
         f_in = w.shape[1]
         dev = y.device
-        g = torch.empty(n, f_out, dtype=_F32, device=dev)
         flat = torch.empty(f_out * f_in + f_out, dtype=_F32, device=dev)      # [dW | db]: one all-reduce when sharded
         d_w, d_b = flat[: f_out * f_in].view(f_out, f_in), flat[f_out * f_in:]
+        if ctx.sparse_x is None and not ctx.needs_input_grad[0] and f_in <= 16 and f_out <= 256:
+            # a narrow dense input that takes no gradient (the raw features): dW and db in ONE pass over (y, dy, x), the
+            # [n, f_out] matrix G = dL/d(pre-activation) never stored (acm_linear_bwd)
+            nbytes = C.c_size_t()
+            _lib.check(lib.acm_linear_bwd_workspace_bytes(n, f_in, f_out, C.byref(nbytes)), "acm_linear_bwd_workspace_bytes")
+            ws = torch.empty(max(nbytes.value // 4, 1), dtype=_F32, device=dev)
+            with _device_ctx(dev), _Timed(f"linear_bwd/{n}x{f_out}x{f_in}"):
+                st = lib.acm_linear_bwd(n, f_in, f_out, _vp(x), x.stride(0), _vp(y), y.stride(0), _vp(dy), dy.stride(0),
+                                        float(ctx.keep_scale), int(ctx.relu), _vp(d_w), f_in, _vp(d_b), _vp(ws), nbytes.value,
+                                        ctx.defer.pointer() if ctx.defer is not None else None, _stream())
+            _lib.check(st, "acm_linear_bwd")
+            if ctx.defer is not None:
+                ctx.defer.hold(ws, [d_w, d_b], keep=[flat, x, y, dy])
+            if ctx.group is not None:
+                import torch.distributed as dist
+                if ctx.defer is not None:
+                    ctx.defer.allreduce(flat, ctx.group)
+                else:
+                    dist.all_reduce(flat, group=ctx.group)
+            return None, d_w, (d_b if ctx.has_bias else None), None, None, None, None
+        g = torch.empty(n, f_out, dtype=_F32, device=dev)
         nbytes = C.c_size_t()
         _lib.check(lib.acm_bias_act_bwd_workspace_bytes(n, f_out, C.byref(nbytes)), "acm_bias_act_bwd_workspace_bytes")
         ws = torch.empty(max(nbytes.value // 4, 1), dtype=_F32, device=dev)

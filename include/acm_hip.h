@@ -350,6 +350,15 @@ int acm_bias_act_bwd_workspace_bytes(int64_t n_rows, int f, size_t* bytes);
 int acm_bias_act_bwd(int64_t n_rows, int f, const float* Y, int64_t ldy, const float* dY, int64_t lddy,
                      float keep_scale, int relu, float* G, int64_t ldg, float* d_bias,
                      void* workspace, size_t workspace_bytes, acm_reduce_list_t* defer, acm_stream_t stream);
+/*   acm_linear_bwd    (ABI 24) the whole backward of that Linear on a NARROW dense input that takes no gradient (f_in <= 16:
+ *                     the raw features of twitch-gamer, 7 columns): dW = G^T X ([f_out, f_in], pitch lddw) and d_bias =
+ *                     column sums of G in ONE pass over (Y, dY, X), G as acm_bias_act_bwd forms it but never stored --
+ *                     replaces acm_bias_act_bwd + acm_gemm(transA) and the [n_rows, f_out] matrix between them.
+ *                     Deterministic; both sums honour `defer`.  f_out <= 256. */
+int acm_linear_bwd_workspace_bytes(int64_t n_rows, int f_in, int f_out, size_t* bytes);
+int acm_linear_bwd(int64_t n_rows, int f_in, int f_out, const float* X, int64_t ldx, const float* Y, int64_t ldy,
+                   const float* dY, int64_t lddy, float keep_scale, int relu, float* dW, int64_t lddw, float* d_bias,
+                   void* workspace, size_t workspace_bytes, acm_reduce_list_t* defer, acm_stream_t stream);
 
 /* ----------------------------------------------------------------- SpMM --
  * Y[r, 0:width] = sum_j A[r,j] * G[j, 0:width]   (plain CSR x dense; used for

@@ -558,6 +558,22 @@ class FakeLib:
         Y[...] = out * dropout_factors(self._drop_obj(drop), n, f)
         return 0
 
+    def acm_linear_bwd_workspace_bytes(self, n, f_in, f_out, out):
+        if f_in > 16 or f_out > 256:
+            self._err = b"acm_linear_bwd: unsupported shape"
+            return 4
+        out._obj.value = 64
+        return 0
+
+    def acm_linear_bwd(self, n, f_in, f_out, x, ldx, y, ldy, dy, lddy, keep, relu, dw, lddw, db, ws, wsb, defer, stream):
+        Y, G = _view(y, n, f_out, ldy).astype(np.float64), _view(dy, n, f_out, lddy).astype(np.float64)
+        if relu:
+            G = np.where(Y > 0, G * keep, 0.0)
+        elif keep != 1.0:
+            G = np.where(Y != 0, G * keep, 0.0)
+        X = _view(x, n, f_in, ldx).astype(np.float64)
+        return self._emit(defer, [(_view(dw, f_out, f_in, lddw), G.T @ X), (_vec(db, f_out), G.sum(0))])
+
     def acm_bias_act_bwd_workspace_bytes(self, n, f, out):
         out._obj.value = 4 * f * min(max(n, 1), 1024)
         return 0

@@ -564,3 +564,83 @@ def test_wide_weight_gradient_with_the_dropout_in_the_operand_load():
     ref = xd.cpu().double().T @ dz.cpu().double()
     scale = xd.cpu().abs().double().T @ dz.cpu().abs().double()
     assert float(((dw.cpu().double() - ref).abs() / (scale + 1e-30)).max()) < 1e-6
+
+
+@pytest.mark.parametrize("n,f_in,f_out,relu,p", [(1, 1, 2, 1, 0.0), (1000, 7, 64, 1, 0.3), (70001, 16, 200, 0, 0.4), (4099, 9, 33, 1, 0.0),
+                                                 (168114, 7, 64, 1, 0.1)])
+def test_linear_backward_in_one_pass_matches_fp64(n, f_in, f_out, relu, p):
+    """acm_linear_bwd (the ACM-GCN++ residual Linear on a narrow dense input, models.py:26-27,55-56 backward): dW = G^T X and
+    db = column sums of G with G = dY * keep * [Y > 0] formed in registers -- against float64 and against the two calls it
+    replaces (acm_bias_act_bwd + acm_gemm), twice over bit for bit; padded pitches."""
+    import ctypes as C
+    from acm_gnn_amd import _lib, functional as AF
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(n + f_in)
+    ldx, ldy = f_in + (n % 2), f_out + 3
+    x = torch.randn(n, ldx, generator=g).to(DEV)
+    pre = torch.randn(n, ldy, generator=g)
+    keep = (torch.rand(n, ldy, generator=g) >= p).float() / (1.0 - p) if p else torch.ones(n, ldy)
+    y = ((pre.clamp_min(0) if relu else pre) * keep).to(DEV)
+    dy = torch.randn(n, ldy, generator=g).to(DEV)
+    ks = 1.0 / (1.0 - p)
+    nb = C.c_size_t()
+    _lib.check(lib.acm_linear_bwd_workspace_bytes(n, f_in, f_out, C.byref(nb)))
+    ws = torch.empty(nb.value // 4, device=DEV)
+    outs = []
+    for _ in range(2):
+        dw = torch.full((f_out, f_in + 1), float("nan"), device=DEV)
+        db = torch.full((f_out,), float("nan"), device=DEV)
+        _lib.check(lib.acm_linear_bwd(n, f_in, f_out, x.data_ptr(), ldx, y.data_ptr(), ldy, dy.data_ptr(), ldy, ks, relu, dw.data_ptr(),
+                                      f_in + 1, db.data_ptr(), ws.data_ptr(), nb.value, None, None), "acm_linear_bwd")
+        torch.cuda.synchronize()
+        outs.append((dw.clone(), db.clone()))
+    assert torch.equal(outs[0][0][:, :f_in], outs[1][0][:, :f_in]) and torch.equal(outs[0][1], outs[1][1])
+    assert torch.isnan(outs[0][0][:, f_in]).all()                       # the pitch column is not written
+    y64, dy64, x64 = (t.cpu().double() for t in (y[:, :f_out], dy[:, :f_out], x[:, :f_in]))
+    g64 = torch.where(y64 > 0, dy64 * ks, torch.zeros_like(dy64)) if relu else (
+        torch.where(y64 != 0, dy64 * ks, torch.zeros_like(dy64)) if p else dy64)
+    want_w, want_b = g64.t() @ x64, g64.sum(0)
+    scale = max(1.0, float(want_w.abs().max()))
+    assert float((outs[0][0][:, :f_in].cpu().double() - want_w).abs().max()) < 2e-5 * scale
+    assert float((outs[0][1].cpu().double() - want_b).abs().max()) < 2e-5 * max(1.0, float(want_b.abs().max()))
+    assert lib.acm_linear_bwd_workspace_bytes(n, 17, f_out, C.byref(nb)) == 4
+
+
+@pytest.mark.parametrize("f_in,f_out,relu,p", [(7, 64, 1, 0.3), (16, 200, 0, 0.0), (1, 2, 1, 0.5), (9, 65, 1, 0.0)])
+def test_linear_forward_of_a_narrow_input_streams_with_the_bits_of_the_gemm_route(f_in, f_out, relu, p):
+    """acm_linear_fwd with f_in <= 16 and >= 1024 rows runs the streaming kernel of acm_linear.hip; fewer rows run the MFMA
+    tile GEMM with the same epilogue.  Same fmaf chain in k order, same bias -> ReLU -> dropout: the first rows of a long
+    call equal a short call bit for bit (the counter-based mask depends on the row index only), and both match float64."""
+    import ctypes as C
+    from acm_gnn_amd import _lib, functional as AF
+    lib = _lib.load()
+    n, m = 70003, 1000
+    g = torch.Generator().manual_seed(f_in * 100 + f_out)
+    x = torch.randn(n, f_in + 1, generator=g).to(DEV)
+    w = torch.randn(f_out, f_in, generator=g).to(DEV)
+    b = torch.randn(f_out, generator=g).to(DEV)
+    state = AF.DropoutState(DEV, seed=11)
+    spec = AF._drop_spec((p, 3, state), 0) if p else None
+    outs = []
+    for rows in (n, m):
+        y = torch.full((rows, f_out + 2), float("nan"), device=DEV)
+        nb = C.c_size_t()
+        _lib.check(lib.acm_gemm_workspace_bytes(0, 1, rows, f_out, f_in, C.byref(nb)))
+        ws = torch.empty(max(nb.value // 4, 1), device=DEV)
+        _lib.check(lib.acm_linear_fwd(rows, f_in, f_out, x.data_ptr(), f_in + 1, w.data_ptr(), f_in, b.data_ptr(), relu,
+                                      C.byref(spec) if spec is not None else None, y.data_ptr(), f_out + 2, ws.data_ptr(), nb.value, None),
+                   "acm_linear_fwd")
+        torch.cuda.synchronize()
+        outs.append(y)
+    assert torch.equal(outs[0][:m, :f_out], outs[1][:, :f_out])
+    assert torch.isnan(outs[0][:, f_out:]).all()
+    pre = x[:, :f_in].cpu().double() @ w.cpu().double().t() + b.cpu().double()
+    if relu:
+        pre = pre.clamp_min(0)
+    got = outs[0][:, :f_out].cpu().double()
+    kept = got != 0 if p else torch.ones_like(got, dtype=torch.bool)
+    scale = 1.0 / (1.0 - p)
+    assert float(((got - pre * scale) * kept).abs().max()) < 2e-5 * max(1.0, float(pre.abs().max()))
+    if p:
+        frac = float(((got == 0) & (pre > 1e-6 if relu else pre.abs() > 1e-6)).double().mean() / max(float((pre > 1e-6 if relu else pre.abs() > 1e-6).double().mean()), 1e-9))
+        assert abs(frac - p) < 0.02
