@@ -325,8 +325,12 @@ class InputPipeline:
         from .graph import FilterOperators
         if tuning.HOST.pipeline <= 0 or not isinstance(ops, FilterOperators) or not isinstance(x, torch.Tensor):
             return False
-        if getattr(model, "model_type", None) not in ("acmgcn", "acmgcnp"):
+        if getattr(model, "model_type", None) not in ("acmgcn", "acmgcnp", "acmgcnpp"):
             return False
+        if model.model_type == "acmgcnpp":       # the residual Linear reads the table too: its fused form only (it then takes
+            lins = getattr(getattr(model, "mlpX", None), "lins", None)          # this step's rows from ``saved`` in its backward)
+            if lins is None or len(lins) != 1 or lins[0].out_features > 256:
+                return False
         gcns = getattr(model, "gcns", None)
         if not gcns or len(gcns) != 2 or not getattr(model, "fused_dropout", False) or getattr(model, "dropout", 0) <= 0:
             return False
@@ -858,9 +862,12 @@ class _ResidualLinear(torch.autograd.Function):
     acm_bias_act_bwd (masks read off y), then dW = G^T x; row-sharded runs sum [dW | db] over the ranks."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, relu, drop, group, call=None):
+    def forward(ctx, x, weight, bias, relu, drop, group, call=None, pipe=None):
         lib = _lib.load()
         ctx.defer = call.defer if call is not None else None
+        # ``pipe``: x is the input pipeline's table (InputPipeline.local_table()), which the first layer's forward refills
+        # with the NEXT step's dropped input once it has adopted it -- this step's rows are then in pipe.saved[0]
+        ctx.pipe = pipe
         sparse_x = isinstance(x, SparseFeatures)
         w = _as_f32c(weight, "weight")
         b = _as_f32c(bias, "bias") if bias is not None else None
@@ -897,6 +904,8 @@ class _ResidualLinear(torch.autograd.Function):
     def backward(ctx, dy):
         lib = _lib.load()
         x, w, y = ctx.saved_tensors
+        if ctx.pipe is not None and ctx.pipe.adopted:
+            x = ctx.pipe.saved[0]                 # (the table itself holds step t + 1's rows by now)
         dy = _as_f32c(dy, "grad")
         n, f_out = y.shape
         f_in = w.shape[1]
@@ -922,7 +931,7 @@ class _ResidualLinear(torch.autograd.Function):
                     ctx.defer.allreduce(flat, ctx.group)
                 else:
                     dist.all_reduce(flat, group=ctx.group)
-            return None, d_w, (d_b if ctx.has_bias else None), None, None, None, None
+            return None, d_w, (d_b if ctx.has_bias else None), None, None, None, None, None
         g = torch.empty(n, f_out, dtype=_F32, device=dev)
         nbytes = C.c_size_t()
         _lib.check(lib.acm_bias_act_bwd_workspace_bytes(n, f_out, C.byref(nbytes)), "acm_bias_act_bwd_workspace_bytes")
@@ -954,16 +963,18 @@ class _ResidualLinear(torch.autograd.Function):
                 ctx.defer.allreduce(flat, ctx.group)
             else:
                 dist.all_reduce(flat, group=ctx.group)
-        return d_x, d_w, (d_b if ctx.has_bias else None), None, None, None, None
+        return d_x, d_w, (d_b if ctx.has_bias else None), None, None, None, None, None
 
 
-def residual_linear(x, weight, bias, relu=True, drop=None, group=None, call=None):
+def residual_linear(x, weight, bias, relu=True, drop=None, group=None, call=None, pipe=None):
     """dropout(relu(x @ weight.T + bias)) on the HIP kernels.  ``drop = (p, tag, DropoutState, row_offset)`` draws the
     counter-based mask in the epilogue; ``group``: row-sharded run (the parameter gradients are summed over it);
-    ``call``: the model call's CallContext (its deferral list; default: the thread's ambient one)."""
+    ``call``: the model call's CallContext (its deferral list; default: the thread's ambient one); ``pipe``: x is the
+    table of that InputPipeline (the backward then reads this step's rows from its saved copy once the first layer's forward
+    has refilled the table)."""
     if drop is not None and not drop[0] > 0:
         drop = None
-    return _ResidualLinear.apply(x, weight, bias, bool(relu), drop, group, _call_or_ambient(call))
+    return _ResidualLinear.apply(x, weight, bias, bool(relu), drop, group, _call_or_ambient(call), pipe)
 
 
 # --------------------------------------------------------------------------

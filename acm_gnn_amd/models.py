@@ -74,7 +74,7 @@ class GCN(nn.Module):
         if self.model_type == "acmgcnpp":
             self.mlpX.reset_parameters()
 
-    def _residual(self, x, adj_low, drop=None, call=None):
+    def _residual(self, x, adj_low, drop=None, call=None, pipe=None):
         """relu(Linear(x)) of the ACM-GCN++ branch (ACM-Geometric/models.py:26-27,55-56), optionally with the
         counter-based dropout in the same epilogue (``drop`` = (p, tag, state, row_offset)): one GEMM launch
         (functional.residual_linear; CSR features: acm_spmm_v + acm_bias_act).  Row-sharded: the Linear's weight / bias
@@ -85,7 +85,7 @@ class GCN(nn.Module):
         group = ops.group if (ops is not None and ops.sharded) else None
         if len(self.mlpX.lins) == 1 and self.mlpX.lins[0].out_features <= 256:      # (acm_bias_act_bwd's column budget)
             lin = self.mlpX.lins[0]
-            return AF.residual_linear(x, lin.weight, lin.bias, relu=True, drop=drop, group=group, call=call)
+            return AF.residual_linear(x, lin.weight, lin.bias, relu=True, drop=drop, group=group, call=call, pipe=pipe)
         if group is not None:
             raise NotImplementedError("row-sharded acmgcnpp supports init_layers_X = 1 with nhid <= 256 (the torch fallback "
                                       "does not reduce its gradients over the ranks)")
@@ -139,7 +139,9 @@ class GCN(nn.Module):
         if self.model_type == "acmsgc":
             return self.gcns[0](x, adj_low, adj_high, adj_low_unnormalized, rows_permuted=self._rows_permuted, call=call, **kw)
         if self.model_type == "acmgcnpp":
-            xx = self._residual(x, adj_low, drop=(p, 2, st, off), call=call)
+            # (piped: x is the pipeline's table, which the first layer's forward below refills for the next step)
+            xx = self._residual(x, adj_low, drop=(p, 2, st, off), call=call,
+                                pipe=call.pipe if (not isinstance(x, SparseFeatures) and piped) else None)
         # the output layer's narrow projection may ride the hidden layer's epilogue (CallContext.next_proj / pre_proj); not
         # with the ACM-GCN++ residual, which changes the hidden activations in between
         call.next_proj = self.gcns[1] if self.model_type != "acmgcnpp" else None

@@ -232,7 +232,8 @@ def _pipeline_case(n, avg, seed, relabel=False):
 
 @pytest.mark.parametrize("use_graph", [False, True], ids=["eager", "graph"])
 @pytest.mark.parametrize("n,avg,model_type", [(3000, 40, "acmgcnp"), (20000, 24, "acmgcnp"), (3000, 40, "acmgcn"),
-                                              (3001, 40, "acmgcnp")])          # 3001: degree relabelling inside the operator
+                                              (3001, 40, "acmgcnp"),           # 3001: degree relabelling inside the operator
+                                              (3000, 40, "acmgcnpp")])         # the residual Linear reads the table too
 def test_input_pipeline_matches_plain_step(monkeypatch, n, avg, model_type, use_graph, tune):
     """TrainStep with the input pipeline (the next step's P = A_low dropout(x) gathered by two extra waves per SIMD of the
     first layer's backward kernel; acm_conv_agg_bwd_t.next_agg, acm_conv_agg_fwd_t.agg_given / agg_copy,

@@ -720,6 +720,34 @@ def _dense_graph_ops(n=160, avg=20, seed=5):
     return make_sharded_operators(low, deg, torch.device("cpu")), n
 
 
+def test_input_pipeline_with_the_residual_branch_of_acmgcnpp(monkeypatch, tune):
+    """ACM-GCN++ under the input pipeline: the residual Linear (models.py:55-56) reads the pipeline's table in its forward
+    and -- because the first layer's forward refills that table with the NEXT step's dropped input -- this step's rows from
+    the pipeline's saved copy in its backward.  Losses and parameters equal the plain step's."""
+    fake_lib.install(monkeypatch)
+    tune(pipeline=32)
+    from acm_gnn_amd import GCN, FusedAdamW, functional as AF, train as T
+    ops, n = _dense_graph_ops()
+    x, y = torch.randn(n, 7, generator=torch.Generator().manual_seed(1)), torch.randint(0, 2, (n,), generator=torch.Generator().manual_seed(2))
+    w = T.row_weights(torch.arange(0, n, 2), n)
+
+    def run(pipeline):
+        torch.manual_seed(0)
+        model = GCN(7, 64, 2, 2, n, 0.3, "acmgcnpp", 0, variant=False, attn_layernorm=True)
+        model.dropout_state = AF.DropoutState(torch.device("cpu"), seed=77)
+        opt = FusedAdamW(model.parameters(), lr=0.02)
+        step = T.TrainStep(model, opt, x, ops, y, w, use_graph=False, fused_dropout=True, pipeline_input=pipeline)
+        losses = [float(step()) for _ in range(5)]
+        return step, losses, {k: v.clone() for k, v in model.state_dict().items()}
+
+    step_a, loss_a, sd_a = run(False)
+    step_b, loss_b, sd_b = run(None)
+    assert step_a.pipe is None and step_b.pipe is not None and step_b.pipe.primed
+    np.testing.assert_allclose(loss_b, loss_a, rtol=1e-5, atol=1e-6)
+    for k in sd_a:
+        np.testing.assert_allclose(sd_b[k].numpy(), sd_a[k].numpy(), rtol=1e-4, atol=1e-5, err_msg=k)
+
+
 def test_input_pipeline_equals_plain_train_step(monkeypatch, tune):
     """train.TrainStep with the input pipeline (functional.InputPipeline: the first layer's P = A_low dropout(x) of step
     t + 1 gathered inside the layer's backward of step t, acm_conv_agg_bwd_t.next_agg / acm_dropout_t.step_offset)
