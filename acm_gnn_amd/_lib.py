@@ -26,7 +26,7 @@ EXPORTED_SYMBOLS = (
     "acm_reduce_flush", "acm_conv_fwd_tail_workspace_bytes", "acm_conv_fwd_tail", "acm_shard_plan",
     "acm_conv_acmii_fwd_workspace_bytes", "acm_conv_acmii_fwd", "acm_linear_fwd", "acm_bias_act", "acm_bias_act_bwd_workspace_bytes", "acm_bias_act_bwd",
     "acm_acmii_table_bytes", "acm_acmii_table", "acm_conv_acmii_v_fwd", "acm_conv_acmii_v_bwd_workspace_bytes", "acm_conv_acmii_v_bwd",
-    "acm_linear_bwd_workspace_bytes", "acm_linear_bwd",
+    "acm_linear_bwd_workspace_bytes", "acm_linear_bwd", "acm_linear_fwd_add", "acm_linear_bwd_recompute",
 )
 
 
@@ -233,6 +233,8 @@ def _declare(lib):
     lib.acm_bias_act.argtypes = [i64, i32, vp, i64, vp, i32, vp, vp]
     lib.acm_linear_bwd_workspace_bytes.argtypes = [i64, i32, i32, C.POINTER(sz)]
     lib.acm_linear_bwd.argtypes = [i64, i32, i32, vp, i64, vp, i64, vp, i64, C.c_float, i32, vp, i64, vp, vp, sz, vp, vp]
+    lib.acm_linear_fwd_add.argtypes = [i64, i32, i32, vp, i64, vp, i64, vp, i32, vp, vp, i64, vp, i64, vp]
+    lib.acm_linear_bwd_recompute.argtypes = [i64, i32, i32, vp, i64, vp, i64, vp, i32, vp, vp, i64, vp, i64, vp, vp, sz, vp, vp]
     lib.acm_bias_act_bwd_workspace_bytes.argtypes = [i64, i32, C.POINTER(sz)]
     lib.acm_bias_act_bwd.argtypes = [i64, i32, vp, i64, vp, i64, C.c_float, i32, vp, i64, vp, vp, sz, vp, vp]
     lib.acm_spmm_workspace_bytes.argtypes = [vp, i32, C.POINTER(sz)]

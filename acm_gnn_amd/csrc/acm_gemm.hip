@@ -31,7 +31,8 @@ int acm_gemm_bx3_tn(int64_t n_rows, int64_t K, int64_t N, const float* X, int64_
                     float* slabs, int blocks, const acm_dropout_t* drop, hipStream_t st);
 
 int acm_linear_fwd_narrow(int64_t n_rows, int64_t f_in, int64_t f_out, const float* X, int64_t ldx, const float* W, int64_t ldw,
-                          const float* bias, int relu, const acm_dropout_t* drop, float* Y, int64_t ldy, hipStream_t s);   // acm_linear.hip
+                          const float* bias, int relu, const acm_dropout_t* drop, float* Y, int64_t ldy, hipStream_t s,
+                          const float* add, int64_t ld_add);   // acm_linear.hip
 
 namespace {
 
@@ -328,7 +329,7 @@ extern "C" int acm_linear_fwd(int64_t n_rows, int64_t f_in, int64_t f_out, const
                               void* workspace, size_t workspace_bytes, acm_stream_t stream) {
     ACM_REQUIRE(X && W && Y, ACM_EINVAL, "acm_linear_fwd: NULL argument");
     {   // a narrow input (the raw features of the ACM-GCN++ residual: f_in <= 16) streams instead (acm_linear.hip)
-        const int st = acm_linear_fwd_narrow(n_rows, f_in, f_out, X, ldx, W, ldw, bias, relu, drop, Y, ldy, (hipStream_t)stream);
+        const int st = acm_linear_fwd_narrow(n_rows, f_in, f_out, X, ldx, W, ldw, bias, relu, drop, Y, ldy, (hipStream_t)stream, nullptr, 0);
         if (st != ACM_EUNSUPPORTED) return st;
     }
     return gemm_core(0, 1, n_rows, f_out, f_in, X, ldx, W, ldw, Y, ldy, 0, 0, 0, nullptr, 0, relu, workspace, workspace_bytes,

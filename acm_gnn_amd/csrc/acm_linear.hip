@@ -69,7 +69,8 @@ __device__ __forceinline__ void stage_x_rows(float* xs, const float* __restrict_
 template <int FI>
 __global__ __launch_bounds__(256) void linear_fwd_narrow_kernel(long n_rows, int f_in, int f_out, const float* __restrict__ x, long ldx,
                                                                 const float* __restrict__ w, long ldw, const float* __restrict__ bias,
-                                                                int relu, acm_dropout_t drop, float* __restrict__ y, long ldy) {
+                                                                int relu, acm_dropout_t drop, const float* add, long ld_add,
+                                                                float* y, long ldy) {
     __shared__ __attribute__((aligned(16))) float xs_all[4][8 * FI];
     __shared__ float fac_all[4][8 * 64];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, g = lane >> 4, i = lane & 15;
@@ -107,7 +108,10 @@ __global__ __launch_bounds__(256) void linear_fwd_narrow_kernel(long n_rows, int
                 v += b;
                 if (relu) v = fmaxf(v, 0.f);
                 if (dc.on) v *= fac[u * 64 + lane];
-                if (ok && r < n_rows) y[r * ldy + o] = v;
+                if (ok && r < n_rows) {
+                    if (add) v += add[r * ld_add + o];          // (y may be add itself: each element is read, then written, by one lane)
+                    y[r * ldy + o] = v;
+                }
             }
         }
     }
@@ -117,14 +121,27 @@ __global__ __launch_bounds__(256) void linear_fwd_narrow_kernel(long n_rows, int
 // registers and never stored -- the two launches it replaces wrote and re-read the [n, f_out] matrix G (2 x 43 MB on the
 // twitch graph) and ran 64 of 256 threads.  Fixed summation order: deterministic.
 // partial: [groups of 32 columns][block][32], column = f * f_out + o (f = f_in: the bias).
-template <int FI>
+// RECOMPUTE: the masks are not read off Y (which the caller no longer has: acm_linear_fwd_add added another tensor to it) but
+// formed again -- the pre-activation by the forward's own fmaf chain (same bits, so the same sign), the dropout factors from
+// the counter (same Philox call per four columns): the pass reads dY and X only.
+struct LinRecompute {
+    const float* w;
+    long ldw;
+    const float* bias;
+    acm_dropout_t drop;
+};
+template <int FI, bool RECOMPUTE>
 __global__ __launch_bounds__(256) void linear_bwd_narrow_kernel(long n_rows, int f_in, int f_out, const float* __restrict__ x, long ldx,
                                                                 const float* __restrict__ y, long ldy, const float* __restrict__ dy,
-                                                                long lddy, float inv_keep, int relu, float* __restrict__ partial) {
+                                                                long lddy, float inv_keep, int relu, LinRecompute rc,
+                                                                float* __restrict__ partial) {
     __shared__ __attribute__((aligned(16))) float xs_all[4][8 * FI];
     __shared__ float red[4][64 * (FI + 1)];
+    __shared__ float fac_all[RECOMPUTE ? 4 : 1][RECOMPUTE ? 8 * 64 : 1];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     float* xs = xs_all[wv];
+    float* fac = fac_all[RECOMPUTE ? wv : 0];
+    const AcmDropCtx dc = acm_drop_ctx(rc.drop);
     const long n_waves = (long)gridDim.x * 4, gw = (long)blockIdx.x * 4 + wv;
     const long gstride = (long)gridDim.x * 32;
     const long n_chunks = (n_rows + 7) / 8;
@@ -132,25 +149,52 @@ __global__ __launch_bounds__(256) void linear_bwd_narrow_kernel(long n_rows, int
         const int o = c0 + lane;
         const bool ok = o < f_out;
         const int oc = ok ? o : 0;
-        float acc[FI], accb = 0.f;
+        float acc[FI], accb = 0.f, wr[FI];
 #pragma unroll
-        for (int f = 0; f < FI; ++f) acc[f] = 0.f;
+        for (int f = 0; f < FI; ++f) {
+            acc[f] = 0.f;
+            wr[f] = (RECOMPUTE && ok && f < f_in) ? rc.w[(long)o * rc.ldw + f] : 0.f;
+        }
+        const float bo = (RECOMPUTE && ok && rc.bias) ? rc.bias[o] : 0.f;
         for (long ch = gw; ch < n_chunks; ch += n_waves) {
             const long r0 = ch * 8;
             float gv[8];
+            if (RECOMPUTE) {
+                stage_x_rows<FI>(xs, x, ldx, r0, n_rows, f_in, lane);
+                if (dc.on) {
+                    const int g = lane >> 4, i = lane & 15;
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        float f4[4];
+                        acm_drop4(dc, r0 + 4 * h + g, i + 16 * (c0 >> 6), f4);
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) fac[(4 * h + g) * 64 + 16 * q + i] = f4[q];
+                    }
+                }
+            }
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
                 const long r = r0 + u;
                 const bool in = r < n_rows;
-                const long rc = in ? r : r0;
-                const float out = y[rc * ldy + oc];
-                float v = dy[rc * lddy + oc];
-                // (bias_act_bwd_kernel's formula: both masks are read off the forward's output)
-                if (relu) v = out > 0.f ? v * inv_keep : 0.f;
-                else if (inv_keep != 1.f) v = out != 0.f ? v * inv_keep : 0.f;
+                const long rw = in ? r : r0;
+                float v = dy[rw * lddy + oc];
+                if (RECOMPUTE) {
+                    float pre = 0.f;
+#pragma unroll
+                    for (int f = 0; f < FI; ++f)
+                        if (f < f_in) pre = fmaf(xs[u * FI + f], wr[f], pre);
+                    pre += bo;
+                    if (relu) v = pre > 0.f ? v : 0.f;
+                    if (dc.on) v *= fac[u * 64 + lane];
+                } else {
+                    const float out = y[rw * ldy + oc];
+                    // (bias_act_bwd_kernel's formula: both masks are read off the forward's output)
+                    if (relu) v = out > 0.f ? v * inv_keep : 0.f;
+                    else if (inv_keep != 1.f) v = out != 0.f ? v * inv_keep : 0.f;
+                }
                 gv[u] = (in && ok) ? v : 0.f;
             }
-            stage_x_rows<FI>(xs, x, ldx, r0, n_rows, f_in, lane);
+            if (!RECOMPUTE) stage_x_rows<FI>(xs, x, ldx, r0, n_rows, f_in, lane);
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
                 accb += gv[u];
@@ -226,6 +270,14 @@ extern "C" int acm_bias_act_bwd(int64_t n_rows, int f, const float* Y, int64_t l
     return acm_reduce_emit(defer, &seg, 1, (hipStream_t)stream);
 }
 
+// dW[o][f] <- column f * f_out + o: inner = f_out columns per "row" f, destination o * lddw + f (col_block 1, block_stride lddw)
+static int linear_bwd_segments(float* partial, int nblk, int f_in, int f_out, float* dW, int64_t lddw, float* d_bias,
+                               acm_reduce_list_t* defer, hipStream_t s) {
+    const acm_reduce_seg_t segs[2] = {{partial, nblk, 32, 0, f_in * f_out, dW, f_out, 1, 1, lddw, nblk * 32, 0},
+                                      {partial, nblk, 32, f_in * f_out, f_out, d_bias, f_out, 0, 0, 0, nblk * 32, 0}};
+    return acm_reduce_emit(defer, segs, 2, s);
+}
+
 extern "C" int acm_linear_bwd_workspace_bytes(int64_t n_rows, int f_in, int f_out, size_t* bytes) {
     ACM_REQUIRE(bytes, ACM_EINVAL, "acm_linear_bwd_workspace_bytes: NULL argument");
     ACM_REQUIRE(n_rows >= 0 && f_in >= 1 && f_in <= 16 && f_out >= 1 && f_out <= 256, ACM_EUNSUPPORTED,
@@ -251,23 +303,55 @@ extern "C" int acm_linear_bwd(int64_t n_rows, int f_in, int f_out, const float* 
     const int nblk = linear_bwd_blocks(n_rows);
     float* partial = (float*)workspace;
     if (n_rows == 0) ACM_CHECK_HIP(hipMemsetAsync(partial, 0, need, s));
-    else if (f_in <= 8)
-        hipLaunchKernelGGL(linear_bwd_narrow_kernel<8>, dim3(nblk), dim3(256), 0, s, (long)n_rows, f_in, f_out, X, (long)ldx, Y, (long)ldy,
-                           dY, (long)lddy, keep_scale, relu, partial);
-    else
-        hipLaunchKernelGGL(linear_bwd_narrow_kernel<16>, dim3(nblk), dim3(256), 0, s, (long)n_rows, f_in, f_out, X, (long)ldx, Y, (long)ldy,
-                           dY, (long)lddy, keep_scale, relu, partial);
+    else {
+        const LinRecompute none = {nullptr, 0, nullptr, {0.f, 0, 0, nullptr, 0}};
+        if (f_in <= 8)
+            hipLaunchKernelGGL((linear_bwd_narrow_kernel<8, false>), dim3(nblk), dim3(256), 0, s, (long)n_rows, f_in, f_out, X, (long)ldx, Y,
+                               (long)ldy, dY, (long)lddy, keep_scale, relu, none, partial);
+        else
+            hipLaunchKernelGGL((linear_bwd_narrow_kernel<16, false>), dim3(nblk), dim3(256), 0, s, (long)n_rows, f_in, f_out, X, (long)ldx, Y,
+                               (long)ldy, dY, (long)lddy, keep_scale, relu, none, partial);
+    }
     ACM_CHECK_HIP(hipGetLastError());
-    // dW[o][f] <- column f * f_out + o: inner = f_out columns per "row" f, destination o * lddw + f (col_block 1, block_stride lddw)
-    const acm_reduce_seg_t segs[2] = {{partial, nblk, 32, 0, f_in * f_out, dW, f_out, 1, 1, lddw, nblk * 32, 0},
-                                      {partial, nblk, 32, f_in * f_out, f_out, d_bias, f_out, 0, 0, 0, nblk * 32, 0}};
-    return acm_reduce_emit(defer, segs, 2, s);
+    return linear_bwd_segments(partial, nblk, f_in, f_out, dW, lddw, d_bias, defer, s);
+}
+
+extern "C" int acm_linear_bwd_recompute(int64_t n_rows, int f_in, int f_out, const float* X, int64_t ldx, const float* W, int64_t ldw,
+                                        const float* bias, int relu, const acm_dropout_t* drop, const float* dY, int64_t lddy,
+                                        float* dW, int64_t lddw, float* d_bias, void* workspace, size_t workspace_bytes,
+                                        acm_reduce_list_t* defer, acm_stream_t stream) {
+    ACM_REQUIRE(X && W && dY && dW && d_bias, ACM_EINVAL, "acm_linear_bwd_recompute: NULL argument");
+    size_t need = 0;
+    const int st = acm_linear_bwd_workspace_bytes(n_rows, f_in, f_out, &need);
+    if (st != ACM_OK) return st;
+    acm_dropout_t d = {0.f, 0, 0, nullptr, 0};
+    if (drop) d = *drop;
+    ACM_REQUIRE(d.p == 0.f || (d.p > 0.f && d.p < 1.f && d.step), ACM_EINVAL, "acm_linear_bwd_recompute: bad dropout spec");
+    ACM_REQUIRE(ldx >= f_in && ldw >= f_in && lddy >= f_out && lddw >= f_in, ACM_ESHAPE, "acm_linear_bwd_recompute: leading dimension too small");
+    ACM_REQUIRE(workspace && workspace_bytes >= need && ((uintptr_t)workspace) % 16 == 0, ACM_ENOMEM,
+                "acm_linear_bwd_recompute: workspace %zu B < required %zu B (or not 16-byte aligned)", workspace_bytes, need);
+    hipStream_t s = (hipStream_t)stream;
+    const int nblk = linear_bwd_blocks(n_rows);
+    float* partial = (float*)workspace;
+    const LinRecompute rc = {W, (long)ldw, bias, d};
+    if (n_rows == 0) ACM_CHECK_HIP(hipMemsetAsync(partial, 0, need, s));
+    else if (f_in <= 8)
+        hipLaunchKernelGGL((linear_bwd_narrow_kernel<8, true>), dim3(nblk), dim3(256), 0, s, (long)n_rows, f_in, f_out, X, (long)ldx, nullptr,
+                           0L, dY, (long)lddy, 1.f, relu, rc, partial);
+    else
+        hipLaunchKernelGGL((linear_bwd_narrow_kernel<16, true>), dim3(nblk), dim3(256), 0, s, (long)n_rows, f_in, f_out, X, (long)ldx, nullptr,
+                           0L, dY, (long)lddy, 1.f, relu, rc, partial);
+    ACM_CHECK_HIP(hipGetLastError());
+    return linear_bwd_segments(partial, nblk, f_in, f_out, dW, lddw, d_bias, defer, s);
 }
 
 // acm_linear_fwd's route for narrow inputs (called from acm_gemm.hip); ACM_EUNSUPPORTED: the GEMM route
 int acm_linear_fwd_narrow(int64_t n_rows, int64_t f_in, int64_t f_out, const float* X, int64_t ldx, const float* W, int64_t ldw,
-                          const float* bias, int relu, const acm_dropout_t* drop, float* Y, int64_t ldy, hipStream_t s) {
-    if (f_in < 1 || f_in > 16 || f_out < 1 || f_out > 256 || n_rows < 1024) return ACM_EUNSUPPORTED;
+                          const float* bias, int relu, const acm_dropout_t* drop, float* Y, int64_t ldy, hipStream_t s,
+                          const float* add, int64_t ld_add) {
+    if (f_in < 1 || f_in > 16 || f_out < 1 || f_out > 256 || (n_rows < 1024 && !add)) return ACM_EUNSUPPORTED;
+    ACM_REQUIRE(!add || ld_add >= f_out, ACM_ESHAPE, "acm_linear_fwd_add: ld_add too small");
+    if (n_rows == 0) return ACM_OK;
     acm_dropout_t d = {0.f, 0, 0, nullptr, 0};
     if (drop) d = *drop;
     ACM_REQUIRE(d.p == 0.f || (d.p > 0.f && d.p < 1.f && d.step), ACM_EINVAL, "acm_linear_fwd: bad dropout spec");
@@ -275,10 +359,22 @@ int acm_linear_fwd_narrow(int64_t n_rows, int64_t f_in, int64_t f_out, const flo
     const int nblk = linear_bwd_blocks(n_rows);
     if (f_in <= 8)
         hipLaunchKernelGGL(linear_fwd_narrow_kernel<8>, dim3(nblk), dim3(256), 0, s, (long)n_rows, (int)f_in, (int)f_out, X, (long)ldx, W,
-                           (long)ldw, bias, relu, d, Y, (long)ldy);
+                           (long)ldw, bias, relu, d, add, (long)ld_add, Y, (long)ldy);
     else
         hipLaunchKernelGGL(linear_fwd_narrow_kernel<16>, dim3(nblk), dim3(256), 0, s, (long)n_rows, (int)f_in, (int)f_out, X, (long)ldx, W,
-                           (long)ldw, bias, relu, d, Y, (long)ldy);
+                           (long)ldw, bias, relu, d, add, (long)ld_add, Y, (long)ldy);
     ACM_CHECK_HIP(hipGetLastError());
     return ACM_OK;
+}
+
+// Y = add + dropout(relu(X W^T + b)): the ACM-GCN++ hidden activations fea1 + xX (ACM-Geometric/models.py:73) in the Linear's own
+// launch -- no [n, f_out] tensor xX, no separate add.  Narrow dense inputs only (f_in <= 16, f_out <= 256).
+extern "C" int acm_linear_fwd_add(int64_t n_rows, int f_in, int f_out, const float* X, int64_t ldx, const float* W, int64_t ldw,
+                                  const float* bias, int relu, const acm_dropout_t* drop, const float* add, int64_t ld_add, float* Y,
+                                  int64_t ldy, acm_stream_t stream) {
+    ACM_REQUIRE(X && W && Y && add, ACM_EINVAL, "acm_linear_fwd_add: NULL argument");
+    ACM_REQUIRE(n_rows >= 0, ACM_ESHAPE, "acm_linear_fwd_add: negative row count");
+    const int st = acm_linear_fwd_narrow(n_rows, f_in, f_out, X, ldx, W, ldw, bias, relu, drop, Y, ldy, (hipStream_t)stream, add, ld_add);
+    if (st == ACM_EUNSUPPORTED) acm_set_error("acm_linear_fwd_add: f_in %d (1..16), f_out %d (1..256)", f_in, f_out);
+    return st;
 }

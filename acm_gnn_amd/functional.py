@@ -966,6 +966,76 @@ class _ResidualLinear(torch.autograd.Function):
         return d_x, d_w, (d_b if ctx.has_bias else None), None, None, None, None, None
 
 
+class _ResidualAddLinear(torch.autograd.Function):
+    """out = fea + dropout(relu(x W^T + b)) in ONE launch (acm_linear_fwd_add: the ACM-GCN++ hidden activations fea1 + xX,
+    ACM-Geometric/models.py:55-56,73) for a narrow dense x that takes no gradient; the backward recomputes both masks
+    (acm_linear_bwd_recompute: reads dY and x only) and hands dY through to fea."""
+
+    @staticmethod
+    def forward(ctx, fea, x, weight, bias, relu, drop, group, call):
+        lib = _lib.load()
+        ctx.defer = call.defer if call is not None else None
+        fea, x = _as_f32_rows(fea, "fea"), _as_f32c(x, "input")
+        w = _as_f32c(weight, "weight")
+        b = _as_f32c(bias, "bias") if bias is not None else None
+        f_out, f_in = w.shape
+        n, dev = x.shape[0], w.device
+        out = torch.empty(n, f_out, dtype=_F32, device=dev)
+        spec = _drop_spec(drop[:3], drop[3]) if drop is not None else None
+        with _device_ctx(dev), _Timed(f"linear_fwd_add/{n}x{f_out}x{f_in}"):
+            st = lib.acm_linear_fwd_add(n, f_in, f_out, _vp(x), x.stride(0), _vp(w), w.stride(0), _vp(b), int(relu),
+                                        C.byref(spec) if spec is not None else None, _vp(fea), fea.stride(0), _vp(out),
+                                        out.stride(0), _stream())
+        _lib.check(st, "acm_linear_fwd_add")
+        ctx.relu, ctx.group, ctx.has_bias, ctx.spec = bool(relu), group, b is not None, spec
+        ctx.save_for_backward(x, w, b if b is not None else w.new_zeros(0))
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        lib = _lib.load()
+        x, w, b = ctx.saved_tensors
+        dy = _as_f32_rows(dy, "grad")
+        f_out, f_in = w.shape
+        n, dev = x.shape[0], w.device
+        flat = torch.empty(f_out * f_in + f_out, dtype=_F32, device=dev)      # [dW | db]: one all-reduce when sharded
+        d_w, d_b = flat[: f_out * f_in].view(f_out, f_in), flat[f_out * f_in:]
+        nbytes = C.c_size_t()
+        _lib.check(lib.acm_linear_bwd_workspace_bytes(n, f_in, f_out, C.byref(nbytes)), "acm_linear_bwd_workspace_bytes")
+        ws = torch.empty(max(nbytes.value // 4, 1), dtype=_F32, device=dev)
+        with _device_ctx(dev), _Timed(f"linear_bwd_recompute/{n}x{f_out}x{f_in}"):
+            st = lib.acm_linear_bwd_recompute(n, f_in, f_out, _vp(x), x.stride(0), _vp(w), w.stride(0),
+                                              _vp(b) if ctx.has_bias else None, int(ctx.relu),
+                                              C.byref(ctx.spec) if ctx.spec is not None else None, _vp(dy), dy.stride(0),
+                                              _vp(d_w), f_in, _vp(d_b), _vp(ws), nbytes.value,
+                                              ctx.defer.pointer() if ctx.defer is not None else None, _stream())
+        _lib.check(st, "acm_linear_bwd_recompute")
+        if ctx.defer is not None:
+            ctx.defer.hold(ws, [d_w, d_b], keep=[flat, x, dy])
+        if ctx.group is not None:
+            import torch.distributed as dist
+            if ctx.defer is not None:
+                ctx.defer.allreduce(flat, ctx.group)
+            else:
+                dist.all_reduce(flat, group=ctx.group)
+        return dy, None, d_w, (d_b if ctx.has_bias else None), None, None, None, None
+
+
+def residual_add_supported(x, weight):
+    """Shapes acm_linear_fwd_add / acm_linear_bwd_recompute take: a dense input of <= 16 columns that needs no gradient,
+    <= 256 outputs."""
+    return (isinstance(x, torch.Tensor) and not x.requires_grad and x.dim() == 2 and weight.shape[1] <= 16
+            and weight.shape[1] <= x.shape[1] and weight.shape[0] <= 256)
+
+
+def residual_add_linear(fea, x, weight, bias, relu=True, drop=None, group=None, call=None):
+    """fea + dropout(relu(x @ weight.T + bias)) as one launch, masks recomputed in the backward (see _ResidualAddLinear);
+    arguments as residual_linear."""
+    if drop is not None and not drop[0] > 0:
+        drop = None
+    return _ResidualAddLinear.apply(fea, x, weight, bias, bool(relu), drop, group, _call_or_ambient(call))
+
+
 def residual_linear(x, weight, bias, relu=True, drop=None, group=None, call=None, pipe=None):
     """dropout(relu(x @ weight.T + bias)) on the HIP kernels.  ``drop = (p, tag, DropoutState, row_offset)`` draws the
     counter-based mask in the epilogue; ``group``: row-sharded run (the parameter gradients are summed over it);

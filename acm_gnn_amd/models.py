@@ -138,7 +138,12 @@ class GCN(nn.Module):
                 x = AF.dropout(x, p, st, tag=0, pad_to=pad, row_offset=off)
         if self.model_type == "acmsgc":
             return self.gcns[0](x, adj_low, adj_high, adj_low_unnormalized, rows_permuted=self._rows_permuted, call=call, **kw)
-        if self.model_type == "acmgcnpp":
+        xx = None
+        lin = self.mlpX.lins[0] if (self.model_type == "acmgcnpp" and len(self.mlpX.lins) == 1) else None
+        # the residual branch of a narrow dense input rides ONE launch behind the first layer (fea + xX: functional.
+        # residual_add_linear, masks recomputed in its backward); every other case computes xX first, as the reference does
+        add_fused = lin is not None and AF.residual_add_supported(x, lin.weight)
+        if self.model_type == "acmgcnpp" and not add_fused:
             # (piped: x is the pipeline's table, which the first layer's forward below refills for the next step)
             xx = self._residual(x, adj_low, drop=(p, 2, st, off), call=call,
                                 pipe=call.pipe if (not isinstance(x, SparseFeatures) and piped) else None)
@@ -148,7 +153,14 @@ class GCN(nn.Module):
         fea = self.gcns[0](x, adj_low, adj_high, adj_low_unnormalized, post_relu=True, post_drop=(p, 1, st), **kw,
                            rows_permuted=self._rows_permuted, call=call)
         call.next_proj = None
-        if self.model_type == "acmgcnpp":
+        if add_fused:
+            ops_ = adj_low if isinstance(adj_low, FilterOperators) else None
+            xr = x
+            if call.pipe is not None and x.data_ptr() == call.pipe.local_table().data_ptr() and call.pipe.adopted:
+                xr = call.pipe.saved[0]        # the table holds step t + 1's rows by now: this step's are in the saved copy
+            fea = AF.residual_add_linear(fea, xr, lin.weight, lin.bias, relu=True, drop=(p, 2, st, off),
+                                         group=ops_.group if (ops_ is not None and ops_.sharded) else None, call=call)
+        elif self.model_type == "acmgcnpp":
             fea = fea + xx
         else:
             call.hidden_private = fea          # consumed by the output layer only: its gradient may stay implicit

@@ -355,10 +355,23 @@ int acm_bias_act_bwd(int64_t n_rows, int f, const float* Y, int64_t ldy, const f
  *                     column sums of G in ONE pass over (Y, dY, X), G as acm_bias_act_bwd forms it but never stored --
  *                     replaces acm_bias_act_bwd + acm_gemm(transA) and the [n_rows, f_out] matrix between them.
  *                     Deterministic; both sums honour `defer`.  f_out <= 256. */
+/*   acm_linear_fwd_add        Y = add + dropout(relu(X W^T + b)): the ACM-GCN++ hidden activations fea1 + xX (models.py:73) in
+ *                             the Linear's own launch (Y may alias add); same shapes as acm_linear_bwd.
+ *   acm_linear_bwd_recompute  its backward: Y no longer shows the masks, so they are formed again -- the pre-activation by
+ *                             the forward's own fmaf chain (same bits, same sign), the dropout factors from the counter
+ *                             (`drop` as in the forward, same step): the pass reads dY and X only.  Workspace:
+ *                             acm_linear_bwd_workspace_bytes. */
 int acm_linear_bwd_workspace_bytes(int64_t n_rows, int f_in, int f_out, size_t* bytes);
 int acm_linear_bwd(int64_t n_rows, int f_in, int f_out, const float* X, int64_t ldx, const float* Y, int64_t ldy,
                    const float* dY, int64_t lddy, float keep_scale, int relu, float* dW, int64_t lddw, float* d_bias,
                    void* workspace, size_t workspace_bytes, acm_reduce_list_t* defer, acm_stream_t stream);
+int acm_linear_fwd_add(int64_t n_rows, int f_in, int f_out, const float* X, int64_t ldx, const float* W, int64_t ldw,
+                       const float* bias, int relu, const acm_dropout_t* drop, const float* add, int64_t ld_add,
+                       float* Y, int64_t ldy, acm_stream_t stream);
+int acm_linear_bwd_recompute(int64_t n_rows, int f_in, int f_out, const float* X, int64_t ldx, const float* W, int64_t ldw,
+                             const float* bias, int relu, const acm_dropout_t* drop, const float* dY, int64_t lddy,
+                             float* dW, int64_t lddw, float* d_bias, void* workspace, size_t workspace_bytes,
+                             acm_reduce_list_t* defer, acm_stream_t stream);
 
 /* ----------------------------------------------------------------- SpMM --
  * Y[r, 0:width] = sum_j A[r,j] * G[j, 0:width]   (plain CSR x dense; used for

@@ -558,6 +558,33 @@ class FakeLib:
         Y[...] = out * dropout_factors(self._drop_obj(drop), n, f)
         return 0
 
+    def _lin_pre_and_factor(self, n, f_in, f_out, x, ldx, w, ldw, bias, drop):
+        pre = _view(x, n, f_in, ldx).astype(np.float64) @ _view(w, f_out, f_in, ldw).astype(np.float64).T
+        if bias:
+            pre = pre + _vec(bias, f_out).astype(np.float64)
+        d = self._drop_obj(drop)
+        fac = dropout_factors(d, n, f_out) if (d is not None and d.p > 0) else np.ones((n, f_out))
+        return pre, fac
+
+    def acm_linear_fwd_add(self, n, f_in, f_out, x, ldx, w, ldw, bias, relu, drop, add, ld_add, y, ldy, stream):
+        if f_in > 16 or f_out > 256:
+            self._err = b"acm_linear_fwd_add: unsupported shape"
+            return 4
+        pre, fac = self._lin_pre_and_factor(n, f_in, f_out, x, ldx, w, ldw, bias, drop)
+        if relu:
+            pre = np.maximum(pre, 0)
+        _view(y, n, f_out, ldy)[...] = _view(add, n, f_out, ld_add).astype(np.float64) + pre * fac
+        return 0
+
+    def acm_linear_bwd_recompute(self, n, f_in, f_out, x, ldx, w, ldw, bias, relu, drop, dy, lddy, dw, lddw, db, ws, wsb, defer,
+                                 stream):
+        pre, fac = self._lin_pre_and_factor(n, f_in, f_out, x, ldx, w, ldw, bias, drop)
+        G = _view(dy, n, f_out, lddy).astype(np.float64) * fac
+        if relu:
+            G = np.where(pre > 0, G, 0.0)
+        X = _view(x, n, f_in, ldx).astype(np.float64)
+        return self._emit(defer, [(_view(dw, f_out, f_in, lddw), G.T @ X), (_vec(db, f_out), G.sum(0))])
+
     def acm_linear_bwd_workspace_bytes(self, n, f_in, f_out, out):
         if f_in > 16 or f_out > 256:
             self._err = b"acm_linear_bwd: unsupported shape"

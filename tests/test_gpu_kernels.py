@@ -644,3 +644,57 @@ def test_linear_forward_of_a_narrow_input_streams_with_the_bits_of_the_gemm_rout
     if p:
         frac = float(((got == 0) & (pre > 1e-6 if relu else pre.abs() > 1e-6)).double().mean() / max(float((pre > 1e-6 if relu else pre.abs() > 1e-6).double().mean()), 1e-9))
         assert abs(frac - p) < 0.02
+
+
+@pytest.mark.parametrize("n,f_in,f_out,relu,p", [(1, 1, 2, 1, 0.0), (1000, 7, 64, 1, 0.3), (70001, 16, 200, 0, 0.4), (168114, 7, 64, 1, 0.1)])
+def test_residual_add_and_its_recomputing_backward(n, f_in, f_out, relu, p):
+    """acm_linear_fwd_add (Y = add + dropout(relu(X W^T + b)), in place over add as well) against acm_linear_fwd + an add, bit
+    for bit; acm_linear_bwd_recompute (masks formed again from X, W, b and the counter) against acm_linear_bwd on the plain
+    forward's output, bit for bit -- the recomputed pre-activation and factors ARE the forward's."""
+    import ctypes as C
+    from acm_gnn_amd import _lib, functional as AF
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(n + f_out)
+    x = torch.randn(n, f_in + 1, generator=g).to(DEV)
+    w = torch.randn(f_out, f_in, generator=g).to(DEV)
+    b = torch.randn(f_out, generator=g).to(DEV)
+    add = torch.randn(n, f_out + 1, generator=g).to(DEV)
+    dy = torch.randn(n, f_out, generator=g).to(DEV)
+    state = AF.DropoutState(DEV, seed=5)
+    spec = AF._drop_spec((p, 2, state), 0) if p else None
+    sp = C.byref(spec) if spec is not None else None
+    # plain forward (the streaming route needs >= 1024 rows; below that the GEMM route -- same bits)
+    y = torch.empty(n, f_out, device=DEV)
+    nb = C.c_size_t()
+    _lib.check(lib.acm_gemm_workspace_bytes(0, 1, n, f_out, f_in, C.byref(nb)))
+    ws = torch.empty(max(nb.value // 4, 1), device=DEV)
+    _lib.check(lib.acm_linear_fwd(n, f_in, f_out, x.data_ptr(), f_in + 1, w.data_ptr(), f_in, b.data_ptr(), relu, sp, y.data_ptr(), f_out,
+                                  ws.data_ptr(), nb.value, None), "acm_linear_fwd")
+    out = torch.full((n, f_out), float("nan"), device=DEV)
+    _lib.check(lib.acm_linear_fwd_add(n, f_in, f_out, x.data_ptr(), f_in + 1, w.data_ptr(), f_in, b.data_ptr(), relu, sp, add.data_ptr(),
+                                      f_out + 1, out.data_ptr(), f_out, None), "acm_linear_fwd_add")
+    assert torch.equal(out, y + add[:, :f_out])
+    inplace = add.clone()
+    _lib.check(lib.acm_linear_fwd_add(n, f_in, f_out, x.data_ptr(), f_in + 1, w.data_ptr(), f_in, b.data_ptr(), relu, sp, inplace.data_ptr(),
+                                      f_out + 1, inplace.data_ptr(), f_out + 1, None), "acm_linear_fwd_add")
+    assert torch.equal(inplace[:, :f_out], out) and torch.equal(inplace[:, f_out], add[:, f_out])
+    # backward: masks read off y against masks recomputed
+    nb2 = C.c_size_t()
+    _lib.check(lib.acm_linear_bwd_workspace_bytes(n, f_in, f_out, C.byref(nb2)))
+    ws2 = torch.empty(nb2.value // 4, device=DEV)
+    res = []
+    for which in (0, 1):
+        dw, db = torch.full((f_out, f_in), float("nan"), device=DEV), torch.full((f_out,), float("nan"), device=DEV)
+        if which == 0:
+            st = lib.acm_linear_bwd(n, f_in, f_out, x.data_ptr(), f_in + 1, y.data_ptr(), f_out, dy.data_ptr(), f_out, 1.0 / (1.0 - p), relu,
+                                    dw.data_ptr(), f_in, db.data_ptr(), ws2.data_ptr(), nb2.value, None, None)
+        else:
+            st = lib.acm_linear_bwd_recompute(n, f_in, f_out, x.data_ptr(), f_in + 1, w.data_ptr(), f_in, b.data_ptr(), relu, sp,
+                                              dy.data_ptr(), f_out, dw.data_ptr(), f_in, db.data_ptr(), ws2.data_ptr(), nb2.value, None, None)
+        _lib.check(st, "acm_linear_bwd*")
+        torch.cuda.synchronize()
+        res.append((dw, db))
+    if relu or not p:                    # (without a ReLU the mask read off y also drops kept exact zeros: measure zero)
+        assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])
+    else:
+        torch.testing.assert_close(res[1][0], res[0][0], rtol=1e-5, atol=1e-5)

@@ -449,9 +449,13 @@ def test_acmgcnpp_residual_branch_matches_oracle(variant, structure, f_in, p_dro
     finally:
         AF.set_kernel_timer(None)
     used = set(k.split("/")[0] for k in timer.events)
-    assert ("bias_act" in used) == sparse_x and ("linear_fwd" in used) == (not sparse_x), used
-    # backward of the residual Linear: one pass for a narrow dense input (acm_linear_bwd), else acm_bias_act_bwd + a product
-    assert ("linear_bwd" in used) == (not sparse_x and f_in <= 16) and ("bias_act_bwd" in used) == (sparse_x or f_in > 16), used
+    # the residual Linear: a narrow dense input rides one launch behind the first layer (fea1 + xX: acm_linear_fwd_add, masks
+    # recomputed by acm_linear_bwd_recompute); else acm_linear_fwd / acm_spmm_v + acm_bias_act, and acm_bias_act_bwd + a product
+    narrow = not sparse_x and f_in <= 16
+    fused = narrow and p_drop > 0           # (the training forward with counter-based dropout; without dropout: xX first, one-pass backward)
+    assert ("bias_act" in used) == sparse_x and ("linear_fwd" in used) == (not sparse_x and not fused), used
+    assert ({"linear_fwd_add", "linear_bwd_recompute"} <= used) == fused and ("linear_bwd" in used) == (narrow and not fused), used
+    assert ("bias_act_bwd" in used) == (not narrow), used
     ref = O.gcn_forward(params, x, low, high, un if structure else None, model_type="acmgcnpp", variant=bool(variant),
                         structure_info=structure, attn_layernorm=True, dropout=p_drop, training=True, masks=masks)
     ref_loss = O.nll_loss_on(ref, y, idx)
