@@ -52,14 +52,24 @@ int bias_bwd_blocks(int64_t n_rows) { return (int)(n_rows < 1024 ? (n_rows < 1 ?
 // kernels.  A wave takes chunks of EIGHT consecutive rows (chunk = wave index + k * waves): the 8 x FI block of X goes through
 // 256-512 B of wave-private LDS (one coalesced load, then broadcast reads: no barrier, one wave, in-order LDS), lane = output
 // column, 8 (forward: stores) or 16 (backward: Y and dY) row accesses in flight.
+// (load and LDS store are separate so that a wave requests the NEXT chunk's block -- and its Y / dY / add rows -- before it
+//  works on the one in hand: a wave has only two or three chunks, every exposed round trip counts)
 template <int FI>
-__device__ __forceinline__ void stage_x_rows(float* xs, const float* __restrict__ x, long ldx, long r0, long n_rows, int f_in, int lane) {
+__device__ __forceinline__ void load_x_rows(float (&xe)[FI / 8], const float* __restrict__ x, long ldx, long r0, long n_rows, int f_in,
+                                            int lane) {
 #pragma unroll
-    for (int e0 = 0; e0 < 8 * FI; e0 += 64) {
-        const int e = e0 + lane, u = e / FI, f = e % FI;
+    for (int k = 0; k < FI / 8; ++k) {
+        const int e = 64 * k + lane, u = e / FI, f = e % FI;
         const long r = r0 + u;
-        xs[e] = (r < n_rows && f < f_in) ? x[r * ldx + f] : 0.f;
+        const bool in = r < n_rows && f < f_in;
+        const float v = x[(in ? r : 0) * ldx + (in ? f : 0)];
+        xe[k] = in ? v : 0.f;
     }
+}
+template <int FI>
+__device__ __forceinline__ void store_x_rows(float* xs, const float (&xe)[FI / 8], int lane) {
+#pragma unroll
+    for (int k = 0; k < FI / 8; ++k) xs[64 * k + lane] = xe[k];
 }
 
 // Forward: Y = dropout(relu(X W^T + b)).  The product is an fmaf chain in k order from zero, bias -> ReLU -> dropout after it: the
@@ -86,9 +96,24 @@ __global__ __launch_bounds__(256) void linear_fwd_narrow_kernel(long n_rows, int
 #pragma unroll
         for (int f = 0; f < FI; ++f) wr[f] = (ok && f < f_in) ? w[(long)o * ldw + f] : 0.f;
         const float b = (ok && bias) ? bias[o] : 0.f;
+        float xe[FI / 8], av[8];
+        auto fetch = [&](long ch) {                      // chunk ch's block of X and rows of `add` (clamped addresses, no branches)
+            const long r0 = ch * 8;
+            load_x_rows<FI>(xe, x, ldx, r0, n_rows, f_in, lane);
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const long r = (r0 + u < n_rows) ? r0 + u : 0;
+                av[u] = add ? add[r * ld_add + (ok ? o : 0)] : 0.f;
+            }
+        };
+        if (gw < n_chunks) fetch(gw);
         for (long ch = gw; ch < n_chunks; ch += n_waves) {
             const long r0 = ch * 8;
-            stage_x_rows<FI>(xs, x, ldx, r0, n_rows, f_in, lane);
+            store_x_rows<FI>(xs, xe, lane);
+            float ac[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) ac[u] = av[u];
+            if (ch + n_waves < n_chunks) fetch(ch + n_waves);
             if (dc.on) {
 #pragma unroll
                 for (int h = 0; h < 2; ++h) {
@@ -108,10 +133,8 @@ __global__ __launch_bounds__(256) void linear_fwd_narrow_kernel(long n_rows, int
                 v += b;
                 if (relu) v = fmaxf(v, 0.f);
                 if (dc.on) v *= fac[u * 64 + lane];
-                if (ok && r < n_rows) {
-                    if (add) v += add[r * ld_add + o];          // (y may be add itself: each element is read, then written, by one lane)
-                    y[r * ldy + o] = v;
-                }
+                if (ok && r < n_rows) y[r * ldy + o] = add ? v + ac[u] : v;   // (y may be add itself: a chunk's rows are read before they are
+                                                                     //  written, and only this wave touches them)
             }
         }
     }
@@ -156,11 +179,26 @@ __global__ __launch_bounds__(256) void linear_bwd_narrow_kernel(long n_rows, int
             wr[f] = (RECOMPUTE && ok && f < f_in) ? rc.w[(long)o * rc.ldw + f] : 0.f;
         }
         const float bo = (RECOMPUTE && ok && rc.bias) ? rc.bias[o] : 0.f;
+        float xe[FI / 8], dn[8], yn[8];
+        auto fetch = [&](long ch) {                      // chunk ch's block of X and its rows of dY (and Y): clamped addresses
+            const long r0 = ch * 8;
+            load_x_rows<FI>(xe, x, ldx, r0, n_rows, f_in, lane);
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const long r = (r0 + u < n_rows) ? r0 + u : 0;
+                dn[u] = dy[r * lddy + oc];
+                yn[u] = RECOMPUTE ? 0.f : y[r * ldy + oc];
+            }
+        };
+        if (gw < n_chunks) fetch(gw);
         for (long ch = gw; ch < n_chunks; ch += n_waves) {
             const long r0 = ch * 8;
-            float gv[8];
+            float gv[8], dv[8], yv[8];
+            store_x_rows<FI>(xs, xe, lane);
+#pragma unroll
+            for (int u = 0; u < 8; ++u) dv[u] = dn[u], yv[u] = yn[u];
+            if (ch + n_waves < n_chunks) fetch(ch + n_waves);
             if (RECOMPUTE) {
-                stage_x_rows<FI>(xs, x, ldx, r0, n_rows, f_in, lane);
                 if (dc.on) {
                     const int g = lane >> 4, i = lane & 15;
 #pragma unroll
@@ -174,10 +212,8 @@ __global__ __launch_bounds__(256) void linear_bwd_narrow_kernel(long n_rows, int
             }
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
-                const long r = r0 + u;
-                const bool in = r < n_rows;
-                const long rw = in ? r : r0;
-                float v = dy[rw * lddy + oc];
+                const bool in = r0 + u < n_rows;
+                float v = dv[u];
                 if (RECOMPUTE) {
                     float pre = 0.f;
 #pragma unroll
@@ -187,14 +223,13 @@ __global__ __launch_bounds__(256) void linear_bwd_narrow_kernel(long n_rows, int
                     if (relu) v = pre > 0.f ? v : 0.f;
                     if (dc.on) v *= fac[u * 64 + lane];
                 } else {
-                    const float out = y[rw * ldy + oc];
+                    const float out = yv[u];
                     // (bias_act_bwd_kernel's formula: both masks are read off the forward's output)
                     if (relu) v = out > 0.f ? v * inv_keep : 0.f;
                     else if (inv_keep != 1.f) v = out != 0.f ? v * inv_keep : 0.f;
                 }
                 gv[u] = (in && ok) ? v : 0.f;
             }
-            if (!RECOMPUTE) stage_x_rows<FI>(xs, x, ldx, r0, n_rows, f_in, lane);
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
                 accb += gv[u];
