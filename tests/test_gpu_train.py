@@ -210,7 +210,7 @@ def test_eval_passes_reuse_the_aggregated_input_on_the_gpu(monkeypatch):
     assert torch.equal(og, oe) and ag == ae and lg == le          # both are shortened passes by now
 
 
-def _pipeline_case(n, avg, seed, relabel=False):
+def _pipeline_case(n, avg, seed, relabel=False, with_structure=False):
     """A random graph in the input pipeline's regime (dense input of 7 features, 12 < nnz / n <= 160) + a fresh model."""
     from acm_gnn_amd import data as D
     from acm_gnn_amd.distributed import make_sharded_operators
@@ -223,7 +223,7 @@ def _pipeline_case(n, avg, seed, relabel=False):
     adj.setdiag(0)
     adj.eliminate_zeros()
     low, deg = D.build_filters(adj)
-    ops = make_sharded_operators(low, deg, torch.device(DEV), relabel=relabel)
+    ops = make_sharded_operators(low, deg, torch.device(DEV), relabel=relabel, with_structure=with_structure)
     g = torch.Generator().manual_seed(seed)
     x = torch.randn(n, 7, generator=g).to(DEV)
     y = torch.randint(0, 2, (n,), generator=g).to(DEV)
@@ -324,6 +324,44 @@ def test_fit_with_the_input_pipeline_equals_fit_without(monkeypatch, use_graph, 
     a = np.array([[float(v) for v in h.values()] if isinstance(h, dict) else [float(v) for v in h] for h in hist_a])
     b = np.array([[float(v) for v in h.values()] if isinstance(h, dict) else [float(v) for v in h] for h in hist_b])
     np.testing.assert_allclose(b, a, rtol=5e-3, atol=5e-3)
+
+
+@pytest.mark.parametrize("model_type,s", [("acmgcnp", 0), ("acmgcnpp", 1)])
+def test_fit_of_the_acmii_variant_captured_equals_eager_and_the_fp32_kernels(model_type, s, tune):
+    """train.fit with the reference's default variant (ACMII, ACM-Geometric/parse.py:57) on a narrow input: the mask form of the
+    first layer (acm_conv_acmii_v.hip: the table is rebuilt inside every captured step and evaluation pass, the item streams
+    come from the warm-up) captured against eager, and against the fp32-MFMA forward + transposed-gather backward it
+    replaces (rewrites without bit 4): same histories."""
+    from acm_gnn_amd import GCN, FusedAdamW, functional as AF, train as T
+    n = 5000
+    ops, x, y = _pipeline_case(n, 30, seed=17, with_structure=bool(s))
+    idx = torch.randperm(n, generator=torch.Generator().manual_seed(3)).to(DEV)
+    sets = (idx[: n // 2], idx[n // 2: 3 * n // 4], idx[3 * n // 4:])
+
+    def run(use_graph, mask):
+        tune(acmii_mask=int(mask))
+        torch.manual_seed(0)
+        model = GCN(7, 64, 2, 2, n, 0.3, model_type, s, variant=True, attn_layernorm=True).to(DEV)
+        model.dropout_state = AF.DropoutState(torch.device(DEV), seed=5)
+        opt = FusedAdamW(model.parameters(), lr=0.01, weight_decay=1e-3)
+        timer = AF.KernelTimer()
+        AF.set_kernel_timer(timer if not use_graph else None)
+        try:
+            acc, hist = T.fit(model, opt, x, ops, y, *sets, epochs=10, use_graph=use_graph)
+        finally:
+            AF.set_kernel_timer(None)
+        used = set(k.split("/")[0] for k in timer.events)
+        rows = np.array([[float(v) for v in h.values()] if isinstance(h, dict) else [float(v) for v in h] for h in hist])
+        return acc, rows, used
+
+    acc_e, hist_e, used = run(False, True)
+    assert {"acmii_table", "conv_acmii_v_fwd", "conv_acmii_v_bwd"} <= used, sorted(used)
+    acc_g, hist_g, _ = run(True, True)
+    acc_o, hist_o, used_o = run(False, False)
+    assert "conv_acmii_fwd" in used_o and "conv_acmii_v_fwd" not in used_o, sorted(used_o)
+    np.testing.assert_allclose(hist_g, hist_e, rtol=5e-3, atol=5e-3)
+    np.testing.assert_allclose(hist_o, hist_e, rtol=5e-3, atol=5e-3)
+    assert abs(acc_g - acc_e) < 5e-3 and abs(acc_o - acc_e) < 5e-3
 
 
 def test_carried_gather_leaves_the_backward_unchanged():
