@@ -129,7 +129,7 @@ __global__ __launch_bounds__(256) void linear_fwd_narrow_kernel(long n_rows, int
                 float v = 0.f;
 #pragma unroll
                 for (int f = 0; f < FI; ++f)
-                    if (f < f_in) v = fmaf(xs[u * FI + f], wr[f], v);
+                    v = fmaf(xs[u * FI + f], wr[f], v);       // (columns beyond f_in: zeros in xs and wr)
                 v += b;
                 if (relu) v = fmaxf(v, 0.f);
                 if (dc.on) v *= fac[u * 64 + lane];
@@ -218,7 +218,7 @@ __global__ __launch_bounds__(256) void linear_bwd_narrow_kernel(long n_rows, int
                     float pre = 0.f;
 #pragma unroll
                     for (int f = 0; f < FI; ++f)
-                        if (f < f_in) pre = fmaf(xs[u * FI + f], wr[f], pre);
+                        pre = fmaf(xs[u * FI + f], wr[f], pre);   // (columns beyond f_in: zeros in xs and wr)
                     pre += bo;
                     if (relu) v = pre > 0.f ? v : 0.f;
                     if (dc.on) v *= fac[u * 64 + lane];
@@ -235,7 +235,7 @@ __global__ __launch_bounds__(256) void linear_bwd_narrow_kernel(long n_rows, int
                 accb += gv[u];
 #pragma unroll
                 for (int f = 0; f < FI; ++f)
-                    if (f < f_in) acc[f] = fmaf(gv[u], xs[u * FI + f], acc[f]);
+                    acc[f] = fmaf(gv[u], xs[u * FI + f], acc[f]);   // (columns beyond f_in: zeros in xs; never written out)
             }
         }
 #pragma unroll
