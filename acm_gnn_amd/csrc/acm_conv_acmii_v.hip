@@ -165,7 +165,10 @@ __device__ __forceinline__ void v_batch(unsigned char* lds, int lane, u32x4 r0, 
 #ifndef ACM_V_RD
 #define ACM_V_RD 2
 #endif
-constexpr int V_RD = ACM_V_RD, V_JD = ACM_V_RD, V_RING = V_RD + V_JD;
+#ifndef ACM_V_JD
+#define ACM_V_JD ACM_V_RD
+#endif
+constexpr int V_RD = ACM_V_RD, V_JD = ACM_V_JD, V_RING = V_RD + V_JD;
 
 // The wave's quads [qb, qe) with their batches.  `quad_begin(id)` (id = lane row kq's item {row, slot, batches, flags}) runs before
 // a quad's first batch, `item_begin(u)` before item u's first batch, `item_end(u, d)` after its last one (also for items
