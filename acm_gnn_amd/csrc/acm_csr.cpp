@@ -614,7 +614,7 @@ extern "C" int acm_csr_build_item_streams(acm_csr_t* a, int n_waves) {
         qb[(size_t)(i / 4)] += nb;
         total += nb;
     }
-    ACM_REQUIRE((total + ACM_ITEM_STREAM_PAD) * 32 < ((int64_t)1 << 31), ACM_EUNSUPPORTED,
+    ACM_REQUIRE((total + ACM_ITEM_STREAM_PAD) * 128 < ((int64_t)1 << 32), ACM_EUNSUPPORTED,       // (the kernels keep BYTE offsets in 32 bits)
                 "acm_csr_build_item_streams: %lld batches exceed 32-bit stream offsets", (long long)total);
     if (n_waves <= 0) {
         int cus = 256;
