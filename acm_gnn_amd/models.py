@@ -22,6 +22,8 @@ from . import functional as AF
 from .graph import FilterOperators, SparseFeatures
 from .layers import GraphConvolution, MLP
 
+_TORCH_DROPOUT = F.dropout          # to notice a patched F.dropout (mask replay in tests): see GCN.auto_csr
+
 _TWO_LAYER = ("acmgcn", "acmgcnp", "acmgcnpp")
 
 
@@ -194,6 +196,20 @@ class GCN(nn.Module):
             blocks.append(h)
         return self.gcns[-1](torch.cat([x] + blocks, 1), adj_low, adj_high, None, rows_permuted=self._rows_permuted, call=call)
 
+    def auto_csr(self, x, ops):
+        """Wide, mostly-zero features handed over dense -> their CSR twin (graph.SparseFeatures.auto, tuning key
+        ``csr_features``), where this model has the CSR route: not acmsnowball (it concatenates the input with the hidden
+        blocks), not an mlpX stack the residual kernel does not cover, not row-sharded operators (a rank's block keeps the
+        dense halo exchange), and not while someone has replaced ``F.dropout`` (a mask-replay harness hands out masks of
+        the dense shape: the input stays what the masks were recorded for)."""
+        if not isinstance(x, torch.Tensor) or F.dropout is not _TORCH_DROPOUT or self.model_type == "acmsnowball":
+            return x
+        if ops is not None and ops.sharded:
+            return x
+        if self.model_type == "acmgcnpp" and not (len(self.mlpX.lins) == 1 and self.mlpX.lins[0].out_features <= 256):
+            return x
+        return SparseFeatures.auto(x)
+
     def forward(self, x, adj_low, adj_high=None, adj_low_unnormalized=None, rows_permuted=False, call=None):
         """Reference signature.  With relabelled operators (graph.relabel_by_degree) the rows are translated ONCE here
         -- x on the way in, the logits on the way out -- and every layer in between works in the relabelled numbering
@@ -207,6 +223,8 @@ class GCN(nn.Module):
             four = self.structure_info and self.model_type in ("acmgcnp", "acmgcnpp")
             ops = adj_low = operators_for(adj_low, adj_high, adj_low_unnormalized if four else None)
         self._rows_permuted = ops is not None and ops.perm is not None
+        if not rows_permuted:                  # (a caller that already permuted -- train.TrainStep -- asked before it did)
+            x = self.auto_csr(x, ops)
         if self._rows_permuted and not rows_permuted:
             x = x.permute_rows(ops.perm) if isinstance(x, SparseFeatures) else x.index_select(0, ops.perm)
             return self._forward(x, adj_low, adj_high, adj_low_unnormalized, call).index_select(0, ops.inv_perm)

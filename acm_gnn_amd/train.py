@@ -65,6 +65,9 @@ class TrainStep:
         if not isinstance(adj, FilterOperators) and isinstance(adj, torch.Tensor) and hasattr(model, "structure_info"):
             four = model.structure_info and getattr(model, "model_type", "") in ("acmgcnp", "acmgcnpp")
             ops = operators_for(adj, adj_high, adj_un if four else None)
+        if hasattr(model, "auto_csr"):
+            # wide one-hot / bag-of-words features handed over dense: the CSR twin, made here once (tuning csr_features)
+            self.x = x = model.auto_csr(x, ops if isinstance(ops, FilterOperators) else None)
         if isinstance(ops, FilterOperators) and ops.perm is not None and hasattr(model, "_forward"):
             self.adj = ops
             self.x = x.permute_rows(ops.perm) if isinstance(x, SparseFeatures) else x.index_select(0, ops.perm)

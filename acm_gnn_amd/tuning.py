@@ -22,6 +22,9 @@ Host-level keys:
     relabel    in-operator degree relabelling: -1 = graphs of >= 32 768 nodes (default), 0 = never, 1 = always
     pipeline   the training loop's input pipeline (next step's first-layer gather inside this step's backward):
                0 = off, n > 0 = on for graphs of at least n rows.  Default 8192
+    csr_features  wide, mostly-zero feature matrices handed over DENSE (bag-of-words, one-hot: the reference's loaders
+               densify them) are projected from a CSR copy made once per tensor (graph.SparseFeatures.auto): 0 = never,
+               n > 0 = for inputs of at least n columns with at most 1/16 of the entries nonzero.  Default 256
 
 Tests and probes flip forms with ``override(...)`` (a context manager; restores both records on exit) -- or, for child
 processes, by putting ACM_TUNING into the child's environment.
@@ -32,8 +35,8 @@ import os
 import threading
 
 KERNEL_KEYS = ("chunk", "wide_form", "bwd_split", "rows16", "agg_fused", "gemm_forms")
-HOST_DEFAULTS = {"rewrites": 7, "implicit": 1, "relabel": -1, "pipeline": 8192}
-HOST_RANGES = {"rewrites": (0, 7), "implicit": (0, 1), "relabel": (-1, 1), "pipeline": (0, 1 << 31)}
+HOST_DEFAULTS = {"rewrites": 7, "implicit": 1, "relabel": -1, "pipeline": 8192, "csr_features": 256}
+HOST_RANGES = {"rewrites": (0, 7), "implicit": (0, 1), "relabel": (-1, 1), "pipeline": (0, 1 << 31), "csr_features": (0, 1 << 31)}
 
 REWRITE_AGG_FIRST = 1
 REWRITE_ACMII_RECOMPUTE = 2

@@ -52,6 +52,11 @@ CONFIGS = {
     "cora/acmgcn/csrX": dict(graph="cora", f_in=1433, classes=7, method="acmgcn", s=0, variant=0, dropout=0.6, sparse=1),
     "squirrel/acmgcnp+A/csrX": dict(graph="squirrel", f_in=2089, classes=5, method="acmgcnp", s=1, variant=0, dropout=0.6, sparse=1),
     "penn94/acmgcnp/csrX": dict(graph="syn:penn94", method="acmgcnp", s=0, variant=0, dropout=0.1, sparse=1),
+    # ... and handed over DENSE, as the reference's loaders do: the model makes the CSR twin itself (tuning csr_features)
+    "cora/acmgcn/auto": dict(graph="cora", f_in=1433, classes=7, method="acmgcn", s=0, variant=0, dropout=0.6, sparse="auto"),
+    "squirrel/acmgcnp+A/auto": dict(graph="squirrel", f_in=2089, classes=5, method="acmgcnp", s=1, variant=0, dropout=0.6, sparse="auto"),
+    "penn94/acmgcnp/auto": dict(graph="syn:penn94", method="acmgcnp", s=0, variant=0, dropout=0.1, sparse="auto"),
+    "penn94/acmsgc-3hop/auto": dict(graph="syn:penn94", method="acmsgc", s=0, variant=0, dropout=0.1, sparse="auto", hops=3),
     # BASELINE config 5: ACM-SGC 3-hop (one linear ACM layer, the low channel through A_low three times)
     "arxiv-year/acmsgc-3hop": dict(graph="syn:arxiv-year", method="acmsgc", s=0, variant=0, dropout=0.1, hops=3),
     "penn94/acmsgc-3hop/csrX": dict(graph="syn:penn94", method="acmsgc", s=0, variant=0, dropout=0.1, sparse=1, hops=3),
@@ -78,7 +83,9 @@ def run(name, cfg, steps=20):
     ops = DD.make_sharded_operators(low, deg, DEV, with_structure=bool(cfg["s"]))
     ops.hops = cfg.get("hops", 1)
     x, y = torch.from_numpy(x_np).to(DEV), torch.from_numpy(y_np.astype(np.int64)).to(DEV)
-    if cfg.get("sparse"):
+    from acm_gnn_amd import tuning
+    tuning.apply(csr_features=256 if cfg.get("sparse") == "auto" else 0)      # the dense rows measure the dense projection
+    if cfg.get("sparse") == 1:
         x = acm_gnn_amd.SparseFeatures.from_scipy(sp.csr_matrix(x_np), DEV)
     torch.manual_seed(0)
     model = acm_gnn_amd.GCN(f_in, 64, classes, 2, n, cfg["dropout"], cfg["method"], cfg["s"],

@@ -338,7 +338,7 @@ def test_twitch_shaped_pipelined_steps_match_oracle(mode):
     _record(f"twitch-pipelined/{mode}", **rec)
 
 
-@pytest.mark.parametrize("dataset,sparse_x", [("arxiv-year", False), ("penn94", True), ("penn94", False)])
+@pytest.mark.parametrize("dataset,sparse_x", [("arxiv-year", False), ("penn94", True), ("penn94", False), ("penn94", "auto")])
 def test_three_hop_acm_sgc_at_linkx_size(dataset, sparse_x):
     """BASELINE config 5 on one GPU: GCN('acmsgc') with FilterOperators.hops = 3 (chain of 1-hop products, forward
     and transposed backward) against the oracle's float64 chain."""
@@ -357,6 +357,9 @@ def test_three_hop_acm_sgc_at_linkx_size(dataset, sparse_x):
     p64 = {k: v.detach().cpu().double().clone().requires_grad_(True) for k, v in layer.named_parameters()}
     low64 = _csr_t(wl["low"].astype(np.float64), torch.float64)
     high64 = _csr_t((sp.identity(n, dtype=np.float64, format="csr") - wl["low"].astype(np.float64)).tocsr(), torch.float64)
+    # sparse_x: True = the caller hands over SparseFeatures; "auto" = dense one-hot features, the model makes the CSR twin
+    # itself (tuning csr_features, the default); False = the dense projection (key off for Penn94, whose features qualify)
+    auto = sparse_x == "auto"
     x64 = _csr_t(sp.csr_matrix(wl["x"].astype(np.float64)), torch.float64) if sparse_x else torch.from_numpy(wl["x"]).double()
     ref = O.sgc_khop_forward(p64, x64, low64, high64, 3)
     ref_loss = O.nll_loss_on(ref, y, torch.from_numpy(tr))
@@ -365,13 +368,16 @@ def test_three_hop_acm_sgc_at_linkx_size(dataset, sparse_x):
     model = model.to(DEV)
     ops = DD.make_sharded_operators(wl["low"], wl["deg"], DEV)
     ops.hops = 3
-    xd = SparseFeatures.from_scipy(sp.csr_matrix(wl["x"]), DEV) if sparse_x else torch.from_numpy(wl["x"]).to(DEV)
+    xd = (SparseFeatures.from_scipy(sp.csr_matrix(wl["x"]), DEV) if sparse_x is True else torch.from_numpy(wl["x"]).to(DEV))
     w = T.row_weights(torch.from_numpy(tr).to(DEV), n)
     model.train()
-    logits = model(xd, ops)
-    loss = AF.masked_nll(logits, y.to(DEV), w)
-    loss.backward()
+    from acm_gnn_amd import tuning
+    with tuning.override(csr_features=256 if auto else 0):
+        logits = model(xd, ops)
+        loss = AF.masked_nll(logits, y.to(DEV), w)
+        loss.backward()
     torch.cuda.synchronize()
+    assert (getattr(xd, "_acm_csr_twin", (0, None))[1] is not None) == auto
     d, rel = _errs(logits.detach().cpu(), ref.detach())
     rec = {"logits_abs": d, "logits_rel": rel, "loss": float(loss), "loss_ref": float(ref_loss)}
     assert rel < FWD_TOL, (d, rel)
@@ -387,4 +393,4 @@ def test_three_hop_acm_sgc_at_linkx_size(dataset, sparse_x):
         worst = max(worst, r)
         assert r < GRAD_TOL, (k, dd, r)
     rec["grad_worst_rel"] = worst
-    _record(f"sgc3hop/{dataset}/{'csr' if sparse_x else 'dense'}-features", **rec)
+    _record(f"sgc3hop/{dataset}/{'auto-csr' if auto else 'csr' if sparse_x else 'dense'}-features", **rec)

@@ -1194,3 +1194,70 @@ def test_training_without_input_dropout_gathers_the_static_input_once(s, monkeyp
     np.testing.assert_allclose(la, lb, rtol=1e-5)
     for u, v in zip(pa, pb):
         torch.testing.assert_close(u, v, rtol=1e-4, atol=1e-6)
+
+
+def test_wide_sparse_features_handed_over_dense_take_the_csr_route(monkeypatch):
+    """graph.SparseFeatures.auto / GCN.auto_csr (tuning key csr_features): the reference's loaders hand one-hot / bag-of-words
+    features over dense (ACM-Geometric/train.py:66-67); the model projects them from a CSR twin made once per tensor.  Same
+    logits and gradients as with the key off (dense route), the twin is made once, and the refusals hold: dense-valued
+    inputs, narrow inputs, inputs that need a gradient, acmsnowball, a patched F.dropout."""
+    fake_lib.install(monkeypatch)
+    from acm_gnn_amd import GCN, SparseFeatures, graph, tuning, train as T
+    low, high, un, g = graph_tensors("geometric")
+    n = low.shape[0]
+    gen = torch.Generator().manual_seed(5)
+    f_in = 300
+    x = (torch.rand(n, f_in, generator=gen) < 0.02).float() * torch.rand(n, f_in, generator=gen)
+    y = torch.randint(0, 3, (n,), generator=gen)
+    idx = torch.arange(0, n, 2)
+    made = []
+    real = SparseFeatures.from_torch.__func__
+    monkeypatch.setattr(SparseFeatures, "from_torch", classmethod(lambda cls, t: (made.append(1), real(cls, t))[1]))
+    outs = {}
+    for key in (256, 0):
+        with tuning.override(csr_features=key):
+            for method in ("acmgcnp", "acmgcnpp", "acmsgc"):
+                torch.manual_seed(1)
+                model = GCN(f_in, 16, 3, 2, n, 0.0, method, 0, variant=False, attn_layernorm=True)
+                seen = []
+                layer = model.gcns[0]
+                fwd = layer.forward
+                layer.forward = lambda inp, *a, _f=fwd, _s=seen, **k: (_s.append(type(inp).__name__), _f(inp, *a, **k))[1]
+                for _ in range(2):
+                    model.zero_grad()
+                    out = model(x, low, high, un)
+                    F.nll_loss(F.log_softmax(out, 1)[idx], y[idx]).backward()
+                assert seen == (["SparseFeatures"] * 2 if key else ["Tensor"] * 2), (key, method, seen)
+                outs[key, method] = (out.detach(), _model_grads(model))
+    assert len(made) == 1, made                       # one twin per tensor object, across models and calls
+    for method in ("acmgcnp", "acmgcnpp", "acmsgc"):
+        _close(outs[256, method][0], outs[0, method][0].numpy(), method + ": csr twin vs dense logits", **FWD)
+        for k, v in outs[0, method][1].items():
+            _close(outs[256, method][1][k], v.numpy(), method + ": csr twin vs dense " + k)
+    # train.TrainStep asks the model before it permutes the rows (relabelled operators): same loss as the dense route
+    w = T.row_weights(idx, n)
+    losses = {}
+    for key in (256, 0):
+        with tuning.override(csr_features=key, relabel=1):
+            graph.clear_cache()
+            torch.manual_seed(1)
+            model = GCN(f_in, 16, 3, 2, n, 0.0, "acmgcnp", 0, attn_layernorm=True)
+            step = T.TrainStep(model, torch.optim.SGD(model.parameters(), lr=0.0), x, low, y, w, high, un)
+            assert step._permuted and isinstance(step.x, SparseFeatures) == bool(key)
+            losses[key] = float(step())
+    graph.clear_cache()
+    assert abs(losses[256] - losses[0]) < 1e-6, losses
+    assert len(made) == 1, made
+    # an in-place edit of the features is noticed (tensor version): a new twin
+    x.mul_(2.0)
+    assert isinstance(SparseFeatures.auto(x), SparseFeatures) and len(made) == 2
+    # refusals
+    assert SparseFeatures.auto(torch.randn(n, f_in)) .__class__ is torch.Tensor                 # dense values
+    assert SparseFeatures.auto(x[:, :100].contiguous()).__class__ is torch.Tensor               # narrow
+    assert SparseFeatures.auto(x.clone().requires_grad_(True)).__class__ is torch.Tensor        # needs a gradient
+    snow = GCN(f_in, 8, 3, 2, n, 0.0, "acmsnowball", 0)
+    assert snow.auto_csr(x, None) is x
+    model = GCN(f_in, 16, 3, 2, n, 0.5, "acmgcnp", 0)
+    monkeypatch.setattr(F, "dropout", lambda t, p=0.5, training=True, inplace=False: t)         # a mask-replay harness
+    assert model.auto_csr(x, None) is x
+    monkeypatch.undo()
