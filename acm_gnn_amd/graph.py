@@ -288,6 +288,32 @@ class SparseFeatures:
         x._acm_csr_twin = (x._version, twin)
         return x if twin is None else twin
 
+    @staticmethod
+    def known_twin(x):
+        """The twin ``auto`` already made for this very tensor object (and version), or None -- a lookup, no device work."""
+        memo = getattr(x, "_acm_csr_twin", None) if isinstance(x, torch.Tensor) else None
+        return memo[1] if (memo is not None and memo[0] == x._version) else None
+
+    def twin_of_masked(self, x):
+        """``x`` = this matrix with some entries zeroed and the others rescaled (the caller's ``F.dropout`` of the
+        features, a NEW dense tensor every step: ACM-Geometric/models.py:54, ACM-Pytorch/models/models.py:70) -> the
+        same structure with x's values at the stored positions, or None when x has a nonzero entry outside the structure
+        (it is then not a masked copy of this matrix).  The check reads x once and costs one small device-to-host copy."""
+        if tuple(x.shape) != tuple(self.shape) or not x.is_contiguous():
+            return None
+        flat = getattr(self, "_flat_index", None)
+        if flat is None:
+            ip, ix, _ = self.csr.arrays()
+            ip = ip.to(torch.int64)
+            rows = torch.repeat_interleave(torch.arange(self.shape[0], device=ip.device), ip[1:] - ip[:-1])
+            flat = self._flat_index = rows * self.shape[1] + ix.to(torch.int64)
+        vals = x.reshape(-1).index_select(0, flat)
+        if int(torch.count_nonzero(x) - torch.count_nonzero(vals)) != 0:
+            return None
+        out = self.with_values(vals)
+        out._flat_index = flat
+        return out
+
     def with_values(self, values):
         if values.shape != self.values.shape:
             raise ValueError("values must keep the CSR order and length")

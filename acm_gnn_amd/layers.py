@@ -19,10 +19,14 @@ import math
 
 import torch
 import torch.nn as nn
+import torch.nn.functional as F
 from torch.nn.parameter import Parameter
 
 from . import functional as AF
+from . import tuning
 from .graph import FilterOperators, SparseFeatures, operators_for
+
+_TORCH_DROPOUT = F.dropout          # to notice a patched F.dropout (mask replay in tests): see _csr_input
 
 DEFAULT_ATTN_LAYERNORM = True
 _PLUS_LITERAL = ("acmgcn+", "acmgcn++")          # spellings for which ACM-Pytorch's LN fires
@@ -96,6 +100,36 @@ class GraphConvolution(nn.Module):
             "layer_norm_struc_low.bias": self.layer_norm_struc_low.bias,
         }
 
+    # the drop-in route's CSR features (see _csr_input): inputs below this many elements are not support-checked per
+    # step (the check's device-to-host copy would cost a small graph more than the dense projection does)
+    CSR_CHECK_MIN_ELEMENTS = 1 << 24
+
+    def _csr_input(self, x):
+        """The reference's own model code in front of this layer (the drop-in route: its GCN applies ``F.dropout`` to the
+        dense features and hands the result over, models.py:54) -> CSR features where that pays (tuning csr_features;
+        graph.SparseFeatures.auto).  An evaluation pass sees the loader's feature tensor itself: its twin is made once and
+        remembered as this layer's reference structure.  A training pass sees a fresh dropped copy every step: for large
+        inputs it becomes that structure with the copy's values, after a check that the copy has no entry outside it
+        (one read of x + one small host copy; Penn94-shaped first layer: 2 ms of dense projection saved); small inputs
+        and anything that fails the check keep the dense projection."""
+        if F.dropout is not _TORCH_DROPOUT:          # a mask-replay harness: the input stays what its masks were recorded for
+            return x
+        twin = SparseFeatures.known_twin(x)
+        if twin is not None:
+            return twin
+        if not self.training:
+            out = SparseFeatures.auto(x)
+            if out is not x:
+                self._csr_ref = out
+            return out
+        ref = getattr(self, "_csr_ref", None)
+        if (ref is None or x.requires_grad or x.dtype != torch.float32 or x.dim() != 2
+                or x.numel() < self.CSR_CHECK_MIN_ELEMENTS or tuning.HOST.csr_features <= 0
+                or (x.is_cuda and torch.cuda.is_current_stream_capturing())):
+            return x
+        out = ref.twin_of_masked(x)
+        return x if out is None else out
+
     def forward(self, input, adj_low, adj_high=None, adj_low_unnormalized=None, post_relu=False, post_scale=None,
                 post_drop=None, rows_permuted=False, call=None, input_drop=None):
         """Reference signature plus optional keyword arguments: ``post_relu`` / ``post_scale`` fuse the
@@ -121,6 +155,9 @@ class GraphConvolution(nn.Module):
         cfg = self._config()
         if isinstance(input, torch.Tensor) and input.layout != torch.strided:
             input = SparseFeatures.from_torch(input)          # torch-sparse features: CSR projection
+        elif (isinstance(input, torch.Tensor) and input_drop is None and not rows_permuted
+                and not (isinstance(adj_low, FilterOperators) and adj_low.sharded)):
+            input = self._csr_input(input)                    # wide one-hot / bag-of-words features handed over dense
         if isinstance(adj_low, FilterOperators):
             ops = adj_low
         else:

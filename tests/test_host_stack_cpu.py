@@ -1261,3 +1261,64 @@ def test_wide_sparse_features_handed_over_dense_take_the_csr_route(monkeypatch):
     monkeypatch.setattr(F, "dropout", lambda t, p=0.5, training=True, inplace=False: t)         # a mask-replay harness
     assert model.auto_csr(x, None) is x
     monkeypatch.undo()
+
+
+def test_drop_in_route_projects_dropped_dense_features_from_the_reference_structure(monkeypatch):
+    """layers.GraphConvolution._csr_input: the reference's own GCN applies F.dropout to the dense features and hands a NEW
+    tensor to the first layer every step (ACM-Geometric/models.py:54).  An evaluation pass (the loader's tensor itself)
+    makes the CSR twin and leaves it as the layer's reference structure; a training pass takes that structure with the
+    dropped copy's values after the support check -- same output and gradients as the dense projection; a tensor with an
+    entry outside the structure, small inputs and the first training pass (no structure yet) stay dense."""
+    fake_lib.install(monkeypatch)
+    from acm_gnn_amd import GraphConvolution, SparseFeatures, tuning
+    low, high, un, g = graph_tensors("geometric")
+    n = low.shape[0]
+    gen = torch.Generator().manual_seed(6)
+    f_in = 320
+    x = (torch.rand(n, f_in, generator=gen) < 0.02).float()
+    torch.manual_seed(2)
+    layer = GraphConvolution(f_in, 16, n, "acmgcnp", structure_info=0)
+    seen = []
+    import acm_gnn_amd.layers as L
+    real = L.AF.acm_conv
+    monkeypatch.setattr(L.AF, "acm_conv", lambda inp, *a, **k: (seen.append(type(inp).__name__), real(inp, *a, **k))[1])
+    monkeypatch.setattr(GraphConvolution, "CSR_CHECK_MIN_ELEMENTS", 1)
+
+    def train_pass(inp):
+        layer.train()
+        layer.zero_grad()
+        out = layer(inp, low, high, un)
+        out.square().sum().backward()
+        return out.detach(), {k: p.grad.clone() for k, p in layer.named_parameters() if p.grad is not None}
+
+    xd = F.dropout(x, 0.5, training=True)
+    train_pass(xd)                                            # no reference structure yet
+    assert seen == ["Tensor"]
+    layer.eval()
+    with torch.no_grad():
+        e1 = layer(x, low, high, un)
+        e2 = layer(x, low, high, un)
+    assert seen[1:] == ["SparseFeatures"] * 2 and torch.equal(e1, e2)
+    with tuning.override(csr_features=0):
+        with torch.no_grad():
+            e0 = layer(x.clone(), low, high, un)
+    _close(e1, e0.numpy(), "evaluation: csr twin vs dense", **FWD)
+    del seen[:]
+    out_c, g_c = train_pass(xd)
+    assert seen == ["SparseFeatures"]
+    with tuning.override(csr_features=0):
+        out_d, g_d = train_pass(xd)
+    assert seen == ["SparseFeatures", "Tensor"]
+    _close(out_c, out_d.numpy(), "training: reference structure vs dense", **FWD)
+    for k, v in g_d.items():
+        _close(g_c[k], v.numpy(), "training: reference structure vs dense, " + k)
+    # an entry outside the structure: not a masked copy of the features -> dense
+    bad = xd.clone()
+    bad[0, int((x[0] == 0).nonzero()[0])] = 1.0
+    del seen[:]
+    train_pass(bad)
+    assert seen == ["Tensor"]
+    # small inputs are not checked per step
+    monkeypatch.setattr(GraphConvolution, "CSR_CHECK_MIN_ELEMENTS", 1 << 24)
+    train_pass(xd)
+    assert seen == ["Tensor", "Tensor"]
