@@ -308,7 +308,15 @@ class SparseFeatures:
             rows = torch.repeat_interleave(torch.arange(self.shape[0], device=ip.device), ip[1:] - ip[:-1])
             flat = self._flat_index = rows * self.shape[1] + ix.to(torch.int64)
         vals = x.reshape(-1).index_select(0, flat)
-        if int(torch.count_nonzero(x) - torch.count_nonzero(vals)) != 0:
+        if flat.numel() < (1 << 24):
+            # the L0 "norm" is the nonzero count as an fp32 sum of ones: exact below 2^24 and never below 2^24 for a larger
+            # true count (sums of positive terms round monotonically), so it equals the count over the stored positions
+            # only if x has no entry elsewhere.  One streaming pass at 0.23 ms for Penn94's 200 M entries, where
+            # torch.count_nonzero takes 1.08 ms (scripts/micro/probe_support_check.py)
+            same = bool(torch.linalg.vector_norm(x, 0) == torch.linalg.vector_norm(vals, 0))
+        else:
+            same = int(torch.count_nonzero(x) - torch.count_nonzero(vals)) == 0
+        if not same:
             return None
         out = self.with_values(vals)
         out._flat_index = flat

@@ -4,6 +4,7 @@ initialisation, same dropout masks (tests/replay.py), same optimizer and model-s
 and compare the selected test accuracy per split.  Target: mean within
 +-0.2 pp of the reference run; single splits may differ by a few test nodes."""
 import os
+import threading
 
 import numpy as np
 import pytest
@@ -96,6 +97,43 @@ def _prepare(name):
 
 
 _REPLAYS_DONE = {}        # (dataset, gather dtype) -> {split: result}: the fp32 replays serve both tests below (gate time)
+_REPLAY_LOCKS = {}        # (dataset, gather dtype) -> lock: a test waits for the prefetch thread's batch instead of repeating it
+_REPLAY_LOCKS_GUARD = threading.Lock()
+BF16_REPLAYS = ["film_v1", "squirrel"]
+
+
+def _fixed_split_todo(name):
+    """The splits test_fixed_split_accuracy_matches_reference_run replays (None: fixture not generated)."""
+    path = os.path.join(GOLDEN, f"accuracy_{name}.npz")
+    if not os.path.exists(path):
+        return None
+    cfg = load_npz(path)["cfg"]
+    _, _, _, _, _, _, masks, *_ = _prepare(name)
+    return [s for s in cfg["splits"] if s in masks]
+
+
+def prefetch_replays():
+    """Gate time: the replays are bound by the CPU generation of the recorded masks and leave the GPU mostly idle, so
+    conftest.py starts them in a background thread when the session begins and moves this module's tests to the END of
+    the run -- the worker processes then train underneath the other GPU tests.  Same batches, same worker count, same
+    results (every worker is its own process with its own HIP context); a batch that fails here is simply run again, and
+    reported, by the test that needs it."""
+    def work():
+        plan = [(name, "fp32") for name in REPLAYS] + [(name, "bf16") for name in BF16_REPLAYS]
+        for name, dt in plan:
+            try:
+                if dt == "fp32":
+                    todo = _fixed_split_todo(name)
+                else:
+                    path = os.path.join(GOLDEN, f"accuracy_{name}.npz")
+                    todo = list(load_npz(path)["cfg"]["splits"])[:5] if os.path.exists(path) else None
+                if todo:
+                    _replay_parallel(name, todo, dt)
+            except Exception:                      # noqa: BLE001 -- the test repeats the batch and shows the error
+                pass
+    t = threading.Thread(target=work, name="accuracy-replay-prefetch", daemon=True)
+    t.start()
+    return t
 
 
 def _replay_parallel(name, todo, gather_dtype="fp32"):
@@ -103,15 +141,18 @@ def _replay_parallel(name, todo, gather_dtype="fp32"):
     same GPU); results are kept for the other tests of this module."""
     import concurrent.futures as cf
     import multiprocessing as mp
-    have = _REPLAYS_DONE.setdefault((name, gather_dtype), {})
-    missing = [s for s in todo if s not in have]
-    if missing:
-        workers = min(5, len(missing))            # (ten processes on the one GPU were measured slower: 48 s against 27 s for Film)
-        chunks = [missing[i::workers] for i in range(workers)]
-        with cf.ProcessPoolExecutor(max_workers=workers, mp_context=mp.get_context("spawn")) as pool:
-            for part in pool.map(_replay_splits, [name] * workers, chunks, [gather_dtype] * workers):
-                have.update(part)
-    return {s: have[s] for s in todo}
+    with _REPLAY_LOCKS_GUARD:
+        lock = _REPLAY_LOCKS.setdefault((name, gather_dtype), threading.Lock())
+    with lock:
+        have = _REPLAYS_DONE.setdefault((name, gather_dtype), {})
+        missing = [s for s in todo if s not in have]
+        if missing:
+            workers = min(5, len(missing))        # (ten processes on the one GPU were measured slower: 48 s against 27 s for Film)
+            chunks = [missing[i::workers] for i in range(workers)]
+            with cf.ProcessPoolExecutor(max_workers=workers, mp_context=mp.get_context("spawn")) as pool:
+                for part in pool.map(_replay_splits, [name] * workers, chunks, [gather_dtype] * workers):
+                    have.update(part)
+        return {s: have[s] for s in todo}
 
 
 def _replay_splits(name, splits, gather_dtype="fp32"):
@@ -229,7 +270,7 @@ def test_fixed_split_accuracy_matches_reference_run(name):
     assert abs(got.mean() - ref.mean()) <= mean_bound, (got.mean(), ref.mean())
 
 
-@pytest.mark.parametrize("name", ["film_v1", "squirrel"])
+@pytest.mark.parametrize("name", BF16_REPLAYS)
 def test_bf16_gathered_operands_keep_the_accuracy(name):
     """the opt-in bf16 storage of the gathered operands (gather_dtype = "bf16": the wide forward
     gathers, the structure-channel gathers, and -- new -- the transposed products of the backward, acm_conv_bwd_spmm_t.
