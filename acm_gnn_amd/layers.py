@@ -118,9 +118,15 @@ class GraphConvolution(nn.Module):
         if twin is not None:
             return twin
         if not self.training:
+            # (a layer that once refused a tensor of this shape does not count the nonzeros of every new tensor of that
+            # shape -- wide hidden activations arrive as fresh objects each pass; the loader's tensor carries its answer)
+            if getattr(x, "_acm_csr_twin", None) is None and getattr(self, "_csr_refused", None) == tuple(x.shape):
+                return x
             out = SparseFeatures.auto(x)
             if out is not x:
                 self._csr_ref = out
+            else:
+                self._csr_refused = tuple(x.shape)
             return out
         ref = getattr(self, "_csr_ref", None)
         if (ref is None or x.requires_grad or x.dtype != torch.float32 or x.dim() != 2
