@@ -1,10 +1,12 @@
 #!/bin/bash
 # rocprofv3 kernel stats of a few bench_configs.py configurations -> gpurun_out/configs_kernel_stats.txt
+#   bash scripts/configs_kernel_stats.sh [config ...]      (default: the eight below)
 cd /tmp; export TMPDIR=/tmp
 REPO=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$REPO/gpurun_out/configs_kernel_stats.txt
 mkdir -p $REPO/gpurun_out; : > $OUT
-for cfg in twitch/acmiigcnp twitch/acmiigcnp+A twitch/acmgcnpp twitch/acmgcnp+A arxiv-year/acmgcnp arxiv-year/acmsgc-3hop squirrel/acmgcnp+A penn94/acmgcnp/csrX; do
+CFGS=${@:-twitch/acmiigcnp twitch/acmiigcnp+A twitch/acmgcnpp twitch/acmgcnp+A arxiv-year/acmgcnp arxiv-year/acmsgc-3hop squirrel/acmgcnp+A penn94/acmgcnp/csrX}
+for cfg in $CFGS; do
   rm -rf /tmp/pp
   rocprofv3 --kernel-trace --stats -d /tmp/pp -o pp -- python $REPO/scripts/bench_configs.py $cfg > /dev/null 2>&1
   echo "== $cfg   (kernel | calls | avg us | % of GPU time; torch / rocprim preparation kernels omitted)" >> $OUT
