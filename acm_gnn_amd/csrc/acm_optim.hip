@@ -17,7 +17,7 @@
 
 namespace {
 
-constexpr int PACK = 32;          // tensors per launch
+constexpr int PACK = 40;          // tensors per launch (a 2-layer model with the structure channel has 34-36 with gradients)
 constexpr int CHUNK = 2048;       // elements per block
 
 struct AdamPack {
@@ -127,13 +127,14 @@ __global__ __launch_bounds__(256) void adam_kernel(AdamPack pk, AdamScalars hp, 
 
 // The pending second phases of the step + the update, one grid: blocks [0, pd.blocks) reduce, the rest update the tensors
 // no segment writes (pk.first_block counts those only).  `covered` = the tensors whose whole gradient the segments produce.
-constexpr int FUSED_SEGS = 24;
+constexpr int FUSED_SEGS = 28;
 struct PendingPack {
     int n, blocks;
-    unsigned covered;
+    unsigned long long covered;      // bit t: tensor t of the pack (PACK <= 64)
     int first[FUSED_SEGS + 1];
     acm_reduce_seg_t seg[FUSED_SEGS];
 };
+static_assert(PACK <= 64, "PendingPack::covered is a 64-bit mask");
 static_assert(sizeof(AdamPack) + sizeof(PendingPack) + sizeof(AdamScalars) + 16 <= 4096, "kernel arguments: 4 KB");
 
 __global__ __launch_bounds__(256) void adam_flush_kernel(AdamPack pk, PendingPack pd, AdamScalars hp, int* arrive,
@@ -146,7 +147,7 @@ __global__ __launch_bounds__(256) void adam_flush_kernel(AdamPack pk, PendingPac
         acm_reduce_block(pd.seg[i], e - pd.first[i], red, [&](float* dst, float gsum) {
             *dst = gsum;
             for (int t = 0; t < pk.n; ++t) {                     // (uniform index: the tables stay in scalar registers)
-                if (!((pd.covered >> t) & 1u)) continue;
+                if (!((pd.covered >> t) & 1ull)) continue;
                 const float* g0 = pk.g[t];
                 if (dst < g0 || dst >= g0 + pk.numel[t]) continue;
                 const long idx = dst - g0;
@@ -222,7 +223,7 @@ int adam_with_flush(int n_tensors, const acm_adam_tensor_t* tensors, const acm_a
         pk.p[t] = a.param, pk.g[t] = a.grad, pk.m[t] = a.exp_avg, pk.v[t] = a.exp_avg_sq, pk.step[t] = a.step;
         pk.numel[t] = (long)a.numel;
         pk.first_block[t] = blocks;
-        if (hit) pd.covered |= 1u << t;
+        if (hit) pd.covered |= 1ull << t;
         else blocks += (int)((a.numel + CHUNK - 1) / CHUNK);
     }
     pk.first_block[n_tensors] = blocks;

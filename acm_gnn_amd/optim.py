@@ -1,6 +1,6 @@
 """Fused Adam / AdamW: the optimizer update that closes the reference's training step
 (ACM-Geometric/train.py:113-119 construct torch.optim.Adam / AdamW, :137 ``optimizer.step()``;
-ACM-Pytorch/train.py:70-84, utils.py:572) as ONE kernel launch per 32 parameter tensors
+ACM-Pytorch/train.py:70-84, utils.py:572) as ONE kernel launch per 40 parameter tensors
 (``acm_adam_step``) instead of torch's ~80 launches for the 26 parameters of the two-layer model.
 
 Same constructor arguments, update formulas, ``state`` keys (``step`` / ``exp_avg`` /

@@ -831,7 +831,7 @@ int acm_conv_fwd_tail(const acm_csr_t* a_low, const acm_conv_fwd_t* fwd, const a
                       void* tail_workspace, size_t tail_workspace_bytes, acm_stream_t stream);
 
 /* ------------------------------------------------ fused optimizer update --
- * Adam / AdamW over a list of fp32 parameter tensors in one launch per 32 tensors: the update of
+ * Adam / AdamW over a list of fp32 parameter tensors in one launch per 40 tensors: the update of
  * torch.optim.Adam / AdamW that closes the reference's training step (ACM-Geometric/train.py:113-119,137;
  * ACM-Pytorch/train.py:70-84, utils.py:572), same formulas in the same order:
  *     step += 1
@@ -864,7 +864,7 @@ typedef struct {
                                           inside the update launch itself where it can: the reducing blocks lead the grid,
                                           a sum that is an element of a tensor's `grad` is stored AND applied at once (same
                                           formulas, same values as flush-then-update: bit-identical), the other tensors are
-                                          updated by the blocks behind.  Needs `arrive`, <= 32 tensors, <= 24 segments and
+                                          updated by the blocks behind.  Needs `arrive`, <= 40 tensors, <= 28 segments and
                                           every `grad` written by the segments entirely or not at all; otherwise the call
                                           runs acm_reduce_flush first and then the plain update.  The list is empty afterwards */
 } acm_adam_config_t;
