@@ -55,6 +55,7 @@ CONFIGS = {
     # ... and handed over DENSE, as the reference's loaders do: the model makes the CSR twin itself (tuning csr_features)
     "cora/acmgcn/auto": dict(graph="cora", f_in=1433, classes=7, method="acmgcn", s=0, variant=0, dropout=0.6, sparse="auto"),
     "squirrel/acmgcnp+A/auto": dict(graph="squirrel", f_in=2089, classes=5, method="acmgcnp", s=1, variant=0, dropout=0.6, sparse="auto"),
+    "chameleon/acmgcnp+A/auto": dict(graph="chameleon", f_in=2325, classes=5, method="acmgcnp", s=1, variant=0, dropout=0.7, sparse="auto"),
     "penn94/acmgcnp/auto": dict(graph="syn:penn94", method="acmgcnp", s=0, variant=0, dropout=0.1, sparse="auto"),
     "penn94/acmsgc-3hop/auto": dict(graph="syn:penn94", method="acmsgc", s=0, variant=0, dropout=0.1, sparse="auto", hops=3),
     # BASELINE config 5: ACM-SGC 3-hop (one linear ACM layer, the low channel through A_low three times)
