@@ -36,6 +36,9 @@ def _accuracy_replay_prefetch(request):
     if len(wanted) >= 4 and len(names) < len(request.session.items) and torch.cuda.is_available():
         import test_gpu_accuracy
         test_gpu_accuracy.prefetch_replays()
+        # the oracle's CPU steps of the other tests now share the host with five worker processes: an OpenMP team as wide
+        # as the machine waits for its descheduled members (a 17 s test took 70 s); a team of 48 leaves them room
+        torch.set_num_threads(min(os.cpu_count() or 8, 48))
     yield
 
 
