@@ -1120,8 +1120,14 @@ int launch_gather(const acm_csr* a, const GatherSrc& g, int F, const typename Ep
         // 4 k columns, 8-byte aligned); the two-neighbours-per-instruction pair kernel otherwise.  On the twitch-shaped
         // graph the pair kernel is SLOWER than the fp32 vector form (conv_bwd_spmm 619 -> 707 us: half the bytes, but two
         // neighbours per instruction instead of four)
+        // ... except under the fused head once the tables outgrow the 256 MB Infinity Cache: every row then comes from
+        // HBM, the kernel lives on loads in flight, and the vector layout (the head four times, fewer waves) loses to the
+        // pair kernel -- pokec-shaped forward (1.63 M rows, 418 MB of bf16 tables) 5.39 -> 3.89 ms, while the head-less
+        // transposed gather of the backward keeps the vector form (2.32 against 2.88 ms): profiles/r04_bench_scale.jsonl
+        const bool head_beyond_cache = __is_same(Epi, EpiFwd) && (size_t)a->n_cols * F * NG * 2u > ((size_t)256 << 20);
         bool vec16 = bf16 && F % 4 == 0 && form != 1 && form != 3 &&
-                     ((NG == 1 && a->nnz >= 16 * a->n_rows) || (NG > 1 && a->nnz >= 4 * a->n_rows) || form == 2);
+                     ((NG == 1 && a->nnz >= 16 * a->n_rows) || (NG > 1 && a->nnz >= 4 * a->n_rows && !head_beyond_cache) ||
+                      form == 2);
         for (int c = 0; c < NG && vec16; ++c)
             vec16 = ((uintptr_t)g.p[c]) % 8 == 0 && g.ld[c] % 4 == 0 && (uint64_t)a->n_cols * (uint64_t)g.ld[c] * 2u < (1ull << 32);
         if (vec16) {

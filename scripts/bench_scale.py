@@ -6,7 +6,11 @@ the rows of the benchmark graph, drawn on the GPU by the generator of tests/test
 same shapes against the oracle).  One JSON line per graph: ms/step, stored edges per second, peak device memory, the
 per-kernel HIP-event breakdown.
 
-    python scripts/bench_scale.py [pokec] [snap-patents]
+    python scripts/bench_scale.py [pokec] [snap-patents] [pokec/bf16] [snap-patents/bf16]
+
+``<graph>/bf16``: the opt-in bf16 storage of the gathered operands (GCN(gather_dtype="bf16"): BASELINE config 3's tolerance;
+fp32 sums) -- at these sizes the wide gathers are HBM-bandwidth kernels (profiles/r04_pokec_pmc.txt), so bytes per edge are
+what moves them.
 """
 import json
 import os
@@ -30,6 +34,7 @@ SHAPES = {"pokec": (1_632_803, 30_622_564, 14_854, 65, 2, False),
 
 def run(name, steps=20):
     from test_gpu_scale import _powerlaw_graph_on_gpu
+    name, _, dt = name.partition("/")
     n, n_edges, max_deg, f_in, n_cls, directed = SHAPES[name]
     t0 = time.time()
     adj = _powerlaw_graph_on_gpu(n, n_edges, max_deg, seed=3, directed=directed)
@@ -41,7 +46,8 @@ def run(name, steps=20):
     ops = relabel_by_degree(as_implicit(FilterOperators(CsrGraph.from_scipy(low, DEV))))
     prep = time.time() - t0
     torch.manual_seed(0)
-    model = acm_gnn_amd.GCN(f_in, 64, n_cls, 2, n, 0.1, "acmgcnp", 0, variant=False, attn_layernorm=True).to(DEV)
+    model = acm_gnn_amd.GCN(f_in, 64, n_cls, 2, n, 0.1, "acmgcnp", 0, variant=False, attn_layernorm=True,
+                            gather_dtype=dt or None).to(DEV)
     opt = acm_gnn_amd.FusedAdamW(model.parameters(), lr=0.01, weight_decay=1e-3)
     w = T.row_weights(tr, n)
     torch.cuda.reset_peak_memory_stats()
@@ -69,7 +75,7 @@ def run(name, steps=20):
         gstep()
     graph, loss = timed(gstep)
     ms = min(eager, graph)
-    return {"graph": name, "nodes": n, "nnz_A_low": int(low.nnz), "f_in": f_in, "directed": directed,
+    return {"graph": name, "gather_dtype": dt or "fp32", "nodes": n, "nnz_A_low": int(low.nnz), "f_in": f_in, "directed": directed,
             "operator": "pattern-only" if ops.implicit else "explicit + transposed CSR",
             "eager_ms": round(eager, 3), "graph_ms": round(graph, 3),
             "stored_edges_per_s": round(low.nnz / (ms * 1e-3), 1), "loss": loss, "prep_s": round(prep, 1),
