@@ -90,3 +90,36 @@ def test_bf16_gather_tolerance(name, model_type, variant, s, f_out):
     os.makedirs(out_dir, exist_ok=True)
     with open(os.path.join(out_dir, "bf16_sweep.json"), "w") as fh:
         json.dump(TABLE, fh, indent=1, sort_keys=True)
+
+
+@pytest.mark.parametrize("model_type,variant,s", [("acmgcnp", 0, 0), ("acmgcnp", 1, 1)])
+def test_bf16_forward_forms_agree(model_type, variant, s):
+    """The two kernels a bf16 wide gather under the fused head can take (acm_conv.hip: the four-neighbour vector form on
+    cache-resident tables, the pair kernel once the tables outgrow the Infinity Cache -- pokec / snap-patents sizes) read the
+    same bf16 tables and differ in fp32 summation order only: same output and gradients on the Squirrel structure."""
+    from conftest import tune_now as tune
+    from acm_gnn_amd import GraphConvolution
+    from acm_gnn_amd.graph import clear_cache
+    g = load_npz(os.path.join(GOLDEN, "graph_squirrel.npz"))
+    n = int(g["n"])
+    adj = sp.csr_matrix((np.ones(len(g["adj_un_indices"])), g["adj_un_indices"], g["adj_un_indptr"]), shape=(n, n))
+    low, high, un = O.filters_linkx(adj)
+    gen = torch.Generator().manual_seed(1)
+    x = torch.randn(n, 40, generator=gen)
+    gout = torch.randn(n, 64, generator=gen)
+    res = {}
+    for form in (2, 3):                                  # 2: vector form everywhere, 3: the pair kernel
+        tune(wide_form=form)
+        clear_cache()
+        torch.manual_seed(3)
+        layer = GraphConvolution(40, 64, n, model_type, variant=variant, structure_info=s, attn_layernorm=True,
+                                 gather_dtype="bf16").to(DEV)
+        xd = x.to(DEV).requires_grad_(True)
+        out = layer(xd, low.to(DEV), high.to(DEV), un.to(DEV) if s else None)
+        out.backward(gout.to(DEV))
+        res[form] = (out.detach().cpu(), xd.grad.cpu(), {k: p.grad.cpu() for k, p in layer.named_parameters() if p.grad is not None})
+    a, b = res[2], res[3]
+    assert float((a[0] - b[0]).abs().max()) < 2e-5 * max(1.0, float(a[0].abs().max()))
+    assert float((a[1] - b[1]).abs().max()) < 1e-4 * max(1.0, float(a[1].abs().max()))
+    for k, v in a[2].items():
+        assert float((b[2][k] - v).abs().max()) < 2e-4 * max(1.0, float(v.abs().max())), k
