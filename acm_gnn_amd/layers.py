@@ -208,11 +208,21 @@ class GraphConvolution(nn.Module):
         # (the entry also keeps the operators alive and compares them by identity: an id() of a collected object can be
         # handed to the next one)
         key = (x.data_ptr(), x._version, tuple(x.shape), tuple(x.stride()))
-        cached = getattr(self, "_eval_agg", None)
+        # one entry per ROLE: a training step and the evaluation pass of the same epoch may hand over different tensor
+        # objects (relabelled operators: the training loop permutes x once, an evaluation forward permutes it again) --
+        # with a single entry each replaced the other's, P was recomputed every pass and a captured training step lost the
+        # P its graph reads
+        role = "train" if (self.training and torch.is_grad_enabled()) else "eval"
+        slots = self.__dict__.setdefault("_eval_agg", {})
+        cached = slots.get(role)
         if cached is None or cached[0] != key or cached[3] is not ops:
             cached = (key, x, {"agg": None}, ops)
-            self._eval_agg = cached
+            slots[role] = cached
         return cached[2]
+
+    def held_entries(self):
+        """The cache entries as they are now (a captured step keeps them: train.TrainStep / EvalStep ``_held``)."""
+        return list(self.__dict__.get("_eval_agg", {}).values())
 
     # After a forward the reference's layer holds att_low / att_high / att_mlp (/ att_struc_vec_low): N x 1 tensors, 0
     # before the first call (layers.py:17, 91, 107).  Here they are views of the kernel's [n, 4] output, translated

@@ -29,6 +29,17 @@ def row_weights(train_idx, n_rows, n_train_total=None, device=None):
     return w
 
 
+def _held_entries(model):
+    """What a captured pass over ``model`` reads beyond its graph's own pool: the layers' P = A_low X cache entries
+    (layers.GraphConvolution._eval_agg_holder: key, input, {"agg": P, "xpad": ...}, operators) as they are right now."""
+    held = []
+    for m in model.modules():
+        entries = getattr(m, "held_entries", None)
+        if entries is not None:
+            held.extend(entries())
+    return held
+
+
 def _capture_mode():
     """Keyword arguments of torch.cuda.graph for a capture.  With a process group alive, ProcessGroupNCCL's watchdog
     thread polls the events of earlier collectives (hipEventQuery) whenever it wakes up; under the default GLOBAL capture
@@ -74,6 +85,7 @@ class TrainStep:
             self.labels, self.weights = labels.index_select(0, ops.perm), weights.index_select(0, ops.perm)
             self._permuted = True
         self.graph, self.loss = None, None
+        self._held = None                   # what a captured step reads beyond its graph's pool (see _capture)
         # counter-based dropout: this loop owns the step structure (one advance per optimizer step), so the
         # model may draw its masks inside the kernels; the advance rides FusedAdam's step-counter kernel
         # (default: on, unless someone replaced F.dropout -- a mask-replay harness must keep seeing its masks)
@@ -253,6 +265,20 @@ class TrainStep:
                 losses.append(loss)
             self.loss, self.losses = loss, losses
         del loss, losses
+        # A dropout-0 model reuses the first layer's P = A_low X from the layer's cache (layers._eval_agg_holder): the
+        # graph bakes in the address of the P its capture read.  Only the layer's cache entry keeps that tensor alive, and
+        # another forward of the same model on another input object replaces the entry -- held here (as EvalStep does), the
+        # replay keeps reading valid memory whatever the layers cache afterwards (use-after-free).
+        self._held = _held_entries(self.model)
+
+    def refresh(self):
+        """Re-capture after an in-place edit of the features (or of anything else the captured step read once: a captured
+        step assumes ``x`` is static, like EvalStep)."""
+        if self.graph is not None:
+            self.graph = None
+            if self.pipe is not None:
+                self.pipe.primed = False
+            self._capture()
 
     def _opt_step(self):
         pending, self._unflushed = self._unflushed, None
@@ -352,7 +378,7 @@ class EvalStep:
         # what the captured kernels read beyond the pool of the graph: the layers' evaluation-pass cache entries
         # (key, input, {"agg": P}, operators) as they are now -- held here so that a later eval-mode forward of the same
         # model on another input cannot free them under the replay
-        self._held = [m._eval_agg for m in self.model.modules() if getattr(m, "_eval_agg", None) is not None]
+        self._held = _held_entries(self.model)
 
     def __call__(self):
         if self.graph is not None:

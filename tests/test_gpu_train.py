@@ -507,3 +507,39 @@ def test_drop_in_route_with_dense_one_hot_features_takes_the_csr_projection():
     finally:
         L.AF.acm_conv = conv
         clear_cache()
+
+
+@pytest.mark.gpu
+def test_captured_dropout_free_fit_on_relabelled_operators_survives_an_emptied_cache():
+    """fit(use_graph=True) of a dropout-0 model on relabelled operators.  The captured training step
+    reads the first layer's P = A_low X at the address its capture saw; the EvalStep built next hands the model a fresh
+    permuted copy of x, which used to replace the layer's only cache entry and free that P.  TrainStep now holds the
+    entries it captured with (and training / evaluation inputs have their own): emptying the allocator's cache and
+    churning memory between the replays must not change a single loss against the eager loop."""
+    from acm_gnn_amd import GCN, FusedAdamW, train as T
+    n = 3001
+    ops, x, y = _pipeline_case(n, 40, seed=7, relabel=True)
+    assert ops.perm is not None
+    idx = torch.randperm(n, generator=torch.Generator().manual_seed(1)).to(DEV)
+    tr, va, te = idx[:1500], idx[1500:2250], idx[2250:]
+
+    def run(use_graph):
+        torch.manual_seed(0)
+        model = GCN(7, 64, 2, 2, n, 0.0, "acmgcnp", 0, variant=False, attn_layernorm=True).to(DEV)
+        opt = FusedAdamW(model.parameters(), lr=0.01)
+        w = T.row_weights(tr, n, device=DEV)
+        step = T.TrainStep(model, opt, x, ops, y, w, use_graph=use_graph)
+        ev = T.EvalStep(model, x, ops, y, (tr, va, te), use_graph=use_graph)
+        if use_graph:
+            assert step._held, "the captured step holds no cache entry: nothing keeps its P alive"
+        out = []
+        for _ in range(6):
+            loss = float(step())
+            torch.cuda.empty_cache()
+            junk = [torch.full((n, 8), float("nan"), device=DEV) for _ in range(8)]      # whatever is free gets overwritten
+            del junk
+            _, accs, vloss = ev()
+            out.append((loss, vloss) + tuple(accs))
+        return np.asarray(out)
+
+    np.testing.assert_allclose(run(True), run(False), rtol=2e-5, atol=1e-6)

@@ -1322,3 +1322,49 @@ def test_drop_in_route_projects_dropped_dense_features_from_the_reference_struct
     monkeypatch.setattr(GraphConvolution, "CSR_CHECK_MIN_ELEMENTS", 1 << 24)
     train_pass(xd)
     assert seen == ["Tensor", "Tensor"]
+
+
+def test_training_and_evaluation_inputs_keep_separate_p_cache_entries(monkeypatch):
+    """a dropout-0 training step reuses the first layer's P = A_low X from the layer's cache, and a
+    captured step bakes in that tensor's address.  With relabelled operators the evaluation pass hands the layer a FRESH
+    permuted copy of x: with one cache entry per layer that replaced the training entry and freed the P a captured replay
+    still reads.  Now (a) training and evaluation have their own entries -- neither evicts the other, so the gather runs
+    once per role, not once per pass -- and (b) a step that captures holds the entries (`_held_entries`)."""
+    import weakref
+    fake = fake_lib.install(monkeypatch)
+    from acm_gnn_amd import GCN, train as T
+    ops, n = _dense_graph_ops(seed=9)
+    x = torch.randn(n, 7, generator=torch.Generator().manual_seed(2))
+    gathers = []
+    orig = fake.acm_conv_agg_fwd
+    monkeypatch.setattr(fake, "acm_conv_agg_fwd", lambda h, pp, *a: (gathers.append(int(pp._obj.agg_given)), orig(h, pp, *a))[1])
+    torch.manual_seed(3)
+    model = GCN(7, 64, 2, 2, n, 0.0, "acmgcnp", 0, variant=0, attn_layernorm=True)
+    opt = torch.optim.SGD(model.parameters(), lr=0.05)
+
+    def train_pass():
+        model.train()
+        opt.zero_grad()
+        model(x, ops).square().mean().backward()
+        opt.step()
+
+    def eval_pass():
+        model.eval()
+        with torch.no_grad():
+            return model(x.clone(), ops)             # a fresh tensor object every pass, as x.index_select(perm) is
+
+    train_pass()
+    p_train = weakref.ref(model.gcns[0].held_entries()[0][2]["agg"])
+    assert p_train() is not None
+    held = T._held_entries(model)                    # what TrainStep._capture keeps
+    gathers.clear()
+    eval_pass()
+    train_pass()
+    eval_pass()
+    train_pass()
+    # the training entry survived both evaluation passes: its P was given (1) both times; the evaluation input is a new
+    # object each pass and gathers (0) -- by design
+    assert gathers[0::2] == [0, 0] and gathers[1::2] == [1, 1], gathers
+    assert p_train() is not None and held[0][2]["agg"] is p_train()
+    roles = model.gcns[0].__dict__["_eval_agg"]
+    assert set(roles) == {"train", "eval"}
