@@ -19,10 +19,17 @@ _F32 = torch.float32
 class KernelTimer:
     """Per-launch HIP-event timing (torch.cuda.Event on the stream the kernels are launched
     on).  ``only`` restricts timing to labels that start with it, so that the events around the
-    one kernel under study do not perturb the rest of a timed region."""
+    one kernel under study do not perturb the rest of a timed region.
 
-    def __init__(self, only=None):
+    ``external=True``: launches made while the stream is being CAPTURED are bracketed by *external* events (event-record
+    nodes of the hipGraph, ``torch.cuda.Event(external=True)``): every replay re-records them, so after a replay and a
+    synchronize ``captured_ms(label)`` is that kernel's duration INSIDE the replayed graph -- the time that belongs next
+    to a hipGraph-replay ``ms_per_step`` (bench.py's roofline).  Without it, launches under capture
+    are not timed at all (a plain event recorded in a capture cannot be read)."""
+
+    def __init__(self, only=None, external=False):
         self.only, self.events = only, {}
+        self.external, self.captured = bool(external), {}
         self.bytes = {}                 # label -> bytes this rank SENT into collectives under that label
 
     def wants(self, label):
@@ -32,6 +39,11 @@ class KernelTimer:
         """label -> (launches, total ms); synchronises."""
         torch.cuda.synchronize()
         return {k: (len(v), sum(a.elapsed_time(b) for a, b in v)) for k, v in self.events.items()}
+
+    def captured_ms(self, label):
+        """ms of every captured launch under ``label`` in the LAST replay of the graph(s) that hold them; synchronises."""
+        torch.cuda.synchronize()
+        return [a.elapsed_time(b) for a, b in self.captured.get(label, [])]
 
 
 _TIMER = None
@@ -46,20 +58,25 @@ class _Timed:
     def __init__(self, label, nbytes=0):
         self.label = label
         self.on = _TIMER is not None and _TIMER.wants(label)
+        self.capturing = False
+        if self.on and torch.cuda.is_available() and torch.cuda.is_current_stream_capturing():
+            self.capturing = True
+            self.on = _TIMER.external
         if self.on and nbytes:
             _TIMER.bytes[label] = _TIMER.bytes.get(label, 0) + int(nbytes)
 
     def __enter__(self):
         if self.on:
-            self.a = torch.cuda.Event(enable_timing=True)
-            self.b = torch.cuda.Event(enable_timing=True)
+            kw = {"external": True} if self.capturing else {}
+            self.a = torch.cuda.Event(enable_timing=True, **kw)
+            self.b = torch.cuda.Event(enable_timing=True, **kw)
             self.a.record()
         return self
 
     def __exit__(self, *exc):
         if self.on:
             self.b.record()
-            _TIMER.events.setdefault(self.label, []).append((self.a, self.b))
+            (_TIMER.captured if self.capturing else _TIMER.events).setdefault(self.label, []).append((self.a, self.b))
         return False
 
 

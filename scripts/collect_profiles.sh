@@ -26,7 +26,8 @@ for PASS in "FETCH_SIZE:pmc_fetch_size_kb" "WRITE_SIZE:pmc_write_size_kb" "TCC_H
   python $REPO/scripts/rocpd_pmc_summary.py $DB > $OUT/$NAME.csv 2>> $OUT/$NAME.err
 done
 if [ "$COMMIT" = "unknown" ]; then echo "collect_profiles.sh: pass the commit the box runs (git rev-parse --short HEAD) as the second argument" >&2; fi
-python $REPO/scripts/make_traffic_json.py $OUT/pmc_fetch_size_kb.csv $OUT/pmc_write_size_kb.csv $COMMIT > $OUT/pmc_traffic.json
+# every label of the bench line must resolve against the counter CSVs (exit status 1 and a message otherwise)
+python $REPO/scripts/make_traffic_json.py $OUT/pmc_fetch_size_kb.csv $OUT/pmc_write_size_kb.csv $COMMIT --require-from $OUT/bench.json > $OUT/pmc_traffic.json || echo "collect_profiles.sh: pmc_traffic.json is INCOMPLETE (see the message above)" >&2
 # the driver's line LAST, quoting the counters just collected (same kernel sources by construction: no stale traffic)
 mv $OUT/bench.json $OUT/bench_first.json
 $BENCH --traffic-json $OUT/pmc_traffic.json > $OUT/bench.json 2>> $OUT/bench.err

@@ -129,11 +129,16 @@ def main(fetch_csv, write_csv, commit=None, required=()):
 
 
 if __name__ == "__main__":
-    # make_traffic_json.py fetch.csv write.csv [commit] [--require label,label,...]   (the labels of the bench line)
+    # make_traffic_json.py fetch.csv write.csv [commit] [--require label,label,...] [--require-from bench.json]
     argv = sys.argv[1:]
     req = ()
     if "--require" in argv:
         i = argv.index("--require")
         req = tuple(x for x in argv[i + 1].split(",") if x)
+        del argv[i:i + 2]
+    if "--require-from" in argv:                 # ... or read off a bench line (config.kernel_ms of bench.py's JSON)
+        i = argv.index("--require-from")
+        with open(argv[i + 1]) as fh:
+            req = req + tuple(json.loads(fh.read().strip().splitlines()[-1])["config"]["kernel_ms"])
         del argv[i:i + 2]
     main(argv[0], argv[1], argv[2] if len(argv) > 2 else None, req)
