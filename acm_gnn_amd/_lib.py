@@ -14,7 +14,7 @@ c_i32p = C.POINTER(C.c_int32)
 
 ACM_OK = 0
 STATUS_NAMES = {1: "ACM_EINVAL", 2: "ACM_ESHAPE", 3: "ACM_EHIP", 4: "ACM_EUNSUPPORTED", 5: "ACM_ENOMEM"}
-ABI_VERSION = 24
+ABI_VERSION = 25
 
 # every symbol include/acm_hip.h declares
 EXPORTED_SYMBOLS = (
@@ -27,6 +27,7 @@ EXPORTED_SYMBOLS = (
     "acm_conv_acmii_fwd_workspace_bytes", "acm_conv_acmii_fwd", "acm_linear_fwd", "acm_bias_act", "acm_bias_act_bwd_workspace_bytes", "acm_bias_act_bwd",
     "acm_acmii_table_bytes", "acm_acmii_table", "acm_conv_acmii_v_fwd", "acm_conv_acmii_v_bwd_workspace_bytes", "acm_conv_acmii_v_bwd",
     "acm_linear_bwd_workspace_bytes", "acm_linear_bwd", "acm_linear_fwd_add", "acm_linear_bwd_recompute",
+    "acm_small_step_workspace_bytes", "acm_small_step",
 )
 
 
@@ -203,6 +204,25 @@ class AdamConfig(C.Structure):
                 ("arrive", C.c_void_p), ("pending", C.c_void_p)]
 
 
+SMALL_ROLES = 17
+# acm_small_step_t.t[layer][role]: role indices (include/acm_hip.h: ACM_SR_*)
+SR_W_LOW, SR_W_HIGH, SR_W_MLP, SR_V_LOW, SR_V_HIGH, SR_V_MLP, SR_V_STRUC = range(7)
+SR_LNW_LOW, SR_LNW_HIGH, SR_LNW_MLP, SR_LNW_STRUC, SR_LNB_LOW, SR_LNB_HIGH, SR_LNB_MLP, SR_LNB_STRUC, SR_MIX, SR_STRUC = range(7, 17)
+
+
+class SmallStep(C.Structure):
+    _fields_ = [("n_classes", C.c_int32), ("n_channels", C.c_int32), ("relu_before", C.c_int32), ("layernorm", C.c_int32),
+                ("scale", C.c_float), ("train", C.c_int32), ("update", C.c_int32), ("phases", C.c_int32),
+                ("t", (AdamTensor * SMALL_ROLES) * 2),
+                ("x_vals", C.c_void_p), ("xt_src_pos", C.c_void_p), ("z1_given", C.c_void_p), ("w1_grad_given", C.c_int32),
+                ("f_in", C.c_int32), ("drop_in", Dropout), ("drop_hidden", Dropout),
+                ("row_scale", C.c_void_p), ("labels", C.c_void_p), ("row_weight", C.c_void_p), ("loss", C.c_void_p),
+                ("logits", C.c_void_p), ("att1", C.c_void_p), ("att2", C.c_void_p), ("dz1", C.c_void_p),
+                ("lr", C.c_double), ("beta1", C.c_double), ("beta2", C.c_double), ("eps", C.c_double),
+                ("weight_decay", C.c_double), ("decoupled", C.c_int32), ("also_advance", C.c_void_p), ("arrive", C.c_void_p),
+                ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t)]
+
+
 _lib = None
 _lock = threading.Lock()
 
@@ -266,6 +286,8 @@ def _declare(lib):
     lib.acm_reduce_flush.argtypes = [vp, vp]
     lib.acm_conv_fwd_tail_workspace_bytes.argtypes = [i64, i32, i32, C.POINTER(sz)]
     lib.acm_conv_fwd_tail.argtypes = [vp, C.POINTER(ConvFwd), C.POINTER(Loss), C.POINTER(ConvBwdLocal), vp, sz, vp, sz, vp]
+    lib.acm_small_step_workspace_bytes.argtypes = [vp, vp, vp, C.POINTER(sz)]
+    lib.acm_small_step.argtypes = [vp, vp, vp, C.POINTER(SmallStep), vp]
     for name in EXPORTED_SYMBOLS:
         fn = getattr(lib, name)
         if name not in ("acm_version", "acm_last_error", "acm_csr_destroy"):

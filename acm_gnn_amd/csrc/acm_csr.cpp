@@ -36,7 +36,7 @@ const TuningField kTuningFields[] = {{"chunk", &acm_tuning_t::chunk},           
                                      {"bwd_split", &acm_tuning_t::bwd_split},   {"rows16", &acm_tuning_t::rows16},
                                      {"agg_fused", &acm_tuning_t::agg_fused},   {"gemm_forms", &acm_tuning_t::gemm_forms}};
 // host-side keys of the same variable (acm_gnn_amd/tuning.py reads them; listed here so that they are not "unknown")
-const char* const kHostKeys[] = {"rewrites", "implicit", "relabel", "pipeline", "csr_features"};
+const char* const kHostKeys[] = {"rewrites", "implicit", "relabel", "pipeline", "csr_features", "small_step"};
 
 const char* tuning_invalid(const acm_tuning_t& t) {
     if (t.chunk != 0 && (t.chunk < 8 || t.chunk > 4096 || (t.chunk & (t.chunk - 1)))) return "chunk";

@@ -14,6 +14,7 @@
 #include <math.h>
 
 #include "acm_reduce_device.h"
+#include "acm_adam_device.h"
 
 namespace {
 
@@ -29,30 +30,6 @@ struct AdamPack {
     long numel[PACK];
     int first_block[PACK + 1];
     int n;
-};
-
-struct AdamScalars {
-    double lr, beta1, beta2, eps, weight_decay;
-    int decoupled;
-};
-
-__device__ __forceinline__ void adam_one(float& p, float g, float& m, float& v, float decay, float wd, bool decoupled,
-                                         float w1, float b2, float w2, float step_size, float bc2_sqrt, float eps) {
-    if (decoupled) p *= decay;
-    else g = g + wd * p;
-    m = m + w1 * (g - m);
-    v = v * b2 + w2 * g * g;
-    const float denom = sqrtf(v) / bc2_sqrt + eps;
-    p = p - step_size * (m / denom);
-}
-
-struct AdamFactors {
-    float decay_eff, wd, w1, b2, w2, eps;
-    bool decoupled;
-    __device__ explicit AdamFactors(const AdamScalars& hp)
-        : decay_eff(hp.weight_decay == 0.0 ? 1.0f : (float)(1.0 - hp.lr * hp.weight_decay)), wd((float)hp.weight_decay),
-          w1((float)(1.0 - hp.beta1)), b2((float)hp.beta2), w2((float)(1.0 - hp.beta2)), eps((float)hp.eps),
-          decoupled(hp.decoupled != 0 || hp.weight_decay == 0.0) {}
 };
 
 // block `blk` of the update of pack `pk` (blk counts from the pack's first block)
@@ -178,6 +155,17 @@ __global__ void adam_advance_kernel(AdamPack pk, int64_t* also_advance) {
 // dst[(e / inner) * outer_stride + blk(e % inner)] -- runs of consecutive addresses of length col_block (or inner).
 long seg_overlap(const acm_reduce_seg_t& sg, const float* lo, const float* hi) {
     long hit = 0;
+    if (sg.len <= 0) return 0;
+    if (sg.outer_stride >= 0 && sg.block_stride >= 0) {
+        // most (tensor, segment) pairs are disjoint: compare the segment's bounding range first.  (The run walk below
+        // costs two 64-bit divisions per run, and a dW segment with col_block = 1 has one run per element: tens of
+        // thousands of iterations per eager step over ~36 tensors x ~10 segments)
+        const long jmax = (sg.len - 1) / sg.inner;
+        const long maxcol = sg.col_block ? ((long)(sg.inner - 1) / sg.col_block) * sg.block_stride + sg.col_block : (long)sg.inner;
+        const float* b0 = sg.dst;
+        const float* b1 = sg.dst + jmax * sg.outer_stride + maxcol;
+        if (b1 <= lo || b0 >= hi) return 0;
+    }
     for (long el = 0; el < sg.len;) {
         const long j = el / sg.inner, q = el % sg.inner;
         long run = sg.col_block ? sg.col_block - q % sg.col_block : sg.inner - q;

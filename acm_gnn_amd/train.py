@@ -54,8 +54,11 @@ def _capture_mode():
 
 class TrainStep:
     def __init__(self, model, optimizer, x, adj, labels, weights, adj_high=None, adj_un=None, use_graph=False,
-                 fused_dropout=None, pipeline_input=None, steps_per_graph=1, flush_in_optimizer=True):
-        """``flush_in_optimizer``: with this package's FusedAdam / FusedAdamW the step's deferred gradient sums are flushed by
+                 fused_dropout=None, pipeline_input=None, steps_per_graph=1, flush_in_optimizer=True, small_step=None):
+        """``small_step``: the fused six-launch step for small graphs (small.SmallPlan / acm_small_step): None = where it
+        applies (``self.small`` is the plan, ``self.small_refused`` the reason it does not), False = never.
+
+        ``flush_in_optimizer``: with this package's FusedAdam / FusedAdamW the step's deferred gradient sums are flushed by
         the optimizer's own launch (acm_adam_config_t.pending) instead of a launch of their own.
 
         ``steps_per_graph`` (with ``use_graph``): capture that many consecutive optimizer steps in ONE hipGraph, so that a
@@ -116,8 +119,32 @@ class TrainStep:
         if pipeline_input is not False and not self._manual_advance and getattr(model, "fused_dropout", False) \
                 and AF.InputPipeline.eligible(model, self.adj, self.x):
             self.pipe = AF.InputPipeline(self.adj, self.x, model.dropout, model.dropout_state, tag=0)
+        # small graphs: the whole step behind one C-ABI call (six launches, updates applied where gradients finish)
+        self.small, self.small_refused = None, "not requested"
+        if small_step is not False:
+            from .small import SmallPlan
+            why = "the loop advances the dropout counter by hand" if self._manual_advance else \
+                SmallPlan.why_not(model, self.x, self.adj, optimizer)
+            if why is None and getattr(model, "dropout", 0) > 0 and not getattr(model, "fused_dropout", False):
+                why = "F.dropout masks (counter-based dropout only)"
+            self.small_refused = why
+            if why is None:
+                self.small = SmallPlan(model, self.x, self.adj, self.labels, self.weights, optimizer)
+                self.pipe = None
         if use_graph:
             self._capture()
+
+    def _one_step(self):
+        """Forward + loss + backward + update (+ the dropout counter's advance): one step, eager or under capture."""
+        if self.small is not None:
+            loss = self.small.run()
+        else:
+            loss = self._forward_backward(for_optimizer=True)
+            self._opt_step()
+        self._count_advance()
+        if self.pipe is not None:
+            self.pipe.end_step()
+        return loss
 
     def _forward_backward(self, for_optimizer=False):
         """Forward, fused loss and backward; the loss sum and the parameter-gradient sums of the backward kernels run
@@ -188,11 +215,7 @@ class TrainStep:
         if not self.model.training:
             self.model.train()
         self.opt.zero_grad(set_to_none=True)
-        loss = self._forward_backward(for_optimizer=True)
-        self._opt_step()
-        self._count_advance()
-        if self.pipe is not None:
-            self.pipe.end_step()
+        loss = self._one_step()
         return loss                 # never hand out the autograd graph: a live AccumulateGrad node pins its
                                     # stream and breaks a later graph capture
 
@@ -257,11 +280,9 @@ class TrainStep:
             for k in range(self.steps_per_call):
                 if k:
                     self.opt.zero_grad(set_to_none=True)
-                loss = self._forward_backward(for_optimizer=True)
-                self._opt_step()
-                self._count_advance()
-                if self.pipe is not None:
-                    self.pipe.end_step()
+                loss = self._one_step()
+                if self.small is not None and self.steps_per_call > 1:
+                    loss = loss.clone()          # the plan's loss scalar is rewritten by the next step of the same graph
                 losses.append(loss)
             self.loss, self.losses = loss, losses
         del loss, losses
@@ -332,7 +353,8 @@ class EvalStep:
     in place afterwards (call :meth:`refresh` if it was) and it keeps those tensors alive itself: another evaluation of
     the same model on other inputs may replace the layers' cache entries, the replay still reads valid memory."""
 
-    def __init__(self, model, x, adj, labels, index_sets, adj_high=None, adj_un=None, loss_set=1, use_graph=False):
+    def __init__(self, model, x, adj, labels, index_sets, adj_high=None, adj_un=None, loss_set=1, use_graph=False,
+                 small_step=None):
         self.model, self.x, self.adj, self.adj_high, self.adj_un = model, x, adj, adj_high, adj_un
         self.labels = labels
         self._labels_safe = labels.clamp_min(0)             # -1 = unlabeled (never in an index set)
@@ -343,6 +365,19 @@ class EvalStep:
             idx = idx.nonzero().view(-1) if idx.dtype == torch.bool else idx.long()
             w[k].index_fill_(0, idx, 1.0 / max(int(idx.numel()), 1))
         self.w, self.loss_set = w, int(loss_set)
+        # small graphs: the evaluation forward as one call (small.SmallPlan without an optimizer)
+        self.small, self.small_refused = None, "not requested"
+        if small_step is not False:
+            from .graph import FilterOperators, operators_for
+            from .small import SmallPlan
+            ops = adj
+            if not isinstance(adj, FilterOperators) and isinstance(adj, torch.Tensor) and hasattr(model, "structure_info"):
+                four = model.structure_info and getattr(model, "model_type", "") in ("acmgcnp", "acmgcnpp")
+                ops = operators_for(adj, adj_high, adj_un if four else None)
+            xs = model.auto_csr(x, ops if isinstance(ops, FilterOperators) else None) if hasattr(model, "auto_csr") else x
+            self.small_refused = SmallPlan.why_not(model, xs, ops, None, need_dropout_state=False)
+            if self.small_refused is None:
+                self.small = SmallPlan(model, xs, ops)
         self.graph, self.out, self.res = None, None, None
         self._held = None
         self._use_graph = bool(use_graph)
@@ -358,7 +393,10 @@ class EvalStep:
     @torch.no_grad()
     def _run(self):
         self.model.eval()
-        out = self.model(self.x, self.adj, self.adj_high, self.adj_un)
+        if self.small is not None:
+            out = self.small.run()                       # three launches, one C-ABI call (acm_small_step, train = 0)
+        else:
+            out = self.model(self.x, self.adj, self.adj_high, self.adj_un)
         correct = (out.argmax(dim=1) == self.labels).to(torch.float32)
         nll = -F.log_softmax(out, 1).gather(1, self._labels_safe.view(-1, 1)).view(-1)
         res = torch.cat([self.w @ correct, (self.w[self.loss_set] * nll).sum().view(1)])

@@ -25,6 +25,12 @@ Host-level keys:
     csr_features  wide, mostly-zero feature matrices handed over DENSE (bag-of-words, one-hot: the reference's loaders
                densify them) are projected from a CSR copy made once per tensor (graph.SparseFeatures.auto): 0 = never,
                n > 0 = for inputs of at least n columns with at most 1/16 of the entries nonzero.  Default 256
+    small_step the fused six-launch training step / three-launch evaluation pass for small graphs (small.SmallPlan,
+               acm_small_step): 0 = never, n > 0 = for graphs of at most n rows (the kernels take <= 16384).  Default 16384
+
+One policy for a malformed ACM_TUNING in both readers: the item is REPORTED on stderr and IGNORED -- by the
+library when it is loaded, by this module when it is imported (``parse(text)`` itself stays strict for programmatic use:
+it raises ValueError).  Switches of earlier rounds that still sit in the environment (ACM_GATHER_DTYPE, ...) are reported once.
 
 Tests and probes flip forms with ``override(...)`` (a context manager; restores both records on exit) -- or, for child
 processes, by putting ACM_TUNING into the child's environment.
@@ -35,8 +41,9 @@ import os
 import threading
 
 KERNEL_KEYS = ("chunk", "wide_form", "bwd_split", "rows16", "agg_fused", "gemm_forms")
-HOST_DEFAULTS = {"rewrites": 7, "implicit": 1, "relabel": -1, "pipeline": 8192, "csr_features": 256}
-HOST_RANGES = {"rewrites": (0, 7), "implicit": (0, 1), "relabel": (-1, 1), "pipeline": (0, 1 << 31), "csr_features": (0, 1 << 31)}
+HOST_DEFAULTS = {"rewrites": 7, "implicit": 1, "relabel": -1, "pipeline": 8192, "csr_features": 256, "small_step": 16384}
+HOST_RANGES = {"rewrites": (0, 7), "implicit": (0, 1), "relabel": (-1, 1), "pipeline": (0, 1 << 31), "csr_features": (0, 1 << 31),
+               "small_step": (0, 16384)}
 
 REWRITE_AGG_FIRST = 1
 REWRITE_ACMII_RECOMPUTE = 2
@@ -87,7 +94,41 @@ def parse(text):
     return kern, host
 
 
-_LOADED_HOST = parse(os.environ.get("ACM_TUNING", ""))[1]           # read ONCE, at import
+def parse_lenient(text, report=None):
+    """``parse`` item by item: a malformed / unknown / out-of-range item is reported (``report(message)``, default: one
+    line on stderr) and ignored -- what the library does with the same variable when it is loaded."""
+    import sys
+    report = report or (lambda msg: sys.stderr.write(f"acm_gnn_amd: {msg} (ignored)\n"))
+    kern, host = {}, {}
+    for item in (text or "").split(","):
+        if not item.strip():
+            continue
+        try:
+            k, h = parse(item)
+        except ValueError as exc:
+            report(str(exc))
+            continue
+        kern.update(k)
+        host.update(h)
+    return kern, host
+
+
+# switches of rounds 1-3 that no launch path reads any more: say so once instead of ignoring them silently
+LEGACY_ENV = ("ACM_GATHER_DTYPE", "ACM_EVAL_AGG_CACHE", "ACM_CHUNK", "ACM_WIDE_FORM", "ACM_BWD_SPLIT", "ACM_AGG_FUSED", "ACM_PIPELINE",
+              "ACM_IMPLICIT", "ACM_RELABEL", "ACM_REWRITES", "ACM_ROWS16", "ACM_GEMM_FORMS")
+
+
+def _report_legacy(environ, report=None):
+    import sys
+    report = report or (lambda msg: sys.stderr.write(f"acm_gnn_amd: {msg}\n"))
+    found = [k for k in LEGACY_ENV if k in environ]
+    if found:
+        report(f"{', '.join(found)}: environment switches of earlier rounds are no longer read; use ACM_TUNING=\"key=value,...\"")
+    return found
+
+
+_LOADED_HOST = parse_lenient(os.environ.get("ACM_TUNING", ""))[1]           # read ONCE, at import
+_report_legacy(os.environ)
 HOST = _Host(**_LOADED_HOST)
 _lock = threading.RLock()
 _kernel_cache = None

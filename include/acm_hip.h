@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define ACM_ABI_VERSION 24
+#define ACM_ABI_VERSION 25
 
 typedef enum {
     ACM_OK = 0,
@@ -871,6 +871,83 @@ typedef struct {
 
 int acm_adam_step(int32_t n_tensors, const acm_adam_tensor_t* tensors, const acm_adam_config_t* cfg,
                   acm_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------------------------
+ * Small graphs (round 5, ABI 25): the WHOLE training step of the two-layer ACM model in six launches.
+ *
+ * Replaces, for graphs whose every table fits the caches (Cora / Chameleon / Squirrel: BASELINE configs 1-3;
+ * ACM-Pytorch/train.py:95-139 runs them for thousands of epochs x 10 splits), the ~250 ATen launches of one step of
+ * ACM-Pytorch/models/models.py:100-166 + utils.py:547-574 (model forward, log_softmax + nll_loss, backward, Adam) --
+ * and the 17-18 launches the general path of this library needs -- by one launch per DEPENDENCY LEVEL of the step:
+ *
+ *   1  Z1 = drop(X) [W_L | W_H | W_I]                                  (CSR features; rows of W gathered by feature id)
+ *   2  layer 1: gather [Z_L | Z_H | S] over the operator, head, mix, ReLU + dropout -> H; Z2 = H [W2_L | W2_H | W2_I]
+ *   3  layer 2: gather [Z2_L | Z2_H | S2], head -> logits; masked NLL; the layer's own row-local backward
+ *   4  layer 2: gather [G_L | G_H | G_S] (transposed operator = the same pattern) -> dZ2, dS2 (+ update of S2);
+ *      dH = dZ2 W2^T; dW2 partial sums; layer 1's row-local backward
+ *   5  layer 1: gather [G_L | G_H | G_S] -> dZ1, dS (+ update of S)
+ *   6  dW1 = drop(X)^T dZ1 by feature row + update of W1; every other parameter-gradient sum + its update; the loss;
+ *      the step counters
+ *
+ * Rows are never split over launches: a row longer than the handle's chunk is cut into pieces whose partial sums meet
+ * in a slot buffer, and the piece that arrives last finishes the row (fixed order of additions: deterministic, no float
+ * atomics).  Hidden width 64, at most 8 classes, pattern-only operator (acm_csr_create with vals = NULL) + row scale.
+ * With `update` the Adam / AdamW update of every parameter is applied where its gradient becomes final (same formulas
+ * as acm_adam_step); without it the gradients are written to t[..].grad and nothing is updated.
+ * `train = 0`: launches 1-3 only, forward (evaluation pass: logits, att).
+ */
+#define ACM_SMALL_ROLES 17
+enum {
+    ACM_SR_W_LOW = 0, ACM_SR_W_HIGH, ACM_SR_W_MLP,                         /* [f_in, F] row-major                  */
+    ACM_SR_V_LOW, ACM_SR_V_HIGH, ACM_SR_V_MLP, ACM_SR_V_STRUC,              /* att_vec_*: F floats                  */
+    ACM_SR_LNW_LOW, ACM_SR_LNW_HIGH, ACM_SR_LNW_MLP, ACM_SR_LNW_STRUC,      /* LayerNorm gamma                      */
+    ACM_SR_LNB_LOW, ACM_SR_LNB_HIGH, ACM_SR_LNB_MLP, ACM_SR_LNB_STRUC,      /* LayerNorm beta                       */
+    ACM_SR_MIX,                                                             /* att_vec: k x k row-major             */
+    ACM_SR_STRUC                                                            /* struc_low: [n, F]                    */
+};
+
+typedef struct {
+    int32_t n_classes;          /* C <= 8: width of layer 2 (layer 1 is f_in -> 64)                                  */
+    int32_t n_channels;         /* k = 3, or 4 with the structure channel                                            */
+    int32_t relu_before;        /* 1: ACMII (`variant`): ReLU between projection and filter; 0: ACM, ReLU after      */
+    int32_t layernorm;          /* 1: LayerNorm feeds the attention logits (ACM-Geometric dialect)                   */
+    float   scale;              /* 3, or 1 with the structure channel                                                */
+    int32_t train;              /* 1: the step; 0: forward only (launches 1-3)                                       */
+    int32_t update;             /* 1: apply Adam / AdamW in place; 0: write gradients to t[..].grad                   */
+    int32_t phases;             /* bit l-1 set: run launch l (0 = all the mode needs); dense features split the call  */
+    /* t[layer][role]: param NULL = the role is absent / takes no gradient.  exp_avg / exp_avg_sq / step as in
+     * acm_adam_tensor_t (needed with `update`); grad: optional output (required without `update`).  numel is ignored. */
+    acm_adam_tensor_t t[2][ACM_SMALL_ROLES];
+    /* first-layer input: CSR features (the handles passed to the call) with this call's values ...               */
+    const float* x_vals;        /* nnz(X) values in the order of the x handle                                        */
+    const int32_t* xt_src_pos;  /* nnz(X): position in x_vals of every entry of the TRANSPOSED handle                */
+    /* ... or dense features: the caller computes Z1 = drop(X) [W_L | W_H | W_I] (acm_gemm) before, and
+     * dW1 = drop(X)^T dZ1 into t[0][W_*].grad between launches 5 and 6 (phases)                                      */
+    const float* z1_given;      /* [n, 192] row-major, or NULL                                                       */
+    int32_t w1_grad_given;      /* 1: launch 6 updates W1 from t[0][W_*].grad (f_in x 64 each) instead of computing it */
+    int32_t f_in;
+    acm_dropout_t drop_in;      /* on x_vals: element (position, 0)                                                  */
+    acm_dropout_t drop_hidden;  /* on the hidden activations: element (row, column)                                  */
+    const float* row_scale;     /* 1 / d_i                                                                           */
+    const int64_t* labels;      /* [n]                                                                               */
+    const float* row_weight;    /* [n]: 1 / |train| on training rows, else 0                                         */
+    float* loss;                /* device scalar                                                                     */
+    float* logits;              /* [n, C] contiguous                                                                 */
+    float* att1; float* att2;   /* [n, 4] mixing weights of the two layers                                           */
+    float* dz1;                 /* [n, 192]: dL/dZ1 (output of launch 5; dense features read it for dW1)             */
+    double  lr, beta1, beta2, eps, weight_decay;
+    int32_t decoupled;
+    int64_t* also_advance;      /* optional device counter incremented with the step counters (dropout step)         */
+    int32_t* arrive;            /* device int32, zero between calls                                                  */
+    void*   workspace;          /* acm_small_step_workspace_bytes; ZERO-FILLED by the caller once, kept between calls */
+    size_t  workspace_bytes;
+} acm_small_step_t;
+
+int acm_small_step_workspace_bytes(const acm_csr_t* a_low, const acm_csr_t* x, const acm_csr_t* x_t, size_t* bytes);
+/* x / x_t: CSR handles of the features and of their transpose (pattern; values come from p->x_vals), or NULL with
+ * z1_given.  Errors: ACM_EUNSUPPORTED outside the envelope (explicit values, > 8 classes, > 16384 rows, ...). */
+int acm_small_step(const acm_csr_t* a_low, const acm_csr_t* x, const acm_csr_t* x_t, const acm_small_step_t* p,
+                   acm_stream_t stream);
 
 #ifdef __cplusplus
 }

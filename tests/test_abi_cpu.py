@@ -46,7 +46,7 @@ def test_calls_without_gpu_fail_loudly_not_silently():
 STRUCTS = {"acm_csr_info_t": "CsrInfo", "acm_conv_fwd_t": "ConvFwd", "acm_conv_bwd_local_t": "ConvBwdLocal",
            "acm_conv_bwd_spmm_t": "ConvBwdSpmm", "acm_conv_agg_fwd_t": "ConvAggFwd", "acm_conv_agg_bwd_t": "ConvAggBwd",
            "acm_spmm_opts_t": "SpmmOpts", "acm_dropout_t": "Dropout", "acm_adam_tensor_t": "AdamTensor", "acm_adam_config_t": "AdamConfig",
-           "acm_tuning_t": "Tuning"}
+           "acm_tuning_t": "Tuning", "acm_small_step_t": "SmallStep"}
 
 
 def _struct(pyname):
@@ -132,8 +132,12 @@ def test_acm_tuning_variable_is_read_once_at_load(tmp_path):
     out = subprocess.run([sys.executable, "-c", f"import ctypes\nctypes.CDLL({_lib.library_path()!r})"], env=env,
                          capture_output=True, text=True)                   # the library alone: reports and ignores the items
     assert "bad value 'rows16=9'" in out.stderr and "unknown key 'nonsense'" in out.stderr, out.stderr
-    out = subprocess.run([sys.executable, "-c", "import acm_gnn_amd"], env=env, capture_output=True, text=True)
-    assert out.returncode != 0 and "unknown key 'nonsense'" in out.stderr   # the package refuses to start with it
+    # ... and the package does the same with it (one policy): reported, ignored, the valid items taken
+    code2 = "import acm_gnn_amd\nfrom acm_gnn_amd import tuning\nprint(tuning.HOST.pipeline)\n"
+    env2 = dict(env, ACM_TUNING="pipeline=77,nonsense=1,relabel=7", ACM_GATHER_DTYPE="bf16")
+    out = subprocess.run([sys.executable, "-c", code2], env=env2, capture_output=True, text=True)
+    assert out.returncode == 0 and out.stdout.split() == ["77"], (out.stdout, out.stderr)
+    assert "unknown key 'nonsense'" in out.stderr and "relabel=7 outside" in out.stderr and "ACM_GATHER_DTYPE" in out.stderr
     from acm_gnn_amd import tuning
     with pytest.raises(ValueError):
         tuning.parse("nonsense=1")
