@@ -214,7 +214,7 @@ class SmallStep(C.Structure):
     _fields_ = [("n_classes", C.c_int32), ("n_channels", C.c_int32), ("relu_before", C.c_int32), ("layernorm", C.c_int32),
                 ("scale", C.c_float), ("train", C.c_int32), ("update", C.c_int32), ("phases", C.c_int32),
                 ("t", (AdamTensor * SMALL_ROLES) * 2),
-                ("x_vals", C.c_void_p), ("xt_src_pos", C.c_void_p), ("z1_given", C.c_void_p), ("w1_grad_given", C.c_int32),
+                ("x_vals", C.c_void_p), ("xt_src_pos", C.c_void_p), ("xt_vals", C.c_void_p), ("z1_given", C.c_void_p), ("w1_grad_given", C.c_int32),
                 ("f_in", C.c_int32), ("drop_in", Dropout), ("drop_hidden", Dropout),
                 ("row_scale", C.c_void_p), ("labels", C.c_void_p), ("row_weight", C.c_void_p), ("loss", C.c_void_p),
                 ("logits", C.c_void_p), ("att1", C.c_void_p), ("att2", C.c_void_p), ("dz1", C.c_void_p),

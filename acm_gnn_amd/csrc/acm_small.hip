@@ -30,8 +30,10 @@ typedef float f4 __attribute__((ext_vector_type(4)));
 
 constexpr int F = 64;                 // hidden width
 constexpr int C8 = 8;                 // padded class count
-constexpr int WAVES = 4;              // per workgroup
-constexpr int MAX_WG = 256;           // persistent workgroups of the gather phases (one per CU)
+constexpr int WAVES = 8;              // per workgroup of the gather phases (two per SIMD: the second hides the first's latency chain)
+constexpr int MAX_WG = 2048;          // workgroups of a gather phase: one work item per wave up to 16384 items (a wave's item is a
+                                      // latency chain of ~2 000 dependent instructions; more waves, not longer loops, hide it)
+constexpr int RED_EL = 32;            // elements of the partial-sum vectors per reducing block of the last launch
 constexpr int PART4 = 3 * F * C8 + 3 * 4 * F + 16;      // dW2 [3][64][8] | dv1 [4][64] | dgamma1 | dbeta1 | dmix1 [4][4]
 constexpr int PART3 = 3 * 4 * C8 + 16 + 1;              // dv2 [4][8] | dgamma2 | dbeta2 | dmix2 | loss
 constexpr int PART3_PITCH = 128;
@@ -66,7 +68,8 @@ struct SmallDev {
     float* logits;
     float *att1, *att2;
     // workspace
-    float *Z1, *H1, *ST1, *OUT1, *T2, *Z2I, *G2, *DZ2, *G1, *DZ1, *slots, *part3, *part4;
+    float *Z1, *H1, *ST1, *OUT1, *T2, *Z2I, *G2, *DZ2, *G1, *DZ1, *slots, *part3, *part4, *W2T, *FACT;
+    const float* xt_vals;
     int* counters;
     int nwg3, nwg4;                  // producer workgroups of the two partial-sum buffers
     int w1_grad_given;
@@ -113,39 +116,53 @@ __device__ __forceinline__ void wide_gather(const int32_t* __restrict__ ids, int
         const int id = ok ? ids[pos] : safe;
         const float w = ok ? weight(pos) : 0.f;
         const int steps = (min(end - k0, 64) + 3) >> 2;              // uniform
-#define ACM_WG_BLOCK(U0)                                                                        \
-        if (steps > U0) {                                                                       \
-            f4 v[4][NCH];                                                                       \
-            float ww[4];                                                                        \
-            _Pragma("unroll") for (int s = 0; s < 4; ++s) {                                     \
+        // CNT steps (x NCH rows) requested before the first is consumed: a step is a dependent L2 round trip, and with one
+        // item per wave nothing else hides it
+#define ACM_WG_BLOCK(U0, CNT)                                                                   \
+        {                                                                                       \
+            f4 v[CNT][NCH];                                                                     \
+            float ww[CNT];                                                                      \
+            _Pragma("unroll") for (int s = 0; s < CNT; ++s) {                                   \
                 const int j = acm_row_bcast(id, U0 + s);                                        \
                 ww[s] = bcast_f(w, U0 + s);                                                     \
                 _Pragma("unroll") for (int c = 0; c < NCH; ++c)                                 \
                     v[s][c] = ld4(tab[c] + (long)j * ld[c] + 4 * m);                            \
             }                                                                                   \
-            _Pragma("unroll") for (int s = 0; s < 4; ++s)                                       \
+            _Pragma("unroll") for (int s = 0; s < CNT; ++s)                                     \
                 _Pragma("unroll") for (int c = 0; c < NCH; ++c) {                               \
                     f4 x = v[s][c];                                                             \
                     if ((RELU_MASK >> c) & 1) x = relu4(x);                                     \
                     acc[c] += ww[s] * x;                                                        \
                 }                                                                               \
         }
-        ACM_WG_BLOCK(0)
-        ACM_WG_BLOCK(4)
-        ACM_WG_BLOCK(8)
-        ACM_WG_BLOCK(12)
+        if (steps <= 4) {
+            ACM_WG_BLOCK(0, 4)
+        } else if (steps <= 8) {
+            ACM_WG_BLOCK(0, 8)
+        } else {
+            ACM_WG_BLOCK(0, 8)
+            if (steps <= 12) {
+                ACM_WG_BLOCK(8, 4)
+            } else {
+                ACM_WG_BLOCK(8, 8)
+            }
+        }
 #undef ACM_WG_BLOCK
     }
 }
 
 // The item loop of a wide phase: every wave takes the items wave, wave + n_waves, ...; `gather(item, acc)` fills the lane's
 // partial sums, `epi(row, acc)` runs once per ROW with the complete sums (in every group).
-template <int NCH, class Gather, class Epi>
-__device__ __forceinline__ void wide_items(const ItemView& iv, float* slots, int* counters, int wave, int n_waves, Gather&& gather,
-                                           Epi&& epi) {
+// `pre(row)`: the loads of the row's epilogue that depend on nothing but the row number, requested BEFORE the gather (they
+// travel while the item -> ids -> rows chain runs; with one item per wave that chain is the kernel's duration).
+template <int NCH, class Pre, class Gather, class Epi>
+__device__ __forceinline__ void wide_items(const ItemView& iv, float* slots, int* counters, int wave, int n_waves, Pre&& pre,
+                                           Gather&& gather, Epi&& epi) {
     const int lane = threadIdx.x & 63, g = lane >> 4, m = lane & 15;
     for (int it = wave; it < iv.n_items; it += n_waves) {
-        const AcmItem item = iv.items[it];
+        AcmItem item = iv.items[it];
+        item.row = acm_uniform(item.row), item.begin = acm_uniform(item.begin), item.end = acm_uniform(item.end), item.slot = acm_uniform(item.slot);
+        auto pf = pre(item.row);
         f4 acc[3] = {zero4(), zero4(), zero4()};
         gather(item, acc);
 #pragma unroll
@@ -168,7 +185,7 @@ __device__ __forceinline__ void wide_items(const ItemView& iv, float* slots, int
                 for (int c = 0; c < NCH; ++c) acc[c] += ld4_coherent(qp + c * F);
             }
         }
-        epi(item.row, acc);
+        epi(item.row, acc, pf);
     }
 }
 
@@ -179,25 +196,35 @@ template <int NQ>
 __device__ __forceinline__ f4 narrow_gather(const int32_t* __restrict__ ids, int begin, int end, const float* __restrict__ tab,
                                             int ld, int safe, bool relu01) {
     const int lane = threadIdx.x & 63, q = lane & 7, base = lane & ~7;
-    const bool mine = q < NQ;
-    const bool relu = relu01 && q < 4;
+    const int qq = q < NQ ? q : NQ - 1;                  // idle lanes repeat the last block (unconditional loads: a guarded load
+    const bool relu = relu01 && q < 4;                   // makes the compiler wait for every one before the next)
     f4 acc = zero4();
     for (int k0 = begin; k0 < end; k0 += 64) {
         const int pos = k0 + 8 * q + (lane >> 3);
-        const int id = pos < end ? ids[pos] : -1;
+        const bool ok = pos < end;
+        const int id = ok ? ids[pos] : safe;
+        const float w = ok ? 1.f : 0.f;
         const int steps = (min(end - k0, 64) + 7) >> 3;
+        f4 v[8];
+        float ww[8];
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
-            if (u < steps) {
+            if (u < steps || u < 2) {                    // (uniform; two steps always: most rows of a small graph end there)
                 const int j = __shfl(id, base + u);
-                if (j >= 0 && mine) {
-                    f4 x = ld4(tab + (long)j * ld + 4 * q);
-                    if (relu) x = relu4(x);
-                    acc += x;
-                }
+                ww[u] = __shfl(w, base + u);
+                v[u] = ld4(tab + (long)j * ld + 4 * qq);
+            } else {
+                v[u] = zero4(), ww[u] = 0.f;
             }
         }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            f4 x = v[u];
+            if (relu) x = relu4(x);
+            acc += ww[u] * x;
+        }
     }
+    if (q >= NQ) acc = zero4();
 #pragma unroll
     for (int off = 8; off < 64; off <<= 1) {
         acc.x += __shfl_xor(acc.x, off);
@@ -208,12 +235,14 @@ __device__ __forceinline__ f4 narrow_gather(const int32_t* __restrict__ ids, int
     return acc;
 }
 
-template <int NQ, class Gather, class Epi>
-__device__ __forceinline__ void narrow_items(const ItemView& iv, float* slots, int* counters, int wave, int n_waves, Gather&& gather,
-                                             Epi&& epi) {
+template <int NQ, class Pre, class Gather, class Epi>
+__device__ __forceinline__ void narrow_items(const ItemView& iv, float* slots, int* counters, int wave, int n_waves, Pre&& pre,
+                                             Gather&& gather, Epi&& epi) {
     const int lane = threadIdx.x & 63, q = lane & 7;
     for (int it = wave; it < iv.n_items; it += n_waves) {
-        const AcmItem item = iv.items[it];
+        AcmItem item = iv.items[it];
+        item.row = acm_uniform(item.row), item.begin = acm_uniform(item.begin), item.end = acm_uniform(item.end), item.slot = acm_uniform(item.slot);
+        auto pf = pre(item.row);
         f4 acc = gather(item);
         if (item.slot >= 0) {
             float* sp = slots + (long)item.slot * (3 * F);
@@ -230,7 +259,7 @@ __device__ __forceinline__ void narrow_items(const ItemView& iv, float* slots, i
             if (q < NQ)
                 for (int s = lr.slot_begin; s < lr.slot_end; ++s) acc += ld4_coherent(slots + (long)s * (3 * F) + 4 * q);
         }
-        epi(item.row, acc);
+        epi(item.row, acc, pf);
     }
 }
 
@@ -260,26 +289,38 @@ __device__ __forceinline__ void adam_four(const SmallTensor& t, long i, f4 g, co
     st4(t.p + i, f4{pp[0], pp[1], pp[2], pp[3]}), st4(t.m + i, f4{mm[0], mm[1], mm[2], mm[3]}), st4(t.v + i, f4{vv[0], vv[1], vv[2], vv[3]});
 }
 
-// the step-dependent factors of one tensor, computed once per workgroup (double-precision pow) and shared through LDS
-__device__ __forceinline__ void stage_factors(const AdamScalars& hp, const SmallTensor& t, float* sc) {
-    if (threadIdx.x == 0 && t.p && t.step) acm_adam_step_factors(hp, t.step[0], sc[0], sc[1]);
+// What the later launches of the step read as tables, written by the first workgroup of launch 1 (both change every step):
+//   W2T  [idx = ch * 8 + c][col]: layer 2's weights, classes padded to 8 -- a lane's four columns of one output are one
+//        16-byte load, for the forward projection (launch 2) and for dH = dZ2 W2^T (launch 4) alike
+//   FACT [layer * 17 + role][2]: the step-dependent Adam factors of every tensor (double-precision pow: once, not per block)
+__device__ __forceinline__ void write_tables(const SmallDev& d) {
+    if (blockIdx.x != 0) return;
+    for (int e = threadIdx.x; e < 3 * F * C8; e += blockDim.x) {
+        const int idx = e / F, col = e % F, ch = idx >> 3, c = idx & 7;
+        d.W2T[e] = c < d.C ? d.t[1][ACM_SR_W_LOW + ch].p[col * d.C + c] : 0.f;
+    }
+    if ((int)threadIdx.x < 2 * ACM_SMALL_ROLES && d.update) {
+        const SmallTensor& t = d.t[threadIdx.x / ACM_SMALL_ROLES][threadIdx.x % ACM_SMALL_ROLES];
+        if (t.p && t.step) acm_adam_step_factors(d.hp, t.step[0], d.FACT[2 * threadIdx.x], d.FACT[2 * threadIdx.x + 1]);
+    }
 }
 
 // ------------------------------------------------------------------------------------------------ launch 1: Z1 = drop(X) Wcat
 __global__ __launch_bounds__(256) void small_proj1_kernel(SmallDev d) {
+    write_tables(d);
     const int lane = threadIdx.x & 63, g = lane >> 4, m = lane & 15;
-    const int wave = (int)blockIdx.x * WAVES + (threadIdx.x >> 6), n_waves = (int)gridDim.x * WAVES;
+    const int wave = (int)blockIdx.x * 4 + (threadIdx.x >> 6), n_waves = (int)gridDim.x * 4;
     const AcmDropCtx dc = acm_drop_ctx(d.drop_in);
     const float* tab[3] = {d.t[0][ACM_SR_W_LOW].p, d.t[0][ACM_SR_W_HIGH].p, d.t[0][ACM_SR_W_MLP].p};
     const int ld[3] = {F, F, F};
     const float* __restrict__ xv = d.x_vals;
     wide_items<3>(
-        d.x, d.slots, d.counters, wave, n_waves,
+        d.x, d.slots, d.counters, wave, n_waves, [](int) { return 0; },
         [&](const AcmItem& item, f4(&acc)[3]) {
             wide_gather<3, 0>(d.x.indices, item.begin, item.end, tab, ld, 0,
                               [&](int pos) { return xv[pos] * acm_drop1(dc, pos, 0); }, acc);
         },
-        [&](int row, f4(&acc)[3]) {
+        [&](int row, f4(&acc)[3], int) {
             if (g < 3) st4(d.Z1 + (long)row * (3 * F) + g * F + 4 * m, sel4(g, acc[0], acc[1], acc[2], acc[2]));
             // the structure parameter of layer 2 as a block of the narrow table (refreshed every step: it is a parameter)
             if (d.k == 4 && g == 3 && m < C8) d.T2[(long)row * 24 + 16 + m] = m < d.C ? d.t[1][ACM_SR_STRUC].p[(long)row * d.C + m] : 0.f;
@@ -288,8 +329,9 @@ __global__ __launch_bounds__(256) void small_proj1_kernel(SmallDev d) {
 
 // dense features: Z1 was computed by the caller; only the structure block of the narrow table is refreshed
 __global__ __launch_bounds__(256) void small_struc_copy_kernel(SmallDev d) {
+    write_tables(d);
     const long i = (long)blockIdx.x * 256 + threadIdx.x;
-    if (i < (long)d.n * C8) {
+    if (d.k == 4 && i < (long)d.n * C8) {
         const long row = i >> 3;
         const int c = (int)(i & 7);
         d.T2[row * 24 + 16 + c] = c < d.C ? d.t[1][ACM_SR_STRUC].p[row * d.C + c] : 0.f;
@@ -298,14 +340,12 @@ __global__ __launch_bounds__(256) void small_struc_copy_kernel(SmallDev d) {
 
 // ------------------------------------------------------------------------------------------------ launch 2: layer 1 forward
 // per-row math of a WIDE layer (64 columns), group g = channel g.  `acc` = complete gathered sums (in every group).
+struct Pre2 {
+    float rs;
+    f4 own;
+};
 template <bool FOUR, bool VARIANT>
-__global__ __launch_bounds__(256) void small_conv1_fwd_kernel(SmallDev d, const float* z1) {
-    __shared__ __attribute__((aligned(16))) float w2s[3 * F * C8];          // [ch][col][8] of layer 2's weights
-    for (int e = threadIdx.x; e < 3 * F * C8; e += 256) {
-        const int ch = e / (F * C8), col = (e / C8) % F, c = e % C8;
-        w2s[e] = c < d.C ? d.t[1][ACM_SR_W_LOW + ch].p[col * d.C + c] : 0.f;
-    }
-    __syncthreads();
+__global__ __launch_bounds__(64 * WAVES) void small_conv1_fwd_kernel(SmallDev d, const float* z1) {
     const int lane = threadIdx.x & 63, g = lane >> 4, m = lane & 15;
     const int wave = (int)blockIdx.x * WAVES + (threadIdx.x >> 6), n_waves = (int)gridDim.x * WAVES;
     constexpr int NCH = FOUR ? 3 : 2;
@@ -314,7 +354,7 @@ __global__ __launch_bounds__(256) void small_conv1_fwd_kernel(SmallDev d, const 
     const float* tab[3] = {z1, z1 + F, FOUR ? d.t[0][ACM_SR_STRUC].p : z1};
     const int ld[3] = {3 * F, 3 * F, F};
     const bool act = g < K;
-    // this lane's channel parameters (columns 4m .. 4m+3)
+    // this lane's channel parameters (columns 4m .. 4m+3) and its share of layer 2's weights: output idx = g + 4t
     const f4 av = act ? ld4(d.t[0][ACM_SR_V_LOW + g].p + 4 * m) : zero4();
     f4 gam = zero4(), bet = zero4();
     if (d.layernorm && act) gam = ld4(d.t[0][ACM_SR_LNW_LOW + g].p + 4 * m), bet = ld4(d.t[0][ACM_SR_LNB_LOW + g].p + 4 * m);
@@ -323,17 +363,26 @@ __global__ __launch_bounds__(256) void small_conv1_fwd_kernel(SmallDev d, const 
     for (int a = 0; a < K; ++a)
 #pragma unroll
         for (int b = 0; b < K; ++b) mix[a][b] = d.t[0][ACM_SR_MIX].p[a * K + b];
+    f4 w2t[6];
+#pragma unroll
+    for (int t = 0; t < 6; ++t) w2t[t] = ld4(d.W2T + (g + 4 * t) * F + 4 * m);
+    // the row's own terms: group 1 its Z_H row, group 2 its Z_I row, group 3 its struc_low row
+    const float* own_base = g == 1 ? z1 + F : (g == 2 ? z1 + 2 * F : (FOUR ? d.t[0][ACM_SR_STRUC].p : z1));
+    const int own_ld = (g == 1 || g == 2) ? 3 * F : F;
     wide_items<NCH>(
         d.graph, d.slots, d.counters, wave, n_waves,
+        [&](int row) {
+            Pre2 pf;
+            pf.rs = d.row_scale[row];
+            pf.own = (g == 0 || (!FOUR && g == 3)) ? zero4() : ld4(own_base + (long)row * own_ld + 4 * m);
+            return pf;
+        },
         [&](const AcmItem& item, f4(&acc)[3]) {
             wide_gather<NCH, VARIANT ? 3 : 0>(d.graph.indices, item.begin, item.end, tab, ld, item.row, [](int) { return 1.f; }, acc);
         },
-        [&](int row, f4(&acc)[3]) {
-            const float rs = d.row_scale[row];
-            f4 own = zero4();
-            if (g == 1) own = ld4(z1 + (long)row * (3 * F) + F + 4 * m);
-            if (g == 2) own = ld4(z1 + (long)row * (3 * F) + 2 * F + 4 * m);
-            if (FOUR && g == 3) own = ld4(d.t[0][ACM_SR_STRUC].p + (long)row * F + 4 * m);
+        [&](int row, f4(&acc)[3], const Pre2& pf) {
+            const float rs = pf.rs;
+            const f4 own = pf.own;
             f4 h;
             if (VARIANT) h = sel4(g, rs * acc[0], relu4(own) - rs * acc[1], relu4(own), relu4(acc[2] - own));
             else h = sel4(g, relu4(rs * acc[0]), relu4(own - rs * acc[1]), relu4(own), relu4(acc[2] - own));
@@ -385,9 +434,7 @@ __global__ __launch_bounds__(256) void small_conv1_fwd_kernel(SmallDev d, const 
 #pragma unroll
             for (int t = 0; t < 6; ++t) {
                 const int idx = g + 4 * t, ch = idx >> 3, c = idx & 7;
-                const float* wp = w2s + ch * (F * C8) + (4 * m) * C8 + c;
-                float s = out.x * wp[0] + out.y * wp[C8] + out.z * wp[2 * C8] + out.w * wp[3 * C8];
-                s = acm_group_sum<16>(s);
+                const float s = acm_group_sum<16>(hsum4(out * w2t[t]));
                 if (m == 0 && c < d.C) {
                     if (ch < 2) d.T2[(long)row * 24 + ch * 8 + c] = s;
                     else d.Z2I[(long)row * C8 + c] = s;
@@ -397,8 +444,12 @@ __global__ __launch_bounds__(256) void small_conv1_fwd_kernel(SmallDev d, const 
 }
 
 // ------------------------------------------------------------------------------------------------ launch 3: layer 2 forward + loss + K3
+struct Pre3 {
+    float rs, zH, zI, sS, w;
+    int y;
+};
 template <bool FOUR>
-__global__ __launch_bounds__(256) void small_conv2_fwd_kernel(SmallDev d) {
+__global__ __launch_bounds__(64 * WAVES) void small_conv2_fwd_kernel(SmallDev d) {
     __shared__ float red[WAVES][PART3_PITCH];
     const int lane = threadIdx.x & 63, c = lane & 7, wv = threadIdx.x >> 6;
     const int wave = (int)blockIdx.x * WAVES + wv, n_waves = (int)gridDim.x * WAVES;
@@ -429,16 +480,25 @@ __global__ __launch_bounds__(256) void small_conv2_fwd_kernel(SmallDev d) {
     }
     narrow_items<NQ>(
         d.graph, d.slots, d.counters, wave, n_waves,
+        [&](int row) {
+            Pre3 pf;
+            pf.rs = d.row_scale[row];
+            pf.zH = d.T2[(long)row * 24 + 8 + c], pf.zI = d.Z2I[(long)row * C8 + c];
+            pf.sS = FOUR ? d.T2[(long)row * 24 + 16 + c] : 0.f;
+            pf.w = d.train ? d.row_weight[row] : 0.f;
+            pf.y = d.train ? (int)d.labels[row] : 0;
+            return pf;
+        },
         [&](const AcmItem& item) { return narrow_gather<NQ>(d.graph.indices, item.begin, item.end, d.T2, 24, item.row, variant); },
-        [&](int row, f4 acc) {
-            const float rs = d.row_scale[row];
+        [&](int row, f4 acc, const Pre3& pf) {
+            const float rs = pf.rs;
             const float aL = narrow_pick(acc, 0), aH = narrow_pick(acc, 1), aS = FOUR ? narrow_pick(acc, 2) : 0.f;
-            const float zH = d.T2[(long)row * 24 + 8 + c], zI = d.Z2I[(long)row * C8 + c];
+            const float zH = pf.zH, zI = pf.zI;
             float h[K];
             if (variant) h[0] = rs * aL, h[1] = fmaxf(zH, 0.f) - rs * aH;
             else h[0] = fmaxf(rs * aL, 0.f), h[1] = fmaxf(zH - rs * aH, 0.f);
             h[2] = fmaxf(zI, 0.f);
-            if (FOUR) h[K - 1] = fmaxf(aS - d.T2[(long)row * 24 + 16 + c], 0.f);
+            if (FOUR) h[K - 1] = fmaxf(aS - pf.sS, 0.f);
             float xh[K], hn[K], rstd[K], sig[K], tt[K], al[K];
 #pragma unroll
             for (int ch = 0; ch < K; ++ch) {
@@ -475,13 +535,13 @@ __global__ __launch_bounds__(256) void small_conv2_fwd_kernel(SmallDev d) {
             if (lane < K) d.att2[(long)row * 4 + lane] = lane == 0 ? al[0] : (lane == 1 ? al[1] : (lane == 2 ? al[2] : al[K - 1]));
             if (!d.train) return;
             // masked NLL of the row and its gradient (acm_nll_row)
-            const float w = d.row_weight[row];
+            const float w = pf.w;
             float dl = 0.f;
             if (w != 0.f) {
                 const float mz = gmax8(valid ? z : -INFINITY);
                 const float ex = valid ? expf(z - mz) : 0.f;
                 const float s = gsum8(ex);
-                const int y = (int)d.labels[row];
+                const int y = pf.y;
                 const float zy = __shfl(z, (lane & ~7) + y);
                 a_loss += w * ((mz + logf(s)) - zy);
                 dl = valid ? w * (ex * (1.0f / s) - (c == y ? 1.f : 0.f)) : 0.f;
@@ -541,22 +601,23 @@ __global__ __launch_bounds__(256) void small_conv2_fwd_kernel(SmallDev d) {
         red[wv][112] = a_loss;
     }
     __syncthreads();
-    if (threadIdx.x < PART3)
-        d.part3[(long)blockIdx.x * PART3_PITCH + threadIdx.x] = ((red[0][threadIdx.x] + red[1][threadIdx.x]) + red[2][threadIdx.x]) + red[3][threadIdx.x];
+    if (threadIdx.x < PART3) {
+        float s = red[0][threadIdx.x];
+#pragma unroll
+        for (int w = 1; w < WAVES; ++w) s += red[w][threadIdx.x];
+        d.part3[(long)blockIdx.x * PART3_PITCH + threadIdx.x] = s;
+    }
 }
 
 // ------------------------------------------------------------------------------------------------ launch 4: layer 2 backward gather + dH + layer 1 K3
+struct Pre4 {
+    float rs, gH, dzI, zL, zH, gS, sp, sm, sv;
+    f4 o, h;
+    float mean, rstd, sa[8];
+};
 template <bool FOUR>
-__global__ __launch_bounds__(256) void small_conv2_bwd_kernel(SmallDev d, const float* z1) {
-    __shared__ __attribute__((aligned(16))) float w2s[3 * F * C8];
-    __shared__ float red[PART4];
-    __shared__ float sc[2];
-    for (int e = threadIdx.x; e < 3 * F * C8; e += 256) {
-        const int ch = e / (F * C8), col = (e / C8) % F, c = e % C8;
-        w2s[e] = c < d.C ? d.t[1][ACM_SR_W_LOW + ch].p[col * d.C + c] : 0.f;
-    }
-    if (FOUR && d.update) stage_factors(d.hp, d.t[1][ACM_SR_STRUC], sc);
-    __syncthreads();
+__global__ __launch_bounds__(64 * WAVES) void small_conv2_bwd_kernel(SmallDev d, const float* z1) {
+    __shared__ __attribute__((aligned(16))) float red[WAVES / 2][PART4];  // the waves' sums side by side (two rounds: 37 KB)
     const int lane = threadIdx.x & 63, g = lane >> 4, m = lane & 15, c = lane & 7, wv = threadIdx.x >> 6;
     const int wave = (int)blockIdx.x * WAVES + wv, n_waves = (int)gridDim.x * WAVES;
     constexpr int NQ = FOUR ? 6 : 4;
@@ -576,37 +637,54 @@ __global__ __launch_bounds__(256) void small_conv2_bwd_kernel(SmallDev d, const 
     for (int a = 0; a < K; ++a)
 #pragma unroll
         for (int b = 0; b < K; ++b) mix[a][b] = d.t[0][ACM_SR_MIX].p[a * K + b];
-    AdamFactors af(d.hp);
+    const AdamFactors af(d.hp);
+    const SmallTensor& ts2 = d.t[1][ACM_SR_STRUC];
+    const bool s2_lane = FOUR && lane < 8 && c < C;
     f4 a_w2[6];
 #pragma unroll
     for (int t = 0; t < 6; ++t) a_w2[t] = zero4();
     f4 a_dv = zero4(), a_dg = zero4(), a_db = zero4();
-    float a_dm[K][K];
-#pragma unroll
-    for (int a = 0; a < K; ++a)
-#pragma unroll
-        for (int b = 0; b < K; ++b) a_dm[a][b] = 0.f;
+    float a_dm = 0.f;                                 // d(mix): lane L < 16 holds element (L >> 2, L & 3)
     narrow_items<NQ>(
         d.graph, d.slots, d.counters, wave, n_waves,
-        [&](const AcmItem& item) { return narrow_gather<NQ>(d.graph.indices, item.begin, item.end, d.G2, 24, item.row, false); },
-        [&](int row, f4 acc) {
-            const float aL = narrow_pick(acc, 0), aH = narrow_pick(acc, 1), aS = FOUR ? narrow_pick(acc, 2) : 0.f;
+        [&](int row) {                                   // everything the row's epilogue reads that is not a gathered sum
+            Pre4 pf;
+            pf.rs = d.row_scale[row];
             const float* dzp = d.DZ2 + (long)row * 24;
-            float dzL = aL, dzH = dzp[8 + c] - aH;
-            const float dzI = dzp[16 + c];
-            if (variant) {
-                if (!(d.T2[(long)row * 24 + c] > 0.f)) dzL = 0.f;
-                if (!(d.T2[(long)row * 24 + 8 + c] > 0.f)) dzH = 0.f;
-            }
-            if (FOUR && lane < 8 && c < C) {              // dS2 = P G_S - G_S: final here, the parameter row is updated in place
-                const float ds = aS - d.G2[(long)row * 24 + 16 + c];
-                const SmallTensor& ts = d.t[1][ACM_SR_STRUC];
+            pf.gH = dzp[8 + c], pf.dzI = dzp[16 + c];
+            pf.zL = variant ? d.T2[(long)row * 24 + c] : 1.f, pf.zH = variant ? d.T2[(long)row * 24 + 8 + c] : 1.f;
+            pf.gS = FOUR ? d.G2[(long)row * 24 + 16 + c] : 0.f;
+            pf.sp = pf.sm = pf.sv = 0.f;
+            if (s2_lane && d.update) {
                 const long i = (long)row * C + c;
-                if (ts.g) ts.g[i] = ds;
+                pf.sp = ts2.p[i], pf.sm = ts2.m[i], pf.sv = ts2.v[i];
+            }
+            pf.o = ld4(d.OUT1 + (long)row * F + 4 * m);
+            pf.h = act ? ld4(d.H1 + (long)row * (4 * F) + g * F + 4 * m) : zero4();
+            const float* st = d.ST1 + (long)row * 16;
+            pf.mean = st[g], pf.rstd = st[4 + g];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) pf.sa[q] = st[8 + q];         // sigmoid and alpha of the four channels (wave-uniform)
+            return pf;
+        },
+        [&](const AcmItem& item) { return narrow_gather<NQ>(d.graph.indices, item.begin, item.end, d.G2, 24, item.row, false); },
+        [&](int row, f4 acc, const Pre4& pf) {
+            const float aL = narrow_pick(acc, 0), aH = narrow_pick(acc, 1), aS = FOUR ? narrow_pick(acc, 2) : 0.f;
+            float dzL = aL, dzH = pf.gH - aH;
+            const float dzI = pf.dzI;
+            if (variant) {
+                if (!(pf.zL > 0.f)) dzL = 0.f;
+                if (!(pf.zH > 0.f)) dzH = 0.f;
+            }
+            if (s2_lane) {                                // dS2 = P G_S - G_S: final here, the parameter row is updated in place
+                const float ds = aS - pf.gS;
+                const long i = (long)row * C + c;
+                if (ts2.g) ts2.g[i] = ds;
                 if (d.update) {
-                    float pp = ts.p[i], mm = ts.m[i], vv = ts.v[i];
-                    adam_one(pp, ds, mm, vv, af.decay_eff, af.wd, af.decoupled, af.w1, af.b2, af.w2, sc[0], sc[1], af.eps);
-                    ts.p[i] = pp, ts.m[i] = mm, ts.v[i] = vv;
+                    float pp = pf.sp, mm = pf.sm, vv = pf.sv;
+                    const float* fc = d.FACT + 2 * (ACM_SMALL_ROLES + ACM_SR_STRUC);
+                    adam_one(pp, ds, mm, vv, af.decay_eff, af.wd, af.decoupled, af.w1, af.b2, af.w2, fc[0], fc[1], af.eps);
+                    ts2.p[i] = pp, ts2.m[i] = mm, ts2.v[i] = vv;
                 }
             }
             // dZ2 of this row as wave-uniform values, idx = ch * 8 + c
@@ -617,20 +695,21 @@ __global__ __launch_bounds__(256) void small_conv2_bwd_kernel(SmallDev d, const 
                 dz[8 + cc] = acm_lane_f(dzH, cc);
                 dz[16 + cc] = acm_lane_f(dzI, cc);
             }
-            const f4 o = ld4(d.OUT1 + (long)row * F + 4 * m);
+            const f4 o = pf.o;
             // dH = dZ2 Wcat2^T (columns 4m .. 4m+3) and dWcat2 += H^T dZ2 (group g: idx = g, g + 4, ...)
-            f4 dH = zero4();
+            // (W2T is 6 KB read by every wave of the launch: L1 / L2-hot, its 24 loads go out together right here; held in
+            // registers across the gather they cost 96 VGPRs and spilled)
+            f4 dH0 = zero4(), dH1 = zero4();
 #pragma unroll
-            for (int ch = 0; ch < 3; ++ch) {
-                const float* wp = w2s + ch * (F * C8) + (4 * m) * C8;
-                const f4 w0a = ld4(wp), w0b = ld4(wp + 4), w1a = ld4(wp + C8), w1b = ld4(wp + C8 + 4);
-                const f4 w2a = ld4(wp + 2 * C8), w2b = ld4(wp + 2 * C8 + 4), w3a = ld4(wp + 3 * C8), w3b = ld4(wp + 3 * C8 + 4);
-                const float* z = dz + ch * 8;
-                dH.x += (z[0] * w0a.x + z[1] * w0a.y + z[2] * w0a.z + z[3] * w0a.w) + (z[4] * w0b.x + z[5] * w0b.y + z[6] * w0b.z + z[7] * w0b.w);
-                dH.y += (z[0] * w1a.x + z[1] * w1a.y + z[2] * w1a.z + z[3] * w1a.w) + (z[4] * w1b.x + z[5] * w1b.y + z[6] * w1b.z + z[7] * w1b.w);
-                dH.z += (z[0] * w2a.x + z[1] * w2a.y + z[2] * w2a.z + z[3] * w2a.w) + (z[4] * w2b.x + z[5] * w2b.y + z[6] * w2b.z + z[7] * w2b.w);
-                dH.w += (z[0] * w3a.x + z[1] * w3a.y + z[2] * w3a.z + z[3] * w3a.w) + (z[4] * w3b.x + z[5] * w3b.y + z[6] * w3b.z + z[7] * w3b.w);
+            for (int ch = 0; ch < 3; ++ch) {             // eight rows of W2T in flight at a time (96 VGPRs for all 24 spilled)
+                f4 wv8[8];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) wv8[q] = ld4(d.W2T + (ch * 8 + q) * F + 4 * m);
+#pragma unroll
+                for (int q = 0; q < 8; q += 2) dH0 += dz[ch * 8 + q] * wv8[q], dH1 += dz[ch * 8 + q + 1] * wv8[q + 1];
+                __builtin_amdgcn_sched_barrier(0);
             }
+            const f4 dH = dH0 + dH1;
 #pragma unroll
             for (int t = 0; t < 6; ++t) {
                 const float zz = g == 0 ? dz[4 * t] : (g == 1 ? dz[4 * t + 1] : (g == 2 ? dz[4 * t + 2] : dz[4 * t + 3]));
@@ -641,13 +720,12 @@ __global__ __launch_bounds__(256) void small_conv2_bwd_kernel(SmallDev d, const 
             dmix.x = o.x > 0.f ? dH.x * inv_keep : 0.f, dmix.y = o.y > 0.f ? dH.y * inv_keep : 0.f;
             dmix.z = o.z > 0.f ? dH.z * inv_keep : 0.f, dmix.w = o.w > 0.f ? dH.w * inv_keep : 0.f;
             // row-local backward of layer 1, channel g in group g
-            const float rs = d.row_scale[row];
-            const f4 h = act ? ld4(d.H1 + (long)row * (4 * F) + g * F + 4 * m) : zero4();
-            const float* st = d.ST1 + (long)row * 16;
+            const float rs = pf.rs;
+            const f4 h = pf.h;
             float sig[K], al[K];
 #pragma unroll
-            for (int ch = 0; ch < K; ++ch) sig[ch] = st[8 + ch], al[ch] = st[12 + ch];
-            const float mean = act ? st[g] : 0.f, rstd = act ? st[4 + g] : 1.f;
+            for (int ch = 0; ch < K; ++ch) sig[ch] = pf.sa[ch], al[ch] = pf.sa[4 + ch];
+            const float mean = pf.mean, rstd = pf.rstd;
             const float dal_mine = d.scale * acm_group_sum<16>(hsum4(dmix * h));
             float dal[K], dot = 0.f;
 #pragma unroll
@@ -659,12 +737,15 @@ __global__ __launch_bounds__(256) void small_conv2_bwd_kernel(SmallDev d, const 
             for (int ch = 0; ch < K; ++ch) {
                 float dsig = 0.f;
 #pragma unroll
-                for (int b = 0; b < K; ++b) {
-                    dsig += dt[b] * mix[ch][b];
-                    a_dm[ch][b] += sig[ch] * dt[b] / (float)K;
-                }
+                for (int b = 0; b < K; ++b) dsig += dt[b] * mix[ch][b];
                 dsig /= (float)K;
                 dlg[ch] = dsig * sig[ch] * (1.0f - sig[ch]);
+            }
+            {
+                const int ma = (lane >> 2) & 3, mb = lane & 3;
+                const float sa = ma == 0 ? sig[0] : (ma == 1 ? sig[1] : (ma == 2 ? sig[2] : sig[K - 1]));
+                const float tb = mb == 0 ? dt[0] : (mb == 1 ? dt[1] : (mb == 2 ? dt[2] : dt[K - 1]));
+                if (ma < K && mb < K) a_dm += sa * tb / (float)K;
             }
             const float my_dl = g == 0 ? dlg[0] : (g == 1 ? dlg[1] : (g == 2 ? dlg[2] : (K == 4 ? dlg[K - 1] : 0.f)));
             const float my_al = g == 0 ? al[0] : (g == 1 ? al[1] : (g == 2 ? al[2] : (K == 4 ? al[K - 1] : 0.f)));
@@ -693,79 +774,97 @@ __global__ __launch_bounds__(256) void small_conv2_bwd_kernel(SmallDev d, const 
             if (g == 2) st4(dz1 + 2 * F, dhc);
             if (FOUR && g == 3) st4(g1 + 2 * F, dhc);
         });
-    // per-workgroup partial sums, waves in order
-    for (int w = 0; w < WAVES; ++w) {
-        if (wv == w) {
+    // per-workgroup partial sums: waves 0-3 leave their sums in a slice each, waves 4-7 add theirs on top, then every thread
+    // adds the four slices of its elements -- a fixed order of additions (deterministic), two barriers
+#pragma unroll
+    for (int round = 0; round < 2; ++round) {
+        if ((wv >> 2) == round) {
+            float* mine = red[wv & 3];
 #pragma unroll
             for (int t = 0; t < 6; ++t) {
                 const int idx = g + 4 * t, ch = idx >> 3, cc = idx & 7;
-                float* rp = red + ch * (F * C8) + (4 * m) * C8 + cc;
-                if (w == 0) rp[0] = a_w2[t].x, rp[C8] = a_w2[t].y, rp[2 * C8] = a_w2[t].z, rp[3 * C8] = a_w2[t].w;
+                float* rp = mine + ch * (F * C8) + (4 * m) * C8 + cc;
+                if (round == 0) rp[0] = a_w2[t].x, rp[C8] = a_w2[t].y, rp[2 * C8] = a_w2[t].z, rp[3 * C8] = a_w2[t].w;
                 else rp[0] += a_w2[t].x, rp[C8] += a_w2[t].y, rp[2 * C8] += a_w2[t].z, rp[3 * C8] += a_w2[t].w;
             }
-            float* r1 = red + 3 * F * C8 + g * F + 4 * m;
+            float* r1 = mine + 3 * F * C8 + g * F + 4 * m;
             const f4 zv = zero4();
             const f4 v0 = act ? a_dv : zv, v1 = act ? a_dg : zv, v2 = act ? a_db : zv;
-            if (w == 0) st4(r1, v0), st4(r1 + 4 * F, v1), st4(r1 + 8 * F, v2);
+            if (round == 0) st4(r1, v0), st4(r1 + 4 * F, v1), st4(r1 + 8 * F, v2);
             else st4(r1, ld4(r1) + v0), st4(r1 + 4 * F, ld4(r1 + 4 * F) + v1), st4(r1 + 8 * F, ld4(r1 + 8 * F) + v2);
-            if (lane == 0) {
-                float* rm = red + 3 * F * C8 + 12 * F;
-#pragma unroll
-                for (int a = 0; a < 4; ++a)
-#pragma unroll
-                    for (int b = 0; b < 4; ++b) {
-                        const float x = (a < K && b < K) ? a_dm[a < K ? a : 0][b < K ? b : 0] : 0.f;
-                        if (w == 0) rm[a * 4 + b] = x;
-                        else rm[a * 4 + b] += x;
-                    }
+            if (lane < 16) {
+                float* rm = mine + 3 * F * C8 + 12 * F + lane;
+                if (round == 0) rm[0] = a_dm;
+                else rm[0] += a_dm;
             }
         }
         __syncthreads();
     }
-    for (int e = threadIdx.x; e < PART4; e += 256) d.part4[(long)blockIdx.x * PART4 + e] = red[e];
+    for (int e = threadIdx.x; e < PART4; e += 64 * WAVES)
+        d.part4[(long)blockIdx.x * PART4 + e] = (red[0][e] + red[1][e]) + (red[2][e] + red[3][e]);
 }
 
 // ------------------------------------------------------------------------------------------------ launch 5: layer 1 backward gather
+struct Pre5 {
+    f4 a, b, pp, mm, vv;
+};
 template <bool FOUR, bool VARIANT>
-__global__ __launch_bounds__(256) void small_conv1_bwd_kernel(SmallDev d, const float* z1) {
-    __shared__ float sc[2];
-    if (FOUR && d.update) stage_factors(d.hp, d.t[0][ACM_SR_STRUC], sc);
-    __syncthreads();
+__global__ __launch_bounds__(64 * WAVES) void small_conv1_bwd_kernel(SmallDev d, const float* z1) {
     const int lane = threadIdx.x & 63, g = lane >> 4, m = lane & 15;
     const int wave = (int)blockIdx.x * WAVES + (threadIdx.x >> 6), n_waves = (int)gridDim.x * WAVES;
     constexpr int NCH = FOUR ? 3 : 2;
     const float* tab[3] = {d.G1, d.G1 + F, d.G1 + 2 * F};
     const int ld[3] = {3 * F, 3 * F, 3 * F};
     const AdamFactors af(d.hp);
+    const SmallTensor& ts = d.t[0][ACM_SR_STRUC];
     wide_items<NCH>(
         d.graph, d.slots, d.counters, wave, n_waves,
+        [&](int row) {
+            // group 0: the ReLU mask of Z_L (ACMII); group 1: its direct term dZ_H and the mask of Z_H; group 3: G_S of the row
+            // and the parameter row with its moments
+            Pre5 pf;
+            pf.a = pf.b = pf.pp = pf.mm = pf.vv = zero4();
+            const float* zr = z1 + (long)row * (3 * F) + 4 * m;
+            if (g == 0 && VARIANT) pf.b = ld4(zr);
+            if (g == 1) {
+                pf.a = ld4(d.DZ1 + (long)row * (3 * F) + F + 4 * m);
+                if (VARIANT) pf.b = ld4(zr + F);
+            }
+            if (FOUR && g == 3) {
+                pf.a = ld4(d.G1 + (long)row * (3 * F) + 2 * F + 4 * m);
+                if (d.update) {
+                    const long i = (long)row * F + 4 * m;
+                    pf.pp = ld4(ts.p + i), pf.mm = ld4(ts.m + i), pf.vv = ld4(ts.v + i);
+                }
+            }
+            return pf;
+        },
         [&](const AcmItem& item, f4(&acc)[3]) {
             wide_gather<NCH, 0>(d.graph.indices, item.begin, item.end, tab, ld, item.row, [](int) { return 1.f; }, acc);
         },
-        [&](int row, f4(&acc)[3]) {
+        [&](int row, f4(&acc)[3], const Pre5& pf) {
             float* dz1 = d.DZ1 + (long)row * (3 * F) + 4 * m;
-            const float* zr = z1 + (long)row * (3 * F) + 4 * m;
-            if (g == 0) {
-                f4 dz = acc[0];
+            if (g == 0 || g == 1) {
+                f4 dz = g == 0 ? acc[0] : pf.a - acc[1];
                 if (VARIANT) {
-                    const f4 z = ld4(zr);
+                    const f4 z = pf.b;
                     dz.x = z.x > 0.f ? dz.x : 0.f, dz.y = z.y > 0.f ? dz.y : 0.f, dz.z = z.z > 0.f ? dz.z : 0.f, dz.w = z.w > 0.f ? dz.w : 0.f;
                 }
-                st4(dz1, dz);
-            } else if (g == 1) {
-                f4 dz = ld4(dz1 + F) - acc[1];
-                if (VARIANT) {
-                    const f4 z = ld4(zr + F);
-                    dz.x = z.x > 0.f ? dz.x : 0.f, dz.y = z.y > 0.f ? dz.y : 0.f, dz.z = z.z > 0.f ? dz.z : 0.f, dz.w = z.w > 0.f ? dz.w : 0.f;
-                }
-                st4(dz1 + F, dz);
+                st4(dz1 + g * F, dz);
             } else if (FOUR && g == 3) {                   // dS = P G_S - G_S: final, the parameter row is updated in place
-                const f4 ds = acc[2] - ld4(d.G1 + (long)row * (3 * F) + 2 * F + 4 * m);
-                const SmallTensor& ts = d.t[0][ACM_SR_STRUC];
+                const f4 ds = acc[2] - pf.a;
                 const long i = (long)row * F + 4 * m;
                 if (ts.g) st4(ts.g + i, ds);
                 if (d.update) {
-                    adam_four(ts, i, ds, af, sc[0], sc[1]);
+                    const float* fc = d.FACT + 2 * ACM_SR_STRUC;
+                    float pp[4] = {pf.pp.x, pf.pp.y, pf.pp.z, pf.pp.w}, mm[4] = {pf.mm.x, pf.mm.y, pf.mm.z, pf.mm.w};
+                    float vv[4] = {pf.vv.x, pf.vv.y, pf.vv.z, pf.vv.w};
+                    const float gg[4] = {ds.x, ds.y, ds.z, ds.w};
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        adam_one(pp[r], gg[r], mm[r], vv[r], af.decay_eff, af.wd, af.decoupled, af.w1, af.b2, af.w2, fc[0], fc[1], af.eps);
+                    st4(ts.p + i, f4{pp[0], pp[1], pp[2], pp[3]}), st4(ts.m + i, f4{mm[0], mm[1], mm[2], mm[3]});
+                    st4(ts.v + i, f4{vv[0], vv[1], vv[2], vv[3]});
                 }
             }
         });
@@ -777,21 +876,16 @@ __global__ __launch_bounds__(256) void small_conv1_bwd_kernel(SmallDev d, const 
 // then -- dense features -- the elementwise update of W1 from the caller's gradient.  The last block to finish advances the
 // step counters.
 __global__ __launch_bounds__(256) void small_finish_kernel(SmallDev d, int item_blocks, int red_blocks) {
-    __shared__ float sc[2 * ACM_SMALL_ROLES][2];
+    __shared__ float red8[8][RED_EL];
     __shared__ int s_last;
-    // step factors of every present tensor (one thread each)
-    if ((int)threadIdx.x < 2 * ACM_SMALL_ROLES && d.update) {
-        const SmallTensor& t = d.t[threadIdx.x / ACM_SMALL_ROLES][threadIdx.x % ACM_SMALL_ROLES];
-        if (t.p && t.step) acm_adam_step_factors(d.hp, t.step[0], sc[threadIdx.x][0], sc[threadIdx.x][1]);
-    }
-    __syncthreads();
+    const float* __restrict__ fact = d.FACT;              // step factors of every tensor (launch 1 wrote them)
     const AdamFactors af(d.hp);
     auto apply = [&](int layer, int role, long i, float gsum) {
         const SmallTensor& t = d.t[layer][role];
         if (!t.p) return;
         if (t.g) t.g[i] = gsum;
         if (!d.update) return;
-        const float* s = sc[layer * ACM_SMALL_ROLES + role];
+        const float* s = fact + 2 * (layer * ACM_SMALL_ROLES + role);
         float pp = t.p[i], mm = t.m[i], vv = t.v[i];
         adam_one(pp, gsum, mm, vv, af.decay_eff, af.wd, af.decoupled, af.w1, af.b2, af.w2, s[0], s[1], af.eps);
         t.p[i] = pp, t.m[i] = mm, t.v[i] = vv;
@@ -799,52 +893,94 @@ __global__ __launch_bounds__(256) void small_finish_kernel(SmallDev d, int item_
     const int blk = (int)blockIdx.x;
     if (blk < item_blocks) {
         const int lane = threadIdx.x & 63, g = lane >> 4, m = lane & 15;
-        const int wave = blk * WAVES + (threadIdx.x >> 6), n_waves = item_blocks * WAVES;
+        const int wave = blk * 4 + (threadIdx.x >> 6), n_waves = item_blocks * 4;
         const AcmDropCtx dc = acm_drop_ctx(d.drop_in);
         const float* tab[3] = {d.DZ1, d.DZ1 + F, d.DZ1 + 2 * F};
         const int ld[3] = {3 * F, 3 * F, 3 * F};
         const float* __restrict__ xv = d.x_vals;
+        const float* __restrict__ xtv = d.xt_vals;
         const int32_t* __restrict__ sp = d.xt_src_pos;
         wide_items<3>(
             d.xt, d.slots, d.counters, wave, n_waves,
-            [&](const AcmItem& item, f4(&acc)[3]) {
-                wide_gather<3, 0>(d.xt.indices, item.begin, item.end, tab, ld, 0,
-                                  [&](int pos) { const int s = sp[pos]; return xv[s] * acm_drop1(dc, s, 0); }, acc);
+            [&](int frow) {                                // the weight rows this wave will update, with their moments
+                Pre5 pf;
+                pf.a = pf.b = pf.pp = pf.mm = pf.vv = zero4();
+                if (g < 3 && d.update) {
+                    const SmallTensor& t = d.t[0][ACM_SR_W_LOW + g];
+                    const long i = (long)frow * F + 4 * m;
+                    pf.pp = ld4(t.p + i), pf.mm = ld4(t.m + i), pf.vv = ld4(t.v + i);
+                }
+                return pf;
             },
-            [&](int frow, f4(&acc)[3]) {
+            [&](const AcmItem& item, f4(&acc)[3]) {
+                if (xtv)
+                    wide_gather<3, 0>(d.xt.indices, item.begin, item.end, tab, ld, 0,
+                                      [&](int pos) { return xtv[pos] * acm_drop1(dc, sp[pos], 0); }, acc);
+                else
+                    wide_gather<3, 0>(d.xt.indices, item.begin, item.end, tab, ld, 0,
+                                      [&](int pos) { const int s = sp[pos]; return xv[s] * acm_drop1(dc, s, 0); }, acc);
+            },
+            [&](int frow, f4(&acc)[3], const Pre5& pf) {
                 if (g < 3) {
                     const f4 gw = sel4(g, acc[0], acc[1], acc[2], acc[2]);
                     const SmallTensor& t = d.t[0][ACM_SR_W_LOW + g];
                     const long i = (long)frow * F + 4 * m;
                     if (t.g) st4(t.g + i, gw);
                     if (d.update) {
-                        const float* s = sc[ACM_SR_W_LOW + g];
-                        adam_four(t, i, gw, af, s[0], s[1]);
+                        const float* fc = fact + 2 * (ACM_SR_W_LOW + g);
+                        float pp[4] = {pf.pp.x, pf.pp.y, pf.pp.z, pf.pp.w}, mm[4] = {pf.mm.x, pf.mm.y, pf.mm.z, pf.mm.w};
+                        float vv[4] = {pf.vv.x, pf.vv.y, pf.vv.z, pf.vv.w};
+                        const float gg[4] = {gw.x, gw.y, gw.z, gw.w};
+#pragma unroll
+                        for (int r = 0; r < 4; ++r)
+                            adam_one(pp[r], gg[r], mm[r], vv[r], af.decay_eff, af.wd, af.decoupled, af.w1, af.b2, af.w2, fc[0], fc[1], af.eps);
+                        st4(t.p + i, f4{pp[0], pp[1], pp[2], pp[3]}), st4(t.m + i, f4{mm[0], mm[1], mm[2], mm[3]});
+                        st4(t.v + i, f4{vv[0], vv[1], vv[2], vv[3]});
                     }
                 }
             });
     } else if (blk < item_blocks + red_blocks) {
-        const int e = (blk - item_blocks) * 256 + (int)threadIdx.x;
+        // RED_EL elements per block: thread (wl, el) adds the producer workgroups wl, wl + 8, ... (independent loads in
+        // flight), the eight partial sums meet in LDS in a fixed order
+        const int el = (int)threadIdx.x & (RED_EL - 1), wl = (int)threadIdx.x / RED_EL;
+        const int e = (blk - item_blocks) * RED_EL + el;
         const int K = d.k, C = d.C;
-        if (e < PART4) {
-            float s = 0.f;
-            for (int w = 0; w < d.nwg4; ++w) s += d.part4[(long)w * PART4 + e];
-            if (e < 3 * F * C8) {
-                const int ch = e / (F * C8), col = (e / C8) % F, c = e % C8;
-                if (c < C) apply(1, ACM_SR_W_LOW + ch, (long)col * C + c, s);
-            } else if (e < 3 * F * C8 + 12 * F) {
-                const int q = e - 3 * F * C8, kind = q / (4 * F), ch = (q / F) % 4, col = q % F;
-                if (ch < K && (kind == 0 || d.layernorm))
-                    apply(0, (kind == 0 ? ACM_SR_V_LOW : (kind == 1 ? ACM_SR_LNW_LOW : ACM_SR_LNB_LOW)) + ch, col, s);
-            } else {
-                const int q = e - 3 * F * C8 - 12 * F, a = q / 4, b = q % 4;
-                if (a < K && b < K) apply(0, ACM_SR_MIX, a * K + b, s);
+        const bool four = e < PART4;
+        const int q = e - PART4;
+        float s = 0.f;
+        if (e < PART4 + PART3) {
+            const float* src = four ? d.part4 + e : d.part3 + q;
+            const long pitch = four ? PART4 : PART3_PITCH;
+            const int nw = four ? d.nwg4 : d.nwg3;
+            // sixteen loads in flight per thread, added in the order of the producer workgroups
+            for (int w0 = wl; w0 < nw; w0 += 128) {
+                float v[16];
+#pragma unroll
+                for (int j = 0; j < 16; ++j) {
+                    const int w = w0 + 8 * j;
+                    v[j] = w < nw ? src[(long)w * pitch] : 0.f;
+                }
+#pragma unroll
+                for (int j = 0; j < 16; ++j) s += v[j];
             }
-        } else if (e < PART4 + PART3) {
-            const int q = e - PART4;
-            float s = 0.f;
-            for (int w = 0; w < d.nwg3; ++w) s += d.part3[(long)w * PART3_PITCH + q];
-            if (q < 96) {
+        }
+        red8[wl][el] = s;
+        __syncthreads();
+        if (wl == 0 && e < PART4 + PART3) {
+            s = ((red8[0][el] + red8[1][el]) + (red8[2][el] + red8[3][el])) + ((red8[4][el] + red8[5][el]) + (red8[6][el] + red8[7][el]));
+            if (four) {
+                if (e < 3 * F * C8) {
+                    const int ch = e / (F * C8), col = (e / C8) % F, c = e % C8;
+                    if (c < C) apply(1, ACM_SR_W_LOW + ch, (long)col * C + c, s);
+                } else if (e < 3 * F * C8 + 12 * F) {
+                    const int r = e - 3 * F * C8, kind = r / (4 * F), ch = (r / F) % 4, col = r % F;
+                    if (ch < K && (kind == 0 || d.layernorm))
+                        apply(0, (kind == 0 ? ACM_SR_V_LOW : (kind == 1 ? ACM_SR_LNW_LOW : ACM_SR_LNB_LOW)) + ch, col, s);
+                } else {
+                    const int r = e - 3 * F * C8 - 12 * F, a = r / 4, b = r % 4;
+                    if (a < K && b < K) apply(0, ACM_SR_MIX, a * K + b, s);
+                }
+            } else if (q < 96) {
                 const int kind = q / 32, ch = (q / 8) % 4, c = q % 8;
                 if (ch < K && c < C && (kind == 0 || d.layernorm))
                     apply(1, (kind == 0 ? ACM_SR_V_LOW : (kind == 1 ? ACM_SR_LNW_LOW : ACM_SR_LNB_LOW)) + ch, c, s);
@@ -862,7 +998,7 @@ __global__ __launch_bounds__(256) void small_finish_kernel(SmallDev d, int item_
             const int ch = (int)(i / per);
             const SmallTensor& t = d.t[0][ACM_SR_W_LOW + ch];
             const long j = i % per;
-            const float* s = sc[ACM_SR_W_LOW + ch];
+            const float* s = fact + 2 * (ACM_SR_W_LOW + ch);
             float pp = t.p[j], mm = t.m[j], vv = t.v[j];
             adam_one(pp, t.g[j], mm, vv, af.decay_eff, af.wd, af.decoupled, af.w1, af.b2, af.w2, s[0], s[1], af.eps);
             t.p[j] = pp, t.m[j] = mm, t.v[j] = vv;
@@ -904,7 +1040,7 @@ ItemView view_of(const acm_csr* a) {
 }
 
 struct Layout {
-    size_t Z1, H1, ST1, OUT1, T2, Z2I, G2, DZ2, G1, DZ1, slots, part3, part4, counters, total;
+    size_t Z1, H1, ST1, OUT1, T2, Z2I, G2, DZ2, G1, DZ1, slots, part3, part4, W2T, FACT, counters, total;
 };
 
 Layout layout_of(const acm_csr* a, const acm_csr* x, const acm_csr* xt) {
@@ -924,7 +1060,9 @@ Layout layout_of(const acm_csr* a, const acm_csr* x, const acm_csr* xt) {
     L.T2 = take(n * 24), L.Z2I = take(n * 8), L.G2 = take(n * 24), L.DZ2 = take(n * 24);
     L.G1 = take(n * 192), L.DZ1 = take(n * 192);
     L.slots = take((n_slots + 1) * 192);
-    L.part3 = take((size_t)MAX_WG * PART3_PITCH), L.part4 = take((size_t)MAX_WG * PART4);
+    const size_t wg = (size_t)std::min<int64_t>(MAX_WG, (a->n_items + WAVES - 1) / WAVES);      // = the gather phases' grid
+    L.part3 = take(wg * PART3_PITCH), L.part4 = take(wg * PART4);
+    L.W2T = take(3 * F * C8), L.FACT = take(2 * ACM_SMALL_ROLES * 2);
     L.counters = take(n_long + 64);
     L.total = o * sizeof(float);
     return L;
@@ -995,7 +1133,8 @@ extern "C" int acm_small_step(const acm_csr_t* a, const acm_csr_t* x, const acm_
     float* ws = (float*)p->workspace;
     d.Z1 = ws + L.Z1, d.H1 = ws + L.H1, d.ST1 = ws + L.ST1, d.OUT1 = ws + L.OUT1, d.T2 = ws + L.T2, d.Z2I = ws + L.Z2I;
     d.G2 = ws + L.G2, d.DZ2 = ws + L.DZ2, d.G1 = ws + L.G1, d.DZ1 = p->dz1 ? p->dz1 : ws + L.DZ1;
-    d.slots = ws + L.slots, d.part3 = ws + L.part3, d.part4 = ws + L.part4;
+    d.slots = ws + L.slots, d.part3 = ws + L.part3, d.part4 = ws + L.part4, d.W2T = ws + L.W2T, d.FACT = ws + L.FACT;
+    d.xt_vals = p->xt_vals;
     d.counters = (int*)(ws + L.counters);
     d.w1_grad_given = p->w1_grad_given;
     d.drop_in = p->drop_in, d.drop_hidden = p->drop_hidden;
@@ -1008,35 +1147,35 @@ extern "C" int acm_small_step(const acm_csr_t* a, const acm_csr_t* x, const acm_
     const bool four = K == 4, variant = p->relu_before != 0;
     if (phases & 1) {
         if (!dense) {
-            const int wg = (int)std::min<int64_t>(4 * MAX_WG, (x->n_items + WAVES - 1) / WAVES);
+            const int wg = (int)std::min<int64_t>(2 * MAX_WG, (x->n_items + 3) / 4);
             hipLaunchKernelGGL(small_proj1_kernel, dim3(std::max(wg, 1)), dim3(256), 0, s, d);
-        } else if (four) {
+        } else {
             hipLaunchKernelGGL(small_struc_copy_kernel, dim3((d.n * C8 + 255) / 256), dim3(256), 0, s, d);
         }
     }
     if (phases & 2) {
-        if (four && variant) hipLaunchKernelGGL((small_conv1_fwd_kernel<true, true>), dim3(graph_wg), dim3(256), 0, s, d, z1);
-        else if (four) hipLaunchKernelGGL((small_conv1_fwd_kernel<true, false>), dim3(graph_wg), dim3(256), 0, s, d, z1);
-        else if (variant) hipLaunchKernelGGL((small_conv1_fwd_kernel<false, true>), dim3(graph_wg), dim3(256), 0, s, d, z1);
-        else hipLaunchKernelGGL((small_conv1_fwd_kernel<false, false>), dim3(graph_wg), dim3(256), 0, s, d, z1);
+        if (four && variant) hipLaunchKernelGGL((small_conv1_fwd_kernel<true, true>), dim3(graph_wg), dim3(64 * WAVES), 0, s, d, z1);
+        else if (four) hipLaunchKernelGGL((small_conv1_fwd_kernel<true, false>), dim3(graph_wg), dim3(64 * WAVES), 0, s, d, z1);
+        else if (variant) hipLaunchKernelGGL((small_conv1_fwd_kernel<false, true>), dim3(graph_wg), dim3(64 * WAVES), 0, s, d, z1);
+        else hipLaunchKernelGGL((small_conv1_fwd_kernel<false, false>), dim3(graph_wg), dim3(64 * WAVES), 0, s, d, z1);
     }
     if (phases & 4) {
-        if (four) hipLaunchKernelGGL(small_conv2_fwd_kernel<true>, dim3(graph_wg), dim3(256), 0, s, d);
-        else hipLaunchKernelGGL(small_conv2_fwd_kernel<false>, dim3(graph_wg), dim3(256), 0, s, d);
+        if (four) hipLaunchKernelGGL(small_conv2_fwd_kernel<true>, dim3(graph_wg), dim3(64 * WAVES), 0, s, d);
+        else hipLaunchKernelGGL(small_conv2_fwd_kernel<false>, dim3(graph_wg), dim3(64 * WAVES), 0, s, d);
     }
     if (phases & 8) {
-        if (four) hipLaunchKernelGGL(small_conv2_bwd_kernel<true>, dim3(graph_wg), dim3(256), 0, s, d, z1);
-        else hipLaunchKernelGGL(small_conv2_bwd_kernel<false>, dim3(graph_wg), dim3(256), 0, s, d, z1);
+        if (four) hipLaunchKernelGGL(small_conv2_bwd_kernel<true>, dim3(graph_wg), dim3(64 * WAVES), 0, s, d, z1);
+        else hipLaunchKernelGGL(small_conv2_bwd_kernel<false>, dim3(graph_wg), dim3(64 * WAVES), 0, s, d, z1);
     }
     if (phases & 16) {
-        if (four && variant) hipLaunchKernelGGL((small_conv1_bwd_kernel<true, true>), dim3(graph_wg), dim3(256), 0, s, d, z1);
-        else if (four) hipLaunchKernelGGL((small_conv1_bwd_kernel<true, false>), dim3(graph_wg), dim3(256), 0, s, d, z1);
-        else if (variant) hipLaunchKernelGGL((small_conv1_bwd_kernel<false, true>), dim3(graph_wg), dim3(256), 0, s, d, z1);
-        else hipLaunchKernelGGL((small_conv1_bwd_kernel<false, false>), dim3(graph_wg), dim3(256), 0, s, d, z1);
+        if (four && variant) hipLaunchKernelGGL((small_conv1_bwd_kernel<true, true>), dim3(graph_wg), dim3(64 * WAVES), 0, s, d, z1);
+        else if (four) hipLaunchKernelGGL((small_conv1_bwd_kernel<true, false>), dim3(graph_wg), dim3(64 * WAVES), 0, s, d, z1);
+        else if (variant) hipLaunchKernelGGL((small_conv1_bwd_kernel<false, true>), dim3(graph_wg), dim3(64 * WAVES), 0, s, d, z1);
+        else hipLaunchKernelGGL((small_conv1_bwd_kernel<false, false>), dim3(graph_wg), dim3(64 * WAVES), 0, s, d, z1);
     }
     if (phases & 32) {
-        const int item_blocks = dense ? 0 : (int)std::min<int64_t>(4 * MAX_WG, (xt->n_items + WAVES - 1) / WAVES);
-        const int red_blocks = (PART4 + PART3 + 255) / 256;
+        const int item_blocks = dense ? 0 : (int)std::min<int64_t>(2 * MAX_WG, (xt->n_items + 3) / 4);
+        const int red_blocks = (PART4 + PART3 + RED_EL - 1) / RED_EL;
         const int w1_blocks = (dense && p->w1_grad_given && p->update) ? (int)((3LL * p->f_in * F + 255) / 256) : 0;
         hipLaunchKernelGGL(small_finish_kernel, dim3(item_blocks + red_blocks + w1_blocks), dim3(256), 0, s, d, item_blocks, red_blocks);
     }

@@ -21,6 +21,7 @@ from . import _lib, tuning
 from .graph import FilterOperators, SparseFeatures, _device_ctx, _stream
 
 _F32 = torch.float32
+_ON_DEVICE = lambda t: t.is_cuda          # noqa: E731  (the CPU test double of the library lifts this guard)
 MAX_ROWS = 16384
 HIDDEN = 64
 MAX_CLASSES = 8
@@ -91,7 +92,7 @@ class SmallPlan:
             return "structure channel without degrees"
         if not isinstance(x, SparseFeatures):
             return "dense features (CSR features only)"
-        if x.shape != (n, l0.in_features) or x.values.dtype != _F32 or not x.values.is_cuda:
+        if x.shape != (n, l0.in_features) or x.values.dtype != _F32 or not _ON_DEVICE(x.values):
             return "feature matrix shape / dtype / device"
         dev = x.values.device
         if any(p.device != dev or p.dtype != _F32 or not p.is_contiguous() for p in model.parameters()):
@@ -148,6 +149,8 @@ class SmallPlan:
         p.x_vals = x.values.data_ptr()
         if self._xt is not None:
             p.xt_src_pos = self._xt._src_pos_ptr
+            self.xt_vals = x.values.index_select(0, self._xt.src_pos)      # the (static) values in the transposed order
+            p.xt_vals = self.xt_vals.data_ptr()
         p.row_scale = ops.row_scale.data_ptr()
         p.logits, p.att1, p.att2, p.loss = self.logits.data_ptr(), self.att1.data_ptr(), self.att2.data_ptr(), self.loss.data_ptr()
         p.arrive = self.arrive.data_ptr()

@@ -921,6 +921,7 @@ typedef struct {
     /* first-layer input: CSR features (the handles passed to the call) with this call's values ...               */
     const float* x_vals;        /* nnz(X) values in the order of the x handle                                        */
     const int32_t* xt_src_pos;  /* nnz(X): position in x_vals of every entry of the TRANSPOSED handle                */
+    const float* xt_vals;       /* optional: x_vals in the transposed handle's order (x_vals[xt_src_pos[k]]), made once     */
     /* ... or dense features: the caller computes Z1 = drop(X) [W_L | W_H | W_I] (acm_gemm) before, and
      * dW1 = drop(X)^T dZ1 into t[0][W_*].grad between launches 5 and 6 (phases)                                      */
     const float* z1_given;      /* [n, 192] row-major, or NULL                                                       */

@@ -965,6 +965,110 @@ class FakeLib:
         no_post = not q.post_relu and not q.post_scale and not q.post_drop.p > 0
         return (fp == 8 and F == 64 and bool(q.head_stats) and out_mask and (self._tuning["rows16"] & 2) != 0)
 
+    # ---- the fused small-graph step (ABI 25): stated with the oracle's layer + torch autograd (float64) -------------
+    def acm_small_step_workspace_bytes(self, a, x, xt, out):
+        out._obj.value = 4096
+        return 0
+
+    def acm_small_step(self, a, x, xt, pp, stream):
+        import scipy.sparse as sp
+        import torch
+        from acm_gnn_amd import _lib
+        from oracle import acm_oracle as O
+        p = pp._obj
+        g = self._get(a)
+        n, C_, k = g.n_rows, int(p.n_classes), int(p.n_channels)
+        if np.any(g.vals != 1) or g.n_rows != g.n_cols or C_ > 8 or n > 16384:
+            self._err = b"acm_small_step: outside the envelope"
+            return 4
+        self.small_calls = getattr(self, "small_calls", 0) + 1
+        pat = sp.csr_matrix((np.ones(len(g.indices)), g.indices, g.indptr), shape=(n, n))
+        rs = _vec(p.row_scale, n).astype(np.float64)
+        low = torch.from_numpy((sp.diags(rs) @ pat).toarray())
+        high = torch.eye(n, dtype=torch.float64) - low
+        raw = torch.from_numpy((pat - sp.identity(n)).toarray())
+        fx = self._get(x)
+        f_in = int(p.f_in)
+        vals = _vec(p.x_vals, len(fx.indices)).astype(np.float64)
+        train = bool(p.train)
+        if train:
+            vals = vals * dropout_factors(p.drop_in, len(vals), 1)[:, 0]
+        xd = torch.from_numpy(sp.csr_matrix((vals, fx.indices, fx.indptr), shape=(n, f_in)).toarray())
+        names = {_lib.SR_W_LOW: "weight_low", _lib.SR_W_HIGH: "weight_high", _lib.SR_W_MLP: "weight_mlp", _lib.SR_V_LOW: "att_vec_low",
+                 _lib.SR_V_HIGH: "att_vec_high", _lib.SR_V_MLP: "att_vec_mlp", _lib.SR_V_STRUC: "att_struc_low",
+                 _lib.SR_LNW_LOW: "layer_norm_low.weight", _lib.SR_LNW_HIGH: "layer_norm_high.weight", _lib.SR_LNW_MLP: "layer_norm_mlp.weight",
+                 _lib.SR_LNW_STRUC: "layer_norm_struc_low.weight", _lib.SR_LNB_LOW: "layer_norm_low.bias",
+                 _lib.SR_LNB_HIGH: "layer_norm_high.bias", _lib.SR_LNB_MLP: "layer_norm_mlp.bias", _lib.SR_LNB_STRUC: "layer_norm_struc_low.bias",
+                 _lib.SR_MIX: "att_vec", _lib.SR_STRUC: "struc_low"}
+        dims = [(f_in, 64), (64, C_)]
+
+        def shape(li, role):
+            fi, fo = dims[li]
+            if role <= _lib.SR_W_MLP:
+                return (fi, fo)
+            if role == _lib.SR_MIX:
+                return (k, k)
+            if role == _lib.SR_STRUC:
+                return (n, fo)
+            return (fo, 1) if role <= _lib.SR_V_STRUC else (fo,)
+
+        views, leaves = {}, [{}, {}]
+        for li in range(2):
+            for role, nm in names.items():
+                t = p.t[li][role]
+                if not t.param:
+                    continue
+                sh = shape(li, role)
+                v = _vec(t.param, int(np.prod(sh)))
+                views[(li, role)] = (v, t)
+                leaves[li][nm] = torch.from_numpy(v.astype(np.float64).reshape(sh)).requires_grad_(train)
+        kw = dict(model_type="acmgcnp", variant=bool(p.relu_before), structure_info=int(k == 4), attn_layernorm=bool(p.layernorm))
+        un = raw if k == 4 else None
+        fea, att1 = O.layer_forward(leaves[0], xd, low, high, un, return_att=True, **kw)
+        fea = torch.relu(fea)
+        if train:
+            fea = fea * torch.from_numpy(dropout_factors(p.drop_hidden, n, 64))
+        out, att2 = O.layer_forward(leaves[1], fea, low, high, un, return_att=True, **kw)
+        _view(p.logits, n, C_, C_)[...] = out.detach().numpy()
+        _view(p.att1, n, 4, 4)[:, :k] = att1.detach().numpy()
+        _view(p.att2, n, 4, 4)[:, :k] = att2.detach().numpy()
+        if not train:
+            return 0
+        y = torch.from_numpy(_vec(p.labels, n, np.int64).copy())
+        w = torch.from_numpy(_vec(p.row_weight, n).astype(np.float64))
+        loss = -(w * torch.log_softmax(out, 1).gather(1, y.view(-1, 1)).view(-1)).sum()
+        loss.backward()
+        _vec(p.loss, 1)[0] = float(loss.detach())
+        f32 = np.float32
+        stepped = set()
+        for (li, role), (v, t) in views.items():
+            gr = leaves[li][names[role]].grad
+            gr = (torch.zeros_like(leaves[li][names[role]]) if gr is None else gr).numpy().reshape(-1).astype(np.float32)
+            if t.grad:
+                _vec(t.grad, len(v))[...] = gr
+            if not p.update:
+                continue
+            m, vv, step = _vec(t.exp_avg, len(v)), _vec(t.exp_avg_sq, len(v)), _vec(t.step, 1)
+            kk = float(step[0]) + 1.0
+            step_size = f32(p.lr / (1.0 - p.beta1 ** kk))
+            bc2_sqrt = f32((1.0 - p.beta2 ** kk) ** 0.5)
+            gg = gr.copy()
+            if p.weight_decay != 0:
+                if p.decoupled:
+                    v *= f32(1.0 - p.lr * p.weight_decay)
+                else:
+                    gg = gg + f32(p.weight_decay) * v
+            m += f32(1.0 - p.beta1) * (gg - m)
+            vv[...] = vv * f32(p.beta2) + f32(1.0 - p.beta2) * gg * gg
+            v -= step_size * (m / (np.sqrt(vv) / bc2_sqrt + f32(p.eps)))
+            stepped.add(int(t.step))
+        if p.update:
+            for addr in stepped:
+                _vec(addr, 1)[0] += 1.0
+            if p.also_advance:
+                _vec(p.also_advance, 1, np.int64)[0] += 1
+        return 0
+
     def acm_dropout(self, n, c, src, lds, dst, ldd, dst_cols, d, stream):
         out = np.zeros((n, dst_cols))
         out[:, :c] = _view(src, n, c, lds).astype(np.float64) * dropout_factors(d._obj, n, c)
@@ -1010,9 +1114,13 @@ def install(monkeypatch):
     monkeypatch.setattr(_lib, "load", lambda build_if_missing=True: fake)
     monkeypatch.setattr(_lib, "check", lambda st, what="": (_ for _ in ()).throw(
         RuntimeError(f"{what}: {fake.acm_last_error().decode()} ({_lib.STATUS_NAMES.get(st, st)})")) if st else None)
+    from acm_gnn_amd import small
     for mod in (graph, functional, optim):
         monkeypatch.setattr(mod, "_require_cuda", lambda t, name: None)
         monkeypatch.setattr(mod, "_stream", lambda: None)
+    monkeypatch.setattr(small, "_stream", lambda: None)
+    monkeypatch.setattr(small, "_device_ctx", lambda dev: contextlib.nullcontext())
+    monkeypatch.setattr(small, "_ON_DEVICE", lambda t: True)
     monkeypatch.setattr(functional, "_device_ctx", lambda dev: contextlib.nullcontext())
     monkeypatch.setattr(optim, "_device_ctx", lambda dev: contextlib.nullcontext())
     monkeypatch.setattr(graph, "_device_ctx", lambda dev: contextlib.nullcontext())

@@ -1368,3 +1368,71 @@ def test_training_and_evaluation_inputs_keep_separate_p_cache_entries(monkeypatc
     assert p_train() is not None and held[0][2]["agg"] is p_train()
     roles = model.gcns[0].__dict__["_eval_agg"]
     assert set(roles) == {"train", "eval"}
+
+
+@pytest.mark.parametrize("model_type,s,variant,p_drop", [("acmgcnp", 1, 0, 0.5), ("acmgcn", 0, 1, 0.0)])
+def test_small_graph_step_host_path_equals_the_general_path(model_type, s, variant, p_drop, monkeypatch):
+    """small.SmallPlan (acm_small_step, ABI 25) behind train.TrainStep / EvalStep: a small graph with CSR features and this
+    package's FusedAdam takes the fused step -- one C-ABI call per step, parameters and the optimizer's own state tensors
+    updated in place, the dropout counter advanced -- and lands where the general path (autograd Functions + acm_adam_step)
+    lands; anything outside the envelope says why and stays on the general path."""
+    import scipy.sparse as sp
+    fake = fake_lib.install(monkeypatch)
+    from acm_gnn_amd import GCN, FusedAdamW, SparseFeatures, functional as AF, train as T
+    from acm_gnn_amd.graph import CsrGraph, FilterOperators
+    from acm_gnn_amd.small import SmallPlan
+    ops0, n = _dense_graph_ops(n=90, avg=8, seed=12)
+    ip, ix, _ = ops0.low.arrays()
+    pat = sp.csr_matrix((np.ones(len(ix), np.float32), ix.numpy(), ip.numpy()), shape=(n, n))
+    deg = np.asarray(pat.sum(1)).ravel().astype(np.float32)
+    from acm_gnn_amd import graph as G
+    ops = G.as_implicit(FilterOperators(CsrGraph.from_scipy(sp.csr_matrix(sp.diags(1.0 / deg) @ pat).astype(np.float32), "cpu"),
+                                        deg=torch.from_numpy(deg)))
+    assert ops.implicit
+    rng = np.random.default_rng(0)
+    x_np = ((rng.random((n, 50)) < 0.08) * rng.uniform(0.5, 1.5, (n, 50))).astype(np.float32)
+    xs = SparseFeatures.from_scipy(sp.csr_matrix(x_np), "cpu")
+    y = torch.from_numpy(rng.integers(0, 3, n))
+    w = T.row_weights(torch.arange(0, n, 2), n)
+
+    def run(small):
+        torch.manual_seed(1)
+        model = GCN(50, 64, 3, 2, n, p_drop, model_type, s, variant=bool(variant), attn_layernorm=model_type == "acmgcnp")
+        model.dropout_state = AF.DropoutState("cpu", seed=21) if p_drop > 0 else None
+        opt = FusedAdamW(model.parameters(), lr=0.02, weight_decay=1e-2)
+        step = T.TrainStep(model, opt, xs, ops, y, w, small_step=None if small else False)
+        assert (step.small is not None) == small, step.small_refused
+        calls = getattr(fake, "small_calls", 0)
+        losses = [float(step()) for _ in range(5)]
+        assert getattr(fake, "small_calls", 0) - calls == (5 if small else 0)
+        ev = T.EvalStep(model, xs, ops, y, (torch.arange(0, n, 2), torch.arange(1, n, 2)), small_step=None if small else False)
+        assert (ev.small is not None) == small
+        out, accs, vloss = ev()
+        return model, opt, losses, out, accs, vloss
+
+    ma, oa, la, out_a, acc_a, vl_a = run(True)
+    mb, ob, lb, out_b, acc_b, vl_b = run(False)
+    np.testing.assert_allclose(la, lb, rtol=2e-4, atol=1e-6)
+    for (k, pa), (_, pb) in zip(ma.state_dict().items(), mb.state_dict().items()):
+        torch.testing.assert_close(pa, pb, rtol=2e-3, atol=2e-5, msg=k)
+    torch.testing.assert_close(out_a, out_b, rtol=1e-3, atol=1e-4)
+    assert acc_a == pytest.approx(acc_b, abs=0.03) and vl_a == pytest.approx(vl_b, rel=1e-3)
+    # the optimizer's state is the plan's state: same tensors, same step counts as optimizer.step() leaves
+    for pa, pb in zip(ma.parameters(), mb.parameters()):
+        sa, sb = oa.state.get(pa, {}), ob.state.get(pb, {})
+        assert set(sa) == set(sb), "the fused step touched a parameter the reference's autograd leaves without gradient"
+        if sa:
+            assert float(sa["step"]) == float(sb["step"]) == 5.0
+    if p_drop > 0:
+        assert int(ma.dropout_state.step.item()) == 5 and ma.dropout_state.host_steps == 5
+    # after a forward the layers carry the mixing weights, like the reference's (layers.py:91,107)
+    assert ma.gcns[0].att_low.shape == (n, 1) and float(ma.gcns[1].att_mlp.abs().sum()) > 0
+    # outside the envelope: says why
+    assert "dense features" in SmallPlan.why_not(ma, torch.from_numpy(x_np), ops)
+    with __import__("acm_gnn_amd").tuning.override(small_step=0):
+        assert "switched off" in SmallPlan.why_not(ma, xs, ops)
+    m3 = GCN(50, 32, 3, 2, n, 0.0, "acmgcn", 0)
+    assert "hidden width" in SmallPlan.why_not(m3, xs, ops)
+    m4 = GCN(50, 64, 3, 2, n, 0.0, "acmgcnpp", 0)
+    assert "model_type" in SmallPlan.why_not(m4, xs, ops)
+    assert "optimizer" in SmallPlan.why_not(ma, xs, ops, torch.optim.Adam(ma.parameters()))
