@@ -33,10 +33,11 @@ constexpr int C8 = 8;                 // padded class count
 constexpr int WAVES = 8;              // per workgroup of the gather phases (two per SIMD: the second hides the first's latency chain)
 constexpr int MAX_WG = 2048;          // workgroups of a gather phase: one work item per wave up to 16384 items (a wave's item is a
                                       // latency chain of ~2 000 dependent instructions; more waves, not longer loops, hide it)
-constexpr int RED_EL = 32;            // elements of the partial-sum vectors per reducing block of the last launch
+constexpr int RED_EL = 8;             // elements of the partial-sum vectors per reducing block of the last launch (x 32 producer lanes)
 constexpr int PART4 = 3 * F * C8 + 3 * 4 * F + 16;      // dW2 [3][64][8] | dv1 [4][64] | dgamma1 | dbeta1 | dmix1 [4][4]
 constexpr int PART3 = 3 * 4 * C8 + 16 + 1;              // dv2 [4][8] | dgamma2 | dbeta2 | dmix2 | loss
 constexpr int PART3_PITCH = 128;
+constexpr int LONG4 = 3 * 4 * F + 16;                  // a long row's record of launch 4: dv1 | dgamma1 | dbeta1 | dmix1 (its dW2 term is recomputed)
 
 struct SmallTensor {
     float* p;
@@ -69,6 +70,8 @@ struct SmallDev {
     float *att1, *att2;
     // workspace
     float *Z1, *H1, *ST1, *OUT1, *T2, *Z2I, *G2, *DZ2, *G1, *DZ1, *slots, *part3, *part4, *W2T, *FACT;
+    float *long3, *long4;            // [n_long][PART3_PITCH] / [n_long][LONG4]: the parameter-gradient terms of the long rows
+    int n_long;
     const float* xt_vals;
     int* counters;
     int nwg3, nwg4;                  // producer workgroups of the two partial-sum buffers
@@ -110,11 +113,15 @@ template <int NCH, int RELU_MASK, class W>
 __device__ __forceinline__ void wide_gather(const int32_t* __restrict__ ids, int begin, int end, const float* const (&tab)[3],
                                             const int (&ld)[3], int safe, W&& weight, f4 (&acc)[3]) {
     const int lane = threadIdx.x & 63, g = lane >> 4, m = lane & 15;
+    int id = safe;
+    float w = 0.f;
+    if (begin + 4 * m + g < end) id = ids[begin + 4 * m + g], w = weight(begin + 4 * m + g);
     for (int k0 = begin; k0 < end; k0 += 64) {
-        const int pos = k0 + 4 * m + g;
-        const bool ok = pos < end;
-        const int id = ok ? ids[pos] : safe;
-        const float w = ok ? weight(pos) : 0.f;
+        // the NEXT chunk's ids travel while this chunk's rows do (one dependent round trip less per 64 entries)
+        const int npos = k0 + 64 + 4 * m + g;
+        int nid = safe;
+        float nw = 0.f;
+        if (npos < end) nid = ids[npos], nw = weight(npos);
         const int steps = (min(end - k0, 64) + 3) >> 2;              // uniform
         // CNT steps (x NCH rows) requested before the first is consumed: a step is a dependent L2 round trip, and with one
         // item per wave nothing else hides it
@@ -148,6 +155,7 @@ __device__ __forceinline__ void wide_gather(const int32_t* __restrict__ ids, int
             }
         }
 #undef ACM_WG_BLOCK
+        id = nid, w = nw;
     }
 }
 
@@ -199,11 +207,14 @@ __device__ __forceinline__ f4 narrow_gather(const int32_t* __restrict__ ids, int
     const int qq = q < NQ ? q : NQ - 1;                  // idle lanes repeat the last block (unconditional loads: a guarded load
     const bool relu = relu01 && q < 4;                   // makes the compiler wait for every one before the next)
     f4 acc = zero4();
+    int id = safe;
+    float w = 0.f;
+    if (begin + 8 * q + (lane >> 3) < end) id = ids[begin + 8 * q + (lane >> 3)], w = 1.f;
     for (int k0 = begin; k0 < end; k0 += 64) {
-        const int pos = k0 + 8 * q + (lane >> 3);
-        const bool ok = pos < end;
-        const int id = ok ? ids[pos] : safe;
-        const float w = ok ? 1.f : 0.f;
+        const int npos = k0 + 64 + 8 * q + (lane >> 3);       // the next chunk's ids, requested before this chunk's rows
+        int nid = safe;
+        float nw = 0.f;
+        if (npos < end) nid = ids[npos], nw = 1.f;
         const int steps = (min(end - k0, 64) + 7) >> 3;
         f4 v[8];
         float ww[8];
@@ -223,6 +234,7 @@ __device__ __forceinline__ f4 narrow_gather(const int32_t* __restrict__ ids, int
             if (relu) x = relu4(x);
             acc += ww[u] * x;
         }
+        id = nid, w = nw;
     }
     if (q >= NQ) acc = zero4();
 #pragma unroll
@@ -235,6 +247,9 @@ __device__ __forceinline__ f4 narrow_gather(const int32_t* __restrict__ ids, int
     return acc;
 }
 
+// The epilogue also receives the row's long-row index (-1: a whole row).  WHICH wave finishes a long row depends on the
+// arrival order, so a finisher must not add the row's parameter-gradient terms to its own running sums (the sums of the
+// workgroups would differ from run to run in the last bit): it leaves them in the row's own record (SmallDev::long3 / long4).
 template <int NQ, class Pre, class Gather, class Epi>
 __device__ __forceinline__ void narrow_items(const ItemView& iv, float* slots, int* counters, int wave, int n_waves, Pre&& pre,
                                              Gather&& gather, Epi&& epi) {
@@ -244,11 +259,12 @@ __device__ __forceinline__ void narrow_items(const ItemView& iv, float* slots, i
         item.row = acm_uniform(item.row), item.begin = acm_uniform(item.begin), item.end = acm_uniform(item.end), item.slot = acm_uniform(item.slot);
         auto pf = pre(item.row);
         f4 acc = gather(item);
+        int li = -1;
         if (item.slot >= 0) {
             float* sp = slots + (long)item.slot * (3 * F);
             if (lane < 8 && q < NQ) st4_coherent(sp + 4 * q, acc);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            const int li = iv.long_index[item.row];
+            li = iv.long_index[item.row];
             const AcmLongRow lr = iv.long_rows[li];
             int old = 0;
             if (lane == 0) old = __hip_atomic_fetch_add(counters + li, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -259,7 +275,7 @@ __device__ __forceinline__ void narrow_items(const ItemView& iv, float* slots, i
             if (q < NQ)
                 for (int s = lr.slot_begin; s < lr.slot_end; ++s) acc += ld4_coherent(slots + (long)s * (3 * F) + 4 * q);
         }
-        epi(item.row, acc, pf);
+        epi(item.row, acc, pf, li);
     }
 }
 
@@ -490,7 +506,7 @@ __global__ __launch_bounds__(64 * WAVES) void small_conv2_fwd_kernel(SmallDev d)
             return pf;
         },
         [&](const AcmItem& item) { return narrow_gather<NQ>(d.graph.indices, item.begin, item.end, d.T2, 24, item.row, variant); },
-        [&](int row, f4 acc, const Pre3& pf) {
+        [&](int row, f4 acc, const Pre3& pf, int li) {
             const float rs = pf.rs;
             const float aL = narrow_pick(acc, 0), aH = narrow_pick(acc, 1), aS = FOUR ? narrow_pick(acc, 2) : 0.f;
             const float zH = pf.zH, zI = pf.zI;
@@ -536,14 +552,15 @@ __global__ __launch_bounds__(64 * WAVES) void small_conv2_fwd_kernel(SmallDev d)
             if (!d.train) return;
             // masked NLL of the row and its gradient (acm_nll_row)
             const float w = pf.w;
-            float dl = 0.f;
+            float dl = 0.f, r_loss = 0.f;
+            float r_dv[K], r_dg[K], r_db[K], r_dm[K][K];        // this row's terms of the parameter gradients
             if (w != 0.f) {
                 const float mz = gmax8(valid ? z : -INFINITY);
                 const float ex = valid ? expf(z - mz) : 0.f;
                 const float s = gsum8(ex);
                 const int y = pf.y;
                 const float zy = __shfl(z, (lane & ~7) + y);
-                a_loss += w * ((mz + logf(s)) - zy);
+                r_loss = w * ((mz + logf(s)) - zy);
                 dl = valid ? w * (ex * (1.0f / s) - (c == y ? 1.f : 0.f)) : 0.f;
             }
             // row-local backward of the layer (no post-op on an output layer)
@@ -560,16 +577,17 @@ __global__ __launch_bounds__(64 * WAVES) void small_conv2_fwd_kernel(SmallDev d)
 #pragma unroll
                 for (int b = 0; b < K; ++b) {
                     dsig += dt[b] * mix[ch][b];
-                    a_dm[ch][b] += sig[ch] * dt[b] / (float)K;
+                    r_dm[ch][b] = sig[ch] * dt[b] / (float)K;
                 }
                 dsig /= (float)K;
                 const float dlg = dsig * sig[ch] * (1.0f - sig[ch]);
-                a_dv[ch] += dlg * hn[ch];
+                r_dv[ch] = dlg * hn[ch];
+                r_dg[ch] = r_db[ch] = 0.f;
                 const float dhn = dlg * av[ch];
                 float dln = dhn;
                 if (d.layernorm) {
-                    a_dg[ch] += dhn * xh[ch];
-                    a_db[ch] += valid ? dhn : 0.f;
+                    r_dg[ch] = dhn * xh[ch];
+                    r_db[ch] = valid ? dhn : 0.f;
                     const float u = dhn * gam[ch];
                     const float s1 = gsum8(u) * invC, s2 = gsum8(u * xh[ch]) * invC;
                     dln = valid ? rstd[ch] * (u - s1 - xh[ch] * s2) : 0.f;
@@ -584,6 +602,32 @@ __global__ __launch_bounds__(64 * WAVES) void small_conv2_fwd_kernel(SmallDev d)
                 if (FOUR) gp[16 + c] = gch[K - 1];
                 float* dz = d.DZ2 + (long)row * 24;
                 dz[8 + c] = gch[1], dz[16 + c] = gch[2];
+            }
+            if (li < 0) {
+                a_loss += r_loss;
+#pragma unroll
+                for (int ch = 0; ch < K; ++ch) {
+                    a_dv[ch] += r_dv[ch], a_dg[ch] += r_dg[ch], a_db[ch] += r_db[ch];
+#pragma unroll
+                    for (int b = 0; b < K; ++b) a_dm[ch][b] += r_dm[ch][b];
+                }
+            } else {                                      // the finisher of a long row: its terms go to the row's own record
+                float* rec = d.long3 + (long)li * PART3_PITCH;
+                if (lane < 8) {
+#pragma unroll
+                    for (int ch = 0; ch < 4; ++ch) {
+                        const bool on = ch < K;
+                        rec[ch * 8 + c] = on ? r_dv[on ? ch : 0] : 0.f, rec[32 + ch * 8 + c] = on ? r_dg[on ? ch : 0] : 0.f;
+                        rec[64 + ch * 8 + c] = on ? r_db[on ? ch : 0] : 0.f;
+                    }
+                }
+                if (lane == 0) {
+#pragma unroll
+                    for (int a = 0; a < 4; ++a)
+#pragma unroll
+                        for (int b = 0; b < 4; ++b) rec[96 + a * 4 + b] = (a < K && b < K) ? r_dm[a < K ? a : 0][b < K ? b : 0] : 0.f;
+                    rec[112] = r_loss;
+                }
             }
         });
     if (!d.train) return;
@@ -668,7 +712,7 @@ __global__ __launch_bounds__(64 * WAVES) void small_conv2_bwd_kernel(SmallDev d,
             return pf;
         },
         [&](const AcmItem& item) { return narrow_gather<NQ>(d.graph.indices, item.begin, item.end, d.G2, 24, item.row, false); },
-        [&](int row, f4 acc, const Pre4& pf) {
+        [&](int row, f4 acc, const Pre4& pf, int li) {
             const float aL = narrow_pick(acc, 0), aH = narrow_pick(acc, 1), aS = FOUR ? narrow_pick(acc, 2) : 0.f;
             float dzL = aL, dzH = pf.gH - aH;
             const float dzI = pf.dzI;
@@ -710,10 +754,15 @@ __global__ __launch_bounds__(64 * WAVES) void small_conv2_bwd_kernel(SmallDev d,
                 __builtin_amdgcn_sched_barrier(0);
             }
             const f4 dH = dH0 + dH1;
+            if (li < 0) {
 #pragma unroll
-            for (int t = 0; t < 6; ++t) {
-                const float zz = g == 0 ? dz[4 * t] : (g == 1 ? dz[4 * t + 1] : (g == 2 ? dz[4 * t + 2] : dz[4 * t + 3]));
-                a_w2[t] += zz * o;
+                for (int t = 0; t < 6; ++t) {
+                    const float zz = g == 0 ? dz[4 * t] : (g == 1 ? dz[4 * t + 1] : (g == 2 ? dz[4 * t + 2] : dz[4 * t + 3]));
+                    a_w2[t] += zz * o;
+                }
+            } else if (lane < 8) {                        // a long row: launch 6 forms its dW2 term from H and dZ2 of the row
+                float* dzr = d.DZ2 + (long)row * 24;
+                dzr[c] = dzL, dzr[8 + c] = dzH;            // (dzr[16 + c] = dzI is there already)
             }
             // through dropout(relu(.)): the forward's output is non-zero exactly where both let the element pass
             f4 dmix;
@@ -741,22 +790,23 @@ __global__ __launch_bounds__(64 * WAVES) void small_conv2_bwd_kernel(SmallDev d,
                 dsig /= (float)K;
                 dlg[ch] = dsig * sig[ch] * (1.0f - sig[ch]);
             }
+            float r_dm = 0.f;
             {
                 const int ma = (lane >> 2) & 3, mb = lane & 3;
                 const float sa = ma == 0 ? sig[0] : (ma == 1 ? sig[1] : (ma == 2 ? sig[2] : sig[K - 1]));
                 const float tb = mb == 0 ? dt[0] : (mb == 1 ? dt[1] : (mb == 2 ? dt[2] : dt[K - 1]));
-                if (ma < K && mb < K) a_dm += sa * tb / (float)K;
+                if (ma < K && mb < K) r_dm = sa * tb / (float)K;
             }
             const float my_dl = g == 0 ? dlg[0] : (g == 1 ? dlg[1] : (g == 2 ? dlg[2] : (K == 4 ? dlg[K - 1] : 0.f)));
             const float my_al = g == 0 ? al[0] : (g == 1 ? al[1] : (g == 2 ? al[2] : (K == 4 ? al[K - 1] : 0.f)));
             f4 xh = zero4(), hn = h;
             if (d.layernorm) xh = (h - mean) * rstd, hn = xh * gam + bet;
-            a_dv += my_dl * hn;
+            const f4 r_dv = my_dl * hn;
             const f4 dhn = my_dl * av;
-            f4 dln = dhn;
+            f4 dln = dhn, r_dg = zero4(), r_db = zero4();
             if (d.layernorm) {
-                a_dg += dhn * xh;
-                a_db += dhn;
+                r_dg = dhn * xh;
+                r_db = dhn;
                 const f4 u = dhn * gam;
                 const float s1 = acm_group_sum<16>(hsum4(u)) * (1.0f / F), s2 = acm_group_sum<16>(hsum4(u * xh)) * (1.0f / F);
                 dln = rstd * (u - s1 - xh * s2);
@@ -773,6 +823,15 @@ __global__ __launch_bounds__(64 * WAVES) void small_conv2_bwd_kernel(SmallDev d,
             if (g == 1) st4(g1 + F, rs * dhc), st4(dz1 + F, dhc);
             if (g == 2) st4(dz1 + 2 * F, dhc);
             if (FOUR && g == 3) st4(g1 + 2 * F, dhc);
+            if (li < 0) {
+                a_dv += r_dv, a_dg += r_dg, a_db += r_db, a_dm += r_dm;
+            } else {                                      // the finisher of a long row: its terms go to the row's own record
+                float* rec = d.long4 + (long)li * LONG4;
+                const f4 zv = zero4();
+                st4(rec + g * F + 4 * m, act ? r_dv : zv), st4(rec + 4 * F + g * F + 4 * m, act ? r_dg : zv);
+                st4(rec + 8 * F + g * F + 4 * m, act ? r_db : zv);
+                if (lane < 16) rec[12 * F + lane] = r_dm;
+            }
         });
     // per-workgroup partial sums: waves 0-3 leave their sums in a slice each, waves 4-7 add theirs on top, then every thread
     // adds the four slices of its elements -- a fixed order of additions (deterministic), two barriers
@@ -876,7 +935,7 @@ __global__ __launch_bounds__(64 * WAVES) void small_conv1_bwd_kernel(SmallDev d,
 // then -- dense features -- the elementwise update of W1 from the caller's gradient.  The last block to finish advances the
 // step counters.
 __global__ __launch_bounds__(256) void small_finish_kernel(SmallDev d, int item_blocks, int red_blocks) {
-    __shared__ float red8[8][RED_EL];
+    __shared__ float red8[256 / RED_EL][RED_EL];
     __shared__ int s_last;
     const float* __restrict__ fact = d.FACT;              // step factors of every tensor (launch 1 wrote them)
     const AdamFactors af(d.hp);
@@ -940,8 +999,8 @@ __global__ __launch_bounds__(256) void small_finish_kernel(SmallDev d, int item_
                 }
             });
     } else if (blk < item_blocks + red_blocks) {
-        // RED_EL elements per block: thread (wl, el) adds the producer workgroups wl, wl + 8, ... (independent loads in
-        // flight), the eight partial sums meet in LDS in a fixed order
+        // RED_EL elements per block: thread (wl, el) adds the producer workgroups wl, wl + 32, ... (independent loads in
+        // flight), the 32 partial sums meet in LDS in a fixed order
         const int el = (int)threadIdx.x & (RED_EL - 1), wl = (int)threadIdx.x / RED_EL;
         const int e = (blk - item_blocks) * RED_EL + el;
         const int K = d.k, C = d.C;
@@ -953,21 +1012,38 @@ __global__ __launch_bounds__(256) void small_finish_kernel(SmallDev d, int item_
             const long pitch = four ? PART4 : PART3_PITCH;
             const int nw = four ? d.nwg4 : d.nwg3;
             // sixteen loads in flight per thread, added in the order of the producer workgroups
-            for (int w0 = wl; w0 < nw; w0 += 128) {
+            constexpr int WL = 256 / RED_EL;
+            for (int w0 = wl; w0 < nw; w0 += 16 * WL) {
                 float v[16];
 #pragma unroll
                 for (int j = 0; j < 16; ++j) {
-                    const int w = w0 + 8 * j;
+                    const int w = w0 + WL * j;
                     v[j] = w < nw ? src[(long)w * pitch] : 0.f;
                 }
 #pragma unroll
                 for (int j = 0; j < 16; ++j) s += v[j];
             }
+            // ... and the long rows' own records (their finisher varies from run to run, their place in this sum does not):
+            // dW2 terms are formed here from the row's H and dZ2, the others were stored by the finisher
+            const bool w2 = four && e < 3 * F * C8;
+            const int col = (e / C8) % F, idx = (e / (F * C8)) * 8 + e % C8;
+            for (int l0 = wl; l0 < d.n_long; l0 += WL) {
+                float x;
+                if (w2) {
+                    const long r = d.graph.long_rows[l0].row;
+                    x = d.OUT1[r * F + col] * d.DZ2[r * 24 + idx];
+                } else {
+                    x = four ? d.long4[(long)l0 * LONG4 + (e - 3 * F * C8)] : d.long3[(long)l0 * PART3_PITCH + q];
+                }
+                s += x;
+            }
         }
         red8[wl][el] = s;
         __syncthreads();
         if (wl == 0 && e < PART4 + PART3) {
-            s = ((red8[0][el] + red8[1][el]) + (red8[2][el] + red8[3][el])) + ((red8[4][el] + red8[5][el]) + (red8[6][el] + red8[7][el]));
+            s = 0.f;
+#pragma unroll
+            for (int j = 0; j < 256 / RED_EL; ++j) s += red8[j][el];
             if (four) {
                 if (e < 3 * F * C8) {
                     const int ch = e / (F * C8), col = (e / C8) % F, c = e % C8;
@@ -1040,7 +1116,7 @@ ItemView view_of(const acm_csr* a) {
 }
 
 struct Layout {
-    size_t Z1, H1, ST1, OUT1, T2, Z2I, G2, DZ2, G1, DZ1, slots, part3, part4, W2T, FACT, counters, total;
+    size_t Z1, H1, ST1, OUT1, T2, Z2I, G2, DZ2, G1, DZ1, slots, part3, part4, W2T, FACT, long3, long4, counters, total;
 };
 
 Layout layout_of(const acm_csr* a, const acm_csr* x, const acm_csr* xt) {
@@ -1063,6 +1139,7 @@ Layout layout_of(const acm_csr* a, const acm_csr* x, const acm_csr* xt) {
     const size_t wg = (size_t)std::min<int64_t>(MAX_WG, (a->n_items + WAVES - 1) / WAVES);      // = the gather phases' grid
     L.part3 = take(wg * PART3_PITCH), L.part4 = take(wg * PART4);
     L.W2T = take(3 * F * C8), L.FACT = take(2 * ACM_SMALL_ROLES * 2);
+    L.long3 = take((size_t)a->n_long * PART3_PITCH + 64), L.long4 = take((size_t)a->n_long * LONG4 + 64);
     L.counters = take(n_long + 64);
     L.total = o * sizeof(float);
     return L;
@@ -1135,6 +1212,7 @@ extern "C" int acm_small_step(const acm_csr_t* a, const acm_csr_t* x, const acm_
     d.G2 = ws + L.G2, d.DZ2 = ws + L.DZ2, d.G1 = ws + L.G1, d.DZ1 = p->dz1 ? p->dz1 : ws + L.DZ1;
     d.slots = ws + L.slots, d.part3 = ws + L.part3, d.part4 = ws + L.part4, d.W2T = ws + L.W2T, d.FACT = ws + L.FACT;
     d.xt_vals = p->xt_vals;
+    d.long3 = ws + L.long3, d.long4 = ws + L.long4, d.n_long = (int)a->n_long;
     d.counters = (int*)(ws + L.counters);
     d.w1_grad_given = p->w1_grad_given;
     d.drop_in = p->drop_in, d.drop_hidden = p->drop_hidden;
