@@ -37,7 +37,7 @@ constexpr int RED_EL = 8;             // elements of the partial-sum vectors per
 constexpr int PART4 = 3 * F * C8 + 3 * 4 * F + 16;      // dW2 [3][64][8] | dv1 [4][64] | dgamma1 | dbeta1 | dmix1 [4][4]
 constexpr int PART3 = 3 * 4 * C8 + 16 + 1;              // dv2 [4][8] | dgamma2 | dbeta2 | dmix2 | loss
 constexpr int PART3_PITCH = 128;
-constexpr int LONG4 = 3 * 4 * F + 16;                  // a long row's record of launch 4: dv1 | dgamma1 | dbeta1 | dmix1 (its dW2 term is recomputed)
+constexpr int LONG4 = PART4;                            // a long row's record of launch 4: the row's terms in the layout of a partial
 
 struct SmallTensor {
     float* p;
@@ -760,9 +760,15 @@ __global__ __launch_bounds__(64 * WAVES) void small_conv2_bwd_kernel(SmallDev d,
                     const float zz = g == 0 ? dz[4 * t] : (g == 1 ? dz[4 * t + 1] : (g == 2 ? dz[4 * t + 2] : dz[4 * t + 3]));
                     a_w2[t] += zz * o;
                 }
-            } else if (lane < 8) {                        // a long row: launch 6 forms its dW2 term from H and dZ2 of the row
-                float* dzr = d.DZ2 + (long)row * 24;
-                dzr[c] = dzL, dzr[8 + c] = dzH;            // (dzr[16 + c] = dzI is there already)
+            } else {                                      // a long row: its dW2 term goes to the row's own record
+                float* rec = d.long4 + (long)li * LONG4;
+#pragma unroll
+                for (int t = 0; t < 6; ++t) {
+                    const int idx = g + 4 * t, ch = idx >> 3, cc = idx & 7;
+                    const float zz = g == 0 ? dz[4 * t] : (g == 1 ? dz[4 * t + 1] : (g == 2 ? dz[4 * t + 2] : dz[4 * t + 3]));
+                    float* rp = rec + ch * (F * C8) + (4 * m) * C8 + cc;
+                    rp[0] = zz * o.x, rp[C8] = zz * o.y, rp[2 * C8] = zz * o.z, rp[3 * C8] = zz * o.w;
+                }
             }
             // through dropout(relu(.)): the forward's output is non-zero exactly where both let the element pass
             f4 dmix;
@@ -826,7 +832,7 @@ __global__ __launch_bounds__(64 * WAVES) void small_conv2_bwd_kernel(SmallDev d,
             if (li < 0) {
                 a_dv += r_dv, a_dg += r_dg, a_db += r_db, a_dm += r_dm;
             } else {                                      // the finisher of a long row: its terms go to the row's own record
-                float* rec = d.long4 + (long)li * LONG4;
+                float* rec = d.long4 + (long)li * LONG4 + 3 * F * C8;
                 const f4 zv = zero4();
                 st4(rec + g * F + 4 * m, act ? r_dv : zv), st4(rec + 4 * F + g * F + 4 * m, act ? r_dg : zv);
                 st4(rec + 8 * F + g * F + 4 * m, act ? r_db : zv);
@@ -1012,30 +1018,21 @@ __global__ __launch_bounds__(256) void small_finish_kernel(SmallDev d, int item_
             const long pitch = four ? PART4 : PART3_PITCH;
             const int nw = four ? d.nwg4 : d.nwg3;
             // sixteen loads in flight per thread, added in the order of the producer workgroups
+            // the long rows' own records follow the workgroups' partials as further producers (their finisher varies from
+            // run to run, their place in this sum does not)
+            const float* lsrc = four ? d.long4 + e : d.long3 + q;
+            const long lpitch = four ? LONG4 : PART3_PITCH;
+            const int total = nw + d.n_long;
             constexpr int WL = 256 / RED_EL;
-            for (int w0 = wl; w0 < nw; w0 += 16 * WL) {
+            for (int w0 = wl; w0 < total; w0 += 16 * WL) {
                 float v[16];
 #pragma unroll
                 for (int j = 0; j < 16; ++j) {
                     const int w = w0 + WL * j;
-                    v[j] = w < nw ? src[(long)w * pitch] : 0.f;
+                    v[j] = w < nw ? src[(long)w * pitch] : (w < total ? lsrc[(long)(w - nw) * lpitch] : 0.f);
                 }
 #pragma unroll
                 for (int j = 0; j < 16; ++j) s += v[j];
-            }
-            // ... and the long rows' own records (their finisher varies from run to run, their place in this sum does not):
-            // dW2 terms are formed here from the row's H and dZ2, the others were stored by the finisher
-            const bool w2 = four && e < 3 * F * C8;
-            const int col = (e / C8) % F, idx = (e / (F * C8)) * 8 + e % C8;
-            for (int l0 = wl; l0 < d.n_long; l0 += WL) {
-                float x;
-                if (w2) {
-                    const long r = d.graph.long_rows[l0].row;
-                    x = d.OUT1[r * F + col] * d.DZ2[r * 24 + idx];
-                } else {
-                    x = four ? d.long4[(long)l0 * LONG4 + (e - 3 * F * C8)] : d.long3[(long)l0 * PART3_PITCH + q];
-                }
-                s += x;
             }
         }
         red8[wl][el] = s;
