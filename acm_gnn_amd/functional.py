@@ -518,7 +518,7 @@ def gemm(a, b, trans_a=False, trans_b=False, relu=False, out=None, col_blocks=0,
     """out = op(a) @ op(b) on the fp32 MFMA pipe (acm_gemm).  ``col_blocks=j`` returns the product as a
     contiguous [j, m, n / j] tensor of column blocks (acm_gemm_blocks).  ``a_drop``: an acm_dropout_t applied to the stored
     matrix ``a`` while its tiles are staged (acm_gemm_drop; see gemm_drop_supported)."""
-    a, b = _as_f32c(a, "a"), _as_f32c(b, "b")
+    a, b = _as_f32_rows(a, "a"), _as_f32_rows(b, "b")          # column slices of wider matrices: (pointer, ld), no copy
     m, k = (a.shape[1], a.shape[0]) if trans_a else (a.shape[0], a.shape[1])
     k2, n = (b.shape[1], b.shape[0]) if trans_b else (b.shape[0], b.shape[1])
     if k != k2:
@@ -2069,6 +2069,157 @@ def _backward_agg(ctx, grad_out):
 AcmConvFunction._backward_agg = staticmethod(_backward_agg)
 
 
+# --------------------------------------------------------------------------
+# aggregate-first for WIDE dense inputs (16 < F_in <= 128), round 5
+# --------------------------------------------------------------------------
+AGG_WIDE_MIN_DEGREE = 24          # stored entries of A_low per row from which the wide aggregate-first form is taken
+
+
+def agg_wide_supported(x, ops, cfg, f_in, f_out, post_scale=None, call=None, tail_layer=False):
+    """The first layer of the arXiv-year / pokec class (ACM-Geometric/layers.py:101-104 with 128 / 65 input features, 64
+    hidden): without a ReLU between projection and filter, A (X W) = (A X) W.  P = A_low drop(X) is ONE gather of F_in floats
+    per edge (the literal form gathers 2 F = 128), and because the input takes no gradient the backward needs NO transposed
+    gather at all:  dW_L = P^T G_L,  dW_H = X^T G_H - P^T G_H,  dW_I = X^T G_I  -- three tall-skinny products on the split-bf16
+    matrix pipe.  Three-channel ACM / acmsgc layers on one device; tuning rewrites bit 1 switches it off."""
+    from .graph import FilterOperators
+    if not (tuning.HOST.rewrites & tuning.REWRITE_AGG_FIRST) or not isinstance(ops, FilterOperators):
+        return False
+    if not isinstance(x, torch.Tensor) or x.layout != torch.strided or x.dim() != 2 or x.dtype != _F32 or x.requires_grad:
+        return False
+    if cfg.relu_before or cfg.n_channels != 3 or cfg.gather_bf16 or f_out != 64 or not 16 < f_in <= 128 or x.shape[1] != f_in:
+        return False
+    if ops.sharded or getattr(ops, "general", False) or int(getattr(ops, "hops", 1)) != 1 or x.shape[0] != ops.n_local:
+        return False
+    if x.shape[0] < 8192 or tail_layer:
+        return False
+    # Where it pays (measured, profiles/r05_agg_wide.txt): the rewrite trades 4 F - F_in gathered floats per EDGE for one more
+    # pass over ~3 KB per ROW (the dropped copy of X, the head as its own launch, a third more projection flops).  pokec-shaped
+    # (mean degree 38, F_in 65): 12.1 -> 7.5 ms per step; arXiv-year-shaped (mean degree 15, F_in 128): 0.822 -> 0.832, a wash.
+    return ops.low.nnz >= AGG_WIDE_MIN_DEGREE * x.shape[0]
+
+
+class _AcmAggWide(torch.autograd.Function):
+    """out, att = three-channel ACM layer in the aggregate-first form for a wide dense input (see agg_wide_supported).
+
+    forward : [acm_dropout] -> acm_spmm_ex (P = A_low Xd) -> 2 x acm_gemm ([P W_L | P W_H], [Xd W_H | Xd W_I]) -> acm_conv_fwd over
+              the IDENTITY operator (the fused kernel as a row-local epilogue: pre_L = P W_L, pre_H = Xd W_H - P W_H)
+    backward: acm_conv_bwd_local (K3) -> 2 x acm_gemm TN ([P^T G_L | P^T G_H], [Xd^T G_H | Xd^T G_I])"""
+
+    @staticmethod
+    def forward(ctx, x, w_low, w_high, w_mlp, v_low, v_high, v_mlp, att_mix, lnw_low, lnw_high, lnw_mlp, lnb_low, lnb_high,
+                lnb_mlp, ops, cfg, post_relu, post_scale, post_drop, call, in_drop):
+        lib = _lib.load()
+        ctx.set_materialize_grads(False)
+        call = ctx.call = _call_or_ambient(call)
+        call.next_proj = None                      # (the narrow projection hand-off rides the f_pad <= 16 kernels only)
+        x = _as_f32c(x, "input")
+        dev = x.device
+        n, f_in = x.shape
+        f, k = w_low.shape[1], 3
+        fp = -(-f_in // 4) * 4                     # rows of 16-byte blocks for the gather and the split-bf16 products
+        spec = _drop_spec(in_drop, ops.row_offset) if (in_drop is not None and in_drop[0] > 0) else None
+        if spec is not None:                       # the caller's input dropout, written straight into the padded rows
+            xd = torch.empty(n, fp, dtype=_F32, device=dev)
+            with _device_ctx(dev), _Timed(f"dropout/{n}x{f_in}"):
+                st = lib.acm_dropout(n, f_in, _vp(x), x.stride(0), _vp(xd), xd.stride(0), fp, C.byref(spec), _stream())
+            _lib.check(st, "acm_dropout")
+        else:
+            xd = x if fp == f_in else torch.nn.functional.pad(x, (0, fp - f_in))
+        agg = spmm(ops.low, xd, row_scale=ops.row_scale if ops.implicit else None)          # P = A_low Xd  [n, fp]
+        w3 = [_as_f32c(w, "weight") for w in (w_low, w_high, w_mlp)]
+        pad = (0, 0, 0, fp - f_in)
+        wa = torch.nn.functional.pad(torch.cat((w3[0], w3[1]), 1), pad) if fp != f_in else torch.cat((w3[0], w3[1]), 1)
+        wb = torch.nn.functional.pad(torch.cat((w3[1], w3[2]), 1), pad) if fp != f_in else torch.cat((w3[1], w3[2]), 1)
+        za = gemm(agg, wa)                         # [P W_L | P W_H]
+        zb = gemm(xd, wb)                          # [Xd W_H | Xd W_I]
+        vecs = [_as_f32c(t, "att_vec") for t in (v_low, v_high, v_mlp)]
+        lnw = [_as_f32c(t, "ln") for t in (lnw_low, lnw_high, lnw_mlp)] if cfg.layernorm else []
+        lnb = [_as_f32c(t, "ln") for t in (lnb_low, lnb_high, lnb_mlp)] if cfg.layernorm else []
+        mix = _as_f32c(att_mix, "att_vec")
+        if post_scale is not None:
+            post_scale = _as_f32c(post_scale, "post_scale")
+        ctx.post_relu, ctx.post_scale = bool(post_relu), post_scale
+        ctx.post_drop = post_drop if (post_drop is not None and post_drop[0] > 0) else None
+        out = torch.empty(n, f, dtype=_F32, device=dev)
+        att = torch.empty(n, 4, dtype=_F32, device=dev)
+        pre = torch.empty(n, 2 * f, dtype=_F32, device=dev)
+        p = _lib.ConvFwd()
+        p.f_out, p.n_channels = f, k
+        p.relu_after, p.relu_mlp, p.layernorm = int(cfg.relu_after), int(cfg.relu_mlp), int(cfg.layernorm)
+        p.scale, p.row_offset = cfg.scale, ops.row_offset
+        p.g_low, p.ld_g_low = za.data_ptr(), za.stride(0)                 # "gathered" over I: pre_L = 1 * (P W_L)
+        p.g_high, p.ld_g_high = za.data_ptr() + 4 * f, za.stride(0)       #                    pre_H = Xd W_H - 1 * (P W_H)
+        p.s_high, p.ld_s_high = zb.data_ptr(), zb.stride(0)
+        p.s_mlp, p.ld_s_mlp = zb.data_ptr() + 4 * f, zb.stride(0)
+        p.att_vec = _ptr_array(vecs)
+        p.ln_weight, p.ln_bias = _ptr_array(lnw), _ptr_array(lnb)
+        p.att_mix = mix.data_ptr()
+        p.out, p.ld_out = out.data_ptr(), out.stride(0)
+        p.pre, p.ld_pre = pre.data_ptr(), pre.stride(0)
+        p.att = att.data_ptr()
+        p.post_relu = int(ctx.post_relu)
+        if post_scale is not None:
+            p.post_scale, p.ld_post_scale = post_scale.data_ptr(), post_scale.stride(0)
+        dspec = _drop_spec(ctx.post_drop, ops.row_offset)
+        if dspec is not None:
+            p.post_drop = dspec
+        eye = ops.eye
+        ws = eye.workspace(2 * f)
+        with _device_ctx(dev), _Timed(f"conv_head/F{f}k{k}"):
+            st = lib.acm_conv_fwd(eye.handle, C.byref(p), _vp(ws), ws.numel() * 4, _stream())
+        _lib.check(st, "acm_conv_fwd")
+        ctx.ops, ctx.cfg, ctx.f_in, ctx.fp = ops, cfg, f_in, fp
+        ctx.save_for_backward(xd, agg, zb, pre, mix, *vecs, *lnw, *lnb)
+        ctx.mark_non_differentiable(att)
+        return out, att
+
+    @staticmethod
+    def backward(ctx, grad_out, _grad_att):
+        if grad_out is None:
+            return (None,) * 21
+        lib = _lib.load()
+        ops, cfg, f_in, fp = ctx.ops, ctx.cfg, ctx.f_in, ctx.fp
+        xd, agg, zb, pre, mix, *rest = ctx.saved_tensors
+        k = 3
+        vecs = rest[:k]
+        lnw = rest[k:2 * k] if cfg.layernorm else []
+        lnb = rest[2 * k:3 * k] if cfg.layernorm else []
+        n, dev = xd.shape[0], xd.device
+        f = pre.shape[1] // 2
+        defer = ctx.call.defer
+        grad_out = _as_f32c(grad_out, "grad_out")
+        zi = zb[:, f:]
+        st3 = _k3_setup(cfg, ops, k, f, n, dev, f_in, pre, zi, vecs, lnw, lnb, mix, grad_out, ctx.post_relu, ctx.post_scale,
+                        ctx.post_drop)
+        q, flat, nw = st3["q"], st3["flat"], st3["nw"]
+        # K3 writes [G_L | G_H | G_I] side by side, UNSCALED (the filter was applied before the projection: nothing is
+        # gathered over the transposed operator here)
+        gcat = torch.empty(n, 3 * f, dtype=_F32, device=dev)
+        q.g_scale = None
+        q.g_low, q.ld_g_low = gcat.data_ptr(), gcat.stride(0)
+        q.g_high, q.ld_g_high = gcat.data_ptr() + 4 * f, gcat.stride(0)
+        q.g_mlp, q.ld_g_mlp = gcat.data_ptr() + 8 * f, gcat.stride(0)
+        d_vec, d_lnw, d_lnb, d_mix = _flat_views(flat, nw, k, f, cfg.layernorm)
+        nbytes = C.c_size_t()
+        _lib.check(lib.acm_conv_bwd_local_workspace_bytes(n, f, k, C.byref(nbytes)))
+        ws = torch.empty(max(nbytes.value // 4, 1), dtype=_F32, device=dev)
+        q.defer = defer.pointer() if defer is not None else None
+        with _device_ctx(dev), _Timed(f"conv_bwd_local/F{f}k{k}"):
+            st = lib.acm_conv_bwd_local(n, C.byref(q), _vp(ws), ws.numel() * 4, _stream())
+        _lib.check(st, "acm_conv_bwd_local")
+        if defer is not None:
+            defer.hold(ws, [d_mix, *d_vec, *d_lnw, *d_lnb], keep=[flat])
+        del st3
+        a1 = gemm(agg, gcat[:, : 2 * f], trans_a=True, col_blocks=2)          # [P^T G_L | P^T G_H]   as [2, fp, f]
+        a2 = gemm(xd, gcat[:, f:], trans_a=True, col_blocks=2)                # [Xd^T G_H | Xd^T G_I]
+        d_wl = a1[0][:f_in]
+        d_wh = (a2[0] - a1[1])[:f_in]
+        d_wm = a2[1][:f_in]
+        none3 = [None] * 3
+        return (None, d_wl, d_wh, d_wm, d_vec[0], d_vec[1], d_vec[2], d_mix,
+                *(d_lnw if cfg.layernorm else none3), *(d_lnb if cfg.layernorm else none3), None, None, None, None, None, None, None)
+
+
 def in_drop_supported(x, ops, cfg, f_in, f_out):
     """Whether a layer can take its caller's input dropout into its dense projection (AcmConvFunction ``in_drop``): the
     literal form on the MFMA GEMM (not aggregate-first, not the narrow streaming projection, not CSR features), an input
@@ -2094,6 +2245,11 @@ def acm_conv(x, params, ops, cfg, post_relu=False, post_scale=None, post_drop=No
     dropout with the mask generated in registers (acm_dropout_t) instead of read from a tensor.
     call / tail_layer / agg_holder: see AcmConvFunction.forward."""
     p = params
+    if agg_wide_supported(x, ops, cfg, p["weight_low"].shape[0], p["weight_low"].shape[1], post_scale, call, tail_layer):
+        return _AcmAggWide.apply(x, p["weight_low"], p["weight_high"], p["weight_mlp"], p["att_vec_low"], p["att_vec_high"],
+                                 p["att_vec_mlp"], p["att_vec"], p["layer_norm_low.weight"], p["layer_norm_high.weight"],
+                                 p["layer_norm_mlp.weight"], p["layer_norm_low.bias"], p["layer_norm_high.bias"],
+                                 p["layer_norm_mlp.bias"], ops, cfg, post_relu, post_scale, post_drop, call, in_drop)
     return AcmConvFunction.apply(
         x, p["weight_low"], p["weight_high"], p["weight_mlp"], p["att_vec_low"], p["att_vec_high"],
         p["att_vec_mlp"], p["att_struc_low"], p["struc_low"], p["att_vec"],

@@ -124,9 +124,12 @@ class GCN(nn.Module):
                 x = call.pipe.local_table()
                 if ops.sharded:
                     ops._pregathered = (x, call.pipe.table())
-            elif ops is not None and ops.sharded and ops.uniform and ops.x_full is not None:
+            elif ops is not None and ops.sharded and ops.uniform and ops.x_full is not None and nfeat <= 16:
+                # (a first layer that GATHERS its input -- aggregate-first, F_in <= 16 -- needs every node's dropped row)
                 # the mask is a function of the global position: drop the replicated full input locally instead of
-                # all-gathering the dropped row blocks (equal blocks only: there the halo numbering is the global one)
+                # all-gathering the dropped row blocks (equal blocks only: there the halo numbering is the global one).
+                # A wider input is projected first, from the rank's OWN rows: those alone are dropped below (round 5: the
+                # Penn94-shaped rank of an 8-rank plan spent 439 of its 640 us dropping the other ranks' 4 814-wide rows)
                 xg = AF.dropout(ops.x_full, p, st, tag=0, pad_to=pad, row_offset=0)
                 x = xg[off:off + x.shape[0]]
                 ops._pregathered = (x, xg)

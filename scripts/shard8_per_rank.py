@@ -11,6 +11,11 @@ and no other process shares the GPU while a rank is measured.  (Two ranks on one
 checked for RESULTS in tests/test_gpu_sharded.py; RCCL itself needs N devices.)
 
     python scripts/shard8_per_rank.py [--world 8] [--steps 5] > gpurun_out/r04_shard8_per_rank.json
+
+Round 5: ``--dataset arxiv-year|penn94 --method acmsgc --hops 3`` measures BASELINE config 5 (3-hop
+ACM-SGC on the arXiv-year / Penn94 shapes: one linear ACM layer whose low channel goes through A_low three times -- three
+halo exchanges forward, three backward), ``--dataset pokec`` the pokec-shaped graph (1.63 M nodes: the size at which a
+rank's gathered table -- the FULL all-gathered halo -- no longer fits the Infinity Cache); ``--world`` takes a list.
 """
 import argparse
 import json
@@ -63,15 +68,38 @@ def install_stand_ins():
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--world", type=int, default=8)
+    ap.add_argument("--world", default="8", help="ranks of the plan; a comma-separated list measures every N (one JSON line each)")
+    ap.add_argument("--method", default="acmgcnp")
+    ap.add_argument("--hops", type=int, default=1)
+    ap.add_argument("--dropout", type=float, default=0.1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--dataset", default="twitch-gamer")
     ap.add_argument("--ranks", default="", help="comma-separated ranks to measure (default: all)")
     args = ap.parse_args()
     dev = torch.device("cuda", 0)
     install_stand_ins()
-    world = args.world
-    wl = D.bench_workload(args.dataset, seed=0, node_order="degree", pad_to=world)
+    for world in [int(w) for w in str(args.world).split(",")]:
+        measure(args, world, dev)
+
+
+def pokec_workload(world):
+    """The pokec-shaped graph of scripts/bench_scale.py (1 632 803 nodes, 30.6 M edges, 65 features, 2 classes), padded to
+    a multiple of `world` rows, in degree order."""
+    import scipy.sparse as sp
+    n, m, max_deg, f_in, classes = 1_632_803, 30_622_564, 14_854, 65, 2
+    n += (-n) % world
+    adj = D.chung_lu_graph(n, m, max_deg, seed=0)
+    rng = np.random.default_rng(0)
+    x = rng.standard_normal((n, f_in), dtype=np.float32)
+    y = rng.integers(0, classes, n)
+    tr = np.sort(rng.permutation(n)[: n // 2])
+    perm = D.degree_order(adj)
+    adj, x, y, (tr, va, te) = D.permute_dataset(adj, x, y, (tr, tr, tr), perm)
+    return {"adj": adj, "x": x, "y": y, "splits": (tr, va, te)}
+
+
+def measure(args, world, dev):
+    wl = pokec_workload(world) if args.dataset == "pokec" else D.bench_workload(args.dataset, seed=0, node_order="degree", pad_to=world)
     adj, x_np, y_np, (tr, va, te) = wl["adj"], wl["x"], wl["y"], wl["splits"]
     n = adj.shape[0]
     adj, x_np, y_np, (tr, va, te) = D.permute_dataset(adj, x_np, y_np, (tr, va, te), DD.interleave_order(n, world))
@@ -93,7 +121,8 @@ def main():
         y = torch.from_numpy(np.ascontiguousarray(y_np[b:e])).to(dev)
         tr_loc = torch.from_numpy(DD.local_index(tr, plan, rank)).to(dev)
         torch.manual_seed(0)
-        model = acm_gnn_amd.GCN(x.shape[1], 64, int(y_np.max()) + 1, 2, e - b, 0.1, "acmgcnp", 0, variant=False,
+        ops.hops = args.hops
+        model = acm_gnn_amd.GCN(x.shape[1], 64, int(y_np.max()) + 1, 2, e - b, args.dropout, args.method, 0, variant=False,
                                 attn_layernorm=True).to(dev)
         opt = acm_gnn_amd.FusedAdamW(model.parameters(), lr=0.05, weight_decay=1e-3)
         w = T.row_weights(tr_loc, e - b, n_train_total=len(tr), device=dev)
@@ -130,13 +159,14 @@ def main():
         del step, gstep, model, opt, ops, x, y, w
         torch.cuda.empty_cache()
     ks = [r["kernels_ms_per_step"] for r in per_rank]
-    print(json.dumps({"workload": f"{args.dataset}-shaped graph, {n} nodes, nnz(A_low) {low.nnz}; ACM-GCN+ 2 layers, hidden 64, "
-                                  "dropout 0.1 (counter-based), AdamW (fused)",
+    print(json.dumps({"workload": f"{args.dataset}-shaped graph, {n} nodes, nnz(A_low) {low.nnz}; {args.method}"
+                                  + (f" {args.hops}-hop" if args.hops > 1 else "") + f", hidden 64, dropout {args.dropout} "
+                                  "(counter-based), AdamW (fused)",
                       "world": world, "plan": "degree ranking dealt to the ranks like cards, equal blocks, replicated static input",
                       "method": "each rank's step run alone on one MI355X, collectives replaced by local stand-ins of the same "
                                 "shapes (scripts/shard8_per_rank.py)",
                       "kernels_ms_per_step": {"min": min(ks), "max": max(ks), "mean": round(float(np.mean(ks)), 4)},
-                      "per_rank": per_rank}, indent=1))
+                      "per_rank": per_rank}), flush=True)
 
 
 if __name__ == "__main__":

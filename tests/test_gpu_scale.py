@@ -254,3 +254,68 @@ def test_rows_times_pitch_beyond_2_31_takes_the_64_bit_kernels_or_fails_loudly()
             assert rc == 4 and b"2^31" in lib.acm_last_error(), (rc, lib.acm_last_error())
         else:
             assert rc == 0 and torch.isfinite(gl).all() and torch.isfinite(flat).all(), lib.acm_last_error()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("model_type,f_in,p_drop,ln", [("acmgcnp", 128, 0.3, True), ("acmgcn", 65, 0.0, False), ("acmgcnp", 40, 0.2, True)])
+def test_aggregate_first_for_wide_inputs_matches_the_literal_form_and_the_oracle(model_type, f_in, p_drop, ln, tune):
+    """functional._AcmAggWide (round 5): first layers with 16 < F_in <= 128 dense features (arXiv-year 128, pokec 65) gather
+    P = A_low drop(X) once and run no transposed gather in the backward.  Logits, loss and every gradient against the literal
+    form (tuning rewrites bit 1 off) at fp32 re-association level, and the logits against the oracle on sampled rows."""
+    import scipy.sparse as sp
+    from acm_gnn_amd import GCN, data as D, functional as AF, train as T
+    from acm_gnn_amd.distributed import make_sharded_operators
+    from oracle import acm_oracle as O
+    n = 30000
+    rng = np.random.default_rng(5)
+    m = n * 18                                       # mean degree ~36: the form is taken from 24 on
+    r, c = rng.integers(0, n, m), rng.integers(0, n, m)
+    adj = sp.csr_matrix((np.ones(m, np.float32), (r, c)), shape=(n, n))
+    adj = ((adj + adj.T) > 0).astype(np.float32).tocsr()
+    adj.setdiag(0)
+    adj.eliminate_zeros()
+    low, deg = D.build_filters(adj)
+    ops = make_sharded_operators(low, deg, torch.device(DEV))
+    x = torch.randn(n, f_in, generator=torch.Generator().manual_seed(1)).to(DEV)
+    y = torch.randint(0, 4, (n,), generator=torch.Generator().manual_seed(2)).to(DEV)
+    w = T.row_weights(torch.arange(0, n, 2, device=DEV), n)
+
+    def run(agg):
+        tune(agg_first=int(agg))
+        torch.manual_seed(3)
+        model = GCN(f_in, 64, 4, 2, n, p_drop, model_type, 0, variant=False, attn_layernorm=ln).to(DEV)
+        model.train()
+        if p_drop > 0:
+            model.fused_dropout, model.dropout_state = True, AF.DropoutState(torch.device(DEV), seed=7)
+        timer = AF.KernelTimer()
+        AF.set_kernel_timer(timer)
+        out = model(x, ops)
+        loss = AF.masked_nll(out, y, w)
+        loss.backward()
+        AF.set_kernel_timer(None)
+        labels = set(timer.summary())
+        return model, out.detach(), float(loss), {k: p.grad.clone() for k, p in model.named_parameters() if p.grad is not None}, labels
+
+    ma, out_a, loss_a, g_a, lab_a = run(True)
+    mb, out_b, loss_b, g_b, lab_b = run(False)
+    assert any(k.startswith("conv_head/") for k in lab_a) and not any(k.startswith("conv_head/") for k in lab_b)
+    assert sum(k.startswith("conv_bwd_spmm/") for k in lab_a) == 1 and sum(k.startswith("conv_bwd_spmm/") for k in lab_b) == 2
+    scale = float(out_b.abs().max())
+    assert float((out_a - out_b).abs().max()) <= 2e-5 * scale + 1e-6
+    np.testing.assert_allclose(loss_a, loss_b, rtol=2e-5)
+    assert g_a.keys() == g_b.keys()
+    for k in g_a:
+        tol = 2e-4 * float(g_b[k].abs().max()) + 1e-8
+        assert float((g_a[k] - g_b[k]).abs().max()) <= tol, k
+    if p_drop == 0:                                  # eval-mode logits against the oracle (CPU, CSR operands) on sampled rows
+        ma.eval()
+        with torch.no_grad():
+            got = ma(x, ops).cpu()
+        params = {k: v.detach().cpu() for k, v in ma.state_dict().items() if k.startswith("gcns.")}
+        lo = torch.sparse_csr_tensor(torch.from_numpy(low.indptr.astype(np.int64)), torch.from_numpy(low.indices.astype(np.int64)),
+                                     torch.from_numpy(low.data.astype(np.float32)), size=low.shape)
+        hi_sp = (sp.identity(n, format="csr") - low).tocsr()
+        hi = torch.sparse_csr_tensor(torch.from_numpy(hi_sp.indptr.astype(np.int64)), torch.from_numpy(hi_sp.indices.astype(np.int64)),
+                                     torch.from_numpy(hi_sp.data.astype(np.float32)), size=low.shape)
+        ref = O.gcn_forward(params, x.cpu(), lo, hi, None, model_type=model_type, variant=False, structure_info=0, attn_layernorm=ln)
+        assert float((got - ref).abs().max()) <= 1e-4 * float(ref.abs().max()) + 1e-5

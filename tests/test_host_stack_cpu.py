@@ -1124,6 +1124,7 @@ def test_input_dropout_rides_the_dense_projection(monkeypatch, model_type, hops,
         monkeypatch.setattr(fake, name, (lambda o, nm: lambda *a: (calls.append(nm), o(*a))[1])(orig, name))
 
     def run(fused):
+        tune(agg_first=0)                              # the LITERAL form (round 5: aggregate-first takes 16 < F_in <= 128 by default)
         if not fused:
             tune(gemm_forms=6)                         # no row-panel kernels: no dropout in the operand loads either
         calls.clear()
@@ -1436,3 +1437,41 @@ def test_small_graph_step_host_path_equals_the_general_path(model_type, s, varia
     m4 = GCN(50, 64, 3, 2, n, 0.0, "acmgcnpp", 0)
     assert "model_type" in SmallPlan.why_not(m4, xs, ops)
     assert "optimizer" in SmallPlan.why_not(ma, xs, ops, torch.optim.Adam(ma.parameters()))
+
+
+@pytest.mark.parametrize("model_type,f_in,p_drop,ln", [("acmgcnp", 128, 0.4, True), ("acmgcn", 65, 0.0, False), ("acmgcnp", 40, 0.3, True)])
+def test_aggregate_first_for_wide_dense_inputs_equals_the_literal_form(model_type, f_in, p_drop, ln, monkeypatch, tune):
+    """Round 5 (functional._AcmAggWide): a first layer with 16 < F_in <= 128 dense features, no ReLU before the filter and an
+    input that takes no gradient gathers P = A_low drop(X) once (F_in floats per edge instead of 2 F) and needs NO transposed
+    gather in its backward: dW_L = P^T G_L, dW_H = X^T G_H - P^T G_H, dW_I = X^T G_I.  Same logits and gradients as the
+    literal project-then-gather form (tuning rewrites bit 1 off); F_in that is no multiple of 4 is padded (pokec: 65)."""
+    fake = fake_lib.install(monkeypatch)
+    from acm_gnn_amd import GCN, functional as AF
+    ops, n = _dense_graph_ops(n=8192, avg=30, seed=3)          # (the form is taken from a mean degree of 24 on)
+    x = torch.randn(n, f_in, generator=torch.Generator().manual_seed(2))
+    calls = []
+    for name in ("acm_conv_bwd_spmm", "acm_spmm_ex", "acm_spmm"):
+        orig = getattr(fake, name)
+        monkeypatch.setattr(fake, name, (lambda o, nm: lambda *a: (calls.append(nm), o(*a))[1])(orig, name))
+
+    def run(agg):
+        tune(agg_first=int(agg))
+        calls.clear()
+        torch.manual_seed(4)
+        model = GCN(f_in, 64, 3, 2, n, p_drop, model_type, 0, variant=0, attn_layernorm=ln)
+        model.train()
+        if p_drop > 0:
+            model.fused_dropout, model.dropout_state = True, AF.DropoutState(torch.device("cpu"), seed=11)
+        out = model(x, ops)
+        out.square().sum().backward()
+        return out.detach(), {k: p.grad.clone() for k, p in model.named_parameters() if p.grad is not None}, list(calls)
+
+    out_a, g_a, calls_a = run(True)
+    out_b, g_b, calls_b = run(False)
+    # one gather forward for the first layer, none backward (the output layer keeps its two)
+    assert calls_a.count("acm_conv_bwd_spmm") == 1 and calls_b.count("acm_conv_bwd_spmm") == 2, (calls_a, calls_b)
+    assert len([c for c in calls_a if c.startswith("acm_spmm")]) == 1
+    torch.testing.assert_close(out_a, out_b, rtol=1e-5, atol=1e-5 * float(out_b.abs().max()))
+    assert g_a.keys() == g_b.keys()
+    for k in g_a:
+        torch.testing.assert_close(g_a[k], g_b[k], rtol=1e-4, atol=1e-5 * float(g_b[k].abs().max()), msg=lambda m, k=k: f"{k}: {m}")
