@@ -291,6 +291,26 @@ def test_bf16_gathered_operands_keep_the_accuracy(name):
         a32, a16 = np.asarray(runs["fp32"][s][2]), np.asarray(runs["bf16"][s][2])
         m = min(len(a32), len(a16))
         half.append(float(a16[m // 2:m].mean() - a32[m // 2:m].mean()))
+    # anatomy of the selection: the selected accuracy is the test accuracy at the arg-min of the
+    # validation loss.  Storing the gathered operands in bf16 perturbs the validation-loss curve by delta = max_e |v16 - v32|;
+    # the arg-min of the perturbed curve then lies anywhere on the fp32 curve's 2-delta plateau (v32[e16] <= v16[e16] + delta
+    # <= v16[e32] + delta <= v32[e32] + 2 delta), and the selected accuracy anywhere in the range of test accuracies over
+    # that plateau (+ the difference of the two test-accuracy curves there).
+    anatomy = []
+    for s in todo:
+        v32, a32 = np.asarray(runs["fp32"][s][1]), np.asarray(runs["fp32"][s][2])
+        v16, a16 = np.asarray(runs["bf16"][s][1]), np.asarray(runs["bf16"][s][2])
+        m = min(len(v32), len(v16))
+        e32, e16 = int(np.argmin(v32)), int(np.argmin(v16))
+        delta = float(np.abs(v16[:m] - v32[:m]).max())
+        plateau = np.nonzero(v32[:m] <= v32.min() + 2 * delta)[0]
+        anatomy.append({"split": int(s), "epochs_fp32": len(v32), "epochs_bf16": len(v16), "argmin_fp32": e32, "argmin_bf16": e16,
+                        "val_min_fp32": float(v32.min()), "val_min_bf16": float(v16.min()), "max_val_curve_diff": delta,
+                        "plateau_epochs": int(len(plateau)), "plateau_first_last": [int(plateau.min()), int(plateau.max())],
+                        "fp32_test_acc_over_plateau_pp": [float(100 * a32[plateau].min()), float(100 * a32[plateau].max())],
+                        "test_acc_pp": {"fp32@fp32": float(100 * a32[e32]), "bf16@fp32": float(100 * a16[min(e32, len(a16) - 1)]),
+                                        "fp32@bf16": float(100 * a32[min(e16, len(a32) - 1)]), "bf16@bf16": float(100 * a16[e16])},
+                        "max_test_curve_diff_on_plateau_pp": float(100 * np.abs(a16[plateau] - a32[plateau]).max())})
     band = _reference_band(name, todo)
     bound = max(0.002, band[0]) if band is not None else 0.004
     print(f"\n{name}: fp32 {100 * sel['fp32'].mean():.2f} % | bf16 {100 * sel['bf16'].mean():.2f} % | selected, per split "
@@ -301,7 +321,9 @@ def test_bf16_gathered_operands_keep_the_accuracy(name):
         import json
         json.dump({"fp32_selected": sel["fp32"].tolist(), "bf16_selected": sel["bf16"].tolist(),
                    "selected_mean_diff_pp": float(100 * (sel["bf16"].mean() - sel["fp32"].mean())),
-                   "curve_second_half_diff_pp": (100 * np.asarray(half)).tolist(), "selected_bound_pp": 100 * bound}, fh)
+                   "curve_second_half_diff_pp": (100 * np.asarray(half)).tolist(), "selected_bound_pp": 100 * bound,
+                   "at_fp32_epoch_diff_pp": [a["test_acc_pp"]["bf16@fp32"] - a["test_acc_pp"]["fp32@fp32"] for a in anatomy],
+                   "selection_anatomy": anatomy}, fh, indent=1)
     # the curves agree; the SELECTED accuracy must not be lower by more than the bound (measured: Film ACMII-GCN+ selects
     # +0.44 pp HIGHER under bf16 -- per split -0.13 ... +1.18 pp, the arg-min of a flat validation loss landing elsewhere --
     # with the curves 0.06 pp apart; Squirrel see the printed line); a two-sided sanity bound of 0.8 pp on top
