@@ -70,6 +70,7 @@ struct SmallDev {
     float *att1, *att2;
     // workspace
     float *Z1, *H1, *ST1, *OUT1, *T2, *Z2I, *G2, *DZ2, *G1, *DZ1, *slots, *part3, *part4, *W2T, *FACT;
+    int64_t* latch;                  // the dropout counter as launch 1 found it: what launches 2-6 draw their masks with
     float *long3, *long4;            // [n_long][PART3_PITCH] / [n_long][LONG4]: the parameter-gradient terms of the long rows
     int n_long;
     const float* xt_vals;
@@ -319,6 +320,9 @@ __device__ __forceinline__ void write_tables(const SmallDev& d) {
         const SmallTensor& t = d.t[threadIdx.x / ACM_SMALL_ROLES][threadIdx.x % ACM_SMALL_ROLES];
         if (t.p && t.step) acm_adam_step_factors(d.hp, t.step[0], d.FACT[2 * threadIdx.x], d.FACT[2 * threadIdx.x + 1]);
     }
+    // the dropout counter of THIS step: the later launches draw their masks with this copy, so the last launch may advance
+    // the live counter whenever it likes (no arrival barrier over its ~900 blocks: their atomics on one address were 10 us)
+    if (threadIdx.x == 0) d.latch[0] = d.drop_hidden.step ? d.drop_hidden.step[0] : (d.drop_in.step ? d.drop_in.step[0] : 0);
 }
 
 // ------------------------------------------------------------------------------------------------ launch 1: Z1 = drop(X) Wcat
@@ -942,7 +946,6 @@ __global__ __launch_bounds__(64 * WAVES) void small_conv1_bwd_kernel(SmallDev d,
 // step counters.
 __global__ __launch_bounds__(256) void small_finish_kernel(SmallDev d, int item_blocks, int red_blocks) {
     __shared__ float red8[256 / RED_EL][RED_EL];
-    __shared__ int s_last;
     const float* __restrict__ fact = d.FACT;              // step factors of every tensor (launch 1 wrote them)
     const AdamFactors af(d.hp);
     auto apply = [&](int layer, int role, long i, float gsum) {
@@ -1027,12 +1030,13 @@ __global__ __launch_bounds__(256) void small_finish_kernel(SmallDev d, int item_
             for (int w0 = wl; w0 < total; w0 += 16 * WL) {
                 float v[16];
 #pragma unroll
-                for (int j = 0; j < 16; ++j) {
-                    const int w = w0 + WL * j;
-                    v[j] = w < nw ? src[(long)w * pitch] : (w < total ? lsrc[(long)(w - nw) * lpitch] : 0.f);
+                for (int j = 0; j < 16; ++j) {             // unconditional loads (a guarded load is waited for before the next)
+                    const int w = min(w0 + WL * j, total - 1);
+                    const float* pw = w < nw ? src + (long)w * pitch : lsrc + (long)(w - nw) * lpitch;
+                    v[j] = *pw;
                 }
 #pragma unroll
-                for (int j = 0; j < 16; ++j) s += v[j];
+                for (int j = 0; j < 16; ++j) s += (w0 + WL * j < total) ? v[j] : 0.f;
             }
         }
         red8[wl][el] = s;
@@ -1077,15 +1081,9 @@ __global__ __launch_bounds__(256) void small_finish_kernel(SmallDev d, int item_
             t.p[j] = pp, t.m[j] = mm, t.v[j] = vv;
         }
     }
-    // every block has read the step counters it needs: the last one to arrive advances them
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        const int ticket = atomicAdd(d.arrive, 1);
-        s_last = ticket == (int)gridDim.x - 1;
-        if (s_last) atomicExch(d.arrive, 0);
-    }
-    __syncthreads();
-    if (s_last && d.update) {
+    // nothing in this launch reads a step counter (launch 1 left the factors and the dropout counter of the step in the
+    // workspace): the first block advances them
+    if (blk == 0 && d.update) {
         if ((int)threadIdx.x < 2 * ACM_SMALL_ROLES) {
             const SmallTensor& t = d.t[threadIdx.x / ACM_SMALL_ROLES][threadIdx.x % ACM_SMALL_ROLES];
             if (t.p && t.step) {
@@ -1113,7 +1111,7 @@ ItemView view_of(const acm_csr* a) {
 }
 
 struct Layout {
-    size_t Z1, H1, ST1, OUT1, T2, Z2I, G2, DZ2, G1, DZ1, slots, part3, part4, W2T, FACT, long3, long4, counters, total;
+    size_t Z1, H1, ST1, OUT1, T2, Z2I, G2, DZ2, G1, DZ1, slots, part3, part4, W2T, FACT, latch, long3, long4, counters, total;
 };
 
 Layout layout_of(const acm_csr* a, const acm_csr* x, const acm_csr* xt) {
@@ -1135,7 +1133,7 @@ Layout layout_of(const acm_csr* a, const acm_csr* x, const acm_csr* xt) {
     L.slots = take((n_slots + 1) * 192);
     const size_t wg = (size_t)std::min<int64_t>(MAX_WG, (a->n_items + WAVES - 1) / WAVES);      // = the gather phases' grid
     L.part3 = take(wg * PART3_PITCH), L.part4 = take(wg * PART4);
-    L.W2T = take(3 * F * C8), L.FACT = take(2 * ACM_SMALL_ROLES * 2);
+    L.W2T = take(3 * F * C8), L.FACT = take(2 * ACM_SMALL_ROLES * 2), L.latch = take(4);
     L.long3 = take((size_t)a->n_long * PART3_PITCH + 64), L.long4 = take((size_t)a->n_long * LONG4 + 64);
     L.counters = take(n_long + 64);
     L.total = o * sizeof(float);
@@ -1167,7 +1165,7 @@ extern "C" int acm_small_step(const acm_csr_t* a, const acm_csr_t* x, const acm_
     const int all = p->train ? 63 : 7;
     const int phases = p->phases ? (p->phases & all) : all;
     if (p->train) {
-        ACM_REQUIRE(p->labels && p->row_weight && p->loss && p->arrive, ACM_EINVAL, "acm_small_step: labels / row_weight / loss / arrive");
+        ACM_REQUIRE(p->labels && p->row_weight && p->loss, ACM_EINVAL, "acm_small_step: labels / row_weight / loss");
         ACM_REQUIRE(dense || !(phases & 32) || (xt && p->xt_src_pos && xt->n_rows == p->f_in && xt->n_cols == a->n_rows), ACM_EINVAL,
                     "acm_small_step: the transposed feature handle (x_t, xt_src_pos) is needed for dW1");
         ACM_REQUIRE(!dense || p->w1_grad_given || !(phases & 32) || !p->update, ACM_EINVAL,
@@ -1210,6 +1208,7 @@ extern "C" int acm_small_step(const acm_csr_t* a, const acm_csr_t* x, const acm_
     d.slots = ws + L.slots, d.part3 = ws + L.part3, d.part4 = ws + L.part4, d.W2T = ws + L.W2T, d.FACT = ws + L.FACT;
     d.xt_vals = p->xt_vals;
     d.long3 = ws + L.long3, d.long4 = ws + L.long4, d.n_long = (int)a->n_long;
+    d.latch = reinterpret_cast<int64_t*>(ws + L.latch);
     d.counters = (int*)(ws + L.counters);
     d.w1_grad_given = p->w1_grad_given;
     d.drop_in = p->drop_in, d.drop_hidden = p->drop_hidden;
@@ -1217,15 +1216,18 @@ extern "C" int acm_small_step(const acm_csr_t* a, const acm_csr_t* x, const acm_
     d.also_advance = p->also_advance, d.arrive = p->arrive;
     const float* z1 = dense ? p->z1_given : d.Z1;
     hipStream_t s = (hipStream_t)stream;
+    SmallDev d1 = d;                               // launch 1 reads the live dropout counter and latches it for the others
+    if (d.drop_in.p > 0.f) d.drop_in.step = d.latch;
+    if (d.drop_hidden.p > 0.f) d.drop_hidden.step = d.latch;
     const int graph_wg = (int)std::min<int64_t>(MAX_WG, (a->n_items + WAVES - 1) / WAVES);
     d.nwg3 = d.nwg4 = graph_wg;
     const bool four = K == 4, variant = p->relu_before != 0;
     if (phases & 1) {
         if (!dense) {
             const int wg = (int)std::min<int64_t>(2 * MAX_WG, (x->n_items + 3) / 4);
-            hipLaunchKernelGGL(small_proj1_kernel, dim3(std::max(wg, 1)), dim3(256), 0, s, d);
+            hipLaunchKernelGGL(small_proj1_kernel, dim3(std::max(wg, 1)), dim3(256), 0, s, d1);
         } else {
-            hipLaunchKernelGGL(small_struc_copy_kernel, dim3((d.n * C8 + 255) / 256), dim3(256), 0, s, d);
+            hipLaunchKernelGGL(small_struc_copy_kernel, dim3((d.n * C8 + 255) / 256), dim3(256), 0, s, d1);
         }
     }
     if (phases & 2) {

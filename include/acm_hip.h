@@ -939,7 +939,7 @@ typedef struct {
     double  lr, beta1, beta2, eps, weight_decay;
     int32_t decoupled;
     int64_t* also_advance;      /* optional device counter incremented with the step counters (dropout step)         */
-    int32_t* arrive;            /* device int32, zero between calls                                                  */
+    int32_t* arrive;            /* reserved (not read: the last launch needs no arrival barrier)                     */
     void*   workspace;          /* acm_small_step_workspace_bytes; ZERO-FILLED by the caller once, kept between calls */
     size_t  workspace_bytes;
 } acm_small_step_t;
