@@ -31,8 +31,10 @@ typedef float f4 __attribute__((ext_vector_type(4)));
 constexpr int F = 64;                 // hidden width
 constexpr int C8 = 8;                 // padded class count
 constexpr int WAVES = 8;              // per workgroup of the gather phases (two per SIMD: the second hides the first's latency chain)
-constexpr int MAX_WG = 2048;          // workgroups of a gather phase: one work item per wave up to 16384 items (a wave's item is a
-                                      // latency chain of ~2 000 dependent instructions; more waves, not longer loops, hide it)
+constexpr int MAX_WG = 512;           // workgroups of the phases that leave per-workgroup partial sums (launches 3, 4): beyond that a
+                                      // wave loops over work items (Squirrel: 875 -> 512 workgroups, launch 4 56 -> 47 us)
+constexpr int MAX_WG_WIDE = 2048;     // ... of the wide gather phases (launches 2, 5): one work item per wave up to 16384 items (a
+                                      // wave's item is a chain of ~2 000 dependent instructions; more waves, not longer loops, hide it)
 constexpr int RED_EL = 8;             // elements of the partial-sum vectors per reducing block of the last launch (x 32 producer lanes)
 constexpr int PART4 = 3 * F * C8 + 3 * 4 * F + 16;      // dW2 [3][64][8] | dv1 [4][64] | dgamma1 | dbeta1 | dmix1 [4][4]
 constexpr int PART3 = 3 * 4 * C8 + 16 + 1;              // dv2 [4][8] | dgamma2 | dbeta2 | dmix2 | loss
@@ -1220,6 +1222,7 @@ extern "C" int acm_small_step(const acm_csr_t* a, const acm_csr_t* x, const acm_
     if (d.drop_in.p > 0.f) d.drop_in.step = d.latch;
     if (d.drop_hidden.p > 0.f) d.drop_hidden.step = d.latch;
     const int graph_wg = (int)std::min<int64_t>(MAX_WG, (a->n_items + WAVES - 1) / WAVES);
+    const int wide_wg = (int)std::min<int64_t>(MAX_WG_WIDE, (a->n_items + WAVES - 1) / WAVES);
     d.nwg3 = d.nwg4 = graph_wg;
     const bool four = K == 4, variant = p->relu_before != 0;
     if (phases & 1) {
@@ -1231,10 +1234,10 @@ extern "C" int acm_small_step(const acm_csr_t* a, const acm_csr_t* x, const acm_
         }
     }
     if (phases & 2) {
-        if (four && variant) hipLaunchKernelGGL((small_conv1_fwd_kernel<true, true>), dim3(graph_wg), dim3(64 * WAVES), 0, s, d, z1);
-        else if (four) hipLaunchKernelGGL((small_conv1_fwd_kernel<true, false>), dim3(graph_wg), dim3(64 * WAVES), 0, s, d, z1);
-        else if (variant) hipLaunchKernelGGL((small_conv1_fwd_kernel<false, true>), dim3(graph_wg), dim3(64 * WAVES), 0, s, d, z1);
-        else hipLaunchKernelGGL((small_conv1_fwd_kernel<false, false>), dim3(graph_wg), dim3(64 * WAVES), 0, s, d, z1);
+        if (four && variant) hipLaunchKernelGGL((small_conv1_fwd_kernel<true, true>), dim3(wide_wg), dim3(64 * WAVES), 0, s, d, z1);
+        else if (four) hipLaunchKernelGGL((small_conv1_fwd_kernel<true, false>), dim3(wide_wg), dim3(64 * WAVES), 0, s, d, z1);
+        else if (variant) hipLaunchKernelGGL((small_conv1_fwd_kernel<false, true>), dim3(wide_wg), dim3(64 * WAVES), 0, s, d, z1);
+        else hipLaunchKernelGGL((small_conv1_fwd_kernel<false, false>), dim3(wide_wg), dim3(64 * WAVES), 0, s, d, z1);
     }
     if (phases & 4) {
         if (four) hipLaunchKernelGGL(small_conv2_fwd_kernel<true>, dim3(graph_wg), dim3(64 * WAVES), 0, s, d);
@@ -1245,10 +1248,10 @@ extern "C" int acm_small_step(const acm_csr_t* a, const acm_csr_t* x, const acm_
         else hipLaunchKernelGGL(small_conv2_bwd_kernel<false>, dim3(graph_wg), dim3(64 * WAVES), 0, s, d, z1);
     }
     if (phases & 16) {
-        if (four && variant) hipLaunchKernelGGL((small_conv1_bwd_kernel<true, true>), dim3(graph_wg), dim3(64 * WAVES), 0, s, d, z1);
-        else if (four) hipLaunchKernelGGL((small_conv1_bwd_kernel<true, false>), dim3(graph_wg), dim3(64 * WAVES), 0, s, d, z1);
-        else if (variant) hipLaunchKernelGGL((small_conv1_bwd_kernel<false, true>), dim3(graph_wg), dim3(64 * WAVES), 0, s, d, z1);
-        else hipLaunchKernelGGL((small_conv1_bwd_kernel<false, false>), dim3(graph_wg), dim3(64 * WAVES), 0, s, d, z1);
+        if (four && variant) hipLaunchKernelGGL((small_conv1_bwd_kernel<true, true>), dim3(wide_wg), dim3(64 * WAVES), 0, s, d, z1);
+        else if (four) hipLaunchKernelGGL((small_conv1_bwd_kernel<true, false>), dim3(wide_wg), dim3(64 * WAVES), 0, s, d, z1);
+        else if (variant) hipLaunchKernelGGL((small_conv1_bwd_kernel<false, true>), dim3(wide_wg), dim3(64 * WAVES), 0, s, d, z1);
+        else hipLaunchKernelGGL((small_conv1_bwd_kernel<false, false>), dim3(wide_wg), dim3(64 * WAVES), 0, s, d, z1);
     }
     if (phases & 32) {
         const int item_blocks = dense ? 0 : (int)std::min<int64_t>(2 * MAX_WG, (xt->n_items + 3) / 4);
