@@ -197,6 +197,56 @@ __global__ __launch_bounds__(256) void conv_fwd_rows_kernel(acm_conv_fwd_t p, in
     EpiFwd::apply<LaySerial<FP>, NG>(p, row, lay, F, acc);     // overwrites this row of `pre` with the final values
 }
 
+// The row-local head of a wide three-channel layer as a kernel of its own (acm_conv_head_fwd): the channels' pre-activations
+// come from products the caller has already made -- pre_L = g_low[row], pre_H = s_high[row] - g_high[row], Z_I = s_mlp[row]
+// (the aggregate-first form for wide inputs: functional._AcmAggWide) -- so there is nothing to gather: a 16-lane group takes a
+// row (four rows per wave, 16-byte loads), EpiFwd does the rest exactly as behind a gather.
+__global__ __launch_bounds__(256) void conv_head_rows_kernel(acm_conv_fwd_t p, int n_rows) {
+    const int lane = threadIdx.x & 63, m = lane & 15;
+    const int row = ((int)blockIdx.x * 4 + (threadIdx.x >> 6)) * 4 + (lane >> 4);
+    if (row >= n_rows) return;                          // (whole 16-lane groups leave: the group sums stay complete)
+    constexpr int F = 64;
+    // EpiFwd::apply for NG = 2 with 16-byte loads and stores (the arithmetic, statement for statement, is the same)
+    const float4 a = *reinterpret_cast<const float4*>(p.g_low + (long)row * p.ld_g_low + 4 * m);
+    const float4 b = *reinterpret_cast<const float4*>(p.g_high + (long)row * p.ld_g_high + 4 * m);
+    const float4 zh4 = *reinterpret_cast<const float4*>(p.s_high + (long)row * p.ld_s_high + 4 * m);
+    const float4 zi4 = *reinterpret_cast<const float4*>(p.s_mlp + (long)row * p.ld_s_mlp + 4 * m);
+    const float aa[4] = {a.x, a.y, a.z, a.w}, bb[4] = {b.x, b.y, b.z, b.w};
+    const float zh[4] = {zh4.x, zh4.y, zh4.z, zh4.w}, zi[4] = {zi4.x, zi4.y, zi4.z, zi4.w};
+    float H[4][4], hn[4][4], xhat[4][4], pre[2][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const float p0 = 1.f * aa[i];
+        const float p1 = zh[i] - 1.f * bb[i];
+        pre[0][i] = p0, pre[1][i] = p1;
+        H[0][i] = p.relu_after ? fmaxf(p0, 0.f) : p0;
+        H[1][i] = p.relu_after ? fmaxf(p1, 0.f) : p1;
+        H[2][i] = p.relu_mlp ? fmaxf(zi[i], 0.f) : zi[i];
+        H[3][i] = 0.f;
+    }
+    const LayRow16 lay{lane};
+    HeadOut ho;
+    const HeadParams hp = acm_head_params(p);
+    acm_head<LayRow16, 3>(lay, F, p.layernorm, hp, H, hn, xhat, ho);
+    float o[4];
+    const AcmDropCtx dc = acm_drop_ctx(p.post_drop);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int col = 4 * m + i;
+        float v = ho.alpha[0] * H[0][i] + ho.alpha[1] * H[1][i] + ho.alpha[2] * H[2][i];
+        v *= p.scale;
+        if (p.post_relu) v = fmaxf(v, 0.f);
+        if (p.post_scale) v *= p.post_scale[(long)row * p.ld_post_scale + col];
+        if (p.post_drop.p > 0.f) v *= acm_drop1(dc, row, col);
+        o[i] = v;
+    }
+    *reinterpret_cast<float4*>(p.out + (long)row * p.ld_out + 4 * m) = make_float4(o[0], o[1], o[2], o[3]);
+    float* pr = p.pre + (long)row * p.ld_pre + 4 * m;
+    *reinterpret_cast<float4*>(pr) = make_float4(pre[0][0], pre[0][1], pre[0][2], pre[0][3]);
+    *reinterpret_cast<float4*>(pr + F) = make_float4(pre[1][0], pre[1][1], pre[1][2], pre[1][3]);
+    if (m == 0) *reinterpret_cast<float4*>(p.att + (long)row * 4) = make_float4(ho.alpha[0], ho.alpha[1], ho.alpha[2], ho.alpha[3]);
+}
+
 struct EpiBwd {
     using Args = acm_conv_bwd_spmm_t;
     template <class L, int NG>
@@ -1204,6 +1254,23 @@ extern "C" int acm_cast_bf16(int64_t n_rows, int64_t n_cols, const float* src, i
     if (blocks > 4096) blocks = 4096;
     hipLaunchKernelGGL(cast_bf16_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (long)n_rows,
                        (int)n_cols, src, (long)ld_src, dst, (long)ld_dst);
+    ACM_CHECK_HIP(hipGetLastError());
+    return ACM_OK;
+}
+
+extern "C" int acm_conv_head_fwd(int64_t n_rows, const acm_conv_fwd_t* p, acm_stream_t stream) {
+    ACM_REQUIRE(p, ACM_EINVAL, "acm_conv_head_fwd: NULL argument");
+    ACM_REQUIRE(n_rows >= 0 && n_rows < INT32_MAX, ACM_ESHAPE, "acm_conv_head_fwd: bad row count");
+    ACM_REQUIRE(p->f_out == 64 && p->n_channels == 3 && !p->gather_bf16 && !p->row_scale && !p->deg, ACM_EUNSUPPORTED,
+                "acm_conv_head_fwd: three fp32 channels of 64 columns, no row scale (got F %d, k %d)", p->f_out, p->n_channels);
+    ACM_REQUIRE(p->g_low && p->g_high && p->s_high && p->s_mlp && p->out && p->pre && p->att && p->att_mix, ACM_EINVAL,
+                "acm_conv_head_fwd: NULL pointer in the parameter block");
+    const uintptr_t bits = (uintptr_t)p->g_low | (uintptr_t)p->g_high | (uintptr_t)p->s_high | (uintptr_t)p->s_mlp | (uintptr_t)p->out |
+                           (uintptr_t)p->pre | (uintptr_t)p->att;
+    ACM_REQUIRE((p->ld_g_low | p->ld_g_high | p->ld_s_high | p->ld_s_mlp | p->ld_out | p->ld_pre) % 4 == 0 && (bits & 15) == 0,
+                ACM_EUNSUPPORTED, "acm_conv_head_fwd: every row (inputs, out, pre, att) must be 16-byte aligned");
+    if (n_rows == 0) return ACM_OK;
+    hipLaunchKernelGGL(conv_head_rows_kernel, dim3((unsigned)((n_rows + 15) / 16)), dim3(256), 0, (hipStream_t)stream, *p, (int)n_rows);
     ACM_CHECK_HIP(hipGetLastError());
     return ACM_OK;
 }

@@ -51,6 +51,14 @@ struct LayVec16 {  // F: 16 lanes x float4 per 64-column block (NB blocks): lane
     __device__ __forceinline__ float rsum(float v) const { return acm_group_sum<16>(v); }
     __device__ __forceinline__ bool leader() const { return lane == 0; }
 };
+struct LayRow16 {   // G: the columns of layout F (one 64-column block), but each 16-lane group holds ITS OWN row -- four rows per
+                    //    wave, every group stores: the row-local head as a kernel of its own (conv_head_rows_kernel)
+    static constexpr int NV = 4;
+    int lane;
+    __device__ __forceinline__ int col(int i) const { return 4 * (lane & 15) + (i & 3); }
+    __device__ __forceinline__ float rsum(float v) const { return acm_group_sum<16>(v); }
+    __device__ __forceinline__ bool leader() const { return (lane & 15) == 0; }
+};
 template <int FP>
 struct LaySerial {  // C: every lane holds the whole row
     static constexpr int NV = FP;

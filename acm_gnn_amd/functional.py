@@ -2072,7 +2072,7 @@ AcmConvFunction._backward_agg = staticmethod(_backward_agg)
 # --------------------------------------------------------------------------
 # aggregate-first for WIDE dense inputs (16 < F_in <= 128), round 5
 # --------------------------------------------------------------------------
-AGG_WIDE_MIN_DEGREE = 24          # stored entries of A_low per row from which the wide aggregate-first form is taken
+AGG_WIDE_MIN_DEGREE = 12          # stored entries of A_low per row from which the wide aggregate-first form is taken
 
 
 def agg_wide_supported(x, ops, cfg, f_in, f_out, post_scale=None, call=None, tail_layer=False):
@@ -2094,15 +2094,15 @@ def agg_wide_supported(x, ops, cfg, f_in, f_out, post_scale=None, call=None, tai
         return False
     # Where it pays (measured, profiles/r05_agg_wide.txt): the rewrite trades 4 F - F_in gathered floats per EDGE for one more
     # pass over ~3 KB per ROW (the dropped copy of X, the head as its own launch, a third more projection flops).  pokec-shaped
-    # (mean degree 38, F_in 65): 12.1 -> 7.5 ms per step; arXiv-year-shaped (mean degree 15, F_in 128): 0.822 -> 0.832, a wash.
+    # (mean degree 38, F_in 65): 12.1 -> 7.0 ms per step; arXiv-year-shaped (mean degree 15, F_in 128): 0.822 -> 0.792.
     return ops.low.nnz >= AGG_WIDE_MIN_DEGREE * x.shape[0]
 
 
 class _AcmAggWide(torch.autograd.Function):
     """out, att = three-channel ACM layer in the aggregate-first form for a wide dense input (see agg_wide_supported).
 
-    forward : [acm_dropout] -> acm_spmm_ex (P = A_low Xd) -> 2 x acm_gemm ([P W_L | P W_H], [Xd W_H | Xd W_I]) -> acm_conv_fwd over
-              the IDENTITY operator (the fused kernel as a row-local epilogue: pre_L = P W_L, pre_H = Xd W_H - P W_H)
+    forward : [acm_dropout] -> acm_spmm_ex (P = A_low Xd) -> 2 x acm_gemm ([P W_L | P W_H], [Xd W_H | Xd W_I]) -> acm_conv_head_fwd
+              (acm_conv_fwd's epilogue as a row-local kernel: pre_L = P W_L, pre_H = Xd W_H - P W_H)
     backward: acm_conv_bwd_local (K3) -> 2 x acm_gemm TN ([P^T G_L | P^T G_H], [Xd^T G_H | Xd^T G_I])"""
 
     @staticmethod
@@ -2163,11 +2163,9 @@ class _AcmAggWide(torch.autograd.Function):
         dspec = _drop_spec(ctx.post_drop, ops.row_offset)
         if dspec is not None:
             p.post_drop = dspec
-        eye = ops.eye
-        ws = eye.workspace(2 * f)
-        with _device_ctx(dev), _Timed(f"conv_head/F{f}k{k}"):
-            st = lib.acm_conv_fwd(eye.handle, C.byref(p), _vp(ws), ws.numel() * 4, _stream())
-        _lib.check(st, "acm_conv_fwd")
+        with _device_ctx(dev), _Timed(f"conv_head/F{f}k{k}"):           # the fused epilogue as a row-local kernel of its own
+            st = lib.acm_conv_head_fwd(n, C.byref(p), _stream())
+        _lib.check(st, "acm_conv_head_fwd")
         ctx.ops, ctx.cfg, ctx.f_in, ctx.fp = ops, cfg, f_in, fp
         ctx.save_for_backward(xd, agg, zb, pre, mix, *vecs, *lnw, *lnb)
         ctx.mark_non_differentiable(att)

@@ -478,6 +478,13 @@ typedef struct {
 int acm_conv_fwd(const acm_csr_t* a_low, const acm_conv_fwd_t* p,
                  void* workspace, size_t workspace_bytes, acm_stream_t stream);
 
+/* The same epilogue WITHOUT a gather (ABI 25): the caller has formed the filtered channels itself -- the aggregate-first
+ * form for wide inputs computes A_low (X W) as (A_low X) W (G:101-104 with the products reordered) -- and hands over
+ *   pre_L = g_low[row],   pre_H = s_high[row] - g_high[row],   Z_I = s_mlp[row]
+ * (three channels of 64 fp32 columns, rows 16-byte aligned, no row_scale / deg).  Everything behind that -- ReLU,
+ * LayerNorm, attention head, mixing, post-op, the outputs `out`, `pre`, `att` -- is acm_conv_fwd's, bit for bit. */
+int acm_conv_head_fwd(int64_t n_rows, const acm_conv_fwd_t* p, acm_stream_t stream);
+
 /* ------------------------------------------- backward, row-local part (K3) --
  * From grad_out and the saved pre-activations recompute the attention head and
  * produce (a) the per-row gradients G_c = dL/d pre_c that feed the transposed

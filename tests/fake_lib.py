@@ -770,6 +770,17 @@ class FakeLib:
         att[:, :k] = hd["alpha"]
         return 0
 
+    def acm_conv_head_fwd(self, n, pp, stream):
+        """acm_conv_fwd's epilogue without a gather = acm_conv_fwd over the identity operator."""
+        eye = _Csr(np.arange(n + 1, dtype=np.int32), np.arange(n, dtype=np.int32), np.ones(n, np.float32), n, 0)
+        h = self._next
+        self._next += 1
+        self._handles[h] = eye
+        try:
+            return self.acm_conv_fwd(C.c_void_p(h), pp, None, 0, stream)
+        finally:
+            self._handles.pop(h, None)
+
     def acm_conv_bwd_local(self, n, qq, ws, wsb, stream):
         q = qq._obj
         F, k = q.f_out, q.n_channels

@@ -268,7 +268,7 @@ def test_aggregate_first_for_wide_inputs_matches_the_literal_form_and_the_oracle
     from oracle import acm_oracle as O
     n = 30000
     rng = np.random.default_rng(5)
-    m = n * 18                                       # mean degree ~36: the form is taken from 24 on
+    m = n * 18                                       # mean degree ~36: the form is taken from 12 on
     r, c = rng.integers(0, n, m), rng.integers(0, n, m)
     adj = sp.csr_matrix((np.ones(m, np.float32), (r, c)), shape=(n, n))
     adj = ((adj + adj.T) > 0).astype(np.float32).tocsr()

@@ -1447,7 +1447,7 @@ def test_aggregate_first_for_wide_dense_inputs_equals_the_literal_form(model_typ
     literal project-then-gather form (tuning rewrites bit 1 off); F_in that is no multiple of 4 is padded (pokec: 65)."""
     fake = fake_lib.install(monkeypatch)
     from acm_gnn_amd import GCN, functional as AF
-    ops, n = _dense_graph_ops(n=8192, avg=30, seed=3)          # (the form is taken from a mean degree of 24 on)
+    ops, n = _dense_graph_ops(n=8192, avg=30, seed=3)          # (the form is taken from a mean degree of 12 on)
     x = torch.randn(n, f_in, generator=torch.Generator().manual_seed(2))
     calls = []
     for name in ("acm_conv_bwd_spmm", "acm_spmm_ex", "acm_spmm"):
