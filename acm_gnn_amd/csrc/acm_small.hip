@@ -668,6 +668,9 @@ struct Pre4 {
 template <bool FOUR>
 __global__ __launch_bounds__(64 * WAVES) void small_conv2_bwd_kernel(SmallDev d, const float* z1) {
     __shared__ __attribute__((aligned(16))) float red[WAVES / 2][PART4];  // the waves' sums side by side (two rounds: 37 KB)
+    __shared__ __attribute__((aligned(16))) float w2s[3 * F * C8];        // W2T [idx][col]: 24 rows of 64, read by every row's dH
+    for (int e = 4 * threadIdx.x; e < 3 * F * C8; e += 4 * 64 * WAVES) st4(w2s + e, ld4(d.W2T + e));
+    __syncthreads();
     const int lane = threadIdx.x & 63, g = lane >> 4, m = lane & 15, c = lane & 7, wv = threadIdx.x >> 6;
     const int wave = (int)blockIdx.x * WAVES + wv, n_waves = (int)gridDim.x * WAVES;
     constexpr int NQ = FOUR ? 6 : 4;
@@ -747,18 +750,10 @@ __global__ __launch_bounds__(64 * WAVES) void small_conv2_bwd_kernel(SmallDev d,
             }
             const f4 o = pf.o;
             // dH = dZ2 Wcat2^T (columns 4m .. 4m+3) and dWcat2 += H^T dZ2 (group g: idx = g, g + 4, ...)
-            // (W2T is 6 KB read by every wave of the launch: L1 / L2-hot, its 24 loads go out together right here; held in
-            // registers across the gather they cost 96 VGPRs and spilled)
+            // (W2T from LDS, staged once per workgroup: as global loads its 24 rows were three dependent round trips per row)
             f4 dH0 = zero4(), dH1 = zero4();
 #pragma unroll
-            for (int ch = 0; ch < 3; ++ch) {             // eight rows of W2T in flight at a time (96 VGPRs for all 24 spilled)
-                f4 wv8[8];
-#pragma unroll
-                for (int q = 0; q < 8; ++q) wv8[q] = ld4(d.W2T + (ch * 8 + q) * F + 4 * m);
-#pragma unroll
-                for (int q = 0; q < 8; q += 2) dH0 += dz[ch * 8 + q] * wv8[q], dH1 += dz[ch * 8 + q + 1] * wv8[q + 1];
-                __builtin_amdgcn_sched_barrier(0);
-            }
+            for (int q = 0; q < 24; q += 2) dH0 += dz[q] * ld4(w2s + q * F + 4 * m), dH1 += dz[q + 1] * ld4(w2s + (q + 1) * F + 4 * m);
             const f4 dH = dH0 + dH1;
             if (li < 0) {
 #pragma unroll
