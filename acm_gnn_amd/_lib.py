@@ -212,12 +212,11 @@ SR_LNW_LOW, SR_LNW_HIGH, SR_LNW_MLP, SR_LNW_STRUC, SR_LNB_LOW, SR_LNB_HIGH, SR_L
 
 class SmallStep(C.Structure):
     _fields_ = [("n_classes", C.c_int32), ("n_channels", C.c_int32), ("relu_before", C.c_int32), ("layernorm", C.c_int32),
-                ("scale", C.c_float), ("train", C.c_int32), ("update", C.c_int32), ("phases", C.c_int32),
+                ("scale", C.c_float), ("train", C.c_int32), ("update", C.c_int32), ("reserved0", C.c_int32),
                 ("t", (AdamTensor * SMALL_ROLES) * 2),
-                ("x_vals", C.c_void_p), ("xt_src_pos", C.c_void_p), ("xt_vals", C.c_void_p), ("z1_given", C.c_void_p), ("w1_grad_given", C.c_int32),
-                ("f_in", C.c_int32), ("drop_in", Dropout), ("drop_hidden", Dropout),
+                ("x_vals", C.c_void_p), ("xt_src_pos", C.c_void_p), ("xt_vals", C.c_void_p), ("f_in", C.c_int32), ("reserved1", C.c_int32), ("drop_in", Dropout), ("drop_hidden", Dropout),
                 ("row_scale", C.c_void_p), ("labels", C.c_void_p), ("row_weight", C.c_void_p), ("loss", C.c_void_p),
-                ("logits", C.c_void_p), ("att1", C.c_void_p), ("att2", C.c_void_p), ("dz1", C.c_void_p),
+                ("logits", C.c_void_p), ("att1", C.c_void_p), ("att2", C.c_void_p),
                 ("lr", C.c_double), ("beta1", C.c_double), ("beta2", C.c_double), ("eps", C.c_double),
                 ("weight_decay", C.c_double), ("decoupled", C.c_int32), ("also_advance", C.c_void_p), ("arrive", C.c_void_p),
                 ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t)]

@@ -78,7 +78,6 @@ struct SmallDev {
     const float* xt_vals;
     int* counters;
     int nwg3, nwg4;                  // producer workgroups of the two partial-sum buffers
-    int w1_grad_given;
     acm_dropout_t drop_in, drop_hidden;
     AdamScalars hp;
     int64_t* also_advance;
@@ -347,17 +346,6 @@ __global__ __launch_bounds__(256) void small_proj1_kernel(SmallDev d) {
             // the structure parameter of layer 2 as a block of the narrow table (refreshed every step: it is a parameter)
             if (d.k == 4 && g == 3 && m < C8) d.T2[(long)row * 24 + 16 + m] = m < d.C ? d.t[1][ACM_SR_STRUC].p[(long)row * d.C + m] : 0.f;
         });
-}
-
-// dense features: Z1 was computed by the caller; only the structure block of the narrow table is refreshed
-__global__ __launch_bounds__(256) void small_struc_copy_kernel(SmallDev d) {
-    write_tables(d);
-    const long i = (long)blockIdx.x * 256 + threadIdx.x;
-    if (d.k == 4 && i < (long)d.n * C8) {
-        const long row = i >> 3;
-        const int c = (int)(i & 7);
-        d.T2[row * 24 + 16 + c] = c < d.C ? d.t[1][ACM_SR_STRUC].p[row * d.C + c] : 0.f;
-    }
 }
 
 // ------------------------------------------------------------------------------------------------ launch 2: layer 1 forward
@@ -938,9 +926,8 @@ __global__ __launch_bounds__(64 * WAVES) void small_conv1_bwd_kernel(SmallDev d,
 
 // ------------------------------------------------------------------------------------------------ launch 6: dW1, every other sum, the updates
 // blocks [0, item_blocks): dW1 = drop(X)^T dZ1 by feature row (the transposed feature handle's items) + its update;
-// blocks behind: one thread per element of the two partial-sum vectors (sum over the producer workgroups, then the update),
-// then -- dense features -- the elementwise update of W1 from the caller's gradient.  The last block to finish advances the
-// step counters.
+// blocks behind: RED_EL elements of the two partial-sum vectors per block (sum over the producer workgroups and the long
+// rows' records, then the update).  The first block advances the step counters.
 __global__ __launch_bounds__(256) void small_finish_kernel(SmallDev d, int item_blocks, int red_blocks) {
     __shared__ float red8[256 / RED_EL][RED_EL];
     const float* __restrict__ fact = d.FACT;              // step factors of every tensor (launch 1 wrote them)
@@ -1065,18 +1052,6 @@ __global__ __launch_bounds__(256) void small_finish_kernel(SmallDev d, int item_
                 d.loss[0] = s;
             }
         }
-    } else {                                              // dense features: W1 from the caller's gradient
-        const long i = (long)(blk - item_blocks - red_blocks) * 256 + threadIdx.x;
-        const long per = (long)d.f_in * F;
-        if (i < 3 * per && d.update) {
-            const int ch = (int)(i / per);
-            const SmallTensor& t = d.t[0][ACM_SR_W_LOW + ch];
-            const long j = i % per;
-            const float* s = fact + 2 * (ACM_SR_W_LOW + ch);
-            float pp = t.p[j], mm = t.m[j], vv = t.v[j];
-            adam_one(pp, t.g[j], mm, vv, af.decay_eff, af.wd, af.decoupled, af.w1, af.b2, af.w2, s[0], s[1], af.eps);
-            t.p[j] = pp, t.m[j] = mm, t.v[j] = vv;
-        }
     }
     // nothing in this launch reads a step counter (launch 1 left the factors and the dropout counter of the step in the
     // workspace): the first block advances them
@@ -1154,21 +1129,16 @@ extern "C" int acm_small_step(const acm_csr_t* a, const acm_csr_t* x, const acm_
     ACM_REQUIRE(p->n_classes >= 1 && p->n_classes <= C8, ACM_EUNSUPPORTED, "acm_small_step: 1 .. 8 classes (got %d)", p->n_classes);
     ACM_REQUIRE(p->n_channels == 3 || p->n_channels == 4, ACM_EINVAL, "acm_small_step: n_channels must be 3 or 4");
     ACM_REQUIRE(p->row_scale && p->logits && p->att1 && p->att2 && p->workspace, ACM_EINVAL, "acm_small_step: NULL buffer");
-    const bool dense = p->z1_given != nullptr;
-    ACM_REQUIRE(dense || (x && p->x_vals), ACM_EINVAL, "acm_small_step: CSR features (x, x_vals) or z1_given");
-    ACM_REQUIRE(dense || (x->n_rows == a->n_rows && x->n_cols == p->f_in), ACM_ESHAPE, "acm_small_step: feature handle is %lld x %lld, expected %lld x %d",
-                dense ? 0LL : (long long)x->n_rows, dense ? 0LL : (long long)x->n_cols, (long long)a->n_rows, p->f_in);
+    ACM_REQUIRE(x && p->x_vals, ACM_EINVAL, "acm_small_step: the CSR feature handle and its values (x, x_vals)");
+    ACM_REQUIRE(x->n_rows == a->n_rows && x->n_cols == p->f_in, ACM_ESHAPE, "acm_small_step: feature handle is %lld x %lld, expected %lld x %d",
+                (long long)x->n_rows, (long long)x->n_cols, (long long)a->n_rows, p->f_in);
     const int K = p->n_channels;
-    const int all = p->train ? 63 : 7;
-    const int phases = p->phases ? (p->phases & all) : all;
     if (p->train) {
         ACM_REQUIRE(p->labels && p->row_weight && p->loss, ACM_EINVAL, "acm_small_step: labels / row_weight / loss");
-        ACM_REQUIRE(dense || !(phases & 32) || (xt && p->xt_src_pos && xt->n_rows == p->f_in && xt->n_cols == a->n_rows), ACM_EINVAL,
+        ACM_REQUIRE(xt && p->xt_src_pos && xt->n_rows == p->f_in && xt->n_cols == a->n_rows, ACM_EINVAL,
                     "acm_small_step: the transposed feature handle (x_t, xt_src_pos) is needed for dW1");
-        ACM_REQUIRE(!dense || p->w1_grad_given || !(phases & 32) || !p->update, ACM_EINVAL,
-                    "acm_small_step: dense features update W1 from the caller's gradient (w1_grad_given)");
     }
-    const Layout L = layout_of(a, dense ? nullptr : x, dense ? nullptr : xt);
+    const Layout L = layout_of(a, x, p->train ? xt : nullptr);
     ACM_REQUIRE(p->workspace_bytes >= L.total, ACM_ESHAPE, "acm_small_step: workspace of %zu bytes, %zu needed", p->workspace_bytes, L.total);
     // required roles
     for (int l = 0; l < 2; ++l) {
@@ -1196,22 +1166,21 @@ extern "C" int acm_small_step(const acm_csr_t* a, const acm_csr_t* x, const acm_
             if (p->train && p->update) ACM_REQUIRE(t.m && t.v && t.step, ACM_EINVAL, "acm_small_step: layer %d role %d lacks Adam state", l, r);
             if (p->train && !p->update) ACM_REQUIRE(t.g, ACM_EINVAL, "acm_small_step: layer %d role %d has no gradient buffer (update = 0)", l, r);
         }
-    d.graph = view_of(a), d.x = view_of(dense ? nullptr : x), d.xt = view_of(dense ? nullptr : xt);
+    d.graph = view_of(a), d.x = view_of(x), d.xt = view_of(p->train ? xt : nullptr);
     d.x_vals = p->x_vals, d.xt_src_pos = p->xt_src_pos, d.row_scale = p->row_scale;
     d.labels = p->labels, d.row_weight = p->row_weight, d.loss = p->loss, d.logits = p->logits, d.att1 = p->att1, d.att2 = p->att2;
     float* ws = (float*)p->workspace;
     d.Z1 = ws + L.Z1, d.H1 = ws + L.H1, d.ST1 = ws + L.ST1, d.OUT1 = ws + L.OUT1, d.T2 = ws + L.T2, d.Z2I = ws + L.Z2I;
-    d.G2 = ws + L.G2, d.DZ2 = ws + L.DZ2, d.G1 = ws + L.G1, d.DZ1 = p->dz1 ? p->dz1 : ws + L.DZ1;
+    d.G2 = ws + L.G2, d.DZ2 = ws + L.DZ2, d.G1 = ws + L.G1, d.DZ1 = ws + L.DZ1;
     d.slots = ws + L.slots, d.part3 = ws + L.part3, d.part4 = ws + L.part4, d.W2T = ws + L.W2T, d.FACT = ws + L.FACT;
     d.xt_vals = p->xt_vals;
     d.long3 = ws + L.long3, d.long4 = ws + L.long4, d.n_long = (int)a->n_long;
     d.latch = reinterpret_cast<int64_t*>(ws + L.latch);
     d.counters = (int*)(ws + L.counters);
-    d.w1_grad_given = p->w1_grad_given;
     d.drop_in = p->drop_in, d.drop_hidden = p->drop_hidden;
     d.hp = AdamScalars{p->lr, p->beta1, p->beta2, p->eps, p->weight_decay, p->decoupled};
     d.also_advance = p->also_advance, d.arrive = p->arrive;
-    const float* z1 = dense ? p->z1_given : d.Z1;
+    const float* z1 = d.Z1;
     hipStream_t s = (hipStream_t)stream;
     SmallDev d1 = d;                               // launch 1 reads the live dropout counter and latches it for the others
     if (d.drop_in.p > 0.f) d.drop_in.step = d.latch;
@@ -1220,39 +1189,31 @@ extern "C" int acm_small_step(const acm_csr_t* a, const acm_csr_t* x, const acm_
     const int wide_wg = (int)std::min<int64_t>(MAX_WG_WIDE, (a->n_items + WAVES - 1) / WAVES);
     d.nwg3 = d.nwg4 = graph_wg;
     const bool four = K == 4, variant = p->relu_before != 0;
-    if (phases & 1) {
-        if (!dense) {
-            const int wg = (int)std::min<int64_t>(2 * MAX_WG, (x->n_items + 3) / 4);
-            hipLaunchKernelGGL(small_proj1_kernel, dim3(std::max(wg, 1)), dim3(256), 0, s, d1);
-        } else {
-            hipLaunchKernelGGL(small_struc_copy_kernel, dim3((d.n * C8 + 255) / 256), dim3(256), 0, s, d1);
-        }
+    {   // launch 1
+        const int wg = (int)std::min<int64_t>(2 * MAX_WG, (x->n_items + 3) / 4);
+        hipLaunchKernelGGL(small_proj1_kernel, dim3(std::max(wg, 1)), dim3(256), 0, s, d1);
     }
-    if (phases & 2) {
-        if (four && variant) hipLaunchKernelGGL((small_conv1_fwd_kernel<true, true>), dim3(wide_wg), dim3(64 * WAVES), 0, s, d, z1);
-        else if (four) hipLaunchKernelGGL((small_conv1_fwd_kernel<true, false>), dim3(wide_wg), dim3(64 * WAVES), 0, s, d, z1);
-        else if (variant) hipLaunchKernelGGL((small_conv1_fwd_kernel<false, true>), dim3(wide_wg), dim3(64 * WAVES), 0, s, d, z1);
-        else hipLaunchKernelGGL((small_conv1_fwd_kernel<false, false>), dim3(wide_wg), dim3(64 * WAVES), 0, s, d, z1);
-    }
-    if (phases & 4) {
-        if (four) hipLaunchKernelGGL(small_conv2_fwd_kernel<true>, dim3(graph_wg), dim3(64 * WAVES), 0, s, d);
-        else hipLaunchKernelGGL(small_conv2_fwd_kernel<false>, dim3(graph_wg), dim3(64 * WAVES), 0, s, d);
-    }
-    if (phases & 8) {
+    // launch 2
+    if (four && variant) hipLaunchKernelGGL((small_conv1_fwd_kernel<true, true>), dim3(wide_wg), dim3(64 * WAVES), 0, s, d, z1);
+    else if (four) hipLaunchKernelGGL((small_conv1_fwd_kernel<true, false>), dim3(wide_wg), dim3(64 * WAVES), 0, s, d, z1);
+    else if (variant) hipLaunchKernelGGL((small_conv1_fwd_kernel<false, true>), dim3(wide_wg), dim3(64 * WAVES), 0, s, d, z1);
+    else hipLaunchKernelGGL((small_conv1_fwd_kernel<false, false>), dim3(wide_wg), dim3(64 * WAVES), 0, s, d, z1);
+    // launch 3
+    if (four) hipLaunchKernelGGL(small_conv2_fwd_kernel<true>, dim3(graph_wg), dim3(64 * WAVES), 0, s, d);
+    else hipLaunchKernelGGL(small_conv2_fwd_kernel<false>, dim3(graph_wg), dim3(64 * WAVES), 0, s, d);
+    if (p->train) {
+        // launch 4
         if (four) hipLaunchKernelGGL(small_conv2_bwd_kernel<true>, dim3(graph_wg), dim3(64 * WAVES), 0, s, d, z1);
         else hipLaunchKernelGGL(small_conv2_bwd_kernel<false>, dim3(graph_wg), dim3(64 * WAVES), 0, s, d, z1);
-    }
-    if (phases & 16) {
+        // launch 5
         if (four && variant) hipLaunchKernelGGL((small_conv1_bwd_kernel<true, true>), dim3(wide_wg), dim3(64 * WAVES), 0, s, d, z1);
         else if (four) hipLaunchKernelGGL((small_conv1_bwd_kernel<true, false>), dim3(wide_wg), dim3(64 * WAVES), 0, s, d, z1);
         else if (variant) hipLaunchKernelGGL((small_conv1_bwd_kernel<false, true>), dim3(wide_wg), dim3(64 * WAVES), 0, s, d, z1);
         else hipLaunchKernelGGL((small_conv1_bwd_kernel<false, false>), dim3(wide_wg), dim3(64 * WAVES), 0, s, d, z1);
-    }
-    if (phases & 32) {
-        const int item_blocks = dense ? 0 : (int)std::min<int64_t>(2 * MAX_WG, (xt->n_items + 3) / 4);
+        // launch 6
+        const int item_blocks = (int)std::min<int64_t>(2 * MAX_WG, (xt->n_items + 3) / 4);
         const int red_blocks = (PART4 + PART3 + RED_EL - 1) / RED_EL;
-        const int w1_blocks = (dense && p->w1_grad_given && p->update) ? (int)((3LL * p->f_in * F + 255) / 256) : 0;
-        hipLaunchKernelGGL(small_finish_kernel, dim3(item_blocks + red_blocks + w1_blocks), dim3(256), 0, s, d, item_blocks, red_blocks);
+        hipLaunchKernelGGL(small_finish_kernel, dim3(item_blocks + red_blocks), dim3(256), 0, s, d, item_blocks, red_blocks);
     }
     ACM_CHECK_HIP(hipGetLastError());
     return ACM_OK;

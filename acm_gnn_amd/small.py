@@ -145,7 +145,7 @@ class SmallPlan:
             for li, layer in enumerate(model.gcns):
                 for role in _roles(cfg):
                     self.grads[(li, _ROLE_NAMES[role])] = torch.zeros_like(_param(layer, role))
-        p.scale, p.train, p.update, p.phases = cfg.scale, int(self.train), int(self.update), 0
+        p.scale, p.train, p.update = cfg.scale, int(self.train), int(self.update)
         p.f_in = l0.in_features
         p.x_vals = x.values.data_ptr()
         if self._xt is not None:

@@ -901,7 +901,7 @@ int acm_adam_step(int32_t n_tensors, const acm_adam_tensor_t* tensors, const acm
  * atomics).  Hidden width 64, at most 8 classes, pattern-only operator (acm_csr_create with vals = NULL) + row scale.
  * With `update` the Adam / AdamW update of every parameter is applied where its gradient becomes final (same formulas
  * as acm_adam_step); without it the gradients are written to t[..].grad and nothing is updated.
- * `train = 0`: launches 1-3 only, forward (evaluation pass: logits, att).
+ * `train = 0`: launches 1-3 only, forward (evaluation pass: logits, att).  Dense features: convert once (CSR copy).
  */
 #define ACM_SMALL_ROLES 17
 enum {
@@ -921,19 +921,16 @@ typedef struct {
     float   scale;              /* 3, or 1 with the structure channel                                                */
     int32_t train;              /* 1: the step; 0: forward only (launches 1-3)                                       */
     int32_t update;             /* 1: apply Adam / AdamW in place; 0: write gradients to t[..].grad                   */
-    int32_t phases;             /* bit l-1 set: run launch l (0 = all the mode needs); dense features split the call  */
+    int32_t reserved0;
     /* t[layer][role]: param NULL = the role is absent / takes no gradient.  exp_avg / exp_avg_sq / step as in
      * acm_adam_tensor_t (needed with `update`); grad: optional output (required without `update`).  numel is ignored. */
     acm_adam_tensor_t t[2][ACM_SMALL_ROLES];
-    /* first-layer input: CSR features (the handles passed to the call) with this call's values ...               */
+    /* first-layer input: CSR features (the handles passed to the call) with this call's values                          */
     const float* x_vals;        /* nnz(X) values in the order of the x handle                                        */
     const int32_t* xt_src_pos;  /* nnz(X): position in x_vals of every entry of the TRANSPOSED handle                */
     const float* xt_vals;       /* optional: x_vals in the transposed handle's order (x_vals[xt_src_pos[k]]), made once     */
-    /* ... or dense features: the caller computes Z1 = drop(X) [W_L | W_H | W_I] (acm_gemm) before, and
-     * dW1 = drop(X)^T dZ1 into t[0][W_*].grad between launches 5 and 6 (phases)                                      */
-    const float* z1_given;      /* [n, 192] row-major, or NULL                                                       */
-    int32_t w1_grad_given;      /* 1: launch 6 updates W1 from t[0][W_*].grad (f_in x 64 each) instead of computing it */
     int32_t f_in;
+    int32_t reserved1;
     acm_dropout_t drop_in;      /* on x_vals: element (position, 0)                                                  */
     acm_dropout_t drop_hidden;  /* on the hidden activations: element (row, column)                                  */
     const float* row_scale;     /* 1 / d_i                                                                           */
@@ -942,7 +939,6 @@ typedef struct {
     float* loss;                /* device scalar                                                                     */
     float* logits;              /* [n, C] contiguous                                                                 */
     float* att1; float* att2;   /* [n, 4] mixing weights of the two layers                                           */
-    float* dz1;                 /* [n, 192]: dL/dZ1 (output of launch 5; dense features read it for dW1)             */
     double  lr, beta1, beta2, eps, weight_decay;
     int32_t decoupled;
     int64_t* also_advance;      /* optional device counter incremented with the step counters (dropout step)         */
@@ -952,8 +948,8 @@ typedef struct {
 } acm_small_step_t;
 
 int acm_small_step_workspace_bytes(const acm_csr_t* a_low, const acm_csr_t* x, const acm_csr_t* x_t, size_t* bytes);
-/* x / x_t: CSR handles of the features and of their transpose (pattern; values come from p->x_vals), or NULL with
- * z1_given.  Errors: ACM_EUNSUPPORTED outside the envelope (explicit values, > 8 classes, > 16384 rows, ...). */
+/* x / x_t: CSR handles of the features and of their transpose (pattern; values come from p->x_vals; x_t may be NULL with
+ * train = 0).  Errors: ACM_EUNSUPPORTED outside the envelope (explicit values, > 8 classes, > 16384 rows, ...). */
 int acm_small_step(const acm_csr_t* a_low, const acm_csr_t* x, const acm_csr_t* x_t, const acm_small_step_t* p,
                    acm_stream_t stream);
 
