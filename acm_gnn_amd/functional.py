@@ -1095,10 +1095,11 @@ class AcmConfig:
 
 
 def _ptr_array(tensors):
-    arr = (C.c_void_p * 4)()
-    for i in range(4):
-        arr[i] = tensors[i].data_ptr() if i < len(tensors) and tensors[i] is not None else None
-    return arr
+    n = len(tensors)
+    return _VP4(*[tensors[i].data_ptr() if i < n and tensors[i] is not None else None for i in range(4)])
+
+
+_VP4 = C.c_void_p * 4
 
 
 def cast_bf16(src):
@@ -1157,12 +1158,15 @@ def _low_product(ops, t_local, transpose=False, out=None):
 def _flat_views(flat, nw, k, f, layernorm):
     """The head-parameter gradients as views of the layer's flat gradient buffer (fresh tensor objects on every call:
     autograd adopts a returned gradient only while nobody else holds that tensor object)."""
-    nln = k * f if layernorm else 0
-    d_vec = [flat[nw + c * f: nw + (c + 1) * f].view(f, 1) for c in range(k)]
-    o1 = nw + k * f
-    d_lnw = [flat[o1 + c * f: o1 + (c + 1) * f] for c in range(k)] if layernorm else []
-    d_lnb = [flat[o1 + nln + c * f: o1 + nln + (c + 1) * f] for c in range(k)] if layernorm else []
-    d_mix = flat[o1 + 2 * nln:].view(k, k)
+    # (one split call: 3 k + 1 views; slicing them one by one costs a layer 30 us of host time)
+    if layernorm:
+        parts = flat[nw:].split([f] * (3 * k) + [k * k])
+        d_vec = [t.view(f, 1) for t in parts[:k]]
+        d_lnw, d_lnb = list(parts[k:2 * k]), list(parts[2 * k:3 * k])
+    else:
+        parts = flat[nw:].split([f] * k + [k * k])
+        d_vec, d_lnw, d_lnb = [t.view(f, 1) for t in parts[:k]], [], []
+    d_mix = parts[-1].view(k, k)
     return d_vec, d_lnw, d_lnb, d_mix
 
 

@@ -191,7 +191,8 @@ class GraphConvolution(nn.Module):
         if translate:
             out = out.index_select(0, ops.inv_perm)
         # the mixing weights stay where the kernel wrote them; the attributes translate rows when they are read
-        self._att_raw, self._att_inv, self._att_k = att, ops.inv_perm, cfg.n_channels
+        d = self.__dict__                       # (plain attributes: not through Module.__setattr__'s parameter / buffer checks)
+        d["_att_raw"], d["_att_inv"], d["_att_k"] = att, ops.inv_perm, cfg.n_channels
         return out
 
     def _eval_agg_holder(self, x, ops):

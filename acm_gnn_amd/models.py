@@ -225,7 +225,7 @@ class GCN(nn.Module):
             from .graph import operators_for
             four = self.structure_info and self.model_type in ("acmgcnp", "acmgcnpp")
             ops = adj_low = operators_for(adj_low, adj_high, adj_low_unnormalized if four else None)
-        self._rows_permuted = ops is not None and ops.perm is not None
+        self.__dict__["_rows_permuted"] = ops is not None and ops.perm is not None
         if not rows_permuted:                  # (a caller that already permuted -- train.TrainStep -- asked before it did)
             x = self.auto_csr(x, ops)
         if self._rows_permuted and not rows_permuted:

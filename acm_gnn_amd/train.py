@@ -214,7 +214,12 @@ class TrainStep:
     def _eager(self):
         if not self.model.training:
             self.model.train()
-        self.opt.zero_grad(set_to_none=True)
+        if type(self.opt).zero_grad is torch.optim.Optimizer.zero_grad:
+            for group in self.opt.param_groups:      # = the stock zero_grad(set_to_none=True) without its dispatch wrapper (30 us)
+                for p in group["params"]:
+                    p.grad = None
+        else:
+            self.opt.zero_grad(set_to_none=True)
         loss = self._one_step()
         return loss                 # never hand out the autograd graph: a live AccumulateGrad node pins its
                                     # stream and breaks a later graph capture
