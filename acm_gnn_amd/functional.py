@@ -22,10 +22,10 @@ class KernelTimer:
     one kernel under study do not perturb the rest of a timed region.
 
     ``external=True``: launches made while the stream is being CAPTURED are bracketed by *external* events (event-record
-    nodes of the hipGraph, ``torch.cuda.Event(external=True)``): every replay re-records them, so after a replay and a
-    synchronize ``captured_ms(label)`` is that kernel's duration INSIDE the replayed graph -- the time that belongs next
-    to a hipGraph-replay ``ms_per_step`` (bench.py's roofline).  Without it, launches under capture
-    are not timed at all (a plain event recorded in a capture cannot be read)."""
+    nodes of the hipGraph, added through the HIP graph API: _HipEvent): every replay re-records them, so after a replay and a synchronize
+    ``captured_ms(label)`` is that kernel's duration INSIDE the replayed graph -- the time that belongs next to a
+    hipGraph-replay ``ms_per_step`` (bench.py's roofline).  Without it, launches under capture are not
+    timed at all (a plain event recorded in a capture cannot be read)."""
 
     def __init__(self, only=None, external=False):
         self.only, self.events = only, {}
@@ -44,6 +44,59 @@ class KernelTimer:
         """ms of every captured launch under ``label`` in the LAST replay of the graph(s) that hold them; synchronises."""
         torch.cuda.synchronize()
         return [a.elapsed_time(b) for a, b in self.captured.get(label, [])]
+
+
+class _HipEvent:
+    """A timing hipEvent_t recorded by an EVENT-RECORD NODE of the hipGraph the current stream is being captured into:
+    hipStreamGetCaptureInfo_v2 -> hipGraphAddEventRecordNode behind the capture's current dependencies ->
+    hipStreamUpdateCaptureDependencies (ROCm 7.2 rejects hipEventRecordWithFlags(hipEventRecordExternal), hipError 1,
+    and torch refuses Event(external=True) on ROCm; the explicit node is what both stand for)."""
+    _hip = None
+
+    def __init__(self):
+        if _HipEvent._hip is None:
+            hip = C.CDLL("libamdhip64.so")
+            hip.hipEventCreate.argtypes = [C.POINTER(C.c_void_p)]
+            hip.hipStreamGetCaptureInfo_v2.argtypes = [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_ulonglong),
+                                                       C.POINTER(C.c_void_p), C.POINTER(C.POINTER(C.c_void_p)),
+                                                       C.POINTER(C.c_size_t)]
+            hip.hipGraphAddEventRecordNode.argtypes = [C.POINTER(C.c_void_p), C.c_void_p, C.POINTER(C.c_void_p), C.c_size_t,
+                                                       C.c_void_p]
+            hip.hipStreamUpdateCaptureDependencies.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.c_size_t, C.c_uint]
+            hip.hipEventElapsedTime.argtypes = [C.POINTER(C.c_float), C.c_void_p, C.c_void_p]
+            hip.hipEventDestroy.argtypes = [C.c_void_p]
+            _HipEvent._hip = hip
+        self.handle = C.c_void_p()
+        self._check(self._hip.hipEventCreate(C.byref(self.handle)), "hipEventCreate")
+
+    @staticmethod
+    def _check(status, what):
+        if status != 0:
+            raise RuntimeError(f"{what} failed with hipError_t {status}")
+
+    def record(self):
+        hip, stream = self._hip, _stream()
+        status, cap_id, graph = C.c_int(), C.c_ulonglong(), C.c_void_p()
+        deps, n_deps = C.POINTER(C.c_void_p)(), C.c_size_t()
+        self._check(hip.hipStreamGetCaptureInfo_v2(stream, C.byref(status), C.byref(cap_id), C.byref(graph), C.byref(deps),
+                                                   C.byref(n_deps)), "hipStreamGetCaptureInfo_v2")
+        if status.value != 1:                          # hipStreamCaptureStatusActive
+            raise RuntimeError("_HipEvent.record: the current stream is not being captured")
+        node = C.c_void_p()
+        self._check(hip.hipGraphAddEventRecordNode(C.byref(node), graph, deps, n_deps.value, self.handle),
+                    "hipGraphAddEventRecordNode")
+        self._check(hip.hipStreamUpdateCaptureDependencies(stream, C.byref(node), 1, 1),     # 1 = set (replace) dependencies
+                    "hipStreamUpdateCaptureDependencies")
+
+    def elapsed_time(self, other):
+        ms = C.c_float()
+        self._check(self._hip.hipEventElapsedTime(C.byref(ms), self.handle, other.handle), "hipEventElapsedTime")
+        return ms.value
+
+    def __del__(self):
+        hip = getattr(type(self), "_hip", None)            # (module globals are gone at interpreter shutdown)
+        if self.handle and hip is not None:
+            hip.hipEventDestroy(self.handle)
 
 
 _TIMER = None
@@ -67,9 +120,10 @@ class _Timed:
 
     def __enter__(self):
         if self.on:
-            kw = {"external": True} if self.capturing else {}
-            self.a = torch.cuda.Event(enable_timing=True, **kw)
-            self.b = torch.cuda.Event(enable_timing=True, **kw)
+            if self.capturing:
+                self.a, self.b = _HipEvent(), _HipEvent()
+            else:
+                self.a, self.b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             self.a.record()
         return self
 

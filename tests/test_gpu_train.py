@@ -543,3 +543,37 @@ def test_captured_dropout_free_fit_on_relabelled_operators_survives_an_emptied_c
         return np.asarray(out)
 
     np.testing.assert_allclose(run(True), run(False), rtol=2e-5, atol=1e-6)
+
+
+@pytest.mark.gpu
+def test_kernel_timer_brackets_captured_launches_with_event_record_nodes():
+    """functional.KernelTimer(external=True): a launch made under capture sits between two event-record nodes of the
+    hipGraph (added through hipGraphAddEventRecordNode: ROCm rejects external event records, torch refuses them), every
+    replay re-records them, and the replayed losses are those of a capture without the timer (bench.py's roofline.avg_ms)."""
+    from acm_gnn_amd import GCN, FusedAdamW, data as D, functional as AF, train as T
+    from acm_gnn_amd.graph import CsrGraph, FilterOperators
+    adj, x_np, y_np, (tr, _, _), _ = D.synthetic_dataset("tiny", seed=1)
+    low, deg = D.build_filters(adj)
+    ops = FilterOperators(CsrGraph.from_scipy(low, DEV))
+    x, y = torch.from_numpy(D.row_normalize_features(x_np)).to(DEV), torch.from_numpy(y_np).to(DEV)
+    w = T.row_weights(torch.from_numpy(tr).to(DEV), x.shape[0])
+    losses = []
+    for timed in (False, True):
+        torch.manual_seed(0)
+        model = GCN(7, 64, 2, 2, x.shape[0], 0.0, "acmgcnp", 0, variant=False).to(DEV)
+        opt = FusedAdamW(model.parameters(), lr=0.01, weight_decay=1e-3)
+        probe = AF.KernelTimer(only="conv_", external=True) if timed else None
+        AF.set_kernel_timer(probe)
+        try:
+            step = T.TrainStep(model, opt, x, ops, y, w, use_graph=True, small_step=False)
+        finally:
+            AF.set_kernel_timer(None)
+        losses.append([float(step()) for _ in range(4)])
+        if timed:
+            assert probe.captured
+            for label in probe.captured:
+                for _ in range(2):
+                    step()
+                    ms = probe.captured_ms(label)
+                    assert len(ms) == len(probe.captured[label]) and all(0.0 < v < 5.0 for v in ms), (label, ms)
+    np.testing.assert_allclose(losses[1], losses[0], rtol=1e-6)
