@@ -15,7 +15,7 @@ CSRC = os.path.join(HERE, "csrc")
 INCLUDE = os.path.join(ROOT, "include")
 LIB_DIR = os.path.join(HERE, "lib")
 LIB_PATH = os.path.join(LIB_DIR, "libacm_hip.so")
-SOURCES = ["acm_csr.cpp", "acm_gemm.hip", "acm_conv.hip", "acm_conv_agg.hip", "acm_loss.hip", "acm_optim.hip", "acm_dropout.hip", "acm_proj.hip", "acm_reduce.hip", "acm_linear.hip", "acm_conv_acmii.hip", "acm_conv_agg16.hip", "acm_gemm_rows.hip", "acm_gemm_bx3.hip", "acm_conv_local16.hip", "acm_conv_acmii_v.hip", "acm_small.hip"]
+SOURCES = ["acm_csr.cpp", "acm_gemm.hip", "acm_conv.hip", "acm_conv_agg.hip", "acm_loss.hip", "acm_optim.hip", "acm_dropout.hip", "acm_proj.hip", "acm_reduce.hip", "acm_linear.hip", "acm_conv_acmii.hip", "acm_conv_agg16.hip", "acm_gemm_rows.hip", "acm_gemm_bx3.hip", "acm_conv_local16.hip", "acm_conv_acmii_v.hip", "acm_small.hip", "acm_conv_aggw.hip"]
 ARCH = "gfx950"
 # Per-source compiler switches.  acm_conv_acmii.hip reads every MFMA result on the VALU right away (ReLU + sum per edge):
 # with the results in AGPRs hipcc copies each of them through v_accvgpr_read (32 extra VALU instructions per 16 MFMAs and
@@ -35,7 +35,7 @@ def _hipcc():
 
 def _deps():
     out = [os.path.join(CSRC, s) for s in SOURCES]
-    out += [os.path.join(CSRC, "acm_common.h"), os.path.join(CSRC, "acm_conv_device.h"), os.path.join(CSRC, "acm_stream_device.h"), os.path.join(CSRC, "acm_rows16_device.h"), os.path.join(CSRC, "acm_adam_device.h"), os.path.join(CSRC, "acm_reduce_device.h"),
+    out += [os.path.join(CSRC, "acm_common.h"), os.path.join(CSRC, "acm_conv_device.h"), os.path.join(CSRC, "acm_stream_device.h"), os.path.join(CSRC, "acm_rows16_device.h"), os.path.join(CSRC, "acm_adam_device.h"), os.path.join(CSRC, "acm_bx3_device.h"), os.path.join(CSRC, "acm_reduce_device.h"),
             os.path.join(INCLUDE, "acm_hip.h")]
     return out
 

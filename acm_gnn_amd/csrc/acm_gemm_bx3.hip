@@ -22,37 +22,9 @@
 // columns c, c + 16, c + 32, c + 48 of a 64-column group -- the four words of ONE Philox call (acm_dropout.hip) -- sit in one
 // lane: lane (g, row m) loads the 16-byte pieces at columns 64 G + 16 q + 4 g (G = 0..1, q = 0..3).
 #include "acm_common.h"
+#include "acm_bx3_device.h"
 
 namespace {
-
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-
-__device__ __forceinline__ unsigned fbits(float x) { return __builtin_bit_cast(unsigned, x); }
-__device__ __forceinline__ float bitsf(unsigned x) { return __builtin_bit_cast(float, x); }
-// two fp32 -> their upper halves as one dword (element 2t in the low half)
-__device__ __forceinline__ unsigned pack_hi16(unsigned a, unsigned b) { return __builtin_amdgcn_perm(b, a, 0x07060302u); }
-
-// eight fp32 -> three vectors of eight bf16 (hi, mid, lo), x = hi + mid + lo exactly
-__device__ __forceinline__ void split3(const float (&x)[8], u32x4& hi, u32x4& mid, u32x4& lo) {
-#pragma unroll
-    for (int t = 0; t < 4; ++t) {
-        const float a = x[2 * t], b = x[2 * t + 1];
-        const float ra = a - bitsf(fbits(a) & 0xFFFF0000u), rb = b - bitsf(fbits(b) & 0xFFFF0000u);
-        const float sa = ra - bitsf(fbits(ra) & 0xFFFF0000u), sb = rb - bitsf(fbits(rb) & 0xFFFF0000u);
-        hi[t] = pack_hi16(fbits(a), fbits(b));
-        mid[t] = pack_hi16(fbits(ra), fbits(rb));
-        lo[t] = pack_hi16(fbits(sa), fbits(sb));
-    }
-}
-
-__device__ __forceinline__ f32x4 mma(u32x4 a, u32x4 b, f32x4 c) {
-    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
-}
-
-// column of X / row of W behind contraction slot (k block kb, lane group g, element e)
-__device__ __forceinline__ int bx3_k(int kb, int g, int e) { return 64 * (kb >> 1) + 16 * (2 * (kb & 1) + (e >> 2)) + 4 * g + (e & 3); }
 
 // Where the columns of the product come from and go to.  b1 != nullptr: B = [B0 0 | B1 0 | B2], three [K, f] matrices read in
 // place, the first two at a column pitch of fb >= f (zero columns between: acm_proj3).  split > 0: columns [0, split) to C,

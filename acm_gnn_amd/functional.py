@@ -2159,8 +2159,9 @@ def agg_wide_supported(x, ops, cfg, f_in, f_out, post_scale=None, call=None, tai
 class _AcmAggWide(torch.autograd.Function):
     """out, att = three-channel ACM layer in the aggregate-first form for a wide dense input (see agg_wide_supported).
 
-    forward : [acm_dropout] -> acm_spmm_ex (P = A_low Xd) -> 2 x acm_gemm ([P W_L | P W_H], [Xd W_H | Xd W_I]) -> acm_conv_head_fwd
-              (acm_conv_fwd's epilogue as a row-local kernel: pre_L = P W_L, pre_H = Xd W_H - P W_H)
+    forward : [acm_dropout] -> acm_spmm_ex (P = A_low Xd) -> acm_conv_aggw_fwd (projections on the split-bf16 matrix pipe + head,
+              one row-local kernel: pre_L = P W_L, pre_H = (Xd - P) W_H); with tuning rewrites bit 8 off: 2 x acm_gemm
+              ([P W_L | P W_H], [Xd W_H | Xd W_I]) -> acm_conv_head_fwd
     backward: acm_conv_bwd_local (K3) -> 2 x acm_gemm TN ([P^T G_L | P^T G_H], [Xd^T G_H | Xd^T G_I])"""
 
     @staticmethod
@@ -2185,11 +2186,6 @@ class _AcmAggWide(torch.autograd.Function):
             xd = x if fp == f_in else torch.nn.functional.pad(x, (0, fp - f_in))
         agg = spmm(ops.low, xd, row_scale=ops.row_scale if ops.implicit else None)          # P = A_low Xd  [n, fp]
         w3 = [_as_f32c(w, "weight") for w in (w_low, w_high, w_mlp)]
-        pad = (0, 0, 0, fp - f_in)
-        wa = torch.nn.functional.pad(torch.cat((w3[0], w3[1]), 1), pad) if fp != f_in else torch.cat((w3[0], w3[1]), 1)
-        wb = torch.nn.functional.pad(torch.cat((w3[1], w3[2]), 1), pad) if fp != f_in else torch.cat((w3[1], w3[2]), 1)
-        za = gemm(agg, wa)                         # [P W_L | P W_H]
-        zb = gemm(xd, wb)                          # [Xd W_H | Xd W_I]
         vecs = [_as_f32c(t, "att_vec") for t in (v_low, v_high, v_mlp)]
         lnw = [_as_f32c(t, "ln") for t in (lnw_low, lnw_high, lnw_mlp)] if cfg.layernorm else []
         lnb = [_as_f32c(t, "ln") for t in (lnb_low, lnb_high, lnb_mlp)] if cfg.layernorm else []
@@ -2205,10 +2201,6 @@ class _AcmAggWide(torch.autograd.Function):
         p.f_out, p.n_channels = f, k
         p.relu_after, p.relu_mlp, p.layernorm = int(cfg.relu_after), int(cfg.relu_mlp), int(cfg.layernorm)
         p.scale, p.row_offset = cfg.scale, ops.row_offset
-        p.g_low, p.ld_g_low = za.data_ptr(), za.stride(0)                 # "gathered" over I: pre_L = 1 * (P W_L)
-        p.g_high, p.ld_g_high = za.data_ptr() + 4 * f, za.stride(0)       #                    pre_H = Xd W_H - 1 * (P W_H)
-        p.s_high, p.ld_s_high = zb.data_ptr(), zb.stride(0)
-        p.s_mlp, p.ld_s_mlp = zb.data_ptr() + 4 * f, zb.stride(0)
         p.att_vec = _ptr_array(vecs)
         p.ln_weight, p.ln_bias = _ptr_array(lnw), _ptr_array(lnb)
         p.att_mix = mix.data_ptr()
@@ -2221,11 +2213,30 @@ class _AcmAggWide(torch.autograd.Function):
         dspec = _drop_spec(ctx.post_drop, ops.row_offset)
         if dspec is not None:
             p.post_drop = dspec
-        with _device_ctx(dev), _Timed(f"conv_head/F{f}k{k}"):           # the fused epilogue as a row-local kernel of its own
-            st = lib.acm_conv_head_fwd(n, C.byref(p), _stream())
-        _lib.check(st, "acm_conv_head_fwd")
+        same_pitch = w3[0].stride(0) == w3[1].stride(0) == w3[2].stride(0)
+        if (tuning.HOST.rewrites & tuning.REWRITE_AGGW_FUSED) and same_pitch:
+            # projections + head behind the gather as ONE row-local kernel: pre_L = P W_L, pre_H = (Xd - P) W_H, Z_I = Xd W_I
+            zi = torch.empty(n, f, dtype=_F32, device=dev)
+            with _device_ctx(dev), _Timed(f"conv_aggw/F{f}k{k}i{f_in}"):
+                st = lib.acm_conv_aggw_fwd(n, f_in, fp, _vp(agg), agg.stride(0), _vp(xd), xd.stride(0), _vp(w3[0]), _vp(w3[1]),
+                                           _vp(w3[2]), w3[0].stride(0), _vp(zi), zi.stride(0), C.byref(p), _stream())
+            _lib.check(st, "acm_conv_aggw_fwd")
+        else:
+            pad = (0, 0, 0, fp - f_in)
+            wa = torch.nn.functional.pad(torch.cat((w3[0], w3[1]), 1), pad) if fp != f_in else torch.cat((w3[0], w3[1]), 1)
+            wb = torch.nn.functional.pad(torch.cat((w3[1], w3[2]), 1), pad) if fp != f_in else torch.cat((w3[1], w3[2]), 1)
+            za = gemm(agg, wa)                         # [P W_L | P W_H]
+            zb = gemm(xd, wb)                          # [Xd W_H | Xd W_I]
+            zi = zb[:, f:]
+            p.g_low, p.ld_g_low = za.data_ptr(), za.stride(0)                 # "gathered" over I: pre_L = 1 * (P W_L)
+            p.g_high, p.ld_g_high = za.data_ptr() + 4 * f, za.stride(0)       #                    pre_H = Xd W_H - 1 * (P W_H)
+            p.s_high, p.ld_s_high = zb.data_ptr(), zb.stride(0)
+            p.s_mlp, p.ld_s_mlp = zb.data_ptr() + 4 * f, zb.stride(0)
+            with _device_ctx(dev), _Timed(f"conv_head/F{f}k{k}"):           # the fused epilogue as a row-local kernel of its own
+                st = lib.acm_conv_head_fwd(n, C.byref(p), _stream())
+            _lib.check(st, "acm_conv_head_fwd")
         ctx.ops, ctx.cfg, ctx.f_in, ctx.fp = ops, cfg, f_in, fp
-        ctx.save_for_backward(xd, agg, zb, pre, mix, *vecs, *lnw, *lnb)
+        ctx.save_for_backward(xd, agg, zi, pre, mix, *vecs, *lnw, *lnb)
         ctx.mark_non_differentiable(att)
         return out, att
 
@@ -2235,7 +2246,7 @@ class _AcmAggWide(torch.autograd.Function):
             return (None,) * 21
         lib = _lib.load()
         ops, cfg, f_in, fp = ctx.ops, ctx.cfg, ctx.f_in, ctx.fp
-        xd, agg, zb, pre, mix, *rest = ctx.saved_tensors
+        xd, agg, zi, pre, mix, *rest = ctx.saved_tensors
         k = 3
         vecs = rest[:k]
         lnw = rest[k:2 * k] if cfg.layernorm else []
@@ -2244,7 +2255,6 @@ class _AcmAggWide(torch.autograd.Function):
         f = pre.shape[1] // 2
         defer = ctx.call.defer
         grad_out = _as_f32c(grad_out, "grad_out")
-        zi = zb[:, f:]
         st3 = _k3_setup(cfg, ops, k, f, n, dev, f_in, pre, zi, vecs, lnw, lnb, mix, grad_out, ctx.post_relu, ctx.post_scale,
                         ctx.post_drop)
         q, flat, nw = st3["q"], st3["flat"], st3["nw"]

@@ -15,8 +15,10 @@ Kernel-level keys (acm_tuning_t; see the header for the values):
 Host-level keys:
     rewrites   bit mask of the algebraic rewrites of a first layer: 1 = aggregate-first ``A (X W) = (A X) W`` (ACM,
                acmsgc), 2 = ACMII recompute-on-gather, 4 = with 2, the mask form of it on the bf16 matrix pipe (forward and
-               weight gradients from V = masks^T inputs: acm_conv_acmii_v.hip).  Default 7; 0 = the literal form (project,
-               then gather 2F floats per edge) -- ``bench.py``'s ``literal_ms_per_step`` and the parity tests compare them
+               weight gradients from V = masks^T inputs: acm_conv_acmii_v.hip), 8 = with 1, for wide dense inputs
+               (16 < F_in <= 128) the projections and the head behind the gather as ONE kernel (acm_conv_aggw_fwd) instead of
+               two products + acm_conv_head_fwd.  Default 15; 0 = the literal form (project, then gather 2F floats per
+               edge) -- ``bench.py``'s ``literal_ms_per_step`` and the parity tests compare them
     implicit   1 = pattern-only operators where the filter allows (one 4-byte id stream, row scales in the epilogues);
                0 = always the explicit (id, value) form with an explicit transposed CSR.  Default 1
     relabel    in-operator degree relabelling: -1 = graphs of >= 32 768 nodes (default), 0 = never, 1 = always
@@ -41,13 +43,14 @@ import os
 import threading
 
 KERNEL_KEYS = ("chunk", "wide_form", "bwd_split", "rows16", "agg_fused", "gemm_forms")
-HOST_DEFAULTS = {"rewrites": 7, "implicit": 1, "relabel": -1, "pipeline": 8192, "csr_features": 256, "small_step": 16384}
-HOST_RANGES = {"rewrites": (0, 7), "implicit": (0, 1), "relabel": (-1, 1), "pipeline": (0, 1 << 31), "csr_features": (0, 1 << 31),
+HOST_DEFAULTS = {"rewrites": 15, "implicit": 1, "relabel": -1, "pipeline": 8192, "csr_features": 256, "small_step": 16384}
+HOST_RANGES = {"rewrites": (0, 15), "implicit": (0, 1), "relabel": (-1, 1), "pipeline": (0, 1 << 31), "csr_features": (0, 1 << 31),
                "small_step": (0, 16384)}
 
 REWRITE_AGG_FIRST = 1
 REWRITE_ACMII_RECOMPUTE = 2
 REWRITE_ACMII_MASK = 4
+REWRITE_AGGW_FUSED = 8
 ROWS16_EPI, ROWS16_BWD, ROWS16_LOCAL = 1, 2, 4
 GEMM_ROWS, GEMM_BX3, GEMM_BX3_WIDE, GEMM_ROWS_ALWAYS = 1, 2, 4, 8
 

@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define ACM_ABI_VERSION 25
+#define ACM_ABI_VERSION 26
 
 typedef enum {
     ACM_OK = 0,
@@ -484,6 +484,19 @@ int acm_conv_fwd(const acm_csr_t* a_low, const acm_conv_fwd_t* p,
  * (three channels of 64 fp32 columns, rows 16-byte aligned, no row_scale / deg).  Everything behind that -- ReLU,
  * LayerNorm, attention head, mixing, post-op, the outputs `out`, `pre`, `att` -- is acm_conv_fwd's, bit for bit. */
 int acm_conv_head_fwd(int64_t n_rows, const acm_conv_fwd_t* p, acm_stream_t stream);
+
+/* The wide aggregate-first layer behind its gather (ABI 26): from P = A_low Xd (`agg`) and the dropped input Xd (`xs`), both
+ * [n_rows, f_pad] fp32 with f_pad % 4 == 0, f_in <= f_pad <= 128 and 16-byte aligned rows whose pad columns are zero, and the
+ * three [f_in, 64] weight matrices (row pitch ld_w), ONE row-local kernel computes
+ *   pre_L = P W_L,   pre_H = (Xd - P) W_H,   Z_I = Xd W_I        (G:101-104 with A_low (X W) = (A_low X) W; fp32 numbers
+ *                                                                  split into three bf16 each, six products kept: fp32 accuracy)
+ * and acm_conv_fwd's epilogue on them.  Of `p` it reads the head (relu_after / relu_mlp / layernorm / scale, att_vec, ln_*,
+ * att_mix), the post-op and the outputs `out`, `pre` = [pre_L | pre_H] and `att`; Z_I goes to `zi` (the s_mlp of the layer's
+ * acm_conv_bwd_local).  f_out = 64, three channels; ACM_EUNSUPPORTED otherwise.  Replaces two acm_gemm calls and
+ * acm_conv_head_fwd (and 2 x 512 bytes per row written and read back between them). */
+int acm_conv_aggw_fwd(int64_t n_rows, int64_t f_in, int64_t f_pad, const float* agg, int64_t ld_agg, const float* xs,
+                      int64_t ld_xs, const float* w_low, const float* w_high, const float* w_mlp, int64_t ld_w,
+                      float* zi, int64_t ld_zi, const acm_conv_fwd_t* p, acm_stream_t stream);
 
 /* ------------------------------------------- backward, row-local part (K3) --
  * From grad_out and the saved pre-activations recompute the attention head and

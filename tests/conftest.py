@@ -84,10 +84,11 @@ def golden_dir():
 def tune_now(**kw):
     """``tune_now(agg_first=0, rows16=5, ...)``: set tuning switches (acm_gnn_amd.tuning: the host record and the library's
     acm_tuning_t) for the rest of the running test -- the autouse guard below restores both records afterwards.  Besides
-    the real keys it takes three conveniences: ``agg_first`` / ``acmii_recompute`` / ``acmii_mask`` = bits 1 / 2 / 4 of ``rewrites``."""
+    the real keys it takes four conveniences: ``agg_first`` / ``acmii_recompute`` / ``acmii_mask`` / ``aggw_fused`` = bits 1 / 2 / 4 / 8 of
+    ``rewrites``."""
     from acm_gnn_amd import tuning
     bits = {"agg_first": tuning.REWRITE_AGG_FIRST, "acmii_recompute": tuning.REWRITE_ACMII_RECOMPUTE,
-            "acmii_mask": tuning.REWRITE_ACMII_MASK}
+            "acmii_mask": tuning.REWRITE_ACMII_MASK, "aggw_fused": tuning.REWRITE_AGGW_FUSED}
     rew = tuning.HOST.rewrites
     for name, bit in bits.items():
         if name in kw:

@@ -781,6 +781,29 @@ class FakeLib:
         finally:
             self._handles.pop(h, None)
 
+    def acm_conv_aggw_fwd(self, n, f_in, f_pad, agg, ld_agg, xs, ld_xs, wl, wh, wm, ld_w, zi, ld_zi, pp, stream):
+        """pre_L = P W_L, pre_H = (Xd - P) W_H, Z_I = Xd W_I (float64 products, stored fp32), then acm_conv_fwd's epilogue."""
+        p = pp._obj
+        F = p.f_out
+        if F != 64 or p.n_channels != 3 or not 0 < f_in <= f_pad <= 128 or f_pad % 4:
+            self._err = b"acm_conv_aggw_fwd: unsupported shape"
+            return 4
+        P = _view(agg, n, f_in, ld_agg).astype(np.float64)
+        X = _view(xs, n, f_in, ld_xs).astype(np.float64)
+        W = [_view(w, f_in, F, ld_w).astype(np.float64) for w in (wl, wh, wm)]
+        zl = (P @ W[0]).astype(np.float32)
+        zh = ((X - P) @ W[1]).astype(np.float32)
+        z_i = (X @ W[2]).astype(np.float32)
+        _view(zi, n, F, ld_zi)[...] = z_i
+        zero = np.zeros((n, F), np.float32)
+        q = type(p).from_buffer_copy(p)                       # the head over the identity: pre_L = zl, pre_H = zh - 0, Z_I
+        q.g_low, q.ld_g_low = zl.ctypes.data, F
+        q.g_high, q.ld_g_high = zero.ctypes.data, F
+        q.s_high, q.ld_s_high = zh.ctypes.data, F
+        q.s_mlp, q.ld_s_mlp = z_i.ctypes.data, F
+        q.row_scale = None
+        return FakeLib.acm_conv_head_fwd(self, n, C.byref(q), stream)      # (the class's own: tests wrap the instance's entry points)
+
     def acm_conv_bwd_local(self, n, qq, ws, wsb, stream):
         q = qq._obj
         F, k = q.f_out, q.n_channels

@@ -146,7 +146,7 @@ def test_acm_tuning_variable_is_read_once_at_load(tmp_path):
     assert tuning.parse("rows16=5, rewrites=0") == ({"rows16": 5}, {"rewrites": 0})
     with tuning.override(rewrites=0, implicit=0):
         assert (tuning.HOST.rewrites, tuning.HOST.implicit) == (0, 0)
-    assert (tuning.HOST.rewrites, tuning.HOST.implicit) == (7, 1)
+    assert (tuning.HOST.rewrites, tuning.HOST.implicit) == (15, 1)
 
 
 def test_header_is_plain_c():

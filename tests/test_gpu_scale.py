@@ -257,11 +257,14 @@ def test_rows_times_pitch_beyond_2_31_takes_the_64_bit_kernels_or_fails_loudly()
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("fused", [True, False], ids=["one_kernel", "products_then_head"])
 @pytest.mark.parametrize("model_type,f_in,p_drop,ln", [("acmgcnp", 128, 0.3, True), ("acmgcn", 65, 0.0, False), ("acmgcnp", 40, 0.2, True)])
-def test_aggregate_first_for_wide_inputs_matches_the_literal_form_and_the_oracle(model_type, f_in, p_drop, ln, tune):
+def test_aggregate_first_for_wide_inputs_matches_the_literal_form_and_the_oracle(model_type, f_in, p_drop, ln, fused, tune):
     """functional._AcmAggWide (round 5): first layers with 16 < F_in <= 128 dense features (arXiv-year 128, pokec 65) gather
     P = A_low drop(X) once and run no transposed gather in the backward.  Logits, loss and every gradient against the literal
-    form (tuning rewrites bit 1 off) at fp32 re-association level, and the logits against the oracle on sampled rows."""
+    form (tuning rewrites bit 1 off) at fp32 re-association level, and the logits against the oracle on sampled rows.
+    ``fused``: projections + head behind the gather as ONE kernel (acm_conv_aggw_fwd: split-bf16 MFMA products feeding the
+    sixteen-rows head in registers) or as two products + acm_conv_head_fwd (tuning rewrites bit 8 off)."""
     import scipy.sparse as sp
     from acm_gnn_amd import GCN, data as D, functional as AF, train as T
     from acm_gnn_amd.distributed import make_sharded_operators
@@ -281,7 +284,7 @@ def test_aggregate_first_for_wide_inputs_matches_the_literal_form_and_the_oracle
     w = T.row_weights(torch.arange(0, n, 2, device=DEV), n)
 
     def run(agg):
-        tune(agg_first=int(agg))
+        tune(agg_first=int(agg), aggw_fused=int(fused))
         torch.manual_seed(3)
         model = GCN(f_in, 64, 4, 2, n, p_drop, model_type, 0, variant=False, attn_layernorm=ln).to(DEV)
         model.train()
@@ -298,7 +301,8 @@ def test_aggregate_first_for_wide_inputs_matches_the_literal_form_and_the_oracle
 
     ma, out_a, loss_a, g_a, lab_a = run(True)
     mb, out_b, loss_b, g_b, lab_b = run(False)
-    assert any(k.startswith("conv_head/") for k in lab_a) and not any(k.startswith("conv_head/") for k in lab_b)
+    assert any(k.startswith("conv_aggw/" if fused else "conv_head/") for k in lab_a), lab_a
+    assert not any(k.startswith(("conv_head/", "conv_aggw/")) for k in lab_b)
     assert sum(k.startswith("conv_bwd_spmm/") for k in lab_a) == 1 and sum(k.startswith("conv_bwd_spmm/") for k in lab_b) == 2
     scale = float(out_b.abs().max())
     assert float((out_a - out_b).abs().max()) <= 2e-5 * scale + 1e-6
@@ -319,3 +323,73 @@ def test_aggregate_first_for_wide_inputs_matches_the_literal_form_and_the_oracle
                                      torch.from_numpy(hi_sp.data.astype(np.float32)), size=low.shape)
         ref = O.gcn_forward(params, x.cpu(), lo, hi, None, model_type=model_type, variant=False, structure_info=0, attn_layernorm=ln)
         assert float((got - ref).abs().max()) <= 1e-4 * float(ref.abs().max()) + 1e-5
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,f_in,ln,relu_after,post", [(4099, 128, True, True, "drop"), (1000, 65, False, True, "scale"), (37, 20, True, False, None),
+                                                       (20000, 100, True, True, None)])
+def test_wide_aggregate_first_kernel_against_float64(n, f_in, ln, relu_after, post):
+    """acm_conv_aggw_fwd through the C ABI on random rows: pre_L = P W_L, pre_H = (Xd - P) W_H, Z_I = Xd W_I at fp32 accuracy
+    (float64 products as the referee: the split-bf16 products keep six of nine partial products), then the head of
+    acm_conv_head_fwd on the SAME pre-activations (the stored ones), so that the head is compared at fp32 re-association level
+    whatever the ReLU does to entries near zero.  Ragged row counts, padded F_in, post-op forms."""
+    import ctypes as C
+    from acm_gnn_amd import _lib, functional as AF
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(n + f_in)
+    fp = -(-f_in // 4) * 4
+    P = torch.zeros(n, fp)
+    X = torch.zeros(n, fp)
+    P[:, :f_in] = torch.randn(n, f_in, generator=g)
+    X[:, :f_in] = torch.randn(n, f_in, generator=g)
+    W = [torch.randn(f_in, 64, generator=g) * 0.2 for _ in range(3)]
+    vecs = [torch.randn(64, generator=g) for _ in range(3)]
+    lnw = [torch.rand(64, generator=g) + 0.5 for _ in range(3)]
+    lnb = [torch.randn(64, generator=g) * 0.1 for _ in range(3)]
+    mix = torch.randn(3, 3, generator=g)
+    dev = lambda t: t.to(DEV).contiguous()
+    Pd, Xd, Wd, vd, lwd, lbd, mixd = dev(P), dev(X), [dev(w) for w in W], [dev(v) for v in vecs], [dev(t) for t in lnw], \
+        [dev(t) for t in lnb], dev(mix)
+    keep = dev((torch.rand(n, 64, generator=g) > 0.3).float() / 0.7) if post == "scale" else None
+    state = AF.DropoutState(torch.device(DEV), seed=5) if post == "drop" else None
+
+    def block(out, pre, att):
+        p = _lib.ConvFwd()
+        p.f_out, p.n_channels, p.relu_after, p.relu_mlp, p.layernorm, p.scale = 64, 3, int(relu_after), 1, int(ln), 3.0
+        p.att_vec = AF._ptr_array(vd)
+        if ln:
+            p.ln_weight, p.ln_bias = AF._ptr_array(lwd), AF._ptr_array(lbd)
+        p.att_mix = mixd.data_ptr()
+        p.out, p.ld_out, p.pre, p.ld_pre, p.att = out.data_ptr(), 64, pre.data_ptr(), 128, att.data_ptr()
+        p.post_relu = 1
+        if keep is not None:
+            p.post_scale, p.ld_post_scale = keep.data_ptr(), 64
+        if state is not None:
+            p.post_drop = AF._drop_spec((0.4, 1, state), 0)
+        return p
+    out, pre, att = torch.empty(n, 64, device=DEV), torch.empty(n, 128, device=DEV), torch.empty(n, 4, device=DEV)
+    zi = torch.empty(n, 64, device=DEV)
+    p = block(out, pre, att)
+    st = lib.acm_conv_aggw_fwd(n, f_in, fp, Pd.data_ptr(), fp, Xd.data_ptr(), fp, Wd[0].data_ptr(), Wd[1].data_ptr(), Wd[2].data_ptr(),
+                               64, zi.data_ptr(), 64, C.byref(p), AF._stream())
+    _lib.check(st, "acm_conv_aggw_fwd")
+    torch.cuda.synchronize()
+    P64, X64, W64 = P[:, :f_in].double(), X[:, :f_in].double(), [w.double() for w in W]
+    want = [P64 @ W64[0], (X64 - P64) @ W64[1], X64 @ W64[2]]
+    got = [pre[:, :64].cpu().double(), pre[:, 64:].cpu().double(), zi.cpu().double()]
+    for wv, gv, name in zip(want, got, ("pre_L", "pre_H", "Z_I")):
+        # an fp32 FMA chain over K terms errs by ~K eps |terms|: the split products must stay inside that
+        bound = 4e-7 * float((P64.abs() + X64.abs()).max() * max(w.abs().max() for w in W64)) * f_in
+        assert float((wv - gv).abs().max()) <= bound, (name, float((wv - gv).abs().max()), bound)
+    # the head on the stored pre-activations: acm_conv_head_fwd (g_low = pre_L, s_high - g_high = pre_H - 0, s_mlp = Z_I)
+    out2, pre2, att2 = torch.empty_like(out), torch.empty_like(pre), torch.empty_like(att)
+    zero = torch.zeros(n, 64, device=DEV)
+    q = block(out2, pre2, att2)
+    q.g_low, q.ld_g_low, q.g_high, q.ld_g_high = pre.data_ptr(), 128, zero.data_ptr(), 64
+    q.s_high, q.ld_s_high, q.s_mlp, q.ld_s_mlp = pre.data_ptr() + 256, 128, zi.data_ptr(), 64
+    _lib.check(lib.acm_conv_head_fwd(n, C.byref(q), AF._stream()), "acm_conv_head_fwd")
+    torch.cuda.synchronize()
+    assert torch.equal(pre2, pre)
+    torch.testing.assert_close(att, att2, rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(out, out2, rtol=2e-5, atol=2e-6 * float(out2.abs().max()))
+    assert (out2 == 0).float().mean() < 0.9 and torch.isfinite(out).all()

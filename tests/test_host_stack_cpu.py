@@ -1439,23 +1439,25 @@ def test_small_graph_step_host_path_equals_the_general_path(model_type, s, varia
     assert "optimizer" in SmallPlan.why_not(ma, xs, ops, torch.optim.Adam(ma.parameters()))
 
 
+@pytest.mark.parametrize("fused", [True, False], ids=["one_kernel", "products_then_head"])
 @pytest.mark.parametrize("model_type,f_in,p_drop,ln", [("acmgcnp", 128, 0.4, True), ("acmgcn", 65, 0.0, False), ("acmgcnp", 40, 0.3, True)])
-def test_aggregate_first_for_wide_dense_inputs_equals_the_literal_form(model_type, f_in, p_drop, ln, monkeypatch, tune):
+def test_aggregate_first_for_wide_dense_inputs_equals_the_literal_form(model_type, f_in, p_drop, ln, fused, monkeypatch, tune):
     """Round 5 (functional._AcmAggWide): a first layer with 16 < F_in <= 128 dense features, no ReLU before the filter and an
     input that takes no gradient gathers P = A_low drop(X) once (F_in floats per edge instead of 2 F) and needs NO transposed
     gather in its backward: dW_L = P^T G_L, dW_H = X^T G_H - P^T G_H, dW_I = X^T G_I.  Same logits and gradients as the
-    literal project-then-gather form (tuning rewrites bit 1 off); F_in that is no multiple of 4 is padded (pokec: 65)."""
+    literal project-then-gather form (tuning rewrites bit 1 off); F_in that is no multiple of 4 is padded (pokec: 65).
+    ``fused``: projections + head behind the gather as one call (acm_conv_aggw_fwd, rewrites bit 8) or two products + the head."""
     fake = fake_lib.install(monkeypatch)
     from acm_gnn_amd import GCN, functional as AF
     ops, n = _dense_graph_ops(n=8192, avg=30, seed=3)          # (the form is taken from a mean degree of 12 on)
     x = torch.randn(n, f_in, generator=torch.Generator().manual_seed(2))
     calls = []
-    for name in ("acm_conv_bwd_spmm", "acm_spmm_ex", "acm_spmm"):
+    for name in ("acm_conv_bwd_spmm", "acm_spmm_ex", "acm_spmm", "acm_conv_aggw_fwd", "acm_conv_head_fwd"):
         orig = getattr(fake, name)
         monkeypatch.setattr(fake, name, (lambda o, nm: lambda *a: (calls.append(nm), o(*a))[1])(orig, name))
 
     def run(agg):
-        tune(agg_first=int(agg))
+        tune(agg_first=int(agg), aggw_fused=int(fused))
         calls.clear()
         torch.manual_seed(4)
         model = GCN(f_in, 64, 3, 2, n, p_drop, model_type, 0, variant=0, attn_layernorm=ln)
@@ -1471,6 +1473,7 @@ def test_aggregate_first_for_wide_dense_inputs_equals_the_literal_form(model_typ
     # one gather forward for the first layer, none backward (the output layer keeps its two)
     assert calls_a.count("acm_conv_bwd_spmm") == 1 and calls_b.count("acm_conv_bwd_spmm") == 2, (calls_a, calls_b)
     assert len([c for c in calls_a if c.startswith("acm_spmm")]) == 1
+    assert (calls_a.count("acm_conv_aggw_fwd"), calls_a.count("acm_conv_head_fwd")) == ((1, 0) if fused else (0, 1))
     torch.testing.assert_close(out_a, out_b, rtol=1e-5, atol=1e-5 * float(out_b.abs().max()))
     assert g_a.keys() == g_b.keys()
     for k in g_a:
