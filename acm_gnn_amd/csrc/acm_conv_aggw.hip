@@ -22,29 +22,46 @@ constexpr int AW_TILES = 12;              // 3 channels x 4 column tiles of 16
 // first column of X behind k block kb (see bx3_k: kb 0, 1 -> columns 0..63, kb 2, 3 -> 64..127)
 __device__ __forceinline__ int aw_kb_first(int kb) { return 64 * (kb >> 1) + 32 * (kb & 1); }
 
-template <bool LN>
+template <bool LN, int NKB>
 __global__ __launch_bounds__(512, 2) void aggw_head_kernel(int n_rows, int K, int f_in, const float* __restrict__ agg, long ld_agg,
                                                            const float* __restrict__ xs, long ld_xs, const float* __restrict__ w_low,
                                                            const float* __restrict__ w_high, const float* __restrict__ w_mlp, long ld_w,
-                                                           float* __restrict__ zi, long ld_zi, int n_kb, acm_conv_fwd_t p) {
+                                                           float* __restrict__ zi, long ld_zi, acm_conv_fwd_t p) {
+    constexpr int n_kb = NKB;                      // k blocks of 32 input columns in use (compile time: every LDS operand read is
+                                                   // one base register + an immediate offset)
     extern __shared__ __attribute__((aligned(16))) u32x4 Ws[];       // [part 3][tile 12][kb n_kb][lane 64] | u[3][64] floats
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, m = lane & 15, g = lane >> 4;
     float* ulds = reinterpret_cast<float*>(Ws + 3 * AW_TILES * n_kb * 64);
-    // W_c^T as A operands: lane (gi, i) of tile j = 4 c + t, k block kb holds W_c[bx3_k(kb, gi, e)][16 t + i], e = 0..7
-    for (int idx = threadIdx.x; idx < AW_TILES * n_kb * 64; idx += 512) {
-        const int ln = idx & 63, kb = (idx >> 6) % n_kb, j = (idx >> 6) / n_kb, gi = ln >> 4, col = 16 * (j & 3) + (ln & 15);
-        const float* w = (j >> 2) == 0 ? w_low : ((j >> 2) == 1 ? w_high : w_mlp);
-        float w8[8];
+    // W_c^T as A operands: lane (gi, i) of tile j = 4 c + t, k block kb holds W_c[bx3_k(kb, gi, e)][16 t + i], e = 0..7.
+    // Every load of the block is in flight before the first split (unconditional loads from a clamped row: a guarded load
+    // makes the compiler wait for each one -- 48 dependent round trips before the first row panel).
+    {
+        constexpr int WIT = (AW_TILES * NKB * 64 + 511) / 512;
+        float wst[WIT][8];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            const int kr = bx3_k(kb, gi, e);
-            w8[e] = kr < f_in ? w[(long)kr * ld_w + col] : 0.f;
+        for (int it = 0; it < WIT; ++it) {
+            const int idx = min((int)threadIdx.x + 512 * it, AW_TILES * NKB * 64 - 1);
+            const int ln = idx & 63, kb = (idx >> 6) % NKB, j = (idx >> 6) / NKB, gi = ln >> 4, col = 16 * (j & 3) + (ln & 15);
+            const float* w = (j >> 2) == 0 ? w_low : ((j >> 2) == 1 ? w_high : w_mlp);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int kr = bx3_k(kb, gi, e);
+                const float v = w[(long)min(kr, f_in - 1) * ld_w + col];
+                wst[it][e] = kr < f_in ? v : 0.f;
+            }
         }
-        u32x4 h, mdl, l;
-        split3(w8, h, mdl, l);
-        Ws[((0 * AW_TILES + j) * n_kb + kb) * 64 + ln] = h;
-        Ws[((1 * AW_TILES + j) * n_kb + kb) * 64 + ln] = mdl;
-        Ws[((2 * AW_TILES + j) * n_kb + kb) * 64 + ln] = l;
+#pragma unroll
+        for (int it = 0; it < WIT; ++it) {
+            const int idx = threadIdx.x + 512 * it;
+            const int ln = idx & 63, kb = (idx >> 6) % NKB, j = (idx >> 6) / NKB;
+            u32x4 h, mdl, l;
+            split3(wst[it], h, mdl, l);
+            if (idx < AW_TILES * NKB * 64) {
+                Ws[((0 * AW_TILES + j) * NKB + kb) * 64 + ln] = h;
+                Ws[((1 * AW_TILES + j) * NKB + kb) * 64 + ln] = mdl;
+                Ws[((2 * AW_TILES + j) * NKB + kb) * 64 + ln] = l;
+            }
+        }
     }
     // u_c = gamma_c (.) att_vec_c (LayerNorm folded into the attention vector, as in acm_conv_agg16.hip)
 #pragma unroll
@@ -67,22 +84,26 @@ __global__ __launch_bounds__(512, 2) void aggw_head_kernel(int n_rows, int K, in
     const int npan = (n_rows + 15) / 16, stride = gridDim.x * 8;
 
     f32x4 nP[2][4], nX[2][4];
-    auto fetch = [&](int pan) {
+    // half G of a panel's rows: columns 64 G .. 64 G + 63 (k blocks 2 G, 2 G + 1)
+    auto fetch_half = [&](int pan, int G) {
         int row = pan * 16 + m;
         row = row < n_rows ? row : n_rows - 1;                        // (results of such rows are not stored)
-        const float* ap = agg + (long)row * ld_agg + 4 * g;
-        const float* xp = xs + (long)row * ld_xs + 4 * g;
+        const float* ap = agg + (long)row * ld_agg;
+        const float* xp = xs + (long)row * ld_xs;
 #pragma unroll
-        for (int G = 0; G < 2; ++G)
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const bool in = 64 * G + 16 * q + 4 * g < K;
-                nP[G][q] = in ? *reinterpret_cast<const f32x4*>(ap + 64 * G + 16 * q) : (f32x4){0.f, 0.f, 0.f, 0.f};
-                nX[G][q] = in ? *reinterpret_cast<const f32x4*>(xp + 64 * G + 16 * q) : (f32x4){0.f, 0.f, 0.f, 0.f};
-            }
+        for (int q = 0; q < 4; ++q) {
+            // (pad columns beyond K are never multiplied by a nonzero weight row: they are read from the last valid
+            //  16-byte block instead of being branched around)
+            const int off = min(64 * G + 16 * q + 4 * g, K - 4);
+            nP[G][q] = *reinterpret_cast<const f32x4*>(ap + off);
+            nX[G][q] = *reinterpret_cast<const f32x4*>(xp + off);
+        }
     };
     int pan = blockIdx.x * 8 + wv;
-    if (pan < npan) fetch(pan);
+    if (pan < npan) {
+        fetch_half(pan, 0);
+        if (NKB > 2) fetch_half(pan, 1);
+    }
     __syncthreads();                               // W and u are in LDS
     for (; pan < npan; pan += stride) {
         f32x4 D[3][4];
@@ -92,7 +113,7 @@ __global__ __launch_bounds__(512, 2) void aggw_head_kernel(int n_rows, int K, in
             for (int t = 0; t < 4; ++t) D[c][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int kb = 0; kb < 4; ++kb) {
-            if (aw_kb_first(kb) >= K) continue;                      // (uniform)
+            if (kb >= NKB) continue;
             // operands of the three channels: P, Xd - P, Xd
             u32x4 oh[3], om[3], ol[3];
             {
@@ -137,11 +158,11 @@ __global__ __launch_bounds__(512, 2) void aggw_head_kernel(int n_rows, int K, in
                 D[c][t1] = mma(bh, om[c], D[c][t1]);
                 D[c][t0] = mma(ah, oh[c], D[c][t0]);
                 D[c][t1] = mma(bh, oh[c], D[c][t1]);
-                __builtin_amdgcn_sched_barrier(0);
             }
+            // the half of the operand rows that has just been consumed is requested for the NEXT panel at once: those loads
+            // travel during the rest of this panel's products and its head (one register set, not two)
+            if (kb == 1 || kb == NKB - 1) fetch_half(pan + stride < npan ? pan + stride : pan, kb >> 1);
         }
-        // the next panel's rows travel during this one's head (the operand registers are free again: one set, not two)
-        fetch(pan + stride < npan ? pan + stride : pan);
         const int row = pan * 16 + m;
         const bool valid = row < n_rows;
         const long rr = valid ? row : n_rows - 1;
@@ -270,15 +291,26 @@ extern "C" int acm_conv_aggw_fwd(int64_t n_rows, int64_t f_in, int64_t f_pad, co
     const int64_t npan = (n_rows + 15) / 16;
     int grid = (int)((npan + 7) / 8);
     if (grid > 256) grid = 256;
-    if (p->layernorm) {
-        ACM_CHECK_HIP(hipFuncSetAttribute((const void*)aggw_head_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL((aggw_head_kernel<true>), dim3(grid), dim3(512), lds, st, (int)n_rows, (int)f_pad, (int)f_in, agg, (long)ld_agg,
-                           xs, (long)ld_xs, w_low, w_high, w_mlp, (long)ld_w, zi, (long)ld_zi, n_kb, *p);
-    } else {
-        ACM_CHECK_HIP(hipFuncSetAttribute((const void*)aggw_head_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL((aggw_head_kernel<false>), dim3(grid), dim3(512), lds, st, (int)n_rows, (int)f_pad, (int)f_in, agg, (long)ld_agg,
-                           xs, (long)ld_xs, w_low, w_high, w_mlp, (long)ld_w, zi, (long)ld_zi, n_kb, *p);
+#define ACM_AGGW(LNv, KBv)                                                                                                        \
+    do {                                                                                                                          \
+        ACM_CHECK_HIP(hipFuncSetAttribute((const void*)aggw_head_kernel<LNv, KBv>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+        hipLaunchKernelGGL((aggw_head_kernel<LNv, KBv>), dim3(grid), dim3(512), lds, st, (int)n_rows, (int)f_pad, (int)f_in, agg,      \
+                           (long)ld_agg, xs, (long)ld_xs, w_low, w_high, w_mlp, (long)ld_w, zi, (long)ld_zi, *p);                   \
+    } while (0)
+#define ACM_AGGW_KB(LNv)                    \
+    switch (n_kb) {                         \
+        case 1: ACM_AGGW(LNv, 1); break;    \
+        case 2: ACM_AGGW(LNv, 2); break;    \
+        case 3: ACM_AGGW(LNv, 3); break;    \
+        default: ACM_AGGW(LNv, 4); break;   \
     }
+    if (p->layernorm) {
+        ACM_AGGW_KB(true)
+    } else {
+        ACM_AGGW_KB(false)
+    }
+#undef ACM_AGGW_KB
+#undef ACM_AGGW
     ACM_CHECK_HIP(hipGetLastError());
     return ACM_OK;
 }
