@@ -2144,7 +2144,9 @@ def agg_wide_supported(x, ops, cfg, f_in, f_out, post_scale=None, call=None, tai
         return False
     if not isinstance(x, torch.Tensor) or x.layout != torch.strided or x.dim() != 2 or x.dtype != _F32 or x.requires_grad:
         return False
-    if cfg.relu_before or cfg.n_channels != 3 or cfg.gather_bf16 or f_out != 64 or not 16 < f_in <= 128 or x.shape[1] != f_in:
+    # (gather_dtype="bf16" takes this form too: its ONE gather reads the fp32 input, F_in x 4 bytes per edge -- no more than the
+    #  2 F x 2 bytes of the literal form's bf16 tables, and exact)
+    if cfg.relu_before or cfg.n_channels != 3 or f_out != 64 or not 16 < f_in <= 128 or x.shape[1] != f_in:
         return False
     if ops.sharded or getattr(ops, "general", False) or int(getattr(ops, "hops", 1)) != 1 or x.shape[0] != ops.n_local:
         return False

@@ -327,7 +327,8 @@ def test_aggregate_first_for_wide_inputs_matches_the_literal_form_and_the_oracle
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("n,f_in,ln,relu_after,post", [(4099, 128, True, True, "drop"), (1000, 65, False, True, "scale"), (37, 20, True, False, None),
-                                                       (20000, 100, True, True, None)])
+                                                       (20000, 100, True, True, None), (257, 5, True, True, None),
+                                                       (64, 16, False, True, "drop"), (1, 33, True, True, None)])
 def test_wide_aggregate_first_kernel_against_float64(n, f_in, ln, relu_after, post):
     """acm_conv_aggw_fwd through the C ABI on random rows: pre_L = P W_L, pre_H = (Xd - P) W_H, Z_I = Xd W_I at fp32 accuracy
     (float64 products as the referee: the split-bf16 products keep six of nine partial products), then the head of
