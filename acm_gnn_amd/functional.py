@@ -2138,7 +2138,8 @@ def agg_wide_supported(x, ops, cfg, f_in, f_out, post_scale=None, call=None, tai
     hidden): without a ReLU between projection and filter, A (X W) = (A X) W.  P = A_low drop(X) is ONE gather of F_in floats
     per edge (the literal form gathers 2 F = 128), and because the input takes no gradient the backward needs NO transposed
     gather at all:  dW_L = P^T G_L,  dW_H = X^T G_H - P^T G_H,  dW_I = X^T G_I  -- three tall-skinny products on the split-bf16
-    matrix pipe.  Three-channel ACM / acmsgc layers on one device; tuning rewrites bit 1 switches it off."""
+    matrix pipe.  Three-channel ACM layers; row-sharded: the ONE halo exchange of the layer is the all-gather of the dropped
+    F_in-wide input rows (the literal form all-gathers 2 F-wide rows forward AND backward); tuning rewrites bit 1 switches it off."""
     from .graph import FilterOperators
     if not (tuning.HOST.rewrites & tuning.REWRITE_AGG_FIRST) or not isinstance(ops, FilterOperators):
         return False
@@ -2148,9 +2149,17 @@ def agg_wide_supported(x, ops, cfg, f_in, f_out, post_scale=None, call=None, tai
     #  2 F x 2 bytes of the literal form's bf16 tables, and exact)
     if cfg.relu_before or cfg.n_channels != 3 or f_out != 64 or not 16 < f_in <= 128 or x.shape[1] != f_in:
         return False
-    if ops.sharded or getattr(ops, "general", False) or int(getattr(ops, "hops", 1)) != 1 or x.shape[0] != ops.n_local:
+    if getattr(ops, "general", False) or int(getattr(ops, "hops", 1)) != 1 or x.shape[0] != ops.n_local:
         return False
-    if x.shape[0] < 8192 or tail_layer:
+    if tail_layer:
+        return False
+    if ops.sharded:
+        # every rank must take the same form (its collectives differ from the literal form's): decided by what all ranks know,
+        # the longest row block of the plan -- and row-sharded the rewrite pays at any degree (one F_in-wide halo exchange
+        # instead of two 2 F-wide ones)
+        import torch.distributed as dist
+        return ops.n_gathered // dist.get_world_size(ops.group) >= 8192
+    if x.shape[0] < 8192:
         return False
     # Where it pays (measured, profiles/r05_agg_wide.txt): the rewrite trades 4 F - F_in gathered floats per EDGE for one more
     # pass over ~3 KB per ROW (the dropped copy of X, the head as its own launch, a third more projection flops).  pokec-shaped
@@ -2186,7 +2195,8 @@ class _AcmAggWide(torch.autograd.Function):
             _lib.check(st, "acm_dropout")
         else:
             xd = x if fp == f_in else torch.nn.functional.pad(x, (0, fp - f_in))
-        agg = spmm(ops.low, xd, row_scale=ops.row_scale if ops.implicit else None)          # P = A_low Xd  [n, fp]
+        # P = A_low Xd  [n, fp]; row-sharded: the operator's columns are the all-gathered rows (the layer's only halo exchange)
+        agg = spmm(ops.low, _gather_rows(ops, xd), row_scale=ops.row_scale if ops.implicit else None)
         w3 = [_as_f32c(w, "weight") for w in (w_low, w_high, w_mlp)]
         vecs = [_as_f32c(t, "att_vec") for t in (v_low, v_high, v_mlp)]
         lnw = [_as_f32c(t, "ln") for t in (lnw_low, lnw_high, lnw_mlp)] if cfg.layernorm else []
@@ -2280,9 +2290,23 @@ class _AcmAggWide(torch.autograd.Function):
         del st3
         a1 = gemm(agg, gcat[:, : 2 * f], trans_a=True, col_blocks=2)          # [P^T G_L | P^T G_H]   as [2, fp, f]
         a2 = gemm(xd, gcat[:, f:], trans_a=True, col_blocks=2)                # [Xd^T G_H | Xd^T G_I]
-        d_wl = a1[0][:f_in]
-        d_wh = (a2[0] - a1[1])[:f_in]
-        d_wm = a2[1][:f_in]
+        if ops.sharded:
+            # replicated parameters: the weight gradients join the head's in the layer's flat buffer, ONE all-reduce sums the
+            # row-shard partials (after the step's single flush when the second phases are deferred)
+            import torch.distributed as dist
+            dw = flat[:nw].view(3, f_in, f)
+            dw[0].copy_(a1[0][:f_in])
+            torch.sub(a2[0][:f_in], a1[1][:f_in], out=dw[1])
+            dw[2].copy_(a2[1][:f_in])
+            d_wl, d_wh, d_wm = dw[0], dw[1], dw[2]
+            if defer is not None:
+                defer.allreduce(flat, ops.group)
+            else:
+                dist.all_reduce(flat, group=ops.group)
+        else:
+            d_wl = a1[0][:f_in]
+            d_wh = (a2[0] - a1[1])[:f_in]
+            d_wm = a2[1][:f_in]
         none3 = [None] * 3
         return (None, d_wl, d_wh, d_wm, d_vec[0], d_vec[1], d_vec[2], d_mix,
                 *(d_lnw if cfg.layernorm else none3), *(d_lnb if cfg.layernorm else none3), None, None, None, None, None, None, None)

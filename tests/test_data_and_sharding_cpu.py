@@ -162,6 +162,31 @@ def _free_port():
     return p
 
 
+def _lib_now():
+    from acm_gnn_amd import _lib
+    return _lib.load()
+
+
+def _case_dataset(cfg, world):
+    """(adj, x, y, train idx) of a sharding case: the tiny graph (7 features), or -- ``wide=F_in`` -- a random graph with 8 192
+    rows per rank, mean degree 24 and F_in dense features: the regime of the wide aggregate-first layer (functional._AcmAggWide)."""
+    from acm_gnn_amd import data as D
+    if not cfg.get("wide"):
+        adj, x_np, y_np, (tr, _, _), _ = D.synthetic_dataset("tiny", seed=5, pad_to=world)
+        return adj, x_np, y_np, tr
+    import scipy.sparse as sp
+    n, rng = 8192 * world, np.random.default_rng(11)
+    m = n * 12
+    r, c = rng.integers(0, n, m), rng.integers(0, n, m)
+    adj = sp.csr_matrix((np.ones(m, np.float32), (r, c)), shape=(n, n))
+    adj = ((adj + adj.T) > 0).astype(np.float32).tocsr()
+    adj.setdiag(0)
+    adj.eliminate_zeros()
+    x_np = rng.standard_normal((n, int(cfg["wide"]))).astype(np.float32)
+    y_np = rng.integers(0, 2, n).astype(np.int64)
+    return adj, x_np, y_np, np.sort(rng.permutation(n)[: n // 2])
+
+
 def _worker(rank, world, port, cfg, ret):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -180,7 +205,8 @@ def _worker(rank, world, port, cfg, ret):
         tuning.HOST.implicit = int(cfg.get("implicit", 1))          # (a child process of its own: nothing to restore)
         import torch.nn.functional as F
         from acm_gnn_amd import GCN, data as D, distributed as DD
-        adj, x_np, y_np, (tr, _, _), _ = D.synthetic_dataset("tiny", seed=5, pad_to=world)
+        adj, x_np, y_np, tr = _case_dataset(cfg, world)
+        f_in = x_np.shape[1]
         if cfg.get("plan") == "work":                 # hubs first: the case equal blocks cannot balance
             adj, x_np, y_np, (tr, _, _) = D.permute_dataset(adj, x_np, y_np, (tr, tr, tr), D.degree_order(adj))
         low, deg = D.build_filters(adj)
@@ -195,8 +221,8 @@ def _worker(rank, world, port, cfg, ret):
         torch.manual_seed(0)
         pdrop = cfg.get("dropout", 0.0)
         hid = cfg.get("hid", 16)
-        full = GCN(7, hid, 2, 2, n, pdrop, cfg["model"], cfg["s"], variant=bool(cfg["variant"]), attn_layernorm=True)
-        model = GCN(7, hid, 2, 2, e - b, pdrop, cfg["model"], cfg["s"], variant=bool(cfg["variant"]), attn_layernorm=True)
+        full = GCN(f_in, hid, 2, 2, n, pdrop, cfg["model"], cfg["s"], variant=bool(cfg["variant"]), attn_layernorm=True)
+        model = GCN(f_in, hid, 2, 2, e - b, pdrop, cfg["model"], cfg["s"], variant=bool(cfg["variant"]), attn_layernorm=True)
         if pdrop:                                       # counter-based dropout: every rank draws the global mask
             from acm_gnn_amd import functional as AF
             model.fused_dropout, model.dropout_state = True, AF.DropoutState("cpu", seed=7)
@@ -210,9 +236,16 @@ def _worker(rank, world, port, cfg, ret):
         x = torch.from_numpy(x_np[b:e])
         y = torch.from_numpy(y_np[b:e])
         idx = torch.from_numpy(DD.local_index(tr, plan, rank))
+        calls = []
+        if cfg.get("wide"):
+            fake = _lib_now()
+            for name in ("acm_conv_aggw_fwd", "acm_conv_bwd_spmm"):
+                fake.__dict__[name] = (lambda o, nm: lambda *a: (calls.append(nm), o(*a))[1])(getattr(fake, name), name)
         out = model(x, ops)
         loss = F.nll_loss(F.log_softmax(out, 1)[idx], y[idx], reduction="sum") / len(tr)
         loss.backward()
+        if cfg.get("wide"):                             # the first layer ran in the wide aggregate-first form on every rank: one
+            assert calls.count("acm_conv_aggw_fwd") == 1 and calls.count("acm_conv_bwd_spmm") == 1, calls     # transposed gather left
         tot = loss.detach().clone()
         dist.all_reduce(tot)
         grads = {k: p.grad.numpy().copy() for k, p in model.named_parameters() if p.grad is not None}
@@ -242,14 +275,17 @@ def _worker(rank, world, port, cfg, ret):
                                  dict(model="acmgcnp", s=1, variant=1, hid=64, plan="work"),
                                  dict(model="acmgcnp", s=1, variant=0, world=8, plan="work", dropout=0.5),
                                  dict(model="acmsgc", s=0, variant=0, hops=3, world=8, plan="work"),
-                                 dict(model="acmgcnp", s=0, variant=0, world=8, dropout=0.5, x_full=1)],
+                                 dict(model="acmgcnp", s=0, variant=0, world=8, dropout=0.5, x_full=1),
+                                 dict(model="acmgcnp", s=0, variant=0, hid=64, wide=40, dropout=0.3),
+                                 dict(model="acmgcn", s=0, variant=0, hid=64, wide=65, plan="work")],
                          ids=["agg+literal", "struct-acmii", "acmii", "struct-agg", "struct-agg-explicit",
                               "struct-acmii-explicit", "dropout", "dropout-xfull-struct", "dropout-xfull-acmii",
                               "sgc-3hop", "sgc-2hop-explicit", "work-plan-struct-agg", "work-plan-acmii-explicit",
                               "work-plan-dropout", "4-ranks-struct-acmii", "4-ranks-work-plan-dropout",
                               "4-ranks-work-plan-sgc-3hop", "acmgcnpp-dropout", "4-ranks-work-plan-acmgcnpp",
                               "acmii-recompute-dropout-xfull", "acmii-recompute-struct-work-plan",
-                              "8-ranks-work-plan-struct-dropout", "8-ranks-work-plan-sgc-3hop", "8-ranks-equal-blocks-xfull"])
+                              "8-ranks-work-plan-struct-dropout", "8-ranks-work-plan-sgc-3hop", "8-ranks-equal-blocks-xfull",
+                              "wide-aggregate-first-dropout", "wide-aggregate-first-work-plan"])
 def test_row_shard_equals_single_process(cfg, monkeypatch, tune):
     """world_size = 2, 4 and 8 (the node's GPU count) over gloo: the sharded forward/backward (halo all-gathers + parameter-gradient
     all-reduce issued by functional.AcmConvFunction) must reproduce the 1-process result -- with equal blocks and
@@ -283,18 +319,20 @@ def test_row_shard_equals_single_process(cfg, monkeypatch, tune):
     fake_lib.install(monkeypatch)
     tune(implicit=0)                   # the single-process reference keeps explicit values
     from acm_gnn_amd import GCN, data as D, distributed as DD
-    adj, x_np, y_np, (tr, _, _), _ = D.synthetic_dataset("tiny", seed=5, pad_to=world)
+    adj, x_np, y_np, tr = _case_dataset(cfg, world)
     if cfg.get("plan") == "work":
         adj, x_np, y_np, (tr, _, _) = D.permute_dataset(adj, x_np, y_np, (tr, tr, tr), D.degree_order(adj))
     low, deg = D.build_filters(adj)
     n = adj.shape[0]
+    if cfg.get("wide"):
+        tune(agg_first=0)                # ... and the literal project-then-gather form
     ops = DD.make_sharded_operators(low, deg, "cpu", with_structure=bool(cfg["s"]))
     assert not ops.sharded and not ops.implicit
     if cfg.get("plan") == "work":
         assert len({r[4][1] - r[4][0] for r in results}) > 1               # the blocks really differ in length
     ops.hops = cfg.get("hops", 1)
     torch.manual_seed(0)
-    full = GCN(7, cfg.get("hid", 16), 2, 2, n, cfg.get("dropout", 0.0), cfg["model"], cfg["s"], variant=bool(cfg["variant"]),
+    full = GCN(x_np.shape[1], cfg.get("hid", 16), 2, 2, n, cfg.get("dropout", 0.0), cfg["model"], cfg["s"], variant=bool(cfg["variant"]),
                attn_layernorm=True)
     if cfg.get("dropout"):
         from acm_gnn_amd import functional as AF

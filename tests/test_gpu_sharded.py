@@ -95,6 +95,11 @@ def _worker(rank, world, port, cfg, ret):
             used = set(k.split("/")[0] for k in timer.events)
             assert {"acmii_table", "conv_acmii_v_fwd", "conv_acmii_v_bwd"} <= used, sorted(used)
             assert not any(k.startswith("all_gather/") and k.endswith("x128") for k in timer.events), sorted(timer.events)
+        if cfg.get("wide"):
+            used = sorted(timer.events)
+            assert any(k.startswith("conv_aggw/") for k in used), used
+            assert [k for k in used if k.startswith("all_gather/") and k.endswith("x128")] == [f"all_gather/{plan.n_max}x128"], used
+            assert sum(len(v) for k, v in timer.events.items() if k.startswith("all_gather/") and k.endswith("x128")) == 1
         grads = {k: p.grad.cpu().numpy().copy() for k, p in model.named_parameters() if p.grad is not None}
         ret.put((rank, out.detach().cpu().numpy().copy(), grads, (b, e)))
     finally:
@@ -110,11 +115,14 @@ def _worker(rank, world, port, cfg, ret):
                                  dict(model="acmgcnp", s=0, variant=0, dropout=0.1, dataset="twitch-gamer", plan="interleave"),
                                  dict(model="acmgcnp", s=0, variant=0, dropout=0.1, dataset="twitch-gamer", plan="work"),
                                  dict(model="acmsgc", s=0, variant=0, dropout=0.0, dataset="arxiv-year", plan="work", hops=3),
+                                 # the wide aggregate-first first layer row-sharded: ONE 128-wide halo exchange (the dropped input)
+                                 dict(model="acmgcnp", s=0, variant=0, dropout=0.2, dataset="arxiv-year", plan="interleave", wide=1),
                                  # EIGHT ranks on the one device: eight HIP contexts, the halos through gloo
                                  dict(model="acmgcnp", s=1, variant=0, dropout=0.3, world=8),
                                  dict(model="acmgcnp", s=0, variant=1, dropout=0.3, plan="work", world=8)],
                          ids=["agg", "struct-dropout", "acmii", "work-plan-struct-acmii", "work-plan-agg", "acmgcnpp",
                               "twitch-degree-interleaved", "twitch-random-work-plan", "arxiv-year-3hop-sgc-work-plan",
+                              "arxiv-year-wide-aggregate-first",
                               "world8-struct-dropout", "world8-work-plan-acmii"])
 def test_two_ranks_on_one_gpu_equal_single_process(cfg):
     import queue
