@@ -14,7 +14,7 @@ c_i32p = C.POINTER(C.c_int32)
 
 ACM_OK = 0
 STATUS_NAMES = {1: "ACM_EINVAL", 2: "ACM_ESHAPE", 3: "ACM_EHIP", 4: "ACM_EUNSUPPORTED", 5: "ACM_ENOMEM"}
-ABI_VERSION = 26
+ABI_VERSION = 27
 
 # every symbol include/acm_hip.h declares
 EXPORTED_SYMBOLS = (
@@ -27,7 +27,7 @@ EXPORTED_SYMBOLS = (
     "acm_conv_acmii_fwd_workspace_bytes", "acm_conv_acmii_fwd", "acm_linear_fwd", "acm_bias_act", "acm_bias_act_bwd_workspace_bytes", "acm_bias_act_bwd",
     "acm_acmii_table_bytes", "acm_acmii_table", "acm_conv_acmii_v_fwd", "acm_conv_acmii_v_bwd_workspace_bytes", "acm_conv_acmii_v_bwd",
     "acm_linear_bwd_workspace_bytes", "acm_linear_bwd", "acm_linear_fwd_add", "acm_linear_bwd_recompute",
-    "acm_small_step_workspace_bytes", "acm_small_step", "acm_conv_head_fwd", "acm_conv_aggw_fwd",
+    "acm_small_step_workspace_bytes", "acm_small_step", "acm_conv_head_fwd", "acm_conv_aggw_fwd", "acm_conv_aggw_bwd_workspace_bytes", "acm_conv_aggw_bwd",
 )
 
 
@@ -275,6 +275,8 @@ def _declare(lib):
     lib.acm_cast_bf16.argtypes = [i64, i64, vp, i64, vp, i64, vp]
     lib.acm_conv_fwd.argtypes = [vp, C.POINTER(ConvFwd), vp, sz, vp]
     lib.acm_conv_head_fwd.argtypes = [i64, C.POINTER(ConvFwd), vp]
+    lib.acm_conv_aggw_bwd_workspace_bytes.argtypes = [i64, i64, C.POINTER(C.c_size_t)]
+    lib.acm_conv_aggw_bwd.argtypes = [i64, i64, i64, vp, i64, vp, i64, C.POINTER(ConvBwdLocal), vp, vp, vp, i64, vp, C.c_size_t, vp]
     lib.acm_conv_aggw_fwd.argtypes = [i64, i64, i64, vp, i64, vp, i64, vp, vp, vp, i64, vp, i64, C.POINTER(ConvFwd), vp]
     lib.acm_conv_bwd_local_workspace_bytes.argtypes = [i64, i32, i32, C.POINTER(sz)]
     lib.acm_conv_bwd_local.argtypes = [i64, C.POINTER(ConvBwdLocal), vp, sz, vp]

@@ -2173,7 +2173,8 @@ class _AcmAggWide(torch.autograd.Function):
     forward : [acm_dropout] -> acm_spmm_ex (P = A_low Xd) -> acm_conv_aggw_fwd (projections on the split-bf16 matrix pipe + head,
               one row-local kernel: pre_L = P W_L, pre_H = (Xd - P) W_H); with tuning rewrites bit 8 off: 2 x acm_gemm
               ([P W_L | P W_H], [Xd W_H | Xd W_I]) -> acm_conv_head_fwd
-    backward: acm_conv_bwd_local (K3) -> 2 x acm_gemm TN ([P^T G_L | P^T G_H], [Xd^T G_H | Xd^T G_I])"""
+    backward: acm_conv_aggw_bwd (K3 + the three weight gradients, one kernel); with tuning rewrites bit 8 off (or a post_scale mask
+              tensor): acm_conv_bwd_local (K3) -> 2 x acm_gemm TN ([P^T G_L | P^T G_H], [Xd^T G_H | Xd^T G_I])"""
 
     @staticmethod
     def forward(ctx, x, w_low, w_high, w_mlp, v_low, v_high, v_mlp, att_mix, lnw_low, lnw_high, lnw_mlp, lnb_low, lnb_high,
@@ -2270,43 +2271,52 @@ class _AcmAggWide(torch.autograd.Function):
         st3 = _k3_setup(cfg, ops, k, f, n, dev, f_in, pre, zi, vecs, lnw, lnb, mix, grad_out, ctx.post_relu, ctx.post_scale,
                         ctx.post_drop)
         q, flat, nw = st3["q"], st3["flat"], st3["nw"]
-        # K3 writes [G_L | G_H | G_I] side by side, UNSCALED (the filter was applied before the projection: nothing is
-        # gathered over the transposed operator here)
-        gcat = torch.empty(n, 3 * f, dtype=_F32, device=dev)
-        q.g_scale = None
-        q.g_low, q.ld_g_low = gcat.data_ptr(), gcat.stride(0)
-        q.g_high, q.ld_g_high = gcat.data_ptr() + 4 * f, gcat.stride(0)
-        q.g_mlp, q.ld_g_mlp = gcat.data_ptr() + 8 * f, gcat.stride(0)
+        q.g_scale = None                           # (the filter was applied before the projection: no transposed gather here)
         d_vec, d_lnw, d_lnb, d_mix = _flat_views(flat, nw, k, f, cfg.layernorm)
-        nbytes = C.c_size_t()
-        _lib.check(lib.acm_conv_bwd_local_workspace_bytes(n, f, k, C.byref(nbytes)))
-        ws = torch.empty(max(nbytes.value // 4, 1), dtype=_F32, device=dev)
         q.defer = defer.pointer() if defer is not None else None
-        with _device_ctx(dev), _Timed(f"conv_bwd_local/F{f}k{k}"):
-            st = lib.acm_conv_bwd_local(n, C.byref(q), _vp(ws), ws.numel() * 4, _stream())
-        _lib.check(st, "acm_conv_bwd_local")
-        if defer is not None:
-            defer.hold(ws, [d_mix, *d_vec, *d_lnw, *d_lnb], keep=[flat])
-        del st3
-        a1 = gemm(agg, gcat[:, : 2 * f], trans_a=True, col_blocks=2)          # [P^T G_L | P^T G_H]   as [2, fp, f]
-        a2 = gemm(xd, gcat[:, f:], trans_a=True, col_blocks=2)                # [Xd^T G_H | Xd^T G_I]
-        if ops.sharded:
-            # replicated parameters: the weight gradients join the head's in the layer's flat buffer, ONE all-reduce sums the
-            # row-shard partials (after the step's single flush when the second phases are deferred)
-            import torch.distributed as dist
-            dw = flat[:nw].view(3, f_in, f)
+        dw = flat[:nw].view(3, f_in, f)            # the weight gradients lead the layer's flat gradient buffer
+        if (tuning.HOST.rewrites & tuning.REWRITE_AGGW_FUSED) and ctx.post_scale is None:
+            # K3 and the three weight gradients in ONE kernel: [G_L | G_H | G_I] never reach memory
+            q.g_low = q.g_high = q.g_mlp = None
+            nbytes = C.c_size_t()
+            _lib.check(lib.acm_conv_aggw_bwd_workspace_bytes(n, fp, C.byref(nbytes)), "acm_conv_aggw_bwd_workspace_bytes")
+            ws = torch.empty(max(nbytes.value // 4, 1), dtype=_F32, device=dev)
+            with _device_ctx(dev), _Timed(f"conv_aggw_bwd/F{f}k{k}i{f_in}"):
+                st = lib.acm_conv_aggw_bwd(n, f_in, fp, _vp(agg), agg.stride(0), _vp(xd), xd.stride(0), C.byref(q), _vp(dw[0]),
+                                           _vp(dw[1]), _vp(dw[2]), f, _vp(ws), ws.numel() * 4, _stream())
+            _lib.check(st, "acm_conv_aggw_bwd")
+            if defer is not None:
+                defer.hold(ws, [d_mix, *d_vec, *d_lnw, *d_lnb, dw], keep=[flat])
+            del st3
+        else:
+            # K3 writes [G_L | G_H | G_I] side by side, UNSCALED; two transposed split-bf16 products read them back
+            gcat = torch.empty(n, 3 * f, dtype=_F32, device=dev)
+            q.g_low, q.ld_g_low = gcat.data_ptr(), gcat.stride(0)
+            q.g_high, q.ld_g_high = gcat.data_ptr() + 4 * f, gcat.stride(0)
+            q.g_mlp, q.ld_g_mlp = gcat.data_ptr() + 8 * f, gcat.stride(0)
+            nbytes = C.c_size_t()
+            _lib.check(lib.acm_conv_bwd_local_workspace_bytes(n, f, k, C.byref(nbytes)))
+            ws = torch.empty(max(nbytes.value // 4, 1), dtype=_F32, device=dev)
+            with _device_ctx(dev), _Timed(f"conv_bwd_local/F{f}k{k}"):
+                st = lib.acm_conv_bwd_local(n, C.byref(q), _vp(ws), ws.numel() * 4, _stream())
+            _lib.check(st, "acm_conv_bwd_local")
+            if defer is not None:
+                defer.hold(ws, [d_mix, *d_vec, *d_lnw, *d_lnb], keep=[flat])
+            del st3
+            a1 = gemm(agg, gcat[:, : 2 * f], trans_a=True, col_blocks=2)          # [P^T G_L | P^T G_H]   as [2, fp, f]
+            a2 = gemm(xd, gcat[:, f:], trans_a=True, col_blocks=2)                # [Xd^T G_H | Xd^T G_I]
             dw[0].copy_(a1[0][:f_in])
             torch.sub(a2[0][:f_in], a1[1][:f_in], out=dw[1])
             dw[2].copy_(a2[1][:f_in])
-            d_wl, d_wh, d_wm = dw[0], dw[1], dw[2]
+        d_wl, d_wh, d_wm = dw[0], dw[1], dw[2]
+        if ops.sharded:
+            # replicated parameters: the weight gradients sit with the head's in the layer's flat buffer, ONE all-reduce sums the
+            # row-shard partials (after the step's single flush when the second phases are deferred)
+            import torch.distributed as dist
             if defer is not None:
                 defer.allreduce(flat, ops.group)
             else:
                 dist.all_reduce(flat, group=ops.group)
-        else:
-            d_wl = a1[0][:f_in]
-            d_wh = (a2[0] - a1[1])[:f_in]
-            d_wm = a2[1][:f_in]
         none3 = [None] * 3
         return (None, d_wl, d_wh, d_wm, d_vec[0], d_vec[1], d_vec[2], d_mix,
                 *(d_lnw if cfg.layernorm else none3), *(d_lnb if cfg.layernorm else none3), None, None, None, None, None, None, None)

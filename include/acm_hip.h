@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define ACM_ABI_VERSION 26
+#define ACM_ABI_VERSION 27
 
 typedef enum {
     ACM_OK = 0,
@@ -539,6 +539,20 @@ typedef struct {
 int acm_conv_bwd_local_workspace_bytes(int64_t n_rows, int f_out, int n_channels, size_t* bytes);
 int acm_conv_bwd_local(int64_t n_rows, const acm_conv_bwd_local_t* p,
                        void* workspace, size_t workspace_bytes, acm_stream_t stream);
+
+/* The backward of the wide aggregate-first layer (acm_conv_aggw_fwd) in ONE kernel (ABI 27): acm_conv_bwd_local's row-local
+ * head backward and the three weight gradients
+ *   dW_L = P^T G_L,   dW_H = (Xd - P)^T G_H,   dW_I = Xd^T G_I          (the MmBackward of G:101-103 in aggregate-first order)
+ * without [G_L | G_H | G_I] ever reaching memory: a workgroup computes G for 128 rows, leaves it in LDS as split-bf16 matrix
+ * operands and contracts it with the rows of `agg` = P and `xs` = Xd loaded transposed ([n_rows, f_pad] as in the forward).
+ * Of `p` it reads grad_out / pre / s_mlp, the head, the post-op (post_relu, post_drop; post_scale and g_scale must be NULL) and
+ * writes d_att_vec / d_ln_* / d_att_mix; g_low / g_high / g_mlp are not touched.  d_w_*: [f_in, 64] at row pitch ld_dw.
+ * All reduced outputs follow p->defer like acm_conv_bwd_local's.  f_out = 64, three channels; ACM_EUNSUPPORTED otherwise.
+ * Replaces acm_conv_bwd_local + two transposed acm_gemm_blocks calls. */
+int acm_conv_aggw_bwd_workspace_bytes(int64_t n_rows, int64_t f_pad, size_t* bytes);
+int acm_conv_aggw_bwd(int64_t n_rows, int64_t f_in, int64_t f_pad, const float* agg, int64_t ld_agg, const float* xs,
+                      int64_t ld_xs, const acm_conv_bwd_local_t* p, float* d_w_low, float* d_w_high, float* d_w_mlp,
+                      int64_t ld_dw, void* workspace, size_t workspace_bytes, acm_stream_t stream);
 
 /* ------------------------------------- backward, transposed SpMM part (K4) --
  *   dZ_L = mask_L * (A_low^T G_L)

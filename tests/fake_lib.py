@@ -835,6 +835,29 @@ class FakeLib:
         writes.append((_view(q.d_att_mix, k, k, k), d_mix))
         return self._emit(q.defer, writes)
 
+    def acm_conv_aggw_bwd_workspace_bytes(self, n, f_pad, out):
+        out._obj.value = 1024
+        return 0
+
+    def acm_conv_aggw_bwd(self, n, f_in, f_pad, agg, ld_agg, xs, ld_xs, qq, dwl, dwh, dwm, ld_dw, ws, wsb, stream):
+        """acm_conv_bwd_local's G tables (kept in host arrays) contracted with P, Xd - P, Xd: dW_L, dW_H, dW_I."""
+        q = qq._obj
+        F = q.f_out
+        if F != 64 or q.n_channels != 3 or q.post_scale or q.g_scale or not 0 < f_in <= f_pad <= 128:
+            self._err = b"acm_conv_aggw_bwd: unsupported configuration"
+            return 4
+        G = [np.zeros((n, F), np.float32) for _ in range(3)]
+        r = type(q).from_buffer_copy(q)
+        r.g_low, r.g_high, r.g_mlp = (t.ctypes.data for t in G)
+        r.ld_g_low = r.ld_g_high = r.ld_g_mlp = F
+        st = FakeLib.acm_conv_bwd_local(self, n, C.byref(r), ws, wsb, stream)
+        if st:
+            return st
+        P = _view(agg, n, f_in, ld_agg).astype(np.float64)
+        X = _view(xs, n, f_in, ld_xs).astype(np.float64)
+        prods = (P.T @ G[0].astype(np.float64), (X - P).T @ G[1].astype(np.float64), X.T @ G[2].astype(np.float64))
+        return self._emit(q.defer, [(_view(dst, f_in, F, ld_dw), val) for dst, val in zip((dwl, dwh, dwm), prods)])
+
     def acm_conv_bwd_spmm(self, h, rr, ws, wsb, stream):
         at, r = self._get(h), rr._obj
         n, F = at.n_rows, r.f_out

@@ -394,3 +394,78 @@ def test_wide_aggregate_first_kernel_against_float64(n, f_in, ln, relu_after, po
     torch.testing.assert_close(att, att2, rtol=1e-5, atol=1e-6)
     torch.testing.assert_close(out, out2, rtol=2e-5, atol=2e-6 * float(out2.abs().max()))
     assert (out2 == 0).float().mean() < 0.9 and torch.isfinite(out).all()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,f_in,ln,post", [(4099, 128, True, "drop"), (1000, 65, False, None), (37, 20, True, None), (20000, 100, True, "relu"),
+                                            (129, 5, True, None), (70000, 128, True, "drop")])
+def test_wide_aggregate_first_backward_kernel_against_k3_and_float64_products(n, f_in, ln, post):
+    """acm_conv_aggw_bwd through the C ABI: its head-parameter gradients against acm_conv_bwd_local's on the same inputs
+    (re-association level), its weight gradients against float64 products of P, Xd - P, Xd with the G tables acm_conv_bwd_local
+    wrote (the fused kernel never stores G).  Ragged row counts (slabs of 128), padded F_in, several slabs per workgroup."""
+    import ctypes as C
+    from acm_gnn_amd import _lib, functional as AF
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(3 * n + f_in)
+    fp = -(-f_in // 4) * 4
+    P, X = torch.zeros(n, fp), torch.zeros(n, fp)
+    P[:, :f_in] = torch.randn(n, f_in, generator=g)
+    X[:, :f_in] = torch.randn(n, f_in, generator=g)
+    pre = torch.randn(n, 128, generator=g)
+    zi = torch.randn(n, 64, generator=g)
+    go = torch.randn(n, 64, generator=g)
+    vecs = [torch.randn(64, generator=g) for _ in range(3)]
+    lnw = [torch.rand(64, generator=g) + 0.5 for _ in range(3)]
+    lnb = [torch.randn(64, generator=g) * 0.1 for _ in range(3)]
+    mix = torch.randn(3, 3, generator=g)
+    dev = lambda t: t.to(DEV).contiguous()
+    Pd, Xd, pred, zid, god, mixd = dev(P), dev(X), dev(pre), dev(zi), dev(go), dev(mix)
+    vd, lwd, lbd = [dev(v) for v in vecs], [dev(t) for t in lnw], [dev(t) for t in lnb]
+    state = AF.DropoutState(torch.device(DEV), seed=5) if post == "drop" else None
+
+    def block(flat):
+        q = _lib.ConvBwdLocal()
+        q.f_out, q.n_channels, q.relu_after, q.relu_mlp, q.layernorm, q.scale = 64, 3, 1, 1, int(ln), 3.0
+        q.grad_out, q.ld_grad_out, q.pre, q.ld_pre, q.s_mlp, q.ld_s_mlp = god.data_ptr(), 64, pred.data_ptr(), 128, zid.data_ptr(), 64
+        q.att_vec = AF._ptr_array(vd)
+        if ln:
+            q.ln_weight, q.ln_bias = AF._ptr_array(lwd), AF._ptr_array(lbd)
+        q.att_mix = mixd.data_ptr()
+        d_vec, d_lnw, d_lnb, d_mix = AF._flat_views(flat, 0, 3, 64, ln)
+        q.d_att_vec = AF._ptr_array(d_vec)
+        if ln:
+            q.d_ln_weight, q.d_ln_bias = AF._ptr_array(d_lnw), AF._ptr_array(d_lnb)
+        q.d_att_mix = d_mix.data_ptr()
+        q.post_relu = int(post is not None)
+        if state is not None:
+            q.post_drop = AF._drop_spec((0.4, 1, state), 0)
+        return q
+    nflat = 3 * 64 + (6 * 64 if ln else 0) + 9
+    # reference: K3 with its G tables in memory
+    flat_ref = torch.zeros(nflat, device=DEV)
+    gcat = torch.empty(n, 192, device=DEV)
+    q = block(flat_ref)
+    q.g_low, q.ld_g_low, q.g_high, q.ld_g_high, q.g_mlp, q.ld_g_mlp = gcat.data_ptr(), 192, gcat.data_ptr() + 256, 192, gcat.data_ptr() + 512, 192
+    nb = C.c_size_t()
+    _lib.check(lib.acm_conv_bwd_local_workspace_bytes(n, 64, 3, C.byref(nb)))
+    ws = torch.empty(max(nb.value // 4, 1), device=DEV)
+    _lib.check(lib.acm_conv_bwd_local(n, C.byref(q), ws.data_ptr(), ws.numel() * 4, AF._stream()), "acm_conv_bwd_local")
+    # the fused kernel
+    flat = torch.zeros(nflat, device=DEV)
+    dw = torch.full((3, f_in, 64), float("nan"), device=DEV)
+    q2 = block(flat)
+    _lib.check(lib.acm_conv_aggw_bwd_workspace_bytes(n, fp, C.byref(nb)))
+    ws2 = torch.empty(max(nb.value // 4, 1), device=DEV)
+    st = lib.acm_conv_aggw_bwd(n, f_in, fp, Pd.data_ptr(), fp, Xd.data_ptr(), fp, C.byref(q2), dw[0].data_ptr(), dw[1].data_ptr(),
+                               dw[2].data_ptr(), 64, ws2.data_ptr(), ws2.numel() * 4, AF._stream())
+    _lib.check(st, "acm_conv_aggw_bwd")
+    torch.cuda.synchronize()
+    assert torch.isfinite(dw).all() and torch.isfinite(flat).all()
+    scale = float(flat_ref.abs().max())
+    assert float((flat - flat_ref).abs().max()) <= 2e-5 * scale * max(1.0, (n / 4096) ** 0.5) + 1e-6
+    G = gcat.cpu().double()
+    P64, X64 = P[:, :f_in].double(), X[:, :f_in].double()
+    want = torch.stack([P64.T @ G[:, :64], (X64 - P64).T @ G[:, 64:128], X64.T @ G[:, 128:]])
+    # a sum of n products of O(1) factors in fp32: ~ eps * sqrt(n) * |term| per element (the accumulators are fp32)
+    mag = float((P64.abs().max() + X64.abs().max()) * G.abs().max())
+    assert float((dw.cpu().double() - want).abs().max()) <= 3e-7 * mag * n ** 0.5 + 1e-6 * float(want.abs().max())

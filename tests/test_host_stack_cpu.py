@@ -1452,7 +1452,7 @@ def test_aggregate_first_for_wide_dense_inputs_equals_the_literal_form(model_typ
     ops, n = _dense_graph_ops(n=8192, avg=30, seed=3)          # (the form is taken from a mean degree of 12 on)
     x = torch.randn(n, f_in, generator=torch.Generator().manual_seed(2))
     calls = []
-    for name in ("acm_conv_bwd_spmm", "acm_spmm_ex", "acm_spmm", "acm_conv_aggw_fwd", "acm_conv_head_fwd"):
+    for name in ("acm_conv_bwd_spmm", "acm_spmm_ex", "acm_spmm", "acm_conv_aggw_fwd", "acm_conv_head_fwd", "acm_conv_aggw_bwd"):
         orig = getattr(fake, name)
         monkeypatch.setattr(fake, name, (lambda o, nm: lambda *a: (calls.append(nm), o(*a))[1])(orig, name))
 
@@ -1473,7 +1473,8 @@ def test_aggregate_first_for_wide_dense_inputs_equals_the_literal_form(model_typ
     # one gather forward for the first layer, none backward (the output layer keeps its two)
     assert calls_a.count("acm_conv_bwd_spmm") == 1 and calls_b.count("acm_conv_bwd_spmm") == 2, (calls_a, calls_b)
     assert len([c for c in calls_a if c.startswith("acm_spmm")]) == 1
-    assert (calls_a.count("acm_conv_aggw_fwd"), calls_a.count("acm_conv_head_fwd")) == ((1, 0) if fused else (0, 1))
+    assert (calls_a.count("acm_conv_aggw_fwd"), calls_a.count("acm_conv_head_fwd"), calls_a.count("acm_conv_aggw_bwd")) == \
+        ((1, 0, 1) if fused else (0, 1, 0))
     torch.testing.assert_close(out_a, out_b, rtol=1e-5, atol=1e-5 * float(out_b.abs().max()))
     assert g_a.keys() == g_b.keys()
     for k in g_a:
