@@ -24,11 +24,14 @@ __global__ __launch_bounds__(256) void dropout_wide_kernel(long n_rows, int n_co
                                                            long ld_src, float* __restrict__ dst, long ld_dst, int dst_cols,
                                                            acm_dropout_t d) {
     const AcmDropCtx dc = acm_drop_ctx(d);
-    const int panels = (dst_cols + 63) / 64;
-    const long total = n_rows * panels * 16;
+    // Philox blocks of a row that hold a column at all: 16 per full panel, min(16, columns) of the last one (68 columns -- pokec's
+    // 65 padded -- are 20 blocks, not 32)
+    const int last = dst_cols - 64 * ((dst_cols - 1) / 64);
+    const int bpr = 16 * ((dst_cols - 1) / 64) + (last < 16 ? last : 16);
+    const long total = n_rows * bpr;
     for (long q = (long)blockIdx.x * 256 + threadIdx.x; q < total; q += (long)gridDim.x * 256) {
-        const long r = q / (panels * 16);
-        const int b = (int)(q - r * (panels * 16));           // block id: (col & 15) + 16 * (col >> 6)
+        const long r = q / bpr;
+        const int b = (int)(q - r * bpr);                     // block id: (col & 15) + 16 * (col >> 6)
         const int c0 = (b & 15) + 64 * (b >> 4);
         float f[4];
         acm_drop4(dc, r, b, f);
@@ -52,7 +55,8 @@ extern "C" int acm_dropout(int64_t n_rows, int64_t n_cols, const float* src, int
     ACM_REQUIRE(n_cols <= 65536, ACM_EUNSUPPORTED, "acm_dropout: more than 65536 columns");
     if (n_rows == 0 || dst_cols == 0) return ACM_OK;
     if (dst_cols >= 64) {
-        long blocks = (n_rows * ((dst_cols + 63) / 64) * 16 + 255) / 256;
+        const long last = dst_cols - 64 * ((dst_cols - 1) / 64);
+        long blocks = (n_rows * (16 * ((dst_cols - 1) / 64) + (last < 16 ? last : 16)) + 255) / 256;
         if (blocks > 16384) blocks = 16384;
         hipLaunchKernelGGL(dropout_wide_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (long)n_rows,
                            (int)n_cols, src, (long)ld_src, dst, (long)ld_dst, (int)dst_cols, *d);
