@@ -178,3 +178,42 @@ def test_fused_loss_tail_is_taken_by_the_output_layer_and_equals_the_three_calls
     with AF.fused_loss_tail(y, w) as tail:
         hidden = model.gcns[0](x, ops)
     assert tail.out is None and not tail.matches(hidden)
+
+
+def test_train_step_with_the_wide_aggregate_first_layer_defers_its_weight_gradients_too(monkeypatch, tune):
+    """functional._AcmAggWide under train.TrainStep: acm_conv_aggw_bwd leaves the head-parameter sums AND the three weight
+    gradients (views of the layer's flat buffer) to the step's one flush -- the step stays deferred (every gradient adopted), and
+    the trajectory equals the immediate one and the unfused form's (K3 + two transposed products)."""
+    fake = fake_lib.install(monkeypatch)
+    import scipy.sparse as sp
+    from acm_gnn_amd import GCN, FusedAdamW, data as D, train as T
+    from acm_gnn_amd.distributed import make_sharded_operators
+    rng = np.random.default_rng(3)
+    n = 8192
+    m = n * 12
+    r, c = rng.integers(0, n, m), rng.integers(0, n, m)
+    adj = sp.csr_matrix((np.ones(m, np.float32), (r, c)), shape=(n, n))
+    adj = ((adj + adj.T) > 0).astype(np.float32).tocsr()
+    adj.setdiag(0)
+    adj.eliminate_zeros()
+    low, deg = D.build_filters(adj)
+    ops = make_sharded_operators(low, deg, torch.device("cpu"))
+    x = torch.randn(n, 40, generator=torch.Generator().manual_seed(1))
+    y = torch.randint(0, 3, (n,), generator=torch.Generator().manual_seed(2))
+    w = T.row_weights(torch.arange(0, n, 2), n)
+    calls = []
+    orig = fake.acm_conv_aggw_bwd
+    monkeypatch.setattr(fake, "acm_conv_aggw_bwd", lambda *a: (calls.append(1), orig(*a))[1])
+    traj = {}
+    for key, fused, defer in (("fused+deferred", 1, True), ("fused", 1, False), ("unfused+deferred", 0, True)):
+        tune(aggw_fused=fused)
+        torch.manual_seed(0)
+        model = GCN(40, 64, 3, 2, n, 0.3, "acmgcnp", 0, variant=False, attn_layernorm=True)
+        step = T.TrainStep(model, FusedAdamW(model.parameters(), lr=0.01, weight_decay=1e-3), x, ops, y, w, small_step=False)
+        step._defer = defer
+        calls.clear()
+        traj[key] = [float(step()) for _ in range(3)]
+        assert step._defer == defer and len(calls) == (3 if fused else 0)
+        assert all(torch.isfinite(p).all() for p in model.parameters())
+    assert traj["fused+deferred"] == traj["fused"]
+    np.testing.assert_allclose(traj["fused+deferred"], traj["unfused+deferred"], rtol=1e-5)
