@@ -2178,7 +2178,7 @@ class _AcmAggWide(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, w_low, w_high, w_mlp, v_low, v_high, v_mlp, att_mix, lnw_low, lnw_high, lnw_mlp, lnb_low, lnb_high,
-                lnb_mlp, ops, cfg, post_relu, post_scale, post_drop, call, in_drop):
+                lnb_mlp, ops, cfg, post_relu, post_scale, post_drop, call, in_drop, agg_holder=None):
         lib = _lib.load()
         ctx.set_materialize_grads(False)
         call = ctx.call = _call_or_ambient(call)
@@ -2189,15 +2189,34 @@ class _AcmAggWide(torch.autograd.Function):
         f, k = w_low.shape[1], 3
         fp = -(-f_in // 4) * 4                     # rows of 16-byte blocks for the gather and the split-bf16 products
         spec = _drop_spec(in_drop, ops.row_offset) if (in_drop is not None and in_drop[0] > 0) else None
+        # ``agg_holder`` (layers.GraphConvolution._eval_agg_holder): P = A_low X and the padded copy of a STATIC input from the
+        # previous pass over it -- every evaluation pass after the first and every training step of a model without input
+        # dropout then skips the layer's gather (a third of the arXiv-year evaluation forward, two thirds of pokec's)
+        if spec is not None or ops.sharded:
+            agg_holder = None
+        agg = None
         if spec is not None:                       # the caller's input dropout, written straight into the padded rows
             xd = torch.empty(n, fp, dtype=_F32, device=dev)
             with _device_ctx(dev), _Timed(f"dropout/{n}x{f_in}"):
                 st = lib.acm_dropout(n, f_in, _vp(x), x.stride(0), _vp(xd), xd.stride(0), fp, C.byref(spec), _stream())
             _lib.check(st, "acm_dropout")
+        elif fp == f_in:
+            xd = x
         else:
-            xd = x if fp == f_in else torch.nn.functional.pad(x, (0, fp - f_in))
-        # P = A_low Xd  [n, fp]; row-sharded: the operator's columns are the all-gathered rows (the layer's only halo exchange)
-        agg = spmm(ops.low, _gather_rows(ops, xd), row_scale=ops.row_scale if ops.implicit else None)
+            xd = agg_holder.get("xpad") if agg_holder is not None else None
+            if xd is None or tuple(xd.shape) != (n, fp):
+                xd = torch.nn.functional.pad(x, (0, fp - f_in))
+                if agg_holder is not None:
+                    agg_holder["xpad"], agg_holder["agg"] = xd, None
+        if agg_holder is not None:
+            agg = agg_holder.get("agg")
+            if agg is not None and tuple(agg.shape) != (n, fp):
+                agg = None
+        if agg is None:
+            # P = A_low Xd  [n, fp]; row-sharded: the operator's columns are the all-gathered rows (the layer's only halo exchange)
+            agg = spmm(ops.low, _gather_rows(ops, xd), row_scale=ops.row_scale if ops.implicit else None)
+            if agg_holder is not None:
+                agg_holder["agg"] = agg
         w3 = [_as_f32c(w, "weight") for w in (w_low, w_high, w_mlp)]
         vecs = [_as_f32c(t, "att_vec") for t in (v_low, v_high, v_mlp)]
         lnw = [_as_f32c(t, "ln") for t in (lnw_low, lnw_high, lnw_mlp)] if cfg.layernorm else []
@@ -2256,7 +2275,7 @@ class _AcmAggWide(torch.autograd.Function):
     @staticmethod
     def backward(ctx, grad_out, _grad_att):
         if grad_out is None:
-            return (None,) * 21
+            return (None,) * 22
         lib = _lib.load()
         ops, cfg, f_in, fp = ctx.ops, ctx.cfg, ctx.f_in, ctx.fp
         xd, agg, zi, pre, mix, *rest = ctx.saved_tensors
@@ -2319,7 +2338,8 @@ class _AcmAggWide(torch.autograd.Function):
                 dist.all_reduce(flat, group=ops.group)
         none3 = [None] * 3
         return (None, d_wl, d_wh, d_wm, d_vec[0], d_vec[1], d_vec[2], d_mix,
-                *(d_lnw if cfg.layernorm else none3), *(d_lnb if cfg.layernorm else none3), None, None, None, None, None, None, None)
+                *(d_lnw if cfg.layernorm else none3), *(d_lnb if cfg.layernorm else none3), None, None, None, None, None, None, None,
+                None)
 
 
 def in_drop_supported(x, ops, cfg, f_in, f_out):
@@ -2351,7 +2371,7 @@ def acm_conv(x, params, ops, cfg, post_relu=False, post_scale=None, post_drop=No
         return _AcmAggWide.apply(x, p["weight_low"], p["weight_high"], p["weight_mlp"], p["att_vec_low"], p["att_vec_high"],
                                  p["att_vec_mlp"], p["att_vec"], p["layer_norm_low.weight"], p["layer_norm_high.weight"],
                                  p["layer_norm_mlp.weight"], p["layer_norm_low.bias"], p["layer_norm_high.bias"],
-                                 p["layer_norm_mlp.bias"], ops, cfg, post_relu, post_scale, post_drop, call, in_drop)
+                                 p["layer_norm_mlp.bias"], ops, cfg, post_relu, post_scale, post_drop, call, in_drop, agg_holder)
     return AcmConvFunction.apply(
         x, p["weight_low"], p["weight_high"], p["weight_mlp"], p["att_vec_low"], p["att_vec_high"],
         p["att_vec_mlp"], p["att_struc_low"], p["struc_low"], p["att_vec"],

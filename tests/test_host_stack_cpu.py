@@ -1479,3 +1479,52 @@ def test_aggregate_first_for_wide_dense_inputs_equals_the_literal_form(model_typ
     assert g_a.keys() == g_b.keys()
     for k in g_a:
         torch.testing.assert_close(g_a[k], g_b[k], rtol=1e-4, atol=1e-5 * float(g_b[k].abs().max()), msg=lambda m, k=k: f"{k}: {m}")
+
+
+@pytest.mark.parametrize("f_in", [40, 65])
+def test_wide_aggregate_first_layer_gathers_a_static_input_once(f_in, monkeypatch):
+    """functional._AcmAggWide with layers.GraphConvolution's P cache: evaluation passes over the same unmodified features and
+    training steps of a model without input dropout gather P = A_low X once (F_in 65: the zero-padded copy is kept with it); an
+    in-place edit of the features, another tensor or a model WITH input dropout in training mode takes the gather again."""
+    fake = fake_lib.install(monkeypatch)
+    from acm_gnn_amd import GCN, functional as AF
+    ops, n = _dense_graph_ops(n=8192, avg=30, seed=3)
+    gathers = []
+    for name in ("acm_spmm_ex", "acm_spmm"):
+        orig = getattr(fake, name)
+        monkeypatch.setattr(fake, name, (lambda o: lambda h, g, ldg, width, *a: (gathers.append(int(width)), o(h, g, ldg, width, *a))[1])(orig))
+    fp = -(-f_in // 4) * 4
+    torch.manual_seed(2)
+    model = GCN(f_in, 64, 3, 2, n, 0.0, "acmgcnp", 0, variant=False)
+    x = torch.randn(n, f_in, generator=torch.Generator().manual_seed(5))
+    model.eval()
+    with torch.no_grad():
+        o1 = model(x, ops)
+        o2 = model(x, ops)
+        assert gathers.count(fp) == 1 and torch.equal(o1, o2)
+        x.mul_(1.5)
+        o3 = model(x, ops)
+        assert gathers.count(fp) == 2 and not torch.equal(o1, o3)
+        model(x.clone(), ops)
+        assert gathers.count(fp) == 3
+    # training without input dropout: one gather for the whole run, gradients as without the cache
+    model.train()
+    gathers.clear()
+    grads = []
+    for cache in (True, True, False):
+        for layer in model.gcns:
+            layer.eval_agg_cache = cache
+        model.zero_grad(set_to_none=True)
+        model(x, ops).square().sum().backward()
+        grads.append({k: p.grad.clone() for k, p in model.named_parameters() if p.grad is not None})
+    assert gathers.count(fp) == 2                              # first cached step + the uncached one
+    for k in grads[0]:
+        assert torch.equal(grads[0][k], grads[1][k]) and torch.equal(grads[0][k], grads[2][k]), k
+    # with input dropout (counter-based) every training step draws a new input: never from the cache
+    for layer in model.gcns:
+        layer.eval_agg_cache = True
+    model.dropout, model.fused_dropout, model.dropout_state = 0.3, True, AF.DropoutState(torch.device("cpu"), seed=3)
+    gathers.clear()
+    for _ in range(2):
+        model(x, ops).square().sum().backward()
+    assert gathers.count(fp) == 2
