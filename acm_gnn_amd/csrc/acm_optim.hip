@@ -19,7 +19,12 @@
 namespace {
 
 constexpr int PACK = 40;          // tensors per launch (a 2-layer model with the structure channel has 34-36 with gradients)
-constexpr int CHUNK = 2048;       // elements per block
+constexpr int CHUNK = 2048;       // elements per block and round
+constexpr int MAX_BLOCKS = 1024;  // per tensor: a large tensor's blocks take several rounds each (every block ends in an atomic on
+                                  // ONE arrival counter, ~11 ns apiece: 5 254 blocks of the twitch-sized N x 64 parameter = 58 us)
+// rounds of CHUNK elements a block of a tensor of n elements takes, and the blocks of that tensor
+__host__ __device__ inline int adam_rounds(long n) { return (int)((n + (long)CHUNK * MAX_BLOCKS - 1) / ((long)CHUNK * MAX_BLOCKS)) > 1 ? (int)((n + (long)CHUNK * MAX_BLOCKS - 1) / ((long)CHUNK * MAX_BLOCKS)) : 1; }
+__host__ __device__ inline int adam_blocks(long n) { return (int)((n + (long)CHUNK * adam_rounds(n) - 1) / ((long)CHUNK * adam_rounds(n))); }
 
 struct AdamPack {
     float* p[PACK];
@@ -49,7 +54,10 @@ __device__ __forceinline__ void adam_block(const AdamPack& pk, const AdamScalars
     float* __restrict__ m = pk.m[t];
     float* __restrict__ v = pk.v[t];
     const long n = pk.numel[t];
-    const long base = (long)(blk - pk.first_block[t]) * CHUNK;
+    const int rounds = adam_rounds(n);
+    for (int rd = 0; rd < rounds; ++rd) {
+    const long base = ((long)(blk - pk.first_block[t]) * rounds + rd) * CHUNK;
+    if (base >= n) break;
     const long end = base + CHUNK < n ? base + CHUNK : n;
     const bool vec = ((((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) & 15) == 0) && end - base == CHUNK;
     if (vec) {
@@ -74,6 +82,7 @@ __device__ __forceinline__ void adam_block(const AdamPack& pk, const AdamScalars
             m[i] = mm;
             v[i] = vv;
         }
+    }
     }
 }
 
@@ -212,7 +221,7 @@ int adam_with_flush(int n_tensors, const acm_adam_tensor_t* tensors, const acm_a
         pk.numel[t] = (long)a.numel;
         pk.first_block[t] = blocks;
         if (hit) pd.covered |= 1ull << t;
-        else blocks += (int)((a.numel + CHUNK - 1) / CHUNK);
+        else blocks += adam_blocks((long)a.numel);
     }
     pk.first_block[n_tensors] = blocks;
     // adam_block() finds its tensor by first_block: a covered tensor has no blocks (first_block[t] == first_block[t + 1])
@@ -260,7 +269,7 @@ extern "C" int acm_adam_step(int32_t n_tensors, const acm_adam_tensor_t* tensors
             pk.p[i] = t.param, pk.g[i] = t.grad, pk.m[i] = t.exp_avg, pk.v[i] = t.exp_avg_sq, pk.step[i] = t.step;
             pk.numel[i] = (long)t.numel;
             pk.first_block[i] = blocks;
-            blocks += (int)((t.numel + CHUNK - 1) / CHUNK);
+            blocks += adam_blocks((long)t.numel);
         }
         pk.first_block[pk.n] = blocks;
         int64_t* adv = first + PACK >= n_tensors ? cfg->also_advance : nullptr;
