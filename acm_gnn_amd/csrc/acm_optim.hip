@@ -23,7 +23,10 @@ constexpr int CHUNK = 2048;       // elements per block and round
 constexpr int MAX_BLOCKS = 1024;  // per tensor: a large tensor's blocks take several rounds each (every block ends in an atomic on
                                   // ONE arrival counter, ~11 ns apiece: 5 254 blocks of the twitch-sized N x 64 parameter = 58 us)
 // rounds of CHUNK elements a block of a tensor of n elements takes, and the blocks of that tensor
-__host__ __device__ inline int adam_rounds(long n) { return (int)((n + (long)CHUNK * MAX_BLOCKS - 1) / ((long)CHUNK * MAX_BLOCKS)) > 1 ? (int)((n + (long)CHUNK * MAX_BLOCKS - 1) / ((long)CHUNK * MAX_BLOCKS)) : 1; }
+__host__ __device__ inline int adam_rounds(long n) {
+    const long r = (n + (long)CHUNK * MAX_BLOCKS - 1) / ((long)CHUNK * MAX_BLOCKS);
+    return r > 1 ? (int)r : 1;
+}
 __host__ __device__ inline int adam_blocks(long n) { return (int)((n + (long)CHUNK * adam_rounds(n) - 1) / ((long)CHUNK * adam_rounds(n))); }
 
 struct AdamPack {
