@@ -2294,7 +2294,10 @@ class _AcmAggWide(torch.autograd.Function):
         d_vec, d_lnw, d_lnb, d_mix = _flat_views(flat, nw, k, f, cfg.layernorm)
         q.defer = defer.pointer() if defer is not None else None
         dw = flat[:nw].view(3, f_in, f)            # the weight gradients lead the layer's flat gradient buffer
-        if (tuning.HOST.rewrites & tuning.REWRITE_AGGW_FUSED) and ctx.post_scale is None:
+        if n == 0:                                 # a rank without rows (row-sharded, degenerate plan): zero partial sums, same collectives
+            flat.zero_()
+            del st3
+        elif (tuning.HOST.rewrites & tuning.REWRITE_AGGW_FUSED) and ctx.post_scale is None:
             # K3 and the three weight gradients in ONE kernel: [G_L | G_H | G_I] never reach memory
             q.g_low = q.g_high = q.g_mlp = None
             nbytes = C.c_size_t()
