@@ -269,6 +269,114 @@ def _call_or_ambient(call):
     return call if call is not None else CallContext.from_ambient()
 
 
+class TapeBroken(RuntimeError):
+    """A step cannot run on a Tape (see there): something other than this package's Functions sits between them."""
+
+
+class _TapeCtx:
+    """What a Function's forward / backward see in place of autograd's ctx when the call runs on a Tape."""
+
+    def __init__(self, needs_input_grad):
+        self.needs_input_grad = needs_input_grad
+        self.saved_tensors = ()
+
+    def save_for_backward(self, *tensors):
+        self.saved_tensors = tensors
+
+    def mark_non_differentiable(self, *tensors):
+        pass
+
+    def set_materialize_grads(self, value):
+        pass                                  # (Tape.backward hands None to outputs without a gradient, as the Functions ask)
+
+
+class Tape:
+    """The training step's own record of the Functions it runs, replayed backwards by ``backward`` -- instead of an autograd
+    graph (train.TrainStep, eager steps).  A two-layer step is two or three of this package's Functions in a row with 26
+    parameters: autograd spends more host time on them (``Function.apply``, 26 AccumulateGrad nodes, gradient validation,
+    the engine's thread hand-off: ~0.3 ms) than the kernels take.  The tape calls ``forward(ctx, *args)`` under no_grad,
+    remembers (Function, ctx, args, outputs), and ``backward(out, grad)`` walks the records in reverse: output gradients
+    by tensor identity, parameter gradients assigned (added, when a parameter is used twice) to ``.grad``.
+
+    It is only sound while every tensor that carries a gradient between two records is the very object a record returned:
+    outputs are marked ``requires_grad`` so that a torch op in between leaves a ``grad_fn`` on its result, and such an argument
+    (or a final output the tape did not produce) raises TapeBroken -- the step then runs on autograd, for good."""
+
+    def __init__(self):
+        self.records = []
+        self.produced = {}                    # id(tensor) -> tensor (kept alive: an id must not be handed to another object)
+
+    def run(self, fn, args):
+        needs = []
+        for a in args:
+            if not isinstance(a, torch.Tensor):
+                needs.append(False)
+            elif id(a) in self.produced:
+                needs.append(True)
+            elif a.grad_fn is not None:
+                raise TapeBroken(f"{fn.__name__}: an argument was computed by torch operations from tensors that need gradients")
+            else:
+                needs.append(bool(a.requires_grad))          # a parameter, or a constant (features, a mask tensor)
+        ctx = _TapeCtx(tuple(needs))
+        with torch.no_grad():
+            out = fn.forward(ctx, *args)
+        outs = out if isinstance(out, tuple) else (out,)
+        if not any(needs):                        # as under autograd: nothing to differentiate, the outputs are constants
+            return out                            # (the dropped copy of the input features)
+        for o in outs:
+            if isinstance(o, torch.Tensor) and o.is_floating_point():
+                o.requires_grad_(True)
+                o._acm_tape_ctx = ctx             # (the stand-in for ``tensor.grad_fn`` of the lazy-gradient hand-off)
+                self.produced[id(o)] = o
+        self.records.append((fn, ctx, args, outs))
+        return out
+
+    def backward(self, out, grad):
+        if id(out) not in self.produced:
+            raise TapeBroken("the model's output is not the output of one of this package's Functions")
+        grads = {id(out): grad}
+        with torch.no_grad():
+            for fn, ctx, args, outs in reversed(self.records):
+                gouts = tuple(grads.pop(id(o), None) if isinstance(o, torch.Tensor) else None for o in outs)
+                if all(g is None for g in gouts):
+                    continue
+                gins = fn.backward(ctx, *gouts)
+                if not isinstance(gins, tuple):
+                    gins = (gins,)
+                for a, g in zip(args, gins):
+                    if g is None or not isinstance(a, torch.Tensor):
+                        continue
+                    if id(a) in self.produced:
+                        grads[id(a)] = g if id(a) not in grads else grads[id(a)] + g
+                    elif a.requires_grad:
+                        if g.stride() != a.stride():          # AccumulateGrad's layout contract: a strided view is copied (a
+                            g = g.contiguous()                # deferred output copied too early fails the step's all_adopted check)
+                        a.grad = g if a.grad is None else a.grad + g
+        self.records, self.produced = [], {}
+
+
+class on_tape:
+    """``with on_tape(tape): out = model(...)`` -- the Functions the calling thread runs inside go to ``tape``."""
+
+    def __init__(self, tape):
+        self.tape = tape
+
+    def __enter__(self):
+        self.prev = getattr(_TLS, "tape", None)
+        _TLS.tape = self.tape
+        return self.tape
+
+    def __exit__(self, *exc):
+        _TLS.tape = self.prev
+        return False
+
+
+def _run(fn, *args):
+    """``fn.apply(*args)``, or the same call on the calling thread's Tape."""
+    tape = getattr(_TLS, "tape", None)
+    return fn.apply(*args) if tape is None else tape.run(fn, args)
+
+
 class deferred_reductions:
     """``with deferred_reductions() as d: ...; d.flush()`` -- the calls the thread makes inside (and the backward of what
     it ran forward inside) append their second phases to ``d``.  Leaving the block flushes whatever is still pending (or
@@ -779,7 +887,7 @@ class _Mm(torch.autograd.Function):
 
 
 def mm(a, b):
-    return _Mm.apply(a, b)
+    return _run(_Mm, a, b)
 
 
 class _MaskedNll(torch.autograd.Function):
@@ -837,7 +945,7 @@ def masked_nll(logits, labels, row_weight):
     """Fused log-softmax + NLL over the rows with non-zero weight (weights = 1/|train| on the
     training rows reproduces F.log_softmax + NLLLoss(out[train_idx], y[train_idx]),
     ACM-Geometric/train.py:133-134)."""
-    return _MaskedNll.apply(logits, labels, row_weight, _ambient().defer)
+    return _run(_MaskedNll, logits, labels, row_weight, _ambient().defer)
 
 
 # --------------------------------------------------------------------------
@@ -916,7 +1024,7 @@ def dropout(x, p, state, tag=0, pad_to=None, row_offset=0):
     it to the layer with ``input_zero_padded=True``), saving the pad fill + copy."""
     if p <= 0 and not (pad_to and pad_to > x.shape[1]):
         return x
-    return _FusedDropout.apply(x, float(p), int(tag), state, pad_to, int(row_offset))
+    return _run(_FusedDropout, x, float(p), int(tag), state, pad_to, int(row_offset))
 
 
 def agg_pad_width(f_in):
@@ -1104,7 +1212,7 @@ def residual_add_linear(fea, x, weight, bias, relu=True, drop=None, group=None, 
     arguments as residual_linear."""
     if drop is not None and not drop[0] > 0:
         drop = None
-    return _ResidualAddLinear.apply(fea, x, weight, bias, bool(relu), drop, group, _call_or_ambient(call))
+    return _run(_ResidualAddLinear, fea, x, weight, bias, bool(relu), drop, group, _call_or_ambient(call))
 
 
 def residual_linear(x, weight, bias, relu=True, drop=None, group=None, call=None, pipe=None):
@@ -1115,7 +1223,7 @@ def residual_linear(x, weight, bias, relu=True, drop=None, group=None, call=None
     has refilled the table)."""
     if drop is not None and not drop[0] > 0:
         drop = None
-    return _ResidualLinear.apply(x, weight, bias, bool(relu), drop, group, _call_or_ambient(call), pipe)
+    return _run(_ResidualLinear, x, weight, bias, bool(relu), drop, group, _call_or_ambient(call), pipe)
 
 
 # --------------------------------------------------------------------------
@@ -1772,7 +1880,7 @@ class AcmConvFunction(torch.autograd.Function):
         # (zero_grad(set_to_none=False), gradient accumulation, hooks), or the producer's backward may never run
         # (torch.autograd.grad on a subset): the plain GCN API therefore materialises dX and dW' here.
         ctx.lazy_producer = None
-        prod = getattr(x, "grad_fn", None) if not sparse_x else None
+        prod = (getattr(x, "grad_fn", None) or getattr(x, "_acm_tape_ctx", None)) if not sparse_x else None
         if (call.hidden_private is x and prod is not None and getattr(prod, "agg_first", False) and getattr(prod, "call", None) is call
                 and not zero_padded and hops == 1 and call.defer is not None):
             ctx.lazy_producer = prod
@@ -2371,12 +2479,12 @@ def acm_conv(x, params, ops, cfg, post_relu=False, post_scale=None, post_drop=No
     call / tail_layer / agg_holder: see AcmConvFunction.forward."""
     p = params
     if agg_wide_supported(x, ops, cfg, p["weight_low"].shape[0], p["weight_low"].shape[1], post_scale, call, tail_layer):
-        return _AcmAggWide.apply(x, p["weight_low"], p["weight_high"], p["weight_mlp"], p["att_vec_low"], p["att_vec_high"],
+        return _run(_AcmAggWide, x, p["weight_low"], p["weight_high"], p["weight_mlp"], p["att_vec_low"], p["att_vec_high"],
                                  p["att_vec_mlp"], p["att_vec"], p["layer_norm_low.weight"], p["layer_norm_high.weight"],
                                  p["layer_norm_mlp.weight"], p["layer_norm_low.bias"], p["layer_norm_high.bias"],
                                  p["layer_norm_mlp.bias"], ops, cfg, post_relu, post_scale, post_drop, call, in_drop, agg_holder)
-    return AcmConvFunction.apply(
-        x, p["weight_low"], p["weight_high"], p["weight_mlp"], p["att_vec_low"], p["att_vec_high"],
+    return _run(
+        AcmConvFunction, x, p["weight_low"], p["weight_high"], p["weight_mlp"], p["att_vec_low"], p["att_vec_high"],
         p["att_vec_mlp"], p["att_struc_low"], p["struc_low"], p["att_vec"],
         p["layer_norm_low.weight"], p["layer_norm_high.weight"], p["layer_norm_mlp.weight"],
         p["layer_norm_struc_low.weight"], p["layer_norm_low.bias"], p["layer_norm_high.bias"],

@@ -54,8 +54,12 @@ def _capture_mode():
 
 class TrainStep:
     def __init__(self, model, optimizer, x, adj, labels, weights, adj_high=None, adj_un=None, use_graph=False,
-                 fused_dropout=None, pipeline_input=None, steps_per_graph=1, flush_in_optimizer=True, small_step=None):
-        """``small_step``: the fused six-launch step for small graphs (small.SmallPlan / acm_small_step): None = where it
+                 fused_dropout=None, pipeline_input=None, steps_per_graph=1, flush_in_optimizer=True, small_step=None, tape=False):
+        """``tape``: eager steps record this package's Functions on a functional.Tape and replay them backwards themselves
+        instead of building an autograd graph (no Function.apply, no AccumulateGrad nodes, no engine hand-off: the host side of
+        an eager step); a model with torch operations between its layers falls back to autograd on its first step, for good.
+
+        ``small_step``: the fused six-launch step for small graphs (small.SmallPlan / acm_small_step): None = where it
         applies (``self.small`` is the plan, ``self.small_refused`` the reason it does not), False = never.
 
         ``flush_in_optimizer``: with this package's FusedAdam / FusedAdamW the step's deferred gradient sums are flushed by
@@ -94,6 +98,7 @@ class TrainStep:
         # (default: on, unless someone replaced F.dropout -- a mask-replay harness must keep seeing its masks)
         self._manual_advance = False
         self._defer = True
+        self._tape = bool(tape)
         from .optim import _FusedAdamBase
         self._opt_flushes = bool(flush_in_optimizer) and isinstance(optimizer, _FusedAdamBase)
         self._unflushed = None
@@ -164,12 +169,27 @@ class TrainStep:
         # (and, captured by the autograd Functions, with its backward) -- nothing is parked in module state
         pending = AF.DeferredReductions() if self._defer else None
         call = AF.CallContext(defer=pending, pipe=pipe)
+        # eager steps: the Functions on the step's own tape (a capture keeps autograd: nothing to save in a replayed graph)
+        tape = AF.Tape() if (self._tape and not (torch.cuda.is_available() and torch.cuda.is_current_stream_capturing())) else None
         try:
-            loss, dz, out = self._forward_loss(call)
+            with AF.on_tape(tape):
+                loss, dz, out = self._forward_loss(call)
             if pipe is not None:
                 pipe.make_next()              # dropout_{t+1}(x): the operand of the gather the backward carries (only if
                                               # the forward adopted the pipeline's buffers)
-            out.backward(dz)
+            if tape is not None:
+                tape.backward(out, dz)
+            else:
+                out.backward(dz)
+        except AF.TapeBroken:
+            # torch operations between the layers: this model's steps run on autograd from now on; the step is redone
+            self._tape = False
+            if pending is not None:
+                pending.discard()
+            self.opt.zero_grad(set_to_none=True)
+            if pipe is not None:
+                pipe.primed = False
+            return self._forward_backward(for_optimizer)
         except BaseException:
             if pending is not None:
                 pending.discard()

@@ -3,6 +3,7 @@ the outputs of a deferred call with NaN until acm_reduce_flush: the host plumbin
 train.TrainStep) must flush before anything reads a gradient, give the results of the immediate form, and fall back
 to the immediate form when autograd did not adopt the kernels' output tensors."""
 import numpy as np
+import pytest
 import torch
 
 import fake_lib
@@ -217,3 +218,54 @@ def test_train_step_with_the_wide_aggregate_first_layer_defers_its_weight_gradie
         assert all(torch.isfinite(p).all() for p in model.parameters())
     assert traj["fused+deferred"] == traj["fused"]
     np.testing.assert_allclose(traj["fused+deferred"], traj["unfused+deferred"], rtol=1e-5)
+
+
+@pytest.mark.parametrize("cfg", [dict(model_type="acmgcnp", s=0, variant=0, hidden=64, dropout=0.3),
+                                 dict(model_type="acmgcnp", s=0, variant=0, hidden=16, dropout=0.0),
+                                 dict(model_type="acmgcn", s=0, variant=1, hidden=64, dropout=0.3),
+                                 dict(model_type="acmgcnp", s=1, variant=0, hidden=64, dropout=0.3),
+                                 dict(model_type="acmgcnp", s=1, variant=1, hidden=16, dropout=0.0),
+                                 dict(model_type="acmgcnpp", s=0, variant=0, hidden=64, dropout=0.3),
+                                 dict(model_type="acmgcnp", s=0, variant=0, hidden=64, dropout=0.3, csr=1),
+                                 dict(model_type="acmgcnp", s=0, variant=0, hidden=64, dropout=0.3, torch_dropout=1)],
+                         ids=["agg-first", "literal", "acmii", "structure", "structure-acmii", "residual", "csr-features", "mask-tensors"])
+def test_train_step_on_its_own_tape_equals_the_autograd_step(cfg, monkeypatch):
+    """train.TrainStep(tape=True): the step records this package's Functions itself (functional.Tape) and replays them backwards
+    -- no autograd graph.  Same losses, same parameters and the same library calls as the autograd step (the fused loss tail,
+    the lazy projection backward and the input pipeline included: the tape stands in for ``grad_fn`` and ``needs_input_grad``)."""
+    fake = fake_lib.install(monkeypatch)
+    from acm_gnn_amd import GCN, FusedAdamW, data as D, functional as AF, train as T
+    from acm_gnn_amd.graph import CsrGraph, FilterOperators, SparseFeatures
+    adj, x_np, y_np, (tr, _, _), _ = D.synthetic_dataset("tiny", seed=3)
+    low, deg = D.build_filters(adj)
+    from acm_gnn_amd.distributed import make_sharded_operators
+    ops = make_sharded_operators(low, deg, torch.device("cpu"), with_structure=bool(cfg["s"]))
+    x = torch.from_numpy(D.row_normalize_features(x_np))
+    if cfg.get("csr"):
+        import scipy.sparse as sp
+        x = SparseFeatures.from_scipy(sp.csr_matrix(x.numpy()), "cpu")
+    y = torch.from_numpy(y_np)
+    w = T.row_weights(torch.from_numpy(tr), y.shape[0])
+    runs, calls = {}, []
+    for name in [k for k in dir(fake) if k.startswith("acm_") and not k.endswith("_bytes") and k not in ("acm_last_error",)]:
+        orig = getattr(fake, name)
+        if callable(orig):
+            monkeypatch.setattr(fake, name, (lambda o, nm: lambda *a: (calls.append(nm), o(*a))[1])(orig, name))
+    for tape in (False, True):
+        calls.clear()
+        torch.manual_seed(0)
+        model = GCN(7, cfg["hidden"], int(y.max()) + 1, 2, y.shape[0], cfg["dropout"], cfg["model_type"], cfg["s"],
+                    variant=bool(cfg["variant"]), attn_layernorm=True)
+        step = T.TrainStep(model, FusedAdamW(model.parameters(), lr=0.01, weight_decay=1e-3), x, ops, y, w, small_step=False,
+                           tape=tape, fused_dropout=not cfg.get("torch_dropout"))
+        torch.manual_seed(1)                                   # (F.dropout mask tensors of the mask-tensors case)
+        losses = [float(step()) for _ in range(2)]
+        calls.clear()                                          # (the first steps carry one-off work: item streams, a redone step)
+        losses.append(float(step()))
+        runs[tape] = (losses, {k: v.detach().clone() for k, v in model.named_parameters()}, list(calls), step._tape)
+    assert runs[True][3] is True, "the step fell back to autograd"
+    assert runs[True][0] == runs[False][0]
+    for k in runs[False][1]:
+        assert torch.equal(runs[True][1][k], runs[False][1][k]), k
+    strip = lambda cs: [c for c in cs if c not in ("acm_tuning_get", "acm_csr_info")]
+    assert strip(runs[True][2]) == strip(runs[False][2])
