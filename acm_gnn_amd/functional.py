@@ -351,7 +351,10 @@ class Tape:
                     elif a.requires_grad:
                         if g.stride() != a.stride():          # AccumulateGrad's layout contract: a strided view is copied (a
                             g = g.contiguous()                # deferred output copied too early fails the step's all_adopted check)
-                        a.grad = g if a.grad is None else a.grad + g
+                        if a.grad is None:
+                            a.grad = g
+                        else:
+                            a.grad.add_(g)                    # (in place, as AccumulateGrad does without a graph)
         self.records, self.produced = [], {}
 
 

@@ -54,7 +54,7 @@ def _capture_mode():
 
 class TrainStep:
     def __init__(self, model, optimizer, x, adj, labels, weights, adj_high=None, adj_un=None, use_graph=False,
-                 fused_dropout=None, pipeline_input=None, steps_per_graph=1, flush_in_optimizer=True, small_step=None, tape=False):
+                 fused_dropout=None, pipeline_input=None, steps_per_graph=1, flush_in_optimizer=True, small_step=None, tape=True):
         """``tape``: eager steps record this package's Functions on a functional.Tape and replay them backwards themselves
         instead of building an autograd graph (no Function.apply, no AccumulateGrad nodes, no engine hand-off: the host side of
         an eager step); a model with torch operations between its layers falls back to autograd on its first step, for good.
