@@ -13,6 +13,10 @@ script imports them, so ``train.py`` runs unmodified with the MI355X kernels:
     cd /path/to/ACM-GNN/ACM-Pytorch
     python -m acm_gnn_amd.dropin pytorch train.py --model acmgcnp --dataset_name squirrel ...
 
+``--fused-optimizer`` (before the script's name) additionally binds ``torch.optim.Adam`` / ``torch.optim.AdamW`` to this
+package's FusedAdam / FusedAdamW for the run (``train.py:112-117`` constructs them by those names): same arguments, update
+formulas and ``state_dict`` layout, ONE launch per step instead of torch's ~80 -- the other half of an eager step's launches.
+
 The dialect also selects the attention-LayerNorm behaviour: on for
 ACM-Geometric, off for ACM-Pytorch (whose layer only normalises for the never-used spellings
 "acmgcn+"/"acmgcn++").
@@ -46,12 +50,27 @@ def install(dialect):
     return shim
 
 
+def install_fused_optimizers():
+    """Bind torch.optim.Adam / AdamW to FusedAdam / FusedAdamW (the reference constructs its optimizer by those names,
+    ACM-Geometric/train.py:112-117, ACM-Pytorch/train.py:70-84).  Returns the (Adam, AdamW) classes that were bound before."""
+    import torch
+    from ..optim import FusedAdam, FusedAdamW
+    before = (torch.optim.Adam, torch.optim.AdamW)
+    torch.optim.Adam, torch.optim.AdamW = FusedAdam, FusedAdamW
+    return before
+
+
 def main(argv=None):
     argv = list(sys.argv[1:] if argv is None else argv)
+    fused = "--fused-optimizer" in argv[:2]
+    if fused:
+        argv.remove("--fused-optimizer")
     if len(argv) < 2:
-        sys.exit("usage: python -m acm_gnn_amd.dropin {geometric|pytorch} train.py [script args...]")
+        sys.exit("usage: python -m acm_gnn_amd.dropin {geometric|pytorch} [--fused-optimizer] train.py [script args...]")
     dialect, script = argv[0], argv[1]
     sys.path.insert(0, os.path.dirname(os.path.abspath(script)) or os.getcwd())
     install(dialect)
+    if fused:
+        install_fused_optimizers()
     sys.argv = [script] + argv[2:]
     runpy.run_path(script, run_name="__main__")

@@ -49,3 +49,29 @@ def test_unknown_dialect():
     from acm_gnn_amd import dropin
     with pytest.raises(ValueError):
         dropin.install("jax")
+
+
+def test_fused_optimizer_flag_binds_adam_and_adamw_for_the_script(clean_modules, tmp_path, monkeypatch):
+    """``python -m acm_gnn_amd.dropin geometric --fused-optimizer train.py``: the script's ``torch.optim.AdamW(...)`` /
+    ``torch.optim.Adam(...)`` (ACM-Geometric/train.py:112-117) are this package's one-launch optimizers; without the flag
+    they stay torch's."""
+    import torch
+    from acm_gnn_amd import dropin, optim
+    script = tmp_path / "train.py"
+    script.write_text("import sys, torch\nfrom layers import GraphConvolution\n"
+                      "p = [torch.nn.Parameter(torch.zeros(3))]\n"
+                      "RESULT = (type(torch.optim.AdamW(p, lr=0.01, weight_decay=1e-3)).__name__,\n"
+                      "          type(torch.optim.Adam(p, lr=0.01)).__name__, sys.argv[1:])\n")
+    before = (torch.optim.Adam, torch.optim.AdamW)
+    seen = {}
+    import runpy
+    real = runpy.run_path
+    monkeypatch.setattr(runpy, "run_path", lambda path, run_name=None: seen.update(real(path, run_name="not_main")))
+    try:
+        dropin.main(["geometric", "--fused-optimizer", str(script), "--dataset", "x"])
+        assert seen["RESULT"] == ("FusedAdamW", "FusedAdam", ["--dataset", "x"])
+        assert torch.optim.AdamW is optim.FusedAdamW
+    finally:
+        torch.optim.Adam, torch.optim.AdamW = before
+    dropin.main(["geometric", str(script)])
+    assert seen["RESULT"][:2] == ("AdamW", "Adam")
