@@ -83,6 +83,11 @@ class TrainStep:
         if not isinstance(adj, FilterOperators) and isinstance(adj, torch.Tensor) and hasattr(model, "structure_info"):
             four = model.structure_info and getattr(model, "model_type", "") in ("acmgcnp", "acmgcnpp")
             ops = operators_for(adj, adj_high, adj_un if four else None)
+            # the step keeps the operator set it built (the model's forward would look the same set up again, per call, by
+            # the tensors' identity): a caller that hands over the reference's adjacency TENSORS -- the drop-in loop,
+            # ACM-Pytorch/train.py:95-139 -- then reaches every plan that asks for FilterOperators, the fused small-graph
+            # step first of all (round 5: such a caller silently stayed on the general path)
+            self.adj = ops
         if hasattr(model, "auto_csr"):
             # wide one-hot / bag-of-words features handed over dense: the CSR twin, made here once (tuning csr_features)
             self.x = x = model.auto_csr(x, ops if isinstance(ops, FilterOperators) else None)

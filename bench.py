@@ -1,8 +1,8 @@
 #!/usr/bin/env python3
 """Benchmark: edges/sec of one full-batch ACM-GCN training step on a twitch-gamer-shaped graph.
 
-    python bench.py [--gpus N --steps K --warmup W]
-    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+    python bench.py [--gpus N --steps K --warmup W]          # N > 1: starts its own ranks (one per GPU, see self_launch)
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...      # or is started as ranks
 
 A "step" = zero_grad + 2-layer forward + log-softmax/NLL loss + backward + AdamW update on the
 whole graph (the reference's hot loop, ACM-Geometric/train.py:119-136, without its per-epoch
@@ -67,7 +67,34 @@ def parse():
                     help="skip the side measurements of the single-GPU run (literal form, random node order)")
     ap.add_argument("--no-check", action="store_true", help="skip the comparisons with the CPU oracle (eval-mode logits on "
                     "sampled rows; one training-mode step: loss and every parameter gradient)")
+    ap.add_argument("--dry-run-launch", action="store_true",
+                    help="print (as one JSON line) the command and environment bench.py would start its ranks with, then exit; "
+                         "{\"launch\": null} when this process would run the benchmark itself")
     return ap.parse_args()
+
+
+def self_launch(args, argv=None, environ=None):
+    """``python bench.py --gpus N`` WITHOUT a torch.distributed launcher around it (WORLD_SIZE unset): the command that starts
+    one rank per GPU on this node -- torch.distributed.run over RCCL, rendezvous on 127.0.0.1 (the container's hostname may
+    not resolve) on a free port -- with this very command line, or None when this process is the benchmark: already a rank
+    (WORLD_SIZE set), or one GPU without --force-sharded.  Rank 0 of the started job prints the one JSON line; the launcher
+    process is replaced by torch.distributed.run (os.execvpe), so its exit status is the job's.
+
+    (Round 5: such a call exited with "must be launched through torch.distributed.run" -- a driver that runs the N = 1 command
+    with another N would have got no scaling point.)"""
+    environ = os.environ if environ is None else environ
+    argv = [a for a in (sys.argv[1:] if argv is None else argv) if a != "--dry-run-launch"]
+    if "WORLD_SIZE" in environ or not (args.gpus > 1 or args.force_sharded):
+        return None
+    import socket
+    with socket.socket() as sock:                       # a free rendezvous port
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={max(args.gpus, 1)}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + argv
+    env = {"HSA_ENABLE_IPC_MODE_LEGACY": environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"),   # dmabuf IPC (RCCL needs it here)
+           "OMP_NUM_THREADS": environ.get("OMP_NUM_THREADS", str(max((os.cpu_count() or 8) // max(args.gpus, 1), 1)))}
+    return cmd, env
 
 
 def algorithmic_bytes(label, n, nnz, implicit=False):
@@ -116,6 +143,14 @@ def algorithmic_bytes(label, n, nnz, implicit=False):
 
 def main():
     args = parse()
+    launch = self_launch(args)
+    if args.dry_run_launch:
+        print(json.dumps({"launch": None if launch is None else {"cmd": launch[0], "env": launch[1]}}))
+        return
+    if launch is not None:
+        cmd, env = launch
+        sys.stdout.flush()
+        os.execvpe(cmd[0], cmd, dict(os.environ, **env))
     import torch
     import torch.distributed as dist
     import torch.nn.functional as F
@@ -124,9 +159,7 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            sys.exit("bench.py: --gpus N > 1 must be launched through torch.distributed.run (one rank per GPU)")
-        args.gpus = world
+        args.gpus = world                     # started as ranks by someone else's launcher: its world size is the job's
     if not torch.cuda.is_available():
         sys.exit("bench.py needs an MI355X (torch.cuda.is_available() is False)")
     torch.cuda.set_device(local_rank)

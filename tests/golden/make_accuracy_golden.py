@@ -12,6 +12,13 @@ exact same experiment on the MI355X.
 
     python tests/golden/make_accuracy_golden.py squirrel --b        # the SAME experiment once more with another fp32
                                                                     # summation order (see below) -> accuracy_<name>_b.npz
+    python tests/golden/make_accuracy_golden.py cora --philox       # the same experiment with the masks of the library's
+    python tests/golden/make_accuracy_golden.py squirrel --philox   # COUNTER-BASED dropout injected into the reference
+                                                                    # (tests/replay.py: PhiloxDropout over oracle/philox.py,
+                                                                    # seed PHILOX_SEED + split, step = epoch) ->
+                                                                    # accuracy_<name>_philox.npz: the run the fused
+                                                                    # small-graph step (acm_small_step + FusedAdam, masks
+                                                                    # drawn inside the kernels) replays on the MI355X
 
 Splits already recorded in accuracy_<name>.npz are kept (the run is merged into the file).
 
@@ -40,7 +47,10 @@ import torch
 warnings.filterwarnings("ignore")
 HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.dirname(HERE))
-from replay import SeededDropout  # noqa: E402
+sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))       # oracle/philox.py (the --philox masks)
+from replay import PhiloxDropout, SeededDropout  # noqa: E402
+
+PHILOX_SEED = 0x5EED0ACC00000000          # + split: the DropoutState seed of the replay (tests/test_gpu_accuracy.py)
 
 REF = "/root/reference"
 CONFIGS = {
@@ -77,7 +87,7 @@ def dump_film_graph(U, adj_un, features, labels):
     np.savez_compressed(os.path.join(HERE, "graph_film.npz"), **rec)
 
 
-def main(name, only=None, run_b=False):
+def main(name, only=None, run_b=False, philox=False):
     cfg = dict(CONFIGS[name])
     if run_b:
         torch.set_num_threads(3)
@@ -115,7 +125,7 @@ def main(name, only=None, run_b=False):
     if run_b:                                      # same matrices, CSR layout: torch.spmm takes another kernel
         adj_high = adj_high.coalesce().to_sparse_csr()
         adj_unn = adj_unn.coalesce().to_sparse_csr() if adj_unn is not None else None
-    path = os.path.join(HERE, f"accuracy_{name}{'_b' if run_b else ''}.npz")
+    path = os.path.join(HERE, f"accuracy_{name}{'_b' if run_b else ''}{'_philox' if philox else ''}.npz")
     out, accs_by_split = {}, {}
     if os.path.exists(path):                       # keep what an earlier run recorded
         with np.load(path, allow_pickle=False) as f:
@@ -135,7 +145,7 @@ def main(name, only=None, run_b=False):
             model.fea_param.zero_()
             model.xX_param.zero_()
         opt = torch.optim.Adam(model.parameters(), lr=cfg["lr"], weight_decay=cfg["weight_decay"])
-        drop = SeededDropout(seed=split)
+        drop = PhiloxDropout(PHILOX_SEED + split, features) if philox else SeededDropout(seed=split)
         real = F.dropout
         F.dropout = drop
         best_val, curr, hist = float("inf"), 0.0, []
@@ -162,7 +172,8 @@ def main(name, only=None, run_b=False):
         print(f"{name} split {split}: test acc {curr:.4f} after {len(hist)} epochs", flush=True)
         done = sorted(accs_by_split)
         out["cfg"] = json.dumps(dict(cfg, splits=done, dataset=dataset, dialect="pytorch", attn_layernorm=0,
-                                     optimizer="adam", **({"run": "b: CSR sparse operands, 3 threads"} if run_b else {})))
+                                     optimizer="adam", **({"run": "b: CSR sparse operands, 3 threads"} if run_b else {}),
+                                     **({"masks": "philox", "philox_seed": PHILOX_SEED} if philox else {})))
         out["test_acc"] = np.asarray([accs_by_split[s_] for s_ in done])
         np.savez_compressed(path, **out)           # after every split: an interrupted run keeps its work
     accs = list(accs_by_split.values())
@@ -170,5 +181,5 @@ def main(name, only=None, run_b=False):
 
 
 if __name__ == "__main__":
-    args = [a for a in sys.argv[2:] if a != "--b"]
-    main(sys.argv[1], [int(v) for v in args] or None, run_b="--b" in sys.argv[2:])
+    args = [a for a in sys.argv[2:] if a not in ("--b", "--philox")]
+    main(sys.argv[1], [int(v) for v in args] or None, run_b="--b" in sys.argv[2:], philox="--philox" in sys.argv[2:])

@@ -48,3 +48,14 @@ def test_torchrun_launch_with_collectives_in_the_captured_step():
     assert KEYS <= set(d) and d["config"]["checked"] is True
     assert d["config"]["launch"].startswith("hipGraph"), d["config"]["launch"]
     assert d["config"]["shard"]["work_max_over_mean"] <= 1.05
+
+
+def test_bench_starts_its_own_ranks():
+    """``python bench.py --gpus N`` without a launcher around it starts one rank per GPU itself
+    (bench.self_launch: torch.distributed.run, 127.0.0.1 rendezvous).  On the one-GPU box the same entry is reached with
+    ``--gpus 1 --force-sharded``: RCCL initialised, the row-sharded step with its collectives captured, one JSON line."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    d = _run([sys.executable, "bench.py", "--gpus", "1", "--steps", "10", "--warmup", "3", "--no-cpu-baseline", "--force-sharded"], env)
+    assert KEYS <= set(d) and d["n_gpus"] == 1 and d["config"]["checked"] is True
+    assert d["config"]["launch"].startswith("hipGraph"), d["config"]["launch"]
+    assert d["config"]["shard"]["work_max_over_mean"] <= 1.05

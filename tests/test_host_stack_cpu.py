@@ -1439,6 +1439,58 @@ def test_small_graph_step_host_path_equals_the_general_path(model_type, s, varia
     assert "optimizer" in SmallPlan.why_not(ma, xs, ops, torch.optim.Adam(ma.parameters()))
 
 
+def test_train_step_keeps_the_operators_it_builds_from_adjacency_tensors(monkeypatch):
+    """a caller that hands TrainStep the reference's TENSORS (ACM-Pytorch dialect: dense adj_low, sparse
+    adj_high / adj_low_unnormalized, dense bag-of-words features; ACM-Pytorch/train.py:95-139) gets the operator set built
+    once and kept (``step.adj``), the CSR twin of the features, and therefore the fused small-graph step -- the same plan,
+    and the same numbers, as a caller that passes FilterOperators + SparseFeatures himself."""
+    import scipy.sparse as sp
+    fake = fake_lib.install(monkeypatch)
+    from acm_gnn_amd import GCN, FusedAdam, SparseFeatures, functional as AF, train as T
+    from acm_gnn_amd.graph import FilterOperators, operators_for
+    n = 120
+    rng = np.random.default_rng(4)
+    a = sp.random(n, n, density=0.06, random_state=3, format="csr")
+    a = ((a + a.T) > 0).astype(np.float32).tocsr()
+    a.setdiag(0)
+    a.eliminate_zeros()
+    a_un = torch.from_numpy(a.toarray())
+    rowsum = (torch.eye(n) + a_un).sum(1)
+    adj_low = torch.mm(torch.diag(torch.pow(rowsum, -1)), torch.eye(n) + a_un)        # utils.normalize_tensor
+    adj_high = (torch.eye(n) - adj_low).to_sparse()
+    x = torch.from_numpy(((rng.random((n, 400)) < 0.03) * 1.0).astype(np.float32))
+    y = torch.from_numpy(rng.integers(0, 3, n))
+    w = T.row_weights(torch.arange(0, n, 2), n)
+
+    def run(tensors):
+        torch.manual_seed(1)
+        model = GCN(400, 64, 3, 1, n, 0.5, "acmgcnp", 1, variant=False, attn_layernorm=False)
+        model.dropout_state = AF.DropoutState("cpu", seed=9)
+        opt = FusedAdam(model.parameters(), lr=0.01, weight_decay=1e-4)
+        if tensors:
+            step = T.TrainStep(model, opt, x, adj_low, y, w, adj_high, a_un.to_sparse())
+        else:
+            ops = operators_for(adj_low, adj_high, a_un.to_sparse())
+            step = T.TrainStep(model, opt, SparseFeatures.from_torch(x), ops, y, w)
+        assert isinstance(step.adj, FilterOperators) and isinstance(step.x, SparseFeatures)
+        assert step.small is not None, step.small_refused
+        calls = getattr(fake, "small_calls", 0)
+        losses = [float(step()) for _ in range(3)]
+        assert getattr(fake, "small_calls", 0) - calls == 3
+        return losses, [p.detach().clone() for p in model.parameters()]
+
+    la, pa = run(True)
+    lb, pb = run(False)
+    assert la == lb
+    for u, v in zip(pa, pb):
+        assert torch.equal(u, v)
+    # and EvalStep from the same tensors
+    torch.manual_seed(1)
+    model = GCN(400, 64, 3, 1, n, 0.5, "acmgcnp", 1, variant=False, attn_layernorm=False)
+    ev = T.EvalStep(model, x, adj_low, y, (torch.arange(0, n, 2),), adj_high, a_un.to_sparse(), loss_set=0)
+    assert ev.small is not None, ev.small_refused
+
+
 @pytest.mark.parametrize("fused", [True, False], ids=["one_kernel", "products_then_head"])
 @pytest.mark.parametrize("model_type,f_in,p_drop,ln", [("acmgcnp", 128, 0.4, True), ("acmgcn", 65, 0.0, False), ("acmgcnp", 40, 0.3, True)])
 def test_aggregate_first_for_wide_dense_inputs_equals_the_literal_form(model_type, f_in, p_drop, ln, fused, monkeypatch, tune):
