@@ -279,12 +279,20 @@ class _TapeCtx:
     def __init__(self, needs_input_grad):
         self.needs_input_grad = needs_input_grad
         self.saved_tensors = ()
+        self.non_differentiable = ()
 
     def save_for_backward(self, *tensors):
         self.saved_tensors = tensors
 
     def mark_non_differentiable(self, *tensors):
-        pass
+        # (the mixing weights ``att``: Tape.run neither tags them nor gives them requires_grad -- a layer that keeps its
+        # ``att`` around must not keep the step's saved activations alive with it)
+        self.non_differentiable = tuple(id(t) for t in tensors)
+
+    def release(self):
+        """Drop everything the record holds (saved activations, hand-offs parked on the ctx by the Functions)."""
+        self.__dict__.clear()
+        self.saved_tensors = ()
 
     def set_materialize_grads(self, value):
         pass                                  # (Tape.backward hands None to outputs without a gradient, as the Functions ask)
@@ -305,6 +313,11 @@ class Tape:
     def __init__(self):
         self.records = []
         self.produced = {}                    # id(tensor) -> tensor (kept alive: an id must not be handed to another object)
+        self.ctx_of = {}                      # id(tensor) -> the record's ctx: the stand-in for ``tensor.grad_fn`` of the
+                                              # lazy-gradient hand-off.  On the TAPE, not on the tensor: a tensor that outlives
+                                              # the step (a layer's ``att``, an output a caller keeps) must not pin the step's
+                                              # saved activations, and ``out -> ctx -> saved out`` must not be a cycle only the
+                                              # cyclic collector frees (live bytes grew 1.5 -> 8.9 MB in ten steps)
 
     def run(self, fn, args):
         needs = []
@@ -324,17 +337,33 @@ class Tape:
         if not any(needs):                        # as under autograd: nothing to differentiate, the outputs are constants
             return out                            # (the dropped copy of the input features)
         for o in outs:
-            if isinstance(o, torch.Tensor) and o.is_floating_point():
+            if isinstance(o, torch.Tensor) and o.is_floating_point() and id(o) not in ctx.non_differentiable:
                 o.requires_grad_(True)
-                o._acm_tape_ctx = ctx             # (the stand-in for ``tensor.grad_fn`` of the lazy-gradient hand-off)
+                self.ctx_of[id(o)] = ctx
                 self.produced[id(o)] = o
         self.records.append((fn, ctx, args, outs))
         return out
+
+    def producer(self, t):
+        """The ctx of the record that produced ``t`` on this tape (None: not a differentiable output of one)."""
+        return self.ctx_of.get(id(t)) if self.produced.get(id(t)) is t else None
+
+    def release(self):
+        """End of the step (or of the attempt): every record lets go of what it saved."""
+        for _, ctx, _, _ in self.records:
+            ctx.release()
+        self.records, self.produced, self.ctx_of = [], {}, {}
 
     def backward(self, out, grad):
         if id(out) not in self.produced:
             raise TapeBroken("the model's output is not the output of one of this package's Functions")
         grads = {id(out): grad}
+        try:
+            self._backward(grads)
+        finally:
+            self.release()
+
+    def _backward(self, grads):
         with torch.no_grad():
             for fn, ctx, args, outs in reversed(self.records):
                 gouts = tuple(grads.pop(id(o), None) if isinstance(o, torch.Tensor) else None for o in outs)
@@ -355,7 +384,6 @@ class Tape:
                             a.grad = g
                         else:
                             a.grad.add_(g)                    # (in place, as AccumulateGrad does without a graph)
-        self.records, self.produced = [], {}
 
 
 class on_tape:
@@ -1883,7 +1911,8 @@ class AcmConvFunction(torch.autograd.Function):
         # (zero_grad(set_to_none=False), gradient accumulation, hooks), or the producer's backward may never run
         # (torch.autograd.grad on a subset): the plain GCN API therefore materialises dX and dW' here.
         ctx.lazy_producer = None
-        prod = (getattr(x, "grad_fn", None) or getattr(x, "_acm_tape_ctx", None)) if not sparse_x else None
+        tape = getattr(_TLS, "tape", None)
+        prod = (getattr(x, "grad_fn", None) or (tape.producer(x) if tape is not None else None)) if not sparse_x else None
         if (call.hidden_private is x and prod is not None and getattr(prod, "agg_first", False) and getattr(prod, "call", None) is call
                 and not zero_padded and hops == 1 and call.defer is not None):
             ctx.lazy_producer = prod

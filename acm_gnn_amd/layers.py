@@ -182,12 +182,16 @@ class GraphConvolution(nn.Module):
         # the request's labels / weights are rows of the numbering the layer works in
         tail_layer = (bool(self.output_layer) and not post_relu and post_scale is None and post_drop is None
                       and not translate)
+        # P = A_low X of an earlier pass is reusable only for the SAME operand: with an input dropout in play -- carried by
+        # the projection or applied right here -- the operand changes with the step counter while ``raw_input`` (the
+        # holder's key) does not (a stale P when the layer drops the input itself)
+        holder = self._eval_agg_holder(raw_input, ops) if (input_drop is None or input_drop[0] <= 0) else None
         if input_drop is not None and not AF.in_drop_supported(input, ops, cfg, self.in_features, self.out_features):
             p_in, tag_in, st_in = input_drop          # the projection cannot carry it: the dropped copy, as a launch of its own
             input = AF.dropout(input, p_in, st_in, tag=tag_in, row_offset=ops.row_offset)
             input_drop = None
         out, att = AF.acm_conv(input, params, ops, cfg, post_relu, post_scale, post_drop, call=call,
-                               tail_layer=tail_layer, agg_holder=self._eval_agg_holder(raw_input, ops), in_drop=input_drop)
+                               tail_layer=tail_layer, agg_holder=holder, in_drop=input_drop)
         if translate:
             out = out.index_select(0, ops.inv_perm)
         # the mixing weights stay where the kernel wrote them; the attributes translate rows when they are read

@@ -57,8 +57,29 @@ def _param(layer, role):
     return obj
 
 
+def _has_hooks(model, optimizer=None):
+    """Forward / backward hooks on any module, gradient hooks on any parameter, step hooks on the optimizer."""
+    for m in model.modules():
+        if m._forward_hooks or m._forward_pre_hooks or m._backward_hooks or getattr(m, "_backward_pre_hooks", None):
+            return True
+    for p in model.parameters():
+        if getattr(p, "_backward_hooks", None) or getattr(p, "_post_accumulate_grad_hooks", None):
+            return True
+    if optimizer is not None:
+        if getattr(optimizer, "_optimizer_step_pre_hooks", None) or getattr(optimizer, "_optimizer_step_post_hooks", None):
+            return True
+    return False
+
+
 class SmallPlan:
-    """Everything ``acm_small_step`` needs, bound once to (model, optimizer, features, operators, labels, row weights)."""
+    """Everything ``acm_small_step`` needs, bound once to (model, optimizer, features, operators, labels, row weights).
+
+    What a caller of TrainStep / EvalStep does NOT get on this path (by construction: the step is six kernels, not a forward,
+    a backward and an optimizer call): ``p.grad`` stays None (``keep_grads=True`` writes the gradients to ``plan.grads``
+    instead), ``model.forward`` and ``optimizer.step`` are not called -- hooks would not fire, so ``why_not`` refuses a
+    hooked model / parameter / optimizer -- and hyper-parameters are read on every call (eager) or baked in at capture
+    (``use_graph``: like the general path, re-capture after a scheduler changed ``lr``).  Parameters and the optimizer's
+    own state tensors are updated in place: ``state_dict()`` of both is what a stock loop would have left."""
 
     @staticmethod
     def why_not(model, x, ops, optimizer=None, need_dropout_state=True):
@@ -102,6 +123,11 @@ class SmallPlan:
         p_drop = float(getattr(model, "dropout", 0.0))
         if p_drop > 0 and need_dropout_state and not getattr(model, "fused_dropout", False):
             return "F.dropout masks (counter-based dropout only)"
+        if _has_hooks(model, optimizer):
+            # the fused step never calls model.forward, never materialises a .grad and never calls optimizer.step():
+            # nothing a hook is attached to happens, so a hooked model / parameter / optimizer keeps the path
+            # on which its hooks fire
+            return "hooks registered on the model, a parameter or the optimizer"
         if optimizer is not None:
             if not isinstance(optimizer, _FusedAdamBase) or len(optimizer.param_groups) != 1:
                 return "optimizer: FusedAdam / FusedAdamW with one parameter group"

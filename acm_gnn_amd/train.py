@@ -29,6 +29,30 @@ def row_weights(train_idx, n_rows, n_train_total=None, device=None):
     return w
 
 
+def _tape_safe(model):
+    """models.GCN configurations whose training forward is a chain of this package's Functions only (nothing for a Tape to
+    trip over): the two-layer ACM-GCN / ACM-GCN+ and the single-layer ACM-SGC.  ACM-GCN++ adds its residual branch with a
+    torch operation unless the fused dropout's one-launch form applies; acmsnowball concatenates blocks."""
+    from .models import GCN
+    return type(model) is GCN and model.model_type in ("acmgcn", "acmgcnp", "acmsgc")
+
+
+def _rng_snapshot(device):
+    """States of the generators F.dropout draws from: torch's CPU generator and the device's."""
+    dev = torch.device(device)
+    cuda = torch.cuda.get_rng_state(dev) if (dev.type == "cuda" and not torch.cuda.is_current_stream_capturing()) else None
+    return torch.get_rng_state(), cuda, dev
+
+
+def _rng_restore(snap):
+    if snap is None:
+        return
+    cpu, cuda, dev = snap
+    torch.set_rng_state(cpu)
+    if cuda is not None:
+        torch.cuda.set_rng_state(cuda, dev)
+
+
 def _held_entries(model):
     """What a captured pass over ``model`` reads beyond its graph's own pool: the layers' P = A_low X cache entries
     (layers.GraphConvolution._eval_agg_holder: key, input, {"agg": P, "xpad": ...}, operators) as they are right now."""
@@ -60,7 +84,9 @@ class TrainStep:
         an eager step); a model with torch operations between its layers falls back to autograd on its first step, for good.
 
         ``small_step``: the fused six-launch step for small graphs (small.SmallPlan / acm_small_step): None = where it
-        applies (``self.small`` is the plan, ``self.small_refused`` the reason it does not), False = never.
+        applies (``self.small`` is the plan, ``self.small_refused`` the reason it does not), False = never.  On that path
+        ``p.grad`` stays None and neither ``model.forward`` nor ``optimizer.step`` is called (see small.SmallPlan): a model,
+        parameter or optimizer with hooks registered keeps the general path.
 
         ``flush_in_optimizer``: with this package's FusedAdam / FusedAdamW the step's deferred gradient sums are flushed by
         the optimizer's own launch (acm_adam_config_t.pending) instead of a launch of their own.
@@ -104,6 +130,12 @@ class TrainStep:
         self._manual_advance = False
         self._defer = True
         self._tape = bool(tape)
+        self._tape_proven = False           # a first taped step went through: the model's Functions are all this package's
+        if self._tape and F.dropout is not _TORCH_DROPOUT and getattr(model, "dropout", 0) > 0 and not _tape_safe(model):
+            # someone replaced F.dropout (a mask-replay harness: it hands out recorded masks by call position) and this model
+            # may break the tape (torch operations between its layers): the redo of the step on autograd would draw the NEXT
+            # masks of the harness -- its state cannot be put back like a generator's.  Such a step starts on autograd.
+            self._tape = False
         from .optim import _FusedAdamBase
         self._opt_flushes = bool(flush_in_optimizer) and isinstance(optimizer, _FusedAdamBase)
         self._unflushed = None
@@ -176,6 +208,10 @@ class TrainStep:
         call = AF.CallContext(defer=pending, pipe=pipe)
         # eager steps: the Functions on the step's own tape (a capture keeps autograd: nothing to save in a replayed graph)
         tape = AF.Tape() if (self._tape and not (torch.cuda.is_available() and torch.cuda.is_current_stream_capturing())) else None
+        # until a taped step has gone through once, the attempt may have to be redone on autograd: the generators' states are
+        # put back first, so that the redo draws the masks (F.dropout) the aborted forward drew -- the step then IS the step an
+        # autograd run of the same seeds takes (acmgcnpp trained on other masks with tape=True than with False)
+        rng = _rng_snapshot(self.labels.device) if (tape is not None and not self._tape_proven) else None
         try:
             with AF.on_tape(tape):
                 loss, dz, out = self._forward_loss(call)
@@ -184,18 +220,29 @@ class TrainStep:
                                               # the forward adopted the pipeline's buffers)
             if tape is not None:
                 tape.backward(out, dz)
+                self._tape_proven = True
             else:
                 out.backward(dz)
-        except AF.TapeBroken:
-            # torch operations between the layers: this model's steps run on autograd from now on; the step is redone
-            self._tape = False
+        except (AF.TapeBroken, RuntimeError) as err:
+            if tape is not None:
+                tape.release()
             if pending is not None:
                 pending.discard()
+            # an in-place torch operation on a taped output fails inside torch ("a leaf Variable that requires grad is being
+            # used in an in-place operation") before the tape can notice: the same verdict
+            broken = tape is not None and not self._tape_proven and (isinstance(err, AF.TapeBroken) or "leaf Variable" in str(err))
+            if not broken:
+                raise
+            # torch operations between the layers: this model's steps run on autograd from now on; the step is redone
+            self._tape = False
+            _rng_restore(rng)
             self.opt.zero_grad(set_to_none=True)
             if pipe is not None:
                 pipe.primed = False
             return self._forward_backward(for_optimizer)
         except BaseException:
+            if tape is not None:
+                tape.release()
             if pending is not None:
                 pending.discard()
             raise
@@ -381,7 +428,10 @@ class EvalStep:
     the gather.  A CAPTURED pass bakes in the addresses of what its warm-up left behind -- in particular the first layer's
     P = A_low X of an aggregate-first layer (layers.GraphConvolution._eval_agg) -- so it assumes ``x`` is not modified
     in place afterwards (call :meth:`refresh` if it was) and it keeps those tensors alive itself: another evaluation of
-    the same model on other inputs may replace the layers' cache entries, the replay still reads valid memory."""
+    the same model on other inputs may replace the layers' cache entries, the replay still reads valid memory.
+
+    ``small_step`` (None = where it applies): small graphs run the forward as three launches behind one C-ABI call
+    (small.SmallPlan) WITHOUT calling ``model.forward`` -- a model with forward hooks keeps the general path."""
 
     def __init__(self, model, x, adj, labels, index_sets, adj_high=None, adj_un=None, loss_set=1, use_graph=False,
                  small_step=None):

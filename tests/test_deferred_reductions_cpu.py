@@ -269,3 +269,85 @@ def test_train_step_on_its_own_tape_equals_the_autograd_step(cfg, monkeypatch):
         assert torch.equal(runs[True][1][k], runs[False][1][k]), k
     strip = lambda cs: [c for c in cs if c not in ("acm_tuning_get", "acm_csr_info")]
     assert strip(runs[True][2]) == strip(runs[False][2])
+
+
+def test_a_broken_tape_redoes_the_step_on_the_masks_it_drew(monkeypatch):
+    """ACM-GCN++ with F.dropout masks adds its residual branch with a torch operation (models.py:55-56), so the
+    first taped step aborts (TapeBroken) AFTER the forward has drawn F.dropout masks and is redone on autograd.  The redo must
+    draw the SAME masks -- the generators' states are put back -- so that tape=True (the default) trains exactly like
+    tape=False on the same seeds; a mask-replay harness in place of F.dropout (whose state cannot be put back) makes such a
+    model start on autograd instead."""
+    fake_lib.install(monkeypatch)
+    import torch.nn.functional as F
+    from acm_gnn_amd import GCN, FusedAdamW, data as D, train as T
+    from acm_gnn_amd.distributed import make_sharded_operators
+    adj, x_np, y_np, (tr, _, _), _ = D.synthetic_dataset("tiny", seed=3)
+    low, deg = D.build_filters(adj)
+    ops = make_sharded_operators(low, deg, torch.device("cpu"))
+    x, y = torch.from_numpy(D.row_normalize_features(x_np)), torch.from_numpy(y_np)
+    w = T.row_weights(torch.from_numpy(tr), y.shape[0])
+
+    def run(tape, mt="acmgcnpp"):
+        torch.manual_seed(0)
+        model = GCN(7, 64, int(y.max()) + 1, 2, y.shape[0], 0.4, mt, 0, attn_layernorm=True)
+        step = T.TrainStep(model, FusedAdamW(model.parameters(), lr=0.01), x, ops, y, w, small_step=False, tape=tape, fused_dropout=False)
+        torch.manual_seed(5)
+        return [float(step()) for _ in range(3)], step
+
+    la, sa = run(False)
+    lb, sb = run(True)
+    assert sb._tape is False, "the residual add is a torch operation: the tape must have broken"
+    assert la == lb
+    # a patched F.dropout: acmgcnpp never starts on the tape, the two-layer models keep it
+    calls = []
+    real = F.dropout
+    monkeypatch.setattr(F, "dropout", lambda inp, p=0.5, training=True, inplace=False: (calls.append(1), real(inp, p, training))[1])
+    _, s1 = run(True)
+    assert s1._tape is False and len(calls) == 3 * 3            # three sites per forward, three forwards: none drawn twice
+    calls.clear()
+    _, s2 = run(True, "acmgcnp")
+    assert s2._tape is True and s2._tape_proven
+
+
+def test_a_taped_step_releases_what_it_saved(monkeypatch):
+    """the records of a Tape hold the step's saved activations; nothing that outlives the step -- the layers'
+    ``att`` tensors, the returned loss -- may keep them alive, and no reference cycle may be left for the cyclic collector:
+    with the collector switched off, the bytes of live tensors stay constant from step to step."""
+    import gc
+    fake_lib.install(monkeypatch)
+    from acm_gnn_amd import GCN, FusedAdamW, data as D, functional as AF, train as T
+    from acm_gnn_amd.distributed import make_sharded_operators
+    adj, x_np, y_np, (tr, _, _), _ = D.synthetic_dataset("tiny", seed=3)
+    low, deg = D.build_filters(adj)
+    ops = make_sharded_operators(low, deg, torch.device("cpu"))
+    x, y = torch.from_numpy(D.row_normalize_features(x_np)), torch.from_numpy(y_np)
+    w = T.row_weights(torch.from_numpy(tr), y.shape[0])
+    torch.manual_seed(0)
+    model = GCN(7, 64, int(y.max()) + 1, 2, y.shape[0], 0.3, "acmgcnp", 0, attn_layernorm=True)
+    model.dropout_state = AF.DropoutState("cpu", seed=3)
+    step = T.TrainStep(model, FusedAdamW(model.parameters(), lr=0.01), x, ops, y, w, small_step=False, tape=True, pipeline_input=False)
+
+    def live_bytes():
+        seen, total = set(), 0
+        for o in gc.get_objects():
+            if isinstance(o, torch.Tensor) and o.device.type == "cpu":
+                st = o.untyped_storage()
+                if st.data_ptr() not in seen:
+                    seen.add(st.data_ptr())
+                    total += st.nbytes()
+        return total
+
+    for _ in range(3):
+        step()
+    gc.collect()
+    gc.disable()
+    try:
+        before = live_bytes()
+        for _ in range(6):
+            step()
+        after = live_bytes()
+    finally:
+        gc.enable()
+    assert step._tape is True
+    assert after <= before + 4096, (before, after)
+    assert not model.gcns[0].att_low.requires_grad and not hasattr(model.gcns[0].att_low, "_acm_tape_ctx")

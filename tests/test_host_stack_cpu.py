@@ -1580,3 +1580,66 @@ def test_wide_aggregate_first_layer_gathers_a_static_input_once(f_in, monkeypatc
     for _ in range(2):
         model(x, ops).square().sum().backward()
     assert gathers.count(fp) == 2
+
+
+def test_small_plan_refuses_hooked_models_and_optimizers(monkeypatch):
+    """the fused small-graph step calls neither model.forward nor optimizer.step and leaves p.grad None -- a hook
+    on any of them would silently never fire, so such a model / optimizer keeps the general path."""
+    import scipy.sparse as sp
+    fake_lib.install(monkeypatch)
+    from acm_gnn_amd import GCN, FusedAdam, SparseFeatures, train as T
+    from acm_gnn_amd.small import SmallPlan
+    ops, n = _dense_graph_ops(n=90, avg=8, seed=12)
+    rng = np.random.default_rng(0)
+    xs = SparseFeatures.from_scipy(sp.csr_matrix(((rng.random((n, 50)) < 0.08) * 1.0).astype(np.float32)), "cpu")
+    y, w = torch.from_numpy(rng.integers(0, 3, n)), T.row_weights(torch.arange(0, n, 2), n)
+
+    def fresh():
+        torch.manual_seed(1)
+        m = GCN(50, 64, 3, 2, n, 0.0, "acmgcn", 0)
+        return m, FusedAdam(m.parameters(), lr=0.01)
+
+    m, o = fresh()
+    assert SmallPlan.why_not(m, xs, ops, o) is None
+    h = m.gcns[0].register_forward_hook(lambda *a: None)
+    assert "hooks" in SmallPlan.why_not(m, xs, ops, o)
+    step = T.TrainStep(m, o, xs, ops, y, w)
+    assert step.small is None and "hooks" in step.small_refused
+    h.remove()
+    assert SmallPlan.why_not(m, xs, ops, o) is None
+    m, o = fresh()
+    m.gcns[1].weight_low.register_hook(lambda g: g)
+    assert "hooks" in SmallPlan.why_not(m, xs, ops, o)
+    m, o = fresh()
+    o.register_step_post_hook(lambda *a: None)
+    assert "hooks" in SmallPlan.why_not(m, xs, ops, o)
+    assert SmallPlan.why_not(m, xs, ops, None, need_dropout_state=False) is None         # (an evaluation plan has no optimizer)
+
+
+def test_layer_applied_input_dropout_never_reuses_a_cached_aggregate(monkeypatch):
+    """``GraphConvolution.forward(..., input_drop=(p, tag, state))`` on an aggregate-first layer whose projection
+    cannot carry the dropout drops the input itself -- the operand of P = A_low X then changes with the step counter while the
+    raw input tensor (the key of the layer's P cache) does not: the cache must stay out of it."""
+    fake_lib.install(monkeypatch)
+    from acm_gnn_amd import functional as AF
+    from acm_gnn_amd.layers import GraphConvolution
+    ops, n = _dense_graph_ops()
+    x = torch.randn(n, 7, generator=torch.Generator().manual_seed(1))
+    monkeypatch.setattr(AF, "in_drop_supported", lambda *a, **k: False)
+    torch.manual_seed(0)
+    layer = GraphConvolution(7, 64, n, "acmgcnp", attn_layernorm=True)
+    layer.eval()                                           # (no gradient: the P cache is at its most eager)
+    st = AF.DropoutState("cpu", seed=5)
+    with torch.no_grad():
+        a0 = layer(x, ops, input_drop=(0.5, 0, st)).clone()
+        again = layer(x, ops, input_drop=(0.5, 0, st)).clone()
+        st.advance()
+        a1 = layer(x, ops, input_drop=(0.5, 0, st)).clone()
+        layer.__dict__.pop("_eval_agg", None)              # a layer without history, same counter value
+        b1 = layer(x, ops, input_drop=(0.5, 0, st)).clone()
+        plain0 = layer(x, ops).clone()                      # without dropout the cache serves the second pass
+        plain1 = layer(x, ops).clone()
+    assert torch.equal(a0, again) and not torch.equal(a0, a1)
+    assert torch.equal(a1, b1), "the second step used the first step's P"
+    torch.testing.assert_close(plain0, plain1)
+    assert layer.held_entries()
