@@ -19,6 +19,15 @@ for NAME in $PASSES; do
     ta) CNT="TA_BUSY_avr TA_TA_BUSY_sum TD_TD_BUSY_sum TCP_PENDING_STALL_CYCLES_sum TA_ADDR_STALLED_BY_TC_CYCLES_sum TA_DATA_STALLED_BY_TC_CYCLES_sum";;
     lds) CNT="SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_ACTIVE_INST_VMEM SQ_INST_LEVEL_VMEM SQ_BUSY_CU_CYCLES SQ_INSTS_VMEM_WR";;
     mfma) CNT="SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_WAIT_INST_ANY";;
+    # (round 6) the texture path, two counters of a block per pass: r05's six-counter "ta" pass returned no rows
+    ta1) CNT="TA_TA_BUSY_sum TA_BUSY_avr";;
+    ta2) CNT="TA_ADDR_STALLED_BY_TC_CYCLES_sum TA_DATA_STALLED_BY_TC_CYCLES_sum";;
+    ta3) CNT="TA_BUFFER_WAVEFRONTS_sum TA_BUFFER_READ_WAVEFRONTS_sum";;
+    tcp1) CNT="TCP_PENDING_STALL_CYCLES_sum TCP_TA_DATA_STALL_CYCLES_sum";;
+    tcp2) CNT="TCP_TCR_TCP_STALL_CYCLES_sum TCP_READ_TAGCONFLICT_STALL_CYCLES_sum";;
+    tcp3) CNT="TCP_TCC_READ_REQ_LATENCY_sum TCP_TCC_READ_REQ_sum";;
+    tcp4) CNT="TCP_GATE_EN1_sum TCP_GATE_EN2_sum";;
+    occ) CNT="SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_LEVEL_WAVES GRBM_GUI_ACTIVE";;
     fetch) CNT="FETCH_SIZE";;
     write) CNT="WRITE_SIZE";;
   esac
