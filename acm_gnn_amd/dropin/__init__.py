@@ -19,6 +19,10 @@ per step instead of torch's ~80 -- the other half of an eager step's launches.  
 script, amsgrad, a tensor lr) the construction falls back to torch's own class with a warning; ``--torch-optimizer`` (before
 the script's name) switches the binding off altogether (``--fused-optimizer`` is accepted for older command lines).
 
+For ACM-Pytorch the launcher also binds ``utils.train_model`` (the script's training step, utils.py:547-574) to the fused
+small-graph step where it applies (``install_fused_train_step``): Cora / Chameleon / Squirrel-class runs train in six launches
+per step instead of the ~250 of the eager loop.  ``--reference-step`` keeps the reference's own function.
+
 The dialect also selects the attention-LayerNorm behaviour: on for
 ACM-Geometric, off for ACM-Pytorch (whose layer only normalises for the never-used spellings
 "acmgcn+"/"acmgcn++").
@@ -52,6 +56,7 @@ def install(dialect):
     return shim
 
 
+_ON_DEVICE = lambda t: t.is_cuda          # noqa: E731  (the CPU test double of the library lifts this guard)
 _ADAM_POSITIONAL = ("lr", "betas", "eps", "weight_decay", "amsgrad")
 _WARNED = set()
 
@@ -69,7 +74,7 @@ def _why_not_fused(params, args, kw):
         tensors.extend(item["params"] if isinstance(item, dict) else [item])
     if not tensors:
         return "no parameters"
-    if any((not t.is_cuda) or t.dtype != torch.float32 for t in tensors):
+    if any((not _ON_DEVICE(t)) or t.dtype != torch.float32 for t in tensors):
         return "parameters that are not fp32 tensors on a GPU (a CPU run of the script)"
     return None
 
@@ -107,19 +112,125 @@ def install_fused_optimizers():
     return before
 
 
+def _fused_step_refusal(model, optimizer, features, labels, criterion, dataset_name):
+    """None when utils.train_model's step can run as train.TrainStep's fused small-graph step, else the reason (a string)."""
+    import torch
+    from ..optim import _FusedAdamBase
+    if dataset_name == "deezer-europe":
+        return "deezer-europe (2-D labels, AdamW)"
+    if type(criterion) is not torch.nn.NLLLoss or criterion.weight is not None or criterion.reduction != "mean" \
+            or criterion.ignore_index != -100:
+        return "criterion is not a plain nn.NLLLoss()"
+    if not isinstance(optimizer, _FusedAdamBase):
+        return "optimizer is not this package's FusedAdam (the launcher's optimizer binding is off, or did not apply)"
+    if not isinstance(features, torch.Tensor) or features.layout != torch.strided or not _ON_DEVICE(features) or labels.dim() != 1:
+        return "features / labels: a dense feature matrix on the GPU and 1-D labels"
+    if not hasattr(model, "gcns") or not hasattr(model, "dropout") or not hasattr(model, "model_type"):
+        return "not the reference's GCN wrapper"
+    return None
+
+
+def install_fused_train_step():
+    """Bind ``utils.train_model`` -- the training step of ACM-Pytorch/train.py (utils.py:547-574: model.train(), zero_grad,
+    forward, log_softmax + NLLLoss on the training rows, accuracy, backward, optimizer.step()) -- to this package's fused
+    small-graph step (train.TrainStep -> small.SmallPlan: the whole step as six launches behind one C-ABI call) WHERE IT
+    APPLIES: a two-layer acmgcn / acmgcnp model of hidden width 64 on a graph of <= 16 384 nodes with bag-of-words features,
+    ``nn.NLLLoss()``, the launcher's FusedAdam.  Same signature, same return value (100 * training accuracy, training
+    loss -- both of the training-mode forward, as in the reference), parameters and optimizer state updated as
+    ``optimizer.step()`` leaves them.  What differs, on purpose: the dropout masks are the library's counter-based ones
+    (seeded from torch's seed) instead of torch's generator stream -- the accuracy parity of exactly this path against the
+    reference is pinned by tests/test_gpu_accuracy.py (reference runs recorded with these masks injected).  Everything else
+    -- other models, hidden widths, CPU runs, hooks, a scheduler-free-form optimizer -- runs the reference's own function,
+    untouched.  Returns the function that was bound before (None when there is no ``utils.train_model`` to bind)."""
+    try:
+        utils = importlib.import_module("utils")
+    except ImportError:
+        return None
+    ref = getattr(utils, "train_model", None)
+    if ref is None or getattr(ref, "_acm_fused", False):
+        return None
+    import weakref
+
+    import torch
+    steps = {}                                   # id(model) -> (weakref(model), id(optimizer), TrainStep | None, key of the inputs)
+
+    def train_model(model, optimizer, adj_low, adj_high, adj_low_unnormalized, features, labels, idx_train, criterion,
+                    dataset_name):
+        from .. import train as T
+        from ..graph import SparseFeatures
+        inputs = (id(adj_low), id(features), id(labels), id(idx_train), int(idx_train.numel()))
+        entry = steps.get(id(model))
+        if entry is None or entry[0]() is not model or entry[1] != id(optimizer) or entry[3] != inputs:
+            step = None
+            why = _fused_step_refusal(model, optimizer, features, labels, criterion, dataset_name)
+            if why is None:
+                had = {k: getattr(model, k) for k in ("fused_dropout", "dropout_state") if hasattr(model, k)}
+                try:
+                    # (the reference's GCN wrapper has no dropout switches of its own: the step only needs the attributes)
+                    model.fused_dropout, model.dropout_state = getattr(model, "fused_dropout", False), getattr(model, "dropout_state", None)
+                    n = labels.shape[0]
+                    rows = idx_train.nonzero().view(-1) if idx_train.dtype == torch.bool else idx_train.long()    # (the fixed
+                    cand = T.TrainStep(model, optimizer, SparseFeatures.auto(features), adj_low, labels,         # splits are masks)
+                                       T.row_weights(rows, n), adj_high, adj_low_unnormalized, fused_dropout=True)
+                    if cand.small is not None:
+                        step = cand
+                    else:
+                        why = cand.small_refused
+                except (RuntimeError, ValueError, TypeError, NotImplementedError) as exc:
+                    why = f"{type(exc).__name__}: {exc}"
+                if step is None:                  # leave the model and the optimizer as the reference's own step expects them
+                    if hasattr(optimizer, "also_advance"):
+                        optimizer.also_advance = None
+                    for k in ("fused_dropout", "dropout_state"):
+                        if k in had:
+                            setattr(model, k, had[k])
+                        elif hasattr(model, k):
+                            try:
+                                delattr(model, k)
+                            except AttributeError:
+                                pass
+            if step is None and why not in _WARNED:
+                _WARNED.add(why)
+                import warnings
+                warnings.warn(f"acm_gnn_amd.dropin: utils.train_model stays the reference's own ({why})", stacklevel=2)
+            for k in [k for k, v in steps.items() if v[0]() is None]:
+                del steps[k]
+            entry = steps[id(model)] = (weakref.ref(model), id(optimizer), step, inputs)
+        step = entry[2]
+        if step is None:
+            return ref(model, optimizer, adj_low, adj_high, adj_low_unnormalized, features, labels, idx_train, criterion,
+                       dataset_name)
+        model.train()
+        loss = step()
+        logits = step.small.logits                # the training-mode logits of the step (log_softmax keeps the arg-max)
+        acc = (logits[idx_train].argmax(1) == labels[idx_train]).double().mean()
+        acc_v, loss_v = torch.stack([100 * acc, loss.double()]).tolist()        # ONE synchronising copy (the reference: two .item())
+        return acc_v, loss_v
+
+    train_model._acm_fused, train_model.reference = True, ref
+    utils.train_model = train_model
+    return ref
+
+
 def main(argv=None):
     argv = list(sys.argv[1:] if argv is None else argv)
     fused = True                                  # on by default since round 6 (it degrades to torch's own where it does not apply)
-    for flag in ("--fused-optimizer", "--torch-optimizer"):
-        if flag in argv[:3] and argv.index(flag) < 3:
+    fused_step = True                             # ... and so is the fused small-graph step behind utils.train_model (ACM-Pytorch)
+    for flag in ("--fused-optimizer", "--torch-optimizer", "--reference-step"):
+        if flag in argv[:4] and argv.index(flag) < 4:
             argv.remove(flag)
-            fused = flag == "--fused-optimizer"
+            if flag == "--reference-step":
+                fused_step = False
+            else:
+                fused = flag == "--fused-optimizer"
     if len(argv) < 2:
-        sys.exit("usage: python -m acm_gnn_amd.dropin {geometric|pytorch} [--torch-optimizer] train.py [script args...]")
+        sys.exit("usage: python -m acm_gnn_amd.dropin {geometric|pytorch} [--torch-optimizer] [--reference-step] train.py [script args...]")
     dialect, script = argv[0], argv[1]
     sys.path.insert(0, os.path.dirname(os.path.abspath(script)) or os.getcwd())
     install(dialect)
     if fused:
         install_fused_optimizers()
+    if fused and fused_step and dialect == "pytorch":
+        install_fused_train_step()
     sys.argv = [script] + argv[2:]
     runpy.run_path(script, run_name="__main__")

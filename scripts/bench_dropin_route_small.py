@@ -1,0 +1,139 @@
+#!/usr/bin/env python3
+"""The zero-edit route on the small graphs, timed where the reference runs it: the loop body of ACM-Pytorch/utils.py:547-574
+(train_model: model.train(), zero_grad, forward on the DENSE adj_low + sparse adj_high [+ adj_low_unnormalized] the loader
+builds, F.log_softmax, NLLLoss on the training rows, accuracy(...).item(), backward, torch.optim.Adam, loss.item()) + the
+evaluation forward of ACM-Pytorch/train.py:112-121, on Cora / Squirrel / Chameleon (real structures; Cora / Squirrel real
+features, Chameleon a Bernoulli stand-in of the real width) -- what a user of the unmodified script gets from the drop-in
+layer (dialect "pytorch": attention LayerNorm off, F.dropout mask tensors, the launcher's optimizer binding).
+
+Per graph: ms per epoch of that loop (host + device: the two .item() calls synchronise every step), the library's kernel time
+inside it (HIP events around every C-ABI call) and, beside it, the same model on this package's own loop (train.TrainStep +
+EvalStep: the fused small-graph step, captured) -- the distance is the price of zero edits."""
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import scipy.sparse as sp
+import torch
+import torch.nn.functional as F
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import acm_gnn_amd  # noqa: E402
+from acm_gnn_amd import dropin, functional as AF, graph, train as T  # noqa: E402
+
+DEV = torch.device("cuda:0")
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+CASES = {"cora": dict(model="acmgcn", s=0, classes=7, p=0.6, lr=0.01, wd=5e-5),
+         "squirrel": dict(model="acmgcnp", s=1, classes=5, p=0.6, lr=0.002, wd=1e-4),
+         "chameleon": dict(model="acmgcnp", s=1, classes=5, p=0.6, lr=0.002, wd=1e-4)}
+
+
+def load(name):
+    g = np.load(os.path.join(GOLDEN, f"graph_{name}.npz"))
+    n = int(g["n"])
+    a = sp.csr_matrix((np.ones(len(g["adj_un_indices"]), np.float32), g["adj_un_indices"], g["adj_un_indptr"]), shape=(n, n))
+    if "feat_indices" in g.files:
+        vals = g["feat_vals"] if "feat_vals" in g.files else np.ones(len(g["feat_indices"]), np.float32)
+        x = sp.csr_matrix((vals, g["feat_indices"], g["feat_indptr"]), shape=(n, int(g["feat_dim"]))).toarray().astype(np.float32)
+    else:
+        x = (np.random.default_rng(2325).random((n, 2325)) < 0.0086).astype(np.float32)
+    y = g["labels"] if "labels" in g.files else np.random.default_rng(0).integers(0, 5, n)
+    return n, a, x, np.asarray(y, np.int64)
+
+
+def run(name, steps=60):
+    cfg = CASES[name]
+    n, a, x_np, y_np = load(name)
+    graph.clear_cache()
+    a_un = torch.from_numpy(a.toarray())
+    rowsum = (torch.eye(n) + a_un).sum(1)
+    adj_low = torch.mm(torch.diag(torch.pow(rowsum, -1)), torch.eye(n) + a_un).to(DEV)          # utils.normalize_tensor: dense
+    adj_high = (torch.eye(n, device=DEV) - adj_low).to_sparse()
+    adj_un = a_un.to_sparse().to(DEV) if cfg["s"] else None
+    x, y = torch.from_numpy(x_np).to(DEV), torch.from_numpy(y_np).to(DEV)
+    if not cfg["s"]:
+        x = x / x.sum(1, keepdim=True).clamp_min(1e-12)
+    perm = torch.randperm(n, generator=torch.Generator().manual_seed(0))
+    tr, va, te = perm[: int(0.6 * n)].to(DEV), perm[int(0.6 * n): int(0.8 * n)].to(DEV), perm[int(0.8 * n):].to(DEV)
+    crit = torch.nn.NLLLoss()
+
+    def model_and_opt(adam):
+        torch.manual_seed(0)
+        m = acm_gnn_amd.GCN(x.shape[1], 64, cfg["classes"], 1, n, cfg["p"], cfg["model"], cfg["s"], variant=False,
+                            attn_layernorm=False).to(DEV)
+        return m, adam(m.parameters(), lr=cfg["lr"], weight_decay=cfg["wd"])
+
+    out = {"graph": name, "nodes": n, "nnz_low": int(a.nnz + n), "f_in": int(x.shape[1]), "model": cfg["model"], "structure_info": cfg["s"]}
+
+    def train_model(model, optimizer, adj_low, adj_high, adj_low_unnormalized, features, labels, idx_train, criterion, dataset_name):
+        model.train()                                               # utils.py:547-574, restated (the checkout does not travel)
+        optimizer.zero_grad()
+        o = F.log_softmax(model(features, adj_low, adj_high, adj_low_unnormalized), dim=1)
+        loss = criterion(o[idx_train], labels[idx_train])
+        acc = (o[idx_train].max(1)[1] == labels[idx_train]).double().sum() / idx_train.numel()
+        loss.backward()
+        optimizer.step()
+        return 100 * acc.item(), loss.item()
+
+    import types
+    utils = types.ModuleType("utils")
+    utils.train_model = train_model
+    sys.modules["utils"] = utils
+    before = dropin.install_fused_optimizers()                    # what `python -m acm_gnn_amd.dropin pytorch train.py` does ...
+    try:
+        for label, adam, bind in (("launcher_default", torch.optim.Adam, True),           # ... + utils.train_model bound (round 6)
+                                  ("reference_step_fused_optimizer", torch.optim.Adam, False),        # --reference-step
+                                  ("reference_step_torch_optimizer", before[0], False)):            # --torch-optimizer
+            utils.train_model = train_model
+            if bind:
+                dropin.install_fused_train_step()
+            model, opt = model_and_opt(adam)
+
+            def epoch():                                            # train.py:97-121: train_model, then the evaluation forward
+                r = utils.train_model(model, opt, adj_low, adj_high, adj_un, x, y, tr, crit, name)
+                model.eval()
+                o = F.log_softmax(model(x, adj_low, adj_high, adj_un), dim=1)
+                return r, crit(o[va], y[va])
+
+            for _ in range(5):
+                epoch()
+            torch.cuda.synchronize()
+            t = time.perf_counter()
+            for _ in range(steps):
+                epoch()
+            torch.cuda.synchronize()
+            out[f"{label}_ms_per_epoch"] = round((time.perf_counter() - t) / steps * 1e3, 3)
+            timer = AF.KernelTimer()
+            AF.set_kernel_timer(timer)
+            for _ in range(5):
+                epoch()
+            out[f"{label}_library_kernels_us_per_epoch"] = round(sum(v[1] for v in timer.summary().values()) / 5 * 1e3, 1)
+            AF.set_kernel_timer(None)
+            out[f"{label}_optimizer"] = type(opt).__name__
+            out[f"{label}_train_model"] = "fused small-graph step" if getattr(utils.train_model, "_acm_fused", False) else "reference"
+    finally:
+        torch.optim.Adam, torch.optim.AdamW = before
+        sys.modules.pop("utils", None)
+    # this package's own loop on the same tensors: the fused small-graph step + the three-launch evaluation pass, captured
+    model, opt = model_and_opt(acm_gnn_amd.FusedAdam)
+    step = T.TrainStep(model, opt, x, adj_low, y, T.row_weights(tr, n), adj_high, adj_un, use_graph=True)
+    ev = T.EvalStep(model, x, adj_low, y, (va,), adj_high, adj_un, loss_set=0, use_graph=True)
+    for _ in range(5):
+        step(), ev()
+    torch.cuda.synchronize()
+    t = time.perf_counter()
+    for _ in range(steps):
+        step()
+        ev()
+    torch.cuda.synchronize()
+    out["own_loop_ms_per_epoch"] = round((time.perf_counter() - t) / steps * 1e3, 3)
+    out["own_loop_small_step"] = step.small is not None and ev.small is not None
+    return out
+
+
+if __name__ == "__main__":
+    for name in sys.argv[1:] or list(CASES):
+        print(json.dumps(run(name)), flush=True)
