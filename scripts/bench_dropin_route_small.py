@@ -100,12 +100,15 @@ def run(name, steps=60):
 
             for _ in range(5):
                 epoch()
-            torch.cuda.synchronize()
-            t = time.perf_counter()
-            for _ in range(steps):
-                epoch()
-            torch.cuda.synchronize()
-            out[f"{label}_ms_per_epoch"] = round((time.perf_counter() - t) / steps * 1e3, 3)
+            best = 1e9
+            for _ in range(3):                                      # (host-bound loops: the best of three windows)
+                torch.cuda.synchronize()
+                t = time.perf_counter()
+                for _ in range(steps):
+                    epoch()
+                torch.cuda.synchronize()
+                best = min(best, (time.perf_counter() - t) / steps * 1e3)
+            out[f"{label}_ms_per_epoch"] = round(best, 3)
             timer = AF.KernelTimer()
             AF.set_kernel_timer(timer)
             for _ in range(5):
@@ -123,13 +126,16 @@ def run(name, steps=60):
     ev = T.EvalStep(model, x, adj_low, y, (va,), adj_high, adj_un, loss_set=0, use_graph=True)
     for _ in range(5):
         step(), ev()
-    torch.cuda.synchronize()
-    t = time.perf_counter()
-    for _ in range(steps):
-        step()
-        ev()
-    torch.cuda.synchronize()
-    out["own_loop_ms_per_epoch"] = round((time.perf_counter() - t) / steps * 1e3, 3)
+    best = 1e9
+    for _ in range(3):
+        torch.cuda.synchronize()
+        t = time.perf_counter()
+        for _ in range(steps):
+            step()
+            ev()
+        torch.cuda.synchronize()
+        best = min(best, (time.perf_counter() - t) / steps * 1e3)
+    out["own_loop_ms_per_epoch"] = round(best, 3)
     out["own_loop_small_step"] = step.small is not None and ev.small is not None
     return out
 
