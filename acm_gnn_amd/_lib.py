@@ -14,7 +14,7 @@ c_i32p = C.POINTER(C.c_int32)
 
 ACM_OK = 0
 STATUS_NAMES = {1: "ACM_EINVAL", 2: "ACM_ESHAPE", 3: "ACM_EHIP", 4: "ACM_EUNSUPPORTED", 5: "ACM_ENOMEM"}
-ABI_VERSION = 27
+ABI_VERSION = 28
 
 # every symbol include/acm_hip.h declares
 EXPORTED_SYMBOLS = (
@@ -28,6 +28,7 @@ EXPORTED_SYMBOLS = (
     "acm_acmii_table_bytes", "acm_acmii_table", "acm_conv_acmii_v_fwd", "acm_conv_acmii_v_bwd_workspace_bytes", "acm_conv_acmii_v_bwd",
     "acm_linear_bwd_workspace_bytes", "acm_linear_bwd", "acm_linear_fwd_add", "acm_linear_bwd_recompute",
     "acm_small_step_workspace_bytes", "acm_small_step", "acm_conv_head_fwd", "acm_conv_aggw_fwd", "acm_conv_aggw_bwd_workspace_bytes", "acm_conv_aggw_bwd",
+    "acm_eval_metrics_workspace_bytes", "acm_eval_metrics",
 )
 
 
@@ -286,6 +287,8 @@ def _declare(lib):
     lib.acm_conv_agg_bwd.argtypes = [i64, C.POINTER(ConvAggBwd), vp, sz, vp]
     lib.acm_nll_loss_workspace_bytes.argtypes = [i64, C.POINTER(sz)]
     lib.acm_nll_loss.argtypes = [i64, i32, vp, i64, vp, vp, vp, vp, i64, vp, sz, vp, vp]
+    lib.acm_eval_metrics_workspace_bytes.argtypes = [i64, i32, C.POINTER(sz)]
+    lib.acm_eval_metrics.argtypes = [i64, i32, vp, i64, vp, vp, i64, i32, i32, vp, vp, sz, vp]
     lib.acm_reduce_flush.argtypes = [vp, vp]
     lib.acm_conv_fwd_tail_workspace_bytes.argtypes = [i64, i32, i32, C.POINTER(sz)]
     lib.acm_conv_fwd_tail.argtypes = [vp, C.POINTER(ConvFwd), C.POINTER(Loss), C.POINTER(ConvBwdLocal), vp, sz, vp, sz, vp]

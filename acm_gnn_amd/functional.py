@@ -982,6 +982,33 @@ def masked_nll(logits, labels, row_weight):
 # --------------------------------------------------------------------------
 # counter-based dropout (acm_dropout_t)
 # --------------------------------------------------------------------------
+def eval_metrics_buffers(n_rows, n_sets, device):
+    """(result [n_sets + 1], workspace) for :func:`eval_metrics`; the workspace is zeroed ONCE (its arrival counter resets
+    itself after every launch)."""
+    nbytes = C.c_size_t()
+    _lib.check(_lib.load().acm_eval_metrics_workspace_bytes(int(n_rows), int(n_sets), C.byref(nbytes)), "acm_eval_metrics_workspace_bytes")
+    return (torch.empty(n_sets + 1, dtype=_F32, device=device),
+            torch.zeros(max(nbytes.value // 4, 1), dtype=_F32, device=device))
+
+
+def eval_metrics(logits, labels, weights, loss_set, buffers=None):
+    """Accuracy on every index set and the NLL on set ``loss_set`` from eval-mode logits, as one launch (acm_eval_metrics:
+    the evaluation of ACM-Geometric/train.py:138-140 + data_utils.py:153-168 and ACM-Pytorch/train.py:112-139).
+    ``weights`` [k, n]: 1 / |set| on the set's rows, 0 elsewhere (rows of weight 0 may carry the label -1).  Returns the
+    fp32 tensor [acc_0 .. acc_{k-1}, nll]."""
+    _require_cuda(logits, "logits")
+    n, c = logits.shape
+    k = weights.shape[0]
+    if weights.shape[1] != n or weights.dtype != _F32 or weights.stride(1) != 1 or labels.shape[0] != n:
+        raise ValueError("eval_metrics: weights must be fp32 [k, n] with contiguous rows, labels [n]")
+    res, ws = buffers if buffers is not None else eval_metrics_buffers(n, k, logits.device)
+    with _device_ctx(logits.device), _Timed(f"eval_metrics/{n}x{c}k{k}"):
+        st = _lib.load().acm_eval_metrics(n, c, _vp(logits), logits.stride(0), _vp(labels), _vp(weights), weights.stride(0), k,
+                                          int(loss_set), _vp(res), _vp(ws), ws.numel() * 4, _stream())
+    _lib.check(st, "acm_eval_metrics")
+    return res
+
+
 class DropoutState:
     """Seed + device step counter of the counter-based dropout.  The mask of element (row, col) is a pure
     function of (seed, step, tag, row, col), so forward and backward kernels regenerate it instead of storing

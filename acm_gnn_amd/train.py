@@ -434,8 +434,9 @@ class EvalStep:
     (small.SmallPlan) WITHOUT calling ``model.forward`` -- a model with forward hooks keeps the general path."""
 
     def __init__(self, model, x, adj, labels, index_sets, adj_high=None, adj_un=None, loss_set=1, use_graph=False,
-                 small_step=None):
+                 small_step=None, fused_metrics=True):
         self.model, self.x, self.adj, self.adj_high, self.adj_un = model, x, adj, adj_high, adj_un
+        self.fused_metrics, self._metrics = bool(fused_metrics), None
         self.labels = labels
         self._labels_safe = labels.clamp_min(0)             # -1 = unlabeled (never in an index set)
         n, dev = labels.shape[0], labels.device
@@ -477,10 +478,26 @@ class EvalStep:
             out = self.small.run()                       # three launches, one C-ABI call (acm_small_step, train = 0)
         else:
             out = self.model(self.x, self.adj, self.adj_high, self.adj_un)
+        if self._metrics_ok(out):
+            # accuracy on every index set + the NLL on one of them as ONE launch over the logits (acm_eval_metrics, ABI 28)
+            # instead of argmax / compare / log_softmax / gather / matmul / sum / cat (eight torch launches)
+            return out, AF.eval_metrics(out, self.labels, self.w, self.loss_set, self._metrics_buffers(out))
         correct = (out.argmax(dim=1) == self.labels).to(torch.float32)
         nll = -F.log_softmax(out, 1).gather(1, self._labels_safe.view(-1, 1)).view(-1)
         res = torch.cat([self.w @ correct, (self.w[self.loss_set] * nll).sum().view(1)])
         return out, res
+
+    def _metrics_ok(self, out):
+        return (self.fused_metrics and out.dim() == 2 and out.shape[1] <= 64 and 1 <= self.w.shape[0] <= 8
+                and out.dtype == torch.float32 and out.stride(1) == 1 and self.labels.dtype == torch.int64
+                and self.labels.dim() == 1 and self.labels.is_contiguous())
+
+    def _metrics_buffers(self, out):
+        """(result [k + 1], zero-initialised workspace) of acm_eval_metrics, made once per pass object: a captured pass bakes
+        their addresses in."""
+        if self._metrics is None:
+            self._metrics = AF.eval_metrics_buffers(out.shape[0], self.w.shape[0], out.device)
+        return self._metrics
 
     def _capture(self):
         side = torch.cuda.Stream()

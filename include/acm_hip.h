@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define ACM_ABI_VERSION 27
+#define ACM_ABI_VERSION 28
 
 typedef enum {
     ACM_OK = 0,
@@ -839,6 +839,24 @@ int acm_nll_loss(int64_t n_rows, int n_classes, const float* logits, int64_t ld_
                  const int64_t* labels, const float* row_weight,
                  float* loss, float* dlogits, int64_t ld_dlogits,
                  void* workspace, size_t workspace_bytes, acm_reduce_list_t* defer, acm_stream_t stream);
+
+/* ------------------------------------------------ evaluation metrics (ABI 28) --
+ * The per-epoch evaluation of the reference's loops -- eval-mode logits -> accuracy on each index set and the NLL on the
+ * validation set (ACM-Geometric/train.py:138-140 + data_utils.py:153-168: eval_acc over train / valid / test;
+ * ACM-Pytorch/train.py:112-139: log_softmax, criterion(output[idx_val], labels[idx_val]), accuracy on idx_val / idx_test) --
+ * as ONE launch over the logits instead of argmax / compare / log_softmax / gather / index / mean kernels:
+ *     out[s]      = sum_i weights[s][i] * [argmax_c z_i[c] == y_i]          s = 0 .. n_sets - 1
+ *     out[n_sets] = sum_i weights[loss_set][i] * (logsumexp(z_i) - z_i[y_i])
+ * weights[s] = 1 / |set s| on the set's rows and 0 elsewhere (rows outside every set may carry the label -1 the
+ * reference uses for "unlabeled": a zero-weight row is never looked up).  argmax takes the FIRST maximum, like torch.
+ * Deterministic: per-block partial sums in `workspace` (fixed tree), the block that arrives last adds them in block
+ * order; the arrival counter (the last 4 bytes of the workspace, zero before the first call) resets itself.
+ * n_classes <= 64, n_sets <= 8.  Workspace: acm_eval_metrics_workspace_bytes (zero-initialised once by the caller).
+ */
+int acm_eval_metrics_workspace_bytes(int64_t n_rows, int n_sets, size_t* bytes);
+int acm_eval_metrics(int64_t n_rows, int n_classes, const float* logits, int64_t ld_logits, const int64_t* labels,
+                     const float* weights, int64_t ld_weights, int n_sets, int loss_set, float* out,
+                     void* workspace, size_t workspace_bytes, acm_stream_t stream);
 
 /* ---------------------------------------- output layer + loss + K3, fused --
  * For a narrow OUTPUT layer (f_out = n_classes <= 8, three channels, no post-op) whose result goes straight into the

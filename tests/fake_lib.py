@@ -404,6 +404,29 @@ class FakeLib:
         _view(dz, n, c, ldd)[...] = W[:, None] * (e / s - onehot)
         return self._emit(defer, [(_vec(loss, 1), float((W * (lse - Z[np.arange(n), Y])).sum()))])
 
+    # ---- evaluation metrics (ABI 28): accuracy per index set + NLL on one of them, from eval-mode logits
+    def acm_eval_metrics_workspace_bytes(self, n, n_sets, out):
+        out._obj.value = 4 * (int(n_sets) + 2)
+        return 0
+
+    def acm_eval_metrics(self, n, c, z, ldz, y, w, ldw, n_sets, loss_set, out, ws, wsb, stream):
+        if not (1 <= n_sets <= 8 and 0 <= loss_set < n_sets and c <= 64):
+            self._err = b"acm_eval_metrics: bad sizes"
+            return 2
+        self.eval_metrics_calls = getattr(self, "eval_metrics_calls", 0) + 1
+        Z = _view(z, n, c, ldz).astype(np.float64)
+        Y = _vec(y, n, np.int64)
+        W = _view(w, n_sets, n, ldw).astype(np.float64)
+        used = (W != 0).any(0)
+        Ys = np.where(used, Y, 0)
+        hit = (Z.argmax(1) == Ys) & used                 # (numpy's argmax takes the first maximum too)
+        m = Z.max(1)
+        nll = np.where(used, m + np.log(np.exp(Z - m[:, None]).sum(1)) - Z[np.arange(n), Ys], 0.0)
+        res = _vec(out, n_sets + 1)
+        res[:n_sets] = W @ hit.astype(np.float64)
+        res[n_sets] = float((W[loss_set] * nll).sum())
+        return 0
+
     # ---- compute ----------------------------------------------------------
     def acm_gemm(self, ta, tb, m, n, k, a, lda, b, ldb, c, ldc, relu, ws, wsb, stream):
         A = _view(a, k, m, lda).T if ta else _view(a, m, k, lda)

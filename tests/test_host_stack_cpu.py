@@ -1643,3 +1643,29 @@ def test_layer_applied_input_dropout_never_reuses_a_cached_aggregate(monkeypatch
     assert torch.equal(a1, b1), "the second step used the first step's P"
     torch.testing.assert_close(plain0, plain1)
     assert layer.held_entries()
+
+
+def test_eval_step_takes_the_one_launch_metrics(monkeypatch):
+    """train.EvalStep: accuracy per index set + validation NLL from ONE library call (acm_eval_metrics, ABI 28) instead of
+    eight torch launches; same numbers as the torch ops, unlabeled rows (-1) outside the sets allowed, and anything the call
+    does not cover (more than 64 classes, more than eight sets) keeps the torch ops."""
+    fake = fake_lib.install(monkeypatch)
+    from acm_gnn_amd import GCN, train as T
+    ops, n = _dense_graph_ops(n=200, avg=10, seed=2)
+    g = torch.Generator().manual_seed(0)
+    x, y = torch.randn(n, 7, generator=g), torch.randint(0, 3, (n,), generator=g)
+    sets = (torch.arange(0, 80), torch.arange(80, 140), torch.arange(140, 190))
+    y[190:] = -1
+    torch.manual_seed(0)
+    model = GCN(7, 64, 3, 2, n, 0.2, "acmgcnp", 0, attn_layernorm=True)
+    a = T.EvalStep(model, x, ops, y, sets)
+    b = T.EvalStep(model, x, ops, y, sets, fused_metrics=False)
+    calls = getattr(fake, "eval_metrics_calls", 0)
+    (oa, acc_a, la), (ob, acc_b, lb) = a(), b()
+    assert getattr(fake, "eval_metrics_calls", 0) - calls == 1
+    torch.testing.assert_close(oa, ob)
+    np.testing.assert_allclose(acc_a, acc_b, rtol=1e-6)
+    np.testing.assert_allclose(la, lb, rtol=1e-5)
+    many = T.EvalStep(model, x, ops, y, tuple(torch.arange(q, q + 10) for q in range(0, 90, 10)))      # nine sets
+    many()
+    assert getattr(fake, "eval_metrics_calls", 0) - calls == 1
