@@ -1,6 +1,6 @@
 /* A plain-C client of libacm_hip.so: no Python, no torch -- only the HIP runtime for device memory.
  * Builds a small graph, runs acm_spmm / acm_spmm_ex (pattern-only handle + row scale) / acm_gemm / acm_adam_step /
- * acm_nll_loss (immediate and deferred + acm_reduce_flush)
+ * acm_nll_loss (immediate and deferred + acm_reduce_flush) / acm_eval_metrics
  * and checks them against loops on the host.  Compiled and run by tests/test_gpu_c_abi.py:
  *     gcc -std=c11 -D__HIP_PLATFORM_AMD__ abi_smoke.c -I include -I/opt/rocm/include -L acm_gnn_amd/lib -lacm_hip \
  *         -L/opt/rocm/lib -lamdhip64 -lm -o abi_smoke
@@ -154,6 +154,43 @@ int main(void) {
     if (loss2[0] != loss2[1] || fabs(loss2[0] - want) > 1e-5) { printf("acm_nll_loss %g / deferred %g vs %g\n", loss2[0], loss2[1], want); return 14; }
     pending.cap = 0;
     if (acm_nll_loss(N, C2, d_z, C2, (const int64_t*)d_lab, d_w, d_loss, d_dz, C2, lw, lws, &pending, NULL) != ACM_ENOMEM) { printf("full deferral list accepted\n"); return 15; }
+
+    /* 5b. acm_eval_metrics (ABI 28): accuracy on two index sets + the NLL on the second, one launch, twice (the arrival
+     *     counter in the workspace resets itself) */
+    {
+        float w2[2 * N];
+        int n0 = 0, n1 = 0;
+        for (int i = 0; i < N; ++i) { n0 += i % 3 == 0; n1 += i % 3 == 1; }
+        for (int i = 0; i < N; ++i) { w2[i] = (i % 3 == 0) ? 1.0f / n0 : 0.f; w2[N + i] = (i % 3 == 1) ? 1.0f / n1 : 0.f; }
+        long long lab2[N];
+        for (int i = 0; i < N; ++i) lab2[i] = (i % 3 == 2) ? -1 : lab[i];              /* rows outside both sets: unlabeled */
+        float* d_w2 = (float*)to_dev(w2, sizeof(w2));
+        long long* d_lab2 = (long long*)to_dev(lab2, sizeof(lab2));
+        float* d_m = (float*)to_dev(NULL, 3 * sizeof(float));
+        size_t mws = 0;
+        CHECK_ACM(acm_eval_metrics_workspace_bytes(N, 2, &mws));
+        void* mw = to_dev(NULL, mws);
+        CHECK_HIP(hipMemset(mw, 0, mws));
+        double acc0 = 0, acc1 = 0, nll1 = 0;
+        for (int i = 0; i < N; ++i) {
+            if (i % 3 == 2) continue;
+            double a0 = zz[2 * i], a1 = zz[2 * i + 1], mx = fmax(a0, a1), lse = mx + log(exp(a0 - mx) + exp(a1 - mx));
+            int arg = a1 > a0 ? 1 : 0;                                                  /* the first maximum wins */
+            if (i % 3 == 0) acc0 += (arg == lab[i]) ? 1.0 / n0 : 0.0;
+            else { acc1 += (arg == lab[i]) ? 1.0 / n1 : 0.0; nll1 += (lse - zz[2 * i + lab[i]]) / n1; }
+        }
+        for (int rep = 0; rep < 2; ++rep) {
+            float m3[3];
+            CHECK_ACM(acm_eval_metrics(N, C2, d_z, C2, (const int64_t*)d_lab2, d_w2, N, 2, 1, d_m, mw, mws, NULL));
+            CHECK_HIP(hipDeviceSynchronize());
+            CHECK_HIP(hipMemcpy(m3, d_m, sizeof(m3), hipMemcpyDeviceToHost));
+            if (fabs(m3[0] - acc0) > 1e-6 || fabs(m3[1] - acc1) > 1e-6 || fabs(m3[2] - nll1) > 1e-5) {
+                printf("acm_eval_metrics (%d) %g %g %g vs %g %g %g\n", rep, m3[0], m3[1], m3[2], acc0, acc1, nll1);
+                return 16;
+            }
+        }
+        if (acm_eval_metrics(N, C2, d_z, C2, (const int64_t*)d_lab2, d_w2, N, 2, 2, d_m, mw, mws, NULL) != ACM_ESHAPE) { printf("bad loss set accepted\n"); return 17; }
+    }
 
     /* 6. errors are codes + messages, never crashes */
     if (acm_spmm(NULL, d_x, W, W, d_y, W, ws, ws_bytes, NULL) != ACM_EINVAL) { printf("NULL handle accepted\n"); return 10; }
