@@ -82,5 +82,8 @@ def test_eval_step_with_and_without_the_fused_metrics(use_graph):
     ref_acc = [float((oa.argmax(1)[s] == y[s]).double().mean()) for s in sets]
     np.testing.assert_allclose(acc_a, ref_acc, rtol=2e-6, atol=1e-7)
     np.testing.assert_allclose(la, float(F.nll_loss(F.log_softmax(oa.double(), 1)[sets[1]], y[sets[1]])), rtol=5e-6)
-    (_, acc_a2, la2) = a()
-    assert acc_a2 == acc_a and la2 == la
+    (_, acc_a2, la2) = a()                                  # (eager: this pass reuses the cached P -- logits to rounding)
+    np.testing.assert_allclose(acc_a2, acc_a, atol=2.0 / 64)
+    np.testing.assert_allclose(la2, la, rtol=1e-5)
+    (_, acc_a3, la3) = a()
+    assert acc_a3 == acc_a2 and la3 == la2                  # same kernels, same bits
