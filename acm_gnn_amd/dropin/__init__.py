@@ -23,6 +23,10 @@ For ACM-Pytorch the launcher also binds ``utils.train_model`` (the script's trai
 small-graph step where it applies (``install_fused_train_step``): Cora / Chameleon / Squirrel-class runs train in six launches
 per step instead of the ~250 of the eager loop.  ``--reference-step`` keeps the reference's own function.
 
+For ACM-Geometric it binds ``data_utils.evaluate_acmgcn`` (the per-epoch evaluation, data_utils.py:153-168) to the same forward
+followed by one launch for the three accuracies instead of six device-to-host copies + numpy (``install_fast_evaluate``; exact
+counts, identical numbers).  ``--reference-eval`` keeps the reference's function.
+
 The dialect also selects the attention-LayerNorm behaviour: on for
 ACM-Geometric, off for ACM-Pytorch (whose layer only normalises for the never-used spellings
 "acmgcn+"/"acmgcn++").
@@ -212,19 +216,78 @@ def install_fused_train_step():
     return ref
 
 
+def install_fast_evaluate():
+    """Bind ``data_utils.evaluate_acmgcn`` -- the per-epoch evaluation of ACM-Geometric/train.py:137-138 (data_utils.py:153-168:
+    eval-mode forward, then ``eval_func`` on the train / valid / test rows; ``eval_acc`` (data_utils.py:114-124) pulls labels and
+    predictions to the host three times and counts in numpy) -- to the same forward followed by ONE launch over the logits
+    (``acm_eval_metrics``, weights 1 on a split's rows: exact counts) and ONE four-byte-per-number copy, WHERE IT APPLIES:
+    ``eval_func`` is the module's own ``eval_acc``, integer labels of shape [n] / [n, 1] on the GPU, fp32 logits of <= 64 classes.
+    Same return value ``(train_acc, valid_acc, test_acc, out)`` -- the accuracies are count / len in float64 exactly as the
+    reference forms them.  Anything else (``eval_rocauc``, multi-label targets, a precomputed ``result``) runs the reference's
+    own function.  Returns the function that was bound before (None when there is no ``data_utils.evaluate_acmgcn``)."""
+    try:
+        du = importlib.import_module("data_utils")
+    except ImportError:
+        return None
+    ref, ref_acc = getattr(du, "evaluate_acmgcn", None), getattr(du, "eval_acc", None)
+    if ref is None or ref_acc is None or getattr(ref, "_acm_fused", False):
+        return None
+    import torch
+    cache = []                                      # [(split_idx, label, labels_flat, weights, sizes, buffers)], newest last
+
+    def evaluate_acmgcn(model, x, adj_low, adj_high, adj_low_unnormalized, dataset, split_idx, eval_func, result=None):
+        label = getattr(dataset, "label", None)
+        ok = (result is None and eval_func is ref_acc and isinstance(label, torch.Tensor) and _ON_DEVICE(label)
+              and label.dtype == torch.int64 and (label.dim() == 1 or (label.dim() == 2 and label.shape[1] == 1))
+              and isinstance(split_idx, dict) and all(isinstance(split_idx.get(k), torch.Tensor) for k in ("train", "valid", "test")))
+        if not ok:
+            return ref(model, x, adj_low, adj_high, adj_low_unnormalized, dataset, split_idx, eval_func, result)
+        with torch.no_grad():
+            model.eval()
+            out = model(x, adj_low, adj_high, adj_low_unnormalized)
+            if not (out.dim() == 2 and out.shape[1] <= 64 and out.dtype == torch.float32 and _ON_DEVICE(out) and out.stride(1) == 1):
+                return ref(model, x, adj_low, adj_high, adj_low_unnormalized, dataset, split_idx, eval_func, out)
+            from .. import functional as AF
+            entry = next((e for e in cache if e[0] is split_idx and e[1] is label), None)
+            if entry is None:
+                n = label.shape[0]
+                w = torch.zeros(3, n, dtype=torch.float32, device=label.device)
+                sizes = []
+                for q, k in enumerate(("train", "valid", "test")):
+                    idx = split_idx[k].to(label.device)
+                    idx = idx.nonzero().view(-1) if idx.dtype == torch.bool else idx.long()
+                    w[q].index_fill_(0, idx, 1.0)                    # (weight 1: the sums are exact counts below 2^24)
+                    sizes.append(int(idx.numel()))
+                entry = (split_idx, label, label.reshape(-1).contiguous(), w, sizes, AF.eval_metrics_buffers(n, 3, label.device))
+                cache.append(entry)
+                del cache[:-4]
+            _, _, flat, w, sizes, bufs = entry
+            counts = AF.eval_metrics(out, flat, w, 1, bufs).tolist()          # the one synchronising copy of the pass
+        accs = [float(counts[q]) / sizes[q] if sizes[q] else float("nan") for q in range(3)]
+        return accs[0], accs[1], accs[2], out
+
+    evaluate_acmgcn._acm_fused, evaluate_acmgcn.reference = True, ref
+    du.evaluate_acmgcn = evaluate_acmgcn
+    return ref
+
+
 def main(argv=None):
     argv = list(sys.argv[1:] if argv is None else argv)
     fused = True                                  # on by default since round 6 (it degrades to torch's own where it does not apply)
     fused_step = True                             # ... and so is the fused small-graph step behind utils.train_model (ACM-Pytorch)
-    for flag in ("--fused-optimizer", "--torch-optimizer", "--reference-step"):
-        if flag in argv[:4] and argv.index(flag) < 4:
+    fast_eval = True                              # ... and the one-launch accuracies behind data_utils.evaluate_acmgcn (ACM-Geometric)
+    for flag in ("--fused-optimizer", "--torch-optimizer", "--reference-step", "--reference-eval"):
+        if flag in argv[:5] and argv.index(flag) < 5:
             argv.remove(flag)
             if flag == "--reference-step":
                 fused_step = False
+            elif flag == "--reference-eval":
+                fast_eval = False
             else:
                 fused = flag == "--fused-optimizer"
     if len(argv) < 2:
-        sys.exit("usage: python -m acm_gnn_amd.dropin {geometric|pytorch} [--torch-optimizer] [--reference-step] train.py [script args...]")
+        sys.exit("usage: python -m acm_gnn_amd.dropin {geometric|pytorch} [--torch-optimizer] [--reference-step] [--reference-eval] "
+                 "train.py [script args...]")
     dialect, script = argv[0], argv[1]
     sys.path.insert(0, os.path.dirname(os.path.abspath(script)) or os.getcwd())
     install(dialect)
@@ -232,5 +295,7 @@ def main(argv=None):
         install_fused_optimizers()
     if fused and fused_step and dialect == "pytorch":
         install_fused_train_step()
+    if fast_eval and dialect == "geometric":
+        install_fast_evaluate()
     sys.argv = [script] + argv[2:]
     runpy.run_path(script, run_name="__main__")

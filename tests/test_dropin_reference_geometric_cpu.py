@@ -196,3 +196,52 @@ def test_reference_geometric_train_script_runs_on_the_dropin(method, variant, st
     for p in ns["model"].parameters():                   # the reference's optimizer stepped our parameters
         if p.grad is not None:
             assert torch.isfinite(p.grad).all()
+
+
+def test_bound_evaluate_acmgcn_returns_the_reference_numbers(reference_geometric, tmp_path, monkeypatch, capsys):
+    """Round 6: the launcher binds ``data_utils.evaluate_acmgcn`` (the per-epoch evaluation of train.py:137-138) to the same
+    eval-mode forward + ONE launch for the three accuracies (dropin.install_fast_evaluate -> acm_eval_metrics, exact counts)
+    instead of six device-to-host copies + numpy.  The unmodified script prints the SAME epoch lines with and without the
+    binding (same seeds), one library call per epoch; anything outside the envelope (eval_rocauc, a precomputed result) runs
+    the reference's own function."""
+    fake, _ = reference_geometric
+    from acm_gnn_amd import dropin
+    monkeypatch.setattr(dropin, "_ON_DEVICE", lambda t: True)           # (no GPU here: the test double takes CPU tensors)
+    (tmp_path / "results").mkdir()
+    monkeypatch.chdir(tmp_path)
+    epochs = 4
+    argv = ["train.py", "--dataset", "stub", "--method", "acmgcnp", "--variant", "0", "--structure_info", "0", "--rand_split",
+            "--num_splits", "1", "--epochs", str(epochs), "--hidden_channels", "64", "--lr", "0.01", "--dropout", "0.3"]
+
+    def run(bind):
+        for m in ("data_utils", "models", "parse", "utils", "logger", "dataset"):
+            sys.modules.pop(m, None)
+        sys.modules.update(_stub_data_modules())
+        if bind:
+            ref = dropin.install_fast_evaluate()
+            assert ref is not None and ref.__module__ == "data_utils" and dropin.install_fast_evaluate() is None     # (binds once)
+        monkeypatch.setattr(sys, "argv", argv)
+        calls = getattr(fake, "eval_metrics_calls", 0)
+        ns = runpy.run_path(os.path.join(GEO, "train.py"), run_name="__main__")
+        out = capsys.readouterr().out
+        return [ln for ln in out.splitlines() if ln.startswith("Epoch:")], getattr(fake, "eval_metrics_calls", 0) - calls, ns
+
+    lines_ref, n_ref, _ = run(False)
+    lines_new, n_new, ns = run(True)
+    assert n_ref == 0 and n_new == epochs
+    strip = lambda ls: [ln.split(", Time:")[0] for ln in ls]                # (the wall-clock column differs)
+    assert len(lines_new) == epochs and strip(lines_new) == strip(lines_ref)
+    # outside the envelope: the reference's own function
+    du = sys.modules["data_utils"]
+    assert getattr(du.evaluate_acmgcn, "_acm_fused", False)
+    model, ds, split = ns["model"], ns["dataset"], ns["split_idx"]
+    x, lo, hi = ns["x"], ns["adj_low"], ns["adj_high"]
+    calls = fake.eval_metrics_calls
+    out = du.evaluate_acmgcn(model, x, lo, hi, None, ds, split, du.eval_acc)
+    assert fake.eval_metrics_calls == calls + 1
+    again = du.evaluate_acmgcn(model, x, lo, hi, None, ds, split, du.eval_acc, result=out[3])       # a precomputed result
+    other = du.evaluate_acmgcn(model, x, lo, hi, None, ds, split, lambda yt, yp: 0.5)                # another metric
+    assert fake.eval_metrics_calls == calls + 1
+    assert again[:3] == out[:3] and other[:3] == (0.5, 0.5, 0.5)
+    want = du.evaluate_acmgcn.reference(model, x, lo, hi, None, ds, split, du.eval_acc)
+    assert out[:3] == want[:3]
