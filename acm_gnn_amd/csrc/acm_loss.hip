@@ -88,12 +88,23 @@ __global__ __launch_bounds__(256) void eval_metrics_kernel(int n, int C, const f
     __syncthreads();
     if (!last) return;
     __threadfence();
-    if ((int)threadIdx.x <= S) {
-        float t = 0.f;
-        for (int b = 0; b < (int)gridDim.x; ++b)
-            t += __hip_atomic_load(partial + (long)b * (S + 1) + threadIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        out[threadIdx.x] = t;
+    // thread b takes block b's record (at most 256 blocks: eval_blocks), then the same fixed tree -- a serial walk of 256
+    // cache-bypassing loads by one thread cost 38 us of the 43 us launch on the twitch-shaped graph
+#pragma unroll
+    for (int s = 0; s <= EVAL_MAX_SETS; ++s) {
+        const int col = s < EVAL_MAX_SETS ? s : S;              // (slot S of a record = the loss sum)
+        const bool have = (int)threadIdx.x < (int)gridDim.x && (s < S || s == EVAL_MAX_SETS);
+        red[s][threadIdx.x] = have ? __hip_atomic_load(partial + (long)threadIdx.x * (S + 1) + col, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.f;
     }
+    __syncthreads();
+    for (int k = 128; k >= 1; k >>= 1) {
+        if ((int)threadIdx.x < k) {
+#pragma unroll
+            for (int s = 0; s <= EVAL_MAX_SETS; ++s) red[s][threadIdx.x] += red[s][threadIdx.x + k];
+        }
+        __syncthreads();
+    }
+    if ((int)threadIdx.x <= S) out[threadIdx.x] = red[(int)threadIdx.x < S ? threadIdx.x : EVAL_MAX_SETS][0];
     if (threadIdx.x == 0) __hip_atomic_store(arrive, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
