@@ -1669,3 +1669,26 @@ def test_eval_step_takes_the_one_launch_metrics(monkeypatch):
     many = T.EvalStep(model, x, ops, y, tuple(torch.arange(q, q + 10) for q in range(0, 90, 10)))      # nine sets
     many()
     assert getattr(fake, "eval_metrics_calls", 0) - calls == 1
+
+
+def test_fit_concurrent_without_streams_is_fit_run_by_run(monkeypatch):
+    """train.fit_concurrent on the CPU double (no stream to overlap on): every run is fit() of its model, in order."""
+    import scipy.sparse as sp
+    fake_lib.install(monkeypatch)
+    from acm_gnn_amd import GCN, FusedAdam, SparseFeatures, train as T
+    ops, n = _dense_graph_ops(n=90, avg=8, seed=12)
+    rng = np.random.default_rng(0)
+    xs = SparseFeatures.from_scipy(sp.csr_matrix(((rng.random((n, 50)) < 0.08) * 1.0).astype(np.float32)), "cpu")
+    y = torch.from_numpy(rng.integers(0, 3, n))
+
+    def make(k):
+        torch.manual_seed(k)
+        m = GCN(50, 64, 3, 2, n, 0.0, "acmgcn", 0)
+        idx = torch.randperm(n, generator=torch.Generator().manual_seed(k))
+        return m, FusedAdam(m.parameters(), lr=0.01), idx[:40], idx[40:65], idx[65:]
+
+    got = T.fit_concurrent([make(k) for k in range(3)], xs, ops, y, epochs=4, rule="max_val_acc")
+    for k in range(3):
+        m, opt, tr, va, te = make(k)
+        sel, hist = T.fit(m, opt, xs, ops, y, tr, va, te, 4, rule="max_val_acc")
+        assert got[k][0] == sel and got[k][1] == hist
