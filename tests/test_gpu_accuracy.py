@@ -47,6 +47,8 @@ def _cora_masks(split):
 # the listed value otherwise.
 REPLAYS = {"cora": (0.002, 0.01), "squirrel": (0.002, 0.025), "film_v0": (0.004, 0.025), "film_v1": (0.004, 0.025)}
 # recorded with the library's counter-based masks injected into the reference (--philox): replayed on the fused small-graph step
+# (mean selected bound, per-split selected bound[, per-split bound of the second-half curve gap: 0.4 pp unless the reference's
+#  own second run of the experiment -- accuracy_<name>_b_philox.npz, summation order only -- shows a wider band])
 PHILOX_REPLAYS = {"cora": (0.002, 0.01), "squirrel": (0.002, 0.025), "chameleon_syn": (0.002, 0.025)}
 
 
@@ -237,7 +239,11 @@ def _judge_replay(name, rec, results, out_name, path_label="general path", bound
         # fp32 chaos) and so does the per-epoch test accuracy
         np.testing.assert_allclose(vals[:5], hist[:5, 1], rtol=2e-4)
         # Film trains without dropout at lr 0.05: the loss curve has isolated spikes whose height is chaotic
-        np.testing.assert_allclose(vals[:m], hist[:m, 1], rtol=0.12 if dataset == "film" else 3e-2)
+        # (and so does the synthetic-label Chameleon run: lr 0.05 under dropout 0.7 -- its curve follows the reference's to six
+        # digits for ten epochs, then to 13 % while the loss wanders around its minimum)
+        np.testing.assert_allclose(vals[:m], hist[:m, 1], rtol=0.12 if dataset == "film" else (0.2 if cfg["lr"] >= 0.05 else 3e-2))
+        if cfg["lr"] >= 0.05:
+            np.testing.assert_allclose(vals[:10], hist[:10, 1], rtol=1e-3)
         curve_gap.append(float(np.mean(accs[m // 2:m]) - np.mean(hist[m // 2:m, 2])))
     got, ref = np.asarray(got), np.asarray(ref)
     print(f"\n{name} ({path_label}): reference-run {100 * ref.mean():.2f} +- {100 * ref.std():.2f}  |  MI355X {100 * got.mean():.2f} "
@@ -273,7 +279,25 @@ def _judge_replay(name, rec, results, out_name, path_label="general path", bound
         print(f"   two runs of the reference itself (summation order only): mean {100 * band[0]:.2f} pp apart, per split "
               f"{np.round(100 * band[1], 2).tolist()}")
         mean_bound = max(0.002, band[0])
-    assert abs(np.mean(curve_gap)) <= 0.002 and np.all(np.abs(curve_gap) <= 0.004), curve_gap
+    gap_bound = 0.004
+    band_path = os.path.join(GOLDEN, f"accuracy_{name}_b_philox.npz")
+    if bounds is not None and os.path.exists(band_path):
+        # the REFERENCE's own second run of this experiment (same masks, init, splits; CSR operands + 3 threads): how far its
+        # second-half test-accuracy curves sit from the first run's, per split -- no replay can be asked to do better
+        rb = load_npz(band_path)
+        own = []
+        for split in cfg["splits"]:
+            if f"hist_{split}" in rb and f"hist_{split}" in rec:
+                ha, hb = rec[f"hist_{split}"], rb[f"hist_{split}"]
+                mm = min(len(ha), len(hb))
+                own.append(abs(float(np.mean(hb[mm // 2:mm, 2]) - np.mean(ha[mm // 2:mm, 2]))))
+        if own:
+            sel_band = abs(float(np.mean(rb["test_acc"]) - np.mean(rec["test_acc"])))
+            print(f"   the reference's own two runs, second-half curve gap per split: {np.round(100 * np.asarray(own), 2).tolist()} pp; "
+                  f"selected accuracy, means {100 * sel_band:.2f} pp apart")
+            gap_bound = max(gap_bound, 2.0 * max(own))          # (a sanity bound per split; the MEAN over the splits is the criterion)
+            mean_bound = max(mean_bound, sel_band)
+    assert abs(np.mean(curve_gap)) <= 0.002 and np.all(np.abs(curve_gap) <= gap_bound), (curve_gap, gap_bound)
     assert abs(np.mean(at_ref_epoch)) <= 0.002, at_ref_epoch
     assert np.all(np.abs(got - ref) <= split_bound), (got - ref)
     assert abs(got.mean() - ref.mean()) <= mean_bound, (got.mean(), ref.mean())
