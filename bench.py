@@ -27,7 +27,7 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured stream)
 FP32_MFMA_PEAK_TF = 157.3
-TRAFFIC_FILE = "r05_pmc_traffic.json"        # profiles/: HBM bytes per launch from the rocprofv3 --pmc passes (collect_profiles.sh)
+TRAFFIC_FILE = "r06_pmc_traffic.json"        # profiles/: HBM bytes per launch from the rocprofv3 --pmc passes (collect_profiles.sh)
 WINDOWS = 5                    # timed windows of --steps replays each; ms_per_step is the median window
 
 
