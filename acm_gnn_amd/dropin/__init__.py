@@ -180,7 +180,7 @@ def install_fused_train_step():
                         step = cand
                     else:
                         why = cand.small_refused
-                except (RuntimeError, ValueError, TypeError, NotImplementedError) as exc:
+                except Exception as exc:          # noqa: BLE001 -- a binding must never break the script it serves
                     why = f"{type(exc).__name__}: {exc}"
                 if step is None:                  # leave the model and the optimizer as the reference's own step expects them
                     if hasattr(optimizer, "also_advance"):
@@ -197,7 +197,9 @@ def install_fused_train_step():
                 _WARNED.add(why)
                 import warnings
                 warnings.warn(f"acm_gnn_amd.dropin: utils.train_model stays the reference's own ({why})", stacklevel=2)
-            for k in [k for k, v in steps.items() if v[0]() is None]:
+            # (a step keeps its model alive, and with it the plan's workspace: the script trains one split at a time, so the
+            # entries of earlier splits are dropped -- at most two stay)
+            for k in list(steps)[:-1]:
                 del steps[k]
             entry = steps[id(model)] = (weakref.ref(model), id(optimizer), step, inputs)
         step = entry[2]
@@ -242,6 +244,17 @@ def install_fast_evaluate():
               and isinstance(split_idx, dict) and all(isinstance(split_idx.get(k), torch.Tensor) for k in ("train", "valid", "test")))
         if not ok:
             return ref(model, x, adj_low, adj_high, adj_low_unnormalized, dataset, split_idx, eval_func, result)
+        try:
+            return fast(model, x, adj_low, adj_high, adj_low_unnormalized, dataset, split_idx, eval_func, label)
+        except Exception as exc:                 # noqa: BLE001 -- a binding must never break the script it serves
+            why = f"{type(exc).__name__}: {exc}"
+            if why not in _WARNED:
+                _WARNED.add(why)
+                import warnings
+                warnings.warn(f"acm_gnn_amd.dropin: data_utils.evaluate_acmgcn stays the reference's own ({why})", stacklevel=2)
+            return ref(model, x, adj_low, adj_high, adj_low_unnormalized, dataset, split_idx, eval_func, result)
+
+    def fast(model, x, adj_low, adj_high, adj_low_unnormalized, dataset, split_idx, eval_func, label):
         with torch.no_grad():
             model.eval()
             out = model(x, adj_low, adj_high, adj_low_unnormalized)
