@@ -33,7 +33,7 @@ __global__ __launch_bounds__(256) void eval_metrics_kernel(int n, int C, const f
                                                            const int64_t* __restrict__ y, const float* __restrict__ w, long ldw,
                                                            int S, int loss_set, float* __restrict__ out,
                                                            float* __restrict__ partial, int* __restrict__ arrive) {
-    __shared__ float red[EVAL_MAX_SETS + 1][256];
+    __shared__ float red[EVAL_MAX_SETS + 1][4];
     __shared__ int last;
     float acc[EVAL_MAX_SETS + 1];
 #pragma unroll
@@ -66,19 +66,21 @@ __global__ __launch_bounds__(256) void eval_metrics_kernel(int n, int C, const f
         for (int s = 0; s < EVAL_MAX_SETS; ++s) wl = s == loss_set ? ws[s] : wl;
         acc[EVAL_MAX_SETS] = fmaf(wl, nll, acc[EVAL_MAX_SETS]);
     }
+    // block sums: every wave adds its 64 lanes in registers (DPP: a fixed order), the four wave sums meet in LDS
+    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
 #pragma unroll
-    for (int s = 0; s <= EVAL_MAX_SETS; ++s) red[s][threadIdx.x] = acc[s];          // (compile-time register indices)
-    __syncthreads();
-    for (int k = 128; k >= 1; k >>= 1) {
-        if ((int)threadIdx.x < k) {
-#pragma unroll
-            for (int s = 0; s <= EVAL_MAX_SETS; ++s) red[s][threadIdx.x] += red[s][threadIdx.x + k];
+    for (int s = 0; s <= EVAL_MAX_SETS; ++s) {
+        if (s < S || s == EVAL_MAX_SETS) {                      // (S is uniform: no divergence)
+            const float t = acm_group_sum<64>(acc[s]);
+            if (lane == 0) red[s][wv] = t;
         }
-        __syncthreads();
     }
-    if ((int)threadIdx.x <= S)                       // slot S of a block's record = the loss sum
-        __hip_atomic_store(partial + (long)blockIdx.x * (S + 1) + threadIdx.x,
-                           red[(int)threadIdx.x < S ? threadIdx.x : EVAL_MAX_SETS][0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    if ((int)threadIdx.x <= S) {                     // slot S of a block's record = the loss sum
+        const float* r = red[(int)threadIdx.x < S ? threadIdx.x : EVAL_MAX_SETS];
+        __hip_atomic_store(partial + (long)blockIdx.x * (S + 1) + threadIdx.x, (r[0] + r[1]) + (r[2] + r[3]), __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_AGENT);
+    }
     __syncthreads();
     if (threadIdx.x == 0) {
         __threadfence();
@@ -92,19 +94,19 @@ __global__ __launch_bounds__(256) void eval_metrics_kernel(int n, int C, const f
     // cache-bypassing loads by one thread cost 38 us of the 43 us launch on the twitch-shaped graph
 #pragma unroll
     for (int s = 0; s <= EVAL_MAX_SETS; ++s) {
-        const int col = s < EVAL_MAX_SETS ? s : S;              // (slot S of a record = the loss sum)
-        const bool have = (int)threadIdx.x < (int)gridDim.x && (s < S || s == EVAL_MAX_SETS);
-        red[s][threadIdx.x] = have ? __hip_atomic_load(partial + (long)threadIdx.x * (S + 1) + col, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.f;
+        if (s < S || s == EVAL_MAX_SETS) {
+            const int col = s < EVAL_MAX_SETS ? s : S;              // (slot S of a record = the loss sum)
+            const float v = (int)threadIdx.x < (int)gridDim.x
+                                ? __hip_atomic_load(partial + (long)threadIdx.x * (S + 1) + col, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.f;
+            const float t = acm_group_sum<64>(v);
+            if (lane == 0) red[s][wv] = t;
+        }
     }
     __syncthreads();
-    for (int k = 128; k >= 1; k >>= 1) {
-        if ((int)threadIdx.x < k) {
-#pragma unroll
-            for (int s = 0; s <= EVAL_MAX_SETS; ++s) red[s][threadIdx.x] += red[s][threadIdx.x + k];
-        }
-        __syncthreads();
+    if ((int)threadIdx.x <= S) {
+        const float* r = red[(int)threadIdx.x < S ? threadIdx.x : EVAL_MAX_SETS];
+        out[threadIdx.x] = (r[0] + r[1]) + (r[2] + r[3]);
     }
-    if ((int)threadIdx.x <= S) out[threadIdx.x] = red[(int)threadIdx.x < S ? threadIdx.x : EVAL_MAX_SETS][0];
     if (threadIdx.x == 0) __hip_atomic_store(arrive, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
